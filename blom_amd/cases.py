@@ -1,0 +1,253 @@
+"""Synthetic, fully analytic input cases for the BLOM dynamical-core hot path.
+
+Host-side (numpy) input generation only: grid metrics, bathymetry, initial layer
+structure and the namelist-type options each stage reads.  The shapes follow
+BASELINE.json's configs:
+
+  fuk95    156x32x12  closed in i / periodic in j (nreg=4)  bld/fuk95/patch.input.1
+  channel  208x512x53 periodic in i / closed in j (nreg=1)  bld/channel/patch.input.1
+  chan_s   20x24x6    small channel used by the parity tests
+  box_s    24x20x8    small closed basin with an island and a promontory coast
+
+The idealised definitions mirror the spirit of the reference's test cases
+(fuk95/mod_fuk95.F90:122-447 flat-bottom front; channel/mod_channel.F90:61-323 tanh
+shelves + tanh stratification) but are restated in SI units and kept netCDF-free.
+The channel namelists &IDLGEO/&IDLINI/&IDLFOR have no defaults anywhere in the
+reference, so the values below ARE this project's published choice.
+
+Array convention everywhere on the host side: numpy C-order (nlev, jdm+8, idm+8);
+Fortran a(i,j,k) is arr[k-1, j+3, i+3]  (nbdy = 4, phy/mod_xc.F90:45).
+"""
+from dataclasses import dataclass, field
+import numpy as np
+
+NBDY = 4
+ONEM = 9806.0          # phy/mod_constants.F90:49
+GRAV = 9.806
+SPVAL = 1.0e33
+
+# Coefficients of the functional fit of in situ density, phy/mod_eos.F90:36-54
+_A11, _A12, _A13, _A14, _A15, _A16 = (9.9985372432159340e+02, 1.0380621928183473e+01,
+                                       1.7073577195684715e+00, -3.6570490496333680e-02,
+                                       -7.3677944503527477e-03, -3.5529175999643348e-03)
+_B11, _B12, _B13 = 1.7083494994335439e-06, 7.1567921402953455e-09, 1.2821026080049485e-09
+_A21, _A22, _A23, _A24, _A25, _A26 = (1.0, 1.0316374535350838e-02, 8.9521792365142522e-04,
+                                       -2.8438341552142710e-05, -1.1887778959461776e-05,
+                                       -4.0163964812921489e-06)
+_B21, _B22, _B23 = 1.1995545126831476e-09, 5.5234008384648383e-12, 8.4310335919950873e-13
+_ALPHA0 = 1.0e-3
+
+
+def eos_pref_coeffs(pref):
+    """ap11..ap26 of inieos (phy/mod_eos.F90:105-116)."""
+    ap21 = _A21 + _B21 * pref
+    ap22 = _A22 + _B22 * pref
+    ap23 = _A23 + _B23 * pref
+    ap24, ap25, ap26 = _A24, _A25, _A26
+    ap11 = _A11 + _B11 * pref - ap21 / _ALPHA0
+    ap12 = _A12 + _B12 * pref - ap22 / _ALPHA0
+    ap13 = _A13 + _B13 * pref - ap23 / _ALPHA0
+    ap14 = _A14 - ap24 / _ALPHA0
+    ap15 = _A15 - ap25 / _ALPHA0
+    ap16 = _A16 - ap26 / _ALPHA0
+    return (ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26)
+
+
+def sig(th, s, pref):
+    """Potential density in sigma units (phy/mod_eos.F90:191-203)."""
+    ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26 = eos_pref_coeffs(pref)
+    return ((ap11 + (ap12 + ap14 * th + ap15 * s) * th + (ap13 + ap16 * s) * s)
+            / (ap21 + (ap22 + ap24 * th + ap25 * s) * th + (ap23 + ap26 * s) * s))
+
+
+def tofsig(sg, s, pref):
+    """Potential temperature from potential density and salinity (mod_eos.F90:346-364)."""
+    ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26 = eos_pref_coeffs(pref)
+    a = ap14 - ap24 * sg
+    b = ap12 - ap22 * sg + (ap15 - ap25 * sg) * s
+    c = ap11 - ap21 * sg + (ap13 - ap23 * sg + (ap16 - ap26 * sg) * s) * s
+    return (-b - np.sqrt(b * b - 4.0 * a * c)) / (2.0 * a)
+
+
+@dataclass
+class Case:
+    name: str
+    idm: int
+    jdm: int
+    kdm: int
+    nreg: int                       # phy/mod_bigrid.F90:81-95 region type
+    params: dict                    # namelist-type options (reals, ints, strings)
+    depth: np.ndarray               # (nj, ni) incl. halo, 0 = land, interior only significant
+    grid: dict = field(default_factory=dict)   # metric arrays (nj, ni)
+    ic: dict = field(default_factory=dict)     # initial wet-point state, see hostinit.py
+    ntr: int = 1
+
+    @property
+    def ni(self):
+        return self.idm + 2 * NBDY
+
+    @property
+    def nj(self):
+        return self.jdm + 2 * NBDY
+
+
+_DIMS = {
+    # name: (idm, jdm, kdm, nreg, dx[m], baclin, batrop)
+    "chan_s": (20, 24, 6, 1, 10.0e3, 900.0, 18.0),
+    "box_s": (24, 20, 8, 0, 10.0e3, 900.0, 18.0),
+    "fuk95": (156, 32, 12, 4, 650.0, 180.0, 6.0),
+    "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
+}
+
+
+def default_params(baclin, batrop):
+    lstep = 2 * int(np.ceil(0.5 * baclin / batrop))       # phy/mod_time.F90:139
+    return dict(
+        expcnf="channel",
+        baclin=baclin, batrop=batrop, lstep=lstep, dlt=baclin / lstep,  # mod_time.F90:142
+        delt1=baclin,                                      # forward first step, mod_blom_init.F90:231
+        pref=2000.0e4,
+        mdv2hi=0.02, mdv2lo=0.004, mdv4hi=0.005, mdv4lo=0.005,
+        mdc2hi=5000.0, mdc2lo=300.0,
+        vsc2hi=0.5, vsc2lo=0.5, vsc4hi=0.06, vsc4lo=0.06,
+        cbar=0.05, cb=0.002, cwbdts=5.0e-5, cwbdls=25.0,
+        mommth="enscon", pgfmth="geopotential", bmcmth="uc", advmth="remap",
+        vcoord_tag=1,        # vcoord_isopyc_bulkml, phy/mod_vcoord.F90
+        ltedtp_opt=1,        # ltedtp_layer, phy/mod_diffusion.F90
+        bdmtyp=2, bdmc1=5.0e-8, bdmc2=1.0e-5, iwdflg=1, iwdfac=0.06, nubmin=1.0e-6,
+        bdmldp=0,
+        # frozen diffusivities (difest needs CVMix, absent: SURVEY.md 8c)
+        difiso0=300.0, difint0=300.0, difdia0=1.0e-5, difwgt0=1.0,
+        taux0=0.1,           # zonal wind stress amplitude [N m-2]
+    )
+
+
+def _depth_for(name, idm, jdm, dx):
+    """Bathymetry [m] on the interior (jdm, idm); 0 = land."""
+    ii = np.arange(1, idm + 1)[None, :]
+    jj = np.arange(1, jdm + 1)[:, None]
+    if name in ("chan_s", "channel"):
+        # tanh shelves on both walls (cf. channel/mod_channel.F90:168-207), southern and
+        # northern-most rows land
+        sf, sl = (200.0, 800.0) if name == "chan_s" else (200.0, 3800.0)
+        width = 0.18 * jdm * dx
+        ys = (jj - 0.5) * dx
+        yn = (jdm - jj + 0.5) * dx
+        y = np.minimum(ys, yn)
+        d = sf + 0.5 * sl * (1.0 + np.tanh(np.pi * (y - 1.2 * width) / width))
+        # gentle along-channel corrugation so that fields vary in i as well
+        d = d * (1.0 + 0.05 * np.sin(2.0 * np.pi * ii / idm) * np.exp(-((y - 1.2 * width) / width) ** 2))
+        d = np.broadcast_to(d, (jdm, idm)).copy()
+        d[0, :] = 0.0
+        d[-1, :] = 0.0
+        return d
+    if name == "fuk95":
+        d = np.full((jdm, idm), 200.0)     # fuk95/mod_fuk95.F90:126-134 flat, walls in i
+        d[:, 0] = 0.0
+        d[:, -1] = 0.0
+        return d
+    if name == "box_s":
+        d = np.full((jdm, idm), 900.0)
+        x = (ii - 0.5) / idm
+        y = (jj - 0.5) / jdm
+        d = 300.0 + 600.0 * np.sin(np.pi * x) * np.sin(np.pi * y) + 0.0 * d
+        d[0, :] = 0.0
+        d[-1, :] = 0.0
+        d[:, 0] = 0.0
+        d[:, -1] = 0.0
+        # irregular coast: a promontory, a bay, an island (no 1-point inlets,
+        # phy/mod_bigrid.F90:165-193)
+        d[1:4, 1:6] = 0.0
+        d[1:3, 14:19] = 0.0
+        d[jdm - 5:jdm - 1, 8:12] = 0.0
+        d[9:12, 11:14] = 0.0               # island
+        d[6:8, 20:23] = 0.0
+        return d
+    raise KeyError(name)
+
+
+def make_case(name, ntr=1):
+    idm, jdm, kdm, nreg, dx, baclin, batrop = _DIMS[name]
+    ni, nj = idm + 2 * NBDY, jdm + 2 * NBDY
+    p = default_params(baclin, batrop)
+    if name == "fuk95":
+        p.update(expcnf="fuk95", taux0=0.0, cwbdts=0.0)
+
+    depth = np.zeros((nj, ni))
+    depth[NBDY:NBDY + jdm, NBDY:NBDY + idm] = _depth_for(name, idm, jdm, dx)
+
+    # ---- grid metrics: uniform Cartesian f-plane (channel/mod_channel.F90:140-161) ----
+    g = {}
+    one = np.ones((nj, ni))
+    for nm in ("scqx", "scqy", "scpx", "scpy", "scux", "scuy", "scvx", "scvy"):
+        g[nm] = dx * one
+    for nm in ("scq2", "scp2", "scu2", "scv2"):
+        g[nm] = (dx * dx) * one
+    for nm, src in (("scq2i", "scq2"), ("scp2i", "scp2"), ("scuxi", "scux"), ("scuyi", "scuy"),
+                    ("scvxi", "scvx"), ("scvyi", "scvy")):
+        g[nm] = 1.0 / g[src]
+    f0 = 1.0e-4
+    g["corioq"] = f0 * one
+    g["coriop"] = f0 * one
+    g["betafp"] = 0.0 * one
+
+    # ---- initial layer structure on the interior ------------------------------------
+    pref = p["pref"]
+    S0 = 35.0
+    k = np.arange(1, kdm + 1)
+    # reference potential densities [kg m-3, sigma units], tanh profile
+    # (cf. channel/mod_channel.F90:245-253)
+    sigmr0 = 33.0 + 4.2 * (k - 1) / max(1, kdm - 1) + 0.6 * np.tanh(3.0 * (k - 1) / kdm)
+    sigmr0[0] = sigmr0[1] = sigmr0[2] - 0.4 if kdm > 2 else sigmr0[0]
+    maxdep = depth.max()
+    # nominal interior layer thickness [m]: thin on top, thicker below, sum > max depth
+    dz0 = np.empty(kdm)
+    dz0[0] = dz0[1] = 10.0
+    w = np.tanh(2.5 * (k[2:] - 1) / kdm)
+    dz0[2:] = w / w.sum() * (1.15 * maxdep - 20.0)
+
+    jj_, ii_ = np.meshgrid(np.arange(1, jdm + 1), np.arange(1, idm + 1), indexing="ij")
+    x = (ii_ - 0.5) / idm
+    y = (jj_ - 0.5) / jdm
+    dep = depth[NBDY:NBDY + jdm, NBDY:NBDY + idm]
+    wet = dep > 0.0
+
+    z = np.zeros((kdm + 1, jdm, idm))
+    for kk_ in range(kdm):
+        # smooth interface undulations (a front across the domain + a wave) that decay
+        # with depth; drives pressure gradients, geostrophic adjustment and advection
+        amp = 0.35 * dz0[kk_] if kk_ >= 2 else 0.0
+        if name == "fuk95":
+            pert = amp * (np.tanh((x - 0.5) * 12.0) + 0.3 * np.sin(2 * np.pi * y) * np.exp(-((x - 0.5) * 6) ** 2))
+        else:
+            pert = amp * (np.tanh((y - 0.5) * 8.0) + 0.3 * np.sin(2 * np.pi * x * 2) * np.exp(-((y - 0.5) * 5) ** 2))
+        z[kk_ + 1] = np.minimum(dep, z[kk_] + np.maximum(0.0, dz0[kk_] + pert))
+    # (cf. channel/mod_channel.F90:296-306) collapse thin slivers above the bottom
+    for kk_ in range(2, kdm):
+        thin = (dep - z[kk_]) < 1.0e-3
+        z[kk_][thin] = dep[thin]
+    z[kdm] = dep
+    dz = np.diff(z, axis=0)
+    dz[:, ~wet] = 0.0
+
+    dp = ONEM * dz                                   # [Pa], 1 m = 9806 Pa
+    sigmar = np.broadcast_to(sigmr0[:, None, None], (kdm, jdm, idm)).copy()
+    saln = np.full((kdm, jdm, idm), S0)
+    temp = tofsig(sigmar, saln, pref)
+    # mixed layer (layers 1-2) slightly lighter and laterally varying
+    dsg = 0.25 * (1.0 + np.cos(2 * np.pi * (y if name != "fuk95" else x)))
+    for kk_ in range(min(2, kdm)):
+        temp[kk_] = tofsig(sigmr0[2] - 0.4 - dsg, saln[kk_], pref)
+    sigma = sig(temp, saln, pref)
+    # a passive tracer with structure (ideal-age-like, trc/mod_tracers.F90:96-102)
+    trc = (1.0 + 0.5 * np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y))[None] * (1.0 + 0.1 * k[:, None, None])
+
+    def pad3(a):
+        out = np.zeros((a.shape[0], nj, ni))
+        out[:, NBDY:NBDY + jdm, NBDY:NBDY + idm] = a
+        return out
+
+    ic = dict(dp=pad3(dp), temp=pad3(temp), saln=pad3(saln), sigma=pad3(sigma),
+              sigmar=pad3(sigmar), trc=pad3(trc)[None].repeat(max(ntr, 1), axis=0)[:ntr])
+    return Case(name=name, idm=idm, jdm=jdm, kdm=kdm, nreg=nreg, params=p, depth=depth,
+                grid=g, ic=ic, ntr=ntr)

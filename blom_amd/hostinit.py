@@ -1,0 +1,357 @@
+"""Host-side initialisation of the dynamical-core state (numpy).
+
+This is the netCDF-free equivalent of what blom_init_phase1/2 and inicon do between
+"grid + layer structure known" and "first blom_step" (phy/mod_blom_init.F90:203-444,
+phy/mod_inicon.F90:932-1459), plus the integer mask construction of bigrid
+(phy/mod_bigrid.F90:44-317) and the single-tile halo rules of xctilr
+(phy/mod_xc.F90:4222-4428).  It drives any backend that offers
+
+    get(name) -> ndarray(nlev, nj, ni)      put(name, ndarray)
+    set(name, scalar)                       stage(name, m, n, mm, nn, k1m, k1n)
+    masks: dict(ip, iu, iv, iq)             kdm, idm, jdm, ntr
+
+so the very same input state can be handed to the device library and (in tests) to the
+reference.  Fortran a(i,j,k) == arr[k-1, j+3, i+3].
+"""
+import numpy as np
+
+NBDY = 4
+EPSILP = 1.0e-12        # phy/mod_constants.F90:43
+SPVAL = 1.0e33
+GRAV = 9.806            # phy/mod_constants.F90:32
+
+
+def sl(lo, hi):
+    """numpy slice for the Fortran index range lo..hi (inclusive) of a halo-4 axis."""
+    return slice(lo + NBDY - 1, hi + NBDY)
+
+
+# ----------------------------------------------------------------------------------
+# xctilr, single tile (phy/mod_xc.F90:4374-4419; arctic form not needed for nreg != 2)
+# ----------------------------------------------------------------------------------
+def xctilr_np(a, l1, ld, mh, nh, nreg, ii, jj, vland=0.0):
+    """In-place halo update of levels l1..ld (1-based) of a (nlev, nj, ni) array."""
+    assert nreg in (0, 1, 3, 4), "tripolar seam (nreg=2) is handled on the device only"
+    mhl = max(0, min(mh, NBDY))
+    nhl = max(0, min(nh, NBDY))
+    v = a[l1 - 1:ld]
+    o = NBDY - 1            # index of Fortran 0
+    if nhl > 0:
+        if nreg <= 2:       # closed in latitude
+            v[:, o + 1 - nhl:o + 1, sl(1, ii)] = vland
+            v[:, o + jj + 1:o + jj + 1 + nhl, sl(1, ii)] = vland
+        else:
+            for j in range(1, nhl + 1):
+                v[:, o + 1 - j, sl(1, ii)] = v[:, o + jj + 1 - j, sl(1, ii)]
+                v[:, o + jj + j, sl(1, ii)] = v[:, o + j, sl(1, ii)]
+    if mhl > 0:
+        js = sl(1 - nhl, jj + nhl)
+        if nreg in (0, 4):  # closed in longitude
+            v[:, js, o + 1 - mhl:o + 1] = vland
+            v[:, js, o + ii + 1:o + ii + 1 + mhl] = vland
+        else:
+            for i in range(1, mhl + 1):
+                v[:, js, o + 1 - i] = v[:, js, o + ii + 1 - i]
+                v[:, js, o + ii + i] = v[:, js, o + i]
+
+
+# ----------------------------------------------------------------------------------
+# bigrid: integer masks (bit-exact integer work)
+# ----------------------------------------------------------------------------------
+def bigrid_np(depth_in, idm, jdm):
+    """Returns (nreg, depth_with_halo, ip, iu, iv, iq) following phy/mod_bigrid.F90:59-302
+    for a single tile (i0=j0=0, ii=idm, jj=jdm)."""
+    ii, jj = idm, jdm
+    depth = depth_in.copy()
+    o = NBDY - 1
+    lperiodi = depth[sl(1, jj), o + ii].max() > 0.0
+    lperiodj = depth[o + jj, sl(1, ii)].max() > 0.0
+    if not lperiodi and not lperiodj:
+        nreg = 0
+    elif lperiodi and not lperiodj:
+        nreg = 1
+    elif lperiodi and lperiodj:
+        nreg = 3
+    else:
+        nreg = 4
+    d3 = depth[None]
+    xctilr_np(d3, 1, 1, NBDY, NBDY, nreg, ii, jj)
+    if not lperiodj:
+        depth[:o + 1, :] = 0.0
+        depth[o + jj + 1:, :] = 0.0
+    if not lperiodi:
+        depth[:, :o + 1] = 0.0
+        depth[:, o + ii + 1:] = 0.0
+    nj, ni = depth.shape
+    ip = (depth > 0.0).astype(np.int32)
+    iu = np.zeros_like(ip)
+    iv = np.zeros_like(ip)
+    iq = np.zeros_like(ip)
+    J, I = sl(1, jj), sl(1, ii)
+    Jm, Im = sl(0, jj - 1), sl(0, ii - 1)
+    iu[J, I] = ((ip[J, Im] > 0) & (ip[J, I] > 0)).astype(np.int32)
+    iv[J, I] = ((ip[Jm, I] > 0) & (ip[J, I] > 0)).astype(np.int32)
+    allfour = np.minimum(np.minimum(ip[J, I], ip[J, Im]), np.minimum(ip[Jm, I], ip[Jm, Im])) > 0
+    diag = ((ip[J, I] > 0) & (ip[Jm, Im] > 0)) | ((ip[J, Im] > 0) & (ip[Jm, I] > 0))
+    iq[J, I] = (allfour | diag).astype(np.int32)
+    for msk in (iu, iv, iq):
+        f = msk.astype(np.float64)[None]
+        xctilr_np(f, 1, 1, NBDY, NBDY, nreg, ii, jj)
+        msk[:, :] = np.rint(f[0]).astype(np.int32)
+        if not lperiodj:
+            msk[:o + 1, :] = 0
+            msk[o + jj + 1:, :] = 0
+        if not lperiodi:
+            msk[:, :o + 1] = 0
+            msk[:, o + ii + 1:] = 0
+    return nreg, depth, ip, iu, iv, iq
+
+
+# ----------------------------------------------------------------------------------
+# numerical_bounds (phy/mod_blom_init.F90:446-555)
+# ----------------------------------------------------------------------------------
+def numerical_bounds_np(grid, masks, baclin, nreg, ii, jj):
+    scpx, scpy, scqx, scqy = grid["scpx"], grid["scpy"], grid["scqx"], grid["scqy"]
+    dx2, dy2 = scpx * scpx, scpy * scpy
+    difmxp = .9 * .5 * dx2 * dy2 / np.maximum(1.0, (dx2 + dy2) * (baclin + baclin))
+    dx2, dy2 = scqx * scqx, scqy * scqy
+    difmxq = .9 * .5 * dx2 * dy2 / np.maximum(1.0, (dx2 + dy2) * (baclin + baclin))
+    scp2, scuy, scvx = grid["scp2"], grid["scuy"], grid["scvx"]
+    umax = np.zeros_like(scp2)
+    vmax = np.zeros_like(scp2)
+    J, I = sl(1, jj), sl(1, ii)
+    Jm, Im = sl(0, jj - 1), sl(0, ii - 1)
+    um = .9 * .125 * np.minimum(scp2[J, Im], scp2[J, I]) / (scuy[J, I] * baclin)
+    vm = .9 * .125 * np.minimum(scp2[Jm, I], scp2[J, I]) / (scvx[J, I] * baclin)
+    umax[J, I] = np.where(masks["iu"][J, I] > 0, um, 0.0)
+    vmax[J, I] = np.where(masks["iv"][J, I] > 0, vm, 0.0)
+    for a in (umax, vmax):
+        xctilr_np(a[None], 1, 1, NBDY, NBDY, nreg, ii, jj)
+    return difmxp, difmxq, umax, vmax
+
+
+# ----------------------------------------------------------------------------------
+# the initialisation sequence proper
+# ----------------------------------------------------------------------------------
+def _halo(be, name, nlev, mh, nh, nreg, ii, jj, l1=1):
+    a = be.get(name)
+    xctilr_np(a, l1, nlev, mh, nh, nreg, ii, jj)
+    be.put(name, a)
+
+
+def init_state(be, case):
+    """Bring backend `be` (already set up for case.depth: masks known, arrays holding
+    their inivar_* patterns) to the state blom_step expects at nstep = 0."""
+    kk, ii, jj, nreg = case.kdm, case.idm, case.jdm, case.nreg
+    P = case.params
+    ip, iu, iv, iq = (be.masks[k] for k in ("ip", "iu", "iv", "iq"))
+    J, I = sl(1, jj), sl(1, ii)
+    wet = ip[J, I] > 0
+
+    for nm, v in P.items():
+        if nm.endswith("0"):
+            continue            # generator-only amplitudes (difiso0, taux0, ...)
+        be.set(nm, v)
+    be.set("nstep", 0)
+
+    for nm, arr in case.grid.items():
+        be.put(nm, arr[None])
+    difmxp, difmxq, umax, vmax = numerical_bounds_np(case.grid, be.masks, P["baclin"], nreg, ii, jj)
+    be.put("difmxp", difmxp[None])
+    be.put("difmxq", difmxq[None])
+    be.put("umax", umax[None])
+    be.put("vmax", vmax[None])
+
+    # -- layer structure at both time levels (mod_inicon.F90:1163-1186) ---------------
+    for nm in ("dp", "temp", "saln", "sigma"):
+        a = be.get(nm)
+        src = case.ic[nm]
+        for lev in (0, kk):
+            a[lev:lev + kk, J, I] = np.where(wet, src[:, J, I], a[lev:lev + kk, J, I])
+        be.put(nm, a)
+    a = be.get("sigmar")
+    a[:, J, I] = np.where(wet, case.ic["sigmar"][:, J, I], a[:, J, I])
+    be.put("sigmar", a)
+    if be.ntr > 0:
+        a = be.get("trc")                      # (ntr*2*kk, nj, ni), Fortran trc(i,j,k,nt)
+        for nt in range(be.ntr):
+            for lev in (0, kk):
+                b = nt * 2 * kk + lev
+                a[b:b + kk, J, I] = np.where(wet, case.ic["trc"][nt][:, J, I], a[b:b + kk, J, I])
+        be.put("trc", a)
+
+    # -- first physical interior layer kfpla (mod_inicon.F90:1394-1420), bulkml only ---
+    dp = be.get("dp")
+    kf = be.get("kfpla")
+    d1 = dp[:kk]
+    for jx in range(NBDY, NBDY + jj):
+        for ix in range(NBDY, NBDY + ii):
+            if ip[jx, ix] == 0:
+                continue
+            k = 3
+            dps = 0.0
+            while k <= kk and d1[k - 1, jx, ix] < EPSILP:
+                dps += d1[k - 1, jx, ix]
+                d1[k - 1, jx, ix] = 0.0
+                k += 1
+            if k > kk:
+                d1[1, jx, ix] += dps
+            else:
+                d1[k - 1, jx, ix] += dps
+            kf[0, jx, ix] = k
+            kf[1, jx, ix] = k
+    dp[kk:2 * kk, J, I] = np.where(wet, dp[:kk, J, I], dp[kk:2 * kk, J, I])
+    be.put("dp", dp)
+    be.put("kfpla", kf)
+
+    for nm, nl in (("dp", 2 * kk), ("temp", 2 * kk), ("saln", 2 * kk), ("sigma", 2 * kk), ("sigmar", kk)):
+        _halo(be, nm, nl, NBDY, NBDY, nreg, ii, jj)
+    if be.ntr > 0:
+        _halo(be, "trc", 2 * kk * be.ntr, NBDY, NBDY, nreg, ii, jj)
+
+    # -- interface pressures and velocity-point thicknesses (mod_blom_init.F90:269-310) -
+    dp = be.get("dp")
+    p = be.get("p")
+    dpu, dpv = be.get("dpu"), be.get("dpv")
+    pu, pv = be.get("pu"), be.get("pv")
+    Jp, Ip = sl(-2, jj + 2), sl(-2, ii + 2)
+    wp = ip[Jp, Ip] > 0
+    for mmt in (0, kk):                        # n = 1 first, then m = 2
+        for k in range(kk):
+            p[k + 1, Jp, Ip] = np.where(wp, p[k, Jp, Ip] + dp[k + mmt, Jp, Ip], p[k + 1, Jp, Ip])
+        Ju, Iu = sl(-1, jj + 2), sl(-1, ii + 2)
+        Jum, Ium = sl(-2, jj + 1), sl(-2, ii + 1)
+        mu = iu[Ju, Iu] > 0
+        mv = iv[Ju, Iu] > 0
+        qu = np.minimum(p[kk, Ju, Iu], p[kk, Ju, Ium])
+        qv = np.minimum(p[kk, Ju, Iu], p[kk, Jum, Iu])
+        for k in range(kk):
+            du = .5 * ((np.minimum(qu, p[k + 1, Ju, Ium]) - np.minimum(qu, p[k, Ju, Ium]))
+                       + (np.minimum(qu, p[k + 1, Ju, Iu]) - np.minimum(qu, p[k, Ju, Iu])))
+            dv = .5 * ((np.minimum(qv, p[k + 1, Jum, Iu]) - np.minimum(qv, p[k, Jum, Iu]))
+                       + (np.minimum(qv, p[k + 1, Ju, Iu]) - np.minimum(qv, p[k, Ju, Iu])))
+            dpu[k + mmt, Ju, Iu] = np.where(mu, du, dpu[k + mmt, Ju, Iu])
+            dpv[k + mmt, Ju, Iu] = np.where(mv, dv, dpv[k + mmt, Ju, Iu])
+            if mmt == 0:                       # mod_inicon.F90:1138,1148
+                pu[k + 1, Ju, Iu] = np.where(mu, pu[k, Ju, Iu] + du, pu[k + 1, Ju, Iu])
+                pv[k + 1, Ju, Iu] = np.where(mv, pv[k, Ju, Iu] + dv, pv[k + 1, Ju, Iu])
+    for nm, a in (("p", p), ("dpu", dpu), ("dpv", dpv), ("pu", pu), ("pv", pv)):
+        be.put(nm, a)
+
+    # -- bottom pressures (mod_inicon.F90:1095-1125) ------------------------------------
+    J0, I0 = sl(0, jj + 1), sl(0, ii + 1)
+    w0 = ip[J0, I0] > 0
+    pb, pb_mn, pb_p = be.get("pb"), be.get("pb_mn"), be.get("pb_p")
+    for a in (pb, pb_mn):
+        for lev in (0, 1):
+            a[lev, J0, I0] = np.where(w0, p[kk, J0, I0], a[lev, J0, I0])
+    pb_p[0, J0, I0] = np.where(w0, p[kk, J0, I0], pb_p[0, J0, I0])
+    be.put("pb", pb)
+    be.put("pb_mn", pb_mn)
+    be.put("pb_p", pb_p)
+    Jm, Im = sl(0, jj - 1), sl(0, ii - 1)
+    pbu, pbv, pbu_p, pbv_p = be.get("pbu"), be.get("pbv"), be.get("pbu_p"), be.get("pbv_p")
+    mu, mv = iu[J, I] > 0, iv[J, I] > 0
+    bu = np.minimum(pb[0, J, I], pb[0, J, Im])
+    bv = np.minimum(pb[0, J, I], pb[0, Jm, I])
+    for lev in (0, 1):
+        pbu[lev, J, I] = np.where(mu, bu, pbu[lev, J, I])
+        pbv[lev, J, I] = np.where(mv, bv, pbv[lev, J, I])
+    pbu_p[0, J, I] = np.where(mu, bu, pbu_p[0, J, I])
+    pbv_p[0, J, I] = np.where(mv, bv, pbv_p[0, J, I])
+    for nm, a in (("pbu", pbu), ("pbv", pbv), ("pbu_p", pbu_p), ("pbv_p", pbv_p)):
+        be.put(nm, a)
+
+    # -- barotropic potential vorticity (mod_inicon.F90:1192-1232) ----------------------
+    corioq = case.grid["corioq"]
+    pv_ = be.get("pvtrop")
+    o = NBDY - 1
+    for j in range(0, jj + 1):
+        for i in range(1, ii + 1):
+            if iu[o + j, o + i]:
+                q = 2. / (pb_p[0, o + j, o + i] + pb_p[0, o + j, o + i - 1])
+                pv_[:, o + j, o + i] = corioq[o + j, o + i] * q
+                pv_[:, o + j + 1, o + i] = corioq[o + j + 1, o + i] * q
+    for j in range(1, jj + 1):
+        for i in range(0, ii + 1):
+            if iv[o + j, o + i]:
+                q = 2. / (pb_p[0, o + j, o + i] + pb_p[0, o + j - 1, o + i])
+                pv_[:, o + j, o + i] = corioq[o + j, o + i] * q
+                pv_[:, o + j, o + i + 1] = corioq[o + j, o + i + 1] * q
+    for j in range(1, jj + 1):
+        for i in range(1, ii + 1):
+            if iq[o + j, o + i]:
+                pv_[:, o + j, o + i] = corioq[o + j, o + i] * 4. / (
+                    pb_p[0, o + j, o + i] + pb_p[0, o + j, o + i - 1]
+                    + pb_p[0, o + j - 1, o + i] + pb_p[0, o + j - 1, o + i - 1])
+    be.put("pvtrop", pv_)
+
+    # -- frozen diffusivities and forcing (difest_* needs CVMix: out of scope) ----------
+    wfull = ip > 0
+    for nm, v in (("difiso", P["difiso0"]), ("difint", P["difint0"]), ("difdia", P["difdia0"])):
+        a = be.get(nm)
+        a[:] = np.where(wfull[None], np.minimum(v, difmxp[None]), a)
+        be.put(nm, a)
+    a = be.get("difwgt")
+    a[:] = np.where(wfull[None], P["difwgt0"], a)
+    be.put("difwgt", a)
+    jy = (np.arange(1, jj + 1)[:, None] - 0.5) / jj
+    taux = be.get("taux")
+    taux[0, J, I] = np.where(iu[J, I] > 0, P["taux0"] * np.sin(np.pi * jy) ** 2 * np.ones((jj, ii)),
+                             taux[0, J, I])
+    be.put("taux", taux)
+    tauy = be.get("tauy")
+    tauy[0, J, I] = np.where(iv[J, I] > 0, 0.0, tauy[0, J, I])
+    be.put("tauy", tauy)
+    for nm in ("umfltd", "vmfltd", "umflsm", "vmflsm", "utfltd", "vtfltd", "utflsm", "vtflsm",
+               "usfltd", "vsfltd", "usflsm", "vsflsm"):
+        a = be.get(nm)
+        msk = (iu if nm[0] == "u" else iv) > 0
+        a[:] = np.where(msk[None], 0.0, a)
+        be.put(nm, a)
+
+    # -- geopotential of the sea floor (cf. channel/mod_channel.F90:311-320) ------------
+    _, depth_h, _, _, _, _ = bigrid_np(case.depth, ii, jj)
+    phi = be.get("phi")
+    phi[kk] = np.where(wfull, -GRAV * depth_h, phi[kk])
+    be.put("phi", phi)
+
+    # -- pressure gradient force fields via the stage itself (mod_inicon.F90:1351) ------
+    be.stage("pgforc", 2, 1, kk, 0, kk + 1, 1)
+    for nm, msk in (("pgfx", mu), ("pgfy", mv)):
+        a = be.get(nm)
+        a[kk:2 * kk, J, I] = np.where(msk, a[:kk, J, I], a[kk:2 * kk, J, I])
+        be.put(nm, a)
+    for nm, msk in (("pgfxm", mu), ("xixp", mu), ("xixm", mu), ("pgfym", mv), ("xiyp", mv), ("xiym", mv)):
+        a = be.get(nm)
+        a[1, J, I] = np.where(msk, a[0, J, I], a[1, J, I])
+        be.put(nm, a)
+
+    # -- old-level copies for the time filters (mod_inicon.F90:1426-1437, initms) --------
+    dp = be.get("dp")
+    dpold = be.get("dpold")
+    for lev in (0, kk):
+        dpold[lev:lev + kk, J, I] = np.where(wet, dp[:kk, J, I], dpold[lev:lev + kk, J, I])
+    be.put("dpold", dpold)
+    be.stage("initms", 2, 1, kk, 0, kk + 1, 1)
+
+    # -- halo updates of blom_init_phase2 (mod_blom_init.F90:360-378) --------------------
+    for nm, nl, mh, nh in (("sigmar", kk, 2, 2), ("uflx", 2 * kk, 1, 1), ("vflx", 2 * kk, 1, 1),
+                           ("pvtrop", 2, 1, 3), ("pgfxm", 2, 1, 2), ("xixp", 2, 1, 2),
+                           ("xixm", 2, 1, 2), ("pgfym", 2, 1, 2), ("xiyp", 2, 1, 2),
+                           ("xiym", 2, 1, 2), ("difiso", kk, 1, 1), ("taux", 1, 1, 1),
+                           ("tauy", 1, 1, 1)):
+        _halo(be, nm, nl, mh, nh, nreg, ii, jj)
+    a = be.get("phi")
+    xctilr_np(a, kk + 1, kk + 1, 2, 2, nreg, ii, jj)
+    be.put("phi", a)
+
+
+def step_indices(nstep, kk):
+    """Time-level sextuple of blom_step (phy/mod_blom_step.F90:89-94) for the value of
+    nstep BEFORE step_time increments it."""
+    m = nstep % 2 + 1
+    n = (nstep + 1) % 2 + 1
+    mm = (m - 1) * kk
+    nn = (n - 1) * kk
+    return m, n, mm, nn, 1 + mm, 1 + nn

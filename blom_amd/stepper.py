@@ -1,0 +1,30 @@
+"""Stage sequencing of one baroclinic step of the dynamical core.
+
+Mirrors the order of phy/mod_blom_step.F90:96-253 for the isopyc_bulkml branch,
+restricted to the stages of the hot path and the ones sitting between them
+(SURVEY.md 8a/8f).  Stages whose reference modules need netCDF/CVMix (cmnfld, difest,
+eddtra, mxlayr, thermf) are not part of the sequence: diffusivities stay frozen and the
+eddy-induced fluxes umfltd/vmfltd stay zero.
+"""
+from .hostinit import step_indices
+
+DYNCORE_STAGES = ("init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", "pbcor1",
+                  "diffus", "pgforc", "momtum", "diapfl", "mxlayr_tail", "barotp", "pbcor2",
+                  "tmsmt2")
+# halo_cmnfld2 / halo_difest : the xctilr calls of phy/mod_cmnfld_routines.F90:1171-1172 and
+#   phy/mod_difest.F90:750-755 (the stages themselves are out of scope, their halo updates
+#   are not: advect and momtum read those halos).
+# mxlayr_tail : phy/mod_mxlayr.F90:1266-1310, halo of dp at the new level + dpu/dpv.
+
+
+def dyncore_step(be, nstep, baclin, stages=DYNCORE_STAGES, hook=None):
+    """Advance backend `be` from step count nstep to nstep+1.  `hook(stage, sextuple)` is
+    called before each stage (tests use it to snapshot stage inputs)."""
+    six = step_indices(nstep, be.kdm)
+    be.set("nstep", nstep + 1)               # step_time, phy/mod_blom_step.F90:99
+    for st in stages:
+        if hook is not None:
+            hook(st, six)
+        be.stage(st, *six)
+    be.set("delt1", baclin + baclin)         # phy/mod_blom_step.F90:300
+    return nstep + 1

@@ -1,0 +1,457 @@
+! ------------------------------------------------------------------------------
+! TEST INFRASTRUCTURE (oracle) -- not product code.
+!
+! C-callable harness around the *reference's own* BLOM modules (compiled from
+! /root/reference by oracle/Makefile into oracle/_ref/<cfg>/libblomref.so).
+! It exposes
+!   ref_dims        compile-time dimensions of this build
+!   ref_setup       xcspmd + bigrid(depths) + the inivar_* of every module that
+!                   builds here (the netCDF/CVMix dependent ones are absent)
+!   ref_field       address/shape of a reference module array (numpy view)
+!   ref_set_* / ref_get_*   scalar namelist-type options (mod_rdlim is netCDF
+!                   bound, so options are poked directly into their modules)
+!   ref_stage       call one reference stage with the (m,n,mm,nn,k1m,k1n) sextuple
+!   ref_xctilr      the reference halo update
+! Nothing here restates reference arithmetic; it only calls it.
+! ------------------------------------------------------------------------------
+module ref_harness
+
+  use iso_c_binding
+  use dimensions,    only: idm, jdm, kdm, itdm, jtdm
+  use mod_xc
+  use mod_config,    only: expcnf
+  use mod_time,      only: baclin, batrop, delt1, dlt, lstep, nstep
+  use mod_grid
+  use mod_state
+  use mod_eos,       only: pref, inieos
+  use mod_bigrid,    only: bigrid
+  use mod_checksum,  only: csdiag
+  use mod_vcoord,    only: vcoord_tag, sigmar, inivar_vcoord
+  use mod_pgforc
+  use mod_momtum
+  use mod_barotp
+  use mod_tmsmt
+  use mod_diffusion
+  use mod_utility
+  use mod_forcing
+  use mod_advect,    only: advect, advmth
+  use mod_pbcor,     only: pbcor1, pbcor2, bmcmth
+  use mod_diffus,    only: diffus
+  use mod_diapfl,    only: diapfl
+  use mod_convec,    only: convec
+  use mod_tracers,   only: ntr, trc, trcold, inivar_tracers
+  use mod_cmnfld,    only: inivar_cmnfld
+  use mod_ifdefs,    only: use_TRC
+
+  implicit none
+  private
+
+  interface
+    subroutine ref_capture_r8(a, out) bind(C, name='ref_capture_r8')
+      import :: c_double, c_ptr
+      real(c_double) :: a(*)
+      type(c_ptr)    :: out
+    end subroutine
+    subroutine ref_capture_i4(a, out) bind(C, name='ref_capture_i4')
+      import :: c_int, c_ptr
+      integer(c_int) :: a(*)
+      type(c_ptr)    :: out
+    end subroutine
+  end interface
+
+contains
+
+  function cstr(s) result(f)
+    character(kind=c_char), intent(in) :: s(*)
+    character(len=80) :: f
+    integer :: i
+    f = ' '
+    do i = 1, 80
+      if (s(i) == c_null_char) exit
+      f(i:i) = s(i)
+    end do
+  end function cstr
+
+  subroutine ref_dims(d) bind(C, name='ref_dims')
+    integer(c_int), intent(out) :: d(8)
+    d(1) = idm; d(2) = jdm; d(3) = kdm; d(4) = nbdy
+    d(5) = itdm; d(6) = jtdm; d(7) = ntr; d(8) = nreg
+  end subroutine ref_dims
+
+  subroutine ref_setup(depth) bind(C, name='ref_setup')
+    real(c_double), intent(in) :: depth(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy)
+    call xcspmd
+    depths(:,:) = depth(:,:)
+    call bigrid(depths)
+    call inivar_tracers
+    call inivar_vcoord
+    call inivar_state
+    call inivar_pgforc
+    call inivar_momtum
+    call inivar_barotp
+    call inivar_tmsmt
+    call inivar_diffusion
+    call inivar_utility
+    call inivar_forcing
+    call inivar_cmnfld
+    call inieos
+  end subroutine ref_setup
+
+  subroutine ref_set_real(name, v, ierr) bind(C, name='ref_set_real')
+    character(kind=c_char), intent(in) :: name(*)
+    real(c_double), value :: v
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+      case ('baclin'); baclin = v
+      case ('batrop'); batrop = v
+      case ('delt1');  delt1 = v
+      case ('dlt');    dlt = v
+      case ('pref');   pref = v
+      case ('mdv2hi'); mdv2hi = v
+      case ('mdv2lo'); mdv2lo = v
+      case ('mdv4hi'); mdv4hi = v
+      case ('mdv4lo'); mdv4lo = v
+      case ('mdc2hi'); mdc2hi = v
+      case ('mdc2lo'); mdc2lo = v
+      case ('vsc2hi'); vsc2hi = v
+      case ('vsc2lo'); vsc2lo = v
+      case ('vsc4hi'); vsc4hi = v
+      case ('vsc4lo'); vsc4lo = v
+      case ('cbar');   cbar = v
+      case ('cb');     cb = v
+      case ('cwbdts'); cwbdts = v
+      case ('cwbdls'); cwbdls = v
+      case ('wuv1');   wuv1 = v
+      case ('wuv2');   wuv2 = v
+      case ('wts1');   wts1 = v
+      case ('wts2');   wts2 = v
+      case ('wbaro');  wbaro = v
+      case ('bdmc1');  bdmc1 = v
+      case ('bdmc2');  bdmc2 = v
+      case ('iwdfac'); iwdfac = v
+      case ('nubmin'); nubmin = v
+      case ('vland');  vland = v
+      case default; ierr = 1
+    end select
+  end subroutine ref_set_real
+
+  subroutine ref_get_real(name, v, ierr) bind(C, name='ref_get_real')
+    character(kind=c_char), intent(in) :: name(*)
+    real(c_double), intent(out) :: v
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+      case ('baclin'); v = baclin
+      case ('batrop'); v = batrop
+      case ('delt1');  v = delt1
+      case ('dlt');    v = dlt
+      case ('pref');   v = pref
+      case ('wbaro');  v = wbaro
+      case ('wpgf');   v = wpgf
+      case default; ierr = 1; v = 0
+    end select
+  end subroutine ref_get_real
+
+  subroutine ref_set_int(name, v, ierr) bind(C, name='ref_set_int')
+    character(kind=c_char), intent(in) :: name(*)
+    integer(c_int), value :: v
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+      case ('lstep');      lstep = v
+      case ('nstep');      nstep = v
+      case ('vcoord_tag'); vcoord_tag = v
+      case ('ltedtp_opt'); ltedtp_opt = v
+      case ('bdmtyp');     bdmtyp = v
+      case ('iwdflg');     iwdflg = v
+      case ('csdiag');     csdiag = (v /= 0)
+      case ('bdmldp');     bdmldp = (v /= 0)
+      case default; ierr = 1
+    end select
+  end subroutine ref_set_int
+
+  subroutine ref_get_int(name, v, ierr) bind(C, name='ref_get_int')
+    character(kind=c_char), intent(in) :: name(*)
+    integer(c_int), intent(out) :: v
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+      case ('lstep'); v = lstep
+      case ('nstep'); v = nstep
+      case ('nreg');  v = nreg
+      case ('ntr');   v = ntr
+      case ('ii');    v = ii
+      case ('jj');    v = jj
+      case default; ierr = 1; v = 0
+    end select
+  end subroutine ref_get_int
+
+  subroutine ref_set_str(name, s, ierr) bind(C, name='ref_set_str')
+    character(kind=c_char), intent(in) :: name(*), s(*)
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+      case ('expcnf'); expcnf = trim(cstr(s))
+      case ('mommth'); mommth = trim(cstr(s))
+      case ('pgfmth'); pgfmth = trim(cstr(s))
+      case ('advmth'); advmth = trim(cstr(s))
+      case ('bmcmth'); bmcmth = trim(cstr(s))
+      case default; ierr = 1
+    end select
+  end subroutine ref_set_str
+
+  ! kind: 0 = real(8), 1 = integer(4).  nlev = size of 3rd dimension (1 for 2-D).
+  subroutine ref_field(name, ptr, nlev, kind) bind(C, name='ref_field')
+    character(kind=c_char), intent(in) :: name(*)
+    type(c_ptr), intent(out) :: ptr
+    integer(c_int), intent(out) :: nlev, kind
+    kind = 0
+    nlev = 1
+    ptr = c_null_ptr
+#define R3(nm, nl) case (#nm); call ref_capture_r8(nm, ptr); nlev = nl
+#define R2(nm) case (#nm); call ref_capture_r8(nm, ptr); nlev = 1
+#define I2(nm) case (#nm); call ref_capture_i4(nm, ptr); nlev = 1; kind = 1
+    select case (trim(cstr(name)))
+      ! mod_state
+      R3(u, 2*kdm)
+      R3(v, 2*kdm)
+      R3(dp, 2*kdm)
+      R3(dpu, 2*kdm)
+      R3(dpv, 2*kdm)
+      R3(temp, 2*kdm)
+      R3(saln, 2*kdm)
+      R3(sigma, 2*kdm)
+      R3(uflx, 2*kdm)
+      R3(vflx, 2*kdm)
+      R3(utflx, 2*kdm)
+      R3(vtflx, 2*kdm)
+      R3(usflx, 2*kdm)
+      R3(vsflx, 2*kdm)
+      R3(p, kdm+1)
+      R3(pu, kdm+1)
+      R3(pv, kdm+1)
+      R3(phi, kdm+1)
+      R3(cau, kdm)
+      R3(cav, kdm)
+      R3(ubflxs, 3)
+      R3(vbflxs, 3)
+      R3(ub, 2)
+      R3(vb, 2)
+      R3(pb, 2)
+      R3(pbu, 2)
+      R3(pbv, 2)
+      R3(ubflxs_p, 2)
+      R3(vbflxs_p, 2)
+      R2(pb_p)
+      R2(pbu_p)
+      R2(pbv_p)
+      R2(ubcors_p)
+      R2(vbcors_p)
+      R2(sealv)
+      case ('kfpla'); call ref_capture_i4(kfpla, ptr); nlev = 2; kind = 1
+      ! masks (mod_xc)
+      I2(ip)
+      I2(iu)
+      I2(iv)
+      I2(iq)
+      ! mod_grid
+      R2(scqx)
+      R2(scqy)
+      R2(scpx)
+      R2(scpy)
+      R2(scux)
+      R2(scuy)
+      R2(scvx)
+      R2(scvy)
+      R2(scq2)
+      R2(scp2)
+      R2(scu2)
+      R2(scv2)
+      R2(scq2i)
+      R2(scp2i)
+      R2(scuxi)
+      R2(scuyi)
+      R2(scvxi)
+      R2(scvyi)
+      R2(depths)
+      R2(corioq)
+      R2(coriop)
+      R2(betafp)
+      ! mod_pgforc
+      R3(pgfx, 2*kdm)
+      R3(pgfy, 2*kdm)
+      R3(pgfx_o, kdm)
+      R3(pgfy_o, kdm)
+      R3(pgfxm, 2)
+      R3(pgfym, 2)
+      R3(xixp, 2)
+      R3(xixm, 2)
+      R3(xiyp, 2)
+      R3(xiym, 2)
+      R2(pgfxm_o)
+      R2(pgfym_o)
+      R2(xixp_o)
+      R2(xixm_o)
+      R2(xiyp_o)
+      R2(xiym_o)
+      ! mod_momtum
+      R3(absvor, 2*kdm)
+      R3(dpvor, 2*kdm)
+      ! mod_barotp
+      R3(ubflx, 2)
+      R3(vbflx, 2)
+      R3(pb_mn, 2)
+      R3(ubflx_mn, 2)
+      R3(vbflx_mn, 2)
+      R3(pvtrop, 2)
+      ! mod_tmsmt
+      R3(dpold, 2*kdm)
+      R3(dpuold, kdm)
+      R3(dpvold, kdm)
+      ! mod_vcoord
+      R3(sigmar, kdm)
+      ! mod_diffusion
+      R3(difint, kdm)
+      R3(difiso, kdm)
+      R3(difdia, kdm)
+      R2(difmxp)
+      R2(difmxq)
+      R2(difwgt)
+      R3(umfltd, 2*kdm)
+      R3(vmfltd, 2*kdm)
+      R3(umflsm, 2*kdm)
+      R3(vmflsm, 2*kdm)
+      R3(utfltd, 2*kdm)
+      R3(vtfltd, 2*kdm)
+      R3(utflsm, 2*kdm)
+      R3(vtflsm, 2*kdm)
+      R3(utflld, 2*kdm)
+      R3(vtflld, 2*kdm)
+      R3(usfltd, 2*kdm)
+      R3(vsfltd, 2*kdm)
+      R3(usflsm, 2*kdm)
+      R3(vsflsm, 2*kdm)
+      R3(usflld, 2*kdm)
+      R3(vsflld, 2*kdm)
+      ! mod_utility
+      R2(utotm)
+      R2(vtotm)
+      R2(utotn)
+      R2(vtotn)
+      R2(uflux)
+      R2(vflux)
+      R2(uflux2)
+      R2(vflux2)
+      R2(uflux3)
+      R2(vflux3)
+      R2(umax)
+      R2(vmax)
+      R2(util1)
+      R2(util2)
+      R2(util3)
+      R2(util4)
+      ! mod_forcing
+      R2(taux)
+      R2(tauy)
+      R2(ustarb)
+      ! mod_tracers (allocatable; ntr may be 0)
+      case ('trc')
+        if (allocated(trc)) then
+          call ref_capture_r8(trc, ptr); nlev = 2*kdm*ntr
+        end if
+      case ('trcold')
+        if (allocated(trcold)) then
+          call ref_capture_r8(trcold, ptr); nlev = kdm*ntr
+        end if
+      case default
+        nlev = 0
+    end select
+  end subroutine ref_field
+
+  subroutine ref_stage(name, m, n, mm, nn, k1m, k1n, ierr) bind(C, name='ref_stage')
+    character(kind=c_char), intent(in) :: name(*)
+    integer(c_int), value :: m, n, mm, nn, k1m, k1n
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+      case ('init_fluxes'); call init_fluxes(m,n,mm,nn,k1m,k1n,.false.)
+      case ('tmsmt1');  call tmsmt1(nn)
+      case ('initms');  call initms(mm)
+      case ('advect');  call advect(m,n,mm,nn,k1m,k1n)
+      case ('pbcor1');  call pbcor1(m,n,mm,nn,k1m,k1n)
+      case ('diffus');  call diffus(m,n,mm,nn,k1m,k1n)
+      case ('pgforc');  call pgforc(m,n,mm,nn,k1m,k1n)
+      case ('momtum');  call momtum(m,n,mm,nn,k1m,k1n)
+      case ('convec');  call convec(m,n,mm,nn,k1m,k1n)
+      case ('diapfl');  call diapfl(n,nn,k1n)
+      case ('barotp');  call barotp(m,n,mm,nn,k1m,k1n)
+      case ('pbcor2');  call pbcor2(m,n,mm,nn,k1m,k1n)
+      case ('tmsmt2');  call tmsmt2(m,mm,nn,k1m)
+      ! Halo updates the reference performs inside stages that cannot be built here
+      ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.
+      case ('halo_cmnfld2')   ! phy/mod_cmnfld_routines.F90:1171-1172
+        call xctilr(temp, 1, 2*kk, 3, 3, halo_ps)
+        call xctilr(saln, 1, 2*kk, 3, 3, halo_ps)
+      case ('halo_difest')    ! phy/mod_difest.F90:750-755
+        call xctilr(u, 1,2*kk, 2,2, halo_uv)
+        call xctilr(v, 1,2*kk, 2,2, halo_vv)
+        call xctilr(ubflxs_p, 1,2, 2,2, halo_uv)
+        call xctilr(vbflxs_p, 1,2, 2,2, halo_vv)
+        call xctilr(pbu, 1,2, 2,2, halo_us)
+        call xctilr(pbv, 1,2, 2,2, halo_vs)
+      case ('mxlayr_tail');  call mxlayr_tail(nn, k1n)
+      case default; ierr = 1
+    end select
+  end subroutine ref_stage
+
+  subroutine mxlayr_tail(nn, k1n)
+    ! RESTATEMENT of phy/mod_mxlayr.F90:1266-1310 ("store 'new' layer thicknesses in
+    ! -dpu,dpv-"): mod_mxlayr itself cannot be built here (netCDF), and its bulk mixed
+    ! layer physics is out of scope, but the next step relies on this halo update of
+    ! dp(:,:,k1n:) and on dpu/dpv at the new time level being consistent with it.
+    ! The arithmetic is identical to the tail of tmsmt2 (phy/mod_tmsmt.F90:352-391).
+    integer, intent(in) :: nn, k1n
+    integer :: i, j, k, l, kn
+    real(8) :: q
+    call xctilr(dp(1-nbdy,1-nbdy,k1n), 1,kk, 3,3, halo_ps)
+    do j = -2,jj+2
+      do k = 1,kk
+        kn = k+nn
+        do l = 1,isp(j)
+          do i = max(-2,ifp(j,l)),min(ii+2,ilp(j,l))
+            p(i,j,k+1) = p(i,j,k)+dp(i,j,kn)
+          end do
+        end do
+      end do
+    end do
+    do j = -1,jj+2
+      do k = 1,kk
+        kn = k+nn
+        do l = 1,isu(j)
+          do i = max(-1,ifu(j,l)),min(ii+2,ilu(j,l))
+            q = min(p(i,j,kk+1),p(i-1,j,kk+1))
+            dpu(i,j,kn)= &
+                 .5*((min(q,p(i-1,j,k+1))-min(q,p(i-1,j,k))) &
+                 +(min(q,p(i  ,j,k+1))-min(q,p(i  ,j,k))))
+          end do
+        end do
+        do l = 1,isv(j)
+          do i = max(-1,ifv(j,l)),min(ii+2,ilv(j,l))
+            q = min(p(i,j,kk+1),p(i,j-1,kk+1))
+            dpv(i,j,kn)= &
+                 .5*((min(q,p(i,j-1,k+1))-min(q,p(i,j-1,k))) &
+                    +(min(q,p(i,j  ,k+1))-min(q,p(i,j  ,k))))
+          end do
+        end do
+      end do
+    end do
+  end subroutine mxlayr_tail
+
+  subroutine ref_xctilr(a, l1, ld, mh, nh, itype) bind(C, name='ref_xctilr')
+    integer(c_int), value :: l1, ld, mh, nh, itype
+    real(c_double), intent(inout) :: a(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,ld)
+    call xctilr(a, l1, ld, mh, nh, itype)
+  end subroutine ref_xctilr
+
+end module ref_harness

@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE (oracle) -- ctypes access to oracle/_ref/<cfg>/libblomref.so,
+i.e. the reference's own Fortran stage routines (phy/mod_advect.F90 ... compiled by
+oracle/Makefile) behind oracle/harness/ref_harness.F90.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Arrays are zero-copy numpy views of the reference's module storage with shape
+(nlev, jdm+2*nbdy, idm+2*nbdy): Fortran a(i,j,k) == view[k-1, j+nbdy-1, i+nbdy-1].
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def ref_lib_path(cfg):
+    return os.path.join(_HERE, "_ref", cfg, "libblomref.so")
+
+
+def have_ref(cfg):
+    return os.path.exists(ref_lib_path(cfg))
+
+
+class RefBlom:
+    """One instance per process and configuration (the reference keeps all state
+    in Fortran module globals)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        # RTLD_LOCAL + distinct file => several configs can coexist in a process.
+        self.lib = C.CDLL(ref_lib_path(cfg), mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        d = (C.c_int * 8)()
+        self.lib.ref_dims(d)
+        self.idm, self.jdm, self.kdm, self.nbdy, self.itdm, self.jtdm, _, _ = list(d)
+        self.ni = self.idm + 2 * self.nbdy
+        self.nj = self.jdm + 2 * self.nbdy
+        self._views = {}
+
+    # -- scalars ---------------------------------------------------------
+    def set(self, name, v):
+        ierr = C.c_int(0)
+        if isinstance(v, str):
+            self.lib.ref_set_str(name.encode(), v.encode(), C.byref(ierr))
+        elif isinstance(v, (bool, int, np.integer)):
+            self.lib.ref_set_int(name.encode(), C.c_int(int(v)), C.byref(ierr))
+        else:
+            self.lib.ref_set_real(name.encode(), C.c_double(float(v)), C.byref(ierr))
+        if ierr.value:
+            raise KeyError(f"reference harness has no scalar {name!r}")
+
+    def get_int(self, name):
+        v, ierr = C.c_int(0), C.c_int(0)
+        self.lib.ref_get_int(name.encode(), C.byref(v), C.byref(ierr))
+        if ierr.value:
+            raise KeyError(name)
+        return v.value
+
+    def get_real(self, name):
+        v, ierr = C.c_double(0), C.c_int(0)
+        self.lib.ref_get_real(name.encode(), C.byref(v), C.byref(ierr))
+        if ierr.value:
+            raise KeyError(name)
+        return v.value
+
+    # -- setup -----------------------------------------------------------
+    def setup(self, depth):
+        depth = np.ascontiguousarray(depth, dtype=np.float64)
+        assert depth.shape == (self.nj, self.ni)
+        self.lib.ref_setup(depth.ctypes.data_as(C.c_void_p))
+        self._views.clear()
+        self.ntr = self.get_int("ntr")
+        self.nreg = self.get_int("nreg")
+
+    # -- fields ----------------------------------------------------------
+    def field(self, name):
+        if name in self._views:
+            return self._views[name]
+        ptr, nlev, kind = C.c_void_p(), C.c_int(0), C.c_int(0)
+        self.lib.ref_field(name.encode(), C.byref(ptr), C.byref(nlev), C.byref(kind))
+        if not ptr.value or nlev.value <= 0:
+            raise KeyError(f"reference harness has no field {name!r}")
+        ctype = C.c_int32 if kind.value else C.c_double
+        n = nlev.value * self.nj * self.ni
+        buf = (ctype * n).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=np.int32 if kind.value else np.float64)
+        a = a.reshape(nlev.value, self.nj, self.ni)
+        self._views[name] = a
+        return a
+
+    def has_field(self, name):
+        try:
+            self.field(name)
+            return True
+        except KeyError:
+            return False
+
+    # -- stages ----------------------------------------------------------
+    def stage(self, name, m, n, mm, nn, k1m, k1n):
+        ierr = C.c_int(0)
+        self.lib.ref_stage(name.encode(), m, n, mm, nn, k1m, k1n, C.byref(ierr))
+        if ierr.value:
+            raise KeyError(f"reference harness has no stage {name!r}")
+
+    def xctilr(self, a, l1, ld, mh, nh, itype):
+        """Reference halo update on a (>=ld, nj, ni) float64 array (view), in place."""
+        assert a.flags.c_contiguous and a.dtype == np.float64
+        self.lib.ref_xctilr(a.ctypes.data_as(C.c_void_p), l1, ld, mh, nh, itype)
+
+
+class RefBackend:
+    """Adapter giving RefBlom the backend interface blom_amd.hostinit drives."""
+
+    def __init__(self, cfg, depth):
+        self.ref = RefBlom(cfg)
+        self.ref.set("expcnf", "channel")
+        self.ref.setup(depth)
+        self.kdm, self.idm, self.jdm = self.ref.kdm, self.ref.idm, self.ref.jdm
+        self.ntr = self.ref.ntr
+        self.nreg = self.ref.nreg
+        self.masks = {k: self.ref.field(k)[0] for k in ("ip", "iu", "iv", "iq")}
+
+    def get(self, name):
+        return self.ref.field(name)          # live view: edits land in the reference
+
+    def put(self, name, arr):
+        v = self.ref.field(name)
+        if v is not arr:
+            v[...] = np.asarray(arr).reshape(v.shape)
+
+    def set(self, name, v):
+        try:
+            self.ref.set(name, v)
+        except KeyError:
+            pass                             # option not read by any reference stage we call
+
+    def stage(self, name, m, n, mm, nn, k1m, k1n):
+        self.ref.stage(name, m, n, mm, nn, k1m, k1n)
