@@ -1,0 +1,357 @@
+// C-ABI of libblomgpu.so: context, field registry, options, dispatcher, stepping.
+// See include/blomgpu.h for the contract and the reference interfaces it mirrors.
+#include "../../include/blomgpu.h"
+#include "blomgpu_internal.h"
+#include <cstring>
+
+static thread_local std::string g_err;
+
+int ctx_fail(blomgpu_ctx *c, const std::string &msg) {
+  if (c) c->err = msg;
+  g_err = msg;
+  return 1;
+}
+
+void ctx_sync_view(blomgpu_ctx *c) {
+  if (!c->dirty) return;
+  (void)hipMemcpyAsync(c->d, &c->h, sizeof(DevView), hipMemcpyHostToDevice, c->stream);
+  c->dirty = false;
+}
+
+TimeScope::TimeScope(blomgpu_ctx *c_, const char *w) : c(c_), what(w) {
+  if (!c->timing) return;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, c->stream);
+}
+TimeScope::~TimeScope() {
+  if (!c->timing) return;
+  (void)hipEventRecord(b, c->stream);
+  c->timers[what].pending.emplace_back(a, b);
+}
+
+// inieos, phy/mod_eos.F90:105-116
+static void set_eos(Params &P) {
+  const double a11 = 9.9985372432159340e+02, a12 = 1.0380621928183473e+01,
+               a13 = 1.7073577195684715e+00, a14 = -3.6570490496333680e-02,
+               a15 = -7.3677944503527477e-03, a16 = -3.5529175999643348e-03,
+               b11 = 1.7083494994335439e-06, b12 = 7.1567921402953455e-09,
+               b13 = 1.2821026080049485e-09, a21 = 1.0, a22 = 1.0316374535350838e-02,
+               a23 = 8.9521792365142522e-04, a24 = -2.8438341552142710e-05,
+               a25 = -1.1887778959461776e-05, a26 = -4.0163964812921489e-06,
+               b21 = 1.1995545126831476e-09, b22 = 5.5234008384648383e-12,
+               b23 = 8.4310335919950873e-13, alpha0 = 1.e-3;
+  P.ap21 = a21 + b21 * P.pref;
+  P.ap22 = a22 + b22 * P.pref;
+  P.ap23 = a23 + b23 * P.pref;
+  P.ap24 = a24;
+  P.ap25 = a25;
+  P.ap26 = a26;
+  P.ap11 = a11 + b11 * P.pref - P.ap21 / alpha0;
+  P.ap12 = a12 + b12 * P.pref - P.ap22 / alpha0;
+  P.ap13 = a13 + b13 * P.pref - P.ap23 / alpha0;
+  P.ap14 = a14 - P.ap24 / alpha0;
+  P.ap15 = a15 - P.ap25 / alpha0;
+  P.ap16 = a16 - P.ap26 / alpha0;
+}
+
+extern "C" {
+
+const char *blomgpu_last_error(const blomgpu_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
+  if (!d || !out) return ctx_fail(nullptr, "blomgpu_create: null argument");
+  if (d->nbdy != NBDY) return ctx_fail(nullptr, "blomgpu_create: nbdy must be 4 (phy/mod_xc.F90:45)");
+  if (d->idm < 1 || d->jdm < 1 || d->kdm < 3 || d->ntr < 0)
+    return ctx_fail(nullptr, "blomgpu_create: bad dimensions");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return ctx_fail(nullptr, "blomgpu_create: no HIP device -- libblomgpu has no host fallback");
+  if (d->device < 0 || d->device >= ndev) return ctx_fail(nullptr, "blomgpu_create: bad device ordinal");
+  blomgpu_ctx *c = new blomgpu_ctx();
+  c->device = d->device;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DevView &h = c->h;
+  memset(&h, 0, sizeof(h));
+  h.ii = d->idm; h.jj = d->jdm; h.kk = d->kdm;
+  h.ni = d->idm + 2 * NBDY; h.nj = d->jdm + 2 * NBDY; h.nplane = h.ni * h.nj;
+  h.itdm = d->itdm; h.jtdm = d->jtdm; h.i0 = d->i0; h.j0 = d->j0; h.nreg = d->nreg; h.ntr = d->ntr;
+  Params &P = h.P;
+  // defaults of the reference's module variables (phy/mod_tmsmt.F90:46-51)
+  P.wuv1 = .75; P.wuv2 = .125; P.wts1 = .875; P.wts2 = .0625; P.wbaro = .125;
+  P.vland = 0.0; P.vcoord_tag = 1; P.ltedtp_opt = 1;
+  P.pref = 2000.e4;
+  set_eos(P);
+  const int K = d->kdm, NT = d->ntr > 0 ? d->ntr : 1;
+  int id = 0;
+#define X(name, lev)                                                                   \
+  c->nlev_real[id] = (lev);                                                            \
+  c->real_ids[#name] = id;                                                             \
+  id++;
+  BLOM_REAL_FIELDS(X)
+#undef X
+  id = 0;
+#define X(name, lev)                                                                   \
+  c->nlev_int[id] = (lev);                                                             \
+  c->int_ids[#name] = id;                                                              \
+  id++;
+  BLOM_INT_FIELDS(X)
+#undef X
+  for (int f = 0; f < NF_REAL; f++) {
+    size_t bytes = sizeof(double) * (size_t)c->nlev_real[f] * h.nplane;
+    HIPCHK(c, hipMalloc((void **)&h.f[f], bytes));
+    HIPCHK(c, hipMemsetAsync(h.f[f], 0, bytes, c->stream));
+  }
+  for (int f = 0; f < NF_INT; f++) {
+    size_t bytes = sizeof(int) * (size_t)c->nlev_int[f] * h.nplane;
+    HIPCHK(c, hipMalloc((void **)&h.m[f], bytes));
+    HIPCHK(c, hipMemsetAsync(h.m[f], 0, bytes, c->stream));
+  }
+  HIPCHK(c, hipMalloc((void **)&c->d, sizeof(DevView)));
+  c->dirty = true;
+  ctx_sync_view(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+int blomgpu_destroy(blomgpu_ctx *c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int f = 0; f < NF_REAL; f++) (void)hipFree(c->h.f[f]);
+  for (int f = 0; f < NF_INT; f++) (void)hipFree(c->h.m[f]);
+  (void)hipFree(c->d);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int blomgpu_sync(blomgpu_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
+  Params &P = c->h.P;
+  std::string s(name);
+#define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
+  R(baclin) R(batrop) R(delt1) R(dlt) R(mdv2hi) R(mdv2lo) R(mdv4hi) R(mdv4lo) R(mdc2hi)
+  R(mdc2lo) R(vsc2hi) R(vsc2lo) R(vsc4hi) R(vsc4lo) R(cbar) R(cb) R(cwbdts) R(cwbdls)
+  R(wuv1) R(wuv2) R(wts1) R(wts2) R(wbaro) R(bdmc1) R(bdmc2) R(iwdfac) R(nubmin) R(vland)
+#undef R
+  if (s == "pref") { P.pref = v; set_eos(P); c->dirty = true; return 0; }
+  return ctx_fail(c, "blomgpu_set_real: unknown option " + s);
+}
+
+int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
+  Params &P = c->h.P;
+  std::string s(name);
+#define R(nm) if (s == #nm) { *v = P.nm; return 0; }
+  R(baclin) R(batrop) R(delt1) R(dlt) R(pref) R(wbaro)
+#undef R
+  return ctx_fail(c, "blomgpu_get_real: unknown option " + s);
+}
+
+int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
+  Params &P = c->h.P;
+  std::string s(name);
+#define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
+  R(lstep) R(nstep) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+#undef R
+  if (s == "csdiag") return 0;
+  if (s == "timing") { c->timing = v != 0; return 0; }
+  return ctx_fail(c, "blomgpu_set_int: unknown option " + s);
+}
+
+int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
+  Params &P = c->h.P;
+  std::string s(name), v(val);
+  c->dirty = true;
+  if (s == "expcnf") return 0;
+  if (s == "mommth") {
+    if (v == "enscon") P.mommth = 0; else if (v == "enecon") P.mommth = 1; else if (v == "enedis") P.mommth = 2;
+    else return ctx_fail(c, " mommth = " + v + " is unsupported!");   // phy/mod_momtum.F90:815-820
+    return 0;
+  }
+  if (s == "pgfmth") {
+    if (v == "geopotential") P.pgfmth = 0; else if (v == "dynamic enthalpy") P.pgfmth = 1;
+    else return ctx_fail(c, " pgfmth = " + v + " is unsupported!");   // phy/mod_pgforc.F90:529-534
+    return 0;
+  }
+  if (s == "advmth") {
+    if (v == "remap") P.advmth = 0; else if (v == "cppm") P.advmth = 1;
+    else return ctx_fail(c, " advmth = " + v + " is unsupported!");   // phy/mod_advect.F90:166-171
+    return 0;
+  }
+  if (s == "bmcmth") {
+    if (v == "uc") P.bmcmth = 0; else if (v == "dluc") P.bmcmth = 1;
+    else return ctx_fail(c, " bmcmth = " + v + " is unsupported!");   // phy/mod_pbcor.F90:112-117
+    return 0;
+  }
+  return ctx_fail(c, "blomgpu_set_str: unknown option " + s);
+}
+
+int blomgpu_field_info(blomgpu_ctx *c, const char *name, int *nlev, int *is_int) {
+  auto it = c->real_ids.find(name);
+  if (it != c->real_ids.end()) {
+    *nlev = c->nlev_real[it->second];
+    if (std::string(name) == "trc" || std::string(name) == "trcold")
+      *nlev = c->h.ntr * (std::string(name) == "trc" ? 2 : 1) * c->h.kk;
+    *is_int = 0;
+    return 0;
+  }
+  auto jt = c->int_ids.find(name);
+  if (jt != c->int_ids.end()) { *nlev = c->nlev_int[jt->second]; *is_int = 1; return 0; }
+  return ctx_fail(c, std::string("unknown field ") + name);
+}
+
+static int locate(blomgpu_ctx *c, const char *name, int nlev, void **ptr, size_t *bytes) {
+  int nl, isint;
+  if (blomgpu_field_info(c, name, &nl, &isint)) return 1;
+  if (nlev < 1 || nlev > nl) return ctx_fail(c, std::string("bad level count for field ") + name);
+  if (isint) {
+    *ptr = c->h.m[c->int_ids[name]];
+    *bytes = sizeof(int) * (size_t)nlev * c->h.nplane;
+  } else {
+    *ptr = c->h.f[c->real_ids[name]];
+    *bytes = sizeof(double) * (size_t)nlev * c->h.nplane;
+  }
+  return 0;
+}
+
+int blomgpu_upload(blomgpu_ctx *c, const char *name, const void *host, int nlev) {
+  void *p; size_t bytes;
+  if (locate(c, name, nlev, &p, &bytes)) return 1;
+  HIPCHK(c, hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int blomgpu_download(blomgpu_ctx *c, const char *name, void *host, int nlev) {
+  void *p; size_t bytes;
+  if (locate(c, name, nlev, &p, &bytes)) return 1;
+  HIPCHK(c, hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int blomgpu_set_masks(blomgpu_ctx *c, const int *ip, const int *iu, const int *iv, const int *iq) {
+  return blomgpu_upload(c, "ip", ip, 1) || blomgpu_upload(c, "iu", iu, 1) ||
+         blomgpu_upload(c, "iv", iv, 1) || blomgpu_upload(c, "iq", iq, 1);
+}
+
+int blomgpu_xctilr(blomgpu_ctx *c, const char *name, int lev0, int l1, int ld, int mh, int nh, int itype) {
+  auto it = c->real_ids.find(name);
+  if (it == c->real_ids.end()) return ctx_fail(c, std::string("xctilr: unknown field ") + name);
+  int nl = c->nlev_real[it->second];
+  if (lev0 < 1 || l1 < 1 || lev0 - 1 + ld > nl) return ctx_fail(c, "xctilr: level range outside field");
+  ctx_sync_view(c);
+  return st_xctilr(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, l1, ld, mh, nh, itype);
+}
+
+int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, unsigned *crc) {
+  auto it = c->real_ids.find(name);
+  if (it == c->real_ids.end()) return ctx_fail(c, std::string("crc: unknown field ") + name);
+  ctx_sync_view(c);
+  return st_crc(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, crc);
+}
+
+#define STAGE6(nm)                                                                         \
+  int blomgpu_##nm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {       \
+    ctx_sync_view(c);                                                                      \
+    return st_##nm(c, m, n, mm, nn, k1m, k1n);                                             \
+  }
+STAGE6(init_fluxes) STAGE6(advect) STAGE6(pbcor1) STAGE6(pbcor2) STAGE6(diffus) STAGE6(pgforc)
+STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra)
+int blomgpu_tmsmt1(blomgpu_ctx *c, int nn) { ctx_sync_view(c); return st_tmsmt1(c, nn); }
+int blomgpu_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) { ctx_sync_view(c); return st_tmsmt2(c, m, mm, nn, k1m); }
+int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(c, mm); }
+int blomgpu_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) { ctx_sync_view(c); return st_diapfl(c, n, nn, k1n); }
+int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
+
+int blomgpu_halo_cmnfld2(blomgpu_ctx *c) {            // phy/mod_cmnfld_routines.F90:1171-1172
+  ctx_sync_view(c);
+  const int kk = c->h.kk;
+  return st_xctilr(c, c->h.f[F_temp], 1, 2 * kk, 3, 3, 1) || st_xctilr(c, c->h.f[F_saln], 1, 2 * kk, 3, 3, 1);
+}
+int blomgpu_halo_difest(blomgpu_ctx *c) {             // phy/mod_difest.F90:750-755
+  ctx_sync_view(c);
+  const int kk = c->h.kk;
+  return st_xctilr(c, c->h.f[F_u], 1, 2 * kk, 2, 2, 13) || st_xctilr(c, c->h.f[F_v], 1, 2 * kk, 2, 2, 14) ||
+         st_xctilr(c, c->h.f[F_ubflxs_p], 1, 2, 2, 2, 13) || st_xctilr(c, c->h.f[F_vbflxs_p], 1, 2, 2, 2, 14) ||
+         st_xctilr(c, c->h.f[F_pbu], 1, 2, 2, 2, 3) || st_xctilr(c, c->h.f[F_pbv], 1, 2, 2, 2, 4);
+}
+
+int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int nn, int k1m, int k1n) {
+  std::string s(stage);
+  if (s == "init_fluxes") return blomgpu_init_fluxes(c, m, n, mm, nn, k1m, k1n);
+  if (s == "tmsmt1") return blomgpu_tmsmt1(c, nn);
+  if (s == "tmsmt2") return blomgpu_tmsmt2(c, m, mm, nn, k1m);
+  if (s == "initms") return blomgpu_initms(c, mm);
+  if (s == "advect") return blomgpu_advect(c, m, n, mm, nn, k1m, k1n);
+  if (s == "pbcor1") return blomgpu_pbcor1(c, m, n, mm, nn, k1m, k1n);
+  if (s == "pbcor2") return blomgpu_pbcor2(c, m, n, mm, nn, k1m, k1n);
+  if (s == "diffus") return blomgpu_diffus(c, m, n, mm, nn, k1m, k1n);
+  if (s == "pgforc") return blomgpu_pgforc(c, m, n, mm, nn, k1m, k1n);
+  if (s == "momtum") return blomgpu_momtum(c, m, n, mm, nn, k1m, k1n);
+  if (s == "diapfl") return blomgpu_diapfl(c, n, nn, k1n);
+  if (s == "barotp") return blomgpu_barotp(c, m, n, mm, nn, k1m, k1n);
+  if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);
+  if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c);
+  if (s == "halo_difest") return blomgpu_halo_difest(c);
+  if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
+  return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
+}
+
+// Stage sequence of one baroclinic step, phy/mod_blom_step.F90:89-253 (hot path only).
+int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
+  const int kk = c->h.kk;
+  for (int it = 0; it < nsteps; it++) {
+    const int ns = *nstep;
+    const int m = ns % 2 + 1, n = (ns + 1) % 2 + 1;
+    const int mm = (m - 1) * kk, nn = (n - 1) * kk, k1m = 1 + mm, k1n = 1 + nn;
+    c->h.P.nstep = ns + 1;
+    c->dirty = true;
+    static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect",
+                                "pbcor1", "diffus", "pgforc", "momtum", "diapfl", "mxlayr_tail",
+                                "barotp", "pbcor2", "tmsmt2"};
+    for (const char *st : seq)
+      if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) return rc;
+    c->h.P.delt1 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300
+    c->dirty = true;
+    *nstep = ns + 1;
+  }
+  return 0;
+}
+
+int blomgpu_timer_reset(blomgpu_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto &kv : c->timers) {
+    for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    kv.second = KTimer();
+  }
+  return 0;
+}
+
+int blomgpu_timer_get(blomgpu_ctx *c, const char *what, double *ms_total, int *launches) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  KTimer &t = c->timers[what];
+  for (auto &ev : t.pending) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev.first, ev.second);
+    t.ms += ms;
+    t.launches++;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  t.pending.clear();
+  *ms_total = t.ms;
+  *launches = t.launches;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// Internal declarations of libblomgpu.so (HIP, gfx950).  Not part of the C-ABI.
+//
+// Data layout in HBM: every BLOM module array keeps the reference's layout
+//   a(1-nbdy:idm+nbdy, 1-nbdy:jdm+nbdy, k), i fastest           (phy/mod_state.F90:34-86)
+// so that a level is one contiguous (ni x nj) plane, rows are unit-stride in i (coalesced
+// across a wavefront) and host<->device transfers are plain memcpys of Fortran storage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define NBDY 4
+
+// ---- field table -------------------------------------------------------------------
+// X(name, levels) with levels in terms of K = kdm and NT = ntr.
+#define BLOM_REAL_FIELDS(X)                                                              \
+  /* mod_state */                                                                        \
+  X(u, 2 * K) X(v, 2 * K) X(dp, 2 * K) X(dpu, 2 * K) X(dpv, 2 * K) X(temp, 2 * K)        \
+  X(saln, 2 * K) X(sigma, 2 * K) X(uflx, 2 * K) X(vflx, 2 * K) X(utflx, 2 * K)           \
+  X(vtflx, 2 * K) X(usflx, 2 * K) X(vsflx, 2 * K)                                        \
+  X(p, K + 1) X(pu, K + 1) X(pv, K + 1) X(phi, K + 1) X(cau, K) X(cav, K)                \
+  X(ubflxs, 3) X(vbflxs, 3) X(ub, 2) X(vb, 2) X(pb, 2) X(pbu, 2) X(pbv, 2)               \
+  X(ubflxs_p, 2) X(vbflxs_p, 2) X(pb_p, 1) X(pbu_p, 1) X(pbv_p, 1) X(ubcors_p, 1)        \
+  X(vbcors_p, 1) X(sealv, 1)                                                             \
+  /* mod_grid */                                                                         \
+  X(scqx, 1) X(scqy, 1) X(scpx, 1) X(scpy, 1) X(scux, 1) X(scuy, 1) X(scvx, 1)           \
+  X(scvy, 1) X(scq2, 1) X(scp2, 1) X(scu2, 1) X(scv2, 1) X(scq2i, 1) X(scp2i, 1)         \
+  X(scuxi, 1) X(scuyi, 1) X(scvxi, 1) X(scvyi, 1) X(corioq, 1) X(coriop, 1)              \
+  X(betafp, 1) X(depths, 1)                                                              \
+  /* mod_pgforc */                                                                       \
+  X(pgfx, 2 * K) X(pgfy, 2 * K) X(pgfx_o, K) X(pgfy_o, K) X(pgfxm, 2) X(pgfym, 2)        \
+  X(xixp, 2) X(xixm, 2) X(xiyp, 2) X(xiym, 2) X(pgfxm_o, 1) X(pgfym_o, 1)                \
+  X(xixp_o, 1) X(xixm_o, 1) X(xiyp_o, 1) X(xiym_o, 1)                                    \
+  /* mod_momtum */                                                                       \
+  X(absvor, 2 * K) X(dpvor, 2 * K)                                                       \
+  /* mod_barotp (module arrays + the implicitly SAVEd locals, mod_barotp.F90:155-167) */ \
+  X(ubflx, 2) X(vbflx, 2) X(pb_mn, 2) X(ubflx_mn, 2) X(vbflx_mn, 2) X(pvtrop, 2)         \
+  X(pvtrop_o, 1) X(pb_t, 2) X(ubflx_t, 2) X(vbflx_t, 2) X(umaxb, 1) X(uminb, 1)          \
+  X(vmaxb, 1) X(vminb, 1) X(uglue, 1) X(vglue, 1) X(ubflxs_t, 1) X(vbflxs_t, 1)          \
+  X(ubcors_t, 1) X(vbcors_t, 1)                                                          \
+  /* mod_tmsmt */                                                                        \
+  X(dpold, 2 * K) X(dpuold, K) X(dpvold, K) X(told, K) X(sold, K)                        \
+  /* mod_vcoord / mod_diffusion */                                                       \
+  X(sigmar, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)          \
+  X(difwgt, 1) X(umfltd, 2 * K) X(vmfltd, 2 * K) X(umflsm, 2 * K) X(vmflsm, 2 * K)       \
+  X(utfltd, 2 * K) X(vtfltd, 2 * K) X(utflsm, 2 * K) X(vtflsm, 2 * K) X(utflld, 2 * K)   \
+  X(vtflld, 2 * K) X(usfltd, 2 * K) X(vsfltd, 2 * K) X(usflsm, 2 * K) X(vsflsm, 2 * K)   \
+  X(usflld, 2 * K) X(vsflld, 2 * K)                                                      \
+  /* mod_utility / mod_forcing */                                                        \
+  X(utotm, 1) X(vtotm, 1) X(utotn, 1) X(vtotn, 1) X(uflux, 1) X(vflux, 1) X(uflux2, 1)   \
+  X(vflux2, 1) X(uflux3, 1) X(vflux3, 1) X(umax, 1) X(vmax, 1) X(util1, 1) X(util2, 1)   \
+  X(util3, 1) X(util4, 1) X(taux, 1) X(tauy, 1) X(ustarb, 1)                             \
+  /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
+  X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
+  /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
+  X(fpug, K) X(fplg, K)                                                                  \
+  /* device work space (the reference's stage-local 2-D/3-D temporaries) */              \
+  X(wk0, K) X(wk1, K) X(wk2, K) X(wk3, K) X(wk4, K) X(wk5, K) X(wk6, K) X(wk7, K)        \
+  X(wk8, K) X(wk9, K) X(wk10, K) X(wk11, K) X(wk12, K) X(wk13, K) X(wk14, K)             \
+  X(wk15, K) X(wk16, K) X(wk17, K) X(wk18, K) X(wk19, K) X(wk20, K) X(wk21, K)           \
+  X(wk22, K) X(wk23, K) X(wk24, K) X(wk25, K) X(wk26, K) X(wk27, K) X(wk28, K)           \
+  X(wk29, K) X(wk30, K) X(wk31, K) X(wkp0, K + 1) X(wkp1, K + 1)
+
+#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1)
+
+enum FieldId {
+#define X(name, lev) F_##name,
+  BLOM_REAL_FIELDS(X)
+#undef X
+      NF_REAL
+};
+enum IFieldId {
+#define X(name, lev) I_##name,
+  BLOM_INT_FIELDS(X)
+#undef X
+      NF_INT
+};
+
+// ---- scalar options (namelist-type module variables of the reference) ----------------
+struct Params {
+  // mod_time
+  double baclin, batrop, delt1, dlt;
+  int lstep, nstep;
+  // mod_eos (inieos, phy/mod_eos.F90:105-129)
+  double pref;
+  double ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26;
+  // mod_momtum
+  double mdv2hi, mdv2lo, mdv4hi, mdv4lo, mdc2hi, mdc2lo, vsc2hi, vsc2lo, vsc4hi, vsc4lo;
+  double cbar, cb;
+  // mod_barotp
+  double cwbdts, cwbdls;
+  // mod_tmsmt
+  double wuv1, wuv2, wts1, wts2, wbaro;
+  // mod_diffusion (diapfl)
+  double bdmc1, bdmc2, iwdfac, nubmin;
+  int bdmtyp, iwdflg, bdmldp;
+  // option codes
+  int mommth;      // 0 enscon, 1 enecon, 2 enedis          (phy/mod_momtum.F90:723-765)
+  int pgfmth;      // 0 geopotential, 1 dynamic enthalpy    (phy/mod_pgforc.F90:525-527)
+  int advmth;      // 0 remap, 1 cppm                       (phy/mod_advect.F90:96,155)
+  int bmcmth;      // 0 uc, 1 dluc                          (phy/mod_pbcor.F90:99-105)
+  int vcoord_tag;  // 1 isopyc_bulkml                       (phy/mod_vcoord.F90)
+  int ltedtp_opt;  // 1 layer, 2 neutral                    (phy/mod_diffusion.F90)
+  double vland;    // halo fill value for closed boundaries (phy/mod_xc.F90:104)
+};
+
+// ---- what a kernel sees ----------------------------------------------------------------
+struct DevView {
+  int ii, jj, kk;        // tile extents (== idm, jdm, kdm)
+  int ni, nj;            // padded plane: idm+2*nbdy, jdm+2*nbdy
+  int nplane;            // ni*nj
+  int itdm, jtdm, i0, j0, nreg, ntr;
+  Params P;
+  double *f[NF_REAL];
+  int *m[NF_INT];
+};
+
+// index of Fortran (i,j) inside a plane; level stride is V.nplane
+#define IDX(V, i, j) (((i) + NBDY - 1) + (V).ni * ((j) + NBDY - 1))
+
+// Fortran MAX/MIN as amdflang lowers them (fcmp ogt/olt + select): on ties -- in
+// particular (+0,-0) -- the SECOND operand is returned.
+__host__ __device__ inline double fmax2(double a, double b) { return a > b ? a : b; }
+__host__ __device__ inline double fmin2(double a, double b) { return a < b ? a : b; }
+__host__ __device__ inline double fmax3(double a, double b, double c) { return fmax2(fmax2(a, b), c); }
+__host__ __device__ inline double fmin3(double a, double b, double c) { return fmin2(fmin2(a, b), c); }
+
+// ---- context ---------------------------------------------------------------------------
+struct KTimer {
+  double ms = 0.0;
+  int launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct blomgpu_ctx {
+  DevView h;                 // host copy (pointers are device pointers)
+  DevView *d = nullptr;      // device copy handed to kernels
+  bool dirty = true;         // host copy changed since last upload
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int nlev_real[NF_REAL];
+  int nlev_int[NF_INT];
+  std::unordered_map<std::string, int> real_ids, int_ids;
+  std::unordered_map<std::string, KTimer> timers;
+  bool timing = false;
+  std::string err;
+};
+
+int  ctx_fail(blomgpu_ctx *c, const std::string &msg);
+void ctx_sync_view(blomgpu_ctx *c);      // uploads h -> d if dirty
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return ctx_fail((c), std::string(#call) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+// timing scope around a kernel class (HIP events on the context stream)
+struct TimeScope {
+  blomgpu_ctx *c;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char *what;
+  TimeScope(blomgpu_ctx *c_, const char *w);
+  ~TimeScope();
+};
+
+// ---- stage implementations (one translation unit per stage) ---------------------------
+int st_init_fluxes(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_tmsmt1(blomgpu_ctx *, int nn);
+int st_tmsmt2(blomgpu_ctx *, int m, int mm, int nn, int k1m);
+int st_initms(blomgpu_ctx *, int mm);
+int st_advect(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_pbcor1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_pbcor2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_diffus(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_pgforc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
+int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
+// xctilr on a device plane stack: `base` points at level lev0 of the field
+int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);
+int st_crc(blomgpu_ctx *, const double *base, int nlev, unsigned *crc);
+
+// launch helpers: 1 thread per point of the padded plane, blockIdx.y = level
+static inline dim3 plane_grid(const DevView &h, int nlev = 1, int block = 256) {
+  return dim3((h.nplane + block - 1) / block, nlev, 1);
+}

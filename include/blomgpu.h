@@ -1,0 +1,112 @@
+/* blomgpu.h -- C-ABI of the MI355X-native BLOM dynamical core (libblomgpu.so).
+ *
+ * BLOM has no plugin/FFI layer: its operator API is the uniform Fortran stage signature
+ *     subroutine <stage>(m,n,mm,nn,k1m,k1n)           phy/mod_blom_step.F90:89-253
+ * acting on module-global, halo-4 arrays a(1-nbdy:idm+nbdy, 1-nbdy:jdm+nbdy, k)
+ * (phy/mod_state.F90:34-86, phy/mod_xc.F90:45).  This header is what an
+ * ISO_C_BINDING shim for that path binds to (INTEGRATION.md shows the shim): one entry
+ * point per stage with the reference's name and argument meaning, field upload/download
+ * for the module arrays, the xctilr halo update and the xccrc-style checksum.
+ *
+ * Conventions
+ *  - all indices are the reference's 1-based Fortran values, passed by value;
+ *  - a field is addressed by the reference's variable name ("dp", "utflx", "pgfxm" ...);
+ *    element (i,j,k) lives at  (i+nbdy-1) + (idm+2*nbdy)*((j+nbdy-1) + (jdm+2*nbdy)*(k-1));
+ *  - every function returns 0 on success, non-zero on error (the reference prints and
+ *    calls xcstop/xchalt, e.g. phy/mod_advect.F90:166-172; the Fortran shim maps a
+ *    non-zero status to xchalt); blomgpu_last_error() gives the text;
+ *  - no host fallback exists: without a HIP device every compute entry fails.
+ */
+#ifndef BLOMGPU_H
+#define BLOMGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct blomgpu_ctx blomgpu_ctx;
+
+/* Tile geometry, cf. module dimensions (bld/blom_dimensions:152-265) and xcspmd
+ * (phy/mod_xc.F90:1332-2027): this tile owns i0+1..i0+ii, j0+1..j0+jj of the
+ * itdm x jtdm global grid.  nreg as in phy/mod_bigrid.F90:81-95. */
+typedef struct {
+  int idm, jdm, kdm;   /* tile extents (== ii, jj) and number of layers            */
+  int nbdy;            /* halo width, must be 4 (phy/mod_xc.F90:45)                 */
+  int itdm, jtdm;      /* global grid size                                          */
+  int i0, j0;          /* tile offsets                                              */
+  int nreg;            /* 0 closed, 1 periodic-i, 2 arctic, 3 doubly periodic, 4 periodic-j */
+  int ntr;             /* number of advected tracers (trc/mod_tracers.F90:225)      */
+  int device;          /* HIP device ordinal                                        */
+} blomgpu_dims;
+
+int  blomgpu_create(const blomgpu_dims *dims, blomgpu_ctx **out);
+int  blomgpu_destroy(blomgpu_ctx *ctx);
+const char *blomgpu_last_error(const blomgpu_ctx *ctx);   /* ctx may be NULL */
+
+/* Namelist-type options that the reference keeps as module variables set by rdlim
+ * (phy/mod_rdlim.F90:137-155): baclin, batrop, delt1, dlt, lstep, nstep, pref, mdv2hi ...
+ * cb, cwbdts, cwbdls, wuv1 ... wbaro, mommth, pgfmth, advmth, bmcmth, vcoord_tag ... */
+int  blomgpu_set_real(blomgpu_ctx *ctx, const char *name, double v);
+int  blomgpu_set_int (blomgpu_ctx *ctx, const char *name, int v);
+int  blomgpu_set_str (blomgpu_ctx *ctx, const char *name, const char *v);
+int  blomgpu_get_real(blomgpu_ctx *ctx, const char *name, double *v);
+
+/* Field access.  nlev is the size of the third dimension (trc: 2*kdm*ntr). */
+int  blomgpu_field_info(blomgpu_ctx *ctx, const char *name, int *nlev, int *is_int);
+int  blomgpu_upload  (blomgpu_ctx *ctx, const char *name, const void *host, int nlev);
+int  blomgpu_download(blomgpu_ctx *ctx, const char *name, void *host, int nlev);
+/* Integer masks ip,iu,iv,iq (phy/mod_xc.F90:62-65), built by bigrid on the host. */
+int  blomgpu_set_masks(blomgpu_ctx *ctx, const int *ip, const int *iu, const int *iv,
+                       const int *iq);
+
+/* xctilr(a,l1,ld,mh,nh,itype), phy/mod_xc.F90:2342 / :4222.  `lev0` (1-based) is the
+ * level of `name` that the reference passes as a(1-nbdy,1-nbdy,lev0). */
+int  blomgpu_xctilr(blomgpu_ctx *ctx, const char *name, int lev0, int l1, int ld,
+                    int mh, int nh, int itype);
+
+/* CRC32 of levels lev0..lev0+nlev-1 over the tile interior, matching chksum/xccrc for a
+ * single tile (phy/mod_checksum.F90:41-74, phy/mod_xc.F90:4164). */
+int  blomgpu_crc(blomgpu_ctx *ctx, const char *name, int lev0, int nlev, unsigned *crc);
+
+/* Stages: same names, same argument meaning as the reference. */
+int  blomgpu_init_fluxes(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n); /* phy/mod_state.F90:341   */
+int  blomgpu_tmsmt1 (blomgpu_ctx *, int nn);                                             /* phy/mod_tmsmt.F90:209   */
+int  blomgpu_tmsmt2 (blomgpu_ctx *, int m, int mm, int nn, int k1m);                     /* phy/mod_tmsmt.F90:281   */
+int  blomgpu_initms (blomgpu_ctx *, int mm);                                             /* phy/mod_tmsmt.F90:161   */
+int  blomgpu_advect (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_advect.F90:59   */
+int  blomgpu_pbcor1 (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_pbcor.F90:66    */
+int  blomgpu_pbcor2 (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_pbcor.F90:416   */
+int  blomgpu_diffus (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_diffus.F90:41   */
+int  blomgpu_pgforc (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_pgforc.F90:438  */
+int  blomgpu_momtum (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_momtum.F90:215  */
+int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                             /* phy/mod_diapfl.F90:49   */
+int  blomgpu_barotp (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_barotp.F90:148  */
+int  blomgpu_eddtra (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_eddtra.F90:1808 */
+/* Halo updates the reference performs inside stages that are outside the hot path
+ * (phy/mod_cmnfld_routines.F90:1171-1172, phy/mod_difest.F90:750-755) and the
+ * dp-halo/dpu/dpv tail of mxlayr (phy/mod_mxlayr.F90:1266-1310). */
+int  blomgpu_halo_cmnfld2(blomgpu_ctx *);
+int  blomgpu_halo_difest (blomgpu_ctx *);
+int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
+
+/* Generic dispatcher over the entries above ("advect", "tmsmt1", ...). */
+int  blomgpu_stage(blomgpu_ctx *, const char *stage, int m, int n, int mm, int nn,
+                   int k1m, int k1n);
+
+/* Device-resident time stepping: `nsteps` passes of the stage sequence of
+ * phy/mod_blom_step.F90:96-253 (hot-path stages only), starting from step count
+ * `nstep` (value before step_time).  Returns the new step count in *nstep. */
+int  blomgpu_step(blomgpu_ctx *, int *nstep, int nsteps);
+
+/* Synchronise the context's stream (all entries above are asynchronous on it). */
+int  blomgpu_sync(blomgpu_ctx *);
+
+/* Timing of the dominant kernel with HIP events on the context's stream: average
+ * duration [ms] of kernel class `what` ("remap", "momtum", ...) since the last reset. */
+int  blomgpu_timer_reset(blomgpu_ctx *);
+int  blomgpu_timer_get(blomgpu_ctx *, const char *what, double *ms_total, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

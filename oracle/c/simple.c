@@ -1,0 +1,161 @@
+/* TEST INFRASTRUCTURE (oracle): restatement of xctilr (single tile), init_fluxes, the
+ * time-smoothing stages and the dp/dpu/dpv tail of mxlayr. */
+#include "ostate.h"
+
+/* xctilr, serial non-arctic form, phy/mod_xc.F90:4374-4419 */
+void orc_xctilr(OState *S, double *a, int l1, int ld, int mh, int nh, int itype) {
+  (void)itype;
+  const int ii = S->ii, jj = S->jj;
+  const int mhl = imax2(0, imin2(mh, NBDY)), nhl = imax2(0, imin2(nh, NBDY));
+#define A(i, j, k) a[IX(S, i, j) + (size_t)S->nplane * ((k)-1)]
+  if (nhl > 0) {
+    if (S->nreg <= 2) {
+      for (int k = l1; k <= ld; k++)
+        for (int j = 1; j <= nhl; j++)
+          for (int i = 1; i <= ii; i++) { A(i, 1 - j, k) = S->vland; A(i, jj + j, k) = S->vland; }
+    } else {
+      for (int k = l1; k <= ld; k++)
+        for (int j = 1; j <= nhl; j++)
+          for (int i = 1; i <= ii; i++) { A(i, 1 - j, k) = A(i, jj + 1 - j, k); A(i, jj + j, k) = A(i, j, k); }
+    }
+  }
+  if (mhl > 0) {
+    if (S->nreg == 0 || S->nreg == 4) {
+      for (int k = l1; k <= ld; k++)
+        for (int j = 1 - nhl; j <= jj + nhl; j++)
+          for (int i = 1; i <= mhl; i++) { A(1 - i, j, k) = S->vland; A(ii + i, j, k) = S->vland; }
+    } else {
+      for (int k = l1; k <= ld; k++)
+        for (int j = 1 - nhl; j <= jj + nhl; j++)
+          for (int i = 1; i <= mhl; i++) { A(1 - i, j, k) = A(ii + 1 - i, j, k); A(ii + i, j, k) = A(i, j, k); }
+    }
+  }
+#undef A
+}
+
+/* init_fluxes, phy/mod_state.F90:341-383 (update_flux_halos = .false.) */
+void orc_init_fluxes(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
+  for (int j = 0; j <= S->jj + 2; j++)
+    for (int k = 1; k <= S->kk; k++) {
+      int km = k + mm;
+      for (int i = 0; i <= S->ii + 2; i++) {
+        if (A2(S, iu, i, j)) { A3(S, uflx, i, j, km) = 0.; A3(S, utflx, i, j, km) = 0.; A3(S, usflx, i, j, km) = 0.; }
+        if (A2(S, iv, i, j)) { A3(S, vflx, i, j, km) = 0.; A3(S, vtflx, i, j, km) = 0.; A3(S, vsflx, i, j, km) = 0.; }
+      }
+    }
+}
+
+/* initms, phy/mod_tmsmt.F90:161-205 */
+void orc_initms(OState *S, int mm) {
+  for (int j = 1; j <= S->jj; j++)
+    for (int k = 1; k <= S->kk; k++) {
+      int km = k + mm;
+      for (int i = 1; i <= S->ii; i++)
+        if (A2(S, ip, i, j)) {
+          A3(S, told, i, j, k) = A3(S, temp, i, j, km);
+          A3(S, sold, i, j, k) = A3(S, saln, i, j, km);
+          for (int nt = 1; nt <= S->ntr; nt++) TRCOLD(S, i, j, k, nt) = TRC(S, i, j, km, nt);
+        }
+    }
+}
+
+/* tmsmt1, phy/mod_tmsmt.F90:209-277 */
+void orc_tmsmt1(OState *S, int nn) {
+  for (int j = 1; j <= S->jj; j++)
+    for (int k = 1; k <= S->kk; k++) {
+      int kn = k + nn;
+      for (int i = 1; i <= S->ii; i++) {
+        if (A2(S, ip, i, j)) {
+          A3(S, dpold, i, j, kn) = A3(S, dp, i, j, kn);
+          A3(S, told, i, j, k) = A3(S, temp, i, j, kn);
+          A3(S, sold, i, j, k) = A3(S, saln, i, j, kn);
+          for (int nt = 1; nt <= S->ntr; nt++) TRCOLD(S, i, j, k, nt) = TRC(S, i, j, kn, nt);
+        }
+        if (S->vcoord_tag == 1) {
+          if (A2(S, iu, i, j)) A3(S, dpuold, i, j, k) = A3(S, dpu, i, j, kn);
+          if (A2(S, iv, i, j)) A3(S, dpvold, i, j, k) = A3(S, dpv, i, j, kn);
+        }
+      }
+    }
+}
+
+/* p(k+1)=p(k)+dp(k+off) over -2..+2 and dpu/dpv over -1..+2:
+ * phy/mod_tmsmt.F90:354-391 == phy/mod_mxlayr.F90:1270-1310 == phy/mod_pgforc.F90:451-485 */
+static void p_dpu_dpv(OState *S, int off, int with_pupv) {
+  const int ii = S->ii, jj = S->jj, kk = S->kk;
+  for (int j = -2; j <= jj + 2; j++)
+    for (int k = 1; k <= kk; k++)
+      for (int i = -2; i <= ii + 2; i++)
+        if (A2(S, ip, i, j)) A3(S, p, i, j, k + 1) = A3(S, p, i, j, k) + A3(S, dp, i, j, k + off);
+  for (int j = -1; j <= jj + 2; j++)
+    for (int k = 1; k <= kk; k++) {
+      int kx = k + off;
+      for (int i = -1; i <= ii + 2; i++) {
+        if (A2(S, iu, i, j)) {
+          double q = fmin2(A3(S, p, i, j, kk + 1), A3(S, p, i - 1, j, kk + 1));
+          A3(S, dpu, i, j, kx) = .5 * ((fmin2(q, A3(S, p, i - 1, j, k + 1)) - fmin2(q, A3(S, p, i - 1, j, k))) +
+                                       (fmin2(q, A3(S, p, i, j, k + 1)) - fmin2(q, A3(S, p, i, j, k))));
+          if (with_pupv) A3(S, pu, i, j, k + 1) = A3(S, pu, i, j, k) + A3(S, dpu, i, j, kx);
+        }
+        if (A2(S, iv, i, j)) {
+          double q = fmin2(A3(S, p, i, j, kk + 1), A3(S, p, i, j - 1, kk + 1));
+          A3(S, dpv, i, j, kx) = .5 * ((fmin2(q, A3(S, p, i, j - 1, k + 1)) - fmin2(q, A3(S, p, i, j - 1, k))) +
+                                       (fmin2(q, A3(S, p, i, j, k + 1)) - fmin2(q, A3(S, p, i, j, k))));
+          if (with_pupv) A3(S, pv, i, j, k + 1) = A3(S, pv, i, j, k) + A3(S, dpv, i, j, kx);
+        }
+      }
+    }
+}
+void orc_p_dpu_dpv(OState *S, int off, int with_pupv) { p_dpu_dpv(S, off, with_pupv); }
+
+/* tmsmt2, phy/mod_tmsmt.F90:281-410 */
+void orc_tmsmt2(OState *S, int m, int mm, int nn, int k1m) {
+  const int ii = S->ii, jj = S->jj, kk = S->kk;
+  const double wts1 = S->wts1, wts2 = S->wts2;
+  for (int j = 1; j <= jj; j++)
+    for (int i = 1; i <= ii; i++) {
+      if (!A2(S, ip, i, j)) continue;
+      double pbfaco = 0., pbfacn = 0.;
+      for (int k = 1; k <= kk; k++) {
+        int kn = k + nn;
+        pbfaco = pbfaco + A3(S, dpold, i, j, kn);
+        pbfacn = pbfacn + A3(S, dp, i, j, kn);
+      }
+      pbfaco = A3(S, pb, i, j, m) / pbfaco;
+      pbfacn = A3(S, pb, i, j, m) / pbfacn;
+      for (int k = 1; k <= kk; k++) {
+        int km = k + mm, kn = k + nn;
+        double pold = fmax2(0., A3(S, dpold, i, j, kn) * pbfaco);
+        double pmid = fmax2(0., A3(S, dp, i, j, km));
+        double pnew = fmax2(0., A3(S, dp, i, j, kn) * pbfacn);
+        A3(S, dp, i, j, km) = wts1 * pmid + wts2 * (pold + pnew);
+        pold = pold + EPSILP;
+        pmid = pmid + EPSILP;
+        pnew = pnew + EPSILP;
+        A3(S, temp, i, j, km) = (wts1 * pmid * A3(S, temp, i, j, km) +
+                                 wts2 * (pold * A3(S, told, i, j, k) + pnew * A3(S, temp, i, j, kn))) /
+                                (A3(S, dp, i, j, km) + EPSILP);
+        A3(S, saln, i, j, km) = (wts1 * pmid * A3(S, saln, i, j, km) +
+                                 wts2 * (pold * A3(S, sold, i, j, k) + pnew * A3(S, saln, i, j, kn))) /
+                                (A3(S, dp, i, j, km) + EPSILP);
+        for (int nt = 1; nt <= S->ntr; nt++)
+          TRC(S, i, j, km, nt) = (wts1 * pmid * TRC(S, i, j, km, nt) +
+                                  wts2 * (pold * TRCOLD(S, i, j, k, nt) + pnew * TRC(S, i, j, kn, nt))) /
+                                 (A3(S, dp, i, j, km) + EPSILP);
+      }
+    }
+  orc_xctilr(S, S->dp + (size_t)S->nplane * (k1m - 1), 1, kk, 3, 3, 1);
+  if (S->vcoord_tag == 1) p_dpu_dpv(S, mm, 0);
+  else
+    for (int j = -2; j <= jj + 2; j++)
+      for (int k = 1; k <= kk; k++)
+        for (int i = -2; i <= ii + 2; i++)
+          if (A2(S, ip, i, j)) A3(S, p, i, j, k + 1) = A3(S, p, i, j, k) + A3(S, dp, i, j, k + mm);
+}
+
+/* tail of mxlayr, phy/mod_mxlayr.F90:1266-1310 */
+void orc_mxlayr_tail(OState *S, int nn, int k1n) {
+  orc_xctilr(S, S->dp + (size_t)S->nplane * (k1n - 1), 1, S->kk, 3, 3, 1);
+  p_dpu_dpv(S, nn, 0);
+}

@@ -107,7 +107,7 @@ contains
       case ('batrop'); batrop = v
       case ('delt1');  delt1 = v
       case ('dlt');    dlt = v
-      case ('pref');   pref = v
+      case ('pref');   pref = v; call inieos   ! coefficients depend on pref (mod_eos.F90:105)
       case ('mdv2hi'); mdv2hi = v
       case ('mdv2lo'); mdv2lo = v
       case ('mdv4hi'); mdv4hi = v

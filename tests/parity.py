@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests: field lists, state transfer between backends and
+exact comparison with readable diagnostics."""
+import numpy as np
+
+# every array that is an input or output of some stage on the path
+STATE_FIELDS = [
+    "u", "v", "dp", "dpu", "dpv", "temp", "saln", "sigma", "uflx", "vflx", "utflx", "vtflx",
+    "usflx", "vsflx", "p", "pu", "pv", "phi", "cau", "cav", "ubflxs", "vbflxs", "ub", "vb", "pb",
+    "pbu", "pbv", "ubflxs_p", "vbflxs_p", "pb_p", "pbu_p", "pbv_p", "ubcors_p", "vbcors_p", "sealv",
+    "pgfx", "pgfy", "pgfx_o", "pgfy_o", "pgfxm", "pgfym", "xixp", "xixm", "xiyp", "xiym",
+    "pgfxm_o", "pgfym_o", "xixp_o", "xixm_o", "xiyp_o", "xiym_o",
+    "ubflx", "vbflx", "pb_mn", "ubflx_mn", "vbflx_mn", "pvtrop",
+    "dpold", "dpuold", "dpvold", "sigmar", "difint", "difiso", "difdia", "difmxp", "difmxq", "difwgt",
+    "umfltd", "vmfltd", "umflsm", "vmflsm", "utfltd", "vtfltd", "utflsm", "vtflsm", "utflld", "vtflld",
+    "usfltd", "vsfltd", "usflsm", "vsflsm", "usflld", "vsflld",
+    "utotm", "vtotm", "utotn", "vtotn", "uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3",
+    "umax", "vmax", "util1", "util2", "taux", "tauy", "ustarb", "trc",
+]
+GRID_FIELDS = ["scqx", "scqy", "scpx", "scpy", "scux", "scuy", "scvx", "scvy", "scq2", "scp2", "scu2",
+               "scv2", "scq2i", "scp2i", "scuxi", "scuyi", "scvxi", "scvyi", "corioq", "coriop"]
+INT_FIELDS = ["kfpla"]
+
+
+def copy_state(src, dst, fields=None):
+    """Copy every field both backends know from src to dst."""
+    for nm in (fields or (STATE_FIELDS + GRID_FIELDS + INT_FIELDS)):
+        try:
+            a = src.get(nm)
+        except KeyError:
+            continue
+        if hasattr(dst, "has_field") and not dst.has_field(nm):
+            continue
+        dst.put(nm, a)
+
+
+def diff_report(ref, cand, fields=None, rtol=0.0, atol=0.0):
+    """Returns a list of (field, nbad, maxabs, first_index) for fields that differ."""
+    bad = []
+    for nm in (fields or (STATE_FIELDS + INT_FIELDS)):
+        try:
+            a = np.asarray(ref.get(nm))
+            b = np.asarray(cand.get(nm))
+        except KeyError:
+            continue
+        n = min(a.shape[0], b.shape[0])
+        a, b = a[:n], b[:n]
+        if rtol == 0.0 and atol == 0.0:
+            ne = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+        else:
+            with np.errstate(invalid="ignore"):
+                ne = ~((np.abs(a - b) <= atol + rtol * np.abs(a)) | (np.isnan(a) & np.isnan(b)) | (a == b))
+        if ne.any():
+            k, j, i = np.argwhere(ne)[0]
+            with np.errstate(invalid="ignore", over="ignore"):
+                d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+                mx = float(np.nanmax(np.where(ne, d, 0.0)))
+            bad.append((nm, int(ne.sum()), mx, (int(k) + 1, int(j) - 3, int(i) - 3),
+                        float(a[k, j, i]), float(b[k, j, i])))
+    return bad
+
+
+def fmt_report(bad):
+    return "\n".join(f"  {nm}: {n} differ, max|d|={mx:.3e}, first at (k,j,i)={idx} ref={ra!r} got={rb!r}"
+                     for nm, n, mx, idx, ra, rb in bad)
