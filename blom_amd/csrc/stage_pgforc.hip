@@ -1,0 +1,164 @@
+// pgforc -- pressure gradient force, phy/mod_pgforc.F90:438-615, with
+// pgforc_geopotential (:95-260).
+//
+// Kernels (one thread per water column unless noted; planes are read coalesced in i while
+// each lane walks its own column in k -- the k-recurrences phi(k) = phi(k+1) - dphi and
+// the monotone search indices kup/kum are per-column serial by construction):
+//   k_pscan + k_dpudpv      p, dpu, dpv, pu, pv                                 (:450-485)
+//   k_pgf_copy_old          *_o copies of the previous PGF fields                (:488-522)
+//   k_pgf_phi               bottom-up geopotential and phip at p-points          (:112-134)
+//   k_pgf_uv                per u-/v-column: downward index search, delphi at the
+//                           mid-layer pressure, pgfx/pgfy and the vertical sums
+//                           pgfxm, xixp, xixm; then the normalisation by pbu_p, the
+//                           barotropic part removal and the /pb_p scaling        (:140-257, :543-589)
+//   sealv                                                                       (:591-595)
+// Algorithmic bytes: 15 F.  Roofline: HBM (EOS is ~100 flop per 8-byte load).
+#include "blomgpu_internal.h"
+#include "eos.h"
+
+int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int with_pupv);
+
+#define EPSILP 1.e-12
+#define GRAV 9.806
+
+__global__ void k_pgf_copy_old2d(const DevView *Vp, int n) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 1) return;
+  const size_t c = t, on = (size_t)(n - 1) * V.nplane;
+  if (V.m[I_iu][c]) {
+    V.f[F_xixp_o][c] = V.f[F_xixp][c + on];
+    V.f[F_xixm_o][c] = V.f[F_xixm][c + on];
+    V.f[F_pgfxm_o][c] = V.f[F_pgfxm][c + on];
+  }
+  if (V.m[I_iv][c]) {
+    V.f[F_xiyp_o][c] = V.f[F_xiyp][c + on];
+    V.f[F_xiym_o][c] = V.f[F_xiym][c + on];
+    V.f[F_pgfym_o][c] = V.f[F_pgfym][c + on];
+  }
+}
+
+__global__ void k_pgf_copy_old3d(const DevView *Vp, int nn) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const int k = blockIdx.y;
+  const size_t c = t, ok = (size_t)k * V.nplane, okn = (size_t)(k + nn) * V.nplane;
+  if (V.m[I_iu][c]) V.f[F_pgfx_o][c + ok] = V.f[F_pgfx][c + okn];
+  if (V.m[I_iv][c]) V.f[F_pgfy_o][c + ok] = V.f[F_pgfy][c + okn];
+}
+
+// phi, phip at p-points, j,i = 0..jj/ii, phy/mod_pgforc.F90:112-134.  phip -> wkp0.
+__global__ void k_pgf_phi(const DevView *Vp, int nn) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][t]) return;
+  const size_t c = t, np = V.nplane;
+  const int kk = V.kk;
+  double *phi = V.f[F_phi], *phip = V.f[F_wkp0];
+  const double *p = V.f[F_p];
+  double ph = phi[c + (size_t)kk * np], php = 0.;
+  phip[c + (size_t)kk * np] = 0.;
+  double plo = p[c + (size_t)kk * np];
+  for (int k = kk - 1; k >= 0; k--) {
+    const double pup = p[c + (size_t)k * np];
+    const size_t okn = c + (size_t)(k + nn) * np;
+    if (!(V.f[F_dp][okn] < EPSILP)) {
+      double dphi, alpu, alpl;
+      eos::delphi(pup, plo, V.f[F_temp][okn], V.f[F_saln][okn], dphi, alpu, alpl);
+      ph = ph - dphi;
+      php = php + plo * alpl - pup * alpu;
+    }
+    phi[c + (size_t)k * np] = ph;
+    phip[c + (size_t)k * np] = php;
+    plo = pup;
+  }
+}
+
+// One u- or v-column per thread (blockIdx.y = 0: u, 1: v), phy/mod_pgforc.F90:140-257 and the
+// per-column part of :543-589.  `sh` is the plane offset of the "minus" neighbour (-1 or -ni).
+__global__ void k_pgf_uv(const DevView *Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const bool isv = blockIdx.y == 1;
+  const size_t c = t, np = V.nplane;
+  if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
+  const size_t mns = isv ? c - V.ni : c - 1;
+  const int kk = V.kk;
+  const double *p = V.f[F_p], *phi = V.f[F_phi], *phip = V.f[F_wkp0];
+  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
+  const double *pz = isv ? V.f[F_pv] : V.f[F_pu];
+  const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  int kp = kk, km = kk;                  // kup/kum (1-based layer indices as in the reference)
+  double xip = 0., xim = 0., pgfm = 0.;
+  for (int k = kk; k >= 1; k--) {
+    const double dpk = dpz[c + (size_t)(k - 1) * np];
+    const double prs = pz[c + (size_t)k * np] - .5 * dpk;
+    while (p[c + (size_t)(kp - 1) * np] > prs) kp--;
+    while (p[mns + (size_t)(km - 1) * np] > prs) km--;
+    double dphip, alpup, alplp, dphim, alpum, alplm;
+    const double pplo = p[c + (size_t)kp * np], pmlo = p[mns + (size_t)km * np];
+    eos::delphi(prs, pplo, temp[c + (size_t)(kp - 1) * np], saln[c + (size_t)(kp - 1) * np], dphip, alpup, alplp);
+    eos::delphi(prs, pmlo, temp[mns + (size_t)(km - 1) * np], saln[mns + (size_t)(km - 1) * np], dphim, alpum, alplm);
+    double cp = .25 * (p[c + (size_t)k * np] + p[c + (size_t)(k - 1) * np]);
+    double cm = .25 * (p[mns + (size_t)k * np] + p[mns + (size_t)(k - 1) * np]);
+    const double q = prs / (cp + cm);
+    cp = q * cp;
+    cm = q * cm;
+    const double phi_p = phi[c + (size_t)kp * np] - dphip;
+    xip = xip + (phip[c + (size_t)kp * np] + pplo * alplp - cp * (alpup - alpum)) * dpk;
+    const double phi_m = phi[mns + (size_t)km * np] - dphim;
+    xim = xim + (phip[mns + (size_t)km * np] + pmlo * alplm - cm * (alpum - alpup)) * dpk;
+    const double g = -(phi_p - phi_m);
+    pgf[c + (size_t)(k - 1) * np] = g;
+    pgfm = pgfm + g * dpk;
+  }
+  // :543-589
+  const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
+  pgfm = pgfm * q;
+  xip = xip * q;
+  xim = xim * q;
+  for (int k = 0; k < kk; k++) pgf[c + (size_t)k * np] = pgf[c + (size_t)k * np] - pgfm;
+  const size_t on = (size_t)(n - 1) * np;
+  (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
+  (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
+  (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+}
+
+__global__ void k_pgf_sealv(const DevView *Vp) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][t]) return;
+  V.f[F_sealv][t] = V.f[F_phi][t] / GRAV;
+}
+
+int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)mm; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.P.pgfmth != 0) return ctx_fail(c, "pgforc: pgfmth = 'dynamic enthalpy' is not built yet");
+  if (int rc = launch_p_dpu_dpv(c, nn, 1)) return rc;
+  hipLaunchKernelGGL(k_pgf_copy_old2d, plane_grid(h), dim3(256), 0, c->stream, c->d, n);
+  hipLaunchKernelGGL(k_pgf_copy_old3d, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+  {
+    TimeScope ts(c, "pgforc");
+    hipLaunchKernelGGL(k_pgf_phi, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn);
+    // xctilr(pb_p,1,1,1,1) at :540 precedes the /pb_p(i-1,j) scaling done inside k_pgf_uv
+    if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
+    hipLaunchKernelGGL(k_pgf_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+  }
+  hipLaunchKernelGGL(k_pgf_sealv, plane_grid(h), dim3(256), 0, c->stream, c->d);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

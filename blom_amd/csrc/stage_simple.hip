@@ -1,0 +1,179 @@
+// init_fluxes, tmsmt1, tmsmt2, initms and the shared "interface pressure + velocity-point
+// thickness" kernels (tail of tmsmt2 / mxlayr, head of pgforc).
+//
+// All of these are pure streaming: one thread per point of the padded (ni x nj) plane,
+// consecutive lanes on consecutive i (unit stride, 8 B/lane), layers on blockIdx.y or in a
+// per-column loop where a k-recurrence exists.  Roofline: HBM.
+#include "blomgpu_internal.h"
+
+#define PLANE_IJ(V)                                                        \
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  if (t_ >= (V).nplane) return;                                            \
+  const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
+  const size_t c = t_;                                                     \
+  (void)i; (void)j; (void)c
+
+// ---- init_fluxes, phy/mod_state.F90:352-372 ------------------------------------------------
+__global__ void k_init_fluxes(const DevView *Vp, int mm) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 0 || j > V.jj + 2 || i < 0 || i > V.ii + 2) return;
+  const size_t o = c + (size_t)(blockIdx.y + mm) * V.nplane;
+  if (V.m[I_iu][c]) { V.f[F_uflx][o] = 0.; V.f[F_utflx][o] = 0.; V.f[F_usflx][o] = 0.; }
+  if (V.m[I_iv][c]) { V.f[F_vflx][o] = 0.; V.f[F_vtflx][o] = 0.; V.f[F_vsflx][o] = 0.; }
+}
+
+int st_init_fluxes(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
+  hipLaunchKernelGGL(k_init_fluxes, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- initms / tmsmt1, phy/mod_tmsmt.F90:161-277 ---------------------------------------------
+__global__ void k_tmsmt1(const DevView *Vp, int off, int is_initms) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const int k = blockIdx.y;                         // 0-based layer
+  const size_t ok = c + (size_t)k * V.nplane, okn = c + (size_t)(k + off) * V.nplane;
+  if (V.m[I_ip][c]) {
+    if (!is_initms) V.f[F_dpold][okn] = V.f[F_dp][okn];
+    V.f[F_told][ok] = V.f[F_temp][okn];
+    V.f[F_sold][ok] = V.f[F_saln][okn];
+    for (int nt = 0; nt < V.ntr; nt++)
+      V.f[F_trcold][ok + (size_t)nt * V.kk * V.nplane] = V.f[F_trc][okn + (size_t)nt * 2 * V.kk * V.nplane];
+  }
+  if (!is_initms && V.P.vcoord_tag == 1) {
+    if (V.m[I_iu][c]) V.f[F_dpuold][ok] = V.f[F_dpu][okn];
+    if (V.m[I_iv][c]) V.f[F_dpvold][ok] = V.f[F_dpv][okn];
+  }
+}
+
+int st_tmsmt1(blomgpu_ctx *c, int nn) {
+  hipLaunchKernelGGL(k_tmsmt1, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, nn, 0);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int st_initms(blomgpu_ctx *c, int mm) {
+  hipLaunchKernelGGL(k_tmsmt1, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, 1);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- p(k+1) = p(k) + dp(k+off), j,i = -2..+2 (mod_tmsmt.F90:354-365, mod_pgforc.F90:451-461,
+//      mod_mxlayr.F90:1270-1280).  One thread per column, coalesced plane-by-plane. -----------
+__global__ void k_pscan(const DevView *Vp, int off, int lo, int hi_off) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < lo || j > V.jj + hi_off || i < lo || i > V.ii + hi_off || !V.m[I_ip][c]) return;
+  const double *dp = V.f[F_dp] + (size_t)off * V.nplane;
+  double *p = V.f[F_p];
+  double acc = p[c];
+  for (int k = 0; k < V.kk; k++) {
+    acc = acc + dp[c + (size_t)k * V.nplane];
+    p[c + (size_t)(k + 1) * V.nplane] = acc;
+  }
+}
+
+// ---- dpu,dpv (and optionally pu,pv) from p, j,i = -1..+2 (mod_tmsmt.F90:369-391,
+//      mod_pgforc.F90:463-485, mod_mxlayr.F90:1282-1310) --------------------------------------
+__global__ void k_dpudpv(const DevView *Vp, int off, int with_pupv) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
+  const bool wu = V.m[I_iu][c] != 0, wv = V.m[I_iv][c] != 0;
+  if (!wu && !wv) return;
+  const double *p = V.f[F_p];
+  const size_t np = V.nplane, w = c - 1, s = c - V.ni;
+  const size_t bot = (size_t)V.kk * np;
+  const double pc_b = p[c + bot];
+  const double qu = wu ? fmin2(pc_b, p[w + bot]) : 0., qv = wv ? fmin2(pc_b, p[s + bot]) : 0.;
+  double *dpu = V.f[F_dpu] + (size_t)off * np, *dpv = V.f[F_dpv] + (size_t)off * np;
+  double pu = wu ? V.f[F_pu][c] : 0., pv = wv ? V.f[F_pv][c] : 0.;
+  double pc0 = p[c], pw0 = wu ? p[w] : 0., ps0 = wv ? p[s] : 0.;
+  for (int k = 0; k < V.kk; k++) {
+    const size_t o1 = (size_t)(k + 1) * np;
+    const double pc1 = p[c + o1];
+    if (wu) {
+      const double pw1 = p[w + o1];
+      const double d = .5 * ((fmin2(qu, pw1) - fmin2(qu, pw0)) + (fmin2(qu, pc1) - fmin2(qu, pc0)));
+      dpu[c + (size_t)k * np] = d;
+      if (with_pupv) { pu = pu + d; V.f[F_pu][c + o1] = pu; }
+      pw0 = pw1;
+    }
+    if (wv) {
+      const double ps1 = p[s + o1];
+      const double d = .5 * ((fmin2(qv, ps1) - fmin2(qv, ps0)) + (fmin2(qv, pc1) - fmin2(qv, pc0)));
+      dpv[c + (size_t)k * np] = d;
+      if (with_pupv) { pv = pv + d; V.f[F_pv][c + o1] = pv; }
+      ps0 = ps1;
+    }
+    pc0 = pc1;
+  }
+}
+
+int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int with_pupv) {
+  hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, -2, 2);
+  hipLaunchKernelGGL(k_dpudpv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, with_pupv);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int launch_pscan(blomgpu_ctx *c, int off, int lo, int hi_off) {
+  hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, lo, hi_off);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// ---- tmsmt2, phy/mod_tmsmt.F90:295-350: column sums then per-layer filter --------------------
+__global__ void k_tmsmt2(const DevView *Vp, int m, int mm, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const double epsilp = 1.e-12;
+  double pbfaco = 0., pbfacn = 0.;
+  for (int k = 0; k < V.kk; k++) {
+    pbfaco = pbfaco + V.f[F_dpold][c + (size_t)(k + nn) * np];
+    pbfacn = pbfacn + V.f[F_dp][c + (size_t)(k + nn) * np];
+  }
+  const double pbm = V.f[F_pb][c + (size_t)(m - 1) * np];
+  pbfaco = pbm / pbfaco;
+  pbfacn = pbm / pbfacn;
+  const double wts1 = V.P.wts1, wts2 = V.P.wts2;
+  for (int k = 0; k < V.kk; k++) {
+    const size_t okm = c + (size_t)(k + mm) * np, okn = c + (size_t)(k + nn) * np, ok = c + (size_t)k * np;
+    double pold = fmax2(0., V.f[F_dpold][okn] * pbfaco);
+    double pmid = fmax2(0., V.f[F_dp][okm]);
+    double pnew = fmax2(0., V.f[F_dp][okn] * pbfacn);
+    const double dpm = wts1 * pmid + wts2 * (pold + pnew);
+    V.f[F_dp][okm] = dpm;
+    pold = pold + epsilp;
+    pmid = pmid + epsilp;
+    pnew = pnew + epsilp;
+    V.f[F_temp][okm] = (wts1 * pmid * V.f[F_temp][okm] + wts2 * (pold * V.f[F_told][ok] + pnew * V.f[F_temp][okn])) /
+                       (dpm + epsilp);
+    V.f[F_saln][okm] = (wts1 * pmid * V.f[F_saln][okm] + wts2 * (pold * V.f[F_sold][ok] + pnew * V.f[F_saln][okn])) /
+                       (dpm + epsilp);
+    for (int nt = 0; nt < V.ntr; nt++) {
+      double *tr = V.f[F_trc] + (size_t)nt * 2 * V.kk * np;
+      const double *tro = V.f[F_trcold] + (size_t)nt * V.kk * np;
+      tr[okm] = (wts1 * pmid * tr[okm] + wts2 * (pold * tro[ok] + pnew * tr[okn])) / (dpm + epsilp);
+    }
+  }
+}
+
+int st_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) {
+  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, mm, nn);
+  HIPCHK(c, hipGetLastError());
+  if (int rc = st_xctilr(c, c->h.f[F_dp] + (size_t)(k1m - 1) * c->h.nplane, 1, c->h.kk, 3, 3, 1)) return rc;
+  if (c->h.P.vcoord_tag == 1) return launch_p_dpu_dpv(c, mm, 0);
+  return launch_pscan(c, mm, -2, 2);
+}
+
+// ---- tail of mxlayr, phy/mod_mxlayr.F90:1266-1310 -------------------------------------------
+int st_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) {
+  if (int rc = st_xctilr(c, c->h.f[F_dp] + (size_t)(k1n - 1) * c->h.nplane, 1, c->h.kk, 3, 3, 1)) return rc;
+  return launch_p_dpu_dpv(c, nn, 0);
+}

@@ -1,0 +1,132 @@
+"""Host-side mirror of the reference's stage interface on top of libblomgpu.so (ctypes).
+
+`BlomGpu` offers exactly what blom_amd.hostinit / blom_amd.stepper drive (get/put/set/stage
+and the integer masks), with the reference's stage names and (m,n,mm,nn,k1m,k1n) argument
+meaning (phy/mod_blom_step.F90:89-253).  There is no CPU fallback: if the HIP library is
+missing or no device is present, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libblomgpu.so")
+
+
+class blomgpu_dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("idm", "jdm", "kdm", "nbdy", "itdm", "jtdm", "i0", "j0",
+                                       "nreg", "ntr", "device")]
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
+                           "blom_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.blomgpu_last_error.restype = C.c_char_p
+    lib.blomgpu_last_error.argtypes = [C.c_void_p]
+    return lib
+
+
+class BlomGpuError(RuntimeError):
+    pass
+
+
+class BlomGpu:
+    def __init__(self, idm, jdm, kdm, ntr, nreg, masks, device=0, itdm=None, jtdm=None, i0=0, j0=0):
+        self.lib = load_library()
+        self.idm, self.jdm, self.kdm, self.ntr, self.nreg = idm, jdm, kdm, ntr, nreg
+        self.ni, self.nj = idm + 8, jdm + 8
+        d = blomgpu_dims(idm, jdm, kdm, 4, itdm or idm, jtdm or jdm, i0, j0, nreg, ntr, device)
+        self.ctx = C.c_void_p()
+        rc = self.lib.blomgpu_create(C.byref(d), C.byref(self.ctx))
+        if rc:
+            raise BlomGpuError(self.lib.blomgpu_last_error(None).decode())
+        self.masks = {k: np.ascontiguousarray(masks[k], dtype=np.int32) for k in ("ip", "iu", "iv", "iq")}
+        self._chk(self.lib.blomgpu_set_masks(self.ctx, *[self.masks[k].ctypes.data_as(C.c_void_p)
+                                                         for k in ("ip", "iu", "iv", "iq")]))
+        self._info = {}
+
+    def close(self):
+        if self.ctx:
+            self.lib.blomgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise BlomGpuError(self.lib.blomgpu_last_error(self.ctx).decode())
+
+    # -- fields -----------------------------------------------------------------------
+    def field_info(self, name):
+        if name not in self._info:
+            nlev, isint = C.c_int(0), C.c_int(0)
+            rc = self.lib.blomgpu_field_info(self.ctx, name.encode(), C.byref(nlev), C.byref(isint))
+            if rc:
+                raise KeyError(name)
+            self._info[name] = (nlev.value, bool(isint.value))
+        return self._info[name]
+
+    def has_field(self, name):
+        try:
+            self.field_info(name)
+            return True
+        except KeyError:
+            return False
+
+    def get(self, name):
+        nlev, isint = self.field_info(name)
+        a = np.empty((nlev, self.nj, self.ni), dtype=np.int32 if isint else np.float64)
+        self._chk(self.lib.blomgpu_download(self.ctx, name.encode(), a.ctypes.data_as(C.c_void_p), nlev))
+        return a
+
+    def put(self, name, arr):
+        nlev, isint = self.field_info(name)
+        a = np.ascontiguousarray(arr, dtype=np.int32 if isint else np.float64)
+        a = a.reshape((-1, self.nj, self.ni))
+        n = min(nlev, a.shape[0])
+        self._chk(self.lib.blomgpu_upload(self.ctx, name.encode(), a.ctypes.data_as(C.c_void_p), n))
+
+    # -- options ----------------------------------------------------------------------
+    def set(self, name, v):
+        if isinstance(v, str):
+            self._chk(self.lib.blomgpu_set_str(self.ctx, name.encode(), v.encode()))
+        elif isinstance(v, (bool, int, np.integer)):
+            rc = self.lib.blomgpu_set_int(self.ctx, name.encode(), C.c_int(int(v)))
+            if rc:
+                self._chk(self.lib.blomgpu_set_real(self.ctx, name.encode(), C.c_double(float(v))))
+        else:
+            self._chk(self.lib.blomgpu_set_real(self.ctx, name.encode(), C.c_double(float(v))))
+
+    # -- stages -----------------------------------------------------------------------
+    def stage(self, name, m, n, mm, nn, k1m, k1n):
+        self._chk(self.lib.blomgpu_stage(self.ctx, name.encode(), m, n, mm, nn, k1m, k1n))
+
+    def xctilr(self, name, lev0, l1, ld, mh, nh, itype):
+        self._chk(self.lib.blomgpu_xctilr(self.ctx, name.encode(), lev0, l1, ld, mh, nh, itype))
+
+    def step(self, nstep, nsteps=1):
+        ns = C.c_int(nstep)
+        self._chk(self.lib.blomgpu_step(self.ctx, C.byref(ns), nsteps))
+        return ns.value
+
+    def sync(self):
+        self._chk(self.lib.blomgpu_sync(self.ctx))
+
+    def crc(self, name, lev0, nlev):
+        v = C.c_uint(0)
+        self._chk(self.lib.blomgpu_crc(self.ctx, name.encode(), lev0, nlev, C.byref(v)))
+        return v.value
+
+    def timer_reset(self):
+        self._chk(self.lib.blomgpu_timer_reset(self.ctx))
+
+    def timer_get(self, what):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._chk(self.lib.blomgpu_timer_get(self.ctx, what.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
