@@ -110,6 +110,11 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
     HIPCHK(c, hipMalloc((void **)&h.m[f], bytes));
     HIPCHK(c, hipMemsetAsync(h.m[f], 0, bytes, c->stream));
   }
+  h.nwk = 24 + 5 * NT;
+  HIPCHK(c, hipMalloc((void **)&h.wk, sizeof(double) * (size_t)h.nwk * K * h.nplane));
+  HIPCHK(c, hipMemsetAsync(h.wk, 0, sizeof(double) * (size_t)h.nwk * K * h.nplane, c->stream));
+  HIPCHK(c, hipMalloc((void **)&h.wk2d, sizeof(double) * (size_t)NWK2D * h.nplane));
+  HIPCHK(c, hipMemsetAsync(h.wk2d, 0, sizeof(double) * (size_t)NWK2D * h.nplane, c->stream));
   HIPCHK(c, hipMalloc((void **)&c->d, sizeof(DevView)));
   c->dirty = true;
   ctx_sync_view(c);
@@ -124,6 +129,8 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (int f = 0; f < NF_REAL; f++) (void)hipFree(c->h.f[f]);
   for (int f = 0; f < NF_INT; f++) (void)hipFree(c->h.m[f]);
+  (void)hipFree(c->h.wk);
+  (void)hipFree(c->h.wk2d);
   (void)hipFree(c->d);
   (void)hipStreamDestroy(c->stream);
   delete c;

@@ -56,12 +56,8 @@
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
   X(fpug, K) X(fplg, K)                                                                  \
-  /* device work space (the reference's stage-local 2-D/3-D temporaries) */              \
-  X(wk0, K) X(wk1, K) X(wk2, K) X(wk3, K) X(wk4, K) X(wk5, K) X(wk6, K) X(wk7, K)        \
-  X(wk8, K) X(wk9, K) X(wk10, K) X(wk11, K) X(wk12, K) X(wk13, K) X(wk14, K)             \
-  X(wk15, K) X(wk16, K) X(wk17, K) X(wk18, K) X(wk19, K) X(wk20, K) X(wk21, K)           \
-  X(wk22, K) X(wk23, K) X(wk24, K) X(wk25, K) X(wk26, K) X(wk27, K) X(wk28, K)           \
-  X(wk29, K) X(wk30, K) X(wk31, K) X(wkp0, K + 1) X(wkp1, K + 1)
+  /* (K+1)-level work fields (phip of pgforc_geopotential, ...) */                       \
+  X(wkp0, K + 1) X(wkp1, K + 1)
 
 #define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1)
 
@@ -115,7 +111,16 @@ struct DevView {
   Params P;
   double *f[NF_REAL];
   int *m[NF_INT];
+  // work space standing in for the reference's stage-local temporaries:
+  //   wk   : nwk fields of kk levels each   (field w, level k at wk + (w*kk + k)*nplane)
+  //   wk2d : NWK2D single planes
+  double *wk;
+  double *wk2d;
+  int nwk;
 };
+#define NWK2D 48
+#define WK(V, w) ((V).wk + (size_t)(w) * (V).kk * (V).nplane)
+#define WK2(V, w) ((V).wk2d + (size_t)(w) * (V).nplane)
 
 // index of Fortran (i,j) inside a plane; level stride is V.nplane
 #define IDX(V, i, j) (((i) + NBDY - 1) + (V).ni * ((j) + NBDY - 1))

@@ -32,7 +32,7 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
     V.f[F_utflld][c + okm] = ft;
     for (int nt = 0; nt < V.ntr; nt++) {
       const double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
-      V.f[F_wk0 + 2 * nt][c + ok] = q * (tr[w] - tr[c]);
+      WK(V, 2 * nt)[c + ok] = q * (tr[w] - tr[c]);
     }
     V.f[F_usflx][c + okm] = V.f[F_usflx][c + okm] + fs;
     V.f[F_utflx][c + okm] = V.f[F_utflx][c + okm] + ft;
@@ -46,7 +46,7 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
     V.f[F_vtflld][c + okm] = ft;
     for (int nt = 0; nt < V.ntr; nt++) {
       const double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
-      V.f[F_wk1 + 2 * nt][c + ok] = q * (tr[s] - tr[c]);
+      WK(V, 2 * nt + 1)[c + ok] = q * (tr[s] - tr[c]);
     }
     V.f[F_vsflx][c + okm] = V.f[F_vsflx][c + okm] + fs;
     V.f[F_vtflx][c + okm] = V.f[F_vtflx][c + okm] + ft;
@@ -71,7 +71,7 @@ __global__ void k_diffus_update(const DevView *Vp, int mm, int nn) {
   V.f[F_temp][c + okn] = tn;
   for (int nt = 0; nt < V.ntr; nt++) {
     double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
-    const double *fu = V.f[F_wk0 + 2 * nt] + ok, *fv = V.f[F_wk1 + 2 * nt] + ok;
+    const double *fu = WK(V, 2 * nt) + ok, *fv = WK(V, 2 * nt + 1) + ok;
     tr[c] = tr[c] - q * (fu[e] - fu[c] + fv[nb] - fv[c]);
   }
   V.f[F_sigma][c + okn] = eos::sig(V.P, tn, sn);
@@ -82,7 +82,6 @@ int st_diffus(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   const size_t np = h.nplane;
   if (h.P.ltedtp_opt != 1) return ctx_fail(c, "diffus: ltedtp = 'neutral' (hybrid coordinate) is not built yet");
-  if (2 * h.ntr > 32) return ctx_fail(c, "diffus: too many tracers for the device work space");
   if (int rc = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, 3, 3, 1)) return rc;        // :58
   if (int rc = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, 2, 2, 1)) return rc;      // :72
   if (int rc = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 2, 2, 1)) return rc;      // :73

@@ -4,8 +4,5 @@
 #include <stdlib.h>
 #define TODO(name) { fprintf(stderr, "oracle/c: stage %s not restated yet\n", name); abort(); }
 void orc_momtum(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) TODO("momtum")
-void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) TODO("barotp")
 void orc_diapfl(OState *S, int n, int nn, int k1n) TODO("diapfl")
-void orc_advect(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) TODO("advect")
-void orc_pbcor1(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) TODO("pbcor1")
-void orc_pbcor2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) TODO("pbcor2")
+
