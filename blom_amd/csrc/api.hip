@@ -110,7 +110,7 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
     HIPCHK(c, hipMalloc((void **)&h.m[f], bytes));
     HIPCHK(c, hipMemsetAsync(h.m[f], 0, bytes, c->stream));
   }
-  h.nwk = 24 + 5 * NT;
+  h.nwk = 32 + 5 * NT;
   HIPCHK(c, hipMalloc((void **)&h.wk, sizeof(double) * (size_t)h.nwk * K * h.nplane));
   HIPCHK(c, hipMemsetAsync(h.wk, 0, sizeof(double) * (size_t)h.nwk * K * h.nplane, c->stream));
   HIPCHK(c, hipMalloc((void **)&h.wk2d, sizeof(double) * (size_t)NWK2D * h.nplane));

@@ -1,5 +1,5 @@
 // Stages of the hot path whose kernels are not written yet fail loudly.
 #include "blomgpu_internal.h"
 #define TODO6(nm) int st_##nm(blomgpu_ctx *c, int, int, int, int, int, int) { return ctx_fail(c, #nm ": HIP kernels not built yet"); }
-TODO6(momtum) TODO6(barotp) TODO6(eddtra)
+TODO6(eddtra)
 int st_diapfl(blomgpu_ctx *c, int, int, int) { return ctx_fail(c, "diapfl: HIP kernels not built yet"); }

@@ -3,6 +3,5 @@
 #include <stdio.h>
 #include <stdlib.h>
 #define TODO(name) { fprintf(stderr, "oracle/c: stage %s not restated yet\n", name); abort(); }
-void orc_momtum(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) TODO("momtum")
 void orc_diapfl(OState *S, int n, int nn, int k1n) TODO("diapfl")
 
