@@ -36,6 +36,9 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
     }
     V.f[F_usflx][c + okm] = V.f[F_usflx][c + okm] + fs;
     V.f[F_utflx][c + okm] = V.f[F_utflx][c + okm] + ft;
+  } else if (j >= 0 && j <= V.jj + 1 && i >= 0 && i <= V.ii + 2) {
+    // uflxtr is 0 where no u-point exists (trc/mod_tracers.F90:166-186); the work space is shared
+    for (int nt = 0; nt < V.ntr; nt++) WK(V, 2 * nt)[c + ok] = 0.;
   }
   if (V.m[I_iv][c] && j >= 0 && j <= V.jj + 2 && i >= 0 && i <= V.ii + 1) {
     const double q = delt1 * .5 * (difiso[s] + difiso[c]) * V.f[F_scvx][c] * V.f[F_scvyi][c] *
@@ -50,6 +53,8 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
     }
     V.f[F_vsflx][c + okm] = V.f[F_vsflx][c + okm] + fs;
     V.f[F_vtflx][c + okm] = V.f[F_vtflx][c + okm] + ft;
+  } else if (j >= 0 && j <= V.jj + 2 && i >= 0 && i <= V.ii + 1) {
+    for (int nt = 0; nt < V.ntr; nt++) WK(V, 2 * nt + 1)[c + ok] = 0.;
   }
 }
 

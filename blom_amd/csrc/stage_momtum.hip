@@ -134,7 +134,11 @@ __global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn) {
       WK(V, M_UTOTM)[c + ok] = ut;
       WK(V, M_UFLUX)[c + ok] = ut * fmax2(V.f[F_dpu][c + okm], cutoff);
     }
-    WK(V, M_UTOTN)[c + ok] = V.f[F_u][c + okn] + V.f[F_ubflxs_p][c + on] * tsfac / (V.f[F_pbu][c + on] * scuy);
+    const double un = V.f[F_u][c + okn] + V.f[F_ubflxs_p][c + on] * tsfac / (V.f[F_pbu][c + on] * scuy);
+    WK(V, M_UTOTN)[c + ok] = un;
+    // the reference's module array utotn is left holding the last layer's values outside the
+    // interior (the interior receives the barotropic forcing at :1158-1175, :1238)
+    if (k == V.kk - 1) V.f[F_utotn][c] = un;
   } else {
     if (in01) { WK(V, M_UTOTM)[c + ok] = 0.; WK(V, M_UFLUX)[c + ok] = 0.; }
     WK(V, M_UTOTN)[c + ok] = 0.;
@@ -146,7 +150,9 @@ __global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn) {
       WK(V, M_VTOTM)[c + ok] = vt;
       WK(V, M_VFLUX)[c + ok] = vt * fmax2(V.f[F_dpv][c + okm], cutoff);
     }
-    WK(V, M_VTOTN)[c + ok] = V.f[F_v][c + okn] + V.f[F_vbflxs_p][c + on] * tsfac / (V.f[F_pbv][c + on] * scvx);
+    const double vn = V.f[F_v][c + okn] + V.f[F_vbflxs_p][c + on] * tsfac / (V.f[F_pbv][c + on] * scvx);
+    WK(V, M_VTOTN)[c + ok] = vn;
+    if (k == V.kk - 1) V.f[F_vtotn][c] = vn;
   } else {
     if (in01) { WK(V, M_VTOTM)[c + ok] = 0.; WK(V, M_VFLUX)[c + ok] = 0.; }
     WK(V, M_VTOTN)[c + ok] = 0.;

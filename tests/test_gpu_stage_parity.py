@@ -13,14 +13,18 @@ import pytest
 from blom_amd.cases import make_case
 from blom_amd import hostinit
 from blom_amd.stepper import dyncore_step
-from parity import copy_state, diff_report, fmt_report
+from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, INT_FIELDS
 
 pytestmark = pytest.mark.gpu
 
 # stage -> (rtol, atol); default exact
 TOL = {"barotp": (1e-12, 1e-9), "diapfl": (1e-11, 1e-12)}
-GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "diffus", "pgforc", "mxlayr_tail",
-              "tmsmt2"]
+GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", "pbcor1", "diffus", "pgforc",
+              "momtum", "mxlayr_tail", "barotp", "pbcor2", "tmsmt2"]
+# 2-D scratch arrays of mod_utility that the reference leaves holding the last layer's
+# temporaries (phy/mod_momtum.F90:398-423, phy/mod_pbcor.F90:172-236); the device keeps such
+# temporaries in its work space instead.
+SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "vtotm"}
 
 
 def _run(cfg, nsteps, stages):
@@ -43,7 +47,8 @@ def _run(cfg, nsteps, stages):
         if "st" in pending:
             st = pending.pop("st")
             rtol, atol = TOL.get(st, (0.0, 0.0))
-            bad = diff_report(ref, gpu, rtol=rtol, atol=atol)
+            fields = [f for f in STATE_FIELDS + INT_FIELDS if f not in SCRATCH]
+            bad = diff_report(ref, gpu, fields=fields, rtol=rtol, atol=atol)
             if bad:
                 failures.append(f"step {nstep[0] + 1} stage {st}:\n" + fmt_report(bad))
 
@@ -62,7 +67,7 @@ def _run(cfg, nsteps, stages):
         check()
         nstep[0] = new
     gpu.close()
-    assert not failures, "\n".join(failures[:6])
+    assert not failures, "\n".join(failures[:40])
 
 
 @pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
