@@ -43,7 +43,7 @@
   /* mod_tmsmt */                                                                        \
   X(dpold, 2 * K) X(dpuold, K) X(dpvold, K) X(told, K) X(sold, K)                        \
   /* mod_vcoord / mod_diffusion */                                                       \
-  X(sigmar, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)          \
+  X(sigmar, K) X(temmin, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)          \
   X(difwgt, 1) X(umfltd, 2 * K) X(vmfltd, 2 * K) X(umflsm, 2 * K) X(vmflsm, 2 * K)       \
   X(utfltd, 2 * K) X(vtfltd, 2 * K) X(utflsm, 2 * K) X(vtflsm, 2 * K) X(utflld, 2 * K)   \
   X(vtflld, 2 * K) X(usfltd, 2 * K) X(vsfltd, 2 * K) X(usflsm, 2 * K) X(vsflsm, 2 * K)   \

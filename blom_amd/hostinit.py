@@ -295,6 +295,11 @@ def init_state(be, case):
     a = be.get("difwgt")
     a[:] = np.where(wfull[None], P["difwgt0"], a)
     be.put("difwgt", a)
+    # minimum physical layer temperature (phy/mod_temmin.F90:57-66 uses -3 for non-bulkml
+    # configurations; settemmin itself is an initialisation routine outside the path)
+    a = be.get("temmin")
+    a[:] = np.where(wfull[None], -3.0, a)
+    be.put("temmin", a)
     jy = (np.arange(1, jj + 1)[:, None] - 0.5) / jj
     taux = be.get("taux")
     taux[0, J, I] = np.where(iu[J, I] > 0, P["taux0"] * np.sin(np.pi * jy) ** 2 * np.ones((jj, ii)),

@@ -1,5 +1,6 @@
 /* TEST INFRASTRUCTURE (oracle): restatement of phy/mod_eos.F90. */
 #include "ostate.h"
+#include <math.h>
 
 /* phy/mod_eos.F90:36-54 */
 static const double a11 = 9.9985372432159340e+02, a12 = 1.0380621928183473e+01,
@@ -75,4 +76,26 @@ void eos_delphi(double p1, double p2, double th, double s, double *dphi, double 
   *dphi = -2. * r * (a2 + b2 * pm + (a2 - a1 * b2 / b1) * qq * (r1_3 + qq * (r1_5 + qq * (r1_7 + qq * r1_9))));
   *alp1 = (a2 + b2 * p1) / (a1 + b1 * p1);
   *alp2 = (a2 + b2 * p2) / (a1 + b1 * p2);
+}
+
+/* dsigdt, phy/mod_eos.F90:243-261 */
+double eos_dsigdt(const OState *S, double th, double s) {
+  double r1 = S->ap11 + (S->ap12 + S->ap14 * th + S->ap15 * s) * th + (S->ap13 + S->ap16 * s) * s;
+  double r2i = 1. / (S->ap21 + (S->ap22 + S->ap24 * th + S->ap25 * s) * th + (S->ap23 + S->ap26 * s) * s);
+  return (S->ap12 + 2. * S->ap14 * th + S->ap15 * s - (S->ap22 + 2. * S->ap24 * th + S->ap25 * s) * r1 * r2i) * r2i;
+}
+
+/* dsigds, phy/mod_eos.F90:306-323 */
+double eos_dsigds(const OState *S, double th, double s) {
+  double r1 = S->ap11 + (S->ap12 + S->ap14 * th + S->ap15 * s) * th + (S->ap13 + S->ap16 * s) * s;
+  double r2i = 1. / (S->ap21 + (S->ap22 + S->ap24 * th + S->ap25 * s) * th + (S->ap23 + S->ap26 * s) * s);
+  return (S->ap13 + S->ap15 * th + 2. * S->ap16 * s - (S->ap23 + S->ap25 * th + 2. * S->ap26 * s) * r1 * r2i) * r2i;
+}
+
+/* sofsig, phy/mod_eos.F90:366-384 */
+double eos_sofsig(const OState *S, double sg, double th) {
+  double a = S->ap16 - S->ap26 * sg;
+  double b = S->ap13 - S->ap23 * sg + (S->ap15 - S->ap25 * sg) * th;
+  double c = S->ap11 - S->ap21 * sg + (S->ap12 - S->ap22 * sg + (S->ap14 - S->ap24 * sg) * th) * th;
+  return (-b + sqrt(b * b - 4. * a * c)) / (2. * a);
 }

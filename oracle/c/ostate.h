@@ -40,7 +40,7 @@
   X(vmaxb, 1) X(vminb, 1) X(uglue, 1) X(vglue, 1) X(ubflxs_t, 1) X(vbflxs_t, 1)           \
   X(ubcors_t, 1) X(vbcors_t, 1)                                                           \
   X(dpold, 2 * K) X(dpuold, K) X(dpvold, K) X(told, K) X(sold, K)                         \
-  X(sigmar, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)           \
+  X(sigmar, K) X(temmin, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)           \
   X(difwgt, 1) X(umfltd, 2 * K) X(vmfltd, 2 * K) X(umflsm, 2 * K) X(vmflsm, 2 * K)        \
   X(utfltd, 2 * K) X(vtfltd, 2 * K) X(utflsm, 2 * K) X(vtflsm, 2 * K) X(utflld, 2 * K)    \
   X(vtflld, 2 * K) X(usfltd, 2 * K) X(vsfltd, 2 * K) X(usflsm, 2 * K) X(vsflsm, 2 * K)    \
@@ -106,6 +106,9 @@ double eos_rho(double p, double th, double s);
 double eos_alp(double p, double th, double s);
 void eos_delphi(double p1, double p2, double th, double s, double *dphi, double *alp1, double *alp2);
 double eos_p_alpha(double p1, double p2, double th, double s);
+double eos_dsigdt(const OState *S, double th, double s);
+double eos_dsigds(const OState *S, double th, double s);
+double eos_sofsig(const OState *S, double sg, double th);
 void eos_set_pref(OState *S, double pref);
 
 /* stages */

@@ -3,5 +3,4 @@
 #include <stdio.h>
 #include <stdlib.h>
 #define TODO(name) { fprintf(stderr, "oracle/c: stage %s not restated yet\n", name); abort(); }
-void orc_diapfl(OState *S, int n, int nn, int k1n) TODO("diapfl")
 

@@ -42,6 +42,7 @@ module ref_harness
   use mod_tracers,   only: ntr, trc, trcold, inivar_tracers
   use mod_cmnfld,    only: inivar_cmnfld
   use mod_ifdefs,    only: use_TRC
+  use mod_temmin,    only: temmin
 
   implicit none
   private
@@ -309,8 +310,9 @@ contains
       R3(dpold, 2*kdm)
       R3(dpuold, kdm)
       R3(dpvold, kdm)
-      ! mod_vcoord
+      ! mod_vcoord, mod_temmin
       R3(sigmar, kdm)
+      R3(temmin, kdm)
       ! mod_diffusion
       R3(difint, kdm)
       R3(difiso, kdm)

@@ -10,7 +10,7 @@ STATE_FIELDS = [
     "pgfx", "pgfy", "pgfx_o", "pgfy_o", "pgfxm", "pgfym", "xixp", "xixm", "xiyp", "xiym",
     "pgfxm_o", "pgfym_o", "xixp_o", "xixm_o", "xiyp_o", "xiym_o",
     "ubflx", "vbflx", "pb_mn", "ubflx_mn", "vbflx_mn", "pvtrop",
-    "dpold", "dpuold", "dpvold", "sigmar", "difint", "difiso", "difdia", "difmxp", "difmxq", "difwgt",
+    "dpold", "dpuold", "dpvold", "sigmar", "temmin", "difint", "difiso", "difdia", "difmxp", "difmxq", "difwgt",
     "umfltd", "vmfltd", "umflsm", "vmflsm", "utfltd", "vtfltd", "utflsm", "vtflsm", "utflld", "vtflld",
     "usfltd", "vsfltd", "usflsm", "vsflsm", "usflld", "vsflld",
     "utotm", "vtotm", "utotn", "vtotn", "uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3",
