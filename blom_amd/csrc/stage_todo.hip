@@ -2,4 +2,3 @@
 #include "blomgpu_internal.h"
 #define TODO6(nm) int st_##nm(blomgpu_ctx *c, int, int, int, int, int, int) { return ctx_fail(c, #nm ": HIP kernels not built yet"); }
 TODO6(eddtra)
-int st_diapfl(blomgpu_ctx *c, int, int, int) { return ctx_fail(c, "diapfl: HIP kernels not built yet"); }

@@ -107,17 +107,52 @@ class RefBlom:
         self.lib.ref_xctilr(a.ctypes.data_as(C.c_void_p), l1, ld, mh, nh, itype)
 
 
+ALL_REF_FIELDS = """u v dp dpu dpv temp saln sigma uflx vflx utflx vtflx usflx vsflx p pu pv phi cau cav
+ubflxs vbflxs ub vb pb pbu pbv ubflxs_p vbflxs_p pb_p pbu_p pbv_p ubcors_p vbcors_p sealv kfpla
+scqx scqy scpx scpy scux scuy scvx scvy scq2 scp2 scu2 scv2 scq2i scp2i scuxi scuyi scvxi scvyi depths
+corioq coriop betafp pgfx pgfy pgfx_o pgfy_o pgfxm pgfym xixp xixm xiyp xiym pgfxm_o pgfym_o xixp_o
+xixm_o xiyp_o xiym_o absvor dpvor ubflx vbflx pb_mn ubflx_mn vbflx_mn pvtrop dpold dpuold dpvold
+sigmar temmin difint difiso difdia difmxp difmxq difwgt umfltd vmfltd umflsm vmflsm utfltd vtfltd
+utflsm vtflsm utflld vtflld usfltd vsfltd usflsm vsflsm usflld vsflld utotm vtotm utotn vtotn uflux
+vflux uflux2 vflux2 uflux3 vflux3 umax vmax util1 util2 util3 util4 taux tauy ustarb trc trcold""".split()
+
+_BACKENDS = {}
+
+
+def get_ref_backend(cfg, depth):
+    """The reference keeps all state in Fortran module globals and cannot be set up twice in
+    one process; hand out one backend per configuration and restore its post-inivar state."""
+    if cfg in _BACKENDS:
+        be = _BACKENDS[cfg]
+        be.restore_pristine()
+        return be
+    be = RefBackend(cfg, depth)
+    _BACKENDS[cfg] = be
+    return be
+
+
 class RefBackend:
-    """Adapter giving RefBlom the backend interface blom_amd.hostinit drives."""
+    """Adapter giving RefBlom the backend interface blom_amd.hostinit drives.
+    Use get_ref_backend() rather than constructing this twice for one configuration."""
 
     def __init__(self, cfg, depth):
         self.ref = RefBlom(cfg)
         self.ref.set("expcnf", "channel")
         self.ref.setup(depth)
+        self._pristine = {}
+        for nm in ALL_REF_FIELDS:
+            try:
+                self._pristine[nm] = self.ref.field(nm).copy()
+            except KeyError:
+                pass
         self.kdm, self.idm, self.jdm = self.ref.kdm, self.ref.idm, self.ref.jdm
         self.ntr = self.ref.ntr
         self.nreg = self.ref.nreg
         self.masks = {k: self.ref.field(k)[0] for k in ("ip", "iu", "iv", "iq")}
+
+    def restore_pristine(self):
+        for nm, a in self._pristine.items():
+            self.ref.field(nm)[...] = a
 
     def get(self, name):
         return self.ref.field(name)          # live view: edits land in the reference
