@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native BLOM dynamical core.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one baroclinic time step of the hot path (stage sequence of
+phy/mod_blom_step.F90:96-253 restricted to the dynamical core: init_fluxes, tmsmt1, [halo updates
+of cmnfld2/difest], advect(remap), pbcor1, diffus, pgforc, momtum, diapfl, [mxlayr dp-halo tail],
+barotp, pbcor2, tmsmt2) on the `channel` configuration of BASELINE.json (208x512x53, 1 tile),
+with the state resident in HBM.  metric = simulated model days per wall second
+= steps/s * baclin / 86400.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, algorithmic bytes /
+HIP-event duration vs 8 TB/s), `step_roofline` (SURVEY.md 8d A_step / step time), `stages`
+(ms per stage) and `cpu_baseline` (the reference's own compiled Fortran, or the C restatement,
+timed on a bounded number of steps on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_case(cfg):
+    import numpy as np
+    from blom_amd.cases import make_case
+    from blom_amd import hostinit
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    return case, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq)
+
+
+def algorithmic_bytes(case, ntr):
+    """A_step = (124 + 6 ntr) F + 2.5 lstep 62 G, with eddtra's 14 F removed
+    because eddtra is not part of the timed sequence yet."""
+    F = case.idm * case.jdm * case.kdm * 8.0
+    G = case.idm * case.jdm * 8.0
+    a3d = (124 - 14 + 6 * ntr) * F
+    a2d = 2.5 * case.params["lstep"] * 62 * G
+    return a3d, a2d
+
+
+# compulsory HBM bytes per launch of each timed kernel class, in units of F (one 3-D field):
+# every distinct array the class reads or writes counted once (2-D coefficient arrays ignored);
+# see DESIGN.md "Kernels" for the derivation.
+def class_bytes_F(ntr):
+    return {
+        "remap": 25 + 2 * ntr, "diffus": 19 + 2 * ntr, "pgforc": 15, "momtum": 26,
+        "diapfl": 23 + 2 * ntr, "pbcor1": 12 + 2 * ntr, "pbcor2": 13 + 2 * ntr,
+    }
+
+
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
+    """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
+    2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
+    default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
+    import threading
+    res = {}
+    threading.stack_size(2 << 30)
+    th = threading.Thread(target=lambda: res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds)))
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    return res
+
+
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
+    """Reference (preferred) or C restatement timed on the host for a bounded number of steps."""
+    from blom_amd import hostinit
+    from blom_amd.stepper import dyncore_step
+    kind = None
+    try:
+        from oracle.refblom import get_ref_backend, have_ref
+        if have_ref(cfg):
+            be = get_ref_backend(cfg, case.depth)
+            kind = "reference"
+    except Exception:
+        kind = None
+    if kind is None:
+        from oracle.coracle import COracle
+        be = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+        kind = "port"
+    hostinit.init_state(be, case)
+    ns = dyncore_step(be, 0, case.params["baclin"])          # forward first step (untimed)
+    t0 = time.time()
+    n = 0
+    while n < 3 or (time.time() - t0 < max_seconds and n < 200):
+        ns = dyncore_step(be, ns, case.params["baclin"])
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=1, kind=kind,
+                sample=f"{n} baroclinic steps of the same {cfg} workload, {dt * 1e3:.1f} ms/step, single thread "
+                       f"(reference built without OpenMP)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="channel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+
+    from blom_amd.gpu import BlomGpu
+    from blom_amd import hostinit
+    case, nreg, masks = build_case(args.config)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
+    hostinit.init_state(gpu, case)
+    baclin = case.params["baclin"]
+
+    # ---- warm-up: first (forward) step + W-1 leap-frog steps, with per-class HIP-event timing ----
+    ns = gpu.step(0, 1)
+    gpu.set("timing", 1)
+    gpu.timer_reset()
+    if args.warmup > 1:
+        ns = gpu.step(ns, args.warmup - 1)
+    gpu.sync()
+    classes = ["remap", "diffus", "pgforc", "momtum", "diapfl", "barotp", "pbcor1", "pbcor2"]
+    stage_ms = {}
+    for cl in classes:
+        ms, n = gpu.timer_get(cl)
+        if n:
+            stage_ms[cl] = ms / n
+    gpu.set("timing", 0)
+
+    # ---- timed region --------------------------------------------------------------------------
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    barrier()
+    gpu.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ns = gpu.step(ns, args.steps)
+    gpu.sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- dominant kernel class, timed with HIP events on the library's stream over K more steps
+    gpu.set("timing", 1)
+    gpu.timer_reset()
+    ns = gpu.step(ns, min(args.steps, 5))
+    gpu.sync()
+    live = {}
+    for cl in classes:
+        ms, n = gpu.timer_get(cl)
+        if n:
+            live[cl] = ms / n
+    gpu.set("timing", 0)
+    import numpy as np
+    finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps * baclin / 86400.0 / dt       # every rank integrates its own replica
+    F = case.idm * case.jdm * case.kdm * 8.0
+    cb = class_bytes_F(case.ntr)
+    hbm_classes = {k: v for k, v in live.items() if k in cb}
+    dom = max(hbm_classes, key=hbm_classes.get)
+    a3d, a2d = algorithmic_bytes(case, case.ntr)
+    out = {
+        "metric": "simulated-days/sec", "value": value, "unit": "simulated-days/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config} {case.idm}x{case.jdm}x{case.kdm}, 1 tile per GPU, "
+                               f"isopyc_bulkml/remap/geopotential/uc/enscon, ntr={case.ntr}, "
+                               f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
+                               "dyncore stage sequence without eddtra (replicas only for N>1)",
+                   "state_finite": finite},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom]},
+        "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
+                          "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,
+                          "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "stages_ms": live,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.config, case, masks, nreg)
+            except Exception as e:                       # the bench line must still be produced
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    gpu.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

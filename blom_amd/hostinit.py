@@ -183,23 +183,24 @@ def init_state(be, case):
     # -- first physical interior layer kfpla (mod_inicon.F90:1394-1420), bulkml only ---
     dp = be.get("dp")
     kf = be.get("kfpla")
-    d1 = dp[:kk]
-    for jx in range(NBDY, NBDY + jj):
-        for ix in range(NBDY, NBDY + ii):
-            if ip[jx, ix] == 0:
-                continue
-            k = 3
-            dps = 0.0
-            while k <= kk and d1[k - 1, jx, ix] < EPSILP:
-                dps += d1[k - 1, jx, ix]
-                d1[k - 1, jx, ix] = 0.0
-                k += 1
-            if k > kk:
-                d1[1, jx, ix] += dps
-            else:
-                d1[k - 1, jx, ix] += dps
-            kf[0, jx, ix] = k
-            kf[1, jx, ix] = k
+    d1 = dp[:kk, J, I].copy()                       # vectorised over columns
+    # k = first layer index >= 3 with dp >= epsilp (kk+1 if none); thin layers above it are
+    # emptied and their mass (summed top-down, as the reference does) moved to layer k, or to
+    # layer 2 when the column holds no interior mass
+    thick = d1[2:] >= EPSILP                        # layers 3..kk
+    anyt = thick.any(axis=0)
+    first = np.where(anyt, thick.argmax(axis=0) + 3, kk + 1)
+    dps = np.zeros_like(d1[0])
+    for k in range(3, kk + 1):
+        sel = wet & (k < first)
+        dps = np.where(sel, dps + d1[k - 1], dps)
+        d1[k - 1] = np.where(sel, 0.0, d1[k - 1])
+    d1[1] = np.where(wet & (first > kk), d1[1] + dps, d1[1])
+    for k in range(3, kk + 1):
+        d1[k - 1] = np.where(wet & (first == k), d1[k - 1] + dps, d1[k - 1])
+    dp[:kk, J, I] = np.where(wet, d1, dp[:kk, J, I])
+    for lev in (0, 1):
+        kf[lev, J, I] = np.where(wet, first, kf[lev, J, I])
     dp[kk:2 * kk, J, I] = np.where(wet, dp[:kk, J, I], dp[kk:2 * kk, J, I])
     be.put("dp", dp)
     be.put("kfpla", kf)
@@ -265,25 +266,29 @@ def init_state(be, case):
     # -- barotropic potential vorticity (mod_inicon.F90:1192-1232) ----------------------
     corioq = case.grid["corioq"]
     pv_ = be.get("pvtrop")
-    o = NBDY - 1
-    for j in range(0, jj + 1):
-        for i in range(1, ii + 1):
-            if iu[o + j, o + i]:
-                q = 2. / (pb_p[0, o + j, o + i] + pb_p[0, o + j, o + i - 1])
-                pv_[:, o + j, o + i] = corioq[o + j, o + i] * q
-                pv_[:, o + j + 1, o + i] = corioq[o + j + 1, o + i] * q
-    for j in range(1, jj + 1):
-        for i in range(0, ii + 1):
-            if iv[o + j, o + i]:
-                q = 2. / (pb_p[0, o + j, o + i] + pb_p[0, o + j - 1, o + i])
-                pv_[:, o + j, o + i] = corioq[o + j, o + i] * q
-                pv_[:, o + j, o + i + 1] = corioq[o + j, o + i + 1] * q
-    for j in range(1, jj + 1):
-        for i in range(1, ii + 1):
-            if iq[o + j, o + i]:
-                pv_[:, o + j, o + i] = corioq[o + j, o + i] * 4. / (
-                    pb_p[0, o + j, o + i] + pb_p[0, o + j, o + i - 1]
-                    + pb_p[0, o + j - 1, o + i] + pb_p[0, o + j - 1, o + i - 1])
+    # three sweeps, later ones overriding earlier ones, and within a sweep the later loop index
+    # overriding the earlier one -- applied in that order with masked assignments
+    def q2(a, b):
+        return 2. / (a + b)
+    Ju0, Iu0 = sl(0, jj), sl(1, ii)                       # u-points j=0..jj, i=1..ii
+    mu0 = iu[Ju0, Iu0] > 0
+    qu = q2(pb_p[0, Ju0, Iu0], pb_p[0, Ju0, sl(0, ii - 1)])
+    # writer (i,j') -> q(i,j'+1) first (it is overridden by writer (i,j'+1) -> q(i,j'+1) if valid)
+    tgt = pv_[:, sl(1, jj + 1), Iu0]
+    tgt[:] = np.where(mu0[None], (corioq[sl(1, jj + 1), Iu0] * qu)[None], tgt)
+    tgt = pv_[:, Ju0, Iu0]
+    tgt[:] = np.where(mu0[None], (corioq[Ju0, Iu0] * qu)[None], tgt)
+    Jv0, Iv0 = sl(1, jj), sl(0, ii)                       # v-points j=1..jj, i=0..ii
+    mv0 = iv[Jv0, Iv0] > 0
+    qv = q2(pb_p[0, Jv0, Iv0], pb_p[0, sl(0, jj - 1), Iv0])
+    tgt = pv_[:, Jv0, sl(1, ii + 1)]
+    tgt[:] = np.where(mv0[None], (corioq[Jv0, sl(1, ii + 1)] * qv)[None], tgt)
+    tgt = pv_[:, Jv0, Iv0]
+    tgt[:] = np.where(mv0[None], (corioq[Jv0, Iv0] * qv)[None], tgt)
+    mq = iq[J, I] > 0
+    qq = corioq[J, I] * 4. / (pb_p[0, J, I] + pb_p[0, J, Im] + pb_p[0, Jm, I] + pb_p[0, Jm, Im])
+    tgt = pv_[:, J, I]
+    tgt[:] = np.where(mq[None], qq[None], tgt)
     be.put("pvtrop", pv_)
 
     # -- frozen diffusivities and forcing (difest_* needs CVMix: out of scope) ----------
