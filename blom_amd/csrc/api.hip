@@ -260,11 +260,11 @@ int blomgpu_xctilr(blomgpu_ctx *c, const char *name, int lev0, int l1, int ld, i
   return st_xctilr(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, l1, ld, mh, nh, itype);
 }
 
-int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, unsigned *crc) {
+int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype, unsigned *crc) {
   auto it = c->real_ids.find(name);
   if (it == c->real_ids.end()) return ctx_fail(c, std::string("crc: unknown field ") + name);
   ctx_sync_view(c);
-  return st_crc(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, crc);
+  return st_crc(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, itype, crc);
 }
 
 #define STAGE6(nm)                                                                         \

@@ -188,7 +188,7 @@ int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);
-int st_crc(blomgpu_ctx *, const double *base, int nlev, unsigned *crc);
+int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc);
 
 // launch helpers: 1 thread per point of the padded plane, blockIdx.y = level
 static inline dim3 plane_grid(const DevView &h, int nlev = 1, int block = 256) {

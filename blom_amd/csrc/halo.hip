@@ -101,16 +101,15 @@ static unsigned host_crc_bytes(const unsigned char *p, size_t n, unsigned init) 
   return ~crc;
 }
 
-int st_crc(blomgpu_ctx *c, const double *base, int nlev, unsigned *crc) {
-  // mask: p-points (chksum with halo_ps); other grids are served by blomgpu_crc_masked later
+int st_crc(blomgpu_ctx *c, const double *base, int nlev, int itype, unsigned *crc) {
+  const int g = itype % 10;   // phy/mod_checksum.F90:53-68
+  const int *mask = g == 1 ? c->h.m[I_ip] : g == 2 ? c->h.m[I_iq] : g == 3 ? c->h.m[I_iu] : c->h.m[I_iv];
   const DevView &h = c->h;
-  const int nstrip = (h.ii + 2 * NBDY) / (2 * NBDY + 1);
   const int ns = (h.ii + 2 * NBDY + 1 - 1) / (2 * NBDY + 1);
-  (void)nstrip;
   unsigned *dout = nullptr;
   HIPCHK(c, hipMalloc((void **)&dout, sizeof(unsigned) * ns * h.jj));
   hipLaunchKernelGGL(k_crc_strips, dim3((ns * h.jj + 63) / 64), dim3(64), 0, c->stream, c->d, base,
-                     nlev, c->h.m[I_ip], ns, dout);
+                     nlev, mask, ns, dout);
   std::vector<unsigned> hs((size_t)ns * h.jj);
   HIPCHK(c, hipMemcpyAsync(hs.data(), dout, sizeof(unsigned) * hs.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -118,9 +118,9 @@ class BlomGpu:
     def sync(self):
         self._chk(self.lib.blomgpu_sync(self.ctx))
 
-    def crc(self, name, lev0, nlev):
+    def crc(self, name, lev0, nlev, itype=1):
         v = C.c_uint(0)
-        self._chk(self.lib.blomgpu_crc(self.ctx, name.encode(), lev0, nlev, C.byref(v)))
+        self._chk(self.lib.blomgpu_crc(self.ctx, name.encode(), lev0, nlev, itype, C.byref(v)))
         return v.value
 
     def timer_reset(self):

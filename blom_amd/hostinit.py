@@ -269,7 +269,8 @@ def init_state(be, case):
     # three sweeps, later ones overriding earlier ones, and within a sweep the later loop index
     # overriding the earlier one -- applied in that order with masked assignments
     def q2(a, b):
-        return 2. / (a + b)
+        with np.errstate(divide="ignore"):          # land points are masked out below
+            return 2. / (a + b)
     Ju0, Iu0 = sl(0, jj), sl(1, ii)                       # u-points j=0..jj, i=1..ii
     mu0 = iu[Ju0, Iu0] > 0
     qu = q2(pb_p[0, Ju0, Iu0], pb_p[0, Ju0, sl(0, ii - 1)])
@@ -286,7 +287,8 @@ def init_state(be, case):
     tgt = pv_[:, Jv0, Iv0]
     tgt[:] = np.where(mv0[None], (corioq[Jv0, Iv0] * qv)[None], tgt)
     mq = iq[J, I] > 0
-    qq = corioq[J, I] * 4. / (pb_p[0, J, I] + pb_p[0, J, Im] + pb_p[0, Jm, I] + pb_p[0, Jm, Im])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        qq = corioq[J, I] * 4. / (pb_p[0, J, I] + pb_p[0, J, Im] + pb_p[0, Jm, I] + pb_p[0, Jm, Im])
     tgt = pv_[:, J, I]
     tgt[:] = np.where(mq[None], qq[None], tgt)
     be.put("pvtrop", pv_)

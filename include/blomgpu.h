@@ -64,9 +64,10 @@ int  blomgpu_set_masks(blomgpu_ctx *ctx, const int *ip, const int *iu, const int
 int  blomgpu_xctilr(blomgpu_ctx *ctx, const char *name, int lev0, int l1, int ld,
                     int mh, int nh, int itype);
 
-/* CRC32 of levels lev0..lev0+nlev-1 over the tile interior, matching chksum/xccrc for a
- * single tile (phy/mod_checksum.F90:41-74, phy/mod_xc.F90:4164). */
-int  blomgpu_crc(blomgpu_ctx *ctx, const char *name, int lev0, int nlev, unsigned *crc);
+/* CRC32 of levels lev0..lev0+nlev-1 over the tile interior where the mask of the grid selected
+ * by itype (1/11 p, 2/12 q, 3/13 u, 4/14 v) is 1 -- chksum/xccrc for a single tile
+ * (phy/mod_checksum.F90:41-74, phy/mod_xc.F90:4164). */
+int  blomgpu_crc(blomgpu_ctx *ctx, const char *name, int lev0, int nlev, int itype, unsigned *crc);
 
 /* Stages: same names, same argument meaning as the reference. */
 int  blomgpu_init_fluxes(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n); /* phy/mod_state.F90:341   */

@@ -450,6 +450,20 @@ contains
     end do
   end subroutine mxlayr_tail
 
+  ! The reference's own field checksum (chksum -> xccrc, phy/mod_checksum.F90:41-74,
+  ! phy/mod_xc.F90:4164-4205): CRC-32 over the tile interior where the grid's mask is 1.
+  subroutine ref_xccrc(a, nlev, itype, crc) bind(C, name='ref_xccrc')
+    integer(c_int), value :: nlev, itype
+    real(c_double), intent(in) :: a(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,nlev)
+    integer(c_int), intent(out) :: crc
+    select case (itype)
+      case (halo_ps, halo_pv); call xccrc(crc, a, nlev, ip, itype)
+      case (halo_qs, halo_qv); call xccrc(crc, a, nlev, iq, itype)
+      case (halo_us, halo_uv); call xccrc(crc, a, nlev, iu, itype)
+      case default;            call xccrc(crc, a, nlev, iv, itype)
+    end select
+  end subroutine ref_xccrc
+
   subroutine ref_xctilr(a, l1, ld, mh, nh, itype) bind(C, name='ref_xctilr')
     integer(c_int), value :: l1, ld, mh, nh, itype
     real(c_double), intent(inout) :: a(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,ld)

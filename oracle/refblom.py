@@ -101,6 +101,13 @@ class RefBlom:
         if ierr.value:
             raise KeyError(f"reference harness has no stage {name!r}")
 
+    def xccrc(self, a, itype):
+        """The reference's own checksum of a (nlev, nj, ni) float64 array (chksum/xccrc)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        crc = C.c_int(0)
+        self.lib.ref_xccrc(a.ctypes.data_as(C.c_void_p), a.shape[0], itype, C.byref(crc))
+        return crc.value & 0xFFFFFFFF
+
     def xctilr(self, a, l1, ld, mh, nh, itype):
         """Reference halo update on a (>=ld, nj, ni) float64 array (view), in place."""
         assert a.flags.c_contiguous and a.dtype == np.float64

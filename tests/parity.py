@@ -62,3 +62,19 @@ def diff_report(ref, cand, fields=None, rtol=0.0, atol=0.0):
 def fmt_report(bad):
     return "\n".join(f"  {nm}: {n} differ, max|d|={mx:.3e}, first at (k,j,i)={idx} ref={ra!r} got={rb!r}"
                      for nm, n, mx, idx, ra, rb in bad)
+
+
+def load_golden_init(cfg):
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", f"{cfg}_init.npz"))
+    masks = {m: z["mask_" + m] for m in ("ip", "iu", "iv", "iq")}
+    fields = {k: z[k] for k in z.files if not k.startswith("mask_")}
+    return masks, fields
+
+
+def put_fields(be, fields):
+    for nm, a in fields.items():
+        if hasattr(be, "has_field") and not be.has_field(nm):
+            continue
+        be.put(nm, a)

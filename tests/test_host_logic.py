@@ -1,0 +1,59 @@
+"""Host-side logic: integer masks (bit-exact), single-tile halo rules, time-level indices."""
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd import hostinit
+from parity import load_golden_init
+
+
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
+def test_bigrid_masks_match_reference(cfg):
+    """ip/iu/iv/iq from bigrid_np == the masks the reference's bigrid produced (fixture)."""
+    case = make_case(cfg)
+    masks, _ = load_golden_init(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    assert nreg == case.nreg
+    for nm, a in (("ip", ip), ("iu", iu), ("iv", iv), ("iq", iq)):
+        assert a.dtype == np.int32 and np.array_equal(a, masks[nm]), nm
+
+
+@pytest.mark.parametrize("nreg", [0, 1, 3, 4])
+@pytest.mark.parametrize("mh,nh", [(0, 0), (1, 2), (3, 3), (4, 0), (0, 4), (4, 4), (7, 9)])
+def test_xctilr_np_matches_c_oracle(nreg, mh, nh):
+    from oracle.coracle import COracle, have_coracle
+    import ctypes as C
+    if not have_coracle():
+        pytest.skip("liboracle_c.so not built")
+    idm, jdm, kdm = 11, 7, 3
+    masks = {k: np.ones((jdm + 8, idm + 8), np.int32) for k in ("ip", "iu", "iv", "iq")}
+    co = COracle(idm, jdm, kdm, 0, nreg, masks)
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((2 * kdm, jdm + 8, idm + 8))
+    b = a.copy()
+    hostinit.xctilr_np(a, 2, 5, mh, nh, nreg, idm, jdm)
+    co.lib.orc_xctilr(co.S, b.ctypes.data_as(C.c_void_p), 2, 5, mh, nh, 1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[5], b[5])      # untouched levels
+
+
+def test_xctilr_np_matches_reference():
+    from oracle.refblom import get_ref_backend, have_ref
+    if not have_ref("chan_s"):
+        pytest.skip("reference library not built")
+    case = make_case("chan_s")
+    ref = get_ref_backend("chan_s", case.depth)
+    rng = np.random.default_rng(3)
+    for mh, nh in ((1, 1), (2, 3), (4, 4), (3, 0)):
+        a = rng.standard_normal((4, case.jdm + 8, case.idm + 8))
+        b = a.copy()
+        hostinit.xctilr_np(a, 1, 4, mh, nh, ref.nreg, case.idm, case.jdm)
+        ref.ref.xctilr(b, 1, 4, mh, nh, 1)
+        assert np.array_equal(a, b), (mh, nh)
+
+
+def test_step_indices_follow_blom_step():
+    # phy/mod_blom_step.F90:89-94
+    assert hostinit.step_indices(0, 12) == (1, 2, 0, 12, 1, 13)
+    assert hostinit.step_indices(1, 12) == (2, 1, 12, 0, 13, 1)
+    assert hostinit.step_indices(6, 53) == (1, 2, 0, 53, 1, 54)

@@ -1,0 +1,58 @@
+"""The plain-C restatement (oracle/c) against the committed golden vectors: starting from the
+fixture's initial state it must reproduce, after EVERY stage of three steps, the reference's own
+chksum/xccrc value of EVERY field (bit-exact; tests/golden/make_golden.py generated them from the
+reference's compiled Fortran)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd.checksum import chksum
+from blom_amd.stepper import dyncore_step
+from parity import load_golden_init, put_fields
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
+def test_c_oracle_reproduces_reference_checksums(cfg):
+    from oracle.coracle import COracle, have_coracle
+    if not have_coracle():
+        pytest.skip("oracle/_ref/liboracle_c.so not built (run __graft_entry__.build())")
+    case = make_case(cfg)
+    masks, fields = load_golden_init(cfg)
+    gold = json.load(open(os.path.join(HERE, "golden", f"{cfg}_crc.json")))
+    nreg = case.nreg
+    co = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            co.set(nm, v)
+    put_fields(co, fields)
+    co.set("delt1", case.params["baclin"])
+    bad = []
+    state = {}
+
+    def check(st):
+        exp = gold["crc"][str(state["step"])][st]
+        for nm, want in exp.items():
+            got = chksum(nm, co.get(nm), masks, case.idm, case.jdm)
+            if got != want:
+                bad.append(f"step {state['step']} {st} {nm}: crc 0x{got:08x} != 0x{want:08x}")
+
+    ns = 0
+    for _ in range(gold["nsteps"]):
+        state["step"] = ns + 1
+        pending = []
+
+        def hook(st, six):
+            if pending:
+                check(pending.pop())
+            pending.append(st)
+        ns = dyncore_step(co, ns, case.params["baclin"], hook=hook)
+        check(pending.pop())
+    assert not bad, "\n".join(bad[:20])
+    z = np.load(os.path.join(HERE, "golden", f"{cfg}_final.npz"))
+    for nm in z.files:
+        assert np.array_equal(co.get(nm)[:z[nm].shape[0]], z[nm]), nm
