@@ -1,0 +1,104 @@
+! ------------------------------------------------------------------------------
+! program blom_dyncore -- standalone Fortran driver of the device-resident
+! dynamical core, in the shape of the reference's `program blom`
+! (drivers/nocoupler/blom.F:20-66): initialise, loop blom_step until the last step,
+! print the final field checksum of dp (blom.F:56-57), write 'success' to run.status.
+!
+! Initial state: a raw binary dump (blom_amd/statefile.py writes it from the numpy host
+! initialisation); the reference reads netCDF here, which is out of scope.
+!   record 1: idm jdm kdm ntr nreg nsteps  (int32 x6), baclin (real64)
+!   then per entry: name (16 chars), kind (int32: 0 real field, 1 int field, 2 real option,
+!                   3 int option, 4 string option), nlev (int32), payload
+! ------------------------------------------------------------------------------
+program blom_dyncore
+
+  use mod_blomgpu
+  implicit none
+
+  character(len=256) :: fname
+  character(len=16)  :: name
+  character(len=32)  :: sval
+  integer :: u, ios, kind, nlev, nsteps, nstep, i4(6), ival
+  real(8) :: baclin, rval
+  real(8), allocatable :: buf(:,:,:)
+  integer, allocatable :: ibuf(:,:,:)
+
+  call get_command_argument(1, fname)
+  if (len_trim(fname) == 0) fname = 'blom_state.bin'
+  open (newunit=u, file=trim(fname), access='stream', form='unformatted', status='old', action='read')
+  read (u) i4, baclin
+  nsteps = i4(6)
+  call gpu_init(i4(1), i4(2), i4(3), i4(4), i4(5), 0)
+  do
+    read (u, iostat=ios) name, kind, nlev
+    if (ios /= 0) exit
+    select case (kind)
+      case (0)
+        allocate (buf(idm+2*nbdy, jdm+2*nbdy, nlev))
+        read (u) buf
+        call gpu_upload(trim(name), buf, nlev)
+        deallocate (buf)
+      case (1)
+        allocate (ibuf(idm+2*nbdy, jdm+2*nbdy, nlev))
+        read (u) ibuf
+        call gpu_upload_int(trim(name), ibuf, nlev)
+        deallocate (ibuf)
+      case (2)
+        read (u) rval
+        call gpu_set(trim(name), rval)
+      case (3)
+        read (u) ival
+        call gpu_set(trim(name), ival)
+      case (4)
+        read (u) sval
+        call gpu_set(trim(name), trim(sval))
+    end select
+  end do
+  close (u)
+
+  nstep = 0
+  do while (nstep < nsteps)
+    call blom_step(nstep)
+  end do
+
+  call gpu_sync()
+  call gpu_chksum('dp', 2*kdm, 1, 'dp')          ! blom.F:56-57
+  call gpu_chksum('temp', 2*kdm, 1, 'temp')
+  call gpu_chksum('u', 2*kdm, 13, 'u')
+  open (newunit=u, file='run.status', status='unknown')
+  write (u,*) 'success'                          ! blom.F:59-61
+  close (u)
+  call gpu_finalize()
+
+contains
+
+  subroutine blom_step(nstep)
+    ! stage sequence of phy/mod_blom_step.F90:89-253, dynamical core only
+    integer, intent(inout) :: nstep
+    integer :: m, n, mm, nn, k1m, k1n
+    m = mod(nstep  ,2)+1
+    n = mod(nstep+1,2)+1
+    mm = (m-1)*kdm
+    nn = (n-1)*kdm
+    k1m = 1+mm
+    k1n = 1+nn
+    nstep = nstep+1                                ! step_time
+    call gpu_set('nstep', nstep)
+    call init_fluxes(m,n,mm,nn,k1m,k1n)
+    call tmsmt1(nn)
+    call halo_cmnfld2()
+    call halo_difest()
+    call advect(m,n,mm,nn,k1m,k1n)
+    call pbcor1(m,n,mm,nn,k1m,k1n)
+    call diffus(m,n,mm,nn,k1m,k1n)
+    call pgforc(m,n,mm,nn,k1m,k1n)
+    call momtum(m,n,mm,nn,k1m,k1n)
+    call diapfl(n,nn,k1n)
+    call mxlayr_tail(nn,k1n)
+    call barotp(m,n,mm,nn,k1m,k1n)
+    call pbcor2(m,n,mm,nn,k1m,k1n)
+    call tmsmt2(m,mm,nn,k1m)
+    call gpu_set('delt1', baclin+baclin)           ! phy/mod_blom_step.F90:300
+  end subroutine blom_step
+
+end program blom_dyncore
