@@ -37,7 +37,7 @@
   X(absvor, 2 * K) X(dpvor, 2 * K)                                                       \
   /* mod_barotp (module arrays + the implicitly SAVEd locals, mod_barotp.F90:155-167) */ \
   X(ubflx, 2) X(vbflx, 2) X(pb_mn, 2) X(ubflx_mn, 2) X(vbflx_mn, 2) X(pvtrop, 2)         \
-  X(pvtrop_o, 1) X(pb_t, 2) X(ubflx_t, 2) X(vbflx_t, 2) X(umaxb, 1) X(uminb, 1)          \
+  X(pvtrop_o, 1) X(pb_t, 2) X(ubflx_t, 2) X(vbflx_t, 2) X(pb_t2, 2) X(ubflx_t2, 2) X(vbflx_t2, 2) X(umaxb, 1) X(uminb, 1)          \
   X(vmaxb, 1) X(vminb, 1) X(uglue, 1) X(vglue, 1) X(ubflxs_t, 1) X(vbflxs_t, 1)          \
   X(ubcors_t, 1) X(vbcors_t, 1)                                                          \
   /* mod_tmsmt */                                                                        \
@@ -150,6 +150,7 @@ struct blomgpu_ctx {
   std::unordered_map<std::string, int> real_ids, int_ids;
   std::unordered_map<std::string, KTimer> timers;
   bool timing = false;
+  int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   std::string err;
 };
 

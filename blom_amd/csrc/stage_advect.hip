@@ -24,7 +24,8 @@
 
 #define DPEPS 1.e-12   // phy/mod_remap.F90:40
 #define ONEMM 9.806
-#define MAXTR 8
+#define MAXTR 4   // tracer accumulators live in registers: every loop over them has a
+                  // compile-time trip count (a runtime-indexed array would go to scratch)
 
 // work-space slots (fields of kk levels)
 #define G_DX 0
@@ -306,9 +307,11 @@ __device__ inline void add_contrib(const DevView &V, size_t ok, const double *dp
   const double qy = ay * dl + axy * dx + ayy * dy;
   A.ft = A.ft + fd * WK(V, G_TD)[x + ok] + qx * WK(V, G_TX)[x + ok] + qy * WK(V, G_TY)[x + ok];
   A.fs = A.fs + fd * WK(V, G_SD)[x + ok] + qx * WK(V, G_SX)[x + ok] + qy * WK(V, G_SY)[x + ok];
-  for (int nt = 0; nt < V.ntr; nt++)
-    A.ftr[nt] = A.ftr[nt] + fd * WK(V, G_TRD(nt))[x + ok] + qx * WK(V, G_TRX(nt))[x + ok] +
-                qy * WK(V, G_TRY(nt))[x + ok];
+#pragma unroll
+  for (int nt = 0; nt < MAXTR; nt++)
+    if (nt < V.ntr)
+      A.ftr[nt] = A.ftr[nt] + fd * WK(V, G_TRD(nt))[x + ok] + qx * WK(V, G_TRX(nt))[x + ok] +
+                  qy * WK(V, G_TRY(nt))[x + ok];
 }
 
 // ---- mod_remap.F90:588-1462 ----------------------------------------------------------------------
@@ -331,7 +334,8 @@ __global__ void k_remap_flux(const DevView *Vp, int n, int mm, int nn) {
   if (in_u) {
     Acc A;
     A.fd = 0.; A.ft = 0.; A.fs = 0.;
-    for (int nt = 0; nt < ntr; nt++) A.ftr[nt] = 0.;
+#pragma unroll
+    for (int nt = 0; nt < MAXTR; nt++) A.ftr[nt] = 0.;
     if (do_u) {
       double cuc1, cvc1;
       corner(V, cau, cav, c + ni, cuc1, cvc1);
@@ -374,13 +378,16 @@ __global__ void k_remap_flux(const DevView *Vp, int n, int mm, int nn) {
     WK(V, W_FDU(ntr))[c + ok] = A.fd;
     WK(V, W_FTU(ntr))[c + ok] = A.ft;
     WK(V, W_FSU(ntr))[c + ok] = A.fs;
-    for (int nt = 0; nt < ntr; nt++) WK(V, W_FTRU(ntr, nt))[c + ok] = A.ftr[nt];
+#pragma unroll
+    for (int nt = 0; nt < MAXTR; nt++)
+      if (nt < ntr) WK(V, W_FTRU(ntr, nt))[c + ok] = A.ftr[nt];
   }
 
   if (in_v) {
     Acc A;
     A.fd = 0.; A.ft = 0.; A.fs = 0.;
-    for (int nt = 0; nt < ntr; nt++) A.ftr[nt] = 0.;
+#pragma unroll
+    for (int nt = 0; nt < MAXTR; nt++) A.ftr[nt] = 0.;
     if (do_v) {
       double cuc1, cvc1;
       corner(V, cau, cav, c + 1, cuc1, cvc1);
@@ -423,7 +430,9 @@ __global__ void k_remap_flux(const DevView *Vp, int n, int mm, int nn) {
     WK(V, W_FDV(ntr))[c + ok] = A.fd;
     WK(V, W_FTV(ntr))[c + ok] = A.ft;
     WK(V, W_FSV(ntr))[c + ok] = A.fs;
-    for (int nt = 0; nt < ntr; nt++) WK(V, W_FTRV(ntr, nt))[c + ok] = A.ftr[nt];
+#pragma unroll
+    for (int nt = 0; nt < MAXTR; nt++)
+      if (nt < ntr) WK(V, W_FTRV(ntr, nt))[c + ok] = A.ftr[nt];
   }
 }
 

@@ -92,7 +92,7 @@ __global__ void k_bt_pvtrop(const DevView *Vp, int n) {
 }
 
 // ---- nb == 1 reload of the subcycling state, :339-348 --------------------------------------------
-__global__ void k_bt_load(const DevView *Vp) {
+__global__ void k_bt_load(const DevView *Vp) {   // always into buffer set 0 (*_t)
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -202,14 +202,15 @@ __global__ void k_bt_vmom(const DevView *Vp, BtArgs a) {
 }
 
 // ---- phase epilogues, :847-977 ------------------------------------------------------------------------
-__global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, int nl) {
+__global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, int nl, int set) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
   const size_t np = V.nplane, om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const size_t oml = (size_t)(ml - 1) * np, onl = (size_t)(nl - 1) * np, o3 = 2 * np;
   const bool wp = V.m[I_ip][c], wu = V.m[I_iu][c], wv = V.m[I_iv][c];
-  const double *pbt = V.f[F_pb_t], *ubt = V.f[F_ubflx_t], *vbt = V.f[F_vbflx_t];
+  const double *pbt = set ? V.f[F_pb_t2] : V.f[F_pb_t], *ubt = set ? V.f[F_ubflx_t2] : V.f[F_ubflx_t];
+  const double *vbt = set ? V.f[F_vbflx_t2] : V.f[F_vbflx_t];
   const double us = V.f[F_ubflxs_t][c], vs = V.f[F_vbflxs_t][c];
   if (nb == 1 || nb == 3) {
     const size_t ol = nb == 1 ? om : on;
@@ -279,6 +280,10 @@ __global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, i
   }
 }
 
+int bt_pair_halo(blomgpu_ctx *c, int set);
+int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
+                   int do_odd, int do_even, int src);
+
 int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
@@ -300,7 +305,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   for (auto &x : hl)
     if (int rc = st_xctilr(c, h.f[x.f] + (size_t)x.lev * np, 1, 1, 1, x.nh, x.it)) return rc;
 
-  int lll0 = 1, ml = 1, nl = 2;
+  int lll0 = 1, ml = 1, nl = 2, set = 0;     // set: which buffer set (*_t / *_t2) holds the current state
   double woa = 0., wob = 0., wna = 0., wnb = 0.;
   for (int nb = 1; nb <= 5; nb++) {
     if (nb == 1) {
@@ -317,6 +322,31 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       wna = 0.; wnb = 1.;
     }
     hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
+    const int last = lll0 + lstep / 2 - 1;
+    if (c->barotp_fused) {
+      // fused odd+even substep pairs per LDS tile (stage_barotp_pair.hip); single substeps only
+      // where a pair would straddle a phase boundary (epilogue + sum reset sit in between)
+      int lll = lll0;
+      while (lll <= last) {
+        const bool odd = lll % 2 == 1;
+        const bool both = odd && lll + 1 <= last;
+        double wo[2], wm[2], wn[2];
+        for (int x = 0; x < 2; x++) {
+          const int l = both ? lll + x : lll;
+          wo[x] = woa * l + wob;
+          wn[x] = wna * l + wnb;
+          wm[x] = 1. - wo[x] - wn[x];
+        }
+        if (!both && !odd) { wo[1] = wo[0]; wm[1] = wm[0]; wn[1] = wn[0]; }
+        // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
+        if (!(h.itdm == h.ii && h.jtdm == h.jj && h.nreg != 2))
+          if (int rc = bt_pair_halo(c, set)) return rc;
+        bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set);
+        set ^= 1;
+        if (!both) { const int ll = ml; ml = nl; nl = ll; }
+        lll += both ? 2 : 1;
+      }
+    } else
     for (int lll = lll0; lll <= lll0 + lstep / 2 - 1; lll++) {
       BtArgs a;
       a.m = m; a.n = n; a.ml = ml; a.nl = nl;
@@ -344,7 +374,10 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       const int ll = ml; ml = nl; nl = ll;
     }
     lll0 = lll0 + lstep / 2;
-    hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl);
+    // the epilogue reads pb_t(i-1,j), pb_t(i,j-1); the fused kernels write tile interiors only
+    if (c->barotp_fused)
+      if (int rc = bt_pair_halo(c, set)) return rc;
+    hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl, set);
   }
   HIPCHK(c, hipGetLastError());
   return 0;

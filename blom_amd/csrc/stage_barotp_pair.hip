@@ -1,0 +1,266 @@
+// barotp, fused substep kernel.  One launch advances the barotropic state by one odd+even
+// substep pair (or one half of it at the phase boundaries) for a tile of the domain held in LDS.
+//
+// phy/mod_barotp.F90:387-843: an odd substep is halo update + continuity + u + v, computed 2-3
+// cells into the halo; the even substep is continuity + v + u on ranges shrunk accordingly, with
+// no communication.  A workgroup therefore loads its TI x TJ tile plus a 3-cell rim of the six
+// dynamic planes (pb_t, ubflx_t, vbflx_t at both time levels) into LDS, runs the six sweeps with
+// workgroup barriers in between on the shrinking rectangle where inputs are valid (intersected
+// with the reference's own loop ranges, so every LDS value equals the reference's array value),
+// and writes back the tile interior.  Neighbouring tiles recompute the rim redundantly
+// (836/512 points) instead of synchronising grid-wide six times per pair.  Reads come from one
+// buffer set and writes go to the other (ping-pong), since a neighbour may still be loading.
+// All values are per-point identical to the unfused kernels (same expressions, same order).
+#include "blomgpu_internal.h"
+
+#define TI 32
+#define TJ 16
+#define HB 3
+#define BI (TI + 2 * HB)     // 38
+#define BJ (TJ + 2 * HB)     // 22
+#define NPT (BI * BJ)        // 836
+#define NTHR 896             // 14 waves
+
+struct PairArgs {
+  int m, n, ml, nl;          // baroclinic levels m,n; barotropic levels at the start of the launch
+  double wo[2], wm[2], wn[2];  // time weights of the odd [0] and even [1] substep
+  int do_odd, do_even;
+  int src;                   // 0: read *_t write *_t2, 1: the other way round
+  int fold_halo;             // single tile: apply the xctilr rule (wrap / vland) while loading
+};
+
+__global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a) {
+  const DevView &V = *Vp;
+  __shared__ double s_pb[2][BJ][BI + 1], s_ub[2][BJ][BI + 1], s_vb[2][BJ][BI + 1];
+  // coefficients that the momentum equations read at neighbouring points: staged once per launch
+  __shared__ double s_pvo[BJ][BI + 1], s_pvm[BJ][BI + 1], s_pvn[BJ][BI + 1], s_sx[BJ][BI + 1], s_sy[BJ][BI + 1];
+  const int tid = threadIdx.x;
+  const bool act = tid < NPT;
+  const int li = act ? tid % BI : 0, lj = act ? tid / BI : 0;
+  // Fortran indices of this thread's point
+  const int gi = blockIdx.x * TI + 1 + li - HB, gj = blockIdx.y * TJ + 1 + lj - HB;
+  const int ii = V.ii, jj = V.jj, ni = V.ni;
+  const bool inarr = act && gi >= 1 - NBDY && gi <= ii + NBDY && gj >= 1 - NBDY && gj <= jj + NBDY;
+  const size_t np = V.nplane;
+  const size_t c = inarr ? (size_t)IDX(V, gi, gj) : 0;
+  const double *g_pb = a.src ? V.f[F_pb_t2] : V.f[F_pb_t], *g_ub = a.src ? V.f[F_ubflx_t2] : V.f[F_ubflx_t];
+  const double *g_vb = a.src ? V.f[F_vbflx_t2] : V.f[F_vbflx_t];
+  double *o_pb = a.src ? V.f[F_pb_t] : V.f[F_pb_t2], *o_ub = a.src ? V.f[F_ubflx_t] : V.f[F_ubflx_t2];
+  double *o_vb = a.src ? V.f[F_vbflx_t] : V.f[F_vbflx_t2];
+  const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
+  if (act) {
+    // source of the state planes: the point itself, or -- single tile, halo point -- what xctilr
+    // would have put there (phy/mod_xc.F90:4374-4419): wrapped interior point or vland
+    size_t cs = c;
+    bool land = false;
+    if (a.fold_halo && inarr) {
+      const bool oi = gi < 1 || gi > ii, oj = gj < 1 || gj > jj;
+      if (oi || oj) {
+        land = (oi && (V.nreg == 0 || V.nreg == 4)) || (oj && V.nreg <= 2);
+        const int is = gi < 1 ? gi + ii : (gi > ii ? gi - ii : gi), js = gj < 1 ? gj + jj : (gj > jj ? gj - jj : gj);
+        cs = (size_t)IDX(V, is, js);
+      }
+    }
+    const bool ok = inarr && !land;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      s_pb[l][lj][li] = ok ? g_pb[cs + l * np] : (inarr ? V.P.vland : 0.);
+      s_ub[l][lj][li] = ok ? g_ub[cs + l * np] : (inarr ? V.P.vland : 0.);
+      s_vb[l][lj][li] = ok ? g_vb[cs + l * np] : (inarr ? V.P.vland : 0.);
+    }
+    s_pvo[lj][li] = inarr ? V.f[F_pvtrop_o][c] : 0.;
+    s_pvm[lj][li] = inarr ? V.f[F_pvtrop][c + om] : 0.;
+    s_pvn[lj][li] = inarr ? V.f[F_pvtrop][c + on] : 0.;
+    s_sx[lj][li] = inarr ? V.f[F_scvxi][c] : 0.;
+    s_sy[lj][li] = inarr ? V.f[F_scuyi][c] : 0.;
+  }
+  const bool wp = inarr && V.m[I_ip][c], wu = inarr && V.m[I_iu][c], wv = inarr && V.m[I_iv][c];
+  const double wbaro = V.P.wbaro, dlt = V.P.dlt;
+  // per-point coefficients (read once, used by both substeps)
+  double scp2i = 0.;
+  double u_pgo = 0., u_xpo = 0., u_xmo = 0., u_pgm = 0., u_xpm = 0., u_xmm = 0., u_pgn = 0., u_xpn = 0., u_xmn = 0.;
+  double u_scuxi = 0., u_scuy = 0., u_tot = 0., u_glue = 0., u_max = 0., u_min = 0.;
+  double v_pgo = 0., v_xpo = 0., v_xmo = 0., v_pgm = 0., v_xpm = 0., v_xmm = 0., v_pgn = 0., v_xpn = 0., v_xmn = 0.;
+  double v_scvyi = 0., v_scvx = 0., v_tot = 0., v_glue = 0., v_max = 0., v_min = 0.;
+  if (wp) scp2i = V.f[F_scp2i][c];
+  if (wu) {
+    u_pgo = V.f[F_pgfxm_o][c]; u_xpo = V.f[F_xixp_o][c]; u_xmo = V.f[F_xixm_o][c];
+    u_pgm = V.f[F_pgfxm][c + om]; u_xpm = V.f[F_xixp][c + om]; u_xmm = V.f[F_xixm][c + om];
+    u_pgn = V.f[F_pgfxm][c + on]; u_xpn = V.f[F_xixp][c + on]; u_xmn = V.f[F_xixm][c + on];
+    u_scuxi = V.f[F_scuxi][c]; u_scuy = V.f[F_scuy][c]; u_tot = V.f[F_utotn][c]; u_glue = V.f[F_uglue][c];
+    u_max = V.f[F_umaxb][c]; u_min = V.f[F_uminb][c];
+  }
+  if (wv) {
+    v_pgo = V.f[F_pgfym_o][c]; v_xpo = V.f[F_xiyp_o][c]; v_xmo = V.f[F_xiym_o][c];
+    v_pgm = V.f[F_pgfym][c + om]; v_xpm = V.f[F_xiyp][c + om]; v_xmm = V.f[F_xiym][c + om];
+    v_pgn = V.f[F_pgfym][c + on]; v_xpn = V.f[F_xiyp][c + on]; v_xmn = V.f[F_xiym][c + on];
+    v_scvyi = V.f[F_scvyi][c]; v_scvx = V.f[F_scvx][c]; v_tot = V.f[F_vtotn][c]; v_glue = V.f[F_vglue][c];
+    v_max = V.f[F_vmaxb][c]; v_min = V.f[F_vminb][c];
+  }
+  double us_acc = 0., uc_acc = 0., vs_acc = 0., vc_acc = 0.;     // ubflxs_t, ubcors_t, vbflxs_t, vbcors_t increments
+  const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
+  if (mine) {
+    if (wu) { us_acc = V.f[F_ubflxs_t][c]; uc_acc = V.f[F_ubcors_t][c]; }
+    if (wv) { vs_acc = V.f[F_vbflxs_t][c]; vc_acc = V.f[F_vbcors_t][c]; }
+  }
+  __syncthreads();
+
+  int ml = a.ml - 1, nl = a.nl - 1;     // 0-based LDS level indices
+  // tile-local validity rectangle of what has been computed so far (inclusive, in li/lj)
+  int vlo_i = 0, vhi_i = BI - 1, vlo_j = 0, vhi_j = BJ - 1;
+  const bool mom_scon = V.P.mommth == 0;
+
+#define IN(lo_i, hi_i, lo_j, hi_j) (act && li >= (lo_i) && li <= (hi_i) && lj >= (lo_j) && lj <= (hi_j))
+
+  for (int half = 0; half < 2; half++) {
+    if (half == 0 ? !a.do_odd : !a.do_even) continue;
+    const bool odd = half == 0;
+    const double wo = a.wo[half], wm = a.wm[half], wn = a.wn[half];
+    // ---- continuity: needs ub(i+1), vb(j+1) at level ml ------------------------------------------
+    {
+      const int r_i0 = odd ? -1 : 0, r_i1 = odd ? ii + 1 : ii, r_j0 = odd ? -1 : 0, r_j1 = odd ? jj + 2 : jj + 1;
+      if (wp && IN(vlo_i, vhi_i - 1, vlo_j, vhi_j - 1) && gi >= r_i0 && gi <= r_i1 && gj >= r_j0 && gj <= r_j1)
+        s_pb[nl][lj][li] = (1. - wbaro) * s_pb[ml][lj][li] + wbaro * s_pb[nl][lj][li] -
+                           (1. + wbaro) * dlt *
+                               (s_ub[ml][lj][li + 1] - s_ub[ml][lj][li] + s_vb[ml][lj + 1][li] - s_vb[ml][lj][li]) * scp2i;
+    }
+    __syncthreads();
+    // after continuity pb[nl] is valid on [vlo_i, vhi_i-1] x [vlo_j, vhi_j-1]
+    const int p_hi_i = vhi_i - 1, p_hi_j = vhi_j - 1;
+    auto do_u = [&](int lv, int lo_i, int hi_i, int lo_j, int hi_j, int r_i0, int r_i1, int r_j0, int r_j1) {
+      if (wu && IN(lo_i, hi_i, lo_j, hi_j) && gi >= r_i0 && gi <= r_i1 && gj >= r_j0 && gj <= r_j1) {
+        const double ubml = s_ub[ml][lj][li], ubnl = s_ub[nl][lj][li];
+        if (mine) us_acc = us_acc - wbaro * ubnl + (1. + wbaro) * ubml;
+        const double vc = s_vb[lv][lj][li], vn = s_vb[lv][lj + 1][li], vw = s_vb[lv][lj][li - 1], vnw = s_vb[lv][lj + 1][li - 1];
+        const double sx_c = s_sx[lj][li], sx_n = s_sx[lj + 1][li], sx_w = s_sx[lj][li - 1], sx_nw = s_sx[lj + 1][li - 1];
+        const double pvo_c = s_pvo[lj][li], pvm_c = s_pvm[lj][li], pvn_c = s_pvn[lj][li];
+        const double pvo_n = s_pvo[lj + 1][li], pvm_n = s_pvm[lj + 1][li], pvn_n = s_pvn[lj + 1][li];
+        double q;
+        if (mom_scon)
+          q = (vc * sx_c + vn * sx_n + vw * sx_w + vnw * sx_nw) *
+              (wo * (pvo_c + pvo_n) + wm * (pvm_c + pvm_n) + wn * (pvn_c + pvn_n)) * .125;
+        else
+          q = .25 * ((vc * sx_c + vw * sx_w) * (wo * pvo_c + wm * pvm_c + wn * pvn_c) +
+                     (vn * sx_n + vnw * sx_nw) * (wo * pvo_n + wm * pvm_n + wn * pvn_n));
+        if (mine) uc_acc = uc_acc + q;
+        const double pbc = s_pb[nl][lj][li], pbw = s_pb[nl][lj][li - 1];
+        const double utndcy = q + (wo * (u_pgo - (u_xpo * pbc - u_xmo * pbw)) + wm * (u_pgm - (u_xpm * pbc - u_xmm * pbw)) +
+                                   wn * (u_pgn - (u_xpn * pbc - u_xmn * pbw))) * u_scuxi;
+        const double x = (1. - wbaro) * ubml + wbaro * ubnl +
+                         (1. + wbaro) * dlt * ((utndcy + u_tot) * u_scuy * fmin2(pbw, pbc) - u_glue * ubml);
+        s_ub[nl][lj][li] = fmax2(-u_min, fmin2(u_max, x));
+      }
+    };
+    auto do_v = [&](int lu, int lo_i, int hi_i, int lo_j, int hi_j, int r_i0, int r_i1, int r_j0, int r_j1) {
+      if (wv && IN(lo_i, hi_i, lo_j, hi_j) && gi >= r_i0 && gi <= r_i1 && gj >= r_j0 && gj <= r_j1) {
+        const double vbml = s_vb[ml][lj][li], vbnl = s_vb[nl][lj][li];
+        if (mine) vs_acc = vs_acc - wbaro * vbnl + (1. + wbaro) * vbml;
+        const double uc = s_ub[lu][lj][li], ue = s_ub[lu][lj][li + 1], us = s_ub[lu][lj - 1][li], use = s_ub[lu][lj - 1][li + 1];
+        const double sy_c = s_sy[lj][li], sy_e = s_sy[lj][li + 1], sy_s = s_sy[lj - 1][li], sy_se = s_sy[lj - 1][li + 1];
+        const double pvo_c = s_pvo[lj][li], pvm_c = s_pvm[lj][li], pvn_c = s_pvn[lj][li];
+        const double pvo_e = s_pvo[lj][li + 1], pvm_e = s_pvm[lj][li + 1], pvn_e = s_pvn[lj][li + 1];
+        double q;
+        if (mom_scon)
+          q = -(uc * sy_c + ue * sy_e + us * sy_s + use * sy_se) *
+              (wo * (pvo_c + pvo_e) + wm * (pvm_c + pvm_e) + wn * (pvn_c + pvn_e)) * .125;
+        else
+          q = -.25 * ((uc * sy_c + us * sy_s) * (wo * pvo_c + wm * pvm_c + wn * pvn_c) +
+                      (ue * sy_e + use * sy_se) * (wo * pvo_e + wm * pvm_e + wn * pvn_e));
+        if (mine) vc_acc = vc_acc + q;
+        const double pbc = s_pb[nl][lj][li], pbs = s_pb[nl][lj - 1][li];
+        const double vtndcy = q + (wo * (v_pgo - (v_xpo * pbc - v_xmo * pbs)) + wm * (v_pgm - (v_xpm * pbc - v_xmm * pbs)) +
+                                   wn * (v_pgn - (v_xpn * pbc - v_xmn * pbs))) * v_scvyi;
+        const double x = (1. - wbaro) * vbml + wbaro * vbnl +
+                         (1. + wbaro) * dlt * ((vtndcy + v_tot) * v_scvx * fmin2(pbs, pbc) - v_glue * vbml);
+        s_vb[nl][lj][li] = fmax2(-v_min, fmin2(v_max, x));
+      }
+    };
+    if (odd) {
+      // u: needs pb[nl] at i-1,i ; vb[ml] at (i-1..i, j..j+1)                       (:420-457)
+      const int u_lo_i = vlo_i + 1, u_hi_i = p_hi_i, u_lo_j = vlo_j, u_hi_j = p_hi_j;
+      do_u(ml, u_lo_i, u_hi_i, u_lo_j, u_hi_j, 0, ii + 1, -1, jj + 2);
+      __syncthreads();
+      // v: needs ub[nl] at (i..i+1, j-1..j) ; pb[nl] at j-1,j                          (:520-557)
+      const int v_lo_i = u_lo_i, v_hi_i = u_hi_i - 1, v_lo_j = u_lo_j + 1, v_hi_j = u_hi_j;
+      do_v(nl, v_lo_i, v_hi_i, v_lo_j, v_hi_j, 0, ii, 0, jj + 2);
+      __syncthreads();
+      vlo_i = v_lo_i; vhi_i = v_hi_i; vlo_j = v_lo_j; vhi_j = v_hi_j;
+    } else {
+      // v first: needs ub[ml] at (i..i+1, j-1..j) ; pb[nl] at j-1,j                     (:646-682)
+      const int v_lo_i = vlo_i, v_hi_i = p_hi_i, v_lo_j = vlo_j + 1, v_hi_j = p_hi_j;
+      do_v(ml, v_lo_i, v_hi_i, v_lo_j, v_hi_j, 0, ii, 1, jj + 1);
+      __syncthreads();
+      // u: needs vb[nl] at (i-1..i, j..j+1) ; pb[nl] at i-1,i                           (:745-781)
+      const int u_lo_i = v_lo_i + 1, u_hi_i = v_hi_i, u_lo_j = v_lo_j, u_hi_j = v_hi_j - 1;
+      do_u(nl, u_lo_i, u_hi_i, u_lo_j, u_hi_j, 1, ii, 1, jj);
+      __syncthreads();
+      vlo_i = u_lo_i; vhi_i = u_hi_i; vlo_j = u_lo_j; vhi_j = u_hi_j;
+    }
+    const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
+  }
+  if (mine) {
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      o_pb[c + l * np] = s_pb[l][lj][li];
+      o_ub[c + l * np] = s_ub[l][lj][li];
+      o_vb[c + l * np] = s_vb[l][lj][li];
+    }
+    if (wu) { V.f[F_ubflxs_t][c] = us_acc; V.f[F_ubcors_t][c] = uc_acc; }
+    if (wv) { V.f[F_vbflxs_t][c] = vs_acc; V.f[F_vbcors_t][c] = vc_acc; }
+  }
+}
+
+// Halo update of the three subcycling fields of buffer set `set`, both levels, in ONE launch:
+// widths (3,3), a superset of the reference's (2,2),(2,2),(2,3) at :395-397.  Same gather rule as
+// k_xctilr_single (halo.hip): closed direction -> vland, periodic direction -> wrapped source.
+__global__ void k_bt_halo3(const DevView *Vp, int set, int mhl, int nhl) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj;
+  const int nns = 2 * nhl * ii, new_ = 2 * mhl * (jj + 2 * nhl);
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nns + new_) return;
+  int i, j;
+  if (t < nns) {
+    const int r = t / ii;
+    i = t % ii + 1;
+    j = r < nhl ? -r : jj + (r - nhl) + 1;
+  } else {
+    t -= nns;
+    const int cidx = t % (2 * mhl);
+    j = t / (2 * mhl) + 1 - nhl;
+    i = cidx < mhl ? -cidx : ii + (cidx - mhl) + 1;
+  }
+  const bool inew = i < 1 || i > ii, ins = j < 1 || j > jj;
+  const bool land = (inew && (V.nreg == 0 || V.nreg == 4)) || (ins && V.nreg <= 2);
+  int is = i, js = j;
+  if (i < 1) is = i + ii; else if (i > ii) is = i - ii;
+  if (j < 1) js = j + jj; else if (j > jj) js = j - jj;
+  const size_t dst = IDX(V, i, j), src = IDX(V, is, js);
+  double *f = blockIdx.y == 0 ? (set ? V.f[F_pb_t2] : V.f[F_pb_t])
+            : blockIdx.y == 1 ? (set ? V.f[F_ubflx_t2] : V.f[F_ubflx_t]) : (set ? V.f[F_vbflx_t2] : V.f[F_vbflx_t]);
+  for (int l = 0; l < 2; l++) {
+    double *pl = f + (size_t)l * V.nplane;
+    pl[dst] = land ? V.P.vland : pl[src];
+  }
+}
+
+int bt_pair_halo(blomgpu_ctx *c, int set) {
+  const DevView &h = c->h;
+  if (h.nreg == 2 || h.itdm != h.ii || h.jtdm != h.jj) return ctx_fail(c, "barotp: multi-tile / tripolar halo not built yet");
+  const int ntarget = 2 * 3 * h.ii + 2 * 3 * (h.jj + 6);
+  hipLaunchKernelGGL(k_bt_halo3, dim3((ntarget + 255) / 256, 3), dim3(256), 0, c->stream, c->d, set, 3, 3);
+  return 0;
+}
+
+int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
+                   int do_odd, int do_even, int src) {
+  const DevView &h = c->h;
+  PairArgs a;
+  a.m = m; a.n = n; a.ml = ml; a.nl = nl;
+  for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
+  a.do_odd = do_odd; a.do_even = do_even; a.src = src;
+  a.fold_halo = (h.itdm == h.ii && h.jtdm == h.jj && h.nreg != 2) ? 1 : 0;
+  dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
+  hipLaunchKernelGGL(k_bt_pair, grid, dim3(NTHR), 0, c->stream, c->d, a);
+  return 0;
+}
