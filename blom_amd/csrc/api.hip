@@ -286,12 +286,14 @@ int blomgpu_halo_cmnfld2(blomgpu_ctx *c) {            // phy/mod_cmnfld_routines
   const int kk = c->h.kk;
   return st_xctilr(c, c->h.f[F_temp], 1, 2 * kk, 3, 3, 1) || st_xctilr(c, c->h.f[F_saln], 1, 2 * kk, 3, 3, 1);
 }
-int blomgpu_halo_difest(blomgpu_ctx *c) {             // phy/mod_difest.F90:750-755
+int blomgpu_halo_difest(blomgpu_ctx *c, int nn) {     // phy/mod_difest.F90:750-772
   ctx_sync_view(c);
   const int kk = c->h.kk;
-  return st_xctilr(c, c->h.f[F_u], 1, 2 * kk, 2, 2, 13) || st_xctilr(c, c->h.f[F_v], 1, 2 * kk, 2, 2, 14) ||
-         st_xctilr(c, c->h.f[F_ubflxs_p], 1, 2, 2, 2, 13) || st_xctilr(c, c->h.f[F_vbflxs_p], 1, 2, 2, 2, 14) ||
-         st_xctilr(c, c->h.f[F_pbu], 1, 2, 2, 2, 3) || st_xctilr(c, c->h.f[F_pbv], 1, 2, 2, 2, 4);
+  if (st_xctilr(c, c->h.f[F_u], 1, 2 * kk, 2, 2, 13) || st_xctilr(c, c->h.f[F_v], 1, 2 * kk, 2, 2, 14) ||
+      st_xctilr(c, c->h.f[F_ubflxs_p], 1, 2, 2, 2, 13) || st_xctilr(c, c->h.f[F_vbflxs_p], 1, 2, 2, 2, 14) ||
+      st_xctilr(c, c->h.f[F_pbu], 1, 2, 2, 2, 3) || st_xctilr(c, c->h.f[F_pbv], 1, 2, 2, 2, 4))
+    return 1;
+  return launch_pscan(c, nn, -2, 3);                  // interface pressure out to ii+3 for remap (:761-772)
 }
 
 int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int nn, int k1m, int k1n) {
@@ -310,7 +312,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "barotp") return blomgpu_barotp(c, m, n, mm, nn, k1m, k1n);
   if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c);
-  if (s == "halo_difest") return blomgpu_halo_difest(c);
+  if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
 }

@@ -139,6 +139,18 @@ struct KTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// ---- tile decomposition / halo transport (mod_xc's xcspmd + xctilr, phy/mod_xc.F90:1332-3188) ------
+struct blomgpu_ctx;
+struct TileGroup;            // in-process transport: several tiles (contexts) on one device, one host thread each
+struct RcclComm;             // one process per GPU, neighbour ncclSend/ncclRecv over xGMI
+struct Tiling {
+  int npx = 1, npy = 1;      // uniform tile grid (mproc x nproc)
+  int px = 0, py = 0;        // this tile
+  TileGroup *group = nullptr;
+  RcclComm *rccl = nullptr;
+  bool multi() const { return npx * npy > 1 || rccl != nullptr; }
+};
+
 struct blomgpu_ctx {
   DevView h;                 // host copy (pointers are device pointers)
   DevView *d = nullptr;      // device copy handed to kernels
@@ -150,6 +162,7 @@ struct blomgpu_ctx {
   std::unordered_map<std::string, int> real_ids, int_ids;
   std::unordered_map<std::string, KTimer> timers;
   bool timing = false;
+  Tiling tiling;
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   std::string err;
 };
@@ -187,9 +200,13 @@ int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
+int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);
 int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc);
+// locate the field (and level offset) a device pointer belongs to; returns field id or -1
+int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);
+int rccl_xctilr(blomgpu_ctx *, double *base, int nlev, int mhl, int nhl);   // comm_rccl.hip
 
 // launch helpers: 1 thread per point of the padded plane, blockIdx.y = level
 static inline dim3 plane_grid(const DevView &h, int nlev = 1, int block = 256) {

@@ -1,0 +1,148 @@
+// xctilr over RCCL: one process per GPU, neighbour ncclSend/ncclRecv (xGMI is point-to-point, a
+// halo exchange touches only the two neighbouring GPUs).  Tiles are laid out along i (npx x 1),
+// which is how the channel case is weak-scaled in bench.py: phase 1 (N/S) is local -- the domain
+// is closed or periodic in j within the tile -- and phase 2 (E/W, rows 1-nhl..jj+nhl so that the
+// corners travel with it) is the exchange, exactly the reference's two phases
+// (phy/mod_xc.F90:3036-3106 N-S, :3131-3178 E-W).  Messages: mhl*(jj+2*nhl)*nlev reals per
+// neighbour, packed/unpacked by small kernels on the context's stream; RCCL runs on the same
+// stream, so ordering with the stage kernels needs no events.
+#include "blomgpu_internal.h"
+#include <rccl/rccl.h>
+#include <cstring>
+
+struct RcclComm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  double *sbuf[2] = {nullptr, nullptr}, *rbuf[2] = {nullptr, nullptr};   // [0] west, [1] east
+  size_t cap = 0;
+};
+
+struct HaloSrcNS {
+  const double *p[3];
+};
+
+// pack columns: side 0 -> my west-most mhl interior columns (go to the west neighbour's east halo),
+//               side 1 -> my east-most mhl interior columns
+__global__ void k_pack_ew(const DevView *Vp, const double *__restrict__ a, double *__restrict__ west,
+                          double *__restrict__ east, int nlev, int mhl, int nhl) {
+  const DevView &V = *Vp;
+  const int nrow = V.jj + 2 * nhl, per = mhl * nrow;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per) return;
+  const int q = t % mhl, r = t / mhl;          // q-th column of the strip, row index
+  const int j = r + 1 - nhl;
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    west[(size_t)k * per + t] = a[IDX(V, 1 + q, j) + o];                 // columns 1..mhl
+    east[(size_t)k * per + t] = a[IDX(V, V.ii - mhl + 1 + q, j) + o];    // columns ii-mhl+1..ii
+  }
+}
+
+// unpack: from_west holds the west neighbour's east-most columns -> my columns 1-mhl..0;
+//         from_east holds the east neighbour's west-most columns -> my columns ii+1..ii+mhl
+__global__ void k_unpack_ew(const DevView *Vp, double *__restrict__ a, const double *__restrict__ from_west,
+                            const double *__restrict__ from_east, int nlev, int mhl, int nhl, int has_w, int has_e) {
+  const DevView &V = *Vp;
+  const int nrow = V.jj + 2 * nhl, per = mhl * nrow;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per) return;
+  const int q = t % mhl, r = t / mhl;
+  const int j = r + 1 - nhl;
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[IDX(V, 1 - mhl + q, j) + o] = has_w ? from_west[(size_t)k * per + t] : V.P.vland;
+    a[IDX(V, V.ii + 1 + q, j) + o] = has_e ? from_east[(size_t)k * per + t] : V.P.vland;
+  }
+}
+
+// phase 1: N/S halo of columns 1..ii from the tile itself (periodic) or vland (closed)
+__global__ void k_halo_ns_local(const DevView *Vp, double *__restrict__ a, int nlev, int nhl, int periodic) {
+  const DevView &V = *Vp;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * nhl * V.ii) return;
+  const int r = t / V.ii, i = t % V.ii + 1;
+  const int j = r < nhl ? -r : V.jj + (r - nhl) + 1;
+  const int js = j < 1 ? j + V.jj : j - V.jj;
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[IDX(V, i, j) + o] = periodic ? a[IDX(V, i, js) + o] : V.P.vland;
+  }
+}
+
+int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
+  const DevView &h = c->h;
+  RcclComm *R = c->tiling.rccl;
+  const Tiling &T = c->tiling;
+  const int ly = nlev > 64 ? 64 : nlev;
+  if (nhl > 0) {
+    hipLaunchKernelGGL(k_halo_ns_local, dim3((2 * nhl * h.ii + 255) / 256, ly), dim3(256), 0, c->stream, c->d, a, nlev,
+                       nhl, h.nreg > 2 ? 1 : 0);
+  }
+  if (mhl > 0) {
+    const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev;
+    if (need > R->cap) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (int s = 0; s < 2; s++) {
+        if (R->sbuf[s]) (void)hipFree(R->sbuf[s]);
+        if (R->rbuf[s]) (void)hipFree(R->rbuf[s]);
+        HIPCHK(c, hipMalloc((void **)&R->sbuf[s], need * sizeof(double)));
+        HIPCHK(c, hipMalloc((void **)&R->rbuf[s], need * sizeof(double)));
+      }
+      R->cap = need;
+    }
+    const bool per_i = !(h.nreg == 0 || h.nreg == 4);
+    const int west = T.px > 0 ? R->rank - 1 : (per_i ? R->rank + T.npx - 1 : -1);
+    const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? R->rank - (T.npx - 1) : -1);
+    dim3 g((unsigned)((per + 255) / 256), ly);
+    hipLaunchKernelGGL(k_pack_ew, g, dim3(256), 0, c->stream, c->d, a, R->sbuf[0], R->sbuf[1], nlev, mhl, nhl);
+    // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
+    // point-to-point operations between the same pair match in issue order, so every rank sends
+    // west then east and receives east then west -- my east halo is the peer's FIRST send.
+    ncclGroupStart();
+    if (west >= 0) ncclSend(R->sbuf[0], need, ncclDouble, west, R->comm, c->stream);
+    if (east >= 0) ncclSend(R->sbuf[1], need, ncclDouble, east, R->comm, c->stream);
+    if (east >= 0) ncclRecv(R->rbuf[1], need, ncclDouble, east, R->comm, c->stream);
+    if (west >= 0) ncclRecv(R->rbuf[0], need, ncclDouble, west, R->comm, c->stream);
+    ncclResult_t rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL halo exchange: ") + ncclGetErrorString(rc));
+    hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, c->stream, c->d, a, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
+                       west >= 0 ? 1 : 0, east >= 0 ? 1 : 0);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+// 128-byte ncclUniqueId created on rank 0 and distributed by the launcher (torch.distributed in
+// bench.py); every rank then joins the communicator.  Tiles: npx = nranks along i, npy = 1.
+int blomgpu_rccl_unique_id(void *id128) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+  memcpy(id128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
+  return 0;
+}
+int blomgpu_rccl_init(blomgpu_ctx *c, const void *id128, int rank, int nranks) {
+  if (c->h.i0 != rank * c->h.ii || c->h.itdm != nranks * c->h.ii || c->h.jtdm != c->h.jj)
+    return ctx_fail(c, "rccl_init: tiles must be laid out along i with equal extents (i0 = rank*idm, itdm = nranks*idm)");
+  HIPCHK(c, hipSetDevice(c->device));
+  RcclComm *R = new RcclComm();
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
+  ncclResult_t rc = ncclCommInitRank(&R->comm, nranks, id, rank);
+  if (rc != ncclSuccess) { delete R; return ctx_fail(c, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc)); }
+  R->rank = rank; R->nranks = nranks;
+  c->tiling.rccl = R;
+  c->tiling.npx = nranks; c->tiling.npy = 1; c->tiling.px = rank; c->tiling.py = 0;
+  return 0;
+}
+int blomgpu_rccl_finalize(blomgpu_ctx *c) {
+  RcclComm *R = c->tiling.rccl;
+  if (!R) return 0;
+  (void)hipStreamSynchronize(c->stream);
+  ncclCommDestroy(R->comm);
+  for (int s = 0; s < 2; s++) { (void)hipFree(R->sbuf[s]); (void)hipFree(R->rbuf[s]); }
+  delete R;
+  c->tiling.rccl = nullptr;
+  return 0;
+}
+}

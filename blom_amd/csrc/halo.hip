@@ -9,8 +9,16 @@
 // HBM traffic: (2*nhl*ii + 2*mhl*(jj+2*nhl)) * nlev * 16 B; negligible next to the stages.
 #include "blomgpu_internal.h"
 
-__global__ void k_xctilr_single(const DevView *Vp, double *__restrict__ a, int nlev, int mhl,
-                                int nhl) {
+// One gather kernel serves a single tile and the in-process multi-tile transport: src[dy+1][dx+1]
+// is the same (field, level) plane stack in the tile that owns the halo strip in direction
+// (dx,dy) -- the tile itself where the direction is periodic and the grid has one tile there,
+// nullptr where the domain is closed (vland).  Halo width <= nbdy < tile extent, so a halo point
+// has exactly one owner.
+struct HaloSrc {
+  const double *p[3][3];
+};
+
+__global__ void k_xctilr_gather(const DevView *Vp, double *__restrict__ a, HaloSrc S, int nlev, int mhl, int nhl) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj;
   // enumerate halo targets: N/S strips (2*nhl rows x ii) then E/W strips (2*mhl cols x (jj+2nhl))
@@ -20,44 +28,111 @@ __global__ void k_xctilr_single(const DevView *Vp, double *__restrict__ a, int n
   if (t >= nns + new_) return;
   int i, j;
   if (t < nns) {
-    int r = t / ii;                 // 0..2*nhl-1
+    const int r = t / ii;                 // 0..2*nhl-1
     i = t % ii + 1;
     j = r < nhl ? -r : jj + (r - nhl) + 1;      // 0,-1,.. ; jj+1,..
   } else {
     t -= nns;
-    int cidx = t % (2 * mhl);
+    const int cidx = t % (2 * mhl);
     j = t / (2 * mhl) + 1 - nhl;
     i = cidx < mhl ? -cidx : ii + (cidx - mhl) + 1;
   }
-  const bool inew = i < 1 || i > ii, ins = j < 1 || j > jj;
-  const bool ew_closed = V.nreg == 0 || V.nreg == 4;
-  const bool ns_closed = V.nreg <= 2;
-  const bool land = (inew && ew_closed) || (ins && ns_closed);
-  int is = i, js = j;
-  if (i < 1) is = i + ii; else if (i > ii) is = i - ii;
-  if (j < 1) js = j + jj; else if (j > jj) js = j - jj;
-  const size_t dst = IDX(V, i, j), src = IDX(V, is, js);
+  const int dx = i < 1 ? -1 : (i > ii ? 1 : 0), dy = j < 1 ? -1 : (j > jj ? 1 : 0);
+  const double *sp = S.p[dy + 1][dx + 1];
+  const size_t dst = IDX(V, i, j), src = IDX(V, i - dx * ii, j - dy * jj);
   for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
-    double *pl = a + (size_t)k * V.nplane;
-    pl[dst] = land ? V.P.vland : pl[src];
+    const size_t o = (size_t)k * V.nplane;
+    a[dst + o] = sp ? sp[src + o] : V.P.vland;
   }
 }
+
+#include <pthread.h>
+struct TileGroup {
+  int npx, npy;
+  std::vector<blomgpu_ctx *> tiles;      // index py*npx + px
+  pthread_barrier_t bar;
+};
+
+int ctx_locate_ptr(const blomgpu_ctx *c, const double *p, size_t *offset) {
+  for (int f = 0; f < NF_REAL; f++) {
+    const double *b = c->h.f[f];
+    const size_t n = (size_t)c->nlev_real[f] * c->h.nplane;
+    if (p >= b && p < b + n) { *offset = (size_t)(p - b); return f; }
+  }
+  return -1;
+}
+
+// closed / periodic rule of the global domain in each direction (phy/mod_xc.F90:4378,4400)
+static inline bool ew_periodic(int nreg) { return !(nreg == 0 || nreg == 4); }
+static inline bool ns_periodic(int nreg) { return nreg > 2; }
 
 int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int itype) {
   (void)itype;   // only distinguishes grids/vectors across the arctic seam (phy/mod_xc.F90:4248-4250)
   const DevView &h = c->h;
   if (h.nreg == 2) return ctx_fail(c, "xctilr: tripolar seam (nreg=2) not built yet");
-  if (h.itdm != h.ii || h.jtdm != h.jj) return ctx_fail(c, "xctilr: multi-tile exchange not built yet");
   const int mhl = mh < 0 ? 0 : (mh > NBDY ? NBDY : mh);
   const int nhl = nh < 0 ? 0 : (nh > NBDY ? NBDY : nh);
   const int nlev = ld - l1 + 1;
   const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
   if (ntarget == 0 || nlev <= 0) return 0;
+  double *a = base + (size_t)(l1 - 1) * h.nplane;
+  const Tiling &T = c->tiling;
+  if (T.rccl) return rccl_xctilr(c, a, nlev, mhl, nhl);
+  if (!T.group && (h.itdm != h.ii || h.jtdm != h.jj))
+    return ctx_fail(c, "xctilr: this context is one tile of a larger domain but no halo transport is attached");
+  HaloSrc S;
+  TileGroup *G = T.group;
+  size_t off = 0;
+  int fid = -1;
+  if (G) {
+    fid = ctx_locate_ptr(c, a, &off);
+    if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
+  }
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++) {
+      int qx = T.px + dx, qy = T.py + dy;
+      bool land = false;
+      if (qx < 0 || qx >= T.npx) { if (ew_periodic(h.nreg)) qx = (qx + T.npx) % T.npx; else land = true; }
+      if (qy < 0 || qy >= T.npy) { if (ns_periodic(h.nreg)) qy = (qy + T.npy) % T.npy; else land = true; }
+      if (land) S.p[dy + 1][dx + 1] = nullptr;
+      else if (!G) S.p[dy + 1][dx + 1] = a;                             // single tile: wraps onto itself
+      else S.p[dy + 1][dx + 1] = G->tiles[(size_t)qy * G->npx + qx]->h.f[fid] + off;
+    }
+  if (G) {                     // every tile's interior must be complete before anyone gathers
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);
+  }
   dim3 grid((ntarget + 255) / 256, nlev > 64 ? 64 : nlev);
-  hipLaunchKernelGGL(k_xctilr_single, grid, dim3(256), 0, c->stream, c->d,
-                     base + (size_t)(l1 - 1) * h.nplane, nlev, mhl, nhl);
+  hipLaunchKernelGGL(k_xctilr_gather, grid, dim3(256), 0, c->stream, c->d, a, S, nlev, mhl, nhl);
   HIPCHK(c, hipGetLastError());
+  if (G) {                     // ... and nobody may go on modifying its interior before all have read
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);
+  }
   return 0;
+}
+
+extern "C" {
+// In-process tile group (tests of the decomposition on one device; one host thread per tile).
+int blomgpu_group_create(int npx, int npy, TileGroup **out) {
+  TileGroup *G = new TileGroup();
+  G->npx = npx; G->npy = npy;
+  G->tiles.assign((size_t)npx * npy, nullptr);
+  pthread_barrier_init(&G->bar, nullptr, npx * npy);
+  *out = G;
+  return 0;
+}
+int blomgpu_group_attach(TileGroup *G, blomgpu_ctx *c, int px, int py) {
+  if (px < 0 || px >= G->npx || py < 0 || py >= G->npy) return ctx_fail(c, "group_attach: tile index out of range");
+  G->tiles[(size_t)py * G->npx + px] = c;
+  c->tiling.npx = G->npx; c->tiling.npy = G->npy; c->tiling.px = px; c->tiling.py = py; c->tiling.group = G;
+  return 0;
+}
+int blomgpu_group_destroy(TileGroup *G) {
+  pthread_barrier_destroy(&G->bar);
+  delete G;
+  return 0;
+}
 }
 
 // ---- xccrc (phy/mod_xc.F90:4164-4205, CRC-32 of phy/mod_crc32.F90) -----------------------

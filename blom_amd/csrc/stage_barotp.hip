@@ -339,7 +339,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
         if (!both && !odd) { wo[1] = wo[0]; wm[1] = wm[0]; wn[1] = wn[0]; }
         // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
-        if (!(h.itdm == h.ii && h.jtdm == h.jj && h.nreg != 2))
+        if (c->tiling.multi())
           if (int rc = bt_pair_halo(c, set)) return rc;
         bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set);
         set ^= 1;

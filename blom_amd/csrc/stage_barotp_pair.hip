@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
   const int li = act ? tid % BI : 0, lj = act ? tid / BI : 0;
   // Fortran indices of this thread's point
   const int gi = blockIdx.x * TI + 1 + li - HB, gj = blockIdx.y * TJ + 1 + lj - HB;
-  const int ii = V.ii, jj = V.jj, ni = V.ni;
+  const int ii = V.ii, jj = V.jj;
   const bool inarr = act && gi >= 1 - NBDY && gi <= ii + NBDY && gj >= 1 - NBDY && gj <= jj + NBDY;
   const size_t np = V.nplane;
   const size_t c = inarr ? (size_t)IDX(V, gi, gj) : 0;
@@ -246,7 +246,14 @@ __global__ void k_bt_halo3(const DevView *Vp, int set, int mhl, int nhl) {
 
 int bt_pair_halo(blomgpu_ctx *c, int set) {
   const DevView &h = c->h;
-  if (h.nreg == 2 || h.itdm != h.ii || h.jtdm != h.jj) return ctx_fail(c, "barotp: multi-tile / tripolar halo not built yet");
+  if (c->tiling.multi()) {            // neighbour exchange through the tile transport
+    double *f[3] = {set ? h.f[F_pb_t2] : h.f[F_pb_t], set ? h.f[F_ubflx_t2] : h.f[F_ubflx_t],
+                    set ? h.f[F_vbflx_t2] : h.f[F_vbflx_t]};
+    static const int it[3] = {1, 13, 14};
+    for (int x = 0; x < 3; x++)
+      if (int rc = st_xctilr(c, f[x], 1, 2, 3, 3, it[x])) return rc;
+    return 0;
+  }
   const int ntarget = 2 * 3 * h.ii + 2 * 3 * (h.jj + 6);
   hipLaunchKernelGGL(k_bt_halo3, dim3((ntarget + 255) / 256, 3), dim3(256), 0, c->stream, c->d, set, 3, 3);
   return 0;
@@ -259,7 +266,7 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;
   for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
-  a.fold_halo = (h.itdm == h.ii && h.jtdm == h.jj && h.nreg != 2) ? 1 : 0;
+  a.fold_halo = c->tiling.multi() ? 0 : 1;
   dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
   hipLaunchKernelGGL(k_bt_pair, grid, dim3(NTHR), 0, c->stream, c->d, a);
   return 0;

@@ -87,7 +87,7 @@ contains
     call init_fluxes(m,n,mm,nn,k1m,k1n)
     call tmsmt1(nn)
     call halo_cmnfld2()
-    call halo_difest()
+    call halo_difest(nn)
     call advect(m,n,mm,nn,k1m,k1n)
     call pbcor1(m,n,mm,nn,k1m,k1n)
     call diffus(m,n,mm,nn,k1m,k1n)

@@ -269,8 +269,9 @@ contains
   subroutine halo_cmnfld2()                    ! phy/mod_cmnfld_routines.F90:1171-1172
     call stage6('halo_cmnfld2',0,0,0,0,0,0)
   end subroutine
-  subroutine halo_difest()                     ! phy/mod_difest.F90:750-755
-    call stage6('halo_difest',0,0,0,0,0,0)
+  subroutine halo_difest(nn)                   ! phy/mod_difest.F90:750-772
+    integer, intent(in) :: nn
+    call stage6('halo_difest',0,0,0,nn,0,0)
   end subroutine
   subroutine mxlayr_tail(nn,k1n)               ! phy/mod_mxlayr.F90:1266-1310
     integer, intent(in) :: nn,k1n

@@ -123,6 +123,14 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_crc(self.ctx, name.encode(), lev0, nlev, itype, C.byref(v)))
         return v.value
 
+    # -- tile decomposition ---------------------------------------------------------------
+    def rccl_init(self, id128, rank, nranks):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.lib.blomgpu_rccl_init(self.ctx, buf, rank, nranks))
+
+    def rccl_finalize(self):
+        self.lib.blomgpu_rccl_finalize(self.ctx)
+
     def timer_reset(self):
         self._chk(self.lib.blomgpu_timer_reset(self.ctx))
 
@@ -130,3 +138,28 @@ class BlomGpu:
         ms, n = C.c_double(0), C.c_int(0)
         self._chk(self.lib.blomgpu_timer_get(self.ctx, what.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def rccl_unique_id():
+    lib = load_library()
+    buf = (C.c_char * 128)()
+    if lib.blomgpu_rccl_unique_id(buf):
+        raise BlomGpuError("ncclGetUniqueId failed")
+    return bytes(buf)
+
+
+class TileGroup:
+    """Several tiles of one domain on ONE device in one process (one host thread per tile): the
+    in-process halo transport used to check decomposition independence (tests)."""
+
+    def __init__(self, npx, npy):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        self.lib.blomgpu_group_create(npx, npy, C.byref(self.h))
+        self.npx, self.npy = npx, npy
+
+    def attach(self, gpu, px, py):
+        gpu._chk(self.lib.blomgpu_group_attach(self.h, gpu.ctx, px, py))
+
+    def destroy(self):
+        self.lib.blomgpu_group_destroy(self.h)

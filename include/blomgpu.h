@@ -84,10 +84,10 @@ int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                    
 int  blomgpu_barotp (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_barotp.F90:148  */
 int  blomgpu_eddtra (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_eddtra.F90:1808 */
 /* Halo updates the reference performs inside stages that are outside the hot path
- * (phy/mod_cmnfld_routines.F90:1171-1172, phy/mod_difest.F90:750-755) and the
+ * (phy/mod_cmnfld_routines.F90:1171-1172, phy/mod_difest.F90:750-772: halos + interface pressure p out to ii+3) and the
  * dp-halo/dpu/dpv tail of mxlayr (phy/mod_mxlayr.F90:1266-1310). */
 int  blomgpu_halo_cmnfld2(blomgpu_ctx *);
-int  blomgpu_halo_difest (blomgpu_ctx *);
+int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
 
 /* Generic dispatcher over the entries above ("advect", "tmsmt1", ...). */
@@ -98,6 +98,19 @@ int  blomgpu_stage(blomgpu_ctx *, const char *stage, int m, int n, int mm, int n
  * phy/mod_blom_step.F90:96-253 (hot-path stages only), starting from step count
  * `nstep` (value before step_time).  Returns the new step count in *nstep. */
 int  blomgpu_step(blomgpu_ctx *, int *nstep, int nsteps);
+
+/* Tile decomposition (xcspmd/xctilr, phy/mod_xc.F90:1332-3188).  A context is one tile
+ * (dims.i0/j0/itdm/jtdm).  Two transports serve blomgpu_xctilr and every halo update inside the stages:
+ *  - RCCL: one process per GPU, tiles laid out along i; rank 0 creates the 128-byte id, the launcher
+ *    distributes it, every rank calls blomgpu_rccl_init;
+ *  - an in-process group (several tiles on one device, one host thread per tile) used by the parity tests. */
+int  blomgpu_rccl_unique_id(void *id128);
+int  blomgpu_rccl_init(blomgpu_ctx *, const void *id128, int rank, int nranks);
+int  blomgpu_rccl_finalize(blomgpu_ctx *);
+typedef struct TileGroup blomgpu_group;
+int  blomgpu_group_create(int npx, int npy, blomgpu_group **out);
+int  blomgpu_group_attach(blomgpu_group *, blomgpu_ctx *, int px, int py);
+int  blomgpu_group_destroy(blomgpu_group *);
 
 /* Synchronise the context's stream (all entries above are asynchronous on it). */
 int  blomgpu_sync(blomgpu_ctx *);

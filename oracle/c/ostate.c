@@ -94,13 +94,17 @@ int orc_stage(OState *S, const char *st, int m, int n, int mm, int nn, int k1m, 
   else if (!strcmp(st, "halo_cmnfld2")) {  /* phy/mod_cmnfld_routines.F90:1171-1172 */
     orc_xctilr(S, S->temp, 1, 2 * kk, 3, 3, 1);
     orc_xctilr(S, S->saln, 1, 2 * kk, 3, 3, 1);
-  } else if (!strcmp(st, "halo_difest")) { /* phy/mod_difest.F90:750-755 */
+  } else if (!strcmp(st, "halo_difest")) { /* phy/mod_difest.F90:750-772 */
     orc_xctilr(S, S->u, 1, 2 * kk, 2, 2, 13);
     orc_xctilr(S, S->v, 1, 2 * kk, 2, 2, 14);
     orc_xctilr(S, S->ubflxs_p, 1, 2, 2, 2, 13);
     orc_xctilr(S, S->vbflxs_p, 1, 2, 2, 2, 14);
     orc_xctilr(S, S->pbu, 1, 2, 2, 2, 3);
     orc_xctilr(S, S->pbv, 1, 2, 2, 2, 4);
+    for (int j = -2; j <= S->jj + 3; j++)   /* phy/mod_difest.F90:761-772 */
+      for (int k = 1; k <= kk; k++)
+        for (int i = -2; i <= S->ii + 3; i++)
+          if (A2(S, ip, i, j)) A3(S, p, i, j, k + 1) = A3(S, p, i, j, k) + A3(S, dp, i, j, k + nn);
   } else return 1;
   return 0;
 }

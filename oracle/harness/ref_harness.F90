@@ -395,17 +395,34 @@ contains
       case ('halo_cmnfld2')   ! phy/mod_cmnfld_routines.F90:1171-1172
         call xctilr(temp, 1, 2*kk, 3, 3, halo_ps)
         call xctilr(saln, 1, 2*kk, 3, 3, halo_ps)
-      case ('halo_difest')    ! phy/mod_difest.F90:750-755
+      case ('halo_difest')    ! phy/mod_difest.F90:750-772
         call xctilr(u, 1,2*kk, 2,2, halo_uv)
         call xctilr(v, 1,2*kk, 2,2, halo_vv)
         call xctilr(ubflxs_p, 1,2, 2,2, halo_uv)
         call xctilr(vbflxs_p, 1,2, 2,2, halo_vv)
         call xctilr(pbu, 1,2, 2,2, halo_us)
         call xctilr(pbv, 1,2, 2,2, halo_vs)
+        call difest_p(nn)
       case ('mxlayr_tail');  call mxlayr_tail(nn, k1n)
       case default; ierr = 1
     end select
   end subroutine ref_stage
+
+  subroutine difest_p(nn)
+    ! RESTATEMENT of "Update layer interface pressure", phy/mod_difest.F90:761-772: difest_isobml
+    ! itself is outside the hot path, but advect/remap consume p out to ii+3.
+    integer, intent(in) :: nn
+    integer :: i, j, k, l
+    do j = -2,jj+3
+      do k = 1,kk
+        do l = 1,isp(j)
+          do i = max(-2,ifp(j,l)),min(ii+3,ilp(j,l))
+            p(i,j,k+1) = p(i,j,k)+dp(i,j,k+nn)
+          end do
+        end do
+      end do
+    end do
+  end subroutine difest_p
 
   subroutine mxlayr_tail(nn, k1n)
     ! RESTATEMENT of phy/mod_mxlayr.F90:1266-1310 ("store 'new' layer thicknesses in

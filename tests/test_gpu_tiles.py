@@ -1,0 +1,98 @@
+"""Decomposition independence on the device: the same case integrated as 1 tile and as several tiles
+(in-process transport, one thread per tile, all on one GPU) must give bit-identical interiors --
+the property the reference guarantees by computing redundantly into exchanged halos.
+Also: the RCCL transport with a single rank (periodic direction wraps onto the rank itself) must
+reproduce the plain single-tile halo update."""
+import threading
+
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd.tiles import tile_extents, tile_window, scatter_state, gather_interior
+from parity import STATE_FIELDS, GRID_FIELDS, INT_FIELDS, load_golden_init, put_fields
+
+pytestmark = pytest.mark.gpu
+ALL = STATE_FIELDS + GRID_FIELDS + INT_FIELDS
+CHECK = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "ubflxs_p", "pb_p", "trc", "uflx", "vflx",
+         "pgfx", "pgfy", "dpu", "dpv", "pbu", "pbv", "ubflx", "vbflx", "pb_mn", "ubcors_p"]
+
+
+def _single(cfg, nsteps):
+    from blom_amd.gpu import BlomGpu
+    case = make_case(cfg)
+    masks, fields = load_golden_init(cfg)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, case.nreg, masks)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            gpu.set(nm, v)
+    put_fields(gpu, fields)
+    gpu.set("delt1", case.params["baclin"])
+    return case, masks, fields, gpu
+
+
+@pytest.mark.parametrize("cfg,npx,npy", [("chan_s", 2, 1), ("chan_s", 1, 2), ("chan_s", 2, 2), ("box_s", 2, 2),
+                                         ("box_s", 3, 1)])
+def test_tiles_match_single_tile(cfg, npx, npy):
+    from blom_amd.gpu import BlomGpu, TileGroup
+    nsteps = 4
+    case, masks, fields, ref = _single(cfg, nsteps)
+    ii, jj = tile_extents(case, npx, npy)
+    grp = TileGroup(npx, npy)
+    tiles = {}
+    for py in range(npy):
+        for px in range(npx):
+            tm = {k: tile_window(masks[k], case, npx, npy, px, py) for k in masks}
+            t = BlomGpu(ii, jj, case.kdm, case.ntr, case.nreg, tm, itdm=case.idm, jtdm=case.jdm, i0=px * ii, j0=py * jj)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            t.set("delt1", case.params["baclin"])
+            grp.attach(t, px, py)
+            tiles[(px, py)] = t
+    scatter_state(ref, tiles, case, npx, npy, [f for f in ALL if f in fields])
+    assert ref.step(0, nsteps) == nsteps
+    errs = []
+
+    def run(t):
+        try:
+            t.step(0, nsteps)
+            t.sync()
+        except Exception as e:          # a failing tile would leave the others at a barrier
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(t,)) for t in tiles.values()]
+    [x.start() for x in th]
+    [x.join(timeout=300) for x in th]
+    assert not errs, errs
+    bad = []
+    for nm in CHECK:
+        a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
+        b = gather_interior(tiles, case, npx, npy, nm)
+        if not np.array_equal(a, b):
+            bad.append((nm, int((a != b).sum()), float(np.nanmax(np.abs(a - b)))))
+    for t in tiles.values():
+        t.close()
+    ref.close()
+    grp.destroy()
+    assert not bad, bad
+
+
+def test_rccl_transport_single_rank_equals_single_tile():
+    from blom_amd.gpu import BlomGpu, rccl_unique_id
+    nsteps = 3
+    case, masks, fields, ref = _single("chan_s", nsteps)
+    t = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, case.nreg, masks)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            t.set(nm, v)
+    put_fields(t, fields)
+    t.set("delt1", case.params["baclin"])
+    t.rccl_init(rccl_unique_id(), 0, 1)
+    ref.step(0, nsteps)
+    t.step(0, nsteps)
+    t.sync()
+    bad = [nm for nm in CHECK if not np.array_equal(ref.get(nm), t.get(nm))]
+    t.rccl_finalize()
+    t.close()
+    ref.close()
+    assert not bad, bad
