@@ -6,8 +6,9 @@
 A "step" is one baroclinic time step of the hot path (stage sequence of
 phy/mod_blom_step.F90:96-253 restricted to the dynamical core: init_fluxes, tmsmt1, [halo updates
 of cmnfld2/difest], advect(remap), pbcor1, diffus, pgforc, momtum, diapfl, [mxlayr dp-halo tail],
-barotp, pbcor2, tmsmt2) on the `channel` configuration of BASELINE.json (208x512x53, 1 tile),
-with the state resident in HBM.  metric = simulated model days per wall second
+barotp, pbcor2, tmsmt2) on the `channel` configuration of BASELINE.json (208x512x53, 1 tile per
+GPU; for N>1 the channel is N times as long and the tiles exchange halos over RCCL), with the
+state resident in HBM.  metric = simulated model days per wall second
 = steps/s * baclin / 86400.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, algorithmic bytes /
@@ -107,21 +108,38 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-self", action="store_true",
+                    help="N=1 only: route the halo update through the RCCL transport (rank sends to itself) "
+                         "to measure the exchange overhead of the N>1 path on one GPU")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from blom_amd import launch
+    env = launch.rank_env()
+    rank, world, local = env.rank, env.world, env.local
     import torch
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from blom_amd.gpu import BlomGpu
+    from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd import hostinit
     case, nreg, masks = build_case(args.config)
-    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
+    if world > 1:
+        # Weak scaling: the channel is made `world` times as long in i (its bathymetry repeated
+        # with the tile's period) and cut into `world` tiles along i, one per GPU.  Every tile
+        # then starts from the single-tile state -- its periodic wrap IS its neighbours' data --
+        # and the halos travel between GPUs over RCCL (blom_amd/csrc/comm_rccl.hip).
+        if nreg in (0, 4):
+            raise SystemExit("bench.py --gpus N>1 needs a configuration that is periodic in i")
+        lay = launch.tile_layout(case.idm, rank, world)
+        gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local,
+                      itdm=lay["itdm"], jtdm=case.jdm, i0=lay["i0"], j0=0)
+        gpu.rccl_init(launch.share_unique_id(rccl_unique_id, env), rank, world)
+    else:
+        gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
+        if args.rccl_self:
+            gpu.rccl_init(rccl_unique_id(), 0, 1)
     hostinit.init_state(gpu, case)
     baclin = case.params["baclin"]
 
@@ -143,7 +161,7 @@ def main():
     # ---- timed region --------------------------------------------------------------------------
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local])
     barrier()
     gpu.sync()
     torch.cuda.synchronize()
@@ -153,10 +171,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = launch.max_over_ranks(dt, env, device="cuda")
 
     # ---- dominant kernel class, timed with HIP events on the library's stream over K more steps
     gpu.set("timing", 1)
@@ -171,9 +186,13 @@ def main():
     gpu.set("timing", 0)
     import numpy as np
     finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
+    # every tile integrates the same periodic pattern, so all ranks must hold the same bits
+    crcs = launch.all_gather_ints(gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3), env)
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps * baclin / 86400.0 / dt       # every rank integrates its own replica
+    # units all ranks processed / time: model days of one 208x512x53-sized tile, times the number
+    # of tiles (the N-GPU job integrates an N-times longer channel at the same days/s)
+    value = world * args.steps * baclin / 86400.0 / dt
     F = case.idm * case.jdm * case.kdm * 8.0
     cb = class_bytes_F(case.ntr)
     hbm_classes = {k: v for k, v in live.items() if k in cb}
@@ -183,11 +202,14 @@ def main():
         "metric": "simulated-days/sec", "value": value, "unit": "simulated-days/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config} {case.idm}x{case.jdm}x{case.kdm}, 1 tile per GPU, "
+        "config": {"workload": f"{args.config} {case.idm * world}x{case.jdm}x{case.kdm} as {world} tile(s) of "
+                               f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, "
                                f"isopyc_bulkml/remap/geopotential/uc/enscon, ntr={case.ntr}, "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
-                               "dyncore stage sequence without eddtra (replicas only for N>1)",
-                   "state_finite": finite},
+                               "dyncore stage sequence without eddtra; N>1: halos over RCCL send/recv, "
+                               "value counts tile-days/s" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
+                   "state_finite": finite, "tiles_bit_identical": len(set(crcs)) == 1,
+                   "state_crc": f"{crcs[0]:08x}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -204,6 +226,8 @@ def main():
             except Exception as e:                       # the bench line must still be produced
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
+    if world > 1 or args.rccl_self:
+        gpu.rccl_finalize()
     gpu.close()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -264,6 +264,8 @@ int blomgpu_xctilr(blomgpu_ctx *c, const char *name, int lev0, int l1, int ld, i
 int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype, unsigned *crc) {
   auto it = c->real_ids.find(name);
   if (it == c->real_ids.end()) return ctx_fail(c, std::string("crc: unknown field ") + name);
+  if (lev0 < 1 || nlev < 1 || lev0 - 1 + nlev > c->nlev_real[it->second])
+    return ctx_fail(c, std::string("crc: levels out of range for field ") + name + " (lev0 is 1-based)");
   ctx_sync_view(c);
   return st_crc(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, itype, crc);
 }

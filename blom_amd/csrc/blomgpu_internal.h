@@ -207,6 +207,7 @@ int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc
 // locate the field (and level offset) a device pointer belongs to; returns field id or -1
 int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);
 int rccl_xctilr(blomgpu_ctx *, double *base, int nlev, int mhl, int nhl);   // comm_rccl.hip
+int rccl_xctilr_multi(blomgpu_ctx *, double *const *fields, int nf, int nlev, int mhl, int nhl);  // one message per neighbour for up to 4 plane stacks
 
 // launch helpers: 1 thread per point of the padded plane, blockIdx.y = level
 static inline dim3 plane_grid(const DevView &h, int nlev = 1, int block = 256) {

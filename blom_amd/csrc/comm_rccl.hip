@@ -17,30 +17,34 @@ struct RcclComm {
   size_t cap = 0;
 };
 
-struct HaloSrcNS {
-  const double *p[3];
+// up to MAXF plane stacks (same nlev, same halo widths) travel in one message per neighbour
+#define MAXF 4
+struct FieldSet {
+  double *p[MAXF];
 };
 
-// pack columns: side 0 -> my west-most mhl interior columns (go to the west neighbour's east halo),
-//               side 1 -> my east-most mhl interior columns
-__global__ void k_pack_ew(const DevView *Vp, const double *__restrict__ a, double *__restrict__ west,
-                          double *__restrict__ east, int nlev, int mhl, int nhl) {
+// pack columns: west buffer <- my west-most mhl interior columns (they become the west neighbour's
+// east halo), east buffer <- my east-most mhl interior columns.  Buffer layout [field][level][row][q].
+__global__ void k_pack_ew(const DevView *Vp, FieldSet F, double *__restrict__ west, double *__restrict__ east,
+                          int nlev, int mhl, int nhl) {
   const DevView &V = *Vp;
   const int nrow = V.jj + 2 * nhl, per = mhl * nrow;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= per) return;
   const int q = t % mhl, r = t / mhl;          // q-th column of the strip, row index
   const int j = r + 1 - nhl;
+  const double *a = F.p[blockIdx.z];
+  const size_t fo = (size_t)blockIdx.z * nlev * per;
   for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
     const size_t o = (size_t)k * V.nplane;
-    west[(size_t)k * per + t] = a[IDX(V, 1 + q, j) + o];                 // columns 1..mhl
-    east[(size_t)k * per + t] = a[IDX(V, V.ii - mhl + 1 + q, j) + o];    // columns ii-mhl+1..ii
+    west[fo + (size_t)k * per + t] = a[IDX(V, 1 + q, j) + o];                 // columns 1..mhl
+    east[fo + (size_t)k * per + t] = a[IDX(V, V.ii - mhl + 1 + q, j) + o];    // columns ii-mhl+1..ii
   }
 }
 
 // unpack: from_west holds the west neighbour's east-most columns -> my columns 1-mhl..0;
 //         from_east holds the east neighbour's west-most columns -> my columns ii+1..ii+mhl
-__global__ void k_unpack_ew(const DevView *Vp, double *__restrict__ a, const double *__restrict__ from_west,
+__global__ void k_unpack_ew(const DevView *Vp, FieldSet F, const double *__restrict__ from_west,
                             const double *__restrict__ from_east, int nlev, int mhl, int nhl, int has_w, int has_e) {
   const DevView &V = *Vp;
   const int nrow = V.jj + 2 * nhl, per = mhl * nrow;
@@ -48,38 +52,44 @@ __global__ void k_unpack_ew(const DevView *Vp, double *__restrict__ a, const dou
   if (t >= per) return;
   const int q = t % mhl, r = t / mhl;
   const int j = r + 1 - nhl;
+  double *a = F.p[blockIdx.z];
+  const size_t fo = (size_t)blockIdx.z * nlev * per;
   for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
     const size_t o = (size_t)k * V.nplane;
-    a[IDX(V, 1 - mhl + q, j) + o] = has_w ? from_west[(size_t)k * per + t] : V.P.vland;
-    a[IDX(V, V.ii + 1 + q, j) + o] = has_e ? from_east[(size_t)k * per + t] : V.P.vland;
+    a[IDX(V, 1 - mhl + q, j) + o] = has_w ? from_west[fo + (size_t)k * per + t] : V.P.vland;
+    a[IDX(V, V.ii + 1 + q, j) + o] = has_e ? from_east[fo + (size_t)k * per + t] : V.P.vland;
   }
 }
 
 // phase 1: N/S halo of columns 1..ii from the tile itself (periodic) or vland (closed)
-__global__ void k_halo_ns_local(const DevView *Vp, double *__restrict__ a, int nlev, int nhl, int periodic) {
+__global__ void k_halo_ns_local(const DevView *Vp, FieldSet F, int nlev, int nhl, int periodic) {
   const DevView &V = *Vp;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * nhl * V.ii) return;
   const int r = t / V.ii, i = t % V.ii + 1;
   const int j = r < nhl ? -r : V.jj + (r - nhl) + 1;
   const int js = j < 1 ? j + V.jj : j - V.jj;
+  double *a = F.p[blockIdx.z];
   for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
     const size_t o = (size_t)k * V.nplane;
     a[IDX(V, i, j) + o] = periodic ? a[IDX(V, i, js) + o] : V.P.vland;
   }
 }
 
-int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
+int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl) {
   const DevView &h = c->h;
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
+  if (nf < 1 || nf > MAXF) return ctx_fail(c, "rccl_xctilr_multi: 1..4 fields per exchange");
+  FieldSet F;
+  for (int x = 0; x < MAXF; x++) F.p[x] = fields[x < nf ? x : 0];
   const int ly = nlev > 64 ? 64 : nlev;
   if (nhl > 0) {
-    hipLaunchKernelGGL(k_halo_ns_local, dim3((2 * nhl * h.ii + 255) / 256, ly), dim3(256), 0, c->stream, c->d, a, nlev,
-                       nhl, h.nreg > 2 ? 1 : 0);
+    hipLaunchKernelGGL(k_halo_ns_local, dim3((2 * nhl * h.ii + 255) / 256, ly, nf), dim3(256), 0, c->stream, c->d, F,
+                       nlev, nhl, h.nreg > 2 ? 1 : 0);
   }
   if (mhl > 0) {
-    const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev;
+    const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev * nf;
     if (need > R->cap) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       for (int s = 0; s < 2; s++) {
@@ -93,8 +103,8 @@ int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
     const bool per_i = !(h.nreg == 0 || h.nreg == 4);
     const int west = T.px > 0 ? R->rank - 1 : (per_i ? R->rank + T.npx - 1 : -1);
     const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? R->rank - (T.npx - 1) : -1);
-    dim3 g((unsigned)((per + 255) / 256), ly);
-    hipLaunchKernelGGL(k_pack_ew, g, dim3(256), 0, c->stream, c->d, a, R->sbuf[0], R->sbuf[1], nlev, mhl, nhl);
+    dim3 g((unsigned)((per + 255) / 256), ly, nf);
+    hipLaunchKernelGGL(k_pack_ew, g, dim3(256), 0, c->stream, c->d, F, R->sbuf[0], R->sbuf[1], nlev, mhl, nhl);
     // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
     // point-to-point operations between the same pair match in issue order, so every rank sends
     // west then east and receives east then west -- my east halo is the peer's FIRST send.
@@ -105,11 +115,15 @@ int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
     if (west >= 0) ncclRecv(R->rbuf[0], need, ncclDouble, west, R->comm, c->stream);
     ncclResult_t rc = ncclGroupEnd();
     if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL halo exchange: ") + ncclGetErrorString(rc));
-    hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, c->stream, c->d, a, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
+    hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, c->stream, c->d, F, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
                        west >= 0 ? 1 : 0, east >= 0 ? 1 : 0);
   }
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
+  return rccl_xctilr_multi(c, &a, 1, nlev, mhl, nhl);
 }
 
 extern "C" {

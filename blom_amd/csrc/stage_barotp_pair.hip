@@ -250,6 +250,7 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
     double *f[3] = {set ? h.f[F_pb_t2] : h.f[F_pb_t], set ? h.f[F_ubflx_t2] : h.f[F_ubflx_t],
                     set ? h.f[F_vbflx_t2] : h.f[F_vbflx_t]};
     static const int it[3] = {1, 13, 14};
+    if (c->tiling.rccl) return rccl_xctilr_multi(c, f, 3, 2, 3, 3);       // one message per neighbour
     for (int x = 0; x < 3; x++)
       if (int rc = st_xctilr(c, f[x], 1, 2, 3, 3, it[x])) return rc;
     return 0;

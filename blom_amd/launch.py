@@ -1,0 +1,99 @@
+"""Host-side plumbing of the one-process-per-GPU run: rank environment, tile layout along i,
+distribution of the RCCL unique id, reductions of timings.  torch.distributed is used for
+rendezvous and for scalar reductions only; the halo data path is RCCL point-to-point inside the
+library (blom_amd/csrc/comm_rccl.hip).
+
+Decomposition: the reference splits the global (itdm, jtdm) grid into tiles listed in
+patch.input (bld/blom_dimensions:104-148); here tiles are equal and laid out along i, tile `rank`
+owning global columns rank*idm+1 .. (rank+1)*idm.
+"""
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class RankEnv:
+    rank: int
+    world: int
+    local: int
+
+
+def rank_env(environ=None):
+    e = os.environ if environ is None else environ
+    return RankEnv(int(e.get("RANK", "0")), int(e.get("WORLD_SIZE", "1")), int(e.get("LOCAL_RANK", "0")))
+
+
+def tile_layout(idm, rank, world):
+    """(itdm, i0, px, npx) of the tile `rank` owns when `world` tiles of width idm lie along i."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return dict(itdm=idm * world, i0=rank * idm, px=rank, npx=world)
+
+
+def neighbours(rank, world, periodic):
+    """(west, east) ranks of a tile along i, -1 where the domain is closed
+    (closed/periodic rule of phy/mod_xc.F90:4400-4416)."""
+    west = rank - 1 if rank > 0 else (world - 1 if periodic else -1)
+    east = rank + 1 if rank < world - 1 else (0 if periodic else -1)
+    return west, east
+
+
+def share_unique_id(make_id, env):
+    """Rank 0 calls make_id() -> 128 bytes (ncclGetUniqueId); every rank returns the same bytes."""
+    if env.world == 1:
+        return make_id()
+    import torch.distributed as dist
+    box = [make_id() if env.rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def max_over_ranks(x, env, device="cpu"):
+    if env.world == 1:
+        return float(x)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_gather_ints(v, env):
+    if env.world == 1:
+        return [int(v)]
+    import torch.distributed as dist
+    out = [None] * env.world
+    dist.all_gather_object(out, int(v))
+    return out
+
+
+def exchange_ew_host(a, idm, jdm, mhl, nhl, env, periodic):
+    """Host (numpy + torch.distributed p2p) statement of the E/W phase of comm_rccl.hip, used by
+    the gloo tests to check the message-order rule on real ranks: every rank sends west then
+    east and receives east then west, so that with west == east (2 ranks, periodic) the peer's
+    FIRST message lands in my east halo.  `a` is (nlev, jdm+8, idm+8), updated in place."""
+    import torch
+    import torch.distributed as dist
+    west, east = neighbours(env.rank, env.world, periodic)
+    rows = slice(4 - nhl, 4 + jdm + nhl)
+    to_w = torch.from_numpy(np.ascontiguousarray(a[:, rows, 4:4 + mhl]))
+    to_e = torch.from_numpy(np.ascontiguousarray(a[:, rows, 4 + idm - mhl:4 + idm]))
+    from_e, from_w = torch.empty_like(to_w), torch.empty_like(to_e)
+    ops = []
+    if west >= 0:
+        ops.append(dist.P2POp(dist.isend, to_w, west))
+    if east >= 0:
+        ops.append(dist.P2POp(dist.isend, to_e, east))
+    if east >= 0:
+        ops.append(dist.P2POp(dist.irecv, from_e, east))
+    if west >= 0:
+        ops.append(dist.P2POp(dist.irecv, from_w, west))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    vland = 0.0
+    a[:, rows, 4 - mhl:4] = from_w.numpy() if west >= 0 else vland
+    a[:, rows, 4 + idm:4 + idm + mhl] = from_e.numpy() if east >= 0 else vland
+    return a

@@ -1,0 +1,94 @@
+"""N > 1 host path on CPU: two real ranks over gloo (127.0.0.1) exercise the launcher helpers of
+blom_amd/launch.py -- unique-id distribution, max-over-ranks timing, tile layout -- and the
+message-order rule of the E/W halo exchange (blom_amd/csrc/comm_rccl.hip) against the global
+xctilr of phy/mod_xc.F90:4374-4419 for periodic (west == east == the other rank) and closed
+domains."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from blom_amd import launch
+from blom_amd.hostinit import xctilr_np
+
+IDM, JDM, NLEV = 12, 10, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = launch.rank_env()
+        assert (env.rank, env.world, env.local) == (rank, world, rank)
+        res = {}
+        uid = launch.share_unique_id(lambda: bytes((7 * i + 3) % 256 for i in range(128)) if rank == 0 else b"", env)
+        res["uid"] = uid
+        res["tmax"] = launch.max_over_ranks(1.5 + rank, env)
+        res["crcs"] = launch.all_gather_ints(1000 + rank, env)
+        lay = launch.tile_layout(IDM, rank, world)
+        res["layout"] = lay
+        for nreg, mh, nh in ((1, 3, 3), (1, 1, 2), (0, 2, 2), (3, 4, 1), (4, 2, 3)):
+            periodic = nreg not in (0, 4)
+            rng = np.random.default_rng(5)                      # same global array on every rank
+            G = rng.standard_normal((NLEV, JDM + 8, IDM * world + 8))
+            want = G.copy()
+            xctilr_np(want, 1, NLEV, mh, nh, nreg, IDM * world, JDM)
+            i0 = lay["i0"]
+            a = G[:, :, i0:i0 + IDM + 8].copy()
+            a[:, :, :4] = np.nan                                # halos unknown before the update
+            a[:, :, 4 + IDM:] = np.nan
+            xctilr_np(a, 1, NLEV, 0, nh, nreg, IDM, JDM)        # phase 1: N/S is tile-local
+            launch.exchange_ew_host(a, IDM, JDM, mh, nh, env, periodic)
+            w = want[:, :, i0:i0 + IDM + 8]
+            sel = (slice(None), slice(4 - nh, 4 + JDM + nh), slice(4 - mh, 4 + IDM + mh))
+            res[f"halo{nreg}_{mh}_{nh}"] = bool(np.array_equal(a[sel], w[sel]))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    uid0 = got[0]["uid"]
+    assert len(uid0) == 128
+    for r in range(world):
+        g = got[r]
+        assert g["uid"] == uid0
+        assert g["tmax"] == 1.5 + world - 1
+        assert g["crcs"] == [1000 + i for i in range(world)]
+        assert g["layout"] == dict(itdm=IDM * world, i0=r * IDM, px=r, npx=world)
+        for k, v in g.items():
+            if k.startswith("halo"):
+                assert v, (r, k)
+
+
+def test_single_rank_helpers_need_no_process_group():
+    env = launch.RankEnv(0, 1, 0)
+    assert launch.share_unique_id(lambda: b"x" * 128, env) == b"x" * 128
+    assert launch.max_over_ranks(2.5, env) == 2.5
+    assert launch.all_gather_ints(7, env) == [7]
+    assert launch.neighbours(0, 1, True) == (0, 0) and launch.neighbours(0, 1, False) == (-1, -1)
+    assert launch.neighbours(0, 2, True) == (1, 1) and launch.neighbours(1, 2, False) == (0, -1)
+    with pytest.raises(ValueError):
+        launch.tile_layout(8, 2, 2)
