@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+/* test-side instrumentation: trip-count histograms of the two data-dependent loops */
+long orc_diapfl_stat_lim[101], orc_diapfl_stat_niter[101], orc_diapfl_stat_span;
+
 #define KMAXD 130
 
 static void mix_momentum(OState *S, int nn, int k1n, int isv);
@@ -118,9 +121,10 @@ void orc_diapfl(OState *S, int n, int nn, int k1n) {
           }
           fmax[kfpl - 1] = 0.; /* :292-330 */
           fmax[kmax] = 0.;
-          int done = 0, niter = 0, kfmaxu = 0;
+          int done = 0, niter = 0, kfmaxu = 0, nlim = 0;
           while (!done) {
             done = 1;
+            nlim++;
             for (k = kmax - 1; k >= kfpl; k--) {
               double q = ((fmax[k + 1] + fcu[k + 1]) * dsgui[k + 1] + pres[kmax + 1] - pres[k + 1]) * dsgl[k];
               fcl[k] = fmax2(-q, fcl[k]);
@@ -134,6 +138,7 @@ void orc_diapfl(OState *S, int n, int nn, int k1n) {
             }
             if (niter == 100) { fprintf(stderr, "oracle diapfl: no convergence in flux limit!\n"); abort(); }
           }
+          orc_diapfl_stat_lim[nlim < 100 ? nlim : 100]++;
           k = kfpl - 1; /* :334-353 */
           f0[k] = 0.; f[k] = 0.; gtd[k] = 0.;
           double dflim = 0.;
@@ -219,7 +224,7 @@ void orc_diapfl(OState *S, int n, int nn, int k1n) {
               }
             }
             niter = niter + 1;
-            if (maxdf <= dflim) break;
+            if (maxdf <= dflim) { orc_diapfl_stat_niter[niter]++; orc_diapfl_stat_span += kmax - kfpl; break; }
             if (niter == 100) { fprintf(stderr, "oracle diapfl: no convergence in implicit diffusion!\n"); abort(); }
           }
           for (k = kfpl; k <= kmax - 1; k++) { /* :536-540 */
