@@ -111,7 +111,7 @@ def default_params(baclin, batrop):
         mdc2hi=5000.0, mdc2lo=300.0,
         vsc2hi=0.5, vsc2lo=0.5, vsc4hi=0.06, vsc4lo=0.06,
         cbar=0.05, cb=0.002, cwbdts=5.0e-5, cwbdls=25.0,
-        mommth="enscon", pgfmth="geopotential", bmcmth="uc", advmth="remap",
+        mommth="enscon", pgfmth="geopotential", bmcmth="uc", advmth="remap", eitmth="gm",
         vcoord_tag=1,        # vcoord_isopyc_bulkml, phy/mod_vcoord.F90
         ltedtp_opt=1,        # ltedtp_layer, phy/mod_diffusion.F90
         bdmtyp=2, bdmc1=5.0e-8, bdmc2=1.0e-5, iwdflg=1, iwdfac=0.06, nubmin=1.0e-6,
@@ -119,6 +119,7 @@ def default_params(baclin, batrop):
         # frozen diffusivities (difest needs CVMix, absent: SURVEY.md 8c)
         difiso0=300.0, difint0=300.0, difdia0=1.0e-5, difwgt0=1.0,
         taux0=0.1,           # zonal wind stress amplitude [N m-2]
+        nslp0=0.0,           # amplitude of the frozen isopycnal slopes nslpx/nslpy [] (cmnfld2 is out of scope)
     )
 
 
@@ -166,12 +167,13 @@ def _depth_for(name, idm, jdm, dx):
     raise KeyError(name)
 
 
-def make_case(name, ntr=1):
+def make_case(name, ntr=1, **overrides):
     idm, jdm, kdm, nreg, dx, baclin, batrop = _DIMS[name]
     ni, nj = idm + 2 * NBDY, jdm + 2 * NBDY
     p = default_params(baclin, batrop)
     if name == "fuk95":
         p.update(expcnf="fuk95", taux0=0.0, cwbdts=0.0)
+    p.update(overrides)
 
     depth = np.zeros((nj, ni))
     depth[NBDY:NBDY + jdm, NBDY:NBDY + idm] = _depth_for(name, idm, jdm, dx)

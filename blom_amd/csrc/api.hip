@@ -82,7 +82,7 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
   Params &P = h.P;
   // defaults of the reference's module variables (phy/mod_tmsmt.F90:46-51)
   P.wuv1 = .75; P.wuv2 = .125; P.wts1 = .875; P.wts2 = .0625; P.wbaro = .125;
-  P.vland = 0.0; P.vcoord_tag = 1; P.ltedtp_opt = 1;
+  P.vland = 0.0; P.vcoord_tag = 1; P.ltedtp_opt = 1; P.eitmth = 2;
   P.pref = 2000.e4;
   set_eos(P);
   const int K = d->kdm, NT = d->ntr > 0 ? d->ntr : 1;
@@ -196,6 +196,12 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     else return ctx_fail(c, " advmth = " + v + " is unsupported!");   // phy/mod_advect.F90:166-171
     return 0;
   }
+  if (s == "eitmth") {
+    if (v == "intdif") P.eitmth = 1; else if (v == "gm") P.eitmth = 2;
+    else return ctx_fail(c, " eitmth = " + v + " is unsupported!");   // phy/mod_diffusion.F90:316-327
+    c->dirty = true;
+    return 0;
+  }
   if (s == "bmcmth") {
     if (v == "uc") P.bmcmth = 0; else if (v == "dluc") P.bmcmth = 1;
     else return ctx_fail(c, " bmcmth = " + v + " is unsupported!");   // phy/mod_pbcor.F90:112-117
@@ -284,10 +290,11 @@ int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(
 int blomgpu_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) { ctx_sync_view(c); return st_diapfl(c, n, nn, k1n); }
 int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
 
-int blomgpu_halo_cmnfld2(blomgpu_ctx *c) {            // phy/mod_cmnfld_routines.F90:1171-1172
+int blomgpu_halo_cmnfld2(blomgpu_ctx *c, int n) {     // phy/mod_cmnfld_routines.F90:1171-1196
   ctx_sync_view(c);
   const int kk = c->h.kk;
-  return st_xctilr(c, c->h.f[F_temp], 1, 2 * kk, 3, 3, 1) || st_xctilr(c, c->h.f[F_saln], 1, 2 * kk, 3, 3, 1);
+  if (st_xctilr(c, c->h.f[F_temp], 1, 2 * kk, 3, 3, 1) || st_xctilr(c, c->h.f[F_saln], 1, 2 * kk, 3, 3, 1)) return 1;
+  return st_kfpla_halo(c, n);                         // kfpla(:,:,n) halo through util1, :1176-1196
 }
 int blomgpu_halo_difest(blomgpu_ctx *c, int nn) {     // phy/mod_difest.F90:750-772
   ctx_sync_view(c);
@@ -314,7 +321,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "diapfl") return blomgpu_diapfl(c, n, nn, k1n);
   if (s == "barotp") return blomgpu_barotp(c, m, n, mm, nn, k1m, k1n);
   if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);
-  if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c);
+  if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c, n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
@@ -329,7 +336,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     const int mm = (m - 1) * kk, nn = (n - 1) * kk, k1m = 1 + mm, k1n = 1 + nn;
     c->h.P.nstep = ns + 1;
     c->dirty = true;
-    static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect",
+    static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
                                 "pbcor1", "diffus", "pgforc", "momtum", "diapfl", "mxlayr_tail",
                                 "barotp", "pbcor2", "tmsmt2"};
     for (const char *st : seq)

@@ -55,7 +55,7 @@
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
-  X(fpug, K) X(fplg, K)                                                                  \
+  X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K)                                                                  \
   /* (K+1)-level work fields (phip of pgforc_geopotential, ...) */                       \
   X(wkp0, K + 1) X(wkp1, K + 1)
 
@@ -97,6 +97,7 @@ struct Params {
   int pgfmth;      // 0 geopotential, 1 dynamic enthalpy    (phy/mod_pgforc.F90:525-527)
   int advmth;      // 0 remap, 1 cppm                       (phy/mod_advect.F90:96,155)
   int bmcmth;      // 0 uc, 1 dluc                          (phy/mod_pbcor.F90:99-105)
+  int eitmth;      // 1 intdif, 2 gm                        (phy/mod_diffusion.F90:112-113)
   int vcoord_tag;  // 1 isopyc_bulkml                       (phy/mod_vcoord.F90)
   int ltedtp_opt;  // 1 layer, 2 neutral                    (phy/mod_diffusion.F90)
   double vland;    // halo fill value for closed boundaries (phy/mod_xc.F90:104)
@@ -163,6 +164,7 @@ struct blomgpu_ctx {
   std::unordered_map<std::string, KTimer> timers;
   bool timing = false;
   Tiling tiling;
+  long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   std::string err;
@@ -201,6 +203,7 @@ int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
+int st_kfpla_halo(blomgpu_ctx *, int n);   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field

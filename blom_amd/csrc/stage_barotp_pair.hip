@@ -27,6 +27,7 @@ struct PairArgs {
   int do_odd, do_even;
   int src;                   // 0: read *_t write *_t2, 1: the other way round
   int fold_halo;             // single tile: apply the xctilr rule (wrap / vland) while loading
+  long long *prof;           // debug: per-block phase timestamps (nullptr in production)
 };
 
 __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a) {
@@ -35,6 +36,14 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
   // coefficients that the momentum equations read at neighbouring points: staged once per launch
   __shared__ double s_pvo[BJ][BI + 1], s_pvm[BJ][BI + 1], s_pvn[BJ][BI + 1], s_sx[BJ][BI + 1], s_sy[BJ][BI + 1];
   const int tid = threadIdx.x;
+  long long *prof = a.prof ? a.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+  int pslot = 0;
+#ifdef BT_PROFILE
+#define PROF_MARK() do { if (prof && tid == 0) prof[pslot++] = wall_clock64(); } while (0)
+#else
+#define PROF_MARK() do { (void)prof; (void)pslot; } while (0)
+#endif
+  PROF_MARK();
   const bool act = tid < NPT;
   const int li = act ? tid % BI : 0, lj = act ? tid / BI : 0;
   // Fortran indices of this thread's point
@@ -103,7 +112,9 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
     if (wu) { us_acc = V.f[F_ubflxs_t][c]; uc_acc = V.f[F_ubcors_t][c]; }
     if (wv) { vs_acc = V.f[F_vbflxs_t][c]; vc_acc = V.f[F_vbcors_t][c]; }
   }
+  PROF_MARK();
   __syncthreads();
+  PROF_MARK();
 
   int ml = a.ml - 1, nl = a.nl - 1;     // 0-based LDS level indices
   // tile-local validity rectangle of what has been computed so far (inclusive, in li/lj)
@@ -125,6 +136,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
                                (s_ub[ml][lj][li + 1] - s_ub[ml][lj][li] + s_vb[ml][lj + 1][li] - s_vb[ml][lj][li]) * scp2i;
     }
     __syncthreads();
+    PROF_MARK();
     // after continuity pb[nl] is valid on [vlo_i, vhi_i-1] x [vlo_j, vhi_j-1]
     const int p_hi_i = vhi_i - 1, p_hi_j = vhi_j - 1;
     auto do_u = [&](int lv, int lo_i, int hi_i, int lo_j, int hi_j, int r_i0, int r_i1, int r_j0, int r_j1) {
@@ -196,6 +208,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
       __syncthreads();
       vlo_i = u_lo_i; vhi_i = u_hi_i; vlo_j = u_lo_j; vhi_j = u_hi_j;
     }
+    PROF_MARK();
     const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
   }
   if (mine) {
@@ -208,6 +221,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
     if (wu) { V.f[F_ubflxs_t][c] = us_acc; V.f[F_ubcors_t][c] = uc_acc; }
     if (wv) { V.f[F_vbflxs_t][c] = vs_acc; V.f[F_vbcors_t][c] = vc_acc; }
   }
+  PROF_MARK();
 }
 
 // Halo update of the three subcycling fields of buffer set `set`, both levels, in ONE launch:
@@ -268,7 +282,24 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
   a.fold_halo = c->tiling.multi() ? 0 : 1;
+  a.prof = c->bt_prof;
   dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
   hipLaunchKernelGGL(k_bt_pair, grid, dim3(NTHR), 0, c->stream, c->d, a);
+  return 0;
+}
+
+// debug hook (not part of the C-ABI): per-block wall_clock64 timestamps of the last pair launch
+extern "C" int blomgpu_dbg_bt_profile(blomgpu_ctx *c, long long *host, int nblocks_max, int *nblocks) {
+  const DevView &h = c->h;
+  const int nb = ((h.ii + TI - 1) / TI) * ((h.jj + TJ - 1) / TJ);
+  *nblocks = nb;
+  if (!host) {                                    // arm
+    if (!c->bt_prof) HIPCHK(c, hipMalloc((void **)&c->bt_prof, sizeof(long long) * 16 * nb));
+    HIPCHK(c, hipMemset(c->bt_prof, 0, sizeof(long long) * 16 * nb));
+    return 0;
+  }
+  if (!c->bt_prof || nb > nblocks_max) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host, c->bt_prof, sizeof(long long) * 16 * nb, hipMemcpyDeviceToHost));
   return 0;
 }

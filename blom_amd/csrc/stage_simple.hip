@@ -177,3 +177,23 @@ int st_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) {
   if (int rc = st_xctilr(c, c->h.f[F_dp] + (size_t)(k1n - 1) * c->h.nplane, 1, c->h.kk, 3, 3, 1)) return rc;
   return launch_p_dpu_dpv(c, nn, 0);
 }
+
+// ---- kfpla halo through util1, phy/mod_cmnfld_routines.F90:1176-1196 --------------------------
+__global__ void k_kfpla_util(const DevView *Vp, int n, int back) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (!V.m[I_ip][c]) return;
+  int *kf = V.m[I_kfpla] + (size_t)(n - 1) * V.nplane;
+  if (!back) {
+    if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii) V.f[F_util1][c] = (double)kf[c];
+  } else if (j >= -1 && j <= V.jj + 2 && i >= -1 && i <= V.ii + 2)
+    kf[c] = (int)lround(V.f[F_util1][c]);
+}
+
+int st_kfpla_halo(blomgpu_ctx *c, int n) {
+  hipLaunchKernelGGL(k_kfpla_util, plane_grid(c->h), dim3(256), 0, c->stream, c->d, n, 0);
+  if (int rc = st_xctilr(c, c->h.f[F_util1], 1, 1, 2, 2, 1)) return rc;
+  hipLaunchKernelGGL(k_kfpla_util, plane_grid(c->h), dim3(256), 0, c->stream, c->d, n, 1);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

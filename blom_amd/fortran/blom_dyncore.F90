@@ -86,8 +86,9 @@ contains
     call gpu_set('nstep', nstep)
     call init_fluxes(m,n,mm,nn,k1m,k1n)
     call tmsmt1(nn)
-    call halo_cmnfld2()
+    call halo_cmnfld2(n)
     call halo_difest(nn)
+    call eddtra(m,n,mm,nn,k1m,k1n)
     call advect(m,n,mm,nn,k1m,k1n)
     call pbcor1(m,n,mm,nn,k1m,k1n)
     call diffus(m,n,mm,nn,k1m,k1n)

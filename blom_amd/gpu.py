@@ -72,6 +72,9 @@ class BlomGpu:
             self._info[name] = (nlev.value, bool(isint.value))
         return self._info[name]
 
+    def has_stage(self, name):
+        return True
+
     def has_field(self, name):
         try:
             self.field_info(name)

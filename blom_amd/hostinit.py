@@ -322,6 +322,17 @@ def init_state(be, case):
         a[:] = np.where(msk[None], 0.0, a)
         be.put(nm, a)
 
+    # -- frozen isopycnal slopes read by eddtra (cmnfld2, phy/mod_cmnfld_routines.F90:1090, is out
+    #    of scope): an analytic pattern of amplitude nslp0, growing with depth ------------
+    if be.has_field("nslpx"):
+        ji, ii_ = np.meshgrid(np.arange(1, jj + 1), np.arange(1, ii + 1), indexing="ij")
+        prof = (np.arange(1, kk + 1) / kk)[:, None, None]
+        for nm, msk, pat in (("nslpx", iu, np.sin(2 * np.pi * ii_ / ii) * np.sin(np.pi * ji / jj)),
+                             ("nslpy", iv, np.cos(2 * np.pi * ii_ / ii) * np.sin(2 * np.pi * ji / jj))):
+            a = be.get(nm)
+            a[:, J, I] = np.where(msk[J, I] > 0, P.get("nslp0", 0.0) * prof * pat[None], 0.0)
+            be.put(nm, a)
+
     # -- geopotential of the sea floor (cf. channel/mod_channel.F90:311-320) ------------
     _, depth_h, _, _, _, _ = bigrid_np(case.depth, ii, jj)
     phi = be.get("phi")

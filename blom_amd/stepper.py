@@ -2,15 +2,18 @@
 
 Mirrors the order of phy/mod_blom_step.F90:96-253 for the isopyc_bulkml branch,
 restricted to the stages of the hot path and the ones sitting between them
-(SURVEY.md 8a/8f).  Stages whose reference modules need netCDF/CVMix (cmnfld, difest,
-eddtra, mxlayr, thermf) are not part of the sequence: diffusivities stay frozen and the
-eddy-induced fluxes umfltd/vmfltd stay zero.
+(SURVEY.md 8a/8f).  Stages whose reference modules need netCDF/CVMix (cmnfld, difest, mxlayr,
+thermf) are not part of the sequence: diffusivities and isopycnal slopes stay frozen.  eddtra is
+part of it; the reference build used as oracle cannot contain it (mod_eddtra needs mod_difest ->
+CVMix), so a backend without it skips it -- with zero slopes nslpx/nslpy, which is what the
+reference-pinned cases use, eddtra's result is exactly the zero fluxes that backend keeps.
 """
 from .hostinit import step_indices
 
-DYNCORE_STAGES = ("init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", "pbcor1",
+DYNCORE_STAGES = ("init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect", "pbcor1",
                   "diffus", "pgforc", "momtum", "diapfl", "mxlayr_tail", "barotp", "pbcor2",
                   "tmsmt2")
+OPTIONAL_STAGES = ("eddtra",)
 # halo_cmnfld2 / halo_difest : the xctilr calls of phy/mod_cmnfld_routines.F90:1171-1172 and
 #   phy/mod_difest.F90:750-755 (the stages themselves are out of scope, their halo updates
 #   are not: advect and momtum read those halos).
@@ -23,6 +26,8 @@ def dyncore_step(be, nstep, baclin, stages=DYNCORE_STAGES, hook=None):
     six = step_indices(nstep, be.kdm)
     be.set("nstep", nstep + 1)               # step_time, phy/mod_blom_step.F90:99
     for st in stages:
+        if st in OPTIONAL_STAGES and not getattr(be, "has_stage", lambda s: True)(st):
+            continue
         if hook is not None:
             hook(st, six)
         be.stage(st, *six)

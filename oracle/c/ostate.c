@@ -3,6 +3,7 @@
 #include "ostate.h"
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 OState *orc_create(int idm, int jdm, int kdm, int ntr, int nreg) {
   OState *S = (OState *)calloc(1, sizeof(OState));
@@ -17,7 +18,7 @@ OState *orc_create(int idm, int jdm, int kdm, int ntr, int nreg) {
 #undef X
   /* module defaults, phy/mod_tmsmt.F90:46-51 */
   S->wuv1 = .75; S->wuv2 = .125; S->wts1 = .875; S->wts2 = .0625; S->wbaro = .125;
-  S->vland = 0.; S->vcoord_tag = 1; S->ltedtp_opt = 1;
+  S->vland = 0.; S->vcoord_tag = 1; S->ltedtp_opt = 1; S->eitmth = 2;   /* eitmth default gm, phy/mod_diffusion.F90 */
   eos_set_pref(S, 2000.e4);
   return S;
 }
@@ -72,6 +73,7 @@ int orc_set_str(OState *S, const char *name, const char *v) {
   }
   if (!strcmp(name, "advmth")) { S->advmth = !strcmp(v, "remap") ? 0 : !strcmp(v, "cppm") ? 1 : -1; return S->advmth < 0; }
   if (!strcmp(name, "bmcmth")) { S->bmcmth = !strcmp(v, "uc") ? 0 : !strcmp(v, "dluc") ? 1 : -1; return S->bmcmth < 0; }
+  if (!strcmp(name, "eitmth")) { S->eitmth = !strcmp(v, "intdif") ? 1 : !strcmp(v, "gm") ? 2 : -1; return S->eitmth < 0; }
   if (!strcmp(name, "expcnf")) return 0;
   return 1;
 }
@@ -90,10 +92,18 @@ int orc_stage(OState *S, const char *st, int m, int n, int mm, int nn, int k1m, 
   else if (!strcmp(st, "momtum")) orc_momtum(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "barotp")) orc_barotp(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "diapfl")) orc_diapfl(S, n, nn, k1n);
+  else if (!strcmp(st, "eddtra")) return orc_eddtra(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "mxlayr_tail")) orc_mxlayr_tail(S, nn, k1n);
-  else if (!strcmp(st, "halo_cmnfld2")) {  /* phy/mod_cmnfld_routines.F90:1171-1172 */
+  else if (!strcmp(st, "halo_cmnfld2")) {  /* phy/mod_cmnfld_routines.F90:1171-1196 */
     orc_xctilr(S, S->temp, 1, 2 * kk, 3, 3, 1);
     orc_xctilr(S, S->saln, 1, 2 * kk, 3, 3, 1);
+    for (int j = 1; j <= S->jj; j++)        /* kfpla halo through util1, :1176-1196 */
+      for (int i = 1; i <= S->ii; i++)
+        if (A2(S, ip, i, j)) A2(S, util1, i, j) = (double)A3(S, kfpla, i, j, n);
+    orc_xctilr(S, S->util1, 1, 1, 2, 2, 1);
+    for (int j = -1; j <= S->jj + 2; j++)
+      for (int i = -1; i <= S->ii + 2; i++)
+        if (A2(S, ip, i, j)) A3(S, kfpla, i, j, n) = (int)lround(A2(S, util1, i, j));
   } else if (!strcmp(st, "halo_difest")) { /* phy/mod_difest.F90:750-772 */
     orc_xctilr(S, S->u, 1, 2 * kk, 2, 2, 13);
     orc_xctilr(S, S->v, 1, 2 * kk, 2, 2, 14);

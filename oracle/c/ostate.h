@@ -48,7 +48,7 @@
   X(utotm, 1) X(vtotm, 1) X(utotn, 1) X(vtotn, 1) X(uflux, 1) X(vflux, 1) X(uflux2, 1)    \
   X(vflux2, 1) X(uflux3, 1) X(vflux3, 1) X(umax, 1) X(vmax, 1) X(util1, 1) X(util2, 1)    \
   X(util3, 1) X(util4, 1) X(taux, 1) X(tauy, 1) X(ustarb, 1)                              \
-  X(trc, 2 * K * NT) X(trcold, K * NT) X(fpug, K) X(fplg, K)
+  X(trc, 2 * K * NT) X(trcold, K * NT) X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K)
 
 #define ORC_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1)
 
@@ -67,6 +67,7 @@ typedef struct {
   double bdmc1, bdmc2, iwdfac, nubmin;
   int bdmtyp, iwdflg, bdmldp;
   int mommth, pgfmth, advmth, bmcmth, vcoord_tag, ltedtp_opt;
+  int eitmth;      /* 1 intdif, 2 gm (phy/mod_diffusion.F90:112-113) */
   double vland;
 #define X(name, lev) double *name;
   ORC_REAL_FIELDS(X)
@@ -125,5 +126,6 @@ void orc_pbcor2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_momtum(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_diapfl(OState *S, int n, int nn, int k1n);
+int orc_eddtra(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);   /* PARITY UNPINNED, see eddtra.c */
 void orc_mxlayr_tail(OState *S, int nn, int k1n);
 #endif

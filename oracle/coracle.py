@@ -45,6 +45,9 @@ class COracle:
         self._views[name] = a
         return a
 
+    def has_stage(self, name):
+        return True
+
     def has_field(self, name):
         try:
             self.get(name)

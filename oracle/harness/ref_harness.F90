@@ -392,9 +392,10 @@ contains
       case ('tmsmt2');  call tmsmt2(m,mm,nn,k1m)
       ! Halo updates the reference performs inside stages that cannot be built here
       ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.
-      case ('halo_cmnfld2')   ! phy/mod_cmnfld_routines.F90:1171-1172
+      case ('halo_cmnfld2')   ! phy/mod_cmnfld_routines.F90:1171-1196
         call xctilr(temp, 1, 2*kk, 3, 3, halo_ps)
         call xctilr(saln, 1, 2*kk, 3, 3, halo_ps)
+        call cmnfld2_kfpla(n)
       case ('halo_difest')    ! phy/mod_difest.F90:750-772
         call xctilr(u, 1,2*kk, 2,2, halo_uv)
         call xctilr(v, 1,2*kk, 2,2, halo_vv)
@@ -407,6 +408,28 @@ contains
       case default; ierr = 1
     end select
   end subroutine ref_stage
+
+  subroutine cmnfld2_kfpla(n)
+    ! RESTATEMENT of the halo update of kfpla through util1, phy/mod_cmnfld_routines.F90:1176-1196
+    ! (cmnfld2 itself is outside the hot path; eddtra reads kfpla(i-1,j,n), kfpla(i,j-1,n)).
+    integer, intent(in) :: n
+    integer :: i, j, l
+    do j = 1, jj
+      do l = 1, isp(j)
+        do i = max(1, ifp(j,l)), min(ii, ilp(j,l))
+          util1(i,j) = kfpla(i,j,n)
+        enddo
+      enddo
+    enddo
+    call xctilr(util1, 1, 1, 2, 2, halo_ps)
+    do j = - 1, jj + 2
+      do l = 1, isp(j)
+        do i = max(- 1, ifp(j,l)), min(ii + 2, ilp(j,l))
+          kfpla(i,j,n) = nint(util1(i,j))
+        enddo
+      enddo
+    enddo
+  end subroutine cmnfld2_kfpla
 
   subroutine difest_p(nn)
     ! RESTATEMENT of "Update layer interface pressure", phy/mod_difest.F90:761-772: difest_isobml

@@ -175,5 +175,11 @@ class RefBackend:
         except KeyError:
             pass                             # option not read by any reference stage we call
 
+    def has_field(self, name):
+        return self.ref.has_field(name)
+
+    def has_stage(self, name):
+        return name != "eddtra"          # mod_eddtra is not part of the reference build (CVMix)
+
     def stage(self, name, m, n, mm, nn, k1m, k1n):
         self.ref.stage(name, m, n, mm, nn, k1m, k1n)
