@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="library option for A/B runs of kernel variants, e.g. momtum_v=1 (default: production kernels)")
     ap.add_argument("--rccl-self", action="store_true",
                     help="N=1 only: route the halo update through the RCCL transport (rank sends to itself) "
                          "to measure the exchange overhead of the N>1 path on one GPU")
@@ -157,6 +159,9 @@ def main():
         if args.rccl_self:
             gpu.rccl_init(rccl_unique_id(), 0, 1)
     hostinit.init_state(gpu, case)
+    for o in args.opt:
+        nm, v = o.split("=")
+        gpu.set(nm, int(v))
     baclin = case.params["baclin"]
 
     # ---- warm-up: first (forward) step + W-1 leap-frog steps, with per-class HIP-event timing ----

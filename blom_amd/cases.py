@@ -7,6 +7,7 @@ BASELINE.json's configs:
   fuk95    156x32x12  closed in i / periodic in j (nreg=4)  bld/fuk95/patch.input.1
   channel  208x512x53 periodic in i / closed in j (nreg=1)  bld/channel/patch.input.1
   chan_s   20x24x6    small channel used by the parity tests
+  chan_m   80x40x8    channel spanning several device tiles (kernel-variant tests)
   box_s    24x20x8    small closed basin with an island and a promontory coast
 
 The idealised definitions mirror the spirit of the reference's test cases
@@ -94,6 +95,7 @@ class Case:
 _DIMS = {
     # name: (idm, jdm, kdm, nreg, dx[m], baclin, batrop)
     "chan_s": (20, 24, 6, 1, 10.0e3, 900.0, 18.0),
+    "chan_m": (80, 40, 8, 1, 10.0e3, 900.0, 18.0),     # several 32x8 device tiles, periodic in i
     "box_s": (24, 20, 8, 0, 10.0e3, 900.0, 18.0),
     "fuk95": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
@@ -127,10 +129,10 @@ def _depth_for(name, idm, jdm, dx):
     """Bathymetry [m] on the interior (jdm, idm); 0 = land."""
     ii = np.arange(1, idm + 1)[None, :]
     jj = np.arange(1, jdm + 1)[:, None]
-    if name in ("chan_s", "channel"):
+    if name in ("chan_s", "chan_m", "channel"):
         # tanh shelves on both walls (cf. channel/mod_channel.F90:168-207), southern and
         # northern-most rows land
-        sf, sl = (200.0, 800.0) if name == "chan_s" else (200.0, 3800.0)
+        sf, sl = (200.0, 800.0) if name in ("chan_s", "chan_m") else (200.0, 3800.0)
         width = 0.18 * jdm * dx
         ys = (jj - 0.5) * dx
         yn = (jdm - jj + 0.5) * dx

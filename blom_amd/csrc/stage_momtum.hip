@@ -19,7 +19,12 @@
 // "first/last point of a wet segment" logic (ifu/ilu/jfu/jlu lists, phy/mod_bigrid.F90:320-429)
 // is expressed with the masks: i is a segment start iff iu(i,j)=1 and iu(i-1,j)=0, etc.; where
 // several sweeps of the reference write the same q-point the last writer in its order wins.
-// Algorithmic bytes: 26 F; this first version adds the work-space round trips.
+// Algorithmic bytes: 26 F plus the work-space round trips.  A fused LDS-tiled layer kernel
+// (tile + 3-cell rim, temporaries in LDS, layer loop with coefficients resident) was built and verified
+// bit-identical, and measured SLOWER on MI355X (2.7 ms vs 1.7 ms): the stage needs ~2000 fp64
+// instructions per point (25 divisions), so the 2.1x rim recomputation makes it ALU bound (~0.7 ms
+// at perfect issue) and the single 9-wave workgroup per CU cannot hide its own latencies across
+// seven barriers per layer.  The sweeps therefore stay separate kernels.
 // Roofline: HBM.
 #include "blomgpu_internal.h"
 
