@@ -1,0 +1,38 @@
+"""Turn rocprofv3 outputs under gpurun_out/ into the per-round summaries committed under profiles/.
+usage: prof_summarize.py <tag> <kernel_stats.csv> <nsteps_total> [<fetch_counter.csv> <write_counter.csv>]"""
+import csv, sys, collections
+tag, stats, nst = sys.argv[1], sys.argv[2], int(sys.argv[3])
+rows = list(csv.DictReader(open(stats)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(f"profiles/{tag}_kernel_stats.txt", "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (channel 208x512x53, 1 GPU)\n")
+    f.write(f"# {nst} baroclinic steps in the trace; kernel time per step {tot / 1e6 / nst:.3f} ms\n")
+    f.write(f"# {'kernel':42s} {'calls/step':>10s} {'avg_us':>10s} {'ms/step':>9s} {'%':>6s}\n")
+    for r in rows:
+        n, t = int(r["Calls"]), float(r["TotalDurationNs"])
+        if t / tot < 0.0005:
+            continue
+        f.write(f"{r['Name'].split('(')[0][:44]:44s} {n / nst:10.1f} {t / n / 1e3:10.1f} {t / 1e6 / nst:9.3f} {100 * t / tot:6.1f}\n")
+if len(sys.argv) > 5:
+    def per_kernel(path, cname):
+        acc = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != cname:
+                continue
+            a = acc[r["Kernel_Name"].split("(")[0]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        return acc
+    fe, wr = per_kernel(sys.argv[4], "FETCH_SIZE"), per_kernel(sys.argv[5], "WRITE_SIZE")
+    with open(f"profiles/{tag}_pmc_hbm_traffic.txt", "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 2 (channel 208x512x53)\n")
+        f.write("# per-launch averages in MB (counters are in KB).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports\n")
+        f.write("# half the bytes of a wide coalesced stream: fetch_x2 is the corrected estimate for 16 B/lane streams; the 8 B/lane loads of\n")
+        f.write("# these fp64 kernels calibrated at ~1.5x on this code (DESIGN.md 4), so the truth lies between the two columns.\n")
+        f.write(f"# {'kernel':30s} {'launches':>8s} {'fetch_MB':>10s} {'fetch_x2_MB':>12s} {'write_MB':>10s}\n")
+        ks = sorted(fe, key=lambda k: -(fe[k][1] + wr.get(k, [0, 0])[1]))
+        for k in ks[:40]:
+            n, v = fe[k]
+            w = wr.get(k, [1, 0.0])
+            f.write(f"{k[:32]:32s} {n:8d} {v / n / 1024:10.2f} {2 * v / n / 1024:12.2f} {w[1] / max(1, w[0]) / 1024:10.2f}\n")
+print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3500])
