@@ -196,6 +196,16 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     else return ctx_fail(c, " advmth = " + v + " is unsupported!");   // phy/mod_advect.F90:166-171
     return 0;
   }
+  if (s == "cppm_compatibility") {
+    if (v == "full") c->cppm_compat = 1; else if (v == "partial") c->cppm_compat = 2;
+    else return ctx_fail(c, " init_cppm: cppm_compatibility = " + v + " is unsupported!");   // phy/mod_cppm.F90:2524-2535
+    return 0;
+  }
+  if (s == "cppm_limiting") {
+    if (v == "monotonic") c->cppm_limiting = 1; else if (v == "non_oscillatory") c->cppm_limiting = 2;
+    else return ctx_fail(c, " init_cppm: cppm_limiting = " + v + " is unsupported!");        // phy/mod_cppm.F90:2536-2548
+    return 0;
+  }
   if (s == "eitmth") {
     if (v == "intdif") P.eitmth = 1; else if (v == "gm") P.eitmth = 2;
     else return ctx_fail(c, " eitmth = " + v + " is unsupported!");   // phy/mod_diffusion.F90:316-327
@@ -288,6 +298,7 @@ int blomgpu_tmsmt1(blomgpu_ctx *c, int nn) { ctx_sync_view(c); return st_tmsmt1(
 int blomgpu_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) { ctx_sync_view(c); return st_tmsmt2(c, m, mm, nn, k1m); }
 int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(c, mm); }
 int blomgpu_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) { ctx_sync_view(c); return st_diapfl(c, n, nn, k1n); }
+int blomgpu_init_cppm(blomgpu_ctx *c) { ctx_sync_view(c); return st_init_cppm(c); }   // phy/mod_cppm.F90:2504
 int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
 
 int blomgpu_halo_cmnfld2(blomgpu_ctx *c, int n) {     // phy/mod_cmnfld_routines.F90:1171-1196
@@ -321,6 +332,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "diapfl") return blomgpu_diapfl(c, n, nn, k1n);
   if (s == "barotp") return blomgpu_barotp(c, m, n, mm, nn, k1m, k1n);
   if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);
+  if (s == "init_cppm") return blomgpu_init_cppm(c);
   if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c, n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);

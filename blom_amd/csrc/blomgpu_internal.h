@@ -56,10 +56,15 @@
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
   X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K)                                                                  \
+  /* mod_cppm: thickness edge values and the coefficient tables of init_cppm (mod_cppm.F90:79-89);     \
+     the j-tables in (i,j) order (the reference's "_perm" layout, :2511-2518) */                        \
+  X(hel_3d, K) X(her_3d, K) X(hevc1i, 1) X(hevc2i, 1) X(hevc3i, 1) X(hevc4i, 1) X(ssci, 1) X(scci, 1)    \
+  X(d2mi, 1) X(tmc0i, 12) X(tmcli, 12) X(tmcri, 12) X(hevc1j, 1) X(hevc2j, 1) X(hevc3j, 1) X(hevc4j, 1)   \
+  X(sscj, 1) X(sccj, 1) X(d2mj, 1) X(tmc0j, 12) X(tmclj, 12) X(tmcrj, 12)                                                                  \
   /* (K+1)-level work fields (phip of pgforc_geopotential, ...) */                       \
   X(wkp0, K + 1) X(wkp1, K + 1)
 
-#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1)
+#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1) X(cppm_sti, 1) X(cppm_stj, 1)
 
 enum FieldId {
 #define X(name, lev) F_##name,
@@ -164,6 +169,9 @@ struct blomgpu_ctx {
   std::unordered_map<std::string, KTimer> timers;
   bool timing = false;
   Tiling tiling;
+  bool cppm_ready = false;   // init_cppm has run (tables on the device)
+  int cppm_compat = 1;       // 1 full, 2 partial            (phy/mod_cppm.F90:55-58)
+  int cppm_limiting = 2;     // 1 monotonic, 2 non_oscillatory
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
@@ -202,6 +210,8 @@ int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_cppm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     // stage_cppm.hip, called by advect
+int st_init_cppm(blomgpu_ctx *);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
 int st_kfpla_halo(blomgpu_ctx *, int n);   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);

@@ -467,12 +467,22 @@ __global__ void k_remap_update(const DevView *Vp, int nn) {
 }
 
 int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
-  (void)k1m;
   const DevView &h = c->h;
   const size_t np = h.nplane;
-  if (h.P.advmth != 0) return ctx_fail(c, "advect: advmth = 'cppm' is not built yet");
   if (h.ntr > MAXTR) return ctx_fail(c, "advect: more tracers than MAXTR");
   hipLaunchKernelGGL(k_adv_flux_area, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, m, mm, nn);
+  if (h.P.advmth == 1) {                                                              // mod_advect:155-164
+    {
+      TimeScope ts(c, "cppm");
+      if (int rc = st_cppm(c, m, n, mm, nn, k1m, k1n)) return rc;
+    }
+    if (int rc = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc;
+    if (int rc = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc;
+    if (int rc = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc;
+    for (int nt = 0; nt < h.ntr; nt++)
+      if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 1, 1, 1)) return rc;
+    return 0;
+  }
   hipLaunchKernelGGL(k_adv_pbmin, plane_grid(h), dim3(256), 0, c->stream, c->d);
   if (int rc = st_xctilr(c, h.f[F_cau], 1, h.kk, 3, 3, 13)) return rc;                 // mod_advect:124
   if (int rc = st_xctilr(c, h.f[F_cav], 1, h.kk, 3, 3, 14)) return rc;                 // mod_advect:125

@@ -350,6 +350,10 @@ def init_state(be, case):
         a[1, J, I] = np.where(msk, a[0, J, I], a[1, J, I])
         be.put(nm, a)
 
+    # -- cppm coefficient tables (init_cppm, phy/mod_cppm.F90:2504, called from blom_init) ---
+    if P.get("advmth") == "cppm":
+        be.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
+
     # -- old-level copies for the time filters (mod_inicon.F90:1426-1437, initms) --------
     dp = be.get("dp")
     dpold = be.get("dpold")

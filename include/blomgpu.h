@@ -86,6 +86,9 @@ int  blomgpu_eddtra (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 /* Halo updates the reference performs inside stages that are outside the hot path
  * (phy/mod_cmnfld_routines.F90:1171-1196: temp/saln halos and the kfpla halo through util1, phy/mod_difest.F90:750-772: halos + interface pressure p out to ii+3) and the
  * dp-halo/dpu/dpv tail of mxlayr (phy/mod_mxlayr.F90:1266-1310). */
+/* cppm (advmth = 'cppm'): stencil tags and coefficient tables from ip, scpx, scpy; call once after the
+ * grid has been uploaded.  phy/mod_cppm.F90:2504 (init_cppm, called from blom_init). */
+int  blomgpu_init_cppm(blomgpu_ctx *);
 int  blomgpu_halo_cmnfld2(blomgpu_ctx *, int n);
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);

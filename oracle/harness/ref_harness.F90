@@ -35,6 +35,7 @@ module ref_harness
   use mod_utility
   use mod_forcing
   use mod_advect,    only: advect, advmth
+  use mod_cppm,      only: init_cppm, cppm_compatibility, cppm_limiting
   use mod_pbcor,     only: pbcor1, pbcor2, bmcmth
   use mod_diffus,    only: diffus
   use mod_diapfl,    only: diapfl
@@ -197,6 +198,8 @@ contains
       case ('mommth'); mommth = trim(cstr(s))
       case ('pgfmth'); pgfmth = trim(cstr(s))
       case ('advmth'); advmth = trim(cstr(s))
+      case ('cppm_compatibility'); cppm_compatibility = trim(cstr(s))
+      case ('cppm_limiting'); cppm_limiting = trim(cstr(s))
       case ('bmcmth'); bmcmth = trim(cstr(s))
       case default; ierr = 1
     end select
@@ -392,6 +395,7 @@ contains
       case ('tmsmt2');  call tmsmt2(m,mm,nn,k1m)
       ! Halo updates the reference performs inside stages that cannot be built here
       ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.
+      case ('init_cppm');  call init_cppm          ! phy/mod_cppm.F90:2504 (called from blom_init)
       case ('halo_cmnfld2')   ! phy/mod_cmnfld_routines.F90:1171-1196
         call xctilr(temp, 1, 2*kk, 3, 3, halo_ps)
         call xctilr(saln, 1, 2*kk, 3, 3, halo_ps)
