@@ -23,7 +23,9 @@
 // k_cppm_init + halo updates; the j-tables keep (i,j) order (the reference's "_perm" layout) and
 // are addressed with stride ni, which is what its final transposition (:2717-2733) achieves on the
 // CPU.  Algorithmic bytes per step: (48 + 4 ntr) F.  Roofline: HBM.
-// Not built: cppm_limiting = 'monotonic', cppm_compatibility = 'partial', the arctic-seam swaps.
+// All four variants of the reference are instantiated from the same templates: limiting non_oscillatory
+// (reach 4) / monotonic (reach 3) x compatibility full (LU edge coefficients, hel_3d/her_3d exchanged) /
+// partial (thickness edge coefficients re-used for tracers).  Not built: the arctic-seam swaps (nreg=2).
 #include "blomgpu_internal.h"
 
 #define DPEPS 1.e-12
@@ -239,12 +241,13 @@ int st_init_cppm(blomgpu_ctx *c) {
   const int sdm = DIR ? (V).jj : (V).ii, odm = DIR ? (V).ii : (V).jj;      \
   (void)od; (void)sd
 
-template <int DIR>
+// LIM = 0: non-oscillatory limiting (reach 4 cells along the sweep), 1: monotonic (reach 3)
+template <int DIR, int LIM>
 __global__ void k_cppm_hm(const DevView *Vp, int nn, int second_pass) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
-  if (o < 1 || o > odm || s < -3 || s > sdm + 4) return;
+  if (o < 1 || o > odm || s < -3 + LIM || s > sdm + 4 - LIM) return;
   const int k = blockIdx.y;
   const size_t np = V.nplane, ok = (size_t)k * np;
   double h = fmax2(0., V.f[F_dp][c + (size_t)(k + nn) * np]) + DPEPS;
@@ -255,35 +258,32 @@ __global__ void k_cppm_hm(const DevView *Vp, int nn, int second_pass) {
   WK(V, W_HM)[c + ok] = h;
 }
 
-// h_edges_nosc, :361-434
-template <int DIR>
-__global__ void k_cppm_hedges(const DevView *Vp) {
-  const DevView &V = *Vp;
-  THREAD_IJ(V);
-  SWEEP_COORDS(V);
-  if (o < 1 || o > odm || s < 1 || s > sdm) return;
-  const int k = blockIdx.y;
-  const size_t ok = (size_t)k * V.nplane;
-  const CppmTab T = cppm_tab(V, DIR);
-  const double *hmv = WK(V, W_HM) + ok;
+// Thickness edge values of cell c with limiting: h_edges_nosc :361-434 (LIM 0), h_edges_mono :436-488
+// (LIM 1); the same code opens parabola_coeffs_pc_nosc :1144-1207 and parabola_coeffs_pc_mono :1294-1326.
+template <int LIM>
+__device__ inline void cppm_h_edges(const CppmTab &T, size_t c, int sd, const double *hmv, double &hel, double &her) {
   double hm[7];                                  // hm(s-3..s+3)
 #pragma unroll
-  for (int q = 0; q < 7; q++) hm[q] = hmv[c + (q - 3) * sd];
+  for (int q = LIM; q < 7 - LIM; q++) hm[q] = hmv[c + (q - 3) * sd];
 #define HM(x) hm[(x) + 3]
-  double he[4];                                  // edge values at s-1..s+2
+  double he[4];                                  // edge values at s-1..s+2 (LIM 1: only s, s+1 are used)
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = LIM; q < 4 - LIM; q++) {
     const int x = q - 1;
     const size_t cx = c + x * sd;
     he[q] = T.hevc[0][cx] * HM(x - 2) + T.hevc[1][cx] * HM(x - 1) + T.hevc[2][cx] * HM(x) + T.hevc[3][cx] * HM(x + 1);
   }
-  // hel(x) = he(x), her(x) = he(x+1); d2h at s-1, s, s+1
-  double d2h[3];
-#pragma unroll
-  for (int q = 0; q < 3; q++) d2h[q] = T.d2m[c + (q - 1) * sd] * (he[q] - 2. * HM(q - 1) + he[q + 1]);
-  double hel = he[1], her = he[2];
+  hel = he[1];
+  her = he[2];
   const double hm0 = HM(0), hmm = HM(-1), hmp = HM(1);
-  if (d2h[0] * d2h[1] <= 0. || d2h[1] * d2h[2] <= 0.) {
+  bool limit = true;
+  if (LIM == 0) {                                // hel(x) = he(x), her(x) = he(x+1); d2h at s-1, s, s+1
+    double d2h[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) d2h[q] = T.d2m[c + (q - 1) * sd] * (he[q] - 2. * HM(q - 1) + he[q + 1]);
+    limit = d2h[0] * d2h[1] <= 0. || d2h[1] * d2h[2] <= 0.;
+  }
+  if (limit) {
     const double ssc = T.ssc[c];
     const double sl = ssc * (hm0 - hmm), sr = ssc * (hmp - hm0);
     if (sl * sr > 0.) {
@@ -301,24 +301,38 @@ __global__ void k_cppm_hedges(const DevView *Vp) {
       her = hm0;
     }
   }
-  hel = fmax2(hel, DPEPS);
-  her = fmax2(her, DPEPS);
-  const double sl = 2. * (3. * hm0 - 2. * hel - her);
-  const double a2 = 3. * (hel - 2. * hm0 + her);
-  const double sr = sl + 2. * a2;
-  if (sl < 0. && sr > 0.) {
-    if (a2 * hel - .25 * sl * sl < a2 * DPEPS) {
-      const double q = 3. * hm0 / (3. * sl * sr + 4. * a2 * a2);
-      hel = sl * sl * q;
-      her = sr * sr * q;
+  if (LIM == 0) {
+    hel = fmax2(hel, DPEPS);
+    her = fmax2(her, DPEPS);
+    const double sl = 2. * (3. * hm0 - 2. * hel - her);
+    const double a2 = 3. * (hel - 2. * hm0 + her);
+    const double sr = sl + 2. * a2;
+    if (sl < 0. && sr > 0.) {
+      if (a2 * hel - .25 * sl * sl < a2 * DPEPS) {
+        const double q = 3. * hm0 / (3. * sl * sr + 4. * a2 * a2);
+        hel = sl * sl * q;
+        her = sr * sr * q;
+      }
     }
   }
-  V.f[F_hel_3d][c + ok] = hel;
-  V.f[F_her_3d][c + ok] = her;
 #undef HM
 }
 
-// tracer edge value coefficients of one edge, parabola_coeffs_fc_nosc :520-731; x = edge index offset from c
+template <int DIR, int LIM>
+__global__ void k_cppm_hedges(const DevView *Vp) {
+  const DevView &V = *Vp;
+  THREAD_IJ(V);
+  SWEEP_COORDS(V);
+  if (o < 1 || o > odm || s < 1 || s > sdm) return;
+  const size_t ok = (size_t)blockIdx.y * V.nplane;
+  const CppmTab T = cppm_tab(V, DIR);
+  double hel, her;
+  cppm_h_edges<LIM>(T, c, sd, WK(V, W_HM) + ok, hel, her);
+  V.f[F_hel_3d][c + ok] = hel;
+  V.f[F_her_3d][c + ok] = her;
+}
+
+// tracer edge value coefficients of one edge, parabola_coeffs_fc_nosc :520-731 == parabola_coeffs_fc_mono :845-1050
 __device__ inline void cppm_tevc(const CppmTab &T, size_t np, size_t cx, int sd, const double *hm, const double *hel,
                                  const double *her, double &t1, double &t2, double &t3, double &t4) {
 #define TM0(q) T.tmc0[cx + (size_t)((q)-1) * np]
@@ -434,25 +448,29 @@ __device__ inline double *cppm_tracer(const DevView &V, int nt, int k, int nn) {
   return V.f[F_trc] + ((size_t)(k + nn) + (size_t)(nt - 2) * 2 * V.kk) * np;
 }
 
-template <int DIR>
+// tracer edge values at every edge.  FC = 1: coefficients compatible with the thickness reconstruction
+// (4x4 LU, above); FC = 0 ('partial'): the thickness edge coefficients hevc (:1146-1157, :1296-1307)
+template <int DIR, int LIM, int FC>
 __global__ void k_cppm_tedge(const DevView *Vp, int nn, int ntl) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
-  if (o < 1 || o > odm || s < -1 || s > sdm + 3) return;
+  if (o < 1 || o > odm || s < -1 + LIM || s > sdm + 3 - LIM) return;
   const int k = blockIdx.y;
   const size_t np = V.nplane, ok = (size_t)k * np;
   const CppmTab T = cppm_tab(V, DIR);
   double t1, t2, t3, t4;
-  cppm_tevc(T, np, c, sd, WK(V, W_HM) + ok, V.f[F_hel_3d] + ok, V.f[F_her_3d] + ok, t1, t2, t3, t4);
+  if (FC) cppm_tevc(T, np, c, sd, WK(V, W_HM) + ok, V.f[F_hel_3d] + ok, V.f[F_her_3d] + ok, t1, t2, t3, t4);
+  else { t1 = T.hevc[0][c]; t2 = T.hevc[1][c]; t3 = T.hevc[2][c]; t4 = T.hevc[3][c]; }
   for (int nt = 0; nt < ntl; nt++) {
     const double *tm = cppm_tracer(V, nt, k, nn);
     WK(V, W_TE + nt)[c + ok] = t1 * tm[c - 2 * sd] + t2 * tm[c - sd] + t3 * tm[c] + t4 * tm[c + sd];
   }
 }
 
-// limiting and parabola coefficients, :733-816
-template <int DIR>
+// limiting and parabola coefficients: parabola_coeffs_fc_nosc :733-816, _fc_mono :1062-1114,
+// _pc_nosc :1159-1262, _pc_mono :1309-1369
+template <int DIR, int LIM, int FC>
 __global__ void k_cppm_parab(const DevView *Vp, int nn, int ntl) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
@@ -461,63 +479,96 @@ __global__ void k_cppm_parab(const DevView *Vp, int nn, int ntl) {
   const int k = blockIdx.y;
   const size_t np = V.nplane, ok = (size_t)k * np;
   const CppmTab T = cppm_tab(V, DIR);
-  const double *hmv = WK(V, W_HM) + ok, *helv = V.f[F_hel_3d] + ok, *herv = V.f[F_her_3d] + ok;
+  const double *hmv = WK(V, W_HM) + ok;
+  const double hm0 = hmv[c];
+  double hel0, her0;
+  // thickness factors of the tracer parabolas (FC) at s-1, s, s+1; for 'partial' they are constants
   double hf2m[3], hf2l[3], hf2r[3], d2mv[3];
-  double hf1m = 0., hf1l = 0., hf1r = 0.;
+  double hf1m = 6., hf1l = -4., hf1r = -2.;
+  if (FC) {
+    const double *helv = V.f[F_hel_3d] + ok, *herv = V.f[F_her_3d] + ok;
+    hel0 = helv[c];
+    her0 = herv[c];
 #pragma unroll
-  for (int q = 0; q < 3; q++) {                                                       // :735-750
-    const size_t cx = c + (q - 1) * sd;
-    const double hm = hmv[cx], hel = helv[cx], her = herv[cx];
-    const double qq = 1. / (12. * hm - hel - her);
-    const double f1m = 60. * hm * qq;
-    hf2m[q] = -f1m;
-    hf2l[q] = 5. * (6. * hm + hel - her) * qq;
-    hf2r[q] = 5. * (6. * hm - hel + her) * qq;
-    d2mv[q] = T.d2m[cx];
-    if (q == 1) {
-      hf1m = f1m;
-      hf1l = -(42. * hm + 4. * hel - 6. * her) * qq;
-      hf1r = -(18. * hm - 4. * hel + 6. * her) * qq;
+    for (int q = LIM; q < 3 - LIM; q++) {                                             // :735-750, :1064-1071
+      const size_t cx = c + (q - 1) * sd;
+      const double hm = hmv[cx], hel = helv[cx], her = herv[cx];
+      const double qq = 1. / (12. * hm - hel - her);
+      const double f1m = 60. * hm * qq;
+      hf2m[q] = -f1m;
+      hf2l[q] = 5. * (6. * hm + hel - her) * qq;
+      hf2r[q] = 5. * (6. * hm - hel + her) * qq;
+      if (q == 1) {
+        hf1m = f1m;
+        hf1l = -(42. * hm + 4. * hel - 6. * her) * qq;
+        hf1r = -(18. * hm - 4. * hel + 6. * her) * qq;
+      }
     }
+  } else {
+    cppm_h_edges<LIM>(T, c, sd, hmv, hel0, her0);
+#pragma unroll
+    for (int q = 0; q < 3; q++) { hf2m[q] = -2.; hf2l[q] = 1.; hf2r[q] = 1.; }        // d2t = d2m*(tel - 2 tm + ter)
   }
-  const double hm0 = hmv[c], hel0 = helv[c], her0 = herv[c];
+  if (LIM == 0) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) d2mv[q] = T.d2m[c + (q - 1) * sd];
+  }
   const double ssc = T.ssc[c], scc = T.scc[c];
   for (int nt = 0; nt < ntl; nt++) {
     const double *tm = cppm_tracer(V, nt, k, nn), *te = WK(V, W_TE + nt) + ok;
     const double tmm = tm[c - sd], tm0 = tm[c], tmp = tm[c + sd];
-    double d2t[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const size_t cx = c + (q - 1) * sd;
-      d2t[q] = d2mv[q] * (hf2m[q] * tm[cx] + hf2l[q] * te[cx] + hf2r[q] * te[cx + sd]);
-    }
     double tel = te[c], ter = te[c + sd];
-    if (d2t[0] * d2t[1] <= 0. || d2t[1] * d2t[2] <= 0.) {                             // :755-791
+    bool limit = true;
+    if (LIM == 0) {
+      double d2t[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const size_t cx = c + (q - 1) * sd;
+        if (FC) d2t[q] = d2mv[q] * (hf2m[q] * tm[cx] + hf2l[q] * te[cx] + hf2r[q] * te[cx + sd]);
+        else d2t[q] = d2mv[q] * (te[cx] - 2. * tm[cx] + te[cx + sd]);
+      }
+      limit = d2t[0] * d2t[1] <= 0. || d2t[1] * d2t[2] <= 0.;
+    }
+    if (limit) {
       double sl = ssc * (tm0 - tmm), sr = ssc * (tmp - tm0);
       if (sl * sr > 0.) {
         double sc = scc * (tmp - tmm);
         sc = copysign(fmin2(fmin2(fabs(sl), fabs(sr)), fabs(sc)), sc);
         if ((tmm - tel) * (tm0 - tel) > 0.) tel = tm0 - copysign(fmin2(.5 * fabs(sc), fabs(tel - tm0)), sc);
         if ((tmp - ter) * (tm0 - ter) > 0.) ter = tm0 + copysign(fmin2(.5 * fabs(sc), fabs(ter - tm0)), sc);
-        sl = hf1m * tm0 + hf1l * tel + hf1r * ter;
-        const double a2 = hf2m[1] * tm0 + hf2l[1] * tel + hf2r[1] * ter;
-        sr = sl + 2. * a2;
-        if (sl * sr < 0.) {
-          if ((ter - tel) * a2 < 0.)
-            tel = -((hf1m + 2. * hf2m[1]) * tm0 + (hf1r + 2. * hf2r[1]) * ter) / (hf1l + 2. * hf2l[1]);
-          else
-            ter = -(hf1m * tm0 + hf1l * tel) / hf1r;
+        if (FC) {
+          sl = hf1m * tm0 + hf1l * tel + hf1r * ter;
+          const double a2 = hf2m[1] * tm0 + hf2l[1] * tel + hf2r[1] * ter;
+          sr = sl + 2. * a2;
+          if (sl * sr < 0.) {
+            if ((ter - tel) * a2 < 0.)
+              tel = -((hf1m + 2. * hf2m[1]) * tm0 + (hf1r + 2. * hf2r[1]) * ter) / (hf1l + 2. * hf2l[1]);
+            else
+              ter = -(hf1m * tm0 + hf1l * tel) / hf1r;
+          }
+        } else {
+          const double d = ter - tel;
+          const double q = d * (2. * tm0 - tel - ter);
+          const double r = (1. / 3.) * d * d;
+          if (q > r) tel = 3. * tm0 - 2. * ter;
+          else if (-r > q) ter = 3. * tm0 - 2. * tel;
         }
       } else {
         tel = tm0;
         ter = tm0;
       }
     }
-    if (nt >= 1) {                                                                    // :793-806 (nt = 2..ntr_loc)
+    if (LIM == 0 && nt >= 1) {                                                        // nt = 2..ntr_loc: positive definite
       tel = fmax2(tel, 0.);
       ter = fmax2(ter, 0.);
-      const double sl = hf1m * tm0 + hf1l * tel + hf1r * ter;
-      const double a2 = hf2m[1] * tm0 + hf2l[1] * tel + hf2r[1] * ter;
+      double sl, a2;
+      if (FC) {
+        sl = hf1m * tm0 + hf1l * tel + hf1r * ter;
+        a2 = hf2m[1] * tm0 + hf2l[1] * tel + hf2r[1] * ter;
+      } else {
+        sl = 2. * (3. * tm0 - 2. * tel - ter);
+        a2 = 3. * (tel - 2. * tm0 + ter);
+      }
       const double sr = sl + 2. * a2;
       if (sl < 0. && sr > 0.) {
         if (a2 * tel - .25 * sl * sl < 0.) {
@@ -528,10 +579,15 @@ __global__ void k_cppm_parab(const DevView *Vp, int nn, int ntl) {
       }
     }
     WK(V, W_TPC0(ntl) + nt)[c + ok] = tel;
-    WK(V, W_TPC1(ntl) + nt)[c + ok] = hf1m * tm0 + hf1l * tel + hf1r * ter;
-    WK(V, W_TPC2(ntl) + nt)[c + ok] = hf2m[1] * tm0 + hf2l[1] * tel + hf2r[1] * ter;
+    if (FC) {
+      WK(V, W_TPC1(ntl) + nt)[c + ok] = hf1m * tm0 + hf1l * tel + hf1r * ter;
+      WK(V, W_TPC2(ntl) + nt)[c + ok] = hf2m[1] * tm0 + hf2l[1] * tel + hf2r[1] * ter;
+    } else {
+      WK(V, W_TPC1(ntl) + nt)[c + ok] = 6. * tm0 - 4. * tel - 2. * ter;
+      WK(V, W_TPC2(ntl) + nt)[c + ok] = 3. * (tel - 2. * tm0 + ter);
+    }
   }
-  WK(V, W_HPC0)[c + ok] = hel0;                                                       // :808-810
+  WK(V, W_HPC0)[c + ok] = hel0;
   WK(V, W_HPC1)[c + ok] = 6. * hm0 - 4. * hel0 - 2. * her0;
   WK(V, W_HPC2)[c + ok] = 3. * (hel0 - 2. * hm0 + her0);
 }
@@ -624,27 +680,43 @@ __global__ void k_cppm_update(const DevView *Vp, int nn, int ntl) {
   V.f[F_dp][c + okn] = fmax2(0., hn - DPEPS);
 }
 
-template <int DIR>
+template <int DIR, int LIM, int FC>
 static int cppm_sweep(blomgpu_ctx *c, int n, int mm, int nn, int k1n, bool second_pass) {
   const DevView &h = c->h;
   const size_t np = h.nplane;
-  const int ntl = 2 + h.ntr, mh = DIR ? 0 : 4, nh = DIR ? 4 : 0;
+  const int ntl = 2 + h.ntr, w = 4 - LIM, mh = DIR ? 0 : w, nh = DIR ? w : 0;
   const dim3 g = plane_grid(h, h.kk), b(256);
   if (int rc = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, mh, nh, 1)) return rc;           // :1484-1489
   if (int rc = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, mh, nh, 1)) return rc;
   if (int rc = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, mh, nh, 1)) return rc;
   for (int nt = 0; nt < h.ntr; nt++)
     if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, mh, nh, 1)) return rc;
-  hipLaunchKernelGGL((k_cppm_hm<DIR>), g, b, 0, c->stream, c->d, nn, second_pass ? 1 : 0);
-  hipLaunchKernelGGL((k_cppm_hedges<DIR>), g, b, 0, c->stream, c->d);
-  if (int rc = st_xctilr(c, h.f[F_hel_3d], 1, h.kk, mh, nh, 1)) return rc;                                    // :1527-1528
-  if (int rc = st_xctilr(c, h.f[F_her_3d], 1, h.kk, mh, nh, 1)) return rc;
-  hipLaunchKernelGGL((k_cppm_tedge<DIR>), g, b, 0, c->stream, c->d, nn, ntl);
-  hipLaunchKernelGGL((k_cppm_parab<DIR>), g, b, 0, c->stream, c->d, nn, ntl);
+  hipLaunchKernelGGL((k_cppm_hm<DIR, LIM>), g, b, 0, c->stream, c->d, nn, second_pass ? 1 : 0);
+  if (FC) {
+    hipLaunchKernelGGL((k_cppm_hedges<DIR, LIM>), g, b, 0, c->stream, c->d);
+    if (int rc = st_xctilr(c, h.f[F_hel_3d], 1, h.kk, mh, nh, 1)) return rc;                                  // :1527-1528
+    if (int rc = st_xctilr(c, h.f[F_her_3d], 1, h.kk, mh, nh, 1)) return rc;
+  }
+  hipLaunchKernelGGL((k_cppm_tedge<DIR, LIM, FC>), g, b, 0, c->stream, c->d, nn, ntl);
+  hipLaunchKernelGGL((k_cppm_parab<DIR, LIM, FC>), g, b, 0, c->stream, c->d, nn, ntl);
   hipLaunchKernelGGL((k_cppm_flux<DIR>), g, b, 0, c->stream, c->d, n, mm, ntl);
   hipLaunchKernelGGL((k_cppm_update<DIR>), g, b, 0, c->stream, c->d, nn, ntl);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+
+template <int LIM, int FC>
+static int cppm_variant(blomgpu_ctx *c, int n, int mm, int nn, int k1n) {
+  const DevView &h = c->h;
+  const int w = 4 - LIM;
+  if (int rc = st_xctilr(c, h.f[F_cau], 1, h.kk, w, w, 13)) return rc;                  // :2761-2762, :2779-2780
+  if (int rc = st_xctilr(c, h.f[F_cav], 1, h.kk, w, w, 14)) return rc;
+  if (h.P.nstep % 2 == 1) {                                                             // :2764-2774
+    if (int rc = cppm_sweep<0, LIM, FC>(c, n, mm, nn, k1n, false)) return rc;
+    return cppm_sweep<1, LIM, FC>(c, n, mm, nn, k1n, true);
+  }
+  if (int rc = cppm_sweep<1, LIM, FC>(c, n, mm, nn, k1n, false)) return rc;
+  return cppm_sweep<0, LIM, FC>(c, n, mm, nn, k1n, true);
 }
 
 // cppm, :2748-2834
@@ -654,14 +726,7 @@ int st_cppm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   if (!c->cppm_ready) return ctx_fail(c, "cppm: init_cppm has not been called (blomgpu_init_cppm)");
   if (h.nreg == 2) return ctx_fail(c, "cppm: arctic-seam edge swaps (nreg=2) are not built");
   if (2 + h.ntr > MAXTL || W_NSLOT(2 + h.ntr) > h.nwk) return ctx_fail(c, "cppm: too many tracers for the device work space");
-  if (c->cppm_compat != 1) return ctx_fail(c, " cppm_compatibility = 'partial' is not built");
-  if (c->cppm_limiting != 2) return ctx_fail(c, " cppm_limiting = 'monotonic' is not built");
-  if (int rc = st_xctilr(c, h.f[F_cau], 1, h.kk, 4, 4, 13)) return rc;                  // :2761-2762
-  if (int rc = st_xctilr(c, h.f[F_cav], 1, h.kk, 4, 4, 14)) return rc;
-  if (h.P.nstep % 2 == 1) {                                                             // :2764-2774
-    if (int rc = cppm_sweep<0>(c, n, mm, nn, k1n, false)) return rc;
-    return cppm_sweep<1>(c, n, mm, nn, k1n, true);
-  }
-  if (int rc = cppm_sweep<1>(c, n, mm, nn, k1n, false)) return rc;
-  return cppm_sweep<0>(c, n, mm, nn, k1n, true);
+  const bool fc = c->cppm_compat == 1, mono = c->cppm_limiting == 1;
+  if (fc) return mono ? cppm_variant<1, 1>(c, n, mm, nn, k1n) : cppm_variant<0, 1>(c, n, mm, nn, k1n);
+  return mono ? cppm_variant<1, 0>(c, n, mm, nn, k1n) : cppm_variant<0, 0>(c, n, mm, nn, k1n);
 }

@@ -1,5 +1,5 @@
-"""advect with advmth = 'cppm' (phy/mod_cppm.F90, default variant: full compatibility,
-non-oscillatory limiting) on the device against the reference's own compiled code, bit for bit.
+"""advect with advmth = 'cppm' (phy/mod_cppm.F90; all four variants: cppm_compatibility
+full/partial x cppm_limiting non_oscillatory/monotonic) on the device against the reference's own compiled code, bit for bit.
 
 The reference library runs the whole stage sequence with cppm; before every advect its state is
 uploaded to the device, advect is run there, and every array is compared (==).  The coefficient
@@ -17,12 +17,15 @@ pytestmark = pytest.mark.gpu
 SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "vtotm", "util1"}
 
 
-def _setup(cfg):
+VARIANTS = [("full", "non_oscillatory"), ("full", "monotonic"), ("partial", "non_oscillatory"), ("partial", "monotonic")]
+
+
+def _setup(cfg, compat="full", limiting="non_oscillatory"):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
         pytest.skip(f"oracle/_ref/{cfg}/libblomref.so not built")
-    case = make_case(cfg, advmth="cppm")
+    case = make_case(cfg, advmth="cppm", cppm_compatibility=compat, cppm_limiting=limiting)
     ref = get_ref_backend(cfg, case.depth)
     hostinit.init_state(ref, case)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
@@ -32,9 +35,10 @@ def _setup(cfg):
     return case, ref, gpu
 
 
+@pytest.mark.parametrize("compat,limiting", VARIANTS)
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 6), ("box_s", 6), ("fuk95", 4)])
-def test_advect_cppm_stage_parity(cfg, nsteps):
-    case, ref, gpu = _setup(cfg)
+def test_advect_cppm_stage_parity(cfg, nsteps, compat, limiting):
+    case, ref, gpu = _setup(cfg, compat, limiting)
     failures, pending, nstep, ready = [], {}, [0], [False]
 
     def check():
