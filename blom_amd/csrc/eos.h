@@ -64,4 +64,56 @@ __device__ inline double p_alpha(double p1, double p2, double th, double s) {
   const double qq = q * q;
   return 2. * r * (a2 + b2 * pm + (a2 - a1 * b2 / b1) * qq * (r1_3 + qq * (r1_5 + qq * (r1_7 + qq * r1_9))));
 }
+
+// dalpdt(p,th,s), phy/mod_eos.F90:531-552
+__device__ inline double dalpdt(double p, double th, double s) {
+  const double r1 = a21 + (a22 + a24 * th + a25 * s) * th + (a23 + a26 * s) * s + (b21 + b22 * th + b23 * s) * p;
+  const double r2i = 1. / (a11 + (a12 + a14 * th + a15 * s) * th + (a13 + a16 * s) * s + (b11 + b12 * th + b13 * s) * p);
+  return (a22 + 2. * a24 * th + a25 * s + b22 * p - (a12 + 2. * a14 * th + a15 * s + b12 * p) * r1 * r2i) * r2i;
+}
+
+// dalpds(p,th,s), phy/mod_eos.F90:554-574
+__device__ inline double dalpds(double p, double th, double s) {
+  const double r1 = a21 + (a22 + a24 * th + a25 * s) * th + (a23 + a26 * s) * s + (b21 + b22 * th + b23 * s) * p;
+  const double r2i = 1. / (a11 + (a12 + a14 * th + a15 * s) * th + (a13 + a16 * s) * s + (b11 + b12 * th + b13 * s) * p);
+  return (a23 + a25 * th + 2. * a26 * s + b23 * p - (a13 + a15 * th + 2. * a16 * s + b13 * p) * r1 * r2i) * r2i;
+}
+
+// dynh_derivatives(p0,p1,p2,th,s,dynh_th,dynh_s), phy/mod_eos.F90:576-695 (truncated series form)
+__device__ inline void dynh_derivatives(double p0, double p1, double p2, double th, double s, double &dynh_th, double &dynh_s) {
+  const double r1_2 = 1. / 2., r1_3 = 1. / 3., r1_4 = 1. / 4., r1_5 = 1. / 5., r1_6 = 1. / 6., r1_7 = 1. / 7., r1_8 = 1. / 8.,
+               r1_9 = 1. / 9., r1_10 = 1. / 10., r1_11 = 1. / 11.;
+  const double b1i = 1. / (b11 + b12 * th + b13 * s);
+  const double A1 = (a11 + (a12 + a14 * th + a15 * s) * th + (a13 + a16 * s) * s) * b1i;
+  const double A2 = (a21 + (a22 + a24 * th + a25 * s) * th + (a23 + a26 * s) * s) * b1i;
+  const double B2 = (b21 + b22 * th + b23 * s) * b1i;
+  const double a1_th = (a12 + 2. * a14 * th + a15 * s - A1 * b12) * b1i;
+  const double a2_th = (a22 + 2. * a24 * th + a25 * s - A2 * b12) * b1i;
+  const double b2_th = (b22 - B2 * b12) * b1i;
+  const double a1_s = (a13 + a15 * th + 2. * a16 * s - A1 * b13) * b1i;
+  const double a2_s = (a23 + a25 * th + 2. * a26 * s - A2 * b13) * b1i;
+  const double b2_s = (b23 - B2 * b13) * b1i;
+  const double pm1 = r1_2 * (p2 + p1), pp1 = r1_2 * (p2 - p1);
+  const double pm0 = r1_2 * (pm1 + p0), pp0 = r1_2 * (pm1 - p0);
+  const double t1 = 1. / (A1 + pm1), t0 = 1. / (A1 + pm0);
+  const double q1 = pp1 * t1, q0 = pp0 * t0;
+  const double qq1 = q1 * q1, qq0 = q0 * q0;
+  double f = (A2 - A1 * B2) * a1_th;
+  double c1 = a2_th - A1 * b2_th - B2 * a1_th;
+  double c2 = f * t1, c3 = f * t0;
+  dynh_th = 2. * (pp0 * b2_th +
+                  ((((((r1_11 * c1 - c3) * qq0 + (r1_9 * c1 - c3)) * qq0 + (r1_7 * c1 - c3)) * qq0 + (r1_5 * c1 - c3)) * qq0 +
+                    (r1_3 * c1 - c3)) * qq0 + (c1 - c3)) * q0) -
+            ((((r1_11 * (r1_10 * c1 - c2) * qq1 + r1_9 * (r1_8 * c1 - c2)) * qq1 + r1_7 * (r1_6 * c1 - c2)) * qq1 +
+               r1_5 * (r1_4 * c1 - c2)) * qq1 + r1_3 * (r1_2 * c1 - c2)) * qq1;
+  f = (A2 - A1 * B2) * a1_s;
+  c1 = a2_s - A1 * b2_s - B2 * a1_s;
+  c2 = f * t1;
+  c3 = f * t0;
+  dynh_s = 2. * (pp0 * b2_s +
+                 ((((((r1_11 * c1 - c3) * qq0 + (r1_9 * c1 - c3)) * qq0 + (r1_7 * c1 - c3)) * qq0 + (r1_5 * c1 - c3)) * qq0 +
+                   (r1_3 * c1 - c3)) * qq0 + (c1 - c3)) * q0) -
+           ((((r1_11 * (r1_10 * c1 - c2) * qq1 + r1_9 * (r1_8 * c1 - c2)) * qq1 + r1_7 * (r1_6 * c1 - c2)) * qq1 +
+              r1_5 * (r1_4 * c1 - c2)) * qq1 + r1_3 * (r1_2 * c1 - c2)) * qq1;
+}
 }  // namespace eos

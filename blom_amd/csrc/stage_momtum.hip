@@ -48,7 +48,7 @@
 enum {
   M_UTOTM, M_UFLUX, M_UTOTN, M_VTOTM, M_VFLUX, M_VTOTN, M_DPMX, M_WGTJA, M_WGTJB, M_UJA, M_UJB, M_DL2U,
   M_WGTIA, M_WGTIB, M_VIA, M_VIB, M_DL2V, M_POTVOR, M_DEFOR1, M_DEFOR2, M_KE, M_VSC2U, M_VSC4U, M_VSC2V,
-  M_VSC4V, M_UFLUX1, M_VFLUX1, M_NSLOT
+  M_VSC4V, M_UFLUX1, M_VFLUX1, M_UHMIN, M_UHMAX, M_VHMIN, M_VHMAX, M_NSLOT
 };
 #define S2_DRAG 3      // 2-D work plane
 
@@ -290,6 +290,35 @@ __global__ void k_mom_vort(const DevView *Vp, int mm) {
   }
 }
 
+// ---- :662-715 min,max transports for the energy conserving scheme with dissipation (mommth = 'enedis') --
+__device__ inline void enedis_minmax(double hc, double hm, double &hmin, double &hmax) {
+  const double c1 = 1. - 1.5 * .5, c2 = 1. - .5, c3 = 2., slope = .5;                 // :221
+  if (fabs(hc) < .1 * fabs(hm)) hm = 10. * hc;
+  else if (fabs(hc) > c1 * fabs(hm)) {
+    if (fabs(hc) < c2 * fabs(hm)) hc = (3. * hc + (1. - c2 * 3.) * hm);
+    else if (fabs(hc) <= c3 * fabs(hm)) hc = hm;
+    else hc = slope * hc + (1. - c3 * slope) * hm;
+  }
+  if (hc > hm) { hmin = hm; hmax = hc; }
+  else { hmax = hm; hmin = hc; }
+}
+
+__global__ void k_mom_enedis(const DevView *Vp, int mm) {
+  const DevView &V = *Vp;
+  THREAD_IJ(V);
+  if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
+  const int k = blockIdx.y;
+  const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
+  const double *dp = V.f[F_dp] + okm;
+  // the reference's local arrays are zeroed once per call (:238-241) and written at wet points only
+  double a = 0., b = 0.;
+  if (V.m[I_iu][c]) enedis_minmax(.5 * WK(V, M_UTOTM)[c + ok] * (dp[c] + dp[c - 1]), WK(V, M_UFLUX)[c + ok], a, b);
+  WK(V, M_UHMIN)[c + ok] = a; WK(V, M_UHMAX)[c + ok] = b;
+  a = 0.; b = 0.;
+  if (V.m[I_iv][c]) enedis_minmax(.5 * WK(V, M_VTOTM)[c + ok] * (dp[c] + dp[c - V.ni]), WK(V, M_VFLUX)[c + ok], a, b);
+  WK(V, M_VHMIN)[c + ok] = a; WK(V, M_VHMAX)[c + ok] = b;
+}
+
 // ---- :829-841 and :988-1000 deformation dependent viscosities ---------------------------------------
 __global__ void k_mom_visc(const DevView *Vp) {
   const DevView &V = *Vp;
@@ -369,8 +398,21 @@ __global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn) {
     double cau;
     if (P.mommth == 0)
       cau = .125 * (vflux[c] + vflux[nb] + vflux[w] + vflux[w + ni]) * (potvor[c] + potvor[nb]);
-    else
+    else if (P.mommth == 1)
       cau = .25 * ((vflux[c] + vflux[w]) * potvor[c] + (vflux[nb] + vflux[w + ni]) * potvor[nb]);
+    else {                                                                   // enedis, :771-790
+      const double *vhmx = WK(V, M_VHMAX) + ok, *vhmn = WK(V, M_VHMIN) + ok;
+      const double utm = WK(V, M_UTOTM)[c + ok];
+      double t1, t2;
+      const double pn = potvor[nb], pc = potvor[c];
+      if (pn * utm == 0.) t1 = pn * ((vhmx[nb] + vhmx[w + ni]) + (vhmn[nb] + vhmn[w + ni])) * .5;
+      else if (pn * utm < 0.) t1 = pn * (vhmx[nb] + vhmx[w + ni]);
+      else t1 = pn * (vhmn[nb] + vhmn[w + ni]);
+      if (pc * utm == 0.) t2 = pc * ((vhmx[c] + vhmx[w]) + (vhmn[c] + vhmn[w])) * .5;
+      else if (pc * utm < 0.) t2 = pc * (vhmx[c] + vhmx[w]);
+      else t2 = pc * (vhmn[c] + vhmn[w]);
+      cau = .25 * (t1 + t2);
+    }
     // lateral turbulent momentum fluxes, :879-913
     const double wja = WK(V, M_WGTJA)[c + ok], wjb = WK(V, M_WGTJB)[c + ok];
     const double dpxy = fmax2(dpu[c], ONEMM);
@@ -413,8 +455,21 @@ __global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn) {
     double cav;
     if (P.mommth == 0)
       cav = -.125 * (uflux[c] + uflux[e] + uflux[s] + uflux[e - ni]) * (potvor[c] + potvor[e]);
-    else
+    else if (P.mommth == 1)
       cav = -.25 * ((uflux[c] + uflux[s]) * potvor[c] + (uflux[e] + uflux[e - ni]) * potvor[e]);
+    else {                                                                   // enedis, :793-812
+      const double *uhmx = WK(V, M_UHMAX) + ok, *uhmn = WK(V, M_UHMIN) + ok;
+      const double vtm = WK(V, M_VTOTM)[c + ok];
+      double t1, t2;
+      const double pe = potvor[e], pc = potvor[c];
+      if (pe * vtm == 0.) t1 = pe * ((uhmx[e] + uhmx[e - ni]) + (uhmn[e] + uhmn[e - ni])) * .5;
+      else if (pe * vtm > 0.) t1 = pe * (uhmx[e] + uhmx[e - ni]);
+      else t1 = pe * (uhmn[e] + uhmn[e - ni]);
+      if (pc * vtm == 0.) t2 = pc * ((uhmx[c] + uhmx[s]) + (uhmn[c] + uhmn[s])) * .5;
+      else if (pc * vtm > 0.) t2 = pc * (uhmx[c] + uhmx[s]);
+      else t2 = pc * (uhmn[c] + uhmn[s]);
+      cav = -.25 * (t1 + t2);
+    }
     const double wia = WK(V, M_WGTIA)[c + ok], wib = WK(V, M_WGTIB)[c + ok];
     const double dpxy = fmax2(dpv[c], ONEMM);
     double dpia = fmax2(dpv[w], ONEMM);
@@ -494,7 +549,6 @@ __global__ void k_mom_column(const DevView *Vp, int m, int mm, int nn) {
 int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)k1m; (void)k1n;
   const DevView &h = c->h;
-  if (h.P.mommth == 2) return ctx_fail(c, "momtum: mommth = 'enedis' is not built yet");
   if (h.P.vcoord_tag != 1) return ctx_fail(c, "momtum: hybrid-coordinate wind stress (mu_nonloc) is not built yet");
   if (h.nwk < M_NSLOT) return ctx_fail(c, "momtum: device work space too small");
   const dim3 g3 = plane_grid(h, h.kk), gcol = plane_grid(h, 1, 64), b(256), b64(64);
@@ -506,6 +560,7 @@ int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   hipLaunchKernelGGL(k_mom_tot, g3, b, 0, c->stream, c->d, m, n, mm, nn);
   hipLaunchKernelGGL(k_mom_wall, g3, b, 0, c->stream, c->d, m);
   hipLaunchKernelGGL(k_mom_vort, g3, b, 0, c->stream, c->d, mm);
+  if (h.P.mommth == 2) hipLaunchKernelGGL(k_mom_enedis, g3, b, 0, c->stream, c->d, mm);
   hipLaunchKernelGGL(k_mom_visc, g3, b, 0, c->stream, c->d);
   hipLaunchKernelGGL(k_mom_flux1, g3, b, 0, c->stream, c->d, mm);
   hipLaunchKernelGGL(k_mom_update, g3, b, 0, c->stream, c->d, m, mm, nn);

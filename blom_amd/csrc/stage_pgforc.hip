@@ -135,6 +135,100 @@ __global__ void k_pgf_uv(const DevView *Vp, int n, int nn) {
   (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
 }
 
+// ---- pgforc_dynamic_enthalpy, phy/mod_pgforc.F90:269-412 ---------------------------------------------
+// work-space slots of the layer potentials
+enum { DH_POT = 0, DH_POTPB, DH_A, DH_T, DH_ALPR, DH_NSLOT };
+#define P0_DYNH 0.           // phy/mod_pgforc.F90:49
+#define ONEMM_ 9.806
+
+// per p-column, j,i = 0..jj/ii: bottom-up potentials (:282-312) and the derivatives (:318-341)
+__global__ void k_pgf_dynh_col(const DevView *Vp, int nn) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][t]) return;
+  const size_t c = t, np = V.nplane;
+  const int kk = V.kk;
+  const double pref = V.P.pref;
+  double *phi = V.f[F_phi];
+  const double *p = V.f[F_p];
+  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
+#define LV(a, k) (a)[c + (size_t)((k)-1) * np]
+  double pot, potpb, ph = LV(phi, kk + 1);
+  {
+    const double tk = LV(temp, kk), sk = LV(saln, kk), pl = LV(p, kk + 1);
+    pot = ph + eos::p_alpha(P0_DYNH, pl, tk, sk);
+    potpb = eos::alp(pl, tk, sk) * pl;
+    ph = ph + eos::p_alpha(LV(p, kk), pl, tk, sk);
+    LV(WK(V, DH_POT), kk) = pot;
+    LV(WK(V, DH_POTPB), kk) = potpb;
+    LV(phi, kk) = ph;
+  }
+  for (int k = kk - 1; k >= 1; k--) {
+    const double tk = LV(temp, k), sk = LV(saln, k), tl = LV(temp, k + 1), sl = LV(saln, k + 1), pl = LV(p, k + 1);
+    pot = pot + eos::p_alpha(P0_DYNH, pl, tk, sk) - eos::p_alpha(P0_DYNH, pl, tl, sl);
+    potpb = potpb + (eos::alp(pl, tk, sk) - eos::alp(pl, tl, sl)) * pl;
+    ph = ph + eos::p_alpha(LV(p, k), pl, tk, sk);
+    LV(WK(V, DH_POT), k) = pot;
+    LV(WK(V, DH_POTPB), k) = potpb;
+    LV(phi, k) = ph;
+  }
+  for (int k = 1; k <= kk; k++) {
+    const double tk = LV(temp, k), sk = LV(saln, k);
+    double da = 0., dt = 0.;
+    if (!(LV(dp, k) < ONEMM_)) {
+      double ts_t, ts_s;
+      eos::dynh_derivatives(P0_DYNH, LV(p, k), LV(p, k + 1), tk, sk, ts_t, ts_s);
+      da = ts_s / eos::dalpds(pref, tk, sk);
+      dt = ts_t - da * eos::dalpdt(pref, tk, sk);
+    }
+    LV(WK(V, DH_A), k) = da;
+    LV(WK(V, DH_T), k) = dt;
+    LV(WK(V, DH_ALPR), k) = eos::alp(pref, tk, sk);
+  }
+#undef LV
+}
+
+// per u-/v-column (blockIdx.y = 0: u, 1: v): layer PGF and the vertical sums, :345-410, then :543-589
+__global__ void k_pgf_dynh_uv(const DevView *Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const bool isv = blockIdx.y == 1;
+  const size_t c = t, np = V.nplane;
+  if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
+  const size_t mns = isv ? c - V.ni : c - 1;
+  const int kk = V.kk;
+  const double *temp = V.f[F_temp] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
+  const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  const double *pot = WK(V, DH_POT), *potpb = WK(V, DH_POTPB), *da = WK(V, DH_A), *dt = WK(V, DH_T), *ar = WK(V, DH_ALPR);
+  double xip = 0., xim = 0., pgfm = 0.;
+  for (int k = kk; k >= 1; k--) {
+    const size_t o = (size_t)(k - 1) * np;
+    double g = -(pot[c + o] - pot[mns + o]);
+    if (dp[mns + o] >= ONEMM_ && dp[c + o] >= ONEMM_)
+      g = g + .5 * ((dt[mns + o] + dt[c + o]) * (temp[c + o] - temp[mns + o]) + (da[mns + o] + da[c + o]) * (ar[c + o] - ar[mns + o]));
+    pgf[c + o] = g;
+    const double dpk = dpz[c + o];
+    pgfm = pgfm + g * dpk;
+    xim = xim + potpb[mns + o] * dpk;
+    xip = xip + potpb[c + o] * dpk;
+  }
+  const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
+  pgfm = pgfm * q;
+  xip = xip * q;
+  xim = xim * q;
+  for (int k = 0; k < kk; k++) pgf[c + (size_t)k * np] = pgf[c + (size_t)k * np] - pgfm;
+  const size_t on = (size_t)(n - 1) * np;
+  (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
+  (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
+  (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+}
+
 __global__ void k_pgf_sealv(const DevView *Vp) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,16 +241,17 @@ __global__ void k_pgf_sealv(const DevView *Vp) {
 int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
-  if (h.P.pgfmth != 0) return ctx_fail(c, "pgforc: pgfmth = 'dynamic enthalpy' is not built yet");
   if (int rc = launch_p_dpu_dpv(c, nn, 1)) return rc;
   hipLaunchKernelGGL(k_pgf_copy_old2d, plane_grid(h), dim3(256), 0, c->stream, c->d, n);
   hipLaunchKernelGGL(k_pgf_copy_old3d, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
   {
     TimeScope ts(c, "pgforc");
-    hipLaunchKernelGGL(k_pgf_phi, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn);
+    if (h.P.pgfmth == 0) hipLaunchKernelGGL(k_pgf_phi, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn);
+    else hipLaunchKernelGGL(k_pgf_dynh_col, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn);
     // xctilr(pb_p,1,1,1,1) at :540 precedes the /pb_p(i-1,j) scaling done inside k_pgf_uv
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
-    hipLaunchKernelGGL(k_pgf_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+    if (h.P.pgfmth == 0) hipLaunchKernelGGL(k_pgf_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+    else hipLaunchKernelGGL(k_pgf_dynh_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
   }
   hipLaunchKernelGGL(k_pgf_sealv, plane_grid(h), dim3(256), 0, c->stream, c->d);
   HIPCHK(c, hipGetLastError());

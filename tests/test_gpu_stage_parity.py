@@ -27,12 +27,12 @@ GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", 
 SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "vtotm"}
 
 
-def _run(cfg, nsteps, stages):
+def _run(cfg, nsteps, stages, **overrides):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
         pytest.skip(f"oracle/_ref/{cfg}/libblomref.so not built")
-    case = make_case(cfg)
+    case = make_case(cfg, **overrides)
     ref = get_ref_backend(cfg, case.depth)
     hostinit.init_state(ref, case)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
@@ -77,6 +77,21 @@ def test_stage_parity_small(cfg):
 
 def test_stage_parity_fuk95():
     _run("fuk95", 2, GPU_STAGES)
+
+
+# namelist-selected variants of the stages (phy/mod_momtum.F90:723-820, phy/mod_pgforc.F90:524-534,
+# phy/mod_pbcor.F90:99-105), each against the reference run with the same option
+@pytest.mark.parametrize("opts", [dict(mommth="enecon"), dict(mommth="enedis"), dict(pgfmth="dynamic enthalpy"),
+                                  dict(bmcmth="dluc"), dict(mommth="enedis", pgfmth="dynamic enthalpy", bmcmth="dluc")],
+                         ids=lambda o: "+".join(f"{k}={v}" for k, v in o.items()).replace(" ", "_"))
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
+def test_stage_parity_option_variants(cfg, opts):
+    try:
+        _run(cfg, 3, GPU_STAGES, **opts)
+    finally:                        # the reference instance is shared between tests: back to the defaults
+        from oracle.refblom import get_ref_backend
+        case = make_case(cfg)
+        hostinit.init_state(get_ref_backend(cfg, case.depth), case)
 
 
 # ---------------------------------------------------------------------------------------------
