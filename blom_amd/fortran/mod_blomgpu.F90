@@ -103,7 +103,7 @@ module mod_blomgpu
   public :: gpu_init, gpu_finalize, gpu_set, gpu_upload, gpu_upload_int, gpu_download, gpu_nlev, &
             gpu_halo, gpu_chksum, gpu_sync
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
-            diapfl, barotp, eddtra, halo_cmnfld2, halo_difest, mxlayr_tail
+            diapfl, barotp, eddtra, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -269,6 +269,9 @@ contains
   subroutine eddtra(m,n,mm,nn,k1m,k1n)         ! phy/mod_eddtra.F90:148
     integer, intent(in) :: m,n,mm,nn,k1m,k1n
     call stage6('eddtra',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine init_cppm()                       ! phy/mod_cppm.F90:2504
+    call stage6('init_cppm',0,0,0,0,0,0)
   end subroutine
   subroutine halo_cmnfld2(n)                   ! phy/mod_cmnfld_routines.F90:1171-1196
     integer, intent(in) :: n
