@@ -362,8 +362,37 @@ __global__ void k_diapfl_kming(const DevView *Vp) {                             
   V.m[I_kming][c] = (int)rint(V.f[F_util1][c]);
 }
 
-// momentum mixing of one component (blockIdx.y = 0: u, 1: v), :740-852 / :856-966
-enum { U_UC = 0, U_DELP, U_FPU, U_FPL, U_GTD, U_NSLOT };
+// momentum mixing of one component (blockIdx.y = 0: u, 1: v), :740-852 / :856-966.
+// As in the column pass, the reference's work arrays uc, delp (the mixed layer moved to positions
+// kmin, kmin+1) are the velocity and thickness arrays themselves under the position -> layer map
+// (kmin -> 1, kmin+1 -> 2), the interface fluxes fpu/fpl are evaluated where the tridiagonal sweep
+// consumes them, and the forward-eliminated velocity is kept in place; only gtd needs a work plane.
+enum { U_GTD = 0, U_NSLOT };
+
+// fluxes through the upper interface of position k (fpu(k)) and, same interface seen from above,
+// fpl(k-1): the average of the two neighbouring p-columns, clipped at the velocity-point bottom (:779-817)
+__device__ inline void diapfl_mom_flux(const double *p, const double *fpug, const double *fplg, size_t mns, size_t c, size_t np,
+                                       int k, double pzb, double &fpu_k, double &fpl_km1) {
+  double fpum, fplm, fpup, fplp;
+  const size_t o = (size_t)(k - 1) * np, om = (size_t)(k - 2) * np;
+  double pnew = p[mns + o], fu = fpug[mns + o], fl = fplg[mns + om];
+  double pold = pnew - fl + fu;
+  if (pold <= pzb) {
+    if (pnew <= pzb) { fpum = fu; fplm = fl; } else { fpum = fu; fplm = fl - pnew + pzb; }
+  } else {
+    if (pnew <= pzb) { fpum = fu - pold + pzb; fplm = fl; } else { fpum = .5 * (fu + fl); fplm = fpum; }
+  }
+  pnew = p[c + o]; fu = fpug[c + o]; fl = fplg[c + om];
+  pold = pnew - fl + fu;
+  if (pold <= pzb) {
+    if (pnew <= pzb) { fpup = fu; fplp = fl; } else { fpup = fu; fplp = fl - pnew + pzb; }
+  } else {
+    if (pnew <= pzb) { fpup = fu - pold + pzb; fplp = fl; } else { fpup = .5 * (fu + fl); fplp = fpup; }
+  }
+  fpu_k = .5 * (fpum + fpup);
+  fpl_km1 = .5 * (fplm + fplp);
+}
+
 __global__ void k_diapfl_momentum(const DevView *Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
@@ -376,59 +405,46 @@ __global__ void k_diapfl_momentum(const DevView *Vp, int nn) {
   const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
   const double *p = V.f[F_p], *fpug = V.f[F_fpug], *fplg = V.f[F_fplg];
 #define LV(a, k) (a)[c + (size_t)((k)-1) * np]
-#define LM(a, k) (a)[mns + (size_t)((k)-1) * np]
   const int kmin = min(V.m[I_kming][mns], V.m[I_kming][c]);
   int kmax = 1;
   for (int k = 2; k <= kk; k++)
     if (LV(dpz, k) > 0.) kmax = k;
   if (!(kmin < kmax)) return;
-  AR(sb + U_UC, kmin + 1) = LV(vel, 2);
-  AR(sb + U_UC, kmin) = LV(vel, 1);
-  AR(sb + U_DELP, kmin + 1) = LV(dpz, 2);
-  AR(sb + U_DELP, kmin) = LV(dpz, 1);
-  for (int k = kmin + 2; k <= kmax; k++) { AR(sb + U_UC, k) = LV(vel, k); AR(sb + U_DELP, k) = LV(dpz, k); }
   const double pzb = (isv ? V.f[F_pv] : V.f[F_pu])[c + (size_t)kk * np];
-  AR(sb + U_FPU, kmin) = 0.;
-  for (int k = kmin + 1; k <= kmax; k++) {
-    double fpum, fplm, fpup, fplp;
-    double pnew = LM(p, k), fu = LM(fpug, k), fl = LM(fplg, k - 1);
-    double pold = pnew - fl + fu;
-    if (pold <= pzb) {
-      if (pnew <= pzb) { fpum = fu; fplm = fl; } else { fpum = fu; fplm = fl - pnew + pzb; }
-    } else {
-      if (pnew <= pzb) { fpum = fu - pold + pzb; fplm = fl; } else { fpum = .5 * (fu + fl); fplm = fpum; }
-    }
-    pnew = LV(p, k); fu = LV(fpug, k); fl = LV(fplg, k - 1);
-    pold = pnew - fl + fu;
-    if (pold <= pzb) {
-      if (pnew <= pzb) { fpup = fu; fplp = fl; } else { fpup = fu; fplp = fl - pnew + pzb; }
-    } else {
-      if (pnew <= pzb) { fpup = fu - pold + pzb; fplp = fl; } else { fpup = .5 * (fu + fl); fplp = fpup; }
-    }
-    AR(sb + U_FPU, k) = .5 * (fpum + fpup);
-    AR(sb + U_FPL, k - 1) = .5 * (fplm + fplp);
-  }
-  AR(sb + U_FPL, kmax) = 0.;
-  double ctd = 0., bitd = 1.;
+  // forward elimination over positions kmin..kmax, :822-836; position -> layer: kmin -> 1, kmin+1 -> 2
+  double ctd = 0., bitd = 1., g = 0., uprev = 0.;
+  double fu = 0., fl_prev_unused = 0.;                        // fpu(kmin) = 0
+  (void)fl_prev_unused;
+  double fu_next = 0., fl;
   for (int k = kmin; k <= kmax; k++) {
-    const double g = ctd * bitd;
+    const int lay = k == kmin ? 1 : (k == kmin + 1 ? 2 : k);
+    if (k < kmax) diapfl_mom_flux(p, fpug, fplg, mns, c, np, k + 1, pzb, fu_next, fl);    // fpu(k+1), fpl(k)
+    else fl = 0.;                                                                         // fpl(kmax) = 0
+    g = ctd * bitd;
     AR(sb + U_GTD, k) = g;
-    const double dk = AR(sb + U_DELP, k), fu = AR(sb + U_FPU, k), fl = AR(sb + U_FPL, k);
+    const double dk = LV(dpz, lay);
     const double q = 1. / (dk + fu + fl);
     const double atd = -fu * q;
     ctd = -fl * q;
     const double dtd = dk * q;
     bitd = 1. / (1. - atd * g);
-    const int km1 = k - 1 > kmin ? k - 1 : kmin;
-    AR(sb + U_UC, k) = (dtd * AR(sb + U_UC, k) - atd * AR(sb + U_UC, km1)) * bitd;
+    const double uk = LV(vel, lay);
+    // km1 = max(k-1, kmin): at k = kmin the reference reads uc(kmin) itself, i.e. the unmodified value
+    uprev = (dtd * uk - atd * (k == kmin ? uk : uprev)) * bitd;
+    LV(vel, lay) = uprev;
+    fu = fu_next;
   }
-  for (int k = kmax - 1; k >= kmin; k--) AR(sb + U_UC, k) = AR(sb + U_UC, k) - AR(sb + U_GTD, k + 1) * AR(sb + U_UC, k + 1);
-  LV(vel, 1) = AR(sb + U_UC, kmin);
-  LV(vel, 2) = AR(sb + U_UC, kmin + 1);
-  for (int k = kmin + 2; k <= kmax; k++) LV(vel, k) = AR(sb + U_UC, k);
-  const double ub = AR(sb + U_UC, kmax);
+  // back substitution, :838
+  double unext = uprev, gnext = g;
+  for (int k = kmax - 1; k >= kmin; k--) {
+    const int lay = k == kmin ? 1 : (k == kmin + 1 ? 2 : k);
+    unext = LV(vel, lay) - gnext * unext;
+    LV(vel, lay) = unext;
+    gnext = AR(sb + U_GTD, k);
+  }
+  const double ub = uprev;                                    // uc(kmax): untouched by the back substitution
   for (int k = kmax + 1; k <= kk; k++)
-    if (fmin2(LM(p, k), LV(p, k)) < pzb) LV(vel, k) = ub;
+    if (fmin2(p[mns + (size_t)(k - 1) * np], LV(p, k)) < pzb) LV(vel, k) = ub;
 }
 
 // dpu/dpv at the new level from the updated p, :971-1000 (u: i 1..ii+1, j 1..jj ; v: i 1..ii, j 1..jj+1)

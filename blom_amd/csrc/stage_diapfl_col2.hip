@@ -29,7 +29,9 @@ enum { E_SU, E_SL, E_FCU, E_FCL, E_FMAX, E_H, E_R, E_T, E_F, E_FT, E_GTD, E_NSLO
 #define PRES(k) pres[c + (size_t)((k)-1) * np]
 #define TRC(nt, k) trc[c + (size_t)((k)-1 + (nt)*2 * kk) * np]
 
-__global__ void k_diapfl_column2(const DevView *Vp, int n, int nn, int *__restrict__ errflag) {
+// one wavefront per 64 columns and ~1700 wavefronts in all: occupancy cannot exceed 2 waves per SIMD anyway,
+// so let the register allocator use up to 256 VGPRs instead of spilling at 128
+__global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *Vp, int n, int nn, int *__restrict__ errflag) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
   if (t_ >= V.nplane) return;
