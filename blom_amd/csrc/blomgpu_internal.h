@@ -172,6 +172,9 @@ struct blomgpu_ctx {
   bool cppm_ready = false;   // init_cppm has run (tables on the device)
   int cppm_compat = 1;       // 1 full, 2 partial            (phy/mod_cppm.F90:55-58)
   int cppm_limiting = 2;     // 1 monotonic, 2 non_oscillatory
+  unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel
+  int num_cus = 0;
+  int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation

@@ -281,6 +281,10 @@ __global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, i
 }
 
 int bt_pair_halo(blomgpu_ctx *c, int set);
+bool bt_phase_usable(blomgpu_ctx *c);
+int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
+                    int last, int src, int *src_out, int *ml_out, int *nl_out);
+int bt_phase_check(blomgpu_ctx *c);
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
                    int do_odd, int do_even, int src);
 
@@ -323,7 +327,13 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     }
     hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
     const int last = lll0 + lstep / 2 - 1;
-    if (c->barotp_fused) {
+    if (c->barotp_fused && c->barotp_persist && bt_phase_usable(c)) {
+      // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
+      // their edge values through memory
+      int so, mo, no;
+      if (int rc = bt_phase_launch(c, m, n, ml, nl, woa, wob, wna, wnb, lll0, last, set, &so, &mo, &no)) return rc;
+      set = so; ml = mo; nl = no;
+    } else if (c->barotp_fused) {
       // fused odd+even substep pairs per LDS tile (stage_barotp_pair.hip); single substeps only
       // where a pair would straddle a phase boundary (epilogue + sum reset sit in between)
       int lll = lll0;
@@ -380,5 +390,6 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl, set);
   }
   HIPCHK(c, hipGetLastError());
+  if (c->barotp_fused && c->barotp_persist && bt_phase_usable(c)) return bt_phase_check(c);
   return 0;
 }

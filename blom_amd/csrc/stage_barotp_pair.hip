@@ -28,13 +28,29 @@ struct PairArgs {
   int src;                   // 0: read *_t write *_t2, 1: the other way round
   int fold_halo;             // single tile: apply the xctilr rule (wrap / vland) while loading
   long long *prof;           // debug: per-block phase timestamps (nullptr in production)
+  // persistent form (k_bt_steps<true>): the launch walks substeps lll0..last itself
+  int lll0, last;            // first and last substep of the phase
+  double woa, wob, wna, wnb; // time weights wo = woa*l + wob, wn = wna*l + wnb, wm = 1 - wo - wn (:352-360)
+  unsigned *flags;           // one word per tile: number of iterations this tile has completed and published
+  unsigned *abort_word;      // set by any tile whose wait ran out; every spin also watches it
 };
 
-__global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a) {
+// PERSIST = false: one odd+even pair (or one half) per launch, neighbours synchronise at the kernel
+// boundary.  PERSIST = true: one launch per barotropic phase.  The 45 coefficient planes a launch reads
+// are constant over the whole phase, and re-reading them (67 MB per launch on the channel grid, 15 of
+// the 20 us of a pair launch) is what the non-persistent form spends its time on; here they stay in
+// registers/LDS and only the state moves: after every iteration a tile publishes its interior
+// (write-through stores) and a completion count, waits for the counts of its up to 8 neighbours
+// (relaxed polls by 8 lanes, one agent-scope acquire, bounded spin with a chip-wide abort word) and
+// re-reads just the rim.  Reads alternate between the two buffer sets exactly as the launches did.
+// All workgroups must be resident: the launcher checks tiles <= CUs.
+template <bool PERSIST>
+__global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a) {
   const DevView &V = *Vp;
   __shared__ double s_pb[2][BJ][BI + 1], s_ub[2][BJ][BI + 1], s_vb[2][BJ][BI + 1];
   // coefficients that the momentum equations read at neighbouring points: staged once per launch
   __shared__ double s_pvo[BJ][BI + 1], s_pvm[BJ][BI + 1], s_pvn[BJ][BI + 1], s_sx[BJ][BI + 1], s_sy[BJ][BI + 1];
+  __shared__ int s_abort;
   const int tid = threadIdx.x;
   long long *prof = a.prof ? a.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
   int pslot = 0;
@@ -52,31 +68,36 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
   const bool inarr = act && gi >= 1 - NBDY && gi <= ii + NBDY && gj >= 1 - NBDY && gj <= jj + NBDY;
   const size_t np = V.nplane;
   const size_t c = inarr ? (size_t)IDX(V, gi, gj) : 0;
-  const double *g_pb = a.src ? V.f[F_pb_t2] : V.f[F_pb_t], *g_ub = a.src ? V.f[F_ubflx_t2] : V.f[F_ubflx_t];
-  const double *g_vb = a.src ? V.f[F_vbflx_t2] : V.f[F_vbflx_t];
-  double *o_pb = a.src ? V.f[F_pb_t] : V.f[F_pb_t2], *o_ub = a.src ? V.f[F_ubflx_t] : V.f[F_ubflx_t2];
-  double *o_vb = a.src ? V.f[F_vbflx_t] : V.f[F_vbflx_t2];
+  double *const b_pb[2] = {V.f[F_pb_t], V.f[F_pb_t2]}, *const b_ub[2] = {V.f[F_ubflx_t], V.f[F_ubflx_t2]};
+  double *const b_vb[2] = {V.f[F_vbflx_t], V.f[F_vbflx_t2]};
+  int src = a.src;                       // buffer set that holds the current state
   const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
-  if (act) {
-    // source of the state planes: the point itself, or -- single tile, halo point -- what xctilr
-    // would have put there (phy/mod_xc.F90:4374-4419): wrapped interior point or vland
-    size_t cs = c;
-    bool land = false;
-    if (a.fold_halo && inarr) {
-      const bool oi = gi < 1 || gi > ii, oj = gj < 1 || gj > jj;
-      if (oi || oj) {
-        land = (oi && (V.nreg == 0 || V.nreg == 4)) || (oj && V.nreg <= 2);
-        const int is = gi < 1 ? gi + ii : (gi > ii ? gi - ii : gi), js = gj < 1 ? gj + jj : (gj > jj ? gj - jj : gj);
-        cs = (size_t)IDX(V, is, js);
-      }
+  // source of the state planes: the point itself, or -- single tile, halo point -- what xctilr
+  // would have put there (phy/mod_xc.F90:4374-4419): wrapped interior point or vland
+  size_t cs = c;
+  bool land = false;
+  if (a.fold_halo && inarr) {
+    const bool oi = gi < 1 || gi > ii, oj = gj < 1 || gj > jj;
+    if (oi || oj) {
+      land = (oi && (V.nreg == 0 || V.nreg == 4)) || (oj && V.nreg <= 2);
+      const int is = gi < 1 ? gi + ii : (gi > ii ? gi - ii : gi), js = gj < 1 ? gj + jj : (gj > jj ? gj - jj : gj);
+      cs = (size_t)IDX(V, is, js);
     }
-    const bool ok = inarr && !land;
+  }
+  const bool ok_src = inarr && !land;
+  const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
+  auto load_state = [&](bool rim_only) {
+    if (!act || (rim_only && mine)) return;
+    const double *g_pb = b_pb[src], *g_ub = b_ub[src], *g_vb = b_vb[src];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
-      s_pb[l][lj][li] = ok ? g_pb[cs + l * np] : (inarr ? V.P.vland : 0.);
-      s_ub[l][lj][li] = ok ? g_ub[cs + l * np] : (inarr ? V.P.vland : 0.);
-      s_vb[l][lj][li] = ok ? g_vb[cs + l * np] : (inarr ? V.P.vland : 0.);
+      s_pb[l][lj][li] = ok_src ? g_pb[cs + l * np] : (inarr ? V.P.vland : 0.);
+      s_ub[l][lj][li] = ok_src ? g_ub[cs + l * np] : (inarr ? V.P.vland : 0.);
+      s_vb[l][lj][li] = ok_src ? g_vb[cs + l * np] : (inarr ? V.P.vland : 0.);
     }
+  };
+  load_state(false);
+  if (act) {
     s_pvo[lj][li] = inarr ? V.f[F_pvtrop_o][c] : 0.;
     s_pvm[lj][li] = inarr ? V.f[F_pvtrop][c + om] : 0.;
     s_pvn[lj][li] = inarr ? V.f[F_pvtrop][c + on] : 0.;
@@ -107,7 +128,6 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
     v_max = V.f[F_vmaxb][c]; v_min = V.f[F_vminb][c];
   }
   double us_acc = 0., uc_acc = 0., vs_acc = 0., vc_acc = 0.;     // ubflxs_t, ubcors_t, vbflxs_t, vbcors_t increments
-  const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
   if (mine) {
     if (wu) { us_acc = V.f[F_ubflxs_t][c]; uc_acc = V.f[F_ubcors_t][c]; }
     if (wv) { vs_acc = V.f[F_vbflxs_t][c]; vc_acc = V.f[F_vbcors_t][c]; }
@@ -117,16 +137,68 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
   PROF_MARK();
 
   int ml = a.ml - 1, nl = a.nl - 1;     // 0-based LDS level indices
-  // tile-local validity rectangle of what has been computed so far (inclusive, in li/lj)
-  int vlo_i = 0, vhi_i = BI - 1, vlo_j = 0, vhi_j = BJ - 1;
   const bool mom_scon = V.P.mommth == 0;
+  // persistent form: neighbour tiles (wrapped where the domain is periodic, none where it is closed)
+  const int nbx = gridDim.x, nby = gridDim.y;
+  int nb_tile = -1;                     // lanes 0..7 of wave 0 watch one neighbour each
+  if (PERSIST && tid < 8) {
+    const int dx = (tid < 3 ? -1 : (tid < 5 ? 0 : 1)), dy = (tid == 0 || tid == 3 || tid == 5) ? -1 : ((tid == 1 || tid == 6) ? 0 : 1);
+    // tid: 0 (-1,-1) 1 (-1,0) 2 (-1,1) 3 (0,-1) 4 (0,1) 5 (1,-1) 6 (1,0) 7 (1,1)
+    int qx = (int)blockIdx.x + dx, qy = (int)blockIdx.y + dy;
+    bool exists = true;
+    if (qx < 0 || qx >= nbx) { if (V.nreg == 0 || V.nreg == 4) exists = false; else qx = (qx + nbx) % nbx; }
+    if (qy < 0 || qy >= nby) { if (V.nreg <= 2) exists = false; else qy = (qy + nby) % nby; }
+    if (exists) nb_tile = qy * nbx + qx;
+  }
+  unsigned done_iters = 0;              // iterations this tile has completed
+  int lll = a.lll0;
+  bool aborted = false;
 
 #define IN(lo_i, hi_i, lo_j, hi_j) (act && li >= (lo_i) && li <= (hi_i) && lj >= (lo_j) && lj <= (hi_j))
 
+  do {
+  int do_odd = a.do_odd, do_even = a.do_even;
+  double wo_[2] = {a.wo[0], a.wo[1]}, wm_[2] = {a.wm[0], a.wm[1]}, wn_[2] = {a.wn[0], a.wn[1]};
+  if (PERSIST) {                        // the host loop of st_barotp (:352-360, :387-392), per iteration
+    const bool odd = lll % 2 == 1, both = odd && lll + 1 <= a.last;
+    for (int x = 0; x < 2; x++) {
+      const int l = both ? lll + x : lll;
+      wo_[x] = a.woa * l + a.wob;
+      wn_[x] = a.wna * l + a.wnb;
+      wm_[x] = 1. - wo_[x] - wn_[x];
+    }
+    if (!both && !odd) { wo_[1] = wo_[0]; wm_[1] = wm_[0]; wn_[1] = wn_[0]; }
+    do_odd = odd ? 1 : 0;
+    do_even = (both || !odd) ? 1 : 0;
+    lll += both ? 2 : 1;
+    if (done_iters > 0) {               // wait for the neighbours' previous iteration, then re-read the rim
+      if (tid < 64) {
+        bool ready = nb_tile < 0;
+        unsigned spins = 0;
+        while (true) {
+          if (!ready) ready = __hip_atomic_load(a.flags + nb_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= done_iters;
+          if (__all(ready)) break;
+          if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { aborted = true; break; }
+          if (++spins > 400000u) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // one LDS word tells the other waves about an abort
+      if (tid == 0) s_abort = aborted ? 1 : 0;
+      __syncthreads();
+      if (s_abort) break;
+      load_state(true);
+      __syncthreads();
+    }
+  }
+  // tile-local validity rectangle of what has been computed so far (inclusive, in li/lj)
+  int vlo_i = 0, vhi_i = BI - 1, vlo_j = 0, vhi_j = BJ - 1;
   for (int half = 0; half < 2; half++) {
-    if (half == 0 ? !a.do_odd : !a.do_even) continue;
+    if (half == 0 ? !do_odd : !do_even) continue;
     const bool odd = half == 0;
-    const double wo = a.wo[half], wm = a.wm[half], wn = a.wn[half];
+    const double wo = wo_[half], wm = wm_[half], wn = wn_[half];
     // ---- continuity: needs ub(i+1), vb(j+1) at level ml ------------------------------------------
     {
       const int r_i0 = odd ? -1 : 0, r_i1 = odd ? ii + 1 : ii, r_j0 = odd ? -1 : 0, r_j1 = odd ? jj + 2 : jj + 1;
@@ -211,13 +283,31 @@ __global__ void __launch_bounds__(NTHR) k_bt_pair(const DevView *Vp, PairArgs a)
     PROF_MARK();
     const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
   }
+  // publish the interior in the other buffer set
+  src ^= 1;
   if (mine) {
+    double *o_pb = b_pb[src], *o_ub = b_ub[src], *o_vb = b_vb[src];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
-      o_pb[c + l * np] = s_pb[l][lj][li];
-      o_ub[c + l * np] = s_ub[l][lj][li];
-      o_vb[c + l * np] = s_vb[l][lj][li];
+      if (PERSIST) {                     // write-through stores: visible to the other XCDs without a release fence
+        __hip_atomic_store(o_pb + c + l * np, s_pb[l][lj][li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o_ub + c + l * np, s_ub[l][lj][li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o_vb + c + l * np, s_vb[l][lj][li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        o_pb[c + l * np] = s_pb[l][lj][li];
+        o_ub[c + l * np] = s_ub[l][lj][li];
+        o_vb[c + l * np] = s_vb[l][lj][li];
+      }
     }
+  }
+  if (PERSIST) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the count goes out
+    __syncthreads();
+    done_iters++;
+    if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + blockIdx.x), done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  } while (PERSIST && lll <= a.last);
+  if (mine) {
     if (wu) { V.f[F_ubflxs_t][c] = us_acc; V.f[F_ubcors_t][c] = uc_acc; }
     if (wv) { V.f[F_vbflxs_t][c] = vs_acc; V.f[F_vbcors_t][c] = vc_acc; }
   }
@@ -283,8 +373,63 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
   a.fold_halo = c->tiling.multi() ? 0 : 1;
   a.prof = c->bt_prof;
+  a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr;
   dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
-  hipLaunchKernelGGL(k_bt_pair, grid, dim3(NTHR), 0, c->stream, c->d, a);
+  hipLaunchKernelGGL(k_bt_steps<false>, grid, dim3(NTHR), 0, c->stream, c->d, a);
+  return 0;
+}
+
+// Can the persistent form be used?  Every tile must be resident (one 896-thread workgroup per CU) and a
+// tile's rim must come from its direct neighbours only (also across the periodic seam).
+bool bt_phase_usable(blomgpu_ctx *c) {
+  const DevView &h = c->h;
+  if (c->tiling.multi()) return false;
+  const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
+  if (h.ii - (nbx - 1) * TI < HB || h.jj - (nby - 1) * TJ < HB) return false;
+  if (c->num_cus <= 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return false;
+    c->num_cus = prop.multiProcessorCount;
+  }
+  return nbx * nby <= c->num_cus;
+}
+
+// one launch for the substeps lll0..last of a phase; `src` as in bt_pair_launch; returns the buffer set
+// that holds the state afterwards in *src_out and the level indices in *ml_out, *nl_out
+int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
+                    int last, int src, int *src_out, int *ml_out, int *nl_out) {
+  const DevView &h = c->h;
+  const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
+  if (!c->bt_flags) HIPCHK(c, hipMalloc((void **)&c->bt_flags, sizeof(unsigned) * (nbx * nby + 16)));
+  HIPCHK(c, hipMemsetAsync(c->bt_flags, 0, sizeof(unsigned) * (nbx * nby + 16), c->stream));
+  PairArgs a;
+  a.m = m; a.n = n; a.ml = ml; a.nl = nl;
+  for (int x = 0; x < 2; x++) { a.wo[x] = a.wm[x] = a.wn[x] = 0.; }
+  a.do_odd = a.do_even = 0; a.src = src;
+  a.fold_halo = 1;
+  a.prof = nullptr;
+  a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
+  a.flags = c->bt_flags + 16;
+  a.abort_word = c->bt_flags;            // first word of the zeroed block
+  hipLaunchKernelGGL(k_bt_steps<true>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);
+  // replay the iteration bookkeeping of the kernel
+  for (int lll = lll0; lll <= last;) {
+    const bool odd = lll % 2 == 1, both = odd && lll + 1 <= last;
+    src ^= 1;
+    if (!both) { const int t = ml; ml = nl; nl = t; }
+    lll += both ? 2 : 1;
+  }
+  *src_out = src; *ml_out = ml; *nl_out = nl;
+  return 0;
+}
+
+// did any tile of the persistent launches give up waiting?  (checked once per barotp call)
+int bt_phase_check(blomgpu_ctx *c) {
+  if (!c->bt_flags) return 0;
+  unsigned w = 0;
+  HIPCHK(c, hipMemcpyAsync(&w, c->bt_flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (w) return ctx_fail(c, "barotp: a tile of the persistent substep kernel timed out waiting for its neighbours");
   return 0;
 }
 
