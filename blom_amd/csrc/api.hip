@@ -55,6 +55,27 @@ static void set_eos(Params &P) {
   P.ap16 = a16 - P.ap26 / alpha0;
 }
 
+int ctx_err_words(blomgpu_ctx *c) {
+  if (!c->err_dev) {
+    HIPCHK(c, hipMalloc((void **)&c->err_dev, sizeof(int) * 8));
+    HIPCHK(c, hipMemsetAsync(c->err_dev, 0, sizeof(int) * 8, c->stream));
+  }
+  return 0;
+}
+
+int ctx_check_errors(blomgpu_ctx *c) {
+  if (!c->err_dev) return 0;
+  int e[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (e[0] & 2) return ctx_fail(c, "blom: diapfl: no convergence in implicit diffusion!");        // mod_diapfl.F90:520-530
+  if (e[0] & 1) return ctx_fail(c, "blom: diapfl: no convergence in flux limit!");
+  if (e[1] & 1) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: no convergence");              // mod_eddtra.F90:536-555
+  if (e[1] & 2) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: flux bound violated");          // mod_eddtra.F90:640-660
+  if (e[2]) return ctx_fail(c, "barotp: a tile of the persistent substep kernel timed out waiting for its neighbours");
+  return 0;
+}
+
 extern "C" {
 
 const char *blomgpu_last_error(const blomgpu_ctx *ctx) {
@@ -352,8 +373,11 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
                                 "pbcor1", "diffus", "pgforc", "momtum", "diapfl", "mxlayr_tail",
                                 "barotp", "pbcor2", "tmsmt2"};
+    c->defer_checks = true;
     for (const char *st : seq)
-      if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) return rc;
+      if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
+    c->defer_checks = false;
+    if (int rc = ctx_check_errors(c)) return rc;
     c->h.P.delt1 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300
     c->dirty = true;
     *nstep = ns + 1;

@@ -172,6 +172,10 @@ struct blomgpu_ctx {
   bool cppm_ready = false;   // init_cppm has run (tables on the device)
   int cppm_compat = 1;       // 1 full, 2 partial            (phy/mod_cppm.F90:55-58)
   int cppm_limiting = 2;     // 1 monotonic, 2 non_oscillatory
+  // device error words: [0] diapfl, [1] eddtra, [2] barotp abort.  Stage entries read theirs back at once;
+  // blomgpu_step defers the read-back to the end of the step (one host sync per step instead of three)
+  int *err_dev = nullptr;
+  bool defer_checks = false;
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel
   int num_cus = 0;
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
@@ -216,6 +220,8 @@ int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_cppm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     // stage_cppm.hip, called by advect
 int st_init_cppm(blomgpu_ctx *);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
+int ctx_err_words(blomgpu_ctx *);            // allocate err_dev on first use
+int ctx_check_errors(blomgpu_ctx *);         // read back all error words, fail with the reference's message
 int st_kfpla_halo(blomgpu_ctx *, int n);   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off

@@ -309,6 +309,8 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   for (auto &x : hl)
     if (int rc = st_xctilr(c, h.f[x.f] + (size_t)x.lev * np, 1, 1, 1, x.nh, x.it)) return rc;
 
+  if (int rc = ctx_err_words(c)) return rc;
+  HIPCHK(c, hipMemsetAsync(c->err_dev + 2, 0, sizeof(int), c->stream));
   int lll0 = 1, ml = 1, nl = 2, set = 0;     // set: which buffer set (*_t / *_t2) holds the current state
   double woa = 0., wob = 0., wna = 0., wnb = 0.;
   for (int nb = 1; nb <= 5; nb++) {

@@ -410,7 +410,8 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   a.prof = nullptr;
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
-  a.abort_word = c->bt_flags;            // first word of the zeroed block
+  if (int rc = ctx_err_words(c)) return rc;
+  a.abort_word = (unsigned *)(c->err_dev + 2);
   hipLaunchKernelGGL(k_bt_steps<true>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);
   // replay the iteration bookkeeping of the kernel
   for (int lll = lll0; lll <= last;) {
@@ -425,26 +426,6 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
 
 // did any tile of the persistent launches give up waiting?  (checked once per barotp call)
 int bt_phase_check(blomgpu_ctx *c) {
-  if (!c->bt_flags) return 0;
-  unsigned w = 0;
-  HIPCHK(c, hipMemcpyAsync(&w, c->bt_flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (w) return ctx_fail(c, "barotp: a tile of the persistent substep kernel timed out waiting for its neighbours");
-  return 0;
-}
-
-// debug hook (not part of the C-ABI): per-block wall_clock64 timestamps of the last pair launch
-extern "C" int blomgpu_dbg_bt_profile(blomgpu_ctx *c, long long *host, int nblocks_max, int *nblocks) {
-  const DevView &h = c->h;
-  const int nb = ((h.ii + TI - 1) / TI) * ((h.jj + TJ - 1) / TJ);
-  *nblocks = nb;
-  if (!host) {                                    // arm
-    if (!c->bt_prof) HIPCHK(c, hipMalloc((void **)&c->bt_prof, sizeof(long long) * 16 * nb));
-    HIPCHK(c, hipMemset(c->bt_prof, 0, sizeof(long long) * 16 * nb));
-    return 0;
-  }
-  if (!c->bt_prof || nb > nblocks_max) return 1;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(host, c->bt_prof, sizeof(long long) * 16 * nb, hipMemcpyDeviceToHost));
-  return 0;
+  if (c->defer_checks) return 0;
+  return ctx_check_errors(c);
 }

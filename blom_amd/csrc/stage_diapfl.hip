@@ -471,8 +471,8 @@ int st_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) {
   const DevView &h = c->h;
   if (h.ntr > MAXTR || D_TTRC + h.ntr > h.nwk) return ctx_fail(c, "diapfl: device work space too small");
   if (h.P.vcoord_tag != 1) return ctx_fail(c, "diapfl is only called for isopyc_bulkml (phy/mod_blom_step.F90:172-186)");
-  static int *errflag = nullptr;
-  if (!errflag) HIPCHK(c, hipMalloc((void **)&errflag, sizeof(int)));
+  if (int rc = ctx_err_words(c)) return rc;
+  int *errflag = c->err_dev + 0;
   HIPCHK(c, hipMemsetAsync(errflag, 0, sizeof(int), c->stream));
   {
     TimeScope ts(c, "diapfl");
@@ -488,10 +488,6 @@ int st_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) {
   }
   HIPCHK(c, hipGetLastError());
   // the reference aborts (xchalt) when the implicit solve does not converge, :520-530
-  int e = 0;
-  HIPCHK(c, hipMemcpyAsync(&e, errflag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (e & 2) return ctx_fail(c, "blom: diapfl: no convergence in implicit diffusion!");
-  if (e & 1) return ctx_fail(c, "blom: diapfl: no convergence in flux limit!");
+  if (!c->defer_checks) return ctx_check_errors(c);
   return 0;
 }

@@ -253,8 +253,8 @@ int st_eddtra(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (h.P.vcoord_tag != 1) return ctx_fail(c, "eddtra: only vcoord = 'isopyc_bulkml' is built (eddtra_ale is not)");
   if (h.nwk < 2 * G_NSLOT) return ctx_fail(c, "eddtra: device work space too small");
-  static int *errflag = nullptr;
-  if (!errflag) HIPCHK(c, hipMalloc((void **)&errflag, sizeof(int)));
+  if (int rc = ctx_err_words(c)) return rc;
+  int *errflag = c->err_dev + 1;
   HIPCHK(c, hipMemsetAsync(errflag, 0, sizeof(int), c->stream));
   {
     TimeScope ts(c, "eddtra");
@@ -265,12 +265,6 @@ int st_eddtra(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     hipLaunchKernelGGL(k_eddtra_ts, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, mm);
   }
   HIPCHK(c, hipGetLastError());
-  if (h.P.eitmth == 2) {
-    int e = 0;
-    HIPCHK(c, hipMemcpyAsync(&e, errflag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (e & 1) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: no convergence");      // :536-555
-    if (e & 2) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: flux bound violated");   // :640-660
-  }
+  if (h.P.eitmth == 2 && !c->defer_checks) return ctx_check_errors(c);      // :536-555, :640-660
   return 0;
 }
