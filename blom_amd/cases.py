@@ -8,6 +8,8 @@ BASELINE.json's configs:
   channel  208x512x53 periodic in i / closed in j (nreg=1)  bld/channel/patch.input.1
   chan_s   20x24x6    small channel used by the parity tests
   chan_m   80x40x8    channel spanning several device tiles (kernel-variant tests)
+  tri_s    24x20x6    small ocean with the arctic patch of the tripolar grids (nreg=2): closed in the south,
+                      folded onto itself across the last row, periodic in i
   box_s    24x20x8    small closed basin with an island and a promontory coast
 
 The idealised definitions mirror the spirit of the reference's test cases
@@ -96,6 +98,7 @@ _DIMS = {
     # name: (idm, jdm, kdm, nreg, dx[m], baclin, batrop)
     "chan_s": (20, 24, 6, 1, 10.0e3, 900.0, 18.0),
     "chan_m": (80, 40, 8, 1, 10.0e3, 900.0, 18.0),     # several 32x8 device tiles, periodic in i
+    "tri_s": (24, 20, 6, 2, 10.0e3, 900.0, 18.0),      # periodic in i, arctic patch along the last row (nreg = 2)
     "box_s": (24, 20, 8, 0, 10.0e3, 900.0, 18.0),
     "fuk95": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
@@ -143,6 +146,17 @@ def _depth_for(name, idm, jdm, dx):
         d = np.broadcast_to(d, (jdm, idm)).copy()
         d[0, :] = 0.0
         d[-1, :] = 0.0
+        return d
+    if name == "tri_s":
+        # open ocean up to the arctic seam, a southern coast, one continent reaching the seam; the last
+        # row is overwritten with the mirror image of the row below it by the arctic halo rule
+        x = (ii - 0.5) / idm
+        y = (jj - 0.5) / jdm
+        d = 400.0 + 400.0 * (0.5 + 0.5 * np.sin(2.0 * np.pi * x)) * np.sin(0.5 * np.pi * y) + 0.0 * (ii + jj)
+        d[0, :] = 0.0
+        d[1:3, 3:9] = 0.0
+        d[jdm - 6:, 15:19] = 0.0           # land touching the seam
+        d[8:11, 5:8] = 0.0                 # island
         return d
     if name == "fuk95":
         d = np.full((jdm, idm), 200.0)     # fuk95/mod_fuk95.F90:126-134 flat, walls in i

@@ -46,6 +46,57 @@ __global__ void k_xctilr_gather(const DevView *Vp, double *__restrict__ a, HaloS
   }
 }
 
+// Arctic patch (nreg = 2, one tile), phy/mod_xc.F90:4262-4372: closed in the south, periodic in i,
+// and across the last row the grid folds onto itself -- row jj+j takes the mirrored row jj-1-j (p-,
+// u-grid, from j = 0: row jj itself is a copy) or jj-j (q-, v-grid, where only the second half of row
+// jj is a copy), vector fields change sign.  The reference's three sweeps only move data, so every
+// target (south rows, rows jj.., E/W strips of all those rows) is one composite gather; no source is
+// itself a target.
+__global__ void k_xctilr_arctic(const DevView *Vp, double *__restrict__ a, int nlev, int mhl, int nhl, int itype) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj;
+  const int g = itype % 10;
+  const double sgn = itype > 10 ? -1. : 1.;
+  // targets: rows 1-nhl..0 and jj..jj+nhl over i = 1-mhl..ii+mhl, plus E/W strips of rows 1..jj-1
+  const int wrow = ii + 2 * mhl, nrow = 2 * nhl + 1;
+  const int nrowpts = nrow * wrow, nside = 2 * mhl * (jj - 1);
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nrowpts + nside) return;
+  int i, j;
+  if (t < nrowpts) {
+    const int r = t / wrow;
+    i = t % wrow + 1 - mhl;
+    j = r < nhl ? -r : jj + (r - nhl);            // 0,-1,..,1-nhl ; jj, jj+1, .., jj+nhl
+  } else {
+    t -= nrowpts;
+    const int cidx = t % (2 * mhl);
+    j = t / (2 * mhl) + 1;                        // 1..jj-1
+    i = cidx < mhl ? -cidx : ii + (cidx - mhl) + 1;
+  }
+  const int iw = i < 1 ? i + ii : (i > ii ? i - ii : i);      // periodic in i
+  bool land = false, flip = false;
+  int is = iw, js = j;
+  if (j < 1) land = true;
+  else if (j >= jj) {
+    const int d = j - jj;
+    if (g == 1 || g == 3) {                                   // p-, u-grid
+      is = g == 1 ? ii - (iw - 1) % ii : (ii - (iw - 1)) % ii + 1;
+      js = jj - 1 - d;
+      flip = true;
+    } else if (d > 0 || iw > ii / 2) {                        // q-, v-grid
+      is = g == 2 ? (ii - (iw - 1)) % ii + 1 : ii - (iw - 1) % ii;
+      js = jj - d;
+      flip = true;
+    }
+  }
+  if (!land && !flip && i == iw) return;                      // first half of row jj on the q-/v-grid: not a target
+  const size_t dst = IDX(V, i, j), src = IDX(V, is, js);
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[dst + o] = land ? V.P.vland : (flip ? sgn * a[src + o] : a[src + o]);
+  }
+}
+
 #include <pthread.h>
 struct TileGroup {
   int npx, npy;
@@ -67,16 +118,24 @@ static inline bool ew_periodic(int nreg) { return !(nreg == 0 || nreg == 4); }
 static inline bool ns_periodic(int nreg) { return nreg > 2; }
 
 int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int itype) {
-  (void)itype;   // only distinguishes grids/vectors across the arctic seam (phy/mod_xc.F90:4248-4250)
+  // itype only distinguishes grids/vectors across the arctic seam (phy/mod_xc.F90:4248-4250)
   const DevView &h = c->h;
-  if (h.nreg == 2) return ctx_fail(c, "xctilr: tripolar seam (nreg=2) not built yet");
   const int mhl = mh < 0 ? 0 : (mh > NBDY ? NBDY : mh);
   const int nhl = nh < 0 ? 0 : (nh > NBDY ? NBDY : nh);
   const int nlev = ld - l1 + 1;
-  const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
-  if (ntarget == 0 || nlev <= 0) return 0;
   double *a = base + (size_t)(l1 - 1) * h.nplane;
   const Tiling &T = c->tiling;
+  if (h.nreg == 2) {
+    if (T.multi()) return ctx_fail(c, "xctilr: the arctic patch (nreg=2) is built for a single tile only");
+    if (nlev <= 0) return 0;
+    const int nt = (2 * nhl + 1) * (h.ii + 2 * mhl) + 2 * mhl * (h.jj - 1);
+    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
+    hipLaunchKernelGGL(k_xctilr_arctic, grid, dim3(256), 0, c->stream, c->d, a, nlev, mhl, nhl, itype);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
+  if (ntarget == 0 || nlev <= 0) return 0;
   if (T.rccl) return rccl_xctilr(c, a, nlev, mhl, nhl);
   if (!T.group && (h.itdm != h.ii || h.jtdm != h.jj))
     return ctx_fail(c, "xctilr: this context is one tile of a larger domain but no halo transport is attached");

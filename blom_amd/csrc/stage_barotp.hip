@@ -280,6 +280,23 @@ __global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, i
   }
 }
 
+// with the arctic patch umaxb/uminb, vmaxb/vminb, xixp/xixm, xiyp/xiym change roles in the halo next to the
+// grid intersection, phy/mod_barotp.F90:290-325
+__global__ void k_bt_arctic_swap(const DevView *Vp, int n) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (i < 0 || i > V.ii + 1 || j < V.jj || j > V.jj + 2) return;
+  const size_t c = t, on = (size_t)(n - 1) * V.nplane;
+  double q = V.f[F_umaxb][c]; V.f[F_umaxb][c] = V.f[F_uminb][c]; V.f[F_uminb][c] = q;
+  q = V.f[F_xixp][c + on]; V.f[F_xixp][c + on] = V.f[F_xixm][c + on]; V.f[F_xixm][c + on] = q;
+  if (j > V.jj || i >= V.ii / 2 + 1) {
+    q = V.f[F_vmaxb][c]; V.f[F_vmaxb][c] = V.f[F_vminb][c]; V.f[F_vminb][c] = q;
+    q = V.f[F_xiyp][c + on]; V.f[F_xiyp][c + on] = V.f[F_xiym][c + on]; V.f[F_xiym][c + on] = q;
+  }
+}
+
 int bt_pair_halo(blomgpu_ctx *c, int set);
 bool bt_phase_usable(blomgpu_ctx *c);
 int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
@@ -293,7 +310,6 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   const size_t np = h.nplane;
   const int ii = h.ii, jj = h.jj, lstep = h.P.lstep;
-  if (h.nreg == 2) return ctx_fail(c, "barotp: tripolar seam (nreg=2) not built yet");
   if (lstep < 2 || lstep % 2) return ctx_fail(c, "barotp: lstep must be even (phy/mod_time.F90:137-139)");
   const dim3 g = plane_grid(h), b(256);
   TimeScope ts(c, "barotp");
@@ -309,6 +325,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   for (auto &x : hl)
     if (int rc = st_xctilr(c, h.f[x.f] + (size_t)x.lev * np, 1, 1, 1, x.nh, x.it)) return rc;
 
+  if (h.nreg == 2) hipLaunchKernelGGL(k_bt_arctic_swap, g, b, 0, c->stream, c->d, n);       // :290-325
   if (int rc = ctx_err_words(c)) return rc;
   HIPCHK(c, hipMemsetAsync(c->err_dev + 2, 0, sizeof(int), c->stream));
   int lll0 = 1, ml = 1, nl = 2, set = 0;     // set: which buffer set (*_t / *_t2) holds the current state
@@ -329,13 +346,17 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     }
     hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
     const int last = lll0 + lstep / 2 - 1;
-    if (c->barotp_fused && c->barotp_persist && bt_phase_usable(c)) {
+    // With the arctic patch the halo update also rewrites the seam row jj, an interior row, so it must
+    // happen exactly where the reference has it (before odd substeps only); the fused kernels need their
+    // rim refreshed before a lone even substep as well, hence nreg = 2 takes the one-kernel-per-equation path.
+    const bool fused = c->barotp_fused && h.nreg != 2;
+    if (fused && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
       // their edge values through memory
       int so, mo, no;
       if (int rc = bt_phase_launch(c, m, n, ml, nl, woa, wob, wna, wnb, lll0, last, set, &so, &mo, &no)) return rc;
       set = so; ml = mo; nl = no;
-    } else if (c->barotp_fused) {
+    } else if (fused) {
       // fused odd+even substep pairs per LDS tile (stage_barotp_pair.hip); single substeps only
       // where a pair would straddle a phase boundary (epilogue + sum reset sit in between)
       int lll = lll0;
@@ -351,7 +372,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
         if (!both && !odd) { wo[1] = wo[0]; wm[1] = wm[0]; wn[1] = wn[0]; }
         // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
-        if (c->tiling.multi())
+        if (c->tiling.multi() || h.nreg == 2)
           if (int rc = bt_pair_halo(c, set)) return rc;
         bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set);
         set ^= 1;
@@ -387,11 +408,11 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     }
     lll0 = lll0 + lstep / 2;
     // the epilogue reads pb_t(i-1,j), pb_t(i,j-1); the fused kernels write tile interiors only
-    if (c->barotp_fused)
+    if (fused)
       if (int rc = bt_pair_halo(c, set)) return rc;
     hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl, set);
   }
   HIPCHK(c, hipGetLastError());
-  if (c->barotp_fused && c->barotp_persist && bt_phase_usable(c)) return bt_phase_check(c);
+  if (c->barotp_fused && h.nreg != 2 && c->barotp_persist && bt_phase_usable(c)) return bt_phase_check(c);
   return 0;
 }

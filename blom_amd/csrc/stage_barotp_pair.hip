@@ -350,7 +350,7 @@ __global__ void k_bt_halo3(const DevView *Vp, int set, int mhl, int nhl) {
 
 int bt_pair_halo(blomgpu_ctx *c, int set) {
   const DevView &h = c->h;
-  if (c->tiling.multi()) {            // neighbour exchange through the tile transport
+  if (c->tiling.multi() || h.nreg == 2) {   // neighbour exchange through the tile transport / the arctic rule of xctilr
     double *f[3] = {set ? h.f[F_pb_t2] : h.f[F_pb_t], set ? h.f[F_ubflx_t2] : h.f[F_ubflx_t],
                     set ? h.f[F_vbflx_t2] : h.f[F_vbflx_t]};
     static const int it[3] = {1, 13, 14};
@@ -371,7 +371,7 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;
   for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
-  a.fold_halo = c->tiling.multi() ? 0 : 1;
+  a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
   a.prof = c->bt_prof;
   a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr;
   dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
@@ -383,7 +383,7 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
 // tile's rim must come from its direct neighbours only (also across the periodic seam).
 bool bt_phase_usable(blomgpu_ctx *c) {
   const DevView &h = c->h;
-  if (c->tiling.multi()) return false;
+  if (c->tiling.multi() || h.nreg == 2) return false;
   const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
   if (h.ii - (nbx - 1) * TI < HB || h.jj - (nby - 1) * TJ < HB) return false;
   if (c->num_cus <= 0) {

@@ -29,13 +29,42 @@ def sl(lo, hi):
 # ----------------------------------------------------------------------------------
 # xctilr, single tile (phy/mod_xc.F90:4374-4419; arctic form not needed for nreg != 2)
 # ----------------------------------------------------------------------------------
-def xctilr_np(a, l1, ld, mh, nh, nreg, ii, jj, vland=0.0):
-    """In-place halo update of levels l1..ld (1-based) of a (nlev, nj, ni) array."""
-    assert nreg in (0, 1, 3, 4), "tripolar seam (nreg=2) is handled on the device only"
+def xctilr_np(a, l1, ld, mh, nh, nreg, ii, jj, vland=0.0, itype=1):
+    """In-place halo update of levels l1..ld (1-based) of a (nlev, nj, ni) array.
+    nreg = 2 (arctic patch, single tile): phy/mod_xc.F90:4262-4372 -- closed in the south, the
+    northern rows mirrored across the arctic seam according to the grid (itype % 10: 1 p, 2 q,
+    3 u, 4 v) with a sign change for vector fields (itype > 10), periodic in i."""
     mhl = max(0, min(mh, NBDY))
     nhl = max(0, min(nh, NBDY))
     v = a[l1 - 1:ld]
     o = NBDY - 1            # index of Fortran 0
+    if nreg == 2:
+        sgn = -1.0 if itype > 10 else 1.0
+        g = itype % 10
+        i = np.arange(1, ii + 1)
+        if nhl > 0:
+            v[:, o + 1 - nhl:o + 1, sl(1, ii)] = vland
+        if g in (1, 4):
+            io = ii - (i - 1) % ii                      # p-, v-grid
+        else:
+            io = (ii - (i - 1)) % ii + 1                # q-, u-grid
+        if g in (1, 3):                                 # p-, u-grid: rows jj..jj+nhl <- rows jj-1..jj-1-nhl
+            for j in range(0, nhl + 1):
+                v[:, o + jj + j, o + i] = sgn * v[:, o + jj - 1 - j, o + io]
+        else:                                           # q-, v-grid: second half of row jj, rows jj+1..
+            h = i > ii // 2
+            v[:, o + jj, o + i[h]] = sgn * v[:, o + jj, o + io[h]]
+            for j in range(1, nhl + 1):
+                v[:, o + jj + j, o + i] = sgn * v[:, o + jj - j, o + io]
+        if mhl > 0:
+            # the reference's E/W loop runs over k = 1..ld (not l1..ld); same data movement for the
+            # levels a caller passes, which is all this helper is given
+            js = sl(1 - nhl, jj + nhl)
+            for q in range(1, mhl + 1):
+                v[:, js, o + 1 - q] = v[:, js, o + ii + 1 - q]
+                v[:, js, o + ii + q] = v[:, js, o + q]
+        return
+    assert nreg in (0, 1, 3, 4)
     if nhl > 0:
         if nreg <= 2:       # closed in latitude
             v[:, o + 1 - nhl:o + 1, sl(1, ii)] = vland
@@ -58,15 +87,21 @@ def xctilr_np(a, l1, ld, mh, nh, nreg, ii, jj, vland=0.0):
 # ----------------------------------------------------------------------------------
 # bigrid: integer masks (bit-exact integer work)
 # ----------------------------------------------------------------------------------
-def bigrid_np(depth_in, idm, jdm):
+def bigrid_np(depth_in, idm, jdm, arctic=False):
     """Returns (nreg, depth_with_halo, ip, iu, iv, iq) following phy/mod_bigrid.F90:59-302
-    for a single tile (i0=j0=0, ii=idm, jj=jdm)."""
+    for a single tile (i0=j0=0, ii=idm, jj=jdm).  Water in the last row means periodicity in j, or
+    -- with `arctic`, the reference's nreg = 2 from patch.input -- the arctic patch (:77-78)."""
     ii, jj = idm, jdm
     depth = depth_in.copy()
     o = NBDY - 1
     lperiodi = depth[sl(1, jj), o + ii].max() > 0.0
-    lperiodj = depth[o + jj, sl(1, ii)].max() > 0.0
-    if not lperiodi and not lperiodj:
+    top = depth[o + jj, sl(1, ii)].max() > 0.0
+    larctic = top and arctic
+    lperiodj = top and not arctic
+    if larctic:
+        assert lperiodi, "the arctic patch needs a domain that is periodic in i"
+        nreg = 2
+    elif not lperiodi and not lperiodj:
         nreg = 0
     elif lperiodi and not lperiodj:
         nreg = 1
@@ -75,10 +110,11 @@ def bigrid_np(depth_in, idm, jdm):
     else:
         nreg = 4
     d3 = depth[None]
-    xctilr_np(d3, 1, 1, NBDY, NBDY, nreg, ii, jj)
+    xctilr_np(d3, 1, 1, NBDY, NBDY, nreg, ii, jj, itype=1)
     if not lperiodj:
         depth[:o + 1, :] = 0.0
-        depth[o + jj + 1:, :] = 0.0
+        if not larctic:
+            depth[o + jj + 1:, :] = 0.0
     if not lperiodi:
         depth[:, :o + 1] = 0.0
         depth[:, o + ii + 1:] = 0.0
@@ -94,13 +130,14 @@ def bigrid_np(depth_in, idm, jdm):
     allfour = np.minimum(np.minimum(ip[J, I], ip[J, Im]), np.minimum(ip[Jm, I], ip[Jm, Im])) > 0
     diag = ((ip[J, I] > 0) & (ip[Jm, Im] > 0)) | ((ip[J, Im] > 0) & (ip[Jm, I] > 0))
     iq[J, I] = (allfour | diag).astype(np.int32)
-    for msk in (iu, iv, iq):
+    for msk, it in ((iu, 3), (iv, 4), (iq, 2)):               # halo_us, halo_vs, halo_qs, :249-251
         f = msk.astype(np.float64)[None]
-        xctilr_np(f, 1, 1, NBDY, NBDY, nreg, ii, jj)
+        xctilr_np(f, 1, 1, NBDY, NBDY, nreg, ii, jj, itype=it)
         msk[:, :] = np.rint(f[0]).astype(np.int32)
         if not lperiodj:
             msk[:o + 1, :] = 0
-            msk[o + jj + 1:, :] = 0
+            if not larctic:
+                msk[o + jj + 1:, :] = 0
         if not lperiodi:
             msk[:, :o + 1] = 0
             msk[:, o + ii + 1:] = 0
@@ -125,17 +162,17 @@ def numerical_bounds_np(grid, masks, baclin, nreg, ii, jj):
     vm = .9 * .125 * np.minimum(scp2[Jm, I], scp2[J, I]) / (scvx[J, I] * baclin)
     umax[J, I] = np.where(masks["iu"][J, I] > 0, um, 0.0)
     vmax[J, I] = np.where(masks["iv"][J, I] > 0, vm, 0.0)
-    for a in (umax, vmax):
-        xctilr_np(a[None], 1, 1, NBDY, NBDY, nreg, ii, jj)
+    for a, it in ((umax, 3), (vmax, 4)):                 # halo_us, halo_vs
+        xctilr_np(a[None], 1, 1, NBDY, NBDY, nreg, ii, jj, itype=it)
     return difmxp, difmxq, umax, vmax
 
 
 # ----------------------------------------------------------------------------------
 # the initialisation sequence proper
 # ----------------------------------------------------------------------------------
-def _halo(be, name, nlev, mh, nh, nreg, ii, jj, l1=1):
+def _halo(be, name, nlev, mh, nh, nreg, ii, jj, l1=1, itype=1):
     a = be.get(name)
-    xctilr_np(a, l1, nlev, mh, nh, nreg, ii, jj)
+    xctilr_np(a, l1, nlev, mh, nh, nreg, ii, jj, itype=itype)
     be.put(name, a)
 
 
@@ -334,7 +371,7 @@ def init_state(be, case):
             be.put(nm, a)
 
     # -- geopotential of the sea floor (cf. channel/mod_channel.F90:311-320) ------------
-    _, depth_h, _, _, _, _ = bigrid_np(case.depth, ii, jj)
+    _, depth_h, _, _, _, _ = bigrid_np(case.depth, ii, jj, arctic=nreg == 2)
     phi = be.get("phi")
     phi[kk] = np.where(wfull, -GRAV * depth_h, phi[kk])
     be.put("phi", phi)
@@ -362,16 +399,41 @@ def init_state(be, case):
     be.put("dpold", dpold)
     be.stage("initms", 2, 1, kk, 0, kk + 1, 1)
 
-    # -- halo updates of blom_init_phase2 (mod_blom_init.F90:360-378) --------------------
-    for nm, nl, mh, nh in (("sigmar", kk, 2, 2), ("uflx", 2 * kk, 1, 1), ("vflx", 2 * kk, 1, 1),
-                           ("pvtrop", 2, 1, 3), ("pgfxm", 2, 1, 2), ("xixp", 2, 1, 2),
-                           ("xixm", 2, 1, 2), ("pgfym", 2, 1, 2), ("xiyp", 2, 1, 2),
-                           ("xiym", 2, 1, 2), ("difiso", kk, 1, 1), ("taux", 1, 1, 1),
-                           ("tauy", 1, 1, 1)):
-        _halo(be, nm, nl, mh, nh, nreg, ii, jj)
+    # -- halo updates of blom_init_phase2 (mod_blom_init.F90:360-378), with the grid/field types that
+    #    matter across the arctic seam (halo_ps 1, halo_qs 2, halo_us 3, halo_vs 4, halo_uv 13, halo_vv 14)
+    for nm, nl, mh, nh, it in (("sigmar", kk, 2, 2, 1), ("uflx", 2 * kk, 1, 1, 13), ("vflx", 2 * kk, 1, 1, 14),
+                               ("pvtrop", 2, 1, 3, 2), ("pgfxm", 2, 1, 2, 13), ("xixp", 2, 1, 2, 3),
+                               ("xixm", 2, 1, 2, 3), ("pgfym", 2, 1, 2, 14), ("xiyp", 2, 1, 2, 4),
+                               ("xiym", 2, 1, 2, 4), ("difiso", kk, 1, 1, 1), ("taux", 1, 1, 1, 13),
+                               ("tauy", 1, 1, 1, 14)):
+        _halo(be, nm, nl, mh, nh, nreg, ii, jj, itype=it)
     a = be.get("phi")
     xctilr_np(a, kk + 1, kk + 1, 2, 2, nreg, ii, jj)
     be.put("phi", a)
+    if nreg == 2:
+        # with the arctic patch xixp <-> xixm and xiyp <-> xiym change roles in the halo next to the
+        # grid intersection (mod_blom_init.F90:380-400)
+        xp, xm = be.get("xixp"), be.get("xixm")
+        Js, Is = sl(jj, jj + 2), sl(0, ii + 1)
+        for lev in (0, 1):
+            t = xp[lev, Js, Is].copy()
+            xp[lev, Js, Is] = xm[lev, Js, Is]
+            xm[lev, Js, Is] = t
+        be.put("xixp", xp)
+        be.put("xixm", xm)
+        yp, ym = be.get("xiyp"), be.get("xiym")
+        o = NBDY - 1
+        Iy = sl(max(0, ii // 2 + 1), ii + 1)
+        J2, I2 = sl(jj + 1, jj + 2), sl(0, ii + 1)
+        for lev in (0, 1):
+            t = yp[lev, o + jj, Iy].copy()
+            yp[lev, o + jj, Iy] = ym[lev, o + jj, Iy]
+            ym[lev, o + jj, Iy] = t
+            t = yp[lev, J2, I2].copy()
+            yp[lev, J2, I2] = ym[lev, J2, I2]
+            ym[lev, J2, I2] = t
+        be.put("xiyp", yp)
+        be.put("xiym", ym)
 
 
 def step_indices(nstep, kk):

@@ -95,7 +95,6 @@ void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)mm; (void)k1m; (void)k1n;
   const int ii = S->ii, jj = S->jj, kk = S->kk, lstep = S->lstep;
   const size_t lev = (size_t)S->nplane;
-  if (S->nreg == 2) abort();
   /* :177-224 */
   for (int j = 1; j <= jj; j++)
     for (int i = 1; i <= ii; i++) {
@@ -158,6 +157,18 @@ void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
   orc_xctilr(S, S->pgfym + lev * (n - 1), 1, 1, 1, 2, 14);
   orc_xctilr(S, S->xiyp + lev * (n - 1), 1, 1, 1, 2, 4);
   orc_xctilr(S, S->xiym + lev * (n - 1), 1, 1, 1, 2, 4);
+  if (S->nreg == 2) { /* arctic patch: the min/max and +/- fields change roles across the seam, :290-325 */
+    const int ii_ = S->ii, jj_ = S->jj;
+#define SWAP(a, b) { const double q_ = (a); (a) = (b); (b) = q_; }
+    for (int j = jj_; j <= jj_ + 2; j++)
+      for (int i = 0; i <= ii_ + 1; i++) { SWAP(A2(S, umaxb, i, j), A2(S, uminb, i, j)); SWAP(A3(S, xixp, i, j, n), A3(S, xixm, i, j, n)); }
+    for (int i = (ii_ / 2 + 1 > 0 ? ii_ / 2 + 1 : 0); i <= ii_ + 1; i++) {
+      SWAP(A2(S, vmaxb, i, jj_), A2(S, vminb, i, jj_)); SWAP(A3(S, xiyp, i, jj_, n), A3(S, xiym, i, jj_, n));
+    }
+    for (int j = jj_ + 1; j <= jj_ + 2; j++)
+      for (int i = 0; i <= ii_ + 1; i++) { SWAP(A2(S, vmaxb, i, j), A2(S, vminb, i, j)); SWAP(A3(S, xiyp, i, j, n), A3(S, xiym, i, j, n)); }
+#undef SWAP
+  }
 
   int lll0 = 1, ml = 1, nl = 2;
   double woa = 0., wob = 0., wna = 0., wnb = 0.;

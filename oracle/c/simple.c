@@ -4,10 +4,39 @@
 
 /* xctilr, serial non-arctic form, phy/mod_xc.F90:4374-4419 */
 void orc_xctilr(OState *S, double *a, int l1, int ld, int mh, int nh, int itype) {
-  (void)itype;
   const int ii = S->ii, jj = S->jj;
   const int mhl = imax2(0, imin2(mh, NBDY)), nhl = imax2(0, imin2(nh, NBDY));
 #define A(i, j, k) a[IX(S, i, j) + (size_t)S->nplane * ((k)-1)]
+  if (S->nreg == 2) { /* arctic patch, phy/mod_xc.F90:4262-4372 */
+    const double sgn = itype > 10 ? -1. : 1.;
+    const int g = itype % 10;
+    for (int k = l1; k <= ld; k++) {
+      for (int j = 1; j <= nhl; j++)
+        for (int i = 1; i <= ii; i++) A(i, 1 - j, k) = S->vland;
+      if (g == 1 || g == 3) { /* p-, u-grid */
+        for (int j = 0; j <= nhl; j++)
+          for (int i = 1; i <= ii; i++) {
+            const int io = g == 1 ? ii - (i - 1) % ii : (ii - (i - 1)) % ii + 1;
+            A(i, jj + j, k) = sgn * A(io, jj - 1 - j, k);
+          }
+      } else { /* q-, v-grid */
+        for (int i = ii / 2 + 1; i <= ii; i++) {
+          const int io = g == 2 ? (ii - (i - 1)) % ii + 1 : ii - (i - 1) % ii;
+          A(i, jj, k) = sgn * A(io, jj, k);
+        }
+        for (int j = 1; j <= nhl; j++)
+          for (int i = 1; i <= ii; i++) {
+            const int io = g == 2 ? (ii - (i - 1)) % ii + 1 : ii - (i - 1) % ii;
+            A(i, jj + j, k) = sgn * A(io, jj - j, k);
+          }
+      }
+    }
+    if (mhl > 0) /* the reference runs this loop over k = 1..ld; callers here always pass l1 = 1 or own the levels */
+      for (int k = l1; k <= ld; k++)
+        for (int j = 1 - nhl; j <= jj + nhl; j++)
+          for (int i = 1; i <= mhl; i++) { A(1 - i, j, k) = A(ii + 1 - i, j, k); A(ii + i, j, k) = A(i, j, k); }
+    return;
+  }
   if (nhl > 0) {
     if (S->nreg <= 2) {
       for (int k = l1; k <= ld; k++)

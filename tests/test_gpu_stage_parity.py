@@ -70,7 +70,7 @@ def _run(cfg, nsteps, stages, **overrides):
     assert not failures, "\n".join(failures[:40])
 
 
-@pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s"])
 def test_stage_parity_small(cfg):
     _run(cfg, 4, GPU_STAGES)
 
@@ -133,3 +133,26 @@ def test_freerun_device_resident(cfg, nsteps, rtol):
     bad = diff_report(ref, gpu, fields=FREERUN_FIELDS, rtol=rtol, atol=rtol)
     gpu.close()
     assert not bad, fmt_report(bad)
+
+
+@pytest.mark.parametrize("itype", [1, 2, 3, 4, 11, 12, 13, 14])
+def test_xctilr_arctic_patch_matches_reference(itype):
+    """nreg = 2: the device halo update for every grid/field type (phy/mod_xc.F90:107-110, :4262-4372)
+    against the reference built with ARCTIC, through the C-ABI."""
+    from oracle.refblom import get_ref_backend, have_ref
+    from blom_amd.gpu import BlomGpu
+    if not have_ref("tri_s"):
+        pytest.skip("oracle/_ref/tri_s/libblomref.so not built")
+    case = make_case("tri_s")
+    ref = get_ref_backend("tri_s", case.depth)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
+    rng = np.random.default_rng(itype)
+    kk = case.kdm
+    for mh, nh in ((0, 0), (1, 1), (2, 3), (4, 4), (3, 0), (0, 2)):
+        a = rng.standard_normal((2 * kk, case.jdm + 8, case.idm + 8))
+        b = a.copy()
+        gpu.put("u", a)
+        gpu.xctilr("u", 1, 1, 2 * kk, mh, nh, itype)
+        ref.ref.xctilr(b, 1, 2 * kk, mh, nh, itype)
+        assert np.array_equal(gpu.get("u"), b), (itype, mh, nh)
+    gpu.close()

@@ -57,3 +57,26 @@ def test_step_indices_follow_blom_step():
     assert hostinit.step_indices(0, 12) == (1, 2, 0, 12, 1, 13)
     assert hostinit.step_indices(1, 12) == (2, 1, 12, 0, 13, 1)
     assert hostinit.step_indices(6, 53) == (1, 2, 0, 53, 1, 54)
+
+
+def test_arctic_patch_masks_and_halo_rule_match_reference():
+    """nreg = 2 (tripolar grids): bigrid_np's masks and xctilr_np for every grid/field type
+    (phy/mod_xc.F90:107-110) against the reference built with ARCTIC for the tri_s grid."""
+    from oracle.refblom import get_ref_backend, have_ref
+    if not have_ref("tri_s"):
+        pytest.skip("reference library for tri_s not built")
+    case = make_case("tri_s")
+    ref = get_ref_backend("tri_s", case.depth)
+    assert ref.nreg == 2
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=True)
+    assert nreg == 2
+    for nm, a in (("ip", ip), ("iu", iu), ("iv", iv), ("iq", iq)):
+        assert np.array_equal(a, ref.masks[nm]), nm
+    rng = np.random.default_rng(11)
+    for itype in (1, 2, 3, 4, 11, 12, 13, 14):
+        for mh, nh in ((0, 0), (1, 1), (2, 3), (4, 4), (3, 0), (0, 2)):
+            a = rng.standard_normal((3, case.jdm + 8, case.idm + 8))
+            b = a.copy()
+            hostinit.xctilr_np(a, 1, 3, mh, nh, 2, case.idm, case.jdm, itype=itype)
+            ref.ref.xctilr(b, 1, 3, mh, nh, itype)
+            assert np.array_equal(a, b), (itype, mh, nh)
