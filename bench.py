@@ -35,7 +35,7 @@ def build_case(cfg):
     from blom_amd.cases import make_case
     from blom_amd import hostinit
     case = make_case(cfg, nslp0=NSLP0)
-    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     return case, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq)
 
 

@@ -8,6 +8,7 @@ BASELINE.json's configs:
   channel  208x512x53 periodic in i / closed in j (nreg=1)  bld/channel/patch.input.1
   chan_s   20x24x6    small channel used by the parity tests
   chan_m   80x40x8    channel spanning several device tiles (kernel-variant tests)
+  tnx2v1s  180x193x53 synthetic stand-in for the tnx2v1 tripolar production grid (nreg=2)
   tri_s    24x20x6    small ocean with the arctic patch of the tripolar grids (nreg=2): closed in the south,
                       folded onto itself across the last row, periodic in i
   box_s    24x20x8    small closed basin with an island and a promontory coast
@@ -99,6 +100,9 @@ _DIMS = {
     "chan_s": (20, 24, 6, 1, 10.0e3, 900.0, 18.0),
     "chan_m": (80, 40, 8, 1, 10.0e3, 900.0, 18.0),     # several 32x8 device tiles, periodic in i
     "tri_s": (24, 20, 6, 2, 10.0e3, 900.0, 18.0),      # periodic in i, arctic patch along the last row (nreg = 2)
+    # synthetic stand-in for the tnx2v1 production grid: its dimensions, region type
+    # and time steps (baclin 4800 s, batrop 96 s => lstep 50); analytic continents instead of grid.nc
+    "tnx2v1s": (180, 193, 53, 2, 100.0e3, 4800.0, 96.0),
     "box_s": (24, 20, 8, 0, 10.0e3, 900.0, 18.0),
     "fuk95": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
@@ -147,6 +151,18 @@ def _depth_for(name, idm, jdm, dx):
         d[0, :] = 0.0
         d[-1, :] = 0.0
         return d
+    if name == "tnx2v1s":
+        x = (ii - 0.5) / idm
+        y = (jj - 0.5) / jdm
+        d = 3000.0 + 1500.0 * np.sin(2.0 * np.pi * x) * np.sin(np.pi * y) + 0.0 * (ii + jj)
+        d[0:4, :] = 0.0                                           # antarctic coast
+        # two meridional continents with shelves, one reaching the arctic seam
+        for x0, w, j0, j1 in ((0.20, 0.055, 0.25, 0.80), (0.62, 0.07, 0.30, 1.01)):
+            land = (np.abs(x - x0) < w * (0.6 + 0.4 * np.sin(np.pi * (y - j0) / (j1 - j0)))) & (y > j0) & (y < j1)
+            shelf = (np.abs(x - x0) < 1.6 * w) & (y > j0 - 0.03) & (y < j1 + 0.03)
+            d = np.where(shelf, np.minimum(d, 400.0), d)
+            d = np.where(land, 0.0, d)
+        return np.broadcast_to(d, (jdm, idm)).copy()
     if name == "tri_s":
         # open ocean up to the arctic seam, a southern coast, one continent reaching the seam; the last
         # row is overwritten with the mirror image of the row below it by the arctic halo rule
