@@ -68,6 +68,8 @@ int ctx_check_errors(blomgpu_ctx *c) {
   int e[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the words are only ever set by a failing kernel (zeroed at allocation): clear them once reported
+  if (e[0] || e[1] || e[2]) HIPCHK(c, hipMemsetAsync(c->err_dev, 0, sizeof(int) * 8, c->stream));
   if (e[0] & 2) return ctx_fail(c, "blom: diapfl: no convergence in implicit diffusion!");        // mod_diapfl.F90:520-530
   if (e[0] & 1) return ctx_fail(c, "blom: diapfl: no convergence in flux limit!");
   if (e[1] & 1) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: no convergence");              // mod_eddtra.F90:536-555
@@ -326,16 +328,21 @@ int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); ret
 int blomgpu_halo_cmnfld2(blomgpu_ctx *c, int n) {     // phy/mod_cmnfld_routines.F90:1171-1196
   ctx_sync_view(c);
   const int kk = c->h.kk;
-  if (st_xctilr(c, c->h.f[F_temp], 1, 2 * kk, 3, 3, 1) || st_xctilr(c, c->h.f[F_saln], 1, 2 * kk, 3, 3, 1)) return 1;
+  {
+    double *ptrs[2] = {c->h.f[F_temp], c->h.f[F_saln]};
+    const int nl[2] = {2 * kk, 2 * kk}, it[2] = {1, 1};
+    if (st_xctilr_multi(c, 2, ptrs, nl, 3, 3, it)) return 1;
+  }
   return st_kfpla_halo(c, n);                         // kfpla(:,:,n) halo through util1, :1176-1196
 }
 int blomgpu_halo_difest(blomgpu_ctx *c, int nn) {     // phy/mod_difest.F90:750-772
   ctx_sync_view(c);
   const int kk = c->h.kk;
-  if (st_xctilr(c, c->h.f[F_u], 1, 2 * kk, 2, 2, 13) || st_xctilr(c, c->h.f[F_v], 1, 2 * kk, 2, 2, 14) ||
-      st_xctilr(c, c->h.f[F_ubflxs_p], 1, 2, 2, 2, 13) || st_xctilr(c, c->h.f[F_vbflxs_p], 1, 2, 2, 2, 14) ||
-      st_xctilr(c, c->h.f[F_pbu], 1, 2, 2, 2, 3) || st_xctilr(c, c->h.f[F_pbv], 1, 2, 2, 2, 4))
-    return 1;
+  {
+    double *ptrs[6] = {c->h.f[F_u], c->h.f[F_v], c->h.f[F_ubflxs_p], c->h.f[F_vbflxs_p], c->h.f[F_pbu], c->h.f[F_pbv]};
+    const int nl[6] = {2 * kk, 2 * kk, 2, 2, 2, 2}, it[6] = {13, 14, 13, 14, 3, 4};
+    if (st_xctilr_multi(c, 6, ptrs, nl, 2, 2, it)) return 1;
+  }
   return launch_pscan(c, nn, -2, 3);                  // interface pressure out to ii+3 for remap (:761-772)
 }
 

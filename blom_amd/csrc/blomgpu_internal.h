@@ -176,6 +176,7 @@ struct blomgpu_ctx {
   // blomgpu_step defers the read-back to the end of the step (one host sync per step instead of three)
   int *err_dev = nullptr;
   bool defer_checks = false;
+  unsigned bt_epoch = 0;          // completion count every tile has reached after the launches so far
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel
   int num_cus = 0;
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
@@ -227,6 +228,8 @@ int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);
+// several stacks (ptrs[f] = first level, nlevs[f] levels) with common widths in one launch where possible
+int st_xctilr_multi(blomgpu_ctx *, int nf, double *const *ptrs, const int *nlevs, int mh, int nh, const int *itypes);
 int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc);
 // locate the field (and level offset) a device pointer belongs to; returns field id or -1
 int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);

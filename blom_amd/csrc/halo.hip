@@ -171,6 +171,67 @@ int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int 
   return 0;
 }
 
+// Several plane stacks with the same halo widths in one launch (single tile, no arctic patch): what the
+// stages issue back to back (15 single planes before the barotropic loop, 6 stacks in halo_difest, ...).
+// Other decompositions fall back to one update per stack.
+#define XCT_MAXF 16
+struct HaloMulti {
+  double *p[XCT_MAXF];
+  int nlev[XCT_MAXF];
+};
+
+__global__ void k_xctilr_multi(const DevView *Vp, HaloMulti M, int mhl, int nhl, int land_ew, int land_ns) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj;
+  const int nns = 2 * nhl * ii;
+  const int new_ = 2 * mhl * (jj + 2 * nhl);
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nns + new_) return;
+  int i, j;
+  if (t < nns) {
+    const int r = t / ii;
+    i = t % ii + 1;
+    j = r < nhl ? -r : jj + (r - nhl) + 1;
+  } else {
+    t -= nns;
+    const int cidx = t % (2 * mhl);
+    j = t / (2 * mhl) + 1 - nhl;
+    i = cidx < mhl ? -cidx : ii + (cidx - mhl) + 1;
+  }
+  const int dx = i < 1 ? -1 : (i > ii ? 1 : 0), dy = j < 1 ? -1 : (j > jj ? 1 : 0);
+  const bool land = (dx != 0 && land_ew) || (dy != 0 && land_ns);
+  const size_t dst = IDX(V, i, j), src = IDX(V, i - dx * ii, j - dy * jj);
+  double *a = M.p[blockIdx.z];
+  const int nlev = M.nlev[blockIdx.z];
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[dst + o] = land ? V.P.vland : a[src + o];
+  }
+}
+
+int st_xctilr_multi(blomgpu_ctx *c, int nf, double *const *ptrs, const int *nlevs, int mh, int nh, const int *itypes) {
+  const DevView &h = c->h;
+  if (c->tiling.multi() || h.nreg == 2 || nf > XCT_MAXF) {
+    for (int f = 0; f < nf; f++)
+      if (int rc = st_xctilr(c, ptrs[f], 1, nlevs[f], mh, nh, itypes[f])) return rc;
+    return 0;
+  }
+  const int mhl = mh < 0 ? 0 : (mh > NBDY ? NBDY : mh);
+  const int nhl = nh < 0 ? 0 : (nh > NBDY ? NBDY : nh);
+  const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
+  if (ntarget == 0 || nf <= 0) return 0;
+  if (h.itdm != h.ii || h.jtdm != h.jj)
+    return ctx_fail(c, "xctilr: this context is one tile of a larger domain but no halo transport is attached");
+  HaloMulti M;
+  int maxlev = 1;
+  for (int f = 0; f < XCT_MAXF; f++) { M.p[f] = f < nf ? ptrs[f] : nullptr; M.nlev[f] = f < nf ? nlevs[f] : 0; if (f < nf && nlevs[f] > maxlev) maxlev = nlevs[f]; }
+  dim3 grid((ntarget + 255) / 256, maxlev > 64 ? 64 : maxlev, nf);
+  hipLaunchKernelGGL(k_xctilr_multi, grid, dim3(256), 0, c->stream, c->d, M, mhl, nhl, ew_periodic(h.nreg) ? 0 : 1,
+                     ns_periodic(h.nreg) ? 0 : 1);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 // In-process tile group (tests of the decomposition on one device; one host thread per tile).
 int blomgpu_group_create(int npx, int npy, TileGroup **out) {

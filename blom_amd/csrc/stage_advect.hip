@@ -484,11 +484,16 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     return 0;
   }
   hipLaunchKernelGGL(k_adv_pbmin, plane_grid(h), dim3(256), 0, c->stream, c->d);
-  if (int rc = st_xctilr(c, h.f[F_cau], 1, h.kk, 3, 3, 13)) return rc;                 // mod_advect:124
-  if (int rc = st_xctilr(c, h.f[F_cav], 1, h.kk, 3, 3, 14)) return rc;                 // mod_advect:125
-  for (int nt = 0; nt < h.ntr; nt++)                                                  // mod_advect:126-131
-    if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 3, 3, 1))
-      return rc;
+  {                                                                                   // mod_advect:124-131
+    double *ptrs[2 + MAXTR] = {h.f[F_cau], h.f[F_cav]};
+    int nl[2 + MAXTR] = {h.kk, h.kk}, it[2 + MAXTR] = {13, 14};
+    for (int nt = 0; nt < h.ntr; nt++) {
+      ptrs[2 + nt] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
+      nl[2 + nt] = h.kk;
+      it[2 + nt] = 1;
+    }
+    if (int rc = st_xctilr_multi(c, 2 + h.ntr, ptrs, nl, 3, 3, it)) return rc;
+  }
   {
     TimeScope ts(c, "remap");
     hipLaunchKernelGGL(k_remap_grad, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);

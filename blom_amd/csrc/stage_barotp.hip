@@ -322,12 +322,16 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       {F_vglue, 0, 2, 4}, {F_vtotn, 0, 2, 14}, {F_vmaxb, 0, 2, 4}, {F_vminb, 0, 2, 4},
       {F_pvtrop, n - 1, 3, 2}, {F_pgfxm, n - 1, 2, 13}, {F_xixp, n - 1, 2, 3}, {F_xixm, n - 1, 2, 3},
       {F_pgfym, n - 1, 2, 14}, {F_xiyp, n - 1, 2, 4}, {F_xiym, n - 1, 2, 4}};
-  for (auto &x : hl)
-    if (int rc = st_xctilr(c, h.f[x.f] + (size_t)x.lev * np, 1, 1, 1, x.nh, x.it)) return rc;
+  for (int nhw = 2; nhw <= 3; nhw++) {        // one launch per halo width
+    double *ptrs[16];
+    int nl[16], it[16], nf = 0;
+    for (auto &x : hl)
+      if (x.nh == nhw) { ptrs[nf] = h.f[x.f] + (size_t)x.lev * np; nl[nf] = 1; it[nf] = x.it; nf++; }
+    if (int rc = st_xctilr_multi(c, nf, ptrs, nl, 1, nhw, it)) return rc;
+  }
 
   if (h.nreg == 2) hipLaunchKernelGGL(k_bt_arctic_swap, g, b, 0, c->stream, c->d, n);       // :290-325
   if (int rc = ctx_err_words(c)) return rc;
-  HIPCHK(c, hipMemsetAsync(c->err_dev + 2, 0, sizeof(int), c->stream));
   int lll0 = 1, ml = 1, nl = 2, set = 0;     // set: which buffer set (*_t / *_t2) holds the current state
   double woa = 0., wob = 0., wna = 0., wnb = 0.;
   for (int nb = 1; nb <= 5; nb++) {

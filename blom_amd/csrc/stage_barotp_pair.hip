@@ -31,7 +31,8 @@ struct PairArgs {
   // persistent form (k_bt_steps<true>): the launch walks substeps lll0..last itself
   int lll0, last;            // first and last substep of the phase
   double woa, wob, wna, wnb; // time weights wo = woa*l + wob, wn = wna*l + wnb, wm = 1 - wo - wn (:352-360)
-  unsigned *flags;           // one word per tile: number of iterations this tile has completed and published
+  unsigned *flags;           // one word per tile: epoch_base + number of iterations this tile has completed and published
+  unsigned epoch_base;       // flags are never reset: every launch counts on from where the previous one stopped
   unsigned *abort_word;      // set by any tile whose wait ran out; every spin also watches it
 };
 
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
         bool ready = nb_tile < 0;
         unsigned spins = 0;
         while (true) {
-          if (!ready) ready = __hip_atomic_load(a.flags + nb_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= done_iters;
+          if (!ready) ready = __hip_atomic_load(a.flags + nb_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.epoch_base + done_iters;
           if (__all(ready)) break;
           if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { aborted = true; break; }
           if (++spins > 400000u) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the count goes out
     __syncthreads();
     done_iters++;
-    if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + blockIdx.x), done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + blockIdx.x), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   } while (PERSIST && lll <= a.last);
   if (mine) {
@@ -373,7 +374,7 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
   a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
   a.prof = c->bt_prof;
-  a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr;
+  a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr; a.epoch_base = 0;
   dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
   hipLaunchKernelGGL(k_bt_steps<false>, grid, dim3(NTHR), 0, c->stream, c->d, a);
   return 0;
@@ -400,8 +401,13 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
                     int last, int src, int *src_out, int *ml_out, int *nl_out) {
   const DevView &h = c->h;
   const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
-  if (!c->bt_flags) HIPCHK(c, hipMalloc((void **)&c->bt_flags, sizeof(unsigned) * (nbx * nby + 16)));
-  HIPCHK(c, hipMemsetAsync(c->bt_flags, 0, sizeof(unsigned) * (nbx * nby + 16), c->stream));
+  int niter = 0;
+  for (int lll = lll0; lll <= last; niter++) lll += (lll % 2 == 1 && lll + 1 <= last) ? 2 : 1;
+  if (!c->bt_flags || c->bt_epoch > 0xf0000000u) {        // (re)start the completion counters
+    if (!c->bt_flags) HIPCHK(c, hipMalloc((void **)&c->bt_flags, sizeof(unsigned) * (nbx * nby + 16)));
+    HIPCHK(c, hipMemsetAsync(c->bt_flags, 0, sizeof(unsigned) * (nbx * nby + 16), c->stream));
+    c->bt_epoch = 0;
+  }
   PairArgs a;
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;
   for (int x = 0; x < 2; x++) { a.wo[x] = a.wm[x] = a.wn[x] = 0.; }
@@ -410,6 +416,8 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   a.prof = nullptr;
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
+  a.epoch_base = c->bt_epoch;
+  c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;
   a.abort_word = (unsigned *)(c->err_dev + 2);
   hipLaunchKernelGGL(k_bt_steps<true>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);

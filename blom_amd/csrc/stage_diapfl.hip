@@ -473,15 +473,15 @@ int st_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) {
   if (h.P.vcoord_tag != 1) return ctx_fail(c, "diapfl is only called for isopyc_bulkml (phy/mod_blom_step.F90:172-186)");
   if (int rc = ctx_err_words(c)) return rc;
   int *errflag = c->err_dev + 0;
-  HIPCHK(c, hipMemsetAsync(errflag, 0, sizeof(int), c->stream));
   {
     TimeScope ts(c, "diapfl");
     if (c->diapfl_v == 2) { if (int rc = diapfl_column2_launch(c, n, nn, errflag)) return rc; }
     else hipLaunchKernelGGL(k_diapfl_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, n, nn, errflag);
-    if (int rc = st_xctilr(c, h.f[F_p], 1, h.kk + 1, 1, 1, 1)) return rc;                 // :711-713
-    if (int rc = st_xctilr(c, h.f[F_fpug], 1, h.kk, 1, 1, 1)) return rc;
-    if (int rc = st_xctilr(c, h.f[F_fplg], 1, h.kk, 1, 1, 1)) return rc;
-    if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, 1, 1, 1)) return rc;                    // :723
+    {                                                                                     // :711-713, :723
+      double *ptrs[4] = {h.f[F_p], h.f[F_fpug], h.f[F_fplg], h.f[F_util1]};
+      const int nl[4] = {h.kk + 1, h.kk, h.kk, 1}, it[4] = {1, 1, 1, 1};
+      if (int rc = st_xctilr_multi(c, 4, ptrs, nl, 1, 1, it)) return rc;
+    }
     hipLaunchKernelGGL(k_diapfl_kming, plane_grid(h), dim3(256), 0, c->stream, c->d);
     hipLaunchKernelGGL(k_diapfl_momentum, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, nn);
     hipLaunchKernelGGL(k_diapfl_dpudpv, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);

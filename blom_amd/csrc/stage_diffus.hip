@@ -88,11 +88,19 @@ int st_diffus(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const size_t np = h.nplane;
   if (h.P.ltedtp_opt != 1) return ctx_fail(c, "diffus: ltedtp = 'neutral' (hybrid coordinate) is not built yet");
   if (int rc = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, 3, 3, 1)) return rc;        // :58
-  if (int rc = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, 2, 2, 1)) return rc;      // :72
-  if (int rc = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 2, 2, 1)) return rc;      // :73
-  for (int nt = 0; nt < h.ntr; nt++)                                                                // :75-80
-    if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 2, 2, 1))
-      return rc;
+  {                                                                                                 // :72-80
+    double *ptrs[10] = {h.f[F_temp] + (size_t)(k1n - 1) * np, h.f[F_saln] + (size_t)(k1n - 1) * np};
+    int nl[10] = {h.kk, h.kk}, it[10] = {1, 1};
+    const int ntr = h.ntr < 8 ? h.ntr : 8;
+    for (int nt = 0; nt < ntr; nt++) {
+      ptrs[2 + nt] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
+      nl[2 + nt] = h.kk;
+      it[2 + nt] = 1;
+    }
+    if (int rc = st_xctilr_multi(c, 2 + ntr, ptrs, nl, 2, 2, it)) return rc;
+    for (int nt = ntr; nt < h.ntr; nt++)
+      if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 2, 2, 1)) return rc;
+  }
   // The reference's per-layer flux work arrays uflxtr/vflxtr keep stale values where no
   // u/v point exists; ours are per-layer planes of wk0.. that must start from the same
   // stale content (0 after inivar_tracers, trc/mod_tracers.F90:166-209).

@@ -255,7 +255,6 @@ int st_eddtra(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   if (h.nwk < 2 * G_NSLOT) return ctx_fail(c, "eddtra: device work space too small");
   if (int rc = ctx_err_words(c)) return rc;
   int *errflag = c->err_dev + 1;
-  HIPCHK(c, hipMemsetAsync(errflag, 0, sizeof(int), c->stream));
   {
     TimeScope ts(c, "eddtra");
     if (h.P.eitmth == 1) hipLaunchKernelGGL(k_eddtra_intdif, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, mm, nn);
