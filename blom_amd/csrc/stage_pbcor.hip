@@ -10,6 +10,9 @@
 //   k_pbc_rescale  p scan, pbfac = pb/p(kk+1), dp *= pbfac                            (column)
 // The per-layer 2-D scratch arrays uflux,uflux2,uflux3,uflxtr of the reference become work-space
 // fields over all layers (layers are independent given utot).  Roofline: HBM.
+// Measured alternative, not kept: one kernel evaluating the four face fluxes of a cell and updating it (new
+// state to work planes, moved into place by the rescale pass) -- 0.57/0.63 ms against 0.52/0.56 ms for
+// pbcor1/2: the 4 divisions per cell and the column-wise copy cost more than the 8 flux planes saved.
 #include "blomgpu_internal.h"
 #include "eos.h"
 
