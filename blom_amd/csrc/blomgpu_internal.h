@@ -236,6 +236,20 @@ int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);
 int rccl_xctilr(blomgpu_ctx *, double *base, int nlev, int mhl, int nhl);   // comm_rccl.hip
 int rccl_xctilr_multi(blomgpu_ctx *, double *const *fields, int nf, int nlev, int mhl, int nhl);  // one message per neighbour for up to 4 plane stacks
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own
+// 4 MB L2, so with the natural order the rows j-1, j, j+1 of a stencil land in three different L2s and are
+// fetched from HBM/Infinity Cache three times.  Re-number the blocks so that XCD x walks a CONTIGUOUS
+// eighth of the (layer, row) space: a bijection of [0, gridDim.x*gridDim.y), returned as (bx, by).
+__device__ inline void xcd_block(unsigned &bx, unsigned &by) {
+  const unsigned gx = gridDim.x, n = gx * gridDim.y;
+  const unsigned lin = blockIdx.y * gx + blockIdx.x;
+  const unsigned x = lin & 7u, s = lin >> 3;
+  const unsigned q = n >> 3, r = n & 7u;
+  const unsigned nl = x * q + (x < r ? x : r) + s;
+  bx = nl % gx;
+  by = nl / gx;
+}
+
 // launch helpers: 1 thread per point of the padded plane, blockIdx.y = level
 static inline dim3 plane_grid(const DevView &h, int nlev = 1, int block = 256) {
   return dim3((h.nplane + block - 1) / block, nlev, 1);

@@ -50,7 +50,10 @@
 #define W_FTRV(ntr, nt) (F_BASE(ntr) + 7 + 2 * (nt))
 
 #define THREAD_IJ(V)                                                       \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_
@@ -60,7 +63,7 @@ __global__ void k_adv_flux_area(const DevView *Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, okm = c + (size_t)(k + mm) * np, okn = c + (size_t)(k + nn) * np;
   const size_t om = c + (size_t)(m - 1) * np;
   const double delt1 = V.P.delt1, dlt = V.P.dlt;
@@ -162,7 +165,7 @@ __global__ void k_remap_grad(const DevView *Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np;
   const double *dp = V.f[F_dp] + okn, *plo = V.f[F_p] + (size_t)(k + 1) * np;
   const Nbr b = wet_nbr(V, c);
@@ -318,7 +321,7 @@ __device__ inline void add_contrib(const DevView &V, size_t ok, const double *dp
 __global__ void k_remap_flux(const DevView *Vp, int n, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
-  const int k = blockIdx.y;
+  const int k = by_;
   const int ni = V.ni, ntr = V.ntr;
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np;
   const double *dp = V.f[F_dp] + okn, *plo = V.f[F_p] + (size_t)(k + 1) * np;
@@ -441,7 +444,7 @@ __global__ void k_remap_update(const DevView *Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -2 || j > V.jj + 3 || i < -2 || i > V.ii + 3 || !V.m[I_ip][c]) return;
-  const int k = blockIdx.y, ntr = V.ntr;
+  const int k = by_, ntr = V.ntr;
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np;
   double *dp = V.f[F_dp] + okn;
   const double q = fmax2(0., dp[c]) + DPEPS;

@@ -32,7 +32,10 @@
 #define MAXTL 6              // ntr_loc = 2 + ntr
 
 #define THREAD_IJ(V)                                                       \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_
@@ -72,7 +75,7 @@ __device__ inline CppmTab cppm_tab(const DevView &V, int dir) {
 __global__ void k_cppm_init(const DevView *Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
-  const int dir = blockIdx.y;
+  const int dir = by_;
   const size_t np = V.nplane;
   CppmTab T = cppm_tab(V, dir);
   // :2553-2574 everything zero / stencil_0000 outside the interior (halos come from xctilr afterwards)
@@ -248,7 +251,7 @@ __global__ void k_cppm_hm(const DevView *Vp, int nn, int second_pass) {
   THREAD_IJ(V);
   SWEEP_COORDS(V);
   if (o < 1 || o > odm || s < -3 + LIM || s > sdm + 4 - LIM) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np;
   double h = fmax2(0., V.f[F_dp][c + (size_t)(k + nn) * np]) + DPEPS;
   if (second_pass) {                       // divergence of the other direction's Courant number, :1501-1509
@@ -324,7 +327,7 @@ __global__ void k_cppm_hedges(const DevView *Vp) {
   THREAD_IJ(V);
   SWEEP_COORDS(V);
   if (o < 1 || o > odm || s < 1 || s > sdm) return;
-  const size_t ok = (size_t)blockIdx.y * V.nplane;
+  const size_t ok = (size_t)by_ * V.nplane;
   const CppmTab T = cppm_tab(V, DIR);
   double hel, her;
   cppm_h_edges<LIM>(T, c, sd, WK(V, W_HM) + ok, hel, her);
@@ -456,7 +459,7 @@ __global__ void k_cppm_tedge(const DevView *Vp, int nn, int ntl) {
   THREAD_IJ(V);
   SWEEP_COORDS(V);
   if (o < 1 || o > odm || s < -1 + LIM || s > sdm + 3 - LIM) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np;
   const CppmTab T = cppm_tab(V, DIR);
   double t1, t2, t3, t4;
@@ -476,7 +479,7 @@ __global__ void k_cppm_parab(const DevView *Vp, int nn, int ntl) {
   THREAD_IJ(V);
   SWEEP_COORDS(V);
   if (o < 1 || o > odm || s < 0 || s > sdm + 1) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np;
   const CppmTab T = cppm_tab(V, DIR);
   const double *hmv = WK(V, W_HM) + ok;
@@ -599,7 +602,7 @@ __global__ void k_cppm_flux(const DevView *Vp, int n, int mm, int ntl) {
   THREAD_IJ(V);
   SWEEP_COORDS(V);
   if (o < 1 || o > odm || s < 1 || s > sdm + 1) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const double c1_2 = 1. / 2., c1_3 = 1. / 3., c1_4 = 1. / 4., c1_5 = 1. / 5.;
   const double ca = (DIR ? V.f[F_cav] : V.f[F_cau])[c + ok];
@@ -665,7 +668,7 @@ __global__ void k_cppm_update(const DevView *Vp, int nn, int ntl) {
   THREAD_IJ(V);
   SWEEP_COORDS(V);
   if (o < 1 || o > odm || s < 1 || s > sdm) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np;
   const double ai = V.f[F_scp2i][c];
   const double ho = fmax2(0., V.f[F_dp][c + okn]) + DPEPS;

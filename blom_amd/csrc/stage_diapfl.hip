@@ -20,7 +20,10 @@
 #define MAXTR 8
 
 #define THREAD_IJ(V)                                                       \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_
@@ -397,7 +400,7 @@ __global__ void k_diapfl_momentum(const DevView *Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const bool isv = blockIdx.y == 1;
+  const bool isv = by_ == 1;
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t np = V.nplane, mns = isv ? c - V.ni : c - 1;
   const int kk = V.kk, sb = isv ? U_NSLOT : 0;
@@ -451,7 +454,7 @@ __global__ void k_diapfl_momentum(const DevView *Vp, int nn) {
 __global__ void k_diapfl_dpudpv(const DevView *Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, o0 = (size_t)k * np, o1 = (size_t)(k + 1) * np, ob = (size_t)V.kk * np;
   const double *p = V.f[F_p];
   if (V.m[I_iu][c] && j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1) {

@@ -14,10 +14,12 @@
 
 __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
   const DevView &V = *Vp;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  const int t = bx_ * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
   const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, c = t, w = c - 1, s = c - V.ni;
   const size_t okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np, ok = (size_t)k * np;
   const double *dp = V.f[F_dp] + okn, *temp = V.f[F_temp] + okn, *saln = V.f[F_saln] + okn;
@@ -60,11 +62,13 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
 
 __global__ void k_diffus_update(const DevView *Vp, int mm, int nn) {
   const DevView &V = *Vp;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  const int t = bx_ * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
   const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][t]) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, c = t, e = c + 1, nb = c + V.ni;
   const size_t okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np, ok = (size_t)k * np;
   const double q = 1. / (V.f[F_scp2][c] * fmax2(V.f[F_dp][c + okn], DPEPS));

@@ -19,7 +19,10 @@
 #define EPSILP 1.e-12
 
 #define THREAD_IJ(V)                                                       \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_
@@ -31,7 +34,7 @@ __global__ void k_eddtra_gm(const DevView *Vp, int n, int mm, int nn, int *__res
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const bool isv = blockIdx.y == 1;
+  const bool isv = by_ == 1;
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t np = V.nplane, xb = c, xa = isv ? c - V.ni : c - 1;
   const int kk = V.kk, sb = isv ? G_NSLOT : 0;
@@ -197,7 +200,7 @@ __global__ void k_eddtra_intdif(const DevView *Vp, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const int k = blockIdx.y + 1, kk = V.kk, ni = V.ni;
+  const int k = by_ + 1, kk = V.kk, ni = V.ni;
   const size_t np = V.nplane;
   const double delt1 = V.P.delt1;
   const double *dp = V.f[F_dp] + (size_t)nn * np, *p = V.f[F_p], *difint = V.f[F_difint], *scp2 = V.f[F_scp2];
@@ -234,7 +237,7 @@ __global__ void k_eddtra_ts(const DevView *Vp, int mm) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const size_t np = V.nplane, o = c + (size_t)(blockIdx.y + mm) * np;
+  const size_t np = V.nplane, o = c + (size_t)(by_ + mm) * np;
   const double *temp = V.f[F_temp], *saln = V.f[F_saln];
   if (V.m[I_iu][c]) {
     const double f = V.f[F_umfltd][o];

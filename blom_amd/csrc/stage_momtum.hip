@@ -39,7 +39,10 @@
 #define WPGF .25        // phy/mod_pgforc.F90:47
 
 #define THREAD_IJ(V)                                                       \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_
@@ -115,7 +118,7 @@ __global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
-  const int k = blockIdx.y, ni = V.ni, ii = V.ii, jj = V.jj;
+  const int k = by_, ni = V.ni, ii = V.ii, jj = V.jj;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
   const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const double tsfac = V.P.dlt / V.P.delt1, cutoff = ONEM;
@@ -168,7 +171,7 @@ __global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn) {
 __global__ void k_mom_wall(const DevView *Vp, int m) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
-  const int k = blockIdx.y, ni = V.ni;
+  const int k = by_, ni = V.ni;
   const size_t np = V.nplane, ok = (size_t)k * np, om = (size_t)(m - 1) * np;
   if (V.m[I_iu][c] && j >= -1 && j <= V.jj + 2 && i >= 0 && i <= V.ii + 2) {
     const double *utotn = WK(V, M_UTOTN) + ok;
@@ -211,7 +214,7 @@ __global__ void k_mom_vort(const DevView *Vp, int mm) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
-  const int k = blockIdx.y, ni = V.ni, ii = V.ii, jj = V.jj;
+  const int k = by_, ni = V.ni, ii = V.ii, jj = V.jj;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const int *ip = V.m[I_ip], *iu = V.m[I_iu], *iv = V.m[I_iv], *iq = V.m[I_iq];
   const double *utotm = WK(V, M_UTOTM) + ok, *vtotm = WK(V, M_VTOTM) + ok;
@@ -307,7 +310,7 @@ __global__ void k_mom_enedis(const DevView *Vp, int mm) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
-  const int k = blockIdx.y;
+  const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const double *dp = V.f[F_dp] + okm;
   // the reference's local arrays are zeroed once per call (:238-241) and written at wet points only
@@ -324,7 +327,7 @@ __global__ void k_mom_visc(const DevView *Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
-  const int k = blockIdx.y, ni = V.ni;
+  const int k = by_, ni = V.ni;
   const size_t ok = (size_t)k * V.nplane;
   const double *d1 = WK(V, M_DEFOR1) + ok, *d2 = WK(V, M_DEFOR2) + ok, *difwgt = V.f[F_difwgt];
   const Params &P = V.P;
@@ -356,7 +359,7 @@ __global__ void k_mom_flux1(const DevView *Vp, int mm) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][c]) return;
-  const int k = blockIdx.y, ni = V.ni;
+  const int k = by_, ni = V.ni;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const int *iu = V.m[I_iu], *iv = V.m[I_iv];
   const double difmxp = V.f[F_difmxp][c];
@@ -383,7 +386,7 @@ __global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const int k = blockIdx.y, ni = V.ni;
+  const int k = by_, ni = V.ni;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
   const size_t om = (size_t)(m - 1) * np;
   const int *iu = V.m[I_iu], *iv = V.m[I_iv];
@@ -510,7 +513,7 @@ __global__ void k_mom_column(const DevView *Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const bool isv = blockIdx.y == 1;
+  const bool isv = by_ == 1;
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t np = V.nplane;
   const int kk = V.kk;

@@ -21,7 +21,10 @@
 #define DPEPS2 1.e-7   // phy/mod_pbcor.F90:59
 
 #define THREAD_IJ(V)                                                       \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_
@@ -80,7 +83,7 @@ __global__ void k_pbc_total(const DevView *Vp, int which, int m, int n, int offf
 __global__ void k_pbc_flux(const DevView *Vp, int which, int offc, int offf) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
-  const int k = blockIdx.y, ntr = V.ntr;
+  const int k = by_, ntr = V.ntr;
   const size_t np = V.nplane, ok = (size_t)k * np, okc = (size_t)(k + offc) * np, okf = (size_t)(k + offf) * np;
   const double *dp = V.f[F_dp] + okc, *saln = V.f[F_saln] + okc, *temp = V.f[F_temp] + okc;
   const double *p = V.f[F_p];
@@ -139,7 +142,7 @@ __global__ void k_pbc_update(const DevView *Vp, int which, int offc) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
-  const int k = blockIdx.y, ntr = V.ntr;
+  const int k = by_, ntr = V.ntr;
   const size_t np = V.nplane, ok = (size_t)k * np, okc = (size_t)(k + offc) * np, e = c + 1, nb = c + V.ni;
   double *dp = V.f[F_dp] + okc, *saln = V.f[F_saln] + okc, *temp = V.f[F_temp] + okc;
   const double *uf = WK(V, S_UF) + ok, *uf2 = WK(V, S_UF2) + ok, *uf3 = WK(V, S_UF3) + ok;

@@ -7,7 +7,10 @@
 #include "blomgpu_internal.h"
 
 #define PLANE_IJ(V)                                                        \
-  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
   if (t_ >= (V).nplane) return;                                            \
   const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
   const size_t c = t_;                                                     \
@@ -18,7 +21,7 @@ __global__ void k_init_fluxes(const DevView *Vp, int mm) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 0 || j > V.jj + 2 || i < 0 || i > V.ii + 2) return;
-  const size_t o = c + (size_t)(blockIdx.y + mm) * V.nplane;
+  const size_t o = c + (size_t)(by_ + mm) * V.nplane;
   if (V.m[I_iu][c]) { V.f[F_uflx][o] = 0.; V.f[F_utflx][o] = 0.; V.f[F_usflx][o] = 0.; }
   if (V.m[I_iv][c]) { V.f[F_vflx][o] = 0.; V.f[F_vtflx][o] = 0.; V.f[F_vsflx][o] = 0.; }
 }
@@ -35,7 +38,7 @@ __global__ void k_tmsmt1(const DevView *Vp, int off, int is_initms) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const int k = blockIdx.y;                         // 0-based layer
+  const int k = by_;                         // 0-based layer
   const size_t ok = c + (size_t)k * V.nplane, okn = c + (size_t)(k + off) * V.nplane;
   if (V.m[I_ip][c]) {
     if (!is_initms) V.f[F_dpold][okn] = V.f[F_dp][okn];
