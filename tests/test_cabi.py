@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "blomgpu.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(blomgpu_[a-z0-9_]+)\s*\(", txt)))
+    syms = set()
+    for hdr in ("blomgpu.h", "blomgpu_hor3map.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b(blomgpu_[a-z0-9_]+)\s*\(", txt))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():
@@ -37,6 +40,18 @@ def test_create_fails_loudly_without_device():
     m = {k: np.ones((16, 16), np.int32) for k in ("ip", "iu", "iv", "iq")}
     with pytest.raises(BlomGpuError, match="no HIP device"):
         BlomGpu(8, 8, 4, 0, 1, m)
+
+
+def test_hor3map_grid_create_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from blom_amd import hor3map
+    from blom_amd.gpu import LIB_PATH
+    if not os.path.exists(LIB_PATH):
+        pytest.skip("libblomgpu.so not built")
+    with pytest.raises(hor3map.Hor3mapError, match="no HIP device"):
+        hor3map.ReconGrid(8, 5)
 
 
 def test_python_package_has_no_oracle_import():

@@ -1,0 +1,86 @@
+"""hor3map on the CPU side of the suite (no GPU needed):
+  * the reference's own mod_hor3map (oracle/_ref/hor3map, built only where /root/reference exists)
+    must reproduce the committed golden vectors -- guards the fixtures and the generators;
+  * the device column routines, compiled for the host (tests/hostcheck), must be BIT-identical to the
+    golden vectors and, where the reference library is present, to the reference on larger seeded
+    slabs, for every method / limiter / boundary option / regrid method / grid orientation."""
+import os
+
+import numpy as np
+import pytest
+
+import h3m_cases as hc
+from golden.make_hor3map_golden import NCOL, N_SRC, N_DST, N_GRD, golden_cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "hor3map.npz"))
+
+
+def _gold(golden, name):
+    return {k: golden[f"{name}/{k}"] for k in ("polycoeff", "u_dst", "x_grd", "errs", "n_act", "m_act")}
+
+
+def test_reference_reproduces_golden(golden):
+    if not hc.have_ref():
+        pytest.skip("oracle/_ref/hor3map/libhor3mapref.so not built")
+    bad = []
+    for name, cfg, kind, rm, seed, dec in golden_cases():
+        x, u, xd, ug = hc.make_columns(seed, NCOL, N_SRC, N_DST, N_GRD, kind, dec)
+        assert np.array_equal(x, golden[f"{name}/x_src"]) and np.array_equal(u, golden[f"{name}/u_src"]), name
+        bad += hc.compare(_gold(golden, name), hc.run_ref(*cfg, x, u, xd, ug, rm), name)
+    assert not bad, "\n".join(bad[:10])
+
+
+def test_device_routines_on_host_match_golden(golden):
+    if not hc.have_hostcheck():
+        pytest.skip("tests/hostcheck/libh3m_hostcheck.so not built (run __graft_entry__.build())")
+    bad = []
+    seen_err, seen_methods = set(), set()
+    for name, cfg, kind, rm, seed, dec in golden_cases():
+        x, u, xd, ug = hc.make_columns(seed, NCOL, N_SRC, N_DST, N_GRD, kind, dec)
+        g = _gold(golden, name)
+        bad += hc.compare(g, hc.run_hostcheck(*cfg, x, u, xd, ug, rm), name)
+        seen_err |= set(np.unique(g["errs"]).tolist())
+        seen_methods |= set(np.unique(g["m_act"][g["errs"][:, 0] == 0]).tolist())
+    assert not bad, "\n".join(bad[:10])
+    # the fixtures do exercise the error paths and the method fall-back chain
+    assert {3, 6, 8, 9, 16, 19} <= seen_err, seen_err
+    assert seen_methods == {hc.PCM, hc.PLM, hc.PPM, hc.PQM}
+
+
+@pytest.mark.parametrize("cfg", hc.CONFIGS, ids=lambda c: "-".join(map(str, map(int, c))))
+def test_device_routines_on_host_match_reference(cfg):
+    if not (hc.have_ref() and hc.have_hostcheck()):
+        pytest.skip("reference / hostcheck libraries not built")
+    bad = []
+    for ik, kind in enumerate(hc.KINDS):
+        for rm in (hc.METHOD_1, hc.METHOD_2):
+            for dec in (False, True):
+                x, u, xd, ug = hc.make_columns(77 + ik, 300, 53, 53, 54, kind, dec)
+                a = hc.run_ref(*cfg, x, u, xd, ug, rm)
+                b = hc.run_hostcheck(*cfg, x, u, xd, ug, rm)
+                bad += hc.compare(a, b, f"{kind} rm{rm} dec{dec}")
+    assert not bad, "\n".join(bad[:10])
+
+
+def test_remap_conserves_and_preserves_constants():
+    """size-independent properties of the algorithm itself (host build): the remapped column
+    integral equals the source integral, and a constant field stays constant"""
+    if not hc.have_hostcheck():
+        pytest.skip("hostcheck library not built")
+    x, u, xd, ug = hc.make_columns(5, 400, 53, 40, 8, "tracer")
+    for cfg in hc.CONFIGS:
+        r = hc.run_hostcheck(*cfg, x, u, xd, ug, hc.METHOD_1)
+        ok = r["errs"][:, 5] == 0
+        assert ok.sum() > 300
+        src = (u * np.diff(x, axis=1)).sum(1)
+        dst = (r["u_dst"] * np.diff(xd, axis=1)).sum(1)
+        scale = np.abs(u).max() * x[:, -1]
+        assert np.all(np.abs(src - dst)[ok] <= 1e-12 * scale[ok]), cfg
+        c = hc.run_hostcheck(*cfg, x, np.full_like(u, 3.25), xd, ug, hc.METHOD_1)
+        # (weights carry the rounding of the edge positions: scale the bound with cell thickness)
+        assert np.all((np.abs(c["u_dst"] - 3.25) * np.diff(xd, axis=1))[ok] <= 1e-13 * 3.25 * x[ok, -1:]), cfg
