@@ -42,3 +42,37 @@ def test_fortran_driver_matches_python_driver(tmp_path):
     got = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"chksum: (\w+): 0x([0-9A-Fa-f]+)", out.stdout)}
     assert got == want, (got, want, out.stdout)
     assert open(tmp_path / "run.status").read().strip() == "success"
+
+
+def test_fortran_hor3map_shim(tmp_path):
+    """blom_amd/fortran/mod_hor3map_gpu.F90 (the reference's mod_hor3map names over the C ABI),
+    driven by h3m_demo, against the Python binding on the same analytic columns"""
+    import numpy as np
+    from blom_amd import hor3map as h3
+    exe = os.path.join(ROOT, "blom_amd", "lib", "h3m_demo")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran hor3map demo not built")
+    out = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {m.group(1): float(m.group(2)) for m in re.finditer(r"(sum_\w+):\s+(\S+)", out.stdout)}
+    assert "errstat 3: Source grid edges do not monotonically increase or decrease!" in out.stdout
+    ncol, ns, nd = 96, 20, 15
+    i = np.arange(1, ncol + 1)[:, None]
+    k = np.arange(1, ns + 1)[None, :]
+    h = np.where((k + i) % 5 == 0, 0.0, 9806.0 * (1.0 + 0.5 * np.sin(0.37 * k + 0.11 * i)))
+    p_src = np.concatenate([np.zeros((ncol, 1)), np.cumsum(h, 1)], 1)
+    trc = 1.0 + np.sin(0.5 * k + 0.05 * i)
+    p_dst = p_src[:, -1:] * (np.arange(nd + 1)[None, :] / nd) ** 2
+    p_dst[:, -1] = p_src[:, -1]
+    g = h3.ReconGrid(ncol, ns, h3.PPM, 6, 4)
+    s = h3.ReconSrc(g, h3.NON_OSCILLATORY_POSDEF, True, False)
+    r = h3.Remap(g, nd)
+    g.prepare_reconstruction(np.ascontiguousarray(p_src))
+    s.reconstruct(np.ascontiguousarray(trc))
+    pc = s.extract_polycoeff()
+    r.prepare_remapping(np.ascontiguousarray(p_dst))
+    ud = r.remap(s)
+    g.free()
+    # inputs are recomputed with another libm (sin): equal to rounding, not bitwise
+    assert abs(got["sum_polycoeff"] - pc.sum()) <= 1e-9 * abs(pc).sum()
+    assert abs(got["sum_remapped"] - ud.sum()) <= 1e-9 * abs(ud).sum()
