@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import h3m_cases as hc                    # noqa: E402
 from blom_amd import hor3map as h3        # noqa: E402
 
-ncol, n = 106080, 53
+ncol, n = int(os.environ.get("H3M_NCOL", "106080")), 53
 reps = int(os.environ.get("H3M_REPS", "20"))
 cfgs = {"ppm_tracer": (hc.PPM, 6, 4, hc.NON_OSCILLATORY_POSDEF, True, False),
         "ppm_density": (hc.PPM, 6, 4, hc.MONOTONIC, False, False),
