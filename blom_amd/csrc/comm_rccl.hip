@@ -23,22 +23,41 @@ struct FieldSet {
   double *p[MAXF];
 };
 
-// pack columns: west buffer <- my west-most mhl interior columns (they become the west neighbour's
-// east halo), east buffer <- my east-most mhl interior columns.  Buffer layout [field][level][row][q].
-__global__ void k_pack_ew(const DevView *Vp, FieldSet F, double *__restrict__ west, double *__restrict__ east,
-                          int nlev, int mhl, int nhl) {
+// One launch before the exchange does both of the reference's pre-send steps: phase 1 (N/S halo of
+// columns 1..ii from the tile itself, periodic or vland -- blocks >= gpack) and the packing of the
+// E/W strips (blocks < gpack): west buffer <- my west-most mhl interior columns (they become the west
+// neighbour's east halo), east buffer <- my east-most mhl columns, rows 1-nhl..jj+nhl.  The strip rows
+// outside 1..jj are the very values phase 1 writes, so the packer derives them itself instead of
+// waiting for them.  Buffer layout [field][level][row][q].
+__global__ void k_pack_ew_ns(const DevView *Vp, FieldSet F, double *__restrict__ west, double *__restrict__ east,
+                             int nlev, int mhl, int nhl, int periodic, int gpack) {
   const DevView &V = *Vp;
+  double *a = F.p[blockIdx.z];
+  if ((int)blockIdx.x >= gpack) {
+    const int t = (blockIdx.x - gpack) * blockDim.x + threadIdx.x;
+    if (t >= 2 * nhl * V.ii) return;
+    const int r = t / V.ii, i = t % V.ii + 1;
+    const int j = r < nhl ? -r : V.jj + (r - nhl) + 1;
+    const int js = j < 1 ? j + V.jj : j - V.jj;
+    for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+      const size_t o = (size_t)k * V.nplane;
+      a[IDX(V, i, j) + o] = periodic ? a[IDX(V, i, js) + o] : V.P.vland;
+    }
+    return;
+  }
   const int nrow = V.jj + 2 * nhl, per = mhl * nrow;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= per) return;
   const int q = t % mhl, r = t / mhl;          // q-th column of the strip, row index
   const int j = r + 1 - nhl;
-  const double *a = F.p[blockIdx.z];
+  const bool inside = j >= 1 && j <= V.jj;
+  const int js = inside ? j : (j < 1 ? j + V.jj : j - V.jj);
+  const bool land = !inside && !periodic;
   const size_t fo = (size_t)blockIdx.z * nlev * per;
   for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
     const size_t o = (size_t)k * V.nplane;
-    west[fo + (size_t)k * per + t] = a[IDX(V, 1 + q, j) + o];                 // columns 1..mhl
-    east[fo + (size_t)k * per + t] = a[IDX(V, V.ii - mhl + 1 + q, j) + o];    // columns ii-mhl+1..ii
+    west[fo + (size_t)k * per + t] = land ? V.P.vland : a[IDX(V, 1 + q, js) + o];                 // columns 1..mhl
+    east[fo + (size_t)k * per + t] = land ? V.P.vland : a[IDX(V, V.ii - mhl + 1 + q, js) + o];    // ii-mhl+1..ii
   }
 }
 
@@ -61,21 +80,6 @@ __global__ void k_unpack_ew(const DevView *Vp, FieldSet F, const double *__restr
   }
 }
 
-// phase 1: N/S halo of columns 1..ii from the tile itself (periodic) or vland (closed)
-__global__ void k_halo_ns_local(const DevView *Vp, FieldSet F, int nlev, int nhl, int periodic) {
-  const DevView &V = *Vp;
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * nhl * V.ii) return;
-  const int r = t / V.ii, i = t % V.ii + 1;
-  const int j = r < nhl ? -r : V.jj + (r - nhl) + 1;
-  const int js = j < 1 ? j + V.jj : j - V.jj;
-  double *a = F.p[blockIdx.z];
-  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
-    const size_t o = (size_t)k * V.nplane;
-    a[IDX(V, i, j) + o] = periodic ? a[IDX(V, i, js) + o] : V.P.vland;
-  }
-}
-
 int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl) {
   const DevView &h = c->h;
   RcclComm *R = c->tiling.rccl;
@@ -84,11 +88,13 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
   FieldSet F;
   for (int x = 0; x < MAXF; x++) F.p[x] = fields[x < nf ? x : 0];
   const int ly = nlev > 64 ? 64 : nlev;
-  if (nhl > 0) {
-    hipLaunchKernelGGL(k_halo_ns_local, dim3((2 * nhl * h.ii + 255) / 256, ly, nf), dim3(256), 0, c->stream, c->d, F,
-                       nlev, nhl, h.nreg > 2 ? 1 : 0);
-  }
-  if (mhl > 0) {
+  const int periodic_j = h.nreg > 2 ? 1 : 0;
+  const unsigned gns = nhl > 0 ? (unsigned)((2 * nhl * h.ii + 255) / 256) : 0u;
+  if (mhl <= 0) {
+    if (nhl > 0)
+      hipLaunchKernelGGL(k_pack_ew_ns, dim3(gns, ly, nf), dim3(256), 0, c->stream, c->d, F, nullptr, nullptr, nlev, 0,
+                         nhl, periodic_j, 0);
+  } else {
     const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev * nf;
     if (need > R->cap) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -103,8 +109,10 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
     const bool per_i = !(h.nreg == 0 || h.nreg == 4);
     const int west = T.px > 0 ? R->rank - 1 : (per_i ? R->rank + T.npx - 1 : -1);
     const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? R->rank - (T.npx - 1) : -1);
-    dim3 g((unsigned)((per + 255) / 256), ly, nf);
-    hipLaunchKernelGGL(k_pack_ew, g, dim3(256), 0, c->stream, c->d, F, R->sbuf[0], R->sbuf[1], nlev, mhl, nhl);
+    const unsigned gpack = (unsigned)((per + 255) / 256);
+    dim3 g(gpack, ly, nf);
+    hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, c->stream, c->d, F, R->sbuf[0],
+                       R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack);
     // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
     // point-to-point operations between the same pair match in issue order, so every rank sends
     // west then east and receives east then west -- my east halo is the peer's FIRST send.
