@@ -155,6 +155,9 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   (void)hipFree(c->h.wk);
   (void)hipFree(c->h.wk2d);
   (void)hipFree(c->d);
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -196,6 +199,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "timing") { c->timing = v != 0; return 0; }
   if (s == "barotp_fused") { c->barotp_fused = v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
+  if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   return ctx_fail(c, "blomgpu_set_int: unknown option " + s);
 }

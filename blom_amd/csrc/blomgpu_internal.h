@@ -163,6 +163,11 @@ struct blomgpu_ctx {
   bool dirty = true;         // host copy changed since last upload
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream for halo exchanges that overlap with compute (RCCL tiles: barotp), its fork/join events,
+  // and the stream the RCCL transport enqueues on when set (otherwise `stream`)
+  hipStream_t xstream = nullptr, halo_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int barotp_overlap = 0;   // measured slower (see stage_barotp_pair.hip: bt_overlap_usable)
   int nlev_real[NF_REAL];
   int nlev_int[NF_INT];
   std::unordered_map<std::string, int> real_ids, int_ids;

@@ -84,6 +84,7 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
   const DevView &h = c->h;
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
+  hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
   if (nf < 1 || nf > MAXF) return ctx_fail(c, "rccl_xctilr_multi: 1..4 fields per exchange");
   FieldSet F;
   for (int x = 0; x < MAXF; x++) F.p[x] = fields[x < nf ? x : 0];
@@ -92,12 +93,12 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
   const unsigned gns = nhl > 0 ? (unsigned)((2 * nhl * h.ii + 255) / 256) : 0u;
   if (mhl <= 0) {
     if (nhl > 0)
-      hipLaunchKernelGGL(k_pack_ew_ns, dim3(gns, ly, nf), dim3(256), 0, c->stream, c->d, F, nullptr, nullptr, nlev, 0,
+      hipLaunchKernelGGL(k_pack_ew_ns, dim3(gns, ly, nf), dim3(256), 0, st, c->d, F, nullptr, nullptr, nlev, 0,
                          nhl, periodic_j, 0);
   } else {
     const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev * nf;
     if (need > R->cap) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipStreamSynchronize(st));
       for (int s = 0; s < 2; s++) {
         if (R->sbuf[s]) (void)hipFree(R->sbuf[s]);
         if (R->rbuf[s]) (void)hipFree(R->rbuf[s]);
@@ -111,19 +112,19 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
     const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? R->rank - (T.npx - 1) : -1);
     const unsigned gpack = (unsigned)((per + 255) / 256);
     dim3 g(gpack, ly, nf);
-    hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, c->stream, c->d, F, R->sbuf[0],
+    hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, st, c->d, F, R->sbuf[0],
                        R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack);
     // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
     // point-to-point operations between the same pair match in issue order, so every rank sends
     // west then east and receives east then west -- my east halo is the peer's FIRST send.
     ncclGroupStart();
-    if (west >= 0) ncclSend(R->sbuf[0], need, ncclDouble, west, R->comm, c->stream);
-    if (east >= 0) ncclSend(R->sbuf[1], need, ncclDouble, east, R->comm, c->stream);
-    if (east >= 0) ncclRecv(R->rbuf[1], need, ncclDouble, east, R->comm, c->stream);
-    if (west >= 0) ncclRecv(R->rbuf[0], need, ncclDouble, west, R->comm, c->stream);
+    if (west >= 0) ncclSend(R->sbuf[0], need, ncclDouble, west, R->comm, st);
+    if (east >= 0) ncclSend(R->sbuf[1], need, ncclDouble, east, R->comm, st);
+    if (east >= 0) ncclRecv(R->rbuf[1], need, ncclDouble, east, R->comm, st);
+    if (west >= 0) ncclRecv(R->rbuf[0], need, ncclDouble, west, R->comm, st);
     ncclResult_t rc = ncclGroupEnd();
     if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL halo exchange: ") + ncclGetErrorString(rc));
-    hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, c->stream, c->d, F, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
+    hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, st, c->d, F, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
                        west >= 0 ? 1 : 0, east >= 0 ? 1 : 0);
   }
   HIPCHK(c, hipGetLastError());
@@ -154,6 +155,11 @@ int blomgpu_rccl_init(blomgpu_ctx *c, const void *id128, int rank, int nranks) {
   if (rc != ncclSuccess) { delete R; return ctx_fail(c, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc)); }
   R->rank = rank; R->nranks = nranks;
   c->tiling.rccl = R;
+  if (!c->xstream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
   c->tiling.npx = nranks; c->tiling.npy = 1; c->tiling.px = rank; c->tiling.py = 0;
   return 0;
 }
@@ -161,6 +167,7 @@ int blomgpu_rccl_finalize(blomgpu_ctx *c) {
   RcclComm *R = c->tiling.rccl;
   if (!R) return 0;
   (void)hipStreamSynchronize(c->stream);
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   ncclCommDestroy(R->comm);
   for (int s = 0; s < 2; s++) { (void)hipFree(R->sbuf[s]); (void)hipFree(R->rbuf[s]); }
   delete R;

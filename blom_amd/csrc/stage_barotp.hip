@@ -302,8 +302,9 @@ bool bt_phase_usable(blomgpu_ctx *c);
 int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
                     int last, int src, int *src_out, int *ml_out, int *nl_out);
 int bt_phase_check(blomgpu_ctx *c);
+int bt_overlap_usable(blomgpu_ctx *c);
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
-                   int do_odd, int do_even, int src);
+                   int do_odd, int do_even, int src, int tsel);
 
 int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)mm; (void)k1m; (void)k1n;
@@ -354,6 +355,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     // happen exactly where the reference has it (before odd substeps only); the fused kernels need their
     // rim refreshed before a lone even substep as well, hence nreg = 2 takes the one-kernel-per-equation path.
     const bool fused = c->barotp_fused && h.nreg != 2;
+    bool halo_done = false;
     if (fused && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
       // their edge values through memory
@@ -364,6 +366,8 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       // fused odd+even substep pairs per LDS tile (stage_barotp_pair.hip); single substeps only
       // where a pair would straddle a phase boundary (epilogue + sum reset sit in between)
       int lll = lll0;
+      const bool ovl = bt_overlap_usable(c) != 0;
+      halo_done = false;
       while (lll <= last) {
         const bool odd = lll % 2 == 1;
         const bool both = odd && lll + 1 <= last;
@@ -376,10 +380,25 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
         if (!both && !odd) { wo[1] = wo[0]; wm[1] = wm[0]; wn[1] = wn[0]; }
         // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
-        if (c->tiling.multi() || h.nreg == 2)
+        if ((c->tiling.multi() || h.nreg == 2) && !halo_done)
           if (int rc = bt_pair_halo(c, set)) return rc;
-        bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set);
-        set ^= 1;
+        if (ovl) {
+          // fork: outer tile columns + exchange of the new state on xstream, inner columns on stream; join
+          HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+          HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
+          bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set, 1);
+          set ^= 1;
+          c->halo_stream = c->xstream;
+          const int rc = bt_pair_halo(c, set);
+          c->halo_stream = nullptr;
+          if (rc) return rc;
+          HIPCHK(c, hipEventRecord(c->ev_join, c->xstream));
+          HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+          halo_done = true;
+        } else {
+          bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set, 0);
+          set ^= 1;
+        }
         if (!both) { const int ll = ml; ml = nl; nl = ll; }
         lll += both ? 2 : 1;
       }
@@ -412,8 +431,9 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     }
     lll0 = lll0 + lstep / 2;
     // the epilogue reads pb_t(i-1,j), pb_t(i,j-1); the fused kernels write tile interiors only
-    if (fused)
+    if (fused && !halo_done)
       if (int rc = bt_pair_halo(c, set)) return rc;
+    halo_done = false;
     hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl, set);
   }
   HIPCHK(c, hipGetLastError());

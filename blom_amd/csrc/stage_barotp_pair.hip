@@ -34,6 +34,9 @@ struct PairArgs {
   unsigned *flags;           // one word per tile: epoch_base + number of iterations this tile has completed and published
   unsigned epoch_base;       // flags are never reset: every launch counts on from where the previous one stopped
   unsigned *abort_word;      // set by any tile whose wait ran out; every spin also watches it
+  // split launches (PERSIST = false, RCCL tiles): 0 all tile columns, 1 only the west-most and east-most
+  // column of tiles (they produce the E/W strips the exchange sends), 2 only the columns in between
+  int tsel, nbx;
 };
 
 // PERSIST = false: one odd+even pair (or one half) per launch, neighbours synchronise at the kernel
@@ -53,7 +56,8 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
   __shared__ double s_pvo[BJ][BI + 1], s_pvm[BJ][BI + 1], s_pvn[BJ][BI + 1], s_sx[BJ][BI + 1], s_sy[BJ][BI + 1];
   __shared__ int s_abort;
   const int tid = threadIdx.x;
-  long long *prof = a.prof ? a.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+  const unsigned bx = PERSIST || a.tsel == 0 ? blockIdx.x : (a.tsel == 1 ? (blockIdx.x ? a.nbx - 1 : 0u) : blockIdx.x + 1);
+  long long *prof = a.prof ? a.prof + (size_t)(blockIdx.y * gridDim.x + bx) * 16 : nullptr;
   int pslot = 0;
 #ifdef BT_PROFILE
 #define PROF_MARK() do { if (prof && tid == 0) prof[pslot++] = wall_clock64(); } while (0)
@@ -64,7 +68,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
   const bool act = tid < NPT;
   const int li = act ? tid % BI : 0, lj = act ? tid / BI : 0;
   // Fortran indices of this thread's point
-  const int gi = blockIdx.x * TI + 1 + li - HB, gj = blockIdx.y * TJ + 1 + lj - HB;
+  const int gi = bx * TI + 1 + li - HB, gj = blockIdx.y * TJ + 1 + lj - HB;
   const int ii = V.ii, jj = V.jj;
   const bool inarr = act && gi >= 1 - NBDY && gi <= ii + NBDY && gj >= 1 - NBDY && gj <= jj + NBDY;
   const size_t np = V.nplane;
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
   if (PERSIST && tid < 8) {
     const int dx = (tid < 3 ? -1 : (tid < 5 ? 0 : 1)), dy = (tid == 0 || tid == 3 || tid == 5) ? -1 : ((tid == 1 || tid == 6) ? 0 : 1);
     // tid: 0 (-1,-1) 1 (-1,0) 2 (-1,1) 3 (0,-1) 4 (0,1) 5 (1,-1) 6 (1,0) 7 (1,1)
-    int qx = (int)blockIdx.x + dx, qy = (int)blockIdx.y + dy;
+    int qx = (int)bx + dx, qy = (int)blockIdx.y + dy;
     bool exists = true;
     if (qx < 0 || qx >= nbx) { if (V.nreg == 0 || V.nreg == 4) exists = false; else qx = (qx + nbx) % nbx; }
     if (qy < 0 || qy >= nby) { if (V.nreg <= 2) exists = false; else qy = (qy + nby) % nby; }
@@ -305,7 +309,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the count goes out
     __syncthreads();
     done_iters++;
-    if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + blockIdx.x), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + bx), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   } while (PERSIST && lll <= a.last);
   if (mine) {
@@ -366,7 +370,7 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
 }
 
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
-                   int do_odd, int do_even, int src) {
+                   int do_odd, int do_even, int src, int tsel) {
   const DevView &h = c->h;
   PairArgs a;
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;
@@ -375,9 +379,39 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
   a.prof = c->bt_prof;
   a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr; a.epoch_base = 0;
-  dim3 grid((h.ii + TI - 1) / TI, (h.jj + TJ - 1) / TJ);
-  hipLaunchKernelGGL(k_bt_steps<false>, grid, dim3(NTHR), 0, c->stream, c->d, a);
+  const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
+  a.nbx = nbx;
+  if (tsel == 0) {
+    a.tsel = 0;
+    hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);
+    return 0;
+  }
+  // edge tile columns on the exchange stream (their output is what gets packed), the rest on the main stream
+  a.tsel = 1;
+  hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx > 1 ? 2 : 1, nby), dim3(NTHR), 0, c->xstream, c->d, a);
+  if (nbx > 2) {
+    a.tsel = 2;
+    hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx - 2, nby), dim3(NTHR), 0, c->stream, c->d, a);
+  }
   return 0;
+}
+
+// RCCL tiles along i, closed in j: the E/W strips a pair produces come from the two outer columns of
+// LDS tiles only, so those run first on the exchange stream, followed by pack / ncclSend+Recv / unpack,
+// while the columns in between compute on the main stream (the reference's "exchange, then compute"
+// order, phy/mod_barotp.F90:395-397, with the exchange moved to where its input is ready).  With a
+// periodic j the N/S phase of the exchange would read rows the inner tiles are still writing.
+// MEASURED (channel, RCCL self-send, one MI355X): bit-identical, but barotp 4.87 ms instead of 3.26 ms.
+// The pair kernel is latency-bound (15 of its 20 us are the coefficient load), so two half-size
+// launches each still take ~20 us, and the cross-stream fork/join events add ~10 us per pair: there is
+// no throughput-bound interior to hide the exchange behind.  Kept as an option (barotp_overlap=1),
+// off by default.
+int bt_overlap_usable(blomgpu_ctx *c) {
+  const DevView &h = c->h;
+  if (!c->tiling.rccl || !c->xstream || !c->barotp_overlap) return 0;
+  if (h.nreg > 2 || h.nreg == 2) return 0;
+  if (c->tiling.npy != 1) return 0;
+  return (h.ii + TI - 1) / TI >= 3 ? 1 : 0;
 }
 
 // Can the persistent form be used?  Every tile must be resident (one 896-thread workgroup per CU) and a
@@ -416,6 +450,7 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   a.prof = nullptr;
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
+  a.tsel = 0; a.nbx = nbx;
   a.epoch_base = c->bt_epoch;
   c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;
