@@ -54,7 +54,7 @@ def algorithmic_bytes(case, ntr):
 def class_bytes_F(ntr):
     return {
         "remap": 25 + 2 * ntr, "diffus": 19 + 2 * ntr, "pgforc": 15, "momtum": 26, "eddtra": 14,
-        "diapfl": 23 + 2 * ntr, "pbcor1": 12 + 2 * ntr, "pbcor2": 13 + 2 * ntr,
+        "diapfl": 23 + 2 * ntr, "pbcor1": 12 + 2 * ntr, "pbcor2": 13 + 2 * ntr, "convec": 19 + 2 * ntr,
     }
 
 
@@ -198,7 +198,7 @@ def main():
     if args.warmup > 1:
         ns = gpu.step(ns, args.warmup - 1)
     gpu.sync()
-    classes = ["eddtra", "remap", "diffus", "pgforc", "momtum", "diapfl", "barotp", "pbcor1", "pbcor2"]
+    classes = ["eddtra", "remap", "diffus", "pgforc", "momtum", "convec", "diapfl", "barotp", "pbcor1", "pbcor2"]
     stage_ms = {}
     for cl in classes:
         ms, n = gpu.timer_get(cl)
@@ -254,7 +254,7 @@ def main():
                                f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, "
                                f"isopyc_bulkml/remap/geopotential/uc/enscon, ntr={case.ntr}, "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
-                               f"full dyncore stage sequence incl. eddtra (gm, frozen slopes of amplitude {NSLP0:g}); "
+                               f"full dyncore stage sequence incl. eddtra and convec (gm, frozen slopes of amplitude {NSLP0:g}); "
                                "N>1: halos over RCCL send/recv, "
                                "value counts tile-days/s" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
                    "state_finite": finite, "tiles_bit_identical": len(set(crcs)) == 1,

@@ -221,6 +221,7 @@ int st_diffus(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_pgforc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
+int st_convec(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_cppm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     // stage_cppm.hip, called by advect

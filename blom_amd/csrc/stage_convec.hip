@@ -1,0 +1,264 @@
+// convec -- removal of static instabilities between the mixed layer and the interior layers, then
+// redistribution of momentum onto the new layer structure (phy/mod_convec.F90:43-449; called between
+// momtum and diapfl for isopyc_bulkml, phy/mod_blom_step.F90:172-176).
+//
+// One thread per column.  The reference copies a column into 1-D arrays, edits them and copies them
+// back; the 1-D arrays ARE the column's planes here, edited in place (the planes of 64 neighbouring
+// columns are contiguous, so every access of a wavefront is one 512-byte segment).  Almost all columns
+// are statically stable and leave after one density comparison; their only work is the interface
+// pressure scan p(k+1) = p(k) + dp(k).  The velocity remap needs the old column after the new one has
+// started to be written, so it goes through one work plane stack.
+#include "blomgpu_internal.h"
+#include "eos.h"
+#include "diapfl_common.h"
+
+#define PLANE_IJ(V)                                                        \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
+  if (t_ >= (V).nplane) return;                                            \
+  const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
+  const size_t c = t_;                                                     \
+  (void)i; (void)j; (void)c
+
+#define MAXTR 8
+enum { CV_UN = 0 };   // work field: remapped velocity column
+
+__global__ __launch_bounds__(64) void k_convec_column(const DevView *Vp, int n, int nn, int *errflag) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int kk = V.kk, ntr = V.ntr;
+  const size_t np = V.nplane;
+  const double epsilp = 1.e-12;
+  // 1-based level k of the time level n: element c + (k - 1 + nn) * np
+  double *ttem = V.f[F_temp] + c + (size_t)nn * np - np, *ssal = V.f[F_saln] + c + (size_t)nn * np - np;
+  double *delp = V.f[F_dp] + c + (size_t)nn * np - np, *dens = V.f[F_sigma] + c + (size_t)nn * np - np;
+  const double *densr = V.f[F_sigmar] + c - np;
+  double *trc = V.f[F_trc] + c + (size_t)nn * np - np;      // tracer nt: + nt * 2 * kk * np
+  const size_t ntl = (size_t)2 * kk * np;
+#define TT(k) ttem[(size_t)(k) * np]
+#define SS(k) ssal[(size_t)(k) * np]
+#define DP(k) delp[(size_t)(k) * np]
+#define DN(k) dens[(size_t)(k) * np]
+#define DR(k) densr[(size_t)(k) * np]
+#define TR(nt, k) trc[(size_t)(nt) * ntl + (size_t)(k) * np]
+  double trdps[MAXTR];
+  double tdps, sdps, dps, ttmp, stmp, dtmp, q = 0.;
+
+  // first physical interior layer, :95-109
+  int k = 3;
+  dps = 0.;
+  while (DP(k) < epsilp) {
+    dps = dps + DP(k);
+    DP(k) = 0.;
+    k = k + 1;
+    if (k > kk) break;
+  }
+  if (k > kk) DP(2) = DP(2) + dps;
+  else DP(k) = DP(k) + dps;
+  int kfpl = k;
+  int *kfpla = V.m[I_kfpla] + c + (size_t)(n - 1) * np;
+  const int kfplo = *kfpla;
+  if (kfpl < kfplo) {                                        // :110-191
+    tdps = 0.; sdps = 0.; dps = 0.;
+    for (int nt = 0; nt < ntr; nt++) trdps[nt] = 0.;
+    if (kfplo <= kk) {
+      for (k = kfpl; k <= kfplo; k++) {
+        const double d = DP(k);
+        tdps = tdps + TT(k) * d;
+        sdps = sdps + SS(k) * d;
+        dps = dps + d;
+        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * d;
+      }
+      q = 1. / dps;
+      ttmp = tdps * q;
+      stmp = sdps * q;
+      dtmp = eos::sig(V.P, ttmp, stmp);
+      if (dtmp > DR(kfplo)) {
+        for (k = kfpl; k <= kfplo - 1; k++) DP(k) = 0.;
+        kfpl = kfplo;
+        TT(kfpl) = ttmp; SS(kfpl) = stmp; DN(kfpl) = dtmp; DP(kfpl) = dps;
+        for (int nt = 0; nt < ntr; nt++) TR(nt, kfpl) = trdps[nt] * q;
+      }
+    } else {
+      for (k = kfpl; k <= kk; k++) {
+        const double d = DP(k);
+        tdps = tdps + TT(k) * d;
+        sdps = sdps + SS(k) * d;
+        dps = dps + d;
+        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * d;
+        DP(k) = 0.;
+      }
+      q = 1. / dps;
+      ttmp = tdps * q;
+      stmp = sdps * q;
+      dtmp = eos::sig(V.P, ttmp, stmp);
+      kfpl = kk;
+      while (dtmp < DR(kfpl)) {
+        if (kfpl == 3) break;
+        kfpl = kfpl - 1;
+      }
+      TT(kfpl) = ttmp; SS(kfpl) = stmp; DN(kfpl) = dtmp; DP(kfpl) = dps;
+      for (int nt = 0; nt < ntr; nt++) TR(nt, kfpl) = trdps[nt] * q;
+    }
+  }
+
+  if (kfpl <= kk) {                                          // :193-283
+    bool done = false;
+    int niter = 0;
+    while (!done) {
+      niter = niter + 1;
+      if (niter == 100) {                                    // the reference prints and goes on, :203-206
+        atomicOr(errflag, 1);
+        break;
+      }
+      done = true;
+      const double t2 = TT(2), s2 = SS(2), d2 = DP(2);
+      tdps = t2 * d2;
+      sdps = s2 * d2;
+      dps = d2;
+      for (int nt = 0; nt < ntr; nt++) trdps[nt] = TR(nt, 2) * d2;
+      ttmp = t2;
+      stmp = s2;
+      k = kfpl;
+      while (true) {
+        const double tk = TT(k), sk = SS(k), dk = DP(k);
+        if (!(eos::rho(dps, ttmp, stmp) > eos::rho(dps, tk, sk) || dk < epsilp)) break;
+        tdps = tdps + tk * dk;
+        sdps = sdps + sk * dk;
+        dps = dps + dk;
+        q = 1. / dps;
+        ttmp = tdps * q;
+        stmp = sdps * q;
+        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * dk;
+        k = k + 1;
+        if (k > kk) break;
+      }
+      const int kmix = k - 1;
+      if (kmix >= kfpl) {
+        const double dn2 = eos::sig(V.P, ttmp, stmp);
+        TT(2) = ttmp;
+        SS(2) = stmp;
+        DN(2) = dn2;
+        for (int nt = 0; nt < ntr; nt++) TR(nt, 2) = trdps[nt] * q;
+        dps = 0.;
+        for (k = kfpl; k <= kmix; k++) {
+          dps = dps + DP(k);
+          DP(k) = 0.;
+        }
+        k = kmix;
+        while (dn2 < DR(k)) {
+          if (k == 3) break;
+          k = k - 1;
+        }
+        kfpl = k;
+        TT(kfpl) = ttmp; SS(kfpl) = stmp; DN(kfpl) = dn2; DP(kfpl) = dps;
+        for (int nt = 0; nt < ntr; nt++) TR(nt, kfpl) = TR(nt, 2);
+        for (k = kfpl + 1; k <= kmix; k++) {
+          const double dr = DR(k);
+          TT(k) = ttmp;
+          DN(k) = dr;
+          SS(k) = eosd::sofsig(V.P, dr, ttmp);
+        }
+      }
+    }
+  }
+  *kfpla = kfpl;
+  double *p = V.f[F_p] + c;                                  // :288-302
+  double acc = p[0];
+  for (k = 1; k <= kk; k++) {
+    acc = acc + DP(k);
+    p[(size_t)k * np] = acc;
+  }
+#undef TT
+#undef SS
+#undef DP
+#undef DN
+#undef DR
+#undef TR
+}
+
+// :315-391: u (blockIdx.y = 0) / v (1) columns are remapped conservatively from the old interface
+// pressures at the velocity point (pu, pv) to the new ones
+__global__ __launch_bounds__(64) void k_convec_velocity(const DevView *Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const bool isv = by_ == 1;
+  if (!V.m[isv ? I_iv : I_iu][c]) return;
+  const int kk = V.kk;
+  const size_t np = V.nplane, cm = isv ? c - V.ni : c - 1;
+  double *vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np - np;       // 1-based level
+  const double *po = V.f[isv ? F_pv : F_pu] + c - np;                   // po(k), k = 2..kk+1; po(1) = 0
+  const double *p = V.f[F_p] - np;
+  double *un = WK(V, CV_UN + (isv ? 1 : 0)) + c - np;
+  const double pbot = po[(size_t)(kk + 1) * np];
+  int ko = 1;
+  double po_lo = 0., po_hi = po[(size_t)2 * np];                         // po(ko), po(ko+1)
+  double pn_lo = 0.;                                                     // pn(kn)
+  for (int kn = 1; kn <= kk; kn++) {
+    const double pn_hi = .5 * (fmin2(pbot, p[c + (size_t)(kn + 1) * np]) + fmin2(pbot, p[cm + (size_t)(kn + 1) * np]));
+    double r;
+    if (pn_hi - pn_lo == 0.) {
+      r = 0.;
+    } else {
+      double udpn = 0.;
+      while (pn_hi > po_hi) {
+        udpn = udpn + vel[(size_t)ko * np] * (po_hi - fmax2(po_lo, pn_lo));
+        ko = ko + 1;
+        po_lo = po_hi;
+        po_hi = ko <= kk ? po[(size_t)(ko + 1) * np] : 1.e300;   // (never reached: pn <= po(kk+1))
+      }
+      r = (udpn + vel[(size_t)ko * np] * (pn_hi - fmax2(po_lo, pn_lo))) / (pn_hi - pn_lo);
+    }
+    un[(size_t)kn * np] = r;
+    pn_lo = pn_hi;
+  }
+  for (int k = 1; k <= kk; k++) vel[(size_t)k * np] = un[(size_t)k * np];
+}
+
+// :393-414
+__global__ void k_convec_dpudpv(const DevView *Vp, int nn) {
+  const DevView &V = *Vp;
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  const int t_ = bx_ * blockDim.x + threadIdx.x;
+  if (t_ >= V.nplane) return;
+  const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const size_t c = t_;
+  const int k = by_;
+  const size_t np = V.nplane, o0 = (size_t)k * np, o1 = (size_t)(k + 1) * np, ob = (size_t)V.kk * np;
+  const double *p = V.f[F_p];
+  if (V.m[I_iu][c]) {
+    const size_t w = c - 1;
+    const double q = fmin2(p[c + ob], p[w + ob]);
+    V.f[F_dpu][c + (size_t)(k + nn) * np] =
+        .5 * ((fmin2(q, p[w + o1]) - fmin2(q, p[w + o0])) + (fmin2(q, p[c + o1]) - fmin2(q, p[c + o0])));
+  }
+  if (V.m[I_iv][c]) {
+    const size_t s = c - V.ni;
+    const double q = fmin2(p[c + ob], p[s + ob]);
+    V.f[F_dpv][c + (size_t)(k + nn) * np] =
+        .5 * ((fmin2(q, p[s + o1]) - fmin2(q, p[s + o0])) + (fmin2(q, p[c + o1]) - fmin2(q, p[c + o0])));
+  }
+}
+
+int st_convec(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)mm; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.ntr > MAXTR) return ctx_fail(c, "convec: too many tracers for the device kernels");
+  if (h.P.vcoord_tag != 1) return ctx_fail(c, "convec is only called for isopyc_bulkml (phy/mod_blom_step.F90:172-176)");
+  if (int rc = ctx_err_words(c)) return rc;
+  {
+    TimeScope ts(c, "convec");
+    hipLaunchKernelGGL(k_convec_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, n, nn, c->err_dev + 3);
+    if (int rc = st_xctilr(c, h.f[F_p], 1, h.kk + 1, 1, 1, 1)) return rc;                       // :313
+    hipLaunchKernelGGL(k_convec_velocity, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, nn);
+    hipLaunchKernelGGL(k_convec_dpudpv, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

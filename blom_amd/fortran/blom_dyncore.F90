@@ -94,6 +94,7 @@ contains
     call diffus(m,n,mm,nn,k1m,k1n)
     call pgforc(m,n,mm,nn,k1m,k1n)
     call momtum(m,n,mm,nn,k1m,k1n)
+    call convec(m,n,mm,nn,k1m,k1n)
     call diapfl(n,nn,k1n)
     call mxlayr_tail(nn,k1n)
     call barotp(m,n,mm,nn,k1m,k1n)

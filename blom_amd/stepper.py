@@ -2,8 +2,8 @@
 
 Mirrors the order of phy/mod_blom_step.F90:96-253 for the isopyc_bulkml branch,
 restricted to the stages of the hot path and the ones sitting between them
-(SURVEY.md 8a/8f).  Stages whose reference modules need netCDF/CVMix (cmnfld, difest, mxlayr,
-thermf) are not part of the sequence: diffusivities and isopycnal slopes stay frozen.  eddtra is
+(SURVEY.md 8a/8f).  convec (phy/mod_blom_step.F90:174, between momtum and diapfl) is part of it.  Stages whose
+reference modules need netCDF/CVMix (cmnfld, difest, mxlayr, thermf) are not part of the sequence: diffusivities and isopycnal slopes stay frozen.  eddtra is
 part of it; the reference build used as oracle cannot contain it (mod_eddtra needs mod_difest ->
 CVMix), so a backend without it skips it -- with zero slopes nslpx/nslpy, which is what the
 reference-pinned cases use, eddtra's result is exactly the zero fluxes that backend keeps.
@@ -11,7 +11,7 @@ reference-pinned cases use, eddtra's result is exactly the zero fluxes that back
 from .hostinit import step_indices
 
 DYNCORE_STAGES = ("init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect", "pbcor1",
-                  "diffus", "pgforc", "momtum", "diapfl", "mxlayr_tail", "barotp", "pbcor2",
+                  "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "barotp", "pbcor2",
                   "tmsmt2")
 OPTIONAL_STAGES = ("eddtra",)
 # halo_cmnfld2 / halo_difest : the xctilr calls of phy/mod_cmnfld_routines.F90:1171-1172 and

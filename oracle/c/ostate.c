@@ -91,6 +91,7 @@ int orc_stage(OState *S, const char *st, int m, int n, int mm, int nn, int k1m, 
   else if (!strcmp(st, "pbcor2")) orc_pbcor2(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "momtum")) orc_momtum(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "barotp")) orc_barotp(S, m, n, mm, nn, k1m, k1n);
+  else if (!strcmp(st, "convec")) orc_convec(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "diapfl")) orc_diapfl(S, n, nn, k1n);
   else if (!strcmp(st, "eddtra")) return orc_eddtra(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "mxlayr_tail")) orc_mxlayr_tail(S, nn, k1n);

@@ -125,6 +125,7 @@ void orc_pbcor1(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_pbcor2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_momtum(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
+void orc_convec(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_diapfl(OState *S, int n, int nn, int k1n);
 int orc_eddtra(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);   /* PARITY UNPINNED, see eddtra.c */
 void orc_mxlayr_tail(OState *S, int nn, int k1n);

@@ -78,3 +78,36 @@ def put_fields(be, fields):
         if hasattr(be, "has_field") and not be.has_field(nm):
             continue
         be.put(nm, a)
+
+
+def destabilise_for_convec(be, case, n, seed=0):
+    """Edits backend `be` (level n = 1|2 of the two-time-level arrays) so that convec has real work:
+    in about a third of the columns the mixed layer (layers 1, 2) is made colder and saltier than
+    several interior layers, some interior layers are emptied, and kfpla is moved both below and
+    beyond the first non-empty interior layer (the `kfpl < kfplo <= kk` and `kfplo > kk` branches,
+    phy/mod_convec.F90:110-191).  Returns the number of edited columns."""
+    kk = case.kdm
+    nn = (n - 1) * kk
+    rng = np.random.default_rng(seed)
+    temp, saln, dp, kf = (np.array(be.get(nm)) for nm in ("temp", "saln", "dp", "kfpla"))
+    nj, ni = temp.shape[1:]
+    pick = rng.random((nj, ni)) < 0.35
+    dT = rng.uniform(2.0, 14.0, (nj, ni))
+    dS = rng.uniform(0.0, 1.5, (nj, ni))
+    for k in (0, 1):
+        temp[nn + k][pick] -= dT[pick]
+        saln[nn + k][pick] += dS[pick]
+    empty = (rng.random((kk, nj, ni)) < 0.15) & pick[None]
+    empty[:2] = False
+    dpn = dp[nn:nn + kk]
+    dpn[empty] = 0.0
+    kf[n - 1][pick] = rng.integers(3, kk + 2, (nj, ni))[pick]
+    be.put("temp", temp)
+    be.put("saln", saln)
+    be.put("dp", dp)
+    be.put("kfpla", kf)
+    for nm in ("u", "v"):                      # a sheared flow for the velocity remap to redistribute
+        a = np.array(be.get(nm))
+        a[nn:nn + kk] = 0.1 * rng.standard_normal((kk, nj, ni))
+        be.put(nm, a)
+    return int(pick.sum())
