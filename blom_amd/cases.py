@@ -12,6 +12,7 @@ BASELINE.json's configs:
   tri_s    24x20x6    small ocean with the arctic patch of the tripolar grids (nreg=2): closed in the south,
                       folded onto itself across the last row, periodic in i
   box_s    24x20x8    small closed basin with an island and a promontory coast
+  per_s    24x24x6    doubly periodic (nreg = 3): halo corner and N/S-exchange tests
 
 The idealised definitions mirror the spirit of the reference's test cases
 (fuk95/mod_fuk95.F90:122-447 flat-bottom front; channel/mod_channel.F90:61-323 tanh
@@ -104,6 +105,7 @@ _DIMS = {
     # and time steps (baclin 4800 s, batrop 96 s => lstep 50); analytic continents instead of grid.nc
     "tnx2v1s": (180, 193, 53, 2, 100.0e3, 4800.0, 96.0),
     "box_s": (24, 20, 8, 0, 10.0e3, 900.0, 18.0),
+    "per_s": (24, 24, 6, 3, 10.0e3, 900.0, 18.0),      # doubly periodic f-plane with an island and a seamount
     "fuk95": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
 }
@@ -173,6 +175,12 @@ def _depth_for(name, idm, jdm, dx):
         d[1:3, 3:9] = 0.0
         d[jdm - 6:, 15:19] = 0.0           # land touching the seam
         d[8:11, 5:8] = 0.0                 # island
+        return d
+    if name == "per_s":
+        x = (ii - 0.5) / idm
+        y = (jj - 0.5) / jdm
+        d = 700.0 - 300.0 * np.exp(-((x - 0.7) ** 2 + (y - 0.3) ** 2) / 0.02) + 0.0 * (ii + jj)
+        d[10:13, 6:10] = 0.0               # island
         return d
     if name == "fuk95":
         d = np.full((jdm, idm), 200.0)     # fuk95/mod_fuk95.F90:126-134 flat, walls in i

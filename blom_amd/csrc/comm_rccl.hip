@@ -1,9 +1,9 @@
 // xctilr over RCCL: one process per GPU, neighbour ncclSend/ncclRecv (xGMI is point-to-point, a
-// halo exchange touches only the two neighbouring GPUs).  Tiles are laid out along i (npx x 1),
-// which is how the channel case is weak-scaled in bench.py: phase 1 (N/S) is local -- the domain
-// is closed or periodic in j within the tile -- and phase 2 (E/W, rows 1-nhl..jj+nhl so that the
-// corners travel with it) is the exchange, exactly the reference's two phases
-// (phy/mod_xc.F90:3036-3106 N-S, :3131-3178 E-W).  Messages: mhl*(jj+2*nhl)*nlev reals per
+// halo exchange touches only the neighbouring GPUs).  Uniform npx x npy tile grid, rank = px + npx*py
+// (the reference's mproc/nproc numbering, bld/blom_dimensions:104-148).  The reference's two phases
+// (phy/mod_xc.F90:3036-3106 N-S, :3131-3178 E-W): phase 1 exchanges rows of the columns 1..ii with the
+// south/north neighbours (tile-local when npy = 1: periodic wrap or vland), phase 2 exchanges the E/W
+// strips over rows 1-nhl..jj+nhl, so the corners travel with it.  Messages: mhl*(jj+2*nhl)*nlev reals per
 // neighbour, packed/unpacked by small kernels on the context's stream; RCCL runs on the same
 // stream, so ordering with the stage kernels needs no events.
 #include "blomgpu_internal.h"
@@ -15,6 +15,9 @@ struct RcclComm {
   int rank = 0, nranks = 1;
   double *sbuf[2] = {nullptr, nullptr}, *rbuf[2] = {nullptr, nullptr};   // [0] west, [1] east
   size_t cap = 0;
+  double *sbuf_ns[2] = {nullptr, nullptr}, *rbuf_ns[2] = {nullptr, nullptr};   // [0] south, [1] north
+  size_t cap_ns = 0;
+  int force_ns = 0;          // test hook: route a tile-local periodic N/S wrap through send/recv to itself
 };
 
 // up to MAXF plane stacks (same nlev, same halo widths) travel in one message per neighbour
@@ -30,7 +33,7 @@ struct FieldSet {
 // outside 1..jj are the very values phase 1 writes, so the packer derives them itself instead of
 // waiting for them.  Buffer layout [field][level][row][q].
 __global__ void k_pack_ew_ns(const DevView *Vp, FieldSet F, double *__restrict__ west, double *__restrict__ east,
-                             int nlev, int mhl, int nhl, int periodic, int gpack) {
+                             int nlev, int mhl, int nhl, int periodic, int gpack, int rows_present) {
   const DevView &V = *Vp;
   double *a = F.p[blockIdx.z];
   if ((int)blockIdx.x >= gpack) {
@@ -50,7 +53,8 @@ __global__ void k_pack_ew_ns(const DevView *Vp, FieldSet F, double *__restrict__
   if (t >= per) return;
   const int q = t % mhl, r = t / mhl;          // q-th column of the strip, row index
   const int j = r + 1 - nhl;
-  const bool inside = j >= 1 && j <= V.jj;
+  // rows_present: phase 1 was an exchange and its result is in the array; else derive the local rule
+  const bool inside = rows_present || (j >= 1 && j <= V.jj);
   const int js = inside ? j : (j < 1 ? j + V.jj : j - V.jj);
   const bool land = !inside && !periodic;
   const size_t fo = (size_t)blockIdx.z * nlev * per;
@@ -80,21 +84,87 @@ __global__ void k_unpack_ew(const DevView *Vp, FieldSet F, const double *__restr
   }
 }
 
+// phase 1 as an exchange (npy > 1): rows of the columns 1..ii.  south buffer <- my rows 1..nhl (they
+// become the south neighbour's north halo), north buffer <- my rows jj-nhl+1..jj.  Layout [field][level][r][i].
+__global__ void k_pack_ns(const DevView *Vp, FieldSet F, double *__restrict__ south, double *__restrict__ north,
+                          int nlev, int nhl) {
+  const DevView &V = *Vp;
+  const int per = nhl * V.ii;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per) return;
+  const int i = t % V.ii + 1, r = t / V.ii;
+  const double *a = F.p[blockIdx.z];
+  const size_t fo = (size_t)blockIdx.z * nlev * per;
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    south[fo + (size_t)k * per + t] = a[IDX(V, i, 1 + r) + o];
+    north[fo + (size_t)k * per + t] = a[IDX(V, i, V.jj - nhl + 1 + r) + o];
+  }
+}
+// from_south holds the south neighbour's north-most rows -> my rows 1-nhl..0; from_north the north
+// neighbour's south-most rows -> my rows jj+1..jj+nhl; vland where the domain is closed
+__global__ void k_unpack_ns(const DevView *Vp, FieldSet F, const double *__restrict__ from_south,
+                            const double *__restrict__ from_north, int nlev, int nhl, int has_s, int has_n) {
+  const DevView &V = *Vp;
+  const int per = nhl * V.ii;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per) return;
+  const int i = t % V.ii + 1, r = t / V.ii;
+  double *a = F.p[blockIdx.z];
+  const size_t fo = (size_t)blockIdx.z * nlev * per;
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[IDX(V, i, 1 - nhl + r) + o] = has_s ? from_south[fo + (size_t)k * per + t] : V.P.vland;
+    a[IDX(V, i, V.jj + 1 + r) + o] = has_n ? from_north[fo + (size_t)k * per + t] : V.P.vland;
+  }
+}
+
 int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl) {
   const DevView &h = c->h;
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
   hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
   if (nf < 1 || nf > MAXF) return ctx_fail(c, "rccl_xctilr_multi: 1..4 fields per exchange");
+  if (h.nreg == 2) return ctx_fail(c, "RCCL tiles: the arctic patch (nreg = 2) is not built for more than one tile");
   FieldSet F;
   for (int x = 0; x < MAXF; x++) F.p[x] = fields[x < nf ? x : 0];
   const int ly = nlev > 64 ? 64 : nlev;
   const int periodic_j = h.nreg > 2 ? 1 : 0;
-  const unsigned gns = nhl > 0 ? (unsigned)((2 * nhl * h.ii + 255) / 256) : 0u;
+  const bool per_i = !(h.nreg == 0 || h.nreg == 4);
+  // ---- phase 1 as an exchange: several tile rows, or the single-rank test hook -----------------------
+  const bool ns_exchange = nhl > 0 && (T.npy > 1 || (R->force_ns && periodic_j));
+  if (ns_exchange) {
+    const size_t per = (size_t)nhl * h.ii, need = per * nlev * nf;
+    if (need > R->cap_ns) {
+      HIPCHK(c, hipStreamSynchronize(st));
+      for (int s = 0; s < 2; s++) {
+        if (R->sbuf_ns[s]) (void)hipFree(R->sbuf_ns[s]);
+        if (R->rbuf_ns[s]) (void)hipFree(R->rbuf_ns[s]);
+        HIPCHK(c, hipMalloc((void **)&R->sbuf_ns[s], need * sizeof(double)));
+        HIPCHK(c, hipMalloc((void **)&R->rbuf_ns[s], need * sizeof(double)));
+      }
+      R->cap_ns = need;
+    }
+    const int south = T.py > 0 ? R->rank - T.npx : (periodic_j ? R->rank + T.npx * (T.npy - 1) : -1);
+    const int north = T.py < T.npy - 1 ? R->rank + T.npx : (periodic_j ? R->rank - T.npx * (T.npy - 1) : -1);
+    dim3 g((unsigned)((per + 255) / 256), ly, nf);
+    hipLaunchKernelGGL(k_pack_ns, g, dim3(256), 0, st, c->d, F, R->sbuf_ns[0], R->sbuf_ns[1], nlev, nhl);
+    // same matching rule as E/W below: send south, send north, receive north, receive south
+    ncclGroupStart();
+    if (south >= 0) ncclSend(R->sbuf_ns[0], need, ncclDouble, south, R->comm, st);
+    if (north >= 0) ncclSend(R->sbuf_ns[1], need, ncclDouble, north, R->comm, st);
+    if (north >= 0) ncclRecv(R->rbuf_ns[1], need, ncclDouble, north, R->comm, st);
+    if (south >= 0) ncclRecv(R->rbuf_ns[0], need, ncclDouble, south, R->comm, st);
+    ncclResult_t rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL halo exchange (N/S): ") + ncclGetErrorString(rc));
+    hipLaunchKernelGGL(k_unpack_ns, g, dim3(256), 0, st, c->d, F, R->rbuf_ns[0], R->rbuf_ns[1], nlev, nhl,
+                       south >= 0 ? 1 : 0, north >= 0 ? 1 : 0);
+  }
+  const unsigned gns = nhl > 0 && !ns_exchange ? (unsigned)((2 * nhl * h.ii + 255) / 256) : 0u;
   if (mhl <= 0) {
-    if (nhl > 0)
+    if (gns)
       hipLaunchKernelGGL(k_pack_ew_ns, dim3(gns, ly, nf), dim3(256), 0, st, c->d, F, nullptr, nullptr, nlev, 0,
-                         nhl, periodic_j, 0);
+                         nhl, periodic_j, 0, 0);
   } else {
     const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev * nf;
     if (need > R->cap) {
@@ -107,13 +177,13 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
       }
       R->cap = need;
     }
-    const bool per_i = !(h.nreg == 0 || h.nreg == 4);
-    const int west = T.px > 0 ? R->rank - 1 : (per_i ? R->rank + T.npx - 1 : -1);
-    const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? R->rank - (T.npx - 1) : -1);
+    const int row0 = R->rank - T.px;        // first rank of my tile row
+    const int west = T.px > 0 ? R->rank - 1 : (per_i ? row0 + T.npx - 1 : -1);
+    const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? row0 : -1);
     const unsigned gpack = (unsigned)((per + 255) / 256);
     dim3 g(gpack, ly, nf);
     hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, st, c->d, F, R->sbuf[0],
-                       R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack);
+                       R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack, ns_exchange ? 1 : 0);
     // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
     // point-to-point operations between the same pair match in issue order, so every rank sends
     // west then east and receives east then west -- my east halo is the peer's FIRST send.
@@ -144,23 +214,40 @@ int blomgpu_rccl_unique_id(void *id128) {
   memcpy(id128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
   return 0;
 }
-int blomgpu_rccl_init(blomgpu_ctx *c, const void *id128, int rank, int nranks) {
-  if (c->h.i0 != rank * c->h.ii || c->h.itdm != nranks * c->h.ii || c->h.jtdm != c->h.jj)
-    return ctx_fail(c, "rccl_init: tiles must be laid out along i with equal extents (i0 = rank*idm, itdm = nranks*idm)");
+// Tiles: npx x npy, rank = px + npx*py; the context must have been created with the matching window
+// (i0 = px*ii, j0 = py*jj, itdm = npx*ii, jtdm = npy*jj).
+int blomgpu_rccl_init_2d(blomgpu_ctx *c, const void *id128, int rank, int npx, int npy) {
+  if (npx < 1 || npy < 1 || rank < 0 || rank >= npx * npy) return ctx_fail(c, "rccl_init: bad tile grid");
+  const int px = rank % npx, py = rank / npx;
+  if (c->h.i0 != px * c->h.ii || c->h.itdm != npx * c->h.ii || c->h.j0 != py * c->h.jj || c->h.jtdm != npy * c->h.jj)
+    return ctx_fail(c, "rccl_init: the context's window does not match tile (px,py) of a uniform npx x npy grid "
+                       "(i0 = px*idm, j0 = py*jdm, itdm = npx*idm, jtdm = npy*jdm)");
+  if (c->h.nreg == 2 && npx * npy > 1)
+    return ctx_fail(c, "rccl_init: the arctic patch (nreg = 2) is not built for more than one tile");
   HIPCHK(c, hipSetDevice(c->device));
   RcclComm *R = new RcclComm();
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
-  ncclResult_t rc = ncclCommInitRank(&R->comm, nranks, id, rank);
+  ncclResult_t rc = ncclCommInitRank(&R->comm, npx * npy, id, rank);
   if (rc != ncclSuccess) { delete R; return ctx_fail(c, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc)); }
-  R->rank = rank; R->nranks = nranks;
+  R->rank = rank; R->nranks = npx * npy;
   c->tiling.rccl = R;
   if (!c->xstream) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
-  c->tiling.npx = nranks; c->tiling.npy = 1; c->tiling.px = rank; c->tiling.py = 0;
+  c->tiling.npx = npx; c->tiling.npy = npy; c->tiling.px = px; c->tiling.py = py;
+  return 0;
+}
+int blomgpu_rccl_init(blomgpu_ctx *c, const void *id128, int rank, int nranks) {      // tiles along i
+  return blomgpu_rccl_init_2d(c, id128, rank, nranks, 1);
+}
+// test hook: with one tile row and a j-periodic domain, route the N/S wrap through send/recv (to the
+// rank itself) instead of the local copy, so that the phase-1 exchange code runs on a single GPU
+int blomgpu_rccl_force_ns_exchange(blomgpu_ctx *c, int on) {
+  if (!c->tiling.rccl) return ctx_fail(c, "rccl_force_ns_exchange: no RCCL transport");
+  c->tiling.rccl->force_ns = on;
   return 0;
 }
 int blomgpu_rccl_finalize(blomgpu_ctx *c) {
@@ -169,7 +256,10 @@ int blomgpu_rccl_finalize(blomgpu_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   ncclCommDestroy(R->comm);
-  for (int s = 0; s < 2; s++) { (void)hipFree(R->sbuf[s]); (void)hipFree(R->rbuf[s]); }
+  for (int s = 0; s < 2; s++) {
+    (void)hipFree(R->sbuf[s]); (void)hipFree(R->rbuf[s]);
+    (void)hipFree(R->sbuf_ns[s]); (void)hipFree(R->rbuf_ns[s]);
+  }
   delete R;
   c->tiling.rccl = nullptr;
   return 0;

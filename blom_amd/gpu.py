@@ -131,6 +131,13 @@ class BlomGpu:
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
         self._chk(self.lib.blomgpu_rccl_init(self.ctx, buf, rank, nranks))
 
+    def rccl_init_2d(self, id128, rank, npx, npy):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.lib.blomgpu_rccl_init_2d(self.ctx, buf, rank, npx, npy))
+
+    def rccl_force_ns_exchange(self, on=True):
+        self._chk(self.lib.blomgpu_rccl_force_ns_exchange(self.ctx, int(on)))
+
     def rccl_finalize(self):
         self.lib.blomgpu_rccl_finalize(self.ctx)
 

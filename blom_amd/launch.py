@@ -97,3 +97,78 @@ def exchange_ew_host(a, idm, jdm, mhl, nhl, env, periodic):
     a[:, rows, 4 - mhl:4] = from_w.numpy() if west >= 0 else vland
     a[:, rows, 4 + idm:4 + idm + mhl] = from_e.numpy() if east >= 0 else vland
     return a
+
+
+def tile_layout_2d(idm, jdm, rank, npx, npy):
+    """window of tile `rank` = px + npx*py in a uniform npx x npy grid (bld/blom_dimensions:104-148)"""
+    if not (0 <= rank < npx * npy):
+        raise ValueError(f"rank {rank} outside a {npx}x{npy} tile grid")
+    px, py = rank % npx, rank // npx
+    return dict(itdm=idm * npx, jtdm=jdm * npy, i0=px * idm, j0=py * jdm, px=px, py=py, npx=npx, npy=npy)
+
+
+def neighbours_2d(rank, npx, npy, periodic_i, periodic_j):
+    """(west, east, south, north) ranks, -1 where the domain is closed -- the rule of
+    rccl_xctilr_multi in blom_amd/csrc/comm_rccl.hip"""
+    px, py = rank % npx, rank // npx
+    row0 = rank - px
+    west = rank - 1 if px > 0 else (row0 + npx - 1 if periodic_i else -1)
+    east = rank + 1 if px < npx - 1 else (row0 if periodic_i else -1)
+    south = rank - npx if py > 0 else (rank + npx * (npy - 1) if periodic_j else -1)
+    north = rank + npx if py < npy - 1 else (rank - npx * (npy - 1) if periodic_j else -1)
+    return west, east, south, north
+
+
+def _sendrecv_pair(to_lo, to_hi, lo, hi):
+    """send lo, send hi, receive hi, receive lo -- the matching order of comm_rccl.hip"""
+    import torch
+    import torch.distributed as dist
+    from_hi, from_lo = torch.empty_like(to_lo), torch.empty_like(to_hi)
+    ops = []
+    if lo >= 0:
+        ops.append(dist.P2POp(dist.isend, to_lo, lo))
+    if hi >= 0:
+        ops.append(dist.P2POp(dist.isend, to_hi, hi))
+    if hi >= 0:
+        ops.append(dist.P2POp(dist.irecv, from_hi, hi))
+    if lo >= 0:
+        ops.append(dist.P2POp(dist.irecv, from_lo, lo))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    return from_lo, from_hi
+
+
+def exchange_2d_host(a, idm, jdm, mhl, nhl, rank, npx, npy, nreg):
+    """Host (numpy + torch.distributed p2p) statement of both phases of rccl_xctilr_multi for an
+    npx x npy tile grid: phase 1 rows of the columns 1..idm with south/north (tile-local for npy = 1),
+    phase 2 the E/W strips over rows 1-nhl..jdm+nhl.  `a` is (nlev, jdm+8, idm+8), updated in place."""
+    import torch
+    periodic_i, periodic_j = nreg not in (0, 4), nreg > 2
+    west, east, south, north = neighbours_2d(rank, npx, npy, periodic_i, periodic_j)
+    vland = 0.0
+    cols = slice(4, 4 + idm)
+    if nhl > 0:
+        if npy > 1:
+            to_s = torch.from_numpy(np.ascontiguousarray(a[:, 4:4 + nhl, cols]))
+            to_n = torch.from_numpy(np.ascontiguousarray(a[:, 4 + jdm - nhl:4 + jdm, cols]))
+            from_s, from_n = _sendrecv_pair(to_s, to_n, south, north)
+            a[:, 4 - nhl:4, cols] = from_s.numpy() if south >= 0 else vland
+            a[:, 4 + jdm:4 + jdm + nhl, cols] = from_n.numpy() if north >= 0 else vland
+        elif periodic_j:
+            a[:, 4 - nhl:4, cols] = a[:, 4 + jdm - nhl:4 + jdm, cols]
+            a[:, 4 + jdm:4 + jdm + nhl, cols] = a[:, 4:4 + nhl, cols]
+        else:
+            a[:, 4 - nhl:4, cols] = vland
+            a[:, 4 + jdm:4 + jdm + nhl, cols] = vland
+    if mhl > 0:
+        rows = slice(4 - nhl, 4 + jdm + nhl)
+        to_w = torch.from_numpy(np.ascontiguousarray(a[:, rows, 4:4 + mhl]))
+        to_e = torch.from_numpy(np.ascontiguousarray(a[:, rows, 4 + idm - mhl:4 + idm]))
+        if west == rank:            # one tile column, periodic: the wrap is tile-local (gloo has no self pair;
+            from_w, from_e = to_e, to_w   # RCCL does send to itself there, tests/test_gpu_variants.py)
+        else:
+            from_w, from_e = _sendrecv_pair(to_w, to_e, west, east)
+        a[:, rows, 4 - mhl:4] = from_w.numpy() if west >= 0 else vland
+        a[:, rows, 4 + idm:4 + idm + mhl] = from_e.numpy() if east >= 0 else vland
+    return a

@@ -109,7 +109,9 @@ int  blomgpu_step(blomgpu_ctx *, int *nstep, int nsteps);
  *    distributes it, every rank calls blomgpu_rccl_init;
  *  - an in-process group (several tiles on one device, one host thread per tile) used by the parity tests. */
 int  blomgpu_rccl_unique_id(void *id128);
-int  blomgpu_rccl_init(blomgpu_ctx *, const void *id128, int rank, int nranks);
+int  blomgpu_rccl_init(blomgpu_ctx *, const void *id128, int rank, int nranks);          /* npx = nranks, npy = 1 */
+int  blomgpu_rccl_init_2d(blomgpu_ctx *, const void *id128, int rank, int npx, int npy);  /* rank = px + npx*py */
+int  blomgpu_rccl_force_ns_exchange(blomgpu_ctx *, int on);   /* test hook, see comm_rccl.hip */
 int  blomgpu_rccl_finalize(blomgpu_ctx *);
 typedef struct TileGroup blomgpu_group;
 int  blomgpu_group_create(int npx, int npy, blomgpu_group **out);

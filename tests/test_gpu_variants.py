@@ -81,3 +81,33 @@ def test_rccl_exchange_overlapped_with_barotp_interior(overlap):
     b = _run_rccl_self("chan_m", 6, barotp_overlap=overlap)
     bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
     assert not bad, bad
+
+
+def _run_rccl_2d_self(cfg, nsteps, force_ns):
+    from blom_amd.gpu import BlomGpu, rccl_unique_id
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    gpu.rccl_init_2d(rccl_unique_id(), 0, 1, 1)
+    gpu.rccl_force_ns_exchange(force_ns)
+    assert gpu.step(0, nsteps) == nsteps
+    gpu.sync()
+    out = {nm: gpu.get(nm) for nm in STATE_FIELDS if gpu.has_field(nm)}
+    gpu.rccl_finalize()
+    gpu.close()
+    return out
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("fuk95", 3), ("per_s", 6)])
+def test_rccl_north_south_exchange_single_rank(cfg, nsteps):
+    """2-D RCCL transport on one GPU: in a j-periodic domain the N/S phase is forced through
+    pack / ncclSend+Recv (to the rank itself) / unpack; per_s is periodic in i as well, so the corners
+    then travel N/S first and E/W second, as between real tiles.  Must equal the plain halo update."""
+    skip = {"util1", "util2", "util3", "util4"}
+    a = _run(cfg, nsteps)
+    assert all(np.isfinite(a[nm]).all() for nm in ("u", "dp", "temp"))
+    for force in (0, 1):
+        b = _run_rccl_2d_self(cfg, nsteps, force)
+        bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
+        assert not bad, (force, bad)

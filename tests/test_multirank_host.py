@@ -83,6 +83,56 @@ def test_ranks_over_gloo(world):
                 assert v, (r, k)
 
 
+def _worker_2d(rank, npx, npy, port, q):
+    world = npx * npy
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = launch.tile_layout_2d(IDM, JDM, rank, npx, npy)
+        res = {"layout": lay}
+        for nreg, mh, nh in ((1, 3, 3), (0, 2, 2), (3, 4, 1), (3, 2, 3), (4, 2, 3), (1, 1, 0), (4, 0, 2)):
+            rng = np.random.default_rng(9)                      # same global array on every rank
+            G = rng.standard_normal((NLEV, JDM * npy + 8, IDM * npx + 8))
+            want = G.copy()
+            xctilr_np(want, 1, NLEV, mh, nh, nreg, IDM * npx, JDM * npy)
+            i0, j0 = lay["i0"], lay["j0"]
+            a = G[:, j0:j0 + JDM + 8, i0:i0 + IDM + 8].copy()
+            keep = a[:, 4:4 + JDM, 4:4 + IDM].copy()
+            a[...] = np.nan                                     # halos unknown before the update
+            a[:, 4:4 + JDM, 4:4 + IDM] = keep
+            launch.exchange_2d_host(a, IDM, JDM, mh, nh, rank, npx, npy, nreg)
+            w = want[:, j0:j0 + JDM + 8, i0:i0 + IDM + 8]
+            # what xctilr defines: columns 1..ii of the halo rows, and all rows 1-nh..jj+nh of the halo columns
+            ok = np.array_equal(a[:, 4 - nh:4 + JDM + nh, 4:4 + IDM], w[:, 4 - nh:4 + JDM + nh, 4:4 + IDM])
+            for cs in (slice(4 - mh, 4), slice(4 + IDM, 4 + IDM + mh)):
+                ok = ok and np.array_equal(a[:, 4 - nh:4 + JDM + nh, cs], w[:, 4 - nh:4 + JDM + nh, cs])
+            res[f"halo{nreg}_{mh}_{nh}"] = bool(ok)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("npx,npy", [(2, 2), (1, 2), (3, 2)])
+def test_2d_tile_grid_over_gloo(npx, npy):
+    """both phases of the 2-D exchange (blom_amd/csrc/comm_rccl.hip: rccl_xctilr_multi) with real ranks:
+    N/S partners incl. the periodic wrap onto the same rank pair, corners travelling with the E/W strips"""
+    world = npx * npy
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_2d, args=(r, npx, npy, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=180) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for r in range(world):
+        assert got[r]["layout"]["i0"] == (r % npx) * IDM and got[r]["layout"]["j0"] == (r // npx) * JDM
+        for k, v in got[r].items():
+            if k.startswith("halo"):
+                assert v, (r, k)
+
+
 def test_single_rank_helpers_need_no_process_group():
     env = launch.RankEnv(0, 1, 0)
     assert launch.share_unique_id(lambda: b"x" * 128, env) == b"x" * 128
@@ -92,3 +142,6 @@ def test_single_rank_helpers_need_no_process_group():
     assert launch.neighbours(0, 2, True) == (1, 1) and launch.neighbours(1, 2, False) == (0, -1)
     with pytest.raises(ValueError):
         launch.tile_layout(8, 2, 2)
+    assert launch.neighbours_2d(0, 1, 1, True, True) == (0, 0, 0, 0)
+    assert launch.neighbours_2d(3, 2, 2, True, False) == (2, 2, 1, -1)
+    assert launch.neighbours_2d(4, 3, 2, False, True) == (3, 5, 1, 1)
