@@ -97,6 +97,52 @@ __global__ void k_xctilr_arctic(const DevView *Vp, double *__restrict__ a, int n
   }
 }
 
+// The same rule for a tile of a decomposed arctic domain (npx x npy tiles of one process, pointer
+// transport): every target -- the tile's halo ring, and the seam row of the tiles in the last tile row --
+// is mapped to the point of the GLOBAL domain it takes its value from (periodic wrap in i, fold across
+// row jtdm), and read straight from the interior of the tile that owns that point.  With peer-mapped
+// pointers the very same gather works across GPUs; no strip is packed or staged.
+#define XCT_MAXTILES 64
+struct TileTab {
+  double *p[XCT_MAXTILES];      // the array being updated, in every tile (index py*npx + px)
+};
+__global__ void k_xctilr_arctic_tiles(const DevView *Vp, double *__restrict__ a, TileTab tab, int npx, int npy,
+                                      int px, int py, int nlev, int mhl, int nhl, int itype) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj, itdm = npx * ii, jtdm = npy * jj;
+  const int g = itype % 10;
+  const double sgn = itype > 10 ? -1. : 1.;
+  const int wrow = ii + 2 * mhl, nrow = jj + 2 * nhl;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= wrow * nrow) return;
+  const int i = t % wrow + 1 - mhl, j = t / wrow + 1 - nhl;
+  const int ig = px * ii + i, jg = py * jj + j;
+  const int iw = ig < 1 ? ig + itdm : (ig > itdm ? ig - itdm : ig);      // periodic in i
+  bool land = false, flip = false;
+  int is = iw, js = jg;
+  if (jg < 1) land = true;
+  else if (jg >= jtdm) {
+    const int d = jg - jtdm;
+    if (g == 1 || g == 3) {                                              // p-, u-grid
+      is = g == 1 ? itdm - (iw - 1) % itdm : (itdm - (iw - 1)) % itdm + 1;
+      js = jtdm - 1 - d;
+      flip = true;
+    } else if (d > 0 || iw > itdm / 2) {                                 // q-, v-grid
+      is = g == 2 ? (itdm - (iw - 1)) % itdm + 1 : itdm - (iw - 1) % itdm;
+      js = jtdm - d;
+      flip = true;
+    }
+  }
+  if (!land && !flip && i >= 1 && i <= ii && j >= 1 && j <= jj) return;  // interior point, not a target
+  const int qx = (is - 1) / ii, qy = (js - 1) / jj;
+  const double *src = land ? a : tab.p[qy * npx + qx];
+  const size_t dst = IDX(V, i, j), so = land ? 0 : (size_t)IDX(V, is - qx * ii, js - qy * jj);
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[dst + o] = land ? V.P.vland : (flip ? sgn * src[so + o] : src[so + o]);
+  }
+}
+
 #include <pthread.h>
 struct TileGroup {
   int npx, npy;
@@ -125,8 +171,31 @@ int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int 
   const int nlev = ld - l1 + 1;
   double *a = base + (size_t)(l1 - 1) * h.nplane;
   const Tiling &T = c->tiling;
+  if (h.nreg == 2 && T.group) {
+    // decomposed arctic domain, all tiles in this process: global gather through the tile pointer table
+    TileGroup *G = T.group;
+    if (T.npx * T.npy > XCT_MAXTILES) return ctx_fail(c, "xctilr: too many tiles for the arctic gather");
+    if (T.npx > 1 && T.npx % 2) return ctx_fail(c, "xctilr: the arctic patch needs an even number of tile columns (phy/mod_xc.F90:1600-1603)");
+    if (nlev <= 0) return 0;
+    size_t off = 0;
+    const int fid = ctx_locate_ptr(c, a, &off);
+    if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
+    TileTab tab;
+    for (int q = 0; q < XCT_MAXTILES; q++)
+      tab.p[q] = q < T.npx * T.npy ? G->tiles[(size_t)q]->h.f[fid] + off : nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);
+    const int nt = (h.ii + 2 * mhl) * (h.jj + 2 * nhl);
+    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
+    hipLaunchKernelGGL(k_xctilr_arctic_tiles, grid, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.npy, T.px, T.py,
+                       nlev, mhl, nhl, itype);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);
+    return 0;
+  }
   if (h.nreg == 2) {
-    if (T.multi()) return ctx_fail(c, "xctilr: the arctic patch (nreg=2) is built for a single tile only");
+    if (T.multi()) return ctx_fail(c, "xctilr: the arctic patch (nreg=2) over RCCL tiles is not built (single tile, or tiles of one process)");
     if (nlev <= 0) return 0;
     const int nt = (2 * nhl + 1) * (h.ii + 2 * mhl) + 2 * mhl * (h.jj - 1);
     dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);

@@ -286,12 +286,14 @@ __global__ void k_bt_arctic_swap(const DevView *Vp, int n) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
+  if (V.j0 + V.jj != V.jtdm) return;                       // nproc == jpr: only the last tile row holds the seam
   const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
   if (i < 0 || i > V.ii + 1 || j < V.jj || j > V.jj + 2) return;
   const size_t c = t, on = (size_t)(n - 1) * V.nplane;
   double q = V.f[F_umaxb][c]; V.f[F_umaxb][c] = V.f[F_uminb][c]; V.f[F_uminb][c] = q;
   q = V.f[F_xixp][c + on]; V.f[F_xixp][c + on] = V.f[F_xixm][c + on]; V.f[F_xixm][c + on] = q;
-  if (j > V.jj || i >= V.ii / 2 + 1) {
+  const int ilo = V.itdm / 2 - V.i0 + 1;                   // do i = max(0,itdm/2-i0+1),ii+1   (:303)
+  if (j > V.jj || i >= (ilo > 0 ? ilo : 0)) {
     q = V.f[F_vmaxb][c]; V.f[F_vmaxb][c] = V.f[F_vminb][c]; V.f[F_vminb][c] = q;
     q = V.f[F_xiyp][c + on]; V.f[F_xiyp][c + on] = V.f[F_xiym][c + on]; V.f[F_xiym][c + on] = q;
   }
