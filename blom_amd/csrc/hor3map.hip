@@ -44,6 +44,9 @@ struct blomgpu_h3m_grid {
   size_t stage_in_n = 0, stage_out_n = 0;
   double *tin = nullptr, *tout = nullptr;             // [level][column] staging
   size_t tin_n = 0, tout_n = 0;
+  double *tmany = nullptr;                            // [field][level][column] staging of the *_many entries
+  size_t tmany_n = 0;
+  int *err_many = nullptr;                            // per-field, per-column status of the last *_many call
   std::vector<blomgpu_h3m_src *> srcs;
   std::vector<blomgpu_h3m_map *> maps;
 };
@@ -131,6 +134,29 @@ __global__ __launch_bounds__(H3_BLOCK) void k_h3m_remap(H3Grid g, H3Src s, H3Map
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
   if (col >= g.nc) return;
   h3_report(g.err, ff, col, h3_remap(g, s, r, udst, col));
+}
+
+// Several source fields on one grid in a single launch (blockIdx.y = field): the column routines are
+// bound by memory latency at 6.5 wavefronts per CU (measured: time grows 1.8x from 26k to 106k columns),
+// and BLOM's callers have ntr tracers per grid, so the fields of a tracer loop fill the machine.
+#define H3_MAXF 8
+struct H3SrcSet {
+  H3Src s[H3_MAXF];
+  double *io[H3_MAXF];          // [level][column] staging of each field's caller array
+};
+__global__ __launch_bounds__(H3_BLOCK) void k_h3m_reconstruct_many(H3Grid g, H3SrcSet S, int *err_f,
+                                                                   unsigned long long *ff) {
+  const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
+  if (col >= g.nc) return;
+  const int f = blockIdx.y;
+  h3_report(err_f + (size_t)f * g.nc, ff, col, h3_reconstruct(g, S.s[f], S.io[f], col));
+}
+__global__ __launch_bounds__(H3_BLOCK) void k_h3m_remap_many(H3Grid g, H3SrcSet S, H3Map r, int *err_f,
+                                                             unsigned long long *ff) {
+  const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
+  if (col >= g.nc) return;
+  const int f = blockIdx.y;
+  h3_report(err_f + (size_t)f * g.nc, ff, col, h3_remap(g, S.s[f], r, S.io[f], col));
 }
 
 constexpr int E_DEVICE = -1, E_ALLOC = -2, E_HANDLE = -3, E_ARG = -4;
@@ -362,7 +388,8 @@ void blomgpu_h3m_grid_free(blomgpu_h3m_grid *G) {
   while (!G->srcs.empty()) blomgpu_h3m_src_free(G->srcs.back());
   while (!G->maps.empty()) blomgpu_h3m_map_free(G->maps.back());
   G->pool.release();
-  for (double *p : {G->stage_in, G->stage_out, G->tin, G->tout})
+  if (G->err_many) (void)hipFree(G->err_many);
+  for (double *p : {G->stage_in, G->stage_out, G->tin, G->tout, G->tmany})
     if (p) (void)hipFree(p);
   if (G->ev0) (void)hipEventDestroy(G->ev0);
   if (G->ev1) (void)hipEventDestroy(G->ev1);
@@ -464,6 +491,51 @@ int blomgpu_h3m_remap(blomgpu_h3m_src *S, blomgpu_h3m_map *M, double *u_dst) {
                      G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
   if ((rc = store_output(G, G->tout, m, u_dst))) return rc;
+  return end_call(G);
+}
+
+int blomgpu_h3m_reconstruct_many(blomgpu_h3m_grid *G, int nf, blomgpu_h3m_src *const *srcs,
+                                 const double *const *u_srcs) {
+  if (!G || !srcs || !u_srcs || nf < 1 || nf > H3_MAXF) return E_HANDLE;
+  int rc = begin_call(G);
+  if (rc) return rc;
+  const size_t per = (size_t)G->g.n_src * G->g.nc;
+  if (!grow(G, G->tmany, G->tmany_n, per * H3_MAXF)) return E_ALLOC;
+  if (!G->err_many && hipMalloc((void **)&G->err_many, sizeof(int) * H3_MAXF * G->g.nc) != hipSuccess) return E_ALLOC;
+  H3SrcSet S{};
+  for (int f = 0; f < nf; f++) {
+    if (!srcs[f] || srcs[f]->grid != G) return H3_INCONSISTENT_RCGS;
+    S.s[f] = srcs[f]->s;
+    S.io[f] = G->tmany + (size_t)f * per;
+    if ((rc = load_input(G, u_srcs[f], G->g.n_src, S.io[f]))) return rc;
+  }
+  H3CHK(hipEventRecord(G->ev0, G->stream));
+  hipLaunchKernelGGL(k_h3m_reconstruct_many, dim3(col_grid(G).x, nf), dim3(H3_BLOCK), 0, G->stream, G->g, S,
+                     G->err_many, G->first_fail);
+  H3CHK(hipEventRecord(G->ev1, G->stream));
+  return end_call(G);
+}
+
+int blomgpu_h3m_remap_many(int nf, blomgpu_h3m_src *const *srcs, blomgpu_h3m_map *M, double *const *u_dsts) {
+  if (!M || !srcs || !u_dsts || nf < 1 || nf > H3_MAXF) return E_HANDLE;
+  blomgpu_h3m_grid *G = M->grid;
+  int rc = begin_call(G);
+  if (rc) return rc;
+  const size_t per = (size_t)M->r.n_dst * G->g.nc;
+  if (!grow(G, G->tmany, G->tmany_n, per * H3_MAXF)) return E_ALLOC;
+  if (!G->err_many && hipMalloc((void **)&G->err_many, sizeof(int) * H3_MAXF * G->g.nc) != hipSuccess) return E_ALLOC;
+  H3SrcSet S{};
+  for (int f = 0; f < nf; f++) {
+    if (!srcs[f] || srcs[f]->grid != G) return H3_INCONSISTENT_RCGS;
+    S.s[f] = srcs[f]->s;
+    S.io[f] = G->tmany + (size_t)f * per;
+  }
+  H3CHK(hipEventRecord(G->ev0, G->stream));
+  hipLaunchKernelGGL(k_h3m_remap_many, dim3(col_grid(G).x, nf), dim3(H3_BLOCK), 0, G->stream, G->g, S, M->r,
+                     G->err_many, G->first_fail);
+  H3CHK(hipEventRecord(G->ev1, G->stream));
+  for (int f = 0; f < nf; f++)
+    if ((rc = store_output(G, S.io[f], M->r.n_dst, u_dsts[f]))) return rc;
   return end_call(G);
 }
 

@@ -48,6 +48,8 @@ def lib():
         L.blomgpu_h3m_regrid.argtypes = [_vp, ci, _vp, _vp, cd, ci]
         L.blomgpu_h3m_prepare_remapping.argtypes = [_vp, _vp, _vp]
         L.blomgpu_h3m_remap.argtypes = [_vp, _vp, _vp]
+        L.blomgpu_h3m_reconstruct_many.argtypes = [_vp, ci, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]
+        L.blomgpu_h3m_remap_many.argtypes = [ci, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp)]
         L.blomgpu_h3m_errstat.argtypes = [_vp, ctypes.POINTER(ci)]
         L.blomgpu_h3m_grid_info.argtypes = [_vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.blomgpu_h3m_sync.argtypes = [_vp]
@@ -149,6 +151,25 @@ class ReconSrc:
         rc = _check(lib().blomgpu_h3m_regrid(self.h, n_grd, _ptr(u_edge_grd), _ptr(out), missing_value,
                                              regrid_method), g.raise_on_error)
         return out if g.raise_on_error else (out, rc)
+
+
+def reconstruct_many(grid, srcs, u_srcs):
+    """reconstruct for several source fields of one grid in a single launch (the tracer loop)"""
+    n = len(srcs)
+    hs = (_vp * n)(*[s.h for s in srcs])
+    ps = (_vp * n)(*[_ptr(u) for u in u_srcs])
+    return _check(lib().blomgpu_h3m_reconstruct_many(grid.h, n, hs, ps), grid.raise_on_error)
+
+
+def remap_many(srcs, rmap, outs=None):
+    g = rmap.grid
+    n = len(srcs)
+    if outs is None:
+        outs = [np.zeros((g.ncol, rmap.n_dst)) for _ in range(n)]
+    hs = (_vp * n)(*[s.h for s in srcs])
+    ps = (_vp * n)(*[_ptr(u) for u in outs])
+    _check(lib().blomgpu_h3m_remap_many(n, hs, rmap.h, ps), g.raise_on_error)
+    return outs
 
 
 class Remap:

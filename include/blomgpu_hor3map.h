@@ -61,6 +61,14 @@ int  blomgpu_h3m_regrid(blomgpu_h3m_src *src, int n_grd, const double *u_edge_gr
 int  blomgpu_h3m_prepare_remapping(blomgpu_h3m_grid *grid, blomgpu_h3m_map *map, const double *x_edge_dst);
 int  blomgpu_h3m_remap(blomgpu_h3m_src *src, blomgpu_h3m_map *map, double *u_dst);
 
+/* The same for up to 8 source fields on one grid in ONE launch -- the tracer loops of the reference's
+ * callers (do nt = 1,ntr: reconstruct(rcgs, trc_rcss(nt), ...) / remap(trc_rcss(nt), rms, ...),
+ * phy/mod_ale_regrid_remap.F90:231-243, :1044-1053).  The column routines are latency bound, so n fields
+ * cost about the time of one.  Return value: the errstat of the lowest failing column over the fields. */
+int  blomgpu_h3m_reconstruct_many(blomgpu_h3m_grid *grid, int nf, blomgpu_h3m_src *const *srcs,
+                                  const double *const *u_srcs);
+int  blomgpu_h3m_remap_many(int nf, blomgpu_h3m_src *const *srcs, blomgpu_h3m_map *map, double *const *u_dsts);
+
 /* per-column status of the last call (ncol ints, host), and per-column n_src_actual / method_actual */
 int  blomgpu_h3m_errstat(blomgpu_h3m_grid *grid, int *errstat);
 int  blomgpu_h3m_grid_info(blomgpu_h3m_grid *grid, int *n_src_actual, int *method_actual);

@@ -100,3 +100,32 @@ def test_full_channel_slab_properties():
     r.prepare_remapping(xd)
     assert np.array_equal(r.remap(s)[:1500], small["u_dst"])
     g.free()
+
+
+def test_many_fields_in_one_launch_equal_single_calls():
+    """reconstruct_many / remap_many (the tracer loop in one launch) against one call per field"""
+    from blom_amd import hor3map as h3
+    ncol, n, nd = 3000, 53, 40
+    x, u, xd, ug = hc.make_columns(21, ncol, n, nd, 8, "tracer")
+    rng = np.random.default_rng(2)
+    fields = [np.ascontiguousarray(u * s + o) for s, o in ((1.0, 0.0), (-0.5, 1.0), (2.0, 3.0), (0.1, -0.2), (1.5, 0.5))]
+    fields.append(np.ascontiguousarray(rng.standard_normal((ncol, n))))
+    lims = [h3.NON_OSCILLATORY_POSDEF, h3.MONOTONIC, h3.NON_OSCILLATORY, h3.NO_LIMITING, h3.MONOTONIC,
+            h3.NON_OSCILLATORY_POSDEF]
+    for method in (h3.PPM, h3.PQM, h3.PLM):
+        g = h3.ReconGrid(ncol, n, method, 6, 4)
+        g.prepare_reconstruction(x)
+        r = h3.Remap(g, nd)
+        r.prepare_remapping(xd)
+        singles = []
+        for f, lim in zip(fields, lims):
+            s = h3.ReconSrc(g, lim, True, False)
+            s.reconstruct(f)
+            singles.append((s.extract_polycoeff(), r.remap(s)))
+        srcs = [h3.ReconSrc(g, lim, True, False) for lim in lims]
+        h3.reconstruct_many(g, srcs, fields)
+        outs = h3.remap_many(srcs, r)
+        for k, s in enumerate(srcs):
+            assert np.array_equal(s.extract_polycoeff(), singles[k][0]), (method, k)
+            assert np.array_equal(outs[k], singles[k][1]), (method, k)
+        g.free()

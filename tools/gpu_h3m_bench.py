@@ -72,3 +72,28 @@ if hc.have_ref():
         dt = time.perf_counter() - t0
         print(f"reference (1 core) {name}: {dt / m * ncol * 1e3:.1f} ms per slab for the 6-call sequence "
               f"(sample {m} columns)", flush=True)
+
+# several fields per launch (the tracer loop): kernel time vs number of fields
+cfg = cfgs["ppm_tracer"]
+g = h3.ReconGrid(ncol, n, cfg[0], cfg[1], cfg[2])
+g.set_io(device_pointers=True, check_errors=False)
+g.prepare_reconstruction(tx.data_ptr())
+r = h3.Remap(g, n)
+r.prepare_remapping(txd.data_ptr())
+srcs = [h3.ReconSrc(g, cfg[3], cfg[4], cfg[5]) for _ in range(8)]
+ins = [tu.clone() for _ in range(8)]
+outs = [torch.empty((ncol, n), dtype=torch.float64, device=dev) for _ in range(8)]
+for nf in (1, 2, 4, 8):
+    t_rec, t_rem = [], []
+    for _ in range(reps):
+        h3.reconstruct_many(g, srcs[:nf], [t.data_ptr() for t in ins[:nf]])
+        g.sync()
+        t_rec.append(g.last_kernel_ms())
+        h3.remap_many(srcs[:nf], r, [t.data_ptr() for t in outs[:nf]])
+        g.sync()
+        t_rem.append(g.last_kernel_ms())
+    a, b = float(np.median(t_rec)), float(np.median(t_rem))
+    F = ncol * n * 8.0
+    print(f"many nf={nf}: reconstruct {a:.3f} ms ({a / nf:.3f} per field, {nf * F / a / 1e6:.0f} GB/s alg), "
+          f"remap {b:.3f} ms ({b / nf:.3f} per field, {nf * F / b / 1e6:.0f} GB/s alg)", flush=True)
+g.free()
