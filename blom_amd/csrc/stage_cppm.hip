@@ -25,7 +25,8 @@
 // CPU.  Algorithmic bytes per step: (48 + 4 ntr) F.  Roofline: HBM.
 // All four variants of the reference are instantiated from the same templates: limiting non_oscillatory
 // (reach 4) / monotonic (reach 3) x compatibility full (LU edge coefficients, hel_3d/her_3d exchanged) /
-// partial (thickness edge coefficients re-used for tracers).  Not built: the arctic-seam swaps (nreg=2).
+// partial (thickness edge coefficients re-used for tracers).  With the arctic patch (nreg=2) the tags, edge coefficients
+// and thickness edge values next to the seam change roles (:1531-1541, :1686-1704, :1848-1858, :2002-2020, :2650-2722).
 #include "blomgpu_internal.h"
 
 #define DPEPS 1.e-12
@@ -214,26 +215,90 @@ __global__ void k_cppm_tag_convert(const DevView *Vp, int dir, int back) {
   else st[c] = (int)lround(V.f[F_util1][c]);
 }
 
+// With the arctic patch the grid folds onto itself across row jj: what is "left" of a cell there is
+// "right" in the mirrored halo, so the one-sided stencil tags and the edge-value coefficients swap
+// (phy/mod_cppm.F90:2650-2722).  which = 0: i-direction tables on row jj, i = 1-nbdy..ii+nbdy;
+// which = 1: j-direction tables on row jj from the global mid column on, and on rows jj+1..jj+nbdy.
+__device__ inline int cppm_mirror_tag(int st) {
+  switch (st) {
+    case ST_1110: return ST_0111;
+    case ST_0111: return ST_1110;
+    case ST_1100: return ST_0011;
+    case ST_0011: return ST_1100;
+    case ST_0100: return ST_0010;
+    case ST_0010: return ST_0100;
+    default: return st;
+  }
+}
+__global__ void k_cppm_arctic_init_swap(const DevView *Vp) {
+  const DevView &V = *Vp;
+  THREAD_IJ(V);
+  if (V.j0 + V.jj != V.jtdm) return;                        // nproc == jpr
+  const int which = by_;
+  if (which == 0) {
+    if (j != V.jj) return;                                  // i = 1-nbdy..ii+nbdy: the whole padded row
+  } else {
+    const int ilo = V.itdm / 2 - V.i0 + 1;
+    const bool seam = j == V.jj && i >= (ilo > 1 ? ilo : 1) && i <= V.ii;
+    const bool beyond = j >= V.jj + 1 && j <= V.jj + NBDY && i >= 1 && i <= V.ii;
+    if (!seam && !beyond) return;
+  }
+  int *st = which ? V.m[I_cppm_stj] : V.m[I_cppm_sti];
+  st[c] = cppm_mirror_tag(st[c]);
+  double *h1 = V.f[which ? F_hevc1j : F_hevc1i], *h2 = V.f[which ? F_hevc2j : F_hevc2i];
+  double *h3 = V.f[which ? F_hevc3j : F_hevc3i], *h4 = V.f[which ? F_hevc4j : F_hevc4i];
+  double t = h1[c]; h1[c] = h4[c]; h4[c] = t;
+  t = h2[c]; h2[c] = h3[c]; h3[c] = t;
+}
+
 int st_init_cppm(blomgpu_ctx *c) {
   const DevView &h = c->h;
-  if (h.nreg == 2) return ctx_fail(c, "init_cppm: arctic-seam swaps (nreg=2) are not built");
+  if (h.nreg == 2 && c->tiling.multi()) return ctx_fail(c, "init_cppm: the arctic patch is built for a single tile");
   hipLaunchKernelGGL(k_cppm_init, plane_grid(h, 2), dim3(256), 0, c->stream, c->d);
   for (int dir = 0; dir < 2; dir++) {
-    const int mh = dir ? 0 : NBDY, nh = dir ? NBDY : 0;
+    // halo types as in the reference (:2606-2648): u-grid for the i tables, v-grid for the j tables,
+    // p-grid for the slope/curvature masks; they only matter across the arctic seam
+    const int mh = dir ? 0 : NBDY, nh = dir ? NBDY : 0, it = dir ? 4 : 3;
     hipLaunchKernelGGL(k_cppm_tag_convert, plane_grid(h), dim3(256), 0, c->stream, c->d, dir, 0);
-    if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, mh, nh, dir ? 4 : 3)) return rc;
+    if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, mh, nh, it)) return rc;
     hipLaunchKernelGGL(k_cppm_tag_convert, plane_grid(h), dim3(256), 0, c->stream, c->d, dir, 1);
-    const int one[] = {dir ? F_hevc1j : F_hevc1i, dir ? F_hevc2j : F_hevc2i, dir ? F_hevc3j : F_hevc3i,
-                       dir ? F_hevc4j : F_hevc4i, dir ? F_sscj : F_ssci, dir ? F_sccj : F_scci, dir ? F_d2mj : F_d2mi};
-    for (int f : one)
-      if (int rc = st_xctilr(c, h.f[f], 1, 1, mh, nh, 1)) return rc;
+    const int edge[] = {dir ? F_hevc1j : F_hevc1i, dir ? F_hevc2j : F_hevc2i, dir ? F_hevc3j : F_hevc3i,
+                        dir ? F_hevc4j : F_hevc4i};
+    for (int f : edge)
+      if (int rc = st_xctilr(c, h.f[f], 1, 1, mh, nh, it)) return rc;
     const int twelve[] = {dir ? F_tmc0j : F_tmc0i, dir ? F_tmclj : F_tmcli, dir ? F_tmcrj : F_tmcri};
     for (int f : twelve)
-      if (int rc = st_xctilr(c, h.f[f], 1, 12, mh, nh, 1)) return rc;
+      if (int rc = st_xctilr(c, h.f[f], 1, 12, mh, nh, it)) return rc;
+    const int mask[] = {dir ? F_sscj : F_ssci, dir ? F_sccj : F_scci, dir ? F_d2mj : F_d2mi};
+    for (int f : mask)
+      if (int rc = st_xctilr(c, h.f[f], 1, 1, mh, nh, 1)) return rc;
   }
+  if (h.nreg == 2) hipLaunchKernelGGL(k_cppm_arctic_init_swap, plane_grid(h, 2), dim3(256), 0, c->stream, c->d);
   HIPCHK(c, hipGetLastError());
   c->cppm_ready = true;
   return 0;
+}
+
+// thickness edge values next to the arctic seam swap left and right after their halo update
+// (i sweeps :1531-1541 / :1848-1858: row jj, i = 1-w..ii+w; j sweeps :1686-1704 / :2002-2020: row jj from
+// the global mid column on, rows jj+1..jj+w for i = 1..ii)
+template <int DIR>
+__global__ void k_cppm_arctic_edge_swap(const DevView *Vp, int w) {
+  const DevView &V = *Vp;
+  THREAD_IJ(V);
+  if (V.j0 + V.jj != V.jtdm) return;
+  if (DIR == 0) {
+    if (j != V.jj || i < 1 - w || i > V.ii + w) return;
+  } else {
+    const int ilo = V.itdm / 2 - V.i0 + 1;
+    const bool seam = j == V.jj && i >= (ilo > 1 ? ilo : 1) && i <= V.ii;
+    const bool beyond = j >= V.jj + 1 && j <= V.jj + w && i >= 1 && i <= V.ii;
+    if (!seam && !beyond) return;
+  }
+  const size_t o = c + (size_t)by_ * V.nplane;
+  const double t = V.f[F_hel_3d][o];
+  V.f[F_hel_3d][o] = V.f[F_her_3d][o];
+  V.f[F_her_3d][o] = t;
 }
 
 // ---- sweep kernels, DIR = 0: along i (transport by cau), 1: along j (cav) ---------------------------
@@ -699,6 +764,7 @@ static int cppm_sweep(blomgpu_ctx *c, int n, int mm, int nn, int k1n, bool secon
     hipLaunchKernelGGL((k_cppm_hedges<DIR, LIM>), g, b, 0, c->stream, c->d);
     if (int rc = st_xctilr(c, h.f[F_hel_3d], 1, h.kk, mh, nh, 1)) return rc;                                  // :1527-1528
     if (int rc = st_xctilr(c, h.f[F_her_3d], 1, h.kk, mh, nh, 1)) return rc;
+    if (h.nreg == 2) hipLaunchKernelGGL((k_cppm_arctic_edge_swap<DIR>), g, b, 0, c->stream, c->d, w);
   }
   hipLaunchKernelGGL((k_cppm_tedge<DIR, LIM, FC>), g, b, 0, c->stream, c->d, nn, ntl);
   hipLaunchKernelGGL((k_cppm_parab<DIR, LIM, FC>), g, b, 0, c->stream, c->d, nn, ntl);
@@ -727,7 +793,7 @@ int st_cppm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)k1m;
   const DevView &h = c->h;
   if (!c->cppm_ready) return ctx_fail(c, "cppm: init_cppm has not been called (blomgpu_init_cppm)");
-  if (h.nreg == 2) return ctx_fail(c, "cppm: arctic-seam edge swaps (nreg=2) are not built");
+  if (h.nreg == 2 && c->tiling.multi()) return ctx_fail(c, "cppm: the arctic patch is built for a single tile");
   if (2 + h.ntr > MAXTL || W_NSLOT(2 + h.ntr) > h.nwk) return ctx_fail(c, "cppm: too many tracers for the device work space");
   const bool fc = c->cppm_compat == 1, mono = c->cppm_limiting == 1;
   if (fc) return mono ? cppm_variant<1, 1>(c, n, mm, nn, k1n) : cppm_variant<0, 1>(c, n, mm, nn, k1n);

@@ -36,7 +36,7 @@ def _setup(cfg, compat="full", limiting="non_oscillatory"):
 
 
 @pytest.mark.parametrize("compat,limiting", VARIANTS)
-@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 6), ("box_s", 6), ("fuk95", 4)])
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 6), ("box_s", 6), ("fuk95", 4), ("tri_s", 6)])
 def test_advect_cppm_stage_parity(cfg, nsteps, compat, limiting):
     case, ref, gpu = _setup(cfg, compat, limiting)
     failures, pending, nstep, ready = [], {}, [0], [False]
