@@ -30,11 +30,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 NSLP0 = 2.0e-4             # amplitude of the frozen isopycnal slopes that drive eddtra (cases.py)
 
 
-def build_case(cfg):
+def build_case(cfg, advmth="remap"):
     import numpy as np
     from blom_amd.cases import make_case
     from blom_amd import hostinit
-    case = make_case(cfg, nslp0=NSLP0)
+    case = make_case(cfg, nslp0=NSLP0, advmth=advmth)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     return case, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq)
 
@@ -54,7 +54,7 @@ def algorithmic_bytes(case, ntr):
 def class_bytes_F(ntr):
     return {
         "remap": 25 + 2 * ntr, "diffus": 19 + 2 * ntr, "pgforc": 15, "momtum": 26, "eddtra": 14,
-        "diapfl": 23 + 2 * ntr, "pbcor1": 12 + 2 * ntr, "pbcor2": 13 + 2 * ntr, "convec": 19 + 2 * ntr,
+        "cppm": 48 + 4 * ntr, "diapfl": 23 + 2 * ntr, "pbcor1": 12 + 2 * ntr, "pbcor2": 13 + 2 * ntr, "convec": 19 + 2 * ntr,
     }
 
 
@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="channel")
+    ap.add_argument("--advmth", default="remap", choices=["remap", "cppm"],
+                    help="advection method (the reference's advmth); the headline configuration is remap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs of kernel variants, e.g. momtum_v=1 (default: production kernels)")
@@ -169,7 +171,7 @@ def main():
 
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd import hostinit
-    case, nreg, masks = build_case(args.config)
+    case, nreg, masks = build_case(args.config, args.advmth)
     if world > 1:
         # Weak scaling: the channel is made `world` times as long in i (its bathymetry repeated
         # with the tile's period) and cut into `world` tiles along i, one per GPU.  Every tile
@@ -198,7 +200,7 @@ def main():
     if args.warmup > 1:
         ns = gpu.step(ns, args.warmup - 1)
     gpu.sync()
-    classes = ["eddtra", "remap", "diffus", "pgforc", "momtum", "convec", "diapfl", "barotp", "pbcor1", "pbcor2"]
+    classes = ["eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "barotp", "pbcor1", "pbcor2"]
     stage_ms = {}
     for cl in classes:
         ms, n = gpu.timer_get(cl)
@@ -252,7 +254,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.config} {case.idm * world}x{case.jdm}x{case.kdm} as {world} tile(s) of "
                                f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, "
-                               f"isopyc_bulkml/remap/geopotential/uc/enscon, ntr={case.ntr}, "
+                               f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr}, "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
                                f"full dyncore stage sequence incl. eddtra and convec (gm, frozen slopes of amplitude {NSLP0:g}); "
                                "N>1: halos over RCCL send/recv, "

@@ -234,6 +234,8 @@ int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);
+int st_xctilr_arctic_multi(blomgpu_ctx *, int nf, double *const *ptrs, const int *nlevs, const int *mhs, const int *nhs,
+                           const int *itypes);
 // several stacks (ptrs[f] = first level, nlevs[f] levels) with common widths in one launch where possible
 int st_xctilr_multi(blomgpu_ctx *, int nf, double *const *ptrs, const int *nlevs, int mh, int nh, const int *itypes);
 int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc);

@@ -278,8 +278,97 @@ __global__ void k_xctilr_multi(const DevView *Vp, HaloMulti M, int mhl, int nhl,
   }
 }
 
+// The arctic rule for several plane stacks in one launch (single tile), each with its own grid/field
+// type and halo widths: barotp's one-kernel-per-equation path updates pb (p scalar), ubflx (u vector) and
+// vbflx (v vector, one more row) before every odd substep -- 63 times per baroclinic step on the
+// tripolar grids.  Same composite gather as k_xctilr_arctic.
+struct ArcticMulti {
+  double *p[XCT_MAXF];
+  int nlev[XCT_MAXF], itype[XCT_MAXF], mhl[XCT_MAXF], nhl[XCT_MAXF];
+};
+__global__ void k_xctilr_arctic_multi(const DevView *Vp, ArcticMulti M) {
+  const DevView &V = *Vp;
+  const int f = blockIdx.z;
+  const int ii = V.ii, jj = V.jj, mhl = M.mhl[f], nhl = M.nhl[f], itype = M.itype[f];
+  const int g = itype % 10;
+  const double sgn = itype > 10 ? -1. : 1.;
+  const int wrow = ii + 2 * mhl, nrow = 2 * nhl + 1;
+  const int nrowpts = nrow * wrow, nside = 2 * mhl * (jj - 1);
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nrowpts + nside) return;
+  int i, j;
+  if (t < nrowpts) {
+    const int r = t / wrow;
+    i = t % wrow + 1 - mhl;
+    j = r < nhl ? -r : jj + (r - nhl);
+  } else {
+    t -= nrowpts;
+    const int cidx = t % (2 * mhl);
+    j = t / (2 * mhl) + 1;
+    i = cidx < mhl ? -cidx : ii + (cidx - mhl) + 1;
+  }
+  const int iw = i < 1 ? i + ii : (i > ii ? i - ii : i);
+  bool land = false, flip = false;
+  int is = iw, js = j;
+  if (j < 1) land = true;
+  else if (j >= jj) {
+    const int d = j - jj;
+    if (g == 1 || g == 3) {
+      is = g == 1 ? ii - (iw - 1) % ii : (ii - (iw - 1)) % ii + 1;
+      js = jj - 1 - d;
+      flip = true;
+    } else if (d > 0 || iw > ii / 2) {
+      is = g == 2 ? (ii - (iw - 1)) % ii + 1 : ii - (iw - 1) % ii;
+      js = jj - d;
+      flip = true;
+    }
+  }
+  if (!land && !flip && i == iw) return;
+  const size_t dst = IDX(V, i, j), src = IDX(V, is, js);
+  double *a = M.p[f];
+  const int nlev = M.nlev[f];
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
+    const size_t o = (size_t)k * V.nplane;
+    a[dst + o] = land ? V.P.vland : (flip ? sgn * a[src + o] : a[src + o]);
+  }
+}
+
+// per-stack halo widths; single tile with the arctic patch only (the caller falls back otherwise)
+int st_xctilr_arctic_multi(blomgpu_ctx *c, int nf, double *const *ptrs, const int *nlevs, const int *mhs, const int *nhs,
+                           const int *itypes) {
+  const DevView &h = c->h;
+  if (h.nreg != 2 || c->tiling.multi() || nf > XCT_MAXF) {
+    for (int f = 0; f < nf; f++)
+      if (int rc = st_xctilr(c, ptrs[f], 1, nlevs[f], mhs[f], nhs[f], itypes[f])) return rc;
+    return 0;
+  }
+  if (nf <= 0) return 0;
+  ArcticMulti M;
+  int maxlev = 1, maxt = 0;
+  for (int f = 0; f < XCT_MAXF; f++) {
+    const bool on = f < nf;
+    M.p[f] = on ? ptrs[f] : nullptr;
+    M.nlev[f] = on ? nlevs[f] : 0;
+    M.itype[f] = on ? itypes[f] : 1;
+    M.mhl[f] = on ? (mhs[f] < 0 ? 0 : (mhs[f] > NBDY ? NBDY : mhs[f])) : 0;
+    M.nhl[f] = on ? (nhs[f] < 0 ? 0 : (nhs[f] > NBDY ? NBDY : nhs[f])) : 0;
+    if (on && nlevs[f] > maxlev) maxlev = nlevs[f];
+    const int nt = (2 * M.nhl[f] + 1) * (h.ii + 2 * M.mhl[f]) + 2 * M.mhl[f] * (h.jj - 1);
+    if (on && nt > maxt) maxt = nt;
+  }
+  dim3 grid((maxt + 255) / 256, maxlev > 64 ? 64 : maxlev, nf);
+  hipLaunchKernelGGL(k_xctilr_arctic_multi, grid, dim3(256), 0, c->stream, c->d, M);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int st_xctilr_multi(blomgpu_ctx *c, int nf, double *const *ptrs, const int *nlevs, int mh, int nh, const int *itypes) {
   const DevView &h = c->h;
+  if (h.nreg == 2 && !c->tiling.multi() && nf <= XCT_MAXF) {
+    int mhs[XCT_MAXF], nhs[XCT_MAXF];
+    for (int f = 0; f < nf; f++) { mhs[f] = mh; nhs[f] = nh; }
+    return st_xctilr_arctic_multi(c, nf, ptrs, nlevs, mhs, nhs, itypes);
+  }
   if (c->tiling.multi() || h.nreg == 2 || nf > XCT_MAXF) {
     for (int f = 0; f < nf; f++)
       if (int rc = st_xctilr(c, ptrs[f], 1, nlevs[f], mh, nh, itypes[f])) return rc;

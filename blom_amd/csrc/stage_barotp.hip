@@ -354,11 +354,13 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
     const int last = lll0 + lstep / 2 - 1;
     // With the arctic patch the halo update also rewrites the seam row jj, an interior row, so it must
-    // happen exactly where the reference has it (before odd substeps only); the fused kernels need their
-    // rim refreshed before a lone even substep as well, hence nreg = 2 takes the one-kernel-per-equation path.
-    const bool fused = c->barotp_fused && h.nreg != 2;
+    // happen exactly where the reference has it: before odd substeps only.  The fused kernels then publish
+    // the margins they computed (PairArgs::write_margin), which is what the reference's arrays hold before
+    // a lone even substep and before the epilogue; single tile only.
+    const bool arctic1 = h.nreg == 2 && !c->tiling.multi();
+    const bool fused = c->barotp_fused && (h.nreg != 2 || arctic1);
     bool halo_done = false;
-    if (fused && c->barotp_persist && bt_phase_usable(c)) {
+    if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
       // their edge values through memory
       int so, mo, no;
@@ -382,7 +384,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
         if (!both && !odd) { wo[1] = wo[0]; wm[1] = wm[0]; wn[1] = wn[0]; }
         // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
-        if ((c->tiling.multi() || h.nreg == 2) && !halo_done)
+        if ((c->tiling.multi() || (arctic1 && odd)) && !halo_done)
           if (int rc = bt_pair_halo(c, set)) return rc;
         if (ovl) {
           // fork: outer tile columns + exchange of the new state on xstream, inner columns on stream; join
@@ -412,9 +414,11 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       a.wn = wna * lll + wnb;
       a.wm = 1. - a.wo - a.wn;
       if (lll % 2 == 1) {
-        if (int rc = st_xctilr(c, h.f[F_pb_t], 1, 2, 2, 2, 1)) return rc;       // :395-397
-        if (int rc = st_xctilr(c, h.f[F_ubflx_t], 1, 2, 2, 2, 13)) return rc;
-        if (int rc = st_xctilr(c, h.f[F_vbflx_t], 1, 2, 2, 3, 14)) return rc;
+        {                                                                          // :395-397, one launch
+          double *ptrs[3] = {h.f[F_pb_t], h.f[F_ubflx_t], h.f[F_vbflx_t]};
+          const int nl3[3] = {2, 2, 2}, mh3[3] = {2, 2, 2}, nh3[3] = {2, 2, 3}, it3[3] = {1, 13, 14};
+          if (int rc = st_xctilr_arctic_multi(c, 3, ptrs, nl3, mh3, nh3, it3)) return rc;
+        }
         a.j0 = -1; a.j1 = jj + 2; a.i0 = -1; a.i1 = ii + 1; a.lv = 0;
         hipLaunchKernelGGL(k_bt_cont, g, b, 0, c->stream, c->d, a);
         a.j0 = -1; a.j1 = jj + 2; a.i0 = 0; a.i1 = ii + 1; a.lv = ml;
@@ -433,7 +437,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     }
     lll0 = lll0 + lstep / 2;
     // the epilogue reads pb_t(i-1,j), pb_t(i,j-1); the fused kernels write tile interiors only
-    if (fused && !halo_done)
+    if (fused && !halo_done && !arctic1)
       if (int rc = bt_pair_halo(c, set)) return rc;
     halo_done = false;
     hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl, set);

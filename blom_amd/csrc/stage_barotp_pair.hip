@@ -37,6 +37,10 @@ struct PairArgs {
   // split launches (PERSIST = false, RCCL tiles): 0 all tile columns, 1 only the west-most and east-most
   // column of tiles (they produce the E/W strips the exchange sends), 2 only the columns in between
   int tsel, nbx;
+  // arctic patch: also publish the halo cells this tile computed redundantly (the reference's margins,
+  // :420-457 etc. run over j = -1..jj+2), so that a following launch needs no halo update -- which with
+  // the arctic patch would rewrite the seam row at a point where the reference does not
+  int write_margin;
 };
 
 // PERSIST = false: one odd+even pair (or one half) per launch, neighbours synchronise at the kernel
@@ -91,6 +95,12 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
   }
   const bool ok_src = inarr && !land;
   const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
+  // halo cell owned by this tile: the tile that holds the nearest interior point (each halo cell has one owner)
+  bool own_halo = false;
+  if (!PERSIST && a.write_margin && inarr && !(gi >= 1 && gi <= ii && gj >= 1 && gj <= jj)) {
+    const int ci = gi < 1 ? 1 : (gi > ii ? ii : gi), cj = gj < 1 ? 1 : (gj > jj ? jj : gj);
+    own_halo = (ci - 1) / TI == (int)bx && (cj - 1) / TJ == (int)blockIdx.y;
+  }
   auto load_state = [&](bool rim_only) {
     if (!act || (rim_only && mine)) return;
     const double *g_pb = b_pb[src], *g_ub = b_ub[src], *g_vb = b_vb[src];
@@ -288,9 +298,9 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
     PROF_MARK();
     const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
   }
-  // publish the interior in the other buffer set
+  // publish the interior (and, with the arctic patch, the owned margin) in the other buffer set
   src ^= 1;
-  if (mine) {
+  if (mine || own_halo) {
     double *o_pb = b_pb[src], *o_ub = b_ub[src], *o_vb = b_vb[src];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
@@ -360,6 +370,10 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
                     set ? h.f[F_vbflx_t2] : h.f[F_vbflx_t]};
     static const int it[3] = {1, 13, 14};
     if (c->tiling.rccl) return rccl_xctilr_multi(c, f, 3, 2, 3, 3);       // one message per neighbour
+    if (h.nreg == 2 && !c->tiling.multi()) {
+      const int nl3[3] = {2, 2, 2}, w3[3] = {3, 3, 3};
+      return st_xctilr_arctic_multi(c, 3, f, nl3, w3, w3, it);
+    }
     for (int x = 0; x < 3; x++)
       if (int rc = st_xctilr(c, f[x], 1, 2, 3, 3, it[x])) return rc;
     return 0;
@@ -377,6 +391,7 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
   a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
+  a.write_margin = (h.nreg == 2 && !c->tiling.multi()) ? 1 : 0;
   a.prof = c->bt_prof;
   a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr; a.epoch_base = 0;
   const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
@@ -450,7 +465,7 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   a.prof = nullptr;
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
-  a.tsel = 0; a.nbx = nbx;
+  a.tsel = 0; a.nbx = nbx; a.write_margin = 0;
   a.epoch_base = c->bt_epoch;
   c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _run(cfg, nsteps, **opts):
     from blom_amd.gpu import BlomGpu
     case = make_case(cfg)
-    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     for k, v in opts.items():
         gpu.set(k, v)
@@ -27,7 +27,7 @@ def _run(cfg, nsteps, **opts):
     return out
 
 
-@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 8), ("fuk95", 6), ("chan_m", 6)])
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 8), ("fuk95", 6), ("chan_m", 6), ("tri_s", 8)])
 @pytest.mark.parametrize("opt,variants", [("diapfl_v", (1, 2)), ("barotp_fused", (0, 1)), ("barotp_persist", (0, 1))])
 def test_variants_bit_identical(cfg, nsteps, opt, variants):
     a = _run(cfg, nsteps, **{opt: variants[0]})
