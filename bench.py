@@ -58,6 +58,21 @@ def class_bytes_F(ntr):
     }
 
 
+def class_traffic(config):
+    """HBM bytes per step and kernel class from the newest committed PMC profile of this configuration
+    (profiles/*_class_traffic.json, written by tools/prof_summarize.py from separate rocprofv3 --pmc
+    passes of this very command); None when there is none."""
+    import glob
+    import json
+    if config != "channel":
+        return None, None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_class_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("bytes_per_step", {}), os.path.basename(files[-1])
+
+
 def usable_cores():
     """Cores this process may actually use: the cgroup CPU quota if there is one (the GPU box shows 256
     logical CPUs but grants 16 cores; 256 threads ran the reference 35x slower than 16), else the CPU count."""
@@ -248,6 +263,7 @@ def main():
     hbm_classes = {k: v for k, v in live.items() if k in cb}
     dom = max(hbm_classes, key=hbm_classes.get)
     a3d, a2d = algorithmic_bytes(case, case.ntr)
+    traffic, traffic_src = class_traffic(args.config)
     out = {
         "metric": "simulated-days/sec", "value": value, "unit": "simulated-days/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -263,7 +279,8 @@ def main():
                    "state_crc": f"{crcs[0]:08x}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get(dom), "traffic_source": traffic_src,
                      "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom]},
         "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
                           "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,

@@ -35,4 +35,24 @@ if len(sys.argv) > 5:
             n, v = fe[k]
             w = wr.get(k, [1, 0.0])
             f.write(f"{k[:32]:32s} {n:8d} {v / n / 1024:10.2f} {2 * v / n / 1024:12.2f} {w[1] / max(1, w[0]) / 1024:10.2f}\n")
+    # per bench class (bench.py `stages_ms` keys): HBM bytes per baroclinic step from the two PMC passes,
+    # fetch corrected by the 1.5x calibrated for the 8 B/lane loads of these fp64 kernels (DESIGN.md 4;
+    # the guide's 2x holds for 16 B/lane streams), writes as counted.  bench.py reports it as roofline.traffic.
+    import json
+    prefixes = [("k_mom_", "momtum"), ("k_remap_", "remap"), ("k_adv_", "remap"), ("k_cppm_", "cppm"),
+                ("k_diffus_", "diffus"), ("k_pgf_", "pgforc"), ("k_diapfl_", "diapfl"), ("k_convec_", "convec"),
+                ("k_bt_", "barotp"), ("void k_bt_", "barotp"), ("k_pbc_", "pbcor"), ("k_eddtra_", "eddtra")]
+    nsteps_pmc = max(fe[k][0] for k in fe if k.startswith("k_mom_update")) if any(k.startswith("k_mom_update") for k in fe) else 1
+    cls = collections.defaultdict(float)
+    for k in fe:
+        for pre, c in prefixes:
+            if k.startswith(pre):
+                cls[c] += (1.5 * fe[k][1] + wr.get(k, [0, 0.0])[1]) * 1024.0 / nsteps_pmc
+                break
+    if "pbcor" in cls:
+        cls["pbcor1"] = cls["pbcor2"] = cls.pop("pbcor") / 2
+    with open(f"profiles/{tag}_class_traffic.json", "w") as f:
+        json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                   "correction": "1.5 x FETCH_SIZE + WRITE_SIZE, bytes per baroclinic step and class",
+                   "bytes_per_step": {k: round(v) for k, v in sorted(cls.items())}}, f, indent=1)
 print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3500])
