@@ -4,6 +4,7 @@
 // the launches and the error plumbing.  No host fallback: without a HIP device grid_create fails.
 #include "hor3map_core.h"
 #include "hor3map_pqm.h"
+#include "hor3map_ppm_fused.h"
 #include "../../include/blomgpu_hor3map.h"
 #include <cstdio>
 #include <cstring>

@@ -557,64 +557,6 @@ H3HD void h3_reconstruct_plm(const H3Grid &g, const H3Src &s, int col, bool limi
     for (int j = 1; j <= g.n_src; ++j) PC(c, j) = 0.0;
 }
 
-// mod_hor3map.F90:1707-1763.  The right boundary tests lb_ord, as the reference does (:1734).
-H3HD void h3_ppm_edge_values(const H3Grid &g, const H3Src &s, int col) {
-  const int nc = g.nc;
-  const int ns = g.n_act[col], lb_ord = g.lb_act[col], rb_ord = g.rb_act[col];
-  double *uedge = s.wk, *gam = s.wk + (size_t)(g.n_src + 1) * nc;
-  double x[H3_LD], lu[H3_LD * H3_LD];
-  if (lb_ord == 1) {
-    H3A(uedge, 1) = H3A(s.u, 1);
-  } else {
-    for (int i = 1; i <= lb_ord; ++i) x[i - 1] = H3A(s.u, i);
-    for (int j = 1; j <= lb_ord; ++j)
-      for (int i = 1; i <= lb_ord; ++i) lu[(i - 1) + H3_LD * (j - 1)] = H3A2(g.lblu, i, j, H3_LD);
-    h3_lu_solve(lb_ord, lu, H3_LD, x);
-    H3A(uedge, 1) = x[0];
-  }
-  if (lb_ord == 1) {
-    H3A(uedge, ns + 1) = H3A(s.u, ns);
-  } else {
-    for (int i = 1; i <= rb_ord; ++i) x[i - 1] = H3A(s.u, ns - rb_ord + i);
-    for (int j = 1; j <= rb_ord; ++j)
-      for (int i = 1; i <= rb_ord; ++i) lu[(i - 1) + H3_LD * (j - 1)] = H3A2(g.rblu, i, j, H3_LD);
-    h3_lu_solve(rb_ord, lu, H3_LD, x);
-    H3A(uedge, ns + 1) = x[0];
-  }
-  H3A(gam, 1) = 0.0;
-  for (int j = 2; j <= ns; ++j) {
-    const double t1 = H3A2(g.tde, 1, j, g.ncoef);
-    const double rhs = H3A2(g.tde, 3, j, g.ncoef) * H3A(s.u, j - 1) + H3A2(g.tde, 4, j, g.ncoef) * H3A(s.u, j);
-    const double bei = 1.0 / (1.0 - t1 * H3A(gam, j - 1));
-    H3A(uedge, j) = (rhs - t1 * H3A(uedge, j - 1)) * bei;
-    H3A(gam, j) = H3A2(g.tde, 2, j, g.ncoef) * bei;
-  }
-  for (int j = ns; j >= 2; --j) H3A(uedge, j) = H3A(uedge, j) - H3A(gam, j) * H3A(uedge, j + 1);
-  for (int j = 1; j <= ns; ++j) {
-    H3A(s.uel, j) = H3A(uedge, j);
-    H3A(s.uer, j) = H3A(uedge, j + 1);
-  }
-}
-
-// the limited-slope edge correction shared by both interior PPM limiters (mod_hor3map.F90:1886-1904)
-H3HD void h3_ppm_limit_cell(const H3Grid &g, const H3Src &s, int col, int j) {
-  const int nc = g.nc;
-  const double um = H3A(s.u, j - 1), u0 = H3A(s.u, j), up = H3A(s.u, j + 1);
-  const double sl = 2.0 * (u0 - um) * H3A(g.hi, j);
-  const double sr = 2.0 * (up - u0) * H3A(g.hi, j);
-  if (sl * sr > 0.0) {
-    double sc = (up - um) * H3A(g.hci, j);
-    sc = h3_sign(h3_min(h3_min(h3_abs(sl), h3_abs(sr)), h3_abs(sc)), sc);
-    const double el = H3A(s.uel, j), er = H3A(s.uer, j);
-    if ((um - el) * (u0 - el) > 0.0)
-      H3A(s.uel, j) = u0 - h3_sign(h3_min(0.5 * H3A(g.h, j) * h3_abs(sc), h3_abs(el - u0)), sc);
-    if ((up - er) * (u0 - er) > 0.0)
-      H3A(s.uer, j) = u0 + h3_sign(h3_min(0.5 * H3A(g.h, j) * h3_abs(sc), h3_abs(er - u0)), sc);
-  } else {
-    H3A(s.uel, j) = u0;
-    H3A(s.uer, j) = u0;
-  }
-}
 H3HD void h3_ppm_edge_consistency(const H3Src &s, int nc, int col, int ns) {   // :1908-1914
   for (int j = 3; j <= ns - 1; ++j)
     if ((H3A(s.uel, j) - H3A(s.uer, j - 1)) * (H3A(s.u, j) - H3A(s.u, j - 1)) < 0.0) {
@@ -622,92 +564,8 @@ H3HD void h3_ppm_edge_consistency(const H3Src &s, int nc, int col, int ns) {   /
       H3A(s.uer, j - 1) = H3A(s.uel, j);
     }
 }
-H3HD void h3_ppm_no_overshoot(const H3Src &s, int nc, int col, int j) {        // :1917-1924
-  const double d = H3A(s.uer, j) - H3A(s.uel, j);
-  const double q = d * (2.0 * H3A(s.u, j) - H3A(s.uel, j) - H3A(s.uer, j));
-  const double r = (1.0 / 3.0) * d * d;
-  if (q > r) H3A(s.uel, j) = 3.0 * H3A(s.u, j) - 2.0 * H3A(s.uer, j);
-  else if (-r > q) H3A(s.uer, j) = 3.0 * H3A(s.u, j) - 2.0 * H3A(s.uel, j);
-}
-// mod_hor3map.F90:1872-1927
-H3HD void h3_limit_ppm_monotonic(const H3Grid &g, const H3Src &s, int col) {
-  const int nc = g.nc, ns = g.n_act[col];
-  for (int j = 2; j <= ns - 1; ++j) h3_ppm_limit_cell(g, s, col, j);
-  h3_ppm_edge_consistency(s, nc, col, ns);
-  for (int j = 2; j <= ns - 1; ++j) h3_ppm_no_overshoot(s, nc, col, j);
-}
-// mod_hor3map.F90:1929-1998
-H3HD void h3_limit_ppm_non_oscillatory(const H3Grid &g, const H3Src &s, int col) {
-  const int nc = g.nc, ns = g.n_act[col];
-  double *d2 = s.wk;
-  for (int j = 1; j <= ns; ++j) H3A(d2, j) = H3A(s.uel, j) - 2.0 * H3A(s.u, j) + H3A(s.uer, j);
-  for (int j = 2; j <= ns - 1; ++j)
-    if (H3A(d2, j - 1) * H3A(d2, j) < 0.0 || H3A(d2, j) * H3A(d2, j + 1) < 0.0) h3_ppm_limit_cell(g, s, col, j);
-  h3_ppm_edge_consistency(s, nc, col, ns);
-  for (int j = 2; j <= ns - 1; ++j)
-    if (H3A(d2, j - 1) * H3A(d2, j) < 0.0 || H3A(d2, j) * H3A(d2, j + 1) < 0.0) h3_ppm_no_overshoot(s, nc, col, j);
-}
-// mod_hor3map.F90:2000-2070
-H3HD void h3_limit_ppm_boundary(const H3Grid &g, const H3Src &s, int col) {
-  const int nc = g.nc, ns = g.n_act[col];
-  if (s.pc_left) {
-    H3A(s.uel, 1) = H3A(s.u, 1);
-    H3A(s.uer, 1) = H3A(s.u, 1);
-  } else if ((H3A(s.u, 2) - H3A(s.uer, 1)) * (H3A(s.u, 1) - H3A(s.uer, 1)) > 0.0) {
-    H3A(s.uel, 1) = H3A(s.u, 1);
-    H3A(s.uer, 1) = H3A(s.u, 1);
-  } else {
-    const double sl = 2.0 * (H3A(s.u, 3) - H3A(s.u, 2)) / (H3A(g.h, 2) + H3A(g.h, 3));
-    const double b = H3A(s.u, 1) + (1.0 / 3.0) * sl * H3A(g.h, 1);
-    if (sl > 0) H3A(s.uer, 1) = h3_max(H3A(s.u, 1), h3_min(H3A(s.uer, 1), b));
-    else H3A(s.uer, 1) = h3_min(H3A(s.u, 1), h3_max(H3A(s.uer, 1), b));
-    H3A(s.uel, 1) = 0.5 * (3.0 * H3A(s.u, 1) - H3A(s.uer, 1));
-  }
-  if (s.pc_right) {
-    H3A(s.uel, ns) = H3A(s.u, ns);
-    H3A(s.uer, ns) = H3A(s.u, ns);
-  } else if ((H3A(s.u, ns) - H3A(s.uel, ns)) * (H3A(s.u, ns - 1) - H3A(s.uel, ns)) > 0.0) {
-    H3A(s.uel, ns) = H3A(s.u, ns);
-    H3A(s.uer, ns) = H3A(s.u, ns);
-  } else {
-    const double sl = 2.0 * (H3A(s.u, ns - 1) - H3A(s.u, ns - 2)) / (H3A(g.h, ns - 2) + H3A(g.h, ns - 1));
-    const double b = H3A(s.u, ns) - (1.0 / 3.0) * sl * H3A(g.h, ns);
-    if (sl > 0) H3A(s.uel, ns) = h3_min(H3A(s.u, ns), h3_max(H3A(s.uel, ns), b));
-    else H3A(s.uel, ns) = h3_max(H3A(s.u, ns), h3_min(H3A(s.uel, ns), b));
-    H3A(s.uer, ns) = 0.5 * (3.0 * H3A(s.u, ns) - H3A(s.uel, ns));
-  }
-}
-// mod_hor3map.F90:2072-2098
-H3HD void h3_limit_ppm_posdef(const H3Grid &g, const H3Src &s, int col) {
-  const int nc = g.nc, ns = g.n_act[col];
-  for (int j = 1; j <= ns; ++j) {
-    const double u0 = H3A(s.u, j);
-    const double min_u_0 = h3_min(u0, 0.0);
-    H3A(s.uel, j) = h3_max(H3A(s.uel, j), min_u_0);
-    H3A(s.uer, j) = h3_max(H3A(s.uer, j), min_u_0);
-    const double sl = 2.0 * (3.0 * u0 - 2.0 * H3A(s.uel, j) - H3A(s.uer, j));
-    const double a2 = 3.0 * (H3A(s.uel, j) - 2.0 * u0 + H3A(s.uer, j));
-    const double sr = sl + 2.0 * a2;
-    if (sl < 0.0 && sr > 0.0)
-      if (a2 * H3A(s.uel, j) - 0.25 * sl * sl < a2 * min_u_0) {
-        const double q = 3.0 * u0 / (3.0 * sl * sr + 4.0 * a2 * a2);
-        H3A(s.uel, j) = sl * sl * q;
-        H3A(s.uer, j) = sr * sr * q;
-      }
-  }
-}
-// mod_hor3map.F90:2100-2117
-H3HD void h3_polycoeff_ppm(const H3Grid &g, const H3Src &s, int col) {
-  const int nc = g.nc, np = g.p_ord + 1, ns = g.n_act[col];
-  for (int j = 1; j <= ns; ++j) {
-    const double u0 = H3A(s.u, j), el = H3A(s.uel, j), er = H3A(s.uer, j);
-    PC(1, j) = el;
-    PC(2, j) = 6.0 * u0 - 4.0 * el - 2.0 * er;
-    PC(3, j) = 3.0 * (el - 2.0 * u0 + er);
-  }
-}
-
 H3HD void h3_reconstruct_pqm(const H3Grid &g, const H3Src &s, int col);   // hor3map_pqm.h
+H3HD void h3_reconstruct_ppm_fused(const H3Grid &g, const H3Src &s, int col);   // hor3map_ppm_fused.h
 
 // reconstruct (mod_hor3map.F90:4145-4272); the caller's data are in uin [level][column]
 H3HD int h3_reconstruct(const H3Grid &g, const H3Src &s, const double *uin, int col) {
@@ -743,17 +601,8 @@ H3HD int h3_reconstruct(const H3Grid &g, const H3Src &s, const double *uin, int 
     if (!known) return H3_INVALID_PLM_LIMITING;
     h3_reconstruct_plm(g, s, col, lim != H3_NO_LIMITING);
   } else if (m == H3_PPM) {
-    h3_ppm_edge_values(g, s, col);
     if (!known) return H3_INVALID_PPM_LIMITING;
-    if (lim == H3_MONOTONIC) {
-      h3_limit_ppm_monotonic(g, s, col);
-      h3_limit_ppm_boundary(g, s, col);
-    } else if (lim == H3_NON_OSCILLATORY || lim == H3_NON_OSCILLATORY_POSDEF) {
-      h3_limit_ppm_non_oscillatory(g, s, col);
-      h3_limit_ppm_boundary(g, s, col);
-      if (lim == H3_NON_OSCILLATORY_POSDEF) h3_limit_ppm_posdef(g, s, col);
-    }
-    h3_polycoeff_ppm(g, s, col);
+    h3_reconstruct_ppm_fused(g, s, col);        // hor3map_ppm_fused.h
   } else if (m == H3_PQM) {
     if (!known) return H3_INVALID_PQM_LIMITING;
     h3_reconstruct_pqm(g, s, col);
@@ -1097,7 +946,18 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
   const int nc = g.nc, np = g.p_ord + 1, nd = r.n_dst;
   if (!r.prepared[col]) return H3_REMAP_NOT_PREPARED;
   if (!s.reconstructed[col]) return H3_RECON_NOT_AVAILABLE;
-  for (int j = 1; j <= nd; ++j) H3A(udst, j) = 0.0;
+  // The reference zeroes u_dst and accumulates segment by segment into memory; the destination index only
+  // ever moves forward, so the running cell lives in a register and every destination cell is written once
+  // (acc starts from 0.0 and adds in the same order: the same bits, incl. 0.0 + (-0.0) = +0.0).
+  int cur = 0;
+  double acc = 0.0;
+#define H3_DST(jd)                                          \
+  if ((jd) != cur) {                                        \
+    if (cur > 0) H3A(udst, cur) = acc;                      \
+    for (int q_ = cur + 1; q_ < (jd); ++q_) H3A(udst, q_) = 0.0; \
+    cur = (jd);                                             \
+    acc = 0.0;                                              \
+  }
   const int ns = g.n_act[col], m = g.m_act[col];
   int iseg = 0;
   for (int js = 1; js <= ns; ++js) {
@@ -1105,7 +965,8 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
     if (nseg == 1) {
       iseg = iseg + 1;
       const int jd = H3A(r.sdst, iseg);
-      H3A(udst, jd) = H3A(udst, jd) + H3A(s.u, js) * H3A(r.wgt, iseg);
+      H3_DST(jd);
+      acc = acc + H3A(s.u, js) * H3A(r.wgt, iseg);
       continue;
     }
     double xil = 0.0;
@@ -1121,11 +982,12 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
       const double xir = H3A(r.lim, iseg);
       const int jd = H3A(r.sdst, iseg);
       const double wgt = H3A(r.wgt, iseg);
+      H3_DST(jd);
       if (m == H3_PCM) {
-        if (xil == xir) H3A(udst, jd) = p1;
-        else { H3A(udst, jd) = H3A(udst, jd) + p1 * wgt; xil = xir; }
+        if (xil == xir) acc = p1;
+        else { acc = acc + p1 * wgt; xil = xir; }
       } else if (m == H3_PLM) {
-        if (xil == xir) { H3A(udst, jd) = p2 * xir + p1; continue; }
+        if (xil == xir) { acc = p2 * xir + p1; continue; }
         double v;
         if (xil == 0.0) v = 0.5 * p2 * xir + p1;
         else {
@@ -1133,10 +995,10 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
           const double b1 = xir == 1.0 ? p1 + b2 : p1 + b2 * xir;
           v = b2 * xil + b1;
         }
-        H3A(udst, jd) = H3A(udst, jd) + v * wgt;
+        acc = acc + v * wgt;
         xil = xir;
       } else if (m == H3_PPM) {
-        if (xil == xir) { H3A(udst, jd) = (p3 * xir + p2) * xir + p1; continue; }
+        if (xil == xir) { acc = (p3 * xir + p2) * xir + p1; continue; }
         double v;
         if (xil == 0.0) v = ((1.0 / 3.0) * p3 * xir + 0.5 * p2) * xir + p1;
         else {
@@ -1146,10 +1008,10 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
           else { b2 = 0.5 * p2 + b3 * xir; b1 = p1 + b2 * xir; }
           v = (b3 * xil + b2) * xil + b1;
         }
-        H3A(udst, jd) = H3A(udst, jd) + v * wgt;
+        acc = acc + v * wgt;
         xil = xir;
       } else {
-        if (xil == xir) { H3A(udst, jd) = (((p5 * xir + p4) * xir + p3) * xir + p2) * xir + p1; continue; }
+        if (xil == xir) { acc = (((p5 * xir + p4) * xir + p3) * xir + p2) * xir + p1; continue; }
         double v;
         if (xil == 0.0)
           v = ((((1.0 / 5.0) * p5 * xir + 0.25 * p4) * xir + (1.0 / 3.0) * p3) * xir + 0.5 * p2) * xir + p1;
@@ -1160,11 +1022,14 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
           else { b4 = 0.25 * p4 + b5 * xir; b3 = (1.0 / 3.0) * p3 + b4 * xir; b2 = 0.5 * p2 + b3 * xir; b1 = p1 + b2 * xir; }
           v = (((b5 * xil + b4) * xil + b3) * xil + b2) * xil + b1;
         }
-        H3A(udst, jd) = H3A(udst, jd) + v * wgt;
+        acc = acc + v * wgt;
         xil = xir;
       }
     }
   }
+  if (cur > 0) H3A(udst, cur) = acc;
+  for (int q_ = cur + 1; q_ <= nd; ++q_) H3A(udst, q_) = 0.0;
+#undef H3_DST
   // near-empty destination cells at either end
   const int d1 = H3A(r.sdst, 1), dl = H3A(r.sdst, iseg);
   if (m == H3_PCM) {

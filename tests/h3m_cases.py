@@ -27,6 +27,38 @@ def have_hostcheck():
     return os.path.exists(HOST_LIB)
 
 
+def make_slab(seed, ncol, n_src, n_dst, n_grd):
+    """Columns as a model slab holds them (bench input): neighbouring columns resemble each other -- the
+    water depth varies smoothly along the slab, layers below the bottom are massless (one contiguous run at
+    the end of the column), interior thicknesses are a smooth profile with a few percent of noise, the
+    destination grid is the source grid relaxed towards fixed target depths.  (make_columns below draws
+    every layer of every column independently, empty and thin layers anywhere: the worst case for
+    wavefront divergence, which is what the parity tests want.)"""
+    rng = np.random.default_rng(seed)
+    s = np.arange(ncol) / 512.0
+    depth = 2500.0 + 1500.0 * np.sin(0.7 * s) * np.cos(0.23 * s) + 300.0 * np.sin(5.1 * s)        # m
+    depth = np.maximum(depth, 150.0) * 9806.0
+    k = np.arange(n_src)
+    prof = 10.0 * 1.09 ** k * 9806.0                                                                  # stretched
+    h = prof[None, :] * (1.0 + 0.03 * rng.standard_normal((ncol, n_src)))
+    top = np.concatenate([np.zeros((ncol, 1)), np.cumsum(h, 1)], 1)
+    x_src = np.minimum(top, depth[:, None])                       # layers below the bottom become massless
+    x_src[:, -1] = depth
+    zc = 0.5 * (x_src[:, 1:] + x_src[:, :-1]) / depth[:, None]
+    u = 24.0 + 6.0 * zc ** 0.7 + 0.02 * np.sin(9.0 * zc + s[:, None]) + 0.002 * rng.standard_normal((ncol, n_src))
+    kd = np.arange(n_dst)
+    tgt = np.concatenate([[0.0], np.cumsum(12.0 * 1.085 ** kd)]) * 9806.0
+    x_dst = np.minimum(0.7 * tgt[None, :] + 0.3 * np.interp(np.linspace(0, n_src, n_dst + 1), np.arange(n_src + 1), top[0])[None, :],
+                       depth[:, None])
+    x_dst[:, 0] = 0.0
+    x_dst[:, -1] = depth
+    x_dst = np.maximum.accumulate(x_dst, axis=1)
+    lo, hi = u.min(1, keepdims=True), u.max(1, keepdims=True)
+    u_grd = lo + (hi - lo) * (np.arange(n_grd)[None, :] + 0.5) / n_grd
+    return (np.ascontiguousarray(x_src), np.ascontiguousarray(u), np.ascontiguousarray(x_dst),
+            np.ascontiguousarray(u_grd))
+
+
 def make_columns(seed, ncol, n_src, n_dst, n_grd, kind="ocean", decreasing=False):
     """Seeded synthetic columns in the shape BLOM feeds hor3map (mod_ale_regrid_remap.F90:224-247):
     interface pressures with empty and very thin layers, a stratified field with noise, a

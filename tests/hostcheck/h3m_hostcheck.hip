@@ -4,6 +4,7 @@
 // never linked into libblomgpu.so and nothing in the product calls it.
 #include "../../blom_amd/csrc/hor3map_core.h"
 #include "../../blom_amd/csrc/hor3map_pqm.h"
+#include "../../blom_amd/csrc/hor3map_ppm_fused.h"
 #include <vector>
 #include <cstring>
 

@@ -21,7 +21,10 @@ cfgs = {"ppm_tracer": (hc.PPM, 6, 4, hc.NON_OSCILLATORY_POSDEF, True, False),
         "ppm_density": (hc.PPM, 6, 4, hc.MONOTONIC, False, False),
         "pqm_tracer": (hc.PQM, 6, 4, hc.NON_OSCILLATORY_POSDEF, True, False),
         "plm": (hc.PLM, 0, 0, hc.MONOTONIC, True, False)}
-x, u, xd, ug = hc.make_columns(11, ncol, n, n, n + 1, "tracer")
+kind = os.environ.get("H3M_KIND", "slab")
+x, u, xd, ug = hc.make_slab(11, ncol, n, n, n + 1) if kind == "slab" else hc.make_columns(11, ncol, n, n, n + 1, kind)
+if os.environ.get("H3M_UNIFORM"):
+    x = np.ascontiguousarray(np.tile(np.arange(n + 1.0) * 9806.0, (ncol, 1))); xd = x.copy()
 dev = torch.device("cuda:0")
 tx, tu, txd, tug = (torch.from_numpy(a).to(dev) for a in (x, u, xd, ug))
 out = {}
