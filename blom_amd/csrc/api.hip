@@ -200,6 +200,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "barotp_fused") { c->barotp_fused = v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
+  if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   return ctx_fail(c, "blomgpu_set_int: unknown option " + s);
 }

@@ -167,6 +167,7 @@ struct blomgpu_ctx {
   // and the stream the RCCL transport enqueues on when set (otherwise `stream`)
   hipStream_t xstream = nullptr, halo_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int barotp_rimbuf = 1;    // RCCL tiles: barotp's pair kernel reads its E/W rim from the receive buffers
   int barotp_overlap = 0;   // measured slower (see stage_barotp_pair.hip: bt_overlap_usable)
   int nlev_real[NF_REAL];
   int nlev_int[NF_INT];
@@ -242,6 +243,13 @@ int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc
 // locate the field (and level offset) a device pointer belongs to; returns field id or -1
 int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);
 int rccl_xctilr(blomgpu_ctx *, double *base, int nlev, int mhl, int nhl);   // comm_rccl.hip
+struct RcclLanded {          // received E/W strips left in the transport's buffers, layout [field][level][row][q]
+  const double *from_west = nullptr, *from_east = nullptr;
+  int has_w = 0, has_e = 0, per = 0, mhl = 0, nhl = 0, nlev = 0;
+  double *send_west = nullptr, *send_east = nullptr;   // the send strips (same layout), for a producer that packs them itself
+  int prepacked = 0;          // in: the send strips are already packed, skip the pack launch (and phase 1)
+};
+int rccl_xctilr_multi_ex(blomgpu_ctx *, double *const *fields, int nf, int nlev, int mhl, int nhl, RcclLanded *landed);
 int rccl_xctilr_multi(blomgpu_ctx *, double *const *fields, int nf, int nlev, int mhl, int nhl);  // one message per neighbour for up to 4 plane stacks
 
 // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own

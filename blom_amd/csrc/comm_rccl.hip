@@ -119,7 +119,15 @@ __global__ void k_unpack_ns(const DevView *Vp, FieldSet F, const double *__restr
   }
 }
 
+// `landed` != nullptr: leave the received E/W strips in the receive buffers (no unpack launch) and report
+// them; the consumer reads its rim straight from there (barotp's substep-pair kernel).
+int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl, RcclLanded *landed);
 int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl) {
+  return rccl_xctilr_multi_ex(c, fields, nf, nlev, mhl, nhl, nullptr);
+}
+int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl, RcclLanded *landed) {
+  const bool prepacked = landed && landed->prepacked;
+  if (landed) { landed->from_west = landed->from_east = nullptr; landed->send_west = landed->send_east = nullptr; }
   const DevView &h = c->h;
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
@@ -182,8 +190,9 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
     const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? row0 : -1);
     const unsigned gpack = (unsigned)((per + 255) / 256);
     dim3 g(gpack, ly, nf);
-    hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, st, c->d, F, R->sbuf[0],
-                       R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack, ns_exchange ? 1 : 0);
+    if (!(prepacked && need <= R->cap))
+      hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, st, c->d, F, R->sbuf[0],
+                         R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack, ns_exchange ? 1 : 0);
     // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
     // point-to-point operations between the same pair match in issue order, so every rank sends
     // west then east and receives east then west -- my east halo is the peer's FIRST send.
@@ -194,8 +203,15 @@ int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, i
     if (west >= 0) ncclRecv(R->rbuf[0], need, ncclDouble, west, R->comm, st);
     ncclResult_t rc = ncclGroupEnd();
     if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL halo exchange: ") + ncclGetErrorString(rc));
-    hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, st, c->d, F, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
-                       west >= 0 ? 1 : 0, east >= 0 ? 1 : 0);
+    if (landed) {
+      landed->from_west = R->rbuf[0]; landed->from_east = R->rbuf[1];
+      landed->has_w = west >= 0 ? 1 : 0; landed->has_e = east >= 0 ? 1 : 0;
+      landed->per = (int)per; landed->mhl = mhl; landed->nhl = nhl; landed->nlev = nlev;
+      landed->send_west = R->sbuf[0]; landed->send_east = R->sbuf[1];
+    } else {
+      hipLaunchKernelGGL(k_unpack_ew, g, dim3(256), 0, st, c->d, F, R->rbuf[0], R->rbuf[1], nlev, mhl, nhl,
+                         west >= 0 ? 1 : 0, east >= 0 ? 1 : 0);
+    }
   }
   HIPCHK(c, hipGetLastError());
   return 0;

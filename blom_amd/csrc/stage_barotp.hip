@@ -306,7 +306,8 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
 int bt_phase_check(blomgpu_ctx *c);
 int bt_overlap_usable(blomgpu_ctx *c);
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
-                   int do_odd, int do_even, int src, int tsel);
+                   int do_odd, int do_even, int src, int tsel, RcclLanded *rim);
+int bt_pair_halo_landed(blomgpu_ctx *c, int set, RcclLanded *landed);
 
 int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)mm; (void)k1m; (void)k1n;
@@ -372,6 +373,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       int lll = lll0;
       const bool ovl = bt_overlap_usable(c) != 0;
       halo_done = false;
+      RcclLanded landed;          // .prepacked carries over from launch to launch within the phase
       while (lll <= last) {
         const bool odd = lll % 2 == 1;
         const bool both = odd && lll + 1 <= last;
@@ -384,13 +386,18 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
         if (!both && !odd) { wo[1] = wo[0]; wm[1] = wm[0]; wn[1] = wn[0]; }
         // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
-        if ((c->tiling.multi() || (arctic1 && odd)) && !halo_done)
-          if (int rc = bt_pair_halo(c, set)) return rc;
+        // RCCL tiles along i: the received strips stay in the transport's buffers and the kernel loads its
+        // E/W rim from there (c->barotp_rimbuf), saving the unpack launch of every exchange
+        const bool rimbuf = c->tiling.rccl && c->barotp_rimbuf && c->tiling.npy == 1 && !ovl;
+        if ((c->tiling.multi() || (arctic1 && odd)) && !halo_done) {
+          if (rimbuf) { if (int rc = bt_pair_halo_landed(c, set, &landed)) return rc; }
+          else if (int rc = bt_pair_halo(c, set)) return rc;
+        }
         if (ovl) {
           // fork: outer tile columns + exchange of the new state on xstream, inner columns on stream; join
           HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
           HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
-          bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set, 1);
+          bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set, 1, nullptr);
           set ^= 1;
           c->halo_stream = c->xstream;
           const int rc = bt_pair_halo(c, set);
@@ -400,7 +407,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
           HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
           halo_done = true;
         } else {
-          bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set, 0);
+          bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, odd ? 1 : 0, (both || !odd) ? 1 : 0, set, 0, rimbuf ? &landed : nullptr);
           set ^= 1;
         }
         if (!both) { const int ll = ml; ml = nl; nl = ll; }

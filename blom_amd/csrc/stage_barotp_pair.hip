@@ -41,6 +41,13 @@ struct PairArgs {
   // :420-457 etc. run over j = -1..jj+2), so that a following launch needs no halo update -- which with
   // the arctic patch would rewrite the seam row at a point where the reference does not
   int write_margin;
+  // RCCL tiles: the E/W rim comes straight from the transport's receive buffers (no unpack launch)
+  const double *rim_w, *rim_e;
+  int rim_has_w, rim_has_e, rim_per, rim_on;
+  // ... and the tiles that hold the outermost HB columns write their part of the next exchange's send
+  // strips themselves (no pack launch); N/S rim cells of the columns 1..ii then follow the local rule at load
+  double *pack_w, *pack_e;
+  int pack_on;
 };
 
 // PERSIST = false: one odd+even pair (or one half) per launch, neighbours synchronise at the kernel
@@ -93,6 +100,10 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
       cs = (size_t)IDX(V, is, js);
     }
   }
+  if (!PERSIST && a.rim_on && !a.fold_halo && inarr && gi >= 1 && gi <= ii && (gj < 1 || gj > jj)) {
+    land = V.nreg <= 2;                                   // one tile row: closed in j, or the tile's own periodic wrap
+    cs = (size_t)IDX(V, gi, gj < 1 ? gj + jj : gj - jj);
+  }
   const bool ok_src = inarr && !land;
   const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
   // halo cell owned by this tile: the tile that holds the nearest interior point (each halo cell has one owner)
@@ -101,9 +112,24 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
     const int ci = gi < 1 ? 1 : (gi > ii ? ii : gi), cj = gj < 1 ? 1 : (gj > jj ? jj : gj);
     own_halo = (ci - 1) / TI == (int)bx && (cj - 1) / TJ == (int)blockIdx.y;
   }
+  // E/W rim cell served by the exchange buffers: strip row r = gj - (1 - 3), column q within the strip
+  const bool from_buf = !PERSIST && a.rim_on && inarr && (gi < 1 || gi > ii);
+  const double *rb = gi < 1 ? a.rim_w : a.rim_e;
+  const bool rb_has = gi < 1 ? a.rim_has_w != 0 : a.rim_has_e != 0;
+  const size_t rb_i = from_buf ? (size_t)(gj + HB - 1) * HB + (size_t)(gi < 1 ? gi + HB - 1 : gi - ii - 1) : 0;
   auto load_state = [&](bool rim_only) {
     if (!act || (rim_only && mine)) return;
     const double *g_pb = b_pb[src], *g_ub = b_ub[src], *g_vb = b_vb[src];
+    if (from_buf) {
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        const size_t o = (size_t)l * a.rim_per + rb_i, fs = (size_t)2 * a.rim_per;
+        s_pb[l][lj][li] = rb_has ? rb[o] : V.P.vland;
+        s_ub[l][lj][li] = rb_has ? rb[fs + o] : V.P.vland;
+        s_vb[l][lj][li] = rb_has ? rb[2 * fs + o] : V.P.vland;
+      }
+      return;
+    }
 #pragma unroll
     for (int l = 0; l < 2; l++) {
       s_pb[l][lj][li] = ok_src ? g_pb[cs + l * np] : (inarr ? V.P.vland : 0.);
@@ -315,6 +341,41 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
       }
     }
   }
+  if (!PERSIST && a.pack_on && act) {
+    // send strips of the NEXT exchange, layout [field][level][row][q] with rows 1-HB..jj+HB (comm_rccl.hip):
+    // west strip = columns 1..HB, east strip = columns ii-HB+1..ii
+    const bool inw = gi >= 1 && gi <= HB, ine = gi > ii - HB && gi <= ii;
+    const bool perj = V.nreg > 2;
+    if (inw || ine) {
+      const size_t per = (size_t)a.rim_per, fs = 2 * per;
+      auto put = [&](int row, bool landv) {                // row = strip row index of global row gj'
+        const size_t base = (size_t)row * HB;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+          const double vp = landv ? V.P.vland : s_pb[l][lj][li], vu = landv ? V.P.vland : s_ub[l][lj][li];
+          const double vv = landv ? V.P.vland : s_vb[l][lj][li];
+          if (inw) {
+            const size_t o = l * per + base + (size_t)(gi - 1);
+            a.pack_w[o] = vp; a.pack_w[fs + o] = vu; a.pack_w[2 * fs + o] = vv;
+          }
+          if (ine) {
+            const size_t o = l * per + base + (size_t)(gi - (ii - HB + 1));
+            a.pack_e[o] = vp; a.pack_e[fs + o] = vu; a.pack_e[2 * fs + o] = vv;
+          }
+        }
+      };
+      if (mine) {
+        put(gj + HB - 1, false);
+        if (perj) {                                       // the rows that are the periodic images of halo rows
+          if (gj <= HB) put(gj + jj + HB - 1, false);
+          if (gj > jj - HB) put(gj - jj + HB - 1, false);
+        }
+      } else if (!perj && (gi - 1) / TI == (int)bx &&
+                 ((gj < 1 && gj >= 1 - HB && blockIdx.y == 0) || (gj > jj && gj <= jj + HB && blockIdx.y == gridDim.y - 1))) {
+        put(gj + HB - 1, true);                           // closed in j: halo rows of the strips are land
+      }
+    }
+  }
   if (PERSIST) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the count goes out
     __syncthreads();
@@ -363,6 +424,14 @@ __global__ void k_bt_halo3(const DevView *Vp, int set, int mhl, int nhl) {
   }
 }
 
+// RCCL tiles: exchange without the unpack launch; the strips stay in the transport's receive buffers
+int bt_pair_halo_landed(blomgpu_ctx *c, int set, RcclLanded *landed) {
+  const DevView &h = c->h;
+  double *f[3] = {set ? h.f[F_pb_t2] : h.f[F_pb_t], set ? h.f[F_ubflx_t2] : h.f[F_ubflx_t],
+                  set ? h.f[F_vbflx_t2] : h.f[F_vbflx_t]};
+  return rccl_xctilr_multi_ex(c, f, 3, 2, 3, 3, landed);
+}
+
 int bt_pair_halo(blomgpu_ctx *c, int set) {
   const DevView &h = c->h;
   if (c->tiling.multi() || h.nreg == 2) {   // neighbour exchange through the tile transport / the arctic rule of xctilr
@@ -384,7 +453,7 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
 }
 
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
-                   int do_odd, int do_even, int src, int tsel) {
+                   int do_odd, int do_even, int src, int tsel, RcclLanded *rim) {
   const DevView &h = c->h;
   PairArgs a;
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;
@@ -392,10 +461,20 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
   a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
   a.write_margin = (h.nreg == 2 && !c->tiling.multi()) ? 1 : 0;
+  a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
+  if (rim && rim->from_west) {
+    a.rim_on = 1; a.rim_w = rim->from_west; a.rim_e = rim->from_east;
+    a.rim_has_w = rim->has_w; a.rim_has_e = rim->has_e; a.rim_per = rim->per;
+  }
+  a.pack_on = 0; a.pack_w = a.pack_e = nullptr;
+  if (rim && rim->from_west && rim->send_west && h.jj >= 2 * HB && h.ii >= 2 * HB) {
+    a.pack_on = 1; a.pack_w = rim->send_west; a.pack_e = rim->send_east;
+  }
   a.prof = c->bt_prof;
   a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr; a.epoch_base = 0;
   const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
   a.nbx = nbx;
+  if (rim) rim->prepacked = a.pack_on;      // the launch below leaves the next exchange's send strips packed
   if (tsel == 0) {
     a.tsel = 0;
     hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);
@@ -466,6 +545,8 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
   a.tsel = 0; a.nbx = nbx; a.write_margin = 0;
+  a.pack_on = 0; a.pack_w = a.pack_e = nullptr;
+  a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
   a.epoch_base = c->bt_epoch;
   c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;
