@@ -209,7 +209,7 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
   Params &P = c->h.P;
   std::string s(name), v(val);
   c->dirty = true;
-  if (s == "expcnf") return 0;
+  if (s == "expcnf") { c->expcnf = v; return 0; }
   if (s == "mommth") {
     if (v == "enscon") P.mommth = 0; else if (v == "enecon") P.mommth = 1; else if (v == "enedis") P.mommth = 2;
     else return ctx_fail(c, " mommth = " + v + " is unsupported!");   // phy/mod_momtum.F90:815-820
@@ -327,6 +327,17 @@ int blomgpu_tmsmt1(blomgpu_ctx *c, int nn) { ctx_sync_view(c); return st_tmsmt1(
 int blomgpu_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) { ctx_sync_view(c); return st_tmsmt2(c, m, mm, nn, k1m); }
 int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(c, mm); }
 int blomgpu_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) { ctx_sync_view(c); return st_diapfl(c, n, nn, k1n); }
+// sfcstr, phy/mod_sfcstr.F90:33-62: the surface stress of the idealised experiments is set at initialisation
+// (or absent), so the stage is empty for them; the coupled/reanalysis branches live in modules that are
+// not part of this path.
+int blomgpu_sfcstr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)mm; (void)nn; (void)k1m; (void)k1n;
+  const std::string &e = c->expcnf;
+  if (e == "noforcing" || e == "fuk95" || e == "channel") return 0;
+  if (e == "cesm" || e == "ben02clim" || e == "ben02syn" || e == "single_column")
+    return ctx_fail(c, " sfcstr: expcnf = " + e + " is not built on the device (sfcstr_cesm / sfcstr_ben02)");
+  return ctx_fail(c, " sfcstr: expcnf = " + e + " is unsupported!");          // :54-60
+}
 int blomgpu_init_cppm(blomgpu_ctx *c) { ctx_sync_view(c); return st_init_cppm(c); }   // phy/mod_cppm.F90:2504
 int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
 
@@ -364,6 +375,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "pgforc") return blomgpu_pgforc(c, m, n, mm, nn, k1m, k1n);
   if (s == "momtum") return blomgpu_momtum(c, m, n, mm, nn, k1m, k1n);
   if (s == "convec") return blomgpu_convec(c, m, n, mm, nn, k1m, k1n);
+  if (s == "sfcstr") return blomgpu_sfcstr(c, m, n, mm, nn, k1m, k1n);
   if (s == "diapfl") return blomgpu_diapfl(c, n, nn, k1n);
   if (s == "barotp") return blomgpu_barotp(c, m, n, mm, nn, k1m, k1n);
   if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);

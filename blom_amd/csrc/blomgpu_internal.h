@@ -190,6 +190,7 @@ struct blomgpu_ctx {
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   std::string err;
+  std::string expcnf = "channel";   // experiment configuration (mod_config): selects the forcing branches
 };
 
 int  ctx_fail(blomgpu_ctx *c, const std::string &msg);

@@ -92,6 +92,7 @@ contains
     call advect(m,n,mm,nn,k1m,k1n)
     call pbcor1(m,n,mm,nn,k1m,k1n)
     call diffus(m,n,mm,nn,k1m,k1n)
+    call sfcstr(m,n,mm,nn,k1m,k1n)
     call pgforc(m,n,mm,nn,k1m,k1n)
     call momtum(m,n,mm,nn,k1m,k1n)
     call convec(m,n,mm,nn,k1m,k1n)

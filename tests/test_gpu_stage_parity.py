@@ -156,3 +156,22 @@ def test_xctilr_arctic_patch_matches_reference(itype):
         ref.ref.xctilr(b, 1, 2 * kk, mh, nh, itype)
         assert np.array_equal(gpu.get("u"), b), (itype, mh, nh)
     gpu.close()
+
+
+def test_sfcstr_follows_the_reference_switch():
+    """phy/mod_sfcstr.F90:33-62: empty for the idealised experiments, an error for unknown ones"""
+    from blom_amd.gpu import BlomGpu, BlomGpuError
+    case = make_case("chan_s")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    six = hostinit.step_indices(0, case.kdm)
+    for e in ("channel", "fuk95", "noforcing"):
+        gpu.set("expcnf", e)
+        gpu.stage("sfcstr", *six)
+    gpu.set("expcnf", "nonsense")
+    with pytest.raises(BlomGpuError, match="sfcstr: expcnf = nonsense is unsupported!"):
+        gpu.stage("sfcstr", *six)
+    gpu.set("expcnf", "cesm")
+    with pytest.raises(BlomGpuError, match="not built on the device"):
+        gpu.stage("sfcstr", *six)
+    gpu.close()
