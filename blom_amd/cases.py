@@ -129,6 +129,8 @@ def default_params(baclin, batrop):
         bdmldp=0,
         # frozen diffusivities (difest needs CVMix, absent: SURVEY.md 8c)
         difiso0=300.0, difint0=300.0, difdia0=1.0e-5, difwgt0=1.0,
+        nday_in_year=365,    # mod_time (calendar): scales the ideal age increment, idlage/mod_idlage.F90:81
+        itriag=1,            # index of the ideal age tracer (trc/mod_tracers.F90:100 with -DTRC -DIDLAGE)
         taux0=0.1,           # zonal wind stress amplitude [N m-2]
         nslp0=0.0,           # amplitude of the frozen isopycnal slopes nslpx/nslpy [] (cmnfld2 is out of scope)
     )

@@ -193,7 +193,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   Params &P = c->h.P;
   std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
-  R(lstep) R(nstep) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   if (s == "csdiag") return 0;
   if (s == "timing") { c->timing = v != 0; return 0; }
@@ -322,7 +322,7 @@ int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype,
     return st_##nm(c, m, n, mm, nn, k1m, k1n);                                             \
   }
 STAGE6(init_fluxes) STAGE6(advect) STAGE6(pbcor1) STAGE6(pbcor2) STAGE6(diffus) STAGE6(pgforc)
-STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra) STAGE6(convec)
+STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra) STAGE6(convec) STAGE6(updtrc)
 int blomgpu_tmsmt1(blomgpu_ctx *c, int nn) { ctx_sync_view(c); return st_tmsmt1(c, nn); }
 int blomgpu_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) { ctx_sync_view(c); return st_tmsmt2(c, m, mm, nn, k1m); }
 int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(c, mm); }
@@ -376,6 +376,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "momtum") return blomgpu_momtum(c, m, n, mm, nn, k1m, k1n);
   if (s == "convec") return blomgpu_convec(c, m, n, mm, nn, k1m, k1n);
   if (s == "sfcstr") return blomgpu_sfcstr(c, m, n, mm, nn, k1m, k1n);
+  if (s == "updtrc") return blomgpu_updtrc(c, m, n, mm, nn, k1m, k1n);
   if (s == "diapfl") return blomgpu_diapfl(c, n, nn, k1n);
   if (s == "barotp") return blomgpu_barotp(c, m, n, mm, nn, k1m, k1n);
   if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);
@@ -396,7 +397,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     c->h.P.nstep = ns + 1;
     c->dirty = true;
     static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
-                                "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail",
+                                "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
                                 "barotp", "pbcor2", "tmsmt2"};
     c->defer_checks = true;
     for (const char *st : seq)

@@ -84,6 +84,7 @@ struct Params {
   // mod_time
   double baclin, batrop, delt1, dlt;
   int lstep, nstep;
+  int nday_in_year, itriag;   // mod_time; index of the ideal age tracer (trc/mod_tracers.F90:100), < 1: none
   // mod_eos (inieos, phy/mod_eos.F90:105-129)
   double pref;
   double ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26;
@@ -224,6 +225,7 @@ int st_pgforc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_convec(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_updtrc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_cppm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     // stage_cppm.hip, called by advect

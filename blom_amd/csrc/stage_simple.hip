@@ -200,3 +200,26 @@ int st_kfpla_halo(blomgpu_ctx *c, int n) {
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+
+// ---- updtrc, trc/mod_tracers_update.F90:152-170 = hamocc_step (iHAMOCC, not on this path) + idlage_step,
+//      idlage/mod_idlage.F90:57-96: surface layer reset, deeper layers aged, all p-points incl. the halo ----
+__global__ void k_idlage_step(const DevView *Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (!V.m[I_ip][c]) return;
+  const int k = by_;
+  const size_t np = V.nplane;
+  double *t = V.f[F_trc] + c + ((size_t)(k + nn) + (size_t)(V.P.itriag - 1) * 2 * V.kk) * np;
+  if (k == 0) *t = 0.;
+  else *t = *t + V.P.delt1 / (86400. * V.P.nday_in_year);
+}
+
+int st_updtrc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)mm; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.P.itriag < 1 || h.P.itriag > h.ntr) return 0;       // no ideal age tracer configured
+  if (h.P.nday_in_year < 1) return ctx_fail(c, "updtrc: nday_in_year is not set (mod_time)");
+  hipLaunchKernelGGL(k_idlage_step, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

@@ -98,6 +98,7 @@ contains
     call convec(m,n,mm,nn,k1m,k1n)
     call diapfl(n,nn,k1n)
     call mxlayr_tail(nn,k1n)
+    call updtrc(m,n,mm,nn,k1m,k1n)
     call barotp(m,n,mm,nn,k1m,k1n)
     call pbcor2(m,n,mm,nn,k1m,k1n)
     call tmsmt2(m,mm,nn,k1m)

@@ -103,7 +103,7 @@ module mod_blomgpu
   public :: gpu_init, gpu_finalize, gpu_set, gpu_upload, gpu_upload_int, gpu_download, gpu_nlev, &
             gpu_halo, gpu_chksum, gpu_sync
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
-            diapfl, barotp, eddtra, convec, sfcstr, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail
+            diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -265,6 +265,10 @@ contains
   subroutine barotp(m,n,mm,nn,k1m,k1n)         ! phy/mod_barotp.F90:148
     integer, intent(in) :: m,n,mm,nn,k1m,k1n
     call stage6('barotp',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine updtrc(m,n,mm,nn,k1m,k1n)         ! trc/mod_tracers_update.F90:152
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('updtrc',m,n,mm,nn,k1m,k1n)
   end subroutine
   subroutine sfcstr(m,n,mm,nn,k1m,k1n)         ! phy/mod_sfcstr.F90:33
     integer, intent(in) :: m,n,mm,nn,k1m,k1n

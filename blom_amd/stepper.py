@@ -11,7 +11,7 @@ reference-pinned cases use, eddtra's result is exactly the zero fluxes that back
 from .hostinit import step_indices
 
 DYNCORE_STAGES = ("init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect", "pbcor1",
-                  "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "barotp", "pbcor2",
+                  "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc", "barotp", "pbcor2",
                   "tmsmt2")
 OPTIONAL_STAGES = ("eddtra",)
 # halo_cmnfld2 / halo_difest : the xctilr calls of phy/mod_cmnfld_routines.F90:1171-1172 and

@@ -81,6 +81,7 @@ int  blomgpu_diffus (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 int  blomgpu_pgforc (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_pgforc.F90:438  */
 int  blomgpu_momtum (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_momtum.F90:215  */
 int  blomgpu_convec (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* phy/mod_convec.F90:43   */
+int  blomgpu_updtrc (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* trc/mod_tracers_update.F90:152: its idlage_step, idlage/mod_idlage.F90:57 */
 int  blomgpu_sfcstr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* phy/mod_sfcstr.F90:33 (empty for channel/fuk95/noforcing) */
 int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                             /* phy/mod_diapfl.F90:49   */
 int  blomgpu_barotp (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_barotp.F90:148  */

@@ -57,7 +57,7 @@ int orc_set_real(OState *S, const char *name, double v) {
 
 int orc_set_int(OState *S, const char *name, int v) {
 #define R(nm) if (!strcmp(name, #nm)) { S->nm = v; return 0; }
-  R(lstep) R(nstep) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   return 1;
 }
@@ -92,6 +92,7 @@ int orc_stage(OState *S, const char *st, int m, int n, int mm, int nn, int k1m, 
   else if (!strcmp(st, "momtum")) orc_momtum(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "barotp")) orc_barotp(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "convec")) orc_convec(S, m, n, mm, nn, k1m, k1n);
+  else if (!strcmp(st, "updtrc")) orc_updtrc(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "diapfl")) orc_diapfl(S, n, nn, k1n);
   else if (!strcmp(st, "eddtra")) return orc_eddtra(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "mxlayr_tail")) orc_mxlayr_tail(S, nn, k1n);

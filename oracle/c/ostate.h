@@ -56,7 +56,7 @@ typedef struct {
   int ii, jj, kk, ni, nj, nplane, nreg, ntr;
   /* mod_time */
   double baclin, batrop, delt1, dlt;
-  int lstep, nstep;
+  int lstep, nstep, nday_in_year, itriag;
   /* mod_eos */
   double pref, ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26;
   /* mod_momtum */
@@ -126,6 +126,7 @@ void orc_pbcor2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_momtum(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_convec(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
+void orc_updtrc(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_diapfl(OState *S, int n, int nn, int k1n);
 int orc_eddtra(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);   /* PARITY UNPINNED, see eddtra.c */
 void orc_mxlayr_tail(OState *S, int nn, int k1n);

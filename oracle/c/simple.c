@@ -188,3 +188,19 @@ void orc_mxlayr_tail(OState *S, int nn, int k1n) {
   orc_xctilr(S, S->dp + (size_t)S->nplane * (k1n - 1), 1, S->kk, 3, 3, 1);
   p_dpu_dpv(S, nn, 0);
 }
+
+/* updtrc, trc/mod_tracers_update.F90:152-170: hamocc_step (iHAMOCC, not part of this path) + idlage_step,
+ * idlage/mod_idlage.F90:57-96: the ideal age tracer is reset in the surface layer and aged by
+ * delt1 / (86400 nday_in_year) below it, on all p-points including the halo. */
+void orc_updtrc(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)mm; (void)k1m;
+  if (S->itriag < 1 || S->itriag > S->ntr) return;
+  const int kk = S->kk;
+  const double q = S->delt1 / (86400. * S->nday_in_year);
+  for (int j = 1 - NBDY; j <= S->jj + NBDY; j++)
+    for (int i = 1 - NBDY; i <= S->ii + NBDY; i++) {
+      if (!A2(S, ip, i, j)) continue;
+      TRC(S, i, j, k1n, S->itriag) = 0.;
+      for (int k = 2; k <= kk; k++) TRC(S, i, j, k + nn, S->itriag) = TRC(S, i, j, k + nn, S->itriag) + q;
+    }
+}

@@ -20,7 +20,7 @@ module ref_harness
   use dimensions,    only: idm, jdm, kdm, itdm, jtdm
   use mod_xc
   use mod_config,    only: expcnf
-  use mod_time,      only: baclin, batrop, delt1, dlt, lstep, nstep
+  use mod_time,      only: baclin, batrop, delt1, dlt, lstep, nstep, nday_in_year
   use mod_grid
   use mod_state
   use mod_eos,       only: pref, inieos
@@ -40,6 +40,7 @@ module ref_harness
   use mod_diffus,    only: diffus
   use mod_diapfl,    only: diapfl
   use mod_convec,    only: convec
+  use mod_idlage,    only: idlage_step
   use mod_tracers,   only: ntr, trc, trcold, inivar_tracers
   use mod_cmnfld,    only: inivar_cmnfld
   use mod_ifdefs,    only: use_TRC
@@ -163,6 +164,7 @@ contains
     select case (trim(cstr(name)))
       case ('lstep');      lstep = v
       case ('nstep');      nstep = v
+      case ('nday_in_year'); nday_in_year = v
       case ('vcoord_tag'); vcoord_tag = v
       case ('ltedtp_opt'); ltedtp_opt = v
       case ('bdmtyp');     bdmtyp = v
@@ -389,6 +391,8 @@ contains
       case ('pgforc');  call pgforc(m,n,mm,nn,k1m,k1n)
       case ('momtum');  call momtum(m,n,mm,nn,k1m,k1n)
       case ('convec');  call convec(m,n,mm,nn,k1m,k1n)
+      ! updtrc (trc/mod_tracers_update.F90:152-170) = hamocc_step (not built) + idlage_step; the latter is called
+      case ('updtrc');  call idlage_step(m,n,mm,nn,k1m,k1n)
       case ('diapfl');  call diapfl(n,nn,k1n)
       case ('barotp');  call barotp(m,n,mm,nn,k1m,k1n)
       case ('pbcor2');  call pbcor2(m,n,mm,nn,k1m,k1n)

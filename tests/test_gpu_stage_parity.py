@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 # stage -> (rtol, atol); default exact
 TOL = {"barotp": (1e-12, 1e-9), "diapfl": (1e-11, 1e-12)}
 GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", "pbcor1", "diffus", "pgforc",
-              "momtum", "convec", "diapfl", "mxlayr_tail", "barotp", "pbcor2", "tmsmt2"]
+              "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc", "barotp", "pbcor2", "tmsmt2"]
 # 2-D scratch arrays of mod_utility that the reference leaves holding the last layer's
 # temporaries (phy/mod_momtum.F90:398-423, phy/mod_pbcor.F90:172-236); the device keeps such
 # temporaries in its work space instead.
