@@ -3,7 +3,8 @@
 (oracle/_ref/<cfg>/libblomref.so, built from /root/reference by oracle/Makefile).  Run in the
 build container only:   python tests/golden/make_golden.py
 
-Per configuration (chan_s, box_s):
+Per configuration (chan_s, box_s; for fuk95 -- the reference's own test case, 156x32x12 -- and tri_s --
+arctic patch -- only the CRC file: their inputs are the analytic host initialisation, which the tests redo):
   <cfg>_init.npz   complete model state + masks + grid after host initialisation (the inputs)
   <cfg>_crc.json   for steps 1..NSTEPS and every stage of the dyncore sequence: the reference's own
                    chksum/xccrc value (phy/mod_checksum.F90, phy/mod_xc.F90:4164) of every field
@@ -34,14 +35,17 @@ SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "v
 CRC_FIELDS = [f for f in STATE_FIELDS if f not in SCRATCH]
 FINAL_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "trc"]
 
-for cfg in ("chan_s", "box_s"):
+for cfg in ("chan_s", "box_s", "fuk95", "tri_s"):
+    crc_only = cfg in ("fuk95", "tri_s")
+    NSTEPS = 2 if cfg == "fuk95" else 3
     case = make_case(cfg)
     ref = get_ref_backend(cfg, case.depth)
     hostinit.init_state(ref, case)
     init = {nm: ref.get(nm).copy() for nm in STATE_FIELDS + GRID_FIELDS + INT_FIELDS if ref.ref.has_field(nm) or nm in ("trc",)}
     for m in ("ip", "iu", "iv", "iq"):
         init["mask_" + m] = ref.masks[m].copy()
-    np.savez_compressed(os.path.join(HERE, f"{cfg}_init.npz"), **init)
+    if not crc_only:
+        np.savez_compressed(os.path.join(HERE, f"{cfg}_init.npz"), **init)
     crcs = {}
     state = {}
 
@@ -62,5 +66,6 @@ for cfg in ("chan_s", "box_s"):
         record(pending.pop())
     json.dump({"nsteps": NSTEPS, "fields": CRC_FIELDS, "crc": crcs},
               open(os.path.join(HERE, f"{cfg}_crc.json"), "w"))
-    np.savez_compressed(os.path.join(HERE, f"{cfg}_final.npz"), **{nm: ref.get(nm).copy() for nm in FINAL_FIELDS})
+    if not crc_only:
+        np.savez_compressed(os.path.join(HERE, f"{cfg}_final.npz"), **{nm: ref.get(nm).copy() for nm in FINAL_FIELDS})
     print(cfg, "fixtures written")
