@@ -1,0 +1,72 @@
+"""The device against the COMMITTED golden fixtures alone (no reference library needed on the GPU box):
+tests/golden/<cfg>_init.npz is the input state, <cfg>_crc.json the reference's own checksum of every field
+after every stage, <cfg>_final.npz the reference's fields after three steps.
+
+  * step 1, every stage up to (not including) the first one that calls exp() (diapfl): the device's fields
+    must have the reference's CRCs -- bit-exact;
+  * the free run to the end of step 3: equal to the reference's final fields within 1e-9 relative (the one
+    ulp of exp in diapfl/barotp is the only source of difference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd.checksum import chksum
+from blom_amd.stepper import dyncore_step
+from parity import load_golden_init, put_fields
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+EDDTRA_OUT = {"umfltd", "vmfltd", "utfltd", "vtfltd", "usfltd", "vsfltd"}     # see tests/test_oracle_golden.py
+
+
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
+def test_device_reproduces_golden_fixtures(cfg):
+    from blom_amd.gpu import BlomGpu
+    case = make_case(cfg)
+    masks, fields = load_golden_init(cfg)
+    gold = json.load(open(os.path.join(HERE, "golden", f"{cfg}_crc.json")))
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, case.nreg, masks)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            gpu.set(nm, v)
+    put_fields(gpu, fields)
+    gpu.set("delt1", case.params["baclin"])
+    bad, state = [], {"exact": True, "checked": 0}
+
+    def check(st):
+        if st == "diapfl":
+            state["exact"] = False               # exp() from here on: last-bit differences are legitimate
+        exp = gold["crc"]["1"].get(st)
+        if exp is None or not state["exact"]:
+            return
+        for nm, want in exp.items():
+            if nm in EDDTRA_OUT or not gpu.has_field(nm):
+                continue
+            got = chksum(nm, gpu.get(nm), masks, case.idm, case.jdm)
+            state["checked"] += 1
+            if got != want:
+                bad.append(f"step 1 {st} {nm}: crc 0x{got:08x} != 0x{want:08x}")
+
+    pending = []
+
+    def hook(st, six):
+        if pending:
+            check(pending.pop())
+        pending.append(st)
+    ns = dyncore_step(gpu, 0, case.params["baclin"], hook=hook)
+    check(pending.pop())
+    assert not bad, "\\n".join(bad[:20])
+    assert state["checked"] > 500
+    for _ in range(gold["nsteps"] - 1):
+        ns = dyncore_step(gpu, ns, case.params["baclin"])
+    z = np.load(os.path.join(HERE, "golden", f"{cfg}_final.npz"))
+    J, I = slice(4, 4 + case.jdm), slice(4, 4 + case.idm)
+    for nm in z.files:
+        a = z[nm][:, J, I]
+        b = gpu.get(nm)[:a.shape[0], J, I]
+        scale = np.abs(a).max() or 1.0
+        assert np.abs(a - b).max() <= 1e-9 * scale, (nm, float(np.abs(a - b).max()), scale)
+    gpu.close()
