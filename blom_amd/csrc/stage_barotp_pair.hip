@@ -326,7 +326,10 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
   }
   // publish the interior (and, with the arctic patch, the owned margin) in the other buffer set
   src ^= 1;
-  if (mine || own_halo) {
+  // persistent form: between iterations only the cells within HB of the tile edge are read by anybody (the
+  // neighbours' rims); the core of the tile lives in LDS and goes to memory with the last iteration
+  const bool edge_cell = li < 2 * HB || li >= TI || lj < 2 * HB || lj >= TJ || gi > ii - HB || gj > jj - HB;
+  if ((mine && (!PERSIST || edge_cell || lll > a.last)) || own_halo) {
     double *o_pb = b_pb[src], *o_ub = b_ub[src], *o_vb = b_vb[src];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
