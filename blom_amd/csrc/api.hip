@@ -201,6 +201,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
+  if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   return ctx_fail(c, "blomgpu_set_int: unknown option " + s);
 }
@@ -330,6 +331,21 @@ int blomgpu_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) { ctx_sync_view(c); r
 // sfcstr, phy/mod_sfcstr.F90:33-62: the surface stress of the idealised experiments is set at initialisation
 // (or absent), so the stage is empty for them; the coupled/reanalysis branches live in modules that are
 // not part of this path.
+// xcsum of level `lev` (1-based) of a named field, mask by grid type as in xctilr/xccrc (p-grid: ips)
+int blomgpu_xcsum(blomgpu_ctx *c, const char *name, int lev, int itype, double *sum) {
+  ctx_sync_view(c);
+  auto it = c->real_ids.find(name);
+  if (it == c->real_ids.end()) return ctx_fail(c, std::string("blomgpu_xcsum: unknown field ") + name);
+  if (lev < 1 || lev > c->nlev_real[it->second]) return ctx_fail(c, "blomgpu_xcsum: level out of range");
+  return st_xcsum(c, c->h.f[it->second] + (size_t)(lev - 1) * c->h.nplane, itype, sum);
+}
+int blomgpu_budget_sums(blomgpu_ctx *c, int ncall, int n, int nn) { ctx_sync_view(c); return st_budget_sums(c, ncall, n, nn); }
+// which: 0 sdp, 1 tdp, 2 trdp (phy/mod_budget.F90:50-59)
+int blomgpu_budget_get(blomgpu_ctx *c, int which, int ncall, int n, double *v) {
+  if (which < 0 || which > 2 || ncall < 1 || ncall > 7 || n < 1 || n > 2) return ctx_fail(c, "blomgpu_budget_get: index out of range");
+  *v = c->budget[which][ncall - 1][n - 1];
+  return 0;
+}
 int blomgpu_sfcstr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)n; (void)mm; (void)nn; (void)k1m; (void)k1n;
   const std::string &e = c->expcnf;

@@ -190,6 +190,9 @@ struct blomgpu_ctx {
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
+  double *xcsum_buf = nullptr;                 // [0] the sum, [1..jj] the row sums of xcsum
+  int cnsvdi = 0;                              // mod_budget: conservation diagnostics on/off
+  double budget[3][7][2] = {};                 // sdp, tdp, trdp (ncall, n)
   std::string err;
   std::string expcnf = "channel";   // experiment configuration (mod_config): selects the forcing branches
 };
@@ -226,6 +229,8 @@ int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_convec(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_updtrc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_xcsum(blomgpu_ctx *, const double *a, int itype, double *sum);
+int st_budget_sums(blomgpu_ctx *, int ncall, int n, int nn);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_cppm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     // stage_cppm.hip, called by advect

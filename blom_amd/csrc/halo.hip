@@ -477,3 +477,48 @@ int st_crc(blomgpu_ctx *c, const double *base, int nlev, int itype, unsigned *cr
   *crc = host_crc_bytes((const unsigned char *)rows.data(), 4 * rows.size(), 0);
   return 0;
 }
+
+// ---- xcsum (phy/mod_xc.F90:4116-4161): masked sum of a 2-D array that is reproducible bit for bit --------
+// Every row is summed in strips of 2*nbdy+1 = 9 points, strip sums are added to the row sum in order, and
+// the row sums are added serially: the order is part of the definition, so the rows go to the threads of ONE
+// workgroup and thread 0 adds the row sums.  The mask of the global sums is ips (phy/mod_inigeo.F90:189-208):
+// ip without the seam row of an arctic patch.  Single tile.
+__global__ void k_xcsum(const DevView *Vp, const double *__restrict__ a, const int *__restrict__ mask, int skip_seam,
+                        double *rowsum, double *out) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj;
+  for (int j = 1 + (int)threadIdx.x; j <= jj; j += blockDim.x) {
+    double sum8 = 0.;
+    const bool dead = skip_seam && j >= jj;
+    for (int i1 = 1; i1 <= ii; i1 += 2 * NBDY + 1) {
+      double sum8p = 0.;
+      const int ie = i1 + 2 * NBDY < ii ? i1 + 2 * NBDY : ii;
+      for (int i = i1; i <= ie; i++) {
+        const size_t x = IDX(V, i, j);
+        if (!dead && mask[x] == 1) sum8p = sum8p + a[x];
+      }
+      sum8 = sum8 + sum8p;
+    }
+    rowsum[j - 1] = sum8;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = rowsum[0];
+    for (int j = 2; j <= jj; j++) s = s + rowsum[j - 1];
+    *out = s;
+  }
+}
+
+int st_xcsum(blomgpu_ctx *c, const double *a, int itype, double *sum) {
+  const DevView &h = c->h;
+  if (c->tiling.multi()) return ctx_fail(c, "xcsum: built for a single tile");
+  if (!c->xcsum_buf) HIPCHK(c, hipMalloc((void **)&c->xcsum_buf, sizeof(double) * (size_t)(h.jj + 8)));
+  const int g = itype % 10;
+  const int *mask = g == 1 ? h.m[I_ip] : g == 2 ? h.m[I_iq] : g == 3 ? h.m[I_iu] : h.m[I_iv];
+  hipLaunchKernelGGL(k_xcsum, dim3(1), dim3(256), 0, c->stream, c->d, a, mask, (g == 1 && h.nreg == 2) ? 1 : 0,
+                     c->xcsum_buf + 1, c->xcsum_buf);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(sum, c->xcsum_buf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}

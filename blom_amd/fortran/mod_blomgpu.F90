@@ -94,6 +94,24 @@ module mod_blomgpu
       integer(c_int), value :: lev0, nlev, itype
       integer(c_int), intent(out) :: crc
     end function
+    integer(c_int) function blomgpu_xcsum(c, name, lev, itype, s) bind(C, name='blomgpu_xcsum')
+      import :: c_ptr, c_int, c_char, c_double
+      type(c_ptr), value :: c
+      character(kind=c_char), intent(in) :: name(*)
+      integer(c_int), value :: lev, itype
+      real(c_double), intent(out) :: s
+    end function
+    integer(c_int) function blomgpu_budget_sums(c, ncall, n, nn) bind(C, name='blomgpu_budget_sums')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: c
+      integer(c_int), value :: ncall, n, nn
+    end function
+    integer(c_int) function blomgpu_budget_get(c, which, ncall, n, v) bind(C, name='blomgpu_budget_get')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: c
+      integer(c_int), value :: which, ncall, n
+      real(c_double), intent(out) :: v
+    end function
     integer(c_int) function blomgpu_sync(c) bind(C, name='blomgpu_sync')
       import :: c_ptr, c_int
       type(c_ptr), value :: c
@@ -101,7 +119,7 @@ module mod_blomgpu
   end interface
 
   public :: gpu_init, gpu_finalize, gpu_set, gpu_upload, gpu_upload_int, gpu_download, gpu_nlev, &
-            gpu_halo, gpu_chksum, gpu_sync
+            gpu_halo, gpu_chksum, gpu_sync, gpu_xcsum, budget_sums, gpu_budget
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
             diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail
 
@@ -210,6 +228,22 @@ contains
     call gpu_check(blomgpu_crc(ctx, cz(name), 1, kcsd, itype, crc), 'chksum')
     write (*,'(3a,z8.8)') ' chksum: ', trim(text), ': 0x', crc
   end subroutine
+
+  subroutine gpu_xcsum(s, name, lev, itype)    ! phy/mod_xc.F90:4116 xcsum(sum, a, mask) on a device field
+    real(c_double), intent(out) :: s
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: lev, itype
+    call gpu_check(blomgpu_xcsum(ctx, cz(name), lev, itype, s), 'xcsum')
+  end subroutine
+  subroutine budget_sums(ncall, n, nn)         ! phy/mod_budget.F90:95
+    integer, intent(in) :: ncall, n, nn
+    call gpu_check(blomgpu_budget_sums(ctx, ncall, n, nn), 'budget_sums')
+  end subroutine
+  function gpu_budget(which, ncall, n) result(v)   ! sdp/tdp/trdp(ncall,n), phy/mod_budget.F90:50-59
+    integer, intent(in) :: which, ncall, n
+    real(c_double) :: v
+    call gpu_check(blomgpu_budget_get(ctx, which, ncall, n, v), 'budget_get')
+  end function
 
   subroutine gpu_sync()
     call gpu_check(blomgpu_sync(ctx), 'gpu_sync')

@@ -126,6 +126,21 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_crc(self.ctx, name.encode(), lev0, nlev, itype, C.byref(v)))
         return v.value
 
+    def xcsum(self, name, lev=1, itype=1):
+        """xcsum (phy/mod_xc.F90:4116) of one level of a device field; p-grid mask: ips."""
+        v = C.c_double(0.0)
+        self._chk(self.lib.blomgpu_xcsum(self.ctx, name.encode(), lev, itype, C.byref(v)))
+        return v.value
+
+    def budget_sums(self, ncall, n, nn):
+        """budget_sums (phy/mod_budget.F90:95); does nothing unless the option cnsvdi is set."""
+        self._chk(self.lib.blomgpu_budget_sums(self.ctx, ncall, n, nn))
+
+    def budget_get(self, which, ncall, n):
+        v = C.c_double(0.0)
+        self._chk(self.lib.blomgpu_budget_get(self.ctx, {"sdp": 0, "tdp": 1, "trdp": 2}[which], ncall, n, C.byref(v)))
+        return v.value
+
     # -- tile decomposition ---------------------------------------------------------------
     def rccl_init(self, id128, rank, nranks):
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))

@@ -57,7 +57,7 @@ int orc_set_real(OState *S, const char *name, double v) {
 
 int orc_set_int(OState *S, const char *name, int v) {
 #define R(nm) if (!strcmp(name, #nm)) { S->nm = v; return 0; }
-  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(cnsvdi) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   return 1;
 }
@@ -119,4 +119,16 @@ int orc_stage(OState *S, const char *st, int m, int n, int mm, int nn, int k1m, 
           if (A2(S, ip, i, j)) A3(S, p, i, j, k + 1) = A3(S, p, i, j, k) + A3(S, dp, i, j, k + nn);
   } else return 1;
   return 0;
+}
+
+double orc_budget_get(const OState *S, int which, int ncall, int n) { return S->budget[which][ncall - 1][n - 1]; }
+
+/* xcsum of level lev (1-based) of a named field; itype as for xctilr/xccrc selects the mask */
+double orc_xcsum_field(OState *S, const char *name, int lev, int itype) {
+  int nlev = 0, isint = 0;
+  const double *a = (const double *)orc_field(S, name, &nlev, &isint);
+  if (!a || isint || lev < 1 || lev > nlev) return 0. / 0.;
+  const int g = itype % 10;
+  const int *mask = g == 1 ? S->ip : g == 2 ? S->iq : g == 3 ? S->iu : S->iv;
+  return orc_xcsum(S, a + (size_t)(lev - 1) * S->nplane, mask, g == 1);
 }

@@ -56,7 +56,8 @@ typedef struct {
   int ii, jj, kk, ni, nj, nplane, nreg, ntr;
   /* mod_time */
   double baclin, batrop, delt1, dlt;
-  int lstep, nstep, nday_in_year, itriag;
+  int lstep, nstep, nday_in_year, itriag, cnsvdi;
+  double budget[3][7][2];    /* sdp, tdp, trdp of mod_budget (ncall, n) */
   /* mod_eos */
   double pref, ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26;
   /* mod_momtum */
@@ -127,6 +128,10 @@ void orc_momtum(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_barotp(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_convec(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_updtrc(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
+double orc_xcsum(const OState *S, const double *a, const int *mask, int use_ips);
+void orc_budget_sums(OState *S, int ncall, int n, int nn);
+double orc_budget_get(const OState *S, int which, int ncall, int n);
+double orc_xcsum_field(OState *S, const char *name, int lev, int itype);
 void orc_diapfl(OState *S, int n, int nn, int k1n);
 int orc_eddtra(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);   /* PARITY UNPINNED, see eddtra.c */
 void orc_mxlayr_tail(OState *S, int nn, int k1n);

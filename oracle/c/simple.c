@@ -204,3 +204,62 @@ void orc_updtrc(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
       for (int k = 2; k <= kk; k++) TRC(S, i, j, k + nn, S->itriag) = TRC(S, i, j, k + nn, S->itriag) + q;
     }
 }
+
+/* xcsum, phy/mod_xc.F90:4116-4161: masked sum of a 2-D array, reproducible bit for bit: every row is summed
+ * in strips of 2*nbdy+1 = 9 points (strip sums added to the row sum in order), then the row sums are added
+ * serially.  The mask of the global sums is ips (phy/mod_inigeo.F90:189-208): ip, without the seam row of an
+ * arctic patch. */
+double orc_xcsum(const OState *S, const double *a, const int *mask, int use_ips) {
+  const int ii = S->ii, jj = S->jj;
+  double total = 0.;
+  for (int j = 1; j <= jj; j++) {
+    double sum8 = 0.;
+    for (int i1 = 1; i1 <= ii; i1 += 2 * NBDY + 1) {
+      double sum8p = 0.;
+      const int ie = i1 + 2 * NBDY < ii ? i1 + 2 * NBDY : ii;
+      for (int i = i1; i <= ie; i++) {
+        int mk = mask[IX(S, i, j)];
+        if (use_ips && S->nreg == 2 && j >= jj) mk = 0;
+        if (mk == 1) sum8p = sum8p + a[IX(S, i, j)];
+      }
+      sum8 = sum8 + sum8p;
+    }
+    total = j == 1 ? sum8 : total + sum8;
+  }
+  return total;
+}
+
+/* budget_sums, phy/mod_budget.F90:95-196 (use_TRC, no TKE): mass weighted column sums of salinity and
+ * temperature into util1, util2 and their global sums; then the same for tracer 1 through util1.  The salt
+ * correction term of call 5 (:182-194) needs mod_forcing's salt_corr, which no stage of this path produces:
+ * it is taken as zero.  Results: S->budget[0..2][ncall-1][n-1] = sdp, tdp, trdp. */
+void orc_budget_sums(OState *S, int ncall, int n, int nn) {
+  if (!S->cnsvdi) return;
+  const int ii = S->ii, jj = S->jj, kk = S->kk;
+  for (int j = 1; j <= jj; j++)
+    for (int i = 1; i <= ii; i++)
+      if (A2(S, ip, i, j)) { A2(S, util1, i, j) = 0.; A2(S, util2, i, j) = 0.; }
+  for (int j = 1; j <= jj; j++)
+    for (int k = 1; k <= kk; k++)
+      for (int i = 1; i <= ii; i++)
+        if (A2(S, ip, i, j)) {
+          const double q = A3(S, dp, i, j, k + nn) * A2(S, scp2, i, j);
+          A2(S, util1, i, j) = A2(S, util1, i, j) + A3(S, saln, i, j, k + nn) * q;
+          A2(S, util2, i, j) = A2(S, util2, i, j) + A3(S, temp, i, j, k + nn) * q;
+        }
+  S->budget[0][ncall - 1][n - 1] = orc_xcsum(S, S->util1, S->ip, 1);
+  S->budget[1][ncall - 1][n - 1] = orc_xcsum(S, S->util2, S->ip, 1);
+  if (S->ntr >= 1) {
+    for (int j = 1; j <= jj; j++)
+      for (int i = 1; i <= ii; i++)
+        if (A2(S, ip, i, j)) A2(S, util1, i, j) = 0.;
+    for (int j = 1; j <= jj; j++)
+      for (int k = 1; k <= kk; k++)
+        for (int i = 1; i <= ii; i++)
+          if (A2(S, ip, i, j)) {
+            const double q = A3(S, dp, i, j, k + nn) * A2(S, scp2, i, j);
+            A2(S, util1, i, j) = A2(S, util1, i, j) + TRC(S, i, j, k + nn, 1) * q;
+          }
+    S->budget[2][ncall - 1][n - 1] = orc_xcsum(S, S->util1, S->ip, 1);
+  }
+}

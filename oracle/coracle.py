@@ -72,6 +72,17 @@ class COracle:
             rc = self.lib.orc_set_real(self.S, name.encode(), C.c_double(float(v)))
         return rc
 
+    def xcsum(self, name, lev=1, itype=1):
+        self.lib.orc_xcsum_field.restype = C.c_double
+        return self.lib.orc_xcsum_field(self.S, name.encode(), lev, itype)
+
+    def budget_sums(self, ncall, n, nn):
+        self.lib.orc_budget_sums(self.S, ncall, n, nn)
+
+    def budget_get(self, which, ncall, n):
+        self.lib.orc_budget_get.restype = C.c_double
+        return self.lib.orc_budget_get(self.S, {"sdp": 0, "tdp": 1, "trdp": 2}[which], ncall, n)
+
     def stage(self, name, m, n, mm, nn, k1m, k1n):
         rc = self.lib.orc_stage(self.S, name.encode(), m, n, mm, nn, k1m, k1n)
         if rc:

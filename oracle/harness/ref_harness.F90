@@ -41,6 +41,7 @@ module ref_harness
   use mod_diapfl,    only: diapfl
   use mod_convec,    only: convec
   use mod_idlage,    only: idlage_step
+  use mod_budget,    only: budget_sums, cnsvdi
   use mod_tracers,   only: ntr, trc, trcold, inivar_tracers
   use mod_cmnfld,    only: inivar_cmnfld
   use mod_ifdefs,    only: use_TRC
@@ -98,6 +99,10 @@ contains
     call inivar_forcing
     call inivar_cmnfld
     call inieos
+    ! mask of the global sums: restatement of phy/mod_inigeo.F90:189-208 (mod_inigeo itself needs netCDF) --
+    ! ip, without the seam and halo rows of an arctic patch
+    ips(:,:) = ip(:,:)
+    if (nreg == 2) ips(:,jj:jj+nbdy) = 0
   end subroutine ref_setup
 
   subroutine ref_set_real(name, v, ierr) bind(C, name='ref_set_real')
@@ -170,6 +175,7 @@ contains
       case ('bdmtyp');     bdmtyp = v
       case ('iwdflg');     iwdflg = v
       case ('csdiag');     csdiag = (v /= 0)
+      case ('cnsvdi');     cnsvdi = (v /= 0)
       case ('bdmldp');     bdmldp = (v /= 0)
       case default; ierr = 1
     end select
@@ -511,6 +517,26 @@ contains
       case default;            call xccrc(crc, a, nlev, iv, itype)
     end select
   end subroutine ref_xccrc
+
+  ! xcsum (phy/mod_xc.F90:4116-4161): the reference's reproducible masked sum of a 2-D array; mask by grid type
+  subroutine ref_xcsum(a, itype, s) bind(C, name='ref_xcsum')
+    integer(c_int), value :: itype
+    real(c_double), intent(inout) :: a(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy)
+    real(c_double), intent(out) :: s
+    select case (itype)
+      case (halo_ps, halo_pv); call xcsum(s, a, ips)
+      case (halo_qs, halo_qv); call xcsum(s, a, iq)
+      case (halo_us, halo_uv); call xcsum(s, a, iu)
+      case default;            call xcsum(s, a, iv)
+    end select
+  end subroutine ref_xcsum
+
+  ! budget_sums (phy/mod_budget.F90:95): its sums are private to mod_budget; what it leaves behind in
+  ! util1, util2 (the mass weighted column sums) is public and is what the tests compare
+  subroutine ref_budget_sums(ncall, n, nn) bind(C, name='ref_budget_sums')
+    integer(c_int), value :: ncall, n, nn
+    call budget_sums(ncall, n, nn)
+  end subroutine ref_budget_sums
 
   subroutine ref_xctilr(a, l1, ld, mh, nh, itype) bind(C, name='ref_xctilr')
     integer(c_int), value :: l1, ld, mh, nh, itype

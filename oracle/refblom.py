@@ -108,6 +108,16 @@ class RefBlom:
         self.lib.ref_xccrc(a.ctypes.data_as(C.c_void_p), a.shape[0], itype, C.byref(crc))
         return crc.value & 0xFFFFFFFF
 
+    def xcsum(self, a, itype=1):
+        """The reference's own reproducible masked sum (xcsum) of a (nj, ni) float64 array."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        s = C.c_double(0.0)
+        self.lib.ref_xcsum(a.ctypes.data_as(C.c_void_p), itype, C.byref(s))
+        return s.value
+
+    def budget_sums(self, ncall, n, nn):
+        self.lib.ref_budget_sums(ncall, n, nn)
+
     def xctilr(self, a, l1, ld, mh, nh, itype):
         """Reference halo update on a (>=ld, nj, ni) float64 array (view), in place."""
         assert a.flags.c_contiguous and a.dtype == np.float64
@@ -177,6 +187,12 @@ class RefBackend:
 
     def has_field(self, name):
         return self.ref.has_field(name)
+
+    def xcsum(self, a, itype=1):
+        return self.ref.xcsum(a, itype)
+
+    def budget_sums(self, ncall, n, nn):
+        self.ref.budget_sums(ncall, n, nn)
 
     def has_stage(self, name):
         return name != "eddtra"          # mod_eddtra is not part of the reference build (CVMix)
