@@ -30,20 +30,30 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 NSLP0 = 2.0e-4             # amplitude of the frozen isopycnal slopes that drive eddtra (cases.py)
 
 
-def build_case(cfg, advmth="remap"):
+def build_case(cfg, advmth="remap", tracers="default"):
     import numpy as np
     from blom_amd.cases import make_case
     from blom_amd import hostinit
-    case = make_case(cfg, nslp0=NSLP0, advmth=advmth)
+    # "default": the reference's default build options (meson_options.txt:17-21: TKE + advection of it, ideal age)
+    # => ntr = 3, the tracer count SURVEY.md 8(d) quotes the channel on; "iage": -DTRC -DIDLAGE only, ntr = 1
+    case = make_case(cfg + ("_tke" if tracers == "default" else ""), nslp0=NSLP0, advmth=advmth)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     return case, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq)
 
 
+def ntr_diffused(case):
+    """Tracers diffus acts on: the TKE and length-scale tracers are left out unless built with -DTKEIDF
+    (phy/mod_diffus.F90:64-66)."""
+    p = case.params
+    return case.ntr - (2 if p.get("itrtke", -1) >= 1 and not p.get("tkeidf", 0) else 0)
+
+
 def algorithmic_bytes(case, ntr):
-    """A_step = (124 + 6 ntr) F + 2.5 lstep 62 G."""
+    """A_step = (124 + 6 ntr) F + 2.5 lstep 62 G; of the 6 ntr, 2 ntr are diffus' and count
+    only the tracers diffus acts on."""
     F = case.idm * case.jdm * case.kdm * 8.0
     G = case.idm * case.jdm * 8.0
-    a3d = (124 + 6 * ntr) * F
+    a3d = (124 + 4 * ntr + 2 * ntr_diffused(case)) * F
     a2d = 2.5 * case.params["lstep"] * 62 * G
     return a3d, a2d
 
@@ -51,14 +61,15 @@ def algorithmic_bytes(case, ntr):
 # compulsory HBM bytes per launch of each timed kernel class, in units of F (one 3-D field):
 # every distinct array the class reads or writes counted once (2-D coefficient arrays ignored);
 # see DESIGN.md "Kernels" for the derivation.
-def class_bytes_F(ntr):
+def class_bytes_F(ntr, ntr_dif=None):
+    ntr_dif = ntr if ntr_dif is None else ntr_dif
     return {
-        "remap": 25 + 2 * ntr, "diffus": 19 + 2 * ntr, "pgforc": 15, "momtum": 26, "eddtra": 14,
+        "remap": 25 + 2 * ntr, "diffus": 19 + 2 * ntr_dif, "pgforc": 15, "momtum": 26, "eddtra": 14,
         "cppm": 48 + 4 * ntr, "diapfl": 23 + 2 * ntr, "pbcor1": 12 + 2 * ntr, "pbcor2": 13 + 2 * ntr, "convec": 19 + 2 * ntr,
     }
 
 
-def class_traffic(config):
+def class_traffic(config, ntr=1):
     """HBM bytes per step and kernel class from the newest committed PMC profile of this configuration
     (profiles/*_class_traffic.json, written by tools/prof_summarize.py from separate rocprofv3 --pmc
     passes of this very command); None when there is none."""
@@ -69,8 +80,11 @@ def class_traffic(config):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_class_traffic.json")))
     if not files:
         return None, None
-    d = json.load(open(files[-1]))
-    return d.get("bytes_per_step", {}), os.path.basename(files[-1])
+    for f in reversed(files):
+        d = json.load(open(f))
+        if d.get("ntr", 1) == ntr:                      # a profile of this very workload
+            return d.get("bytes_per_step", {}), os.path.basename(f)
+    return None, None
 
 
 def usable_cores():
@@ -167,6 +181,9 @@ def main():
     ap.add_argument("--config", default="channel")
     ap.add_argument("--advmth", default="remap", choices=["remap", "cppm"],
                     help="advection method (the reference's advmth); the headline configuration is remap")
+    ap.add_argument("--tracers", default="default", choices=["default", "iage"],
+                    help="default: the reference's default option set (TKE, its advection, ideal age: ntr = 3); "
+                         "iage: ideal age only (ntr = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs of kernel variants, e.g. momtum_v=1 (default: production kernels)")
@@ -186,7 +203,7 @@ def main():
 
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd import hostinit
-    case, nreg, masks = build_case(args.config, args.advmth)
+    case, nreg, masks = build_case(args.config, args.advmth, args.tracers)
     if world > 1:
         # Weak scaling: the channel is made `world` times as long in i (its bathymetry repeated
         # with the tile's period) and cut into `world` tiles along i, one per GPU.  Every tile
@@ -259,18 +276,19 @@ def main():
     # of tiles (the N-GPU job integrates an N-times longer channel at the same days/s)
     value = world * args.steps * baclin / 86400.0 / dt
     F = case.idm * case.jdm * case.kdm * 8.0
-    cb = class_bytes_F(case.ntr)
+    cb = class_bytes_F(case.ntr, ntr_diffused(case))
     hbm_classes = {k: v for k, v in live.items() if k in cb}
     dom = max(hbm_classes, key=hbm_classes.get)
     a3d, a2d = algorithmic_bytes(case, case.ntr)
-    traffic, traffic_src = class_traffic(args.config)
+    traffic, traffic_src = class_traffic(args.config, case.ntr)
     out = {
         "metric": "simulated-days/sec", "value": value, "unit": "simulated-days/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.config} {case.idm * world}x{case.jdm}x{case.kdm} as {world} tile(s) of "
                                f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, "
-                               f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr}, "
+                               f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr} "
+                               f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age'}), "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
                                f"full dyncore stage sequence incl. eddtra and convec (gm, frozen slopes of amplitude {NSLP0:g}); "
                                "N>1: halos over RCCL send/recv, "
@@ -296,7 +314,7 @@ def main():
         os.dup2(2, 1)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.config, case, masks, nreg)
+                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg)
             except Exception as e:                       # the bench line must still be produced
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -131,6 +131,7 @@ def default_params(baclin, batrop):
         difiso0=300.0, difint0=300.0, difdia0=1.0e-5, difwgt0=1.0,
         nday_in_year=365,    # mod_time (calendar): scales the ideal age increment, idlage/mod_idlage.F90:81
         itriag=1,            # index of the ideal age tracer (trc/mod_tracers.F90:100 with -DTRC -DIDLAGE)
+        itrtke=-1, itrgls=-1, tkeadv=1, tkeidf=0, gls=0,   # phy/mod_ifdefs.F90:16-35 without -DTKE
         taux0=0.1,           # zonal wind stress amplitude [N m-2]
         nslp0=0.0,           # amplitude of the frozen isopycnal slopes nslpx/nslpy [] (cmnfld2 is out of scope)
     )
@@ -209,10 +210,21 @@ def _depth_for(name, idm, jdm, dx):
     raise KeyError(name)
 
 
-def make_case(name, ntr=1, **overrides):
+def make_case(name, ntr=None, **overrides):
+    """`<grid>_tke`: the grid with the reference's default tracer set (meson_options.txt:17-21: turbclo = oneeq +
+    advection, iage => -DTKE -DTKEADV -DIDLAGE): ntr = 3 = TKE, the generic-length-scale slot, ideal age
+    (trc/mod_tracers.F90:85-127).  Without the suffix: the -DTRC -DIDLAGE build, ntr = 1."""
+    full_name = name
+    tke = name.endswith("_tke")
+    if tke:
+        name = name[:-4]
+    if ntr is None:
+        ntr = 3 if tke else 1
     idm, jdm, kdm, nreg, dx, baclin, batrop = _DIMS[name]
     ni, nj = idm + 2 * NBDY, jdm + 2 * NBDY
     p = default_params(baclin, batrop)
+    if tke:
+        p.update(itrtke=1, itrgls=2, itriag=3, tkeadv=1, tkeidf=0, gls=0)
     if name == "fuk95":
         p.update(expcnf="fuk95", taux0=0.0, cwbdts=0.0)
     p.update(overrides)
@@ -291,7 +303,15 @@ def make_case(name, ntr=1, **overrides):
         out[:, NBDY:NBDY + jdm, NBDY:NBDY + idm] = a
         return out
 
+    trcs = pad3(trc)[None].repeat(max(ntr, 1), axis=0)[:ntr]
+    if tke:
+        # TKE [m2 s-2] decaying from the surface, in places below tke_min = 7.6e-8 (phy/mod_tke.F90:61) so that
+        # diapfl's lower bound acts; the generic-length-scale slot is carried as a plain tracer (no -DGLS)
+        tk = 2.0e-5 * np.exp(-1.2 * (k[:, None, None] - 1)) * (1.0 + 0.8 * np.sin(2 * np.pi * (x + y)))[None]
+        trcs[0] = pad3(tk)
+        trcs[1] = pad3(1.0e-9 * (1.0 + 0.5 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y))[None] * (1.0 + 0.2 * k[:, None, None]))
+        trcs[2] = pad3(trc)
     ic = dict(dp=pad3(dp), temp=pad3(temp), saln=pad3(saln), sigma=pad3(sigma),
-              sigmar=pad3(sigmar), trc=pad3(trc)[None].repeat(max(ntr, 1), axis=0)[:ntr])
-    return Case(name=name, idm=idm, jdm=jdm, kdm=kdm, nreg=nreg, params=p, depth=depth,
+              sigmar=pad3(sigmar), trc=trcs)
+    return Case(name=full_name, idm=idm, jdm=jdm, kdm=kdm, nreg=nreg, params=p, depth=depth,
                 grid=g, ic=ic, ntr=ntr)

@@ -193,7 +193,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   Params &P = c->h.P;
   std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
-  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   if (s == "csdiag") return 0;
   if (s == "timing") { c->timing = v != 0; return 0; }
@@ -339,10 +339,28 @@ int blomgpu_xcsum(blomgpu_ctx *c, const char *name, int lev, int itype, double *
   if (lev < 1 || lev > c->nlev_real[it->second]) return ctx_fail(c, "blomgpu_xcsum: level out of range");
   return st_xcsum(c, c->h.f[it->second] + (size_t)(lev - 1) * c->h.nplane, itype, sum);
 }
+// exp() as the kernels evaluate it (exp_libm.h), elementwise on host arrays: lets a caller check that the
+// device returns the bits of its own libm (tests/test_exp_libm.py)
+__global__ void k_exp_libm(int n, const double *x, double *y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) y[t] = exp_libm(x[t]);
+}
+int blomgpu_exp(blomgpu_ctx *c, int n, const double *x, double *y) {
+  if (n <= 0) return 0;
+  double *d = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d, sizeof(double) * 2 * (size_t)n));
+  int rc = 0;
+  if (hipMemcpyAsync(d, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = 1;
+  hipLaunchKernelGGL(k_exp_libm, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, d + n);
+  if (hipMemcpyAsync(y, d + n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = 1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+  (void)hipFree(d);
+  return rc ? ctx_fail(c, "blomgpu_exp: copy or launch failed") : 0;
+}
 int blomgpu_budget_sums(blomgpu_ctx *c, int ncall, int n, int nn) { ctx_sync_view(c); return st_budget_sums(c, ncall, n, nn); }
-// which: 0 sdp, 1 tdp, 2 trdp (phy/mod_budget.F90:50-59)
+// which: 0 sdp, 1 tdp, 2 trdp, 3 tkedp (phy/mod_budget.F90:50-59)
 int blomgpu_budget_get(blomgpu_ctx *c, int which, int ncall, int n, double *v) {
-  if (which < 0 || which > 2 || ncall < 1 || ncall > 7 || n < 1 || n > 2) return ctx_fail(c, "blomgpu_budget_get: index out of range");
+  if (which < 0 || which > 3 || ncall < 1 || ncall > 7 || n < 1 || n > 2) return ctx_fail(c, "blomgpu_budget_get: index out of range");
   *v = c->budget[which][ncall - 1][n - 1];
   return 0;
 }

@@ -10,6 +10,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include "exp_libm.h"
 
 #define NBDY 4
 
@@ -85,6 +86,9 @@ struct Params {
   double baclin, batrop, delt1, dlt;
   int lstep, nstep;
   int nday_in_year, itriag;   // mod_time; index of the ideal age tracer (trc/mod_tracers.F90:100), < 1: none
+  // the reference's TKE build options (phy/mod_ifdefs.F90:16-35) as run-time switches: itrtke >= 1 <=> use_TKE;
+  // itrtke, itrgls: tracer indices (trc/mod_tracers.F90:87-91); tkeadv, tkeidf, gls <=> use_TKEADV, use_TKEIDF, use_GLS
+  int itrtke, itrgls, tkeadv, tkeidf, gls;
   // mod_eos (inieos, phy/mod_eos.F90:105-129)
   double pref;
   double ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26;
@@ -108,6 +112,10 @@ struct Params {
   int ltedtp_opt;  // 1 layer, 2 neutral                    (phy/mod_diffusion.F90)
   double vland;    // halo fill value for closed boundaries (phy/mod_xc.F90:104)
 };
+// tracers (1-based nt) left out of layer diffusion (phy/mod_diffus.F90:64-66) and of advection (phy/mod_remap.F90:314-316)
+__host__ __device__ inline bool trc_skip_dif(const Params &P, int nt) { return P.itrtke >= 1 && !P.tkeidf && (nt == P.itrtke || nt == P.itrgls); }
+__host__ __device__ inline bool trc_skip_adv(const Params &P, int nt) { return P.itrtke >= 1 && !P.tkeadv && (nt == P.itrtke || nt == P.itrgls); }
+constexpr double TKE_MIN = 7.6e-8, GLS_PSI_MIN = 1.e-14;      // phy/mod_tke.F90:61-62
 
 // ---- what a kernel sees ----------------------------------------------------------------
 struct DevView {
@@ -192,7 +200,7 @@ struct blomgpu_ctx {
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   double *xcsum_buf = nullptr;                 // [0] the sum, [1..jj] the row sums of xcsum
   int cnsvdi = 0;                              // mod_budget: conservation diagnostics on/off
-  double budget[3][7][2] = {};                 // sdp, tdp, trdp (ncall, n)
+  double budget[4][7][2] = {};                 // sdp, tdp, trdp, tkedp (ncall, n)
   std::string err;
   std::string expcnf = "channel";   // experiment configuration (mod_config): selects the forcing branches
 };

@@ -28,7 +28,7 @@ __global__ void k_bt_bounds(const DevView *Vp, int m, int nn) {
   const size_t np = V.nplane, om = c + (size_t)(m - 1) * np;
   if (V.m[I_iu][c]) {
     const double pbu = V.f[F_pbu][om];
-    V.f[F_uglue][c] = V.P.cwbdts * exp(1. - pbu / (V.P.cwbdls * ONEM));
+    V.f[F_uglue][c] = V.P.cwbdts * exp_libm(1. - pbu / (V.P.cwbdls * ONEM));
     double mx = 0., mn = 0.;
     for (int k = 0; k < V.kk; k++) {
       const double u = V.f[F_u][c + (size_t)(k + nn) * np];
@@ -40,7 +40,7 @@ __global__ void k_bt_bounds(const DevView *Vp, int m, int nn) {
   }
   if (V.m[I_iv][c]) {
     const double pbv = V.f[F_pbv][om];
-    V.f[F_vglue][c] = V.P.cwbdts * exp(1. - pbv / (V.P.cwbdls * ONEM));
+    V.f[F_vglue][c] = V.P.cwbdts * exp_libm(1. - pbv / (V.P.cwbdls * ONEM));
     double mx = 0., mn = 0.;
     for (int k = 0; k < V.kk; k++) {
       const double v = V.f[F_v][c + (size_t)(k + nn) * np];

@@ -95,7 +95,7 @@ __global__ void k_diapfl_column(const DevView *Vp, int n, int nn, int *__restric
         k = kmax - 1;
         const double us = V.f[F_ustarb][c];
         const double nubbl = gbbl * (us * us * us) *
-                             exp(-(AR(D_DELP, k + 1) + .5 * AR(D_DELP, k)) * fabs(V.f[F_coriop][c]) * ALPHA0 /
+                             exp_libm(-(AR(D_DELP, k + 1) + .5 * AR(D_DELP, k)) * fabs(V.f[F_coriop][c]) * ALPHA0 /
                                  (kappa * fmax2(ustmin, us) * GRAV)) /
                              (ALPHA0 * GRAV * (SIGR(k + 1) - SIGR(k)));
         const double nuk = fmax2(AR(D_NU, k), nubbl);
@@ -317,7 +317,11 @@ __global__ void k_diapfl_column(const DevView *Vp, int n, int nn, int *__restric
       AR(D_DENS, k) = SIGR(k);
       AR(D_SSAL, k) = eosd::sofsig(P, SIGR(k), tk);
       AR(D_DELP, k) = 0.;
-      for (int nt = 0; nt < ntr; nt++) AR(D_TTRC + nt, k) = AR(D_TTRC + nt, 2);
+      for (int nt = 0; nt < ntr; nt++) {                                           // :612-626
+        const double v = AR(D_TTRC + nt, 2);
+        AR(D_TTRC + nt, k) = (P.itrtke >= 1 && nt + 1 == P.itrtke) ? fmax2(v, TKE_MIN)
+                           : (P.itrtke >= 1 && P.gls && nt + 1 == P.itrgls) ? fmax2(v, GLS_PSI_MIN) : v;
+      }
     }
   } else {
     const double tf = AR(D_TTEM, kfpl);
@@ -346,7 +350,11 @@ __global__ void k_diapfl_column(const DevView *Vp, int n, int nn, int *__restric
     sigma[o] = AR(D_DENS, k);
     pacc = pacc + d;
     V.f[F_p][c + (size_t)k * np] = pacc;
-    for (int nt = 0; nt < ntr; nt++) V.f[F_trc][o + (size_t)(nn + nt * 2 * kk) * np] = AR(D_TTRC + nt, k);
+    for (int nt = 0; nt < ntr; nt++) {                                             // :662-677
+      const double v = AR(D_TTRC + nt, k);
+      V.f[F_trc][o + (size_t)(nn + nt * 2 * kk) * np] = (P.itrtke >= 1 && nt + 1 == P.itrtke) ? fmax2(v, TKE_MIN)
+                                                     : (P.itrtke >= 1 && P.gls && nt + 1 == P.itrgls) ? fmax2(v, GLS_PSI_MIN) : v;
+    }
   }
   V.f[F_util1][c] = (double)kmin;                                                  // :681-700, :718
   if (kmin < kmax) {

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *Vp, int
         k = kmax - 1;
         const double us = V.f[F_ustarb][c];
         const double nubbl = gbbl * (us * us * us) *
-                             exp(-(ST(dp, k + 1) + .5 * ST(dp, k)) * fabs(V.f[F_coriop][c]) * ALPHA0 /
+                             exp_libm(-(ST(dp, k + 1) + .5 * ST(dp, k)) * fabs(V.f[F_coriop][c]) * ALPHA0 /
                                  (kappa * fmax2(ustmin, us) * GRAV)) /
                              (ALPHA0 * GRAV * (SIGR(k + 1) - SIGR(k)));
         ST(nu, k) = fmax2(ST(nu, k), nubbl);
@@ -368,6 +368,15 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *Vp, int
       ST(sigma, k) = SIGR(k);
       ST(saln, k) = eosd::sofsig(P, SIGR(k), tm);
       for (int nt = 0; nt < ntr; nt++) TRC(nt, k) = TRC(nt, kmax);
+    }
+  }
+  // ---- lower bounds of the TKE / generic-length-scale tracers (:612-626 in the massless layers, :662-677 on
+  //      every layer at the copy-back; max is idempotent, so one pass over the column covers both) ----------
+  if (P.itrtke >= 1) {
+    const int a = P.itrtke - 1, b = P.itrgls - 1;
+    for (int k = 1; k <= kk; k++) {
+      if (a < ntr) TRC(a, k) = fmax2(TRC(a, k), TKE_MIN);
+      if (P.gls && b >= 0 && b < ntr) TRC(b, k) = fmax2(TRC(b, k), GLS_PSI_MIN);
     }
   }
   // ---- interface pressure and the fluxes handed to the momentum mixing, :654-700, :718 ---------

@@ -33,6 +33,7 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
     V.f[F_usflld][c + okm] = fs;
     V.f[F_utflld][c + okm] = ft;
     for (int nt = 0; nt < V.ntr; nt++) {
+      if (trc_skip_dif(V.P, nt + 1)) continue;
       const double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
       WK(V, 2 * nt)[c + ok] = q * (tr[w] - tr[c]);
     }
@@ -50,6 +51,7 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
     V.f[F_vsflld][c + okm] = fs;
     V.f[F_vtflld][c + okm] = ft;
     for (int nt = 0; nt < V.ntr; nt++) {
+      if (trc_skip_dif(V.P, nt + 1)) continue;
       const double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
       WK(V, 2 * nt + 1)[c + ok] = q * (tr[s] - tr[c]);
     }
@@ -79,6 +81,7 @@ __global__ void k_diffus_update(const DevView *Vp, int mm, int nn) {
   V.f[F_saln][c + okn] = sn;
   V.f[F_temp][c + okn] = tn;
   for (int nt = 0; nt < V.ntr; nt++) {
+    if (trc_skip_dif(V.P, nt + 1)) continue;
     double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
     const double *fu = WK(V, 2 * nt) + ok, *fv = WK(V, 2 * nt + 1) + ok;
     tr[c] = tr[c] - q * (fu[e] - fu[c] + fv[nb] - fv[c]);
@@ -96,14 +99,16 @@ int st_diffus(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     double *ptrs[10] = {h.f[F_temp] + (size_t)(k1n - 1) * np, h.f[F_saln] + (size_t)(k1n - 1) * np};
     int nl[10] = {h.kk, h.kk}, it[10] = {1, 1};
     const int ntr = h.ntr < 8 ? h.ntr : 8;
+    int nf = 2;
     for (int nt = 0; nt < ntr; nt++) {
-      ptrs[2 + nt] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
-      nl[2 + nt] = h.kk;
-      it[2 + nt] = 1;
+      if (trc_skip_dif(h.P, nt + 1)) continue;               // :76-78: no halo either
+      ptrs[nf] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
+      nl[nf] = h.kk;
+      it[nf++] = 1;
     }
-    if (int rc = st_xctilr_multi(c, 2 + ntr, ptrs, nl, 2, 2, it)) return rc;
+    if (int rc = st_xctilr_multi(c, nf, ptrs, nl, 2, 2, it)) return rc;
     for (int nt = ntr; nt < h.ntr; nt++)
-      if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 2, 2, 1)) return rc;
+      if (int rc = trc_skip_dif(h.P, nt + 1) ? 0 : st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 2, 2, 1)) return rc;
   }
   // The reference's per-layer flux work arrays uflxtr/vflxtr keep stale values where no
   // u/v point exists; ours are per-layer planes of wk0.. that must start from the same

@@ -224,8 +224,8 @@ int st_updtrc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   return 0;
 }
 
-// ---- budget_sums, phy/mod_budget.F90:95-196 (use_TRC, no TKE): mass weighted column sums of S and T into util1,
-//      util2 (which = 0) or of tracer 1 into util1 (which = 1); their global sums through xcsum.  The salt
+// ---- budget_sums, phy/mod_budget.F90:95-196 (use_TRC; no GLS): mass weighted column sums of S and T (and the TKE
+//      tracer, util3) into util1, util2 (which = 0) or of tracer 1 into util1 (which = 1); their global sums through xcsum.  The salt
 //      correction term of call 5 (:182-194) needs mod_forcing's salt_corr, which no stage here produces. ----
 __global__ void k_budget_columns(const DevView *Vp, int nn, int which) {
   const DevView &V = *Vp;
@@ -233,19 +233,22 @@ __global__ void k_budget_columns(const DevView *Vp, int nn, int which) {
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const double scp2 = V.f[F_scp2][c];
-  double s1 = 0., s2 = 0.;
+  double s1 = 0., s2 = 0., s3 = 0.;
+  const bool tke = which == 0 && V.P.itrtke >= 1;
   for (int k = 0; k < V.kk; k++) {
     const size_t o = c + (size_t)(k + nn) * np;
     const double q = V.f[F_dp][o] * scp2;
     if (which == 0) {
       s1 = s1 + V.f[F_saln][o] * q;
       s2 = s2 + V.f[F_temp][o] * q;
+      if (tke) s3 = s3 + V.f[F_trc][o + (size_t)(V.P.itrtke - 1) * 2 * V.kk * np] * q;
     } else {
       s1 = s1 + V.f[F_trc][o] * q;
     }
   }
   V.f[F_util1][c] = s1;
   if (which == 0) V.f[F_util2][c] = s2;
+  if (tke) V.f[F_util3][c] = s3;
 }
 
 int st_budget_sums(blomgpu_ctx *c, int ncall, int n, int nn) {
@@ -255,6 +258,8 @@ int st_budget_sums(blomgpu_ctx *c, int ncall, int n, int nn) {
   hipLaunchKernelGGL(k_budget_columns, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn, 0);
   if (int rc = st_xcsum(c, h.f[F_util1], 1, &c->budget[0][ncall - 1][n - 1])) return rc;
   if (int rc = st_xcsum(c, h.f[F_util2], 1, &c->budget[1][ncall - 1][n - 1])) return rc;
+  if (h.P.itrtke >= 1)
+    if (int rc = st_xcsum(c, h.f[F_util3], 1, &c->budget[3][ncall - 1][n - 1])) return rc;
   if (h.ntr >= 1) {
     hipLaunchKernelGGL(k_budget_columns, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn, 1);
     if (int rc = st_xcsum(c, h.f[F_util1], 1, &c->budget[2][ncall - 1][n - 1])) return rc;

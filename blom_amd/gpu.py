@@ -132,13 +132,20 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_xcsum(self.ctx, name.encode(), lev, itype, C.byref(v)))
         return v.value
 
+    def exp(self, x):
+        """exp() as the kernels evaluate it (blom_amd/csrc/exp_libm.h), elementwise."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        y = np.empty_like(x)
+        self._chk(self.lib.blomgpu_exp(self.ctx, x.size, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
+        return y
+
     def budget_sums(self, ncall, n, nn):
         """budget_sums (phy/mod_budget.F90:95); does nothing unless the option cnsvdi is set."""
         self._chk(self.lib.blomgpu_budget_sums(self.ctx, ncall, n, nn))
 
     def budget_get(self, which, ncall, n):
         v = C.c_double(0.0)
-        self._chk(self.lib.blomgpu_budget_get(self.ctx, {"sdp": 0, "tdp": 1, "trdp": 2}[which], ncall, n, C.byref(v)))
+        self._chk(self.lib.blomgpu_budget_get(self.ctx, {"sdp": 0, "tdp": 1, "trdp": 2, "tkedp": 3}[which], ncall, n, C.byref(v)))
         return v.value
 
     # -- tile decomposition ---------------------------------------------------------------

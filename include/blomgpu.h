@@ -84,10 +84,13 @@ int  blomgpu_convec (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 /* xcsum (phy/mod_xc.F90:4116): reproducible masked sum of one level of a device field (strips of 9 points per
  * row, rows added serially); itype selects the mask as for xctilr (p-grid: the mask of the global sums, ips).
  * budget_sums (phy/mod_budget.F90:95; active with the option cnsvdi = 1): mass weighted global sums of S, T and
- * tracer 1 after call `ncall` of the step; blomgpu_budget_get(which = 0 sdp | 1 tdp | 2 trdp). */
+ * tracer 1 after call `ncall` of the step; blomgpu_budget_get(which = 0 sdp | 1 tdp | 2 trdp | 3 tkedp). */
 int  blomgpu_xcsum(blomgpu_ctx *, const char *name, int lev, int itype, double *sum);
 int  blomgpu_budget_sums(blomgpu_ctx *, int ncall, int n, int nn);
 int  blomgpu_budget_get(blomgpu_ctx *, int which, int ncall, int n, double *value);
+/* exp() as the kernels evaluate it -- the algorithm and bits of the glibc libm that the reference's compiled Fortran
+ * calls (blom_amd/csrc/exp_libm.h; phy/mod_barotp.F90:183,205, phy/mod_diapfl.F90:204) -- elementwise on host arrays. */
+int  blomgpu_exp(blomgpu_ctx *, int n, const double *x, double *y);
 int  blomgpu_updtrc (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* trc/mod_tracers_update.F90:152: its idlage_step, idlage/mod_idlage.F90:57 */
 int  blomgpu_sfcstr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* phy/mod_sfcstr.F90:33 (empty for channel/fuk95/noforcing) */
 int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                             /* phy/mod_diapfl.F90:49   */

@@ -271,7 +271,11 @@ void orc_diapfl(OState *S, int n, int nn, int k1n) {
           dens[k] = sigr[k];
           ssal[k] = eos_sofsig(S, dens[k], ttem[k]);
           delp[k] = 0.;
-          for (int nt = 0; nt < ntr; nt++) ttrc[nt][k] = ttrc[nt][2];
+          for (int nt = 0; nt < ntr; nt++) {                               /* :612-626 */
+            if (S->itrtke >= 1 && nt + 1 == S->itrtke) ttrc[nt][k] = fmax2(ttrc[nt][2], ORC_TKE_MIN);
+            else if (S->itrtke >= 1 && S->gls && nt + 1 == S->itrgls) ttrc[nt][k] = fmax2(ttrc[nt][2], ORC_GLS_PSI_MIN);
+            else ttrc[nt][k] = ttrc[nt][2];
+          }
         }
       } else {
         for (int k = 3; k <= kfpl - 1; k++) {
@@ -295,7 +299,11 @@ void orc_diapfl(OState *S, int n, int nn, int k1n) {
         A3(S, dp, i, j, kn) = delp[k];
         A3(S, sigma, i, j, kn) = dens[k];
         A3(S, p, i, j, k + 1) = A3(S, p, i, j, k) + A3(S, dp, i, j, kn);
-        for (int nt = 1; nt <= ntr; nt++) TRC(S, i, j, kn, nt) = ttrc[nt - 1][k];
+        for (int nt = 1; nt <= ntr; nt++) {                                /* :662-677 */
+          if (S->itrtke >= 1 && nt == S->itrtke) TRC(S, i, j, kn, nt) = fmax2(ttrc[nt - 1][k], ORC_TKE_MIN);
+          else if (S->itrtke >= 1 && S->gls && nt == S->itrgls) TRC(S, i, j, kn, nt) = fmax2(ttrc[nt - 1][k], ORC_GLS_PSI_MIN);
+          else TRC(S, i, j, kn, nt) = ttrc[nt - 1][k];
+        }
       }
       A2(S, kming, i, j) = kmin; /* :681-700 */
       if (kmin < kmax) {

@@ -1,5 +1,5 @@
 /* TEST INFRASTRUCTURE (oracle): restatement of diffus, phy/mod_diffus.F90:41-185
- * (ltedtp_opt == ltedtp_layer; no TKE tracers). */
+ * (ltedtp_opt == ltedtp_layer). */
 #include "ostate.h"
 #include <stdlib.h>
 
@@ -12,7 +12,7 @@ void orc_diffus(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
   orc_xctilr(S, S->temp + lev * (k1n - 1), 1, kk, 2, 2, 1);           /* :72-73 */
   orc_xctilr(S, S->saln + lev * (k1n - 1), 1, kk, 2, 2, 1);
   for (int nt = 1; nt <= ntr; nt++)                                   /* :74-80 */
-    orc_xctilr(S, S->trc + lev * ((size_t)(k1n - 1) + 2 * kk * (nt - 1)), 1, kk, 2, 2, 1);
+    if (!orc_skip_dif(S, nt)) orc_xctilr(S, S->trc + lev * ((size_t)(k1n - 1) + 2 * kk * (nt - 1)), 1, kk, 2, 2, 1);
   double *uflxtr = (double *)calloc((size_t)(ntr > 0 ? ntr : 1) * S->nplane, sizeof(double));
   double *vflxtr = (double *)calloc((size_t)(ntr > 0 ? ntr : 1) * S->nplane, sizeof(double));
 #define UTR(nt, i, j) uflxtr[IX(S, i, j) + lev * ((nt)-1)]
@@ -26,7 +26,7 @@ void orc_diffus(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
                    A2(S, scuxi, i, j) * fmax2(fmin2(A3(S, dp, i - 1, j, kn), A3(S, dp, i, j, kn)), dpeps);
         A3(S, usflld, i, j, km) = q * (A3(S, saln, i - 1, j, kn) - A3(S, saln, i, j, kn));
         A3(S, utflld, i, j, km) = q * (A3(S, temp, i - 1, j, kn) - A3(S, temp, i, j, kn));
-        for (int nt = 1; nt <= ntr; nt++) UTR(nt, i, j) = q * (TRC(S, i - 1, j, kn, nt) - TRC(S, i, j, kn, nt));
+        for (int nt = 1; nt <= ntr; nt++) if (!orc_skip_dif(S, nt)) UTR(nt, i, j) = q * (TRC(S, i - 1, j, kn, nt) - TRC(S, i, j, kn, nt));
         A3(S, usflx, i, j, km) = A3(S, usflx, i, j, km) + A3(S, usflld, i, j, km);
         A3(S, utflx, i, j, km) = A3(S, utflx, i, j, km) + A3(S, utflld, i, j, km);
       }
@@ -37,7 +37,7 @@ void orc_diffus(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
                    A2(S, scvyi, i, j) * fmax2(fmin2(A3(S, dp, i, j - 1, kn), A3(S, dp, i, j, kn)), dpeps);
         A3(S, vsflld, i, j, km) = q * (A3(S, saln, i, j - 1, kn) - A3(S, saln, i, j, kn));
         A3(S, vtflld, i, j, km) = q * (A3(S, temp, i, j - 1, kn) - A3(S, temp, i, j, kn));
-        for (int nt = 1; nt <= ntr; nt++) VTR(nt, i, j) = q * (TRC(S, i, j - 1, kn, nt) - TRC(S, i, j, kn, nt));
+        for (int nt = 1; nt <= ntr; nt++) if (!orc_skip_dif(S, nt)) VTR(nt, i, j) = q * (TRC(S, i, j - 1, kn, nt) - TRC(S, i, j, kn, nt));
         A3(S, vsflx, i, j, km) = A3(S, vsflx, i, j, km) + A3(S, vsflld, i, j, km);
         A3(S, vtflx, i, j, km) = A3(S, vtflx, i, j, km) + A3(S, vtflld, i, j, km);
       }
@@ -52,7 +52,7 @@ void orc_diffus(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
                                 q * (A3(S, utflld, i + 1, j, km) - A3(S, utflld, i, j, km) +
                                      A3(S, vtflld, i, j + 1, km) - A3(S, vtflld, i, j, km));
         for (int nt = 1; nt <= ntr; nt++)
-          TRC(S, i, j, kn, nt) = TRC(S, i, j, kn, nt) -
+          if (!orc_skip_dif(S, nt)) TRC(S, i, j, kn, nt) = TRC(S, i, j, kn, nt) -
                                  q * (UTR(nt, i + 1, j) - UTR(nt, i, j) + VTR(nt, i, j + 1) - VTR(nt, i, j));
         A3(S, sigma, i, j, kn) = eos_sig(S, A3(S, temp, i, j, kn), A3(S, saln, i, j, kn));
       }

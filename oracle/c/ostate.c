@@ -57,7 +57,7 @@ int orc_set_real(OState *S, const char *name, double v) {
 
 int orc_set_int(OState *S, const char *name, int v) {
 #define R(nm) if (!strcmp(name, #nm)) { S->nm = v; return 0; }
-  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(cnsvdi) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(cnsvdi) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   return 1;
 }

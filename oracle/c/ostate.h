@@ -57,7 +57,10 @@ typedef struct {
   /* mod_time */
   double baclin, batrop, delt1, dlt;
   int lstep, nstep, nday_in_year, itriag, cnsvdi;
-  double budget[3][7][2];    /* sdp, tdp, trdp of mod_budget (ncall, n) */
+  /* the reference's TKE build options (phy/mod_ifdefs.F90:16-35) as run-time switches: itrtke >= 1 <=> use_TKE;
+   * itrtke, itrgls = tracer indices (trc/mod_tracers.F90:87-91); tkeadv, tkeidf, gls <=> use_TKEADV, use_TKEIDF, use_GLS */
+  int itrtke, itrgls, tkeadv, tkeidf, gls;
+  double budget[4][7][2];    /* sdp, tdp, trdp, tkedp of mod_budget (ncall, n) */
   /* mod_eos */
   double pref, ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26;
   /* mod_momtum */
@@ -130,6 +133,11 @@ void orc_convec(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 void orc_updtrc(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
 double orc_xcsum(const OState *S, const double *a, const int *mask, int use_ips);
 void orc_budget_sums(OState *S, int ncall, int n, int nn);
+/* tracers left out of advection (phy/mod_remap.F90:314-316 ..) and of layer diffusion (phy/mod_diffus.F90:64-66) */
+static inline int orc_skip_adv(const OState *S, int nt) { return S->itrtke >= 1 && !S->tkeadv && (nt == S->itrtke || nt == S->itrgls); }
+static inline int orc_skip_dif(const OState *S, int nt) { return S->itrtke >= 1 && !S->tkeidf && (nt == S->itrtke || nt == S->itrgls); }
+#define ORC_TKE_MIN 7.6e-8      /* phy/mod_tke.F90:61 */
+#define ORC_GLS_PSI_MIN 1.e-14  /* phy/mod_tke.F90:62 */
 double orc_budget_get(const OState *S, int which, int ncall, int n);
 double orc_xcsum_field(OState *S, const char *name, int lev, int itype);
 void orc_diapfl(OState *S, int n, int nn, int k1n);

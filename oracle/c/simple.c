@@ -229,16 +229,16 @@ double orc_xcsum(const OState *S, const double *a, const int *mask, int use_ips)
   return total;
 }
 
-/* budget_sums, phy/mod_budget.F90:95-196 (use_TRC, no TKE): mass weighted column sums of salinity and
- * temperature into util1, util2 and their global sums; then the same for tracer 1 through util1.  The salt
+/* budget_sums, phy/mod_budget.F90:95-196 (use_TRC; no GLS): mass weighted column sums of salinity and
+ * temperature into util1, util2 (and of the TKE tracer into util3) and their global sums; then the same for tracer 1 through util1.  The salt
  * correction term of call 5 (:182-194) needs mod_forcing's salt_corr, which no stage of this path produces:
- * it is taken as zero.  Results: S->budget[0..2][ncall-1][n-1] = sdp, tdp, trdp. */
+ * it is taken as zero.  Results: S->budget[0..3][ncall-1][n-1] = sdp, tdp, trdp, tkedp. */
 void orc_budget_sums(OState *S, int ncall, int n, int nn) {
   if (!S->cnsvdi) return;
   const int ii = S->ii, jj = S->jj, kk = S->kk;
   for (int j = 1; j <= jj; j++)
     for (int i = 1; i <= ii; i++)
-      if (A2(S, ip, i, j)) { A2(S, util1, i, j) = 0.; A2(S, util2, i, j) = 0.; }
+      if (A2(S, ip, i, j)) { A2(S, util1, i, j) = 0.; A2(S, util2, i, j) = 0.; if (S->itrtke >= 1) A2(S, util3, i, j) = 0.; }
   for (int j = 1; j <= jj; j++)
     for (int k = 1; k <= kk; k++)
       for (int i = 1; i <= ii; i++)
@@ -246,9 +246,11 @@ void orc_budget_sums(OState *S, int ncall, int n, int nn) {
           const double q = A3(S, dp, i, j, k + nn) * A2(S, scp2, i, j);
           A2(S, util1, i, j) = A2(S, util1, i, j) + A3(S, saln, i, j, k + nn) * q;
           A2(S, util2, i, j) = A2(S, util2, i, j) + A3(S, temp, i, j, k + nn) * q;
+          if (S->itrtke >= 1) A2(S, util3, i, j) = A2(S, util3, i, j) + TRC(S, i, j, k + nn, S->itrtke) * q;
         }
   S->budget[0][ncall - 1][n - 1] = orc_xcsum(S, S->util1, S->ip, 1);
   S->budget[1][ncall - 1][n - 1] = orc_xcsum(S, S->util2, S->ip, 1);
+  if (S->itrtke >= 1) S->budget[3][ncall - 1][n - 1] = orc_xcsum(S, S->util3, S->ip, 1);
   if (S->ntr >= 1) {
     for (int j = 1; j <= jj; j++)
       for (int i = 1; i <= ii; i++)

@@ -81,7 +81,7 @@ class COracle:
 
     def budget_get(self, which, ncall, n):
         self.lib.orc_budget_get.restype = C.c_double
-        return self.lib.orc_budget_get(self.S, {"sdp": 0, "tdp": 1, "trdp": 2}[which], ncall, n)
+        return self.lib.orc_budget_get(self.S, {"sdp": 0, "tdp": 1, "trdp": 2, "tkedp": 3}[which], ncall, n)
 
     def stage(self, name, m, n, mm, nn, k1m, k1n):
         rc = self.lib.orc_stage(self.S, name.encode(), m, n, mm, nn, k1m, k1n)

@@ -64,7 +64,7 @@ def _drive(cfg, nsteps, make_other):
         assert ch["dp"] > 0 and ch["temp"] > 0 and ch["kfpla"] > 0 and ch["u"] > 0, ch
 
 
-@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "fuk95", "tri_s"])
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke"])
 def test_c_restatement_matches_reference_on_unstable_columns(cfg):
     from oracle.coracle import COracle, have_coracle
     if not have_coracle():
@@ -80,7 +80,7 @@ def test_c_restatement_matches_reference_on_unstable_columns(cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "fuk95", "tri_s"])
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke"])
 def test_device_matches_reference_on_unstable_columns(cfg):
     from blom_amd.gpu import BlomGpu
 

@@ -2,10 +2,9 @@
 tests/golden/<cfg>_init.npz is the input state, <cfg>_crc.json the reference's own checksum of every field
 after every stage, <cfg>_final.npz the reference's fields after three steps.
 
-  * step 1, every stage up to (not including) the first one that calls exp() (diapfl): the device's fields
-    must have the reference's CRCs -- bit-exact;
-  * the free run to the end of step 3: equal to the reference's final fields within 1e-9 relative (the one
-    ulp of exp in diapfl/barotp is the only source of difference)."""
+  * after every stage of every recorded step the device's fields must have the reference's CRCs;
+  * at the end the device's fields must equal the reference's final fields.
+Both bit for bit (exp() included: blom_amd/csrc/exp_libm.h)."""
 import json
 import os
 
@@ -34,13 +33,11 @@ def test_device_reproduces_golden_fixtures(cfg):
             gpu.set(nm, v)
     put_fields(gpu, fields)
     gpu.set("delt1", case.params["baclin"])
-    bad, state = [], {"exact": True, "checked": 0}
+    bad, state = [], {"step": 1, "checked": 0}
 
     def check(st):
-        if st == "diapfl":
-            state["exact"] = False               # exp() from here on: last-bit differences are legitimate
-        exp = gold["crc"]["1"].get(st)
-        if exp is None or not state["exact"]:
+        exp = gold["crc"].get(str(state["step"]), {}).get(st)
+        if exp is None:
             return
         for nm, want in exp.items():
             if nm in EDDTRA_OUT or not gpu.has_field(nm):
@@ -48,7 +45,7 @@ def test_device_reproduces_golden_fixtures(cfg):
             got = chksum(nm, gpu.get(nm), masks, case.idm, case.jdm)
             state["checked"] += 1
             if got != want:
-                bad.append(f"step 1 {st} {nm}: crc 0x{got:08x} != 0x{want:08x}")
+                bad.append(f"step {state['step']} {st} {nm}: crc 0x{got:08x} != 0x{want:08x}")
 
     pending = []
 
@@ -67,6 +64,5 @@ def test_device_reproduces_golden_fixtures(cfg):
     for nm in z.files:
         a = z[nm][:, J, I]
         b = gpu.get(nm)[:a.shape[0], J, I]
-        scale = np.abs(a).max() or 1.0
-        assert np.abs(a - b).max() <= 1e-9 * scale, (nm, float(np.abs(a - b).max()), scale)
+        assert np.array_equal(a, b, equal_nan=True), (nm, float(np.abs(a - b).max()))
     gpu.close()

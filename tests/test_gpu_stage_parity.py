@@ -17,8 +17,9 @@ from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, INT_FIELDS
 
 pytestmark = pytest.mark.gpu
 
-# stage -> (rtol, atol); default exact
-TOL = {"barotp": (1e-12, 1e-9), "diapfl": (1e-11, 1e-12)}
+# stage -> (rtol, atol); default exact.  Empty: every stage is compared bit for bit, exp() included
+# (blom_amd/csrc/exp_libm.h evaluates it the way the libm under the reference does; tests/test_exp_libm.py)
+TOL = {}
 GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", "pbcor1", "diffus", "pgforc",
               "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc", "barotp", "pbcor2", "tmsmt2"]
 # 2-D scratch arrays of mod_utility that the reference leaves holding the last layer's
@@ -70,7 +71,7 @@ def _run(cfg, nsteps, stages, **overrides):
     assert not failures, "\n".join(failures[:40])
 
 
-@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s"])
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s", "chan_s_tke", "box_s_tke"])
 def test_stage_parity_small(cfg):
     _run(cfg, 4, GPU_STAGES)
 
@@ -96,19 +97,18 @@ def test_stage_parity_option_variants(cfg, opts):
 
 # ---------------------------------------------------------------------------------------------
 # Free-running: the device-resident stepping loop (blomgpu_step) against the reference stepped
-# stage by stage, from the same initial state.  exp() enters through barotp's coastal damping
-# coefficient and diapfl's bottom boundary layer term (phy/mod_barotp.F90:183,205,
-# phy/mod_diapfl.F90:204): device exp and glibc exp may differ in the last bit, so after nsteps
-# the comparison uses rtol 1e-9 on fields and reports the exact-equality count for information.
+# stage by stage, from the same initial state.  Bit for bit: exp() -- barotp's coastal damping
+# coefficient, diapfl's bottom boundary layer term (phy/mod_barotp.F90:183,205,
+# phy/mod_diapfl.F90:204) -- is evaluated on the device with the algorithm and the fused operations
+# of the libm the reference calls (blom_amd/csrc/exp_libm.h), so no tolerance is needed; with the
+# device math library's exp (1 ulp) runs used to decorrelate through limiter decisions.
 # ---------------------------------------------------------------------------------------------
 FREERUN_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "ubflxs_p", "pb_p", "trc",
                   "uflx", "vflx", "pgfx", "pgfy", "dpu", "dpv"]
 
 
-# Step counts are kept short because a one-ulp exp() difference, once it exists, is amplified by the
-# scheme's limiter/branch decisions (measured: per-stage parity stays exact over 40 re-synchronised
-# steps on every grid, tools/gpu_stage_long.py, while free runs decorrelate at ~4x per step).
-@pytest.mark.parametrize("cfg,nsteps,rtol", [("chan_s", 12, 1e-9), ("box_s", 4, 1e-7), ("fuk95", 6, 0.0)])
+@pytest.mark.parametrize("cfg,nsteps,rtol", [("chan_s", 40, 0.0), ("box_s", 40, 0.0), ("fuk95", 12, 0.0),
+                                             ("chan_s_tke", 40, 0.0), ("tri_s", 24, 0.0), ("tri_s_tke", 24, 0.0)])
 def test_freerun_device_resident(cfg, nsteps, rtol):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
@@ -133,6 +133,51 @@ def test_freerun_device_resident(cfg, nsteps, rtol):
     bad = diff_report(ref, gpu, fields=FREERUN_FIELDS, rtol=rtol, atol=rtol)
     gpu.close()
     assert not bad, fmt_report(bad)
+
+
+def test_full_size_matches_reference():
+    """BASELINE.json's channel (208x512x53) with the reference's default tracer set (ntr = 3), the bench workload:
+    the device-resident sequence against the reference's own Fortran (built with its OpenMP directives,
+    oracle/_ref/channel_tke_omp) over the forward step and three leap-frog steps.  Bit for bit."""
+    import os
+    import threading
+    from oracle.refblom import get_ref_backend, have_ref
+    from blom_amd.gpu import BlomGpu
+    cfg = "channel_tke"
+    if not have_ref(cfg + "_omp"):
+        pytest.skip("oracle/_ref/channel_tke_omp/libblomref.so not built")
+    nsteps, res = 4, {}
+
+    def body():
+        case = make_case(cfg)
+        ref = get_ref_backend(cfg + "_omp", case.depth)
+        hostinit.init_state(ref, case)
+        gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
+        for nm, v in case.params.items():
+            if not nm.endswith("0"):
+                gpu.set(nm, v)
+        copy_state(ref, gpu)
+        gpu.set("delt1", case.params["baclin"])
+        ns = 0
+        for _ in range(nsteps):
+            ns = dyncore_step(ref, ns, case.params["baclin"])
+        assert gpu.step(0, nsteps) == nsteps
+        gpu.sync()
+        res["bad"] = diff_report(ref, gpu, fields=FREERUN_FIELDS)
+        res["ntr"] = ref.ntr
+        gpu.close()
+
+    # the reference keeps its stage-local 2-D work arrays on the stack (BLOM runs with ulimit -s unlimited)
+    os.environ["OMP_NUM_THREADS"] = str(min(16, os.cpu_count() or 1))
+    os.environ["OMP_STACKSIZE"] = "1G"
+    threading.stack_size(2 << 30)
+    th = threading.Thread(target=lambda: res.update(err=None) or body())
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    assert "bad" in res, "the comparison did not complete"
+    assert res["ntr"] == 3
+    assert not res["bad"], fmt_report(res["bad"])
 
 
 @pytest.mark.parametrize("itype", [1, 2, 3, 4, 11, 12, 13, 14])

@@ -43,7 +43,8 @@ def _single(cfg, nsteps):
 
 
 @pytest.mark.parametrize("cfg,npx,npy", [("chan_s", 2, 1), ("chan_s", 1, 2), ("chan_s", 2, 2), ("box_s", 2, 2),
-                                         ("box_s", 3, 1), ("tri_s", 2, 1), ("tri_s", 2, 2), ("tri_s", 4, 2)])
+                                         ("box_s", 3, 1), ("tri_s", 2, 1), ("tri_s", 2, 2), ("tri_s", 4, 2),
+                                         ("chan_s_tke", 2, 2), ("tri_s_tke", 2, 2)])
 def test_tiles_match_single_tile(cfg, npx, npy):
     from blom_amd.gpu import BlomGpu, TileGroup
     nsteps = 4

@@ -15,7 +15,7 @@ from blom_amd import hostinit
 from blom_amd.stepper import dyncore_step
 from parity import copy_state
 
-CFGS = ["chan_s", "box_s", "fuk95", "tri_s"]
+CFGS = ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "tri_s_tke"]
 
 
 def _setup(cfg, make_other, nsteps=2):
@@ -75,6 +75,9 @@ def _check_budget(case, ref, other, nstep):
     assert other.budget_get("tdp", 2, n) == ref.xcsum(pl("util2")[0], 1)
     if ref.ntr >= 1:
         assert other.budget_get("trdp", 2, n) == ref.xcsum(pl("util1")[0], 1)
+    if case.params.get("itrtke", -1) >= 1:
+        assert np.array_equal(np.asarray(ref.get("util3")), np.asarray(other.get("util3")))
+        assert other.budget_get("tkedp", 2, n) == ref.xcsum(pl("util3")[0], 1) != 0.0
     # sdp: the salt columns were overwritten by the tracer's; rebuild them with the statement order of :130-132
     s = np.zeros_like(pl("util1")[0])
     for k in range(kk):

@@ -1,11 +1,12 @@
 """Turn rocprofv3 outputs under gpurun_out/ into the per-round summaries committed under profiles/.
-usage: prof_summarize.py <tag> <kernel_stats.csv> <nsteps_total> [<fetch_counter.csv> <write_counter.csv>]"""
-import csv, sys, collections
+usage: [NTR=3] prof_summarize.py <tag> <kernel_stats.csv> <nsteps_total> [<fetch_counter.csv> <write_counter.csv>]"""
+import csv, os, sys, collections
+ntr = int(os.environ.get("NTR", "3"))
 tag, stats, nst = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"profiles/{tag}_kernel_stats.txt", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (channel 208x512x53, 1 GPU)\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (channel 208x512x53, ntr = {ntr}, 1 GPU)\n")
     f.write(f"# {nst} baroclinic steps in the trace; kernel time per step {tot / 1e6 / nst:.3f} ms\n")
     f.write(f"# {'kernel':42s} {'calls/step':>10s} {'avg_us':>10s} {'ms/step':>9s} {'%':>6s}\n")
     for r in rows:
@@ -25,7 +26,7 @@ if len(sys.argv) > 5:
         return acc
     fe, wr = per_kernel(sys.argv[4], "FETCH_SIZE"), per_kernel(sys.argv[5], "WRITE_SIZE")
     with open(f"profiles/{tag}_pmc_hbm_traffic.txt", "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 2 (channel 208x512x53)\n")
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 2 (channel 208x512x53, ntr = {ntr})\n")
         f.write("# per-launch averages in MB (counters are in KB).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports\n")
         f.write("# half the bytes of a wide coalesced stream: fetch_x2 is the corrected estimate for 16 B/lane streams; the 8 B/lane loads of\n")
         f.write("# these fp64 kernels calibrated at ~1.5x on this code (DESIGN.md 4), so the truth lies between the two columns.\n")
@@ -54,5 +55,6 @@ if len(sys.argv) > 5:
     with open(f"profiles/{tag}_class_traffic.json", "w") as f:
         json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                    "correction": "1.5 x FETCH_SIZE + WRITE_SIZE, bytes per baroclinic step and class",
+                   "ntr": ntr,
                    "bytes_per_step": {k: round(v) for k, v in sorted(cls.items())}}, f, indent=1)
 print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3500])
