@@ -114,11 +114,11 @@ __global__ void k_mom_drag(const DevView *Vp, int n, int nn) {
 }
 
 // ---- :360-431 total velocities, fluxes, dpmx ---------------------------------------------------------
-__global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn) {
+__global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
-  const int k = by_, ni = V.ni, ii = V.ii, jj = V.jj;
+  const int k = by_ + klo, ni = V.ni, ii = V.ii, jj = V.jj;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
   const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const double tsfac = V.P.dlt / V.P.delt1, cutoff = ONEM;
@@ -168,10 +168,10 @@ __global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn) {
 }
 
 // ---- :438-472 side-wall weights, auxiliary velocities, del2 fields -------------------------------------
-__global__ void k_mom_wall(const DevView *Vp, int m) {
+__global__ void k_mom_wall(const DevView *Vp, int m, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
-  const int k = by_, ni = V.ni;
+  const int k = by_ + klo, ni = V.ni;
   const size_t np = V.nplane, ok = (size_t)k * np, om = (size_t)(m - 1) * np;
   if (V.m[I_iu][c] && j >= -1 && j <= V.jj + 2 && i >= 0 && i <= V.ii + 2) {
     const double *utotn = WK(V, M_UTOTN) + ok;
@@ -210,11 +210,11 @@ __global__ void k_mom_wall(const DevView *Vp, int m) {
 }
 
 // ---- :477-585 vorticity, potential vorticity, deformation; :613-629 kinetic energy ---------------------
-__global__ void k_mom_vort(const DevView *Vp, int mm) {
+__global__ void k_mom_vort(const DevView *Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
-  const int k = by_, ni = V.ni, ii = V.ii, jj = V.jj;
+  const int k = by_ + klo, ni = V.ni, ii = V.ii, jj = V.jj;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const int *ip = V.m[I_ip], *iu = V.m[I_iu], *iv = V.m[I_iv], *iq = V.m[I_iq];
   const double *utotm = WK(V, M_UTOTM) + ok, *vtotm = WK(V, M_VTOTM) + ok;
@@ -306,11 +306,11 @@ __device__ inline void enedis_minmax(double hc, double hm, double &hmin, double 
   else { hmax = hm; hmin = hc; }
 }
 
-__global__ void k_mom_enedis(const DevView *Vp, int mm) {
+__global__ void k_mom_enedis(const DevView *Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
-  const int k = by_;
+  const int k = by_ + klo;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const double *dp = V.f[F_dp] + okm;
   // the reference's local arrays are zeroed once per call (:238-241) and written at wet points only
@@ -323,11 +323,11 @@ __global__ void k_mom_enedis(const DevView *Vp, int mm) {
 }
 
 // ---- :829-841 and :988-1000 deformation dependent viscosities ---------------------------------------
-__global__ void k_mom_visc(const DevView *Vp) {
+__global__ void k_mom_visc(const DevView *Vp, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
-  const int k = by_, ni = V.ni;
+  const int k = by_ + klo, ni = V.ni;
   const size_t ok = (size_t)k * V.nplane;
   const double *d1 = WK(V, M_DEFOR1) + ok, *d2 = WK(V, M_DEFOR2) + ok, *difwgt = V.f[F_difwgt];
   const Params &P = V.P;
@@ -355,11 +355,11 @@ __device__ inline double ext_j(const int *msk, const double *f, size_t x, int ni
 }
 
 // ---- :860-873 and :1019-1034 longitudinal turbulent momentum fluxes at p-points ------------------------
-__global__ void k_mom_flux1(const DevView *Vp, int mm) {
+__global__ void k_mom_flux1(const DevView *Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][c]) return;
-  const int k = by_, ni = V.ni;
+  const int k = by_ + klo, ni = V.ni;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np;
   const int *iu = V.m[I_iu], *iv = V.m[I_iv];
   const double difmxp = V.f[F_difmxp][c];
@@ -382,11 +382,11 @@ __global__ void k_mom_flux1(const DevView *Vp, int mm) {
 }
 
 // ---- update of u and v at interior points: :723-813, :879-980, :1040-1143 --------------------------------
-__global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn) {
+__global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const int k = by_, ni = V.ni;
+  const int k = by_ + klo, ni = V.ni;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
   const size_t om = (size_t)(m - 1) * np;
   const int *iu = V.m[I_iu], *iv = V.m[I_iv];
@@ -554,19 +554,25 @@ int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (h.P.vcoord_tag != 1) return ctx_fail(c, "momtum: hybrid-coordinate wind stress (mu_nonloc) is not built yet");
   if (h.nwk < M_NSLOT) return ctx_fail(c, "momtum: device work space too small");
-  const dim3 g3 = plane_grid(h, h.kk), gcol = plane_grid(h, 1, 64), b(256), b64(64);
+  const dim3 gcol = plane_grid(h, 1, 64), b(256), b64(64);
   TimeScope ts(c, "momtum");
   hipLaunchKernelGGL(k_mom_pscan, gcol, b64, 0, c->stream, c->d, mm, -1, 2);
   hipLaunchKernelGGL(k_mom_drag, gcol, b64, 0, c->stream, c->d, n, nn);
   hipLaunchKernelGGL(k_mom_pupv, gcol, b64, 0, c->stream, c->d, mm, -1, 2);
   if (int rc = st_xctilr(c, h.f[F_difwgt], 1, 1, 2, 2, 1)) return rc;                       // :340
-  hipLaunchKernelGGL(k_mom_tot, g3, b, 0, c->stream, c->d, m, n, mm, nn);
-  hipLaunchKernelGGL(k_mom_wall, g3, b, 0, c->stream, c->d, m);
-  hipLaunchKernelGGL(k_mom_vort, g3, b, 0, c->stream, c->d, mm);
-  if (h.P.mommth == 2) hipLaunchKernelGGL(k_mom_enedis, g3, b, 0, c->stream, c->d, mm);
-  hipLaunchKernelGGL(k_mom_visc, g3, b, 0, c->stream, c->d);
-  hipLaunchKernelGGL(k_mom_flux1, g3, b, 0, c->stream, c->d, mm);
-  hipLaunchKernelGGL(k_mom_update, g3, b, 0, c->stream, c->d, m, mm, nn);
+  // The layer loop (:342) in chunks: a chunk's ~55 planes (inputs, ~30 temporaries, outputs) of `ch` layers each are
+  // produced and consumed by consecutive kernels while they still sit in the 256 MiB Infinity Cache.
+  const int ch = c->momtum_chunk > 0 ? c->momtum_chunk : h.kk;
+  for (int klo = 0; klo < h.kk; klo += ch) {
+    const dim3 g = plane_grid(h, h.kk - klo < ch ? h.kk - klo : ch);
+    hipLaunchKernelGGL(k_mom_tot, g, b, 0, c->stream, c->d, m, n, mm, nn, klo);
+    hipLaunchKernelGGL(k_mom_wall, g, b, 0, c->stream, c->d, m, klo);
+    hipLaunchKernelGGL(k_mom_vort, g, b, 0, c->stream, c->d, mm, klo);
+    if (h.P.mommth == 2) hipLaunchKernelGGL(k_mom_enedis, g, b, 0, c->stream, c->d, mm, klo);
+    hipLaunchKernelGGL(k_mom_visc, g, b, 0, c->stream, c->d, klo);
+    hipLaunchKernelGGL(k_mom_flux1, g, b, 0, c->stream, c->d, mm, klo);
+    hipLaunchKernelGGL(k_mom_update, g, b, 0, c->stream, c->d, m, mm, nn, klo);
+  }
   hipLaunchKernelGGL(k_mom_column, plane_grid(h, 2, 64), b64, 0, c->stream, c->d, m, mm, nn);
   HIPCHK(c, hipGetLastError());
   return 0;
