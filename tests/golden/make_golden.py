@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Generates the golden fixtures under tests/golden/ from the REFERENCE's own compiled code
 (oracle/_ref/<cfg>/libblomref.so, built from /root/reference by oracle/Makefile).  Run in the
-build container only:   python tests/golden/make_golden.py
+build container only:   python tests/golden/make_golden.py [cfg ...]      (default: all)
 
-Per configuration (chan_s, box_s; for fuk95 -- the reference's own test case, 156x32x12 -- and tri_s --
-arctic patch -- only the CRC file: their inputs are the analytic host initialisation, which the tests redo):
+Per configuration (chan_s, box_s; for fuk95 -- the reference's own test case, 156x32x12 --, tri_s -- arctic patch --,
+chan_s_tke -- the reference's default tracer set, ntr = 3 -- and channel_tke -- BASELINE.json's channel at full size,
+208x512x53, ntr = 3, the bench workload, prognostic fields only -- only the CRC file: their inputs are the analytic
+host initialisation, which the tests redo):
   <cfg>_init.npz   complete model state + masks + grid after host initialisation (the inputs)
   <cfg>_crc.json   for steps 1..NSTEPS and every stage of the dyncore sequence: the reference's own
                    chksum/xccrc value (phy/mod_checksum.F90, phy/mod_xc.F90:4164) of every field
@@ -35,11 +37,19 @@ SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "v
 CRC_FIELDS = [f for f in STATE_FIELDS if f not in SCRATCH]
 FINAL_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "trc"]
 
-for cfg in ("chan_s", "box_s", "fuk95", "tri_s"):
-    crc_only = cfg in ("fuk95", "tri_s")
+# the channel: fields a stage sequence can be judged by, kept short because every record checksums them at full size
+CHANNEL_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "trc", "p", "dpu", "dpv", "uflx", "vflx", "pgfx", "pgfy",
+                  "pb", "ub", "vb", "pbu", "pbv", "ubflxs_p", "vbflxs_p", "pb_p"]
+
+
+def generate(cfg):
+    global NSTEPS
+    crc_only = cfg in ("fuk95", "tri_s", "chan_s_tke", "channel_tke")
     NSTEPS = 2 if cfg == "fuk95" else 3
     case = make_case(cfg)
-    ref = get_ref_backend(cfg, case.depth)
+    # the channel-sized reference is built with its OpenMP directives on (same results, oracle/Makefile)
+    ref = get_ref_backend(cfg + "_omp" if cfg.startswith("channel") else cfg, case.depth)
+    crc_fields = CHANNEL_FIELDS if cfg.startswith("channel") else CRC_FIELDS
     hostinit.init_state(ref, case)
     init = {nm: ref.get(nm).copy() for nm in STATE_FIELDS + GRID_FIELDS + INT_FIELDS if ref.ref.has_field(nm) or nm in ("trc",)}
     for m in ("ip", "iu", "iv", "iq"):
@@ -51,7 +61,7 @@ for cfg in ("chan_s", "box_s", "fuk95", "tri_s"):
 
     def record(st):
         crcs.setdefault(str(state["step"]), {})[st] = {
-            nm: ref.ref.xccrc(ref.get(nm), grid_of(nm)) for nm in CRC_FIELDS}
+            nm: ref.ref.xccrc(ref.get(nm), grid_of(nm)) for nm in crc_fields}
 
     ns = 0
     for _ in range(NSTEPS):
@@ -64,8 +74,20 @@ for cfg in ("chan_s", "box_s", "fuk95", "tri_s"):
             pending.append(st)
         ns = dyncore_step(ref, ns, case.params["baclin"], hook=hook)
         record(pending.pop())
-    json.dump({"nsteps": NSTEPS, "fields": CRC_FIELDS, "crc": crcs},
+    json.dump({"nsteps": NSTEPS, "fields": crc_fields, "crc": crcs},
               open(os.path.join(HERE, f"{cfg}_crc.json"), "w"))
     if not crc_only:
         np.savez_compressed(os.path.join(HERE, f"{cfg}_final.npz"), **{nm: ref.get(nm).copy() for nm in FINAL_FIELDS})
     print(cfg, "fixtures written")
+
+
+if __name__ == "__main__":
+    import threading
+    cfgs = sys.argv[1:] or ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "channel_tke"]
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+    os.environ["OMP_STACKSIZE"] = "1G"
+    threading.stack_size(2 << 30)            # the reference keeps stage-local 2-D work arrays on the stack
+    for cfg in cfgs:
+        th = threading.Thread(target=generate, args=(cfg,))
+        th.start()
+        th.join()
