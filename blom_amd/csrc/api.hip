@@ -202,6 +202,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
+  if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "momtum_chunk") { c->momtum_chunk = v; return 0; }
   return ctx_fail(c, "blomgpu_set_int: unknown option " + s);

@@ -199,6 +199,9 @@ struct blomgpu_ctx {
   int momtum_chunk = 0;      // layers per launch group of momtum's layer kernels (0: all)
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
+  double *arc_strip = nullptr;                 // arctic patch, tiles of one process in strips mode: this tile's strip
+  size_t arc_cap = 0;
+  int arctic_strips = 0;                       // tiles of one process: arctic fold through packed strips (test of the RCCL path's kernels)
   double *xcsum_buf = nullptr;                 // [0] the sum, [1..jj] the row sums of xcsum
   int cnsvdi = 0;                              // mod_budget: conservation diagnostics on/off
   double budget[4][7][2] = {};                 // sdp, tdp, trdp, tkedp (ncall, n)

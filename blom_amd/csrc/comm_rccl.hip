@@ -17,6 +17,8 @@ struct RcclComm {
   size_t cap = 0;
   double *sbuf_ns[2] = {nullptr, nullptr}, *rbuf_ns[2] = {nullptr, nullptr};   // [0] south, [1] north
   size_t cap_ns = 0;
+  double *arc_send = nullptr, *arc_gath = nullptr;   // arctic patch: my strip (self-send hook), the top row's strips
+  size_t arc_cap = 0;
   int force_ns = 0;          // test hook: route a tile-local periodic N/S wrap through send/recv to itself
 };
 
@@ -133,7 +135,6 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
   const Tiling &T = c->tiling;
   hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
   if (nf < 1 || nf > MAXF) return ctx_fail(c, "rccl_xctilr_multi: 1..4 fields per exchange");
-  if (h.nreg == 2) return ctx_fail(c, "RCCL tiles: the arctic patch (nreg = 2) is not built for more than one tile");
   FieldSet F;
   for (int x = 0; x < MAXF; x++) F.p[x] = fields[x < nf ? x : 0];
   const int ly = nlev > 64 ? 64 : nlev;
@@ -217,6 +218,44 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
   return 0;
 }
 
+// Arctic patch (nreg = 2): brings the strips of all tiles of the top row together on every rank of that row
+// (halo.hip: k_arctic_pack / k_arctic_fill).  strips[q] <- device pointer of tile column q's strip.  The fold's
+// mirror image of a tile's columns lies in the mirror tile and, for the u- and q-grid, one column beyond it
+// (the reference's second "aia" partner, phy/mod_xc.F90:2640-2653), so instead of pairing tiles every top-row rank
+// sends its strip ((nhl+2)*ii*nlev reals, a few 100 KB) to every other one: npx-1 messages per rank in one group.
+void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, const double *a, double *strip, int nlev, int nrows);   // halo.hip
+int rccl_arctic_gather(blomgpu_ctx *c, const double *a, int nlev, int nrows, const double **strips) {
+  const DevView &h = c->h;
+  RcclComm *R = c->tiling.rccl;
+  const Tiling &T = c->tiling;
+  hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
+  const size_t need = (size_t)nrows * h.ii * nlev;
+  if (need > R->arc_cap) {
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (R->arc_send) (void)hipFree(R->arc_send);
+    if (R->arc_gath) (void)hipFree(R->arc_gath);
+    HIPCHK(c, hipMalloc((void **)&R->arc_send, need * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&R->arc_gath, need * T.npx * sizeof(double)));
+    R->arc_cap = need;
+  }
+  const bool self = T.npx == 1 && R->force_ns;           // test hook: my own strip travels through send/recv
+  double *mine = self ? R->arc_send : R->arc_gath + (size_t)T.px * need;
+  arctic_pack_launch(c, st, a, mine, nlev, nrows);
+  if (T.npx > 1 || self) {
+    const int row0 = T.npx * (T.npy - 1);
+    ncclGroupStart();
+    for (int q = 0; q < T.npx; q++)
+      if (q != T.px || self) ncclSend(mine, need, ncclDouble, row0 + q, R->comm, st);
+    for (int q = 0; q < T.npx; q++)
+      if (q != T.px || self) ncclRecv(R->arc_gath + (size_t)q * need, need, ncclDouble, row0 + q, R->comm, st);
+    ncclResult_t rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL arctic exchange: ") + ncclGetErrorString(rc));
+  }
+  for (int q = 0; q < T.npx; q++) strips[q] = R->arc_gath + (size_t)q * need;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
   return rccl_xctilr_multi(c, &a, 1, nlev, mhl, nhl);
 }
@@ -238,8 +277,6 @@ int blomgpu_rccl_init_2d(blomgpu_ctx *c, const void *id128, int rank, int npx, i
   if (c->h.i0 != px * c->h.ii || c->h.itdm != npx * c->h.ii || c->h.j0 != py * c->h.jj || c->h.jtdm != npy * c->h.jj)
     return ctx_fail(c, "rccl_init: the context's window does not match tile (px,py) of a uniform npx x npy grid "
                        "(i0 = px*idm, j0 = py*jdm, itdm = npx*idm, jtdm = npy*jdm)");
-  if (c->h.nreg == 2 && npx * npy > 1)
-    return ctx_fail(c, "rccl_init: the arctic patch (nreg = 2) is not built for more than one tile");
   HIPCHK(c, hipSetDevice(c->device));
   RcclComm *R = new RcclComm();
   ncclUniqueId id;
@@ -276,6 +313,8 @@ int blomgpu_rccl_finalize(blomgpu_ctx *c) {
     (void)hipFree(R->sbuf[s]); (void)hipFree(R->rbuf[s]);
     (void)hipFree(R->sbuf_ns[s]); (void)hipFree(R->rbuf_ns[s]);
   }
+  if (R->arc_send) (void)hipFree(R->arc_send);
+  if (R->arc_gath) (void)hipFree(R->arc_gath);
   delete R;
   c->tiling.rccl = nullptr;
   return 0;

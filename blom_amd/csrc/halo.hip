@@ -143,6 +143,60 @@ __global__ void k_xctilr_arctic_tiles(const DevView *Vp, double *__restrict__ a,
   }
 }
 
+// ---- the arctic rule for tiles that cannot read each other's memory (one process per GPU) ---------------------
+// Every tile of the top row packs its last `nrows` = nhl+2 interior rows (the only rows the fold reads: jtdm-1-nhl
+// .. jtdm) into a strip [level][row][i]; the strips of the whole row are brought together (RCCL send/recv between
+// the top-row ranks, comm_rccl.hip; a pointer table for tiles of one process), and each tile fills its fold targets
+// -- rows jj.. over i = 1-mhl..ii+mhl, the E/W halo of those rows included -- from the strip of whichever tile owns
+// the mirrored column.  Everything else (E/W, south) is the ordinary exchange, done before.  Same index rule as
+// k_xctilr_arctic_tiles above, so the result is the single tile's.
+struct StripTab {
+  const double *p[XCT_MAXTILES];      // strip of top-row tile qx
+};
+__global__ void k_arctic_pack(const DevView *Vp, const double *__restrict__ a, double *__restrict__ strip, int nlev, int nrows) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ii * nrows) return;
+  const int i = t % ii + 1, r = t / ii, j = jj - nrows + 1 + r;
+  const size_t src = IDX(V, i, j);
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y)
+    strip[((size_t)k * nrows + r) * ii + (i - 1)] = j >= 1 ? a[src + (size_t)k * V.nplane] : 0.;
+}
+__global__ void k_arctic_fill(const DevView *Vp, double *__restrict__ a, StripTab tab, int npx, int px, int nlev, int mhl,
+                              int nhl, int itype, int nrows) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj, itdm = npx * ii;
+  const int g = itype % 10;
+  const double sgn = itype > 10 ? -1. : 1.;
+  const int wrow = ii + 2 * mhl;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= wrow * (nhl + 1)) return;
+  const int i = t % wrow + 1 - mhl, d = t / wrow;                         // row jj + d
+  const int ig = px * ii + i;
+  const int iw = ig < 1 ? ig + itdm : (ig > itdm ? ig - itdm : ig);      // periodic in i
+  int is, back;                                                          // source column, rows below the last one
+  if (g == 1 || g == 3) {                                                // p-, u-grid
+    is = g == 1 ? itdm - (iw - 1) % itdm : (itdm - (iw - 1)) % itdm + 1;
+    back = 1 + d;
+  } else if (d > 0 || iw > itdm / 2) {                                   // q-, v-grid
+    is = g == 2 ? (itdm - (iw - 1)) % itdm + 1 : itdm - (iw - 1) % itdm;
+    back = d;
+  } else {
+    return;                                                              // first half of the seam row: not a target
+  }
+  const int qx = (is - 1) / ii, r = nrows - 1 - back;
+  const double *src = tab.p[qx] + (size_t)r * ii + (is - qx * ii - 1);
+  const size_t dst = IDX(V, i, jj + d);
+  for (int k = blockIdx.y; k < nlev; k += gridDim.y)
+    a[dst + (size_t)k * V.nplane] = sgn * src[(size_t)k * nrows * ii];
+}
+
+void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, const double *a, double *strip, int nlev, int nrows) {
+  const dim3 g((unsigned)((nrows * c->h.ii + 255) / 256), nlev > 64 ? 64 : nlev);
+  hipLaunchKernelGGL(k_arctic_pack, g, dim3(256), 0, st, c->d, a, strip, nlev, nrows);
+}
+
 #include <pthread.h>
 struct TileGroup {
   int npx, npy;
@@ -163,46 +217,10 @@ int ctx_locate_ptr(const blomgpu_ctx *c, const double *p, size_t *offset) {
 static inline bool ew_periodic(int nreg) { return !(nreg == 0 || nreg == 4); }
 static inline bool ns_periodic(int nreg) { return nreg > 2; }
 
-int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int itype) {
-  // itype only distinguishes grids/vectors across the arctic seam (phy/mod_xc.F90:4248-4250)
+// the ordinary update: E/W and N/S neighbours (or the tile itself), land beyond closed boundaries
+static int xctilr_plain(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
   const DevView &h = c->h;
-  const int mhl = mh < 0 ? 0 : (mh > NBDY ? NBDY : mh);
-  const int nhl = nh < 0 ? 0 : (nh > NBDY ? NBDY : nh);
-  const int nlev = ld - l1 + 1;
-  double *a = base + (size_t)(l1 - 1) * h.nplane;
   const Tiling &T = c->tiling;
-  if (h.nreg == 2 && T.group) {
-    // decomposed arctic domain, all tiles in this process: global gather through the tile pointer table
-    TileGroup *G = T.group;
-    if (T.npx * T.npy > XCT_MAXTILES) return ctx_fail(c, "xctilr: too many tiles for the arctic gather");
-    if (T.npx > 1 && T.npx % 2) return ctx_fail(c, "xctilr: the arctic patch needs an even number of tile columns (phy/mod_xc.F90:1600-1603)");
-    if (nlev <= 0) return 0;
-    size_t off = 0;
-    const int fid = ctx_locate_ptr(c, a, &off);
-    if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
-    TileTab tab;
-    for (int q = 0; q < XCT_MAXTILES; q++)
-      tab.p[q] = q < T.npx * T.npy ? G->tiles[(size_t)q]->h.f[fid] + off : nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    pthread_barrier_wait(&G->bar);
-    const int nt = (h.ii + 2 * mhl) * (h.jj + 2 * nhl);
-    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
-    hipLaunchKernelGGL(k_xctilr_arctic_tiles, grid, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.npy, T.px, T.py,
-                       nlev, mhl, nhl, itype);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    pthread_barrier_wait(&G->bar);
-    return 0;
-  }
-  if (h.nreg == 2) {
-    if (T.multi()) return ctx_fail(c, "xctilr: the arctic patch (nreg=2) over RCCL tiles is not built (single tile, or tiles of one process)");
-    if (nlev <= 0) return 0;
-    const int nt = (2 * nhl + 1) * (h.ii + 2 * mhl) + 2 * mhl * (h.jj - 1);
-    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
-    hipLaunchKernelGGL(k_xctilr_arctic, grid, dim3(256), 0, c->stream, c->d, a, nlev, mhl, nhl, itype);
-    HIPCHK(c, hipGetLastError());
-    return 0;
-  }
   const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
   if (ntarget == 0 || nlev <= 0) return 0;
   if (T.rccl) return rccl_xctilr(c, a, nlev, mhl, nhl);
@@ -238,6 +256,94 @@ int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int 
     pthread_barrier_wait(&G->bar);
   }
   return 0;
+}
+
+int rccl_arctic_gather(blomgpu_ctx *c, const double *a, int nlev, int nrows, const double **strips);
+
+// arctic patch over tiles that exchange strips (RCCL ranks; tiles of one process with the option arctic_strips, which
+// exists so that the pack/fill kernels can be tested for several tile columns on one GPU)
+static int xctilr_arctic_strips(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl, int itype) {
+  const DevView &h = c->h;
+  const Tiling &T = c->tiling;
+  if (T.npx > XCT_MAXTILES) return ctx_fail(c, "xctilr: too many tile columns for the arctic strips");
+  if (int rc = xctilr_plain(c, a, nlev, mhl, nhl)) return rc;
+  const bool top = T.py == T.npy - 1;
+  const int nrows = nhl + 2;
+  if (nrows > h.jj) return ctx_fail(c, "xctilr: tile has fewer rows than the arctic fold reads");
+  StripTab tab;
+  for (int q = 0; q < XCT_MAXTILES; q++) tab.p[q] = nullptr;
+  const size_t need = (size_t)nrows * h.ii * nlev;
+  if (T.rccl) {
+    if (!top) return 0;
+    if (int rc = rccl_arctic_gather(c, a, nlev, nrows, tab.p)) return rc;
+  } else {
+    TileGroup *G = T.group;
+    if (top) {
+      if (need > c->arc_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->arc_strip) (void)hipFree(c->arc_strip);
+        HIPCHK(c, hipMalloc((void **)&c->arc_strip, need * sizeof(double)));
+        c->arc_cap = need;
+      }
+      arctic_pack_launch(c, c->stream, a, c->arc_strip, nlev, nrows);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);                       // every strip is complete
+    for (int q = 0; q < T.npx; q++) tab.p[q] = G->tiles[(size_t)(T.npy - 1) * T.npx + q]->arc_strip;
+  }
+  if (top) {
+    const dim3 gf((unsigned)(((h.ii + 2 * mhl) * (nhl + 1) + 255) / 256), nlev > 64 ? 64 : nlev);
+    hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.px, nlev, mhl, nhl, itype, nrows);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (!T.rccl) {                                         // nobody repacks before everybody has read
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&T.group->bar);
+  }
+  return 0;
+}
+
+int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int itype) {
+  // itype only distinguishes grids/vectors across the arctic seam (phy/mod_xc.F90:4248-4250)
+  const DevView &h = c->h;
+  const int mhl = mh < 0 ? 0 : (mh > NBDY ? NBDY : mh);
+  const int nhl = nh < 0 ? 0 : (nh > NBDY ? NBDY : nh);
+  const int nlev = ld - l1 + 1;
+  double *a = base + (size_t)(l1 - 1) * h.nplane;
+  const Tiling &T = c->tiling;
+  if (h.nreg == 2 && nlev > 0 && (T.rccl || (T.group && c->arctic_strips))) return xctilr_arctic_strips(c, a, nlev, mhl, nhl, itype);
+  if (h.nreg == 2 && T.group) {
+    // decomposed arctic domain, all tiles in this process: global gather through the tile pointer table
+    TileGroup *G = T.group;
+    if (T.npx * T.npy > XCT_MAXTILES) return ctx_fail(c, "xctilr: too many tiles for the arctic gather");
+    if (T.npx > 1 && T.npx % 2) return ctx_fail(c, "xctilr: the arctic patch needs an even number of tile columns (phy/mod_xc.F90:1600-1603)");
+    if (nlev <= 0) return 0;
+    size_t off = 0;
+    const int fid = ctx_locate_ptr(c, a, &off);
+    if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
+    TileTab tab;
+    for (int q = 0; q < XCT_MAXTILES; q++)
+      tab.p[q] = q < T.npx * T.npy ? G->tiles[(size_t)q]->h.f[fid] + off : nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);
+    const int nt = (h.ii + 2 * mhl) * (h.jj + 2 * nhl);
+    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
+    hipLaunchKernelGGL(k_xctilr_arctic_tiles, grid, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.npy, T.px, T.py,
+                       nlev, mhl, nhl, itype);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&G->bar);
+    return 0;
+  }
+  if (h.nreg == 2) {
+    if (nlev <= 0) return 0;
+    const int nt = (2 * nhl + 1) * (h.ii + 2 * mhl) + 2 * mhl * (h.jj - 1);
+    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
+    hipLaunchKernelGGL(k_xctilr_arctic, grid, dim3(256), 0, c->stream, c->d, a, nlev, mhl, nhl, itype);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  return xctilr_plain(c, a, nlev, mhl, nhl);
 }
 
 // Several plane stacks with the same halo widths in one launch (single tile, no arctic patch): what the

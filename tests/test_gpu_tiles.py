@@ -44,10 +44,16 @@ def _single(cfg, nsteps):
 
 @pytest.mark.parametrize("cfg,npx,npy", [("chan_s", 2, 1), ("chan_s", 1, 2), ("chan_s", 2, 2), ("box_s", 2, 2),
                                          ("box_s", 3, 1), ("tri_s", 2, 1), ("tri_s", 2, 2), ("tri_s", 4, 2),
-                                         ("chan_s_tke", 2, 2), ("tri_s_tke", 2, 2)])
+                                         ("chan_s_tke", 2, 2), ("tri_s_tke", 2, 2),
+                                         # arctic fold through packed strips -- the kernels of the RCCL transport's
+                                         # arctic exchange, here with the strips handed over by pointer
+                                         ("tri_s+strips", 2, 1), ("tri_s+strips", 2, 2), ("tri_s+strips", 4, 2),
+                                         ("tri_s+strips", 3, 1), ("tri_s_tke+strips", 4, 1)])
 def test_tiles_match_single_tile(cfg, npx, npy):
     from blom_amd.gpu import BlomGpu, TileGroup
     nsteps = 4
+    strips = cfg.endswith("+strips")
+    cfg = cfg.split("+")[0]
     case, masks, fields, ref = _single(cfg, nsteps)
     ii, jj = tile_extents(case, npx, npy)
     grp = TileGroup(npx, npy)
@@ -60,6 +66,7 @@ def test_tiles_match_single_tile(cfg, npx, npy):
                 if not nm.endswith("0"):
                     t.set(nm, v)
             t.set("delt1", case.params["baclin"])
+            t.set("arctic_strips", 1 if strips else 0)
             grp.attach(t, px, py)
             tiles[(px, py)] = t
     scatter_state(ref, tiles, case, npx, npy, [f for f in ALL if f in fields])

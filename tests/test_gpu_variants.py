@@ -72,6 +72,20 @@ def _run_rccl_self(cfg, nsteps, **opts):
     return out
 
 
+@pytest.mark.parametrize("cfg", ["tri_s", "tri_s_tke"])
+def test_rccl_arctic_exchange_single_rank(cfg):
+    """Arctic patch (nreg = 2) on the RCCL transport, one rank: E/W through send/recv to the rank itself, then the
+    fold -- strip packed, with force = 1 sent to and received from the rank itself, fold targets filled from the
+    gathered strips.  Must equal the single tile's halo rule (pinned on the reference built with ARCTIC)."""
+    skip = {"util1", "util2", "util3", "util4"}
+    a = _run(cfg, 6)
+    assert all(np.isfinite(a[nm]).all() for nm in ("u", "dp", "temp"))
+    for force in (0, 1):
+        b = _run_rccl_2d_self(cfg, 6, force)
+        bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
+        assert not bad, (force, bad)
+
+
 @pytest.mark.parametrize("overlap", [0, 1])
 def test_rccl_exchange_overlapped_with_barotp_interior(overlap):
     """chan_m is three LDS tiles wide, so barotp's split launch (outer tile columns + exchange on the
@@ -87,7 +101,7 @@ def test_rccl_exchange_overlapped_with_barotp_interior(overlap):
 def _run_rccl_2d_self(cfg, nsteps, force_ns):
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     case = make_case(cfg)
-    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     hostinit.init_state(gpu, case)
     gpu.rccl_init_2d(rccl_unique_id(), 0, 1, 1)
