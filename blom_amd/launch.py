@@ -172,3 +172,41 @@ def exchange_2d_host(a, idm, jdm, mhl, nhl, rank, npx, npy, nreg):
         a[:, rows, 4 - mhl:4] = from_w.numpy() if west >= 0 else vland
         a[:, rows, 4 + idm:4 + idm + mhl] = from_e.numpy() if east >= 0 else vland
     return a
+
+
+def exchange_arctic_host(a, idm, jdm, mhl, nhl, rank, npx, npy, itype):
+    """Host statement of the arctic update over ranks (comm_rccl.hip: rccl_arctic_gather; halo.hip: k_arctic_pack,
+    k_arctic_fill): the ordinary exchange of a domain that is periodic in i and closed in j, then the ranks of the
+    last tile row send each other their last nhl+2 interior rows and fill the fold targets -- rows jdm.. over the
+    columns 1-mhl..idm+mhl -- from the strip of the tile that owns the mirrored column."""
+    import torch
+    import torch.distributed as dist
+    exchange_2d_host(a, idm, jdm, mhl, nhl, rank, npx, npy, 2)
+    px, py = rank % npx, rank // npx
+    if py != npy - 1:
+        return a
+    nrows, row0 = nhl + 2, npx * (npy - 1)
+    mine = torch.from_numpy(np.ascontiguousarray(a[:, 4 + jdm - nrows:4 + jdm, 4:4 + idm]))
+    strips = [mine if q == px else torch.empty_like(mine) for q in range(npx)]
+    ops = [dist.P2POp(dist.isend, mine, row0 + q) for q in range(npx) if q != px]
+    ops += [dist.P2POp(dist.irecv, strips[q], row0 + q) for q in range(npx) if q != px]
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    strips = [s.numpy() for s in strips]
+    itdm, g, sgn = npx * idm, itype % 10, (-1.0 if itype > 10 else 1.0)
+    for d in range(nhl + 1):
+        for i in range(1 - mhl, idm + mhl + 1):
+            ig = px * idm + i
+            iw = ig + itdm if ig < 1 else (ig - itdm if ig > itdm else ig)
+            if g in (1, 3):
+                src = itdm - (iw - 1) % itdm if g == 1 else (itdm - (iw - 1)) % itdm + 1
+                back = 1 + d
+            elif d > 0 or iw > itdm // 2:
+                src = (itdm - (iw - 1)) % itdm + 1 if g == 2 else itdm - (iw - 1) % itdm
+                back = d
+            else:
+                continue
+            qx = (src - 1) // idm
+            a[:, 3 + jdm + d, 3 + i] = sgn * strips[qx][:, nrows - 1 - back, src - qx * idm - 1]
+    return a

@@ -113,6 +113,55 @@ def _worker_2d(rank, npx, npy, port, q):
         dist.destroy_process_group()
 
 
+def _worker_arctic(rank, npx, npy, port, q):
+    world = npx * npy
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = launch.tile_layout_2d(IDM, JDM, rank, npx, npy)
+        res = {}
+        for itype in (1, 2, 3, 4, 11, 12, 13, 14):
+            for mh, nh in ((3, 3), (4, 4), (2, 0), (0, 2), (1, 4)):
+                rng = np.random.default_rng(itype)                  # same global array on every rank
+                G = rng.standard_normal((NLEV, JDM * npy + 8, IDM * npx + 8))
+                want = G.copy()
+                xctilr_np(want, 1, NLEV, mh, nh, 2, IDM * npx, JDM * npy, itype=itype)   # single tile rule
+                i0, j0 = lay["i0"], lay["j0"]
+                a = G[:, j0:j0 + JDM + 8, i0:i0 + IDM + 8].copy()
+                keep = a[:, 4:4 + JDM, 4:4 + IDM].copy()
+                a[...] = np.nan
+                a[:, 4:4 + JDM, 4:4 + IDM] = keep
+                launch.exchange_arctic_host(a, IDM, JDM, mh, nh, rank, npx, npy, itype)
+                w = want[:, j0:j0 + JDM + 8, i0:i0 + IDM + 8]
+                # interior (the seam row changes in the last tile row), halo rows over 1..ii, halo columns over all rows
+                ok = np.array_equal(a[:, 4 - nh:4 + JDM + nh, 4:4 + IDM], w[:, 4 - nh:4 + JDM + nh, 4:4 + IDM])
+                for cs in (slice(4 - mh, 4), slice(4 + IDM, 4 + IDM + mh)):
+                    ok = ok and np.array_equal(a[:, 4 - nh:4 + JDM + nh, cs], w[:, 4 - nh:4 + JDM + nh, cs])
+                res[f"arctic{itype}_{mh}_{nh}"] = bool(ok)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("npx,npy", [(2, 1), (2, 2), (4, 1), (3, 1)])
+def test_arctic_patch_over_gloo(npx, npy):
+    """the arctic update of the RCCL transport (ordinary exchange + strips of the last tile row to all of its ranks
+    + fill of the fold targets) with real ranks, for all eight grid/field types: every tile's halo -- and the seam
+    row -- must be what the single-tile rule (phy/mod_xc.F90:4262-4372) gives on the global array"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_arctic, args=(r, npx, npy, port, q)) for r in range(npx * npy)]
+    [p.start() for p in procs]
+    out = dict(q.get(timeout=180) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    for r, res in out.items():
+        bad = [k for k, v in res.items() if not v]
+        assert not bad, (r, bad)
+        assert len(res) == 40
+
+
 @pytest.mark.parametrize("npx,npy", [(2, 2), (1, 2), (3, 2)])
 def test_2d_tile_grid_over_gloo(npx, npy):
     """both phases of the 2-D exchange (blom_amd/csrc/comm_rccl.hip: rccl_xctilr_multi) with real ranks:
