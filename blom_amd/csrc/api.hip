@@ -201,6 +201,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
+  if (s == "barotp_arctic_fused") { c->barotp_arctic_fused = v; return 0; }
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }

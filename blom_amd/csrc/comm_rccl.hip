@@ -224,12 +224,14 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
 // (the reference's second "aia" partner, phy/mod_xc.F90:2640-2653), so instead of pairing tiles every top-row rank
 // sends its strip ((nhl+2)*ii*nlev reals, a few 100 KB) to every other one: npx-1 messages per rank in one group.
 void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, const double *a, double *strip, int nlev, int nrows);   // halo.hip
-int rccl_arctic_gather(blomgpu_ctx *c, const double *a, int nlev, int nrows, const double **strips) {
+// Several plane stacks of the same depth travel in one message: rank q's block is [field][level][row][i].
+int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int nrows, const double **strips, size_t *field_stride) {
   const DevView &h = c->h;
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
   hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
-  const size_t need = (size_t)nrows * h.ii * nlev;
+  const size_t per_field = (size_t)nrows * h.ii * nlev, need = per_field * nf;
+  *field_stride = per_field;
   if (need > R->arc_cap) {
     HIPCHK(c, hipStreamSynchronize(st));
     if (R->arc_send) (void)hipFree(R->arc_send);
@@ -240,7 +242,7 @@ int rccl_arctic_gather(blomgpu_ctx *c, const double *a, int nlev, int nrows, con
   }
   const bool self = T.npx == 1 && R->force_ns;           // test hook: my own strip travels through send/recv
   double *mine = self ? R->arc_send : R->arc_gath + (size_t)T.px * need;
-  arctic_pack_launch(c, st, a, mine, nlev, nrows);
+  for (int f = 0; f < nf; f++) arctic_pack_launch(c, st, fields[f], mine + (size_t)f * per_field, nlev, nrows);
   if (T.npx > 1 || self) {
     const int row0 = T.npx * (T.npy - 1);
     ncclGroupStart();

@@ -258,7 +258,8 @@ static int xctilr_plain(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
   return 0;
 }
 
-int rccl_arctic_gather(blomgpu_ctx *c, const double *a, int nlev, int nrows, const double **strips);
+int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int nrows, const double **strips, size_t *field_stride);
+int rccl_xctilr_multi(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int mhl, int nhl);
 
 // arctic patch over tiles that exchange strips (RCCL ranks; tiles of one process with the option arctic_strips, which
 // exists so that the pack/fill kernels can be tested for several tile columns on one GPU)
@@ -275,7 +276,9 @@ static int xctilr_arctic_strips(blomgpu_ctx *c, double *a, int nlev, int mhl, in
   const size_t need = (size_t)nrows * h.ii * nlev;
   if (T.rccl) {
     if (!top) return 0;
-    if (int rc = rccl_arctic_gather(c, a, nlev, nrows, tab.p)) return rc;
+    size_t fs = 0;
+    double *one[1] = {a};
+    if (int rc = rccl_arctic_gather(c, one, 1, nlev, nrows, tab.p, &fs)) return rc;
   } else {
     TileGroup *G = T.group;
     if (top) {
@@ -300,6 +303,32 @@ static int xctilr_arctic_strips(blomgpu_ctx *c, double *a, int nlev, int mhl, in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     pthread_barrier_wait(&T.group->bar);
   }
+  return 0;
+}
+
+// up to 4 stacks of the same depth and halo widths over RCCL with the arctic patch: one E/W message per neighbour
+// and one strip message per top-row rank for all of them (barotp's pb, ubflx, vbflx before every odd substep)
+static int xctilr_arctic_rccl_multi(blomgpu_ctx *c, int nf, double *const *ptrs, int nlev, int mhl, int nhl, const int *itypes) {
+  const DevView &h = c->h;
+  const Tiling &T = c->tiling;
+  if (T.npx > XCT_MAXTILES) return ctx_fail(c, "xctilr: too many tile columns for the arctic strips");
+  const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
+  if (ntarget > 0)
+    if (int rc = rccl_xctilr_multi(c, ptrs, nf, nlev, mhl, nhl)) return rc;
+  if (T.py != T.npy - 1) return 0;
+  const int nrows = nhl + 2;
+  if (nrows > h.jj) return ctx_fail(c, "xctilr: tile has fewer rows than the arctic fold reads");
+  StripTab tab;
+  for (int q = 0; q < XCT_MAXTILES; q++) tab.p[q] = nullptr;
+  size_t fs = 0;
+  if (int rc = rccl_arctic_gather(c, ptrs, nf, nlev, nrows, tab.p, &fs)) return rc;
+  const dim3 gf((unsigned)(((h.ii + 2 * mhl) * (nhl + 1) + 255) / 256), nlev > 64 ? 64 : nlev);
+  for (int f = 0; f < nf; f++) {
+    StripTab tf = tab;
+    for (int q = 0; q < T.npx; q++) tf.p[q] = tab.p[q] + (size_t)f * fs;
+    hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, ptrs[f], tf, T.npx, T.px, nlev, mhl, nhl, itypes[f], nrows);
+  }
+  HIPCHK(c, hipGetLastError());
   return 0;
 }
 
@@ -443,6 +472,14 @@ __global__ void k_xctilr_arctic_multi(const DevView *Vp, ArcticMulti M) {
 int st_xctilr_arctic_multi(blomgpu_ctx *c, int nf, double *const *ptrs, const int *nlevs, const int *mhs, const int *nhs,
                            const int *itypes) {
   const DevView &h = c->h;
+  if (h.nreg == 2 && c->tiling.rccl && nf >= 1 && nf <= 4) {
+    bool same = nlevs[0] > 0;
+    for (int f = 1; f < nf; f++) same = same && nlevs[f] == nlevs[0] && mhs[f] == mhs[0] && nhs[f] == nhs[0];
+    if (same) {
+      const int mhl = mhs[0] < 0 ? 0 : (mhs[0] > NBDY ? NBDY : mhs[0]), nhl = nhs[0] < 0 ? 0 : (nhs[0] > NBDY ? NBDY : nhs[0]);
+      return xctilr_arctic_rccl_multi(c, nf, ptrs, nlevs[0], mhl, nhl, itypes);
+    }
+  }
   if (h.nreg != 2 || c->tiling.multi() || nf > XCT_MAXF) {
     for (int f = 0; f < nf; f++)
       if (int rc = st_xctilr(c, ptrs[f], 1, nlevs[f], mhs[f], nhs[f], itypes[f])) return rc;
@@ -474,6 +511,17 @@ int st_xctilr_multi(blomgpu_ctx *c, int nf, double *const *ptrs, const int *nlev
     int mhs[XCT_MAXF], nhs[XCT_MAXF];
     for (int f = 0; f < nf; f++) { mhs[f] = mh; nhs[f] = nh; }
     return st_xctilr_arctic_multi(c, nf, ptrs, nlevs, mhs, nhs, itypes);
+  }
+  if (h.nreg == 2 && c->tiling.rccl) {                 // runs of stacks of equal depth share their messages
+    for (int f = 0; f < nf;) {
+      int g = 1;
+      while (f + g < nf && g < 4 && nlevs[f + g] == nlevs[f]) g++;
+      int mhs[4], nhs[4];
+      for (int x = 0; x < g; x++) { mhs[x] = mh; nhs[x] = nh; }
+      if (int rc = st_xctilr_arctic_multi(c, g, ptrs + f, nlevs + f, mhs, nhs, itypes + f)) return rc;
+      f += g;
+    }
+    return 0;
   }
   if (c->tiling.multi() || h.nreg == 2 || nf > XCT_MAXF) {
     for (int f = 0; f < nf; f++)

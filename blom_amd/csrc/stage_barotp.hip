@@ -358,7 +358,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     // happen exactly where the reference has it: before odd substeps only.  The fused kernels then publish
     // the margins they computed (PairArgs::write_margin), which is what the reference's arrays hold before
     // a lone even substep and before the epilogue; single tile only.
-    const bool arctic1 = h.nreg == 2 && !c->tiling.multi();
+    const bool arctic1 = h.nreg == 2 && (!c->tiling.multi() || c->barotp_arctic_fused);
     const bool fused = c->barotp_fused && (h.nreg != 2 || arctic1);
     bool halo_done = false;
     if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
@@ -388,8 +388,8 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         // single tile: the pair kernel applies the halo rule while loading; otherwise exchange first
         // RCCL tiles along i: the received strips stay in the transport's buffers and the kernel loads its
         // E/W rim from there (c->barotp_rimbuf), saving the unpack launch of every exchange
-        const bool rimbuf = c->tiling.rccl && c->barotp_rimbuf && c->tiling.npy == 1 && !ovl;
-        if ((c->tiling.multi() || (arctic1 && odd)) && !halo_done) {
+        const bool rimbuf = c->tiling.rccl && c->barotp_rimbuf && c->tiling.npy == 1 && !ovl && h.nreg != 2;
+        if ((arctic1 ? odd : c->tiling.multi()) && !halo_done) {
           if (rimbuf) { if (int rc = bt_pair_halo_landed(c, set, &landed)) return rc; }
           else if (int rc = bt_pair_halo(c, set)) return rc;
         }

@@ -441,11 +441,11 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
     double *f[3] = {set ? h.f[F_pb_t2] : h.f[F_pb_t], set ? h.f[F_ubflx_t2] : h.f[F_ubflx_t],
                     set ? h.f[F_vbflx_t2] : h.f[F_vbflx_t]};
     static const int it[3] = {1, 13, 14};
-    if (c->tiling.rccl) return rccl_xctilr_multi(c, f, 3, 2, 3, 3);       // one message per neighbour
-    if (h.nreg == 2 && !c->tiling.multi()) {
+    if (h.nreg == 2) {                                                     // single tile, RCCL (batched), tiles of one process
       const int nl3[3] = {2, 2, 2}, w3[3] = {3, 3, 3};
       return st_xctilr_arctic_multi(c, 3, f, nl3, w3, w3, it);
     }
+    if (c->tiling.rccl) return rccl_xctilr_multi(c, f, 3, 2, 3, 3);       // one message per neighbour
     for (int x = 0; x < 3; x++)
       if (int rc = st_xctilr(c, f[x], 1, 2, 3, 3, it[x])) return rc;
     return 0;
@@ -463,7 +463,7 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
   a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
-  a.write_margin = (h.nreg == 2 && !c->tiling.multi()) ? 1 : 0;
+  a.write_margin = (h.nreg == 2 && (!c->tiling.multi() || c->barotp_arctic_fused)) ? 1 : 0;
   a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
   if (rim && rim->from_west) {
     a.rim_on = 1; a.rim_w = rim->from_west; a.rim_e = rim->from_east;
