@@ -215,7 +215,8 @@ def make_case(name, ntr=None, **overrides):
     advection, iage => -DTKE -DTKEADV -DIDLAGE): ntr = 3 = TKE, the generic-length-scale slot, ideal age
     (trc/mod_tracers.F90:85-127).  Without the suffix: the -DTRC -DIDLAGE build, ntr = 1."""
     full_name = name
-    tke = name.endswith("_tke")
+    tk2 = name.endswith("_tk2")          # turbclo = twoeq, advection, isodif: -DTKE -DGLS -DTKEADV -DTKEIDF
+    tke = name.endswith("_tke") or tk2
     if tke:
         name = name[:-4]
     if ntr is None:
@@ -224,7 +225,7 @@ def make_case(name, ntr=None, **overrides):
     ni, nj = idm + 2 * NBDY, jdm + 2 * NBDY
     p = default_params(baclin, batrop)
     if tke:
-        p.update(itrtke=1, itrgls=2, itriag=3, tkeadv=1, tkeidf=0, gls=0)
+        p.update(itrtke=1, itrgls=2, itriag=3, tkeadv=1, tkeidf=1 if tk2 else 0, gls=1 if tk2 else 0)
     if name == "fuk95":
         p.update(expcnf="fuk95", taux0=0.0, cwbdts=0.0)
     p.update(overrides)
@@ -309,7 +310,8 @@ def make_case(name, ntr=None, **overrides):
         # diapfl's lower bound acts; the generic-length-scale slot is carried as a plain tracer (no -DGLS)
         tk = 2.0e-5 * np.exp(-1.2 * (k[:, None, None] - 1)) * (1.0 + 0.8 * np.sin(2 * np.pi * (x + y)))[None]
         trcs[0] = pad3(tk)
-        trcs[1] = pad3(1.0e-9 * (1.0 + 0.5 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y))[None] * (1.0 + 0.2 * k[:, None, None]))
+        # in the _tk2 build it is the length-scale variable, in places below gls_psi_min = 1e-14 (phy/mod_tke.F90:62)
+        trcs[1] = pad3((1.0e-15 if tk2 else 1.0e-9) * (1.0 + 0.5 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y))[None] * (1.0 + 0.2 * k[:, None, None]))
         trcs[2] = pad3(trc)
     ic = dict(dp=pad3(dp), temp=pad3(temp), saln=pad3(saln), sigma=pad3(sigma),
               sigmar=pad3(sigmar), trc=trcs)

@@ -320,8 +320,18 @@ int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype,
   return st_crc(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, itype, crc);
 }
 
+// settings of the reference's compile-time tracer switches that this library does not carry
+static int check_tracer_options(blomgpu_ctx *c) {
+  const Params &P = c->h.P;
+  if (P.itrtke >= 1 && !P.tkeadv)
+    return ctx_fail(c, "TKE tracers left out of advection (the reference built with -DTKE but without -DTKEADV) are not built");
+  if (P.itrtke >= 1 && (P.itrtke > c->h.ntr || P.itrgls > c->h.ntr || P.itrgls < 1))
+    return ctx_fail(c, "itrtke / itrgls outside 1..ntr");
+  return 0;
+}
 #define STAGE6(nm)                                                                         \
   int blomgpu_##nm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {       \
+    if (int rc = check_tracer_options(c)) return rc;                                       \
     ctx_sync_view(c);                                                                      \
     return st_##nm(c, m, n, mm, nn, k1m, k1n);                                             \
   }

@@ -156,3 +156,19 @@ def test_full_size_mass_conservation():
     for nm in ("u", "v", "dp", "temp", "saln"):
         assert np.isfinite(gpu.get(nm)).all(), nm
     gpu.close()
+
+
+def test_tracer_switch_that_is_not_built_fails_loudly():
+    """the reference built with -DTKE but without -DTKEADV leaves the TKE tracers out of advection
+    (phy/mod_remap.F90:314-316); the library does not carry that setting and must say so instead of advecting them"""
+    from blom_amd.gpu import BlomGpu
+    case = make_case("chan_s_tke")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    gpu.set("tkeadv", 0)
+    with pytest.raises(Exception, match="TKEADV"):
+        gpu.step(0, 1)
+    gpu.set("tkeadv", 1)
+    assert gpu.step(0, 1) == 1
+    gpu.close()

@@ -15,7 +15,7 @@ from blom_amd import hostinit
 from blom_amd.stepper import dyncore_step
 from parity import copy_state
 
-CFGS = ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "tri_s_tke"]
+CFGS = ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "tri_s_tke", "chan_s_tk2"]
 
 
 def _setup(cfg, make_other, nsteps=2):
