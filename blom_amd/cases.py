@@ -216,7 +216,8 @@ def make_case(name, ntr=None, **overrides):
     (trc/mod_tracers.F90:85-127).  Without the suffix: the -DTRC -DIDLAGE build, ntr = 1."""
     full_name = name
     tk2 = name.endswith("_tk2")          # turbclo = twoeq, advection, isodif: -DTKE -DGLS -DTKEADV -DTKEIDF
-    tke = name.endswith("_tke") or tk2
+    tk0 = name.endswith("_tk0")          # turbclo = oneeq: -DTKE alone, TKE tracers not advected
+    tke = name.endswith("_tke") or tk2 or tk0
     if tke:
         name = name[:-4]
     if ntr is None:
@@ -225,7 +226,7 @@ def make_case(name, ntr=None, **overrides):
     ni, nj = idm + 2 * NBDY, jdm + 2 * NBDY
     p = default_params(baclin, batrop)
     if tke:
-        p.update(itrtke=1, itrgls=2, itriag=3, tkeadv=1, tkeidf=1 if tk2 else 0, gls=1 if tk2 else 0)
+        p.update(itrtke=1, itrgls=2, itriag=3, tkeadv=0 if tk0 else 1, tkeidf=1 if tk2 else 0, gls=1 if tk2 else 0)
     if name == "fuk95":
         p.update(expcnf="fuk95", taux0=0.0, cwbdts=0.0)
     p.update(overrides)

@@ -323,8 +323,8 @@ int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype,
 // settings of the reference's compile-time tracer switches that this library does not carry
 static int check_tracer_options(blomgpu_ctx *c) {
   const Params &P = c->h.P;
-  if (P.itrtke >= 1 && !P.tkeadv)
-    return ctx_fail(c, "TKE tracers left out of advection (the reference built with -DTKE but without -DTKEADV) are not built");
+  if (P.itrtke >= 1 && !P.tkeadv && P.advmth == 1)
+    return ctx_fail(c, "cppm advects every tracer (phy/mod_cppm.F90 has no TKEADV switch): tkeadv = 0 only with advmth = 'remap'");
   if (P.itrtke >= 1 && (P.itrtke > c->h.ntr || P.itrgls > c->h.ntr || P.itrgls < 1))
     return ctx_fail(c, "itrtke / itrgls outside 1..ntr");
   return 0;

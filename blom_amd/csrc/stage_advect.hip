@@ -462,6 +462,7 @@ __global__ void k_remap_update(const DevView *Vp, int nn) {
   temp[c] = (q * temp[c] - (ftu[e] - ftu[c] + ftv[nb] - ftv[c]) * s2i) / dpn;
   saln[c] = (q * saln[c] - (fsu[e] - fsu[c] + fsv[nb] - fsv[c]) * s2i) / dpn;
   for (int nt = 0; nt < ntr; nt++) {
+    if (trc_skip_adv(V.P, nt + 1)) continue;                   // phy/mod_remap.F90:1497-1499
     double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
     const double *fu = WK(V, W_FTRU(ntr, nt)) + ok, *fv = WK(V, W_FTRV(ntr, nt)) + ok;
     tr[c] = (q * tr[c] - (fu[e] - fu[c] + fv[nb] - fv[c]) * s2i) / dpn;
@@ -490,12 +491,14 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   {                                                                                   // mod_advect:124-131
     double *ptrs[2 + MAXTR] = {h.f[F_cau], h.f[F_cav]};
     int nl[2 + MAXTR] = {h.kk, h.kk}, it[2 + MAXTR] = {13, 14};
+    int nf = 2;
     for (int nt = 0; nt < h.ntr; nt++) {
-      ptrs[2 + nt] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
-      nl[2 + nt] = h.kk;
-      it[2 + nt] = 1;
+      if (trc_skip_adv(h.P, nt + 1)) continue;                                        // :127-129
+      ptrs[nf] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
+      nl[nf] = h.kk;
+      it[nf++] = 1;
     }
-    if (int rc = st_xctilr_multi(c, 2 + h.ntr, ptrs, nl, 3, 3, it)) return rc;
+    if (int rc = st_xctilr_multi(c, nf, ptrs, nl, 3, 3, it)) return rc;
   }
   {
     TimeScope ts(c, "remap");

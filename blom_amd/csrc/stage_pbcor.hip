@@ -159,6 +159,7 @@ __global__ void k_pbc_update(const DevView *Vp, int which, int offc) {
     saln[c] = (dpo * saln[c] - dv2 * s2i) * dpni;
     temp[c] = (dpo * temp[c] - dv3 * s2i) * dpni;
     for (int nt = 0; nt < ntr; nt++) {
+      if (trc_skip_adv(V.P, nt + 1)) continue;          // phy/mod_pbcor.F90:353-355 (pbcor2, :684, has no such test)
       double *tr = V.f[F_trc] + okc + (size_t)nt * 2 * V.kk * np;
       const double *fu = WK(V, S_UTR(nt)) + ok, *fv = WK(V, S_VTR(nt)) + ok;
       tr[c] = (dpo * tr[c] - (fu[e] - fu[c] + fv[nb] - fv[c]) * s2i) * dpni;

@@ -341,7 +341,7 @@ static void remap(OState *S, RemapWork *W, const double *pbmin, const double *pb
       temp[c] = (q * temp[c] - (W->ftu[e] - W->ftu[c] + W->ftv[nb] - W->ftv[c]) * scp2i[c]) / dp[c];
       saln[c] = (q * saln[c] - (W->fsu[e] - W->fsu[c] + W->fsv[nb] - W->fsv[c]) * scp2i[c]) / dp[c];
       for (int nt = 0; nt < ntr; nt++)
-        trck[nt][c] = (q * trck[nt][c] -
+        if (!orc_skip_adv(S, nt + 1)) trck[nt][c] = (q * trck[nt][c] -
                        (W->ftru[nt][e] - W->ftru[nt][c] + W->ftrv[nt][nb] - W->ftrv[nt][c]) * scp2i[c]) / dp[c];
       dp[c] = fmax2(0., dp[c] - DPEPS);
     }
@@ -389,7 +389,7 @@ void orc_advect(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
   orc_xctilr(S, S->cau, 1, kk, 3, 3, 13);                              /* :124-131 */
   orc_xctilr(S, S->cav, 1, kk, 3, 3, 14);
   for (int nt = 1; nt <= ntr; nt++)
-    orc_xctilr(S, S->trc + lev * ((size_t)(k1n - 1) + 2 * kk * (nt - 1)), 1, kk, 3, 3, 1);
+    if (!orc_skip_adv(S, nt)) orc_xctilr(S, S->trc + lev * ((size_t)(k1n - 1) + 2 * kk * (nt - 1)), 1, kk, 3, 3, 1);
   RemapWork W;
   double **all = (double **)&W;
   const int nw = sizeof(RemapWork) / sizeof(double *);

@@ -102,7 +102,7 @@ static void pbcor(OState *S, int which, int m, int n, int mm, int nn, int k1m) {
           A3(S, saln, i, j, kc) = (dpo * A3(S, saln, i, j, kc) - dv2 * s2i) * dpni;
           A3(S, temp, i, j, kc) = (dpo * A3(S, temp, i, j, kc) - dv3 * s2i) * dpni;
           for (int nt = 1; nt <= ntr; nt++)
-            TRC(S, i, j, kc, nt) = (dpo * TRC(S, i, j, kc, nt) -
+            if (!orc_skip_adv(S, nt)) /* pbcor1 only: :353-355; pbcor2 :684 has no such test */ TRC(S, i, j, kc, nt) = (dpo * TRC(S, i, j, kc, nt) -
                                     (UTR(nt, i + 1, j) - UTR(nt, i, j) + VTR(nt, i, j + 1) - VTR(nt, i, j)) * s2i) * dpni;
           if (A3(S, dp, i, j, kc) < DPEPS2) A3(S, dp, i, j, kc) = 0.;
         } else { /* :671-692 */

@@ -71,7 +71,7 @@ def _run(cfg, nsteps, stages, **overrides):
     assert not failures, "\n".join(failures[:40])
 
 
-@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s", "chan_s_tke", "box_s_tke", "chan_s_tk2"])
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s", "chan_s_tke", "box_s_tke", "chan_s_tk2", "chan_s_tk0"])
 def test_stage_parity_small(cfg):
     _run(cfg, 4, GPU_STAGES)
 
@@ -108,7 +108,7 @@ FREERUN_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "ub
 
 
 @pytest.mark.parametrize("cfg,nsteps,rtol", [("chan_s", 40, 0.0), ("box_s", 40, 0.0), ("fuk95", 12, 0.0),
-                                             ("chan_s_tke", 40, 0.0), ("tri_s", 24, 0.0), ("tri_s_tke", 24, 0.0), ("chan_s_tk2", 40, 0.0)])
+                                             ("chan_s_tke", 40, 0.0), ("tri_s", 24, 0.0), ("tri_s_tke", 24, 0.0), ("chan_s_tk2", 40, 0.0), ("chan_s_tk0", 40, 0.0)])
 def test_freerun_device_resident(cfg, nsteps, rtol):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu

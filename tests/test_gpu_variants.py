@@ -159,12 +159,13 @@ def test_full_size_mass_conservation():
 
 
 def test_tracer_switch_that_is_not_built_fails_loudly():
-    """the reference built with -DTKE but without -DTKEADV leaves the TKE tracers out of advection
-    (phy/mod_remap.F90:314-316); the library does not carry that setting and must say so instead of advecting them"""
+    """cppm advects every tracer (phy/mod_cppm.F90 has no TKEADV switch), so `TKE tracers not advected` together with
+    advmth = 'cppm' is a combination the reference cannot be in; the library says so instead of guessing"""
     from blom_amd.gpu import BlomGpu
-    case = make_case("chan_s_tke")
+    case = make_case("chan_s_tk0", advmth="cppm")
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    case.params["tkeadv"] = 1
     hostinit.init_state(gpu, case)
     gpu.set("tkeadv", 0)
     with pytest.raises(Exception, match="TKEADV"):

@@ -10,7 +10,7 @@ from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, INT_FIELDS
 
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 12), ("fuk95", 3), ("tri_s", 8),
-                                        ("chan_s_tke", 12), ("box_s_tke", 8), ("tri_s_tke", 8), ("chan_s_tk2", 12)])
+                                        ("chan_s_tke", 12), ("box_s_tke", 8), ("tri_s_tke", 8), ("chan_s_tk2", 12), ("chan_s_tk0", 12)])
 def test_freerun_bit_identical(cfg, nsteps):
     from oracle.refblom import get_ref_backend, have_ref
     from oracle.coracle import COracle, have_coracle
