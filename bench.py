@@ -145,10 +145,19 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
         kind = "port"
     hostinit.init_state(be, case)
     ns = dyncore_step(be, 0, case.params["baclin"])          # forward first step (untimed)
+    # per-stage host times beside the device's stages_ms: the hook fires before every stage
+    per_stage, mark = {}, [None, 0.0]
+
+    def hook(st, six):
+        now = time.perf_counter()
+        if mark[0] is not None:
+            per_stage[mark[0]] = per_stage.get(mark[0], 0.0) + (now - mark[1])
+        mark[0], mark[1] = st, now
     t0 = time.time()
     n = 0
     while n < 3 or (time.time() - t0 < max_seconds and n < 200):
-        ns = dyncore_step(be, ns, case.params["baclin"])
+        ns = dyncore_step(be, ns, case.params["baclin"], hook=hook)
+        hook(None, None)
         n += 1
     dt = (time.time() - t0) / n
     note = ""
@@ -166,10 +175,15 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
             co.stage("eddtra", *six)
         de = (time.time() - t1) / 3
         dt += de
+        per_stage["eddtra"] = de * n
         note = f"; eddtra ({de * 1e3:.1f} ms) timed on the C restatement since the reference build lacks it"
     how = (f"{cores} OpenMP threads (reference built with -fopenmp)" if cores > 1 else
            "single thread (reference built without OpenMP)" if kind == "reference" else "single thread (C restatement)")
-    return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=cores, kind=kind,
+    stages_ms = {k: round(v / n * 1e3, 2) for k, v in per_stage.items() if k}
+    # the device reports advect as "remap" (or "cppm"): same name here
+    if "advect" in stages_ms:
+        stages_ms[case.params.get("advmth", "remap")] = stages_ms.pop("advect")
+    return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=cores, kind=kind, stages_ms=stages_ms,
                 sample=f"{n} baroclinic steps of the same {cfg} workload, {dt * 1e3:.1f} ms/step, {how}{note}")
 
 
