@@ -223,7 +223,7 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
 // mirror image of a tile's columns lies in the mirror tile and, for the u- and q-grid, one column beyond it
 // (the reference's second "aia" partner, phy/mod_xc.F90:2640-2653), so instead of pairing tiles every top-row rank
 // sends its strip ((nhl+2)*ii*nlev reals, a few 100 KB) to every other one: npx-1 messages per rank in one group.
-void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, const double *a, double *strip, int nlev, int nrows);   // halo.hip
+void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, double *const *fields, int nf, double *strip, int nlev, int nrows);   // halo.hip
 // Several plane stacks of the same depth travel in one message: rank q's block is [field][level][row][i].
 int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, int nrows, const double **strips, size_t *field_stride) {
   const DevView &h = c->h;
@@ -242,7 +242,8 @@ int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, 
   }
   const bool self = T.npx == 1 && R->force_ns;           // test hook: my own strip travels through send/recv
   double *mine = self ? R->arc_send : R->arc_gath + (size_t)T.px * need;
-  for (int f = 0; f < nf; f++) arctic_pack_launch(c, st, fields[f], mine + (size_t)f * per_field, nlev, nrows);
+  if (nf > 4) return ctx_fail(c, "rccl_arctic_gather: at most 4 stacks per exchange");
+  arctic_pack_launch(c, st, fields, nf, mine, nlev, nrows);
   if (T.npx > 1 || self) {
     const int row0 = T.npx * (T.npy - 1);
     ncclGroupStart();

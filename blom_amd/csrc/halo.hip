@@ -153,8 +153,11 @@ __global__ void k_xctilr_arctic_tiles(const DevView *Vp, double *__restrict__ a,
 struct StripTab {
   const double *p[XCT_MAXTILES];      // strip of top-row tile qx
 };
-__global__ void k_arctic_pack(const DevView *Vp, const double *__restrict__ a, double *__restrict__ strip, int nlev, int nrows) {
+struct PackSet { const double *a[4]; };
+__global__ void k_arctic_pack(const DevView *Vp, PackSet P, double *__restrict__ strip0, int nlev, int nrows) {
   const DevView &V = *Vp;
+  const double *__restrict__ a = P.a[blockIdx.z];
+  double *__restrict__ strip = strip0 + (size_t)blockIdx.z * nrows * V.ii * nlev;
   const int ii = V.ii, jj = V.jj;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ii * nrows) return;
@@ -163,9 +166,16 @@ __global__ void k_arctic_pack(const DevView *Vp, const double *__restrict__ a, d
   for (int k = blockIdx.y; k < nlev; k += gridDim.y)
     strip[((size_t)k * nrows + r) * ii + (i - 1)] = j >= 1 ? a[src + (size_t)k * V.nplane] : 0.;
 }
-__global__ void k_arctic_fill(const DevView *Vp, double *__restrict__ a, StripTab tab, int npx, int px, int nlev, int mhl,
-                              int nhl, int itype, int nrows) {
+struct FillSet {                      // up to 4 stacks per launch (blockIdx.z): array, grid/field type, offset in a rank's block
+  double *a[4];
+  int itype[4];
+  size_t off[4];
+};
+__global__ void k_arctic_fill(const DevView *Vp, FillSet F, StripTab tab, int npx, int px, int nlev, int mhl,
+                              int nhl, int nrows) {
   const DevView &V = *Vp;
+  double *__restrict__ a = F.a[blockIdx.z];
+  const int itype = F.itype[blockIdx.z];
   const int ii = V.ii, jj = V.jj, itdm = npx * ii;
   const int g = itype % 10;
   const double sgn = itype > 10 ? -1. : 1.;
@@ -186,15 +196,18 @@ __global__ void k_arctic_fill(const DevView *Vp, double *__restrict__ a, StripTa
     return;                                                              // first half of the seam row: not a target
   }
   const int qx = (is - 1) / ii, r = nrows - 1 - back;
-  const double *src = tab.p[qx] + (size_t)r * ii + (is - qx * ii - 1);
+  const double *src = tab.p[qx] + F.off[blockIdx.z] + (size_t)r * ii + (is - qx * ii - 1);
   const size_t dst = IDX(V, i, jj + d);
   for (int k = blockIdx.y; k < nlev; k += gridDim.y)
     a[dst + (size_t)k * V.nplane] = sgn * src[(size_t)k * nrows * ii];
 }
 
-void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, const double *a, double *strip, int nlev, int nrows) {
-  const dim3 g((unsigned)((nrows * c->h.ii + 255) / 256), nlev > 64 ? 64 : nlev);
-  hipLaunchKernelGGL(k_arctic_pack, g, dim3(256), 0, st, c->d, a, strip, nlev, nrows);
+// strips of nf <= 4 stacks, one after the other, in one launch
+void arctic_pack_launch(blomgpu_ctx *c, hipStream_t st, double *const *fields, int nf, double *strip, int nlev, int nrows) {
+  const dim3 g((unsigned)((nrows * c->h.ii + 255) / 256), nlev > 64 ? 64 : nlev, nf);
+  PackSet P;
+  for (int f = 0; f < 4; f++) P.a[f] = fields[f < nf ? f : 0];
+  hipLaunchKernelGGL(k_arctic_pack, g, dim3(256), 0, st, c->d, P, strip, nlev, nrows);
 }
 
 #include <pthread.h>
@@ -288,7 +301,8 @@ static int xctilr_arctic_strips(blomgpu_ctx *c, double *a, int nlev, int mhl, in
         HIPCHK(c, hipMalloc((void **)&c->arc_strip, need * sizeof(double)));
         c->arc_cap = need;
       }
-      arctic_pack_launch(c, c->stream, a, c->arc_strip, nlev, nrows);
+      double *one[1] = {a};
+      arctic_pack_launch(c, c->stream, one, 1, c->arc_strip, nlev, nrows);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     pthread_barrier_wait(&G->bar);                       // every strip is complete
@@ -296,7 +310,9 @@ static int xctilr_arctic_strips(blomgpu_ctx *c, double *a, int nlev, int mhl, in
   }
   if (top) {
     const dim3 gf((unsigned)(((h.ii + 2 * mhl) * (nhl + 1) + 255) / 256), nlev > 64 ? 64 : nlev);
-    hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.px, nlev, mhl, nhl, itype, nrows);
+    FillSet F;
+    for (int f = 0; f < 4; f++) { F.a[f] = a; F.itype[f] = itype; F.off[f] = 0; }
+    hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, F, tab, T.npx, T.px, nlev, mhl, nhl, nrows);
     HIPCHK(c, hipGetLastError());
   }
   if (!T.rccl) {                                         // nobody repacks before everybody has read
@@ -322,12 +338,10 @@ static int xctilr_arctic_rccl_multi(blomgpu_ctx *c, int nf, double *const *ptrs,
   for (int q = 0; q < XCT_MAXTILES; q++) tab.p[q] = nullptr;
   size_t fs = 0;
   if (int rc = rccl_arctic_gather(c, ptrs, nf, nlev, nrows, tab.p, &fs)) return rc;
-  const dim3 gf((unsigned)(((h.ii + 2 * mhl) * (nhl + 1) + 255) / 256), nlev > 64 ? 64 : nlev);
-  for (int f = 0; f < nf; f++) {
-    StripTab tf = tab;
-    for (int q = 0; q < T.npx; q++) tf.p[q] = tab.p[q] + (size_t)f * fs;
-    hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, ptrs[f], tf, T.npx, T.px, nlev, mhl, nhl, itypes[f], nrows);
-  }
+  const dim3 gf((unsigned)(((h.ii + 2 * mhl) * (nhl + 1) + 255) / 256), nlev > 64 ? 64 : nlev, nf);
+  FillSet F;
+  for (int f = 0; f < 4; f++) { F.a[f] = ptrs[f < nf ? f : 0]; F.itype[f] = itypes[f < nf ? f : 0]; F.off[f] = (size_t)(f < nf ? f : 0) * fs; }
+  hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, F, tab, T.npx, T.px, nlev, mhl, nhl, nrows);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
