@@ -537,6 +537,18 @@ int st_xctilr_multi(blomgpu_ctx *c, int nf, double *const *ptrs, const int *nlev
     }
     return 0;
   }
+  if (c->tiling.rccl && h.nreg != 2) {                 // runs of stacks of equal depth travel in one message per neighbour
+    const int mhl = mh < 0 ? 0 : (mh > NBDY ? NBDY : mh), nhl = nh < 0 ? 0 : (nh > NBDY ? NBDY : nh);
+    if (2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl) == 0) return 0;
+    for (int f = 0; f < nf;) {
+      int g = 1;
+      while (f + g < nf && g < 4 && nlevs[f + g] == nlevs[f]) g++;
+      if (nlevs[f] > 0)
+        if (int rc = rccl_xctilr_multi(c, ptrs + f, g, nlevs[f], mhl, nhl)) return rc;
+      f += g;
+    }
+    return 0;
+  }
   if (c->tiling.multi() || h.nreg == 2 || nf > XCT_MAXF) {
     for (int f = 0; f < nf; f++)
       if (int rc = st_xctilr(c, ptrs[f], 1, nlevs[f], mh, nh, itypes[f])) return rc;
