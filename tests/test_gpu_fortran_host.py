@@ -76,3 +76,39 @@ def test_fortran_hor3map_shim(tmp_path):
     # inputs are recomputed with another libm (sin): equal to rounding, not bitwise
     assert abs(got["sum_polycoeff"] - pc.sum()) <= 1e-9 * abs(pc).sum()
     assert abs(got["sum_remapped"] - ud.sum()) <= 1e-9 * abs(ud).sum()
+
+
+def test_fortran_driver_reproduces_reference_checksums_at_full_size(tmp_path):
+    """The north-star configuration end to end: a Fortran host program (blom_amd/fortran/blom_dyncore.F90, the shape
+    of the reference's drivers/nocoupler/blom.F) drives the device through the ISO_C_BINDING shim on BASELINE.json's
+    channel (208x512x53, default tracer set) for three steps and prints, with the reference's chksum line format, the
+    checksums the REFERENCE's own Fortran produced (tests/golden/channel_tke_crc.json, after tmsmt2 of step 3)."""
+    import json
+    import shutil
+    import numpy as np
+    from blom_amd.gpu import BlomGpu
+    from blom_amd import hostinit
+    exe = os.path.join(ROOT, "blom_amd", "lib", "blom_dyncore")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built")
+    if shutil.disk_usage(str(tmp_path)).free < 16 << 30:
+        pytest.skip("less than 16 GiB free for the state file")
+    cfg = "channel_tke"
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", f"{cfg}_crc.json")))
+    nsteps = gold["nsteps"]
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    # the device zero-initialises its arrays: only fields the initialisation filled need to travel
+    names = [n for n in STATE_FIELDS + GRID_FIELDS + INT_FIELDS if gpu.has_field(n) and np.any(gpu.get(n))]
+    state = str(tmp_path / "blom_state.bin")
+    write_state(state, gpu, case, nsteps, names)
+    gpu.close()
+    out = subprocess.run([exe, state], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    os.remove(state)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"chksum: (\w+): 0x([0-9A-Fa-f]+)", out.stdout)}
+    want = {nm: gold["crc"][str(nsteps)]["tmsmt2"][nm] for nm in ("dp", "temp", "u")}
+    assert got == want, (got, want)
+    assert open(tmp_path / "run.status").read().strip() == "success"
