@@ -206,6 +206,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "momtum_chunk") { c->momtum_chunk = v; return 0; }
+  if (s == "diffus_shfl") { c->diffus_shfl = v; return 0; }
   return ctx_fail(c, "blomgpu_set_int: unknown option " + s);
 }
 
