@@ -210,7 +210,7 @@ def _depth_for(name, idm, jdm, dx):
     raise KeyError(name)
 
 
-def make_case(name, ntr=None, **overrides):
+def make_case(name, ntr=None, carve=None, **overrides):
     """`<grid>_tke`: the grid with the reference's default tracer set (meson_options.txt:17-21: turbclo = oneeq +
     advection, iage => -DTKE -DTKEADV -DIDLAGE): ntr = 3 = TKE, the generic-length-scale slot, ideal age
     (trc/mod_tracers.F90:85-127).  Without the suffix: the -DTRC -DIDLAGE build, ntr = 1."""
@@ -233,6 +233,8 @@ def make_case(name, ntr=None, **overrides):
 
     depth = np.zeros((nj, ni))
     depth[NBDY:NBDY + jdm, NBDY:NBDY + idm] = _depth_for(name, idm, jdm, dx)
+    if carve is not None:          # test hook: edit the interior bathymetry (0 = land) before the state is derived from it
+        carve(depth[NBDY:NBDY + jdm, NBDY:NBDY + idm])
 
     # ---- grid metrics: uniform Cartesian f-plane (channel/mod_channel.F90:140-161) ----
     g = {}

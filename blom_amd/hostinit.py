@@ -118,6 +118,16 @@ def bigrid_np(depth_in, idm, jdm, arctic=False):
     if not lperiodi:
         depth[:, :o + 1] = 0.0
         depth[:, o + ii + 1:] = 0.0
+    # single-width inlets and 1-point seas are refused, as the reference does (:164-195: "Must correct bathymetry
+    # before running BLOM", xcstop)
+    J, I = sl(1, jj), sl(1, ii)
+    wet = depth[J, I] > 0.0
+    nzero = ((depth[J, sl(0, ii - 1)] <= 0.0).astype(int) + (depth[J, sl(2, ii + 1)] <= 0.0)
+             + (depth[sl(0, jj - 1), I] <= 0.0) + (depth[sl(2, jj + 1), I] <= 0.0))
+    bad = np.argwhere(wet & (nzero >= 3))
+    if len(bad):
+        raise ValueError("bigrid: must correct bathymetry before running BLOM: " +
+                         ", ".join(f"dh({i + 1},{j + 1}) has {nzero[j, i]} land neighbours" for j, i in bad[:8]))
     nj, ni = depth.shape
     ip = (depth > 0.0).astype(np.int32)
     iu = np.zeros_like(ip)
