@@ -46,8 +46,9 @@ if len(sys.argv) > 5:
     nsteps_pmc = max(fe[k][0] for k in fe if k.startswith("k_mom_update")) if any(k.startswith("k_mom_update") for k in fe) else 1
     cls = collections.defaultdict(float)
     for k in fe:
+        kk_ = k[5:] if k.startswith("void ") else k          # templated kernels are reported as "void name<..>"
         for pre, c in prefixes:
-            if k.startswith(pre):
+            if kk_.startswith(pre):
                 cls[c] += (1.5 * fe[k][1] + wr.get(k, [0, 0.0])[1]) * 1024.0 / nsteps_pmc
                 break
     if "pbcor" in cls:
