@@ -1,0 +1,54 @@
+"""Free run at BASELINE.json's channel size: the device-resident loop against the reference's own Fortran (OpenMP build,
+oracle/_ref/channel_tke_omp) for N steps from the same initial state, compared bit for bit every `every` steps.
+usage: python tools/gpu_fullsize_freerun.py [nsteps=100] [every=25]"""
+import os, sys, threading, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import numpy as np
+from blom_amd.cases import make_case
+from blom_amd import hostinit
+from blom_amd.stepper import dyncore_step
+from parity import copy_state, diff_report, fmt_report
+
+FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "trc", "p", "pb", "ub", "vb", "dpu", "dpv", "uflx", "vflx", "pgfx", "pgfy",
+          "ubflxs_p", "pb_p", "kfpla"]
+
+
+def body(nsteps, every):
+    from oracle.refblom import get_ref_backend
+    from blom_amd.gpu import BlomGpu
+    cfg = "channel_tke"
+    case = make_case(cfg)
+    ref = get_ref_backend(cfg + "_omp", case.depth)
+    hostinit.init_state(ref, case)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            gpu.set(nm, v)
+    copy_state(ref, gpu)
+    gpu.set("delt1", case.params["baclin"])
+    nr = ng = 0
+    t0 = time.time()
+    while nr < nsteps:
+        for _ in range(min(every, nsteps - nr)):
+            nr = dyncore_step(ref, nr, case.params["baclin"])
+        ng = gpu.step(ng, nr - ng)
+        gpu.sync()
+        bad = diff_report(ref, gpu, fields=FIELDS)
+        ua = np.abs(np.asarray(ref.get("u")))
+        umax = float(ua[ua < 1e30].max())                       # land points hold the reference's fill value
+        print(f"step {nr}: {'bit-identical in ' + str(len(FIELDS)) + ' fields' if not bad else 'DIFFERS'}; max|u| = {umax:.4f} m/s; "
+              f"{time.time() - t0:.0f} s", flush=True)
+        if bad:
+            print(fmt_report(bad[:10]), flush=True)
+            break
+    gpu.close()
+
+
+os.environ["OMP_NUM_THREADS"] = str(min(16, os.cpu_count() or 1))
+os.environ["OMP_STACKSIZE"] = "1G"
+threading.stack_size(2 << 30)
+a = sys.argv[1:]
+th = threading.Thread(target=body, args=(int(a[0]) if a else 100, int(a[1]) if len(a) > 1 else 25))
+th.start()
+th.join()
