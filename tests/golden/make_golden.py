@@ -4,8 +4,9 @@
 build container only:   python tests/golden/make_golden.py [cfg ...]      (default: all)
 
 Per configuration (chan_s, box_s; for fuk95 -- the reference's own test case, 156x32x12 --, tri_s -- arctic patch --,
-chan_s_tke -- the reference's default tracer set, ntr = 3 -- and channel_tke -- BASELINE.json's channel at full size,
-208x512x53, ntr = 3, the bench workload, prognostic fields only -- only the CRC file: their inputs are the analytic
+chan_s_tke -- the reference's default tracer set, ntr = 3 --, channel_tke -- BASELINE.json's channel at full size,
+208x512x53, ntr = 3, the bench workload, prognostic fields only -- and tnx2v1s_tke -- the tnx2v1 grid's dimensions,
+180x193x53, arctic patch, synthetic bathymetry -- only the CRC file: their inputs are the analytic
 host initialisation, which the tests redo):
   <cfg>_init.npz   complete model state + masks + grid after host initialisation (the inputs)
   <cfg>_crc.json   for steps 1..NSTEPS and every stage of the dyncore sequence: the reference's own
@@ -44,12 +45,13 @@ CHANNEL_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "trc", "p", "dpu", "d
 
 def generate(cfg):
     global NSTEPS
-    crc_only = cfg in ("fuk95", "tri_s", "chan_s_tke", "channel_tke")
+    big = cfg.startswith("channel") or cfg.startswith("tnx2v1s")
+    crc_only = big or cfg in ("fuk95", "tri_s", "chan_s_tke")
     NSTEPS = 2 if cfg == "fuk95" else 3
     case = make_case(cfg)
     # the channel-sized reference is built with its OpenMP directives on (same results, oracle/Makefile)
-    ref = get_ref_backend(cfg + "_omp" if cfg.startswith("channel") else cfg, case.depth)
-    crc_fields = CHANNEL_FIELDS if cfg.startswith("channel") else CRC_FIELDS
+    ref = get_ref_backend(cfg + "_omp" if big else cfg, case.depth)
+    crc_fields = CHANNEL_FIELDS if big else CRC_FIELDS
     hostinit.init_state(ref, case)
     init = {nm: ref.get(nm).copy() for nm in STATE_FIELDS + GRID_FIELDS + INT_FIELDS if ref.ref.has_field(nm) or nm in ("trc",)}
     for m in ("ip", "iu", "iv", "iq"):
@@ -83,7 +85,7 @@ def generate(cfg):
 
 if __name__ == "__main__":
     import threading
-    cfgs = sys.argv[1:] or ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "channel_tke"]
+    cfgs = sys.argv[1:] or ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke"]
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     os.environ["OMP_STACKSIZE"] = "1G"
     threading.stack_size(2 << 30)            # the reference keeps stage-local 2-D work arrays on the stack

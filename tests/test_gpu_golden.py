@@ -68,12 +68,12 @@ def test_device_reproduces_golden_fixtures(cfg):
     gpu.close()
 
 
-@pytest.mark.parametrize("cfg", ["fuk95", "tri_s", "chan_s_tke", "channel_tke"])
+@pytest.mark.parametrize("cfg", ["fuk95", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke"])
 def test_device_reproduces_reference_checksums_from_analytic_init(cfg):
     """Fixtures that hold only the reference's per-stage checksums; the inputs are the analytic host initialisation.
     channel_tke is BASELINE.json's channel at full size (208x512x53, ntr = 3, the bench workload): the device must
     produce the checksums the reference's own Fortran produced for every recorded field after every stage of three
-    steps.  The checksums are taken on the device (blomgpu_crc = xccrc, phy/mod_xc.F90:4164)."""
+    steps; tnx2v1s_tke has the dimensions of the tnx2v1 production grid (180x193x53) with the arctic patch.  The checksums are taken on the device (blomgpu_crc = xccrc, phy/mod_xc.F90:4164)."""
     from blom_amd.gpu import BlomGpu
     from blom_amd import hostinit
     from blom_amd.checksum import grid_of

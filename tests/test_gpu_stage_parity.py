@@ -135,17 +135,18 @@ def test_freerun_device_resident(cfg, nsteps, rtol):
     assert not bad, fmt_report(bad)
 
 
-def test_full_size_matches_reference():
-    """BASELINE.json's channel (208x512x53) with the reference's default tracer set (ntr = 3), the bench workload:
-    the device-resident sequence against the reference's own Fortran (built with its OpenMP directives,
-    oracle/_ref/channel_tke_omp) over the forward step and three leap-frog steps.  Bit for bit."""
+@pytest.mark.parametrize("cfg", ["channel_tke", "tnx2v1s_tke"])
+def test_full_size_matches_reference(cfg):
+    """BASELINE.json's channel (208x512x53) with the reference's default tracer set (ntr = 3), the bench workload, and
+    the tnx2v1 grid's dimensions (180x193x53, arctic patch, synthetic bathymetry): the device-resident sequence against
+    the reference's own Fortran (built with its OpenMP directives, oracle/_ref/<cfg>_omp) over the forward step and
+    three leap-frog steps.  Bit for bit."""
     import os
     import threading
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
-    cfg = "channel_tke"
     if not have_ref(cfg + "_omp"):
-        pytest.skip("oracle/_ref/channel_tke_omp/libblomref.so not built")
+        pytest.skip(f"oracle/_ref/{cfg}_omp/libblomref.so not built")
     nsteps, res = 4, {}
 
     def body():
