@@ -1,6 +1,6 @@
 """Free run at BASELINE.json's channel size: the device-resident loop against the reference's own Fortran (OpenMP build,
 oracle/_ref/channel_tke_omp) for N steps from the same initial state, compared bit for bit every `every` steps.
-usage: python tools/gpu_fullsize_freerun.py [nsteps=100] [every=25]"""
+usage: python tools/gpu_fullsize_freerun.py [nsteps=100] [every=25] [cfg=channel_tke | tnx2v1s_tke]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
@@ -14,10 +14,9 @@ FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "trc", "p", "pb", "ub", "vb",
           "ubflxs_p", "pb_p", "kfpla"]
 
 
-def body(nsteps, every):
+def body(nsteps, every, cfg):
     from oracle.refblom import get_ref_backend
     from blom_amd.gpu import BlomGpu
-    cfg = "channel_tke"
     case = make_case(cfg)
     ref = get_ref_backend(cfg + "_omp", case.depth)
     hostinit.init_state(ref, case)
@@ -49,6 +48,7 @@ os.environ["OMP_NUM_THREADS"] = str(min(16, os.cpu_count() or 1))
 os.environ["OMP_STACKSIZE"] = "1G"
 threading.stack_size(2 << 30)
 a = sys.argv[1:]
-th = threading.Thread(target=body, args=(int(a[0]) if a else 100, int(a[1]) if len(a) > 1 else 25))
+th = threading.Thread(target=body, args=(int(a[0]) if a else 100, int(a[1]) if len(a) > 1 else 25,
+                                        a[2] if len(a) > 2 else "channel_tke"))
 th.start()
 th.join()
