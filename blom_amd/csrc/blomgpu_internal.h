@@ -14,6 +14,15 @@
 
 #define NBDY 4
 
+// every vector-memory operation of this wave has completed (inline asm: invisible to the compiler pass that would
+// otherwise drop the wait behind a release fence, MI355X_MICROARCH.md "Compiler hazard").  tests/hostemu compiles
+// these sources for the host to check kernel logic on the CPU; there the wait is empty.
+#ifdef BLOM_HOSTEMU
+#define WAIT_VMCNT0() ((void)0)
+#else
+#define WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // ---- field table -------------------------------------------------------------------
 // X(name, levels) with levels in terms of K = kdm and NT = ntr.
 #define BLOM_REAL_FIELDS(X)                                                              \

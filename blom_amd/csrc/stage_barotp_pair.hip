@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
           __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAIT_VMCNT0();
       }
       // one LDS word tells the other waves about an abort
       if (tid == 0) s_abort = aborted ? 1 : 0;
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
     }
   }
   if (PERSIST) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the count goes out
+    WAIT_VMCNT0();     // every storing wave drains before the count goes out
     __syncthreads();
     done_iters++;
     if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + bx), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

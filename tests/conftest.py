@@ -9,3 +9,17 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` via gpurun)")
+
+
+# BLOM_HOSTEMU=1: run the `-m gpu` tests on the CPU against tests/hostemu/libblomgpu_hostemu.so -- the device
+# library's own sources compiled for the host with an emulation shim (tests/hostemu/shim/hip/hip_runtime.h).  A
+# development aid for checking kernel logic before GPU time is spent; never set on the GPU box, and nothing in the
+# product looks at it.
+if os.environ.get("BLOM_HOSTEMU") == "1":
+    import blom_amd.gpu as _g
+    import blom_amd.hor3map as _h
+    _emu = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostemu", "libblomgpu_hostemu.so")
+    if not os.path.exists(_emu):
+        raise RuntimeError("BLOM_HOSTEMU=1 but tests/hostemu/libblomgpu_hostemu.so is missing: make -C tests/hostemu")
+    _g.LIB_PATH = _emu
+    _h._LIB = _emu

@@ -28,8 +28,8 @@ if len(sys.argv) > 5:
     with open(f"profiles/{tag}_pmc_hbm_traffic.txt", "w") as f:
         f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 2 (channel 208x512x53, ntr = {ntr})\n")
         f.write("# per-launch averages in MB (counters are in KB).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports\n")
-        f.write("# half the bytes of a wide coalesced stream: fetch_x2 is the corrected estimate for 16 B/lane streams; the 8 B/lane loads of\n")
-        f.write("# these fp64 kernels calibrated at ~1.5x on this code (DESIGN.md 4), so the truth lies between the two columns.\n")
+        f.write("# half the bytes of a coalesced stream, for the 8 B/lane loads of these fp64 kernels as for 16 B/lane ones (calibrated on known\n")
+        f.write("# byte counts: tools/probes/fetch_calib.hip, profiles/r02_fetch_calibration.txt): fetch_x2 is the corrected figure.\n")
         f.write(f"# {'kernel':30s} {'launches':>8s} {'fetch_MB':>10s} {'fetch_x2_MB':>12s} {'write_MB':>10s}\n")
         ks = sorted(fe, key=lambda k: -(fe[k][1] + wr.get(k, [0, 0])[1]))
         for k in ks[:40]:
@@ -37,8 +37,8 @@ if len(sys.argv) > 5:
             w = wr.get(k, [1, 0.0])
             f.write(f"{k[:32]:32s} {n:8d} {v / n / 1024:10.2f} {2 * v / n / 1024:12.2f} {w[1] / max(1, w[0]) / 1024:10.2f}\n")
     # per bench class (bench.py `stages_ms` keys): HBM bytes per baroclinic step from the two PMC passes,
-    # fetch corrected by the 1.5x calibrated for the 8 B/lane loads of these fp64 kernels (DESIGN.md 4;
-    # the guide's 2x holds for 16 B/lane streams), writes as counted.  bench.py reports it as roofline.traffic.
+    # fetch corrected by the 2.0x calibrated for the 8 B/lane loads of these fp64 kernels
+    # (profiles/r02_fetch_calibration.txt), writes as counted.  bench.py reports it as roofline.traffic.
     import json
     prefixes = [("k_mom_", "momtum"), ("k_remap_", "remap"), ("k_adv_", "remap"), ("k_cppm_", "cppm"),
                 ("k_diffus_", "diffus"), ("k_pgf_", "pgforc"), ("k_diapfl_", "diapfl"), ("k_convec_", "convec"),
@@ -49,13 +49,13 @@ if len(sys.argv) > 5:
         kk_ = k[5:] if k.startswith("void ") else k          # templated kernels are reported as "void name<..>"
         for pre, c in prefixes:
             if kk_.startswith(pre):
-                cls[c] += (1.5 * fe[k][1] + wr.get(k, [0, 0.0])[1]) * 1024.0 / nsteps_pmc
+                cls[c] += (2.0 * fe[k][1] + wr.get(k, [0, 0.0])[1]) * 1024.0 / nsteps_pmc
                 break
     if "pbcor" in cls:
         cls["pbcor1"] = cls["pbcor2"] = cls.pop("pbcor") / 2
     with open(f"profiles/{tag}_class_traffic.json", "w") as f:
         json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                   "correction": "1.5 x FETCH_SIZE + WRITE_SIZE, bytes per baroclinic step and class",
+                   "correction": "2.0 x FETCH_SIZE (calibrated: profiles/r02_fetch_calibration.txt) + WRITE_SIZE, bytes per baroclinic step and class",
                    "ntr": ntr,
                    "bytes_per_step": {k: round(v) for k, v in sorted(cls.items())}}, f, indent=1)
 print(open(f"profiles/{tag}_kernel_stats.txt").read()[:3500])
