@@ -74,7 +74,7 @@
   /* (K+1)-level work fields (phip of pgforc_geopotential, ...) */                       \
   X(wkp0, K + 1) X(wkp1, K + 1)
 
-#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1) X(cppm_sti, 1) X(cppm_stj, 1)
+#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1) X(cppm_sti, 1) X(cppm_stj, 1) X(mpack, 1)
 
 enum FieldId {
 #define X(name, lev) F_##name,
@@ -208,6 +208,8 @@ struct blomgpu_ctx {
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int momtum_chunk = 0;      // layers per launch group of momtum's layer kernels (0: all)
+  int momtum_v = 2;          // 2: row-marching fused layer kernels (stage_momtum_fused.hip), 1: one kernel per sweep
+  int momtum_chunks_a = 0, momtum_chunks_b = 0;   // j-chunks per layer of the two fused kernels (0: one round of workgroups)
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   double *arc_strip = nullptr;                 // arctic patch, tiles of one process in strips mode: this tile's strip
@@ -221,6 +223,7 @@ struct blomgpu_ctx {
 };
 
 int  ctx_fail(blomgpu_ctx *c, const std::string &msg);
+int  ctx_pack_masks(blomgpu_ctx *c);     // mpack = ip | iu << 1 | iv << 2 | iq << 3, after any upload of a mask
 void ctx_sync_view(blomgpu_ctx *c);      // uploads h -> d if dirty
 #define HIPCHK(c, call)                                                                   \
   do {                                                                                    \
@@ -249,6 +252,7 @@ int st_pbcor2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_diffus(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_pgforc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_momtum_fused_layers(blomgpu_ctx *, int m, int n, int mm, int nn);
 int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_convec(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_updtrc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);

@@ -28,15 +28,7 @@
 // Roofline: HBM.
 #include "blomgpu_internal.h"
 
-#define GRAV 9.806
-#define ALPHA0 1.e-3
-#define EPSILPL 1.e-14
-#define EPSILP 1.e-12
-#define ONEM 9806.
-#define ONEMM 9.806
-#define SLIP (-1.)      // phy/mod_momtum.F90:94
-#define THKBOT 10.      // phy/mod_momtum.F90:97
-#define WPGF .25        // phy/mod_pgforc.F90:47
+#include "momtum_common.h"
 
 #define THREAD_IJ(V)                                                       \
   unsigned bx_, by_;                                                       \
@@ -55,7 +47,6 @@ enum {
 };
 #define S2_DRAG 3      // 2-D work plane
 
-__device__ inline double hfharm(double a, double b) { return a * b / (a + b); }   // :131-141
 
 // pu(k+1) = pu(k) + dpu(k+off), same for pv; range lo..+hi (:322-338 with lo=-1,hi=2; :1252-1267 interior)
 __global__ void k_mom_pupv(const DevView *Vp, int off, int lo, int hi) {
@@ -293,19 +284,6 @@ __global__ void k_mom_vort(const DevView *Vp, int mm, int klo) {
   }
 }
 
-// ---- :662-715 min,max transports for the energy conserving scheme with dissipation (mommth = 'enedis') --
-__device__ inline void enedis_minmax(double hc, double hm, double &hmin, double &hmax) {
-  const double c1 = 1. - 1.5 * .5, c2 = 1. - .5, c3 = 2., slope = .5;                 // :221
-  if (fabs(hc) < .1 * fabs(hm)) hm = 10. * hc;
-  else if (fabs(hc) > c1 * fabs(hm)) {
-    if (fabs(hc) < c2 * fabs(hm)) hc = (3. * hc + (1. - c2 * 3.) * hm);
-    else if (fabs(hc) <= c3 * fabs(hm)) hc = hm;
-    else hc = slope * hc + (1. - c3 * slope) * hm;
-  }
-  if (hc > hm) { hmin = hm; hmax = hc; }
-  else { hmax = hm; hmin = hc; }
-}
-
 __global__ void k_mom_enedis(const DevView *Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
@@ -343,15 +321,6 @@ __global__ void k_mom_visc(const DevView *Vp, int klo) {
     WK(V, M_VSC2V)[c + ok] = fmax2(q * P.mdv2hi + (1. - q) * P.mdv2lo, (q * P.vsc2hi + (1. - q) * P.vsc2lo) * deform);
     WK(V, M_VSC4V)[c + ok] = fmax2(q * P.mdv4hi + (1. - q) * P.mdv4lo, (q * P.vsc4hi + (1. - q) * P.vsc4lo) * deform);
   }
-}
-
-// viscosity at x along a row, extended one point beyond wet u-segments (:845-856): a land point
-// takes the value of the u-point to its right (segment start, written last) else of the one to its left
-__device__ inline double ext_i(const int *msk, const double *f, size_t x) {
-  return msk[x] ? f[x] : (msk[x + 1] ? f[x + 1] : f[x - 1]);
-}
-__device__ inline double ext_j(const int *msk, const double *f, size_t x, int ni) {
-  return msk[x] ? f[x] : (msk[x + ni] ? f[x + ni] : f[x - ni]);
 }
 
 // ---- :860-873 and :1019-1034 longitudinal turbulent momentum fluxes at p-points ------------------------
@@ -560,6 +529,7 @@ int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   hipLaunchKernelGGL(k_mom_drag, gcol, b64, 0, c->stream, c->d, n, nn);
   hipLaunchKernelGGL(k_mom_pupv, gcol, b64, 0, c->stream, c->d, mm, -1, 2);
   if (int rc = st_xctilr(c, h.f[F_difwgt], 1, 1, 2, 2, 1)) return rc;                       // :340
+  if (c->momtum_v == 2) return st_momtum_fused_layers(c, m, n, mm, nn);                     // stage_momtum_fused.hip
   // The layer loop (:342) in chunks: a chunk's ~55 planes (inputs, ~30 temporaries, outputs) of `ch` layers each are
   // produced and consumed by consecutive kernels while they still sit in the 256 MiB Infinity Cache.
   const int ch = c->momtum_chunk > 0 ? c->momtum_chunk : h.kk;

@@ -23,3 +23,11 @@ if os.environ.get("BLOM_HOSTEMU") == "1":
         raise RuntimeError("BLOM_HOSTEMU=1 but tests/hostemu/libblomgpu_hostemu.so is missing: make -C tests/hostemu")
     _g.LIB_PATH = _emu
     _h._LIB = _emu
+
+
+    def pytest_collection_modifyitems(config, items):
+        # what the emulation cannot stand in for: the Fortran host program (links the real library) and full-size runs
+        skip = pytest.mark.skip(reason="not under BLOM_HOSTEMU")
+        for it in items:
+            if "test_gpu_fortran_host" in it.nodeid or "full_size" in it.nodeid:
+                it.add_marker(skip)

@@ -130,3 +130,5 @@ inline int __any(int pred) { return pred; }
 #include <algorithm>
 using std::max;
 using std::min;
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
