@@ -56,7 +56,7 @@ static void set_eos(Params &P) {
 }
 
 // the four wet masks of a point in one word (bit 0 ip, 1 iu, 2 iv, 3 iq): one load instead of four in the fused kernels
-__global__ void k_pack_masks(const DevView *Vp) {
+__global__ void k_pack_masks(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -207,7 +207,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   Params &P = c->h.P;
   std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
-  R(lstep) R(nstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  if (s == "nstep") { P.nstep = v; return 0; }      // host-side only (stage_cppm.hip): the device view is not touched
+  R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   if (s == "csdiag") return 0;
   if (s == "timing") { c->timing = v != 0; return 0; }
@@ -221,6 +222,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "momtum_chunk") { c->momtum_chunk = v; return 0; }
   if (s == "momtum_v") { c->momtum_v = v; return 0; }
+  if (s == "momtum_bs") { c->momtum_bs = v; return 0; }
+  if (s == "momtum_order") { c->momtum_order = v; return 0; }
   if (s == "momtum_chunks_a") { c->momtum_chunks_a = v; return 0; }
   if (s == "momtum_chunks_b") { c->momtum_chunks_b = v; return 0; }
   if (s == "diffus_shfl") { c->diffus_shfl = v; return 0; }
@@ -461,8 +464,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     const int ns = *nstep;
     const int m = ns % 2 + 1, n = (ns + 1) % 2 + 1;
     const int mm = (m - 1) * kk, nn = (n - 1) * kk, k1m = 1 + mm, k1n = 1 + nn;
-    c->h.P.nstep = ns + 1;
-    c->dirty = true;
+    c->h.P.nstep = ns + 1;                             // read by host code only: no upload of the view for it
     static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
                                 "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
                                 "barotp", "pbcor2", "tmsmt2"};
@@ -471,8 +473,8 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
       if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
     c->defer_checks = false;
     if (int rc = ctx_check_errors(c)) return rc;
-    c->h.P.delt1 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300
-    c->dirty = true;
+    const double delt2 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300
+    if (c->h.P.delt1 != delt2) { c->h.P.delt1 = delt2; c->dirty = true; }   // changes after the first step only
     *nstep = ns + 1;
   }
   return 0;

@@ -209,6 +209,8 @@ struct blomgpu_ctx {
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int momtum_chunk = 0;      // layers per launch group of momtum's layer kernels (0: all)
   int momtum_v = 2;          // 2: row-marching fused layer kernels (stage_momtum_fused.hip), 1: one kernel per sweep
+  int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major
+  int momtum_bs = 0;         // lanes per workgroup of the fused kernels (0: 64, one wavefront)
   int momtum_chunks_a = 0, momtum_chunks_b = 0;   // j-chunks per layer of the two fused kernels (0: one round of workgroups)
   int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation

@@ -34,7 +34,7 @@ struct FieldSet {
 // neighbour's east halo), east buffer <- my east-most mhl columns, rows 1-nhl..jj+nhl.  The strip rows
 // outside 1..jj are the very values phase 1 writes, so the packer derives them itself instead of
 // waiting for them.  Buffer layout [field][level][row][q].
-__global__ void k_pack_ew_ns(const DevView *Vp, FieldSet F, double *__restrict__ west, double *__restrict__ east,
+__global__ void k_pack_ew_ns(const DevView *__restrict__ Vp, FieldSet F, double *__restrict__ west, double *__restrict__ east,
                              int nlev, int mhl, int nhl, int periodic, int gpack, int rows_present) {
   const DevView &V = *Vp;
   double *a = F.p[blockIdx.z];
@@ -69,7 +69,7 @@ __global__ void k_pack_ew_ns(const DevView *Vp, FieldSet F, double *__restrict__
 
 // unpack: from_west holds the west neighbour's east-most columns -> my columns 1-mhl..0;
 //         from_east holds the east neighbour's west-most columns -> my columns ii+1..ii+mhl
-__global__ void k_unpack_ew(const DevView *Vp, FieldSet F, const double *__restrict__ from_west,
+__global__ void k_unpack_ew(const DevView *__restrict__ Vp, FieldSet F, const double *__restrict__ from_west,
                             const double *__restrict__ from_east, int nlev, int mhl, int nhl, int has_w, int has_e) {
   const DevView &V = *Vp;
   const int nrow = V.jj + 2 * nhl, per = mhl * nrow;
@@ -88,7 +88,7 @@ __global__ void k_unpack_ew(const DevView *Vp, FieldSet F, const double *__restr
 
 // phase 1 as an exchange (npy > 1): rows of the columns 1..ii.  south buffer <- my rows 1..nhl (they
 // become the south neighbour's north halo), north buffer <- my rows jj-nhl+1..jj.  Layout [field][level][r][i].
-__global__ void k_pack_ns(const DevView *Vp, FieldSet F, double *__restrict__ south, double *__restrict__ north,
+__global__ void k_pack_ns(const DevView *__restrict__ Vp, FieldSet F, double *__restrict__ south, double *__restrict__ north,
                           int nlev, int nhl) {
   const DevView &V = *Vp;
   const int per = nhl * V.ii;
@@ -105,7 +105,7 @@ __global__ void k_pack_ns(const DevView *Vp, FieldSet F, double *__restrict__ so
 }
 // from_south holds the south neighbour's north-most rows -> my rows 1-nhl..0; from_north the north
 // neighbour's south-most rows -> my rows jj+1..jj+nhl; vland where the domain is closed
-__global__ void k_unpack_ns(const DevView *Vp, FieldSet F, const double *__restrict__ from_south,
+__global__ void k_unpack_ns(const DevView *__restrict__ Vp, FieldSet F, const double *__restrict__ from_south,
                             const double *__restrict__ from_north, int nlev, int nhl, int has_s, int has_n) {
   const DevView &V = *Vp;
   const int per = nhl * V.ii;

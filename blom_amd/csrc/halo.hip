@@ -18,7 +18,7 @@ struct HaloSrc {
   const double *p[3][3];
 };
 
-__global__ void k_xctilr_gather(const DevView *Vp, double *__restrict__ a, HaloSrc S, int nlev, int mhl, int nhl) {
+__global__ void k_xctilr_gather(const DevView *__restrict__ Vp, double *__restrict__ a, HaloSrc S, int nlev, int mhl, int nhl) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj;
   // enumerate halo targets: N/S strips (2*nhl rows x ii) then E/W strips (2*mhl cols x (jj+2nhl))
@@ -52,7 +52,7 @@ __global__ void k_xctilr_gather(const DevView *Vp, double *__restrict__ a, HaloS
 // jj is a copy), vector fields change sign.  The reference's three sweeps only move data, so every
 // target (south rows, rows jj.., E/W strips of all those rows) is one composite gather; no source is
 // itself a target.
-__global__ void k_xctilr_arctic(const DevView *Vp, double *__restrict__ a, int nlev, int mhl, int nhl, int itype) {
+__global__ void k_xctilr_arctic(const DevView *__restrict__ Vp, double *__restrict__ a, int nlev, int mhl, int nhl, int itype) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj;
   const int g = itype % 10;
@@ -106,7 +106,7 @@ __global__ void k_xctilr_arctic(const DevView *Vp, double *__restrict__ a, int n
 struct TileTab {
   double *p[XCT_MAXTILES];      // the array being updated, in every tile (index py*npx + px)
 };
-__global__ void k_xctilr_arctic_tiles(const DevView *Vp, double *__restrict__ a, TileTab tab, int npx, int npy,
+__global__ void k_xctilr_arctic_tiles(const DevView *__restrict__ Vp, double *__restrict__ a, TileTab tab, int npx, int npy,
                                       int px, int py, int nlev, int mhl, int nhl, int itype) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj, itdm = npx * ii, jtdm = npy * jj;
@@ -154,7 +154,7 @@ struct StripTab {
   const double *p[XCT_MAXTILES];      // strip of top-row tile qx
 };
 struct PackSet { const double *a[4]; };
-__global__ void k_arctic_pack(const DevView *Vp, PackSet P, double *__restrict__ strip0, int nlev, int nrows) {
+__global__ void k_arctic_pack(const DevView *__restrict__ Vp, PackSet P, double *__restrict__ strip0, int nlev, int nrows) {
   const DevView &V = *Vp;
   const double *__restrict__ a = P.a[blockIdx.z];
   double *__restrict__ strip = strip0 + (size_t)blockIdx.z * nrows * V.ii * nlev;
@@ -171,7 +171,7 @@ struct FillSet {                      // up to 4 stacks per launch (blockIdx.z):
   int itype[4];
   size_t off[4];
 };
-__global__ void k_arctic_fill(const DevView *Vp, FillSet F, StripTab tab, int npx, int px, int nlev, int mhl,
+__global__ void k_arctic_fill(const DevView *__restrict__ Vp, FillSet F, StripTab tab, int npx, int px, int nlev, int mhl,
                               int nhl, int nrows) {
   const DevView &V = *Vp;
   double *__restrict__ a = F.a[blockIdx.z];
@@ -398,7 +398,7 @@ struct HaloMulti {
   int nlev[XCT_MAXF];
 };
 
-__global__ void k_xctilr_multi(const DevView *Vp, HaloMulti M, int mhl, int nhl, int land_ew, int land_ns) {
+__global__ void k_xctilr_multi(const DevView *__restrict__ Vp, HaloMulti M, int mhl, int nhl, int land_ew, int land_ns) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj;
   const int nns = 2 * nhl * ii;
@@ -435,7 +435,7 @@ struct ArcticMulti {
   double *p[XCT_MAXF];
   int nlev[XCT_MAXF], itype[XCT_MAXF], mhl[XCT_MAXF], nhl[XCT_MAXF];
 };
-__global__ void k_xctilr_arctic_multi(const DevView *Vp, ArcticMulti M) {
+__global__ void k_xctilr_arctic_multi(const DevView *__restrict__ Vp, ArcticMulti M) {
   const DevView &V = *Vp;
   const int f = blockIdx.z;
   const int ii = V.ii, jj = V.jj, mhl = M.mhl[f], nhl = M.nhl[f], itype = M.itype[f];
@@ -603,7 +603,7 @@ __device__ inline unsigned crc_byte(unsigned crc, unsigned b) {
   return (crc >> 8) ^ k;
 }
 
-__global__ void k_crc_strips(const DevView *Vp, const double *__restrict__ a, int nlev,
+__global__ void k_crc_strips(const DevView *__restrict__ Vp, const double *__restrict__ a, int nlev,
                              const int *__restrict__ mask, int nstrip, unsigned *__restrict__ out) {
   const DevView &V = *Vp;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,7 +663,7 @@ int st_crc(blomgpu_ctx *c, const double *base, int nlev, int itype, unsigned *cr
 // the row sums are added serially: the order is part of the definition, so the rows go to the threads of ONE
 // workgroup and thread 0 adds the row sums.  The mask of the global sums is ips (phy/mod_inigeo.F90:189-208):
 // ip without the seam row of an arctic patch.  Single tile.
-__global__ void k_xcsum(const DevView *Vp, const double *__restrict__ a, const int *__restrict__ mask, int skip_seam,
+__global__ void k_xcsum(const DevView *__restrict__ Vp, const double *__restrict__ a, const int *__restrict__ mask, int skip_seam,
                         double *rowsum, double *out) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj;

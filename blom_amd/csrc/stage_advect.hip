@@ -59,7 +59,7 @@
   const size_t c = t_
 
 // ---- mod_advect.F90:71-94 --------------------------------------------------------------------
-__global__ void k_adv_flux_area(const DevView *Vp, int m, int mm, int nn) {
+__global__ void k_adv_flux_area(const DevView *__restrict__ Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -110,7 +110,7 @@ __device__ inline Nbr wet_nbr(const DevView &V, size_t c) {
 }
 
 // ---- mod_advect.F90:100-121 ---------------------------------------------------------------------
-__global__ void k_adv_pbmin(const DevView *Vp) {
+__global__ void k_adv_pbmin(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
@@ -161,7 +161,7 @@ __device__ inline void limited_gradient(const double *__restrict__ f, const Nbr 
 }
 
 // ---- mod_remap.F90:358-584 ---------------------------------------------------------------------
-__global__ void k_remap_grad(const DevView *Vp, int nn) {
+__global__ void k_remap_grad(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
@@ -318,7 +318,7 @@ __device__ inline void add_contrib(const DevView &V, size_t ok, const double *dp
 }
 
 // ---- mod_remap.F90:588-1462 ----------------------------------------------------------------------
-__global__ void k_remap_flux(const DevView *Vp, int n, int mm, int nn) {
+__global__ void k_remap_flux(const DevView *__restrict__ Vp, int n, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const int k = by_;
@@ -440,7 +440,7 @@ __global__ void k_remap_flux(const DevView *Vp, int n, int mm, int nn) {
 }
 
 // ---- mod_remap.F90:1468-1520 (+ the in-place dp side effect of :297-303 on the outer ring) --------
-__global__ void k_remap_update(const DevView *Vp, int nn) {
+__global__ void k_remap_update(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -2 || j > V.jj + 3 || i < -2 || i > V.ii + 3 || !V.m[I_ip][c]) return;

@@ -21,7 +21,7 @@
   const size_t c = t_
 
 // ---- :177-224 velocity bounds and coastal wave breaking coefficients (column max/min of u,v) ----
-__global__ void k_bt_bounds(const DevView *Vp, int m, int nn) {
+__global__ void k_bt_bounds(const DevView *__restrict__ Vp, int m, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -55,14 +55,14 @@ __global__ void k_bt_bounds(const DevView *Vp, int m, int nn) {
 // ---- :230-268 barotropic potential vorticity.  The reference writes pvtrop(:,:,n) in three
 // sweeps (u-point pairs, v-point pairs, interior q-points), later sweeps overriding earlier
 // ones; per q-point the surviving value is that of the LAST writer in that order. ------------
-__global__ void k_bt_pvtrop_old(const DevView *Vp, int n) {
+__global__ void k_bt_pvtrop_old(const DevView *__restrict__ Vp, int n) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -2 || j > V.jj + 3 || i < 0 || i > V.ii + 1) return;
   V.f[F_pvtrop_o][c] = V.f[F_pvtrop][c + (size_t)(n - 1) * V.nplane];
 }
 
-__global__ void k_bt_pvtrop(const DevView *Vp, int n) {
+__global__ void k_bt_pvtrop(const DevView *__restrict__ Vp, int n) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const int ii = V.ii, jj = V.jj, ni = V.ni;
@@ -92,7 +92,7 @@ __global__ void k_bt_pvtrop(const DevView *Vp, int n) {
 }
 
 // ---- nb == 1 reload of the subcycling state, :339-348 --------------------------------------------
-__global__ void k_bt_load(const DevView *Vp) {   // always into buffer set 0 (*_t)
+__global__ void k_bt_load(const DevView *__restrict__ Vp) {   // always into buffer set 0 (*_t)
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -104,7 +104,7 @@ __global__ void k_bt_load(const DevView *Vp) {   // always into buffer set 0 (*_
   }
 }
 
-__global__ void k_bt_zero_sums(const DevView *Vp) {       // :361-379
+__global__ void k_bt_zero_sums(const DevView *__restrict__ Vp) {       // :361-379
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j >= -1 && j <= V.jj + 2 && i >= 0 && i <= V.ii + 1 && V.m[I_iu][c]) { V.f[F_ubflxs_t][c] = 0.; V.f[F_ubcors_t][c] = 0.; }
@@ -119,7 +119,7 @@ struct BtArgs {
 };
 
 // ---- continuity, :401-411 / :626-636 ---------------------------------------------------------------
-__global__ void k_bt_cont(const DevView *Vp, BtArgs a) {
+__global__ void k_bt_cont(const DevView *__restrict__ Vp, BtArgs a) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < a.j0 || j > a.j1 || i < a.i0 || i > a.i1 || !V.m[I_ip][c]) return;
@@ -132,7 +132,7 @@ __global__ void k_bt_cont(const DevView *Vp, BtArgs a) {
 }
 
 // ---- u momentum, :420-457 / :745-781 (enscon) and :464-502 / :788-826 (enecon, enedis) ------------
-__global__ void k_bt_umom(const DevView *Vp, BtArgs a) {
+__global__ void k_bt_umom(const DevView *__restrict__ Vp, BtArgs a) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < a.j0 || j > a.j1 || i < a.i0 || i > a.i1 || !V.m[I_iu][c]) return;
@@ -167,7 +167,7 @@ __global__ void k_bt_umom(const DevView *Vp, BtArgs a) {
 }
 
 // ---- v momentum, :520-557 / :646-682 (enscon) and :564-602 / :690-728 ------------------------------
-__global__ void k_bt_vmom(const DevView *Vp, BtArgs a) {
+__global__ void k_bt_vmom(const DevView *__restrict__ Vp, BtArgs a) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < a.j0 || j > a.j1 || i < a.i0 || i > a.i1 || !V.m[I_iv][c]) return;
@@ -202,7 +202,7 @@ __global__ void k_bt_vmom(const DevView *Vp, BtArgs a) {
 }
 
 // ---- phase epilogues, :847-977 ------------------------------------------------------------------------
-__global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, int nl, int set) {
+__global__ void k_bt_epilogue(const DevView *__restrict__ Vp, int nb, int m, int n, int ml, int nl, int set) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -282,7 +282,7 @@ __global__ void k_bt_epilogue(const DevView *Vp, int nb, int m, int n, int ml, i
 
 // with the arctic patch umaxb/uminb, vmaxb/vminb, xixp/xixm, xiyp/xiym change roles in the halo next to the
 // grid intersection, phy/mod_barotp.F90:290-325
-__global__ void k_bt_arctic_swap(const DevView *Vp, int n) {
+__global__ void k_bt_arctic_swap(const DevView *__restrict__ Vp, int n) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;

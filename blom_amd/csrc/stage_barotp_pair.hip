@@ -60,7 +60,7 @@ struct PairArgs {
 // re-reads just the rim.  Reads alternate between the two buffer sets exactly as the launches did.
 // All workgroups must be resident: the launcher checks tiles <= CUs.
 template <bool PERSIST>
-__global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a) {
+__global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ Vp, PairArgs a) {
   const DevView &V = *Vp;
   __shared__ double s_pb[2][BJ][BI + 1], s_ub[2][BJ][BI + 1], s_vb[2][BJ][BI + 1];
   // coefficients that the momentum equations read at neighbouring points: staged once per launch
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *Vp, PairArgs a
 // Halo update of the three subcycling fields of buffer set `set`, both levels, in ONE launch:
 // widths (3,3), a superset of the reference's (2,2),(2,2),(2,3) at :395-397.  Same gather rule as
 // k_xctilr_single (halo.hip): closed direction -> vland, periodic direction -> wrapped source.
-__global__ void k_bt_halo3(const DevView *Vp, int set, int mhl, int nhl) {
+__global__ void k_bt_halo3(const DevView *__restrict__ Vp, int set, int mhl, int nhl) {
   const DevView &V = *Vp;
   const int ii = V.ii, jj = V.jj;
   const int nns = 2 * nhl * ii, new_ = 2 * mhl * (jj + 2 * nhl);

@@ -25,7 +25,7 @@
 #define MAXTR 8
 enum { CV_UN = 0 };   // work field: remapped velocity column
 
-__global__ __launch_bounds__(64) void k_convec_column(const DevView *Vp, int n, int nn, int *errflag) {
+__global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict__ Vp, int n, int nn, int *errflag) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *Vp, int n, 
 
 // :315-391: u (blockIdx.y = 0) / v (1) columns are remapped conservatively from the old interface
 // pressures at the velocity point (pu, pv) to the new ones
-__global__ __launch_bounds__(64) void k_convec_velocity(const DevView *Vp, int nn) {
+__global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *Vp, int n
 }
 
 // :393-414
-__global__ void k_convec_dpudpv(const DevView *Vp, int nn) {
+__global__ void k_convec_dpudpv(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);

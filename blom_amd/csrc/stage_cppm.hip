@@ -73,7 +73,7 @@ __device__ inline CppmTab cppm_tab(const DevView &V, int dir) {
   return T;
 }
 
-__global__ void k_cppm_init(const DevView *Vp) {
+__global__ void k_cppm_init(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const int dir = by_;
@@ -206,7 +206,7 @@ __global__ void k_cppm_init(const DevView *Vp) {
 }
 
 // stencil tag halo through a real plane, :2612-2614 / :2635-2637
-__global__ void k_cppm_tag_convert(const DevView *Vp, int dir, int back) {
+__global__ void k_cppm_tag_convert(const DevView *__restrict__ Vp, int dir, int back) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   (void)i; (void)j;
@@ -230,7 +230,7 @@ __device__ inline int cppm_mirror_tag(int st) {
     default: return st;
   }
 }
-__global__ void k_cppm_arctic_init_swap(const DevView *Vp) {
+__global__ void k_cppm_arctic_init_swap(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (V.j0 + V.jj != V.jtdm) return;                        // nproc == jpr
@@ -283,7 +283,7 @@ int st_init_cppm(blomgpu_ctx *c) {
 // (i sweeps :1531-1541 / :1848-1858: row jj, i = 1-w..ii+w; j sweeps :1686-1704 / :2002-2020: row jj from
 // the global mid column on, rows jj+1..jj+w for i = 1..ii)
 template <int DIR>
-__global__ void k_cppm_arctic_edge_swap(const DevView *Vp, int w) {
+__global__ void k_cppm_arctic_edge_swap(const DevView *__restrict__ Vp, int w) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (V.j0 + V.jj != V.jtdm) return;
@@ -311,7 +311,7 @@ __global__ void k_cppm_arctic_edge_swap(const DevView *Vp, int w) {
 
 // LIM = 0: non-oscillatory limiting (reach 4 cells along the sweep), 1: monotonic (reach 3)
 template <int DIR, int LIM>
-__global__ void k_cppm_hm(const DevView *Vp, int nn, int second_pass) {
+__global__ void k_cppm_hm(const DevView *__restrict__ Vp, int nn, int second_pass) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
@@ -387,7 +387,7 @@ __device__ inline void cppm_h_edges(const CppmTab &T, size_t c, int sd, const do
 }
 
 template <int DIR, int LIM>
-__global__ void k_cppm_hedges(const DevView *Vp) {
+__global__ void k_cppm_hedges(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
@@ -519,7 +519,7 @@ __device__ inline double *cppm_tracer(const DevView &V, int nt, int k, int nn) {
 // tracer edge values at every edge.  FC = 1: coefficients compatible with the thickness reconstruction
 // (4x4 LU, above); FC = 0 ('partial'): the thickness edge coefficients hevc (:1146-1157, :1296-1307)
 template <int DIR, int LIM, int FC>
-__global__ void k_cppm_tedge(const DevView *Vp, int nn, int ntl) {
+__global__ void k_cppm_tedge(const DevView *__restrict__ Vp, int nn, int ntl) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
@@ -539,7 +539,7 @@ __global__ void k_cppm_tedge(const DevView *Vp, int nn, int ntl) {
 // limiting and parabola coefficients: parabola_coeffs_fc_nosc :733-816, _fc_mono :1062-1114,
 // _pc_nosc :1159-1262, _pc_mono :1309-1369
 template <int DIR, int LIM, int FC>
-__global__ void k_cppm_parab(const DevView *Vp, int nn, int ntl) {
+__global__ void k_cppm_parab(const DevView *__restrict__ Vp, int nn, int ntl) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
@@ -662,7 +662,7 @@ __global__ void k_cppm_parab(const DevView *Vp, int nn, int ntl) {
 
 // flux_integration :1373-1468 + flux accumulation :1612-1618
 template <int DIR>
-__global__ void k_cppm_flux(const DevView *Vp, int n, int mm, int ntl) {
+__global__ void k_cppm_flux(const DevView *__restrict__ Vp, int n, int mm, int ntl) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);
@@ -728,7 +728,7 @@ __global__ void k_cppm_flux(const DevView *Vp, int n, int mm, int ntl) {
 
 // update with flux divergences, :1597-1610
 template <int DIR>
-__global__ void k_cppm_update(const DevView *Vp, int nn, int ntl) {
+__global__ void k_cppm_update(const DevView *__restrict__ Vp, int nn, int ntl) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   SWEEP_COORDS(V);

@@ -35,7 +35,7 @@ enum { D_TTEM, D_SSAL, D_DELP, D_DENS, D_NU, D_FPU, D_FPL, D_FCU, D_FCL, D_DSGU,
 
 #include "diapfl_common.h"
 
-__global__ void k_diapfl_column(const DevView *Vp, int n, int nn, int *__restrict__ errflag) {
+__global__ void k_diapfl_column(const DevView *__restrict__ Vp, int n, int nn, int *__restrict__ errflag) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -366,7 +366,7 @@ __global__ void k_diapfl_column(const DevView *Vp, int n, int nn, int *__restric
     for (int k = 1; k <= kk; k++) { V.f[F_fpug][c + (size_t)(k - 1) * np] = 0.; V.f[F_fplg][c + (size_t)(k - 1) * np] = 0.; }
 }
 
-__global__ void k_diapfl_kming(const DevView *Vp) {                                // :725-733
+__global__ void k_diapfl_kming(const DevView *__restrict__ Vp) {                                // :725-733
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][c]) return;
@@ -404,7 +404,7 @@ __device__ inline void diapfl_mom_flux(const double *p, const double *fpug, cons
   fpl_km1 = .5 * (fplm + fplp);
 }
 
-__global__ void k_diapfl_momentum(const DevView *Vp, int nn) {
+__global__ void k_diapfl_momentum(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -459,7 +459,7 @@ __global__ void k_diapfl_momentum(const DevView *Vp, int nn) {
 }
 
 // dpu/dpv at the new level from the updated p, :971-1000 (u: i 1..ii+1, j 1..jj ; v: i 1..ii, j 1..jj+1)
-__global__ void k_diapfl_dpudpv(const DevView *Vp, int nn) {
+__global__ void k_diapfl_dpudpv(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const int k = by_;

@@ -31,7 +31,7 @@ enum { E_SU, E_SL, E_FCU, E_FCL, E_FMAX, E_H, E_R, E_T, E_F, E_FT, E_GTD, E_NSLO
 
 // one wavefront per 64 columns and ~1700 wavefronts in all: occupancy cannot exceed 2 waves per SIMD anyway,
 // so let the register allocator use up to 256 VGPRs instead of spilling at 128
-__global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *Vp, int n, int nn, int *__restrict__ errflag) {
+__global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restrict__ Vp, int n, int nn, int *__restrict__ errflag) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
   if (t_ >= V.nplane) return;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *Vp, int
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk, ntr = V.ntr;
-  const Params &P = V.P;
+  const Params P = V.P;        // by value: the equation-of-state coefficients stay in registers across the stores
   const double dsgmnr = .1, fcmxr = .25, dsgcr0 = .25, dfeps = 1.e-12, gbbl = .2, kappa = .4, ustmin = .0001;
   const double cc = GRAV * GRAV * P.delt1 / (ALPHA0 * ALPHA0);                       // :95
   const double *sigr = V.f[F_sigmar];

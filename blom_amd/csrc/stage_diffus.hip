@@ -15,7 +15,7 @@
 // SHFL: the west neighbour's dp, S, T, difiso come from the adjacent lane (DPP row shift / __shfl_up) instead of a
 // second, cached load; lane 0 of a wavefront still loads.  A/B option diffus_shfl; measured 3 % slower than the cached load.
 template <bool SHFL>
-__global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
+__global__ void k_diffus_flux(const DevView *__restrict__ Vp, int mm, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -73,7 +73,7 @@ __global__ void k_diffus_flux(const DevView *Vp, int mm, int nn) {
   }
 }
 
-__global__ void k_diffus_update(const DevView *Vp, int mm, int nn) {
+__global__ void k_diffus_update(const DevView *__restrict__ Vp, int mm, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);

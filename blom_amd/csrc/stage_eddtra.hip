@@ -30,7 +30,7 @@
 // work-space slots per component: mfl needs kk+1 levels and borrows the first level of the next slot
 enum { G_MFL = 0, G_SPARE, G_DLM, G_DLP, G_NSLOT };
 
-__global__ void k_eddtra_gm(const DevView *Vp, int n, int mm, int nn, int *__restrict__ errflag) {
+__global__ void k_eddtra_gm(const DevView *__restrict__ Vp, int n, int mm, int nn, int *__restrict__ errflag) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -196,7 +196,7 @@ __global__ void k_eddtra_gm(const DevView *Vp, int n, int mm, int nn, int *__res
 }
 
 // interface diffusion, :152-226
-__global__ void k_eddtra_intdif(const DevView *Vp, int mm, int nn) {
+__global__ void k_eddtra_intdif(const DevView *__restrict__ Vp, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -233,7 +233,7 @@ __global__ void k_eddtra_intdif(const DevView *Vp, int mm, int nn) {
 }
 
 // heat and salt components, :1837-1857
-__global__ void k_eddtra_ts(const DevView *Vp, int mm) {
+__global__ void k_eddtra_ts(const DevView *__restrict__ Vp, int mm) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;

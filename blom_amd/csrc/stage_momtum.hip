@@ -49,7 +49,7 @@ enum {
 
 
 // pu(k+1) = pu(k) + dpu(k+off), same for pv; range lo..+hi (:322-338 with lo=-1,hi=2; :1252-1267 interior)
-__global__ void k_mom_pupv(const DevView *Vp, int off, int lo, int hi) {
+__global__ void k_mom_pupv(const DevView *__restrict__ Vp, int off, int lo, int hi) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < lo || j > V.jj + hi || i < lo || i > V.ii + hi) return;
@@ -65,7 +65,7 @@ __global__ void k_mom_pupv(const DevView *Vp, int off, int lo, int hi) {
 }
 
 // p(k+1) = p(k) + dp(k+off) for j,i = lo..+hi
-__global__ void k_mom_pscan(const DevView *Vp, int off, int lo, int hi) {
+__global__ void k_mom_pscan(const DevView *__restrict__ Vp, int off, int lo, int hi) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < lo || j > V.jj + hi || i < lo || i > V.ii + hi || !V.m[I_ip][c]) return;
@@ -75,7 +75,7 @@ __global__ void k_mom_pscan(const DevView *Vp, int off, int lo, int hi) {
 }
 
 // ---- :260-292 bottom drag ------------------------------------------------------------------------
-__global__ void k_mom_drag(const DevView *Vp, int n, int nn) {
+__global__ void k_mom_drag(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][c]) return;
@@ -105,7 +105,7 @@ __global__ void k_mom_drag(const DevView *Vp, int n, int nn) {
 }
 
 // ---- :360-431 total velocities, fluxes, dpmx ---------------------------------------------------------
-__global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn, int klo) {
+__global__ void k_mom_tot(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
@@ -159,7 +159,7 @@ __global__ void k_mom_tot(const DevView *Vp, int m, int n, int mm, int nn, int k
 }
 
 // ---- :438-472 side-wall weights, auxiliary velocities, del2 fields -------------------------------------
-__global__ void k_mom_wall(const DevView *Vp, int m, int klo) {
+__global__ void k_mom_wall(const DevView *__restrict__ Vp, int m, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const int k = by_ + klo, ni = V.ni;
@@ -201,7 +201,7 @@ __global__ void k_mom_wall(const DevView *Vp, int m, int klo) {
 }
 
 // ---- :477-585 vorticity, potential vorticity, deformation; :613-629 kinetic energy ---------------------
-__global__ void k_mom_vort(const DevView *Vp, int mm, int klo) {
+__global__ void k_mom_vort(const DevView *__restrict__ Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
@@ -284,7 +284,7 @@ __global__ void k_mom_vort(const DevView *Vp, int mm, int klo) {
   }
 }
 
-__global__ void k_mom_enedis(const DevView *Vp, int mm, int klo) {
+__global__ void k_mom_enedis(const DevView *__restrict__ Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
@@ -301,7 +301,7 @@ __global__ void k_mom_enedis(const DevView *Vp, int mm, int klo) {
 }
 
 // ---- :829-841 and :988-1000 deformation dependent viscosities ---------------------------------------
-__global__ void k_mom_visc(const DevView *Vp, int klo) {
+__global__ void k_mom_visc(const DevView *__restrict__ Vp, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
@@ -324,7 +324,7 @@ __global__ void k_mom_visc(const DevView *Vp, int klo) {
 }
 
 // ---- :860-873 and :1019-1034 longitudinal turbulent momentum fluxes at p-points ------------------------
-__global__ void k_mom_flux1(const DevView *Vp, int mm, int klo) {
+__global__ void k_mom_flux1(const DevView *__restrict__ Vp, int mm, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][c]) return;
@@ -351,7 +351,7 @@ __global__ void k_mom_flux1(const DevView *Vp, int mm, int klo) {
 }
 
 // ---- update of u and v at interior points: :723-813, :879-980, :1040-1143 --------------------------------
-__global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn, int klo) {
+__global__ void k_mom_update(const DevView *__restrict__ Vp, int m, int mm, int nn, int klo) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -478,7 +478,7 @@ __global__ void k_mom_update(const DevView *Vp, int m, int mm, int nn, int klo) 
 }
 
 // ---- :1154-1267 vertical pass: massless layers, barotropic part, time filter part 2, pu/pv --------------
-__global__ void k_mom_column(const DevView *Vp, int m, int mm, int nn) {
+__global__ void k_mom_column(const DevView *__restrict__ Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;

@@ -16,7 +16,7 @@
 //                      with the neighbouring chunk's reads; k_mom_column_from reads the scratch planes and does the
 //                      vertical pass into u, v, so no extra pass over the fields is needed).
 // Expressions are those of stage_momtum.hip's kernels, operator for operator; loop bounds of every sweep as there.
-// LDS: 60 rows (visc) / 21 or 35 rows (cor) of ni doubles.  Roofline: HBM; ~35 F moved by the two kernels.
+// LDS: 37 rows (visc) / 21 or 35 rows (cor) of a strip.  Roofline: HBM; ~35 F moved by the two kernels.
 #include "momtum_common.h"
 
 // kk-level work-space slots of the fused path
@@ -36,20 +36,28 @@ typedef double GLOBAL_AS *gd_t;
 typedef const int GLOBAL_AS *gci_t;
 #define GF(V, id) ((gcd_t)(V).f[id])
 
+// ring of D rows of a strip: lane l of row r at row(r)[l]; two pad columns on either side so that l-1 .. l+2 of
+// the edge lanes stay inside the row (what is read there belongs to no owned point)
 template <int D> struct Ring {
   double *b;
   int nip;
-  __device__ inline double *row(int r) const { return b + ((r + 16 * D) % D) * nip; }
+  __device__ inline double *row(int r) const { return b + ((r + 16 * D) % D) * nip + 2; }
 };
 
 // chunk-major work item of this workgroup; XCD x (blockIdx % 8) walks a contiguous eighth of the items so that the
 // workgroups of one XCD share the 2-D coefficient rows of their chunk in its L2
-__device__ inline void march_item(int kk, int jj, int nchunk, int &k, int &ja, int &jb) {
+__device__ inline void march_item(int kk, int jj, int nchunk_, int nstrip, int &k, int &ja, int &jb, int &strip) {
+  const bool chunk_major = nchunk_ < 0;
+  const int nchunk = chunk_major ? -nchunk_ : nchunk_;
   const unsigned nitem = gridDim.x, lin = blockIdx.x;
   const unsigned xq = lin & 7u, sq = lin >> 3, q = nitem >> 3, rr = nitem & 7u;
-  const unsigned item = xq * q + (xq < rr ? xq : rr) + sq;
-  const int ch = item / kk;
-  k = item % kk;
+  unsigned item = xq * q + (xq < rr ? xq : rr) + sq;
+  strip = item % nstrip;          // the strips of a row chunk are neighbours in the numbering: they share rows in L2
+  item /= nstrip;
+  // chunk-major: the workgroups of an XCD work on the same rows of different layers at about the same time, so the
+  // 2-D coefficient rows (25 planes, read by every layer) are served by its L2
+  const int ch = chunk_major ? item / kk : item % nchunk;
+  k = chunk_major ? item % kk : item / nchunk;
   const int rows = (jj + nchunk - 1) / nchunk;
   ja = 1 + ch * rows;
   jb = ja + rows - 1 < jj ? ja + rows - 1 : jj;
@@ -67,15 +75,22 @@ __device__ inline void march_item(int kk, int jj, int nchunk, int &k, int &ja, i
 #define MV(m) (((m) >> 2) & 1)
 #define MQ(m) (((m) >> 3) & 1)
 template <int BS>
-__global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m, int n, int mm, int nn, int nchunk) {
+__global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip) {
   const DevView &V = *Vp;
   HIP_DYNAMIC_SHARED(double, lds)
-  const int x = threadIdx.x, ni = V.ni, ii = V.ii, jj = V.jj, kk = V.kk;
+  const int l = threadIdx.x, ni = V.ni, ii = V.ii, jj = V.jj, kk = V.kk;
+  int k, ja, jb, strip;
+  march_item(kk, jj, nchunk, nstrip, k, ja, jb, strip);
+  if (ja > jb) return;
+  // strip of the row: BS lanes, the outer HL / HR of them only feed their neighbours (stencil reach of the chain in i);
+  // owned columns ox0..ox1 (x = i + 3), interior points i = 1..ii shared out over the strips
+  constexpr int HL = 4, HR = 4, OW = BS - HL - HR;
+  const int ox0 = NBDY + strip * OW, ox1 = (ox0 + OW - 1 < ii + NBDY - 1) ? ox0 + OW - 1 : ii + NBDY - 1;
+  if (ox0 > ox1) return;
+  const int x = ox0 - HL + l;
   const bool act = x < ni;
   const int i = x - (NBDY - 1);
-  int k, ja, jb;
-  march_item(kk, jj, nchunk, k, ja, jb);
-  if (ja > jb) return;
+  const bool own = x >= ox0 && x <= ox1;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
   const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   // scalars of the step in registers: left in the DevView they would be re-loaded inside the loop (the kernel stores
@@ -93,16 +108,20 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
   };
 
   double *lp = lds;
-  auto take = [&](int d) { double *b = lp; lp += d * ni; return b; };
-  const Ring<4> UTN{take(4), ni}, VTN{take(4), ni};
-  const Ring<3> WJA{take(3), ni}, WJB{take(3), ni}, UJA{take(3), ni}, UJB{take(3), ni};
-  const Ring<4> DL2U{take(4), ni};
-  const Ring<3> WIA{take(3), ni}, WIB{take(3), ni}, VIA{take(3), ni}, VIB{take(3), ni}, DL2V{take(3), ni};
-  const Ring<2> D1{take(2), ni}, D2{take(2), ni};
-  const Ring<3> VS2U{take(3), ni}, VS4U{take(3), ni};
-  const Ring<4> VS2V{take(4), ni}, VS4V{take(4), ni};
-  const Ring<1> UFL1{take(1), ni};
-  const Ring<2> VFL1{take(2), ni};
+  constexpr int NP = BS + 4;
+  auto take = [&](int d) { double *b = lp; lp += d * NP; return b; };
+  const Ring<4> UTN{take(4), NP}, VTN{take(4), NP};
+  const Ring<4> DL2U{take(4), NP};
+  const Ring<3> VIB{take(3), NP}, DL2V{take(3), NP};
+  const Ring<2> D1{take(2), NP}, D2{take(2), NP};
+  const Ring<3> VS2U{take(3), NP}, VS4U{take(3), NP};
+  const Ring<4> VS2V{take(4), NP}, VS4V{take(4), NP};
+  const Ring<1> UFL1{take(1), NP};
+  // fields that are only ever read at the lane that wrote them live in registers: value of row s-1 (written this
+  // step by W), s-2, s-3 (read by U); ujb of row s-2 is read by V; vflux1 of rows s-3, s-4
+  double wja1 = 0., wja2 = 0., wja3 = 0., wjb1 = 0., wjb2 = 0., wjb3 = 0., uja1 = 0., uja2 = 0., uja3 = 0.;
+  double ujb1 = 0., ujb2 = 0., ujb3 = 0., wia1 = 0., wia2 = 0., wia3 = 0., wib1 = 0., wib2 = 0., wib3 = 0.;
+  double via1 = 0., via2 = 0., via3 = 0., vfl3 = 0., vfl4 = 0.;
 
   const gcd_t f_u = GF(V, F_u) + okn, f_v = GF(V, F_v) + okn;
   const gcd_t f_ubf = GF(V, F_ubflxs_p) + on, f_vbf = GF(V, F_vbflxs_p) + on, f_pbun = GF(V, F_pbu) + on, f_pbvn = GF(V, F_pbv) + on;
@@ -168,8 +187,8 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
         vn = tc.v + tc.vb * tsfac / (tc.pbv * tc.sx);
         if (k == kk - 1) o_vtotn[c] = vn;
       }
-      UTN.row(s)[x] = un;
-      VTN.row(s)[x] = vn;
+      UTN.row(s)[l] = un;
+      VTN.row(s)[l] = vn;
     }
     __syncthreads();
     // ---- W: side-wall weights, auxiliary velocities, del2 fields, row s-1 (:438-472) ---------------------------
@@ -182,16 +201,16 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
           const double den = fmax2(w_pu1 - w_pu0, EPSILP);
           const double wa = fmax2(0., fmin2(1., (w_pu1 - w_pbua) / den));
           const double wb = fmax2(0., fmin2(1., (w_pu1 - w_pbub) / den));
-          const double un = ut0[x];
-          uja = (1. - wa) * utm[x] + wa * SLIP * un;
-          ujb = (1. - wb) * utp[x] + wb * SLIP * un;
-          d2u = un - .25 * (ut0[x + 1] + ut0[x - 1] + uja + ujb);
-          WJA.row(r)[x] = wa;
-          WJB.row(r)[x] = wb;
+          const double un = ut0[l];
+          uja = (1. - wa) * utm[l] + wa * SLIP * un;
+          ujb = (1. - wb) * utp[l] + wb * SLIP * un;
+          d2u = un - .25 * (ut0[l + 1] + ut0[l - 1] + uja + ujb);
+          wja1 = wa;
+          wjb1 = wb;
         }
-        UJA.row(r)[x] = uja;
-        UJB.row(r)[x] = ujb;
-        DL2U.row(r)[x] = d2u;
+        uja1 = uja;
+        ujb1 = ujb;
+        DL2U.row(r)[l] = d2u;
       }
       if (act && r >= 0 && r <= jj + 2 && i >= -1 && i <= ii + 2) {
         double via = 0., vib = 0., d2v = 0.;
@@ -200,16 +219,16 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
           const double den = fmax2(w_pv1 - w_pv0, EPSILP);
           const double wa = fmax2(0., fmin2(1., (w_pv1 - w_pbva) / den));
           const double wb = fmax2(0., fmin2(1., (w_pv1 - w_pbvb) / den));
-          const double vn = vt0[x];
-          via = (1. - wa) * vt0[x - 1] + wa * SLIP * vn;
-          vib = (1. - wb) * vt0[x + 1] + wb * SLIP * vn;
-          d2v = vn - .25 * (vtp[x] + vtm[x] + via + vib);
-          WIA.row(r)[x] = wa;
-          WIB.row(r)[x] = wb;
+          const double vn = vt0[l];
+          via = (1. - wa) * vt0[l - 1] + wa * SLIP * vn;
+          vib = (1. - wb) * vt0[l + 1] + wb * SLIP * vn;
+          d2v = vn - .25 * (vtp[l] + vtm[l] + via + vib);
+          wia1 = wa;
+          wib1 = wb;
         }
-        VIA.row(r)[x] = via;
-        VIB.row(r)[x] = vib;
-        DL2V.row(r)[x] = d2v;
+        via1 = via;
+        VIB.row(r)[l] = vib;
+        DL2V.row(r)[l] = d2v;
       }
     }
     __syncthreads();
@@ -220,22 +239,21 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
         const double *ut0 = UTN.row(r), *utm = UTN.row(r - 1), *vt0 = VTN.row(r);
         bool have = false;
         double d2 = 0.;
-        if (MV(w_m) && !MV(w_mw)) { const double t = vt0[x] * (1. - SLIP) * v_scvy; d2 = t * t * v_scq2i; have = true; }
-        else if (MV(w_mw) && !MV(w_m)) { const double t = vt0[x - 1] * (1. - SLIP) * v_scvyw; d2 = t * t * v_scq2i; have = true; }
-        if (MU(w_m) && !MU(w_ms)) { const double t = ut0[x] * (1. - SLIP) * v_scux; d2 = t * t * v_scq2i; have = true; }
-        else if (MU(w_ms) && !MU(w_m)) { const double t = utm[x] * (1. - SLIP) * v_scuxs; d2 = t * t * v_scq2i; have = true; }
+        if (MV(w_m) && !MV(w_mw)) { const double t = vt0[l] * (1. - SLIP) * v_scvy; d2 = t * t * v_scq2i; have = true; }
+        else if (MV(w_mw) && !MV(w_m)) { const double t = vt0[l - 1] * (1. - SLIP) * v_scvyw; d2 = t * t * v_scq2i; have = true; }
+        if (MU(w_m) && !MU(w_ms)) { const double t = ut0[l] * (1. - SLIP) * v_scux; d2 = t * t * v_scq2i; have = true; }
+        else if (MU(w_ms) && !MU(w_m)) { const double t = utm[l] * (1. - SLIP) * v_scuxs; d2 = t * t * v_scq2i; have = true; }
         if (MQ(w_m)) {
-          const double t = VIB.row(r)[x - 1] * v_scvy - VIA.row(r)[x] * v_scvyw + UJB.row(r - 1)[x] * v_scux -
-                           UJA.row(r)[x] * v_scuxs;
+          const double t = VIB.row(r)[l - 1] * v_scvy - via1 * v_scvyw + ujb2 * v_scux - uja1 * v_scuxs;
           d2 = t * t * v_scq2i;
           have = true;
         }
-        if (have) D2.row(r)[x] = d2;
+        if (have) D2.row(r)[l] = d2;
       }
       if (act && r >= -1 && r <= jj + 1 && i >= -1 && i <= ii + 1 && MP(w_m)) {   // defor1 at p-points
         const double *ut0 = UTN.row(r), *vt0 = VTN.row(r), *vtp = VTN.row(r + 1);
-        const double t = (ut0[x + 1] * v_scuye - ut0[x] * v_scuy) - (vtp[x] * v_scvxn - vt0[x] * v_scvx);
-        D1.row(r)[x] = t * t * v_scp2i;
+        const double t = (ut0[l + 1] * v_scuye - ut0[l] * v_scuy) - (vtp[l] * v_scvxn - vt0[l] * v_scvx);
+        D1.row(r)[l] = t * t * v_scp2i;
       }
     }
     __syncthreads();
@@ -246,9 +264,9 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
         if (r >= 0 && r <= jj + 1 && MU(s_m)) {
           const double *d1 = D1.row(r), *d2 = D2.row(r), *d2p = D2.row(r + 1);
           const double q = .5 * (su_dww + su_dw);
-          const double deform = sqrt(.5 * (d1[x] + d1[x - 1] + d2[x] + d2p[x]));
-          VS2U.row(r)[x] = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
-          VS4U.row(r)[x] = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
+          const double deform = sqrt(.5 * (d1[l] + d1[l - 1] + d2[l] + d2p[l]));
+          VS2U.row(r)[l] = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
+          VS4U.row(r)[l] = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
         }
       }
       {
@@ -256,9 +274,9 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
         if (r >= 0 && r <= jj + 1 && MV(w_m)) {
           const double *d1 = D1.row(r), *d1m = D1.row(r - 1), *d2 = D2.row(r);
           const double q = .5 * (sv_dws + sv_dw);
-          const double deform = sqrt(.5 * (d1[x] + d1m[x] + d2[x] + d2[x + 1]));
-          VS2V.row(r)[x] = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
-          VS4V.row(r)[x] = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
+          const double deform = sqrt(.5 * (d1[l] + d1m[l] + d2[l] + d2[l + 1]));
+          VS2V.row(r)[l] = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
+          VS4V.row(r)[l] = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
         }
       }
     }
@@ -273,10 +291,10 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
           const double dpxy = fmax2(dpu_c, ONEMM), dpib = fmax2(dpu_e, ONEMM);
           // viscosity extended one point beyond wet u-segments (:845-856), cf. ext_i
           const int m0 = MU(f_m), m1 = MU(f_me), m2 = MU(f_me2);
-          const double v2 = (m0 ? v2r[x] : (m1 ? v2r[x + 1] : v2r[x - 1])) + (m1 ? v2r[x + 1] : (m2 ? v2r[x + 2] : v2r[x]));
-          const double v4 = (m0 ? v4r[x] : (m1 ? v4r[x + 1] : v4r[x - 1])) + (m1 ? v4r[x + 1] : (m2 ? v4r[x + 2] : v4r[x]));
-          UFL1.row(r)[x] = fmin2(v_difmxp, v2 * v_scpy) * hfharm(dpxy, dpib) * (ut0[x] - ut0[x + 1]) +
-                           fmin2(.125 * v_difmxp, v4 * v_scpy) * hfharm(dpxy, dpib) * (dl2[x] - dl2[x + 1]);
+          const double v2 = (m0 ? v2r[l] : (m1 ? v2r[l + 1] : v2r[l - 1])) + (m1 ? v2r[l + 1] : (m2 ? v2r[l + 2] : v2r[l]));
+          const double v4 = (m0 ? v4r[l] : (m1 ? v4r[l + 1] : v4r[l - 1])) + (m1 ? v4r[l + 1] : (m2 ? v4r[l + 2] : v4r[l]));
+          UFL1.row(r)[l] = fmin2(v_difmxp, v2 * v_scpy) * hfharm(dpxy, dpib) * (ut0[l] - ut0[l + 1]) +
+                           fmin2(.125 * v_difmxp, v4 * v_scpy) * hfharm(dpxy, dpib) * (dl2[l] - dl2[l + 1]);
         }
         if (i >= 1 && MV(f_m) + MV(f_mn) > 0) {
           const double *vt0 = VTN.row(r), *vtp = VTN.row(r + 1);
@@ -285,10 +303,10 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
           const int m0 = MV(f_m), m1 = MV(f_mn), m2 = MV(f_mn2);
           const double *a2m = VS2V.row(r - 1), *a20 = VS2V.row(r), *a2p = VS2V.row(r + 1), *a2q = VS2V.row(r + 2);
           const double *a4m = VS4V.row(r - 1), *a40 = VS4V.row(r), *a4p = VS4V.row(r + 1), *a4q = VS4V.row(r + 2);
-          const double v2 = (m0 ? a20[x] : (m1 ? a2p[x] : a2m[x])) + (m1 ? a2p[x] : (m2 ? a2q[x] : a20[x]));
-          const double v4 = (m0 ? a40[x] : (m1 ? a4p[x] : a4m[x])) + (m1 ? a4p[x] : (m2 ? a4q[x] : a40[x]));
-          VFL1.row(r)[x] = fmin2(v_difmxp, v2 * v_scpx) * hfharm(dpxy, dpjb) * (vt0[x] - vtp[x]) +
-                           fmin2(.125 * v_difmxp, v4 * v_scpx) * hfharm(dpxy, dpjb) * (dl2[x] - dl2p[x]);
+          const double v2 = (m0 ? a20[l] : (m1 ? a2p[l] : a2m[l])) + (m1 ? a2p[l] : (m2 ? a2q[l] : a20[l]));
+          const double v4 = (m0 ? a40[l] : (m1 ? a4p[l] : a4m[l])) + (m1 ? a4p[l] : (m2 ? a4q[l] : a40[l]));
+          vfl3 = fmin2(v_difmxp, v2 * v_scpx) * hfharm(dpxy, dpjb) * (vt0[l] - vtp[l]) +
+                           fmin2(.125 * v_difmxp, v4 * v_scpx) * hfharm(dpxy, dpjb) * (dl2[l] - dl2p[l]);
         }
       }
     }
@@ -297,49 +315,51 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
     {
       const int r = s - 3;
       const size_t c = (size_t)x + (size_t)ni * (r + NBDY - 1);
-      if (act && r >= ja && r <= jb && i >= 1 && i <= ii) {
+      if (act && own && r >= ja && r <= jb && i >= 1 && i <= ii) {
         if (MU(f_m)) {
-          const double wja = WJA.row(r)[x], wjb = WJB.row(r)[x];
+          const double wja = wja3, wjb = wjb3;
           const double dpxy = fmax2(dpu_c, ONEMM);
           double dpja = fmax2(dpu_s, ONEMM);
           dpja = dpja + wja * (dpxy - dpja);
           double dpjb = fmax2(dpu_n, ONEMM);
           dpjb = dpjb + wjb * (dpxy - dpjb);
-          const double v2c = VS2U.row(r)[x], v4c = VS4U.row(r)[x];
-          const double vsc2a = MU(f_ms) == 0 ? v2c : VS2U.row(r - 1)[x], vsc4a = MU(f_ms) == 0 ? v4c : VS4U.row(r - 1)[x];
-          const double vsc2b = MU(f_mn) == 0 ? v2c : VS2U.row(r + 1)[x], vsc4b = MU(f_mn) == 0 ? v4c : VS4U.row(r + 1)[x];
-          const double un = UTN.row(r)[x], d2 = DL2U.row(r)[x];
-          const double dl2uja = (1. - wja) * DL2U.row(r - 1)[x] + wja * SLIP * d2;          // :594-597
-          const double dl2ujb = (1. - wjb) * DL2U.row(r + 1)[x] + wjb * SLIP * d2;
-          const double uflux2 = fmin2(dmq_c, (v2c + vsc2a) * scqx_c) * hfharm(dpja, dpxy) * (UJA.row(r)[x] - un) +
+          const double v2c = VS2U.row(r)[l], v4c = VS4U.row(r)[l];
+          const double vsc2a = MU(f_ms) == 0 ? v2c : VS2U.row(r - 1)[l], vsc4a = MU(f_ms) == 0 ? v4c : VS4U.row(r - 1)[l];
+          const double vsc2b = MU(f_mn) == 0 ? v2c : VS2U.row(r + 1)[l], vsc4b = MU(f_mn) == 0 ? v4c : VS4U.row(r + 1)[l];
+          const double un = UTN.row(r)[l], d2 = DL2U.row(r)[l];
+          const double dl2uja = (1. - wja) * DL2U.row(r - 1)[l] + wja * SLIP * d2;          // :594-597
+          const double dl2ujb = (1. - wjb) * DL2U.row(r + 1)[l] + wjb * SLIP * d2;
+          const double uflux2 = fmin2(dmq_c, (v2c + vsc2a) * scqx_c) * hfharm(dpja, dpxy) * (uja3 - un) +
                                 fmin2(.125 * dmq_c, (v4c + vsc4a) * scqx_c) * hfharm(dpja, dpxy) * (dl2uja - d2);
-          const double uflux3 = fmin2(dmq_n, (v2c + vsc2b) * scqx_n) * hfharm(dpjb, dpxy) * (un - UJB.row(r)[x]) +
+          const double uflux3 = fmin2(dmq_n, (v2c + vsc2b) * scqx_n) * hfharm(dpjb, dpxy) * (un - ujb3) +
                                 fmin2(.125 * dmq_n, (v4c + vsc4b) * scqx_n) * hfharm(dpjb, dpxy) * (d2 - dl2ujb);
           const double *uflux1 = UFL1.row(r);
-          o_visu[c] = (uflux1[x] - uflux1[x - 1] + uflux3 - uflux2) / (scu2_c * fmax2(dpu_c, ONEMM));
+          o_visu[c] = (uflux1[l] - uflux1[l - 1] + uflux3 - uflux2) / (scu2_c * fmax2(dpu_c, ONEMM));
         }
         if (MV(f_m)) {
-          const double wia = WIA.row(r)[x], wib = WIB.row(r)[x];
+          const double wia = wia3, wib = wib3;
           const double dpxy = fmax2(dpv_c, ONEMM);
           double dpia = fmax2(dpv_w, ONEMM);
           dpia = dpia + wia * (dpxy - dpia);
           double dpib = fmax2(dpv_e, ONEMM);
           dpib = dpib + wib * (dpxy - dpib);
           const double *vsc2 = VS2V.row(r), *vsc4 = VS4V.row(r), *dl2v = DL2V.row(r);
-          const double vsc2a = MV(f_mw) == 0 ? vsc2[x] : vsc2[x - 1], vsc4a = MV(f_mw) == 0 ? vsc4[x] : vsc4[x - 1];
-          const double vsc2b = MV(f_me) == 0 ? vsc2[x] : vsc2[x + 1], vsc4b = MV(f_me) == 0 ? vsc4[x] : vsc4[x + 1];
-          const double vn = VTN.row(r)[x], d2 = dl2v[x];
-          const double dl2via = (1. - wia) * dl2v[x - 1] + wia * SLIP * d2;          // :602-605
-          const double dl2vib = (1. - wib) * dl2v[x + 1] + wib * SLIP * d2;
-          const double vflux2 = fmin2(dmq_c, (vsc2[x] + vsc2a) * scqy_c) * hfharm(dpia, dpxy) * (VIA.row(r)[x] - vn) +
-                                fmin2(.125 * dmq_c, (vsc4[x] + vsc4a) * scqy_c) * hfharm(dpia, dpxy) * (dl2via - d2);
-          const double vflux3 = fmin2(dmq_e, (vsc2[x] + vsc2b) * scqy_e) * hfharm(dpib, dpxy) * (vn - VIB.row(r)[x]) +
-                                fmin2(.125 * dmq_e, (vsc4[x] + vsc4b) * scqy_e) * hfharm(dpib, dpxy) * (d2 - dl2vib);
-          o_visv[c] = (VFL1.row(r)[x] - VFL1.row(r - 1)[x] + vflux3 - vflux2) / (scv2_c * fmax2(dpv_c, ONEMM));
+          const double vsc2a = MV(f_mw) == 0 ? vsc2[l] : vsc2[l - 1], vsc4a = MV(f_mw) == 0 ? vsc4[l] : vsc4[l - 1];
+          const double vsc2b = MV(f_me) == 0 ? vsc2[l] : vsc2[l + 1], vsc4b = MV(f_me) == 0 ? vsc4[l] : vsc4[l + 1];
+          const double vn = VTN.row(r)[l], d2 = dl2v[l];
+          const double dl2via = (1. - wia) * dl2v[l - 1] + wia * SLIP * d2;          // :602-605
+          const double dl2vib = (1. - wib) * dl2v[l + 1] + wib * SLIP * d2;
+          const double vflux2 = fmin2(dmq_c, (vsc2[l] + vsc2a) * scqy_c) * hfharm(dpia, dpxy) * (via3 - vn) +
+                                fmin2(.125 * dmq_c, (vsc4[l] + vsc4a) * scqy_c) * hfharm(dpia, dpxy) * (dl2via - d2);
+          const double vflux3 = fmin2(dmq_e, (vsc2[l] + vsc2b) * scqy_e) * hfharm(dpib, dpxy) * (vn - VIB.row(r)[l]) +
+                                fmin2(.125 * dmq_e, (vsc4[l] + vsc4b) * scqy_e) * hfharm(dpib, dpxy) * (d2 - dl2vib);
+          o_visv[c] = (vfl3 - vfl4 + vflux3 - vflux2) / (scv2_c * fmax2(dpv_c, ONEMM));
         }
       }
     }
     __syncthreads();
+    wja3 = wja2; wja2 = wja1; wjb3 = wjb2; wjb2 = wjb1; uja3 = uja2; uja2 = uja1; ujb3 = ujb2; ujb2 = ujb1;
+    wia3 = wia2; wia2 = wia1; wib3 = wib2; wib2 = wib1; via3 = via2; via2 = via1; vfl4 = vfl3;
     tc = tn;
   }
 }
@@ -348,15 +368,22 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *Vp, int m,
 // Coriolis chain + update
 // ======================================================================================================
 template <int BS, bool ENEDIS>
-__global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, int n, int mm, int nn, int nchunk) {
+__global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip) {
   const DevView &V = *Vp;
   HIP_DYNAMIC_SHARED(double, lds)
-  const int x = threadIdx.x, ni = V.ni, ii = V.ii, jj = V.jj, kk = V.kk;
+  const int l = threadIdx.x, ni = V.ni, ii = V.ii, jj = V.jj, kk = V.kk;
+  int k, ja, jb, strip;
+  march_item(kk, jj, nchunk, nstrip, k, ja, jb, strip);
+  if (ja > jb) return;
+  // strip of the row: BS lanes, the outer HL / HR of them only feed their neighbours (stencil reach of the chain in i);
+  // owned columns ox0..ox1 (x = i + 3), interior points i = 1..ii shared out over the strips
+  constexpr int HL = 2, HR = 2, OW = BS - HL - HR;
+  const int ox0 = NBDY + strip * OW, ox1 = (ox0 + OW - 1 < ii + NBDY - 1) ? ox0 + OW - 1 : ii + NBDY - 1;
+  if (ox0 > ox1) return;
+  const int x = ox0 - HL + l;
   const bool act = x < ni;
   const int i = x - (NBDY - 1);
-  int k, ja, jb;
-  march_item(kk, jj, nchunk, k, ja, jb);
-  if (ja > jb) return;
+  const bool own = x >= ox0 && x <= ox1;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
   const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const double delt1 = V.P.delt1, tsfac = V.P.dlt / V.P.delt1, cutoff = ONEM, thkbop = THKBOT * ONEM;
@@ -371,14 +398,15 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
   };
 
   double *lp = lds;
-  auto take = [&](int d) { double *b = lp; lp += d * ni; return b; };
-  const Ring<3> UTM{take(3), ni}, VTM{take(3), ni};
-  const Ring<4> UFX{take(4), ni};
-  const Ring<3> VFX{take(3), ni}, DPMX{take(3), ni};
-  const Ring<2> PV{take(2), ni};
-  const Ring<3> KE{take(3), ni};
-  const Ring<4> UHMN{take(ENEDIS ? 4 : 0), ni}, UHMX{take(ENEDIS ? 4 : 0), ni};
-  const Ring<3> VHMN{take(ENEDIS ? 3 : 0), ni}, VHMX{take(ENEDIS ? 3 : 0), ni};
+  constexpr int NP = BS + 4;
+  auto take = [&](int d) { double *b = lp; lp += d * NP; return b; };
+  const Ring<3> UTM{take(3), NP}, VTM{take(3), NP};
+  const Ring<4> UFX{take(4), NP};
+  const Ring<3> VFX{take(3), NP}, DPMX{take(3), NP};
+  const Ring<2> PV{take(2), NP};
+  const Ring<3> KE{take(3), NP};
+  const Ring<4> UHMN{take(ENEDIS ? 4 : 0), NP}, UHMX{take(ENEDIS ? 4 : 0), NP};
+  const Ring<3> VHMN{take(ENEDIS ? 3 : 0), NP}, VHMX{take(ENEDIS ? 3 : 0), NP};
 
   const gcd_t dp = GF(V, F_dp) + okm, f_um = GF(V, F_u) + okm, f_vm = GF(V, F_v) + okm, f_un = GF(V, F_u) + okn, f_vn = GF(V, F_v) + okn;
   const gcd_t f_ubfm = GF(V, F_ubflxs_p) + om, f_vbfm = GF(V, F_vbflxs_p) + om, f_pbum = GF(V, F_pbu) + om, f_pbvm = GF(V, F_pbv) + om;
@@ -395,48 +423,55 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
   const gd_t o_um = (gd_t)WK(V, MF_UM) + ok, o_un = (gd_t)WK(V, MF_UN) + ok, o_vm = (gd_t)WK(V, MF_VM) + ok, o_vn = (gd_t)WK(V, MF_VN) + ok;
   const gd_t o_absvor = (gd_t)V.f[F_absvor] + ok, o_dpvor = (gd_t)V.f[F_dpvor] + ok;
 
-  // inputs of the first sweep, one step ahead
-  struct TIn { int mk, mks, mkw; double dc, dw, ds, dsw, u, ub, pbu, sy, dpu, v, vb, pbv, sx, dpv; };
+  // Inputs of the first sweep are loaded one step ahead; what the later sweeps need of the same rows (the wet masks
+  // and dp of rows s-1, s-2 for the vorticity, u, v, dpu, dpv and the 2-D coefficients of row s-2 for the update)
+  // is carried in registers from step to step instead of being read again: the second read of a row, two march
+  // steps later and with ~2000 waves streaming through the same L2, mostly missed it.
+  struct TIn { int mk, mkw; double dc, dw, u, ub, pbu, sy, dpu, v, vb, pbv, sx, dpv; };
   auto load_t = [&](int r) {
     const size_t c = cidx(r);
     TIn t;
-    t.mk = mpk[c]; t.mks = mpk[c - ni]; t.mkw = mpk[c - 1];
-    t.dc = dp[c]; t.dw = dp[c - 1]; t.ds = dp[c - ni]; t.dsw = dp[c - ni - 1];
+    t.mk = mpk[c]; t.mkw = mpk[c - 1];
+    t.dc = dp[c]; t.dw = dp[c - 1];
     t.u = f_um[c]; t.ub = f_ubfm[c]; t.pbu = f_pbum[c]; t.sy = scuy[c]; t.dpu = f_dpu[c];
     t.v = f_vm[c]; t.vb = f_vbfm[c]; t.pbv = f_pbvm[c]; t.sx = scvx[c]; t.dpv = f_dpv[c];
     return t;
   };
-  TIn tc = load_t(ja - 1);
+  TIn tpp = load_t(ja - 3), tp = load_t(ja - 2), tc = load_t(ja - 1);      // rows s-2, s-1, s
+  double pr_p0 = p0[cidx(ja - 4)], pr_p1 = p1[cidx(ja - 4)], pr_drag = drag[cidx(ja - 4)];   // row s-3
 
   for (int s = ja - 1; s <= jb + 2; s++) {
     // ================= loads of this step =================
     const TIn tn = load_t(s + 1);
-    // V (row s-1)
+    // V (row s-1): 2-D coefficients
     const size_t cv = cidx(s - 1);
-    const int v_m = mpk[cv], v_mw = mpk[cv - 1], v_ms = mpk[cv - ni];
+    const int v_m = tp.mk, v_mw = tp.mkw, v_ms = tpp.mk;
     const double v_scvy = scvy[cv], v_scvyw = scvy[cv - 1], v_scux = scux[cv], v_scuxs = scux[cv - ni], v_scq2i = scq2i[cv];
-    const double v_dc = dp[cv], v_dw = dp[cv - 1], v_ds = dp[cv - ni], v_dsw = dp[cv - ni - 1], v_cor = corioq[cv];
+    const double v_dc = tp.dc, v_dw = tp.dw, v_ds = tpp.dc, v_dsw = tpp.dw, v_cor = corioq[cv];
     const double v_scu2 = scu2[cv], v_scu2e = scu2[cv + 1], v_scv2 = scv2[cv], v_scv2n = scv2[cv + ni], v_scp2 = scp2[cv];
     // U (row s-2)
     const size_t cu = cidx(s - 2);
-    const int u_m = mpk[cu];
-    const double u_drag = drag[cu], u_dragw = drag[cu - 1], u_drags = drag[cu - ni];
-    const double u_p0 = p0[cu], u_p0w = p0[cu - 1], u_p0s = p0[cu - ni], u_p1 = p1[cu], u_p1w = p1[cu - 1], u_p1s = p1[cu - ni];
-    const double u_dpu = f_dpu[cu], u_pbum = f_pbum[cu], u_ukm = f_um[cu], u_ukn = f_un[cu], u_ubfn = f_ubfn[cu], u_pbun = f_pbun[cu];
-    const double u_scuy = scuy[cu], u_pgm = pgfx_m[cu], u_pgo = pgfx_o[cu], u_pgn = pgfx_n[cu], u_dpuold = dpuold[cu];
+    const int u_m = tpp.mk;
+    const double u_drag = drag[cu], u_dragw = drag[cu - 1], u_drags = pr_drag;
+    const double u_p0 = p0[cu], u_p0w = p0[cu - 1], u_p0s = pr_p0, u_p1 = p1[cu], u_p1w = p1[cu - 1], u_p1s = pr_p1;
+    const double u_dpu = tpp.dpu, u_pbum = tpp.pbu, u_ukm = tpp.u, u_ukn = f_un[cu], u_ubfn = f_ubfn[cu], u_pbun = f_pbun[cu];
+    const double u_scuy = tpp.sy, u_pgm = pgfx_m[cu], u_pgo = pgfx_o[cu], u_pgn = pgfx_n[cu], u_dpuold = dpuold[cu];
     const double u_ubcors = ubcors[cu], u_scuxi = scuxi[cu], u_visu = visu[cu];
-    const double u_dpv = f_dpv[cu], u_pbvm = f_pbvm[cu], u_vkm = f_vm[cu], u_vkn = f_vn[cu], u_vbfn = f_vbfn[cu], u_pbvn = f_pbvn[cu];
-    const double u_scvx = scvx[cu], u_pgym = pgfy_m[cu], u_pgyo = pgfy_o[cu], u_pgyn = pgfy_n[cu], u_dpvold = dpvold[cu];
+    const double u_dpv = tpp.dpv, u_pbvm = tpp.pbv, u_vkm = tpp.v, u_vkn = f_vn[cu], u_vbfn = f_vbfn[cu], u_pbvn = f_pbvn[cu];
+    const double u_scvx = tpp.sx, u_pgym = pgfy_m[cu], u_pgyo = pgfy_o[cu], u_pgyn = pgfy_n[cu], u_dpvold = dpvold[cu];
     const double u_vbcors = vbcors[cu], u_scvyi = scvyi[cu], u_visv = visv[cu];
+    // the first sweep's neighbours to the south come from the row loaded a step earlier
+    const int t_mks = tp.mk;
+    const double t_ds = tp.dc, t_dsw = tp.dw;
 
     // ---- T: total velocities at the mid time level, fluxes, dpmx, row s (:360-406; rows 0..jj+1 / dpmx 0..jj+2) ----
     if (act && s >= 0 && s <= jj + 2 && i >= 0 && i <= ii + 2) {
       double d = 8. * cutoff;
       if (MU(tc.mk)) d = fmax2(d, tc.dc + tc.dw);
-      if (MU(tc.mks)) d = fmax2(d, tc.ds + tc.dsw);
-      if (MV(tc.mk)) d = fmax2(d, tc.dc + tc.ds);
-      if (MV(tc.mkw)) d = fmax2(d, tc.dw + tc.dsw);
-      DPMX.row(s)[x] = d;
+      if (MU(t_mks)) d = fmax2(d, t_ds + t_dsw);
+      if (MV(tc.mk)) d = fmax2(d, tc.dc + t_ds);
+      if (MV(tc.mkw)) d = fmax2(d, tc.dw + t_dsw);
+      DPMX.row(s)[l] = d;
       if (s <= jj + 1 && i <= ii + 1) {
         double ut = 0., uf = 0., vt = 0., vf = 0.;
         if (MU(tc.mk)) {
@@ -447,17 +482,17 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
           vt = tc.v + tc.vb * tsfac / (tc.pbv * tc.sx);
           vf = vt * fmax2(tc.dpv, cutoff);
         }
-        UTM.row(s)[x] = ut;
-        UFX.row(s)[x] = uf;
-        VTM.row(s)[x] = vt;
-        VFX.row(s)[x] = vf;
+        UTM.row(s)[l] = ut;
+        UFX.row(s)[l] = uf;
+        VTM.row(s)[l] = vt;
+        VFX.row(s)[l] = vf;
         if (ENEDIS) {                                    // :662-715, rows 0..jj+1
           double a = 0., b = 0.;
           if (MU(tc.mk)) enedis_minmax(.5 * ut * (tc.dc + tc.dw), uf, a, b);
-          UHMN.row(s)[x] = a; UHMX.row(s)[x] = b;
+          UHMN.row(s)[l] = a; UHMX.row(s)[l] = b;
           a = 0.; b = 0.;
-          if (MV(tc.mk)) enedis_minmax(.5 * vt * (tc.dc + tc.ds), vf, a, b);
-          VHMN.row(s)[x] = a; VHMX.row(s)[x] = b;
+          if (MV(tc.mk)) enedis_minmax(.5 * vt * (tc.dc + t_ds), vf, a, b);
+          VHMN.row(s)[l] = a; VHMX.row(s)[l] = b;
         }
       }
     }
@@ -472,46 +507,46 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
         bool have = false;
         double vort = 0., dpv = 1.;
         if (MV(v_m) && !MV(v_mw)) {                      // first point of a v-segment, :479-486
-          vort = vtm0[x] * (1. - SLIP) * v_scvy * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_ds), dx0[x]), dx0[x + 1]);
+          vort = vtm0[l] * (1. - SLIP) * v_scvy * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_ds), dx0[l]), dx0[l + 1]);
           have = true;
         } else if (MV(v_mw) && !MV(v_m)) {               // one past the last point of a v-segment, :487-494
-          vort = -vtm0[x - 1] * (1. - SLIP) * v_scvyw * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_dw + v_dsw), dx0[x - 1]), dx0[x]);
+          vort = -vtm0[l - 1] * (1. - SLIP) * v_scvyw * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_dw + v_dsw), dx0[l - 1]), dx0[l]);
           have = true;
         }
         if (MU(v_m) && !MU(v_ms)) {                      // first point (in j) of a u-segment, :513-520
-          vort = -utm0[x] * (1. - SLIP) * v_scux * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_dw), dx0[x]), dxp[x]);
+          vort = -utm0[l] * (1. - SLIP) * v_scux * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_dw), dx0[l]), dxp[l]);
           have = true;
         } else if (MU(v_ms) && !MU(v_m)) {               // one past the last point, :521-528
-          vort = utmm[x] * (1. - SLIP) * v_scuxs * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_ds + v_dsw), dxm[x]), dx0[x]);
+          vort = utmm[l] * (1. - SLIP) * v_scuxs * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_ds + v_dsw), dxm[l]), dx0[l]);
           have = true;
         }
         if (MQ(v_m)) {                                   // interior (incl. promontories), :561-575
-          vort = (vtm0[x] * v_scvy - vtm0[x - 1] * v_scvyw - utm0[x] * v_scux + utmm[x] * v_scuxs) * v_scq2i;
-          double d = fmax2(2. * (v_dc + v_dw + v_ds + v_dsw), dx0[x]);
-          d = fmax2(d, dx0[x - 1]);
-          d = fmax2(d, dx0[x + 1]);
-          d = fmax2(d, dxm[x]);
-          d = fmax2(d, dxp[x]);
+          vort = (vtm0[l] * v_scvy - vtm0[l - 1] * v_scvyw - utm0[l] * v_scux + utmm[l] * v_scuxs) * v_scq2i;
+          double d = fmax2(2. * (v_dc + v_dw + v_ds + v_dsw), dx0[l]);
+          d = fmax2(d, dx0[l - 1]);
+          d = fmax2(d, dx0[l + 1]);
+          d = fmax2(d, dxm[l]);
+          d = fmax2(d, dxp[l]);
           dpv = .125 * d;
           have = true;
         }
         if (have) {
           const double av = vort + v_cor;
-          if ((r >= ja && r <= jb) || (last_chunk && r == jj + 1)) {
+          if ((own || (x == ii + NBDY && ox1 == ii + NBDY - 1)) && ((r >= ja && r <= jb) || (last_chunk && r == jj + 1))) {
             o_absvor[c] = av;
             o_dpvor[c] = dpv;
           }
-          PV.row(r)[x] = av / dpv;
+          PV.row(r)[l] = av / dpv;
         }
       }
       if (act && r >= 0 && r <= jj && i >= 0 && i <= ii && MP(v_m)) {
         const double *utm0 = UTM.row(r), *vtm0 = VTM.row(r), *vtmp = VTM.row(r + 1);
-        const double ue = utm0[x + 1], uw = utm0[x], vn = vtmp[x], vs = vtm0[x];
-        KE.row(r)[x] = .25 * (v_scu2 * (uw * uw) + v_scu2e * (ue * ue) + v_scv2 * (vs * vs) + v_scv2n * (vn * vn)) / v_scp2;
+        const double ue = utm0[l + 1], uw = utm0[l], vn = vtmp[l], vs = vtm0[l];
+        KE.row(r)[l] = .25 * (v_scu2 * (uw * uw) + v_scu2e * (ue * ue) + v_scv2 * (vs * vs) + v_scv2n * (vn * vn)) / v_scp2;
       }
     }
     __syncthreads();
@@ -519,27 +554,27 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
     {
       const int r = s - 2;
       const size_t c = (size_t)x + (size_t)ni * (r + NBDY - 1);
-      if (act && r >= ja && r <= jb && i >= 1 && i <= ii) {
+      if (act && own && r >= ja && r <= jb && i >= 1 && i <= ii) {
         const double *pv0 = PV.row(r), *pvp = PV.row(r + 1), *ke0 = KE.row(r), *kem = KE.row(r - 1);
         if (MU(u_m)) {
           const double *vf0 = VFX.row(r), *vfp = VFX.row(r + 1);
           double cau;
           if (ENEDIS) {                                                            // enedis, :771-790
             const double *mx0 = VHMX.row(r), *mxp = VHMX.row(r + 1), *mn0 = VHMN.row(r), *mnp = VHMN.row(r + 1);
-            const double utm = UTM.row(r)[x];
+            const double utm = UTM.row(r)[l];
             double t1, t2;
-            const double pn = pvp[x], pc = pv0[x];
-            if (pn * utm == 0.) t1 = pn * ((mxp[x] + mxp[x - 1]) + (mnp[x] + mnp[x - 1])) * .5;
-            else if (pn * utm < 0.) t1 = pn * (mxp[x] + mxp[x - 1]);
-            else t1 = pn * (mnp[x] + mnp[x - 1]);
-            if (pc * utm == 0.) t2 = pc * ((mx0[x] + mx0[x - 1]) + (mn0[x] + mn0[x - 1])) * .5;
-            else if (pc * utm < 0.) t2 = pc * (mx0[x] + mx0[x - 1]);
-            else t2 = pc * (mn0[x] + mn0[x - 1]);
+            const double pn = pvp[l], pc = pv0[l];
+            if (pn * utm == 0.) t1 = pn * ((mxp[l] + mxp[l - 1]) + (mnp[l] + mnp[l - 1])) * .5;
+            else if (pn * utm < 0.) t1 = pn * (mxp[l] + mxp[l - 1]);
+            else t1 = pn * (mnp[l] + mnp[l - 1]);
+            if (pc * utm == 0.) t2 = pc * ((mx0[l] + mx0[l - 1]) + (mn0[l] + mn0[l - 1])) * .5;
+            else if (pc * utm < 0.) t2 = pc * (mx0[l] + mx0[l - 1]);
+            else t2 = pc * (mn0[l] + mn0[l - 1]);
             cau = .25 * (t1 + t2);
           } else if (mommth == 0)
-            cau = .125 * (vf0[x] + vfp[x] + vf0[x - 1] + vfp[x - 1]) * (pv0[x] + pvp[x]);
+            cau = .125 * (vf0[l] + vfp[l] + vf0[l - 1] + vfp[l - 1]) * (pv0[l] + pvp[l]);
           else
-            cau = .25 * ((vf0[x] + vf0[x - 1]) * pv0[x] + (vfp[x] + vfp[x - 1]) * pvp[x]);
+            cau = .25 * ((vf0[l] + vf0[l - 1]) * pv0[l] + (vfp[l] + vfp[l - 1]) * pvp[l]);
           // wind stress (isopyc_bulkml: top layer only), :919-936
           double stress = 0.;
           if (k == 0) stress = -2. * taux[c] * GRAV * scux[c] / (p_1[c] + p_1[c - 1]);
@@ -554,27 +589,27 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
           const double pgf = (1. - 2. * WPGF) * u_pgm + WPGF * (u_pgo + u_pgn);
           o_um[c] = ukm * (wuv1 * u_dpu + ONEMM) + ukn * wuv2 * u_dpuold;
           const double ubrhs = u_ubcors * tsfac;                                    // :302
-          o_un[c] = ukn + delt1 * (-u_scuxi * (-pgf + stress + (ke0[x] - ke0[x - 1])) + cau - ubrhs + botstr - u_visu);
+          o_un[c] = ukn + delt1 * (-u_scuxi * (-pgf + stress + (ke0[l] - ke0[l - 1])) + cau - ubrhs + botstr - u_visu);
         }
         if (MV(u_m)) {
           const double *uf0 = UFX.row(r), *ufm = UFX.row(r - 1);
           double cav;
           if (ENEDIS) {                                                            // enedis, :793-812
             const double *mx0 = UHMX.row(r), *mxm = UHMX.row(r - 1), *mn0 = UHMN.row(r), *mnm = UHMN.row(r - 1);
-            const double vtm = VTM.row(r)[x];
+            const double vtm = VTM.row(r)[l];
             double t1, t2;
-            const double pe = pv0[x + 1], pc = pv0[x];
-            if (pe * vtm == 0.) t1 = pe * ((mx0[x + 1] + mxm[x + 1]) + (mn0[x + 1] + mnm[x + 1])) * .5;
-            else if (pe * vtm > 0.) t1 = pe * (mx0[x + 1] + mxm[x + 1]);
-            else t1 = pe * (mn0[x + 1] + mnm[x + 1]);
-            if (pc * vtm == 0.) t2 = pc * ((mx0[x] + mxm[x]) + (mn0[x] + mnm[x])) * .5;
-            else if (pc * vtm > 0.) t2 = pc * (mx0[x] + mxm[x]);
-            else t2 = pc * (mn0[x] + mnm[x]);
+            const double pe = pv0[l + 1], pc = pv0[l];
+            if (pe * vtm == 0.) t1 = pe * ((mx0[l + 1] + mxm[l + 1]) + (mn0[l + 1] + mnm[l + 1])) * .5;
+            else if (pe * vtm > 0.) t1 = pe * (mx0[l + 1] + mxm[l + 1]);
+            else t1 = pe * (mn0[l + 1] + mnm[l + 1]);
+            if (pc * vtm == 0.) t2 = pc * ((mx0[l] + mxm[l]) + (mn0[l] + mnm[l])) * .5;
+            else if (pc * vtm > 0.) t2 = pc * (mx0[l] + mxm[l]);
+            else t2 = pc * (mn0[l] + mnm[l]);
             cav = -.25 * (t1 + t2);
           } else if (mommth == 0)
-            cav = -.125 * (uf0[x] + uf0[x + 1] + ufm[x] + ufm[x + 1]) * (pv0[x] + pv0[x + 1]);
+            cav = -.125 * (uf0[l] + uf0[l + 1] + ufm[l] + ufm[l + 1]) * (pv0[l] + pv0[l + 1]);
           else
-            cav = -.25 * ((uf0[x] + ufm[x]) * pv0[x] + (uf0[x + 1] + ufm[x + 1]) * pv0[x + 1]);
+            cav = -.25 * ((uf0[l] + ufm[l]) * pv0[l] + (uf0[l + 1] + ufm[l + 1]) * pv0[l + 1]);
           double stress = 0.;
           if (k == 0) stress = -2. * tauy[c] * GRAV * scvy[c] / (p_1[c] + p_1[c - ni]);
           const double pbv = u_pbvm;
@@ -588,18 +623,19 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *Vp, int m, 
           const double pgf = (1. - 2. * WPGF) * u_pgym + WPGF * (u_pgyo + u_pgyn);
           o_vm[c] = vkm * (wuv1 * u_dpv + ONEMM) + vkn * wuv2 * u_dpvold;
           const double vbrhs = u_vbcors * tsfac;                                    // :307
-          o_vn[c] = vkn + delt1 * (-u_scvyi * (-pgf + stress + (ke0[x] - kem[x])) + cav - vbrhs + botstr - u_visv);
+          o_vn[c] = vkn + delt1 * (-u_scvyi * (-pgf + stress + (ke0[l] - kem[l])) + cav - vbrhs + botstr - u_visv);
         }
       }
     }
     __syncthreads();
-    tc = tn;
+    pr_p0 = u_p0; pr_p1 = u_p1; pr_drag = u_drag;
+    tpp = tp; tp = tc; tc = tn;
   }
 }
 
 // ---- :1154-1267 vertical pass, reading the updated velocities from the scratch planes ----------------------------
 // (k_mom_column of stage_momtum.hip with u(km), u(kn) taken from MF_UM/MF_UN, v likewise)
-__global__ void k_mom_column_from(const DevView *Vp, int m, int mm, int nn) {
+__global__ void k_mom_column_from(const DevView *__restrict__ Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -648,40 +684,39 @@ __global__ void k_mom_column_from(const DevView *Vp, int m, int mm, int nn) {
 template <int BS>
 static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca, int ncb) {
   const DevView &h = c->h;
-  const size_t la = sizeof(double) * 60 * h.ni, lb = sizeof(double) * (h.P.mommth == 2 ? 35 : 21) * h.ni;
+  const int nsa = (h.ii + (BS - 8) - 1) / (BS - 8), nsb = (h.ii + (BS - 4) - 1) / (BS - 4);
+  const size_t la = sizeof(double) * 37 * (BS + 4), lb = sizeof(double) * (h.P.mommth == 2 ? 35 : 21) * (BS + 4);
   // more than 64 KB of dynamic LDS has to be asked for
   (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-  hipLaunchKernelGGL(k_mom_visc_march<BS>, dim3(h.kk * nca), dim3(BS), la, c->stream, c->d, m, n, mm, nn, nca);
+  hipLaunchKernelGGL(k_mom_visc_march<BS>, dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, c->d, m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
   if (h.P.mommth == 2)
-    hipLaunchKernelGGL((k_mom_cor_march<BS, true>), dim3(h.kk * ncb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, ncb);
+    hipLaunchKernelGGL((k_mom_cor_march<BS, true>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
   else
-    hipLaunchKernelGGL((k_mom_cor_march<BS, false>), dim3(h.kk * ncb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, ncb);
+    hipLaunchKernelGGL((k_mom_cor_march<BS, false>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
 }
 
 // the layer loop and the vertical pass of momtum; the caller (st_momtum) has done p/pu/pv, the drag and difwgt's halo
 int st_momtum_fused_layers(blomgpu_ctx *c, int m, int n, int mm, int nn) {
   const DevView &h = c->h;
   if (h.nwk < MF_NSLOT) return ctx_fail(c, "momtum: device work space too small");
-  if (h.ni > 1024) return ctx_fail(c, "momtum (fused): rows longer than 1024 points are not built; set momtum_v = 1");
-  // chunks in j: one round of workgroups on the chip where the rows allow it (60 rows of LDS: one workgroup of the
-  // viscous chain per CU; 21 rows: four of the Coriolis chain)
+  // One wavefront per workgroup (the barriers of the march then cost nothing and 5 / 14 workgroups fit a CU by their
+  // LDS): strips of 56 / 60 owned columns.  Chunks in j: about one round of workgroups on the chip.
   const int cus = c->num_cus > 0 ? c->num_cus : 256;
-  auto chunks = [&](int slots, int opt) {
-    int nc = opt > 0 ? opt : slots / h.kk;
-    if (nc < 1) nc = 1;
-    if (nc > (h.jj + 7) / 8) nc = (h.jj + 7) / 8;          // at least 8 rows per chunk: the warm-up is 4-5 rows
+  const int bs = c->momtum_bs > 0 ? c->momtum_bs : 64;
+  auto chunks = [&](int slots, int nstrip, int opt) {
+    int nc = opt > 0 ? opt : slots / (h.kk * nstrip);
+    if (nc > (h.jj + 15) / 16) nc = (h.jj + 15) / 16;      // at least 16 rows per chunk: the warm-up is 4-5 rows
     return nc < 1 ? 1 : nc;
   };
-  const int nca = chunks(cus, c->momtum_chunks_a), ncb = chunks(4 * cus, c->momtum_chunks_b);
-  if (h.ni <= 64) launch_marches<64>(c, m, n, mm, nn, nca, ncb);
-  else if (h.ni <= 128) launch_marches<128>(c, m, n, mm, nn, nca, ncb);
-  else if (h.ni <= 192) launch_marches<192>(c, m, n, mm, nn, nca, ncb);
-  else if (h.ni <= 256) launch_marches<256>(c, m, n, mm, nn, nca, ncb);
-  else if (h.ni <= 384) launch_marches<384>(c, m, n, mm, nn, nca, ncb);
-  else if (h.ni <= 512) launch_marches<512>(c, m, n, mm, nn, nca, ncb);
-  else launch_marches<1024>(c, m, n, mm, nn, nca, ncb);
+  const int nsa = (h.ii + (bs - 8) - 1) / (bs - 8), nsb = (h.ii + (bs - 4) - 1) / (bs - 4);
+  const int nca = chunks(cus * (bs == 64 ? 8 : 160 * 1024 / (37 * (bs + 4) * 8)), nsa, c->momtum_chunks_a);
+  const int ncb = chunks(cus * 8 * 64 / bs, nsb, c->momtum_chunks_b);
+  if (bs == 64) launch_marches<64>(c, m, n, mm, nn, nca, ncb);
+  else if (bs == 128) launch_marches<128>(c, m, n, mm, nn, nca, ncb);
+  else if (bs == 256) launch_marches<256>(c, m, n, mm, nn, nca, ncb);
+  else return ctx_fail(c, "momtum: momtum_bs must be 64, 128 or 256");
   hipLaunchKernelGGL(k_mom_column_from, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, m, mm, nn);
   HIPCHK(c, hipGetLastError());
   return 0;

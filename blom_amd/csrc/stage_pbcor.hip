@@ -41,7 +41,7 @@
 #define S2_PBUT 1
 #define S2_PBVT 2
 
-__global__ void k_pbc_pscan(const DevView *Vp, int which, int offc) {
+__global__ void k_pbc_pscan(const DevView *__restrict__ Vp, int which, int offc) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][c]) return;
@@ -56,7 +56,7 @@ __global__ void k_pbc_pscan(const DevView *Vp, int which, int offc) {
   }
 }
 
-__global__ void k_pbc_total(const DevView *Vp, int which, int m, int n, int offf) {
+__global__ void k_pbc_total(const DevView *__restrict__ Vp, int which, int m, int n, int offf) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const size_t np = V.nplane;
@@ -80,7 +80,7 @@ __global__ void k_pbc_total(const DevView *Vp, int which, int m, int n, int offf
   }
 }
 
-__global__ void k_pbc_flux(const DevView *Vp, int which, int offc, int offf) {
+__global__ void k_pbc_flux(const DevView *__restrict__ Vp, int which, int offc, int offf) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   const int k = by_, ntr = V.ntr;
@@ -138,7 +138,7 @@ __global__ void k_pbc_flux(const DevView *Vp, int which, int offc, int offf) {
   }
 }
 
-__global__ void k_pbc_update(const DevView *Vp, int which, int offc) {
+__global__ void k_pbc_update(const DevView *__restrict__ Vp, int which, int offc) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -183,7 +183,7 @@ __global__ void k_pbc_update(const DevView *Vp, int which, int offc) {
   }
 }
 
-__global__ void k_pbc_rescale(const DevView *Vp, int which, int m, int offc) {
+__global__ void k_pbc_rescale(const DevView *__restrict__ Vp, int which, int m, int offc) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;

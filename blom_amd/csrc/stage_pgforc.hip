@@ -21,7 +21,7 @@ int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int with_pupv);
 #define EPSILP 1.e-12
 #define GRAV 9.806
 
-__global__ void k_pgf_copy_old2d(const DevView *Vp, int n) {
+__global__ void k_pgf_copy_old2d(const DevView *__restrict__ Vp, int n) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -40,7 +40,7 @@ __global__ void k_pgf_copy_old2d(const DevView *Vp, int n) {
   }
 }
 
-__global__ void k_pgf_copy_old3d(const DevView *Vp, int nn) {
+__global__ void k_pgf_copy_old3d(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -53,7 +53,7 @@ __global__ void k_pgf_copy_old3d(const DevView *Vp, int nn) {
 }
 
 // phi, phip at p-points, j,i = 0..jj/ii, phy/mod_pgforc.F90:112-134.  phip -> wkp0.
-__global__ void k_pgf_phi(const DevView *Vp, int nn) {
+__global__ void k_pgf_phi(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -83,7 +83,7 @@ __global__ void k_pgf_phi(const DevView *Vp, int nn) {
 
 // One u- or v-column per thread (blockIdx.y = 0: u, 1: v), phy/mod_pgforc.F90:140-257 and the
 // per-column part of :543-589.  `sh` is the plane offset of the "minus" neighbour (-1 or -ni).
-__global__ void k_pgf_uv(const DevView *Vp, int n, int nn) {
+__global__ void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -142,7 +142,7 @@ enum { DH_POT = 0, DH_POTPB, DH_A, DH_T, DH_ALPR, DH_NSLOT };
 #define ONEMM_ 9.806
 
 // per p-column, j,i = 0..jj/ii: bottom-up potentials (:282-312) and the derivatives (:318-341)
-__global__ void k_pgf_dynh_col(const DevView *Vp, int nn) {
+__global__ void k_pgf_dynh_col(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -191,7 +191,7 @@ __global__ void k_pgf_dynh_col(const DevView *Vp, int nn) {
 }
 
 // per u-/v-column (blockIdx.y = 0: u, 1: v): layer PGF and the vertical sums, :345-410, then :543-589
-__global__ void k_pgf_dynh_uv(const DevView *Vp, int n, int nn) {
+__global__ void k_pgf_dynh_uv(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -229,7 +229,7 @@ __global__ void k_pgf_dynh_uv(const DevView *Vp, int n, int nn) {
   (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
 }
 
-__global__ void k_pgf_sealv(const DevView *Vp) {
+__global__ void k_pgf_sealv(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;

@@ -17,7 +17,7 @@
   (void)i; (void)j; (void)c
 
 // ---- init_fluxes, phy/mod_state.F90:352-372 ------------------------------------------------
-__global__ void k_init_fluxes(const DevView *Vp, int mm) {
+__global__ void k_init_fluxes(const DevView *__restrict__ Vp, int mm) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 0 || j > V.jj + 2 || i < 0 || i > V.ii + 2) return;
@@ -34,7 +34,7 @@ int st_init_fluxes(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1
 }
 
 // ---- initms / tmsmt1, phy/mod_tmsmt.F90:161-277 ---------------------------------------------
-__global__ void k_tmsmt1(const DevView *Vp, int off, int is_initms) {
+__global__ void k_tmsmt1(const DevView *__restrict__ Vp, int off, int is_initms) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
@@ -66,7 +66,7 @@ int st_initms(blomgpu_ctx *c, int mm) {
 
 // ---- p(k+1) = p(k) + dp(k+off), j,i = -2..+2 (mod_tmsmt.F90:354-365, mod_pgforc.F90:451-461,
 //      mod_mxlayr.F90:1270-1280).  One thread per column, coalesced plane-by-plane. -----------
-__global__ void k_pscan(const DevView *Vp, int off, int lo, int hi_off) {
+__global__ void k_pscan(const DevView *__restrict__ Vp, int off, int lo, int hi_off) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < lo || j > V.jj + hi_off || i < lo || i > V.ii + hi_off || !V.m[I_ip][c]) return;
@@ -81,7 +81,7 @@ __global__ void k_pscan(const DevView *Vp, int off, int lo, int hi_off) {
 
 // ---- dpu,dpv (and optionally pu,pv) from p, j,i = -1..+2 (mod_tmsmt.F90:369-391,
 //      mod_pgforc.F90:463-485, mod_mxlayr.F90:1282-1310) --------------------------------------
-__global__ void k_dpudpv(const DevView *Vp, int off, int with_pupv) {
+__global__ void k_dpudpv(const DevView *__restrict__ Vp, int off, int with_pupv) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
@@ -130,7 +130,7 @@ int launch_pscan(blomgpu_ctx *c, int off, int lo, int hi_off) {
 }
 
 // ---- tmsmt2, phy/mod_tmsmt.F90:295-350: column sums then per-layer filter --------------------
-__global__ void k_tmsmt2(const DevView *Vp, int m, int mm, int nn) {
+__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -182,7 +182,7 @@ int st_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) {
 }
 
 // ---- kfpla halo through util1, phy/mod_cmnfld_routines.F90:1176-1196 --------------------------
-__global__ void k_kfpla_util(const DevView *Vp, int n, int back) {
+__global__ void k_kfpla_util(const DevView *__restrict__ Vp, int n, int back) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (!V.m[I_ip][c]) return;
@@ -203,7 +203,7 @@ int st_kfpla_halo(blomgpu_ctx *c, int n) {
 
 // ---- updtrc, trc/mod_tracers_update.F90:152-170 = hamocc_step (iHAMOCC, not on this path) + idlage_step,
 //      idlage/mod_idlage.F90:57-96: surface layer reset, deeper layers aged, all p-points incl. the halo ----
-__global__ void k_idlage_step(const DevView *Vp, int nn) {
+__global__ void k_idlage_step(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (!V.m[I_ip][c]) return;
@@ -227,7 +227,7 @@ int st_updtrc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
 // ---- budget_sums, phy/mod_budget.F90:95-196 (use_TRC; no GLS): mass weighted column sums of S and T (and the TKE
 //      tracer, util3) into util1, util2 (which = 0) or of tracer 1 into util1 (which = 1); their global sums through xcsum.  The salt
 //      correction term of call 5 (:182-194) needs mod_forcing's salt_corr, which no stage here produces. ----
-__global__ void k_budget_columns(const DevView *Vp, int nn, int which) {
+__global__ void k_budget_columns(const DevView *__restrict__ Vp, int nn, int which) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
