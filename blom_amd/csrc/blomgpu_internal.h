@@ -303,6 +303,25 @@ __device__ inline void xcd_block(unsigned &bx, unsigned &by) {
   by = nl / gx;
 }
 
+// Column kernels (one thread per column, levels walked serially) have one dependent load in flight per thread, and with
+// ~1700 wavefronts on the chip that is half the bandwidth a copy reaches (2.8 against 5.9 TB/s,
+// profiles/r02_fetch_calibration.txt: k_column8 / k_column8_u<4>).  COLUMN_U levels' loads are therefore issued
+// before the first of them is used; the arithmetic and its order are unchanged.
+#define COLUMN_U 8
+// dst(k+1) = dst(k) + src(k), k = 0..kk-1; src, dst point at level 0 of this thread's column; returns the last sum
+__device__ inline double column_scan(double acc, const double *__restrict__ src, double *__restrict__ dst, size_t np, int kk) {
+  int k = 0;
+  for (; k + COLUMN_U <= kk; k += COLUMN_U) {
+    double v[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) v[u] = src[(size_t)(k + u) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) { acc = acc + v[u]; dst[(size_t)(k + u + 1) * np] = acc; }
+  }
+  for (; k < kk; k++) { acc = acc + src[(size_t)k * np]; dst[(size_t)(k + 1) * np] = acc; }
+  return acc;
+}
+
 // launch helpers: 1 thread per point of the padded plane, blockIdx.y = level
 static inline dim3 plane_grid(const DevView &h, int nlev = 1, int block = 256) {
   return dim3((h.nplane + block - 1) / block, nlev, 1);

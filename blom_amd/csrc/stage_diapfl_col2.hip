@@ -23,7 +23,7 @@
 #define MAXTR 4
 
 enum { E_SU, E_SL, E_FCU, E_FCL, E_FMAX, E_H, E_R, E_T, E_F, E_FT, E_GTD, E_NSLOT };
-#define W(slot, k) WK(V, slot)[c + (size_t)((k)-1) * np]
+#define W(slot, k) w_##slot[c + (size_t)((k)-1) * np]
 #define ST(a, k) (a)[c + (size_t)((k)-1) * np]
 #define SIGR(k) sigr[c + (size_t)((k)-1) * np]
 #define PRES(k) pres[c + (size_t)((k)-1) * np]
@@ -43,12 +43,18 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
   const Params P = V.P;        // by value: the equation-of-state coefficients stay in registers across the stores
   const double dsgmnr = .1, fcmxr = .25, dsgcr0 = .25, dfeps = 1.e-12, gbbl = .2, kappa = .4, ustmin = .0001;
   const double cc = GRAV * GRAV * P.delt1 / (ALPHA0 * ALPHA0);                       // :95
-  const double *sigr = V.f[F_sigmar];
-  double *pres = V.f[F_wkp1];
-  double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
-  double *dp = V.f[F_dp] + (size_t)nn * np, *sigma = V.f[F_sigma] + (size_t)nn * np;
-  double *trc = V.f[F_trc] + (size_t)nn * np, *nu = V.f[F_difdia];
-  double *fpug = V.f[F_fpug], *fplg = V.f[F_fplg];
+  const double *__restrict__ sigr = V.f[F_sigmar];
+  double *__restrict__ pres = V.f[F_wkp1];
+  // one restrict pointer per work plane: the planes do not overlap, and knowing it lets the compiler keep the loads
+  // of the next levels in flight across the stores of this one
+  double *__restrict__ w_E_SU = WK(V, E_SU), *__restrict__ w_E_SL = WK(V, E_SL), *__restrict__ w_E_FCU = WK(V, E_FCU);
+  double *__restrict__ w_E_FCL = WK(V, E_FCL), *__restrict__ w_E_FMAX = WK(V, E_FMAX), *__restrict__ w_E_H = WK(V, E_H);
+  double *__restrict__ w_E_R = WK(V, E_R), *__restrict__ w_E_T = WK(V, E_T), *__restrict__ w_E_F = WK(V, E_F);
+  double *__restrict__ w_E_FT = WK(V, E_FT), *__restrict__ w_E_GTD = WK(V, E_GTD);
+  double *__restrict__ temp = V.f[F_temp] + (size_t)nn * np, *__restrict__ saln = V.f[F_saln] + (size_t)nn * np;
+  double *__restrict__ dp = V.f[F_dp] + (size_t)nn * np, *__restrict__ sigma = V.f[F_sigma] + (size_t)nn * np;
+  double *__restrict__ trc = V.f[F_trc] + (size_t)nn * np, *__restrict__ nu = V.f[F_difdia];
+  double *__restrict__ fpug = V.f[F_fpug], *__restrict__ fplg = V.f[F_fplg];
 
   int kmax = 1;                                                                      // :139-143
   for (int k = 2; k <= kk; k++)
@@ -94,6 +100,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
       int rst2 = -1;
       if (kfpl != kmax)
         if (dens_k > .5 * (sr_k + SIGR(kfpl + 1))) rst2 = kfpl + 1;
+      #pragma unroll 4
       for (k = kfpl; k <= kmax - 1; k++) {
         const double tp = ST(temp, k + 1), sp = ST(saln, k + 1), dens_p = ST(sigma, k + 1), sr_p = SIGR(k + 1);
         double su = 1., sl = 1., fcu = 0., fcl = 0.;
@@ -146,6 +153,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
       while (!done) {
         done = true;
         double fmax_p = 0., fcu_p = fcu_b, sui_p = sui_b;
+        #pragma unroll 4
         for (k = kmax - 1; k >= kfpl; k--) {
           const double q = ((fmax_p + fcu_p) * sui_p + presb - PRES(k + 1)) * W(E_SL, k);
           const double fcl = fmax2(-q, W(E_FCL, k));
@@ -157,6 +165,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
         }
         kfmaxu = 0;
         double fmax_m = 0., fcl_m = -fpl1, sli_m = 1.;
+        #pragma unroll 4
         for (k = kfpl; k <= kmax - 1; k++) {
           const double q = ((fmax_m - fcl_m) * sli_m + PRES(k) - preskf) * W(E_SU, k);
           double fcu = W(E_FCU, k);
@@ -176,6 +185,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
       {
         double fcl_m = -fpl1, sli_m = 1.;
         double fcu_k = kfpl <= kmax - 1 ? W(E_FCU, kfpl) : 0., su_k = kfpl <= kmax - 1 ? W(E_SU, kfpl) : 1.;
+        #pragma unroll 4
         for (k = kfpl; k <= kmax - 1; k++) {
           const double fcu_n = k + 1 <= kmax - 1 ? W(E_FCU, k + 1) : fcu_b;
           const double su_n = k + 1 <= kmax - 1 ? W(E_SU, k + 1) : su_b;
@@ -203,6 +213,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
         bool remfmx = false;
         if (dwnwrd) {
           double f0m = 0., fnew_m = 0., slim = 1.;             // f0, f, dsgli of level kfpl-1
+          #pragma unroll 4
           for (k = kfpl; k <= kmax - 1; k++) {
             const double fmx = W(E_FMAX, k);
             if (remfmx) { W(E_GTD, k) = 0.; W(E_FT, k) = fmx; }
@@ -225,6 +236,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
             }
           }
           double fnew_p = 0., gtd_p = 0.;                       // f, gtd of level kmax
+          #pragma unroll 4
           for (k = kmax - 1; k >= kfpl; k--) {
             const double fk = fmin2(W(E_FMAX, k), W(E_FT, k) - gtd_p * fnew_p);
             maxdf = fmax2(maxdf, fabs(fk - W(E_F, k)));
@@ -234,6 +246,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
           }
         } else {
           double f0p = 0., fnew_p = 0., suip = sui_b;           // f0, f of level kmax; dsgui(kmax)
+          #pragma unroll 4
           for (k = kmax - 1; k >= kfpl; k--) {
             const double fmx = W(E_FMAX, k);
             if (remfmx) { W(E_GTD, k) = 0.; W(E_FT, k) = fmx; }
@@ -256,6 +269,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
             }
           }
           double fnew_m = 0., gtd_m = 0.;                       // f, gtd of level kfpl-1
+          #pragma unroll 4
           for (k = kfpl; k <= kmax - 1; k++) {
             const double fk = fmin2(W(E_FMAX, k), W(E_FT, k) - gtd_m * fnew_m);
             maxdf = fmax2(maxdf, fabs(fk - W(E_F, k)));
@@ -269,6 +283,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
         if (niter == 100) { atomicOr(errflag, 2); break; }                         // :520-532 (xchalt)
       }
       // ---- interface fluxes, :536-541 -------------------------------------------------------------
+      #pragma unroll 4
       for (k = kfpl; k <= kmax - 1; k++) {
         const double fk = W(E_F, k);
         ST(fpug, k) = (fk + W(E_FCU, k)) * (1. / W(E_SU, k));
@@ -380,11 +395,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column2(const DevView *__restr
     }
   }
   // ---- interface pressure and the fluxes handed to the momentum mixing, :654-700, :718 ---------
-  double pacc = V.f[F_p][c];
-  for (int k = 1; k <= kk; k++) {
-    pacc = pacc + ST(dp, k);
-    V.f[F_p][c + (size_t)k * np] = pacc;
-  }
+  column_scan(V.f[F_p][c], dp + c, V.f[F_p] + c, np, kk);
   V.f[F_util1][c] = (double)kmin;
   if (mixing) {
     for (int k = 1; k <= kmin; k++) { ST(fpug, k) = fpl0; ST(fplg, k) = fpl0; }

@@ -54,14 +54,8 @@ __global__ void k_mom_pupv(const DevView *__restrict__ Vp, int off, int lo, int 
   THREAD_IJ(V);
   if (j < lo || j > V.jj + hi || i < lo || i > V.ii + hi) return;
   const size_t np = V.nplane;
-  if (V.m[I_iu][c]) {
-    double acc = V.f[F_pu][c];
-    for (int k = 0; k < V.kk; k++) { acc = acc + V.f[F_dpu][c + (size_t)(k + off) * np]; V.f[F_pu][c + (size_t)(k + 1) * np] = acc; }
-  }
-  if (V.m[I_iv][c]) {
-    double acc = V.f[F_pv][c];
-    for (int k = 0; k < V.kk; k++) { acc = acc + V.f[F_dpv][c + (size_t)(k + off) * np]; V.f[F_pv][c + (size_t)(k + 1) * np] = acc; }
-  }
+  if (V.m[I_iu][c]) column_scan(V.f[F_pu][c], V.f[F_dpu] + (size_t)off * np + c, V.f[F_pu] + c, np, V.kk);
+  if (V.m[I_iv][c]) column_scan(V.f[F_pv][c], V.f[F_dpv] + (size_t)off * np + c, V.f[F_pv] + c, np, V.kk);
 }
 
 // p(k+1) = p(k) + dp(k+off) for j,i = lo..+hi
@@ -70,8 +64,7 @@ __global__ void k_mom_pscan(const DevView *__restrict__ Vp, int off, int lo, int
   THREAD_IJ(V);
   if (j < lo || j > V.jj + hi || i < lo || i > V.ii + hi || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
-  double acc = V.f[F_p][c];
-  for (int k = 0; k < V.kk; k++) { acc = acc + V.f[F_dp][c + (size_t)(k + off) * np]; V.f[F_p][c + (size_t)(k + 1) * np] = acc; }
+  column_scan(V.f[F_p][c], V.f[F_dp] + (size_t)off * np + c, V.f[F_p] + c, np, V.kk);
 }
 
 // ---- :260-292 bottom drag ------------------------------------------------------------------------

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
 
 // ---- :1154-1267 vertical pass, reading the updated velocities from the scratch planes ----------------------------
 // (k_mom_column of stage_momtum.hip with u(km), u(kn) taken from MF_UM/MF_UN, v likewise)
-__global__ void k_mom_column_from(const DevView *__restrict__ Vp, int m, int mm, int nn) {
+__global__ __launch_bounds__(64) void k_mom_column_from(const DevView *__restrict__ Vp, int m, int mm, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -655,28 +655,54 @@ __global__ void k_mom_column_from(const DevView *__restrict__ Vp, int m, int mm,
   const double ub = (isv ? V.f[F_vb] : V.f[F_ub])[c + (size_t)(m - 1) * np];
   const double wuv1 = V.P.wuv1, wuv2 = V.P.wuv2;
   double tot = 0., uabove = 0.;
-  for (int k = 0; k < kk; k++) {
-    const size_t okm = c + (size_t)(k + mm) * np, okn = c + (size_t)(k + nn) * np;
-    const double dn = dpu[okn];
-    const double q = fmin2(fmin2(dpu[okm], dn), ONEM);
-    double un = sn[c + (size_t)k * np];
-    const double ukan = k == 0 ? un : uabove;                              // kan = max(1,k-1)+nn
-    un = (un * q + ukan * (ONEM - q)) / ONEM;
-    un = fmax2(-umax, fmin2(umax, un + ub)) - ub;
-    u[okn] = un;
-    uabove = un;
-    tot = tot + un * dn;
+  const double *dpum = dpu + c + (size_t)mm * np, *dpun = dpu + c + (size_t)nn * np;
+  double *um = u + c + (size_t)mm * np, *un_ = u + c + (size_t)nn * np;
+  sm += c; sn += c; dpuold += c;
+  for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {                // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+    double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const size_t o = (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np;
+      a[u] = dpum[o]; b[u] = dpun[o]; d[u] = sn[o];
+    }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 + u;
+      if (k < kk) {
+        const double dn = b[u];
+        const double q = fmin2(fmin2(a[u], dn), ONEM);
+        double un = d[u];
+        const double ukan = k == 0 ? un : uabove;                              // kan = max(1,k-1)+nn
+        un = (un * q + ukan * (ONEM - q)) / ONEM;
+        un = fmax2(-umax, fmin2(umax, un + ub)) - ub;
+        un_[(size_t)k * np] = un;
+        uabove = un;
+        tot = tot + un * dn;
+      }
+    }
   }
   tot = tot / (isv ? V.f[F_pbv_p] : V.f[F_pbu_p])[c];
   double pacc = (isv ? V.f[F_pv] : V.f[F_pu])[c];
-  for (int k = 0; k < kk; k++) {
-    const size_t okm = c + (size_t)(k + mm) * np, okn = c + (size_t)(k + nn) * np;
-    const double dn = dpu[okn];
-    const double un = u[okn] - tot;
-    u[okn] = un;
-    u[okm] = (sm[c + (size_t)k * np] + un * wuv2 * dn) / (wuv1 * dpu[okm] + ONEMM + wuv2 * (dpuold[c + (size_t)k * np] + dn));
-    pacc = pacc + dn;
-    (isv ? V.f[F_pv] : V.f[F_pu])[c + (size_t)(k + 1) * np] = pacc;
+  double *pun = (isv ? V.f[F_pv] : V.f[F_pu]) + c;
+  for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
+    double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U], f[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const size_t o = (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np;
+      a[u] = dpum[o]; b[u] = dpun[o]; d[u] = un_[o]; e[u] = sm[o]; f[u] = dpuold[o];
+    }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 + u;
+      if (k < kk) {
+        const double dn = b[u];
+        const double un = d[u] - tot;
+        un_[(size_t)k * np] = un;
+        um[(size_t)k * np] = (e[u] + un * wuv2 * dn) / (wuv1 * a[u] + ONEMM + wuv2 * (f[u] + dn));
+        pacc = pacc + dn;
+        pun[(size_t)(k + 1) * np] = pacc;
+      }
+    }
   }
   (isv ? V.f[F_vtotn] : V.f[F_utotn])[c] = tot * (1. / V.P.delt1);
 }

@@ -48,7 +48,20 @@ __global__ void k_pbc_pscan(const DevView *__restrict__ Vp, int which, int offc)
   const size_t np = V.nplane;
   double *dp = V.f[F_dp] + (size_t)offc * np, *p = V.f[F_p];
   double acc = p[c];
-  for (int k = 0; k < V.kk; k++) {
+  int k = 0;
+  for (; k + COLUMN_U <= V.kk; k += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+    double v[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) v[u] = dp[c + (size_t)(k + u) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      double d = v[u];
+      if (which == 2) { d = fmax2(0., d) + EPSILP; dp[c + (size_t)(k + u) * np] = d; }   // :448
+      acc = acc + d;
+      p[c + (size_t)(k + u + 1) * np] = acc;
+    }
+  }
+  for (; k < V.kk; k++) {
     double d = dp[c + (size_t)k * np];
     if (which == 2) { d = fmax2(0., d) + EPSILP; dp[c + (size_t)k * np] = d; }   // :448
     acc = acc + d;

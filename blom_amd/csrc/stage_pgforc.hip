@@ -53,7 +53,7 @@ __global__ void k_pgf_copy_old3d(const DevView *__restrict__ Vp, int nn) {
 }
 
 // phi, phip at p-points, j,i = 0..jj/ii, phy/mod_pgforc.F90:112-134.  phip -> wkp0.
-__global__ void k_pgf_phi(const DevView *__restrict__ Vp, int nn) {
+__global__ __launch_bounds__(64) void k_pgf_phi(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
@@ -66,18 +66,30 @@ __global__ void k_pgf_phi(const DevView *__restrict__ Vp, int nn) {
   double ph = phi[c + (size_t)kk * np], php = 0.;
   phip[c + (size_t)kk * np] = 0.;
   double plo = p[c + (size_t)kk * np];
-  for (int k = kk - 1; k >= 0; k--) {
-    const double pup = p[c + (size_t)k * np];
-    const size_t okn = c + (size_t)(k + nn) * np;
-    if (!(V.f[F_dp][okn] < EPSILP)) {
-      double dphi, alpu, alpl;
-      eos::delphi(pup, plo, V.f[F_temp][okn], V.f[F_saln][okn], dphi, alpu, alpl);
-      ph = ph - dphi;
-      php = php + plo * alpl - pup * alpu;
+  const double *dpn = V.f[F_dp] + (size_t)nn * np + c, *tn = V.f[F_temp] + (size_t)nn * np + c, *sn = V.f[F_saln] + (size_t)nn * np + c;
+  for (int k0 = kk - 1; k0 >= 0; k0 -= COLUMN_U) {            // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+    double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const size_t o = (size_t)(k0 - u >= 0 ? k0 - u : 0) * np;
+      a[u] = p[c + o]; b[u] = dpn[o]; d[u] = tn[o]; e[u] = sn[o];
     }
-    phi[c + (size_t)k * np] = ph;
-    phip[c + (size_t)k * np] = php;
-    plo = pup;
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 - u;
+      if (k >= 0) {
+        const double pup = a[u];
+        if (!(b[u] < EPSILP)) {
+          double dphi, alpu, alpl;
+          eos::delphi(pup, plo, d[u], e[u], dphi, alpu, alpl);
+          ph = ph - dphi;
+          php = php + plo * alpl - pup * alpu;
+        }
+        phi[c + (size_t)k * np] = ph;
+        phip[c + (size_t)k * np] = php;
+        plo = pup;
+      }
+    }
   }
 }
 

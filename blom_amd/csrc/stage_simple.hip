@@ -70,18 +70,12 @@ __global__ void k_pscan(const DevView *__restrict__ Vp, int off, int lo, int hi_
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < lo || j > V.jj + hi_off || i < lo || i > V.ii + hi_off || !V.m[I_ip][c]) return;
-  const double *dp = V.f[F_dp] + (size_t)off * V.nplane;
-  double *p = V.f[F_p];
-  double acc = p[c];
-  for (int k = 0; k < V.kk; k++) {
-    acc = acc + dp[c + (size_t)k * V.nplane];
-    p[c + (size_t)(k + 1) * V.nplane] = acc;
-  }
+  column_scan(V.f[F_p][c], V.f[F_dp] + (size_t)off * V.nplane + c, V.f[F_p] + c, V.nplane, V.kk);
 }
 
 // ---- dpu,dpv (and optionally pu,pv) from p, j,i = -1..+2 (mod_tmsmt.F90:369-391,
 //      mod_pgforc.F90:463-485, mod_mxlayr.F90:1282-1310) --------------------------------------
-__global__ void k_dpudpv(const DevView *__restrict__ Vp, int off, int with_pupv) {
+__global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, int off, int with_pupv) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
@@ -95,24 +89,39 @@ __global__ void k_dpudpv(const DevView *__restrict__ Vp, int off, int with_pupv)
   double *dpu = V.f[F_dpu] + (size_t)off * np, *dpv = V.f[F_dpv] + (size_t)off * np;
   double pu = wu ? V.f[F_pu][c] : 0., pv = wv ? V.f[F_pv][c] : 0.;
   double pc0 = p[c], pw0 = wu ? p[w] : 0., ps0 = wv ? p[s] : 0.;
-  for (int k = 0; k < V.kk; k++) {
-    const size_t o1 = (size_t)(k + 1) * np;
-    const double pc1 = p[c + o1];
-    if (wu) {
-      const double pw1 = p[w + o1];
-      const double d = .5 * ((fmin2(qu, pw1) - fmin2(qu, pw0)) + (fmin2(qu, pc1) - fmin2(qu, pc0)));
-      dpu[c + (size_t)k * np] = d;
-      if (with_pupv) { pu = pu + d; V.f[F_pu][c + o1] = pu; }
-      pw0 = pw1;
+  double *pug = V.f[F_pu], *pvg = V.f[F_pv];
+  const size_t wl = wu ? w : c, sl = wv ? s : c;           // a land neighbour's column is not read: take the own one
+  const int kk = V.kk;
+  for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+    double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const size_t o1 = (size_t)((k0 + u < kk ? k0 + u : kk - 1) + 1) * np;
+      a[u] = p[c + o1]; b[u] = p[wl + o1]; d[u] = p[sl + o1];
     }
-    if (wv) {
-      const double ps1 = p[s + o1];
-      const double d = .5 * ((fmin2(qv, ps1) - fmin2(qv, ps0)) + (fmin2(qv, pc1) - fmin2(qv, pc0)));
-      dpv[c + (size_t)k * np] = d;
-      if (with_pupv) { pv = pv + d; V.f[F_pv][c + o1] = pv; }
-      ps0 = ps1;
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 + u;
+      if (k < kk) {
+        const size_t o1 = (size_t)(k + 1) * np;
+        const double pc1 = a[u];
+        if (wu) {
+          const double pw1 = b[u];
+          const double dd = .5 * ((fmin2(qu, pw1) - fmin2(qu, pw0)) + (fmin2(qu, pc1) - fmin2(qu, pc0)));
+          dpu[c + (size_t)k * np] = dd;
+          if (with_pupv) { pu = pu + dd; pug[c + o1] = pu; }
+          pw0 = pw1;
+        }
+        if (wv) {
+          const double ps1 = d[u];
+          const double dd = .5 * ((fmin2(qv, ps1) - fmin2(qv, ps0)) + (fmin2(qv, pc1) - fmin2(qv, pc0)));
+          dpv[c + (size_t)k * np] = dd;
+          if (with_pupv) { pv = pv + dd; pvg[c + o1] = pv; }
+          ps0 = ps1;
+        }
+        pc0 = pc1;
+      }
     }
-    pc0 = pc1;
   }
 }
 

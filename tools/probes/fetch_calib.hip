@@ -45,6 +45,23 @@ __global__ void k_column8(const double *__restrict__ a, double *__restrict__ b, 
   for (int k = 0; k < nk; k++) { acc = acc + a[(size_t)k * np + t]; b[(size_t)k * np + t] = acc; }
 }
 
+// the column pattern with U levels' loads in flight per thread (manual software pipelining)
+template <int U>
+__global__ void k_column8_u(const double *__restrict__ a, double *__restrict__ b, int np, int nk) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np) return;
+  double acc = 0.0;
+  int k = 0;
+  for (; k + U <= nk; k += U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = a[(size_t)(k + u) * np + t];
+#pragma unroll
+    for (int u = 0; u < U; u++) { acc = acc + v[u]; b[(size_t)(k + u) * np + t] = acc; }
+  }
+  for (; k < nk; k++) { acc = acc + a[(size_t)k * np + t]; b[(size_t)k * np + t] = acc; }
+}
+
 int main() {
   const int ni = 216, nj = 520, nk = 1060;                 // 1060 planes of the channel's padded size: 0.95 GB per array
   const size_t n = (size_t)ni * nj * nk, bytes = n * 8;
@@ -60,6 +77,9 @@ int main() {
     hipLaunchKernelGGL(k_read8, dim3((n + B - 1) / B), dim3(B), 0, 0, a, b, n);
     hipLaunchKernelGGL(k_stencil8, dim3((ni * nj + B - 1) / B, nk), dim3(B), 0, 0, a, b, ni, nj, nk);
     hipLaunchKernelGGL(k_column8, dim3((ni * nj + 63) / 64), dim3(64), 0, 0, a, b, ni * nj, nk);
+    hipLaunchKernelGGL(k_column8_u<4>, dim3((ni * nj + 63) / 64), dim3(64), 0, 0, a, b, ni * nj, nk);
+    hipLaunchKernelGGL(k_column8_u<8>, dim3((ni * nj + 63) / 64), dim3(64), 0, 0, a, b, ni * nj, nk);
+    hipLaunchKernelGGL(k_column8_u<16>, dim3((ni * nj + 63) / 64), dim3(64), 0, 0, a, b, ni * nj, nk);
   }
   CHK(hipDeviceSynchronize());
   printf("bytes_per_array %zu\n", bytes);
