@@ -343,6 +343,29 @@ int blomgpu_crc(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype,
   return st_crc(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, itype, crc);
 }
 
+int blomgpu_crc_strips(blomgpu_ctx *c, const char *name, int lev0, int nlev, int itype, unsigned *out, int cap, int *l0, int *ns) {
+  auto it = c->real_ids.find(name);
+  if (it == c->real_ids.end()) return ctx_fail(c, std::string("crc_strips: unknown field ") + name);
+  if (lev0 < 1 || nlev < 1 || lev0 - 1 + nlev > c->nlev_real[it->second])
+    return ctx_fail(c, std::string("crc_strips: levels out of range for field ") + name);
+  ctx_sync_view(c);
+  return st_crc_strips(c, c->h.f[it->second] + (size_t)(lev0 - 1) * c->h.nplane, nlev, itype, out, cap, l0, ns);
+}
+
+// names of the registered fields, in registry order (reals first): lets a host scatter a whole state over tiles
+int blomgpu_field_name(blomgpu_ctx *c, int index, char *buf, int cap) {
+  const int nr = (int)c->real_ids.size(), ni = (int)c->int_ids.size();
+  if (index < 0 || index >= nr + ni || cap < 2) return 1;
+  const auto &m = index < nr ? c->real_ids : c->int_ids;
+  const int want = index < nr ? index : index - nr;
+  for (const auto &kv : m)
+    if (kv.second == want) {
+      snprintf(buf, cap, "%s", kv.first.c_str());
+      return 0;
+    }
+  return 1;
+}
+
 // settings of the reference's compile-time tracer switches that this library does not carry
 static int check_tracer_options(blomgpu_ctx *c) {
   const Params &P = c->h.P;

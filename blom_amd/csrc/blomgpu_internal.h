@@ -277,6 +277,7 @@ int st_xctilr_arctic_multi(blomgpu_ctx *, int nf, double *const *ptrs, const int
 // several stacks (ptrs[f] = first level, nlevs[f] levels) with common widths in one launch where possible
 int st_xctilr_multi(blomgpu_ctx *, int nf, double *const *ptrs, const int *nlevs, int mh, int nh, const int *itypes);
 int st_crc(blomgpu_ctx *, const double *base, int nlev, int itype, unsigned *crc);
+int st_crc_strips(blomgpu_ctx *, double *base, int nlev, int itype, unsigned *out, int cap, int *l0, int *ns);
 // locate the field (and level offset) a device pointer belongs to; returns field id or -1
 int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);
 int rccl_xctilr(blomgpu_ctx *, double *base, int nlev, int mhl, int nhl);   // comm_rccl.hip

@@ -272,14 +272,23 @@ int blomgpu_rccl_unique_id(void *id128) {
   memcpy(id128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
   return 0;
 }
-// Tiles: npx x npy, rank = px + npx*py; the context must have been created with the matching window
-// (i0 = px*ii, j0 = py*jj, itdm = npx*ii, jtdm = npy*jj).
+// Tiles: npx x npy, rank = px + npx*py, laid out as the reference's patch.input does it (bld/blom_dimensions:104-148;
+// e.g. bld/tnx2v1/patch.input.8: four tile columns of 45, two tile rows of 97 and 96): every tile of a tile column
+// has the same i-extent, every tile of a tile row the same j-extent, so E/W neighbours agree on the strip length and
+// N/S neighbours on the row length without knowing each other's sizes.  The context must have been created with its
+// window (i0, j0, ii, jj) of the (itdm, jtdm) domain; the tile columns must be equally wide on a tripolar grid (the
+// fold pairs tile column q with npx-1-q).
 int blomgpu_rccl_init_2d(blomgpu_ctx *c, const void *id128, int rank, int npx, int npy) {
   if (npx < 1 || npy < 1 || rank < 0 || rank >= npx * npy) return ctx_fail(c, "rccl_init: bad tile grid");
   const int px = rank % npx, py = rank / npx;
-  if (c->h.i0 != px * c->h.ii || c->h.itdm != npx * c->h.ii || c->h.j0 != py * c->h.jj || c->h.jtdm != npy * c->h.jj)
-    return ctx_fail(c, "rccl_init: the context's window does not match tile (px,py) of a uniform npx x npy grid "
-                       "(i0 = px*idm, j0 = py*jdm, itdm = npx*idm, jtdm = npy*jdm)");
+  const DevView &h = c->h;
+  const bool first_i = px == 0, last_i = px == npx - 1, first_j = py == 0, last_j = py == npy - 1;
+  if ((h.i0 == 0) != first_i || (h.i0 + h.ii == h.itdm) != last_i || (h.j0 == 0) != first_j || (h.j0 + h.jj == h.jtdm) != last_j ||
+      h.i0 < 0 || h.j0 < 0 || h.i0 + h.ii > h.itdm || h.j0 + h.jj > h.jtdm)
+    return ctx_fail(c, "rccl_init: the context's window (i0, j0, idm, jdm) does not fit tile (px,py) of the npx x npy grid");
+  if (h.nreg == 2 && (h.i0 != px * h.ii || h.itdm != npx * h.ii))
+    return ctx_fail(c, "rccl_init: a tripolar grid needs equally wide tile columns (i0 = px*idm, itdm = npx*idm)");
+  if (h.ii < NBDY || h.jj < NBDY) return ctx_fail(c, "rccl_init: a tile must be at least nbdy points wide");
   HIPCHK(c, hipSetDevice(c->device));
   RcclComm *R = new RcclComm();
   ncclUniqueId id;

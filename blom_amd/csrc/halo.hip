@@ -658,6 +658,73 @@ int st_crc(blomgpu_ctx *c, const double *base, int nlev, int itype, unsigned *cr
   return 0;
 }
 
+// ---- xccrc over several tiles (phy/mod_xc.F90:2195-2322) ---------------------------------------------------------
+// The checksum is defined on the GLOBAL domain: rows are cut into strips of 2*nbdy+1 = 9 columns starting at global
+// column 1, a strip's CRC runs over its wet points, a row's CRC chains its strips' CRCs, the result chains the rows'.
+// A strip belongs to the tile that holds its centre column, which therefore finds all of it inside its halo of width
+// nbdy after a halo update with vland = 0 (:2232-2240).  This entry does the halo update and returns the CRCs of the
+// tile's own strips, [row 1..jj][strip], plus the global index of its first strip; the caller chains them over the
+// tiles (blom_amd/tiles.py: chain_crc; between processes over torch.distributed) -- a diagnostic, off the hot path.
+__global__ void k_crc_strips_tile(const DevView *__restrict__ Vp, const double *__restrict__ a, int nlev,
+                                  const int *__restrict__ mask, int l0, int nstrip, unsigned *__restrict__ out) {
+  const DevView &V = *Vp;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nstrip * V.jj) return;
+  const int j = t / nstrip + 1, s = t % nstrip;
+  const int g1 = 1 + (l0 + s) * (2 * NBDY + 1);                 // global columns g1..g2
+  const int g2 = min(g1 + 2 * NBDY, V.itdm);
+  unsigned crc8p = 0;
+  for (int ig = g1; ig <= g2; ig++) {
+    const int i = ig - V.i0;                                     // 1-nbdy .. ii+nbdy by the ownership rule
+    if (mask[IDX(V, i, j)] != 1) continue;
+    unsigned crc = ~crc8p;
+    for (int k = 0; k < nlev; k++) {
+      unsigned long long bits = __double_as_longlong(a[(size_t)k * V.nplane + IDX(V, i, j)]);
+      for (int b = 0; b < 8; b++) crc = crc_byte(crc, (unsigned)(bits >> (8 * b)) & 255u);
+    }
+    crc8p = ~crc;
+  }
+  out[t] = crc8p;
+}
+
+int st_crc_strips(blomgpu_ctx *c, double *base, int nlev, int itype, unsigned *out, int cap, int *l0_out, int *ns_out) {
+  DevView &h = c->h;
+  const int g = itype % 10, W = 2 * NBDY + 1;
+  const int *mask = g == 1 ? h.m[I_ip] : g == 2 ? h.m[I_iq] : g == 3 ? h.m[I_iu] : h.m[I_iv];
+  // strips whose centre column (clipped to the domain) lies in i0+1 .. i0+ii
+  const int ntot = (h.itdm + W - 1) / W;
+  int l0 = -1, ns = 0;
+  for (int l = 0; l < ntot; l++) {
+    const int ctr = min(1 + l * W + NBDY, h.itdm);
+    if (ctr > h.i0 && ctr <= h.i0 + h.ii) { if (l0 < 0) l0 = l; ns++; }
+  }
+  *l0_out = l0 < 0 ? 0 : l0;
+  *ns_out = ns;
+  if (ns * h.jj > cap) return ctx_fail(c, "crc_strips: output buffer too small");
+  if (c->tiling.multi()) {                    // halo in i so that the strips are on chip (one tile: every strip is interior)
+    // A plain E/W update (rows 1..jj, vland = 0): on a tripolar grid the fold is left out of it -- the serial xccrc
+    // the golden checksums come from (phy/mod_xc.F90:4164-4205) reads the seam row as it stands, and so must the
+    // strips that reach into a neighbour's columns (the reference's MPI form updates with the fold and restores the
+    // seam row afterwards, :2233-2240, :2307-2311).
+    const double vsave = h.P.vland;
+    const int nreg_save = h.nreg;
+    h.P.vland = 0.0;
+    if (h.nreg == 2) h.nreg = 1;
+    c->dirty = true; ctx_sync_view(c);
+    int rc = st_xctilr(c, base, 1, nlev, NBDY, 0, itype % 10);
+    h.P.vland = vsave; h.nreg = nreg_save; c->dirty = true; ctx_sync_view(c);
+    if (rc) return rc;
+  }
+  if (ns == 0) return 0;                      // a narrow tile may own no strip; it still took part in the halo update
+  unsigned *dout = nullptr;
+  HIPCHK(c, hipMalloc((void **)&dout, sizeof(unsigned) * ns * h.jj));
+  hipLaunchKernelGGL(k_crc_strips_tile, dim3((ns * h.jj + 63) / 64), dim3(64), 0, c->stream, c->d, base, nlev, mask, l0, ns, dout);
+  HIPCHK(c, hipMemcpyAsync(out, dout, sizeof(unsigned) * ns * h.jj, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dout);
+  return 0;
+}
+
 // ---- xcsum (phy/mod_xc.F90:4116-4161): masked sum of a 2-D array that is reproducible bit for bit --------
 // Every row is summed in strips of 2*nbdy+1 = 9 points, strip sums are added to the row sum in order, and
 // the row sums are added serially: the order is part of the definition, so the rows go to the threads of ONE

@@ -126,6 +126,24 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_crc(self.ctx, name.encode(), lev0, nlev, itype, C.byref(v)))
         return v.value
 
+    def crc_strips(self, name, lev0, nlev, itype=1):
+        """This tile's share of the decomposition-independent checksum (xccrc, phy/mod_xc.F90:2195-2322): (l0, strips)
+        with strips[row, s] the CRC of its s-th own 9-column strip of the global rows; chain with tiles.chain_crc."""
+        cap = self.jdm * ((self.idm + 8) // 9 + 2)
+        out = np.zeros(cap, dtype=np.uint32)
+        l0, ns = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.blomgpu_crc_strips(self.ctx, name.encode(), lev0, nlev, itype, out.ctypes.data_as(C.c_void_p),
+                                              cap, C.byref(l0), C.byref(ns)))
+        return l0.value, out[:self.jdm * ns.value].reshape(self.jdm, ns.value).copy()
+
+    def field_names(self):
+        """every registered field (reals, then integers): the arrays a whole state consists of"""
+        names, buf, k = [], C.create_string_buffer(64), 0
+        while self.lib.blomgpu_field_name(self.ctx, k, buf, 64) == 0:
+            names.append(buf.value.decode())
+            k += 1
+        return names
+
     def xcsum(self, name, lev=1, itype=1):
         """xcsum (phy/mod_xc.F90:4116) of one level of a device field; p-grid mask: ips."""
         v = C.c_double(0.0)

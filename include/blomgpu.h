@@ -69,6 +69,16 @@ int  blomgpu_xctilr(blomgpu_ctx *ctx, const char *name, int lev0, int l1, int ld
  * (phy/mod_checksum.F90:41-74, phy/mod_xc.F90:4164). */
 int  blomgpu_crc(blomgpu_ctx *ctx, const char *name, int lev0, int nlev, int itype, unsigned *crc);
 
+/* xccrc on a decomposed domain (phy/mod_xc.F90:2195-2322): after the halo update the reference performs there, the
+ * CRCs of the 9-column strips this tile owns (those whose centre column lies in the tile), out[row 1..jdm][strip];
+ * *l0 = global index of its first strip, *ns = their number.  Chaining the strips of a tile row in global order, then
+ * the rows, gives the decomposition-independent checksum (blom_amd/tiles.py: chain_crc); for one tile that is
+ * blomgpu_crc. */
+int  blomgpu_crc_strips(blomgpu_ctx *ctx, const char *name, int lev0, int nlev, int itype, unsigned *out, int cap,
+                        int *l0, int *ns);
+/* Name of registered field number `index` (0-based; 1 when there is none): enumeration for hosts that move whole states. */
+int  blomgpu_field_name(blomgpu_ctx *ctx, int index, char *buf, int cap);
+
 /* Stages: same names, same argument meaning as the reference. */
 int  blomgpu_init_fluxes(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n); /* phy/mod_state.F90:341   */
 int  blomgpu_tmsmt1 (blomgpu_ctx *, int nn);                                             /* phy/mod_tmsmt.F90:209   */

@@ -29,5 +29,5 @@ if os.environ.get("BLOM_HOSTEMU") == "1":
         # what the emulation cannot stand in for: the Fortran host program (links the real library) and full-size runs
         skip = pytest.mark.skip(reason="not under BLOM_HOSTEMU")
         for it in items:
-            if "test_gpu_fortran_host" in it.nodeid or "full_size" in it.nodeid:
+            if any(w in it.nodeid for w in ("test_gpu_fortran_host", "full_size", "channel", "tnx2v1s")):
                 it.add_marker(skip)

@@ -56,8 +56,14 @@ static ncclResult_t do_recv(ncclComm_t c, const Pending &p) {
   World &w = *c->w;
   std::unique_lock<std::mutex> l(w.mu);
   auto &q = w.box[{p.peer, c->rank}];
-  if (!w.cv.wait_for(l, std::chrono::seconds(60), [&] { return !q.empty(); })) return ncclInternalError;
-  if (q.front().size() != p.bytes) return ncclInternalError;       // the two sides disagree on the message size
+  if (!w.cv.wait_for(l, std::chrono::seconds(20), [&] { return !q.empty(); })) {
+    fprintf(stderr, "hostemu rccl: rank %d waited 20 s for a message of %zu bytes from rank %d\n", c->rank, p.bytes, p.peer);
+    return ncclInternalError;
+  }
+  if (q.front().size() != p.bytes) {                              // the two sides disagree on the message size
+    fprintf(stderr, "hostemu rccl: rank %d expects %zu bytes from rank %d, the message has %zu\n", c->rank, p.bytes, p.peer, q.front().size());
+    return ncclInternalError;
+  }
   memcpy(p.buf, q.front().data(), p.bytes);
   q.pop_front();
   return ncclSuccess;

@@ -1,0 +1,113 @@
+"""The library's RCCL transport with SEVERAL ranks, on the CPU: tests/hostemu compiles the device library's own
+sources for the host (kernels run thread by thread, one fiber per thread) and stands in for RCCL with mailboxes between
+host threads, so every rank here is a thread with its own context running the real pack / ncclSend+Recv / unpack code
+of blom_amd/csrc/comm_rccl.hip -- tile grids with several rows and columns, tiles of unequal height as in the
+reference's bld/tnx2v1/patch.input.8, closed and periodic and tripolar domains.  Requirement: interiors bit-identical to
+the single tile, and the decomposition-independent checksum (xccrc) chained over the tiles equal to the single tile's.
+(Several ranks cannot share the one GPU of the test box -- RCCL refuses it -- so this is where that code runs.)"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "hostemu", "libblomgpu_hostemu.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(EMU), reason="tests/hostemu/libblomgpu_hostemu.so not built")
+
+CHECK = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "ubflxs_p", "pb_p", "trc", "uflx", "vflx",
+         "pgfx", "pgfy", "dpu", "dpv", "pbu", "pbv", "ubflx", "vbflx", "pb_mn", "ubcors_p"]
+
+
+@pytest.fixture()
+def emu_lib():
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    yield
+    g.LIB_PATH = old
+
+
+def _run_case(cfg, isizes, jsizes, nsteps=3):
+    from blom_amd.gpu import BlomGpu, rccl_unique_id
+    from blom_amd.tiles import TileLayout, scatter_to_tile, gather_interior_layout, chain_crc
+    from test_gpu_tiles import _single
+    case, masks, fields, ref = _single(cfg, nsteps)
+    lay = TileLayout(tuple(isizes), tuple(jsizes))
+    assert lay.itdm == case.idm and lay.jtdm == case.jdm
+    uid = rccl_unique_id()
+    tiles, errs, crcs = {}, [], {}
+    crc_fields = [("dp", 1, 2 * case.kdm, 1), ("u", 1, 2 * case.kdm, 3), ("v", 1, 2 * case.kdm, 4), ("pb", 1, 2, 1)]
+    lock = threading.Lock()
+
+    def rank_main(rank):
+        try:
+            px, py = lay.rank_tile(rank)
+            i0, j0, ii, jj = lay.tile(px, py)
+            tm = {k: lay.window(masks[k], px, py) for k in masks}
+            t = BlomGpu(ii, jj, case.kdm, case.ntr, case.nreg, tm, itdm=case.idm, jtdm=case.jdm, i0=i0, j0=j0)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            t.set("delt1", case.params["baclin"])
+            with lock:                                    # the whole-domain backend is shared: read it one rank at a time
+                scatter_to_tile(ref, t, lay, px, py)
+            t.rccl_init_2d(uid, rank, lay.npx, lay.npy)
+            with lock:
+                tiles[(px, py)] = t
+            barrier.wait()
+            assert t.step(0, nsteps) == nsteps
+            t.sync()
+            crcs[(px, py)] = {f[0]: t.crc_strips(*f) for f in crc_fields}
+        except Exception as e:                            # a failing rank would leave the others waiting
+            errs.append(e)
+            barrier.abort()
+
+    n = lay.npx * lay.npy
+    barrier = threading.Barrier(n)
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(n)]
+    [x.start() for x in th]
+    [x.join(timeout=600) for x in th]
+    assert not errs, errs
+    assert ref.step(0, nsteps) == nsteps
+    bad = []
+    for nm in CHECK:
+        a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
+        b = gather_interior_layout(tiles, lay, nm)
+        if not np.array_equal(a, b):
+            bad.append((nm, int((a != b).sum())))
+    crc_bad = []
+    for f in crc_fields:
+        want = ref.crc(*f)
+        got = chain_crc({k: v[f[0]] for k, v in crcs.items()}, lay)
+        if want != got:
+            crc_bad.append((f[0], hex(want), hex(got)))
+    for t in tiles.values():
+        t.rccl_finalize()
+        t.close()
+    ref.close()
+    assert not bad, bad
+    assert not crc_bad, crc_bad
+
+
+@pytest.mark.parametrize("cfg,isizes,jsizes", [
+    ("chan_s", (10, 10), (12, 12)),            # periodic in i, closed in j: 2 x 2
+    ("chan_s", (20,), (13, 11)),               # tile rows of unequal height
+    ("chan_s", (7, 7, 6), (24,)),              # three tile columns of unequal width, E/W wrap between first and last
+    ("box_s", (12, 12), (11, 9)),              # closed basin with an island, unequal rows
+    ("tri_s", (12, 12), (11, 9)),              # arctic patch: fold across the top row between mirror tiles
+    ("tri_s_tke", (6, 6, 6, 6), (10, 10)),     # the reference's 4 x 2 shape of bld/tnx2v1/patch.input.8
+])
+def test_rccl_ranks_match_single_tile(emu_lib, cfg, isizes, jsizes):
+    _run_case(cfg, isizes, jsizes)
+
+
+def test_patch_input_layout():
+    from blom_amd.tiles import TileLayout
+    p = "/root/reference/bld/tnx2v1/patch.input.8"
+    if not os.path.exists(p):
+        pytest.skip("reference tree not present")
+    lay = TileLayout.from_patch_input(p)
+    assert lay.isizes == (45, 45, 45, 45) and lay.jsizes == (97, 96)
+    assert TileLayout.regular(180, 193, 4, 2).jsizes == (97, 96)
+    assert lay.tile(3, 1) == (135, 97, 45, 96)
