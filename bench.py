@@ -5,11 +5,18 @@
 
 A "step" is one baroclinic time step of the hot path (stage sequence of
 phy/mod_blom_step.F90:96-253 restricted to the dynamical core: init_fluxes, tmsmt1, [halo updates
-of cmnfld2/difest], advect(remap), pbcor1, diffus, pgforc, momtum, diapfl, [mxlayr dp-halo tail],
-barotp, pbcor2, tmsmt2) on the `channel` configuration of BASELINE.json (208x512x53, 1 tile per
-GPU; for N>1 the channel is N times as long and the tiles exchange halos over RCCL), with the
-state resident in HBM.  metric = simulated model days per wall second
-= steps/s * baclin / 86400.
+of cmnfld2/difest], eddtra, advect(remap), pbcor1, diffus, pgforc, momtum, convec, diapfl, [mxlayr
+dp-halo tail], updtrc, barotp, pbcor2, tmsmt2) on the `channel` configuration of BASELINE.json
+(208x512x53), with the state resident in HBM.  metric = simulated model days per wall second
+= steps/s * baclin / 86400 of the domain that is integrated.
+
+N > 1 (default --scaling strong): BASELINE.json's configs 3/4 -- the SAME domain cut into npx x npy tiles
+in the reference's patch.input scheme (channel: 1x2, 2x2, 2x4 tiles; tnx2v1s: 2x1, 2x2 and the
+reference's 4x2 with tile rows of 97 and 96), one tile per GPU, halos over RCCL send/recv.  The
+checksum of the final state (xccrc chained over the tiles) is decomposition independent: it is the
+same for every N at equal --steps/--warmup.  --scaling weak keeps round 1's mode (the channel made
+N times as long, one 208x512 tile per GPU).  Launched without torchrun (`python bench.py --gpus N`),
+the script starts the N ranks itself.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, algorithmic bytes /
 HIP-event duration vs 8 TB/s), `step_roofline` (SURVEY.md 8d A_step / step time), `stages`
@@ -201,6 +208,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs of kernel variants, e.g. momtum_v=1 (default: production kernels)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the BASELINE domain cut into tiles; weak = N times as long a channel")
+    ap.add_argument("--tiles", default=None, metavar="NPXxNPY", help="tile grid of the strong-scaling run (default: by N)")
     ap.add_argument("--rccl-self", action="store_true",
                     help="N=1 only: route the halo update through the RCCL transport (rank sends to itself) "
                          "to measure the exchange overhead of the N>1 path on one GPU")
@@ -208,7 +218,18 @@ def main():
 
     from blom_amd import launch
     env = launch.rank_env()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N`: start the N ranks (one process per GPU) as children of this process,
+        # which has not touched the GPU, and pass rank 0's JSON line on
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if args.gpus != env.world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {env.world}")
     rank, world, local = env.rank, env.world, env.local
+    scaling = (args.scaling or "strong") if (world > 1 or args.tiles) else "weak"
     import torch
     if world > 1:
         import torch.distributed as dist
@@ -218,7 +239,34 @@ def main():
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd import hostinit
     case, nreg, masks = build_case(args.config, args.advmth, args.tracers)
-    if world > 1:
+    layout = None
+    if (world > 1 and scaling == "strong") or args.tiles:       # --tiles 1x1 at N = 1: the same code path with one rank
+        # BASELINE.json configs 3/4: the same domain, npx x npy tiles (bld/blom_dimensions:104-148), one per GPU.
+        from blom_amd.tiles import TileLayout, scatter_to_tile
+        default_grid = {"channel": {2: (1, 2), 4: (2, 2), 8: (2, 4)}, "tnx2v1s": {2: (2, 1), 4: (2, 2), 8: (4, 2)}}
+        if args.tiles:
+            npx, npy = (int(x) for x in args.tiles.lower().split("x"))
+        else:
+            npx, npy = default_grid.get(args.config, {}).get(world, (1, world))
+        if npx * npy != world:
+            raise SystemExit(f"bench.py: {npx}x{npy} tiles for {world} GPUs")
+        layout = TileLayout.regular(case.idm, case.jdm, npx, npy)
+        px, py = layout.rank_tile(rank)
+        i0, j0, tii, tjj = layout.tile(px, py)
+        # every rank initialises the whole domain on its own GPU (the initialisation runs stages on the device),
+        # keeps its window of every field and frees the rest: 10 of 288 GB for a moment
+        whole = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
+        hostinit.init_state(whole, case)
+        gpu = BlomGpu(tii, tjj, case.kdm, case.ntr, nreg, {k: layout.window(masks[k], px, py) for k in masks}, device=local,
+                      itdm=case.idm, jtdm=case.jdm, i0=i0, j0=j0)
+        for nm, v in case.params.items():
+            if not nm.endswith("0"):
+                gpu.set(nm, v)
+        scatter_to_tile(whole, gpu, layout, px, py)
+        whole.close()
+        gpu.set("delt1", case.params["baclin"])
+        gpu.rccl_init_2d(launch.share_unique_id(rccl_unique_id, env), rank, npx, npy)
+    elif world > 1:
         # Weak scaling: the channel is made `world` times as long in i (its bathymetry repeated
         # with the tile's period) and cut into `world` tiles along i, one per GPU.  Every tile
         # then starts from the single-tile state -- its periodic wrap IS its neighbours' data --
@@ -233,7 +281,8 @@ def main():
         gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
         if args.rccl_self:
             gpu.rccl_init(rccl_unique_id(), 0, 1)
-    hostinit.init_state(gpu, case)
+    if layout is None:
+        hostinit.init_state(gpu, case)
     for o in args.opt:
         nm, v = o.split("=")
         gpu.set(nm, int(v))
@@ -282,14 +331,23 @@ def main():
     gpu.set("timing", 0)
     import numpy as np
     finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
-    # every tile integrates the same periodic pattern, so all ranks must hold the same bits
-    crcs = launch.all_gather_ints(gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3), env)
+    finite = all(launch.all_gather_ints(int(finite), env))
+    if layout is not None:
+        # xccrc of the whole domain (phy/mod_xc.F90:2195-2322) chained over the tiles: equal to the single tile's
+        from blom_amd.tiles import chain_crc
+        parts = launch.all_gather_objects({nm: gpu.crc_strips(nm, 1, 2 * case.kdm, it) for nm, it in (("dp", 1), ("u", 3))}, env)
+        tiles_of = {layout.rank_tile(r): p for r, p in enumerate(parts)}
+        crcs = [chain_crc({k: v["dp"] for k, v in tiles_of.items()}, layout) ^ chain_crc({k: v["u"] for k, v in tiles_of.items()}, layout)]
+    else:
+        # weak scaling: every tile integrates the same periodic pattern, so all ranks must hold the same bits
+        crcs = launch.all_gather_ints(gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3), env)
 
     ms_per_step = dt / args.steps * 1e3
-    # units all ranks processed / time: model days of one 208x512x53-sized tile, times the number
-    # of tiles (the N-GPU job integrates an N-times longer channel at the same days/s)
-    value = world * args.steps * baclin / 86400.0 / dt
-    F = case.idm * case.jdm * case.kdm * 8.0
+    # model days per wall second of the domain that is integrated (for --scaling weak that domain is N times as long:
+    # tile_days_per_s = N x value is reported beside it, not as the value)
+    value = args.steps * baclin / 86400.0 / dt
+    tile_i, tile_j = (layout.tile(*layout.rank_tile(rank))[2:] if layout is not None else (case.idm, case.jdm))
+    F = tile_i * tile_j * case.kdm * 8.0
     cb = class_bytes_F(case.ntr, ntr_diffused(case))
     hbm_classes = {k: v for k, v in live.items() if k in cb}
     dom = max(hbm_classes, key=hbm_classes.get)
@@ -298,15 +356,19 @@ def main():
     out = {
         "metric": "simulated-days/sec", "value": value, "unit": "simulated-days/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config} {case.idm * world}x{case.jdm}x{case.kdm} as {world} tile(s) of "
-                               f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, "
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"{args.config} {case.idm}x{case.jdm}x{case.kdm} as {world} tiles ({layout.npx}x{layout.npy}: columns "
+                                f"{'/'.join(map(str, layout.isizes))}, rows {'/'.join(map(str, layout.jsizes))}), 1 tile per GPU, "
+                                if layout is not None else
+                                f"{args.config} {case.idm * world}x{case.jdm}x{case.kdm} as {world} tile(s) of "
+                                f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, ") +
                                f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr} "
                                f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age'}), "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
                                f"full dyncore stage sequence incl. eddtra and convec (gm, frozen slopes of amplitude {NSLP0:g}); "
-                               "N>1: halos over RCCL send/recv, "
-                               "value counts tile-days/s" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
+                               "N>1: halos over RCCL send/recv; state_crc = xccrc(dp) ^ xccrc(u) of the whole domain, "
+                               "the same for every N at equal --steps/--warmup" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
+                   "eddtra_parity": "unpinned (mod_eddtra needs CVMix: the reference build lacks it; checked against the C restatement)",
                    "state_finite": finite, "tiles_bit_identical": len(set(crcs)) == 1,
                    "state_crc": f"{crcs[0]:08x}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
@@ -316,9 +378,11 @@ def main():
                      "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom]},
         "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
                           "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,
-                          "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1))},
         "stages_ms": live,
     }
+    if world > 1 and layout is None:
+        out["tile_days_per_s"] = world * value
     if rank == 0:
         # stdout carries the ONE JSON line and nothing else: the reference library prints through the Fortran
         # runtime (bigrid messages, buffered unit 6 flushed at exit), so from here on file descriptor 1 points
@@ -333,7 +397,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         os.close(real_stdout)
-    if world > 1 or args.rccl_self:
+    if world > 1 or args.rccl_self or layout is not None:
         gpu.rccl_finalize()
     gpu.close()
     if world > 1:

@@ -69,6 +69,16 @@ def all_gather_ints(v, env):
     return out
 
 
+def all_gather_objects(obj, env):
+    """every rank's `obj` (picklable), in rank order, on every rank"""
+    if env.world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * env.world
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def exchange_ew_host(a, idm, jdm, mhl, nhl, env, periodic):
     """Host (numpy + torch.distributed p2p) statement of the E/W phase of comm_rccl.hip, used by
     the gloo tests to check the message-order rule on real ranks: every rank sends west then

@@ -115,3 +115,76 @@ def test_rccl_transport_single_rank_equals_single_tile():
     t.close()
     ref.close()
     assert not bad, bad
+
+
+def test_channel_as_eight_tiles_reproduces_the_reference_checksums():
+    """BASELINE.json config 3 on one GPU: the channel at full size (208x512x53, ntr = 3) cut into the 2 x 4 tiles
+    of 104 x 128 that `bench.py --gpus 8` uses, the eight tiles on one device with the in-process transport (RCCL
+    refuses several ranks per GPU).  After each of three steps the decomposition-independent checksum (xccrc chained
+    over the tiles, blom_amd/tiles.py) of every recorded field must be the one the reference's own Fortran produced
+    on ONE tile (tests/golden/channel_tke_crc.json)."""
+    import json
+    import os
+    from blom_amd.gpu import BlomGpu, TileGroup
+    from blom_amd import hostinit
+    from blom_amd.checksum import grid_of
+    from blom_amd.tiles import TileLayout, scatter_to_tile, chain_crc
+    cfg, npx, npy = "channel_tke", 2, 4
+    case = make_case(cfg)
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{cfg}_crc.json")))
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    whole = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(whole, case)
+    lay = TileLayout.regular(case.idm, case.jdm, npx, npy)
+    grp = TileGroup(npx, npy)
+    tiles = {}
+    for py in range(npy):
+        for px in range(npx):
+            i0, j0, ii, jj = lay.tile(px, py)
+            t = BlomGpu(ii, jj, case.kdm, case.ntr, nreg, {k: lay.window(masks[k], px, py) for k in masks},
+                        itdm=case.idm, jtdm=case.jdm, i0=i0, j0=j0)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            scatter_to_tile(whole, t, lay, px, py)
+            t.set("delt1", case.params["baclin"])
+            grp.attach(t, px, py)
+            tiles[(px, py)] = t
+    whole.close()
+    names = [nm for nm in gold["crc"]["1"]["tmsmt2"] if nm not in ("umfltd", "vmfltd", "utfltd", "vtfltd", "usfltd", "vsfltd")]
+    parts, errs = {}, []
+    bar = threading.Barrier(npx * npy)
+
+    def run(key):
+        t = tiles[key]
+        try:
+            ns = 0
+            for step in range(1, gold["nsteps"] + 1):
+                ns = t.step(ns, 1)
+                for nm in names:
+                    if t.has_field(nm):
+                        parts[(step, nm, key)] = t.crc_strips(nm, 1, t.field_info(nm)[0], grid_of(nm))
+            t.sync()
+        except Exception as e:
+            errs.append(e)
+            bar.abort()
+    th = [threading.Thread(target=run, args=(k,)) for k in tiles]
+    [x.start() for x in th]
+    [x.join(timeout=900) for x in th]
+    assert not errs, errs
+    bad, checked = [], 0
+    for step in range(1, gold["nsteps"] + 1):
+        for nm in names:
+            if (step, nm, (0, 0)) not in parts:
+                continue
+            got = chain_crc({k: parts[(step, nm, k)] for k in tiles}, lay)
+            want = gold["crc"][str(step)]["tmsmt2"][nm]
+            checked += 1
+            if got != want:
+                bad.append(f"step {step} {nm}: 0x{got:08x} != 0x{want:08x}")
+    for t in tiles.values():
+        t.close()
+    grp.destroy()
+    assert not bad, bad[:20]
+    assert checked >= 45
