@@ -83,3 +83,62 @@ def test_freerun_with_eddtra(cfg):
     bad = diff_report(orc, gpu, fields=["u", "v", "dp", "temp", "saln", "umfltd", "vmfltd", "uflx", "vflx"], rtol=1e-7, atol=1e-7)
     gpu.close()
     assert not bad, fmt_report(bad)
+
+
+def test_uniform_slope_gives_the_streamfunction_of_the_equations_on_the_device():
+    """The analytic column of tests/test_oracle_eddtra.py (expectation written from the equations) on the device."""
+    from blom_amd.gpu import BlomGpu
+    from blom_amd.hostinit import step_indices
+    from test_oracle_eddtra import uniform_slope_expectation, check_uniform_slope
+    case = make_case("chan_s", nslp0=0.0)
+    nreg, masks = _bigrid(case)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    m_, n_, mm, nn, k1m, k1n = step_indices(0, case.kdm)
+    X = uniform_slope_expectation(gpu, case, 1.0e-3, 300.0)
+    gpu.stage("eddtra", m_, n_, mm, nn, k1m, k1n)
+    check_uniform_slope(gpu, case, X, masks, nn, mm)
+    gpu.close()
+
+
+def test_eddtra_of_the_bench_workload_at_full_size_matches_the_restatement():
+    """BASELINE.json's channel at full size with the frozen slopes bench.py runs (nslp0 = 2e-4): over three steps of the
+    device-resident sequence, eddtra's inputs are handed to the C restatement before the stage and its six outputs
+    compared after it, all bits.  (The restatement is unpinned; this closes the gap between the reference-pinned
+    full-size runs, which use zero slopes, and the bench workload.)"""
+    from oracle.coracle import COracle
+    from blom_amd.gpu import BlomGpu
+    from blom_amd.hostinit import step_indices
+    case = make_case("channel_tke", nslp0=2e-4)
+    nreg, masks = _bigrid(case)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    orc = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            orc.set(nm, v)
+    static = ["scp2", "scuy", "scvx", "scu2", "scv2", "scuxi", "scvyi", "difint", "nslpx", "nslpy"]
+    dynamic = ["dp", "p", "temp", "saln", "kfpla", "pbu", "pbv", "dpu", "dpv"]
+    copy_state(gpu, orc, fields=static)
+    ns, bad, nz = 0, [], 0
+    for step in range(3):
+        six = step_indices(ns, case.kdm)
+        gpu.set("nstep", ns + 1)
+        from blom_amd.stepper import DYNCORE_STAGES
+        for st in DYNCORE_STAGES:
+            if st == "eddtra":
+                copy_state(gpu, orc, fields=dynamic)
+                orc.set("delt1", case.params["baclin"] * (1 if ns == 0 else 2))
+                orc.stage("eddtra", *six)
+                gpu.stage("eddtra", *six)
+                rep = diff_report(orc, gpu, fields=OUT)
+                nz += int(np.count_nonzero(orc.get("umfltd")))
+                if rep:
+                    bad.append(f"step {step + 1}:\n" + fmt_report(rep))
+            else:
+                gpu.stage(st, *six)
+        gpu.set("delt1", 2 * case.params["baclin"])
+        ns += 1
+    gpu.close()
+    assert not bad, "\n".join(bad)
+    assert nz > 100000

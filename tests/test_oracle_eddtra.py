@@ -54,3 +54,66 @@ def test_gm_fluxes_bounded_and_column_neutral(cfg, nslp0):
         mass_b = mass[:, J, I]
         bound = 0.0625 * (np.maximum(mass_a, mass_b) + 1e-12 * scp2[J, I]) * (1 + 1e-12)
         assert np.all(np.abs(f[2:][:, wet]) <= bound[2:][:, wet])
+
+
+def uniform_slope_expectation(be, case, slope, kappa):
+    """Written from the equations, not from the code: with a uniform interface diffusivity kappa and a uniform slope s of
+    all interfaces below the mixed layer, the Gent-McWilliams streamfunction is psi = -kappa*s on every such interface
+    and 0 at the surface and at the sea floor (phy/mod_eddtra.F90:228-500), so the eddy-induced mass transport
+    [pressure x area per step] of a u-column is  X = g rho0 dt dy kappa s  in the mixed layer (shared by its two layers
+    in proportion to their thickness), -X in the deepest layer that holds mass, and exactly 0 in between.
+    Sets the state of backend `be` up and returns (X at the u-points, index of the deepest layer with mass)."""
+    kk = case.kdm
+    a = be.get("nslpx")
+    a[:] = slope
+    be.put("nslpx", a)
+    a = be.get("nslpy")
+    a[:] = 0.0
+    be.put("nslpy", a)
+    a = be.get("difint")
+    a[:] = kappa
+    be.put("difint", a)
+    be.set("delt1", case.params["baclin"])
+    grav, rho0 = 9.806, 1.e3
+    et2mf = -grav * rho0 * case.params["baclin"] * be.get("scuy")[0]
+    X = et2mf * (-kappa * slope)
+    return X
+
+
+def check_uniform_slope(be, case, X, masks, nn, mm):
+    kk = case.kdm
+    J, I = slice(4, 4 + case.jdm), slice(4, 4 + case.idm)
+    f = be.get("umfltd")[mm:mm + kk][:, J, I]
+    dp = be.get("dp")[nn:nn + kk]
+    kf = be.get("kfpla")[0]
+    both = (masks["iu"][J, I] > 0) & (kf[J, I] == 3) & (np.roll(kf, 1, axis=1)[J, I] == 3)
+    mass = (dp[:, J, I] > 1e-12) | (np.roll(dp, 1, axis=2)[:, J, I] > 1e-12)
+    kmax = kk - 1 - np.argmax(mass[::-1], axis=0)                    # deepest layer with mass on either side (0-based)
+    Xi = X[J, I]
+    # the return flow sits in the deepest layer only where that layer can supply it: a layer gives up at most 1/16 of
+    # what it holds at the upstream point (:504-524), so ask for ample mass on both sides of the u-point
+    scp2 = be.get("scp2")[0]
+    ja, ia = np.indices(kmax.shape)
+    deep_b = dp[:, J, I][kmax, ja, ia] * scp2[J, I]
+    deep_a = np.roll(dp, 1, axis=2)[:, J, I][kmax, ja, ia] * np.roll(scp2, 1, axis=1)[J, I]
+    both &= (np.minimum(deep_a, deep_b) > 32. * np.abs(Xi))
+    assert both.sum() > 50
+    top = f[0] + f[1]
+    assert np.all(np.abs(top[both] - Xi[both]) <= 4e-16 * np.abs(Xi[both]))          # the mixed layer carries +X
+    jj, ii = np.nonzero(both)
+    bot = f[kmax[jj, ii], jj, ii]
+    assert np.array_equal(bot, -Xi[jj, ii])                                          # the deepest layer -X, exactly
+    for k in range(2, kk):
+        inner = both & (k < kmax)
+        assert not np.any(f[k][inner] != 0.0), k                                     # nothing in between
+    tot = f.sum(axis=0)
+    assert np.all(np.abs(tot[both]) <= 1e-15 * np.abs(Xi[both]))                     # the column is mass neutral
+    assert not np.any(be.get("vmfltd")[mm:mm + kk][:, J, I] != 0.0)                  # no slope in y: no transport in y
+
+
+def test_uniform_slope_gives_the_streamfunction_of_the_equations():
+    case, orc, m = _setup("chan_s", nslp0=0.0)
+    m_, n_, mm, nn, k1m, k1n = step_indices(0, case.kdm)
+    X = uniform_slope_expectation(orc, case, 1.0e-3, 300.0)
+    orc.stage("eddtra", m_, n_, mm, nn, k1m, k1n)
+    check_uniform_slope(orc, case, X, m, nn, mm)
