@@ -183,7 +183,15 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
         de = (time.time() - t1) / 3
         dt += de
         per_stage["eddtra"] = de * n
-        note = f"; eddtra ({de * 1e3:.1f} ms) timed on the C restatement since the reference build lacks it"
+        # likewise cmnfld2's buoyancy frequency + neutral slopes (mod_cmnfld_routines needs netCDF through mod_dia)
+        t1 = time.time()
+        for _ in range(3):
+            co.stage("cmnfld2", *six)
+        dc = (time.time() - t1) / 3
+        dt += dc
+        per_stage["cmnfld"] = dc * n
+        note = (f"; eddtra ({de * 1e3:.1f} ms) and cmnfld2's slopes ({dc * 1e3:.1f} ms) timed on the C restatements "
+                "(single thread) since the reference build lacks both modules")
     how = (f"{cores} OpenMP threads (reference built with -fopenmp)" if cores > 1 else
            "single thread (reference built without OpenMP)" if kind == "reference" else "single thread (C restatement)")
     stages_ms = {k: round(v / n * 1e3, 2) for k, v in per_stage.items() if k}
@@ -205,6 +213,9 @@ def main():
     ap.add_argument("--tracers", default="default", choices=["default", "iage"],
                     help="default: the reference's default option set (TKE, its advection, ideal age: ntr = 3); "
                          "iage: ideal age only (ntr = 1)")
+    ap.add_argument("--slopes", default="live", choices=["live", "frozen"],
+                    help="live: cmnfld2 computes the neutral slopes eddtra consumes every step (phy/mod_cmnfld_routines.F90:1158); "
+                         "frozen: round 1's analytic pattern of amplitude NSLP0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs of kernel variants, e.g. momtum_v=1 (default: production kernels)")
@@ -283,6 +294,7 @@ def main():
             gpu.rccl_init(rccl_unique_id(), 0, 1)
     if layout is None:
         hostinit.init_state(gpu, case)
+    gpu.set("live_slopes", 1 if args.slopes == "live" else 0)
     for o in args.opt:
         nm, v = o.split("=")
         gpu.set(nm, int(v))
@@ -295,7 +307,7 @@ def main():
     if args.warmup > 1:
         ns = gpu.step(ns, args.warmup - 1)
     gpu.sync()
-    classes = ["eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "barotp", "pbcor1", "pbcor2"]
+    classes = ["cmnfld", "eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "barotp", "pbcor1", "pbcor2"]
     stage_ms = {}
     for cl in classes:
         ms, n = gpu.timer_get(cl)
@@ -365,7 +377,8 @@ def main():
                                f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr} "
                                f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age'}), "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
-                               f"full dyncore stage sequence incl. eddtra and convec (gm, frozen slopes of amplitude {NSLP0:g}); "
+                               f"full dyncore stage sequence incl. cmnfld2, eddtra and convec (gm, " +
+                               (f"neutral slopes from cmnfld2 every step" if args.slopes == "live" else f"frozen slopes of amplitude {NSLP0:g}") + "); "
                                "N>1: halos over RCCL send/recv; state_crc = xccrc(dp) ^ xccrc(u) of the whole domain, "
                                "the same for every N at equal --steps/--warmup" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
                    "eddtra_parity": "unpinned (mod_eddtra needs CVMix: the reference build lacks it; checked against the C restatement)",

@@ -221,6 +221,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "momtum_chunk") { c->momtum_chunk = v; return 0; }
+  if (s == "live_slopes") { c->live_slopes = v; return 0; }
   if (s == "momtum_v") { c->momtum_v = v; return 0; }
   if (s == "momtum_bs") { c->momtum_bs = v; return 0; }
   if (s == "momtum_order") { c->momtum_order = v; return 0; }
@@ -382,7 +383,7 @@ static int check_tracer_options(blomgpu_ctx *c) {
     return st_##nm(c, m, n, mm, nn, k1m, k1n);                                             \
   }
 STAGE6(init_fluxes) STAGE6(advect) STAGE6(pbcor1) STAGE6(pbcor2) STAGE6(diffus) STAGE6(pgforc)
-STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra) STAGE6(convec) STAGE6(updtrc)
+STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra) STAGE6(convec) STAGE6(updtrc) STAGE6(cmnfld2)
 int blomgpu_tmsmt1(blomgpu_ctx *c, int nn) { ctx_sync_view(c); return st_tmsmt1(c, nn); }
 int blomgpu_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) { ctx_sync_view(c); return st_tmsmt2(c, m, mm, nn, k1m); }
 int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(c, mm); }
@@ -475,6 +476,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "eddtra") return blomgpu_eddtra(c, m, n, mm, nn, k1m, k1n);
   if (s == "init_cppm") return blomgpu_init_cppm(c);
   if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c, n);
+  if (s == "cmnfld2") return blomgpu_cmnfld2(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
@@ -492,8 +494,11 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
                                 "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
                                 "barotp", "pbcor2", "tmsmt2"};
     c->defer_checks = true;
-    for (const char *st : seq)
-      if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
+    for (const char *st : seq) {
+      // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
+      const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
+      if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
+    }
     c->defer_checks = false;
     if (int rc = ctx_check_errors(c)) return rc;
     const double delt2 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300

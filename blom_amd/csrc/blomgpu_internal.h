@@ -65,7 +65,7 @@
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
-  X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K)                                                                  \
+  X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K) X(nnslpx, K) X(nnslpy, K) X(bfsqi, K + 1) X(bfsql, K) X(bfsqf, K + 1)                                                                 \
   /* mod_cppm: thickness edge values and the coefficient tables of init_cppm (mod_cppm.F90:79-89);     \
      the j-tables in (i,j) order (the reference's "_perm" layout, :2511-2518) */                        \
   X(hel_3d, K) X(her_3d, K) X(hevc1i, 1) X(hevc2i, 1) X(hevc3i, 1) X(hevc4i, 1) X(ssci, 1) X(scci, 1)    \
@@ -208,6 +208,7 @@ struct blomgpu_ctx {
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int momtum_chunk = 0;      // layers per launch group of momtum's layer kernels (0: all)
+  int live_slopes = 0;       // blomgpu_step: 1 = cmnfld2 computes nslpx/nslpy every step (stage_cmnfld.hip); 0 = they stay as uploaded
   int momtum_v = 2;          // 2: row-marching fused layer kernels (stage_momtum_fused.hip), 1: one kernel per sweep
   int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major
   int momtum_bs = 0;         // lanes per workgroup of the fused kernels (0: 64, one wavefront)
@@ -267,7 +268,8 @@ int st_init_cppm(blomgpu_ctx *);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
 int ctx_err_words(blomgpu_ctx *);            // allocate err_dev on first use
 int ctx_check_errors(blomgpu_ctx *);         // read back all error words, fail with the reference's message
-int st_kfpla_halo(blomgpu_ctx *, int n);   // phy/mod_cmnfld_routines.F90:1176-1196
+int st_kfpla_halo(blomgpu_ctx *, int n);
+int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field

@@ -1,0 +1,228 @@
+// cmnfld2 for vcoord = isopyc_bulkml -- phy/mod_cmnfld_routines.F90:1158-1238: the halo updates of temp, saln and
+// kfpla (:1171-1196), the buoyancy frequency squared on interfaces, in layers and vertically filtered
+// (cmnfld_bfsqf_isopyc_bulkml, :61-227), the interface geopotential and the slope of the local neutral surface at
+// velocity points (cmnfld_nslope_isopyc_bulkml, :423-652) -- the producer of nslpx/nslpy that eddtra consumes.
+// PARITY UNPINNED: mod_cmnfld_routines uses mod_dia (netCDF) and cannot be built in this image; the kernels agree bit
+// for bit with the C restatement oracle/c/cmnfld.c written from the same lines, and both are checked by construction
+// (tests/test_cmnfld.py).
+// All three kernels are column kernels (one thread per column, coalesced plane by plane); HBM-bound, ~16 F.
+#include "blomgpu_internal.h"
+#include "eos.h"
+
+#define GRAV 9.806
+#define RHO0 1.e3
+#define EPSILP 1.e-12
+#define ONEM 9806.
+#define ONEMM 9.806
+// phy/mod_cmnfld.F90:36-46
+#define SLS0 (10. * ONEM)
+#define SLSMFQ 2.
+#define SLSELS 2.
+#define BFSQMN 1.e-7
+
+enum { CM_DELP, CM_BFSQ, CM_SLS2, CM_GAM, CM_NSLOT };
+
+#define COLUMN_IJ(V)                                                     \
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                  \
+  if (t_ >= (V).nplane) return;                                          \
+  const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);  \
+  const size_t c = t_
+
+// ---- :61-227 ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cmn_bfsqf(const DevView *__restrict__ Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
+  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
+  double *bfsqi = V.f[F_bfsqi] + c, *bfsql = V.f[F_bfsql] + c, *bfsqf = V.f[F_bfsqf] + c;
+  double *delp = WK(V, CM_DELP) + c, *bfsq = WK(V, CM_BFSQ) + c, *sls2 = WK(V, CM_SLS2) + c, *gam = WK(V, CM_GAM) + c;
+#define L(a, k) (a)[(size_t)((k)-1) * np]          /* Fortran level k */
+  const double b1 = .5 * GRAV * GRAV * (eos::rho(L(p, 2), L(temp, 2), L(saln, 2)) - eos::rho(L(p, 2), L(temp, 1), L(saln, 1))) /
+                    (L(dp, 1) + L(dp, 2));
+  L(bfsqi, 1) = b1; L(bfsqi, 2) = b1; L(bfsql, 1) = b1; L(bfsql, 2) = b1;
+  const int kfpl = V.m[I_kfpla][c + (size_t)(n - 1) * np];
+  if (kfpl > kk) {                                                         // mixed layer down to the bottom, :105-115
+    for (int k = 3; k <= kk; k++) { L(bfsqi, k) = b1; L(bfsql, k) = b1; }
+    L(bfsqi, kk + 1) = b1;
+    for (int k = 1; k <= kk + 1; k++) L(bfsqf, k) = BFSQMN;
+    return;
+  }
+  const double pbot = L(p, kk + 1);
+  const double pml = fmax2(.5 * (L(p, 3) + L(p, 1)), .5 * (3. * L(p, 3) - L(p, kfpl + 1)));
+  const double dml = pml - L(p, 1);
+  L(delp, kfpl - 1) = dml;
+  L(bfsqi, kfpl - 1) = L(bfsqi, 2);
+  L(bfsq, kfpl - 1) = BFSQMN;
+  {
+    const double q = fmax2(SLS0, dml * SLSMFQ);
+    L(sls2, kfpl - 1) = q * q;
+  }
+  double pup = pml, tup = L(temp, 2), sup = L(saln, 2);
+  for (int k = kfpl; k <= kk; k++) {
+    const double pk = L(p, k);
+    if (pbot - pk < EPSILP) {
+      L(delp, k) = ONEMM;
+      L(bfsqi, k) = L(bfsqi, k - 1);
+      L(bfsq, k) = BFSQMN;
+      double q = exp_libm(-(pbot - pml) / (SLSELS * dml));
+      q = fmax2(SLS0, dml * SLSMFQ * q + SLS0 * (1. - q));
+      L(sls2, k) = q * q;
+    } else {
+      const double pk1 = L(p, k + 1);
+      const double plo = pbot - pk1 < EPSILP ? pbot : .5 * (pk + pk1);
+      const double tlo = L(temp, k), slo = L(saln, k);
+      const double dk = fmax2(ONEMM, plo - pup);
+      L(delp, k) = dk;
+      double bi = GRAV * GRAV * (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) / dk;
+      L(bfsq, k) = fmax2(BFSQMN, bi);
+      bi = bi * dk / fmax2(ONEM, dk);
+      if (pbot - pk < ONEM) bi = L(bfsqi, k - 1);
+      L(bfsqi, k) = bi;
+      double q = exp_libm(-(pk - pml) / (SLSELS * dml));
+      q = fmax2(SLS0, dml * SLSMFQ * q + SLS0 * (1. - q));
+      L(sls2, k) = q * q;
+      pup = plo; tup = tlo; sup = slo;
+    }
+  }
+  for (int k = kfpl; k <= kk - 1; k++) L(bfsql, k) = .5 * (L(bfsqi, k) + L(bfsqi, k + 1));      // :157-165
+  L(bfsql, kk) = L(bfsqi, kk);
+  for (int k = 3; k <= kfpl - 1; k++) { L(bfsqi, k) = L(bfsqi, kfpl); L(bfsql, k) = L(bfsql, kfpl); }
+  // tridiagonal system of the implicit vertical filter, :170-199; coefficients formed where they are used
+  int k = kfpl - 1;
+  double ctd = -2. * L(sls2, k) / (L(delp, k) * (L(delp, k) + L(delp, k + 1)));
+  double btd = 1. - ctd;
+  double bei = 1. / btd;
+  double fprev = L(bfsq, k) * bei;
+  L(bfsqf, k) = fprev;
+  for (k = kfpl; k <= kk; k++) {
+    const double atd = -2. * L(sls2, k - 1) / (L(delp, k) * (L(delp, k - 1) + L(delp, k)));
+    const double g = ctd * bei;                    // ctd of level k-1
+    L(gam, k) = g;
+    if (k <= kk - 1) {
+      ctd = -2. * L(sls2, k) / (L(delp, k) * (L(delp, k) + L(delp, k + 1)));
+      btd = 1. - atd - ctd;
+    } else
+      btd = 1. - atd;
+    bei = 1. / (btd - atd * g);
+    fprev = (L(bfsq, k) - atd * fprev) * bei;
+    L(bfsqf, k) = fprev;
+  }
+  for (k = kk - 1; k >= kfpl - 1; k--) {
+    fprev = L(bfsqf, k) - L(gam, k + 1) * fprev;
+    L(bfsqf, k) = fprev;
+  }
+  for (k = 1; k <= kfpl - 2; k++) L(bfsqf, k) = fprev;                     // = bfsqf(kfpl-1)
+  L(bfsqi, kk + 1) = L(bfsqi, kk);
+  L(bfsqf, kk + 1) = L(bfsqf, kk);
+#undef L
+}
+
+// ---- geopotential at layer interfaces, :437-455 ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cmn_phi(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
+  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
+  double *phi = V.f[F_phi] + c;
+  double ph = phi[(size_t)kk * np], plo = p[(size_t)kk * np];
+  for (int k0 = kk - 1; k0 >= 0; k0 -= COLUMN_U) {             // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+    double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const size_t o = (size_t)(k0 - u >= 0 ? k0 - u : 0) * np;
+      a[u] = p[o]; b[u] = dp[o]; d[u] = temp[o]; e[u] = saln[o];
+    }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 - u;
+      if (k >= 0) {
+        if (!(b[u] < EPSILP)) ph = ph - eos::p_alpha(plo, a[u], d[u], e[u]);
+        phi[(size_t)k * np] = ph;
+        plo = a[u];
+      }
+    }
+  }
+}
+
+// ---- slope of the local neutral surface at u- (blockIdx.y = 0) and v-points (1), :465-641 -----------------------------
+__global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  const bool isv = blockIdx.y == 1;
+  if (isv ? (j < 0 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_iv][c])
+          : (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 2 || !V.m[I_iu][c])) return;
+  const size_t np = V.nplane, a_ = isv ? c - V.ni : c - 1, b_ = c;      // scalar points (i-1,j)|(i,j-1) and (i,j)
+  const int kk = V.kk;
+  const double *p = V.f[F_p], *phi = V.f[F_phi], *bf = V.f[F_bfsqf];
+  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
+  double *nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c, *nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
+  const double sci = (isv ? V.f[F_scvyi] : V.f[F_scuxi])[c];
+#define A(f, x, k) (f)[(x) + (size_t)((k)-1) * np]
+#define O(f, k) (f)[(size_t)((k)-1) * np]
+  for (int k = 1; k <= kk; k++) { O(nslp, k) = 0.; O(nnslp, k) = 0.; }
+  const int kfa = V.m[I_kfpla][a_ + (size_t)(n - 1) * np], kfb = V.m[I_kfpla][b_ + (size_t)(n - 1) * np];
+  if (!(kfa <= kk || kfb <= kk)) return;
+  int kmax = 1;
+  for (int k = 3; k <= kk; k++)
+    if (A(dp, a_, k) > EPSILP || A(dp, b_, k) > EPSILP) kmax = k;
+  const int kintr = kfa > kfb ? kfa : kfb;
+  int knnsl = 2;
+  const double phba = A(phi, a_, kk + 1), phbb = A(phi, b_, kk + 1);
+  {                                                                      // mixed layer base
+    const double pm = .5 * (A(p, a_, 3) + A(p, b_, 3));
+    const double rx = eos::rho(pm, A(temp, b_, 2), A(saln, b_, 2)) - eos::rho(pm, A(temp, a_, 2), A(saln, a_, 2));
+    const double px = A(phi, b_, 3) - A(phi, a_, 3);
+    const double bm = .5 * (A(bf, a_, 3) + A(bf, b_, 3));
+    const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
+    O(nslp, 3) = s;
+    if (A(phi, b_, 3) > phba && A(phi, a_, 3) > phbb) { O(nnslp, 3) = sqrt(bm) * s; knnsl = 3; }
+  }
+  for (int k = kintr + 1; k <= kmax; k++) {                              // interior interfaces
+    const double pm = .5 * (A(p, a_, k) + A(p, b_, k));
+    const double rx = .5 * (eos::rho(pm, A(temp, b_, k - 1), A(saln, b_, k - 1)) - eos::rho(pm, A(temp, a_, k - 1), A(saln, a_, k - 1)) +
+                            eos::rho(pm, A(temp, b_, k), A(saln, b_, k)) - eos::rho(pm, A(temp, a_, k), A(saln, a_, k)));
+    const double px = A(phi, b_, k) - A(phi, a_, k);
+    const double bm = .5 * (A(bf, a_, k) + A(bf, b_, k));
+    const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
+    O(nslp, k) = s;
+    if (A(phi, b_, k) > phba && A(phi, a_, k) > phbb) { O(nnslp, k) = sqrt(bm) * s; knnsl = k; }
+  }
+  for (int k = knnsl + 1; k <= kmax; k++) O(nnslp, k) = O(nnslp, knnsl);
+  if (kintr < kmax) {
+    const double s = O(nslp, kintr + 1), ns = O(nnslp, kintr + 1);
+    for (int k = 4; k <= kintr; k++) { O(nslp, k) = s; O(nnslp, k) = ns; }
+  } else {
+    const double s = O(nslp, 3), ns = O(nnslp, 3);
+    for (int k = 4; k <= kmax; k++) { O(nslp, k) = s; O(nnslp, k) = ns; }
+  }
+#undef A
+#undef O
+}
+
+// cmnfld2(m,n,mm,nn,k1m,k1n) for isopyc_bulkml; the slope part only with eitmth = 'gm' (:1208-1235; edritp is not carried)
+int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)mm; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.P.vcoord_tag != 1) return ctx_fail(c, "cmnfld2: only vcoord = isopyc_bulkml is built (cmnfld_bfsqf_ale / nslope_ale are not)");
+  if (h.nwk < CM_NSLOT) return ctx_fail(c, "cmnfld2: device work space too small");
+  {
+    double *ptrs[2] = {h.f[F_temp], h.f[F_saln]};                                           // :1171-1172
+    const int nl[2] = {2 * h.kk, 2 * h.kk}, it[2] = {1, 1};
+    if (int rc = st_xctilr_multi(c, 2, ptrs, nl, 3, 3, it)) return rc;
+  }
+  if (int rc = st_kfpla_halo(c, n)) return rc;                                              // :1176-1196
+  if (h.P.eitmth != 2) return 0;
+  TimeScope ts(c, "cmnfld");
+  const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64);
+  hipLaunchKernelGGL(k_cmn_bfsqf, g1, dim3(64), 0, c->stream, c->d, n, nn);
+  hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
+  hipLaunchKernelGGL(k_cmn_nslope, g2, dim3(64), 0, c->stream, c->d, n, nn);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

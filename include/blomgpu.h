@@ -113,6 +113,9 @@ int  blomgpu_eddtra (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
  * grid has been uploaded.  phy/mod_cppm.F90:2504 (init_cppm, called from blom_init). */
 int  blomgpu_init_cppm(blomgpu_ctx *);
 int  blomgpu_halo_cmnfld2(blomgpu_ctx *, int n);
+/* cmnfld2 for isopyc_bulkml (phy/mod_cmnfld_routines.F90:1158): the halo updates above plus, with eitmth = 'gm', the
+ * filtered buoyancy frequency (:61-227) and the neutral slopes nslpx/nslpy, nnslpx/nnslpy (:423-652) eddtra consumes. */
+int  blomgpu_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
 
