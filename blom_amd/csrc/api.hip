@@ -169,6 +169,11 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   (void)hipFree(c->h.wk);
   (void)hipFree(c->h.wk2d);
   (void)hipFree(c->d);
+  if (c->tiling.rccl) (void)blomgpu_rccl_finalize(c);
+  if (c->err_dev) (void)hipFree(c->err_dev);
+  if (c->bt_flags) (void)hipFree(c->bt_flags);
+  if (c->arc_strip) (void)hipFree(c->arc_strip);
+  if (c->xcsum_buf) (void)hipFree(c->xcsum_buf);
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);

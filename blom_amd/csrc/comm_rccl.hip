@@ -176,7 +176,9 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
                          nhl, periodic_j, 0, 0);
   } else {
     const size_t per = (size_t)mhl * (h.jj + 2 * nhl), need = per * nlev * nf;
+    bool regrown = false;          // buffers replaced in this call: strips a producer packed into the old ones are gone
     if (need > R->cap) {
+      regrown = true;
       HIPCHK(c, hipStreamSynchronize(st));
       for (int s = 0; s < 2; s++) {
         if (R->sbuf[s]) (void)hipFree(R->sbuf[s]);
@@ -191,7 +193,7 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
     const int east = T.px < T.npx - 1 ? R->rank + 1 : (per_i ? row0 : -1);
     const unsigned gpack = (unsigned)((per + 255) / 256);
     dim3 g(gpack, ly, nf);
-    if (!(prepacked && need <= R->cap))
+    if (!prepacked || regrown)
       hipLaunchKernelGGL(k_pack_ew_ns, dim3(gpack + gns, ly, nf), dim3(256), 0, st, c->d, F, R->sbuf[0],
                          R->sbuf[1], nlev, mhl, nhl, periodic_j, (int)gpack, ns_exchange ? 1 : 0);
     // Message order matters when west == east (2 ranks periodic, or 1 rank sending to itself):
@@ -230,6 +232,7 @@ int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, 
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
   hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
+  if (nf > 4) return ctx_fail(c, "rccl_arctic_gather: at most 4 stacks per exchange");
   const size_t per_field = (size_t)nrows * h.ii * nlev, need = per_field * nf;
   *field_stride = per_field;
   if (need > R->arc_cap) {
@@ -242,7 +245,6 @@ int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, 
   }
   const bool self = T.npx == 1 && R->force_ns;           // test hook: my own strip travels through send/recv
   double *mine = self ? R->arc_send : R->arc_gath + (size_t)T.px * need;
-  if (nf > 4) return ctx_fail(c, "rccl_arctic_gather: at most 4 stacks per exchange");
   arctic_pack_launch(c, st, fields, nf, mine, nlev, nrows);
   if (T.npx > 1 || self) {
     const int row0 = T.npx * (T.npy - 1);

@@ -523,7 +523,14 @@ bool bt_phase_usable(blomgpu_ctx *c) {
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return false;
     c->num_cus = prop.multiProcessorCount;
   }
-  return nbx * nby <= c->num_cus;
+  // the tiles wait for each other inside the launch: every one of them must be resident.  Ask the runtime how many
+  // workgroups of this kernel a CU takes (registers, LDS) instead of assuming one.
+  if (c->bt_blocks_per_cu < 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps<true>, NTHR, 0) != hipSuccess) nb = 0;
+    c->bt_blocks_per_cu = nb;
+  }
+  return c->bt_blocks_per_cu >= 1 && nbx * nby <= c->num_cus;
 }
 
 // one launch for the substeps lll0..last of a phase; `src` as in bt_pair_launch; returns the buffer set

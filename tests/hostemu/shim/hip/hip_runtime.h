@@ -132,3 +132,4 @@ using std::max;
 using std::min;
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
