@@ -107,6 +107,8 @@ _DIMS = {
     "box_s": (24, 20, 8, 0, 10.0e3, 900.0, 18.0),
     "per_s": (24, 24, 6, 3, 10.0e3, 900.0, 18.0),      # doubly periodic f-plane with an island and a seamount
     "fuk95": (156, 32, 12, 4, 650.0, 180.0, 6.0),
+    # the reference's own test case restated from its generator routines, see fuk95_ref_case below
+    "fuk95_ref": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
 }
 
@@ -210,10 +212,163 @@ def _depth_for(name, idm, jdm, dx):
     raise KeyError(name)
 
 
+# ---- the reference's fuk95 test case, from its own generator routines --------------------------------------------
+_RHO0_REF, _PI_REF, _RADIAN_REF, _REARTH_REF = 1.e3, 3.1415926536, 57.295779513, 6.37122e6   # phy/mod_constants.F90:30-44
+
+
+def _rho(p, th, s):
+    """in situ density, phy/mod_eos.F90:157-172"""
+    return ((_A11 + (_A12 + _A14 * th + _A15 * s) * th + (_A13 + _A16 * s) * s + (_B11 + _B12 * th + _B13 * s) * p)
+            / (_A21 + (_A22 + _A24 * th + _A25 * s) * th + (_A23 + _A26 * s) * s + (_B21 + _B22 * th + _B23 * s) * p))
+
+
+def _delphi(p1, p2, th, s):
+    """delphi(p1,p2,th,s) -> (dphi, alp2), phy/mod_eos.F90:478-529"""
+    a1 = _A11 + (_A12 + _A14 * th + _A15 * s) * th + (_A13 + _A16 * s) * s
+    a2 = _A21 + (_A22 + _A24 * th + _A25 * s) * th + (_A23 + _A26 * s) * s
+    b1 = _B11 + _B12 * th + _B13 * s
+    b2 = _B21 + _B22 * th + _B23 * s
+    pm = .5 * (p2 + p1)
+    r = .5 * (p2 - p1) / (a1 + b1 * pm)
+    q = b1 * r
+    qq = q * q
+    dphi = -2. * r * (a2 + b2 * pm + (a2 - a1 * b2 / b1) * qq * (1. / 3. + qq * (1. / 5. + qq * (1. / 7. + qq * (1. / 9.)))))
+    return dphi, (a2 + b2 * p2) / (a1 + b1 * p2)
+
+
+def _getpl(th, s, phiu, phil, pup):
+    """pressure at the lower interface of a layer from the geopotentials of its interfaces, phy/mod_inicon.F90:105-137
+    (vectorised: every column iterates until its own correction is below the reference's 1e-5)"""
+    plo = pup - _rho(pup, th, s) * (phil - phiu)
+    q = np.ones_like(plo)
+    for _ in range(50):
+        act = np.abs(q) > 1.e-5
+        if not act.any():
+            break
+        dphi, alpl = _delphi(pup, plo, th, s)
+        qn = (phil - phiu - dphi) / alpl
+        q = np.where(act, qn, q)
+        plo = np.where(act, plo - qn, plo)
+    return plo
+
+
+def sofsig(sg, th, pref):
+    """salinity from potential density and temperature, phy/mod_eos.F90:366-384"""
+    ap11, ap12, ap13, ap14, ap15, ap16, ap21, ap22, ap23, ap24, ap25, ap26 = eos_pref_coeffs(pref)
+    a = ap16 - ap26 * sg
+    b = ap13 - ap23 * sg + (ap15 - ap25 * sg) * th
+    c = ap11 - ap21 * sg + (ap12 - ap22 * sg + (ap14 - ap24 * sg) * th) * th
+    return (-b + np.sqrt(b * b - 4. * a * c)) / (2. * a)
+
+
+# tests/fuk95/limits of the reference: the options of its `run fuk95` test that the dynamical core reads (the vertical
+# coordinate is taken as isopyc_bulkml with remap/geopotential, SURVEY.md 8d config 1, second variant; the file's own
+# cntiso_hybrid + cppm + dynamic enthalpy needs the ALE stack)
+FUK95_LIMITS = dict(pref=0., baclin=180., batrop=6., mdv2hi=0., mdv2lo=0., mdv4hi=0., mdv4lo=0., mdc2hi=0., mdc2lo=0.,
+                    vsc2hi=.2, vsc2lo=.2, vsc4hi=0., vsc4lo=0., cbar=.05, cb=.002, cwbdts=0., cwbdls=25.,
+                    mommth="enscon", bmcmth="uc", eitmth="gm", bdmtyp=2, bdmc1=5.e-8, bdmc2=1.e-5, bdmldp=0, iwdflg=1,
+                    iwdfac=.06, nubmin=1.e-6, expcnf="fuk95")
+
+
+def fuk95_ref_case(ntr=1, **overrides):
+    """The reference's fuk95 case from its generator: geoenv_fuk95 (fuk95/mod_fuk95.F90:117-229: flat channel of depth
+    h0 closed at i = 1 and i = itdm, grid spacing lambda/jtdm, f-plane) and inicon_fuk95 for isopyc_bulkml (:262-338,
+    :412-445: reference densities, the front of Fukamachi et al. (1995) in the interface depths, mixed layer of
+    thickness mltmin, zero velocity), followed by the steps of the generic inicon that turn them into a model state
+    (phy/mod_inicon.F90:985-1095: freezing-point floor, salinity of the isopycnic layers from sigmar, interface
+    pressures by getpl, layer thickness).  Options: tests/fuk95/limits.  Single tile (i0 = j0 = 0)."""
+    idm, jdm, kdm, nreg, dx, baclin, batrop = _DIMS["fuk95_ref"]
+    kk, itdm, jtdm = kdm, idm, jdm
+    ni, nj = idm + 2 * NBDY, jdm + 2 * NBDY
+    u0, h1, h0, l0, drho, rhoc, rhob, f = .3, 1.e2, 2.e2, 2.e4, 0.19, 1025.9, 1027.0, 1.e-4     # :44-56
+    lat0, lam, mindz, saln0, mltmin = 45., 20.8e3, 1., 35., 5.                                  # mltmin: phy/mod_mxlayr.F90:73
+    rho0, pi, grav = _RHO0_REF, _PI_REF, GRAV
+    p = default_params(baclin, batrop)
+    p.update(FUK95_LIMITS)
+    p.update(taux0=0.0, nslp0=0.0)
+    p.update(overrides)
+    pref = p["pref"]
+    depth = np.zeros((nj, ni))
+    d = np.full((jdm, idm), h0)
+    d[:, 0] = 0.0
+    d[:, -1] = 0.0
+    depth[NBDY:NBDY + jdm, NBDY:NBDY + idm] = d
+    gs = lam / jtdm
+    g, one = {}, np.ones((nj, ni))
+    for nm in ("scqx", "scqy", "scpx", "scpy", "scux", "scuy", "scvx", "scvy"):
+        g[nm] = gs * one
+    for nm in ("scq2", "scp2", "scu2", "scv2"):
+        g[nm] = (gs * gs) * one
+    for nm, src in (("scq2i", "scq2"), ("scp2i", "scp2"), ("scuxi", "scux"), ("scuyi", "scuy"), ("scvxi", "scvx"), ("scvyi", "scvy")):
+        g[nm] = 1.0 / g[src]
+    g["corioq"] = f * one
+    g["coriop"] = f * one
+    g["betafp"] = (f / (np.tan(lat0 / _RADIAN_REF) * _REARTH_REF)) * one
+
+    def x_nudge(ri, rj):                                                               # :66-76
+        return (ri - itdm // 2 - .5 + .1 * np.sin(2. * (rj - 1) * pi / jtdm)) * lam / jtdm
+
+    def x_psi(x):                                                                      # :94-108
+        return np.where(x <= -l0, -.5 * l0, np.where(x >= l0, .5 * l0, .5 * (x + l0 / pi * np.sin(pi * x / l0))))
+
+    drhojet = rhoc * f * u0 * l0 / (grav * h1)                                         # :283-290
+    dsig = (drho + drhojet) / (kk - 4)
+    sigref = np.zeros(kk)
+    sigref[kk - 1] = rhob - rho0
+    sigref[kk - 2] = rhoc + .5 * (drho + drhojet) - rho0
+    for k in range(kk - 2, 0, -1):
+        sigref[k - 1] = sigref[k] - dsig
+    jj_, ii_ = np.meshgrid(np.arange(1., jdm + 1), np.arange(1., idm + 1), indexing="ij")
+    x = x_nudge(ii_, jj_)
+    sigmar = np.broadcast_to(sigref[:, None, None], (kk, jdm, idm)).copy()
+    sigma = sigmar.copy()
+    saln = np.full((kk, jdm, idm), saln0)
+    temp = tofsig(sigma, saln, pref)
+    z = np.zeros((kk + 1, jdm, idm))
+    z[1] = .5 * mltmin
+    z[2] = mltmin
+    z[kk - 1] = h1
+    z[kk] = h0
+    sigm = rhoc * (1. + f * u0 * x_psi(x) / (grav * h1)) - rho0
+    sigma[0] = sigm + .5 * drho * (z[1] + z[0] - h1) / h1
+    sigma[1] = sigm + .5 * drho * (z[2] + z[1] - h1) / h1
+    temp[0] = tofsig(sigma[0], saln[0], pref)
+    temp[1] = tofsig(sigma[1], saln[1], pref)
+    for k in range(4, kk):                                                              # :320-332
+        sigi = .5 * (sigref[k - 2] + sigref[k - 1])
+        zk = ((sigi - sigm) / drho + .5) * h1
+        z[k - 1] = np.minimum(z[kk - 1] - mindz * (kk - k), np.maximum(z[2], zk))
+    phi = -grav * z                                                                     # :433-443
+    # generic part, phy/mod_inicon.F90:985-1095 (atf = -0.0547, btf = ctf = 0 for expcnf = 'fuk95', phy/mod_eos.F90:137-141)
+    tfrz = -0.0547 * saln
+    temp = np.maximum(tfrz, temp)
+    saln[2:] = sofsig(sigmar[2:], temp[2:], pref)
+    sigma = sig(temp, saln, pref)
+    pint = np.zeros((kk + 1, jdm, idm))
+    pint[0] = _getpl(temp[0], saln[0], 0., phi[0], 0.)
+    for k in range(kk):
+        pint[k + 1] = _getpl(temp[k], saln[k], phi[k], phi[k + 1], pint[k])
+    dp = np.diff(pint, axis=0)
+    wet = d > 0.0
+    dp[:, ~wet] = 0.0
+    kgrid = np.arange(1, kk + 1)
+    trc = (1.0 + 0.5 * np.sin(2 * np.pi * (ii_ - .5) / idm) * np.cos(2 * np.pi * (jj_ - .5) / jdm))[None] * (1.0 + 0.1 * kgrid[:, None, None])
+
+    def pad3(a):
+        out = np.zeros((a.shape[0], nj, ni))
+        out[:, NBDY:NBDY + jdm, NBDY:NBDY + idm] = a
+        return out
+    ic = dict(dp=pad3(dp), temp=pad3(temp), saln=pad3(saln), sigma=pad3(sigma), sigmar=pad3(sigmar),
+              trc=pad3(trc)[None].repeat(max(ntr, 1), axis=0)[:ntr], z=pad3(z), phi=pad3(phi))
+    return Case(name="fuk95_ref", idm=idm, jdm=jdm, kdm=kdm, nreg=nreg, params=p, depth=depth, grid=g, ic=ic, ntr=ntr)
+
+
 def make_case(name, ntr=None, carve=None, **overrides):
     """`<grid>_tke`: the grid with the reference's default tracer set (meson_options.txt:17-21: turbclo = oneeq +
     advection, iage => -DTKE -DTKEADV -DIDLAGE): ntr = 3 = TKE, the generic-length-scale slot, ideal age
     (trc/mod_tracers.F90:85-127).  Without the suffix: the -DTRC -DIDLAGE build, ntr = 1."""
+    if name == "fuk95_ref":
+        return fuk95_ref_case(ntr=1 if ntr is None else ntr, **overrides)
     full_name = name
     tk2 = name.endswith("_tk2")          # turbclo = twoeq, advection, isodif: -DTKE -DGLS -DTKEADV -DTKEIDF
     tk0 = name.endswith("_tk0")          # turbclo = oneeq: -DTKE alone, TKE tracers not advected

@@ -4,6 +4,7 @@
 ! (drivers/nocoupler/blom.F:20-66): initialise, loop blom_step until the last step,
 ! print the final field checksum of dp (blom.F:56-57), write 'success' to run.status.
 !
+! Options: the reference's `limits` namelist file (mod_rdlim_gpu.F90).
 ! Initial state: a raw binary dump (blom_amd/statefile.py writes it from the numpy host
 ! initialisation); the reference reads netCDF here, which is out of scope.
 !   record 1: idm jdm kdm ntr nreg nsteps  (int32 x6), baclin (real64)
@@ -13,6 +14,7 @@
 program blom_dyncore
 
   use mod_blomgpu
+  use mod_rdlim_gpu, only: rdlim_gpu
   implicit none
 
   character(len=256) :: fname
@@ -20,6 +22,7 @@ program blom_dyncore
   character(len=32)  :: sval
   integer :: u, ios, kind, nlev, nsteps, nstep, i4(6), ival
   real(8) :: baclin, rval
+  logical :: have_limits
   real(8), allocatable :: buf(:,:,:)
   integer, allocatable :: ibuf(:,:,:)
 
@@ -55,6 +58,11 @@ program blom_dyncore
     end select
   end do
   close (u)
+  ! options: the reference's namelist file `limits` / `ocn_in` in the working directory, when there is one, decides them
+  ! (rdlim, phy/mod_rdlim.F90:137-175) and the length of the run; the option records of the state file are the fall-back
+  call rdlim_gpu(have_limits, nsteps, baclin)
+  call get_command_argument(2, sval)               ! optional: stop after this many steps (short test runs)
+  if (len_trim(sval) > 0) read (sval, *) nsteps
 
   nstep = 0
   do while (nstep < nsteps)

@@ -13,8 +13,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# cases that run on another case's reference build (same compile-time dimensions and options)
+_BUILD_OF = {"fuk95_ref": "fuk95"}
+
+
 def ref_lib_path(cfg):
-    return os.path.join(_HERE, "_ref", cfg, "libblomref.so")
+    return os.path.join(_HERE, "_ref", _BUILD_OF.get(cfg, cfg), "libblomref.so")
 
 
 def have_ref(cfg):

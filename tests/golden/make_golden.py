@@ -46,7 +46,7 @@ CHANNEL_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "trc", "p", "dpu", "d
 def generate(cfg):
     global NSTEPS
     big = cfg.startswith("channel") or cfg.startswith("tnx2v1s")
-    crc_only = big or cfg in ("fuk95", "tri_s", "chan_s_tke")
+    crc_only = big or cfg in ("fuk95", "fuk95_ref", "tri_s", "chan_s_tke")
     NSTEPS = 2 if cfg == "fuk95" else 3
     case = make_case(cfg)
     # the channel-sized reference is built with its OpenMP directives on (same results, oracle/Makefile)

@@ -1,0 +1,70 @@
+"""The Fortran host driven by the reference's namelist input: `program blom_dyncore` (blom_amd/fortran) finds a `limits`
+file in its working directory, reads the groups &LIMITS, &VCOORD and &DIFFUSION with the reference's variable lists
+(mod_rdlim_gpu.F90 <- phy/mod_rdlim.F90:137-175, phy/mod_vcoord.F90:818, phy/mod_diffusion.F90:214), sets the options
+through the ISO_C_BINDING shim and runs NDAY2-NDAY1 days.  The file is the reference's own tests/fuk95/limits
+(fixture tests/golden/fuk95_limits) with the three settings that select parts not built here changed (vertical
+coordinate, advection and pressure gradient method: SURVEY.md 8d config 1, second variant) and a shorter run.
+Here the program is linked against the host emulation of the device library (tests/hostemu); the same check runs
+on the GPU in tests/test_gpu_fortran_host.py."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd import hostinit
+from blom_amd.statefile import write_state
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "hostemu", "libblomgpu_hostemu.so")
+EXE = os.path.join(HERE, "hostemu", "blom_dyncore_hostemu")
+
+
+def limits_for_dyncore(dst, nday2_frac_steps=None):
+    """the reference's fuk95 limits file with VCOORD_TYPE / ADVMTH / PGFMTH of the isopyc_bulkml variant"""
+    txt = open(os.path.join(HERE, "golden", "fuk95_limits")).read()
+    txt = txt.replace("VCOORD_TYPE            = 'cntiso_hybrid'", "VCOORD_TYPE            = 'isopyc_bulkml'")
+    txt = txt.replace("ADVMTH   = 'cppm'", "ADVMTH   = 'remap'").replace("PGFMTH   = 'dynamic enthalpy'", "PGFMTH   = 'geopotential'")
+    assert "isopyc_bulkml" in txt and "'remap'" in txt and "'geopotential'" in txt
+    open(dst, "w").write(txt)
+
+
+def run_case(tmp_path, exe, backend_cls, nsteps_check):
+    import numpy as np
+    case = make_case("fuk95_ref")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    gpu = backend_cls(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    names = [n for n in gpu.field_names() if n not in ("mpack", "ip", "iu", "iv", "iq") and not n.startswith("wkp")]
+    state = str(tmp_path / "blom_state.bin")
+    # no option records in the state file: the namelist file is the only source of options
+    bare = make_case("fuk95_ref")
+    bare.params = {k: v for k, v in bare.params.items() if k in ("baclin",)}
+    write_state(state, gpu, bare, 0, names)
+    limits_for_dyncore(str(tmp_path / "limits"))
+    out = subprocess.run([exe, state] + ([str(nsteps_check)] if nsteps_check != 480 else []), cwd=str(tmp_path),
+                         capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "BLOM LIMITS NAMELIST GROUP" in out.stdout and "VCOORD_TYPE isopyc_bulkml" in out.stdout
+    got = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"chksum: (\w+): 0x([0-9A-Fa-f]+)", out.stdout)}
+    gpu.set("delt1", case.params["baclin"])
+    assert gpu.step(0, nsteps_check) == nsteps_check
+    want = {"dp": gpu.crc("dp", 1, 2 * case.kdm, 1), "temp": gpu.crc("temp", 1, 2 * case.kdm, 1), "u": gpu.crc("u", 1, 2 * case.kdm, 13)}
+    assert np.isfinite(gpu.get("u")).all()
+    gpu.close()
+    assert got == want, (got, want)
+    assert open(tmp_path / "run.status").read().strip() == "success"
+
+
+@pytest.mark.skipif(not (os.path.exists(EMU) and os.path.exists(EXE)), reason="tests/hostemu not built")
+def test_namelist_file_drives_the_fortran_host(tmp_path):
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    try:
+        # NDAY2 = 1 in the file means 480 steps of 180 s (the GPU test runs them all); the emulation stops after 3
+        run_case(tmp_path, EXE, g.BlomGpu, 3)
+    finally:
+        g.LIB_PATH = old

@@ -112,3 +112,14 @@ def test_fortran_driver_reproduces_reference_checksums_at_full_size(tmp_path):
     want = {nm: gold["crc"][str(nsteps)]["tmsmt2"][nm] for nm in ("dp", "temp", "u")}
     assert got == want, (got, want)
     assert open(tmp_path / "run.status").read().strip() == "success"
+
+
+def test_namelist_file_drives_the_fortran_host_for_a_model_day(tmp_path):
+    """the reference's tests/fuk95/limits (isopyc_bulkml variant) as the only source of options: one model day, 480 steps,
+    of the reference's own test case restated from its generator (fuk95_ref); see tests/test_fortran_namelist_host.py"""
+    from blom_amd.gpu import BlomGpu
+    from test_fortran_namelist_host import run_case
+    exe = os.path.join(ROOT, "blom_amd", "lib", "blom_dyncore")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built")
+    run_case(tmp_path, exe, BlomGpu, 480)

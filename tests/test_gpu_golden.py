@@ -68,7 +68,7 @@ def test_device_reproduces_golden_fixtures(cfg):
     gpu.close()
 
 
-@pytest.mark.parametrize("cfg", ["fuk95", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke"])
+@pytest.mark.parametrize("cfg", ["fuk95", "fuk95_ref", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke"])
 def test_device_reproduces_reference_checksums_from_analytic_init(cfg):
     """Fixtures that hold only the reference's per-stage checksums; the inputs are the analytic host initialisation.
     channel_tke is BASELINE.json's channel at full size (208x512x53, ntr = 3, the bench workload): the device must

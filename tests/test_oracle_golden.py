@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EDDTRA_OUT = {"umfltd", "vmfltd", "utfltd", "vtfltd", "usfltd", "vsfltd"}
 
 
-@pytest.mark.parametrize("cfg", ["fuk95", "tri_s", "chan_s_tke"])
+@pytest.mark.parametrize("cfg", ["fuk95", "fuk95_ref", "tri_s", "chan_s_tke"])
 def test_c_oracle_reproduces_reference_checksums_from_analytic_init(cfg):
     """fuk95 (the reference's own test case), tri_s (arctic patch), chan_s_tke (default tracer set): the fixture holds only the reference's
     per-stage checksums; the inputs are the analytic host initialisation, redone here on the C restatement"""
