@@ -40,10 +40,11 @@ if len(sys.argv) > 5:
     # fetch corrected by the 2.0x calibrated for the 8 B/lane loads of these fp64 kernels
     # (profiles/r02_fetch_calibration.txt), writes as counted.  bench.py reports it as roofline.traffic.
     import json
-    prefixes = [("k_mom_", "momtum"), ("k_remap_", "remap"), ("k_adv_", "remap"), ("k_cppm_", "cppm"),
+    prefixes = [("k_cmn_", "cmnfld"), ("k_mom_", "momtum"), ("void k_mom_", "momtum"), ("k_remap_", "remap"), ("k_adv_", "remap"), ("k_cppm_", "cppm"),
                 ("k_diffus_", "diffus"), ("k_pgf_", "pgforc"), ("k_diapfl_", "diapfl"), ("k_convec_", "convec"),
                 ("k_bt_", "barotp"), ("void k_bt_", "barotp"), ("k_pbc_", "pbcor"), ("k_eddtra_", "eddtra")]
-    nsteps_pmc = max(fe[k][0] for k in fe if k.startswith("k_mom_update")) if any(k.startswith("k_mom_update") for k in fe) else 1
+    once = [k for k in fe if k.startswith("k_mom_column") or k.startswith("k_mom_update")]
+    nsteps_pmc = max(fe[k][0] for k in once) if once else 1
     cls = collections.defaultdict(float)
     for k in fe:
         kk_ = k[5:] if k.startswith("void ") else k          # templated kernels are reported as "void name<..>"
