@@ -94,6 +94,26 @@ def class_traffic(config, ntr=1):
     return None, None
 
 
+def dominant_kernel(config):
+    """the single largest kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
+    (profiles/*_kernel_stats.txt, newest): name, average us, share of the kernel time"""
+    import glob
+    if config != "channel":
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernel_stats.txt")))
+    for f in reversed(files):
+        for line in open(f):
+            if line.startswith("#") or not line.strip():
+                continue
+            parts = line.split()
+            try:
+                return {"name": " ".join(parts[:-4]), "avg_us": float(parts[-3]), "percent_of_kernel_time": float(parts[-1]),
+                        "source": os.path.basename(f)}
+            except ValueError:
+                break
+    return None
+
+
 def usable_cores():
     """Cores this process may actually use: the cgroup CPU quota if there is one (the GPU box shows 256
     logical CPUs but grants 16 cores; 256 threads ran the reference 35x slower than 16), else the CPU count."""
@@ -388,7 +408,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (traffic or {}).get(dom), "traffic_source": traffic_src,
-                     "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom]},
+                     "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom],
+                     "dominant_single_kernel": dominant_kernel(args.config)},
         "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
                           "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,
                           "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1))},

@@ -214,7 +214,9 @@ struct blomgpu_ctx {
   int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major
   int momtum_bs = 0;         // lanes per workgroup of the fused kernels (0: 64, one wavefront)
   int momtum_chunks_a = 0, momtum_chunks_b = 0;   // j-chunks per layer of the two fused kernels (0: one round of workgroups)
-  int diapfl_v = 2;          // 2: traffic-lean column kernel (stage_diapfl_col2.hip), 1: first version
+  int diapfl_v = 3;          // 3: col2 with DU levels' loads in flight (stage_diapfl_col3.hip), 2: traffic-lean column kernel
+                             // (stage_diapfl_col2.hip), 1: first version
+  int diapfl_du = 8;         // levels whose loads k_diapfl_column3 keeps in flight (2, 4, 8)
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   double *arc_strip = nullptr;                 // arctic patch, tiles of one process in strips mode: this tile's strip
   size_t arc_cap = 0;
@@ -272,6 +274,7 @@ int ctx_check_errors(blomgpu_ctx *);         // read back all error words, fail 
 int st_kfpla_halo(blomgpu_ctx *, int n);
 int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
+int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);

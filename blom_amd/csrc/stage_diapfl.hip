@@ -486,7 +486,8 @@ int st_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) {
   int *errflag = c->err_dev + 0;
   {
     TimeScope ts(c, "diapfl");
-    if (c->diapfl_v == 2) { if (int rc = diapfl_column2_launch(c, n, nn, errflag)) return rc; }
+    if (c->diapfl_v == 3) { if (int rc = diapfl_column3_launch(c, n, nn, errflag)) return rc; }
+    else if (c->diapfl_v == 2) { if (int rc = diapfl_column2_launch(c, n, nn, errflag)) return rc; }
     else hipLaunchKernelGGL(k_diapfl_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, n, nn, errflag);
     {                                                                                     // :711-713, :723
       double *ptrs[4] = {h.f[F_p], h.f[F_fpug], h.f[F_fplg], h.f[F_util1]};

@@ -29,7 +29,7 @@ def _run(cfg, nsteps, **opts):
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 8), ("fuk95", 6), ("chan_m", 6), ("tri_s", 8),
                                         ("chan_s_tke", 12), ("tri_s_tke", 8)])
-@pytest.mark.parametrize("opt,variants", [("diapfl_v", (1, 2)), ("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)),
+@pytest.mark.parametrize("opt,variants", [("diapfl_v", (1, 3)), ("diapfl_v", (2, 3)), ("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)),
                                           ("momtum_v", (1, 2))])
 def test_variants_bit_identical(cfg, nsteps, opt, variants):
     a = _run(cfg, nsteps, **{opt: variants[0]})

@@ -2,7 +2,7 @@
 import csv, glob, sys, collections
 d, pats = sys.argv[1], sys.argv[2:]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].split("(")[0]
         if any(p in n for p in pats):
