@@ -1,0 +1,382 @@
+// remap: gradient and flux sweep of a layer in one LDS-tiled kernel -- phy/mod_remap.F90:358-1462.
+//
+// The one-kernel-per-sweep form (stage_advect.hip) writes 8 + 3 ntr gradient planes per layer to HBM and its flux sweep
+// fetches them 2.9 times over (donor cells are the point's and its neighbours': 3.0 GB per launch); both sweeps are
+// chains of dependent loads (masks -> neighbour indices -> values; corner velocities -> donor cell -> gradients), ~140
+// exposed memory latencies per wavefront.  Here a workgroup owns a tile of RT_TW x RT_TH points of one layer:
+//   phase 0  every global load of the workgroup, all independent and issued up front: the scalars (dp, p, T, S, tracers)
+//            and masks of the tile with a 2-point rim go to LDS; each thread keeps what its own point needs later
+//            (flux areas, metrics, face pressures, old fluxes) in registers; non-dimensional face velocities cu, cv of
+//            the tile with a 1-point rim go to LDS                                              (mod_remap:588-610)
+//   phase 1  one thread per point of the tile with a 1-point rim: limited gradients from the LDS scalars and the
+//            corner velocities from cu, cv, into registers                                      (:358-584, :623-659)
+//   phase 2  these replace the scalars in LDS
+//   phase 3  one thread per point of the tile: u- and v-face flux polygons, donor cells read from LDS      (:661-1462)
+// The gradient planes never reach HBM; the price is the rim, 1.33 gradient evaluations per point.
+// Expressions are those of k_remap_grad / k_remap_flux (stage_advect.hip), operator for operator: every neighbour value
+// selected there by a wet-restricted index is selected here by the same index into the tile.
+// Roofline: HBM, ~(19 + 4 ntr) F per launch (scalars with rim 1.7 x (4 + ntr) F, cau, cav, 6 old/new fluxes, 2 (3+ntr) F
+// of flux planes for k_remap_update).
+#include "remap_common.h"
+
+#define RT_TW 32
+#define RT_TH 8
+#define RT_GW (RT_TW + 2)                 // gradient region: the tile and a 1-point rim
+#define RT_GN (RT_GW * (RT_TH + 2))
+#define RT_SW (RT_TW + 4)                 // scalar region: the tile and a 2-point rim
+#define RT_SN (RT_SW * (RT_TH + 4))
+#define RT_NT 512                         // threads of a workgroup: >= RT_SN, and two per point of the tile
+#define RT_NSC(ntr) (4 + (ntr))           // scalars: dp, p(k+1), T, S, tracers
+#define RT_NG(ntr) (10 + 3 * (ntr))       // gradient slots (remap_common.h) + dp', pup of the cell
+#define RT_G_DPT(ntr) (8 + 3 * (ntr))
+#define RT_G_PUP(ntr) (9 + 3 * (ntr))
+
+#define MP(m) ((m) & 1)
+#define MU(m) (((m) >> 1) & 1)
+#define MV(m) (((m) >> 2) & 1)
+
+static_assert(RT_NT >= RT_SN && RT_NT == 2 * RT_TW * RT_TH, "thread count of k_remap_tile");
+
+// limited gradient of one scalar from its tile, mod_remap.F90:412-439 (limited_gradient of stage_advect.hip)
+struct TNbr {
+  int w, e, s, n, sw, se, nw, ne;
+};
+__device__ inline void limited_gradient_t(const double *f, const TNbr &b, int c, double dxi, double dyi, double xd, double yd,
+                                          double &gx, double &gy, double &gd) {
+  const double fc = f[c], fw = f[b.w], fe = f[b.e], fs = f[b.s], fn = f[b.n];
+  double tx = (fe - fw) * dxi;
+  double ty = (fn - fs) * dyi;
+  const double q1 = tx * (-.5 - xd), q2 = tx * (.5 - xd), q3 = ty * (-.5 - yd), q4 = ty * (.5 - yd);
+  const double tgmx = fmax2(q1, q2) + fmax2(q3, q4);
+  const double tgmn = fmin2(q1, q2) + fmin2(q3, q4);
+  const double fsw = f[b.sw], fse = f[b.se], fnw = f[b.nw], fne = f[b.ne];
+  const double tfmx = fmax2(0., max8(fsw, fs, fse, fw, fe, fnw, fn, fne) - fc);
+  const double tfmn = fmin2(0., min8(fsw, fs, fse, fw, fe, fnw, fn, fne) - fc);
+  if (tfmx > 0. && tfmn < 0.) {
+    const double q = fmin2(tfmx / fmax2(tfmx, tgmx), tfmn / fmin2(tfmn, tgmn));
+    tx = tx * q;
+    ty = ty * q;
+    gd = fc - tx * xd - ty * yd;
+  } else {
+    tx = 0.;
+    ty = 0.;
+    gd = fc;
+  }
+  gx = tx;
+  gy = ty;
+}
+
+// one polygon's contribution from the donor cell at index x of the gradient region (add_contrib of stage_advect.hip)
+__device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbface, double a, double ax, double ay, double axx,
+                                     double ayy, double axy, Acc &A) {
+  const double dpt = g[RT_G_DPT(ntr) * RT_GN + x];
+  const double pup = g[RT_G_PUP(ntr) * RT_GN + x];
+  const double dl = fmin2(dpt, fmax2(0., pbface - pup));
+  const double dx = g[G_DX * RT_GN + x], dy = g[G_DY * RT_GN + x];
+  const double fd = a * dl + ax * dx + ay * dy;
+  A.fd = A.fd + fd;
+  const double qx = ax * dl + axx * dx + axy * dy;
+  const double qy = ay * dl + axy * dx + ayy * dy;
+  A.ft = A.ft + fd * g[G_TD * RT_GN + x] + qx * g[G_TX * RT_GN + x] + qy * g[G_TY * RT_GN + x];
+  A.fs = A.fs + fd * g[G_SD * RT_GN + x] + qx * g[G_SX * RT_GN + x] + qy * g[G_SY * RT_GN + x];
+#pragma unroll
+  for (int nt = 0; nt < MAXTR; nt++)
+    if (nt < ntr)
+      A.ftr[nt] = A.ftr[nt] + fd * g[G_TRD(nt) * RT_GN + x] + qx * g[G_TRX(nt) * RT_GN + x] + qy * g[G_TRY(nt) * RT_GN + x];
+}
+
+__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv, unsigned atr) {
+  const DevView &V = *Vp;
+  HIP_DYNAMIC_SHARED(double, lds)
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  // nadv tracers are advected, tracer a of them is tracer (atr >> 8a) & 255 of the model (TKE and its length scale are
+  // not unless use_TKEADV, mod_remap.F90:314-316 and every tracer loop after it)
+  const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
+  const int x0 = (bx_ % ntx) * RT_TW, y0 = (bx_ / ntx) * RT_TH;        // first point of the tile in the padded plane
+  const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np;
+  // LDS: [ scalars | ... ] then, from phase 2 on, [ gradient slots ] over the same space; cu, cv / corner velocities; masks
+  double *const sc = lds;                                   // RT_NSC x RT_SN
+  double *const gr = lds;                                   // RT_NG x RT_GN
+  double *const cuv = lds + RT_NG(nadv) * RT_GN;            // 2 x RT_GN: cu, cv in phases 0-1, corner velocities after
+  int *const mpl = (int *)(cuv + 2 * RT_GN);                // RT_SN masks
+  const int *mpk = V.m[I_mpack];
+  const double *scp2 = V.f[F_scp2], *scp2i = V.f[F_scp2i];
+
+  // ---- phase 0 -------------------------------------------------------------------------------------------------
+  // (a) the scalar region: one point per thread
+  double sv[4 + MAXTR];
+  int sm;
+  {
+    const double *f_dp = V.f[F_dp] + okn, *f_p = V.f[F_p] + (size_t)(k + 1) * np, *f_t = V.f[F_temp] + okn;
+    const double *f_s = V.f[F_saln] + okn, *f_tr = V.f[F_trc] + okn;
+    const int xs = x0 - 2 + t % RT_SW, ys = y0 - 2 + t / RT_SW;
+    const bool in = t < RT_SN && xs >= 0 && xs < ni && ys >= 0 && ys < nj;
+    const size_t cs = in ? (size_t)ys * ni + xs : 0;
+    sm = in ? mpk[cs] : 0;
+    sv[0] = f_dp[cs]; sv[1] = f_p[cs]; sv[2] = f_t[cs]; sv[3] = f_s[cs];
+#pragma unroll
+    for (int a = 0; a < MAXTR; a++) sv[4 + a] = a < nadv ? f_tr[cs + (size_t)((atr >> (8 * a)) & 255u) * 2 * V.kk * np] : 0.;
+  }
+  // (b) this thread's point of the gradient region (threads 0 .. RT_GN-1): the tile's points first, then the rim
+  int gx, gy;
+  if (t < RT_TW * RT_TH) { gx = t % RT_TW + 1; gy = t / RT_TW + 1; }
+  else {
+    const int r = t - RT_TW * RT_TH;
+    if (r < RT_GW) { gx = r; gy = 0; }
+    else if (r < 2 * RT_GW) { gx = r - RT_GW; gy = RT_TH + 1; }
+    else if (r < 2 * RT_GW + RT_TH) { gx = 0; gy = r - 2 * RT_GW + 1; }
+    else { gx = RT_GW - 1; gy = r - 2 * RT_GW - RT_TH + 1; }
+  }
+  const bool gthread = t < RT_GN;
+  const int q = gy * RT_GW + gx;                             // index in the gradient region
+  const int sidx = (gy + 1) * RT_SW + gx + 1;                // index in the scalar region
+  int mpc;
+  double cu, cv, pm;
+  bool gpoint;
+  {
+    const int x = x0 - 1 + gx, y = y0 - 1 + gy;
+    const bool inplane = gthread && x >= 0 && x < ni && y >= 0 && y < nj;
+    const int i = x - (NBDY - 1), j = y - (NBDY - 1);
+    // clamped so that c-1, c-ni exist: what a clamped point reads belongs to no point of any sweep's range
+    const int xc = x < 1 ? 1 : (x > ni - 1 ? ni - 1 : x), yc = y < 1 ? 1 : (y > nj - 1 ? nj - 1 : y);
+    const size_t c = (size_t)yc * ni + xc;
+    mpc = inplane ? mpk[c] : 0;
+    const double cau_c = V.f[F_cau][c + ok], cav_c = V.f[F_cav][c + ok];
+    const double si_w = scp2i[c - 1], si_c = scp2i[c], si_s = scp2i[c - ni];
+    pm = WK2(V, 0)[c];
+    // non-dimensional face velocities (mod_remap.F90:588-610); zero where no u/v point exists
+    cu = MU(mpc) ? (cau_c > 0. ? cau_c * si_w : cau_c * si_c) : 0.;
+    cv = MV(mpc) ? (cav_c > 0. ? cav_c * si_s : cav_c * si_c) : 0.;
+    gpoint = inplane && j >= -1 && j <= V.jj + 2 && i >= -1 && i <= V.ii + 2 && MP(mpc);
+  }
+  // (c) this thread's face: threads 0..255 the u-face, threads 256..511 the v-face of tile point t mod 256.
+  // Metrics of the face's donor cells in face coordinates: m2[a][b] is scp2 at offset (a-1) ACROSS the face's normal
+  // and (b-1) ALONG it -- u-face: (di, dj) = (b-1, a-1); v-face: (di, dj) = (a-1, b-1); b = 2 is never a donor.
+  const bool uface = t < RT_TW * RT_TH;
+  const int ft = t % (RT_TW * RT_TH);
+  const int fq = (ft / RT_TW + 1) * RT_GW + ft % RT_TW + 1;
+  const int fx = x0 + ft % RT_TW, fy = y0 + ft / RT_TW;
+  const bool fin = fx >= 1 && fx < ni - 1 && fy >= 1 && fy < nj - 1;      // every point with a face has neighbours
+  const size_t fc = fin ? (size_t)fy * ni + fx : (size_t)ni + 1;
+  const int fi = fx - (NBDY - 1), fj = fy - (NBDY - 1);
+  double m2[3][2], m2i[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const size_t cc = uface ? fc + (b - 1) + (ptrdiff_t)(a - 1) * ni : fc + (a - 1) + (ptrdiff_t)(b - 1) * ni;
+      m2[a][b] = scp2[cc];
+      m2i[a][b] = scp2i[cc];
+    }
+  const int mpf = fin ? mpk[fc] : 0;
+  const double caf = (uface ? V.f[F_cau] : V.f[F_cav])[fc + ok];
+  const double pbf = (uface ? V.f[F_pbu] : V.f[F_pbv])[fc + (size_t)(n - 1) * np];
+  double *const o_f = (uface ? V.f[F_uflx] : V.f[F_vflx]) + fc + okm;
+  double *const o_ft = (uface ? V.f[F_utflx] : V.f[F_vtflx]) + fc + okm;
+  double *const o_fs = (uface ? V.f[F_usflx] : V.f[F_vsflx]) + fc + okm;
+  const double f_o = *o_f, ft_o = *o_ft, fs_o = *o_fs;          // old fluxes (the u-face accumulates, :1054-1056)
+  const bool fmask = uface ? MU(mpf) : MV(mpf);
+  const double cf = fmask ? (caf > 0. ? caf * m2i[1][0] : caf * m2i[1][1]) : 0.;     // cu resp. cv of the face
+
+  if (t < RT_SN) {
+    mpl[t] = sm;
+#pragma unroll
+    for (int s = 0; s < 4 + MAXTR; s++)
+      if (s < 4 + nadv) sc[s * RT_SN + t] = sv[s];
+  }
+  if (gthread) { cuv[q] = cu; cuv[RT_GN + q] = cv; }
+  __syncthreads();
+
+  // ---- phase 1: gradients (k_remap_grad) and corner velocities (corner()) of this thread's point ------------------
+  double gv[10 + 3 * MAXTR];
+#pragma unroll
+  for (int s = 0; s < 10 + 3 * MAXTR; s++) gv[s] = 0.;
+  double cuc = 0., cvc = 0.;
+  if (gpoint) {
+    // wet-restricted neighbours, mod_remap.F90:365-376 (wet_nbr of stage_advect.hip)
+    const int a = MU(mpc), b = MU(mpl[sidx + 1]), d = MV(mpc), e = MV(mpl[sidx + RT_SW]);
+    TNbr nb;
+    nb.w = sidx - a;
+    nb.e = sidx + b;
+    nb.s = sidx - d * RT_SW;
+    nb.n = sidx + e * RT_SW;
+    const int sw = sidx - a - d * RT_SW, se = sidx + b - d * RT_SW, nw = sidx - a + e * RT_SW, ne = sidx + b + e * RT_SW;
+    nb.sw = MP(mpl[sw]) ? sw : sidx;
+    nb.se = MP(mpl[se]) ? se : sidx;
+    nb.nw = MP(mpl[nw]) ? nw : sidx;
+    nb.ne = MP(mpl[ne]) ? ne : sidx;
+    const int dxw = a + b, dyw = d + e;
+    const double dxi = 1. / (dxw > 1 ? dxw : 1);
+    const double dyi = 1. / (dyw > 1 ? dyw : 1);
+    const double *dp = sc, *plo = sc + RT_SN;
+    // dp' = max(0,dp)+dpeps ; pup = plo - dp' ; lim = max(dpeps, min(pbmin - pup, dp'))
+#define LIM(x) ({ const double d_ = fmax2(0., dp[x]) + DPEPS; fmax2(DPEPS, fmin2(pm - (plo[x] - d_), d_)); })
+    const double dpsw = LIM(nb.sw), dps = LIM(nb.s), dpse = LIM(nb.se), dpw = LIM(nb.w), dpc = LIM(sidx);
+    const double dpe = LIM(nb.e), dpnw = LIM(nb.nw), dpn = LIM(nb.n), dpne = LIM(nb.ne);
+#undef LIM
+    double dx = (dpe - dpw) * dxi, dy = (dpn - dps) * dyi;
+    const double dgmx = .5 * (fabs(dx) + fabs(dy));
+    const double dfmx = fmax2(0., max8(dpsw, dps, dpse, dpw, dpe, dpnw, dpn, dpne) - dpc);
+    const double dfmn = fmin2(0., min8(dpsw, dps, dpse, dpw, dpe, dpnw, dpn, dpne) - dpc);
+    const double dpt = fmax2(0., dp[sidx]) + DPEPS;
+    double xd, yd;
+    if (dfmx > 0. && dfmn < 0.) {
+      const double qq = fmin2(dfmx / fmax2(dfmx, dgmx), dfmn / fmin2(dfmn, -dgmx));
+      dx = dx * qq;
+      dy = dy * qq;
+      xd = dx / (12. * dpt);
+      yd = dy / (12. * dpt);
+    } else {
+      dx = 0.; dy = 0.; xd = 0.; yd = 0.;
+    }
+    gv[G_DX] = dx;
+    gv[G_DY] = dy;
+    gv[8 + 3 * MAXTR] = dpt;                     // stored at RT_G_DPT / RT_G_PUP
+    gv[9 + 3 * MAXTR] = plo[sidx] - dpt;
+    limited_gradient_t(sc + 2 * RT_SN, nb, sidx, dxi, dyi, xd, yd, gv[G_TX], gv[G_TY], gv[G_TD]);
+    limited_gradient_t(sc + 3 * RT_SN, nb, sidx, dxi, dyi, xd, yd, gv[G_SX], gv[G_SY], gv[G_SD]);
+#pragma unroll
+    for (int nt = 0; nt < MAXTR; nt++)
+      if (nt < nadv)
+        limited_gradient_t(sc + (4 + nt) * RT_SN, nb, sidx, dxi, dyi, xd, yd, gv[G_TRX(nt)], gv[G_TRY(nt)], gv[G_TRD(nt)]);
+  }
+  if (gthread && gx >= 1 && gy >= 1) {
+    // corner velocities at the corner common to (x-1,y-1), (x,y-1), (x-1,y), (x,y), mod_remap.F90:623-659
+    const int psw = MP(mpl[sidx - 1 - RT_SW]), pse = MP(mpl[sidx - RT_SW]), pnw = MP(mpl[sidx - 1]), pne = MP(mpc);
+    const int nw = psw + pse + pnw + pne;
+    const double cus = cuv[q - RT_GW], cun = cu, cvw = cuv[RT_GN + q - 1], cve = cv;
+    if (nw == 4) {
+      cuc = (cus * cun <= 0.) ? 0. : 2. * cus * cun / (cus + cun);
+      cvc = (cvw * cve <= 0.) ? 0. : 2. * cvw * cve / (cvw + cve);
+    } else if (nw == 2) {
+      if (psw + pse == 2) { cuc = cus; cvc = 0.; }
+      else if (pnw + pne == 2) { cuc = cun; cvc = 0.; }
+      else if (psw + pnw == 2) { cuc = 0.; cvc = cvw; }
+      else if (pse + pne == 2) { cuc = 0.; cvc = cve; }
+      else { cuc = 0.; cvc = 0.; }
+    } else {
+      cuc = 0.; cvc = 0.;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: the gradient fields replace the scalars ---------------------------------------------------------
+  if (gthread) {
+#pragma unroll
+    for (int s = 0; s < 8 + 3 * MAXTR; s++)
+      if (s < 8 + 3 * nadv) gr[s * RT_GN + q] = gv[s];
+    gr[RT_G_DPT(nadv) * RT_GN + q] = gv[8 + 3 * MAXTR];
+    gr[RT_G_PUP(nadv) * RT_GN + q] = gv[9 + 3 * MAXTR];
+    cuv[q] = cuc;
+    cuv[RT_GN + q] = cvc;
+  }
+  __syncthreads();
+  if (!fin) return;
+
+  // ---- phase 3: flux through this thread's face (k_remap_flux) ---------------------------------------------------------
+  const bool in_f = uface ? (fj >= 0 && fj <= V.jj + 1 && fi >= 0 && fi <= V.ii + 2) : (fj >= 0 && fj <= V.jj + 2 && fi >= 0 && fi <= V.ii + 1);
+  if (!in_f) return;
+  Acc A;
+  A.fd = 0.; A.ft = 0.; A.fs = 0.;
+#pragma unroll
+  for (int nt = 0; nt < MAXTR; nt++) A.ftr[nt] = 0.;
+  if (fmask) {
+    const double cuc0 = cuv[fq], cvc0 = cuv[RT_GN + fq];
+    const bool near = cf > 0.;                       // donor column i-1 (u-face) resp. donor row j-1 (v-face)
+    const double sh = near ? .5 : -.5;
+    const double s2_c = near ? m2[1][0] : m2[1][1], s2_m = near ? m2[0][0] : m2[0][1], s2_p = near ? m2[2][0] : m2[2][1];
+    const double s2i_m = near ? m2i[0][0] : m2i[0][1], s2i_p = near ? m2i[2][0] : m2i[2][1];
+    double a, ax, ay, axx, ayy, axy, x2, y2, x4, y4;
+    if (uface) {
+      const double cuc1 = cuv[fq + RT_GW], cvc1 = cuv[RT_GN + fq + RT_GW];
+      const double ym = -.5 * (cvc0 + cvc1);
+      const double xm = ((ym + .5) * cuc0 - (ym - .5) * cuc1 - 2. * cf) / (1. + cvc0 - cvc1);
+      const int ic = near ? fq - 1 : fq;             // donor column
+      if (cvc0 > 0.) {
+        const double xc0 = (xm * cvc0 - cuc0 * (ym + .5)) / (cvc0 + ym + .5);
+        const double xc1 = xc0 * s2_c * s2i_m;
+        x4 = xc0 + sh;
+        y4 = -.5;
+        triint(s2_m, xc1 + sh, .5, -cuc0 + sh, -cvc0 + .5, sh, .5, a, ax, ay, axx, ayy, axy);
+        add_contrib_t(gr, nadv, ic - RT_GW, pbf, a, ax, ay, axx, ayy, axy, A);
+      } else {
+        x4 = -cuc0 + sh;
+        y4 = -cvc0 - .5;
+      }
+      if (cvc1 < 0.) {
+        const double xc0 = (xm * cvc1 - cuc1 * (ym - .5)) / (cvc1 + ym - .5);
+        const double xc1 = xc0 * s2_c * s2i_p;
+        x2 = xc0 + sh;
+        y2 = .5;
+        triint(s2_p, xc1 + sh, -.5, sh, -.5, -cuc1 + sh, -cvc1 - .5, a, ax, ay, axx, ayy, axy);
+        add_contrib_t(gr, nadv, ic + RT_GW, pbf, a, ax, ay, axx, ayy, axy, A);
+      } else {
+        x2 = -cuc1 + sh;
+        y2 = -cvc1 + .5;
+      }
+      penint(s2_c, sh, .5, x2, y2, xm + sh, ym, x4, y4, sh, -.5, a, ax, ay, axx, ayy, axy);
+      add_contrib_t(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A);
+      // mod_remap.F90:1054-1056
+      *o_f = f_o + A.fd;
+      *o_ft = ft_o + A.ft;
+      *o_fs = fs_o + A.fs;
+    } else {
+      const double cuc1 = cuv[fq + 1], cvc1 = cuv[RT_GN + fq + 1];
+      const double xm = -.5 * (cuc0 + cuc1);
+      const double ym = ((xm + .5) * cvc0 - (xm - .5) * cvc1 - 2. * cf) / (1. + cuc0 - cuc1);
+      const int jc = near ? fq - RT_GW : fq;         // donor row
+      if (cuc0 > 0.) {
+        const double yc0 = (ym * cuc0 - cvc0 * (xm + .5)) / (cuc0 + xm + .5);
+        const double yc1 = yc0 * s2_c * s2i_m;
+        x2 = -.5;
+        y2 = yc0 + sh;
+        triint(s2_m, .5, yc1 + sh, .5, sh, -cuc0 + .5, -cvc0 + sh, a, ax, ay, axx, ayy, axy);
+        add_contrib_t(gr, nadv, jc - 1, pbf, a, ax, ay, axx, ayy, axy, A);
+      } else {
+        x2 = -cuc0 - .5;
+        y2 = -cvc0 + sh;
+      }
+      if (cuc1 < 0.) {
+        const double yc0 = (ym * cuc1 - cvc1 * (xm - .5)) / (cuc1 + xm - .5);
+        const double yc1 = yc0 * s2_c * s2i_p;
+        x4 = .5;
+        y4 = yc0 + sh;
+        triint(s2_p, -.5, yc1 + sh, -cuc1 - .5, -cvc1 + sh, -.5, sh, a, ax, ay, axx, ayy, axy);
+        add_contrib_t(gr, nadv, jc + 1, pbf, a, ax, ay, axx, ayy, axy, A);
+      } else {
+        x4 = -cuc1 + .5;
+        y4 = -cvc1 + sh;
+      }
+      penint(s2_c, -.5, sh, x2, y2, xm, ym + sh, x4, y4, .5, sh, a, ax, ay, axx, ayy, axy);
+      add_contrib_t(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A);
+      // mod_remap.F90:1455-1457: assignment (not accumulation) for the v-components
+      *o_f = A.fd;
+      *o_ft = A.ft;
+      *o_fs = A.fs;
+    }
+  }
+  // the flux planes of k_remap_update: W_FDU, W_FDV, W_FTU, W_FTV, .. alternate
+  const int off = uface ? 0 : 1;
+  WK(V, W_FDU(ntr) + off)[fc + ok] = A.fd;
+  WK(V, W_FTU(ntr) + off)[fc + ok] = A.ft;
+  WK(V, W_FSU(ntr) + off)[fc + ok] = A.fs;
+#pragma unroll
+  for (int nt = 0; nt < MAXTR; nt++)
+    if (nt < nadv) WK(V, W_FTRU(ntr, (atr >> (8 * nt)) & 255u) + off)[fc + ok] = A.ftr[nt];
+}
+
+int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn) {
+  const DevView &h = c->h;
+  if (h.ntr > MAXTR) return ctx_fail(c, "remap: more tracers than MAXTR");
+  const int ntx = (h.ni + RT_TW - 1) / RT_TW, nty = (h.nj + RT_TH - 1) / RT_TH;
+  int nadv = 0;
+  unsigned atr = 0;
+  for (int nt = 0; nt < h.ntr; nt++)
+    if (!trc_skip_adv(h.P, nt + 1)) atr |= (unsigned)nt << (8 * nadv++);
+  const size_t lds = sizeof(double) * (RT_NG(nadv) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
+  static_assert(RT_NSC(MAXTR) * RT_SN <= RT_NG(MAXTR) * RT_GN, "the scalars must fit under the gradient slots");
+
+  hipLaunchKernelGGL(k_remap_tile, dim3(ntx * nty, h.kk), dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, atr);
+  return 0;
+}
