@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqf(const DevView *__restrict__ Vp
   const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
   const double *dp = V.f[F_dp] + c + (size_t)nn * np;
   double *bfsqi = V.f[F_bfsqi] + c, *bfsql = V.f[F_bfsql] + c, *bfsqf = V.f[F_bfsqf] + c;
-  double *delp = WK(V, CM_DELP) + c, *bfsq = WK(V, CM_BFSQ) + c, *sls2 = WK(V, CM_SLS2) + c, *gam = WK(V, CM_GAM) + c;
+  double *gam = WK(V, CM_GAM) + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]          /* Fortran level k */
   const double b1 = .5 * GRAV * GRAV * (eos::rho(L(p, 2), L(temp, 2), L(saln, 2)) - eos::rho(L(p, 2), L(temp, 1), L(saln, 1))) /
                     (L(dp, 1) + L(dp, 2));
@@ -53,70 +53,111 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqf(const DevView *__restrict__ Vp
   const double pbot = L(p, kk + 1);
   const double pml = fmax2(.5 * (L(p, 3) + L(p, 1)), .5 * (3. * L(p, 3) - L(p, kfpl + 1)));
   const double dml = pml - L(p, 1);
-  L(delp, kfpl - 1) = dml;
   L(bfsqi, kfpl - 1) = L(bfsqi, 2);
-  L(bfsq, kfpl - 1) = BFSQMN;
+  // One pass down the column does :117-199: the layer quantities delp, bfsq, sls2 of a level (the reference's work arrays)
+  // stay in registers for the two levels that still need them; the interface value of level k-1 is averaged into
+  // bfsql(k-1) and the forward elimination of the filter's tridiagonal system is done for level k-1 as soon as level
+  // k's delp is known.  Only gam goes through memory (to the back substitution).  COLUMN_U levels' loads in flight.
+  double delp_mm = 0., delp_m = dml, sls2_mm = 0., sls2_m, bfsq_m = BFSQMN, bi_m = b1;
   {
     const double q = fmax2(SLS0, dml * SLSMFQ);
-    L(sls2, kfpl - 1) = q * q;
+    sls2_m = q * q;
   }
   double pup = pml, tup = L(temp, 2), sup = L(saln, 2);
-  for (int k = kfpl; k <= kk; k++) {
-    const double pk = L(p, k);
-    if (pbot - pk < EPSILP) {
-      L(delp, k) = ONEMM;
-      L(bfsqi, k) = L(bfsqi, k - 1);
-      L(bfsq, k) = BFSQMN;
-      double q = exp_libm(-(pbot - pml) / (SLSELS * dml));
-      q = fmax2(SLS0, dml * SLSMFQ * q + SLS0 * (1. - q));
-      L(sls2, k) = q * q;
-    } else {
-      const double pk1 = L(p, k + 1);
-      const double plo = pbot - pk1 < EPSILP ? pbot : .5 * (pk + pk1);
-      const double tlo = L(temp, k), slo = L(saln, k);
-      const double dk = fmax2(ONEMM, plo - pup);
-      L(delp, k) = dk;
-      double bi = GRAV * GRAV * (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) / dk;
-      L(bfsq, k) = fmax2(BFSQMN, bi);
-      bi = bi * dk / fmax2(ONEM, dk);
-      if (pbot - pk < ONEM) bi = L(bfsqi, k - 1);
+  double pk = L(p, kfpl);
+  double ctd = 0., btd, bei = 0., fprev = 0., bi_kfpl = 0., bl_kfpl = 0.;
+  for (int k0 = kfpl; k0 <= kk; k0 += COLUMN_U) {
+    double a0[COLUMN_U], a1[COLUMN_U], a2[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int kq = k0 + u <= kk ? k0 + u : kk;
+      a0[u] = L(p, kq + 1); a1[u] = L(temp, kq); a2[u] = L(saln, kq);
+    }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 + u;
+      if (k > kk) break;
+      const double pk1 = a0[u];
+      double delp_k, bfsq_k, sls2_k, bi;
+      if (pbot - pk < EPSILP) {
+        delp_k = ONEMM;
+        bi = bi_m;
+        bfsq_k = BFSQMN;
+        double q = exp_libm(-(pbot - pml) / (SLSELS * dml));
+        q = fmax2(SLS0, dml * SLSMFQ * q + SLS0 * (1. - q));
+        sls2_k = q * q;
+      } else {
+        const double plo = pbot - pk1 < EPSILP ? pbot : .5 * (pk + pk1);
+        const double tlo = a1[u], slo = a2[u];
+        const double dk = fmax2(ONEMM, plo - pup);
+        delp_k = dk;
+        bi = GRAV * GRAV * (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) / dk;
+        bfsq_k = fmax2(BFSQMN, bi);
+        bi = bi * dk / fmax2(ONEM, dk);
+        if (pbot - pk < ONEM) bi = bi_m;
+        double q = exp_libm(-(pk - pml) / (SLSELS * dml));
+        q = fmax2(SLS0, dml * SLSMFQ * q + SLS0 * (1. - q));
+        sls2_k = q * q;
+        pup = plo; tup = tlo; sup = slo;
+      }
       L(bfsqi, k) = bi;
-      double q = exp_libm(-(pk - pml) / (SLSELS * dml));
-      q = fmax2(SLS0, dml * SLSMFQ * q + SLS0 * (1. - q));
-      L(sls2, k) = q * q;
-      pup = plo; tup = tlo; sup = slo;
+      if (k == kfpl) {
+        bi_kfpl = bi;
+        // first row of the tridiagonal system, level kfpl-1, :170-183
+        ctd = -2. * sls2_m / (delp_m * (delp_m + delp_k));
+        btd = 1. - ctd;
+        bei = 1. / btd;
+        fprev = bfsq_m * bei;
+        L(bfsqf, k - 1) = fprev;
+      } else {
+        const double bl = .5 * (bi_m + bi);                                                       // :157-159
+        L(bfsql, k - 1) = bl;
+        if (k == kfpl + 1) bl_kfpl = bl;
+        // forward elimination of level k-1, :184-196
+        const double atd = -2. * sls2_mm / (delp_m * (delp_mm + delp_m));
+        const double g = ctd * bei;                  // ctd of level k-2
+        L(gam, k - 1) = g;
+        ctd = -2. * sls2_m / (delp_m * (delp_m + delp_k));
+        btd = 1. - atd - ctd;
+        bei = 1. / (btd - atd * g);
+        fprev = (bfsq_m - atd * fprev) * bei;
+        L(bfsqf, k - 1) = fprev;
+      }
+      delp_mm = delp_m; delp_m = delp_k; sls2_mm = sls2_m; sls2_m = sls2_k; bfsq_m = bfsq_k; bi_m = bi;
+      pk = pk1;
     }
   }
-  for (int k = kfpl; k <= kk - 1; k++) L(bfsql, k) = .5 * (L(bfsqi, k) + L(bfsqi, k + 1));      // :157-165
-  L(bfsql, kk) = L(bfsqi, kk);
-  for (int k = 3; k <= kfpl - 1; k++) { L(bfsqi, k) = L(bfsqi, kfpl); L(bfsql, k) = L(bfsql, kfpl); }
-  // tridiagonal system of the implicit vertical filter, :170-199; coefficients formed where they are used
-  int k = kfpl - 1;
-  double ctd = -2. * L(sls2, k) / (L(delp, k) * (L(delp, k) + L(delp, k + 1)));
-  double btd = 1. - ctd;
-  double bei = 1. / btd;
-  double fprev = L(bfsq, k) * bei;
-  L(bfsqf, k) = fprev;
-  for (k = kfpl; k <= kk; k++) {
-    const double atd = -2. * L(sls2, k - 1) / (L(delp, k) * (L(delp, k - 1) + L(delp, k)));
-    const double g = ctd * bei;                    // ctd of level k-1
-    L(gam, k) = g;
-    if (k <= kk - 1) {
-      ctd = -2. * L(sls2, k) / (L(delp, k) * (L(delp, k) + L(delp, k + 1)));
-      btd = 1. - atd - ctd;
-    } else
-      btd = 1. - atd;
+  L(bfsql, kk) = bi_m;                                                                            // :160
+  if (kfpl == kk) bl_kfpl = bi_m;
+  for (int k = 3; k <= kfpl - 1; k++) { L(bfsqi, k) = bi_kfpl; L(bfsql, k) = bl_kfpl; }            // :161-165
+  {                                                                                               // level kk, :184-196
+    const double atd = -2. * sls2_mm / (delp_m * (delp_mm + delp_m));
+    const double g = ctd * bei;
+    L(gam, kk) = g;
+    btd = 1. - atd;
     bei = 1. / (btd - atd * g);
-    fprev = (L(bfsq, k) - atd * fprev) * bei;
-    L(bfsqf, k) = fprev;
+    fprev = (bfsq_m - atd * fprev) * bei;
+    L(bfsqf, kk) = fprev;
   }
-  for (k = kk - 1; k >= kfpl - 1; k--) {
-    fprev = L(bfsqf, k) - L(gam, k + 1) * fprev;
-    L(bfsqf, k) = fprev;
+  const double f_kk = fprev;
+  for (int k0 = kk - 1; k0 >= kfpl - 1; k0 -= COLUMN_U) {                                          // :197-199
+    double a0[COLUMN_U], a1[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int kq = k0 - u >= kfpl - 1 ? k0 - u : kfpl - 1;
+      a0[u] = L(bfsqf, kq); a1[u] = L(gam, kq + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 - u;
+      if (k < kfpl - 1) break;
+      fprev = a0[u] - a1[u] * fprev;
+      L(bfsqf, k) = fprev;
+    }
   }
-  for (k = 1; k <= kfpl - 2; k++) L(bfsqf, k) = fprev;                     // = bfsqf(kfpl-1)
-  L(bfsqi, kk + 1) = L(bfsqi, kk);
-  L(bfsqf, kk + 1) = L(bfsqf, kk);
+  for (int k = 1; k <= kfpl - 2; k++) L(bfsqf, k) = fprev;                 // = bfsqf(kfpl-1)
+  L(bfsqi, kk + 1) = bi_m;
+  L(bfsqf, kk + 1) = f_kk;
 #undef L
 }
 
