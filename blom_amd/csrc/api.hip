@@ -227,6 +227,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
   if (s == "remap_v") { c->remap_v = v; return 0; }
+  if (s == "pbcor_v") { c->pbcor_v = v; return 0; }
   if (s == "momtum_chunk") { c->momtum_chunk = v; return 0; }
   if (s == "live_slopes") { c->live_slopes = v; return 0; }
   if (s == "momtum_v") { c->momtum_v = v; return 0; }

@@ -217,6 +217,7 @@ struct blomgpu_ctx {
   int diapfl_v = 3;          // 3: col2 with DU levels' loads in flight (stage_diapfl_col3.hip), 2: traffic-lean column kernel
                              // (stage_diapfl_col2.hip), 1: first version
   int remap_v = 2;           // 2: gradient + flux sweep of remap in one LDS-tiled kernel (stage_remap_tile.hip), 1: separate kernels
+  int pbcor_v = 2;           // 2: fluxes + update of pbcor in one LDS-tiled kernel (stage_pbcor_tile.hip), 1: separate kernels
   int diapfl_du = 8;         // levels whose loads k_diapfl_column3 keeps in flight (2, 4, 8)
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   double *arc_strip = nullptr;                 // arctic patch, tiles of one process in strips mode: this tile's strip
@@ -277,6 +278,7 @@ int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);  
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn);            // stage_remap_tile.hip
+int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf);   // stage_pbcor_tile.hip
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);

@@ -230,9 +230,13 @@ static int pbcor(blomgpu_ctx *c, int which, int m, int n, int mm, int nn, int k1
   TimeScope ts(c, which == 1 ? "pbcor1" : "pbcor2");
   hipLaunchKernelGGL(k_pbc_pscan, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, offc);
   hipLaunchKernelGGL(k_pbc_total, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, n, offf);
-  hipLaunchKernelGGL(k_pbc_flux, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, which, offc, offf);
-  hipLaunchKernelGGL(k_pbc_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, which, offc);
-  hipLaunchKernelGGL(k_pbc_rescale, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, offc);
+  if (c->pbcor_v == 2) {
+    if (int rc = pbcor_tile_launch(c, which, m, offc, offf)) return rc;
+  } else {
+    hipLaunchKernelGGL(k_pbc_flux, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, which, offc, offf);
+    hipLaunchKernelGGL(k_pbc_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, which, offc);
+    hipLaunchKernelGGL(k_pbc_rescale, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, offc);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
