@@ -1,9 +1,11 @@
 """Turn rocprofv3 outputs under gpurun_out/ into the per-round summaries committed under profiles/.
-usage: [NTR=3] prof_summarize.py <tag> <kernel_stats.csv> <nsteps_total> [<fetch_counter.csv> <write_counter.csv>]"""
+usage: [NTR=3] prof_summarize.py <tag> <kernel_stats.csv> <nsteps_total | 0: count them> [<fetch_counter.csv> <write_counter.csv>]"""
 import csv, os, sys, collections
 ntr = int(os.environ.get("NTR", "3"))
 tag, stats, nst = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rows = list(csv.DictReader(open(stats)))
+if nst <= 0:                                   # one k_init_fluxes launch per baroclinic step
+    nst = next(int(r["Calls"]) for r in rows if r["Name"].startswith("k_init_fluxes"))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"profiles/{tag}_kernel_stats.txt", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (channel 208x512x53, ntr = {ntr}, 1 GPU)\n")
