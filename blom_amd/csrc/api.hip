@@ -508,7 +508,9 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
       if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
     }
     c->defer_checks = false;
-    if (int rc = ctx_check_errors(c)) return rc;
+    // the stages' error words are sticky: one read-back (a host synchronisation) per 8 steps and at the end of the call
+    if (it == nsteps - 1 || (it & 7) == 7)
+      if (int rc = ctx_check_errors(c)) return rc;
     const double delt2 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300
     if (c->h.P.delt1 != delt2) { c->h.P.delt1 = delt2; c->dirty = true; }   // changes after the first step only
     *nstep = ns + 1;

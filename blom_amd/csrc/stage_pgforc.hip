@@ -111,36 +111,66 @@ __global__ void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn) {
   const double *pz = isv ? V.f[F_pv] : V.f[F_pu];
   const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
   double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  // The layers kp, km of the two scalar columns that hold the pressure of the velocity point's layer centre move
+  // upwards with k, usually by one.  What the level needs of layer kp -- p above and below, T, S, phi, phi' -- is kept
+  // in registers together with the same record of layer kp-1, re-loaded in the background when kp moves; the fixed-index
+  // loads of level k-1 are issued while level k is worked on.  Without this every level waits for three to four
+  // dependent memory round trips (0.34 ms per call for 3500 wavefronts).
+  struct Rec { double pu, pl, t, s, ph, php; };
+  auto load_rec = [&](size_t col, int kq) {
+    const int kc = kq < 1 ? 1 : kq;
+    Rec r;
+    r.pu = p[col + (size_t)(kc - 1) * np]; r.pl = p[col + (size_t)kc * np];
+    r.t = temp[col + (size_t)(kc - 1) * np]; r.s = saln[col + (size_t)(kc - 1) * np];
+    r.ph = phi[col + (size_t)kc * np]; r.php = phip[col + (size_t)kc * np];
+    return r;
+  };
   int kp = kk, km = kk;                  // kup/kum (1-based layer indices as in the reference)
+  Rec rp = load_rec(c, kp), rp1 = load_rec(c, kp - 1), rm = load_rec(mns, km), rm1 = load_rec(mns, km - 1);
   double xip = 0., xim = 0., pgfm = 0.;
+  double dpk_n = dpz[c + (size_t)(kk - 1) * np], pz_n = pz[c + (size_t)kk * np];
+  double pck = p[c + (size_t)kk * np], pmk = p[mns + (size_t)kk * np];
+  double pck1_n = p[c + (size_t)(kk - 1) * np], pmk1_n = p[mns + (size_t)(kk - 1) * np];
   for (int k = kk; k >= 1; k--) {
-    const double dpk = dpz[c + (size_t)(k - 1) * np];
-    const double prs = pz[c + (size_t)k * np] - .5 * dpk;
-    while (p[c + (size_t)(kp - 1) * np] > prs) kp--;
-    while (p[mns + (size_t)(km - 1) * np] > prs) km--;
+    const double dpk = dpk_n, pzk = pz_n, pck1 = pck1_n, pmk1 = pmk1_n;
+    if (k > 1) {                                             // level k-1's fixed-index loads
+      dpk_n = dpz[c + (size_t)(k - 2) * np]; pz_n = pz[c + (size_t)(k - 1) * np];
+      pck1_n = p[c + (size_t)(k - 2) * np]; pmk1_n = p[mns + (size_t)(k - 2) * np];
+    }
+    const double prs = pzk - .5 * dpk;
+    while (rp.pu > prs) { kp--; rp = rp1; rp1 = load_rec(c, kp - 1); }
+    while (rm.pu > prs) { km--; rm = rm1; rm1 = load_rec(mns, km - 1); }
     double dphip, alpup, alplp, dphim, alpum, alplm;
-    const double pplo = p[c + (size_t)kp * np], pmlo = p[mns + (size_t)km * np];
-    eos::delphi(prs, pplo, temp[c + (size_t)(kp - 1) * np], saln[c + (size_t)(kp - 1) * np], dphip, alpup, alplp);
-    eos::delphi(prs, pmlo, temp[mns + (size_t)(km - 1) * np], saln[mns + (size_t)(km - 1) * np], dphim, alpum, alplm);
-    double cp = .25 * (p[c + (size_t)k * np] + p[c + (size_t)(k - 1) * np]);
-    double cm = .25 * (p[mns + (size_t)k * np] + p[mns + (size_t)(k - 1) * np]);
+    const double pplo = rp.pl, pmlo = rm.pl;
+    eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
+    eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    double cp = .25 * (pck + pck1);
+    double cm = .25 * (pmk + pmk1);
     const double q = prs / (cp + cm);
     cp = q * cp;
     cm = q * cm;
-    const double phi_p = phi[c + (size_t)kp * np] - dphip;
-    xip = xip + (phip[c + (size_t)kp * np] + pplo * alplp - cp * (alpup - alpum)) * dpk;
-    const double phi_m = phi[mns + (size_t)km * np] - dphim;
-    xim = xim + (phip[mns + (size_t)km * np] + pmlo * alplm - cm * (alpum - alpup)) * dpk;
+    const double phi_p = rp.ph - dphip;
+    xip = xip + (rp.php + pplo * alplp - cp * (alpup - alpum)) * dpk;
+    const double phi_m = rm.ph - dphim;
+    xim = xim + (rm.php + pmlo * alplm - cm * (alpum - alpup)) * dpk;
     const double g = -(phi_p - phi_m);
     pgf[c + (size_t)(k - 1) * np] = g;
     pgfm = pgfm + g * dpk;
+    pck = pck1; pmk = pmk1;
   }
   // :543-589
   const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
   pgfm = pgfm * q;
   xip = xip * q;
   xim = xim * q;
-  for (int k = 0; k < kk; k++) pgf[c + (size_t)k * np] = pgf[c + (size_t)k * np] - pgfm;
+  for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
+    double a0[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) a0[u] = pgf[c + (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++)
+      if (k0 + u < kk) pgf[c + (size_t)(k0 + u) * np] = a0[u] - pgfm;
+  }
   const size_t on = (size_t)(n - 1) * np;
   (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
   (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
