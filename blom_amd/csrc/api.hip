@@ -12,8 +12,14 @@ int ctx_fail(blomgpu_ctx *c, const std::string &msg) {
   return 1;
 }
 
+void ctx_drop_graphs(blomgpu_ctx *c) {
+  for (auto &g : c->step_graph)
+    if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
+
 void ctx_sync_view(blomgpu_ctx *c) {
   if (!c->dirty) return;
+  ctx_drop_graphs(c);
   (void)hipMemcpyAsync(c->d, &c->h, sizeof(DevView), hipMemcpyHostToDevice, c->stream);
   c->dirty = false;
 }
@@ -164,6 +170,7 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  ctx_drop_graphs(c);
   for (int f = 0; f < NF_REAL; f++) (void)hipFree(c->h.f[f]);
   for (int f = 0; f < NF_INT; f++) (void)hipFree(c->h.m[f]);
   (void)hipFree(c->h.wk);
@@ -188,6 +195,7 @@ int blomgpu_sync(blomgpu_ctx *c) {
 }
 
 int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
+  if (c) ctx_drop_graphs(c);
   Params &P = c->h.P;
   std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
@@ -209,6 +217,7 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
 }
 
 int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
+  if (c) ctx_drop_graphs(c);
   Params &P = c->h.P;
   std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
@@ -224,6 +233,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "barotp_arctic_fused") { c->barotp_arctic_fused = v; return 0; }
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
+  if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
   if (s == "remap_v") { c->remap_v = v; return 0; }
@@ -240,6 +250,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
 }
 
 int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
+  if (c) ctx_drop_graphs(c);
   Params &P = c->h.P;
   std::string s(name), v(val);
   c->dirty = true;
@@ -330,6 +341,7 @@ int blomgpu_download(blomgpu_ctx *c, const char *name, void *host, int nlev) {
 }
 
 int blomgpu_set_masks(blomgpu_ctx *c, const int *ip, const int *iu, const int *iv, const int *iq) {
+  if (c) ctx_drop_graphs(c);
   return blomgpu_upload(c, "ip", ip, 1) || blomgpu_upload(c, "iu", iu, 1) ||
          blomgpu_upload(c, "iv", iv, 1) || blomgpu_upload(c, "iq", iq, 1);
 }
@@ -491,6 +503,24 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
 }
 
 // Stage sequence of one baroclinic step, phy/mod_blom_step.F90:89-253 (hot path only).
+static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
+                              "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
+                              "barotp", "pbcor2", "tmsmt2"};
+  c->defer_checks = true;
+  for (const char *st : seq) {
+    // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
+    const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
+    if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
+  }
+  c->defer_checks = false;
+  return 0;
+}
+
+// A step is ~100 kernel launches, and on the smaller grids most of them are shorter than the time it takes to launch
+// them.  The sequence depends on the step only through the parity of the time levels, so it is captured from the stream
+// once per parity (after two plain steps: work buffers are allocated on first use) and replayed as a HIP graph.
+// Single tile only (the RCCL transport and the in-process tile groups synchronise on the host); not while stage timers run.
 int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
   const int kk = c->h.kk;
   for (int it = 0; it < nsteps; it++) {
@@ -498,16 +528,27 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     const int m = ns % 2 + 1, n = (ns + 1) % 2 + 1;
     const int mm = (m - 1) * kk, nn = (n - 1) * kk, k1m = 1 + mm, k1n = 1 + nn;
     c->h.P.nstep = ns + 1;                             // read by host code only: no upload of the view for it
-    static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
-                                "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
-                                "barotp", "pbcor2", "tmsmt2"};
-    c->defer_checks = true;
-    for (const char *st : seq) {
-      // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
-      const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
-      if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
+    ctx_sync_view(c);
+    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_done >= 4;
+    hipGraphExec_t &ge = c->step_graph[ns & 1];
+    if (graph && !ge && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      c->use_graph = 0;                                // no stream capture here: plain launches from now on
+      graph = false;
     }
-    c->defer_checks = false;
+    if (graph && !ge) {
+      hipGraph_t g = nullptr;
+      const int rc = step_sequence(c, m, n, mm, nn, k1m, k1n);
+      const hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess || !g) return ctx_fail(c, std::string("blomgpu_step: stream capture failed: ") + hipGetErrorString(e));
+      const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ei != hipSuccess) { ge = nullptr; return ctx_fail(c, std::string("blomgpu_step: hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+    }
+    if (graph) HIPCHK(c, hipGraphLaunch(ge, c->stream));
+    else if (int rc = step_sequence(c, m, n, mm, nn, k1m, k1n)) return rc;
+    c->steps_done++;
     // the stages' error words are sticky: one read-back (a host synchronisation) per 8 steps and at the end of the call
     if (it == nsteps - 1 || (it & 7) == 7)
       if (int rc = ctx_check_errors(c)) return rc;

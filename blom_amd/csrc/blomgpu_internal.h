@@ -201,6 +201,12 @@ struct blomgpu_ctx {
   // blomgpu_step defers the read-back to the end of the step (one host sync per step instead of three)
   int *err_dev = nullptr;
   bool defer_checks = false;
+  // blomgpu_step replays the stage sequence of a step as a HIP graph (one per parity of the time levels), captured from
+  // the stream once the lazily allocated buffers exist; any option / parameter / mask change drops the graphs
+  int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default
+  hipGraphExec_t step_graph[2] = {nullptr, nullptr};
+  int steps_done = 0;
+  bool bt_restart = true;        // the next persistent barotp launch zeroes the completion counts and starts at epoch 0
   unsigned bt_epoch = 0;          // completion count every tile has reached after the launches so far
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel
   int num_cus = 0;
@@ -233,6 +239,7 @@ struct blomgpu_ctx {
 int  ctx_fail(blomgpu_ctx *c, const std::string &msg);
 int  ctx_pack_masks(blomgpu_ctx *c);     // mpack = ip | iu << 1 | iv << 2 | iq << 3, after any upload of a mask
 void ctx_sync_view(blomgpu_ctx *c);      // uploads h -> d if dirty
+void ctx_drop_graphs(blomgpu_ctx *c);    // forget the captured step graphs (an option, parameter or mask changed)
 #define HIPCHK(c, call)                                                                   \
   do {                                                                                    \
     hipError_t e_ = (call);                                                               \

@@ -336,6 +336,7 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
 
   if (h.nreg == 2) hipLaunchKernelGGL(k_bt_arctic_swap, g, b, 0, c->stream, c->d, n);       // :290-325
   if (int rc = ctx_err_words(c)) return rc;
+  c->bt_restart = true;
   int lll0 = 1, ml = 1, nl = 2, set = 0;     // set: which buffer set (*_t / *_t2) holds the current state
   double woa = 0., wob = 0., wna = 0., wnb = 0.;
   for (int nb = 1; nb <= 5; nb++) {

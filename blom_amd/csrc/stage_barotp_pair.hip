@@ -541,10 +541,13 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
   int niter = 0;
   for (int lll = lll0; lll <= last; niter++) lll += (lll % 2 == 1 && lll + 1 <= last) ? 2 : 1;
-  if (!c->bt_flags || c->bt_epoch > 0xf0000000u) {        // (re)start the completion counters
+  // the completion counters start at 0 with the first launch of every barotp call (st_barotp sets bt_restart): the
+  // launches of a step then carry the same epochs every step, which lets blomgpu_step replay them as a graph
+  if (!c->bt_flags || c->bt_restart) {
     if (!c->bt_flags) HIPCHK(c, hipMalloc((void **)&c->bt_flags, sizeof(unsigned) * (nbx * nby + 16)));
     HIPCHK(c, hipMemsetAsync(c->bt_flags, 0, sizeof(unsigned) * (nbx * nby + 16), c->stream));
     c->bt_epoch = 0;
+    c->bt_restart = false;
   }
   PairArgs a;
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;

@@ -44,14 +44,26 @@ __global__ void k_eddtra_gm(const DevView *__restrict__ Vp, int n, int mm, int n
   const double *p = V.f[F_p], *dp = V.f[F_dp] + (size_t)nn * np, *difint = V.f[F_difint];
   const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
 #define AT(a, x, k) (a)[(x) + (size_t)((k)-1) * np]
-#define MFL(k) WK(V, sb + G_MFL)[c + (size_t)((k)-1) * np]
-#define DLM(k) WK(V, sb + G_DLM)[c + (size_t)((k)-1) * np]
-#define DLP(k) WK(V, sb + G_DLP)[c + (size_t)((k)-1) * np]
+  // the column's private arrays mfl(kk+1), dlm, dlp, wavefront-major: level k of the 64 columns of a wavefront in three
+  // consecutive rows of 64 doubles (one piece of memory per level instead of three that lie a field apart)
+  double *const wb = V.wk + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * 3) * 64 + threadIdx.x;
+  (void)sb;
+#define MFL(k) wb[((size_t)((k)-1) * 3 + 0) * 64]
+#define DLM(k) wb[((size_t)((k)-1) * 3 + 1) * 64]
+#define DLP(k) wb[((size_t)((k)-1) * 3 + 2) * 64]
+#define GU 8       /* levels whose loads a sweep keeps in flight */
+#define CLK(k, lo, hi) ((k) < (lo) ? (lo) : ((k) > (hi) ? (hi) : (k)))
   for (int k = 1; k <= kk; k++) AT(mf, xb, k) = 0.;                                   // :300-303
   const double et2mf = -GRAV * RHO0 * delt1 * (isv ? V.f[F_scvx] : V.f[F_scuy])[c];   // :306
   int kmax = 1;                                                                       // :310-314
-  for (int k = 3; k <= kk; k++)
-    if (AT(dp, xa, k) > EPSILP || AT(dp, xb, k) > EPSILP) kmax = k;
+  for (int k0 = 3; k0 <= kk; k0 += GU) {
+    double a0[GU], a1[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) { const int kq = CLK(k0 + u, 3, kk); a0[u] = AT(dp, xa, kq); a1[u] = AT(dp, xb, kq); }
+#pragma unroll
+    for (int u = 0; u < GU; u++)
+      if (k0 + u <= kk && (a0[u] > EPSILP || a1[u] > EPSILP)) kmax = k0 + u;
+  }
   const int kfa = V.m[I_kfpla][xa + (size_t)(n - 1) * np], kfb = V.m[I_kfpla][xb + (size_t)(n - 1) * np];
   const double scp2a = V.f[F_scp2][xa], scp2b = V.f[F_scp2][xb];
   const double pb = (isv ? V.f[F_pbv] : V.f[F_pbu])[c + (size_t)(n - 1) * np];
@@ -109,19 +121,45 @@ __global__ void k_eddtra_gm(const DevView *__restrict__ Vp, int n, int mm, int n
     MFL(kmin) = 0.;
     // (with kfpla < 3, which valid states never hold, the copy above lands on upsilon(3) itself)
     MFL(kintr) = et2mf * (shift && kintr + 1 == 3 ? ups_k1 : ups3);
-    if (shift) {
-      MFL(kintr + 1) = et2mf * ups_k1;
-      for (int k = kintr + 2; k <= kmax; k++) MFL(k) = et2mf * ups(k);
-    } else
-      for (int k = kintr + 1; k <= kmax; k++) MFL(k) = et2mf * ups(k);
+    int kf = kintr + 1;
+    if (shift) { MFL(kintr + 1) = et2mf * ups_k1; kf = kintr + 2; }
+    if (kf <= kmax) {
+      // mfl(k) = et2mf * upsilon(k), k = kf..kmax: the difint values of level k-1 are carried over from level k
+      double da = AT(difint, xa, kf - 1), db = AT(difint, xb, kf - 1);
+      for (int k0 = kf; k0 <= kmax; k0 += GU) {
+        double a0[GU], a1[GU], a2[GU];
+#pragma unroll
+        for (int u = 0; u < GU; u++) { const int kq = CLK(k0 + u, kf, kmax); a0[u] = AT(difint, xa, kq); a1[u] = AT(difint, xb, kq); a2[u] = AT(nslp, xb, kq); }
+#pragma unroll
+        for (int u = 0; u < GU; u++) {
+          const int k = k0 + u;
+          if (k > kmax) break;
+          const double kappa = .25 * (da + db + a0[u] + a1[u]);
+          MFL(k) = et2mf * (-kappa * a2[u]);
+          da = a0[u]; db = a1[u];
+        }
+      }
+    }
     MFL(kmax + 1) = 0.;
   }
   // layer thicknesses available for depletion, :493-502
   DLM(kmin) = fmax2(0., fmin2(pa3, pb) - fmax2(AT(p, xa, 1), pt));
   DLP(kmin) = fmax2(0., fmin2(pb3, pb) - fmax2(AT(p, xb, 1), pt));
-  for (int k = kintr; k <= kmax; k++) {
-    DLM(k) = fmax2(0., fmin2(AT(p, xa, k + 1), pb) - fmax2(AT(p, xa, k), pt));
-    DLP(k) = fmax2(0., fmin2(AT(p, xb, k + 1), pb) - fmax2(AT(p, xb, k), pt));
+  {
+    double pa_k = AT(p, xa, kintr <= kk ? kintr : kk), pb_k = AT(p, xb, kintr <= kk ? kintr : kk);
+    for (int k0 = kintr; k0 <= kmax; k0 += GU) {
+      double a0[GU], a1[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) { const int kq = CLK(k0 + u, kintr, kmax); a0[u] = AT(p, xa, kq + 1); a1[u] = AT(p, xb, kq + 1); }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int k = k0 + u;
+        if (k > kmax) break;
+        DLM(k) = fmax2(0., fmin2(a0[u], pb) - fmax2(pa_k, pt));
+        DLP(k) = fmax2(0., fmin2(a1[u], pb) - fmax2(pb_k, pt));
+        pa_k = a0[u]; pb_k = a1[u];
+      }
+    }
   }
   {                                                                                   // :507-524
     const double fhi = fface * fmax2(0., fmin2((pa3 - pt) * scp2a, (pb - AT(p, xb, kintr)) * scp2b));
@@ -144,34 +182,51 @@ __global__ void k_eddtra_gm(const DevView *__restrict__ Vp, int n, int mm, int n
     if (niter == 1000) { atomicOr(errflag, 1); return; }
     changed = false;
     kdir = -kdir;
-    const int k0 = ((1 - kdir) * kmax + (1 + kdir) * kmin) / 2, k1 = ((1 - kdir) * kmin + (1 + kdir) * kmax) / 2;
-    for (int k = k0; kdir > 0 ? k <= k1 : k >= k1; k += kdir) {
-      double lo = MFL(k), hi = MFL(k + 1);
-      if (fabs(hi - lo) > eps * fmax2(EPSILP * s2, fabs(hi + lo))) {
-        const double dm = DLM(k), dq = DLP(k);
-        if (hi - lo > ffac * fmax2(EPSILP, dm) * scp2a) {
-          const double q = fface * dm * scp2a;
-          if (hi > -lo) {
-            if (lo > -.5 * q) hi = lo + q;
-            else { hi = .5 * q; lo = -hi; }
-          } else {
-            if (hi < .5 * q) lo = hi - q;
-            else { lo = -.5 * q; hi = -lo; }
+    // A sweep walks the interfaces pairwise; the value a step leaves in the interface it shares with the next step
+    // travels in a register (`carry`), the far interface and the two thicknesses of GU steps are loaded ahead: no
+    // step of the sweep writes what a later step's look-ahead reads.
+    const bool up = kdir > 0;
+    double carry = up ? MFL(kmin) : MFL(kmax + 1);
+    for (int s0 = 0; s0 <= kmax - kmin; s0 += GU) {
+      double a0[GU], a1[GU], a2[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int st = s0 + u <= kmax - kmin ? s0 + u : kmax - kmin;
+        const int kq = up ? kmin + st : kmax - st;
+        a0[u] = up ? MFL(kq + 1) : MFL(kq); a1[u] = DLM(kq); a2[u] = DLP(kq);
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        if (s0 + u > kmax - kmin) break;
+        const int k = up ? kmin + s0 + u : kmax - s0 - u;
+        double lo = up ? carry : a0[u], hi = up ? a0[u] : carry;
+        if (fabs(hi - lo) > eps * fmax2(EPSILP * s2, fabs(hi + lo))) {
+          const double dm = a1[u], dq = a2[u];
+          if (hi - lo > ffac * fmax2(EPSILP, dm) * scp2a) {
+            const double q = fface * dm * scp2a;
+            if (hi > -lo) {
+              if (lo > -.5 * q) hi = lo + q;
+              else { hi = .5 * q; lo = -hi; }
+            } else {
+              if (hi < .5 * q) lo = hi - q;
+              else { lo = -.5 * q; hi = -lo; }
+            }
+            MFL(k) = lo; MFL(k + 1) = hi;
+            changed = true;
+          } else if (hi - lo < -ffac * fmax2(EPSILP, dq) * scp2b) {
+            const double q = fface * dq * scp2b;
+            if (hi < -lo) {
+              if (lo < .5 * q) hi = lo - q;
+              else { hi = -.5 * q; lo = -hi; }
+            } else {
+              if (hi > -.5 * q) lo = hi + q;
+              else { lo = .5 * q; hi = -lo; }
+            }
+            MFL(k) = lo; MFL(k + 1) = hi;
+            changed = true;
           }
-          MFL(k) = lo; MFL(k + 1) = hi;
-          changed = true;
-        } else if (hi - lo < -ffac * fmax2(EPSILP, dq) * scp2b) {
-          const double q = fface * dq * scp2b;
-          if (hi < -lo) {
-            if (lo < .5 * q) hi = lo - q;
-            else { hi = -.5 * q; lo = -hi; }
-          } else {
-            if (hi > -.5 * q) lo = hi + q;
-            else { lo = .5 * q; hi = -lo; }
-          }
-          MFL(k) = lo; MFL(k + 1) = hi;
-          changed = true;
         }
+        carry = up ? hi : lo;
       }
     }
   }
@@ -186,12 +241,24 @@ __global__ void k_eddtra_gm(const DevView *__restrict__ Vp, int n, int mm, int n
       AT(mf, xb, 2) = f2 - f1;
     }
   }
-  for (int k = kintr; k <= kmax; k++) {
-    const double lo = MFL(k), hi = MFL(k + 1);
-    double f = 0.;
-    if (fabs(hi - lo) > eps * fmax2(EPSILP * s2, fabs(hi + lo))) f = hi - lo;
-    AT(mf, xb, k) = f;
-    if (f > ffac * fmax2(EPSILP, DLM(k)) * scp2a || f < -ffac * fmax2(EPSILP, DLP(k)) * scp2b) atomicOr(errflag, 2);
+  {
+    double lo = MFL(kintr);
+    for (int k0 = kintr; k0 <= kmax; k0 += GU) {
+      double a0[GU], a1[GU], a2[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) { const int kq = CLK(k0 + u, kintr, kmax); a0[u] = MFL(kq + 1); a1[u] = DLM(kq); a2[u] = DLP(kq); }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int k = k0 + u;
+        if (k > kmax) break;
+        const double hi = a0[u];
+        double f = 0.;
+        if (fabs(hi - lo) > eps * fmax2(EPSILP * s2, fabs(hi + lo))) f = hi - lo;
+        AT(mf, xb, k) = f;
+        if (f > ffac * fmax2(EPSILP, a1[u]) * scp2a || f < -ffac * fmax2(EPSILP, a2[u]) * scp2b) atomicOr(errflag, 2);
+        lo = hi;
+      }
+    }
   }
 }
 

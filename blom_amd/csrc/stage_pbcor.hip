@@ -80,7 +80,14 @@ __global__ void k_pbc_total(const DevView *__restrict__ Vp, int which, int m, in
     double t = dlt * bfx[c];
     if (V.P.bmcmth == 1) WK2(V, S2_PBUT)[c] = fmin2(pbot[c], pbot[c - 1]);
     const double *uflx = V.f[F_uflx] + (size_t)offf * np;
-    for (int k = 0; k < V.kk; k++) t = t - uflx[c + (size_t)k * np];
+    for (int k0 = 0; k0 < V.kk; k0 += COLUMN_U) {                // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+      double a0[COLUMN_U];
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++) a0[u] = uflx[c + (size_t)(k0 + u < V.kk ? k0 + u : V.kk - 1) * np];
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++)
+        if (k0 + u < V.kk) t = t - a0[u];
+    }
     (which == 1 ? V.f[F_utotm] : V.f[F_utotn])[c] = t;
   }
   if (j >= 1 && j <= V.jj + 1 && i >= 1 && i <= V.ii && V.m[I_iv][c]) {
@@ -88,7 +95,14 @@ __global__ void k_pbc_total(const DevView *__restrict__ Vp, int which, int m, in
     double t = dlt * bfx[c];
     if (V.P.bmcmth == 1) WK2(V, S2_PBVT)[c] = fmin2(pbot[c], pbot[c - V.ni]);
     const double *vflx = V.f[F_vflx] + (size_t)offf * np;
-    for (int k = 0; k < V.kk; k++) t = t - vflx[c + (size_t)k * np];
+    for (int k0 = 0; k0 < V.kk; k0 += COLUMN_U) {
+      double a0[COLUMN_U];
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++) a0[u] = vflx[c + (size_t)(k0 + u < V.kk ? k0 + u : V.kk - 1) * np];
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++)
+        if (k0 + u < V.kk) t = t - a0[u];
+    }
     (which == 1 ? V.f[F_vtotm] : V.f[F_vtotn])[c] = t;
   }
 }

@@ -98,6 +98,13 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *
 // graphs: capture is not emulated; the library checks hostemu and steps eagerly
 typedef struct hostemu_graph *hipGraph_t;
 typedef struct hostemu_graphexec *hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorUnknown; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorUnknown; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorUnknown; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorUnknown; }
 
 // ---- device functions ---------------------------------------------------------------------------------
 inline long long wall_clock64() { return 0; }
