@@ -390,7 +390,8 @@ int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         // RCCL tiles along i: the received strips stay in the transport's buffers and the kernel loads its
         // E/W rim from there (c->barotp_rimbuf), saving the unpack launch of every exchange
         const bool rimbuf = c->tiling.rccl && c->barotp_rimbuf && c->tiling.npy == 1 && !ovl && h.nreg != 2;
-        if ((arctic1 ? odd : c->tiling.multi()) && !halo_done) {
+        // (single tile with the arctic patch: the pair kernel applies xctilr's seam rule while loading, before odd substeps)
+        if ((arctic1 ? odd && c->tiling.multi() : c->tiling.multi()) && !halo_done) {
           if (rimbuf) { if (int rc = bt_pair_halo_landed(c, set, &landed)) return rc; }
           else if (int rc = bt_pair_halo(c, set)) return rc;
         }

@@ -90,19 +90,35 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
   const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
   // source of the state planes: the point itself, or -- single tile, halo point -- what xctilr
   // would have put there (phy/mod_xc.F90:4374-4419): wrapped interior point or vland
-  size_t cs = c;
+  // With the arctic patch (nreg = 2, single tile) the rule is xctilr's for the tripolar seam (k_xctilr_arctic, halo.hip;
+  // phy/mod_xc.F90:4277-4371): rows jj.. mirror the rows below the seam about the pole, the source and, for the two
+  // vector fields, the sign depend on the grid the field lives on (pb_t: p, ubflx_t: u, vbflx_t: v), and the seam row jj
+  // itself is a target on the p- and u-grid and in its second half on the v-grid.
+  size_t cs = c, cs_u = c, cs_v = c;
+  double sg_u = 1., sg_v = 1.;
   bool land = false;
   if (a.fold_halo && inarr) {
     const bool oi = gi < 1 || gi > ii, oj = gj < 1 || gj > jj;
-    if (oi || oj) {
+    if (V.nreg == 2) {
+      const int iw = gi < 1 ? gi + ii : (gi > ii ? gi - ii : gi);
+      if (gj < 1) land = true;
+      else if (gj >= jj) {
+        const int d = gj - jj;
+        cs = (size_t)IDX(V, ii - (iw - 1) % ii, jj - 1 - d);
+        cs_u = (size_t)IDX(V, (ii - (iw - 1)) % ii + 1, jj - 1 - d);
+        sg_u = -1.;
+        if (d > 0 || iw > ii / 2) { cs_v = (size_t)IDX(V, ii - (iw - 1) % ii, jj - d); sg_v = -1.; }
+        else cs_v = (size_t)IDX(V, iw, gj);
+      } else if (oi) cs = cs_u = cs_v = (size_t)IDX(V, iw, gj);
+    } else if (oi || oj) {
       land = (oi && (V.nreg == 0 || V.nreg == 4)) || (oj && V.nreg <= 2);
       const int is = gi < 1 ? gi + ii : (gi > ii ? gi - ii : gi), js = gj < 1 ? gj + jj : (gj > jj ? gj - jj : gj);
-      cs = (size_t)IDX(V, is, js);
+      cs = cs_u = cs_v = (size_t)IDX(V, is, js);
     }
   }
   if (!PERSIST && a.rim_on && !a.fold_halo && inarr && gi >= 1 && gi <= ii && (gj < 1 || gj > jj)) {
     land = V.nreg <= 2;                                   // one tile row: closed in j, or the tile's own periodic wrap
-    cs = (size_t)IDX(V, gi, gj < 1 ? gj + jj : gj - jj);
+    cs = cs_u = cs_v = (size_t)IDX(V, gi, gj < 1 ? gj + jj : gj - jj);
   }
   const bool ok_src = inarr && !land;
   const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
@@ -133,8 +149,8 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
 #pragma unroll
     for (int l = 0; l < 2; l++) {
       s_pb[l][lj][li] = ok_src ? g_pb[cs + l * np] : (inarr ? V.P.vland : 0.);
-      s_ub[l][lj][li] = ok_src ? g_ub[cs + l * np] : (inarr ? V.P.vland : 0.);
-      s_vb[l][lj][li] = ok_src ? g_vb[cs + l * np] : (inarr ? V.P.vland : 0.);
+      s_ub[l][lj][li] = ok_src ? sg_u * g_ub[cs_u + l * np] : (inarr ? V.P.vland : 0.);
+      s_vb[l][lj][li] = ok_src ? sg_v * g_vb[cs_v + l * np] : (inarr ? V.P.vland : 0.);
     }
   };
   load_state(false);
@@ -462,7 +478,9 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   a.m = m; a.n = n; a.ml = ml; a.nl = nl;
   for (int x = 0; x < 2; x++) { a.wo[x] = wo[x]; a.wm[x] = wm[x]; a.wn[x] = wn[x]; }
   a.do_odd = do_odd; a.do_even = do_even; a.src = src;
-  a.fold_halo = (c->tiling.multi() || h.nreg == 2) ? 0 : 1;
+  // single tile: the halo rule is applied while loading; with the arctic patch only where the reference has its halo
+  // update, in front of an odd substep (a lone even substep reads the margins the launch before it published)
+  a.fold_halo = c->tiling.multi() ? 0 : (h.nreg == 2 ? (do_odd ? 1 : 0) : 1);
   a.write_margin = (h.nreg == 2 && (!c->tiling.multi() || c->barotp_arctic_fused)) ? 1 : 0;
   a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
   if (rim && rim->from_west) {
