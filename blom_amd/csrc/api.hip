@@ -234,6 +234,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
+  if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
   if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
   if (s == "remap_v") { c->remap_v = v; return 0; }
@@ -403,7 +404,7 @@ static int check_tracer_options(blomgpu_ctx *c) {
     return st_##nm(c, m, n, mm, nn, k1m, k1n);                                             \
   }
 STAGE6(init_fluxes) STAGE6(advect) STAGE6(pbcor1) STAGE6(pbcor2) STAGE6(diffus) STAGE6(pgforc)
-STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra) STAGE6(convec) STAGE6(updtrc) STAGE6(cmnfld2)
+STAGE6(momtum) STAGE6(barotp) STAGE6(eddtra) STAGE6(convec) STAGE6(updtrc) STAGE6(cmnfld2) STAGE6(cmnfld1)
 int blomgpu_tmsmt1(blomgpu_ctx *c, int nn) { ctx_sync_view(c); return st_tmsmt1(c, nn); }
 int blomgpu_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) { ctx_sync_view(c); return st_tmsmt2(c, m, mm, nn, k1m); }
 int blomgpu_initms(blomgpu_ctx *c, int mm) { ctx_sync_view(c); return st_initms(c, mm); }
@@ -497,6 +498,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "init_cppm") return blomgpu_init_cppm(c);
   if (s == "halo_cmnfld2") return blomgpu_halo_cmnfld2(c, n);
   if (s == "cmnfld2") return blomgpu_cmnfld2(c, m, n, mm, nn, k1m, k1n);
+  if (s == "cmnfld1") return blomgpu_cmnfld1(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
@@ -514,6 +516,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
     if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
   }
   c->defer_checks = false;
+  if (c->cmnfld1) return blomgpu_stage(c, "cmnfld1", m, n, mm, nn, k1m, k1n);     // phy/mod_blom_step.F90:233
   return 0;
 }
 

@@ -66,6 +66,8 @@
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
   X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K) X(nnslpx, K) X(nnslpy, K) X(bfsqi, K + 1) X(bfsql, K) X(bfsqf, K + 1)                                                                 \
+  /* mod_cmnfld: depth of the layer interfaces and layer thickness [m] (cmnfld1) */    \
+  X(z, K + 1) X(dz, K)                                                                   \
   /* mod_cppm: thickness edge values and the coefficient tables of init_cppm (mod_cppm.F90:79-89);     \
      the j-tables in (i,j) order (the reference's "_perm" layout, :2511-2518) */                        \
   X(hel_3d, K) X(her_3d, K) X(hevc1i, 1) X(hevc2i, 1) X(hevc3i, 1) X(hevc4i, 1) X(ssci, 1) X(scci, 1)    \
@@ -203,6 +205,7 @@ struct blomgpu_ctx {
   bool defer_checks = false;
   // blomgpu_step replays the stage sequence of a step as a HIP graph (one per parity of the time levels), captured from
   // the stream once the lazily allocated buffers exist; any option / parameter / mask change drops the graphs
+  int cmnfld1 = 0;               // blomgpu_step ends with cmnfld1 (z, dz of the new state; consumed by diagnostics and difest only)
   int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default
   hipGraphExec_t step_graph[2] = {nullptr, nullptr};
   int steps_done = 0;
@@ -281,6 +284,7 @@ int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);
 int ctx_err_words(blomgpu_ctx *);            // allocate err_dev on first use
 int ctx_check_errors(blomgpu_ctx *);         // read back all error words, fail with the reference's message
 int st_kfpla_halo(blomgpu_ctx *, int n);
+int st_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1090-1156
 int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);

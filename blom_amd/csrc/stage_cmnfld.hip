@@ -246,6 +246,48 @@ __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ V
 #undef O
 }
 
+// ---- cmnfld1 for isopyc_bulkml = cmnfld_z: depth of the layer interfaces, thickness of the layers, :885-921 ----------------
+// (the mixed-layer-depth estimates of :1110-1150 belong to the other vertical coordinates and to diagnostics)
+__global__ __launch_bounds__(64) void k_cmn_z(const DevView *__restrict__ Vp, int mm) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)mm * np, *saln = V.f[F_saln] + c + (size_t)mm * np;
+  const double *dp = V.f[F_dp] + c + (size_t)mm * np;
+  double *z = V.f[F_z] + c, *dz = V.f[F_dz] + c;
+  double zlo = -V.f[F_phi][c + (size_t)kk * np] / GRAV, plo = p[(size_t)kk * np];
+  z[(size_t)kk * np] = zlo;
+  for (int k0 = kk - 1; k0 >= 0; k0 -= COLUMN_U) {             // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+    double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const size_t o = (size_t)(k0 - u >= 0 ? k0 - u : 0) * np;
+      a[u] = p[o]; b[u] = dp[o]; d[u] = temp[o]; e[u] = saln[o];
+    }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) {
+      const int k = k0 - u;
+      if (k < 0) break;
+      const double zk = b[u] < EPSILP ? zlo : zlo + eos::p_alpha(plo, a[u], d[u], e[u]) / GRAV;
+      z[(size_t)k * np] = zk;
+      dz[(size_t)k * np] = zlo - zk;
+      zlo = zk; plo = a[u];
+    }
+  }
+}
+
+int st_cmnfld1(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.P.vcoord_tag != 1) return ctx_fail(c, "cmnfld1: only vcoord = 'isopyc_bulkml' is built");
+  TimeScope ts(c, "cmnfld");
+  hipLaunchKernelGGL(k_cmn_z, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, mm);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 // cmnfld2(m,n,mm,nn,k1m,k1n) for isopyc_bulkml; the slope part only with eitmth = 'gm' (:1208-1235; edritp is not carried)
 int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)mm; (void)k1m; (void)k1n;

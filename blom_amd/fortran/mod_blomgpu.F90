@@ -121,7 +121,8 @@ module mod_blomgpu
   public :: gpu_init, gpu_finalize, gpu_set, gpu_upload, gpu_upload_int, gpu_download, gpu_nlev, &
             gpu_halo, gpu_chksum, gpu_sync, gpu_xcsum, budget_sums, gpu_budget
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
-            diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail
+            diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail, &
+            cmnfld1, cmnfld2
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -324,6 +325,14 @@ contains
     integer, intent(in) :: n
     call stage6('halo_cmnfld2',0,n,0,0,0,0)
   end subroutine
+  subroutine cmnfld1(m,n,mm,nn,k1m,k1n)         ! phy/mod_cmnfld_routines.F90:1090 (isopyc_bulkml: cmnfld_z)
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('cmnfld1',m,n,mm,nn,k1m,k1n)
+  end subroutine cmnfld1
+  subroutine cmnfld2(m,n,mm,nn,k1m,k1n)         ! phy/mod_cmnfld_routines.F90:1158 (halo updates, bfsqf, neutral slopes)
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('cmnfld2',m,n,mm,nn,k1m,k1n)
+  end subroutine cmnfld2
   subroutine halo_difest(nn)                   ! phy/mod_difest.F90:750-772
     integer, intent(in) :: nn
     call stage6('halo_difest',0,0,0,nn,0,0)

@@ -116,6 +116,9 @@ int  blomgpu_halo_cmnfld2(blomgpu_ctx *, int n);
 /* cmnfld2 for isopyc_bulkml (phy/mod_cmnfld_routines.F90:1158): the halo updates above plus, with eitmth = 'gm', the
  * filtered buoyancy frequency (:61-227) and the neutral slopes nslpx/nslpy, nnslpx/nnslpy (:423-652) eddtra consumes. */
 int  blomgpu_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+/* cmnfld1 for isopyc_bulkml (phy/mod_cmnfld_routines.F90:1090): cmnfld_z (:885-921), z and dz from phi, p, dp, temp, saln
+   of time level m; called after tmsmt2 (phy/mod_blom_step.F90:233).  PARITY UNPINNED (the module needs netCDF). */
+int  blomgpu_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
 

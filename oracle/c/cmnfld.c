@@ -195,3 +195,28 @@ int orc_cmnfld2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
       if (A2(S, iv, i, j)) nslope_column(S, i, j, i, j - 1, n, nn, S->nslpy, S->nnslpy, A2(S, scvyi, i, j));
   return 0;
 }
+
+/* cmnfld1 for vcoord = isopyc_bulkml without the mixed-layer-depth diagnostics: cmnfld_z, depth of the layer interfaces
+   and thickness of the layers, phy/mod_cmnfld_routines.F90:885-921 (called at :1106).  The depth of the sea floor is
+   minus its geopotential over g; going up, an interface lies p_alpha(p(k+1), p(k), T, S)/g above the one below it,
+   layers without mass have no thickness. */
+int orc_cmnfld1(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
+  const int ii = S->ii, jj = S->jj, kk = S->kk;
+  for (int j = 1; j <= jj; j++)
+    for (int i = 1; i <= ii; i++)
+      if (A2(S, ip, i, j)) A3(S, z, i, j, kk + 1) = -A3(S, phi, i, j, kk + 1) / GRAV;
+  for (int j = 1; j <= jj; j++)
+    for (int k = kk; k >= 1; k--) {
+      const int km = k + mm;
+      for (int i = 1; i <= ii; i++)
+        if (A2(S, ip, i, j)) {
+          if (A3(S, dp, i, j, km) < EPSILP) A3(S, z, i, j, k) = A3(S, z, i, j, k + 1);
+          else
+            A3(S, z, i, j, k) = A3(S, z, i, j, k + 1) +
+                                eos_p_alpha(A3(S, p, i, j, k + 1), A3(S, p, i, j, k), A3(S, temp, i, j, km), A3(S, saln, i, j, km)) / GRAV;
+          A3(S, dz, i, j, k) = A3(S, z, i, j, k + 1) - A3(S, z, i, j, k);
+        }
+    }
+  return 0;
+}

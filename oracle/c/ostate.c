@@ -96,6 +96,7 @@ int orc_stage(OState *S, const char *st, int m, int n, int mm, int nn, int k1m, 
   else if (!strcmp(st, "diapfl")) orc_diapfl(S, n, nn, k1n);
   else if (!strcmp(st, "eddtra")) return orc_eddtra(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "cmnfld2")) return orc_cmnfld2(S, m, n, mm, nn, k1m, k1n);
+  else if (!strcmp(st, "cmnfld1")) return orc_cmnfld1(S, m, n, mm, nn, k1m, k1n);
   else if (!strcmp(st, "mxlayr_tail")) orc_mxlayr_tail(S, nn, k1n);
   else if (!strcmp(st, "halo_cmnfld2")) {  /* phy/mod_cmnfld_routines.F90:1171-1196 */
     orc_xctilr(S, S->temp, 1, 2 * kk, 3, 3, 1);

@@ -49,7 +49,7 @@
   X(vflux2, 1) X(uflux3, 1) X(vflux3, 1) X(umax, 1) X(vmax, 1) X(util1, 1) X(util2, 1)    \
   X(util3, 1) X(util4, 1) X(taux, 1) X(tauy, 1) X(ustarb, 1)                              \
   X(trc, 2 * K * NT) X(trcold, K * NT) X(fpug, K) X(fplg, K) X(nslpx, K) X(nslpy, K)       \
-  X(nnslpx, K) X(nnslpy, K) X(bfsqi, K + 1) X(bfsql, K) X(bfsqf, K + 1)
+  X(nnslpx, K) X(nnslpy, K) X(bfsqi, K + 1) X(bfsql, K) X(bfsqf, K + 1) X(z, K + 1) X(dz, K)
 
 #define ORC_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1)
 
@@ -143,6 +143,7 @@ double orc_budget_get(const OState *S, int which, int ncall, int n);
 double orc_xcsum_field(OState *S, const char *name, int lev, int itype);
 void orc_diapfl(OState *S, int n, int nn, int k1n);
 int orc_eddtra(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);
+int orc_cmnfld1(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);  /* PARITY UNPINNED, see cmnfld.c */
 int orc_cmnfld2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n);  /* PARITY UNPINNED, see cmnfld.c */   /* PARITY UNPINNED, see eddtra.c */
 void orc_mxlayr_tail(OState *S, int nn, int k1n);
 #endif

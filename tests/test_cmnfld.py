@@ -129,3 +129,44 @@ def test_bfsq_from_its_definition():
 def test_slope_of_tilted_layers():
     case, be, masks = _setup()
     check_slope_of_tilted_layers(be, case, masks)
+
+
+def check_depths(be, case, masks):
+    """cmnfld1 (cmnfld_z, phy/mod_cmnfld_routines.F90:885-921) from the definitions: the sea floor lies at -phi/g; an
+    interface lies the hydrostatic thickness of the layer above the one below it -- alpha dp / g with the specific volume
+    at the layer's mean pressure, to the accuracy of that mid-point rule; layers without mass have no thickness; dz is the
+    difference of the interface depths."""
+    kk = case.kdm
+    m, n, mm, nn, k1m, k1n = step_indices(0, kk)
+    be.stage("cmnfld2", m, n, mm, nn, k1m, k1n)                 # phi of the columns (hydrostatic, checked above)
+    phi = be.get("phi")
+    dpm = be.get("dp")
+    dpm[mm:mm + kk] = dpm[nn:nn + kk]                           # cmnfld1 works on time level m: give it the same state
+    be.put("dp", dpm)
+    for nm in ("temp", "saln"):
+        a = be.get(nm)
+        a[mm:mm + kk] = a[nn:nn + kk]
+        be.put(nm, a)
+    be.stage("cmnfld1", m, n, mm, nn, k1m, k1n)
+    J, I = slice(4, 4 + case.jdm), slice(4, 4 + case.idm)
+    wet = masks["ip"][J, I] > 0
+    z, dz = be.get("z")[:, J, I], be.get("dz")[:, J, I]
+    p, dp = be.get("p")[:, J, I], be.get("dp")[mm:mm + kk, J, I]
+    T, S = be.get("temp")[mm:mm + kk, J, I], be.get("saln")[mm:mm + kk, J, I]
+    assert np.array_equal(z[kk][wet], (-phi[kk, J, I] / GRAV)[wet])
+    for k in range(kk):
+        assert np.array_equal(dz[k][wet], (z[k + 1] - z[k])[wet])
+        empty = wet & (dp[k] < 1e-12)
+        assert not np.any(dz[k][empty] != 0.0)
+        full = wet & (dp[k] > ONEM)
+        if not full.any():
+            continue
+        want = (p[k + 1] - p[k]) / rho(.5 * (p[k] + p[k + 1]), T[k], S[k]) / GRAV
+        assert np.all(np.abs(dz[k][full] - want[full]) <= 1e-5 * want[full]), k      # mid-point rule over layers up to 400 m thick
+    # the surface ends up where the geopotential of the surface puts it (same hydrostatic integral, other routine)
+    assert np.all(np.abs(z[0][wet] + phi[0, J, I][wet] / GRAV) <= 1e-9 * np.abs(z[kk][wet]) + 1e-9)
+
+
+def test_cmnfld1_depths_from_their_definition():
+    case, be, masks = _setup()
+    check_depths(be, case, masks)

@@ -8,6 +8,7 @@ import pytest
 from blom_amd.cases import make_case
 from blom_amd import hostinit
 from blom_amd.stepper import dyncore_step, DYNCORE_STAGES
+from blom_amd.hostinit import step_indices
 from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, INT_FIELDS
 
 pytestmark = pytest.mark.gpu
@@ -65,6 +66,37 @@ def test_construction_checks_on_the_device():
     case, be, masks = _setup(backend=BlomGpu)
     check_slope_of_tilted_layers(be, case, masks)
     be.close()
+    from test_cmnfld import check_depths
+    case, be, masks = _setup(backend=BlomGpu)
+    check_depths(be, case, masks)
+    be.close()
+
+
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s"])
+def test_cmnfld1_matches_restatement(cfg):
+    """cmnfld1 (z, dz) at the end of a step: the device bit for bit the C restatement, stage call and step option alike"""
+    from blom_amd.gpu import BlomGpu
+    from oracle.coracle import COracle
+    case = make_case(cfg, nslp0=0.0)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    orc = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(orc, case)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    gpu.set("live_slopes", 1)
+    gpu.set("cmnfld1", 1)
+    ns = 0
+    for _ in range(3):
+        six = step_indices(ns, case.kdm)
+        ns = dyncore_step(orc, ns, case.params["baclin"], stages=LIVE)
+        orc.stage("cmnfld1", *six)
+    assert gpu.step(0, 3) == 3
+    bad = diff_report(orc, gpu, fields=["z", "dz", "dp", "temp", "phi"])
+    J, I = slice(4, 4 + case.jdm), slice(4, 4 + case.idm)
+    assert np.abs(gpu.get("dz")[:, J, I]).max() > 1.0
+    gpu.close()
+    assert not bad, fmt_report(bad)
 
 
 def test_live_slopes_in_the_device_resident_step():
