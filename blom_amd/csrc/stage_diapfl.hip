@@ -382,6 +382,27 @@ enum { U_GTD = 0, U_NSLOT };
 
 // fluxes through the upper interface of position k (fpu(k)) and, same interface seen from above,
 // fpl(k-1): the average of the two neighbouring p-columns, clipped at the velocity-point bottom (:779-817)
+// the same from the six values it reads: p, fpug of level k and fplg of level k-1 at the two p-columns (m: mns, c)
+__device__ inline void diapfl_mom_flux_v(double pm, double fum, double flm, double pc, double fuc, double flc, double pzb,
+                                         double &fpu_k, double &fpl_km1) {
+  double fpum, fplm, fpup, fplp;
+  double pnew = pm, fu = fum, fl = flm;
+  double pold = pnew - fl + fu;
+  if (pold <= pzb) {
+    if (pnew <= pzb) { fpum = fu; fplm = fl; } else { fpum = fu; fplm = fl - pnew + pzb; }
+  } else {
+    if (pnew <= pzb) { fpum = fu - pold + pzb; fplm = fl; } else { fpum = .5 * (fu + fl); fplm = fpum; }
+  }
+  pnew = pc; fu = fuc; fl = flc;
+  pold = pnew - fl + fu;
+  if (pold <= pzb) {
+    if (pnew <= pzb) { fpup = fu; fplp = fl; } else { fpup = fu; fplp = fl - pnew + pzb; }
+  } else {
+    if (pnew <= pzb) { fpup = fu - pold + pzb; fplp = fl; } else { fpup = .5 * (fu + fl); fplp = fpup; }
+  }
+  fpu_k = .5 * (fpum + fpup);
+  fpl_km1 = .5 * (fplm + fplp);
+}
 __device__ inline void diapfl_mom_flux(const double *p, const double *fpug, const double *fplg, size_t mns, size_t c, size_t np,
                                        int k, double pzb, double &fpu_k, double &fpl_km1) {
   double fpum, fplm, fpup, fplp;
@@ -418,8 +439,15 @@ __global__ void k_diapfl_momentum(const DevView *__restrict__ Vp, int nn) {
 #define LV(a, k) (a)[c + (size_t)((k)-1) * np]
   const int kmin = min(V.m[I_kming][mns], V.m[I_kming][c]);
   int kmax = 1;
-  for (int k = 2; k <= kk; k++)
-    if (LV(dpz, k) > 0.) kmax = k;
+#define MU_ 4       /* levels whose loads a sweep keeps in flight */
+  for (int k0 = 2; k0 <= kk; k0 += 2 * MU_) {
+    double a0[2 * MU_];
+#pragma unroll
+    for (int u = 0; u < 2 * MU_; u++) a0[u] = LV(dpz, k0 + u <= kk ? k0 + u : kk);
+#pragma unroll
+    for (int u = 0; u < 2 * MU_; u++)
+      if (k0 + u <= kk && a0[u] > 0.) kmax = k0 + u;
+  }
   if (!(kmin < kmax)) return;
   const double pzb = (isv ? V.f[F_pv] : V.f[F_pu])[c + (size_t)kk * np];
   // forward elimination over positions kmin..kmax, :822-836; position -> layer: kmin -> 1, kmin+1 -> 2
@@ -427,31 +455,58 @@ __global__ void k_diapfl_momentum(const DevView *__restrict__ Vp, int nn) {
   double fu = 0., fl_prev_unused = 0.;                        // fpu(kmin) = 0
   (void)fl_prev_unused;
   double fu_next = 0., fl;
-  for (int k = kmin; k <= kmax; k++) {
+  for (int k0 = kmin; k0 <= kmax; k0 += MU_) {
+   double b0[MU_], b1[MU_], b2[MU_], b3[MU_], b4[MU_], b5[MU_], b6[MU_], b7[MU_];
+#pragma unroll
+   for (int u = 0; u < MU_; u++) {
+     const int kq = k0 + u <= kmax ? k0 + u : kmax, kn = kq + 1 <= kk ? kq + 1 : kk;
+     const int lq = kq == kmin ? 1 : (kq == kmin + 1 ? 2 : kq);
+     const size_t o = (size_t)(kn - 1) * np, om = (size_t)(kn - 2) * np;
+     b0[u] = p[mns + o]; b1[u] = fpug[mns + o]; b2[u] = fplg[mns + om];
+     b3[u] = p[c + o]; b4[u] = fpug[c + o]; b5[u] = fplg[c + om];
+     b6[u] = LV(dpz, lq); b7[u] = LV(vel, lq);
+   }
+#pragma unroll
+   for (int u = 0; u < MU_; u++) {
+    const int k = k0 + u;
+    if (k > kmax) break;
     const int lay = k == kmin ? 1 : (k == kmin + 1 ? 2 : k);
-    if (k < kmax) diapfl_mom_flux(p, fpug, fplg, mns, c, np, k + 1, pzb, fu_next, fl);    // fpu(k+1), fpl(k)
+    if (k < kmax) diapfl_mom_flux_v(b0[u], b1[u], b2[u], b3[u], b4[u], b5[u], pzb, fu_next, fl);    // fpu(k+1), fpl(k)
     else fl = 0.;                                                                         // fpl(kmax) = 0
     g = ctd * bitd;
     AR(sb + U_GTD, k) = g;
-    const double dk = LV(dpz, lay);
+    const double dk = b6[u];
     const double q = 1. / (dk + fu + fl);
     const double atd = -fu * q;
     ctd = -fl * q;
     const double dtd = dk * q;
     bitd = 1. / (1. - atd * g);
-    const double uk = LV(vel, lay);
+    const double uk = b7[u];
     // km1 = max(k-1, kmin): at k = kmin the reference reads uc(kmin) itself, i.e. the unmodified value
     uprev = (dtd * uk - atd * (k == kmin ? uk : uprev)) * bitd;
     LV(vel, lay) = uprev;
     fu = fu_next;
+   }
   }
   // back substitution, :838
   double unext = uprev, gnext = g;
-  for (int k = kmax - 1; k >= kmin; k--) {
-    const int lay = k == kmin ? 1 : (k == kmin + 1 ? 2 : k);
-    unext = LV(vel, lay) - gnext * unext;
-    LV(vel, lay) = unext;
-    gnext = AR(sb + U_GTD, k);
+  for (int k0 = kmax - 1; k0 >= kmin; k0 -= 2 * MU_) {
+    double b0[2 * MU_], b1[2 * MU_];
+#pragma unroll
+    for (int u = 0; u < 2 * MU_; u++) {
+      const int kq = k0 - u >= kmin ? k0 - u : kmin;
+      const int lq = kq == kmin ? 1 : (kq == kmin + 1 ? 2 : kq);
+      b0[u] = LV(vel, lq); b1[u] = AR(sb + U_GTD, kq);
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * MU_; u++) {
+      const int k = k0 - u;
+      if (k < kmin) break;
+      const int lay = k == kmin ? 1 : (k == kmin + 1 ? 2 : k);
+      unext = b0[u] - gnext * unext;
+      LV(vel, lay) = unext;
+      gnext = b1[u];
+    }
   }
   const double ub = uprev;                                    // uc(kmax): untouched by the back substitution
   for (int k = kmax + 1; k <= kk; k++)
