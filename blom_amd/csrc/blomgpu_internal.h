@@ -205,6 +205,8 @@ struct blomgpu_ctx {
   bool defer_checks = false;
   // blomgpu_step replays the stage sequence of a step as a HIP graph (one per parity of the time levels), captured from
   // the stream once the lazily allocated buffers exist; any option / parameter / mask change drops the graphs
+  int halo_overlap = 0;          // RCCL tiles: the halo exchange in front of remap runs on xstream while the inner tiles compute
+                                 // (bit-identical; in self-send on one GPU 9.78 against 9.59 ms per step: off by default)
   int cmnfld1 = 0;               // blomgpu_step ends with cmnfld1 (z, dz of the new state; consumed by diagnostics and difest only)
   int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default
   hipGraphExec_t step_graph[2] = {nullptr, nullptr};
@@ -288,7 +290,7 @@ int st_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);  
 int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
-int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn);            // stage_remap_tile.hip
+int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn, int tsel);  // stage_remap_tile.hip; tsel 0 all tiles, 1 those that read no halo point, 2 the others
 int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf);   // stage_pbcor_tile.hip
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field

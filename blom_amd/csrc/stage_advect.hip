@@ -399,22 +399,36 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     return 0;
   }
   hipLaunchKernelGGL(k_adv_pbmin, plane_grid(h), dim3(256), 0, c->stream, c->d);
-  {                                                                                   // mod_advect:124-131
-    double *ptrs[2 + MAXTR] = {h.f[F_cau], h.f[F_cav]};
-    int nl[2 + MAXTR] = {h.kk, h.kk}, it[2 + MAXTR] = {13, 14};
-    int nf = 2;
-    for (int nt = 0; nt < h.ntr; nt++) {
-      if (trc_skip_adv(h.P, nt + 1)) continue;                                        // :127-129
-      ptrs[nf] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
-      nl[nf] = h.kk;
-      it[nf++] = 1;
-    }
-    if (int rc = st_xctilr_multi(c, nf, ptrs, nl, 3, 3, it)) return rc;
+  double *ptrs[2 + MAXTR] = {h.f[F_cau], h.f[F_cav]};                                 // mod_advect:124-131
+  int nl[2 + MAXTR] = {h.kk, h.kk}, it[2 + MAXTR] = {13, 14};
+  int nf = 2;
+  for (int nt = 0; nt < h.ntr; nt++) {
+    if (trc_skip_adv(h.P, nt + 1)) continue;                                          // :127-129
+    ptrs[nf] = h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np;
+    nl[nf] = h.kk;
+    it[nf++] = 1;
   }
-  {
+  // RCCL tiles: the exchange (pack, send/recv, unpack) goes to the second stream and the tiles of k_remap_tile whose
+  // rim lies inside the tile -- they read no halo point of cau, cav or the tracers -- run meanwhile; the tiles along the
+  // edge follow when the halos have landed.  The exchange reads interior strips and writes halo points only.
+  const bool ovl = c->tiling.rccl && c->xstream && c->halo_overlap && c->remap_v == 2 && h.nreg != 2 && !c->timing;
+  if (ovl) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
+    c->halo_stream = c->xstream;
+    const int rc = st_xctilr_multi(c, nf, ptrs, nl, 3, 3, it);
+    c->halo_stream = nullptr;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->xstream));
+    if (int rc2 = remap_tile_launch(c, n, mm, nn, 1)) return rc2;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (int rc2 = remap_tile_launch(c, n, mm, nn, 2)) return rc2;
+    hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+  } else {
+    if (int rc = st_xctilr_multi(c, nf, ptrs, nl, 3, 3, it)) return rc;
     TimeScope ts(c, "remap");
     if (c->remap_v == 2) {
-      if (int rc = remap_tile_launch(c, n, mm, nn)) return rc;
+      if (int rc = remap_tile_launch(c, n, mm, nn, 0)) return rc;
     } else {
       hipLaunchKernelGGL(k_remap_grad, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
       hipLaunchKernelGGL(k_remap_flux, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, n, mm, nn);

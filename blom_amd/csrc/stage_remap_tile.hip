@@ -85,7 +85,7 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
       A.ftr[nt] = A.ftr[nt] + fd * g[G_TRD(nt) * RT_GN + x] + qx * g[G_TRX(nt) * RT_GN + x] + qy * g[G_TRY(nt) * RT_GN + x];
 }
 
-__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv, unsigned atr) {
+__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv, unsigned atr, int tsel) {
   const DevView &V = *Vp;
   HIP_DYNAMIC_SHARED(double, lds)
   unsigned bx_, by_;
@@ -94,6 +94,12 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   // not unless use_TKEADV, mod_remap.F90:314-316 and every tracer loop after it)
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
   const int x0 = (bx_ % ntx) * RT_TW, y0 = (bx_ / ntx) * RT_TH;        // first point of the tile in the padded plane
+  if (tsel) {
+    // tsel 1: only the tiles that read no halo point (their 2-point rim lies inside 1..ii x 1..jj) -- they can run
+    // while the halo exchange of cau, cav and the tracers is still under way; tsel 2: only the others
+    const bool inner = x0 - 2 >= NBDY && x0 + RT_TW + 1 <= V.ii + NBDY - 1 && y0 - 2 >= NBDY && y0 + RT_TH + 1 <= V.jj + NBDY - 1;
+    if (inner != (tsel == 1)) return;
+  }
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np;
   // LDS: [ scalars | ... ] then, from phase 2 on, [ gradient slots ] over the same space; cu, cv / corner velocities; masks
   double *const sc = lds;                                   // RT_NSC x RT_SN
@@ -366,7 +372,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     if (nt < nadv) WK(V, W_FTRU(ntr, (atr >> (8 * nt)) & 255u) + off)[fc + ok] = A.ftr[nt];
 }
 
-int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn) {
+int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
   const DevView &h = c->h;
   if (h.ntr > MAXTR) return ctx_fail(c, "remap: more tracers than MAXTR");
   const int ntx = (h.ni + RT_TW - 1) / RT_TW, nty = (h.nj + RT_TH - 1) / RT_TH;
@@ -377,6 +383,6 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn) {
   const size_t lds = sizeof(double) * (RT_NG(nadv) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
   static_assert(RT_NSC(MAXTR) * RT_SN <= RT_NG(MAXTR) * RT_GN, "the scalars must fit under the gradient slots");
 
-  hipLaunchKernelGGL(k_remap_tile, dim3(ntx * nty, h.kk), dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, atr);
+  hipLaunchKernelGGL(k_remap_tile, dim3(ntx * nty, h.kk), dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, atr, tsel);
   return 0;
 }
