@@ -174,3 +174,27 @@ def test_tracer_switch_that_is_not_built_fails_loudly():
     gpu.set("tkeadv", 1)
     assert gpu.step(0, 1) == 1
     gpu.close()
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("tri_s", 10), ("fuk95", 8)])
+def test_step_replayed_as_a_hip_graph_is_identical(cfg, nsteps):
+    """blomgpu_step captures the stage sequence of a step once per parity of the time levels (after four plain steps) and
+    replays it; the persistent barotp kernel's epochs restart with every barotp call so that the launches are the same
+    from step to step.  Same bits as plain launches."""
+    a = _run(cfg, nsteps, use_graph=0)
+    b = _run(cfg, nsteps, use_graph=1)
+    skip = {"util1", "util2", "util3", "util4"}
+    bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
+    assert not bad, bad
+
+
+def test_halo_exchange_overlapped_with_the_inner_tiles_of_remap():
+    """RCCL transport (one rank sending to itself): the exchange of cau, cav and the tracers in front of remap on the second
+    stream while k_remap_tile runs the tiles that read no halo point, the edge tiles afterwards (halo_overlap = 1): same
+    bits as the serial exchange and as the plain single tile.  chan_m is 80 x 40: 3 x 5 tiles of 32 x 8, three of them inner."""
+    skip = {"util1", "util2", "util3", "util4"}
+    a = _run("chan_m", 6)
+    for ovl in (0, 1):
+        b = _run_rccl_self("chan_m", 6, halo_overlap=ovl)
+        bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
+        assert not bad, (ovl, bad)
