@@ -198,3 +198,13 @@ def test_halo_exchange_overlapped_with_the_inner_tiles_of_remap():
         b = _run_rccl_self("chan_m", 6, halo_overlap=ovl)
         bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
         assert not bad, (ovl, bad)
+
+
+def test_variants_identical_on_tnx2v1s():
+    """the tripolar grid at tnx2v1's size (180 x 193 x 53, arctic patch, unequal wet areas): this round's kernels against
+    round 1's, and the pair kernel's seam rule at the tile load against the separate halo launches of the unfused path"""
+    keep = ("u", "v", "dp", "temp", "saln", "pb", "ub", "vb", "trc")
+    old = _run("tnx2v1s", 3, diapfl_v=1, barotp_fused=0, barotp_persist=0, momtum_v=1, remap_v=1, pbcor_v=1)
+    new = _run("tnx2v1s", 3)
+    for nm in keep:
+        assert np.array_equal(old[nm], new[nm], equal_nan=True), nm
