@@ -17,6 +17,8 @@
 #pragma once
 #include "hor3map_core.h"
 
+#define H3F_U 8
+
 struct H3Cell {
   double u, el, er;     // mean, left and right edge value
   bool lim;             // interior cell on which the limiter acts (always, or by the non-oscillatory switch)
@@ -94,8 +96,19 @@ H3HD void h3_reconstruct_ppm_fused(const H3Grid &g, const H3Src &s, int col) {
     double ue_prev = e_first, gam_prev = 0.0;
     double h1 = H3A(g.h, 1), u1 = H3A(s.u, 1);
     H3A(uedge, 1) = e_first;
-    for (int j = 2; j <= ns; ++j) {
-      const double h2 = H3A(g.h, j), u2 = H3A(s.u, j);
+    // H3F_U levels' loads are issued before the first is used (one dependent load per level is what bounds a
+    // thread-per-column walk); the arithmetic and its order are unchanged
+    for (int j0 = 2; j0 <= ns; j0 += H3F_U) {
+     double ah[H3F_U], au[H3F_U];
+     for (int w_ = 0; w_ < H3F_U; ++w_) {
+       const int jq = j0 + w_ <= ns ? j0 + w_ : ns;
+       ah[w_] = H3A(g.h, jq);
+       au[w_] = H3A(s.u, jq);
+     }
+     for (int w_ = 0; w_ < H3F_U; ++w_) {
+      const int j = j0 + w_;
+      if (j > ns) break;
+      const double h2 = ah[w_], u2 = au[w_];
       // edge_ih4_coeff(h(j-1:j)) (:642-646)
       const double q = 1.0 / (h1 + h2);
       const double t1 = h2 * h2 * q * q, t2 = h1 * h1 * q * q;
@@ -108,6 +121,7 @@ H3HD void h3_reconstruct_ppm_fused(const H3Grid &g, const H3Src &s, int col) {
       H3A(gam, j) = gam_prev;
       h1 = h2;
       u1 = u2;
+     }
     }
   }
 
@@ -133,7 +147,19 @@ H3HD void h3_reconstruct_ppm_fused(const H3Grid &g, const H3Src &s, int col) {
   double h_hi = 0.0, h_mid = H3A(g.h, ns), h_lo = H3A(g.h, ns - 1);        // h(j+1), h(j), h(j-1)
   double d2_hi = 0.0;                            // raw second derivative of cell j+1
   H3Cell hi{0.0, 0.0, 0.0, false};
-  for (int j = ns; j >= 1; --j) {
+  for (int j0 = ns; j0 >= 1; j0 -= H3F_U) {
+   // what the window takes in at level j: u, h and the edge system's row of level j-2
+   double bu[H3F_U], bh[H3F_U], be[H3F_U], bg[H3F_U];
+   for (int q = 0; q < H3F_U; ++q) {
+     const int jq = j0 - q - 2 >= 1 ? j0 - q - 2 : 1;
+     bu[q] = H3A(s.u, jq);
+     bh[q] = H3A(g.h, jq);
+     be[q] = H3A(uedge, jq);
+     bg[q] = H3A(gam, jq >= 2 ? jq : 2);
+   }
+   for (int q = 0; q < H3F_U; ++q) {
+    const int j = j0 - q;
+    if (j < 1) break;
     // raw parabola of cell j and of the cell below it
     H3Cell mid{u_mid, e_mid, e_hi, false};
     const double d2_mid = e_mid - 2.0 * u_mid + e_hi;
@@ -181,10 +207,11 @@ H3HD void h3_reconstruct_ppm_fused(const H3Grid &g, const H3Src &s, int col) {
     h_hi = h_mid; h_mid = h_lo;
     e_hi = e_mid; e_mid = e_lo;
     if (j >= 3) {
-      u_lo = H3A(s.u, j - 2);
-      h_lo = H3A(g.h, j - 2);
-      e_lo = edge(j - 2, e_mid);
+      u_lo = bu[q];
+      h_lo = bh[q];
+      e_lo = j - 2 >= 2 ? be[q] - bg[q] * e_mid : e_first;
     }
+   }
   }
   store(1, hi);
 }
