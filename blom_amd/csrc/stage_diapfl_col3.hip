@@ -45,9 +45,13 @@ enum { E_SU, E_SL, E_FCU, E_FCL, E_FMAX, E_H, E_R, E_T, E_F, E_FT, E_GTD, E_NSLO
 
 // one wavefront per 64 columns and ~1700 wavefronts in all: occupancy cannot exceed 2 waves per SIMD anyway,
 // so let the register allocator use up to 256 VGPRs instead of spilling at 128
+// DU: levels whose loads the light sweeps keep in flight; the two fused sweeps (stratification + limiter down, limiter
+// up + first guess) carry an equation-of-state evaluation resp. a square root and four divisions per level and are
+// unrolled DH = min(DU, 4) deep: 8 deep they need 255 VGPRs and spill 300 SGPRs
 template <int DU>
 __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restrict__ Vp, int n, int nn, int *__restrict__ errflag) {
   const DevView &V = *Vp;
+  constexpr int DH = DU < 4 ? DU : 4;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
   if (t_ >= V.nplane) return;
   const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
@@ -113,79 +117,92 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
                              (ALPHA0 * GRAV * (SIGR(k + 1) - SIGR(k)));
         ST(nu, k) = fmax2(ST(nu, k), nubbl);
       }
-      // ---- stratification and density-restoring fluxes, :217-287 ------------------------------
+      // ---- stratification and density-restoring fluxes, :217-287, and the flux limiter's first downward sweep, :292-305,
+      //      in ONE pass from the bottom up: the stratification of a level is a stencil over the levels k-1, k, k+1 (no
+      //      recurrence), so it can be evaluated in the order the limiter's downward sweep visits the levels, and the
+      //      limiter takes dsgu, dsgl, fcu, fcl of the level from registers instead of reading them back.
       const int rst1 = kfpl;
-      double tm = ST(temp, 2), sm = ST(saln, 2);                    // position kfpl-1 holds layer 2
-      double tk = ST(temp, kfpl), sk = ST(saln, kfpl);
-      double dens_m = ST(sigma, kfpl - 1), dens_k = ST(sigma, kfpl);
-      double sr_m = SIGR(kfpl - 1), sr_k = SIGR(kfpl);
       int rst2 = -1;
       if (kfpl != kmax)
-        if (dens_k > .5 * (sr_k + SIGR(kfpl + 1))) rst2 = kfpl + 1;
-      for (int k0 = kfpl; k0 <= kmax - 1; k0 += DU) {
-       double a0[DU], a1[DU], a2[DU], a3[DU], a4[DU], a5[DU];
-#pragma unroll
-       for (int u = 0; u < DU; u++) {
-         const int kq = CLAMPK(k0 + u, kfpl, kmax - 1);
-         a0[u] = ST(temp, kq + 1); a1[u] = ST(saln, kq + 1); a2[u] = ST(sigma, kq + 1); a3[u] = SIGR(kq + 1);
-         a4[u] = ST(dp, kq); a5[u] = ST(nu, kq);
-       }
-#pragma unroll
-       for (int u = 0; u < DU; u++) {
-        k = k0 + u;
-        if (k > kmax - 1) break;
-        const double tp = a0[u], sp = a1[u], dens_p = a2[u], sr_p = a3[u];
-        double su = 1., sl = 1., fcu = 0., fcl = 0.;
-        if (k != rst1 && k != rst2) {
-          const double dk = a4[u], nuk = a5[u];
-          const double dsgdt = eosd::dsigdt(P, tk, sk), dsgds = eosd::dsigds(P, tk, sk);
-          su = fmax2(dsgmnr * (sr_k - sr_m), dsgdt * (tk - tm) + dsgds * (sk - sm));
-          sl = fmax2(dsgmnr * (sr_p - sr_k), dsgdt * (tp - tk) + dsgds * (sp - sk));
-          const double shm = 2. * su * sl / (su + sl);
-          const double sg = .5 * (su + sl);
-          const double sui = 1. / su, sli = 1. / sl;
-          const double fcmx = .25 * (sqrt(dk * dk + 4. * cc * nuk * sg * (sui + sli)) - dk) * shm * fcmxr;
-          const double dsgc = dens_k - sr_k;
-          if (dsgc > 0.) {
-            if (dens_m < sr_k) {
-              double q = fmax2(0., (dens_k - sr_p) / ((sr_k - sr_p) * (1. - dsgcr0)));
-              q = fmax2(0., 1. - q * q);
-              q = q * q * q;
-              fcu = dsgc * dk;
-              fcu = fmin2(q * fcu + (1. - q) * fcmx, fcu);
-            }
-          } else {
-            if (dens_p > sr_k) {
-              double q = fmax2(0., (dens_k - sr_m) / ((sr_k - sr_m) * (1. - dsgcr0)));
-              q = fmax2(0., 1. - q * q);
-              q = q * q * q;
-              fcl = dsgc * dk;
-              fcl = fmax2(q * fcl - (1. - q) * fcmx, fcl);
-            }
-          }
-        }
-        W(E_SU, k) = su; W(E_SL, k) = sl; W(E_FCU, k) = fcu; W(E_FCL, k) = fcl;
-        tm = tk; sm = sk; tk = tp; sk = sp;
-        dens_m = dens_k; dens_k = dens_p; sr_m = sr_k; sr_k = sr_p;
-       }
-      }
-      // k = kmax, :275-287 (tk, sk, dens_k, sr_k now belong to kmax; *_m to position kmax-1)
+        if (ST(sigma, kfpl) > .5 * (SIGR(kfpl) + SIGR(kfpl + 1))) rst2 = kfpl + 1;
+      // position kfpl-1 holds layer 2: its T, S are layer 2's; its density and reference density stay those of kfpl-1
+#define TIX(kq) ((kq) == kfpl - 1 ? 2 : (kq))
+      double tp = ST(temp, kmax), sp = ST(saln, kmax), dens_p = ST(sigma, kmax), sr_p = SIGR(kmax);               // level k+1
+      double tk = ST(temp, TIX(kmax - 1)), sk = ST(saln, TIX(kmax - 1)), dens_k = ST(sigma, kmax - 1), sr_k = SIGR(kmax - 1);
+      // k = kmax, :275-287 (its own values are the sweep's first "level k+1", position kmax-1 its first "level k")
       double su_b, sui_b, fpu_b, fcu_b;
       {
-        const double dsgdt = eosd::dsigdt(P, tk, sk), dsgds = eosd::dsigds(P, tk, sk);
-        su_b = fmax2(dsgmnr * (sr_k - sr_m), dsgdt * (tk - tm) + dsgds * (sk - sm));
+        const double dsgdt = eosd::dsigdt(P, tp, sp), dsgds = eosd::dsigds(P, tp, sp);
+        su_b = fmax2(dsgmnr * (sr_p - sr_k), dsgdt * (tp - tk) + dsgds * (sp - sk));
         sui_b = 1. / su_b;
         const double dkm1 = kmax - 1 == kmin + 1 ? d2 : ST(dp, kmax - 1);
-        if (dens_k > sr_k && dens_m < sr_k) fpu_b = fmin2(dkm1, (dens_k - sr_k) * ST(dp, kmax) * sui_b);
+        if (dens_p > sr_p && dens_k < sr_p) fpu_b = fmin2(dkm1, (dens_p - sr_p) * ST(dp, kmax) * sui_b);
         else fpu_b = 0.;
         fcu_b = fpu_b * su_b;
       }
       // ---- flux limiter, :292-330 ------------------------------------------------------------
-      bool done = false;
+      bool done = false, first = true;
       int niter = 0, kfmaxu = 0;
+      double dflim = 0.;
       while (!done) {
         done = true;
         double fmax_p = 0., fcu_p = fcu_b, sui_p = sui_b;
+        if (first) {
+          first = false;
+          for (int k0 = kmax - 1; k0 >= kfpl; k0 -= DH) {
+            double a0[DH], a1[DH], a2[DH], a3[DH], a4[DH], a5[DH], a6[DH];
+#pragma unroll
+            for (int u = 0; u < DH; u++) {
+              const int kq = CLAMPK(k0 - u, kfpl, kmax - 1);
+              a0[u] = ST(temp, TIX(kq - 1)); a1[u] = ST(saln, TIX(kq - 1)); a2[u] = ST(sigma, kq - 1); a3[u] = SIGR(kq - 1);
+              a4[u] = ST(dp, kq); a5[u] = ST(nu, kq); a6[u] = PRES(kq + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < DH; u++) {
+              k = k0 - u;
+              if (k < kfpl) break;
+              const double tm = a0[u], sm = a1[u], dens_m = a2[u], sr_m = a3[u];
+              double su = 1., sl = 1., fcu = 0., fcl = 0.;
+              if (k != rst1 && k != rst2) {
+                const double dk = a4[u], nuk = a5[u];
+                const double dsgdt = eosd::dsigdt(P, tk, sk), dsgds = eosd::dsigds(P, tk, sk);
+                su = fmax2(dsgmnr * (sr_k - sr_m), dsgdt * (tk - tm) + dsgds * (sk - sm));
+                sl = fmax2(dsgmnr * (sr_p - sr_k), dsgdt * (tp - tk) + dsgds * (sp - sk));
+                const double shm = 2. * su * sl / (su + sl);
+                const double sg = .5 * (su + sl);
+                const double sui = 1. / su, sli = 1. / sl;
+                const double fcmx = .25 * (sqrt(dk * dk + 4. * cc * nuk * sg * (sui + sli)) - dk) * shm * fcmxr;
+                const double dsgc = dens_k - sr_k;
+                if (dsgc > 0.) {
+                  if (dens_m < sr_k) {
+                    double q = fmax2(0., (dens_k - sr_p) / ((sr_k - sr_p) * (1. - dsgcr0)));
+                    q = fmax2(0., 1. - q * q);
+                    q = q * q * q;
+                    fcu = dsgc * dk;
+                    fcu = fmin2(q * fcu + (1. - q) * fcmx, fcu);
+                  }
+                } else {
+                  if (dens_p > sr_k) {
+                    double q = fmax2(0., (dens_k - sr_m) / ((sr_k - sr_m) * (1. - dsgcr0)));
+                    q = fmax2(0., 1. - q * q);
+                    q = q * q * q;
+                    fcl = dsgc * dk;
+                    fcl = fmax2(q * fcl - (1. - q) * fcmx, fcl);
+                  }
+                }
+              }
+              // the limiter's step for this level, :296-304
+              const double q = ((fmax_p + fcu_p) * sui_p + presb - a6[u]) * sl;
+              fcl = fmax2(-q, fcl);
+              fmax_p = q + fcl;
+              W(E_SU, k) = su; W(E_SL, k) = sl; W(E_FCU, k) = fcu; W(E_FCL, k) = fcl; W(E_FMAX, k) = fmax_p;
+              fcu_p = fcu;
+              sui_p = 1. / su;
+              tp = tk; sp = sk; dens_p = dens_k; sr_p = sr_k;
+              tk = tm; sk = sm; dens_k = dens_m; sr_k = sr_m;
+            }
+          }
+        } else
         for (int k0 = kmax - 1; k0 >= kfpl; k0 -= DU) {
           double a0[DU], a1[DU], a2[DU], a3[DU], a4[DU];
 #pragma unroll
@@ -208,16 +225,37 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
           }
         }
         kfmaxu = 0;
+        // The upward sweep, :306-316, carries the first guess, :334-353, one level behind it: level k-1's guess needs
+        // fcu and dsgu of level k, final once the sweep has visited it, and otherwise what the sweep holds of level k-1
+        // in registers.  A sweep that has to be repeated (done = false) leaves guesses that the next one overwrites.
         double fmax_m = 0., fcl_m = -fpl1, sli_m = 1.;
-        for (int k0 = kfpl; k0 <= kmax - 1; k0 += DU) {
-          double a0[DU], a1[DU], a2[DU], a3[DU], a4[DU], a5[DU];
+        double g_fcl_m = -fpl1, g_sli_m = 1.;                     // the first guess's fcl, 1/dsgl of level k-2
+        double v_su = 1., v_sl = 1., v_fcu = 0., v_fm = 0., v_fcl = 0., v_nu = 0., v_dp = 0.;   // level k-1
+        dflim = 0.;
+#define DIAPFL_GUESS(kl, fcu_n, su_n)                                                                                     \
+        {                                                                                                                 \
+          const double su = v_su, sl = v_sl;                                                                              \
+          const double shm = 2. * su * sl / (su + sl);                                                                    \
+          const double sg = .5 * (su + sl);                                                                               \
+          const double sui = 1. / su, sli = 1. / sl;                                                                      \
+          const double fk = fmin2(fmin2(v_fm, .5 * sqrt(cc * v_nu * sg * (sui + sli)) * shm), cc * v_nu * sg / fmax2(EPSILP, v_dp)); \
+          W(E_F, kl) = fk;                                                                                                \
+          W(E_H, kl) = v_fcu * sui - v_fcl * sli + g_fcl_m * g_sli_m - (fcu_n) * (1. / (su_n));                          \
+          W(E_R, kl) = 4. * cc * v_nu * sg * (sui + sli);                                                                 \
+          W(E_T, kl) = .25 * shm;                                                                                         \
+          dflim = fmax2(dflim, v_fm);                                                                                     \
+          g_fcl_m = v_fcl; g_sli_m = sli;                                                                                 \
+        }
+        for (int k0 = kfpl; k0 <= kmax - 1; k0 += DH) {
+          double a0[DH], a1[DH], a2[DH], a3[DH], a4[DH], a5[DH], a6[DH], a7[DH];
 #pragma unroll
-          for (int u = 0; u < DU; u++) {
+          for (int u = 0; u < DH; u++) {
             const int kq = CLAMPK(k0 + u, kfpl, kmax - 1);
             a0[u] = PRES(kq); a1[u] = W(E_SU, kq); a2[u] = W(E_FCU, kq); a3[u] = W(E_FMAX, kq); a4[u] = W(E_FCL, kq); a5[u] = W(E_SL, kq);
+            a6[u] = ST(nu, kq); a7[u] = ST(dp, kq);
           }
 #pragma unroll
-          for (int u = 0; u < DU; u++) {
+          for (int u = 0; u < DH; u++) {
             k = k0 + u;
             if (k <= kmax - 1) {
               const double q = ((fmax_m - fcl_m) * sli_m + a0[u] - preskf) * a1[u];
@@ -228,47 +266,16 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
               fmax_m = fm;
               fcl_m = a4[u];
               sli_m = 1. / a5[u];
+              if (k > kfpl) DIAPFL_GUESS(k - 1, fcu, a1[u])
+              v_su = a1[u]; v_sl = a5[u]; v_fcu = fcu; v_fm = fm; v_fcl = a4[u]; v_nu = a6[u]; v_dp = a7[u];
             }
           }
         }
+        if (kfpl <= kmax - 1) DIAPFL_GUESS(kmax - 1, fcu_b, su_b)
+#undef DIAPFL_GUESS
         // the reference tests niter == 100 without ever incrementing niter in this loop (:317),
         // i.e. it never aborts here; we bound the loop defensively and flag it.
         if (++niter > 100000) { atomicOr(errflag, 1); break; }
-      }
-      // ---- first guess, :334-353 ---------------------------------------------------------------
-      double dflim = 0.;
-      {
-        double fcl_m = -fpl1, sli_m = 1.;
-        double fcu_k = kfpl <= kmax - 1 ? W(E_FCU, kfpl) : 0., su_k = kfpl <= kmax - 1 ? W(E_SU, kfpl) : 1.;
-        for (int k0 = kfpl; k0 <= kmax - 1; k0 += DU) {
-          double a0[DU], a1[DU], a2[DU], a3[DU], a4[DU], a5[DU], a6[DU];
-#pragma unroll
-          for (int u = 0; u < DU; u++) {
-            const int kq = CLAMPK(k0 + u, kfpl, kmax - 1), kn = CLAMPK(kq + 1, kfpl, kmax - 1);
-            a0[u] = W(E_FCU, kn); a1[u] = W(E_SU, kn); a2[u] = ST(nu, kq); a3[u] = W(E_SL, kq); a4[u] = W(E_FMAX, kq);
-            a5[u] = W(E_FCL, kq); a6[u] = ST(dp, kq);
-          }
-#pragma unroll
-          for (int u = 0; u < DU; u++) {
-            k = k0 + u;
-            if (k <= kmax - 1) {
-              const double fcu_n = k + 1 <= kmax - 1 ? a0[u] : fcu_b;
-              const double su_n = k + 1 <= kmax - 1 ? a1[u] : su_b;
-              const double nuk = a2[u], sl = a3[u], fmx = a4[u], fcl_k = a5[u];
-              const double su = su_k;
-              const double shm = 2. * su * sl / (su + sl);
-              const double sg = .5 * (su + sl);
-              const double sui = 1. / su, sli = 1. / sl;
-              const double fk = fmin2(fmin2(fmx, .5 * sqrt(cc * nuk * sg * (sui + sli)) * shm), cc * nuk * sg / fmax2(EPSILP, a6[u]));
-              W(E_F, k) = fk;
-              W(E_H, k) = fcu_k * sui - fcl_k * sli + fcl_m * sli_m - fcu_n * (1. / su_n);
-              W(E_R, k) = 4. * cc * nuk * sg * (sui + sli);
-              W(E_T, k) = .25 * shm;
-              dflim = fmax2(dflim, fmx);
-              fcl_m = fcl_k; sli_m = sli; fcu_k = fcu_n; su_k = su_n;
-            }
-          }
-        }
       }
       dflim = dflim * dfeps;
       // ---- implicit solve by alternating sweeps, :357-533 ------------------------------------
