@@ -224,15 +224,34 @@ __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ V
     O(nslp, 3) = s;
     if (A(phi, b_, 3) > phba && A(phi, a_, 3) > phbb) { O(nnslp, 3) = sqrt(bm) * s; knnsl = 3; }
   }
-  for (int k = kintr + 1; k <= kmax; k++) {                              // interior interfaces
-    const double pm = .5 * (A(p, a_, k) + A(p, b_, k));
-    const double rx = .5 * (eos::rho(pm, A(temp, b_, k - 1), A(saln, b_, k - 1)) - eos::rho(pm, A(temp, a_, k - 1), A(saln, a_, k - 1)) +
-                            eos::rho(pm, A(temp, b_, k), A(saln, b_, k)) - eos::rho(pm, A(temp, a_, k), A(saln, a_, k)));
-    const double px = A(phi, b_, k) - A(phi, a_, k);
-    const double bm = .5 * (A(bf, a_, k) + A(bf, b_, k));
-    const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
-    O(nslp, k) = s;
-    if (A(phi, b_, k) > phba && A(phi, a_, k) > phbb) { O(nnslp, k) = sqrt(bm) * s; knnsl = k; }
+  {                                                                      // interior interfaces
+    // 4 interfaces' loads in flight; T, S of the layer above an interface are the previous interface's layer below
+    const int kf = kintr + 1;
+    double tbm = kf <= kmax ? A(temp, b_, kf - 1) : 0., sbm = kf <= kmax ? A(saln, b_, kf - 1) : 0.;
+    double tam = kf <= kmax ? A(temp, a_, kf - 1) : 0., sam = kf <= kmax ? A(saln, a_, kf - 1) : 0.;
+    for (int k0 = kf; k0 <= kmax; k0 += 4) {
+      double pa[4], pb[4], tb[4], sb[4], ta[4], sa[4], fb[4], fa[4], ba[4], bb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int kq = k0 + u <= kmax ? k0 + u : kmax;
+        pa[u] = A(p, a_, kq); pb[u] = A(p, b_, kq);
+        tb[u] = A(temp, b_, kq); sb[u] = A(saln, b_, kq); ta[u] = A(temp, a_, kq); sa[u] = A(saln, a_, kq);
+        fb[u] = A(phi, b_, kq); fa[u] = A(phi, a_, kq); ba[u] = A(bf, a_, kq); bb[u] = A(bf, b_, kq);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u;
+        if (k > kmax) break;
+        const double pm = .5 * (pa[u] + pb[u]);
+        const double rx = .5 * (eos::rho(pm, tbm, sbm) - eos::rho(pm, tam, sam) + eos::rho(pm, tb[u], sb[u]) - eos::rho(pm, ta[u], sa[u]));
+        const double px = fb[u] - fa[u];
+        const double bm = .5 * (ba[u] + bb[u]);
+        const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
+        O(nslp, k) = s;
+        if (fb[u] > phba && fa[u] > phbb) { O(nnslp, k) = sqrt(bm) * s; knnsl = k; }
+        tbm = tb[u]; sbm = sb[u]; tam = ta[u]; sam = sa[u];
+      }
+    }
   }
   for (int k = knnsl + 1; k <= kmax; k++) O(nnslp, k) = O(nnslp, knnsl);
   if (kintr < kmax) {
