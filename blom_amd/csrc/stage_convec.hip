@@ -195,28 +195,55 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restric
   const double *p = V.f[F_p] - np;
   double *un = WK(V, CV_UN + (isv ? 1 : 0)) + c - np;
   const double pbot = po[(size_t)(kk + 1) * np];
+  // The old layer ko that holds the new interface moves down with kn, usually by one: its velocity and lower interface
+  // are kept in registers together with those of layer ko+1, re-loaded in the background when ko moves; the new
+  // interfaces' pressures of CV_U levels are loaded ahead (u is not written before the copy at the end).
+#define CV_U 8
   int ko = 1;
   double po_lo = 0., po_hi = po[(size_t)2 * np];                         // po(ko), po(ko+1)
+  double v_cur = vel[(size_t)1 * np], v_nxt = vel[(size_t)(kk >= 2 ? 2 : 1) * np];       // u(ko), u(ko+1)
+  double po_nx = kk >= 2 ? po[(size_t)3 * np] : 1.e300;                   // po(ko+2)
   double pn_lo = 0.;                                                     // pn(kn)
-  for (int kn = 1; kn <= kk; kn++) {
-    const double pn_hi = .5 * (fmin2(pbot, p[c + (size_t)(kn + 1) * np]) + fmin2(pbot, p[cm + (size_t)(kn + 1) * np]));
-    double r;
-    if (pn_hi - pn_lo == 0.) {
-      r = 0.;
-    } else {
-      double udpn = 0.;
-      while (pn_hi > po_hi) {
-        udpn = udpn + vel[(size_t)ko * np] * (po_hi - fmax2(po_lo, pn_lo));
-        ko = ko + 1;
-        po_lo = po_hi;
-        po_hi = ko <= kk ? po[(size_t)(ko + 1) * np] : 1.e300;   // (never reached: pn <= po(kk+1))
-      }
-      r = (udpn + vel[(size_t)ko * np] * (pn_hi - fmax2(po_lo, pn_lo))) / (pn_hi - pn_lo);
+  for (int k0 = 1; k0 <= kk; k0 += CV_U) {
+    double a0[CV_U], a1[CV_U];
+#pragma unroll
+    for (int u = 0; u < CV_U; u++) {
+      const int kq = k0 + u <= kk ? k0 + u : kk;
+      a0[u] = p[c + (size_t)(kq + 1) * np]; a1[u] = p[cm + (size_t)(kq + 1) * np];
     }
-    un[(size_t)kn * np] = r;
-    pn_lo = pn_hi;
+#pragma unroll
+    for (int u = 0; u < CV_U; u++) {
+      const int kn = k0 + u;
+      if (kn > kk) break;
+      const double pn_hi = .5 * (fmin2(pbot, a0[u]) + fmin2(pbot, a1[u]));
+      double r;
+      if (pn_hi - pn_lo == 0.) {
+        r = 0.;
+      } else {
+        double udpn = 0.;
+        while (pn_hi > po_hi) {
+          udpn = udpn + v_cur * (po_hi - fmax2(po_lo, pn_lo));
+          ko = ko + 1;
+          po_lo = po_hi;
+          po_hi = ko <= kk ? po_nx : 1.e300;   // (never reached: pn <= po(kk+1))
+          v_cur = v_nxt;
+          v_nxt = vel[(size_t)(ko + 1 <= kk ? ko + 1 : kk) * np];
+          po_nx = ko + 1 <= kk ? po[(size_t)(ko + 2) * np] : 1.e300;
+        }
+        r = (udpn + v_cur * (pn_hi - fmax2(po_lo, pn_lo))) / (pn_hi - pn_lo);
+      }
+      un[(size_t)kn * np] = r;
+      pn_lo = pn_hi;
+    }
   }
-  for (int k = 1; k <= kk; k++) vel[(size_t)k * np] = un[(size_t)k * np];
+  for (int k0 = 1; k0 <= kk; k0 += CV_U) {
+    double a0[CV_U];
+#pragma unroll
+    for (int u = 0; u < CV_U; u++) a0[u] = un[(size_t)(k0 + u <= kk ? k0 + u : kk) * np];
+#pragma unroll
+    for (int u = 0; u < CV_U; u++)
+      if (k0 + u <= kk) vel[(size_t)(k0 + u) * np] = a0[u];
+  }
 }
 
 // :393-414
