@@ -30,10 +30,13 @@ __global__ void k_bt_bounds(const DevView *__restrict__ Vp, int m, int nn) {
     const double pbu = V.f[F_pbu][om];
     V.f[F_uglue][c] = V.P.cwbdts * exp_libm(1. - pbu / (V.P.cwbdls * ONEM));
     double mx = 0., mn = 0.;
-    for (int k = 0; k < V.kk; k++) {
-      const double u = V.f[F_u][c + (size_t)(k + nn) * np];
-      mx = fmax2(mx, u);
-      mn = fmin2(mn, u);
+    for (int k0 = 0; k0 < V.kk; k0 += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+      double a0[COLUMN_U];
+#pragma unroll
+      for (int q = 0; q < COLUMN_U; q++) a0[q] = V.f[F_u][c + (size_t)((k0 + q < V.kk ? k0 + q : V.kk - 1) + nn) * np];
+#pragma unroll
+      for (int q = 0; q < COLUMN_U; q++)
+        if (k0 + q < V.kk) { mx = fmax2(mx, a0[q]); mn = fmin2(mn, a0[q]); }
     }
     V.f[F_umaxb][c] = (V.f[F_umax][c] - mx) * pbu * V.f[F_scuy][c];
     V.f[F_uminb][c] = (V.f[F_umax][c] + mn) * pbu * V.f[F_scuy][c];
@@ -42,10 +45,13 @@ __global__ void k_bt_bounds(const DevView *__restrict__ Vp, int m, int nn) {
     const double pbv = V.f[F_pbv][om];
     V.f[F_vglue][c] = V.P.cwbdts * exp_libm(1. - pbv / (V.P.cwbdls * ONEM));
     double mx = 0., mn = 0.;
-    for (int k = 0; k < V.kk; k++) {
-      const double v = V.f[F_v][c + (size_t)(k + nn) * np];
-      mx = fmax2(mx, v);
-      mn = fmin2(mn, v);
+    for (int k0 = 0; k0 < V.kk; k0 += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
+      double a0[COLUMN_U];
+#pragma unroll
+      for (int q = 0; q < COLUMN_U; q++) a0[q] = V.f[F_v][c + (size_t)((k0 + q < V.kk ? k0 + q : V.kk - 1) + nn) * np];
+#pragma unroll
+      for (int q = 0; q < COLUMN_U; q++)
+        if (k0 + q < V.kk) { mx = fmax2(mx, a0[q]); mn = fmin2(mn, a0[q]); }
     }
     V.f[F_vmaxb][c] = (V.f[F_vmax][c] - mx) * pbv * V.f[F_scvx][c];
     V.f[F_vminb][c] = (V.f[F_vmax][c] + mn) * pbv * V.f[F_scvx][c];
