@@ -412,7 +412,11 @@ def main():
                      "dominant_single_kernel": dominant_kernel(args.config)},
         "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
                           "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,
-                          "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1))},
+                          "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1)),
+                          # HBM bytes the PMC counters saw per step in the committed profile of this workload (all stage
+                          # classes), and the rate they correspond to at this run's step time
+                          "counted_traffic_bytes": sum(traffic.values()) if traffic else None,
+                          "counted_traffic_GBs": (sum(traffic.values()) / (ms_per_step * 1e-3) / 1e9) if traffic else None},
         "stages_ms": live,
     }
     if world > 1 and layout is None:
