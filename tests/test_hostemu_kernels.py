@@ -1,0 +1,71 @@
+"""This round's kernels on the CPU: the device library compiled for the host (tests/hostemu: every kernel runs thread by
+thread, one fiber per thread, workgroup barriers and LDS as on the device, dynamic LDS poisoned with NaN) stepped through the
+stage sequence with the current kernels and with the first generation -- LDS-tiled remap and pbcor against one kernel per
+sweep, the pipelined diapfl column pass against the plain one, the fused momtum marches against the sweep kernels -- and
+against the C restatement.  The GPU suite makes the same comparisons on the device (tests/test_gpu_variants.py); this one
+runs where there is no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd import hostinit
+from blom_amd.stepper import dyncore_step
+from parity import STATE_FIELDS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "hostemu", "libblomgpu_hostemu.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(EMU), reason="tests/hostemu/libblomgpu_hostemu.so not built")
+
+OLD = dict(diapfl_v=1, momtum_v=1, remap_v=1, pbcor_v=1, barotp_fused=0, barotp_persist=0)
+SKIP = {"util1", "util2", "util3", "util4"}
+
+
+@pytest.fixture()
+def emu_lib():
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    yield
+    g.LIB_PATH = old
+
+
+def _run(cfg, nsteps, **opts):
+    from blom_amd.gpu import BlomGpu
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    for k, v in opts.items():
+        gpu.set(k, v)
+    assert gpu.step(0, nsteps) == nsteps
+    out = {nm: gpu.get(nm) for nm in STATE_FIELDS if gpu.has_field(nm)}
+    gpu.close()
+    return case, out
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 4), ("box_s", 3), ("tri_s", 3)])
+def test_current_kernels_equal_the_first_generation(emu_lib, cfg, nsteps):
+    _, new = _run(cfg, nsteps)
+    _, old = _run(cfg, nsteps, **OLD)
+    bad = [nm for nm in new if nm not in SKIP and not np.array_equal(new[nm], old[nm], equal_nan=True)]
+    assert not bad, bad
+    assert np.isfinite(new["u"]).all() and np.abs(new["u"]).max() > 0.0
+
+
+def test_current_kernels_equal_the_c_restatement(emu_lib):
+    """the same sequence on the C restatement (pinned on the compiled reference, tests/test_oracle_vs_reference.py)"""
+    from oracle.coracle import COracle
+    nsteps = 3
+    case, new = _run("chan_s", nsteps)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    orc = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(orc, case)
+    ns = 0
+    for _ in range(nsteps):
+        ns = dyncore_step(orc, ns, case.params["baclin"])
+    J, I = slice(4, 4 + case.jdm), slice(4, 4 + case.idm)
+    for nm in ("dp", "temp", "saln", "u", "v", "pb", "ub", "vb", "uflx", "vflx"):
+        a, b = orc.get(nm)[..., J, I], new[nm][..., J, I]
+        assert np.array_equal(a, b, equal_nan=True), nm
