@@ -563,6 +563,20 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
   return 0;
 }
 
+// debug (builds with -DBT_PROFILE only record anything): host == nullptr allocates and zeroes nwords of timestamps for the
+// persistent barotp kernel, otherwise copies them back
+int blomgpu_dbg_bt_prof(blomgpu_ctx *c, long long *host, int nwords) {
+  if (!host) {
+    if (c->bt_prof) (void)hipFree(c->bt_prof);
+    HIPCHK(c, hipMalloc((void **)&c->bt_prof, sizeof(long long) * nwords));
+    HIPCHK(c, hipMemset(c->bt_prof, 0, sizeof(long long) * nwords));
+    return 0;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host, c->bt_prof, sizeof(long long) * nwords, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int blomgpu_timer_reset(blomgpu_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto &kv : c->timers) {

@@ -75,6 +75,14 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
 #else
 #define PROF_MARK() do { (void)prof; (void)pslot; } while (0)
 #endif
+  // persistent form, -DBT_PROFILE: [tile][iteration < 16][8] timestamps (100 MHz): 0 top of the iteration, 1 neighbours'
+  // counts seen, 2 rim re-read, 3 sweeps done, 4 stores drained, 5 count published
+#ifdef BT_PROFILE
+#define PMARK(slot) do { if (PERSIST && a.prof && tid == 0 && done_iters < 16u) \
+    a.prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + done_iters) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PMARK(slot) do { } while (0)
+#endif
   PROF_MARK();
   const bool act = tid < NPT;
   const int li = act ? tid % BI : 0, lj = act ? tid / BI : 0;
@@ -228,6 +236,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
     do_odd = odd ? 1 : 0;
     do_even = (both || !odd) ? 1 : 0;
     lll += both ? 2 : 1;
+    PMARK(0);
     if (done_iters > 0) {               // wait for the neighbours' previous iteration, then re-read the rim
       if (tid < 64) {
         bool ready = nb_tile < 0;
@@ -241,6 +250,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         WAIT_VMCNT0();
+        PMARK(1);
       }
       // one LDS word tells the other waves about an abort
       if (tid == 0) s_abort = aborted ? 1 : 0;
@@ -248,6 +258,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
       if (s_abort) break;
       load_state(true);
       __syncthreads();
+      PMARK(2);
     }
   }
   // tile-local validity rectangle of what has been computed so far (inclusive, in li/lj)
@@ -341,6 +352,7 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
     const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
   }
   // publish the interior (and, with the arctic patch, the owned margin) in the other buffer set
+  PMARK(3);
   src ^= 1;
   // persistent form: between iterations only the cells within HB of the tile edge are read by anybody (the
   // neighbours' rims); the core of the tile lives in LDS and goes to memory with the last iteration
@@ -398,8 +410,13 @@ __global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ V
   if (PERSIST) {
     WAIT_VMCNT0();     // every storing wave drains before the count goes out
     __syncthreads();
+    PMARK(4);
     done_iters++;
     if (tid == 0) __hip_atomic_store(a.flags + (blockIdx.y * nbx + bx), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BT_PROFILE
+    if (PERSIST && a.prof && tid == 0 && done_iters <= 16u)
+      a.prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + done_iters - 1) * 8 + 5] = wall_clock64();
+#endif
   }
   } while (PERSIST && lll <= a.last);
   if (mine) {
@@ -572,7 +589,7 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   for (int x = 0; x < 2; x++) { a.wo[x] = a.wm[x] = a.wn[x] = 0.; }
   a.do_odd = a.do_even = 0; a.src = src;
   a.fold_halo = 1;
-  a.prof = nullptr;
+  a.prof = c->bt_prof;
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
   a.tsel = 0; a.nbx = nbx; a.write_margin = 0;
