@@ -227,6 +227,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "csdiag") return 0;
   if (s == "timing") { c->timing = v != 0; return 0; }
   if (s == "barotp_fused") { c->barotp_fused = v; return 0; }
+  if (s == "barotp_tile") { c->barotp_tile = v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }

@@ -230,6 +230,7 @@ struct blomgpu_ctx {
   int remap_v = 2;           // 2: gradient + flux sweep of remap in one LDS-tiled kernel (stage_remap_tile.hip), 1: separate kernels
   int pbcor_v = 2;           // 2: fluxes + update of pbcor in one LDS-tiled kernel (stage_pbcor_tile.hip), 1: separate kernels
   int diapfl_du = 8;         // levels whose loads k_diapfl_column3 keeps in flight (2, 4, 8)
+  int barotp_tile = 0;       // tile shape of the pair kernel, 100*TI + TJ (3216, 3208, 1608); 0: chosen from the tile count
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
   double *arc_strip = nullptr;                 // arctic patch, tiles of one process in strips mode: this tile's strip
   size_t arc_cap = 0;

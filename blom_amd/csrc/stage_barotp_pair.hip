@@ -13,13 +13,14 @@
 // All values are per-point identical to the unfused kernels (same expressions, same order).
 #include "blomgpu_internal.h"
 
-#define TI 32
-#define TJ 16
+// Tile shapes: 32 x 16 (836 points with the rim, 14 wavefronts) is the persistent form's and the default; the smaller ones
+// serve contexts whose domain is only a few of those tiles -- the tiles of a multi-GPU decomposition, small grids -- where a
+// launch is bound by the sweeps of ONE tile on ONE CU (6.7 of 12.4 us per substep pair) while most CUs are idle.
 #define HB 3
-#define BI (TI + 2 * HB)     // 38
-#define BJ (TJ + 2 * HB)     // 22
-#define NPT (BI * BJ)        // 836
-#define NTHR 896             // 14 waves
+#define TI_D 32
+#define TJ_D 16
+constexpr int bt_threads(int ti, int tj) { return ((ti + 2 * HB) * (tj + 2 * HB) + 63) / 64 * 64; }
+struct BtShape { int ti, tj; };
 
 struct PairArgs {
   int m, n, ml, nl;          // baroclinic levels m,n; barotropic levels at the start of the launch
@@ -59,8 +60,9 @@ struct PairArgs {
 // (relaxed polls by 8 lanes, one agent-scope acquire, bounded spin with a chip-wide abort word) and
 // re-reads just the rim.  Reads alternate between the two buffer sets exactly as the launches did.
 // All workgroups must be resident: the launcher checks tiles <= CUs.
-template <bool PERSIST>
-__global__ void __launch_bounds__(NTHR) k_bt_steps(const DevView *__restrict__ Vp, PairArgs a) {
+template <bool PERSIST, int TI, int TJ>
+__global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *__restrict__ Vp, PairArgs a) {
+  constexpr int BI = TI + 2 * HB, BJ = TJ + 2 * HB, NPT = BI * BJ;
   const DevView &V = *Vp;
   __shared__ double s_pb[2][BJ][BI + 1], s_ub[2][BJ][BI + 1], s_vb[2][BJ][BI + 1];
   // coefficients that the momentum equations read at neighbouring points: staged once per launch
@@ -488,6 +490,34 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
   return 0;
 }
 
+bool bt_phase_usable(blomgpu_ctx *c);
+// Tile shape of the one-pair-per-launch form.  Where the persistent form runs, its shape; otherwise chosen from the
+// number of tiles (option barotp_tile = 3216 / 3208 / 1608 overrides).
+static BtShape bt_shape(blomgpu_ctx *c) {
+  if (c->barotp_tile) return BtShape{c->barotp_tile / 100, c->barotp_tile % 100};
+  const DevView &h = c->h;
+  if (c->barotp_persist && bt_phase_usable(c)) return BtShape{TI_D, TJ_D};
+  if (c->num_cus <= 0) {
+    hipDeviceProp_t prop;
+    c->num_cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  // the smallest shape whose tiles all find a CU of their own (measured on the 180 x 193 tripolar grid: 32x16 = 78 tiles
+  // 16.4 us per launch, 32x8 = 150 tiles 13.5 us, 16x8 = 300 tiles on 256 CUs 22.7 us)
+  static const BtShape shapes[3] = {{16, 8}, {32, 8}, {32, 16}};
+  for (const BtShape &sh : shapes) {
+    const int nt = ((h.ii + sh.ti - 1) / sh.ti) * ((h.jj + sh.tj - 1) / sh.tj);
+    if (nt <= c->num_cus) return sh;
+  }
+  return shapes[2];
+}
+static int bt_launch_pair(blomgpu_ctx *c, BtShape sh, dim3 grid, hipStream_t st, const PairArgs &a) {
+  if (sh.ti == 32 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 32, 16>), grid, dim3(bt_threads(32, 16)), 0, st, c->d, a);
+  else if (sh.ti == 32 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 32, 8>), grid, dim3(bt_threads(32, 8)), 0, st, c->d, a);
+  else if (sh.ti == 16 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 16, 8>), grid, dim3(bt_threads(16, 8)), 0, st, c->d, a);
+  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208 or 1608");
+  return 0;
+}
+
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
                    int do_odd, int do_even, int src, int tsel, RcclLanded *rim) {
   const DevView &h = c->h;
@@ -510,20 +540,20 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
   }
   a.prof = c->bt_prof;
   a.lll0 = a.last = 0; a.woa = a.wob = a.wna = a.wnb = 0.; a.flags = nullptr; a.abort_word = nullptr; a.epoch_base = 0;
-  const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
+  const BtShape sh = bt_shape(c);
+  const int nbx = (h.ii + sh.ti - 1) / sh.ti, nby = (h.jj + sh.tj - 1) / sh.tj;
   a.nbx = nbx;
   if (rim) rim->prepacked = a.pack_on;      // the launch below leaves the next exchange's send strips packed
   if (tsel == 0) {
     a.tsel = 0;
-    hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);
-    return 0;
+    return bt_launch_pair(c, sh, dim3(nbx, nby), c->stream, a);
   }
   // edge tile columns on the exchange stream (their output is what gets packed), the rest on the main stream
   a.tsel = 1;
-  hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx > 1 ? 2 : 1, nby), dim3(NTHR), 0, c->xstream, c->d, a);
+  if (int rc = bt_launch_pair(c, sh, dim3(nbx > 1 ? 2 : 1, nby), c->xstream, a)) return rc;
   if (nbx > 2) {
     a.tsel = 2;
-    hipLaunchKernelGGL(k_bt_steps<false>, dim3(nbx - 2, nby), dim3(NTHR), 0, c->stream, c->d, a);
+    if (int rc = bt_launch_pair(c, sh, dim3(nbx - 2, nby), c->stream, a)) return rc;
   }
   return 0;
 }
@@ -543,7 +573,8 @@ int bt_overlap_usable(blomgpu_ctx *c) {
   if (!c->tiling.rccl || !c->xstream || !c->barotp_overlap) return 0;
   if (h.nreg > 2 || h.nreg == 2) return 0;
   if (c->tiling.npy != 1) return 0;
-  return (h.ii + TI - 1) / TI >= 3 ? 1 : 0;
+  const BtShape sh = bt_shape(c);
+  return (h.ii + sh.ti - 1) / sh.ti >= 3 ? 1 : 0;
 }
 
 // Can the persistent form be used?  Every tile must be resident (one 896-thread workgroup per CU) and a
@@ -551,8 +582,9 @@ int bt_overlap_usable(blomgpu_ctx *c) {
 bool bt_phase_usable(blomgpu_ctx *c) {
   const DevView &h = c->h;
   if (c->tiling.multi() || h.nreg == 2) return false;
-  const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
-  if (h.ii - (nbx - 1) * TI < HB || h.jj - (nby - 1) * TJ < HB) return false;
+  if (c->barotp_tile && c->barotp_tile != 100 * TI_D + TJ_D) return false;
+  const int nbx = (h.ii + TI_D - 1) / TI_D, nby = (h.jj + TJ_D - 1) / TJ_D;
+  if (h.ii - (nbx - 1) * TI_D < HB || h.jj - (nby - 1) * TJ_D < HB) return false;
   if (c->num_cus <= 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return false;
@@ -562,7 +594,7 @@ bool bt_phase_usable(blomgpu_ctx *c) {
   // workgroups of this kernel a CU takes (registers, LDS) instead of assuming one.
   if (c->bt_blocks_per_cu < 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps<true>, NTHR, 0) != hipSuccess) nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps<true, TI_D, TJ_D>, bt_threads(TI_D, TJ_D), 0) != hipSuccess) nb = 0;
     c->bt_blocks_per_cu = nb;
   }
   return c->bt_blocks_per_cu >= 1 && nbx * nby <= c->num_cus;
@@ -573,7 +605,7 @@ bool bt_phase_usable(blomgpu_ctx *c) {
 int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
                     int last, int src, int *src_out, int *ml_out, int *nl_out) {
   const DevView &h = c->h;
-  const int nbx = (h.ii + TI - 1) / TI, nby = (h.jj + TJ - 1) / TJ;
+  const int nbx = (h.ii + TI_D - 1) / TI_D, nby = (h.jj + TJ_D - 1) / TJ_D;
   int niter = 0;
   for (int lll = lll0; lll <= last; niter++) lll += (lll % 2 == 1 && lll + 1 <= last) ? 2 : 1;
   // the completion counters start at 0 with the first launch of every barotp call (st_barotp sets bt_restart): the
@@ -599,7 +631,7 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;
   a.abort_word = (unsigned *)(c->err_dev + 2);
-  hipLaunchKernelGGL(k_bt_steps<true>, dim3(nbx, nby), dim3(NTHR), 0, c->stream, c->d, a);
+  hipLaunchKernelGGL((k_bt_steps<true, TI_D, TJ_D>), dim3(nbx, nby), dim3(bt_threads(TI_D, TJ_D)), 0, c->stream, c->d, a);
   // replay the iteration bookkeeping of the kernel
   for (int lll = lll0; lll <= last;) {
     const bool odd = lll % 2 == 1, both = odd && lll + 1 <= last;
