@@ -110,6 +110,9 @@ _DIMS = {
     # the reference's own test case restated from its generator routines, see fuk95_ref_case below
     "fuk95_ref": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
+    # a channel of the size of ONE tile of the 2 x 4 decomposition of `channel` (bench.py --gpus 8): what a rank of that run
+    # computes per step, for timing on one GPU (tools/); not a configuration of the reference
+    "chan_t8": (104, 128, 53, 1, 10.0e3, 900.0, 18.0),
 }
 
 
@@ -143,7 +146,7 @@ def _depth_for(name, idm, jdm, dx):
     """Bathymetry [m] on the interior (jdm, idm); 0 = land."""
     ii = np.arange(1, idm + 1)[None, :]
     jj = np.arange(1, jdm + 1)[:, None]
-    if name in ("chan_s", "chan_m", "channel"):
+    if name in ("chan_s", "chan_m", "channel", "chan_t8"):
         # tanh shelves on both walls (cf. channel/mod_channel.F90:168-207), southern and
         # northern-most rows land
         sf, sl = (200.0, 800.0) if name in ("chan_s", "chan_m") else (200.0, 3800.0)
