@@ -76,18 +76,27 @@ def class_bytes_F(ntr, ntr_dif=None):
     }
 
 
+KNOWN_CONFIGS = ("channel", "tnx2v1s", "tnx1v4s", "chan_t8")
+
+
+def _profiles_of(config, suffix):
+    """committed profile summaries of THIS configuration, oldest first: profiles/<tag>_<config>_<suffix> (tools/prof_summarize.py);
+    files of rounds 1-2 carry no configuration tag when they are the channel's"""
+    import glob
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_" + suffix))):
+        b = os.path.basename(f)
+        tagged = [c for c in KNOWN_CONFIGS if f"_{c}_{suffix}" in b]
+        if (tagged and tagged[0] == config) or (not tagged and config == "channel"):
+            out.append(f)
+    return out
+
+
 def class_traffic(config, ntr=1):
     """HBM bytes per step and kernel class from the newest committed PMC profile of this configuration
     (profiles/*_class_traffic.json, written by tools/prof_summarize.py from separate rocprofv3 --pmc
     passes of this very command); None when there is none."""
-    import glob
-    import json
-    if config != "channel":
-        return None, None
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_class_traffic.json")))
-    if not files:
-        return None, None
-    for f in reversed(files):
+    for f in reversed(_profiles_of(config, "class_traffic.json")):
         d = json.load(open(f))
         if d.get("ntr", 1) == ntr:                      # a profile of this very workload
             return d.get("bytes_per_step", {}), os.path.basename(f)
@@ -95,13 +104,9 @@ def class_traffic(config, ntr=1):
 
 
 def dominant_kernel(config):
-    """the single largest kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
-    (profiles/*_kernel_stats.txt, newest): name, average us, share of the kernel time"""
-    import glob
-    if config != "channel":
-        return None
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_kernel_stats.txt")))
-    for f in reversed(files):
+    """the single largest kernel of the committed rocprofv3 --kernel-trace --stats summary of this configuration
+    (profiles/*_kernel_stats.txt of the SAME configuration, newest): name, average us, share of the kernel time"""
+    for f in reversed(_profiles_of(config, "kernel_stats.txt")):
         for line in open(f):
             if line.startswith("#") or not line.strip():
                 continue
@@ -131,7 +136,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=25.0):
     """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
     2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
     default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
@@ -145,17 +150,19 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
     return res
 
 
-def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=25.0):
     """Reference (preferred) or C restatement timed on the host for a bounded number of steps."""
     from blom_amd import hostinit
     from blom_amd.stepper import dyncore_step
     kind = None
     cores = 1
+    # one thread count for every leg: the reference's OpenMP build and the OpenMP'd loops of the C restatement
+    # (oracle/c/eddtra.c, cmnfld.c; gcc -fopenmp) both read OMP_NUM_THREADS when their runtimes start
+    os.environ["OMP_NUM_THREADS"] = str(usable_cores())
     try:
         from oracle.refblom import get_ref_backend, have_ref
         if have_ref(cfg + "_omp"):          # the reference with its OpenMP directives on, all host cores
             cores = usable_cores()
-            os.environ["OMP_NUM_THREADS"] = str(cores)
             os.environ.setdefault("OMP_PROC_BIND", "close")
             os.environ["OMP_STACKSIZE"] = "1G"   # the stages keep private 2-D work arrays on the thread stacks
             be = get_ref_backend(cfg + "_omp", case.depth)
@@ -182,11 +189,12 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
         mark[0], mark[1] = st, now
     t0 = time.time()
     n = 0
-    while n < 3 or (time.time() - t0 < max_seconds and n < 200):
+    while n < 3 or (time.time() - t0 < max_seconds and n < 120):
         ns = dyncore_step(be, ns, case.params["baclin"], hook=hook)
         hook(None, None)
         n += 1
     dt = (time.time() - t0) / n
+    ref_only_ms = dt * 1e3
     note = ""
     if kind == "reference":
         # mod_eddtra is not part of the reference build (it needs mod_difest -> CVMix): time that one
@@ -211,7 +219,7 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
         dt += dc
         per_stage["cmnfld"] = dc * n
         note = (f"; eddtra ({de * 1e3:.1f} ms) and cmnfld2's slopes ({dc * 1e3:.1f} ms) timed on the C restatements "
-                "(single thread) since the reference build lacks both modules")
+                f"(their j-loops under OpenMP, the same {cores} threads) since the reference build lacks both modules")
     how = (f"{cores} OpenMP threads (reference built with -fopenmp)" if cores > 1 else
            "single thread (reference built without OpenMP)" if kind == "reference" else "single thread (C restatement)")
     stages_ms = {k: round(v / n * 1e3, 2) for k, v in per_stage.items() if k}
@@ -219,6 +227,7 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=20.0):
     if "advect" in stages_ms:
         stages_ms[case.params.get("advmth", "remap")] = stages_ms.pop("advect")
     return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=cores, kind=kind, stages_ms=stages_ms,
+                reference_only_ms=round(ref_only_ms, 2), steps_timed=n,
                 sample=f"{n} baroclinic steps of the same {cfg} workload, {dt * 1e3:.1f} ms/step, {how}{note}")
 
 
@@ -409,6 +418,9 @@ def main():
                      "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (traffic or {}).get(dom), "traffic_source": traffic_src,
                      "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom],
+                     # the 3-D (HBM) part of the step alone: A3D / step time against the peak -- A2D, barotp's 2-D working set,
+                     # stays on chip and is left out of this one
+                     "step_hbm_frac": a3d / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1)),
                      "dominant_single_kernel": dominant_kernel(args.config)},
         "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
                           "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,

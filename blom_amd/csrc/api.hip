@@ -15,6 +15,9 @@ int ctx_fail(blomgpu_ctx *c, const std::string &msg) {
 void ctx_drop_graphs(blomgpu_ctx *c) {
   for (auto &g : c->step_graph)
     if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+  // an option switched after the warm-up may select kernels whose lazily allocated buffers / occupancy queries have
+  // not run yet: a capture must not be the first execution of such a sequence, so the warm-up count restarts
+  c->steps_warm = 0;
 }
 
 void ctx_sync_view(blomgpu_ctx *c) {
@@ -224,10 +227,16 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "nstep") { P.nstep = v; return 0; }      // host-side only (stage_cppm.hip): the device view is not touched
   R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
-  if (s == "csdiag") return 0;
+  if (s == "csdiag") { c->csdiag = v != 0; return 0; }
   if (s == "timing") { c->timing = v != 0; return 0; }
   if (s == "barotp_fused") { c->barotp_fused = v; return 0; }
-  if (s == "barotp_tile") { c->barotp_tile = v; return 0; }
+  if (s == "barotp_tile") {
+    if (v != 0 && v != 3216 && v != 3208 && v != 1608) return ctx_fail(c, "blomgpu_set_int: barotp_tile must be 0, 3216, 3208 or 1608");
+    c->barotp_tile = v;
+    return 0;
+  }
+  if (s == "eddtra_frozen") { c->eddtra_frozen = v; return 0; }
+  if (s == "check_period") { c->check_period = v < 1 ? 1 : v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
@@ -515,6 +524,9 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
+    // eddtra_frozen: the eddy-induced fluxes umfltd.. stay as uploaded (the reference build of the oracle has no mod_eddtra;
+    // tests pin advect/remap on non-zero fluxes this way)
+    if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
     if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
   }
   c->defer_checks = false;
@@ -534,29 +546,39 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     const int mm = (m - 1) * kk, nn = (n - 1) * kk, k1m = 1 + mm, k1n = 1 + nn;
     c->h.P.nstep = ns + 1;                             // read by host code only: no upload of the view for it
     ctx_sync_view(c);
-    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_done >= 4;
+    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4;
     hipGraphExec_t &ge = c->step_graph[ns & 1];
-    if (graph && !ge && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      c->use_graph = 0;                                // no stream capture here: plain launches from now on
-      graph = false;
-    }
     if (graph && !ge) {
+      // capture; nothing executes while capturing, so on any failure the step is simply run with plain launches
       hipGraph_t g = nullptr;
-      const int rc = step_sequence(c, m, n, mm, nn, k1m, k1n);
-      const hipError_t e = hipStreamEndCapture(c->stream, &g);
-      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-      if (e != hipSuccess || !g) return ctx_fail(c, std::string("blomgpu_step: stream capture failed: ") + hipGetErrorString(e));
-      const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      if (ei != hipSuccess) { ge = nullptr; return ctx_fail(c, std::string("blomgpu_step: hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+      bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rc = step_sequence(c, m, n, mm, nn, k1m, k1n);
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        ok = rc == 0 && e == hipSuccess && g != nullptr;
+        if (ok && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { ge = nullptr; ok = false; }
+        if (g) (void)hipGraphDestroy(g);
+      }
+      if (!ok) {
+        (void)hipGetLastError();
+        c->err.clear();
+        c->use_graph = 0;                              // plain launches from now on
+        graph = false;
+      }
     }
     if (graph) HIPCHK(c, hipGraphLaunch(ge, c->stream));
     else if (int rc = step_sequence(c, m, n, mm, nn, k1m, k1n)) return rc;
     c->steps_done++;
-    // the stages' error words are sticky: one read-back (a host synchronisation) per 8 steps and at the end of the call
-    if (it == nsteps - 1 || (it & 7) == 7)
-      if (int rc = ctx_check_errors(c)) return rc;
+    c->steps_warm++;
+    // the stages' error words are sticky: one read-back (a host synchronisation) per check_period steps (every step with
+    // csdiag or stage timing, where the reference's stop-in-the-failing-step matters) and at the end of the call
+    const int period = (c->csdiag || c->timing) ? 1 : c->check_period;
+    if (it == nsteps - 1 || (it + 1) % period == 0)
+      if (int rc = ctx_check_errors(c)) {
+        const int first = ns + 1 - (it % period);
+        c->err += " (raised in one of the steps nstep = " + std::to_string(first) + ".." + std::to_string(ns + 1) + ")";
+        return rc;
+      }
     const double delt2 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300
     if (c->h.P.delt1 != delt2) { c->h.P.delt1 = delt2; c->dirty = true; }   // changes after the first step only
     *nstep = ns + 1;

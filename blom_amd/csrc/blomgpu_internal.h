@@ -211,6 +211,10 @@ struct blomgpu_ctx {
   int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default
   hipGraphExec_t step_graph[2] = {nullptr, nullptr};
   int steps_done = 0;
+  int steps_warm = 0;            // plain steps since the last option change (graph capture waits for 4)
+  int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded
+  int check_period = 8;          // steps between read-backs of the sticky stage error words in blomgpu_step
+  bool csdiag = false;           // mod_checksum's switch: error words read back every step
   bool bt_restart = true;        // the next persistent barotp launch zeroes the completion counts and starts at epoch 0
   unsigned bt_epoch = 0;          // completion count every tile has reached after the launches so far
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel

@@ -454,3 +454,37 @@ def step_indices(nstep, kk):
     mm = (m - 1) * kk
     nn = (n - 1) * kk
     return m, n, mm, nn, 1 + mm, 1 + nn
+
+
+def frozen_eddy_fluxes(be, case, amp=0.15, spike=3.0):
+    """A synthetic, frozen field of eddy-induced mass fluxes umfltd, vmfltd (thickness diffusion) and umflsm, vmflsm
+    (submesoscale) at both time levels: what eddtra would hand to advect (phy/mod_advect.F90:72-94,
+    cau = ... + (umfltd+umflsm)/max(onemm,dpu)), as an analytic function of the grid and of the state the backend
+    holds.  Smooth, sign-changing, a fraction `amp` of the flux area the CFL clamp allows times the layer thickness at
+    the velocity point; every 97th wet velocity point carries `spike` times the clamp (either sign), so that both
+    branches of the clamp act.  Land points keep what the backend has there (the reference's inivar pattern).
+    The reference build used as oracle has no mod_eddtra (CVMix), so its advect otherwise only ever sees zeros here;
+    tests write this field into the reference's module arrays and into the device (option eddtra_frozen)."""
+    kk, ii, jj = case.kdm, case.idm, case.jdm
+    baclin = case.params["baclin"]
+    J, I = sl(1, jj), sl(1, ii)
+    jg, ig = np.meshgrid(np.arange(1, jj + 1, dtype=np.float64), np.arange(1, ii + 1, dtype=np.float64), indexing="ij")
+    cnt = (np.arange(jj * ii).reshape(jj, ii) % 97) == 13
+    for comp, (flds, mask, vmx, sc, dpn) in enumerate(((("umfltd", "umflsm"), "iu", "umax", "scuy", "dpu"),
+                                                      (("vmfltd", "vmflsm"), "iv", "vmax", "scvx", "dpv"))):
+        wet = be.masks[mask][J, I] > 0
+        clamp = be.get(vmx)[0][J, I] * (2.0 * baclin) * be.get(sc)[0][J, I]          # umax*delt1*scuy: an area
+        dpv = be.get(dpn)
+        for nf, nm in enumerate(flds):
+            a = be.get(nm)
+            for lev in range(2 * kk):
+                k = lev % kk
+                ph = 0.37 * k + 1.3 * (lev // kk) + 0.9 * comp + 2.1 * nf
+                pat = np.sin(2.0 * np.pi * ig / 11.0 + ph) * np.cos(2.0 * np.pi * jg / 7.0 - 0.61 * ph)
+                pat = (amp if nf == 0 else 0.4 * amp) * pat
+                if nf == 0:
+                    sgn = np.where(((ig + jg + k) % 2) == 0, 1.0, -1.0)
+                    pat = np.where(cnt & ((k % 5) == 2), spike * sgn, pat)
+                val = pat * clamp * dpv[k + (1 - lev // kk) * kk][J, I]
+                a[lev][J, I] = np.where(wet, val, a[lev][J, I])
+            be.put(nm, a)

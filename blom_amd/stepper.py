@@ -20,6 +20,9 @@ OPTIONAL_STAGES = ("eddtra",)
 # mxlayr_tail : phy/mod_mxlayr.F90:1266-1310, halo of dp at the new level + dpu/dpv.
 
 
+STAGES_FROZEN_EDDY_FLUXES = tuple(s for s in DYNCORE_STAGES if s != "eddtra")    # umfltd.. stay as uploaded
+
+
 def dyncore_step(be, nstep, baclin, stages=DYNCORE_STAGES, hook=None):
     """Advance backend `be` from step count nstep to nstep+1.  `hook(stage, sextuple)` is
     called before each stage (tests use it to snapshot stage inputs)."""

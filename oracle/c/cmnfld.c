@@ -176,9 +176,11 @@ int orc_cmnfld2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
     for (int i = -1; i <= ii + 2; i++)
       if (A2(S, ip, i, j)) A3(S, kfpla, i, j, n) = (int)lround(A2(S, util1, i, j));
   if (S->eitmth != 2) return 0;
+#pragma omp parallel for schedule(dynamic, 4)
   for (int j = -1; j <= jj + 2; j++)                              /* :83-212 */
     for (int i = -1; i <= ii + 2; i++)
       if (A2(S, ip, i, j)) bfsqf_column(S, i, j, n, nn);
+#pragma omp parallel for schedule(dynamic, 4)
   for (int j = -1; j <= jj + 2; j++)                              /* :437-455 */
     for (int k = kk; k >= 1; k--)
       for (int i = -1; i <= ii + 2; i++)
@@ -187,9 +189,11 @@ int orc_cmnfld2(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
           if (A3(S, dp, i, j, kn) < EPSILP) A3(S, phi, i, j, k) = A3(S, phi, i, j, k + 1);
           else A3(S, phi, i, j, k) = A3(S, phi, i, j, k + 1) - eos_p_alpha(A3(S, p, i, j, k + 1), A3(S, p, i, j, k), A3(S, temp, i, j, kn), A3(S, saln, i, j, kn));
         }
+#pragma omp parallel for schedule(dynamic, 4)
   for (int j = -1; j <= jj + 2; j++)                              /* :465-550 */
     for (int i = 0; i <= ii + 2; i++)
       if (A2(S, iu, i, j)) nslope_column(S, i, j, i - 1, j, n, nn, S->nslpx, S->nnslpx, A2(S, scuxi, i, j));
+#pragma omp parallel for schedule(dynamic, 4)
   for (int j = 0; j <= jj + 2; j++)                               /* :556-641 */
     for (int i = -1; i <= ii + 2; i++)
       if (A2(S, iv, i, j)) nslope_column(S, i, j, i, j - 1, n, nn, S->nslpy, S->nnslpy, A2(S, scvyi, i, j));

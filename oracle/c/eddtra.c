@@ -233,25 +233,30 @@ int orc_eddtra(OState *S, int m, int n, int mm, int nn, int k1m, int k1n) {
   if (kk > KMAXDIM) { fprintf(stderr, "oracle eddtra: kdm too large\n"); return 1; }
   if (S->eitmth == 1) intdif(S, mm, nn);
   else if (S->eitmth == 2) {
+    int bad = 0;
+    /* the reference's j-loop carries an OpenMP directive (:247); rows are independent (a column writes only its own fluxes) */
+#pragma omp parallel for schedule(dynamic, 4) reduction(| : bad)
     for (int j = 1; j <= jj; j++) {
       for (int i = 1; i <= ii; i++)                           /* :259-268: ptu, then the u-column */
         if (A2(S, iu, i, j)) {
           const size_t xb = IX(S, i, j), xa = xb - 1;
           const double ptu = fmax2(L3(p, xa, 1), L3(p, xb, 1));
-          if (gm_column(S, xa, xb, n, mm, nn, S->scuy[xb], S->nslpx, S->pbu, S->dpu, S->scu2[xb], S->umfltd, ptu)) return 1;
+          bad |= gm_column(S, xa, xb, n, mm, nn, S->scuy[xb], S->nslpx, S->pbu, S->dpu, S->scu2[xb], S->umfltd, ptu);
         }
       for (int i = 1; i <= ii; i++)
         if (A2(S, iv, i, j)) {
           const size_t xb = IX(S, i, j), xa = xb - (size_t)S->ni;
           const double ptv = fmax2(L3(p, xa, 1), L3(p, xb, 1));
-          if (gm_column(S, xa, xb, n, mm, nn, S->scvx[xb], S->nslpy, S->pbv, S->dpv, S->scv2[xb], S->vmfltd, ptv)) return 1;
+          bad |= gm_column(S, xa, xb, n, mm, nn, S->scvx[xb], S->nslpy, S->pbv, S->dpv, S->scv2[xb], S->vmfltd, ptv);
         }
     }
+    if (bad) return 1;
   } else {
     fprintf(stderr, "oracle eddtra: eitmth_opt = %d is unsupported for vcoord = 'isopyc_bulkml'!\n", S->eitmth);
     return 1;
   }
   /* heat and salt components, :1837-1857 */
+#pragma omp parallel for
   for (int j = 1; j <= jj; j++)
     for (int k = 1; k <= kk; k++) {
       const int km = k + mm;

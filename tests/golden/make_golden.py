@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from blom_amd.cases import make_case            # noqa: E402
 from blom_amd import hostinit                    # noqa: E402
 from blom_amd.checksum import grid_of            # noqa: E402
-from blom_amd.stepper import dyncore_step        # noqa: E402
+from blom_amd.stepper import dyncore_step, DYNCORE_STAGES, STAGES_FROZEN_EDDY_FLUXES   # noqa: E402
 from oracle.refblom import get_ref_backend       # noqa: E402
 from parity import STATE_FIELDS, GRID_FIELDS, INT_FIELDS   # noqa: E402
 
@@ -44,15 +44,22 @@ CHANNEL_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "trc", "p", "dpu", "d
 
 
 def generate(cfg):
+    """cfg 'name' or 'name+edf': the latter with hostinit.frozen_eddy_fluxes (non-zero umfltd, vmfltd, umflsm, vmflsm
+    in front of advect, frozen; the reference build has no mod_eddtra) -> <name>_edf_crc.json"""
     global NSTEPS
+    eddy = cfg.endswith("+edf")
+    cfg = cfg[:-4] if eddy else cfg
+    out = cfg + "_edf" if eddy else cfg
     big = cfg.startswith("channel") or cfg.startswith("tnx2v1s")
-    crc_only = big or cfg in ("fuk95", "fuk95_ref", "tri_s", "chan_s_tke")
+    crc_only = eddy or big or cfg in ("fuk95", "fuk95_ref", "tri_s", "chan_s_tke")
     NSTEPS = 2 if cfg == "fuk95" else 3
     case = make_case(cfg)
     # the channel-sized reference is built with its OpenMP directives on (same results, oracle/Makefile)
     ref = get_ref_backend(cfg + "_omp" if big else cfg, case.depth)
     crc_fields = CHANNEL_FIELDS if big else CRC_FIELDS
     hostinit.init_state(ref, case)
+    if eddy:
+        hostinit.frozen_eddy_fluxes(ref, case)
     init = {nm: ref.get(nm).copy() for nm in STATE_FIELDS + GRID_FIELDS + INT_FIELDS if ref.ref.has_field(nm) or nm in ("trc",)}
     for m in ("ip", "iu", "iv", "iq"):
         init["mask_" + m] = ref.masks[m].copy()
@@ -74,18 +81,20 @@ def generate(cfg):
             if pending:
                 record(pending.pop())
             pending.append(st)
-        ns = dyncore_step(ref, ns, case.params["baclin"], hook=hook)
+        ns = dyncore_step(ref, ns, case.params["baclin"], hook=hook,
+                          stages=STAGES_FROZEN_EDDY_FLUXES if eddy else DYNCORE_STAGES)
         record(pending.pop())
-    json.dump({"nsteps": NSTEPS, "fields": crc_fields, "crc": crcs},
-              open(os.path.join(HERE, f"{cfg}_crc.json"), "w"))
+    json.dump({"nsteps": NSTEPS, "fields": crc_fields, "crc": crcs, "eddy_fluxes": "hostinit.frozen_eddy_fluxes" if eddy else "zero"},
+              open(os.path.join(HERE, f"{out}_crc.json"), "w"))
     if not crc_only:
         np.savez_compressed(os.path.join(HERE, f"{cfg}_final.npz"), **{nm: ref.get(nm).copy() for nm in FINAL_FIELDS})
-    print(cfg, "fixtures written")
+    print(out, "fixtures written")
 
 
 if __name__ == "__main__":
     import threading
-    cfgs = sys.argv[1:] or ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke"]
+    cfgs = sys.argv[1:] or ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke",
+                            "tri_s+edf", "chan_s_tke+edf", "channel_tke+edf", "tnx2v1s_tke+edf"]
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     os.environ["OMP_STACKSIZE"] = "1G"
     threading.stack_size(2 << 30)            # the reference keeps stage-local 2-D work arrays on the stack

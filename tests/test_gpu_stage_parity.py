@@ -12,7 +12,7 @@ import pytest
 
 from blom_amd.cases import make_case
 from blom_amd import hostinit
-from blom_amd.stepper import dyncore_step
+from blom_amd.stepper import dyncore_step, DYNCORE_STAGES, STAGES_FROZEN_EDDY_FLUXES
 from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, INT_FIELDS
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +28,7 @@ GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", 
 SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "vtotm"}
 
 
-def _run(cfg, nsteps, stages, **overrides):
+def _run(cfg, nsteps, stages, eddy=False, **overrides):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
@@ -36,6 +36,8 @@ def _run(cfg, nsteps, stages, **overrides):
     case = make_case(cfg, **overrides)
     ref = get_ref_backend(cfg, case.depth)
     hostinit.init_state(ref, case)
+    if eddy:                                    # non-zero umfltd, vmfltd, umflsm, vmflsm in front of advect
+        hostinit.frozen_eddy_fluxes(ref, case)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
     for nm, v in case.params.items():
         if not nm.endswith("0"):
@@ -64,7 +66,8 @@ def _run(cfg, nsteps, stages, **overrides):
         pending["st"] = st
 
     for _ in range(nsteps):
-        new = dyncore_step(ref, nstep[0], case.params["baclin"], hook=hook)
+        new = dyncore_step(ref, nstep[0], case.params["baclin"], hook=hook,
+                           stages=STAGES_FROZEN_EDDY_FLUXES if eddy else DYNCORE_STAGES)
         check()
         nstep[0] = new
     gpu.close()
@@ -74,6 +77,14 @@ def _run(cfg, nsteps, stages, **overrides):
 @pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s", "chan_s_tke", "box_s_tke", "chan_s_tk2", "chan_s_tk0"])
 def test_stage_parity_small(cfg):
     _run(cfg, 4, GPU_STAGES)
+
+
+@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "tri_s", "chan_s_tke", "tri_s_tke"])
+def test_stage_parity_with_eddy_fluxes(cfg):
+    """The bench workload has eddtra's non-zero mass fluxes in front of advect; the reference build has no mod_eddtra, so
+    a synthetic field of them (smooth, sign-changing, every 97th point beyond the CFL clamp) is written into its module
+    arrays: advect's cau/cav (phy/mod_advect.F90:72-94) and everything downstream of them against the compiled reference."""
+    _run(cfg, 4, GPU_STAGES, eddy=True)
 
 
 def test_stage_parity_fuk95():
@@ -110,6 +121,17 @@ FREERUN_FIELDS = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "ub
 @pytest.mark.parametrize("cfg,nsteps,rtol", [("chan_s", 40, 0.0), ("box_s", 40, 0.0), ("fuk95", 12, 0.0),
                                              ("chan_s_tke", 40, 0.0), ("tri_s", 24, 0.0), ("tri_s_tke", 24, 0.0), ("chan_s_tk2", 40, 0.0), ("chan_s_tk0", 40, 0.0)])
 def test_freerun_device_resident(cfg, nsteps, rtol):
+    _freerun_device(cfg, nsteps, rtol, False)
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 24), ("box_s", 24), ("chan_s_tke", 24), ("tri_s", 16), ("tri_s_tke", 16)])
+def test_freerun_device_resident_with_eddy_fluxes(cfg, nsteps):
+    """blomgpu_step with the option eddtra_frozen against the reference stepped stage by stage, both holding the same frozen
+    field of non-zero eddy-induced mass fluxes."""
+    _freerun_device(cfg, nsteps, 0.0, True)
+
+
+def _freerun_device(cfg, nsteps, rtol, eddy):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
@@ -117,15 +139,18 @@ def test_freerun_device_resident(cfg, nsteps, rtol):
     case = make_case(cfg)
     ref = get_ref_backend(cfg, case.depth)
     hostinit.init_state(ref, case)
+    if eddy:
+        hostinit.frozen_eddy_fluxes(ref, case)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
     for nm, v in case.params.items():
         if not nm.endswith("0"):
             gpu.set(nm, v)
+    gpu.set("eddtra_frozen", int(eddy))
     copy_state(ref, gpu)
     gpu.set("delt1", case.params["baclin"])
     ns = 0
     for _ in range(nsteps):
-        ns = dyncore_step(ref, ns, case.params["baclin"])
+        ns = dyncore_step(ref, ns, case.params["baclin"], stages=STAGES_FROZEN_EDDY_FLUXES if eddy else DYNCORE_STAGES)
     assert gpu.step(0, nsteps) == nsteps
     gpu.sync()
     exact = diff_report(ref, gpu, fields=FREERUN_FIELDS)
@@ -135,8 +160,9 @@ def test_freerun_device_resident(cfg, nsteps, rtol):
     assert not bad, fmt_report(bad)
 
 
+@pytest.mark.parametrize("eddy", [False, True], ids=["zero_eddy_fluxes", "eddy_fluxes"])
 @pytest.mark.parametrize("cfg", ["channel_tke", "tnx2v1s_tke"])
-def test_full_size_matches_reference(cfg):
+def test_full_size_matches_reference(cfg, eddy):
     """BASELINE.json's channel (208x512x53) with the reference's default tracer set (ntr = 3), the bench workload, and
     the tnx2v1 grid's dimensions (180x193x53, arctic patch, synthetic bathymetry): the device-resident sequence against
     the reference's own Fortran (built with its OpenMP directives, oracle/_ref/<cfg>_omp) over the forward step and
@@ -153,15 +179,18 @@ def test_full_size_matches_reference(cfg):
         case = make_case(cfg)
         ref = get_ref_backend(cfg + "_omp", case.depth)
         hostinit.init_state(ref, case)
+        if eddy:
+            hostinit.frozen_eddy_fluxes(ref, case)
         gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
         for nm, v in case.params.items():
             if not nm.endswith("0"):
                 gpu.set(nm, v)
+        gpu.set("eddtra_frozen", int(eddy))
         copy_state(ref, gpu)
         gpu.set("delt1", case.params["baclin"])
         ns = 0
         for _ in range(nsteps):
-            ns = dyncore_step(ref, ns, case.params["baclin"])
+            ns = dyncore_step(ref, ns, case.params["baclin"], stages=STAGES_FROZEN_EDDY_FLUXES if eddy else DYNCORE_STAGES)
         assert gpu.step(0, nsteps) == nsteps
         gpu.sync()
         res["bad"] = diff_report(ref, gpu, fields=FREERUN_FIELDS)

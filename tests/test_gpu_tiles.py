@@ -117,26 +117,35 @@ def test_rccl_transport_single_rank_equals_single_tile():
     assert not bad, bad
 
 
-def test_channel_as_eight_tiles_reproduces_the_reference_checksums():
-    """BASELINE.json config 3 on one GPU: the channel at full size (208x512x53, ntr = 3) cut into the 2 x 4 tiles
-    of 104 x 128 that `bench.py --gpus 8` uses, the eight tiles on one device with the in-process transport (RCCL
-    refuses several ranks per GPU).  After each of three steps the decomposition-independent checksum (xccrc chained
-    over the tiles, blom_amd/tiles.py) of every recorded field must be the one the reference's own Fortran produced
-    on ONE tile (tests/golden/channel_tke_crc.json)."""
+@pytest.mark.parametrize("cfg,npx,npy,eddy", [("channel_tke", 2, 4, False), ("channel_tke", 2, 4, True),
+                                              ("tnx2v1s_tke", 4, 2, False), ("tnx2v1s_tke", 4, 2, True)],
+                         ids=["channel_2x4", "channel_2x4_eddy_fluxes", "tnx2v1s_4x2", "tnx2v1s_4x2_eddy_fluxes"])
+def test_full_size_as_eight_tiles_reproduces_the_reference_checksums(cfg, npx, npy, eddy):
+    """BASELINE.json configs 3 and 4 on one GPU.  The channel at full size (208x512x53, ntr = 3) cut into the 2 x 4 tiles
+    of 104 x 128 that `bench.py --gpus 8` uses, and the tnx2v1 grid's dimensions (180x193x53, arctic patch) in the
+    reference's own 4 x 2 tiling of bld/tnx2v1/patch.input.8 (tile columns of 45, tile rows of 97 and 96): the eight tiles
+    on one device with the in-process transport (RCCL refuses several ranks per GPU).  After each of three steps the
+    decomposition-independent checksum (xccrc chained over the tiles, blom_amd/tiles.py) of every recorded field must be
+    the one the reference's own Fortran produced on ONE tile (tests/golden/<cfg>_crc.json; with `eddy` the fixture and the
+    tiles hold the frozen non-zero eddy-induced mass fluxes of hostinit.frozen_eddy_fluxes, <cfg>_edf_crc.json)."""
     import json
     import os
     from blom_amd.gpu import BlomGpu, TileGroup
     from blom_amd import hostinit
     from blom_amd.checksum import grid_of
     from blom_amd.tiles import TileLayout, scatter_to_tile, chain_crc
-    cfg, npx, npy = "channel_tke", 2, 4
     case = make_case(cfg)
-    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{cfg}_crc.json")))
-    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       f"{cfg}_edf_crc.json" if eddy else f"{cfg}_crc.json")))
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
     whole = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
     hostinit.init_state(whole, case)
+    if eddy:
+        hostinit.frozen_eddy_fluxes(whole, case)
     lay = TileLayout.regular(case.idm, case.jdm, npx, npy)
+    if cfg.startswith("tnx2v1s"):
+        assert lay.isizes == (45, 45, 45, 45) and lay.jsizes == (97, 96)      # bld/tnx2v1/patch.input.8
     grp = TileGroup(npx, npy)
     tiles = {}
     for py in range(npy):
@@ -149,10 +158,11 @@ def test_channel_as_eight_tiles_reproduces_the_reference_checksums():
                     t.set(nm, v)
             scatter_to_tile(whole, t, lay, px, py)
             t.set("delt1", case.params["baclin"])
+            t.set("eddtra_frozen", int(eddy))
             grp.attach(t, px, py)
             tiles[(px, py)] = t
     whole.close()
-    names = [nm for nm in gold["crc"]["1"]["tmsmt2"] if nm not in ("umfltd", "vmfltd", "utfltd", "vtfltd", "usfltd", "vsfltd")]
+    names = [nm for nm in gold["crc"]["1"]["tmsmt2"] if eddy or nm not in ("umfltd", "vmfltd", "utfltd", "vtfltd", "usfltd", "vsfltd")]
     parts, errs = {}, []
     bar = threading.Barrier(npx * npy)
 

@@ -5,13 +5,25 @@ import pytest
 
 from blom_amd.cases import make_case
 from blom_amd import hostinit
-from blom_amd.stepper import dyncore_step
+from blom_amd.stepper import dyncore_step, DYNCORE_STAGES, STAGES_FROZEN_EDDY_FLUXES
 from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, INT_FIELDS
 
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 12), ("fuk95", 3), ("tri_s", 8),
                                         ("chan_s_tke", 12), ("box_s_tke", 8), ("tri_s_tke", 8), ("chan_s_tk2", 12), ("chan_s_tk0", 12)])
 def test_freerun_bit_identical(cfg, nsteps):
+    _freerun(cfg, nsteps, False)
+
+
+# the same with non-zero eddy-induced mass fluxes in front of advect (hostinit.frozen_eddy_fluxes: a frozen synthetic field,
+# written into the reference's module arrays; its build has no mod_eddtra): cau/cav of phy/mod_advect.F90:72-94 with the
+# umfltd/umflsm terms acting and the clamp reached, remap on the flux areas they cause
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 12), ("tri_s", 8), ("chan_s_tke", 12), ("tri_s_tke", 8)])
+def test_freerun_bit_identical_with_eddy_fluxes(cfg, nsteps):
+    _freerun(cfg, nsteps, True)
+
+
+def _freerun(cfg, nsteps, eddy):
     from oracle.refblom import get_ref_backend, have_ref
     from oracle.coracle import COracle, have_coracle
     if not (have_ref(cfg) and have_coracle()):
@@ -19,6 +31,9 @@ def test_freerun_bit_identical(cfg, nsteps):
     case = make_case(cfg)
     ref = get_ref_backend(cfg, case.depth)
     hostinit.init_state(ref, case)
+    if eddy:
+        hostinit.frozen_eddy_fluxes(ref, case)
+    stages = STAGES_FROZEN_EDDY_FLUXES if eddy else DYNCORE_STAGES
     co = COracle(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
     for nm, v in case.params.items():
         if not nm.endswith("0"):
@@ -28,7 +43,7 @@ def test_freerun_bit_identical(cfg, nsteps):
     fields = [f for f in STATE_FIELDS + INT_FIELDS if f not in ("util1", "util2")]
     nr = nc = 0
     for _ in range(nsteps):
-        nr = dyncore_step(ref, nr, case.params["baclin"])
-        nc = dyncore_step(co, nc, case.params["baclin"])
+        nr = dyncore_step(ref, nr, case.params["baclin"], stages=stages)
+        nc = dyncore_step(co, nc, case.params["baclin"], stages=stages)
         bad = diff_report(ref, co, fields=fields)
         assert not bad, f"step {nr}\n" + fmt_report(bad[:8])
