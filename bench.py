@@ -43,7 +43,9 @@ def build_case(cfg, advmth="remap", tracers="default"):
     from blom_amd import hostinit
     # "default": the reference's default build options (meson_options.txt:17-21: TKE + advection of it, ideal age)
     # => ntr = 3, the tracer count SURVEY.md 8(d) quotes the channel on; "iage": -DTRC -DIDLAGE only, ntr = 1
-    case = make_case(cfg + ("_tke" if tracers == "default" else ""), nslp0=NSLP0, advmth=advmth)
+    # an integer N > 3: the default set plus N - 3 passive tracers (what iHAMOCC's are to the dynamical core, config 5)
+    ntr = int(tracers) if tracers.isdigit() else None
+    case = make_case(cfg + ("" if tracers == "iage" else "_tke"), ntr=ntr, nslp0=NSLP0, advmth=advmth)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     return case, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq)
 
@@ -239,9 +241,10 @@ def main():
     ap.add_argument("--config", default="channel")
     ap.add_argument("--advmth", default="remap", choices=["remap", "cppm"],
                     help="advection method (the reference's advmth); the headline configuration is remap")
-    ap.add_argument("--tracers", default="default", choices=["default", "iage"],
+    ap.add_argument("--tracers", default="default",
                     help="default: the reference's default option set (TKE, its advection, ideal age: ntr = 3); "
-                         "iage: ideal age only (ntr = 1)")
+                         "iage: ideal age only (ntr = 1); an integer N > 3: the default set plus N - 3 passive tracers "
+                         "(BASELINE.json config 5 advects iHAMOCC's tracers through the same stages)")
     ap.add_argument("--slopes", default="live", choices=["live", "frozen"],
                     help="live: cmnfld2 computes the neutral slopes eddtra consumes every step (phy/mod_cmnfld_routines.F90:1158); "
                          "frozen: round 1's analytic pattern of amplitude NSLP0")
@@ -251,6 +254,9 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
                     help="N > 1: strong (default) = the BASELINE domain cut into tiles; weak = N times as long a channel")
     ap.add_argument("--tiles", default=None, metavar="NPXxNPY", help="tile grid of the strong-scaling run (default: by N)")
+    ap.add_argument("--barotp", default="replicated", choices=["replicated", "decomposed"],
+                    help="tiles (N > 1 or --tiles): replicated = every rank gathers barotp's 2-D inputs once per step and solves "
+                         "the whole barotropic domain itself; decomposed = the reference's scheme, one exchange per substep pair")
     ap.add_argument("--rccl-self", action="store_true",
                     help="N=1 only: route the halo update through the RCCL transport (rank sends to itself) "
                          "to measure the exchange overhead of the N>1 path on one GPU")
@@ -283,7 +289,8 @@ def main():
     if (world > 1 and scaling == "strong") or args.tiles:       # --tiles 1x1 at N = 1: the same code path with one rank
         # BASELINE.json configs 3/4: the same domain, npx x npy tiles (bld/blom_dimensions:104-148), one per GPU.
         from blom_amd.tiles import TileLayout, scatter_to_tile
-        default_grid = {"channel": {2: (1, 2), 4: (2, 2), 8: (2, 4)}, "tnx2v1s": {2: (2, 1), 4: (2, 2), 8: (4, 2)}}
+        default_grid = {"channel": {2: (1, 2), 4: (2, 2), 8: (2, 4)}, "tnx2v1s": {2: (2, 1), 4: (2, 2), 8: (4, 2)},
+                        "tnx1v4s": {2: (2, 1), 4: (2, 2), 8: (4, 2)}}
         if args.tiles:
             npx, npy = (int(x) for x in args.tiles.lower().split("x"))
         else:
@@ -303,9 +310,16 @@ def main():
             if not nm.endswith("0"):
                 gpu.set(nm, v)
         scatter_to_tile(whole, gpu, layout, px, py)
+        # every rank solves the whole 2-D barotropic domain on a second context (no exchange inside barotp's substep loop)
+        glob = None
+        if args.barotp == "replicated":
+            from blom_amd.tiles import make_barotp_global
+            glob = make_barotp_global(whole, case, masks, device=local)
         whole.close()
         gpu.set("delt1", case.params["baclin"])
         gpu.rccl_init_2d(launch.share_unique_id(rccl_unique_id, env), rank, npx, npy)
+        if glob is not None:
+            gpu.rccl_attach_barotp_global(glob, layout.isizes, layout.jsizes)
     elif world > 1:
         # Weak scaling: the channel is made `world` times as long in i (its bathymetry repeated
         # with the tile's period) and cut into `world` tiles along i, one per GPU.  Every tile
@@ -404,11 +418,11 @@ def main():
                                 f"{args.config} {case.idm * world}x{case.jdm}x{case.kdm} as {world} tile(s) of "
                                 f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, ") +
                                f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr} "
-                               f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age'}), "
+                               f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age' if case.ntr == 1 else f'the default three + {case.ntr - 3} passive tracers'}), "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
                                f"full dyncore stage sequence incl. cmnfld2, eddtra and convec (gm, " +
                                (f"neutral slopes from cmnfld2 every step" if args.slopes == "live" else f"frozen slopes of amplitude {NSLP0:g}") + "); "
-                               "N>1: halos over RCCL send/recv; state_crc = xccrc(dp) ^ xccrc(u) of the whole domain, "
+                               "N>1: halos over RCCL send/recv" + (f", barotropic solve {args.barotp}" if layout is not None else "") + "; state_crc = xccrc(dp) ^ xccrc(u) of the whole domain, "
                                "the same for every N at equal --steps/--warmup" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
                    "eddtra_parity": "unpinned (mod_eddtra needs CVMix: the reference build lacks it; checked against the C restatement)",
                    "state_finite": finite, "tiles_bit_identical": len(set(crcs)) == 1,

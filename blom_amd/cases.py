@@ -9,6 +9,7 @@ BASELINE.json's configs:
   chan_s   20x24x6    small channel used by the parity tests
   chan_m   80x40x8    channel spanning several device tiles (kernel-variant tests)
   tnx2v1s  180x193x53 synthetic stand-in for the tnx2v1 tripolar production grid (nreg=2)
+  tnx1v4s  360x385x53 synthetic stand-in for the tnx1v4 grid (nreg=2); with ntr > 3 the extra tracers stand in for iHAMOCC's
   tri_s    24x20x6    small ocean with the arctic patch of the tripolar grids (nreg=2): closed in the south,
                       folded onto itself across the last row, periodic in i
   box_s    24x20x8    small closed basin with an island and a promontory coast
@@ -110,6 +111,9 @@ _DIMS = {
     # the reference's own test case restated from its generator routines, see fuk95_ref_case below
     "fuk95_ref": (156, 32, 12, 4, 650.0, 180.0, 6.0),
     "channel": (208, 512, 53, 1, 10.0e3, 900.0, 18.0),
+    # synthetic stand-in for the tnx1v4 production grid (BASELINE.json config 5; bld/tnx1v4/patch.input.32: 360 x 385, kdm 53
+    # for isopyc_bulkml, nreg = 2; baclin 3200 s, batrop 64 s): tnx2v1s' analytic continents at these dimensions
+    "tnx1v4s": (360, 385, 53, 2, 50.0e3, 3200.0, 64.0),
     # a channel of the size of ONE tile of the 2 x 4 decomposition of `channel` (bench.py --gpus 8): what a rank of that run
     # computes per step, for timing on one GPU (tools/); not a configuration of the reference
     "chan_t8": (104, 128, 53, 1, 10.0e3, 900.0, 18.0),
@@ -161,7 +165,7 @@ def _depth_for(name, idm, jdm, dx):
         d[0, :] = 0.0
         d[-1, :] = 0.0
         return d
-    if name == "tnx2v1s":
+    if name in ("tnx2v1s", "tnx1v4s"):
         x = (ii - 0.5) / idm
         y = (jj - 0.5) / jdm
         d = 3000.0 + 1500.0 * np.sin(2.0 * np.pi * x) * np.sin(np.pi * y) + 0.0 * (ii + jj)
@@ -474,6 +478,11 @@ def make_case(name, ntr=None, carve=None, **overrides):
         # in the _tk2 build it is the length-scale variable, in places below gls_psi_min = 1e-14 (phy/mod_tke.F90:62)
         trcs[1] = pad3((1.0e-15 if tk2 else 1.0e-9) * (1.0 + 0.5 * np.cos(2 * np.pi * x) * np.sin(4 * np.pi * y))[None] * (1.0 + 0.2 * k[:, None, None]))
         trcs[2] = pad3(trc)
+        # further tracers (ntr > 3): plain passive tracers, as the biogeochemical ones are to the dynamical core
+        # (trc/mod_tracers.F90:116-126: ntr = ... + ntrbgc), each with its own structure
+        for nt in range(3, ntr):
+            trcs[nt] = pad3((1.0 + 0.3 * np.sin(2 * np.pi * (x * (1 + nt % 3) + 0.1 * nt)) * np.cos(2 * np.pi * y * (1 + nt % 2)))[None]
+                            * (1.0 + 0.05 * nt + 0.1 * k[:, None, None]))
     ic = dict(dp=pad3(dp), temp=pad3(temp), saln=pad3(saln), sigma=pad3(sigma),
               sigmar=pad3(sigmar), trc=trcs)
     return Case(name=full_name, idm=idm, jdm=jdm, kdm=kdm, nreg=nreg, params=p, depth=depth,

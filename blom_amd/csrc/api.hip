@@ -87,6 +87,8 @@ int ctx_err_words(blomgpu_ctx *c) {
 }
 
 int ctx_check_errors(blomgpu_ctx *c) {
+  if (blomgpu_ctx *G = bt_global_ctx(c))                   // RCCL tiles: the barotropic solver's words live in its own context
+    if (ctx_check_errors(G)) { c->err = G->err; return 1; }
   if (!c->err_dev) return 0;
   int e[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost, c->stream));
@@ -172,7 +174,7 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
 int blomgpu_destroy(blomgpu_ctx *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (!c->stream_borrowed) (void)hipStreamSynchronize(c->stream);
   ctx_drop_graphs(c);
   for (int f = 0; f < NF_REAL; f++) (void)hipFree(c->h.f[f]);
   for (int f = 0; f < NF_INT; f++) (void)hipFree(c->h.m[f]);
@@ -187,7 +189,7 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  (void)hipStreamDestroy(c->stream);
+  if (!c->stream_borrowed) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -246,13 +248,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
-  if (s == "diapfl_v") { c->diapfl_v = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
-  if (s == "remap_v") { c->remap_v = v; return 0; }
-  if (s == "pbcor_v") { c->pbcor_v = v; return 0; }
-  if (s == "momtum_chunk") { c->momtum_chunk = v; return 0; }
   if (s == "live_slopes") { c->live_slopes = v; return 0; }
-  if (s == "momtum_v") { c->momtum_v = v; return 0; }
   if (s == "momtum_bs") { c->momtum_bs = v; return 0; }
   if (s == "momtum_order") { c->momtum_order = v; return 0; }
   if (s == "momtum_chunks_a") { c->momtum_chunks_a = v; return 0; }
@@ -521,15 +518,18 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
                               "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
                               "barotp", "pbcor2", "tmsmt2"};
   c->defer_checks = true;
+  c->in_sequence = true;
+  c->pbcor1_handed_over = c->pbcor2_handed_over = false;
   for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
     // eddtra_frozen: the eddy-induced fluxes umfltd.. stay as uploaded (the reference build of the oracle has no mod_eddtra;
     // tests pin advect/remap on non-zero fluxes this way)
     if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
-    if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; return rc; }
+    if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; c->in_sequence = false; return rc; }
   }
   c->defer_checks = false;
+  c->in_sequence = false;
   if (c->cmnfld1) return blomgpu_stage(c, "cmnfld1", m, n, mm, nn, k1m, k1n);     // phy/mod_blom_step.F90:233
   return 0;
 }

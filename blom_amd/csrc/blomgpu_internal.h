@@ -169,6 +169,7 @@ struct KTimer {
 struct blomgpu_ctx;
 struct TileGroup;            // in-process transport: several tiles (contexts) on one device, one host thread each
 struct RcclComm;             // one process per GPU, neighbour ncclSend/ncclRecv over xGMI
+struct BtGlobal;             // RCCL tiles: the barotropic solve replicated on every rank (comm_rccl.hip)
 struct Tiling {
   int npx = 1, npy = 1;      // uniform tile grid (mproc x nproc)
   int px = 0, py = 0;        // this tile
@@ -211,6 +212,11 @@ struct blomgpu_ctx {
   int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default
   hipGraphExec_t step_graph[2] = {nullptr, nullptr};
   int steps_done = 0;
+  BtGlobal *bt_global = nullptr; // RCCL tiles: barotp gathers its 2-D inputs and solves the global domain on a second context
+  bool stream_borrowed = false;  // this context runs on another context's stream (the global barotropic context of a tile)
+  bool in_sequence = false;      // blomgpu_step is running its stage sequence: a stage may hand data to the next one through the work space
+  bool pbcor2_handed_over = false;   // likewise pbcor2 (level m) for tmsmt2
+  bool pbcor1_handed_over = false;   // pbcor1 left S, T, tracers of the new level in the work space (slots N_S, N_T, N_TR): diffus starts there
   int steps_warm = 0;            // plain steps since the last option change (graph capture waits for 4)
   int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded
   int check_period = 8;          // steps between read-backs of the sticky stage error words in blomgpu_step
@@ -223,16 +229,10 @@ struct blomgpu_ctx {
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
-  int momtum_chunk = 0;      // layers per launch group of momtum's layer kernels (0: all)
   int live_slopes = 0;       // blomgpu_step: 1 = cmnfld2 computes nslpx/nslpy every step (stage_cmnfld.hip); 0 = they stay as uploaded
-  int momtum_v = 2;          // 2: row-marching fused layer kernels (stage_momtum_fused.hip), 1: one kernel per sweep
   int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major
   int momtum_bs = 0;         // lanes per workgroup of the fused kernels (0: 64, one wavefront)
   int momtum_chunks_a = 0, momtum_chunks_b = 0;   // j-chunks per layer of the two fused kernels (0: one round of workgroups)
-  int diapfl_v = 3;          // 3: col2 with DU levels' loads in flight (stage_diapfl_col3.hip), 2: traffic-lean column kernel
-                             // (stage_diapfl_col2.hip), 1: first version
-  int remap_v = 2;           // 2: gradient + flux sweep of remap in one LDS-tiled kernel (stage_remap_tile.hip), 1: separate kernels
-  int pbcor_v = 2;           // 2: fluxes + update of pbcor in one LDS-tiled kernel (stage_pbcor_tile.hip), 1: separate kernels
   int diapfl_du = 8;         // levels whose loads k_diapfl_column3 keeps in flight (2, 4, 8)
   int barotp_tile = 0;       // tile shape of the pair kernel, 100*TI + TJ (3216, 3208, 1608); 0: chosen from the tile count
   int barotp_fused = 1;      // 1: LDS-tiled substep pairs (stage_barotp_pair.hip), 0: one kernel per equation
@@ -293,7 +293,6 @@ int ctx_check_errors(blomgpu_ctx *);         // read back all error words, fail 
 int st_kfpla_halo(blomgpu_ctx *, int n);
 int st_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1090-1156
 int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1176-1196
-int diapfl_column2_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn, int tsel);  // stage_remap_tile.hip; tsel 0 all tiles, 1 those that read no halo point, 2 the others
 int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf);   // stage_pbcor_tile.hip
@@ -309,6 +308,8 @@ int st_crc_strips(blomgpu_ctx *, double *base, int nlev, int itype, unsigned *ou
 // locate the field (and level offset) a device pointer belongs to; returns field id or -1
 int ctx_locate_ptr(const blomgpu_ctx *, const double *p, size_t *offset);
 int rccl_xctilr(blomgpu_ctx *, double *base, int nlev, int mhl, int nhl);   // comm_rccl.hip
+int rccl_barotp_replicated(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // comm_rccl.hip
+blomgpu_ctx *bt_global_ctx(const blomgpu_ctx *);                              // the global barotropic context of a tile, or nullptr
 struct RcclLanded {          // received E/W strips left in the transport's buffers, layout [field][level][row][q]
   const double *from_west = nullptr, *from_east = nullptr;
   int has_w = 0, has_e = 0, per = 0, mhl = 0, nhl = 0, nlev = 0;

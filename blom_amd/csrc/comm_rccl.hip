@@ -261,6 +261,112 @@ int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, 
   return 0;
 }
 
+// ---- the barotropic solve replicated on every rank ---------------------------------------------------------------------
+// barotp (phy/mod_barotp.F90:330-1003) subcycles 2.5 lstep times per baroclinic step with one halo exchange per odd+even
+// pair; its substep kernel is bound by latency, not by the size of the domain (one CU per 32 x 16 tile, ~12 us per pair
+// whatever the tile count), so cutting its 2-D domain into one piece per GPU buys nothing and puts ~60 exchanges per step
+// on the critical path.  Instead every rank solves the WHOLE 2-D barotropic domain: the tiles bring the 2-D fields the
+// solver reads together on every rank (one grouped send/recv per step), each rank runs the single tile's
+// substep loop on a second context G that spans the global domain (kdm = 3: it holds 2-D fields), and takes its window of
+// the results, halo included.  No exchange inside the loop.  Bit-identity with the decomposed solve is the reference's
+// own guarantee (tiles compute redundantly into exchanged halos, so every tiling gives the single tile's bits).
+static const int kBtFields[] = {
+    F_uglue, F_vglue, F_umaxb, F_uminb, F_vmaxb, F_vminb, F_utotn, F_vtotn, F_pgfxm, F_pgfym, F_xixp, F_xixm, F_xiyp, F_xiym,
+    F_pgfxm_o, F_pgfym_o, F_xixp_o, F_xixm_o, F_xiyp_o, F_xiym_o, F_pb, F_pbu, F_pbv, F_ub, F_vb, F_ubflxs, F_vbflxs,
+    F_ubflxs_p, F_vbflxs_p, F_pb_p, F_pbu_p, F_pbv_p, F_ubcors_p, F_vbcors_p, F_ubflx, F_vbflx, F_pb_mn, F_ubflx_mn,
+    F_vbflx_mn, F_pvtrop, F_pvtrop_o};
+#define BT_MAXPLANES 96
+struct BtPlanes {
+  double *p[BT_MAXPLANES];
+};
+struct BtGlobal {
+  blomgpu_ctx *G = nullptr;
+  int nplanes = 0;
+  std::vector<int> i0, j0, ii, jj;       // window of every rank
+  std::vector<size_t> off;               // offset of rank q's block in the gather buffer (doubles)
+  double *buf = nullptr;                 // all ranks' blocks, [rank][plane][j][i]
+  int *geo_dev = nullptr;                // (i0, j0, ii, jj, offset/plane-stride) per rank for the unpack kernel
+  int maxpts = 0;
+};
+// every listed plane of tile T, halo included -> its block
+__global__ void k_btg_pack(const DevView *__restrict__ Vp, BtPlanes P, double *__restrict__ blk) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  blk[(size_t)blockIdx.y * V.nplane + t] = P.p[blockIdx.y][t];
+}
+// every rank's block -> the global planes of G (blockIdx.z = rank): a tile's interior points, and those of its halo
+// points that lie in the halo of the GLOBAL domain (fields whose halos other stages filled -- pb_p, pbu_p.. -- are read
+// there by the solver without another update, as on a single tile)
+__global__ void k_btg_unpack(const DevView *__restrict__ Gp, BtPlanes P, const double *__restrict__ buf, const int *__restrict__ geo,
+                             const size_t *__restrict__ offs) {
+  const DevView &G = *Gp;
+  const int q = blockIdx.z, i0 = geo[4 * q], j0 = geo[4 * q + 1], ii = geo[4 * q + 2], jj = geo[4 * q + 3];
+  const int ni = ii + 2 * NBDY, n = ni * (jj + 2 * NBDY);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = t % ni - (NBDY - 1), j = t / ni - (NBDY - 1);
+  const int gi = i0 + i, gj = j0 + j;
+  // a halo point of the tile is taken where it lies beyond the edge of the global domain in that direction and inside the
+  // tile's own range in the other (the corner pieces over a neighbour's rows / columns are that neighbour's to give)
+  const bool x_ok = (i >= 1 && i <= ii) || gi < 1 || gi > G.ii;
+  const bool y_ok = (j >= 1 && j <= jj) || gj < 1 || gj > G.jj;
+  if (!x_ok || !y_ok) return;
+  P.p[blockIdx.y][IDX(G, gi, gj)] = buf[offs[q] + (size_t)blockIdx.y * n + t];
+}
+// window of G (halo included) -> tile T
+__global__ void k_btg_window(const DevView *__restrict__ Vp, BtPlanes PT, BtPlanes PG, int gni) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int x = t % V.ni, y = t / V.ni;
+  PT.p[blockIdx.y][t] = PG.p[blockIdx.y][(size_t)(V.j0 + y) * gni + V.i0 + x];
+}
+
+blomgpu_ctx *bt_global_ctx(const blomgpu_ctx *c) { return c->bt_global ? c->bt_global->G : nullptr; }
+int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n, bool with_bounds);     // stage_barotp.hip
+int st_barotp_bounds(blomgpu_ctx *c, int m, int nn);
+
+int rccl_barotp_replicated(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  BtGlobal *B = c->bt_global;
+  blomgpu_ctx *G = B->G;
+  RcclComm *R = c->tiling.rccl;
+  const DevView &h = c->h;
+  hipStream_t st = c->stream;
+  // the solver's scalar options follow the tile's (set through the tile's context only)
+  if (memcmp(&G->h.P, &h.P, sizeof(Params)) != 0) { G->h.P = h.P; G->dirty = true; }
+  G->defer_checks = c->defer_checks;
+  ctx_sync_view(G);
+  if (int rc = st_barotp_bounds(c, m, nn)) return rc;        // :177-224: the one part of barotp that reads 3-D fields
+  BtPlanes PT, PG;
+  int np_ = 0;
+  for (int f : kBtFields)
+    for (int l = 0; l < c->nlev_real[f]; l++) {
+      PT.p[np_] = h.f[f] + (size_t)l * h.nplane;
+      PG.p[np_] = G->h.f[f] + (size_t)l * G->h.nplane;
+      np_++;
+    }
+  for (int x = np_; x < BT_MAXPLANES; x++) { PT.p[x] = PT.p[0]; PG.p[x] = PG.p[0]; }
+  const int me = R->rank, nr = R->nranks;
+  const int npts = h.nplane;
+  hipLaunchKernelGGL(k_btg_pack, dim3((npts + 255) / 256, np_), dim3(256), 0, st, c->d, PT, B->buf + B->off[me]);
+  if (nr > 1) {
+    ncclGroupStart();
+    for (int q = 0; q < nr; q++)
+      if (q != me) ncclSend(B->buf + B->off[me], (size_t)npts * np_, ncclDouble, q, R->comm, st);
+    for (int q = 0; q < nr; q++)
+      if (q != me) ncclRecv(B->buf + B->off[q], (size_t)(B->ii[q] + 2 * NBDY) * (B->jj[q] + 2 * NBDY) * np_, ncclDouble, q, R->comm, st);
+    ncclResult_t rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL barotropic gather: ") + ncclGetErrorString(rc));
+  }
+  hipLaunchKernelGGL(k_btg_unpack, dim3((B->maxpts + 255) / 256, np_, nr), dim3(256), 0, st, G->d, PG, B->buf, B->geo_dev,
+                     (const size_t *)(B->geo_dev + 4 * nr + (4 * nr) % 2));
+  if (int rc = st_barotp_on(G, m, n, mm, nn, k1m, k1n, false)) { c->err = G->err; return rc; }
+  hipLaunchKernelGGL(k_btg_window, dim3((h.nplane + 255) / 256, np_), dim3(256), 0, st, c->d, PT, PG, G->h.ni);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
   return rccl_xctilr_multi(c, &a, 1, nlev, mhl, nhl);
 }
@@ -317,8 +423,62 @@ int blomgpu_rccl_force_ns_exchange(blomgpu_ctx *c, int on) {
   c->tiling.rccl->force_ns = on;
   return 0;
 }
+// Replicated barotropic solve: G is a context of the GLOBAL domain (itdm x jtdm, kdm >= 3, same nreg, global masks and grid
+// metrics uploaded by the caller) on the same device; isizes[npx], jsizes[npy] are the widths / heights of the tile columns
+// and rows (bld/blom_dimensions:104-148).  From then on the tile's barotp gathers, solves on G and takes its window.
+int blomgpu_rccl_attach_barotp_global(blomgpu_ctx *c, blomgpu_ctx *G, const int *isizes, const int *jsizes) {
+  RcclComm *R = c->tiling.rccl;
+  const Tiling &T = c->tiling;
+  if (!R) return ctx_fail(c, "attach_barotp_global: no RCCL transport");
+  if (!G || G->h.ii != c->h.itdm || G->h.jj != c->h.jtdm || G->h.nreg != c->h.nreg || G->tiling.multi() || G->device != c->device)
+    return ctx_fail(c, "attach_barotp_global: the second context must span the global domain as a single tile on the same device");
+  BtGlobal *B = new BtGlobal();
+  B->G = G;
+  for (int f : kBtFields) B->nplanes += c->nlev_real[f];
+  if (B->nplanes > BT_MAXPLANES) { delete B; return ctx_fail(c, "attach_barotp_global: too many planes"); }
+  const int nr = T.npx * T.npy;
+  size_t off = 0;
+  std::vector<int> geo;
+  std::vector<size_t> offs;
+  for (int q = 0; q < nr; q++) {
+    const int qx = q % T.npx, qy = q / T.npx;
+    int i0 = 0, j0 = 0;
+    for (int x = 0; x < qx; x++) i0 += isizes[x];
+    for (int y = 0; y < qy; y++) j0 += jsizes[y];
+    B->i0.push_back(i0); B->j0.push_back(j0); B->ii.push_back(isizes[qx]); B->jj.push_back(jsizes[qy]);
+    B->off.push_back(off);
+    offs.push_back(off);
+    geo.insert(geo.end(), {i0, j0, isizes[qx], jsizes[qy]});
+    const int pts = (isizes[qx] + 2 * NBDY) * (jsizes[qy] + 2 * NBDY);       // a tile's planes travel with their halos
+    off += (size_t)pts * B->nplanes;
+    if (pts > B->maxpts) B->maxpts = pts;
+  }
+  if (B->i0[R->rank] != c->h.i0 || B->j0[R->rank] != c->h.j0 || B->ii[R->rank] != c->h.ii || B->jj[R->rank] != c->h.jj) {
+    delete B;
+    return ctx_fail(c, "attach_barotp_global: the tile sizes do not give this rank's window");
+  }
+  HIPCHK(c, hipMalloc((void **)&B->buf, off * sizeof(double)));
+  const size_t ngeo = 4 * (size_t)nr + (4 * nr) % 2;          // keeps the size_t offsets behind it 8-byte aligned
+  HIPCHK(c, hipMalloc((void **)&B->geo_dev, ngeo * sizeof(int) + nr * sizeof(size_t)));
+  HIPCHK(c, hipMemcpy(B->geo_dev, geo.data(), geo.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(B->geo_dev + ngeo, offs.data(), nr * sizeof(size_t), hipMemcpyHostToDevice));
+  // one stream for both contexts: the gather, the solve and the window copy are ordered by it
+  HIPCHK(c, hipStreamSynchronize(G->stream));
+  if (!G->stream_borrowed) (void)hipStreamDestroy(G->stream);
+  G->stream = c->stream;
+  G->stream_borrowed = true;
+  c->bt_global = B;
+  return 0;
+}
 int blomgpu_rccl_finalize(blomgpu_ctx *c) {
   RcclComm *R = c->tiling.rccl;
+  if (c->bt_global) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->bt_global->buf);
+    (void)hipFree(c->bt_global->geo_dev);
+    delete c->bt_global;
+    c->bt_global = nullptr;
+  }
   if (!R) return 0;
   (void)hipStreamSynchronize(c->stream);
   if (c->xstream) (void)hipStreamSynchronize(c->xstream);

@@ -1,4 +1,4 @@
-// Shared device helpers of the diapfl kernels (stage_diapfl.hip, stage_diapfl_col2.hip).
+// Shared device helpers of the diapfl kernels (stage_diapfl.hip, stage_diapfl_col3.hip).
 #pragma once
 #include "blomgpu_internal.h"
 #include "eos.h"

@@ -103,25 +103,37 @@ __global__ void k_xctilr_arctic(const DevView *__restrict__ Vp, double *__restri
 // row jtdm), and read straight from the interior of the tile that owns that point.  With peer-mapped
 // pointers the very same gather works across GPUs; no strip is packed or staged.
 #define XCT_MAXTILES 64
+#define XCT_MAXDIM 16
 struct TileTab {
   double *p[XCT_MAXTILES];      // the array being updated, in every tile (index py*npx + px)
+  int xoff[XCT_MAXDIM + 1];     // tile column q owns the global columns xoff[q]+1 .. xoff[q+1]   (bld/blom_dimensions:104-148:
+  int yoff[XCT_MAXDIM + 1];     // tile rows likewise                                               tiles need not be equal)
 };
-__global__ void k_xctilr_arctic_tiles(const DevView *__restrict__ Vp, double *__restrict__ a, TileTab tab, int npx, int npy,
-                                      int px, int py, int nlev, int mhl, int nhl, int itype) {
+// nreg decides what lies beyond the edges of the global domain: periodic wrap, land (vland), or -- nreg = 2 -- the fold
+// across row jtdm (arctic = 1).  Tiles of unequal size: the owner of a global point is found in xoff / yoff, and its
+// padded plane has its own row length and level stride.
+__global__ void k_xctilr_tiles(const DevView *__restrict__ Vp, double *__restrict__ a, TileTab tab, int npx, int npy,
+                               int px, int py, int nlev, int mhl, int nhl, int itype, int ew_per, int ns_per, int arctic) {
   const DevView &V = *Vp;
-  const int ii = V.ii, jj = V.jj, itdm = npx * ii, jtdm = npy * jj;
+  const int ii = V.ii, jj = V.jj, itdm = tab.xoff[npx], jtdm = tab.yoff[npy];
   const int g = itype % 10;
   const double sgn = itype > 10 ? -1. : 1.;
   const int wrow = ii + 2 * mhl, nrow = jj + 2 * nhl;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= wrow * nrow) return;
   const int i = t % wrow + 1 - mhl, j = t / wrow + 1 - nhl;
-  const int ig = px * ii + i, jg = py * jj + j;
-  const int iw = ig < 1 ? ig + itdm : (ig > itdm ? ig - itdm : ig);      // periodic in i
+  const int ig = tab.xoff[px] + i, jg = tab.yoff[py] + j;
   bool land = false, flip = false;
+  int iw = ig;
+  if (ig < 1 || ig > itdm) {
+    if (ew_per) iw = ig < 1 ? ig + itdm : ig - itdm;
+    else land = true;
+  }
   int is = iw, js = jg;
-  if (jg < 1) land = true;
-  else if (jg >= jtdm) {
+  if (jg < 1) {
+    if (ns_per) js = jg + jtdm;
+    else land = true;
+  } else if (arctic && jg >= jtdm) {
     const int d = jg - jtdm;
     if (g == 1 || g == 3) {                                              // p-, u-grid
       is = g == 1 ? itdm - (iw - 1) % itdm : (itdm - (iw - 1)) % itdm + 1;
@@ -132,14 +144,24 @@ __global__ void k_xctilr_arctic_tiles(const DevView *__restrict__ Vp, double *__
       js = jtdm - d;
       flip = true;
     }
+  } else if (jg > jtdm) {
+    if (ns_per) js = jg - jtdm;
+    else land = true;
   }
   if (!land && !flip && i >= 1 && i <= ii && j >= 1 && j <= jj) return;  // interior point, not a target
-  const int qx = (is - 1) / ii, qy = (js - 1) / jj;
+  int qx = 0, qy = 0;
+  if (!land) {
+    while (qx + 1 < npx && is > tab.xoff[qx + 1]) qx++;
+    while (qy + 1 < npy && js > tab.yoff[qy + 1]) qy++;
+  }
   const double *src = land ? a : tab.p[qy * npx + qx];
-  const size_t dst = IDX(V, i, j), so = land ? 0 : (size_t)IDX(V, is - qx * ii, js - qy * jj);
+  const int sni = tab.xoff[qx + 1] - tab.xoff[qx] + 2 * NBDY, snj = tab.yoff[qy + 1] - tab.yoff[qy] + 2 * NBDY;
+  const size_t snp = (size_t)sni * snj;
+  const size_t dst = IDX(V, i, j);
+  const size_t so = land ? 0 : (size_t)(is - tab.xoff[qx] + NBDY - 1) + (size_t)sni * (js - tab.yoff[qy] + NBDY - 1);
   for (int k = blockIdx.y; k < nlev; k += gridDim.y) {
-    const size_t o = (size_t)k * V.nplane;
-    a[dst + o] = land ? V.P.vland : (flip ? sgn * src[so + o] : src[so + o]);
+    const double v = land ? V.P.vland : (flip ? sgn * src[so + (size_t)k * snp] : src[so + (size_t)k * snp]);
+    a[dst + (size_t)k * V.nplane] = v;
   }
 }
 
@@ -223,12 +245,53 @@ int ctx_locate_ptr(const blomgpu_ctx *c, const double *p, size_t *offset) {
     const size_t n = (size_t)c->nlev_real[f] * c->h.nplane;
     if (p >= b && p < b + n) { *offset = (size_t)(p - b); return f; }
   }
+  // the kk-level work space (stages that hand their result to the next one through it update its halos too): id NF_REAL
+  const size_t nw = (size_t)c->h.nwk * c->h.kk * c->h.nplane;
+  if (c->h.wk && p >= c->h.wk && p < c->h.wk + nw) { *offset = (size_t)(p - c->h.wk); return NF_REAL; }
   return -1;
 }
+static inline double *located_base(const blomgpu_ctx *c, int fid) { return fid == NF_REAL ? c->h.wk : c->h.f[fid]; }
 
 // closed / periodic rule of the global domain in each direction (phy/mod_xc.F90:4378,4400)
 static inline bool ew_periodic(int nreg) { return !(nreg == 0 || nreg == 4); }
 static inline bool ns_periodic(int nreg) { return nreg > 2; }
+
+// tiles of one process (TileGroup): every target is read from the interior of the tile that owns its source point
+// fold: apply the arctic rule across row jtdm (otherwise the domain ends in land or wraps there, by nreg)
+static int xctilr_group(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl, int itype, bool fold) {
+  const DevView &h = c->h;
+  const Tiling &T = c->tiling;
+  TileGroup *G = T.group;
+  if (T.npx * T.npy > XCT_MAXTILES || T.npx > XCT_MAXDIM || T.npy > XCT_MAXDIM) return ctx_fail(c, "xctilr: too many tiles for the in-process gather");
+  if (fold && T.npx > 1 && T.npx % 2) return ctx_fail(c, "xctilr: the arctic patch needs an even number of tile columns (phy/mod_xc.F90:1600-1603)");
+  if (nlev <= 0) return 0;
+  size_t off = 0;
+  const int fid = ctx_locate_ptr(c, a, &off);
+  if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
+  // a level offset inside the owner's array: its planes have their own size
+  const size_t lev = off / h.nplane;
+  if (off % h.nplane) return ctx_fail(c, "xctilr: pointer is not the start of a plane");
+  TileTab tab;
+  for (int q = 0; q < XCT_MAXTILES; q++) {
+    if (q >= T.npx * T.npy) { tab.p[q] = nullptr; continue; }
+    const blomgpu_ctx *o = G->tiles[(size_t)q];
+    tab.p[q] = located_base(o, fid) + lev * o->h.nplane;
+  }
+  for (int q = 0; q <= XCT_MAXDIM; q++) tab.xoff[q] = tab.yoff[q] = 0;
+  for (int q = 0; q < T.npx; q++) { const DevView &o = G->tiles[(size_t)q]->h; tab.xoff[q] = o.i0; tab.xoff[q + 1] = o.i0 + o.ii; }
+  for (int q = 0; q < T.npy; q++) { const DevView &o = G->tiles[(size_t)q * T.npx]->h; tab.yoff[q] = o.j0; tab.yoff[q + 1] = o.j0 + o.jj; }
+  if (tab.xoff[T.npx] != h.itdm || tab.yoff[T.npy] != h.jtdm) return ctx_fail(c, "xctilr: the tiles of the group do not cover the global domain");
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // every tile's interior must be complete before anyone gathers
+  pthread_barrier_wait(&G->bar);
+  const int nt = (h.ii + 2 * mhl) * (h.jj + 2 * nhl);
+  dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
+  hipLaunchKernelGGL(k_xctilr_tiles, grid, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.npy, T.px, T.py, nlev, mhl, nhl, itype,
+                     ew_periodic(h.nreg) ? 1 : 0, ns_periodic(h.nreg) ? 1 : 0, fold ? 1 : 0);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // ... and nobody may go on modifying its interior before all have read
+  pthread_barrier_wait(&G->bar);
+  return 0;
+}
 
 // the ordinary update: E/W and N/S neighbours (or the tile itself), land beyond closed boundaries
 static int xctilr_plain(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
@@ -237,37 +300,18 @@ static int xctilr_plain(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
   const int ntarget = 2 * nhl * h.ii + 2 * mhl * (h.jj + 2 * nhl);
   if (ntarget == 0 || nlev <= 0) return 0;
   if (T.rccl) return rccl_xctilr(c, a, nlev, mhl, nhl);
-  if (!T.group && (h.itdm != h.ii || h.jtdm != h.jj))
+  if (T.group) return xctilr_group(c, a, nlev, mhl, nhl, 1, false);
+  if (h.itdm != h.ii || h.jtdm != h.jj)
     return ctx_fail(c, "xctilr: this context is one tile of a larger domain but no halo transport is attached");
   HaloSrc S;
-  TileGroup *G = T.group;
-  size_t off = 0;
-  int fid = -1;
-  if (G) {
-    fid = ctx_locate_ptr(c, a, &off);
-    if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
-  }
   for (int dy = -1; dy <= 1; dy++)
     for (int dx = -1; dx <= 1; dx++) {
-      int qx = T.px + dx, qy = T.py + dy;
-      bool land = false;
-      if (qx < 0 || qx >= T.npx) { if (ew_periodic(h.nreg)) qx = (qx + T.npx) % T.npx; else land = true; }
-      if (qy < 0 || qy >= T.npy) { if (ns_periodic(h.nreg)) qy = (qy + T.npy) % T.npy; else land = true; }
-      if (land) S.p[dy + 1][dx + 1] = nullptr;
-      else if (!G) S.p[dy + 1][dx + 1] = a;                             // single tile: wraps onto itself
-      else S.p[dy + 1][dx + 1] = G->tiles[(size_t)qy * G->npx + qx]->h.f[fid] + off;
+      const bool land = (dx != 0 && !ew_periodic(h.nreg)) || (dy != 0 && !ns_periodic(h.nreg));
+      S.p[dy + 1][dx + 1] = land ? nullptr : a;                          // single tile: wraps onto itself
     }
-  if (G) {                     // every tile's interior must be complete before anyone gathers
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    pthread_barrier_wait(&G->bar);
-  }
   dim3 grid((ntarget + 255) / 256, nlev > 64 ? 64 : nlev);
   hipLaunchKernelGGL(k_xctilr_gather, grid, dim3(256), 0, c->stream, c->d, a, S, nlev, mhl, nhl);
   HIPCHK(c, hipGetLastError());
-  if (G) {                     // ... and nobody may go on modifying its interior before all have read
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    pthread_barrier_wait(&G->bar);
-  }
   return 0;
 }
 
@@ -355,29 +399,7 @@ int st_xctilr(blomgpu_ctx *c, double *base, int l1, int ld, int mh, int nh, int 
   double *a = base + (size_t)(l1 - 1) * h.nplane;
   const Tiling &T = c->tiling;
   if (h.nreg == 2 && nlev > 0 && (T.rccl || (T.group && c->arctic_strips))) return xctilr_arctic_strips(c, a, nlev, mhl, nhl, itype);
-  if (h.nreg == 2 && T.group) {
-    // decomposed arctic domain, all tiles in this process: global gather through the tile pointer table
-    TileGroup *G = T.group;
-    if (T.npx * T.npy > XCT_MAXTILES) return ctx_fail(c, "xctilr: too many tiles for the arctic gather");
-    if (T.npx > 1 && T.npx % 2) return ctx_fail(c, "xctilr: the arctic patch needs an even number of tile columns (phy/mod_xc.F90:1600-1603)");
-    if (nlev <= 0) return 0;
-    size_t off = 0;
-    const int fid = ctx_locate_ptr(c, a, &off);
-    if (fid < 0) return ctx_fail(c, "xctilr: pointer does not belong to a registered field");
-    TileTab tab;
-    for (int q = 0; q < XCT_MAXTILES; q++)
-      tab.p[q] = q < T.npx * T.npy ? G->tiles[(size_t)q]->h.f[fid] + off : nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    pthread_barrier_wait(&G->bar);
-    const int nt = (h.ii + 2 * mhl) * (h.jj + 2 * nhl);
-    dim3 grid((nt + 255) / 256, nlev > 64 ? 64 : nlev);
-    hipLaunchKernelGGL(k_xctilr_arctic_tiles, grid, dim3(256), 0, c->stream, c->d, a, tab, T.npx, T.npy, T.px, T.py,
-                       nlev, mhl, nhl, itype);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    pthread_barrier_wait(&G->bar);
-    return 0;
-  }
+  if (h.nreg == 2 && T.group) return xctilr_group(c, a, nlev, mhl, nhl, itype, true);   // decomposed arctic domain, all tiles in this process
   if (h.nreg == 2) {
     if (nlev <= 0) return 0;
     const int nt = (2 * nhl + 1) * (h.ii + 2 * mhl) + 2 * mhl * (h.jj - 1);

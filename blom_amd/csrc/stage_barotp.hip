@@ -315,15 +315,27 @@ int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *w
                    int do_odd, int do_even, int src, int tsel, RcclLanded *rim);
 int bt_pair_halo_landed(blomgpu_ctx *c, int set, RcclLanded *landed);
 
+int st_barotp_bounds(blomgpu_ctx *c, int m, int nn) {
+  hipLaunchKernelGGL(k_bt_bounds, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn);
+  return 0;
+}
+int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n, bool with_bounds);
 int st_barotp(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  TimeScope ts(c, "barotp");
+  // RCCL tiles with a global barotropic context attached: gather, solve the whole 2-D domain here, take the window
+  if (c->tiling.rccl && c->bt_global) return rccl_barotp_replicated(c, m, n, mm, nn, k1m, k1n);
+  return st_barotp_on(c, m, n, mm, nn, k1m, k1n, true);
+}
+// with_bounds = false: the velocity bounds and wave-breaking coefficients (:177-224, the part that reads 3-D fields) are
+// already in umaxb.., uglue.. (the global barotropic context of RCCL tiles holds no 3-D state)
+int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n, bool with_bounds) {
   (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
   const size_t np = h.nplane;
   const int ii = h.ii, jj = h.jj, lstep = h.P.lstep;
   if (lstep < 2 || lstep % 2) return ctx_fail(c, "barotp: lstep must be even (phy/mod_time.F90:137-139)");
   const dim3 g = plane_grid(h), b(256);
-  TimeScope ts(c, "barotp");
-  hipLaunchKernelGGL(k_bt_bounds, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn);
+  if (with_bounds) hipLaunchKernelGGL(k_bt_bounds, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn);
   hipLaunchKernelGGL(k_bt_pvtrop_old, g, b, 0, c->stream, c->d, n);
   hipLaunchKernelGGL(k_bt_pvtrop, g, b, 0, c->stream, c->d, n);
   // :271-285

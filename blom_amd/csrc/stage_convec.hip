@@ -22,7 +22,7 @@
   const size_t c = t_;                                                     \
   (void)i; (void)j; (void)c
 
-#define MAXTR 8
+#define MAXTR 64   // tracer sums of a column: dynamically indexed (private memory), any tracer count up to this
 enum { CV_UN = 0 };   // work field: remapped velocity column
 
 __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict__ Vp, int n, int nn, int *errflag) {

@@ -428,6 +428,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
     //      thickness update :572-576 (which only reads fluxes) ------------------------------------
     {
       const bool interior = kfpl <= kmax;
+      const bool more_tracers = ntr > MAXTR;               // tracers beyond the first MAXTR: same system, coefficients from the work space
       double ctd = 0., bitd = 1., g = 0.;
       const int km1 = kmin - 1 > 1 ? kmin - 1 : 1;
       double s_prev = ST(saln, km1), t_prev = ST(temp, km1);
@@ -462,6 +463,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
         ctd = -fl * q;
         const double dtd = dk * q;
         bitd = 1. / (1. - atd * g);
+        if (more_tracers) { W(E_R, pos) = dtd; W(E_T, pos) = atd; W(E_F, pos) = bitd; }   // the solve's slots are free by now
         s_prev = (dtd * b3[u] - atd * s_prev) * bitd;
         t_prev = (dtd * b4[u] - atd * t_prev) * bitd;
         ST(saln, lay) = s_prev;
@@ -510,6 +512,34 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
         g_next = b0[u];
        }
       }
+      // the tracers beyond the first MAXTR, MAXTR at a time: the same two sweeps with the stored coefficients
+      for (int nt0 = MAXTR; nt0 < ntr; nt0 += MAXTR) {
+        double xp[MAXTR];
+#pragma unroll
+        for (int b = 0; b < MAXTR; b++) xp[b] = nt0 + b < ntr ? TRC(nt0 + b, km1) : 0.;
+        for (int pos = kmin; pos <= kmax; pos++) {
+          const int lay = pos == kmin ? 1 : (pos == kmin + 1 ? 2 : pos);
+          const double dtd = W(E_R, pos), atd = W(E_T, pos), bi = W(E_F, pos);
+          double xv[MAXTR];
+#pragma unroll
+          for (int b = 0; b < MAXTR; b++) xv[b] = nt0 + b < ntr ? TRC(nt0 + b, lay) : 0.;
+#pragma unroll
+          for (int b = 0; b < MAXTR; b++)
+            if (nt0 + b < ntr) { xp[b] = (dtd * xv[b] - atd * xp[b]) * bi; TRC(nt0 + b, lay) = xp[b]; }
+        }
+        double gn = g;
+        for (int pos = kmax - 1; pos >= kmin; pos--) {
+          const int lay = pos == kmin ? 1 : (pos == kmin + 1 ? 2 : pos);
+          const double gp = W(E_GTD, pos);
+          double xv[MAXTR];
+#pragma unroll
+          for (int b = 0; b < MAXTR; b++) xv[b] = nt0 + b < ntr ? TRC(nt0 + b, lay) : 0.;
+#pragma unroll
+          for (int b = 0; b < MAXTR; b++)
+            if (nt0 + b < ntr) { xp[b] = xv[b] - gn * xp[b]; TRC(nt0 + b, lay) = xp[b]; }
+          gn = gp;
+        }
+      }
     }
     // dens is the one work array the reference does not move with the mixed layer (:159-172): when the
     // column has no interior mass (kmax = kmin+1) position kmin+1 is not re-evaluated by the sweep
@@ -549,6 +579,11 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
         for (int nt = 0; nt < MAXTR; nt++)
           if (nt < ntr) TRC(nt, k) = trf[nt];
       }
+    }
+    for (int nt = MAXTR; nt < ntr; nt++) {
+      const double xf = TRC(nt, kfpl), xm = TRC(nt, kmax);
+      for (int k = 3; k <= kfpl - 1; k++) TRC(nt, k) = xf;
+      for (int k = kmax + 1; k <= kk; k++) TRC(nt, k) = xm;
     }
     for (int k0 = kmax + 1; k0 <= kk; k0 += 2 * DU) {
       double a0[2 * DU];
@@ -603,7 +638,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
 
 int diapfl_column3_launch(blomgpu_ctx *c, int n, int nn, int *errflag) {
   const DevView &h = c->h;
-  if (h.ntr > MAXTR || E_NSLOT > h.nwk) return ctx_fail(c, "diapfl: more than 4 tracers / work space too small");
+  if (E_NSLOT > h.nwk) return ctx_fail(c, "diapfl: work space too small");
   const dim3 g = plane_grid(h, 1, 64);
   if ((size_t)g.x * (h.kk + 1) * WNS * 64 > (size_t)h.nwk * h.kk * h.nplane) return ctx_fail(c, "diapfl: work space too small");
   if (c->diapfl_du == 8) hipLaunchKernelGGL(k_diapfl_column3<8>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);

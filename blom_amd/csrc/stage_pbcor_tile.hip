@@ -21,7 +21,6 @@
 #define EPSILP 1.e-12
 #define DPEPS1 1.e-5   // phy/mod_pbcor.F90:58
 #define DPEPS2 1.e-7   // phy/mod_pbcor.F90:59
-#define MAXTR 4
 
 #define PT_TW 32
 #define PT_TH 8
@@ -42,17 +41,18 @@
 #define MU(m) (((m) >> 1) & 1)
 #define MV(m) (((m) >> 2) & 1)
 
+#define PT_TB 4                    // tracers per batch: any number of tracers passes through the same PT_TB LDS slots
+
 struct FaceFlux {
-  double f, f2, f3, ftr[MAXTR];
+  double f, f2, f3;
+  int up;                          // tile index of the upstream cell
 };
 
 // flux through a face with transport tot from the upstream cell at index up of the tile / plane index cup;
 // k_pbc_flux, mod_pbcor.F90:246-275 resp. :592-621
-__device__ inline void face_flux(const DevView &V, const double *sc, int ntr, bool wet, double tot, int up, size_t cup, double pbot_up,
+__device__ inline void face_flux(const DevView &V, const double *sc, bool wet, double tot, int up, size_t cup, double pbot_up,
                                  double pbt, int k, FaceFlux &F) {
-  F.f = 0.; F.f2 = 0.; F.f3 = 0.;
-#pragma unroll
-  for (int nt = 0; nt < MAXTR; nt++) F.ftr[nt] = 0.;
+  F.f = 0.; F.f2 = 0.; F.f3 = 0.; F.up = up;
   if (!wet) return;
   if (V.P.bmcmth == 0) F.f = tot * sc[up] / pbot_up;
   else {
@@ -61,14 +61,11 @@ __device__ inline void face_flux(const DevView &V, const double *sc, int ntr, bo
   }
   F.f2 = F.f * sc[PT_LN + up];
   F.f3 = F.f * sc[2 * PT_LN + up];
-#pragma unroll
-  for (int nt = 0; nt < MAXTR; nt++)
-    if (nt < ntr) F.ftr[nt] = F.f * sc[(3 + nt) * PT_LN + up];
 }
 
 __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ Vp, int which, int offc, int offf, int ntx) {
   const DevView &V = *Vp;
-  HIP_DYNAMIC_SHARED(double, sc)                             // (3 + ntr) x PT_LN: dp, saln, temp, tracers
+  __shared__ double sc[(3 + PT_TB) * PT_LN];                 // dp, saln, temp, one batch of tracers
   unsigned bx_, by_;
   xcd_block(bx_, by_);
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
@@ -77,16 +74,18 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
   const double *f_dp = V.f[F_dp] + okc, *f_s = V.f[F_saln] + okc, *f_t = V.f[F_temp] + okc, *f_tr = V.f[F_trc] + okc;
 
   // ---- phase 0 ---------------------------------------------------------------------------------------------------
-  double sv[2][3 + MAXTR];
+  double sv[2][3 + PT_TB];
+  size_t csr[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int m = t + r * PT_NT;
     const int xs = x0 - 1 + m % PT_LW, ys = y0 - 1 + m / PT_LW;
     const bool in = m < PT_LN && xs >= 0 && xs < ni && ys >= 0 && ys < nj;
     const size_t cs = in ? (size_t)ys * ni + xs : 0;
+    csr[r] = cs;
     sv[r][0] = f_dp[cs]; sv[r][1] = f_s[cs]; sv[r][2] = f_t[cs];
 #pragma unroll
-    for (int nt = 0; nt < MAXTR; nt++) sv[r][3 + nt] = nt < ntr ? f_tr[cs + (size_t)nt * 2 * V.kk * np] : 0.;
+    for (int nt = 0; nt < PT_TB; nt++) sv[r][3 + nt] = nt < ntr ? f_tr[cs + (size_t)nt * 2 * V.kk * np] : 0.;
   }
   const int lx = t % PT_TW, ly = t / PT_TW;
   const int x = x0 + lx, y = y0 + ly;
@@ -113,19 +112,18 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
     const int m = t + r * PT_NT;
     if (m < PT_LN) {
 #pragma unroll
-      for (int s = 0; s < 3 + MAXTR; s++)
-        if (s < 3 + ntr) sc[s * PT_LN + m] = sv[r][s];
+      for (int s = 0; s < 3 + PT_TB; s++) sc[s * PT_LN + m] = sv[r][s];
     }
   }
   __syncthreads();
-  if (!live) return;
 
   // ---- phase 1 ---------------------------------------------------------------------------------------------------
   // faces of the reference's loops: u-faces at j = 1..jj, i = 1..ii+1; v-faces at j = 1..jj+1, i = 1..ii
-  const bool uw = j <= V.jj && MU(mp_c), vs = i <= V.ii && MV(mp_c);
-  FaceFlux W, S;
-  face_flux(V, sc, ntr, uw, ut_c, ut_c > 0. ? q - 1 : q, ut_c > 0. ? c - 1 : c, ut_c > 0. ? pb_w : pb_c, pbut_c, k, W);
-  face_flux(V, sc, ntr, vs, vt_c, vt_c > 0. ? q - PT_LW : q, vt_c > 0. ? c - ni : c, vt_c > 0. ? pb_s : pb_c, pbvt_c, k, S);
+  const bool uw = live && j <= V.jj && MU(mp_c), vs = live && i <= V.ii && MV(mp_c);
+  const bool upd = live && j <= V.jj && i <= V.ii && MP(mp_c);
+  FaceFlux W, S, E, N;
+  face_flux(V, sc, uw, ut_c, ut_c > 0. ? q - 1 : q, ut_c > 0. ? c - 1 : c, ut_c > 0. ? pb_w : pb_c, pbut_c, k, W);
+  face_flux(V, sc, vs, vt_c, vt_c > 0. ? q - PT_LW : q, vt_c > 0. ? c - ni : c, vt_c > 0. ? pb_s : pb_c, pbvt_c, k, S);
   if (uw) {                                                  // :262-264, :608-610
     *o_uf = uf_o + W.f;
     *o_us = us_o + W.f2;
@@ -136,48 +134,77 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
     *o_vs = vs_o + S.f2;
     *o_vt = vt_o + S.f3;
   }
-  if (j > V.jj || i > V.ii || !MP(mp_c)) return;
-  FaceFlux E, N;
-  face_flux(V, sc, ntr, MU(mp_e), ut_e, ut_e > 0. ? q : q + 1, ut_e > 0. ? c : e, ut_e > 0. ? pb_c : pb_e, pbut_e, k, E);
-  face_flux(V, sc, ntr, MV(mp_n), vt_n, vt_n > 0. ? q : q + PT_LW, vt_n > 0. ? c : nb, vt_n > 0. ? pb_c : pb_n, pbvt_n, k, N);
+  face_flux(V, sc, upd && MU(mp_e), ut_e, ut_e > 0. ? q : q + 1, ut_e > 0. ? c : e, ut_e > 0. ? pb_c : pb_e, pbut_e, k, E);
+  face_flux(V, sc, upd && MV(mp_n), vt_n, vt_n > 0. ? q : q + PT_LW, vt_n > 0. ? c : nb, vt_n > 0. ? pb_c : pb_n, pbvt_n, k, N);
   // k_pbc_update, :339-361 resp. :671-692
-  const double dv = E.f - W.f + N.f - S.f;
-  const double dv2 = E.f2 - W.f2 + N.f2 - S.f2;
-  const double dv3 = E.f3 - W.f3 + N.f3 - S.f3;
-  double dpo = sc[q];
-  const double so = sc[PT_LN + q], to = sc[2 * PT_LN + q];
-  if (which == 1) {
-    const double dpn = fmax2(0., dpo - dv * s2i);
-    dpo = dpo + DPEPS1;
-    const double dpni = 1. / (dpn + DPEPS1);
-    WK(V, N_S)[c + ok] = (dpo * so - dv2 * s2i) * dpni;
-    WK(V, N_T)[c + ok] = (dpo * to - dv3 * s2i) * dpni;
+  double dpo = sc[q], dpni = 0.;
+  if (upd) {
+    const double dv = E.f - W.f + N.f - S.f;
+    const double dv2 = E.f2 - W.f2 + N.f2 - S.f2;
+    const double dv3 = E.f3 - W.f3 + N.f3 - S.f3;
+    const double so = sc[PT_LN + q], to = sc[2 * PT_LN + q];
+    if (which == 1) {
+      const double dpn = fmax2(0., dpo - dv * s2i);
+      dpo = dpo + DPEPS1;
+      dpni = 1. / (dpn + DPEPS1);
+      WK(V, N_S)[c + ok] = (dpo * so - dv2 * s2i) * dpni;
+      WK(V, N_T)[c + ok] = (dpo * to - dv3 * s2i) * dpni;
+      WK(V, N_DP)[c + ok] = dpn < DPEPS2 ? 0. : dpn;
+    } else {
+      double dpn = dpo - s2i * dv;
+      dpni = 1. / dpn;
+      const double sn = (dpo * so - s2i * dv2) * dpni;
+      const double tn = (dpo * to - s2i * dv3) * dpni;
+      WK(V, N_S)[c + ok] = sn;
+      WK(V, N_T)[c + ok] = tn;
+      V.f[F_sigma][c + (size_t)(k + offc) * np] = eos::sig(V.P, tn, sn);
+      dpn = dpn - EPSILP;
+      WK(V, N_DP)[c + ok] = dpn < DPEPS2 ? 0. : dpn;
+    }
+  }
+
+  // ---- phase 2: the tracers, PT_TB at a time through the same LDS slots (the first batch came in with phase 0) ----------
+  for (int nt0 = 0; nt0 < ntr; nt0 += PT_TB) {
+    if (nt0 > 0) {
+      double tv[2][PT_TB];
 #pragma unroll
-    for (int nt = 0; nt < MAXTR; nt++)
-      if (nt < ntr && !trc_skip_adv(V.P, nt + 1))             // :353-355 (pbcor2, :684, has no such test)
-        WK(V, N_TR(nt))[c + ok] = (dpo * sc[(3 + nt) * PT_LN + q] - (E.ftr[nt] - W.ftr[nt] + N.ftr[nt] - S.ftr[nt]) * s2i) * dpni;
-    WK(V, N_DP)[c + ok] = dpn < DPEPS2 ? 0. : dpn;
-  } else {
-    double dpn = dpo - s2i * dv;
-    const double dpni = 1. / dpn;
-    const double sn = (dpo * so - s2i * dv2) * dpni;
-    const double tn = (dpo * to - s2i * dv3) * dpni;
-    WK(V, N_S)[c + ok] = sn;
-    WK(V, N_T)[c + ok] = tn;
+      for (int r = 0; r < 2; r++)
 #pragma unroll
-    for (int nt = 0; nt < MAXTR; nt++)
-      if (nt < ntr)
-        WK(V, N_TR(nt))[c + ok] = (dpo * sc[(3 + nt) * PT_LN + q] - (E.ftr[nt] - W.ftr[nt] + N.ftr[nt] - S.ftr[nt]) * s2i) * dpni;
-    V.f[F_sigma][c + (size_t)(k + offc) * np] = eos::sig(V.P, tn, sn);
-    dpn = dpn - EPSILP;
-    WK(V, N_DP)[c + ok] = dpn < DPEPS2 ? 0. : dpn;
+        for (int b = 0; b < PT_TB; b++) tv[r][b] = nt0 + b < ntr ? f_tr[csr[r] + (size_t)(nt0 + b) * 2 * V.kk * np] : 0.;
+      __syncthreads();                                       // the previous batch has been read
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int m = t + r * PT_NT;
+        if (m < PT_LN) {
+#pragma unroll
+          for (int b = 0; b < PT_TB; b++) sc[(3 + b) * PT_LN + m] = tv[r][b];
+        }
+      }
+      __syncthreads();
+    }
+    if (upd) {
+#pragma unroll
+      for (int b = 0; b < PT_TB; b++) {
+        const int nt = nt0 + b;
+        if (nt >= ntr) break;
+        if (which == 1 && trc_skip_adv(V.P, nt + 1)) continue;            // :353-355 (pbcor2, :684, has no such test)
+        const double *l_x = sc + (3 + b) * PT_LN;
+        // a face without a u-/v-point carries no flux (F.f = 0 there, but 0 * tracer could be -0 or NaN: keep the exact 0)
+        const double fw = uw ? W.f * l_x[W.up] : 0., fs = vs ? S.f * l_x[S.up] : 0.;
+        const double fe = MU(mp_e) ? E.f * l_x[E.up] : 0., fn = MV(mp_n) ? N.f * l_x[N.up] : 0.;
+        if (which == 1) WK(V, N_TR(nt))[c + ok] = (dpo * l_x[q] - (fe - fw + fn - fs) * s2i) * dpni;
+        else WK(V, N_TR(nt))[c + ok] = (dpo * l_x[q] - (fe - fw + fn - fs) * s2i) * dpni;
+      }
+    }
   }
 }
 
 // k_pbc_rescale (stage_pbcor.hip) reading the new state from the work space: p scan, pbfac = pb / p(kk+1), dp *= pbfac;
 // S, T and the updated tracers move into their fields.  mod_pbcor.F90:365-395, :696-726.
 #define RS_U 4
-__global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restrict__ Vp, int which, int m, int offc) {
+// move = 0: only dp is rescaled into its field; S, T and the tracers stay in the work space for the next stage (pbcor1 inside
+// blomgpu_step: diffus takes them from there, stage_diffus.hip)
+__global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restrict__ Vp, int which, int m, int offc, int move) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
   if (t_ >= V.nplane) return;
@@ -190,21 +217,18 @@ __global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restri
   double *saln = V.f[F_saln] + (size_t)offc * np + c, *temp = V.f[F_temp] + (size_t)offc * np + c;
   double *trc = V.f[F_trc] + (size_t)offc * np + c;
   const double *ndp = WK(V, N_DP) + c, *ns = WK(V, N_S) + c, *nt_ = WK(V, N_T) + c;
-  bool mv[MAXTR];
-#pragma unroll
-  for (int nt = 0; nt < MAXTR; nt++) mv[nt] = nt < ntr && !(which == 1 && trc_skip_adv(V.P, nt + 1));
   const double ptop = p[0];
   const double psum = column_scan(ptop, ndp, p, np, kk);
   const double pbfac = (which == 1 ? V.f[F_pb_p][c] : V.f[F_pb][c + (size_t)(m - 1) * np]) / psum;
   double acc = ptop;
   for (int k0 = 0; k0 < kk; k0 += RS_U) {
-    double a0[RS_U], a1[RS_U], a2[RS_U], at[MAXTR][RS_U];
+    double a0[RS_U], a1[RS_U], a2[RS_U];
 #pragma unroll
     for (int u = 0; u < RS_U; u++) {
       const size_t o = (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np;
-      a0[u] = ndp[o]; a1[u] = ns[o]; a2[u] = nt_[o];
-#pragma unroll
-      for (int nt = 0; nt < MAXTR; nt++) at[nt][u] = mv[nt] ? WK(V, N_TR(nt))[c + o] : 0.;
+      a0[u] = ndp[o];
+      a1[u] = move ? ns[o] : 0.;
+      a2[u] = move ? nt_[o] : 0.;
     }
 #pragma unroll
     for (int u = 0; u < RS_U; u++) {
@@ -214,21 +238,33 @@ __global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restri
       const double d = a0[u] * pbfac;
       dp[o] = d;
       if (which == 2) { acc = acc + d; p[o + np] = acc; }
-      saln[o] = a1[u];
-      temp[o] = a2[u];
+      if (move) { saln[o] = a1[u]; temp[o] = a2[u]; }
+    }
+  }
+  if (!move) return;
+  for (int nt = 0; nt < ntr; nt++) {
+    if (which == 1 && trc_skip_adv(V.P, nt + 1)) continue;
+    const double *src = WK(V, N_TR(nt)) + c;
+    double *dst = trc + (size_t)nt * 2 * kk * np;
+    for (int k0 = 0; k0 < kk; k0 += 2 * RS_U) {
+      double a[2 * RS_U];
 #pragma unroll
-      for (int nt = 0; nt < MAXTR; nt++)
-        if (mv[nt]) trc[o + (size_t)nt * 2 * kk * np] = at[nt][u];
+      for (int u = 0; u < 2 * RS_U; u++) a[u] = src[(size_t)(k0 + u < kk ? k0 + u : kk - 1) * np];
+#pragma unroll
+      for (int u = 0; u < 2 * RS_U; u++)
+        if (k0 + u < kk) dst[(size_t)(k0 + u) * np] = a[u];
     }
   }
 }
 
 int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf) {
   const DevView &h = c->h;
-  if (h.ntr > MAXTR || 3 + h.ntr > h.nwk) return ctx_fail(c, "pbcor: more tracers than MAXTR / work space too small");
+  if (3 + h.ntr > h.nwk) return ctx_fail(c, "pbcor: work space too small for this many tracers");
   const int ntx = (h.ni + PT_TW - 1) / PT_TW, nty = (h.nj + PT_TH - 1) / PT_TH;
-  const size_t lds = sizeof(double) * (3 + h.ntr) * PT_LN;
-  hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), lds, c->stream, c->d, which, offc, offf, ntx);
-  hipLaunchKernelGGL(k_pbc_rescale_from, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, offc);
+  hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx);
+  // inside blomgpu_step pbcor1 hands S, T and the tracers to diffus through the work space, pbcor2 to tmsmt2
+  const int move = !c->in_sequence;
+  (which == 1 ? c->pbcor1_handed_over : c->pbcor2_handed_over) = !move;
+  hipLaunchKernelGGL(k_pbc_rescale_from, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, offc, move);
   return 0;
 }

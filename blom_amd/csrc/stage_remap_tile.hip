@@ -85,7 +85,9 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
       A.ftr[nt] = A.ftr[nt] + fd * g[G_TRD(nt) * RT_GN + x] + qx * g[G_TRX(nt) * RT_GN + x] + qy * g[G_TRY(nt) * RT_GN + x];
 }
 
-__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv, unsigned atr, int tsel) {
+__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv, unsigned atr, int tsel, int base) {
+  // base = 0: a further batch of tracers (the launches carry at most MAXTR advected tracers each); the geometry is redone,
+  // only the tracer flux planes are written
   const DevView &V = *Vp;
   HIP_DYNAMIC_SHARED(double, lds)
   unsigned bx_, by_;
@@ -324,9 +326,11 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
       penint(s2_c, sh, .5, x2, y2, xm + sh, ym, x4, y4, sh, -.5, a, ax, ay, axx, ayy, axy);
       add_contrib_t(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A);
       // mod_remap.F90:1054-1056
-      *o_f = f_o + A.fd;
-      *o_ft = ft_o + A.ft;
-      *o_fs = fs_o + A.fs;
+      if (base) {
+        *o_f = f_o + A.fd;
+        *o_ft = ft_o + A.ft;
+        *o_fs = fs_o + A.fs;
+      }
     } else {
       const double cuc1 = cuv[fq + 1], cvc1 = cuv[RT_GN + fq + 1];
       const double xm = -.5 * (cuc0 + cuc1);
@@ -357,16 +361,20 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
       penint(s2_c, -.5, sh, x2, y2, xm, ym + sh, x4, y4, .5, sh, a, ax, ay, axx, ayy, axy);
       add_contrib_t(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A);
       // mod_remap.F90:1455-1457: assignment (not accumulation) for the v-components
-      *o_f = A.fd;
-      *o_ft = A.ft;
-      *o_fs = A.fs;
+      if (base) {
+        *o_f = A.fd;
+        *o_ft = A.ft;
+        *o_fs = A.fs;
+      }
     }
   }
   // the flux planes of k_remap_update: W_FDU, W_FDV, W_FTU, W_FTV, .. alternate
   const int off = uface ? 0 : 1;
-  WK(V, W_FDU(ntr) + off)[fc + ok] = A.fd;
-  WK(V, W_FTU(ntr) + off)[fc + ok] = A.ft;
-  WK(V, W_FSU(ntr) + off)[fc + ok] = A.fs;
+  if (base) {
+    WK(V, W_FDU(ntr) + off)[fc + ok] = A.fd;
+    WK(V, W_FTU(ntr) + off)[fc + ok] = A.ft;
+    WK(V, W_FSU(ntr) + off)[fc + ok] = A.fs;
+  }
 #pragma unroll
   for (int nt = 0; nt < MAXTR; nt++)
     if (nt < nadv) WK(V, W_FTRU(ntr, (atr >> (8 * nt)) & 255u) + off)[fc + ok] = A.ftr[nt];
@@ -374,15 +382,23 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
 
 int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
   const DevView &h = c->h;
-  if (h.ntr > MAXTR) return ctx_fail(c, "remap: more tracers than MAXTR");
   const int ntx = (h.ni + RT_TW - 1) / RT_TW, nty = (h.nj + RT_TH - 1) / RT_TH;
-  int nadv = 0;
-  unsigned atr = 0;
-  for (int nt = 0; nt < h.ntr; nt++)
-    if (!trc_skip_adv(h.P, nt + 1)) atr |= (unsigned)nt << (8 * nadv++);
-  const size_t lds = sizeof(double) * (RT_NG(nadv) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
   static_assert(RT_NSC(MAXTR) * RT_SN <= RT_NG(MAXTR) * RT_GN, "the scalars must fit under the gradient slots");
-
-  hipLaunchKernelGGL(k_remap_tile, dim3(ntx * nty, h.kk), dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, atr, tsel);
+  if (h.ntr > 255) return ctx_fail(c, "remap: tracer indices are packed in 8 bits");
+  if (W_FTRV(h.ntr, h.ntr - 1) >= h.nwk) return ctx_fail(c, "remap: work space too small for this many tracers");
+  // the advected tracers MAXTR at a time (TKE and its length scale are not advected unless use_TKEADV); the first launch
+  // also carries dp, T, S
+  int nt = 0, launches = 0;
+  do {
+    int nadv = 0;
+    unsigned atr = 0;
+    for (; nt < h.ntr && nadv < MAXTR; nt++)
+      if (!trc_skip_adv(h.P, nt + 1)) atr |= (unsigned)nt << (8 * nadv++);
+    if (launches > 0 && nadv == 0) break;
+    const size_t lds = sizeof(double) * (RT_NG(nadv) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
+    hipLaunchKernelGGL(k_remap_tile, dim3(ntx * nty, h.kk), dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, atr, tsel,
+                       launches == 0 ? 1 : 0);
+    launches++;
+  } while (nt < h.ntr);
   return 0;
 }

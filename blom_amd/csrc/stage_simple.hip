@@ -169,7 +169,9 @@ __global__ __launch_bounds__(64) void k_tmsmt2_fac(const DevView *__restrict__ V
   WK2(V, S2_PBFACN)[c] = pbm / pbfacn;
 }
 
-__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn) {
+// from_wk: pbcor2 left S, T and the tracers of level m in the work space (slots 1, 2, 3 + nt; stage_pbcor_tile.hip) instead of
+// moving them into their fields: they are read there and written, filtered, to the fields
+__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int from_wk) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -187,20 +189,24 @@ __global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn) {
   pold = pold + epsilp;
   pmid = pmid + epsilp;
   pnew = pnew + epsilp;
-  V.f[F_temp][okm] = (wts1 * pmid * V.f[F_temp][okm] + wts2 * (pold * V.f[F_told][ok] + pnew * V.f[F_temp][okn])) /
+  const double tmid = from_wk ? WK(V, 2)[ok] : V.f[F_temp][okm], smid = from_wk ? WK(V, 1)[ok] : V.f[F_saln][okm];
+  V.f[F_temp][okm] = (wts1 * pmid * tmid + wts2 * (pold * V.f[F_told][ok] + pnew * V.f[F_temp][okn])) /
                      (dpm + epsilp);
-  V.f[F_saln][okm] = (wts1 * pmid * V.f[F_saln][okm] + wts2 * (pold * V.f[F_sold][ok] + pnew * V.f[F_saln][okn])) /
+  V.f[F_saln][okm] = (wts1 * pmid * smid + wts2 * (pold * V.f[F_sold][ok] + pnew * V.f[F_saln][okn])) /
                      (dpm + epsilp);
   for (int nt = 0; nt < V.ntr; nt++) {
     double *tr = V.f[F_trc] + (size_t)nt * 2 * V.kk * np;
     const double *tro = V.f[F_trcold] + (size_t)nt * V.kk * np;
-    tr[okm] = (wts1 * pmid * tr[okm] + wts2 * (pold * tro[ok] + pnew * tr[okn])) / (dpm + epsilp);
+    const double xmid = from_wk ? WK(V, 3 + nt)[ok] : tr[okm];
+    tr[okm] = (wts1 * pmid * xmid + wts2 * (pold * tro[ok] + pnew * tr[okn])) / (dpm + epsilp);
   }
 }
 
 int st_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) {
   hipLaunchKernelGGL(k_tmsmt2_fac, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn);
-  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, nn);
+  const int from_wk = c->pbcor2_handed_over ? 1 : 0;
+  c->pbcor2_handed_over = false;
+  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, nn, from_wk);
   HIPCHK(c, hipGetLastError());
   if (int rc = st_xctilr(c, c->h.f[F_dp] + (size_t)(k1m - 1) * c->h.nplane, 1, c->h.kk, 3, 3, 1)) return rc;
   if (c->h.P.vcoord_tag == 1) return launch_p_dpu_dpv(c, mm, 0);

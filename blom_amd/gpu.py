@@ -175,6 +175,13 @@ class BlomGpu:
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
         self._chk(self.lib.blomgpu_rccl_init_2d(self.ctx, buf, rank, npx, npy))
 
+    def rccl_attach_barotp_global(self, glob, isizes, jsizes):
+        """every rank solves the whole 2-D barotropic domain on `glob`, a BlomGpu of the global domain (blomgpu.h)"""
+        a = (C.c_int * len(isizes))(*[int(x) for x in isizes])
+        b = (C.c_int * len(jsizes))(*[int(x) for x in jsizes])
+        self._chk(self.lib.blomgpu_rccl_attach_barotp_global(self.ctx, glob.ctx, a, b))
+        self._bt_global = glob               # keep it alive as long as the tile
+
     def rccl_force_ns_exchange(self, on=True):
         self._chk(self.lib.blomgpu_rccl_force_ns_exchange(self.ctx, int(on)))
 

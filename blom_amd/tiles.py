@@ -139,3 +139,18 @@ def chain_crc(parts, layout):
                     crc8 = zlib.crc32(np.array([v], dtype="<u4").tobytes(), crc8)
             rows.append(crc8)
     return zlib.crc32(np.array(rows, dtype="<u4").tobytes()) & 0xFFFFFFFF
+
+
+def make_barotp_global(src, case, masks, device=0):
+    """The second context of an RCCL tile that solves the whole 2-D barotropic domain (blomgpu_rccl_attach_barotp_global):
+    global dimensions, kdm = 3 (it holds 2-D fields only), no tracers, the global masks, and every 2-D field of the
+    whole-domain backend `src` (grid metrics, the barotropic state at start)."""
+    from .gpu import BlomGpu
+    g = BlomGpu(case.idm, case.jdm, 3, 0, case.nreg, masks, device=device)
+    for nm in src.field_names():
+        if nm == "mpack" or nm.startswith("wkp") or nm in masks:
+            continue
+        nlev, isint = src.field_info(nm)
+        if nlev <= 3 and not isint and g.has_field(nm) and g.field_info(nm)[0] == nlev:
+            g.put(nm, src.get(nm))
+    return g

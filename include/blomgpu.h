@@ -140,6 +140,12 @@ int  blomgpu_rccl_unique_id(void *id128);
 int  blomgpu_rccl_init(blomgpu_ctx *, const void *id128, int rank, int nranks);          /* npx = nranks, npy = 1 */
 int  blomgpu_rccl_init_2d(blomgpu_ctx *, const void *id128, int rank, int npx, int npy);  /* rank = px + npx*py */
 int  blomgpu_rccl_force_ns_exchange(blomgpu_ctx *, int on);   /* test hook, see comm_rccl.hip */
+/* The barotropic solve (barotp, phy/mod_barotp.F90:330-1003: 2.5 lstep substeps per step, one xctilr per substep pair in
+ * the reference) replicated on every rank instead of decomposed: `global` is a second context on the same device that
+ * spans the whole itdm x jtdm domain (kdm >= 3, the global masks and grid metrics uploaded); isizes[npx] / jsizes[npy]
+ * are the widths / heights of the tile columns / rows.  From then on blomgpu_barotp of the tile gathers the 2-D fields
+ * the solver reads (one grouped exchange), solves on `global`, and takes its window of the results. */
+int  blomgpu_rccl_attach_barotp_global(blomgpu_ctx *tile, blomgpu_ctx *global, const int *isizes, const int *jsizes);
 int  blomgpu_rccl_finalize(blomgpu_ctx *);
 typedef struct TileGroup blomgpu_group;
 int  blomgpu_group_create(int npx, int npy, blomgpu_group **out);

@@ -16,7 +16,7 @@
 #include <stddef.h>
 
 #define NBDY 4
-#define MAXTR 8
+#define MAXTR 64
 
 /* X(name, levels) -- K = kdm, NT = max(ntr,1) */
 #define ORC_REAL_FIELDS(X)                                                                \

@@ -42,7 +42,7 @@ module ref_harness
   use mod_convec,    only: convec
   use mod_idlage,    only: idlage_step
   use mod_budget,    only: budget_sums, cnsvdi
-  use mod_tracers,   only: ntr, trc, trcold, inivar_tracers
+  use mod_tracers,   only: ntr, trc, trcold, uflxtr, vflxtr, trflx, inivar_tracers
   use mod_cmnfld,    only: inivar_cmnfld
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
@@ -60,6 +60,11 @@ module ref_harness
       import :: c_int, c_ptr
       integer(c_int) :: a(*)
       type(c_ptr)    :: out
+    end subroutine
+    subroutine ref_poke_i4(a, v) bind(C, name='ref_poke_i4')
+      import :: c_int
+      integer(c_int) :: a
+      integer(c_int), value :: v
     end subroutine
   end interface
 
@@ -104,6 +109,30 @@ contains
     ips(:,:) = ip(:,:)
     if (nreg == 2) ips(:,jj:jj+nbdy) = 0
   end subroutine ref_setup
+
+  ! The reference's tracer count is a run-time quantity: ntr = ntrocn + ntrtke + ntrgls + ntriag + ntrbgc
+  ! (trc/mod_tracers.F90:116-126), its arrays are allocated with it (:211-262) and every stage loops `do nt = 1,ntr`.
+  ! The builds here have no iHAMOCC (ntrbgc = 0), so this gives the reference's own stages MORE tracers to carry: the
+  ! tracer arrays are re-allocated for nnew tracers, the new ones start as copies of what inivar_tracers left in tracer 1
+  ! (its spval / zero-flux patterns), and ntr -- PROTECTED -- is set through its address.  Tracers beyond the compiled
+  ! ones are plain passive tracers to every stage (not TKE, not ideal age), as the bgc tracers are.
+  subroutine ref_set_ntr(nnew) bind(C, name='ref_set_ntr')
+    integer(c_int), value :: nnew
+    real(8), allocatable :: t4(:,:,:,:), o4(:,:,:,:), u3(:,:,:), v3(:,:,:), f3(:,:,:)
+    integer :: nt, nold
+    nold = ntr
+    if (nnew < 1 .or. nold < 1 .or. nnew == nold) return
+    call move_alloc(trc, t4); call move_alloc(trcold, o4)
+    call move_alloc(uflxtr, u3); call move_alloc(vflxtr, v3); call move_alloc(trflx, f3)
+    allocate(trc(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,2*kdm,nnew), trcold(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,kdm,nnew))
+    allocate(uflxtr(nnew,1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy), vflxtr(nnew,1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy))
+    allocate(trflx(nnew,1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy))
+    do nt = 1, nnew
+      trc(:,:,:,nt) = t4(:,:,:,min(nt,nold)); trcold(:,:,:,nt) = o4(:,:,:,min(nt,nold))
+      uflxtr(nt,:,:) = u3(min(nt,nold),:,:); vflxtr(nt,:,:) = v3(min(nt,nold),:,:); trflx(nt,:,:) = f3(min(nt,nold),:,:)
+    end do
+    call ref_poke_i4(ntr, nnew)
+  end subroutine ref_set_ntr
 
   subroutine ref_set_real(name, v, ierr) bind(C, name='ref_set_real')
     character(kind=c_char), intent(in) :: name(*)

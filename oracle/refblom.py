@@ -140,15 +140,20 @@ vflux uflux2 vflux2 uflux3 vflux3 umax vmax util1 util2 util3 util4 taux tauy us
 _BACKENDS = {}
 
 
-def get_ref_backend(cfg, depth):
+def get_ref_backend(cfg, depth, ntr=None):
     """The reference keeps all state in Fortran module globals and cannot be set up twice in
-    one process; hand out one backend per configuration and restore its post-inivar state."""
+    one process; hand out one backend per configuration and restore its post-inivar state.
+    ntr: give the reference's stages that many tracers to carry (ref_set_ntr in oracle/harness/ref_harness.F90: its
+    tracer count is a run-time quantity, trc/mod_tracers.F90:116-126); default: the count of the build."""
     if cfg in _BACKENDS:
         be = _BACKENDS[cfg]
-        be.restore_pristine()
-        return be
-    be = RefBackend(cfg, depth)
-    _BACKENDS[cfg] = be
+    else:
+        be = RefBackend(cfg, depth)
+        _BACKENDS[cfg] = be
+    want = be.ntr_compiled if ntr is None else ntr
+    if want != be.ntr:
+        be.set_tracer_count(want)
+    be.restore_pristine()
     return be
 
 
@@ -167,13 +172,25 @@ class RefBackend:
             except KeyError:
                 pass
         self.kdm, self.idm, self.jdm = self.ref.kdm, self.ref.idm, self.ref.jdm
-        self.ntr = self.ref.ntr
+        self.ntr = self.ntr_compiled = self.ref.ntr
         self.nreg = self.ref.nreg
         self.masks = {k: self.ref.field(k)[0] for k in ("ip", "iu", "iv", "iq")}
 
     def restore_pristine(self):
         for nm, a in self._pristine.items():
             self.ref.field(nm)[...] = a
+
+    def set_tracer_count(self, ntr):
+        """re-allocate the reference's tracer arrays for ntr tracers; tracers beyond those it had start as copies of
+        the last one's post-inivar pattern"""
+        one = {nm: self._pristine[nm][:self._pristine[nm].shape[0] // self.ntr] for nm in ("trc", "trcold") if nm in self._pristine}
+        self.ref.lib.ref_set_ntr(C.c_int(int(ntr)))
+        self.ref._views.clear()
+        self.ref.ntr = self.ref.get_int("ntr")
+        assert self.ref.ntr == ntr, (self.ref.ntr, ntr)
+        self.ntr = ntr
+        for nm, a in one.items():
+            self._pristine[nm] = np.concatenate([a] * ntr, axis=0)
 
     def get(self, name):
         return self.ref.field(name)          # live view: edits land in the reference

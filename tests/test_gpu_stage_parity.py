@@ -28,13 +28,13 @@ GPU_STAGES = ["init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "advect", 
 SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "vtotm"}
 
 
-def _run(cfg, nsteps, stages, eddy=False, **overrides):
+def _run(cfg, nsteps, stages, eddy=False, ntr=None, **overrides):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
         pytest.skip(f"oracle/_ref/{cfg}/libblomref.so not built")
-    case = make_case(cfg, **overrides)
-    ref = get_ref_backend(cfg, case.depth)
+    case = make_case(cfg, ntr=ntr, **overrides)
+    ref = get_ref_backend(cfg, case.depth, ntr=ntr)
     hostinit.init_state(ref, case)
     if eddy:                                    # non-zero umfltd, vmfltd, umflsm, vmflsm in front of advect
         hostinit.frozen_eddy_fluxes(ref, case)
@@ -87,6 +87,15 @@ def test_stage_parity_with_eddy_fluxes(cfg):
     _run(cfg, 4, GPU_STAGES, eddy=True)
 
 
+@pytest.mark.parametrize("cfg,ntr", [("chan_s_tke", 11), ("tri_s_tke", 6), ("box_s_tke", 9), ("chan_s_tk0", 7)])
+def test_stage_parity_with_many_tracers(cfg, ntr):
+    """More tracers than one batch (4) of the tile kernels holds -- BASELINE.json's config 5 advects iHAMOCC's through these
+    stages -- against the reference's own stages carrying that many (its tracer count is a run-time quantity,
+    trc/mod_tracers.F90:116-126: ntr = ... + ntrbgc; the harness re-allocates its tracer arrays, ref_set_ntr).  The extra
+    tracers are plain passive ones.  With the eddy-induced fluxes on, so that remap works on all of them."""
+    _run(cfg, 4, GPU_STAGES, eddy=True, ntr=ntr)
+
+
 def test_stage_parity_fuk95():
     _run("fuk95", 2, GPU_STAGES)
 
@@ -131,13 +140,18 @@ def test_freerun_device_resident_with_eddy_fluxes(cfg, nsteps):
     _freerun_device(cfg, nsteps, 0.0, True)
 
 
-def _freerun_device(cfg, nsteps, rtol, eddy):
+@pytest.mark.parametrize("cfg,nsteps,ntr", [("chan_s_tke", 24, 11), ("tri_s_tke", 16, 6), ("box_s_tke", 16, 24)])
+def test_freerun_device_resident_with_many_tracers(cfg, nsteps, ntr):
+    _freerun_device(cfg, nsteps, 0.0, True, ntr=ntr)
+
+
+def _freerun_device(cfg, nsteps, rtol, eddy, ntr=None):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
         pytest.skip(f"oracle/_ref/{cfg}/libblomref.so not built")
-    case = make_case(cfg)
-    ref = get_ref_backend(cfg, case.depth)
+    case = make_case(cfg, ntr=ntr)
+    ref = get_ref_backend(cfg, case.depth, ntr=ntr)
     hostinit.init_state(ref, case)
     if eddy:
         hostinit.frozen_eddy_fluxes(ref, case)

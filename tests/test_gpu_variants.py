@@ -29,8 +29,7 @@ def _run(cfg, nsteps, **opts):
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 8), ("fuk95", 6), ("chan_m", 6), ("tri_s", 8),
                                         ("chan_s_tke", 12), ("tri_s_tke", 8)])
-@pytest.mark.parametrize("opt,variants", [("diapfl_v", (1, 3)), ("diapfl_v", (2, 3)), ("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)),
-                                          ("momtum_v", (1, 2)), ("remap_v", (1, 2)), ("pbcor_v", (1, 2)),
+@pytest.mark.parametrize("opt,variants", [("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)), ("diapfl_du", (4, 8)),
                                           ("barotp_tile", (3216, 3208)), ("barotp_tile", (3216, 1608))])
 def test_variants_bit_identical(cfg, nsteps, opt, variants):
     a = _run(cfg, nsteps, **{opt: variants[0]})
@@ -48,12 +47,12 @@ def test_variants_at_full_size_are_deterministic_and_identical():
     old values in their rims) shows up; small grids do not expose it."""
     keep = ("u", "v", "dp", "temp", "saln", "pb", "ub", "vb")
     runs = []
-    for opts in ({"diapfl_v": 1, "barotp_fused": 0, "barotp_persist": 0, "momtum_v": 1, "remap_v": 1, "pbcor_v": 1}, {}, {}):
+    for opts in ({"barotp_fused": 0, "barotp_persist": 0}, {}, {}):
         out = _run("channel", 2, **opts)
         runs.append({k: out[k] for k in keep})
     for nm in keep:
         assert np.array_equal(runs[1][nm], runs[2][nm], equal_nan=True), f"{nm}: not deterministic"
-        assert np.array_equal(runs[0][nm], runs[1][nm], equal_nan=True), f"{nm}: production kernels != first versions"
+        assert np.array_equal(runs[0][nm], runs[1][nm], equal_nan=True), f"{nm}: production kernels != the one-kernel-per-equation barotp"
 
 
 def _run_rccl_self(cfg, nsteps, **opts):
@@ -205,7 +204,7 @@ def test_variants_identical_on_tnx2v1s():
     """the tripolar grid at tnx2v1's size (180 x 193 x 53, arctic patch, unequal wet areas): this round's kernels against
     round 1's, and the pair kernel's seam rule at the tile load against the separate halo launches of the unfused path"""
     keep = ("u", "v", "dp", "temp", "saln", "pb", "ub", "vb", "trc")
-    old = _run("tnx2v1s", 3, diapfl_v=1, barotp_fused=0, barotp_persist=0, momtum_v=1, remap_v=1, pbcor_v=1)
+    old = _run("tnx2v1s", 3, barotp_fused=0, barotp_persist=0)
     new = _run("tnx2v1s", 3)
     for nm in keep:
         assert np.array_equal(old[nm], new[nm], equal_nan=True), nm

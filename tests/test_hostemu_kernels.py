@@ -1,9 +1,8 @@
-"""This round's kernels on the CPU: the device library compiled for the host (tests/hostemu: every kernel runs thread by
+"""The device kernels on the CPU: the device library compiled for the host (tests/hostemu: every kernel runs thread by
 thread, one fiber per thread, workgroup barriers and LDS as on the device, dynamic LDS poisoned with NaN) stepped through the
-stage sequence with the current kernels and with the first generation -- LDS-tiled remap and pbcor against one kernel per
-sweep, the pipelined diapfl column pass against the plain one, the fused momtum marches against the sweep kernels -- and
-against the C restatement.  The GPU suite makes the same comparisons on the device (tests/test_gpu_variants.py); this one
-runs where there is no GPU."""
+stage sequence -- the LDS-tiled remap, pbcor and diffus kernels, the pipelined diapfl column pass, the fused momtum marches,
+the barotropic pair kernel against one kernel per equation -- and against the C restatement, also with more tracers than one
+batch of the tile kernels holds.  The GPU suite makes the comparisons on the device; this one runs where there is no GPU."""
 import os
 
 import numpy as np
@@ -18,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "hostemu", "libblomgpu_hostemu.so")
 pytestmark = pytest.mark.skipif(not os.path.exists(EMU), reason="tests/hostemu/libblomgpu_hostemu.so not built")
 
-OLD = dict(diapfl_v=1, momtum_v=1, remap_v=1, pbcor_v=1, barotp_fused=0, barotp_persist=0)
+OLD = dict(barotp_fused=0, barotp_persist=0)
 SKIP = {"util1", "util2", "util3", "util4"}
 
 
@@ -31,9 +30,9 @@ def emu_lib():
     g.LIB_PATH = old
 
 
-def _run(cfg, nsteps, **opts):
+def _run(cfg, nsteps, ntr=None, **opts):
     from blom_amd.gpu import BlomGpu
-    case = make_case(cfg)
+    case = make_case(cfg, ntr=ntr)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     hostinit.init_state(gpu, case)
@@ -46,7 +45,7 @@ def _run(cfg, nsteps, **opts):
 
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 4), ("box_s", 3), ("tri_s", 3)])
-def test_current_kernels_equal_the_first_generation(emu_lib, cfg, nsteps):
+def test_pair_kernel_equals_one_kernel_per_equation(emu_lib, cfg, nsteps):
     _, new = _run(cfg, nsteps)
     _, old = _run(cfg, nsteps, **OLD)
     bad = [nm for nm in new if nm not in SKIP and not np.array_equal(new[nm], old[nm], equal_nan=True)]
@@ -54,18 +53,20 @@ def test_current_kernels_equal_the_first_generation(emu_lib, cfg, nsteps):
     assert np.isfinite(new["u"]).all() and np.abs(new["u"]).max() > 0.0
 
 
-def test_current_kernels_equal_the_c_restatement(emu_lib):
-    """the same sequence on the C restatement (pinned on the compiled reference, tests/test_oracle_vs_reference.py)"""
+@pytest.mark.parametrize("cfg,ntr", [("chan_s", None), ("box_s", None), ("tri_s", None), ("chan_s_tke", 11), ("tri_s_tke", 6)])
+def test_current_kernels_equal_the_c_restatement(emu_lib, cfg, ntr):
+    """the same sequence on the C restatement (pinned on the compiled reference, tests/test_oracle_vs_reference.py, also with
+    the reference carrying 11 tracers); ntr = 11, 6: more than the 4 tracers one batch of the tile kernels holds"""
     from oracle.coracle import COracle
     nsteps = 3
-    case, new = _run("chan_s", nsteps)
-    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    case, new = _run(cfg, nsteps, ntr=ntr)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     orc = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     hostinit.init_state(orc, case)
     ns = 0
     for _ in range(nsteps):
         ns = dyncore_step(orc, ns, case.params["baclin"])
     J, I = slice(4, 4 + case.jdm), slice(4, 4 + case.idm)
-    for nm in ("dp", "temp", "saln", "u", "v", "pb", "ub", "vb", "uflx", "vflx"):
+    for nm in ("dp", "temp", "saln", "u", "v", "pb", "ub", "vb", "uflx", "vflx", "trc"):
         a, b = orc.get(nm)[..., J, I], new[nm][..., J, I]
         assert np.array_equal(a, b, equal_nan=True), nm

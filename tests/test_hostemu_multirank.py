@@ -28,9 +28,9 @@ def emu_lib():
     g.LIB_PATH = old
 
 
-def _run_case(cfg, isizes, jsizes, nsteps=3):
+def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False):
     from blom_amd.gpu import BlomGpu, rccl_unique_id
-    from blom_amd.tiles import TileLayout, scatter_to_tile, gather_interior_layout, chain_crc
+    from blom_amd.tiles import TileLayout, scatter_to_tile, gather_interior_layout, chain_crc, make_barotp_global
     from test_gpu_tiles import _single
     case, masks, fields, ref = _single(cfg, nsteps)
     lay = TileLayout(tuple(isizes), tuple(jsizes))
@@ -52,7 +52,10 @@ def _run_case(cfg, isizes, jsizes, nsteps=3):
             t.set("delt1", case.params["baclin"])
             with lock:                                    # the whole-domain backend is shared: read it one rank at a time
                 scatter_to_tile(ref, t, lay, px, py)
+                glob = make_barotp_global(ref, case, masks) if bt_global else None
             t.rccl_init_2d(uid, rank, lay.npx, lay.npy)
+            if bt_global:                                 # every rank solves the whole 2-D barotropic domain
+                t.rccl_attach_barotp_global(glob, lay.isizes, lay.jsizes)
             with lock:
                 tiles[(px, py)] = t
             barrier.wait()
@@ -100,6 +103,20 @@ def _run_case(cfg, isizes, jsizes, nsteps=3):
 ])
 def test_rccl_ranks_match_single_tile(emu_lib, cfg, isizes, jsizes):
     _run_case(cfg, isizes, jsizes)
+
+
+@pytest.mark.parametrize("cfg,isizes,jsizes", [
+    ("chan_s", (10, 10), (12, 12)),
+    ("chan_s", (7, 7, 6), (13, 11)),           # unequal columns and rows
+    ("box_s", (12, 12), (11, 9)),
+    ("tri_s", (12, 12), (11, 9)),              # arctic patch: the global context folds onto itself, no strips travel for barotp
+    ("tri_s_tke", (6, 6, 6, 6), (10, 10)),
+])
+def test_rccl_ranks_with_replicated_barotropic_solve(emu_lib, cfg, isizes, jsizes):
+    """blomgpu_rccl_attach_barotp_global: the tiles gather the 2-D fields barotp reads once per step, every rank solves the
+    whole barotropic domain on a second context and takes its window -- no exchange inside the substep loop.  Same
+    requirement: the single tile's bits."""
+    _run_case(cfg, isizes, jsizes, bt_global=True)
 
 
 def test_patch_input_layout():

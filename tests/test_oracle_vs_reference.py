@@ -23,13 +23,23 @@ def test_freerun_bit_identical_with_eddy_fluxes(cfg, nsteps):
     _freerun(cfg, nsteps, True)
 
 
-def _freerun(cfg, nsteps, eddy):
+# the reference's stages carrying MORE tracers than its build options give it: its tracer count is a run-time quantity
+# (ntr = ntrocn + ntrtke + ntrgls + ntriag + ntrbgc, trc/mod_tracers.F90:116-126; every stage loops do nt = 1,ntr), the
+# harness re-allocates its tracer arrays (ref_set_ntr).  The extra tracers are plain passive ones, what iHAMOCC's are to
+# the dynamical core.  ntr = 11, 6: beyond the 4 tracers one batch of the device's tile kernels holds.
+@pytest.mark.parametrize("cfg,nsteps,ntr", [("chan_s_tke", 8, 11), ("tri_s_tke", 6, 6), ("box_s_tke", 6, 9)])
+def test_freerun_bit_identical_with_many_tracers(cfg, nsteps, ntr):
+    _freerun(cfg, nsteps, True, ntr=ntr)
+
+
+def _freerun(cfg, nsteps, eddy, ntr=None):
     from oracle.refblom import get_ref_backend, have_ref
     from oracle.coracle import COracle, have_coracle
     if not (have_ref(cfg) and have_coracle()):
         pytest.skip("reference / C oracle libraries not built")
-    case = make_case(cfg)
-    ref = get_ref_backend(cfg, case.depth)
+    case = make_case(cfg, ntr=ntr)
+    ref = get_ref_backend(cfg, case.depth, ntr=ntr)
+    assert ref.ntr == case.ntr
     hostinit.init_state(ref, case)
     if eddy:
         hostinit.frozen_eddy_fluxes(ref, case)
