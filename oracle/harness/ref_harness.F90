@@ -43,7 +43,11 @@ module ref_harness
   use mod_idlage,    only: idlage_step
   use mod_budget,    only: budget_sums, cnsvdi
   use mod_tracers,   only: ntr, trc, trcold, uflxtr, vflxtr, trflx, inivar_tracers
-  use mod_cmnfld,    only: inivar_cmnfld
+  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy
+#ifdef XCHECK_EDDTRA
+  ! cross-check builds only (oracle/Makefile *_xed): the reference's real mod_eddtra, compiled against a stand-in for mod_difest
+  use mod_eddtra,    only: eddtra
+#endif
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
 
@@ -238,6 +242,12 @@ contains
       case ('cppm_compatibility'); cppm_compatibility = trim(cstr(s))
       case ('cppm_limiting'); cppm_limiting = trim(cstr(s))
       case ('bmcmth'); bmcmth = trim(cstr(s))
+      case ('eitmth')            ! readnml_diffusion's translation, phy/mod_diffusion.F90:316-327
+        if (trim(cstr(s)) == 'intdif') then
+          eitmth_opt = eitmth_intdif
+        else
+          eitmth_opt = eitmth_gm
+        end if
       case default; ierr = 1
     end select
   end subroutine ref_set_str
@@ -355,6 +365,8 @@ contains
       R3(temmin, kdm)
       ! mod_diffusion
       R3(difint, kdm)
+      R3(nslpx, kdm)
+      R3(nslpy, kdm)
       R3(difiso, kdm)
       R3(difdia, kdm)
       R2(difmxp)
@@ -432,6 +444,9 @@ contains
       case ('barotp');  call barotp(m,n,mm,nn,k1m,k1n)
       case ('pbcor2');  call pbcor2(m,n,mm,nn,k1m,k1n)
       case ('tmsmt2');  call tmsmt2(m,mm,nn,k1m)
+#ifdef XCHECK_EDDTRA
+      case ('eddtra');  call eddtra(m,n,mm,nn,k1m,k1n)
+#endif
       ! Halo updates the reference performs inside stages that cannot be built here
       ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.
       case ('init_cppm');  call init_cppm          ! phy/mod_cppm.F90:2504 (called from blom_init)
