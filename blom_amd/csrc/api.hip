@@ -238,7 +238,6 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
     return 0;
   }
   if (s == "eddtra_frozen") { c->eddtra_frozen = v; return 0; }
-  if (s == "stage_overlap") { c->stage_overlap = v; return 0; }
   if (s == "check_period") { c->check_period = v < 1 ? 1 : v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
@@ -514,63 +513,23 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
 }
 
 // Stage sequence of one baroclinic step, phy/mod_blom_step.F90:89-253 (hot path only).
-// Two places of the sequence hold stages that do not touch each other's data and are bound by different things, so they
-// run side by side on the context's second stream (single tile, no stage timers, option stage_overlap):
-//   * init_fluxes + tmsmt1 (streaming copies of the new level's interior to the *old arrays, zeroing of the flux
-//     accumulators) beside cmnfld2 / its halo part + halo_difest + eddtra (column kernels bound by latency; they read the
-//     same fields and write slopes, halos, p and the eddy fluxes);
-//   * mxlayr_tail + updtrc (dp halo, dpu/dpv, tracer ageing) beside barotp (2-D, bound by latency; of the 3-D state it
-//     reads u, v only).
-// Same kernels, same arithmetic, same results; only the order in time between independent launches changes.
 static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
+                              "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
+                              "barotp", "pbcor2", "tmsmt2"};
   c->defer_checks = true;
   c->in_sequence = true;
   c->pbcor1_handed_over = c->pbcor2_handed_over = false;
-  bool ovl = c->stage_overlap && !c->timing && !c->tiling.multi() && !c->use_graph;
-  if (ovl && !c->xstream) {
-    if (hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      c->xstream = nullptr;
-      ovl = false;
-    }
-  }
-  hipStream_t const main = c->stream;
-  int rc = 0;
-  auto run = [&](const char *st) {
-    if (rc) return;
+  for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
-    const char *name = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
+    const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
     // eddtra_frozen: the eddy-induced fluxes umfltd.. stay as uploaded (the reference build of the oracle has no mod_eddtra;
     // tests pin advect/remap on non-zero fluxes this way)
-    if (c->eddtra_frozen && !strcmp(st, "eddtra")) return;
-    rc = blomgpu_stage(c, name, m, n, mm, nn, k1m, k1n);
-  };
-  // side: stages for the second stream; then the main stream's stages; both done before the sequence goes on
-  auto beside = [&](std::initializer_list<const char *> side, std::initializer_list<const char *> mainst) {
-    if (ovl && !rc) {
-      if (hipEventRecord(c->ev_fork, main) != hipSuccess || hipStreamWaitEvent(c->xstream, c->ev_fork, 0) != hipSuccess) rc = ctx_fail(c, "step: fork failed");
-      c->stream = c->xstream;
-      for (const char *st : side) run(st);
-      c->stream = main;
-      if (!rc && hipEventRecord(c->ev_join, c->xstream) != hipSuccess) rc = ctx_fail(c, "step: join failed");
-      for (const char *st : mainst) run(st);
-      if (!rc && hipStreamWaitEvent(main, c->ev_join, 0) != hipSuccess) rc = ctx_fail(c, "step: join failed");
-    } else {
-      for (const char *st : side) run(st);
-      for (const char *st : mainst) run(st);
-    }
-  };
-  // phy/mod_blom_step.F90:89-253 (hot path only)
-  beside({"init_fluxes", "tmsmt1"}, {"halo_cmnfld2", "halo_difest", "eddtra"});
-  for (const char *st : {"advect", "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl"}) run(st);
-  beside({"mxlayr_tail", "updtrc"}, {"barotp"});
-  for (const char *st : {"pbcor2", "tmsmt2"}) run(st);
-  c->stream = main;
+    if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
+    if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; c->in_sequence = false; return rc; }
+  }
   c->defer_checks = false;
   c->in_sequence = false;
-  if (rc) return rc;
   if (c->cmnfld1) return blomgpu_stage(c, "cmnfld1", m, n, mm, nn, k1m, k1n);     // phy/mod_blom_step.F90:233
   return 0;
 }

@@ -218,7 +218,6 @@ struct blomgpu_ctx {
   bool pbcor2_handed_over = false;   // likewise pbcor2 (level m) for tmsmt2
   bool pbcor1_handed_over = false;   // pbcor1 left S, T, tracers of the new level in the work space (slots N_S, N_T, N_TR): diffus starts there
   int steps_warm = 0;            // plain steps since the last option change (graph capture waits for 4)
-  int stage_overlap = 1;         // blomgpu_step: independent stages side by side on the second stream (api.hip: step_sequence)
   int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded
   int check_period = 8;          // steps between read-backs of the sticky stage error words in blomgpu_step
   bool csdiag = false;           // mod_checksum's switch: error words read back every step

@@ -29,7 +29,7 @@ def _run(cfg, nsteps, **opts):
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 8), ("fuk95", 6), ("chan_m", 6), ("tri_s", 8),
                                         ("chan_s_tke", 12), ("tri_s_tke", 8)])
-@pytest.mark.parametrize("opt,variants", [("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)), ("diapfl_du", (4, 8)), ("stage_overlap", (0, 1)),
+@pytest.mark.parametrize("opt,variants", [("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)), ("diapfl_du", (4, 8)),
                                           ("barotp_tile", (3216, 3208)), ("barotp_tile", (3216, 1608))])
 def test_variants_bit_identical(cfg, nsteps, opt, variants):
     a = _run(cfg, nsteps, **{opt: variants[0]})
@@ -47,7 +47,7 @@ def test_variants_at_full_size_are_deterministic_and_identical():
     old values in their rims) shows up; small grids do not expose it."""
     keep = ("u", "v", "dp", "temp", "saln", "pb", "ub", "vb")
     runs = []
-    for opts in ({"barotp_fused": 0, "barotp_persist": 0, "stage_overlap": 0}, {}, {}):
+    for opts in ({"barotp_fused": 0, "barotp_persist": 0}, {}, {}):
         out = _run("channel", 2, **opts)
         runs.append({k: out[k] for k in keep})
     for nm in keep:
