@@ -20,7 +20,7 @@ program blom_dyncore
   character(len=256) :: fname
   character(len=16)  :: name
   character(len=32)  :: sval
-  integer :: u, ios, kind, nlev, nsteps, nstep, i4(6), ival
+  integer :: u, ios, kind, nlev, nsteps, nstep, nstep1, nstep2, i4(6), ival
   real(8) :: baclin, rval
   logical :: have_limits
   real(8), allocatable :: buf(:,:,:)
@@ -60,12 +60,18 @@ program blom_dyncore
   close (u)
   ! options: the reference's namelist file `limits` / `ocn_in` in the working directory, when there is one, decides them
   ! (rdlim, phy/mod_rdlim.F90:137-175) and the length of the run; the option records of the state file are the fall-back
-  call rdlim_gpu(have_limits, nsteps, baclin)
+  nstep1 = 0
+  nstep2 = nsteps
+  call rdlim_gpu(have_limits, nstep1, nstep2, baclin)
   call get_command_argument(2, sval)               ! optional: stop after this many steps (short test runs)
-  if (len_trim(sval) > 0) read (sval, *) nsteps
+  if (len_trim(sval) > 0) then
+    read (sval, *) nsteps
+    nstep2 = nstep1+nsteps
+  end if
 
-  nstep = 0
-  do while (nstep < nsteps)
+  ! the step counter starts at nstep1 = nday1*nstep_in_day (its parity decides the time levels and the order of cppm's sweeps)
+  nstep = nstep1
+  do while (nstep < nstep2)
     call blom_step(nstep)
   end do
 

@@ -15,9 +15,10 @@ module mod_rdlim_gpu
 
 contains
 
-  subroutine rdlim_gpu(found, nsteps, baclin_out)
+  ! nstep1, nstep2: the model is integrated from time step nstep1 to nstep2 (phy/mod_rdlim.F90:1149-1156)
+  subroutine rdlim_gpu(found, nstep1, nstep2, baclin_out)
     logical, intent(out) :: found
-    integer, intent(inout) :: nsteps
+    integer, intent(inout) :: nstep1, nstep2
     real(8), intent(inout) :: baclin_out
 
     ! &LIMITS
@@ -54,8 +55,9 @@ contains
     character(len=80) :: lngmtp = 'none', eitmth = 'gm', edritp = 'large scale', edwmth = 'smooth', ltedtp = 'layer'
 
     character(len=80) :: nlfnm
-    integer :: nfu, ios, lstep
+    integer :: nfu, ios, lstep, nstep_in_day
     logical :: fexist
+    real(8), parameter :: epsilt = 1.d-11              ! phy/mod_constants.F90
 
     namelist /limits/ nday1,nday2,idate,idate0,runid,runtyp, rpoint, expcnf, &
          grfile,icfile,woa_nuopc_provided,pref,baclin,batrop, &
@@ -95,10 +97,21 @@ contains
       write (*,*) 'rdlim: could not read the namelist group LIMITS of '//trim(nlfnm)
       error stop '(rdlim)'
     end if
+    ! the other groups keep their defaults when ABSENT (end of file); a group that is present and malformed stops the
+    ! run as in the reference (phy/mod_vcoord.F90:829-838, phy/mod_diffusion.F90:236-247)
     rewind (nfu)
-    read (unit=nfu, nml=vcoord, iostat=ios)            ! optional groups keep their defaults when absent
+    read (unit=nfu, nml=vcoord, iostat=ios)
+    if (ios > 0) then
+      write (*,*) 'readnml_vcoord: No vertical coordinate variable group found in namelist. ', &
+                  'could not read the namelist group VCOORD of '//trim(nlfnm)
+      error stop '(readnml_vcoord)'
+    end if
     rewind (nfu)
     read (unit=nfu, nml=diffusion, iostat=ios)
+    if (ios > 0) then
+      write (*,*) 'readnml_diffusion: could not read the namelist group DIFFUSION of '//trim(nlfnm)
+      error stop '(readnml_diffusion)'
+    end if
     close (nfu)
 
     write (*,*) 'rdlim: BLOM LIMITS NAMELIST GROUP (dynamical core):'
@@ -150,7 +163,19 @@ contains
         error stop '(readnml_diffusion)'
     end select
     baclin_out = baclin
-    nsteps = (nday2-nday1)*nint(86400.d0/baclin)       ! phy/mod_rdlim.F90: integration from day nday1 to nday2
+    ! an integer number of baroclinic steps per day, phy/mod_time.F90:121-130
+    nstep_in_day = nint(86400.d0/baclin)
+    if (abs(86400.d0/baclin - nstep_in_day) > epsilt) then
+      write (*,*) 'init_timevars: must have an integer number of baroclinic time steps pr. day!'
+      error stop '(init_timevars)'
+    end if
+    ! integration from time step nstep1 to nstep2; with csdiag, five steps (phy/mod_rdlim.F90:1149-1156)
+    nstep1 = nday1*nstep_in_day
+    nstep2 = nday2*nstep_in_day
+    if (csdiag) then
+      nstep2 = nstep1+5
+      call gpu_set('csdiag', 1)
+    end if
   end subroutine rdlim_gpu
 
 end module mod_rdlim_gpu

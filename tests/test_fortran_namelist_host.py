@@ -68,3 +68,53 @@ def test_namelist_file_drives_the_fortran_host(tmp_path):
         run_case(tmp_path, EXE, g.BlomGpu, 3)
     finally:
         g.LIB_PATH = old
+
+
+def _prepared(tmp_path, edit):
+    """state file + an edited copy of the limits file in tmp_path"""
+    import blom_amd.gpu as g
+    case = make_case("fuk95_ref")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = g.BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    names = [n for n in gpu.field_names() if n not in ("mpack", "ip", "iu", "iv", "iq") and not n.startswith("wkp")]
+    state = str(tmp_path / "blom_state.bin")
+    bare = make_case("fuk95_ref")
+    bare.params = {k: v for k, v in bare.params.items() if k in ("baclin",)}
+    write_state(state, gpu, bare, 0, names)
+    gpu.close()
+    limits_for_dyncore(str(tmp_path / "limits"))
+    txt = open(tmp_path / "limits").read()
+    new = edit(txt)
+    assert new != txt
+    open(tmp_path / "limits", "w").write(new)
+    return state
+
+
+@pytest.mark.skipif(not (os.path.exists(EMU) and os.path.exists(EXE)), reason="tests/hostemu not built")
+@pytest.mark.parametrize("what", ["malformed_diffusion_group", "steps_per_day", "csdiag_five_steps"])
+def test_run_length_and_error_behaviour_follow_the_reference(tmp_path, what):
+    """phy/mod_diffusion.F90:236-247 (a present but malformed group stops the run), phy/mod_time.F90:121-130 (an integer
+    number of baroclinic steps per day), phy/mod_rdlim.F90:1154-1156 (csdiag: five steps)."""
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    try:
+        edits = {
+            "malformed_diffusion_group": lambda t: re.sub(r"(?im)^(\s*BDMC1\s*=\s*)\S+", r"\g<1>'not a number'", t, count=1),
+            "steps_per_day": lambda t: re.sub(r"(?im)^(\s*BACLIN\s*=\s*)\S+", r"\g<1>181.", t, count=1),
+            "csdiag_five_steps": lambda t: re.sub(r"(?im)^(\s*CSDIAG\s*=\s*)\S+", r"\g<1>.true.", t, count=1),
+        }
+        state = _prepared(tmp_path, edits[what])
+    finally:
+        g.LIB_PATH = old
+    out = subprocess.run([EXE, state], cwd=str(tmp_path), capture_output=True, text=True, timeout=3000)
+    if what == "malformed_diffusion_group":
+        assert out.returncode != 0 and "readnml_diffusion" in out.stdout + out.stderr
+    elif what == "steps_per_day":
+        assert out.returncode != 0 and "integer number of baroclinic time steps" in out.stdout + out.stderr
+    else:
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert open(tmp_path / "run.status").read().strip() == "success"
+        steps = re.findall(r"(?m)^\s*step\s+(\d+)", out.stdout)
+        assert not steps or int(steps[-1]) == 5, steps[-3:]
