@@ -236,6 +236,81 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0):
                 sample=f"{n} baroclinic steps of the same {cfg} workload, {dt * 1e3:.1f} ms/step, {how}{note}")
 
 
+def bench_hor3map(args):
+    """`--config hor3map`: SURVEY.md 8 row a5 on its own.  A step is the six-call PPM sequence of one tracer-type field
+    (prepare_reconstruction, reconstruct, extract_polycoeff, regrid, prepare_remapping, remap -- what
+    phy/mod_ale_regrid_remap.F90:224-247, :405-415, :1038-1046 does per column) on a model-like slab of the channel's
+    106 080 columns x 53 layers, inputs resident in HBM.  One JSON line; roofline: the slowest of the six kernels against
+    its caller-visible bytes."""
+    import numpy as np
+    import torch
+    import h3m_cases as hc
+    from blom_amd import hor3map as h3
+    ncol, n = 106080, 53
+    x, u, xd, ug = hc.make_slab(11, ncol, n, n, n + 1)
+    dev = torch.device("cuda:0")
+    tx, tu, txd, tug = (torch.from_numpy(a).to(dev) for a in (x, u, xd, ug))
+    cfg = (hc.PPM, 6, 4, hc.NON_OSCILLATORY_POSDEF, True, False)
+    g = h3.ReconGrid(ncol, n, cfg[0], cfg[1], cfg[2])
+    g.set_io(device_pointers=True, check_errors=False)
+    s_, r = h3.ReconSrc(g, cfg[3], cfg[4], cfg[5]), h3.Remap(g, n)
+    npc = h3.P_ORD[cfg[0]] + 1
+    tpc = torch.empty((ncol, n, npc), dtype=torch.float64, device=dev)
+    tud = torch.empty((ncol, n), dtype=torch.float64, device=dev)
+    txg = torch.empty((ncol, n + 1), dtype=torch.float64, device=dev)
+    calls = [("prepare_reconstruction", lambda: g.prepare_reconstruction(tx.data_ptr()), 1),
+             ("reconstruct", lambda: s_.reconstruct(tu.data_ptr()), 1),
+             ("extract_polycoeff", lambda: s_.extract_polycoeff(out=tpc.data_ptr()), npc),
+             ("regrid", lambda: s_.regrid(tug.data_ptr(), -1e33, h3.REGRID_METHOD_2, out=txg.data_ptr(), n_grd=n + 1), 2),
+             ("prepare_remapping", lambda: r.prepare_remapping(txd.data_ptr()), 1),
+             ("remap", lambda: r.remap(s_, out=tud.data_ptr()), 1)]
+    F = ncol * n * 8.0
+    for _ in range(max(1, args.warmup)):
+        for _, f, _ in calls:
+            f()
+    g.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for _, f, _ in calls:
+            f()
+    g.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = {}
+    for nm, f, _ in calls:                     # per-kernel HIP-event times (the library's own events), median of 9
+        v = []
+        for _ in range(9):
+            f()
+            g.sync()
+            v.append(g.last_kernel_ms())
+        kms[nm] = float(np.median(v))
+    dom = max(kms, key=kms.get)
+    alg = {nm: nf * F for nm, _, nf in calls}
+    out = {"metric": "hor3map PPM six-call sequences of a 106080 x 53 slab per second", "value": args.steps / dt,
+           "unit": "slab-sequences/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "mod_hor3map API (phy/mod_hor3map.F90:3834-4559), PPM / non-oscillatory posdef limiting / boundary "
+                                  "orders 6, 4: prepare_reconstruction, reconstruct, extract_polycoeff, regrid (method 2), "
+                                  "prepare_remapping, remap on 106080 columns x 53 layers (tests/h3m_cases.py: make_slab)"},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes": alg[dom], "avg_ms": kms[dom],
+                        "note": "caller-visible arrays in + out; the kernels are bound by dependent fp64 arithmetic at 1.6 "
+                                "wavefronts per SIMD, not by bytes (DESIGN.md 3a)"},
+           "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
+    if not args.no_cpu_baseline and hc.have_ref():
+        m = 6000
+        t0 = time.perf_counter()
+        hc.run_ref(*cfg, x[:m].copy(), u[:m].copy(), xd[:m].copy(), ug[:m].copy(), hc.METHOD_2)
+        dtc = (time.perf_counter() - t0) / m * ncol
+        out["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "slab-sequences/sec", "cores": 1, "kind": "reference",
+                               "sample": f"the reference's compiled mod_hor3map on {m} of the slab's columns, one core, scaled to the slab"}
+    g.free()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +339,8 @@ def main():
                     help="N=1 only: route the halo update through the RCCL transport (rank sends to itself) "
                          "to measure the exchange overhead of the N>1 path on one GPU")
     args = ap.parse_args()
+    if args.config == "hor3map":
+        return bench_hor3map(args)
 
     from blom_amd import launch
     env = launch.rank_env()

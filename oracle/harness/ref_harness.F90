@@ -43,10 +43,11 @@ module ref_harness
   use mod_idlage,    only: idlage_step
   use mod_budget,    only: budget_sums, cnsvdi
   use mod_tracers,   only: ntr, trc, trcold, uflxtr, vflxtr, trflx, inivar_tracers
-  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy
+  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy, nnslpx, nnslpy, bfsqi, bfsqf, bfsql, z, dz
 #ifdef XCHECK_EDDTRA
   ! cross-check builds only (oracle/Makefile *_xed): the reference's real mod_eddtra, compiled against a stand-in for mod_difest
   use mod_eddtra,    only: eddtra
+  use mod_cmnfld_routines, only: cmnfld1, cmnfld2
 #endif
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
@@ -367,6 +368,13 @@ contains
       R3(difint, kdm)
       R3(nslpx, kdm)
       R3(nslpy, kdm)
+      R3(nnslpx, kdm)
+      R3(nnslpy, kdm)
+      R3(bfsqi, kdm+1)
+      R3(bfsqf, kdm+1)
+      R3(bfsql, kdm)
+      R3(z, kdm+1)
+      R3(dz, kdm)
       R3(difiso, kdm)
       R3(difdia, kdm)
       R2(difmxp)
@@ -446,6 +454,8 @@ contains
       case ('tmsmt2');  call tmsmt2(m,mm,nn,k1m)
 #ifdef XCHECK_EDDTRA
       case ('eddtra');  call eddtra(m,n,mm,nn,k1m,k1n)
+      case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
+      case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
 #endif
       ! Halo updates the reference performs inside stages that cannot be built here
       ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.
