@@ -30,7 +30,6 @@
 #include "blomgpu_internal.h"
 
 #define DPEPS 1.e-12
-#define MAXTL 6              // ntr_loc = 2 + ntr
 
 #define THREAD_IJ(V)                                                       \
   unsigned bx_, by_;                                                       \
@@ -794,7 +793,7 @@ int st_cppm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (!c->cppm_ready) return ctx_fail(c, "cppm: init_cppm has not been called (blomgpu_init_cppm)");
   if (h.nreg == 2 && c->tiling.multi()) return ctx_fail(c, "cppm: the arctic patch is built for a single tile");
-  if (2 + h.ntr > MAXTL || W_NSLOT(2 + h.ntr) > h.nwk) return ctx_fail(c, "cppm: too many tracers for the device work space");
+  if (W_NSLOT(2 + h.ntr) > h.nwk) return ctx_fail(c, "cppm: device work space too small for this many tracers");
   const bool fc = c->cppm_compat == 1, mono = c->cppm_limiting == 1;
   if (fc) return mono ? cppm_variant<1, 1>(c, n, mm, nn, k1n) : cppm_variant<0, 1>(c, n, mm, nn, k1n);
   return mono ? cppm_variant<1, 0>(c, n, mm, nn, k1n) : cppm_variant<0, 0>(c, n, mm, nn, k1n);

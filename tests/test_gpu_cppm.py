@@ -20,13 +20,13 @@ SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "v
 VARIANTS = [("full", "non_oscillatory"), ("full", "monotonic"), ("partial", "non_oscillatory"), ("partial", "monotonic")]
 
 
-def _setup(cfg, compat="full", limiting="non_oscillatory"):
+def _setup(cfg, compat="full", limiting="non_oscillatory", ntr=None):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg):
         pytest.skip(f"oracle/_ref/{cfg}/libblomref.so not built")
-    case = make_case(cfg, advmth="cppm", cppm_compatibility=compat, cppm_limiting=limiting)
-    ref = get_ref_backend(cfg, case.depth)
+    case = make_case(cfg, ntr=ntr, advmth="cppm", cppm_compatibility=compat, cppm_limiting=limiting)
+    ref = get_ref_backend(cfg, case.depth, ntr=ntr)
     hostinit.init_state(ref, case)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, ref.ntr, ref.nreg, ref.masks)
     for nm, v in case.params.items():
@@ -35,10 +35,16 @@ def _setup(cfg, compat="full", limiting="non_oscillatory"):
     return case, ref, gpu
 
 
+def test_advect_cppm_with_many_tracers():
+    """cppm carrying 9 tracers, against the reference's own cppm carrying them (oracle/harness: ref_set_ntr)"""
+    test_advect_cppm_stage_parity("chan_s_tke", 4, "full", "non_oscillatory", ntr=9)
+    test_advect_cppm_stage_parity("tri_s_tke", 4, "partial", "monotonic", ntr=6)
+
+
 @pytest.mark.parametrize("compat,limiting", VARIANTS)
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 6), ("box_s", 6), ("fuk95", 4), ("tri_s", 6), ("chan_s_tke", 6)])
-def test_advect_cppm_stage_parity(cfg, nsteps, compat, limiting):
-    case, ref, gpu = _setup(cfg, compat, limiting)
+def test_advect_cppm_stage_parity(cfg, nsteps, compat, limiting, ntr=None):
+    case, ref, gpu = _setup(cfg, compat, limiting, ntr)
     failures, pending, nstep, ready = [], {}, [0], [False]
 
     def check():
@@ -66,7 +72,9 @@ def test_advect_cppm_stage_parity(cfg, nsteps, compat, limiting):
         check()
         nstep[0] = new
     gpu.close()
-    hostinit.init_state(ref, make_case(cfg))            # leave the shared reference instance on 'remap'
+    from oracle.refblom import get_ref_backend           # leave the shared reference instance on 'remap', with its own tracers
+    dflt = make_case(cfg)
+    hostinit.init_state(get_ref_backend(cfg, dflt.depth), dflt)   #
     assert not failures, "\n".join(failures[:20])
 
 
