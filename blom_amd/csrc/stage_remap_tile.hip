@@ -66,9 +66,19 @@ __device__ inline void limited_gradient_t(const double *f, const TNbr &b, int c,
   gy = ty;
 }
 
+// what a face keeps of one polygon for the tracers of later batches: the mass-flux contribution and the two moments, and
+// the donor cell
+struct PolyRec {
+  double fd, qx, qy;
+  int x;
+};
+struct AdvList {               // model indices of the advected tracers, in order
+  unsigned char idx[64];
+};
 // one polygon's contribution from the donor cell at index x of the gradient region (add_contrib of stage_advect.hip)
+template <bool MORE>
 __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbface, double a, double ax, double ay, double axx,
-                                     double ayy, double axy, Acc &A) {
+                                     double ayy, double axy, Acc &A, PolyRec *rec, int &npoly) {
   const double dpt = g[RT_G_DPT(ntr) * RT_GN + x];
   const double pup = g[RT_G_PUP(ntr) * RT_GN + x];
   const double dl = fmin2(dpt, fmax2(0., pbface - pup));
@@ -83,12 +93,21 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
   for (int nt = 0; nt < MAXTR; nt++)
     if (nt < ntr)
       A.ftr[nt] = A.ftr[nt] + fd * g[G_TRD(nt) * RT_GN + x] + qx * g[G_TRX(nt) * RT_GN + x] + qy * g[G_TRY(nt) * RT_GN + x];
+  if (MORE) {
+    rec[npoly].fd = fd; rec[npoly].qx = qx; rec[npoly].qy = qy; rec[npoly].x = x;
+    npoly++;
+  }
 }
 
-__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv, unsigned atr, int tsel, int base) {
-  // base = 0: a further batch of tracers (the launches carry at most MAXTR advected tracers each); the geometry is redone,
-  // only the tracer flux planes are written
+// MORE = true (more than MAXTR advected tracers): the first MAXTR ride with dp, T, S as always; the others follow in batches
+// of MAXTR through the same LDS slots -- their scalars in, their limited gradients (the wet-restricted neighbours, dxi, dyi
+// and the centre-of-mass offsets of the point kept in registers), their fluxes from the polygons' mass-flux contribution
+// and moments each face recorded (PolyRec): the geometry is evaluated once for all tracers.
+template <bool MORE>
+__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv_all, AdvList L, int tsel) {
   const DevView &V = *Vp;
+  const int nadv = nadv_all < MAXTR ? nadv_all : MAXTR;
+  const int base = 1;
   HIP_DYNAMIC_SHARED(double, lds)
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -115,6 +134,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   // (a) the scalar region: one point per thread
   double sv[4 + MAXTR];
   int sm;
+  size_t cs_keep = 0;
   {
     const double *f_dp = V.f[F_dp] + okn, *f_p = V.f[F_p] + (size_t)(k + 1) * np, *f_t = V.f[F_temp] + okn;
     const double *f_s = V.f[F_saln] + okn, *f_tr = V.f[F_trc] + okn;
@@ -124,7 +144,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     sm = in ? mpk[cs] : 0;
     sv[0] = f_dp[cs]; sv[1] = f_p[cs]; sv[2] = f_t[cs]; sv[3] = f_s[cs];
 #pragma unroll
-    for (int a = 0; a < MAXTR; a++) sv[4 + a] = a < nadv ? f_tr[cs + (size_t)((atr >> (8 * a)) & 255u) * 2 * V.kk * np] : 0.;
+    for (int a = 0; a < MAXTR; a++) sv[4 + a] = a < nadv ? f_tr[cs + (size_t)L.idx[a] * 2 * V.kk * np] : 0.;
+    cs_keep = cs;
   }
   // (b) this thread's point of the gradient region (threads 0 .. RT_GN-1): the tile's points first, then the rim
   int gx, gy;
@@ -201,10 +222,12 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
 #pragma unroll
   for (int s = 0; s < 10 + 3 * MAXTR; s++) gv[s] = 0.;
   double cuc = 0., cvc = 0.;
+  TNbr nb;
+  nb.w = nb.e = nb.s = nb.n = nb.sw = nb.se = nb.nw = nb.ne = 0;
+  double k_dxi = 0., k_dyi = 0., k_xd = 0., k_yd = 0.;       // kept for the tracers of later batches (MORE)
   if (gpoint) {
     // wet-restricted neighbours, mod_remap.F90:365-376 (wet_nbr of stage_advect.hip)
     const int a = MU(mpc), b = MU(mpl[sidx + 1]), d = MV(mpc), e = MV(mpl[sidx + RT_SW]);
-    TNbr nb;
     nb.w = sidx - a;
     nb.e = sidx + b;
     nb.s = sidx - d * RT_SW;
@@ -238,6 +261,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     } else {
       dx = 0.; dy = 0.; xd = 0.; yd = 0.;
     }
+    if (MORE) { k_dxi = dxi; k_dyi = dyi; k_xd = xd; k_yd = yd; }
     gv[G_DX] = dx;
     gv[G_DY] = dy;
     gv[8 + 3 * MAXTR] = dpt;                     // stored at RT_G_DPT / RT_G_PUP
@@ -280,11 +304,15 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     cuv[RT_GN + q] = cvc;
   }
   __syncthreads();
-  if (!fin) return;
+  if (!MORE && !fin) return;
 
   // ---- phase 3: flux through this thread's face (k_remap_flux) ---------------------------------------------------------
   const bool in_f = uface ? (fj >= 0 && fj <= V.jj + 1 && fi >= 0 && fi <= V.ii + 2) : (fj >= 0 && fj <= V.jj + 2 && fi >= 0 && fi <= V.ii + 1);
-  if (!in_f) return;
+  if (!MORE && !in_f) return;
+  const bool do_face = fin && in_f;
+  PolyRec rec[3];
+  int npoly = 0;
+  if (do_face) {
   Acc A;
   A.fd = 0.; A.ft = 0.; A.fs = 0.;
 #pragma unroll
@@ -307,7 +335,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x4 = xc0 + sh;
         y4 = -.5;
         triint(s2_m, xc1 + sh, .5, -cuc0 + sh, -cvc0 + .5, sh, .5, a, ax, ay, axx, ayy, axy);
-        add_contrib_t(gr, nadv, ic - RT_GW, pbf, a, ax, ay, axx, ayy, axy, A);
+        add_contrib_t<MORE>(gr, nadv, ic - RT_GW, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       } else {
         x4 = -cuc0 + sh;
         y4 = -cvc0 - .5;
@@ -318,13 +346,13 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x2 = xc0 + sh;
         y2 = .5;
         triint(s2_p, xc1 + sh, -.5, sh, -.5, -cuc1 + sh, -cvc1 - .5, a, ax, ay, axx, ayy, axy);
-        add_contrib_t(gr, nadv, ic + RT_GW, pbf, a, ax, ay, axx, ayy, axy, A);
+        add_contrib_t<MORE>(gr, nadv, ic + RT_GW, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       } else {
         x2 = -cuc1 + sh;
         y2 = -cvc1 + .5;
       }
       penint(s2_c, sh, .5, x2, y2, xm + sh, ym, x4, y4, sh, -.5, a, ax, ay, axx, ayy, axy);
-      add_contrib_t(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A);
+      add_contrib_t<MORE>(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       // mod_remap.F90:1054-1056
       if (base) {
         *o_f = f_o + A.fd;
@@ -342,7 +370,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x2 = -.5;
         y2 = yc0 + sh;
         triint(s2_m, .5, yc1 + sh, .5, sh, -cuc0 + .5, -cvc0 + sh, a, ax, ay, axx, ayy, axy);
-        add_contrib_t(gr, nadv, jc - 1, pbf, a, ax, ay, axx, ayy, axy, A);
+        add_contrib_t<MORE>(gr, nadv, jc - 1, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       } else {
         x2 = -cuc0 - .5;
         y2 = -cvc0 + sh;
@@ -353,13 +381,13 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x4 = .5;
         y4 = yc0 + sh;
         triint(s2_p, -.5, yc1 + sh, -cuc1 - .5, -cvc1 + sh, -.5, sh, a, ax, ay, axx, ayy, axy);
-        add_contrib_t(gr, nadv, jc + 1, pbf, a, ax, ay, axx, ayy, axy, A);
+        add_contrib_t<MORE>(gr, nadv, jc + 1, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       } else {
         x4 = -cuc1 + .5;
         y4 = -cvc1 + sh;
       }
       penint(s2_c, -.5, sh, x2, y2, xm, ym + sh, x4, y4, .5, sh, a, ax, ay, axx, ayy, axy);
-      add_contrib_t(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A);
+      add_contrib_t<MORE>(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       // mod_remap.F90:1455-1457: assignment (not accumulation) for the v-components
       if (base) {
         *o_f = A.fd;
@@ -377,7 +405,51 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   }
 #pragma unroll
   for (int nt = 0; nt < MAXTR; nt++)
-    if (nt < nadv) WK(V, W_FTRU(ntr, (atr >> (8 * nt)) & 255u) + off)[fc + ok] = A.ftr[nt];
+    if (nt < nadv) WK(V, W_FTRU(ntr, L.idx[nt]) + off)[fc + ok] = A.ftr[nt];
+  }
+  if (!MORE) return;
+  // ---- the other advected tracers, MAXTR at a time ----------------------------------------------------------------------
+  const double *f_tr = V.f[F_trc] + okn;
+  const int off2 = uface ? 0 : 1;
+  for (int b0 = MAXTR; b0 < nadv_all; b0 += MAXTR) {
+    const int nb_ = nadv_all - b0 < MAXTR ? nadv_all - b0 : MAXTR;
+    double tv[MAXTR];
+#pragma unroll
+    for (int a = 0; a < MAXTR; a++) tv[a] = (a < nb_ && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[b0 + a] * 2 * V.kk * np] : 0.;
+    __syncthreads();                                         // the gradient slots of the previous batch have been read
+    if (t < RT_SN) {
+#pragma unroll
+      for (int a = 0; a < MAXTR; a++)
+        if (a < nb_) sc[a * RT_SN + t] = tv[a];
+    }
+    __syncthreads();
+    // the scalars lie in slots 0..3 of the scalar region (below RT_SN * MAXTR doubles), the tracer gradient slots start at
+    // 8 * RT_GN: no overlap, the gradients go straight to their slots
+    static_assert(MAXTR * RT_SN <= 8 * RT_GN, "batch scalars and tracer gradient slots must not overlap");
+    if (gthread) {
+#pragma unroll
+      for (int a = 0; a < MAXTR; a++)
+        if (a < nb_) {
+          double gxx = 0., gyy = 0., gdd = 0.;
+          if (gpoint) limited_gradient_t(sc + a * RT_SN, nb, sidx, k_dxi, k_dyi, k_xd, k_yd, gxx, gyy, gdd);
+          gr[G_TRX(a) * RT_GN + q] = gxx;
+          gr[G_TRY(a) * RT_GN + q] = gyy;
+          gr[G_TRD(a) * RT_GN + q] = gdd;
+        }
+    }
+    __syncthreads();
+    if (do_face) {
+#pragma unroll
+      for (int a = 0; a < MAXTR; a++)
+        if (a < nb_) {
+          double f = 0.;
+          for (int pz = 0; pz < npoly; pz++)
+            f = f + rec[pz].fd * gr[G_TRD(a) * RT_GN + rec[pz].x] + rec[pz].qx * gr[G_TRX(a) * RT_GN + rec[pz].x] +
+                rec[pz].qy * gr[G_TRY(a) * RT_GN + rec[pz].x];
+          WK(V, W_FTRU(ntr, L.idx[b0 + a]) + off2)[fc + ok] = f;
+        }
+    }
+  }
 }
 
 int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
@@ -385,20 +457,20 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
   const int ntx = (h.ni + RT_TW - 1) / RT_TW, nty = (h.nj + RT_TH - 1) / RT_TH;
   static_assert(RT_NSC(MAXTR) * RT_SN <= RT_NG(MAXTR) * RT_GN, "the scalars must fit under the gradient slots");
   if (h.ntr > 255) return ctx_fail(c, "remap: tracer indices are packed in 8 bits");
-  if (W_FTRV(h.ntr, h.ntr - 1) >= h.nwk) return ctx_fail(c, "remap: work space too small for this many tracers");
-  // the advected tracers MAXTR at a time (TKE and its length scale are not advected unless use_TKEADV); the first launch
-  // also carries dp, T, S
-  int nt = 0, launches = 0;
-  do {
-    int nadv = 0;
-    unsigned atr = 0;
-    for (; nt < h.ntr && nadv < MAXTR; nt++)
-      if (!trc_skip_adv(h.P, nt + 1)) atr |= (unsigned)nt << (8 * nadv++);
-    if (launches > 0 && nadv == 0) break;
-    const size_t lds = sizeof(double) * (RT_NG(nadv) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
-    hipLaunchKernelGGL(k_remap_tile, dim3(ntx * nty, h.kk), dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, atr, tsel,
-                       launches == 0 ? 1 : 0);
-    launches++;
-  } while (nt < h.ntr);
+  if (h.ntr > 0 && W_FTRV(h.ntr, h.ntr - 1) >= h.nwk) return ctx_fail(c, "remap: work space too small for this many tracers");
+  // the advected tracers (TKE and its length scale are not advected unless use_TKEADV, mod_remap.F90:314-316)
+  AdvList L;
+  int nadv = 0;
+  for (int nt = 0; nt < h.ntr; nt++)
+    if (!trc_skip_adv(h.P, nt + 1)) {
+      if (nadv == 64) return ctx_fail(c, "remap: more than 64 advected tracers");
+      L.idx[nadv++] = (unsigned char)nt;
+    }
+  for (int a = nadv; a < 64; a++) L.idx[a] = 0;
+  const int nfirst = nadv < MAXTR ? nadv : MAXTR;
+  const size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
+  const dim3 grid(ntx * nty, h.kk);
+  if (nadv > MAXTR) hipLaunchKernelGGL(k_remap_tile<true>, grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+  else hipLaunchKernelGGL(k_remap_tile<false>, grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
   return 0;
 }
