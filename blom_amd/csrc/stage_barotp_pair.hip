@@ -503,7 +503,9 @@ static BtShape bt_shape(blomgpu_ctx *c) {
   }
   // the smallest shape whose tiles all find a CU of their own (measured on the 180 x 193 tripolar grid: 32x16 = 78 tiles
   // 16.4 us per launch, 32x8 = 150 tiles 13.5 us, 16x8 = 300 tiles on 256 CUs 22.7 us)
-  static const BtShape shapes[3] = {{16, 8}, {32, 8}, {32, 16}};
+  // 40x16 (1012 of the 1024 threads a workgroup may have): for domains whose 32x16 tiles outnumber the CUs -- the tnx1v4
+  // dimensions, 360 x 385: 300 tiles of 32x16 take two rounds on 256 CUs (42 us per pair), 225 tiles of 40x16 one
+  static const BtShape shapes[4] = {{16, 8}, {32, 8}, {32, 16}, {40, 16}};
   for (const BtShape &sh : shapes) {
     const int nt = ((h.ii + sh.ti - 1) / sh.ti) * ((h.jj + sh.tj - 1) / sh.tj);
     if (nt <= c->num_cus) return sh;
@@ -514,7 +516,8 @@ static int bt_launch_pair(blomgpu_ctx *c, BtShape sh, dim3 grid, hipStream_t st,
   if (sh.ti == 32 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 32, 16>), grid, dim3(bt_threads(32, 16)), 0, st, c->d, a);
   else if (sh.ti == 32 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 32, 8>), grid, dim3(bt_threads(32, 8)), 0, st, c->d, a);
   else if (sh.ti == 16 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 16, 8>), grid, dim3(bt_threads(16, 8)), 0, st, c->d, a);
-  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208 or 1608");
+  else if (sh.ti == 40 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 40, 16>), grid, dim3(bt_threads(40, 16)), 0, st, c->d, a);
+  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208, 1608 or 4016");
   return 0;
 }
 
