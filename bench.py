@@ -138,36 +138,41 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0):
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0, live=True):
     """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
     2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
     default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
     import threading
     res = {}
     threading.stack_size(2 << 30)
-    th = threading.Thread(target=lambda: res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds)))
+    th = threading.Thread(target=lambda: res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live)))
     th.start()
     th.join()
     threading.stack_size(0)
     return res
 
 
-def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0):
-    """Reference (preferred) or C restatement timed on the host for a bounded number of steps."""
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0, live=True):
+    """The reference's own Fortran (preferred) or the C restatement, timed on the host for a bounded number of steps.
+    Preferred build: oracle/_ref/<cfg>_omp_xed -- the reference's hot-path modules INCLUDING its real mod_cmnfld_routines and
+    mod_eddtra (compiled against the two small stand-in modules of oracle/xcheck/, see there), with its OpenMP directives
+    on: every stage of the sequence the device is timed on (cmnfld2's slopes from the evolving state, eddtra on them) runs in
+    the reference's code on all host cores.  Without it: <cfg>_omp, which lacks those two stages -- they are then timed on the
+    C restatement on one thread and reported beside `value`, not inside it."""
     from blom_amd import hostinit
-    from blom_amd.stepper import dyncore_step
+    from blom_amd.stepper import dyncore_step, DYNCORE_STAGES
     from oracle.refblom import get_ref_backend, have_ref
     from oracle.coracle import COracle
     ncores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(ncores)
-    ref_cfg = cfg + "_omp" if have_ref(cfg + "_omp") else (cfg if have_ref(cfg) else None)
-    # mod_eddtra and cmnfld2's slopes are not part of the reference build (CVMix / netCDF).  They are timed on the C
-    # restatement and reported beside the baseline (`restatement_legs`), NOT inside `value`: `value` is the reference's own
-    # Fortran alone, so that it is one thread count throughout.  (Their j-loops carry OpenMP pragmas, but on the GPU box
-    # gcc's runtime next to PyTorch's and LLVM's thread pools ran them 2-3x SLOWER on 16 threads than on one -- 201 / 505 ms
-    # against 78 / 288 ms -- so they are timed on one thread, before the reference's library and its thread team exist.)
+    full = have_ref(cfg + "_omp_xed")
+    ref_cfg = cfg + "_omp_xed" if full else (cfg + "_omp" if have_ref(cfg + "_omp") else (cfg if have_ref(cfg) else None))
+    stages = DYNCORE_STAGES
     note, de, dc = "", 0.0, 0.0
-    if ref_cfg is not None:
+    if ref_cfg is not None and not full:
+        # (The restatement's j-loops carry OpenMP pragmas, but on the GPU box gcc's runtime next to PyTorch's and LLVM's thread
+        # pools ran them 2-3x SLOWER on 16 threads than on one, so they are timed on one thread, before the reference's
+        # library and its thread team exist.)
         import ctypes
         try:
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
@@ -190,24 +195,31 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0):
         co.stage("cmnfld2", *six)
         dc = best_of("cmnfld2")
         del co
-        note = (f"; not in value: eddtra ({de * 1e3:.1f} ms) and cmnfld2's slopes ({dc * 1e3:.1f} ms), which the reference build "
+        note = (f"; not in value: eddtra ({de * 1e3:.1f} ms) and cmnfld2's slopes ({dc * 1e3:.1f} ms), which this reference build "
                 "lacks, timed on the C restatements on one thread")
     kind, cores = None, 1
     try:
         if ref_cfg is not None:
-            if ref_cfg.endswith("_omp"):        # the reference with its OpenMP directives on, all host cores
+            if "_omp" in ref_cfg:               # the reference with its OpenMP directives on, all host cores
                 cores = ncores
                 os.environ.setdefault("OMP_PROC_BIND", "close")
                 os.environ["OMP_STACKSIZE"] = "1G"   # the stages keep private 2-D work arrays on the thread stacks
             be = get_ref_backend(ref_cfg, case.depth)
             kind = "reference"
+            if full:
+                be.ref.set("eitmth", "gm")
+                be.has_stage = lambda name: True             # this build's harness knows eddtra and cmnfld2
+                if live:
+                    stages = tuple("cmnfld2" if s_ == "halo_cmnfld2" else s_ for s_ in DYNCORE_STAGES)
+                note = ("; every stage in the reference's own code, mod_cmnfld_routines and mod_eddtra compiled against the "
+                        "stand-in modules of oracle/xcheck/ (one array of mod_difest, the diagnostic flags of mod_dia)")
     except Exception:
-        kind, cores, de, dc, note = None, 1, 0.0, 0.0, ""
+        kind, cores, de, dc, note, full, stages = None, 1, 0.0, 0.0, "", False, DYNCORE_STAGES
     if kind is None:
         be = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
         kind = "port"
     hostinit.init_state(be, case)
-    ns = dyncore_step(be, 0, case.params["baclin"])          # forward first step (untimed)
+    ns = dyncore_step(be, 0, case.params["baclin"], stages=stages)          # forward first step (untimed)
     # per-stage host times beside the device's stages_ms: the hook fires before every stage
     per_stage, mark = {}, [None, 0.0]
 
@@ -219,7 +231,7 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0):
     t0 = time.time()
     n = 0
     while n < 3 or (time.time() - t0 < max_seconds and n < 120):
-        ns = dyncore_step(be, ns, case.params["baclin"], hook=hook)
+        ns = dyncore_step(be, ns, case.params["baclin"], hook=hook, stages=stages)
         hook(None, None)
         n += 1
     dt = (time.time() - t0) / n
@@ -230,9 +242,13 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0):
     # the device reports advect as "remap" (or "cppm"): same name here
     if "advect" in stages_ms:
         stages_ms[case.params.get("advmth", "remap")] = stages_ms.pop("advect")
+    if "cmnfld2" in stages_ms:
+        stages_ms["cmnfld"] = stages_ms.pop("cmnfld2")
     return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=cores, kind=kind, stages_ms=stages_ms,
                 reference_only_ms=round(ref_only_ms, 2), steps_timed=n,
-                restatement_legs={"eddtra_ms": round(de * 1e3, 2), "cmnfld2_ms": round(dc * 1e3, 2), "threads": 1, "in_value": False},
+                build=ref_cfg,
+                restatement_legs=(None if full or kind != "reference" else
+                                  {"eddtra_ms": round(de * 1e3, 2), "cmnfld2_ms": round(dc * 1e3, 2), "threads": 1, "in_value": False}),
                 sample=f"{n} baroclinic steps of the same {cfg} workload, {dt * 1e3:.1f} ms/step, {how}{note}")
 
 
@@ -536,7 +552,7 @@ def main():
         os.dup2(2, 1)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg)
+                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live")
             except Exception as e:                       # the bench line must still be produced
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
