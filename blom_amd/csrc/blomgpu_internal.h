@@ -218,6 +218,9 @@ struct blomgpu_ctx {
   bool pbcor2_handed_over = false;   // likewise pbcor2 (level m) for tmsmt2
   bool pbcor1_handed_over = false;   // pbcor1 left S, T, tracers of the new level in the work space (slots N_S, N_T, N_TR): diffus starts there
   int steps_warm = 0;            // plain steps since the last option change (graph capture waits for 4)
+  int pgf_uv_pair = 0;           // k_pgf_uv, A/B option: 1 = the u- and v-column wavefronts of 64 points in one workgroup with XCD-contiguous
+                                 // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
+                                 // each): the kernel waits on its k-serial chain, not on bytes.  Off.
   int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded
   int check_period = 8;          // steps between read-backs of the sticky stage error words in blomgpu_step
   bool csdiag = false;           // mod_checksum's switch: error words read back every step

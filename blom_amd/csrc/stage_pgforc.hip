@@ -99,16 +99,16 @@ __global__ __launch_bounds__(64) void k_pgf_phi(const DevView *__restrict__ Vp, 
 // numbered so that an XCD walks a contiguous eighth of the plane (xcd_block): the p-column records (p, T, S, phi, phi')
 // that the u- and the v-column of a point and their row neighbours share are then fetched into one L2 instead of up to
 // four (the u- and v-columns used to be separate workgroups: 1.44 GB fetched for ~0.5 GB of distinct bytes).
+template <bool PAIR>
 __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
-  (void)by_;
-  const int t = bx_ * 64 + (threadIdx.x & 63);
+  const int t = PAIR ? bx_ * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V.nplane) return;
   const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
-  const bool isv = threadIdx.x >= 64;
+  const bool isv = PAIR ? threadIdx.x >= 64 : blockIdx.y == 1;
   const size_t c = t, np = V.nplane;
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t mns = isv ? c - V.ni : c - 1;
@@ -299,7 +299,10 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     else hipLaunchKernelGGL(k_pgf_dynh_col, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn);
     // xctilr(pb_p,1,1,1,1) at :540 precedes the /pb_p(i-1,j) scaling done inside k_pgf_uv
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
-    if (h.P.pgfmth == 0) hipLaunchKernelGGL(k_pgf_uv, plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
+    if (h.P.pgfmth == 0) {
+      if (c->pgf_uv_pair) hipLaunchKernelGGL(k_pgf_uv<true>, plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
+      else hipLaunchKernelGGL(k_pgf_uv<false>, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+    }
     else hipLaunchKernelGGL(k_pgf_dynh_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
   }
   hipLaunchKernelGGL(k_pgf_sealv, plane_grid(h), dim3(256), 0, c->stream, c->d);
