@@ -221,6 +221,7 @@ struct blomgpu_ctx {
   int pgf_uv_pair = 0;           // k_pgf_uv, A/B option: 1 = the u- and v-column wavefronts of 64 points in one workgroup with XCD-contiguous
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
+  int pgf_copy_fused = 1;        // pgforc: the pgfx_o/pgfy_o copy rides along in k_pgf_uv
   int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded
   int check_period = 8;          // steps between read-backs of the sticky stage error words in blomgpu_step
   bool csdiag = false;           // mod_checksum's switch: error words read back every step

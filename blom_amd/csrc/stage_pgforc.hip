@@ -99,7 +99,9 @@ __global__ __launch_bounds__(64) void k_pgf_phi(const DevView *__restrict__ Vp, 
 // numbered so that an XCD walks a contiguous eighth of the plane (xcd_block): the p-column records (p, T, S, phi, phi')
 // that the u- and the v-column of a point and their row neighbours share are then fetched into one L2 instead of up to
 // four (the u- and v-columns used to be separate workgroups: 1.44 GB fetched for ~0.5 GB of distinct bytes).
-template <bool PAIR>
+// COPY: the *_o copy of the previous pressure gradient (:488-522, k_pgf_copy_old3d) rides along -- the kernel overwrites
+// pgfx/pgfy(kn) level by level and takes the old value on the way (one launch and one sweep over the field less)
+template <bool PAIR, bool COPY>
 __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
   const double *pz = isv ? V.f[F_pv] : V.f[F_pu];
   const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
   double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  double *pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
   // The layers kp, km of the two scalar columns that hold the pressure of the velocity point's layer centre move
   // upwards with k, usually by one.  What the level needs of layer kp -- p above and below, T, S, phi, phi' -- is kept
   // in registers together with the same record of layer kp-1, re-loaded in the background when kp moves; the fixed-index
@@ -138,12 +141,15 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
   double dpk_n = dpz[c + (size_t)(kk - 1) * np], pz_n = pz[c + (size_t)kk * np];
   double pck = p[c + (size_t)kk * np], pmk = p[mns + (size_t)kk * np];
   double pck1_n = p[c + (size_t)(kk - 1) * np], pmk1_n = p[mns + (size_t)(kk - 1) * np];
+  double old_n = COPY ? pgf[c + (size_t)(kk - 1) * np] : 0.;
   for (int k = kk; k >= 1; k--) {
-    const double dpk = dpk_n, pzk = pz_n, pck1 = pck1_n, pmk1 = pmk1_n;
+    const double dpk = dpk_n, pzk = pz_n, pck1 = pck1_n, pmk1 = pmk1_n, old = old_n;
     if (k > 1) {                                             // level k-1's fixed-index loads
       dpk_n = dpz[c + (size_t)(k - 2) * np]; pz_n = pz[c + (size_t)(k - 1) * np];
       pck1_n = p[c + (size_t)(k - 2) * np]; pmk1_n = p[mns + (size_t)(k - 2) * np];
+      if (COPY) old_n = pgf[c + (size_t)(k - 2) * np];
     }
+    if (COPY) pgf_o[c + (size_t)(k - 1) * np] = old;
     const double prs = pzk - .5 * dpk;
     while (rp.pu > prs) { kp--; rp = rp1; rp1 = load_rec(c, kp - 1); }
     while (rm.pu > prs) { km--; rm = rm1; rm1 = load_rec(mns, km - 1); }
@@ -254,6 +260,7 @@ __global__ void k_pgf_dynh_uv(const DevView *__restrict__ Vp, int n, int nn) {
   const double *temp = V.f[F_temp] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
   const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
   double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  double *pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
   const double *pot = WK(V, DH_POT), *potpb = WK(V, DH_POTPB), *da = WK(V, DH_A), *dt = WK(V, DH_T), *ar = WK(V, DH_ALPR);
   double xip = 0., xim = 0., pgfm = 0.;
   for (int k = kk; k >= 1; k--) {
@@ -292,7 +299,8 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (int rc = launch_p_dpu_dpv(c, nn, 1)) return rc;
   hipLaunchKernelGGL(k_pgf_copy_old2d, plane_grid(h), dim3(256), 0, c->stream, c->d, n);
-  hipLaunchKernelGGL(k_pgf_copy_old3d, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+  const bool copy_fused = h.P.pgfmth == 0 && c->pgf_copy_fused && !c->pgf_uv_pair;
+  if (!copy_fused) hipLaunchKernelGGL(k_pgf_copy_old3d, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
   {
     TimeScope ts(c, "pgforc");
     if (h.P.pgfmth == 0) hipLaunchKernelGGL(k_pgf_phi, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn);
@@ -300,8 +308,9 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     // xctilr(pb_p,1,1,1,1) at :540 precedes the /pb_p(i-1,j) scaling done inside k_pgf_uv
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
     if (h.P.pgfmth == 0) {
-      if (c->pgf_uv_pair) hipLaunchKernelGGL(k_pgf_uv<true>, plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
-      else hipLaunchKernelGGL(k_pgf_uv<false>, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+      if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
+      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
     }
     else hipLaunchKernelGGL(k_pgf_dynh_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
   }
