@@ -138,7 +138,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0, live=True):
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
     """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
     2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
     default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
@@ -152,7 +152,7 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0, live=True):
     return res
 
 
-def _cpu_baseline(cfg, case, masks, nreg, max_seconds=36.0, live=True):
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
     """The reference's own Fortran (preferred) or the C restatement, timed on the host for a bounded number of steps.
     Preferred build: oracle/_ref/<cfg>_omp_xed -- the reference's hot-path modules INCLUDING its real mod_cmnfld_routines and
     mod_eddtra (compiled against the two small stand-in modules of oracle/xcheck/, see there), with its OpenMP directives

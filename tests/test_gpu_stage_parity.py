@@ -174,9 +174,15 @@ def _freerun_device(cfg, nsteps, rtol, eddy, ntr=None):
     assert not bad, fmt_report(bad)
 
 
+def test_full_size_with_24_tracers_matches_reference():
+    """BASELINE.json's channel at full size carrying 24 tracers (config 5 advects iHAMOCC's through these stages), with the
+    eddy-induced fluxes on: the reference's own Fortran carrying them (ref_set_ntr) against the device-resident sequence."""
+    test_full_size_matches_reference("channel_tke", True, ntr=24, nsteps=3)
+
+
 @pytest.mark.parametrize("eddy", [False, True], ids=["zero_eddy_fluxes", "eddy_fluxes"])
 @pytest.mark.parametrize("cfg", ["channel_tke", "tnx2v1s_tke"])
-def test_full_size_matches_reference(cfg, eddy):
+def test_full_size_matches_reference(cfg, eddy, ntr=None, nsteps=4):
     """BASELINE.json's channel (208x512x53) with the reference's default tracer set (ntr = 3), the bench workload, and
     the tnx2v1 grid's dimensions (180x193x53, arctic patch, synthetic bathymetry): the device-resident sequence against
     the reference's own Fortran (built with its OpenMP directives, oracle/_ref/<cfg>_omp) over the forward step and
@@ -187,11 +193,11 @@ def test_full_size_matches_reference(cfg, eddy):
     from blom_amd.gpu import BlomGpu
     if not have_ref(cfg + "_omp"):
         pytest.skip(f"oracle/_ref/{cfg}_omp/libblomref.so not built")
-    nsteps, res = 4, {}
+    res = {}
 
     def body():
-        case = make_case(cfg)
-        ref = get_ref_backend(cfg + "_omp", case.depth)
+        case = make_case(cfg, ntr=ntr)
+        ref = get_ref_backend(cfg + "_omp", case.depth, ntr=ntr)
         hostinit.init_state(ref, case)
         if eddy:
             hostinit.frozen_eddy_fluxes(ref, case)
@@ -220,7 +226,7 @@ def test_full_size_matches_reference(cfg, eddy):
     th.join()
     threading.stack_size(0)
     assert "bad" in res, "the comparison did not complete"
-    assert res["ntr"] == 3
+    assert res["ntr"] == (ntr or 3)
     assert not res["bad"], fmt_report(res["bad"])
 
 
