@@ -64,9 +64,12 @@ template <bool PERSIST, int TI, int TJ>
 __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *__restrict__ Vp, PairArgs a) {
   constexpr int BI = TI + 2 * HB, BJ = TJ + 2 * HB, NPT = BI * BJ;
   const DevView &V = *Vp;
-  __shared__ double s_pb[2][BJ][BI + 1], s_ub[2][BJ][BI + 1], s_vb[2][BJ][BI + 1];
+#ifndef BT_PAD
+#define BT_PAD 1
+#endif
+  __shared__ double s_pb[2][BJ][BI + BT_PAD], s_ub[2][BJ][BI + BT_PAD], s_vb[2][BJ][BI + BT_PAD];
   // coefficients that the momentum equations read at neighbouring points: staged once per launch
-  __shared__ double s_pvo[BJ][BI + 1], s_pvm[BJ][BI + 1], s_pvn[BJ][BI + 1], s_sx[BJ][BI + 1], s_sy[BJ][BI + 1];
+  __shared__ double s_pvo[BJ][BI + BT_PAD], s_pvm[BJ][BI + BT_PAD], s_pvn[BJ][BI + BT_PAD], s_sx[BJ][BI + BT_PAD], s_sy[BJ][BI + BT_PAD];
   __shared__ int s_abort;
   const int tid = threadIdx.x;
   const unsigned bx = PERSIST || a.tsel == 0 ? blockIdx.x : (a.tsel == 1 ? (blockIdx.x ? a.nbx - 1 : 0u) : blockIdx.x + 1);

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libblomgpu.so")
+# BLOMGPU_LIB: another build of the same library (A/B timing of kernel variants, tools/); never a different implementation
+LIB_PATH = os.environ.get("BLOMGPU_LIB") or os.path.join(_HERE, "lib", "libblomgpu.so")
 
 
 class blomgpu_dims(C.Structure):
