@@ -17,8 +17,16 @@
 // serve contexts whose domain is only a few of those tiles -- the tiles of a multi-GPU decomposition, small grids -- where a
 // launch is bound by the sweeps of ONE tile on ONE CU (6.7 of 12.4 us per substep pair) while most CUs are idle.
 #define HB 3
-#define TI_D 32
+// The persistent form's tile is 26 x 16 (704 points with the rim = 11 wavefronts): a workgroup of at most 768 threads may use
+// 168 VGPRs, and the kernel needs 158 -- the 32 x 16 tile of rounds 1-2 (896 threads, 128 VGPRs) spilled 80 of them to
+// scratch memory, which cost a quarter of every iteration (in-kernel timestamps: the even substep's sweeps took 5.4 us
+// against 1.4 us for the odd one's).  208 x 512 points are 8 x 32 = 256 such tiles: one per CU.
+#ifndef TI_D
+#define TI_D 26
+#endif
+#ifndef TJ_D
 #define TJ_D 16
+#endif
 constexpr int bt_threads(int ti, int tj) { return ((ti + 2 * HB) * (tj + 2 * HB) + 63) / 64 * 64; }
 struct BtShape { int ti, tj; };
 
@@ -282,6 +290,7 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
     }
     __syncthreads();
     PROF_MARK();
+    if (half == 1) PMARK(7);                 // the even substep's continuity sweep done
     // after continuity pb[nl] is valid on [vlo_i, vhi_i-1] x [vlo_j, vhi_j-1]
     const int p_hi_i = vhi_i - 1, p_hi_j = vhi_j - 1;
     auto do_u = [&](int lv, int lo_i, int hi_i, int lo_j, int hi_j, int r_i0, int r_i1, int r_j0, int r_j1) {
@@ -354,6 +363,7 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
       vlo_i = u_lo_i; vhi_i = u_hi_i; vlo_j = u_lo_j; vhi_j = u_hi_j;
     }
     PROF_MARK();
+    if (half == 0) PMARK(6);                 // the odd substep's three sweeps done
     const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
   }
   // publish the interior (and, with the arctic patch, the owned margin) in the other buffer set
@@ -508,19 +518,20 @@ static BtShape bt_shape(blomgpu_ctx *c) {
   // 16.4 us per launch, 32x8 = 150 tiles 13.5 us, 16x8 = 300 tiles on 256 CUs 22.7 us)
   // 40x16 (1012 of the 1024 threads a workgroup may have): for domains whose 32x16 tiles outnumber the CUs -- the tnx1v4
   // dimensions, 360 x 385: 300 tiles of 32x16 take two rounds on 256 CUs (42 us per pair), 225 tiles of 40x16 one
-  static const BtShape shapes[4] = {{16, 8}, {32, 8}, {32, 16}, {40, 16}};
+  static const BtShape shapes[5] = {{16, 8}, {32, 8}, {26, 16}, {32, 16}, {40, 16}};
   for (const BtShape &sh : shapes) {
     const int nt = ((h.ii + sh.ti - 1) / sh.ti) * ((h.jj + sh.tj - 1) / sh.tj);
     if (nt <= c->num_cus) return sh;
   }
-  return shapes[2];
+  return shapes[3];
 }
 static int bt_launch_pair(blomgpu_ctx *c, BtShape sh, dim3 grid, hipStream_t st, const PairArgs &a) {
   if (sh.ti == 32 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 32, 16>), grid, dim3(bt_threads(32, 16)), 0, st, c->d, a);
   else if (sh.ti == 32 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 32, 8>), grid, dim3(bt_threads(32, 8)), 0, st, c->d, a);
   else if (sh.ti == 16 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 16, 8>), grid, dim3(bt_threads(16, 8)), 0, st, c->d, a);
   else if (sh.ti == 40 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 40, 16>), grid, dim3(bt_threads(40, 16)), 0, st, c->d, a);
-  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208, 1608 or 4016");
+  else if (sh.ti == 26 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 26, 16>), grid, dim3(bt_threads(26, 16)), 0, st, c->d, a);
+  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208, 1608, 4016 or 2616");
   return 0;
 }
 

@@ -30,7 +30,7 @@ def _run(cfg, nsteps, **opts):
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("box_s", 8), ("fuk95", 6), ("chan_m", 6), ("tri_s", 8),
                                         ("chan_s_tke", 12), ("tri_s_tke", 8)])
 @pytest.mark.parametrize("opt,variants", [("barotp_fused", (0, 1)), ("barotp_persist", (0, 1)), ("diapfl_du", (4, 8)),
-                                          ("barotp_tile", (3216, 3208)), ("barotp_tile", (3216, 1608)), ("barotp_tile", (3216, 4016))])
+                                          ("barotp_tile", (3216, 3208)), ("barotp_tile", (3216, 1608)), ("barotp_tile", (3216, 4016)), ("barotp_tile", (3216, 2616))])
 def test_variants_bit_identical(cfg, nsteps, opt, variants):
     a = _run(cfg, nsteps, **{opt: variants[0]})
     b = _run(cfg, nsteps, **{opt: variants[1]})
