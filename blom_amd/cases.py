@@ -102,6 +102,8 @@ _DIMS = {
     "chan_s": (20, 24, 6, 1, 10.0e3, 900.0, 18.0),
     "chan_m": (80, 40, 8, 1, 10.0e3, 900.0, 18.0),     # several 32x8 device tiles, periodic in i
     "tri_s": (24, 20, 6, 2, 10.0e3, 900.0, 18.0),      # periodic in i, arctic patch along the last row (nreg = 2)
+    # the same topology over several 26 x 16 tiles of barotp's persistent kernel (3 x 3, last column 12 wide, last row 8 high)
+    "tri_m": (64, 40, 6, 2, 10.0e3, 900.0, 18.0),
     # synthetic stand-in for the tnx2v1 production grid: its dimensions, region type
     # and time steps (baclin 4800 s, batrop 96 s => lstep 50); analytic continents instead of grid.nc
     "tnx2v1s": (180, 193, 53, 2, 100.0e3, 4800.0, 96.0),
@@ -165,16 +167,18 @@ def _depth_for(name, idm, jdm, dx):
         d[0, :] = 0.0
         d[-1, :] = 0.0
         return d
-    if name in ("tnx2v1s", "tnx1v4s"):
+    if name in ("tnx2v1s", "tnx1v4s", "tri_m"):
         x = (ii - 0.5) / idm
         y = (jj - 0.5) / jdm
         d = 3000.0 + 1500.0 * np.sin(2.0 * np.pi * x) * np.sin(np.pi * y) + 0.0 * (ii + jj)
+        if name == "tri_m":
+            d = d * 0.2
         d[0:4, :] = 0.0                                           # antarctic coast
         # two meridional continents with shelves, one reaching the arctic seam
         for x0, w, j0, j1 in ((0.20, 0.055, 0.25, 0.80), (0.62, 0.07, 0.30, 1.01)):
             land = (np.abs(x - x0) < w * (0.6 + 0.4 * np.sin(np.pi * (y - j0) / (j1 - j0)))) & (y > j0) & (y < j1)
             shelf = (np.abs(x - x0) < 1.6 * w) & (y > j0 - 0.03) & (y < j1 + 0.03)
-            d = np.where(shelf, np.minimum(d, 400.0), d)
+            d = np.where(shelf, np.minimum(d, 400.0 if name != "tri_m" else 150.0), d)
             d = np.where(land, 0.0, d)
         return np.broadcast_to(d, (jdm, idm)).copy()
     if name == "tri_s":

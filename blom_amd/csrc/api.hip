@@ -245,6 +245,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
   if (s == "barotp_arctic_fused") { c->barotp_arctic_fused = v; return 0; }
+  if (s == "barotp_arctic_persist") { c->barotp_arctic_persist = v; return 0; }
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }

@@ -189,6 +189,7 @@ struct blomgpu_ctx {
   hipStream_t xstream = nullptr, halo_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int barotp_rimbuf = 1;    // RCCL tiles: barotp's pair kernel reads its E/W rim from the receive buffers
+  int barotp_arctic_persist = 1; // arctic patch, single tile: the odd+even pairs of a phase in the persistent launch (stage_barotp.hip)
   int barotp_arctic_fused = 1;   // decomposed arctic domain: fused pair kernel with the single tile's exchange schedule
   int barotp_overlap = 0;   // measured slower (see stage_barotp_pair.hip: bt_overlap_usable)
   int nlev_real[NF_REAL];

@@ -380,7 +380,38 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     const bool arctic1 = h.nreg == 2 && (!c->tiling.multi() || c->barotp_arctic_fused);
     const bool fused = c->barotp_fused && (h.nreg != 2 || arctic1);
     bool halo_done = false;
-    if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
+    if (fused && arctic1 && !c->tiling.multi() && c->barotp_persist && bt_phase_usable(c)) {
+      // arctic patch, single tile: the halo update -- which also rewrites the seam row -- belongs in front of odd substeps
+      // only, so the persistent launch takes the whole odd+even pairs of the phase (its tiles re-read rim and seam at the
+      // top of every pair), and a lone even substep at the start or a lone odd one at the end of a phase is its own launch
+      int lll = lll0;
+      double wo[2], wm[2], wn[2];
+      auto weights = [&](int l) {
+        wo[0] = wo[1] = woa * l + wob;
+        wn[0] = wn[1] = wna * l + wnb;
+        wm[0] = wm[1] = 1. - wo[0] - wn[0];
+      };
+      if (lll % 2 == 0) {                                                  // lone even substep: reads the published margins
+        weights(lll);
+        bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, 0, 1, set, 0, nullptr);
+        set ^= 1;
+        { const int ll = ml; ml = nl; nl = ll; }
+        lll++;
+      }
+      const int npair = (last - lll + 1) / 2;
+      if (npair > 0) {
+        int so, mo, no;
+        if (int rc = bt_phase_launch(c, m, n, ml, nl, woa, wob, wna, wnb, lll, lll + 2 * npair - 1, set, &so, &mo, &no)) return rc;
+        set = so; ml = mo; nl = no;
+        lll += 2 * npair;
+      }
+      if (lll <= last) {                                                   // lone odd substep: folds while loading
+        weights(lll);
+        bt_pair_launch(c, m, n, ml, nl, wo, wm, wn, 1, 0, set, 0, nullptr);
+        set ^= 1;
+        { const int ll = ml; ml = nl; nl = ll; }
+      }
+    } else if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
       // their edge values through memory
       int so, mo, no;
@@ -470,6 +501,6 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     hipLaunchKernelGGL(k_bt_epilogue, g, b, 0, c->stream, c->d, nb, m, n, ml, nl, set);
   }
   HIPCHK(c, hipGetLastError());
-  if (c->barotp_fused && h.nreg != 2 && c->barotp_persist && bt_phase_usable(c)) return bt_phase_check(c);
+  if (c->barotp_fused && !c->tiling.multi() && c->barotp_persist && bt_phase_usable(c)) return bt_phase_check(c);
   return 0;
 }

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
   const bool mine = act && li >= HB && li < HB + TI && lj >= HB && lj < HB + TJ && gi <= ii && gj <= jj;
   // halo cell owned by this tile: the tile that holds the nearest interior point (each halo cell has one owner)
   bool own_halo = false;
-  if (!PERSIST && a.write_margin && inarr && !(gi >= 1 && gi <= ii && gj >= 1 && gj <= jj)) {
+  if (a.write_margin && inarr && !(gi >= 1 && gi <= ii && gj >= 1 && gj <= jj)) {
     const int ci = gi < 1 ? 1 : (gi > ii ? ii : gi), cj = gj < 1 ? 1 : (gj > jj ? jj : gj);
     own_halo = (ci - 1) / TI == (int)bx && (cj - 1) / TJ == (int)blockIdx.y;
   }
@@ -154,9 +154,23 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
   const double *rb = gi < 1 ? a.rim_w : a.rim_e;
   const bool rb_has = gi < 1 ? a.rim_has_w != 0 : a.rim_has_e != 0;
   const size_t rb_i = from_buf ? (size_t)(gj + HB - 1) * HB + (size_t)(gi < 1 ? gi + HB - 1 : gi - ii - 1) : 0;
+  // arctic patch, persistent form: the fold also rewrites cells of the tile itself -- the seam row jj (on the p- and u-grid all
+  // of it, on the v-grid its second half) takes the mirror image at every halo update, i.e. before every odd substep
+  const bool seam_pb = PERSIST && mine && cs != c, seam_ub = PERSIST && mine && cs_u != c, seam_vb = PERSIST && mine && cs_v != c;
   auto load_state = [&](bool rim_only) {
-    if (!act || (rim_only && mine)) return;
+    if (!act) return;
     const double *g_pb = b_pb[src], *g_ub = b_ub[src], *g_vb = b_vb[src];
+    if (rim_only && mine) {
+      if (seam_pb || seam_ub || seam_vb) {
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+          if (seam_pb) s_pb[l][lj][li] = g_pb[cs + l * np];
+          if (seam_ub) s_ub[l][lj][li] = sg_u * g_ub[cs_u + l * np];
+          if (seam_vb) s_vb[l][lj][li] = sg_v * g_vb[cs_v + l * np];
+        }
+      }
+      return;
+    }
     if (from_buf) {
 #pragma unroll
       for (int l = 0; l < 2; l++) {
@@ -227,6 +241,17 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
     if (qx < 0 || qx >= nbx) { if (V.nreg == 0 || V.nreg == 4) exists = false; else qx = (qx + nbx) % nbx; }
     if (qy < 0 || qy >= nby) { if (V.nreg <= 2) exists = false; else qy = (qy + nby) % nby; }
     if (exists) nb_tile = qy * nbx + qx;
+  }
+  if (PERSIST && V.nreg == 2 && tid >= 8 && tid < 12 && (int)blockIdx.y == nby - 1) {
+    // arctic patch: the rows above the seam mirror the top rows of the tiles that hold the mirrored columns (the tile's own
+    // columns and rim, reflected: column i <-> ii+1-i, one more on the u-grid); lanes 8..11 watch up to four of them
+    const int lo = ii + 1 - ((int)bx * TI + TI + HB) - 1, hi = ii + 1 - ((int)bx * TI + 1 - HB) + 1;
+    // four sample columns at most (hi - lo + 2) / 3 <= 12 apart: every tile at least 12 columns wide (bt_phase_usable)
+    // that reaches into [lo, hi] holds one of them
+    int col = lo + (tid - 8) * ((hi - lo + 2) / 3);
+    if (col > hi) col = hi;
+    col = ((col - 1) % ii + ii) % ii + 1;                    // periodic in i
+    nb_tile = (nby - 1) * nbx + (col - 1) / TI;
   }
   unsigned done_iters = 0;              // iterations this tile has completed
   int lll = a.lll0;
@@ -371,8 +396,9 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
   src ^= 1;
   // persistent form: between iterations only the cells within HB of the tile edge are read by anybody (the
   // neighbours' rims); the core of the tile lives in LDS and goes to memory with the last iteration
-  const bool edge_cell = li < 2 * HB || li >= TI || lj < 2 * HB || lj >= TJ || gi > ii - HB || gj > jj - HB;
-  if ((mine && (!PERSIST || edge_cell || lll > a.last)) || own_halo) {
+  const bool edge_cell = li < 2 * HB || li >= TI || lj < 2 * HB || lj >= TJ || gi > ii - HB || gj > jj - HB ||
+                         (V.nreg == 2 && gj > jj - 2 * HB);
+  if ((mine && (!PERSIST || edge_cell || lll > a.last)) || (own_halo && (!PERSIST || lll > a.last))) {
     double *o_pb = b_pb[src], *o_ub = b_ub[src], *o_vb = b_vb[src];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
@@ -598,10 +624,12 @@ int bt_overlap_usable(blomgpu_ctx *c) {
 // tile's rim must come from its direct neighbours only (also across the periodic seam).
 bool bt_phase_usable(blomgpu_ctx *c) {
   const DevView &h = c->h;
-  if (c->tiling.multi() || h.nreg == 2) return false;
+  if (c->tiling.multi()) return false;
   if (c->barotp_tile && c->barotp_tile != 100 * TI_D + TJ_D) return false;
   const int nbx = (h.ii + TI_D - 1) / TI_D, nby = (h.jj + TJ_D - 1) / TJ_D;
   if (h.ii - (nbx - 1) * TI_D < HB || h.jj - (nby - 1) * TJ_D < HB) return false;
+  // arctic patch: the fold reads the rows jj-1-HB..jj, which must lie in the last tile row; at least two tile columns
+  if (h.nreg == 2 && (h.jj - (nby - 1) * TJ_D < 2 * HB || nbx < 2 || h.ii - (nbx - 1) * TI_D < 12 || !c->barotp_arctic_persist)) return false;
   if (c->num_cus <= 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return false;
@@ -641,7 +669,9 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   a.prof = c->bt_prof;
   a.lll0 = lll0; a.last = last; a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
   a.flags = c->bt_flags + 16;
-  a.tsel = 0; a.nbx = nbx; a.write_margin = 0;
+  // arctic patch: the launch covers whole odd+even pairs only (st_barotp_on); its last iteration also publishes the margins
+  // beyond the edges of the domain, which a following lone even substep and the epilogue read without a halo update
+  a.tsel = 0; a.nbx = nbx; a.write_margin = h.nreg == 2 ? 1 : 0;
   a.pack_on = 0; a.pack_w = a.pack_e = nullptr;
   a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
   a.epoch_base = c->bt_epoch;

@@ -41,6 +41,20 @@ def test_variants_bit_identical(cfg, nsteps, opt, variants):
 
 
 
+@pytest.mark.parametrize("cfg", ["tri_m", "tri_m_tke"])
+def test_persistent_barotp_with_the_arctic_patch(cfg):
+    """the odd+even pairs of a barotropic phase in the persistent launch on a tripolar grid (tiles re-read rim AND seam row from
+    their mirror tiles at the top of every pair) against one launch per pair and one kernel per equation"""
+    a = _run(cfg, 8, barotp_arctic_persist=1)
+    b = _run(cfg, 8, barotp_arctic_persist=0)
+    d = _run(cfg, 8, barotp_fused=0, barotp_persist=0)
+    skip = {"util1", "util2", "util3", "util4"}
+    for other, what in ((b, "one launch per pair"), (d, "one kernel per equation")):
+        bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], other[nm], equal_nan=True)]
+        assert not bad, (what, bad)
+    assert np.isfinite(a["ub"]).all() and float(np.abs(a["ub"]).max()) > 0.0
+
+
 def test_variants_at_full_size_are_deterministic_and_identical():
     """BASELINE.json's channel size: hundreds of workgroups in flight, the regime where an
     inter-workgroup hazard (a tile updating a field in place while its neighbours still read the
