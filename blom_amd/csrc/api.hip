@@ -233,7 +233,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "timing") { c->timing = v != 0; return 0; }
   if (s == "barotp_fused") { c->barotp_fused = v; return 0; }
   if (s == "barotp_tile") {
-    if (v != 0 && v != 3216 && v != 3208 && v != 1608 && v != 4016 && v != 2616) return ctx_fail(c, "blomgpu_set_int: barotp_tile must be 0, 3216, 3208, 1608, 4016 or 2616");
+    if (v != 0 && v != 3216 && v != 3208 && v != 1608 && v != 4016 && v != 2616 && v != 2615 && v != 4015)
+      return ctx_fail(c, "blomgpu_set_int: barotp_tile must be 0, 3216, 3208, 1608, 4016, 2616, 2615 or 4015");
     c->barotp_tile = v;
     return 0;
   }

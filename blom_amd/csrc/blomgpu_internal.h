@@ -230,7 +230,7 @@ struct blomgpu_ctx {
   unsigned bt_epoch = 0;          // completion count every tile has reached after the launches so far
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel
   int num_cus = 0;
-  int bt_blocks_per_cu = -1;   // occupancy query result for the persistent barotp kernel (-1: not asked yet)
+  int bt_blocks_per_cu[4] = {-1, -1, -1, -1};   // occupancy query results for the persistent barotp kernel's shapes (-1: not asked yet)
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles

@@ -21,12 +21,8 @@
 // 168 VGPRs, and the kernel needs 158 -- the 32 x 16 tile of rounds 1-2 (896 threads, 128 VGPRs) spilled 80 of them to
 // scratch memory, which cost a quarter of every iteration (in-kernel timestamps: the even substep's sweeps took 5.4 us
 // against 1.4 us for the odd one's).  208 x 512 points are 8 x 32 = 256 such tiles: one per CU.
-#ifndef TI_D
-#define TI_D 26
-#endif
-#ifndef TJ_D
-#define TJ_D 16
-#endif
+// (where the rows do not come out -- 193 = 12 x 16 + 1 leaves a last tile row of one -- 26 x 15; 40 x 16 / 40 x 15, which
+// spill 15 registers, for domains of more than 256 such tiles.)
 constexpr int bt_threads(int ti, int tj) { return ((ti + 2 * HB) * (tj + 2 * HB) + 63) / 64 * 64; }
 struct BtShape { int ti, tj; };
 
@@ -246,8 +242,8 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
     // arctic patch: the rows above the seam mirror the top rows of the tiles that hold the mirrored columns (the tile's own
     // columns and rim, reflected: column i <-> ii+1-i, one more on the u-grid); lanes 8..11 watch up to four of them
     const int lo = ii + 1 - ((int)bx * TI + TI + HB) - 1, hi = ii + 1 - ((int)bx * TI + 1 - HB) + 1;
-    // four sample columns at most (hi - lo + 2) / 3 <= 12 apart: every tile at least 12 columns wide (bt_phase_usable)
-    // that reaches into [lo, hi] holds one of them
+    // four sample columns (hi - lo + 2) / 3 apart: every tile wider than that (bt_phase_shape) that reaches into [lo, hi]
+    // holds one of them
     int col = lo + (tid - 8) * ((hi - lo + 2) / 3);
     if (col > hi) col = hi;
     col = ((col - 1) % ii + ii) % ii + 1;                    // periodic in i
@@ -532,10 +528,11 @@ int bt_pair_halo(blomgpu_ctx *c, int set) {
 bool bt_phase_usable(blomgpu_ctx *c);
 // Tile shape of the one-pair-per-launch form.  Where the persistent form runs, its shape; otherwise chosen from the
 // number of tiles (option barotp_tile = 3216 / 3208 / 1608 overrides).
+static BtShape bt_phase_shape(blomgpu_ctx *c);
 static BtShape bt_shape(blomgpu_ctx *c) {
   if (c->barotp_tile) return BtShape{c->barotp_tile / 100, c->barotp_tile % 100};
   const DevView &h = c->h;
-  if (c->barotp_persist && bt_phase_usable(c)) return BtShape{TI_D, TJ_D};
+  if (c->barotp_persist && bt_phase_usable(c)) return bt_phase_shape(c);
   if (c->num_cus <= 0) {
     hipDeviceProp_t prop;
     c->num_cus = hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -557,7 +554,9 @@ static int bt_launch_pair(blomgpu_ctx *c, BtShape sh, dim3 grid, hipStream_t st,
   else if (sh.ti == 16 && sh.tj == 8) hipLaunchKernelGGL((k_bt_steps<false, 16, 8>), grid, dim3(bt_threads(16, 8)), 0, st, c->d, a);
   else if (sh.ti == 40 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 40, 16>), grid, dim3(bt_threads(40, 16)), 0, st, c->d, a);
   else if (sh.ti == 26 && sh.tj == 16) hipLaunchKernelGGL((k_bt_steps<false, 26, 16>), grid, dim3(bt_threads(26, 16)), 0, st, c->d, a);
-  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208, 1608, 4016 or 2616");
+  else if (sh.ti == 26 && sh.tj == 15) hipLaunchKernelGGL((k_bt_steps<false, 26, 15>), grid, dim3(bt_threads(26, 15)), 0, st, c->d, a);
+  else if (sh.ti == 40 && sh.tj == 15) hipLaunchKernelGGL((k_bt_steps<false, 40, 15>), grid, dim3(bt_threads(40, 15)), 0, st, c->d, a);
+  else return ctx_fail(c, "barotp: tile shape must be 3216, 3208, 1608, 4016, 2616, 2615 or 4015");
   return 0;
 }
 
@@ -620,37 +619,57 @@ int bt_overlap_usable(blomgpu_ctx *c) {
   return (h.ii + sh.ti - 1) / sh.ti >= 3 ? 1 : 0;
 }
 
-// Can the persistent form be used?  Every tile must be resident (one 896-thread workgroup per CU) and a
-// tile's rim must come from its direct neighbours only (also across the periodic seam).
-bool bt_phase_usable(blomgpu_ctx *c) {
+// Can the persistent form be used, and with which tile shape?  Every tile must be resident (one workgroup per CU) and a
+// tile's rim must come from its direct neighbours only (also across the periodic seam; with the arctic patch from the
+// mirror tiles of the last tile row too).  Shapes in the order of preference: 26 x 16 and 26 x 15 stay below 768 threads
+// (168 VGPRs: no spills); 40 x 16 / 40 x 15 serve domains that need more than 256 of those (the tnx1v4 dimensions).
+// {0, 0}: not usable -- one launch per substep pair then.
+struct BtPersistShape { int ti, tj; };
+static const BtPersistShape kPersistShapes[4] = {{26, 16}, {26, 15}, {40, 16}, {40, 15}};
+template <int TI, int TJ>
+static int bt_persist_blocks_per_cu() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps<true, TI, TJ>, bt_threads(TI, TJ), 0) != hipSuccess) nb = 0;
+  return nb;
+}
+static BtShape bt_phase_shape(blomgpu_ctx *c) {
   const DevView &h = c->h;
-  if (c->tiling.multi()) return false;
-  if (c->barotp_tile && c->barotp_tile != 100 * TI_D + TJ_D) return false;
-  const int nbx = (h.ii + TI_D - 1) / TI_D, nby = (h.jj + TJ_D - 1) / TJ_D;
-  if (h.ii - (nbx - 1) * TI_D < HB || h.jj - (nby - 1) * TJ_D < HB) return false;
-  // arctic patch: the fold reads the rows jj-1-HB..jj, which must lie in the last tile row; at least two tile columns
-  if (h.nreg == 2 && (h.jj - (nby - 1) * TJ_D < 2 * HB || nbx < 2 || h.ii - (nbx - 1) * TI_D < 12 || !c->barotp_arctic_persist)) return false;
+  const BtShape none{0, 0};
+  if (c->tiling.multi()) return none;
   if (c->num_cus <= 0) {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return false;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return none;
     c->num_cus = prop.multiProcessorCount;
   }
-  // the tiles wait for each other inside the launch: every one of them must be resident.  Ask the runtime how many
-  // workgroups of this kernel a CU takes (registers, LDS) instead of assuming one.
-  if (c->bt_blocks_per_cu < 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps<true, TI_D, TJ_D>, bt_threads(TI_D, TJ_D), 0) != hipSuccess) nb = 0;
-    c->bt_blocks_per_cu = nb;
+  for (int x = 0; x < 4; x++) {
+    const int ti = kPersistShapes[x].ti, tj = kPersistShapes[x].tj;
+    if (c->barotp_tile && c->barotp_tile != 100 * ti + tj) continue;
+    const int nbx = (h.ii + ti - 1) / ti, nby = (h.jj + tj - 1) / tj;
+    if (nbx * nby > c->num_cus) continue;
+    if (h.ii - (nbx - 1) * ti < HB || h.jj - (nby - 1) * tj < HB) continue;
+    // arctic patch: the fold reads the rows jj-1-HB..jj, which must lie in the last tile row; at least two tile columns,
+    // the last one wider than the sampling step with which the kernel finds its mirror tiles
+    if (h.nreg == 2 && (h.jj - (nby - 1) * tj < 2 * HB || nbx < 2 || h.ii - (nbx - 1) * ti < (ti + 2 * HB + 3) / 3 + 1 || !c->barotp_arctic_persist)) continue;
+    // the tiles wait for each other inside the launch: every one of them must be resident.  Ask the runtime how many
+    // workgroups of this kernel a CU takes (registers, LDS) instead of assuming one.
+    if (c->bt_blocks_per_cu[x] < 0)
+      c->bt_blocks_per_cu[x] = x == 0 ? bt_persist_blocks_per_cu<26, 16>() : x == 1 ? bt_persist_blocks_per_cu<26, 15>()
+                               : x == 2 ? bt_persist_blocks_per_cu<40, 16>() : bt_persist_blocks_per_cu<40, 15>();
+    if (c->bt_blocks_per_cu[x] < 1) continue;
+    return BtShape{ti, tj};
   }
-  return c->bt_blocks_per_cu >= 1 && nbx * nby <= c->num_cus;
+  return none;
 }
+bool bt_phase_usable(blomgpu_ctx *c) { return bt_phase_shape(c).ti != 0; }
 
 // one launch for the substeps lll0..last of a phase; `src` as in bt_pair_launch; returns the buffer set
 // that holds the state afterwards in *src_out and the level indices in *ml_out, *nl_out
 int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
                     int last, int src, int *src_out, int *ml_out, int *nl_out) {
   const DevView &h = c->h;
-  const int nbx = (h.ii + TI_D - 1) / TI_D, nby = (h.jj + TJ_D - 1) / TJ_D;
+  const BtShape psh = bt_phase_shape(c);
+  if (!psh.ti) return ctx_fail(c, "barotp: the persistent form is not usable on this domain");
+  const int nbx = (h.ii + psh.ti - 1) / psh.ti, nby = (h.jj + psh.tj - 1) / psh.tj;
   int niter = 0;
   for (int lll = lll0; lll <= last; niter++) lll += (lll % 2 == 1 && lll + 1 <= last) ? 2 : 1;
   // the completion counters start at 0 with the first launch of every barotp call (st_barotp sets bt_restart): the
@@ -678,7 +697,10 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;
   a.abort_word = (unsigned *)(c->err_dev + 2);
-  hipLaunchKernelGGL((k_bt_steps<true, TI_D, TJ_D>), dim3(nbx, nby), dim3(bt_threads(TI_D, TJ_D)), 0, c->stream, c->d, a);
+  if (psh.ti == 26 && psh.tj == 16) hipLaunchKernelGGL((k_bt_steps<true, 26, 16>), dim3(nbx, nby), dim3(bt_threads(26, 16)), 0, c->stream, c->d, a);
+  else if (psh.ti == 26) hipLaunchKernelGGL((k_bt_steps<true, 26, 15>), dim3(nbx, nby), dim3(bt_threads(26, 15)), 0, c->stream, c->d, a);
+  else if (psh.tj == 16) hipLaunchKernelGGL((k_bt_steps<true, 40, 16>), dim3(nbx, nby), dim3(bt_threads(40, 16)), 0, c->stream, c->d, a);
+  else hipLaunchKernelGGL((k_bt_steps<true, 40, 15>), dim3(nbx, nby), dim3(bt_threads(40, 15)), 0, c->stream, c->d, a);
   // replay the iteration bookkeeping of the kernel
   for (int lll = lll0; lll <= last;) {
     const bool odd = lll % 2 == 1, both = odd && lll + 1 <= last;
