@@ -250,6 +250,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
+  if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
@@ -530,7 +531,12 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
     // eddtra_frozen: the eddy-induced fluxes umfltd.. stay as uploaded (the reference build of the oracle has no mod_eddtra;
     // tests pin advect/remap on non-zero fluxes this way)
     if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
-    if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) { c->defer_checks = false; c->in_sequence = false; return rc; }
+    // the step before this one, in the same call, has done this step's tmsmt1 in its tmsmt2
+    if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }
+    if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) {
+      c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+      return rc;
+    }
   }
   c->defer_checks = false;
   c->in_sequence = false;
@@ -550,6 +556,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     const int mm = (m - 1) * kk, nn = (n - 1) * kk, k1m = 1 + mm, k1n = 1 + nn;
     c->h.P.nstep = ns + 1;                             // read by host code only: no upload of the view for it
     ctx_sync_view(c);
+    c->tmsmt1_ahead = !c->use_graph && !c->csdiag && it < nsteps - 1 && c->tmsmt_ahead;
     bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4;
     hipGraphExec_t &ge = c->step_graph[ns & 1];
     if (graph && !ge) {
@@ -571,7 +578,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
       }
     }
     if (graph) HIPCHK(c, hipGraphLaunch(ge, c->stream));
-    else if (int rc = step_sequence(c, m, n, mm, nn, k1m, k1n)) return rc;
+    else if (int rc = step_sequence(c, m, n, mm, nn, k1m, k1n)) { c->tmsmt1_done_ahead = false; return rc; }
     c->steps_done++;
     c->steps_warm++;
     // the stages' error words are sticky: one read-back (a host synchronisation) per check_period steps (every step with
@@ -581,6 +588,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
       if (int rc = ctx_check_errors(c)) {
         const int first = ns + 1 - (it % period);
         c->err += " (raised in one of the steps nstep = " + std::to_string(first) + ".." + std::to_string(ns + 1) + ")";
+        c->tmsmt1_done_ahead = false;
         return rc;
       }
     const double delt2 = c->h.P.baclin + c->h.P.baclin;      // phy/mod_blom_step.F90:300

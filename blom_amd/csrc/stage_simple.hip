@@ -75,10 +75,13 @@ __global__ void k_pscan(const DevView *__restrict__ Vp, int off, int lo, int hi_
 
 // ---- dpu,dpv (and optionally pu,pv) from p, j,i = -1..+2 (mod_tmsmt.F90:369-391,
 //      mod_pgforc.F90:463-485, mod_mxlayr.F90:1282-1310) --------------------------------------
-__global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, int off, int with_pupv) {
+// flags: 1 = pu, pv as well; 2 = the next step's tmsmt1 here (dpuold, dpvold = the new dpu, dpv, at the points of the tile)
+__global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, int off, int flags) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
+  const int with_pupv = flags & 1;
+  const bool old_too = (flags & 2) && j >= 1 && j <= V.jj && i >= 1 && i <= V.ii;
   const bool wu = V.m[I_iu][c] != 0, wv = V.m[I_iv][c] != 0;
   if (!wu && !wv) return;
   const double *p = V.f[F_p];
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, i
           const double pw1 = b[u];
           const double dd = .5 * ((fmin2(qu, pw1) - fmin2(qu, pw0)) + (fmin2(qu, pc1) - fmin2(qu, pc0)));
           dpu[c + (size_t)k * np] = dd;
+          if (old_too) V.f[F_dpuold][c + (size_t)k * np] = dd;
           if (with_pupv) { pu = pu + dd; pug[c + o1] = pu; }
           pw0 = pw1;
         }
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, i
           const double ps1 = d[u];
           const double dd = .5 * ((fmin2(qv, ps1) - fmin2(qv, ps0)) + (fmin2(qv, pc1) - fmin2(qv, pc0)));
           dpv[c + (size_t)k * np] = dd;
+          if (old_too) V.f[F_dpvold][c + (size_t)k * np] = dd;
           if (with_pupv) { pv = pv + dd; pvg[c + o1] = pv; }
           ps0 = ps1;
         }
@@ -125,9 +130,9 @@ __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, i
   }
 }
 
-int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int with_pupv) {
+int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int flags) {
   hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, -2, 2);
-  hipLaunchKernelGGL(k_dpudpv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, with_pupv);
+  hipLaunchKernelGGL(k_dpudpv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, flags);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -171,7 +176,10 @@ __global__ __launch_bounds__(64) void k_tmsmt2_fac(const DevView *__restrict__ V
 
 // from_wk: pbcor2 left S, T and the tracers of level m in the work space (slots 1, 2, 3 + nt; stage_pbcor_tile.hip) instead of
 // moving them into their fields: they are read there and written, filtered, to the fields
-__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int from_wk) {
+// ahead: another step follows within this call (blomgpu_step): its tmsmt1 (:230-277) would copy exactly the values written
+// here -- level m of this step is level n of the next -- so they go to dpold, told, sold, trcold as well and that tmsmt1 is
+// not launched (k_dpudpv does the same for dpuold, dpvold)
+__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int from_wk, int ahead) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -190,26 +198,45 @@ __global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int fro
   pmid = pmid + epsilp;
   pnew = pnew + epsilp;
   const double tmid = from_wk ? WK(V, 2)[ok] : V.f[F_temp][okm], smid = from_wk ? WK(V, 1)[ok] : V.f[F_saln][okm];
-  V.f[F_temp][okm] = (wts1 * pmid * tmid + wts2 * (pold * V.f[F_told][ok] + pnew * V.f[F_temp][okn])) /
-                     (dpm + epsilp);
-  V.f[F_saln][okm] = (wts1 * pmid * smid + wts2 * (pold * V.f[F_sold][ok] + pnew * V.f[F_saln][okn])) /
-                     (dpm + epsilp);
+  const double tnew = (wts1 * pmid * tmid + wts2 * (pold * V.f[F_told][ok] + pnew * V.f[F_temp][okn])) / (dpm + epsilp);
+  const double snew = (wts1 * pmid * smid + wts2 * (pold * V.f[F_sold][ok] + pnew * V.f[F_saln][okn])) / (dpm + epsilp);
+  V.f[F_temp][okm] = tnew;
+  V.f[F_saln][okm] = snew;
+  if (ahead) { V.f[F_dpold][okm] = dpm; V.f[F_told][ok] = tnew; V.f[F_sold][ok] = snew; }
   for (int nt = 0; nt < V.ntr; nt++) {
     double *tr = V.f[F_trc] + (size_t)nt * 2 * V.kk * np;
-    const double *tro = V.f[F_trcold] + (size_t)nt * V.kk * np;
+    double *tro = V.f[F_trcold] + (size_t)nt * V.kk * np;
     const double xmid = from_wk ? WK(V, 3 + nt)[ok] : tr[okm];
-    tr[okm] = (wts1 * pmid * xmid + wts2 * (pold * tro[ok] + pnew * tr[okn])) / (dpm + epsilp);
+    const double xnew = (wts1 * pmid * xmid + wts2 * (pold * tro[ok] + pnew * tr[okn])) / (dpm + epsilp);
+    tr[okm] = xnew;
+    if (ahead) tro[ok] = xnew;
   }
+}
+
+// ahead, arctic patch: the halo update that follows the filter rewrites the seam row jj of dp(km), and the next step's tmsmt1
+// would copy what it left there
+__global__ void k_tmsmt_dpold_seam(const DevView *__restrict__ Vp, int mm) {
+  const DevView &V = *Vp;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, k = blockIdx.y;
+  if (i > V.ii) return;
+  const size_t c = IDX(V, i, V.jj);
+  if (!V.m[I_ip][c]) return;
+  const size_t okm = c + (size_t)(k + mm) * V.nplane;
+  V.f[F_dpold][okm] = V.f[F_dp][okm];
 }
 
 int st_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) {
   hipLaunchKernelGGL(k_tmsmt2_fac, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn);
   const int from_wk = c->pbcor2_handed_over ? 1 : 0;
   c->pbcor2_handed_over = false;
-  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, nn, from_wk);
+  const int ahead = c->in_sequence && c->tmsmt1_ahead ? 1 : 0;
+  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, nn, from_wk, ahead);
   HIPCHK(c, hipGetLastError());
+  c->tmsmt1_done_ahead = ahead != 0;
   if (int rc = st_xctilr(c, c->h.f[F_dp] + (size_t)(k1m - 1) * c->h.nplane, 1, c->h.kk, 3, 3, 1)) return rc;
-  if (c->h.P.vcoord_tag == 1) return launch_p_dpu_dpv(c, mm, 0);
+  if (ahead && c->h.nreg == 2)
+    hipLaunchKernelGGL(k_tmsmt_dpold_seam, dim3((c->h.ii + 63) / 64, c->h.kk), dim3(64), 0, c->stream, c->d, mm);
+  if (c->h.P.vcoord_tag == 1) return launch_p_dpu_dpv(c, mm, ahead ? 2 : 0);
   return launch_pscan(c, mm, -2, 2);
 }
 

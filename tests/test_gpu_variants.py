@@ -22,7 +22,7 @@ def _run(cfg, nsteps, **opts):
     for k, v in opts.items():
         gpu.set(k, v)
     assert gpu.step(0, nsteps) == nsteps
-    out = {nm: gpu.get(nm) for nm in STATE_FIELDS if gpu.has_field(nm)}
+    out = {nm: gpu.get(nm) for nm in STATE_FIELDS + ["told", "sold", "trcold"] if gpu.has_field(nm)}
     gpu.close()
     return out
 
@@ -39,6 +39,31 @@ def test_variants_bit_identical(cfg, nsteps, opt, variants):
     detail = [(nm, int((~((a[nm] == b[nm]) | (np.isnan(a[nm]) & np.isnan(b[nm])))).sum())) for nm in bad]
     assert not bad, detail
 
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 7), ("tri_s_tke", 6), ("fuk95", 5), ("box_s", 6)])
+def test_tmsmt1_done_by_the_previous_steps_tmsmt2(cfg, nsteps):
+    """blomgpu_step with several steps in one call: tmsmt2 also writes dpold, told, sold, trcold, dpuold, dpvold for the step
+    that follows, which then launches no tmsmt1 (phy/mod_tmsmt.F90:230-277 copies exactly those values).  Against every step
+    launching its own, and against one call per step; all fields, the *old ones included."""
+    from blom_amd.gpu import BlomGpu
+    a = _run(cfg, nsteps, tmsmt_ahead=1)
+    b = _run(cfg, nsteps, tmsmt_ahead=0)
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    ns = 0
+    for _ in range(nsteps):
+        ns = gpu.step(ns, 1)
+    d = {nm: gpu.get(nm) for nm in a}
+    gpu.close()
+    skip = {"util1", "util2", "util3", "util4"}
+    for other, what in ((b, "own tmsmt1 every step"), (d, "one call per step")):
+        bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], other[nm], equal_nan=True)]
+        assert not bad, (what, bad)
+    for nm in ("told", "sold", "dpold", "dpuold", "dpvold", "trcold"):
+        assert nm in a, nm
 
 
 @pytest.mark.parametrize("cfg", ["tri_m", "tri_m_tke"])
