@@ -525,6 +525,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   c->defer_checks = true;
   c->in_sequence = true;
   c->pbcor1_handed_over = c->pbcor2_handed_over = false;
+  c->fluxes_zeroed = false;
   for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;

@@ -229,6 +229,7 @@ struct blomgpu_ctx {
   bool bt_restart = true;        // the next persistent barotp launch zeroes the completion counts and starts at epoch 0
   unsigned bt_epoch = 0;          // completion count every tile has reached after the launches so far
   // blomgpu_step with more steps to come: tmsmt2 also writes what the next step's tmsmt1 would copy (stage_simple.hip)
+  bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
   bool tmsmt1_ahead = false, tmsmt1_done_ahead = false;
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel

@@ -115,6 +115,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   // not unless use_TKEADV, mod_remap.F90:314-316 and every tracer loop after it)
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
   const int x0 = (bx_ % ntx) * RT_TW, y0 = (bx_ / ntx) * RT_TH;        // first point of the tile in the padded plane
+  const bool zero_old = (tsel & 4) != 0;
+  tsel &= 3;
   if (tsel) {
     // tsel 1: only the tiles that read no halo point (their 2-point rim lies inside 1..ii x 1..jj) -- they can run
     // while the halo exchange of cau, cav and the tracers is still under way; tsel 2: only the others
@@ -204,7 +206,10 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   double *const o_f = (uface ? V.f[F_uflx] : V.f[F_vflx]) + fc + okm;
   double *const o_ft = (uface ? V.f[F_utflx] : V.f[F_vtflx]) + fc + okm;
   double *const o_fs = (uface ? V.f[F_usflx] : V.f[F_vsflx]) + fc + okm;
-  const double f_o = *o_f, ft_o = *o_ft, fs_o = *o_fs;          // old fluxes (the u-face accumulates, :1054-1056)
+  // old fluxes: the u-face accumulates (:1054-1056), the v-face assigns (:1455-1457).  Inside blomgpu_step init_fluxes has
+  // zeroed them earlier in the step and nothing has added to them since (zero_old): 0 + flux without the read
+  const bool rd_old = uface && !zero_old;
+  const double f_o = rd_old ? *o_f : 0., ft_o = rd_old ? *o_ft : 0., fs_o = rd_old ? *o_fs : 0.;
   const bool fmask = uface ? MU(mpf) : MV(mpf);
   const double cf = fmask ? (caf > 0. ? caf * m2i[1][0] : caf * m2i[1][1]) : 0.;     // cu resp. cv of the face
 
@@ -453,6 +458,9 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
 }
 
 int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
+  const bool zeroed = c->in_sequence && c->fluxes_zeroed;
+  if (tsel == 0 || tsel == 2) c->fluxes_zeroed = false;             // (a split launch: tiles 1, then tiles 2)
+  if (zeroed) tsel |= 4;
   const DevView &h = c->h;
   const int ntx = (h.ni + RT_TW - 1) / RT_TW, nty = (h.nj + RT_TH - 1) / RT_TH;
   static_assert(RT_NSC(MAXTR) * RT_SN <= RT_NG(MAXTR) * RT_GN, "the scalars must fit under the gradient slots");

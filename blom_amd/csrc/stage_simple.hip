@@ -30,6 +30,7 @@ int st_init_fluxes(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1
   (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
   hipLaunchKernelGGL(k_init_fluxes, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm);
   HIPCHK(c, hipGetLastError());
+  c->fluxes_zeroed = c->in_sequence;
   return 0;
 }
 

@@ -11,7 +11,7 @@ from parity import STATE_FIELDS
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, nsteps, **opts):
+def _run(cfg, nsteps, _extra=(), **opts):
     from blom_amd.gpu import BlomGpu
     case = make_case(cfg)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
@@ -22,7 +22,7 @@ def _run(cfg, nsteps, **opts):
     for k, v in opts.items():
         gpu.set(k, v)
     assert gpu.step(0, nsteps) == nsteps
-    out = {nm: gpu.get(nm) for nm in STATE_FIELDS + ["told", "sold", "trcold"] if gpu.has_field(nm)}
+    out = {nm: gpu.get(nm) for nm in STATE_FIELDS + list(_extra) if gpu.has_field(nm)}
     gpu.close()
     return out
 
@@ -47,8 +47,9 @@ def test_tmsmt1_done_by_the_previous_steps_tmsmt2(cfg, nsteps):
     that follows, which then launches no tmsmt1 (phy/mod_tmsmt.F90:230-277 copies exactly those values).  Against every step
     launching its own, and against one call per step; all fields, the *old ones included."""
     from blom_amd.gpu import BlomGpu
-    a = _run(cfg, nsteps, tmsmt_ahead=1)
-    b = _run(cfg, nsteps, tmsmt_ahead=0)
+    old = ("told", "sold", "trcold")
+    a = _run(cfg, nsteps, _extra=old, tmsmt_ahead=1)
+    b = _run(cfg, nsteps, _extra=old, tmsmt_ahead=0)
     case = make_case(cfg)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
