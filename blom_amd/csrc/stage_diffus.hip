@@ -133,17 +133,26 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
   }
 
   // ---- phase 2: tracers ----------------------------------------------------------------------------------------------
+  // which tracers of a batch are diffused (uniform over the workgroup); a batch's values are loaded while the batch before it
+  // is worked on (tv is free again once it has gone to LDS)
+  bool dif[DT_TB], any = false;
+  double tv[2][DT_TB];
+  auto look = [&](int nt0, bool *d) {
+    bool a = false;
+#pragma unroll
+    for (int b = 0; b < DT_TB; b++) { d[b] = nt0 + b < ntr && !trc_skip_dif(V.P, nt0 + b + 1); a = a || d[b]; }
+    return a;
+  };
+  auto fetch = [&](int nt0, const bool *d) {
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int b = 0; b < DT_TB; b++) tv[r][b] = d[b] ? WK(V, N_TR(nt0 + b))[csr[r] + ok] : 0.;
+  };
+  any = look(0, dif);
+  if (any) fetch(0, dif);
   for (int nt0 = 0; nt0 < ntr; nt0 += DT_TB) {
-    // which tracers of this batch are diffused (uniform over the workgroup)
-    bool dif[DT_TB], any = false;
-#pragma unroll
-    for (int b = 0; b < DT_TB; b++) { dif[b] = nt0 + b < ntr && !trc_skip_dif(V.P, nt0 + b + 1); any = any || dif[b]; }
     if (any) {
-      double tv[2][DT_TB];
-#pragma unroll
-      for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int b = 0; b < DT_TB; b++) tv[r][b] = dif[b] ? WK(V, N_TR(nt0 + b))[csr[r] + ok] : 0.;
       __syncthreads();                                       // the previous batch has been read
 #pragma unroll
       for (int r = 0; r < 2; r++) {
@@ -153,8 +162,11 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
           for (int b = 0; b < DT_TB; b++) sc[(4 + b) * DT_LN + m] = tv[r][b];
         }
       }
-      __syncthreads();
     }
+    bool dif_n[DT_TB];
+    const bool any_n = nt0 + DT_TB < ntr && look(nt0 + DT_TB, dif_n);
+    if (any_n) fetch(nt0 + DT_TB, dif_n);
+    if (any) __syncthreads();
 #pragma unroll
     for (int b = 0; b < DT_TB; b++) {
       const int nt = nt0 + b;
@@ -169,6 +181,9 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
         } else if (ring2) tr[c] = l_x[q];
       } else if (interior && ((move_mask >> nt) & 1ull)) tr[c] = WK(V, N_TR(nt))[c + ok];
     }
+    any = any_n;
+#pragma unroll
+    for (int b = 0; b < DT_TB; b++) dif[b] = any_n && dif_n[b];
   }
 }
 

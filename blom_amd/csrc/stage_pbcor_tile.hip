@@ -164,13 +164,14 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
   }
 
   // ---- phase 2: the tracers, PT_TB at a time through the same LDS slots (the first batch came in with phase 0) ----------
+  // a batch's values are loaded while the batch before it is worked on: tv is free again once it has gone to LDS
+  double tv[2][PT_TB];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int b = 0; b < PT_TB; b++) tv[r][b] = PT_TB + b < ntr ? f_tr[csr[r] + (size_t)(PT_TB + b) * 2 * V.kk * np] : 0.;
   for (int nt0 = 0; nt0 < ntr; nt0 += PT_TB) {
     if (nt0 > 0) {
-      double tv[2][PT_TB];
-#pragma unroll
-      for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int b = 0; b < PT_TB; b++) tv[r][b] = nt0 + b < ntr ? f_tr[csr[r] + (size_t)(nt0 + b) * 2 * V.kk * np] : 0.;
       __syncthreads();                                       // the previous batch has been read
 #pragma unroll
       for (int r = 0; r < 2; r++) {
@@ -180,6 +181,11 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
           for (int b = 0; b < PT_TB; b++) sc[(3 + b) * PT_LN + m] = tv[r][b];
         }
       }
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int b = 0; b < PT_TB; b++)
+          tv[r][b] = nt0 + PT_TB + b < ntr ? f_tr[csr[r] + (size_t)(nt0 + PT_TB + b) * 2 * V.kk * np] : 0.;
       __syncthreads();
     }
     if (upd) {

@@ -416,17 +416,21 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   // ---- the other advected tracers, MAXTR at a time ----------------------------------------------------------------------
   const double *f_tr = V.f[F_trc] + okn;
   const int off2 = uface ? 0 : 1;
+  // the scalars of a batch are loaded while the batch before it is worked on: tv is free again once it has gone to LDS
+  double tv[MAXTR];
+#pragma unroll
+  for (int a = 0; a < MAXTR; a++) tv[a] = (MAXTR + a < nadv_all && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[MAXTR + a] * 2 * V.kk * np] : 0.;
   for (int b0 = MAXTR; b0 < nadv_all; b0 += MAXTR) {
     const int nb_ = nadv_all - b0 < MAXTR ? nadv_all - b0 : MAXTR;
-    double tv[MAXTR];
-#pragma unroll
-    for (int a = 0; a < MAXTR; a++) tv[a] = (a < nb_ && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[b0 + a] * 2 * V.kk * np] : 0.;
     __syncthreads();                                         // the gradient slots of the previous batch have been read
     if (t < RT_SN) {
 #pragma unroll
       for (int a = 0; a < MAXTR; a++)
         if (a < nb_) sc[a * RT_SN + t] = tv[a];
     }
+#pragma unroll
+    for (int a = 0; a < MAXTR; a++)
+      tv[a] = (b0 + MAXTR + a < nadv_all && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[b0 + MAXTR + a] * 2 * V.kk * np] : 0.;
     __syncthreads();
     // the scalars lie in slots 0..3 of the scalar region (below RT_SN * MAXTR doubles), the tracer gradient slots start at
     // 8 * RT_GN: no overlap, the gradients go straight to their slots
