@@ -251,6 +251,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
+  if (s == "remap_fold") { c->remap_fold = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
@@ -526,6 +527,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   c->in_sequence = true;
   c->pbcor1_handed_over = c->pbcor2_handed_over = false;
   c->fluxes_zeroed = false;
+  c->remap_handed_over = false;
   for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;

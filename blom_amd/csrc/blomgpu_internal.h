@@ -229,6 +229,11 @@ struct blomgpu_ctx {
   bool bt_restart = true;        // the next persistent barotp launch zeroes the completion counts and starts at epoch 0
   unsigned bt_epoch = 0;          // completion count every tile has reached after the launches so far
   // blomgpu_step with more steps to come: tmsmt2 also writes what the next step's tmsmt1 would copy (stage_simple.hip)
+  // option: inside blomgpu_step k_remap_tile also does k_remap_update's work (stage_remap_tile.hip).  Off: measured equal
+  // (channel 6.41-6.45 against 6.43-6.45 ms per step, remap 0.910 against 0.906 ms) to slower (tnx2v1s 3.71 against 3.66 ms) -- the
+  // overlapping tiles cost the tile kernel what the update kernel took, though 1.1 GB less crosses HBM
+  int remap_fold = 0;
+  bool remap_handed_over = false;   // ... and has left dp, T, S, tracers of the new level in the work space for pbcor1
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
   bool tmsmt1_ahead = false, tmsmt1_done_ahead = false;
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1
@@ -303,8 +308,15 @@ int st_kfpla_halo(blomgpu_ctx *, int n);
 int st_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1090-1156
 int st_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_cmnfld.hip   // phy/mod_cmnfld_routines.F90:1176-1196
 int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
-int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn, int tsel);  // stage_remap_tile.hip; tsel 0 all tiles, 1 those that read no halo point, 2 the others
-int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf);   // stage_pbcor_tile.hip
+// work-space slots in which k_remap_tile<.., FOLD = true> leaves the new dp, T, S and advected tracers of level kn for pbcor1
+// (the slots of the flux planes between k_remap_tile and k_remap_update, remap_common.h: nothing else uses them then)
+#define R_BASE(ntr) (8 + 3 * (ntr))
+#define R_DP(ntr) (R_BASE(ntr) + 0)
+#define R_T(ntr) (R_BASE(ntr) + 1)
+#define R_S(ntr) (R_BASE(ntr) + 2)
+#define R_TR(ntr, nt) (R_BASE(ntr) + 3 + (nt))
+int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn, int tsel, bool fold);  // stage_remap_tile.hip; tsel 0 all tiles, 1 those that read no halo point, 2 the others
+int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf, int from_remap);   // stage_pbcor_tile.hip
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off
 // xctilr on a device plane stack: `base` points at level lev0 of the field
 int st_xctilr(blomgpu_ctx *, double *base, int l1, int ld, int mh, int nh, int itype);

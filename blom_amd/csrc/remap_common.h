@@ -29,6 +29,7 @@
 #define W_FSV(ntr) (F_BASE(ntr) + 5)
 #define W_FTRU(ntr, nt) (F_BASE(ntr) + 6 + 2 * (nt))
 #define W_FTRV(ntr, nt) (F_BASE(ntr) + 7 + 2 * (nt))
+static_assert(F_BASE(3) == R_BASE(3) && F_BASE(0) == R_BASE(0), "R_DP.. (blomgpu_internal.h) reuse the flux planes' slots");
 
 __device__ inline double max8(double a, double b, double c, double d, double e, double f, double g, double h) {
   return fmax2(fmax2(fmax2(fmax2(fmax2(fmax2(fmax2(a, b), c), d), e), f), g), h);

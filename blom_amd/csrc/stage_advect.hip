@@ -165,6 +165,8 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   // RCCL tiles: the exchange (pack, send/recv, unpack) goes to the second stream and the tiles of k_remap_tile whose
   // rim lies inside the tile -- they read no halo point of cau, cav or the tracers -- run meanwhile; the tiles along the
   // edge follow when the halos have landed.  The exchange reads interior strips and writes halo points only.
+  // inside blomgpu_step the tile kernel also does the update and hands the new dp, T, S, tracers to pbcor1 through the work space
+  const bool fold = c->in_sequence && c->remap_fold;
   const bool ovl = c->tiling.rccl && c->xstream && c->halo_overlap && h.nreg != 2 && !c->timing;
   if (ovl) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -174,16 +176,17 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     c->halo_stream = nullptr;
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev_join, c->xstream));
-    if (int rc2 = remap_tile_launch(c, n, mm, nn, 1)) return rc2;
+    if (int rc2 = remap_tile_launch(c, n, mm, nn, 1, fold)) return rc2;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    if (int rc2 = remap_tile_launch(c, n, mm, nn, 2)) return rc2;
-    hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    if (int rc2 = remap_tile_launch(c, n, mm, nn, 2, fold)) return rc2;
+    if (!fold) hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
   } else {
     if (int rc = halo_all()) return rc;
     TimeScope ts(c, "remap");
-    if (int rc = remap_tile_launch(c, n, mm, nn, 0)) return rc;
-    hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    if (int rc = remap_tile_launch(c, n, mm, nn, 0, fold)) return rc;
+    if (!fold) hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
   }
+  c->remap_handed_over = fold;
   HIPCHK(c, hipGetLastError());
   return 0;
 }

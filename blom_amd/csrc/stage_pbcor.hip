@@ -28,12 +28,13 @@
 #define S2_PBUT 1
 #define S2_PBVT 2
 
-__global__ void k_pbc_pscan(const DevView *__restrict__ Vp, int which, int offc) {
+// from_remap: remap left the new dp in the work space (stage_remap_tile.hip, FOLD)
+__global__ void k_pbc_pscan(const DevView *__restrict__ Vp, int which, int offc, int from_remap) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
-  double *dp = V.f[F_dp] + (size_t)offc * np, *p = V.f[F_p];
+  double *dp = from_remap ? WK(V, R_DP(V.ntr)) : V.f[F_dp] + (size_t)offc * np, *p = V.f[F_p];
   double acc = p[c];
   int k = 0;
   for (; k + COLUMN_U <= V.kk; k += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
@@ -106,9 +107,11 @@ static int pbcor(blomgpu_ctx *c, int which, int m, int n, int mm, int nn, int k1
         return rc;
   }
   TimeScope ts(c, which == 1 ? "pbcor1" : "pbcor2");
-  hipLaunchKernelGGL(k_pbc_pscan, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, offc);
+  const int from_remap = which == 1 && c->in_sequence && c->remap_handed_over ? 1 : 0;
+  if (which == 1) c->remap_handed_over = false;
+  hipLaunchKernelGGL(k_pbc_pscan, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, offc, from_remap);
   hipLaunchKernelGGL(k_pbc_total, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, n, offf);
-  if (int rc = pbcor_tile_launch(c, which, m, offc, offf)) return rc;
+  if (int rc = pbcor_tile_launch(c, which, m, offc, offf, from_remap)) return rc;
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -63,7 +63,9 @@ __device__ inline void face_flux(const DevView &V, const double *sc, bool wet, d
   F.f3 = F.f * sc[2 * PT_LN + up];
 }
 
-__global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ Vp, int which, int offc, int offf, int ntx) {
+// from_remap (pbcor1 inside blomgpu_step): dp, T, S and the advected tracers of the level come from the work-space planes in
+// which remap left them (stage_remap_tile.hip, FOLD), not from their fields
+__global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ Vp, int which, int offc, int offf, int ntx, int from_remap) {
   const DevView &V = *Vp;
   __shared__ double sc[(3 + PT_TB) * PT_LN];                 // dp, saln, temp, one batch of tracers
   unsigned bx_, by_;
@@ -71,7 +73,14 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
   const int x0 = (bx_ % ntx) * PT_TW, y0 = (bx_ / ntx) * PT_TH;
   const size_t np = V.nplane, ok = (size_t)k * np, okc = (size_t)(k + offc) * np, okf = (size_t)(k + offf) * np;
-  const double *f_dp = V.f[F_dp] + okc, *f_s = V.f[F_saln] + okc, *f_t = V.f[F_temp] + okc, *f_tr = V.f[F_trc] + okc;
+  const double *f_dp = from_remap ? WK(V, R_DP(ntr)) + ok : V.f[F_dp] + okc;
+  const double *f_s = from_remap ? WK(V, R_S(ntr)) + ok : V.f[F_saln] + okc;
+  const double *f_t = from_remap ? WK(V, R_T(ntr)) + ok : V.f[F_temp] + okc;
+  const double *f_tr = V.f[F_trc] + okc;
+  // tracer nt of the level: remap advected it (then it lies in the work space) or left it alone (mod_remap.F90:314-316)
+  auto trc_at = [&](int nt, size_t cs) {
+    return from_remap && !trc_skip_adv(V.P, nt + 1) ? WK(V, R_TR(ntr, nt))[cs + ok] : f_tr[cs + (size_t)nt * 2 * V.kk * np];
+  };
 
   // ---- phase 0 ---------------------------------------------------------------------------------------------------
   double sv[2][3 + PT_TB];
@@ -85,7 +94,7 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
     csr[r] = cs;
     sv[r][0] = f_dp[cs]; sv[r][1] = f_s[cs]; sv[r][2] = f_t[cs];
 #pragma unroll
-    for (int nt = 0; nt < PT_TB; nt++) sv[r][3 + nt] = nt < ntr ? f_tr[cs + (size_t)nt * 2 * V.kk * np] : 0.;
+    for (int nt = 0; nt < PT_TB; nt++) sv[r][3 + nt] = nt < ntr ? trc_at(nt, cs) : 0.;
   }
   const int lx = t % PT_TW, ly = t / PT_TW;
   const int x = x0 + lx, y = y0 + ly;
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
 #pragma unroll
   for (int r = 0; r < 2; r++)
 #pragma unroll
-    for (int b = 0; b < PT_TB; b++) tv[r][b] = PT_TB + b < ntr ? f_tr[csr[r] + (size_t)(PT_TB + b) * 2 * V.kk * np] : 0.;
+    for (int b = 0; b < PT_TB; b++) tv[r][b] = PT_TB + b < ntr ? trc_at(PT_TB + b, csr[r]) : 0.;
   for (int nt0 = 0; nt0 < ntr; nt0 += PT_TB) {
     if (nt0 > 0) {
       __syncthreads();                                       // the previous batch has been read
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
       for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int b = 0; b < PT_TB; b++)
-          tv[r][b] = nt0 + PT_TB + b < ntr ? f_tr[csr[r] + (size_t)(nt0 + PT_TB + b) * 2 * V.kk * np] : 0.;
+          tv[r][b] = nt0 + PT_TB + b < ntr ? trc_at(nt0 + PT_TB + b, csr[r]) : 0.;
       __syncthreads();
     }
     if (upd) {
@@ -263,11 +272,11 @@ __global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restri
   }
 }
 
-int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf) {
+int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf, int from_remap) {
   const DevView &h = c->h;
   if (3 + h.ntr > h.nwk) return ctx_fail(c, "pbcor: work space too small for this many tracers");
   const int ntx = (h.ni + PT_TW - 1) / PT_TW, nty = (h.nj + PT_TH - 1) / PT_TH;
-  hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx);
+  hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx, from_remap);
   // inside blomgpu_step pbcor1 hands S, T and the tracers to diffus through the work space, pbcor2 to tmsmt2
   const int move = !c->in_sequence;
   (which == 1 ? c->pbcor1_handed_over : c->pbcor2_handed_over) = !move;

@@ -103,7 +103,14 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
 // of MAXTR through the same LDS slots -- their scalars in, their limited gradients (the wet-restricted neighbours, dxi, dyi
 // and the centre-of-mass offsets of the point kept in registers), their fluxes from the polygons' mass-flux contribution
 // and moments each face recorded (PolyRec): the geometry is evaluated once for all tracers.
-template <bool MORE>
+// FOLD = true (inside blomgpu_step): the flux-divergence update of k_remap_update (mod_remap.F90:1468-1520) is done here.  A
+// cell needs the fluxes through its east and north face as well, which are the west and south face of its neighbours: the
+// tiles are laid out RT_TW-1 x RT_TH-1 apart, a workgroup evaluates the faces of all its RT_TW x RT_TH points but OWNS only
+// those with a neighbour to the east and to the north inside the tile -- for these it accumulates uflx.. and writes the new
+// dp, T, S and tracers.  Not in place (the neighbouring tiles still read the old values in their rims): into work-space
+// planes, where pbcor1 -- the next stage, and the only reader before diffus rewrites the fields -- takes them
+// (remap_common.h: R_DP..).  The 12 + 2 ntr flux planes between the two kernels never reach memory.
+template <bool MORE, bool FOLD>
 __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv_all, AdvList L, int tsel) {
   const DevView &V = *Vp;
   const int nadv = nadv_all < MAXTR ? nadv_all : MAXTR;
@@ -114,7 +121,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   // nadv tracers are advected, tracer a of them is tracer (atr >> 8a) & 255 of the model (TKE and its length scale are
   // not unless use_TKEADV, mod_remap.F90:314-316 and every tracer loop after it)
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
-  const int x0 = (bx_ % ntx) * RT_TW, y0 = (bx_ / ntx) * RT_TH;        // first point of the tile in the padded plane
+  constexpr int STX = FOLD ? RT_TW - 1 : RT_TW, STY = FOLD ? RT_TH - 1 : RT_TH;
+  const int x0 = (bx_ % ntx) * STX, y0 = (bx_ / ntx) * STY;            // first point of the tile in the padded plane
   const bool zero_old = (tsel & 4) != 0;
   tsel &= 3;
   if (tsel) {
@@ -208,7 +216,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   double *const o_fs = (uface ? V.f[F_usflx] : V.f[F_vsflx]) + fc + okm;
   // old fluxes: the u-face accumulates (:1054-1056), the v-face assigns (:1455-1457).  Inside blomgpu_step init_fluxes has
   // zeroed them earlier in the step and nothing has added to them since (zero_old): 0 + flux without the read
-  const bool rd_old = uface && !zero_old;
+  const bool own = !FOLD || (ft % RT_TW < RT_TW - 1 && ft / RT_TW < RT_TH - 1);
+  const bool rd_old = uface && !zero_old && own;
   const double f_o = rd_old ? *o_f : 0., ft_o = rd_old ? *o_ft : 0., fs_o = rd_old ? *o_fs : 0.;
   const bool fmask = uface ? MU(mpf) : MV(mpf);
   const double cf = fmask ? (caf > 0. ? caf * m2i[1][0] : caf * m2i[1][1]) : 0.;     // cu resp. cv of the face
@@ -309,19 +318,19 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     cuv[RT_GN + q] = cvc;
   }
   __syncthreads();
-  if (!MORE && !fin) return;
+  if (!MORE && !FOLD && !fin) return;
 
   // ---- phase 3: flux through this thread's face (k_remap_flux) ---------------------------------------------------------
   const bool in_f = uface ? (fj >= 0 && fj <= V.jj + 1 && fi >= 0 && fi <= V.ii + 2) : (fj >= 0 && fj <= V.jj + 2 && fi >= 0 && fi <= V.ii + 1);
-  if (!MORE && !in_f) return;
+  if (!MORE && !FOLD && !in_f) return;
   const bool do_face = fin && in_f;
   PolyRec rec[3];
   int npoly = 0;
-  if (do_face) {
   Acc A;
   A.fd = 0.; A.ft = 0.; A.fs = 0.;
 #pragma unroll
   for (int nt = 0; nt < MAXTR; nt++) A.ftr[nt] = 0.;
+  if (do_face) {
   if (fmask) {
     const double cuc0 = cuv[fq], cvc0 = cuv[RT_GN + fq];
     const bool near = cf > 0.;                       // donor column i-1 (u-face) resp. donor row j-1 (v-face)
@@ -359,7 +368,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
       penint(s2_c, sh, .5, x2, y2, xm + sh, ym, x4, y4, sh, -.5, a, ax, ay, axx, ayy, axy);
       add_contrib_t<MORE>(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       // mod_remap.F90:1054-1056
-      if (base) {
+      if (base && own) {
         *o_f = f_o + A.fd;
         *o_ft = ft_o + A.ft;
         *o_fs = fs_o + A.fs;
@@ -394,7 +403,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
       penint(s2_c, -.5, sh, x2, y2, xm, ym + sh, x4, y4, .5, sh, a, ax, ay, axx, ayy, axy);
       add_contrib_t<MORE>(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
       // mod_remap.F90:1455-1457: assignment (not accumulation) for the v-components
-      if (base) {
+      if (base && own) {
         *o_f = A.fd;
         *o_ft = A.ft;
         *o_fs = A.fs;
@@ -403,14 +412,48 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   }
   // the flux planes of k_remap_update: W_FDU, W_FDV, W_FTU, W_FTV, .. alternate
   const int off = uface ? 0 : 1;
-  if (base) {
-    WK(V, W_FDU(ntr) + off)[fc + ok] = A.fd;
-    WK(V, W_FTU(ntr) + off)[fc + ok] = A.ft;
-    WK(V, W_FSU(ntr) + off)[fc + ok] = A.fs;
-  }
+  if (!FOLD) {
+    if (base) {
+      WK(V, W_FDU(ntr) + off)[fc + ok] = A.fd;
+      WK(V, W_FTU(ntr) + off)[fc + ok] = A.ft;
+      WK(V, W_FSU(ntr) + off)[fc + ok] = A.fs;
+    }
 #pragma unroll
-  for (int nt = 0; nt < MAXTR; nt++)
-    if (nt < nadv) WK(V, W_FTRU(ntr, L.idx[nt]) + off)[fc + ok] = A.ftr[nt];
+    for (int nt = 0; nt < MAXTR; nt++)
+      if (nt < nadv) WK(V, W_FTRU(ntr, L.idx[nt]) + off)[fc + ok] = A.ftr[nt];
+  }
+  }
+  // ---- FOLD: the update of the owned cells, mod_remap.F90:1468-1520 ------------------------------------------------------
+  // thread t < 256 is the cell whose west face it evaluated; its east face is thread t + 1's, its south face thread 256 + t's,
+  // its north face thread 256 + t + RT_TW's: the fluxes meet in LDS (the gradient slots have been read by now)
+  const int cx = fx - (NBDY - 1), cy = fy - (NBDY - 1);
+  const bool upd = FOLD && uface && own && fin && cy >= 0 && cy <= V.jj + 1 && cx >= 0 && cx <= V.ii + 1 && MP(mpf);
+  double q_dp = 0., dpn = 1.;
+  double *const fl = lds;
+  if (FOLD) {
+    __syncthreads();
+    fl[t] = A.fd; fl[RT_NT + t] = A.ft; fl[2 * RT_NT + t] = A.fs;
+#pragma unroll
+    for (int nt = 0; nt < MAXTR; nt++)
+      if (nt < nadv) fl[(3 + nt) * RT_NT + t] = A.ftr[nt];
+    __syncthreads();
+    if (upd) {
+      const int te = t + 1, ts = RT_TW * RT_TH + t, tn = ts + RT_TW;
+      const double s2i = m2i[1][1];
+      q_dp = fmax2(0., V.f[F_dp][fc + okn]) + DPEPS;
+      dpn = q_dp - (fl[te] - fl[t] + fl[tn] - fl[ts]) * s2i;
+      const double told = V.f[F_temp][fc + okn], sold = V.f[F_saln][fc + okn];
+      WK(V, R_T(ntr))[fc + ok] = (q_dp * told - (fl[RT_NT + te] - fl[RT_NT + t] + fl[RT_NT + tn] - fl[RT_NT + ts]) * s2i) / dpn;
+      WK(V, R_S(ntr))[fc + ok] = (q_dp * sold - (fl[2 * RT_NT + te] - fl[2 * RT_NT + t] + fl[2 * RT_NT + tn] - fl[2 * RT_NT + ts]) * s2i) / dpn;
+#pragma unroll
+      for (int nt = 0; nt < MAXTR; nt++)
+        if (nt < nadv) {
+          const double *f = fl + (3 + nt) * RT_NT;
+          const double xold = V.f[F_trc][fc + okn + (size_t)L.idx[nt] * 2 * V.kk * np];
+          WK(V, R_TR(ntr, L.idx[nt]))[fc + ok] = (q_dp * xold - (f[te] - f[t] + f[tn] - f[ts]) * s2i) / dpn;
+        }
+      WK(V, R_DP(ntr))[fc + ok] = fmax2(0., dpn - DPEPS);
+    }
   }
   if (!MORE) return;
   // ---- the other advected tracers, MAXTR at a time ----------------------------------------------------------------------
@@ -455,18 +498,77 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
           for (int pz = 0; pz < npoly; pz++)
             f = f + rec[pz].fd * gr[G_TRD(a) * RT_GN + rec[pz].x] + rec[pz].qx * gr[G_TRX(a) * RT_GN + rec[pz].x] +
                 rec[pz].qy * gr[G_TRY(a) * RT_GN + rec[pz].x];
-          WK(V, W_FTRU(ntr, L.idx[b0 + a]) + off2)[fc + ok] = f;
+          if (FOLD) fl[a * RT_NT + t] = f;
+          else WK(V, W_FTRU(ntr, L.idx[b0 + a]) + off2)[fc + ok] = f;
         }
+    }
+    if (FOLD) {
+      // (the batch's scalars, which lay where the fluxes now are, were last read before the barrier above; a face that
+      // is not evaluated contributes nothing)
+      if (!do_face) {
+#pragma unroll
+        for (int a = 0; a < MAXTR; a++)
+          if (a < nb_) fl[a * RT_NT + t] = 0.;
+      }
+      __syncthreads();
+      if (upd) {
+        const int te = t + 1, ts = RT_TW * RT_TH + t, tn = ts + RT_TW;
+        const double s2i = m2i[1][1];
+#pragma unroll
+        for (int a = 0; a < MAXTR; a++)
+          if (a < nb_) {
+            const double *f = fl + a * RT_NT;
+            const double xold = V.f[F_trc][fc + okn + (size_t)L.idx[b0 + a] * 2 * V.kk * np];
+            WK(V, R_TR(ntr, L.idx[b0 + a]))[fc + ok] = (q_dp * xold - (f[te] - f[t] + f[tn] - f[ts]) * s2i) / dpn;
+          }
+      }
     }
   }
 }
 
-int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
+// FOLD: what k_remap_update leaves in the HALO of the fields.  It updates the cells 0..ii+1 x 0..jj+1, one ring beyond the tile,
+// and commits dp = max(0, dp) + dpeps on the two rings beyond that (mod_remap.F90:297-303); the tile kernel cannot write halo
+// cells in place (other workgroups read them in their rims), and pbcor1 takes the interior from the work space.  Most of
+// these halo values are overwritten by the next halo update before anything reads them, but not all arrays get one before
+// the step ends (tracers that are advected but not diffused), and the state after a step is the reference's to the halo.
+__global__ void k_remap_ring(const DevView *__restrict__ Vp, int nn, int nadv_all, AdvList L) {
+  const DevView &V = *Vp;
+  const int ii = V.ii, jj = V.jj, w = ii + 6;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int i, j;
+  if (t < 6 * w) {                                     // rows -2..0 and jj+1..jj+3, i = -2..ii+3
+    const int r = t / w;
+    j = r < 3 ? r - 2 : jj + 1 + (r - 3);
+    i = t % w - 2;
+  } else {
+    t -= 6 * w;
+    if (t >= 6 * jj) return;                            // rows 1..jj: i = -2..0 and ii+1..ii+3
+    j = t / 6 + 1;
+    const int q = t % 6;
+    i = q < 3 ? q - 2 : ii + 1 + (q - 3);
+  }
+  const size_t c = IDX(V, i, j);
+  if (!V.m[I_ip][c]) return;
+  const int k = blockIdx.y, ntr = V.ntr;
+  const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np;
+  if (j < 0 || j > jj + 1 || i < 0 || i > ii + 1) {
+    V.f[F_dp][c + okn] = fmax2(0., V.f[F_dp][c + okn]) + DPEPS;
+    return;
+  }
+  V.f[F_dp][c + okn] = WK(V, R_DP(ntr))[c + ok];
+  V.f[F_temp][c + okn] = WK(V, R_T(ntr))[c + ok];
+  V.f[F_saln][c + okn] = WK(V, R_S(ntr))[c + ok];
+  for (int a = 0; a < nadv_all; a++)
+    V.f[F_trc][c + okn + (size_t)L.idx[a] * 2 * V.kk * np] = WK(V, R_TR(ntr, L.idx[a]))[c + ok];
+}
+
+int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold) {
   const bool zeroed = c->in_sequence && c->fluxes_zeroed;
   if (tsel == 0 || tsel == 2) c->fluxes_zeroed = false;             // (a split launch: tiles 1, then tiles 2)
   if (zeroed) tsel |= 4;
   const DevView &h = c->h;
-  const int ntx = (h.ni + RT_TW - 1) / RT_TW, nty = (h.nj + RT_TH - 1) / RT_TH;
+  const int stx = fold ? RT_TW - 1 : RT_TW, sty = fold ? RT_TH - 1 : RT_TH;
+  const int ntx = (h.ni + stx - 1) / stx, nty = (h.nj + sty - 1) / sty;
   static_assert(RT_NSC(MAXTR) * RT_SN <= RT_NG(MAXTR) * RT_GN, "the scalars must fit under the gradient slots");
   if (h.ntr > 255) return ctx_fail(c, "remap: tracer indices are packed in 8 bits");
   if (h.ntr > 0 && W_FTRV(h.ntr, h.ntr - 1) >= h.nwk) return ctx_fail(c, "remap: work space too small for this many tracers");
@@ -482,7 +584,14 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel) {
   const int nfirst = nadv < MAXTR ? nadv : MAXTR;
   const size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
   const dim3 grid(ntx * nty, h.kk);
-  if (nadv > MAXTR) hipLaunchKernelGGL(k_remap_tile<true>, grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
-  else hipLaunchKernelGGL(k_remap_tile<false>, grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+  if (fold) {
+    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+    else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+    if ((tsel & 3) != 1)                                // (a split launch: after the second part)
+      hipLaunchKernelGGL(k_remap_ring, dim3((6 * (h.ii + 6) + 6 * h.jj + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, nn, nadv, L);
+  } else {
+    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+    else hipLaunchKernelGGL((k_remap_tile<false, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+  }
   return 0;
 }

@@ -11,9 +11,9 @@ from parity import STATE_FIELDS
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, nsteps, _extra=(), **opts):
+def _run(cfg, nsteps, _extra=(), _ntr=None, **opts):
     from blom_amd.gpu import BlomGpu
-    case = make_case(cfg)
+    case = make_case(cfg, ntr=_ntr)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     for k, v in opts.items():
@@ -65,6 +65,21 @@ def test_tmsmt1_done_by_the_previous_steps_tmsmt2(cfg, nsteps):
         assert not bad, (what, bad)
     for nm in ("told", "sold", "dpold", "dpuold", "dpvold", "trcold"):
         assert nm in a, nm
+
+
+@pytest.mark.parametrize("cfg,nsteps,ntr", [("chan_s_tke", 6, None), ("tri_s_tke", 5, None), ("box_s", 5, None), ("chan_s_tke", 4, 11),
+                                            ("chan_m", 3, None)])
+def test_remap_with_the_update_folded_in(cfg, nsteps, ntr):
+    """option remap_fold: inside blomgpu_step the tile kernel of remap owns RT_TW-1 x RT_TH-1 cells of its tile, does
+    k_remap_update's flux-divergence update for them (phy/mod_remap.F90:1468-1520) and hands dp, T, S and the advected tracers to
+    pbcor1 through the work space; k_remap_ring commits what the update leaves in the halo.  Same bits in every array, halo
+    included, as two kernels with the flux planes between them."""
+    skip = {"util1", "util2", "util3", "util4"}
+    kw = {} if ntr is None else {"_ntr": ntr}
+    a = _run(cfg, nsteps, remap_fold=1, **kw)
+    b = _run(cfg, nsteps, remap_fold=0, **kw)
+    bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("cfg", ["tri_m", "tri_m_tke"])
