@@ -252,7 +252,6 @@ __global__ void k_cppm_arctic_init_swap(const DevView *__restrict__ Vp) {
 
 int st_init_cppm(blomgpu_ctx *c) {
   const DevView &h = c->h;
-  if (h.nreg == 2 && c->tiling.multi()) return ctx_fail(c, "init_cppm: the arctic patch is built for a single tile");
   hipLaunchKernelGGL(k_cppm_init, plane_grid(h, 2), dim3(256), 0, c->stream, c->d);
   for (int dir = 0; dir < 2; dir++) {
     // halo types as in the reference (:2606-2648): u-grid for the i tables, v-grid for the j tables,
@@ -792,7 +791,6 @@ int st_cppm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)k1m;
   const DevView &h = c->h;
   if (!c->cppm_ready) return ctx_fail(c, "cppm: init_cppm has not been called (blomgpu_init_cppm)");
-  if (h.nreg == 2 && c->tiling.multi()) return ctx_fail(c, "cppm: the arctic patch is built for a single tile");
   if (W_NSLOT(2 + h.ntr) > h.nwk) return ctx_fail(c, "cppm: device work space too small for this many tracers");
   const bool fc = c->cppm_compat == 1, mono = c->cppm_limiting == 1;
   if (fc) return mono ? cppm_variant<1, 1>(c, n, mm, nn, k1n) : cppm_variant<0, 1>(c, n, mm, nn, k1n);

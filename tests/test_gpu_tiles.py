@@ -96,6 +96,64 @@ def test_tiles_match_single_tile(cfg, npx, npy):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("cfg,npx,npy", [("chan_s", 2, 2), ("box_s", 2, 2), ("tri_s", 2, 1), ("tri_s", 2, 2), ("tri_s_tke", 4, 2)])
+def test_cppm_on_tiles_matches_single_tile(cfg, npx, npy):
+    """advect with advmth = 'cppm' on a decomposed domain: every tile builds its coefficient tables (init_cppm,
+    phy/mod_cppm.F90:2504-2722, halo updates of tags and edge coefficients included) and steps; on a tripolar grid the tiles
+    that hold the seam swap tags and edge coefficients across it (:2650-2722, :1531-1541, :1686-1704) -- the rule is written
+    in global indices.  Interiors as on the single tile."""
+    from blom_amd.gpu import BlomGpu, TileGroup
+    from blom_amd import hostinit
+    nsteps = 4
+    case = make_case(cfg, advmth="cppm")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    ref = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(ref, case)
+    fields = [nm for nm in ALL if ref.has_field(nm)]
+    ref.set("delt1", case.params["baclin"])
+    ii, jj = tile_extents(case, npx, npy)
+    grp = TileGroup(npx, npy)
+    tiles = {}
+    for py in range(npy):
+        for px in range(npx):
+            tm = {k: tile_window(masks[k], case, npx, npy, px, py) for k in masks}
+            t = BlomGpu(ii, jj, case.kdm, case.ntr, case.nreg, tm, itdm=case.idm, jtdm=case.jdm, i0=px * ii, j0=py * jj)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            t.set("delt1", case.params["baclin"])
+            grp.attach(t, px, py)
+            tiles[(px, py)] = t
+    scatter_state(ref, tiles, case, npx, npy, fields)
+    assert ref.step(0, nsteps) == nsteps
+    errs = []
+    kk = case.kdm
+
+    def run(t):
+        try:
+            t.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
+            t.step(0, nsteps)
+            t.sync()
+        except Exception as e:          # a failing tile would leave the others at a barrier
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(t,), daemon=True) for t in tiles.values()]
+    [x.start() for x in th]
+    [x.join(timeout=300) for x in th]
+    assert not errs, errs
+    bad = []
+    for nm in CHECK:
+        a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
+        b = gather_interior(tiles, case, npx, npy, nm)
+        if not np.array_equal(a, b):
+            bad.append((nm, int((a != b).sum()), float(np.nanmax(np.abs(a - b)))))
+    for t in tiles.values():
+        t.close()
+    ref.close()
+    grp.destroy()
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("cfg,isizes,jsizes", [("box_s", (12, 12), (11, 9)), ("chan_s", (7, 7, 6), (13, 11)),
                                                ("tri_s", (6, 6, 6, 6), (11, 9)), ("tri_s_tke", (12, 12), (9, 11))])
 def test_unequal_tiles_match_single_tile(cfg, isizes, jsizes):

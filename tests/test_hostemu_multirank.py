@@ -28,11 +28,21 @@ def emu_lib():
     g.LIB_PATH = old
 
 
-def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False):
+def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False):
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd.tiles import TileLayout, scatter_to_tile, gather_interior_layout, chain_crc, make_barotp_global
     from test_gpu_tiles import _single
-    case, masks, fields, ref = _single(cfg, nsteps)
+    if cppm:
+        from blom_amd import hostinit
+        from blom_amd.cases import make_case
+        case = make_case(cfg, advmth="cppm")
+        nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+        masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+        ref = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+        hostinit.init_state(ref, case)
+        ref.set("delt1", case.params["baclin"])
+    else:
+        case, masks, fields, ref = _single(cfg, nsteps)
     lay = TileLayout(tuple(isizes), tuple(jsizes))
     assert lay.itdm == case.idm and lay.jtdm == case.jdm
     uid = rccl_unique_id()
@@ -59,6 +69,8 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False):
             with lock:
                 tiles[(px, py)] = t
             barrier.wait()
+            if cppm:                                      # every rank builds its coefficient tables (halo updates included)
+                t.stage("init_cppm", 2, 1, case.kdm, 0, case.kdm + 1, 1)
             assert t.step(0, nsteps) == nsteps
             t.sync()
             crcs[(px, py)] = {f[0]: t.crc_strips(*f) for f in crc_fields}
@@ -103,6 +115,17 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False):
 ])
 def test_rccl_ranks_match_single_tile(emu_lib, cfg, isizes, jsizes):
     _run_case(cfg, isizes, jsizes)
+
+
+@pytest.mark.parametrize("cfg,isizes,jsizes", [
+    ("chan_s", (7, 7, 6), (13, 11)),
+    ("box_s", (12, 12), (11, 9)),
+    ("tri_s", (12, 12), (11, 9)),              # arctic patch: tags and edge coefficients swap across the seam (mod_cppm.F90:2650-2722)
+    ("tri_s_tke", (6, 6, 6, 6), (10, 10)),
+])
+def test_rccl_ranks_with_cppm(emu_lib, cfg, isizes, jsizes):
+    """advmth = 'cppm' through the RCCL transport, also on a decomposed tripolar grid"""
+    _run_case(cfg, isizes, jsizes, cppm=True)
 
 
 @pytest.mark.parametrize("cfg,isizes,jsizes", [
