@@ -184,6 +184,8 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   if (c->tiling.rccl) (void)blomgpu_rccl_finalize(c);
   if (c->err_dev) (void)hipFree(c->err_dev);
   if (c->bt_flags) (void)hipFree(c->bt_flags);
+  ale_free(c);
+  if (c->ale_plevel) (void)hipFree(c->ale_plevel);
   if (c->arc_strip) (void)hipFree(c->arc_strip);
   if (c->xcsum_buf) (void)hipFree(c->xcsum_buf);
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
@@ -251,6 +253,12 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
+  if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; return 0; }
+  if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; return 0; }
+  if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; return 0; }
+  if (s == "ale_tracer_pc_lower_bndr") { c->ale_tracer_pc_lower = v != 0; return 0; }
+  if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; return 0; }
+  if (s == "ale_velocity_pc_lower_bndr") { c->ale_velocity_pc_lower = v != 0; return 0; }
   if (s == "remap_fold") { c->remap_fold = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
@@ -299,6 +307,24 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     if (v == "intdif") P.eitmth = 1; else if (v == "gm") P.eitmth = 2;
     else return ctx_fail(c, " eitmth = " + v + " is unsupported!");   // phy/mod_diffusion.F90:316-327
     c->dirty = true;
+    return 0;
+  }
+  // &ALE_REGRID_REMAP, phy/mod_ale_regrid_remap.F90:1185-1355 (readnml_ale_regrid_remap; same words, same refusals)
+  if (s == "vcoord_type") {                               // phy/mod_vcoord.F90:908-921
+    if (v == "isopyc_bulkml") P.vcoord_tag = 1; else if (v == "cntiso_hybrid") P.vcoord_tag = 2; else if (v == "plevel") P.vcoord_tag = 3;
+    else return ctx_fail(c, " readnml_vcoord: vcoord_type = " + v + " is unsupported!");
+    return 0;
+  }
+  if (s == "ale_reconstruction_method") {
+    if (v == "plm") c->ale_method = 101; else if (v == "ppm") c->ale_method = 102; else if (v == "pqm") c->ale_method = 103;
+    else return ctx_fail(c, " readnml_ale_regrid_remap: reconstruction_method = " + v + " is unsupported!");
+    return 0;
+  }
+  if (s == "ale_tracer_limiting" || s == "ale_velocity_limiting") {
+    int lim;
+    if (v == "monotonic") lim = 201; else if (v == "non_oscillatory") lim = 203;
+    else return ctx_fail(c, " readnml_ale_regrid_remap: " + s.substr(4) + " = " + v + " is unsupported!");
+    (s == "ale_tracer_limiting" ? c->ale_tracer_limiting : c->ale_velocity_limiting) = lim;
     return 0;
   }
   if (s == "bmcmth") {
@@ -469,6 +495,22 @@ int blomgpu_sfcstr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1
 }
 int blomgpu_init_cppm(blomgpu_ctx *c) { ctx_sync_view(c); return st_init_cppm(c); }   // phy/mod_cppm.F90:2504
 int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
+int blomgpu_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {   // phy/mod_ale_regrid_remap.F90:1486
+  ctx_sync_view(c);
+  return st_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
+}
+// 1-D module arrays of the reference: "plevel" (kdm pressure levels of vcoord_type = 'plevel', phy/mod_vcoord.F90:99)
+int blomgpu_set_vector(blomgpu_ctx *c, const char *name, const double *v, int nv) {
+  if (!c || !name || !v) return ctx_fail(c, "blomgpu_set_vector: null argument");
+  const std::string s(name);
+  if (s == "plevel") {
+    if (nv != c->h.kk) return ctx_fail(c, " readnml_vcoord: number of plevel values does not match vertical dimension!");   // :965
+    if (!c->ale_plevel) HIPCHK(c, hipMalloc((void **)&c->ale_plevel, sizeof(double) * nv));
+    HIPCHK(c, hipMemcpy(c->ale_plevel, v, sizeof(double) * nv, hipMemcpyHostToDevice));
+    return 0;
+  }
+  return ctx_fail(c, "blomgpu_set_vector: unknown array " + s);
+}
 
 int blomgpu_halo_cmnfld2(blomgpu_ctx *c, int n) {     // phy/mod_cmnfld_routines.F90:1171-1196
   ctx_sync_view(c);
@@ -515,6 +557,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "cmnfld1") return blomgpu_cmnfld1(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
+  if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
 }
 

@@ -234,6 +234,12 @@ struct blomgpu_ctx {
   // overlapping tiles cost the tile kernel what the update kernel took, though 1.1 GB less crosses HBM
   int remap_fold = 0;
   bool remap_handed_over = false;   // ... and has left dp, T, S, tracers of the new level in the work space for pbcor1
+  // ale_regrid_remap (stage_ale.hip): the options of &ALE_REGRID_REMAP with the reference's defaults (mod_ale_regrid_remap.F90:69-95),
+  // as hor3map codes (include/blomgpu_hor3map.h); the engine's structures; the pressure levels of vcoord_type = 'plevel'
+  int ale_method = 102, ale_upper_bndr_ord = 6, ale_lower_bndr_ord = 4, ale_tracer_limiting = 203, ale_velocity_limiting = 203;
+  bool ale_tracer_pc_upper = true, ale_tracer_pc_lower = false, ale_velocity_pc_upper = true, ale_velocity_pc_lower = false;
+  void *ale = nullptr;
+  double *ale_plevel = nullptr;
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
   bool tmsmt1_ahead = false, tmsmt1_done_ahead = false;
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1
@@ -315,6 +321,9 @@ int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 #define R_T(ntr) (R_BASE(ntr) + 1)
 #define R_S(ntr) (R_BASE(ntr) + 2)
 #define R_TR(ntr, nt) (R_BASE(ntr) + 3 + (nt))
+int st_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_ale.hip
+void ale_free(blomgpu_ctx *);
+int launch_dpudpv(blomgpu_ctx *, int off, int flags);                                        // stage_simple.hip
 int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn, int tsel, bool fold);  // stage_remap_tile.hip; tsel 0 all tiles, 1 those that read no halo point, 2 the others
 int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf, int from_remap);   // stage_pbcor_tile.hip
 int launch_pscan(blomgpu_ctx *, int off, int lo, int hi_off);   // p(k+1)=p(k)+dp(k+off) over lo..ii+hi_off

@@ -40,6 +40,8 @@ struct blomgpu_h3m_grid {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Pool pool;
   bool device_io = false, check = true;
+  bool plane_io = false;      // device pointers in the library's own [level][column] layout: no transpose (the model's planes)
+  bool own_stream = true;
   unsigned long long *first_fail = nullptr;   // (column << 8 | errstat) of the first failing column
   double *stage_in = nullptr, *stage_out = nullptr;   // caller-layout staging for host pointers
   size_t stage_in_n = 0, stage_out_n = 0;
@@ -188,6 +190,10 @@ int load_input(blomgpu_h3m_grid *G, const double *a, int m, double *dst) {
   const int nc = G->g.nc;
   const size_t n = (size_t)m * nc;
   const double *src = a;
+  if (G->plane_io) {
+    H3CHK(hipMemcpyAsync(dst, a, n * sizeof(double), hipMemcpyDeviceToDevice, G->stream));
+    return 0;
+  }
   if (!G->device_io) {
     if (!grow(G, G->stage_in, G->stage_in_n, n)) return E_ALLOC;
     H3CHK(hipMemcpyAsync(G->stage_in, a, n * sizeof(double), hipMemcpyHostToDevice, G->stream));
@@ -201,6 +207,10 @@ int store_output(blomgpu_h3m_grid *G, const double *t, int m, double *a) {
   const int nc = G->g.nc;
   const size_t n = (size_t)m * nc;
   double *dst = a;
+  if (G->plane_io) {
+    H3CHK(hipMemcpyAsync(a, t, n * sizeof(double), hipMemcpyDeviceToDevice, G->stream));
+    return 0;
+  }
   if (!G->device_io) {
     if (!grow(G, G->stage_out, G->stage_out_n, n)) return E_ALLOC;
     dst = G->stage_out;
@@ -394,16 +404,29 @@ void blomgpu_h3m_grid_free(blomgpu_h3m_grid *G) {
     if (p) (void)hipFree(p);
   if (G->ev0) (void)hipEventDestroy(G->ev0);
   if (G->ev1) (void)hipEventDestroy(G->ev1);
-  if (G->stream) (void)hipStreamDestroy(G->stream);
+  if (G->stream && G->own_stream) (void)hipStreamDestroy(G->stream);
   delete G;
 }
 
 int blomgpu_h3m_set_io(blomgpu_h3m_grid *G, int device_pointers, int check_errors) {
   if (!G) return E_HANDLE;
   G->device_io = device_pointers != 0;
+  G->plane_io = device_pointers == 2;
   G->check = check_errors != 0;
   return 0;
 }
+
+}  // extern "C"
+// inside the library (stage_ale.hip): the grid works on the model context's stream
+int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream) {
+  if (!G) return E_HANDLE;
+  H3CHK(hipStreamSynchronize(G->stream));
+  if (G->own_stream && G->stream) (void)hipStreamDestroy(G->stream);
+  G->stream = stream;
+  G->own_stream = false;
+  return 0;
+}
+extern "C" {
 
 int blomgpu_h3m_prepare_reconstruction(blomgpu_h3m_grid *G, const double *x_edge_src) {
   if (!G || !x_edge_src) return E_HANDLE;

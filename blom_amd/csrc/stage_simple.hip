@@ -76,13 +76,14 @@ __global__ void k_pscan(const DevView *__restrict__ Vp, int off, int lo, int hi_
 
 // ---- dpu,dpv (and optionally pu,pv) from p, j,i = -1..+2 (mod_tmsmt.F90:369-391,
 //      mod_pgforc.F90:463-485, mod_mxlayr.F90:1282-1310) --------------------------------------
-// flags: 1 = pu, pv as well; 2 = the next step's tmsmt1 here (dpuold, dpvold = the new dpu, dpv, at the points of the tile)
+// flags: 1 = pu, pv as well; 2 = the next step's tmsmt1 here (dpuold, dpvold = the new dpu, dpv, at the points of the tile);
+// 4 = dpuold, dpvold at every point of the range (ale_regrid_remap, phy/mod_ale_regrid_remap.F90:1735-1762)
 __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, int off, int flags) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2) return;
   const int with_pupv = flags & 1;
-  const bool old_too = (flags & 2) && j >= 1 && j <= V.jj && i >= 1 && i <= V.ii;
+  const bool old_too = ((flags & 2) && j >= 1 && j <= V.jj && i >= 1 && i <= V.ii) || (flags & 4);
   const bool wu = V.m[I_iu][c] != 0, wv = V.m[I_iv][c] != 0;
   if (!wu && !wv) return;
   const double *p = V.f[F_p];
@@ -133,6 +134,12 @@ __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, i
 
 int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int flags) {
   hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, -2, 2);
+  hipLaunchKernelGGL(k_dpudpv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, flags);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int launch_dpudpv(blomgpu_ctx *c, int off, int flags) {
   hipLaunchKernelGGL(k_dpudpv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, flags);
   HIPCHK(c, hipGetLastError());
   return 0;

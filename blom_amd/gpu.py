@@ -114,6 +114,12 @@ class BlomGpu:
     def xctilr(self, name, lev0, l1, ld, mh, nh, itype):
         self._chk(self.lib.blomgpu_xctilr(self.ctx, name.encode(), lev0, l1, ld, mh, nh, itype))
 
+    def set_vector(self, name, v):
+        """1-D module arrays of the reference ("plevel", phy/mod_vcoord.F90:99)"""
+        a = np.ascontiguousarray(v, dtype=np.float64)
+        self.lib.blomgpu_set_vector.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        self._chk(self.lib.blomgpu_set_vector(self.ctx, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
     def step(self, nstep, nsteps=1):
         ns = C.c_int(nstep)
         self._chk(self.lib.blomgpu_step(self.ctx, C.byref(ns), nsteps))

@@ -121,6 +121,14 @@ int  blomgpu_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 int  blomgpu_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
+/* phy/mod_ale_regrid_remap.F90:1486 ale_regrid_remap(m,n,mm,nn,k1m,k1n): regrid the layer interfaces and remap T, S, tracers, u, v
+ * (first piece: vcoord_type = 'plevel'; other coordinates fail loudly).  Options: blomgpu_set_str "vcoord_type",
+ * "ale_reconstruction_method", "ale_tracer_limiting", "ale_velocity_limiting"; blomgpu_set_int "ale_upper_bndr_ord",
+ * "ale_lower_bndr_ord", "ale_{tracer,velocity}_pc_{upper,lower}_bndr" -- the variables of &ALE_REGRID_REMAP (:1193-1201). */
+int  blomgpu_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+/* 1-D module arrays: "plevel", the kdm pressure levels [g cm-1 s-2 as the model's p] of vcoord_type = 'plevel'
+ * (phy/mod_vcoord.F90:99, :948-970) */
+int  blomgpu_set_vector(blomgpu_ctx *, const char *name, const double *v, int nv);
 
 /* Generic dispatcher over the entries above ("advect", "tmsmt1", ...). */
 int  blomgpu_stage(blomgpu_ctx *, const char *stage, int m, int n, int mm, int nn,

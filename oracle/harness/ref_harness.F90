@@ -49,6 +49,11 @@ module ref_harness
   use mod_eddtra,    only: eddtra
   use mod_cmnfld_routines, only: cmnfld1, cmnfld2
 #endif
+#ifdef XCHECK_ALE
+  ! cross-check builds only (oracle/Makefile *_xale): the reference's real mod_ale_regrid_remap against the mod_dia stand-in
+  use mod_ale_regrid_remap, only: readnml_ale_regrid_remap, init_ale_regrid_remap, ale_regrid_remap
+  use mod_vcoord,    only: plevel
+#endif
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
 
@@ -194,6 +199,21 @@ contains
       case default; ierr = 1; v = 0
     end select
   end subroutine ref_get_real
+
+  ! 1-D module arrays (plevel: the pressure levels of vcoord_type = 'plevel', phy/mod_vcoord.F90:99)
+  subroutine ref_set_vec(name, v, nv, ierr) bind(C, name='ref_set_vec')
+    character(kind=c_char), intent(in) :: name(*)
+    integer(c_int), value :: nv
+    real(c_double), intent(in) :: v(nv)
+    integer(c_int), intent(out) :: ierr
+    ierr = 0
+    select case (trim(cstr(name)))
+#ifdef XCHECK_ALE
+      case ('plevel'); plevel(1:nv) = v(1:nv)
+#endif
+      case default; ierr = 1
+    end select
+  end subroutine ref_set_vec
 
   subroutine ref_set_int(name, v, ierr) bind(C, name='ref_set_int')
     character(kind=c_char), intent(in) :: name(*)
@@ -456,6 +476,14 @@ contains
       case ('eddtra');  call eddtra(m,n,mm,nn,k1m,k1n)
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
+#endif
+#ifdef XCHECK_ALE
+      ! ale_init: the group &ALE_REGRID_REMAP of the file `limits` in the working directory, then the reconstruction and
+      ! remapping structures (mod_blom_init.F90 calls the two in this order); vcoord_tag must have been set before
+      case ('ale_init')
+        call readnml_ale_regrid_remap
+        call init_ale_regrid_remap
+      case ('ale_regrid_remap'); call ale_regrid_remap(m,n,mm,nn,k1m,k1n)
 #endif
       ! Halo updates the reference performs inside stages that cannot be built here
       ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.

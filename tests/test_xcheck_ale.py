@@ -1,0 +1,137 @@
+"""CROSS-CHECK (not a pin) of the device's ale_regrid_remap against the reference's REAL phy/mod_ale_regrid_remap.F90.
+
+SURVEY.md 8 row f3, first piece: the regrid + remap step of the vertical coordinates other than isopyc_bulkml, built on the
+device hor3map (blom_amd/csrc/stage_ale.hip).  The reference module imports the z-level diagnostic flags and arrays of the
+netCDF-bound mod_dia, so it is compiled against oracle/xcheck/mod_dia_standin.F90 (all flags zero: no diagnostic requested)
+in the *_xale builds of oracle/Makefile -- hence a cross-check, not a pin.  What is compared: after a few steps
+of the isopycnic sequence on the device (so that the layers are uneven, some massless, and the velocities non-zero) the
+state goes to the reference, both run ale_regrid_remap with vcoord_type = 'plevel' and the options of the namelist group
+&ALE_REGRID_REMAP -- the reference reads them from a file `limits`, the device takes them through blomgpu_set_str /
+set_int -- and every array the stage writes must agree bit for bit: dp, T, S, sigma, tracers, u, v, dpu, dpv, dpuold, dpvold,
+p, pu, pv."""
+import os
+
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd import hostinit
+from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, GRID_FIELDS, INT_FIELDS
+
+pytestmark = pytest.mark.gpu
+
+# one reference library per configuration, and its ALE structures can be initialised once per process: one option set each
+OPTIONS = {
+    # the group of the reference's own tests/fuk95/limits
+    "fuk95": dict(reconstruction_method="ppm", upper_bndr_ord=6, lower_bndr_ord=4, tracer_limiting="non_oscillatory",
+                  velocity_limiting="non_oscillatory", tracer_pc_upper_bndr=True, tracer_pc_lower_bndr=False,
+                  velocity_pc_upper_bndr=True, velocity_pc_lower_bndr=False),
+    "chan_s": dict(reconstruction_method="pqm", upper_bndr_ord=4, lower_bndr_ord=4, tracer_limiting="monotonic",
+                   velocity_limiting="monotonic", tracer_pc_upper_bndr=False, tracer_pc_lower_bndr=True,
+                   velocity_pc_upper_bndr=False, velocity_pc_lower_bndr=False),
+    "box_s": dict(reconstruction_method="plm", upper_bndr_ord=2, lower_bndr_ord=2, tracer_limiting="non_oscillatory",
+                  velocity_limiting="monotonic", tracer_pc_upper_bndr=True, tracer_pc_lower_bndr=True,
+                  velocity_pc_upper_bndr=True, velocity_pc_lower_bndr=True),
+    "tri_s": dict(reconstruction_method="ppm", upper_bndr_ord=3, lower_bndr_ord=2, tracer_limiting="non_oscillatory",
+                  velocity_limiting="non_oscillatory", tracer_pc_upper_bndr=True, tracer_pc_lower_bndr=False,
+                  velocity_pc_upper_bndr=True, velocity_pc_lower_bndr=False),
+}
+OUT = ["dp", "temp", "saln", "sigma", "trc", "u", "v", "dpu", "dpv", "dpuold", "dpvold", "p", "pu", "pv"]
+_INITIALISED = set()
+
+
+def _limits_text(o):
+    f = lambda b: ".true." if b else ".false."
+    return (" &ALE_REGRID_REMAP\n"
+            f"  RECONSTRUCTION_METHOD  = '{o['reconstruction_method']}'\n  UPPER_BNDR_ORD = {o['upper_bndr_ord']}\n"
+            f"  LOWER_BNDR_ORD = {o['lower_bndr_ord']}\n  DENSITY_LIMITING = 'monotonic'\n"
+            f"  TRACER_LIMITING = '{o['tracer_limiting']}'\n  VELOCITY_LIMITING = '{o['velocity_limiting']}'\n"
+            f"  TRACER_PC_UPPER_BNDR = {f(o['tracer_pc_upper_bndr'])}\n  TRACER_PC_LOWER_BNDR = {f(o['tracer_pc_lower_bndr'])}\n"
+            f"  VELOCITY_PC_UPPER_BNDR = {f(o['velocity_pc_upper_bndr'])}\n  VELOCITY_PC_LOWER_BNDR = {f(o['velocity_pc_lower_bndr'])}\n"
+            "  REGRID_METHOD = 'direct'\n /\n")
+
+
+@pytest.mark.parametrize("cfg,nsteps,spread", [("fuk95", 3, 1.0), ("chan_s", 4, 1.0), ("chan_s", 2, 0.35), ("box_s", 4, 1.3),
+                                               ("tri_s", 3, 1.0)])
+def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, tmp_path):
+    import ctypes as C
+    from oracle.refblom import get_ref_backend, have_ref
+    from blom_amd.gpu import BlomGpu
+    if not have_ref(cfg + "_xale"):
+        pytest.skip(f"oracle/_ref/{cfg}_xale/libblomref.so not built")
+    o = OPTIONS[cfg]
+    case = make_case(cfg)
+    ref = get_ref_backend(cfg + "_xale", case.depth)
+    kk = case.kdm
+    # device: the isopycnic sequence for a few steps
+    gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
+    hostinit.init_state(gpu, case)
+    assert gpu.step(0, nsteps) == nsteps
+    # pressure levels: from the surface to `spread` times the deepest bottom pressure (levels below the bottom collapse there)
+    pbot = float(np.nanmax(gpu.get("p")[kk][4:-4, 4:-4] * (ref.masks["ip"][4:-4, 4:-4] > 0)))
+    plevel = spread * pbot * (np.arange(kk) / kk) ** 1.3
+    # reference: same state, vcoord_type = 'plevel', its structures from the namelist group
+    hostinit.init_state(ref, case)
+    copy_state(gpu, ref, fields=STATE_FIELDS + GRID_FIELDS + INT_FIELDS)
+    ref.ref.set("vcoord_tag", 3)
+    ierr = C.c_int(0)
+    v = np.ascontiguousarray(plevel, dtype=np.float64)
+    ref.ref.lib.ref_set_vec(b"plevel", v.ctypes.data_as(C.c_void_p), C.c_int(kk), C.byref(ierr))
+    assert ierr.value == 0
+    six = hostinit.step_indices(nsteps, kk)
+    if cfg not in _INITIALISED:
+        (tmp_path / "limits").write_text(_limits_text(o))
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            ref.ref.stage("ale_init", *six)
+        finally:
+            os.chdir(cwd)
+        _INITIALISED.add(cfg)
+    try:
+        ref.ref.stage("ale_regrid_remap", *six)
+        # device
+        gpu.set("vcoord_type", "plevel")
+        gpu.set("ale_reconstruction_method", o["reconstruction_method"])
+        gpu.set("ale_tracer_limiting", o["tracer_limiting"])
+        gpu.set("ale_velocity_limiting", o["velocity_limiting"])
+        for nm in ("upper_bndr_ord", "lower_bndr_ord"):
+            gpu.set("ale_" + nm, int(o[nm]))
+        for nm in ("tracer_pc_upper_bndr", "tracer_pc_lower_bndr", "velocity_pc_upper_bndr", "velocity_pc_lower_bndr"):
+            gpu.set("ale_" + nm, 1 if o[nm] else 0)
+        gpu.set_vector("plevel", plevel)
+        before = gpu.get("dp").copy()
+        gpu.stage("ale_regrid_remap", *six)
+        bad = diff_report(ref, gpu, fields=OUT)
+        assert not bad, fmt_report(bad[:10])
+        # the stage did something: layers moved, and mass, heat and salt of every column are what they were
+        after = gpu.get("dp")
+        nn = six[3]
+        assert np.abs(after[nn:nn + kk] - before[nn:nn + kk])[:, 4:-4, 4:-4].max() > 0.0
+        wet = ref.masks["ip"][4:-4, 4:-4] > 0
+        col0 = before[nn:nn + kk][:, 4:-4, 4:-4].sum(axis=0)[wet]
+        col1 = after[nn:nn + kk][:, 4:-4, 4:-4].sum(axis=0)[wet]
+        np.testing.assert_allclose(col1, col0, rtol=1e-12)
+    finally:
+        ref.ref.set("vcoord_tag", 1)
+        gpu.close()
+
+
+def test_other_coordinates_fail_loudly():
+    from blom_amd.gpu import BlomGpu, BlomGpuError
+    case = make_case("chan_s")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    six = hostinit.step_indices(0, case.kdm)
+    with pytest.raises(BlomGpuError, match="isopyc_bulkml"):
+        gpu.stage("ale_regrid_remap", *six)
+    gpu.set("vcoord_type", "cntiso_hybrid")
+    with pytest.raises(BlomGpuError, match="cntiso_hybrid"):
+        gpu.stage("ale_regrid_remap", *six)
+    gpu.set("vcoord_type", "plevel")
+    with pytest.raises(BlomGpuError, match="plevel"):
+        gpu.stage("ale_regrid_remap", *six)                 # no pressure levels given
+    with pytest.raises(BlomGpuError, match="unsupported"):
+        gpu.set("ale_reconstruction_method", "spline")
+    gpu.close()
