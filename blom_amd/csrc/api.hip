@@ -211,6 +211,7 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   R(wuv1) R(wuv2) R(wts1) R(wts2) R(wbaro) R(bdmc1) R(bdmc2) R(iwdfac) R(nubmin) R(vland)
 #undef R
   if (s == "pref") { P.pref = v; set_eos(P); c->dirty = true; return 0; }
+  if (s == "ale_dpmin_interior") { c->ale_dpmin_interior = v * 9806.; return 0; }   // [m], as in &ALE_REGRID_REMAP (:1352-1353)
   return ctx_fail(c, "blomgpu_set_real: unknown option " + s);
 }
 
@@ -255,6 +256,9 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
   if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; return 0; }
   if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; return 0; }
+  if (s == "ale_k_range_plevel") { c->ale_k_range_plevel = v; return 0; }
+  if (s == "ale_density_pc_upper_bndr") { c->ale_density_pc_upper = v != 0; return 0; }
+  if (s == "ale_density_pc_lower_bndr") { c->ale_density_pc_lower = v != 0; return 0; }
   if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; return 0; }
   if (s == "ale_tracer_pc_lower_bndr") { c->ale_tracer_pc_lower = v != 0; return 0; }
   if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; return 0; }
@@ -318,6 +322,15 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
   if (s == "ale_reconstruction_method") {
     if (v == "plm") c->ale_method = 101; else if (v == "ppm") c->ale_method = 102; else if (v == "pqm") c->ale_method = 103;
     else return ctx_fail(c, " readnml_ale_regrid_remap: reconstruction_method = " + v + " is unsupported!");
+    return 0;
+  }
+  if (s == "ale_regrid_method") {                         // :1323-1337
+    if (v == "direct") c->ale_regrid_method = 1; else if (v == "nudge") c->ale_regrid_method = 2;
+    else return ctx_fail(c, " readnml_ale_regrid_remap: regrid_method = " + v + " is unsupported!");
+    return 0;
+  }
+  if (s == "ale_density_limiting") {
+    if (v != "monotonic") return ctx_fail(c, " readnml_ale_regrid_remap: density_limiting = " + v + " is unsupported!");
     return 0;
   }
   if (s == "ale_tracer_limiting" || s == "ale_velocity_limiting") {

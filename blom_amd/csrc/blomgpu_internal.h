@@ -53,7 +53,7 @@
   /* mod_tmsmt */                                                                        \
   X(dpold, 2 * K) X(dpuold, K) X(dpvold, K) X(told, K) X(sold, K)                        \
   /* mod_vcoord / mod_diffusion */                                                       \
-  X(sigmar, K) X(temmin, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)          \
+  X(sigmar, K) X(sigint, K) X(temmin, K) X(difint, K) X(difiso, K) X(difdia, K) X(difmxp, 1) X(difmxq, 1)          \
   X(difwgt, 1) X(umfltd, 2 * K) X(vmfltd, 2 * K) X(umflsm, 2 * K) X(vmflsm, 2 * K)       \
   X(utfltd, 2 * K) X(vtfltd, 2 * K) X(utflsm, 2 * K) X(vtflsm, 2 * K) X(utflld, 2 * K)   \
   X(vtflld, 2 * K) X(usfltd, 2 * K) X(vsfltd, 2 * K) X(usflsm, 2 * K) X(vsflsm, 2 * K)   \
@@ -238,6 +238,9 @@ struct blomgpu_ctx {
   // as hor3map codes (include/blomgpu_hor3map.h); the engine's structures; the pressure levels of vcoord_type = 'plevel'
   int ale_method = 102, ale_upper_bndr_ord = 6, ale_lower_bndr_ord = 4, ale_tracer_limiting = 203, ale_velocity_limiting = 203;
   bool ale_tracer_pc_upper = true, ale_tracer_pc_lower = false, ale_velocity_pc_upper = true, ale_velocity_pc_lower = false;
+  bool ale_density_pc_upper = false, ale_density_pc_lower = false;
+  int ale_regrid_method = 2, ale_k_range_plevel = 1;      // 'nudge' is the reference's default (not built: set 'direct')
+  double ale_dpmin_interior = .1 * 9806.;                 // [m] in the namelist, times onem (:1352-1353)
   void *ale = nullptr;
   double *ale_plevel = nullptr;
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)

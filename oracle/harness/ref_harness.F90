@@ -26,7 +26,7 @@ module ref_harness
   use mod_eos,       only: pref, inieos
   use mod_bigrid,    only: bigrid
   use mod_checksum,  only: csdiag
-  use mod_vcoord,    only: vcoord_tag, sigmar, inivar_vcoord
+  use mod_vcoord,    only: vcoord_tag, sigmar, sigint, inivar_vcoord
   use mod_pgforc
   use mod_momtum
   use mod_barotp
@@ -383,6 +383,7 @@ contains
       R3(dpvold, kdm)
       ! mod_vcoord, mod_temmin
       R3(sigmar, kdm)
+      R3(sigint, kdm)
       R3(temmin, kdm)
       ! mod_diffusion
       R3(difint, kdm)

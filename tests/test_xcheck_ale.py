@@ -5,10 +5,11 @@ device hor3map (blom_amd/csrc/stage_ale.hip).  The reference module imports the 
 netCDF-bound mod_dia, so it is compiled against oracle/xcheck/mod_dia_standin.F90 (all flags zero: no diagnostic requested)
 in the *_xale builds of oracle/Makefile -- hence a cross-check, not a pin.  What is compared: after a few steps
 of the isopycnic sequence on the device (so that the layers are uneven, some massless, and the velocities non-zero) the
-state goes to the reference, both run ale_regrid_remap with vcoord_type = 'plevel' and the options of the namelist group
+state goes to the reference, both run ale_regrid_remap with vcoord_type = 'plevel' or 'cntiso_hybrid' (regrid_method =
+'direct') and the options of the namelist group
 &ALE_REGRID_REMAP -- the reference reads them from a file `limits`, the device takes them through blomgpu_set_str /
 set_int -- and every array the stage writes must agree bit for bit: dp, T, S, sigma, tracers, u, v, dpu, dpv, dpuold, dpvold,
-p, pu, pv."""
+p, pu, pv, and the diagnostic interface densities sigint."""
 import os
 
 import numpy as np
@@ -51,9 +52,13 @@ def _limits_text(o):
             "  REGRID_METHOD = 'direct'\n /\n")
 
 
-@pytest.mark.parametrize("cfg,nsteps,spread", [("fuk95", 3, 1.0), ("chan_s", 4, 1.0), ("chan_s", 2, 0.35), ("box_s", 4, 1.3),
-                                               ("tri_s", 3, 1.0)])
-def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, tmp_path):
+@pytest.mark.parametrize("cfg,nsteps,spread,vcoord", [
+    ("fuk95", 3, 1.0, "plevel"), ("chan_s", 4, 1.0, "plevel"), ("chan_s", 2, 0.35, "plevel"), ("box_s", 4, 1.3, "plevel"),
+    ("tri_s", 3, 1.0, "plevel"),
+    # regrid_method = 'direct': the interfaces follow the layers' target densities
+    ("fuk95", 3, 0.6, "cntiso_hybrid"), ("chan_s", 4, 0.5, "cntiso_hybrid"), ("chan_s", 2, 0.1, "cntiso_hybrid"),
+    ("box_s", 4, 0.8, "cntiso_hybrid"), ("tri_s", 3, 0.3, "cntiso_hybrid")])
+def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vcoord, tmp_path):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
@@ -73,13 +78,14 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, tmp
     # reference: same state, vcoord_type = 'plevel', its structures from the namelist group
     hostinit.init_state(ref, case)
     copy_state(gpu, ref, fields=STATE_FIELDS + GRID_FIELDS + INT_FIELDS)
-    ref.ref.set("vcoord_tag", 3)
+    tag = 3 if vcoord == "plevel" else 2
     ierr = C.c_int(0)
     v = np.ascontiguousarray(plevel, dtype=np.float64)
     ref.ref.lib.ref_set_vec(b"plevel", v.ctypes.data_as(C.c_void_p), C.c_int(kk), C.byref(ierr))
     assert ierr.value == 0
     six = hostinit.step_indices(nsteps, kk)
     if cfg not in _INITIALISED:
+        ref.ref.set("vcoord_tag", 2)           # the reader resolves regrid_method only for 'cntiso_hybrid' (:1323)
         (tmp_path / "limits").write_text(_limits_text(o))
         cwd = os.getcwd()
         os.chdir(tmp_path)
@@ -89,9 +95,12 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, tmp
             os.chdir(cwd)
         _INITIALISED.add(cfg)
     try:
+        ref.ref.set("vcoord_tag", tag)
+        pre_sigint = ref.get("sigint").copy()
         ref.ref.stage("ale_regrid_remap", *six)
         # device
-        gpu.set("vcoord_type", "plevel")
+        gpu.set("vcoord_type", vcoord)
+        gpu.set("ale_regrid_method", "direct")
         gpu.set("ale_reconstruction_method", o["reconstruction_method"])
         gpu.set("ale_tracer_limiting", o["tracer_limiting"])
         gpu.set("ale_velocity_limiting", o["velocity_limiting"])
@@ -100,9 +109,11 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, tmp
         for nm in ("tracer_pc_upper_bndr", "tracer_pc_lower_bndr", "velocity_pc_upper_bndr", "velocity_pc_lower_bndr"):
             gpu.set("ale_" + nm, 1 if o[nm] else 0)
         gpu.set_vector("plevel", plevel)
+        if tag == 2:
+            gpu.put("sigint", pre_sigint)          # the reference's initial pattern (spval) where the stage does not write
         before = gpu.get("dp").copy()
         gpu.stage("ale_regrid_remap", *six)
-        bad = diff_report(ref, gpu, fields=OUT)
+        bad = diff_report(ref, gpu, fields=OUT + (["sigint"] if tag == 2 else []))
         assert not bad, fmt_report(bad[:10])
         # the stage did something: layers moved, and mass, heat and salt of every column are what they were
         after = gpu.get("dp")
@@ -127,7 +138,7 @@ def test_other_coordinates_fail_loudly():
     with pytest.raises(BlomGpuError, match="isopyc_bulkml"):
         gpu.stage("ale_regrid_remap", *six)
     gpu.set("vcoord_type", "cntiso_hybrid")
-    with pytest.raises(BlomGpuError, match="cntiso_hybrid"):
+    with pytest.raises(BlomGpuError, match="nudge"):          # the reference's default regrid_method
         gpu.stage("ale_regrid_remap", *six)
     gpu.set("vcoord_type", "plevel")
     with pytest.raises(BlomGpuError, match="plevel"):
