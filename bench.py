@@ -327,6 +327,51 @@ def bench_hor3map(args):
     print(json.dumps(out))
 
 
+def bench_ale(args):
+    """`--config ale`: SURVEY.md 8 row f3's first piece on its own -- one ale_regrid_remap (phy/mod_ale_regrid_remap.F90:1486) of
+    BASELINE's channel, vcoord_type = 'cntiso_hybrid' with regrid_method = 'direct', the options of the reference's
+    tests/fuk95/limits: reconstruct T, S and the tracers, regrid the interfaces to their target densities, remap T, S, tracers,
+    u and v.  State: the isopycnic state after two steps of the dynamical core.  One JSON line; the CPU baseline is the
+    reference's real module (oracle/_ref/channel_tke_omp_xale, cross-check build) when it has been built."""
+    import numpy as np
+    import torch
+    from blom_amd.gpu import BlomGpu
+    from blom_amd import hostinit
+    case, nreg, masks = build_case("channel")
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    ns = gpu.step(0, 2)
+    kk = case.kdm
+    pbot = float(np.nanmax(gpu.get("p")[kk]))
+    gpu.set("vcoord_type", "cntiso_hybrid")
+    gpu.set("ale_regrid_method", "direct")
+    gpu.set_vector("plevel", 0.05 * pbot * (np.arange(kk) / kk) ** 1.3)
+    six = hostinit.step_indices(ns, kk)
+    for _ in range(max(1, args.warmup)):
+        gpu.stage("ale_regrid_remap", *six)
+    gpu.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gpu.stage("ale_regrid_remap", *six)
+    gpu.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    F = case.idm * case.jdm * kk * 8.0
+    ntl = 2 + case.ntr
+    alg = (ntl + 1 + 2 + 2) * F + (ntl + 2 + 2 + 2 + 2) * F     # read dp, T, S, trc, u, v, dpu, dpv; write those, sigma, dpuold, dpvold
+    out = {"metric": "ale_regrid_remap calls per second", "value": 1.0 / dt, "unit": "calls/sec", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"ale_regrid_remap on channel {case.idm}x{case.jdm}x{kk}, ntr={case.ntr}: vcoord_type = cntiso_hybrid, "
+                                  "regrid_method = direct, ppm / non_oscillatory, boundary orders 6 / 4 (the reference's tests/fuk95/limits); "
+                                  "every hor3map call synchronises for its error status",
+                      "parity": "cross-checked against the reference's real module built against a stand-in for mod_dia (tests/test_xcheck_ale.py)"},
+           "roofline": {"bound": "hbm", "kernel": "ale_regrid_remap", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg, "avg_ms": dt * 1e3,
+                        "note": "the model's fields in and out once; the column kernels of the engine are latency bound (DESIGN.md 3a)"}}
+    gpu.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -357,6 +402,8 @@ def main():
     args = ap.parse_args()
     if args.config == "hor3map":
         return bench_hor3map(args)
+    if args.config == "ale":
+        return bench_ale(args)
 
     from blom_amd import launch
     env = launch.rank_env()

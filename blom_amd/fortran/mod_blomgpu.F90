@@ -116,13 +116,20 @@ module mod_blomgpu
       import :: c_ptr, c_int
       type(c_ptr), value :: c
     end function
+    integer(c_int) function blomgpu_set_vector(c, name, v, nv) bind(C, name='blomgpu_set_vector')
+      import :: c_ptr, c_int, c_char, c_double
+      type(c_ptr), value :: c
+      character(kind=c_char), intent(in) :: name(*)
+      real(c_double), intent(in) :: v(*)
+      integer(c_int), value :: nv
+    end function
   end interface
 
   public :: gpu_init, gpu_finalize, gpu_set, gpu_upload, gpu_upload_int, gpu_download, gpu_nlev, &
             gpu_halo, gpu_chksum, gpu_sync, gpu_xcsum, budget_sums, gpu_budget
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
             diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail, &
-            cmnfld1, cmnfld2
+            cmnfld1, cmnfld2, ale_regrid_remap, gpu_set_vector
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -340,6 +347,15 @@ contains
   subroutine mxlayr_tail(nn,k1n)               ! phy/mod_mxlayr.F90:1266-1310
     integer, intent(in) :: nn,k1n
     call stage6('mxlayr_tail',0,0,0,nn,0,k1n)
+  end subroutine
+  subroutine ale_regrid_remap(m,n,mm,nn,k1m,k1n)   ! phy/mod_ale_regrid_remap.F90:1486 (vcoord 'plevel', 'cntiso_hybrid'/'direct')
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('ale_regrid_remap',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine gpu_set_vector(name, v)           ! 1-D module arrays: 'plevel' (phy/mod_vcoord.F90:99)
+    character(len=*), intent(in) :: name
+    real(c_double), intent(in) :: v(:)
+    call gpu_check(blomgpu_set_vector(ctx, cz(name), v, size(v)), name)
   end subroutine
 
 end module mod_blomgpu
