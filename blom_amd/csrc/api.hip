@@ -211,6 +211,10 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   R(wuv1) R(wuv2) R(wts1) R(wts2) R(wbaro) R(bdmc1) R(bdmc2) R(iwdfac) R(nubmin) R(vland)
 #undef R
   if (s == "pref") { P.pref = v; set_eos(P); c->dirty = true; return 0; }
+  if (s == "ale_regrid_nudge_ts") { c->ale_regrid_nudge_ts = v; return 0; }
+  if (s == "ale_stab_fac_limit") { c->ale_stab_fac_limit = v; return 0; }
+  if (s == "ale_dpvar_fac") { c->ale_dpvar_fac = v; return 0; }
+  if (s == "ale_smooth_diff_max") { c->ale_smooth_diff_max = v; return 0; }
   if (s == "ale_dpmin_interior") { c->ale_dpmin_interior = v * 9806.; return 0; }   // [m], as in &ALE_REGRID_REMAP (:1352-1353)
   return ctx_fail(c, "blomgpu_set_real: unknown option " + s);
 }
@@ -257,6 +261,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; return 0; }
   if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; return 0; }
   if (s == "ale_k_range_plevel") { c->ale_k_range_plevel = v; return 0; }
+  if (s == "ale_dktzu") { c->ale_dktzu = v; return 0; }
+  if (s == "ale_dktzl") { c->ale_dktzl = v; return 0; }
   if (s == "ale_density_pc_upper_bndr") { c->ale_density_pc_upper = v != 0; return 0; }
   if (s == "ale_density_pc_lower_bndr") { c->ale_density_pc_lower = v != 0; return 0; }
   if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; return 0; }

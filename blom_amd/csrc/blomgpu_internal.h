@@ -239,7 +239,9 @@ struct blomgpu_ctx {
   int ale_method = 102, ale_upper_bndr_ord = 6, ale_lower_bndr_ord = 4, ale_tracer_limiting = 203, ale_velocity_limiting = 203;
   bool ale_tracer_pc_upper = true, ale_tracer_pc_lower = false, ale_velocity_pc_upper = true, ale_velocity_pc_lower = false;
   bool ale_density_pc_upper = false, ale_density_pc_lower = false;
-  int ale_regrid_method = 2, ale_k_range_plevel = 1;      // 'nudge' is the reference's default (not built: set 'direct')
+  int ale_regrid_method = 2, ale_k_range_plevel = 1;      // 'nudge' is the reference's default
+  double ale_regrid_nudge_ts = 86400., ale_stab_fac_limit = .75, ale_dpvar_fac = .75, ale_smooth_diff_max = 50000.;   // :80-85
+  int ale_dktzu = 4, ale_dktzl = 2;
   double ale_dpmin_interior = .1 * 9806.;                 // [m] in the namelist, times onem (:1352-1353)
   void *ale = nullptr;
   double *ale_plevel = nullptr;

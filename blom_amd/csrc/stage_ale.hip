@@ -13,8 +13,12 @@
 // vcoord_type = 'cntiso_hybrid' with regrid_method = 'direct' (regrid_cntiso_hybrid_direct_jslice, :286-558): interfaces where
 // the monotonically reconstructed potential density takes the layers' target values, bounded by minimum thicknesses and blended
 // into the pressure levels towards the surface.
-// Not built yet: regrid_method = 'nudge' (:560-916) with its lateral smoothing (:946-1020), neutral diffusion (mod_ndiff), the
-// z-level diagnostics (remap_trc_diazlv_jslice) -- each fails loudly.
+// ... and with regrid_method = 'nudge', the reference's default (regrid_cntiso_hybrid_nudge_jslice, :560-916): the interfaces
+// move a fraction delt1 / regrid_nudge_ts of the way towards their target densities, with a transition zone of adjusted
+// targets (a quadratic Bezier curve, :680-728) below the pressure-level range, minimum thicknesses, a bound on the variation of
+// neighbouring layer thicknesses (:848-913), and lateral smoothing of the interfaces where the stratification is weak
+// (regrid_smooth_jslice, :946-1020).
+// Not built yet: neutral diffusion (mod_ndiff) and the z-level diagnostics (remap_trc_diazlv_jslice) -- each fails loudly.
 // Parity: cross-checked against the reference's REAL module compiled against a stand-in for mod_dia (oracle/Makefile
 // *_xale, tests/test_xcheck_ale.py) -- a cross-check, not a pin.
 #include "blomgpu_internal.h"
@@ -91,12 +95,12 @@ static int ale_prepare(blomgpu_ctx *c) {
 // source interfaces of the p-columns (:203-211) and their regridded positions for vcoord_type = 'plevel' (:263-284);
 // any other point of the plane: unit layers, left where they are
 __global__ void k_ale_p_src_dst(const DevView *__restrict__ Vp, int nn, const double *__restrict__ plevel, double *__restrict__ psrc,
-                                double *__restrict__ pdst) {
+                                double *__restrict__ pdst, int ring) {
   const DevView &V = *Vp;
   PLANE_T(V);
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const bool col = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && V.m[I_ip][c];
+  const bool col = j >= 1 - ring && j <= V.jj + ring && i >= 1 - ring && i <= V.ii + ring && V.m[I_ip][c];
   if (!col) {
     for (int k = 0; k <= kk; k++) { psrc[c + (size_t)k * np] = (double)k; pdst[c + (size_t)k * np] = (double)k; }
     return;
@@ -319,6 +323,294 @@ __global__ void k_ale_direct_post(const DevView *__restrict__ Vp, const double *
 #undef P
 }
 
+// ---- vcoord_type = 'cntiso_hybrid', regrid_method = 'nudge': regrid_cntiso_hybrid_nudge_jslice, :560-916 -----------------------
+struct NudgePar {
+  double nudge_fac, stab_fac_limit, dpvar_fac, dpmin_interior;
+  int k_range_plevel, dktzu, dktzl, ring;      // ring = 1: also the columns one ring beyond the tile (lateral smoothing follows)
+};
+__device__ inline double dsigdt_(const Params &P, double th, double s) {               // phy/mod_eos.F90:243-261
+  const double r1 = P.ap11 + (P.ap12 + P.ap14 * th + P.ap15 * s) * th + (P.ap13 + P.ap16 * s) * s;
+  const double r2i = 1. / (P.ap21 + (P.ap22 + P.ap24 * th + P.ap25 * s) * th + (P.ap23 + P.ap26 * s) * s);
+  return (P.ap12 + 2. * P.ap14 * th + P.ap15 * s - (P.ap22 + 2. * P.ap24 * th + P.ap25 * s) * r1 * r2i) * r2i;
+}
+__device__ inline double dsigds_(const Params &P, double th, double s) {               // :306-323
+  const double r1 = P.ap11 + (P.ap12 + P.ap14 * th + P.ap15 * s) * th + (P.ap13 + P.ap16 * s) * s;
+  const double r2i = 1. / (P.ap21 + (P.ap22 + P.ap24 * th + P.ap25 * s) * th + (P.ap23 + P.ap26 * s) * s);
+  return (P.ap13 + P.ap15 * th + 2. * P.ap16 * s - (P.ap23 + P.ap25 * th + 2. * P.ap26 * s) * r1 * r2i) * r2i;
+}
+
+// work planes (1-based level accessors below): sd1, sd2 = sig_srcdi(1,:), (2,:); sgt = sig_trg; dsg = dsig_trg; spm = sig_pmin;
+// dpm = dpmin; sfac = smooth_fac
+__global__ void k_ale_nudge(const DevView *__restrict__ Vp, NudgePar Q, const double *__restrict__ psrc, const double *__restrict__ pcT,
+                            const double *__restrict__ pcS, int npc, const double *__restrict__ plevel, double *__restrict__ sd1,
+                            double *__restrict__ sd2, double *__restrict__ sgt, double *__restrict__ dsg, double *__restrict__ spm,
+                            double *__restrict__ dpm, double *__restrict__ pdst, double *__restrict__ sfac) {
+  const DevView &V = *Vp;
+  PLANE_T(V);
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const bool col = j >= 1 - Q.ring && j <= V.jj + Q.ring && i >= 1 - Q.ring && i <= V.ii + Q.ring && V.m[I_ip][c];
+  if (!col) {
+    for (int k = 1; k <= kk + 1; k++) { PL(pdst, k) = PL(psrc, k); PL(sfac, k) = 0.; }
+    return;
+  }
+  auto pc_at = [&](const double *pc, int k, int q) { return q < npc ? pc[c + (size_t)(npc * (k - 1) + q) * np] : 0.; };
+  auto top = [&](const double *pc, int k) { return pc_at(pc, k, 0); };                               // peval0
+  auto bot = [&](const double *pc, int k) {                                                           // peval1
+    double f = pc_at(pc, k, 0);
+    for (int q = 1; q < 5; q++) f = f + pc_at(pc, k, q);
+    return f;
+  };
+  auto dtop = [&](const double *pc, int k) { return pc_at(pc, k, 1); };                              // dpeval0
+  auto dbot = [&](const double *pc, int k) {                                                          // dpeval1
+    return pc_at(pc, k, 1) + 2. * pc_at(pc, k, 2) + 3. * pc_at(pc, k, 3) + 4. * pc_at(pc, k, 4);
+  };
+#define P(k) PL(psrc, k)
+#define D(k) PL(pdst, k)
+#define SD1(k) PL(sd1, k)
+#define SD2(k) PL(sd2, k)
+#define ST(k) PL(sgt, k)
+#define DS(k) PL(dsg, k)
+#define SP(k) PL(spm, k)
+#define DM(k) PL(dpm, k)
+#define SF(k) PL(sfac, k)
+#define LEV(q) plevel[(q)-1]
+  const double dpmin_interior = Q.dpmin_interior, nudge_fac = Q.nudge_fac, stab_fac_limit = Q.stab_fac_limit;
+  int ksmx = kk;                                                                     // :213-217
+  for (int k = kk; k >= 1; k--)
+    if (P(k) == P(kk + 1)) ksmx = k - 1;
+  double sig_max = 0.;                                                                // :591-605
+  double *sigint = V.f[F_sigint];
+  for (int k = 1; k <= ksmx; k++) {
+    SD1(k) = eos::sig(V.P, top(pcT, k), top(pcS, k));
+    SD2(k) = eos::sig(V.P, bot(pcT, k), bot(pcS, k));
+    sig_max = fmax2(sig_max, SD2(k));
+  }
+  PL(sigint, 1) = SD1(1);
+  for (int k = 2; k <= ksmx; k++) PL(sigint, k) = .5 * (SD2(k - 1) + SD1(k));
+  for (int k = ksmx + 1; k <= kk; k++) PL(sigint, k) = SD2(ksmx);
+  const double *sigmar = V.f[F_sigmar];
+  for (int k = 1; k <= kk; k++) ST(k) = PL(sigmar, k);                                // :608-615
+  ST(kk + 1) = ST(kk);
+  for (int k = 1; k <= kk - 1; k++) DS(k) = ST(k + 1) - PL(sigmar, k);
+  DS(kk) = DS(kk - 1);
+  int kdmx;                                                                           // :620-623
+  {
+    int k = kk;
+    for (; k >= 1; k--)
+      if (ST(k) < sig_max) break;
+    kdmx = k > 1 ? k : 1;
+  }
+  const double p1 = P(1), pb = P(kk + 1);
+#define PMIN(k) fmin2(LEV(k) + p1, pb)
+  int kl = 1;                                                                         // :635-652
+  SP(1) = SD1(1);
+  D(1) = PMIN(1);
+  SF(1) = 1.;
+  for (int k = 2; k <= Q.k_range_plevel; k++) {
+    while (P(kl + 1) < PMIN(k)) kl = kl + 1;
+    SP(k) = ((P(kl + 1) - PMIN(k)) * SD1(kl) + (PMIN(k) - P(kl)) * SD2(kl)) / (P(kl + 1) - P(kl));
+    D(k) = P(k) + nudge_fac * (PMIN(k) - P(k));
+    D(k) = fmin2(fmax2(fmax2(D(k), PMIN(k)), D(k - 1) + dpmin_interior), pb);
+    SF(k) = 1.;
+  }
+  int kt = Q.k_range_plevel + 1;                                                       // :661-738
+  while (kt <= kdmx) {
+    while (P(kl + 1) < PMIN(kt)) kl = kl + 1;
+    SP(kt) = ((P(kl + 1) - PMIN(kt)) * SD1(kl) + (PMIN(kt) - P(kl)) * SD2(kl)) / (P(kl + 1) - P(kl));
+    if (ST(kt) > SP(kt)) {
+      int ktzmin = kt - Q.dktzu;
+      if (ktzmin < Q.k_range_plevel + 2) ktzmin = Q.k_range_plevel + 2;
+      int ktzmax = kt + Q.dktzl;
+      if (ktzmax > kk - 1) ktzmax = kk - 1;
+      if (ktzmin < kt && ktzmax - ktzmin > 1) {
+        const double ckt = (ST(kt) - SP(kt)) / (ST(kt) - ST(kt - 1) - SP(kt) + SP(kt - 1));
+        const double sig_up = SP(ktzmin - 1) * ckt + SP(ktzmin) * (1. - ckt);
+        const double sig_lo = ST(ktzmax - 1) * ckt + ST(ktzmax) * (1. - ckt);
+        const double dk = (double)(ktzmax - ktzmin), dki = 1. / dk;
+        double dsigdx_up = .5 * ((SP(ktzmin) - SP(ktzmin - 2)) * ckt + (SP(ktzmin + 1) - SP(ktzmin - 1)) * (1. - ckt)) * dk;
+        const double dsigdx_lo = .5 * ((ST(ktzmax) - ST(ktzmax - 2)) * ckt + (ST(ktzmax + 1) - ST(ktzmax - 1)) * (1. - ckt)) * dk;
+        dsigdx_up = fmax2(0., dsigdx_up);
+        if (dsigdx_lo <= dsigdx_up || sig_up - sig_lo <= -dsigdx_lo || sig_up - sig_lo >= -dsigdx_up) {
+          for (int k = ktzmin; k <= ktzmax - 1; k++) {
+            const double x = ((double)(k - ktzmin) + ckt) * dki;
+            ST(k) = sig_up * (1. - x) + sig_lo * x;
+          }
+        } else {
+          const double xi = (sig_up - sig_lo + dsigdx_lo) / (dsigdx_lo - dsigdx_up);
+          const double si = (dsigdx_lo * (sig_up + dsigdx_up) - dsigdx_up * sig_lo) / (dsigdx_lo - dsigdx_up);
+          if (fabs(xi - .5) < 1.e-14) {
+            for (int k = ktzmin; k <= ktzmax - 1; k++) {
+              const double t = ((double)(k - ktzmin) + ckt) * dki;
+              ST(k) = (1. - t) * ((1. - t) * sig_up + 2. * t * si) + t * t * sig_lo;
+            }
+          } else {
+            for (int k = ktzmin; k <= ktzmax - 1; k++) {
+              const double x = ((double)(k - ktzmin) + ckt) * dki;
+              const double t = (sqrt(xi * (xi - 2. * x) + x) - xi) / (1. - 2. * xi);
+              ST(k) = (1. - t) * ((1. - t) * sig_up + 2. * t * si) + t * t * sig_lo;
+            }
+          }
+        }
+        kt = ktzmin;
+      }
+      break;
+    }
+    D(kt) = P(kt) + nudge_fac * (PMIN(kt) - P(kt));
+    D(kt) = fmin2(fmax2(fmax2(D(kt), PMIN(kt)), D(kt - 1) + dpmin_interior), pb);
+    SF(kt) = 1.;
+    kt = kt + 1;
+  }
+  for (int k = kt; k <= kk + 1; k++) { D(k) = pb; SF(k) = 0.; }                        // :744-747
+  const int kend = ksmx < kdmx ? ksmx : kdmx;
+  for (int k = kt; k <= kend; k++) {                                                  // :749-818
+    double stab_fac;
+    const double tu = bot(pcT, k - 1), su = bot(pcS, k - 1), tl = top(pcT, k), sl = top(pcS, k);
+    if (ST(k) < SD2(k - 1) && ST(k) < SD1(k)) {
+      const double dsig = ST(k) - SD2(k - 1);
+      double dsigdx = dsigdt_(V.P, tu, su) * dbot(pcT, k - 1) + dsigds_(V.P, tu, su) * dbot(pcS, k - 1);
+      stab_fac = dsigdx / DS(k - 1);
+      dsigdx = DS(k - 1) * fmax2(stab_fac, stab_fac_limit);
+      D(k) = P(k) + fmax2(-.5, dsig * nudge_fac / dsigdx) * (P(k) - P(k - 1));
+    } else if (ST(k) > SD2(k - 1) && ST(k) > SD1(k)) {
+      const double dsig = ST(k) - SD1(k);
+      double dsigdx = dsigdt_(V.P, tl, sl) * dtop(pcT, k) + dsigds_(V.P, tl, sl) * dtop(pcS, k);
+      stab_fac = dsigdx / DS(k);
+      dsigdx = DS(k) * fmax2(stab_fac, stab_fac_limit);
+      D(k) = P(k) + fmin2(.5, dsig * nudge_fac / dsigdx) * (P(k + 1) - P(k));
+    } else {
+      const double dsigdx_up = dsigdt_(V.P, tu, su) * dbot(pcT, k - 1) + dsigds_(V.P, tu, su) * dbot(pcS, k - 1);
+      const double dsigdx_lo = dsigdt_(V.P, tl, sl) * dtop(pcT, k) + dsigds_(V.P, tl, sl) * dtop(pcS, k);
+      const double dp_up = fmax2(P(k) - P(k - 1), ALE_EPSILP), dp_lo = fmax2(P(k + 1) - P(k), ALE_EPSILP);
+      double sig_intrp = ((SD1(k) + .5 * dsigdx_lo) * dp_up + (SD2(k - 1) - .5 * dsigdx_up) * dp_lo) / (dp_up + dp_lo);
+      sig_intrp = fmax2(fmin2(SD2(k - 1), SD1(k)), fmin2(fmax2(SD2(k - 1), SD1(k)), sig_intrp));
+      const double dsig = ST(k) - sig_intrp;
+      if (dsig < 0.) {
+        double dsigdx = dsigdx_up + 2. * (sig_intrp - SD2(k - 1));
+        stab_fac = dsigdx / DS(k - 1);
+        dsigdx = DS(k - 1) * fmax2(stab_fac, stab_fac_limit);
+        D(k) = P(k) + fmax2(-.5, dsig * nudge_fac / dsigdx) * (P(k) - P(k - 1));
+      } else {
+        double dsigdx = dsigdx_lo + 2. * (SD1(k) - sig_intrp);
+        stab_fac = dsigdx / DS(k);
+        dsigdx = DS(k) * fmax2(stab_fac, stab_fac_limit);
+        D(k) = P(k) + fmin2(.5, dsig * nudge_fac / dsigdx) * (P(k + 1) - P(k));
+      }
+    }
+    D(k) = fmin2(fmax2(fmax2(D(k), PMIN(k)), D(k - 1) + dpmin_interior), pb);
+    SF(k) = fmax2(0., fmin2(1., (stab_fac_limit - stab_fac) / stab_fac_limit));
+  }
+  for (int k = (kt > kend ? kt : kend) + 1; k <= kdmx; k++) {                           // :820-841
+    if (ST(k) < SD2(ksmx)) {
+      const double tb = bot(pcT, ksmx), sb = bot(pcS, ksmx);
+      const double dsig = ST(k) - SD2(ksmx);
+      double dsigdx = dsigdt_(V.P, tb, sb) * dbot(pcT, ksmx) + dsigds_(V.P, tb, sb) * dbot(pcS, ksmx);
+      const double stab_fac = dsigdx / DS(ksmx - 1);
+      dsigdx = DS(ksmx - 1) * fmax2(stab_fac, stab_fac_limit);
+      D(k) = pb + fmax2(-.5, dsig * nudge_fac / dsigdx) * (pb - P(ksmx));
+      D(k) = fmin2(fmax2(fmax2(D(k), PMIN(k)), D(k - 1) + dpmin_interior), pb);
+      SF(k) = fmax2(0., fmin2(1., (stab_fac_limit - stab_fac) / stab_fac_limit));
+    }
+  }
+  // limit the local variation of the layer thicknesses, :848-913
+  int ks = kt, ke = kk;
+  for (int k = kk; k >= 1; k--)
+    if (D(k) == D(kk + 1)) ke = k - 1;
+  for (int k = ks; k <= ke - 1; k++)
+    DM(k) = fmin2(2. * D(ke + 1) - D(k + 1) - D(k), fmax2(dpmin_interior, Q.dpvar_fac * (D(k + 2) - D(k - 1)) / 3.));
+  int k = ks;
+  while (k < ke) {
+    if (D(k + 1) - D(k) < DM(k)) {
+      int ku = k;
+      kl = k + 1;
+      double dpmin_sum = DM(ku), dp_sum = D(k + 1) - D(k);
+      bool added = true;
+      while (added) {
+        added = false;
+        if (kl + 1 < ke) {
+          const double a = dpmin_sum + DM(kl), b = dp_sum + D(kl + 1) - D(kl);
+          if (a > b) { dpmin_sum = a; dp_sum = b; kl = kl + 1; added = true; }
+        }
+        if (ku > ks) {
+          const double a = dpmin_sum + DM(ku - 1), b = dp_sum + D(ku) - D(ku - 1);
+          if (a > b) { dpmin_sum = a; dp_sum = b; ku = ku - 1; added = true; }
+        }
+      }
+      if (ku == ks) {
+        for (int q = ks; q <= kl - 1; q++) D(q + 1) = fmin2(D(ke + 1), D(q) + DM(q));
+        for (int q = kl; q <= ke - 1; q++) D(q + 1) = fmax2(D(q + 1), D(q));
+        ks = kl - 1;
+        k = ks;
+      } else {
+        const double dp_up = D(ku) - D(ku - 1), dp_lo = D(kl + 1) - D(kl);
+        D(ku) = fmax2(D(ku - 1), D(ku) - (dpmin_sum - dp_sum) * dp_up / fmax2(ALE_EPSILP, dp_up + dp_lo));
+        for (int q = ku; q <= kl - 1; q++) D(q + 1) = fmin2(D(ke + 1), D(q) + DM(q));
+        k = kl;
+      }
+    }
+    k = k + 1;
+  }
+#undef PMIN
+#undef LEV
+#undef SF
+#undef DM
+#undef SP
+#undef DS
+#undef ST
+#undef SD2
+#undef SD1
+#undef D
+#undef P
+}
+
+// regrid_smooth_jslice, :946-1020: lateral smoothing of the regridded interfaces where the stratification is weak.  The
+// reference accumulates the flux convergence of a cell while it walks the faces of three rows at a time: for the cell (i,j) in
+// the order - u-face i, + u-face i+1, - v-face j, + v-face j+1 (faces that are no velocity points contribute nothing); all
+// fluxes are formed from the unsmoothed interfaces.  Here one thread per cell and interface gathers them in that order.
+__global__ void k_ale_smooth(const DevView *__restrict__ Vp, double smooth_diff_max, const double *__restrict__ pdst,
+                             const double *__restrict__ sfac, double *__restrict__ pout) {
+  const DevView &V = *Vp;
+  PLANE_T(V);
+  const size_t np = V.nplane;
+  const int kk = V.kk, ni = V.ni;
+  const int k = blockIdx.y + 1;                                  // interface 1..kk+1
+  double v = pdst[c + (size_t)(k - 1) * np];
+  const bool cell = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && V.m[I_ip][c];
+  if (cell && k >= 2 && k <= kk) {
+    const double delt1 = V.P.delt1;
+    const double *scp2 = V.f[F_scp2], *difmxp = V.f[F_difmxp];
+#define D(x, q) pdst[(x) + (size_t)((q)-1) * np]
+#define SFC(x, q) sfac[(x) + (size_t)((q)-1) * np]
+    auto uflux = [&](size_t cc) {                                // u-face between cc-1 and cc, :962-984
+      const size_t w = cc - 1;
+      const double cdiff = delt1 * V.f[F_scuy][cc] * V.f[F_scuxi][cc];
+      const double difmx = .5 * (difmxp[w] + difmxp[cc]);
+      const double flxhi = .125 * fmin2((D(w, k) - D(w, k - 1)) * scp2[w], (D(cc, k + 1) - D(cc, k)) * scp2[cc]);
+      const double flxlo = -.125 * fmin2((D(cc, k) - D(cc, k - 1)) * scp2[cc], (D(w, k + 1) - D(w, k)) * scp2[w]);
+      const double sdiff = fmin2(.5 * (SFC(w, k) + SFC(cc, k)) * smooth_diff_max, difmx);
+      return fmin2(flxhi, fmax2(flxlo, cdiff * sdiff * (D(w, k) - D(cc, k))));
+    };
+    auto vflux = [&](size_t cc) {                                // v-face between cc-ni and cc, :986-1008
+      const size_t sdn = cc - ni;
+      const double cdiff = delt1 * V.f[F_scvx][cc] * V.f[F_scvyi][cc];
+      const double difmx = .5 * (difmxp[sdn] + difmxp[cc]);
+      const double flxhi = .125 * fmin2((D(sdn, k) - D(sdn, k - 1)) * scp2[sdn], (D(cc, k + 1) - D(cc, k)) * scp2[cc]);
+      const double flxlo = -.125 * fmin2((D(cc, k) - D(cc, k - 1)) * scp2[cc], (D(sdn, k + 1) - D(sdn, k)) * scp2[sdn]);
+      const double sdiff = fmin2(.5 * (SFC(sdn, k) + SFC(cc, k)) * smooth_diff_max, difmx);
+      return fmin2(flxhi, fmax2(flxlo, cdiff * sdiff * (D(sdn, k) - D(cc, k))));
+    };
+    double conv = 0.;
+    if (V.m[I_iu][c]) conv = conv - uflux(c);
+    if (V.m[I_iu][c + 1]) conv = conv + uflux(c + 1);
+    if (V.m[I_iv][c]) conv = conv - vflux(c);
+    if (V.m[I_iv][c + ni]) conv = conv + vflux(c + ni);
+    v = v - conv * V.f[F_scp2i][c];
+#undef SFC
+#undef D
+  }
+  pout[c + (size_t)(k - 1) * np] = v;
+}
+
 // copy_jslice_to_3d (:1153-1179) for up to H3M_MAXF remapped fields starting with field f0 of (T, S, tracer 1, ..)
 __global__ void k_ale_copy_back(const DevView *__restrict__ Vp, int nn, const double *__restrict__ pdst, const double *__restrict__ rm,
                                 int f0, int nf) {
@@ -401,9 +693,6 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   (void)m; (void)n; (void)mm; (void)k1m;
   const DevView &h = c->h;
   if (h.P.vcoord_tag == 1) return ctx_fail(c, "ale_regrid_remap: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:138-149)");
-  if (h.P.vcoord_tag == 2 && c->ale_regrid_method != 1)
-    return ctx_fail(c, "ale_regrid_remap: vcoord_type = 'cntiso_hybrid' is built with regrid_method = 'direct' only ('nudge' and its "
-                       "lateral smoothing, phy/mod_ale_regrid_remap.F90:560-1020, are not)");
   if (h.P.vcoord_tag != 2 && h.P.vcoord_tag != 3) return ctx_fail(c, "ale_regrid_remap: unknown vertical coordinate");
   if (h.P.ltedtp_opt != 1) return ctx_fail(c, "ale_regrid_remap: neutral diffusion (ltedtp = 'neutral', phy/mod_ndiff.F90) is not built");
   if (!c->ale_plevel) return ctx_fail(c, "ale_regrid_remap: the pressure levels are not set (blomgpu_set_vector \"plevel\", phy/mod_vcoord.F90:99)");
@@ -415,7 +704,14 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   const dim3 g1((unsigned)((np + 255) / 256)), gk((unsigned)((np + 255) / 256), h.kk), b(256);
   int rc;
   // ---- tracers ----------------------------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(k_ale_p_src_dst, g1, b, 0, c->stream, c->d, nn, (const double *)c->ale_plevel, psrc, pdst);
+  const bool nudge = h.P.vcoord_tag == 2 && c->ale_regrid_method == 2;
+  const int ring = nudge && c->ale_smooth_diff_max > 0. ? 1 : 0;      // lateral smoothing reads the neighbours' regridded columns
+  if (ring) {                                                          // :1603-1607
+    if (int rc2 = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
+    if (int rc2 = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
+    if (int rc2 = st_xctilr(c, h.f[F_sigma] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
+  }
+  hipLaunchKernelGGL(k_ale_p_src_dst, g1, b, 0, c->stream, c->d, nn, (const double *)c->ale_plevel, psrc, pdst, ring);
   if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid, psrc))) return ale_fail(c, "prepare_reconstruction", rc);
   if (h.P.vcoord_tag == 2) {
     // regrid_cntiso_hybrid_direct_jslice: the interfaces go where the reconstructed potential density takes its target values
@@ -426,12 +722,29 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     if ((rc = blomgpu_h3m_extract_polycoeff(a->trc[0], pcT))) return ale_fail(c, "extract_polycoeff", rc);
     if ((rc = blomgpu_h3m_extract_polycoeff(a->trc[1], pcS))) return ale_fail(c, "extract_polycoeff", rc);
     const int npc = c->ale_method == BLOMGPU_H3M_PLM ? 2 : (c->ale_method == BLOMGPU_H3M_PPM ? 3 : 5);
+    if (nudge) {
+      // regrid_cntiso_hybrid_nudge_jslice; its work arrays lie where the remapped fields will (nothing has been remapped yet)
+      double *sd1 = rm, *sd2 = rm + per, *dsg = rm + 2 * per, *dpm = rm + 3 * per, *spm = rm + 4 * per, *sfac = rm + 6 * per;
+      NudgePar Q;
+      Q.nudge_fac = h.P.delt1 / c->ale_regrid_nudge_ts;                                       // :632
+      Q.stab_fac_limit = c->ale_stab_fac_limit; Q.dpvar_fac = c->ale_dpvar_fac; Q.dpmin_interior = c->ale_dpmin_interior;
+      Q.k_range_plevel = c->ale_k_range_plevel; Q.dktzu = c->ale_dktzu; Q.dktzl = c->ale_dktzl; Q.ring = ring;
+      hipLaunchKernelGGL(k_ale_nudge, g1, b, 0, c->stream, c->d, Q, (const double *)psrc, (const double *)pcT, (const double *)pcS, npc,
+                         (const double *)c->ale_plevel, sd1, sd2, sgt, dsg, spm, dpm, pdst, sfac);
+      if (ring) {                                                                             // regrid_smooth_jslice
+        double *pout = sgs;                               // kk+1 planes: sgs and the first plane of sgt, both free again
+        hipLaunchKernelGGL(k_ale_smooth, dim3((unsigned)((np + 255) / 256), h.kk + 1), b, 0, c->stream, c->d, c->ale_smooth_diff_max,
+                           (const double *)pdst, (const double *)sfac, pout);
+        HIPCHK(c, hipMemcpyAsync(pdst, pout, sizeof(double) * (size_t)(h.kk + 1) * np, hipMemcpyDeviceToDevice, c->stream));
+      }
+    } else {
     hipLaunchKernelGGL(k_ale_direct_pre, g1, b, 0, c->stream, c->d, nn, (const double *)psrc, (const double *)pcT, (const double *)pcS,
                        npc, sgs, sgt);
     if ((rc = blomgpu_h3m_reconstruct(a->grid, a->dens, sgs))) return ale_fail(c, "reconstruct (density)", rc);
     if ((rc = blomgpu_h3m_regrid(a->dens, h.kk + 1, sgt, pdst, -1.e33, 0))) return ale_fail(c, "regrid", rc);
     hipLaunchKernelGGL(k_ale_direct_post, g1, b, 0, c->stream, c->d, (const double *)psrc, (const double *)sgs, (const double *)sgt,
                        (const double *)c->ale_plevel, c->ale_dpmin_interior, c->ale_k_range_plevel, pdst);
+    }
   }
   if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping", rc);
   for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {

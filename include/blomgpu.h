@@ -122,9 +122,12 @@ int  blomgpu_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
 /* phy/mod_ale_regrid_remap.F90:1486 ale_regrid_remap(m,n,mm,nn,k1m,k1n): regrid the layer interfaces and remap T, S, tracers, u, v
- * (first piece: vcoord_type = 'plevel'; other coordinates fail loudly).  Options: blomgpu_set_str "vcoord_type",
- * "ale_reconstruction_method", "ale_tracer_limiting", "ale_velocity_limiting"; blomgpu_set_int "ale_upper_bndr_ord",
- * "ale_lower_bndr_ord", "ale_{tracer,velocity}_pc_{upper,lower}_bndr" -- the variables of &ALE_REGRID_REMAP (:1193-1201). */
+ * (first piece: vcoord_type = 'plevel' and 'cntiso_hybrid' with regrid_method 'direct' or 'nudge'; neutral
+ * diffusion fails loudly).  Options: blomgpu_set_str "vcoord_type", "ale_reconstruction_method", "ale_regrid_method",
+ * "ale_tracer_limiting", "ale_velocity_limiting"; blomgpu_set_int "ale_upper_bndr_ord", "ale_lower_bndr_ord", "ale_k_range_plevel",
+ * "ale_dktzu", "ale_dktzl", "ale_{density,tracer,velocity}_pc_{upper,lower}_bndr"; blomgpu_set_real "ale_dpmin_interior" [m],
+ * "ale_regrid_nudge_ts", "ale_stab_fac_limit", "ale_dpvar_fac", "ale_smooth_diff_max" -- the variables of &ALE_REGRID_REMAP
+ * (:1193-1201) with the reference's defaults (:69-95). */
 int  blomgpu_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* 1-D module arrays: "plevel", the kdm pressure levels [g cm-1 s-2 as the model's p] of vcoord_type = 'plevel'
  * (phy/mod_vcoord.F90:99, :948-970) */

@@ -49,7 +49,7 @@ def _limits_text(o):
             f"  TRACER_LIMITING = '{o['tracer_limiting']}'\n  VELOCITY_LIMITING = '{o['velocity_limiting']}'\n"
             f"  TRACER_PC_UPPER_BNDR = {f(o['tracer_pc_upper_bndr'])}\n  TRACER_PC_LOWER_BNDR = {f(o['tracer_pc_lower_bndr'])}\n"
             f"  VELOCITY_PC_UPPER_BNDR = {f(o['velocity_pc_upper_bndr'])}\n  VELOCITY_PC_LOWER_BNDR = {f(o['velocity_pc_lower_bndr'])}\n"
-            "  REGRID_METHOD = 'direct'\n /\n")
+            f"  REGRID_METHOD = '{o.get('regrid_method', 'direct')}'\n /\n")
 
 
 @pytest.mark.parametrize("cfg,nsteps,spread,vcoord", [
@@ -57,16 +57,22 @@ def _limits_text(o):
     ("tri_s", 3, 1.0, "plevel"),
     # regrid_method = 'direct': the interfaces follow the layers' target densities
     ("fuk95", 3, 0.6, "cntiso_hybrid"), ("chan_s", 4, 0.5, "cntiso_hybrid"), ("chan_s", 2, 0.1, "cntiso_hybrid"),
-    ("box_s", 4, 0.8, "cntiso_hybrid"), ("tri_s", 3, 0.3, "cntiso_hybrid")])
+    ("box_s", 4, 0.8, "cntiso_hybrid"), ("tri_s", 3, 0.3, "cntiso_hybrid"),
+    # regrid_method = 'nudge' (the reference's default; libraries *_xaln), with the lateral smoothing of the interfaces
+    ("fuk95", 3, 0.6, "nudge"), ("chan_s", 4, 0.5, "nudge"), ("chan_s", 2, 0.1, "nudge"), ("box_s", 4, 0.8, "nudge"),
+    ("tri_s", 3, 0.3, "nudge"), ("fuk95", 3, 1.0, "nudge+plevel")])
 def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vcoord, tmp_path):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
-    if not have_ref(cfg + "_xale"):
-        pytest.skip(f"oracle/_ref/{cfg}_xale/libblomref.so not built")
-    o = OPTIONS[cfg]
+    method = "nudge" if vcoord.startswith("nudge") else "direct"
+    lib = cfg + ("_xaln" if method == "nudge" else "_xale")
+    vcoord = "plevel" if vcoord.endswith("plevel") else "cntiso_hybrid"
+    if not have_ref(lib):
+        pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
+    o = dict(OPTIONS[cfg], regrid_method=method)
     case = make_case(cfg)
-    ref = get_ref_backend(cfg + "_xale", case.depth)
+    ref = get_ref_backend(lib, case.depth)
     kk = case.kdm
     # device: the isopycnic sequence for a few steps
     gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
@@ -84,7 +90,7 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vco
     ref.ref.lib.ref_set_vec(b"plevel", v.ctypes.data_as(C.c_void_p), C.c_int(kk), C.byref(ierr))
     assert ierr.value == 0
     six = hostinit.step_indices(nsteps, kk)
-    if cfg not in _INITIALISED:
+    if lib not in _INITIALISED:
         ref.ref.set("vcoord_tag", 2)           # the reader resolves regrid_method only for 'cntiso_hybrid' (:1323)
         (tmp_path / "limits").write_text(_limits_text(o))
         cwd = os.getcwd()
@@ -93,14 +99,17 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vco
             ref.ref.stage("ale_init", *six)
         finally:
             os.chdir(cwd)
-        _INITIALISED.add(cfg)
+        _INITIALISED.add(lib)
     try:
         ref.ref.set("vcoord_tag", tag)
+        delt1 = 2.0 * case.params["baclin"]            # the nudging factor and the smoothing's diffusion read it
+        ref.ref.set("delt1", delt1)
+        gpu.set("delt1", delt1)
         pre_sigint = ref.get("sigint").copy()
         ref.ref.stage("ale_regrid_remap", *six)
         # device
         gpu.set("vcoord_type", vcoord)
-        gpu.set("ale_regrid_method", "direct")
+        gpu.set("ale_regrid_method", method)
         gpu.set("ale_reconstruction_method", o["reconstruction_method"])
         gpu.set("ale_tracer_limiting", o["tracer_limiting"])
         gpu.set("ale_velocity_limiting", o["velocity_limiting"])
@@ -136,9 +145,6 @@ def test_other_coordinates_fail_loudly():
     hostinit.init_state(gpu, case)
     six = hostinit.step_indices(0, case.kdm)
     with pytest.raises(BlomGpuError, match="isopyc_bulkml"):
-        gpu.stage("ale_regrid_remap", *six)
-    gpu.set("vcoord_type", "cntiso_hybrid")
-    with pytest.raises(BlomGpuError, match="nudge"):          # the reference's default regrid_method
         gpu.stage("ale_regrid_remap", *six)
     gpu.set("vcoord_type", "plevel")
     with pytest.raises(BlomGpuError, match="plevel"):
