@@ -518,6 +518,14 @@ int blomgpu_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k
   ctx_sync_view(c);
   return st_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
 }
+int blomgpu_ale_vdifft(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {   // phy/mod_ale_vdiff.F90:50
+  ctx_sync_view(c);
+  return st_ale_vdifft(c, m, n, mm, nn, k1m, k1n);
+}
+int blomgpu_ale_vdiffm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {   // phy/mod_ale_vdiff.F90:245
+  ctx_sync_view(c);
+  return st_ale_vdiffm(c, m, n, mm, nn, k1m, k1n);
+}
 // 1-D module arrays of the reference: "plevel" (kdm pressure levels of vcoord_type = 'plevel', phy/mod_vcoord.F90:99)
 int blomgpu_set_vector(blomgpu_ctx *c, const char *name, const double *v, int nv) {
   if (!c || !name || !v) return ctx_fail(c, "blomgpu_set_vector: null argument");
@@ -577,6 +585,8 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
+  if (s == "ale_vdifft") return blomgpu_ale_vdifft(c, m, n, mm, nn, k1m, k1n);
+  if (s == "ale_vdiffm") return blomgpu_ale_vdiffm(c, m, n, mm, nn, k1m, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);
 }
 

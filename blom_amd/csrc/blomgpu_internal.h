@@ -62,6 +62,12 @@
   X(utotm, 1) X(vtotm, 1) X(utotn, 1) X(vtotn, 1) X(uflux, 1) X(vflux, 1) X(uflux2, 1)   \
   X(vflux2, 1) X(uflux3, 1) X(vflux3, 1) X(umax, 1) X(vmax, 1) X(util1, 1) X(util2, 1)   \
   X(util3, 1) X(util4, 1) X(taux, 1) X(tauy, 1) X(ustarb, 1)                             \
+  /* ale_vdifft / ale_vdiffm (mod_ale_vdiff.F90): vertical diffusivities and non-local transport fractions at the layer     \
+     interfaces (mod_diffusion.F90:131-139, mod_forcing.F90:181-191), surface fluxes (mod_forcing.F90:159-164), the salt and  \
+     tracer corrections (:177-179), the tracers' surface fluxes (mod_tracers.F90:60; here one plane per tracer) */            \
+  X(kvisc_m, K + 1) X(kdiff_t, K + 1) X(kdiff_s, K + 1) X(t_ns_nonloc, K + 1) X(s_nb_nonloc, K + 1) X(t_sw_nonloc, K + 1)    \
+  X(t_rs_nonloc, K + 1) X(s_br_nonloc, K + 1) X(s_rs_nonloc, K + 1) X(surflx, 1) X(sswflx, 1) X(surrlx, 1) X(salflx, 1)     \
+  X(brnflx, 1) X(salrlx, 1) X(salt_corr, 1) X(trc_corr, NT) X(trflx, NT)                                                    \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
@@ -326,6 +332,8 @@ int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 #define R_T(ntr) (R_BASE(ntr) + 1)
 #define R_S(ntr) (R_BASE(ntr) + 2)
 #define R_TR(ntr, nt) (R_BASE(ntr) + 3 + (nt))
+int st_ale_vdifft(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);          // stage_ale_vdiff.hip
+int st_ale_vdiffm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_ale.hip
 void ale_free(blomgpu_ctx *);
 int launch_dpudpv(blomgpu_ctx *, int off, int flags);                                        // stage_simple.hip

@@ -129,6 +129,11 @@ int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
  * "ale_regrid_nudge_ts", "ale_stab_fac_limit", "ale_dpvar_fac", "ale_smooth_diff_max" -- the variables of &ALE_REGRID_REMAP
  * (:1193-1201) with the reference's defaults (:69-95). */
 int  blomgpu_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+/* phy/mod_ale_vdiff.F90:50 ale_vdifft, :245 ale_vdiffm: implicit vertical diffusion of T, S, tracers (with the surface fluxes and
+ * their non-local transport) and of u, v.  Inputs by name: kdiff_t, kdiff_s, kvisc_m, t_{ns,sw,rs}_nonloc, s_{nb,br,rs}_nonloc
+ * (kdm+1 levels), surflx, sswflx, surrlx, salflx, brnflx, salrlx, trflx (ntr planes); salt_corr, trc_corr accumulate. */
+int  blomgpu_ale_vdifft(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int  blomgpu_ale_vdiffm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* 1-D module arrays: "plevel", the kdm pressure levels [g cm-1 s-2 as the model's p] of vcoord_type = 'plevel'
  * (phy/mod_vcoord.F90:99, :948-970) */
 int  blomgpu_set_vector(blomgpu_ctx *, const char *name, const double *v, int nv);

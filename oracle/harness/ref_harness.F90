@@ -49,6 +49,10 @@ module ref_harness
   use mod_eddtra,    only: eddtra
   use mod_cmnfld_routines, only: cmnfld1, cmnfld2
 #endif
+#ifdef WITH_ALE_VDIFF
+  ! builds *_vdf: the reference's phy/mod_ale_vdiff.F90 (no stand-in involved: a pin)
+  use mod_ale_vdiff, only: ale_vdifft, ale_vdiffm
+#endif
 #ifdef XCHECK_ALE
   ! cross-check builds only (oracle/Makefile *_xale): the reference's real mod_ale_regrid_remap against the mod_dia stand-in
   use mod_ale_regrid_remap, only: readnml_ale_regrid_remap, init_ale_regrid_remap, ale_regrid_remap
@@ -59,6 +63,8 @@ module ref_harness
 
   implicit none
   private
+  real(8), allocatable, target, save :: trflx_ij(:,:,:)
+  integer :: nt_
 
   interface
     subroutine ref_capture_r8(a, out) bind(C, name='ref_capture_r8')
@@ -447,6 +453,39 @@ contains
         if (allocated(trcold)) then
           call ref_capture_r8(trcold, ptr); nlev = kdm*ntr
         end if
+      ! inputs and accumulators of ale_vdifft / ale_vdiffm (mod_diffusion.F90:131-139, mod_forcing.F90:159-191)
+      case ('kvisc_m'); call ref_capture_r8(Kvisc_m, ptr); nlev = kdm+1
+      case ('kdiff_t'); call ref_capture_r8(Kdiff_t, ptr); nlev = kdm+1
+      case ('kdiff_s'); call ref_capture_r8(Kdiff_s, ptr); nlev = kdm+1
+      R3(t_ns_nonloc, kdm+1)
+      R3(s_nb_nonloc, kdm+1)
+      R3(t_sw_nonloc, kdm+1)
+      R3(t_rs_nonloc, kdm+1)
+      R3(s_br_nonloc, kdm+1)
+      R3(s_rs_nonloc, kdm+1)
+      R2(surflx)
+      R2(sswflx)
+      R2(surrlx)
+      R2(salflx)
+      R2(brnflx)
+      R2(salrlx)
+      R2(salt_corr)
+      case ('trc_corr')
+        if (allocated(trc_corr)) then
+          call ref_capture_r8(trc_corr, ptr); nlev = ntr
+        end if
+      ! trflx(ntr,i,j) has the tracer index first: it is shown as trflx_ij(i,j,ntr) and copied across around ale_vdifft
+      case ('trflx')
+        if (allocated(trflx)) then
+          if (.not. allocated(trflx_ij)) allocate(trflx_ij(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,ntr))
+          if (size(trflx_ij,3) /= ntr) then
+            deallocate(trflx_ij); allocate(trflx_ij(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,ntr))
+          end if
+          do nt_ = 1, ntr
+            trflx_ij(:,:,nt_) = trflx(nt_,:,:)
+          end do
+          call ref_capture_r8(trflx_ij, ptr); nlev = ntr
+        end if
       case default
         nlev = 0
     end select
@@ -477,6 +516,16 @@ contains
       case ('eddtra');  call eddtra(m,n,mm,nn,k1m,k1n)
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
+#endif
+#ifdef WITH_ALE_VDIFF
+      case ('ale_vdifft')
+        if (allocated(trflx_ij)) then
+          do nt_ = 1, ntr
+            trflx(nt_,:,:) = trflx_ij(:,:,nt_)
+          end do
+        end if
+        call ale_vdifft(m,n,mm,nn,k1m,k1n)
+      case ('ale_vdiffm'); call ale_vdiffm(m,n,mm,nn,k1m,k1n)
 #endif
 #ifdef XCHECK_ALE
       ! ale_init: the group &ALE_REGRID_REMAP of the file `limits` in the working directory, then the reconstruction and
