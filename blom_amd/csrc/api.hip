@@ -211,6 +211,8 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   R(wuv1) R(wuv2) R(wts1) R(wts2) R(wbaro) R(bdmc1) R(bdmc2) R(iwdfac) R(nubmin) R(vland)
 #undef R
   if (s == "pref") { P.pref = v; set_eos(P); c->dirty = true; return 0; }
+  if (s == "swamxd") { c->swamxd = v; return 0; }                           // phy/mod_swabs.F90:179-183
+  if (s == "brine_mlbase_frac") { c->brine_mlbase_frac = v; return 0; }     // phy/mod_forcing.F90:63
   if (s == "ale_regrid_nudge_ts") { c->ale_regrid_nudge_ts = v; return 0; }
   if (s == "ale_stab_fac_limit") { c->ale_stab_fac_limit = v; return 0; }
   if (s == "ale_dpvar_fac") { c->ale_dpvar_fac = v; return 0; }
@@ -518,6 +520,10 @@ int blomgpu_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k
   ctx_sync_view(c);
   return st_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
 }
+int blomgpu_ale_forcing(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {  // phy/mod_ale_forcing.F90:45
+  ctx_sync_view(c);
+  return st_ale_forcing(c, m, n, mm, nn, k1m, k1n);
+}
 int blomgpu_ale_vdifft(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {   // phy/mod_ale_vdiff.F90:50
   ctx_sync_view(c);
   return st_ale_vdifft(c, m, n, mm, nn, k1m, k1n);
@@ -585,6 +591,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
+  if (s == "ale_forcing") return blomgpu_ale_forcing(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_vdifft") return blomgpu_ale_vdifft(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_vdiffm") return blomgpu_ale_vdiffm(c, m, n, mm, nn, k1m, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);

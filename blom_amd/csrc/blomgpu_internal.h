@@ -68,6 +68,9 @@
   X(kvisc_m, K + 1) X(kdiff_t, K + 1) X(kdiff_s, K + 1) X(t_ns_nonloc, K + 1) X(s_nb_nonloc, K + 1) X(t_sw_nonloc, K + 1)    \
   X(t_rs_nonloc, K + 1) X(s_br_nonloc, K + 1) X(s_rs_nonloc, K + 1) X(surflx, 1) X(sswflx, 1) X(surrlx, 1) X(salflx, 1)     \
   X(brnflx, 1) X(salrlx, 1) X(salt_corr, 1) X(trc_corr, NT) X(trflx, NT)                                                    \
+  /* ale_forcing (mod_ale_forcing.F90): the two-band shortwave absorption of mod_swabs, the mixed layer depth of mod_cmnfld    \
+     [m], the interface buoyancy flux (mod_forcing.F90:183) */                                                                \
+  X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(buoyfl, K + 1)                                                 \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
@@ -249,6 +252,7 @@ struct blomgpu_ctx {
   double ale_regrid_nudge_ts = 86400., ale_stab_fac_limit = .75, ale_dpvar_fac = .75, ale_smooth_diff_max = 50000.;   // :80-85
   int ale_dktzu = 4, ale_dktzl = 2;
   double ale_dpmin_interior = .1 * 9806.;                 // [m] in the namelist, times onem (:1352-1353)
+  double swamxd = 200., brine_mlbase_frac = 0.;           // phy/mod_swabs.F90:183 (default); phy/mod_forcing.F90:63 (namelist)
   void *ale = nullptr;
   double *ale_plevel = nullptr;
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
@@ -334,6 +338,7 @@ int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 #define R_TR(ntr, nt) (R_BASE(ntr) + 3 + (nt))
 int st_ale_vdifft(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);          // stage_ale_vdiff.hip
 int st_ale_vdiffm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_ale_forcing(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);         // stage_ale_vdiff.hip
 int st_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_ale.hip
 void ale_free(blomgpu_ctx *);
 int launch_dpudpv(blomgpu_ctx *, int off, int flags);                                        // stage_simple.hip

@@ -149,3 +149,89 @@ int st_ale_vdiffm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+
+// ---- ale_forcing, phy/mod_ale_forcing.F90:45-221: the fractions of the shortwave and of the brine flux that pass the layer
+//      interfaces, and the buoyancy flux at the interfaces.  Inputs by name: swfc1, swfc2, swal1, swal2 (the two-band absorption
+//      of mod_swabs -- netCDF-bound, hence uploaded), mld (mod_cmnfld), the surface fluxes; scalars swamxd, brine_mlbase_frac.
+//      Parity: cross-checked against the real module built against a stand-in for mod_swabs (oracle/xcheck) -- not a pin.
+#include "exp_libm.h"
+#define ONEM 9806.
+#define ONEMU .009806
+__global__ __launch_bounds__(64) void k_ale_forcing(const DevView *__restrict__ Vp, int nn, double swamxd, double brine_mlbase_frac) {
+  const DevView &V = *Vp;
+  COL(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  // cbra1 = 2**(1/3), cbra2 = cbra1*cbra1/12 as the reference's compiler folds them (:56-57)
+  const double cbra1 = __longlong_as_double(0x3FF428A2F98D728BLL), cbra2 = __longlong_as_double(0x3FC0EEA9C37E497ELL);
+  const double cpi = 1. / SPCIFH, gaa = GRAV * ALPHA0 * ALPHA0;
+  const double *dp = V.f[F_dp] + (size_t)nn * np, *p = V.f[F_p];
+  double *tsw = V.f[F_t_sw_nonloc], *sbr = V.f[F_s_br_nonloc], *buoyfl = V.f[F_buoyfl];
+  {                                                                                    // :66-107 shortwave
+    const double pmax = swamxd * ONEM;
+    const double lei1 = 1. / (V.f[F_swal1][c] * ONEM), lei2 = 1. / (V.f[F_swal2][c] * ONEM);
+    const double fc1 = V.f[F_swfc1][c], fc2 = V.f[F_swfc2][c];
+    int kmax = 1;
+    L(tsw, 1) = 1.;
+    for (int k = 1; k <= kk; k++) {
+      if (L(dp, k) > ONEMU) {
+        L(tsw, k + 1) = fc1 * exp_libm(-lei1 * fmin2(pmax, L(p, k + 1))) + fc2 * exp_libm(-lei2 * fmin2(pmax, L(p, k + 1)));
+        kmax = k;
+      } else L(tsw, k + 1) = L(tsw, k);
+      if (L(p, k + 1) > pmax) break;
+    }
+    const double pmaxi = 1. / fmin2(pmax, L(p, kmax + 1)), nlbot = L(tsw, kmax + 1);
+    for (int k = kmax + 1; k <= kk + 1; k++) L(tsw, k) = 0.;
+    for (int k = kmax; k >= 2; k--) {
+      if (L(dp, k) > ONEMU) L(tsw, k) = L(tsw, k) - nlbot * L(p, k) * pmaxi;
+      else L(tsw, k) = L(tsw, k + 1);
+    }
+  }
+  {                                                                                    // :113-161 brine
+    const double mld = V.f[F_mld][c];
+    const double lei = 1. / (mld * ONEM), pmax = cbra1 * mld * ONEM;
+    int kmax = 1;
+    L(sbr, 1) = 1.;
+    for (int k = 1; k <= kk; k++) {
+      if (L(dp, k) > ONEMU) {
+        const double q = fmin2(cbra1, lei * L(p, k + 1));
+        const double q_c = q / cbra1, q3 = q * q * q, q_c3 = q_c * q_c * q_c;
+        L(sbr, k + 1) = brine_mlbase_frac * (1. - cbra2 * q * q3 * (7. - 2. * q3)) +
+                        (1. - brine_mlbase_frac) * (1. - q + q_c3 * q_c3 * (6. * cbra1 - 7. - (5. * cbra1 - 6.) * q_c));
+        kmax = k;
+      } else L(sbr, k + 1) = L(sbr, k);
+      if (L(p, k + 1) > pmax) break;
+    }
+    const double pmaxi = 1. / fmin2(pmax, L(p, kmax + 1)), nlbot = L(sbr, kmax + 1);
+    for (int k = kmax + 1; k <= kk + 1; k++) L(sbr, k) = 0.;
+    for (int k = kmax; k >= 2; k--) {
+      if (L(dp, k) > ONEMU) L(sbr, k) = L(sbr, k) - nlbot * L(p, k) * pmaxi;
+      else L(sbr, k) = L(sbr, k + 1);
+    }
+  }
+  {                                                                                    // :167-199 buoyancy flux
+    using namespace eos;
+    // the coefficients of potential density referenced at the surface, phy/mod_eos.F90:118-129
+    const double ap210 = a21, ap220 = a22, ap230 = a23, ap240 = a24, ap250 = a25, ap260 = a26;
+    const double ap110 = a11 - ap210 / ALPHA0, ap120 = a12 - ap220 / ALPHA0, ap130 = a13 - ap230 / ALPHA0;
+    const double ap140 = a14 - ap240 / ALPHA0, ap150 = a15 - ap250 / ALPHA0, ap160 = a16 - ap260 / ALPHA0;
+    const double th = V.f[F_temp][c + (size_t)nn * np], s = V.f[F_saln][c + (size_t)nn * np];
+    const double r1 = ap110 + (ap120 + ap140 * th + ap150 * s) * th + (ap130 + ap160 * s) * s;           // dsigdt0, dsigds0 :263-343
+    const double r2i = 1. / (ap210 + (ap220 + ap240 * th + ap250 * s) * th + (ap230 + ap260 * s) * s);
+    const double dsgdt = (ap120 + 2. * ap140 * th + ap150 * s - (ap220 + 2. * ap240 * th + ap250 * s) * r1 * r2i) * r2i;
+    const double dsgds = (ap130 + ap150 * th + 2. * ap160 * s - (ap230 + ap250 * th + 2. * ap260 * s) * r1 * r2i) * r2i;
+    const double hf = V.f[F_surflx][c], hfsw = V.f[F_sswflx][c], sf = V.f[F_salflx][c], sfbr = V.f[F_brnflx][c];
+    L(buoyfl, 1) = -(dsgdt * hf * cpi + dsgds * sf) * gaa;
+    for (int k = 2; k <= kk + 1; k++) L(buoyfl, k) = -(dsgdt * L(tsw, k) * hfsw * cpi + dsgds * L(sbr, k) * sfbr) * gaa;
+  }
+}
+
+int st_ale_forcing(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)mm; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.P.vcoord_tag == 1) return ctx_fail(c, "ale_forcing: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:196-212)");
+  hipLaunchKernelGGL(k_ale_forcing, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn, c->swamxd, c->brine_mlbase_frac);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

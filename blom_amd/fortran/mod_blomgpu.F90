@@ -129,7 +129,7 @@ module mod_blomgpu
             gpu_halo, gpu_chksum, gpu_sync, gpu_xcsum, budget_sums, gpu_budget
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
             diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail, &
-            cmnfld1, cmnfld2, ale_regrid_remap, gpu_set_vector
+            cmnfld1, cmnfld2, ale_regrid_remap, ale_vdifft, ale_vdiffm, ale_forcing, gpu_set_vector
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -351,6 +351,18 @@ contains
   subroutine ale_regrid_remap(m,n,mm,nn,k1m,k1n)   ! phy/mod_ale_regrid_remap.F90:1486 (vcoord 'plevel', 'cntiso_hybrid'/'direct')
     integer, intent(in) :: m,n,mm,nn,k1m,k1n
     call stage6('ale_regrid_remap',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine ale_vdifft(m,n,mm,nn,k1m,k1n)          ! phy/mod_ale_vdiff.F90:50
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('ale_vdifft',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine ale_vdiffm(m,n,mm,nn,k1m,k1n)          ! phy/mod_ale_vdiff.F90:245
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('ale_vdiffm',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine ale_forcing(m,n,mm,nn,k1m,k1n)         ! phy/mod_ale_forcing.F90:45
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('ale_forcing',m,n,mm,nn,k1m,k1n)
   end subroutine
   subroutine gpu_set_vector(name, v)           ! 1-D module arrays: 'plevel' (phy/mod_vcoord.F90:99)
     character(len=*), intent(in) :: name
