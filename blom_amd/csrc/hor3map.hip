@@ -40,6 +40,7 @@ struct blomgpu_h3m_grid {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Pool pool;
   bool device_io = false, check = true;
+  bool sticky = false;        // the first failing column is kept across calls until h3m_first_error reads it (one read-back per sequence)
   bool plane_io = false;      // device pointers in the library's own [level][column] layout: no transpose (the model's planes)
   bool own_stream = true;
   unsigned long long *first_fail = nullptr;   // (column << 8 | errstat) of the first failing column
@@ -225,7 +226,7 @@ int store_output(blomgpu_h3m_grid *G, const double *t, int m, double *a) {
 }
 int begin_call(blomgpu_h3m_grid *G) {
   H3CHK(hipSetDevice(G->device));
-  H3CHK(hipMemsetAsync(G->first_fail, 0xFF, sizeof(unsigned long long), G->stream));
+  if (!G->sticky) H3CHK(hipMemsetAsync(G->first_fail, 0xFF, sizeof(unsigned long long), G->stream));
   return 0;
 }
 int end_call(blomgpu_h3m_grid *G) {
@@ -417,6 +418,26 @@ int blomgpu_h3m_set_io(blomgpu_h3m_grid *G, int device_pointers, int check_error
 }
 
 }  // extern "C"
+// inside the library (stage_ale.hip): a sequence of calls whose status is read back once.  h3m_sequence_begin clears the record
+// and makes it sticky (calls return 0 unless the device layer fails); h3m_sequence_end returns an errstat of the lowest column
+// that failed in any call of the sequence (the kernels record failures with atomicMin on column << 8 | errstat) -- enough to
+// stop the stage with the reference's message for that column.
+int h3m_sequence_begin(blomgpu_h3m_grid *G) {
+  if (!G) return E_HANDLE;
+  H3CHK(hipMemsetAsync(G->first_fail, 0xFF, sizeof(unsigned long long), G->stream));
+  G->sticky = true;
+  G->check = false;
+  return 0;
+}
+int h3m_sequence_end(blomgpu_h3m_grid *G) {
+  if (!G) return E_HANDLE;
+  G->sticky = false;
+  G->check = true;
+  unsigned long long ff = H3_NOFAIL;
+  H3CHK(hipMemcpyAsync(&ff, G->first_fail, sizeof(ff), hipMemcpyDeviceToHost, G->stream));
+  H3CHK(hipStreamSynchronize(G->stream));
+  return ff == H3_NOFAIL ? 0 : (int)(ff & 0xFF);
+}
 // inside the library (stage_ale.hip): the grid works on the model context's stream
 int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream) {
   if (!G) return E_HANDLE;

@@ -26,6 +26,8 @@
 #include "../../include/blomgpu_hor3map.h"
 
 int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream);          // hor3map.hip
+int h3m_sequence_begin(blomgpu_h3m_grid *G);
+int h3m_sequence_end(blomgpu_h3m_grid *G);
 
 #define H3M_MAXF 8
 
@@ -703,6 +705,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   double *psrc = a->plane, *pdst = psrc + (size_t)(h.kk + 1) * np, *rm = pdst + (size_t)(h.kk + 1) * np;
   const dim3 g1((unsigned)((np + 255) / 256)), gk((unsigned)((np + 255) / 256), h.kk), b(256);
   int rc;
+  if ((rc = h3m_sequence_begin(a->grid))) return ale_fail(c, "sequence", rc);      // one status read-back for the whole stage
   // ---- tracers ----------------------------------------------------------------------------------------------------------
   const bool nudge = h.P.vcoord_tag == 2 && c->ale_regrid_method == 2;
   const int ring = nudge && c->ale_smooth_diff_max > 0. ? 1 : 0;      // lateral smoothing reads the neighbours' regridded columns
@@ -778,5 +781,6 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     hipLaunchKernelGGL(k_ale_uv_back, gk, b, 0, c->stream, c->d, nn, isv, (const double *)rm);
   }
   HIPCHK(c, hipGetLastError());
+  if ((rc = h3m_sequence_end(a->grid))) return ale_fail(c, "a column failed", rc);
   return 0;
 }

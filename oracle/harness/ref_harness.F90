@@ -43,7 +43,7 @@ module ref_harness
   use mod_idlage,    only: idlage_step
   use mod_budget,    only: budget_sums, cnsvdi
   use mod_tracers,   only: ntr, trc, trcold, uflxtr, vflxtr, trflx, inivar_tracers
-  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy, nnslpx, nnslpy, bfsqi, bfsqf, bfsql, z, dz
+  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy, nnslpx, nnslpy, bfsqi, bfsqf, bfsql, z, dz, mld
 #ifdef XCHECK_EDDTRA
   ! cross-check builds only (oracle/Makefile *_xed): the reference's real mod_eddtra, compiled against a stand-in for mod_difest
   use mod_eddtra,    only: eddtra
@@ -54,9 +54,12 @@ module ref_harness
   use mod_ale_vdiff, only: ale_vdifft, ale_vdiffm
 #endif
 #ifdef XCHECK_ALE
-  ! cross-check builds only (oracle/Makefile *_xale): the reference's real mod_ale_regrid_remap against the mod_dia stand-in
+  ! cross-check builds only (oracle/Makefile *_xale): the reference's real mod_ale_regrid_remap against the mod_dia stand-in,
+  ! its real mod_ale_forcing against the mod_swabs stand-in
   use mod_ale_regrid_remap, only: readnml_ale_regrid_remap, init_ale_regrid_remap, ale_regrid_remap
   use mod_vcoord,    only: plevel
+  use mod_ale_forcing, only: ale_forcing
+  use mod_swabs,     only: swamxd, swfc1, swfc2, swal1, swal2
 #endif
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
@@ -156,6 +159,10 @@ contains
     integer(c_int), intent(out) :: ierr
     ierr = 0
     select case (trim(cstr(name)))
+      case ('brine_mlbase_frac'); brine_mlbase_frac = v
+#ifdef XCHECK_ALE
+      case ('swamxd'); swamxd = v
+#endif
       case ('baclin'); baclin = v
       case ('batrop'); batrop = v
       case ('delt1');  delt1 = v
@@ -470,6 +477,14 @@ contains
       R2(brnflx)
       R2(salrlx)
       R2(salt_corr)
+      R3(buoyfl, kdm+1)
+      R2(mld)
+#ifdef XCHECK_ALE
+      R2(swfc1)
+      R2(swfc2)
+      R2(swal1)
+      R2(swal2)
+#endif
       case ('trc_corr')
         if (allocated(trc_corr)) then
           call ref_capture_r8(trc_corr, ptr); nlev = ntr
@@ -534,6 +549,7 @@ contains
         call readnml_ale_regrid_remap
         call init_ale_regrid_remap
       case ('ale_regrid_remap'); call ale_regrid_remap(m,n,mm,nn,k1m,k1n)
+      case ('ale_forcing'); call ale_forcing(m,n,mm,nn,k1m,k1n)
 #endif
       ! Halo updates the reference performs inside stages that cannot be built here
       ! (netCDF/CVMix).  Only the xctilr calls are reproduced, by calling xctilr.
