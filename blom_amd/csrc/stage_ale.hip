@@ -698,7 +698,6 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   if (h.P.vcoord_tag != 2 && h.P.vcoord_tag != 3) return ctx_fail(c, "ale_regrid_remap: unknown vertical coordinate");
   if (h.P.ltedtp_opt != 1) return ctx_fail(c, "ale_regrid_remap: neutral diffusion (ltedtp = 'neutral', phy/mod_ndiff.F90) is not built");
   if (!c->ale_plevel) return ctx_fail(c, "ale_regrid_remap: the pressure levels are not set (blomgpu_set_vector \"plevel\", phy/mod_vcoord.F90:99)");
-  if (c->tiling.multi()) return ctx_fail(c, "ale_regrid_remap: not built for decomposed domains yet");
   if (int rc = ale_prepare(c)) return rc;
   AleState *a = (AleState *)c->ale;
   const size_t np = h.nplane, per = (size_t)h.kk * np;

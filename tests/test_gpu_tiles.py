@@ -14,6 +14,7 @@ from blom_amd.tiles import tile_extents, tile_window, scatter_state, gather_inte
 from parity import STATE_FIELDS, GRID_FIELDS, INT_FIELDS, load_golden_init, put_fields
 
 pytestmark = pytest.mark.gpu
+from blom_amd.hostinit import step_indices as hostinit_step_indices
 ALL = STATE_FIELDS + GRID_FIELDS + INT_FIELDS
 CHECK = ["u", "v", "dp", "temp", "saln", "sigma", "pb", "ub", "vb", "ubflxs_p", "pb_p", "trc", "uflx", "vflx",
          "pgfx", "pgfy", "dpu", "dpv", "pbu", "pbv", "ubflx", "vbflx", "pb_mn", "ubcors_p"]
@@ -143,6 +144,68 @@ def test_cppm_on_tiles_matches_single_tile(cfg, npx, npy):
     assert not errs, errs
     bad = []
     for nm in CHECK:
+        a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
+        b = gather_interior(tiles, case, npx, npy, nm)
+        if not np.array_equal(a, b):
+            bad.append((nm, int((a != b).sum()), float(np.nanmax(np.abs(a - b)))))
+    for t in tiles.values():
+        t.close()
+    ref.close()
+    grp.destroy()
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("cfg,npx,npy,vcoord,method", [("chan_s", 2, 2, "cntiso_hybrid", "nudge"), ("box_s", 2, 2, "cntiso_hybrid", "direct"),
+                                                        ("tri_s", 2, 2, "cntiso_hybrid", "nudge"), ("tri_s", 4, 2, "plevel", "direct"),
+                                                        ("chan_s", 2, 1, "plevel", "nudge")])
+def test_ale_regrid_remap_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method):
+    """ale_regrid_remap (phy/mod_ale_regrid_remap.F90:1486) on a decomposed domain: every tile has its own engine structures; the
+    lateral smoothing of regrid_method = 'nudge' regrids one ring of columns beyond the tile from halo data and the stage's own
+    halo updates go through the tile transport.  After a few steps of the isopycnic sequence: interiors as on the single tile."""
+    from blom_amd.gpu import BlomGpu, TileGroup
+    nsteps = 3
+    case, masks, fields, ref = _single(cfg, nsteps)
+    kk = case.kdm
+    ii, jj = tile_extents(case, npx, npy)
+    grp = TileGroup(npx, npy)
+    tiles = {}
+    for py in range(npy):
+        for px in range(npx):
+            tm = {k: tile_window(masks[k], case, npx, npy, px, py) for k in masks}
+            t = BlomGpu(ii, jj, kk, case.ntr, case.nreg, tm, itdm=case.idm, jtdm=case.jdm, i0=px * ii, j0=py * jj)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            t.set("delt1", case.params["baclin"])
+            grp.attach(t, px, py)
+            tiles[(px, py)] = t
+    scatter_state(ref, tiles, case, npx, npy, [f for f in ALL if f in fields])
+    assert ref.step(0, nsteps) == nsteps
+    pbot = float(np.nanmax(ref.get("p")[kk]))
+    plevel = 0.4 * pbot * (np.arange(kk) / kk) ** 1.3
+    six = hostinit_step_indices(nsteps, kk)
+
+    def ale(g):
+        g.set("vcoord_type", vcoord)
+        g.set("ale_regrid_method", method)
+        g.set_vector("plevel", plevel)
+        g.stage("ale_regrid_remap", *six)
+    ale(ref)
+    errs = []
+
+    def run(t):
+        try:
+            t.step(0, nsteps)
+            ale(t)
+            t.sync()
+        except Exception as e:          # a failing tile would leave the others at a barrier
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(t,), daemon=True) for t in tiles.values()]
+    [x.start() for x in th]
+    [x.join(timeout=300) for x in th]
+    assert not errs, errs
+    bad = []
+    for nm in ["dp", "temp", "saln", "sigma", "trc", "u", "v", "dpu", "dpv", "p", "pu", "pv"]:
         a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
         b = gather_interior(tiles, case, npx, npy, nm)
         if not np.array_equal(a, b):
