@@ -520,6 +520,10 @@ int blomgpu_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k
   ctx_sync_view(c);
   return st_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
 }
+int blomgpu_cmnfld_bfsqi_ale(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {  // phy/mod_cmnfld_routines.F90:352
+  ctx_sync_view(c);
+  return st_cmnfld_bfsqi_ale(c, m, n, mm, nn, k1m, k1n);
+}
 int blomgpu_ale_forcing(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {  // phy/mod_ale_forcing.F90:45
   ctx_sync_view(c);
   return st_ale_forcing(c, m, n, mm, nn, k1m, k1n);
@@ -592,6 +596,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_forcing") return blomgpu_ale_forcing(c, m, n, mm, nn, k1m, k1n);
+  if (s == "cmnfld_bfsqi_ale") return blomgpu_cmnfld_bfsqi_ale(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_vdifft") return blomgpu_ale_vdifft(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_vdiffm") return blomgpu_ale_vdiffm(c, m, n, mm, nn, k1m, k1n);
   return ctx_fail(c, "blomgpu_stage: unknown stage " + s);

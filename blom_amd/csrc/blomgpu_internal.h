@@ -70,7 +70,7 @@
   X(brnflx, 1) X(salrlx, 1) X(salt_corr, 1) X(trc_corr, NT) X(trflx, NT)                                                    \
   /* ale_forcing (mod_ale_forcing.F90): the two-band shortwave absorption of mod_swabs, the mixed layer depth of mod_cmnfld    \
      [m], the interface buoyancy flux (mod_forcing.F90:183) */                                                                \
-  X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(buoyfl, K + 1)                                                 \
+  X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(mldl82, 1) X(dpml, 1) X(buoyfl, K + 1)                                                 \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
@@ -339,6 +339,7 @@ int diapfl_column3_launch(blomgpu_ctx *, int n, int nn, int *errflag);
 int st_ale_vdifft(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);          // stage_ale_vdiff.hip
 int st_ale_vdiffm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_ale_forcing(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);         // stage_ale_vdiff.hip
+int st_cmnfld_bfsqi_ale(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);    // stage_cmnfld.hip
 int st_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_ale.hip
 void ale_free(blomgpu_ctx *);
 int launch_dpudpv(blomgpu_ctx *, int off, int flags);                                        // stage_simple.hip

@@ -297,12 +297,199 @@ __global__ __launch_bounds__(64) void k_cmn_z(const DevView *__restrict__ Vp, in
   }
 }
 
+// ---- the branches of the vertical coordinates other than isopyc_bulkml (round 3) ---------------------------------------------
+// cmnfld_bfsqf_ale, :229-350: as the isopycnic form without the mixed-layer treatment; delp and bfsq of a level go through two
+// work planes to the tridiagonal filter.  (bfsqi and bfsql are zeroed everywhere first, :247-248: the launcher does that.)
+__global__ __launch_bounds__(64) void k_cmn_bfsqf_ale(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
+  double *bfsqi = V.f[F_bfsqi] + c, *bfsql = V.f[F_bfsql] + c, *bfsqf = V.f[F_bfsqf] + c;
+  double *delp = WK(V, CM_DELP) + c, *bfsq = WK(V, CM_BFSQ) + c, *gam = WK(V, CM_GAM) + c;
+#define L(a, k) (a)[(size_t)((k)-1) * np]
+  const double sls2 = SLS0 * SLS0, pbot = L(p, kk + 1);
+  L(bfsqi, 1) = BFSQMN;
+  double pup = .5 * (L(p, 1) + L(p, 2)), tup = L(temp, 1), sup = L(saln, 1);
+  for (int k = 2; k <= kk; k++) {
+    if (pbot - L(p, k) < EPSILP) {
+      L(delp, k) = ONEMM;
+      L(bfsqi, k) = L(bfsqi, k - 1);
+      L(bfsq, k) = BFSQMN;
+    } else {
+      const double plo = pbot - L(p, k + 1) < EPSILP ? pbot : .5 * (L(p, k) + L(p, k + 1));
+      const double tlo = L(temp, k), slo = L(saln, k);
+      const double dk = fmax2(ONEMM, plo - pup);
+      L(delp, k) = dk;
+      double bi = GRAV * GRAV * (eos::rho(L(p, k), tlo, slo) - eos::rho(L(p, k), tup, sup)) / dk;
+      L(bfsq, k) = fmax2(BFSQMN, bi);
+      bi = bi * dk / fmax2(ONEM, dk);
+      if (pbot - L(p, k) < ONEM) bi = L(bfsqi, k - 1);
+      L(bfsqi, k) = bi;
+      pup = plo; tup = tlo; sup = slo;
+    }
+  }
+  L(delp, 1) = V.f[F_dp][c + (size_t)nn * np];
+  L(bfsqi, 1) = L(bfsqi, 2);
+  L(bfsq, 1) = fmax2(BFSQMN, L(bfsqi, 1));
+  for (int k = 1; k <= kk - 1; k++) L(bfsql, k) = .5 * (L(bfsqi, k) + L(bfsqi, k + 1));
+  L(bfsql, kk) = L(bfsqi, kk);
+  // the tridiagonal system, :306-333 (atd, btd, ctd formed where they are used)
+  auto ctd = [&](int k) { return -2. * sls2 / (L(delp, k) * (L(delp, k) + L(delp, k + 1))); };
+  auto atd = [&](int k) { return -2. * sls2 / (L(delp, k) * (L(delp, k - 1) + L(delp, k))); };
+  double bei = 1. / (1. - ctd(1));
+  L(bfsqf, 1) = L(bfsq, 1) * bei;
+  for (int k = 2; k <= kk; k++) {
+    const double g = ctd(k - 1) * bei;
+    L(gam, k) = g;
+    const double a = atd(k);
+    const double btd = k < kk ? 1. - a - ctd(k) : 1. - a;
+    bei = 1. / (btd - a * g);
+    L(bfsqf, k) = (L(bfsq, k) - a * L(bfsqf, k - 1)) * bei;
+  }
+  for (int k = kk - 1; k >= 1; k--) L(bfsqf, k) = L(bfsqf, k) - L(gam, k + 1) * L(bfsqf, k + 1);
+  L(bfsqi, kk + 1) = L(bfsqi, kk);
+  L(bfsqf, kk + 1) = L(bfsqf, kk);
+#undef L
+}
+
+// cmnfld_bfsqi_ale, :352-421: p from dp (j,i = -2..+3), then the interface buoyancy frequency (j,i = 0..+1)
+__global__ __launch_bounds__(64) void k_cmn_bfsqi_ale(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
+  double *bfsqi = V.f[F_bfsqi] + c;
+#define L(a, k) (a)[(size_t)((k)-1) * np]
+  const double pbot = L(p, kk + 1);
+  L(bfsqi, 1) = BFSQMN;
+  double pup = .5 * (L(p, 1) + L(p, 2)), tup = L(temp, 1), sup = L(saln, 1);
+  for (int k = 2; k <= kk; k++) {
+    if (pbot - L(p, k) < EPSILP) L(bfsqi, k) = L(bfsqi, k - 1);
+    else {
+      const double plo = pbot - L(p, k + 1) < EPSILP ? pbot : .5 * (L(p, k) + L(p, k + 1));
+      const double tlo = L(temp, k), slo = L(saln, k);
+      double bi = GRAV * GRAV * (eos::rho(L(p, k), tlo, slo) - eos::rho(L(p, k), tup, sup)) / fmax2(ONEM, plo - pup);
+      if (pbot - L(p, k) < ONEM) bi = L(bfsqi, k - 1);
+      L(bfsqi, k) = bi;
+      pup = plo; tup = tlo; sup = slo;
+    }
+  }
+  L(bfsqi, 1) = L(bfsqi, 2);
+  L(bfsqi, kk + 1) = L(bfsqi, kk);
+#undef L
+}
+
+// cmnfld_nslope_ale, :654-811 (after the geopotential, which is k_cmn_phi's loop): u- (blockIdx.y = 0) and v-points (1)
+__global__ __launch_bounds__(64) void k_cmn_nslope_ale(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  const bool isv = blockIdx.y == 1;
+  if (isv ? (j < 0 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_iv][c])
+          : (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 2 || !V.m[I_iu][c])) return;
+  const size_t np = V.nplane, a_ = isv ? c - V.ni : c - 1, b_ = c;
+  const int kk = V.kk;
+  const double *p = V.f[F_p], *phi = V.f[F_phi], *bf = V.f[F_bfsqf];
+  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
+  double *nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c, *nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
+  const double sci = (isv ? V.f[F_scvyi] : V.f[F_scuxi])[c];
+#define A(f, x, k) (f)[(x) + (size_t)((k)-1) * np]
+#define O(f, k) (f)[(size_t)((k)-1) * np]
+  for (int k = 1; k <= kk; k++) { O(nslp, k) = 0.; O(nnslp, k) = 0.; }
+  int kmax = 1;
+  for (int k = 2; k <= kk; k++)
+    if (A(dp, a_, k) > EPSILP || A(dp, b_, k) > EPSILP) kmax = k;
+  int knnsl = 2;
+  const double phba = A(phi, a_, kk + 1), phbb = A(phi, b_, kk + 1);
+  for (int k = 2; k <= kmax; k++) {
+    const double pm = .5 * (A(p, a_, k) + A(p, b_, k));
+    const double rx = .5 * (eos::rho(pm, A(temp, b_, k - 1), A(saln, b_, k - 1)) - eos::rho(pm, A(temp, a_, k - 1), A(saln, a_, k - 1)) +
+                            eos::rho(pm, A(temp, b_, k), A(saln, b_, k)) - eos::rho(pm, A(temp, a_, k), A(saln, a_, k)));
+    const double px = A(phi, b_, k) - A(phi, a_, k);
+    const double bm = .5 * (A(bf, a_, k) + A(bf, b_, k));
+    const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
+    O(nslp, k) = s;
+    if (A(phi, b_, k) > phba && A(phi, a_, k) > phbb) { O(nnslp, k) = sqrt(bm) * s; knnsl = k; }
+  }
+  for (int k = knnsl + 1; k <= kmax; k++) O(nnslp, k) = O(nnslp, knnsl);
+#undef A
+#undef O
+}
+
+// p(k+1) = p(k) + dp(kn), j,i = -2..+3 (cmnfld_bfsqi_ale :364-375)
+__global__ __launch_bounds__(64) void k_cmn_pscan3(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < -2 || j > V.jj + 3 || i < -2 || i > V.ii + 3 || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  double a = V.f[F_p][c];
+  for (int k = 0; k < V.kk; k++) { a = a + V.f[F_dp][c + (size_t)(k + nn) * np]; V.f[F_p][c + (size_t)(k + 1) * np] = a; }
+}
+
+int st_cmnfld_bfsqi_ale(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)m; (void)n; (void)mm; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (h.P.vcoord_tag == 1) return ctx_fail(c, "cmnfld_bfsqi_ale: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:196-212)");
+  const dim3 g1 = plane_grid(h, 1, 64);
+  hipLaunchKernelGGL(k_cmn_pscan3, g1, dim3(64), 0, c->stream, c->d, nn);
+  HIPCHK(c, hipMemsetAsync(h.f[F_bfsqi], 0, sizeof(double) * (size_t)(h.kk + 1) * h.nplane, c->stream));        // :378
+  hipLaunchKernelGGL(k_cmn_bfsqi_ale, g1, dim3(64), 0, c->stream, c->d, nn);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// cmnfld_mldl82, :933-995 (mixed layer depth after Levitus 1982) and the selection mld = mldl82, dpml = dpmll82 of cmnfld1 for
+// the vertical coordinates other than isopyc_bulkml with mldmth = 'lev82' (:1121-1131)
+#define DBCL82 .0003
+#define ONECM 98.06
+__global__ __launch_bounds__(64) void k_cmn_mldl82(const DevView *__restrict__ Vp, int mm) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *z = V.f[F_z] + c, *dz = V.f[F_dz] + c;
+  const double *temp = V.f[F_temp] + c + (size_t)mm * np, *saln = V.f[F_saln] + c + (size_t)mm * np, *dp = V.f[F_dp] + c + (size_t)mm * np;
+#define L(a, k) (a)[(size_t)((k)-1) * np]
+  int k = 2;
+  double pup = L(p, 1) + .5 * L(dp, 1), zup = L(z, 1) + .5 * L(dz, 1), dbup = 0., mld, dpml;
+  const double t1 = L(temp, 1), s1 = L(saln, 1);
+  while (true) {
+    if (L(dp, k) > ONECM) {
+      const double plo = L(p, k) + .5 * L(dp, k), zlo = L(z, k) + .5 * L(dz, k);
+      const double dblo = GRAV * (1. - eos::rho(plo, t1, s1) / eos::rho(plo, L(temp, k), L(saln, k)));
+      if (dblo <= DBCL82) { pup = plo; zup = zlo; dbup = dblo; }
+      else {
+        dbup = fmin2(dbup, DBCL82 - EPSILP);
+        mld = (zup * (dblo - DBCL82) + zlo * (DBCL82 - dbup)) / (dblo - dbup) - L(z, 1);
+        dpml = (pup * (dblo - DBCL82) + plo * (DBCL82 - dbup)) / (dblo - dbup) - L(p, 1);
+        break;
+      }
+    }
+    k = k + 1;
+    if (k > kk) {
+      mld = L(z, kk + 1) - L(z, 1);
+      dpml = L(p, kk + 1) - L(p, 1);
+      break;
+    }
+  }
+#undef L
+  V.f[F_mldl82][c] = mld;
+  V.f[F_mld][c] = mld;
+  V.f[F_dpml][c] = dpml;
+}
+
 int st_cmnfld1(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
   const DevView &h = c->h;
-  if (h.P.vcoord_tag != 1) return ctx_fail(c, "cmnfld1: only vcoord = 'isopyc_bulkml' is built");
   TimeScope ts(c, "cmnfld");
   hipLaunchKernelGGL(k_cmn_z, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, mm);
+  // the other vertical coordinates also need the mixed layer depth (mldmth = 'lev82', the default; 'boy04' is not built)
+  if (h.P.vcoord_tag != 1) hipLaunchKernelGGL(k_cmn_mldl82, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, mm);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -311,17 +498,30 @@ int st_cmnfld1(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
 int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
-  if (h.P.vcoord_tag != 1) return ctx_fail(c, "cmnfld2: only vcoord = isopyc_bulkml is built (cmnfld_bfsqf_ale / nslope_ale are not)");
   if (h.nwk < CM_NSLOT) return ctx_fail(c, "cmnfld2: device work space too small");
   {
     double *ptrs[2] = {h.f[F_temp], h.f[F_saln]};                                           // :1171-1172
     const int nl[2] = {2 * h.kk, 2 * h.kk}, it[2] = {1, 1};
     if (int rc = st_xctilr_multi(c, 2, ptrs, nl, 3, 3, it)) return rc;
   }
+  const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64);
+  if (h.P.vcoord_tag != 1) {
+    // the other vertical coordinates, :1203-1234: the filtered buoyancy frequency always, the slopes with eitmth = 'gm'
+    if (h.P.ltedtp_opt != 1) return ctx_fail(c, "cmnfld2: ltedtp = 'neutral' (cmnfld_nnslope_ale) is not built");
+    TimeScope ts(c, "cmnfld");
+    HIPCHK(c, hipMemsetAsync(h.f[F_bfsqi], 0, sizeof(double) * (size_t)(h.kk + 1) * h.nplane, c->stream));      // :247-248
+    HIPCHK(c, hipMemsetAsync(h.f[F_bfsql], 0, sizeof(double) * (size_t)h.kk * h.nplane, c->stream));
+    hipLaunchKernelGGL(k_cmn_bfsqf_ale, g1, dim3(64), 0, c->stream, c->d, nn);
+    if (h.P.eitmth == 2) {
+      hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
+      hipLaunchKernelGGL(k_cmn_nslope_ale, g2, dim3(64), 0, c->stream, c->d, nn);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
   if (int rc = st_kfpla_halo(c, n)) return rc;                                              // :1176-1196
   if (h.P.eitmth != 2) return 0;
   TimeScope ts(c, "cmnfld");
-  const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64);
   hipLaunchKernelGGL(k_cmn_bfsqf, g1, dim3(64), 0, c->stream, c->d, n, nn);
   hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
   hipLaunchKernelGGL(k_cmn_nslope, g2, dim3(64), 0, c->stream, c->d, n, nn);

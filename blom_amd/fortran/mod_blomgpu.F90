@@ -129,7 +129,8 @@ module mod_blomgpu
             gpu_halo, gpu_chksum, gpu_sync, gpu_xcsum, budget_sums, gpu_budget
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
             diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail, &
-            cmnfld1, cmnfld2, ale_regrid_remap, ale_vdifft, ale_vdiffm, ale_forcing, gpu_set_vector
+            cmnfld1, cmnfld2, ale_regrid_remap, ale_vdifft, ale_vdiffm, ale_forcing, &
+            cmnfld_bfsqi_ale, gpu_set_vector
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -359,6 +360,10 @@ contains
   subroutine ale_vdiffm(m,n,mm,nn,k1m,k1n)          ! phy/mod_ale_vdiff.F90:245
     integer, intent(in) :: m,n,mm,nn,k1m,k1n
     call stage6('ale_vdiffm',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)    ! phy/mod_cmnfld_routines.F90:352
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('cmnfld_bfsqi_ale',m,n,mm,nn,k1m,k1n)
   end subroutine
   subroutine ale_forcing(m,n,mm,nn,k1m,k1n)         ! phy/mod_ale_forcing.F90:45
     integer, intent(in) :: m,n,mm,nn,k1m,k1n

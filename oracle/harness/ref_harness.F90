@@ -43,11 +43,11 @@ module ref_harness
   use mod_idlage,    only: idlage_step
   use mod_budget,    only: budget_sums, cnsvdi
   use mod_tracers,   only: ntr, trc, trcold, uflxtr, vflxtr, trflx, inivar_tracers
-  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy, nnslpx, nnslpy, bfsqi, bfsqf, bfsql, z, dz, mld
+  use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy, nnslpx, nnslpy, bfsqi, bfsqf, bfsql, z, dz, mld, mldl82, dpml
 #ifdef XCHECK_EDDTRA
   ! cross-check builds only (oracle/Makefile *_xed): the reference's real mod_eddtra, compiled against a stand-in for mod_difest
   use mod_eddtra,    only: eddtra
-  use mod_cmnfld_routines, only: cmnfld1, cmnfld2
+  use mod_cmnfld_routines, only: cmnfld1, cmnfld2, cmnfld_bfsqi_ale
 #endif
 #ifdef WITH_ALE_VDIFF
   ! builds *_vdf: the reference's phy/mod_ale_vdiff.F90 (no stand-in involved: a pin)
@@ -479,6 +479,8 @@ contains
       R2(salt_corr)
       R3(buoyfl, kdm+1)
       R2(mld)
+      R2(mldl82)
+      R2(dpml)
 #ifdef XCHECK_ALE
       R2(swfc1)
       R2(swfc2)
@@ -531,6 +533,7 @@ contains
       case ('eddtra');  call eddtra(m,n,mm,nn,k1m,k1n)
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
+      case ('cmnfld_bfsqi_ale'); call cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)
 #endif
 #ifdef WITH_ALE_VDIFF
       case ('ale_vdifft')
