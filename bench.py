@@ -342,7 +342,7 @@ def bench_ale(args):
     hostinit.init_state(gpu, case)
     ns = gpu.step(0, 2)
     kk = case.kdm
-    pbot = float(np.nanmax(gpu.get("p")[kk]))
+    pbot = float(np.max(gpu.get("p")[kk][masks["ip"] > 0]))
     gpu.set("vcoord_type", "cntiso_hybrid")
     gpu.set("ale_regrid_method", "direct")
     gpu.set_vector("plevel", 0.05 * pbot * (np.arange(kk) / kk) ** 1.3)

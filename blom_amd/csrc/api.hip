@@ -559,6 +559,22 @@ int blomgpu_halo_cmnfld2(blomgpu_ctx *c, int n) {     // phy/mod_cmnfld_routines
   }
   return st_kfpla_halo(c, n);                         // kfpla(:,:,n) halo through util1, :1176-1196
 }
+// the halo updates of difest_lateral_hybrid (which = 0, phy/mod_difest.F90:826-831) and difest_vertical_hybrid (which = 1,
+// :877-878): the routines need CVMix and are not built, their halo updates are what momtum and ale_vdiffm rely on
+int blomgpu_halo_difest_hyb(blomgpu_ctx *c, int which, int k1n) {
+  ctx_sync_view(c);
+  const int kk = c->h.kk;
+  const size_t np = c->h.nplane;
+  if (which == 0) {
+    double *ptrs[6] = {c->h.f[F_u], c->h.f[F_v], c->h.f[F_ubflxs_p], c->h.f[F_vbflxs_p], c->h.f[F_pbu], c->h.f[F_pbv]};
+    const int nl[6] = {2 * kk, 2 * kk, 2, 2, 2, 2}, it[6] = {13, 14, 13, 14, 3, 4};
+    return st_xctilr_multi(c, 6, ptrs, nl, 2, 2, it);
+  }
+  double *ptrs[2] = {c->h.f[F_u] + (size_t)(k1n - 1) * np, c->h.f[F_v] + (size_t)(k1n - 1) * np};
+  const int nl[2] = {kk, kk}, it[2] = {13, 14};
+  return st_xctilr_multi(c, 2, ptrs, nl, 1, 1, it);
+}
+
 int blomgpu_halo_difest(blomgpu_ctx *c, int nn) {     // phy/mod_difest.F90:750-772
   ctx_sync_view(c);
   const int kk = c->h.kk;
@@ -593,6 +609,8 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "cmnfld2") return blomgpu_cmnfld2(c, m, n, mm, nn, k1m, k1n);
   if (s == "cmnfld1") return blomgpu_cmnfld1(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
+  if (s == "halo_difest_hyb") return blomgpu_halo_difest_hyb(c, 0, k1n);
+  if (s == "halo_difest_vert") return blomgpu_halo_difest_hyb(c, 1, k1n);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_forcing") return blomgpu_ale_forcing(c, m, n, mm, nn, k1m, k1n);
@@ -607,11 +625,28 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   static const char *seq[] = {"init_fluxes", "tmsmt1", "halo_cmnfld2", "halo_difest", "eddtra", "advect",
                               "pbcor1", "diffus", "pgforc", "momtum", "convec", "diapfl", "mxlayr_tail", "updtrc",
                               "barotp", "pbcor2", "tmsmt2"};
+  // the other vertical coordinates (phy/mod_blom_step.F90:126-233 with vcoord_tag /= vcoord_isopyc_bulkml), as far as built:
+  // blom_amd/stepper.py HYBRID_STAGES says what is left out and why
+  static const char *seq_ale[] = {"init_fluxes", "tmsmt1", "ale_regrid_remap", "cmnfld2", "halo_difest_hyb", "advect", "pbcor1",
+                                  "diffus", "pgforc", "momtum", "cmnfld_bfsqi_ale", "ale_forcing", "halo_difest_vert",
+                                  "ale_vdifft", "ale_vdiffm", "updtrc", "barotp", "pbcor2", "tmsmt2", "cmnfld1"};
   c->defer_checks = true;
   c->in_sequence = true;
   c->pbcor1_handed_over = c->pbcor2_handed_over = false;
   c->fluxes_zeroed = false;
   c->remap_handed_over = false;
+  if (c->h.P.vcoord_tag != 1) {
+    for (const char *st : seq_ale) {
+      if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }
+      if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) {
+        c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+        return rc;
+      }
+    }
+    c->defer_checks = false;
+    c->in_sequence = false;
+    return 0;
+  }
   for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;

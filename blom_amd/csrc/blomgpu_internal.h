@@ -70,6 +70,8 @@
   X(brnflx, 1) X(salrlx, 1) X(salt_corr, 1) X(trc_corr, NT) X(trflx, NT)                                                    \
   /* ale_forcing (mod_ale_forcing.F90): the two-band shortwave absorption of mod_swabs, the mixed layer depth of mod_cmnfld    \
      [m], the interface buoyancy flux (mod_forcing.F90:183) */                                                                \
+  /* momtum, the other vertical coordinates: the fractions of the wind stress that pass the interfaces (mod_diffusion.F90:139-142) */ \
+  X(mu_nonloc, K + 1) X(mv_nonloc, K + 1)                                                                                     \
   X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(mldl82, 1) X(dpml, 1) X(buoyfl, K + 1)                                                 \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \

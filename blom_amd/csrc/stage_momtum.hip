@@ -76,7 +76,6 @@ __global__ void k_mom_drag(const DevView *__restrict__ Vp, int n, int nn) {
 int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)k1m; (void)k1n;
   const DevView &h = c->h;
-  if (h.P.vcoord_tag != 1) return ctx_fail(c, "momtum: hybrid-coordinate wind stress (mu_nonloc) is not built yet");
   const dim3 gcol = plane_grid(h, 1, 64), b64(64);
   TimeScope ts(c, "momtum");
   hipLaunchKernelGGL(k_mom_pscan, gcol, b64, 0, c->stream, c->d, mm, -1, 2);

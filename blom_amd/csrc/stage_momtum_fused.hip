@@ -419,6 +419,8 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
   const gcd_t pgfy_m = GF(V, F_pgfy) + okm, pgfy_n = GF(V, F_pgfy) + okn, pgfy_o = GF(V, F_pgfy_o) + ok;
   const gcd_t dpuold = GF(V, F_dpuold) + ok, dpvold = GF(V, F_dpvold) + ok, ubcors = GF(V, F_ubcors_p), vbcors = GF(V, F_vbcors_p);
   const gcd_t scuxi = GF(V, F_scuxi), scvyi = GF(V, F_scvyi), taux = GF(V, F_taux), tauy = GF(V, F_tauy);
+  const bool hybrid = V.P.vcoord_tag != 1;
+  const gcd_t mu_nl = GF(V, F_mu_nonloc), mv_nl = GF(V, F_mv_nonloc);
   const gcd_t visu = (gcd_t)WK(V, MF_VISU) + ok, visv = (gcd_t)WK(V, MF_VISV) + ok;
   const gd_t o_um = (gd_t)WK(V, MF_UM) + ok, o_un = (gd_t)WK(V, MF_UN) + ok, o_vm = (gd_t)WK(V, MF_VM) + ok, o_vn = (gd_t)WK(V, MF_VN) + ok;
   const gd_t o_absvor = (gd_t)V.f[F_absvor] + ok, o_dpvor = (gd_t)V.f[F_dpvor] + ok;
@@ -577,7 +579,9 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
             cau = .25 * ((vf0[l] + vf0[l - 1]) * pv0[l] + (vfp[l] + vfp[l - 1]) * pvp[l]);
           // wind stress (isopyc_bulkml: top layer only), :919-936
           double stress = 0.;
-          if (k == 0) stress = -2. * taux[c] * GRAV * scux[c] / (p_1[c] + p_1[c - 1]);
+          if (hybrid)                    // the other vertical coordinates: the stress spread by the non-local fractions, :937-946
+            stress = -(mu_nl[c + (size_t)k * np] - mu_nl[c + (size_t)(k + 1) * np]) * taux[c] * GRAV * scux[c] / fmax2(ONEMM, u_dpu);
+          else if (k == 0) stress = -2. * taux[c] * GRAV * scux[c] / (p_1[c] + p_1[c - 1]);
           const double pbu = u_pbum;
           const double ptopl = .5 * (fmin2(pbu, u_p0) + fmin2(pbu, u_p0w));
           const double pbotl = .5 * (fmin2(pbu, u_p1) + fmin2(pbu, u_p1w));
@@ -611,7 +615,9 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
           else
             cav = -.25 * ((uf0[l] + ufm[l]) * pv0[l] + (uf0[l + 1] + ufm[l + 1]) * pv0[l + 1]);
           double stress = 0.;
-          if (k == 0) stress = -2. * tauy[c] * GRAV * scvy[c] / (p_1[c] + p_1[c - ni]);
+          if (hybrid)                    // :1100-1109
+            stress = -(mv_nl[c + (size_t)k * np] - mv_nl[c + (size_t)(k + 1) * np]) * tauy[c] * GRAV * scvy[c] / fmax2(ONEMM, u_dpv);
+          else if (k == 0) stress = -2. * tauy[c] * GRAV * scvy[c] / (p_1[c] + p_1[c - ni]);
           const double pbv = u_pbvm;
           const double ptopl = .5 * (fmin2(pbv, u_p0) + fmin2(pbv, u_p0s));
           const double pbotl = .5 * (fmin2(pbv, u_p1) + fmin2(pbv, u_p1s));

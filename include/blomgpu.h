@@ -133,6 +133,8 @@ int  blomgpu_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k
  * their non-local transport) and of u, v.  Inputs by name: kdiff_t, kdiff_s, kvisc_m, t_{ns,sw,rs}_nonloc, s_{nb,br,rs}_nonloc
  * (kdm+1 levels), surflx, sswflx, surrlx, salflx, brnflx, salrlx, trflx (ntr planes); salt_corr, trc_corr accumulate. */
 int  blomgpu_ale_vdifft(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+/* the halo updates of difest_lateral_hybrid (which = 0, phy/mod_difest.F90:826-831) / difest_vertical_hybrid (which = 1, :877-878) */
+int  blomgpu_halo_difest_hyb(blomgpu_ctx *, int which, int k1n);
 /* phy/mod_cmnfld_routines.F90:352 cmnfld_bfsqi_ale (phy/mod_blom_step.F90:199): p from dp, interface buoyancy frequency */
 int  blomgpu_cmnfld_bfsqi_ale(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* phy/mod_ale_forcing.F90:45 ale_forcing: t_sw_nonloc, s_br_nonloc, buoyfl from the surface fluxes, the absorption bands swfc1,

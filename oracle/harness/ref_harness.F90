@@ -464,6 +464,8 @@ contains
       case ('kvisc_m'); call ref_capture_r8(Kvisc_m, ptr); nlev = kdm+1
       case ('kdiff_t'); call ref_capture_r8(Kdiff_t, ptr); nlev = kdm+1
       case ('kdiff_s'); call ref_capture_r8(Kdiff_s, ptr); nlev = kdm+1
+      R3(mu_nonloc, kdm+1)
+      R3(mv_nonloc, kdm+1)
       R3(t_ns_nonloc, kdm+1)
       R3(s_nb_nonloc, kdm+1)
       R3(t_sw_nonloc, kdm+1)
@@ -570,6 +572,18 @@ contains
         call xctilr(pbv, 1,2, 2,2, halo_vs)
         call difest_p(nn)
       case ('mxlayr_tail');  call mxlayr_tail(nn, k1n)
+      ! the halo updates of difest_lateral_hybrid and difest_vertical_hybrid (phy/mod_difest.F90:826-831, :877-878; the
+      ! routines themselves need CVMix)
+      case ('halo_difest_hyb')
+        call xctilr(u, 1,2*kk, 2,2, halo_uv)
+        call xctilr(v, 1,2*kk, 2,2, halo_vv)
+        call xctilr(ubflxs_p, 1,2, 2,2, halo_uv)
+        call xctilr(vbflxs_p, 1,2, 2,2, halo_vv)
+        call xctilr(pbu, 1,2, 2,2, halo_us)
+        call xctilr(pbv, 1,2, 2,2, halo_vs)
+      case ('halo_difest_vert')
+        call xctilr(u(1-nbdy,1-nbdy,k1n), 1,kk, 1,1, halo_uv)
+        call xctilr(v(1-nbdy,1-nbdy,k1n), 1,kk, 1,1, halo_vv)
       case default; ierr = 1
     end select
   end subroutine ref_stage

@@ -112,3 +112,53 @@ def test_ale_vdiff_is_refused_for_the_isopycnic_coordinate():
         with pytest.raises(BlomGpuError, match="isopyc_bulkml"):
             gpu.stage(st, *six)
     gpu.close()
+
+
+@pytest.mark.parametrize("cfg,nsteps,seed", [("chan_s_tke", 3, 11), ("box_s", 3, 12), ("fuk95", 2, 13), ("tri_s_tke", 3, 14)])
+def test_momtum_with_the_wind_stress_of_the_other_coordinates(cfg, nsteps, seed):
+    """momtum for vcoord_type /= 'isopyc_bulkml' (phy/mod_momtum.F90:937-946, :1100-1109): the wind stress enters every layer through
+    the non-local fractions mu_nonloc, mv_nonloc instead of the top layer alone.  PINNED: mod_momtum is part of the plain
+    reference build; the fractions (produced by difest_vertical_hybrid, not built) are synthetic."""
+    from oracle.refblom import get_ref_backend, have_ref
+    from blom_amd.gpu import BlomGpu
+    lib = cfg.replace("_tke", "") + "_vdf"
+    if not have_ref(lib):
+        pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
+    case = make_case(cfg)
+    ref = get_ref_backend(lib, case.depth)
+    if not ref.has_field("mu_nonloc"):
+        pytest.skip("reference library built before mu_nonloc was added to the harness")
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
+    hostinit.init_state(gpu, case)
+    assert gpu.step(0, nsteps) == nsteps
+    hostinit.init_state(ref, case)
+    copy_state(gpu, ref, fields=STATE_FIELDS + GRID_FIELDS + INT_FIELDS)
+    rng = np.random.default_rng(seed)
+    z = np.arange(kk + 1)[:, None, None] / kk
+    f = {}
+    for nm in ("mu_nonloc", "mv_nonloc"):
+        a = np.clip(1.0 - z / rng.uniform(0.1, 0.9, (1, nj, ni)), 0.0, 1.0) ** rng.uniform(1.0, 3.0, (1, nj, ni))
+        a[0] = 1.0
+        f[nm] = a
+    f["taux"] = rng.uniform(-0.3, 0.3, (1, nj, ni))
+    f["tauy"] = rng.uniform(-0.3, 0.3, (1, nj, ni))
+    for be in (ref, gpu):
+        for nm, a in f.items():
+            be.put(nm, a)
+    ref.ref.set("vcoord_tag", 2)
+    gpu.set("vcoord_type", "cntiso_hybrid")
+    delt1 = 2.0 * case.params["baclin"]
+    ref.ref.set("delt1", delt1)
+    gpu.set("delt1", delt1)
+    six = hostinit.step_indices(nsteps, kk)
+    try:
+        u0 = gpu.get("u").copy()
+        ref.ref.stage("momtum", *six)
+        gpu.stage("momtum", *six)
+        bad = diff_report(ref, gpu, fields=["u", "v", "p", "pu", "pv", "utotn", "vtotn", "ubflxs_p", "vbflxs_p"])
+        assert not bad, fmt_report(bad[:10])
+        assert np.abs(gpu.get("u") - u0)[:, 4:-4, 4:-4].max() > 0.0
+    finally:
+        ref.ref.set("vcoord_tag", 1)
+        gpu.close()

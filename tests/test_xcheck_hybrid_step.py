@@ -1,0 +1,135 @@
+"""CROSS-CHECK (not a pin): the step of the hybrid vertical coordinate, as far as it is built, device-resident against the
+reference's own modules stage by stage (config 1 of BASELINE.json is the reference's tests/fuk95/limits:
+cntiso_hybrid + cppm).
+
+Sequence (blom_amd/stepper.py HYBRID_STAGES = the order of phy/mod_blom_step.F90:126-233): init_fluxes, tmsmt1,
+ale_regrid_remap, cmnfld2, advect, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft, ale_vdiffm, updtrc,
+barotp, pbcor2, tmsmt2, cmnfld1.  Left out on BOTH sides because their modules need CVMix or forcing files: difest_lateral_hybrid,
+difest_vertical_hybrid (diffusivities and non-local fractions stay as uploaded), eddtra's ALE form (eddy-induced fluxes zero),
+thermf (surface fluxes as uploaded).  The reference side runs its real modules -- ale_regrid_remap, ale_forcing and cmnfld
+against the stand-ins of oracle/xcheck (hence a cross-check), everything else from the plain build.  The device runs
+blomgpu_step.  After every step all state arrays must agree bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from blom_amd.cases import make_case
+from blom_amd import hostinit
+from blom_amd.stepper import dyncore_step, HYBRID_STAGES
+from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, GRID_FIELDS, INT_FIELDS
+
+pytestmark = pytest.mark.gpu
+_INITIALISED = set()
+ALE_FIELDS = ["kvisc_m", "kdiff_t", "kdiff_s", "t_ns_nonloc", "s_nb_nonloc", "t_sw_nonloc", "t_rs_nonloc", "s_br_nonloc",
+              "s_rs_nonloc", "mu_nonloc", "mv_nonloc", "surflx", "sswflx", "surrlx", "salflx", "brnflx", "salrlx", "salt_corr",
+              "trc_corr", "trflx", "swfc1", "swfc2", "swal1", "swal2", "mld", "mldl82", "dpml", "buoyfl", "sigint", "bfsqi",
+              "bfsql", "bfsqf", "nslpx", "nslpy", "nnslpx", "nnslpy", "z", "dz", "told", "sold", "trcold"]
+CHECK = STATE_FIELDS + ["sigint", "t_sw_nonloc", "s_br_nonloc", "buoyfl", "salt_corr", "trc_corr", "mld", "dpml", "bfsqi", "bfsqf",
+                        "nslpx", "nslpy", "z", "dz"]
+
+
+# work arrays of mod_utility that stages use as scratch (cppm leaves parts of them as they were)
+SCRATCH = ("util1", "util2", "util3", "util4", "utotm", "vtotm", "uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3")
+
+
+def _limits(method):
+    return (" &ALE_REGRID_REMAP\n  RECONSTRUCTION_METHOD = 'ppm'\n  UPPER_BNDR_ORD = 6\n  LOWER_BNDR_ORD = 4\n"
+            "  DENSITY_LIMITING = 'monotonic'\n  TRACER_LIMITING = 'non_oscillatory'\n  VELOCITY_LIMITING = 'non_oscillatory'\n"
+            "  TRACER_PC_UPPER_BNDR = .true.\n  TRACER_PC_LOWER_BNDR = .false.\n  VELOCITY_PC_UPPER_BNDR = .true.\n"
+            f"  VELOCITY_PC_LOWER_BNDR = .false.\n  REGRID_METHOD = '{method}'\n /\n")
+
+
+@pytest.mark.parametrize("cfg,advmth,method,vcoord,nsteps", [
+    # fuk95's layers are not isopycnic (a jet in uniformly thick layers): its densities lie outside the layers' targets and the
+    # density-following coordinate would collapse the column into one layer -- it runs with pressure levels
+    ("fuk95", "cppm", "nudge", "plevel", 4), ("fuk95", "cppm", "nudge", "cntiso_hybrid", 3), ("chan_s", "remap", "nudge", "cntiso_hybrid", 5),
+    ("box_s", "cppm", "direct", "cntiso_hybrid", 4), ("tri_s", "remap", "direct", "cntiso_hybrid", 4),
+    ("chan_s", "cppm", "direct", "plevel", 3)])
+def test_hybrid_step_equals_the_reference_stage_sequence(cfg, advmth, method, vcoord, nsteps, tmp_path):
+    import ctypes as C
+    from oracle.refblom import get_ref_backend, have_ref
+    from blom_amd.gpu import BlomGpu
+    lib = cfg + ("_xaln" if method == "nudge" else "_xale")
+    if not have_ref(lib):
+        pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
+    case = make_case(cfg, advmth=advmth)
+    ref = get_ref_backend(lib, case.depth)
+    if not ref.has_field("mu_nonloc"):
+        pytest.skip("reference library built before the hybrid step's fields were added to the harness")
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
+    hostinit.init_state(ref, case)
+    hostinit.init_state(gpu, case)
+    copy_state(ref, gpu, fields=STATE_FIELDS + GRID_FIELDS + INT_FIELDS)      # the reference's patterns where nothing writes
+    # what the parts of the step that are not built would produce: smooth synthetic fields, the same on both sides
+    rng = np.random.default_rng(7)
+    z = np.arange(kk + 1)[:, None, None] / kk
+    f = {}
+    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
+        f[nm] = 1e-5 + 10.0 ** rng.uniform(-3.5, -2.0, (1, nj, ni)) * np.exp(-((z - 0.1) / 0.15) ** 2)
+    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
+        a = np.clip(1.0 - z / rng.uniform(0.1, 0.6, (1, nj, ni)), 0.0, 1.0) ** 2
+        a[0] = 1.0
+        f[nm] = a
+    f["sswflx"] = -rng.uniform(0.0, 150.0, (1, nj, ni))
+    f["surflx"] = f["sswflx"] + rng.uniform(-100.0, 100.0, (1, nj, ni))
+    f["surrlx"] = rng.uniform(-10.0, 10.0, (1, nj, ni))
+    f["brnflx"] = -rng.uniform(0.0, 1e-4, (1, nj, ni))
+    f["salflx"] = f["brnflx"] + rng.uniform(-2e-3, 2e-3, (1, nj, ni))
+    f["salrlx"] = rng.uniform(-5e-4, 5e-4, (1, nj, ni))
+    f["swfc1"] = rng.uniform(0.4, 0.7, (1, nj, ni))
+    f["swfc2"] = 1.0 - f["swfc1"]
+    f["swal1"] = rng.uniform(0.5, 1.5, (1, nj, ni))
+    f["swal2"] = rng.uniform(10.0, 20.0, (1, nj, ni))
+    if ref.ntr:
+        f["trflx"] = rng.uniform(-1e-6, 1e-6, (ref.ntr, nj, ni))
+        f["trc_corr"] = np.zeros((ref.ntr, nj, ni))
+    f["salt_corr"] = np.zeros((1, nj, ni))
+    pbot = float(np.max(ref.get("p")[kk][4:-4, 4:-4][ref.masks["ip"][4:-4, 4:-4] > 0]))
+    plevel = 0.3 * pbot * (np.arange(kk) / kk) ** 1.3
+    for nm, a in f.items():
+        ref.put(nm, a)
+    for nm in ALE_FIELDS:                     # the reference's initial patterns (spval) where nothing writes
+        if ref.has_field(nm) and gpu.has_field(nm):
+            gpu.put(nm, ref.get(nm))
+    ierr = C.c_int(0)
+    v = np.ascontiguousarray(plevel, dtype=np.float64)
+    ref.ref.lib.ref_set_vec(b"plevel", v.ctypes.data_as(C.c_void_p), C.c_int(kk), C.byref(ierr))
+    assert ierr.value == 0
+    tag = 2 if vcoord == "cntiso_hybrid" else 3
+    ref.ref.set("vcoord_tag", 2)                # the reader resolves regrid_method only for 'cntiso_hybrid'
+    ref.ref.set("swamxd", 200.0)
+    ref.ref.set("brine_mlbase_frac", 0.4)
+    gpu.set("vcoord_type", vcoord)
+    gpu.set("ale_regrid_method", method)
+    gpu.set_vector("plevel", plevel)
+    gpu.set("swamxd", 200.0)
+    gpu.set("brine_mlbase_frac", 0.4)
+    six0 = hostinit.step_indices(0, kk)
+    if lib not in _INITIALISED:
+        (tmp_path / "limits").write_text(_limits(method))
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            ref.ref.stage("ale_init", *six0)
+        finally:
+            os.chdir(cwd)
+        _INITIALISED.add(lib)
+    try:
+        ref.ref.set("vcoord_tag", tag)
+        # blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first ale_forcing reads
+        ref.ref.stage("cmnfld1", *six0)
+        gpu.stage("cmnfld1", *six0)
+        nr = ng = 0
+        for _ in range(nsteps):
+            nr = dyncore_step(ref, nr, case.params["baclin"], stages=HYBRID_STAGES)
+            ng = gpu.step(ng, 1)
+            bad = diff_report(ref, gpu, fields=[nm for nm in CHECK if nm not in SCRATCH])
+            assert not bad, f"step {nr}\n" + fmt_report(bad[:12])
+        wu = (ref.masks["iu"][4:-4, 4:-4] > 0)[None]
+        uu = gpu.get("u")[:, 4:-4, 4:-4]
+        assert np.isfinite(uu[np.broadcast_to(wu, uu.shape)]).all() and np.abs(uu[np.broadcast_to(wu, uu.shape)]).max() > 0.0
+    finally:
+        ref.ref.set("vcoord_tag", 1)
+        gpu.close()
