@@ -38,7 +38,34 @@ OPTIONS = {
                   velocity_pc_upper_bndr=True, velocity_pc_lower_bndr=False),
 }
 OUT = ["dp", "temp", "saln", "sigma", "trc", "u", "v", "dpu", "dpv", "dpuold", "dpvold", "p", "pu", "pv"]
-_INITIALISED = set()
+
+
+def ale_init_once(ref, lib, o, six, tmp_path):
+    """readnml_ale_regrid_remap + init_ale_regrid_remap of a reference library, once per process (the flag lives on the shared
+    backend object: tests/test_xcheck_hybrid_step.py uses the same libraries with the same option sets)"""
+    if getattr(ref, "_ale_options", None) is not None:
+        assert ref._ale_options == o, "the reference library's ALE structures were initialised with other options"
+        return
+    ref.ref.set("vcoord_tag", 2)               # the reader resolves regrid_method only for 'cntiso_hybrid' (:1323)
+    (tmp_path / "limits").write_text(_limits_text(o))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        ref.ref.stage("ale_init", *six)
+    finally:
+        os.chdir(cwd)
+    ref._ale_options = dict(o)
+
+
+def set_device_ale_options(gpu, o):
+    gpu.set("ale_regrid_method", o["regrid_method"])
+    gpu.set("ale_reconstruction_method", o["reconstruction_method"])
+    gpu.set("ale_tracer_limiting", o["tracer_limiting"])
+    gpu.set("ale_velocity_limiting", o["velocity_limiting"])
+    for nm in ("upper_bndr_ord", "lower_bndr_ord"):
+        gpu.set("ale_" + nm, int(o[nm]))
+    for nm in ("tracer_pc_upper_bndr", "tracer_pc_lower_bndr", "velocity_pc_upper_bndr", "velocity_pc_lower_bndr"):
+        gpu.set("ale_" + nm, 1 if o[nm] else 0)
 
 
 def _limits_text(o):
@@ -90,16 +117,7 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vco
     ref.ref.lib.ref_set_vec(b"plevel", v.ctypes.data_as(C.c_void_p), C.c_int(kk), C.byref(ierr))
     assert ierr.value == 0
     six = hostinit.step_indices(nsteps, kk)
-    if lib not in _INITIALISED:
-        ref.ref.set("vcoord_tag", 2)           # the reader resolves regrid_method only for 'cntiso_hybrid' (:1323)
-        (tmp_path / "limits").write_text(_limits_text(o))
-        cwd = os.getcwd()
-        os.chdir(tmp_path)
-        try:
-            ref.ref.stage("ale_init", *six)
-        finally:
-            os.chdir(cwd)
-        _INITIALISED.add(lib)
+    ale_init_once(ref, lib, o, six, tmp_path)
     try:
         ref.ref.set("vcoord_tag", tag)
         delt1 = 2.0 * case.params["baclin"]            # the nudging factor and the smoothing's diffusion read it
@@ -109,14 +127,7 @@ def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vco
         ref.ref.stage("ale_regrid_remap", *six)
         # device
         gpu.set("vcoord_type", vcoord)
-        gpu.set("ale_regrid_method", method)
-        gpu.set("ale_reconstruction_method", o["reconstruction_method"])
-        gpu.set("ale_tracer_limiting", o["tracer_limiting"])
-        gpu.set("ale_velocity_limiting", o["velocity_limiting"])
-        for nm in ("upper_bndr_ord", "lower_bndr_ord"):
-            gpu.set("ale_" + nm, int(o[nm]))
-        for nm in ("tracer_pc_upper_bndr", "tracer_pc_lower_bndr", "velocity_pc_upper_bndr", "velocity_pc_lower_bndr"):
-            gpu.set("ale_" + nm, 1 if o[nm] else 0)
+        set_device_ale_options(gpu, o)
         gpu.set_vector("plevel", plevel)
         if tag == 2:
             gpu.put("sigint", pre_sigint)          # the reference's initial pattern (spval) where the stage does not write

@@ -18,9 +18,9 @@ from blom_amd.cases import make_case
 from blom_amd import hostinit
 from blom_amd.stepper import dyncore_step, HYBRID_STAGES
 from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, GRID_FIELDS, INT_FIELDS
+from test_xcheck_ale import OPTIONS, ale_init_once, set_device_ale_options
 
 pytestmark = pytest.mark.gpu
-_INITIALISED = set()
 ALE_FIELDS = ["kvisc_m", "kdiff_t", "kdiff_s", "t_ns_nonloc", "s_nb_nonloc", "t_sw_nonloc", "t_rs_nonloc", "s_br_nonloc",
               "s_rs_nonloc", "mu_nonloc", "mv_nonloc", "surflx", "sswflx", "surrlx", "salflx", "brnflx", "salrlx", "salt_corr",
               "trc_corr", "trflx", "swfc1", "swfc2", "swal1", "swal2", "mld", "mldl82", "dpml", "buoyfl", "sigint", "bfsqi",
@@ -31,13 +31,6 @@ CHECK = STATE_FIELDS + ["sigint", "t_sw_nonloc", "s_br_nonloc", "buoyfl", "salt_
 
 # work arrays of mod_utility that stages use as scratch (cppm leaves parts of them as they were)
 SCRATCH = ("util1", "util2", "util3", "util4", "utotm", "vtotm", "uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3")
-
-
-def _limits(method):
-    return (" &ALE_REGRID_REMAP\n  RECONSTRUCTION_METHOD = 'ppm'\n  UPPER_BNDR_ORD = 6\n  LOWER_BNDR_ORD = 4\n"
-            "  DENSITY_LIMITING = 'monotonic'\n  TRACER_LIMITING = 'non_oscillatory'\n  VELOCITY_LIMITING = 'non_oscillatory'\n"
-            "  TRACER_PC_UPPER_BNDR = .true.\n  TRACER_PC_LOWER_BNDR = .false.\n  VELOCITY_PC_UPPER_BNDR = .true.\n"
-            f"  VELOCITY_PC_LOWER_BNDR = .false.\n  REGRID_METHOD = '{method}'\n /\n")
 
 
 @pytest.mark.parametrize("cfg,advmth,method,vcoord,nsteps", [
@@ -101,21 +94,14 @@ def test_hybrid_step_equals_the_reference_stage_sequence(cfg, advmth, method, vc
     ref.ref.set("vcoord_tag", 2)                # the reader resolves regrid_method only for 'cntiso_hybrid'
     ref.ref.set("swamxd", 200.0)
     ref.ref.set("brine_mlbase_frac", 0.4)
+    o = dict(OPTIONS[cfg], regrid_method=method)       # one option set per reference library and process (tests/test_xcheck_ale.py)
     gpu.set("vcoord_type", vcoord)
-    gpu.set("ale_regrid_method", method)
+    set_device_ale_options(gpu, o)
     gpu.set_vector("plevel", plevel)
     gpu.set("swamxd", 200.0)
     gpu.set("brine_mlbase_frac", 0.4)
     six0 = hostinit.step_indices(0, kk)
-    if lib not in _INITIALISED:
-        (tmp_path / "limits").write_text(_limits(method))
-        cwd = os.getcwd()
-        os.chdir(tmp_path)
-        try:
-            ref.ref.stage("ale_init", *six0)
-        finally:
-            os.chdir(cwd)
-        _INITIALISED.add(lib)
+    ale_init_once(ref, lib, o, six0, tmp_path)
     try:
         ref.ref.set("vcoord_tag", tag)
         # blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first ale_forcing reads
