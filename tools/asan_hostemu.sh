@@ -1,7 +1,8 @@
 #!/bin/bash
 # TEST INFRASTRUCTURE: the device library's kernels, compiled for the host with AddressSanitizer (make -C tests/hostemu asan),
 # stepped through whole stage sequences -- small grids, 6 and 11 tracers, cppm, the arctic patch, a barotropic solve with one
-# kernel per equation, and 3-8 emulated RCCL ranks with the decomposed and the replicated barotropic solve.  GPU address
+# kernel per equation, the step of the hybrid vertical coordinate (ale_regrid_remap, ale_forcing, ale_vdifft/m, ..), and 3-8 emulated
+# RCCL ranks with the decomposed and the replicated barotropic solve.  GPU address
 # sanitizer runs are not available on the pool; this is the CPU-side check.  Prints one line per case; any ASan report fails it.
 cd "$(dirname "$0")/.." || exit 1
 make -C tests/hostemu asan -j8 > /dev/null || exit 1
@@ -35,6 +36,35 @@ run("fuk95", advmth="cppm")
 run("tri_s", advmth="cppm")
 run("chan_m", steps=2, barotp_fused=0)
 run("tri_m", steps=2)
+# the step of the hybrid vertical coordinate (ale_regrid_remap with both coordinates and regrid methods, ale_forcing, ale_vdifft/m ..)
+def hybrid(cfg, vcoord, method, advmth="remap", steps=3):
+    case = make_case(cfg, advmth=advmth)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    z = np.arange(kk + 1)[:, None, None] / kk
+    frac = np.clip(1.0 - z / 0.4, 0.0, 1.0) ** 2 * np.ones((1, nj, ni))
+    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
+        gpu.put(nm, 1e-4 * np.ones((kk + 1, nj, ni)))
+    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
+        gpu.put(nm, frac)
+    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -50.), ("sswflx", -80.), ("salflx", 1e-3)):
+        gpu.put(nm, v * np.ones((1, nj, ni)))
+    pbot = float(np.max(gpu.get("p")[kk][4:-4, 4:-4][ip[4:-4, 4:-4] > 0]))
+    gpu.set("vcoord_type", vcoord)
+    gpu.set("ale_regrid_method", method)
+    gpu.set_vector("plevel", 0.3 * pbot * (np.arange(kk) / kk) ** 1.3)
+    gpu.stage("cmnfld1", *hostinit.step_indices(0, kk))
+    ns = gpu.step(0, steps)
+    u = gpu.get("u")[:, 4:-4, 4:-4]
+    assert np.isfinite(u[np.broadcast_to((iu[4:-4, 4:-4] > 0)[None], u.shape)]).all()
+    print(cfg, vcoord, method, advmth, "hybrid step ok", ns, flush=True)
+    gpu.close()
+hybrid("chan_s", "cntiso_hybrid", "nudge")
+hybrid("tri_s", "cntiso_hybrid", "direct")
+hybrid("box_s", "plevel", "direct", advmth="cppm")
+hybrid("fuk95", "plevel", "nudge", advmth="cppm", steps=2)
 import test_hostemu_multirank as t
 for cfg, isz, jsz in (("chan_s", (7, 7, 6), (13, 11)), ("tri_s_tke", (6, 6, 6, 6), (10, 10))):
     for g in (True, False):
