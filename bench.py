@@ -372,6 +372,53 @@ def bench_ale(args):
     print(json.dumps(out))
 
 
+def bench_hybrid_step(args):
+    """`--config hybrid`: the step of the hybrid vertical coordinate as far as it is built on
+    BASELINE's channel: ale_regrid_remap (cntiso_hybrid, nudge, ppm: the options of the reference's tests/fuk95/limits), cmnfld2,
+    advect (remap), pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2,
+    cmnfld1; vertical diffusivities, non-local fractions and surface fluxes constant in time (their producers need CVMix / forcing
+    files).  One JSON line, no CPU baseline (the reference's OpenMP builds of the channel do not contain the ALE modules)."""
+    import numpy as np
+    from blom_amd.gpu import BlomGpu
+    from blom_amd import hostinit
+    case, nreg, masks = build_case("channel")
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    z = np.arange(kk + 1)[:, None, None] / kk
+    frac = np.clip(1.0 - z / 0.2, 0.0, 1.0) ** 2 * np.ones((1, nj, ni))
+    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
+        gpu.put(nm, 1e-5 + 1e-3 * np.exp(-((z - 0.03) / 0.05) ** 2) * np.ones((1, nj, ni)))
+    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
+        gpu.put(nm, frac)
+    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -40.), ("sswflx", -60.), ("salflx", 5e-4)):
+        gpu.put(nm, v * np.ones((1, nj, ni)))
+    pbot = float(np.max(gpu.get("p")[kk][4:-4, 4:-4][masks["ip"][4:-4, 4:-4] > 0]))
+    gpu.set("vcoord_type", "cntiso_hybrid")
+    gpu.set("ale_regrid_method", "nudge")
+    gpu.set_vector("plevel", 0.05 * pbot * (np.arange(kk) / kk) ** 1.3)
+    gpu.stage("cmnfld1", *hostinit.step_indices(0, kk))
+    ns = gpu.step(0, max(2, args.warmup))
+    gpu.sync()
+    t0 = time.perf_counter()
+    ns = gpu.step(ns, args.steps)
+    gpu.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    u = gpu.get("u")[:, 4:-4, 4:-4]
+    finite = bool(np.isfinite(u[np.broadcast_to((masks["iu"][4:-4, 4:-4] > 0)[None], u.shape)]).all())
+    baclin = case.params["baclin"]
+    out = {"metric": "simulated-days/sec", "value": baclin / 86400.0 / dt, "unit": "simulated-days/sec", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"channel {case.idm}x{case.jdm}x{kk}, ntr={case.ntr}: the step of vcoord_type = cntiso_hybrid as far as built "
+                                  "(ale_regrid_remap nudge/ppm, cmnfld2, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
+                                  "ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1); diffusivities, non-local fractions, surface fluxes constant",
+                      "parity": "cross-checked stage sequence (tests/test_xcheck_hybrid_step.py)", "state_finite": finite},
+           "roofline": None}
+    gpu.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,6 +451,8 @@ def main():
         return bench_hor3map(args)
     if args.config == "ale":
         return bench_ale(args)
+    if args.config == "hybrid":
+        return bench_hybrid_step(args)
 
     from blom_amd import launch
     env = launch.rank_env()

@@ -163,6 +163,13 @@ __global__ __launch_bounds__(H3_BLOCK) void k_h3m_remap_many(H3Grid g, H3SrcSet 
   h3_report(err_f + (size_t)f * g.nc, ff, col, h3_remap(g, S.s[f], r, S.io[f], col));
 }
 
+__global__ __launch_bounds__(H3_BLOCK) void k_h3m_extract_many(H3Grid g, H3SrcSet S, int *err_f, unsigned long long *ff) {
+  const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
+  if (col >= g.nc) return;
+  const int f = blockIdx.y;
+  h3_report(err_f + (size_t)f * g.nc, ff, col, h3_extract_polycoeff(g, S.s[f], S.io[f], col));
+}
+
 constexpr int E_DEVICE = -1, E_ALLOC = -2, E_HANDLE = -3, E_ARG = -4;
 thread_local std::string g_devmsg;
 
@@ -447,15 +454,39 @@ int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream) {
   G->own_stream = false;
   return 0;
 }
+// inside the library: the launches that follow go to another stream (the caller orders the streams with events); no
+// synchronisation, the grid does not own either stream
+int h3m_set_stream(blomgpu_h3m_grid *G, hipStream_t stream) {
+  if (!G || G->own_stream) return E_HANDLE;
+  G->stream = stream;
+  return 0;
+}
+// inside the library: the polynomial coefficients of several sources of one grid in one launch, written where the caller's
+// [coefficient * level][column] planes lie
+int h3m_extract_polycoeff_many(blomgpu_h3m_grid *G, int nf, blomgpu_h3m_src *const *srcs, double *const *outs) {
+  if (!G || !G->plane_io || nf < 1 || nf > H3_MAXF) return E_HANDLE;
+  if (!G->err_many && hipMalloc((void **)&G->err_many, sizeof(int) * H3_MAXF * G->g.nc) != hipSuccess) return E_ALLOC;
+  H3SrcSet S{};
+  for (int f = 0; f < nf; f++) {
+    if (!srcs[f] || srcs[f]->grid != G) return H3_INCONSISTENT_RCGS;
+    S.s[f] = srcs[f]->s;
+    S.io[f] = outs[f];
+  }
+  hipLaunchKernelGGL(k_h3m_extract_many, dim3(col_grid(G).x, nf), dim3(H3_BLOCK), 0, G->stream, G->g, S, G->err_many, G->first_fail);
+  return end_call(G);
+}
 extern "C" {
 
 int blomgpu_h3m_prepare_reconstruction(blomgpu_h3m_grid *G, const double *x_edge_src) {
   if (!G || !x_edge_src) return E_HANDLE;
   int rc = begin_call(G);
   if (rc) return rc;
-  if ((rc = load_input(G, x_edge_src, G->g.n_src + 1, G->g.xin))) return rc;
+  // the caller's edges are read by this kernel alone (hor3map_core.h: g.xin): planes are taken where they lie
+  H3Grid g = G->g;
+  if (G->plane_io) g.xin = const_cast<double *>(x_edge_src);
+  else if ((rc = load_input(G, x_edge_src, G->g.n_src + 1, G->g.xin))) return rc;
   H3CHK(hipEventRecord(G->ev0, G->stream));
-  hipLaunchKernelGGL(k_h3m_prepare, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, G->first_fail);
+  hipLaunchKernelGGL(k_h3m_prepare, col_grid(G), dim3(H3_BLOCK), 0, G->stream, g, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
   return end_call(G);
 }
@@ -466,11 +497,14 @@ int blomgpu_h3m_reconstruct(blomgpu_h3m_grid *G, blomgpu_h3m_src *S, const doubl
   int rc = begin_call(G);
   if (rc) return rc;
   const size_t n = (size_t)G->g.n_src * G->g.nc;
-  if (!grow(G, G->tin, G->tin_n, n)) return E_ALLOC;
-  if ((rc = load_input(G, u_src, G->g.n_src, G->tin))) return rc;
+  const double *uin = u_src;
+  if (!G->plane_io) {
+    if (!grow(G, G->tin, G->tin_n, n)) return E_ALLOC;
+    if ((rc = load_input(G, u_src, G->g.n_src, G->tin))) return rc;
+    uin = G->tin;
+  }
   H3CHK(hipEventRecord(G->ev0, G->stream));
-  hipLaunchKernelGGL(k_h3m_reconstruct, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s,
-                     (const double *)G->tin, G->first_fail);
+  hipLaunchKernelGGL(k_h3m_reconstruct, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, uin, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
   return end_call(G);
 }
@@ -481,11 +515,15 @@ int blomgpu_h3m_extract_polycoeff(blomgpu_h3m_src *S, double *polycoeff) {
   int rc = begin_call(G);
   if (rc) return rc;
   const int m = (G->g.p_ord + 1) * G->g.n_src;
-  if (!grow(G, G->tout, G->tout_n, (size_t)m * G->g.nc)) return E_ALLOC;
+  double *out = polycoeff;
+  if (!G->plane_io) {
+    if (!grow(G, G->tout, G->tout_n, (size_t)m * G->g.nc)) return E_ALLOC;
+    out = G->tout;
+  }
   H3CHK(hipEventRecord(G->ev0, G->stream));
-  hipLaunchKernelGGL(k_h3m_extract, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, G->tout, G->first_fail);
+  hipLaunchKernelGGL(k_h3m_extract, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, out, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
-  if ((rc = store_output(G, G->tout, m, polycoeff))) return rc;
+  if (!G->plane_io && (rc = store_output(G, G->tout, m, polycoeff))) return rc;
   return end_call(G);
 }
 
@@ -498,13 +536,19 @@ int blomgpu_h3m_regrid(blomgpu_h3m_src *S, int n_grd, const double *u_edge_grd, 
   int rc = begin_call(G);
   if (rc) return rc;
   const size_t n = (size_t)n_grd * G->g.nc;
-  if (!grow(G, G->tin, G->tin_n, n) || !grow(G, G->tout, G->tout_n, n)) return E_ALLOC;
-  if ((rc = load_input(G, u_edge_grd, n_grd, G->tin))) return rc;
+  const double *ugrd = u_edge_grd;
+  double *xgrd = x_edge_grd;
+  if (!G->plane_io) {
+    if (!grow(G, G->tin, G->tin_n, n) || !grow(G, G->tout, G->tout_n, n)) return E_ALLOC;
+    if ((rc = load_input(G, u_edge_grd, n_grd, G->tin))) return rc;
+    ugrd = G->tin;
+    xgrd = G->tout;
+  }
   H3CHK(hipEventRecord(G->ev0, G->stream));
-  hipLaunchKernelGGL(k_h3m_regrid, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, n_grd,
-                     (const double *)G->tin, G->tout, missing_value, regrid_method, G->first_fail);
+  hipLaunchKernelGGL(k_h3m_regrid, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, n_grd, ugrd, xgrd, missing_value,
+                     regrid_method, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
-  if ((rc = store_output(G, G->tout, n_grd, x_edge_grd))) return rc;
+  if (!G->plane_io && (rc = store_output(G, G->tout, n_grd, x_edge_grd))) return rc;
   return end_call(G);
 }
 
@@ -514,11 +558,14 @@ int blomgpu_h3m_prepare_remapping(blomgpu_h3m_grid *G, blomgpu_h3m_map *M, const
   int rc = begin_call(G);
   if (rc) return rc;
   const int m = M->r.n_dst + 1;
-  if (!grow(G, G->tin, G->tin_n, (size_t)m * G->g.nc)) return E_ALLOC;
-  if ((rc = load_input(G, x_edge_dst, m, G->tin))) return rc;
+  const double *xdst = x_edge_dst;
+  if (!G->plane_io) {
+    if (!grow(G, G->tin, G->tin_n, (size_t)m * G->g.nc)) return E_ALLOC;
+    if ((rc = load_input(G, x_edge_dst, m, G->tin))) return rc;
+    xdst = G->tin;
+  }
   H3CHK(hipEventRecord(G->ev0, G->stream));
-  hipLaunchKernelGGL(k_h3m_prepare_remap, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, M->r,
-                     (const double *)G->tin, G->first_fail);
+  hipLaunchKernelGGL(k_h3m_prepare_remap, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, M->r, xdst, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
   return end_call(G);
 }
@@ -530,12 +577,15 @@ int blomgpu_h3m_remap(blomgpu_h3m_src *S, blomgpu_h3m_map *M, double *u_dst) {
   int rc = begin_call(G);
   if (rc) return rc;
   const int m = M->r.n_dst;
-  if (!grow(G, G->tout, G->tout_n, (size_t)m * G->g.nc)) return E_ALLOC;
+  double *out = u_dst;
+  if (!G->plane_io) {
+    if (!grow(G, G->tout, G->tout_n, (size_t)m * G->g.nc)) return E_ALLOC;
+    out = G->tout;
+  }
   H3CHK(hipEventRecord(G->ev0, G->stream));
-  hipLaunchKernelGGL(k_h3m_remap, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, M->r, G->tout,
-                     G->first_fail);
+  hipLaunchKernelGGL(k_h3m_remap, col_grid(G), dim3(H3_BLOCK), 0, G->stream, G->g, S->s, M->r, out, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
-  if ((rc = store_output(G, G->tout, m, u_dst))) return rc;
+  if (!G->plane_io && (rc = store_output(G, G->tout, m, u_dst))) return rc;
   return end_call(G);
 }
 
@@ -545,12 +595,13 @@ int blomgpu_h3m_reconstruct_many(blomgpu_h3m_grid *G, int nf, blomgpu_h3m_src *c
   int rc = begin_call(G);
   if (rc) return rc;
   const size_t per = (size_t)G->g.n_src * G->g.nc;
-  if (!grow(G, G->tmany, G->tmany_n, per * H3_MAXF)) return E_ALLOC;
+  if (!G->plane_io && !grow(G, G->tmany, G->tmany_n, per * H3_MAXF)) return E_ALLOC;
   if (!G->err_many && hipMalloc((void **)&G->err_many, sizeof(int) * H3_MAXF * G->g.nc) != hipSuccess) return E_ALLOC;
   H3SrcSet S{};
   for (int f = 0; f < nf; f++) {
     if (!srcs[f] || srcs[f]->grid != G) return H3_INCONSISTENT_RCGS;
     S.s[f] = srcs[f]->s;
+    if (G->plane_io) { S.io[f] = const_cast<double *>(u_srcs[f]); continue; }
     S.io[f] = G->tmany + (size_t)f * per;
     if ((rc = load_input(G, u_srcs[f], G->g.n_src, S.io[f]))) return rc;
   }
@@ -567,19 +618,19 @@ int blomgpu_h3m_remap_many(int nf, blomgpu_h3m_src *const *srcs, blomgpu_h3m_map
   int rc = begin_call(G);
   if (rc) return rc;
   const size_t per = (size_t)M->r.n_dst * G->g.nc;
-  if (!grow(G, G->tmany, G->tmany_n, per * H3_MAXF)) return E_ALLOC;
+  if (!G->plane_io && !grow(G, G->tmany, G->tmany_n, per * H3_MAXF)) return E_ALLOC;
   if (!G->err_many && hipMalloc((void **)&G->err_many, sizeof(int) * H3_MAXF * G->g.nc) != hipSuccess) return E_ALLOC;
   H3SrcSet S{};
   for (int f = 0; f < nf; f++) {
     if (!srcs[f] || srcs[f]->grid != G) return H3_INCONSISTENT_RCGS;
     S.s[f] = srcs[f]->s;
-    S.io[f] = G->tmany + (size_t)f * per;
+    S.io[f] = G->plane_io ? u_dsts[f] : G->tmany + (size_t)f * per;
   }
   H3CHK(hipEventRecord(G->ev0, G->stream));
   hipLaunchKernelGGL(k_h3m_remap_many, dim3(col_grid(G).x, nf), dim3(H3_BLOCK), 0, G->stream, G->g, S, M->r,
                      G->err_many, G->first_fail);
   H3CHK(hipEventRecord(G->ev1, G->stream));
-  for (int f = 0; f < nf; f++)
+  for (int f = 0; f < nf && !G->plane_io; f++)
     if ((rc = store_output(G, S.io[f], M->r.n_dst, u_dsts[f]))) return rc;
   return end_call(G);
 }

@@ -28,14 +28,23 @@
 int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream);          // hor3map.hip
 int h3m_sequence_begin(blomgpu_h3m_grid *G);
 int h3m_sequence_end(blomgpu_h3m_grid *G);
+int h3m_set_stream(blomgpu_h3m_grid *G, hipStream_t stream);
+int h3m_extract_polycoeff_many(blomgpu_h3m_grid *G, int nf, blomgpu_h3m_src *const *srcs, double *const *outs);
 
 #define H3M_MAXF 8
 
 struct AleState {
   blomgpu_h3m_grid *grid = nullptr;
   std::vector<blomgpu_h3m_src *> trc;       // T, S, tracers (init_ale_regrid_remap :1412-1432)
-  blomgpu_h3m_src *vel = nullptr, *dens = nullptr;
+  blomgpu_h3m_src *dens = nullptr;
   blomgpu_h3m_map *map = nullptr;
+  // the u- and the v-columns side by side as ONE grid of 2 * nplane columns: every launch of the velocity part carries both
+  // (the column routines are bound by the latency of a thread's own loads; twice the wavefronts hide twice as much of it)
+  blomgpu_h3m_grid *grid_uv = nullptr;
+  blomgpu_h3m_src *vel = nullptr;
+  blomgpu_h3m_map *map_uv = nullptr;
+  hipStream_t side = nullptr;               // launches that do not depend on each other run beside the model's stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *plane = nullptr;                  // scratch: p_src, p_dst (kk+1 planes each), remapped fields (kk planes each)
   size_t plane_n = 0;
   int ntr_loc = 0, method = 0;
@@ -45,6 +54,10 @@ void ale_free(blomgpu_ctx *c) {
   AleState *a = (AleState *)c->ale;
   if (!a) return;
   if (a->grid) blomgpu_h3m_grid_free(a->grid);             // frees the sources and the map too
+  if (a->grid_uv) blomgpu_h3m_grid_free(a->grid_uv);
+  if (a->side) (void)hipStreamDestroy(a->side);
+  if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
+  if (a->ev_join) (void)hipEventDestroy(a->ev_join);
   if (a->plane) (void)hipFree(a->plane);
   delete a;
   c->ale = nullptr;
@@ -76,8 +89,16 @@ static int ale_prepare(blomgpu_ctx *c) {
     if ((rc = blomgpu_h3m_src_create(a->grid, &s, lim, c->ale_tracer_pc_upper, c->ale_tracer_pc_lower))) return ale_fail(c, "initialize_rcss", rc);
     a->trc.push_back(s);
   }
-  if ((rc = blomgpu_h3m_src_create(a->grid, &a->vel, c->ale_velocity_limiting, c->ale_velocity_pc_upper, c->ale_velocity_pc_lower)))
+  if ((rc = blomgpu_h3m_grid_create(&a->grid_uv, c->device, 2 * (int)h.nplane, h.kk, c->ale_method, c->ale_upper_bndr_ord, c->ale_lower_bndr_ord)))
+    return ale_fail(c, "initialize_rcgs", rc);
+  if ((rc = h3m_use_stream(a->grid_uv, c->stream))) return ale_fail(c, "stream", rc);
+  (void)blomgpu_h3m_set_io(a->grid_uv, 2, 1);
+  if ((rc = blomgpu_h3m_src_create(a->grid_uv, &a->vel, c->ale_velocity_limiting, c->ale_velocity_pc_upper, c->ale_velocity_pc_lower)))
     return ale_fail(c, "initialize_rcss", rc);
+  if ((rc = blomgpu_h3m_map_create(a->grid_uv, &a->map_uv, h.kk))) return ale_fail(c, "initialize_rms", rc);
+  HIPCHK(c, hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
   // potential density: density_limiting = 'monotonic' is the only value the reference accepts (:1287-1297)
   if ((rc = blomgpu_h3m_src_create(a->grid, &a->dens, BLOMGPU_H3M_MONOTONIC, c->ale_density_pc_upper, c->ale_density_pc_lower)))
     return ale_fail(c, "initialize_rcss", rc);
@@ -662,33 +683,40 @@ __global__ void k_ale_pscan(const DevView *__restrict__ Vp, int nn) {
   for (int k = 0; k < V.kk; k++) { a = a + V.f[F_dp][c + (size_t)(k + nn) * np]; V.f[F_p][c + (size_t)(k + 1) * np] = a; }
 }
 
-// source and destination interfaces of the u- (isv = 0) or v-columns (:1768-1779, :1836-1847): the source interfaces are the
-// old ones rescaled to the new depth of the column
-__global__ void k_ale_uv_src_dst(const DevView *__restrict__ Vp, int nn, int isv, double *__restrict__ psrc, double *__restrict__ pdst) {
+// source and destination interfaces of the u- (blockIdx.y = 0) and the v-columns (1) (:1768-1779, :1836-1847), and the
+// velocities themselves, as columns c and nplane + c of one grid of 2 * nplane columns: the source interfaces are the old ones
+// rescaled to the new depth of the column
+__global__ void k_ale_uv_src_dst(const DevView *__restrict__ Vp, int nn, double *__restrict__ psrc, double *__restrict__ pdst,
+                                 double *__restrict__ uin) {
   const DevView &V = *Vp;
   PLANE_T(V);
-  const size_t np = V.nplane;
+  const int isv = blockIdx.y;
+  const size_t np = V.nplane, nc = 2 * np, cc = c + (size_t)isv * np;
   const int kk = V.kk;
   const bool col = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && (isv ? V.m[I_iv][c] : V.m[I_iu][c]);
   if (!col) {
-    for (int k = 0; k <= kk; k++) { psrc[c + (size_t)k * np] = (double)k; pdst[c + (size_t)k * np] = (double)k; }
+    for (int k = 0; k <= kk; k++) { psrc[cc + (size_t)k * nc] = (double)k; pdst[cc + (size_t)k * nc] = (double)k; }
+    for (int k = 0; k < kk; k++) uin[cc + (size_t)k * nc] = 0.;
     return;
   }
   const double *pz = isv ? V.f[F_pv] : V.f[F_pu], *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  const double *uz = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
   double a = pz[c];
-  pdst[c] = a;
-  for (int k = 0; k < kk; k++) { a = a + dpz[c + (size_t)k * np]; pdst[c + (size_t)(k + 1) * np] = a; }
+  pdst[cc] = a;
+  for (int k = 0; k < kk; k++) { a = a + dpz[c + (size_t)k * np]; pdst[cc + (size_t)(k + 1) * nc] = a; }
   const double *u1 = V.f[F_util1];
   const double q = fmin2(u1[isv ? c - V.ni : c - 1], u1[c]) / pz[c + (size_t)kk * np];
-  for (int k = 0; k <= kk; k++) psrc[c + (size_t)k * np] = pz[c + (size_t)k * np] * q;
+  for (int k = 0; k <= kk; k++) psrc[cc + (size_t)k * nc] = pz[c + (size_t)k * np] * q;
+  for (int k = 0; k < kk; k++) uin[cc + (size_t)k * nc] = uz[c + (size_t)k * np];
 }
 
-__global__ void k_ale_uv_back(const DevView *__restrict__ Vp, int nn, int isv, const double *__restrict__ rm) {
+__global__ void k_ale_uv_back(const DevView *__restrict__ Vp, int nn, const double *__restrict__ rm) {
   const DevView &V = *Vp;
   PLANE_T(V);
+  const int isv = blockIdx.z;
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const int k = blockIdx.y;
-  (isv ? V.f[F_v] : V.f[F_u])[c + (size_t)(k + nn) * V.nplane] = rm[c + (size_t)k * V.nplane];
+  (isv ? V.f[F_v] : V.f[F_u])[c + (size_t)(k + nn) * V.nplane] = rm[c + (size_t)isv * V.nplane + (size_t)k * 2 * V.nplane];
 }
 
 int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
@@ -704,7 +732,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   double *psrc = a->plane, *pdst = psrc + (size_t)(h.kk + 1) * np, *rm = pdst + (size_t)(h.kk + 1) * np;
   const dim3 g1((unsigned)((np + 255) / 256)), gk((unsigned)((np + 255) / 256), h.kk), b(256);
   int rc;
-  if ((rc = h3m_sequence_begin(a->grid))) return ale_fail(c, "sequence", rc);      // one status read-back for the whole stage
+  if ((rc = h3m_sequence_begin(a->grid)) || (rc = h3m_sequence_begin(a->grid_uv))) return ale_fail(c, "sequence", rc);   // the status is read back once
   // ---- tracers ----------------------------------------------------------------------------------------------------------
   const bool nudge = h.P.vcoord_tag == 2 && c->ale_regrid_method == 2;
   const int ring = nudge && c->ale_smooth_diff_max > 0. ? 1 : 0;      // lateral smoothing reads the neighbours' regridded columns
@@ -715,14 +743,41 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   }
   hipLaunchKernelGGL(k_ale_p_src_dst, g1, b, 0, c->stream, c->d, nn, (const double *)c->ale_plevel, psrc, pdst, ring);
   if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid, psrc))) return ale_fail(c, "prepare_reconstruction", rc);
+  // Beside the model's stream: the reconstruction of the first batch's fields that the regridding does not look at -- all of
+  // them for pressure levels, the tracers for the density-following coordinate (T and S are reconstructed for the regridding
+  // and, the grid and the data being the same, not a second time for the remapping).
+  auto field = [&](int nt) -> const double * {
+    return nt == 0 ? h.f[F_temp] + (size_t)nn * np : nt == 1 ? h.f[F_saln] + (size_t)nn * np : h.f[F_trc] + ((size_t)nn + (size_t)(nt - 2) * 2 * h.kk) * np;
+  };
+  const int nf0 = a->ntr_loc < H3M_MAXF ? a->ntr_loc : H3M_MAXF, lo0 = h.P.vcoord_tag == 2 ? 2 : 0;
+  auto fork = [&]() -> int {
+    HIPCHK(c, hipEventRecord(a->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(a->side, a->ev_fork, 0));
+    return 0;
+  };
+  auto join = [&]() -> int {
+    HIPCHK(c, hipEventRecord(a->ev_join, a->side));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, a->ev_join, 0));
+    return 0;
+  };
+  if (nf0 > lo0) {
+    const double *us[H3M_MAXF];
+    blomgpu_h3m_src *ss[H3M_MAXF];
+    for (int f = lo0; f < nf0; f++) { us[f - lo0] = field(f); ss[f - lo0] = a->trc[f]; }
+    if (int rc2 = fork()) return rc2;
+    (void)h3m_set_stream(a->grid, a->side);
+    rc = blomgpu_h3m_reconstruct_many(a->grid, nf0 - lo0, ss, us);
+    (void)h3m_set_stream(a->grid, c->stream);
+    if (rc) return ale_fail(c, "reconstruct", rc);
+  }
   if (h.P.vcoord_tag == 2) {
     // regrid_cntiso_hybrid_direct_jslice: the interfaces go where the reconstructed potential density takes its target values
     double *pcT = rm + (size_t)H3M_MAXF * per, *pcS = pcT + (size_t)5 * per, *sgs = pcS + (size_t)5 * per, *sgt = sgs + per;
-    const double *ts[2] = {h.f[F_temp] + (size_t)nn * np, h.f[F_saln] + (size_t)nn * np};
+    const double *ts[2] = {field(0), field(1)};
     blomgpu_h3m_src *tss[2] = {a->trc[0], a->trc[1]};
+    double *pcs[2] = {pcT, pcS};
     if ((rc = blomgpu_h3m_reconstruct_many(a->grid, 2, tss, ts))) return ale_fail(c, "reconstruct", rc);
-    if ((rc = blomgpu_h3m_extract_polycoeff(a->trc[0], pcT))) return ale_fail(c, "extract_polycoeff", rc);
-    if ((rc = blomgpu_h3m_extract_polycoeff(a->trc[1], pcS))) return ale_fail(c, "extract_polycoeff", rc);
+    if ((rc = h3m_extract_polycoeff_many(a->grid, 2, tss, pcs))) return ale_fail(c, "extract_polycoeff", rc);
     const int npc = c->ale_method == BLOMGPU_H3M_PLM ? 2 : (c->ale_method == BLOMGPU_H3M_PPM ? 3 : 5);
     if (nudge) {
       // regrid_cntiso_hybrid_nudge_jslice; its work arrays lie where the remapped fields will (nothing has been remapped yet)
@@ -737,7 +792,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
         double *pout = sgs;                               // kk+1 planes: sgs and the first plane of sgt, both free again
         hipLaunchKernelGGL(k_ale_smooth, dim3((unsigned)((np + 255) / 256), h.kk + 1), b, 0, c->stream, c->d, c->ale_smooth_diff_max,
                            (const double *)pdst, (const double *)sfac, pout);
-        HIPCHK(c, hipMemcpyAsync(pdst, pout, sizeof(double) * (size_t)(h.kk + 1) * np, hipMemcpyDeviceToDevice, c->stream));
+        pdst = pout;                                      // the smoothed interfaces are the destination grid from here on
       }
     } else {
     hipLaunchKernelGGL(k_ale_direct_pre, g1, b, 0, c->stream, c->d, nn, (const double *)psrc, (const double *)pcT, (const double *)pcS,
@@ -749,19 +804,19 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     }
   }
   if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping", rc);
+  if (nf0 > lo0)
+    if (int rc2 = join()) return rc2;
   for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {
     const int nf = a->ntr_loc - f0 < H3M_MAXF ? a->ntr_loc - f0 : H3M_MAXF;
     const double *us[H3M_MAXF];
     double *ud[H3M_MAXF];
     blomgpu_h3m_src *ss[H3M_MAXF];
     for (int f = 0; f < nf; f++) {
-      const int nt = f0 + f;
-      us[f] = nt == 0 ? h.f[F_temp] + (size_t)nn * np
-            : nt == 1 ? h.f[F_saln] + (size_t)nn * np : h.f[F_trc] + ((size_t)nn + (size_t)(nt - 2) * 2 * h.kk) * np;
+      us[f] = field(f0 + f);
       ud[f] = rm + (size_t)f * per;
-      ss[f] = a->trc[nt];
+      ss[f] = a->trc[f0 + f];
     }
-    if ((rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
+    if (f0 > 0 && (rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
     if ((rc = blomgpu_h3m_remap_many(nf, ss, a->map, ud))) return ale_fail(c, "remap", rc);
     hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf);
   }
@@ -771,15 +826,23 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   hipLaunchKernelGGL(k_ale_pscan, g1, b, 0, c->stream, c->d, nn);
   // dpu, dpv of the new layers and their copies dpuold, dpvold, j,i = -1..+2 (:1735-1762)
   if (int rc2 = launch_dpudpv(c, nn, 4)) return rc2;
-  for (int isv = 0; isv < 2; isv++) {
-    hipLaunchKernelGGL(k_ale_uv_src_dst, g1, b, 0, c->stream, c->d, nn, isv, psrc, pdst);
-    if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid, psrc))) return ale_fail(c, "prepare_reconstruction (velocity)", rc);
-    if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping (velocity)", rc);
-    if ((rc = blomgpu_h3m_reconstruct(a->grid, a->vel, (isv ? h.f[F_v] : h.f[F_u]) + (size_t)nn * np))) return ale_fail(c, "reconstruct (velocity)", rc);
-    if ((rc = blomgpu_h3m_remap(a->vel, a->map, rm))) return ale_fail(c, "remap (velocity)", rc);
-    hipLaunchKernelGGL(k_ale_uv_back, gk, b, 0, c->stream, c->d, nn, isv, (const double *)rm);
+  {
+    // u- and v-columns as one grid of 2 * nplane columns; its planes lie where the tracers' scratch did
+    double *ps2 = a->plane, *pd2 = ps2 + (size_t)2 * (h.kk + 1) * np, *ui2 = pd2 + (size_t)2 * (h.kk + 1) * np, *rm2 = ui2 + (size_t)2 * per;
+    hipLaunchKernelGGL(k_ale_uv_src_dst, dim3((unsigned)((np + 255) / 256), 2), b, 0, c->stream, c->d, nn, ps2, pd2, ui2);
+    if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid_uv, ps2))) return ale_fail(c, "prepare_reconstruction (velocity)", rc);
+    // the segments of the destination grid and the reconstruction need the prepared grid, not each other
+    if (int rc2 = fork()) return rc2;
+    (void)h3m_set_stream(a->grid_uv, a->side);
+    rc = blomgpu_h3m_reconstruct(a->grid_uv, a->vel, ui2);
+    (void)h3m_set_stream(a->grid_uv, c->stream);
+    if (rc) return ale_fail(c, "reconstruct (velocity)", rc);
+    if ((rc = blomgpu_h3m_prepare_remapping(a->grid_uv, a->map_uv, pd2))) return ale_fail(c, "prepare_remapping (velocity)", rc);
+    if (int rc2 = join()) return rc2;
+    if ((rc = blomgpu_h3m_remap(a->vel, a->map_uv, rm2))) return ale_fail(c, "remap (velocity)", rc);
+    hipLaunchKernelGGL(k_ale_uv_back, dim3((unsigned)((np + 255) / 256), h.kk, 2), b, 0, c->stream, c->d, nn, (const double *)rm2);
   }
   HIPCHK(c, hipGetLastError());
-  if ((rc = h3m_sequence_end(a->grid))) return ale_fail(c, "a column failed", rc);
+  if ((rc = h3m_sequence_end(a->grid)) || (rc = h3m_sequence_end(a->grid_uv))) return ale_fail(c, "a column failed", rc);
   return 0;
 }

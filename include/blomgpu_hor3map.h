@@ -50,7 +50,8 @@ void blomgpu_h3m_grid_free(blomgpu_h3m_grid *grid);   /* free_rcgs :4858 (frees 
 
 /* device_pointers: 1 = array arguments are device pointers (same shapes); 2 = device pointers to arrays that are already
  * in the library's own layout, [level][column] with the column fastest -- the layout of the model's 3-D fields (no transpose:
- * the dynamical core's ale_regrid_remap calls the engine this way).  check_errors = 0 defers
+ * the dynamical core's ale_regrid_remap calls the engine this way; the kernels read and write those arrays where they lie,
+ * in stream order: they must not be changed before the call's kernels have run).  check_errors = 0 defers
  * the per-call status read-back (calls then return 0 unless the device layer fails; use
  * blomgpu_h3m_errstat / blomgpu_h3m_sync). */
 int  blomgpu_h3m_set_io(blomgpu_h3m_grid *grid, int device_pointers, int check_errors);
