@@ -375,9 +375,9 @@ def bench_ale(args):
 def bench_hybrid_step(args):
     """`--config hybrid`: the step of the hybrid vertical coordinate as far as it is built on
     BASELINE's channel: ale_regrid_remap (cntiso_hybrid, nudge, ppm: the options of the reference's tests/fuk95/limits), cmnfld2,
-    advect (remap), pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2,
-    cmnfld1; vertical diffusivities, non-local fractions and surface fluxes constant in time (their producers need CVMix / forcing
-    files).  One JSON line, no CPU baseline (the reference's OpenMP builds of the channel do not contain the ALE modules)."""
+    eddtra (eddtra_ale: Gent-McWilliams + fox08), advect (remap), pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft,
+    ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1; vertical diffusivities, non-local fractions, boundary layer depth and surface fluxes
+    constant in time (their producers need CVMix / forcing files).  One JSON line, no CPU baseline (the reference's OpenMP builds of the channel do not contain the ALE modules)."""
     import numpy as np
     from blom_amd.gpu import BlomGpu
     from blom_amd import hostinit
@@ -391,11 +391,13 @@ def bench_hybrid_step(args):
         gpu.put(nm, 1e-5 + 1e-3 * np.exp(-((z - 0.03) / 0.05) ** 2) * np.ones((1, nj, ni)))
     for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
         gpu.put(nm, frac)
-    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -40.), ("sswflx", -60.), ("salflx", 5e-4)):
+    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -40.), ("sswflx", -60.), ("salflx", 5e-4),
+                  ("OBLdepth", 40.)):
         gpu.put(nm, v * np.ones((1, nj, ni)))
     pbot = float(np.max(gpu.get("p")[kk][4:-4, 4:-4][masks["ip"][4:-4, 4:-4] > 0]))
     gpu.set("vcoord_type", "cntiso_hybrid")
     gpu.set("ale_regrid_method", "nudge")
+    gpu.set("mlrmth", "fox08")
     gpu.set_vector("plevel", 0.05 * pbot * (np.arange(kk) / kk) ** 1.3)
     gpu.stage("cmnfld1", *hostinit.step_indices(0, kk))
     ns = gpu.step(0, max(2, args.warmup))
@@ -411,8 +413,8 @@ def bench_hybrid_step(args):
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"channel {case.idm}x{case.jdm}x{kk}, ntr={case.ntr}: the step of vcoord_type = cntiso_hybrid as far as built "
-                                  "(ale_regrid_remap nudge/ppm, cmnfld2, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
-                                  "ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1); diffusivities, non-local fractions, surface fluxes constant",
+                                  "(ale_regrid_remap nudge/ppm, cmnfld2, eddtra_ale gm+fox08, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
+                                  "ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1); diffusivities, non-local fractions, boundary layer depth, surface fluxes constant",
                       "parity": "cross-checked stage sequence (tests/test_xcheck_hybrid_step.py)", "state_finite": finite},
            "roofline": None}
     gpu.close()

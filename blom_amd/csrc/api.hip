@@ -214,6 +214,15 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   if (s == "swamxd") { c->swamxd = v; return 0; }                           // phy/mod_swabs.F90:179-183
   if (s == "brine_mlbase_frac") { c->brine_mlbase_frac = v; return 0; }     // phy/mod_forcing.F90:63
   if (s == "ale_regrid_nudge_ts") { c->ale_regrid_nudge_ts = v; return 0; }
+  // mixed layer restratification of eddtra_ale, phy/mod_eddtra.F90:53-94
+  if (s == "ce") { c->eddtra_ce = v; return 0; }
+  if (s == "tau_mlr") { c->tau_mlr = v; return 0; }
+  if (s == "tau_growing_hbl") { c->tau_growing_hbl = v; return 0; }
+  if (s == "tau_decaying_hbl") { c->tau_decaying_hbl = v; return 0; }
+  if (s == "tau_growing_hml") { c->tau_growing_hml = v; return 0; }
+  if (s == "tau_decaying_hml") { c->tau_decaying_hml = v; return 0; }
+  if (s == "lfmin") { c->lfmin = v; return 0; }
+  if (s == "mlbl_max_ratio") { c->mlbl_max_ratio = v; return 0; }
   if (s == "ale_stab_fac_limit") { c->ale_stab_fac_limit = v; return 0; }
   if (s == "ale_dpvar_fac") { c->ale_dpvar_fac = v; return 0; }
   if (s == "ale_smooth_diff_max") { c->ale_smooth_diff_max = v; return 0; }
@@ -319,6 +328,12 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     if (v == "intdif") P.eitmth = 1; else if (v == "gm") P.eitmth = 2;
     else return ctx_fail(c, " eitmth = " + v + " is unsupported!");   // phy/mod_diffusion.F90:316-327
     c->dirty = true;
+    return 0;
+  }
+  if (s == "mlrmth") {                                    // init_eddtra, phy/mod_eddtra.F90:1773-1806
+    if (v == "none") c->mlrmth = 0; else if (v == "fox08") c->mlrmth = 1;
+    else if (v == "bod23") return ctx_fail(c, " init_eddtra: mlrmth = bod23 is not built (it needs ustar3, wstar3 of the CVMix-bound mod_difest)");
+    else return ctx_fail(c, " init_eddtra: mlrmth = " + v + " is unsupported!");
     return 0;
   }
   // &ALE_REGRID_REMAP, phy/mod_ale_regrid_remap.F90:1185-1355 (readnml_ale_regrid_remap; same words, same refusals)
@@ -627,7 +642,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
                               "barotp", "pbcor2", "tmsmt2"};
   // the other vertical coordinates (phy/mod_blom_step.F90:126-233 with vcoord_tag /= vcoord_isopyc_bulkml), as far as built:
   // blom_amd/stepper.py HYBRID_STAGES says what is left out and why
-  static const char *seq_ale[] = {"init_fluxes", "tmsmt1", "ale_regrid_remap", "cmnfld2", "halo_difest_hyb", "advect", "pbcor1",
+  static const char *seq_ale[] = {"init_fluxes", "tmsmt1", "ale_regrid_remap", "cmnfld2", "halo_difest_hyb", "eddtra", "advect", "pbcor1",
                                   "diffus", "pgforc", "momtum", "cmnfld_bfsqi_ale", "ale_forcing", "halo_difest_vert",
                                   "ale_vdifft", "ale_vdiffm", "updtrc", "barotp", "pbcor2", "tmsmt2", "cmnfld1"};
   c->defer_checks = true;
@@ -638,6 +653,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   if (c->h.P.vcoord_tag != 1) {
     for (const char *st : seq_ale) {
       if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }
+      if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
       if (int rc = blomgpu_stage(c, st, m, n, mm, nn, k1m, k1n)) {
         c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
         return rc;

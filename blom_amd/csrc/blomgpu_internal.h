@@ -72,7 +72,7 @@
      [m], the interface buoyancy flux (mod_forcing.F90:183) */                                                                \
   /* momtum, the other vertical coordinates: the fractions of the wind stress that pass the interfaces (mod_diffusion.F90:139-142) */ \
   X(mu_nonloc, K + 1) X(mv_nonloc, K + 1)                                                                                     \
-  X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(mldl82, 1) X(dpml, 1) X(buoyfl, K + 1)                                                 \
+  X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(mldl82, 1) X(dpml, 1) X(buoyfl, K + 1) X(hbl_tf, 1) X(hml_tf1, 1) X(hml_tf, 1) X(hml_tfbnd, 1) X(OBLdepth, 1)                                                 \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
@@ -257,6 +257,10 @@ struct blomgpu_ctx {
   double swamxd = 200., brine_mlbase_frac = 0.;           // phy/mod_swabs.F90:183 (default); phy/mod_forcing.F90:63 (namelist)
   void *ale = nullptr;
   double *ale_plevel = nullptr;
+  // eddtra_ale (stage_eddtra_ale.hip): the options of &DIFFUSION that phy/mod_eddtra.F90 owns, with its defaults (:53-94)
+  int mlrmth = 1;                                         // 0 none, 1 fox08 (bod23 is not built)
+  double eddtra_ce = .06, tau_mlr = 86400., tau_growing_hbl = 300., tau_decaying_hbl = 86400., tau_growing_hml = 3600.,
+         tau_decaying_hml = 259200., lfmin = 5.e3, mlbl_max_ratio = 3.;
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
   bool tmsmt1_ahead = false, tmsmt1_done_ahead = false;
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1
@@ -322,6 +326,7 @@ int st_xcsum(blomgpu_ctx *, const double *a, int itype, double *sum);
 int st_budget_sums(blomgpu_ctx *, int ncall, int n, int nn);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+int st_eddtra_ale(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_cppm(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     // stage_cppm.hip, called by advect
 int st_init_cppm(blomgpu_ctx *);
 int st_mxlayr_tail(blomgpu_ctx *, int nn, int k1n);

@@ -16,6 +16,15 @@ __device__ constexpr double a11 = 9.9985372432159340e+02, a12 = 1.03806219281834
                             b21 = 1.1995545126831476e-09, b22 = 5.5234008384648383e-12,
                             b23 = 8.4310335919950873e-13;
 
+// sig0(th,s), phy/mod_eos.F90:205-218: sig with the reference pressure at the surface (coefficients :118-129)
+__device__ inline double sig0(double th, double s) {
+  constexpr double alpha0 = 1.e-3;
+  constexpr double ap110 = a11 - a21 / alpha0, ap120 = a12 - a22 / alpha0, ap130 = a13 - a23 / alpha0,
+                   ap140 = a14 - a24 / alpha0, ap150 = a15 - a25 / alpha0, ap160 = a16 - a26 / alpha0;
+  return (ap110 + (ap120 + ap140 * th + ap150 * s) * th + (ap130 + ap160 * s) * s) /
+         (a21 + (a22 + a24 * th + a25 * s) * th + (a23 + a26 * s) * s);
+}
+
 // sig(th,s), phy/mod_eos.F90:191-203
 __device__ inline double sig(const Params &P, double th, double s) {
   return (P.ap11 + (P.ap12 + P.ap14 * th + P.ap15 * s) * th + (P.ap13 + P.ap16 * s) * s) /

@@ -25,10 +25,10 @@ STAGES_FROZEN_EDDY_FLUXES = tuple(s for s in DYNCORE_STAGES if s != "eddtra")   
 # The step of the other vertical coordinates (vcoord_type = 'cntiso_hybrid' or 'plevel'), phy/mod_blom_step.F90:126-233, as far
 # as it is built: ale_regrid_remap in front, the ALE column physics (cmnfld_bfsqi_ale, ale_forcing, ale_vdifft, ale_vdiffm) in
 # place of convec / diapfl / mxlayr, cmnfld1 at the end (the mixed layer depth ale_forcing reads).  Left out, as their modules
-# need CVMix: difest_lateral_hybrid, difest_vertical_hybrid (the diffusivities and non-local fractions stay as uploaded) and
-# eddtra's ALE form (the eddy-induced fluxes stay as uploaded); thermf (the surface fluxes stay as uploaded).
+# need CVMix: difest_lateral_hybrid, difest_vertical_hybrid (the diffusivities, the non-local fractions and the boundary layer
+# depth stay as uploaded); thermf (the surface fluxes stay as uploaded).  eddtra runs its ALE form (eddtra_ale).
 # halo_difest_hyb / halo_difest_vert: the xctilr calls of the two routines that are left out (phy/mod_difest.F90:826-831, :877-878).
-HYBRID_STAGES = ("init_fluxes", "tmsmt1", "ale_regrid_remap", "cmnfld2", "halo_difest_hyb", "advect", "pbcor1", "diffus", "pgforc",
+HYBRID_STAGES = ("init_fluxes", "tmsmt1", "ale_regrid_remap", "cmnfld2", "halo_difest_hyb", "eddtra", "advect", "pbcor1", "diffus", "pgforc",
                  "momtum", "cmnfld_bfsqi_ale", "ale_forcing", "halo_difest_vert", "ale_vdifft", "ale_vdiffm", "updtrc", "barotp",
                  "pbcor2", "tmsmt2", "cmnfld1")
 

@@ -105,7 +105,14 @@ int  blomgpu_updtrc (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 int  blomgpu_sfcstr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* phy/mod_sfcstr.F90:33 (empty for channel/fuk95/noforcing) */
 int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                             /* phy/mod_diapfl.F90:49   */
 int  blomgpu_barotp (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_barotp.F90:148  */
-int  blomgpu_eddtra (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_eddtra.F90:1808 */
+/* phy/mod_eddtra.F90:1808 eddtra.  vcoord_type = 'isopyc_bulkml': eddtra_intdif_isopyc_bulkml / eddtra_gm_isopyc_bulkml (:153, :228).
+ * The other coordinates: eddtra_ale (:1001) -- Gent-McWilliams below the mixed layer, tapered inside it, plus the mixed layer
+ * restratification blomgpu_set_str "mlrmth" = "fox08" (default) or "none" ("bod23" is refused: it needs ustar3 / wstar3 of the
+ * CVMix-bound mod_difest); blomgpu_set_real "ce", "tau_mlr", "tau_growing_hbl", "tau_decaying_hbl", "tau_growing_hml",
+ * "tau_decaying_hml", "lfmin", "mlbl_max_ratio" (:53-94, same defaults).  Inputs by name: nslpx, nslpy (interfaces), difint, mld,
+ * OBLdepth (mod_difest's boundary layer depth); state: hbl_tf, hml_tf1, hml_tf (the running means), hml_tfbnd.  Writes umfltd,
+ * vmfltd, umflsm, vmflsm and the heat and salt components u/v{t,s}fl{td,sm}. */
+int  blomgpu_eddtra (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* Halo updates the reference performs inside stages that are outside the hot path
  * (phy/mod_cmnfld_routines.F90:1171-1196: temp/saln halos and the kfpla halo through util1, phy/mod_difest.F90:750-772: halos + interface pressure p out to ii+3) and the
  * dp-halo/dpu/dpv tail of mxlayr (phy/mod_mxlayr.F90:1266-1310). */

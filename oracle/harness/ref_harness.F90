@@ -46,7 +46,9 @@ module ref_harness
   use mod_cmnfld,    only: inivar_cmnfld, nslpx, nslpy, nnslpx, nnslpy, bfsqi, bfsqf, bfsql, z, dz, mld, mldl82, dpml
 #ifdef XCHECK_EDDTRA
   ! cross-check builds only (oracle/Makefile *_xed): the reference's real mod_eddtra, compiled against a stand-in for mod_difest
-  use mod_eddtra,    only: eddtra
+  use mod_eddtra,    only: eddtra, init_eddtra, inivar_eddtra, mlrmth, ce, tau_mlr, tau_growing_hbl, tau_decaying_hbl, &
+                            tau_growing_hml, tau_decaying_hml, lfmin, mlbl_max_ratio, hbl_tf, hml_tf1, hml_tf
+  use mod_difest,    only: OBLdepth        ! the stand-in's array (oracle/xcheck/mod_difest_standin.F90)
   use mod_cmnfld_routines, only: cmnfld1, cmnfld2, cmnfld_bfsqi_ale
 #endif
 #ifdef WITH_ALE_VDIFF
@@ -162,6 +164,16 @@ contains
       case ('brine_mlbase_frac'); brine_mlbase_frac = v
 #ifdef XCHECK_ALE
       case ('swamxd'); swamxd = v
+#endif
+#ifdef XCHECK_EDDTRA
+      case ('ce'); ce = v
+      case ('tau_mlr'); tau_mlr = v
+      case ('lfmin'); lfmin = v
+      case ('mlbl_max_ratio'); mlbl_max_ratio = v
+      case ('tau_growing_hbl'); tau_growing_hbl = v
+      case ('tau_decaying_hbl'); tau_decaying_hbl = v
+      case ('tau_growing_hml'); tau_growing_hml = v
+      case ('tau_decaying_hml'); tau_decaying_hml = v
 #endif
       case ('baclin'); baclin = v
       case ('batrop'); batrop = v
@@ -483,6 +495,12 @@ contains
       R2(mld)
       R2(mldl82)
       R2(dpml)
+#ifdef XCHECK_EDDTRA
+      R2(hbl_tf)
+      R2(hml_tf1)
+      R2(hml_tf)
+      R2(OBLdepth)
+#endif
 #ifdef XCHECK_ALE
       R2(swfc1)
       R2(swfc2)
@@ -533,6 +551,9 @@ contains
       case ('tmsmt2');  call tmsmt2(m,mm,nn,k1m)
 #ifdef XCHECK_EDDTRA
       case ('eddtra');  call eddtra(m,n,mm,nn,k1m,k1n)
+      ! init_eddtra resolves the mixed layer restratification method from the string (phy/mod_eddtra.F90:1773-1806)
+      case ('eddtra_init_fox08'); mlrmth = 'fox08'; call inivar_eddtra; call init_eddtra
+      case ('eddtra_init_none');  mlrmth = 'none';  call inivar_eddtra; call init_eddtra
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
       case ('cmnfld_bfsqi_ale'); call cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)

@@ -216,7 +216,8 @@ class RefBackend:
         self.ref.budget_sums(ncall, n, nn)
 
     def has_stage(self, name):
-        return name != "eddtra"          # mod_eddtra is not part of the reference build (CVMix)
+        # mod_eddtra is not part of the reference build (CVMix); the cross-check builds compile it against a stand-in
+        return name != "eddtra" or self.ref.cfg.endswith(("_xale", "_xaln"))
 
     def stage(self, name, m, n, mm, nn, k1m, k1n):
         self.ref.stage(name, m, n, mm, nn, k1m, k1n)

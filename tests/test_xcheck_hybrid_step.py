@@ -3,9 +3,9 @@ reference's own modules stage by stage (config 1 of BASELINE
 cntiso_hybrid + cppm).
 
 Sequence (blom_amd/stepper.py HYBRID_STAGES = the order of phy/mod_blom_step.F90:126-233): init_fluxes, tmsmt1,
-ale_regrid_remap, cmnfld2, advect, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft, ale_vdiffm, updtrc,
-barotp, pbcor2, tmsmt2, cmnfld1.  Left out on BOTH sides because their modules need CVMix or forcing files: difest_lateral_hybrid,
-difest_vertical_hybrid (diffusivities and non-local fractions stay as uploaded), eddtra's ALE form (eddy-induced fluxes zero),
+ale_regrid_remap, cmnfld2, eddtra (eddtra_ale), advect, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft,
+ale_vdiffm, updtrc, barotp, pbcor2, tmsmt2, cmnfld1.  Left out on BOTH sides because their modules need CVMix or forcing files:
+difest_lateral_hybrid, difest_vertical_hybrid (diffusivities, non-local fractions and the boundary layer depth stay as uploaded),
 thermf (surface fluxes as uploaded).  The reference side runs its real modules -- ale_regrid_remap, ale_forcing and cmnfld
 against the stand-ins of oracle/xcheck (hence a cross-check), everything else from the plain build.  The device runs
 blomgpu_step.  After every step all state arrays must agree bit for bit."""
@@ -21,11 +21,11 @@ from parity import copy_state, diff_report, fmt_report, STATE_FIELDS, GRID_FIELD
 from test_xcheck_ale import OPTIONS, ale_init_once, set_device_ale_options
 
 pytestmark = pytest.mark.gpu
-ALE_FIELDS = ["kvisc_m", "kdiff_t", "kdiff_s", "t_ns_nonloc", "s_nb_nonloc", "t_sw_nonloc", "t_rs_nonloc", "s_br_nonloc",
+ALE_FIELDS = ["hbl_tf", "hml_tf1", "hml_tf", "OBLdepth", "kvisc_m", "kdiff_t", "kdiff_s", "t_ns_nonloc", "s_nb_nonloc", "t_sw_nonloc", "t_rs_nonloc", "s_br_nonloc",
               "s_rs_nonloc", "mu_nonloc", "mv_nonloc", "surflx", "sswflx", "surrlx", "salflx", "brnflx", "salrlx", "salt_corr",
               "trc_corr", "trflx", "swfc1", "swfc2", "swal1", "swal2", "mld", "mldl82", "dpml", "buoyfl", "sigint", "bfsqi",
               "bfsql", "bfsqf", "nslpx", "nslpy", "nnslpx", "nnslpy", "z", "dz", "told", "sold", "trcold"]
-CHECK = STATE_FIELDS + ["sigint", "t_sw_nonloc", "s_br_nonloc", "buoyfl", "salt_corr", "trc_corr", "mld", "dpml", "bfsqi", "bfsqf",
+CHECK = STATE_FIELDS + ["hbl_tf", "hml_tf1", "hml_tf", "umflsm", "vmflsm", "utflsm", "vtflsm", "usflsm", "vsflsm", "sigint", "t_sw_nonloc", "s_br_nonloc", "buoyfl", "salt_corr", "trc_corr", "mld", "dpml", "bfsqi", "bfsqf",
                         "nslpx", "nslpy", "z", "dz"]
 
 
@@ -79,6 +79,7 @@ def test_hybrid_step_equals_the_reference_stage_sequence(cfg, advmth, method, vc
         f["trflx"] = rng.uniform(-1e-6, 1e-6, (ref.ntr, nj, ni))
         f["trc_corr"] = np.zeros((ref.ntr, nj, ni))
     f["salt_corr"] = np.zeros((1, nj, ni))
+    f["OBLdepth"] = 10.0 ** rng.uniform(0.8, 2.2, (1, nj, ni))      # boundary layer depth (difest_vertical_hybrid's, CVMix)
     pbot = float(np.max(ref.get("p")[kk][4:-4, 4:-4][ref.masks["ip"][4:-4, 4:-4] > 0]))
     plevel = 0.3 * pbot * (np.arange(kk) / kk) ** 1.3
     for nm, a in f.items():
@@ -102,6 +103,12 @@ def test_hybrid_step_equals_the_reference_stage_sequence(cfg, advmth, method, vc
     gpu.set("brine_mlbase_frac", 0.4)
     six0 = hostinit.step_indices(0, kk)
     ale_init_once(ref, lib, o, six0, tmp_path)
+    ref.ref.stage("eddtra_init_fox08", *six0)                     # inivar_eddtra + init_eddtra (mlrmth = 'fox08', the default)
+    for nm in ("hbl_tf", "hml_tf1", "hml_tf"):
+        gpu.put(nm, ref.get(nm))
+    ref.ref.set("eitmth", "gm")
+    gpu.set("eitmth", "gm")
+    gpu.set("mlrmth", "fox08")
     try:
         ref.ref.set("vcoord_tag", tag)
         # blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first ale_forcing reads
@@ -116,6 +123,12 @@ def test_hybrid_step_equals_the_reference_stage_sequence(cfg, advmth, method, vc
         wu = (ref.masks["iu"][4:-4, 4:-4] > 0)[None]
         uu = gpu.get("u")[:, 4:-4, 4:-4]
         assert np.isfinite(uu[np.broadcast_to(wu, uu.shape)]).all() and np.abs(uu[np.broadcast_to(wu, uu.shape)]).max() > 0.0
+        # eddtra_ale took part: Gent-McWilliams mass fluxes are there (submesoscale ones only where the mixed layer spans more than
+        # one layer: tests/test_xcheck_eddtra_ale.py has those)
+        for nm in ("umfltd", "umflsm"):
+            a = gpu.get(nm)[:, 4:-4, 4:-4]
+            a = a[np.broadcast_to(wu, a.shape)]
+            assert np.isfinite(a).all() and (nm == "umflsm" or np.abs(a).max() > 0.0), nm
     finally:
         ref.ref.set("vcoord_tag", 1)
         gpu.close()
