@@ -408,19 +408,9 @@ H3HD void h3_prepare_ppm(const H3Grid &g, int col) {
   h3_compact_and_weights(g, col);
   h3_continuous_edges(g, col, ns);
 
-  for (int j = 2; j <= ns - 1; ++j)
-    H3A(g.hci, j) = 2.0 / (H3A(g.h, j - 1) + 2.0 * H3A(g.h, j) + H3A(g.h, j + 1));
-
-  // edge_ih4_coeff (mod_hor3map.F90:631-648)
-  for (int j = 2; j <= ns; ++j) {
-    const double h1 = H3A(g.h, j - 1), h2 = H3A(g.h, j);
-    const double q = 1.0 / (h1 + h2);
-    const double t1 = h2 * h2 * q * q, t2 = h1 * h1 * q * q;
-    H3A2(g.tde, 1, j, g.ncoef) = t1;
-    H3A2(g.tde, 2, j, g.ncoef) = t2;
-    H3A2(g.tde, 3, j, g.ncoef) = 2.0 * t1 * (h2 + 2.0 * h1) * q;
-    H3A2(g.tde, 4, j, g.ncoef) = 2.0 * t2 * (h1 + 2.0 * h2) * q;
-  }
+  // The reference stores hci_src (:1477) and the edge system's coefficients tdecoeff (edge_ih4_coeff, :631-648) here.  Their only
+  // reader, the PPM reconstruction, recomputes both from the widths with the same expressions (hor3map_ppm_fused.h: the same bits),
+  // so the five planes are not written: 225 of the 460 MB this routine stored per 106 k-column slab.
 
   double hb[H3_LD], a[H3_LD * H3_LD];
   if (lb_ord > 1) {
@@ -578,11 +568,25 @@ H3HD int h3_reconstruct(const H3Grid &g, const H3Src &s, const double *uin, int 
       if (jd != 0) H3A(s.u, jd) = H3A(uin, js);
     }
   } else {
-    for (int j = 1; j <= ns; ++j) H3A(s.u, j) = 0.0;
+    // The reference zeroes u_src and accumulates w * u into memory (:4197-4204).  The source cells of a destination cell are
+    // neighbours, so its sum lives in a register from 0.0 on, with the same additions in the same order, and is stored once; a
+    // destination index that comes back after another one (no merge rule produces it) picks its partial sum up from memory.
+    int cur = 0, top = 0;
+    double acc = 0.0;
     for (int js = 1; js <= g.n_src; ++js) {
       const int jd = H3A(g.sdi, js);
-      if (jd != 0) H3A(s.u, jd) = H3A(s.u, jd) + H3A(g.w, js) * H3A(uin, js);
+      if (jd == 0) continue;
+      if (jd != cur) {
+        if (cur > 0) H3A(s.u, cur) = acc;
+        for (int q = top + 1; q < jd; ++q) H3A(s.u, q) = 0.0;          // cells no source maps to keep the reference's zero
+        acc = jd > top ? 0.0 : H3A(s.u, jd);
+        cur = jd;
+        if (jd > top) top = jd;
+      }
+      acc = acc + H3A(g.w, js) * H3A(uin, js);
     }
+    if (cur > 0) H3A(s.u, cur) = acc;
+    for (int q = top + 1; q <= ns; ++q) H3A(s.u, q) = 0.0;
   }
   double umin = H3A(s.u, 1), umax = umin;
   for (int j = 2; j <= ns; ++j) {
@@ -616,9 +620,13 @@ H3HD int h3_extract_polycoeff(const H3Grid &g, const H3Src &s, double *out, int 
   const int nc = g.nc, np = g.p_ord + 1, n = g.n_src;
   if (!s.reconstructed[col]) return H3_RECON_NOT_AVAILABLE;
 #define OUT(c, j) H3A2(out, c, j, np)
-  for (int j = 1; j <= n; ++j)
-    for (int c = 1; c <= np; ++c) OUT(c, j) = 0.0;
+  // the reference zeroes polycoeff first (:4290); a column on the grid's own PPM / PQM path writes every element below exactly
+  // once instead (zeros included), only a column that fell back to a lower order is pre-filled
   const int m = g.m_act[col];
+  const bool full = (m == H3_PPM && np == 3) || (m == H3_PQM && np == 5);
+  if (!full)
+    for (int j = 1; j <= n; ++j)
+      for (int c = 1; c <= np; ++c) OUT(c, j) = 0.0;
   int js0 = 1, jd;
   if (m == H3_PCM) {
     while (true) {
@@ -649,8 +657,10 @@ H3HD int h3_extract_polycoeff(const H3Grid &g, const H3Src &s, double *out, int 
     const int nq = m == H3_PPM ? 3 : 5;
     while (true) {
       jd = H3A(g.sdi, js0);
-      if (jd == 0) OUT(1, js0) = PC(1, 1);
-      else break;
+      if (jd == 0) {
+        OUT(1, js0) = PC(1, 1);
+        if (full) for (int c = 2; c <= nq; ++c) OUT(c, js0) = 0.0;
+      } else break;
       js0 = js0 + 1;
       if (js0 > n) break;
     }
@@ -662,6 +672,7 @@ H3HD int h3_extract_polycoeff(const H3Grid &g, const H3Src &s, double *out, int 
         double acc = OUT(1, js - 1) + OUT(2, js - 1);
         for (int c = 3; c <= nq; ++c) acc = acc + OUT(c, js - 1);
         OUT(1, js) = acc;
+        if (full) for (int c = 2; c <= nq; ++c) OUT(c, js) = 0.0;
       } else {
         const double w = H3A(g.w, js);
         if (w == 1.0) {
