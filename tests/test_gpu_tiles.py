@@ -217,6 +217,109 @@ def test_ale_regrid_remap_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, me
     assert not bad, bad
 
 
+HYBRID_INPUTS = ["kvisc_m", "kdiff_t", "kdiff_s", "t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc",
+                 "sswflx", "surflx", "surrlx", "brnflx", "salflx", "salrlx", "swfc1", "swfc2", "swal1", "swal2", "OBLdepth", "trflx"]
+
+
+@pytest.mark.parametrize("cfg,npx,npy,vcoord,method,advmth", [
+    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("box_s", 2, 2, "cntiso_hybrid", "direct", "cppm"),
+    ("tri_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("tri_s", 4, 2, "plevel", "direct", "cppm"), ("chan_s", 1, 2, "plevel", "nudge", "remap")])
+def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method, advmth):
+    """The step of the hybrid vertical coordinate (ale_regrid_remap, cmnfld2's hybrid branches, eddtra_ale, advect,
+    .., ale_forcing, ale_vdifft/m, .., cmnfld1) on a decomposed domain: every halo update of the new stages -- the ring of the
+    lateral smoothing, the bounded mixed layer depth and the mixed layer density of eddtra_ale, the viscosity of ale_vdiffm, the
+    slopes and buoyancy frequencies of cmnfld -- goes through the tile transport.  Interiors after a few steps as on the single tile."""
+    from blom_amd.gpu import BlomGpu, TileGroup
+    nsteps = 3
+    case = make_case(cfg, advmth=advmth)
+    _, masks, fields, ref = _single(cfg, nsteps)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            ref.set(nm, v)
+    ref.set("delt1", case.params["baclin"])
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    rng = np.random.default_rng(11)
+    z = np.arange(kk + 1)[:, None, None] / kk
+    f = {}
+    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
+        f[nm] = 1e-5 + 10.0 ** rng.uniform(-3.5, -2.0, (1, nj, ni)) * np.exp(-((z - 0.1) / 0.15) ** 2)
+    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
+        a = np.clip(1.0 - z / rng.uniform(0.1, 0.6, (1, nj, ni)), 0.0, 1.0) ** 2
+        a[0] = 1.0
+        f[nm] = a
+    f["sswflx"] = -rng.uniform(0.0, 150.0, (1, nj, ni))
+    f["surflx"] = f["sswflx"] + rng.uniform(-100.0, 100.0, (1, nj, ni))
+    f["surrlx"] = rng.uniform(-10.0, 10.0, (1, nj, ni))
+    f["brnflx"] = -rng.uniform(0.0, 1e-4, (1, nj, ni))
+    f["salflx"] = f["brnflx"] + rng.uniform(-2e-3, 2e-3, (1, nj, ni))
+    f["salrlx"] = rng.uniform(-5e-4, 5e-4, (1, nj, ni))
+    f["swfc1"] = rng.uniform(0.4, 0.7, (1, nj, ni))
+    f["swfc2"] = 1.0 - f["swfc1"]
+    f["swal1"] = rng.uniform(0.5, 1.5, (1, nj, ni))
+    f["swal2"] = rng.uniform(10.0, 20.0, (1, nj, ni))
+    f["OBLdepth"] = 10.0 ** rng.uniform(0.8, 2.2, (1, nj, ni))
+    if case.ntr:
+        f["trflx"] = rng.uniform(-1e-6, 1e-6, (case.ntr, nj, ni))
+    # the tiles get windows of the same padded arrays, halo points included: whatever a stage reads there without updating it
+    # first is the same number on both sides
+    for nm, a in f.items():
+        ref.put(nm, a)
+    pbot = float(np.max(ref.get("p")[kk][masks["ip"] > 0]))
+    plevel = 0.3 * pbot * (np.arange(kk) / kk) ** 1.3
+    ii, jj = tile_extents(case, npx, npy)
+    grp = TileGroup(npx, npy)
+    tiles = {}
+    for py in range(npy):
+        for px in range(npx):
+            tm = {k: tile_window(masks[k], case, npx, npy, px, py) for k in masks}
+            t = BlomGpu(ii, jj, kk, case.ntr, case.nreg, tm, itdm=case.idm, jtdm=case.jdm, i0=px * ii, j0=py * jj)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            t.set("delt1", case.params["baclin"])
+            grp.attach(t, px, py)
+            tiles[(px, py)] = t
+    scatter_state(ref, tiles, case, npx, npy, [nm for nm in ALL if nm in fields] + [nm for nm in HYBRID_INPUTS if nm in f])
+    six0 = hostinit_step_indices(0, kk)
+
+    def run_hybrid(g):
+        g.set("vcoord_type", vcoord)
+        g.set("ale_regrid_method", method)
+        g.set("mlrmth", "fox08")
+        g.set("swamxd", 200.0)
+        g.set("brine_mlbase_frac", 0.4)
+        g.set_vector("plevel", plevel)
+        if advmth == "cppm":
+            g.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
+        g.stage("cmnfld1", *six0)
+        assert g.step(0, nsteps) == nsteps
+    run_hybrid(ref)
+    errs = []
+
+    def run(t):
+        try:
+            run_hybrid(t)
+            t.sync()
+        except Exception as e:          # a failing tile would leave the others at a barrier
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(t,), daemon=True) for t in tiles.values()]
+    [x.start() for x in th]
+    [x.join(timeout=300) for x in th]
+    assert not errs, errs
+    bad = []
+    for nm in CHECK + ["umfltd", "vmfltd", "umflsm", "vmflsm", "hml_tf", "mld", "bfsqi", "nslpx", "nslpy", "salt_corr", "buoyfl"]:
+        a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
+        b = gather_interior(tiles, case, npx, npy, nm)
+        wet = np.isfinite(a) & (np.abs(a) < 1e30)
+        if not np.array_equal(a[wet], b[wet]):
+            bad.append((nm, int((a[wet] != b[wet]).sum()), float(np.nanmax(np.abs(a[wet] - b[wet])))))
+    for t in tiles.values():
+        t.close()
+    ref.close()
+    grp.destroy()
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("cfg,isizes,jsizes", [("box_s", (12, 12), (11, 9)), ("chan_s", (7, 7, 6), (13, 11)),
                                                ("tri_s", (6, 6, 6, 6), (11, 9)), ("tri_s_tke", (12, 12), (9, 11))])
 def test_unequal_tiles_match_single_tile(cfg, isizes, jsizes):
