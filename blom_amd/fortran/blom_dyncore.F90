@@ -14,7 +14,7 @@
 program blom_dyncore
 
   use mod_blomgpu
-  use mod_rdlim_gpu, only: rdlim_gpu
+  use mod_rdlim_gpu, only: rdlim_gpu, hybrid_coordinate, advect_cppm
   implicit none
 
   character(len=256) :: fname
@@ -71,6 +71,11 @@ program blom_dyncore
 
   ! the step counter starts at nstep1 = nday1*nstep_in_day (its parity decides the time levels and the order of cppm's sweeps)
   nstep = nstep1
+  if (advect_cppm) call init_cppm()
+  if (hybrid_coordinate) then
+    ! blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first eddtra and ale_forcing read
+    call cmnfld1(mod(nstep,2)+1, mod(nstep+1,2)+1, mod(nstep,2)*kdm, mod(nstep+1,2)*kdm, 1+mod(nstep,2)*kdm, 1+mod(nstep+1,2)*kdm)
+  end if
   do while (nstep < nstep2)
     call blom_step(nstep)
   end do
@@ -98,6 +103,34 @@ contains
     k1n = 1+nn
     nstep = nstep+1                                ! step_time
     call gpu_set('nstep', nstep)
+    if (hybrid_coordinate) then
+      ! vcoord_type = 'cntiso_hybrid' or 'plevel', phy/mod_blom_step.F90:126-233 as far as the device library has it
+      ! (DESIGN.md 3h; difest_*_hybrid and thermf are left out: what they produce stays as uploaded)
+      call init_fluxes(m,n,mm,nn,k1m,k1n)
+      call tmsmt1(nn)
+      call ale_regrid_remap(m,n,mm,nn,k1m,k1n)
+      call cmnfld2(m,n,mm,nn,k1m,k1n)
+      call stage6('halo_difest_hyb',m,n,mm,nn,k1m,k1n)
+      call eddtra(m,n,mm,nn,k1m,k1n)
+      call advect(m,n,mm,nn,k1m,k1n)
+      call pbcor1(m,n,mm,nn,k1m,k1n)
+      call diffus(m,n,mm,nn,k1m,k1n)
+      call sfcstr(m,n,mm,nn,k1m,k1n)
+      call pgforc(m,n,mm,nn,k1m,k1n)
+      call momtum(m,n,mm,nn,k1m,k1n)
+      call cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)
+      call ale_forcing(m,n,mm,nn,k1m,k1n)
+      call stage6('halo_difest_vert',m,n,mm,nn,k1m,k1n)
+      call ale_vdifft(m,n,mm,nn,k1m,k1n)
+      call ale_vdiffm(m,n,mm,nn,k1m,k1n)
+      call updtrc(m,n,mm,nn,k1m,k1n)
+      call barotp(m,n,mm,nn,k1m,k1n)
+      call pbcor2(m,n,mm,nn,k1m,k1n)
+      call tmsmt2(m,mm,nn,k1m)
+      call cmnfld1(m,n,mm,nn,k1m,k1n)
+      call gpu_set('delt1', baclin+baclin)
+      return
+    end if
     call init_fluxes(m,n,mm,nn,k1m,k1n)
     call tmsmt1(nn)
     call halo_cmnfld2(n)

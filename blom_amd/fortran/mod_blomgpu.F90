@@ -127,6 +127,7 @@ module mod_blomgpu
 
   public :: gpu_init, gpu_finalize, gpu_set, gpu_upload, gpu_upload_int, gpu_download, gpu_nlev, &
             gpu_halo, gpu_chksum, gpu_sync, gpu_xcsum, budget_sums, gpu_budget
+  public :: stage6
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
             diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail, &
             cmnfld1, cmnfld2, ale_regrid_remap, ale_vdifft, ale_vdiffm, ale_forcing, &

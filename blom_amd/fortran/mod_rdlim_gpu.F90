@@ -1,7 +1,8 @@
 ! ------------------------------------------------------------------------------
 ! module mod_rdlim_gpu -- the namelist input of the reference for the host of the device-resident dynamical core.
 ! Reads the file `limits` (or `ocn_in`) exactly as the reference's readers do -- groups &LIMITS
-! (phy/mod_rdlim.F90:137-175), &VCOORD (phy/mod_vcoord.F90:818-823) and &DIFFUSION (phy/mod_diffusion.F90:214-218),
+! (phy/mod_rdlim.F90:137-175), &VCOORD (phy/mod_vcoord.F90:818-823), &DIFFUSION (phy/mod_diffusion.F90:214-218) and, for the
+! hybrid coordinates, &ALE_REGRID_REMAP (phy/mod_ale_regrid_remap.F90:1193-1201),
 ! each declared with the reference's full variable list so that its input files are accepted unchanged -- and hands
 ! the variables the dynamical core uses to the device library (blomgpu_set_*).  Everything else in the groups is
 ! read and ignored here: it belongs to parts of the model outside this path (I/O, forcing, restart, diagnostics).
@@ -12,6 +13,8 @@ module mod_rdlim_gpu
   implicit none
   private
   public :: rdlim_gpu
+  logical, public :: advect_cppm = .false.           ! advmth = 'cppm': blom_init calls init_cppm (phy/mod_blom_init.F90)
+  logical, public :: hybrid_coordinate = .false.     ! vcoord_type /= 'isopyc_bulkml': blom_step takes the other branch
 
 contains
 
@@ -27,16 +30,18 @@ contains
     character(len=256) :: runid = 'unset', runtyp = 'unset', rpoint = 'unset', expcnf = 'unset', grfile = 'unset', &
                icfile = 'unset', tdfile = 'unset', ccfile = 'unset', svfile = 'unset', scfile = 'unset', atm_path = 'unset'
     character(len=80) :: mommth = 'enscon', pgfmth = 'geopotential', bmcmth = 'uc', advmth = 'remap', &
-               cppm_compatibility = 'full', cppm_limiting = 'non_oscillatory', mldmth = 'lev82', mlrmth = 'none', &
+               cppm_compatibility = 'full', cppm_limiting = 'non_oscillatory', mldmth = 'lev82', mlrmth = 'fox08', &
                mlrttp = 'constant', swamth = 'jerlov', chlopt = 'climatology', wavsrc = 'none'
     logical :: woa_nuopc_provided = .false., aptflx = .false., apsflx = .false., ditflx = .false., disflx = .false., &
                srxbal = .false., smtfrc = .false., sprfac = .false., cnsvdi = .false., csdiag = .false., &
                use_stream_relaxation = .false., use_stream_dust = .false., use_diag = .false.
     real(8) :: pref = 2000.d4, baclin = 0.d0, batrop = 0.d0, mdv2hi = 0.d0, mdv2lo = 0.d0, mdv4hi = 0.d0, mdv4lo = 0.d0, &
                mdc2hi = 0.d0, mdc2lo = 0.d0, vsc2hi = 0.d0, vsc2lo = 0.d0, vsc4hi = 0.d0, vsc4lo = 0.d0, cbar = 0.d0, &
-               cb = 0.d0, cwbdts = 0.d0, cwbdls = 0.d0, ce = 0.d0, cl = 0.d0, tau_mlr = 0.d0, tau_growing_hbl = 0.d0, &
-               tau_decaying_hbl = 0.d0, tau_growing_hml = 0.d0, tau_decaying_hml = 0.d0, lfmin = 0.d0, mstar = 0.d0, &
-               nstar = 0.d0, wpup_min = 0.d0, mlbl_max_ratio = 0.d0, rm0 = 0.d0, rm5 = 0.d0, niwgf = 0.d0, niwbf = 0.d0, &
+               cb = 0.d0, cwbdts = 0.d0, cwbdls = 0.d0, &
+               ! mixed layer restratification, defaults of phy/mod_eddtra.F90:53-94
+               ce = .06d0, cl = .25d0, tau_mlr = 86400.d0, tau_growing_hbl = 300.d0, &
+               tau_decaying_hbl = 86400.d0, tau_growing_hml = 3600.d0, tau_decaying_hml = 259200.d0, lfmin = 5.d3, mstar = .5d0, &
+               nstar = .066d0, wpup_min = 1.d-3, mlbl_max_ratio = 3.d0, rm0 = 0.d0, rm5 = 0.d0, niwgf = 0.d0, niwbf = 0.d0, &
                niwlf = 0.d0, trxday = 0.d0, srxday = 0.d0, trxdpt = 0.d0, srxdpt = 0.d0, trxlim = 0.d0, srxlim = 0.d0, &
                brine_mlbase_frac = 0.d0
     ! &VCOORD
@@ -53,6 +58,18 @@ contains
                bdmldp = .false., smobld = .false., ndiff_surface_align = .false.
     character(len=256) :: tbfile = 'unset'
     character(len=80) :: lngmtp = 'none', eitmth = 'gm', edritp = 'large scale', edwmth = 'smooth', ltedtp = 'layer'
+
+    ! &ALE_REGRID_REMAP, defaults of phy/mod_ale_regrid_remap.F90:69-95
+    character(len=80) :: reconstruction_method = 'ppm', density_limiting = 'monotonic', tracer_limiting = 'non_oscillatory', &
+               velocity_limiting = 'non_oscillatory', regrid_method = 'nudge'
+    logical :: density_pc_upper_bndr = .false., density_pc_lower_bndr = .false., tracer_pc_upper_bndr = .true., &
+               tracer_pc_lower_bndr = .false., velocity_pc_upper_bndr = .true., velocity_pc_lower_bndr = .false.
+    integer :: upper_bndr_ord = 6, lower_bndr_ord = 4, k_range_plevel = 1, dktzu = 4, dktzl = 2
+    real(8) :: dpmin_interior = .1d0, regrid_nudge_ts = 86400.d0, stab_fac_limit = .75d0, dpvar_fac = .75d0, &
+               smooth_diff_max = 50000.d0
+    real(8), parameter :: spval_ = huge(1.d0), onem = 9806.d0
+    real(8) :: dpmin
+    integer :: k
 
     character(len=80) :: nlfnm
     integer :: nfu, ios, lstep, nstep_in_day
@@ -81,7 +98,14 @@ contains
          eddf2d, edsprs, edanis, redi3d, rhsctp, tbfile, edfsmo, smobld, &
          lngmtp, eitmth, edritp, edwmth, ltedtp, ndiff_surface_align
 
+    namelist /ale_regrid_remap/ reconstruction_method, upper_bndr_ord, lower_bndr_ord, density_limiting, tracer_limiting, &
+         velocity_limiting, density_pc_upper_bndr, density_pc_lower_bndr, tracer_pc_upper_bndr, tracer_pc_lower_bndr, &
+         velocity_pc_upper_bndr, velocity_pc_lower_bndr, dpmin_interior, regrid_method, k_range_plevel, regrid_nudge_ts, &
+         stab_fac_limit, dpvar_fac, smooth_diff_max, dktzu, dktzl
+
     found = .false.
+    hybrid_coordinate = .false.
+    plevel(:) = spval_
     nlfnm = 'ocn_in'                                   ! phy/mod_rdlim.F90:160-172
     inquire (file=nlfnm, exist=fexist)
     if (.not. fexist) then
@@ -119,11 +143,72 @@ contains
     write (*,*) 'MOMMTH ', trim(mommth), '  PGFMTH ', trim(pgfmth), '  BMCMTH ', trim(bmcmth), '  ADVMTH ', trim(advmth)
     write (*,*) 'VCOORD_TYPE ', trim(vcoord_type), '  EITMTH ', trim(eitmth), '  LTEDTP ', trim(ltedtp)
 
-    if (trim(vcoord_type) /= 'isopyc_bulkml') then
-      write (*,*) ' vcoord_type = ', trim(vcoord_type), ' is not built on the device (ALE stack)'
-      error stop '(readnml_vcoord)'
-    end if
-    call gpu_set('vcoord_tag', 1)
+    select case (trim(vcoord_type))
+      case ('isopyc_bulkml')
+        call gpu_set('vcoord_type', 'isopyc_bulkml')
+      case ('cntiso_hybrid', 'plevel')
+        ! the step of the other coordinates as far as the device library has it (DESIGN.md 3h): the group &ALE_REGRID_REMAP
+        ! (phy/mod_ale_regrid_remap.F90:1185-1355) and the pressure levels (phy/mod_vcoord.F90:948-976)
+        hybrid_coordinate = .true.
+        open (newunit=nfu, file=nlfnm, status='old', action='read')
+        read (unit=nfu, nml=ale_regrid_remap, iostat=ios)
+        close (nfu)
+        if (ios > 0) then
+          write (*,*) 'readnml_ale_regrid_remap: could not read the namelist group ALE_REGRID_REMAP of '//trim(nlfnm)
+          error stop '(readnml_ale_regrid_remap)'
+        end if
+        call gpu_set('vcoord_type', trim(vcoord_type))
+        call gpu_set('ale_reconstruction_method', trim(reconstruction_method))
+        call gpu_set('ale_density_limiting', trim(density_limiting))
+        call gpu_set('ale_tracer_limiting', trim(tracer_limiting))
+        call gpu_set('ale_velocity_limiting', trim(velocity_limiting))
+        call gpu_set('ale_regrid_method', trim(regrid_method))
+        call gpu_set('ale_upper_bndr_ord', upper_bndr_ord); call gpu_set('ale_lower_bndr_ord', lower_bndr_ord)
+        call gpu_set('ale_k_range_plevel', k_range_plevel); call gpu_set('ale_dktzu', dktzu); call gpu_set('ale_dktzl', dktzl)
+        call gpu_set('ale_density_pc_upper_bndr', merge(1, 0, density_pc_upper_bndr))
+        call gpu_set('ale_density_pc_lower_bndr', merge(1, 0, density_pc_lower_bndr))
+        call gpu_set('ale_tracer_pc_upper_bndr', merge(1, 0, tracer_pc_upper_bndr))
+        call gpu_set('ale_tracer_pc_lower_bndr', merge(1, 0, tracer_pc_lower_bndr))
+        call gpu_set('ale_velocity_pc_upper_bndr', merge(1, 0, velocity_pc_upper_bndr))
+        call gpu_set('ale_velocity_pc_lower_bndr', merge(1, 0, velocity_pc_lower_bndr))
+        call gpu_set('ale_dpmin_interior', dpmin_interior)
+        call gpu_set('ale_regrid_nudge_ts', regrid_nudge_ts); call gpu_set('ale_stab_fac_limit', stab_fac_limit)
+        call gpu_set('ale_dpvar_fac', dpvar_fac); call gpu_set('ale_smooth_diff_max', smooth_diff_max)
+        select case (trim(plevel_spec))
+          case ('inflation')
+            dpmin = dpmin_surface*onem                   ! :906
+            plevel(1) = 0.d0
+            do k = 1, kdm-1
+              plevel(k+1) = plevel(k)+dpmin
+              dpmin = dpmin*dpmin_inflation_factor
+            end do
+          case ('namelist')
+            k = 1
+            do while (plevel(k) /= spval_)
+              k = k+1
+              if (k > size(plevel)) exit
+            end do
+            if (k /= kdm+1) then
+              write (*,*) ' readnml_vcoord: number of plevel values does not match vertical dimension!'
+              error stop '(readnml_vcoord)'
+            end if
+            plevel(1:kdm) = plevel(1:kdm)*onem
+          case default
+            write (*,*) ' readnml_vcoord: plevel_spec = ', trim(plevel_spec), ' is unsupported!'
+            error stop '(readnml_vcoord)'
+        end select
+        call gpu_set_vector('plevel', plevel(1:kdm))
+        ! mixed layer restratification of eddtra_ale (phy/mod_eddtra.F90:1773-1806 init_eddtra)
+        call gpu_set('mlrmth', trim(mlrmth))
+        call gpu_set('ce', ce); call gpu_set('tau_mlr', tau_mlr); call gpu_set('lfmin', lfmin)
+        call gpu_set('tau_growing_hbl', tau_growing_hbl); call gpu_set('tau_decaying_hbl', tau_decaying_hbl)
+        call gpu_set('tau_growing_hml', tau_growing_hml); call gpu_set('tau_decaying_hml', tau_decaying_hml)
+        call gpu_set('mlbl_max_ratio', mlbl_max_ratio)
+        call gpu_set('brine_mlbase_frac', brine_mlbase_frac)
+      case default
+        write (*,*) ' readnml_vcoord: vcoord_type = ', trim(vcoord_type), ' is unsupported!'
+        error stop '(readnml_vcoord)'
+    end select
     call gpu_set('expcnf', trim(expcnf))
     call gpu_set('pref', pref)
     call gpu_set('baclin', baclin)
@@ -140,6 +225,7 @@ contains
     call gpu_set('pgfmth', trim(pgfmth))
     call gpu_set('bmcmth', trim(bmcmth))
     call gpu_set('advmth', trim(advmth))
+    advect_cppm = trim(advmth) == 'cppm'
     call gpu_set('cppm_compatibility', trim(cppm_compatibility))
     call gpu_set('cppm_limiting', trim(cppm_limiting))
     if (cnsvdi) then

@@ -118,3 +118,80 @@ def test_run_length_and_error_behaviour_follow_the_reference(tmp_path, what):
         assert open(tmp_path / "run.status").read().strip() == "success"
         steps = re.findall(r"(?m)^\s*step\s+(\d+)", out.stdout)
         assert not steps or int(steps[-1]) == 5, steps[-3:]
+
+
+def limits_for_hybrid(dst):
+    """the reference's fuk95 limits file as it is -- cntiso_hybrid, cppm, &ALE_REGRID_REMAP with regrid_method = 'nudge' -- but
+    for the pressure gradient method (dynamic enthalpy is not built)"""
+    txt = open(os.path.join(HERE, "golden", "fuk95_limits")).read()
+    txt = txt.replace("PGFMTH   = 'dynamic enthalpy'", "PGFMTH   = 'geopotential'")
+    assert "VCOORD_TYPE            = 'cntiso_hybrid'" in txt and "ADVMTH   = 'cppm'" in txt and "'geopotential'" in txt
+    open(dst, "w").write(txt)
+
+
+def run_case_hybrid(tmp_path, exe, backend_cls, nsteps):
+    """The hybrid-coordinate step from the Fortran host: options from the reference's own tests/fuk95/limits
+    (&VCOORD, &ALE_REGRID_REMAP, the mixed layer restratification variables of &LIMITS), the pressure levels from plevel_spec =
+    'inflation' (phy/mod_vcoord.F90:948-955); the fields the left-out routines would produce travel in the state file."""
+    import numpy as np
+    case = make_case("fuk95_ref", advmth="cppm")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    gpu = backend_cls(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
+    hostinit.init_state(gpu, case)
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    rng = np.random.default_rng(3)
+    z = np.arange(kk + 1)[:, None, None] / kk
+    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
+        gpu.put(nm, 1e-5 + 10.0 ** rng.uniform(-3.5, -2.0, (1, nj, ni)) * np.exp(-((z - 0.1) / 0.15) ** 2))
+    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
+        a = np.clip(1.0 - z / rng.uniform(0.1, 0.6, (1, nj, ni)), 0.0, 1.0) ** 2
+        a[0] = 1.0
+        gpu.put(nm, a)
+    ssw = -rng.uniform(0.0, 150.0, (1, nj, ni))
+    for nm, a in (("sswflx", ssw), ("surflx", ssw + rng.uniform(-100.0, 100.0, (1, nj, ni))), ("salflx", rng.uniform(-2e-3, 2e-3, (1, nj, ni))),
+                  ("swfc1", 0.6 * np.ones((1, nj, ni))), ("swfc2", 0.4 * np.ones((1, nj, ni))), ("swal1", np.ones((1, nj, ni))),
+                  ("swal2", 15.0 * np.ones((1, nj, ni))), ("OBLdepth", 10.0 ** rng.uniform(0.8, 2.0, (1, nj, ni)))):
+        gpu.put(nm, a)
+    names = [n for n in gpu.field_names() if n not in ("mpack", "ip", "iu", "iv", "iq") and not n.startswith("wkp")]
+    state = str(tmp_path / "blom_state.bin")
+    bare = make_case("fuk95_ref")
+    bare.params = {k: v for k, v in bare.params.items() if k in ("baclin",)}
+    write_state(state, gpu, bare, 0, names)
+    limits_for_hybrid(str(tmp_path / "limits"))
+    out = subprocess.run([exe, state, str(nsteps)], cwd=str(tmp_path), capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "VCOORD_TYPE cntiso_hybrid" in out.stdout
+    got = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"chksum: (\w+): 0x([0-9A-Fa-f]+)", out.stdout)}
+    # the same options by hand, as the namelist file gives them
+    gpu.set("delt1", case.params["baclin"])
+    gpu.set("pref", 0.0)
+    gpu.set("pgfmth", "geopotential")
+    gpu.set("vcoord_type", "cntiso_hybrid")
+    gpu.set("ale_regrid_method", "nudge")
+    gpu.set("ale_k_range_plevel", 4)
+    gpu.set_vector("plevel", 1.5 * 9806.0 * np.arange(kk))
+    gpu.set("mlrmth", "fox08")
+    gpu.set("ce", 0.0)
+    gpu.set("brine_mlbase_frac", 1.0)
+    six0 = hostinit.step_indices(0, kk)
+    gpu.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
+    gpu.stage("cmnfld1", *six0)
+    assert gpu.step(0, nsteps) == nsteps
+    want = {"dp": gpu.crc("dp", 1, 2 * kk, 1), "temp": gpu.crc("temp", 1, 2 * kk, 1), "u": gpu.crc("u", 1, 2 * kk, 13)}
+    uu = gpu.get("u")[:, 4:-4, 4:-4]
+    assert np.isfinite(uu[np.broadcast_to((iu[4:-4, 4:-4] > 0)[None], uu.shape)]).all()
+    gpu.close()
+    assert got == want, (got, want, out.stdout[-2000:])
+    assert open(tmp_path / "run.status").read().strip() == "success"
+
+
+@pytest.mark.skipif(not (os.path.exists(EMU) and os.path.exists(EXE)), reason="tests/hostemu not built")
+def test_reference_limits_file_drives_the_hybrid_step(tmp_path):
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    try:
+        run_case_hybrid(tmp_path, EXE, g.BlomGpu, 4)
+    finally:
+        g.LIB_PATH = old
