@@ -21,59 +21,156 @@
   const size_t c = t_
 #define L(a, k) (a)[c + (size_t)((k)-1) * np]
 
-__global__ __launch_bounds__(64) void k_ale_vdifft(const DevView *__restrict__ Vp, int nn) {
+// T, S and up to NTB tracers of a column in ONE forward and ONE backward sweep.  The reference solves field after field (:112-203);
+// the systems of T and of the tracers have the same matrix (nutrc = Kdiff_t), and no solve reads what another wrote, so the
+// statements of the separate solves are carried out side by side, each exactly as it stands: fp(k) = nu(k) * fpbase(k) is formed
+// once per matrix and level and carried to the next level (the reference forms it as fp(k+1) at level k and again as fp(k) at
+// level k+1: the same product), bei and gam once per matrix.  What the sweeps read at the next VU levels is loaded before the
+// recurrence of the current ones runs (the loads do not depend on it).  Tracers beyond NTB: further passes with the same code.
+#define VU 4
+template <int NTB, bool TS>
+__device__ __forceinline__ void vdifft_pass(const DevView &V, size_t c, int nn, int nt0) {
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double cpi = 1. / SPCIFH, dtg = V.P.delt1 * GRAV, cc = GRAV * GRAV * V.P.delt1 / (ALPHA0 * ALPHA0);
+  const double *__restrict__ dp = V.f[F_dp] + (size_t)nn * np;
+  double *__restrict__ temp = V.f[F_temp] + (size_t)nn * np, *__restrict__ saln = V.f[F_saln] + (size_t)nn * np;
+  double *__restrict__ gamT = WK(V, 0), *__restrict__ gamS = WK(V, 1);
+  const double *__restrict__ nut = V.f[F_kdiff_t], *__restrict__ nus = V.f[F_kdiff_s];
+  const double hfsw = V.f[F_sswflx][c], hfns = V.f[F_surflx][c] - hfsw, hfrs = V.f[F_surrlx][c];       // :86-93
+  const double sfbr = V.f[F_brnflx][c], sfnb = V.f[F_salflx][c] - sfbr, sfrs = V.f[F_salrlx][c];
+  const double *__restrict__ tns = V.f[F_t_ns_nonloc], *__restrict__ tsw = V.f[F_t_sw_nonloc], *__restrict__ trs = V.f[F_t_rs_nonloc];
+  const double *__restrict__ snb = V.f[F_s_nb_nonloc], *__restrict__ sbr = V.f[F_s_br_nonloc], *__restrict__ srs = V.f[F_s_rs_nonloc];
+  double *xtr[NTB > 0 ? NTB : 1];
+  double tf[NTB > 0 ? NTB : 1];
+#pragma unroll
+  for (int q = 0; q < NTB; q++) {
+    xtr[q] = V.f[F_trc] + ((size_t)nn + (size_t)(nt0 + q) * 2 * kk) * np;
+    tf[q] = V.f[F_trflx][c + (size_t)(nt0 + q) * np];
+  }
+  // ---- level 1 (:112-120 and twins) -------------------------------------------------------------------------------------------
+  double dpk = L(dp, 1), dpk1 = L(dp, 2);
+  double fpb = cc / fmax2(DPMIN_VDIFF, .5 * (dpk + dpk1));                                               // fpbase(2), :108-110
+  double fT = L(nut, 2) * fpb, fS = L(nus, 2) * fpb;                                                     // fp(2) of the two matrices
+  double beiT = 1. / (dpk + fT), beiS = 1. / (dpk + fS);
+  double n_tns = L(tns, 2), n_tsw = L(tsw, 2), n_trs = L(trs, 2), n_snb = L(snb, 2), n_sbr = L(sbr, 2), n_srs = L(srs, 2);   // level k+1's
+  double xT = 0., xS = 0., xq[NTB > 0 ? NTB : 1];
+  if (TS) {
+    xT = (dpk * L(temp, 1) - ((1. - n_tns) * hfns + (1. - n_tsw) * hfsw + (1. - n_trs) * hfrs) * dtg * cpi) * beiT;
+    L(temp, 1) = xT;
+    xS = (dpk * L(saln, 1) - ((1. - n_snb) * sfnb + (1. - n_sbr) * sfbr + (1. - n_srs) * sfrs) * dtg) * beiS;
+    L(saln, 1) = xS;
+  }
+#pragma unroll
+  for (int q = 0; q < NTB; q++) {
+    xq[q] = (dpk * L(xtr[q], 1) - (1. - n_snb) * tf[q] * dtg) * beiT;
+    L(xtr[q], 1) = xq[q];
+  }
+  // ---- levels 2 .. kk ---------------------------------------------------------------------------------------------------------
+  dpk = dpk1;
+  for (int k0 = 2; k0 <= kk; k0 += VU) {
+    double a_dp[VU], a_nt[VU], a_ns[VU], a_tns[VU], a_tsw[VU], a_trs[VU], a_snb[VU], a_sbr[VU], a_srs[VU], a_t[VU], a_s[VU];
+    double a_x[NTB > 0 ? NTB : 1][VU];
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      const int k = k0 + u <= kk ? k0 + u : kk, k1 = k + 1 <= kk ? k + 1 : kk;       // level k+1 does not exist for k = kk: not used there
+      a_dp[u] = L(dp, k1); a_nt[u] = L(nut, k1); a_ns[u] = L(nus, k1);
+      a_snb[u] = L(snb, k + 1);
+      if (TS) {
+        a_tns[u] = L(tns, k + 1); a_tsw[u] = L(tsw, k + 1); a_trs[u] = L(trs, k + 1); a_sbr[u] = L(sbr, k + 1); a_srs[u] = L(srs, k + 1);
+        a_t[u] = L(temp, k); a_s[u] = L(saln, k);
+      }
+#pragma unroll
+      for (int q = 0; q < NTB; q++) a_x[q][u] = L(xtr[q], k);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      const int k = k0 + u;
+      if (k > kk) break;
+      const double c_tns = n_tns, c_tsw = n_tsw, c_trs = n_trs, c_snb = n_snb, c_sbr = n_sbr, c_srs = n_srs;   // level k's
+      n_snb = a_snb[u];
+      if (TS) { n_tns = a_tns[u]; n_tsw = a_tsw[u]; n_trs = a_trs[u]; n_sbr = a_sbr[u]; n_srs = a_srs[u]; }
+      const double gT = -fT * beiT, gS = -fS * beiS;
+      L(gamT, k) = gT;
+      if (TS) L(gamS, k) = gS;
+      double fT1 = 0., fS1 = 0.;
+      if (k < kk) {
+        dpk1 = a_dp[u];
+        fpb = cc / fmax2(DPMIN_VDIFF, .5 * (dpk + dpk1));
+        fT1 = a_nt[u] * fpb; fS1 = a_ns[u] * fpb;
+        beiT = 1. / (dpk + fT * (1. + gT) + fT1);
+        beiS = 1. / (dpk + fS * (1. + gS) + fS1);
+      } else {
+        beiT = 1. / (dpk + fT * (1. + gT));
+        beiS = 1. / (dpk + fS * (1. + gS));
+      }
+      if (TS) {
+        const double rT = dpk * a_t[u] - ((c_tns - n_tns) * hfns + (c_tsw - n_tsw) * hfsw + (c_trs - n_trs) * hfrs) * dtg * cpi;
+        xT = (rT + fT * xT) * beiT;
+        L(temp, k) = xT;
+        const double rS = dpk * a_s[u] - ((c_snb - n_snb) * sfnb + (c_sbr - n_sbr) * sfbr + (c_srs - n_srs) * sfrs) * dtg;
+        xS = (rS + fS * xS) * beiS;
+        L(saln, k) = xS;
+      }
+#pragma unroll
+      for (int q = 0; q < NTB; q++) {
+        const double r = dpk * a_x[q][u] - (c_snb - n_snb) * tf[q] * dtg;
+        xq[q] = (r + fT * xq[q]) * beiT;
+        L(xtr[q], k) = xq[q];
+      }
+      fT = fT1; fS = fS1; dpk = dpk1;
+    }
+  }
+  // ---- back substitution, k = kk-1 .. 1 ---------------------------------------------------------------------------------------
+  for (int k0 = kk - 1; k0 >= 1; k0 -= VU) {
+    double b_gT[VU], b_gS[VU], b_t[VU], b_s[VU], b_x[NTB > 0 ? NTB : 1][VU];
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      const int k = k0 - u >= 1 ? k0 - u : 1;
+      b_gT[u] = L(gamT, k + 1);
+      if (TS) { b_gS[u] = L(gamS, k + 1); b_t[u] = L(temp, k); b_s[u] = L(saln, k); }
+#pragma unroll
+      for (int q = 0; q < NTB; q++) b_x[q][u] = L(xtr[q], k);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      const int k = k0 - u;
+      if (k < 1) break;
+      if (TS) {
+        xT = b_t[u] - b_gT[u] * xT; L(temp, k) = xT;
+        xS = b_s[u] - b_gS[u] * xS; L(saln, k) = xS;
+      }
+#pragma unroll
+      for (int q = 0; q < NTB; q++) { xq[q] = b_x[q][u] - b_gT[u] * xq[q]; L(xtr[q], k) = xq[q]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_ale_vdifft(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   COL(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk, ntr = V.ntr;
-  const double cpi = 1. / SPCIFH, dtg = V.P.delt1 * GRAV, cc = GRAV * GRAV * V.P.delt1 / (ALPHA0 * ALPHA0);
   const double *dp = V.f[F_dp] + (size_t)nn * np;
   double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *sigma = V.f[F_sigma] + (size_t)nn * np;
-  double *gam = WK(V, 0);
-  const double *nut = V.f[F_kdiff_t], *nus = V.f[F_kdiff_s];
-  const double hfsw = V.f[F_sswflx][c], hfns = V.f[F_surflx][c] - hfsw, hfrs = V.f[F_surrlx][c];       // :86-93
-  const double sfbr = V.f[F_brnflx][c], sfnb = V.f[F_salflx][c] - sfbr, sfrs = V.f[F_salrlx][c];
-  auto fpbase = [&](int k) { return cc / fmax2(DPMIN_VDIFF, .5 * (L(dp, k - 1) + L(dp, k))); };         // :108-110
-  // one tridiagonal solve: x in place, fp(k) = nu(k) * fpbase(k), flux(k) the surface-flux term of level k
-  auto solve = [&](double *x, const double *nu, auto &&flux) {
-    double bei = 1. / (L(dp, 1) + L(nu, 2) * fpbase(2));
-    L(x, 1) = (L(dp, 1) * L(x, 1) - flux(1)) * bei;
-    for (int k = 2; k <= kk - 1; k++) {
-      const double fpk = L(nu, k) * fpbase(k), fpk1 = L(nu, k + 1) * fpbase(k + 1);
-      const double g = -fpk * bei;
-      L(gam, k) = g;
-      bei = 1. / (L(dp, k) + fpk * (1. + g) + fpk1);
-      const double rhs = L(dp, k) * L(x, k) - flux(k);
-      L(x, k) = (rhs + fpk * L(x, k - 1)) * bei;
+  // T and S with the first tracers, then the remaining tracers four at a time
+  const int n0 = ntr < 4 ? ntr : 4;
+  switch (n0) {
+    case 0: vdifft_pass<0, true>(V, c, nn, 0); break;
+    case 1: vdifft_pass<1, true>(V, c, nn, 0); break;
+    case 2: vdifft_pass<2, true>(V, c, nn, 0); break;
+    case 3: vdifft_pass<3, true>(V, c, nn, 0); break;
+    default: vdifft_pass<4, true>(V, c, nn, 0); break;
+  }
+  for (int nt0 = 4; nt0 < ntr; nt0 += 4) {
+    const int nb = ntr - nt0 < 4 ? ntr - nt0 : 4;
+    switch (nb) {
+      case 1: vdifft_pass<1, false>(V, c, nn, nt0); break;
+      case 2: vdifft_pass<2, false>(V, c, nn, nt0); break;
+      case 3: vdifft_pass<3, false>(V, c, nn, nt0); break;
+      default: vdifft_pass<4, false>(V, c, nn, nt0); break;
     }
-    {
-      const double fpk = L(nu, kk) * fpbase(kk);
-      const double g = -fpk * bei;
-      L(gam, kk) = g;
-      bei = 1. / (L(dp, kk) + fpk * (1. + g));
-      const double rhs = L(dp, kk) * L(x, kk) - flux(kk);
-      L(x, kk) = (rhs + fpk * L(x, kk - 1)) * bei;
-    }
-    for (int k = kk - 1; k >= 1; k--) L(x, k) = L(x, k) - L(gam, k + 1) * L(x, k + 1);
-  };
-  const double *tns = V.f[F_t_ns_nonloc], *tsw = V.f[F_t_sw_nonloc], *trs = V.f[F_t_rs_nonloc];
-  const double *snb = V.f[F_s_nb_nonloc], *sbr = V.f[F_s_br_nonloc], *srs = V.f[F_s_rs_nonloc];
-  solve(temp, nut, [&](int k) {                                                                          // :112-139
-    if (k == 1) return ((1. - L(tns, 2)) * hfns + (1. - L(tsw, 2)) * hfsw + (1. - L(trs, 2)) * hfrs) * dtg * cpi;
-    return ((L(tns, k) - L(tns, k + 1)) * hfns + (L(tsw, k) - L(tsw, k + 1)) * hfsw + (L(trs, k) - L(trs, k + 1)) * hfrs) * dtg * cpi;
-  });
-  solve(saln, nus, [&](int k) {                                                                          // :141-168
-    if (k == 1) return ((1. - L(snb, 2)) * sfnb + (1. - L(sbr, 2)) * sfbr + (1. - L(srs, 2)) * sfrs) * dtg;
-    return ((L(snb, k) - L(snb, k + 1)) * sfnb + (L(sbr, k) - L(sbr, k + 1)) * sfbr + (L(srs, k) - L(srs, k + 1)) * sfrs) * dtg;
-  });
-  for (int nt = 0; nt < ntr; nt++) {                                                                     // :170-203 (nutrc = Kdiff_t)
-    double *x = V.f[F_trc] + ((size_t)nn + (size_t)nt * 2 * kk) * np;
-    const double tf = V.f[F_trflx][c + (size_t)nt * np];
-    solve(x, nut, [&](int k) {
-      if (k == 1) return (1. - L(snb, 2)) * tf * dtg;
-      return (L(snb, k) - L(snb, k + 1)) * tf * dtg;
-    });
   }
   double sc = V.f[F_salt_corr][c];                                                                      // :205-222
   for (int k = 1; k <= kk; k++) {

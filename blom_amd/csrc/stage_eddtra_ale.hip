@@ -87,8 +87,16 @@ __global__ void k_eda_mixed_layer(const DevView *__restrict__ Vp, int nn, EdaPar
 }
 
 enum { E_PUV = 0, E_GM, E_SM, E_MFL, E_DLM, E_DLP, E_NARR };
+#define EU 4        /* levels whose loads a pass keeps in flight */
 
-// :1197-1738
+// :1197-1738.  The reference's ten loops over a column are three passes here, each statement as it stands:
+//   1. interface pressures puv, the last layer with mass kmax (:1224-1230); the mixed layer base is found on the way -- puv never
+//      decreases, so the run of interfaces below the base that the reference walks upwards from kmax (:1244-1251) starts at the
+//      first interface above pml;
+//   2. GM and submesoscale interface fluxes, their sum, the thicknesses the limiter may deplete (:1255-1301);
+//   -- the alternating-sweep limiter (:1306-1394), the sweep's shared interface value carried in a register --
+//   3. the split of the limited sum (:1398-1435) and the layer fluxes with the reference's bound checks (:1441-1466).
+// What a pass reads at the next EU levels is loaded before the current ones are worked on.
 __global__ void k_eda_column(const DevView *__restrict__ Vp, int n, int mm, int nn, EdaPar Q, int *__restrict__ errflag) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
@@ -98,37 +106,44 @@ __global__ void k_eda_column(const DevView *__restrict__ Vp, int n, int mm, int 
   const size_t np = V.nplane, xb = c, xa = isv ? c - V.ni : c - 1;
   const int kk = V.kk;
   const double ffac = .0625, fface = .99 * ffac, eps = 1.e-14, c5_21 = 5. / 21., delt1 = V.P.delt1;
-  double *mfgm = (isv ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np, *mfsm = (isv ? V.f[F_vmflsm] : V.f[F_umflsm]) + (size_t)mm * np;
-  const double *nslp = isv ? V.f[F_nslpy] : V.f[F_nslpx], *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  const double *p = V.f[F_p], *dp = V.f[F_dp] + (size_t)nn * np, *difint = V.f[F_difint];
+  double *__restrict__ mfgm = (isv ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
+  double *__restrict__ mfsm = (isv ? V.f[F_vmflsm] : V.f[F_umflsm]) + (size_t)mm * np;
+  const double *__restrict__ nslp = isv ? V.f[F_nslpy] : V.f[F_nslpx], *__restrict__ dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  const double *__restrict__ p = V.f[F_p], *__restrict__ dp = V.f[F_dp] + (size_t)nn * np, *__restrict__ difint = V.f[F_difint];
   const double *hmlb = V.f[F_hml_tfbnd], *scp2 = V.f[F_scp2];
 #define AT(a, x, k) (a)[(x) + (size_t)((k)-1) * np]
-  double *const wb = V.wk + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * E_NARR) * 64 + threadIdx.x;
+#define CLK(k, lo, hi) ((k) < (lo) ? (lo) : ((k) > (hi) ? (hi) : (k)))
+  double *__restrict__ const wb = V.wk + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * E_NARR) * 64 + threadIdx.x;
 #define W(a, k) wb[((size_t)((k)-1) * E_NARR + (a)) * 64]
-  for (int k = 1; k <= kk; k++) { AT(mfgm, xb, k) = 0.; AT(mfsm, xb, k) = 0.; }        // :1209-1213
   const double mfleps = eps * EPSILP * (isv ? V.f[F_scv2] : V.f[F_scu2])[c];           // :1216
   const double et2mf = -GRAV * RHO0 * delt1 * (isv ? V.f[F_scvx] : V.f[F_scuy])[c];    // :1219
   const double pt = fmax2(AT(p, xa, 1), AT(p, xb, 1));                                 // ptu / ptv, :1182-1194
-  // interface pressures and the last layer with mass on either side, :1224-1230
-  int kmax = 1;
+  const double hml = .5 * (hmlb[xa] + hmlb[xb]);                                       // :1233
+  const double puv1 = pt, pml_a = puv1 + hml * ONEM;
+  // ---- pass 1 ------------------------------------------------------------------------------------------------------------------
+  int kmax = 1, ka = kk + 2;                   // ka: first interface k >= 2 with puv(k) > puv(1) + hml*onem
   {
     double a = pt;
     W(E_PUV, 1) = a;
-    for (int k = 1; k <= kk; k++) {
-      a = a + AT(dpz, xb, k);
-      W(E_PUV, k + 1) = a;
-      if (AT(dp, xa, k) > EPSILP || AT(dp, xb, k) > EPSILP) kmax = k;
+    for (int k0 = 1; k0 <= kk; k0 += EU) {
+      double a0[EU], a1[EU], a2[EU];
+#pragma unroll
+      for (int u = 0; u < EU; u++) { const int kq = CLK(k0 + u, 1, kk); a0[u] = AT(dpz, xb, kq); a1[u] = AT(dp, xa, kq); a2[u] = AT(dp, xb, kq); }
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const int k = k0 + u;
+        if (k > kk) break;
+        AT(mfgm, xb, k) = 0.; AT(mfsm, xb, k) = 0.;                                    // :1209-1213
+        a = a + a0[u];
+        W(E_PUV, k + 1) = a;
+        if (a1[u] > EPSILP || a2[u] > EPSILP) kmax = k;
+        if (a > pml_a && ka > k + 1) ka = k + 1;
+      }
     }
   }
-  const double hml = .5 * (hmlb[xa] + hmlb[xb]);                                       // :1233
-  const double puv1 = pt;
-  const double pml = fmin2(puv1 + hml * ONEM, W(E_PUV, kmax + 1));                     // :1236
+  const double pml = fmin2(pml_a, W(E_PUV, kmax + 1));                                 // :1236
   const double dpmli = 1. / (pml - puv1);                                              // :1240
-  int kml = kmax + 1;                                                                  // :1244-1251
-  for (int k = kmax; k >= 2; k--) {
-    if (W(E_PUV, k) > pml) kml = k;
-    else break;
-  }
+  const int kml = ka <= kmax ? ka : kmax + 1;                                          // :1244-1251
   // the submesoscale transport of the column (upsilon), :1125-1176 (fox08) or zero (:1030-1044)
   double upssm = 0.;
   if (Q.mlrmth == 1) {
@@ -139,40 +154,55 @@ __global__ void k_eda_column(const DevView *__restrict__ Vp, int n, int mm, int 
     const double drho = V.f[F_util1][xb] - V.f[F_util1][xa];
     upssm = csm * hml * hml * drho * lfi * absfi;
   }
-  // GM mass flux below the mixed layer base, :1255-1260
-  for (int k = kml; k <= kmax; k++) {
-    const double kappa = .25 * (AT(difint, xa, k - 1) + AT(difint, xb, k - 1) + AT(difint, xa, k) + AT(difint, xb, k));
-    W(E_GM, k) = -kappa * AT(nslp, xb, k) * et2mf;
-  }
-  W(E_GM, kmax + 1) = 0.;
-  // linear in interface pressure inside the mixed layer, :1265-1268
-  W(E_GM, 1) = 0.;
-  {
-    const double gml = W(E_GM, kml);
-    for (int k = 2; k <= kml - 1; k++) W(E_GM, k) = gml * (W(E_PUV, k) - puv1) * dpmli;
-  }
-  // submesoscale mass flux inside the mixed layer, :1273-1280
-  W(E_SM, 1) = 0.;
-  for (int k = 2; k <= kml - 1; k++) {
-    const double r = 2. * (puv1 - W(E_PUV, k)) * dpmli + 1.;
-    const double q = r * r;
-    W(E_SM, k) = -upssm * (1. - q) * (1. + c5_21 * q) * et2mf;
-  }
-  for (int k = kml; k <= kmax + 1; k++) W(E_SM, k) = 0.;
-  for (int k = 1; k <= kmax + 1; k++) W(E_MFL, k) = W(E_GM, k) + W(E_SM, k);           // :1288-1290
-  // thicknesses available to the fluxes, :1296-1301
+  // ---- pass 2 ------------------------------------------------------------------------------------------------------------------
   const double pb = (isv ? V.f[F_pbv] : V.f[F_pbu])[c + (size_t)(n - 1) * np];
   const double scp2a = scp2[xa], scp2b = scp2[xb];
+  auto gm_below = [&](int k, double d0, double d1, double d2, double d3, double sl) {  // :1255-1259
+    (void)k;
+    const double kappa = .25 * (d0 + d1 + d2 + d3);
+    return -kappa * sl * et2mf;
+  };
+  double gml = 0.;                                                                     // mflgm(kml): :1260 when kml = kmax+1
+  if (kml <= kmax) gml = gm_below(kml, AT(difint, xa, kml - 1), AT(difint, xb, kml - 1), AT(difint, xa, kml), AT(difint, xb, kml), AT(nslp, xb, kml));
   {
     double pa_k = AT(p, xa, 1), pb_k = AT(p, xb, 1);
-    for (int k = 1; k <= kmax; k++) {
-      const double pa1 = AT(p, xa, k + 1), pb1 = AT(p, xb, k + 1);
-      W(E_DLM, k) = fmax2(0., fmin2(pa1, pb) - fmax2(pa_k, pt));
-      W(E_DLP, k) = fmax2(0., fmin2(pb1, pb) - fmax2(pb_k, pt));
-      pa_k = pa1; pb_k = pb1;
+    for (int k0 = 1; k0 <= kmax + 1; k0 += EU) {
+      double d0[EU], d1[EU], d2[EU], d3[EU], sl[EU], pu[EU], a0[EU], a1[EU];
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const int kq = CLK(k0 + u, 2, kk);                   // difint(k-1), difint(k), nslp(k): read for kml <= k <= kmax only
+        d0[u] = AT(difint, xa, kq - 1); d1[u] = AT(difint, xb, kq - 1); d2[u] = AT(difint, xa, kq); d3[u] = AT(difint, xb, kq);
+        sl[u] = AT(nslp, xb, kq);
+        pu[u] = W(E_PUV, CLK(k0 + u, 1, kk + 1));
+        const int kp = CLK(k0 + u, 1, kk);                   // p(k+1) of the two columns: read for k <= kmax only
+        a0[u] = AT(p, xa, kp + 1); a1[u] = AT(p, xb, kp + 1);
+      }
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const int k = k0 + u;
+        if (k > kmax + 1) break;
+        double gm, sm;
+        if (k == 1) { gm = 0.; sm = 0.; }                                              // :1264, :1272
+        else if (k < kml) {
+          gm = gml * (pu[u] - puv1) * dpmli;                                           // :1265-1268
+          const double r = 2. * (puv1 - pu[u]) * dpmli + 1.;
+          const double q = r * r;
+          sm = -upssm * (1. - q) * (1. + c5_21 * q) * et2mf;                           // :1273-1277
+        } else {
+          gm = k <= kmax ? gm_below(k, d0[u], d1[u], d2[u], d3[u], sl[u]) : 0.;        // :1255-1260
+          sm = 0.;                                                                     // :1278-1280
+        }
+        W(E_GM, k) = gm; W(E_SM, k) = sm;
+        W(E_MFL, k) = gm + sm;                                                         // :1288-1290
+        if (k <= kmax) {                                                               // :1296-1301
+          W(E_DLM, k) = fmax2(0., fmin2(a0[u], pb) - fmax2(pa_k, pt));
+          W(E_DLP, k) = fmax2(0., fmin2(a1[u], pb) - fmax2(pb_k, pt));
+          pa_k = a0[u]; pb_k = a1[u];
+        }
+      }
     }
   }
-  // iterative limiter by alternating sweeps, :1306-1394
+  // ---- iterative limiter by alternating sweeps, :1306-1394 ----------------------------------------------------------------------
   bool changed = true;
   int niter = 0, kdir = 1;
   while (changed) {
@@ -180,77 +210,102 @@ __global__ void k_eda_column(const DevView *__restrict__ Vp, int n, int mm, int 
     if (niter == 1000) { atomicOr(errflag, 1); return; }
     changed = false;
     kdir = -kdir;
-    const int kb = (1 + kdir + (1 - kdir) * kmax) / 2, ke = (1 - kdir + (1 + kdir) * kmax) / 2;
-    for (int k = kb; kdir > 0 ? k <= ke : k >= ke; k += kdir) {
-      double lo = W(E_MFL, k), hi = W(E_MFL, k + 1);
-      if (fabs(hi - lo) > fmax2(mfleps, eps * fabs(hi + lo))) {
-        const double dm = W(E_DLM, k), dq = W(E_DLP, k);
-        if (hi - lo > ffac * fmax2(EPSILP, dm) * scp2a) {
-          const double q = fface * dm * scp2a;
-          if (hi > -lo) {
-            if (lo > -.5 * q) hi = lo + q;
-            else { hi = .5 * q; lo = -hi; }
-          } else {
-            if (hi < .5 * q) lo = hi - q;
-            else { lo = -.5 * q; hi = -lo; }
+    // a sweep walks the layers 1..kmax pairwise; the value a step leaves in the interface it shares with the next step travels in
+    // a register, the far interface and the two thicknesses of EU steps are loaded ahead (no step writes what a later step's
+    // look-ahead reads)
+    const bool up = kdir > 0;
+    double carry = up ? W(E_MFL, 1) : W(E_MFL, kmax + 1);
+    for (int s0 = 0; s0 <= kmax - 1; s0 += EU) {
+      double a0[EU], a1[EU], a2[EU];
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const int st = s0 + u <= kmax - 1 ? s0 + u : kmax - 1;
+        const int kq = up ? 1 + st : kmax - st;
+        a0[u] = up ? W(E_MFL, kq + 1) : W(E_MFL, kq); a1[u] = W(E_DLM, kq); a2[u] = W(E_DLP, kq);
+      }
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        if (s0 + u > kmax - 1) break;
+        const int k = up ? 1 + s0 + u : kmax - s0 - u;
+        double lo = up ? carry : a0[u], hi = up ? a0[u] : carry;
+        if (fabs(hi - lo) > fmax2(mfleps, eps * fabs(hi + lo))) {
+          const double dm = a1[u], dq = a2[u];
+          if (hi - lo > ffac * fmax2(EPSILP, dm) * scp2a) {
+            const double q = fface * dm * scp2a;
+            if (hi > -lo) {
+              if (lo > -.5 * q) hi = lo + q;
+              else { hi = .5 * q; lo = -hi; }
+            } else {
+              if (hi < .5 * q) lo = hi - q;
+              else { lo = -.5 * q; hi = -lo; }
+            }
+            W(E_MFL, k) = lo; W(E_MFL, k + 1) = hi;
+            changed = true;
+          } else if (hi - lo < -ffac * fmax2(EPSILP, dq) * scp2b) {
+            const double q = fface * dq * scp2b;
+            if (hi < -lo) {
+              if (lo < .5 * q) hi = lo - q;
+              else { hi = -.5 * q; lo = -hi; }
+            } else {
+              if (hi > -.5 * q) lo = hi + q;
+              else { lo = .5 * q; hi = -lo; }
+            }
+            W(E_MFL, k) = lo; W(E_MFL, k + 1) = hi;
+            changed = true;
           }
-          W(E_MFL, k) = lo; W(E_MFL, k + 1) = hi;
-          changed = true;
-        } else if (hi - lo < -ffac * fmax2(EPSILP, dq) * scp2b) {
-          const double q = fface * dq * scp2b;
-          if (hi < -lo) {
-            if (lo < .5 * q) hi = lo - q;
-            else { hi = -.5 * q; lo = -hi; }
-          } else {
-            if (hi > -.5 * q) lo = hi + q;
-            else { lo = .5 * q; hi = -lo; }
-          }
-          W(E_MFL, k) = lo; W(E_MFL, k + 1) = hi;
-          changed = true;
         }
+        carry = up ? hi : lo;
       }
     }
   }
-  // the two parts follow the limited sum, :1398-1435
-  for (int k = 1; k <= kmax + 1; k++) {
-    const double mfl = W(E_MFL, k);
-    double gm = W(E_GM, k), sm = W(E_SM, k);
-    if (fabs(mfl) < mfleps) {
-      W(E_MFL, k) = 0.;
-      gm = 0.; sm = 0.;
-    } else if (mfl > 0.) {
-      if (gm > sm) {
-        if (mfl > 2. * sm) gm = mfl - sm;
-        else { gm = .5 * mfl; sm = gm; }
-      } else {
-        if (mfl > 2. * gm) sm = mfl - gm;
-        else { sm = .5 * mfl; gm = sm; }
-      }
-    } else {
-      if (gm < sm) {
-        if (mfl < 2. * sm) gm = mfl - sm;
-        else { gm = .5 * mfl; sm = gm; }
-      } else {
-        if (mfl < 2. * gm) sm = mfl - gm;
-        else { sm = .5 * mfl; gm = sm; }
-      }
-    }
-    W(E_GM, k) = gm; W(E_SM, k) = sm;
-  }
-  // final mass fluxes and the reference's bound checks, :1441-1466
+  // ---- pass 3: the two parts follow the limited sum (:1398-1435); layer fluxes and the reference's bound checks (:1441-1466) ------
   {
-    double lo = W(E_MFL, 1), glo = W(E_GM, 1), slo = W(E_SM, 1);
-    for (int k = 1; k <= kmax; k++) {
-      const double hi = W(E_MFL, k + 1), ghi = W(E_GM, k + 1), shi = W(E_SM, k + 1);
-      double fg = 0., fs = 0.;
-      if (fabs(hi - lo) > fmax2(mfleps, eps * fabs(hi + lo))) { fg = ghi - glo; fs = shi - slo; }
-      AT(mfgm, xb, k) = fg;
-      AT(mfsm, xb, k) = fs;
-      if (fg + fs > ffac * fmax2(EPSILP, W(E_DLM, k)) * scp2a || fg + fs < -ffac * fmax2(EPSILP, W(E_DLP, k)) * scp2b) atomicOr(errflag, 2);
-      lo = hi; glo = ghi; slo = shi;
+    double lo = 0., glo = 0., slo = 0.;
+    for (int k0 = 1; k0 <= kmax + 1; k0 += EU) {
+      double am[EU], ag[EU], as[EU], a1[EU], a2[EU];
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const int kq = CLK(k0 + u, 1, kmax + 1), kl = CLK(k0 + u - 1, 1, kmax);
+        am[u] = W(E_MFL, kq); ag[u] = W(E_GM, kq); as[u] = W(E_SM, kq);
+        a1[u] = W(E_DLM, kl); a2[u] = W(E_DLP, kl);                 // of the layer above interface k
+      }
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const int k = k0 + u;
+        if (k > kmax + 1) break;
+        double mfl = am[u], gm = ag[u], sm = as[u];
+        if (fabs(mfl) < mfleps) {
+          mfl = 0.; gm = 0.; sm = 0.;
+        } else if (mfl > 0.) {
+          if (gm > sm) {
+            if (mfl > 2. * sm) gm = mfl - sm;
+            else { gm = .5 * mfl; sm = gm; }
+          } else {
+            if (mfl > 2. * gm) sm = mfl - gm;
+            else { sm = .5 * mfl; gm = sm; }
+          }
+        } else {
+          if (gm < sm) {
+            if (mfl < 2. * sm) gm = mfl - sm;
+            else { gm = .5 * mfl; sm = gm; }
+          } else {
+            if (mfl < 2. * gm) sm = mfl - gm;
+            else { sm = .5 * mfl; gm = sm; }
+          }
+        }
+        if (k >= 2) {                                         // layer k-1 between the interfaces k-1 (lo) and k (hi)
+          double fg = 0., fs = 0.;
+          if (fabs(mfl - lo) > fmax2(mfleps, eps * fabs(mfl + lo))) { fg = gm - glo; fs = sm - slo; }
+          AT(mfgm, xb, k - 1) = fg;
+          AT(mfsm, xb, k - 1) = fs;
+          if (fg + fs > ffac * fmax2(EPSILP, a1[u]) * scp2a || fg + fs < -ffac * fmax2(EPSILP, a2[u]) * scp2b) atomicOr(errflag, 2);
+        }
+        lo = mfl; glo = gm; slo = sm;
+      }
     }
   }
 #undef W
+#undef CLK
 #undef AT
 }
 
