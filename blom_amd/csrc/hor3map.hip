@@ -106,37 +106,37 @@ __device__ inline void h3_report(int *err, unsigned long long *first_fail, int c
 
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_prepare(H3Grid g, unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   h3_report(g.err, ff, col, h3_prepare_reconstruction(g, col));
 }
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_reconstruct(H3Grid g, H3Src s, const double *uin,
                                                               unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   h3_report(g.err, ff, col, h3_reconstruct(g, s, uin, col));
 }
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_extract(H3Grid g, H3Src s, double *out, unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   h3_report(g.err, ff, col, h3_extract_polycoeff(g, s, out, col));
 }
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_regrid(H3Grid g, H3Src s, int ng, const double *ugrd,
                                                          double *xgrd, double missing, int method,
                                                          unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   h3_report(g.err, ff, col, h3_regrid(g, s, col, ng, ugrd, xgrd, missing, method));
 }
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_prepare_remap(H3Grid g, H3Map r, const double *xdst,
                                                                 unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   h3_report(g.err, ff, col, h3_prepare_remapping(g, r, xdst, col));
 }
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_remap(H3Grid g, H3Src s, H3Map r, double *udst,
                                                         unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   h3_report(g.err, ff, col, h3_remap(g, s, r, udst, col));
 }
 
@@ -151,21 +151,21 @@ struct H3SrcSet {
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_reconstruct_many(H3Grid g, H3SrcSet S, int *err_f,
                                                                    unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   const int f = blockIdx.y;
   h3_report(err_f + (size_t)f * g.nc, ff, col, h3_reconstruct(g, S.s[f], S.io[f], col));
 }
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_remap_many(H3Grid g, H3SrcSet S, H3Map r, int *err_f,
                                                              unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   const int f = blockIdx.y;
   h3_report(err_f + (size_t)f * g.nc, ff, col, h3_remap(g, S.s[f], r, S.io[f], col));
 }
 
 __global__ __launch_bounds__(H3_BLOCK) void k_h3m_extract_many(H3Grid g, H3SrcSet S, int *err_f, unsigned long long *ff) {
   const int col = blockIdx.x * H3_BLOCK + threadIdx.x;
-  if (col >= g.nc) return;
+  if (col >= g.nc || (g.active && !g.active[col])) return;
   const int f = blockIdx.y;
   h3_report(err_f + (size_t)f * g.nc, ff, col, h3_extract_polycoeff(g, S.s[f], S.io[f], col));
 }
@@ -459,6 +459,13 @@ int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream) {
 int h3m_set_stream(blomgpu_h3m_grid *G, hipStream_t stream) {
   if (!G || G->own_stream) return E_HANDLE;
   G->stream = stream;
+  return 0;
+}
+// inside the library (stage_ale.hip): columns whose entry in `active` (one int per column, device memory) is 0 take no part in
+// the launches that follow -- land and the halo beyond the ring the stage needs; their structures and outputs stay as they are
+int h3m_set_active(blomgpu_h3m_grid *G, const int *active) {
+  if (!G) return E_HANDLE;
+  G->g.active = active;
   return 0;
 }
 // inside the library: the polynomial coefficients of several sources of one grid in one launch, written where the caller's

@@ -51,6 +51,7 @@ struct H3Grid {
   int *sdi;                      // src_dst_index (n_src)
   int *n_act, *m_act, *lb_act, *rb_act, *prepared, *err;
   int *prev, *next;              // work: doubly linked list of the merge passes (n_src)
+  const int *active;             // optional (library-internal callers): columns with 0 here are left out of every launch
 };
 struct H3Src {
   int limiting, pc_left, pc_right;

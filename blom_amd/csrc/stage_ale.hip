@@ -29,6 +29,7 @@ int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream);          // hor3map
 int h3m_sequence_begin(blomgpu_h3m_grid *G);
 int h3m_sequence_end(blomgpu_h3m_grid *G);
 int h3m_set_stream(blomgpu_h3m_grid *G, hipStream_t stream);
+int h3m_set_active(blomgpu_h3m_grid *G, const int *active);
 int h3m_extract_polycoeff_many(blomgpu_h3m_grid *G, int nf, blomgpu_h3m_src *const *srcs, double *const *outs);
 
 #define H3M_MAXF 8
@@ -45,6 +46,7 @@ struct AleState {
   blomgpu_h3m_map *map_uv = nullptr;
   hipStream_t side = nullptr;               // launches that do not depend on each other run beside the model's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int *active = nullptr;                    // nplane + 2 * nplane flags: the columns the engine works on (the others are land or halo)
   double *plane = nullptr;                  // scratch: p_src, p_dst (kk+1 planes each), remapped fields (kk planes each)
   size_t plane_n = 0;
   int ntr_loc = 0, method = 0;
@@ -59,6 +61,7 @@ void ale_free(blomgpu_ctx *c) {
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
   if (a->ev_join) (void)hipEventDestroy(a->ev_join);
   if (a->plane) (void)hipFree(a->plane);
+  if (a->active) (void)hipFree(a->active);
   delete a;
   c->ale = nullptr;
 }
@@ -106,6 +109,8 @@ static int ale_prepare(blomgpu_ctx *c) {
   // p_src, p_dst | remapped fields | polynomial coefficients of T and S (5 per layer at most) | sig_src | sig_trg
   a->plane_n = ((size_t)2 * (h.kk + 1) + (size_t)H3M_MAXF * h.kk + (size_t)10 * h.kk + h.kk + (h.kk + 1)) * h.nplane;
   HIPCHK(c, hipMalloc((void **)&a->plane, sizeof(double) * a->plane_n));
+  HIPCHK(c, hipMalloc((void **)&a->active, sizeof(int) * 3 * h.nplane));
+  if ((rc = h3m_set_active(a->grid, a->active)) || (rc = h3m_set_active(a->grid_uv, a->active + h.nplane))) return ale_fail(c, "active", rc);
   return 0;
 }
 
@@ -118,12 +123,13 @@ static int ale_prepare(blomgpu_ctx *c) {
 // source interfaces of the p-columns (:203-211) and their regridded positions for vcoord_type = 'plevel' (:263-284);
 // any other point of the plane: unit layers, left where they are
 __global__ void k_ale_p_src_dst(const DevView *__restrict__ Vp, int nn, const double *__restrict__ plevel, double *__restrict__ psrc,
-                                double *__restrict__ pdst, int ring) {
+                                double *__restrict__ pdst, int ring, int *__restrict__ active) {
   const DevView &V = *Vp;
   PLANE_T(V);
   const size_t np = V.nplane;
   const int kk = V.kk;
   const bool col = j >= 1 - ring && j <= V.jj + ring && i >= 1 - ring && i <= V.ii + ring && V.m[I_ip][c];
+  active[c] = col;                                               // the engine leaves the other columns out
   if (!col) {
     for (int k = 0; k <= kk; k++) { psrc[c + (size_t)k * np] = (double)k; pdst[c + (size_t)k * np] = (double)k; }
     return;
@@ -687,18 +693,15 @@ __global__ void k_ale_pscan(const DevView *__restrict__ Vp, int nn) {
 // velocities themselves, as columns c and nplane + c of one grid of 2 * nplane columns: the source interfaces are the old ones
 // rescaled to the new depth of the column
 __global__ void k_ale_uv_src_dst(const DevView *__restrict__ Vp, int nn, double *__restrict__ psrc, double *__restrict__ pdst,
-                                 double *__restrict__ uin) {
+                                 double *__restrict__ uin, int *__restrict__ active) {
   const DevView &V = *Vp;
   PLANE_T(V);
   const int isv = blockIdx.y;
   const size_t np = V.nplane, nc = 2 * np, cc = c + (size_t)isv * np;
   const int kk = V.kk;
   const bool col = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && (isv ? V.m[I_iv][c] : V.m[I_iu][c]);
-  if (!col) {
-    for (int k = 0; k <= kk; k++) { psrc[cc + (size_t)k * nc] = (double)k; pdst[cc + (size_t)k * nc] = (double)k; }
-    for (int k = 0; k < kk; k++) uin[cc + (size_t)k * nc] = 0.;
-    return;
-  }
+  active[cc] = col;
+  if (!col) return;                                              // the engine leaves the column out; nothing reads its planes
   const double *pz = isv ? V.f[F_pv] : V.f[F_pu], *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
   const double *uz = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
   double a = pz[c];
@@ -741,7 +744,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     if (int rc2 = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
     if (int rc2 = st_xctilr(c, h.f[F_sigma] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
   }
-  hipLaunchKernelGGL(k_ale_p_src_dst, g1, b, 0, c->stream, c->d, nn, (const double *)c->ale_plevel, psrc, pdst, ring);
+  hipLaunchKernelGGL(k_ale_p_src_dst, g1, b, 0, c->stream, c->d, nn, (const double *)c->ale_plevel, psrc, pdst, ring, a->active);
   if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid, psrc))) return ale_fail(c, "prepare_reconstruction", rc);
   // Beside the model's stream: the reconstruction of the first batch's fields that the regridding does not look at -- all of
   // them for pressure levels, the tracers for the density-following coordinate (T and S are reconstructed for the regridding
@@ -829,7 +832,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   {
     // u- and v-columns as one grid of 2 * nplane columns; its planes lie where the tracers' scratch did
     double *ps2 = a->plane, *pd2 = ps2 + (size_t)2 * (h.kk + 1) * np, *ui2 = pd2 + (size_t)2 * (h.kk + 1) * np, *rm2 = ui2 + (size_t)2 * per;
-    hipLaunchKernelGGL(k_ale_uv_src_dst, dim3((unsigned)((np + 255) / 256), 2), b, 0, c->stream, c->d, nn, ps2, pd2, ui2);
+    hipLaunchKernelGGL(k_ale_uv_src_dst, dim3((unsigned)((np + 255) / 256), 2), b, 0, c->stream, c->d, nn, ps2, pd2, ui2, a->active + np);
     if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid_uv, ps2))) return ale_fail(c, "prepare_reconstruction (velocity)", rc);
     // the segments of the destination grid and the reconstruction need the prepared grid, not each other
     if (int rc2 = fork()) return rc2;
