@@ -221,24 +221,11 @@ HYBRID_INPUTS = ["kvisc_m", "kdiff_t", "kdiff_s", "t_ns_nonloc", "s_nb_nonloc", 
                  "sswflx", "surflx", "surrlx", "brnflx", "salflx", "salrlx", "swfc1", "swfc2", "swal1", "swal2", "OBLdepth", "trflx"]
 
 
-@pytest.mark.parametrize("cfg,npx,npy,vcoord,method,advmth", [
-    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("box_s", 2, 2, "cntiso_hybrid", "direct", "cppm"),
-    ("tri_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("tri_s", 4, 2, "plevel", "direct", "cppm"), ("chan_s", 1, 2, "plevel", "nudge", "remap")])
-def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method, advmth):
-    """The step of the hybrid vertical coordinate (DESIGN.md 3h: ale_regrid_remap, cmnfld2's hybrid branches, eddtra_ale, advect,
-    .., ale_forcing, ale_vdifft/m, .., cmnfld1) on a decomposed domain: every halo update of the new stages -- the ring of the
-    lateral smoothing, the bounded mixed layer depth and the mixed layer density of eddtra_ale, the viscosity of ale_vdiffm, the
-    slopes and buoyancy frequencies of cmnfld -- goes through the tile transport.  Interiors after a few steps as on the single tile."""
-    from blom_amd.gpu import BlomGpu, TileGroup
-    nsteps = 3
-    case = make_case(cfg, advmth=advmth)
-    _, masks, fields, ref = _single(cfg, nsteps)
-    for nm, v in case.params.items():
-        if not nm.endswith("0"):
-            ref.set(nm, v)
-    ref.set("delt1", case.params["baclin"])
+def hybrid_inputs(case, seed=11):
+    """what the routines the hybrid step leaves out would produce (diffusivities, non-local fractions, surface fluxes, absorption
+    bands, boundary layer depth): smooth synthetic fields"""
     kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(seed)
     z = np.arange(kk + 1)[:, None, None] / kk
     f = {}
     for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
@@ -260,6 +247,27 @@ def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method,
     f["OBLdepth"] = 10.0 ** rng.uniform(0.8, 2.2, (1, nj, ni))
     if case.ntr:
         f["trflx"] = rng.uniform(-1e-6, 1e-6, (case.ntr, nj, ni))
+    return f
+
+
+@pytest.mark.parametrize("cfg,npx,npy,vcoord,method,advmth", [
+    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("box_s", 2, 2, "cntiso_hybrid", "direct", "cppm"),
+    ("tri_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("tri_s", 4, 2, "plevel", "direct", "cppm"), ("chan_s", 1, 2, "plevel", "nudge", "remap")])
+def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method, advmth):
+    """The step of the hybrid vertical coordinate (DESIGN.md 3h: ale_regrid_remap, cmnfld2's hybrid branches, eddtra_ale, advect,
+    .., ale_forcing, ale_vdifft/m, .., cmnfld1) on a decomposed domain: every halo update of the new stages -- the ring of the
+    lateral smoothing, the bounded mixed layer depth and the mixed layer density of eddtra_ale, the viscosity of ale_vdiffm, the
+    slopes and buoyancy frequencies of cmnfld -- goes through the tile transport.  Interiors after a few steps as on the single tile."""
+    from blom_amd.gpu import BlomGpu, TileGroup
+    nsteps = 3
+    case = make_case(cfg, advmth=advmth)
+    _, masks, fields, ref = _single(cfg, nsteps)
+    for nm, v in case.params.items():
+        if not nm.endswith("0"):
+            ref.set(nm, v)
+    ref.set("delt1", case.params["baclin"])
+    kk = case.kdm
+    f = hybrid_inputs(case)
     # the tiles get windows of the same padded arrays, halo points included: whatever a stage reads there without updating it
     # first is the same number on both sides
     for nm, a in f.items():

@@ -28,7 +28,7 @@ def emu_lib():
     g.LIB_PATH = old
 
 
-def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False):
+def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid=None):
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd.tiles import TileLayout, scatter_to_tile, gather_interior_layout, chain_crc, make_barotp_global
     from test_gpu_tiles import _single
@@ -45,6 +45,25 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False):
         case, masks, fields, ref = _single(cfg, nsteps)
     lay = TileLayout(tuple(isizes), tuple(jsizes))
     assert lay.itdm == case.idm and lay.jtdm == case.jdm
+    check = list(CHECK)
+    if hybrid:                                            # (vcoord_type, regrid_method): the step of the hybrid coordinate, DESIGN.md 3h
+        from test_gpu_tiles import hybrid_inputs
+        from blom_amd.hostinit import step_indices
+        for nm, a in hybrid_inputs(case).items():
+            ref.put(nm, a)
+        kk = case.kdm
+        pbot = float(np.max(ref.get("p")[kk][masks["ip"] > 0]))
+        plevel = 0.3 * pbot * (np.arange(kk) / kk) ** 1.3
+        check += ["umfltd", "vmfltd", "umflsm", "vmflsm", "hml_tf", "mld", "bfsqi", "nslpx", "nslpy", "salt_corr", "buoyfl"]
+
+        def setup_hybrid(g):
+            g.set("vcoord_type", hybrid[0])
+            g.set("ale_regrid_method", hybrid[1])
+            g.set("mlrmth", "fox08")
+            g.set("swamxd", 200.0)
+            g.set("brine_mlbase_frac", 0.4)
+            g.set_vector("plevel", plevel)
+            g.stage("cmnfld1", *step_indices(0, kk))
     uid = rccl_unique_id()
     tiles, errs, crcs = {}, [], {}
     crc_fields = [("dp", 1, 2 * case.kdm, 1), ("u", 1, 2 * case.kdm, 3), ("v", 1, 2 * case.kdm, 4), ("pb", 1, 2, 1)]
@@ -71,6 +90,8 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False):
             barrier.wait()
             if cppm:                                      # every rank builds its coefficient tables (halo updates included)
                 t.stage("init_cppm", 2, 1, case.kdm, 0, case.kdm + 1, 1)
+            if hybrid:
+                setup_hybrid(t)
             assert t.step(0, nsteps) == nsteps
             t.sync()
             crcs[(px, py)] = {f[0]: t.crc_strips(*f) for f in crc_fields}
@@ -84,13 +105,18 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False):
     [x.start() for x in th]
     [x.join(timeout=600) for x in th]
     assert not errs, errs
+    if cppm and hybrid:
+        ref.stage("init_cppm", 2, 1, case.kdm, 0, case.kdm + 1, 1)
+    if hybrid:
+        setup_hybrid(ref)
     assert ref.step(0, nsteps) == nsteps
     bad = []
-    for nm in CHECK:
+    for nm in check:
         a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
         b = gather_interior_layout(tiles, lay, nm)
-        if not np.array_equal(a, b):
-            bad.append((nm, int((a != b).sum())))
+        ok = np.isfinite(a) & (np.abs(a) < 1e30)          # land keeps whatever pattern it had
+        if not np.array_equal(a[ok], b[ok]):
+            bad.append((nm, int((a[ok] != b[ok]).sum())))
     crc_bad = []
     for f in crc_fields:
         want = ref.crc(*f)
@@ -115,6 +141,18 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False):
 ])
 def test_rccl_ranks_match_single_tile(emu_lib, cfg, isizes, jsizes):
     _run_case(cfg, isizes, jsizes)
+
+
+@pytest.mark.parametrize("cfg,isizes,jsizes,vcoord,method,cppm", [
+    ("chan_s", (10, 10), (13, 11), "cntiso_hybrid", "nudge", False),
+    ("box_s", (12, 12), (11, 9), "cntiso_hybrid", "direct", True),
+    ("tri_s", (12, 12), (11, 9), "cntiso_hybrid", "nudge", False),
+    ("tri_s", (6, 6, 6, 6), (10, 10), "plevel", "direct", True),
+])
+def test_rccl_ranks_with_the_hybrid_step(emu_lib, cfg, isizes, jsizes, vcoord, method, cppm):
+    """the step of the hybrid vertical coordinate (ale_regrid_remap with its smoothing ring, eddtra_ale, ale_vdiffm's viscosity
+    halo, the hybrid branches of cmnfld) through the RCCL transport, tripolar grids included"""
+    _run_case(cfg, isizes, jsizes, cppm=cppm, hybrid=(vcoord, method))
 
 
 @pytest.mark.parametrize("cfg,isizes,jsizes", [
