@@ -908,47 +908,76 @@ H3HD int h3_prepare_remapping(const H3Grid &g, const H3Map &r, const double *xds
     for (int j = 1; j <= nd; ++j)
       if (H3A(xdst, j + 1) > H3A(xdst, j)) return H3_NONMONOTONIC_DST_EDGES;
   }
-  for (int j = 1; j <= nd; ++j) H3A(r.hdst, j) = h3_abs(H3A(xdst, j + 1) - H3A(xdst, j));
+  // The reference keeps h_dst in an array and n_src_seg in memory (:4020-4031, :4046); here the width of the current destination
+  // cell comes from its two edges (the same subtraction), the segment count of the current source cell lives in a register, and
+  // what the walk will need when either index advances -- the next source edge with its cell's width and inverse, the next
+  // destination edge -- is loaded one advance ahead, so that an iteration waits for no load issued in it.  Same statements, same order.
+  const int nsrc = g.n_src;
+  auto xe = [&](int q) { return H3A(g.x_edge, q <= nsrc + 1 ? q : nsrc + 1); };
+  auto xdq = [&](int q) { return H3A(xdst, q <= nd + 1 ? q : nd + 1); };
   int js = 1, jd = 1;
-  while (H3A(r.hdst, jd) <= x_eps) jd = jd + 1;
-  int iseg = 0;
-  H3A(r.nseg, js) = 0;
+  double xd_lo = H3A(xdst, 1), xd = H3A(xdst, 2);               // edges jd, jd+1
+  double hd = h3_abs(xd - xd_lo);
+  while (hd <= x_eps) {
+    jd = jd + 1;
+    xd_lo = xd;
+    xd = xdq(jd + 1);
+    hd = h3_abs(xd - xd_lo);
+  }
+  double xd_nx = xdq(jd + 2);                                    // edge jd+2
+  double xs_lo = H3A(g.x_edge, 1), xs = xe(2), xs_nx = xe(3);   // edges js, js+1, js+2
+  double hs = H3A(g.h, 1), his = H3A(g.hi, 1);
+  double hs_nx = H3A(g.h, 2 <= nsrc ? 2 : nsrc), his_nx = H3A(g.hi, 2 <= nsrc ? 2 : nsrc);
+  int iseg = 0, cnt = 0;
   double xil = 0.0;
+  auto next_src = [&]() {                                        // js = js + 1
+    H3A(r.nseg, js) = cnt;
+    cnt = 0;
+    js = js + 1;
+    xs_lo = xs; xs = xs_nx; hs = hs_nx; his = his_nx;
+    xs_nx = xe(js + 2);
+    const int q = js + 1 <= nsrc ? js + 1 : nsrc;
+    hs_nx = H3A(g.h, q); his_nx = H3A(g.hi, q);
+  };
+  auto next_dst = [&]() {                                        // jd = jd + 1
+    jd = jd + 1;
+    xd_lo = xd; xd = xd_nx;
+    hd = h3_abs(xd - xd_lo);
+    xd_nx = xdq(jd + 2);
+  };
   while (true) {
     iseg = iseg + 1;
-    H3A(r.nseg, js) = H3A(r.nseg, js) + 1;
+    cnt = cnt + 1;
     H3A(r.sdst, iseg) = jd;
-    const double xs = H3A(g.x_edge, js + 1), xd = H3A(xdst, jd + 1);
     if (h3_abs(xs - xd) <= x_eps) {
-      if (H3A(r.hdst, jd) > x_eps) {
+      if (hd > x_eps) {
         H3A(r.lim, iseg) = 1.0;
-        H3A(r.wgt, iseg) = (1.0 - xil) * H3A(g.h, js) / H3A(r.hdst, jd);
+        H3A(r.wgt, iseg) = (1.0 - xil) * hs / hd;
       } else {
         H3A(r.lim, iseg) = xil;
       }
       if (js == nsa) break;
       xil = 0.0;
-      js = js + 1;
-      jd = jd + 1;
-      H3A(r.nseg, js) = 0;
+      next_src();
+      next_dst();
     } else if (incr ? xs < xd : xs > xd) {
       H3A(r.lim, iseg) = 1.0;
-      H3A(r.wgt, iseg) = (1.0 - xil) * H3A(g.h, js) / H3A(r.hdst, jd);
+      H3A(r.wgt, iseg) = (1.0 - xil) * hs / hd;
       xil = 0.0;
-      js = js + 1;
-      H3A(r.nseg, js) = 0;
+      next_src();
     } else {
-      if (H3A(r.hdst, jd) > x_eps) {
-        const double l = incr ? (xd - H3A(g.x_edge, js)) * H3A(g.hi, js) : (H3A(g.x_edge, js) - xd) * H3A(g.hi, js);
+      if (hd > x_eps) {
+        const double l = incr ? (xd - xs_lo) * his : (xs_lo - xd) * his;
         H3A(r.lim, iseg) = l;
-        H3A(r.wgt, iseg) = (l - xil) * H3A(g.h, js) / H3A(r.hdst, jd);
+        H3A(r.wgt, iseg) = (l - xil) * hs / hd;
         xil = l;
       } else {
         H3A(r.lim, iseg) = xil;
       }
-      jd = jd + 1;
+      next_dst();
     }
   }
+  H3A(r.nseg, js) = cnt;
   r.prepared[col] = 1;
   return H3_NOERR;
 }
