@@ -574,25 +574,39 @@ H3HD int h3_reconstruct(const H3Grid &g, const H3Src &s, const double *uin, int 
     // destination index that comes back after another one (no merge rule produces it) picks its partial sum up from memory.
     int cur = 0, top = 0;
     double acc = 0.0;
-    for (int js = 1; js <= g.n_src; ++js) {
-      const int jd = H3A(g.sdi, js);
-      if (jd == 0) continue;
-      if (jd != cur) {
-        if (cur > 0) H3A(s.u, cur) = acc;
-        for (int q = top + 1; q < jd; ++q) H3A(s.u, q) = 0.0;          // cells no source maps to keep the reference's zero
-        acc = jd > top ? 0.0 : H3A(s.u, jd);
-        cur = jd;
-        if (jd > top) top = jd;
+    for (int js0 = 1; js0 <= g.n_src; js0 += 8) {                      // eight levels' loads in flight (they do not depend on the sums)
+      int a_d[8];
+      double a_w[8], a_u[8];
+      for (int q = 0; q < 8; ++q) {
+        const int jq = js0 + q <= g.n_src ? js0 + q : g.n_src;
+        a_d[q] = H3A(g.sdi, jq); a_w[q] = H3A(g.w, jq); a_u[q] = H3A(uin, jq);
       }
-      acc = acc + H3A(g.w, js) * H3A(uin, js);
+      for (int q = 0; q < 8; ++q) {
+        if (js0 + q > g.n_src) break;
+        const int jd = a_d[q];
+        if (jd == 0) continue;
+        if (jd != cur) {
+          if (cur > 0) H3A(s.u, cur) = acc;
+          for (int z = top + 1; z < jd; ++z) H3A(s.u, z) = 0.0;        // cells no source maps to keep the reference's zero
+          acc = jd > top ? 0.0 : H3A(s.u, jd);
+          cur = jd;
+          if (jd > top) top = jd;
+        }
+        acc = acc + a_w[q] * a_u[q];
+      }
     }
     if (cur > 0) H3A(s.u, cur) = acc;
     for (int q = top + 1; q <= ns; ++q) H3A(s.u, q) = 0.0;
   }
   double umin = H3A(s.u, 1), umax = umin;
-  for (int j = 2; j <= ns; ++j) {
-    umin = h3_min(umin, H3A(s.u, j));
-    umax = h3_max(umax, H3A(s.u, j));
+  for (int j0 = 2; j0 <= ns; j0 += 8) {
+    double a_u[8];
+    for (int q = 0; q < 8; ++q) a_u[q] = H3A(s.u, j0 + q <= ns ? j0 + q : ns);
+    for (int q = 0; q < 8; ++q) {
+      if (j0 + q > ns) break;
+      umin = h3_min(umin, a_u[q]);
+      umax = h3_max(umax, a_u[q]);
+    }
   }
   const double u_range = h3_abs(umin - umax);
   s.u_range[col] = u_range;
@@ -1000,29 +1014,55 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
     acc = 0.0;                                              \
   }
   const int ns = g.n_act[col], m = g.m_act[col];
+  // What the walk reads is loaded ahead of its use: the source cells' segment counts, means and coefficients H3R_U cells ahead
+  // (the cell index runs in lock step over the lanes), the next segment's limit, destination index and weight one segment ahead.
+  // (The reference reads the weight of a segment only where it uses it; reading it always changes no result.)
+#define H3R_U 4
+  const int nsegmax = g.n_src + nd;
   int iseg = 0;
-  for (int js = 1; js <= ns; ++js) {
-    const int nseg = H3A(r.nseg, js);
+  double n_lim = H3A(r.lim, 1), n_wgt = H3A(r.wgt, 1);
+  int n_sd = H3A(r.sdst, 1);
+  for (int js0 = 1; js0 <= ns; js0 += H3R_U) {
+   int a_ns[H3R_U];
+   double a_u[H3R_U], a_p1[H3R_U], a_p2[H3R_U], a_p3[H3R_U], a_p4[H3R_U], a_p5[H3R_U];
+   for (int w_ = 0; w_ < H3R_U; ++w_) {
+     const int jq = js0 + w_ <= ns ? js0 + w_ : ns;
+     a_ns[w_] = H3A(r.nseg, jq);
+     a_u[w_] = H3A(s.u, jq);
+     a_p1[w_] = a_p2[w_] = a_p3[w_] = a_p4[w_] = a_p5[w_] = 0;
+     if (m != H3_PCM) {
+       a_p1[w_] = PC(1, jq); a_p2[w_] = PC(2, jq);
+       if (m != H3_PLM) a_p3[w_] = PC(3, jq);
+       if (m == H3_PQM) { a_p4[w_] = PC(4, jq); a_p5[w_] = PC(5, jq); }
+     }
+   }
+   for (int w_ = 0; w_ < H3R_U; ++w_) {
+    const int js = js0 + w_;
+    if (js > ns) break;
+    const int nseg = a_ns[w_];
     if (nseg == 1) {
       iseg = iseg + 1;
-      const int jd = H3A(r.sdst, iseg);
+      const int jd = n_sd;
+      const double wgt1 = n_wgt;
+      { const int q_ = iseg + 1 <= nsegmax ? iseg + 1 : nsegmax; n_lim = H3A(r.lim, q_); n_wgt = H3A(r.wgt, q_); n_sd = H3A(r.sdst, q_); }
       H3_DST(jd);
-      acc = acc + H3A(s.u, js) * H3A(r.wgt, iseg);
+      acc = acc + a_u[w_] * wgt1;
       continue;
     }
     double xil = 0.0;
     double p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
-    if (m == H3_PCM) p1 = H3A(s.u, js);
+    if (m == H3_PCM) p1 = a_u[w_];
     else {
-      p1 = PC(1, js); p2 = PC(2, js);
-      if (m != H3_PLM) p3 = PC(3, js);
-      if (m == H3_PQM) { p4 = PC(4, js); p5 = PC(5, js); }
+      p1 = a_p1[w_]; p2 = a_p2[w_];
+      if (m != H3_PLM) p3 = a_p3[w_];
+      if (m == H3_PQM) { p4 = a_p4[w_]; p5 = a_p5[w_]; }
     }
     for (int i = 1; i <= nseg; ++i) {
       iseg = iseg + 1;
-      const double xir = H3A(r.lim, iseg);
-      const int jd = H3A(r.sdst, iseg);
-      const double wgt = H3A(r.wgt, iseg);
+      const double xir = n_lim;
+      const int jd = n_sd;
+      const double wgt = n_wgt;
+      { const int q_ = iseg + 1 <= nsegmax ? iseg + 1 : nsegmax; n_lim = H3A(r.lim, q_); n_wgt = H3A(r.wgt, q_); n_sd = H3A(r.sdst, q_); }
       H3_DST(jd);
       if (m == H3_PCM) {
         if (xil == xir) acc = p1;
@@ -1067,7 +1107,9 @@ H3HD int h3_remap(const H3Grid &g, const H3Src &s, const H3Map &r, double *udst,
         xil = xir;
       }
     }
+   }
   }
+#undef H3R_U
   if (cur > 0) H3A(udst, cur) = acc;
   for (int q_ = cur + 1; q_ <= nd; ++q_) H3A(udst, q_) = 0.0;
 #undef H3_DST
