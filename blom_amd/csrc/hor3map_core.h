@@ -273,14 +273,23 @@ H3HD void h3_right_bndr_cond(const H3Grid &g, int col, int last_index, int &rb_o
 H3HD void h3_continuous_edges(const H3Grid &g, int col, int ns) {
   const int nc = g.nc;
   H3A(g.x_edge, 1) = H3A(g.xin, 1);
-  int js = 1;
-  for (int j = 1; j <= ns - 1; ++j) {
-    while (true) {
-      js = js + 1;
-      const int d = H3A(g.sdi, js);
-      if (d != j && d != 0) break;
+  // the reference scans, for every kept cell j, forward to the next source index whose destination is neither j nor none; every
+  // source index is looked at once, in order, so the scan runs over the source indices with eight levels' loads in flight
+  int j = 1;
+  for (int js0 = 2; js0 <= g.n_src && j <= ns - 1; js0 += 8) {
+    int a_d[8];
+    double a_x[8];
+    for (int q = 0; q < 8; ++q) {
+      const int jq = js0 + q <= g.n_src ? js0 + q : g.n_src;
+      a_d[q] = H3A(g.sdi, jq); a_x[q] = H3A(g.xin, jq);
     }
-    H3A(g.x_edge, j + 1) = H3A(g.xin, js);
+    for (int q = 0; q < 8; ++q) {
+      if (js0 + q > g.n_src || j > ns - 1) break;
+      if (a_d[q] != j && a_d[q] != 0) {
+        H3A(g.x_edge, j + 1) = a_x[q];
+        j = j + 1;
+      }
+    }
   }
   H3A(g.x_edge, ns + 1) = H3A(g.xin, g.n_src + 1);
 }
@@ -288,23 +297,48 @@ H3HD void h3_continuous_edges(const H3Grid &g, int col, int ns) {
 // resolve merge chains to destination indices and weights, compact widths (mod_hor3map.F90:1430-1459)
 H3HD void h3_compact_and_weights(const H3Grid &g, int col) {
   const int nc = g.nc;
+  // eight levels' loads in flight in both loops: a level's inputs are not written by the levels before it (the compacted index
+  // never runs ahead of the source index; a merge chain ends at the same cell whether or not a link on the way is resolved yet)
   int jd = 0;
-  for (int js = 1; js <= g.n_src; ++js)
-    if (H3A(g.sdi, js) > 0) {
-      jd = jd + 1;
-      H3A(g.sdi, js) = jd;
-      H3A(g.h, jd) = H3A(g.h, js);
-      H3A(g.hi, jd) = 1.0 / H3A(g.h, jd);
+  for (int js0 = 1; js0 <= g.n_src; js0 += 8) {
+    int a_d[8];
+    double a_h[8];
+    for (int q = 0; q < 8; ++q) {
+      const int jq = js0 + q <= g.n_src ? js0 + q : g.n_src;
+      a_d[q] = H3A(g.sdi, jq); a_h[q] = H3A(g.h, jq);
     }
+    for (int q = 0; q < 8; ++q) {
+      const int js = js0 + q;
+      if (js > g.n_src) break;
+      if (a_d[q] > 0) {
+        jd = jd + 1;
+        H3A(g.sdi, js) = jd;
+        H3A(g.h, jd) = a_h[q];
+        H3A(g.hi, jd) = 1.0 / a_h[q];
+      }
+    }
+  }
   const double x_eps = g.x_eps[col];
-  for (int js = 1; js <= g.n_src; ++js) {
-    jd = H3A(g.sdi, js);
-    while (jd < 0) jd = H3A(g.sdi, -jd);
-    H3A(g.sdi, js) = jd;
-    if (jd > 0) {
-      const double h = h3_abs(H3A(g.xin, js + 1) - H3A(g.xin, js));
-      if (h3_abs(h - H3A(g.h, jd)) < x_eps) H3A(g.w, js) = 1.0;
-      else H3A(g.w, js) = h * H3A(g.hi, jd);
+  for (int js0 = 1; js0 <= g.n_src; js0 += 8) {
+    int a_d[8];
+    double a_x[9], a_h[8], a_hi[8];
+    for (int q = 0; q < 8; ++q) a_d[q] = H3A(g.sdi, js0 + q <= g.n_src ? js0 + q : g.n_src);
+    for (int q = 0; q < 9; ++q) a_x[q] = H3A(g.xin, js0 + q <= g.n_src + 1 ? js0 + q : g.n_src + 1);
+    for (int q = 0; q < 8; ++q) {
+      while (a_d[q] < 0) a_d[q] = H3A(g.sdi, -a_d[q]);
+      const int jq = a_d[q] > 0 ? a_d[q] : 1;
+      a_h[q] = H3A(g.h, jq); a_hi[q] = H3A(g.hi, jq);
+    }
+    for (int q = 0; q < 8; ++q) {
+      const int js = js0 + q;
+      if (js > g.n_src) break;
+      jd = a_d[q];
+      H3A(g.sdi, js) = jd;
+      if (jd > 0) {
+        const double h = h3_abs(a_x[q + 1] - a_x[q]);
+        if (h3_abs(h - a_h[q]) < x_eps) H3A(g.w, js) = 1.0;
+        else H3A(g.w, js) = h * a_hi[q];
+      }
     }
   }
 }
@@ -315,17 +349,24 @@ H3HD int h3_link_nonempty(const H3Grid &g, int col, int &first_index, int &last_
   const double x_eps = g.x_eps[col];
   int ns = 0, jp = 0;
   first_index = 0;
-  for (int j = 1; j <= g.n_src; ++j) {
-    H3A(g.h, j) = h3_abs(H3A(g.xin, j + 1) - H3A(g.xin, j));
-    if (H3A(g.h, j) > 2.0 * x_eps) {
-      ns = ns + 1;
-      H3A(g.sdi, j) = 1;
-      H3A(g.prev, j) = jp;
-      if (jp == 0) first_index = j;
-      else H3A(g.next, jp) = j;
-      jp = j;
-    } else {
-      H3A(g.sdi, j) = 0;
+  for (int j0 = 1; j0 <= g.n_src; j0 += 8) {
+    double a_x[9];
+    for (int q = 0; q < 9; ++q) a_x[q] = H3A(g.xin, j0 + q <= g.n_src + 1 ? j0 + q : g.n_src + 1);
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      if (j > g.n_src) break;
+      const double h = h3_abs(a_x[q + 1] - a_x[q]);
+      H3A(g.h, j) = h;
+      if (h > 2.0 * x_eps) {
+        ns = ns + 1;
+        H3A(g.sdi, j) = 1;
+        H3A(g.prev, j) = jp;
+        if (jp == 0) first_index = j;
+        else H3A(g.next, jp) = j;
+        jp = j;
+      } else {
+        H3A(g.sdi, j) = 0;
+      }
     }
   }
   last_index = jp;
@@ -681,38 +722,71 @@ H3HD int h3_extract_polycoeff(const H3Grid &g, const H3Src &s, double *out, int 
     }
     int jd_prev = -1;
     double xi0 = 0.0;
-    for (int js = js0; js <= n; ++js) {
-      jd = H3A(g.sdi, js);
-      if (jd == 0) {
-        double acc = OUT(1, js - 1) + OUT(2, js - 1);
-        for (int c = 3; c <= nq; ++c) acc = acc + OUT(c, js - 1);
-        OUT(1, js) = acc;
-        if (full) for (int c = 2; c <= nq; ++c) OUT(c, js) = 0.0;
-      } else {
-        const double w = H3A(g.w, js);
-        if (w == 1.0) {
-          for (int c = 1; c <= nq; ++c) OUT(c, js) = PC(c, jd);
-        } else {
-          if (jd != jd_prev) xi0 = 0.0;
-          jd_prev = jd;
-          double q = w;
-          if (nq == 3) {
-            OUT(1, js) = (PC(3, jd) * xi0 + PC(2, jd)) * xi0 + PC(1, jd);
-            OUT(2, js) = (2.0 * PC(3, jd) * xi0 + PC(2, jd)) * q;
-            q = q * w;
-            OUT(3, js) = PC(3, jd) * q;
-          } else {
-            OUT(1, js) = (((PC(5, jd) * xi0 + PC(4, jd)) * xi0 + PC(3, jd)) * xi0 + PC(2, jd)) * xi0 + PC(1, jd);
-            OUT(2, js) = (((4.0 * PC(5, jd) * xi0 + 3.0 * PC(4, jd)) * xi0 + 2.0 * PC(3, jd)) * xi0 + PC(2, jd)) * q;
-            q = q * w;
-            OUT(3, js) = ((6.0 * PC(5, jd) * xi0 + 3.0 * PC(4, jd)) * xi0 + PC(3, jd)) * q;
-            q = q * w;
-            OUT(4, js) = (4.0 * PC(5, jd) * xi0 + PC(4, jd)) * q;
-            q = q * w;
-            OUT(5, js) = PC(5, jd) * q;
+    // four levels' loads in flight (destination indices and weights first, then the coefficients they point to); the cell above,
+    // which a near-empty cell continues, travels in registers instead of being read back
+    double pv[5] = {js0 > 1 ? PC(1, 1) : 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int jb = js0; jb <= n; jb += 4) {
+      int a_d[4];
+      double a_w[4], a_p[4][5];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jq = jb + q <= n ? jb + q : n;
+        a_d[q] = H3A(g.sdi, jq); a_w[q] = H3A(g.w, jq);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jq = a_d[q] > 0 ? a_d[q] : 1;
+#pragma unroll
+        for (int c = 1; c <= 5; ++c) a_p[q][c - 1] = c <= nq ? PC(c, jq) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int js = jb + q;
+        if (js > n) break;
+        jd = a_d[q];
+        double o[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (jd == 0) {
+          double acc = pv[0] + pv[1];
+#pragma unroll
+          for (int c = 3; c <= 5; ++c) if (c <= nq) acc = acc + pv[c - 1];
+          o[0] = acc;
+          OUT(1, js) = acc;
+          if (full) {
+#pragma unroll
+            for (int c = 2; c <= 5; ++c) if (c <= nq) OUT(c, js) = 0.0;
           }
-          xi0 = xi0 + w;
+        } else {
+          const double w = a_w[q];
+          const double *pc = a_p[q];
+          if (w == 1.0) {
+#pragma unroll
+            for (int c = 1; c <= 5; ++c) if (c <= nq) o[c - 1] = pc[c - 1];
+          } else {
+            if (jd != jd_prev) xi0 = 0.0;
+            jd_prev = jd;
+            double qq = w;
+            if (nq == 3) {
+              o[0] = (pc[2] * xi0 + pc[1]) * xi0 + pc[0];
+              o[1] = (2.0 * pc[2] * xi0 + pc[1]) * qq;
+              qq = qq * w;
+              o[2] = pc[2] * qq;
+            } else {
+              o[0] = (((pc[4] * xi0 + pc[3]) * xi0 + pc[2]) * xi0 + pc[1]) * xi0 + pc[0];
+              o[1] = (((4.0 * pc[4] * xi0 + 3.0 * pc[3]) * xi0 + 2.0 * pc[2]) * xi0 + pc[1]) * qq;
+              qq = qq * w;
+              o[2] = ((6.0 * pc[4] * xi0 + 3.0 * pc[3]) * xi0 + pc[2]) * qq;
+              qq = qq * w;
+              o[3] = (4.0 * pc[4] * xi0 + pc[3]) * qq;
+              qq = qq * w;
+              o[4] = pc[4] * qq;
+            }
+            xi0 = xi0 + w;
+          }
+#pragma unroll
+          for (int c = 1; c <= 5; ++c) if (c <= nq) OUT(c, js) = o[c - 1];
         }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) pv[c] = o[c];
       }
     }
   }
