@@ -174,6 +174,52 @@ H3HD void h3_edge_slope_rblu(int ord, const double *h, double *a) {
 #undef AA
 }
 
+// The same with the order a compile-time constant: every index is then a constant and the 6 x 6 work matrix lives in registers
+// instead of scratch memory (what the run-time order costs: 300-350 bytes of scratch per lane in prepare and reconstruct).
+template <int N> H3HD void h3_bndr_lu_store(const H3Grid &g, int col, bool left, int j0) {
+  const int nc = g.nc;
+  double hb[N], a[H3_LD * H3_LD];
+#pragma unroll
+  for (int i = 1; i <= N; ++i) hb[i - 1] = H3A(g.h, j0 + i);
+  if (left) h3_edge_slope_lblu(N, hb, a);
+  else h3_edge_slope_rblu(N, hb, a);
+  double *dst = left ? g.lblu : g.rblu;
+#pragma unroll
+  for (int j = 1; j <= N; ++j)
+#pragma unroll
+    for (int i = 1; i <= N; ++i) H3A2(dst, i, j, H3_LD) = a[(i - 1) + H3_LD * (j - 1)];
+}
+H3HD void h3_bndr_lu(const H3Grid &g, int col, bool left, int ord, int j0) {     // cells j0+1 .. j0+ord
+  switch (ord) {
+    case 2: h3_bndr_lu_store<2>(g, col, left, j0); break;
+    case 3: h3_bndr_lu_store<3>(g, col, left, j0); break;
+    case 4: h3_bndr_lu_store<4>(g, col, left, j0); break;
+    case 5: h3_bndr_lu_store<5>(g, col, left, j0); break;
+    default: h3_bndr_lu_store<6>(g, col, left, j0); break;
+  }
+}
+// first unknown of the boundary system (the edge value): lu from the planes, right-hand side u(j0+1 .. j0+N)
+template <int N> H3HD double h3_bndr_solve_first(const double *lup, const double *u, size_t nc, int col, int j0) {
+  double x[N], lu[H3_LD * H3_LD];
+#pragma unroll
+  for (int i = 1; i <= N; ++i) x[i - 1] = H3A(u, j0 + i);
+#pragma unroll
+  for (int j = 1; j <= N; ++j)
+#pragma unroll
+    for (int i = 1; i <= N; ++i) lu[(i - 1) + H3_LD * (j - 1)] = H3A2(lup, i, j, H3_LD);
+  h3_lu_solve(N, lu, H3_LD, x);
+  return x[0];
+}
+H3HD double h3_bndr_first(const double *lup, const double *u, size_t nc, int col, int ord, int j0) {
+  switch (ord) {
+    case 2: return h3_bndr_solve_first<2>(lup, u, nc, col, j0);
+    case 3: return h3_bndr_solve_first<3>(lup, u, nc, col, j0);
+    case 4: return h3_bndr_solve_first<4>(lup, u, nc, col, j0);
+    case 5: return h3_bndr_solve_first<5>(lup, u, nc, col, j0);
+    default: return h3_bndr_solve_first<6>(lup, u, nc, col, j0);
+  }
+}
+
 // ---- merging of thin cells at the boundaries (mod_hor3map.F90:431-575) ---------------------------------------
 H3HD void h3_left_bndr_cond(const H3Grid &g, int col, int &first_index, int &last_index, int &lb_ord, int &ns,
                             int ns_min) {
@@ -454,19 +500,8 @@ H3HD void h3_prepare_ppm(const H3Grid &g, int col) {
   // reader, the PPM reconstruction, recomputes both from the widths with the same expressions (hor3map_ppm_fused.h: the same bits),
   // so the five planes are not written: 225 of the 460 MB this routine stored per 106 k-column slab.
 
-  double hb[H3_LD], a[H3_LD * H3_LD];
-  if (lb_ord > 1) {
-    for (int i = 1; i <= lb_ord; ++i) hb[i - 1] = H3A(g.h, i);
-    h3_edge_slope_lblu(lb_ord, hb, a);
-    for (int j = 1; j <= lb_ord; ++j)
-      for (int i = 1; i <= lb_ord; ++i) H3A2(g.lblu, i, j, H3_LD) = a[(i - 1) + H3_LD * (j - 1)];
-  }
-  if (rb_ord > 1) {
-    for (int i = 1; i <= rb_ord; ++i) hb[i - 1] = H3A(g.h, ns - rb_ord + i);
-    h3_edge_slope_rblu(rb_ord, hb, a);
-    for (int j = 1; j <= rb_ord; ++j)
-      for (int i = 1; i <= rb_ord; ++i) H3A2(g.rblu, i, j, H3_LD) = a[(i - 1) + H3_LD * (j - 1)];
-  }
+  if (lb_ord > 1) h3_bndr_lu(g, col, true, lb_ord, 0);
+  if (rb_ord > 1) h3_bndr_lu(g, col, false, rb_ord, ns - rb_ord);
   g.n_act[col] = ns;
   g.lb_act[col] = lb_ord;
   g.rb_act[col] = rb_ord;

@@ -73,22 +73,13 @@ H3HD void h3_reconstruct_ppm_fused(const H3Grid &g, const H3Src &s, int col) {
   double *uedge = s.wk, *gam = s.wk + (size_t)(g.n_src + 1) * nc;
 
   // ---- boundary edge values (:1724-1740; the right one tests lb_ord, as the reference does) -------------
-  double x[H3_LD], lu[H3_LD * H3_LD];
   double e_first, e_last;
   if (lb_ord == 1) {
     e_first = H3A(s.u, 1);
     e_last = H3A(s.u, ns);
   } else {
-    for (int i = 1; i <= lb_ord; ++i) x[i - 1] = H3A(s.u, i);
-    for (int j = 1; j <= lb_ord; ++j)
-      for (int i = 1; i <= lb_ord; ++i) lu[(i - 1) + H3_LD * (j - 1)] = H3A2(g.lblu, i, j, H3_LD);
-    h3_lu_solve(lb_ord, lu, H3_LD, x);
-    e_first = x[0];
-    for (int i = 1; i <= rb_ord; ++i) x[i - 1] = H3A(s.u, ns - rb_ord + i);
-    for (int j = 1; j <= rb_ord; ++j)
-      for (int i = 1; i <= rb_ord; ++i) lu[(i - 1) + H3_LD * (j - 1)] = H3A2(g.rblu, i, j, H3_LD);
-    h3_lu_solve(rb_ord, lu, H3_LD, x);
-    e_last = x[0];
+    e_first = h3_bndr_first(g.lblu, s.u, nc, col, lb_ord, 0);          // order a compile-time constant inside: no scratch
+    e_last = h3_bndr_first(g.rblu, s.u, nc, col, rb_ord, ns - rb_ord);
   }
 
   // ---- sweep 1, ascending: forward elimination of the edge system (:1743-1754) -------------------------
