@@ -277,7 +277,7 @@ def bench_hor3map(args):
     calls = [("prepare_reconstruction", lambda: g.prepare_reconstruction(tx.data_ptr()), 1),
              ("reconstruct", lambda: s_.reconstruct(tu.data_ptr()), 1),
              ("extract_polycoeff", lambda: s_.extract_polycoeff(out=tpc.data_ptr()), npc),
-             ("regrid", lambda: s_.regrid(tug.data_ptr(), -1e33, h3.REGRID_METHOD_2, out=txg.data_ptr(), n_grd=n + 1), 2),
+             ("regrid", lambda: s_.regrid(tug.data_ptr(), -1e33, h3.REGRID_METHOD_1, out=txg.data_ptr(), n_grd=n + 1), 2),
              ("prepare_remapping", lambda: r.prepare_remapping(txd.data_ptr()), 1),
              ("remap", lambda: r.remap(s_, out=tud.data_ptr()), 1)]
     F = ncol * n * 8.0
@@ -308,18 +308,18 @@ def bench_hor3map(args):
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "mod_hor3map API (phy/mod_hor3map.F90:3834-4559), PPM / non-oscillatory posdef limiting / boundary "
-                                  "orders 6, 4: prepare_reconstruction, reconstruct, extract_polycoeff, regrid (method 2), "
+                                  "orders 6, 4: prepare_reconstruction, reconstruct, extract_polycoeff, regrid (method 1, the default BLOM's ale_regrid_remap calls), "
                                   "prepare_remapping, remap on 106080 columns x 53 layers (tests/h3m_cases.py: make_slab)"},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": alg[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes": alg[dom], "avg_ms": kms[dom],
-                        "note": "caller-visible arrays in + out; the kernels are bound by dependent fp64 arithmetic at 1.6 "
-                                "wavefronts per SIMD, not by bytes (DESIGN.md 3a)"},
+                        "note": "caller-visible arrays in + out; the kernels wait on their own loads (DESIGN.md 3a, 3g: counters "
+                                "and what loading ahead gave)"},
            "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
     if not args.no_cpu_baseline and hc.have_ref():
         m = 6000
         t0 = time.perf_counter()
-        hc.run_ref(*cfg, x[:m].copy(), u[:m].copy(), xd[:m].copy(), ug[:m].copy(), hc.METHOD_2)
+        hc.run_ref(*cfg, x[:m].copy(), u[:m].copy(), xd[:m].copy(), ug[:m].copy(), hc.METHOD_1)
         dtc = (time.perf_counter() - t0) / m * ncol
         out["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "slab-sequences/sec", "cores": 1, "kind": "reference",
                                "sample": f"the reference's compiled mod_hor3map on {m} of the slab's columns, one core, scaled to the slab"}

@@ -871,43 +871,67 @@ H3HD double h3_cell_intersection(const H3Grid &g, const H3Src &s, int col, int m
 #define XEDGE(js, xi) (H3A(g.x_edge, js) + (H3A(g.x_edge, (js) + 1) - H3A(g.x_edge, js)) * (xi))
 
 // regrid_{plm,ppm,pqm}_method_1 (mod_hor3map.F90:3029-3207)
+// The walk over source cells (js) and target values (jg) with what either index will need next loaded one advance ahead: the
+// current cell's edge values, edges and coefficients and the current target live in registers.  Statements and order as in the
+// reference.
+struct H3RgCell { double uer, uel_nx, xlo, xhi, pc[5]; };
+H3HD double h3_cell_intersection_pc(int m, const double *pc, double u, double u_eps, double xil, double xir) {
+  if (m == H3_PLM) return h3_line_intersection(pc[0], pc[1], u, u_eps, xil, xir);
+  if (m == H3_PPM) return h3_parabola_intersection(pc[0], pc[1], pc[2], u, u_eps, xil, xir);
+  return h3_quartic_intersection(pc, u, u_eps, xil, xir);
+}
 H3HD void h3_regrid_method_1(const H3Grid &g, const H3Src &s, int col, int m, double u_sgn, int ng,
                              const double *ugrd, double *xgrd) {
-  const int nc = g.nc;
+  const int nc = g.nc, np = g.p_ord + 1;
   const int ns = g.n_act[col];
+  const double u_eps = s.u_eps[col];
+  const int nq = m == H3_PLM ? 2 : (m == H3_PPM ? 3 : 5);
+  auto load_cell = [&](H3RgCell &c, int j) {
+    const int jj = j <= ns ? j : ns, jn = jj + 1 <= ns ? jj + 1 : ns;
+    c.uer = H3A(s.uer, jj); c.uel_nx = H3A(s.uel, jn);
+    c.xlo = H3A(g.x_edge, jj); c.xhi = H3A(g.x_edge, jj + 1);
+#pragma unroll
+    for (int q = 1; q <= 5; ++q) c.pc[q - 1] = q <= nq ? PC(q, jj) : 0.0;
+  };
+  auto ug_at = [&](int j) { return H3A(ugrd, j <= ng ? j : ng); };
   int jg = 1;
+  double ug = ug_at(1), ug_nx = ug_at(2);
+#define H3RG_NEXT_TARGET() { jg = jg + 1; if (jg > ng) return; ug = ug_nx; ug_nx = ug_at(jg + 1); }
+  const double uel1 = H3A(s.uel, 1);
   while (true) {
-    if ((H3A(ugrd, jg) - H3A(s.uel, 1)) * u_sgn >= 0.0) break;
-    jg = jg + 1;
-    if (jg > ng) return;
+    if ((ug - uel1) * u_sgn >= 0.0) break;
+    H3RG_NEXT_TARGET();
   }
   int js = 1;
+  H3RgCell c, cn;
+  load_cell(c, 1);
+  load_cell(cn, 2);
   while (true) {
     if (js + 1 > ns) break;
-    const double ue_min = h3_min(H3A(s.uer, js) * u_sgn, H3A(s.uel, js + 1) * u_sgn);
+    const double ue_min = h3_min(c.uer * u_sgn, c.uel_nx * u_sgn);
     while (true) {
-      if (H3A(ugrd, jg) * u_sgn >= ue_min) break;
-      const double xi = h3_cell_intersection(g, s, col, m, js, H3A(ugrd, jg), 0.0, 1.0);
-      H3A(xgrd, jg) = XEDGE(js, xi);
-      jg = jg + 1;
-      if (jg > ng) return;
+      if (ug * u_sgn >= ue_min) break;
+      const double xi = h3_cell_intersection_pc(m, c.pc, ug, u_eps, 0.0, 1.0);
+      H3A(xgrd, jg) = c.xlo + (c.xhi - c.xlo) * xi;
+      H3RG_NEXT_TARGET();
     }
-    const double ue_max = h3_max(H3A(s.uer, js) * u_sgn, H3A(s.uel, js + 1) * u_sgn);
+    const double ue_max = h3_max(c.uer * u_sgn, c.uel_nx * u_sgn);
     while (true) {
-      if (H3A(ugrd, jg) * u_sgn > ue_max) break;
-      H3A(xgrd, jg) = H3A(g.x_edge, js + 1);
-      jg = jg + 1;
-      if (jg > ng) return;
+      if (ug * u_sgn > ue_max) break;
+      H3A(xgrd, jg) = c.xhi;
+      H3RG_NEXT_TARGET();
     }
     js = js + 1;
+    c = cn;
+    load_cell(cn, js + 1);
   }
   while (true) {
-    if ((H3A(ugrd, jg) - H3A(s.uer, js)) * u_sgn > 0.0) return;
-    const double xi = h3_cell_intersection(g, s, col, m, js, H3A(ugrd, jg), 0.0, 1.0);
-    H3A(xgrd, jg) = XEDGE(js, xi);
-    jg = jg + 1;
-    if (jg > ng) return;
+    if ((ug - c.uer) * u_sgn > 0.0) return;
+    const double xi = h3_cell_intersection_pc(m, c.pc, ug, u_eps, 0.0, 1.0);
+    H3A(xgrd, jg) = c.xlo + (c.xhi - c.xlo) * xi;
+    H3RG_NEXT_TARGET();
   }
+#undef H3RG_NEXT_TARGET
 }
 
 // value and derivative (d/dxi) of the reconstruction at the cell mid point
