@@ -300,58 +300,104 @@ __global__ __launch_bounds__(64) void k_cmn_z(const DevView *__restrict__ Vp, in
 // ---- the branches of the vertical coordinates other than isopyc_bulkml (round 3) ---------------------------------------------
 // cmnfld_bfsqf_ale, :229-350: as the isopycnic form without the mixed-layer treatment; delp and bfsq of a level go through two
 // work planes to the tridiagonal filter.  (bfsqi and bfsql are zeroed everywhere first, :247-248: the launcher does that.)
+// One pass down the column does what the reference does in four loops (:254-333): the interface values of level k, the layer
+// mean of level k-1 and the forward elimination of row k-1 of the filter's tridiagonal system -- which needs delp(k-2..k) and
+// bfsq(k-1), all still in registers (delp and bfsq are no work planes any more) -- then the back substitution.  Statements as in
+// the reference; the next four levels' p, T, S are loaded ahead.
 __global__ __launch_bounds__(64) void k_cmn_bfsqf_ale(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   COLUMN_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
-  double *bfsqi = V.f[F_bfsqi] + c, *bfsql = V.f[F_bfsql] + c, *bfsqf = V.f[F_bfsqf] + c;
-  double *delp = WK(V, CM_DELP) + c, *bfsq = WK(V, CM_BFSQ) + c, *gam = WK(V, CM_GAM) + c;
+  const double *__restrict__ p = V.f[F_p] + c, *__restrict__ temp = V.f[F_temp] + c + (size_t)nn * np, *__restrict__ saln = V.f[F_saln] + c + (size_t)nn * np;
+  double *__restrict__ bfsqi = V.f[F_bfsqi] + c, *__restrict__ bfsql = V.f[F_bfsql] + c, *__restrict__ bfsqf = V.f[F_bfsqf] + c;
+  double *__restrict__ gam = WK(V, CM_GAM) + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]
   const double sls2 = SLS0 * SLS0, pbot = L(p, kk + 1);
-  L(bfsqi, 1) = BFSQMN;
-  double pup = .5 * (L(p, 1) + L(p, 2)), tup = L(temp, 1), sup = L(saln, 1);
-  for (int k = 2; k <= kk; k++) {
-    if (pbot - L(p, k) < EPSILP) {
-      L(delp, k) = ONEMM;
-      L(bfsqi, k) = L(bfsqi, k - 1);
-      L(bfsq, k) = BFSQMN;
-    } else {
-      const double plo = pbot - L(p, k + 1) < EPSILP ? pbot : .5 * (L(p, k) + L(p, k + 1));
-      const double tlo = L(temp, k), slo = L(saln, k);
-      const double dk = fmax2(ONEMM, plo - pup);
-      L(delp, k) = dk;
-      double bi = GRAV * GRAV * (eos::rho(L(p, k), tlo, slo) - eos::rho(L(p, k), tup, sup)) / dk;
-      L(bfsq, k) = fmax2(BFSQMN, bi);
-      bi = bi * dk / fmax2(ONEM, dk);
-      if (pbot - L(p, k) < ONEM) bi = L(bfsqi, k - 1);
+  double pk = L(p, 2);                                             // p(k) of the level being worked on
+  double pup = .5 * (L(p, 1) + pk), tup = L(temp, 1), sup = L(saln, 1);
+  double bi_prev = BFSQMN;                                         // bfsqi(k-1); bfsqi(1) = bfsqmn while the loop runs (:256)
+  double d_m2 = 0., d_m1 = V.f[F_dp][c + (size_t)nn * np], d_0 = 0.;   // delp(k-2), delp(k-1), delp(k); delp(1) = dp(1) (:300)
+  double q_m1 = 0.;                                                // bfsq(k-1)
+  double bei = 0., f_prev = 0., ctd_prev = 0.;                     // of the last eliminated row
+  for (int k0 = 2; k0 <= kk; k0 += 4) {
+    double a_p[4], a_t[4], a_s[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int kq = k0 + u <= kk ? k0 + u : kk;
+      a_p[u] = L(p, kq + 1); a_t[u] = L(temp, kq); a_s[u] = L(saln, kq);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u;
+      if (k > kk) break;
+      const double pk1 = a_p[u];
+      double bi, bq;
+      if (pbot - pk < EPSILP) {                                    // :259-263
+        d_0 = ONEMM;
+        bi = bi_prev;
+        bq = BFSQMN;
+      } else {                                                     // :264-289
+        const double plo = pbot - pk1 < EPSILP ? pbot : .5 * (pk + pk1);
+        const double tlo = a_t[u], slo = a_s[u];
+        const double dk = fmax2(ONEMM, plo - pup);
+        d_0 = dk;
+        bi = GRAV * GRAV * (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) / dk;
+        bq = fmax2(BFSQMN, bi);
+        bi = bi * dk / fmax2(ONEM, dk);
+        if (pbot - pk < ONEM) bi = bi_prev;
+        pup = plo; tup = tlo; sup = slo;
+      }
       L(bfsqi, k) = bi;
-      pup = plo; tup = tlo; sup = slo;
+      if (k == 2) {
+        // bfsqi(1) = bfsqi(2), bfsq(1) from it (:301-302); bfsql(1); row 1 of the system (:321-322)
+        L(bfsqi, 1) = bi;
+        q_m1 = fmax2(BFSQMN, bi);
+        L(bfsql, 1) = .5 * (bi + bi);
+        ctd_prev = -2. * sls2 / (d_m1 * (d_m1 + d_0));
+        bei = 1. / (1. - ctd_prev);
+        f_prev = q_m1 * bei;
+        L(bfsqf, 1) = f_prev;
+      } else {
+        L(bfsql, k - 1) = .5 * (bi_prev + bi);                     // :304-306
+        // row k-1 (:323-332): delp(k-2), delp(k-1), delp(k) = d_m2, d_m1, d_0
+        const double g = ctd_prev * bei;
+        L(gam, k - 1) = g;
+        const double at = -2. * sls2 / (d_m1 * (d_m2 + d_m1));
+        const double ct = -2. * sls2 / (d_m1 * (d_m1 + d_0));
+        bei = 1. / ((1. - at - ct) - at * g);
+        f_prev = (q_m1 - at * f_prev) * bei;
+        L(bfsqf, k - 1) = f_prev;
+        ctd_prev = ct;
+      }
+      d_m2 = d_m1; d_m1 = d_0; q_m1 = bq; bi_prev = bi; pk = pk1;
     }
   }
-  L(delp, 1) = V.f[F_dp][c + (size_t)nn * np];
-  L(bfsqi, 1) = L(bfsqi, 2);
-  L(bfsq, 1) = fmax2(BFSQMN, L(bfsqi, 1));
-  for (int k = 1; k <= kk - 1; k++) L(bfsql, k) = .5 * (L(bfsqi, k) + L(bfsqi, k + 1));
-  L(bfsql, kk) = L(bfsqi, kk);
-  // the tridiagonal system, :306-333 (atd, btd, ctd formed where they are used)
-  auto ctd = [&](int k) { return -2. * sls2 / (L(delp, k) * (L(delp, k) + L(delp, k + 1))); };
-  auto atd = [&](int k) { return -2. * sls2 / (L(delp, k) * (L(delp, k - 1) + L(delp, k))); };
-  double bei = 1. / (1. - ctd(1));
-  L(bfsqf, 1) = L(bfsq, 1) * bei;
-  for (int k = 2; k <= kk; k++) {
-    const double g = ctd(k - 1) * bei;
-    L(gam, k) = g;
-    const double a = atd(k);
-    const double btd = k < kk ? 1. - a - ctd(k) : 1. - a;
-    bei = 1. / (btd - a * g);
-    L(bfsqf, k) = (L(bfsq, k) - a * L(bfsqf, k - 1)) * bei;
+  L(bfsql, kk) = bi_prev;                                          // :307
+  {                                                                // row kk
+    const double g = ctd_prev * bei;
+    L(gam, kk) = g;
+    const double at = -2. * sls2 / (d_m1 * (d_m2 + d_m1));
+    bei = 1. / ((1. - at) - at * g);
+    f_prev = (q_m1 - at * f_prev) * bei;
+    L(bfsqf, kk) = f_prev;
   }
-  for (int k = kk - 1; k >= 1; k--) L(bfsqf, k) = L(bfsqf, k) - L(gam, k + 1) * L(bfsqf, k + 1);
-  L(bfsqi, kk + 1) = L(bfsqi, kk);
-  L(bfsqf, kk + 1) = L(bfsqf, kk);
+  double fn = f_prev;
+  for (int k0 = kk - 1; k0 >= 1; k0 -= 4) {                        // back substitution, :333
+    double a_f[4], a_g[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int kq = k0 - u >= 1 ? k0 - u : 1; a_f[u] = L(bfsqf, kq); a_g[u] = L(gam, kq + 1); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 - u;
+      if (k < 1) break;
+      fn = a_f[u] - a_g[u] * fn;
+      L(bfsqf, k) = fn;
+    }
+  }
+  L(bfsqi, kk + 1) = bi_prev;
+  L(bfsqf, kk + 1) = f_prev;
 #undef L
 }
 
