@@ -412,21 +412,38 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqi_ale(const DevView *__restrict_
   double *bfsqi = V.f[F_bfsqi] + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]
   const double pbot = L(p, kk + 1);
-  L(bfsqi, 1) = BFSQMN;
-  double pup = .5 * (L(p, 1) + L(p, 2)), tup = L(temp, 1), sup = L(saln, 1);
-  for (int k = 2; k <= kk; k++) {
-    if (pbot - L(p, k) < EPSILP) L(bfsqi, k) = L(bfsqi, k - 1);
-    else {
-      const double plo = pbot - L(p, k + 1) < EPSILP ? pbot : .5 * (L(p, k) + L(p, k + 1));
-      const double tlo = L(temp, k), slo = L(saln, k);
-      double bi = GRAV * GRAV * (eos::rho(L(p, k), tlo, slo) - eos::rho(L(p, k), tup, sup)) / fmax2(ONEM, plo - pup);
-      if (pbot - L(p, k) < ONEM) bi = L(bfsqi, k - 1);
+  // the level above travels in registers (bfsqi(1) = bfsqmn while the loop runs), the next four levels' p, T, S are loaded ahead
+  double pk = L(p, 2);
+  double pup = .5 * (L(p, 1) + pk), tup = L(temp, 1), sup = L(saln, 1);
+  double bi_prev = BFSQMN, bi2 = BFSQMN;
+  for (int k0 = 2; k0 <= kk; k0 += 4) {
+    double a_p[4], a_t[4], a_s[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int kq = k0 + u <= kk ? k0 + u : kk;
+      a_p[u] = L(p, kq + 1); a_t[u] = L(temp, kq); a_s[u] = L(saln, kq);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u;
+      if (k > kk) break;
+      const double pk1 = a_p[u];
+      double bi;
+      if (pbot - pk < EPSILP) bi = bi_prev;
+      else {
+        const double plo = pbot - pk1 < EPSILP ? pbot : .5 * (pk + pk1);
+        const double tlo = a_t[u], slo = a_s[u];
+        bi = GRAV * GRAV * (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) / fmax2(ONEM, plo - pup);
+        if (pbot - pk < ONEM) bi = bi_prev;
+        pup = plo; tup = tlo; sup = slo;
+      }
       L(bfsqi, k) = bi;
-      pup = plo; tup = tlo; sup = slo;
+      if (k == 2) bi2 = bi;
+      bi_prev = bi; pk = pk1;
     }
   }
-  L(bfsqi, 1) = L(bfsqi, 2);
-  L(bfsqi, kk + 1) = L(bfsqi, kk);
+  L(bfsqi, 1) = bi2;
+  L(bfsqi, kk + 1) = bi_prev;
 #undef L
 }
 
@@ -447,19 +464,42 @@ __global__ __launch_bounds__(64) void k_cmn_nslope_ale(const DevView *__restrict
 #define O(f, k) (f)[(size_t)((k)-1) * np]
   for (int k = 1; k <= kk; k++) { O(nslp, k) = 0.; O(nnslp, k) = 0.; }
   int kmax = 1;
-  for (int k = 2; k <= kk; k++)
-    if (A(dp, a_, k) > EPSILP || A(dp, b_, k) > EPSILP) kmax = k;
+  for (int k0 = 2; k0 <= kk; k0 += 8) {                                  // eight levels' loads in flight
+    double d0[8], d1[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int kq = k0 + u <= kk ? k0 + u : kk; d0[u] = A(dp, a_, kq); d1[u] = A(dp, b_, kq); }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (k0 + u <= kk && (d0[u] > EPSILP || d1[u] > EPSILP)) kmax = k0 + u;
+  }
   int knnsl = 2;
   const double phba = A(phi, a_, kk + 1), phbb = A(phi, b_, kk + 1);
-  for (int k = 2; k <= kmax; k++) {
-    const double pm = .5 * (A(p, a_, k) + A(p, b_, k));
-    const double rx = .5 * (eos::rho(pm, A(temp, b_, k - 1), A(saln, b_, k - 1)) - eos::rho(pm, A(temp, a_, k - 1), A(saln, a_, k - 1)) +
-                            eos::rho(pm, A(temp, b_, k), A(saln, b_, k)) - eos::rho(pm, A(temp, a_, k), A(saln, a_, k)));
-    const double px = A(phi, b_, k) - A(phi, a_, k);
-    const double bm = .5 * (A(bf, a_, k) + A(bf, b_, k));
-    const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
-    O(nslp, k) = s;
-    if (A(phi, b_, k) > phba && A(phi, a_, k) > phbb) { O(nnslp, k) = sqrt(bm) * s; knnsl = k; }
+  {
+    // 4 interfaces' loads in flight; T, S of the layer above an interface are the previous interface's layer below
+    double tbm = A(temp, b_, 1), sbm = A(saln, b_, 1), tam = A(temp, a_, 1), sam = A(saln, a_, 1);
+    for (int k0 = 2; k0 <= kmax; k0 += 4) {
+      double pa[4], pb[4], tb[4], sb[4], ta[4], sa[4], fb[4], fa[4], ba[4], bb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int kq = k0 + u <= kmax ? k0 + u : kmax;
+        pa[u] = A(p, a_, kq); pb[u] = A(p, b_, kq);
+        tb[u] = A(temp, b_, kq); sb[u] = A(saln, b_, kq); ta[u] = A(temp, a_, kq); sa[u] = A(saln, a_, kq);
+        fb[u] = A(phi, b_, kq); fa[u] = A(phi, a_, kq); ba[u] = A(bf, a_, kq); bb[u] = A(bf, b_, kq);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u;
+        if (k > kmax) break;
+        const double pm = .5 * (pa[u] + pb[u]);
+        const double rx = .5 * (eos::rho(pm, tbm, sbm) - eos::rho(pm, tam, sam) + eos::rho(pm, tb[u], sb[u]) - eos::rho(pm, ta[u], sa[u]));
+        const double px = fb[u] - fa[u];
+        const double bm = .5 * (ba[u] + bb[u]);
+        const double s = (GRAV * rx / (RHO0 * bm) + px / GRAV) * sci;
+        O(nslp, k) = s;
+        if (fb[u] > phba && fa[u] > phbb) { O(nnslp, k) = sqrt(bm) * s; knnsl = k; }
+        tbm = tb[u]; sbm = sb[u]; tam = ta[u]; sam = sa[u];
+      }
+    }
   }
   for (int k = knnsl + 1; k <= kmax; k++) O(nnslp, k) = O(nnslp, knnsl);
 #undef A
