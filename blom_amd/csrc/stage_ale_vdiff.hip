@@ -205,27 +205,56 @@ __global__ __launch_bounds__(64) void k_ale_vdiffm(const DevView *__restrict__ V
   const double *dp = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np, *kv = V.f[F_kvisc_m];
   double *x = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
   double *gam = WK(V, isv ? 1 : 0);
-  auto fp = [&](int k) {
-    const double nuv = .5 * (kv[mns + (size_t)(k - 1) * np] + L(kv, k));
-    return nuv * (cc / fmax2(DPMIN_VDIFF, .5 * (L(dp, k - 1) + L(dp, k))));
+  // fp(k) = nuv(k) * fpbase(k) is formed once per level and carried to the next one (the reference forms it as fp(k+1) at level k
+  // and again as fp(k) at level k+1: the same product); the next four levels' inputs are loaded ahead
+  auto fpv = [&](double kva, double kvb, double dpa, double dpb) {
+    const double nuv = .5 * (kva + kvb);
+    return nuv * (cc / fmax2(DPMIN_VDIFF, .5 * (dpa + dpb)));
   };
-  double bei = 1. / (L(dp, 1) + fp(2));
-  L(x, 1) = L(dp, 1) * L(x, 1) * bei;
-  for (int k = 2; k <= kk - 1; k++) {
-    const double fpk = fp(k), fpk1 = fp(k + 1);
-    const double g = -fpk * bei;
-    L(gam, k) = g;
-    bei = 1. / (L(dp, k) + fpk * (1. + g) + fpk1);
-    L(x, k) = (L(dp, k) * L(x, k) + fpk * L(x, k - 1)) * bei;
+  double dpk = L(dp, 1), dpk1 = L(dp, 2);
+  double f = fpv(kv[mns + np], L(kv, 2), dpk, dpk1);             // fp(2)
+  double bei = 1. / (dpk + f);
+  double xp = dpk * L(x, 1) * bei;
+  L(x, 1) = xp;
+  dpk = dpk1;
+  for (int k0 = 2; k0 <= kk; k0 += 4) {
+    double a_dp[4], a_ka[4], a_kb[4], a_x[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u <= kk ? k0 + u : kk, k1 = k + 1 <= kk ? k + 1 : kk;
+      a_dp[u] = L(dp, k1); a_ka[u] = kv[mns + (size_t)(k1 - 1) * np]; a_kb[u] = L(kv, k1); a_x[u] = L(x, k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u;
+      if (k > kk) break;
+      const double g = -f * bei;
+      L(gam, k) = g;
+      double f1 = 0.;
+      if (k < kk) {
+        dpk1 = a_dp[u];
+        f1 = fpv(a_ka[u], a_kb[u], dpk, dpk1);
+        bei = 1. / (dpk + f * (1. + g) + f1);
+      } else {
+        bei = 1. / (dpk + f * (1. + g));
+      }
+      xp = (dpk * a_x[u] + f * xp) * bei;
+      L(x, k) = xp;
+      f = f1; dpk = dpk1;
+    }
   }
-  {
-    const double fpk = fp(kk);
-    const double g = -fpk * bei;
-    L(gam, kk) = g;
-    bei = 1. / (L(dp, kk) + fpk * (1. + g));
-    L(x, kk) = (L(dp, kk) * L(x, kk) + fpk * L(x, kk - 1)) * bei;
+  for (int k0 = kk - 1; k0 >= 1; k0 -= 4) {
+    double b_g[4], b_x[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = k0 - u >= 1 ? k0 - u : 1; b_g[u] = L(gam, k + 1); b_x[u] = L(x, k); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 - u;
+      if (k < 1) break;
+      xp = b_x[u] - b_g[u] * xp;
+      L(x, k) = xp;
+    }
   }
-  for (int k = kk - 1; k >= 1; k--) L(x, k) = L(x, k) - L(gam, k + 1) * L(x, k + 1);
 }
 
 int st_ale_vdifft(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
