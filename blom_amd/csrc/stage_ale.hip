@@ -370,7 +370,7 @@ __device__ inline double dsigds_(const Params &P, double th, double s) {        
 
 // work planes (1-based level accessors below): sd1, sd2 = sig_srcdi(1,:), (2,:); sgt = sig_trg; dsg = dsig_trg; spm = sig_pmin;
 // dpm = dpmin; sfac = smooth_fac
-__global__ void k_ale_nudge(const DevView *__restrict__ Vp, NudgePar Q, const double *__restrict__ psrc, const double *__restrict__ pcT,
+__global__ __launch_bounds__(256) void k_ale_nudge(const DevView *__restrict__ Vp, NudgePar Q, const double *__restrict__ psrc, const double *__restrict__ pcT,
                             const double *__restrict__ pcS, int npc, const double *__restrict__ plevel, double *__restrict__ sd1,
                             double *__restrict__ sd2, double *__restrict__ sgt, double *__restrict__ dsg, double *__restrict__ spm,
                             double *__restrict__ dpm, double *__restrict__ pdst, double *__restrict__ sfac) {
@@ -405,24 +405,65 @@ __global__ void k_ale_nudge(const DevView *__restrict__ Vp, NudgePar Q, const do
 #define SF(k) PL(sfac, k)
 #define LEV(q) plevel[(q)-1]
   const double dpmin_interior = Q.dpmin_interior, nudge_fac = Q.nudge_fac, stab_fac_limit = Q.stab_fac_limit;
+  // the plain per-level loops of the set-up with four (eight) levels' loads in flight and the level above in registers
+  const double pbq = P(kk + 1);
   int ksmx = kk;                                                                     // :213-217
-  for (int k = kk; k >= 1; k--)
-    if (P(k) == P(kk + 1)) ksmx = k - 1;
+  for (int k0 = kk; k0 >= 1; k0 -= 8) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = P(k0 - u >= 1 ? k0 - u : 1);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (k0 - u >= 1 && a[u] == pbq) ksmx = k0 - u - 1;
+  }
   double sig_max = 0.;                                                                // :591-605
   double *sigint = V.f[F_sigint];
-  for (int k = 1; k <= ksmx; k++) {
-    SD1(k) = eos::sig(V.P, top(pcT, k), top(pcS, k));
-    SD2(k) = eos::sig(V.P, bot(pcT, k), bot(pcS, k));
-    sig_max = fmax2(sig_max, SD2(k));
+  {
+    double sd2_prev = 0.;
+    for (int k0 = 1; k0 <= ksmx; k0 += 4) {
+      double cT[4][5], cS[4][5];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int kq = k0 + u <= ksmx ? k0 + u : ksmx;
+#pragma unroll
+        for (int q = 0; q < 5; q++) { cT[u][q] = pc_at(pcT, kq, q); cS[u][q] = pc_at(pcS, kq, q); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u;
+        if (k > ksmx) break;
+        double tb = cT[u][0], sb = cS[u][0];                                          // peval1: the coefficients summed in order
+#pragma unroll
+        for (int q = 1; q < 5; q++) { tb = tb + cT[u][q]; sb = sb + cS[u][q]; }
+        const double s1 = eos::sig(V.P, cT[u][0], cS[u][0]), s2 = eos::sig(V.P, tb, sb);
+        SD1(k) = s1;
+        SD2(k) = s2;
+        sig_max = fmax2(sig_max, s2);
+        PL(sigint, k) = k == 1 ? s1 : .5 * (sd2_prev + s1);
+        sd2_prev = s2;
+      }
+    }
+    for (int k = ksmx + 1; k <= kk; k++) PL(sigint, k) = sd2_prev;
   }
-  PL(sigint, 1) = SD1(1);
-  for (int k = 2; k <= ksmx; k++) PL(sigint, k) = .5 * (SD2(k - 1) + SD1(k));
-  for (int k = ksmx + 1; k <= kk; k++) PL(sigint, k) = SD2(ksmx);
   const double *sigmar = V.f[F_sigmar];
-  for (int k = 1; k <= kk; k++) ST(k) = PL(sigmar, k);                                // :608-615
-  ST(kk + 1) = ST(kk);
-  for (int k = 1; k <= kk - 1; k++) DS(k) = ST(k + 1) - PL(sigmar, k);
-  DS(kk) = DS(kk - 1);
+  {                                                                                   // :608-615
+    double st_prev = 0.;
+    for (int k0 = 1; k0 <= kk; k0 += 8) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = PL(sigmar, k0 + u <= kk ? k0 + u : kk);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + u;
+        if (k > kk) break;
+        ST(k) = a[u];
+        if (k >= 2) DS(k - 1) = a[u] - st_prev;
+        st_prev = a[u];
+      }
+    }
+    ST(kk + 1) = st_prev;
+    DS(kk) = DS(kk - 1);
+  }
   int kdmx;                                                                           // :620-623
   {
     int k = kk;
@@ -492,42 +533,73 @@ __global__ void k_ale_nudge(const DevView *__restrict__ Vp, NudgePar Q, const do
   }
   for (int k = kt; k <= kk + 1; k++) { D(k) = pb; SF(k) = 0.; }                        // :744-747
   const int kend = ksmx < kdmx ? ksmx : kdmx;
-  for (int k = kt; k <= kend; k++) {                                                  // :749-818
-    double stab_fac;
-    const double tu = bot(pcT, k - 1), su = bot(pcS, k - 1), tl = top(pcT, k), sl = top(pcS, k);
-    if (ST(k) < SD2(k - 1) && ST(k) < SD1(k)) {
-      const double dsig = ST(k) - SD2(k - 1);
-      double dsigdx = dsigdt_(V.P, tu, su) * dbot(pcT, k - 1) + dsigds_(V.P, tu, su) * dbot(pcS, k - 1);
-      stab_fac = dsigdx / DS(k - 1);
-      dsigdx = DS(k - 1) * fmax2(stab_fac, stab_fac_limit);
-      D(k) = P(k) + fmax2(-.5, dsig * nudge_fac / dsigdx) * (P(k) - P(k - 1));
-    } else if (ST(k) > SD2(k - 1) && ST(k) > SD1(k)) {
-      const double dsig = ST(k) - SD1(k);
-      double dsigdx = dsigdt_(V.P, tl, sl) * dtop(pcT, k) + dsigds_(V.P, tl, sl) * dtop(pcS, k);
-      stab_fac = dsigdx / DS(k);
-      dsigdx = DS(k) * fmax2(stab_fac, stab_fac_limit);
-      D(k) = P(k) + fmin2(.5, dsig * nudge_fac / dsigdx) * (P(k + 1) - P(k));
-    } else {
-      const double dsigdx_up = dsigdt_(V.P, tu, su) * dbot(pcT, k - 1) + dsigds_(V.P, tu, su) * dbot(pcS, k - 1);
-      const double dsigdx_lo = dsigdt_(V.P, tl, sl) * dtop(pcT, k) + dsigds_(V.P, tl, sl) * dtop(pcS, k);
-      const double dp_up = fmax2(P(k) - P(k - 1), ALE_EPSILP), dp_lo = fmax2(P(k + 1) - P(k), ALE_EPSILP);
-      double sig_intrp = ((SD1(k) + .5 * dsigdx_lo) * dp_up + (SD2(k - 1) - .5 * dsigdx_up) * dp_lo) / (dp_up + dp_lo);
-      sig_intrp = fmax2(fmin2(SD2(k - 1), SD1(k)), fmin2(fmax2(SD2(k - 1), SD1(k)), sig_intrp));
-      const double dsig = ST(k) - sig_intrp;
-      if (dsig < 0.) {
-        double dsigdx = dsigdx_up + 2. * (sig_intrp - SD2(k - 1));
-        stab_fac = dsigdx / DS(k - 1);
-        dsigdx = DS(k - 1) * fmax2(stab_fac, stab_fac_limit);
-        D(k) = P(k) + fmax2(-.5, dsig * nudge_fac / dsigdx) * (P(k) - P(k - 1));
-      } else {
-        double dsigdx = dsigdx_lo + 2. * (SD1(k) - sig_intrp);
-        stab_fac = dsigdx / DS(k);
-        dsigdx = DS(k) * fmax2(stab_fac, stab_fac_limit);
-        D(k) = P(k) + fmin2(.5, dsig * nudge_fac / dsigdx) * (P(k + 1) - P(k));
+  if (kt <= kend) {                                                                   // :749-818
+    // four levels' coefficients, densities and pressures loaded ahead; what level k reads of level k-1 travels in registers
+    double cTm[5], cSm[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) { cTm[q] = pc_at(pcT, kt - 1, q); cSm[q] = pc_at(pcS, kt - 1, q); }
+    double sd2_m = SD2(kt - 1), ds_m = DS(kt - 1), p_m = P(kt - 1), p_0 = P(kt), d_m = D(kt - 1);
+    for (int k0 = kt; k0 <= kend; k0 += 4) {
+      double cT[4][5], cS[4][5], a_st[4], a_sd1[4], a_sd2[4], a_ds[4], a_p1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int kq = k0 + u <= kend ? k0 + u : kend;
+#pragma unroll
+        for (int q = 0; q < 5; q++) { cT[u][q] = pc_at(pcT, kq, q); cS[u][q] = pc_at(pcS, kq, q); }
+        a_st[u] = ST(kq); a_sd1[u] = SD1(kq); a_sd2[u] = SD2(kq); a_ds[u] = DS(kq); a_p1[u] = P(kq + 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u;
+        if (k > kend) break;
+        double stab_fac;
+        double tu = cTm[0], su = cSm[0];                                              // peval1 of level k-1
+#pragma unroll
+        for (int q = 1; q < 5; q++) { tu = tu + cTm[q]; su = su + cSm[q]; }
+        const double tl = cT[u][0], sl = cS[u][0];                                    // peval0 of level k
+        const double dbT = cTm[1] + 2. * cTm[2] + 3. * cTm[3] + 4. * cTm[4], dbS = cSm[1] + 2. * cSm[2] + 3. * cSm[3] + 4. * cSm[4];
+        const double dtT = cT[u][1], dtS = cS[u][1];
+        const double st = a_st[u], sd1 = a_sd1[u], p_1 = a_p1[u], ds_0 = a_ds[u];
+        double dn;
+        if (st < sd2_m && st < sd1) {
+          const double dsig = st - sd2_m;
+          double dsigdx = dsigdt_(V.P, tu, su) * dbT + dsigds_(V.P, tu, su) * dbS;
+          stab_fac = dsigdx / ds_m;
+          dsigdx = ds_m * fmax2(stab_fac, stab_fac_limit);
+          dn = p_0 + fmax2(-.5, dsig * nudge_fac / dsigdx) * (p_0 - p_m);
+        } else if (st > sd2_m && st > sd1) {
+          const double dsig = st - sd1;
+          double dsigdx = dsigdt_(V.P, tl, sl) * dtT + dsigds_(V.P, tl, sl) * dtS;
+          stab_fac = dsigdx / ds_0;
+          dsigdx = ds_0 * fmax2(stab_fac, stab_fac_limit);
+          dn = p_0 + fmin2(.5, dsig * nudge_fac / dsigdx) * (p_1 - p_0);
+        } else {
+          const double dsigdx_up = dsigdt_(V.P, tu, su) * dbT + dsigds_(V.P, tu, su) * dbS;
+          const double dsigdx_lo = dsigdt_(V.P, tl, sl) * dtT + dsigds_(V.P, tl, sl) * dtS;
+          const double dp_up = fmax2(p_0 - p_m, ALE_EPSILP), dp_lo = fmax2(p_1 - p_0, ALE_EPSILP);
+          double sig_intrp = ((sd1 + .5 * dsigdx_lo) * dp_up + (sd2_m - .5 * dsigdx_up) * dp_lo) / (dp_up + dp_lo);
+          sig_intrp = fmax2(fmin2(sd2_m, sd1), fmin2(fmax2(sd2_m, sd1), sig_intrp));
+          const double dsig = st - sig_intrp;
+          if (dsig < 0.) {
+            double dsigdx = dsigdx_up + 2. * (sig_intrp - sd2_m);
+            stab_fac = dsigdx / ds_m;
+            dsigdx = ds_m * fmax2(stab_fac, stab_fac_limit);
+            dn = p_0 + fmax2(-.5, dsig * nudge_fac / dsigdx) * (p_0 - p_m);
+          } else {
+            double dsigdx = dsigdx_lo + 2. * (sd1 - sig_intrp);
+            stab_fac = dsigdx / ds_0;
+            dsigdx = ds_0 * fmax2(stab_fac, stab_fac_limit);
+            dn = p_0 + fmin2(.5, dsig * nudge_fac / dsigdx) * (p_1 - p_0);
+          }
+        }
+        dn = fmin2(fmax2(fmax2(dn, PMIN(k)), d_m + dpmin_interior), pb);
+        D(k) = dn;
+        SF(k) = fmax2(0., fmin2(1., (stab_fac_limit - stab_fac) / stab_fac_limit));
+#pragma unroll
+        for (int q = 0; q < 5; q++) { cTm[q] = cT[u][q]; cSm[q] = cS[u][q]; }
+        sd2_m = a_sd2[u]; ds_m = ds_0; p_m = p_0; p_0 = p_1; d_m = dn;
       }
     }
-    D(k) = fmin2(fmax2(fmax2(D(k), PMIN(k)), D(k - 1) + dpmin_interior), pb);
-    SF(k) = fmax2(0., fmin2(1., (stab_fac_limit - stab_fac) / stab_fac_limit));
   }
   for (int k = (kt > kend ? kt : kend) + 1; k <= kdmx; k++) {                           // :820-841
     if (ST(k) < SD2(ksmx)) {
