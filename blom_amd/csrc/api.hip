@@ -695,7 +695,8 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     c->h.P.nstep = ns + 1;                             // read by host code only: no upload of the view for it
     ctx_sync_view(c);
     c->tmsmt1_ahead = !c->use_graph && !c->csdiag && it < nsteps - 1 && c->tmsmt_ahead;
-    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4;
+    // (the hybrid-coordinate sequence reads the engine's status back inside ale_regrid_remap: not capturable)
+    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4 && c->h.P.vcoord_tag == 1;
     hipGraphExec_t &ge = c->step_graph[ns & 1];
     if (graph && !ge) {
       // capture; nothing executes while capturing, so on any failure the step is simply run with plain launches
