@@ -78,7 +78,7 @@ def class_bytes_F(ntr, ntr_dif=None):
     }
 
 
-KNOWN_CONFIGS = ("channel", "tnx2v1s", "tnx1v4s", "chan_t8")
+KNOWN_CONFIGS = ("channel", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")
 
 
 def _profiles_of(config, suffix):
