@@ -139,7 +139,7 @@ contains
   ! ones are plain passive tracers to every stage (not TKE, not ideal age), as the bgc tracers are.
   subroutine ref_set_ntr(nnew) bind(C, name='ref_set_ntr')
     integer(c_int), value :: nnew
-    real(8), allocatable :: t4(:,:,:,:), o4(:,:,:,:), u3(:,:,:), v3(:,:,:), f3(:,:,:)
+    real(8), allocatable :: t4(:,:,:,:), o4(:,:,:,:), u3(:,:,:), v3(:,:,:), f3(:,:,:), c3(:,:,:)
     integer :: nt, nold
     nold = ntr
     if (nnew < 1 .or. nold < 1 .or. nnew == nold) return
@@ -152,6 +152,13 @@ contains
       trc(:,:,:,nt) = t4(:,:,:,min(nt,nold)); trcold(:,:,:,nt) = o4(:,:,:,min(nt,nold))
       uflxtr(nt,:,:) = u3(min(nt,nold),:,:); vflxtr(nt,:,:) = v3(min(nt,nold),:,:); trflx(nt,:,:) = f3(min(nt,nold),:,:)
     end do
+    if (allocated(trc_corr)) then                       ! phy/mod_forcing.F90:272 (ale_vdifft accumulates into it per tracer)
+      call move_alloc(trc_corr, c3)
+      allocate(trc_corr(1-nbdy:idm+nbdy,1-nbdy:jdm+nbdy,nnew))
+      do nt = 1, nnew
+        trc_corr(:,:,nt) = c3(:,:,min(nt,nold))
+      end do
+    end if
     call ref_poke_i4(ntr, nnew)
   end subroutine ref_set_ntr
 

@@ -51,16 +51,19 @@ def _inputs(case, ntr, seed):
     return f
 
 
-@pytest.mark.parametrize("cfg,nsteps,seed", [("chan_s_tke", 4, 1), ("box_s", 4, 2), ("fuk95", 3, 3), ("tri_s_tke", 3, 4),
-                                             ("chan_s_tke", 1, 5)])
-def test_ale_vdiff_equals_the_reference(cfg, nsteps, seed):
+@pytest.mark.parametrize("cfg,nsteps,seed,ntr", [("chan_s_tke", 4, 1, None), ("box_s", 4, 2, None), ("fuk95", 3, 3, None), ("tri_s_tke", 3, 4, None),
+                                                 ("chan_s_tke", 1, 5, None),
+                                                 # more tracers than one pass of the fused kernel carries (4), and counts that
+                                                 # leave 1, 2 tracers to the last pass: the reference carries them itself
+                                                 ("chan_s_tke", 3, 6, 9), ("tri_s_tke", 3, 7, 6), ("box_s", 3, 8, 4), ("chan_s_tke", 3, 9, 5)])
+def test_ale_vdiff_equals_the_reference(cfg, nsteps, seed, ntr):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     lib = cfg.replace("_tke", "") + "_vdf"
     if not have_ref(lib):
         pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
-    case = make_case(cfg)
-    ref = get_ref_backend(lib, case.depth)
+    case = make_case(cfg, ntr=ntr) if ntr else make_case(cfg)
+    ref = get_ref_backend(lib, case.depth, ntr=ntr)
     assert ref.ntr == case.ntr
     kk = case.kdm
     gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
