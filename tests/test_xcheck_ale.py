@@ -163,3 +163,44 @@ def test_other_coordinates_fail_loudly():
     with pytest.raises(BlomGpuError, match="unsupported"):
         gpu.set("ale_reconstruction_method", "spline")
     gpu.close()
+
+
+@pytest.mark.parametrize("cfg,method,ntr", [("chan_s", "nudge", 9), ("tri_s", "direct", 7), ("box_s", "nudge", 12)])
+def test_more_tracers_than_one_engine_batch(cfg, method, ntr):
+    """ale_regrid_remap with more than the eight fields (T, S + tracers) one batch of the engine's *_many calls carries: the
+    further batches reconstruct and remap on their own.  Pinned by reduction: tracers that are copies of the case's one tracer
+    must each come out as that tracer does in the run with one tracer (which the cases above check against the reference),
+    and nothing else may change."""
+    from blom_amd.gpu import BlomGpu
+    nsteps = 3
+    case1, caseN = make_case(cfg), make_case(cfg, ntr=ntr)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case1.depth, case1.idm, case1.jdm, arctic=case1.nreg == 2)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    kk = case1.kdm
+    out = {}
+    for tag, case in (("one", case1), ("many", caseN)):
+        gpu = BlomGpu(case.idm, case.jdm, kk, case.ntr, nreg, masks)
+        hostinit.init_state(gpu, case)
+        assert gpu.step(0, nsteps) == nsteps
+        if tag == "many":                                    # every tracer a copy of the first (the ideal age, which updtrc treats on its own)
+            t = gpu.get("trc")
+            for nt in range(1, case.ntr):
+                t[nt * 2 * kk:(nt + 1) * 2 * kk] = t[:2 * kk]
+            gpu.put("trc", t)
+        pbot = float(np.max(gpu.get("p")[kk][4:-4, 4:-4][ip[4:-4, 4:-4] > 0]))
+        gpu.set("vcoord_type", "cntiso_hybrid")
+        gpu.set("ale_regrid_method", method)
+        gpu.set_vector("plevel", 0.4 * pbot * (np.arange(kk) / kk) ** 1.3)
+        gpu.set("delt1", 2.0 * case.params["baclin"])
+        gpu.stage("ale_regrid_remap", *hostinit.step_indices(nsteps, kk))
+        out[tag] = {nm: gpu.get(nm) for nm in OUT}
+        gpu.close()
+    wet = ip > 0
+    for nm in OUT:
+        if nm == "trc":
+            continue
+        a, b = out["one"][nm], out["many"][nm]
+        assert np.array_equal(a[:, wet], b[:, wet]), nm
+    t1, tn = out["one"]["trc"], out["many"]["trc"]
+    for nt in range(ntr):
+        assert np.array_equal(tn[nt * 2 * kk:(nt + 1) * 2 * kk][:, wet], t1[:2 * kk][:, wet]), f"tracer {nt + 1}"
