@@ -313,8 +313,9 @@ def bench_hor3map(args):
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": alg[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes": alg[dom], "avg_ms": kms[dom],
-                        "note": "caller-visible arrays in + out; the kernels wait on their own loads (DESIGN.md 3a, 3g: counters "
-                                "and what loading ahead gave)"},
+                        "note": "caller-visible arrays in + out; the kernels also move their work planes (DESIGN.md 3g: counted "
+                                "0.4-0.9 GB per kernel before the store cuts) -- with every walk's loads issued ahead they run at "
+                                "4-5 TB/s of counted traffic"},
            "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
     if not args.no_cpu_baseline and hc.have_ref():
         m = 6000
