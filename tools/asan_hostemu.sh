@@ -37,8 +37,8 @@ run("tri_s", advmth="cppm")
 run("chan_m", steps=2, barotp_fused=0)
 run("tri_m", steps=2)
 # the step of the hybrid vertical coordinate (ale_regrid_remap with both coordinates and regrid methods, ale_forcing, ale_vdifft/m ..)
-def hybrid(cfg, vcoord, method, advmth="remap", steps=3):
-    case = make_case(cfg, advmth=advmth)
+def hybrid(cfg, vcoord, method, advmth="remap", steps=3, ntr=None):
+    case = make_case(cfg, advmth=advmth, ntr=ntr)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     hostinit.init_state(gpu, case)
@@ -49,22 +49,27 @@ def hybrid(cfg, vcoord, method, advmth="remap", steps=3):
         gpu.put(nm, 1e-4 * np.ones((kk + 1, nj, ni)))
     for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
         gpu.put(nm, frac)
-    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -50.), ("sswflx", -80.), ("salflx", 1e-3)):
+    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -50.), ("sswflx", -80.), ("salflx", 1e-3), ("OBLdepth", 30.)):
         gpu.put(nm, v * np.ones((1, nj, ni)))
     pbot = float(np.max(gpu.get("p")[kk][4:-4, 4:-4][ip[4:-4, 4:-4] > 0]))
     gpu.set("vcoord_type", vcoord)
     gpu.set("ale_regrid_method", method)
+    gpu.set("mlrmth", "fox08")
     gpu.set_vector("plevel", 0.3 * pbot * (np.arange(kk) / kk) ** 1.3)
+    if advmth == "cppm":
+        gpu.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
     gpu.stage("cmnfld1", *hostinit.step_indices(0, kk))
     ns = gpu.step(0, steps)
     u = gpu.get("u")[:, 4:-4, 4:-4]
     assert np.isfinite(u[np.broadcast_to((iu[4:-4, 4:-4] > 0)[None], u.shape)]).all()
-    print(cfg, vcoord, method, advmth, "hybrid step ok", ns, flush=True)
+    print(cfg, vcoord, method, advmth, ntr, "hybrid step ok", ns, flush=True)
     gpu.close()
 hybrid("chan_s", "cntiso_hybrid", "nudge")
 hybrid("tri_s", "cntiso_hybrid", "direct")
 hybrid("box_s", "plevel", "direct", advmth="cppm")
 hybrid("fuk95", "plevel", "nudge", advmth="cppm", steps=2)
+hybrid("chan_s_tke", "cntiso_hybrid", "nudge", ntr=9)            # further passes of the fused vdifft kernel, two engine batches
+hybrid("tri_s_tke", "cntiso_hybrid", "direct", ntr=6)
 import test_hostemu_multirank as t
 for cfg, isz, jsz in (("chan_s", (7, 7, 6), (13, 11)), ("tri_s_tke", (6, 6, 6, 6), (10, 10))):
     for g in (True, False):
