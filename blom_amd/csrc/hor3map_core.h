@@ -952,27 +952,29 @@ H3HD void h3_regrid_method_2(const H3Grid &g, const H3Src &s, int col, int m, do
   const int nc = g.nc, np = g.p_ord + 1;
   const int ns = g.n_act[col];
   const double u_eps = s.u_eps[col];
+  // the current target value lives in a register, the next one is loaded one advance ahead
+  auto ug_at = [&](int j) { return H3A(ugrd, j <= ng ? j : ng); };
   int jg = 1;
+  double ug = ug_at(1), ug_nx = ug_at(2);
+#define H3RG2_NEXT_TARGET() { jg = jg + 1; if (jg > ng) return; ug = ug_nx; ug_nx = ug_at(jg + 1); }
   while (true) {
-    if ((H3A(ugrd, jg) - H3A(s.uel, 1)) * u_sgn >= 0.0) break;
-    jg = jg + 1;
-    if (jg > ng) return;
+    if ((ug - H3A(s.uel, 1)) * u_sgn >= 0.0) break;
+    H3RG2_NEXT_TARGET();
   }
   int js = 1;
   double umr = h3_mid_value(s, nc, np, col, m, js), uml;
   while (true) {
-    if ((H3A(ugrd, jg) - umr) * u_sgn > 0.0) break;
-    const double xi = h3_cell_intersection(g, s, col, m, js, H3A(ugrd, jg), 0.0, 0.5);
+    if ((ug - umr) * u_sgn > 0.0) break;
+    const double xi = h3_cell_intersection(g, s, col, m, js, ug, 0.0, 0.5);
     H3A(xgrd, jg) = XEDGE(js, xi);
-    jg = jg + 1;
-    if (jg > ng) return;
+    H3RG2_NEXT_TARGET();
   }
   bool done = false;
   while (!done) {
     while (true) {
       uml = umr;
       umr = h3_mid_value(s, nc, np, col, m, js);
-      if ((H3A(ugrd, jg) - umr) * u_sgn <= 0.0) break;
+      if ((ug - umr) * u_sgn <= 0.0) break;
       js = js + 1;
       if (js > ns) { done = true; break; }
     }
@@ -998,28 +1000,26 @@ H3HD void h3_regrid_method_2(const H3Grid &g, const H3Src &s, int col, int m, do
       pcl3 = duml - pcl2;
     }
     while (true) {
-      if ((H3A(ugrd, jg) - pcr1) * u_sgn > 0.0) break;
-      const double xi = h3_parabola_intersection(pcl1, pcl2, pcl3, H3A(ugrd, jg), u_eps, 0.5, 1.0);
+      if ((ug - pcr1) * u_sgn > 0.0) break;
+      const double xi = h3_parabola_intersection(pcl1, pcl2, pcl3, ug, u_eps, 0.5, 1.0);
       H3A(xgrd, jg) = XEDGE(js - 1, xi);
-      jg = jg + 1;
-      if (jg > ng) return;
+      H3RG2_NEXT_TARGET();
     }
     while (true) {
-      if ((H3A(ugrd, jg) - umr) * u_sgn > 0.0) break;
-      const double xi = h3_parabola_intersection(pcr1, pcr2, pcr3, H3A(ugrd, jg), u_eps, 0.0, 0.5);
+      if ((ug - umr) * u_sgn > 0.0) break;
+      const double xi = h3_parabola_intersection(pcr1, pcr2, pcr3, ug, u_eps, 0.0, 0.5);
       H3A(xgrd, jg) = XEDGE(js, xi);
-      jg = jg + 1;
-      if (jg > ng) return;
+      H3RG2_NEXT_TARGET();
     }
   }
   js = ns;
   while (true) {
-    if ((H3A(ugrd, jg) - H3A(s.uer, js)) * u_sgn > 0.0) return;
-    const double xi = h3_cell_intersection(g, s, col, m, js, H3A(ugrd, jg), 0.5, 1.0);
+    if ((ug - H3A(s.uer, js)) * u_sgn > 0.0) return;
+    const double xi = h3_cell_intersection(g, s, col, m, js, ug, 0.5, 1.0);
     H3A(xgrd, jg) = XEDGE(js, xi);
-    jg = jg + 1;
-    if (jg > ng) return;
+    H3RG2_NEXT_TARGET();
   }
+#undef H3RG2_NEXT_TARGET
 }
 
 // regrid (mod_hor3map.F90:4461-4557)
