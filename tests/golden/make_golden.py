@@ -6,7 +6,8 @@ build container only:   python tests/golden/make_golden.py [cfg ...]      (defau
 Per configuration (chan_s, box_s; for fuk95 -- the reference's own test case, 156x32x12 --, tri_s -- arctic patch --,
 chan_s_tke -- the reference's default tracer set, ntr = 3 --, channel_tke -- BASELINE.json's channel at full size,
 208x512x53, ntr = 3, the bench workload, prognostic fields only -- and tnx2v1s_tke -- the tnx2v1 grid's dimensions,
-180x193x53, arctic patch, synthetic bathymetry -- only the CRC file: their inputs are the analytic
+180x193x53, arctic patch, synthetic bathymetry --, tnx1v4s_tke -- the tnx1v4 grid's dimensions, 360x385x53, BASELINE.json's
+config 5, with 3 and with 24 tracers -- only the CRC file: their inputs are the analytic
 host initialisation, which the tests redo):
   <cfg>_init.npz   complete model state + masks + grid after host initialisation (the inputs)
   <cfg>_crc.json   for steps 1..NSTEPS and every stage of the dyncore sequence: the reference's own
@@ -49,13 +50,17 @@ def generate(cfg):
     global NSTEPS
     eddy = cfg.endswith("+edf")
     cfg = cfg[:-4] if eddy else cfg
-    out = cfg + "_edf" if eddy else cfg
-    big = cfg.startswith("channel") or cfg.startswith("tnx2v1s")
+    ntr = None
+    if "@" in cfg:                 # 'name@N': the reference carrying N tracers (ref_set_ntr) -> <name>_nN[_edf]_crc.json
+        cfg, n = cfg.split("@")
+        ntr = int(n)
+    out = cfg + (f"_n{ntr}" if ntr else "") + ("_edf" if eddy else "")
+    big = cfg.startswith("channel") or cfg.startswith("tnx2v1s") or cfg.startswith("tnx1v4s")
     crc_only = eddy or big or cfg in ("fuk95", "fuk95_ref", "tri_s", "chan_s_tke")
     NSTEPS = 2 if cfg == "fuk95" else 3
-    case = make_case(cfg)
+    case = make_case(cfg, ntr=ntr)
     # the channel-sized reference is built with its OpenMP directives on (same results, oracle/Makefile)
-    ref = get_ref_backend(cfg + "_omp" if big else cfg, case.depth)
+    ref = get_ref_backend(cfg + "_omp" if big else cfg, case.depth, ntr=ntr)
     crc_fields = CHANNEL_FIELDS if big else CRC_FIELDS
     hostinit.init_state(ref, case)
     if eddy:
@@ -94,7 +99,8 @@ def generate(cfg):
 if __name__ == "__main__":
     import threading
     cfgs = sys.argv[1:] or ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke",
-                            "tri_s+edf", "chan_s_tke+edf", "channel_tke+edf", "tnx2v1s_tke+edf"]
+                            "tri_s+edf", "chan_s_tke+edf", "channel_tke+edf", "tnx2v1s_tke+edf",
+                            "tnx1v4s_tke+edf", "tnx1v4s_tke@24+edf"]
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     os.environ["OMP_STACKSIZE"] = "1G"
     threading.stack_size(2 << 30)            # the reference keeps stage-local 2-D work arrays on the stack

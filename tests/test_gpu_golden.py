@@ -69,7 +69,8 @@ def test_device_reproduces_golden_fixtures(cfg):
 
 
 @pytest.mark.parametrize("cfg", ["fuk95", "fuk95_ref", "tri_s", "chan_s_tke", "channel_tke", "tnx2v1s_tke",
-                                 "tri_s+edf", "chan_s_tke+edf", "channel_tke+edf", "tnx2v1s_tke+edf"])
+                                 "tri_s+edf", "chan_s_tke+edf", "channel_tke+edf", "tnx2v1s_tke+edf",
+                                 "tnx1v4s_tke+edf", "tnx1v4s_tke@24+edf"])
 def test_device_reproduces_reference_checksums_from_analytic_init(cfg):
     """Fixtures that hold only the reference's per-stage checksums; the inputs are the analytic host initialisation.
     channel_tke is BASELINE.json's channel at full size (208x512x53, ntr = 3, the bench workload): the device must
@@ -80,11 +81,16 @@ def test_device_reproduces_reference_checksums_from_analytic_init(cfg):
     from blom_amd.checksum import grid_of
     # <cfg>+edf: the same run with the frozen synthetic eddy-induced mass fluxes of hostinit.frozen_eddy_fluxes in front
     # of advect (the bench workload has eddtra's there; the fixture was made by writing them into the reference's arrays)
+    # <cfg>@N: with N tracers (tnx1v4s_tke@24: BASELINE.json's config 5 at its size, the extra tracers standing in for iHAMOCC's)
     eddy = cfg.endswith("+edf")
     cfg = cfg[:-4] if eddy else cfg
-    case = make_case(cfg)
+    ntr = None
+    if "@" in cfg:
+        cfg, n = cfg.split("@")
+        ntr = int(n)
+    case = make_case(cfg, ntr=ntr)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
-    gold = json.load(open(os.path.join(HERE, "golden", f"{cfg}_edf_crc.json" if eddy else f"{cfg}_crc.json")))
+    gold = json.load(open(os.path.join(HERE, "golden", cfg + (f"_n{ntr}" if ntr else "") + ("_edf" if eddy else "") + "_crc.json")))
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     hostinit.init_state(gpu, case)
     if eddy:

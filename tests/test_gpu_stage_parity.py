@@ -180,6 +180,15 @@ def test_full_size_with_24_tracers_matches_reference():
     test_full_size_matches_reference("channel_tke", True, ntr=24, nsteps=3)
 
 
+@pytest.mark.parametrize("ntr", [3, 24])
+def test_full_size_tnx1v4s_matches_reference(ntr):
+    """BASELINE.json's config 5 at its size: the tnx1v4 grid's dimensions (360x385x53, bld/tnx1v4/patch.input.32:2, arctic
+    patch, synthetic bathymetry) with the default tracer set and with 24 tracers (the extra ones standing in for iHAMOCC's,
+    advected on the device), eddy-induced fluxes on: three device-resident steps against the reference's own Fortran
+    carrying that many tracers (oracle/_ref/tnx1v4s_tke_omp).  Bit for bit."""
+    test_full_size_matches_reference("tnx1v4s_tke", True, ntr=ntr, nsteps=3)
+
+
 @pytest.mark.parametrize("eddy", [False, True], ids=["zero_eddy_fluxes", "eddy_fluxes"])
 @pytest.mark.parametrize("cfg", ["channel_tke", "tnx2v1s_tke"])
 def test_full_size_matches_reference(cfg, eddy, ntr=None, nsteps=4):
