@@ -21,7 +21,24 @@ def ref_lib_path(cfg):
     return os.path.join(_HERE, "_ref", _BUILD_OF.get(cfg, cfg), "libblomref.so")
 
 
+def _unpack(path):
+    """The channel- and tnx-sized libraries carry ~100 MB of the reference's initialised module arrays each (constant
+    patterns: 1.5 MB gzipped) and the snapshot that travels to the GPU box is limited to 512 MiB, so oracle/Makefile
+    leaves a libblomref.so.gz beside them and .gpurunignore keeps the unpacked files at home; unpack on first use."""
+    gz = path + ".gz"
+    if os.path.exists(path) or not os.path.exists(gz):
+        return
+    import gzip
+    import shutil
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with gzip.open(gz, "rb") as src, open(tmp, "wb") as dst:
+        shutil.copyfileobj(src, dst, 1 << 24)
+    os.chmod(tmp, 0o755)
+    os.replace(tmp, path)
+
+
 def have_ref(cfg):
+    _unpack(ref_lib_path(cfg))
     return os.path.exists(ref_lib_path(cfg))
 
 
@@ -32,6 +49,7 @@ class RefBlom:
     def __init__(self, cfg):
         self.cfg = cfg
         # RTLD_LOCAL + distinct file => several configs can coexist in a process.
+        _unpack(ref_lib_path(cfg))
         self.lib = C.CDLL(ref_lib_path(cfg), mode=os.RTLD_LOCAL | os.RTLD_NOW)
         d = (C.c_int * 8)()
         self.lib.ref_dims(d)

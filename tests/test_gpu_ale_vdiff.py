@@ -57,9 +57,20 @@ def _inputs(case, ntr, seed):
                                                  # leave 1, 2 tracers to the last pass: the reference carries them itself
                                                  ("chan_s_tke", 3, 6, 9), ("tri_s_tke", 3, 7, 6), ("box_s", 3, 8, 4), ("chan_s_tke", 3, 9, 5)])
 def test_ale_vdiff_equals_the_reference(cfg, nsteps, seed, ntr):
+    _ale_vdiff_check(cfg, nsteps, seed, ntr)
+
+
+def test_full_size_channel_ale_vdiff_equals_the_reference():
+    """PINNED at BASELINE.json's channel size (208x512x53, ntr = 3): oracle/_ref/channel_tke_omp_vdf is the reference's own
+    phy/mod_ale_vdiff.F90 on the plain build, no stand-in."""
+    from test_xcheck_ale import run_with_big_stack
+    run_with_big_stack(_ale_vdiff_check, "channel_tke", 2, 21, None)
+
+
+def _ale_vdiff_check(cfg, nsteps, seed, ntr):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
-    lib = cfg.replace("_tke", "") + "_vdf"
+    lib = "channel_tke_omp_vdf" if cfg == "channel_tke" else cfg.replace("_tke", "") + "_vdf"
     if not have_ref(lib):
         pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
     case = make_case(cfg, ntr=ntr) if ntr else make_case(cfg)

@@ -37,6 +37,8 @@ OPTIONS = {
                   velocity_limiting="non_oscillatory", tracer_pc_upper_bndr=True, tracer_pc_lower_bndr=False,
                   velocity_pc_upper_bndr=True, velocity_pc_lower_bndr=False),
 }
+# BASELINE.json's channel at full size (208x512x53, ntr = 3): the group of tests/fuk95/limits (ppm, 6/4)
+OPTIONS["channel_tke"] = dict(OPTIONS["fuk95"])
 OUT = ["dp", "temp", "saln", "sigma", "trc", "u", "v", "dpu", "dpv", "dpuold", "dpvold", "p", "pu", "pv"]
 
 
@@ -89,11 +91,48 @@ def _limits_text(o):
     ("fuk95", 3, 0.6, "nudge"), ("chan_s", 4, 0.5, "nudge"), ("chan_s", 2, 0.1, "nudge"), ("box_s", 4, 0.8, "nudge"),
     ("tri_s", 3, 0.3, "nudge"), ("fuk95", 3, 1.0, "nudge+plevel")])
 def test_device_ale_regrid_remap_equals_the_real_module(cfg, nsteps, spread, vcoord, tmp_path):
+    _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path)
+
+
+def run_with_big_stack(fn, *args):
+    """the channel-sized reference keeps its stage-local work arrays on the stack (BLOM runs with ulimit -s unlimited) and is
+    built with its OpenMP directives on"""
+    import threading
+    res = {}
+
+    def body():
+        try:
+            fn(*args)
+            res["ok"] = True
+        except BaseException as e:          # noqa: BLE001 -- handed to the caller's thread
+            res["err"] = e
+    os.environ["OMP_NUM_THREADS"] = str(min(16, os.cpu_count() or 1))
+    os.environ["OMP_STACKSIZE"] = "1G"
+    threading.stack_size(2 << 30)
+    th = threading.Thread(target=body)
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    if "err" in res:
+        raise res["err"]
+    assert res.get("ok"), "the comparison did not complete"
+
+
+@pytest.mark.parametrize("vcoord", ["nudge", "cntiso_hybrid"])
+def test_full_size_channel_ale_regrid_remap_equals_the_real_module(vcoord, tmp_path):
+    """The same comparison at BASELINE.json's channel size (208x512x53, ntr = 3) with the options of the reference's
+    tests/fuk95/limits (ppm, boundary orders 6/4, non-oscillatory limiting; regrid_method 'nudge' -- the default -- and
+    'direct'): the loads-ahead and active-column logic of stage_ale.hip / hor3map.hip at the column count and depth they are
+    timed on.  Reference: oracle/_ref/channel_tke_omp_xaln / _xale (real phy/mod_ale_regrid_remap.F90, OpenMP)."""
+    run_with_big_stack(_ale_regrid_remap_check, "channel_tke", 3, 0.5, vcoord, tmp_path)
+
+
+def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     method = "nudge" if vcoord.startswith("nudge") else "direct"
-    lib = cfg + ("_xaln" if method == "nudge" else "_xale")
+    lib = (cfg + "_omp" if cfg.startswith("channel") else cfg) + ("_xaln" if method == "nudge" else "_xale")
     vcoord = "plevel" if vcoord.endswith("plevel") else "cntiso_hybrid"
     if not have_ref(lib):
         pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
