@@ -36,14 +36,6 @@ typedef double GLOBAL_AS *gd_t;
 typedef const int GLOBAL_AS *gci_t;
 #define GF(V, id) ((gcd_t)(V).f[id])
 
-// ring of D rows of a strip: lane l of row r at row(r)[l]; two pad columns on either side so that l-1 .. l+2 of
-// the edge lanes stay inside the row (what is read there belongs to no owned point)
-template <int D> struct Ring {
-  double *b;
-  int nip;
-  __device__ inline double *row(int r) const { return b + ((r + 16 * D) % D) * nip + 2; }
-};
-
 // chunk-major work item of this workgroup; XCD x (blockIdx % 8) walks a contiguous eighth of the items so that the
 // workgroups of one XCD share the 2-D coefficient rows of their chunk in its L2
 __device__ inline void march_item(int kk, int jj, int nchunk_, int nstrip, int &k, int &ja, int &jb, int &strip) {
@@ -74,6 +66,30 @@ __device__ inline void march_item(int kk, int jj, int nchunk_, int nstrip, int &
 #define MU(m) (((m) >> 1) & 1)
 #define MV(m) (((m) >> 2) & 1)
 #define MQ(m) (((m) >> 3) & 1)
+// Addressing: a lane's position in a plane is a 32-bit BYTE offset (planes and whole fields are < 4 GB), added to the
+// field's uniform base pointer by the load itself (global_load ... v_off, s[base:base+1] offset:imm): the i-neighbours
+// cost nothing (immediate offsets), a row's offset is computed once per step and shared by every field read on that
+// row.  With 64-bit per-load indices the march spent ~70-110 VALU instructions per step on address arithmetic.
+typedef const char GLOBAL_AS *gcc_t;
+typedef char GLOBAL_AS *gc_t;
+template <int IMM = 0> __device__ inline double ldo(gcd_t b, unsigned o) { return *(gcd_t)((gcc_t)b + o + IMM); }
+template <int IMM = 0> __device__ inline int ldoi(gci_t b, unsigned o) { return *(gci_t)((gcc_t)b + o + IMM); }
+__device__ inline void sto(gd_t b, unsigned o, double v) { *(gd_t)((gc_t)b + o) = v; }
+
+// LDS rings: the rings of one depth share their row slots -- ring X, slot q, lane l at [q][X][l] -- so that a step
+// computes ONE lane pointer per depth and row (9 in all) and every access is that pointer plus a compile-time
+// offset (ring, i-neighbour), i.e. a ds_read/ds_write with an immediate offset.  Slot of row r: (r + 16 D) % D.
+#define RG(p, X, dl) (p)[(X) * NP + (dl)]
+// The marches read ~50 arrays, and 50 base pointers do not fit the 102 SGPRs of a wavefront: kept live across the loop
+// they were spilled into VGPR lanes (v_writelane / v_readlane + hazard nops, ~100-200 instructions per step).  The
+// pointers of the 2-D coefficient planes are therefore fetched again at the top of every step -- one scalar load from
+// the DevView each, through the constant address space, volatile so that it stays inside the loop.
+#ifdef BLOM_HOSTEMU
+#define CONST_AS
+#else
+#define CONST_AS __attribute__((address_space(4)))
+#endif
+#define GFV(id) ((gcd_t) * (double *const volatile CONST_AS *)&Vp->f[id])
 template <int BS>
 __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip) {
   const DevView &V = *Vp;
@@ -102,21 +118,18 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
   // lanes outside every sweep's i-range (i < -1, i > ii+2) and rows outside the array read a neighbour's data instead,
   // which no sweep uses
   const int xl = x < 2 ? 2 : (x > ni - 3 ? ni - 3 : x);
-  auto cidx = [&](int r) {
+  const unsigned x8 = (unsigned)xl * 8u, ni8 = (unsigned)ni * 8u;
+  auto roff = [&](int r) {           // byte offset of (xl, row r clamped into the array) in a plane of doubles
     const int rc = r < -2 ? -2 : (r > jj + 3 ? jj + 3 : r);
-    return (size_t)xl + (size_t)ni * (rc + NBDY - 1);
+    return x8 + ni8 * (unsigned)(rc + NBDY - 1);
   };
 
-  double *lp = lds;
   constexpr int NP = BS + 4;
-  auto take = [&](int d) { double *b = lp; lp += d * NP; return b; };
-  const Ring<4> UTN{take(4), NP}, VTN{take(4), NP};
-  const Ring<4> DL2U{take(4), NP};
-  const Ring<3> VIB{take(3), NP}, DL2V{take(3), NP};
-  const Ring<2> D1{take(2), NP}, D2{take(2), NP};
-  const Ring<3> VS2U{take(3), NP}, VS4U{take(3), NP};
-  const Ring<4> VS2V{take(4), NP}, VS4V{take(4), NP};
-  const Ring<1> UFL1{take(1), NP};
+  enum { R_UTN, R_VTN, R_DL2U, R_VS2V, R_VS4V, N4 };       // depth 4
+  enum { R_VIB, R_DL2V, R_VS2U, R_VS4U, N3 };              // depth 3
+  enum { R_D1, R_D2, N2 };                                 // depth 2
+  double *const l4 = lds + 2 + l;                          // two pad columns on either side: l-1 .. l+2 of the edge lanes stay inside a row
+  double *const l3 = l4 + 4 * N4 * NP, *const l2 = l3 + 3 * N3 * NP, *const ufl1 = l2 + 2 * N2 * NP;
   // fields that are only ever read at the lane that wrote them live in registers: value of row s-1 (written this
   // step by W), s-2, s-3 (read by U); ujb of row s-2 is read by V; vflux1 of rows s-3, s-4
   double wja1 = 0., wja2 = 0., wja3 = 0., wjb1 = 0., wjb2 = 0., wjb3 = 0., uja1 = 0., uja2 = 0., uja3 = 0.;
@@ -126,69 +139,80 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
   const gcd_t f_u = GF(V, F_u) + okn, f_v = GF(V, F_v) + okn;
   const gcd_t f_ubf = GF(V, F_ubflxs_p) + on, f_vbf = GF(V, F_vbflxs_p) + on, f_pbun = GF(V, F_pbu) + on, f_pbvn = GF(V, F_pbv) + on;
   const gcd_t f_pbum = GF(V, F_pbu) + om, f_pbvm = GF(V, F_pbv) + om;
-  const gcd_t f_pu0 = GF(V, F_pu) + ok, f_pu1 = GF(V, F_pu) + (size_t)(k + 1) * np;
-  const gcd_t f_pv0 = GF(V, F_pv) + ok, f_pv1 = GF(V, F_pv) + (size_t)(k + 1) * np;
+  const gcd_t f_pu0 = GF(V, F_pu) + ok, f_pv0 = GF(V, F_pv) + ok;      // the interface below: one plane further on
+  const unsigned np8 = (unsigned)np * 8u;
   const gcd_t f_dpu = GF(V, F_dpu) + okm, f_dpv = GF(V, F_dpv) + okm;
-  const gcd_t scuy = GF(V, F_scuy), scvx = GF(V, F_scvx), scvy = GF(V, F_scvy), scux = GF(V, F_scux);
-  const gcd_t scq2i = GF(V, F_scq2i), scp2i = GF(V, F_scp2i), difwgt = GF(V, F_difwgt);
-  const gcd_t f_difmxp = GF(V, F_difmxp), f_difmxq = GF(V, F_difmxq), f_scpy = GF(V, F_scpy), f_scpx = GF(V, F_scpx);
-  const gcd_t f_scqx = GF(V, F_scqx), f_scqy = GF(V, F_scqy), f_scu2 = GF(V, F_scu2), f_scv2 = GF(V, F_scv2);
   const gd_t o_visu = (gd_t)WK(V, MF_VISU) + ok, o_visv = (gd_t)WK(V, MF_VISV) + ok;
-  const gd_t o_utotn = (gd_t)V.f[F_utotn], o_vtotn = (gd_t)V.f[F_vtotn];
 
   // inputs of the first sweep, one step ahead
   struct TIn { int mk; double u, ub, pbu, sy, v, vb, pbv, sx; };
   auto load_t = [&](int r) {
-    const size_t c = cidx(r);
+    const unsigned o = roff(r);
+    const gcd_t scuy = GFV(F_scuy), scvx = GFV(F_scvx);
     TIn t;
-    t.mk = mpk[c];
-    t.u = f_u[c]; t.ub = f_ubf[c]; t.pbu = f_pbun[c]; t.sy = scuy[c];
-    t.v = f_v[c]; t.vb = f_vbf[c]; t.pbv = f_pbvn[c]; t.sx = scvx[c];
+    t.mk = ldoi(mpk, o >> 1);
+    t.u = ldo(f_u, o); t.ub = ldo(f_ubf, o); t.pbu = ldo(f_pbun, o); t.sy = ldo(scuy, o);
+    t.v = ldo(f_v, o); t.vb = ldo(f_vbf, o); t.pbv = ldo(f_pbvn, o); t.sx = ldo(scvx, o);
     return t;
   };
   TIn tc = load_t(ja - 2);
+  // the packed masks of the rows behind the first sweep are carried along instead of being read again at every lag
+  // (a row's word serves W, V at lag 1, S at lag 2, F, U at lag 3 and their j-neighbours)
+  int mk1 = ldoi(mpk, roff(ja - 3) >> 1), mk2 = ldoi(mpk, roff(ja - 4) >> 1), mk3 = ldoi(mpk, roff(ja - 5) >> 1), mk4 = ldoi(mpk, roff(ja - 6) >> 1);
+  int q3 = (ja - 3 + 48) % 3;        // depth-3 slot of row s-1
 
   for (int s = ja - 2; s <= jb + 3; s++) {
     // ================= loads of this step =================
     const TIn tn = load_t(s + 1);
+    const gcd_t scuy = GFV(F_scuy), scvx = GFV(F_scvx), scvy = GFV(F_scvy), scux = GFV(F_scux);
+    const gcd_t scq2i = GFV(F_scq2i), scp2i = GFV(F_scp2i), difwgt = GFV(F_difwgt);
+    const gcd_t f_difmxp = GFV(F_difmxp), f_difmxq = GFV(F_difmxq), f_scpy = GFV(F_scpy), f_scpx = GFV(F_scpx);
+    const gcd_t f_scqx = GFV(F_scqx), f_scqy = GFV(F_scqy), f_scu2 = GFV(F_scu2), f_scv2 = GFV(F_scv2);
+    gd_t o_utotn = nullptr, o_vtotn = nullptr;
+    if (k == kk - 1) { o_utotn = (gd_t)GFV(F_utotn); o_vtotn = (gd_t)GFV(F_vtotn); }
     // W, V (row s-1)
-    const size_t cw = cidx(s - 1);
-    const int w_m = mpk[cw], w_mw = mpk[cw - 1], w_ms = mpk[cw - ni];
-    const double w_pu1 = f_pu1[cw], w_pu0 = f_pu0[cw], w_pbua = f_pbum[cw - ni], w_pbub = f_pbum[cw + ni];
-    const double w_pv1 = f_pv1[cw], w_pv0 = f_pv0[cw], w_pbva = f_pbvm[cw - 1], w_pbvb = f_pbvm[cw + 1];
-    const double v_scvy = scvy[cw], v_scvyw = scvy[cw - 1], v_scux = scux[cw], v_scuxs = scux[cw - ni], v_scq2i = scq2i[cw];
-    const double v_scuy = scuy[cw], v_scuye = scuy[cw + 1], v_scvx = scvx[cw], v_scvxn = scvx[cw + ni], v_scp2i = scp2i[cw];
-    const double sv_dw = difwgt[cw], sv_dws = difwgt[cw - ni];
+    const unsigned ow = roff(s - 1), own_ = ow + ni8, ows = ow - ni8;
+    const int w_m = mk1, w_mw = ldoi<-4>(mpk, ow >> 1), w_ms = mk2;
+    const double w_pu1 = ldo(f_pu0, ow + np8), w_pu0 = ldo(f_pu0, ow), w_pbua = ldo(f_pbum, ows), w_pbub = ldo(f_pbum, own_);
+    const double w_pv1 = ldo(f_pv0, ow + np8), w_pv0 = ldo(f_pv0, ow), w_pbva = ldo<-8>(f_pbvm, ow), w_pbvb = ldo<8>(f_pbvm, ow);
+    const double v_scvy = ldo(scvy, ow), v_scvyw = ldo<-8>(scvy, ow), v_scux = ldo(scux, ow), v_scuxs = ldo(scux, ows), v_scq2i = ldo(scq2i, ow);
+    const double v_scuy = ldo(scuy, ow), v_scuye = ldo<8>(scuy, ow), v_scvx = ldo(scvx, ow), v_scvxn = ldo(scvx, own_), v_scp2i = ldo(scp2i, ow);
+    const double sv_dw = ldo(difwgt, ow), sv_dws = ldo(difwgt, ows);
     // S at u-points (row s-2)
-    const size_t cs = cidx(s - 2);
-    const int s_m = mpk[cs];
-    const double su_dw = difwgt[cs], su_dww = difwgt[cs - 1];
+    const unsigned os = roff(s - 2);
+    const int s_m = mk2;
+    const double su_dw = ldo(difwgt, os), su_dww = ldo<-8>(difwgt, os);
     // F, U (row s-3)
-    const size_t cf = cidx(s - 3);
-    const int f_m = mpk[cf], f_me = mpk[cf + 1], f_me2 = mpk[cf + 2], f_mn = mpk[cf + ni], f_mn2 = mpk[cidx(s - 2) + ni];
-    const int f_mw = mpk[cf - 1], f_ms = mpk[cf - ni];
-    const double v_difmxp = f_difmxp[cf], v_scpy = f_scpy[cf], v_scpx = f_scpx[cf];
-    const double dpu_c = f_dpu[cf], dpu_e = f_dpu[cf + 1], dpu_s = f_dpu[cf - ni], dpu_n = f_dpu[cf + ni];
-    const double dpv_c = f_dpv[cf], dpv_n = f_dpv[cf + ni], dpv_w = f_dpv[cf - 1], dpv_e = f_dpv[cf + 1];
-    const double dmq_c = f_difmxq[cf], dmq_n = f_difmxq[cf + ni], dmq_e = f_difmxq[cf + 1];
-    const double scqx_c = f_scqx[cf], scqx_n = f_scqx[cf + ni], scqy_c = f_scqy[cf], scqy_e = f_scqy[cf + 1];
-    const double scu2_c = f_scu2[cf], scv2_c = f_scv2[cf];
+    const unsigned of = roff(s - 3), ofn = of + ni8, ofs = of - ni8;
+    const int f_m = mk3, f_me = ldoi<4>(mpk, of >> 1), f_me2 = ldoi<8>(mpk, of >> 1), f_mn = mk2, f_mn2 = mk1;
+    const int f_mw = ldoi<-4>(mpk, of >> 1), f_ms = mk4;
+    const double v_difmxp = ldo(f_difmxp, of), v_scpy = ldo(f_scpy, of), v_scpx = ldo(f_scpx, of);
+    const double dpu_c = ldo(f_dpu, of), dpu_e = ldo<8>(f_dpu, of), dpu_s = ldo(f_dpu, ofs), dpu_n = ldo(f_dpu, ofn);
+    const double dpv_c = ldo(f_dpv, of), dpv_n = ldo(f_dpv, ofn), dpv_w = ldo<-8>(f_dpv, of), dpv_e = ldo<8>(f_dpv, of);
+    const double dmq_c = ldo(f_difmxq, of), dmq_n = ldo(f_difmxq, ofn), dmq_e = ldo<8>(f_difmxq, of);
+    const double scqx_c = ldo(f_scqx, of), scqx_n = ldo(f_scqx, ofn), scqy_c = ldo(f_scqy, of), scqy_e = ldo<8>(f_scqy, of);
+    const double scu2_c = ldo(f_scu2, of), scv2_c = ldo(f_scv2, of);
+    // lane pointers into the ring slots of this step's rows
+    double *const a0 = l4 + (s & 3) * (N4 * NP), *const a1 = l4 + ((s - 1) & 3) * (N4 * NP);        // rows s (and s-4), s-1
+    double *const a2 = l4 + ((s - 2) & 3) * (N4 * NP), *const a3 = l4 + ((s - 3) & 3) * (N4 * NP);  // rows s-2, s-3
+    const int q2 = q3 == 0 ? 2 : q3 - 1, q1 = q2 == 0 ? 2 : q2 - 1;
+    double *const b1 = l3 + q3 * (N3 * NP), *const b2 = l3 + q2 * (N3 * NP), *const b3 = l3 + q1 * (N3 * NP);   // rows s-1 (and s-4), s-2, s-3
+    double *const c1 = l2 + ((s - 1) & 1) * (N2 * NP), *const c2 = l2 + ((s - 2) & 1) * (N2 * NP);   // rows s-1, s-2
 
     // ---- T: total velocities at the old time level, row s (:408-431; rows -1..jj+2, i = -1..ii+2) ------------
     if (act && s >= -1 && s <= jj + 2 && i >= -1 && i <= ii + 2) {
-      const size_t c = (size_t)x + (size_t)ni * (s + NBDY - 1);
       double un = 0., vn = 0.;
       if (MU(tc.mk)) {
         un = tc.u + tc.ub * tsfac / (tc.pbu * tc.sy);
         // the reference's module array utotn is left holding the last layer's values outside the interior
-        if (k == kk - 1) o_utotn[c] = un;
+        if (k == kk - 1) sto(o_utotn, x8 + ni8 * (unsigned)(s + NBDY - 1), un);
       }
       if (MV(tc.mk)) {
         vn = tc.v + tc.vb * tsfac / (tc.pbv * tc.sx);
-        if (k == kk - 1) o_vtotn[c] = vn;
+        if (k == kk - 1) sto(o_vtotn, x8 + ni8 * (unsigned)(s + NBDY - 1), vn);
       }
-      UTN.row(s)[l] = un;
-      VTN.row(s)[l] = vn;
+      RG(a0, R_UTN, 0) = un;
+      RG(a0, R_VTN, 0) = vn;
     }
     __syncthreads();
     // ---- W: side-wall weights, auxiliary velocities, del2 fields, row s-1 (:438-472) ---------------------------
@@ -197,38 +221,36 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       if (act && r >= -1 && r <= jj + 2 && i >= 0 && i <= ii + 2) {
         double uja = 0., ujb = 0., d2u = 0.;
         if (MU(w_m)) {
-          const double *utm = UTN.row(r - 1), *ut0 = UTN.row(r), *utp = UTN.row(r + 1);
           const double den = fmax2(w_pu1 - w_pu0, EPSILP);
           const double wa = fmax2(0., fmin2(1., (w_pu1 - w_pbua) / den));
           const double wb = fmax2(0., fmin2(1., (w_pu1 - w_pbub) / den));
-          const double un = ut0[l];
-          uja = (1. - wa) * utm[l] + wa * SLIP * un;
-          ujb = (1. - wb) * utp[l] + wb * SLIP * un;
-          d2u = un - .25 * (ut0[l + 1] + ut0[l - 1] + uja + ujb);
+          const double un = RG(a1, R_UTN, 0);
+          uja = (1. - wa) * RG(a2, R_UTN, 0) + wa * SLIP * un;
+          ujb = (1. - wb) * RG(a0, R_UTN, 0) + wb * SLIP * un;
+          d2u = un - .25 * (RG(a1, R_UTN, 1) + RG(a1, R_UTN, -1) + uja + ujb);
           wja1 = wa;
           wjb1 = wb;
         }
         uja1 = uja;
         ujb1 = ujb;
-        DL2U.row(r)[l] = d2u;
+        RG(a1, R_DL2U, 0) = d2u;
       }
       if (act && r >= 0 && r <= jj + 2 && i >= -1 && i <= ii + 2) {
         double via = 0., vib = 0., d2v = 0.;
         if (MV(w_m)) {
-          const double *vtm = VTN.row(r - 1), *vt0 = VTN.row(r), *vtp = VTN.row(r + 1);
           const double den = fmax2(w_pv1 - w_pv0, EPSILP);
           const double wa = fmax2(0., fmin2(1., (w_pv1 - w_pbva) / den));
           const double wb = fmax2(0., fmin2(1., (w_pv1 - w_pbvb) / den));
-          const double vn = vt0[l];
-          via = (1. - wa) * vt0[l - 1] + wa * SLIP * vn;
-          vib = (1. - wb) * vt0[l + 1] + wb * SLIP * vn;
-          d2v = vn - .25 * (vtp[l] + vtm[l] + via + vib);
+          const double vn = RG(a1, R_VTN, 0);
+          via = (1. - wa) * RG(a1, R_VTN, -1) + wa * SLIP * vn;
+          vib = (1. - wb) * RG(a1, R_VTN, 1) + wb * SLIP * vn;
+          d2v = vn - .25 * (RG(a0, R_VTN, 0) + RG(a2, R_VTN, 0) + via + vib);
           wia1 = wa;
           wib1 = wb;
         }
         via1 = via;
-        VIB.row(r)[l] = vib;
-        DL2V.row(r)[l] = d2v;
+        RG(b1, R_VIB, 0) = vib;
+        RG(b1, R_DL2V, 0) = d2v;
       }
     }
     __syncthreads();
@@ -236,24 +258,22 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     {
       const int r = s - 1;
       if (act && r >= 0 && r <= jj + 2 && i >= 0 && i <= ii + 2) {          // defor2 at q-points
-        const double *ut0 = UTN.row(r), *utm = UTN.row(r - 1), *vt0 = VTN.row(r);
         bool have = false;
         double d2 = 0.;
-        if (MV(w_m) && !MV(w_mw)) { const double t = vt0[l] * (1. - SLIP) * v_scvy; d2 = t * t * v_scq2i; have = true; }
-        else if (MV(w_mw) && !MV(w_m)) { const double t = vt0[l - 1] * (1. - SLIP) * v_scvyw; d2 = t * t * v_scq2i; have = true; }
-        if (MU(w_m) && !MU(w_ms)) { const double t = ut0[l] * (1. - SLIP) * v_scux; d2 = t * t * v_scq2i; have = true; }
-        else if (MU(w_ms) && !MU(w_m)) { const double t = utm[l] * (1. - SLIP) * v_scuxs; d2 = t * t * v_scq2i; have = true; }
+        if (MV(w_m) && !MV(w_mw)) { const double t = RG(a1, R_VTN, 0) * (1. - SLIP) * v_scvy; d2 = t * t * v_scq2i; have = true; }
+        else if (MV(w_mw) && !MV(w_m)) { const double t = RG(a1, R_VTN, -1) * (1. - SLIP) * v_scvyw; d2 = t * t * v_scq2i; have = true; }
+        if (MU(w_m) && !MU(w_ms)) { const double t = RG(a1, R_UTN, 0) * (1. - SLIP) * v_scux; d2 = t * t * v_scq2i; have = true; }
+        else if (MU(w_ms) && !MU(w_m)) { const double t = RG(a2, R_UTN, 0) * (1. - SLIP) * v_scuxs; d2 = t * t * v_scq2i; have = true; }
         if (MQ(w_m)) {
-          const double t = VIB.row(r)[l - 1] * v_scvy - via1 * v_scvyw + ujb2 * v_scux - uja1 * v_scuxs;
+          const double t = RG(b1, R_VIB, -1) * v_scvy - via1 * v_scvyw + ujb2 * v_scux - uja1 * v_scuxs;
           d2 = t * t * v_scq2i;
           have = true;
         }
-        if (have) D2.row(r)[l] = d2;
+        if (have) RG(c1, R_D2, 0) = d2;
       }
       if (act && r >= -1 && r <= jj + 1 && i >= -1 && i <= ii + 1 && MP(w_m)) {   // defor1 at p-points
-        const double *ut0 = UTN.row(r), *vt0 = VTN.row(r), *vtp = VTN.row(r + 1);
-        const double t = (ut0[l + 1] * v_scuye - ut0[l] * v_scuy) - (vtp[l] * v_scvxn - vt0[l] * v_scvx);
-        D1.row(r)[l] = t * t * v_scp2i;
+        const double t = (RG(a1, R_UTN, 1) * v_scuye - RG(a1, R_UTN, 0) * v_scuy) - (RG(a0, R_VTN, 0) * v_scvxn - RG(a1, R_VTN, 0) * v_scvx);
+        RG(c1, R_D1, 0) = t * t * v_scp2i;
       }
     }
     __syncthreads();
@@ -262,21 +282,19 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       {
         const int r = s - 2;
         if (r >= 0 && r <= jj + 1 && MU(s_m)) {
-          const double *d1 = D1.row(r), *d2 = D2.row(r), *d2p = D2.row(r + 1);
           const double q = .5 * (su_dww + su_dw);
-          const double deform = sqrt(.5 * (d1[l] + d1[l - 1] + d2[l] + d2p[l]));
-          VS2U.row(r)[l] = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
-          VS4U.row(r)[l] = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
+          const double deform = sqrt(.5 * (RG(c2, R_D1, 0) + RG(c2, R_D1, -1) + RG(c2, R_D2, 0) + RG(c1, R_D2, 0)));
+          RG(b2, R_VS2U, 0) = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
+          RG(b2, R_VS4U, 0) = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
         }
       }
       {
         const int r = s - 1;
         if (r >= 0 && r <= jj + 1 && MV(w_m)) {
-          const double *d1 = D1.row(r), *d1m = D1.row(r - 1), *d2 = D2.row(r);
           const double q = .5 * (sv_dws + sv_dw);
-          const double deform = sqrt(.5 * (d1[l] + d1m[l] + d2[l] + d2[l + 1]));
-          VS2V.row(r)[l] = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
-          VS4V.row(r)[l] = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
+          const double deform = sqrt(.5 * (RG(c1, R_D1, 0) + RG(c2, R_D1, 0) + RG(c1, R_D2, 0) + RG(c1, R_D2, 1)));
+          RG(a1, R_VS2V, 0) = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
+          RG(a1, R_VS4V, 0) = fmax2(q * mdv4hi + (1. - q) * mdv4lo, (q * vsc4hi + (1. - q) * vsc4lo) * deform);
         }
       }
     }
@@ -286,27 +304,22 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       const int r = s - 3;
       if (act && r >= 0 && r <= jj && i >= 0 && i <= ii && MP(f_m)) {
         if (r >= 1 && MU(f_m) + MU(f_me) > 0) {
-          const double *ut0 = UTN.row(r), *dl2 = DL2U.row(r);
-          const double *v2r = VS2U.row(r), *v4r = VS4U.row(r);
           const double dpxy = fmax2(dpu_c, ONEMM), dpib = fmax2(dpu_e, ONEMM);
           // viscosity extended one point beyond wet u-segments (:845-856), cf. ext_i
           const int m0 = MU(f_m), m1 = MU(f_me), m2 = MU(f_me2);
-          const double v2 = (m0 ? v2r[l] : (m1 ? v2r[l + 1] : v2r[l - 1])) + (m1 ? v2r[l + 1] : (m2 ? v2r[l + 2] : v2r[l]));
-          const double v4 = (m0 ? v4r[l] : (m1 ? v4r[l + 1] : v4r[l - 1])) + (m1 ? v4r[l + 1] : (m2 ? v4r[l + 2] : v4r[l]));
-          UFL1.row(r)[l] = fmin2(v_difmxp, v2 * v_scpy) * hfharm(dpxy, dpib) * (ut0[l] - ut0[l + 1]) +
-                           fmin2(.125 * v_difmxp, v4 * v_scpy) * hfharm(dpxy, dpib) * (dl2[l] - dl2[l + 1]);
+          const double v2 = (m0 ? RG(b3, R_VS2U, 0) : (m1 ? RG(b3, R_VS2U, 1) : RG(b3, R_VS2U, -1))) + (m1 ? RG(b3, R_VS2U, 1) : (m2 ? RG(b3, R_VS2U, 2) : RG(b3, R_VS2U, 0)));
+          const double v4 = (m0 ? RG(b3, R_VS4U, 0) : (m1 ? RG(b3, R_VS4U, 1) : RG(b3, R_VS4U, -1))) + (m1 ? RG(b3, R_VS4U, 1) : (m2 ? RG(b3, R_VS4U, 2) : RG(b3, R_VS4U, 0)));
+          ufl1[0] = fmin2(v_difmxp, v2 * v_scpy) * hfharm(dpxy, dpib) * (RG(a3, R_UTN, 0) - RG(a3, R_UTN, 1)) +
+                    fmin2(.125 * v_difmxp, v4 * v_scpy) * hfharm(dpxy, dpib) * (RG(a3, R_DL2U, 0) - RG(a3, R_DL2U, 1));
         }
         if (i >= 1 && MV(f_m) + MV(f_mn) > 0) {
-          const double *vt0 = VTN.row(r), *vtp = VTN.row(r + 1);
-          const double *dl2 = DL2V.row(r), *dl2p = DL2V.row(r + 1);
           const double dpxy = fmax2(dpv_c, ONEMM), dpjb = fmax2(dpv_n, ONEMM);
           const int m0 = MV(f_m), m1 = MV(f_mn), m2 = MV(f_mn2);
-          const double *a2m = VS2V.row(r - 1), *a20 = VS2V.row(r), *a2p = VS2V.row(r + 1), *a2q = VS2V.row(r + 2);
-          const double *a4m = VS4V.row(r - 1), *a40 = VS4V.row(r), *a4p = VS4V.row(r + 1), *a4q = VS4V.row(r + 2);
-          const double v2 = (m0 ? a20[l] : (m1 ? a2p[l] : a2m[l])) + (m1 ? a2p[l] : (m2 ? a2q[l] : a20[l]));
-          const double v4 = (m0 ? a40[l] : (m1 ? a4p[l] : a4m[l])) + (m1 ? a4p[l] : (m2 ? a4q[l] : a40[l]));
-          vfl3 = fmin2(v_difmxp, v2 * v_scpx) * hfharm(dpxy, dpjb) * (vt0[l] - vtp[l]) +
-                           fmin2(.125 * v_difmxp, v4 * v_scpx) * hfharm(dpxy, dpjb) * (dl2[l] - dl2p[l]);
+          // rows r-1 (slot of row s), r, r+1, r+2
+          const double v2 = (m0 ? RG(a3, R_VS2V, 0) : (m1 ? RG(a2, R_VS2V, 0) : RG(a0, R_VS2V, 0))) + (m1 ? RG(a2, R_VS2V, 0) : (m2 ? RG(a1, R_VS2V, 0) : RG(a3, R_VS2V, 0)));
+          const double v4 = (m0 ? RG(a3, R_VS4V, 0) : (m1 ? RG(a2, R_VS4V, 0) : RG(a0, R_VS4V, 0))) + (m1 ? RG(a2, R_VS4V, 0) : (m2 ? RG(a1, R_VS4V, 0) : RG(a3, R_VS4V, 0)));
+          vfl3 = fmin2(v_difmxp, v2 * v_scpx) * hfharm(dpxy, dpjb) * (RG(a3, R_VTN, 0) - RG(a2, R_VTN, 0)) +
+                 fmin2(.125 * v_difmxp, v4 * v_scpx) * hfharm(dpxy, dpjb) * (RG(b3, R_DL2V, 0) - RG(b2, R_DL2V, 0));
         }
       }
     }
@@ -314,7 +327,6 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     // ---- U: lateral turbulent momentum fluxes and the flux divergence term, row s-3 (:879-913, :1040-1076) -----
     {
       const int r = s - 3;
-      const size_t c = (size_t)x + (size_t)ni * (r + NBDY - 1);
       if (act && own && r >= ja && r <= jb && i >= 1 && i <= ii) {
         if (MU(f_m)) {
           const double wja = wja3, wjb = wjb3;
@@ -323,18 +335,18 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
           dpja = dpja + wja * (dpxy - dpja);
           double dpjb = fmax2(dpu_n, ONEMM);
           dpjb = dpjb + wjb * (dpxy - dpjb);
-          const double v2c = VS2U.row(r)[l], v4c = VS4U.row(r)[l];
-          const double vsc2a = MU(f_ms) == 0 ? v2c : VS2U.row(r - 1)[l], vsc4a = MU(f_ms) == 0 ? v4c : VS4U.row(r - 1)[l];
-          const double vsc2b = MU(f_mn) == 0 ? v2c : VS2U.row(r + 1)[l], vsc4b = MU(f_mn) == 0 ? v4c : VS4U.row(r + 1)[l];
-          const double un = UTN.row(r)[l], d2 = DL2U.row(r)[l];
-          const double dl2uja = (1. - wja) * DL2U.row(r - 1)[l] + wja * SLIP * d2;          // :594-597
-          const double dl2ujb = (1. - wjb) * DL2U.row(r + 1)[l] + wjb * SLIP * d2;
+          const double v2c = RG(b3, R_VS2U, 0), v4c = RG(b3, R_VS4U, 0);
+          // rows r-1 (the slot of row s-1), r+1
+          const double vsc2a = MU(f_ms) == 0 ? v2c : RG(b1, R_VS2U, 0), vsc4a = MU(f_ms) == 0 ? v4c : RG(b1, R_VS4U, 0);
+          const double vsc2b = MU(f_mn) == 0 ? v2c : RG(b2, R_VS2U, 0), vsc4b = MU(f_mn) == 0 ? v4c : RG(b2, R_VS4U, 0);
+          const double un = RG(a3, R_UTN, 0), d2 = RG(a3, R_DL2U, 0);
+          const double dl2uja = (1. - wja) * RG(a0, R_DL2U, 0) + wja * SLIP * d2;          // :594-597
+          const double dl2ujb = (1. - wjb) * RG(a2, R_DL2U, 0) + wjb * SLIP * d2;
           const double uflux2 = fmin2(dmq_c, (v2c + vsc2a) * scqx_c) * hfharm(dpja, dpxy) * (uja3 - un) +
                                 fmin2(.125 * dmq_c, (v4c + vsc4a) * scqx_c) * hfharm(dpja, dpxy) * (dl2uja - d2);
           const double uflux3 = fmin2(dmq_n, (v2c + vsc2b) * scqx_n) * hfharm(dpjb, dpxy) * (un - ujb3) +
                                 fmin2(.125 * dmq_n, (v4c + vsc4b) * scqx_n) * hfharm(dpjb, dpxy) * (d2 - dl2ujb);
-          const double *uflux1 = UFL1.row(r);
-          o_visu[c] = (uflux1[l] - uflux1[l - 1] + uflux3 - uflux2) / (scu2_c * fmax2(dpu_c, ONEMM));
+          sto(o_visu, of, (ufl1[0] - ufl1[-1] + uflux3 - uflux2) / (scu2_c * fmax2(dpu_c, ONEMM)));
         }
         if (MV(f_m)) {
           const double wia = wia3, wib = wib3;
@@ -343,24 +355,26 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
           dpia = dpia + wia * (dpxy - dpia);
           double dpib = fmax2(dpv_e, ONEMM);
           dpib = dpib + wib * (dpxy - dpib);
-          const double *vsc2 = VS2V.row(r), *vsc4 = VS4V.row(r), *dl2v = DL2V.row(r);
-          const double vsc2a = MV(f_mw) == 0 ? vsc2[l] : vsc2[l - 1], vsc4a = MV(f_mw) == 0 ? vsc4[l] : vsc4[l - 1];
-          const double vsc2b = MV(f_me) == 0 ? vsc2[l] : vsc2[l + 1], vsc4b = MV(f_me) == 0 ? vsc4[l] : vsc4[l + 1];
-          const double vn = VTN.row(r)[l], d2 = dl2v[l];
-          const double dl2via = (1. - wia) * dl2v[l - 1] + wia * SLIP * d2;          // :602-605
-          const double dl2vib = (1. - wib) * dl2v[l + 1] + wib * SLIP * d2;
-          const double vflux2 = fmin2(dmq_c, (vsc2[l] + vsc2a) * scqy_c) * hfharm(dpia, dpxy) * (via3 - vn) +
-                                fmin2(.125 * dmq_c, (vsc4[l] + vsc4a) * scqy_c) * hfharm(dpia, dpxy) * (dl2via - d2);
-          const double vflux3 = fmin2(dmq_e, (vsc2[l] + vsc2b) * scqy_e) * hfharm(dpib, dpxy) * (vn - VIB.row(r)[l]) +
-                                fmin2(.125 * dmq_e, (vsc4[l] + vsc4b) * scqy_e) * hfharm(dpib, dpxy) * (d2 - dl2vib);
-          o_visv[c] = (vfl3 - vfl4 + vflux3 - vflux2) / (scv2_c * fmax2(dpv_c, ONEMM));
+          const double vs2 = RG(a3, R_VS2V, 0), vs4 = RG(a3, R_VS4V, 0);
+          const double vsc2a = MV(f_mw) == 0 ? vs2 : RG(a3, R_VS2V, -1), vsc4a = MV(f_mw) == 0 ? vs4 : RG(a3, R_VS4V, -1);
+          const double vsc2b = MV(f_me) == 0 ? vs2 : RG(a3, R_VS2V, 1), vsc4b = MV(f_me) == 0 ? vs4 : RG(a3, R_VS4V, 1);
+          const double vn = RG(a3, R_VTN, 0), d2 = RG(b3, R_DL2V, 0);
+          const double dl2via = (1. - wia) * RG(b3, R_DL2V, -1) + wia * SLIP * d2;          // :602-605
+          const double dl2vib = (1. - wib) * RG(b3, R_DL2V, 1) + wib * SLIP * d2;
+          const double vflux2 = fmin2(dmq_c, (vs2 + vsc2a) * scqy_c) * hfharm(dpia, dpxy) * (via3 - vn) +
+                                fmin2(.125 * dmq_c, (vs4 + vsc4a) * scqy_c) * hfharm(dpia, dpxy) * (dl2via - d2);
+          const double vflux3 = fmin2(dmq_e, (vs2 + vsc2b) * scqy_e) * hfharm(dpib, dpxy) * (vn - RG(b3, R_VIB, 0)) +
+                                fmin2(.125 * dmq_e, (vs4 + vsc4b) * scqy_e) * hfharm(dpib, dpxy) * (d2 - dl2vib);
+          sto(o_visv, of, (vfl3 - vfl4 + vflux3 - vflux2) / (scv2_c * fmax2(dpv_c, ONEMM)));
         }
       }
     }
     __syncthreads();
     wja3 = wja2; wja2 = wja1; wjb3 = wjb2; wjb2 = wjb1; uja3 = uja2; uja2 = uja1; ujb3 = ujb2; ujb2 = ujb1;
     wia3 = wia2; wia2 = wia1; wib3 = wib2; wib2 = wib1; via3 = via2; via2 = via1; vfl4 = vfl3;
+    mk4 = mk3; mk3 = mk2; mk2 = mk1; mk1 = tc.mk;
     tc = tn;
+    q3 = q3 == 2 ? 0 : q3 + 1;
   }
 }
 
@@ -392,35 +406,33 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
   const bool last_chunk = jb == jj;
   const gci_t mpk = (gci_t)V.m[I_mpack];
   const int xl = x < 2 ? 2 : (x > ni - 3 ? ni - 3 : x);
-  auto cidx = [&](int r) {
+  const unsigned x8 = (unsigned)xl * 8u, ni8 = (unsigned)ni * 8u;
+  auto roff = [&](int r) {           // byte offset of (xl, row r clamped into the array) in a plane of doubles
     const int rc = r < -2 ? -2 : (r > jj + 3 ? jj + 3 : r);
-    return (size_t)xl + (size_t)ni * (rc + NBDY - 1);
+    return x8 + ni8 * (unsigned)(rc + NBDY - 1);
   };
 
-  double *lp = lds;
+  // rings (layout as in k_mom_visc_march): depth 4: UFX (+ UHMN, UHMX), depth 3: UTM, VTM, VFX, DPMX, KE (+ VHMN, VHMX), depth 2: PV
   constexpr int NP = BS + 4;
-  auto take = [&](int d) { double *b = lp; lp += d * NP; return b; };
-  const Ring<3> UTM{take(3), NP}, VTM{take(3), NP};
-  const Ring<4> UFX{take(4), NP};
-  const Ring<3> VFX{take(3), NP}, DPMX{take(3), NP};
-  const Ring<2> PV{take(2), NP};
-  const Ring<3> KE{take(3), NP};
-  const Ring<4> UHMN{take(ENEDIS ? 4 : 0), NP}, UHMX{take(ENEDIS ? 4 : 0), NP};
-  const Ring<3> VHMN{take(ENEDIS ? 3 : 0), NP}, VHMX{take(ENEDIS ? 3 : 0), NP};
+  enum { R_UFX, R_UHMN, R_UHMX };
+  enum { R_UTM, R_VTM, R_VFX, R_DPMX, R_KE, R_VHMN, R_VHMX };
+  constexpr int N4 = ENEDIS ? 3 : 1, N3 = ENEDIS ? 7 : 5;
+  double *const l4 = lds + 2 + l;
+  double *const l3 = l4 + 4 * N4 * NP, *const l2 = l3 + 3 * N3 * NP;
 
-  const gcd_t dp = GF(V, F_dp) + okm, f_um = GF(V, F_u) + okm, f_vm = GF(V, F_v) + okm, f_un = GF(V, F_u) + okn, f_vn = GF(V, F_v) + okn;
-  const gcd_t f_ubfm = GF(V, F_ubflxs_p) + om, f_vbfm = GF(V, F_vbflxs_p) + om, f_pbum = GF(V, F_pbu) + om, f_pbvm = GF(V, F_pbv) + om;
-  const gcd_t f_ubfn = GF(V, F_ubflxs_p) + on, f_vbfn = GF(V, F_vbflxs_p) + on, f_pbun = GF(V, F_pbu) + on, f_pbvn = GF(V, F_pbv) + on;
+  // 3-D fields read at both time levels (u, v, pgfx, pgfy) and the 2-D ones with two time levels (ubflxs_p, vbflxs_p, pbu,
+  // pbv): ONE base pointer each, at the lower of the two levels, the level going into the lane's byte offset
+  const size_t olo = okm < okn ? okm : okn, o2lo = om < on ? om : on;
+  const unsigned dkm = (unsigned)((okm - olo) * 8), dkn = (unsigned)((okn - olo) * 8), d2m = (unsigned)((om - o2lo) * 8), d2n = (unsigned)((on - o2lo) * 8);
+  const unsigned np8 = (unsigned)np * 8u;
+  const gcd_t dp = GF(V, F_dp) + okm, f_u = GF(V, F_u) + olo, f_v = GF(V, F_v) + olo;
+  const gcd_t f_ubf = GF(V, F_ubflxs_p) + o2lo, f_vbf = GF(V, F_vbflxs_p) + o2lo, f_pbu = GF(V, F_pbu) + o2lo, f_pbv = GF(V, F_pbv) + o2lo;
   const gcd_t f_dpu = GF(V, F_dpu) + okm, f_dpv = GF(V, F_dpv) + okm;
-  const gcd_t scuy = GF(V, F_scuy), scvx = GF(V, F_scvx), scvy = GF(V, F_scvy), scux = GF(V, F_scux), scq2i = GF(V, F_scq2i);
-  const gcd_t scu2 = GF(V, F_scu2), scv2 = GF(V, F_scv2), scp2 = GF(V, F_scp2), corioq = GF(V, F_corioq);
-  const gcd_t drag = (gcd_t)WK2(V, S2_DRAG), p0 = GF(V, F_p) + ok, p1 = GF(V, F_p) + (size_t)(k + 1) * np, p_1 = GF(V, F_p) + np;
-  const gcd_t pgfx_m = GF(V, F_pgfx) + okm, pgfx_n = GF(V, F_pgfx) + okn, pgfx_o = GF(V, F_pgfx_o) + ok;
-  const gcd_t pgfy_m = GF(V, F_pgfy) + okm, pgfy_n = GF(V, F_pgfy) + okn, pgfy_o = GF(V, F_pgfy_o) + ok;
-  const gcd_t dpuold = GF(V, F_dpuold) + ok, dpvold = GF(V, F_dpvold) + ok, ubcors = GF(V, F_ubcors_p), vbcors = GF(V, F_vbcors_p);
-  const gcd_t scuxi = GF(V, F_scuxi), scvyi = GF(V, F_scvyi), taux = GF(V, F_taux), tauy = GF(V, F_tauy);
+  const gcd_t p0 = GF(V, F_p) + ok;                 // p1: one plane further on
+  const gcd_t pgfx = GF(V, F_pgfx) + olo, pgfx_o = GF(V, F_pgfx_o) + ok;
+  const gcd_t pgfy = GF(V, F_pgfy) + olo, pgfy_o = GF(V, F_pgfy_o) + ok;
+  const gcd_t dpuold = GF(V, F_dpuold) + ok, dpvold = GF(V, F_dpvold) + ok;
   const bool hybrid = V.P.vcoord_tag != 1;
-  const gcd_t mu_nl = GF(V, F_mu_nonloc), mv_nl = GF(V, F_mv_nonloc);
   const gcd_t visu = (gcd_t)WK(V, MF_VISU) + ok, visv = (gcd_t)WK(V, MF_VISV) + ok;
   const gd_t o_um = (gd_t)WK(V, MF_UM) + ok, o_un = (gd_t)WK(V, MF_UN) + ok, o_vm = (gd_t)WK(V, MF_VM) + ok, o_vn = (gd_t)WK(V, MF_VN) + ok;
   const gd_t o_absvor = (gd_t)V.f[F_absvor] + ok, o_dpvor = (gd_t)V.f[F_dpvor] + ok;
@@ -431,40 +443,54 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
   // steps later and with ~2000 waves streaming through the same L2, mostly missed it.
   struct TIn { int mk, mkw; double dc, dw, u, ub, pbu, sy, dpu, v, vb, pbv, sx, dpv; };
   auto load_t = [&](int r) {
-    const size_t c = cidx(r);
+    const unsigned o = roff(r), o3 = o + dkm, o2 = o + d2m;
+    const gcd_t scuy = GFV(F_scuy), scvx = GFV(F_scvx);
     TIn t;
-    t.mk = mpk[c]; t.mkw = mpk[c - 1];
-    t.dc = dp[c]; t.dw = dp[c - 1];
-    t.u = f_um[c]; t.ub = f_ubfm[c]; t.pbu = f_pbum[c]; t.sy = scuy[c]; t.dpu = f_dpu[c];
-    t.v = f_vm[c]; t.vb = f_vbfm[c]; t.pbv = f_pbvm[c]; t.sx = scvx[c]; t.dpv = f_dpv[c];
+    t.mk = ldoi(mpk, o >> 1); t.mkw = ldoi<-4>(mpk, o >> 1);
+    t.dc = ldo(dp, o); t.dw = ldo<-8>(dp, o);
+    t.u = ldo(f_u, o3); t.ub = ldo(f_ubf, o2); t.pbu = ldo(f_pbu, o2); t.sy = ldo(scuy, o); t.dpu = ldo(f_dpu, o);
+    t.v = ldo(f_v, o3); t.vb = ldo(f_vbf, o2); t.pbv = ldo(f_pbv, o2); t.sx = ldo(scvx, o); t.dpv = ldo(f_dpv, o);
     return t;
   };
   TIn tpp = load_t(ja - 3), tp = load_t(ja - 2), tc = load_t(ja - 1);      // rows s-2, s-1, s
-  double pr_p0 = p0[cidx(ja - 4)], pr_p1 = p1[cidx(ja - 4)], pr_drag = drag[cidx(ja - 4)];   // row s-3
+  double pr_p0 = ldo(p0, roff(ja - 4)), pr_p1 = ldo(p0, roff(ja - 4) + np8), pr_drag = ldo((gcd_t)WK2(V, S2_DRAG), roff(ja - 4));   // row s-3
+  int q0 = (ja - 1 + 48) % 3;        // depth-3 slot of row s
 
   for (int s = ja - 1; s <= jb + 2; s++) {
     // ================= loads of this step =================
     const TIn tn = load_t(s + 1);
+    const gcd_t scvy = GFV(F_scvy), scux = GFV(F_scux), scq2i = GFV(F_scq2i), corioq = GFV(F_corioq);
+    const gcd_t scu2 = GFV(F_scu2), scv2 = GFV(F_scv2), scp2 = GFV(F_scp2);
+    const gcd_t ubcors = GFV(F_ubcors_p), vbcors = GFV(F_vbcors_p), scuxi = GFV(F_scuxi), scvyi = GFV(F_scvyi);
+    const gcd_t drag = (gcd_t)((const double *const volatile CONST_AS &)Vp->wk2d + (size_t)S2_DRAG * np);
+    gcd_t taux = nullptr, tauy = nullptr, munl = nullptr, mvnl = nullptr;      // the wind stress acts on the top layer (isopyc_bulkml) / on every layer
+    if (hybrid || k == 0) { taux = GFV(F_taux); tauy = GFV(F_tauy); }
+    if (hybrid) { munl = GFV(F_mu_nonloc) + ok; mvnl = GFV(F_mv_nonloc) + ok; }
     // V (row s-1): 2-D coefficients
-    const size_t cv = cidx(s - 1);
+    const unsigned ov = roff(s - 1);
     const int v_m = tp.mk, v_mw = tp.mkw, v_ms = tpp.mk;
-    const double v_scvy = scvy[cv], v_scvyw = scvy[cv - 1], v_scux = scux[cv], v_scuxs = scux[cv - ni], v_scq2i = scq2i[cv];
-    const double v_dc = tp.dc, v_dw = tp.dw, v_ds = tpp.dc, v_dsw = tpp.dw, v_cor = corioq[cv];
-    const double v_scu2 = scu2[cv], v_scu2e = scu2[cv + 1], v_scv2 = scv2[cv], v_scv2n = scv2[cv + ni], v_scp2 = scp2[cv];
+    const double v_scvy = ldo(scvy, ov), v_scvyw = ldo<-8>(scvy, ov), v_scux = ldo(scux, ov), v_scuxs = ldo(scux, ov - ni8), v_scq2i = ldo(scq2i, ov);
+    const double v_dc = tp.dc, v_dw = tp.dw, v_ds = tpp.dc, v_dsw = tpp.dw, v_cor = ldo(corioq, ov);
+    const double v_scu2 = ldo(scu2, ov), v_scu2e = ldo<8>(scu2, ov), v_scv2 = ldo(scv2, ov), v_scv2n = ldo(scv2, ov + ni8), v_scp2 = ldo(scp2, ov);
     // U (row s-2)
-    const size_t cu = cidx(s - 2);
+    const unsigned ou = roff(s - 2), ou3 = ou + dkn, ou3m = ou + dkm, ou2 = ou + d2n, oup1 = ou + np8;
     const int u_m = tpp.mk;
-    const double u_drag = drag[cu], u_dragw = drag[cu - 1], u_drags = pr_drag;
-    const double u_p0 = p0[cu], u_p0w = p0[cu - 1], u_p0s = pr_p0, u_p1 = p1[cu], u_p1w = p1[cu - 1], u_p1s = pr_p1;
-    const double u_dpu = tpp.dpu, u_pbum = tpp.pbu, u_ukm = tpp.u, u_ukn = f_un[cu], u_ubfn = f_ubfn[cu], u_pbun = f_pbun[cu];
-    const double u_scuy = tpp.sy, u_pgm = pgfx_m[cu], u_pgo = pgfx_o[cu], u_pgn = pgfx_n[cu], u_dpuold = dpuold[cu];
-    const double u_ubcors = ubcors[cu], u_scuxi = scuxi[cu], u_visu = visu[cu];
-    const double u_dpv = tpp.dpv, u_pbvm = tpp.pbv, u_vkm = tpp.v, u_vkn = f_vn[cu], u_vbfn = f_vbfn[cu], u_pbvn = f_pbvn[cu];
-    const double u_scvx = tpp.sx, u_pgym = pgfy_m[cu], u_pgyo = pgfy_o[cu], u_pgyn = pgfy_n[cu], u_dpvold = dpvold[cu];
-    const double u_vbcors = vbcors[cu], u_scvyi = scvyi[cu], u_visv = visv[cu];
+    const double u_drag = ldo(drag, ou), u_dragw = ldo<-8>(drag, ou), u_drags = pr_drag;
+    const double u_p0 = ldo(p0, ou), u_p0w = ldo<-8>(p0, ou), u_p0s = pr_p0, u_p1 = ldo(p0, oup1), u_p1w = ldo<-8>(p0, oup1), u_p1s = pr_p1;
+    const double u_dpu = tpp.dpu, u_pbum = tpp.pbu, u_ukm = tpp.u, u_ukn = ldo(f_u, ou3), u_ubfn = ldo(f_ubf, ou2), u_pbun = ldo(f_pbu, ou2);
+    const double u_scuy = tpp.sy, u_pgm = ldo(pgfx, ou3m), u_pgo = ldo(pgfx_o, ou), u_pgn = ldo(pgfx, ou3), u_dpuold = ldo(dpuold, ou);
+    const double u_ubcors = ldo(ubcors, ou), u_scuxi = ldo(scuxi, ou), u_visu = ldo(visu, ou);
+    const double u_dpv = tpp.dpv, u_pbvm = tpp.pbv, u_vkm = tpp.v, u_vkn = ldo(f_v, ou3), u_vbfn = ldo(f_vbf, ou2), u_pbvn = ldo(f_pbv, ou2);
+    const double u_scvx = tpp.sx, u_pgym = ldo(pgfy, ou3m), u_pgyo = ldo(pgfy_o, ou), u_pgyn = ldo(pgfy, ou3), u_dpvold = ldo(dpvold, ou);
+    const double u_vbcors = ldo(vbcors, ou), u_scvyi = ldo(scvyi, ou), u_visv = ldo(visv, ou);
     // the first sweep's neighbours to the south come from the row loaded a step earlier
     const int t_mks = tp.mk;
     const double t_ds = tp.dc, t_dsw = tp.dw;
+    // lane pointers into the ring slots of this step's rows
+    double *const a0 = l4 + (s & 3) * (N4 * NP), *const a2 = l4 + ((s - 2) & 3) * (N4 * NP), *const a3 = l4 + ((s - 3) & 3) * (N4 * NP);   // rows s, s-2, s-3
+    const int q1 = q0 == 0 ? 2 : q0 - 1, q2 = q1 == 0 ? 2 : q1 - 1;
+    double *const b0 = l3 + q0 * (N3 * NP), *const b1 = l3 + q1 * (N3 * NP), *const b2 = l3 + q2 * (N3 * NP);   // rows s (and s-3), s-1, s-2
+    double *const c1 = l2 + ((s - 1) & 1) * NP, *const c2 = l2 + ((s - 2) & 1) * NP;                           // PV of rows s-1, s-2
 
     // ---- T: total velocities at the mid time level, fluxes, dpmx, row s (:360-406; rows 0..jj+1 / dpmx 0..jj+2) ----
     if (act && s >= 0 && s <= jj + 2 && i >= 0 && i <= ii + 2) {
@@ -473,7 +499,7 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
       if (MU(t_mks)) d = fmax2(d, t_ds + t_dsw);
       if (MV(tc.mk)) d = fmax2(d, tc.dc + t_ds);
       if (MV(tc.mkw)) d = fmax2(d, tc.dw + t_dsw);
-      DPMX.row(s)[l] = d;
+      RG(b0, R_DPMX, 0) = d;
       if (s <= jj + 1 && i <= ii + 1) {
         double ut = 0., uf = 0., vt = 0., vf = 0.;
         if (MU(tc.mk)) {
@@ -484,17 +510,17 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
           vt = tc.v + tc.vb * tsfac / (tc.pbv * tc.sx);
           vf = vt * fmax2(tc.dpv, cutoff);
         }
-        UTM.row(s)[l] = ut;
-        UFX.row(s)[l] = uf;
-        VTM.row(s)[l] = vt;
-        VFX.row(s)[l] = vf;
+        RG(b0, R_UTM, 0) = ut;
+        RG(a0, R_UFX, 0) = uf;
+        RG(b0, R_VTM, 0) = vt;
+        RG(b0, R_VFX, 0) = vf;
         if (ENEDIS) {                                    // :662-715, rows 0..jj+1
           double a = 0., b = 0.;
           if (MU(tc.mk)) enedis_minmax(.5 * ut * (tc.dc + tc.dw), uf, a, b);
-          UHMN.row(s)[l] = a; UHMX.row(s)[l] = b;
+          RG(a0, R_UHMN, 0) = a; RG(a0, R_UHMX, 0) = b;
           a = 0.; b = 0.;
           if (MV(tc.mk)) enedis_minmax(.5 * vt * (tc.dc + t_ds), vf, a, b);
-          VHMN.row(s)[l] = a; VHMX.row(s)[l] = b;
+          RG(b0, R_VHMN, 0) = a; RG(b0, R_VHMX, 0) = b;
         }
       }
     }
@@ -502,86 +528,81 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
     // ---- V: vorticity / potential vorticity at q-points (:477-575) and kinetic energy (:613-629), row s-1 -------
     {
       const int r = s - 1;
-      const size_t c = (size_t)x + (size_t)ni * (r + NBDY - 1);
       if (act && r >= 1 && r <= jj + 1 && i >= 1 && i <= ii + 1) {
-        const double *utm0 = UTM.row(r), *utmm = UTM.row(r - 1), *vtm0 = VTM.row(r);
-        const double *dx0 = DPMX.row(r), *dxm = DPMX.row(r - 1), *dxp = DPMX.row(r + 1);
+        // UTM rows r, r-1: b1, b2; VTM row r: b1; DPMX rows r, r-1, r+1: b1, b2, b0
         bool have = false;
         double vort = 0., dpv = 1.;
         if (MV(v_m) && !MV(v_mw)) {                      // first point of a v-segment, :479-486
-          vort = vtm0[l] * (1. - SLIP) * v_scvy * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_ds), dx0[l]), dx0[l + 1]);
+          vort = RG(b1, R_VTM, 0) * (1. - SLIP) * v_scvy * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_ds), RG(b1, R_DPMX, 0)), RG(b1, R_DPMX, 1));
           have = true;
         } else if (MV(v_mw) && !MV(v_m)) {               // one past the last point of a v-segment, :487-494
-          vort = -vtm0[l - 1] * (1. - SLIP) * v_scvyw * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_dw + v_dsw), dx0[l - 1]), dx0[l]);
+          vort = -RG(b1, R_VTM, -1) * (1. - SLIP) * v_scvyw * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_dw + v_dsw), RG(b1, R_DPMX, -1)), RG(b1, R_DPMX, 0));
           have = true;
         }
         if (MU(v_m) && !MU(v_ms)) {                      // first point (in j) of a u-segment, :513-520
-          vort = -utm0[l] * (1. - SLIP) * v_scux * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_dw), dx0[l]), dxp[l]);
+          vort = -RG(b1, R_UTM, 0) * (1. - SLIP) * v_scux * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_dc + v_dw), RG(b1, R_DPMX, 0)), RG(b0, R_DPMX, 0));
           have = true;
         } else if (MU(v_ms) && !MU(v_m)) {               // one past the last point, :521-528
-          vort = utmm[l] * (1. - SLIP) * v_scuxs * v_scq2i;
-          dpv = .125 * fmax2(fmax2(4. * (v_ds + v_dsw), dxm[l]), dx0[l]);
+          vort = RG(b2, R_UTM, 0) * (1. - SLIP) * v_scuxs * v_scq2i;
+          dpv = .125 * fmax2(fmax2(4. * (v_ds + v_dsw), RG(b2, R_DPMX, 0)), RG(b1, R_DPMX, 0));
           have = true;
         }
         if (MQ(v_m)) {                                   // interior (incl. promontories), :561-575
-          vort = (vtm0[l] * v_scvy - vtm0[l - 1] * v_scvyw - utm0[l] * v_scux + utmm[l] * v_scuxs) * v_scq2i;
-          double d = fmax2(2. * (v_dc + v_dw + v_ds + v_dsw), dx0[l]);
-          d = fmax2(d, dx0[l - 1]);
-          d = fmax2(d, dx0[l + 1]);
-          d = fmax2(d, dxm[l]);
-          d = fmax2(d, dxp[l]);
+          vort = (RG(b1, R_VTM, 0) * v_scvy - RG(b1, R_VTM, -1) * v_scvyw - RG(b1, R_UTM, 0) * v_scux + RG(b2, R_UTM, 0) * v_scuxs) * v_scq2i;
+          double d = fmax2(2. * (v_dc + v_dw + v_ds + v_dsw), RG(b1, R_DPMX, 0));
+          d = fmax2(d, RG(b1, R_DPMX, -1));
+          d = fmax2(d, RG(b1, R_DPMX, 1));
+          d = fmax2(d, RG(b2, R_DPMX, 0));
+          d = fmax2(d, RG(b0, R_DPMX, 0));
           dpv = .125 * d;
           have = true;
         }
         if (have) {
           const double av = vort + v_cor;
           if ((own || (x == ii + NBDY && ox1 == ii + NBDY - 1)) && ((r >= ja && r <= jb) || (last_chunk && r == jj + 1))) {
-            o_absvor[c] = av;
-            o_dpvor[c] = dpv;
+            sto(o_absvor, ov, av);
+            sto(o_dpvor, ov, dpv);
           }
-          PV.row(r)[l] = av / dpv;
+          c1[0] = av / dpv;
         }
       }
       if (act && r >= 0 && r <= jj && i >= 0 && i <= ii && MP(v_m)) {
-        const double *utm0 = UTM.row(r), *vtm0 = VTM.row(r), *vtmp = VTM.row(r + 1);
-        const double ue = utm0[l + 1], uw = utm0[l], vn = vtmp[l], vs = vtm0[l];
-        KE.row(r)[l] = .25 * (v_scu2 * (uw * uw) + v_scu2e * (ue * ue) + v_scv2 * (vs * vs) + v_scv2n * (vn * vn)) / v_scp2;
+        const double ue = RG(b1, R_UTM, 1), uw = RG(b1, R_UTM, 0), vn = RG(b0, R_VTM, 0), vs = RG(b1, R_VTM, 0);
+        RG(b1, R_KE, 0) = .25 * (v_scu2 * (uw * uw) + v_scu2e * (ue * ue) + v_scv2 * (vs * vs) + v_scv2n * (vn * vn)) / v_scp2;
       }
     }
     __syncthreads();
     // ---- U: Coriolis/advection, stresses, pressure gradient, update of both time levels, row s-2 ----------------
     {
       const int r = s - 2;
-      const size_t c = (size_t)x + (size_t)ni * (r + NBDY - 1);
       if (act && own && r >= ja && r <= jb && i >= 1 && i <= ii) {
-        const double *pv0 = PV.row(r), *pvp = PV.row(r + 1), *ke0 = KE.row(r), *kem = KE.row(r - 1);
+        // PV rows r, r+1: c2, c1; KE rows r, r-1: b2, b0 (the slot of row s holds row s-3)
         if (MU(u_m)) {
-          const double *vf0 = VFX.row(r), *vfp = VFX.row(r + 1);
+          // VFX rows r, r+1: b2, b1
           double cau;
           if (ENEDIS) {                                                            // enedis, :771-790
-            const double *mx0 = VHMX.row(r), *mxp = VHMX.row(r + 1), *mn0 = VHMN.row(r), *mnp = VHMN.row(r + 1);
-            const double utm = UTM.row(r)[l];
+            const double utm = RG(b2, R_UTM, 0);
             double t1, t2;
-            const double pn = pvp[l], pc = pv0[l];
-            if (pn * utm == 0.) t1 = pn * ((mxp[l] + mxp[l - 1]) + (mnp[l] + mnp[l - 1])) * .5;
-            else if (pn * utm < 0.) t1 = pn * (mxp[l] + mxp[l - 1]);
-            else t1 = pn * (mnp[l] + mnp[l - 1]);
-            if (pc * utm == 0.) t2 = pc * ((mx0[l] + mx0[l - 1]) + (mn0[l] + mn0[l - 1])) * .5;
-            else if (pc * utm < 0.) t2 = pc * (mx0[l] + mx0[l - 1]);
-            else t2 = pc * (mn0[l] + mn0[l - 1]);
+            const double pn = c1[0], pc = c2[0];
+            if (pn * utm == 0.) t1 = pn * ((RG(b1, R_VHMX, 0) + RG(b1, R_VHMX, -1)) + (RG(b1, R_VHMN, 0) + RG(b1, R_VHMN, -1))) * .5;
+            else if (pn * utm < 0.) t1 = pn * (RG(b1, R_VHMX, 0) + RG(b1, R_VHMX, -1));
+            else t1 = pn * (RG(b1, R_VHMN, 0) + RG(b1, R_VHMN, -1));
+            if (pc * utm == 0.) t2 = pc * ((RG(b2, R_VHMX, 0) + RG(b2, R_VHMX, -1)) + (RG(b2, R_VHMN, 0) + RG(b2, R_VHMN, -1))) * .5;
+            else if (pc * utm < 0.) t2 = pc * (RG(b2, R_VHMX, 0) + RG(b2, R_VHMX, -1));
+            else t2 = pc * (RG(b2, R_VHMN, 0) + RG(b2, R_VHMN, -1));
             cau = .25 * (t1 + t2);
           } else if (mommth == 0)
-            cau = .125 * (vf0[l] + vfp[l] + vf0[l - 1] + vfp[l - 1]) * (pv0[l] + pvp[l]);
+            cau = .125 * (RG(b2, R_VFX, 0) + RG(b1, R_VFX, 0) + RG(b2, R_VFX, -1) + RG(b1, R_VFX, -1)) * (c2[0] + c1[0]);
           else
-            cau = .25 * ((vf0[l] + vf0[l - 1]) * pv0[l] + (vfp[l] + vfp[l - 1]) * pvp[l]);
+            cau = .25 * ((RG(b2, R_VFX, 0) + RG(b2, R_VFX, -1)) * c2[0] + (RG(b1, R_VFX, 0) + RG(b1, R_VFX, -1)) * c1[0]);
           // wind stress (isopyc_bulkml: top layer only), :919-936
           double stress = 0.;
           if (hybrid)                    // the other vertical coordinates: the stress spread by the non-local fractions, :937-946
-            stress = -(mu_nl[c + (size_t)k * np] - mu_nl[c + (size_t)(k + 1) * np]) * taux[c] * GRAV * scux[c] / fmax2(ONEMM, u_dpu);
-          else if (k == 0) stress = -2. * taux[c] * GRAV * scux[c] / (p_1[c] + p_1[c - 1]);
+            stress = -(ldo(munl, ou) - ldo(munl, oup1)) * ldo(taux, ou) * GRAV * ldo(scux, ou) / fmax2(ONEMM, u_dpu);
+          else if (k == 0) stress = -2. * ldo(taux, ou) * GRAV * ldo(scux, ou) / (ldo(p0, oup1) + ldo<-8>(p0, oup1));
           const double pbu = u_pbum;
           const double ptopl = .5 * (fmin2(pbu, u_p0) + fmin2(pbu, u_p0w));
           const double pbotl = .5 * (fmin2(pbu, u_p1) + fmin2(pbu, u_p1w));
@@ -591,33 +612,32 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
           const double un = ukn + u_ubfn * tsfac / (u_pbun * u_scuy);               // utotn, :408-414
           const double botstr = -un * q / (1. + delt1 * q);
           const double pgf = (1. - 2. * WPGF) * u_pgm + WPGF * (u_pgo + u_pgn);
-          o_um[c] = ukm * (wuv1 * u_dpu + ONEMM) + ukn * wuv2 * u_dpuold;
+          sto(o_um, ou, ukm * (wuv1 * u_dpu + ONEMM) + ukn * wuv2 * u_dpuold);
           const double ubrhs = u_ubcors * tsfac;                                    // :302
-          o_un[c] = ukn + delt1 * (-u_scuxi * (-pgf + stress + (ke0[l] - ke0[l - 1])) + cau - ubrhs + botstr - u_visu);
+          sto(o_un, ou, ukn + delt1 * (-u_scuxi * (-pgf + stress + (RG(b2, R_KE, 0) - RG(b2, R_KE, -1))) + cau - ubrhs + botstr - u_visu));
         }
         if (MV(u_m)) {
-          const double *uf0 = UFX.row(r), *ufm = UFX.row(r - 1);
+          // UFX rows r, r-1: a2, a3
           double cav;
           if (ENEDIS) {                                                            // enedis, :793-812
-            const double *mx0 = UHMX.row(r), *mxm = UHMX.row(r - 1), *mn0 = UHMN.row(r), *mnm = UHMN.row(r - 1);
-            const double vtm = VTM.row(r)[l];
+            const double vtm = RG(b2, R_VTM, 0);
             double t1, t2;
-            const double pe = pv0[l + 1], pc = pv0[l];
-            if (pe * vtm == 0.) t1 = pe * ((mx0[l + 1] + mxm[l + 1]) + (mn0[l + 1] + mnm[l + 1])) * .5;
-            else if (pe * vtm > 0.) t1 = pe * (mx0[l + 1] + mxm[l + 1]);
-            else t1 = pe * (mn0[l + 1] + mnm[l + 1]);
-            if (pc * vtm == 0.) t2 = pc * ((mx0[l] + mxm[l]) + (mn0[l] + mnm[l])) * .5;
-            else if (pc * vtm > 0.) t2 = pc * (mx0[l] + mxm[l]);
-            else t2 = pc * (mn0[l] + mnm[l]);
+            const double pe = c2[1], pc = c2[0];
+            if (pe * vtm == 0.) t1 = pe * ((RG(a2, R_UHMX, 1) + RG(a3, R_UHMX, 1)) + (RG(a2, R_UHMN, 1) + RG(a3, R_UHMN, 1))) * .5;
+            else if (pe * vtm > 0.) t1 = pe * (RG(a2, R_UHMX, 1) + RG(a3, R_UHMX, 1));
+            else t1 = pe * (RG(a2, R_UHMN, 1) + RG(a3, R_UHMN, 1));
+            if (pc * vtm == 0.) t2 = pc * ((RG(a2, R_UHMX, 0) + RG(a3, R_UHMX, 0)) + (RG(a2, R_UHMN, 0) + RG(a3, R_UHMN, 0))) * .5;
+            else if (pc * vtm > 0.) t2 = pc * (RG(a2, R_UHMX, 0) + RG(a3, R_UHMX, 0));
+            else t2 = pc * (RG(a2, R_UHMN, 0) + RG(a3, R_UHMN, 0));
             cav = -.25 * (t1 + t2);
           } else if (mommth == 0)
-            cav = -.125 * (uf0[l] + uf0[l + 1] + ufm[l] + ufm[l + 1]) * (pv0[l] + pv0[l + 1]);
+            cav = -.125 * (RG(a2, R_UFX, 0) + RG(a2, R_UFX, 1) + RG(a3, R_UFX, 0) + RG(a3, R_UFX, 1)) * (c2[0] + c2[1]);
           else
-            cav = -.25 * ((uf0[l] + ufm[l]) * pv0[l] + (uf0[l + 1] + ufm[l + 1]) * pv0[l + 1]);
+            cav = -.25 * ((RG(a2, R_UFX, 0) + RG(a3, R_UFX, 0)) * c2[0] + (RG(a2, R_UFX, 1) + RG(a3, R_UFX, 1)) * c2[1]);
           double stress = 0.;
           if (hybrid)                    // :1100-1109
-            stress = -(mv_nl[c + (size_t)k * np] - mv_nl[c + (size_t)(k + 1) * np]) * tauy[c] * GRAV * scvy[c] / fmax2(ONEMM, u_dpv);
-          else if (k == 0) stress = -2. * tauy[c] * GRAV * scvy[c] / (p_1[c] + p_1[c - ni]);
+            stress = -(ldo(mvnl, ou) - ldo(mvnl, oup1)) * ldo(tauy, ou) * GRAV * ldo(scvy, ou) / fmax2(ONEMM, u_dpv);
+          else if (k == 0) stress = -2. * ldo(tauy, ou) * GRAV * ldo(scvy, ou) / (ldo(p0, oup1) + ldo(p0, oup1 - ni8));
           const double pbv = u_pbvm;
           const double ptopl = .5 * (fmin2(pbv, u_p0) + fmin2(pbv, u_p0s));
           const double pbotl = .5 * (fmin2(pbv, u_p1) + fmin2(pbv, u_p1s));
@@ -627,15 +647,16 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
           const double vn = vkn + u_vbfn * tsfac / (u_pbvn * u_scvx);               // vtotn, :424-430
           const double botstr = -vn * q / (1. + delt1 * q);
           const double pgf = (1. - 2. * WPGF) * u_pgym + WPGF * (u_pgyo + u_pgyn);
-          o_vm[c] = vkm * (wuv1 * u_dpv + ONEMM) + vkn * wuv2 * u_dpvold;
+          sto(o_vm, ou, vkm * (wuv1 * u_dpv + ONEMM) + vkn * wuv2 * u_dpvold);
           const double vbrhs = u_vbcors * tsfac;                                    // :307
-          o_vn[c] = vkn + delt1 * (-u_scvyi * (-pgf + stress + (ke0[l] - kem[l])) + cav - vbrhs + botstr - u_visv);
+          sto(o_vn, ou, vkn + delt1 * (-u_scvyi * (-pgf + stress + (RG(b2, R_KE, 0) - RG(b0, R_KE, 0))) + cav - vbrhs + botstr - u_visv));
         }
       }
     }
     __syncthreads();
     pr_p0 = u_p0; pr_p1 = u_p1; pr_drag = u_drag;
     tpp = tp; tp = tc; tc = tn;
+    q0 = q0 == 2 ? 0 : q0 + 1;
   }
 }
 
