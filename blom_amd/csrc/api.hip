@@ -286,6 +286,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
   if (s == "live_slopes") { c->live_slopes = v; return 0; }
   if (s == "momtum_bs") { c->momtum_bs = v; return 0; }
+  if (s == "momtum_lds_pad") { c->momtum_lds_pad = v; return 0; }
   if (s == "momtum_order") { c->momtum_order = v; return 0; }
   if (s == "momtum_chunks_a") { c->momtum_chunks_a = v; return 0; }
   if (s == "momtum_chunks_b") { c->momtum_chunks_b = v; return 0; }

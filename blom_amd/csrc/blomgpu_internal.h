@@ -272,6 +272,7 @@ struct blomgpu_ctx {
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int live_slopes = 0;       // blomgpu_step: 1 = cmnfld2 computes nslpx/nslpy every step (stage_cmnfld.hip); 0 = they stay as uploaded
   int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major
+  int momtum_lds_pad = 0;    // experiment: extra bytes of LDS per workgroup of the one-wavefront marches (lowers the occupancy)
   int momtum_bs = 0;         // lanes per workgroup of the fused kernels (0: 64, one wavefront)
   int momtum_chunks_a = 0, momtum_chunks_b = 0;   // j-chunks per layer of the two fused kernels (0: one round of workgroups)
   int diapfl_du = 8;         // levels whose loads k_diapfl_column3 keeps in flight (2, 4, 8)

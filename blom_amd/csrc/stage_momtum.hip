@@ -21,6 +21,7 @@
   const size_t c = t_
 
 #define S2_DRAG 3      // 2-D work plane
+#define S2_QUM 4       // four consecutive 2-D work planes: the barotropic part of utotm, vtotm, utotn, vtotn
 
 
 // pu(k+1) = pu(k) + dpu(k+off), same for pv; range lo..+hi (:322-338 with lo=-1,hi=2; :1252-1267 interior)
@@ -73,6 +74,28 @@ __global__ void k_mom_drag(const DevView *__restrict__ Vp, int n, int nn) {
 }
 
 
+// ---- the barotropic part of the total velocities, utotm - u(km) and utotn - u(kn) (:360-431):
+// ubflxs_p*tsfac/(pbu*scuy), the same for every layer -- evaluated once per step into four 2-D work planes
+// (u, v at time levels m, n) instead of once per layer and sweep inside the marches (a division each)
+__global__ void k_mom_qplanes(const DevView *__restrict__ Vp, int m, int n) {
+  const DevView &V = *Vp;
+  THREAD_IJ(V);
+  (void)i; (void)j;
+  const size_t np = V.nplane, om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
+  const double tsfac = V.P.dlt / V.P.delt1;
+  double *q = WK2(V, S2_QUM);
+  if (V.m[I_iu][c]) {
+    const double sy = V.f[F_scuy][c];
+    q[c] = V.f[F_ubflxs_p][c + om] * tsfac / (V.f[F_pbu][c + om] * sy);
+    q[c + 2 * np] = V.f[F_ubflxs_p][c + on] * tsfac / (V.f[F_pbu][c + on] * sy);
+  }
+  if (V.m[I_iv][c]) {
+    const double sx = V.f[F_scvx][c];
+    q[c + np] = V.f[F_vbflxs_p][c + om] * tsfac / (V.f[F_pbv][c + om] * sx);
+    q[c + 3 * np] = V.f[F_vbflxs_p][c + on] * tsfac / (V.f[F_pbv][c + on] * sx);
+  }
+}
+
 int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)k1m; (void)k1n;
   const DevView &h = c->h;
@@ -81,6 +104,7 @@ int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   hipLaunchKernelGGL(k_mom_pscan, gcol, b64, 0, c->stream, c->d, mm, -1, 2);
   hipLaunchKernelGGL(k_mom_drag, gcol, b64, 0, c->stream, c->d, n, nn);
   hipLaunchKernelGGL(k_mom_pupv, gcol, b64, 0, c->stream, c->d, mm, -1, 2);
+  hipLaunchKernelGGL(k_mom_qplanes, plane_grid(h, 1, 256), dim3(256), 0, c->stream, c->d, m, n);
   if (int rc = st_xctilr(c, h.f[F_difwgt], 1, 1, 2, 2, 1)) return rc;                       // :340
   return st_momtum_fused_layers(c, m, n, mm, nn);                                           // stage_momtum_fused.hip
 }

@@ -22,6 +22,8 @@
 // kk-level work-space slots of the fused path
 enum { MF_VISU, MF_VISV, MF_UM, MF_UN, MF_VM, MF_VN, MF_NSLOT };
 #define S2_DRAG 3      // 2-D work plane (written by k_mom_drag, stage_momtum.hip)
+#define S2_QUM 4       // four 2-D work planes (k_mom_qplanes, stage_momtum.hip): ubflxs_p*tsfac/(pbu*scuy) at level m, the same for v, both at level n
+#define WK2V(w) ((gcd_t)((const double *const volatile CONST_AS &)Vp->wk2d + (size_t)(w) * np))
 
 // Field pointers come out of the DevView in memory, so the compiler cannot know their address space and would emit
 // flat loads -- which count on lgkmcnt as well as vmcnt, so that every LDS wait (and the wait in front of every
@@ -137,7 +139,6 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
   double via1 = 0., via2 = 0., via3 = 0., vfl3 = 0., vfl4 = 0.;
 
   const gcd_t f_u = GF(V, F_u) + okn, f_v = GF(V, F_v) + okn;
-  const gcd_t f_ubf = GF(V, F_ubflxs_p) + on, f_vbf = GF(V, F_vbflxs_p) + on, f_pbun = GF(V, F_pbu) + on, f_pbvn = GF(V, F_pbv) + on;
   const gcd_t f_pbum = GF(V, F_pbu) + om, f_pbvm = GF(V, F_pbv) + om;
   const gcd_t f_pu0 = GF(V, F_pu) + ok, f_pv0 = GF(V, F_pv) + ok;      // the interface below: one plane further on
   const unsigned np8 = (unsigned)np * 8u;
@@ -145,14 +146,14 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
   const gd_t o_visu = (gd_t)WK(V, MF_VISU) + ok, o_visv = (gd_t)WK(V, MF_VISV) + ok;
 
   // inputs of the first sweep, one step ahead
-  struct TIn { int mk; double u, ub, pbu, sy, v, vb, pbv, sx; };
+  struct TIn { int mk; double u, qu, v, qv; };
   auto load_t = [&](int r) {
     const unsigned o = roff(r);
-    const gcd_t scuy = GFV(F_scuy), scvx = GFV(F_scvx);
+    const gcd_t qn = WK2V(S2_QUM + 2);
     TIn t;
     t.mk = ldoi(mpk, o >> 1);
-    t.u = ldo(f_u, o); t.ub = ldo(f_ubf, o); t.pbu = ldo(f_pbun, o); t.sy = ldo(scuy, o);
-    t.v = ldo(f_v, o); t.vb = ldo(f_vbf, o); t.pbv = ldo(f_pbvn, o); t.sx = ldo(scvx, o);
+    t.u = ldo(f_u, o); t.qu = ldo(qn, o);
+    t.v = ldo(f_v, o); t.qv = ldo(qn, o + np8);
     return t;
   };
   TIn tc = load_t(ja - 2);
@@ -203,12 +204,12 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     if (act && s >= -1 && s <= jj + 2 && i >= -1 && i <= ii + 2) {
       double un = 0., vn = 0.;
       if (MU(tc.mk)) {
-        un = tc.u + tc.ub * tsfac / (tc.pbu * tc.sy);
+        un = tc.u + tc.qu;
         // the reference's module array utotn is left holding the last layer's values outside the interior
         if (k == kk - 1) sto(o_utotn, x8 + ni8 * (unsigned)(s + NBDY - 1), un);
       }
       if (MV(tc.mk)) {
-        vn = tc.v + tc.vb * tsfac / (tc.pbv * tc.sx);
+        vn = tc.v + tc.qv;
         if (k == kk - 1) sto(o_vtotn, x8 + ni8 * (unsigned)(s + NBDY - 1), vn);
       }
       RG(a0, R_UTN, 0) = un;
@@ -422,11 +423,11 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
 
   // 3-D fields read at both time levels (u, v, pgfx, pgfy) and the 2-D ones with two time levels (ubflxs_p, vbflxs_p, pbu,
   // pbv): ONE base pointer each, at the lower of the two levels, the level going into the lane's byte offset
-  const size_t olo = okm < okn ? okm : okn, o2lo = om < on ? om : on;
-  const unsigned dkm = (unsigned)((okm - olo) * 8), dkn = (unsigned)((okn - olo) * 8), d2m = (unsigned)((om - o2lo) * 8), d2n = (unsigned)((on - o2lo) * 8);
+  const size_t olo = okm < okn ? okm : okn;
+  const unsigned dkm = (unsigned)((okm - olo) * 8), dkn = (unsigned)((okn - olo) * 8);
   const unsigned np8 = (unsigned)np * 8u;
   const gcd_t dp = GF(V, F_dp) + okm, f_u = GF(V, F_u) + olo, f_v = GF(V, F_v) + olo;
-  const gcd_t f_ubf = GF(V, F_ubflxs_p) + o2lo, f_vbf = GF(V, F_vbflxs_p) + o2lo, f_pbu = GF(V, F_pbu) + o2lo, f_pbv = GF(V, F_pbv) + o2lo;
+  const gcd_t f_pbum = GF(V, F_pbu) + om, f_pbvm = GF(V, F_pbv) + om;
   const gcd_t f_dpu = GF(V, F_dpu) + okm, f_dpv = GF(V, F_dpv) + okm;
   const gcd_t p0 = GF(V, F_p) + ok;                 // p1: one plane further on
   const gcd_t pgfx = GF(V, F_pgfx) + olo, pgfx_o = GF(V, F_pgfx_o) + ok;
@@ -441,47 +442,61 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
   // and dp of rows s-1, s-2 for the vorticity, u, v, dpu, dpv and the 2-D coefficients of row s-2 for the update)
   // is carried in registers from step to step instead of being read again: the second read of a row, two march
   // steps later and with ~2000 waves streaming through the same L2, mostly missed it.
-  struct TIn { int mk, mkw; double dc, dw, u, ub, pbu, sy, dpu, v, vb, pbv, sx, dpv; };
+  struct TIn { int mk, mkw; double dc, dw, u, qu, dpu, v, qv, dpv; };
   auto load_t = [&](int r) {
-    const unsigned o = roff(r), o3 = o + dkm, o2 = o + d2m;
-    const gcd_t scuy = GFV(F_scuy), scvx = GFV(F_scvx);
+    const unsigned o = roff(r), o3 = o + dkm;
+    const gcd_t qm = WK2V(S2_QUM);
     TIn t;
     t.mk = ldoi(mpk, o >> 1); t.mkw = ldoi<-4>(mpk, o >> 1);
     t.dc = ldo(dp, o); t.dw = ldo<-8>(dp, o);
-    t.u = ldo(f_u, o3); t.ub = ldo(f_ubf, o2); t.pbu = ldo(f_pbu, o2); t.sy = ldo(scuy, o); t.dpu = ldo(f_dpu, o);
-    t.v = ldo(f_v, o3); t.vb = ldo(f_vbf, o2); t.pbv = ldo(f_pbv, o2); t.sx = ldo(scvx, o); t.dpv = ldo(f_dpv, o);
+    t.u = ldo(f_u, o3); t.qu = ldo(qm, o); t.dpu = ldo(f_dpu, o);
+    t.v = ldo(f_v, o3); t.qv = ldo(qm, o + np8); t.dpv = ldo(f_dpv, o);
+    return t;
+  };
+  struct VIn { double scvy, scvyw, scux, scuxs, scq2i, cor, scu2, scu2e, scv2, scv2n, scp2; };
+  auto load_v = [&](int r) {
+    const unsigned o = roff(r);
+    const gcd_t scvy = GFV(F_scvy), scux = GFV(F_scux), scq2i = GFV(F_scq2i), corioq = GFV(F_corioq);
+    const gcd_t scu2 = GFV(F_scu2), scv2 = GFV(F_scv2), scp2 = GFV(F_scp2);
+    VIn t;
+    t.scvy = ldo(scvy, o); t.scvyw = ldo<-8>(scvy, o); t.scux = ldo(scux, o); t.scuxs = ldo(scux, o - ni8); t.scq2i = ldo(scq2i, o);
+    t.cor = ldo(corioq, o);
+    t.scu2 = ldo(scu2, o); t.scu2e = ldo<8>(scu2, o); t.scv2 = ldo(scv2, o); t.scv2n = ldo(scv2, o + ni8); t.scp2 = ldo(scp2, o);
     return t;
   };
   TIn tpp = load_t(ja - 3), tp = load_t(ja - 2), tc = load_t(ja - 1);      // rows s-2, s-1, s
+  VIn vc = load_v(ja - 2);                                                 // row s-1
   double pr_p0 = ldo(p0, roff(ja - 4)), pr_p1 = ldo(p0, roff(ja - 4) + np8), pr_drag = ldo((gcd_t)WK2(V, S2_DRAG), roff(ja - 4));   // row s-3
   int q0 = (ja - 1 + 48) % 3;        // depth-3 slot of row s
 
   for (int s = ja - 1; s <= jb + 2; s++) {
     // ================= loads of this step =================
     const TIn tn = load_t(s + 1);
-    const gcd_t scvy = GFV(F_scvy), scux = GFV(F_scux), scq2i = GFV(F_scq2i), corioq = GFV(F_corioq);
-    const gcd_t scu2 = GFV(F_scu2), scv2 = GFV(F_scv2), scp2 = GFV(F_scp2);
+    const gcd_t scux = GFV(F_scux), scvy = GFV(F_scvy);
     const gcd_t ubcors = GFV(F_ubcors_p), vbcors = GFV(F_vbcors_p), scuxi = GFV(F_scuxi), scvyi = GFV(F_scvyi);
-    const gcd_t drag = (gcd_t)((const double *const volatile CONST_AS &)Vp->wk2d + (size_t)S2_DRAG * np);
+    const gcd_t drag = WK2V(S2_DRAG);
     gcd_t taux = nullptr, tauy = nullptr, munl = nullptr, mvnl = nullptr;      // the wind stress acts on the top layer (isopyc_bulkml) / on every layer
     if (hybrid || k == 0) { taux = GFV(F_taux); tauy = GFV(F_tauy); }
     if (hybrid) { munl = GFV(F_mu_nonloc) + ok; mvnl = GFV(F_mv_nonloc) + ok; }
-    // V (row s-1): 2-D coefficients
+    // V (row s-1): its 2-D coefficients were loaded a step ahead as well (the sweep follows the short first one at once: loaded in
+    // this step they were waited for, 36 % of the wavefronts' time); this step loads row s for the next
     const unsigned ov = roff(s - 1);
+    const VIn vnx = load_v(s);
     const int v_m = tp.mk, v_mw = tp.mkw, v_ms = tpp.mk;
-    const double v_scvy = ldo(scvy, ov), v_scvyw = ldo<-8>(scvy, ov), v_scux = ldo(scux, ov), v_scuxs = ldo(scux, ov - ni8), v_scq2i = ldo(scq2i, ov);
-    const double v_dc = tp.dc, v_dw = tp.dw, v_ds = tpp.dc, v_dsw = tpp.dw, v_cor = ldo(corioq, ov);
-    const double v_scu2 = ldo(scu2, ov), v_scu2e = ldo<8>(scu2, ov), v_scv2 = ldo(scv2, ov), v_scv2n = ldo(scv2, ov + ni8), v_scp2 = ldo(scp2, ov);
+    const double v_scvy = vc.scvy, v_scvyw = vc.scvyw, v_scux = vc.scux, v_scuxs = vc.scuxs, v_scq2i = vc.scq2i;
+    const double v_dc = tp.dc, v_dw = tp.dw, v_ds = tpp.dc, v_dsw = tpp.dw, v_cor = vc.cor;
+    const double v_scu2 = vc.scu2, v_scu2e = vc.scu2e, v_scv2 = vc.scv2, v_scv2n = vc.scv2n, v_scp2 = vc.scp2;
     // U (row s-2)
-    const unsigned ou = roff(s - 2), ou3 = ou + dkn, ou3m = ou + dkm, ou2 = ou + d2n, oup1 = ou + np8;
+    const unsigned ou = roff(s - 2), ou3 = ou + dkn, ou3m = ou + dkm, oup1 = ou + np8;
+    const gcd_t qn = WK2V(S2_QUM + 2);
     const int u_m = tpp.mk;
     const double u_drag = ldo(drag, ou), u_dragw = ldo<-8>(drag, ou), u_drags = pr_drag;
     const double u_p0 = ldo(p0, ou), u_p0w = ldo<-8>(p0, ou), u_p0s = pr_p0, u_p1 = ldo(p0, oup1), u_p1w = ldo<-8>(p0, oup1), u_p1s = pr_p1;
-    const double u_dpu = tpp.dpu, u_pbum = tpp.pbu, u_ukm = tpp.u, u_ukn = ldo(f_u, ou3), u_ubfn = ldo(f_ubf, ou2), u_pbun = ldo(f_pbu, ou2);
-    const double u_scuy = tpp.sy, u_pgm = ldo(pgfx, ou3m), u_pgo = ldo(pgfx_o, ou), u_pgn = ldo(pgfx, ou3), u_dpuold = ldo(dpuold, ou);
+    const double u_dpu = tpp.dpu, u_pbum = ldo(f_pbum, ou), u_ukm = tpp.u, u_ukn = ldo(f_u, ou3), u_qun = ldo(qn, ou);
+    const double u_pgm = ldo(pgfx, ou3m), u_pgo = ldo(pgfx_o, ou), u_pgn = ldo(pgfx, ou3), u_dpuold = ldo(dpuold, ou);
     const double u_ubcors = ldo(ubcors, ou), u_scuxi = ldo(scuxi, ou), u_visu = ldo(visu, ou);
-    const double u_dpv = tpp.dpv, u_pbvm = tpp.pbv, u_vkm = tpp.v, u_vkn = ldo(f_v, ou3), u_vbfn = ldo(f_vbf, ou2), u_pbvn = ldo(f_pbv, ou2);
-    const double u_scvx = tpp.sx, u_pgym = ldo(pgfy, ou3m), u_pgyo = ldo(pgfy_o, ou), u_pgyn = ldo(pgfy, ou3), u_dpvold = ldo(dpvold, ou);
+    const double u_dpv = tpp.dpv, u_pbvm = ldo(f_pbvm, ou), u_vkm = tpp.v, u_vkn = ldo(f_v, ou3), u_qvn = ldo(qn, ou + np8);
+    const double u_pgym = ldo(pgfy, ou3m), u_pgyo = ldo(pgfy_o, ou), u_pgyn = ldo(pgfy, ou3), u_dpvold = ldo(dpvold, ou);
     const double u_vbcors = ldo(vbcors, ou), u_scvyi = ldo(scvyi, ou), u_visv = ldo(visv, ou);
     // the first sweep's neighbours to the south come from the row loaded a step earlier
     const int t_mks = tp.mk;
@@ -503,11 +518,11 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
       if (s <= jj + 1 && i <= ii + 1) {
         double ut = 0., uf = 0., vt = 0., vf = 0.;
         if (MU(tc.mk)) {
-          ut = tc.u + tc.ub * tsfac / (tc.pbu * tc.sy);
+          ut = tc.u + tc.qu;
           uf = ut * fmax2(tc.dpu, cutoff);
         }
         if (MV(tc.mk)) {
-          vt = tc.v + tc.vb * tsfac / (tc.pbv * tc.sx);
+          vt = tc.v + tc.qv;
           vf = vt * fmax2(tc.dpv, cutoff);
         }
         RG(b0, R_UTM, 0) = ut;
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
           const double q = .5 * (u_drag + u_dragw) * (fmax2(pbu - thkbop, pbotl) - fmax2(pbu - thkbop, fmin2(ptopl, pbotl - ONEMM))) /
                            fmax2(u_dpu, ONEMM);
           const double ukm = u_ukm, ukn = u_ukn;
-          const double un = ukn + u_ubfn * tsfac / (u_pbun * u_scuy);               // utotn, :408-414
+          const double un = ukn + u_qun;                                            // utotn, :408-414
           const double botstr = -un * q / (1. + delt1 * q);
           const double pgf = (1. - 2. * WPGF) * u_pgm + WPGF * (u_pgo + u_pgn);
           sto(o_um, ou, ukm * (wuv1 * u_dpu + ONEMM) + ukn * wuv2 * u_dpuold);
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
           const double q = .5 * (u_drag + u_drags) * (fmax2(pbv - thkbop, pbotl) - fmax2(pbv - thkbop, fmin2(ptopl, pbotl - ONEMM))) /
                            fmax2(u_dpv, ONEMM);
           const double vkm = u_vkm, vkn = u_vkn;
-          const double vn = vkn + u_vbfn * tsfac / (u_pbvn * u_scvx);               // vtotn, :424-430
+          const double vn = vkn + u_qvn;                                            // vtotn, :424-430
           const double botstr = -vn * q / (1. + delt1 * q);
           const double pgf = (1. - 2. * WPGF) * u_pgym + WPGF * (u_pgyo + u_pgyn);
           sto(o_vm, ou, vkm * (wuv1 * u_dpv + ONEMM) + vkn * wuv2 * u_dpvold);
@@ -656,6 +671,7 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
     __syncthreads();
     pr_p0 = u_p0; pr_p1 = u_p1; pr_drag = u_drag;
     tpp = tp; tp = tc; tc = tn;
+    vc = vnx;
     q0 = q0 == 2 ? 0 : q0 + 1;
   }
 }
@@ -738,7 +754,7 @@ template <int BS>
 static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca, int ncb) {
   const DevView &h = c->h;
   const int nsa = (h.ii + (BS - 8) - 1) / (BS - 8), nsb = (h.ii + (BS - 4) - 1) / (BS - 4);
-  const size_t la = sizeof(double) * 37 * (BS + 4), lb = sizeof(double) * (h.P.mommth == 2 ? 35 : 21) * (BS + 4);
+  const size_t la = sizeof(double) * 37 * (BS + 4) + c->momtum_lds_pad, lb = sizeof(double) * (h.P.mommth == 2 ? 35 : 21) * (BS + 4) + c->momtum_lds_pad;
   // more than 64 KB of dynamic LDS has to be asked for
   (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
