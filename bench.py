@@ -400,7 +400,7 @@ def bench_hybrid_step(args):
     gpu.set("ale_regrid_method", "nudge")
     gpu.set("mlrmth", "fox08")
     gpu.set_vector("plevel", 0.05 * pbot * (np.arange(kk) / kk) ** 1.3)
-    gpu.stage("cmnfld1", *hostinit.step_indices(0, kk))
+    gpu.stage("cmnfld1", *hostinit.init_indices(0, kk))
     ns = gpu.step(0, max(2, args.warmup))
     gpu.sync()
     t0 = time.perf_counter()
@@ -439,7 +439,7 @@ def main():
                          "frozen: round 1's analytic pattern of amplitude NSLP0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
-                    help="library option for A/B runs of kernel variants, e.g. momtum_v=1 (default: production kernels)")
+                    help="library option for A/B runs of kernel variants, e.g. barotp_tile=3216 (default: production kernels)")
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
                     help="N > 1: strong (default) = the BASELINE domain cut into tiles; weak = N times as long a channel")
     ap.add_argument("--tiles", default=None, metavar="NPXxNPY", help="tile grid of the strong-scaling run (default: by N)")

@@ -269,17 +269,17 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
-  if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; return 0; }
-  if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; return 0; }
+  if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; ale_free(c); return 0; }
+  if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; ale_free(c); return 0; }
   if (s == "ale_k_range_plevel") { c->ale_k_range_plevel = v; return 0; }
   if (s == "ale_dktzu") { c->ale_dktzu = v; return 0; }
   if (s == "ale_dktzl") { c->ale_dktzl = v; return 0; }
-  if (s == "ale_density_pc_upper_bndr") { c->ale_density_pc_upper = v != 0; return 0; }
-  if (s == "ale_density_pc_lower_bndr") { c->ale_density_pc_lower = v != 0; return 0; }
-  if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; return 0; }
-  if (s == "ale_tracer_pc_lower_bndr") { c->ale_tracer_pc_lower = v != 0; return 0; }
-  if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; return 0; }
-  if (s == "ale_velocity_pc_lower_bndr") { c->ale_velocity_pc_lower = v != 0; return 0; }
+  if (s == "ale_density_pc_upper_bndr") { c->ale_density_pc_upper = v != 0; ale_free(c); return 0; }
+  if (s == "ale_density_pc_lower_bndr") { c->ale_density_pc_lower = v != 0; ale_free(c); return 0; }
+  if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; ale_free(c); return 0; }
+  if (s == "ale_tracer_pc_lower_bndr") { c->ale_tracer_pc_lower = v != 0; ale_free(c); return 0; }
+  if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; ale_free(c); return 0; }
+  if (s == "ale_velocity_pc_lower_bndr") { c->ale_velocity_pc_lower = v != 0; ale_free(c); return 0; }
   if (s == "remap_fold") { c->remap_fold = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
@@ -362,6 +362,7 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     if (v == "monotonic") lim = 201; else if (v == "non_oscillatory") lim = 203;
     else return ctx_fail(c, " readnml_ale_regrid_remap: " + s.substr(4) + " = " + v + " is unsupported!");
     (s == "ale_tracer_limiting" ? c->ale_tracer_limiting : c->ale_velocity_limiting) = lim;
+    ale_free(c);                     // the cached reconstruction structures hold the limiter
     return 0;
   }
   if (s == "bmcmth") {

@@ -74,7 +74,8 @@ program blom_dyncore
   if (advect_cppm) call init_cppm()
   if (hybrid_coordinate) then
     ! blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first eddtra and ale_forcing read
-    call cmnfld1(mod(nstep,2)+1, mod(nstep+1,2)+1, mod(nstep,2)*kdm, mod(nstep+1,2)*kdm, 1+mod(nstep,2)*kdm, 1+mod(nstep+1,2)*kdm)
+    ! with blom_init's time level indices (phy/mod_blom_init.F90:256-261: m = mod(nstep1+1,2)+1, n = mod(nstep1,2)+1)
+    call cmnfld1(mod(nstep+1,2)+1, mod(nstep,2)+1, mod(nstep+1,2)*kdm, mod(nstep,2)*kdm, 1+mod(nstep+1,2)*kdm, 1+mod(nstep,2)*kdm)
   end if
   do while (nstep < nstep2)
     call blom_step(nstep)

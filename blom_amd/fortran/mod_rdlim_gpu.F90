@@ -153,10 +153,9 @@ contains
         open (newunit=nfu, file=nlfnm, status='old', action='read')
         read (unit=nfu, nml=ale_regrid_remap, iostat=ios)
         close (nfu)
-        if (ios > 0) then
-          write (*,*) 'readnml_ale_regrid_remap: could not read the namelist group ALE_REGRID_REMAP of '//trim(nlfnm)
-          error stop '(readnml_ale_regrid_remap)'
-        end if
+        ! phy/mod_ale_regrid_remap.F90:1226-1232: a missing or unreadable group is not an error there
+        if (ios /= 0) write (*,*) 'readnml_ale_regrid_remap: No vertical coordinate variable group found in namelist. Using defaults.'
+
         call gpu_set('vcoord_type', trim(vcoord_type))
         call gpu_set('ale_reconstruction_method', trim(reconstruction_method))
         call gpu_set('ale_density_limiting', trim(density_limiting))

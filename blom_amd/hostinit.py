@@ -456,6 +456,16 @@ def step_indices(nstep, kk):
     return m, n, mm, nn, 1 + mm, 1 + nn
 
 
+def init_indices(nstep1, kk):
+    """Time-level sextuple of blom_init (phy/mod_blom_init.F90:256-261: m = mod(nstep1+1,2)+1, n = mod(nstep1,2)+1): what its
+    start-up cmnfld1 is called with -- the other way round from the first step's."""
+    m = (nstep1 + 1) % 2 + 1
+    n = nstep1 % 2 + 1
+    mm = (m - 1) * kk
+    nn = (n - 1) * kk
+    return m, n, mm, nn, 1 + mm, 1 + nn
+
+
 def frozen_eddy_fluxes(be, case, amp=0.15, spike=3.0):
     """A synthetic, frozen field of eddy-induced mass fluxes umfltd, vmfltd (thickness diffusion) and umflsm, vmflsm
     (submesoscale) at both time levels: what eddtra would hand to advect (phy/mod_advect.F90:72-94,

@@ -124,8 +124,8 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path):
     try:
         ref.ref.set("vcoord_tag", tag)
         # blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first ale_forcing reads
-        ref.ref.stage("cmnfld1", *six0)
-        gpu.stage("cmnfld1", *six0)
+        ref.ref.stage("cmnfld1", *hostinit.init_indices(0, kk))
+        gpu.stage("cmnfld1", *hostinit.init_indices(0, kk))
         nr = ng = 0
         for _ in range(nsteps):
             nr = dyncore_step(ref, nr, case.params["baclin"], stages=HYBRID_STAGES)

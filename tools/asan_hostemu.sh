@@ -58,7 +58,7 @@ def hybrid(cfg, vcoord, method, advmth="remap", steps=3, ntr=None):
     gpu.set_vector("plevel", 0.3 * pbot * (np.arange(kk) / kk) ** 1.3)
     if advmth == "cppm":
         gpu.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
-    gpu.stage("cmnfld1", *hostinit.step_indices(0, kk))
+    gpu.stage("cmnfld1", *hostinit.init_indices(0, kk))
     ns = gpu.step(0, steps)
     u = gpu.get("u")[:, 4:-4, 4:-4]
     assert np.isfinite(u[np.broadcast_to((iu[4:-4, 4:-4] > 0)[None], u.shape)]).all()

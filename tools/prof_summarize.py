@@ -3,8 +3,9 @@
 usage: [NTR=3] [CONFIG=channel] prof_summarize.py <tag> <kernel_trace.csv> [<fetch_counter.csv> <write_counter.csv>]
 
 Only what runs INSIDE the baroclinic steps is counted: the window of a step opens with its k_init_fluxes launch (the
-first kernel of blomgpu_step's sequence) and closes with the last launch of tmsmt2's kernels before the next
-k_init_fluxes (or before the end of the trace).  The initialisation (per-field memsets of blomgpu_create, uploads, the
+first kernel of blomgpu_step's sequence) and closes before the next step's k_init_fluxes -- tmsmt2's dp halo update, its
+pressure scan and k_dpudpv, and cmnfld1 of the other vertical coordinates, belong to the step --; the last step of the trace
+closes with the run of such kernels after its last k_tmsmt2* launch.  The initialisation (per-field memsets of blomgpu_create, uploads, the
 stages init_state runs) and the bench's own checksum kernels lie outside every window and are listed separately.
 Output names carry the configuration: profiles/<tag>_<config>_kernel_stats.txt (bench.py picks the newest one of ITS
 configuration)."""
@@ -26,6 +27,28 @@ def short(name):
     return n[5:] if n.startswith("void ") else n
 
 
+# kernels the bench itself launches between and after the steps
+BENCH_OWN = ("k_crc_", "k_xcsum", "__amd_rocclr_copyBuffer")
+# what tmsmt2 (and, for the other vertical coordinates, cmnfld1) still launches after the k_tmsmt2* kernels: the last step's window
+# closes at the last of these
+STEP_TAIL = ("k_tmsmt2", "k_xctilr", "k_pscan", "k_dpudpv", "k_cmn_")
+
+
+def inside_step(names, k0, knext, mark):
+    """marks the launches of the step that opens at k0: up to the launch before the next step's k_init_fluxes (knext), the
+    bench's own kernels excepted; the last step of the trace (knext None) ends with the contiguous run of step-tail kernels
+    that follows its last k_tmsmt2* launch"""
+    if knext is None:
+        knext = len(names)
+        last = max((k for k in range(k0, knext) if names[k].startswith("k_tmsmt2")), default=k0)
+        while last + 1 < knext and names[last + 1].startswith(STEP_TAIL):
+            last += 1
+        knext = last + 1
+    for k in range(k0, knext):
+        if not names[k].startswith(BENCH_OWN):
+            mark(k)
+
+
 rows = [r for r in csv.DictReader(open(trace)) if r["Kind"] == "KERNEL_DISPATCH"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [short(r["Kernel_Name"]) for r in rows]
@@ -35,10 +58,7 @@ if not first:
 inside = [False] * len(rows)
 nst = len(first)
 for s, k0 in enumerate(first):
-    k1 = first[s + 1] if s + 1 < nst else len(rows)
-    last = max((k for k in range(k0, k1) if names[k].startswith("k_tmsmt2")), default=k0)
-    for k in range(k0, last + 1):
-        inside[k] = True
+    inside_step(names, k0, first[s + 1] if s + 1 < nst else None, lambda k: inside.__setitem__(k, True))
 acc = collections.defaultdict(lambda: [0, 0.0])
 out_acc = collections.defaultdict(lambda: [0, 0.0])
 for r, n, ins in zip(rows, names, inside):
@@ -68,12 +88,11 @@ if len(sys.argv) > 4:
         nm = [short(r["Kernel_Name"]) for r in recs]
         fi = [k for k, n in enumerate(nm) if n.startswith("k_init_fluxes")]
         a = collections.defaultdict(lambda: [0, 0.0])
+        def add(k):
+            a[nm[k]][0] += 1
+            a[nm[k]][1] += float(recs[k]["Counter_Value"])
         for s, k0 in enumerate(fi):
-            k1 = fi[s + 1] if s + 1 < len(fi) else len(recs)
-            last = max((k for k in range(k0, k1) if nm[k].startswith("k_tmsmt2")), default=k0)
-            for k in range(k0, last + 1):
-                a[nm[k]][0] += 1
-                a[nm[k]][1] += float(recs[k]["Counter_Value"])
+            inside_step(nm, k0, fi[s + 1] if s + 1 < len(fi) else None, add)
         return a, len(fi)
     (fe, nst_f), (wr, nst_w) = per_kernel(sys.argv[3], "FETCH_SIZE"), per_kernel(sys.argv[4], "WRITE_SIZE")
     with open(f"{base}_pmc_hbm_traffic.txt", "w") as f:
