@@ -213,6 +213,12 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   if (s == "pref") { P.pref = v; set_eos(P); c->dirty = true; return 0; }
   if (s == "swamxd") { c->swamxd = v; return 0; }                           // phy/mod_swabs.F90:179-183
   if (s == "brine_mlbase_frac") { c->brine_mlbase_frac = v; return 0; }     // phy/mod_forcing.F90:63
+  // mod_mxlayr's and mod_niw's namelist variables (phy/mod_mxlayr.F90:58-68, phy/mod_niw.F90:38-45)
+  if (s == "rm0") { c->rm0 = v; return 0; }
+  if (s == "rm5") { c->rm5 = v; return 0; }
+  if (s == "niwgf") { c->niwgf = v; return 0; }
+  if (s == "niwbf") { c->niwbf = v; return 0; }
+  if (s == "niwlf") { c->niwlf = v; return 0; }
   if (s == "ale_regrid_nudge_ts") { c->ale_regrid_nudge_ts = v; return 0; }
   // mixed layer restratification of eddtra_ale, phy/mod_eddtra.F90:53-94
   if (s == "ce") { c->eddtra_ce = v; return 0; }
@@ -331,6 +337,7 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     c->dirty = true;
     return 0;
   }
+  if (s == "mlrttp") { c->mlrttp = v; return 0; }         // resolved (and refused) in mxlayr, phy/mod_mxlayr.F90:197-212
   if (s == "mlrmth") {                                    // init_eddtra, phy/mod_eddtra.F90:1773-1806
     if (v == "none") c->mlrmth = 0; else if (v == "fox08") c->mlrmth = 1;
     else if (v == "bod23") return ctx_fail(c, " init_eddtra: mlrmth = bod23 is not built (it needs ustar3, wstar3 of the CVMix-bound mod_difest)");
@@ -533,6 +540,7 @@ int blomgpu_sfcstr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1
 }
 int blomgpu_init_cppm(blomgpu_ctx *c) { ctx_sync_view(c); return st_init_cppm(c); }   // phy/mod_cppm.F90:2504
 int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
+int blomgpu_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) { ctx_sync_view(c); return st_mxlayr(c, m, n, mm, nn, k1m, k1n); }
 int blomgpu_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {   // phy/mod_ale_regrid_remap.F90:1486
   ctx_sync_view(c);
   return st_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
@@ -629,6 +637,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "halo_difest_hyb") return blomgpu_halo_difest_hyb(c, 0, k1n);
   if (s == "halo_difest_vert") return blomgpu_halo_difest_hyb(c, 1, k1n);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
+  if (s == "mxlayr") return blomgpu_mxlayr(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_forcing") return blomgpu_ale_forcing(c, m, n, mm, nn, k1m, k1n);
   if (s == "cmnfld_bfsqi_ale") return blomgpu_cmnfld_bfsqi_ale(c, m, n, mm, nn, k1m, k1n);

@@ -73,6 +73,8 @@
   /* momtum, the other vertical coordinates: the fractions of the wind stress that pass the interfaces (mod_diffusion.F90:139-142) */ \
   X(mu_nonloc, K + 1) X(mv_nonloc, K + 1)                                                                                     \
   X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(mldl82, 1) X(dpml, 1) X(buoyfl, K + 1) X(hbl_tf, 1) X(hml_tf1, 1) X(hml_tf, 1) X(hml_tfbnd, 1) X(OBLdepth, 1)                                                 \
+  /* mxlayr (mod_mxlayr.F90:70-91 diagnostics; mod_forcing ustar, ustar3; mod_niw idkedt) */                                  \
+  X(ustar, 1) X(ustar3, 1) X(idkedt, 1) X(mtkeus, 1) X(mtkeni, 1) X(mtkebf, 1) X(mtkers, 1) X(mtkepe, 1) X(mtkeke, 1) X(pbrnda, 1)   \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
@@ -254,6 +256,9 @@ struct blomgpu_ctx {
   double ale_regrid_nudge_ts = 86400., ale_stab_fac_limit = .75, ale_dpvar_fac = .75, ale_smooth_diff_max = 50000.;   // :80-85
   int ale_dktzu = 4, ale_dktzl = 2;
   double ale_dpmin_interior = .1 * 9806.;                 // [m] in the namelist, times onem (:1352-1353)
+  // mod_mxlayr's namelist variables (cime_config/namelist_definition_blom.xml: rm0 = 1.2, rm5 = 0, mlrttp = 'constant'), mod_niw's
+  double rm0 = 1.2, rm5 = 0., niwgf = 0., niwbf = .35, niwlf = .5;
+  std::string mlrttp = "constant";
   double swamxd = 200., brine_mlbase_frac = 0.;           // phy/mod_swabs.F90:183 (default); phy/mod_forcing.F90:63 (namelist)
   void *ale = nullptr;
   double *ale_plevel = nullptr;
@@ -350,6 +355,9 @@ int st_ale_forcing(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n
 int st_cmnfld_bfsqi_ale(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);    // stage_cmnfld.hip
 int st_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_ale.hip
 void ale_free(blomgpu_ctx *);
+int st_mxlayr(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_mxlayr.hip
+int st_mom_pupv(blomgpu_ctx *, int off, int lo, int hi);                          // stage_momtum.hip
+int st_convec_velocity(blomgpu_ctx *, int nn);                                    // stage_convec.hip
 int launch_dpudpv(blomgpu_ctx *, int off, int flags);                                        // stage_simple.hip
 int remap_tile_launch(blomgpu_ctx *, int n, int mm, int nn, int tsel, bool fold);  // stage_remap_tile.hip; tsel 0 all tiles, 1 those that read no halo point, 2 the others
 int pbcor_tile_launch(blomgpu_ctx *, int which, int m, int offc, int offf, int from_remap);   // stage_pbcor_tile.hip

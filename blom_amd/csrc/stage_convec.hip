@@ -273,6 +273,13 @@ __global__ void k_convec_dpudpv(const DevView *__restrict__ Vp, int nn) {
   }
 }
 
+// the velocity remap on its own: mxlayr ends with the same one (phy/mod_mxlayr.F90:1312-1374)
+int st_convec_velocity(blomgpu_ctx *c, int nn) {
+  hipLaunchKernelGGL(k_convec_velocity, plane_grid(c->h, 2, 64), dim3(64), 0, c->stream, c->d, nn);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int st_convec(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;

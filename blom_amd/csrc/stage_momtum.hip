@@ -96,6 +96,13 @@ __global__ void k_mom_qplanes(const DevView *__restrict__ Vp, int m, int n) {
   }
 }
 
+// pu, pv of the range lo..+hi from dpu, dpv at level offset off (mxlayr's 'old' interface pressures, phy/mod_mxlayr.F90:1246-1262)
+int st_mom_pupv(blomgpu_ctx *c, int off, int lo, int hi) {
+  hipLaunchKernelGGL(k_mom_pupv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, lo, hi);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int st_momtum(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)k1m; (void)k1n;
   const DevView &h = c->h;

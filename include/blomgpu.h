@@ -128,6 +128,13 @@ int  blomgpu_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 int  blomgpu_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
+/* phy/mod_mxlayr.F90:130 mxlayr(m,n,mm,nn,k1m,k1n): the bulk mixed layer of vcoord_type = 'isopyc_bulkml' (turbulent kinetic
+ * energy balance, detrainment / entrainment, surface forcing, the new layer structure at the velocity points), called after
+ * thermf (phy/mod_blom_step.F90:188-192).  Reads the surface fluxes surflx, surrlx, sswflx, salflx, brnflx, salrlx, trflx, the
+ * friction velocity ustar and ustar3 = ustar**3, idkedt, swfc2, swal2; options blomgpu_set_real "rm0", "rm5", "niwgf", "niwbf",
+ * "ce", "tau_mlr", "lfmin", "swamxd", blomgpu_set_str "mlrttp".  PARITY UNPINNED (mod_mxlayr imports netCDF-bound modules):
+ * cross-checked against the real module behind stand-ins, tests/test_xcheck_mxlayr.py. */
+int  blomgpu_mxlayr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* phy/mod_ale_regrid_remap.F90:1486 ale_regrid_remap(m,n,mm,nn,k1m,k1n): regrid the layer interfaces and remap T, S, tracers, u, v
  * (first piece: vcoord_type = 'plevel' and 'cntiso_hybrid' with regrid_method 'direct' or 'nudge'; neutral
  * diffusion fails loudly).  Options: blomgpu_set_str "vcoord_type", "ale_reconstruction_method", "ale_regrid_method",

@@ -20,7 +20,7 @@ module ref_harness
   use dimensions,    only: idm, jdm, kdm, itdm, jtdm
   use mod_xc
   use mod_config,    only: expcnf
-  use mod_time,      only: baclin, batrop, delt1, dlt, lstep, nstep, nday_in_year
+  use mod_time,      only: baclin, batrop, delt1, dlt, lstep, nstep, nday_in_year, nday_of_year, nstep_in_day, xmi, l1mi, l2mi, l3mi, l4mi, l5mi
   use mod_grid
   use mod_state
   use mod_eos,       only: pref, inieos
@@ -62,6 +62,15 @@ module ref_harness
   use mod_vcoord,    only: plevel
   use mod_ale_forcing, only: ale_forcing
   use mod_swabs,     only: swamxd, swfc1, swfc2, swal1, swal2
+#endif
+#ifdef XCHECK_ML
+  ! cross-check builds only (oracle/Makefile *_xml): the reference's real mod_mxlayr (stand-ins: mod_nctools, mod_swabs) and
+  ! mod_thermf_channel (stand-in: mod_ben02), its real mod_niw
+  use mod_mxlayr,    only: mxlayr, inivar_mxlayr, rm0, rm5, mlrttp, mtkeus, mtkeni, mtkebf, mtkers, mtkepe, mtkeke, pbrnda
+  use mod_niw,       only: niwgf, niwbf, niwlf, idkedt, inivar_niw, niw_ke_tendency, uml, vml, umlres, vmlres
+  use mod_swabs,     only: swamxd, swfc1, swfc2, swal1, swal2
+  use mod_thermf_channel, only: thermf_channel
+  use mod_ben02,     only: ntda
 #endif
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
@@ -169,8 +178,25 @@ contains
     ierr = 0
     select case (trim(cstr(name)))
       case ('brine_mlbase_frac'); brine_mlbase_frac = v
-#ifdef XCHECK_ALE
+#if defined(XCHECK_ALE) || defined(XCHECK_ML)
       case ('swamxd'); swamxd = v
+#endif
+#ifdef XCHECK_ML
+      case ('rm0'); rm0 = v
+      case ('rm5'); rm5 = v
+      case ('niwgf'); niwgf = v
+      case ('niwbf'); niwbf = v
+      case ('niwlf'); niwlf = v
+      ! mod_forcing: the relaxation of thermf (phy/mod_forcing.F90:53-62, :84)
+      case ('trxday'); trxday = v
+      case ('srxday'); srxday = v
+      case ('trxdpt'); trxdpt = v
+      case ('srxdpt'); srxdpt = v
+      case ('trxlim'); trxlim = v
+      case ('srxlim'); srxlim = v
+      case ('sref'); sref = v
+      case ('area'); area = v
+      case ('xmi'); xmi = v
 #endif
 #ifdef XCHECK_EDDTRA
       case ('ce'); ce = v
@@ -263,6 +289,22 @@ contains
       case ('csdiag');     csdiag = (v /= 0)
       case ('cnsvdi');     cnsvdi = (v /= 0)
       case ('bdmldp');     bdmldp = (v /= 0)
+#ifdef XCHECK_ML
+      ! mod_forcing's switches of thermf and mod_time's calendar position (phy/mod_forcing.F90:43-47, phy/mod_time.F90)
+      case ('aptflx');     aptflx = (v /= 0)
+      case ('apsflx');     apsflx = (v /= 0)
+      case ('ditflx');     ditflx = (v /= 0)
+      case ('disflx');     disflx = (v /= 0)
+      case ('srxbal');     srxbal = (v /= 0)
+      case ('nday_of_year'); nday_of_year = v
+      case ('nstep_in_day'); nstep_in_day = v
+      case ('l1mi'); l1mi = v
+      case ('l2mi'); l2mi = v
+      case ('l3mi'); l3mi = v
+      case ('l4mi'); l4mi = v
+      case ('l5mi'); l5mi = v
+      case ('ntda'); ntda = v
+#endif
       case default; ierr = 1
     end select
   end subroutine ref_set_int
@@ -295,6 +337,9 @@ contains
       case ('cppm_compatibility'); cppm_compatibility = trim(cstr(s))
       case ('cppm_limiting'); cppm_limiting = trim(cstr(s))
       case ('bmcmth'); bmcmth = trim(cstr(s))
+#ifdef XCHECK_ML
+      case ('mlrttp'); mlrttp = trim(cstr(s))
+#endif
       case ('eitmth')            ! readnml_diffusion's translation, phy/mod_diffusion.F90:316-327
         if (trim(cstr(s)) == 'intdif') then
           eitmth_opt = eitmth_intdif
@@ -508,12 +553,47 @@ contains
       R2(hml_tf)
       R2(OBLdepth)
 #endif
-#ifdef XCHECK_ALE
+#if defined(XCHECK_ALE) || defined(XCHECK_ML)
       R2(swfc1)
       R2(swfc2)
       R2(swal1)
       R2(swal2)
 #endif
+#ifdef XCHECK_ML
+      R2(idkedt)
+      R2(mtkeus)
+      R2(mtkeni)
+      R2(mtkebf)
+      R2(mtkers)
+      R2(mtkepe)
+      R2(mtkeke)
+      R2(pbrnda)
+      R3(uml, 4)
+      R3(vml, 4)
+      R3(umlres, 2)
+      R3(vmlres, 2)
+#endif
+      ! mod_forcing: friction velocity and the forcing fields of thermf (phy/mod_forcing.F90:100-175)
+      R2(ustar)
+      R2(ustar3)
+      R2(ustarw)
+      R2(swa)
+      R2(nsf)
+      R2(hmltfz)
+      R2(lip)
+      R2(sop)
+      R2(eva)
+      R2(rnf)
+      R2(rfi)
+      R2(fmltfz)
+      R2(sfl)
+      R3(sstclm, 12)
+      R3(ricclm, 12)
+      R3(sssclm, 12)
+      R3(tflxap, 48)
+      R3(sflxap, 48)
+      R3(tflxdi, 48)
+      R3(sflxdi, 48)
       case ('trc_corr')
         if (allocated(trc_corr)) then
           call ref_capture_r8(trc_corr, ptr); nlev = ntr
@@ -564,6 +644,18 @@ contains
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
       case ('cmnfld_bfsqi_ale'); call cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)
+#endif
+#ifdef XCHECK_ML
+      case ('mxlayr_init'); call inivar_mxlayr; call inivar_niw
+      case ('mxlayr')
+        if (allocated(trflx_ij)) then          ! trflx is shown as trflx_ij(i,j,ntr): see ref_field
+          do nt_ = 1, ntr
+            trflx(nt_,:,:) = trflx_ij(:,:,nt_)
+          end do
+        end if
+        call mxlayr(m,n,mm,nn,k1m,k1n)
+      case ('niw_ke_tendency'); call niw_ke_tendency(m,n,mm,nn,k1m,k1n)
+      case ('thermf');  call thermf_channel(m,n,mm,nn,k1m,k1n)
 #endif
 #ifdef WITH_ALE_VDIFF
       case ('ale_vdifft')
