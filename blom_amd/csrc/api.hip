@@ -214,6 +214,16 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   if (s == "swamxd") { c->swamxd = v; return 0; }                           // phy/mod_swabs.F90:179-183
   if (s == "brine_mlbase_frac") { c->brine_mlbase_frac = v; return 0; }     // phy/mod_forcing.F90:63
   // mod_mxlayr's and mod_niw's namelist variables (phy/mod_mxlayr.F90:58-68, phy/mod_niw.F90:38-45)
+  // thermf: mod_forcing's namelist variables, mod_grid's area, mod_time's interpolation weight of the month
+  if (s == "trxday") { c->trxday = v; return 0; }
+  if (s == "srxday") { c->srxday = v; return 0; }
+  if (s == "trxdpt") { c->trxdpt = v; return 0; }
+  if (s == "srxdpt") { c->srxdpt = v; return 0; }
+  if (s == "trxlim") { c->trxlim = v; return 0; }
+  if (s == "srxlim") { c->srxlim = v; return 0; }
+  if (s == "sref") { c->sref = v; return 0; }
+  if (s == "area") { c->area = v; return 0; }
+  if (s == "xmi") { c->xmi = v; return 0; }
   if (s == "rm0") { c->rm0 = v; return 0; }
   if (s == "rm5") { c->rm5 = v; return 0; }
   if (s == "niwgf") { c->niwgf = v; return 0; }
@@ -254,6 +264,18 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   if (s == "csdiag") { c->csdiag = v != 0; return 0; }
+  // thermf: mod_forcing's switches (phy/mod_forcing.F90:43-47), mod_time's months of the interpolation (l1mi..l5mi), mod_ben02's ntda
+  if (s == "aptflx") { c->aptflx = v != 0; return 0; }
+  if (s == "apsflx") { c->apsflx = v != 0; return 0; }
+  if (s == "ditflx") { c->ditflx = v != 0; return 0; }
+  if (s == "disflx") { c->disflx = v != 0; return 0; }
+  if (s == "srxbal") { c->srxbal = v != 0; return 0; }
+  if (s.size() == 4 && s[0] == 'l' && s[2] == 'm' && s[3] == 'i' && s[1] >= '1' && s[1] <= '5') {
+    if (v < 1 || v > 12) return ctx_fail(c, "blomgpu_set_int: " + s + " is a month, 1..12");
+    c->lmi[s[1] - '1'] = v;
+    return 0;
+  }
+  if (s == "ntda") { c->ntda = v; return 0; }
   if (s == "timing") { c->timing = v != 0; return 0; }
   if (s == "barotp_fused") { c->barotp_fused = v; return 0; }
   if (s == "barotp_tile") {
@@ -540,6 +562,7 @@ int blomgpu_sfcstr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1
 }
 int blomgpu_init_cppm(blomgpu_ctx *c) { ctx_sync_view(c); return st_init_cppm(c); }   // phy/mod_cppm.F90:2504
 int blomgpu_mxlayr_tail(blomgpu_ctx *c, int nn, int k1n) { ctx_sync_view(c); return st_mxlayr_tail(c, nn, k1n); }
+int blomgpu_thermf(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) { ctx_sync_view(c); return st_thermf(c, m, n, mm, nn, k1m, k1n); }
 int blomgpu_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) { ctx_sync_view(c); return st_mxlayr(c, m, n, mm, nn, k1m, k1n); }
 int blomgpu_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {   // phy/mod_ale_regrid_remap.F90:1486
   ctx_sync_view(c);
@@ -638,6 +661,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "halo_difest_vert") return blomgpu_halo_difest_hyb(c, 1, k1n);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
   if (s == "mxlayr") return blomgpu_mxlayr(c, m, n, mm, nn, k1m, k1n);
+  if (s == "thermf") return blomgpu_thermf(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_regrid_remap") return blomgpu_ale_regrid_remap(c, m, n, mm, nn, k1m, k1n);
   if (s == "ale_forcing") return blomgpu_ale_forcing(c, m, n, mm, nn, k1m, k1n);
   if (s == "cmnfld_bfsqi_ale") return blomgpu_cmnfld_bfsqi_ale(c, m, n, mm, nn, k1m, k1n);

@@ -73,6 +73,9 @@
   /* momtum, the other vertical coordinates: the fractions of the wind stress that pass the interfaces (mod_diffusion.F90:139-142) */ \
   X(mu_nonloc, K + 1) X(mv_nonloc, K + 1)                                                                                     \
   X(swfc1, 1) X(swfc2, 1) X(swal1, 1) X(swal2, 1) X(mld, 1) X(mldl82, 1) X(dpml, 1) X(buoyfl, K + 1) X(hbl_tf, 1) X(hml_tf1, 1) X(hml_tf, 1) X(hml_tfbnd, 1) X(OBLdepth, 1)                                                 \
+  /* thermf_channel (channel/mod_thermf_channel.F90): the forcing fields and the climatologies of mod_forcing it reads / sets */   \
+  X(swa, 1) X(nsf, 1) X(hmltfz, 1) X(lip, 1) X(sop, 1) X(eva, 1) X(rnf, 1) X(rfi, 1) X(fmltfz, 1) X(sfl, 1) X(ustarw, 1)           \
+  X(sstclm, 12) X(ricclm, 12) X(sssclm, 12)                                                                                      \
   /* mxlayr (mod_mxlayr.F90:70-91 diagnostics; mod_forcing ustar, ustar3; mod_niw idkedt) */                                  \
   X(ustar, 1) X(ustar3, 1) X(idkedt, 1) X(mtkeus, 1) X(mtkeni, 1) X(mtkebf, 1) X(mtkers, 1) X(mtkepe, 1) X(mtkeke, 1) X(pbrnda, 1)   \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
@@ -259,6 +262,12 @@ struct blomgpu_ctx {
   // mod_mxlayr's namelist variables (cime_config/namelist_definition_blom.xml: rm0 = 1.2, rm5 = 0, mlrttp = 'constant'), mod_niw's
   double rm0 = 1.2, rm5 = 0., niwgf = 0., niwbf = .35, niwlf = .5;
   std::string mlrttp = "constant";
+  // thermf (mod_forcing's namelist variables, phy/mod_forcing.F90:43-62, :84; mod_grid's area; mod_time's position in the year,
+  // phy/mod_time.F90: xmi, l1mi..l5mi; mod_ben02's ntda)
+  double trxday = 0., srxday = 0., trxdpt = 1., srxdpt = 1., trxlim = 1.5, srxlim = .5, sref = 34.65, area = 0., xmi = 0.;
+  int lmi[5] = {11, 12, 1, 2, 3};
+  bool aptflx = false, apsflx = false, ditflx = false, disflx = false, srxbal = false;
+  int ntda = 0;
   double swamxd = 200., brine_mlbase_frac = 0.;           // phy/mod_swabs.F90:183 (default); phy/mod_forcing.F90:63 (namelist)
   void *ale = nullptr;
   double *ale_plevel = nullptr;
@@ -286,6 +295,7 @@ struct blomgpu_ctx {
   double *arc_strip = nullptr;                 // arctic patch, tiles of one process in strips mode: this tile's strip
   size_t arc_cap = 0;
   int arctic_strips = 0;                       // tiles of one process: arctic fold through packed strips (test of the RCCL path's kernels)
+  double *xcsum_dev = nullptr;                 // sums that stay on the device (thermf), 8 slots
   double *xcsum_buf = nullptr;                 // [0] the sum, [1..jj] the row sums of xcsum
   int cnsvdi = 0;                              // mod_budget: conservation diagnostics on/off
   double budget[4][7][2] = {};                 // sdp, tdp, trdp, tkedp (ncall, n)
@@ -329,6 +339,8 @@ int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_convec(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_updtrc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_xcsum(blomgpu_ctx *, const double *a, int itype, double *sum);
+int st_xcsum_dev(blomgpu_ctx *, const double *a, int itype, int slot, double **sums_dev);   // the sum stays on the device: sums_dev[slot]
+int st_thermf(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_thermf.hip
 int st_budget_sums(blomgpu_ctx *, int ncall, int n, int nn);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);

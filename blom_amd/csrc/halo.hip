@@ -778,6 +778,21 @@ __global__ void k_xcsum(const DevView *__restrict__ Vp, const double *__restrict
   }
 }
 
+// the same sum left on the device (slot of c->xcsum_dev): stages that only hand it to their next kernel stay capturable
+int st_xcsum_dev(blomgpu_ctx *c, const double *a, int itype, int slot, double **sums_dev) {
+  const DevView &h = c->h;
+  if (c->tiling.multi()) return ctx_fail(c, "xcsum: built for a single tile");
+  if (!c->xcsum_buf) HIPCHK(c, hipMalloc((void **)&c->xcsum_buf, sizeof(double) * (size_t)(h.jj + 8)));
+  if (!c->xcsum_dev) HIPCHK(c, hipMalloc((void **)&c->xcsum_dev, sizeof(double) * 8));
+  const int g = itype % 10;
+  const int *mask = g == 1 ? h.m[I_ip] : g == 2 ? h.m[I_iq] : g == 3 ? h.m[I_iu] : h.m[I_iv];
+  hipLaunchKernelGGL(k_xcsum, dim3(1), dim3(256), 0, c->stream, c->d, a, mask, (g == 1 && h.nreg == 2) ? 1 : 0,
+                     c->xcsum_buf + 1, c->xcsum_dev + slot);
+  HIPCHK(c, hipGetLastError());
+  *sums_dev = c->xcsum_dev;
+  return 0;
+}
+
 int st_xcsum(blomgpu_ctx *c, const double *a, int itype, double *sum) {
   const DevView &h = c->h;
   if (c->tiling.multi()) return ctx_fail(c, "xcsum: built for a single tile");

@@ -128,6 +128,13 @@ int  blomgpu_cmnfld2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
 int  blomgpu_cmnfld1(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int  blomgpu_halo_difest (blomgpu_ctx *, int nn);
 int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
+/* phy/mod_thermf.F90:35 thermf(m,n,mm,nn,k1m,k1n), for expcnf = 'channel' channel/mod_thermf_channel.F90:56: surface fluxes of
+ * heat (surflx, sswflx, surrlx), salt (salflx, brnflx, salrlx) and tracers (trflx), the friction velocity ustar, from the forcing
+ * fields swa, nsf, eva, lip, sop, rnf, rfi, ustarw and the climatologies sstclm, ricclm, sssclm; options blomgpu_set_real "trxday",
+ * "srxday", "trxdpt", "srxdpt", "trxlim", "srxlim", "sref", "area", "xmi", blomgpu_set_int "l1mi".."l5mi" (mod_time's position
+ * in the year), "aptflx", "apsflx", "ditflx", "disflx", "srxbal" (refused when set: not built).  PARITY UNPINNED (the module
+ * imports the netCDF-bound mod_ben02): cross-checked against the real module behind a stand-in, tests/test_xcheck_thermf.py. */
+int  blomgpu_thermf (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* phy/mod_mxlayr.F90:130 mxlayr(m,n,mm,nn,k1m,k1n): the bulk mixed layer of vcoord_type = 'isopyc_bulkml' (turbulent kinetic
  * energy balance, detrainment / entrainment, surface forcing, the new layer structure at the velocity points), called after
  * thermf (phy/mod_blom_step.F90:188-192).  Reads the surface fluxes surflx, surrlx, sswflx, salflx, brnflx, salrlx, trflx, the

@@ -655,7 +655,18 @@ contains
         end if
         call mxlayr(m,n,mm,nn,k1m,k1n)
       case ('niw_ke_tendency'); call niw_ke_tendency(m,n,mm,nn,k1m,k1n)
-      case ('thermf');  call thermf_channel(m,n,mm,nn,k1m,k1n)
+      case ('thermf')
+        if (allocated(trflx_ij)) then
+          do nt_ = 1, ntr
+            trflx(nt_,:,:) = trflx_ij(:,:,nt_)
+          end do
+        end if
+        call thermf_channel(m,n,mm,nn,k1m,k1n)
+        if (allocated(trflx_ij)) then          ! show the tracer fluxes it computed (trflx_ij: see ref_field)
+          do nt_ = 1, ntr
+            trflx_ij(:,:,nt_) = trflx(nt_,:,:)
+          end do
+        end if
 #endif
 #ifdef WITH_ALE_VDIFF
       case ('ale_vdifft')
