@@ -265,6 +265,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
 #undef R
   if (s == "csdiag") { c->csdiag = v != 0; return 0; }
   // thermf: mod_forcing's switches (phy/mod_forcing.F90:43-47), mod_time's months of the interpolation (l1mi..l5mi), mod_ben02's ntda
+  if (s == "full_physics") { c->full_physics = v != 0; if (v) c->live_slopes = true; return 0; }
   if (s == "aptflx") { c->aptflx = v != 0; return 0; }
   if (s == "apsflx") { c->apsflx = v != 0; return 0; }
   if (s == "ditflx") { c->ditflx = v != 0; return 0; }
@@ -657,6 +658,8 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "cmnfld2") return blomgpu_cmnfld2(c, m, n, mm, nn, k1m, k1n);
   if (s == "cmnfld1") return blomgpu_cmnfld1(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
+  if (s == "difest_isobml_pre") { ctx_sync_view(c); return st_difest_isobml_pre(c, m, n, mm, nn); }
+  if (s == "niw_ke_tendency") { ctx_sync_view(c); return st_niw_ke_tendency(c, m, mm); }
   if (s == "halo_difest_hyb") return blomgpu_halo_difest_hyb(c, 0, k1n);
   if (s == "halo_difest_vert") return blomgpu_halo_difest_hyb(c, 1, k1n);
   if (s == "mxlayr_tail") return blomgpu_mxlayr_tail(c, nn, k1n);
@@ -701,6 +704,16 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   for (const char *st : seq) {
     // live_slopes: cmnfld2 (the halo updates plus buoyancy frequency and neutral slopes) in place of its halo part alone
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
+    // full_physics (blom_amd/stepper.py FULL_STAGES): the built part of difest_isobml, thermf and mxlayr in place of the two
+    // pseudo-stages that stood in for them
+    if (c->full_physics && !strcmp(st, "halo_difest")) run = "difest_isobml_pre";
+    if (c->full_physics && !strcmp(st, "mxlayr_tail")) {
+      if (int rc = blomgpu_stage(c, "thermf", m, n, mm, nn, k1m, k1n)) {
+        c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+        return rc;
+      }
+      run = "mxlayr";
+    }
     // eddtra_frozen: the eddy-induced fluxes umfltd.. stay as uploaded (the reference build of the oracle has no mod_eddtra;
     // tests pin advect/remap on non-zero fluxes this way)
     if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
@@ -713,7 +726,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   }
   c->defer_checks = false;
   c->in_sequence = false;
-  if (c->cmnfld1) return blomgpu_stage(c, "cmnfld1", m, n, mm, nn, k1m, k1n);     // phy/mod_blom_step.F90:233
+  if (c->cmnfld1 || c->full_physics) return blomgpu_stage(c, "cmnfld1", m, n, mm, nn, k1m, k1n);     // phy/mod_blom_step.F90:233
   return 0;
 }
 

@@ -76,6 +76,8 @@
   /* thermf_channel (channel/mod_thermf_channel.F90): the forcing fields and the climatologies of mod_forcing it reads / sets */   \
   X(swa, 1) X(nsf, 1) X(hmltfz, 1) X(lip, 1) X(sop, 1) X(eva, 1) X(rnf, 1) X(rfi, 1) X(fmltfz, 1) X(sfl, 1) X(ustarw, 1)           \
   X(sstclm, 12) X(ricclm, 12) X(sssclm, 12)                                                                                      \
+  /* niw_ke_tendency (mod_niw.F90:52-65): mixed layer velocities of the last steps and their running-mean reservoirs */          \
+  X(uml, 4) X(vml, 4) X(umlres, 2) X(vmlres, 2)                                                                                   \
   /* mxlayr (mod_mxlayr.F90:70-91 diagnostics; mod_forcing ustar, ustar3; mod_niw idkedt) */                                  \
   X(ustar, 1) X(ustar3, 1) X(idkedt, 1) X(mtkeus, 1) X(mtkeni, 1) X(mtkebf, 1) X(mtkers, 1) X(mtkepe, 1) X(mtkeke, 1) X(pbrnda, 1)   \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
@@ -268,6 +270,7 @@ struct blomgpu_ctx {
   int lmi[5] = {11, 12, 1, 2, 3};
   bool aptflx = false, apsflx = false, ditflx = false, disflx = false, srxbal = false;
   int ntda = 0;
+  bool full_physics = false;  // blomgpu_step runs difest_isobml_pre, thermf, mxlayr (+ cmnfld2, cmnfld1): stepper.py FULL_STAGES
   double swamxd = 200., brine_mlbase_frac = 0.;           // phy/mod_swabs.F90:183 (default); phy/mod_forcing.F90:63 (namelist)
   void *ale = nullptr;
   double *ale_plevel = nullptr;
@@ -341,6 +344,8 @@ int st_updtrc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_xcsum(blomgpu_ctx *, const double *a, int itype, double *sum);
 int st_xcsum_dev(blomgpu_ctx *, const double *a, int itype, int slot, double **sums_dev);   // the sum stays on the device: sums_dev[slot]
 int st_thermf(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_thermf.hip
+int st_niw_ke_tendency(blomgpu_ctx *, int m, int mm);                           // stage_difest.hip
+int st_difest_isobml_pre(blomgpu_ctx *, int m, int n, int mm, int nn);
 int st_budget_sums(blomgpu_ctx *, int ncall, int n, int nn);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);

@@ -215,7 +215,8 @@ int st_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) {
     hipLaunchKernelGGL(k_diapfl_momentum, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, nn);
     // inside blomgpu_step the stage that follows (mxlayr's tail, phy/mod_mxlayr.F90:1266-1310) recomputes dpu, dpv of this
     // level from the same p with the same expression over a larger range before anything reads them: skipped there
-    if (!c->in_sequence) hipLaunchKernelGGL(k_diapfl_dpudpv, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    // (with full_physics the real mxlayr follows, which reads them first)
+    if (!c->in_sequence || c->full_physics) hipLaunchKernelGGL(k_diapfl_dpudpv, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
   }
   HIPCHK(c, hipGetLastError());
   // the reference aborts (xchalt) when the implicit solve does not converge, :520-530

@@ -456,6 +456,40 @@ def step_indices(nstep, kk):
     return m, n, mm, nn, 1 + mm, 1 + nn
 
 
+def init_forcing(be, case):
+    """The forcing thermf_channel and mxlayr read, for the idealised channel (channel/mod_channel.F90:365-394: everything zero but
+    the open-water friction velocity 0.005 m/s, the climatologies set to constants that the default relaxation time scales of 0
+    days never touch), the shortwave absorption of Jerlov water type 3 (phy/mod_swabs.F90:104-107, :262-267: the defaults of
+    isopyc_bulkml, cime_config/namelist_definition_blom.xml swamth / jwtype), zero friction velocity and zeroed reservoirs at the
+    start (phy/mod_forcing.F90:310, phy/mod_niw.F90:85-112), the ocean area (mod_grid: area, the xcsum of scp2 over ips)."""
+    nj, ni = case.jdm + 2 * NBDY, case.idm + 2 * NBDY
+    one = np.ones((1, nj, ni))
+    vals = dict(ustarw=0.005, swa=0.0, nsf=0.0, hmltfz=0.0, lip=0.0, sop=0.0, eva=0.0, rnf=0.0, rfi=0.0, fmltfz=0.0, sfl=0.0,
+                swfc1=0.67, swfc2=1.0 - 0.67, swal1=1.0, swal2=17.0, ustar=0.0, ustar3=0.0, idkedt=0.0,
+                surflx=0.0, sswflx=0.0, surrlx=0.0, salflx=0.0, brnflx=0.0, salrlx=0.0, salt_corr=0.0)
+    has = getattr(be, "has_field", lambda nm: True)
+    for nm, v in vals.items():
+        if has(nm):
+            be.put(nm, v * one)
+    for nm, v, nl in (("sstclm", 10.0, 12), ("ricclm", 0.0, 12), ("sssclm", 35.0, 12), ("uml", 0.0, 4), ("vml", 0.0, 4),
+                      ("umlres", 0.0, 2), ("vmlres", 0.0, 2)):
+        if has(nm):
+            be.put(nm, np.full((nl, nj, ni), v))
+    if case.ntr:
+        for nm in ("trflx", "trc_corr"):
+            if has(nm):
+                be.put(nm, np.zeros((case.ntr, nj, ni)))
+    ip = be.masks["ip"] if hasattr(be, "masks") else None
+    if ip is not None:
+        scp2 = np.asarray(be.get("scp2"))[0]
+        w = (ip[NBDY:-NBDY, NBDY:-NBDY] > 0)
+        if case.nreg == 2:
+            w = w.copy()
+            w[-1, :] = False                          # ips: without the seam row of the arctic patch
+        area = float(np.sum(scp2[NBDY:-NBDY, NBDY:-NBDY][w]))
+        be.set("area", area)
+
+
 def init_indices(nstep1, kk):
     """Time-level sextuple of blom_init (phy/mod_blom_init.F90:256-261: m = mod(nstep1+1,2)+1, n = mod(nstep1,2)+1): what its
     start-up cmnfld1 is called with -- the other way round from the first step's."""

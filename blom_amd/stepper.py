@@ -20,6 +20,14 @@ OPTIONAL_STAGES = ("eddtra",)
 # mxlayr_tail : phy/mod_mxlayr.F90:1266-1310, halo of dp at the new level + dpu/dpv.
 
 
+# Config 2 "full blom_step" as far as it is built: cmnfld2 on the live state, the part of difest_isobml in front
+# of the diffusivity estimates (halos, interface pressure, ustar3, niw_ke_tendency: "difest_isobml_pre"), thermf and mxlayr in
+# place of the mxlayr_tail pseudo-stage, cmnfld1 at the end -- the order of phy/mod_blom_step.F90:126-233 for isopyc_bulkml.
+# Still frozen: the diffusivities themselves (difest_common/vertical/lateral_iso need CVMix at module level).
+FULL_STAGES = tuple({"halo_cmnfld2": "cmnfld2", "halo_difest": "difest_isobml_pre"}.get(s, s) for s in DYNCORE_STAGES
+                    if s != "mxlayr_tail")
+FULL_STAGES = FULL_STAGES[:FULL_STAGES.index("diapfl") + 1] + ("thermf", "mxlayr") + FULL_STAGES[FULL_STAGES.index("diapfl") + 1:] + ("cmnfld1",)
+
 STAGES_FROZEN_EDDY_FLUXES = tuple(s for s in DYNCORE_STAGES if s != "eddtra")    # umfltd.. stay as uploaded
 
 # The step of the other vertical coordinates (vcoord_type = 'cntiso_hybrid' or 'plevel'), phy/mod_blom_step.F90:126-233, as far

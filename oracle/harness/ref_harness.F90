@@ -655,6 +655,18 @@ contains
         end if
         call mxlayr(m,n,mm,nn,k1m,k1n)
       case ('niw_ke_tendency'); call niw_ke_tendency(m,n,mm,nn,k1m,k1n)
+      ! difest_isobml up to and including niw_ke_tendency (phy/mod_difest.F90:750-790; the diffusivity estimates behind it need
+      ! CVMix): the halo updates and the pressure scan as under 'halo_difest', ustar3 RESTATED (:778-786), the real niw_ke_tendency
+      case ('difest_isobml_pre')
+        call xctilr(u, 1,2*kk, 2,2, halo_uv)
+        call xctilr(v, 1,2*kk, 2,2, halo_vv)
+        call xctilr(ubflxs_p, 1,2, 2,2, halo_uv)
+        call xctilr(vbflxs_p, 1,2, 2,2, halo_vv)
+        call xctilr(pbu, 1,2, 2,2, halo_us)
+        call xctilr(pbv, 1,2, 2,2, halo_vs)
+        call difest_p(nn)
+        call difest_ustar3
+        call niw_ke_tendency(m,n,mm,nn,k1m,k1n)
       case ('thermf')
         if (allocated(trflx_ij)) then
           do nt_ = 1, ntr
@@ -718,6 +730,20 @@ contains
       case default; ierr = 1
     end select
   end subroutine ref_stage
+
+#ifdef XCHECK_ML
+  subroutine difest_ustar3
+    ! RESTATEMENT of phy/mod_difest.F90:778-786
+    integer :: i, j, l
+    do j = 1,jj
+      do l = 1,isp(j)
+        do i = max(1,ifp(j,l)),min(ii,ilp(j,l))
+          ustar3(i,j) = ustar(i,j)**3
+        end do
+      end do
+    end do
+  end subroutine difest_ustar3
+#endif
 
   subroutine cmnfld2_kfpla(n)
     ! RESTATEMENT of the halo update of kfpla through util1, phy/mod_cmnfld_routines.F90:1176-1196

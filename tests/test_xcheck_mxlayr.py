@@ -171,3 +171,42 @@ def test_mxlayr_refuses_what_the_reference_refuses():
     with pytest.raises(BlomGpuError, match="isopyc_bulkml"):
         gpu.stage("mxlayr", *six)
     gpu.close()
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 3), ("box_s", 4), ("tri_s_tke", 3)])
+def test_device_niw_ke_tendency_equals_the_real_module(cfg, nsteps):
+    """The built part of difest_isobml (phy/mod_difest.F90:778-790): near-inertial wave energy input idkedt with its running-mean
+    reservoirs, against the reference's real phy/mod_niw.F90 (no stand-in inside mod_niw; the library is an *_xml one), called
+    three times in a row with alternating time levels as blom_step does."""
+    from oracle.refblom import get_ref_backend, have_ref
+    from blom_amd.gpu import BlomGpu
+    lib = cfg.replace("_tke", "") + "_xml"
+    if not have_ref(lib):
+        pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
+    case = make_case(cfg)
+    ref = get_ref_backend(lib, case.depth)
+    kk = case.kdm
+    gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
+    hostinit.init_state(gpu, case)
+    assert gpu.step(0, nsteps) == nsteps
+    hostinit.init_state(ref, case)
+    copy_state(gpu, ref, fields=STATE_FIELDS + GRID_FIELDS + INT_FIELDS)
+    ref.ref.stage("mxlayr_init", *hostinit.step_indices(nsteps, kk))
+    fields = ["uml", "vml", "umlres", "vmlres", "idkedt"]
+    for nm in fields:
+        gpu.put(nm, ref.get(nm))
+    delt1 = 2.0 * case.params["baclin"]
+    ref.ref.set("delt1", delt1)
+    gpu.set("delt1", delt1)
+    amax = 0.0
+    for it in range(3):
+        six = hostinit.step_indices(nsteps + it, kk)
+        ref.ref.stage("niw_ke_tendency", *six)
+        gpu.stage("niw_ke_tendency", *six)
+        bad = diff_report(ref, gpu, fields=fields + ["util1", "util2"])
+        assert not bad, f"call {it + 1}\n" + fmt_report(bad[:10])
+        a = gpu.get("idkedt")[0, 4:-4, 4:-4][ref.masks["ip"][4:-4, 4:-4] > 0]
+        assert np.isfinite(a).all()
+        amax = max(amax, float(a.max()))
+    assert amax > 0.0
+    gpu.close()
