@@ -78,6 +78,18 @@ def class_bytes_F(ntr, ntr_dif=None):
     }
 
 
+def kernel_bytes_F(ntr, nadv):
+    """Algorithmic bytes of the kernels that can be the step's longest one, in units of F: every distinct array the KERNEL reads or
+    writes counted once (its scratch planes are outputs / inputs like any other: they are what the kernel is asked to move).
+      k_remap_tile      R dp, T, S, nadv tracers (time level n), cau, cav; W the six mass / heat / salt flux planes + 2 per tracer
+      k_mom_cor_march   R dp, u, v (m), u, v (n), dpu, dpv, p, pgfx, pgfy (m, n, old), dpuold, dpvold, visu, visv;
+                        W the four updated-velocity planes, absvor, dpvor
+      k_mom_visc_march  R u, v (n), pu, pv, dpu, dpv; W visu, visv
+      k_diapfl_column3  R T, S, dp, sigma, tracers, sigmar, difdia; W T, S, dp, sigma, tracers, p, fpug, fplg, difdia"""
+    return {"k_remap_tile": (3 + nadv + 2) + (6 + 2 * nadv), "k_mom_cor_march": 18 + 6, "k_mom_visc_march": 6 + 2,
+            "k_diapfl_column3": (6 + ntr) + (8 + ntr)}
+
+
 KNOWN_CONFIGS = ("channel", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")
 
 
@@ -103,6 +115,34 @@ def class_traffic(config, ntr=1):
         if d.get("ntr", 1) == ntr:                      # a profile of this very workload
             return d.get("bytes_per_step", {}), os.path.basename(f)
     return None, None
+
+
+def kernel_traffic(config, name):
+    """counted HBM bytes per launch of a kernel in the committed PMC summary of this configuration (2 x FETCH_SIZE + WRITE_SIZE)"""
+    for f in reversed(_profiles_of(config, "pmc_hbm_traffic.txt")):
+        for line in open(f):
+            if line.startswith("#"):
+                continue
+            parts = line.split()
+            if len(parts) >= 5 and " ".join(parts[:-4]).startswith(name):
+                return (float(parts[-2]) + float(parts[-1])) * 1e6, os.path.basename(f)
+    return None, None
+
+
+def roofline_of_kernel(kern, kb, F, config):
+    """the `roofline` object for the HBM-bound kernel with the longest launch of this run (HIP events around its launches on the
+    library's stream): its own algorithmic bytes (kernel_bytes_F) over its average launch duration"""
+    cand = {k: v for k, v in kern.items() if k in kb}
+    if not cand:
+        return None
+    k = max(cand, key=lambda q: cand[q][0])
+    ms, per_step = cand[k]
+    ach = kb[k] * F / (ms * 1e-3) / 1e9
+    tr, src = kernel_traffic(config, k)
+    r = {"bound": "hbm", "kernel": k, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr,
+         "traffic_source": src, "algorithmic_bytes": kb[k] * F, "avg_ms": ms, "launches_per_step": per_step,
+         "other_kernels": {q: {"avg_ms": v[0], "frac": kb[q] * F / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS} for q, v in cand.items() if q != k}}
+    return r
 
 
 def dominant_kernel(config):
@@ -138,21 +178,21 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False):
     """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
     2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
     default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
     import threading
     res = {}
     threading.stack_size(2 << 30)
-    th = threading.Thread(target=lambda: res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live)))
+    th = threading.Thread(target=lambda: res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full)))
     th.start()
     th.join()
     threading.stack_size(0)
     return res
 
 
-def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False):
     """The reference's own Fortran (preferred) or the C restatement, timed on the host for a bounded number of steps.
     Preferred build: oracle/_ref/<cfg>_omp_xed -- the reference's hot-path modules INCLUDING its real mod_cmnfld_routines and
     mod_eddtra (compiled against the two small stand-in modules of oracle/xcheck/, see there), with its OpenMP directives
@@ -160,13 +200,17 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
     the reference's code on all host cores.  Without it: <cfg>_omp, which lacks those two stages -- they are then timed on the
     C restatement on one thread and reported beside `value`, not inside it."""
     from blom_amd import hostinit
-    from blom_amd.stepper import dyncore_step, DYNCORE_STAGES
+    from blom_amd.stepper import dyncore_step, DYNCORE_STAGES, FULL_STAGES
     from oracle.refblom import get_ref_backend, have_ref
     from oracle.coracle import COracle
     ncores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(ncores)
-    full = have_ref(cfg + "_omp_xed")
-    ref_cfg = cfg + "_omp_xed" if full else (cfg + "_omp" if have_ref(cfg + "_omp") else (cfg if have_ref(cfg) else None))
+    # --physics full: the build with the reference's real mod_thermf_channel, mod_mxlayr, mod_niw as well (oracle/Makefile *_xml)
+    xml = full_physics and have_ref(cfg + "_omp_xml")
+    if full_physics and not xml:
+        return {"error": f"oracle/_ref/{cfg}_omp_xml/libblomref.so is missing: no CPU baseline for --physics full"}
+    full = xml or have_ref(cfg + "_omp_xed")
+    ref_cfg = cfg + "_omp_xml" if xml else cfg + "_omp_xed" if full else (cfg + "_omp" if have_ref(cfg + "_omp") else (cfg if have_ref(cfg) else None))
     stages = DYNCORE_STAGES
     note, de, dc = "", 0.0, 0.0
     if ref_cfg is not None and not full:
@@ -209,7 +253,9 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
             if full:
                 be.ref.set("eitmth", "gm")
                 be.has_stage = lambda name: True             # this build's harness knows eddtra and cmnfld2
-                if live:
+                if xml:
+                    stages = FULL_STAGES
+                elif live:
                     stages = tuple("cmnfld2" if s_ == "halo_cmnfld2" else s_ for s_ in DYNCORE_STAGES)
                 note = ("; every stage in the reference's own code, mod_cmnfld_routines and mod_eddtra compiled against the "
                         "stand-in modules of oracle/xcheck/ (one array of mod_difest, the diagnostic flags of mod_dia)")
@@ -219,6 +265,17 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
         be = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
         kind = "port"
     hostinit.init_state(be, case)
+    if xml:
+        six0 = hostinit.step_indices(0, case.kdm)
+        be.ref.stage("mxlayr_init", *six0)
+        hostinit.init_forcing(be, case)
+        for nm, v in dict(rm0=1.2, rm5=0.0, niwgf=0.0, niwbf=0.35, niwlf=0.5, ce=0.06, tau_mlr=86400.0, lfmin=5.0e3, swamxd=200.0, sref=34.65,
+                          xmi=0.0, trxday=0.0, srxday=0.0, trxdpt=1.0, srxdpt=1.0, trxlim=1.5, srxlim=0.5).items():
+            be.ref.set(nm, float(v))
+        be.ref.set("mlrttp", "constant")
+        for nm, v in dict(l1mi=11, l2mi=12, l3mi=1, l4mi=2, l5mi=3, aptflx=0, apsflx=0, ditflx=0, disflx=0, srxbal=0, nstep_in_day=96,
+                          nday_of_year=1, nday_in_year=365).items():
+            be.ref.set(nm, int(v))
     ns = dyncore_step(be, 0, case.params["baclin"], stages=stages)          # forward first step (untimed)
     # per-stage host times beside the device's stages_ms: the hook fires before every stage
     per_stage, mark = {}, [None, 0.0]
@@ -243,7 +300,9 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True):
     if "advect" in stages_ms:
         stages_ms[case.params.get("advmth", "remap")] = stages_ms.pop("advect")
     if "cmnfld2" in stages_ms:
-        stages_ms["cmnfld"] = stages_ms.pop("cmnfld2")
+        stages_ms["cmnfld"] = stages_ms.pop("cmnfld2") + stages_ms.pop("cmnfld1", 0.0)
+    if "difest_isobml_pre" in stages_ms:
+        stages_ms["difest"] = stages_ms.pop("difest_isobml_pre")
     return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=cores, kind=kind, stages_ms=stages_ms,
                 reference_only_ms=round(ref_only_ms, 2), steps_timed=n,
                 build=ref_cfg,
@@ -437,6 +496,11 @@ def main():
     ap.add_argument("--slopes", default="live", choices=["live", "frozen"],
                     help="live: cmnfld2 computes the neutral slopes eddtra consumes every step (phy/mod_cmnfld_routines.F90:1158); "
                          "frozen: round 1's analytic pattern of amplitude NSLP0")
+    ap.add_argument("--physics", default="full", choices=["full", "dyncore"],
+                    help="full (default, single tile): config 2's sequence as far as built -- cmnfld2, the built part of difest_isobml "
+                         "(ustar3, niw_ke_tendency), thermf, mxlayr, cmnfld1 besides the dynamical core (stepper.FULL_STAGES); "
+                         "dyncore: the dynamical core alone, as in rounds 1-3 (the only form on several tiles: thermf's global "
+                         "sums are single-tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs of kernel variants, e.g. barotp_tile=3216 (default: production kernels)")
@@ -533,6 +597,11 @@ def main():
     if layout is None:
         hostinit.init_state(gpu, case)
     gpu.set("live_slopes", 1 if args.slopes == "live" else 0)
+    full = args.physics == "full" and world == 1 and layout is None and not args.rccl_self and args.slopes == "live"
+    if full:
+        # the channel experiment's own forcing (channel/mod_channel.F90:365-394): zero fluxes, open-water friction velocity
+        hostinit.init_forcing(gpu, case)
+        gpu.set("full_physics", 1)
     for o in args.opt:
         nm, v = o.split("=")
         gpu.set(nm, int(v))
@@ -545,7 +614,8 @@ def main():
     if args.warmup > 1:
         ns = gpu.step(ns, args.warmup - 1)
     gpu.sync()
-    classes = ["cmnfld", "eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "barotp", "pbcor1", "pbcor2"]
+    classes = ["cmnfld", "difest", "eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "thermf", "mxlayr", "barotp",
+               "pbcor1", "pbcor2"]
     stage_ms = {}
     for cl in classes:
         ms, n = gpu.timer_get(cl)
@@ -578,9 +648,27 @@ def main():
         ms, n = gpu.timer_get(cl)
         if n:
             live[cl] = ms / n
+    kern = {}
+    for kn in ("k_remap_tile", "k_mom_cor_march", "k_mom_visc_march", "k_diapfl_column3", "k_bt_steps"):
+        ms, n = gpu.timer_get(kn)
+        if n:
+            kern[kn] = (ms / n, n / max(1, min(args.steps, 5)))          # average launch duration [ms], launches per step
     gpu.set("timing", 0)
     import numpy as np
     finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
+    crc_state = gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3) if layout is None else None
+    dyncore_ms = None
+    if full:
+        # the dynamical core alone (the sequence rounds 1-3 timed), in the same run on the same device, for comparison
+        gpu.set("full_physics", 0)
+        ns = gpu.step(ns, 3)
+        gpu.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ns = gpu.step(ns, args.steps)
+        gpu.sync()
+        torch.cuda.synchronize()
+        dyncore_ms = (time.perf_counter() - t1) / args.steps * 1e3
     finite = all(launch.all_gather_ints(int(finite), env))
     if layout is not None:
         # xccrc of the whole domain (phy/mod_xc.F90:2195-2322) chained over the tiles: equal to the single tile's
@@ -590,7 +678,7 @@ def main():
         crcs = [chain_crc({k: v["dp"] for k, v in tiles_of.items()}, layout) ^ chain_crc({k: v["u"] for k, v in tiles_of.items()}, layout)]
     else:
         # weak scaling: every tile integrates the same periodic pattern, so all ranks must hold the same bits
-        crcs = launch.all_gather_ints(gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3), env)
+        crcs = launch.all_gather_ints(crc_state, env)
 
     ms_per_step = dt / args.steps * 1e3
     # model days per wall second of the domain that is integrated (for --scaling weak that domain is N times as long:
@@ -602,6 +690,8 @@ def main():
     hbm_classes = {k: v for k, v in live.items() if k in cb}
     dom = max(hbm_classes, key=hbm_classes.get)
     a3d, a2d = algorithmic_bytes(case, case.ntr)
+    kb = kernel_bytes_F(case.ntr, sum(1 for nt in range(1, case.ntr + 1) if not (case.params.get("itrtke", -1) >= 1 and not case.params.get("tkeadv", 1)
+                                                                               and nt in (case.params.get("itrtke"), case.params.get("itrgls")))))
     traffic, traffic_src = class_traffic(args.config, case.ntr)
     out = {
         "metric": "simulated-days/sec", "value": value, "unit": "simulated-days/sec", "n_gpus": world,
@@ -614,15 +704,26 @@ def main():
                                 f"{case.idm}x{case.jdm}x{case.kdm} along i, 1 tile per GPU, ") +
                                f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr} "
                                f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age' if case.ntr == 1 else f'the default three + {case.ntr - 3} passive tracers'}), "
-                               f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; "
-                               f"full dyncore stage sequence incl. cmnfld2, eddtra and convec (gm, " +
+                               f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; " +
+                               (f"config 2's step as far as built (phy/mod_blom_step.F90:96-253: init_fluxes, tmsmt1, cmnfld2, difest_isobml "
+                                f"[halos, pressure, ustar3, niw_ke_tendency; its diffusivity estimates need CVMix: frozen], eddtra, advect, pbcor1, "
+                                f"diffus, pgforc, momtum, convec, diapfl, thermf, mxlayr, updtrc, barotp, pbcor2, tmsmt2, cmnfld1), the channel "
+                                f"experiment's own forcing (zero fluxes, ustarw = 0.005 m/s), (gm, " if full else
+                                f"full dyncore stage sequence incl. cmnfld2, eddtra and convec (gm, ") +
                                (f"neutral slopes from cmnfld2 every step" if args.slopes == "live" else f"frozen slopes of amplitude {NSLP0:g}") + "); "
                                "N>1: halos over RCCL send/recv" + (f", barotropic solve {args.barotp}" if layout is not None else "") + "; state_crc = xccrc(dp) ^ xccrc(u) of the whole domain, "
                                "the same for every N at equal --steps/--warmup" + (" [halo via RCCL self-send]" if args.rccl_self else ""),
                    "eddtra_parity": "unpinned (mod_eddtra needs CVMix: the reference build lacks it; checked against the C restatement)",
                    "state_finite": finite, "tiles_bit_identical": len(set(crcs)) == 1,
                    "state_crc": f"{crcs[0]:08x}"},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
+        "roofline": roofline_of_kernel(kern, kb, F, args.config) or
+                    {"bound": "hbm", "kernel": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get(dom), "traffic_source": traffic_src,
+                     "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom]},
+        # the stage class with the largest time against the bytes SURVEY.md 8(d) gives the class (rounds 1-3 reported this one)
+        "class_roofline": {"bound": "hbm", "class": dom, "achieved": cb[dom] * F / (live[dom] * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": cb[dom] * F / (live[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (traffic or {}).get(dom), "traffic_source": traffic_src,
@@ -632,6 +733,12 @@ def main():
                      "step_hbm_frac": a3d / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1)),
                      "dominant_single_kernel": dominant_kernel(args.config)},
         "step_roofline": {"A3D_bytes": a3d, "A2D_bytes": a2d,
+                          # barotp's substep loop: the 2-D working set it sweeps per step (A2D, SURVEY.md 8d: 62 planes per substep) over
+                          # the time of its k_bt_steps launches -- traffic that stays in registers, LDS and L2, not an HBM figure
+                          "barotp_onchip": ({"kernel": "k_bt_steps", "launches_per_step": kern["k_bt_steps"][1],
+                                             "ms_per_step": kern["k_bt_steps"][0] * kern["k_bt_steps"][1],
+                                             "A2D_GBs": a2d / (kern["k_bt_steps"][0] * kern["k_bt_steps"][1] * 1e-3) / 1e9}
+                                            if "k_bt_steps" in kern else None),
                           "achieved_GBs": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9,
                           "frac": (a3d + a2d) / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * (world if layout is not None else 1)),
                           # HBM bytes the PMC counters saw per step in the committed profile of this workload (all stage
@@ -640,6 +747,10 @@ def main():
                           "counted_traffic_GBs": (sum(traffic.values()) / (ms_per_step * 1e-3) / 1e9) if traffic else None},
         "stages_ms": live,
     }
+    out["config"]["physics"] = "full" if full else "dyncore"
+    if dyncore_ms is not None:
+        out["dyncore_only"] = {"ms_per_step": dyncore_ms, "value": baclin / 86400.0 / (dyncore_ms * 1e-3),
+                               "note": "the dynamical-core sequence of rounds 1-3 (no thermf, mxlayr, difest part, cmnfld1), timed in this run after the main measurement"}
     if world > 1 and layout is None:
         out["tile_days_per_s"] = world * value
     if rank == 0:
@@ -651,7 +762,7 @@ def main():
         os.dup2(2, 1)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live")
+                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live", full=full)
             except Exception as e:                       # the bench line must still be produced
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

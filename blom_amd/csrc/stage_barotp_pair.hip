@@ -697,6 +697,7 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
   c->bt_epoch += (unsigned)niter;
   if (int rc = ctx_err_words(c)) return rc;
   a.abort_word = (unsigned *)(c->err_dev + 2);
+  TimeScope tk(c, "k_bt_steps");
   if (psh.ti == 26 && psh.tj == 16) hipLaunchKernelGGL((k_bt_steps<true, 26, 16>), dim3(nbx, nby), dim3(bt_threads(26, 16)), 0, c->stream, c->d, a);
   else if (psh.ti == 26) hipLaunchKernelGGL((k_bt_steps<true, 26, 15>), dim3(nbx, nby), dim3(bt_threads(26, 15)), 0, c->stream, c->d, a);
   else if (psh.tj == 16) hipLaunchKernelGGL((k_bt_steps<true, 40, 16>), dim3(nbx, nby), dim3(bt_threads(40, 16)), 0, c->stream, c->d, a);

@@ -641,6 +641,7 @@ int diapfl_column3_launch(blomgpu_ctx *c, int n, int nn, int *errflag) {
   if (E_NSLOT > h.nwk) return ctx_fail(c, "diapfl: work space too small");
   const dim3 g = plane_grid(h, 1, 64);
   if ((size_t)g.x * (h.kk + 1) * WNS * 64 > (size_t)h.nwk * h.kk * h.nplane) return ctx_fail(c, "diapfl: work space too small");
+  TimeScope tk(c, "k_diapfl_column3");
   if (c->diapfl_du == 8) hipLaunchKernelGGL(k_diapfl_column3<8>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);
   else if (c->diapfl_du == 2) hipLaunchKernelGGL(k_diapfl_column3<2>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);
   else hipLaunchKernelGGL(k_diapfl_column3<4>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);

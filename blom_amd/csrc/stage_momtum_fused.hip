@@ -759,7 +759,10 @@ static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca
   (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+  { TimeScope tk(c, "k_mom_visc_march");
   hipLaunchKernelGGL(k_mom_visc_march<BS>, dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, c->d, m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
+  }
+  TimeScope tk(c, "k_mom_cor_march");
   if (h.P.mommth == 2)
     hipLaunchKernelGGL((k_mom_cor_march<BS, true>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
   else

@@ -585,11 +585,15 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
   const size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
   const dim3 grid(ntx * nty, h.kk);
   if (fold) {
-    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
-    else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+    {
+      TimeScope tk(c, "k_remap_tile");
+      if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+      else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+    }
     if ((tsel & 3) != 1)                                // (a split launch: after the second part)
       hipLaunchKernelGGL(k_remap_ring, dim3((6 * (h.ii + 6) + 6 * h.jj + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, nn, nadv, L);
   } else {
+    TimeScope tk(c, "k_remap_tile");
     if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
     else hipLaunchKernelGGL((k_remap_tile<false, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
   }

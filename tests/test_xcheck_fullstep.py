@@ -75,8 +75,14 @@ def _full_step_check(cfg, nsteps, relax):
             nr = dyncore_step(ref, nr, case.params["baclin"], stages=FULL_STAGES)
             assert gpu.step(ng, 1) == ng + 1
             ng += 1
-            bad = diff_report(ref, gpu, fields=CHECK)
+            # (the OpenMP build of the reference at channel size leaves utotn, vtotn untouched outside the interior: they are
+            # firstprivate in momtum's layer loop, phy/mod_momtum.F90:342-350 -- interior only there)
+            omp = cfg.startswith("channel")
+            bad = diff_report(ref, gpu, fields=[f for f in CHECK if not (omp and f in ("utotn", "vtotn"))])
             assert not bad, f"step {nr}\n" + fmt_report(bad[:12])
+            if omp:
+                for nm in ("utotn", "vtotn"):
+                    assert np.array_equal(ref.get(nm)[:, 4:-4, 4:-4], gpu.get(nm)[:, 4:-4, 4:-4]), nm
         wet = ref.masks["ip"][4:-4, 4:-4] > 0
         pe = gpu.get("mtkepe")[0, 4:-4, 4:-4][wet]
         assert (pe != 0.0).any(), "mxlayr entrained nowhere"       # (columns of both kinds: tests/test_xcheck_mxlayr.py)
