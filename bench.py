@@ -502,6 +502,8 @@ def main():
                          "dyncore: the dynamical core alone, as in rounds 1-3 (the only form on several tiles: thermf's global "
                          "sums are single-tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dyncore-compare", action="store_true",
+                    help="leave out the extra steps of the dynamical core alone that follow the measurement (profiling runs)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs of kernel variants, e.g. barotp_tile=3216 (default: production kernels)")
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
@@ -658,7 +660,7 @@ def main():
     finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
     crc_state = gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3) if layout is None else None
     dyncore_ms = None
-    if full:
+    if full and not args.no_dyncore_compare:
         # the dynamical core alone (the sequence rounds 1-3 timed), in the same run on the same device, for comparison
         gpu.set("full_physics", 0)
         ns = gpu.step(ns, 3)

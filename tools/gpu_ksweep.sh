@@ -8,7 +8,7 @@ n=0
 for opts in "$@"; do
   n=$((n+1))
   echo "=== run $n: $opts"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$n -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline $opts > $O/kt$n.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$n -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-dyncore-compare $opts > $O/kt$n.log 2>&1
   python3 tools/kstats.py $O/kt$n $PAT
   grep -o '"state_crc": "[0-9a-f]*"' $O/kt$n.log
 done

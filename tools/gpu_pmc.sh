@@ -8,6 +8,6 @@ mkdir -p $O; cd $R
 n=0
 for grp in "$@"; do
   n=$((n+1))
-  rocprofv3 --pmc ${grp//,/ } --output-format csv -d $O/p$n -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $OPTS > $O/p$n.log 2>&1
+  rocprofv3 --pmc ${grp//,/ } --output-format csv -d $O/p$n -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dyncore-compare $OPTS > $O/p$n.log 2>&1
 done
 python3 tools/pmc_summary.py $O $PATS

@@ -5,9 +5,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=$1; OPTS=$2; O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O; cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $OPTS > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline $OPTS > $O/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline $OPTS > $O/pw.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dyncore-compare $OPTS > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-dyncore-compare $OPTS > $O/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-dyncore-compare $OPTS > $O/pw.log 2>&1
 KS=$(ls $O/kt/*/*_kernel_trace.csv | head -1); PF=$(ls $O/pf/*/*_counter_collection.csv | head -1); PW=$(ls $O/pw/*/*_counter_collection.csv | head -1)
 CONFIG=${CONFIG:-channel} python3 tools/prof_summarize.py $TAG $KS $PF $PW > $O/summary.log 2>&1
 cp profiles/${TAG}_* $O/

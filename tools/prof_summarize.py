@@ -28,7 +28,7 @@ def short(name):
 
 
 # kernels the bench itself launches between and after the steps
-BENCH_OWN = ("k_crc_", "k_xcsum", "__amd_rocclr_copyBuffer")
+BENCH_OWN = ("k_crc_", "__amd_rocclr_copyBuffer")
 # what tmsmt2 (and, for the other vertical coordinates, cmnfld1) still launches after the k_tmsmt2* kernels: the last step's window
 # closes at the last of these
 STEP_TAIL = ("k_tmsmt2", "k_xctilr", "k_pscan", "k_dpudpv", "k_cmn_")
@@ -113,7 +113,7 @@ if len(sys.argv) > 4:
     prefixes = [("k_cmn_", "cmnfld"), ("k_mom_", "momtum"), ("k_remap_", "remap"), ("k_adv_", "remap"), ("k_cppm_", "cppm"),
                 ("k_diffus_", "diffus"), ("k_pgf_", "pgforc"), ("k_diapfl_", "diapfl"), ("k_convec_", "convec"),
                 ("k_bt_", "barotp"), ("k_pbc_", "pbcor"), ("k_eddtra_", "eddtra"), ("k_mxl_", "mxlayr"), ("k_difest_", "difest"),
-                ("k_thermf_", "thermf")]
+                ("k_thermf_", "thermf"), ("k_xcsum_", "thermf"), ("k_niw_", "difest")]
     cls = collections.defaultdict(float)
     allk = collections.defaultdict(float)
     for k in set(fe) | set(wr):
