@@ -90,7 +90,7 @@ def kernel_bytes_F(ntr, nadv):
             "k_diapfl_column3": (6 + ntr) + (8 + ntr)}
 
 
-KNOWN_CONFIGS = ("channel", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")
+KNOWN_CONFIGS = ("channel", "chandyn", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")   # chandyn: the channel with --physics dyncore
 
 
 def _profiles_of(config, suffix):
