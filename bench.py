@@ -432,53 +432,195 @@ def bench_ale(args):
     print(json.dumps(out))
 
 
+HYB_OPTS = dict(reconstruction_method="ppm", upper_bndr_ord=6, lower_bndr_ord=4, tracer_limiting="non_oscillatory",
+                velocity_limiting="non_oscillatory", tracer_pc_upper_bndr=True, tracer_pc_lower_bndr=False,
+                velocity_pc_upper_bndr=True, velocity_pc_lower_bndr=False, regrid_method="nudge")      # the group of tests/fuk95/limits
+
+
+def _hybrid_fields(case):
+    """what the parts of the hybrid step that are not built would produce, constant in time: vertical diffusivities, non-local
+    fractions, shortwave absorption, surface fluxes, boundary layer depth"""
+    import numpy as np
+    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
+    z = np.arange(kk + 1)[:, None, None] / kk
+    frac = np.clip(1.0 - z / 0.2, 0.0, 1.0) ** 2 * np.ones((1, nj, ni))
+    f = {}
+    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
+        f[nm] = 1e-5 + 1e-3 * np.exp(-((z - 0.03) / 0.05) ** 2) * np.ones((1, nj, ni))
+    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
+        f[nm] = frac
+    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -40.), ("sswflx", -60.), ("salflx", 5e-4),
+                  ("OBLdepth", 40.)):
+        f[nm] = v * np.ones((1, nj, ni))
+    return f
+
+
+def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0):
+    """the same hybrid stage sequence in the reference's own modules (oracle/_ref/channel_tke_omp_xaln: real mod_ale_regrid_remap,
+    mod_ale_forcing, mod_ale_vdiff, mod_eddtra, mod_cmnfld_routines behind the stand-ins of oracle/xcheck), OpenMP on all cores"""
+    import ctypes as C
+    import tempfile
+    import numpy as np
+    from blom_amd import hostinit
+    from blom_amd.stepper import dyncore_step, HYBRID_STAGES
+    from oracle.refblom import get_ref_backend, have_ref
+    lib = "channel_tke_omp_xaln"
+    if not have_ref(lib):
+        return {"error": f"oracle/_ref/{lib}/libblomref.so is missing"}
+    ncores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(ncores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ["OMP_STACKSIZE"] = "1G"
+    be = get_ref_backend(lib, case.depth)
+    be.has_stage = lambda name: True
+    hostinit.init_state(be, case)
+    for nm, a in _hybrid_fields(case).items():
+        be.put(nm, a)
+    kk = case.kdm
+    ierr = C.c_int(0)
+    v = np.ascontiguousarray(plevel, dtype=np.float64)
+    be.ref.lib.ref_set_vec(b"plevel", v.ctypes.data_as(C.c_void_p), C.c_int(kk), C.byref(ierr))
+    be.ref.set("vcoord_tag", 2)
+    be.ref.set("swamxd", 200.0)
+    six0 = hostinit.step_indices(0, kk)
+    o = HYB_OPTS
+    fl = lambda b_: ".true." if b_ else ".false."
+    txt = (" &ALE_REGRID_REMAP\n"
+           f"  RECONSTRUCTION_METHOD  = '{o['reconstruction_method']}'\n  UPPER_BNDR_ORD = {o['upper_bndr_ord']}\n"
+           f"  LOWER_BNDR_ORD = {o['lower_bndr_ord']}\n  DENSITY_LIMITING = 'monotonic'\n"
+           f"  TRACER_LIMITING = '{o['tracer_limiting']}'\n  VELOCITY_LIMITING = '{o['velocity_limiting']}'\n"
+           f"  TRACER_PC_UPPER_BNDR = {fl(o['tracer_pc_upper_bndr'])}\n  TRACER_PC_LOWER_BNDR = {fl(o['tracer_pc_lower_bndr'])}\n"
+           f"  VELOCITY_PC_UPPER_BNDR = {fl(o['velocity_pc_upper_bndr'])}\n  VELOCITY_PC_LOWER_BNDR = {fl(o['velocity_pc_lower_bndr'])}\n"
+           f"  REGRID_METHOD = '{o['regrid_method']}'\n /\n")
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "limits"), "w").write(txt)
+        cwd = os.getcwd()
+        os.chdir(td)
+        try:
+            be.ref.stage("ale_init", *six0)
+        finally:
+            os.chdir(cwd)
+    be.ref.stage("eddtra_init_fox08", *six0)
+    be.ref.set("eitmth", "gm")
+    be.ref.stage("cmnfld1", *hostinit.init_indices(0, kk))
+    ns = dyncore_step(be, 0, case.params["baclin"], stages=HYBRID_STAGES)
+    per_stage, mark = {}, [None, 0.0]
+
+    def hook(st, six):
+        now = time.perf_counter()
+        if mark[0] is not None:
+            per_stage[mark[0]] = per_stage.get(mark[0], 0.0) + (now - mark[1])
+        mark[0], mark[1] = st, now
+    t0, n = time.time(), 0
+    while n < 2 or (time.time() - t0 < max_seconds and n < 40):
+        ns = dyncore_step(be, ns, case.params["baclin"], hook=hook, stages=HYBRID_STAGES)
+        hook(None, None)
+        n += 1
+    dt = (time.time() - t0) / n
+    be.ref.set("vcoord_tag", 1)
+    return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=ncores, kind="reference", build=lib,
+                stages_ms={k: round(v_ / n * 1e3, 2) for k, v_ in per_stage.items() if k}, steps_timed=n,
+                sample=f"{n} steps of the same hybrid stage sequence on the channel, {dt * 1e3:.1f} ms/step, {ncores} OpenMP threads; every stage in "
+                       "the reference's own code, the modules that import netCDF-bound ones compiled against the stand-ins of oracle/xcheck "
+                       "(cppm's sweeps, which the reference does not thread, are not in this sequence: advmth = remap)")
+
+
 def bench_hybrid_step(args):
     """`--config hybrid`: the step of the hybrid vertical coordinate as far as it is built on
     BASELINE's channel: ale_regrid_remap (cntiso_hybrid, nudge, ppm: the options of the reference's tests/fuk95/limits), cmnfld2,
     eddtra (eddtra_ale: Gent-McWilliams + fox08), advect (remap), pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, ale_vdifft,
     ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1; vertical diffusivities, non-local fractions, boundary layer depth and surface fluxes
-    constant in time (their producers need CVMix / forcing files).  One JSON line, no CPU baseline (the reference's OpenMP builds of the channel do not contain the ALE modules)."""
+    constant in time (their producers need CVMix / forcing files).  One JSON line with `roofline` (the stage class with the largest
+    time against its algorithmic bytes) and `cpu_baseline` (the same stages in the reference's modules, channel_tke_omp_xaln)."""
     import numpy as np
+    import threading
     from blom_amd.gpu import BlomGpu
     from blom_amd import hostinit
     case, nreg, masks = build_case("channel")
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
     hostinit.init_state(gpu, case)
-    kk, nj, ni = case.kdm, case.jdm + 8, case.idm + 8
-    z = np.arange(kk + 1)[:, None, None] / kk
-    frac = np.clip(1.0 - z / 0.2, 0.0, 1.0) ** 2 * np.ones((1, nj, ni))
-    for nm in ("kvisc_m", "kdiff_t", "kdiff_s"):
-        gpu.put(nm, 1e-5 + 1e-3 * np.exp(-((z - 0.03) / 0.05) ** 2) * np.ones((1, nj, ni)))
-    for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
-        gpu.put(nm, frac)
-    for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -40.), ("sswflx", -60.), ("salflx", 5e-4),
-                  ("OBLdepth", 40.)):
-        gpu.put(nm, v * np.ones((1, nj, ni)))
+    kk = case.kdm
+    for nm, a in _hybrid_fields(case).items():
+        gpu.put(nm, a)
     pbot = float(np.max(gpu.get("p")[kk][4:-4, 4:-4][masks["ip"][4:-4, 4:-4] > 0]))
+    plevel = 0.05 * pbot * (np.arange(kk) / kk) ** 1.3
     gpu.set("vcoord_type", "cntiso_hybrid")
-    gpu.set("ale_regrid_method", "nudge")
+    o = HYB_OPTS
+    gpu.set("ale_regrid_method", o["regrid_method"])
+    gpu.set("ale_reconstruction_method", o["reconstruction_method"])
+    gpu.set("ale_tracer_limiting", o["tracer_limiting"])
+    gpu.set("ale_velocity_limiting", o["velocity_limiting"])
+    for nm in ("upper_bndr_ord", "lower_bndr_ord"):
+        gpu.set("ale_" + nm, int(o[nm]))
+    for nm in ("tracer_pc_upper_bndr", "tracer_pc_lower_bndr", "velocity_pc_upper_bndr", "velocity_pc_lower_bndr"):
+        gpu.set("ale_" + nm, 1 if o[nm] else 0)
     gpu.set("mlrmth", "fox08")
-    gpu.set_vector("plevel", 0.05 * pbot * (np.arange(kk) / kk) ** 1.3)
+    gpu.set_vector("plevel", plevel)
+    for o_ in args.opt:
+        nm, v = o_.split("=")
+        gpu.set(nm, int(v))
     gpu.stage("cmnfld1", *hostinit.init_indices(0, kk))
-    ns = gpu.step(0, max(2, args.warmup))
+    ns = gpu.step(0, max(4, args.warmup))
     gpu.sync()
     t0 = time.perf_counter()
     ns = gpu.step(ns, args.steps)
     gpu.sync()
     dt = (time.perf_counter() - t0) / args.steps
+    # per-class HIP-event times over a few more steps
+    gpu.set("timing", 1)
+    gpu.timer_reset()
+    ns = gpu.step(ns, min(args.steps, 5))
+    gpu.sync()
+    classes = ["ale_regrid_remap", "cmnfld", "eddtra", "remap", "diffus", "pgforc", "momtum", "ale_forcing", "ale_vdiff", "barotp", "pbcor1", "pbcor2"]
+    live = {}
+    for cl in classes:
+        ms, n = gpu.timer_get(cl)
+        if n:
+            live[cl] = ms / min(args.steps, 5)           # ms per step of the class (ale_vdiff: its two stages)
+    gpu.set("timing", 0)
     u = gpu.get("u")[:, 4:-4, 4:-4]
     finite = bool(np.isfinite(u[np.broadcast_to((masks["iu"][4:-4, 4:-4] > 0)[None], u.shape)]).all())
     baclin = case.params["baclin"]
+    ntr = case.ntr
+    F = case.idm * case.jdm * kk * 8.0
+    # algorithmic bytes per class in units of F (every distinct 3-D array read or written once): the classes of the isopycnic step as
+    # in SURVEY.md 8(d) (momtum + 2 for mu_nonloc, mv_nonloc), and
+    #   ale_regrid_remap  R dp, T, S, sigma, tracers, u, v (n); W dp, T, S, sigma, tracers, u, v, dpu, dpv, dpuold, dpvold, p, pu, pv
+    #   ale_vdiff         R dp, T, S, tracers, u, v, dpu, dpv, Kdiff_t, Kdiff_s, Kvisc_m, the six non-local fractions; W T, S, tracers, sigma, u, v
+    #   ale_forcing       R dp, T, S, p; W t_sw_nonloc, s_br_nonloc, buoyfl
+    cb = dict(class_bytes_F(ntr, ntr_diffused(case)))
+    cb["momtum"] += 2
+    cb.update(ale_regrid_remap=(6 + ntr) + (13 + ntr), ale_vdiff=(16 + ntr) + (5 + ntr), ale_forcing=4 + 3)
+    hbm = {k: v for k, v in live.items() if k in cb}
+    dom = max(hbm, key=hbm.get)
+    ach = cb[dom] * F / (live[dom] * 1e-3) / 1e9
+    tot = sum(cb[k] for k in hbm) * F
     out = {"metric": "simulated-days/sec", "value": baclin / 86400.0 / dt, "unit": "simulated-days/sec", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"channel {case.idm}x{case.jdm}x{kk}, ntr={case.ntr}: the step of vcoord_type = cntiso_hybrid as far as built "
-                                  "(ale_regrid_remap nudge/ppm, cmnfld2, eddtra_ale gm+fox08, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
+                                  "(ale_regrid_remap nudge/ppm 6/4, cmnfld2, eddtra_ale gm+fox08, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
                                   "ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1); diffusivities, non-local fractions, boundary layer depth, surface fluxes constant",
-                      "parity": "cross-checked stage sequence (tests/test_xcheck_hybrid_step.py)", "state_finite": finite},
-           "roofline": None}
+                      "parity": "cross-checked stage sequence, also at this size (tests/test_xcheck_hybrid_step.py)", "state_finite": finite},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom],
+                        "note": "stage class (its kernels are launched back to back); HIP events on the library's stream",
+                        "step_hbm_frac": tot / dt / 1e9 / HBM_PEAK_GBS},
+           "stages_ms": live}
     gpu.close()
-    print(json.dumps(out))
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if not args.no_cpu_baseline:
+        res = {}
+        threading.stack_size(2 << 30)
+        th = threading.Thread(target=lambda: res.update(_cpu_baseline_hybrid(case, masks, nreg, plevel)))
+        th.start()
+        th.join()
+        threading.stack_size(0)
+        out["cpu_baseline"] = res or {"error": "the reference run did not complete"}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 def main():

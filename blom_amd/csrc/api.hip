@@ -89,6 +89,8 @@ int ctx_err_words(blomgpu_ctx *c) {
 int ctx_check_errors(blomgpu_ctx *c) {
   if (blomgpu_ctx *G = bt_global_ctx(c))                   // RCCL tiles: the barotropic solver's words live in its own context
     if (ctx_check_errors(G)) { c->err = G->err; return 1; }
+  if (c->ale && c->h.P.vcoord_tag != 1)
+    if (int rc = ale_check_deferred(c)) return rc;
   if (!c->err_dev) return 0;
   int e[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost, c->stream));
@@ -743,8 +745,8 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     c->h.P.nstep = ns + 1;                             // read by host code only: no upload of the view for it
     ctx_sync_view(c);
     c->tmsmt1_ahead = !c->use_graph && !c->csdiag && it < nsteps - 1 && c->tmsmt_ahead;
-    // (the hybrid-coordinate sequence reads the engine's status back inside ale_regrid_remap: not capturable)
-    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4 && c->h.P.vcoord_tag == 1;
+    // (the hybrid-coordinate sequence too: the engine's status of ale_regrid_remap stays on the device until the check below)
+    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4;
     hipGraphExec_t &ge = c->step_graph[ns & 1];
     if (graph && !ge) {
       // capture; nothing executes while capturing, so on any failure the step is simply run with plain launches

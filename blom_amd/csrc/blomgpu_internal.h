@@ -372,6 +372,7 @@ int st_ale_forcing(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n
 int st_cmnfld_bfsqi_ale(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);    // stage_cmnfld.hip
 int st_ale_regrid_remap(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_ale.hip
 void ale_free(blomgpu_ctx *);
+int ale_check_deferred(blomgpu_ctx *);      // stage_ale.hip: the engine's status of the steps since the last check
 int st_mxlayr(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_mxlayr.hip
 int st_mom_pupv(blomgpu_ctx *, int off, int lo, int hi);                          // stage_momtum.hip
 int st_convec_velocity(blomgpu_ctx *, int nn);                                    // stage_convec.hip

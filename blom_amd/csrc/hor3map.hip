@@ -313,6 +313,7 @@ int blomgpu_h3m_grid_create(blomgpu_h3m_grid **out, int device, int ncol, int n_
   H3CHK(hipMemsetAsync(g.err, 0, nc * sizeof(int), G->stream));
   H3CHK(hipMemsetAsync(g.n_act, 0, nc * sizeof(int), G->stream));
   H3CHK(hipMemsetAsync(g.m_act, 0, nc * sizeof(int), G->stream));
+  H3CHK(hipMemsetAsync(G->first_fail, 0xFF, sizeof(unsigned long long), G->stream));     // "no column has failed"
   // boundary LU planes are read only where a prepare wrote them, except in the reference's own
   // corner cases (:1734); keep them defined
   H3CHK(hipMemsetAsync(g.lblu, 0, (size_t)H3_LD * H3_LD * nc * sizeof(double), G->stream));
@@ -435,6 +436,31 @@ int h3m_sequence_begin(blomgpu_h3m_grid *G) {
   G->sticky = true;
   G->check = false;
   return 0;
+}
+// Deferred form, inside blomgpu_step: the record is neither cleared at the start of a sequence nor read back at its end (no
+// host synchronisation: the step's launches can be captured into a graph); h3m_sequence_poll reads it -- the model context
+// does so with its other sticky error words, every check_period steps -- and clears it.
+int h3m_sequence_begin_deferred(blomgpu_h3m_grid *G) {
+  if (!G) return E_HANDLE;
+  G->sticky = true;
+  G->check = false;
+  return 0;
+}
+int h3m_sequence_end_deferred(blomgpu_h3m_grid *G) {
+  if (!G) return E_HANDLE;
+  G->sticky = false;
+  G->check = true;
+  return 0;
+}
+int h3m_sequence_poll(blomgpu_h3m_grid *G, unsigned long long *column) {
+  if (!G) return E_HANDLE;
+  unsigned long long ff = H3_NOFAIL;
+  H3CHK(hipMemcpyAsync(&ff, G->first_fail, sizeof(ff), hipMemcpyDeviceToHost, G->stream));
+  H3CHK(hipStreamSynchronize(G->stream));
+  if (ff == H3_NOFAIL) return 0;
+  H3CHK(hipMemsetAsync(G->first_fail, 0xFF, sizeof(unsigned long long), G->stream));
+  if (column) *column = ff >> 8;
+  return (int)(ff & 0xFF);
 }
 int h3m_sequence_end(blomgpu_h3m_grid *G) {
   if (!G) return E_HANDLE;

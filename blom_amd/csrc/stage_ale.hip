@@ -27,6 +27,9 @@
 
 int h3m_use_stream(blomgpu_h3m_grid *G, hipStream_t stream);          // hor3map.hip
 int h3m_sequence_begin(blomgpu_h3m_grid *G);
+int h3m_sequence_begin_deferred(blomgpu_h3m_grid *G);
+int h3m_sequence_end_deferred(blomgpu_h3m_grid *G);
+int h3m_sequence_poll(blomgpu_h3m_grid *G, unsigned long long *column);
 int h3m_sequence_end(blomgpu_h3m_grid *G);
 int h3m_set_stream(blomgpu_h3m_grid *G, hipStream_t stream);
 int h3m_set_active(blomgpu_h3m_grid *G, const int *active);
@@ -802,12 +805,18 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   if (h.P.ltedtp_opt != 1) return ctx_fail(c, "ale_regrid_remap: neutral diffusion (ltedtp = 'neutral', phy/mod_ndiff.F90) is not built");
   if (!c->ale_plevel) return ctx_fail(c, "ale_regrid_remap: the pressure levels are not set (blomgpu_set_vector \"plevel\", phy/mod_vcoord.F90:99)");
   if (int rc = ale_prepare(c)) return rc;
+  TimeScope ts(c, "ale_regrid_remap");
   AleState *a = (AleState *)c->ale;
   const size_t np = h.nplane, per = (size_t)h.kk * np;
   double *psrc = a->plane, *pdst = psrc + (size_t)(h.kk + 1) * np, *rm = pdst + (size_t)(h.kk + 1) * np;
   const dim3 g1((unsigned)((np + 255) / 256)), gk((unsigned)((np + 255) / 256), h.kk), b(256);
   int rc;
-  if ((rc = h3m_sequence_begin(a->grid)) || (rc = h3m_sequence_begin(a->grid_uv))) return ale_fail(c, "sequence", rc);   // the status is read back once
+  // the status of the engine's calls is read back once, at the end -- or, inside blomgpu_step, with the other sticky error
+  // words every check_period steps (ale_check_deferred): no host synchronisation inside the step
+  const bool defer = c->defer_checks;
+  if (defer) {
+    if ((rc = h3m_sequence_begin_deferred(a->grid)) || (rc = h3m_sequence_begin_deferred(a->grid_uv))) return ale_fail(c, "sequence", rc);
+  } else if ((rc = h3m_sequence_begin(a->grid)) || (rc = h3m_sequence_begin(a->grid_uv))) return ale_fail(c, "sequence", rc);
   // ---- tracers ----------------------------------------------------------------------------------------------------------
   const bool nudge = h.P.vcoord_tag == 2 && c->ale_regrid_method == 2;
   const int ring = nudge && c->ale_smooth_diff_max > 0. ? 1 : 0;      // lateral smoothing reads the neighbours' regridded columns
@@ -918,6 +927,20 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     hipLaunchKernelGGL(k_ale_uv_back, dim3((unsigned)((np + 255) / 256), h.kk, 2), b, 0, c->stream, c->d, nn, (const double *)rm2);
   }
   HIPCHK(c, hipGetLastError());
+  if (defer) {
+    if ((rc = h3m_sequence_end_deferred(a->grid)) || (rc = h3m_sequence_end_deferred(a->grid_uv))) return ale_fail(c, "sequence", rc);
+    return 0;
+  }
   if ((rc = h3m_sequence_end(a->grid)) || (rc = h3m_sequence_end(a->grid_uv))) return ale_fail(c, "a column failed", rc);
+  return 0;
+}
+
+// the deferred status of ale_regrid_remap's engine calls (blomgpu_step): 0, or the failure of a column in one of the steps
+// since the last check
+int ale_check_deferred(blomgpu_ctx *c) {
+  AleState *a = (AleState *)c->ale;
+  if (!a) return 0;
+  int rc;
+  if ((rc = h3m_sequence_poll(a->grid, nullptr)) || (rc = h3m_sequence_poll(a->grid_uv, nullptr))) return ale_fail(c, "a column failed", rc);
   return 0;
 }

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64) void k_ale_vdiffm(const DevView *__restrict__ V
 }
 
 int st_ale_vdifft(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  TimeScope ts(c, "ale_vdiff");
   (void)m; (void)n; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
   if (h.P.vcoord_tag == 1) return ctx_fail(c, "ale_vdifft: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:196-212)");
@@ -267,6 +268,7 @@ int st_ale_vdifft(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n
 }
 
 int st_ale_vdiffm(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  TimeScope ts(c, "ale_vdiff");
   (void)m; (void)n; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
   if (h.P.vcoord_tag == 1) return ctx_fail(c, "ale_vdiffm: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:196-212)");
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(64) void k_ale_forcing(const DevView *__restrict__ 
 }
 
 int st_ale_forcing(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  TimeScope ts(c, "ale_forcing");
   (void)m; (void)n; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
   if (h.P.vcoord_tag == 1) return ctx_fail(c, "ale_forcing: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:196-212)");
