@@ -897,6 +897,13 @@ def main():
                                "note": "the dynamical-core sequence of rounds 1-3 (no thermf, mxlayr, difest part, cmnfld1), timed in this run after the main measurement"}
     if world > 1 and layout is None:
         out["tile_days_per_s"] = world * value
+    if layout is not None:
+        # the Amdahl term of the strong-scaling design: with --barotp replicated every rank solves the WHOLE 2-D barotropic domain
+        # (no exchange inside the substep loop), so this part of a step does not shrink with N; rank_share_ms is what does
+        bt = live.get("barotp")
+        out["strong_scaling_terms"] = {"barotp": args.barotp, "barotp_replicated_ms": bt if args.barotp == "replicated" else None,
+                                       "barotp_ms": bt, "rank_share_ms": (ms_per_step - bt) if bt is not None else None,
+                                       "note": "HIP-event time of the barotp class on this rank (rank 0), step time minus it"}
     if rank == 0:
         # stdout carries the ONE JSON line and nothing else: the reference library prints through the Fortran
         # runtime (bigrid messages, buffered unit 6 flushed at exit), so from here on file descriptor 1 points

@@ -225,7 +225,7 @@ struct blomgpu_ctx {
   bool defer_checks = false;
   // blomgpu_step replays the stage sequence of a step as a HIP graph (one per parity of the time levels), captured from
   // the stream once the lazily allocated buffers exist; any option / parameter / mask change drops the graphs
-  int halo_overlap = 0;          // RCCL tiles: the halo exchange in front of remap runs on xstream while the inner tiles compute
+  int halo_overlap = 1;          // RCCL tiles: the halo exchange in front of remap runs on xstream while the inner tiles compute
                                  // (bit-identical; in self-send on one GPU 9.78 against 9.59 ms per step: off by default)
   int cmnfld1 = 0;               // blomgpu_step ends with cmnfld1 (z, dz of the new state; consumed by diagnostics and difest only)
   int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default

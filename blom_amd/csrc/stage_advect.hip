@@ -167,7 +167,7 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   // edge follow when the halos have landed.  The exchange reads interior strips and writes halo points only.
   // inside blomgpu_step the tile kernel also does the update and hands the new dp, T, S, tracers to pbcor1 through the work space
   const bool fold = c->in_sequence && c->remap_fold;
-  const bool ovl = c->tiling.rccl && c->xstream && c->halo_overlap && h.nreg != 2 && !c->timing;
+  const bool ovl = c->tiling.rccl && c->xstream && c->halo_overlap && !c->timing;
   if (ovl) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_fork, 0));

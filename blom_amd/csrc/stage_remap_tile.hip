@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   if (tsel) {
     // tsel 1: only the tiles that read no halo point (their 2-point rim lies inside 1..ii x 1..jj) -- they can run
     // while the halo exchange of cau, cav and the tracers is still under way; tsel 2: only the others
-    const bool inner = x0 - 2 >= NBDY && x0 + RT_TW + 1 <= V.ii + NBDY - 1 && y0 - 2 >= NBDY && y0 + RT_TH + 1 <= V.jj + NBDY - 1;
+    // (a tile that holds the arctic seam: the exchange rewrites its last row, an interior one, phy/mod_xc.F90:4262-4372 -- tiles
+    // whose rim reaches that row wait for it too)
+    const int jlast = V.jj + NBDY - 1 - ((V.nreg == 2 && V.j0 + V.jj == V.jtdm) ? 1 : 0);
+    const bool inner = x0 - 2 >= NBDY && x0 + RT_TW + 1 <= V.ii + NBDY - 1 && y0 - 2 >= NBDY && y0 + RT_TH + 1 <= jlast;
     if (inner != (tsel == 1)) return;
   }
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np;

@@ -114,7 +114,7 @@ def _run_rccl_self(cfg, nsteps, **opts):
     """single rank whose periodic direction wraps onto itself through the RCCL transport"""
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     case = make_case(cfg)
-    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
     hostinit.init_state(gpu, case)
     for k, v in opts.items():
@@ -243,14 +243,17 @@ def test_step_replayed_as_a_hip_graph_is_identical(cfg, nsteps):
     assert not bad, bad
 
 
-def test_halo_exchange_overlapped_with_the_inner_tiles_of_remap():
+@pytest.mark.parametrize("cfg", ["chan_m", "tri_m"])
+def test_halo_exchange_overlapped_with_the_inner_tiles_of_remap(cfg):
     """RCCL transport (one rank sending to itself): the exchange of cau, cav and the tracers in front of remap on the second
-    stream while k_remap_tile runs the tiles that read no halo point, the edge tiles afterwards (halo_overlap = 1): same
-    bits as the serial exchange and as the plain single tile.  chan_m is 80 x 40: 3 x 5 tiles of 32 x 8, three of them inner."""
+    stream while k_remap_tile runs the tiles that read no halo point, the edge tiles afterwards (halo_overlap = 1, the default
+    of the RCCL transport): same bits as the serial exchange and as the plain single tile.  chan_m is 80 x 40: 3 x 5 tiles of
+    32 x 8, three of them inner; tri_m (64 x 40) has the arctic patch: the exchange rewrites the seam row, so the tiles whose rim
+    reaches it wait as well."""
     skip = {"util1", "util2", "util3", "util4"}
-    a = _run("chan_m", 6)
+    a = _run(cfg, 6)
     for ovl in (0, 1):
-        b = _run_rccl_self("chan_m", 6, halo_overlap=ovl)
+        b = _run_rccl_self(cfg, 6, halo_overlap=ovl)
         bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
         assert not bad, (ovl, bad)
 
