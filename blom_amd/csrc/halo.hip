@@ -385,7 +385,8 @@ static int xctilr_arctic_rccl_multi(blomgpu_ctx *c, int nf, double *const *ptrs,
   const dim3 gf((unsigned)(((h.ii + 2 * mhl) * (nhl + 1) + 255) / 256), nlev > 64 ? 64 : nlev, nf);
   FillSet F;
   for (int f = 0; f < 4; f++) { F.a[f] = ptrs[f < nf ? f : 0]; F.itype[f] = itypes[f < nf ? f : 0]; F.off[f] = (size_t)(f < nf ? f : 0) * fs; }
-  hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->stream, c->d, F, tab, T.npx, T.px, nlev, mhl, nhl, nrows);
+  // on the stream the exchange travels on (the second stream when it overlaps compute: stage_advect.hip)
+  hipLaunchKernelGGL(k_arctic_fill, gf, dim3(256), 0, c->halo_stream ? c->halo_stream : c->stream, c->d, F, tab, T.npx, T.px, nlev, mhl, nhl, nrows);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
