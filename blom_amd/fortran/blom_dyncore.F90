@@ -22,7 +22,7 @@ program blom_dyncore
   character(len=32)  :: sval
   integer :: u, ios, kind, nlev, nsteps, nstep, nstep1, nstep2, i4(6), ival
   real(8) :: baclin, rval
-  logical :: have_limits
+  logical :: have_limits, full_physics = .false.
   real(8), allocatable :: buf(:,:,:)
   integer, allocatable :: ibuf(:,:,:)
 
@@ -52,6 +52,9 @@ program blom_dyncore
       case (3)
         read (u) ival
         call gpu_set(trim(name), ival)
+        ! config 2's step as far as the device library has it (thermf, mxlayr, the front of difest_isobml, cmnfld2, cmnfld1):
+        ! the host sequences the stages itself, so it needs to know
+        if (trim(name) == 'full_physics') full_physics = ival /= 0
       case (4)
         read (u) sval
         call gpu_set(trim(name), trim(sval))
@@ -124,6 +127,32 @@ contains
       call stage6('halo_difest_vert',m,n,mm,nn,k1m,k1n)
       call ale_vdifft(m,n,mm,nn,k1m,k1n)
       call ale_vdiffm(m,n,mm,nn,k1m,k1n)
+      call updtrc(m,n,mm,nn,k1m,k1n)
+      call barotp(m,n,mm,nn,k1m,k1n)
+      call pbcor2(m,n,mm,nn,k1m,k1n)
+      call tmsmt2(m,mm,nn,k1m)
+      call cmnfld1(m,n,mm,nn,k1m,k1n)
+      call gpu_set('delt1', baclin+baclin)
+      return
+    end if
+    if (full_physics) then
+      ! phy/mod_blom_step.F90:96-253 for isopyc_bulkml, every stage the device library has (DESIGN.md 3i); of difest_isobml the
+      ! part in front of the diffusivity estimates
+      call init_fluxes(m,n,mm,nn,k1m,k1n)
+      call tmsmt1(nn)
+      call cmnfld2(m,n,mm,nn,k1m,k1n)
+      call difest_isobml(m,n,mm,nn,k1m,k1n)
+      call eddtra(m,n,mm,nn,k1m,k1n)
+      call advect(m,n,mm,nn,k1m,k1n)
+      call pbcor1(m,n,mm,nn,k1m,k1n)
+      call diffus(m,n,mm,nn,k1m,k1n)
+      call sfcstr(m,n,mm,nn,k1m,k1n)
+      call pgforc(m,n,mm,nn,k1m,k1n)
+      call momtum(m,n,mm,nn,k1m,k1n)
+      call convec(m,n,mm,nn,k1m,k1n)
+      call diapfl(n,nn,k1n)
+      call thermf(m,n,mm,nn,k1m,k1n)
+      call mxlayr(m,n,mm,nn,k1m,k1n)
       call updtrc(m,n,mm,nn,k1m,k1n)
       call barotp(m,n,mm,nn,k1m,k1n)
       call pbcor2(m,n,mm,nn,k1m,k1n)

@@ -131,7 +131,7 @@ module mod_blomgpu
   public :: init_fluxes, tmsmt1, tmsmt2, advect, pbcor1, pbcor2, diffus, pgforc, momtum, &
             diapfl, barotp, eddtra, convec, sfcstr, updtrc, init_cppm, halo_cmnfld2, halo_difest, mxlayr_tail, &
             cmnfld1, cmnfld2, ale_regrid_remap, ale_vdifft, ale_vdiffm, ale_forcing, &
-            cmnfld_bfsqi_ale, gpu_set_vector
+            cmnfld_bfsqi_ale, gpu_set_vector, difest_isobml, thermf, mxlayr
 
   interface gpu_set
     module procedure gpu_set_real, gpu_set_int, gpu_set_str
@@ -345,6 +345,18 @@ contains
   subroutine halo_difest(nn)                   ! phy/mod_difest.F90:750-772
     integer, intent(in) :: nn
     call stage6('halo_difest',0,0,0,nn,0,0)
+  end subroutine
+  subroutine difest_isobml(m,n,mm,nn,k1m,k1n)   ! phy/mod_difest.F90:735 -- the part the device library has: :750-790
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('difest_isobml_pre',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine thermf(m,n,mm,nn,k1m,k1n)          ! phy/mod_thermf.F90:35
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('thermf',m,n,mm,nn,k1m,k1n)
+  end subroutine
+  subroutine mxlayr(m,n,mm,nn,k1m,k1n)          ! phy/mod_mxlayr.F90:130
+    integer, intent(in) :: m,n,mm,nn,k1m,k1n
+    call stage6('mxlayr',m,n,mm,nn,k1m,k1n)
   end subroutine
   subroutine mxlayr_tail(nn,k1n)               ! phy/mod_mxlayr.F90:1266-1310
     integer, intent(in) :: nn,k1n

@@ -195,3 +195,52 @@ def test_reference_limits_file_drives_the_hybrid_step(tmp_path):
         run_case_hybrid(tmp_path, EXE, g.BlomGpu, 4)
     finally:
         g.LIB_PATH = old
+
+
+def run_full_physics(tmp_path, exe, BlomGpu, cfg="chan_s_tke", nsteps=6):
+    """the Fortran host sequencing config 2's stages (option record full_physics = 1) against blomgpu_step with that option; a
+    surface heat flux of either sign is switched on"""
+    import re
+    import subprocess
+    import numpy as np
+    from blom_amd import hostinit
+    from blom_amd.cases import make_case
+    from blom_amd.statefile import write_state
+    from parity import STATE_FIELDS, GRID_FIELDS, INT_FIELDS
+    case = make_case(cfg, nslp0=0.0)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    hostinit.init_forcing(gpu, case)
+    nj, ni = case.jdm + 8, case.idm + 8
+    gpu.put("nsf", (250.0 * np.linspace(-1.0, 1.0, nj)[:, None] * np.ones((1, ni)))[None])
+    forcing = ["ustarw", "swa", "nsf", "hmltfz", "lip", "sop", "eva", "rnf", "rfi", "fmltfz", "sfl", "swfc1", "swfc2", "swal1", "swal2", "ustar",
+               "ustar3", "idkedt", "sstclm", "ricclm", "sssclm", "uml", "vml", "umlres", "vmlres"]
+    names = [n for n in STATE_FIELDS + GRID_FIELDS + INT_FIELDS + forcing if gpu.has_field(n) and np.any(gpu.get(n))]
+    names = list(dict.fromkeys(names))
+    case.params["full_physics"] = 1
+    case.params["area"] = float(np.sum(gpu.get("scp2")[0][4:-4, 4:-4][ip[4:-4, 4:-4] > 0]))
+    state = str(tmp_path / "blom_state.bin")
+    write_state(state, gpu, case, nsteps, names)
+    gpu.set("full_physics", 1)
+    gpu.set("delt1", case.params["baclin"])
+    assert gpu.step(0, nsteps) == nsteps
+    want = {"dp": gpu.crc("dp", 1, 2 * case.kdm, 1), "temp": gpu.crc("temp", 1, 2 * case.kdm, 1), "u": gpu.crc("u", 1, 2 * case.kdm, 13)}
+    assert np.abs(gpu.get("surflx")).max() > 0.0
+    gpu.close()
+    out = subprocess.run([exe, state], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"chksum: (\w+): 0x([0-9A-Fa-f]+)", out.stdout)}
+    assert got == want, (got, want, out.stdout[-1500:])
+
+
+@pytest.mark.skipif(not (os.path.exists(EMU) and os.path.exists(EXE)), reason="tests/hostemu not built")
+def test_fortran_host_sequences_the_full_physics_step(tmp_path):
+    """on the host emulation of the device library"""
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    try:
+        run_full_physics(tmp_path, EXE, g.BlomGpu)
+    finally:
+        g.LIB_PATH = old

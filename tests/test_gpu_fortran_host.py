@@ -44,6 +44,18 @@ def test_fortran_driver_matches_python_driver(tmp_path):
     assert open(tmp_path / "run.status").read().strip() == "success"
 
 
+def test_fortran_driver_runs_the_full_physics_sequence(tmp_path):
+    """config 2's step as far as built (thermf, mxlayr, the front of difest_isobml, cmnfld2, cmnfld1), sequenced
+    stage by stage by the Fortran host (option record full_physics = 1 of the state file) against blomgpu_step with the same
+    option: equal checksums; see tests/test_fortran_namelist_host.py"""
+    from blom_amd.gpu import BlomGpu
+    from test_fortran_namelist_host import run_full_physics
+    exe = os.path.join(ROOT, "blom_amd", "lib", "blom_dyncore")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built")
+    run_full_physics(tmp_path, exe, BlomGpu)
+
+
 def test_fortran_hor3map_shim(tmp_path):
     """blom_amd/fortran/mod_hor3map_gpu.F90 (the reference's mod_hor3map names over the C ABI),
     driven by h3m_demo, against the Python binding on the same analytic columns"""
