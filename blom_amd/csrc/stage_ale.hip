@@ -36,6 +36,7 @@ int h3m_set_active(blomgpu_h3m_grid *G, const int *active);
 int h3m_extract_polycoeff_many(blomgpu_h3m_grid *G, int nf, blomgpu_h3m_src *const *srcs, double *const *outs);
 
 #define H3M_MAXF 8
+#include "stage_ndiff.h"
 
 struct AleState {
   blomgpu_h3m_grid *grid = nullptr;
@@ -53,6 +54,11 @@ struct AleState {
   double *plane = nullptr;                  // scratch: p_src, p_dst (kk+1 planes each), remapped fields (kk planes each)
   size_t plane_n = 0;
   int ntr_loc = 0, method = 0;
+  // neutral diffusion (stage_ndiff.hip): polynomial coefficients of every field; T, S and drho/dT, drho/dS at the source
+  // interfaces (8 kk planes), the flux convergence (kk ntr_loc planes) and the flux kernel's work arrays; ksmx, kdmx
+  double *nd_tpc = nullptr, *nd_col = nullptr;
+  int *nd_ks = nullptr;
+  int nd_npc = 0;
 };
 
 void ale_free(blomgpu_ctx *c) {
@@ -65,6 +71,9 @@ void ale_free(blomgpu_ctx *c) {
   if (a->ev_join) (void)hipEventDestroy(a->ev_join);
   if (a->plane) (void)hipFree(a->plane);
   if (a->active) (void)hipFree(a->active);
+  if (a->nd_tpc) (void)hipFree(a->nd_tpc);
+  if (a->nd_col) (void)hipFree(a->nd_col);
+  if (a->nd_ks) (void)hipFree(a->nd_ks);
   delete a;
   c->ale = nullptr;
 }
@@ -117,6 +126,23 @@ static int ale_prepare(blomgpu_ctx *c) {
   return 0;
 }
 
+static int ale_ndiff_buffers(blomgpu_ctx *c, AleState *a) {
+  const DevView &h = c->h;
+  const int npc = c->ale_method == BLOMGPU_H3M_PLM ? 2 : (c->ale_method == BLOMGPU_H3M_PPM ? 3 : 5);
+  if (a->nd_tpc && a->nd_npc == npc) return 0;
+  if (a->nd_tpc) { (void)hipFree(a->nd_tpc); a->nd_tpc = nullptr; }
+  const size_t np = h.nplane, per = (size_t)h.kk * np;
+  HIPCHK(c, hipMalloc((void **)&a->nd_tpc, sizeof(double) * (size_t)a->ntr_loc * npc * per));
+  a->nd_npc = npc;
+  if (!a->nd_col) {
+    HIPCHK(c, hipMalloc((void **)&a->nd_col, sizeof(double) * ((size_t)(8 + a->ntr_loc) * per + ndiff_scratch_planes(h.kk) * np)));
+    HIPCHK(c, hipMalloc((void **)&a->nd_ks, sizeof(int) * 2 * np));
+    HIPCHK(c, hipMemsetAsync(a->nd_col, 0, sizeof(double) * ((size_t)(8 + a->ntr_loc) * per + ndiff_scratch_planes(h.kk) * np), c->stream));
+    HIPCHK(c, hipMemsetAsync(a->nd_ks, 0, sizeof(int) * 2 * np, c->stream));
+  }
+  return 0;
+}
+
 #define PLANE_T(V)                                                         \
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                    \
   if (t_ >= (V).nplane) return;                                            \
@@ -161,12 +187,12 @@ __global__ void k_ale_p_src_dst(const DevView *__restrict__ Vp, int nn, const do
 // made monotonic in depth for the reconstruction that regrid() inverts.  pcT, pcS: the polynomial coefficients of the T and S
 // reconstructions (npc per layer: extract_polycoeff); peval1 (:152-160) sums FIVE coefficients, the absent ones are zero.
 __global__ void k_ale_direct_pre(const DevView *__restrict__ Vp, int nn, const double *__restrict__ psrc, const double *__restrict__ pcT,
-                                 const double *__restrict__ pcS, int npc, double *__restrict__ sgs, double *__restrict__ sgt) {
+                                 const double *__restrict__ pcS, int npc, double *__restrict__ sgs, double *__restrict__ sgt, int ring) {
   const DevView &V = *Vp;
   PLANE_T(V);
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const bool col = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && V.m[I_ip][c];
+  const bool col = j >= 1 - ring && j <= V.jj + ring && i >= 1 - ring && i <= V.ii + ring && V.m[I_ip][c];
   if (!col) {                               // harmless column: densities that increase with depth, targets between them
     for (int k = 1; k <= kk; k++) { PL(sgs, k) = (double)k; PL(sgt, k) = (double)k - .5; }
     PL(sgt, kk + 1) = (double)kk + .5;
@@ -247,12 +273,12 @@ __global__ void k_ale_direct_pre(const DevView *__restrict__ Vp, int nn, const d
 // and blend into the prescribed pressure levels towards the surface
 __global__ void k_ale_direct_post(const DevView *__restrict__ Vp, const double *__restrict__ psrc, const double *__restrict__ sgs,
                                   const double *__restrict__ sgt, const double *__restrict__ plevel, double dpmin_interior,
-                                  int k_range_plevel, double *__restrict__ pdst) {
+                                  int k_range_plevel, double *__restrict__ pdst, int ring) {
   const DevView &V = *Vp;
   PLANE_T(V);
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const bool col = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && V.m[I_ip][c];
+  const bool col = j >= 1 - ring && j <= V.jj + ring && i >= 1 - ring && i <= V.ii + ring && V.m[I_ip][c];
   if (!col) {
     for (int k = 1; k <= kk + 1; k++) PL(pdst, k) = PL(psrc, k);
     return;
@@ -672,14 +698,15 @@ __global__ __launch_bounds__(256) void k_ale_nudge(const DevView *__restrict__ V
 // the order - u-face i, + u-face i+1, - v-face j, + v-face j+1 (faces that are no velocity points contribute nothing); all
 // fluxes are formed from the unsmoothed interfaces.  Here one thread per cell and interface gathers them in that order.
 __global__ void k_ale_smooth(const DevView *__restrict__ Vp, double smooth_diff_max, const double *__restrict__ pdst,
-                             const double *__restrict__ sfac, double *__restrict__ pout) {
+                             const double *__restrict__ sfac, double *__restrict__ pout, int ring) {
   const DevView &V = *Vp;
   PLANE_T(V);
   const size_t np = V.nplane;
   const int kk = V.kk, ni = V.ni;
   const int k = blockIdx.y + 1;                                  // interface 1..kk+1
   double v = pdst[c + (size_t)(k - 1) * np];
-  const bool cell = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && V.m[I_ip][c];
+  // ring = 1 with neutral diffusion, which reads the smoothed interfaces of the cells one ring beyond the tile (:1629-1634)
+  const bool cell = j >= 1 - ring && j <= V.jj + ring && i >= 1 - ring && i <= V.ii + ring && V.m[I_ip][c];
   if (cell && k >= 2 && k <= kk) {
     const double delt1 = V.P.delt1;
     const double *scp2 = V.f[F_scp2], *difmxp = V.f[F_difmxp];
@@ -716,24 +743,30 @@ __global__ void k_ale_smooth(const DevView *__restrict__ Vp, double smooth_diff_
 }
 
 // copy_jslice_to_3d (:1153-1179) for up to H3M_MAXF remapped fields starting with field f0 of (T, S, tracer 1, ..)
+// flx != nullptr: ndiff_update_trc_jslice (phy/mod_ndiff.F90:1149-1175) first -- the flux convergence [layer][field] of the
+// neutral diffusion comes off the remapped value
 __global__ void k_ale_copy_back(const DevView *__restrict__ Vp, int nn, const double *__restrict__ pdst, const double *__restrict__ rm,
-                                int f0, int nf) {
+                                int f0, int nf, const double *__restrict__ flx, int ntr_loc) {
   const DevView &V = *Vp;
   PLANE_T(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane, per = (size_t)V.kk * np;
   const int k = blockIdx.y;
   const size_t okn = c + (size_t)(k + nn) * np, ok = c + (size_t)k * np;
+  double q = 0.;
+  if (flx) q = 1. / (V.f[F_scp2][c] * fmax2(pdst[c + (size_t)(k + 1) * np] - pdst[ok], 1.e-5));
+  double ts[2] = {0., 0.};
   for (int f = 0; f < nf; f++) {
     const int nt = f0 + f;                                 // 0: T, 1: S, 2..: tracers
-    const double v = rm[(size_t)f * per + ok];
-    if (nt == 0) V.f[F_temp][okn] = v;
-    else if (nt == 1) V.f[F_saln][okn] = v;
+    double v = rm[(size_t)f * per + ok];
+    if (flx) v = v - q * flx[c + ((size_t)k * ntr_loc + nt) * np];
+    if (nt == 0) { V.f[F_temp][okn] = v; ts[0] = v; }
+    else if (nt == 1) { V.f[F_saln][okn] = v; ts[1] = v; }
     else V.f[F_trc][okn + (size_t)(nt - 2) * 2 * V.kk * np] = v;
   }
   if (f0 == 0) {                                           // T and S travel in the first group: dp and sigma with them
     V.f[F_dp][okn] = pdst[c + (size_t)(k + 1) * np] - pdst[ok];
-    V.f[F_sigma][okn] = eos::sig(V.P, rm[ok], rm[per + ok]);
+    V.f[F_sigma][okn] = eos::sig(V.P, ts[0], ts[1]);
   }
 }
 
@@ -802,7 +835,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   const DevView &h = c->h;
   if (h.P.vcoord_tag == 1) return ctx_fail(c, "ale_regrid_remap: vcoord_type = 'isopyc_bulkml' has no ALE step (phy/mod_blom_step.F90:138-149)");
   if (h.P.vcoord_tag != 2 && h.P.vcoord_tag != 3) return ctx_fail(c, "ale_regrid_remap: unknown vertical coordinate");
-  if (h.P.ltedtp_opt != 1) return ctx_fail(c, "ale_regrid_remap: neutral diffusion (ltedtp = 'neutral', phy/mod_ndiff.F90) is not built");
+  if (h.P.ltedtp_opt != 1 && h.P.ltedtp_opt != 2) return ctx_fail(c, "ale_regrid_remap: unknown ltedtp_opt");
   if (!c->ale_plevel) return ctx_fail(c, "ale_regrid_remap: the pressure levels are not set (blomgpu_set_vector \"plevel\", phy/mod_vcoord.F90:99)");
   if (int rc = ale_prepare(c)) return rc;
   TimeScope ts(c, "ale_regrid_remap");
@@ -819,11 +852,23 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   } else if ((rc = h3m_sequence_begin(a->grid)) || (rc = h3m_sequence_begin(a->grid_uv))) return ale_fail(c, "sequence", rc);
   // ---- tracers ----------------------------------------------------------------------------------------------------------
   const bool nudge = h.P.vcoord_tag == 2 && c->ale_regrid_method == 2;
-  const int ring = nudge && c->ale_smooth_diff_max > 0. ? 1 : 0;      // lateral smoothing reads the neighbours' regridded columns
+  const bool smooth = nudge && c->ale_smooth_diff_max > 0.;
+  const bool ndiff = h.P.ltedtp_opt == 2;
+  // the j-slice offsets of :1559-1569: neutral diffusion reads the regridded columns one ring beyond the tile, the lateral
+  // smoothing those one ring beyond the cells it smooths
+  const int jofs2 = ndiff ? 1 : 0, ring = jofs2 + (smooth ? 1 : 0);
+  if (ndiff && c->tiling.multi()) return ctx_fail(c, "ale_regrid_remap: neutral diffusion on a decomposed domain is not built");
   if (ring) {                                                          // :1603-1607
-    if (int rc2 = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
-    if (int rc2 = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
-    if (int rc2 = st_xctilr(c, h.f[F_sigma] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc2;
+    if (int rc2 = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, ring, ring, 1)) return rc2;
+    if (int rc2 = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, ring, ring, 1)) return rc2;
+    if (int rc2 = st_xctilr(c, h.f[F_sigma] + (size_t)(k1n - 1) * np, 1, h.kk, ring, ring, 1)) return rc2;
+  }
+  if (ndiff) {                                                         // :1608-1613
+    for (int nt = 0; nt < h.ntr; nt++)
+      if (int rc2 = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 1, 1, 1)) return rc2;
+    if (c->ndiff_surface_align)
+      if (int rc2 = st_xctilr(c, h.f[F_dpml], 1, 1, 1, 1, 1)) return rc2;
+    if (int rc2 = ale_ndiff_buffers(c, a)) return rc2;
   }
   hipLaunchKernelGGL(k_ale_p_src_dst, g1, b, 0, c->stream, c->d, nn, (const double *)c->ale_plevel, psrc, pdst, ring, a->active);
   if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid, psrc))) return ale_fail(c, "prepare_reconstruction", rc);
@@ -833,6 +878,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   auto field = [&](int nt) -> const double * {
     return nt == 0 ? h.f[F_temp] + (size_t)nn * np : nt == 1 ? h.f[F_saln] + (size_t)nn * np : h.f[F_trc] + ((size_t)nn + (size_t)(nt - 2) * 2 * h.kk) * np;
   };
+  const int npc = c->ale_method == BLOMGPU_H3M_PLM ? 2 : (c->ale_method == BLOMGPU_H3M_PPM ? 3 : 5);
   const int nf0 = a->ntr_loc < H3M_MAXF ? a->ntr_loc : H3M_MAXF, lo0 = h.P.vcoord_tag == 2 ? 2 : 0;
   auto fork = [&]() -> int {
     HIPCHK(c, hipEventRecord(a->ev_fork, c->stream));
@@ -844,25 +890,40 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     HIPCHK(c, hipStreamWaitEvent(c->stream, a->ev_join, 0));
     return 0;
   };
+  // with neutral diffusion the coefficients of every field are kept ([field][layer][coefficient] planes, a->nd_tpc), and every
+  // field is reconstructed before the fluxes are formed
+  auto coeff = [&](int nt) -> double * { return a->nd_tpc + (size_t)nt * npc * per; };
   if (nf0 > lo0) {
     const double *us[H3M_MAXF];
     blomgpu_h3m_src *ss[H3M_MAXF];
-    for (int f = lo0; f < nf0; f++) { us[f - lo0] = field(f); ss[f - lo0] = a->trc[f]; }
+    double *pcs[H3M_MAXF];
+    for (int f = lo0; f < nf0; f++) { us[f - lo0] = field(f); ss[f - lo0] = a->trc[f]; pcs[f - lo0] = ndiff ? coeff(f) : nullptr; }
     if (int rc2 = fork()) return rc2;
     (void)h3m_set_stream(a->grid, a->side);
     rc = blomgpu_h3m_reconstruct_many(a->grid, nf0 - lo0, ss, us);
+    if (!rc && ndiff) rc = h3m_extract_polycoeff_many(a->grid, nf0 - lo0, ss, pcs);
     (void)h3m_set_stream(a->grid, c->stream);
     if (rc) return ale_fail(c, "reconstruct", rc);
   }
+  if (ndiff)
+    for (int f0 = H3M_MAXF; f0 < a->ntr_loc; f0 += H3M_MAXF) {
+      const int nf = a->ntr_loc - f0 < H3M_MAXF ? a->ntr_loc - f0 : H3M_MAXF;
+      const double *us[H3M_MAXF];
+      blomgpu_h3m_src *ss[H3M_MAXF];
+      double *pcs[H3M_MAXF];
+      for (int f = 0; f < nf; f++) { us[f] = field(f0 + f); ss[f] = a->trc[f0 + f]; pcs[f] = coeff(f0 + f); }
+      if ((rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
+      if ((rc = h3m_extract_polycoeff_many(a->grid, nf, ss, pcs))) return ale_fail(c, "extract_polycoeff", rc);
+    }
   if (h.P.vcoord_tag == 2) {
     // regrid_cntiso_hybrid_direct_jslice: the interfaces go where the reconstructed potential density takes its target values
     double *pcT = rm + (size_t)H3M_MAXF * per, *pcS = pcT + (size_t)5 * per, *sgs = pcS + (size_t)5 * per, *sgt = sgs + per;
+    if (ndiff) { pcT = coeff(0); pcS = coeff(1); }
     const double *ts[2] = {field(0), field(1)};
     blomgpu_h3m_src *tss[2] = {a->trc[0], a->trc[1]};
     double *pcs[2] = {pcT, pcS};
     if ((rc = blomgpu_h3m_reconstruct_many(a->grid, 2, tss, ts))) return ale_fail(c, "reconstruct", rc);
     if ((rc = h3m_extract_polycoeff_many(a->grid, 2, tss, pcs))) return ale_fail(c, "extract_polycoeff", rc);
-    const int npc = c->ale_method == BLOMGPU_H3M_PLM ? 2 : (c->ale_method == BLOMGPU_H3M_PPM ? 3 : 5);
     if (nudge) {
       // regrid_cntiso_hybrid_nudge_jslice; its work arrays lie where the remapped fields will (nothing has been remapped yet)
       double *sd1 = rm, *sd2 = rm + per, *dsg = rm + 2 * per, *dpm = rm + 3 * per, *spm = rm + 4 * per, *sfac = rm + 6 * per;
@@ -872,24 +933,35 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
       Q.k_range_plevel = c->ale_k_range_plevel; Q.dktzu = c->ale_dktzu; Q.dktzl = c->ale_dktzl; Q.ring = ring;
       hipLaunchKernelGGL(k_ale_nudge, g1, b, 0, c->stream, c->d, Q, (const double *)psrc, (const double *)pcT, (const double *)pcS, npc,
                          (const double *)c->ale_plevel, sd1, sd2, sgt, dsg, spm, dpm, pdst, sfac);
-      if (ring) {                                                                             // regrid_smooth_jslice
+      if (smooth) {                                                                           // regrid_smooth_jslice
         double *pout = sgs;                               // kk+1 planes: sgs and the first plane of sgt, both free again
         hipLaunchKernelGGL(k_ale_smooth, dim3((unsigned)((np + 255) / 256), h.kk + 1), b, 0, c->stream, c->d, c->ale_smooth_diff_max,
-                           (const double *)pdst, (const double *)sfac, pout);
+                           (const double *)pdst, (const double *)sfac, pout, jofs2);
         pdst = pout;                                      // the smoothed interfaces are the destination grid from here on
       }
     } else {
     hipLaunchKernelGGL(k_ale_direct_pre, g1, b, 0, c->stream, c->d, nn, (const double *)psrc, (const double *)pcT, (const double *)pcS,
-                       npc, sgs, sgt);
+                       npc, sgs, sgt, ring);
     if ((rc = blomgpu_h3m_reconstruct(a->grid, a->dens, sgs))) return ale_fail(c, "reconstruct (density)", rc);
     if ((rc = blomgpu_h3m_regrid(a->dens, h.kk + 1, sgt, pdst, -1.e33, 0))) return ale_fail(c, "regrid", rc);
     hipLaunchKernelGGL(k_ale_direct_post, g1, b, 0, c->stream, c->d, (const double *)psrc, (const double *)sgs, (const double *)sgt,
-                       (const double *)c->ale_plevel, c->ale_dpmin_interior, c->ale_k_range_plevel, pdst);
+                       (const double *)c->ale_plevel, c->ale_dpmin_interior, c->ale_k_range_plevel, pdst, ring);
     }
   }
   if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping", rc);
   if (nf0 > lo0)
     if (int rc2 = join()) return rc2;
+  if (ndiff) {
+    // ndiff_prep_jslice, ndiff_uflx_jslice, ndiff_vflx_jslice (:1639-1664): the flux convergence of every destination layer
+    NdArgs A;
+    A.psrc = psrc; A.pdst = pdst; A.ksmx = a->nd_ks; A.kdmx = a->nd_ks + np; A.tpc = a->nd_tpc; A.tsd = a->nd_col;
+    A.drt = a->nd_col + (size_t)4 * per; A.drs = a->nd_col + (size_t)6 * per; A.flx = a->nd_col + (size_t)8 * per;
+    A.scr = A.flx + (size_t)a->ntr_loc * per;
+    A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
+    if (int rc2 = st_ndiff_prep_flux(c, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
+      return rc2;
+  }
+  const double *flx = ndiff ? a->nd_col + (size_t)8 * per : nullptr;
   for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {
     const int nf = a->ntr_loc - f0 < H3M_MAXF ? a->ntr_loc - f0 : H3M_MAXF;
     const double *us[H3M_MAXF];
@@ -900,9 +972,9 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
       ud[f] = rm + (size_t)f * per;
       ss[f] = a->trc[f0 + f];
     }
-    if (f0 > 0 && (rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
+    if (f0 > 0 && !ndiff && (rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
     if ((rc = blomgpu_h3m_remap_many(nf, ss, a->map, ud))) return ale_fail(c, "remap", rc);
-    hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf);
+    hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf, flx, a->ntr_loc);
   }
   // ---- velocities, :1692-1900 -------------------------------------------------------------------------------------------------
   hipLaunchKernelGGL(k_ale_pupv, g1, b, 0, c->stream, c->d, nn);

@@ -447,6 +447,34 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqi_ale(const DevView *__restrict_
 #undef L
 }
 
+// cmnfld_nnslope_ale, :813-883: with ltedtp = 'neutral' the slopes nslpx, nslpy are those the neutral diffusion found between
+// the columns (stage_ndiff.hip); here they are multiplied with the buoyancy frequency as far down as both columns reach
+__global__ __launch_bounds__(64) void k_cmn_nnslope_ale(const DevView *__restrict__ Vp) {
+  const DevView &V = *Vp;
+  COLUMN_IJ(V);
+  const bool isv = blockIdx.y == 1;
+  if (isv ? (j < 0 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_iv][c])
+          : (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 2 || !V.m[I_iu][c])) return;
+  const size_t np = V.nplane, a_ = isv ? c - V.ni : c - 1, b_ = c;
+  const int kk = V.kk;
+  const double *p = V.f[F_p], *bf = V.f[F_bfsqf];
+  const double *nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c;
+  double *nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
+  const double pba = p[a_ + (size_t)kk * np], pbb = p[b_ + (size_t)kk * np];
+  int knnsl = 1;
+  double last = 0.;
+  nnslp[0] = 0.;
+  for (int k = 2; k <= kk; k++) {
+    if (p[b_ + (size_t)(k - 1) * np] < pba && p[a_ + (size_t)(k - 1) * np] < pbb) {
+      const double bfsqm = .5 * (bf[a_ + (size_t)(k - 1) * np] + bf[b_ + (size_t)(k - 1) * np]);
+      last = sqrt(bfsqm) * nslp[(size_t)(k - 1) * np];
+      nnslp[(size_t)(k - 1) * np] = last;
+      knnsl = k;
+    } else break;
+  }
+  for (int k = knnsl + 1; k <= kk; k++) nnslp[(size_t)(k - 1) * np] = last;
+}
+
 // cmnfld_nslope_ale, :654-811 (after the geopotential, which is k_cmn_phi's loop): u- (blockIdx.y = 0) and v-points (1)
 __global__ __launch_bounds__(64) void k_cmn_nslope_ale(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
@@ -593,14 +621,20 @@ int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64);
   if (h.P.vcoord_tag != 1) {
     // the other vertical coordinates, :1203-1234: the filtered buoyancy frequency always, the slopes with eitmth = 'gm'
-    if (h.P.ltedtp_opt != 1) return ctx_fail(c, "cmnfld2: ltedtp = 'neutral' (cmnfld_nnslope_ale) is not built");
+    if (h.P.ltedtp_opt == 2 && h.P.eitmth == 2) {                                           // :817-818
+      if (int rc = st_xctilr(c, h.f[F_nslpx], 1, h.kk, 2, 2, 13)) return rc;
+      if (int rc = st_xctilr(c, h.f[F_nslpy], 1, h.kk, 2, 2, 14)) return rc;
+    }
     TimeScope ts(c, "cmnfld");
     HIPCHK(c, hipMemsetAsync(h.f[F_bfsqi], 0, sizeof(double) * (size_t)(h.kk + 1) * h.nplane, c->stream));      // :247-248
     HIPCHK(c, hipMemsetAsync(h.f[F_bfsql], 0, sizeof(double) * (size_t)h.kk * h.nplane, c->stream));
     hipLaunchKernelGGL(k_cmn_bfsqf_ale, g1, dim3(64), 0, c->stream, c->d, nn);
     if (h.P.eitmth == 2) {
-      hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
-      hipLaunchKernelGGL(k_cmn_nslope_ale, g2, dim3(64), 0, c->stream, c->d, nn);
+      if (h.P.ltedtp_opt == 2) hipLaunchKernelGGL(k_cmn_nnslope_ale, g2, dim3(64), 0, c->stream, c->d);   // :1229-1233
+      else {
+        hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
+        hipLaunchKernelGGL(k_cmn_nslope_ale, g2, dim3(64), 0, c->stream, c->d, nn);
+      }
     }
     HIPCHK(c, hipGetLastError());
     return 0;

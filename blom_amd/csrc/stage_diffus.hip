@@ -216,11 +216,21 @@ int st_diffus(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)n; (void)k1m;
   const DevView &h = c->h;
   const size_t np = h.nplane;
-  if (h.P.ltedtp_opt != 1) return ctx_fail(c, "diffus: ltedtp = 'neutral' (hybrid coordinate) is not built yet");
   if (3 + h.ntr > h.nwk || h.ntr > 64) return ctx_fail(c, "diffus: work space too small for this many tracers");
   const bool handed = c->pbcor1_handed_over;                 // pbcor1 left S, T and its tracers in the work space
   c->pbcor1_handed_over = false;
   if (int rc = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, 3, 3, 1)) return rc;        // :58
+  if (h.P.ltedtp_opt == 2) {
+    // ltedtp = 'neutral', :59-70: the lateral diffusion is ale_regrid_remap's (stage_ndiff.hip); only the halo updates remain
+    if (handed) return ctx_fail(c, "diffus: ltedtp = 'neutral' after a pbcor1 that handed its fields over");
+    if (int rc = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc;
+    if (int rc = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, 1, 1, 1)) return rc;
+    for (int nt = 0; nt < h.ntr; nt++) {
+      if (h.P.itrtke > 0 && !h.P.tkeidf && (nt + 1 == h.P.itrtke || nt + 1 == h.P.itrgls)) continue;
+      if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1n - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 1, 1, 1)) return rc;
+    }
+    return 0;
+  }
   unsigned long long move_mask = 0;
   if (handed) {
     for (int nt = 0; nt < h.ntr; nt++) {

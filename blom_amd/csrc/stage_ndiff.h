@@ -1,0 +1,18 @@
+// what ale_regrid_remap hands to the neutral diffusion (stage_ndiff.hip): the reconstructed source columns and the regridded
+// interfaces, as planes [level][column] over the model's padded plane
+#pragma once
+#include "blomgpu_internal.h"
+
+struct NdArgs {
+  const double *psrc, *pdst;   // source / destination interfaces, kk+1 planes each
+  const int *ksmx, *kdmx;      // deepest source / destination layer with mass
+  const double *tpc;           // polynomial coefficients of T, S, tracers: [field][layer][coefficient 0..npc-1] planes
+  const double *tsd;           // T and S at both interfaces of every source layer: [field 0..1][layer][upper, lower]
+  const double *drt, *drs;     // drho/dT, drho/dS there: [layer][upper, lower]
+  double *flx;                 // flux convergence: [destination layer][field] planes
+  double *scr;                 // the flux kernel's per-thread work arrays, ndiff_scratch_planes(kk) planes
+  int kk, npc, ntr_loc, mm, nn, surface_align;
+};
+
+size_t ndiff_scratch_planes(int kk);
+int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs);

@@ -1,0 +1,695 @@
+// ndiff -- neutral diffusion of tracers for the ALE coordinates (ltedtp = 'neutral', the reference's default with
+// vcoord_type = 'cntiso_hybrid'): phy/mod_ndiff.F90, called from inside ale_regrid_remap's j-slice loop
+// (phy/mod_ale_regrid_remap.F90:1639-1680) between the regridding and the remapping, on the reconstructed source profiles.
+//
+// For every pair of neighbouring columns (a u- or a v-face) the reference searches both columns from the surface for
+// "neutral interfaces" -- depths in the neighbour where the locally referenced density difference vanishes -- first anchored at
+// the source interfaces (search_loop1, a Newton iteration per crossing), then including the destination interfaces
+// (search_loop2); between two consecutive neutral interfaces that lie in one source layer and one destination layer on both
+// sides a diffusive flux of each tracer is formed from the layer means of the reconstruction polynomials and added to the flux
+// convergence of the two destination layers.  The flux convergence is applied to the remapped tracers.
+//
+// The order in which a cell's flux convergence receives its contributions is fixed by the j-slice loop: the v-face j (from the
+// iteration before), the u-faces i and i+1, the v-face j+1; every face adds one term per neutral layer, in search order.  A
+// running sum cannot be split, so here ONE THREAD PER CELL walks its four faces in that order and keeps only its own side of
+// each flux (every face is searched twice, by the cells on either side); the cell on the "plus" side of a face -- the one with
+// the face's own index -- also writes the face's outputs: the fluxes per velocity-point layer (utflld.., utflx..) and the
+// neutral slope (nslpx, nslpy) that cmnfld_nnslope_ale and eddtra_ale consume.
+//
+// Kernels
+//   k_ndiff_prep   ndiff_prep_jslice :959-1026: deepest source/destination layers with mass, the interface values of T and S,
+//                  drho/dT, drho/dS at both interfaces of every source layer; zeroes the face fluxes of the ring it covers
+//   k_ndiff_flux   ndiff_uflx_jslice / ndiff_vflx_jslice / ndiff_flx :166-953, cell-centred as described
+// ndiff_update_trc_jslice (:1149-1175) is fused into the copy-back of the remapped fields (stage_ale.hip).
+// Roofline: latency of dependent loads along a data-dependent search (two columns, ~6 kk steps); HBM bytes are secondary.
+#include "blomgpu_internal.h"
+#include "eos.h"
+#include "stage_ndiff.h"
+
+#define ND_GRAV 9.806
+#define ND_ALPHA0 1.e-3
+#define ND_EPSILP 1.e-12
+#define ND_ONEMM 9.806
+#define ND_MVAL 1.e30
+#define ND_DSTSNP_FAC .01   // :41-44
+#define ND_RHO_EPS 1.e-5
+#define ND_DP_EPS 1.e-5
+
+namespace {
+
+// drhodt, drhods (phy/mod_eos.F90:220-241, :284-304)
+__device__ inline double nd_drhodt(double p, double th, double s) {
+  using namespace eos;
+  const double r1 = a11 + (a12 + a14 * th + a15 * s) * th + (a13 + a16 * s) * s + (b11 + b12 * th + b13 * s) * p;
+  const double r2i = 1. / (a21 + (a22 + a24 * th + a25 * s) * th + (a23 + a26 * s) * s + (b21 + b22 * th + b23 * s) * p);
+  return (a12 + 2. * a14 * th + a15 * s + b12 * p - (a22 + 2. * a24 * th + a25 * s + b22 * p) * r1 * r2i) * r2i;
+}
+__device__ inline double nd_drhods(double p, double th, double s) {
+  using namespace eos;
+  const double r1 = a11 + (a12 + a14 * th + a15 * s) * th + (a13 + a16 * s) * s + (b11 + b12 * th + b13 * s) * p;
+  const double r2i = 1. / (a21 + (a22 + a24 * th + a25 * s) * th + (a23 + a26 * s) * s + (b21 + b22 * th + b23 * s) * p);
+  return (a13 + a15 * th + 2. * a16 * s + b13 * p - (a23 + a25 * th + 2. * a26 * s + b23 * p) * r1 * r2i) * r2i;
+}
+
+struct Pc5 { double c1, c2, c3, c4, c5; };
+
+// the five coefficients of layer ks of field nt of column col (the engine extracts npc per layer; the others are zero, as in
+// the reference's tpc_src of p_ord + 1 = 5 rows, phy/mod_ale_regrid_remap.F90:1495-1500)
+__device__ inline Pc5 nd_pc(const NdArgs &A, size_t np, size_t col, int ks, int nt) {
+  const double *b = A.tpc + col + ((size_t)nt * A.npc * A.kk + (size_t)(ks - 1) * A.npc) * np;
+  Pc5 r;
+  r.c1 = b[0];
+  r.c2 = A.npc > 1 ? b[np] : 0.;
+  r.c3 = A.npc > 2 ? b[2 * np] : 0.;
+  r.c4 = A.npc > 3 ? b[3 * np] : 0.;
+  r.c5 = A.npc > 4 ? b[4 * np] : 0.;
+  return r;
+}
+// peval (:62-75), pmeval (:77-103), peval0 / peval1 (phy/mod_ale_regrid_remap.F90:141-159)
+__device__ inline double nd_peval(const Pc5 &c, double x) { return (((c.c5 * x + c.c4) * x + c.c3) * x + c.c2) * x + c.c1; }
+__device__ inline double nd_pmeval(const Pc5 &c, double x0, double x1) {
+  const double c1_2 = 1. / 2., c1_3 = 1. / 3., c1_4 = 1. / 4., c1_5 = 1. / 5.;
+  const double b5 = c1_5 * c.c5;
+  const double b4 = b5 * x1 + c1_4 * c.c4;
+  const double b3 = b4 * x1 + c1_3 * c.c3;
+  const double b2 = b3 * x1 + c1_2 * c.c2;
+  const double b1 = b2 * x1 + c.c1;
+  return (((b5 * x0 + b4) * x0 + b3) * x0 + b2) * x0 + b1;
+}
+__device__ inline double nd_peval1(const Pc5 &c) { return c.c1 + c.c2 + c.c3 + c.c4 + c.c5; }
+// the value of a field at a neutral interface: kind 0 = the polynomial at x, 1 / 2 = the layer's upper / lower interface value
+__device__ inline double nd_tni(const Pc5 &c, int kind, double x) { return kind == 0 ? nd_peval(c, x) : (kind == 1 ? c.c1 : nd_peval1(c)); }
+
+// drhoroot, :105-152
+__device__ inline double nd_drhoroot(const Pc5 &t, const Pc5 &s, double tf, double sf, double drhodt_l, double drhodt_u, double drhods_l,
+                                     double drhods_u) {
+  const double eps = 1.e-14, x_tol = 1.e-4;
+  double x = .5;
+  const double ddrdtdx = drhodt_l - drhodt_u, ddrdsdx = drhods_l - drhods_u;
+  for (int n = 1; n <= 10; n++) {
+    const double dt = tf - (t.c1 + (t.c2 + (t.c3 + (t.c4 + t.c5 * x) * x) * x) * x);
+    const double ds = sf - (s.c1 + (s.c2 + (s.c3 + (s.c4 + s.c5 * x) * x) * x) * x);
+    const double drdt = drhodt_l * x + drhodt_u * (1. - x);
+    const double drds = drhods_l * x + drhods_u * (1. - x);
+    const double dtdx = -(t.c2 + (2. * t.c3 + (3. * t.c4 + 4. * t.c5 * x) * x) * x);
+    const double dsdx = -(s.c2 + (2. * s.c3 + (3. * s.c4 + 4. * s.c5 * x) * x) * x);
+    const double dr = drdt * dt + drds * ds;
+    const double ddrdx = ddrdtdx * dt + drdt * dtdx + ddrdsdx * ds + drds * dsdx;
+    const double x_old = x;
+    x = fmax2(0., fmin2(1., x_old - dr / copysign(fmax2(eps, fabs(ddrdx)), ddrdx)));
+    if (fabs(x - x_old) < x_tol) return x;
+  }
+  return x;
+}
+
+// ndiff_flx, :166-953, for the face between the columns cm ("minus": i-1 or j-1) and cp ("plus", the face's own index).
+// side 0: this thread's cell is cm, 1: it is cp, 2: neither (a face of the ring, searched for its outputs only); wedge: write
+// the face's outputs.  sc: the thread's scratch column.
+__device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp, bool isv, int side, bool wedge, size_t cown, double *sc) {
+  const size_t np = V.nplane;
+  const int kk = V.kk, mm = A.mm, nn = A.nn, ntr_loc = A.ntr_loc;
+  // 1-based accessors in the reference's names
+#define PSM(is_, ks_) A.psrc[cm + (size_t)((ks_) + (is_)-2) * np]                       /* p_srcdi_m(is,ks) = p_src(ks+is-1) */
+#define PSP(is_, ks_) A.psrc[cp + (size_t)((ks_) + (is_)-2) * np]
+#define TSM(is_, ks_, q_) A.tsd[cm + ((size_t)((q_)*kk + (ks_)-1) * 2 + (is_)-1) * np]   /* t_srcdi_m(is,ks,it|is) */
+#define TSP(is_, ks_, q_) A.tsd[cp + ((size_t)((q_)*kk + (ks_)-1) * 2 + (is_)-1) * np]
+#define DTM(is_, ks_) A.drt[cm + ((size_t)((ks_)-1) * 2 + (is_)-1) * np]
+#define DTP(is_, ks_) A.drt[cp + ((size_t)((ks_)-1) * 2 + (is_)-1) * np]
+#define DSM(is_, ks_) A.drs[cm + ((size_t)((ks_)-1) * 2 + (is_)-1) * np]
+#define DSP(is_, ks_) A.drs[cp + ((size_t)((ks_)-1) * 2 + (is_)-1) * np]
+#define PDM(k_) A.pdst[cm + (size_t)((k_)-1) * np]
+#define PDP(k_) A.pdst[cp + (size_t)((k_)-1) * np]
+#define PNM(is_, ks_) sc[((size_t)((ks_)-1) * 2 + (is_)-1) * np]                          /* p_ni_srcdi_m */
+#define PNP(is_, ks_) sc[((size_t)(2 * kk) + ((ks_)-1) * 2 + (is_)-1) * np]
+#define SNM(k_) sc[((size_t)(4 * kk) + (k_)-1) * np]                                      /* p_dstsnp_m */
+#define SNP(k_) sc[((size_t)(4 * kk) + (kk + 1) + (k_)-1) * np]
+#define NSL(n_) sc[((size_t)(4 * kk) + 2 * (kk + 1) + (n_)-1) * np]                       /* nslp_src */
+#define PNS(n_) sc[((size_t)(4 * kk) + 6 * (kk + 1) + (n_)-1) * np]                       /* p_nslp_src */
+#define DRHO(ism, ksm, isp_, ksp)                                                                                             \
+  ((.5 * (DTM(ism, ksm) + DTP(isp_, ksp))) * (TSP(isp_, ksp, 0) - TSM(ism, ksm, 0)) +                                        \
+   (.5 * (DSM(ism, ksm) + DSP(isp_, ksp))) * (TSP(isp_, ksp, 1) - TSM(ism, ksm, 1)))
+  const int ksmx_m = A.ksmx[cm], ksmx_p = A.ksmx[cp], kdmx_m = A.kdmx[cm], kdmx_p = A.kdmx[cp];
+  double cdiff, cnslp;
+  if (!isv) {                                                   // :1079-1080, :1134-1135
+    cdiff = V.P.delt1 * V.f[F_scuy][cp] * V.f[F_scuxi][cp];
+    cnslp = ND_ALPHA0 * V.f[F_scuxi][cp] / ND_GRAV;
+  } else {
+    cdiff = V.P.delt1 * V.f[F_scvx][cp] * V.f[F_scvyi][cp];
+    cnslp = ND_ALPHA0 * V.f[F_scvyi][cp] / ND_GRAV;
+  }
+  unsigned long long stm[2] = {0ull, 0ull}, stp[2] = {0ull, 0ull};          // stab_src_m, stab_src_p (kk <= 128)
+#define STM(ks_) ((stm[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
+#define STP(ks_) ((stp[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
+#define STM_SET(ks_) stm[((ks_)-1) >> 6] |= 1ull << (((ks_)-1) & 63)
+#define STP_SET(ks_) stp[((ks_)-1) >> 6] |= 1ull << (((ks_)-1) & 63)
+  for (int k = 1; k <= kk; k++) { PNM(1, k) = ND_MVAL; PNM(2, k) = ND_MVAL; PNP(1, k) = ND_MVAL; PNP(2, k) = ND_MVAL; }
+  int nns = 0;
+  int is_m, is_p, ks_m, ks_p, kssa_m = 0, kssa_p = 0;
+  double p_ni_m_prev, p_ni_p_prev, drho_curr = 0., pml = 0.;
+  // ---- first search: neutral interfaces anchored at the source interfaces, :225-392 -------------------------------------------
+  if (A.surface_align) {
+    const double *dpml = V.f[F_dpml];
+    pml = .5 * (PSM(1, 1) + dpml[cm] + PSP(1, 1) + dpml[cp]);
+    kssa_m = 2;
+    while (kssa_m <= ksmx_m) {
+      if (PSM(1, kssa_m) > pml) break;
+      kssa_m = kssa_m + 1;
+    }
+    kssa_p = 2;
+    while (kssa_p <= ksmx_p) {
+      if (PSP(1, kssa_p) > pml) break;
+      kssa_p = kssa_p + 1;
+    }
+    is_m = 1; ks_m = kssa_m; is_p = 1; ks_p = kssa_p;
+    p_ni_m_prev = pml; p_ni_p_prev = pml;
+  } else {
+    is_m = 1; ks_m = 1; is_p = 1; ks_p = 1;
+    p_ni_m_prev = PSM(1, 1); p_ni_p_prev = PSP(1, 1);
+  }
+  if (ks_m <= ksmx_m && ks_p <= ksmx_p) drho_curr = DRHO(is_m, ks_m, is_p, ks_p);
+  while (ks_m <= ksmx_m && ks_p <= ksmx_p) {                    // search_loop1
+    const bool drho_neg = drho_curr <= -ND_RHO_EPS, drho_pos = drho_curr >= ND_RHO_EPS;
+    const bool drho_zero = !(drho_neg || drho_pos);
+    if (is_m + ks_m > 2 && is_p + ks_p > 2) {
+      if (drho_neg) {
+        if (is_m == 2) {
+          const double drhodt_x0 = .5 * (DTM(1, ks_m) + DTP(is_p, ks_p)), drhodt_x1 = .5 * (DTM(2, ks_m) + DTP(is_p, ks_p));
+          const double drhods_x0 = .5 * (DSM(1, ks_m) + DSP(is_p, ks_p)), drhods_x1 = .5 * (DSM(2, ks_m) + DSP(is_p, ks_p));
+          const double x_ni = nd_drhoroot(nd_pc(A, np, cm, ks_m, 0), nd_pc(A, np, cm, ks_m, 1), TSP(is_p, ks_p, 0), TSP(is_p, ks_p, 1),
+                                          drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
+          const double p_ni = PSM(2, ks_m) * x_ni + PSM(1, ks_m) * (1. - x_ni);
+          if (p_ni > p_ni_m_prev) {
+            p_ni_m_prev = p_ni;
+            PNP(is_p, ks_p) = p_ni;
+            nns = nns + 1;
+            if (wedge) { NSL(nns) = -cnslp * (PSP(is_p, ks_p) - p_ni); PNS(nns) = .5 * (PSP(is_p, ks_p) + p_ni); }
+          }
+        }
+      } else if (drho_pos) {
+        if (is_p == 2) {
+          const double drhodt_x0 = .5 * (DTM(is_m, ks_m) + DTP(1, ks_p)), drhodt_x1 = .5 * (DTM(is_m, ks_m) + DTP(2, ks_p));
+          const double drhods_x0 = .5 * (DSM(is_m, ks_m) + DSP(1, ks_p)), drhods_x1 = .5 * (DSM(is_m, ks_m) + DSP(2, ks_p));
+          const double x_ni = nd_drhoroot(nd_pc(A, np, cp, ks_p, 0), nd_pc(A, np, cp, ks_p, 1), TSM(is_m, ks_m, 0), TSM(is_m, ks_m, 1),
+                                          drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
+          const double p_ni = PSP(2, ks_p) * x_ni + PSP(1, ks_p) * (1. - x_ni);
+          if (p_ni > p_ni_p_prev) {
+            p_ni_p_prev = p_ni;
+            PNM(is_m, ks_m) = p_ni;
+            nns = nns + 1;
+            if (wedge) { NSL(nns) = -cnslp * (p_ni - PSM(is_m, ks_m)); PNS(nns) = .5 * (p_ni + PSM(is_m, ks_m)); }
+          }
+        }
+      } else {
+        PNP(is_p, ks_p) = PSM(is_m, ks_m);
+        PNM(is_m, ks_m) = PSP(is_p, ks_p);
+        nns = nns + 1;
+        if (wedge) { NSL(nns) = -cnslp * (PSP(is_p, ks_p) - PSM(is_m, ks_m)); PNS(nns) = .5 * (PSP(is_p, ks_p) + PSM(is_m, ks_m)); }
+      }
+    }
+    bool done = false;
+    if (drho_zero || drho_pos) {
+      while (true) {
+        const double drho_prev = drho_curr;
+        if (is_m == 1) is_m = 2;
+        else {
+          ks_m = ks_m + 1;
+          if (ks_m > ksmx_m) { done = true; break; }
+          is_m = 1;
+        }
+        drho_curr = DRHO(is_m, ks_m, is_p, ks_p);
+        if (drho_prev - drho_curr > ND_RHO_EPS) {
+          if (is_m == 2 && PSM(2, ks_m) - PSM(1, ks_m) > ND_ONEMM) STM_SET(ks_m);
+          break;
+        }
+        if (is_m == 1) PNM(is_m, ks_m) = PNM(2, ks_m - 1);
+      }
+      if (done) break;
+    }
+    if (drho_zero || drho_neg) {
+      while (true) {
+        const double drho_prev = drho_curr;
+        if (is_p == 1) is_p = 2;
+        else {
+          ks_p = ks_p + 1;
+          if (ks_p > ksmx_p) { done = true; break; }
+          is_p = 1;
+        }
+        drho_curr = DRHO(is_m, ks_m, is_p, ks_p);
+        if (drho_curr - drho_prev > ND_RHO_EPS) {
+          if (is_p == 2 && PSP(2, ks_p) - PSP(1, ks_p) > ND_ONEMM) STP_SET(ks_p);
+          break;
+        }
+        if (is_p == 1) PNP(is_p, ks_p) = PNP(2, ks_p - 1);
+      }
+      if (done) break;
+    }
+  }
+  // ---- alignment with the surface above the uppermost neutral interface, :394-464 ---------------------------------------------
+  if (A.surface_align) {
+    int issa_m = 1, issa_p = 1;
+    while (kssa_m <= ksmx_m) {
+      if (PNM(issa_m, kssa_m) != ND_MVAL) break;
+      if (issa_m == 1) issa_m = 2;
+      else { kssa_m = kssa_m + 1; issa_m = 1; }
+    }
+    while (kssa_p <= ksmx_p) {
+      if (PNP(issa_p, kssa_p) != ND_MVAL) break;
+      if (issa_p == 1) issa_p = 2;
+      else { kssa_p = kssa_p + 1; issa_p = 1; }
+    }
+    if (kssa_m > ksmx_m || kssa_p > ksmx_p) {
+      PNM(1, 1) = PSM(1, 1);
+      for (ks_m = 1; ks_m <= ksmx_m - 1; ks_m++) {
+        if (PSM(1, ks_m) > PSP(2, ksmx_p)) break;
+        const double p_ni = fmin2(PSM(2, ks_m), PSP(2, ksmx_p));
+        PNM(1, ks_m + 1) = p_ni;
+        PNM(2, ks_m) = p_ni;
+        STM_SET(ks_m);
+      }
+      PNP(1, 1) = PSP(1, 1);
+      for (ks_p = 1; ks_p <= ksmx_p - 1; ks_p++) {
+        if (PSP(1, ks_p) > PSM(2, ksmx_m)) break;
+        const double p_ni = fmin2(PSP(2, ks_p), PSM(2, ksmx_m));
+        PNP(1, ks_p + 1) = p_ni;
+        PNP(2, ks_p) = p_ni;
+        STP_SET(ks_p);
+      }
+    } else {
+      double p1_m, p2_m, p1_p, p2_p;
+      if (PSM(issa_m, kssa_m) < PNP(issa_p, kssa_p)) {
+        p1_m = PSM(1, 1); p2_m = PSM(issa_m, kssa_m); p1_p = PSP(1, 1); p2_p = PNM(issa_m, kssa_m);
+      } else {
+        p1_m = PSM(1, 1); p2_m = PNP(issa_p, kssa_p); p1_p = PSP(1, 1); p2_p = PSP(issa_p, kssa_p);
+      }
+      PNM(1, 1) = p1_p;
+      for (ks_m = 1; ks_m <= kssa_m - 1; ks_m++) {
+        const double p_ni = ((PSM(2, ks_m) - p1_m) * p2_p + (p2_m - PSM(2, ks_m)) * p1_p) / (p2_m - p1_m);
+        PNM(1, ks_m + 1) = p_ni;
+        PNM(2, ks_m) = p_ni;
+        STM_SET(ks_m);
+      }
+      PNP(1, 1) = p1_m;
+      for (ks_p = 1; ks_p <= kssa_p - 1; ks_p++) {
+        const double p_ni = ((PSP(2, ks_p) - p1_p) * p2_m + (p2_p - PSP(2, ks_p)) * p1_m) / (p2_p - p1_p);
+        PNP(1, ks_p + 1) = p_ni;
+        PNP(2, ks_p) = p_ni;
+        STP_SET(ks_p);
+      }
+    }
+  }
+  // ---- destination interfaces snapped to the source interfaces they nearly coincide with, :476-508 ----------------------------
+  {
+    SNM(1) = PDM(1);
+    double dp_dst_u = PDM(2) - PDM(1);
+    const int km = ksmx_m < kdmx_m ? ksmx_m : kdmx_m;
+    for (int k = 2; k <= km; k++) {
+      const double dp_dst_l = PDM(k + 1) - PDM(k);
+      SNM(k) = fabs(PDM(k) - PSM(1, k)) < fmin2(dp_dst_u, dp_dst_l) * ND_DSTSNP_FAC ? PSM(1, k) : PDM(k);
+      dp_dst_u = dp_dst_l;
+    }
+    for (int k = km + 1; k <= kdmx_m + 1; k++) SNM(k) = PDM(k);
+    SNP(1) = PDP(1);
+    dp_dst_u = PDP(2) - PDP(1);
+    const int kp = ksmx_p < kdmx_p ? ksmx_p : kdmx_p;
+    for (int k = 2; k <= kp; k++) {
+      const double dp_dst_l = PDP(k + 1) - PDP(k);
+      SNP(k) = fabs(PDP(k) - PSP(1, k)) < fmin2(dp_dst_u, dp_dst_l) * ND_DSTSNP_FAC ? PSP(1, k) : PDP(k);
+      dp_dst_u = dp_dst_l;
+    }
+    for (int k = kp + 1; k <= kdmx_p + 1; k++) SNP(k) = PDP(k);
+  }
+  // ---- second search, :510-921 ------------------------------------------------------------------------------------------------
+  {
+    is_m = 2; ks_m = 0; is_p = 2; ks_p = 0;
+    int kd_m = 0, kd_p = 0, isn_m = 1, isn_p = 1, ksn_m = 1, ksn_p = 1, ks_m_prev = 0, ks_p_prev = 0, nip = 0, nic = 1, kuv = 1;
+    bool advance_src_m = true, advance_src_p = true, advance_dst_m = true, advance_dst_p = true;
+    double p_ni_m[2], p_ni_p[2], x_ni_m[2] = {0., 0.}, x_ni_p[2] = {0., 0.};
+    int knd_m[2] = {0, 0}, knd_p[2] = {0, 0};                 // how t_ni_m, t_ni_p of the slot were formed (nd_tni)
+    p_ni_m[nip] = -ND_MVAL; p_ni_p[nip] = -ND_MVAL;
+    p_ni_m[nic] = 0.; p_ni_p[nic] = 0.;
+    const double *puv = isv ? V.f[F_pv] : V.f[F_pu];
+    double *ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), *fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
+    double *ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), *fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
+    const double *difiso = V.f[F_difiso];
+    while (true) {                                              // search_loop2
+      if (advance_src_m) {
+        bool out = false;
+        while (true) {
+          if (is_m == 1) {
+            is_m = 2;
+            if (STM(ks_m)) break;
+          } else {
+            ks_m = ks_m + 1;
+            if (ks_m > ksmx_m) { out = true; break; }
+            is_m = 1;
+            if (STM(ks_m) && PNM(is_m, ks_m) != ND_MVAL) break;
+          }
+        }
+        if (out) break;
+        isn_m = is_m; ksn_m = ks_m;
+        while (PNM(isn_m, ksn_m) == ND_MVAL) {
+          if (isn_m == 1) isn_m = 2;
+          else {
+            if (ksn_m == ksmx_m) break;
+            ksn_m = ksn_m + 1;
+            isn_m = 1;
+          }
+        }
+      }
+      if (advance_src_p) {
+        bool out = false;
+        while (true) {
+          if (is_p == 1) {
+            is_p = 2;
+            if (STP(ks_p)) break;
+          } else {
+            ks_p = ks_p + 1;
+            if (ks_p > ksmx_p) { out = true; break; }
+            is_p = 1;
+            if (STP(ks_p) && PNP(is_p, ks_p) != ND_MVAL) break;
+          }
+        }
+        if (out) break;
+        isn_p = is_p; ksn_p = ks_p;
+        while (PNP(isn_p, ksn_p) == ND_MVAL) {
+          if (isn_p == 1) isn_p = 2;
+          else {
+            if (ksn_p == ksmx_p) break;
+            ksn_p = ksn_p + 1;
+            isn_p = 1;
+          }
+        }
+      }
+      if (p_ni_m[nip] == -ND_MVAL) {
+        if ((PNM(isn_m, ksn_m) - PSP(isn_p, ksn_p)) < (PNP(isn_p, ksn_p) - PSM(isn_m, ksn_m))) {
+          p_ni_m[nip] = PSM(isn_m, ksn_m);
+          p_ni_p[nip] = PNM(isn_m, ksn_m);
+        } else {
+          p_ni_m[nip] = PNP(isn_p, ksn_p);
+          p_ni_p[nip] = PSP(isn_p, ksn_p);
+        }
+      }
+      if (advance_dst_m) {
+        kd_m = kd_m + 1;
+        if (kd_m > kdmx_m) break;
+      }
+      if (advance_dst_p) {
+        kd_p = kd_p + 1;
+        if (kd_p > kdmx_p) break;
+      }
+      {
+        bool out = false;
+        while (SNM(kd_m + 1) <= fmax2(PSM(1, ks_m), p_ni_m[nip])) {
+          kd_m = kd_m + 1;
+          if (kd_m > kdmx_m) { out = true; break; }
+        }
+        if (out) break;
+        while (SNP(kd_p + 1) <= fmax2(PSP(1, ks_p), p_ni_p[nip])) {
+          kd_p = kd_p + 1;
+          if (kd_p > kdmx_p) { out = true; break; }
+        }
+        if (out) break;
+      }
+      advance_src_m = false; advance_src_p = false; advance_dst_m = false; advance_dst_p = false;
+      int case_m = 3, case_p = 3;
+      if (PSM(is_m, ks_m) <= PNP(isn_p, ksn_p)) {
+        if (PSM(is_m, ks_m) <= SNM(kd_m + 1)) case_m = 1;
+      } else if (PNP(isn_p, ksn_p) <= SNM(kd_m + 1)) case_m = 2;
+      if (PSP(is_p, ks_p) <= PNM(isn_m, ksn_m)) {
+        if (PSP(is_p, ks_p) <= SNP(kd_p + 1)) case_p = 1;
+      } else if (PNM(isn_m, ksn_m) <= SNP(kd_p + 1)) case_p = 2;
+      bool found_ni = false;
+      if (case_m == 3 && case_p == 3) {
+        if (is_p == 2 && is_m == 2) {
+          p_ni_m[nic] = SNM(kd_m + 1);
+          p_ni_p[nic] = SNP(kd_p + 1);
+          const double pu_m = p_ni_m[nip], pu_p = p_ni_p[nip];
+          double pl_m, pl_p;
+          if ((PNM(isn_m, ksn_m) - PSP(isn_p, ksn_p)) < (PNP(isn_p, ksn_p) - PSM(isn_m, ksn_m))) {
+            pl_m = PSM(isn_m, ksn_m); pl_p = PNM(isn_m, ksn_m);
+          } else {
+            pl_m = PNP(isn_p, ksn_p); pl_p = PSP(isn_p, ksn_p);
+          }
+          const double pp1 = (p_ni_m[nic] - pu_m) * (pl_p - pu_p), pp2 = (p_ni_p[nic] - pu_p) * (pl_m - pu_m);
+          if (fabs(pp1 - pp2) < ND_DP_EPS * fmax2(ND_DP_EPS, pl_m - pu_m + pl_p - pu_p)) {
+            advance_dst_m = true; advance_dst_p = true;
+          } else if (pp1 < pp2) {
+            p_ni_p[nic] = pu_p + pp1 / (pl_m - pu_m);
+            advance_dst_m = true;
+          } else {
+            p_ni_m[nic] = pu_m + pp2 / (pl_p - pu_p);
+            advance_dst_p = true;
+          }
+          if (p_ni_m[nic] >= PSM(1, ks_m) && p_ni_m[nic] <= PSM(2, ks_m) && p_ni_p[nic] >= PSP(1, ks_p) && p_ni_p[nic] <= PSP(2, ks_p)) {
+            x_ni_m[nic] = (p_ni_m[nic] - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
+            x_ni_p[nic] = (p_ni_p[nic] - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+            knd_m[nic] = 0; knd_p[nic] = 0;
+            found_ni = true;
+          }
+        } else {
+          if (is_p != 2) advance_dst_m = true;
+          if (is_m != 2) advance_dst_p = true;
+        }
+      } else if (case_m == 3) {
+        if (is_p == 2) {
+          p_ni_m[nic] = SNM(kd_m + 1);
+          if (case_p == 1)
+            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (PSP(isn_p, ksn_p) - p_ni_p[nip]) / (PNP(isn_p, ksn_p) - p_ni_m[nip]);
+          else
+            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (PNM(isn_m, ksn_m) - p_ni_p[nip]) / (PSM(isn_m, ksn_m) - p_ni_m[nip]);
+          if (p_ni_p[nic] >= PSP(1, ks_p) && p_ni_p[nic] <= PSP(2, ks_p)) {
+            x_ni_m[nic] = (SNM(kd_m + 1) - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
+            x_ni_p[nic] = (p_ni_p[nic] - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+            knd_m[nic] = 0; knd_p[nic] = 0;
+            found_ni = true;
+            advance_dst_m = true;
+          } else {
+            if (case_p == 1 && PNP(is_p, ks_p) == ND_MVAL) advance_src_p = true;
+            else advance_dst_m = true;
+          }
+        } else advance_dst_m = true;
+      } else if (case_p == 3) {
+        if (is_m == 2) {
+          p_ni_p[nic] = SNP(kd_p + 1);
+          if (case_m == 1)
+            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (PSM(isn_m, ksn_m) - p_ni_m[nip]) / (PNM(isn_m, ksn_m) - p_ni_p[nip]);
+          else
+            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (PNP(isn_p, ksn_p) - p_ni_m[nip]) / (PSP(isn_p, ksn_p) - p_ni_p[nip]);
+          if (p_ni_m[nic] >= PSM(1, ks_m) && p_ni_m[nic] <= PSM(2, ks_m)) {
+            x_ni_p[nic] = (SNP(kd_p + 1) - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+            x_ni_m[nic] = (p_ni_m[nic] - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
+            knd_m[nic] = 0; knd_p[nic] = 0;
+            found_ni = true;
+            advance_dst_p = true;
+          } else {
+            if (case_m == 1 && PNM(is_m, ks_m) == ND_MVAL) advance_src_m = true;
+            else advance_dst_p = true;
+          }
+        } else advance_dst_p = true;
+      } else if (case_m == 1 && case_p == 1) {
+        if (PNM(is_m, ks_m) != ND_MVAL && PNP(is_p, ks_p) != ND_MVAL) {
+          x_ni_m[nic] = (double)(is_m - 1);
+          p_ni_m[nic] = PSM(is_m, ks_m);
+          x_ni_p[nic] = (double)(is_p - 1);
+          p_ni_p[nic] = PSP(is_p, ks_p);
+          knd_m[nic] = is_m; knd_p[nic] = is_p;
+          found_ni = true;
+          advance_src_m = true; advance_src_p = true;
+        } else {
+          if (PNM(is_m, ks_m) == ND_MVAL) advance_src_m = true;
+          if (PNP(is_p, ks_p) == ND_MVAL) advance_src_p = true;
+        }
+      } else if (case_m == 1) {
+        if (PNM(is_m, ks_m) != ND_MVAL && PNM(is_m, ks_m) >= PSP(1, ks_p)) {
+          x_ni_m[nic] = (double)(is_m - 1);
+          p_ni_m[nic] = PSM(is_m, ks_m);
+          p_ni_p[nic] = PNM(is_m, ks_m);
+          x_ni_p[nic] = (p_ni_p[nic] - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+          knd_m[nic] = is_m; knd_p[nic] = 0;
+          found_ni = true;
+        }
+        advance_src_m = true;
+      } else if (case_p == 1) {
+        if (PNP(is_p, ks_p) != ND_MVAL && PNP(is_p, ks_p) >= PSM(1, ks_m)) {
+          x_ni_p[nic] = (double)(is_p - 1);
+          p_ni_p[nic] = PSP(is_p, ks_p);
+          p_ni_m[nic] = PNP(is_p, ks_p);
+          x_ni_m[nic] = (p_ni_m[nic] - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
+          knd_p[nic] = is_p; knd_m[nic] = 0;
+          found_ni = true;
+        }
+        advance_src_p = true;
+      } else {
+        advance_src_m = true; advance_src_p = true;
+      }
+      if (found_ni) {
+        const double dp_ni_m = fmin2(p_ni_m[nic] - p_ni_m[nip], PDM(kd_m + 1) - PDM(kd_m));
+        const double dp_ni_p = fmin2(p_ni_p[nic] - p_ni_p[nip], PDP(kd_p + 1) - PDP(kd_p));
+        const double dp_ni = 2. * dp_ni_m * dp_ni_p / fmax2(dp_ni_m + dp_ni_p, 2. * ND_DP_EPS);
+        if (ks_m == ks_m_prev && ks_p == ks_p_prev && p_ni_m[nip] >= SNM(kd_m) && p_ni_m[nic] <= SNM(kd_m + 1) && p_ni_p[nip] >= SNP(kd_p) &&
+            p_ni_p[nic] <= SNP(kd_p + 1) && dp_ni > 2. * ND_DP_EPS) {
+          const double q = .5 * cdiff * (difiso[cm + (size_t)(ks_m - 1) * np] + difiso[cp + (size_t)(ks_p - 1) * np]) * dp_ni;
+          const size_t om = cm + (size_t)(ks_m - 1 + nn) * np, op = cp + (size_t)(ks_p - 1 + nn) * np;
+          double *fl = A.flx + cown + (size_t)((side == 0 ? kd_m : kd_p) - 1) * ntr_loc * np;
+          Pc5 tm = nd_pc(A, np, cm, ks_m, 0), tp = nd_pc(A, np, cp, ks_p, 0), sm = nd_pc(A, np, cm, ks_m, 1), sp = nd_pc(A, np, cp, ks_p, 1);
+          const double dt = nd_pmeval(tm, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(tp, x_ni_p[nip], x_ni_p[nic]);
+          const double ds = nd_pmeval(sm, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(sp, x_ni_p[nip], x_ni_p[nic]);
+          if (dt * (V.f[F_temp][om] - V.f[F_temp][op]) >= 0. &&
+              dt * (nd_tni(tm, knd_m[nip], x_ni_m[nip]) - nd_tni(tp, knd_p[nip], x_ni_p[nip])) >= 0. &&
+              dt * (nd_tni(tm, knd_m[nic], x_ni_m[nic]) - nd_tni(tp, knd_p[nic], x_ni_p[nic])) >= 0. &&
+              ds * (V.f[F_saln][om] - V.f[F_saln][op]) >= 0. &&
+              ds * (nd_tni(sm, knd_m[nip], x_ni_m[nip]) - nd_tni(sp, knd_p[nip], x_ni_p[nip])) >= 0. &&
+              ds * (nd_tni(sm, knd_m[nic], x_ni_m[nic]) - nd_tni(sp, knd_p[nic], x_ni_p[nic])) >= 0.) {
+            const double tflx = q * dt, sflx = q * ds;
+            if (side == 0) { fl[0] = fl[0] + tflx; fl[np] = fl[np] + sflx; }
+            else if (side == 1) { fl[0] = fl[0] - tflx; fl[np] = fl[np] - sflx; }
+            if (wedge) {
+              const double p_ni_up = .5 * (p_ni_m[nip] + p_ni_p[nip]), p_ni_lo = .5 * (p_ni_m[nic] + p_ni_p[nic]);
+              const double dp_ni_i = 1. / fmax2(ND_EPSILP, p_ni_lo - p_ni_up);
+              while (kuv <= kk) {
+                const size_t ok = cp + (size_t)(kuv - 1 + mm) * np;
+                const double pk1 = puv[cp + (size_t)kuv * np], pk = puv[cp + (size_t)(kuv - 1) * np];
+                if (pk1 < p_ni_lo) {
+                  const double mlfrac = fmax2(0., pk1 - fmax2(p_ni_up, pk)) * dp_ni_i;
+                  ftl[ok] = ftl[ok] + tflx * mlfrac; fsl[ok] = fsl[ok] + sflx * mlfrac;
+                  ftx[ok] = ftx[ok] + tflx * mlfrac; fsx[ok] = fsx[ok] + sflx * mlfrac;
+                  kuv = kuv + 1;
+                } else {
+                  const double mlfrac = (p_ni_lo - fmax2(p_ni_up, pk)) * dp_ni_i;
+                  ftl[ok] = ftl[ok] + tflx * mlfrac; fsl[ok] = fsl[ok] + sflx * mlfrac;
+                  ftx[ok] = ftx[ok] + tflx * mlfrac; fsx[ok] = fsx[ok] + sflx * mlfrac;
+                  break;
+                }
+              }
+            }
+          }
+          if (side != 2)
+            for (int nt = 2; nt < ntr_loc; nt++) {
+              const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
+              const double dtr = nd_pmeval(cm5, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(cp5, x_ni_p[nip], x_ni_p[nic]);
+              const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
+              if (dtr * (V.f[F_trc][om + otr] - V.f[F_trc][op + otr]) >= 0. &&
+                  dtr * (nd_tni(cm5, knd_m[nip], x_ni_m[nip]) - nd_tni(cp5, knd_p[nip], x_ni_p[nip])) >= 0. &&
+                  dtr * (nd_tni(cm5, knd_m[nic], x_ni_m[nic]) - nd_tni(cp5, knd_p[nic], x_ni_p[nic])) >= 0.) {
+                const double tflx = q * dtr;
+                if (side == 0) fl[(size_t)nt * np] = fl[(size_t)nt * np] + tflx;
+                else fl[(size_t)nt * np] = fl[(size_t)nt * np] - tflx;
+              }
+            }
+        }
+        ks_m_prev = ks_m; ks_p_prev = ks_p;
+        nip = 1 - nip; nic = 1 - nic;
+      }
+    }
+  }
+  // ---- neutral slope at the destination interfaces, :923-951 ------------------------------------------------------------------
+  if (wedge) {
+    double *nsl = (isv ? V.f[F_nslpy] : V.f[F_nslpx]);
+#define NSXY(kd_) nsl[cp + (size_t)((kd_)-1) * np]
+    if (nns == 0) {
+      for (int kd = 1; kd <= kk; kd++) NSXY(kd) = 0.;
+    } else {
+      int kd;
+      double p_nslp_dst = 0.;
+      for (kd = 1; kd <= kk; kd++) {
+        p_nslp_dst = .5 * (PDM(kd) + PDP(kd));
+        if (p_nslp_dst > PNS(1)) break;
+        NSXY(kd) = NSL(1);
+      }
+      if (kd <= kk) {
+        int ks = 1;
+        while (true) {                                          // interp_loop
+          bool out = false;
+          while (p_nslp_dst > PNS(ks)) {
+            if (ks == nns) { out = true; break; }
+            ks = ks + 1;
+          }
+          if (out) break;
+          const double q = (PNS(ks) - p_nslp_dst) / fmax2(PNS(ks) - PNS(ks - 1), ND_EPSILP);
+          NSXY(kd) = q * NSL(ks - 1) + (1. - q) * NSL(ks);
+          kd = kd + 1;
+          if (kd > kk) break;
+          p_nslp_dst = .5 * (PDM(kd) + PDP(kd));
+        }
+        for (; kd <= kk; kd++) NSXY(kd) = NSL(nns);
+      }
+    }
+#undef NSXY
+  }
+}
+
+}  // namespace
+
+// ndiff_prep_jslice, :959-1026, for the p-columns of the ring (i = 0..ii+1, j = 0..jj+1)
+__global__ void k_ndiff_prep(const DevView *__restrict__ Vp, NdArgs A, int *__restrict__ ksmx, int *__restrict__ kdmx, double *__restrict__ tsd,
+                             double *__restrict__ drt, double *__restrict__ drs) {
+  const DevView &V = *Vp;
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t_ >= V.nplane) return;
+  const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
+  const size_t c = t_, np = V.nplane;
+  const int kk = V.kk, mm = A.mm;
+  if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
+  if (V.m[I_ip][c]) {
+    // deepest source layer with mass (reconstruct_trc_jslice, phy/mod_ale_regrid_remap.F90:218-222) and destination layer (:981-986)
+    int ks = kk, kd = kk;
+    const double pbs = A.psrc[c + (size_t)kk * np], pbd = A.pdst[c + (size_t)kk * np];
+    for (int k = kk; k >= 1; k--) {
+      if (A.psrc[c + (size_t)(k - 1) * np] == pbs) ks = k - 1;
+      if (A.pdst[c + (size_t)(k - 1) * np] == pbd) kd = k - 1;
+    }
+    ksmx[c] = ks;
+    kdmx[c] = kd;
+    for (int k = 1; k <= ks; k++) {
+      const Pc5 t = nd_pc(A, np, c, k, 0), s = nd_pc(A, np, c, k, 1);
+      const double t1 = t.c1, t2 = nd_peval1(t), s1 = s.c1, s2 = nd_peval1(s);      // t_srcdi, phy/mod_ale_regrid_remap.F90:252-255
+      const double p1 = A.psrc[c + (size_t)(k - 1) * np], p2 = A.psrc[c + (size_t)k * np];
+      tsd[c + ((size_t)(k - 1) * 2) * np] = t1;
+      tsd[c + ((size_t)(k - 1) * 2 + 1) * np] = t2;
+      tsd[c + ((size_t)(kk + k - 1) * 2) * np] = s1;
+      tsd[c + ((size_t)(kk + k - 1) * 2 + 1) * np] = s2;
+      drt[c + ((size_t)(k - 1) * 2) * np] = nd_drhodt(p1, t1, s1);
+      drt[c + ((size_t)(k - 1) * 2 + 1) * np] = nd_drhodt(p2, t2, s2);
+      drs[c + ((size_t)(k - 1) * 2) * np] = nd_drhods(p1, t1, s1);
+      drs[c + ((size_t)(k - 1) * 2 + 1) * np] = nd_drhods(p2, t2, s2);
+    }
+    for (int n = 0; n < kk * A.ntr_loc; n++) A.flx[c + (size_t)n * np] = 0.;
+  }
+  if (V.m[I_iu][c])
+    for (int k = 0; k < kk; k++) { V.f[F_utflld][c + (size_t)(k + mm) * np] = 0.; V.f[F_usflld][c + (size_t)(k + mm) * np] = 0.; }
+  if (V.m[I_iv][c])
+    for (int k = 0; k < kk; k++) { V.f[F_vtflld][c + (size_t)(k + mm) * np] = 0.; V.f[F_vsflld][c + (size_t)(k + mm) * np] = 0.; }
+}
+
+// the four faces of a cell in the order the reference's j-slice loop visits them (header); cells of the ring own faces only
+__global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ Vp, NdArgs A) {
+  const DevView &V = *Vp;
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t_ >= V.nplane) return;
+  const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
+  const size_t c = t_;
+  const int ii = V.ii, jj = V.jj, ni = V.ni;
+  if (j < 1 || j > jj + 1 || i < 1 || i > ii + 1) return;
+  const bool cell = j <= jj && i <= ii && V.m[I_ip][c];
+  double *sc = A.scr + c;
+  // v-face j: rows j-1 | j (ndiff_vflx_jslice of the iteration before, i = 1..ii)
+  if (i <= ii && V.m[I_iv][c]) nd_face(V, A, c - ni, c, true, cell ? 1 : 2, true, c, sc);
+  // u-face i: columns i-1 | i (ndiff_uflx_jslice, rows 1..jj, i = 1..ii+1)
+  if (j <= jj && V.m[I_iu][c]) nd_face(V, A, c - 1, c, false, cell ? 1 : 2, true, c, sc);
+  if (!cell) return;
+  // u-face i+1 and v-face j+1: this cell is on their minus side
+  if (V.m[I_iu][c + 1]) nd_face(V, A, c, c + 1, false, 0, false, c, sc);
+  if (V.m[I_iv][c + ni]) nd_face(V, A, c, c + ni, true, 0, false, c, sc);
+}
+
+size_t ndiff_scratch_planes(int kk) { return (size_t)4 * kk + (size_t)10 * (kk + 1); }
+
+int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs) {
+  const DevView &h = c->h;
+  if (h.kk > 128) return ctx_fail(c, "ndiff: more than 128 layers");
+  const unsigned nb = (unsigned)((h.nplane + 63) / 64);
+  hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, c->stream, c->d, A, ksmx, kdmx, tsd, drt, drs);
+  hipLaunchKernelGGL(k_ndiff_flux, dim3(nb), dim3(64), 0, c->stream, c->d, A);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

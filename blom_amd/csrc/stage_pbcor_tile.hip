@@ -278,7 +278,8 @@ int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf, int 
   const int ntx = (h.ni + PT_TW - 1) / PT_TW, nty = (h.nj + PT_TH - 1) / PT_TH;
   hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx, from_remap);
   // inside blomgpu_step pbcor1 hands S, T and the tracers to diffus through the work space, pbcor2 to tmsmt2
-  const int move = !c->in_sequence;
+  // (with ltedtp = 'neutral' diffus is halo updates only: nothing to hand to it)
+  const int move = !c->in_sequence || (which == 1 && h.P.ltedtp_opt == 2);
   (which == 1 ? c->pbcor1_handed_over : c->pbcor2_handed_over) = !move;
   hipLaunchKernelGGL(k_pbc_rescale_from, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, offc, move);
   return 0;

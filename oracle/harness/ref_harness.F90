@@ -284,6 +284,7 @@ contains
       case ('nday_in_year'); nday_in_year = v
       case ('vcoord_tag'); vcoord_tag = v
       case ('ltedtp_opt'); ltedtp_opt = v
+      case ('ndiff_surface_align'); ndiff_surface_align = (v /= 0)
       case ('bdmtyp');     bdmtyp = v
       case ('iwdflg');     iwdflg = v
       case ('csdiag');     csdiag = (v /= 0)

@@ -49,6 +49,7 @@ def ale_init_once(ref, lib, o, six, tmp_path):
         assert ref._ale_options == o, "the reference library's ALE structures were initialised with other options"
         return
     ref.ref.set("vcoord_tag", 2)               # the reader resolves regrid_method only for 'cntiso_hybrid' (:1323)
+    ref.ref.set("ltedtp_opt", 2)               # the structures get the index range neutral diffusion needs (:1384-1390): a superset
     (tmp_path / "limits").write_text(_limits_text(o))
     cwd = os.getcwd()
     os.chdir(tmp_path)
@@ -56,6 +57,7 @@ def ale_init_once(ref, lib, o, six, tmp_path):
         ref.ref.stage("ale_init", *six)
     finally:
         os.chdir(cwd)
+        ref.ref.set("ltedtp_opt", 1)
     ref._ale_options = dict(o)
 
 
@@ -127,7 +129,21 @@ def test_full_size_channel_ale_regrid_remap_equals_the_real_module(vcoord, tmp_p
     run_with_big_stack(_ale_regrid_remap_check, "channel_tke", 3, 0.5, vcoord, tmp_path)
 
 
-def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path):
+NDIFF_OUT = ["utflld", "usflld", "vtflld", "vsflld", "utflx", "usflx", "vtflx", "vsflx", "nslpx", "nslpy"]
+
+
+@pytest.mark.parametrize("cfg,nsteps,spread,vcoord,align", [
+    ("chan_s", 4, 0.5, "nudge", 1), ("chan_s", 2, 0.1, "nudge", 0), ("fuk95", 3, 0.6, "nudge", 1), ("box_s", 4, 0.8, "nudge", 0),
+    ("tri_s", 3, 0.3, "nudge", 1), ("fuk95", 3, 1.0, "nudge+plevel", 1), ("chan_s", 4, 0.5, "cntiso_hybrid", 1),
+    ("box_s", 4, 0.8, "cntiso_hybrid", 1), ("tri_s", 3, 1.0, "plevel", 0)])
+def test_device_neutral_diffusion_equals_the_real_module(cfg, nsteps, spread, vcoord, align, tmp_path):
+    """ltedtp = 'neutral' (the reference's default with vcoord_type = 'cntiso_hybrid'): ale_regrid_remap with phy/mod_ndiff.F90's
+    neutral diffusion between the regridding and the remapping -- the fluxes per face and layer, the neutral slopes, and the
+    tracers with the flux convergence applied, bit for bit; with and without the alignment with the surface in the mixed layer"""
+    _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path, ndiff=align)
+
+
+def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path, ndiff=None):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
@@ -163,6 +179,19 @@ def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path):
         ref.ref.set("delt1", delt1)
         gpu.set("delt1", delt1)
         pre_sigint = ref.get("sigint").copy()
+        if ndiff is not None:
+            nj, ni = case.jdm + 8, case.idm + 8
+            yy, xx = np.meshgrid(np.linspace(0.0, 1.0, nj), np.linspace(0.0, 2 * np.pi, ni), indexing="ij")
+            difiso = 800.0 * (1.0 + 0.5 * np.sin(xx) * yy)[None] * np.linspace(1.0, 0.3, kk)[:, None, None]
+            dpml = 9806.0 * (20.0 + 60.0 * yy * (1.0 + 0.5 * np.cos(2 * xx)))[None]
+            for be in (ref, gpu):
+                be.put("difiso", difiso)
+                be.put("dpml", dpml)
+            ref.ref.set("ltedtp_opt", 2)
+            ref.ref.set("ndiff_surface_align", int(ndiff))
+            gpu.set("ltedtp_opt", 2)
+            gpu.set("ndiff_surface_align", int(ndiff))
+            copy_state(gpu, ref, fields=NDIFF_OUT)
         ref.ref.stage("ale_regrid_remap", *six)
         # device
         gpu.set("vcoord_type", vcoord)
@@ -172,8 +201,11 @@ def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path):
             gpu.put("sigint", pre_sigint)          # the reference's initial pattern (spval) where the stage does not write
         before = gpu.get("dp").copy()
         gpu.stage("ale_regrid_remap", *six)
-        bad = diff_report(ref, gpu, fields=OUT + (["sigint"] if tag == 2 else []))
+        bad = diff_report(ref, gpu, fields=OUT + (["sigint"] if tag == 2 else []) + (NDIFF_OUT if ndiff is not None else []))
         assert not bad, fmt_report(bad[:10])
+        if ndiff is not None:
+            mmq = six[2]
+            assert np.abs(gpu.get("utflld")[mmq:mmq + kk]).max() > 0.0 and np.abs(gpu.get("nslpx")).max() > 0.0
         # the stage did something: layers moved, and mass, heat and salt of every column are what they were
         after = gpu.get("dp")
         nn = six[3]
@@ -184,6 +216,7 @@ def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path):
         np.testing.assert_allclose(col1, col0, rtol=1e-12)
     finally:
         ref.ref.set("vcoord_tag", 1)
+        ref.ref.set("ltedtp_opt", 1)
         gpu.close()
 
 

@@ -36,7 +36,8 @@ def _forcing(case, be, amp):
 def _full_step_check(cfg, nsteps, relax):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
-    lib = "channel_tke_omp_xml" if cfg == "channel_tke" else cfg.replace("_tke", "") + "_xml"
+    big = cfg.split("_")[0] in ("channel", "tnx2v1s", "tnx1v4s")
+    lib = cfg + "_omp_xml" if big else cfg.replace("_tke", "") + "_xml"
     if not have_ref(lib):
         pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
     case = make_case(cfg, nslp0=0.0)
@@ -77,7 +78,7 @@ def _full_step_check(cfg, nsteps, relax):
             ng += 1
             # (the OpenMP build of the reference at channel size leaves utotn, vtotn untouched outside the interior: they are
             # firstprivate in momtum's layer loop, phy/mod_momtum.F90:342-350 -- interior only there)
-            omp = cfg.startswith("channel")
+            omp = big
             bad = diff_report(ref, gpu, fields=[f for f in CHECK if not (omp and f in ("utotn", "vtotn"))])
             assert not bad, f"step {nr}\n" + fmt_report(bad[:12])
             if omp:
@@ -104,3 +105,10 @@ def test_full_size_channel_full_physics_step_equals_the_reference_stage_sequence
     """three steps at BASELINE.json's channel size (208x512x53, ntr = 3): what `bench.py --opt full_physics=1` times"""
     from test_xcheck_ale import run_with_big_stack
     run_with_big_stack(_full_step_check, "channel_tke", 3, False)
+
+
+def test_full_size_tnx2v1s_full_physics_step_equals_the_reference_stage_sequence():
+    """two steps at the tnx2v1 grid's size (180x193x53, arctic patch): thermf's sums leave the seam row out, mxlayr and the
+    velocity halos cross the patch"""
+    from test_xcheck_ale import run_with_big_stack
+    run_with_big_stack(_full_step_check, "tnx2v1s_tke", 2, True)
