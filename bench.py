@@ -455,7 +455,7 @@ def _hybrid_fields(case):
     return f
 
 
-def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0):
+def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0, neutral=True):
     """the same hybrid stage sequence in the reference's own modules (oracle/_ref/channel_tke_omp_xaln: real mod_ale_regrid_remap,
     mod_ale_forcing, mod_ale_vdiff, mod_eddtra, mod_cmnfld_routines behind the stand-ins of oracle/xcheck), OpenMP on all cores"""
     import ctypes as C
@@ -492,6 +492,7 @@ def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0):
            f"  TRACER_PC_UPPER_BNDR = {fl(o['tracer_pc_upper_bndr'])}\n  TRACER_PC_LOWER_BNDR = {fl(o['tracer_pc_lower_bndr'])}\n"
            f"  VELOCITY_PC_UPPER_BNDR = {fl(o['velocity_pc_upper_bndr'])}\n  VELOCITY_PC_LOWER_BNDR = {fl(o['velocity_pc_lower_bndr'])}\n"
            f"  REGRID_METHOD = '{o['regrid_method']}'\n /\n")
+    be.ref.set("ltedtp_opt", 2)                 # the structures' index range (phy/mod_ale_regrid_remap.F90:1384-1390)
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "limits"), "w").write(txt)
         cwd = os.getcwd()
@@ -502,6 +503,8 @@ def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0):
             os.chdir(cwd)
     be.ref.stage("eddtra_init_fox08", *six0)
     be.ref.set("eitmth", "gm")
+    be.ref.set("ltedtp_opt", 2 if neutral else 1)
+    be.ref.set("ndiff_surface_align", 1)
     be.ref.stage("cmnfld1", *hostinit.init_indices(0, kk))
     ns = dyncore_step(be, 0, case.params["baclin"], stages=HYBRID_STAGES)
     per_stage, mark = {}, [None, 0.0]
@@ -518,6 +521,7 @@ def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0):
         n += 1
     dt = (time.time() - t0) / n
     be.ref.set("vcoord_tag", 1)
+    be.ref.set("ltedtp_opt", 1)
     return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=ncores, kind="reference", build=lib,
                 stages_ms={k: round(v_ / n * 1e3, 2) for k, v_ in per_stage.items() if k}, steps_timed=n,
                 sample=f"{n} steps of the same hybrid stage sequence on the channel, {dt * 1e3:.1f} ms/step, {ncores} OpenMP threads; every stage in "
@@ -556,6 +560,9 @@ def bench_hybrid_step(args):
         gpu.set("ale_" + nm, 1 if o[nm] else 0)
     gpu.set("mlrmth", "fox08")
     gpu.set_vector("plevel", plevel)
+    neutral = args.ltedtp == "neutral"
+    gpu.set("ltedtp_opt", 2 if neutral else 1)
+    gpu.set("ndiff_surface_align", 1)
     for o_ in args.opt:
         nm, v = o_.split("=")
         gpu.set(nm, int(v))
@@ -571,7 +578,7 @@ def bench_hybrid_step(args):
     gpu.timer_reset()
     ns = gpu.step(ns, min(args.steps, 5))
     gpu.sync()
-    classes = ["ale_regrid_remap", "cmnfld", "eddtra", "remap", "diffus", "pgforc", "momtum", "ale_forcing", "ale_vdiff", "barotp", "pbcor1", "pbcor2"]
+    classes = ["ale_regrid_remap", "ndiff", "cmnfld", "eddtra", "remap", "diffus", "pgforc", "momtum", "ale_forcing", "ale_vdiff", "barotp", "pbcor1", "pbcor2"]
     live = {}
     for cl in classes:
         ms, n = gpu.timer_get(cl)
@@ -599,7 +606,7 @@ def bench_hybrid_step(args):
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"channel {case.idm}x{case.jdm}x{kk}, ntr={case.ntr}: the step of vcoord_type = cntiso_hybrid as far as built "
-                                  "(ale_regrid_remap nudge/ppm 6/4, cmnfld2, eddtra_ale gm+fox08, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
+                                  f"(ltedtp = '{args.ltedtp}'; ale_regrid_remap nudge/ppm 6/4" + (" with neutral diffusion" if neutral else "") + ", cmnfld2, eddtra_ale gm+fox08, advect remap, pbcor1, diffus, pgforc, momtum, cmnfld_bfsqi_ale, ale_forcing, "
                                   "ale_vdifft, ale_vdiffm, barotp, pbcor2, tmsmt2, cmnfld1); diffusivities, non-local fractions, boundary layer depth, surface fluxes constant",
                       "parity": "cross-checked stage sequence, also at this size (tests/test_xcheck_hybrid_step.py)", "state_finite": finite},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -614,7 +621,7 @@ def bench_hybrid_step(args):
     if not args.no_cpu_baseline:
         res = {}
         threading.stack_size(2 << 30)
-        th = threading.Thread(target=lambda: res.update(_cpu_baseline_hybrid(case, masks, nreg, plevel)))
+        th = threading.Thread(target=lambda: res.update(_cpu_baseline_hybrid(case, masks, nreg, plevel, neutral=neutral)))
         th.start()
         th.join()
         threading.stack_size(0)
@@ -643,6 +650,9 @@ def main():
                          "(ustar3, niw_ke_tendency), thermf, mxlayr, cmnfld1 besides the dynamical core (stepper.FULL_STAGES); "
                          "dyncore: the dynamical core alone, as in rounds 1-3 (the only form on several tiles: thermf's global "
                          "sums are single-tile)")
+    ap.add_argument("--ltedtp", default="neutral", choices=["neutral", "layer"],
+                    help="--config hybrid: lateral tracer diffusion, 'neutral' (phy/mod_ndiff.F90 inside ale_regrid_remap; the reference's "
+                         "default for cntiso_hybrid) or 'layer' (diffus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dyncore-compare", action="store_true",
                     help="leave out the extra steps of the dynamical core alone that follow the measurement (profiling runs)")

@@ -960,6 +960,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
     if (int rc2 = st_ndiff_prep_flux(c, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
       return rc2;
+    c->fluxes_zeroed = false;                   // utflx .. vsflx carry the diffusive fluxes now: advect must add to them
   }
   const double *flx = ndiff ? a->nd_col + (size_t)8 * per : nullptr;
   for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {

@@ -688,6 +688,7 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *t
   const DevView &h = c->h;
   if (h.kk > 128) return ctx_fail(c, "ndiff: more than 128 layers");
   const unsigned nb = (unsigned)((h.nplane + 63) / 64);
+  TimeScope ts(c, "ndiff");
   hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, c->stream, c->d, A, ksmx, kdmx, tsd, drt, drs);
   hipLaunchKernelGGL(k_ndiff_flux, dim3(nb), dim3(64), 0, c->stream, c->d, A);
   HIPCHK(c, hipGetLastError());

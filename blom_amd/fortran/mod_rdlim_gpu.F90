@@ -247,6 +247,11 @@ contains
         write (*,*) ' ltedtp = ', trim(ltedtp), ' is unsupported!'
         error stop '(readnml_diffusion)'
     end select
+    if (ndiff_surface_align) then
+      call gpu_set('ndiff_surface_align', 1)
+    else
+      call gpu_set('ndiff_surface_align', 0)
+    end if
     baclin_out = baclin
     ! an integer number of baroclinic steps per day, phy/mod_time.F90:121-130
     nstep_in_day = nint(86400.d0/baclin)

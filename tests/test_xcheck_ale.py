@@ -143,6 +143,12 @@ def test_device_neutral_diffusion_equals_the_real_module(cfg, nsteps, spread, vc
     _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path, ndiff=align)
 
 
+def test_full_size_channel_neutral_diffusion_equals_the_real_module(tmp_path):
+    """neutral diffusion at BASELINE.json's channel size (208x512x53, ntr = 3, ppm 6/4, nudge): the cell-centred flux kernel's
+    scratch planes and face ranges at the size it is timed on (oracle/_ref/channel_tke_omp_xaln)"""
+    run_with_big_stack(_ale_regrid_remap_check, "channel_tke", 3, 0.5, "nudge", tmp_path, 1)
+
+
 def _ale_regrid_remap_check(cfg, nsteps, spread, vcoord, tmp_path, ndiff=None):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref

@@ -43,6 +43,16 @@ def test_hybrid_step_equals_the_reference_stage_sequence(cfg, advmth, method, vc
     _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path)
 
 
+@pytest.mark.parametrize("cfg,advmth,method,vcoord,nsteps", [
+    ("chan_s", "remap", "nudge", "cntiso_hybrid", 6), ("fuk95", "cppm", "nudge", "plevel", 4), ("box_s", "cppm", "direct", "cntiso_hybrid", 4),
+    ("tri_s", "remap", "nudge", "cntiso_hybrid", 4)])
+def test_hybrid_step_with_neutral_diffusion_equals_the_reference_stage_sequence(cfg, advmth, method, vcoord, nsteps, tmp_path):
+    """ltedtp = 'neutral', the reference's default for the hybrid coordinate (cime_config/namelist_definition_blom.xml:1851-1862):
+    ale_regrid_remap carries the neutral diffusion (phy/mod_ndiff.F90), cmnfld2 takes its slopes (cmnfld_nnslope_ale) for
+    eddtra_ale, diffus is halo updates only"""
+    _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=True)
+
+
 @pytest.mark.parametrize("advmth,method", [("remap", "nudge"), ("cppm", "direct")])
 def test_full_size_channel_hybrid_step_equals_the_reference_stage_sequence(advmth, method, tmp_path):
     """Two whole hybrid steps at BASELINE.json's channel size (208x512x53, ntr = 3) with the &ALE_REGRID_REMAP group of the
@@ -51,7 +61,12 @@ def test_full_size_channel_hybrid_step_equals_the_reference_stage_sequence(advmt
     run_with_big_stack(_hybrid_step_check, "channel_tke", advmth, method, "cntiso_hybrid", 2, tmp_path)
 
 
-def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path):
+def test_full_size_channel_hybrid_step_with_neutral_diffusion_equals_the_reference_stage_sequence(tmp_path):
+    """what `bench.py --config hybrid` times by default (ltedtp = 'neutral'), two steps at the channel's size"""
+    run_with_big_stack(_hybrid_step_check, "channel_tke", "remap", "nudge", "cntiso_hybrid", 2, tmp_path, True)
+
+
+def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=False):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
@@ -123,18 +138,36 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path):
     gpu.set("mlrmth", "fox08")
     try:
         ref.ref.set("vcoord_tag", tag)
+        for be in (ref.ref, gpu):
+            be.set("ltedtp_opt", 2 if neutral else 1)
+            be.set("ndiff_surface_align", 1)
         # blom_init's cmnfld1 (phy/mod_blom_init.F90): the mixed layer depth the first ale_forcing reads
         ref.ref.stage("cmnfld1", *hostinit.init_indices(0, kk))
         gpu.stage("cmnfld1", *hostinit.init_indices(0, kk))
         nr = ng = 0
         for _ in range(nsteps):
+            if os.environ.get("BLOM_STAGEWISE") == "1":             # development aid: both sides stage by stage, compared after each
+                six = hostinit.step_indices(nr, kk)
+                for be in (ref, gpu):
+                    be.set("nstep", nr + 1)
+                for st in HYBRID_STAGES:
+                    ref.stage(st, *six)
+                    gpu.stage(st, *six)
+                    bad = diff_report(ref, gpu, fields=[nm for nm in CHECK if nm not in SCRATCH])
+                    assert not bad, f"step {nr + 1} after {st}\n" + fmt_report(bad[:12])
+                for be in (ref, gpu):
+                    be.set("delt1", 2 * case.params["baclin"])
+                nr += 1
+                ng += 1
+                continue
             nr = dyncore_step(ref, nr, case.params["baclin"], stages=HYBRID_STAGES)
             ng = gpu.step(ng, 1)
             # the OpenMP build of the reference (channel size) makes utotn, vtotn firstprivate in momtum's layer loop
             # (phy/mod_momtum.F90:342-350), so the module arrays keep whatever they held outside the interior -- in the serial
             # build the last layer's values, which is what the device leaves there.  Interior only for that build.
             omp = cfg.startswith("channel")
-            bad = diff_report(ref, gpu, fields=[nm for nm in CHECK if nm not in SCRATCH and not (omp and nm in ("utotn", "vtotn"))])
+            chk = CHECK + (["nnslpx", "nnslpy", "utflld", "usflld", "vtflld", "vsflld"] if neutral else [])
+            bad = diff_report(ref, gpu, fields=[nm for nm in chk if nm not in SCRATCH and not (omp and nm in ("utotn", "vtotn"))])
             assert not bad, f"step {nr}\n" + fmt_report(bad[:12])
             if omp:
                 for nm in ("utotn", "vtotn"):
@@ -148,6 +181,10 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path):
             a = gpu.get(nm)[:, 4:-4, 4:-4]
             a = a[np.broadcast_to(wu, a.shape)]
             assert np.isfinite(a).all() and (nm == "umflsm" or np.abs(a).max() > 0.0), nm
+        if neutral:
+            mq = hostinit.step_indices(ng - 1, kk)[2]
+            assert np.abs(gpu.get("utflld")[mq:mq + kk]).max() > 0.0 and np.abs(gpu.get("nnslpx")).max() > 0.0
     finally:
         ref.ref.set("vcoord_tag", 1)
+        ref.ref.set("ltedtp_opt", 1)
         gpu.close()
