@@ -450,8 +450,11 @@ def _hybrid_fields(case):
     for nm in ("t_ns_nonloc", "s_nb_nonloc", "t_rs_nonloc", "s_rs_nonloc", "mu_nonloc", "mv_nonloc"):
         f[nm] = frac
     for nm, v in (("swfc1", .6), ("swfc2", .4), ("swal1", 1.), ("swal2", 15.), ("surflx", -40.), ("sswflx", -60.), ("salflx", 5e-4),
-                  ("OBLdepth", 40.)):
+                  ("OBLdepth", 40.), ("surrlx", 0.), ("brnflx", 0.), ("salrlx", 0.), ("salt_corr", 0.)):
         f[nm] = v * np.ones((1, nj, ni))
+    if case.ntr:                         # (the reference's arrays start from its initialisation patterns, not from zero)
+        f["trflx"] = np.zeros((case.ntr, nj, ni))
+        f["trc_corr"] = np.zeros((case.ntr, nj, ni))
     return f
 
 
@@ -522,6 +525,10 @@ def _cpu_baseline_hybrid(case, masks, nreg, plevel, max_seconds=40.0, neutral=Tr
     dt = (time.time() - t0) / n
     be.ref.set("vcoord_tag", 1)
     be.ref.set("ltedtp_opt", 1)
+    tt = be.get("temp")[:, 4:-4, 4:-4]
+    tt = tt[np.broadcast_to((masks["ip"][4:-4, 4:-4] > 0)[None], tt.shape)]
+    if not (np.isfinite(tt).all() and np.abs(tt).max() < 100.0):
+        return {"error": "the reference's state left the physical range during the timed steps"}
     return dict(value=case.params["baclin"] / 86400.0 / dt, unit="simulated-days/sec", cores=ncores, kind="reference", build=lib,
                 stages_ms={k: round(v_ / n * 1e3, 2) for k, v_ in per_stage.items() if k}, steps_timed=n,
                 sample=f"{n} steps of the same hybrid stage sequence on the channel, {dt * 1e3:.1f} ms/step, {ncores} OpenMP threads; every stage in "
