@@ -96,11 +96,12 @@ int ctx_check_errors(blomgpu_ctx *c) {
   HIPCHK(c, hipMemcpyAsync(e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // the words are only ever set by a failing kernel (zeroed at allocation): clear them once reported
-  if (e[0] || e[1] || e[2]) HIPCHK(c, hipMemsetAsync(c->err_dev, 0, sizeof(int) * 8, c->stream));
+  if (e[0] || e[1] || e[2] || e[3]) HIPCHK(c, hipMemsetAsync(c->err_dev, 0, sizeof(int) * 8, c->stream));
   if (e[0] & 2) return ctx_fail(c, "blom: diapfl: no convergence in implicit diffusion!");        // mod_diapfl.F90:520-530
   if (e[0] & 1) return ctx_fail(c, "blom: diapfl: no convergence in flux limit!");
   if (e[1] & 1) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: no convergence");              // mod_eddtra.F90:536-555
   if (e[1] & 2) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: flux bound violated");          // mod_eddtra.F90:640-660
+  if (e[3]) return ctx_fail(c, "ndiff: a face found more neutral layers than its record space holds");
   if (e[2]) return ctx_fail(c, "barotp: a tile of the persistent substep kernel timed out waiting for its neighbours");
   return 0;
 }

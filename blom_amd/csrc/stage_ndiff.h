@@ -10,7 +10,11 @@ struct NdArgs {
   const double *tsd;           // T and S at both interfaces of every source layer: [field 0..1][layer][upper, lower]
   const double *drt, *drs;     // drho/dT, drho/dS there: [layer][upper, lower]
   double *flx;                 // flux convergence: [destination layer][field] planes
-  double *scr;                 // the flux kernel's per-thread work arrays, ndiff_scratch_planes(kk) planes
+  double *scr;                 // the flux kernel's per-face work arrays, ndiff_scratch_planes(kk) planes of 2 nplane faces
+  // the fluxes a face found, in search order (u-faces first, then the v-faces: 2 nplane faces per plane)
+  int *rec_n, *rec_k;          // their number; per record the destination layers kd_m | kd_p << 16
+  double *rec_f;               // per record ntr_loc fluxes (NaN: withheld by the sign tests)
+  int nrec_max;
   int kk, npc, ntr_loc, mm, nn, surface_align;
 };
 

@@ -10,16 +10,19 @@
 // convergence of the two destination layers.  The flux convergence is applied to the remapped tracers.
 //
 // The order in which a cell's flux convergence receives its contributions is fixed by the j-slice loop: the v-face j (from the
-// iteration before), the u-faces i and i+1, the v-face j+1; every face adds one term per neutral layer, in search order.  A
-// running sum cannot be split, so here ONE THREAD PER CELL walks its four faces in that order and keeps only its own side of
-// each flux (every face is searched twice, by the cells on either side); the cell on the "plus" side of a face -- the one with
-// the face's own index -- also writes the face's outputs: the fluxes per velocity-point layer (utflld.., utflx..) and the
-// neutral slope (nslpx, nslpy) that cmnfld_nnslope_ale and eddtra_ale consume.
+// iteration before), the u-faces i and i+1, the v-face j+1; every face adds one term per neutral layer, in search order, and a
+// running sum cannot be split.  So the searches run in parallel, ONE THREAD PER FACE, and RECORD their fluxes -- per neutral
+// layer the two destination layers and one flux per field (a NaN where the reference's sign tests withhold the flux) --; a
+// second kernel, one thread per cell, replays the records of its four faces in the reference's order.  A face also writes its
+// own outputs: the fluxes per velocity-point layer (utflld.., utflx..) and the neutral slope (nslpx, nslpy) that
+// cmnfld_nnslope_ale and eddtra_ale consume.  (Records per face: every neutral layer consumes a source or a destination
+// interface of one of the columns, so 6 kk bounds their number; the space is allocated for that.)
 //
 // Kernels
 //   k_ndiff_prep   ndiff_prep_jslice :959-1026: deepest source/destination layers with mass, the interface values of T and S,
 //                  drho/dT, drho/dS at both interfaces of every source layer; zeroes the face fluxes of the ring it covers
-//   k_ndiff_flux   ndiff_uflx_jslice / ndiff_vflx_jslice / ndiff_flx :166-953, cell-centred as described
+//   k_ndiff_flux   ndiff_uflx_jslice / ndiff_vflx_jslice / ndiff_flx :166-953, one thread per u-face (blockIdx.y 0) or v-face (1)
+//   k_ndiff_apply  the additions of :876-913 to flxconv_js in the order of the j-slice loop, one thread per cell
 // ndiff_update_trc_jslice (:1149-1175) is fused into the copy-back of the remapped fields (stage_ale.hip).
 // Roofline: latency of dependent loads along a data-dependent search (two columns, ~6 kk steps); HBM bytes are secondary.
 #include "blomgpu_internal.h"
@@ -103,10 +106,11 @@ __device__ inline double nd_drhoroot(const Pc5 &t, const Pc5 &s, double tf, doub
 }
 
 // ndiff_flx, :166-953, for the face between the columns cm ("minus": i-1 or j-1) and cp ("plus", the face's own index).
-// side 0: this thread's cell is cm, 1: it is cp, 2: neither (a face of the ring, searched for its outputs only); wedge: write
-// the face's outputs.  sc: the thread's scratch column.
-__device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp, bool isv, int side, bool wedge, size_t cown, double *sc) {
-  const size_t np = V.nplane;
+// sc: the face's scratch column (plane stride nf = 2 nplane); face: its index in the record arrays
+__device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp, bool isv, size_t face, double *sc, int *errw) {
+  const size_t np = V.nplane, nf = 2 * V.nplane;
+  const bool wedge = true;
+  int nrec = 0;
   const int kk = V.kk, mm = A.mm, nn = A.nn, ntr_loc = A.ntr_loc;
   // 1-based accessors in the reference's names
 #define PSM(is_, ks_) A.psrc[cm + (size_t)((ks_) + (is_)-2) * np]                       /* p_srcdi_m(is,ks) = p_src(ks+is-1) */
@@ -119,12 +123,12 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
 #define DSP(is_, ks_) A.drs[cp + ((size_t)((ks_)-1) * 2 + (is_)-1) * np]
 #define PDM(k_) A.pdst[cm + (size_t)((k_)-1) * np]
 #define PDP(k_) A.pdst[cp + (size_t)((k_)-1) * np]
-#define PNM(is_, ks_) sc[((size_t)((ks_)-1) * 2 + (is_)-1) * np]                          /* p_ni_srcdi_m */
-#define PNP(is_, ks_) sc[((size_t)(2 * kk) + ((ks_)-1) * 2 + (is_)-1) * np]
-#define SNM(k_) sc[((size_t)(4 * kk) + (k_)-1) * np]                                      /* p_dstsnp_m */
-#define SNP(k_) sc[((size_t)(4 * kk) + (kk + 1) + (k_)-1) * np]
-#define NSL(n_) sc[((size_t)(4 * kk) + 2 * (kk + 1) + (n_)-1) * np]                       /* nslp_src */
-#define PNS(n_) sc[((size_t)(4 * kk) + 6 * (kk + 1) + (n_)-1) * np]                       /* p_nslp_src */
+#define PNM(is_, ks_) sc[((size_t)((ks_)-1) * 2 + (is_)-1) * nf]                          /* p_ni_srcdi_m */
+#define PNP(is_, ks_) sc[((size_t)(2 * kk) + ((ks_)-1) * 2 + (is_)-1) * nf]
+#define SNM(k_) sc[((size_t)(4 * kk) + (k_)-1) * nf]                                      /* p_dstsnp_m */
+#define SNP(k_) sc[((size_t)(4 * kk) + (kk + 1) + (k_)-1) * nf]
+#define NSL(n_) sc[((size_t)(4 * kk) + 2 * (kk + 1) + (n_)-1) * nf]                       /* nslp_src */
+#define PNS(n_) sc[((size_t)(4 * kk) + 6 * (kk + 1) + (n_)-1) * nf]                       /* p_nslp_src */
 #define DRHO(ism, ksm, isp_, ksp)                                                                                             \
   ((.5 * (DTM(ism, ksm) + DTP(isp_, ksp))) * (TSP(isp_, ksp, 0) - TSM(ism, ksm, 0)) +                                        \
    (.5 * (DSM(ism, ksm) + DSP(isp_, ksp))) * (TSP(isp_, ksp, 1) - TSM(ism, ksm, 1)))
@@ -166,44 +170,59 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     is_m = 1; ks_m = 1; is_p = 1; ks_p = 1;
     p_ni_m_prev = PSM(1, 1); p_ni_p_prev = PSP(1, 1);
   }
-  if (ks_m <= ksmx_m && ks_p <= ksmx_p) drho_curr = DRHO(is_m, ks_m, is_p, ks_p);
+  // the values at the current interface of either column stay in registers and are re-read when the index moves
+  double psm = 0., tsm = 0., ssm = 0., dtm = 0., dsm = 0., psm1 = 0., psp = 0., tsp = 0., ssp = 0., dtp = 0., dsp = 0., psp1 = 0.;
+#define LOAD_M()                                                                                                                \
+  do {                                                                                                                          \
+    psm = PSM(is_m, ks_m); tsm = TSM(is_m, ks_m, 0); ssm = TSM(is_m, ks_m, 1); dtm = DTM(is_m, ks_m); dsm = DSM(is_m, ks_m);      \
+    if (is_m == 1) psm1 = psm;                                                                                                  \
+  } while (0)
+#define LOAD_P()                                                                                                                \
+  do {                                                                                                                          \
+    psp = PSP(is_p, ks_p); tsp = TSP(is_p, ks_p, 0); ssp = TSP(is_p, ks_p, 1); dtp = DTP(is_p, ks_p); dsp = DSP(is_p, ks_p);      \
+    if (is_p == 1) psp1 = psp;                                                                                                  \
+  } while (0)
+#define DRHO_CUR() ((.5 * (dtm + dtp)) * (tsp - tsm) + (.5 * (dsm + dsp)) * (ssp - ssm))
+  if (ks_m <= ksmx_m && ks_p <= ksmx_p) {
+    LOAD_M();
+    LOAD_P();
+    drho_curr = DRHO_CUR();
+  }
   while (ks_m <= ksmx_m && ks_p <= ksmx_p) {                    // search_loop1
     const bool drho_neg = drho_curr <= -ND_RHO_EPS, drho_pos = drho_curr >= ND_RHO_EPS;
     const bool drho_zero = !(drho_neg || drho_pos);
     if (is_m + ks_m > 2 && is_p + ks_p > 2) {
       if (drho_neg) {
         if (is_m == 2) {
-          const double drhodt_x0 = .5 * (DTM(1, ks_m) + DTP(is_p, ks_p)), drhodt_x1 = .5 * (DTM(2, ks_m) + DTP(is_p, ks_p));
-          const double drhods_x0 = .5 * (DSM(1, ks_m) + DSP(is_p, ks_p)), drhods_x1 = .5 * (DSM(2, ks_m) + DSP(is_p, ks_p));
-          const double x_ni = nd_drhoroot(nd_pc(A, np, cm, ks_m, 0), nd_pc(A, np, cm, ks_m, 1), TSP(is_p, ks_p, 0), TSP(is_p, ks_p, 1),
-                                          drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
-          const double p_ni = PSM(2, ks_m) * x_ni + PSM(1, ks_m) * (1. - x_ni);
+          const double drhodt_x0 = .5 * (DTM(1, ks_m) + dtp), drhodt_x1 = .5 * (dtm + dtp);
+          const double drhods_x0 = .5 * (DSM(1, ks_m) + dsp), drhods_x1 = .5 * (dsm + dsp);
+          const double x_ni = nd_drhoroot(nd_pc(A, np, cm, ks_m, 0), nd_pc(A, np, cm, ks_m, 1), tsp, ssp, drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
+          const double p_ni = psm * x_ni + psm1 * (1. - x_ni);
           if (p_ni > p_ni_m_prev) {
             p_ni_m_prev = p_ni;
             PNP(is_p, ks_p) = p_ni;
             nns = nns + 1;
-            if (wedge) { NSL(nns) = -cnslp * (PSP(is_p, ks_p) - p_ni); PNS(nns) = .5 * (PSP(is_p, ks_p) + p_ni); }
+            if (wedge) { NSL(nns) = -cnslp * (psp - p_ni); PNS(nns) = .5 * (psp + p_ni); }
           }
         }
       } else if (drho_pos) {
         if (is_p == 2) {
-          const double drhodt_x0 = .5 * (DTM(is_m, ks_m) + DTP(1, ks_p)), drhodt_x1 = .5 * (DTM(is_m, ks_m) + DTP(2, ks_p));
-          const double drhods_x0 = .5 * (DSM(is_m, ks_m) + DSP(1, ks_p)), drhods_x1 = .5 * (DSM(is_m, ks_m) + DSP(2, ks_p));
-          const double x_ni = nd_drhoroot(nd_pc(A, np, cp, ks_p, 0), nd_pc(A, np, cp, ks_p, 1), TSM(is_m, ks_m, 0), TSM(is_m, ks_m, 1),
-                                          drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
-          const double p_ni = PSP(2, ks_p) * x_ni + PSP(1, ks_p) * (1. - x_ni);
+          const double drhodt_x0 = .5 * (dtm + DTP(1, ks_p)), drhodt_x1 = .5 * (dtm + dtp);
+          const double drhods_x0 = .5 * (dsm + DSP(1, ks_p)), drhods_x1 = .5 * (dsm + dsp);
+          const double x_ni = nd_drhoroot(nd_pc(A, np, cp, ks_p, 0), nd_pc(A, np, cp, ks_p, 1), tsm, ssm, drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
+          const double p_ni = psp * x_ni + psp1 * (1. - x_ni);
           if (p_ni > p_ni_p_prev) {
             p_ni_p_prev = p_ni;
             PNM(is_m, ks_m) = p_ni;
             nns = nns + 1;
-            if (wedge) { NSL(nns) = -cnslp * (p_ni - PSM(is_m, ks_m)); PNS(nns) = .5 * (p_ni + PSM(is_m, ks_m)); }
+            if (wedge) { NSL(nns) = -cnslp * (p_ni - psm); PNS(nns) = .5 * (p_ni + psm); }
           }
         }
       } else {
-        PNP(is_p, ks_p) = PSM(is_m, ks_m);
-        PNM(is_m, ks_m) = PSP(is_p, ks_p);
+        PNP(is_p, ks_p) = psm;
+        PNM(is_m, ks_m) = psp;
         nns = nns + 1;
-        if (wedge) { NSL(nns) = -cnslp * (PSP(is_p, ks_p) - PSM(is_m, ks_m)); PNS(nns) = .5 * (PSP(is_p, ks_p) + PSM(is_m, ks_m)); }
+        if (wedge) { NSL(nns) = -cnslp * (psp - psm); PNS(nns) = .5 * (psp + psm); }
       }
     }
     bool done = false;
@@ -216,9 +235,10 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
           if (ks_m > ksmx_m) { done = true; break; }
           is_m = 1;
         }
-        drho_curr = DRHO(is_m, ks_m, is_p, ks_p);
+        LOAD_M();
+        drho_curr = DRHO_CUR();
         if (drho_prev - drho_curr > ND_RHO_EPS) {
-          if (is_m == 2 && PSM(2, ks_m) - PSM(1, ks_m) > ND_ONEMM) STM_SET(ks_m);
+          if (is_m == 2 && psm - psm1 > ND_ONEMM) STM_SET(ks_m);
           break;
         }
         if (is_m == 1) PNM(is_m, ks_m) = PNM(2, ks_m - 1);
@@ -234,9 +254,10 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
           if (ks_p > ksmx_p) { done = true; break; }
           is_p = 1;
         }
-        drho_curr = DRHO(is_m, ks_m, is_p, ks_p);
+        LOAD_P();
+        drho_curr = DRHO_CUR();
         if (drho_curr - drho_prev > ND_RHO_EPS) {
-          if (is_p == 2 && PSP(2, ks_p) - PSP(1, ks_p) > ND_ONEMM) STP_SET(ks_p);
+          if (is_p == 2 && psp - psp1 > ND_ONEMM) STP_SET(ks_p);
           break;
         }
         if (is_p == 1) PNP(is_p, ks_p) = PNP(2, ks_p - 1);
@@ -244,6 +265,9 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
       if (done) break;
     }
   }
+#undef LOAD_M
+#undef LOAD_P
+#undef DRHO_CUR
   // ---- alignment with the surface above the uppermost neutral interface, :394-464 ---------------------------------------------
   if (A.surface_align) {
     int issa_m = 1, issa_p = 1;
@@ -325,6 +349,8 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     bool advance_src_m = true, advance_src_p = true, advance_dst_m = true, advance_dst_p = true;
     double p_ni_m[2], p_ni_p[2], x_ni_m[2] = {0., 0.}, x_ni_p[2] = {0., 0.};
     int knd_m[2] = {0, 0}, knd_p[2] = {0, 0};                 // how t_ni_m, t_ni_p of the slot were formed (nd_tni)
+    // in registers between index changes: p_srcdi(is,ks), (1,ks), (2,ks), p_ni_srcdi(is,ks), (isn,ksn), p_srcdi(isn,ksn), p_dstsnp(kd+1)
+    double a_m = 0., b_m = 0., c_m = 0., d_m = 0., e_m = 0., f_m = 0., g_m = 0., a_p = 0., b_p = 0., c_p = 0., d_p = 0., e_p = 0., f_p = 0., g_p = 0.;
     p_ni_m[nip] = -ND_MVAL; p_ni_p[nip] = -ND_MVAL;
     p_ni_m[nic] = 0.; p_ni_p[nic] = 0.;
     const double *puv = isv ? V.f[F_pv] : V.f[F_pu];
@@ -347,14 +373,18 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         }
         if (out) break;
         isn_m = is_m; ksn_m = ks_m;
-        while (PNM(isn_m, ksn_m) == ND_MVAL) {
+        d_m = PNM(is_m, ks_m);
+        e_m = d_m;
+        while (e_m == ND_MVAL) {
           if (isn_m == 1) isn_m = 2;
           else {
             if (ksn_m == ksmx_m) break;
             ksn_m = ksn_m + 1;
             isn_m = 1;
           }
+          e_m = PNM(isn_m, ksn_m);
         }
+        a_m = PSM(is_m, ks_m); b_m = PSM(1, ks_m); c_m = PSM(2, ks_m); f_m = PSM(isn_m, ksn_m);
       }
       if (advance_src_p) {
         bool out = false;
@@ -371,64 +401,72 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         }
         if (out) break;
         isn_p = is_p; ksn_p = ks_p;
-        while (PNP(isn_p, ksn_p) == ND_MVAL) {
+        d_p = PNP(is_p, ks_p);
+        e_p = d_p;
+        while (e_p == ND_MVAL) {
           if (isn_p == 1) isn_p = 2;
           else {
             if (ksn_p == ksmx_p) break;
             ksn_p = ksn_p + 1;
             isn_p = 1;
           }
+          e_p = PNP(isn_p, ksn_p);
         }
+        a_p = PSP(is_p, ks_p); b_p = PSP(1, ks_p); c_p = PSP(2, ks_p); f_p = PSP(isn_p, ksn_p);
       }
       if (p_ni_m[nip] == -ND_MVAL) {
-        if ((PNM(isn_m, ksn_m) - PSP(isn_p, ksn_p)) < (PNP(isn_p, ksn_p) - PSM(isn_m, ksn_m))) {
-          p_ni_m[nip] = PSM(isn_m, ksn_m);
-          p_ni_p[nip] = PNM(isn_m, ksn_m);
+        if ((e_m - f_p) < (e_p - f_m)) {
+          p_ni_m[nip] = f_m;
+          p_ni_p[nip] = e_m;
         } else {
-          p_ni_m[nip] = PNP(isn_p, ksn_p);
-          p_ni_p[nip] = PSP(isn_p, ksn_p);
+          p_ni_m[nip] = e_p;
+          p_ni_p[nip] = f_p;
         }
       }
       if (advance_dst_m) {
         kd_m = kd_m + 1;
         if (kd_m > kdmx_m) break;
+        g_m = SNM(kd_m + 1);
       }
       if (advance_dst_p) {
         kd_p = kd_p + 1;
         if (kd_p > kdmx_p) break;
+        g_p = SNP(kd_p + 1);
       }
       {
         bool out = false;
-        while (SNM(kd_m + 1) <= fmax2(PSM(1, ks_m), p_ni_m[nip])) {
+        while (g_m <= fmax2(b_m, p_ni_m[nip])) {
           kd_m = kd_m + 1;
           if (kd_m > kdmx_m) { out = true; break; }
+          g_m = SNM(kd_m + 1);
         }
         if (out) break;
-        while (SNP(kd_p + 1) <= fmax2(PSP(1, ks_p), p_ni_p[nip])) {
+        while (g_p <= fmax2(b_p, p_ni_p[nip])) {
           kd_p = kd_p + 1;
           if (kd_p > kdmx_p) { out = true; break; }
+          g_p = SNP(kd_p + 1);
         }
         if (out) break;
       }
       advance_src_m = false; advance_src_p = false; advance_dst_m = false; advance_dst_p = false;
       int case_m = 3, case_p = 3;
-      if (PSM(is_m, ks_m) <= PNP(isn_p, ksn_p)) {
-        if (PSM(is_m, ks_m) <= SNM(kd_m + 1)) case_m = 1;
-      } else if (PNP(isn_p, ksn_p) <= SNM(kd_m + 1)) case_m = 2;
-      if (PSP(is_p, ks_p) <= PNM(isn_m, ksn_m)) {
-        if (PSP(is_p, ks_p) <= SNP(kd_p + 1)) case_p = 1;
-      } else if (PNM(isn_m, ksn_m) <= SNP(kd_p + 1)) case_p = 2;
+      if (a_m <= e_p) {
+        if (a_m <= g_m) case_m = 1;
+      } else if (e_p <= g_m) case_m = 2;
+      if (a_p <= e_m) {
+        if (a_p <= g_p) case_p = 1;
+      } else if (e_m <= g_p) case_p = 2;
       bool found_ni = false;
       if (case_m == 3 && case_p == 3) {
         if (is_p == 2 && is_m == 2) {
-          p_ni_m[nic] = SNM(kd_m + 1);
-          p_ni_p[nic] = SNP(kd_p + 1);
+          p_ni_m[nic] = g_m;
+          p_ni_p[nic] = g_p;
           const double pu_m = p_ni_m[nip], pu_p = p_ni_p[nip];
           double pl_m, pl_p;
-          if ((PNM(isn_m, ksn_m) - PSP(isn_p, ksn_p)) < (PNP(isn_p, ksn_p) - PSM(isn_m, ksn_m))) {
-            pl_m = PSM(isn_m, ksn_m); pl_p = PNM(isn_m, ksn_m);
+          if ((e_m - f_p) < (e_p - f_m)) {
+            pl_m = f_m; pl_p = e_m;
           } else {
-            pl_m = PNP(isn_p, ksn_p); pl_p = PSP(isn_p, ksn_p);
+            pl_m = e_p; pl_p = f_p;
           }
           const double pp1 = (p_ni_m[nic] - pu_m) * (pl_p - pu_p), pp2 = (p_ni_p[nic] - pu_p) * (pl_m - pu_m);
           if (fabs(pp1 - pp2) < ND_DP_EPS * fmax2(ND_DP_EPS, pl_m - pu_m + pl_p - pu_p)) {
@@ -440,9 +478,9 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
             p_ni_m[nic] = pu_m + pp2 / (pl_p - pu_p);
             advance_dst_p = true;
           }
-          if (p_ni_m[nic] >= PSM(1, ks_m) && p_ni_m[nic] <= PSM(2, ks_m) && p_ni_p[nic] >= PSP(1, ks_p) && p_ni_p[nic] <= PSP(2, ks_p)) {
-            x_ni_m[nic] = (p_ni_m[nic] - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
-            x_ni_p[nic] = (p_ni_p[nic] - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+          if (p_ni_m[nic] >= b_m && p_ni_m[nic] <= c_m && p_ni_p[nic] >= b_p && p_ni_p[nic] <= c_p) {
+            x_ni_m[nic] = (p_ni_m[nic] - b_m) / (c_m - b_m);
+            x_ni_p[nic] = (p_ni_p[nic] - b_p) / (c_p - b_p);
             knd_m[nic] = 0; knd_p[nic] = 0;
             found_ni = true;
           }
@@ -452,69 +490,69 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         }
       } else if (case_m == 3) {
         if (is_p == 2) {
-          p_ni_m[nic] = SNM(kd_m + 1);
+          p_ni_m[nic] = g_m;
           if (case_p == 1)
-            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (PSP(isn_p, ksn_p) - p_ni_p[nip]) / (PNP(isn_p, ksn_p) - p_ni_m[nip]);
+            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (f_p - p_ni_p[nip]) / (e_p - p_ni_m[nip]);
           else
-            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (PNM(isn_m, ksn_m) - p_ni_p[nip]) / (PSM(isn_m, ksn_m) - p_ni_m[nip]);
-          if (p_ni_p[nic] >= PSP(1, ks_p) && p_ni_p[nic] <= PSP(2, ks_p)) {
-            x_ni_m[nic] = (SNM(kd_m + 1) - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
-            x_ni_p[nic] = (p_ni_p[nic] - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (e_m - p_ni_p[nip]) / (f_m - p_ni_m[nip]);
+          if (p_ni_p[nic] >= b_p && p_ni_p[nic] <= c_p) {
+            x_ni_m[nic] = (g_m - b_m) / (c_m - b_m);
+            x_ni_p[nic] = (p_ni_p[nic] - b_p) / (c_p - b_p);
             knd_m[nic] = 0; knd_p[nic] = 0;
             found_ni = true;
             advance_dst_m = true;
           } else {
-            if (case_p == 1 && PNP(is_p, ks_p) == ND_MVAL) advance_src_p = true;
+            if (case_p == 1 && d_p == ND_MVAL) advance_src_p = true;
             else advance_dst_m = true;
           }
         } else advance_dst_m = true;
       } else if (case_p == 3) {
         if (is_m == 2) {
-          p_ni_p[nic] = SNP(kd_p + 1);
+          p_ni_p[nic] = g_p;
           if (case_m == 1)
-            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (PSM(isn_m, ksn_m) - p_ni_m[nip]) / (PNM(isn_m, ksn_m) - p_ni_p[nip]);
+            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (f_m - p_ni_m[nip]) / (e_m - p_ni_p[nip]);
           else
-            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (PNP(isn_p, ksn_p) - p_ni_m[nip]) / (PSP(isn_p, ksn_p) - p_ni_p[nip]);
-          if (p_ni_m[nic] >= PSM(1, ks_m) && p_ni_m[nic] <= PSM(2, ks_m)) {
-            x_ni_p[nic] = (SNP(kd_p + 1) - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
-            x_ni_m[nic] = (p_ni_m[nic] - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
+            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (e_p - p_ni_m[nip]) / (f_p - p_ni_p[nip]);
+          if (p_ni_m[nic] >= b_m && p_ni_m[nic] <= c_m) {
+            x_ni_p[nic] = (g_p - b_p) / (c_p - b_p);
+            x_ni_m[nic] = (p_ni_m[nic] - b_m) / (c_m - b_m);
             knd_m[nic] = 0; knd_p[nic] = 0;
             found_ni = true;
             advance_dst_p = true;
           } else {
-            if (case_m == 1 && PNM(is_m, ks_m) == ND_MVAL) advance_src_m = true;
+            if (case_m == 1 && d_m == ND_MVAL) advance_src_m = true;
             else advance_dst_p = true;
           }
         } else advance_dst_p = true;
       } else if (case_m == 1 && case_p == 1) {
-        if (PNM(is_m, ks_m) != ND_MVAL && PNP(is_p, ks_p) != ND_MVAL) {
+        if (d_m != ND_MVAL && d_p != ND_MVAL) {
           x_ni_m[nic] = (double)(is_m - 1);
-          p_ni_m[nic] = PSM(is_m, ks_m);
+          p_ni_m[nic] = a_m;
           x_ni_p[nic] = (double)(is_p - 1);
-          p_ni_p[nic] = PSP(is_p, ks_p);
+          p_ni_p[nic] = a_p;
           knd_m[nic] = is_m; knd_p[nic] = is_p;
           found_ni = true;
           advance_src_m = true; advance_src_p = true;
         } else {
-          if (PNM(is_m, ks_m) == ND_MVAL) advance_src_m = true;
-          if (PNP(is_p, ks_p) == ND_MVAL) advance_src_p = true;
+          if (d_m == ND_MVAL) advance_src_m = true;
+          if (d_p == ND_MVAL) advance_src_p = true;
         }
       } else if (case_m == 1) {
-        if (PNM(is_m, ks_m) != ND_MVAL && PNM(is_m, ks_m) >= PSP(1, ks_p)) {
+        if (d_m != ND_MVAL && d_m >= b_p) {
           x_ni_m[nic] = (double)(is_m - 1);
-          p_ni_m[nic] = PSM(is_m, ks_m);
-          p_ni_p[nic] = PNM(is_m, ks_m);
-          x_ni_p[nic] = (p_ni_p[nic] - PSP(1, ks_p)) / (PSP(2, ks_p) - PSP(1, ks_p));
+          p_ni_m[nic] = a_m;
+          p_ni_p[nic] = d_m;
+          x_ni_p[nic] = (p_ni_p[nic] - b_p) / (c_p - b_p);
           knd_m[nic] = is_m; knd_p[nic] = 0;
           found_ni = true;
         }
         advance_src_m = true;
       } else if (case_p == 1) {
-        if (PNP(is_p, ks_p) != ND_MVAL && PNP(is_p, ks_p) >= PSM(1, ks_m)) {
+        if (d_p != ND_MVAL && d_p >= b_m) {
           x_ni_p[nic] = (double)(is_p - 1);
-          p_ni_p[nic] = PSP(is_p, ks_p);
-          p_ni_m[nic] = PNP(is_p, ks_p);
-          x_ni_m[nic] = (p_ni_m[nic] - PSM(1, ks_m)) / (PSM(2, ks_m) - PSM(1, ks_m));
+          p_ni_p[nic] = a_p;
+          p_ni_m[nic] = d_p;
+          x_ni_m[nic] = (p_ni_m[nic] - b_m) / (c_m - b_m);
           knd_p[nic] = is_p; knd_m[nic] = 0;
           found_ni = true;
         }
@@ -526,11 +564,17 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         const double dp_ni_m = fmin2(p_ni_m[nic] - p_ni_m[nip], PDM(kd_m + 1) - PDM(kd_m));
         const double dp_ni_p = fmin2(p_ni_p[nic] - p_ni_p[nip], PDP(kd_p + 1) - PDP(kd_p));
         const double dp_ni = 2. * dp_ni_m * dp_ni_p / fmax2(dp_ni_m + dp_ni_p, 2. * ND_DP_EPS);
-        if (ks_m == ks_m_prev && ks_p == ks_p_prev && p_ni_m[nip] >= SNM(kd_m) && p_ni_m[nic] <= SNM(kd_m + 1) && p_ni_p[nip] >= SNP(kd_p) &&
-            p_ni_p[nic] <= SNP(kd_p + 1) && dp_ni > 2. * ND_DP_EPS) {
+        if (ks_m == ks_m_prev && ks_p == ks_p_prev && p_ni_m[nip] >= SNM(kd_m) && p_ni_m[nic] <= g_m && p_ni_p[nip] >= SNP(kd_p) &&
+            p_ni_p[nic] <= g_p && dp_ni > 2. * ND_DP_EPS) {
           const double q = .5 * cdiff * (difiso[cm + (size_t)(ks_m - 1) * np] + difiso[cp + (size_t)(ks_p - 1) * np]) * dp_ni;
           const size_t om = cm + (size_t)(ks_m - 1 + nn) * np, op = cp + (size_t)(ks_p - 1 + nn) * np;
-          double *fl = A.flx + cown + (size_t)((side == 0 ? kd_m : kd_p) - 1) * ntr_loc * np;
+          // the record of this neutral layer: destination layers, then one flux per field (NaN: withheld)
+          const bool keep = nrec < A.nrec_max;
+          if (!keep) atomicOr(errw, 1);
+          double *rf = A.rec_f + face + (size_t)nrec * ntr_loc * nf;
+          if (keep) A.rec_k[face + (size_t)nrec * nf] = kd_m | (kd_p << 16);
+          nrec = nrec + (keep ? 1 : 0);
+          const double withheld = __builtin_nan("");
           Pc5 tm = nd_pc(A, np, cm, ks_m, 0), tp = nd_pc(A, np, cp, ks_p, 0), sm = nd_pc(A, np, cm, ks_m, 1), sp = nd_pc(A, np, cp, ks_p, 1);
           const double dt = nd_pmeval(tm, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(tp, x_ni_p[nip], x_ni_p[nic]);
           const double ds = nd_pmeval(sm, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(sp, x_ni_p[nip], x_ni_p[nic]);
@@ -541,8 +585,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
               ds * (nd_tni(sm, knd_m[nip], x_ni_m[nip]) - nd_tni(sp, knd_p[nip], x_ni_p[nip])) >= 0. &&
               ds * (nd_tni(sm, knd_m[nic], x_ni_m[nic]) - nd_tni(sp, knd_p[nic], x_ni_p[nic])) >= 0.) {
             const double tflx = q * dt, sflx = q * ds;
-            if (side == 0) { fl[0] = fl[0] + tflx; fl[np] = fl[np] + sflx; }
-            else if (side == 1) { fl[0] = fl[0] - tflx; fl[np] = fl[np] - sflx; }
+            if (keep) { rf[0] = tflx; rf[nf] = sflx; }
             if (wedge) {
               const double p_ni_up = .5 * (p_ni_m[nip] + p_ni_p[nip]), p_ni_lo = .5 * (p_ni_m[nic] + p_ni_p[nic]);
               const double dp_ni_i = 1. / fmax2(ND_EPSILP, p_ni_lo - p_ni_up);
@@ -562,26 +605,23 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
                 }
               }
             }
+          } else if (keep) { rf[0] = withheld; rf[nf] = withheld; }
+          for (int nt = 2; nt < ntr_loc; nt++) {
+            const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
+            const double dtr = nd_pmeval(cm5, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(cp5, x_ni_p[nip], x_ni_p[nic]);
+            const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
+            const bool pass = dtr * (V.f[F_trc][om + otr] - V.f[F_trc][op + otr]) >= 0. &&
+                              dtr * (nd_tni(cm5, knd_m[nip], x_ni_m[nip]) - nd_tni(cp5, knd_p[nip], x_ni_p[nip])) >= 0. &&
+                              dtr * (nd_tni(cm5, knd_m[nic], x_ni_m[nic]) - nd_tni(cp5, knd_p[nic], x_ni_p[nic])) >= 0.;
+            if (keep) rf[(size_t)nt * nf] = pass ? q * dtr : withheld;
           }
-          if (side != 2)
-            for (int nt = 2; nt < ntr_loc; nt++) {
-              const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
-              const double dtr = nd_pmeval(cm5, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(cp5, x_ni_p[nip], x_ni_p[nic]);
-              const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
-              if (dtr * (V.f[F_trc][om + otr] - V.f[F_trc][op + otr]) >= 0. &&
-                  dtr * (nd_tni(cm5, knd_m[nip], x_ni_m[nip]) - nd_tni(cp5, knd_p[nip], x_ni_p[nip])) >= 0. &&
-                  dtr * (nd_tni(cm5, knd_m[nic], x_ni_m[nic]) - nd_tni(cp5, knd_p[nic], x_ni_p[nic])) >= 0.) {
-                const double tflx = q * dtr;
-                if (side == 0) fl[(size_t)nt * np] = fl[(size_t)nt * np] + tflx;
-                else fl[(size_t)nt * np] = fl[(size_t)nt * np] - tflx;
-              }
-            }
         }
         ks_m_prev = ks_m; ks_p_prev = ks_p;
         nip = 1 - nip; nic = 1 - nic;
       }
     }
   }
+  A.rec_n[face] = nrec;
   // ---- neutral slope at the destination interfaces, :923-951 ------------------------------------------------------------------
   if (wedge) {
     double *nsl = (isv ? V.f[F_nslpy] : V.f[F_nslpx]);
@@ -661,28 +701,49 @@ __global__ void k_ndiff_prep(const DevView *__restrict__ Vp, NdArgs A, int *__re
     for (int k = 0; k < kk; k++) { V.f[F_vtflld][c + (size_t)(k + mm) * np] = 0.; V.f[F_vsflld][c + (size_t)(k + mm) * np] = 0.; }
 }
 
-// the four faces of a cell in the order the reference's j-slice loop visits them (header); cells of the ring own faces only
-__global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ Vp, NdArgs A) {
+// one thread per u-face (rows 1..jj, i = 1..ii+1: ndiff_uflx_jslice) or v-face (rows 1..jj+1, i = 1..ii: ndiff_vflx_jslice)
+__global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ Vp, NdArgs A, int *__restrict__ errw) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
   if (t_ >= V.nplane) return;
   const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
   const size_t c = t_;
-  const int ii = V.ii, jj = V.jj, ni = V.ni;
-  if (j < 1 || j > jj + 1 || i < 1 || i > ii + 1) return;
-  const bool cell = j <= jj && i <= ii && V.m[I_ip][c];
-  double *sc = A.scr + c;
-  // v-face j: rows j-1 | j (ndiff_vflx_jslice of the iteration before, i = 1..ii)
-  if (i <= ii && V.m[I_iv][c]) nd_face(V, A, c - ni, c, true, cell ? 1 : 2, true, c, sc);
-  // u-face i: columns i-1 | i (ndiff_uflx_jslice, rows 1..jj, i = 1..ii+1)
-  if (j <= jj && V.m[I_iu][c]) nd_face(V, A, c - 1, c, false, cell ? 1 : 2, true, c, sc);
-  if (!cell) return;
-  // u-face i+1 and v-face j+1: this cell is on their minus side
-  if (V.m[I_iu][c + 1]) nd_face(V, A, c, c + 1, false, 0, false, c, sc);
-  if (V.m[I_iv][c + ni]) nd_face(V, A, c, c + ni, true, 0, false, c, sc);
+  const bool isv = blockIdx.y == 1;
+  const size_t face = c + (isv ? V.nplane : 0);
+  const bool on = isv ? (j >= 1 && j <= V.jj + 1 && i >= 1 && i <= V.ii && V.m[I_iv][c]) : (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1 && V.m[I_iu][c]);
+  if (!on) { A.rec_n[face] = 0; return; }
+  nd_face(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
 }
 
-size_t ndiff_scratch_planes(int kk) { return (size_t)4 * kk + (size_t)10 * (kk + 1); }
+// the records of a cell's four faces replayed in the order of the j-slice loop (header): - v-face j, - u-face i, + u-face i+1,
+// + v-face j+1
+__global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ Vp, NdArgs A) {
+  const DevView &V = *Vp;
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t_ >= V.nplane) return;
+  const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
+  const size_t c = t_, np = V.nplane, nf = 2 * np;
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int ntr_loc = A.ntr_loc;
+  const size_t faces[4] = {np + c, c, c + 1, np + c + V.ni};
+  for (int f = 0; f < 4; f++) {
+    const size_t face = faces[f];
+    const int n = A.rec_n[face];
+    const bool plus = f < 2;                                     // this cell is the face's "plus" column: the flux leaves it
+    for (int r = 0; r < n; r++) {
+      const int kdd = A.rec_k[face + (size_t)r * nf];
+      const int kd = plus ? (kdd >> 16) : (kdd & 0xffff);
+      double *fl = A.flx + c + (size_t)(kd - 1) * ntr_loc * np;
+      const double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
+      for (int nt = 0; nt < ntr_loc; nt++) {
+        const double v = rf[(size_t)nt * nf];
+        if (v == v) fl[(size_t)nt * np] = plus ? fl[(size_t)nt * np] - v : fl[(size_t)nt * np] + v;
+      }
+    }
+  }
+}
+
+size_t ndiff_scratch_planes(int kk) { return (size_t)4 * kk + (size_t)10 * (kk + 1); }   // per FACE (2 nplane of them)
 
 int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs) {
   const DevView &h = c->h;
@@ -690,7 +751,9 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *t
   const unsigned nb = (unsigned)((h.nplane + 63) / 64);
   TimeScope ts(c, "ndiff");
   hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, c->stream, c->d, A, ksmx, kdmx, tsd, drt, drs);
-  hipLaunchKernelGGL(k_ndiff_flux, dim3(nb), dim3(64), 0, c->stream, c->d, A);
+  if (int rc = ctx_err_words(c)) return rc;
+  hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, c->stream, c->d, A, c->err_dev + 3);
+  hipLaunchKernelGGL(k_ndiff_apply, dim3(nb), dim3(64), 0, c->stream, c->d, A);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
