@@ -27,15 +27,15 @@ void ctx_sync_view(blomgpu_ctx *c) {
   c->dirty = false;
 }
 
-TimeScope::TimeScope(blomgpu_ctx *c_, const char *w) : c(c_), what(w) {
+TimeScope::TimeScope(blomgpu_ctx *c_, const char *w, hipStream_t s) : c(c_), what(w), st(s ? s : c_->stream) {
   if (!c->timing) return;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  (void)hipEventRecord(a, c->stream);
+  (void)hipEventRecord(a, st);
 }
 TimeScope::~TimeScope() {
   if (!c->timing) return;
-  (void)hipEventRecord(b, c->stream);
+  (void)hipEventRecord(b, st);
   c->timers[what].pending.emplace_back(a, b);
 }
 

@@ -323,7 +323,8 @@ struct TimeScope {
   blomgpu_ctx *c;
   hipEvent_t a = nullptr, b = nullptr;
   const char *what;
-  TimeScope(blomgpu_ctx *c_, const char *w);
+  hipStream_t st = nullptr;      // the stream the bracketed launches go to (default: the model's)
+  TimeScope(blomgpu_ctx *c_, const char *w, hipStream_t s = nullptr);
   ~TimeScope();
 };
 

@@ -18,7 +18,7 @@
 // targets (a quadratic Bezier curve, :680-728) below the pressure-level range, minimum thicknesses, a bound on the variation of
 // neighbouring layer thicknesses (:848-913), and lateral smoothing of the interfaces where the stratification is weak
 // (regrid_smooth_jslice, :946-1020).
-// Not built yet: neutral diffusion (mod_ndiff) and the z-level diagnostics (remap_trc_diazlv_jslice) -- each fails loudly.
+// Neutral diffusion (ltedtp = 'neutral') is stage_ndiff.hip, called from here.  Not built: the z-level diagnostics (remap_trc_diazlv_jslice).
 // Parity: cross-checked against the reference's REAL module compiled against a stand-in for mod_dia (oracle/Makefile
 // *_xale, tests/test_xcheck_ale.py) -- a cross-check, not a pin.
 #include "blomgpu_internal.h"
@@ -954,21 +954,24 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
                        (const double *)c->ale_plevel, c->ale_dpmin_interior, c->ale_k_range_plevel, pdst, ring);
     }
   }
-  if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping", rc);
   if (nf0 > lo0)
     if (int rc2 = join()) return rc2;
   if (ndiff) {
-    // ndiff_prep_jslice, ndiff_uflx_jslice, ndiff_vflx_jslice (:1639-1664): the flux convergence of every destination layer
+    // ndiff_prep_jslice, ndiff_uflx_jslice, ndiff_vflx_jslice (:1639-1664): the flux convergence of every destination layer.
+    // Beside the model's stream: the searches wait on their own loads most of the time, the remapping of the first batch of
+    // fields does not need their result (the copy-back does).
     NdArgs A;
     A.psrc = psrc; A.pdst = pdst; A.ksmx = a->nd_ks; A.kdmx = a->nd_ks + np; A.tpc = a->nd_tpc; A.tsd = a->nd_col;
     A.drt = a->nd_col + (size_t)4 * per; A.drs = a->nd_col + (size_t)6 * per; A.flx = a->nd_col + (size_t)8 * per;
     A.scr = A.flx + (size_t)a->ntr_loc * per;
     A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_f = a->nd_rec; A.nrec_max = 6 * h.kk;
     A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
-    if (int rc2 = st_ndiff_prep_flux(c, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
+    if (int rc2 = fork()) return rc2;
+    if (int rc2 = st_ndiff_prep_flux(c, a->side, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
       return rc2;
     c->fluxes_zeroed = false;                   // utflx .. vsflx carry the diffusive fluxes now: advect must add to them
   }
+  if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping", rc);
   const double *flx = ndiff ? a->nd_col + (size_t)8 * per : nullptr;
   for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {
     const int nf = a->ntr_loc - f0 < H3M_MAXF ? a->ntr_loc - f0 : H3M_MAXF;
@@ -982,6 +985,8 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     }
     if (f0 > 0 && !ndiff && (rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
     if ((rc = blomgpu_h3m_remap_many(nf, ss, a->map, ud))) return ale_fail(c, "remap", rc);
+    if (ndiff && f0 == 0)
+      if (int rc2 = join()) return rc2;
     hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf, flx, a->ntr_loc);
   }
   // ---- velocities, :1692-1900 -------------------------------------------------------------------------------------------------

@@ -19,4 +19,4 @@ struct NdArgs {
 };
 
 size_t ndiff_scratch_planes(int kk);
-int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs);
+int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs);

@@ -716,7 +716,8 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
 }
 
 // the records of a cell's four faces replayed in the order of the j-slice loop (header): - v-face j, - u-face i, + u-face i+1,
-// + v-face j+1
+// + v-face j+1.  One thread per cell AND field (blockIdx.y): the running sums of different fields do not meet.  Within a face
+// the destination layer never decreases, so the sum of the current layer stays in a register until the layer changes.
 __global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ Vp, NdArgs A) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,36 +725,43 @@ __global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ 
   const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
   const size_t c = t_, np = V.nplane, nf = 2 * np;
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
-  const int ntr_loc = A.ntr_loc;
+  const int ntr_loc = A.ntr_loc, nt = blockIdx.y;
   const size_t faces[4] = {np + c, c, c + 1, np + c + V.ni};
+  double *fl = A.flx + c + (size_t)nt * np;                      // layer stride ntr_loc * np
   for (int f = 0; f < 4; f++) {
     const size_t face = faces[f];
     const int n = A.rec_n[face];
     const bool plus = f < 2;                                     // this cell is the face's "plus" column: the flux leaves it
+    int cur = 0;
+    double acc = 0.;
+    const int *rk = A.rec_k + face;
+    const double *rf = A.rec_f + face + (size_t)nt * nf;
     for (int r = 0; r < n; r++) {
-      const int kdd = A.rec_k[face + (size_t)r * nf];
+      const int kdd = rk[(size_t)r * nf];
+      const double v = rf[(size_t)r * ntr_loc * nf];
       const int kd = plus ? (kdd >> 16) : (kdd & 0xffff);
-      double *fl = A.flx + c + (size_t)(kd - 1) * ntr_loc * np;
-      const double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
-      for (int nt = 0; nt < ntr_loc; nt++) {
-        const double v = rf[(size_t)nt * nf];
-        if (v == v) fl[(size_t)nt * np] = plus ? fl[(size_t)nt * np] - v : fl[(size_t)nt * np] + v;
+      if (kd != cur) {
+        if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
+        cur = kd;
+        acc = fl[(size_t)(cur - 1) * ntr_loc * np];
       }
+      if (v == v) acc = plus ? acc - v : acc + v;
     }
+    if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
   }
 }
 
 size_t ndiff_scratch_planes(int kk) { return (size_t)4 * kk + (size_t)10 * (kk + 1); }   // per FACE (2 nplane of them)
 
-int st_ndiff_prep_flux(blomgpu_ctx *c, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs) {
+int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs) {
   const DevView &h = c->h;
   if (h.kk > 128) return ctx_fail(c, "ndiff: more than 128 layers");
   const unsigned nb = (unsigned)((h.nplane + 63) / 64);
-  TimeScope ts(c, "ndiff");
-  hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, c->stream, c->d, A, ksmx, kdmx, tsd, drt, drs);
+  TimeScope ts(c, "ndiff", st);
+  hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, st, c->d, A, ksmx, kdmx, tsd, drt, drs);
   if (int rc = ctx_err_words(c)) return rc;
-  hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, c->stream, c->d, A, c->err_dev + 3);
-  hipLaunchKernelGGL(k_ndiff_apply, dim3(nb), dim3(64), 0, c->stream, c->d, A);
+  hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 3);
+  hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), 0, st, c->d, A);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
