@@ -56,7 +56,7 @@ struct AleState {
   int ntr_loc = 0, method = 0;
   // neutral diffusion (stage_ndiff.hip): polynomial coefficients of every field; T, S and drho/dT, drho/dS at the source
   // interfaces (8 kk planes), the flux convergence (kk ntr_loc planes) and the flux kernel's work arrays; ksmx, kdmx
-  double *nd_tpc = nullptr, *nd_col = nullptr, *nd_rec = nullptr;
+  double *nd_tpc = nullptr, *nd_col = nullptr, *nd_rec = nullptr, *nd_recg = nullptr;
   int *nd_ks = nullptr, *nd_reck = nullptr;
   int nd_npc = 0;
 };
@@ -75,6 +75,7 @@ void ale_free(blomgpu_ctx *c) {
   if (a->nd_col) (void)hipFree(a->nd_col);
   if (a->nd_ks) (void)hipFree(a->nd_ks);
   if (a->nd_rec) (void)hipFree(a->nd_rec);
+  if (a->nd_recg) (void)hipFree(a->nd_recg);
   if (a->nd_reck) (void)hipFree(a->nd_reck);
   delete a;
   c->ale = nullptr;
@@ -141,10 +142,11 @@ static int ale_ndiff_buffers(blomgpu_ctx *c, AleState *a) {
     HIPCHK(c, hipMalloc((void **)&a->nd_col, sizeof(double) * ncol));
     HIPCHK(c, hipMalloc((void **)&a->nd_ks, sizeof(int) * 2 * np));
     HIPCHK(c, hipMalloc((void **)&a->nd_rec, sizeof(double) * nrec * a->ntr_loc * 2 * np));
-    HIPCHK(c, hipMalloc((void **)&a->nd_reck, sizeof(int) * (nrec + 1) * 2 * np));
+    HIPCHK(c, hipMalloc((void **)&a->nd_recg, sizeof(double) * nrec * 7 * 2 * np));
+    HIPCHK(c, hipMalloc((void **)&a->nd_reck, sizeof(int) * (2 * nrec + 1) * 2 * np));
     HIPCHK(c, hipMemsetAsync(a->nd_col, 0, sizeof(double) * ncol, c->stream));
     HIPCHK(c, hipMemsetAsync(a->nd_ks, 0, sizeof(int) * 2 * np, c->stream));
-    HIPCHK(c, hipMemsetAsync(a->nd_reck, 0, sizeof(int) * (nrec + 1) * 2 * np, c->stream));
+    HIPCHK(c, hipMemsetAsync(a->nd_reck, 0, sizeof(int) * (2 * nrec + 1) * 2 * np, c->stream));
   }
   return 0;
 }
@@ -964,7 +966,8 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     A.psrc = psrc; A.pdst = pdst; A.ksmx = a->nd_ks; A.kdmx = a->nd_ks + np; A.tpc = a->nd_tpc; A.tsd = a->nd_col;
     A.drt = a->nd_col + (size_t)4 * per; A.drs = a->nd_col + (size_t)6 * per; A.flx = a->nd_col + (size_t)8 * per;
     A.scr = A.flx + (size_t)a->ntr_loc * per;
-    A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_f = a->nd_rec; A.nrec_max = 6 * h.kk;
+    A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_s = A.rec_k + (size_t)6 * h.kk * 2 * np; A.rec_g = a->nd_recg;
+    A.rec_f = a->nd_rec; A.nrec_max = 6 * h.kk;
     A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
     if (int rc2 = fork()) return rc2;
     if (int rc2 = st_ndiff_prep_flux(c, a->side, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))

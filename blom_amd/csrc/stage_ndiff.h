@@ -12,7 +12,10 @@ struct NdArgs {
   double *flx;                 // flux convergence: [destination layer][field] planes
   double *scr;                 // the flux kernel's per-face work arrays, ndiff_scratch_planes(kk) planes of 2 nplane faces
   // the fluxes a face found, in search order (u-faces first, then the v-faces: 2 nplane faces per plane)
-  int *rec_n, *rec_k;          // their number; per record the destination layers kd_m | kd_p << 16
+  int *rec_n, *rec_k, *rec_s;  // their number; per record the destination layers kd_m | kd_p << 16; the source layers and how the
+                               // values at the two neutral interfaces are taken: ks_m | ks_p << 8 | four 2-bit kinds << 16
+  double *rec_g;               // per record: positions of the two interfaces in the source layers (m, m, p, p), thickness,
+                               // mean pressure of the upper and of the lower interface
   double *rec_f;               // per record ntr_loc fluxes (NaN: withheld by the sign tests)
   int nrec_max;
   int kk, npc, ntr_loc, mm, nn, surface_align;

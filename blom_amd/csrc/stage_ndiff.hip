@@ -353,10 +353,6 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     double a_m = 0., b_m = 0., c_m = 0., d_m = 0., e_m = 0., f_m = 0., g_m = 0., a_p = 0., b_p = 0., c_p = 0., d_p = 0., e_p = 0., f_p = 0., g_p = 0.;
     p_ni_m[nip] = -ND_MVAL; p_ni_p[nip] = -ND_MVAL;
     p_ni_m[nic] = 0.; p_ni_p[nic] = 0.;
-    const double *puv = isv ? V.f[F_pv] : V.f[F_pu];
-    double *ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), *fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
-    double *ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), *fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
-    const double *difiso = V.f[F_difiso];
     while (true) {                                              // search_loop2
       if (advance_src_m) {
         bool out = false;
@@ -566,54 +562,17 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         const double dp_ni = 2. * dp_ni_m * dp_ni_p / fmax2(dp_ni_m + dp_ni_p, 2. * ND_DP_EPS);
         if (ks_m == ks_m_prev && ks_p == ks_p_prev && p_ni_m[nip] >= SNM(kd_m) && p_ni_m[nic] <= g_m && p_ni_p[nip] >= SNP(kd_p) &&
             p_ni_p[nic] <= g_p && dp_ni > 2. * ND_DP_EPS) {
-          const double q = .5 * cdiff * (difiso[cm + (size_t)(ks_m - 1) * np] + difiso[cp + (size_t)(ks_p - 1) * np]) * dp_ni;
-          const size_t om = cm + (size_t)(ks_m - 1 + nn) * np, op = cp + (size_t)(ks_p - 1 + nn) * np;
-          // the record of this neutral layer: destination layers, then one flux per field (NaN: withheld)
+          // the record of this neutral layer (k_ndiff_eval forms the fluxes from it): destination and source layers, how the
+          // interface values are to be taken, the positions of the two neutral interfaces in the source layers, the thickness
           const bool keep = nrec < A.nrec_max;
           if (!keep) atomicOr(errw, 1);
-          double *rf = A.rec_f + face + (size_t)nrec * ntr_loc * nf;
-          if (keep) A.rec_k[face + (size_t)nrec * nf] = kd_m | (kd_p << 16);
-          nrec = nrec + (keep ? 1 : 0);
-          const double withheld = __builtin_nan("");
-          Pc5 tm = nd_pc(A, np, cm, ks_m, 0), tp = nd_pc(A, np, cp, ks_p, 0), sm = nd_pc(A, np, cm, ks_m, 1), sp = nd_pc(A, np, cp, ks_p, 1);
-          const double dt = nd_pmeval(tm, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(tp, x_ni_p[nip], x_ni_p[nic]);
-          const double ds = nd_pmeval(sm, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(sp, x_ni_p[nip], x_ni_p[nic]);
-          if (dt * (V.f[F_temp][om] - V.f[F_temp][op]) >= 0. &&
-              dt * (nd_tni(tm, knd_m[nip], x_ni_m[nip]) - nd_tni(tp, knd_p[nip], x_ni_p[nip])) >= 0. &&
-              dt * (nd_tni(tm, knd_m[nic], x_ni_m[nic]) - nd_tni(tp, knd_p[nic], x_ni_p[nic])) >= 0. &&
-              ds * (V.f[F_saln][om] - V.f[F_saln][op]) >= 0. &&
-              ds * (nd_tni(sm, knd_m[nip], x_ni_m[nip]) - nd_tni(sp, knd_p[nip], x_ni_p[nip])) >= 0. &&
-              ds * (nd_tni(sm, knd_m[nic], x_ni_m[nic]) - nd_tni(sp, knd_p[nic], x_ni_p[nic])) >= 0.) {
-            const double tflx = q * dt, sflx = q * ds;
-            if (keep) { rf[0] = tflx; rf[nf] = sflx; }
-            if (wedge) {
-              const double p_ni_up = .5 * (p_ni_m[nip] + p_ni_p[nip]), p_ni_lo = .5 * (p_ni_m[nic] + p_ni_p[nic]);
-              const double dp_ni_i = 1. / fmax2(ND_EPSILP, p_ni_lo - p_ni_up);
-              while (kuv <= kk) {
-                const size_t ok = cp + (size_t)(kuv - 1 + mm) * np;
-                const double pk1 = puv[cp + (size_t)kuv * np], pk = puv[cp + (size_t)(kuv - 1) * np];
-                if (pk1 < p_ni_lo) {
-                  const double mlfrac = fmax2(0., pk1 - fmax2(p_ni_up, pk)) * dp_ni_i;
-                  ftl[ok] = ftl[ok] + tflx * mlfrac; fsl[ok] = fsl[ok] + sflx * mlfrac;
-                  ftx[ok] = ftx[ok] + tflx * mlfrac; fsx[ok] = fsx[ok] + sflx * mlfrac;
-                  kuv = kuv + 1;
-                } else {
-                  const double mlfrac = (p_ni_lo - fmax2(p_ni_up, pk)) * dp_ni_i;
-                  ftl[ok] = ftl[ok] + tflx * mlfrac; fsl[ok] = fsl[ok] + sflx * mlfrac;
-                  ftx[ok] = ftx[ok] + tflx * mlfrac; fsx[ok] = fsx[ok] + sflx * mlfrac;
-                  break;
-                }
-              }
-            }
-          } else if (keep) { rf[0] = withheld; rf[nf] = withheld; }
-          for (int nt = 2; nt < ntr_loc; nt++) {
-            const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
-            const double dtr = nd_pmeval(cm5, x_ni_m[nip], x_ni_m[nic]) - nd_pmeval(cp5, x_ni_p[nip], x_ni_p[nic]);
-            const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
-            const bool pass = dtr * (V.f[F_trc][om + otr] - V.f[F_trc][op + otr]) >= 0. &&
-                              dtr * (nd_tni(cm5, knd_m[nip], x_ni_m[nip]) - nd_tni(cp5, knd_p[nip], x_ni_p[nip])) >= 0. &&
-                              dtr * (nd_tni(cm5, knd_m[nic], x_ni_m[nic]) - nd_tni(cp5, knd_p[nic], x_ni_p[nic])) >= 0.;
-            if (keep) rf[(size_t)nt * nf] = pass ? q * dtr : withheld;
+          if (keep) {
+            A.rec_k[face + (size_t)nrec * nf] = kd_m | (kd_p << 16);
+            A.rec_s[face + (size_t)nrec * nf] = ks_m | (ks_p << 8) | (knd_m[nip] << 16) | (knd_m[nic] << 18) | (knd_p[nip] << 20) | (knd_p[nic] << 22);
+            double *rg = A.rec_g + face + (size_t)nrec * 7 * nf;
+            rg[0] = x_ni_m[nip]; rg[nf] = x_ni_m[nic]; rg[2 * nf] = x_ni_p[nip]; rg[3 * nf] = x_ni_p[nic]; rg[4 * nf] = dp_ni;
+            rg[5 * nf] = .5 * (p_ni_m[nip] + p_ni_p[nip]); rg[6 * nf] = .5 * (p_ni_m[nic] + p_ni_p[nic]);
+            nrec = nrec + 1;
           }
         }
         ks_m_prev = ks_m; ks_p_prev = ks_p;
@@ -715,6 +674,102 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
   nd_face(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
 }
 
+// the fluxes of a face's records, :860-913.  The records do not depend on each other: blockIdx.y strides over them, blockIdx.z
+// = 0 forms heat and salt (one sign test for both), blockIdx.z = g > 0 the tracer g.  A withheld flux is a NaN in the record.
+#define ND_EVAL_RY 16
+__global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ Vp, NdArgs A) {
+  const DevView &V = *Vp;
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t np = V.nplane, nf = 2 * np;
+  if ((size_t)t_ >= nf) return;
+  const size_t face = t_;
+  const int n = A.rec_n[face];
+  if ((int)blockIdx.y >= n) return;
+  const bool isv = face >= np;
+  const size_t cp = isv ? face - np : face, cm = isv ? cp - V.ni : cp - 1;
+  const int kk = V.kk, nn = A.nn, ntr_loc = A.ntr_loc, g = blockIdx.z;
+  const double cdiff = isv ? V.P.delt1 * V.f[F_scvx][cp] * V.f[F_scvyi][cp] : V.P.delt1 * V.f[F_scuy][cp] * V.f[F_scuxi][cp];   // :1079, :1134
+  const double *difiso = V.f[F_difiso];
+  const double withheld = __builtin_nan("");
+  for (int r = blockIdx.y; r < n; r += ND_EVAL_RY) {
+    const int rs = A.rec_s[face + (size_t)r * nf];
+    const int ks_m = rs & 255, ks_p = (rs >> 8) & 255, km0 = (rs >> 16) & 3, km1 = (rs >> 18) & 3, kp0 = (rs >> 20) & 3, kp1 = (rs >> 22) & 3;
+    const double *rg = A.rec_g + face + (size_t)r * 7 * nf;
+    const double xm0 = rg[0], xm1 = rg[nf], xp0 = rg[2 * nf], xp1 = rg[3 * nf], dp_ni = rg[4 * nf];
+    double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
+    const double q = .5 * cdiff * (difiso[cm + (size_t)(ks_m - 1) * np] + difiso[cp + (size_t)(ks_p - 1) * np]) * dp_ni;
+    const size_t om = cm + (size_t)(ks_m - 1 + nn) * np, op = cp + (size_t)(ks_p - 1 + nn) * np;
+    if (g == 0) {
+      const Pc5 tm = nd_pc(A, np, cm, ks_m, 0), tp = nd_pc(A, np, cp, ks_p, 0), sm = nd_pc(A, np, cm, ks_m, 1), sp = nd_pc(A, np, cp, ks_p, 1);
+      const double dt = nd_pmeval(tm, xm0, xm1) - nd_pmeval(tp, xp0, xp1);
+      const double ds = nd_pmeval(sm, xm0, xm1) - nd_pmeval(sp, xp0, xp1);
+      const bool pass = dt * (V.f[F_temp][om] - V.f[F_temp][op]) >= 0. && dt * (nd_tni(tm, km0, xm0) - nd_tni(tp, kp0, xp0)) >= 0. &&
+                        dt * (nd_tni(tm, km1, xm1) - nd_tni(tp, kp1, xp1)) >= 0. && ds * (V.f[F_saln][om] - V.f[F_saln][op]) >= 0. &&
+                        ds * (nd_tni(sm, km0, xm0) - nd_tni(sp, kp0, xp0)) >= 0. && ds * (nd_tni(sm, km1, xm1) - nd_tni(sp, kp1, xp1)) >= 0.;
+      rf[0] = pass ? q * dt : withheld;
+      rf[nf] = pass ? q * ds : withheld;
+    } else {
+      const int nt = g + 1;
+      const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
+      const double dtr = nd_pmeval(cm5, xm0, xm1) - nd_pmeval(cp5, xp0, xp1);
+      const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
+      const bool pass = dtr * (V.f[F_trc][om + otr] - V.f[F_trc][op + otr]) >= 0. && dtr * (nd_tni(cm5, km0, xm0) - nd_tni(cp5, kp0, xp0)) >= 0. &&
+                        dtr * (nd_tni(cm5, km1, xm1) - nd_tni(cp5, kp1, xp1)) >= 0.;
+      rf[(size_t)nt * nf] = pass ? q * dtr : withheld;
+    }
+  }
+}
+
+// :886-906: the heat and salt flux of every neutral layer distributed over the layers of the velocity point it crosses
+// (utflld.., utflx..); one thread per face walks its records, the layer index kuv only moves down
+__global__ __launch_bounds__(64) void k_ndiff_uvflx(const DevView *__restrict__ Vp, NdArgs A) {
+  const DevView &V = *Vp;
+  const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t np = V.nplane, nf = 2 * np;
+  if ((size_t)t_ >= nf) return;
+  const size_t face = t_;
+  const int n = A.rec_n[face];
+  if (n == 0) return;
+  const bool isv = face >= np;
+  const size_t cp = isv ? face - np : face;
+  const int kk = V.kk, mm = A.mm, ntr_loc = A.ntr_loc;
+  const double *puv = isv ? V.f[F_pv] : V.f[F_pu];
+  double *ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), *fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
+  double *ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), *fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
+  int kuv = 1;
+  // the sums of the layer kuv stay in registers until kuv moves on
+  size_t ok = cp + (size_t)(kuv - 1 + mm) * np;
+  double atl = ftl[ok], asl = fsl[ok], atx = ftx[ok], asx = fsx[ok], pk = puv[cp], pk1 = puv[cp + np];
+  for (int r = 0; r < n; r++) {
+    const double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
+    const double tflx = rf[0], sflx = rf[nf];
+    if (!(tflx == tflx)) continue;
+    const double *rg = A.rec_g + face + (size_t)r * 7 * nf;
+    const double p_ni_up = rg[5 * nf], p_ni_lo = rg[6 * nf];
+    const double dp_ni_i = 1. / fmax2(ND_EPSILP, p_ni_lo - p_ni_up);
+    while (kuv <= kk) {
+      if (pk1 < p_ni_lo) {
+        const double mlfrac = fmax2(0., pk1 - fmax2(p_ni_up, pk)) * dp_ni_i;
+        atl = atl + tflx * mlfrac; asl = asl + sflx * mlfrac;
+        atx = atx + tflx * mlfrac; asx = asx + sflx * mlfrac;
+        ftl[ok] = atl; fsl[ok] = asl; ftx[ok] = atx; fsx[ok] = asx;
+        kuv = kuv + 1;
+        if (kuv <= kk) {
+          ok = cp + (size_t)(kuv - 1 + mm) * np;
+          atl = ftl[ok]; asl = fsl[ok]; atx = ftx[ok]; asx = fsx[ok];
+          pk = pk1; pk1 = puv[cp + (size_t)kuv * np];
+        }
+      } else {
+        const double mlfrac = (p_ni_lo - fmax2(p_ni_up, pk)) * dp_ni_i;
+        atl = atl + tflx * mlfrac; asl = asl + sflx * mlfrac;
+        atx = atx + tflx * mlfrac; asx = asx + sflx * mlfrac;
+        break;
+      }
+    }
+  }
+  if (kuv <= kk) { ftl[ok] = atl; fsl[ok] = asl; ftx[ok] = atx; fsx[ok] = asx; }
+}
+
 // the records of a cell's four faces replayed in the order of the j-slice loop (header): - v-face j, - u-face i, + u-face i+1,
 // + v-face j+1.  One thread per cell AND field (blockIdx.y): the running sums of different fields do not meet.  Within a face
 // the destination layer never decreases, so the sum of the current layer stays in a register until the layer changes.
@@ -761,6 +816,8 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, NdArgs A, int *ksmx, int 
   hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, st, c->d, A, ksmx, kdmx, tsd, drt, drs);
   if (int rc = ctx_err_words(c)) return rc;
   hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 3);
+  hipLaunchKernelGGL(k_ndiff_eval, dim3((unsigned)((2 * h.nplane + 63) / 64), ND_EVAL_RY, A.ntr_loc - 1), dim3(64), 0, st, c->d, A);
+  hipLaunchKernelGGL(k_ndiff_uvflx, dim3((unsigned)((2 * h.nplane + 63) / 64)), dim3(64), 0, st, c->d, A);
   hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), 0, st, c->d, A);
   HIPCHK(c, hipGetLastError());
   return 0;
