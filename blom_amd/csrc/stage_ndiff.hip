@@ -146,6 +146,14 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
 #define STP(ks_) ((stp[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
 #define STM_SET(ks_) stm[((ks_)-1) >> 6] |= 1ull << (((ks_)-1) & 63)
 #define STP_SET(ks_) stp[((ks_)-1) >> 6] |= 1ull << (((ks_)-1) & 63)
+  // which entries of p_ni_srcdi_m, p_ni_srcdi_p have been set (the reference tests them against mval): the index walks of the
+  // second search then need no loads
+  unsigned long long pbm[4] = {0ull, 0ull, 0ull, 0ull}, pbp[4] = {0ull, 0ull, 0ull, 0ull};
+#define PBI(is_, ks_) (((ks_)-1) * 2 + (is_)-1)
+#define PBM(is_, ks_) ((pbm[PBI(is_, ks_) >> 6] >> (PBI(is_, ks_) & 63)) & 1ull)
+#define PBP(is_, ks_) ((pbp[PBI(is_, ks_) >> 6] >> (PBI(is_, ks_) & 63)) & 1ull)
+#define PNM_SET(is_, ks_, v_) do { PNM(is_, ks_) = (v_); pbm[PBI(is_, ks_) >> 6] |= 1ull << (PBI(is_, ks_) & 63); } while (0)
+#define PNP_SET(is_, ks_, v_) do { PNP(is_, ks_) = (v_); pbp[PBI(is_, ks_) >> 6] |= 1ull << (PBI(is_, ks_) & 63); } while (0)
   for (int k = 1; k <= kk; k++) { PNM(1, k) = ND_MVAL; PNM(2, k) = ND_MVAL; PNP(1, k) = ND_MVAL; PNP(2, k) = ND_MVAL; }
   int nns = 0;
   int is_m, is_p, ks_m, ks_p, kssa_m = 0, kssa_p = 0;
@@ -170,132 +178,148 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     is_m = 1; ks_m = 1; is_p = 1; ks_p = 1;
     p_ni_m_prev = PSM(1, 1); p_ni_p_prev = PSP(1, 1);
   }
-  // the values at the current interface of either column stay in registers and are re-read when the index moves
-  double psm = 0., tsm = 0., ssm = 0., dtm = 0., dsm = 0., psm1 = 0., psp = 0., tsp = 0., ssp = 0., dtp = 0., dsp = 0., psp1 = 0.;
-#define LOAD_M()                                                                                                                \
-  do {                                                                                                                          \
-    psm = PSM(is_m, ks_m); tsm = TSM(is_m, ks_m, 0); ssm = TSM(is_m, ks_m, 1); dtm = DTM(is_m, ks_m); dsm = DSM(is_m, ks_m);      \
-    if (is_m == 1) psm1 = psm;                                                                                                  \
-  } while (0)
-#define LOAD_P()                                                                                                                \
-  do {                                                                                                                          \
-    psp = PSP(is_p, ks_p); tsp = TSP(is_p, ks_p, 0); ssp = TSP(is_p, ks_p, 1); dtp = DTP(is_p, ks_p); dsp = DSP(is_p, ks_p);      \
-    if (is_p == 1) psp1 = psp;                                                                                                  \
-  } while (0)
+  // The reference's loop classifies the density difference at the current pair of interfaces and then walks down column m
+  // and / or column p until the difference has moved on by rho_eps.  Here that is ONE loop in which every pass moves one
+  // interface in one of the columns (mode 1: column m, 2: column p; 0: classify first): a pass has a single round of loads
+  // whichever column the lanes of a wavefront are walking.  The values at the current interfaces, and those at the upper
+  // interface of the current layers, stay in registers.
+  double psm = 0., tsm = 0., ssm = 0., dtm = 0., dsm = 0., psm1 = 0., dtm1 = 0., dsm1 = 0.;
+  double psp = 0., tsp = 0., ssp = 0., dtp = 0., dsp = 0., psp1 = 0., dtp1 = 0., dsp1 = 0.;
+  double lastm2 = 0., lastp2 = 0., prevm2 = 0., prevp2 = 0.;      // p_ni_srcdi(2, ks) as last written, and that of the layer above
 #define DRHO_CUR() ((.5 * (dtm + dtp)) * (tsp - tsm) + (.5 * (dsm + dsp)) * (ssp - ssm))
   if (ks_m <= ksmx_m && ks_p <= ksmx_p) {
-    LOAD_M();
-    LOAD_P();
+    psm = PSM(is_m, ks_m); tsm = TSM(is_m, ks_m, 0); ssm = TSM(is_m, ks_m, 1); dtm = DTM(is_m, ks_m); dsm = DSM(is_m, ks_m);
+    psp = PSP(is_p, ks_p); tsp = TSP(is_p, ks_p, 0); ssp = TSP(is_p, ks_p, 1); dtp = DTP(is_p, ks_p); dsp = DSP(is_p, ks_p);
+    psm1 = psm; dtm1 = dtm; dsm1 = dsm; psp1 = psp; dtp1 = dtp; dsp1 = dsp;                // (both start at an upper interface)
     drho_curr = DRHO_CUR();
   }
+  int mode = 0;
+  bool then_p = false;
   while (ks_m <= ksmx_m && ks_p <= ksmx_p) {                    // search_loop1
-    const bool drho_neg = drho_curr <= -ND_RHO_EPS, drho_pos = drho_curr >= ND_RHO_EPS;
-    const bool drho_zero = !(drho_neg || drho_pos);
-    if (is_m + ks_m > 2 && is_p + ks_p > 2) {
-      if (drho_neg) {
-        if (is_m == 2) {
-          const double drhodt_x0 = .5 * (DTM(1, ks_m) + dtp), drhodt_x1 = .5 * (dtm + dtp);
-          const double drhods_x0 = .5 * (DSM(1, ks_m) + dsp), drhods_x1 = .5 * (dsm + dsp);
-          const double x_ni = nd_drhoroot(nd_pc(A, np, cm, ks_m, 0), nd_pc(A, np, cm, ks_m, 1), tsp, ssp, drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
-          const double p_ni = psm * x_ni + psm1 * (1. - x_ni);
-          if (p_ni > p_ni_m_prev) {
-            p_ni_m_prev = p_ni;
-            PNP(is_p, ks_p) = p_ni;
-            nns = nns + 1;
-            if (wedge) { NSL(nns) = -cnslp * (psp - p_ni); PNS(nns) = .5 * (psp + p_ni); }
+    if (mode == 0) {
+      const bool drho_neg = drho_curr <= -ND_RHO_EPS, drho_pos = drho_curr >= ND_RHO_EPS;
+      const bool drho_zero = !(drho_neg || drho_pos);
+      if (is_m + ks_m > 2 && is_p + ks_p > 2) {
+        if (drho_neg) {
+          if (is_m == 2) {
+            const double drhodt_x0 = .5 * (dtm1 + dtp), drhodt_x1 = .5 * (dtm + dtp);
+            const double drhods_x0 = .5 * (dsm1 + dsp), drhods_x1 = .5 * (dsm + dsp);
+            const double x_ni = nd_drhoroot(nd_pc(A, np, cm, ks_m, 0), nd_pc(A, np, cm, ks_m, 1), tsp, ssp, drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
+            const double p_ni = psm * x_ni + psm1 * (1. - x_ni);
+            if (p_ni > p_ni_m_prev) {
+              p_ni_m_prev = p_ni;
+              PNP_SET(is_p, ks_p, p_ni);
+              if (is_p == 2) lastp2 = p_ni;
+              nns = nns + 1;
+              if (wedge) { NSL(nns) = -cnslp * (psp - p_ni); PNS(nns) = .5 * (psp + p_ni); }
+            }
           }
-        }
-      } else if (drho_pos) {
-        if (is_p == 2) {
-          const double drhodt_x0 = .5 * (dtm + DTP(1, ks_p)), drhodt_x1 = .5 * (dtm + dtp);
-          const double drhods_x0 = .5 * (dsm + DSP(1, ks_p)), drhods_x1 = .5 * (dsm + dsp);
-          const double x_ni = nd_drhoroot(nd_pc(A, np, cp, ks_p, 0), nd_pc(A, np, cp, ks_p, 1), tsm, ssm, drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
-          const double p_ni = psp * x_ni + psp1 * (1. - x_ni);
-          if (p_ni > p_ni_p_prev) {
-            p_ni_p_prev = p_ni;
-            PNM(is_m, ks_m) = p_ni;
-            nns = nns + 1;
-            if (wedge) { NSL(nns) = -cnslp * (p_ni - psm); PNS(nns) = .5 * (p_ni + psm); }
+        } else if (drho_pos) {
+          if (is_p == 2) {
+            const double drhodt_x0 = .5 * (dtm + dtp1), drhodt_x1 = .5 * (dtm + dtp);
+            const double drhods_x0 = .5 * (dsm + dsp1), drhods_x1 = .5 * (dsm + dsp);
+            const double x_ni = nd_drhoroot(nd_pc(A, np, cp, ks_p, 0), nd_pc(A, np, cp, ks_p, 1), tsm, ssm, drhodt_x1, drhodt_x0, drhods_x1, drhods_x0);
+            const double p_ni = psp * x_ni + psp1 * (1. - x_ni);
+            if (p_ni > p_ni_p_prev) {
+              p_ni_p_prev = p_ni;
+              PNM_SET(is_m, ks_m, p_ni);
+              if (is_m == 2) lastm2 = p_ni;
+              nns = nns + 1;
+              if (wedge) { NSL(nns) = -cnslp * (p_ni - psm); PNS(nns) = .5 * (p_ni + psm); }
+            }
           }
+        } else {
+          PNP_SET(is_p, ks_p, psm);
+          PNM_SET(is_m, ks_m, psp);
+          if (is_p == 2) lastp2 = psm;
+          if (is_m == 2) lastm2 = psp;
+          nns = nns + 1;
+          if (wedge) { NSL(nns) = -cnslp * (psp - psm); PNS(nns) = .5 * (psp + psm); }
         }
+      }
+      if (drho_zero || drho_pos) { mode = 1; then_p = drho_zero || drho_neg; }
+      else mode = 2;
+    }
+    const double drho_prev = drho_curr;
+    const bool wm = mode == 1;
+    if (wm) {
+      if (is_m == 1) is_m = 2;
+      else {
+        ks_m = ks_m + 1;
+        if (ks_m > ksmx_m) break;
+        is_m = 1;
+        prevm2 = lastm2;
+      }
+    } else {
+      if (is_p == 1) is_p = 2;
+      else {
+        ks_p = ks_p + 1;
+        if (ks_p > ksmx_p) break;
+        is_p = 1;
+        prevp2 = lastp2;
+      }
+    }
+    {
+      const size_t col = wm ? cm : cp;
+      const int is_ = wm ? is_m : is_p, ks_ = wm ? ks_m : ks_p;
+      const double v_ps = A.psrc[col + (size_t)(ks_ + is_ - 2) * np], v_t = A.tsd[col + ((size_t)(ks_ - 1) * 2 + is_ - 1) * np],
+                   v_s = A.tsd[col + ((size_t)(kk + ks_ - 1) * 2 + is_ - 1) * np], v_dt = A.drt[col + ((size_t)(ks_ - 1) * 2 + is_ - 1) * np],
+                   v_ds = A.drs[col + ((size_t)(ks_ - 1) * 2 + is_ - 1) * np];
+      if (wm) {
+        psm = v_ps; tsm = v_t; ssm = v_s; dtm = v_dt; dsm = v_ds;
+        if (is_ == 1) { psm1 = v_ps; dtm1 = v_dt; dsm1 = v_ds; }
       } else {
-        PNP(is_p, ks_p) = psm;
-        PNM(is_m, ks_m) = psp;
-        nns = nns + 1;
-        if (wedge) { NSL(nns) = -cnslp * (psp - psm); PNS(nns) = .5 * (psp + psm); }
+        psp = v_ps; tsp = v_t; ssp = v_s; dtp = v_dt; dsp = v_ds;
+        if (is_ == 1) { psp1 = v_ps; dtp1 = v_dt; dsp1 = v_ds; }
       }
     }
-    bool done = false;
-    if (drho_zero || drho_pos) {
-      while (true) {
-        const double drho_prev = drho_curr;
-        if (is_m == 1) is_m = 2;
-        else {
-          ks_m = ks_m + 1;
-          if (ks_m > ksmx_m) { done = true; break; }
-          is_m = 1;
-        }
-        LOAD_M();
-        drho_curr = DRHO_CUR();
-        if (drho_prev - drho_curr > ND_RHO_EPS) {
-          if (is_m == 2 && psm - psm1 > ND_ONEMM) STM_SET(ks_m);
-          break;
-        }
-        if (is_m == 1) PNM(is_m, ks_m) = PNM(2, ks_m - 1);
+    drho_curr = DRHO_CUR();
+    if (wm) {
+      if (drho_prev - drho_curr > ND_RHO_EPS) {
+        if (is_m == 2 && psm - psm1 > ND_ONEMM) STM_SET(ks_m);
+        mode = then_p ? 2 : 0;
+      } else if (is_m == 1 && PBM(2, ks_m - 1)) {                // (a copy of mval leaves the entry unset)
+        PNM_SET(1, ks_m, prevm2);
       }
-      if (done) break;
-    }
-    if (drho_zero || drho_neg) {
-      while (true) {
-        const double drho_prev = drho_curr;
-        if (is_p == 1) is_p = 2;
-        else {
-          ks_p = ks_p + 1;
-          if (ks_p > ksmx_p) { done = true; break; }
-          is_p = 1;
-        }
-        LOAD_P();
-        drho_curr = DRHO_CUR();
-        if (drho_curr - drho_prev > ND_RHO_EPS) {
-          if (is_p == 2 && psp - psp1 > ND_ONEMM) STP_SET(ks_p);
-          break;
-        }
-        if (is_p == 1) PNP(is_p, ks_p) = PNP(2, ks_p - 1);
+    } else {
+      if (drho_curr - drho_prev > ND_RHO_EPS) {
+        if (is_p == 2 && psp - psp1 > ND_ONEMM) STP_SET(ks_p);
+        mode = 0;
+      } else if (is_p == 1 && PBP(2, ks_p - 1)) {
+        PNP_SET(1, ks_p, prevp2);
       }
-      if (done) break;
     }
   }
-#undef LOAD_M
-#undef LOAD_P
 #undef DRHO_CUR
+  if (A.dbg == 1) { A.rec_n[face] = 0; return; }
   // ---- alignment with the surface above the uppermost neutral interface, :394-464 ---------------------------------------------
   if (A.surface_align) {
     int issa_m = 1, issa_p = 1;
     while (kssa_m <= ksmx_m) {
-      if (PNM(issa_m, kssa_m) != ND_MVAL) break;
+      if (PBM(issa_m, kssa_m)) break;
       if (issa_m == 1) issa_m = 2;
       else { kssa_m = kssa_m + 1; issa_m = 1; }
     }
     while (kssa_p <= ksmx_p) {
-      if (PNP(issa_p, kssa_p) != ND_MVAL) break;
+      if (PBP(issa_p, kssa_p)) break;
       if (issa_p == 1) issa_p = 2;
       else { kssa_p = kssa_p + 1; issa_p = 1; }
     }
     if (kssa_m > ksmx_m || kssa_p > ksmx_p) {
-      PNM(1, 1) = PSM(1, 1);
+      PNM_SET(1, 1, PSM(1, 1));
       for (ks_m = 1; ks_m <= ksmx_m - 1; ks_m++) {
         if (PSM(1, ks_m) > PSP(2, ksmx_p)) break;
         const double p_ni = fmin2(PSM(2, ks_m), PSP(2, ksmx_p));
-        PNM(1, ks_m + 1) = p_ni;
-        PNM(2, ks_m) = p_ni;
+        PNM_SET(1, ks_m + 1, p_ni);
+        PNM_SET(2, ks_m, p_ni);
         STM_SET(ks_m);
       }
-      PNP(1, 1) = PSP(1, 1);
+      PNP_SET(1, 1, PSP(1, 1));
       for (ks_p = 1; ks_p <= ksmx_p - 1; ks_p++) {
         if (PSP(1, ks_p) > PSM(2, ksmx_m)) break;
         const double p_ni = fmin2(PSP(2, ks_p), PSM(2, ksmx_m));
-        PNP(1, ks_p + 1) = p_ni;
-        PNP(2, ks_p) = p_ni;
+        PNP_SET(1, ks_p + 1, p_ni);
+        PNP_SET(2, ks_p, p_ni);
         STP_SET(ks_p);
       }
     } else {
@@ -305,18 +329,18 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
       } else {
         p1_m = PSM(1, 1); p2_m = PNP(issa_p, kssa_p); p1_p = PSP(1, 1); p2_p = PSP(issa_p, kssa_p);
       }
-      PNM(1, 1) = p1_p;
+      PNM_SET(1, 1, p1_p);
       for (ks_m = 1; ks_m <= kssa_m - 1; ks_m++) {
         const double p_ni = ((PSM(2, ks_m) - p1_m) * p2_p + (p2_m - PSM(2, ks_m)) * p1_p) / (p2_m - p1_m);
-        PNM(1, ks_m + 1) = p_ni;
-        PNM(2, ks_m) = p_ni;
+        PNM_SET(1, ks_m + 1, p_ni);
+        PNM_SET(2, ks_m, p_ni);
         STM_SET(ks_m);
       }
-      PNP(1, 1) = p1_m;
+      PNP_SET(1, 1, p1_m);
       for (ks_p = 1; ks_p <= kssa_p - 1; ks_p++) {
         const double p_ni = ((PSP(2, ks_p) - p1_p) * p2_m + (p2_p - PSP(2, ks_p)) * p1_m) / (p2_p - p1_p);
-        PNP(1, ks_p + 1) = p_ni;
-        PNP(2, ks_p) = p_ni;
+        PNP_SET(1, ks_p + 1, p_ni);
+        PNP_SET(2, ks_p, p_ni);
         STP_SET(ks_p);
       }
     }
@@ -342,6 +366,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
     for (int k = kp + 1; k <= kdmx_p + 1; k++) SNP(k) = PDP(k);
   }
+  if (A.dbg == 2) { A.rec_n[face] = 0; return; }
   // ---- second search, :510-921 ------------------------------------------------------------------------------------------------
   {
     is_m = 2; ks_m = 0; is_p = 2; ks_p = 0;
@@ -354,8 +379,10 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     p_ni_m[nip] = -ND_MVAL; p_ni_p[nip] = -ND_MVAL;
     p_ni_m[nic] = 0.; p_ni_p[nic] = 0.;
     while (true) {                                              // search_loop2
+      // the index walks first (no loads: the set-bits of p_ni_srcdi and the stability flags are in registers), then every value
+      // the new indices need in ONE round of loads
+      bool out = false;
       if (advance_src_m) {
-        bool out = false;
         while (true) {
           if (is_m == 1) {
             is_m = 2;
@@ -364,26 +391,23 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
             ks_m = ks_m + 1;
             if (ks_m > ksmx_m) { out = true; break; }
             is_m = 1;
-            if (STM(ks_m) && PNM(is_m, ks_m) != ND_MVAL) break;
+            if (STM(ks_m) && PBM(is_m, ks_m)) break;
           }
         }
-        if (out) break;
-        isn_m = is_m; ksn_m = ks_m;
-        d_m = PNM(is_m, ks_m);
-        e_m = d_m;
-        while (e_m == ND_MVAL) {
-          if (isn_m == 1) isn_m = 2;
-          else {
-            if (ksn_m == ksmx_m) break;
-            ksn_m = ksn_m + 1;
-            isn_m = 1;
+        if (!out) {
+          isn_m = is_m; ksn_m = ks_m;
+          while (!PBM(isn_m, ksn_m)) {
+            if (isn_m == 1) isn_m = 2;
+            else {
+              if (ksn_m == ksmx_m) break;
+              ksn_m = ksn_m + 1;
+              isn_m = 1;
+            }
           }
-          e_m = PNM(isn_m, ksn_m);
         }
-        a_m = PSM(is_m, ks_m); b_m = PSM(1, ks_m); c_m = PSM(2, ks_m); f_m = PSM(isn_m, ksn_m);
       }
+      if (out) break;
       if (advance_src_p) {
-        bool out = false;
         while (true) {
           if (is_p == 1) {
             is_p = 2;
@@ -392,24 +416,40 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
             ks_p = ks_p + 1;
             if (ks_p > ksmx_p) { out = true; break; }
             is_p = 1;
-            if (STP(ks_p) && PNP(is_p, ks_p) != ND_MVAL) break;
+            if (STP(ks_p) && PBP(is_p, ks_p)) break;
           }
         }
-        if (out) break;
-        isn_p = is_p; ksn_p = ks_p;
-        d_p = PNP(is_p, ks_p);
-        e_p = d_p;
-        while (e_p == ND_MVAL) {
-          if (isn_p == 1) isn_p = 2;
-          else {
-            if (ksn_p == ksmx_p) break;
-            ksn_p = ksn_p + 1;
-            isn_p = 1;
+        if (!out) {
+          isn_p = is_p; ksn_p = ks_p;
+          while (!PBP(isn_p, ksn_p)) {
+            if (isn_p == 1) isn_p = 2;
+            else {
+              if (ksn_p == ksmx_p) break;
+              ksn_p = ksn_p + 1;
+              isn_p = 1;
+            }
           }
-          e_p = PNP(isn_p, ksn_p);
         }
+      }
+      if (out) break;
+      if (advance_dst_m) {
+        kd_m = kd_m + 1;
+        if (kd_m > kdmx_m) break;
+      }
+      if (advance_dst_p) {
+        kd_p = kd_p + 1;
+        if (kd_p > kdmx_p) break;
+      }
+      if (advance_src_m) {
+        d_m = PNM(is_m, ks_m); e_m = PNM(isn_m, ksn_m);
+        a_m = PSM(is_m, ks_m); b_m = PSM(1, ks_m); c_m = PSM(2, ks_m); f_m = PSM(isn_m, ksn_m);
+      }
+      if (advance_src_p) {
+        d_p = PNP(is_p, ks_p); e_p = PNP(isn_p, ksn_p);
         a_p = PSP(is_p, ks_p); b_p = PSP(1, ks_p); c_p = PSP(2, ks_p); f_p = PSP(isn_p, ksn_p);
       }
+      if (advance_dst_m) g_m = SNM(kd_m + 1);
+      if (advance_dst_p) g_p = SNP(kd_p + 1);
       if (p_ni_m[nip] == -ND_MVAL) {
         if ((e_m - f_p) < (e_p - f_m)) {
           p_ni_m[nip] = f_m;
@@ -419,31 +459,21 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
           p_ni_p[nip] = f_p;
         }
       }
-      if (advance_dst_m) {
-        kd_m = kd_m + 1;
-        if (kd_m > kdmx_m) break;
-        g_m = SNM(kd_m + 1);
-      }
-      if (advance_dst_p) {
-        kd_p = kd_p + 1;
-        if (kd_p > kdmx_p) break;
-        g_p = SNP(kd_p + 1);
-      }
-      {
-        bool out = false;
-        while (g_m <= fmax2(b_m, p_ni_m[nip])) {
+      while (true) {                                            // both columns' destination indices step together
+        const bool nm = g_m <= fmax2(b_m, p_ni_m[nip]), npp = g_p <= fmax2(b_p, p_ni_p[nip]);
+        if (!nm && !npp) break;
+        if (nm) {
           kd_m = kd_m + 1;
           if (kd_m > kdmx_m) { out = true; break; }
-          g_m = SNM(kd_m + 1);
         }
-        if (out) break;
-        while (g_p <= fmax2(b_p, p_ni_p[nip])) {
+        if (npp) {
           kd_p = kd_p + 1;
           if (kd_p > kdmx_p) { out = true; break; }
-          g_p = SNP(kd_p + 1);
         }
-        if (out) break;
+        if (nm) g_m = SNM(kd_m + 1);
+        if (npp) g_p = SNP(kd_p + 1);
       }
+      if (out) break;
       advance_src_m = false; advance_src_p = false; advance_dst_m = false; advance_dst_p = false;
       int case_m = 3, case_p = 3;
       if (a_m <= e_p) {
@@ -581,6 +611,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
   }
   A.rec_n[face] = nrec;
+  if (A.dbg == 3) return;
   // ---- neutral slope at the destination interfaces, :923-951 ------------------------------------------------------------------
   if (wedge) {
     double *nsl = (isv ? V.f[F_nslpy] : V.f[F_nslpx]);
@@ -674,8 +705,8 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
   nd_face(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
 }
 
-// the fluxes of a face's records, :860-913.  The records do not depend on each other: blockIdx.y strides over them, blockIdx.z
-// = 0 forms heat and salt (one sign test for both), blockIdx.z = g > 0 the tracer g.  A withheld flux is a NaN in the record.
+// the fluxes of a face's records, :860-913.  The records do not depend on each other: blockIdx.y strides over them; heat and
+// salt share one sign test, every tracer has its own.  A withheld flux is a NaN in the record.
 #define ND_EVAL_RY 16
 __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ Vp, NdArgs A) {
   const DevView &V = *Vp;
@@ -687,7 +718,7 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
   if ((int)blockIdx.y >= n) return;
   const bool isv = face >= np;
   const size_t cp = isv ? face - np : face, cm = isv ? cp - V.ni : cp - 1;
-  const int kk = V.kk, nn = A.nn, ntr_loc = A.ntr_loc, g = blockIdx.z;
+  const int kk = V.kk, nn = A.nn, ntr_loc = A.ntr_loc;
   const double cdiff = isv ? V.P.delt1 * V.f[F_scvx][cp] * V.f[F_scvyi][cp] : V.P.delt1 * V.f[F_scuy][cp] * V.f[F_scuxi][cp];   // :1079, :1134
   const double *difiso = V.f[F_difiso];
   const double withheld = __builtin_nan("");
@@ -699,7 +730,7 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
     double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
     const double q = .5 * cdiff * (difiso[cm + (size_t)(ks_m - 1) * np] + difiso[cp + (size_t)(ks_p - 1) * np]) * dp_ni;
     const size_t om = cm + (size_t)(ks_m - 1 + nn) * np, op = cp + (size_t)(ks_p - 1 + nn) * np;
-    if (g == 0) {
+    {
       const Pc5 tm = nd_pc(A, np, cm, ks_m, 0), tp = nd_pc(A, np, cp, ks_p, 0), sm = nd_pc(A, np, cm, ks_m, 1), sp = nd_pc(A, np, cp, ks_p, 1);
       const double dt = nd_pmeval(tm, xm0, xm1) - nd_pmeval(tp, xp0, xp1);
       const double ds = nd_pmeval(sm, xm0, xm1) - nd_pmeval(sp, xp0, xp1);
@@ -708,8 +739,8 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
                         ds * (nd_tni(sm, km0, xm0) - nd_tni(sp, kp0, xp0)) >= 0. && ds * (nd_tni(sm, km1, xm1) - nd_tni(sp, kp1, xp1)) >= 0.;
       rf[0] = pass ? q * dt : withheld;
       rf[nf] = pass ? q * ds : withheld;
-    } else {
-      const int nt = g + 1;
+    }
+    for (int nt = 2; nt < ntr_loc; nt++) {
       const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
       const double dtr = nd_pmeval(cm5, xm0, xm1) - nd_pmeval(cp5, xp0, xp1);
       const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
@@ -816,7 +847,7 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, NdArgs A, int *ksmx, int 
   hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, st, c->d, A, ksmx, kdmx, tsd, drt, drs);
   if (int rc = ctx_err_words(c)) return rc;
   hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 3);
-  hipLaunchKernelGGL(k_ndiff_eval, dim3((unsigned)((2 * h.nplane + 63) / 64), ND_EVAL_RY, A.ntr_loc - 1), dim3(64), 0, st, c->d, A);
+  hipLaunchKernelGGL(k_ndiff_eval, dim3((unsigned)((2 * h.nplane + 63) / 64), ND_EVAL_RY), dim3(64), 0, st, c->d, A);
   hipLaunchKernelGGL(k_ndiff_uvflx, dim3((unsigned)((2 * h.nplane + 63) / 64)), dim3(64), 0, st, c->d, A);
   hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), 0, st, c->d, A);
   HIPCHK(c, hipGetLastError());
