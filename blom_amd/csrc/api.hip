@@ -317,7 +317,6 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
   if (s == "live_slopes") { c->live_slopes = v; return 0; }
-  if (s == "ndiff_dbg") { c->ndiff_dbg = v; return 0; }
   if (s == "ndiff_surface_align") { c->ndiff_surface_align = v != 0; return 0; }
   if (s == "momtum_bs") { c->momtum_bs = v; return 0; }
   if (s == "momtum_lds_pad") { c->momtum_lds_pad = v; return 0; }

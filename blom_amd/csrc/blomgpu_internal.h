@@ -287,7 +287,6 @@ struct blomgpu_ctx {
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
-  int ndiff_dbg = 0;             // timing experiments only (stage_ndiff.hip)
   int ndiff_surface_align = 1;   // phy/mod_diffusion.F90:84 (the namelist default of cime_config is .true.)
   int live_slopes = 0;       // blomgpu_step: 1 = cmnfld2 computes nslpx/nslpy every step (stage_cmnfld.hip); 0 = they stay as uploaded
   int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major

@@ -968,7 +968,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     A.scr = A.flx + (size_t)a->ntr_loc * per;
     A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_s = A.rec_k + (size_t)6 * h.kk * 2 * np; A.rec_g = a->nd_recg;
     A.rec_f = a->nd_rec; A.nrec_max = 6 * h.kk;
-    A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align; A.dbg = c->ndiff_dbg;
+    A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
     if (int rc2 = fork()) return rc2;
     if (int rc2 = st_ndiff_prep_flux(c, a->side, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
       return rc2;

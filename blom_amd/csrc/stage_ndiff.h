@@ -18,7 +18,7 @@ struct NdArgs {
                                // mean pressure of the upper and of the lower interface
   double *rec_f;               // per record ntr_loc fluxes (NaN: withheld by the sign tests)
   int nrec_max;
-  int kk, npc, ntr_loc, mm, nn, surface_align, dbg;
+  int kk, npc, ntr_loc, mm, nn, surface_align;
 };
 
 size_t ndiff_scratch_planes(int kk);

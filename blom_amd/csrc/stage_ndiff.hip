@@ -111,7 +111,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
   const size_t np = V.nplane, nf = 2 * V.nplane;
   const bool wedge = true;
   int nrec = 0;
-  const int kk = V.kk, mm = A.mm, nn = A.nn, ntr_loc = A.ntr_loc;
+  const int kk = V.kk;
   // 1-based accessors in the reference's names
 #define PSM(is_, ks_) A.psrc[cm + (size_t)((ks_) + (is_)-2) * np]                       /* p_srcdi_m(is,ks) = p_src(ks+is-1) */
 #define PSP(is_, ks_) A.psrc[cp + (size_t)((ks_) + (is_)-2) * np]
@@ -133,14 +133,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
   ((.5 * (DTM(ism, ksm) + DTP(isp_, ksp))) * (TSP(isp_, ksp, 0) - TSM(ism, ksm, 0)) +                                        \
    (.5 * (DSM(ism, ksm) + DSP(isp_, ksp))) * (TSP(isp_, ksp, 1) - TSM(ism, ksm, 1)))
   const int ksmx_m = A.ksmx[cm], ksmx_p = A.ksmx[cp], kdmx_m = A.kdmx[cm], kdmx_p = A.kdmx[cp];
-  double cdiff, cnslp;
-  if (!isv) {                                                   // :1079-1080, :1134-1135
-    cdiff = V.P.delt1 * V.f[F_scuy][cp] * V.f[F_scuxi][cp];
-    cnslp = ND_ALPHA0 * V.f[F_scuxi][cp] / ND_GRAV;
-  } else {
-    cdiff = V.P.delt1 * V.f[F_scvx][cp] * V.f[F_scvyi][cp];
-    cnslp = ND_ALPHA0 * V.f[F_scvyi][cp] / ND_GRAV;
-  }
+  const double cnslp = ND_ALPHA0 * (isv ? V.f[F_scvyi][cp] : V.f[F_scuxi][cp]) / ND_GRAV;      // :1080, :1135
   unsigned long long stm[2] = {0ull, 0ull}, stp[2] = {0ull, 0ull};          // stab_src_m, stab_src_p (kk <= 128)
 #define STM(ks_) ((stm[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
 #define STP(ks_) ((stp[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
@@ -291,7 +284,6 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
   }
 #undef DRHO_CUR
-  if (A.dbg == 1) { A.rec_n[face] = 0; return; }
   // ---- alignment with the surface above the uppermost neutral interface, :394-464 ---------------------------------------------
   if (A.surface_align) {
     int issa_m = 1, issa_p = 1;
@@ -366,11 +358,10 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
     for (int k = kp + 1; k <= kdmx_p + 1; k++) SNP(k) = PDP(k);
   }
-  if (A.dbg == 2) { A.rec_n[face] = 0; return; }
   // ---- second search, :510-921 ------------------------------------------------------------------------------------------------
   {
     is_m = 2; ks_m = 0; is_p = 2; ks_p = 0;
-    int kd_m = 0, kd_p = 0, isn_m = 1, isn_p = 1, ksn_m = 1, ksn_p = 1, ks_m_prev = 0, ks_p_prev = 0, nip = 0, nic = 1, kuv = 1;
+    int kd_m = 0, kd_p = 0, isn_m = 1, isn_p = 1, ksn_m = 1, ksn_p = 1, ks_m_prev = 0, ks_p_prev = 0, nip = 0, nic = 1;
     bool advance_src_m = true, advance_src_p = true, advance_dst_m = true, advance_dst_p = true;
     double p_ni_m[2], p_ni_p[2], x_ni_m[2] = {0., 0.}, x_ni_p[2] = {0., 0.};
     int knd_m[2] = {0, 0}, knd_p[2] = {0, 0};                 // how t_ni_m, t_ni_p of the slot were formed (nd_tni)
@@ -611,7 +602,6 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
   }
   A.rec_n[face] = nrec;
-  if (A.dbg == 3) return;
   // ---- neutral slope at the destination interfaces, :923-951 ------------------------------------------------------------------
   if (wedge) {
     double *nsl = (isv ? V.f[F_nslpy] : V.f[F_nslpx]);

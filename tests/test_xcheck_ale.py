@@ -243,12 +243,14 @@ def test_other_coordinates_fail_loudly():
     gpu.close()
 
 
-@pytest.mark.parametrize("cfg,method,ntr", [("chan_s", "nudge", 9), ("tri_s", "direct", 7), ("box_s", "nudge", 12)])
-def test_more_tracers_than_one_engine_batch(cfg, method, ntr):
+@pytest.mark.parametrize("cfg,method,ntr,neutral", [("chan_s", "nudge", 9, False), ("tri_s", "direct", 7, False), ("box_s", "nudge", 12, False),
+                                                    ("chan_s", "nudge", 9, True), ("tri_s", "direct", 11, True)])
+def test_more_tracers_than_one_engine_batch(cfg, method, ntr, neutral):
     """ale_regrid_remap with more than the eight fields (T, S + tracers) one batch of the engine's *_many calls carries: the
     further batches reconstruct and remap on their own.  Pinned by reduction: tracers that are copies of the case's one tracer
     must each come out as that tracer does in the run with one tracer (which the cases above check against the reference),
-    and nothing else may change."""
+    and nothing else may change.  neutral: with the neutral diffusion, which keeps the coefficients of every batch and carries
+    one flux per field in its records."""
     from blom_amd.gpu import BlomGpu
     nsteps = 3
     case1, caseN = make_case(cfg), make_case(cfg, ntr=ntr)
@@ -270,11 +272,15 @@ def test_more_tracers_than_one_engine_batch(cfg, method, ntr):
         gpu.set("ale_regrid_method", method)
         gpu.set_vector("plevel", 0.4 * pbot * (np.arange(kk) / kk) ** 1.3)
         gpu.set("delt1", 2.0 * case.params["baclin"])
+        if neutral:
+            gpu.set("ltedtp_opt", 2)
+            gpu.set("ndiff_surface_align", 1)
+            gpu.put("dpml", 9806.0 * 40.0 * np.ones((1, case.jdm + 8, case.idm + 8)))
         gpu.stage("ale_regrid_remap", *hostinit.step_indices(nsteps, kk))
-        out[tag] = {nm: gpu.get(nm) for nm in OUT}
+        out[tag] = {nm: gpu.get(nm) for nm in OUT + (NDIFF_OUT if neutral else [])}
         gpu.close()
     wet = ip > 0
-    for nm in OUT:
+    for nm in OUT + (NDIFF_OUT if neutral else []):
         if nm == "trc":
             continue
         a, b = out["one"][nm], out["many"][nm]
