@@ -143,8 +143,11 @@ int  blomgpu_thermf (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
  * cross-checked against the real module behind stand-ins, tests/test_xcheck_mxlayr.py. */
 int  blomgpu_mxlayr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* phy/mod_ale_regrid_remap.F90:1486 ale_regrid_remap(m,n,mm,nn,k1m,k1n): regrid the layer interfaces and remap T, S, tracers, u, v
- * (first piece: vcoord_type = 'plevel' and 'cntiso_hybrid' with regrid_method 'direct' or 'nudge'; neutral
- * diffusion fails loudly).  Options: blomgpu_set_str "vcoord_type", "ale_reconstruction_method", "ale_regrid_method",
+ * (vcoord_type = 'plevel' and 'cntiso_hybrid' with regrid_method 'direct' or 'nudge'); with blomgpu_set_int
+ * "ltedtp_opt" = 2 (ltedtp = 'neutral', phy/mod_diffusion.F90:123-124) also the neutral diffusion of phy/mod_ndiff.F90 between
+ * regridding and remapping (option "ndiff_surface_align"; reads difiso, dpml, pu, pv; adds to utflx .. vsflx, sets utflld ..,
+ * nslpx, nslpy; single tile).  PARITY: cross-checked against the real modules (mod_ale_regrid_remap behind the mod_dia stand-in,
+ * mod_ndiff as it is), tests/test_xcheck_ale.py.  Options: blomgpu_set_str "vcoord_type", "ale_reconstruction_method", "ale_regrid_method",
  * "ale_tracer_limiting", "ale_velocity_limiting"; blomgpu_set_int "ale_upper_bndr_ord", "ale_lower_bndr_ord", "ale_k_range_plevel",
  * "ale_dktzu", "ale_dktzl", "ale_{density,tracer,velocity}_pc_{upper,lower}_bndr"; blomgpu_set_real "ale_dpmin_interior" [m],
  * "ale_regrid_nudge_ts", "ale_stab_fac_limit", "ale_dpvar_fac", "ale_smooth_diff_max" -- the variables of &ALE_REGRID_REMAP
