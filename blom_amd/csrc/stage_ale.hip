@@ -865,7 +865,6 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   // the j-slice offsets of :1559-1569: neutral diffusion reads the regridded columns one ring beyond the tile, the lateral
   // smoothing those one ring beyond the cells it smooths
   const int jofs2 = ndiff ? 1 : 0, ring = jofs2 + (smooth ? 1 : 0);
-  if (ndiff && c->tiling.multi()) return ctx_fail(c, "ale_regrid_remap: neutral diffusion on a decomposed domain is not built");
   if (ring) {                                                          // :1603-1607
     if (int rc2 = st_xctilr(c, h.f[F_temp] + (size_t)(k1n - 1) * np, 1, h.kk, ring, ring, 1)) return rc2;
     if (int rc2 = st_xctilr(c, h.f[F_saln] + (size_t)(k1n - 1) * np, 1, h.kk, ring, ring, 1)) return rc2;

@@ -146,7 +146,7 @@ int  blomgpu_mxlayr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k
  * (vcoord_type = 'plevel' and 'cntiso_hybrid' with regrid_method 'direct' or 'nudge'); with blomgpu_set_int
  * "ltedtp_opt" = 2 (ltedtp = 'neutral', phy/mod_diffusion.F90:123-124) also the neutral diffusion of phy/mod_ndiff.F90 between
  * regridding and remapping (option "ndiff_surface_align"; reads difiso, dpml, pu, pv; adds to utflx .. vsflx, sets utflld ..,
- * nslpx, nslpy; single tile).  PARITY: cross-checked against the real modules (mod_ale_regrid_remap behind the mod_dia stand-in,
+ * nslpx, nslpy).  PARITY: cross-checked against the real modules (mod_ale_regrid_remap behind the mod_dia stand-in,
  * mod_ndiff as it is), tests/test_xcheck_ale.py.  Options: blomgpu_set_str "vcoord_type", "ale_reconstruction_method", "ale_regrid_method",
  * "ale_tracer_limiting", "ale_velocity_limiting"; blomgpu_set_int "ale_upper_bndr_ord", "ale_lower_bndr_ord", "ale_k_range_plevel",
  * "ale_dktzu", "ale_dktzl", "ale_{density,tracer,velocity}_pc_{upper,lower}_bndr"; blomgpu_set_real "ale_dpmin_interior" [m],

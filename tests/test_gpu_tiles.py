@@ -155,10 +155,14 @@ def test_cppm_on_tiles_matches_single_tile(cfg, npx, npy):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("cfg,npx,npy,vcoord,method", [("chan_s", 2, 2, "cntiso_hybrid", "nudge"), ("box_s", 2, 2, "cntiso_hybrid", "direct"),
-                                                        ("tri_s", 2, 2, "cntiso_hybrid", "nudge"), ("tri_s", 4, 2, "plevel", "direct"),
-                                                        ("chan_s", 2, 1, "plevel", "nudge")])
-def test_ale_regrid_remap_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method):
+@pytest.mark.parametrize("cfg,npx,npy,vcoord,method,neutral", [
+    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", 0), ("box_s", 2, 2, "cntiso_hybrid", "direct", 0), ("tri_s", 2, 2, "cntiso_hybrid", "nudge", 0),
+    ("tri_s", 4, 2, "plevel", "direct", 0), ("chan_s", 2, 1, "plevel", "nudge", 0),
+    # ltedtp = 'neutral': the regridding covers two rings beyond the tile (neutral diffusion + lateral smoothing), the searches
+    # of the faces on the tile's edge read the neighbour's columns from the halo
+    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", 1), ("box_s", 2, 2, "cntiso_hybrid", "direct", 1), ("tri_s", 2, 2, "cntiso_hybrid", "nudge", 1),
+    ("tri_s", 4, 2, "plevel", "direct", 1)])
+def test_ale_regrid_remap_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method, neutral):
     """ale_regrid_remap (phy/mod_ale_regrid_remap.F90:1486) on a decomposed domain: every tile has its own engine structures; the
     lateral smoothing of regrid_method = 'nudge' regrids one ring of columns beyond the tile from halo data and the stage's own
     halo updates go through the tile transport.  After a few steps of the isopycnic sequence: interiors as on the single tile."""
@@ -185,10 +189,18 @@ def test_ale_regrid_remap_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, me
     plevel = 0.4 * pbot * (np.arange(kk) / kk) ** 1.3
     six = hostinit_step_indices(nsteps, kk)
 
+    dpml = 9806.0 * (20.0 + 60.0 * np.linspace(0.0, 1.0, case.jdm + 8)[:, None] * np.ones((1, case.idm + 8)))[None]
+    if neutral:
+        ref.put("dpml", dpml)
+        scatter_state(ref, tiles, case, npx, npy, ["dpml"])
+
     def ale(g):
         g.set("vcoord_type", vcoord)
         g.set("ale_regrid_method", method)
         g.set_vector("plevel", plevel)
+        if neutral:
+            g.set("ltedtp_opt", 2)
+            g.set("ndiff_surface_align", 1)
         g.stage("ale_regrid_remap", *six)
     ale(ref)
     errs = []
@@ -205,7 +217,8 @@ def test_ale_regrid_remap_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, me
     [x.join(timeout=300) for x in th]
     assert not errs, errs
     bad = []
-    for nm in ["dp", "temp", "saln", "sigma", "trc", "u", "v", "dpu", "dpv", "p", "pu", "pv"]:
+    for nm in ["dp", "temp", "saln", "sigma", "trc", "u", "v", "dpu", "dpv", "p", "pu", "pv"] + \
+            (["utflld", "usflld", "vtflld", "vsflld", "utflx", "usflx", "vtflx", "vsflx", "nslpx", "nslpy"] if neutral else []):
         a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
         b = gather_interior(tiles, case, npx, npy, nm)
         if not np.array_equal(a, b):
@@ -250,10 +263,13 @@ def hybrid_inputs(case, seed=11):
     return f
 
 
-@pytest.mark.parametrize("cfg,npx,npy,vcoord,method,advmth", [
-    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("box_s", 2, 2, "cntiso_hybrid", "direct", "cppm"),
-    ("tri_s", 2, 2, "cntiso_hybrid", "nudge", "remap"), ("tri_s", 4, 2, "plevel", "direct", "cppm"), ("chan_s", 1, 2, "plevel", "nudge", "remap")])
-def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method, advmth):
+@pytest.mark.parametrize("cfg,npx,npy,vcoord,method,advmth,neutral", [
+    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", "remap", 0), ("box_s", 2, 2, "cntiso_hybrid", "direct", "cppm", 0),
+    ("tri_s", 2, 2, "cntiso_hybrid", "nudge", "remap", 0), ("tri_s", 4, 2, "plevel", "direct", "cppm", 0), ("chan_s", 1, 2, "plevel", "nudge", "remap", 0),
+    # with ltedtp = 'neutral' (neutral diffusion inside ale_regrid_remap, its slopes through cmnfld_nnslope_ale into eddtra_ale)
+    ("chan_s", 2, 2, "cntiso_hybrid", "nudge", "remap", 1), ("tri_s", 2, 2, "cntiso_hybrid", "nudge", "remap", 1),
+    ("box_s", 2, 2, "cntiso_hybrid", "direct", "cppm", 1)])
+def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method, advmth, neutral):
     """The step of the hybrid vertical coordinate (ale_regrid_remap, cmnfld2's hybrid branches, eddtra_ale, advect,
     .., ale_forcing, ale_vdifft/m, .., cmnfld1) on a decomposed domain: every halo update of the new stages -- the ring of the
     lateral smoothing, the bounded mixed layer depth and the mixed layer density of eddtra_ale, the viscosity of ale_vdiffm, the
@@ -297,6 +313,8 @@ def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method,
         g.set("swamxd", 200.0)
         g.set("brine_mlbase_frac", 0.4)
         g.set_vector("plevel", plevel)
+        g.set("ltedtp_opt", 2 if neutral else 1)
+        g.set("ndiff_surface_align", 1)
         if advmth == "cppm":
             g.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
         g.stage("cmnfld1", *six0)
@@ -315,7 +333,8 @@ def test_hybrid_step_on_tiles_matches_single_tile(cfg, npx, npy, vcoord, method,
     [x.join(timeout=300) for x in th]
     assert not errs, errs
     bad = []
-    for nm in CHECK + ["umfltd", "vmfltd", "umflsm", "vmflsm", "hml_tf", "mld", "bfsqi", "nslpx", "nslpy", "salt_corr", "buoyfl"]:
+    for nm in CHECK + ["umfltd", "vmfltd", "umflsm", "vmflsm", "hml_tf", "mld", "bfsqi", "nslpx", "nslpy", "salt_corr", "buoyfl"] + \
+            (["nnslpx", "nnslpy", "utflld", "vtflld"] if neutral else []):
         a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
         b = gather_interior(tiles, case, npx, npy, nm)
         wet = np.isfinite(a) & (np.abs(a) < 1e30)

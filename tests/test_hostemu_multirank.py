@@ -63,6 +63,9 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid
             g.set("swamxd", 200.0)
             g.set("brine_mlbase_frac", 0.4)
             g.set_vector("plevel", plevel)
+            if len(hybrid) > 2 and hybrid[2]:                 # ltedtp = 'neutral': neutral diffusion inside ale_regrid_remap
+                g.set("ltedtp_opt", 2)
+                g.set("ndiff_surface_align", 1)
             g.stage("cmnfld1", *step_indices(0, kk))
     uid = rccl_unique_id()
     tiles, errs, crcs = {}, [], {}
@@ -153,6 +156,14 @@ def test_rccl_ranks_with_the_hybrid_step(emu_lib, cfg, isizes, jsizes, vcoord, m
     """the step of the hybrid vertical coordinate (ale_regrid_remap with its smoothing ring, eddtra_ale, ale_vdiffm's viscosity
     halo, the hybrid branches of cmnfld) through the RCCL transport, tripolar grids included"""
     _run_case(cfg, isizes, jsizes, cppm=cppm, hybrid=(vcoord, method))
+
+
+@pytest.mark.parametrize("cfg,isizes,jsizes,method", [("chan_s", (10, 10), (13, 11), "nudge"), ("tri_s", (12, 12), (11, 9), "nudge"),
+                                                      ("box_s", (12, 12), (11, 9), "direct")])
+def test_rccl_ranks_with_neutral_diffusion(emu_lib, cfg, isizes, jsizes, method):
+    """the hybrid step with ltedtp = 'neutral' through the RCCL transport: the regridding two rings beyond the tile, the face
+    searches on the tile's edge, the slopes' halo update of cmnfld_nnslope_ale"""
+    _run_case(cfg, isizes, jsizes, hybrid=("cntiso_hybrid", method, True))
 
 
 @pytest.mark.parametrize("cfg,isizes,jsizes", [
