@@ -37,7 +37,7 @@ run("tri_s", advmth="cppm")
 run("chan_m", steps=2, barotp_fused=0)
 run("tri_m", steps=2)
 # the step of the hybrid vertical coordinate (ale_regrid_remap with both coordinates and regrid methods, ale_forcing, ale_vdifft/m ..)
-def hybrid(cfg, vcoord, method, advmth="remap", steps=3, ntr=None):
+def hybrid(cfg, vcoord, method, advmth="remap", steps=3, ntr=None, neutral=False):
     case = make_case(cfg, advmth=advmth, ntr=ntr)
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
@@ -56,13 +56,16 @@ def hybrid(cfg, vcoord, method, advmth="remap", steps=3, ntr=None):
     gpu.set("ale_regrid_method", method)
     gpu.set("mlrmth", "fox08")
     gpu.set_vector("plevel", 0.3 * pbot * (np.arange(kk) / kk) ** 1.3)
+    if neutral:                                         # neutral diffusion inside ale_regrid_remap (stage_ndiff.hip)
+        gpu.set("ltedtp_opt", 2)
+        gpu.set("ndiff_surface_align", 1)
     if advmth == "cppm":
         gpu.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
     gpu.stage("cmnfld1", *hostinit.init_indices(0, kk))
     ns = gpu.step(0, steps)
     u = gpu.get("u")[:, 4:-4, 4:-4]
     assert np.isfinite(u[np.broadcast_to((iu[4:-4, 4:-4] > 0)[None], u.shape)]).all()
-    print(cfg, vcoord, method, advmth, ntr, "hybrid step ok", ns, flush=True)
+    print(cfg, vcoord, method, advmth, ntr, "neutral" if neutral else "layer", "hybrid step ok", ns, flush=True)
     gpu.close()
 hybrid("chan_s", "cntiso_hybrid", "nudge")
 hybrid("tri_s", "cntiso_hybrid", "direct")
@@ -70,6 +73,30 @@ hybrid("box_s", "plevel", "direct", advmth="cppm")
 hybrid("fuk95", "plevel", "nudge", advmth="cppm", steps=2)
 hybrid("chan_s_tke", "cntiso_hybrid", "nudge", ntr=9)            # further passes of the fused vdifft kernel, two engine batches
 hybrid("tri_s_tke", "cntiso_hybrid", "direct", ntr=6)
+hybrid("chan_s", "cntiso_hybrid", "nudge", neutral=True)
+hybrid("tri_s", "cntiso_hybrid", "nudge", neutral=True)
+hybrid("box_s", "plevel", "direct", advmth="cppm", neutral=True)
+hybrid("chan_s_tke", "cntiso_hybrid", "nudge", ntr=9, neutral=True)   # two engine batches of coefficients, nine fluxes per record
+# config 2's step as far as built: thermf, mxlayr, the front of difest_isobml, cmnfld1 (full_physics)
+def full(cfg, steps=4, ntr=None):
+    case = make_case(cfg, ntr=ntr)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    hostinit.init_forcing(gpu, case)
+    nj, ni = case.jdm + 8, case.idm + 8
+    y = np.linspace(-1.0, 1.0, nj)[:, None] + 0.0 * np.arange(ni)[None, :]
+    gpu.put("nsf", (300.0 * y)[None])
+    gpu.put("swa", (120.0 * (y > -0.5))[None])
+    gpu.put("eva", (-2e-5 * np.ones((nj, ni)))[None])
+    gpu.set("full_physics", 1)
+    ns = gpu.step(0, steps)
+    assert np.isfinite(gpu.get("u")[:, 4:-4, 4:-4]).all()
+    print(cfg, ntr, "full physics ok", ns, flush=True)
+    gpu.close()
+full("chan_s_tke")
+full("tri_s_tke")
+full("box_s", ntr=5)
 import test_hostemu_multirank as t
 for cfg, isz, jsz in (("chan_s", (7, 7, 6), (13, 11)), ("tri_s_tke", (6, 6, 6, 6), (10, 10))):
     for g in (True, False):
