@@ -92,16 +92,16 @@ int ctx_check_errors(blomgpu_ctx *c) {
   if (c->ale && c->h.P.vcoord_tag != 1)
     if (int rc = ale_check_deferred(c)) return rc;
   if (!c->err_dev) return 0;
-  int e[4] = {0, 0, 0, 0};
+  int e[5] = {0, 0, 0, 0, 0};          // (word 3: convec's iteration limit, which the reference only prints: not an error)
   HIPCHK(c, hipMemcpyAsync(e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // the words are only ever set by a failing kernel (zeroed at allocation): clear them once reported
-  if (e[0] || e[1] || e[2] || e[3]) HIPCHK(c, hipMemsetAsync(c->err_dev, 0, sizeof(int) * 8, c->stream));
+  if (e[0] || e[1] || e[2] || e[4]) HIPCHK(c, hipMemsetAsync(c->err_dev, 0, sizeof(int) * 8, c->stream));
   if (e[0] & 2) return ctx_fail(c, "blom: diapfl: no convergence in implicit diffusion!");        // mod_diapfl.F90:520-530
   if (e[0] & 1) return ctx_fail(c, "blom: diapfl: no convergence in flux limit!");
   if (e[1] & 1) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: no convergence");              // mod_eddtra.F90:536-555
   if (e[1] & 2) return ctx_fail(c, "blom: eddtra_gm_isopyc_bulkml: flux bound violated");          // mod_eddtra.F90:640-660
-  if (e[3]) return ctx_fail(c, "ndiff: a face found more neutral layers than its record space holds");
+  if (e[4]) return ctx_fail(c, "ndiff: a face found more neutral layers than its record space holds");
   if (e[2]) return ctx_fail(c, "barotp: a tile of the persistent substep kernel timed out waiting for its neighbours");
   return 0;
 }
