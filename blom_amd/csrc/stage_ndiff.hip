@@ -698,6 +698,7 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
 // the fluxes of a face's records, :860-913.  The records do not depend on each other: blockIdx.y strides over them; heat and
 // salt share one sign test, every tracer has its own.  A withheld flux is a NaN in the record.
 #define ND_EVAL_RY 16
+#define ND_RB 8            // records loaded ahead by the kernels that walk a face's records in order
 __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ Vp, NdArgs A) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -761,30 +762,40 @@ __global__ __launch_bounds__(64) void k_ndiff_uvflx(const DevView *__restrict__ 
   // the sums of the layer kuv stay in registers until kuv moves on
   size_t ok = cp + (size_t)(kuv - 1 + mm) * np;
   double atl = ftl[ok], asl = fsl[ok], atx = ftx[ok], asx = fsx[ok], pk = puv[cp], pk1 = puv[cp + np];
-  for (int r = 0; r < n; r++) {
-    const double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
-    const double tflx = rf[0], sflx = rf[nf];
-    if (!(tflx == tflx)) continue;
-    const double *rg = A.rec_g + face + (size_t)r * 7 * nf;
-    const double p_ni_up = rg[5 * nf], p_ni_lo = rg[6 * nf];
-    const double dp_ni_i = 1. / fmax2(ND_EPSILP, p_ni_lo - p_ni_up);
-    while (kuv <= kk) {
-      if (pk1 < p_ni_lo) {
-        const double mlfrac = fmax2(0., pk1 - fmax2(p_ni_up, pk)) * dp_ni_i;
-        atl = atl + tflx * mlfrac; asl = asl + sflx * mlfrac;
-        atx = atx + tflx * mlfrac; asx = asx + sflx * mlfrac;
-        ftl[ok] = atl; fsl[ok] = asl; ftx[ok] = atx; fsx[ok] = asx;
-        kuv = kuv + 1;
-        if (kuv <= kk) {
-          ok = cp + (size_t)(kuv - 1 + mm) * np;
-          atl = ftl[ok]; asl = fsl[ok]; atx = ftx[ok]; asx = fsx[ok];
-          pk = pk1; pk1 = puv[cp + (size_t)kuv * np];
+  for (int r0 = 0; r0 < n; r0 += ND_RB) {
+    double tf[ND_RB], sf[ND_RB], pup[ND_RB], plo[ND_RB];
+#pragma unroll
+    for (int u = 0; u < ND_RB; u++) {
+      const int r = r0 + u < n ? r0 + u : n - 1;
+      const double *rf = A.rec_f + face + (size_t)r * ntr_loc * nf;
+      const double *rg = A.rec_g + face + (size_t)r * 7 * nf;
+      tf[u] = rf[0]; sf[u] = rf[nf]; pup[u] = rg[5 * nf]; plo[u] = rg[6 * nf];
+    }
+#pragma unroll
+    for (int u = 0; u < ND_RB; u++) {
+      if (r0 + u >= n) break;
+      const double tflx = tf[u], sflx = sf[u];
+      if (!(tflx == tflx)) continue;
+      const double p_ni_up = pup[u], p_ni_lo = plo[u];
+      const double dp_ni_i = 1. / fmax2(ND_EPSILP, p_ni_lo - p_ni_up);
+      while (kuv <= kk) {
+        if (pk1 < p_ni_lo) {
+          const double mlfrac = fmax2(0., pk1 - fmax2(p_ni_up, pk)) * dp_ni_i;
+          atl = atl + tflx * mlfrac; asl = asl + sflx * mlfrac;
+          atx = atx + tflx * mlfrac; asx = asx + sflx * mlfrac;
+          ftl[ok] = atl; fsl[ok] = asl; ftx[ok] = atx; fsx[ok] = asx;
+          kuv = kuv + 1;
+          if (kuv <= kk) {
+            ok = cp + (size_t)(kuv - 1 + mm) * np;
+            atl = ftl[ok]; asl = fsl[ok]; atx = ftx[ok]; asx = fsx[ok];
+            pk = pk1; pk1 = puv[cp + (size_t)kuv * np];
+          }
+        } else {
+          const double mlfrac = (p_ni_lo - fmax2(p_ni_up, pk)) * dp_ni_i;
+          atl = atl + tflx * mlfrac; asl = asl + sflx * mlfrac;
+          atx = atx + tflx * mlfrac; asx = asx + sflx * mlfrac;
+          break;
         }
-      } else {
-        const double mlfrac = (p_ni_lo - fmax2(p_ni_up, pk)) * dp_ni_i;
-        atl = atl + tflx * mlfrac; asl = asl + sflx * mlfrac;
-        atx = atx + tflx * mlfrac; asx = asx + sflx * mlfrac;
-        break;
       }
     }
   }
@@ -812,16 +823,27 @@ __global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ 
     double acc = 0.;
     const int *rk = A.rec_k + face;
     const double *rf = A.rec_f + face + (size_t)nt * nf;
-    for (int r = 0; r < n; r++) {
-      const int kdd = rk[(size_t)r * nf];
-      const double v = rf[(size_t)r * ntr_loc * nf];
-      const int kd = plus ? (kdd >> 16) : (kdd & 0xffff);
-      if (kd != cur) {
-        if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
-        cur = kd;
-        acc = fl[(size_t)(cur - 1) * ntr_loc * np];
+    for (int r0 = 0; r0 < n; r0 += ND_RB) {                      // the records of a batch are loaded together
+      int kdds[ND_RB];
+      double vs[ND_RB];
+#pragma unroll
+      for (int u = 0; u < ND_RB; u++) {
+        const int r = r0 + u < n ? r0 + u : n - 1;
+        kdds[u] = rk[(size_t)r * nf];
+        vs[u] = rf[(size_t)r * ntr_loc * nf];
       }
-      if (v == v) acc = plus ? acc - v : acc + v;
+#pragma unroll
+      for (int u = 0; u < ND_RB; u++) {
+        if (r0 + u >= n) break;
+        const int kd = plus ? (kdds[u] >> 16) : (kdds[u] & 0xffff);
+        const double v = vs[u];
+        if (kd != cur) {
+          if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
+          cur = kd;
+          acc = fl[(size_t)(cur - 1) * ntr_loc * np];
+        }
+        if (v == v) acc = plus ? acc - v : acc + v;
+      }
     }
     if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
   }
