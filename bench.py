@@ -706,6 +706,8 @@ def main():
     from blom_amd import hostinit
     case, nreg, masks = build_case(args.config, args.advmth, args.tracers)
     layout = None
+    full_req = args.physics == "full" and not args.rccl_self and args.slopes == "live"
+    tile_area = None
     if (world > 1 and scaling == "strong") or args.tiles:       # --tiles 1x1 at N = 1: the same code path with one rank
         # BASELINE.json configs 3/4: the same domain, npx x npy tiles (bld/blom_dimensions:104-148), one per GPU.
         from blom_amd.tiles import TileLayout, scatter_to_tile
@@ -724,6 +726,10 @@ def main():
         # keeps its window of every field and frees the rest: 10 of 288 GB for a moment
         whole = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
         hostinit.init_state(whole, case)
+        if full_req and args.barotp == "replicated":
+            # config 2's step on tiles (config 3): thermf's global sums are formed on the replicated solve's global context
+            hostinit.init_forcing(whole, case)
+            tile_area = hostinit.ocean_area(whole, case)
         gpu = BlomGpu(tii, tjj, case.kdm, case.ntr, nreg, {k: layout.window(masks[k], px, py) for k in masks}, device=local,
                       itdm=case.idm, jtdm=case.jdm, i0=i0, j0=j0)
         for nm, v in case.params.items():
@@ -758,10 +764,15 @@ def main():
     if layout is None:
         hostinit.init_state(gpu, case)
     gpu.set("live_slopes", 1 if args.slopes == "live" else 0)
-    full = args.physics == "full" and world == 1 and layout is None and not args.rccl_self and args.slopes == "live"
+    # config 2's step as far as built: on one tile, and on tiles that carry the replicated barotropic solve's global context
+    # (thermf's sums); the weak-scaling layout and --barotp decomposed run the dynamical-core sequence
+    full = full_req and ((world == 1 and layout is None) or tile_area is not None)
     if full:
         # the channel experiment's own forcing (channel/mod_channel.F90:365-394): zero fluxes, open-water friction velocity
-        hostinit.init_forcing(gpu, case)
+        if layout is None:
+            hostinit.init_forcing(gpu, case)
+        else:
+            gpu.set("area", tile_area)                     # (the fields came with the window of the whole domain)
         gpu.set("full_physics", 1)
     for o in args.opt:
         nm, v = o.split("=")

@@ -367,6 +367,44 @@ int rccl_barotp_replicated(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m
   return 0;
 }
 
+// xcsum over RCCL ranks: the plane travels to every rank the way the barotropic solver's fields do (one grouped send/recv
+// into the global context G of the replicated solve), and every rank forms the single tile's sum on G -- the reference's
+// summation order is that of the global domain whatever the tiling (phy/mod_xc.F90:1663-1708, :2071-2192)
+int st_xcsum_dev(blomgpu_ctx *c, const double *a, int itype, int slot, double **sums_dev);
+int rccl_xcsum_dev(blomgpu_ctx *c, const double *a, int itype, int slot) {
+  BtGlobal *B = c->bt_global;
+  if (!B) return ctx_fail(c, "xcsum on RCCL tiles needs the global context of the replicated barotropic solve (blomgpu_rccl_attach_barotp_global)");
+  blomgpu_ctx *G = B->G;
+  RcclComm *R = c->tiling.rccl;
+  const DevView &h = c->h;
+  hipStream_t st = c->stream;
+  size_t off = 0;
+  const int fid = ctx_locate_ptr(c, a, &off);
+  if (fid < 0 || fid >= NF_REAL || off % h.nplane) return ctx_fail(c, "xcsum: pointer is not a plane of a registered field");
+  const size_t lev = off / h.nplane;
+  if ((int)lev >= G->nlev_real[fid]) return ctx_fail(c, "xcsum: the global context does not hold this level");
+  ctx_sync_view(G);
+  BtPlanes PT, PG;
+  for (int x = 0; x < BT_MAXPLANES; x++) { PT.p[x] = const_cast<double *>(a); PG.p[x] = G->h.f[fid] + lev * G->h.nplane; }
+  const int me = R->rank, nr = R->nranks, npts = h.nplane;
+  hipLaunchKernelGGL(k_btg_pack, dim3((npts + 255) / 256, 1), dim3(256), 0, st, c->d, PT, B->buf + B->off[me]);
+  if (nr > 1) {
+    ncclGroupStart();
+    for (int q = 0; q < nr; q++)
+      if (q != me) ncclSend(B->buf + B->off[me], (size_t)npts, ncclDouble, q, R->comm, st);
+    for (int q = 0; q < nr; q++)
+      if (q != me) ncclRecv(B->buf + B->off[q], (size_t)(B->ii[q] + 2 * NBDY) * (B->jj[q] + 2 * NBDY), ncclDouble, q, R->comm, st);
+    ncclResult_t rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL xcsum gather: ") + ncclGetErrorString(rc));
+  }
+  hipLaunchKernelGGL(k_btg_unpack, dim3((B->maxpts + 255) / 256, 1, nr), dim3(256), 0, st, G->d, PG, B->buf, B->geo_dev,
+                     (const size_t *)(B->geo_dev + 4 * nr + (4 * nr) % 2));
+  double *gs = nullptr;
+  if (int rc = st_xcsum_dev(G, G->h.f[fid] + lev * G->h.nplane, itype, slot, &gs)) { c->err = G->err; return rc; }
+  HIPCHK(c, hipMemcpyAsync(c->xcsum_dev + slot, gs + slot, sizeof(double), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 int rccl_xctilr(blomgpu_ctx *c, double *a, int nlev, int mhl, int nhl) {
   return rccl_xctilr_multi(c, &a, 1, nlev, mhl, nhl);
 }

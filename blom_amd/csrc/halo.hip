@@ -822,25 +822,103 @@ __global__ __launch_bounds__(256) void k_xcsum_total(const double *__restrict__ 
   }
 }
 
+// Tiles of one process: every tile forms the sum of the WHOLE domain itself, reading each point from the tile that owns it --
+// the strips, their order and the order of the rows are those of the global domain (phy/mod_xc.F90:1663-1708: a strip belongs to
+// the tile that owns its centre, so the strip sums do not depend on the tiling), hence the single tile's bits on every tile.
+struct XcsTab {
+  const double *a[XCT_MAXTILES];
+  const int *m[XCT_MAXTILES];
+  int ni[XCT_MAXTILES];
+  int xoff[XCT_MAXDIM + 1], yoff[XCT_MAXDIM + 1];
+};
+__global__ __launch_bounds__(64) void k_xcsum_rows_tiles(XcsTab tab, int npx, int npy, int itdm, int jtdm, int skip_seam, double *__restrict__ rowsum) {
+  __shared__ double strip[64];
+  const int j = blockIdx.x + 1, W = 2 * NBDY + 1;
+  const bool dead = skip_seam && j >= jtdm;
+  int py = 0;
+  while (py + 1 < npy && j > tab.yoff[py + 1]) py++;
+  const int nstrip = (itdm + W - 1) / W;
+  double sum8 = 0.;
+  for (int s0 = 0; s0 < nstrip; s0 += 64) {
+    const int sidx = s0 + (int)threadIdx.x;
+    double sum8p = 0.;
+    if (sidx < nstrip) {
+      const int i1 = 1 + sidx * W, ie = i1 + 2 * NBDY < itdm ? i1 + 2 * NBDY : itdm;
+      int px = 0;
+      for (int i = i1; i <= ie; i++) {
+        while (px + 1 < npx && i > tab.xoff[px + 1]) px++;
+        const int q = py * npx + px;
+        const size_t x = (size_t)(j - tab.yoff[py] + NBDY - 1) * tab.ni[q] + (size_t)(i - tab.xoff[px] + NBDY - 1);
+        if (!dead && tab.m[q][x] == 1) sum8p = sum8p + tab.a[q][x];
+      }
+    }
+    strip[threadIdx.x] = sum8p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int n = nstrip - s0 < 64 ? nstrip - s0 : 64;
+      for (int q = 0; q < n; q++) sum8 = sum8 + strip[q];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowsum[j - 1] = sum8;
+}
+
+int rccl_xcsum_dev(blomgpu_ctx *c, const double *a, int itype, int slot);      // comm_rccl.hip
+
+static int xcsum_group(blomgpu_ctx *c, const double *a, int itype, int slot) {
+  const DevView &h = c->h;
+  const Tiling &T = c->tiling;
+  TileGroup *G = T.group;
+  if (T.npx * T.npy > XCT_MAXTILES || T.npx > XCT_MAXDIM || T.npy > XCT_MAXDIM) return ctx_fail(c, "xcsum: too many tiles for the in-process gather");
+  size_t off = 0;
+  const int fid = ctx_locate_ptr(c, a, &off);
+  if (fid < 0 || off % h.nplane) return ctx_fail(c, "xcsum: pointer is not a plane of a registered field");
+  const size_t lev = off / h.nplane;
+  const int g = itype % 10, mid = g == 1 ? I_ip : g == 2 ? I_iq : g == 3 ? I_iu : I_iv;
+  XcsTab tab;
+  for (int q = 0; q < XCT_MAXTILES; q++) {
+    if (q >= T.npx * T.npy) { tab.a[q] = nullptr; tab.m[q] = nullptr; tab.ni[q] = 0; continue; }
+    const blomgpu_ctx *o = G->tiles[(size_t)q];
+    tab.a[q] = located_base(o, fid) + lev * o->h.nplane;
+    tab.m[q] = o->h.m[mid];
+    tab.ni[q] = o->h.ni;
+  }
+  for (int q = 0; q <= XCT_MAXDIM; q++) tab.xoff[q] = tab.yoff[q] = 0;
+  for (int q = 0; q < T.npx; q++) { const DevView &o = G->tiles[(size_t)q]->h; tab.xoff[q] = o.i0; tab.xoff[q + 1] = o.i0 + o.ii; }
+  for (int q = 0; q < T.npy; q++) { const DevView &o = G->tiles[(size_t)q * T.npx]->h; tab.yoff[q] = o.j0; tab.yoff[q + 1] = o.j0 + o.jj; }
+  if (tab.xoff[T.npx] != h.itdm || tab.yoff[T.npy] != h.jtdm) return ctx_fail(c, "xcsum: the tiles of the group do not cover the global domain");
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // every tile's interior must be complete before anyone reads it
+  pthread_barrier_wait(&G->bar);
+  hipLaunchKernelGGL(k_xcsum_rows_tiles, dim3(h.jtdm), dim3(64), 0, c->stream, tab, T.npx, T.npy, h.itdm, h.jtdm, (g == 1 && h.nreg == 2) ? 1 : 0,
+                     c->xcsum_buf + 1);
+  hipLaunchKernelGGL(k_xcsum_total, dim3(1), dim3(256), sizeof(double) * (size_t)h.jtdm, c->stream, c->xcsum_buf + 1, h.jtdm, c->xcsum_dev + slot);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // ... and nobody may go on modifying its interior before all have read
+  pthread_barrier_wait(&G->bar);
+  return 0;
+}
+
 // the sum left on the device (slot of c->xcsum_dev): stages that only hand it to their next kernel stay capturable
 int st_xcsum_dev(blomgpu_ctx *c, const double *a, int itype, int slot, double **sums_dev) {
   const DevView &h = c->h;
-  if (c->tiling.multi()) return ctx_fail(c, "xcsum: built for a single tile");
-  if (!c->xcsum_buf) HIPCHK(c, hipMalloc((void **)&c->xcsum_buf, sizeof(double) * (size_t)(h.jj + 8)));
+  if (!c->xcsum_buf) HIPCHK(c, hipMalloc((void **)&c->xcsum_buf, sizeof(double) * (size_t)(h.jtdm + 8)));
   if (!c->xcsum_dev) HIPCHK(c, hipMalloc((void **)&c->xcsum_dev, sizeof(double) * 8));
+  *sums_dev = c->xcsum_dev;
+  if (c->tiling.rccl) return rccl_xcsum_dev(c, a, itype, slot);
+  if (c->tiling.group) return xcsum_group(c, a, itype, slot);
+  if (h.itdm != h.ii || h.jtdm != h.jj) return ctx_fail(c, "xcsum: this context is one tile of a larger domain but no transport is attached");
   const int g = itype % 10;
   const int *mask = g == 1 ? h.m[I_ip] : g == 2 ? h.m[I_iq] : g == 3 ? h.m[I_iu] : h.m[I_iv];
   hipLaunchKernelGGL(k_xcsum_rows, dim3(h.jj), dim3(64), 0, c->stream, c->d, a, mask, (g == 1 && h.nreg == 2) ? 1 : 0, c->xcsum_buf + 1);
   hipLaunchKernelGGL(k_xcsum_total, dim3(1), dim3(256), sizeof(double) * (size_t)h.jj, c->stream, c->xcsum_buf + 1, h.jj, c->xcsum_dev + slot);
   HIPCHK(c, hipGetLastError());
-  *sums_dev = c->xcsum_dev;
   return 0;
 }
 
 int st_xcsum(blomgpu_ctx *c, const double *a, int itype, double *sum) {
   const DevView &h = c->h;
-  if (c->tiling.multi()) return ctx_fail(c, "xcsum: built for a single tile");
-  if (!c->xcsum_buf) HIPCHK(c, hipMalloc((void **)&c->xcsum_buf, sizeof(double) * (size_t)(h.jj + 8)));
+  if (c->tiling.multi()) return ctx_fail(c, "xcsum with the result on the host: built for a single tile");
+  if (!c->xcsum_buf) HIPCHK(c, hipMalloc((void **)&c->xcsum_buf, sizeof(double) * (size_t)(h.jtdm + 8)));
   const int g = itype % 10;
   const int *mask = g == 1 ? h.m[I_ip] : g == 2 ? h.m[I_iq] : g == 3 ? h.m[I_iu] : h.m[I_iv];
   hipLaunchKernelGGL(k_xcsum, dim3(1), dim3(256), 0, c->stream, c->d, a, mask, (g == 1 && h.nreg == 2) ? 1 : 0,

@@ -10,7 +10,8 @@
 //                           salinity, unit conversion
 // Not built (fail loudly): the diagnosed relaxation fluxes (aptflx, apsflx, ditflx, disflx: four 48-level arrays), the balanced
 // salinity relaxation (srxbal: needs the world ocean mask), the surface flux of the generic length scale (use_GLS: real powers).
-// Single tile (xcsum).  Roofline: HBM, ~20 two-dimensional planes.
+// On decomposed domains the two sums gather the plane (halo.hip: xcsum_group, comm_rccl.hip: rccl_xcsum_dev).
+// Roofline: HBM, ~20 two-dimensional planes.
 #include "blomgpu_internal.h"
 
 #define PLANE_IJ(V)                                                        \
@@ -135,7 +136,6 @@ int st_thermf(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     return ctx_fail(c, "thermf_channel: applying / diagnosing relaxation fluxes (aptflx, apsflx, ditflx, disflx) is not built on the device");
   if (c->srxday > EPSILT && c->srxbal) return ctx_fail(c, "thermf_channel: the balanced salinity relaxation (srxbal) is not built on the device");
   if (h.P.itrtke >= 1 && h.P.gls) return ctx_fail(c, "thermf_channel: the surface flux of the generic length scale (use_GLS) is not built on the device");
-  if (c->tiling.multi()) return ctx_fail(c, "thermf_channel: built for a single tile (xcsum)");
   ThermfPar T;
   T.trxday = c->trxday; T.srxday = c->srxday; T.trxdpt = c->trxdpt; T.srxdpt = c->srxdpt; T.trxlim = c->trxlim; T.srxlim = c->srxlim;
   T.xmi = c->xmi; T.sref = c->sref; T.area = c->area;

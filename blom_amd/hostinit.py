@@ -479,15 +479,22 @@ def init_forcing(be, case):
         for nm in ("trflx", "trc_corr"):
             if has(nm):
                 be.put(nm, np.zeros((case.ntr, nj, ni)))
-    ip = be.masks["ip"] if hasattr(be, "masks") else None
-    if ip is not None:
-        scp2 = np.asarray(be.get("scp2"))[0]
-        w = (ip[NBDY:-NBDY, NBDY:-NBDY] > 0)
-        if case.nreg == 2:
-            w = w.copy()
-            w[-1, :] = False                          # ips: without the seam row of the arctic patch
-        area = float(np.sum(scp2[NBDY:-NBDY, NBDY:-NBDY][w]))
+    area = ocean_area(be, case)
+    if area is not None:
         be.set("area", area)
+
+
+def ocean_area(be, case):
+    """mod_grid's area: the sum of scp2 over ips (ip without the seam row of an arctic patch) of the WHOLE domain `be` holds"""
+    ip = be.masks["ip"] if hasattr(be, "masks") else None
+    if ip is None:
+        return None
+    scp2 = np.asarray(be.get("scp2"))[0]
+    w = (ip[NBDY:-NBDY, NBDY:-NBDY] > 0)
+    if case.nreg == 2:
+        w = w.copy()
+        w[-1, :] = False                          # ips: without the seam row of the arctic patch
+    return float(np.sum(scp2[NBDY:-NBDY, NBDY:-NBDY][w]))
 
 
 def init_indices(nstep1, kk):

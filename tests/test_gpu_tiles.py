@@ -503,3 +503,87 @@ def test_full_size_as_eight_tiles_reproduces_the_reference_checksums(cfg, npx, n
     grp.destroy()
     assert not bad, bad[:20]
     assert checked >= 45
+
+
+FORCING = ["ustarw", "swa", "nsf", "hmltfz", "lip", "sop", "eva", "rnf", "rfi", "fmltfz", "sfl", "swfc1", "swfc2", "swal1", "swal2", "ustar", "ustar3",
+           "idkedt", "surflx", "sswflx", "surrlx", "salflx", "brnflx", "salrlx", "salt_corr", "sstclm", "ricclm", "sssclm", "uml", "vml", "umlres",
+           "vmlres", "trflx", "trc_corr"]
+
+
+@pytest.mark.parametrize("cfg,npx,npy", [("chan_s_tke", 2, 2), ("tri_s_tke", 2, 2), ("box_s", 3, 1), ("tri_s_tke", 4, 2)])
+def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy):
+    """config 2's step as far as built (blomgpu_step with full_physics: + the front of difest_isobml, thermf with its two global
+    sums, mxlayr, cmnfld1) on a decomposed domain: the sums are formed in the global domain's order from the owners' planes
+    (halo.hip: xcsum_group), mxlayr's and the difest front's halo updates go through the tile transport.  A heat flux that
+    changes sign across the domain and a fresh water flux drive entrainment and detrainment.  Interiors as on the single tile."""
+    from blom_amd.gpu import BlomGpu, TileGroup
+    from blom_amd import hostinit
+    nsteps = 4
+    case, masks, fields, ref = _single(cfg, nsteps)
+    kk = case.kdm
+    hostinit.init_forcing(ref, case)
+    nj, ni = case.jdm + 8, case.idm + 8
+    y = np.linspace(-1.0, 1.0, nj)[:, None] + 0.0 * np.arange(ni)[None, :]
+    x = np.linspace(0.0, 2 * np.pi, ni)[None, :] + 0.0 * y
+    ref.put("nsf", (300.0 * (y + 0.3 * np.sin(x)))[None])
+    ref.put("swa", (120.0 * (1.0 + np.cos(x)) * (y > -0.5))[None])
+    ref.put("eva", (-2e-5 * (1.0 + 0.5 * np.sin(2 * x)))[None])
+    ref.put("lip", (3e-5 * (y > 0.0))[None])
+    area = ref.get_real("area") if hasattr(ref, "get_real") else None
+    ii, jj = tile_extents(case, npx, npy)
+    grp = TileGroup(npx, npy)
+    tiles = {}
+    for py in range(npy):
+        for px in range(npx):
+            tm = {k: tile_window(masks[k], case, npx, npy, px, py) for k in masks}
+            t = BlomGpu(ii, jj, kk, case.ntr, case.nreg, tm, itdm=case.idm, jtdm=case.jdm, i0=px * ii, j0=py * jj)
+            for nm, v in case.params.items():
+                if not nm.endswith("0"):
+                    t.set(nm, v)
+            t.set("delt1", case.params["baclin"])
+            grp.attach(t, px, py)
+            tiles[(px, py)] = t
+    scatter_state(ref, tiles, case, npx, npy, [f for f in ALL if f in fields] + [f for f in FORCING if ref.has_field(f)])
+    # the ocean area is a global number (mod_grid: area = xcsum(scp2, ips))
+    scp2 = ref.get("scp2")[0][4:-4, 4:-4]
+    w = masks["ip"][4:-4, 4:-4] > 0
+    if case.nreg == 2:
+        w = w.copy()
+        w[-1, :] = False
+    glob_area = float(np.sum(scp2[w]))
+
+    def setup(g):
+        g.set("area", glob_area)
+        g.set("niwgf", 0.4)
+        g.set("full_physics", 1)
+    setup(ref)
+    assert ref.step(0, nsteps) == nsteps
+    errs = []
+
+    def run(t):
+        try:
+            setup(t)
+            assert t.step(0, nsteps) == nsteps
+            t.sync()
+        except Exception as e:          # a failing tile would leave the others at a barrier
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(t,), daemon=True) for t in tiles.values()]
+    [x_.start() for x_ in th]
+    [x_.join(timeout=300) for x_ in th]
+    assert not errs, errs
+    bad = []
+    for nm in CHECK + ["kfpla", "surflx", "salflx", "ustar", "mtkepe", "pbrnda", "sfl", "idkedt", "uml", "nslpx"]:
+        if not ref.has_field(nm):
+            continue
+        a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]
+        b = gather_interior(tiles, case, npx, npy, nm)
+        wet = np.isfinite(a) & (np.abs(a) < 1e30)
+        if not np.array_equal(a[wet], b[wet]):
+            bad.append((nm, int((a[wet] != b[wet]).sum()), float(np.nanmax(np.abs(a[wet] - b[wet])))))
+    pe = ref.get("mtkepe")[0, 4:-4, 4:-4]
+    for t in tiles.values():
+        t.close()
+    ref.close()
+    grp.destroy()
+    assert not bad, bad
+    assert (pe[masks["ip"][4:-4, 4:-4] > 0] != 0.0).any(), "mxlayr entrained nowhere"

@@ -28,7 +28,7 @@ def emu_lib():
     g.LIB_PATH = old
 
 
-def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid=None):
+def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid=None, full=False):
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd.tiles import TileLayout, scatter_to_tile, gather_interior_layout, chain_crc, make_barotp_global
     from test_gpu_tiles import _single
@@ -67,6 +67,29 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid
                 g.set("ltedtp_opt", 2)
                 g.set("ndiff_surface_align", 1)
             g.stage("cmnfld1", *step_indices(0, kk))
+    extra_fields = []
+    if full:                                              # config 2's step as far as built (thermf's global sums, mxlayr, difest front)
+        from test_gpu_tiles import FORCING
+        from blom_amd import hostinit as hostinit_mod
+        hostinit_mod.init_forcing(ref, case)
+        nj, ni = case.jdm + 8, case.idm + 8
+        yy = np.linspace(-1.0, 1.0, nj)[:, None] + 0.0 * np.arange(ni)[None, :]
+        ref.put("nsf", (300.0 * yy)[None])
+        ref.put("swa", (120.0 * (yy > -0.5))[None])
+        ref.put("eva", (-2e-5 * np.ones((nj, ni)))[None])
+        extra_fields = [f for f in FORCING if ref.has_field(f)]
+        scp2 = ref.get("scp2")[0][4:-4, 4:-4]
+        w = masks["ip"][4:-4, 4:-4] > 0
+        if case.nreg == 2:
+            w = w.copy()
+            w[-1, :] = False
+        glob_area = float(np.sum(scp2[w]))
+        check += ["kfpla", "surflx", "ustar", "mtkepe", "sfl", "uml"]
+
+        def setup_full(g):
+            g.set("area", glob_area)
+            g.set("niwgf", 0.4)
+            g.set("full_physics", 1)
     uid = rccl_unique_id()
     tiles, errs, crcs = {}, [], {}
     crc_fields = [("dp", 1, 2 * case.kdm, 1), ("u", 1, 2 * case.kdm, 3), ("v", 1, 2 * case.kdm, 4), ("pb", 1, 2, 1)]
@@ -95,6 +118,8 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid
                 t.stage("init_cppm", 2, 1, case.kdm, 0, case.kdm + 1, 1)
             if hybrid:
                 setup_hybrid(t)
+            if full:
+                setup_full(t)
             assert t.step(0, nsteps) == nsteps
             t.sync()
             crcs[(px, py)] = {f[0]: t.crc_strips(*f) for f in crc_fields}
@@ -112,6 +137,8 @@ def _run_case(cfg, isizes, jsizes, nsteps=3, bt_global=False, cppm=False, hybrid
         ref.stage("init_cppm", 2, 1, case.kdm, 0, case.kdm + 1, 1)
     if hybrid:
         setup_hybrid(ref)
+    if full:
+        setup_full(ref)
     assert ref.step(0, nsteps) == nsteps
     bad = []
     for nm in check:
@@ -156,6 +183,13 @@ def test_rccl_ranks_with_the_hybrid_step(emu_lib, cfg, isizes, jsizes, vcoord, m
     """the step of the hybrid vertical coordinate (ale_regrid_remap with its smoothing ring, eddtra_ale, ale_vdiffm's viscosity
     halo, the hybrid branches of cmnfld) through the RCCL transport, tripolar grids included"""
     _run_case(cfg, isizes, jsizes, cppm=cppm, hybrid=(vcoord, method))
+
+
+@pytest.mark.parametrize("cfg,isizes,jsizes", [("chan_s_tke", (10, 10), (13, 11)), ("tri_s_tke", (6, 6, 6, 6), (10, 10)), ("box_s", (12, 12), (11, 9))])
+def test_rccl_ranks_with_the_full_physics_step(emu_lib, cfg, isizes, jsizes):
+    """config 2's step as far as built through the RCCL transport: thermf's two global sums travel like the barotropic solver's
+    planes and are formed on the replicated solve's global context (comm_rccl.hip: rccl_xcsum_dev); mxlayr, the difest front"""
+    _run_case(cfg, isizes, jsizes, bt_global=True, full=True)
 
 
 @pytest.mark.parametrize("cfg,isizes,jsizes,method", [("chan_s", (10, 10), (13, 11), "nudge"), ("tri_s", (12, 12), (11, 9), "nudge"),
