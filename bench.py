@@ -653,10 +653,10 @@ def main():
                     help="live: cmnfld2 computes the neutral slopes eddtra consumes every step (phy/mod_cmnfld_routines.F90:1158); "
                          "frozen: round 1's analytic pattern of amplitude NSLP0")
     ap.add_argument("--physics", default="full", choices=["full", "dyncore"],
-                    help="full (default, single tile): config 2's sequence as far as built -- cmnfld2, the built part of difest_isobml "
-                         "(ustar3, niw_ke_tendency), thermf, mxlayr, cmnfld1 besides the dynamical core (stepper.FULL_STAGES); "
-                         "dyncore: the dynamical core alone, as in rounds 1-3 (the only form on several tiles: thermf's global "
-                         "sums are single-tile)")
+                    help="full (default): config 2's sequence as far as built -- cmnfld2, the built part of difest_isobml "
+                         "(ustar3, niw_ke_tendency), thermf, mxlayr, cmnfld1 besides the dynamical core (stepper.FULL_STAGES); on tiles it "
+                         "needs --barotp replicated (thermf's global sums are formed on that solve's global context); "
+                         "dyncore: the dynamical core alone, as in rounds 1-3 (also what --barotp decomposed and the weak-scaling layout run)")
     ap.add_argument("--ltedtp", default="neutral", choices=["neutral", "layer"],
                     help="--config hybrid: lateral tracer diffusion, 'neutral' (phy/mod_ndiff.F90 inside ale_regrid_remap; the reference's "
                          "default for cntiso_hybrid) or 'layer' (diffus)")
