@@ -120,16 +120,19 @@ def test_run_length_and_error_behaviour_follow_the_reference(tmp_path, what):
         assert not steps or int(steps[-1]) == 5, steps[-3:]
 
 
-def limits_for_hybrid(dst):
+def limits_for_hybrid(dst, neutral=False):
     """the reference's fuk95 limits file as it is -- cntiso_hybrid, cppm, &ALE_REGRID_REMAP with regrid_method = 'nudge' -- but
     for the pressure gradient method (dynamic enthalpy is not built)"""
     txt = open(os.path.join(HERE, "golden", "fuk95_limits")).read()
     txt = txt.replace("PGFMTH   = 'dynamic enthalpy'", "PGFMTH   = 'geopotential'")
     assert "VCOORD_TYPE            = 'cntiso_hybrid'" in txt and "ADVMTH   = 'cppm'" in txt and "'geopotential'" in txt
+    if neutral:                                           # the reference's default for this coordinate (cime_config), not this file's
+        assert "LTEDTP   = 'layer'" in txt and "NDIFF_SURFACE_ALIGN = .false." in txt
+        txt = txt.replace("LTEDTP   = 'layer'", "LTEDTP   = 'neutral'").replace("NDIFF_SURFACE_ALIGN = .false.", "NDIFF_SURFACE_ALIGN = .true.")
     open(dst, "w").write(txt)
 
 
-def run_case_hybrid(tmp_path, exe, backend_cls, nsteps):
+def run_case_hybrid(tmp_path, exe, backend_cls, nsteps, neutral=False):
     """The hybrid-coordinate step from the Fortran host: options from the reference's own tests/fuk95/limits
     (&VCOORD, &ALE_REGRID_REMAP, the mixed layer restratification variables of &LIMITS), the pressure levels from plevel_spec =
     'inflation' (phy/mod_vcoord.F90:948-955); the fields the left-out routines would produce travel in the state file."""
@@ -158,10 +161,11 @@ def run_case_hybrid(tmp_path, exe, backend_cls, nsteps):
     bare = make_case("fuk95_ref")
     bare.params = {k: v for k, v in bare.params.items() if k in ("baclin",)}
     write_state(state, gpu, bare, 0, names)
-    limits_for_hybrid(str(tmp_path / "limits"))
+    limits_for_hybrid(str(tmp_path / "limits"), neutral)
     out = subprocess.run([exe, state, str(nsteps)], cwd=str(tmp_path), capture_output=True, text=True, timeout=3000)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "VCOORD_TYPE cntiso_hybrid" in out.stdout
+    assert ("LTEDTP neutral" if neutral else "LTEDTP layer") in out.stdout
     got = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"chksum: (\w+): 0x([0-9A-Fa-f]+)", out.stdout)}
     # the same options by hand, as the namelist file gives them
     gpu.set("delt1", case.params["baclin"])
@@ -174,6 +178,9 @@ def run_case_hybrid(tmp_path, exe, backend_cls, nsteps):
     gpu.set("mlrmth", "fox08")
     gpu.set("ce", 0.0)
     gpu.set("brine_mlbase_frac", 1.0)
+    if neutral:
+        gpu.set("ltedtp_opt", 2)
+        gpu.set("ndiff_surface_align", 1)
     six0 = hostinit.step_indices(0, kk)
     gpu.stage("init_cppm", 2, 1, kk, 0, kk + 1, 1)
     gpu.stage("cmnfld1", *six0)
@@ -187,12 +194,14 @@ def run_case_hybrid(tmp_path, exe, backend_cls, nsteps):
 
 
 @pytest.mark.skipif(not (os.path.exists(EMU) and os.path.exists(EXE)), reason="tests/hostemu not built")
-def test_reference_limits_file_drives_the_hybrid_step(tmp_path):
+@pytest.mark.parametrize("neutral", [False, True])
+def test_reference_limits_file_drives_the_hybrid_step(tmp_path, neutral):
+    """neutral: LTEDTP = 'neutral', NDIFF_SURFACE_ALIGN = .true. in &DIFFUSION -- neutral diffusion inside ale_regrid_remap"""
     import blom_amd.gpu as g
     old = g.LIB_PATH
     g.LIB_PATH = EMU
     try:
-        run_case_hybrid(tmp_path, EXE, g.BlomGpu, 4)
+        run_case_hybrid(tmp_path, EXE, g.BlomGpu, 4, neutral)
     finally:
         g.LIB_PATH = old
 

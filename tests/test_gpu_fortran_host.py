@@ -137,12 +137,14 @@ def test_namelist_file_drives_the_fortran_host_for_a_model_day(tmp_path):
     run_case(tmp_path, exe, BlomGpu, 480)
 
 
-def test_reference_limits_file_drives_the_hybrid_step_on_the_device(tmp_path):
+@pytest.mark.parametrize("neutral", [False, True])
+def test_reference_limits_file_drives_the_hybrid_step_on_the_device(tmp_path, neutral):
     """the reference's tests/fuk95/limits with its own vertical coordinate (cntiso_hybrid, cppm, &ALE_REGRID_REMAP / nudge): the
-    Fortran host takes the hybrid branch of blom_step; see tests/test_fortran_namelist_host.py"""
+    Fortran host takes the hybrid branch of blom_step; see tests/test_fortran_namelist_host.py.  neutral: with LTEDTP = 'neutral'
+    and NDIFF_SURFACE_ALIGN = .true. in &DIFFUSION (neutral diffusion inside ale_regrid_remap)"""
     from blom_amd.gpu import BlomGpu
     from test_fortran_namelist_host import run_case_hybrid
     exe = os.path.join(ROOT, "blom_amd", "lib", "blom_dyncore")
     if not os.path.exists(exe):
         pytest.skip("Fortran driver not built")
-    run_case_hybrid(tmp_path, exe, BlomGpu, 20)
+    run_case_hybrid(tmp_path, exe, BlomGpu, 20, neutral)
