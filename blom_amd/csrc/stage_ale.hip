@@ -50,6 +50,11 @@ struct AleState {
   blomgpu_h3m_map *map_uv = nullptr;
   hipStream_t side = nullptr;               // launches that do not depend on each other run beside the model's stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // neutral diffusion runs on a stream of its own beside the remapping of the tracers AND the velocity part (which then has
+  // its own scratch: plane_uv); ev_snap: the diffusion has taken its copy of pu, pv, which the velocity part overwrites
+  hipStream_t side2 = nullptr;
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_snap = nullptr;
+  double *plane_uv = nullptr;
   int *active = nullptr;                    // nplane + 2 * nplane flags: the columns the engine works on (the others are land or halo)
   double *plane = nullptr;                  // scratch: p_src, p_dst (kk+1 planes each), remapped fields (kk planes each)
   size_t plane_n = 0;
@@ -69,6 +74,11 @@ void ale_free(blomgpu_ctx *c) {
   if (a->side) (void)hipStreamDestroy(a->side);
   if (a->ev_fork) (void)hipEventDestroy(a->ev_fork);
   if (a->ev_join) (void)hipEventDestroy(a->ev_join);
+  if (a->side2) (void)hipStreamDestroy(a->side2);
+  if (a->ev_fork2) (void)hipEventDestroy(a->ev_fork2);
+  if (a->ev_join2) (void)hipEventDestroy(a->ev_join2);
+  if (a->ev_snap) (void)hipEventDestroy(a->ev_snap);
+  if (a->plane_uv) (void)hipFree(a->plane_uv);
   if (a->plane) (void)hipFree(a->plane);
   if (a->active) (void)hipFree(a->active);
   if (a->nd_tpc) (void)hipFree(a->nd_tpc);
@@ -138,7 +148,12 @@ static int ale_ndiff_buffers(blomgpu_ctx *c, AleState *a) {
   HIPCHK(c, hipMalloc((void **)&a->nd_tpc, sizeof(double) * (size_t)a->ntr_loc * npc * per));
   a->nd_npc = npc;
   if (!a->nd_col) {
-    const size_t ncol = (size_t)(8 + a->ntr_loc) * per + ndiff_scratch_planes(h.kk) * 2 * np, nrec = (size_t)6 * h.kk;
+    const size_t ncol = (size_t)(8 + a->ntr_loc) * per + ndiff_scratch_planes(h.kk) * 2 * np + (size_t)2 * (h.kk + 1) * np, nrec = (size_t)6 * h.kk;
+    HIPCHK(c, hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&a->ev_fork2, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&a->ev_snap, hipEventDisableTiming));
+    HIPCHK(c, hipMalloc((void **)&a->plane_uv, sizeof(double) * ((size_t)4 * (h.kk + 1) + (size_t)4 * h.kk) * np));
     HIPCHK(c, hipMalloc((void **)&a->nd_col, sizeof(double) * ncol));
     HIPCHK(c, hipMalloc((void **)&a->nd_ks, sizeof(int) * 2 * np));
     HIPCHK(c, hipMalloc((void **)&a->nd_rec, sizeof(double) * nrec * a->ntr_loc * 2 * np));
@@ -778,6 +793,16 @@ __global__ void k_ale_copy_back(const DevView *__restrict__ Vp, int nn, const do
   }
 }
 
+// the new layer thicknesses alone (copy_jslice_to_3d's dp, :1168), ahead of the copy-back of the tracers
+__global__ void k_ale_dp_new(const DevView *__restrict__ Vp, int nn, const double *__restrict__ pdst) {
+  const DevView &V = *Vp;
+  PLANE_T(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane;
+  const int k = blockIdx.y;
+  V.f[F_dp][c + (size_t)(k + nn) * np] = pdst[c + (size_t)(k + 1) * np] - pdst[c + (size_t)k * np];
+}
+
 // :1696-1711 pu, pv from the OLD dpu, dpv of the interior velocity points
 __global__ void k_ale_pupv(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
@@ -967,39 +992,26 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     A.scr = A.flx + (size_t)a->ntr_loc * per;
     A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_s = A.rec_k + (size_t)6 * h.kk * 2 * np; A.rec_g = a->nd_recg;
     A.rec_f = a->nd_rec; A.nrec_max = 6 * h.kk;
+    A.puv = A.scr + ndiff_scratch_planes(h.kk) * 2 * np;
     A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
-    if (int rc2 = fork()) return rc2;
-    if (int rc2 = st_ndiff_prep_flux(c, a->side, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
+    HIPCHK(c, hipEventRecord(a->ev_fork2, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(a->side2, a->ev_fork2, 0));
+    if (int rc2 = st_ndiff_prep_flux(c, a->side2, a->ev_snap, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
       return rc2;
     c->fluxes_zeroed = false;                   // utflx .. vsflx carry the diffusive fluxes now: advect must add to them
   }
   if ((rc = blomgpu_h3m_prepare_remapping(a->grid, a->map, pdst))) return ale_fail(c, "prepare_remapping", rc);
   const double *flx = ndiff ? a->nd_col + (size_t)8 * per : nullptr;
-  for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {
-    const int nf = a->ntr_loc - f0 < H3M_MAXF ? a->ntr_loc - f0 : H3M_MAXF;
-    const double *us[H3M_MAXF];
-    double *ud[H3M_MAXF];
-    blomgpu_h3m_src *ss[H3M_MAXF];
-    for (int f = 0; f < nf; f++) {
-      us[f] = field(f0 + f);
-      ud[f] = rm + (size_t)f * per;
-      ss[f] = a->trc[f0 + f];
-    }
-    if (f0 > 0 && !ndiff && (rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
-    if ((rc = blomgpu_h3m_remap_many(nf, ss, a->map, ud))) return ale_fail(c, "remap", rc);
-    if (ndiff && f0 == 0)
-      if (int rc2 = join()) return rc2;
-    hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf, flx, a->ntr_loc);
-  }
   // ---- velocities, :1692-1900 -------------------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(k_ale_pupv, g1, b, 0, c->stream, c->d, nn);
-  if (int rc2 = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, 3, 3, 1)) return rc2;
-  hipLaunchKernelGGL(k_ale_pscan, g1, b, 0, c->stream, c->d, nn);
-  // dpu, dpv of the new layers and their copies dpuold, dpvold, j,i = -1..+2 (:1735-1762)
-  if (int rc2 = launch_dpudpv(c, nn, 4)) return rc2;
-  {
-    // u- and v-columns as one grid of 2 * nplane columns; its planes lie where the tracers' scratch did
-    double *ps2 = a->plane, *pd2 = ps2 + (size_t)2 * (h.kk + 1) * np, *ui2 = pd2 + (size_t)2 * (h.kk + 1) * np, *rm2 = ui2 + (size_t)2 * per;
+  // uvp: their scratch planes (where the tracers' scratch was, unless the neutral diffusion is still reading that)
+  auto velocities = [&](double *uvp) -> int {
+    hipLaunchKernelGGL(k_ale_pupv, g1, b, 0, c->stream, c->d, nn);
+    if (int rc2 = st_xctilr(c, h.f[F_dp] + (size_t)(k1n - 1) * np, 1, h.kk, 3, 3, 1)) return rc2;
+    hipLaunchKernelGGL(k_ale_pscan, g1, b, 0, c->stream, c->d, nn);
+    // dpu, dpv of the new layers and their copies dpuold, dpvold, j,i = -1..+2 (:1735-1762)
+    if (int rc2 = launch_dpudpv(c, nn, 4)) return rc2;
+    // u- and v-columns as one grid of 2 * nplane columns
+    double *ps2 = uvp, *pd2 = ps2 + (size_t)2 * (h.kk + 1) * np, *ui2 = pd2 + (size_t)2 * (h.kk + 1) * np, *rm2 = ui2 + (size_t)2 * per;
     hipLaunchKernelGGL(k_ale_uv_src_dst, dim3((unsigned)((np + 255) / 256), 2), b, 0, c->stream, c->d, nn, ps2, pd2, ui2, a->active + np);
     if ((rc = blomgpu_h3m_prepare_reconstruction(a->grid_uv, ps2))) return ale_fail(c, "prepare_reconstruction (velocity)", rc);
     // the segments of the destination grid and the reconstruction need the prepared grid, not each other
@@ -1012,7 +1024,35 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     if (int rc2 = join()) return rc2;
     if ((rc = blomgpu_h3m_remap(a->vel, a->map_uv, rm2))) return ale_fail(c, "remap (velocity)", rc);
     hipLaunchKernelGGL(k_ale_uv_back, dim3((unsigned)((np + 255) / 256), h.kk, 2), b, 0, c->stream, c->d, nn, (const double *)rm2);
+    return 0;
+  };
+  bool vel_done = false;
+  for (int f0 = 0; f0 < a->ntr_loc; f0 += H3M_MAXF) {
+    const int nf = a->ntr_loc - f0 < H3M_MAXF ? a->ntr_loc - f0 : H3M_MAXF;
+    const double *us[H3M_MAXF];
+    double *ud[H3M_MAXF];
+    blomgpu_h3m_src *ss[H3M_MAXF];
+    for (int f = 0; f < nf; f++) {
+      us[f] = field(f0 + f);
+      ud[f] = rm + (size_t)f * per;
+      ss[f] = a->trc[f0 + f];
+    }
+    if (f0 > 0 && !ndiff && (rc = blomgpu_h3m_reconstruct_many(a->grid, nf, ss, us))) return ale_fail(c, "reconstruct", rc);
+    if ((rc = blomgpu_h3m_remap_many(nf, ss, a->map, ud))) return ale_fail(c, "remap", rc);
+    if (ndiff && f0 == 0) {
+      // While the neutral diffusion is at work beside: the new layer thicknesses (all the velocity part needs of the tracers'
+      // result) and the velocity part itself, once the diffusion has its copy of pu, pv.  Then wait for the flux convergence.
+      hipLaunchKernelGGL(k_ale_dp_new, gk, b, 0, c->stream, c->d, nn, (const double *)pdst);
+      HIPCHK(c, hipStreamWaitEvent(c->stream, a->ev_snap, 0));
+      if (int rc2 = velocities(a->plane_uv)) return rc2;
+      vel_done = true;
+      HIPCHK(c, hipEventRecord(a->ev_join2, a->side2));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, a->ev_join2, 0));
+    }
+    hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf, flx, a->ntr_loc);
   }
+  if (!vel_done)
+    if (int rc2 = velocities(a->plane)) return rc2;
   HIPCHK(c, hipGetLastError());
   if (defer) {
     if ((rc = h3m_sequence_end_deferred(a->grid)) || (rc = h3m_sequence_end_deferred(a->grid_uv))) return ale_fail(c, "sequence", rc);

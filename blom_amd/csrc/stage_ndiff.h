@@ -10,6 +10,8 @@ struct NdArgs {
   const double *tsd;           // T and S at both interfaces of every source layer: [field 0..1][layer][upper, lower]
   const double *drt, *drs;     // drho/dT, drho/dS there: [layer][upper, lower]
   double *flx;                 // flux convergence: [destination layer][field] planes
+  double *puv;                 // pu, pv as they are when the stage starts ((kk+1) planes each): the velocity part of
+                               // ale_regrid_remap, which runs beside the diffusion, rewrites them
   double *scr;                 // the flux kernel's per-face work arrays, ndiff_scratch_planes(kk) planes of 2 nplane faces
   // the fluxes a face found, in search order (u-faces first, then the v-faces: 2 nplane faces per plane)
   int *rec_n, *rec_k, *rec_s;  // their number; per record the destination layers kd_m | kd_p << 16; the source layers and how the
@@ -22,4 +24,4 @@ struct NdArgs {
 };
 
 size_t ndiff_scratch_planes(int kk);
-int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs);
+int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, hipEvent_t ev_snap, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs);

@@ -675,6 +675,10 @@ __global__ void k_ndiff_prep(const DevView *__restrict__ Vp, NdArgs A, int *__re
     }
     for (int n = 0; n < kk * A.ntr_loc; n++) A.flx[c + (size_t)n * np] = 0.;
   }
+  for (int k = 0; k <= kk; k++) {
+    A.puv[c + (size_t)k * np] = V.f[F_pu][c + (size_t)k * np];
+    A.puv[c + (size_t)(kk + 1 + k) * np] = V.f[F_pv][c + (size_t)k * np];
+  }
   if (V.m[I_iu][c])
     for (int k = 0; k < kk; k++) { V.f[F_utflld][c + (size_t)(k + mm) * np] = 0.; V.f[F_usflld][c + (size_t)(k + mm) * np] = 0.; }
   if (V.m[I_iv][c])
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(64) void k_ndiff_uvflx(const DevView *__restrict__ 
   const bool isv = face >= np;
   const size_t cp = isv ? face - np : face;
   const int kk = V.kk, mm = A.mm, ntr_loc = A.ntr_loc;
-  const double *puv = isv ? V.f[F_pv] : V.f[F_pu];
+  const double *puv = A.puv + (isv ? (size_t)(kk + 1) * np : 0);
   double *ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), *fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
   double *ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), *fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
   int kuv = 1;
@@ -851,12 +855,13 @@ __global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ 
 
 size_t ndiff_scratch_planes(int kk) { return (size_t)4 * kk + (size_t)10 * (kk + 1); }   // per FACE (2 nplane of them)
 
-int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs) {
+int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, hipEvent_t ev_snap, NdArgs A, int *ksmx, int *kdmx, double *tsd, double *drt, double *drs) {
   const DevView &h = c->h;
   if (h.kk > 128) return ctx_fail(c, "ndiff: more than 128 layers");
   const unsigned nb = (unsigned)((h.nplane + 63) / 64);
   TimeScope ts(c, "ndiff", st);
   hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, st, c->d, A, ksmx, kdmx, tsd, drt, drs);
+  if (ev_snap) HIPCHK(c, hipEventRecord(ev_snap, st));
   if (int rc = ctx_err_words(c)) return rc;
   hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
   hipLaunchKernelGGL(k_ndiff_eval, dim3((unsigned)((2 * h.nplane + 63) / 64), ND_EVAL_RY), dim3(64), 0, st, c->d, A);
