@@ -591,6 +591,7 @@ def bench_hybrid_step(args):
         ms, n = gpu.timer_get(cl)
         if n:
             live[cl] = ms / min(args.steps, 5)           # ms per step of the class (ale_vdiff: its two stages)
+    gpu_timers = {kn: gpu.timer_get(kn) for kn in ("k_ndiff_prep", "k_ndiff_flux", "k_ndiff_eval", "k_ndiff_uvflx", "k_ndiff_apply")}
     gpu.set("timing", 0)
     u = gpu.get("u")[:, 4:-4, 4:-4]
     finite = bool(np.isfinite(u[np.broadcast_to((masks["iu"][4:-4, 4:-4] > 0)[None], u.shape)]).all())
@@ -605,7 +606,19 @@ def bench_hybrid_step(args):
     cb = dict(class_bytes_F(ntr, ntr_diffused(case)))
     cb["momtum"] += 2
     cb.update(ale_regrid_remap=(6 + ntr) + (13 + ntr), ale_vdiff=(16 + ntr) + (5 + ntr), ale_forcing=4 + 3)
-    hbm = {k: v for k, v in live.items() if k in cb}
+    if neutral:
+        #   ndiff (inside ale_regrid_remap)  R source and destination interfaces (2), the reconstruction coefficients of T, S, tracers
+        #                     (3 per layer with ppm), T, S, tracers (n), difiso, pu, pv; W the flux convergence per field, utflld .. vsflld (4),
+        #                     nslpx, nslpy; RW utflx .. vsflx (4)
+        nloc = ntr + 2
+        cb["ndiff"] = 2 + 3 * nloc + nloc + 1 + 2 + nloc + 4 + 2 + 2 * 4
+        cb["ale_regrid_remap"] += cb["ndiff"]
+    nd_k = {}
+    for kn in ("k_ndiff_prep", "k_ndiff_flux", "k_ndiff_eval", "k_ndiff_uvflx", "k_ndiff_apply"):
+        ms, n = gpu_timers.get(kn, (0.0, 0))
+        if n:
+            nd_k[kn] = ms / n
+    hbm = {k: v for k, v in live.items() if k in cb and k != "ndiff"}        # (ndiff's time lies inside ale_regrid_remap's)
     dom = max(hbm, key=hbm.get)
     ach = cb[dom] * F / (live[dom] * 1e-3) / 1e9
     tot = sum(cb[k] for k in hbm) * F
@@ -618,9 +631,13 @@ def bench_hybrid_step(args):
                       "parity": "cross-checked stage sequence, also at this size (tests/test_xcheck_hybrid_step.py)", "state_finite": finite},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": None, "algorithmic_bytes": cb[dom] * F, "avg_ms": live[dom],
-                        "note": "stage class (its kernels are launched back to back); HIP events on the library's stream",
+                        "note": "stage class (its kernels are launched back to back); HIP events on the library's stream" +
+                                ("; with ltedtp = 'neutral' the class contains the neutral diffusion, whose searches are bound by instruction issue and "
+                                 "load latency, not by bytes (DESIGN.md 3j): its kernels run on a stream of their own beside the remapping" if neutral else ""),
                         "step_hbm_frac": tot / dt / 1e9 / HBM_PEAK_GBS},
            "stages_ms": live}
+    if nd_k:
+        out["ndiff_kernels_ms"] = nd_k
     gpu.close()
     sys.stdout.flush()
     real_stdout = os.dup(1)

@@ -860,13 +860,28 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, hipEvent_t ev_snap, NdArg
   if (h.kk > 128) return ctx_fail(c, "ndiff: more than 128 layers");
   const unsigned nb = (unsigned)((h.nplane + 63) / 64);
   TimeScope ts(c, "ndiff", st);
-  hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, st, c->d, A, ksmx, kdmx, tsd, drt, drs);
+  {
+    TimeScope t1(c, "k_ndiff_prep", st);
+    hipLaunchKernelGGL(k_ndiff_prep, dim3((unsigned)((h.nplane + 255) / 256)), dim3(256), 0, st, c->d, A, ksmx, kdmx, tsd, drt, drs);
+  }
   if (ev_snap) HIPCHK(c, hipEventRecord(ev_snap, st));
   if (int rc = ctx_err_words(c)) return rc;
-  hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
-  hipLaunchKernelGGL(k_ndiff_eval, dim3((unsigned)((2 * h.nplane + 63) / 64), ND_EVAL_RY), dim3(64), 0, st, c->d, A);
-  hipLaunchKernelGGL(k_ndiff_uvflx, dim3((unsigned)((2 * h.nplane + 63) / 64)), dim3(64), 0, st, c->d, A);
-  hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), 0, st, c->d, A);
+  {
+    TimeScope t1(c, "k_ndiff_flux", st);
+    hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
+  }
+  {
+    TimeScope t1(c, "k_ndiff_eval", st);
+    hipLaunchKernelGGL(k_ndiff_eval, dim3((unsigned)((2 * h.nplane + 63) / 64), ND_EVAL_RY), dim3(64), 0, st, c->d, A);
+  }
+  {
+    TimeScope t1(c, "k_ndiff_uvflx", st);
+    hipLaunchKernelGGL(k_ndiff_uvflx, dim3((unsigned)((2 * h.nplane + 63) / 64)), dim3(64), 0, st, c->d, A);
+  }
+  {
+    TimeScope t1(c, "k_ndiff_apply", st);
+    hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), 0, st, c->d, A);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
