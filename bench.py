@@ -185,11 +185,16 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False
     import threading
     res = {}
     threading.stack_size(2 << 30)
-    th = threading.Thread(target=lambda: res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full)))
+    def body():
+        try:
+            res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full))
+        except Exception as e:                           # (an exception in a thread would otherwise vanish with its message)
+            res["error"] = repr(e)
+    th = threading.Thread(target=body)
     th.start()
     th.join()
     threading.stack_size(0)
-    return res
+    return res or {"error": "the reference run did not complete"}
 
 
 def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False):
@@ -248,7 +253,7 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_phys
                 cores = ncores
                 os.environ.setdefault("OMP_PROC_BIND", "close")
                 os.environ["OMP_STACKSIZE"] = "1G"   # the stages keep private 2-D work arrays on the thread stacks
-            be = get_ref_backend(ref_cfg, case.depth)
+            be = get_ref_backend(ref_cfg, case.depth, ntr=case.ntr)      # (the reference's tracer count is a run-time quantity)
             kind = "reference"
             if full:
                 be.ref.set("eitmth", "gm")
