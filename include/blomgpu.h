@@ -132,7 +132,9 @@ int  blomgpu_mxlayr_tail (blomgpu_ctx *, int nn, int k1n);
  * heat (surflx, sswflx, surrlx), salt (salflx, brnflx, salrlx) and tracers (trflx), the friction velocity ustar, from the forcing
  * fields swa, nsf, eva, lip, sop, rnf, rfi, ustarw and the climatologies sstclm, ricclm, sssclm; options blomgpu_set_real "trxday",
  * "srxday", "trxdpt", "srxdpt", "trxlim", "srxlim", "sref", "area", "xmi", blomgpu_set_int "l1mi".."l5mi" (mod_time's position
- * in the year), "aptflx", "apsflx", "ditflx", "disflx", "srxbal" (refused when set: not built).  PARITY UNPINNED (the module
+ * in the year), "aptflx", "apsflx", "ditflx", "disflx", "srxbal" (refused when set: not built).  Its two global sums (xcsum,
+ * phy/mod_xc.F90:2071) are formed in the global domain's order on decomposed domains too: "area" is the GLOBAL ocean area, and
+ * RCCL ranks need the global context of the replicated barotropic solve (blomgpu_rccl_attach_barotp_global).  PARITY UNPINNED (the module
  * imports the netCDF-bound mod_ben02): cross-checked against the real module behind a stand-in, tests/test_xcheck_thermf.py. */
 int  blomgpu_thermf (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 /* phy/mod_mxlayr.F90:130 mxlayr(m,n,mm,nn,k1m,k1n): the bulk mixed layer of vcoord_type = 'isopyc_bulkml' (turbulent kinetic
