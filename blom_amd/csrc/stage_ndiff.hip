@@ -107,6 +107,8 @@ __device__ inline double nd_drhoroot(const Pc5 &t, const Pc5 &s, double tf, doub
 
 // ndiff_flx, :166-953, for the face between the columns cm ("minus": i-1 or j-1) and cp ("plus", the face's own index).
 // sc: the face's scratch column (plane stride nf = 2 nplane); face: its index in the record arrays
+// NWS, NWP: 64-bit words of the layers' stability flags (kk bits) and of the set-flags of p_ni_srcdi (2 kk bits)
+template <int NWS, int NWP>
 __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp, bool isv, size_t face, double *sc, int *errw) {
   const size_t np = V.nplane, nf = 2 * V.nplane;
   const bool wedge = true;
@@ -134,19 +136,23 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
    (.5 * (DSM(ism, ksm) + DSP(isp_, ksp))) * (TSP(isp_, ksp, 1) - TSM(ism, ksm, 1)))
   const int ksmx_m = A.ksmx[cm], ksmx_p = A.ksmx[cp], kdmx_m = A.kdmx[cm], kdmx_p = A.kdmx[cp];
   const double cnslp = ND_ALPHA0 * (isv ? V.f[F_scvyi][cp] : V.f[F_scuxi][cp]) / ND_GRAV;      // :1080, :1135
-  unsigned long long stm[2] = {0ull, 0ull}, stp[2] = {0ull, 0ull};          // stab_src_m, stab_src_p (kk <= 128)
-#define STM(ks_) ((stm[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
-#define STP(ks_) ((stp[((ks_)-1) >> 6] >> (((ks_)-1) & 63)) & 1ull)
-#define STM_SET(ks_) stm[((ks_)-1) >> 6] |= 1ull << (((ks_)-1) & 63)
-#define STP_SET(ks_) stp[((ks_)-1) >> 6] |= 1ull << (((ks_)-1) & 63)
+  unsigned long long stm[NWS], stp[NWS];                                   // stab_src_m, stab_src_p (kk <= 64 NWS)
+  for (int q = 0; q < NWS; q++) stm[q] = stp[q] = 0ull;
+#define SWI(ks_) (NWS == 1 ? 0 : ((ks_)-1) >> 6)
+#define STM(ks_) ((stm[SWI(ks_)] >> (((ks_)-1) & 63)) & 1ull)
+#define STP(ks_) ((stp[SWI(ks_)] >> (((ks_)-1) & 63)) & 1ull)
+#define STM_SET(ks_) stm[SWI(ks_)] |= 1ull << (((ks_)-1) & 63)
+#define STP_SET(ks_) stp[SWI(ks_)] |= 1ull << (((ks_)-1) & 63)
   // which entries of p_ni_srcdi_m, p_ni_srcdi_p have been set (the reference tests them against mval): the index walks of the
   // second search then need no loads
-  unsigned long long pbm[4] = {0ull, 0ull, 0ull, 0ull}, pbp[4] = {0ull, 0ull, 0ull, 0ull};
+  unsigned long long pbm[NWP], pbp[NWP];
+  for (int q = 0; q < NWP; q++) pbm[q] = pbp[q] = 0ull;
 #define PBI(is_, ks_) (((ks_)-1) * 2 + (is_)-1)
-#define PBM(is_, ks_) ((pbm[PBI(is_, ks_) >> 6] >> (PBI(is_, ks_) & 63)) & 1ull)
-#define PBP(is_, ks_) ((pbp[PBI(is_, ks_) >> 6] >> (PBI(is_, ks_) & 63)) & 1ull)
-#define PNM_SET(is_, ks_, v_) do { PNM(is_, ks_) = (v_); pbm[PBI(is_, ks_) >> 6] |= 1ull << (PBI(is_, ks_) & 63); } while (0)
-#define PNP_SET(is_, ks_, v_) do { PNP(is_, ks_) = (v_); pbp[PBI(is_, ks_) >> 6] |= 1ull << (PBI(is_, ks_) & 63); } while (0)
+#define PWI(is_, ks_) (NWP == 1 ? 0 : PBI(is_, ks_) >> 6)
+#define PBM(is_, ks_) ((pbm[PWI(is_, ks_)] >> (PBI(is_, ks_) & 63)) & 1ull)
+#define PBP(is_, ks_) ((pbp[PWI(is_, ks_)] >> (PBI(is_, ks_) & 63)) & 1ull)
+#define PNM_SET(is_, ks_, v_) do { PNM(is_, ks_) = (v_); pbm[PWI(is_, ks_)] |= 1ull << (PBI(is_, ks_) & 63); } while (0)
+#define PNP_SET(is_, ks_, v_) do { PNP(is_, ks_) = (v_); pbp[PWI(is_, ks_)] |= 1ull << (PBI(is_, ks_) & 63); } while (0)
   for (int k = 1; k <= kk; k++) { PNM(1, k) = ND_MVAL; PNM(2, k) = ND_MVAL; PNP(1, k) = ND_MVAL; PNP(2, k) = ND_MVAL; }
   int nns = 0;
   int is_m, is_p, ks_m, ks_p, kssa_m = 0, kssa_p = 0;
@@ -361,14 +367,15 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
   // ---- second search, :510-921 ------------------------------------------------------------------------------------------------
   {
     is_m = 2; ks_m = 0; is_p = 2; ks_p = 0;
-    int kd_m = 0, kd_p = 0, isn_m = 1, isn_p = 1, ksn_m = 1, ksn_p = 1, ks_m_prev = 0, ks_p_prev = 0, nip = 0, nic = 1;
+    int kd_m = 0, kd_p = 0, isn_m = 1, isn_p = 1, ksn_m = 1, ksn_p = 1, ks_m_prev = 0, ks_p_prev = 0;
     bool advance_src_m = true, advance_src_p = true, advance_dst_m = true, advance_dst_p = true;
-    double p_ni_m[2], p_ni_p[2], x_ni_m[2] = {0., 0.}, x_ni_p[2] = {0., 0.};
-    int knd_m[2] = {0, 0}, knd_p[2] = {0, 0};                 // how t_ni_m, t_ni_p of the slot were formed (nd_tni)
+    // the previous (P) and the current (C) neutral interface: pressures and positions in the two columns, and how the values
+    // there are to be taken (nd_tni).  The reference flips two slots; here the current one becomes the previous one.
+    double pmP, pmC = 0., ppP, ppC = 0., xmP = 0., xmC = 0., xpP = 0., xpC = 0.;
+    int kmP = 0, kmC = 0, kpP = 0, kpC = 0;
     // in registers between index changes: p_srcdi(is,ks), (1,ks), (2,ks), p_ni_srcdi(is,ks), (isn,ksn), p_srcdi(isn,ksn), p_dstsnp(kd+1)
     double a_m = 0., b_m = 0., c_m = 0., d_m = 0., e_m = 0., f_m = 0., g_m = 0., a_p = 0., b_p = 0., c_p = 0., d_p = 0., e_p = 0., f_p = 0., g_p = 0.;
-    p_ni_m[nip] = -ND_MVAL; p_ni_p[nip] = -ND_MVAL;
-    p_ni_m[nic] = 0.; p_ni_p[nic] = 0.;
+    pmP = -ND_MVAL; ppP = -ND_MVAL;
     while (true) {                                              // search_loop2
       // the index walks first (no loads: the set-bits of p_ni_srcdi and the stability flags are in registers), then every value
       // the new indices need in ONE round of loads
@@ -441,17 +448,17 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
       }
       if (advance_dst_m) g_m = SNM(kd_m + 1);
       if (advance_dst_p) g_p = SNP(kd_p + 1);
-      if (p_ni_m[nip] == -ND_MVAL) {
+      if (pmP == -ND_MVAL) {
         if ((e_m - f_p) < (e_p - f_m)) {
-          p_ni_m[nip] = f_m;
-          p_ni_p[nip] = e_m;
+          pmP = f_m;
+          ppP = e_m;
         } else {
-          p_ni_m[nip] = e_p;
-          p_ni_p[nip] = f_p;
+          pmP = e_p;
+          ppP = f_p;
         }
       }
       while (true) {                                            // both columns' destination indices step together
-        const bool nm = g_m <= fmax2(b_m, p_ni_m[nip]), npp = g_p <= fmax2(b_p, p_ni_p[nip]);
+        const bool nm = g_m <= fmax2(b_m, pmP), npp = g_p <= fmax2(b_p, ppP);
         if (!nm && !npp) break;
         if (nm) {
           kd_m = kd_m + 1;
@@ -476,29 +483,29 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
       bool found_ni = false;
       if (case_m == 3 && case_p == 3) {
         if (is_p == 2 && is_m == 2) {
-          p_ni_m[nic] = g_m;
-          p_ni_p[nic] = g_p;
-          const double pu_m = p_ni_m[nip], pu_p = p_ni_p[nip];
+          pmC = g_m;
+          ppC = g_p;
+          const double pu_m = pmP, pu_p = ppP;
           double pl_m, pl_p;
           if ((e_m - f_p) < (e_p - f_m)) {
             pl_m = f_m; pl_p = e_m;
           } else {
             pl_m = e_p; pl_p = f_p;
           }
-          const double pp1 = (p_ni_m[nic] - pu_m) * (pl_p - pu_p), pp2 = (p_ni_p[nic] - pu_p) * (pl_m - pu_m);
+          const double pp1 = (pmC - pu_m) * (pl_p - pu_p), pp2 = (ppC - pu_p) * (pl_m - pu_m);
           if (fabs(pp1 - pp2) < ND_DP_EPS * fmax2(ND_DP_EPS, pl_m - pu_m + pl_p - pu_p)) {
             advance_dst_m = true; advance_dst_p = true;
           } else if (pp1 < pp2) {
-            p_ni_p[nic] = pu_p + pp1 / (pl_m - pu_m);
+            ppC = pu_p + pp1 / (pl_m - pu_m);
             advance_dst_m = true;
           } else {
-            p_ni_m[nic] = pu_m + pp2 / (pl_p - pu_p);
+            pmC = pu_m + pp2 / (pl_p - pu_p);
             advance_dst_p = true;
           }
-          if (p_ni_m[nic] >= b_m && p_ni_m[nic] <= c_m && p_ni_p[nic] >= b_p && p_ni_p[nic] <= c_p) {
-            x_ni_m[nic] = (p_ni_m[nic] - b_m) / (c_m - b_m);
-            x_ni_p[nic] = (p_ni_p[nic] - b_p) / (c_p - b_p);
-            knd_m[nic] = 0; knd_p[nic] = 0;
+          if (pmC >= b_m && pmC <= c_m && ppC >= b_p && ppC <= c_p) {
+            xmC = (pmC - b_m) / (c_m - b_m);
+            xpC = (ppC - b_p) / (c_p - b_p);
+            kmC = 0; kpC = 0;
             found_ni = true;
           }
         } else {
@@ -507,15 +514,15 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         }
       } else if (case_m == 3) {
         if (is_p == 2) {
-          p_ni_m[nic] = g_m;
+          pmC = g_m;
           if (case_p == 1)
-            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (f_p - p_ni_p[nip]) / (e_p - p_ni_m[nip]);
+            ppC = ppP + (pmC - pmP) * (f_p - ppP) / (e_p - pmP);
           else
-            p_ni_p[nic] = p_ni_p[nip] + (p_ni_m[nic] - p_ni_m[nip]) * (e_m - p_ni_p[nip]) / (f_m - p_ni_m[nip]);
-          if (p_ni_p[nic] >= b_p && p_ni_p[nic] <= c_p) {
-            x_ni_m[nic] = (g_m - b_m) / (c_m - b_m);
-            x_ni_p[nic] = (p_ni_p[nic] - b_p) / (c_p - b_p);
-            knd_m[nic] = 0; knd_p[nic] = 0;
+            ppC = ppP + (pmC - pmP) * (e_m - ppP) / (f_m - pmP);
+          if (ppC >= b_p && ppC <= c_p) {
+            xmC = (g_m - b_m) / (c_m - b_m);
+            xpC = (ppC - b_p) / (c_p - b_p);
+            kmC = 0; kpC = 0;
             found_ni = true;
             advance_dst_m = true;
           } else {
@@ -525,15 +532,15 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         } else advance_dst_m = true;
       } else if (case_p == 3) {
         if (is_m == 2) {
-          p_ni_p[nic] = g_p;
+          ppC = g_p;
           if (case_m == 1)
-            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (f_m - p_ni_m[nip]) / (e_m - p_ni_p[nip]);
+            pmC = pmP + (ppC - ppP) * (f_m - pmP) / (e_m - ppP);
           else
-            p_ni_m[nic] = p_ni_m[nip] + (p_ni_p[nic] - p_ni_p[nip]) * (e_p - p_ni_m[nip]) / (f_p - p_ni_p[nip]);
-          if (p_ni_m[nic] >= b_m && p_ni_m[nic] <= c_m) {
-            x_ni_p[nic] = (g_p - b_p) / (c_p - b_p);
-            x_ni_m[nic] = (p_ni_m[nic] - b_m) / (c_m - b_m);
-            knd_m[nic] = 0; knd_p[nic] = 0;
+            pmC = pmP + (ppC - ppP) * (e_p - pmP) / (f_p - ppP);
+          if (pmC >= b_m && pmC <= c_m) {
+            xpC = (g_p - b_p) / (c_p - b_p);
+            xmC = (pmC - b_m) / (c_m - b_m);
+            kmC = 0; kpC = 0;
             found_ni = true;
             advance_dst_p = true;
           } else {
@@ -543,11 +550,11 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         } else advance_dst_p = true;
       } else if (case_m == 1 && case_p == 1) {
         if (d_m != ND_MVAL && d_p != ND_MVAL) {
-          x_ni_m[nic] = (double)(is_m - 1);
-          p_ni_m[nic] = a_m;
-          x_ni_p[nic] = (double)(is_p - 1);
-          p_ni_p[nic] = a_p;
-          knd_m[nic] = is_m; knd_p[nic] = is_p;
+          xmC = (double)(is_m - 1);
+          pmC = a_m;
+          xpC = (double)(is_p - 1);
+          ppC = a_p;
+          kmC = is_m; kpC = is_p;
           found_ni = true;
           advance_src_m = true; advance_src_p = true;
         } else {
@@ -556,21 +563,21 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         }
       } else if (case_m == 1) {
         if (d_m != ND_MVAL && d_m >= b_p) {
-          x_ni_m[nic] = (double)(is_m - 1);
-          p_ni_m[nic] = a_m;
-          p_ni_p[nic] = d_m;
-          x_ni_p[nic] = (p_ni_p[nic] - b_p) / (c_p - b_p);
-          knd_m[nic] = is_m; knd_p[nic] = 0;
+          xmC = (double)(is_m - 1);
+          pmC = a_m;
+          ppC = d_m;
+          xpC = (ppC - b_p) / (c_p - b_p);
+          kmC = is_m; kpC = 0;
           found_ni = true;
         }
         advance_src_m = true;
       } else if (case_p == 1) {
         if (d_p != ND_MVAL && d_p >= b_m) {
-          x_ni_p[nic] = (double)(is_p - 1);
-          p_ni_p[nic] = a_p;
-          p_ni_m[nic] = d_p;
-          x_ni_m[nic] = (p_ni_m[nic] - b_m) / (c_m - b_m);
-          knd_p[nic] = is_p; knd_m[nic] = 0;
+          xpC = (double)(is_p - 1);
+          ppC = a_p;
+          pmC = d_p;
+          xmC = (pmC - b_m) / (c_m - b_m);
+          kpC = is_p; kmC = 0;
           found_ni = true;
         }
         advance_src_p = true;
@@ -578,26 +585,26 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         advance_src_m = true; advance_src_p = true;
       }
       if (found_ni) {
-        const double dp_ni_m = fmin2(p_ni_m[nic] - p_ni_m[nip], PDM(kd_m + 1) - PDM(kd_m));
-        const double dp_ni_p = fmin2(p_ni_p[nic] - p_ni_p[nip], PDP(kd_p + 1) - PDP(kd_p));
+        const double dp_ni_m = fmin2(pmC - pmP, PDM(kd_m + 1) - PDM(kd_m));
+        const double dp_ni_p = fmin2(ppC - ppP, PDP(kd_p + 1) - PDP(kd_p));
         const double dp_ni = 2. * dp_ni_m * dp_ni_p / fmax2(dp_ni_m + dp_ni_p, 2. * ND_DP_EPS);
-        if (ks_m == ks_m_prev && ks_p == ks_p_prev && p_ni_m[nip] >= SNM(kd_m) && p_ni_m[nic] <= g_m && p_ni_p[nip] >= SNP(kd_p) &&
-            p_ni_p[nic] <= g_p && dp_ni > 2. * ND_DP_EPS) {
+        if (ks_m == ks_m_prev && ks_p == ks_p_prev && pmP >= SNM(kd_m) && pmC <= g_m && ppP >= SNP(kd_p) &&
+            ppC <= g_p && dp_ni > 2. * ND_DP_EPS) {
           // the record of this neutral layer (k_ndiff_eval forms the fluxes from it): destination and source layers, how the
           // interface values are to be taken, the positions of the two neutral interfaces in the source layers, the thickness
           const bool keep = nrec < A.nrec_max;
           if (!keep) atomicOr(errw, 1);
           if (keep) {
             A.rec_k[face + (size_t)nrec * nf] = kd_m | (kd_p << 16);
-            A.rec_s[face + (size_t)nrec * nf] = ks_m | (ks_p << 8) | (knd_m[nip] << 16) | (knd_m[nic] << 18) | (knd_p[nip] << 20) | (knd_p[nic] << 22);
+            A.rec_s[face + (size_t)nrec * nf] = ks_m | (ks_p << 8) | (kmP << 16) | (kmC << 18) | (kpP << 20) | (kpC << 22);
             double *rg = A.rec_g + face + (size_t)nrec * 7 * nf;
-            rg[0] = x_ni_m[nip]; rg[nf] = x_ni_m[nic]; rg[2 * nf] = x_ni_p[nip]; rg[3 * nf] = x_ni_p[nic]; rg[4 * nf] = dp_ni;
-            rg[5 * nf] = .5 * (p_ni_m[nip] + p_ni_p[nip]); rg[6 * nf] = .5 * (p_ni_m[nic] + p_ni_p[nic]);
+            rg[0] = xmP; rg[nf] = xmC; rg[2 * nf] = xpP; rg[3 * nf] = xpC; rg[4 * nf] = dp_ni;
+            rg[5 * nf] = .5 * (pmP + ppP); rg[6 * nf] = .5 * (pmC + ppC);
             nrec = nrec + 1;
           }
         }
         ks_m_prev = ks_m; ks_p_prev = ks_p;
-        nip = 1 - nip; nic = 1 - nic;
+        pmP = pmC; ppP = ppC; xmP = xmC; xpP = xpC; kmP = kmC; kpP = kpC;
       }
     }
   }
@@ -686,6 +693,7 @@ __global__ void k_ndiff_prep(const DevView *__restrict__ Vp, NdArgs A, int *__re
 }
 
 // one thread per u-face (rows 1..jj, i = 1..ii+1: ndiff_uflx_jslice) or v-face (rows 1..jj+1, i = 1..ii: ndiff_vflx_jslice)
+template <int NWS, int NWP>
 __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ Vp, NdArgs A, int *__restrict__ errw) {
   const DevView &V = *Vp;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
   const size_t face = c + (isv ? V.nplane : 0);
   const bool on = isv ? (j >= 1 && j <= V.jj + 1 && i >= 1 && i <= V.ii && V.m[I_iv][c]) : (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1 && V.m[I_iu][c]);
   if (!on) { A.rec_n[face] = 0; return; }
-  nd_face(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
+  nd_face<NWS, NWP>(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
 }
 
 // the fluxes of a face's records, :860-913.  The records do not depend on each other: blockIdx.y strides over them; heat and
@@ -868,7 +876,9 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, hipEvent_t ev_snap, NdArg
   if (int rc = ctx_err_words(c)) return rc;
   {
     TimeScope t1(c, "k_ndiff_flux", st);
-    hipLaunchKernelGGL(k_ndiff_flux, dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
+    if (h.kk <= 32) hipLaunchKernelGGL((k_ndiff_flux<1, 1>), dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
+    else if (h.kk <= 64) hipLaunchKernelGGL((k_ndiff_flux<1, 2>), dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
+    else hipLaunchKernelGGL((k_ndiff_flux<2, 4>), dim3(nb, 2), dim3(64), 0, st, c->d, A, c->err_dev + 4);
   }
   {
     TimeScope t1(c, "k_ndiff_eval", st);
