@@ -24,7 +24,38 @@ void ctx_sync_view(blomgpu_ctx *c) {
   if (!c->dirty) return;
   ctx_drop_graphs(c);
   (void)hipMemcpyAsync(c->d, &c->h, sizeof(DevView), hipMemcpyHostToDevice, c->stream);
+  // the alternative views (blomgpu_internal.h): the same fields and parameters, momtum's own p / pu / pv / work space
+  for (int v = 1; v < NVIEW; v++) {
+    if (!c->dv[v]) continue;
+    DevView &a = c->hv[v];
+    a = c->h;
+    a.wk = c->wk_mom;
+    a.nwk = 6;
+    if (v == VIEW_MOM_A) { a.f[F_pu] = c->pu_alt; a.f[F_pv] = c->pv_alt; }
+    if (v == VIEW_MOM_B) a.f[F_p] = c->p_alt;
+    (void)hipMemcpyAsync(c->dv[v], &a, sizeof(DevView), hipMemcpyHostToDevice, c->stream);
+  }
   c->dirty = false;
+}
+
+// ---- the second stream of blomgpu_step's stage overlap (blomgpu_internal.h: blomgpu_ctx::overlap) -----------------------
+bool ctx_overlap_on(const blomgpu_ctx *c) {
+  // not while stage timers run (their HIP events bracket launches on the context's stream), not on the hybrid coordinates
+  // (their sequence has its own second stream inside ale_regrid_remap)
+  return c->overlap && c->in_sequence && !c->timing && c->h.P.vcoord_tag == 1 && c->side != nullptr;
+}
+int ctx_side_fork(blomgpu_ctx *c, int ev) {
+  HIPCHK(c, hipEventRecord(c->ev_side[ev], c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_side[ev], 0));
+  return 0;
+}
+int ctx_side_done(blomgpu_ctx *c, int ev) {
+  HIPCHK(c, hipEventRecord(c->ev_side[ev], c->side));
+  return 0;
+}
+int ctx_side_join(blomgpu_ctx *c, int ev) {
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_side[ev], 0));
+  return 0;
 }
 
 TimeScope::TimeScope(blomgpu_ctx *c_, const char *w, hipStream_t s) : c(c_), what(w), st(s ? s : c_->stream) {
@@ -167,6 +198,16 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
   HIPCHK(c, hipMalloc((void **)&h.wk2d, sizeof(double) * (size_t)NWK2D * h.nplane));
   HIPCHK(c, hipMemsetAsync(h.wk2d, 0, sizeof(double) * (size_t)NWK2D * h.nplane, c->stream));
   HIPCHK(c, hipMalloc((void **)&c->d, sizeof(DevView)));
+  // momtum's own work space and interface pressures + the second stream (blomgpu_internal.h: blomgpu_ctx::overlap)
+  HIPCHK(c, hipMalloc((void **)&c->wk_mom, sizeof(double) * (size_t)6 * K * h.nplane));
+  HIPCHK(c, hipMemsetAsync(c->wk_mom, 0, sizeof(double) * (size_t)6 * K * h.nplane, c->stream));
+  for (double **pp : {&c->p_alt, &c->pu_alt, &c->pv_alt}) {
+    HIPCHK(c, hipMalloc((void **)pp, sizeof(double) * (size_t)(K + 1) * h.nplane));
+    HIPCHK(c, hipMemsetAsync(*pp, 0, sizeof(double) * (size_t)(K + 1) * h.nplane, c->stream));
+  }
+  for (int v = 1; v < NVIEW; v++) HIPCHK(c, hipMalloc((void **)&c->dv[v], sizeof(DevView)));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (auto &e : c->ev_side) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   c->dirty = true;
   ctx_sync_view(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -184,6 +225,10 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   (void)hipFree(c->h.wk);
   (void)hipFree(c->h.wk2d);
   (void)hipFree(c->d);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  for (auto &e : c->ev_side) if (e) (void)hipEventDestroy(e);
+  for (int v = 1; v < NVIEW; v++) if (c->dv[v]) (void)hipFree(c->dv[v]);
+  (void)hipFree(c->wk_mom); (void)hipFree(c->p_alt); (void)hipFree(c->pu_alt); (void)hipFree(c->pv_alt);
   if (c->tiling.rccl) (void)blomgpu_rccl_finalize(c);
   if (c->err_dev) (void)hipFree(c->err_dev);
   if (c->bt_flags) (void)hipFree(c->bt_flags);
@@ -201,6 +246,7 @@ int blomgpu_destroy(blomgpu_ctx *c) {
 
 int blomgpu_sync(blomgpu_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
   return 0;
 }
 
@@ -300,6 +346,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "cnsvdi") { c->cnsvdi = v; return 0; }
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
+  if (s == "overlap") { c->overlap = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
   if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; ale_free(c); return 0; }
   if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; ale_free(c); return 0; }
@@ -692,6 +739,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   c->pbcor1_handed_over = c->pbcor2_handed_over = false;
   c->fluxes_zeroed = false;
   c->remap_handed_over = false;
+  c->mom_early_done = c->convec_col_ahead = false;
   if (c->h.P.vcoord_tag != 1) {
     for (const char *st : seq_ale) {
       if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }
@@ -727,6 +775,12 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
       c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
       return rc;
     }
+    // momtum's viscous chain starts here, on the second stream (stage_momtum.hip: st_momtum_early)
+    if (!strcmp(st, "halo_difest"))
+      if (int rc = st_momtum_early(c, m, n, mm, nn)) {
+        c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+        return rc;
+      }
   }
   c->defer_checks = false;
   c->in_sequence = false;

@@ -305,7 +305,32 @@ struct blomgpu_ctx {
   double budget[4][7][2] = {};                 // sdp, tdp, trdp, tkedp (ncall, n)
   std::string err;
   std::string expcnf = "channel";   // experiment configuration (mod_config): selects the forcing branches
+  // ---- stage overlap inside blomgpu_step (round 5) ----------------------------------------------------------------
+  // The column kernels of the step (one thread per column, 1.6 wavefronts per SIMD on the channel) wait on their k-serial
+  // chains and leave the issue slots and the memory system idle; kernels of ANOTHER stage that do not depend on them run
+  // beside them on a second stream.  What makes stages independent is that every stage of the reference rebuilds the
+  // interface pressures p, pu, pv for itself: momtum's kernels get private copies (alternative device views of the
+  // context: the same fields, with p / pu / pv / the work space pointing at buffers of momtum's own), so its viscous chain
+  // -- which reads nothing the stages between difest and momtum write -- can start right after difest's halo updates, and
+  // convec's column kernel -- which writes p from dp(kn) -- can run beside momtum's Coriolis kernel, which reads p from dp(km).
+  int overlap = 1;               // option: 0 = every stage on the context's stream, in order
+  hipStream_t side = nullptr;    // the second stream
+  hipEvent_t ev_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  DevView hv[4];                 // host copies of the alternative views (hv[0] unused: the main view is h)
+  DevView *dv[4] = {nullptr, nullptr, nullptr, nullptr};
+  double *wk_mom = nullptr, *p_alt = nullptr, *pu_alt = nullptr, *pv_alt = nullptr;
+  bool mom_early_done = false;   // in sequence: momtum's viscous chain of this step is already running on `side`
+  bool convec_col_ahead = false; // in sequence: convec's column kernel of this step is already running on `side`
 };
+// alternative device views (see blomgpu_ctx::overlap): MOM_A = momtum's work space + its pu, pv (k_mom_pupv, the viscous
+// march); MOM_B = momtum's work space + its p (k_mom_pscan, k_mom_drag, the Coriolis march); MOM_C = momtum's work space
+// with the model's own p, pu, pv (the vertical pass, which leaves pu, pv of the new time level in the module arrays)
+enum { VIEW_MAIN = 0, VIEW_MOM_A, VIEW_MOM_B, VIEW_MOM_C, NVIEW };
+static inline const DevView *ctx_view(const blomgpu_ctx *c, int which) { return which == VIEW_MAIN ? c->d : c->dv[which]; }
+int ctx_side_fork(blomgpu_ctx *c, int ev);     // `side` waits for what is on the context's stream now
+int ctx_side_done(blomgpu_ctx *c, int ev);     // marks the end of a section on `side` ...
+int ctx_side_join(blomgpu_ctx *c, int ev);     // ... and the context's stream waits for it
+bool ctx_overlap_on(const blomgpu_ctx *c);
 
 int  ctx_fail(blomgpu_ctx *c, const std::string &msg);
 int  ctx_pack_masks(blomgpu_ctx *c);     // mpack = ip | iu << 1 | iv << 2 | iq << 3, after any upload of a mask
@@ -339,7 +364,9 @@ int st_pbcor2(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_diffus(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_pgforc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_momtum(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
-int st_momtum_fused_layers(blomgpu_ctx *, int m, int n, int mm, int nn);
+int st_momtum_fused_layers(blomgpu_ctx *, int m, int n, int mm, int nn, int part);   // part: 0 all, 1 the viscous march, 2 the rest
+int st_momtum_early(blomgpu_ctx *, int m, int n, int mm, int nn);   // in sequence: the viscous chain of this step's momtum on the second stream
+int st_convec_column_ahead(blomgpu_ctx *, int n, int nn);         // in sequence: convec's column kernel on the second stream
 int st_diapfl(blomgpu_ctx *, int n, int nn, int k1n);
 int st_convec(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_updtrc(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);

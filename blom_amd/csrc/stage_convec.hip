@@ -280,6 +280,21 @@ int st_convec_velocity(blomgpu_ctx *c, int nn) {
   return 0;
 }
 
+// inside blomgpu_step: the column kernel on the second stream, beside momtum (called at the start of st_momtum, i.e. after
+// pgforc, the last reader of dp, T, S of level n in front of it; momtum reads none of what the kernel writes -- its p is its own copy)
+int st_convec_column_ahead(blomgpu_ctx *c, int n, int nn) {
+  const DevView &h = c->h;
+  c->convec_col_ahead = false;
+  if (h.ntr > MAXTR || h.P.vcoord_tag != 1) return 0;       // st_convec will refuse
+  if (int rc = ctx_err_words(c)) return rc;
+  if (int rc = ctx_side_fork(c, 2)) return rc;
+  hipLaunchKernelGGL(k_convec_column, plane_grid(h, 1, 64), dim3(64), 0, c->side, c->d, n, nn, c->err_dev + 3);
+  HIPCHK(c, hipGetLastError());
+  if (int rc = ctx_side_done(c, 3)) return rc;
+  c->convec_col_ahead = true;
+  return 0;
+}
+
 int st_convec(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)mm; (void)k1m; (void)k1n;
   const DevView &h = c->h;
@@ -288,7 +303,11 @@ int st_convec(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   if (int rc = ctx_err_words(c)) return rc;
   {
     TimeScope ts(c, "convec");
-    hipLaunchKernelGGL(k_convec_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, n, nn, c->err_dev + 3);
+    if (c->convec_col_ahead) {
+      c->convec_col_ahead = false;
+      if (int rc = ctx_side_join(c, 3)) return rc;
+    } else
+      hipLaunchKernelGGL(k_convec_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, n, nn, c->err_dev + 3);
     if (int rc = st_xctilr(c, h.f[F_p], 1, h.kk + 1, 1, 1, 1)) return rc;                       // :313
     hipLaunchKernelGGL(k_convec_velocity, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, nn);
     hipLaunchKernelGGL(k_convec_dpudpv, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);

@@ -751,7 +751,7 @@ __global__ __launch_bounds__(64) void k_mom_column_from(const DevView *__restric
 }
 
 template <int BS>
-static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca, int ncb) {
+static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca, int ncb, int part) {
   const DevView &h = c->h;
   const int nsa = (h.ii + (BS - 8) - 1) / (BS - 8), nsb = (h.ii + (BS - 4) - 1) / (BS - 4);
   const size_t la = sizeof(double) * 37 * (BS + 4) + c->momtum_lds_pad, lb = sizeof(double) * (h.P.mommth == 2 ? 35 : 21) * (BS + 4) + c->momtum_lds_pad;
@@ -759,20 +759,22 @@ static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca
   (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-  { TimeScope tk(c, "k_mom_visc_march");
-  hipLaunchKernelGGL(k_mom_visc_march<BS>, dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, c->d, m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
+  if (part != 2) {
+    TimeScope tk(c, "k_mom_visc_march");
+    hipLaunchKernelGGL(k_mom_visc_march<BS>, dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
   }
+  if (part == 1) return;
   TimeScope tk(c, "k_mom_cor_march");
   if (h.P.mommth == 2)
-    hipLaunchKernelGGL((k_mom_cor_march<BS, true>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
+    hipLaunchKernelGGL((k_mom_cor_march<BS, true>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, ctx_view(c, VIEW_MOM_B), m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
   else
-    hipLaunchKernelGGL((k_mom_cor_march<BS, false>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, c->d, m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
+    hipLaunchKernelGGL((k_mom_cor_march<BS, false>), dim3(h.kk * ncb * nsb), dim3(BS), lb, c->stream, ctx_view(c, VIEW_MOM_B), m, n, mm, nn, c->momtum_order ? ncb : -ncb, nsb);
 }
 
-// the layer loop and the vertical pass of momtum; the caller (st_momtum) has done p/pu/pv, the drag and difwgt's halo
-int st_momtum_fused_layers(blomgpu_ctx *c, int m, int n, int mm, int nn) {
+// the layer loop and the vertical pass of momtum; the caller (st_momtum) has done p/pu/pv, the drag and difwgt's halo.
+// part 1: the viscous march alone; 2: the Coriolis march and the vertical pass; 0: all three
+int st_momtum_fused_layers(blomgpu_ctx *c, int m, int n, int mm, int nn, int part) {
   const DevView &h = c->h;
-  if (h.nwk < MF_NSLOT) return ctx_fail(c, "momtum: device work space too small");
   // One wavefront per workgroup (the barriers of the march then cost nothing and 5 / 14 workgroups fit a CU by their
   // LDS): strips of 56 / 60 owned columns.  Chunks in j: about one round of workgroups on the chip.
   const int cus = c->num_cus > 0 ? c->num_cus : 256;
@@ -785,11 +787,11 @@ int st_momtum_fused_layers(blomgpu_ctx *c, int m, int n, int mm, int nn) {
   const int nsa = (h.ii + (bs - 8) - 1) / (bs - 8), nsb = (h.ii + (bs - 4) - 1) / (bs - 4);
   const int nca = chunks(cus * (bs == 64 ? 8 : 160 * 1024 / (37 * (bs + 4) * 8)), nsa, c->momtum_chunks_a);
   const int ncb = chunks(cus * 8 * 64 / bs, nsb, c->momtum_chunks_b);
-  if (bs == 64) launch_marches<64>(c, m, n, mm, nn, nca, ncb);
-  else if (bs == 128) launch_marches<128>(c, m, n, mm, nn, nca, ncb);
-  else if (bs == 256) launch_marches<256>(c, m, n, mm, nn, nca, ncb);
+  if (bs == 64) launch_marches<64>(c, m, n, mm, nn, nca, ncb, part);
+  else if (bs == 128) launch_marches<128>(c, m, n, mm, nn, nca, ncb, part);
+  else if (bs == 256) launch_marches<256>(c, m, n, mm, nn, nca, ncb, part);
   else return ctx_fail(c, "momtum: momtum_bs must be 64, 128 or 256");
-  hipLaunchKernelGGL(k_mom_column_from, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, m, mm, nn);
+  if (part != 1) hipLaunchKernelGGL(k_mom_column_from, plane_grid(h, 2, 64), dim3(64), 0, c->stream, ctx_view(c, VIEW_MOM_C), m, mm, nn);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
