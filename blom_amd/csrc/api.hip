@@ -347,6 +347,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "overlap") { c->overlap = v; return 0; }
+  if (s == "lean_fluxes") { c->lean_fluxes = v; return 0; }
+  if (s == "tmsmt_fold") { c->tmsmt_fold = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
   if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; ale_free(c); return 0; }
   if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; ale_free(c); return 0; }
@@ -736,7 +738,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
                                   "ale_vdifft", "ale_vdiffm", "updtrc", "barotp", "pbcor2", "tmsmt2", "cmnfld1"};
   c->defer_checks = true;
   c->in_sequence = true;
-  c->pbcor1_handed_over = c->pbcor2_handed_over = false;
+  c->pbcor1_handed_over = c->pbcor2_handed_over = c->pbcor2_dp_in_wk = false;
   c->fluxes_zeroed = false;
   c->remap_handed_over = false;
   c->mom_early_done = c->convec_col_ahead = false;

@@ -235,6 +235,8 @@ struct blomgpu_ctx {
   bool stream_borrowed = false;  // this context runs on another context's stream (the global barotropic context of a tile)
   bool in_sequence = false;      // blomgpu_step is running its stage sequence: a stage may hand data to the next one through the work space
   bool pbcor2_handed_over = false;   // likewise pbcor2 (level m) for tmsmt2
+  bool pbcor2_dp_in_wk = false;      // ... and its column pass (the rescaling of dp) is left to tmsmt2 as well
+  int tmsmt_fold = 1;                // option: 0 = pbcor2 always runs its column pass
   bool pbcor1_handed_over = false;   // pbcor1 left S, T, tracers of the new level in the work space (slots N_S, N_T, N_TR): diffus starts there
   int steps_warm = 0;            // plain steps since the last option change (graph capture waits for 4)
   int pgf_uv_pair = 0;           // k_pgf_uv, A/B option: 1 = the u- and v-column wavefronts of 64 points in one workgroup with XCD-contiguous
@@ -314,6 +316,9 @@ struct blomgpu_ctx {
   // -- which reads nothing the stages between difest and momtum write -- can start right after difest's halo updates, and
   // convec's column kernel -- which writes p from dp(kn) -- can run beside momtum's Coriolis kernel, which reads p from dp(km).
   int overlap = 1;               // option: 0 = every stage on the context's stream, in order
+  // inside blomgpu_step (remap): init_fluxes only zeroes the faces remap does not store, the tile kernel's mass / heat / salt fluxes
+  // go to uflx .. vsflx alone and k_remap_update reads them there (12 F of stores less per step); 0: the work planes of rounds 1-4
+  int lean_fluxes = 1;
   hipStream_t side = nullptr;    // the second stream
   hipEvent_t ev_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   DevView hv[4];                 // host copies of the alternative views (hv[0] unused: the main view is h)

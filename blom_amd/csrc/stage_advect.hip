@@ -100,7 +100,12 @@ __global__ void k_adv_pbmin(const DevView *__restrict__ Vp) {
 }
 
 // ---- mod_remap.F90:1468-1520 (+ the in-place dp side effect of :297-303 on the outer ring) --------
-__global__ void k_remap_update(const DevView *__restrict__ Vp, int nn) {
+// mmlean >= 0 (inside blomgpu_step, where the flux arrays of level m hold nothing but this call's fluxes -- init_fluxes zeroed them
+// earlier in the step): the mass, heat and salt fluxes of the faces are read from uflx .. vsflx (k + mmlean) themselves, where the tile
+// kernel has just stored them, instead of from six more work planes holding the same numbers (a face without a velocity point
+// carries no flux; 0 + f and f may differ in the sign of a zero, which no result of this update can see: q > 0, and a zero
+// difference of fluxes is subtracted from q dp, q T, q S)
+__global__ void k_remap_update(const DevView *__restrict__ Vp, int nn, int mmlean) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -2 || j > V.jj + 3 || i < -2 || i > V.ii + 3 || !V.m[I_ip][c]) return;
@@ -114,13 +119,28 @@ __global__ void k_remap_update(const DevView *__restrict__ Vp, int nn) {
   }
   const size_t e = c + 1, nb = c + V.ni;
   const double s2i = V.f[F_scp2i][c];
-  const double *fdu = WK(V, W_FDU(ntr)) + ok, *fdv = WK(V, W_FDV(ntr)) + ok;
-  const double *ftu = WK(V, W_FTU(ntr)) + ok, *ftv = WK(V, W_FTV(ntr)) + ok;
-  const double *fsu = WK(V, W_FSU(ntr)) + ok, *fsv = WK(V, W_FSV(ntr)) + ok;
-  const double dpn = q - (fdu[e] - fdu[c] + fdv[nb] - fdv[c]) * s2i;
+  double dfd, dft, dfs;
+  if (mmlean >= 0) {
+    const size_t okm = (size_t)(k + mmlean) * np;
+    const int *mpk = V.m[I_mpack];
+    const bool uc = (mpk[c] >> 1) & 1, ue = (mpk[e] >> 1) & 1, vc = (mpk[c] >> 2) & 1, vn = (mpk[nb] >> 2) & 1;
+    const double *fdu = V.f[F_uflx] + okm, *fdv = V.f[F_vflx] + okm, *ftu = V.f[F_utflx] + okm, *ftv = V.f[F_vtflx] + okm;
+    const double *fsu = V.f[F_usflx] + okm, *fsv = V.f[F_vsflx] + okm;
+    dfd = (ue ? fdu[e] : 0.) - (uc ? fdu[c] : 0.) + (vn ? fdv[nb] : 0.) - (vc ? fdv[c] : 0.);
+    dft = (ue ? ftu[e] : 0.) - (uc ? ftu[c] : 0.) + (vn ? ftv[nb] : 0.) - (vc ? ftv[c] : 0.);
+    dfs = (ue ? fsu[e] : 0.) - (uc ? fsu[c] : 0.) + (vn ? fsv[nb] : 0.) - (vc ? fsv[c] : 0.);
+  } else {
+    const double *fdu = WK(V, W_FDU(ntr)) + ok, *fdv = WK(V, W_FDV(ntr)) + ok;
+    const double *ftu = WK(V, W_FTU(ntr)) + ok, *ftv = WK(V, W_FTV(ntr)) + ok;
+    const double *fsu = WK(V, W_FSU(ntr)) + ok, *fsv = WK(V, W_FSV(ntr)) + ok;
+    dfd = fdu[e] - fdu[c] + fdv[nb] - fdv[c];
+    dft = ftu[e] - ftu[c] + ftv[nb] - ftv[c];
+    dfs = fsu[e] - fsu[c] + fsv[nb] - fsv[c];
+  }
+  const double dpn = q - dfd * s2i;
   double *temp = V.f[F_temp] + okn, *saln = V.f[F_saln] + okn;
-  temp[c] = (q * temp[c] - (ftu[e] - ftu[c] + ftv[nb] - ftv[c]) * s2i) / dpn;
-  saln[c] = (q * saln[c] - (fsu[e] - fsu[c] + fsv[nb] - fsv[c]) * s2i) / dpn;
+  temp[c] = (q * temp[c] - dft * s2i) / dpn;
+  saln[c] = (q * saln[c] - dfs * s2i) / dpn;
   for (int nt = 0; nt < ntr; nt++) {
     if (trc_skip_adv(V.P, nt + 1)) continue;                   // phy/mod_remap.F90:1497-1499
     double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
@@ -167,6 +187,8 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   // edge follow when the halos have landed.  The exchange reads interior strips and writes halo points only.
   // inside blomgpu_step the tile kernel also does the update and hands the new dp, T, S, tracers to pbcor1 through the work space
   const bool fold = c->in_sequence && c->remap_fold;
+  // the flux arrays of level m were zeroed in this step and nothing has added to them: the tile kernel's fluxes ARE uflx .. vsflx (m)
+  const int mmlean = !fold && c->in_sequence && c->fluxes_zeroed && c->lean_fluxes ? mm : -1;
   const bool ovl = c->tiling.rccl && c->xstream && c->halo_overlap && !c->timing;
   if (ovl) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -179,12 +201,12 @@ int st_advect(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc2 = remap_tile_launch(c, n, mm, nn, 1, fold)) return rc2;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (int rc2 = remap_tile_launch(c, n, mm, nn, 2, fold)) return rc2;
-    if (!fold) hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    if (!fold) hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn, mmlean);
   } else {
     if (int rc = halo_all()) return rc;
     TimeScope ts(c, "remap");
     if (int rc = remap_tile_launch(c, n, mm, nn, 0, fold)) return rc;
-    if (!fold) hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    if (!fold) hipLaunchKernelGGL(k_remap_update, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn, mmlean);
   }
   c->remap_handed_over = fold;
   HIPCHK(c, hipGetLastError());

@@ -100,11 +100,18 @@ static int pbcor(blomgpu_ctx *c, int which, int m, int n, int mm, int nn, int k1
   const size_t np = h.nplane;
   const int offc = which == 1 ? nn : mm, offf = which == 1 ? mm : nn;
   if (which == 2) {                                                             // :434-440
-    if (int rc = st_xctilr(c, h.f[F_ubflxs] + (size_t)(n - 1) * np, 1, 1, 1, 1, 13)) return rc;
-    if (int rc = st_xctilr(c, h.f[F_vbflxs] + (size_t)(n - 1) * np, 1, 1, 1, 1, 14)) return rc;
-    for (int nt = 0; nt < h.ntr; nt++)
-      if (int rc = st_xctilr(c, h.f[F_trc] + ((size_t)(k1m - 1) + (size_t)nt * 2 * h.kk) * np, 1, h.kk, 1, 1, 1))
-        return rc;
+    // (one gather launch for the lot: up to 16 plane stacks per launch)
+    std::vector<double *> ptrs = {h.f[F_ubflxs] + (size_t)(n - 1) * np, h.f[F_vbflxs] + (size_t)(n - 1) * np};
+    std::vector<int> nl = {1, 1}, it = {13, 14};
+    for (int nt = 0; nt < h.ntr; nt++) {
+      ptrs.push_back(h.f[F_trc] + ((size_t)(k1m - 1) + (size_t)nt * 2 * h.kk) * np);
+      nl.push_back(h.kk);
+      it.push_back(1);
+    }
+    for (int f = 0; f < (int)ptrs.size(); f += 16) {
+      const int g = (int)ptrs.size() - f < 16 ? (int)ptrs.size() - f : 16;
+      if (int rc = st_xctilr_multi(c, g, ptrs.data() + f, nl.data() + f, 1, 1, it.data() + f)) return rc;
+    }
   }
   TimeScope ts(c, which == 1 ? "pbcor1" : "pbcor2");
   const int from_remap = which == 1 && c->in_sequence && c->remap_handed_over ? 1 : 0;

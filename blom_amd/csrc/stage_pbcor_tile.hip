@@ -281,6 +281,9 @@ int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf, int 
   // (with ltedtp = 'neutral' diffus is halo updates only: nothing to hand to it)
   const int move = !c->in_sequence || (which == 1 && h.P.ltedtp_opt == 2);
   (which == 1 ? c->pbcor1_handed_over : c->pbcor2_handed_over) = !move;
+  // pbcor2 inside blomgpu_step: tmsmt2, the next stage, rewrites dp of level m pointwise from what this pass would store and
+  // recomputes p: it takes the unscaled thicknesses from the work space and forms the factor itself (stage_simple.hip: k_tmsmt2_fac)
+  if (which == 2 && !move && c->tmsmt_fold) { c->pbcor2_dp_in_wk = true; return 0; }
   hipLaunchKernelGGL(k_pbc_rescale_from, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, which, m, offc, move);
   return 0;
 }

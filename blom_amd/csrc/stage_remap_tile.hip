@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   constexpr int STX = FOLD ? RT_TW - 1 : RT_TW, STY = FOLD ? RT_TH - 1 : RT_TH;
   const int x0 = (bx_ % ntx) * STX, y0 = (bx_ / ntx) * STY;            // first point of the tile in the padded plane
   const bool zero_old = (tsel & 4) != 0;
+  const bool lean = (tsel & 8) != 0;     // the mass, heat and salt fluxes go to uflx .. vsflx only: k_remap_update reads them there
   tsel &= 3;
   if (tsel) {
     // tsel 1: only the tiles that read no halo point (their 2-point rim lies inside 1..ii x 1..jj) -- they can run
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   // the flux planes of k_remap_update: W_FDU, W_FDV, W_FTU, W_FTV, .. alternate
   const int off = uface ? 0 : 1;
   if (!FOLD) {
-    if (base) {
+    if (base && !lean) {
       WK(V, W_FDU(ntr) + off)[fc + ok] = A.fd;
       WK(V, W_FTU(ntr) + off)[fc + ok] = A.ft;
       WK(V, W_FSU(ntr) + off)[fc + ok] = A.fs;
@@ -569,6 +570,7 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
   const bool zeroed = c->in_sequence && c->fluxes_zeroed;
   if (tsel == 0 || tsel == 2) c->fluxes_zeroed = false;             // (a split launch: tiles 1, then tiles 2)
   if (zeroed) tsel |= 4;
+  if (zeroed && !fold && c->lean_fluxes) tsel |= 8;
   const DevView &h = c->h;
   const int stx = fold ? RT_TW - 1 : RT_TW, sty = fold ? RT_TH - 1 : RT_TH;
   const int ntx = (h.ni + stx - 1) / stx, nty = (h.nj + sty - 1) / sty;

@@ -26,8 +26,32 @@ __global__ void k_init_fluxes(const DevView *__restrict__ Vp, int mm) {
   if (V.m[I_iv][c]) { V.f[F_vflx][o] = 0.; V.f[F_vtflx][o] = 0.; V.f[F_vsflx][o] = 0.; }
 }
 
+// inside blomgpu_step with advmth = 'remap' on the isopycnic coordinate: remap is the first stage that touches the flux arrays of
+// level m and STORES (0 + flux) at every u-face of rows 0..jj+1 and every v-face of columns 0..ii+1 (stage_remap_tile.hip, zero_old),
+// so only the faces beyond -- the u-points of row jj+2, the v-points of column ii+2 -- need their zeros from here
+__global__ void k_init_fluxes_ring(const DevView *__restrict__ Vp, int mm) {
+  const DevView &V = *Vp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  const int nu = V.ii + 3, nv = V.jj + 3;
+  const size_t off = (size_t)(k + mm) * V.nplane;
+  if (t < nu) {
+    const size_t c = IDX(V, t, V.jj + 2);
+    if (V.m[I_iu][c]) { V.f[F_uflx][c + off] = 0.; V.f[F_utflx][c + off] = 0.; V.f[F_usflx][c + off] = 0.; }
+  } else if (t < nu + nv) {
+    const size_t c = IDX(V, V.ii + 2, t - nu);
+    if (V.m[I_iv][c]) { V.f[F_vflx][c + off] = 0.; V.f[F_vtflx][c + off] = 0.; V.f[F_vsflx][c + off] = 0.; }
+  }
+}
+
 int st_init_fluxes(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
+  const DevView &h = c->h;
+  if (c->in_sequence && c->lean_fluxes && h.P.advmth == 0 && h.P.vcoord_tag == 1 && !c->remap_fold) {
+    hipLaunchKernelGGL(k_init_fluxes_ring, dim3((h.ii + h.jj + 6 + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, mm);
+    HIPCHK(c, hipGetLastError());
+    c->fluxes_zeroed = true;
+    return 0;
+  }
   hipLaunchKernelGGL(k_init_fluxes, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm);
   HIPCHK(c, hipGetLastError());
   c->fluxes_zeroed = c->in_sequence;
@@ -158,28 +182,34 @@ int launch_pscan(blomgpu_ctx *c, int off, int lo, int hi_off) {
 // tripolar grid alike.
 #define S2_PBFACO 0
 #define S2_PBFACN 1
-__global__ __launch_bounds__(64) void k_tmsmt2_fac(const DevView *__restrict__ Vp, int m, int nn) {
+#define S2_PBFACM 9
+// dp_in_wk (inside blomgpu_step): pbcor2 left its new, not yet rescaled layer thicknesses of level m in the work space (slot 0,
+// stage_pbcor_tile.hip) and did not launch its column pass: the factor pb / p(kk+1) of that pass (phy/mod_pbcor.F90:696-726) is
+// formed here with the two others, and k_tmsmt2 applies it where it reads dp of level m
+__global__ __launch_bounds__(64) void k_tmsmt2_fac(const DevView *__restrict__ Vp, int m, int nn, int dp_in_wk) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const double *dpo = V.f[F_dpold] + c + (size_t)nn * np, *dpn = V.f[F_dp] + c + (size_t)nn * np;
-  double pbfaco = 0., pbfacn = 0.;
+  const double *ndp = dp_in_wk ? WK(V, 0) + c : dpn;
+  double pbfaco = 0., pbfacn = 0., psum = V.f[F_p][c];
   const int kk = V.kk;
   for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
-    double a0[COLUMN_U], a1[COLUMN_U];
+    double a0[COLUMN_U], a1[COLUMN_U], a2[COLUMN_U];
 #pragma unroll
     for (int u = 0; u < COLUMN_U; u++) {
       const size_t o = (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np;
-      a0[u] = dpo[o]; a1[u] = dpn[o];
+      a0[u] = dpo[o]; a1[u] = dpn[o]; a2[u] = dp_in_wk ? ndp[o] : 0.;
     }
 #pragma unroll
     for (int u = 0; u < COLUMN_U; u++)
-      if (k0 + u < kk) { pbfaco = pbfaco + a0[u]; pbfacn = pbfacn + a1[u]; }
+      if (k0 + u < kk) { pbfaco = pbfaco + a0[u]; pbfacn = pbfacn + a1[u]; psum = psum + a2[u]; }
   }
   const double pbm = V.f[F_pb][c + (size_t)(m - 1) * np];
   WK2(V, S2_PBFACO)[c] = pbm / pbfaco;
   WK2(V, S2_PBFACN)[c] = pbm / pbfacn;
+  if (dp_in_wk) WK2(V, S2_PBFACM)[c] = pbm / psum;
 }
 
 // from_wk: pbcor2 left S, T and the tracers of level m in the work space (slots 1, 2, 3 + nt; stage_pbcor_tile.hip) instead of
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(64) void k_tmsmt2_fac(const DevView *__restrict__ V
 // ahead: another step follows within this call (blomgpu_step): its tmsmt1 (:230-277) would copy exactly the values written
 // here -- level m of this step is level n of the next -- so they go to dpold, told, sold, trcold as well and that tmsmt1 is
 // not launched (k_dpudpv does the same for dpuold, dpvold)
-__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int from_wk, int ahead) {
+__global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int from_wk, int ahead, int dp_in_wk) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -198,7 +228,7 @@ __global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int fro
   const double wts1 = V.P.wts1, wts2 = V.P.wts2;
   const size_t okm = c + (size_t)(k + mm) * np, okn = c + (size_t)(k + nn) * np, ok = c + (size_t)k * np;
   double pold = fmax2(0., V.f[F_dpold][okn] * pbfaco);
-  double pmid = fmax2(0., V.f[F_dp][okm]);
+  double pmid = fmax2(0., dp_in_wk ? WK(V, 0)[ok] * WK2(V, S2_PBFACM)[c] : V.f[F_dp][okm]);
   double pnew = fmax2(0., V.f[F_dp][okn] * pbfacn);
   const double dpm = wts1 * pmid + wts2 * (pold + pnew);
   V.f[F_dp][okm] = dpm;
@@ -234,11 +264,13 @@ __global__ void k_tmsmt_dpold_seam(const DevView *__restrict__ Vp, int mm) {
 }
 
 int st_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) {
-  hipLaunchKernelGGL(k_tmsmt2_fac, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn);
+  const int dp_in_wk = c->pbcor2_dp_in_wk ? 1 : 0;
+  c->pbcor2_dp_in_wk = false;
+  hipLaunchKernelGGL(k_tmsmt2_fac, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn, dp_in_wk);
   const int from_wk = c->pbcor2_handed_over ? 1 : 0;
   c->pbcor2_handed_over = false;
   const int ahead = c->in_sequence && c->tmsmt1_ahead ? 1 : 0;
-  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, nn, from_wk, ahead);
+  hipLaunchKernelGGL(k_tmsmt2, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm, nn, from_wk, ahead, dp_in_wk);
   HIPCHK(c, hipGetLastError());
   c->tmsmt1_done_ahead = ahead != 0;
   if (int rc = st_xctilr(c, c->h.f[F_dp] + (size_t)(k1m - 1) * c->h.nplane, 1, c->h.kk, 3, 3, 1)) return rc;
