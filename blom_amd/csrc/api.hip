@@ -2,6 +2,7 @@
 // See include/blomgpu.h for the contract and the reference interfaces it mirrors.
 #include "../../include/blomgpu.h"
 #include "blomgpu_internal.h"
+#include "pow_libm.h"
 #include <cstring>
 
 static thread_local std::string g_err;
@@ -260,7 +261,18 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   R(wuv1) R(wuv2) R(wts1) R(wts2) R(wbaro) R(bdmc1) R(bdmc2) R(iwdfac) R(nubmin) R(vland)
 #undef R
   if (s == "pref") { P.pref = v; set_eos(P); c->dirty = true; return 0; }
-  if (s == "swamxd") { c->swamxd = v; return 0; }                           // phy/mod_swabs.F90:179-183
+  if (s == "swamxd") { c->swamxd = v; return 0; }
+  // &DIFFUSION, as far as phy/mod_difest.F90's isopycnic routines read it (phy/mod_diffusion.F90:45-110)
+  if (s == "egc") { c->egc = v; return 0; }
+  if (s == "eggam") { c->eggam = v; return 0; }
+  if (s == "eglsmn") { c->eglsmn = v; return 0; }
+  if (s == "egmndf") { c->egmndf = v; return 0; }
+  if (s == "egmxdf") { c->egmxdf = v; return 0; }
+  if (s == "egidfq") { c->egidfq = v; return 0; }
+  if (s == "rhiscf") { c->rhiscf = v; return 0; }
+  if (s == "ri0") { c->ri0 = v; return 0; }
+  if (s == "tkepf") { c->tkepf = v; return 0; }
+  if (s == "bdml_logc") { c->bdml_logc = v; return 0; }                           // phy/mod_swabs.F90:179-183
   if (s == "brine_mlbase_frac") { c->brine_mlbase_frac = v; return 0; }     // phy/mod_forcing.F90:63
   // mod_mxlayr's and mod_niw's namelist variables (phy/mod_mxlayr.F90:58-68, phy/mod_niw.F90:38-45)
   // thermf: mod_forcing's namelist variables, mod_grid's area, mod_time's interpolation weight of the month
@@ -313,6 +325,27 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
 #undef R
   if (s == "csdiag") { c->csdiag = v != 0; return 0; }
+  if (s == "eddf2d") { c->eddf2d = v != 0; return 0; }
+  if (s == "edsprs") { c->edsprs = v != 0; return 0; }
+  if (s == "edanis") { c->edanis = v != 0; return 0; }
+  if (s == "redi3d") { c->redi3d = v != 0; return 0; }
+  if (s == "edfsmo") { c->edfsmo = v != 0; return 0; }
+  if (s == "rhsctp") {
+    if (v) return ctx_fail(c, " difest_lateral_iso: rhsctp = .true. (topographic Rhines scale: sin, atan2 of the flow direction) is not built on the device");
+    c->rhsctp = 0;
+    return 0;
+  }
+  if (s == "edritp_opt") {                            // 1 'shear', 2 'large scale' (phy/mod_diffusion.F90:113-116)
+    if (v != 1 && v != 2) return ctx_fail(c, " readnml_diffusion: edritp is unsupported!");
+    c->edritp_opt = v;
+    return 0;
+  }
+  if (s == "edwmth_opt") {                            // 1 'smooth', 2 'step'
+    if (v != 1 && v != 2) return ctx_fail(c, " readnml_diffusion: edwmth is unsupported!");
+    c->edwmth_opt = v;
+    return 0;
+  }
+  if (s == "difest_live") { c->difest_live = v != 0; return 0; }
   // thermf: mod_forcing's switches (phy/mod_forcing.F90:43-47), mod_time's months of the interpolation (l1mi..l5mi), mod_ben02's ntda
   if (s == "full_physics") { c->full_physics = v != 0; if (v) c->live_slopes = true; return 0; }
   if (s == "aptflx") { c->aptflx = v != 0; return 0; }
@@ -599,6 +632,28 @@ int blomgpu_exp(blomgpu_ctx *c, int n, const double *x, double *y) {
   (void)hipFree(d);
   return rc ? ctx_fail(c, "blomgpu_exp: copy or launch failed") : 0;
 }
+__global__ void k_pow_libm(int n, const double *x, const double *y, double *z) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) z[t] = pow_libm(x[t], y[t]);
+}
+int blomgpu_pow(blomgpu_ctx *c, int n, const double *x, const double *y, double *z) {
+  if (n <= 0) return 0;
+  double *d = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d, sizeof(double) * 3 * (size_t)n));
+  int rc = 0;
+  if (hipMemcpyAsync(d, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = 1;
+  if (hipMemcpyAsync(d + n, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = 1;
+  hipLaunchKernelGGL(k_pow_libm, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, d + n, d + 2 * (size_t)n);
+  if (hipMemcpyAsync(z, d + 2 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = 1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+  (void)hipFree(d);
+  return rc ? ctx_fail(c, "blomgpu_pow: copy or launch failed") : 0;
+}
+int blomgpu_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
+  (void)k1m; (void)k1n;
+  ctx_sync_view(c);
+  return st_difest_isobml(c, m, n, mm, nn);
+}
 int blomgpu_budget_sums(blomgpu_ctx *c, int ncall, int n, int nn) { ctx_sync_view(c); return st_budget_sums(c, ncall, n, nn); }
 // which: 0 sdp, 1 tdp, 2 trdp, 3 tkedp (phy/mod_budget.F90:50-59)
 int blomgpu_budget_get(blomgpu_ctx *c, int which, int ncall, int n, double *v) {
@@ -712,6 +767,7 @@ int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int n
   if (s == "cmnfld1") return blomgpu_cmnfld1(c, m, n, mm, nn, k1m, k1n);
   if (s == "halo_difest") return blomgpu_halo_difest(c, nn);
   if (s == "difest_isobml_pre") { ctx_sync_view(c); return st_difest_isobml_pre(c, m, n, mm, nn); }
+  if (s == "difest_isobml") { ctx_sync_view(c); return st_difest_isobml(c, m, n, mm, nn); }
   if (s == "niw_ke_tendency") { ctx_sync_view(c); return st_niw_ke_tendency(c, m, mm); }
   if (s == "halo_difest_hyb") return blomgpu_halo_difest_hyb(c, 0, k1n);
   if (s == "halo_difest_vert") return blomgpu_halo_difest_hyb(c, 1, k1n);
@@ -760,7 +816,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
     const char *run = c->live_slopes && !strcmp(st, "halo_cmnfld2") ? "cmnfld2" : st;
     // full_physics (blom_amd/stepper.py FULL_STAGES): the built part of difest_isobml, thermf and mxlayr in place of the two
     // pseudo-stages that stood in for them
-    if (c->full_physics && !strcmp(st, "halo_difest")) run = "difest_isobml_pre";
+    if (c->full_physics && !strcmp(st, "halo_difest")) run = c->difest_live ? "difest_isobml" : "difest_isobml_pre";
     if (c->full_physics && !strcmp(st, "mxlayr_tail")) {
       if (int rc = blomgpu_stage(c, "thermf", m, n, mm, nn, k1m, k1n)) {
         c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;

@@ -91,10 +91,17 @@
   X(hel_3d, K) X(her_3d, K) X(hevc1i, 1) X(hevc2i, 1) X(hevc3i, 1) X(hevc4i, 1) X(ssci, 1) X(scci, 1)    \
   X(d2mi, 1) X(tmc0i, 12) X(tmcli, 12) X(tmcri, 12) X(hevc1j, 1) X(hevc2j, 1) X(hevc3j, 1) X(hevc4j, 1)   \
   X(sscj, 1) X(sccj, 1) X(d2mj, 1) X(tmc0j, 12) X(tmclj, 12) X(tmcrj, 12)                                                                  \
+  /* difest_isobml's diffusivity estimates (stage_difest_iso.hip): mod_grid's latitude, topographic beta and grid angles; mod_difest's \
+     rig, du2l, drhol; mod_tke's Prod, Buoy, Shear2, L_scale; mod_tidaldissip's twedon, mod_seaice's ficem; and two planes the host     \
+     fills with its own libm at initialisation: the tidal mixing length scale (a tanh of the latitude, mod_difest.F90:2926-2927) and      \
+     log(2 bvf0 / max(1e-9, |f|)) of the latitude dependent background mixing (:2747-2750) */                                              \
+  X(plat, 1) X(betatp, 1) X(cosang, 1) X(sinang, 1) X(hangle, 1) X(twedon, 1) X(ficem, 1) X(tdmls, 1) X(bdmlq, 1)                          \
+  X(rig, K + 1) X(du2l, K) X(drhol, K) X(Prod, K) X(Buoy, K) X(Shear2, K) X(L_scale, K)                                                    \
   /* (K+1)-level work fields (phip of pgforc_geopotential, ...) */                       \
   X(wkp0, K + 1) X(wkp1, K + 1)
 
-#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1) X(cppm_sti, 1) X(cppm_stj, 1) X(mpack, 1)
+#define BLOM_INT_FIELDS(X) X(ip, 1) X(iu, 1) X(iv, 1) X(iq, 1) X(kfpla, 2) X(kming, 1) X(cppm_sti, 1) X(cppm_stj, 1) X(mpack, 1) \
+  /* mod_difest: kmax, kfil, msku, mskv (mod_difest.F90:97-100) */ X(dfe_kmax, 1) X(dfe_kfil, 1) X(msku, K) X(mskv, K)
 
 enum FieldId {
 #define X(name, lev) F_##name,
@@ -319,6 +326,12 @@ struct blomgpu_ctx {
   // inside blomgpu_step (remap): init_fluxes only zeroes the faces remap does not store, the tile kernel's mass / heat / salt fluxes
   // go to uflx .. vsflx alone and k_remap_update reads them there (12 F of stores less per step); 0: the work planes of rounds 1-4
   int lean_fluxes = 1;
+  // difest_isobml's diffusivity estimates (stage_difest_iso.hip): the variables of &DIFFUSION that phy/mod_difest.F90 reads
+  // (phy/mod_diffusion.F90:45-110), with the values of the reference's own tests/fuk95/limits as defaults
+  double egc = 0., eggam = 200., eglsmn = 4000., egmndf = 0., egmxdf = 1500., egidfq = 1., rhiscf = 0., ri0 = 1.2, tkepf = 0.;
+  double bdml_logc = 0.;         // log(2 bvf0 / cori30) of the host's libm (set with the plane bdmlq when bdmldp is on)
+  int eddf2d = 0, edsprs = 1, edanis = 0, redi3d = 0, rhsctp = 0, edfsmo = 0, edritp_opt = 2, edwmth_opt = 1;
+  int difest_live = 0;           // blomgpu_step: 1 = difest_isobml estimates difint, difiso, difdia, difwgt every step (full_physics)
   hipStream_t side = nullptr;    // the second stream
   hipEvent_t ev_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   DevView hv[4];                 // host copies of the alternative views (hv[0] unused: the main view is h)
@@ -380,6 +393,7 @@ int st_xcsum_dev(blomgpu_ctx *, const double *a, int itype, int slot, double **s
 int st_thermf(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);   // stage_thermf.hip
 int st_niw_ke_tendency(blomgpu_ctx *, int m, int mm);                           // stage_difest.hip
 int st_difest_isobml_pre(blomgpu_ctx *, int m, int n, int mm, int nn);
+int st_difest_isobml(blomgpu_ctx *, int m, int n, int mm, int nn);               // stage_difest_iso.hip: the whole routine
 int st_budget_sums(blomgpu_ctx *, int ncall, int n, int nn);
 int st_barotp(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
 int st_eddtra(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);

@@ -1,0 +1,781 @@
+// difest_isobml's diffusivity estimates -- phy/mod_difest.F90:735-809 (difest_isobml), :353-586 (difest_common_iso), :2629-3084
+// (difest_vertical_iso), :2040-2627 (difest_lateral_iso): what makes difint, difiso, difdia, difwgt -- the coefficients of eddtra,
+// diffus, diapfl and momtum -- follow the state every step.
+//
+// Every routine walks columns: the Richardson number needs running values down a column (tup), the Eady growth rate and the
+// vertical averages are sums over a column's layers in the reference's order, the TKE closure is pointwise in k but sits inside
+// those loops.  One thread per column (u-, v- or p-point), the planes of 64 neighbouring columns contiguous; the reference's
+// per-row 1-D temporaries (cr, bcrrd, dps, egrs ..) are registers, its (i,k) temporaries (du2, dv2, bvfsq, bvf, egr, anisok) planes of
+// the work space.
+//   k_dfi_kmax_kfil   kmax, kfil of the columns 0..ii+1 x 0..jj+1                                   (:366-390; kfil's halo :392-411)
+//   k_dfi_uv2         squared vertical velocity differences at u- and v-columns, msku, mskv         (:413-511)
+//   k_dfi_common      drhol, du2l, rig                                                              (:513-560)
+//   k_dfi_vertical    Brunt-Vaisala frequency, the one-equation TKE closure's source step (or the Richardson number
+//                     parameterisation), background / tidal / weak-stability / near-inertial mixing -> difdia, trc(tke, gls)
+//   k_dfi_lateral     Rossby radius, difwgt, Eady growth rate (shear or large scale), Eden-Greatbatch diffusivities with the
+//                     suppression options -> difint, difiso; then the halo updates (and the optional smoothing) of :2577-2614
+// Real powers and exponentials are the host libm's bits (pow_libm.h, exp_libm.h); tanh of the latitude (tidal mixing length
+// scale, :2926-2927) and log of the Coriolis parameter (bdmldp, :2747-2750) depend on the grid only: the host evaluates them once
+// with its own libm into the planes tdmls and bdmlq.  Not built, refused by the option setters: rhsctp (sin, atan2 of the flow
+// direction), the two-equation closure (use_GLS).
+// Parity: cross-checked against the reference's REAL mod_difest.F90 compiled against interface-only stand-ins for the CVMix
+// modules it imports but does not call on this path (oracle/xcheck/cvmix_standin.F90; builds *_xdf) -- a cross-check, not a pin.
+// Roofline: HBM, ~60 F of column traffic; the kernels are bound by their k-serial chains like the other column kernels.
+#include "blomgpu_internal.h"
+#include "../../include/blomgpu.h"
+#include "eos.h"
+#include "pow_libm.h"
+#include <cmath>
+
+#define PLANE_IJ(V)                                                        \
+  unsigned bx_, by_;                                                       \
+  xcd_block(bx_, by_);                                                     \
+  const int t_ = bx_ * blockDim.x + threadIdx.x;                           \
+  (void)by_;                                                               \
+  if (t_ >= (V).nplane) return;                                            \
+  const int i = t_ % (V).ni - (NBDY - 1), j = t_ / (V).ni - (NBDY - 1);    \
+  const size_t c = t_;                                                     \
+  (void)i; (void)j; (void)c
+
+#define GRAV 9.806
+#define ALPHA0 1.e-3
+#define PI_BLOM 3.1415926536      // phy/mod_constants.F90:40
+#define EPSILP 1.e-12
+#define ONEM 9806.
+#define DPBMIN 98.06              // onecm, :174
+#define DPTMIN 9806.              // `integer, parameter :: dptmin = onem`, :173
+#define DRHOMN 6.e-3
+#define NU0 1.e-5
+#define NUS0 5.e-3
+#define NUG0 2.5e-1
+#define DRHO0 6.e-3
+#define NULS0 5.e-2
+#define DMXEFF .2
+#define TDMQ (1. / 3.)
+#define TKEPLS (20. * ONEM)
+#define NIWLS (300. * ONEM)
+#define CORI30 7.2722e-5
+#define DPGC (300. * ONEM)
+#define DPGRAV (100. * ONEM)
+#define DPDIAV (100. * ONEM)
+#define DPDDAV (10. * ONEM)
+#define DPNBAV (250. * ONEM)
+#define USTMIN .001
+#define KAPPA .4
+#define BFEPS 1.e-16
+#define SLEPS .1
+#define ZETAS (-1.)
+#define CPSEMIN (-0.2)
+#define URMSEMIN 0.05
+#define AS_ (-28.86)
+#define CS_ 98.96
+// mod_tke's parameters, phy/mod_tke.F90:36-63
+#define GLS_CMU0 .527
+#define PR_T 1.
+#define GLS_C1 1.44
+#define GLS_C2 1.92
+#define GLS_C3PLUS 1.
+#define GLS_C3MINUS (-.63)
+#define GLS_GH0 .0329
+#define GLS_GHMIN (-.28)
+#define GLS_GHCRI .03
+#define LS_UNLMT_MIN 1.e-8
+
+// work-space slots (fields of kk levels)
+enum { W_DU2 = 0, W_DV2, W_BVFSQ, W_BVF, W_EGR, W_ANISOK, W_SM1, W_SM2, W_NSLOT };
+
+struct TkeC {            // initke's derived constants, phy/mod_tke.F90:133-160
+  double sqrt2, cmu_fac1, cmu_fac2, cmu_fac3, tke_exp1, gls_exp1, gls_fac6, s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5, cmu0p3;
+};
+struct DfePar {
+  double egc, eggam, eglsmn, egmndf, egmxdf, egidfq, rhiscf, ri0, tkepf, niwgf, niwbf, niwlf, bdml_logc;
+  int eddf2d, edsprs, edanis, redi3d, edritp, edwmth, use_tke, itke, igls;
+  TkeC T;
+};
+
+static TkeC tke_consts() {
+  // the reference's statements evaluated as its compiler does: real powers through the libm's pow (the operands are PARAMETERs, so
+  // flang folds them at compile time -- with the pow of the machine it runs on), integer powers by repeated squaring
+  const double L1 = .107, L2 = .0032, L3 = .0864, L4 = .12, L5 = 11.9, L6 = .4, L7 = .0, L8 = .48;
+  const double gls_p = 3., gls_m = 1.5, gls_n = -1.;
+  TkeC t;
+  t.sqrt2 = std::sqrt(2.);
+  t.cmu_fac1 = std::pow(GLS_CMU0, -gls_p / gls_n);
+  t.cmu_fac2 = std::pow(GLS_CMU0, 3. + gls_p / gls_n);
+  t.cmu_fac3 = t.sqrt2;
+  t.tke_exp1 = gls_m / gls_n;
+  t.gls_exp1 = 1. / gls_n;
+  const double c2 = GLS_CMU0 * GLS_CMU0;
+  t.gls_fac6 = 8. / (c2 * (c2 * c2));
+  t.cmu0p3 = GLS_CMU0 * c2;
+  t.s0 = 1.5 * L1 * (L5 * L5);
+  t.s1 = -L4 * (L6 + L7) + 2. * L4 * L5 * (L1 - 1. / 3. * L2 - L3) + 1.5 * L1 * L5 * L8;
+  t.s2 = -3. / 8. * L1 * (L6 * L6 - L7 * L7);
+  t.s4 = 2. * L5;
+  t.s5 = 2. * L4;
+  t.s6 = 2. / 3. * L5 * (3. * (L3 * L3) - L2 * L2) - .5 * L5 * L1 * (3. * L3 - L2) + .75 * L1 * (L6 - L7);
+  t.b0 = 3. * (L5 * L5);
+  t.b1 = L5 * (7. * L4 + 3. * L8);
+  t.b2 = (L5 * L5) * (3. * (L3 * L3) - L2 * L2) - .75 * (L6 * L6 - L7 * L7);
+  t.b3 = L4 * (4. * L4 + 3. * L8);
+  t.b4 = L4 * (L2 * L6 - 3. * L3 * L7 - L5 * (L2 * L2 - L3 * L3)) + L5 * L8 * (3. * (L3 * L3) - L2 * L2);
+  t.b5 = .25 * (L2 * L2 - 3. * (L3 * L3)) * (L6 * L6 - L7 * L7);
+  return t;
+}
+
+// ---- :366-390 ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dfi_kmax_kfil(const DevView *__restrict__ Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
+  int *kmax = V.m[I_dfe_kmax], *kfil = V.m[I_dfe_kfil];
+  if (!V.m[I_ip][c]) { kmax[c] = 0; return; }
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
+  int km = 1;
+  for (int k0 = 3; k0 <= kk; k0 += COLUMN_U) {
+    double a[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) a[u] = dp[(size_t)((k0 + u <= kk ? k0 + u : kk) - 1) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++)
+      if (k0 + u <= kk && a[u] > DPBMIN) km = k0 + u;
+  }
+  kmax[c] = km;
+  const int kf = V.m[I_kfpla][c + (size_t)(n - 1) * np];
+  int r;
+  if (kf >= km) r = kf + 1;
+  else {
+    const double *sr = V.f[F_sigmar] + c;
+    if (V.f[F_sigma][c + (size_t)(kf - 1 + nn) * np] < .5 * (sr[(size_t)(kf - 1) * np] + sr[(size_t)kf * np])) r = kf + 1;
+    else r = kf + 2;
+  }
+  kfil[c] = r;
+}
+
+// :392-411: kfil of the interior through util1 and its halo update back into kfil on 0..ii+1
+__global__ void k_dfi_kfil_util(const DevView *__restrict__ Vp, int back) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (!V.m[I_ip][c]) return;
+  int *kfil = V.m[I_dfe_kfil];
+  if (!back) {
+    if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii) V.f[F_util1][c] = (double)kfil[c];
+  } else if (j >= 0 && j <= V.jj + 1 && i >= 0 && i <= V.ii + 1)
+    kfil[c] = (int)lround(V.f[F_util1][c]);
+}
+
+// ---- :413-511: blockIdx.y = 0 the u-columns (j = 1..jj, i = 1..ii+1), 1 the v-columns (j = 1..jj+1, i = 1..ii) -------------
+__global__ __launch_bounds__(64) void k_dfi_uv2(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  const bool isv = by_ == 1;
+  if (isv ? (j < 1 || j > V.jj + 1 || i < 1 || i > V.ii) : (j < 1 || j > V.jj || i < 1 || i > V.ii + 1)) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  double *d2 = WK(V, isv ? W_DV2 : W_DU2) + c;
+  int *msk = V.m[isv ? I_mskv : I_msku] + c;
+  if (!V.m[isv ? I_iv : I_iu][c]) {
+    for (int k = 0; k < kk; k++) { d2[(size_t)k * np] = 0.; msk[(size_t)k * np] = 0; }
+    return;
+  }
+  const double *dpz = V.f[isv ? F_dpv : F_dpu] + c + (size_t)nn * np, *vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np;
+  const int *kfil = V.m[I_dfe_kfil];
+  const int ka = kfil[isv ? c - V.ni : c - 1], kb = kfil[c];
+  const int kf = isv ? (ka > kb ? ka : kb) : (ka < kb ? ka : kb);       // max for v (:436), min for u (:482)
+  int klpl = 1, kfpl = kk + 1;
+  for (int k0 = 3; k0 <= kk; k0 += COLUMN_U) {
+    double a[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) a[u] = dpz[(size_t)((k0 + u <= kk ? k0 + u : kk) - 1) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++)
+      if (k0 + u <= kk) {
+        const int k = k0 + u;
+        if (a[u] > DPBMIN) klpl = k;
+        if (k >= 4 && k >= kf && a[u] > DPTMIN && kfpl == kk + 1) kfpl = k;      // the smallest such k (the reference walks k = kk..4)
+      }
+  }
+  double tup = 0., vk = vel[0];
+  for (int k = 1; k <= kk; k++) {
+    const double vn = k < kk ? vel[(size_t)k * np] : 0.;
+    double d = 0.;
+    int m = 0;
+    if (k >= kfpl && k <= klpl && klpl - kfpl >= 1) {
+      if (k == kfpl) {
+        double q = vn - vk;
+        q = q * q;
+        d = q;
+        tup = q;
+      } else if (k < klpl) {
+        double q = vn - vk;
+        q = q * q;
+        d = .5 * (tup + q);
+        tup = q;
+      } else
+        d = tup;
+      m = 1;
+    }
+    d2[(size_t)(k - 1) * np] = d;
+    msk[(size_t)(k - 1) * np] = m;
+    vk = vn;
+  }
+}
+
+// ---- :513-560 ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dfi_common(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
+  if (km - kf < 1) return;
+  const size_t np = V.nplane;
+  const int kk = V.kk, ni = V.ni;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
+  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
+  const double *du2 = WK(V, W_DU2) + c, *dv2 = WK(V, W_DV2) + c;
+  const int *msku = V.m[I_msku] + c, *mskv = V.m[I_mskv] + c;
+  double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *rig = V.f[F_rig] + c;
+  double tup = 0.;
+  const int k1 = kf > 4 ? kf : 4;
+  for (int k = k1; k <= km && k <= kk; k++) {
+    const size_t o = (size_t)(k - 1) * np;
+    double dr;
+    if (k < km) {
+      const double pk1 = p[(size_t)k * np];
+      const double q = fmax2(0., eos::rho(pk1, temp[o + np], saln[o + np]) - eos::rho(pk1, temp[o], saln[o]));
+      if (k == kf) dr = q;
+      else dr = 2. * tup * q / fmax2(1.e-11, tup + q);
+      tup = q;
+    } else
+      dr = tup;
+    drhol[o] = dr;
+    const int mu0 = msku[o], mu1 = msku[o + 1], mv0 = mskv[o], mv1 = mskv[o + ni];
+    const double d2 = ((double)mu0 * du2[o] + (double)mu1 * du2[o + 1]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) +
+                      ((double)mv0 * dv2[o] + (double)mv1 * dv2[o + ni]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1);
+    du2l[o] = d2;
+    rig[o] = ALPHA0 * ALPHA0 * fmax2(DRHOMN, dr) * dp[o] / fmax2(1.e-13, d2);
+  }
+}
+
+// ---- difest_vertical_iso, :2629-3084 ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dfi_vertical(const DevView *__restrict__ Vp, DfePar D, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
+  const bool any = km - kf >= 1;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const Params &P = V.P;
+  const TkeC &T = D.T;
+  const double *p = V.f[F_p] + c, *dp = V.f[F_dp] + c + (size_t)nn * np;
+  const double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *rig = V.f[F_rig] + c;
+  double *difdia = V.f[F_difdia] + c;
+  double *bvfsq = WK(V, W_BVFSQ) + c, *bvf = WK(V, W_BVF) + c;
+  double *Buoy = V.f[F_Buoy] + c, *Shear2 = V.f[F_Shear2] + c, *Prod = V.f[F_Prod] + c, *Lsc = V.f[F_L_scale] + c;
+  double *tke = nullptr, *gls = nullptr;
+  if (D.use_tke) {
+    tke = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
+    gls = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.igls - 1) * 2 * kk) * np;
+  }
+  const double delt1 = P.delt1;
+  const double pbot = p[(size_t)kk * np];
+#define PL(k) p[(size_t)((k) - 1) * np]
+  // Brunt-Vaisala frequency, :2653-2709
+  double bvfbot = 0., dps = 0.;
+  if (any)
+    for (int k = kf > 4 ? kf : 4; k <= km && k <= kk; k++) {
+      const size_t o = (size_t)(k - 1) * np;
+      const double dpk = dp[o];
+      const double b2 = GRAV * GRAV * fmax2(DRHOMN, drhol[o]) / fmax2(EPSILP, dpk);
+      const double b = sqrt(b2);
+      bvfsq[o] = b2;
+      bvf[o] = b;
+      if (D.use_tke) {
+        if (dpk > DPBMIN) {
+          const double dd = difdia[o];
+          Buoy[o] = -dd * b2;
+          const double h = fmax2(ONEM, dpk) * ALPHA0 / GRAV;
+          const double s2 = fmax2(1.e-13, du2l[o]) / (h * h);
+          Shear2[o] = s2;
+          Prod[o] = dd * PR_T * s2;
+        } else {
+          Buoy[o] = 0.;
+          Shear2[o] = 1.e-9;
+          Prod[o] = 0.;
+        }
+      }
+      const double q = fmax2(0., PL(k + 1) - fmax2(pbot - DPNBAV, PL(k)));
+      if (q > 0.) {
+        bvfbot = bvfbot + b * q;
+        dps = dps + q;
+      }
+    }
+  if (dps > 0.) bvfbot = bvfbot / dps;
+  // diapycnal diffusivity, :2715-2977
+  difdia[0] = NU0;
+  double dfddsu = 0., dfddsl = 0.;
+  dps = 0.;
+  const double ficem = V.f[F_ficem][c], ustar = V.f[F_ustar][c];
+  const double pkf = kf <= kk + 1 ? PL(kf < 1 ? 1 : kf) : 0.;
+  for (int k = 2; k <= kk; k++) {
+    const size_t o = (size_t)(k - 1) * np;
+    if (any && k >= kf && k <= km) {
+      const double dpk = dp[o], b2 = bvfsq[o];
+      double nub;
+      if (P.bdmtyp == 1) nub = P.bdmc1 / bvf[o];
+      else if (P.bdmtyp == 2) nub = P.bdmc2;
+      else nub = 0.;
+      if (P.iwdflg == 1) nub = nub * (1. + (P.iwdfac - 1.) * ficem);
+      if (P.bdmldp) {
+        const double q = fmax2(1.e-9, fabs(V.f[F_coriop][c]));
+        nub = nub * q / CORI30 * V.f[F_bdmlq][c] / D.bdml_logc;
+      }
+      nub = fmax2(P.nubmin, nub);
+      double nus;
+      if (!D.use_tke) {
+        const double ri = rig[o];
+        if (ri < D.ri0) {                                                         // :2756-2775
+          double q = (pbot - PL(k) + .5 * dpk) / fmin2(DPGC, .5 * pbot);
+          q = fmax2(0., 1. - q * q);
+          q = q * q * q;
+          nus = q * NUG0 + (1. - q) * NUS0;
+          q = ri / D.ri0;
+          q = fmax2(0., 1. - q * q);
+          nus = nus * q * q * q;
+        } else
+          nus = 0.;
+      } else {                                                                    // the one-equation closure, :2776-2921
+        const double gls_c3 = b2 > 0. ? GLS_C3MINUS : GLS_C3PLUS;
+        const double prod = Prod[o], buoy = Buoy[o];
+        double tk = tke[o], gl = fmax2((GLS_C1 * prod + gls_c3 * buoy) / GLS_C2, GLS_PSI_MIN);
+        // (the real powers trc**(1.5+gls_m/gls_n), trc**(-1./gls_n) have the exponents 0 and 1: the compiler folds them)
+        const double tke_epsilon = T.cmu_fac2 * gl;
+        const double tke_q = tke_epsilon / tk;
+        if (prod + buoy >= 0.) tk = (tk + delt1 * (prod + buoy)) / (1. + delt1 * tke_q);
+        else {
+          tk = (tk + delt1 * prod) / (1. + delt1 * (tke_q - (buoy / tk)));
+          tk = fmax2(tk, TKE_MIN);
+        }
+        if (D.tkepf > 0.) {                                                        // :2840-2850
+          double q;
+          if (dpk < EPSILP) q = exp_libm(-PL(k) / TKEPLS);
+          else q = TKEPLS * (exp_libm(-PL(k) / TKEPLS) - exp_libm(-PL(k + 1) / TKEPLS)) / dpk;
+          tk = tk + 67.83 * D.tkepf * q * (ustar * ustar);
+        }
+        if (dpk < EPSILP) { tk = TKE_MIN; gl = GLS_PSI_MIN; }
+        tke[0] = TKE_MIN; tke[np] = TKE_MIN;
+        gls[0] = GLS_PSI_MIN; gls[np] = GLS_PSI_MIN;
+        if (k == km) {                                                             // bottom boundary condition, :2863-2872
+          const double ust = fmax2(V.f[F_ustarb][c], USTMIN);
+          const double r = ust / GLS_CMU0;
+          tk = fmax2(TKE_MIN, r * r);
+        }
+        tke[o] = tk;
+        gls[o] = gl;
+        const double ls_unlmt = fmax2(LS_UNLMT_MIN, T.cmu_fac1 * pow_libm(gl, T.gls_exp1) * pow_libm(tk, -T.tke_exp1));
+        double ls;
+        if (b2 > 0.) ls = fmin2(ls_unlmt, pow_libm(tk, 1.5) * (1. / gl));
+        else ls = ls_unlmt;
+        double gh = fmin2(GLS_GH0, -(b2 * ls * ls) / (2. * tk));                    // Canuto-A stability functions, :2892-2908
+        const double ghc = gh - GLS_GHCRI;
+        gh = fmin2(gh, (gh - ghc * ghc) / (gh + GLS_GH0 - 2. * GLS_GHCRI));
+        gh = fmax2(gh, GLS_GHMIN);
+        gh = fmin2(gh, GLS_GH0);
+        const double f6 = T.gls_fac6, f62 = f6 * f6;
+        double gm = (T.b0 / f6 - T.b1 * gh + T.b3 * f6 * (gh * gh)) / (T.b2 - T.b4 * f6 * gh);
+        gm = fmin2(gm, Shear2[o] * ls * ls / (2. * tk));
+        const double cff = T.b0 - T.b1 * f6 * gh + T.b2 * f6 * gm + T.b3 * f62 * (gh * gh) - T.b4 * f62 * gh * gm + T.b5 * f62 * gm * gm;
+        double sh = (T.s4 - T.s5 * f6 * gh + T.s6 * f6 * gm) / cff;
+        sh = fmax2(sh, 0.);
+        sh = sh * T.cmu_fac3 / T.cmu0p3;
+        const double ql = T.sqrt2 * ls * sqrt(tk);
+        nus = fmin2(sh * ql, 4.05 * NUG0);
+        Lsc[o] = fmax2(ls, LS_UNLMT_MIN);
+      }
+      double nut;                                                                  // tidally driven mixing, :2924-2937
+      {
+        const double q = V.f[F_tdmls][c];
+        double vsf;
+        if (dpk < EPSILP) vsf = exp_libm(PL(k) / q) / (q * (exp_libm(pbot / q) - 1.));
+        else vsf = (exp_libm(PL(k + 1) / q) - exp_libm(PL(k) / q)) / (dpk * (exp_libm(pbot / q) - 1.));
+        nut = GRAV * TDMQ * DMXEFF * V.f[F_twedon][c] * bvfbot * vsf / b2;
+      }
+      double nuls;                                                                 // weak local stability, :2940-2946
+      const double dr = drhol[o];
+      if (dr < DRHO0) {
+        double q = dr / DRHO0;
+        q = fmax2(0., 1. - q * q);
+        nuls = NULS0 * q * q * q;
+      } else
+        nuls = 0.;
+      const double dd = nub + nus + nut + nuls;
+      difdia[o] = dd;
+      const double q = fmax2(0., fmin2(pkf + DPDDAV, PL(k + 1)) - PL(k));
+      dps = dps + q;
+      dfddsu = dfddsu + nub * q;
+      dfddsl = dfddsl + dd * q;
+    } else {
+      difdia[o] = difdia[o - np];
+      if (D.use_tke) {
+        tke[o] = tke[o - np];
+        Lsc[o] = Lsc[o - np];
+      }
+    }
+  }
+  if (dps > 0.) { dfddsu = dfddsu / dps; dfddsl = dfddsl / dps; }
+  else { dfddsu = NU0; dfddsl = NU0; }
+  const double p3 = PL(3);
+  for (int k = 2; k <= kk - 1; k++)                                                // :2991-3007
+    if (k < kf) {
+      if (k > 2 && kf <= kk && PL(kf < kk ? kf : kk) - p3 > EPSILP) {
+        const double q = .5 * (PL(k + 1) + PL(k));
+        difdia[(size_t)(k - 1) * np] = ((q - p3) * dfddsl + (pkf - q) * dfddsu) / (pkf - p3);
+      } else
+        difdia[(size_t)(k - 1) * np] = dfddsu;
+    }
+  if (any) {                                                                       // near-inertial waves, :3011-3032
+    const double idk = V.f[F_idkedt][c];
+    for (int k = 2; k <= kk - 1 && k <= km; k++) {
+      const size_t o = (size_t)(k - 1) * np;
+      const double q = NIWLS, dpk = dp[o];
+      double vsf;
+      if (k == 2 || dpk < EPSILP) vsf = exp_libm((p3 - PL(k + 1)) / q) / (q * (1. - exp_libm((p3 - pbot) / q)));
+      else vsf = (exp_libm((p3 - PL(k)) / q) - exp_libm((p3 - PL(k + 1)) / q)) / (dpk * (1. - exp_libm((p3 - pbot) / q)));
+      const int kb = k > kf ? k : kf;
+      const double nusm = GRAV * D.niwgf * (1. - D.niwbf) * D.niwlf * DMXEFF * idk * vsf / (ALPHA0 * bvfsq[(size_t)(kb - 1) * np]);
+      difdia[o] = difdia[o] + nusm;
+    }
+  }
+  {                                                                                // the lower interface of the top layer, :3035-3066
+    const double ust = fmax2(USTMIN, ustar);
+    const double bf = V.f[F_buoyfl][c];
+    const double mols = ust * ust * ust / (KAPPA * copysign(fmax2(fabs(bf), BFEPS), -bf));
+    const double p1 = PL(1);
+    const double h = (p3 - p1) / ONEM;
+    const double sg = (PL(2) - p1) / (p3 - p1);
+    double phis;
+    if (mols < 0.) {
+      const double zeta = fmin2(SLEPS, sg) * h / mols;
+      if (zeta > ZETAS) phis = pow_libm(1. - 16. * zeta, -1. / 2.);
+      else phis = pow_libm(AS_ - CS_ * zeta, -(1. / 3.));
+    } else {
+      const double zeta = sg * h / mols;
+      phis = 1. + 5. * zeta;
+    }
+    const double ws = KAPPA * ust / phis;
+    difdia[0] = h * ws * sg * ((1. - sg) * (1. - sg));
+  }
+#undef PL
+}
+
+// ---- difest_lateral_iso, :2040-2575 -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ Vp, DfePar D, int n, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const size_t np = V.nplane, on = (size_t)(n - 1) * np;
+  const int kk = V.kk, ni = V.ni;
+  const Params &P = V.P;
+  const int *kmaxa = V.m[I_dfe_kmax];
+  const int kf = V.m[I_dfe_kfil][c], km = kmaxa[c];
+  const bool any = km - kf >= 1;
+  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
+  double *difint = V.f[F_difint] + c, *difiso = V.f[F_difiso] + c;
+  double *egr = WK(V, W_EGR) + c, *anisok = WK(V, W_ANISOK) + c;
+  const double *rig = V.f[F_rig] + c;
+  const double *u = V.f[F_u] + c + (size_t)nn * np, *v = V.f[F_v] + c + (size_t)nn * np;
+  const double *dpu = V.f[F_dpu] + c + (size_t)nn * np, *dpv = V.f[F_dpv] + c + (size_t)nn * np;
+  const int *msku = V.m[I_msku] + c, *mskv = V.m[I_mskv] + c;
+#define PL(k) p[(size_t)((k) - 1) * np]
+  const double pbot = PL(kk + 1);
+  // first baroclinic Rossby radius (WKB, Chelton et al. 1998), :2065-2107
+  const int kfp = V.m[I_kfpla][c + on];
+  double pup = .5 * (3. * PL(3) - PL((kk < kfp ? kk : kfp) + 1));
+  double tup = temp[np], sup = saln[np], cr = 0.;
+  for (int k = 3; k <= kk; k++)
+    if (k >= kfp) {
+      const size_t o = (size_t)(k - 1) * np;
+      double plo;
+      if (pbot - PL(k + 1) < EPSILP) plo = pbot;
+      else plo = .5 * (PL(k) + PL(k + 1));
+      const double tlo = temp[o], slo = saln[o], pk = PL(k);
+      cr = cr + sqrt(fmax2(0., (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) * (plo - pup)));
+      pup = plo;
+      tup = tlo;
+      sup = slo;
+    }
+  const double coriop = V.f[F_coriop][c], betafp = V.f[F_betafp][c];
+  cr = ALPHA0 * cr / PI_BLOM;
+  const double bcrrd = sqrt(cr * cr / fmax2(coriop * coriop + 2. * betafp * cr, 1.e-24));
+  const double afeql = fmax2(fabs(coriop), sqrt(2. * betafp * cr));
+  double difwgt;
+  {                                                                                // :2111-2131
+    const double sx = V.f[F_scpx][c], sy = V.f[F_scpy][c];
+    const double q = bcrrd / sqrt(.5 * (sx * sx + sy * sy));
+    if (D.edwmth == 1) {
+      difwgt = 1. / (1. + .25 * (q * q * q * q));        // q**4 as the reference's compiler expands it at run time: ((q q) q) q
+    } else
+      difwgt = q <= 2. ? 1. : 0.;
+    V.f[F_difwgt][c] = difwgt;
+  }
+  // Eady growth rate, :2160-2257
+  const bool sa = D.edsprs || D.edanis;
+  double egrs = 0., dps = 0.;
+  if (D.edritp == 1) {
+    if (any)
+      for (int k = kf > 2 ? kf : 2; k <= km && k <= kk; k++) {
+        const size_t o = (size_t)(k - 1) * np;
+        const double e = afeql / sqrt(rig[o] + D.eggam);
+        egr[o] = e;
+        if (sa) {
+          double q;
+          if (D.eddf2d) q = fmax2(0., PL(k + 1) - PL(k));
+          else q = fmax2(0., fmin2(PL(kf) + DPGRAV, PL(k + 1)) - PL(k));
+          dps = dps + q;
+          egrs = egrs + e * q;
+        }
+      }
+  } else if (any) {
+    const double *nx = V.f[F_nnslpx] + c, *ny = V.f[F_nnslpy] + c;
+    const int kmw = kmaxa[c - 1], kme = kmaxa[c + 1], kms = kmaxa[c - ni], kmn = kmaxa[c + ni];
+    auto slope2 = [&](int kq, bool ge) {          // the squared large scale slope x buoyancy frequency at interface kq, :2190-2205 / :2212-2227
+      const size_t o = (size_t)(kq - 1) * np;
+      const bool w = ge ? kmw >= kq : kmw > kq - 1, e = ge ? kme >= kq : kme > kq - 1;
+      const bool s = ge ? kms >= kq : kms > kq - 1, nn_ = ge ? kmn >= kq : kmn > kq - 1;
+      double q;
+      if (w && e) { const double t = nx[o] + nx[o + 1]; q = .25 * (t * t); }
+      else if (w) q = nx[o] * nx[o];
+      else if (e) q = nx[o + 1] * nx[o + 1];
+      else q = 0.;
+      if (s && nn_) { const double t = ny[o] + ny[o + ni]; q = q + .25 * (t * t); }
+      else if (s) q = q + ny[o] * ny[o];
+      else if (nn_) q = q + ny[o + ni] * ny[o + ni];
+      return q;
+    };
+    double egrup = sqrt(slope2(kf, true));
+    for (int k = kf > 2 ? kf : 2; k <= km && k <= kk; k++) {
+      const size_t o = (size_t)(k - 1) * np;
+      if (k < km) {
+        const double egrlo = sqrt(slope2(k + 1, true));
+        const double e = .5 * (egrup + egrlo);
+        egr[o] = e;
+        egrup = egrlo;
+        if (sa) {
+          double q;
+          if (D.eddf2d) q = fmax2(0., PL(k + 1) - PL(k));
+          else q = fmax2(0., fmin2(PL(kf) + DPGRAV, PL(k + 1)) - PL(k));
+          dps = dps + q;
+          egrs = egrs + e * q;
+        }
+      } else
+        egr[o] = egr[o - np];
+    }
+  }
+  if (sa) {
+    if (dps > 0.) egrs = egrs / dps;
+    else egrs = 0.;
+  }
+  difint[0] = D.egmndf;
+  double dfints = 0., anisos = 0.;
+  dps = 0.;
+  // layer interface diffusivities, :2283-2375 (rhsctp is refused by the option setter)
+  for (int k = 2; k <= kk; k++) {
+    const size_t o = (size_t)(k - 1) * np;
+    if (any && k >= kf && k <= km) {
+      const double e = egr[o];
+      const double rhisc = e / fmax2(1.e-22, betafp);
+      double speed = 0.;
+      if (D.edanis) {
+        const double ubc = (u[o] * dpu[o] + u[o + 1] * dpu[o + 1]) / fmax2(EPSILP, dpu[o] + dpu[o + 1]);
+        const double vbc = (v[o] * dpv[o] + v[o + ni] * dpv[o + ni]) / fmax2(EPSILP, dpv[o] + dpv[o + ni]);
+        speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
+      }
+      const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
+      const double di = D.egc * e * els * els;
+      difint[o] = di;
+      double q;
+      if (D.eddf2d) q = fmax2(0., PL(k + 1) - PL(k));
+      else q = fmax2(0., fmin2(PL(kf) + DPDIAV, PL(k + 1)) - PL(k));
+      dps = dps + q;
+      dfints = dfints + di * q;
+      if (D.edanis) {
+        const double r = speed / fmax2(1.e-22, e * els);
+        const double a = 1. / (1. + r * r);
+        anisok[o] = a;
+        anisos = anisos + a * q;
+      }
+    } else
+      difint[o] = difint[o - np];
+  }
+  // the surface non-isopycnic layers, :2383-2513
+  double urmse = 0., cpse = 0., els_s = 0.;
+  if (sa) {
+    const double rhisc = egrs / fmax2(1.e-22, betafp);
+    els_s = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
+    if (D.edsprs) {
+      urmse = 2.86 * D.egc * egrs * els_s;
+      cpse = fmax2(CPSEMIN, -betafp * (bcrrd * bcrrd));
+    }
+  }
+  const double difmxp = V.f[F_difmxp][c];
+  const double cosang = V.f[F_cosang][c], sinang = V.f[F_sinang][c];
+  if (dps > 0.) {
+    dfints = dfints / dps;
+    double esfac;
+    if (sa) {
+      const int *ip = V.m[I_ip];
+      const size_t o2 = np;
+      auto mlvel = [&](const double *w, const double *dw, size_t off) {   // thickness weighted velocity of the two mixed layer layers
+        return (w[off] * dw[off] + w[off + o2] * dw[off + o2]) / (dw[off] + dw[off + o2]);
+      };
+      double ubc, vbc;
+      if (ip[c - 1] + ip[c + 1] == 2) ubc = .5 * (mlvel(u, dpu, 0) + mlvel(u, dpu, 1));
+      else if (ip[c - 1] == 1) ubc = mlvel(u, dpu, 0);
+      else if (ip[c + 1] == 1) ubc = mlvel(u, dpu, 1);
+      else ubc = 0.;
+      if (ip[c - ni] + ip[c + ni] == 2) vbc = .5 * (mlvel(v, dpv, 0) + mlvel(v, dpv, ni));
+      else if (ip[c - ni] == 1) vbc = mlvel(v, dpv, 0);
+      else if (ip[c + ni] == 1) vbc = mlvel(v, dpv, ni);
+      else vbc = 0.;
+      if (D.edanis) {
+        anisos = anisos / dps;
+        const double speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
+        const double r = speed / fmax2(1.e-22, egrs * els_s);
+        esfac = 1. / (1. + r * r);
+      } else {
+        double umnsc = ubc * cosang;
+        umnsc = umnsc - vbc * sinang - cpse;
+        const double r = umnsc / fmax2(URMSEMIN, fabs(urmse));
+        esfac = 1. / (1. + 4. * (r * r));
+      }
+    } else
+      esfac = 1.;
+    if (D.eddf2d) {
+      double d1;
+      if (D.edanis) d1 = anisos * dfints * difwgt;
+      else d1 = dfints * difwgt;
+      if (D.redi3d) difiso[0] = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, esfac * dfints * D.egidfq * difwgt));
+      else difiso[0] = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, d1 * D.egidfq));
+      difint[0] = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, d1));
+    } else {
+      const double d1 = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, dfints * difwgt * esfac));
+      difint[0] = d1;
+      difiso[0] = d1 * D.egidfq;
+    }
+  } else {
+    dfints = D.egmndf;
+    difiso[0] = difint[0] * D.egidfq;
+  }
+  // the isopycnic layers, :2516-2572
+  for (int k = 2; k <= kk; k++) {
+    const size_t o = (size_t)(k - 1) * np;
+    if (any && k >= kf && k <= km) {
+      double esfac;
+      if (D.edsprs) {
+        const int mu0 = msku[o], mu1 = msku[o + 1], mv0 = mskv[o], mv1 = mskv[o + ni];
+        const double umnsc = ((double)mu0 * u[o] + (double)mu1 * u[o + 1]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) * cosang -
+                             ((double)mv0 * v[o] + (double)mv1 * v[o + ni]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1) * sinang - cpse;
+        const double r = umnsc / fmax2(URMSEMIN, fabs(urmse));
+        esfac = 1. / (1. + 4. * (r * r));
+      } else if (D.edanis)
+        esfac = anisok[o];
+      else
+        esfac = 1.;
+      if (D.eddf2d) {
+        difint[o] = difint[0];
+        if (D.redi3d) difiso[o] = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, esfac * dfints * D.egidfq * difwgt));
+        else difiso[o] = difiso[0];
+      } else {
+        const double d = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, difint[o] * difwgt * esfac));
+        difint[o] = d;
+        difiso[o] = d * D.egidfq;
+      }
+    } else {
+      difint[o] = difint[o - np];
+      difiso[o] = difiso[o - np];
+    }
+  }
+#undef PL
+  (void)P;
+}
+
+// ---- :2582-2607: lateral smoothing of difint, difiso (edfsmo); the unsmoothed fields lie in two work-space slots -------------------
+__global__ void k_dfi_smooth(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  const int mrg = 2;
+  if (j < 1 - mrg || j > V.jj + mrg || i < 1 - mrg || i > V.ii + mrg || !V.m[I_ip][c]) return;
+  const int k = by_, ni = V.ni;
+  const size_t np = V.nplane, o = (size_t)k * np, okn = (size_t)(k + nn) * np;
+  const int *ip = V.m[I_ip];
+  const double *dp = V.f[F_dp] + okn, *u1 = WK(V, W_SM1) + o, *u2 = WK(V, W_SM2) + o;
+  const double ws = .125 * (double)ip[c - ni] * fmin2(ONEM, dp[c - ni]) / ONEM;
+  const double ww = .125 * (double)ip[c - 1] * fmin2(ONEM, dp[c - 1]) / ONEM;
+  const double we = .125 * (double)ip[c + 1] * fmin2(ONEM, dp[c + 1]) / ONEM;
+  const double wn = .125 * (double)ip[c + ni] * fmin2(ONEM, dp[c + ni]) / ONEM;
+  const double wc = -((ws + ww) + (we + wn)) + 1.;
+  V.f[F_difint][c + o] = (ws * u1[c - ni] + ww * u1[c - 1]) + (we * u1[c + 1] + wn * u1[c + ni]) + wc * u1[c];
+  V.f[F_difiso][c + o] = (ws * u2[c - ni] + ww * u2[c - 1]) + (we * u2[c + 1] + wn * u2[c + ni]) + wc * u2[c];
+}
+
+// the TKE closure's derived constants as this library evaluates them (tests compare them with the reference's)
+extern "C" int blomgpu_tke_const(const char *name, double *v) {
+  const TkeC t = tke_consts();
+  const std::string s(name);
+#define G(nm, f) if (s == #nm) { *v = t.f; return 0; }
+  G(sqrt2, sqrt2) G(cmu_fac1, cmu_fac1) G(cmu_fac2, cmu_fac2) G(cmu_fac3, cmu_fac3) G(tke_exp1, tke_exp1) G(gls_exp1, gls_exp1)
+  G(gls_fac6, gls_fac6) G(gls_s0, s0) G(gls_s1, s1) G(gls_s2, s2) G(gls_s4, s4) G(gls_s5, s5) G(gls_s6, s6)
+  G(gls_b0, b0) G(gls_b1, b1) G(gls_b2, b2) G(gls_b3, b3) G(gls_b4, b4) G(gls_b5, b5)
+#undef G
+  return 1;
+}
+
+int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
+  const DevView &h = c->h;
+  if (h.P.vcoord_tag != 1) return ctx_fail(c, "difest_isobml is the isopycnic coordinate's (phy/mod_blom_step.F90:140)");
+  if (h.P.itrtke >= 1 && h.P.gls) return ctx_fail(c, " difest_vertical_iso: the two-equation closure (use_GLS) is not built on the device");
+  if (h.P.itrtke >= 1 && (h.P.itrtke > h.ntr || h.P.itrgls < 1 || h.P.itrgls > h.ntr)) return ctx_fail(c, "difest: itrtke / itrgls outside 1..ntr");
+  if (h.P.bdmldp && c->bdml_logc == 0.) return ctx_fail(c, " difest_vertical_iso: bdmldp needs the plane bdmlq and the option bdml_logc (the host's log)");
+  if (W_NSLOT > h.nwk) return ctx_fail(c, "difest: work space too small");
+  if (int rc = st_difest_isobml_pre(c, m, n, mm, nn)) return rc;                  // :750-790
+  DfePar D;
+  D.egc = c->egc; D.eggam = c->eggam; D.eglsmn = c->eglsmn; D.egmndf = c->egmndf; D.egmxdf = c->egmxdf; D.egidfq = c->egidfq;
+  D.rhiscf = c->rhiscf; D.ri0 = c->ri0; D.tkepf = c->tkepf; D.niwgf = c->niwgf; D.niwbf = c->niwbf; D.niwlf = c->niwlf;
+  D.bdml_logc = c->bdml_logc;
+  D.eddf2d = c->eddf2d; D.edsprs = c->edsprs; D.edanis = c->edanis; D.redi3d = c->redi3d; D.edritp = c->edritp_opt; D.edwmth = c->edwmth_opt;
+  D.use_tke = h.P.itrtke >= 1; D.itke = h.P.itrtke; D.igls = h.P.itrgls;
+  D.T = tke_consts();
+  const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64), b64(64);
+  {
+    TimeScope ts(c, "difest");
+    hipLaunchKernelGGL(k_dfi_kmax_kfil, g1, b64, 0, c->stream, c->d, n, nn);
+    hipLaunchKernelGGL(k_dfi_kfil_util, plane_grid(h), dim3(256), 0, c->stream, c->d, 0);
+  }
+  if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, 1, 1, 1)) return rc;
+  {
+    TimeScope ts(c, "difest");
+    hipLaunchKernelGGL(k_dfi_kfil_util, plane_grid(h), dim3(256), 0, c->stream, c->d, 1);
+    hipLaunchKernelGGL(k_dfi_uv2, g2, b64, 0, c->stream, c->d, nn);
+    hipLaunchKernelGGL(k_dfi_common, g1, b64, 0, c->stream, c->d, nn);
+    hipLaunchKernelGGL(k_dfi_vertical, g1, b64, 0, c->stream, c->d, D, nn);
+    hipLaunchKernelGGL(k_dfi_lateral, g1, b64, 0, c->stream, c->d, D, n, nn);
+  }
+  HIPCHK(c, hipGetLastError());
+  const int mrgint = 1, mrgiso = 2;
+  if (c->edfsmo) {
+    if (int rc = st_xctilr(c, h.f[F_difint], 1, h.kk, mrgint + 1, mrgint + 1, 1)) return rc;
+    if (int rc = st_xctilr(c, h.f[F_difiso], 1, h.kk, mrgiso + 1, mrgiso + 1, 1)) return rc;
+    const size_t bytes = sizeof(double) * (size_t)h.kk * h.nplane;
+    HIPCHK(c, hipMemcpyAsync(WK(h, W_SM1), h.f[F_difint], bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(WK(h, W_SM2), h.f[F_difiso], bytes, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_dfi_smooth, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    if (int rc = st_xctilr(c, h.f[F_difint], 1, h.kk, mrgint, mrgint, 1)) return rc;
+    if (int rc = st_xctilr(c, h.f[F_difiso], 1, h.kk, mrgiso, mrgiso, 1)) return rc;
+  }
+  return 0;
+}

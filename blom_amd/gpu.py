@@ -164,6 +164,21 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_exp(self.ctx, x.size, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
         return y
 
+    def pow(self, x, y):
+        """pow() as the kernels evaluate it (blom_amd/csrc/pow_libm.h), elementwise."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        z = np.empty_like(x)
+        self._chk(self.lib.blomgpu_pow(self.ctx, x.size, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)))
+        return z
+
+    def tke_const(self, name):
+        """a derived constant of the TKE closure (phy/mod_tke.F90:133-160) as this library evaluates it"""
+        v = C.c_double(0.0)
+        if self.lib.blomgpu_tke_const(name.encode(), C.byref(v)):
+            raise KeyError(name)
+        return v.value
+
     def budget_sums(self, ncall, n, nn):
         """budget_sums (phy/mod_budget.F90:95); does nothing unless the option cnsvdi is set."""
         self._chk(self.lib.blomgpu_budget_sums(self.ctx, ncall, n, nn))

@@ -539,3 +539,51 @@ def frozen_eddy_fluxes(be, case, amp=0.15, spike=3.0):
                 val = pat * clamp * dpv[k + (1 - lev // kk) * kk][J, I]
                 a[lev][J, I] = np.where(wet, val, a[lev][J, I])
             be.put(nm, a)
+
+
+# constants of phy/mod_difest.F90:200-203, :191, :193 read by the two host-evaluated planes below
+_TDMLS0, _TDMLS1, _TDCLAT, _TDDLAT = 500.0 * 9806.0, 100.0 * 9806.0, 74.5, 3.0
+_CORI30, _BVF0 = 7.2722e-5, 5.24e-3
+
+
+def difest_host_planes(plat, coriop):
+    """The two inputs of difest_vertical_iso that depend on the grid only and go through the libm: the tidally driven mixing length
+    scale `q = .5*(tanh(4.*(abs(plat)-tdclat)/tddlat-2.)+1.); q = (1.-q)*tdmls0+q*tdmls1` (phy/mod_difest.F90:2926-2927) and, for
+    the latitude dependent background mixing (bdmldp, :2747-2750), log(2 bvf0 / max(1e-9, |coriop|)) with the scalar
+    log(2 bvf0 / cori30).  math.tanh / math.log are the C library's, i.e. the functions the reference's compiled Fortran calls on
+    this machine; every other operation is IEEE double arithmetic in the reference's order."""
+    import math
+    plat = np.asarray(plat, dtype=np.float64)
+    cor = np.asarray(coriop, dtype=np.float64)
+    tdmls = np.empty_like(plat)
+    bdmlq = np.empty_like(plat)
+    fp, fc, ft, fb = plat.ravel(), cor.ravel(), tdmls.ravel(), bdmlq.ravel()
+    for x in range(fp.size):
+        q = .5 * (math.tanh(4. * (abs(float(fp[x])) - _TDCLAT) / _TDDLAT - 2.) + 1.)
+        ft[x] = (1. - q) * _TDMLS0 + q * _TDMLS1
+        qq = max(1.e-9, abs(float(fc[x]))) if np.isfinite(fc[x]) else 1.e-9
+        fb[x] = math.log(2. * _BVF0 / qq)
+    return tdmls, bdmlq, math.log(2. * _BVF0 / _CORI30)
+
+
+def init_difest(be, case, twedon0=2.0e-3, ficem0=0.3, device=False):
+    """What difest_isobml's diffusivity estimates read beside the model state, for the idealised cases: latitude, the angle of the
+    grid, the topographic beta (unused: rhsctp is off), a smooth tidal dissipation field and a sea ice concentration (synthetic:
+    the reference reads them from files), zero surface buoyancy flux.  device: also the two host-evaluated planes (the reference
+    evaluates them itself)."""
+    nj, ni = case.jdm + 2 * NBDY, case.idm + 2 * NBDY
+    y = np.linspace(-1.0, 1.0, nj)[:, None] + 0.0 * np.arange(ni)[None, :]
+    x = np.linspace(0.0, 2.0 * np.pi, ni)[None, :] + 0.0 * y
+    plat = (55.0 + 24.0 * y)[None]                           # crosses the critical latitude of the M2 tide (74.5 N)
+    ang = 0.2 * np.sin(x) * y
+    vals = dict(plat=plat, cosang=np.cos(ang)[None], sinang=np.sin(ang)[None], betatp=np.full((1, nj, ni), 1.0e-10), hangle=np.zeros((1, nj, ni)),
+                twedon=(twedon0 * (1.0 + 0.5 * np.cos(2.0 * x)) * (1.0 - 0.3 * y))[None], ficem=(ficem0 * (y > 0.2) * (1.0 + np.sin(x)) * 0.5)[None])
+    has = getattr(be, "has_field", lambda nm: True)
+    for nm, v in vals.items():
+        if has(nm):
+            be.put(nm, v)
+    if device:
+        tdmls, bdmlq, logc = difest_host_planes(plat[0], np.asarray(be.get("coriop"))[0])
+        be.put("tdmls", tdmls[None])
+        be.put("bdmlq", bdmlq[None])
+        be.set("bdml_logc", logc)

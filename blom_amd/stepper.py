@@ -28,6 +28,10 @@ FULL_STAGES = tuple({"halo_cmnfld2": "cmnfld2", "halo_difest": "difest_isobml_pr
                     if s != "mxlayr_tail")
 FULL_STAGES = FULL_STAGES[:FULL_STAGES.index("diapfl") + 1] + ("thermf", "mxlayr") + FULL_STAGES[FULL_STAGES.index("diapfl") + 1:] + ("cmnfld1",)
 
+# ... and with the diffusivity estimates of difest_isobml live (difest_common_iso, difest_vertical_iso, difest_lateral_iso; the device
+# option difest_live): the whole routine in place of its front part
+FULL_STAGES_LIVE = tuple("difest_isobml" if s == "difest_isobml_pre" else s for s in FULL_STAGES)
+
 STAGES_FROZEN_EDDY_FLUXES = tuple(s for s in DYNCORE_STAGES if s != "eddtra")    # umfltd.. stay as uploaded
 
 # The step of the other vertical coordinates (vcoord_type = 'cntiso_hybrid' or 'plevel'), phy/mod_blom_step.F90:126-233, as far

@@ -101,6 +101,20 @@ int  blomgpu_budget_get(blomgpu_ctx *, int which, int ncall, int n, double *valu
 /* exp() as the kernels evaluate it -- the algorithm and bits of the glibc libm that the reference's compiled Fortran
  * calls (blom_amd/csrc/exp_libm.h; phy/mod_barotp.F90:183,205, phy/mod_diapfl.F90:204) -- elementwise on host arrays. */
 int  blomgpu_exp(blomgpu_ctx *, int n, const double *x, double *y);
+/* pow() as the kernels evaluate it: likewise the algorithm and bits of glibc's pow (blom_amd/csrc/pow_libm.h; the real powers of the
+ * TKE closure and of the surface layer's stability function in difest_vertical_iso, phy/mod_difest.F90:2881-2886, :3056-3058). */
+int  blomgpu_pow(blomgpu_ctx *, int n, const double *x, const double *y, double *z);
+/* phy/mod_difest.F90:735 difest_isobml, the whole routine: halo updates, interface pressure, ustar3, niw_ke_tendency (blomgpu_stage
+ * "difest_isobml_pre") and the diffusivity estimates difest_common_iso (:353), difest_vertical_iso (:2629), difest_lateral_iso (:2040)
+ * -> difint, difiso, difdia, difwgt (and the TKE tracers' source step).  Options: blomgpu_set_real "egc", "eggam", "eglsmn", "egmndf",
+ * "egmxdf", "egidfq", "ri0", "tkepf"; blomgpu_set_int "eddf2d", "edsprs", "edanis", "redi3d", "edfsmo", "edritp_opt" (1 shear, 2 large
+ * scale), "edwmth_opt" (1 smooth, 2 step), "bdmtyp", "iwdflg", "bdmldp"; rhsctp and the two-equation closure are refused.  Inputs that
+ * depend on the grid only and need the host's libm are uploaded as planes: "tdmls" (tidal mixing length scale, :2926-2927) and, with
+ * bdmldp, "bdmlq" = log(2 bvf0 / max(1e-9, |coriop|)) with the option "bdml_logc" = log(2 bvf0 / cori30).
+ * PARITY UNPINNED: cross-checked against the reference's real module compiled against interface-only stand-ins for CVMix. */
+int  blomgpu_difest_isobml(blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);
+/* the derived constants of the TKE closure (initke, phy/mod_tke.F90:133-160) as this library evaluates them, by the reference's names */
+int  blomgpu_tke_const(const char *name, double *value);
 int  blomgpu_updtrc (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* trc/mod_tracers_update.F90:152: its idlage_step, idlage/mod_idlage.F90:57 */
 int  blomgpu_sfcstr (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);      /* phy/mod_sfcstr.F90:33 (empty for channel/fuk95/noforcing) */
 int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                             /* phy/mod_diapfl.F90:49   */

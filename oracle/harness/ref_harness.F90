@@ -72,6 +72,15 @@ module ref_harness
   use mod_thermf_channel, only: thermf_channel
   use mod_ben02,     only: ntda
 #endif
+#ifdef XCHECK_DF
+  ! cross-check builds only (oracle/Makefile *_xdf): the reference's real mod_difest (stand-ins: the CVMix modules, interface only,
+  ! and mod_tidaldissip's one array); mod_seaice is the reference's own
+  use mod_difest,    only: difest_isobml, inivar_difest
+  use mod_tidaldissip, only: twedon
+  use mod_seaice,    only: ficem
+  use mod_tke,       only: initke, Prod, Buoy, Shear2, L_scale, sqrt2, cmu_fac1, cmu_fac2, cmu_fac3, tke_exp1, gls_exp1, gls_fac6, &
+                            gls_s0, gls_s1, gls_s2, gls_s4, gls_s5, gls_s6, gls_b0, gls_b1, gls_b2, gls_b3, gls_b4, gls_b5
+#endif
   use mod_ifdefs,    only: use_TRC
   use mod_temmin,    only: temmin
 
@@ -208,6 +217,17 @@ contains
       case ('tau_growing_hml'); tau_growing_hml = v
       case ('tau_decaying_hml'); tau_decaying_hml = v
 #endif
+#ifdef XCHECK_DF
+      case ('egc'); egc = v
+      case ('eggam'); eggam = v
+      case ('eglsmn'); eglsmn = v
+      case ('egmndf'); egmndf = v
+      case ('egmxdf'); egmxdf = v
+      case ('egidfq'); egidfq = v
+      case ('rhiscf'); rhiscf = v
+      case ('ri0'); ri0 = v
+      case ('tkepf'); tkepf = v
+#endif
       case ('baclin'); baclin = v
       case ('batrop'); batrop = v
       case ('delt1');  delt1 = v
@@ -254,6 +274,27 @@ contains
       case ('pref');   v = pref
       case ('wbaro');  v = wbaro
       case ('wpgf');   v = wpgf
+#ifdef XCHECK_DF
+      case ('sqrt2'); v = sqrt2
+      case ('cmu_fac1'); v = cmu_fac1
+      case ('cmu_fac2'); v = cmu_fac2
+      case ('cmu_fac3'); v = cmu_fac3
+      case ('tke_exp1'); v = tke_exp1
+      case ('gls_exp1'); v = gls_exp1
+      case ('gls_fac6'); v = gls_fac6
+      case ('gls_s0'); v = gls_s0
+      case ('gls_s1'); v = gls_s1
+      case ('gls_s2'); v = gls_s2
+      case ('gls_s4'); v = gls_s4
+      case ('gls_s5'); v = gls_s5
+      case ('gls_s6'); v = gls_s6
+      case ('gls_b0'); v = gls_b0
+      case ('gls_b1'); v = gls_b1
+      case ('gls_b2'); v = gls_b2
+      case ('gls_b3'); v = gls_b3
+      case ('gls_b4'); v = gls_b4
+      case ('gls_b5'); v = gls_b5
+#endif
       case default; ierr = 1; v = 0
     end select
   end subroutine ref_get_real
@@ -290,6 +331,16 @@ contains
       case ('csdiag');     csdiag = (v /= 0)
       case ('cnsvdi');     cnsvdi = (v /= 0)
       case ('bdmldp');     bdmldp = (v /= 0)
+#ifdef XCHECK_DF
+      case ('eddf2d');     eddf2d = (v /= 0)
+      case ('edsprs');     edsprs = (v /= 0)
+      case ('edanis');     edanis = (v /= 0)
+      case ('redi3d');     redi3d = (v /= 0)
+      case ('rhsctp');     rhsctp = (v /= 0)
+      case ('edfsmo');     edfsmo = (v /= 0)
+      case ('edritp_opt'); edritp_opt = v        ! 1 shear, 2 large scale (phy/mod_diffusion.F90)
+      case ('edwmth_opt'); edwmth_opt = v        ! 1 smooth, 2 step
+#endif
 #ifdef XCHECK_ML
       ! mod_forcing's switches of thermf and mod_time's calendar position (phy/mod_forcing.F90:43-47, phy/mod_time.F90)
       case ('aptflx');     aptflx = (v /= 0)
@@ -560,6 +611,19 @@ contains
       R2(swal1)
       R2(swal2)
 #endif
+#ifdef XCHECK_DF
+      R2(twedon)
+      R2(ficem)
+      R2(plat)
+      R2(betatp)
+      R2(cosang)
+      R2(sinang)
+      R2(hangle)
+      R3(Prod, kdm)
+      R3(Buoy, kdm)
+      R3(Shear2, kdm)
+      R3(L_scale, kdm)
+#endif
 #ifdef XCHECK_ML
       R2(idkedt)
       R2(mtkeus)
@@ -645,6 +709,12 @@ contains
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
       case ('cmnfld_bfsqi_ale'); call cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)
+#endif
+#ifdef XCHECK_DF
+      ! difest_init: the module's arrays (inivar_difest; init_difest is CVMix's initialisation and is not called), mod_tke's arrays and
+      ! derived constants (initke: cmu_fac1.., tke_exp1, gls_exp1, the stability function coefficients)
+      case ('difest_init'); call inivar_difest; call initke
+      case ('difest_isobml'); call difest_isobml(m,n,mm,nn,k1m,k1n)
 #endif
 #ifdef XCHECK_ML
       case ('mxlayr_init'); call inivar_mxlayr; call inivar_niw

@@ -38,3 +38,12 @@ def test_hybrid_step_with_neutral_diffusion_on_the_host_emulation(emu_lib, tmp_p
 def test_full_physics_step_on_the_host_emulation(emu_lib):
     from test_xcheck_fullstep import _full_step_check
     _full_step_check("chan_s_tke", 5, False)
+
+
+def test_difest_isobml_diffusivity_estimates_on_the_host_emulation(emu_lib):
+    """the cross-checks of tests/test_xcheck_difest.py (GPU suite) on the emulation: the stage on its own and config 2's step with live diffusivities"""
+    from test_xcheck_difest import _live_step_check, OPT_FUK95, OPT_SHEAR, OPT_2D
+    _live_step_check("chan_s_tke", 3, OPT_FUK95, stagewise=True)
+    _live_step_check("box_s", 3, OPT_SHEAR, stagewise=True)
+    _live_step_check("tri_s_tke", 3, OPT_2D, stagewise=True)
+    _live_step_check("chan_s_tke", 4, OPT_FUK95)
