@@ -178,7 +178,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False):
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False, difest=False):
     """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
     2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
     default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
@@ -187,7 +187,7 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False
     threading.stack_size(2 << 30)
     def body():
         try:
-            res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full))
+            res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full, difest))
         except Exception as e:                           # (an exception in a thread would otherwise vanish with its message)
             res["error"] = repr(e)
     th = threading.Thread(target=body)
@@ -197,7 +197,7 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False
     return res or {"error": "the reference run did not complete"}
 
 
-def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False):
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False, difest=False):
     """The reference's own Fortran (preferred) or the C restatement, timed on the host for a bounded number of steps.
     Preferred build: oracle/_ref/<cfg>_omp_xed -- the reference's hot-path modules INCLUDING its real mod_cmnfld_routines and
     mod_eddtra (compiled against the two small stand-in modules of oracle/xcheck/, see there), with its OpenMP directives
@@ -205,17 +205,21 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_phys
     the reference's code on all host cores.  Without it: <cfg>_omp, which lacks those two stages -- they are then timed on the
     C restatement on one thread and reported beside `value`, not inside it."""
     from blom_amd import hostinit
-    from blom_amd.stepper import dyncore_step, DYNCORE_STAGES, FULL_STAGES
+    from blom_amd.stepper import dyncore_step, DYNCORE_STAGES, FULL_STAGES, FULL_STAGES_LIVE
     from oracle.refblom import get_ref_backend, have_ref
     from oracle.coracle import COracle
     ncores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(ncores)
     # --physics full: the build with the reference's real mod_thermf_channel, mod_mxlayr, mod_niw as well (oracle/Makefile *_xml)
-    xml = full_physics and have_ref(cfg + "_omp_xml")
+    # ... and its real mod_difest (oracle/Makefile *_xdf): the diffusivity estimates live, as on the device
+    xdf = full_physics and difest and have_ref(cfg + "_omp_xdf")
+    if full_physics and difest and not xdf:
+        return {"error": f"oracle/_ref/{cfg}_omp_xdf/libblomref.so is missing: no CPU baseline for the step with live diffusivities"}
+    xml = xdf or (full_physics and have_ref(cfg + "_omp_xml"))
     if full_physics and not xml:
         return {"error": f"oracle/_ref/{cfg}_omp_xml/libblomref.so is missing: no CPU baseline for --physics full"}
     full = xml or have_ref(cfg + "_omp_xed")
-    ref_cfg = cfg + "_omp_xml" if xml else cfg + "_omp_xed" if full else (cfg + "_omp" if have_ref(cfg + "_omp") else (cfg if have_ref(cfg) else None))
+    ref_cfg = cfg + "_omp_xdf" if xdf else cfg + "_omp_xml" if xml else cfg + "_omp_xed" if full else (cfg + "_omp" if have_ref(cfg + "_omp") else (cfg if have_ref(cfg) else None))
     stages = DYNCORE_STAGES
     note, de, dc = "", 0.0, 0.0
     if ref_cfg is not None and not full:
@@ -259,7 +263,7 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_phys
                 be.ref.set("eitmth", "gm")
                 be.has_stage = lambda name: True             # this build's harness knows eddtra and cmnfld2
                 if xml:
-                    stages = FULL_STAGES
+                    stages = FULL_STAGES_LIVE if xdf else FULL_STAGES
                 elif live:
                     stages = tuple("cmnfld2" if s_ == "halo_cmnfld2" else s_ for s_ in DYNCORE_STAGES)
                 note = ("; every stage in the reference's own code, mod_cmnfld_routines and mod_eddtra compiled against the "
@@ -269,11 +273,18 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_phys
     if kind is None:
         be = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
         kind = "port"
+    if xdf:
+        be.ref.stage("difest_init", *hostinit.step_indices(0, case.kdm))      # (before the state: initke resets the TKE tracers)
     hostinit.init_state(be, case)
     if xml:
         six0 = hostinit.step_indices(0, case.kdm)
         be.ref.stage("mxlayr_init", *six0)
         hostinit.init_forcing(be, case)
+        if xdf:
+            hostinit.init_difest(be, case)
+            for d_ in hostinit.DIFEST_NORESM:
+                for nm, v in d_.items():
+                    be.ref.set(nm, v)
         for nm, v in dict(rm0=1.2, rm5=0.0, niwgf=0.0, niwbf=0.35, niwlf=0.5, ce=0.06, tau_mlr=86400.0, lfmin=5.0e3, swamxd=200.0, sref=34.65,
                           xmi=0.0, trxday=0.0, srxday=0.0, trxdpt=1.0, srxdpt=1.0, trxlim=1.5, srxlim=0.5).items():
             be.ref.set(nm, float(v))
@@ -682,6 +693,9 @@ def main():
     ap.add_argument("--ltedtp", default="neutral", choices=["neutral", "layer"],
                     help="--config hybrid: lateral tracer diffusion, 'neutral' (phy/mod_ndiff.F90 inside ale_regrid_remap; the reference's "
                          "default for cntiso_hybrid) or 'layer' (diffus)")
+    ap.add_argument("--frozen-diffusivities", action="store_true",
+                    help="--physics full: leave out the diffusivity estimates of difest_isobml (difint, difiso, difdia, difwgt stay at their "
+                         "initial values, as in round 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dyncore-compare", action="store_true",
                     help="leave out the extra steps of the dynamical core alone that follow the measurement (profiling runs)")
@@ -728,6 +742,7 @@ def main():
     from blom_amd import hostinit
     case, nreg, masks = build_case(args.config, args.advmth, args.tracers)
     layout = None
+    difest_live = False
     full_req = args.physics == "full" and not args.rccl_self and args.slopes == "live"
     tile_area = None
     if (world > 1 and scaling == "strong") or args.tiles:       # --tiles 1x1 at N = 1: the same code path with one rank
@@ -796,6 +811,14 @@ def main():
         else:
             gpu.set("area", tile_area)                     # (the fields came with the window of the whole domain)
         gpu.set("full_physics", 1)
+        if layout is None and not args.frozen_diffusivities:
+            # difest_isobml's diffusivity estimates live (stage_difest_iso.hip): NorESM's &DIFFUSION defaults for this coordinate
+            hostinit.init_difest(gpu, case, device=True)
+            for d_ in hostinit.DIFEST_NORESM:
+                for nm, v in d_.items():
+                    gpu.set(nm, v)
+            gpu.set("difest_live", 1)
+            difest_live = True
     for o in args.opt:
         nm, v = o.split("=")
         gpu.set(nm, int(v))
@@ -899,8 +922,8 @@ def main():
                                f"isopyc_bulkml/{args.advmth}/geopotential/uc/enscon, ntr={case.ntr} "
                                f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age' if case.ntr == 1 else f'the default three + {case.ntr - 3} passive tracers'}), "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; " +
-                               (f"config 2's step as far as built (phy/mod_blom_step.F90:96-253: init_fluxes, tmsmt1, cmnfld2, difest_isobml "
-                                f"[halos, pressure, ustar3, niw_ke_tendency; its diffusivity estimates need CVMix: frozen], eddtra, advect, pbcor1, "
+                               (f"config 2's step (phy/mod_blom_step.F90:96-253: init_fluxes, tmsmt1, cmnfld2, difest_isobml "
+                                f"[{'the whole routine: diffusivities estimated every step (NorESM defaults, rhsctp off)' if difest_live else 'halos, pressure, ustar3, niw_ke_tendency; diffusivities frozen'}], eddtra, advect, pbcor1, "
                                 f"diffus, pgforc, momtum, convec, diapfl, thermf, mxlayr, updtrc, barotp, pbcor2, tmsmt2, cmnfld1), the channel "
                                 f"experiment's own forcing (zero fluxes, ustarw = 0.005 m/s), (gm, " if full else
                                 f"full dyncore stage sequence incl. cmnfld2, eddtra and convec (gm, ") +
@@ -963,7 +986,7 @@ def main():
         os.dup2(2, 1)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live", full=full)
+                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live", full=full, difest=difest_live)
             except Exception as e:                       # the bench line must still be produced
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

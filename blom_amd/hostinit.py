@@ -587,3 +587,11 @@ def init_difest(be, case, twedon0=2.0e-3, ficem0=0.3, device=False):
         be.put("tdmls", tdmls[None])
         be.put("bdmlq", bdmlq[None])
         be.set("bdml_logc", logc)
+
+
+# &DIFFUSION as far as difest_isobml reads it, NorESM's defaults for vcoord_type = 'isopyc_bulkml' (cime_config/namelist_definition_blom.xml)
+# with rhsctp = .false. (the topographic Rhines scale needs a topographic-beta file, `tbfile`, which the idealised cases do not have:
+# the reference's own tests/fuk95/limits switches it off the same way); what bench.py runs config 2's step with
+DIFEST_NORESM = (dict(egc=2.5, eggam=200.0, eglsmn=4000.0, egmndf=50.0, egmxdf=2500.0, egidfq=1.25, ri0=1.2, tkepf=0.006,
+                      bdmc1=5.0e-8, bdmc2=1.0e-5, iwdfac=0.06, nubmin=2.0e-6, niwgf=0.0, niwbf=0.35, niwlf=0.5),
+                 dict(eddf2d=1, edsprs=0, edanis=1, redi3d=0, edfsmo=0, edritp_opt=2, edwmth_opt=1, bdmtyp=2, iwdflg=1, bdmldp=1, rhsctp=0))

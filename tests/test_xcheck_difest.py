@@ -153,6 +153,7 @@ def test_full_step_with_live_diffusivities_equals_the_reference_stage_sequence(c
 
 
 def test_full_size_channel_step_with_live_diffusivities_equals_the_reference_stage_sequence():
-    """three steps at BASELINE.json's channel size (208x512x53, ntr = 3): what bench.py times by default"""
+    """three steps at BASELINE.json's channel size (208x512x53, ntr = 3) with the options bench.py times by default (NorESM's &DIFFUSION
+    defaults for isopyc_bulkml, rhsctp off: hostinit.DIFEST_NORESM)"""
     from test_xcheck_ale import run_with_big_stack
-    run_with_big_stack(_live_step_check, "channel_tke", 3, OPT_FUK95)
+    run_with_big_stack(_live_step_check, "channel_tke", 3, hostinit.DIFEST_NORESM)
