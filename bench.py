@@ -87,7 +87,10 @@ def kernel_bytes_F(ntr, nadv):
       k_mom_visc_march  R u, v (n), pu, pv, dpu, dpv; W visu, visv
       k_diapfl_column3  R T, S, dp, sigma, tracers, sigmar, difdia; W T, S, dp, sigma, tracers, p, fpug, fplg, difdia"""
     return {"k_remap_tile": (3 + nadv + 2) + (6 + 2 * nadv), "k_mom_cor_march": 18 + 6, "k_mom_visc_march": 6 + 2,
-            "k_diapfl_column3": (6 + ntr) + (8 + ntr)}
+            "k_diapfl_column3": (6 + ntr) + (8 + ntr),
+            # k_pgf_uv   R p, T, S (n), phi, phi', pu, pv, dpu, dpv, pgfx, pgfy (the values that become the _o copies); W pgfx, pgfy, pgfx_o, pgfy_o
+            # k_pbc_tile R dp, S, T, tracers, the six flux planes; W the six flux planes, the new dp, S, T, tracers
+            "k_pgf_uv": 11 + 4, "k_pbc_tile": (3 + ntr + 6) + (6 + 3 + ntr)}
 
 
 KNOWN_CONFIGS = ("channel", "chandyn", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")   # chandyn: the channel with --physics dyncore
@@ -707,6 +710,10 @@ def main():
     ap.add_argument("--barotp", default="replicated", choices=["replicated", "decomposed"],
                     help="tiles (N > 1 or --tiles): replicated = every rank gathers barotp's 2-D inputs once per step and solves "
                          "the whole barotropic domain itself; decomposed = the reference's scheme, one exchange per substep pair")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 run: nccl (= RCCL, one GPU per rank) or gloo -- the CPU rehearsal of the "
+                         "same launcher / rendezvous / tile code with BLOMGPU_LIB pointing at the host emulation of the library "
+                         "(tests/hostemu, TEST use: tests/test_multirank_host.py); no torch.cuda call is made then")
     ap.add_argument("--rccl-self", action="store_true",
                     help="N=1 only: route the halo update through the RCCL transport (rank sends to itself) "
                          "to measure the exchange overhead of the N>1 path on one GPU")
@@ -733,10 +740,17 @@ def main():
     rank, world, local = env.rank, env.world, env.local
     scaling = (args.scaling or "strong") if (world > 1 or args.tiles) else "weak"
     import torch
+    on_gpu = args.backend == "nccl"
+    if not on_gpu:
+        local = 0                                  # the emulated device
+    cuda_sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if on_gpu:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd import hostinit
@@ -832,7 +846,7 @@ def main():
         ns = gpu.step(ns, args.warmup - 1)
     gpu.sync()
     classes = ["cmnfld", "difest", "eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "thermf", "mxlayr", "barotp",
-               "pbcor1", "pbcor2"]
+               "pbcor1", "pbcor2", "tmsmt", "init_fluxes", "updtrc"]
     stage_ms = {}
     for cl in classes:
         ms, n = gpu.timer_get(cl)
@@ -843,17 +857,17 @@ def main():
     # ---- timed region --------------------------------------------------------------------------
     def barrier():
         if world > 1:
-            torch.distributed.barrier(device_ids=[local])
+            torch.distributed.barrier(device_ids=[local]) if on_gpu else torch.distributed.barrier()
     barrier()
     gpu.sync()
-    torch.cuda.synchronize()
+    cuda_sync()
     t0 = time.perf_counter()
     ns = gpu.step(ns, args.steps)
     gpu.sync()
-    torch.cuda.synchronize()
+    cuda_sync()
     barrier()
     dt = time.perf_counter() - t0
-    dt = launch.max_over_ranks(dt, env, device="cuda")
+    dt = launch.max_over_ranks(dt, env, device="cuda" if on_gpu else "cpu")
 
     # ---- dominant kernel class, timed with HIP events on the library's stream over K more steps
     gpu.set("timing", 1)
@@ -866,7 +880,7 @@ def main():
         if n:
             live[cl] = ms / n
     kern = {}
-    for kn in ("k_remap_tile", "k_mom_cor_march", "k_mom_visc_march", "k_diapfl_column3", "k_bt_steps"):
+    for kn in ("k_remap_tile", "k_mom_cor_march", "k_mom_visc_march", "k_diapfl_column3", "k_bt_steps", "k_pgf_uv", "k_pbc_tile"):
         ms, n = gpu.timer_get(kn)
         if n:
             kern[kn] = (ms / n, n / max(1, min(args.steps, 5)))          # average launch duration [ms], launches per step
@@ -874,23 +888,26 @@ def main():
     import numpy as np
     finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
     crc_state = gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3) if layout is None else None
+    # (the checksums of the state the TIMED steps left -- taken before the comparison steps below, on tiles as on one tile, so that
+    # state_crc is the same for every N at equal --steps/--warmup)
+    my_strips = {nm: gpu.crc_strips(nm, 1, 2 * case.kdm, it) for nm, it in (("dp", 1), ("u", 3))} if layout is not None else None
     dyncore_ms = None
     if full and not args.no_dyncore_compare:
         # the dynamical core alone (the sequence rounds 1-3 timed), in the same run on the same device, for comparison
         gpu.set("full_physics", 0)
         ns = gpu.step(ns, 3)
         gpu.sync()
-        torch.cuda.synchronize()
+        cuda_sync()
         t1 = time.perf_counter()
         ns = gpu.step(ns, args.steps)
         gpu.sync()
-        torch.cuda.synchronize()
+        cuda_sync()
         dyncore_ms = (time.perf_counter() - t1) / args.steps * 1e3
     finite = all(launch.all_gather_ints(int(finite), env))
     if layout is not None:
         # xccrc of the whole domain (phy/mod_xc.F90:2195-2322) chained over the tiles: equal to the single tile's
         from blom_amd.tiles import chain_crc
-        parts = launch.all_gather_objects({nm: gpu.crc_strips(nm, 1, 2 * case.kdm, it) for nm, it in (("dp", 1), ("u", 3))}, env)
+        parts = launch.all_gather_objects(my_strips, env)
         tiles_of = {layout.rank_tile(r): p for r, p in enumerate(parts)}
         crcs = [chain_crc({k: v["dp"] for k, v in tiles_of.items()}, layout) ^ chain_crc({k: v["u"] for k, v in tiles_of.items()}, layout)]
     else:
@@ -963,6 +980,9 @@ def main():
                           "counted_traffic_bytes": sum(traffic.values()) if traffic else None,
                           "counted_traffic_GBs": (sum(traffic.values()) / (ms_per_step * 1e-3) / 1e9) if traffic else None},
         "stages_ms": live,
+        # counted HBM bytes (committed PMC profile of this workload: 2 x FETCH_SIZE + WRITE_SIZE) over the algorithmic bytes of SURVEY.md 8(d),
+        # per stage class that has both
+        "class_counted_over_alg": ({k: round(traffic[k] / (cb[k] * F), 2) for k in cb if traffic and k in traffic and k in live} or None),
     }
     out["config"]["physics"] = "full" if full else "dyncore"
     if dyncore_ms is not None:

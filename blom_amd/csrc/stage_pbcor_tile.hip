@@ -276,7 +276,10 @@ int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf, int 
   const DevView &h = c->h;
   if (3 + h.ntr > h.nwk) return ctx_fail(c, "pbcor: work space too small for this many tracers");
   const int ntx = (h.ni + PT_TW - 1) / PT_TW, nty = (h.nj + PT_TH - 1) / PT_TH;
-  hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx, from_remap);
+  {
+    TimeScope tk(c, "k_pbc_tile");
+    hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx, from_remap);
+  }
   // inside blomgpu_step pbcor1 hands S, T and the tracers to diffus through the work space, pbcor2 to tmsmt2
   // (with ltedtp = 'neutral' diffus is halo updates only: nothing to hand to it)
   const int move = !c->in_sequence || (which == 1 && h.P.ltedtp_opt == 2);

@@ -308,6 +308,7 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     // xctilr(pb_p,1,1,1,1) at :540 precedes the /pb_p(i-1,j) scaling done inside k_pgf_uv
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
     if (h.P.pgfmth == 0) {
+      TimeScope tk(c, "k_pgf_uv");
       if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
       else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
       else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);

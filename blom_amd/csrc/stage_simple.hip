@@ -46,6 +46,7 @@ __global__ void k_init_fluxes_ring(const DevView *__restrict__ Vp, int mm) {
 int st_init_fluxes(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)m; (void)n; (void)nn; (void)k1m; (void)k1n;
   const DevView &h = c->h;
+  TimeScope ts(c, "init_fluxes");
   if (c->in_sequence && c->lean_fluxes && h.P.advmth == 0 && h.P.vcoord_tag == 1 && !c->remap_fold) {
     hipLaunchKernelGGL(k_init_fluxes_ring, dim3((h.ii + h.jj + 6 + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, mm);
     HIPCHK(c, hipGetLastError());
@@ -79,6 +80,7 @@ __global__ void k_tmsmt1(const DevView *__restrict__ Vp, int off, int is_initms)
 }
 
 int st_tmsmt1(blomgpu_ctx *c, int nn) {
+  TimeScope ts(c, "tmsmt");
   hipLaunchKernelGGL(k_tmsmt1, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, nn, 0);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -264,6 +266,7 @@ __global__ void k_tmsmt_dpold_seam(const DevView *__restrict__ Vp, int mm) {
 }
 
 int st_tmsmt2(blomgpu_ctx *c, int m, int mm, int nn, int k1m) {
+  TimeScope ts(c, "tmsmt");
   const int dp_in_wk = c->pbcor2_dp_in_wk ? 1 : 0;
   c->pbcor2_dp_in_wk = false;
   hipLaunchKernelGGL(k_tmsmt2_fac, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, m, nn, dp_in_wk);
@@ -324,6 +327,7 @@ int st_updtrc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (h.P.itriag < 1 || h.P.itriag > h.ntr) return 0;       // no ideal age tracer configured
   if (h.P.nday_in_year < 1) return ctx_fail(c, "updtrc: nday_in_year is not set (mod_time)");
+  TimeScope ts(c, "updtrc");
   hipLaunchKernelGGL(k_idlage_step, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
   HIPCHK(c, hipGetLastError());
   return 0;
