@@ -10,8 +10,9 @@
 //   k_dfi_kmax_kfil   kmax, kfil of the columns 0..ii+1 x 0..jj+1                                   (:366-390; kfil's halo :392-411)
 //   k_dfi_uv2         squared vertical velocity differences at u- and v-columns, msku, mskv         (:413-511)
 //   k_dfi_common      drhol, du2l, rig                                                              (:513-560)
-//   k_dfi_vertical    Brunt-Vaisala frequency, the one-equation TKE closure's source step (or the Richardson number
-//                     parameterisation), background / tidal / weak-stability / near-inertial mixing -> difdia, trc(tke, gls)
+//   k_dfi_vert_a/b/c  Brunt-Vaisala frequency, the one-equation TKE closure's source step (or the Richardson number
+//                     parameterisation), background / tidal / weak-stability / near-inertial mixing -> difdia, trc(tke, gls);
+//                     the per-level part with one thread per point AND level
 //   k_dfi_lateral     Rossby radius, difwgt, Eady growth rate (shear or large scale), Eden-Greatbatch diffusivities with the
 //                     suppression options -> difint, difiso; then the halo updates (and the optional smoothing) of :2577-2614
 // Real powers and exponentials are the host libm's bits (pow_libm.h, exp_libm.h); tanh of the latitude (tidal mixing length
@@ -82,7 +83,7 @@
 #define LS_UNLMT_MIN 1.e-8
 
 // work-space slots (fields of kk levels)
-enum { W_DU2 = 0, W_DV2, W_BVFSQ, W_BVF, W_EGR, W_ANISOK, W_SM1, W_SM2, W_NSLOT };
+enum { W_DU2 = 0, W_DV2, W_BVFSQ, W_BVF, W_EGR, W_ANISOK, W_SM1, W_SM2, W_NUB, W_NSLOT };
 
 struct TkeC {            // initke's derived constants, phy/mod_tke.F90:133-160
   double sqrt2, cmu_fac1, cmu_fac2, cmu_fac3, tke_exp1, gls_exp1, gls_fac6, s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5, cmu0p3;
@@ -260,35 +261,37 @@ __global__ __launch_bounds__(64) void k_dfi_common(const DevView *__restrict__ V
 }
 
 // ---- difest_vertical_iso, :2629-3084 ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dfi_vertical(const DevView *__restrict__ Vp, DfePar D, int nn) {
+// Three kernels.  What the routine does per level inside the range kfil..kmax -- background / shear or TKE-closure / tidal / weak-stability
+// mixing -- reads nothing of the other levels but two column quantities (the bottom-weighted buoyancy frequency bvfbot and
+// exp(p_bottom / q)), so it runs with one thread per point AND level (k_dfi_vert_b: 5.6 M threads on the channel instead of 106 k
+// k-serial ones; the first, all-in-one column kernel took 0.68 ms of a 7 ms step).  The column sums and everything that is a
+// recurrence in k stay column kernels in the reference's order: k_dfi_vert_a in front (bvfsq, bvf, the closure's Buoy / Shear2 / Prod
+// from the old difdia, bvfbot, and exp(p(k)/q) of every interface once -- a level needs its own and the next one's), k_dfi_vert_c
+// behind (values copied down through the levels outside the range, the vertical averages dfddsu / dfddsl, the fill above kfil, the
+// near-inertial term, the surface interface).
+#define S2_BVFBOT 10
+#define S2_EXPB 11
+__global__ __launch_bounds__(64) void k_dfi_vert_a(const DevView *__restrict__ Vp, DfePar D, int nn) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
-  const bool any = km - kf >= 1;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const Params &P = V.P;
-  const TkeC &T = D.T;
   const double *p = V.f[F_p] + c, *dp = V.f[F_dp] + c + (size_t)nn * np;
-  const double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *rig = V.f[F_rig] + c;
-  double *difdia = V.f[F_difdia] + c;
-  double *bvfsq = WK(V, W_BVFSQ) + c, *bvf = WK(V, W_BVF) + c;
-  double *Buoy = V.f[F_Buoy] + c, *Shear2 = V.f[F_Shear2] + c, *Prod = V.f[F_Prod] + c, *Lsc = V.f[F_L_scale] + c;
-  double *tke = nullptr, *gls = nullptr;
-  if (D.use_tke) {
-    tke = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
-    gls = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.igls - 1) * 2 * kk) * np;
-  }
-  const double delt1 = P.delt1;
-  const double pbot = p[(size_t)kk * np];
-#define PL(k) p[(size_t)((k) - 1) * np]
-  // Brunt-Vaisala frequency, :2653-2709
+  const double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *difdia = V.f[F_difdia] + c;
+  double *bvfsq = WK(V, W_BVFSQ) + c, *bvf = WK(V, W_BVF) + c, *ex = V.f[F_wkp1] + c;
+  double *Buoy = V.f[F_Buoy] + c, *Shear2 = V.f[F_Shear2] + c, *Prod = V.f[F_Prod] + c;
+  const double pbot = p[(size_t)kk * np], q = V.f[F_tdmls][c];
   double bvfbot = 0., dps = 0.;
-  if (any)
-    for (int k = kf > 4 ? kf : 4; k <= km && k <= kk; k++) {
+  if (km - kf >= 1) {
+    const int k1 = kf > 4 ? kf : 4;
+    double pk = p[(size_t)(k1 - 1) * np];
+    ex[(size_t)(k1 - 1) * np] = exp_libm(pk / q);
+    for (int k = k1; k <= km && k <= kk; k++) {                                    // :2653-2701
       const size_t o = (size_t)(k - 1) * np;
-      const double dpk = dp[o];
+      const double dpk = dp[o], pk1 = p[o + np];
+      ex[o + np] = exp_libm(pk1 / q);
       const double b2 = GRAV * GRAV * fmax2(DRHOMN, drhol[o]) / fmax2(EPSILP, dpk);
       const double b = sqrt(b2);
       bvfsq[o] = b2;
@@ -307,117 +310,164 @@ __global__ __launch_bounds__(64) void k_dfi_vertical(const DevView *__restrict__
           Prod[o] = 0.;
         }
       }
-      const double q = fmax2(0., PL(k + 1) - fmax2(pbot - DPNBAV, PL(k)));
-      if (q > 0.) {
-        bvfbot = bvfbot + b * q;
-        dps = dps + q;
+      const double w = fmax2(0., pk1 - fmax2(pbot - DPNBAV, pk));
+      if (w > 0.) {
+        bvfbot = bvfbot + b * w;
+        dps = dps + w;
       }
+      pk = pk1;
     }
+  }
   if (dps > 0.) bvfbot = bvfbot / dps;
-  // diapycnal diffusivity, :2715-2977
-  difdia[0] = NU0;
-  double dfddsu = 0., dfddsl = 0.;
-  dps = 0.;
-  const double ficem = V.f[F_ficem][c], ustar = V.f[F_ustar][c];
+  WK2(V, S2_BVFBOT)[c] = bvfbot;
+  WK2(V, S2_EXPB)[c] = exp_libm(pbot / q);
+}
+
+// one thread per point and level: the level's diffusivity, :2729-2949
+__global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int k = by_ + 1;
+  const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
+  if (!(km - kf >= 1 && k >= kf && k <= km && k >= 2)) return;
+  const size_t np = V.nplane, o = (size_t)(k - 1) * np + c;
+  const int kk = V.kk;
+  const Params &P = V.P;
+  const TkeC &T = D.T;
+  const double *p = V.f[F_p];
+  const double pk = p[o], pk1 = p[o + np], pbot = p[c + (size_t)kk * np];
+  const double dpk = V.f[F_dp][o + (size_t)nn * np], b2 = WK(V, W_BVFSQ)[o];
+  double nub;
+  if (P.bdmtyp == 1) nub = P.bdmc1 / WK(V, W_BVF)[o];
+  else if (P.bdmtyp == 2) nub = P.bdmc2;
+  else nub = 0.;
+  if (P.iwdflg == 1) nub = nub * (1. + (P.iwdfac - 1.) * V.f[F_ficem][c]);
+  if (P.bdmldp) {
+    const double q = fmax2(1.e-9, fabs(V.f[F_coriop][c]));
+    nub = nub * q / CORI30 * V.f[F_bdmlq][c] / D.bdml_logc;
+  }
+  nub = fmax2(P.nubmin, nub);
+  double nus;
+  if (!D.use_tke) {
+    const double ri = V.f[F_rig][o];
+    if (ri < D.ri0) {                                                             // :2756-2775
+      double q = (pbot - pk + .5 * dpk) / fmin2(DPGC, .5 * pbot);
+      q = fmax2(0., 1. - q * q);
+      q = q * q * q;
+      nus = q * NUG0 + (1. - q) * NUS0;
+      q = ri / D.ri0;
+      q = fmax2(0., 1. - q * q);
+      nus = nus * q * q * q;
+    } else
+      nus = 0.;
+  } else {                                                                        // the one-equation closure, :2776-2921
+    double *tke = V.f[F_trc] + o + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
+    double *gls = V.f[F_trc] + o + ((size_t)nn + (size_t)(D.igls - 1) * 2 * kk) * np;
+    const double delt1 = P.delt1;
+    const double gls_c3 = b2 > 0. ? GLS_C3MINUS : GLS_C3PLUS;
+    const double prod = V.f[F_Prod][o], buoy = V.f[F_Buoy][o];
+    double tk = *tke, gl = fmax2((GLS_C1 * prod + gls_c3 * buoy) / GLS_C2, GLS_PSI_MIN);
+    // (the real powers trc**(1.5+gls_m/gls_n), trc**(-1./gls_n) have the exponents 0 and 1: the compiler folds them)
+    const double tke_epsilon = T.cmu_fac2 * gl;
+    const double tke_q = tke_epsilon / tk;
+    if (prod + buoy >= 0.) tk = (tk + delt1 * (prod + buoy)) / (1. + delt1 * tke_q);
+    else {
+      tk = (tk + delt1 * prod) / (1. + delt1 * (tke_q - (buoy / tk)));
+      tk = fmax2(tk, TKE_MIN);
+    }
+    if (D.tkepf > 0.) {                                                            // :2840-2850
+      double q;
+      if (dpk < EPSILP) q = exp_libm(-pk / TKEPLS);
+      else q = TKEPLS * (exp_libm(-pk / TKEPLS) - exp_libm(-pk1 / TKEPLS)) / dpk;
+      const double ustar = V.f[F_ustar][c];
+      tk = tk + 67.83 * D.tkepf * q * (ustar * ustar);
+    }
+    if (dpk < EPSILP) { tk = TKE_MIN; gl = GLS_PSI_MIN; }
+    if (k == km) {                                                                 // bottom boundary condition, :2863-2872
+      const double ust = fmax2(V.f[F_ustarb][c], USTMIN);
+      const double r = ust / GLS_CMU0;
+      tk = fmax2(TKE_MIN, r * r);
+    }
+    *tke = tk;
+    *gls = gl;
+    // trc(tke)**(-tke_exp1) and, below, trc(tke)**(-gls_m/gls_n): the same base and the same exponent, 1.5 -- one evaluation
+    const double tk15 = pow_libm(tk, -T.tke_exp1);
+    const double ls_unlmt = fmax2(LS_UNLMT_MIN, T.cmu_fac1 * pow_libm(gl, T.gls_exp1) * tk15);
+    double ls;
+    if (b2 > 0.) ls = fmin2(ls_unlmt, (T.tke_exp1 == -1.5 ? tk15 : pow_libm(tk, 1.5)) * (1. / gl));
+    else ls = ls_unlmt;
+    double gh = fmin2(GLS_GH0, -(b2 * ls * ls) / (2. * tk));                        // Canuto-A stability functions, :2892-2908
+    const double ghc = gh - GLS_GHCRI;
+    gh = fmin2(gh, (gh - ghc * ghc) / (gh + GLS_GH0 - 2. * GLS_GHCRI));
+    gh = fmax2(gh, GLS_GHMIN);
+    gh = fmin2(gh, GLS_GH0);
+    const double f6 = T.gls_fac6, f62 = f6 * f6;
+    double gm = (T.b0 / f6 - T.b1 * gh + T.b3 * f6 * (gh * gh)) / (T.b2 - T.b4 * f6 * gh);
+    gm = fmin2(gm, V.f[F_Shear2][o] * ls * ls / (2. * tk));
+    const double cff = T.b0 - T.b1 * f6 * gh + T.b2 * f6 * gm + T.b3 * f62 * (gh * gh) - T.b4 * f62 * gh * gm + T.b5 * f62 * gm * gm;
+    double sh = (T.s4 - T.s5 * f6 * gh + T.s6 * f6 * gm) / cff;
+    sh = fmax2(sh, 0.);
+    sh = sh * T.cmu_fac3 / T.cmu0p3;
+    const double ql = T.sqrt2 * ls * sqrt(tk);
+    nus = fmin2(sh * ql, 4.05 * NUG0);
+    V.f[F_L_scale][o] = fmax2(ls, LS_UNLMT_MIN);
+  }
+  double nut;                                                                      // tidally driven mixing, :2924-2937
+  {
+    const double q = V.f[F_tdmls][c];
+    const double *ex = V.f[F_wkp1];
+    const double eb = WK2(V, S2_EXPB)[c];
+    double vsf;
+    if (dpk < EPSILP) vsf = ex[o] / (q * (eb - 1.));
+    else vsf = (ex[o + np] - ex[o]) / (dpk * (eb - 1.));
+    nut = GRAV * TDMQ * DMXEFF * V.f[F_twedon][c] * WK2(V, S2_BVFBOT)[c] * vsf / b2;
+  }
+  double nuls;                                                                     // weak local stability, :2940-2946
+  const double dr = V.f[F_drhol][o];
+  if (dr < DRHO0) {
+    double q = dr / DRHO0;
+    q = fmax2(0., 1. - q * q);
+    nuls = NULS0 * q * q * q;
+  } else
+    nuls = 0.;
+  V.f[F_difdia][o] = nub + nus + nut + nuls;
+  WK(V, W_NUB)[o] = nub;
+}
+
+__global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ Vp, DfePar D, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
+  const bool any = km - kf >= 1;
+  const size_t np = V.nplane;
+  const int kk = V.kk;
+  const double *p = V.f[F_p] + c, *dp = V.f[F_dp] + c + (size_t)nn * np;
+  double *difdia = V.f[F_difdia] + c, *Lsc = V.f[F_L_scale] + c;
+  const double *bvfsq = WK(V, W_BVFSQ) + c, *nubw = WK(V, W_NUB) + c;
+  double *tke = nullptr, *gls = nullptr;
+  if (D.use_tke) {
+    tke = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
+    gls = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.igls - 1) * 2 * kk) * np;
+  }
+#define PL(k) p[(size_t)((k) - 1) * np]
+  const double pbot = PL(kk + 1);
+  difdia[0] = NU0;                                                                 // :2715
+  double dfddsu = 0., dfddsl = 0., dps = 0.;
   const double pkf = kf <= kk + 1 ? PL(kf < 1 ? 1 : kf) : 0.;
   for (int k = 2; k <= kk; k++) {
     const size_t o = (size_t)(k - 1) * np;
     if (any && k >= kf && k <= km) {
-      const double dpk = dp[o], b2 = bvfsq[o];
-      double nub;
-      if (P.bdmtyp == 1) nub = P.bdmc1 / bvf[o];
-      else if (P.bdmtyp == 2) nub = P.bdmc2;
-      else nub = 0.;
-      if (P.iwdflg == 1) nub = nub * (1. + (P.iwdfac - 1.) * ficem);
-      if (P.bdmldp) {
-        const double q = fmax2(1.e-9, fabs(V.f[F_coriop][c]));
-        nub = nub * q / CORI30 * V.f[F_bdmlq][c] / D.bdml_logc;
-      }
-      nub = fmax2(P.nubmin, nub);
-      double nus;
-      if (!D.use_tke) {
-        const double ri = rig[o];
-        if (ri < D.ri0) {                                                         // :2756-2775
-          double q = (pbot - PL(k) + .5 * dpk) / fmin2(DPGC, .5 * pbot);
-          q = fmax2(0., 1. - q * q);
-          q = q * q * q;
-          nus = q * NUG0 + (1. - q) * NUS0;
-          q = ri / D.ri0;
-          q = fmax2(0., 1. - q * q);
-          nus = nus * q * q * q;
-        } else
-          nus = 0.;
-      } else {                                                                    // the one-equation closure, :2776-2921
-        const double gls_c3 = b2 > 0. ? GLS_C3MINUS : GLS_C3PLUS;
-        const double prod = Prod[o], buoy = Buoy[o];
-        double tk = tke[o], gl = fmax2((GLS_C1 * prod + gls_c3 * buoy) / GLS_C2, GLS_PSI_MIN);
-        // (the real powers trc**(1.5+gls_m/gls_n), trc**(-1./gls_n) have the exponents 0 and 1: the compiler folds them)
-        const double tke_epsilon = T.cmu_fac2 * gl;
-        const double tke_q = tke_epsilon / tk;
-        if (prod + buoy >= 0.) tk = (tk + delt1 * (prod + buoy)) / (1. + delt1 * tke_q);
-        else {
-          tk = (tk + delt1 * prod) / (1. + delt1 * (tke_q - (buoy / tk)));
-          tk = fmax2(tk, TKE_MIN);
-        }
-        if (D.tkepf > 0.) {                                                        // :2840-2850
-          double q;
-          if (dpk < EPSILP) q = exp_libm(-PL(k) / TKEPLS);
-          else q = TKEPLS * (exp_libm(-PL(k) / TKEPLS) - exp_libm(-PL(k + 1) / TKEPLS)) / dpk;
-          tk = tk + 67.83 * D.tkepf * q * (ustar * ustar);
-        }
-        if (dpk < EPSILP) { tk = TKE_MIN; gl = GLS_PSI_MIN; }
+      if (k == kf && D.use_tke) {             // what the first level inside the range does to the two mixed layer layers, :2857-2860
         tke[0] = TKE_MIN; tke[np] = TKE_MIN;
         gls[0] = GLS_PSI_MIN; gls[np] = GLS_PSI_MIN;
-        if (k == km) {                                                             // bottom boundary condition, :2863-2872
-          const double ust = fmax2(V.f[F_ustarb][c], USTMIN);
-          const double r = ust / GLS_CMU0;
-          tk = fmax2(TKE_MIN, r * r);
-        }
-        tke[o] = tk;
-        gls[o] = gl;
-        const double ls_unlmt = fmax2(LS_UNLMT_MIN, T.cmu_fac1 * pow_libm(gl, T.gls_exp1) * pow_libm(tk, -T.tke_exp1));
-        double ls;
-        if (b2 > 0.) ls = fmin2(ls_unlmt, pow_libm(tk, 1.5) * (1. / gl));
-        else ls = ls_unlmt;
-        double gh = fmin2(GLS_GH0, -(b2 * ls * ls) / (2. * tk));                    // Canuto-A stability functions, :2892-2908
-        const double ghc = gh - GLS_GHCRI;
-        gh = fmin2(gh, (gh - ghc * ghc) / (gh + GLS_GH0 - 2. * GLS_GHCRI));
-        gh = fmax2(gh, GLS_GHMIN);
-        gh = fmin2(gh, GLS_GH0);
-        const double f6 = T.gls_fac6, f62 = f6 * f6;
-        double gm = (T.b0 / f6 - T.b1 * gh + T.b3 * f6 * (gh * gh)) / (T.b2 - T.b4 * f6 * gh);
-        gm = fmin2(gm, Shear2[o] * ls * ls / (2. * tk));
-        const double cff = T.b0 - T.b1 * f6 * gh + T.b2 * f6 * gm + T.b3 * f62 * (gh * gh) - T.b4 * f62 * gh * gm + T.b5 * f62 * gm * gm;
-        double sh = (T.s4 - T.s5 * f6 * gh + T.s6 * f6 * gm) / cff;
-        sh = fmax2(sh, 0.);
-        sh = sh * T.cmu_fac3 / T.cmu0p3;
-        const double ql = T.sqrt2 * ls * sqrt(tk);
-        nus = fmin2(sh * ql, 4.05 * NUG0);
-        Lsc[o] = fmax2(ls, LS_UNLMT_MIN);
       }
-      double nut;                                                                  // tidally driven mixing, :2924-2937
-      {
-        const double q = V.f[F_tdmls][c];
-        double vsf;
-        if (dpk < EPSILP) vsf = exp_libm(PL(k) / q) / (q * (exp_libm(pbot / q) - 1.));
-        else vsf = (exp_libm(PL(k + 1) / q) - exp_libm(PL(k) / q)) / (dpk * (exp_libm(pbot / q) - 1.));
-        nut = GRAV * TDMQ * DMXEFF * V.f[F_twedon][c] * bvfbot * vsf / b2;
-      }
-      double nuls;                                                                 // weak local stability, :2940-2946
-      const double dr = drhol[o];
-      if (dr < DRHO0) {
-        double q = dr / DRHO0;
-        q = fmax2(0., 1. - q * q);
-        nuls = NULS0 * q * q * q;
-      } else
-        nuls = 0.;
-      const double dd = nub + nus + nut + nuls;
-      difdia[o] = dd;
-      const double q = fmax2(0., fmin2(pkf + DPDDAV, PL(k + 1)) - PL(k));
+      const double q = fmax2(0., fmin2(pkf + DPDDAV, PL(k + 1)) - PL(k));           // :2951-2956
       dps = dps + q;
-      dfddsu = dfddsu + nub * q;
-      dfddsl = dfddsl + dd * q;
-    } else {
+      dfddsu = dfddsu + nubw[o] * q;
+      dfddsl = dfddsl + difdia[o] * q;
+    } else {                                                                       // :2958-2970
       difdia[o] = difdia[o - np];
       if (D.use_tke) {
         tke[o] = tke[o - np];
@@ -438,19 +488,24 @@ __global__ __launch_bounds__(64) void k_dfi_vertical(const DevView *__restrict__
     }
   if (any) {                                                                       // near-inertial waves, :3011-3032
     const double idk = V.f[F_idkedt][c];
+    const double q = NIWLS;
+    const double den = 1. - exp_libm((p3 - pbot) / q);
+    double e_lo = exp_libm((p3 - PL(3)) / q);                 // exp((p3 - p(k+1))/q) of k = 2; every level's lower value is the next one's upper
     for (int k = 2; k <= kk - 1 && k <= km; k++) {
       const size_t o = (size_t)(k - 1) * np;
-      const double q = NIWLS, dpk = dp[o];
+      const double dpk = dp[o];
+      const double e_up = k == 2 ? 0. : e_lo;                                      // exp((p3 - p(k))/q)
+      if (k > 2) e_lo = exp_libm((p3 - PL(k + 1)) / q);
       double vsf;
-      if (k == 2 || dpk < EPSILP) vsf = exp_libm((p3 - PL(k + 1)) / q) / (q * (1. - exp_libm((p3 - pbot) / q)));
-      else vsf = (exp_libm((p3 - PL(k)) / q) - exp_libm((p3 - PL(k + 1)) / q)) / (dpk * (1. - exp_libm((p3 - pbot) / q)));
+      if (k == 2 || dpk < EPSILP) vsf = e_lo / (q * den);
+      else vsf = (e_up - e_lo) / (dpk * den);
       const int kb = k > kf ? k : kf;
       const double nusm = GRAV * D.niwgf * (1. - D.niwbf) * D.niwlf * DMXEFF * idk * vsf / (ALPHA0 * bvfsq[(size_t)(kb - 1) * np]);
       difdia[o] = difdia[o] + nusm;
     }
   }
   {                                                                                // the lower interface of the top layer, :3035-3066
-    const double ust = fmax2(USTMIN, ustar);
+    const double ust = fmax2(USTMIN, V.f[F_ustar][c]);
     const double bf = V.f[F_buoyfl][c];
     const double mols = ust * ust * ust / (KAPPA * copysign(fmax2(fabs(bf), BFEPS), -bf));
     const double p1 = PL(1);
@@ -760,7 +815,9 @@ int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
     hipLaunchKernelGGL(k_dfi_kfil_util, plane_grid(h), dim3(256), 0, c->stream, c->d, 1);
     hipLaunchKernelGGL(k_dfi_uv2, g2, b64, 0, c->stream, c->d, nn);
     hipLaunchKernelGGL(k_dfi_common, g1, b64, 0, c->stream, c->d, nn);
-    hipLaunchKernelGGL(k_dfi_vertical, g1, b64, 0, c->stream, c->d, D, nn);
+    hipLaunchKernelGGL(k_dfi_vert_a, g1, b64, 0, c->stream, c->d, D, nn);
+    hipLaunchKernelGGL(k_dfi_vert_b, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, D, nn);
+    hipLaunchKernelGGL(k_dfi_vert_c, g1, b64, 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_lateral, g1, b64, 0, c->stream, c->d, D, n, nn);
   }
   HIPCHK(c, hipGetLastError());
