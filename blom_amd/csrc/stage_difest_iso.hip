@@ -41,6 +41,7 @@
 #define GRAV 9.806
 #define ALPHA0 1.e-3
 #define PI_BLOM 3.1415926536      // phy/mod_constants.F90:40
+#define BU 8                      // levels whose loads the column loops keep in flight
 #define EPSILP 1.e-12
 #define ONEM 9806.
 #define DPBMIN 98.06              // onecm, :174
@@ -199,28 +200,36 @@ __global__ __launch_bounds__(64) void k_dfi_uv2(const DevView *__restrict__ Vp, 
       }
   }
   double tup = 0., vk = vel[0];
-  for (int k = 1; k <= kk; k++) {
-    const double vn = k < kk ? vel[(size_t)k * np] : 0.;
-    double d = 0.;
-    int m = 0;
-    if (k >= kfpl && k <= klpl && klpl - kfpl >= 1) {
-      if (k == kfpl) {
-        double q = vn - vk;
-        q = q * q;
-        d = q;
-        tup = q;
-      } else if (k < klpl) {
-        double q = vn - vk;
-        q = q * q;
-        d = .5 * (tup + q);
-        tup = q;
-      } else
-        d = tup;
-      m = 1;
+  for (int k0 = 1; k0 <= kk; k0 += BU) {
+    double a[BU];
+#pragma unroll
+    for (int uu = 0; uu < BU; uu++) a[uu] = vel[(size_t)(k0 + uu < kk ? k0 + uu : kk - 1) * np];
+#pragma unroll
+    for (int uu = 0; uu < BU; uu++) {
+      const int k = k0 + uu;
+      if (k > kk) break;
+      const double vn = k < kk ? a[uu] : 0.;
+      double d = 0.;
+      int m = 0;
+      if (k >= kfpl && k <= klpl && klpl - kfpl >= 1) {
+        if (k == kfpl) {
+          double q = vn - vk;
+          q = q * q;
+          d = q;
+          tup = q;
+        } else if (k < klpl) {
+          double q = vn - vk;
+          q = q * q;
+          d = .5 * (tup + q);
+          tup = q;
+        } else
+          d = tup;
+        m = 1;
+      }
+      d2[(size_t)(k - 1) * np] = d;
+      msk[(size_t)(k - 1) * np] = m;
+      vk = vn;
     }
-    d2[(size_t)(k - 1) * np] = d;
-    msk[(size_t)(k - 1) * np] = m;
-    vk = vn;
   }
 }
 
@@ -239,24 +248,43 @@ __global__ __launch_bounds__(64) void k_dfi_common(const DevView *__restrict__ V
   const int *msku = V.m[I_msku] + c, *mskv = V.m[I_mskv] + c;
   double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *rig = V.f[F_rig] + c;
   double tup = 0.;
-  const int k1 = kf > 4 ? kf : 4;
-  for (int k = k1; k <= km && k <= kk; k++) {
-    const size_t o = (size_t)(k - 1) * np;
-    double dr;
-    if (k < km) {
-      const double pk1 = p[(size_t)k * np];
-      const double q = fmax2(0., eos::rho(pk1, temp[o + np], saln[o + np]) - eos::rho(pk1, temp[o], saln[o]));
-      if (k == kf) dr = q;
-      else dr = 2. * tup * q / fmax2(1.e-11, tup + q);
-      tup = q;
-    } else
-      dr = tup;
-    drhol[o] = dr;
-    const int mu0 = msku[o], mu1 = msku[o + 1], mv0 = mskv[o], mv1 = mskv[o + ni];
-    const double d2 = ((double)mu0 * du2[o] + (double)mu1 * du2[o + 1]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) +
-                      ((double)mv0 * dv2[o] + (double)mv1 * dv2[o + ni]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1);
-    du2l[o] = d2;
-    rig[o] = ALPHA0 * ALPHA0 * fmax2(DRHOMN, dr) * dp[o] / fmax2(1.e-13, d2);
+  const int k1 = kf > 4 ? kf : 4, k2 = km < kk ? km : kk;
+  if (k1 > k2) return;
+  double tk = temp[(size_t)(k1 - 1) * np], sk = saln[(size_t)(k1 - 1) * np];
+  for (int k0 = k1; k0 <= k2; k0 += BU) {
+    double a0[BU], a1[BU], a2[BU], a3[BU], d0[BU], d1[BU], e0[BU], e1[BU];
+    int m0[BU], m1[BU], n0[BU], n1[BU];
+#pragma unroll
+    for (int uu = 0; uu < BU; uu++) {
+      const int kq = k0 + uu <= k2 ? k0 + uu : k2;
+      const size_t o = (size_t)(kq - 1) * np, o1 = (size_t)(kq < kk ? kq : kk - 1) * np;
+      a0[uu] = p[(size_t)kq * np]; a1[uu] = temp[o1]; a2[uu] = saln[o1]; a3[uu] = dp[o];
+      d0[uu] = du2[o]; d1[uu] = du2[o + 1]; e0[uu] = dv2[o]; e1[uu] = dv2[o + ni];
+      m0[uu] = msku[o]; m1[uu] = msku[o + 1]; n0[uu] = mskv[o]; n1[uu] = mskv[o + ni];
+    }
+#pragma unroll
+    for (int uu = 0; uu < BU; uu++) {
+      const int k = k0 + uu;
+      if (k > k2) break;
+      const size_t o = (size_t)(k - 1) * np;
+      double dr;
+      if (k < km) {
+        const double pk1 = a0[uu];
+        const double q = fmax2(0., eos::rho(pk1, a1[uu], a2[uu]) - eos::rho(pk1, tk, sk));
+        if (k == kf) dr = q;
+        else dr = 2. * tup * q / fmax2(1.e-11, tup + q);
+        tup = q;
+      } else
+        dr = tup;
+      drhol[o] = dr;
+      const int mu0 = m0[uu], mu1 = m1[uu], mv0 = n0[uu], mv1 = n1[uu];
+      const double d2 = ((double)mu0 * d0[uu] + (double)mu1 * d1[uu]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) +
+                        ((double)mv0 * e0[uu] + (double)mv1 * e1[uu]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1);
+      du2l[o] = d2;
+      rig[o] = ALPHA0 * ALPHA0 * fmax2(DRHOMN, dr) * a3[uu] / fmax2(1.e-13, d2);
+      tk = a1[uu];
+      sk = a2[uu];
+    }
   }
 }
 
@@ -288,34 +316,46 @@ __global__ __launch_bounds__(64) void k_dfi_vert_a(const DevView *__restrict__ V
     const int k1 = kf > 4 ? kf : 4;
     double pk = p[(size_t)(k1 - 1) * np];
     ex[(size_t)(k1 - 1) * np] = exp_libm(pk / q);
-    for (int k = k1; k <= km && k <= kk; k++) {                                    // :2653-2701
-      const size_t o = (size_t)(k - 1) * np;
-      const double dpk = dp[o], pk1 = p[o + np];
-      ex[o + np] = exp_libm(pk1 / q);
-      const double b2 = GRAV * GRAV * fmax2(DRHOMN, drhol[o]) / fmax2(EPSILP, dpk);
-      const double b = sqrt(b2);
-      bvfsq[o] = b2;
-      bvf[o] = b;
-      if (D.use_tke) {
-        if (dpk > DPBMIN) {
-          const double dd = difdia[o];
-          Buoy[o] = -dd * b2;
-          const double h = fmax2(ONEM, dpk) * ALPHA0 / GRAV;
-          const double s2 = fmax2(1.e-13, du2l[o]) / (h * h);
-          Shear2[o] = s2;
-          Prod[o] = dd * PR_T * s2;
-        } else {
-          Buoy[o] = 0.;
-          Shear2[o] = 1.e-9;
-          Prod[o] = 0.;
+    const int k2 = km < kk ? km : kk;
+    for (int k0 = k1; k0 <= k2; k0 += BU) {                                        // :2653-2701
+      double a0[BU], a1[BU], a2[BU], a3[BU], a4[BU];
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const size_t o = (size_t)((k0 + uu <= k2 ? k0 + uu : k2) - 1) * np;
+        a0[uu] = dp[o]; a1[uu] = p[o + np]; a2[uu] = drhol[o]; a3[uu] = D.use_tke ? du2l[o] : 0.; a4[uu] = D.use_tke ? difdia[o] : 0.;
+      }
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const int k = k0 + uu;
+        if (k > k2) break;
+        const size_t o = (size_t)(k - 1) * np;
+        const double dpk = a0[uu], pk1 = a1[uu];
+        ex[o + np] = exp_libm(pk1 / q);
+        const double b2 = GRAV * GRAV * fmax2(DRHOMN, a2[uu]) / fmax2(EPSILP, dpk);
+        const double b = sqrt(b2);
+        bvfsq[o] = b2;
+        bvf[o] = b;
+        if (D.use_tke) {
+          if (dpk > DPBMIN) {
+            const double dd = a4[uu];
+            Buoy[o] = -dd * b2;
+            const double h = fmax2(ONEM, dpk) * ALPHA0 / GRAV;
+            const double s2 = fmax2(1.e-13, a3[uu]) / (h * h);
+            Shear2[o] = s2;
+            Prod[o] = dd * PR_T * s2;
+          } else {
+            Buoy[o] = 0.;
+            Shear2[o] = 1.e-9;
+            Prod[o] = 0.;
+          }
         }
+        const double w = fmax2(0., pk1 - fmax2(pbot - DPNBAV, pk));
+        if (w > 0.) {
+          bvfbot = bvfbot + b * w;
+          dps = dps + w;
+        }
+        pk = pk1;
       }
-      const double w = fmax2(0., pk1 - fmax2(pbot - DPNBAV, pk));
-      if (w > 0.) {
-        bvfbot = bvfbot + b * w;
-        dps = dps + w;
-      }
-      pk = pk1;
     }
   }
   if (dps > 0.) bvfbot = bvfbot / dps;
@@ -456,22 +496,45 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
   difdia[0] = NU0;                                                                 // :2715
   double dfddsu = 0., dfddsl = 0., dps = 0.;
   const double pkf = kf <= kk + 1 ? PL(kf < 1 ? 1 : kf) : 0.;
-  for (int k = 2; k <= kk; k++) {
-    const size_t o = (size_t)(k - 1) * np;
-    if (any && k >= kf && k <= km) {
-      if (k == kf && D.use_tke) {             // what the first level inside the range does to the two mixed layer layers, :2857-2860
+  {
+    // levels above the range take the value of the level above them (:2958-2970): difdia = nu0, the TKE and the length scale of layer 1
+    const int ka = any ? (kf > 2 ? kf : 2) : kk + 1, kb = any ? (km < kk ? km : kk) : kk;
+    double ld = NU0, lt = D.use_tke ? tke[0] : 0., ll = D.use_tke ? Lsc[0] : 0.;
+    for (int k = 2; k < ka; k++) {
+      const size_t o = (size_t)(k - 1) * np;
+      difdia[o] = ld;
+      if (D.use_tke) { tke[o] = lt; Lsc[o] = ll; }
+    }
+    if (any) {
+      if (D.use_tke) {                        // what the first level inside the range does to the two mixed layer layers, :2857-2860
         tke[0] = TKE_MIN; tke[np] = TKE_MIN;
         gls[0] = GLS_PSI_MIN; gls[np] = GLS_PSI_MIN;
       }
-      const double q = fmax2(0., fmin2(pkf + DPDDAV, PL(k + 1)) - PL(k));           // :2951-2956
-      dps = dps + q;
-      dfddsu = dfddsu + nubw[o] * q;
-      dfddsl = dfddsl + difdia[o] * q;
-    } else {                                                                       // :2958-2970
-      difdia[o] = difdia[o - np];
-      if (D.use_tke) {
-        tke[o] = tke[o - np];
-        Lsc[o] = Lsc[o - np];
+      const double pq = pkf + DPDDAV;
+      double pk = PL(ka);
+      for (int k0 = ka; k0 <= kb; k0 += BU) {                                      // :2951-2956
+        double a0[BU], a1[BU], a2[BU];
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
+          a0[uu] = p[o + np]; a1[uu] = nubw[o]; a2[uu] = difdia[o];
+        }
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          if (k0 + uu > kb) break;
+          const double q = fmax2(0., fmin2(pq, a0[uu]) - pk);
+          dps = dps + q;
+          dfddsu = dfddsu + a1[uu] * q;
+          dfddsl = dfddsl + a2[uu] * q;
+          pk = a0[uu];
+          ld = a2[uu];
+        }
+      }
+      if (D.use_tke) { lt = tke[(size_t)(kb - 1) * np]; ll = Lsc[(size_t)(kb - 1) * np]; }
+      for (int k = kb + 1; k <= kk; k++) {
+        const size_t o = (size_t)(k - 1) * np;
+        difdia[o] = ld;
+        if (D.use_tke) { tke[o] = lt; Lsc[o] = ll; }
       }
     }
   }
@@ -491,17 +554,28 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
     const double q = NIWLS;
     const double den = 1. - exp_libm((p3 - pbot) / q);
     double e_lo = exp_libm((p3 - PL(3)) / q);                 // exp((p3 - p(k+1))/q) of k = 2; every level's lower value is the next one's upper
-    for (int k = 2; k <= kk - 1 && k <= km; k++) {
-      const size_t o = (size_t)(k - 1) * np;
-      const double dpk = dp[o];
-      const double e_up = k == 2 ? 0. : e_lo;                                      // exp((p3 - p(k))/q)
-      if (k > 2) e_lo = exp_libm((p3 - PL(k + 1)) / q);
-      double vsf;
-      if (k == 2 || dpk < EPSILP) vsf = e_lo / (q * den);
-      else vsf = (e_up - e_lo) / (dpk * den);
-      const int kb = k > kf ? k : kf;
-      const double nusm = GRAV * D.niwgf * (1. - D.niwbf) * D.niwlf * DMXEFF * idk * vsf / (ALPHA0 * bvfsq[(size_t)(kb - 1) * np]);
-      difdia[o] = difdia[o] + nusm;
+    const int kb = km < kk - 1 ? km : kk - 1;
+    for (int k0 = 2; k0 <= kb; k0 += BU) {
+      double a0[BU], a1[BU], a2[BU], a3[BU];
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const int kq = k0 + uu <= kb ? k0 + uu : kb;
+        const size_t o = (size_t)(kq - 1) * np;
+        a0[uu] = dp[o]; a1[uu] = p[o + np]; a2[uu] = bvfsq[(size_t)((kq > kf ? kq : kf) - 1) * np]; a3[uu] = difdia[o];
+      }
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const int k = k0 + uu;
+        if (k > kb) break;
+        const double dpk = a0[uu];
+        const double e_up = k == 2 ? 0. : e_lo;                                    // exp((p3 - p(k))/q)
+        if (k > 2) e_lo = exp_libm((p3 - a1[uu]) / q);
+        double vsf;
+        if (k == 2 || dpk < EPSILP) vsf = e_lo / (q * den);
+        else vsf = (e_up - e_lo) / (dpk * den);
+        const double nusm = GRAV * D.niwgf * (1. - D.niwbf) * D.niwlf * DMXEFF * idk * vsf / (ALPHA0 * a2[uu]);
+        difdia[(size_t)(k - 1) * np] = a3[uu] + nusm;
+      }
     }
   }
   {                                                                                // the lower interface of the top layer, :3035-3066
@@ -550,18 +624,34 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   const int kfp = V.m[I_kfpla][c + on];
   double pup = .5 * (3. * PL(3) - PL((kk < kfp ? kk : kfp) + 1));
   double tup = temp[np], sup = saln[np], cr = 0.;
-  for (int k = 3; k <= kk; k++)
-    if (k >= kfp) {
-      const size_t o = (size_t)(k - 1) * np;
-      double plo;
-      if (pbot - PL(k + 1) < EPSILP) plo = pbot;
-      else plo = .5 * (PL(k) + PL(k + 1));
-      const double tlo = temp[o], slo = saln[o], pk = PL(k);
-      cr = cr + sqrt(fmax2(0., (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) * (plo - pup)));
-      pup = plo;
-      tup = tlo;
-      sup = slo;
+  {
+    // (BU levels' loads issued before the first is used -- blomgpu_internal.h: COLUMN_U -- here and in every loop below: a level's
+    // inputs do not depend on what the loop computes, the sums travel in registers in the reference's order)
+    const int k3 = kfp > 3 ? kfp : 3;
+    double pk = k3 <= kk ? PL(k3) : 0.;
+    for (int k0 = k3; k0 <= kk; k0 += BU) {
+      double a[BU], b[BU], d[BU];
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const size_t o = (size_t)((k0 + uu <= kk ? k0 + uu : kk) - 1) * np;
+        a[uu] = temp[o]; b[uu] = saln[o]; d[uu] = p[o + np];
+      }
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        if (k0 + uu > kk) break;
+        const double pk1 = d[uu];
+        double plo;
+        if (pbot - pk1 < EPSILP) plo = pbot;
+        else plo = .5 * (pk + pk1);
+        const double tlo = a[uu], slo = b[uu];
+        cr = cr + sqrt(fmax2(0., (eos::rho(pk, tlo, slo) - eos::rho(pk, tup, sup)) * (plo - pup)));
+        pup = plo;
+        tup = tlo;
+        sup = slo;
+        pk = pk1;
+      }
     }
+  }
   const double coriop = V.f[F_coriop][c], betafp = V.f[F_betafp][c];
   cr = ALPHA0 * cr / PI_BLOM;
   const double bcrrd = sqrt(cr * cr / fmax2(coriop * coriop + 2. * betafp * cr, 1.e-24));
@@ -579,54 +669,86 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   // Eady growth rate, :2160-2257
   const bool sa = D.edsprs || D.edanis;
   double egrs = 0., dps = 0.;
+  const int ka = kf > 2 ? kf : 2, kb = km < kk ? km : kk;            // the levels inside the range (when there are any)
+  const double pkf_g = any ? PL(kf) + DPGRAV : 0.;
   if (D.edritp == 1) {
-    if (any)
-      for (int k = kf > 2 ? kf : 2; k <= km && k <= kk; k++) {
-        const size_t o = (size_t)(k - 1) * np;
-        const double e = afeql / sqrt(rig[o] + D.eggam);
-        egr[o] = e;
-        if (sa) {
-          double q;
-          if (D.eddf2d) q = fmax2(0., PL(k + 1) - PL(k));
-          else q = fmax2(0., fmin2(PL(kf) + DPGRAV, PL(k + 1)) - PL(k));
-          dps = dps + q;
-          egrs = egrs + e * q;
+    if (any) {
+      double pk = PL(ka);
+      for (int k0 = ka; k0 <= kb; k0 += BU) {
+        double a[BU], d[BU];
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
+          a[uu] = rig[o]; d[uu] = p[o + np];
+        }
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          const int k = k0 + uu;
+          if (k > kb) break;
+          const double e = afeql / sqrt(a[uu] + D.eggam);
+          egr[(size_t)(k - 1) * np] = e;
+          if (sa) {
+            double q;
+            if (D.eddf2d) q = fmax2(0., d[uu] - pk);
+            else q = fmax2(0., fmin2(pkf_g, d[uu]) - pk);
+            dps = dps + q;
+            egrs = egrs + e * q;
+          }
+          pk = d[uu];
         }
       }
+    }
   } else if (any) {
     const double *nx = V.f[F_nnslpx] + c, *ny = V.f[F_nnslpy] + c;
     const int kmw = kmaxa[c - 1], kme = kmaxa[c + 1], kms = kmaxa[c - ni], kmn = kmaxa[c + ni];
-    auto slope2 = [&](int kq, bool ge) {          // the squared large scale slope x buoyancy frequency at interface kq, :2190-2205 / :2212-2227
-      const size_t o = (size_t)(kq - 1) * np;
-      const bool w = ge ? kmw >= kq : kmw > kq - 1, e = ge ? kme >= kq : kme > kq - 1;
-      const bool s = ge ? kms >= kq : kms > kq - 1, nn_ = ge ? kmn >= kq : kmn > kq - 1;
+    // the squared large scale slope x buoyancy frequency at interface kq from the four values around the point, :2190-2205 / :2212-2227
+    auto slope2 = [&](int kq, double x0, double x1, double y0, double y1) {
+      const bool w = kmw >= kq, e = kme >= kq, s_ = kms >= kq, n_ = kmn >= kq;
       double q;
-      if (w && e) { const double t = nx[o] + nx[o + 1]; q = .25 * (t * t); }
-      else if (w) q = nx[o] * nx[o];
-      else if (e) q = nx[o + 1] * nx[o + 1];
+      if (w && e) { const double t = x0 + x1; q = .25 * (t * t); }
+      else if (w) q = x0 * x0;
+      else if (e) q = x1 * x1;
       else q = 0.;
-      if (s && nn_) { const double t = ny[o] + ny[o + ni]; q = q + .25 * (t * t); }
-      else if (s) q = q + ny[o] * ny[o];
-      else if (nn_) q = q + ny[o + ni] * ny[o + ni];
+      if (s_ && n_) { const double t = y0 + y1; q = q + .25 * (t * t); }
+      else if (s_) q = q + y0 * y0;
+      else if (n_) q = q + y1 * y1;
       return q;
     };
-    double egrup = sqrt(slope2(kf, true));
-    for (int k = kf > 2 ? kf : 2; k <= km && k <= kk; k++) {
-      const size_t o = (size_t)(k - 1) * np;
-      if (k < km) {
-        const double egrlo = sqrt(slope2(k + 1, true));
-        const double e = .5 * (egrup + egrlo);
-        egr[o] = e;
-        egrup = egrlo;
-        if (sa) {
-          double q;
-          if (D.eddf2d) q = fmax2(0., PL(k + 1) - PL(k));
-          else q = fmax2(0., fmin2(PL(kf) + DPGRAV, PL(k + 1)) - PL(k));
-          dps = dps + q;
-          egrs = egrs + e * q;
-        }
-      } else
-        egr[o] = egr[o - np];
+    double egrup, egr_prev = 0.;
+    {
+      const size_t o = (size_t)(kf - 1) * np;
+      egrup = sqrt(slope2(kf, nx[o], nx[o + 1], ny[o], ny[o + ni]));
+    }
+    double pk = PL(ka);
+    for (int k0 = ka; k0 <= kb; k0 += BU) {
+      double x0[BU], x1[BU], y0[BU], y1[BU], d[BU];
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const int kq = k0 + uu <= kb ? k0 + uu : kb;
+        const size_t o = (size_t)(kq < kk ? kq : kk - 1) * np;            // the interface below the level (not read for the last level)
+        x0[uu] = nx[o]; x1[uu] = nx[o + 1]; y0[uu] = ny[o]; y1[uu] = ny[o + ni]; d[uu] = p[(size_t)kq * np];
+      }
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const int k = k0 + uu;
+        if (k > kb) break;
+        if (k < km) {
+          const double egrlo = sqrt(slope2(k + 1, x0[uu], x1[uu], y0[uu], y1[uu]));
+          const double e = .5 * (egrup + egrlo);
+          egr[(size_t)(k - 1) * np] = e;
+          egr_prev = e;
+          egrup = egrlo;
+          if (sa) {
+            double q;
+            if (D.eddf2d) q = fmax2(0., d[uu] - pk);
+            else q = fmax2(0., fmin2(pkf_g, d[uu]) - pk);
+            dps = dps + q;
+            egrs = egrs + e * q;
+          }
+        } else
+          egr[(size_t)(k - 1) * np] = egr_prev;
+        pk = d[uu];
+      }
     }
   }
   if (sa) {
@@ -636,35 +758,57 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   difint[0] = D.egmndf;
   double dfints = 0., anisos = 0.;
   dps = 0.;
-  // layer interface diffusivities, :2283-2375 (rhsctp is refused by the option setter)
-  for (int k = 2; k <= kk; k++) {
-    const size_t o = (size_t)(k - 1) * np;
-    if (any && k >= kf && k <= km) {
-      const double e = egr[o];
-      const double rhisc = e / fmax2(1.e-22, betafp);
-      double speed = 0.;
-      if (D.edanis) {
-        const double ubc = (u[o] * dpu[o] + u[o + 1] * dpu[o + 1]) / fmax2(EPSILP, dpu[o] + dpu[o + 1]);
-        const double vbc = (v[o] * dpv[o] + v[o + ni] * dpv[o + ni]) / fmax2(EPSILP, dpv[o] + dpv[o + ni]);
-        speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
+  // layer interface diffusivities, :2283-2375 (rhsctp is refused by the option setter); outside the range a level takes the value of the
+  // one above it: egmndf above the range, the last level's below it
+  if (any) {
+    for (int k = 2; k < ka; k++) difint[(size_t)(k - 1) * np] = D.egmndf;
+    const double pkf_d = PL(kf) + DPDIAV;
+    double pk = PL(ka), last = D.egmndf;
+    for (int k0 = ka; k0 <= kb; k0 += BU) {
+      double ev[BU], d[BU], u0[BU], u1[BU], du0[BU], du1[BU], v0[BU], v1[BU], dv0[BU], dv1[BU];
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
+        ev[uu] = egr[o]; d[uu] = p[o + np];
+        if (D.edanis) {
+          u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
+          v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
+        }
       }
-      const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
-      const double di = D.egc * e * els * els;
-      difint[o] = di;
-      double q;
-      if (D.eddf2d) q = fmax2(0., PL(k + 1) - PL(k));
-      else q = fmax2(0., fmin2(PL(kf) + DPDIAV, PL(k + 1)) - PL(k));
-      dps = dps + q;
-      dfints = dfints + di * q;
-      if (D.edanis) {
-        const double r = speed / fmax2(1.e-22, e * els);
-        const double a = 1. / (1. + r * r);
-        anisok[o] = a;
-        anisos = anisos + a * q;
+#pragma unroll
+      for (int uu = 0; uu < BU; uu++) {
+        const int k = k0 + uu;
+        if (k > kb) break;
+        const size_t o = (size_t)(k - 1) * np;
+        const double e = ev[uu];
+        const double rhisc = e / fmax2(1.e-22, betafp);
+        double speed = 0.;
+        if (D.edanis) {
+          const double ubc = (u0[uu] * du0[uu] + u1[uu] * du1[uu]) / fmax2(EPSILP, du0[uu] + du1[uu]);
+          const double vbc = (v0[uu] * dv0[uu] + v1[uu] * dv1[uu]) / fmax2(EPSILP, dv0[uu] + dv1[uu]);
+          speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
+        }
+        const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
+        const double di = D.egc * e * els * els;
+        difint[o] = di;
+        last = di;
+        double q;
+        if (D.eddf2d) q = fmax2(0., d[uu] - pk);
+        else q = fmax2(0., fmin2(pkf_d, d[uu]) - pk);
+        dps = dps + q;
+        dfints = dfints + di * q;
+        if (D.edanis) {
+          const double r = speed / fmax2(1.e-22, e * els);
+          const double a = 1. / (1. + r * r);
+          anisok[o] = a;
+          anisos = anisos + a * q;
+        }
+        pk = d[uu];
       }
-    } else
-      difint[o] = difint[o - np];
-  }
+    }
+    for (int k = kb + 1; k <= kk; k++) difint[(size_t)(k - 1) * np] = last;
+  } else
+    for (int k = 2; k <= kk; k++) difint[(size_t)(k - 1) * np] = D.egmndf;
   // the surface non-isopycnic layers, :2383-2513
   double urmse = 0., cpse = 0., els_s = 0.;
   if (sa) {
@@ -724,33 +868,54 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
     dfints = D.egmndf;
     difiso[0] = difint[0] * D.egidfq;
   }
-  // the isopycnic layers, :2516-2572
-  for (int k = 2; k <= kk; k++) {
-    const size_t o = (size_t)(k - 1) * np;
-    if (any && k >= kf && k <= km) {
-      double esfac;
-      if (D.edsprs) {
-        const int mu0 = msku[o], mu1 = msku[o + 1], mv0 = mskv[o], mv1 = mskv[o + ni];
-        const double umnsc = ((double)mu0 * u[o] + (double)mu1 * u[o + 1]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) * cosang -
-                             ((double)mv0 * v[o] + (double)mv1 * v[o + ni]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1) * sinang - cpse;
-        const double r = umnsc / fmax2(URMSEMIN, fabs(urmse));
-        esfac = 1. / (1. + 4. * (r * r));
-      } else if (D.edanis)
-        esfac = anisok[o];
-      else
-        esfac = 1.;
-      if (D.eddf2d) {
-        difint[o] = difint[0];
-        if (D.redi3d) difiso[o] = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, esfac * dfints * D.egidfq * difwgt));
-        else difiso[o] = difiso[0];
-      } else {
-        const double d = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, difint[o] * difwgt * esfac));
-        difint[o] = d;
-        difiso[o] = d * D.egidfq;
+  // the isopycnic layers, :2516-2572; outside the range again the value of the level above
+  {
+    double li = difint[0], ls_ = difiso[0];
+    const double di1 = li, ds1 = ls_;
+    const int k_end = any ? ka - 1 : kk;
+    for (int k = 2; k <= k_end; k++) { difint[(size_t)(k - 1) * np] = li; difiso[(size_t)(k - 1) * np] = ls_; }
+    if (any) {
+      for (int k0 = ka; k0 <= kb; k0 += BU) {
+        double dv[BU], av[BU], u0[BU], u1[BU], v0[BU], v1[BU];
+        int mu0[BU], mu1[BU], mv0[BU], mv1[BU];
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
+          dv[uu] = difint[o];
+          av[uu] = D.edanis ? anisok[o] : 1.;
+          if (D.edsprs) {
+            mu0[uu] = msku[o]; mu1[uu] = msku[o + 1]; mv0[uu] = mskv[o]; mv1[uu] = mskv[o + ni];
+            u0[uu] = u[o]; u1[uu] = u[o + 1]; v0[uu] = v[o]; v1[uu] = v[o + ni];
+          }
+        }
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          const int k = k0 + uu;
+          if (k > kb) break;
+          const size_t o = (size_t)(k - 1) * np;
+          double esfac;
+          if (D.edsprs) {
+            const double umnsc = ((double)mu0[uu] * u0[uu] + (double)mu1[uu] * u1[uu]) / (double)(mu0[uu] + mu1[uu] > 1 ? mu0[uu] + mu1[uu] : 1) * cosang -
+                                 ((double)mv0[uu] * v0[uu] + (double)mv1[uu] * v1[uu]) / (double)(mv0[uu] + mv1[uu] > 1 ? mv0[uu] + mv1[uu] : 1) * sinang - cpse;
+            const double r = umnsc / fmax2(URMSEMIN, fabs(urmse));
+            esfac = 1. / (1. + 4. * (r * r));
+          } else if (D.edanis)
+            esfac = av[uu];
+          else
+            esfac = 1.;
+          if (D.eddf2d) {
+            li = di1;
+            if (D.redi3d) ls_ = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, esfac * dfints * D.egidfq * difwgt));
+            else ls_ = ds1;
+          } else {
+            li = fmin3(difmxp, D.egmxdf, fmax2(D.egmndf, dv[uu] * difwgt * esfac));
+            ls_ = li * D.egidfq;
+          }
+          difint[o] = li;
+          difiso[o] = ls_;
+        }
       }
-    } else {
-      difint[o] = difint[o - np];
-      difiso[o] = difiso[o - np];
+      for (int k = kb + 1; k <= kk; k++) { difint[(size_t)(k - 1) * np] = li; difiso[(size_t)(k - 1) * np] = ls_; }
     }
   }
 #undef PL
