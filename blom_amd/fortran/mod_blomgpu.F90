@@ -14,6 +14,7 @@ module mod_blomgpu
 
   use iso_c_binding
   implicit none
+  logical, save :: difest_estimates = .false.   ! see difest_isobml below
   private
 
   integer, parameter, public :: nbdy = 4          ! phy/mod_xc.F90:45
@@ -346,9 +347,17 @@ contains
     integer, intent(in) :: nn
     call stage6('halo_difest',0,0,0,nn,0,0)
   end subroutine
-  subroutine difest_isobml(m,n,mm,nn,k1m,k1n)   ! phy/mod_difest.F90:735 -- the part the device library has: :750-790
+  subroutine difest_isobml(m,n,mm,nn,k1m,k1n)   ! phy/mod_difest.F90:735
+    ! difest_estimates = .true.: the whole routine (difest_common_iso, difest_vertical_iso, difest_lateral_iso: difint, difiso, difdia,
+    ! difwgt estimated every step) -- the host must have uploaded what they read beside the state: plat, cosang, sinang, twedon, ficem,
+    ! buoyfl, the planes tdmls and bdmlq its own libm fills (include/blomgpu.h) and &DIFFUSION's variables through gpu_set;
+    ! .false. (default): the part in front of the estimates, :750-790
     integer, intent(in) :: m,n,mm,nn,k1m,k1n
-    call stage6('difest_isobml_pre',m,n,mm,nn,k1m,k1n)
+    if (difest_estimates) then
+      call stage6('difest_isobml',m,n,mm,nn,k1m,k1n)
+    else
+      call stage6('difest_isobml_pre',m,n,mm,nn,k1m,k1n)
+    end if
   end subroutine
   subroutine thermf(m,n,mm,nn,k1m,k1n)          ! phy/mod_thermf.F90:35
     integer, intent(in) :: m,n,mm,nn,k1m,k1n

@@ -194,3 +194,46 @@ def test_single_rank_helpers_need_no_process_group():
     assert launch.neighbours_2d(0, 1, 1, True, True) == (0, 0, 0, 0)
     assert launch.neighbours_2d(3, 2, 2, True, False) == (2, 2, 1, -1)
     assert launch.neighbours_2d(4, 3, 2, False, True) == (3, 5, 1, 1)
+
+
+# ---- bench.py's N > 1 path end to end, on the CPU ----------------------------------------------------------------------------
+# The driver starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` on an 8-GPU node no
+# session here has ever had.  This is the same command with two ranks, `--backend gloo` (no torch.cuda call) and BLOMGPU_LIB pointing
+# at the host emulation of the library (tests/hostemu; its RCCL passes messages between PROCESSES through BLOM_HOSTEMU_RCCL_DIR):
+# the launcher, the rendezvous, the unique-id share, the tile layout and scatter, the 2-D RCCL init, the replicated barotropic
+# solve's attach, thermf's global sums on tiles, the max-over-ranks timing and the chained checksum all execute, and the state the
+# two tiles end in must be the single tile's.
+def _bench(tmp_path, ngpus, extra=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.join(root, "tests", "hostemu", "libblomgpu_hostemu.so")
+    if not os.path.exists(emu):
+        pytest.skip("tests/hostemu/libblomgpu_hostemu.so not built")
+    box = tmp_path / f"mail{ngpus}"
+    box.mkdir()
+    env = dict(os.environ, BLOMGPU_LIB=emu, BLOM_HOSTEMU_RCCL_DIR=str(box), OMP_NUM_THREADS="1")
+    args = ["bench.py", "--gpus", str(ngpus), "--config", "chan_s", "--steps", "3", "--warmup", "2", "--backend", "gloo", "--no-cpu-baseline",
+            "--no-dyncore-compare", *extra]
+    if ngpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_end_to_end_on_the_host_emulation(tmp_path):
+    one = _bench(tmp_path, 1, ["--frozen-diffusivities"])
+    two = _bench(tmp_path, 2)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["steps"] == 3
+    assert two["config"]["tiles_bit_identical"] is True and two["config"]["state_finite"] is True
+    assert two["config"]["physics"] == "full"                                   # config 2's step on tiles (thermf's sums on the global context)
+    assert "strong_scaling_terms" in two and two["strong_scaling_terms"]["barotp"] == "replicated"
+    # the decomposition-independent checksum: the two tiles end in the single tile's state (bench.py: state_crc)
+    assert two["config"]["state_crc"] == one["config"]["state_crc"], (one["config"]["state_crc"], two["config"]["state_crc"])
