@@ -138,6 +138,15 @@ int ctx_check_errors(blomgpu_ctx *c) {
   return 0;
 }
 
+// an option that the cached ALE structures depend on has changed: report what the engine still holds of earlier steps (its deferred
+// status, polled otherwise every check_period steps), then drop the structures
+static int ale_reset(blomgpu_ctx *c) {
+  if (!c->ale) return 0;
+  const int rc = c->h.P.vcoord_tag != 1 ? ale_check_deferred(c) : 0;
+  ale_free(c);
+  return rc;
+}
+
 extern "C" {
 
 const char *blomgpu_last_error(const blomgpu_ctx *ctx) {
@@ -383,23 +392,24 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "lean_fluxes") { c->lean_fluxes = v; return 0; }
   if (s == "tmsmt_fold") { c->tmsmt_fold = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
-  if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; ale_free(c); return 0; }
-  if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; ale_free(c); return 0; }
+  if (s == "ale_upper_bndr_ord") { c->ale_upper_bndr_ord = v; return ale_reset(c); }
+  if (s == "ale_lower_bndr_ord") { c->ale_lower_bndr_ord = v; return ale_reset(c); }
   if (s == "ale_k_range_plevel") { c->ale_k_range_plevel = v; return 0; }
   if (s == "ale_dktzu") { c->ale_dktzu = v; return 0; }
   if (s == "ale_dktzl") { c->ale_dktzl = v; return 0; }
-  if (s == "ale_density_pc_upper_bndr") { c->ale_density_pc_upper = v != 0; ale_free(c); return 0; }
-  if (s == "ale_density_pc_lower_bndr") { c->ale_density_pc_lower = v != 0; ale_free(c); return 0; }
-  if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; ale_free(c); return 0; }
-  if (s == "ale_tracer_pc_lower_bndr") { c->ale_tracer_pc_lower = v != 0; ale_free(c); return 0; }
-  if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; ale_free(c); return 0; }
-  if (s == "ale_velocity_pc_lower_bndr") { c->ale_velocity_pc_lower = v != 0; ale_free(c); return 0; }
+  if (s == "ale_density_pc_upper_bndr") { c->ale_density_pc_upper = v != 0; return ale_reset(c); }
+  if (s == "ale_density_pc_lower_bndr") { c->ale_density_pc_lower = v != 0; return ale_reset(c); }
+  if (s == "ale_tracer_pc_upper_bndr") { c->ale_tracer_pc_upper = v != 0; return ale_reset(c); }
+  if (s == "ale_tracer_pc_lower_bndr") { c->ale_tracer_pc_lower = v != 0; return ale_reset(c); }
+  if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; return ale_reset(c); }
+  if (s == "ale_velocity_pc_lower_bndr") { c->ale_velocity_pc_lower = v != 0; return ale_reset(c); }
   if (s == "remap_fold") { c->remap_fold = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }
   if (s == "live_slopes") { c->live_slopes = v; return 0; }
   if (s == "ndiff_surface_align") { c->ndiff_surface_align = v != 0; return 0; }
+  if (s == "ndiff_rec_per_face") { c->ndiff_rec_per_face = v < 0 ? 0 : v; return ale_reset(c); }
   if (s == "momtum_bs") { c->momtum_bs = v; return 0; }
   if (s == "momtum_lds_pad") { c->momtum_lds_pad = v; return 0; }
   if (s == "momtum_order") { c->momtum_order = v; return 0; }
@@ -478,8 +488,7 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
     if (v == "monotonic") lim = 201; else if (v == "non_oscillatory") lim = 203;
     else return ctx_fail(c, " readnml_ale_regrid_remap: " + s.substr(4) + " = " + v + " is unsupported!");
     (s == "ale_tracer_limiting" ? c->ale_tracer_limiting : c->ale_velocity_limiting) = lim;
-    ale_free(c);                     // the cached reconstruction structures hold the limiter
-    return 0;
+    return ale_reset(c);             // the cached reconstruction structures hold the limiter
   }
   if (s == "bmcmth") {
     if (v == "uc") P.bmcmth = 0; else if (v == "dluc") P.bmcmth = 1;

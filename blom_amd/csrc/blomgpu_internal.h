@@ -233,7 +233,8 @@ struct blomgpu_ctx {
   // blomgpu_step replays the stage sequence of a step as a HIP graph (one per parity of the time levels), captured from
   // the stream once the lazily allocated buffers exist; any option / parameter / mask change drops the graphs
   int halo_overlap = 1;          // RCCL tiles: the halo exchange in front of remap runs on xstream while the inner tiles compute
-                                 // (bit-identical; in self-send on one GPU 9.78 against 9.59 ms per step: off by default)
+                                 // (bit-identical; ON by default since round 4, the arctic patch included -- in self-send on one GPU it
+                                 // costs 0.2 ms, 9.78 against 9.59 ms per step; what it buys over xGMI has not been measured)
   int cmnfld1 = 0;               // blomgpu_step ends with cmnfld1 (z, dz of the new state; consumed by diagnostics and difest only)
   int use_graph = 0;             // measured slower than plain launches on ROCm 7.2 (channel 8.25 vs 7.90 ms, tnx2v1s 5.44 vs 5.12): off by default
   hipGraphExec_t step_graph[2] = {nullptr, nullptr};
@@ -296,6 +297,7 @@ struct blomgpu_ctx {
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
+  int ndiff_rec_per_face = 0;    // neutral diffusion: records per face (0: 6 kk, the bound; stage_ale.hip)
   int ndiff_surface_align = 1;   // phy/mod_diffusion.F90:84 (the namelist default of cime_config is .true.)
   int live_slopes = 0;       // blomgpu_step: 1 = cmnfld2 computes nslpx/nslpy every step (stage_cmnfld.hip); 0 = they stay as uploaded
   int momtum_order = 0;      // A/B: 0 chunk-major work order of the fused kernels, 1 layer-major

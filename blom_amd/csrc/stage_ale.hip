@@ -62,6 +62,7 @@ struct AleState {
   // neutral diffusion (stage_ndiff.hip): polynomial coefficients of every field; T, S and drho/dT, drho/dS at the source
   // interfaces (8 kk planes), the flux convergence (kk ntr_loc planes) and the flux kernel's work arrays; ksmx, kdmx
   double *nd_tpc = nullptr, *nd_col = nullptr, *nd_rec = nullptr, *nd_recg = nullptr;
+  size_t nd_nrec = 0;                 // record space per face of the neutral diffusion
   int *nd_ks = nullptr, *nd_reck = nullptr;
   int nd_npc = 0;
 };
@@ -148,7 +149,19 @@ static int ale_ndiff_buffers(blomgpu_ctx *c, AleState *a) {
   HIPCHK(c, hipMalloc((void **)&a->nd_tpc, sizeof(double) * (size_t)a->ntr_loc * npc * per));
   a->nd_npc = npc;
   if (!a->nd_col) {
-    const size_t ncol = (size_t)(8 + a->ntr_loc) * per + ndiff_scratch_planes(h.kk) * 2 * np + (size_t)2 * (h.kk + 1) * np, nrec = (size_t)6 * h.kk;
+    const size_t ncol = (size_t)(8 + a->ntr_loc) * per + ndiff_scratch_planes(h.kk) * 2 * np + (size_t)2 * (h.kk + 1) * np;
+    // Record space per face.  Every neutral layer consumes a source or destination interface of one of the two columns, so 6 kk
+    // records bound it (the default); that is (8 + ntr_loc) doubles + 2 ints per record and face, 2 nplane faces: 7.4 GB at channel
+    // size with ntr = 3, 19 GB with 24 tracers.  The option ndiff_rec_per_face lowers it (a face that runs out raises the sticky
+    // error word 4, nothing is silently truncated); the channel's faces use ~100 of the 318.
+    const size_t nrec = c->ndiff_rec_per_face > 0 ? (size_t)c->ndiff_rec_per_face : (size_t)6 * h.kk;
+    a->nd_nrec = nrec;
+    {
+      const double gb = (double)(sizeof(double) * nrec * (a->ntr_loc + 7) + sizeof(int) * (2 * nrec + 1)) * 2. * np / 1e9;
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess && gb * 1e9 > (double)fr)
+        return ctx_fail(c, "ndiff: the record space of ltedtp = 'neutral' needs " + std::to_string(gb) + " GB (6 kk records per face; lower it with the option ndiff_rec_per_face)");
+    }
     HIPCHK(c, hipStreamCreateWithFlags(&a->side2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&a->ev_fork2, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
@@ -880,6 +893,17 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
   // the status of the engine's calls is read back once, at the end -- or, inside blomgpu_step, with the other sticky error
   // words every check_period steps (ale_check_deferred): no host synchronisation inside the step
   const bool defer = c->defer_checks;
+  // an error return between here and the end of the stage must leave no work of the second diffusion stream unjoined and the
+  // engine's grids out of their sticky mode (the status then reaches the caller through the failing call itself)
+  struct Unwind {
+    AleState *a; bool armed = true, forked2 = false;
+    ~Unwind() {
+      if (!armed) return;
+      if (forked2 && a->side2) (void)hipStreamSynchronize(a->side2);
+      (void)h3m_sequence_end_deferred(a->grid);
+      (void)h3m_sequence_end_deferred(a->grid_uv);
+    }
+  } unwind{a};
   if (defer) {
     if ((rc = h3m_sequence_begin_deferred(a->grid)) || (rc = h3m_sequence_begin_deferred(a->grid_uv))) return ale_fail(c, "sequence", rc);
   } else if ((rc = h3m_sequence_begin(a->grid)) || (rc = h3m_sequence_begin(a->grid_uv))) return ale_fail(c, "sequence", rc);
@@ -990,12 +1014,13 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     A.psrc = psrc; A.pdst = pdst; A.ksmx = a->nd_ks; A.kdmx = a->nd_ks + np; A.tpc = a->nd_tpc; A.tsd = a->nd_col;
     A.drt = a->nd_col + (size_t)4 * per; A.drs = a->nd_col + (size_t)6 * per; A.flx = a->nd_col + (size_t)8 * per;
     A.scr = A.flx + (size_t)a->ntr_loc * per;
-    A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_s = A.rec_k + (size_t)6 * h.kk * 2 * np; A.rec_g = a->nd_recg;
-    A.rec_f = a->nd_rec; A.nrec_max = 6 * h.kk;
+    A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_s = A.rec_k + a->nd_nrec * 2 * np; A.rec_g = a->nd_recg;
+    A.rec_f = a->nd_rec; A.nrec_max = (int)a->nd_nrec;
     A.puv = A.scr + ndiff_scratch_planes(h.kk) * 2 * np;
     A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;
     HIPCHK(c, hipEventRecord(a->ev_fork2, c->stream));
     HIPCHK(c, hipStreamWaitEvent(a->side2, a->ev_fork2, 0));
+    unwind.forked2 = true;
     if (int rc2 = st_ndiff_prep_flux(c, a->side2, a->ev_snap, A, a->nd_ks, a->nd_ks + np, a->nd_col, a->nd_col + (size_t)4 * per, a->nd_col + (size_t)6 * per))
       return rc2;
     c->fluxes_zeroed = false;                   // utflx .. vsflx carry the diffusive fluxes now: advect must add to them
@@ -1048,12 +1073,14 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
       vel_done = true;
       HIPCHK(c, hipEventRecord(a->ev_join2, a->side2));
       HIPCHK(c, hipStreamWaitEvent(c->stream, a->ev_join2, 0));
+      unwind.forked2 = false;
     }
     hipLaunchKernelGGL(k_ale_copy_back, gk, b, 0, c->stream, c->d, nn, (const double *)pdst, (const double *)rm, f0, nf, flx, a->ntr_loc);
   }
   if (!vel_done)
     if (int rc2 = velocities(a->plane)) return rc2;
   HIPCHK(c, hipGetLastError());
+  unwind.armed = false;
   if (defer) {
     if ((rc = h3m_sequence_end_deferred(a->grid)) || (rc = h3m_sequence_end_deferred(a->grid_uv))) return ale_fail(c, "sequence", rc);
     return 0;

@@ -725,6 +725,10 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
   const double cdiff = isv ? V.P.delt1 * V.f[F_scvx][cp] * V.f[F_scvyi][cp] : V.P.delt1 * V.f[F_scuy][cp] * V.f[F_scuxi][cp];   // :1079, :1134
   const double *difiso = V.f[F_difiso];
   const double withheld = __builtin_nan("");
+  // A flux that passes the sign tests but is itself a NaN (a NaN in difiso or in the polynomial coefficients: the state has blown up)
+  // must not look like a withheld one, or it would be dropped where the reference carries it into the tracers: it travels as an
+  // infinity, which the sums turn into the non-finite state the reference would show
+  auto flux = [&](bool pass, double f) { return pass ? (f == f ? f : __builtin_inf()) : withheld; };
   for (int r = blockIdx.y; r < n; r += ND_EVAL_RY) {
     const int rs = A.rec_s[face + (size_t)r * nf];
     const int ks_m = rs & 255, ks_p = (rs >> 8) & 255, km0 = (rs >> 16) & 3, km1 = (rs >> 18) & 3, kp0 = (rs >> 20) & 3, kp1 = (rs >> 22) & 3;
@@ -740,8 +744,8 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
       const bool pass = dt * (V.f[F_temp][om] - V.f[F_temp][op]) >= 0. && dt * (nd_tni(tm, km0, xm0) - nd_tni(tp, kp0, xp0)) >= 0. &&
                         dt * (nd_tni(tm, km1, xm1) - nd_tni(tp, kp1, xp1)) >= 0. && ds * (V.f[F_saln][om] - V.f[F_saln][op]) >= 0. &&
                         ds * (nd_tni(sm, km0, xm0) - nd_tni(sp, kp0, xp0)) >= 0. && ds * (nd_tni(sm, km1, xm1) - nd_tni(sp, kp1, xp1)) >= 0.;
-      rf[0] = pass ? q * dt : withheld;
-      rf[nf] = pass ? q * ds : withheld;
+      rf[0] = flux(pass, q * dt);
+      rf[nf] = flux(pass, q * ds);
     }
     for (int nt = 2; nt < ntr_loc; nt++) {
       const Pc5 cm5 = nd_pc(A, np, cm, ks_m, nt), cp5 = nd_pc(A, np, cp, ks_p, nt);
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
       const size_t otr = (size_t)(nt - 2) * 2 * kk * np;
       const bool pass = dtr * (V.f[F_trc][om + otr] - V.f[F_trc][op + otr]) >= 0. && dtr * (nd_tni(cm5, km0, xm0) - nd_tni(cp5, kp0, xp0)) >= 0. &&
                         dtr * (nd_tni(cm5, km1, xm1) - nd_tni(cp5, kp1, xp1)) >= 0.;
-      rf[(size_t)nt * nf] = pass ? q * dtr : withheld;
+      rf[(size_t)nt * nf] = flux(pass, q * dtr);
     }
   }
 }
