@@ -781,6 +781,8 @@ def main():
             # config 2's step on tiles (config 3): thermf's global sums are formed on the replicated solve's global context
             hostinit.init_forcing(whole, case)
             tile_area = hostinit.ocean_area(whole, case)
+            if not args.frozen_diffusivities:
+                hostinit.init_difest(whole, case, device=True)         # (the planes travel to the tile with the other fields)
         gpu = BlomGpu(tii, tjj, case.kdm, case.ntr, nreg, {k: layout.window(masks[k], px, py) for k in masks}, device=local,
                       itdm=case.idm, jtdm=case.jdm, i0=i0, j0=j0)
         for nm, v in case.params.items():
@@ -825,9 +827,13 @@ def main():
         else:
             gpu.set("area", tile_area)                     # (the fields came with the window of the whole domain)
         gpu.set("full_physics", 1)
-        if layout is None and not args.frozen_diffusivities:
+        if not args.frozen_diffusivities:
             # difest_isobml's diffusivity estimates live (stage_difest_iso.hip): NorESM's &DIFFUSION defaults for this coordinate
-            hostinit.init_difest(gpu, case, device=True)
+            if layout is None:
+                hostinit.init_difest(gpu, case, device=True)
+            else:
+                import math
+                gpu.set("bdml_logc", math.log(2. * hostinit._BVF0 / hostinit._CORI30))
             for d_ in hostinit.DIFEST_NORESM:
                 for nm, v in d_.items():
                     gpu.set(nm, v)

@@ -322,6 +322,19 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
 #define R(nm) if (s == #nm) { *v = P.nm; return 0; }
   R(baclin) R(batrop) R(delt1) R(dlt) R(pref) R(wbaro)
 #undef R
+  // diagnostic counters of mxlayr (stage_mxlayr.hip): columns whose iteration for the mixed layer depth ended at its limit since the last
+  // query -- "mxlayr_maxitr_entrain" (phy/mod_mxlayr.F90:437-449), "mxlayr_maxitr_detrain" (:955-982); the reference prints such columns
+  if (s == "mxlayr_maxitr_entrain" || s == "mxlayr_maxitr_detrain") {
+    *v = 0.;
+    if (!c->err_dev) return 0;
+    const int w = s == "mxlayr_maxitr_entrain" ? 5 : 6;
+    int n = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(&n, c->err_dev + w, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->err_dev + w, 0, sizeof(int)));
+    *v = n;
+    return 0;
+  }
   return ctx_fail(c, "blomgpu_get_real: unknown option " + s);
 }
 

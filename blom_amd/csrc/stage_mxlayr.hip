@@ -49,6 +49,7 @@
 struct MxlPar {
   double rm0, rm5, ce, rtau, rlf, niwgf, niwbf, swamxd, mltmin, thktop;
   int rtsflg;
+  int *maxitr_count;     // diagnostic: columns whose TKE-balance iteration ended at maxitr (the reference prints them and goes on)
 };
 
 namespace eos0 {
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       if (fabs(dpmxl) < ONEMM || nitr == MAXITR) break;
     }
     // (nitr == maxitr: the reference prints the column and goes on, :437-449)
+    if (nitr == MAXITR && fabs(dpmxl) >= ONEMM) atomicAdd(M.maxitr_count, 1);
 
     pmxl = fmax2(mltmin * ONEM, pmxl);
     dpfsl = PR(3) - pmxl;
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
             if (fabs(dpmxl) < ONEMM || nitr == MAXITR) break;
           }
           // (nitr == maxitr: the reference prints the column and goes on, :955-982)
+          if (nitr == MAXITR && fabs(dpmxl) >= ONEMM) atomicAdd(M.maxitr_count + 1, 1);
           if (pmxl < presk1 - EPSILP && nitr < MAXITR) {
             tdps = tdps + tk * (pmxl - presk);
             sdps = sdps + sk * (pmxl - presk);
@@ -888,6 +891,8 @@ int st_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   else return ctx_fail(c, " mlrttp = " + c->mlrttp + " is unsupported!");                       // :203-212
   M.rm0 = c->rm0; M.rm5 = c->rm5; M.ce = c->eddtra_ce; M.rtau = 1. / c->tau_mlr; M.rlf = 1. / c->lfmin;
   M.niwgf = c->niwgf; M.niwbf = c->niwbf; M.swamxd = c->swamxd; M.mltmin = 5.; M.thktop = 10.;
+  if (int rc = ctx_err_words(c)) return rc;
+  M.maxitr_count = c->err_dev + 5;          // words 5, 6: counters, not errors
   TimeScope ts(c, "mxlayr");
   hipLaunchKernelGGL(k_mxl_bg2_sig, plane_grid(h), dim3(256), 0, c->stream, c->d, nn);
   if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, 1, 1, 1)) return rc;

@@ -164,6 +164,11 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_exp(self.ctx, x.size, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)))
         return y
 
+    def get_real(self, name):
+        v = C.c_double(0.0)
+        self._chk(self.lib.blomgpu_get_real(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
     def pow(self, x, y):
         """pow() as the kernels evaluate it (blom_amd/csrc/pow_libm.h), elementwise."""
         x = np.ascontiguousarray(x, dtype=np.float64).ravel()

@@ -510,12 +510,18 @@ FORCING = ["ustarw", "swa", "nsf", "hmltfz", "lip", "sop", "eva", "rnf", "rfi", 
            "vmlres", "trflx", "trc_corr"]
 
 
-@pytest.mark.parametrize("cfg,npx,npy", [("chan_s_tke", 2, 2), ("tri_s_tke", 2, 2), ("box_s", 3, 1), ("tri_s_tke", 4, 2)])
-def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy):
+DFE_IN = ["plat", "betatp", "cosang", "sinang", "hangle", "twedon", "ficem", "tdmls", "bdmlq"]
+
+
+@pytest.mark.parametrize("cfg,npx,npy,live", [("chan_s_tke", 2, 2, False), ("tri_s_tke", 2, 2, False), ("box_s", 3, 1, False), ("tri_s_tke", 4, 2, False),
+                                              ("chan_s_tke", 2, 2, True), ("tri_s_tke", 2, 2, True), ("box_s", 3, 1, True)])
+def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy, live):
     """config 2's step as far as built (blomgpu_step with full_physics: + the front of difest_isobml, thermf with its two global
     sums, mxlayr, cmnfld1) on a decomposed domain: the sums are formed in the global domain's order from the owners' planes
     (halo.hip: xcsum_group), mxlayr's and the difest front's halo updates go through the tile transport.  A heat flux that
-    changes sign across the domain and a fresh water flux drive entrainment and detrainment.  Interiors as on the single tile."""
+    changes sign across the domain and a fresh water flux drive entrainment and detrainment.  Interiors as on the single tile.
+    live: with the diffusivity estimates of difest_isobml (stage_difest_iso.hip): kfil's and the diffusivities' halo updates through the
+    tile transport, the neighbours' kmax from halo data."""
     from blom_amd.gpu import BlomGpu, TileGroup
     from blom_amd import hostinit
     nsteps = 4
@@ -530,6 +536,8 @@ def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy):
     ref.put("eva", (-2e-5 * (1.0 + 0.5 * np.sin(2 * x)))[None])
     ref.put("lip", (3e-5 * (y > 0.0))[None])
     area = ref.get_real("area") if hasattr(ref, "get_real") else None
+    if live:
+        hostinit.init_difest(ref, case, device=True)
     ii, jj = tile_extents(case, npx, npy)
     grp = TileGroup(npx, npy)
     tiles = {}
@@ -543,7 +551,7 @@ def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy):
             t.set("delt1", case.params["baclin"])
             grp.attach(t, px, py)
             tiles[(px, py)] = t
-    scatter_state(ref, tiles, case, npx, npy, [f for f in ALL if f in fields] + [f for f in FORCING if ref.has_field(f)])
+    scatter_state(ref, tiles, case, npx, npy, [f for f in ALL if f in fields] + [f for f in FORCING if ref.has_field(f)] + (DFE_IN if live else []))
     # the ocean area is a global number (mod_grid: area = xcsum(scp2, ips))
     scp2 = ref.get("scp2")[0][4:-4, 4:-4]
     w = masks["ip"][4:-4, 4:-4] > 0
@@ -556,6 +564,14 @@ def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy):
         g.set("area", glob_area)
         g.set("niwgf", 0.4)
         g.set("full_physics", 1)
+        if live:
+            import math
+            for d_ in hostinit.DIFEST_NORESM:
+                for nm_, v_ in d_.items():
+                    if nm_ != "niwgf":
+                        g.set(nm_, v_)
+            g.set("bdml_logc", math.log(2. * hostinit._BVF0 / hostinit._CORI30))
+            g.set("difest_live", 1)
     setup(ref)
     assert ref.step(0, nsteps) == nsteps
     errs = []
@@ -572,7 +588,7 @@ def test_full_physics_step_on_tiles_matches_single_tile(cfg, npx, npy):
     [x_.join(timeout=300) for x_ in th]
     assert not errs, errs
     bad = []
-    for nm in CHECK + ["kfpla", "surflx", "salflx", "ustar", "mtkepe", "pbrnda", "sfl", "idkedt", "uml", "nslpx"]:
+    for nm in CHECK + ["kfpla", "surflx", "salflx", "ustar", "mtkepe", "pbrnda", "sfl", "idkedt", "uml", "nslpx"] + (["difint", "difiso", "difdia", "difwgt", "L_scale"] if live else []):
         if not ref.has_field(nm):
             continue
         a = ref.get(nm)[:, 4:4 + case.jdm, 4:4 + case.idm]

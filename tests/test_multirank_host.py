@@ -229,7 +229,7 @@ def _bench(tmp_path, ngpus, extra=()):
 
 
 def test_bench_two_ranks_end_to_end_on_the_host_emulation(tmp_path):
-    one = _bench(tmp_path, 1, ["--frozen-diffusivities"])
+    one = _bench(tmp_path, 1)
     two = _bench(tmp_path, 2)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["steps"] == 3
     assert two["config"]["tiles_bit_identical"] is True and two["config"]["state_finite"] is True
