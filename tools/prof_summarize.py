@@ -113,7 +113,7 @@ if len(sys.argv) > 4:
     prefixes = [("k_cmn_", "cmnfld"), ("k_mom_", "momtum"), ("k_remap_", "remap"), ("k_adv_", "remap"), ("k_cppm_", "cppm"),
                 ("k_diffus_", "diffus"), ("k_pgf_", "pgforc"), ("k_diapfl_", "diapfl"), ("k_convec_", "convec"),
                 ("k_bt_", "barotp"), ("k_pbc_", "pbcor"), ("k_eddtra_", "eddtra"), ("k_mxl_", "mxlayr"), ("k_difest_", "difest"),
-                ("k_thermf_", "thermf"), ("k_xcsum_", "thermf"), ("k_niw_", "difest")]
+                ("k_thermf_", "thermf"), ("k_xcsum_", "thermf"), ("k_niw_", "difest"), ("k_dfi_", "difest")]
     cls = collections.defaultdict(float)
     allk = collections.defaultdict(float)
     for k in set(fe) | set(wr):
