@@ -174,7 +174,7 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
   Params &P = h.P;
   // defaults of the reference's module variables (phy/mod_tmsmt.F90:46-51)
   P.wuv1 = .75; P.wuv2 = .125; P.wts1 = .875; P.wts2 = .0625; P.wbaro = .125;
-  P.vland = 0.0; P.vcoord_tag = 1; P.ltedtp_opt = 1; P.eitmth = 2;
+  P.vland = 0.0; P.allwet = 1; P.vcoord_tag = 1; P.ltedtp_opt = 1; P.eitmth = 2;
   P.pref = 2000.e4;
   set_eos(P);
   const int K = d->kdm, NT = d->ntr > 0 ? d->ntr : 1;
@@ -322,6 +322,8 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
 #define R(nm) if (s == #nm) { *v = P.nm; return 0; }
   R(baclin) R(batrop) R(delt1) R(dlt) R(pref) R(wbaro)
 #undef R
+  if (s == "area") { *v = c->area; return 0; }
+  if (s == "bdml_logc") { *v = c->bdml_logc; return 0; }
   // diagnostic counters of mxlayr (stage_mxlayr.hip): columns whose iteration for the mixed layer depth ended at its limit since the last
   // query -- "mxlayr_maxitr_entrain" (phy/mod_mxlayr.F90:437-449), "mxlayr_maxitr_detrain" (:955-982); the reference prints such columns
   if (s == "mxlayr_maxitr_entrain" || s == "mxlayr_maxitr_detrain") {
@@ -344,7 +346,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
   if (s == "nstep") { P.nstep = v; return 0; }      // host-side only (stage_cppm.hip): the device view is not touched
-  R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp)
+  R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp) R(allwet)
 #undef R
   if (s == "csdiag") { c->csdiag = v != 0; return 0; }
   if (s == "eddf2d") { c->eddf2d = v != 0; return 0; }

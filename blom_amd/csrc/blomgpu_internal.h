@@ -147,6 +147,7 @@ struct Params {
   int vcoord_tag;  // 1 isopyc_bulkml                       (phy/mod_vcoord.F90)
   int ltedtp_opt;  // 1 layer, 2 neutral                    (phy/mod_diffusion.F90)
   double vland;    // halo fill value for closed boundaries (phy/mod_xc.F90:104)
+  int allwet;      // momtum's viscous march: take the all-wet form of a step where the masks allow (A/B option, default 1)
 };
 // tracers (1-based nt) left out of layer diffusion (phy/mod_diffus.F90:64-66) and of advection (phy/mod_remap.F90:314-316)
 __host__ __device__ inline bool trc_skip_dif(const Params &P, int nt) { return P.itrtke >= 1 && !P.tkeidf && (nt == P.itrtke || nt == P.itrgls); }

@@ -18,6 +18,7 @@
 // Expressions are those of stage_momtum.hip's kernels, operator for operator; loop bounds of every sweep as there.
 // LDS: 37 rows (visc) / 21 or 35 rows (cor) of a strip.  Roofline: HBM; ~35 F moved by the two kernels.
 #include "momtum_common.h"
+#include <type_traits>
 
 // kk-level work-space slots of the fused path
 enum { MF_VISU, MF_VISV, MF_UM, MF_UN, MF_VM, MF_VN, MF_NSLOT };
@@ -162,7 +163,28 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
   int mk1 = ldoi(mpk, roff(ja - 3) >> 1), mk2 = ldoi(mpk, roff(ja - 4) >> 1), mk3 = ldoi(mpk, roff(ja - 5) >> 1), mk4 = ldoi(mpk, roff(ja - 6) >> 1);
   int q3 = (ja - 3 + 48) % 3;        // depth-3 slot of row s-1
 
+  // All-wet fast path (round 5).  Almost every strip-row of an ocean grid has no land in its stencil window (the channel: 106 080 of
+  // 106 496 points are wet), and then every mask test of the step is true and every select takes its first operand: the step's body
+  // exists twice, once with the masks as data and once with them compiled out (AW), and a wave-uniform branch picks per step.  The
+  // flag: all 64 lanes' packed mask words of the rows s-4 .. s are 15 -- the words of a row are tested when the row is loaded (one
+  // v_cmp + s_cmp per step) and kept as one bit of a shift register.  The lanes next to the strip (x - 1 of lane 0, x + 1, x + 2 of
+  // lane 63) are not tested: they only reach the strip's outer 4 + 4 lanes, which own no output (the reach argument of the strip
+  // layout).  Same bits by construction: a select on a true mask returns the operand the masked form returns.
+#ifdef BLOM_HOSTEMU
+#define WAVE_ALL(p) false            // (the host emulation runs lanes one after the other: it takes the masked form)
+#else
+#define WAVE_ALL(p) (__all(p) != 0)
+#endif
+#define MUa(m) (AW || MU(m))
+#define MVa(m) (AW || MV(m))
+#define MPa(m) (AW || MP(m))
+#define MQa(m) (AW || MQ(m))
+  unsigned awbits = (WAVE_ALL((tc.mk & 15) == 15) ? 1u : 0u) | (WAVE_ALL((mk1 & 15) == 15) ? 2u : 0u) | (WAVE_ALL((mk2 & 15) == 15) ? 4u : 0u) |
+                    (WAVE_ALL((mk3 & 15) == 15) ? 8u : 0u) | (WAVE_ALL((mk4 & 15) == 15) ? 16u : 0u);
+  const bool aw_on = V.P.allwet != 0;
   for (int s = ja - 2; s <= jb + 3; s++) {
+   auto step = [&](auto awc) {
+    constexpr bool AW = decltype(awc)::value;
     // ================= loads of this step =================
     const TIn tn = load_t(s + 1);
     const gcd_t scuy = GFV(F_scuy), scvx = GFV(F_scvx), scvy = GFV(F_scvy), scux = GFV(F_scux);
@@ -203,12 +225,12 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     // ---- T: total velocities at the old time level, row s (:408-431; rows -1..jj+2, i = -1..ii+2) ------------
     if (act && s >= -1 && s <= jj + 2 && i >= -1 && i <= ii + 2) {
       double un = 0., vn = 0.;
-      if (MU(tc.mk)) {
+      if (MUa(tc.mk)) {
         un = tc.u + tc.qu;
         // the reference's module array utotn is left holding the last layer's values outside the interior
         if (k == kk - 1) sto(o_utotn, x8 + ni8 * (unsigned)(s + NBDY - 1), un);
       }
-      if (MV(tc.mk)) {
+      if (MVa(tc.mk)) {
         vn = tc.v + tc.qv;
         if (k == kk - 1) sto(o_vtotn, x8 + ni8 * (unsigned)(s + NBDY - 1), vn);
       }
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       const int r = s - 1;
       if (act && r >= -1 && r <= jj + 2 && i >= 0 && i <= ii + 2) {
         double uja = 0., ujb = 0., d2u = 0.;
-        if (MU(w_m)) {
+        if (MUa(w_m)) {
           const double den = fmax2(w_pu1 - w_pu0, EPSILP);
           const double wa = fmax2(0., fmin2(1., (w_pu1 - w_pbua) / den));
           const double wb = fmax2(0., fmin2(1., (w_pu1 - w_pbub) / den));
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       }
       if (act && r >= 0 && r <= jj + 2 && i >= -1 && i <= ii + 2) {
         double via = 0., vib = 0., d2v = 0.;
-        if (MV(w_m)) {
+        if (MVa(w_m)) {
           const double den = fmax2(w_pv1 - w_pv0, EPSILP);
           const double wa = fmax2(0., fmin2(1., (w_pv1 - w_pbva) / den));
           const double wb = fmax2(0., fmin2(1., (w_pv1 - w_pbvb) / den));
@@ -261,18 +283,18 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       if (act && r >= 0 && r <= jj + 2 && i >= 0 && i <= ii + 2) {          // defor2 at q-points
         bool have = false;
         double d2 = 0.;
-        if (MV(w_m) && !MV(w_mw)) { const double t = RG(a1, R_VTN, 0) * (1. - SLIP) * v_scvy; d2 = t * t * v_scq2i; have = true; }
-        else if (MV(w_mw) && !MV(w_m)) { const double t = RG(a1, R_VTN, -1) * (1. - SLIP) * v_scvyw; d2 = t * t * v_scq2i; have = true; }
-        if (MU(w_m) && !MU(w_ms)) { const double t = RG(a1, R_UTN, 0) * (1. - SLIP) * v_scux; d2 = t * t * v_scq2i; have = true; }
-        else if (MU(w_ms) && !MU(w_m)) { const double t = RG(a2, R_UTN, 0) * (1. - SLIP) * v_scuxs; d2 = t * t * v_scq2i; have = true; }
-        if (MQ(w_m)) {
+        if (MVa(w_m) && !MVa(w_mw)) { const double t = RG(a1, R_VTN, 0) * (1. - SLIP) * v_scvy; d2 = t * t * v_scq2i; have = true; }
+        else if (MVa(w_mw) && !MVa(w_m)) { const double t = RG(a1, R_VTN, -1) * (1. - SLIP) * v_scvyw; d2 = t * t * v_scq2i; have = true; }
+        if (MUa(w_m) && !MUa(w_ms)) { const double t = RG(a1, R_UTN, 0) * (1. - SLIP) * v_scux; d2 = t * t * v_scq2i; have = true; }
+        else if (MUa(w_ms) && !MUa(w_m)) { const double t = RG(a2, R_UTN, 0) * (1. - SLIP) * v_scuxs; d2 = t * t * v_scq2i; have = true; }
+        if (MQa(w_m)) {
           const double t = RG(b1, R_VIB, -1) * v_scvy - via1 * v_scvyw + ujb2 * v_scux - uja1 * v_scuxs;
           d2 = t * t * v_scq2i;
           have = true;
         }
         if (have) RG(c1, R_D2, 0) = d2;
       }
-      if (act && r >= -1 && r <= jj + 1 && i >= -1 && i <= ii + 1 && MP(w_m)) {   // defor1 at p-points
+      if (act && r >= -1 && r <= jj + 1 && i >= -1 && i <= ii + 1 && MPa(w_m)) {   // defor1 at p-points
         const double t = (RG(a1, R_UTN, 1) * v_scuye - RG(a1, R_UTN, 0) * v_scuy) - (RG(a0, R_VTN, 0) * v_scvxn - RG(a1, R_VTN, 0) * v_scvx);
         RG(c1, R_D1, 0) = t * t * v_scp2i;
       }
@@ -282,7 +304,7 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     if (act && i >= 0 && i <= ii + 1) {
       {
         const int r = s - 2;
-        if (r >= 0 && r <= jj + 1 && MU(s_m)) {
+        if (r >= 0 && r <= jj + 1 && MUa(s_m)) {
           const double q = .5 * (su_dww + su_dw);
           const double deform = sqrt(.5 * (RG(c2, R_D1, 0) + RG(c2, R_D1, -1) + RG(c2, R_D2, 0) + RG(c1, R_D2, 0)));
           RG(b2, R_VS2U, 0) = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
       }
       {
         const int r = s - 1;
-        if (r >= 0 && r <= jj + 1 && MV(w_m)) {
+        if (r >= 0 && r <= jj + 1 && MVa(w_m)) {
           const double q = .5 * (sv_dws + sv_dw);
           const double deform = sqrt(.5 * (RG(c1, R_D1, 0) + RG(c2, R_D1, 0) + RG(c1, R_D2, 0) + RG(c1, R_D2, 1)));
           RG(a1, R_VS2V, 0) = fmax2(q * mdv2hi + (1. - q) * mdv2lo, (q * vsc2hi + (1. - q) * vsc2lo) * deform);
@@ -303,19 +325,19 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     // ---- F: longitudinal turbulent momentum fluxes at p-points, row s-3 (:860-873, :1019-1034) -----------------
     {
       const int r = s - 3;
-      if (act && r >= 0 && r <= jj && i >= 0 && i <= ii && MP(f_m)) {
-        if (r >= 1 && MU(f_m) + MU(f_me) > 0) {
+      if (act && r >= 0 && r <= jj && i >= 0 && i <= ii && MPa(f_m)) {
+        if (r >= 1 && MUa(f_m) + MUa(f_me) > 0) {
           const double dpxy = fmax2(dpu_c, ONEMM), dpib = fmax2(dpu_e, ONEMM);
           // viscosity extended one point beyond wet u-segments (:845-856), cf. ext_i
-          const int m0 = MU(f_m), m1 = MU(f_me), m2 = MU(f_me2);
+          const int m0 = MUa(f_m), m1 = MUa(f_me), m2 = MUa(f_me2);
           const double v2 = (m0 ? RG(b3, R_VS2U, 0) : (m1 ? RG(b3, R_VS2U, 1) : RG(b3, R_VS2U, -1))) + (m1 ? RG(b3, R_VS2U, 1) : (m2 ? RG(b3, R_VS2U, 2) : RG(b3, R_VS2U, 0)));
           const double v4 = (m0 ? RG(b3, R_VS4U, 0) : (m1 ? RG(b3, R_VS4U, 1) : RG(b3, R_VS4U, -1))) + (m1 ? RG(b3, R_VS4U, 1) : (m2 ? RG(b3, R_VS4U, 2) : RG(b3, R_VS4U, 0)));
           ufl1[0] = fmin2(v_difmxp, v2 * v_scpy) * hfharm(dpxy, dpib) * (RG(a3, R_UTN, 0) - RG(a3, R_UTN, 1)) +
                     fmin2(.125 * v_difmxp, v4 * v_scpy) * hfharm(dpxy, dpib) * (RG(a3, R_DL2U, 0) - RG(a3, R_DL2U, 1));
         }
-        if (i >= 1 && MV(f_m) + MV(f_mn) > 0) {
+        if (i >= 1 && MVa(f_m) + MVa(f_mn) > 0) {
           const double dpxy = fmax2(dpv_c, ONEMM), dpjb = fmax2(dpv_n, ONEMM);
-          const int m0 = MV(f_m), m1 = MV(f_mn), m2 = MV(f_mn2);
+          const int m0 = MVa(f_m), m1 = MVa(f_mn), m2 = MVa(f_mn2);
           // rows r-1 (slot of row s), r, r+1, r+2
           const double v2 = (m0 ? RG(a3, R_VS2V, 0) : (m1 ? RG(a2, R_VS2V, 0) : RG(a0, R_VS2V, 0))) + (m1 ? RG(a2, R_VS2V, 0) : (m2 ? RG(a1, R_VS2V, 0) : RG(a3, R_VS2V, 0)));
           const double v4 = (m0 ? RG(a3, R_VS4V, 0) : (m1 ? RG(a2, R_VS4V, 0) : RG(a0, R_VS4V, 0))) + (m1 ? RG(a2, R_VS4V, 0) : (m2 ? RG(a1, R_VS4V, 0) : RG(a3, R_VS4V, 0)));
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     {
       const int r = s - 3;
       if (act && own && r >= ja && r <= jb && i >= 1 && i <= ii) {
-        if (MU(f_m)) {
+        if (MUa(f_m)) {
           const double wja = wja3, wjb = wjb3;
           const double dpxy = fmax2(dpu_c, ONEMM);
           double dpja = fmax2(dpu_s, ONEMM);
@@ -338,8 +360,8 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
           dpjb = dpjb + wjb * (dpxy - dpjb);
           const double v2c = RG(b3, R_VS2U, 0), v4c = RG(b3, R_VS4U, 0);
           // rows r-1 (the slot of row s-1), r+1
-          const double vsc2a = MU(f_ms) == 0 ? v2c : RG(b1, R_VS2U, 0), vsc4a = MU(f_ms) == 0 ? v4c : RG(b1, R_VS4U, 0);
-          const double vsc2b = MU(f_mn) == 0 ? v2c : RG(b2, R_VS2U, 0), vsc4b = MU(f_mn) == 0 ? v4c : RG(b2, R_VS4U, 0);
+          const double vsc2a = MUa(f_ms) == 0 ? v2c : RG(b1, R_VS2U, 0), vsc4a = MUa(f_ms) == 0 ? v4c : RG(b1, R_VS4U, 0);
+          const double vsc2b = MUa(f_mn) == 0 ? v2c : RG(b2, R_VS2U, 0), vsc4b = MUa(f_mn) == 0 ? v4c : RG(b2, R_VS4U, 0);
           const double un = RG(a3, R_UTN, 0), d2 = RG(a3, R_DL2U, 0);
           const double dl2uja = (1. - wja) * RG(a0, R_DL2U, 0) + wja * SLIP * d2;          // :594-597
           const double dl2ujb = (1. - wjb) * RG(a2, R_DL2U, 0) + wjb * SLIP * d2;
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
                                 fmin2(.125 * dmq_n, (v4c + vsc4b) * scqx_n) * hfharm(dpjb, dpxy) * (d2 - dl2ujb);
           sto(o_visu, of, (ufl1[0] - ufl1[-1] + uflux3 - uflux2) / (scu2_c * fmax2(dpu_c, ONEMM)));
         }
-        if (MV(f_m)) {
+        if (MVa(f_m)) {
           const double wia = wia3, wib = wib3;
           const double dpxy = fmax2(dpv_c, ONEMM);
           double dpia = fmax2(dpv_w, ONEMM);
@@ -357,8 +379,8 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
           double dpib = fmax2(dpv_e, ONEMM);
           dpib = dpib + wib * (dpxy - dpib);
           const double vs2 = RG(a3, R_VS2V, 0), vs4 = RG(a3, R_VS4V, 0);
-          const double vsc2a = MV(f_mw) == 0 ? vs2 : RG(a3, R_VS2V, -1), vsc4a = MV(f_mw) == 0 ? vs4 : RG(a3, R_VS4V, -1);
-          const double vsc2b = MV(f_me) == 0 ? vs2 : RG(a3, R_VS2V, 1), vsc4b = MV(f_me) == 0 ? vs4 : RG(a3, R_VS4V, 1);
+          const double vsc2a = MVa(f_mw) == 0 ? vs2 : RG(a3, R_VS2V, -1), vsc4a = MVa(f_mw) == 0 ? vs4 : RG(a3, R_VS4V, -1);
+          const double vsc2b = MVa(f_me) == 0 ? vs2 : RG(a3, R_VS2V, 1), vsc4b = MVa(f_me) == 0 ? vs4 : RG(a3, R_VS4V, 1);
           const double vn = RG(a3, R_VTN, 0), d2 = RG(b3, R_DL2V, 0);
           const double dl2via = (1. - wia) * RG(b3, R_DL2V, -1) + wia * SLIP * d2;          // :602-605
           const double dl2vib = (1. - wib) * RG(b3, R_DL2V, 1) + wib * SLIP * d2;
@@ -376,7 +398,15 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     mk4 = mk3; mk3 = mk2; mk2 = mk1; mk1 = tc.mk;
     tc = tn;
     q3 = q3 == 2 ? 0 : q3 + 1;
+    awbits = (awbits << 1) | (WAVE_ALL((tn.mk & 15) == 15) ? 1u : 0u);
+   };
+   if (aw_on && (awbits & 31u) == 31u) step(std::true_type{});
+   else step(std::false_type{});
   }
+#undef MUa
+#undef MVa
+#undef MPa
+#undef MQa
 }
 
 // ======================================================================================================
