@@ -1,0 +1,79 @@
+"""profiles/r05_bounds.md: for the longest kernels of the step, the time each of three bounds allows beside the time measured.
+
+  bytes    counted HBM-side traffic of a launch (2 x FETCH_SIZE + WRITE_SIZE: profiles/*_pmc_hbm_traffic.txt) at 6.0 TB/s, the rate a
+           plain copy reaches on this part (profiles/r02_fetch_calibration.txt: 5.7 - 6.2); `alg` the same for the kernel's algorithmic
+           bytes where bench.py defines them
+  issue    instructions a SIMD must issue: (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS + SQ_INSTS_VMEM) per wave x waves x 4 cycles
+           / 1024 SIMDs / 2.4 GHz -- every instruction of a wave64 occupies its SIMD's issue port for 4 cycles (DESIGN.md 3b;
+           fp64 division and sqrt sequences are longer, so this is a lower bound)
+  wait     share of the wave cycles in which the wave was parked on a counter (SQ_WAIT_ANY / SQ_WAVE_CYCLES) -- for the column kernels
+           (one thread per column, 1.6 - 3.4 waves per SIMD) the k-serial chain of dependent loads
+
+usage: bounds_table.py <kernel_stats.txt> <pmc_hbm_traffic.txt> <sq_counters.txt> > profiles/r05_bounds.md"""
+import re
+import sys
+
+ks, tr, sq = sys.argv[1:4]
+F = 208 * 512 * 53 * 8.0
+ALG = {"k_remap_tile": 20, "k_mom_cor_march": 24, "k_mom_visc_march": 8, "k_diapfl_column3": 20, "k_pgf_uv": 15, "k_pbc_tile": 24,
+       "k_diffus_tile": 21, "k_tmsmt2": 24, "k_remap_update": 18}
+
+
+def key(n):
+    return n.replace("void ", "").split("<")[0].split("(")[0].strip()
+
+
+stats = []
+for ln in open(ks):
+    if ln.startswith("#") or not ln.strip():
+        continue
+    p = ln.split()
+    try:
+        stats.append((" ".join(p[:-4]), float(p[-4]), float(p[-3]), float(p[-2])))
+    except ValueError:
+        pass
+traffic = {}
+for ln in open(tr):
+    if ln.startswith("#") or not ln.strip():
+        continue
+    p = ln.split()
+    try:
+        traffic[key(" ".join(p[:-4]))] = (float(p[-2]) + float(p[-1])) * 1e6
+    except ValueError:
+        pass
+ctr, cur = {}, None
+for ln in open(sq):
+    if ln.strip() and not ln.startswith(" "):
+        cur = key(ln.strip())
+        ctr.setdefault(cur, {})
+    else:
+        m = re.match(r"\s+(\S+)\s+(\d+)", ln)
+        if m and cur:
+            ctr[cur][m.group(1)] = float(m.group(2))
+print("# Bounds of the longest kernels (round 5)\n")
+print("Channel 208x512x53, ntr = 3, one MI355X; `python3 bench.py` (config 2's step with live diffusivities).  Columns: measured average launch")
+print("(rocprofv3 kernel trace, overlap off), launches per step, and what each bound allows -- see tools/bounds_table.py for the definitions.")
+print("A kernel sits at its floor when `measured` is close to the largest of the bounds; `wait` says how much of the rest is a k-serial chain.\n")
+print("| kernel | per step | measured us | counted MB | bytes bound us (6.0 TB/s) | alg. bytes us (8 TB/s) | instr / wave (VALU+SALU+LDS+VMEM) | waves | issue bound us | wait % | nearest bound / measured |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
+tot = 0.0
+for name, per, avg, ms in stats[:24]:
+    k = key(name)
+    t = traffic.get(k)
+    c = ctr.get(k, {})
+    w = c.get("SQ_WAVES")
+    bb = t / 6.0e12 * 1e6 if t else None
+    alg = ALG.get(k)
+    ab = alg * F / 8.0e12 * 1e6 if alg else None
+    ib = wt = ipw = None
+    if w:
+        n = sum(c.get(x, 0.0) for x in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+        ipw = n / w
+        ib = n * 4.0 / 1024.0 / 2.4e9 * 1e6
+        wc = c.get("SQ_WAVE_CYCLES")
+        wt = 100.0 * c.get("SQ_WAIT_ANY", 0.0) / wc if wc else None
+    best = max([x for x in (bb, ib) if x] or [0.0])
+    f = lambda x, d=0: "-" if x is None else f"{x:.{d}f}"
+    print(f"| `{name}` | {per:.1f} | {avg:.1f} | {f(t / 1e6 if t else None)} | {f(bb)} | {f(ab)} | {f(ipw)} | {f(w)} | {f(ib)} | {f(wt)} | {best / avg:.2f} |")
+    tot += ms
+print(f"\nThe {min(24, len(stats))} kernels above are {tot:.2f} ms of the step.")
