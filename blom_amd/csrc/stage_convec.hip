@@ -50,11 +50,25 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
   // first physical interior layer, :95-109
   int k = 3;
   dps = 0.;
-  while (DP(k) < epsilp) {
-    dps = dps + DP(k);
-    DP(k) = 0.;
-    k = k + 1;
-    if (k > kk) break;
+  {
+    // (the walk over the massless layers under the mixed layer, COLUMN_U levels' loads ahead: with a deep mixed layer it is 20-30
+    // levels long, one dependent load each)
+    bool walking = true;
+    for (int k0 = 3; walking && k0 <= kk; k0 += COLUMN_U) {
+      double a[COLUMN_U];
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++) a[u] = DP(k0 + u <= kk ? k0 + u : kk);
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++) {
+        if (!walking || k0 + u > kk) break;
+        if (a[u] < epsilp) {
+          dps = dps + a[u];
+          DP(k0 + u) = 0.;
+          k = k0 + u + 1;
+        } else
+          walking = false;
+      }
+    }
   }
   if (k > kk) DP(2) = DP(2) + dps;
   else DP(k) = DP(k) + dps;
