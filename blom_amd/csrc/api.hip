@@ -308,6 +308,10 @@ int blomgpu_set_real(blomgpu_ctx *c, const char *name, double v) {
   if (s == "tau_growing_hml") { c->tau_growing_hml = v; return 0; }
   if (s == "tau_decaying_hml") { c->tau_decaying_hml = v; return 0; }
   if (s == "lfmin") { c->lfmin = v; return 0; }
+  if (s == "cl") { c->eddtra_cl = v; return 0; }
+  if (s == "mstar") { c->mstar = v; return 0; }
+  if (s == "nstar") { c->nstar = v; return 0; }
+  if (s == "wpup_min") { c->wpup_min = v; return 0; }
   if (s == "mlbl_max_ratio") { c->mlbl_max_ratio = v; return 0; }
   if (s == "ale_stab_fac_limit") { c->ale_stab_fac_limit = v; return 0; }
   if (s == "ale_dpvar_fac") { c->ale_dpvar_fac = v; return 0; }
@@ -474,7 +478,7 @@ int blomgpu_set_str(blomgpu_ctx *c, const char *name, const char *val) {
   if (s == "mlrttp") { c->mlrttp = v; return 0; }         // resolved (and refused) in mxlayr, phy/mod_mxlayr.F90:197-212
   if (s == "mlrmth") {                                    // init_eddtra, phy/mod_eddtra.F90:1773-1806
     if (v == "none") c->mlrmth = 0; else if (v == "fox08") c->mlrmth = 1;
-    else if (v == "bod23") return ctx_fail(c, " init_eddtra: mlrmth = bod23 is not built (it needs ustar3, wstar3 of the CVMix-bound mod_difest)");
+    else if (v == "bod23") c->mlrmth = 2;                 // refused with isopyc_bulkml when the stage runs (:1787-1795)
     else return ctx_fail(c, " init_eddtra: mlrmth = " + v + " is unsupported!");
     return 0;
   }

@@ -79,7 +79,7 @@
   /* niw_ke_tendency (mod_niw.F90:52-65): mixed layer velocities of the last steps and their running-mean reservoirs */          \
   X(uml, 4) X(vml, 4) X(umlres, 2) X(vmlres, 2)                                                                                   \
   /* mxlayr (mod_mxlayr.F90:70-91 diagnostics; mod_forcing ustar, ustar3; mod_niw idkedt) */                                  \
-  X(ustar, 1) X(ustar3, 1) X(idkedt, 1) X(mtkeus, 1) X(mtkeni, 1) X(mtkebf, 1) X(mtkers, 1) X(mtkepe, 1) X(mtkeke, 1) X(pbrnda, 1)   \
+  X(ustar, 1) X(ustar3, 1) X(wstar3, 1) X(wpup_tf, 1) X(idkedt, 1) X(mtkeus, 1) X(mtkeni, 1) X(mtkebf, 1) X(mtkers, 1) X(mtkepe, 1) X(mtkeke, 1) X(pbrnda, 1)   \
   /* mod_tracers: trc(i,j,2*kdm,ntr), trcold(i,j,kdm,ntr) */                             \
   X(trc, 2 * K * NT) X(trcold, K * NT)                                                   \
   /* mod_diapfl SAVEd arrays (mod_diapfl.F90:59) */                                      \
@@ -286,9 +286,9 @@ struct blomgpu_ctx {
   void *ale = nullptr;
   double *ale_plevel = nullptr;
   // eddtra_ale (stage_eddtra_ale.hip): the options of &DIFFUSION that phy/mod_eddtra.F90 owns, with its defaults (:53-94)
-  int mlrmth = 1;                                         // 0 none, 1 fox08 (bod23 is not built)
+  int mlrmth = 1;                                         // 0 none, 1 fox08, 2 bod23 (hybrid coordinate only)
   double eddtra_ce = .06, tau_mlr = 86400., tau_growing_hbl = 300., tau_decaying_hbl = 86400., tau_growing_hml = 3600.,
-         tau_decaying_hml = 259200., lfmin = 5.e3, mlbl_max_ratio = 3.;
+         tau_decaying_hml = 259200., lfmin = 5.e3, mlbl_max_ratio = 3., eddtra_cl = .25, mstar = .5, nstar = .066, wpup_min = 1.e-3;
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
   bool tmsmt1_ahead = false, tmsmt1_done_ahead = false;
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1

@@ -321,6 +321,7 @@ __global__ void k_eddtra_ts(const DevView *__restrict__ Vp, int mm) {
 int st_eddtra(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (h.P.vcoord_tag != 1) return st_eddtra_ale(c, m, n, mm, nn, k1m, k1n);           // :1859-1901 (stage_eddtra_ale.hip)
+  if (c->mlrmth == 2) return ctx_fail(c, " init_eddtra: mlrmth = bod23 is unsupported with vcoord = 'isopyc_bulkml'!");   // :1787-1795
   if (h.nwk < 2 * G_NSLOT) return ctx_fail(c, "eddtra: device work space too small");
   if (int rc = ctx_err_words(c)) return rc;
   int *errflag = c->err_dev + 1;

@@ -12,12 +12,15 @@
 //                      arrays puv, mflgm, mflsm, mfl, dlm, dlp lie wavefront-major in the work space (level k of the 64 columns
 //                      of a wavefront in six consecutive rows of 64 doubles); upsilon is evaluated in the column
 //   k_eda_ts           utfltd, utflsm, usfltd, usflsm and the v twins
-// mlrmth = 'bod23' needs ustar3 / wstar3 of the CVMix-bound mod_difest and is refused.  Non-convergence of the limiter and a
+// mlrmth = 'bod23' (Bodner et al. 2023, :1058-1081, :1127-1154) takes ustar3 / wstar3 as they stand in mod_forcing -- their producer
+// for this coordinate is the CVMix-bound difest_vertical_hybrid, out of scope: uploaded fields -- and raises their weighted sum to the
+// power 2/3 with the host libm's bits (pow_libm.h); its running mean wpup_tf is state like hbl_tf.  Non-convergence of the limiter and a
 // violated final bound are the reference's xchalt exits and come back as errors.  Roofline: HBM.
 // Parity: cross-checked against the reference's REAL mod_eddtra compiled against a stand-in for mod_difest that holds only
 // OBLdepth (oracle/Makefile *_xale, tests/test_xcheck_eddtra_ale.py) -- a cross-check, not a pin.
 #include "blomgpu_internal.h"
 #include "eos.h"
+#include "pow_libm.h"
 
 #define GRAV 9.806
 #define RHO0 1.e3
@@ -37,7 +40,7 @@
 
 struct EdaPar {
   int mlrmth;
-  double ce, tau_mlr, wf_growing_hbl, wf_decaying_hbl, wf_growing_hml, wf_decaying_hml, lfmin, mlbl_max_ratio;
+  double ce, tau_mlr, wf_growing_hbl, wf_decaying_hbl, wf_growing_hml, wf_decaying_hml, lfmin, mlbl_max_ratio, cl, mstar, nstar, wpup_min;
 };
 
 __device__ inline void rmeanfilt(double &filtered, double signal, double wg, double wd) {   // :121-151
@@ -45,7 +48,7 @@ __device__ inline void rmeanfilt(double &filtered, double signal, double wg, dou
   filtered = wf * filtered + (1. - wf) * signal;
 }
 
-// :1050-1123 (mlrmth = 'fox08')
+// :1050-1123 (mlrmth = 'fox08' or 'bod23')
 __global__ void k_eda_mixed_layer(const DevView *__restrict__ Vp, int nn, EdaPar Q) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
@@ -55,6 +58,13 @@ __global__ void k_eda_mixed_layer(const DevView *__restrict__ Vp, int nn, EdaPar
   const double hbl = V.f[F_OBLdepth][c];
   double hbl_tf = V.f[F_hbl_tf][c], hml_tf1 = V.f[F_hml_tf1][c], hml_tf = V.f[F_hml_tf][c];
   rmeanfilt(hbl_tf, hbl, Q.wf_growing_hbl, Q.wf_decaying_hbl);
+  if (Q.mlrmth == 2) {                                                                 // :1064-1069
+    const double c2_3 = 2. / 3.;
+    const double wpup = fmax2(Q.wpup_min, pow_libm(Q.mstar * V.f[F_ustar3][c] + Q.nstar * V.f[F_wstar3][c], c2_3));
+    double wpup_tf = V.f[F_wpup_tf][c];
+    rmeanfilt(wpup_tf, wpup, Q.wf_growing_hbl, Q.wf_decaying_hbl);
+    V.f[F_wpup_tf][c] = wpup_tf;
+  }
   rmeanfilt(hml_tf1, V.f[F_mld][c], Q.wf_growing_hbl, Q.wf_decaying_hbl);
   rmeanfilt(hml_tf, hml_tf1, Q.wf_growing_hml, Q.wf_decaying_hml);
   const double hml_tfbnd = fmin2(hml_tf, Q.mlbl_max_ratio * hbl_tf);
@@ -144,9 +154,16 @@ __global__ void k_eda_column(const DevView *__restrict__ Vp, int n, int mm, int 
   const double pml = fmin2(pml_a, W(E_PUV, kmax + 1));                                 // :1236
   const double dpmli = 1. / (pml - puv1);                                              // :1240
   const int kml = ka <= kmax ? ka : kmax + 1;                                          // :1244-1251
-  // the submesoscale transport of the column (upsilon), :1125-1176 (fox08) or zero (:1030-1044)
+  // the submesoscale transport of the column (upsilon), :1125-1176 (bod23, fox08) or zero (:1030-1044)
   double upssm = 0.;
-  if (Q.mlrmth == 1) {
+  if (Q.mlrmth == 2) {
+    const double csm = GRAV * ALPHA0 * Q.ce / Q.cl;
+    const double hbl = .5 * (V.f[F_hbl_tf][xa] + V.f[F_hbl_tf][xb]);
+    const double absf = .5 * fabs(V.f[F_coriop][xa] + V.f[F_coriop][xb]);
+    const double wpup = .5 * (V.f[F_wpup_tf][xa] + V.f[F_wpup_tf][xb]);
+    const double drho = V.f[F_util1][xb] - V.f[F_util1][xa];
+    upssm = csm * absf * hbl * hml * hml * drho / wpup;
+  } else if (Q.mlrmth == 1) {
     const double rtau = 1. / Q.tau_mlr, csm = GRAV * ALPHA0 * Q.ce;
     const double f = .5 * (V.f[F_coriop][xa] + V.f[F_coriop][xb]);
     const double absfi = 1. / sqrt(f * f + rtau * rtau);
@@ -345,6 +362,7 @@ int st_eddtra_ale(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n
   int *errflag = c->err_dev + 1;
   EdaPar Q;
   Q.mlrmth = c->mlrmth; Q.ce = c->eddtra_ce; Q.tau_mlr = c->tau_mlr; Q.lfmin = c->lfmin; Q.mlbl_max_ratio = c->mlbl_max_ratio;
+  Q.cl = c->eddtra_cl; Q.mstar = c->mstar; Q.nstar = c->nstar; Q.wpup_min = c->wpup_min;
   const double delt1 = h.P.delt1;
   Q.wf_growing_hbl = c->tau_growing_hbl / (c->tau_growing_hbl + delt1);                // :1054-1057
   Q.wf_decaying_hbl = c->tau_decaying_hbl / (c->tau_decaying_hbl + delt1);
@@ -355,7 +373,11 @@ int st_eddtra_ale(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n
       TimeScope ts(c, "eddtra");
       hipLaunchKernelGGL(k_eda_mixed_layer, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, nn, Q);
     }
-    if (int rc = st_xctilr(c, h.f[F_hml_tfbnd], 1, 1, 1, 1, 1)) return rc;              // :1100, halo_ps
+    if (c->mlrmth == 2) {                                                               // :1079-1080
+      if (int rc = st_xctilr(c, h.f[F_hbl_tf], 1, 1, 1, 1, 1)) return rc;
+      if (int rc = st_xctilr(c, h.f[F_wpup_tf], 1, 1, 1, 1, 1)) return rc;
+    }
+    if (int rc = st_xctilr(c, h.f[F_hml_tfbnd], 1, 1, 1, 1, 1)) return rc;              // :1081 / :1100, halo_ps
     if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, 1, 1, 1)) return rc;                  // :1123
   }
   {

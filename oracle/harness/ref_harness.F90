@@ -47,7 +47,7 @@ module ref_harness
 #ifdef XCHECK_EDDTRA
   ! cross-check builds only (oracle/Makefile *_xed): the reference's real mod_eddtra, compiled against a stand-in for mod_difest
   use mod_eddtra,    only: eddtra, init_eddtra, inivar_eddtra, mlrmth, ce, tau_mlr, tau_growing_hbl, tau_decaying_hbl, &
-                            tau_growing_hml, tau_decaying_hml, lfmin, mlbl_max_ratio, hbl_tf, hml_tf1, hml_tf
+                            tau_growing_hml, tau_decaying_hml, lfmin, mlbl_max_ratio, hbl_tf, hml_tf1, hml_tf, wpup_tf
   use mod_difest,    only: OBLdepth        ! the stand-in's array (oracle/xcheck/mod_difest_standin.F90)
   use mod_cmnfld_routines, only: cmnfld1, cmnfld2, cmnfld_bfsqi_ale
 #endif
@@ -601,6 +601,7 @@ contains
       R2(dpml)
 #ifdef XCHECK_EDDTRA
       R2(hbl_tf)
+      R2(wpup_tf)
       R2(hml_tf1)
       R2(hml_tf)
       R2(OBLdepth)
@@ -641,6 +642,7 @@ contains
       ! mod_forcing: friction velocity and the forcing fields of thermf (phy/mod_forcing.F90:100-175)
       R2(ustar)
       R2(ustar3)
+      R2(wstar3)
       R2(ustarw)
       R2(swa)
       R2(nsf)
@@ -706,6 +708,7 @@ contains
       ! init_eddtra resolves the mixed layer restratification method from the string (phy/mod_eddtra.F90:1773-1806)
       case ('eddtra_init_fox08'); mlrmth = 'fox08'; call inivar_eddtra; call init_eddtra
       case ('eddtra_init_none');  mlrmth = 'none';  call inivar_eddtra; call init_eddtra
+      case ('eddtra_init_bod23'); mlrmth = 'bod23'; call inivar_eddtra; call init_eddtra
       case ('cmnfld2'); call cmnfld2(m,n,mm,nn,k1m,k1n)
       case ('cmnfld1'); call cmnfld1(m,n,mm,nn,k1m,k1n)
       case ('cmnfld_bfsqi_ale'); call cmnfld_bfsqi_ale(m,n,mm,nn,k1m,k1n)
