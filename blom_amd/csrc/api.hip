@@ -423,6 +423,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "ale_velocity_pc_upper_bndr") { c->ale_velocity_pc_upper = v != 0; return ale_reset(c); }
   if (s == "ale_velocity_pc_lower_bndr") { c->ale_velocity_pc_lower = v != 0; return ale_reset(c); }
   if (s == "remap_fold") { c->remap_fold = v; return 0; }
+  if (s == "remap_nfirst") { c->remap_nfirst = v; return 0; }
   if (s == "halo_overlap") { c->halo_overlap = v; return 0; }
   if (s == "cmnfld1") { c->cmnfld1 = v; return 0; }
   if (s == "diapfl_du") { c->diapfl_du = v; return 0; }

@@ -262,6 +262,7 @@ struct blomgpu_ctx {
   // (channel 6.41-6.45 against 6.43-6.45 ms per step, remap 0.910 against 0.906 ms) to slower (tnx2v1s 3.71 against 3.66 ms) -- the
   // overlapping tiles cost the tile kernel what the update kernel took, though 1.1 GB less crosses HBM
   int remap_fold = 0;
+  int remap_nfirst = 4;      // more than 4 advected tracers: how many of them ride with dp, T, S in k_remap_tile's first pass (0..4; 4 measured fastest)
   bool remap_handed_over = false;   // ... and has left dp, T, S, tracers of the new level in the work space for pbcor1
   // ale_regrid_remap (stage_ale.hip): the options of &ALE_REGRID_REMAP with the reference's defaults (mod_ale_regrid_remap.F90:69-95),
   // as hor3map codes (include/blomgpu_hor3map.h); the engine's structures; the pressure levels of vcoord_type = 'plevel'

@@ -44,7 +44,6 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
 #define DN(k) dens[(size_t)(k) * np]
 #define DR(k) densr[(size_t)(k) * np]
 #define TR(nt, k) trc[(size_t)(nt) * ntl + (size_t)(k) * np]
-  double trdps[MAXTR];
   double tdps, sdps, dps, ttmp, stmp, dtmp, q = 0.;
 
   // first physical interior layer, :95-109
@@ -75,26 +74,65 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
   int kfpl = k;
   int *kfpla = V.m[I_kfpla] + c + (size_t)(n - 1) * np;
   const int kfplo = *kfpla;
+  // The tracers' share of a mixing event, :118-122 / :160-164 / :213-217, :233-237 and the assignments that follow them: each tracer's
+  // thickness-weighted sum over the levels ka..kb in the reference's order (after layer 2's term where the event starts there), times
+  // q, into one or two levels.  The reference carries the sums along while it looks for the event's extent; they depend on nothing but
+  // dp, so they are evaluated here once the extent is known -- and not at all in a column without an event, which is nearly every
+  // column: CV_TB tracers at a time, COLUMN_U levels' loads in flight.  (Must run before the event's layers give up their dp.)
+#define CV_TB 4
+  auto mix_tracers = [&](bool from2, double d2, int ka, int kb, double qq, int kd1, int kd2) {
+    for (int nt0 = 0; nt0 < ntr; nt0 += CV_TB) {
+      double acc[CV_TB];
+#pragma unroll
+      for (int b = 0; b < CV_TB; b++) {
+        const int nt = nt0 + b < ntr ? nt0 + b : ntr - 1;
+        acc[b] = 0.;
+        if (from2) acc[b] = TR(nt, 2) * d2;
+      }
+      for (int k0 = ka; k0 <= kb; k0 += COLUMN_U) {
+        double d[COLUMN_U], x[CV_TB][COLUMN_U];
+#pragma unroll
+        for (int u = 0; u < COLUMN_U; u++) {
+          const int kq = k0 + u <= kb ? k0 + u : kb;
+          d[u] = DP(kq);
+#pragma unroll
+          for (int b = 0; b < CV_TB; b++) x[b][u] = TR(nt0 + b < ntr ? nt0 + b : ntr - 1, kq);
+        }
+#pragma unroll
+        for (int u = 0; u < COLUMN_U; u++)
+          if (k0 + u <= kb) {
+#pragma unroll
+            for (int b = 0; b < CV_TB; b++) acc[b] = acc[b] + x[b][u] * d[u];
+          }
+      }
+#pragma unroll
+      for (int b = 0; b < CV_TB; b++)
+        if (nt0 + b < ntr) {
+          const double r = acc[b] * qq;
+          TR(nt0 + b, kd1) = r;
+          if (kd2) TR(nt0 + b, kd2) = r;
+        }
+    }
+  };
   if (kfpl < kfplo) {                                        // :110-191
     tdps = 0.; sdps = 0.; dps = 0.;
-    for (int nt = 0; nt < ntr; nt++) trdps[nt] = 0.;
+    const int kfpl0 = kfpl;
     if (kfplo <= kk) {
       for (k = kfpl; k <= kfplo; k++) {
         const double d = DP(k);
         tdps = tdps + TT(k) * d;
         sdps = sdps + SS(k) * d;
         dps = dps + d;
-        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * d;
       }
       q = 1. / dps;
       ttmp = tdps * q;
       stmp = sdps * q;
       dtmp = eos::sig(V.P, ttmp, stmp);
       if (dtmp > DR(kfplo)) {
+        mix_tracers(false, 0., kfpl0, kfplo, q, kfplo, 0);
         for (k = kfpl; k <= kfplo - 1; k++) DP(k) = 0.;
         kfpl = kfplo;
         TT(kfpl) = ttmp; SS(kfpl) = stmp; DN(kfpl) = dtmp; DP(kfpl) = dps;
-        for (int nt = 0; nt < ntr; nt++) TR(nt, kfpl) = trdps[nt] * q;
       }
     } else {
       for (k = kfpl; k <= kk; k++) {
@@ -102,8 +140,6 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
         tdps = tdps + TT(k) * d;
         sdps = sdps + SS(k) * d;
         dps = dps + d;
-        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * d;
-        DP(k) = 0.;
       }
       q = 1. / dps;
       ttmp = tdps * q;
@@ -114,8 +150,9 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
         if (kfpl == 3) break;
         kfpl = kfpl - 1;
       }
+      mix_tracers(false, 0., kfpl0, kk, q, kfpl, 0);
+      for (k = kfpl0; k <= kk; k++) DP(k) = 0.;
       TT(kfpl) = ttmp; SS(kfpl) = stmp; DN(kfpl) = dtmp; DP(kfpl) = dps;
-      for (int nt = 0; nt < ntr; nt++) TR(nt, kfpl) = trdps[nt] * q;
     }
   }
 
@@ -133,12 +170,13 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
       tdps = t2 * d2;
       sdps = s2 * d2;
       dps = d2;
-      for (int nt = 0; nt < ntr; nt++) trdps[nt] = TR(nt, 2) * d2;
       ttmp = t2;
       stmp = s2;
       k = kfpl;
+      double tk = TT(k), sk = SS(k), dk = DP(k);
       while (true) {
-        const double tk = TT(k), sk = SS(k), dk = DP(k);
+        const int kn = k + 1 <= kk ? k + 1 : kk;             // (the next level's values are on their way during the test)
+        const double tn = TT(kn), sn = SS(kn), dn = DP(kn);
         if (!(eos::rho(dps, ttmp, stmp) > eos::rho(dps, tk, sk) || dk < epsilp)) break;
         tdps = tdps + tk * dk;
         sdps = sdps + sk * dk;
@@ -146,9 +184,9 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
         q = 1. / dps;
         ttmp = tdps * q;
         stmp = sdps * q;
-        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * dk;
         k = k + 1;
         if (k > kk) break;
+        tk = tn; sk = sn; dk = dn;
       }
       const int kmix = k - 1;
       if (kmix >= kfpl) {
@@ -156,20 +194,19 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
         TT(2) = ttmp;
         SS(2) = stmp;
         DN(2) = dn2;
-        for (int nt = 0; nt < ntr; nt++) TR(nt, 2) = trdps[nt] * q;
-        dps = 0.;
-        for (k = kfpl; k <= kmix; k++) {
-          dps = dps + DP(k);
-          DP(k) = 0.;
-        }
         k = kmix;
         while (dn2 < DR(k)) {
           if (k == 3) break;
           k = k - 1;
         }
+        mix_tracers(true, d2, kfpl, kmix, q, 2, k);         // ttrc(nt,2) = trdps(nt)*q, ttrc(nt,kfpl) = ttrc(nt,2)
+        dps = 0.;
+        for (int kz = kfpl; kz <= kmix; kz++) {
+          dps = dps + DP(kz);
+          DP(kz) = 0.;
+        }
         kfpl = k;
         TT(kfpl) = ttmp; SS(kfpl) = stmp; DN(kfpl) = dn2; DP(kfpl) = dps;
-        for (int nt = 0; nt < ntr; nt++) TR(nt, kfpl) = TR(nt, 2);
         for (k = kfpl + 1; k <= kmix; k++) {
           const double dr = DR(k);
           TT(k) = ttmp;

@@ -135,6 +135,23 @@ __global__ void k_mxl_bg2_sum(const DevView *__restrict__ Vp) {
 
 // ---- :293-1241 the column ------------------------------------------------------------------------------------------------
 #define MAXITR 20
+// A loop over the tracers of a column with the loads of four tracers in flight: load(nt, x, y, z) reads what tracer nt needs,
+// use(nt, x, y, z) computes and stores.  (One tracer per iteration is one exposed memory latency per tracer and loop -- with 24
+// tracers most of the kernel's time.)  What the loop reads besides the tracers is loaded by the caller beforehand.
+template <class L, class U>
+__device__ inline void tracers4(int ntr, L load, U use) {
+  for (int nt0 = 0; nt0 < ntr; nt0 += 4) {
+    double x[4], y[4], z[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      x[b] = 0.; y[b] = 0.; z[b] = 0.;
+      load(nt0 + b < ntr ? nt0 + b : ntr - 1, x[b], y[b], z[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (nt0 + b < ntr) use(nt0 + b, x[b], y[b], z[b]);
+  }
+}
 #define MAXTR_MXL 64     // tracer sums of a column: dynamically indexed (private memory), any tracer count up to this
 __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ Vp, MxlPar M, int n, int nn) {
   const DevView &V = *Vp;
@@ -299,29 +316,38 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       sfsl = (SS(2) * DP(2) + SS(1) * (PR(2) - pmxl)) * q;
       TT(2) = TT(1);
       SS(2) = SS(1);
-      for (int nt = 0; nt < ntr; nt++) {
-        trfsl[nt] = (TR(nt, 2) * DP(2) + TR(nt, 1) * (PR(2) - pmxl)) * q;
-        TR(nt, 2) = TR(nt, 1);
+      {
+        const double dp2 = DP(2), w1 = PR(2) - pmxl;
+        tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 2); y = TR(nt, 1); },
+                 [&](int nt, double x, double y, double) { trfsl[nt] = (x * dp2 + y * w1) * q; TR(nt, 2) = y; });
       }
       DP(2) = pmxl - PR(1) - dptopl;
     } else {                                                                          // :473-509
       tfsl = TT(2);
       sfsl = SS(2);
-      for (int nt = 0; nt < ntr; nt++) trfsl[nt] = TR(nt, 2);
+      tracers4(ntr, [&](int nt, double &x, double &, double &) { x = TR(nt, 2); }, [&](int nt, double x, double, double) { trfsl[nt] = x; });
       DP(2) = pmxl - PR(2);
       if (DP(1) > dptopl) {
         dpt = DP(1) - dptopl;
         q = 1. / (DP(2) + dpt);
         TT(2) = (TT(2) * DP(2) + TT(1) * dpt) * q;
         SS(2) = (SS(2) * DP(2) + SS(1) * dpt) * q;
-        for (int nt = 0; nt < ntr; nt++) TR(nt, 2) = (TR(nt, 2) * DP(2) + TR(nt, 1) * dpt) * q;
+        {
+          const double dp2 = DP(2);
+          tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 2); y = TR(nt, 1); },
+                   [&](int nt, double x, double y, double) { TR(nt, 2) = (x * dp2 + y * dpt) * q; });
+        }
         DP(2) = DP(2) + dpt;
       } else {
         dpt = dptopl - DP(1);
         q = 1. / (DP(1) + dpt);
         TT(1) = (TT(1) * DP(1) + TT(2) * dpt) * q;
         SS(1) = (SS(1) * DP(1) + SS(2) * dpt) * q;
-        for (int nt = 0; nt < ntr; nt++) TR(nt, 1) = (TR(nt, 1) * DP(1) + TR(nt, 2) * dpt) * q;
+        {
+          const double dp1 = DP(1);
+          tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 1); y = TR(nt, 2); },
+                   [&](int nt, double x, double y, double) { TR(nt, 1) = (x * dp1 + y * dpt) * q; });
+        }
         DP(2) = DP(2) - dpt;
       }
     }
@@ -454,7 +480,8 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     q = delt1 * GRAV / DP(1);
     TT(1) = TT(1) - (surflx - (pswbas - pswup) * sswflx + surrlx) * q / SPCIFH;
     SS(1) = SS(1) - (salflx - brnflx + salrlx) * q;
-    for (int nt = 0; nt < ntr; nt++) TR(nt, 1) = TR(nt, 1) - V.f[F_trflx][c + (size_t)nt * np] * q;
+    tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 1); y = V.f[F_trflx][c + (size_t)nt * np]; },
+             [&](int nt, double x, double y, double) { TR(nt, 1) = x - y * q; });
 
     // density of the layers the forcing touched, :666-671
     DN(1) = SIG(TT(1), SS(1));
@@ -466,7 +493,11 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       TT(2) = (tfsl * dpfsl + TT(2) * DP(2)) * q;
       SS(2) = (sfsl * dpfsl + SS(2) * DP(2)) * q;
       DN(2) = SIG(TT(2), SS(2));
-      for (int nt = 0; nt < ntr; nt++) TR(nt, 2) = (trfsl[nt] * dpfsl + TR(nt, 2) * DP(2)) * q;
+      {
+        const double dp2 = DP(2);
+        tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trfsl[nt]; y = TR(nt, 2); },
+                 [&](int nt, double x, double y, double) { TR(nt, 2) = (x * dpfsl + y * dp2) * q; });
+      }
       DP(2) = dpfsl + DP(2);
     } else {
       // ---- the fossil mixed layer goes into isopycnic layers, :685-805 ------------------------------------------------
@@ -476,7 +507,11 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     TT(kq) = (tfsl * (dd) + TT(kq) * DP(kq)) * q;                                                   \
     SS(kq) = (sfsl * (dd) + SS(kq) * DP(kq)) * q;                                                   \
     DN(kq) = SIG(TT(kq), SS(kq));                                                                   \
-    for (int nt = 0; nt < ntr; nt++) TR(nt, kq) = (trfsl[nt] * (dd) + TR(nt, kq) * DP(kq)) * q;      \
+    {                                                                                              \
+      const double dd_ = (dd), dpk_ = DP(kq);                                                      \
+      tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trfsl[nt]; y = TR(nt, kq); }, \
+               [&](int nt, double x, double y, double) { TR(nt, kq) = (x * dd_ + y * dpk_) * q; }); \
+    }                                                                                              \
     DP(kq) = (dd) + DP(kq);                                                                         \
   }
       k = kk < kfpl ? kk : kfpl;
@@ -496,7 +531,11 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
             TT(k) = ttmp;
             SS(k) = stmp;
             DN(k) = sigtmp;
-            for (int nt = 0; nt < ntr; nt++) TR(nt, k) = (trfsl[nt] * dpfsl + TR(nt, k) * DP(k)) * q;
+            {
+              const double dpk_ = DP(k);
+              tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trfsl[nt]; y = TR(nt, k); },
+                       [&](int nt, double x, double y, double) { TR(nt, k) = (x * dpfsl + y * dpk_) * q; });
+            }
             DP(k) = dpfsl + DP(k);
           }
         } else {
@@ -532,13 +571,17 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       pmxl = mltmin * ONEM;
       tdps = TT(2) * DP(2);
       sdps = SS(2) * DP(2);
-      for (int nt = 0; nt < ntr; nt++) trdps[nt] = TR(nt, 2) * DP(2);
+      {
+        const double dp2 = DP(2);
+        tracers4(ntr, [&](int nt, double &x, double &, double &) { x = TR(nt, 2); }, [&](int nt, double x, double, double) { trdps[nt] = x * dp2; });
+      }
       k = kfpl;
       while (k <= kk) {
         q = fmin2(pmxl, PR(k + 1)) - PR(k);
         tdps = tdps + TT(k) * q;
         sdps = sdps + SS(k) * q;
-        for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * q;
+        tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, k); },
+                 [&](int nt, double x, double y, double) { trdps[nt] = x + y * q; });
         DP(k) = PR(k + 1) - fmin2(pmxl, PR(k + 1));
         if (PR(k + 1) > pmxl) break;
         k = k + 1;
@@ -563,7 +606,10 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       k = kfpl;
       tdps = TT(2) * DP(2);
       sdps = SS(2) * DP(2);
-      for (int nt = 0; nt < ntr; nt++) trdps[nt] = TR(nt, 2) * DP(2);
+      {
+        const double dp2 = DP(2);
+        tracers4(ntr, [&](int nt, double &x, double &, double &) { x = TR(nt, 2); }, [&](int nt, double x, double, double) { trdps[nt] = x * dp2; });
+      }
       for (;;) {
         if (k > kk) break;
         else if (DP(k) < EPSILP) k = k + 1;
@@ -639,13 +685,18 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
           if (pmxl < presk1 - EPSILP && nitr < MAXITR) {
             tdps = tdps + tk * (pmxl - presk);
             sdps = sdps + sk * (pmxl - presk);
-            for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * (pmxl - presk);
+            {
+              const double w_ = pmxl - presk;
+              tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, k); },
+                       [&](int nt, double x, double y, double) { trdps[nt] = x + y * w_; });
+            }
             DP(k) = presk1 - pmxl;
             break;
           } else {
             tdps = tdps + tk * delpk;
             sdps = sdps + sk * delpk;
-            for (int nt = 0; nt < ntr; nt++) trdps[nt] = trdps[nt] + TR(nt, k) * delpk;
+            tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, k); },
+                     [&](int nt, double x, double y, double) { trdps[nt] = x + y * delpk; });
             pmxl = presk1;
             tmxl = (tmxl0 * (presk - pres1) + tk * (pmxl - presk)) / (pmxl - pres1);
             smxl = (smxl0 * (presk - pres1) + sk * (pmxl - presk)) / (pmxl - pres1);
@@ -675,7 +726,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       q = 1. / DP(2);
       TT(2) = tdps * q;
       SS(2) = sdps * q;
-      for (int nt = 0; nt < ntr; nt++) TR(nt, 2) = trdps[nt] * q;
+      tracers4(ntr, [&](int nt, double &x, double &, double &) { x = trdps[nt]; }, [&](int nt, double x, double, double) { TR(nt, 2) = x * q; });
       kfpl = k;
       for (k = 4; k <= kfpl; k++) PR(k) = p3;
     }
@@ -687,14 +738,22 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       q = 1. / (DP(2) + dpt);
       TT(2) = (TT(2) * DP(2) + TT(1) * dpt) * q;
       SS(2) = (SS(2) * DP(2) + SS(1) * dpt) * q;
-      for (int nt = 0; nt < ntr; nt++) TR(nt, 2) = (TR(nt, 2) * DP(2) + TR(nt, 1) * dpt) * q;
+      {
+        const double dp2 = DP(2);
+        tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 2); y = TR(nt, 1); },
+                 [&](int nt, double x, double y, double) { TR(nt, 2) = (x * dp2 + y * dpt) * q; });
+      }
       DP(2) = DP(2) + dpt;
     } else {
       dpt = dptopl - DP(1);
       q = 1. / (DP(1) + dpt);
       TT(1) = (TT(1) * DP(1) + TT(2) * dpt) * q;
       SS(1) = (SS(1) * DP(1) + SS(2) * dpt) * q;
-      for (int nt = 0; nt < ntr; nt++) TR(nt, 1) = (TR(nt, 1) * DP(1) + TR(nt, 2) * dpt) * q;
+      {
+        const double dp1 = DP(1);
+        tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 1); y = TR(nt, 2); },
+                 [&](int nt, double x, double y, double) { TR(nt, 1) = (x * dp1 + y * dpt) * q; });
+      }
       DP(2) = DP(2) - dpt;
     }
     DP(1) = dptopl;
@@ -803,7 +862,8 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     q = delt1 * GRAV / DP(1);
     TT(1) = TT(1) - (surflx - (pswbas - pswup) * sswflx + surrlx) * q / SPCIFH;
     SS(1) = SS(1) - (salflx - brnflx + salrlx) * q;
-    for (int nt = 0; nt < ntr; nt++) TR(nt, 1) = TR(nt, 1) - V.f[F_trflx][c + (size_t)nt * np] * q;
+    tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = TR(nt, 1); y = V.f[F_trflx][c + (size_t)nt * np]; },
+             [&](int nt, double x, double y, double) { TR(nt, 1) = x - y * q; });
 
     DN(1) = SIG(TT(1), SS(1));                                                        // :1192-1196
     DN(2) = SIG(TT(2), SS(2));
@@ -821,62 +881,75 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
   // first physical layer, :1200-1214
   k = 3;
   dps = 0.;
-  while (DP(k) < EPSILP) {
-    dps = dps + DP(k);
-    DP(k) = 0.;
-    k = k + 1;
-    if (k > kk) break;
+  {
+    bool walking = true;                               // (COLUMN_U levels' loads ahead, as in k_convec_column)
+    for (int k0 = 3; walking && k0 <= kk; k0 += COLUMN_U) {
+      double a[COLUMN_U];
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++) a[u] = DP(k0 + u <= kk ? k0 + u : kk);
+#pragma unroll
+      for (int u = 0; u < COLUMN_U; u++) {
+        if (!walking || k0 + u > kk) break;
+        if (a[u] < EPSILP) {
+          dps = dps + a[u];
+          DP(k0 + u) = 0.;
+          k = k0 + u + 1;
+        } else
+          walking = false;
+      }
+    }
   }
   if (k > kk) DP(2) = DP(2) + dps;
   else DP(k) = DP(k) + dps;
   V.m[I_kfpla][c + (size_t)(n - 1) * np] = k;
+}
 
-  // ---- the copy-back rules, :1216-1241: negative salinities and tracers are set to zero and what that adds is booked in
-  //      salt_corr, trc_corr; the turbulence tracers are bounded below.  (For non-negative values the reference's updates
-  //      subtract zero.)
-  {
-    double sc = V.f[F_salt_corr][c];
-    for (int k0 = 1; k0 <= kk; k0 += COLUMN_U) {
-      double a[COLUMN_U];
+// ---- the copy-back rules, :1216-1241: negative salinities and tracers are set to zero and what that adds is booked in salt_corr,
+//      trc_corr; the turbulence tracers are bounded below.  (For non-negative values the reference's updates subtract zero, and
+//      the sums they are subtracted from are never -0: nothing is done for them.)  One thread per column AND array (blockIdx.y = 0
+//      salinity, 1.. the tracers): the columns of the ntr + 1 arrays are independent of each other, so they go to as many
+//      wavefronts instead of being walked one after the other by the column's one thread.
+__global__ __launch_bounds__(64) void k_mxl_clamp(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int kk = V.kk;
+  const size_t np = V.nplane;
+  const Params &P = V.P;
+  const double *delp = V.f[F_dp] + c + (size_t)nn * np - np;
+  const int nt = (int)by_ - 1;
+  double *x = (nt < 0 ? V.f[F_saln] : V.f[F_trc] + (size_t)nt * 2 * kk * np) + c + (size_t)nn * np - np;
+#define XX(k) x[(size_t)(k) * np]
+  const bool is_tke = nt >= 0 && P.itrtke >= 1 && nt + 1 == P.itrtke, is_gls = nt >= 0 && P.itrtke >= 1 && P.gls && nt + 1 == P.itrgls;
+  if (is_tke || is_gls) {
+    const double lo = is_tke ? TKE_MIN : GLS_PSI_MIN;
+    for (int k0 = 1; k0 <= kk; k0 += 2 * COLUMN_U) {
+      double a[2 * COLUMN_U];
 #pragma unroll
-      for (int u = 0; u < COLUMN_U; u++) a[u] = SS(k0 + u <= kk ? k0 + u : kk);
+      for (int u = 0; u < 2 * COLUMN_U; u++) a[u] = XX(k0 + u <= kk ? k0 + u : kk);
 #pragma unroll
-      for (int u = 0; u < COLUMN_U; u++)
-        if (k0 + u <= kk) {
-          sc = sc - fmin2(0., a[u]) * (a[u] < 0. ? DP(k0 + u) : 0.) / GRAV;
-          if (a[u] < 0.) SS(k0 + u) = 0.;
-        }
+      for (int u = 0; u < 2 * COLUMN_U; u++)
+        if (k0 + u <= kk && !(a[u] > lo)) XX(k0 + u) = fmax2(a[u], lo);
     }
-    V.f[F_salt_corr][c] = sc;
+    return;
   }
-  for (int nt = 0; nt < ntr; nt++) {
-    const bool is_tke = P.itrtke >= 1 && nt + 1 == P.itrtke, is_gls = P.itrtke >= 1 && P.gls && nt + 1 == P.itrgls;
-    if (is_tke || is_gls) {
-      const double lo = is_tke ? TKE_MIN : GLS_PSI_MIN;
-      for (int k0 = 1; k0 <= kk; k0 += COLUMN_U) {
-        double a[COLUMN_U];
+  double *corr = nt < 0 ? V.f[F_salt_corr] + c : V.f[F_trc_corr] + c + (size_t)nt * np;
+  double tc = 0.;
+  bool any = false;
+  for (int k0 = 1; k0 <= kk; k0 += 2 * COLUMN_U) {
+    double a[2 * COLUMN_U];
 #pragma unroll
-        for (int u = 0; u < COLUMN_U; u++) a[u] = TR(nt, k0 + u <= kk ? k0 + u : kk);
+    for (int u = 0; u < 2 * COLUMN_U; u++) a[u] = XX(k0 + u <= kk ? k0 + u : kk);
 #pragma unroll
-        for (int u = 0; u < COLUMN_U; u++)
-          if (k0 + u <= kk && !(a[u] > lo)) TR(nt, k0 + u) = fmax2(a[u], lo);
+    for (int u = 0; u < 2 * COLUMN_U; u++)
+      if (k0 + u <= kk && a[u] < 0.) {
+        if (!any) { tc = *corr; any = true; }
+        tc = tc - fmin2(0., a[u]) * delp[(size_t)(k0 + u) * np] / GRAV;
+        XX(k0 + u) = 0.;
       }
-    } else {
-      double tc = V.f[F_trc_corr][c + (size_t)nt * np];
-      for (int k0 = 1; k0 <= kk; k0 += COLUMN_U) {
-        double a[COLUMN_U];
-#pragma unroll
-        for (int u = 0; u < COLUMN_U; u++) a[u] = TR(nt, k0 + u <= kk ? k0 + u : kk);
-#pragma unroll
-        for (int u = 0; u < COLUMN_U; u++)
-          if (k0 + u <= kk) {
-            tc = tc - fmin2(0., a[u]) * (a[u] < 0. ? DP(k0 + u) : 0.) / GRAV;
-            if (a[u] < 0.) TR(nt, k0 + u) = 0.;
-          }
-      }
-      V.f[F_trc_corr][c + (size_t)nt * np] = tc;
-    }
   }
+  if (any) *corr = tc;
+#undef XX
 }
 
 int st_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
@@ -903,6 +976,7 @@ int st_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc = st_xctilr(c, h.f[F_v] + (size_t)(k1n - 1) * h.nplane, 1, h.kk, 1, 1, 14)) return rc;
   }
   hipLaunchKernelGGL(k_mxl_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, M, n, nn);
+  hipLaunchKernelGGL(k_mxl_clamp, plane_grid(h, h.ntr + 1, 64), dim3(64), 0, c->stream, c->d, nn);
   HIPCHK(c, hipGetLastError());
   // 'old' interface pressures at the velocity points (:1243-1262), the dp halo, p and the new dpu, dpv (:1264-1310), the
   // velocities onto the new layers (:1312-1374)

@@ -26,6 +26,7 @@
 #define RT_SW (RT_TW + 4)                 // scalar region: the tile and a 2-point rim
 #define RT_SN (RT_SW * (RT_TH + 4))
 #define RT_NT 512                         // threads of a workgroup: >= RT_SN, and two per point of the tile
+#define RT_NB 4                           // tracers of a later batch (MORE)
 #define RT_NSC(ntr) (4 + (ntr))           // scalars: dp, p(k+1), T, S, tracers
 #define RT_NG(ntr) (10 + 3 * (ntr))       // gradient slots (remap_common.h) + dp', pup of the cell
 #define RT_G_DPT(ntr) (8 + 3 * (ntr))
@@ -76,9 +77,10 @@ struct AdvList {               // model indices of the advected tracers, in orde
   unsigned char idx[64];
 };
 // one polygon's contribution from the donor cell at index x of the gradient region (add_contrib of stage_advect.hip)
+// (rec[slot]: slot 0 / 1 the triangles at the face's two ends where there is one, slot 2 the pentagon -- the order they are added in)
 template <bool MORE>
 __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbface, double a, double ax, double ay, double axx,
-                                     double ayy, double axy, Acc &A, PolyRec *rec, int &npoly) {
+                                     double ayy, double axy, Acc &A, PolyRec *rec, const int slot) {
   const double dpt = g[RT_G_DPT(ntr) * RT_GN + x];
   const double pup = g[RT_G_PUP(ntr) * RT_GN + x];
   const double dl = fmin2(dpt, fmax2(0., pbface - pup));
@@ -93,10 +95,7 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
   for (int nt = 0; nt < MAXTR; nt++)
     if (nt < ntr)
       A.ftr[nt] = A.ftr[nt] + fd * g[G_TRD(nt) * RT_GN + x] + qx * g[G_TRX(nt) * RT_GN + x] + qy * g[G_TRY(nt) * RT_GN + x];
-  if (MORE) {
-    rec[npoly].fd = fd; rec[npoly].qx = qx; rec[npoly].qy = qy; rec[npoly].x = x;
-    npoly++;
-  }
+  if (MORE) { rec[slot].fd = fd; rec[slot].qx = qx; rec[slot].qy = qy; rec[slot].x = x; }
 }
 
 // MORE = true (more than MAXTR advected tracers): the first MAXTR ride with dp, T, S as always; the others follow in batches
@@ -111,9 +110,9 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
 // planes, where pbcor1 -- the next stage, and the only reader before diffus rewrites the fields -- takes them
 // (remap_common.h: R_DP..).  The 12 + 2 ntr flux planes between the two kernels never reach memory.
 template <bool MORE, bool FOLD>
-__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv_all, AdvList L, int tsel) {
+__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv_all, int nfirst, AdvList L, int tsel) {
   const DevView &V = *Vp;
-  const int nadv = nadv_all < MAXTR ? nadv_all : MAXTR;
+  const int nadv = nfirst;               // tracers that ride with dp, T, S (all of them unless MORE)
   const int base = 1;
   HIP_DYNAMIC_SHARED(double, lds)
   unsigned bx_, by_;
@@ -328,8 +327,11 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   const bool in_f = uface ? (fj >= 0 && fj <= V.jj + 1 && fi >= 0 && fi <= V.ii + 2) : (fj >= 0 && fj <= V.jj + 2 && fi >= 0 && fi <= V.ii + 1);
   if (!MORE && !FOLD && !in_f) return;
   const bool do_face = fin && in_f;
+  // a polygon that does not exist (no triangle at that end; a face without flow) keeps weight zero: +-0 added to a sum that starts
+  // at +0 never changes it, so the later batches add all three slots without a test (and the records stay in registers)
   PolyRec rec[3];
-  int npoly = 0;
+#pragma unroll
+  for (int z = 0; z < 3; z++) { rec[z].fd = 0.; rec[z].qx = 0.; rec[z].qy = 0.; rec[z].x = fq; }
   Acc A;
   A.fd = 0.; A.ft = 0.; A.fs = 0.;
 #pragma unroll
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x4 = xc0 + sh;
         y4 = -.5;
         triint(s2_m, xc1 + sh, .5, -cuc0 + sh, -cvc0 + .5, sh, .5, a, ax, ay, axx, ayy, axy);
-        add_contrib_t<MORE>(gr, nadv, ic - RT_GW, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
+        add_contrib_t<MORE>(gr, nadv, ic - RT_GW, pbf, a, ax, ay, axx, ayy, axy, A, rec, 0);
       } else {
         x4 = -cuc0 + sh;
         y4 = -cvc0 - .5;
@@ -364,13 +366,13 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x2 = xc0 + sh;
         y2 = .5;
         triint(s2_p, xc1 + sh, -.5, sh, -.5, -cuc1 + sh, -cvc1 - .5, a, ax, ay, axx, ayy, axy);
-        add_contrib_t<MORE>(gr, nadv, ic + RT_GW, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
+        add_contrib_t<MORE>(gr, nadv, ic + RT_GW, pbf, a, ax, ay, axx, ayy, axy, A, rec, 1);
       } else {
         x2 = -cuc1 + sh;
         y2 = -cvc1 + .5;
       }
       penint(s2_c, sh, .5, x2, y2, xm + sh, ym, x4, y4, sh, -.5, a, ax, ay, axx, ayy, axy);
-      add_contrib_t<MORE>(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
+      add_contrib_t<MORE>(gr, nadv, ic, pbf, a, ax, ay, axx, ayy, axy, A, rec, 2);
       // mod_remap.F90:1054-1056
       if (base && own) {
         *o_f = f_o + A.fd;
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x2 = -.5;
         y2 = yc0 + sh;
         triint(s2_m, .5, yc1 + sh, .5, sh, -cuc0 + .5, -cvc0 + sh, a, ax, ay, axx, ayy, axy);
-        add_contrib_t<MORE>(gr, nadv, jc - 1, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
+        add_contrib_t<MORE>(gr, nadv, jc - 1, pbf, a, ax, ay, axx, ayy, axy, A, rec, 0);
       } else {
         x2 = -cuc0 - .5;
         y2 = -cvc0 + sh;
@@ -399,13 +401,13 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         x4 = .5;
         y4 = yc0 + sh;
         triint(s2_p, -.5, yc1 + sh, -cuc1 - .5, -cvc1 + sh, -.5, sh, a, ax, ay, axx, ayy, axy);
-        add_contrib_t<MORE>(gr, nadv, jc + 1, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
+        add_contrib_t<MORE>(gr, nadv, jc + 1, pbf, a, ax, ay, axx, ayy, axy, A, rec, 1);
       } else {
         x4 = -cuc1 + .5;
         y4 = -cvc1 + sh;
       }
       penint(s2_c, -.5, sh, x2, y2, xm, ym + sh, x4, y4, .5, sh, a, ax, ay, axx, ayy, axy);
-      add_contrib_t<MORE>(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A, rec, npoly);
+      add_contrib_t<MORE>(gr, nadv, jc, pbf, a, ax, ay, axx, ayy, axy, A, rec, 2);
       // mod_remap.F90:1455-1457: assignment (not accumulation) for the v-components
       if (base && own) {
         *o_f = A.fd;
@@ -460,14 +462,73 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     }
   }
   if (!MORE) return;
-  // ---- the other advected tracers, MAXTR at a time ----------------------------------------------------------------------
+  // ---- the other advected tracers, a batch at a time --------------------------------------------------------------------------
   const double *f_tr = V.f[F_trc] + okn;
   const int off2 = uface ? 0 : 1;
+  if constexpr (!FOLD) {
+    // A batch of RT_NB tracers in LDS: its scalars S (RT_NB x RT_SN), behind them its limited gradients G (3 RT_NB x RT_GN).
+    // Two barriers per batch, and the work between them comes from two batches:
+    //   phase 1  G <- the gradients of this batch (in registers since the previous phase 2), S <- the scalars of the next one
+    //            (in registers since the phase 2 before that)
+    //   phase 2  the loads of the scalars of the batch after the next are issued; the fluxes of this batch from G and the
+    //            polygons' records; the gradients of the next batch from S into registers
+    // so a phase 2 holds global loads, LDS reads of two kinds and two independent strands of arithmetic.
+    double *const bs = lds, *const bg = lds + RT_NB * RT_SN;
+    double tv[RT_NB], gb[3 * RT_NB];
+#pragma unroll
+    for (int a = 0; a < 3 * RT_NB; a++) gb[a] = 0.;
+    auto fetch = [&](int b0) {
+#pragma unroll
+      for (int a = 0; a < RT_NB; a++)
+        tv[a] = (b0 + a < nadv_all && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[b0 + a < 64 ? b0 + a : 0] * 2 * V.kk * np] : 0.;
+    };
+    fetch(nadv);
+    __syncthreads();                                           // the gradient slots of the first pass have been read
+    for (int b0 = nadv - RT_NB; b0 < nadv_all; b0 += RT_NB) {  // (the first round only fills S and evaluates the first gradients)
+      const bool cur = b0 >= nadv, next = b0 + RT_NB < nadv_all;
+      const int nb_ = nadv_all - b0 < RT_NB ? nadv_all - b0 : RT_NB;
+      if (cur && gthread) {
+#pragma unroll
+        for (int a = 0; a < 3 * RT_NB; a++) bg[a * RT_GN + q] = gb[a];
+      }
+      if (next && t < RT_SN) {
+#pragma unroll
+        for (int a = 0; a < RT_NB; a++) bs[a * RT_SN + t] = tv[a];
+      }
+      __syncthreads();
+      if (next) fetch(b0 + 2 * RT_NB);
+      if (cur && do_face) {
+#pragma unroll
+        for (int a = 0; a < RT_NB; a++)
+          if (a < nb_) {
+            double f = 0.;
+#pragma unroll
+            for (int pz = 0; pz < 3; pz++)
+              f = f + rec[pz].fd * bg[(3 * a + 2) * RT_GN + rec[pz].x] + rec[pz].qx * bg[(3 * a) * RT_GN + rec[pz].x] +
+                  rec[pz].qy * bg[(3 * a + 1) * RT_GN + rec[pz].x];
+            WK(V, W_FTRU(ntr, L.idx[b0 + a]) + off2)[fc + ok] = f;
+          }
+      }
+      if (next && gthread) {
+        const int nn_ = nadv_all - (b0 + RT_NB) < RT_NB ? nadv_all - (b0 + RT_NB) : RT_NB;
+#pragma unroll
+        for (int a = 0; a < RT_NB; a++)
+          if (a < nn_) {
+            double gxx = 0., gyy = 0., gdd = 0.;
+            if (gpoint) limited_gradient_t(bs + a * RT_SN, nb, sidx, k_dxi, k_dyi, k_xd, k_yd, gxx, gyy, gdd);
+            gb[3 * a] = gxx; gb[3 * a + 1] = gyy; gb[3 * a + 2] = gdd;
+          }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // (with the update folded in: the batches one after the other, three barriers each)
   // the scalars of a batch are loaded while the batch before it is worked on: tv is free again once it has gone to LDS
   double tv[MAXTR];
 #pragma unroll
-  for (int a = 0; a < MAXTR; a++) tv[a] = (MAXTR + a < nadv_all && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[MAXTR + a] * 2 * V.kk * np] : 0.;
-  for (int b0 = MAXTR; b0 < nadv_all; b0 += MAXTR) {
+  for (int a = 0; a < MAXTR; a++) tv[a] = (nadv + a < nadv_all && t < RT_SN) ? f_tr[cs_keep + (size_t)L.idx[nadv + a] * 2 * V.kk * np] : 0.;
+  for (int b0 = nadv; b0 < nadv_all; b0 += MAXTR) {
     const int nb_ = nadv_all - b0 < MAXTR ? nadv_all - b0 : MAXTR;
     __syncthreads();                                         // the gradient slots of the previous batch have been read
     if (t < RT_SN) {
@@ -494,38 +555,34 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
         }
     }
     __syncthreads();
+#pragma unroll
+    for (int a = 0; a < MAXTR; a++)
+      if (a < nb_) fl[a * RT_NT + t] = 0.;
+    // (the batch's scalars, which lay where the fluxes now are, were last read before the barrier above; a face that
+    // is not evaluated contributes nothing)
     if (do_face) {
 #pragma unroll
       for (int a = 0; a < MAXTR; a++)
         if (a < nb_) {
           double f = 0.;
-          for (int pz = 0; pz < npoly; pz++)
+#pragma unroll
+          for (int pz = 0; pz < 3; pz++)
             f = f + rec[pz].fd * gr[G_TRD(a) * RT_GN + rec[pz].x] + rec[pz].qx * gr[G_TRX(a) * RT_GN + rec[pz].x] +
                 rec[pz].qy * gr[G_TRY(a) * RT_GN + rec[pz].x];
-          if (FOLD) fl[a * RT_NT + t] = f;
-          else WK(V, W_FTRU(ntr, L.idx[b0 + a]) + off2)[fc + ok] = f;
+          fl[a * RT_NT + t] = f;
         }
     }
-    if (FOLD) {
-      // (the batch's scalars, which lay where the fluxes now are, were last read before the barrier above; a face that
-      // is not evaluated contributes nothing)
-      if (!do_face) {
+    __syncthreads();
+    if (upd) {
+      const int te = t + 1, ts = RT_TW * RT_TH + t, tn = ts + RT_TW;
+      const double s2i = m2i[1][1];
 #pragma unroll
-        for (int a = 0; a < MAXTR; a++)
-          if (a < nb_) fl[a * RT_NT + t] = 0.;
-      }
-      __syncthreads();
-      if (upd) {
-        const int te = t + 1, ts = RT_TW * RT_TH + t, tn = ts + RT_TW;
-        const double s2i = m2i[1][1];
-#pragma unroll
-        for (int a = 0; a < MAXTR; a++)
-          if (a < nb_) {
-            const double *f = fl + a * RT_NT;
-            const double xold = V.f[F_trc][fc + okn + (size_t)L.idx[b0 + a] * 2 * V.kk * np];
-            WK(V, R_TR(ntr, L.idx[b0 + a]))[fc + ok] = (q_dp * xold - (f[te] - f[t] + f[tn] - f[ts]) * s2i) / dpn;
-          }
-      }
+      for (int a = 0; a < MAXTR; a++)
+        if (a < nb_) {
+          const double *f = fl + a * RT_NT;
+          const double xold = V.f[F_trc][fc + okn + (size_t)L.idx[b0 + a] * 2 * V.kk * np];
+          WK(V, R_TR(ntr, L.idx[b0 + a]))[fc + ok] = (q_dp * xold - (f[te] - f[t] + f[tn] - f[ts]) * s2i) / dpn;
+        }
     }
   }
 }
@@ -586,21 +643,26 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
       L.idx[nadv++] = (unsigned char)nt;
     }
   for (int a = nadv; a < 64; a++) L.idx[a] = 0;
-  const int nfirst = nadv < MAXTR ? nadv : MAXTR;
-  const size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
+  // without the fold, how many of more than MAXTR tracers ride with the first pass is an option (remap_nfirst): with none the first
+  // pass needs 34 KB of LDS and a batch 46 KB instead of 67 KB, but at 128 VGPRs two workgroups per CU is the limit anyway and
+  // the first pass's tracers are cheaper than a batch's: 3.57 ms with four against 3.74 ms with none (24 tracers, tnx1v4s)
+  int nfirst = nadv < MAXTR ? nadv : MAXTR;
+  if (nadv > MAXTR && !fold) nfirst = c->remap_nfirst < MAXTR ? (c->remap_nfirst > 0 ? c->remap_nfirst : 0) : MAXTR;
+  size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
+  if (nadv > MAXTR && !fold && lds < sizeof(double) * RT_NB * (RT_SN + 3 * RT_GN)) lds = sizeof(double) * RT_NB * (RT_SN + 3 * RT_GN);
   const dim3 grid(ntx * nty, h.kk);
   if (fold) {
     {
       TimeScope tk(c, "k_remap_tile");
-      if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
-      else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+      if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
+      else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
     }
     if ((tsel & 3) != 1)                                // (a split launch: after the second part)
       hipLaunchKernelGGL(k_remap_ring, dim3((6 * (h.ii + 6) + 6 * h.jj + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, nn, nadv, L);
   } else {
     TimeScope tk(c, "k_remap_tile");
-    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
-    else hipLaunchKernelGGL((k_remap_tile<false, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, L, tsel);
+    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
+    else hipLaunchKernelGGL((k_remap_tile<false, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
   }
   return 0;
 }

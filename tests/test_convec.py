@@ -16,12 +16,12 @@ SCRATCH = {"uflux", "vflux", "uflux2", "vflux2", "uflux3", "vflux3", "utotm", "v
            "util4"}
 
 
-def _drive(cfg, nsteps, make_other):
+def _drive(cfg, nsteps, make_other, ntr=None):
     from oracle.refblom import get_ref_backend, have_ref
     if not have_ref(cfg):
         pytest.skip(f"oracle/_ref/{cfg}/libblomref.so not built")
-    case = make_case(cfg)
-    ref = get_ref_backend(cfg, case.depth)
+    case = make_case(cfg, ntr=ntr)
+    ref = get_ref_backend(cfg, case.depth, ntr=ntr)
     hostinit.init_state(ref, case)
     other = make_other(case, ref)
     failures, acted = [], []
@@ -47,7 +47,7 @@ def _drive(cfg, nsteps, make_other):
         other.set("nstep", nstep[0] + 1)
         other.stage(st, *six)
         pending["st"] = st
-        pending["before"] = {nm: np.array(ref.get(nm)) for nm in ("dp", "temp", "saln", "kfpla", "u")}
+        pending["before"] = {nm: np.array(ref.get(nm)) for nm in ("dp", "temp", "saln", "kfpla", "u") + (("trc",) if ntr else ())}
 
     for _ in range(nsteps):
         # the edited state is not meant to be integrated further: only convec itself is compared,
@@ -62,6 +62,7 @@ def _drive(cfg, nsteps, make_other):
     # the stage did real work: layers were merged, the mixed-layer base moved, velocities were remapped
     for ch in acted:
         assert ch["dp"] > 0 and ch["temp"] > 0 and ch["kfpla"] > 0 and ch["u"] > 0, ch
+        assert not ntr or ch["trc"] > 0, ch
 
 
 @pytest.mark.parametrize("cfg", ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke"])
@@ -80,8 +81,11 @@ def test_c_restatement_matches_reference_on_unstable_columns(cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["chan_s", "box_s", "fuk95", "tri_s", "chan_s_tke"])
-def test_device_matches_reference_on_unstable_columns(cfg):
+@pytest.mark.parametrize("cfg,ntr", [("chan_s", None), ("box_s", None), ("fuk95", None), ("tri_s", None), ("chan_s_tke", None),
+                                     ("chan_s_tke", 10), ("box_s_tke", 7), ("tri_s_tke", 13)])
+def test_device_matches_reference_on_unstable_columns(cfg, ntr):
+    """(ntr: the reference carries that many tracers itself, ref_set_ntr -- the tracers' share of a mixing event is evaluated four
+    tracers at a time once the event's extent is known, stage_convec.hip)"""
     from blom_amd.gpu import BlomGpu
 
     def make(case, ref):
@@ -90,4 +94,4 @@ def test_device_matches_reference_on_unstable_columns(cfg):
             if not nm.endswith("0"):
                 gpu.set(nm, v)
         return gpu
-    _drive(cfg, 3, make)
+    _drive(cfg, 3, make, ntr=ntr)

@@ -82,6 +82,20 @@ def test_remap_with_the_update_folded_in(cfg, nsteps, ntr):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("cfg,nsteps,ntr", [("chan_s_tke", 4, 11), ("tri_s_tke", 4, 16), ("box_s_tke", 3, 24)])
+def test_remap_tracer_batches_whatever_rides_with_the_first_pass(cfg, nsteps, ntr):
+    """more than four advected tracers: k_remap_tile evaluates the geometry once and streams the tracers through it in batches of
+    four (two barriers a batch, stage_remap_tile.hip); option remap_nfirst = how many tracers ride with dp, T, S in the first
+    pass instead.  Same bits for 0, 2 and 4 (the default), in every array."""
+    skip = {"util1", "util2", "util3", "util4"}
+    a = _run(cfg, nsteps, _ntr=ntr, remap_nfirst=0)
+    for nf in (2, 4):
+        b = _run(cfg, nsteps, _ntr=ntr, remap_nfirst=nf)
+        bad = [nm for nm in a if nm not in skip and not np.array_equal(a[nm], b[nm], equal_nan=True)]
+        assert not bad, (nf, bad)
+    assert np.ptp(a["trc"][~np.isnan(a["trc"])]) > 0.0
+
+
 @pytest.mark.parametrize("cfg", ["tri_m", "tri_m_tke"])
 def test_persistent_barotp_with_the_arctic_patch(cfg):
     """the odd+even pairs of a barotropic phase in the persistent launch on a tripolar grid (tiles re-read rim AND seam row from

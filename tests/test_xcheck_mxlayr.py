@@ -66,21 +66,29 @@ def test_device_mxlayr_equals_the_real_module(cfg, nsteps, variant):
     _mxlayr_check(cfg, nsteps, variant)
 
 
+@pytest.mark.parametrize("cfg,nsteps,variant,ntr", [("chan_s_tke", 3, "default", 9), ("tri_s_tke", 3, "momentum_entrainment+niw", 6),
+                                                    ("chan_s_tke", 3, list(VARIANTS)[1], 13)])
+def test_device_mxlayr_with_many_tracers(cfg, nsteps, variant, ntr):
+    """more tracers than the column kernel loads at a time (four): the reference carries that many itself (ref_set_ntr); the extra
+    ones are passive tracers with their own surface fluxes, a few values negative so that the copy-back's clamp books into trc_corr"""
+    _mxlayr_check(cfg, nsteps, variant, ntr=ntr)
+
+
 def test_full_size_channel_mxlayr_equals_the_real_module():
     """the same at BASELINE.json's channel size (208x512x53, ntr = 3; oracle/_ref/channel_tke_omp_xml, OpenMP)"""
     from test_xcheck_ale import run_with_big_stack
     run_with_big_stack(_mxlayr_check, "channel_tke", 2, "default")
 
 
-def _mxlayr_check(cfg, nsteps, variant):
+def _mxlayr_check(cfg, nsteps, variant, ntr=None):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     lib = "channel_tke_omp_xml" if cfg == "channel_tke" else cfg.replace("_tke", "") + "_xml"
     if not have_ref(lib):
         pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
     opts, strength = VARIANTS[variant]
-    case = make_case(cfg)
-    ref = get_ref_backend(lib, case.depth)
+    case = make_case(cfg, ntr=ntr)
+    ref = get_ref_backend(lib, case.depth, ntr=ntr)
     assert ref.ntr == case.ntr
     kk = case.kdm
     gpu = BlomGpu(case.idm, case.jdm, kk, ref.ntr, ref.nreg, ref.masks)
