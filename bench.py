@@ -890,7 +890,9 @@ def main():
         ms, n = gpu.timer_get(kn)
         if n:
             kern[kn] = (ms / n, n / max(1, min(args.steps, 5)))          # average launch duration [ms], launches per step
+    exch = gpu.timer_get("exchange")
     gpu.set("timing", 0)
+    exch_all = [round(x, 4) for x in launch.all_gather_objects(exch[0] / max(1, min(args.steps, 5)), env)] if layout is not None else None
     import numpy as np
     finite = bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all())
     crc_state = gpu.crc("dp", 1, 2 * case.kdm, 1) ^ gpu.crc("u", 1, 2 * case.kdm, 3) if layout is None else None
@@ -1002,7 +1004,11 @@ def main():
         bt = live.get("barotp")
         out["strong_scaling_terms"] = {"barotp": args.barotp, "barotp_replicated_ms": bt if args.barotp == "replicated" else None,
                                        "barotp_ms": bt, "rank_share_ms": (ms_per_step - bt) if bt is not None else None,
-                                       "note": "HIP-event time of the barotp class on this rank (rank 0), step time minus it"}
+                                       "exchange_ms_per_rank": exch_all,
+                                       "note": "HIP-event time of the barotp class on this rank (rank 0), step time minus it; exchange_ms_per_rank: "
+                                               "per step and rank, HIP events around every pack + send/recv + unpack on the stream it goes to (halo "
+                                               "updates, the arctic strips, the gather of the replicated barotropic solve), from the K steps "
+                                               "timed by class after the main measurement -- a rank that waits for a slower peer shows it here"}
     if rank == 0:
         # stdout carries the ONE JSON line and nothing else: the reference library prints through the Fortran
         # runtime (bigrid messages, buffered unit 6 flushed at exit), so from here on file descriptor 1 points

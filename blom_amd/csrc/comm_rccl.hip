@@ -134,6 +134,7 @@ int rccl_xctilr_multi_ex(blomgpu_ctx *c, double *const *fields, int nf, int nlev
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
   hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
+  TimeScope tx(c, "exchange", st);         // pack, send/recv, unpack of this rank, on the stream they go to (bench.py: exchange_ms_per_rank)
   if (nf < 1 || nf > MAXF) return ctx_fail(c, "rccl_xctilr_multi: 1..4 fields per exchange");
   FieldSet F;
   for (int x = 0; x < MAXF; x++) F.p[x] = fields[x < nf ? x : 0];
@@ -232,6 +233,7 @@ int rccl_arctic_gather(blomgpu_ctx *c, double *const *fields, int nf, int nlev, 
   RcclComm *R = c->tiling.rccl;
   const Tiling &T = c->tiling;
   hipStream_t st = c->halo_stream ? c->halo_stream : c->stream;
+  TimeScope tx(c, "exchange", st);
   if (nf > 4) return ctx_fail(c, "rccl_arctic_gather: at most 4 stacks per exchange");
   const size_t per_field = (size_t)nrows * h.ii * nlev, need = per_field * nf;
   *field_stride = per_field;
@@ -349,6 +351,7 @@ int rccl_barotp_replicated(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m
   for (int x = np_; x < BT_MAXPLANES; x++) { PT.p[x] = PT.p[0]; PG.p[x] = PG.p[0]; }
   const int me = R->rank, nr = R->nranks;
   const int npts = h.nplane;
+  TimeScope *tx = new TimeScope(c, "exchange", st);        // the gather of the replicated solve's planes: pack, send/recv, unpack
   hipLaunchKernelGGL(k_btg_pack, dim3((npts + 255) / 256, np_), dim3(256), 0, st, c->d, PT, B->buf + B->off[me]);
   if (nr > 1) {
     ncclGroupStart();
@@ -357,10 +360,11 @@ int rccl_barotp_replicated(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m
     for (int q = 0; q < nr; q++)
       if (q != me) ncclRecv(B->buf + B->off[q], (size_t)(B->ii[q] + 2 * NBDY) * (B->jj[q] + 2 * NBDY) * np_, ncclDouble, q, R->comm, st);
     ncclResult_t rc = ncclGroupEnd();
-    if (rc != ncclSuccess) return ctx_fail(c, std::string("RCCL barotropic gather: ") + ncclGetErrorString(rc));
+    if (rc != ncclSuccess) { delete tx; return ctx_fail(c, std::string("RCCL barotropic gather: ") + ncclGetErrorString(rc)); }
   }
   hipLaunchKernelGGL(k_btg_unpack, dim3((B->maxpts + 255) / 256, np_, nr), dim3(256), 0, st, G->d, PG, B->buf, B->geo_dev,
                      (const size_t *)(B->geo_dev + 4 * nr + (4 * nr) % 2));
+  delete tx;
   if (int rc = st_barotp_on(G, m, n, mm, nn, k1m, k1n, false)) { c->err = G->err; return rc; }
   hipLaunchKernelGGL(k_btg_window, dim3((h.nplane + 255) / 256, np_), dim3(256), 0, st, c->d, PT, PG, G->h.ni);
   HIPCHK(c, hipGetLastError());

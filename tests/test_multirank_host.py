@@ -235,5 +235,7 @@ def test_bench_two_ranks_end_to_end_on_the_host_emulation(tmp_path):
     assert two["config"]["tiles_bit_identical"] is True and two["config"]["state_finite"] is True
     assert two["config"]["physics"] == "full"                                   # config 2's step on tiles (thermf's sums on the global context)
     assert "strong_scaling_terms" in two and two["strong_scaling_terms"]["barotp"] == "replicated"
+    ex = two["strong_scaling_terms"]["exchange_ms_per_rank"]             # per rank: HIP events around every pack + send/recv + unpack
+    assert len(ex) == 2 and all(x > 0.0 for x in ex), ex
     # the decomposition-independent checksum: the two tiles end in the single tile's state (bench.py: state_crc)
     assert two["config"]["state_crc"] == one["config"]["state_crc"], (one["config"]["state_crc"], two["config"]["state_crc"])
