@@ -234,58 +234,43 @@ __global__ __launch_bounds__(64) void k_dfi_uv2(const DevView *__restrict__ Vp, 
 }
 
 // ---- :513-560 ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dfi_common(const DevView *__restrict__ Vp, int nn) {
+// One thread per point AND level: the routine's one recurrence in k is the harmonic mean of a level's density jump q(k) with that
+// of the level above, and q(k) is a function of the levels k and k+1 alone -- a thread evaluates both jumps it needs (the upper one
+// a second time, bit for bit what the thread above evaluates) instead of waiting for it.  (As a column kernel: 97 us for 192 MB,
+// a third of what its bytes allow.)
+__global__ void k_dfi_common(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
   if (km - kf < 1) return;
-  const size_t np = V.nplane;
   const int kk = V.kk, ni = V.ni;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
-  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
-  const double *du2 = WK(V, W_DU2) + c, *dv2 = WK(V, W_DV2) + c;
-  const int *msku = V.m[I_msku] + c, *mskv = V.m[I_mskv] + c;
-  double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *rig = V.f[F_rig] + c;
-  double tup = 0.;
+  const int k = by_ + 1;
   const int k1 = kf > 4 ? kf : 4, k2 = km < kk ? km : kk;
-  if (k1 > k2) return;
-  double tk = temp[(size_t)(k1 - 1) * np], sk = saln[(size_t)(k1 - 1) * np];
-  for (int k0 = k1; k0 <= k2; k0 += BU) {
-    double a0[BU], a1[BU], a2[BU], a3[BU], d0[BU], d1[BU], e0[BU], e1[BU];
-    int m0[BU], m1[BU], n0[BU], n1[BU];
-#pragma unroll
-    for (int uu = 0; uu < BU; uu++) {
-      const int kq = k0 + uu <= k2 ? k0 + uu : k2;
-      const size_t o = (size_t)(kq - 1) * np, o1 = (size_t)(kq < kk ? kq : kk - 1) * np;
-      a0[uu] = p[(size_t)kq * np]; a1[uu] = temp[o1]; a2[uu] = saln[o1]; a3[uu] = dp[o];
-      d0[uu] = du2[o]; d1[uu] = du2[o + 1]; e0[uu] = dv2[o]; e1[uu] = dv2[o + ni];
-      m0[uu] = msku[o]; m1[uu] = msku[o + 1]; n0[uu] = mskv[o]; n1[uu] = mskv[o + ni];
-    }
-#pragma unroll
-    for (int uu = 0; uu < BU; uu++) {
-      const int k = k0 + uu;
-      if (k > k2) break;
-      const size_t o = (size_t)(k - 1) * np;
-      double dr;
-      if (k < km) {
-        const double pk1 = a0[uu];
-        const double q = fmax2(0., eos::rho(pk1, a1[uu], a2[uu]) - eos::rho(pk1, tk, sk));
-        if (k == kf) dr = q;
-        else dr = 2. * tup * q / fmax2(1.e-11, tup + q);
-        tup = q;
-      } else
-        dr = tup;
-      drhol[o] = dr;
-      const int mu0 = m0[uu], mu1 = m1[uu], mv0 = n0[uu], mv1 = n1[uu];
-      const double d2 = ((double)mu0 * d0[uu] + (double)mu1 * d1[uu]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) +
-                        ((double)mv0 * e0[uu] + (double)mv1 * e1[uu]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1);
-      du2l[o] = d2;
-      rig[o] = ALPHA0 * ALPHA0 * fmax2(DRHOMN, dr) * a3[uu] / fmax2(1.e-13, d2);
-      tk = a1[uu];
-      sk = a2[uu];
-    }
-  }
+  if (k < k1 || k > k2) return;
+  const size_t np = V.nplane, o = (size_t)(k - 1) * np + c;
+  const double *p = V.f[F_p], *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
+  // the density jump across the interface under level kq (< km), :520-531: both densities at the interface's pressure
+  auto jump = [&](int kq) {
+    const size_t oq = (size_t)(kq - 1) * np + c, o1 = (size_t)(kq < kk ? kq : kk - 1) * np + c;
+    const double pk1 = p[oq + np];
+    return fmax2(0., eos::rho(pk1, temp[o1], saln[o1]) - eos::rho(pk1, temp[oq], saln[oq]));
+  };
+  const double tup = k - 1 >= k1 ? jump(k - 1) : 0.;          // (the sweep starts at level max(kfil, 4) with zero)
+  double dr;
+  if (k < km) {
+    const double q = jump(k);
+    if (k == kf) dr = q;
+    else dr = 2. * tup * q / fmax2(1.e-11, tup + q);
+  } else
+    dr = tup;
+  V.f[F_drhol][o] = dr;
+  const int mu0 = V.m[I_msku][o], mu1 = V.m[I_msku][o + 1], mv0 = V.m[I_mskv][o], mv1 = V.m[I_mskv][o + ni];
+  const double *du2 = WK(V, W_DU2), *dv2 = WK(V, W_DV2);
+  const double d2 = ((double)mu0 * du2[o] + (double)mu1 * du2[o + 1]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) +
+                    ((double)mv0 * dv2[o] + (double)mv1 * dv2[o + ni]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1);
+  V.f[F_du2l][o] = d2;
+  V.f[F_rig][o] = ALPHA0 * ALPHA0 * fmax2(DRHOMN, dr) * V.f[F_dp][o + (size_t)nn * np] / fmax2(1.e-13, d2);
 }
 
 // ---- difest_vertical_iso, :2629-3084 ----------------------------------------------------------------------------------------
@@ -541,15 +526,27 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
   if (dps > 0.) { dfddsu = dfddsu / dps; dfddsl = dfddsl / dps; }
   else { dfddsu = NU0; dfddsl = NU0; }
   const double p3 = PL(3);
-  for (int k = 2; k <= kk - 1; k++)                                                // :2991-3007
-    if (k < kf) {
-      if (k > 2 && kf <= kk && PL(kf < kk ? kf : kk) - p3 > EPSILP) {
-        const double q = .5 * (PL(k + 1) + PL(k));
-        difdia[(size_t)(k - 1) * np] = ((q - p3) * dfddsl + (pkf - q) * dfddsu) / (pkf - p3);
-      } else
-        difdia[(size_t)(k - 1) * np] = dfddsu;
-    }
-  if (any) {                                                                       // near-inertial waves, :3011-3032
+  {                                                                                // :2991-3007
+    const int ke = kf - 1 < kk - 1 ? kf - 1 : kk - 1;         // the levels above the range
+    const bool lin = kf <= kk && PL(kf < kk ? kf : kk) - p3 > EPSILP;
+    if (ke >= 2) difdia[np] = dfddsu;
+    if (!lin)
+      for (int k = 3; k <= ke; k++) difdia[(size_t)(k - 1) * np] = dfddsu;
+    else
+      for (int k0 = 3; k0 <= ke; k0 += BU) {
+        double a[BU + 1];
+#pragma unroll
+        for (int uu = 0; uu <= BU; uu++) a[uu] = PL(k0 + uu <= ke + 1 ? k0 + uu : ke + 1);
+#pragma unroll
+        for (int uu = 0; uu < BU; uu++) {
+          if (k0 + uu > ke) break;
+          const double q = .5 * (a[uu + 1] + a[uu]);
+          difdia[(size_t)(k0 + uu - 1) * np] = ((q - p3) * dfddsl + (pkf - q) * dfddsu) / (pkf - p3);
+        }
+      }
+  }
+  // (niwgf = 0: the term is zero times a finite number, and a diffusivity plus zero is the diffusivity -- nothing to do)
+  if (any && D.niwgf != 0.) {                                                      // near-inertial waves, :3011-3032
     const double idk = V.f[F_idkedt][c];
     const double q = NIWLS;
     const double den = 1. - exp_libm((p3 - pbot) / q);
@@ -613,7 +610,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   const bool any = km - kf >= 1;
   const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
   double *difint = V.f[F_difint] + c, *difiso = V.f[F_difiso] + c;
-  double *egr = WK(V, W_EGR) + c, *anisok = WK(V, W_ANISOK) + c;
+  double *anisok = WK(V, W_ANISOK) + c;
   const double *rig = V.f[F_rig] + c;
   const double *u = V.f[F_u] + c + (size_t)nn * np, *v = V.f[F_v] + c + (size_t)nn * np;
   const double *dpu = V.f[F_dpu] + c + (size_t)nn * np, *dpv = V.f[F_dpv] + c + (size_t)nn * np;
@@ -666,149 +663,144 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
       difwgt = q <= 2. ? 1. : 0.;
     V.f[F_difwgt][c] = difwgt;
   }
-  // Eady growth rate, :2160-2257
+  // Eady growth rate, :2160-2257, and the layer interface diffusivities, :2283-2375 (rhsctp is refused by the option setter), in ONE sweep
+  // over the levels of the range: the reference's second loop reads nothing of the first but egr(k) of the same level (its vertical mean
+  // egrs enters only after both), so a level's diffusivity follows its growth rate while the loads of the next levels are in flight, and
+  // egr never goes to memory.  Each of the two sets of sums keeps its own order.  Outside the range a level takes the value of the one
+  // above it: egmndf above the range, the last level's below it.
   const bool sa = D.edsprs || D.edanis;
-  double egrs = 0., dps = 0.;
+  double egrs = 0., dps_e = 0.;
   const int ka = kf > 2 ? kf : 2, kb = km < kk ? km : kk;            // the levels inside the range (when there are any)
   const double pkf_g = any ? PL(kf) + DPGRAV : 0.;
-  if (D.edritp == 1) {
-    if (any) {
+  const double pkf_d = any ? PL(kf) + DPDIAV : 0.;
+  const bool keep_anisok = D.edanis && !(D.eddf2d && !D.redi3d);     // read again by the last loop of the routine
+  double dfints = 0., anisos = 0., dps = 0., last = D.egmndf;
+  difint[0] = D.egmndf;
+  // a level's diffusivity from its growth rate e; d = p(k+1), pk = p(k)
+  auto diff_level = [&](int k, double e, double d, double pk, double u0, double u1, double du0, double du1, double v0, double v1, double dv0,
+                        double dv1) {
+    const size_t o = (size_t)(k - 1) * np;
+    const double rhisc = e / fmax2(1.e-22, betafp);
+    double speed = 0.;
+    if (D.edanis) {
+      const double ubc = (u0 * du0 + u1 * du1) / fmax2(EPSILP, du0 + du1);
+      const double vbc = (v0 * dv0 + v1 * dv1) / fmax2(EPSILP, dv0 + dv1);
+      speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
+    }
+    const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
+    const double di = D.egc * e * els * els;
+    difint[o] = di;
+    last = di;
+    double q;
+    if (D.eddf2d) q = fmax2(0., d - pk);
+    else q = fmax2(0., fmin2(pkf_d, d) - pk);
+    dps = dps + q;
+    dfints = dfints + di * q;
+    if (D.edanis) {
+      const double r = speed / fmax2(1.e-22, e * els);
+      const double a = 1. / (1. + r * r);
+      if (keep_anisok) anisok[o] = a;
+      anisos = anisos + a * q;
+    }
+  };
+#define BL 4      /* levels in flight in the fused sweep: 13 loads a level */
+  if (any) {
+    for (int k = 2; k < ka; k++) difint[(size_t)(k - 1) * np] = D.egmndf;
+    if (D.edritp == 1) {
       double pk = PL(ka);
-      for (int k0 = ka; k0 <= kb; k0 += BU) {
-        double a[BU], d[BU];
+      for (int k0 = ka; k0 <= kb; k0 += BL) {
+        double a[BL], d[BL], u0[BL], u1[BL], du0[BL], du1[BL], v0[BL], v1[BL], dv0[BL], dv1[BL];
 #pragma unroll
-        for (int uu = 0; uu < BU; uu++) {
+        for (int uu = 0; uu < BL; uu++) {
           const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
           a[uu] = rig[o]; d[uu] = p[o + np];
+          if (D.edanis) {
+            u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
+            v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
+          }
         }
 #pragma unroll
-        for (int uu = 0; uu < BU; uu++) {
+        for (int uu = 0; uu < BL; uu++) {
           const int k = k0 + uu;
           if (k > kb) break;
           const double e = afeql / sqrt(a[uu] + D.eggam);
-          egr[(size_t)(k - 1) * np] = e;
           if (sa) {
             double q;
             if (D.eddf2d) q = fmax2(0., d[uu] - pk);
             else q = fmax2(0., fmin2(pkf_g, d[uu]) - pk);
-            dps = dps + q;
+            dps_e = dps_e + q;
             egrs = egrs + e * q;
           }
+          diff_level(k, e, d[uu], pk, u0[uu], u1[uu], du0[uu], du1[uu], v0[uu], v1[uu], dv0[uu], dv1[uu]);
           pk = d[uu];
         }
       }
-    }
-  } else if (any) {
-    const double *nx = V.f[F_nnslpx] + c, *ny = V.f[F_nnslpy] + c;
-    const int kmw = kmaxa[c - 1], kme = kmaxa[c + 1], kms = kmaxa[c - ni], kmn = kmaxa[c + ni];
-    // the squared large scale slope x buoyancy frequency at interface kq from the four values around the point, :2190-2205 / :2212-2227
-    auto slope2 = [&](int kq, double x0, double x1, double y0, double y1) {
-      const bool w = kmw >= kq, e = kme >= kq, s_ = kms >= kq, n_ = kmn >= kq;
-      double q;
-      if (w && e) { const double t = x0 + x1; q = .25 * (t * t); }
-      else if (w) q = x0 * x0;
-      else if (e) q = x1 * x1;
-      else q = 0.;
-      if (s_ && n_) { const double t = y0 + y1; q = q + .25 * (t * t); }
-      else if (s_) q = q + y0 * y0;
-      else if (n_) q = q + y1 * y1;
-      return q;
-    };
-    double egrup, egr_prev = 0.;
-    {
-      const size_t o = (size_t)(kf - 1) * np;
-      egrup = sqrt(slope2(kf, nx[o], nx[o + 1], ny[o], ny[o + ni]));
-    }
-    double pk = PL(ka);
-    for (int k0 = ka; k0 <= kb; k0 += BU) {
-      double x0[BU], x1[BU], y0[BU], y1[BU], d[BU];
-#pragma unroll
-      for (int uu = 0; uu < BU; uu++) {
-        const int kq = k0 + uu <= kb ? k0 + uu : kb;
-        const size_t o = (size_t)(kq < kk ? kq : kk - 1) * np;            // the interface below the level (not read for the last level)
-        x0[uu] = nx[o]; x1[uu] = nx[o + 1]; y0[uu] = ny[o]; y1[uu] = ny[o + ni]; d[uu] = p[(size_t)kq * np];
-      }
-#pragma unroll
-      for (int uu = 0; uu < BU; uu++) {
-        const int k = k0 + uu;
-        if (k > kb) break;
-        if (k < km) {
-          const double egrlo = sqrt(slope2(k + 1, x0[uu], x1[uu], y0[uu], y1[uu]));
-          const double e = .5 * (egrup + egrlo);
-          egr[(size_t)(k - 1) * np] = e;
-          egr_prev = e;
-          egrup = egrlo;
-          if (sa) {
-            double q;
-            if (D.eddf2d) q = fmax2(0., d[uu] - pk);
-            else q = fmax2(0., fmin2(pkf_g, d[uu]) - pk);
-            dps = dps + q;
-            egrs = egrs + e * q;
-          }
-        } else
-          egr[(size_t)(k - 1) * np] = egr_prev;
-        pk = d[uu];
-      }
-    }
-  }
-  if (sa) {
-    if (dps > 0.) egrs = egrs / dps;
-    else egrs = 0.;
-  }
-  difint[0] = D.egmndf;
-  double dfints = 0., anisos = 0.;
-  dps = 0.;
-  // layer interface diffusivities, :2283-2375 (rhsctp is refused by the option setter); outside the range a level takes the value of the
-  // one above it: egmndf above the range, the last level's below it
-  if (any) {
-    for (int k = 2; k < ka; k++) difint[(size_t)(k - 1) * np] = D.egmndf;
-    const double pkf_d = PL(kf) + DPDIAV;
-    double pk = PL(ka), last = D.egmndf;
-    for (int k0 = ka; k0 <= kb; k0 += BU) {
-      double ev[BU], d[BU], u0[BU], u1[BU], du0[BU], du1[BU], v0[BU], v1[BU], dv0[BU], dv1[BU];
-#pragma unroll
-      for (int uu = 0; uu < BU; uu++) {
-        const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
-        ev[uu] = egr[o]; d[uu] = p[o + np];
-        if (D.edanis) {
-          u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
-          v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
-        }
-      }
-#pragma unroll
-      for (int uu = 0; uu < BU; uu++) {
-        const int k = k0 + uu;
-        if (k > kb) break;
-        const size_t o = (size_t)(k - 1) * np;
-        const double e = ev[uu];
-        const double rhisc = e / fmax2(1.e-22, betafp);
-        double speed = 0.;
-        if (D.edanis) {
-          const double ubc = (u0[uu] * du0[uu] + u1[uu] * du1[uu]) / fmax2(EPSILP, du0[uu] + du1[uu]);
-          const double vbc = (v0[uu] * dv0[uu] + v1[uu] * dv1[uu]) / fmax2(EPSILP, dv0[uu] + dv1[uu]);
-          speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
-        }
-        const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
-        const double di = D.egc * e * els * els;
-        difint[o] = di;
-        last = di;
+    } else {
+      const double *nx = V.f[F_nnslpx] + c, *ny = V.f[F_nnslpy] + c;
+      const int kmw = kmaxa[c - 1], kme = kmaxa[c + 1], kms = kmaxa[c - ni], kmn = kmaxa[c + ni];
+      // the squared large scale slope x buoyancy frequency at interface kq from the four values around the point, :2190-2205 / :2212-2227
+      auto slope2 = [&](int kq, double x0, double x1, double y0, double y1) {
+        const bool w = kmw >= kq, e = kme >= kq, s_ = kms >= kq, n_ = kmn >= kq;
         double q;
-        if (D.eddf2d) q = fmax2(0., d[uu] - pk);
-        else q = fmax2(0., fmin2(pkf_d, d[uu]) - pk);
-        dps = dps + q;
-        dfints = dfints + di * q;
-        if (D.edanis) {
-          const double r = speed / fmax2(1.e-22, e * els);
-          const double a = 1. / (1. + r * r);
-          anisok[o] = a;
-          anisos = anisos + a * q;
+        if (w && e) { const double t = x0 + x1; q = .25 * (t * t); }
+        else if (w) q = x0 * x0;
+        else if (e) q = x1 * x1;
+        else q = 0.;
+        if (s_ && n_) { const double t = y0 + y1; q = q + .25 * (t * t); }
+        else if (s_) q = q + y0 * y0;
+        else if (n_) q = q + y1 * y1;
+        return q;
+      };
+      double egrup, egr_prev = 0.;
+      {
+        const size_t o = (size_t)(kf - 1) * np;
+        egrup = sqrt(slope2(kf, nx[o], nx[o + 1], ny[o], ny[o + ni]));
+      }
+      double pk = PL(ka);
+      for (int k0 = ka; k0 <= kb; k0 += BL) {
+        double x0[BL], x1[BL], y0[BL], y1[BL], d[BL], u0[BL], u1[BL], du0[BL], du1[BL], v0[BL], v1[BL], dv0[BL], dv1[BL];
+#pragma unroll
+        for (int uu = 0; uu < BL; uu++) {
+          const int kq = k0 + uu <= kb ? k0 + uu : kb;
+          const size_t oi = (size_t)(kq < kk ? kq : kk - 1) * np;            // the interface below the level (not read for the last level)
+          x0[uu] = nx[oi]; x1[uu] = nx[oi + 1]; y0[uu] = ny[oi]; y1[uu] = ny[oi + ni]; d[uu] = p[(size_t)kq * np];
+          if (D.edanis) {
+            const size_t o = (size_t)(kq - 1) * np;
+            u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
+            v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
+          }
         }
-        pk = d[uu];
+#pragma unroll
+        for (int uu = 0; uu < BL; uu++) {
+          const int k = k0 + uu;
+          if (k > kb) break;
+          double e;
+          if (k < km) {
+            const double egrlo = sqrt(slope2(k + 1, x0[uu], x1[uu], y0[uu], y1[uu]));
+            e = .5 * (egrup + egrlo);
+            egr_prev = e;
+            egrup = egrlo;
+            if (sa) {
+              double q;
+              if (D.eddf2d) q = fmax2(0., d[uu] - pk);
+              else q = fmax2(0., fmin2(pkf_g, d[uu]) - pk);
+              dps_e = dps_e + q;
+              egrs = egrs + e * q;
+            }
+          } else
+            e = egr_prev;
+          diff_level(k, e, d[uu], pk, u0[uu], u1[uu], du0[uu], du1[uu], v0[uu], v1[uu], dv0[uu], dv1[uu]);
+          pk = d[uu];
+        }
       }
     }
     for (int k = kb + 1; k <= kk; k++) difint[(size_t)(k - 1) * np] = last;
   } else
     for (int k = 2; k <= kk; k++) difint[(size_t)(k - 1) * np] = D.egmndf;
+  if (sa) {
+    if (dps_e > 0.) egrs = egrs / dps_e;
+    else egrs = 0.;
+  }
   // the surface non-isopycnic layers, :2383-2513
   double urmse = 0., cpse = 0., els_s = 0.;
   if (sa) {
@@ -874,7 +866,10 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
     const double di1 = li, ds1 = ls_;
     const int k_end = any ? ka - 1 : kk;
     for (int k = 2; k <= k_end; k++) { difint[(size_t)(k - 1) * np] = li; difiso[(size_t)(k - 1) * np] = ls_; }
-    if (any) {
+    if (any && D.eddf2d && !D.redi3d) {
+      // (one value for the column: nothing of the levels is read)
+      for (int k = ka; k <= kk; k++) { difint[(size_t)(k - 1) * np] = di1; difiso[(size_t)(k - 1) * np] = ds1; }
+    } else if (any) {
       for (int k0 = ka; k0 <= kb; k0 += BU) {
         double dv[BU], av[BU], u0[BU], u1[BU], v0[BU], v1[BU];
         int mu0[BU], mu1[BU], mv0[BU], mv1[BU];
@@ -979,7 +974,7 @@ int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
     TimeScope ts(c, "difest");
     hipLaunchKernelGGL(k_dfi_kfil_util, plane_grid(h), dim3(256), 0, c->stream, c->d, 1);
     hipLaunchKernelGGL(k_dfi_uv2, g2, b64, 0, c->stream, c->d, nn);
-    hipLaunchKernelGGL(k_dfi_common, g1, b64, 0, c->stream, c->d, nn);
+    hipLaunchKernelGGL(k_dfi_common, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
     hipLaunchKernelGGL(k_dfi_vert_a, g1, b64, 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_vert_b, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_vert_c, g1, b64, 0, c->stream, c->d, D, nn);
