@@ -93,7 +93,7 @@ def kernel_bytes_F(ntr, nadv):
             "k_pgf_uv": 11 + 4, "k_pbc_tile": (3 + ntr + 6) + (6 + 3 + ntr)}
 
 
-KNOWN_CONFIGS = ("channel", "chandyn", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")   # chandyn: the channel with --physics dyncore
+KNOWN_CONFIGS = ("channel", "chandyn", "chanovl0", "tnx2v1s", "tnx1v4s", "chan_t8", "hybrid", "hor3map", "ale")   # chandyn: the channel with --physics dyncore; chanovl0: with --opt overlap=0
 
 
 def _profiles_of(config, suffix):

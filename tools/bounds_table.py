@@ -13,7 +13,7 @@
            waves are all resident from the start (1.7 per SIMD), so the launch lasts as long as its LONGEST wave -- the column
            with the deepest mixed layer / the most iterations -- and the mean says how much of the launch is that tail
 
-usage: bounds_table.py <kernel_stats.txt> <pmc_hbm_traffic.txt> <sq_counters.txt> [copy rate of the box, TB/s] > profiles/r05_bounds.md"""
+usage: bounds_table.py <kernel_stats.txt> <pmc_hbm_traffic.txt> <sq_counters.txt> [copy rate of the box, TB/s] [text to append] > profiles/r05_bounds.md"""
 import re
 import sys
 
@@ -62,6 +62,9 @@ print("A kernel sits at its floor when `measured` is close to the largest of the
 print(f"| kernel | per step | measured us | counted MB | bytes bound us ({RATE:.2f} TB/s) | alg. bytes us (8 TB/s) | instr / wave (VALU+SALU+LDS+VMEM) | waves | issue bound us | wait % | mean wave lifetime us | nearest bound / measured |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 tot = 0.0
+floor = 0.0
+floor_col = 0.0
+meas_col = 0.0
 for name, per, avg, ms in stats[:24]:
     k = key(name)
     t = traffic.get(k)
@@ -82,4 +85,13 @@ for name, per, avg, ms in stats[:24]:
     f = lambda x, d=0: "-" if x is None else f"{x:.{d}f}"
     print(f"| `{name}` | {per:.1f} | {avg:.1f} | {f(t / 1e6 if t else None)} | {f(bb)} | {f(ab)} | {f(ipw)} | {f(w)} | {f(ib)} | {f(wt)} | {f(life, 1)} | {best / avg:.2f} |")
     tot += ms
-print(f"\nThe {min(24, len(stats))} kernels above are {tot:.2f} ms of the step.")
+    floor += per * best * 1e-3
+    if w and w < 4000:
+        meas_col += ms
+        floor_col += per * best * 1e-3
+print(f"\nThe {min(24, len(stats))} kernels above are {tot:.2f} ms of the step; the larger of each kernel's two bounds sums to {floor:.2f} ms.")
+print(f"The kernels with fewer than 4 000 waves -- one thread per column or per strip row, at most 3.4 waves per SIMD -- are {meas_col:.2f} ms of that against bounds of {floor_col:.2f} ms;")
+print(f"the tiled and per-level kernels (>= 90 000 waves) are {tot - meas_col:.2f} ms against {floor - floor_col:.2f} ms.")
+if len(sys.argv) > 5:
+    print()
+    print(open(sys.argv[5]).read())
