@@ -857,7 +857,7 @@ def main():
     for cl in classes:
         ms, n = gpu.timer_get(cl)
         if n:
-            stage_ms[cl] = ms / n
+            stage_ms[cl] = ms / max(1, args.warmup - 1)       # per STEP: a class brackets its launches in one or several scopes a step
     gpu.set("timing", 0)
 
     # ---- timed region --------------------------------------------------------------------------
@@ -884,7 +884,7 @@ def main():
     for cl in classes:
         ms, n = gpu.timer_get(cl)
         if n:
-            live[cl] = ms / n
+            live[cl] = ms / max(1, min(args.steps, 5))
     kern = {}
     for kn in ("k_remap_tile", "k_mom_cor_march", "k_mom_visc_march", "k_diapfl_column3", "k_bt_steps", "k_pgf_uv", "k_pbc_tile"):
         ms, n = gpu.timer_get(kn)

@@ -141,13 +141,14 @@ def _live_step_check(cfg, nsteps, opts, stagewise=False):
 
 
 @pytest.mark.parametrize("cfg,opts", [("chan_s_tke", OPT_FUK95), ("chan_s_tke", OPT_SHEAR), ("box_s", OPT_SHEAR), ("tri_s_tke", OPT_2D),
-                                      ("box_s", OPT_2D)])
+                                      ("box_s", OPT_2D), ("chan_s_tke", hostinit.DIFEST_NORESM), ("tri_s_tke", hostinit.DIFEST_NORESM)])
 def test_difest_isobml_on_its_own_equals_the_real_module(cfg, opts):
     _live_step_check(cfg, 4, opts, stagewise=True)
 
 
 @pytest.mark.parametrize("cfg,nsteps,opts", [("chan_s_tke", 8, OPT_FUK95), ("chan_s_tke", 6, OPT_2D), ("box_s", 6, OPT_FUK95), ("box_s", 6, OPT_SHEAR),
-                                             ("tri_s_tke", 6, OPT_FUK95), ("tri_s_tke", 6, OPT_SHEAR)])
+                                             ("tri_s_tke", 6, OPT_FUK95), ("tri_s_tke", 6, OPT_SHEAR), ("chan_s_tke", 6, hostinit.DIFEST_NORESM),
+                                             ("box_s", 6, hostinit.DIFEST_NORESM)])
 def test_full_step_with_live_diffusivities_equals_the_reference_stage_sequence(cfg, nsteps, opts):
     _live_step_check(cfg, nsteps, opts)
 
