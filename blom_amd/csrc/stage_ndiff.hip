@@ -290,6 +290,9 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
   }
 #undef DRHO_CUR
+#ifndef BLOM_HOSTEMU
+  if (A.prof && threadIdx.x == 0) A.prof[6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 3] = wall_clock64();
+#endif
   // ---- alignment with the surface above the uppermost neutral interface, :394-464 ---------------------------------------------
   if (A.surface_align) {
     int issa_m = 1, issa_p = 1;
@@ -364,6 +367,9 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     }
     for (int k = kp + 1; k <= kdmx_p + 1; k++) SNP(k) = PDP(k);
   }
+#ifndef BLOM_HOSTEMU
+  if (A.prof && threadIdx.x == 0) A.prof[6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 4] = wall_clock64();
+#endif
   // ---- second search, :510-921 ------------------------------------------------------------------------------------------------
   {
     is_m = 2; ks_m = 0; is_p = 2; ks_p = 0;
@@ -703,8 +709,20 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
   const bool isv = blockIdx.y == 1;
   const size_t face = c + (isv ? V.nplane : 0);
   const bool on = isv ? (j >= 1 && j <= V.jj + 1 && i >= 1 && i <= V.ii && V.m[I_iv][c]) : (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1 && V.m[I_iu][c]);
-  if (!on) { A.rec_n[face] = 0; return; }
-  nd_face<NWS, NWP>(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
+#ifndef BLOM_HOSTEMU
+  long long t0 = 0;
+  if (A.prof) t0 = wall_clock64();
+#endif
+  if (!on) A.rec_n[face] = 0;
+  else nd_face<NWS, NWP>(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
+#ifndef BLOM_HOSTEMU
+  if (A.prof) {
+    const long long t1 = wall_clock64();
+    const size_t w = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) { A.prof[6 * w] = t0; A.prof[6 * w + 1] = t1; A.prof[6 * w + 2] = 0; }
+    atomicMax((unsigned long long *)&A.prof[6 * w + 2], (unsigned long long)A.rec_n[face]);
+  }
+#endif
 }
 
 // the fluxes of a face's records, :860-913.  The records do not depend on each other: blockIdx.y strides over them; heat and
