@@ -783,28 +783,35 @@ def main():
         layout = TileLayout.regular(case.idm, case.jdm, npx, npy)
         px, py = layout.rank_tile(rank)
         i0, j0, tii, tjj = layout.tile(px, py)
-        # every rank initialises the whole domain on its own GPU (the initialisation runs stages on the device),
-        # keeps its window of every field and frees the rest: 10 of 288 GB for a moment
-        whole = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
-        hostinit.init_state(whole, case)
+        # Rank 0 initialises the whole domain on its GPU (the initialisation runs stages on the device) and hands every field to the
+        # ranks (launch.FieldsFromRank0: one broadcast per field, GPU to GPU with nccl), each of which keeps its window: the other
+        # ranks never hold more than their tile.  (Until round 5 every rank built the whole domain for a moment.)
+        whole = None
+        if rank == 0:
+            whole = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=local)
+            hostinit.init_state(whole, case)
+            if full_req and args.barotp == "replicated":
+                # config 2's step on tiles (config 3): thermf's global sums are formed on the replicated solve's global context
+                hostinit.init_forcing(whole, case)
+                tile_area = hostinit.ocean_area(whole, case)
+                if not args.frozen_diffusivities:
+                    hostinit.init_difest(whole, case, device=True)         # (the planes travel to the tile with the other fields)
         if full_req and args.barotp == "replicated":
-            # config 2's step on tiles (config 3): thermf's global sums are formed on the replicated solve's global context
-            hostinit.init_forcing(whole, case)
-            tile_area = hostinit.ocean_area(whole, case)
-            if not args.frozen_diffusivities:
-                hostinit.init_difest(whole, case, device=True)         # (the planes travel to the tile with the other fields)
+            tile_area = launch.broadcast_object(tile_area, env)
+        src = launch.FieldsFromRank0(whole, env, device=f"cuda:{local}" if on_gpu else "cpu")
         gpu = BlomGpu(tii, tjj, case.kdm, case.ntr, nreg, {k: layout.window(masks[k], px, py) for k in masks}, device=local,
                       itdm=case.idm, jtdm=case.jdm, i0=i0, j0=j0)
         for nm, v in case.params.items():
             if not nm.endswith("0"):
                 gpu.set(nm, v)
-        scatter_to_tile(whole, gpu, layout, px, py)
+        scatter_to_tile(src, gpu, layout, px, py)
         # every rank solves the whole 2-D barotropic domain on a second context (no exchange inside barotp's substep loop)
         glob = None
         if args.barotp == "replicated":
             from blom_amd.tiles import make_barotp_global
-            glob = make_barotp_global(whole, case, masks, device=local)
-        whole.close()
+            glob = make_barotp_global(src, case, masks, device=local)
+        if whole is not None:
+            whole.close()
         gpu.set("delt1", case.params["baclin"])
         gpu.rccl_init_2d(launch.share_unique_id(rccl_unique_id, env), rank, npx, npy)
         if glob is not None:

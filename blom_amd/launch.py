@@ -50,6 +50,61 @@ def share_unique_id(make_id, env):
     return box[0]
 
 
+class FieldsFromRank0:
+    """The fields of a whole-domain backend that exists on rank 0 only, served to every rank: field_names / field_info as the backend
+    has them, get(name) = rank 0's array broadcast to all (a collective: every rank asks for the same names in the same order -- which
+    blom_amd.tiles.scatter_to_tile and make_barotp_global do).  Tiles are initialised from it without the whole domain ever being
+    built on the other ranks' GPUs.  device: "cuda:<n>" with the nccl backend (tensors travel GPU to GPU), "cpu" with gloo."""
+
+    def __init__(self, whole, env, device="cpu"):
+        import torch.distributed as dist
+        self.whole, self.env, self.device = whole, env, device
+        box = [None]
+        if env.rank == 0:
+            names = whole.field_names()
+            box = [(names, {nm: whole.field_info(nm) for nm in names})]
+        if env.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self._names, self._info = box[0]
+
+    def field_names(self):
+        return list(self._names)
+
+    def field_info(self, name):
+        return self._info[name]
+
+    def has_field(self, name):
+        return name in self._info
+
+    def get(self, name):
+        import numpy as np
+        if self.env.world == 1:
+            return self.whole.get(name)
+        import torch
+        import torch.distributed as dist
+        meta = [None]
+        a = None
+        if self.env.rank == 0:
+            a = np.ascontiguousarray(self.whole.get(name))
+            meta = [(a.shape, a.dtype.str)]
+        dist.broadcast_object_list(meta, src=0)
+        shape, dt = meta[0]
+        t = torch.from_numpy(a) if self.env.rank == 0 else torch.empty(shape, dtype=getattr(torch, {"<f8": "float64", "<i4": "int32"}[dt]))
+        if self.device != "cpu":
+            t = t.to(self.device)
+        dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
+
+def broadcast_object(obj, env):
+    if env.world == 1:
+        return obj
+    import torch.distributed as dist
+    box = [obj if env.rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def max_over_ranks(x, env, device="cpu"):
     if env.world == 1:
         return float(x)
