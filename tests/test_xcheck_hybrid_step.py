@@ -53,6 +53,14 @@ def test_hybrid_step_with_neutral_diffusion_equals_the_reference_stage_sequence(
     _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=True)
 
 
+@pytest.mark.parametrize("cfg,advmth,method,nsteps,neutral", [("chan_s", "remap", "nudge", 5, True), ("tri_s", "remap", "direct", 4, False),
+                                                              ("box_s", "cppm", "direct", 4, True)])
+def test_hybrid_step_with_bod23_equals_the_reference_stage_sequence(cfg, advmth, method, nsteps, neutral, tmp_path):
+    """mlrmth = 'bod23' (phy/mod_eddtra.F90:1058-1081, :1127-1154) inside the whole hybrid step: the running means hbl_tf, wpup_tf, hml_tf
+    carry from step to step, the submesoscale transport enters advect"""
+    _hybrid_step_check(cfg, advmth, method, "cntiso_hybrid", nsteps, tmp_path, neutral=neutral, mlrmth="bod23")
+
+
 @pytest.mark.parametrize("advmth,method", [("remap", "nudge"), ("cppm", "direct")])
 def test_full_size_channel_hybrid_step_equals_the_reference_stage_sequence(advmth, method, tmp_path):
     """Two whole hybrid steps at BASELINE.json's channel size (208x512x53, ntr = 3) with the &ALE_REGRID_REMAP group of the
@@ -66,7 +74,7 @@ def test_full_size_channel_hybrid_step_with_neutral_diffusion_equals_the_referen
     run_with_big_stack(_hybrid_step_check, "channel_tke", "remap", "nudge", "cntiso_hybrid", 2, tmp_path, True)
 
 
-def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=False):
+def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=False, mlrmth="fox08"):
     import ctypes as C
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
@@ -107,10 +115,18 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=Fa
         f["trc_corr"] = np.zeros((ref.ntr, nj, ni))
     f["salt_corr"] = np.zeros((1, nj, ni))
     f["OBLdepth"] = 10.0 ** rng.uniform(0.8, 2.2, (1, nj, ni))      # boundary layer depth (difest_vertical_hybrid's, CVMix)
+    if mlrmth == "bod23":                                           # ... and its friction / convective velocities cubed
+        if not ref.has_field("wpup_tf"):
+            pytest.skip("reference library built before bod23's fields were added to the harness")
+        f["ustar3"] = (10.0 ** rng.uniform(-3.0, -1.5, (1, nj, ni))) ** 3
+        f["wstar3"] = np.where(rng.random((1, nj, ni)) < 0.3, 0.0, 10.0 ** rng.uniform(-9.0, -5.0, (1, nj, ni)))
     pbot = float(np.max(ref.get("p")[kk][4:-4, 4:-4][ref.masks["ip"][4:-4, 4:-4] > 0]))
     plevel = 0.3 * pbot * (np.arange(kk) / kk) ** 1.3
     for nm, a in f.items():
         ref.put(nm, a)
+    for nm in ("ustar3", "wstar3"):
+        if nm in f:
+            gpu.put(nm, f[nm])
     for nm in ALE_FIELDS:                     # the reference's initial patterns (spval) where nothing writes
         if ref.has_field(nm) and gpu.has_field(nm):
             gpu.put(nm, ref.get(nm))
@@ -130,12 +146,12 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=Fa
     gpu.set("brine_mlbase_frac", 0.4)
     six0 = hostinit.step_indices(0, kk)
     ale_init_once(ref, lib, o, six0, tmp_path)
-    ref.ref.stage("eddtra_init_fox08", *six0)                     # inivar_eddtra + init_eddtra (mlrmth = 'fox08', the default)
-    for nm in ("hbl_tf", "hml_tf1", "hml_tf"):
+    ref.ref.stage("eddtra_init_" + mlrmth, *six0)                 # inivar_eddtra + init_eddtra (mlrmth = 'fox08' is the default)
+    for nm in ("hbl_tf", "hml_tf1", "hml_tf") + (("wpup_tf",) if mlrmth == "bod23" else ()):
         gpu.put(nm, ref.get(nm))
     ref.ref.set("eitmth", "gm")
     gpu.set("eitmth", "gm")
-    gpu.set("mlrmth", "fox08")
+    gpu.set("mlrmth", mlrmth)
     try:
         ref.ref.set("vcoord_tag", tag)
         for be in (ref.ref, gpu):
@@ -166,7 +182,7 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=Fa
             # (phy/mod_momtum.F90:342-350), so the module arrays keep whatever they held outside the interior -- in the serial
             # build the last layer's values, which is what the device leaves there.  Interior only for that build.
             omp = cfg.startswith("channel")
-            chk = CHECK + (["nnslpx", "nnslpy", "utflld", "usflld", "vtflld", "vsflld"] if neutral else [])
+            chk = CHECK + (["nnslpx", "nnslpy", "utflld", "usflld", "vtflld", "vsflld"] if neutral else []) + (["wpup_tf"] if mlrmth == "bod23" else [])
             bad = diff_report(ref, gpu, fields=[nm for nm in chk if nm not in SCRATCH and not (omp and nm in ("utotn", "vtotn"))])
             assert not bad, f"step {nr}\n" + fmt_report(bad[:12])
             if omp:
@@ -187,4 +203,6 @@ def _hybrid_step_check(cfg, advmth, method, vcoord, nsteps, tmp_path, neutral=Fa
     finally:
         ref.ref.set("vcoord_tag", 1)
         ref.ref.set("ltedtp_opt", 1)
+        if mlrmth != "fox08":
+            ref.ref.stage("eddtra_init_fox08", *six0)           # (the cached backend goes back to the default)
         gpu.close()
