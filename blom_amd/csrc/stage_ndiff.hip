@@ -380,6 +380,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     double pmP, pmC = 0., ppP, ppC = 0., xmP = 0., xmC = 0., xpP = 0., xpC = 0.;
     int kmP = 0, kmC = 0, kpP = 0, kpC = 0;
     // in registers between index changes: p_srcdi(is,ks), (1,ks), (2,ks), p_ni_srcdi(is,ks), (isn,ksn), p_srcdi(isn,ksn), p_dstsnp(kd+1)
+    double sn_m = 0., sn_p = 0., dd_m = 0., dd_p = 0.;      // p_dstsnp(kd), p_dst(kd+1) - p_dst(kd) of the current destination layers
     double a_m = 0., b_m = 0., c_m = 0., d_m = 0., e_m = 0., f_m = 0., g_m = 0., a_p = 0., b_p = 0., c_p = 0., d_p = 0., e_p = 0., f_p = 0., g_p = 0.;
     pmP = -ND_MVAL; ppP = -ND_MVAL;
     while (true) {                                              // search_loop2
@@ -452,8 +453,10 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         d_p = PNP(is_p, ks_p); e_p = PNP(isn_p, ksn_p);
         a_p = PSP(is_p, ks_p); b_p = PSP(1, ks_p); c_p = PSP(2, ks_p); f_p = PSP(isn_p, ksn_p);
       }
-      if (advance_dst_m) g_m = SNM(kd_m + 1);
-      if (advance_dst_p) g_p = SNP(kd_p + 1);
+      // (with a destination index its snapped upper interface and the layer's thickness come along in the same round of loads: a pass
+      // that finds a neutral interface needs them, and asking then would be a second memory round trip in every such pass)
+      if (advance_dst_m) { g_m = SNM(kd_m + 1); sn_m = SNM(kd_m); dd_m = PDM(kd_m + 1) - PDM(kd_m); }
+      if (advance_dst_p) { g_p = SNP(kd_p + 1); sn_p = SNP(kd_p); dd_p = PDP(kd_p + 1) - PDP(kd_p); }
       if (pmP == -ND_MVAL) {
         if ((e_m - f_p) < (e_p - f_m)) {
           pmP = f_m;
@@ -474,8 +477,8 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
           kd_p = kd_p + 1;
           if (kd_p > kdmx_p) { out = true; break; }
         }
-        if (nm) g_m = SNM(kd_m + 1);
-        if (npp) g_p = SNP(kd_p + 1);
+        if (nm) { g_m = SNM(kd_m + 1); sn_m = SNM(kd_m); dd_m = PDM(kd_m + 1) - PDM(kd_m); }
+        if (npp) { g_p = SNP(kd_p + 1); sn_p = SNP(kd_p); dd_p = PDP(kd_p + 1) - PDP(kd_p); }
       }
       if (out) break;
       advance_src_m = false; advance_src_p = false; advance_dst_m = false; advance_dst_p = false;
@@ -591,10 +594,10 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
         advance_src_m = true; advance_src_p = true;
       }
       if (found_ni) {
-        const double dp_ni_m = fmin2(pmC - pmP, PDM(kd_m + 1) - PDM(kd_m));
-        const double dp_ni_p = fmin2(ppC - ppP, PDP(kd_p + 1) - PDP(kd_p));
+        const double dp_ni_m = fmin2(pmC - pmP, dd_m);
+        const double dp_ni_p = fmin2(ppC - ppP, dd_p);
         const double dp_ni = 2. * dp_ni_m * dp_ni_p / fmax2(dp_ni_m + dp_ni_p, 2. * ND_DP_EPS);
-        if (ks_m == ks_m_prev && ks_p == ks_p_prev && pmP >= SNM(kd_m) && pmC <= g_m && ppP >= SNP(kd_p) &&
+        if (ks_m == ks_m_prev && ks_p == ks_p_prev && pmP >= sn_m && pmC <= g_m && ppP >= sn_p &&
             ppC <= g_p && dp_ni > 2. * ND_DP_EPS) {
           // the record of this neutral layer (k_ndiff_eval forms the fluxes from it): destination and source layers, how the
           // interface values are to be taken, the positions of the two neutral interfaces in the source layers, the thickness
