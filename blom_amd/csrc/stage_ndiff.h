@@ -20,6 +20,7 @@ struct NdArgs {
                                // mean pressure of the upper and of the lower interface
   double *rec_f;               // per record ntr_loc fluxes (NaN: withheld by the sign tests)
   int nrec_max;
+  int flux_zero;               // utflx .. vsflx (level m) are zero when the stage starts (inside blomgpu_step: init_fluxes, nothing added since)
   long long *prof;             // debug (blomgpu_dbg_bt_prof): per wave of k_ndiff_flux its start / end timestamp and record count
   int kk, npc, ntr_loc, mm, nn, surface_align;
 };

@@ -796,9 +796,24 @@ __global__ __launch_bounds__(64) void k_ndiff_uvflx(const DevView *__restrict__ 
   double *ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), *fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
   double *ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), *fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
   int kuv = 1;
-  // the sums of the layer kuv stay in registers until kuv moves on
+  // The sums of the layer kuv stay in registers until kuv moves on.  A move must not wait for memory: the lanes of a wave move at
+  // different records, so nearly every record some lane moves, and a load in that path -- even one requested long before for the
+  // lane that moves now -- costs the WAVE a full round trip (its load counter is shared).  So the column of interface pressures goes
+  // to LDS first (each lane its own column: no barrier), and the sums of a layer start from zero without being read where they are
+  // known to be zero: utflld .. always (k_ndiff_prep has just zeroed them), utflx .. inside blomgpu_step (flux_zero).
+  HIP_DYNAMIC_SHARED(double, lds_uvf)
+  double *pl = lds_uvf + threadIdx.x;
+  for (int k0 = 0; k0 <= kk; k0 += ND_RB) {
+    double a[ND_RB];
+#pragma unroll
+    for (int u = 0; u < ND_RB; u++) a[u] = puv[cp + (size_t)(k0 + u <= kk ? k0 + u : kk) * np];
+#pragma unroll
+    for (int u = 0; u < ND_RB; u++)
+      if (k0 + u <= kk) pl[(k0 + u) * 64] = a[u];
+  }
+  const bool fz = A.flux_zero != 0;
   size_t ok = cp + (size_t)(kuv - 1 + mm) * np;
-  double atl = ftl[ok], asl = fsl[ok], atx = ftx[ok], asx = fsx[ok], pk = puv[cp], pk1 = puv[cp + np];
+  double atl = 0., asl = 0., atx = fz ? 0. : ftx[ok], asx = fz ? 0. : fsx[ok], pk = pl[0], pk1 = pl[64];
   for (int r0 = 0; r0 < n; r0 += ND_RB) {
     double tf[ND_RB], sf[ND_RB], pup[ND_RB], plo[ND_RB];
 #pragma unroll
@@ -824,8 +839,9 @@ __global__ __launch_bounds__(64) void k_ndiff_uvflx(const DevView *__restrict__ 
           kuv = kuv + 1;
           if (kuv <= kk) {
             ok = cp + (size_t)(kuv - 1 + mm) * np;
-            atl = ftl[ok]; asl = fsl[ok]; atx = ftx[ok]; asx = fsx[ok];
-            pk = pk1; pk1 = puv[cp + (size_t)kuv * np];
+            atl = 0.; asl = 0.;
+            if (fz) { atx = 0.; asx = 0.; } else { atx = ftx[ok]; asx = fsx[ok]; }
+            pk = pk1; pk1 = pl[kuv * 64];
           }
         } else {
           const double mlfrac = (p_ni_lo - fmax2(p_ni_up, pk)) * dp_ni_i;
@@ -849,9 +865,15 @@ __global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ 
   const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
   const size_t c = t_, np = V.nplane, nf = 2 * np;
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
-  const int ntr_loc = A.ntr_loc, nt = blockIdx.y;
+  const int ntr_loc = A.ntr_loc, nt = blockIdx.y, kk = A.kk;
   const size_t faces[4] = {np + c, c, c + 1, np + c + V.ni};
   double *fl = A.flx + c + (size_t)nt * np;                      // layer stride ntr_loc * np
+  // The cell's column of sums lives in LDS while the four faces are replayed (each lane its own column: no barrier) and goes to
+  // memory once at the end: a change of layer must not read memory -- the lanes of a wave change layers at different records, and a
+  // load in that path costs the whole wave a round trip every time (k_ndiff_uvflx).  k_ndiff_prep has zeroed flx: the sums start at 0.
+  HIP_DYNAMIC_SHARED(double, lds_app)
+  double *fc = lds_app + threadIdx.x;
+  for (int k = 0; k < kk; k++) fc[k * 64] = 0.;
   for (int f = 0; f < 4; f++) {
     const size_t face = faces[f];
     const int n = A.rec_n[face];
@@ -875,15 +897,16 @@ __global__ __launch_bounds__(64) void k_ndiff_apply(const DevView *__restrict__ 
         const int kd = plus ? (kdds[u] >> 16) : (kdds[u] & 0xffff);
         const double v = vs[u];
         if (kd != cur) {
-          if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
+          if (cur) fc[(cur - 1) * 64] = acc;
           cur = kd;
-          acc = fl[(size_t)(cur - 1) * ntr_loc * np];
+          acc = fc[(cur - 1) * 64];
         }
         if (v == v) acc = plus ? acc - v : acc + v;
       }
     }
-    if (cur) fl[(size_t)(cur - 1) * ntr_loc * np] = acc;
+    if (cur) fc[(cur - 1) * 64] = acc;
   }
+  for (int k = 0; k < kk; k++) fl[(size_t)k * ntr_loc * np] = fc[k * 64];
 }
 
 size_t ndiff_scratch_planes(int kk) { return (size_t)4 * kk + (size_t)10 * (kk + 1); }   // per FACE (2 nplane of them)
@@ -911,11 +934,11 @@ int st_ndiff_prep_flux(blomgpu_ctx *c, hipStream_t st, hipEvent_t ev_snap, NdArg
   }
   {
     TimeScope t1(c, "k_ndiff_uvflx", st);
-    hipLaunchKernelGGL(k_ndiff_uvflx, dim3((unsigned)((2 * h.nplane + 63) / 64)), dim3(64), 0, st, c->d, A);
+    hipLaunchKernelGGL(k_ndiff_uvflx, dim3((unsigned)((2 * h.nplane + 63) / 64)), dim3(64), sizeof(double) * 64 * (h.kk + 1), st, c->d, A);
   }
   {
     TimeScope t1(c, "k_ndiff_apply", st);
-    hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), 0, st, c->d, A);
+    hipLaunchKernelGGL(k_ndiff_apply, dim3(nb, A.ntr_loc), dim3(64), sizeof(double) * 64 * h.kk, st, c->d, A);
   }
   HIPCHK(c, hipGetLastError());
   return 0;
