@@ -210,8 +210,14 @@ __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ V
   const int kfa = V.m[I_kfpla][a_ + (size_t)(n - 1) * np], kfb = V.m[I_kfpla][b_ + (size_t)(n - 1) * np];
   if (!(kfa <= kk || kfb <= kk)) return;
   int kmax = 1;
-  for (int k = 3; k <= kk; k++)
-    if (A(dp, a_, k) > EPSILP || A(dp, b_, k) > EPSILP) kmax = k;
+  for (int k0 = 3; k0 <= kk; k0 += COLUMN_U) {                           // (COLUMN_U levels' loads in flight)
+    double da[COLUMN_U], db[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) { const int kq = k0 + u <= kk ? k0 + u : kk; da[u] = A(dp, a_, kq); db[u] = A(dp, b_, kq); }
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++)
+      if (k0 + u <= kk && (da[u] > EPSILP || db[u] > EPSILP)) kmax = k0 + u;
+  }
   const int kintr = kfa > kfb ? kfa : kfb;
   int knnsl = 2;
   const double phba = A(phi, a_, kk + 1), phbb = A(phi, b_, kk + 1);
@@ -253,7 +259,10 @@ __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ V
       }
     }
   }
-  for (int k = knnsl + 1; k <= kmax; k++) O(nnslp, k) = O(nnslp, knnsl);
+  {
+    const double last = O(nnslp, knnsl);
+    for (int k = knnsl + 1; k <= kmax; k++) O(nnslp, k) = last;
+  }
   if (kintr < kmax) {
     const double s = O(nslp, kintr + 1), ns = O(nnslp, kintr + 1);
     for (int k = 4; k <= kintr; k++) { O(nslp, k) = s; O(nnslp, k) = ns; }

@@ -174,8 +174,17 @@ __global__ void k_diapfl_momentum(const DevView *__restrict__ Vp, int nn) {
     }
   }
   const double ub = uprev;                                    // uc(kmax): untouched by the back substitution
-  for (int k = kmax + 1; k <= kk; k++)
-    if (fmin2(p[mns + (size_t)(k - 1) * np], LV(p, k)) < pzb) LV(vel, k) = ub;
+  for (int k0 = kmax + 1; k0 <= kk; k0 += 2 * MU_) {           // (the massless layers under the column: their loads in flight too)
+    double b0[2 * MU_], b1[2 * MU_];
+#pragma unroll
+    for (int u = 0; u < 2 * MU_; u++) {
+      const int kq = k0 + u <= kk ? k0 + u : kk;
+      b0[u] = p[mns + (size_t)(kq - 1) * np]; b1[u] = LV(p, kq);
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * MU_; u++)
+      if (k0 + u <= kk && fmin2(b0[u], b1[u]) < pzb) LV(vel, k0 + u) = ub;
+  }
 }
 
 // dpu/dpv at the new level from the updated p, :971-1000 (u: i 1..ii+1, j 1..jj ; v: i 1..ii, j 1..jj+1)
