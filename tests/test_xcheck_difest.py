@@ -34,15 +34,15 @@ OPT_2D = (dict(egc=0.85, eggam=200.0, eglsmn=4000.0, egmndf=50.0, egmxdf=1500.0,
           dict(eddf2d=1, edsprs=1, edanis=0, redi3d=1, edfsmo=1, edritp_opt=2, edwmth_opt=1, bdmtyp=2, iwdflg=0, bdmldp=1))
 
 
-def _setup(cfg, opts):
+def _setup(cfg, opts, ntr=None):
     from oracle.refblom import get_ref_backend, have_ref
     from blom_amd.gpu import BlomGpu
     big = cfg.split("_")[0] in ("channel",)
     lib = cfg + "_omp_xdf" if big else cfg.replace("_tke", "") + "_xdf"
     if not have_ref(lib):
         pytest.skip(f"oracle/_ref/{lib}/libblomref.so not built")
-    case = make_case(cfg, nslp0=0.0)
-    ref = _WithEddtra(get_ref_backend(lib, case.depth))
+    case = make_case(cfg, nslp0=0.0, ntr=ntr)
+    ref = _WithEddtra(get_ref_backend(lib, case.depth, ntr=ntr))
     ref.ref.set("eitmth", "gm")
     six0 = hostinit.step_indices(0, case.kdm)
     ref.ref.stage("difest_init", *six0)                 # (before the state: initke resets the TKE tracers, difdia, ustarb)
@@ -98,8 +98,8 @@ def test_the_tke_closures_constants_equal_the_reference():
         gpu.close()
 
 
-def _live_step_check(cfg, nsteps, opts, stagewise=False):
-    case, ref, gpu, big = _setup(cfg, opts)
+def _live_step_check(cfg, nsteps, opts, stagewise=False, ntr=None):
+    case, ref, gpu, big = _setup(cfg, opts, ntr=ntr)
     check = [f for f in CHECK if not (big and f in ("utotn", "vtotn"))] + [f for f in DFE_OUT if f not in CHECK]
     try:
         nr = ng = 0
@@ -151,6 +151,20 @@ def test_difest_isobml_on_its_own_equals_the_real_module(cfg, opts):
                                              ("box_s", 6, hostinit.DIFEST_NORESM)])
 def test_full_step_with_live_diffusivities_equals_the_reference_stage_sequence(cfg, nsteps, opts):
     _live_step_check(cfg, nsteps, opts)
+
+
+@pytest.mark.parametrize("cfg,nsteps,ntr", [("chan_s_tke", 5, 9), ("tri_s_tke", 4, 14), ("box_s", 4, 7)])
+def test_full_step_with_live_diffusivities_and_many_tracers(cfg, nsteps, ntr):
+    """config 5's regime on config 2's step: more tracers than the kernels take at a time (remap's batches of four, convec's and mxlayr's
+    groups of four, diapfl's) through the WHOLE step with live diffusivities, the reference carrying them itself (ref_set_ntr)"""
+    _live_step_check(cfg, nsteps, hostinit.DIFEST_NORESM, ntr=ntr)
+
+
+def test_full_size_channel_step_with_24_tracers_equals_the_reference_stage_sequence():
+    """two steps at the channel's size with 24 tracers (the default three + 21 passive ones): what bench.py --tracers 24 times, against the
+    reference's modules carrying them"""
+    from test_xcheck_ale import run_with_big_stack
+    run_with_big_stack(_live_step_check, "channel_tke", 2, hostinit.DIFEST_NORESM, False, 24)
 
 
 def test_full_size_channel_step_with_live_diffusivities_equals_the_reference_stage_sequence():
