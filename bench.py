@@ -37,7 +37,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 NSLP0 = 2.0e-4             # amplitude of the frozen isopycnal slopes that drive eddtra (cases.py)
 
 
-def build_case(cfg, advmth="remap", tracers="default"):
+FORCING = {"default": {}, "calm": {"ustarw0": 5.0e-5}}
+
+
+def build_case(cfg, advmth="remap", tracers="default", forcing="default"):
     import numpy as np
     from blom_amd.cases import make_case
     from blom_amd import hostinit
@@ -45,7 +48,9 @@ def build_case(cfg, advmth="remap", tracers="default"):
     # => ntr = 3, the tracer count SURVEY.md 8(d) quotes the channel on; "iage": -DTRC -DIDLAGE only, ntr = 1
     # an integer N > 3: the default set plus N - 3 passive tracers (what iHAMOCC's are to the dynamical core, config 5)
     ntr = int(tracers) if tracers.isdigit() else None
-    case = make_case(cfg + ("" if tracers == "iage" else "_tke"), ntr=ntr, nslp0=NSLP0, advmth=advmth)
+    # forcing: "default" = channel/mod_channel.F90:365 (ustarw = 0.005, which thermf_channel's 1e2 turns into 0.5 m/s of friction
+    # velocity); "calm" = this project's second published set, ustarw = 5e-5 (0.005 m/s after the factor)
+    case = make_case(cfg + ("" if tracers == "iage" else "_tke"), ntr=ntr, nslp0=NSLP0, advmth=advmth, **FORCING[forcing])
     nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
     return case, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq)
 
@@ -200,6 +205,51 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False
     return res or {"error": "the reference run did not complete"}
 
 
+def device_for_bench(case, nreg, masks, live=True, device=0):
+    """The device state bench.py times on one tile: config 2's step (full_physics) from the case's initial state with the channel
+    experiment's forcing, the diffusivities estimated every step unless live = False (tools/longrun_full_physics.py and the long-run
+    parity test start from the same state)."""
+    from blom_amd.gpu import BlomGpu
+    from blom_amd import hostinit
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks, device=device)
+    hostinit.init_state(gpu, case)
+    gpu.set("live_slopes", 1)
+    hostinit.init_forcing(gpu, case)
+    gpu.set("full_physics", 1)
+    if live:
+        hostinit.init_difest(gpu, case, device=True)
+        for d_ in hostinit.DIFEST_NORESM:
+            for nm, v in d_.items():
+                gpu.set(nm, v)
+        gpu.set("difest_live", 1)
+    return gpu
+
+
+def ref_full_init(be, case, xml, xdf):
+    """The initial state and the options of the bench workload on a reference backend (the CPU baseline, and
+    tools/longrun_reference.py which writes tests/golden/channel_tke_live_long_crc.json from the same state)."""
+    from blom_amd import hostinit
+    if xdf:
+        be.ref.stage("difest_init", *hostinit.step_indices(0, case.kdm))      # (before the state: initke resets the TKE tracers)
+    hostinit.init_state(be, case)
+    if xml:
+        six0 = hostinit.step_indices(0, case.kdm)
+        be.ref.stage("mxlayr_init", *six0)
+        hostinit.init_forcing(be, case)
+        if xdf:
+            hostinit.init_difest(be, case)
+            for d_ in hostinit.DIFEST_NORESM:
+                for nm, v in d_.items():
+                    be.ref.set(nm, v)
+        for nm, v in dict(rm0=1.2, rm5=0.0, niwgf=0.0, niwbf=0.35, niwlf=0.5, ce=0.06, tau_mlr=86400.0, lfmin=5.0e3, swamxd=200.0, sref=34.65,
+                          xmi=0.0, trxday=0.0, srxday=0.0, trxdpt=1.0, srxdpt=1.0, trxlim=1.5, srxlim=0.5).items():
+            be.ref.set(nm, float(v))
+        be.ref.set("mlrttp", "constant")
+        for nm, v in dict(l1mi=11, l2mi=12, l3mi=1, l4mi=2, l5mi=3, aptflx=0, apsflx=0, ditflx=0, disflx=0, srxbal=0, nstep_in_day=96,
+                          nday_of_year=1, nday_in_year=365).items():
+            be.ref.set(nm, int(v))
+
+
 def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False, difest=False):
     """The reference's own Fortran (preferred) or the C restatement, timed on the host for a bounded number of steps.
     Preferred build: oracle/_ref/<cfg>_omp_xed -- the reference's hot-path modules INCLUDING its real mod_cmnfld_routines and
@@ -276,25 +326,7 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_phys
     if kind is None:
         be = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
         kind = "port"
-    if xdf:
-        be.ref.stage("difest_init", *hostinit.step_indices(0, case.kdm))      # (before the state: initke resets the TKE tracers)
-    hostinit.init_state(be, case)
-    if xml:
-        six0 = hostinit.step_indices(0, case.kdm)
-        be.ref.stage("mxlayr_init", *six0)
-        hostinit.init_forcing(be, case)
-        if xdf:
-            hostinit.init_difest(be, case)
-            for d_ in hostinit.DIFEST_NORESM:
-                for nm, v in d_.items():
-                    be.ref.set(nm, v)
-        for nm, v in dict(rm0=1.2, rm5=0.0, niwgf=0.0, niwbf=0.35, niwlf=0.5, ce=0.06, tau_mlr=86400.0, lfmin=5.0e3, swamxd=200.0, sref=34.65,
-                          xmi=0.0, trxday=0.0, srxday=0.0, trxdpt=1.0, srxdpt=1.0, trxlim=1.5, srxlim=0.5).items():
-            be.ref.set(nm, float(v))
-        be.ref.set("mlrttp", "constant")
-        for nm, v in dict(l1mi=11, l2mi=12, l3mi=1, l4mi=2, l5mi=3, aptflx=0, apsflx=0, ditflx=0, disflx=0, srxbal=0, nstep_in_day=96,
-                          nday_of_year=1, nday_in_year=365).items():
-            be.ref.set(nm, int(v))
+    ref_full_init(be, case, xml, xdf)
     ns = dyncore_step(be, 0, case.params["baclin"], stages=stages)          # forward first step (untimed)
     # per-stage host times beside the device's stages_ms: the hook fires before every stage
     per_stage, mark = {}, [None, 0.0]

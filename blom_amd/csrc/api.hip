@@ -222,6 +222,21 @@ int blomgpu_create(const blomgpu_dims *d, blomgpu_ctx **out) {
   ctx_sync_view(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = c;
+  // A/B aid: BLOMGPU_OPTS="name=int,name=int" sets kernel-variant options on every context of the process (so that a whole
+  // test suite or bench run can be repeated with a variant: `BLOMGPU_OPTS=pgf_uv_ring=0 pytest -m gpu ...`); unknown names fail loudly
+  if (const char *env = getenv("BLOMGPU_OPTS")) {
+    std::string e(env);
+    size_t pos = 0;
+    while (pos < e.size()) {
+      size_t end = e.find(',', pos);
+      if (end == std::string::npos) end = e.size();
+      const std::string item = e.substr(pos, end - pos);
+      const size_t eq = item.find('=');
+      if (eq != std::string::npos)
+        if (int rc = blomgpu_set_int(c, item.substr(0, eq).c_str(), atoi(item.substr(eq + 1).c_str()))) return rc;
+      pos = end + 1;
+    }
+  }
   return 0;
 }
 
@@ -329,11 +344,13 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
   if (s == "area") { *v = c->area; return 0; }
   if (s == "bdml_logc") { *v = c->bdml_logc; return 0; }
   // diagnostic counters of mxlayr (stage_mxlayr.hip): columns whose iteration for the mixed layer depth ended at its limit since the last
-  // query -- "mxlayr_maxitr_entrain" (phy/mod_mxlayr.F90:437-449), "mxlayr_maxitr_detrain" (:955-982); the reference prints such columns
+  // query, named by the message the reference prints for such a column: "mxlayr_maxitr_detrain" = the first iteration
+  // (phy/mod_mxlayr.F90:437-449, 'reached maxitr when detraining', :440; word 5), "mxlayr_maxitr_entrain" = the second
+  // (:947-982, 'reached maxitr when entraining', :950; word 6).  (Until round 5 the two names were swapped.)
   if (s == "mxlayr_maxitr_entrain" || s == "mxlayr_maxitr_detrain") {
     *v = 0.;
     if (!c->err_dev) return 0;
-    const int w = s == "mxlayr_maxitr_entrain" ? 5 : 6;
+    const int w = s == "mxlayr_maxitr_detrain" ? 5 : 6;
     int n = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(&n, c->err_dev + w, sizeof(int), hipMemcpyDeviceToHost));
@@ -397,6 +414,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   }
   if (s == "eddtra_frozen") { c->eddtra_frozen = v; return 0; }
   if (s == "pgf_uv_pair") { c->pgf_uv_pair = v; return 0; }
+  if (s == "pgf_uv_ring") { c->pgf_uv_ring = v; return 0; }
   if (s == "pgf_copy_fused") { c->pgf_copy_fused = v; return 0; }
   if (s == "check_period") { c->check_period = v < 1 ? 1 : v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }

@@ -155,14 +155,40 @@ __host__ __device__ inline bool trc_skip_adv(const Params &P, int nt) { return P
 constexpr double TKE_MIN = 7.6e-8, GLS_PSI_MIN = 1.e-14;      // phy/mod_tke.F90:61-62
 
 // ---- what a kernel sees ----------------------------------------------------------------
+// The field pointers a kernel takes out of its DevView are pointers into HBM -- but a pointer LOADED from memory has the generic
+// address space, and hipcc (ROCm 7.2) then emits flat_load / flat_store for everything reached through it: a flat access counts on
+// vmcnt AND lgkmcnt and may complete out of order, so the compiler waits for `vmcnt(0) lgkmcnt(0)` wherever a loaded value is used --
+// for the wave's YOUNGEST access, whatever was requested ahead of it (tools/isa_waits.py shows it; until round 6 every kernel of this
+// library was built that way: 706 flat against 26 global loads in stage_pgforc.o alone).  The tables below hand the pointers out in
+// the global address space (device code only; the conversion to a plain `double *` at the use is implicit), which turns every such
+// access into global_load / global_store with counted waits (`s_waitcnt vmcnt(n)`).  Same arithmetic, same results.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BLOM_GAS __attribute__((address_space(1)))
+#else
+#define BLOM_GAS
+#endif
+template <class T, int N> struct PtrTable {
+  T *p_[N];
+  __host__ __device__ inline T BLOM_GAS *operator[](int i) const { return (T BLOM_GAS *)p_[i]; }
+  __host__ inline T *&operator[](int i) { return p_[i]; }
+};
+template <class T> __host__ __device__ inline T BLOM_GAS *global_ptr(T *p) { return (T BLOM_GAS *)p; }
+// Local pointer variables of a kernel that are used WITHOUT an offset added first (`const double *p = V.f[F_p]`) must keep the
+// address space in their type: the round trip global -> generic right after the table's cast is folded away by the optimiser
+// and the accesses are flat again (tools/flat_census.py lists the kernels that still have some).
+typedef const double BLOM_GAS *gcd_t;
+typedef double BLOM_GAS *gd_t;
+typedef const int BLOM_GAS *gci_t;
+typedef int BLOM_GAS *gi_t;
+
 struct DevView {
   int ii, jj, kk;        // tile extents (== idm, jdm, kdm)
   int ni, nj;            // padded plane: idm+2*nbdy, jdm+2*nbdy
   int nplane;            // ni*nj
   int itdm, jtdm, i0, j0, nreg, ntr;
   Params P;
-  double *f[NF_REAL];
-  int *m[NF_INT];
+  PtrTable<double, NF_REAL> f;
+  PtrTable<int, NF_INT> m;
   // work space standing in for the reference's stage-local temporaries:
   //   wk   : nwk fields of kk levels each   (field w, level k at wk + (w*kk + k)*nplane)
   //   wk2d : NWK2D single planes
@@ -171,8 +197,8 @@ struct DevView {
   int nwk;
 };
 #define NWK2D 48
-#define WK(V, w) ((V).wk + (size_t)(w) * (V).kk * (V).nplane)
-#define WK2(V, w) ((V).wk2d + (size_t)(w) * (V).nplane)
+#define WK(V, w) (global_ptr((V).wk) + (size_t)(w) * (V).kk * (V).nplane)
+#define WK2(V, w) (global_ptr((V).wk2d) + (size_t)(w) * (V).nplane)
 
 // index of Fortran (i,j) inside a plane; level stride is V.nplane
 #define IDX(V, i, j) (((i) + NBDY - 1) + (V).ni * ((j) + NBDY - 1))
@@ -251,6 +277,7 @@ struct blomgpu_ctx {
   int pgf_uv_pair = 0;           // k_pgf_uv, A/B option: 1 = the u- and v-column wavefronts of 64 points in one workgroup with XCD-contiguous
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
+  int pgf_uv_ring = 0;           // k_pgf_uv_ring (round 6: every load of the level loop statically countable): 1 = separate u / v workgroups, 2 = paired + XCD-contiguous
   int pgf_copy_fused = 1;        // pgforc: the pgfx_o/pgfy_o copy rides along in k_pgf_uv
   int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded
   int check_period = 8;          // steps between read-backs of the sticky stage error words in blomgpu_step

@@ -61,7 +61,7 @@ struct Nbr {
   int dxw, dyw;   // ie-iw, jn-js
 };
 __device__ inline Nbr wet_nbr(const DevView &V, size_t c) {
-  const int *ip = V.m[I_ip], *iu = V.m[I_iu], *iv = V.m[I_iv];
+  gci_t ip = V.m[I_ip], iu = V.m[I_iu], iv = V.m[I_iv];
   const int ni = V.ni;
   const int a = iu[c], b = iu[c + 1], d = iv[c], e = iv[c + ni];
   Nbr r;
@@ -86,7 +86,7 @@ __global__ void k_adv_pbmin(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   THREAD_IJ(V);
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
-  const double *pb = V.f[F_p] + (size_t)V.kk * V.nplane;
+  gcd_t pb = V.f[F_p] + (size_t)V.kk * V.nplane;
   const Nbr b = wet_nbr(V, c);
   double r = fmin2(pb[b.sw], pb[b.s]);
   r = fmin2(r, pb[b.se]);
@@ -111,7 +111,7 @@ __global__ void k_remap_update(const DevView *__restrict__ Vp, int nn, int mmlea
   if (j < -2 || j > V.jj + 3 || i < -2 || i > V.ii + 3 || !V.m[I_ip][c]) return;
   const int k = by_, ntr = V.ntr;
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np;
-  double *dp = V.f[F_dp] + okn;
+  gd_t dp = V.f[F_dp] + okn;
   const double q = fmax2(0., dp[c]) + DPEPS;
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) {
     dp[c] = q;
@@ -122,29 +122,29 @@ __global__ void k_remap_update(const DevView *__restrict__ Vp, int nn, int mmlea
   double dfd, dft, dfs;
   if (mmlean >= 0) {
     const size_t okm = (size_t)(k + mmlean) * np;
-    const int *mpk = V.m[I_mpack];
+    gci_t mpk = V.m[I_mpack];
     const bool uc = (mpk[c] >> 1) & 1, ue = (mpk[e] >> 1) & 1, vc = (mpk[c] >> 2) & 1, vn = (mpk[nb] >> 2) & 1;
-    const double *fdu = V.f[F_uflx] + okm, *fdv = V.f[F_vflx] + okm, *ftu = V.f[F_utflx] + okm, *ftv = V.f[F_vtflx] + okm;
-    const double *fsu = V.f[F_usflx] + okm, *fsv = V.f[F_vsflx] + okm;
+    gcd_t fdu = V.f[F_uflx] + okm, fdv = V.f[F_vflx] + okm, ftu = V.f[F_utflx] + okm, ftv = V.f[F_vtflx] + okm;
+    gcd_t fsu = V.f[F_usflx] + okm, fsv = V.f[F_vsflx] + okm;
     dfd = (ue ? fdu[e] : 0.) - (uc ? fdu[c] : 0.) + (vn ? fdv[nb] : 0.) - (vc ? fdv[c] : 0.);
     dft = (ue ? ftu[e] : 0.) - (uc ? ftu[c] : 0.) + (vn ? ftv[nb] : 0.) - (vc ? ftv[c] : 0.);
     dfs = (ue ? fsu[e] : 0.) - (uc ? fsu[c] : 0.) + (vn ? fsv[nb] : 0.) - (vc ? fsv[c] : 0.);
   } else {
-    const double *fdu = WK(V, W_FDU(ntr)) + ok, *fdv = WK(V, W_FDV(ntr)) + ok;
-    const double *ftu = WK(V, W_FTU(ntr)) + ok, *ftv = WK(V, W_FTV(ntr)) + ok;
-    const double *fsu = WK(V, W_FSU(ntr)) + ok, *fsv = WK(V, W_FSV(ntr)) + ok;
+    gcd_t fdu = WK(V, W_FDU(ntr)) + ok, fdv = WK(V, W_FDV(ntr)) + ok;
+    gcd_t ftu = WK(V, W_FTU(ntr)) + ok, ftv = WK(V, W_FTV(ntr)) + ok;
+    gcd_t fsu = WK(V, W_FSU(ntr)) + ok, fsv = WK(V, W_FSV(ntr)) + ok;
     dfd = fdu[e] - fdu[c] + fdv[nb] - fdv[c];
     dft = ftu[e] - ftu[c] + ftv[nb] - ftv[c];
     dfs = fsu[e] - fsu[c] + fsv[nb] - fsv[c];
   }
   const double dpn = q - dfd * s2i;
-  double *temp = V.f[F_temp] + okn, *saln = V.f[F_saln] + okn;
+  gd_t temp = V.f[F_temp] + okn, saln = V.f[F_saln] + okn;
   temp[c] = (q * temp[c] - dft * s2i) / dpn;
   saln[c] = (q * saln[c] - dfs * s2i) / dpn;
   for (int nt = 0; nt < ntr; nt++) {
     if (trc_skip_adv(V.P, nt + 1)) continue;                   // phy/mod_remap.F90:1497-1499
-    double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
-    const double *fu = WK(V, W_FTRU(ntr, nt)) + ok, *fv = WK(V, W_FTRV(ntr, nt)) + ok;
+    gd_t tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
+    gcd_t fu = WK(V, W_FTRU(ntr, nt)) + ok, fv = WK(V, W_FTRV(ntr, nt)) + ok;
     tr[c] = (q * tr[c] - (fu[e] - fu[c] + fv[nb] - fv[c]) * s2i) / dpn;
   }
   dp[c] = fmax2(0., dpn - DPEPS);

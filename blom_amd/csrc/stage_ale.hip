@@ -243,7 +243,7 @@ __global__ void k_ale_direct_pre(const DevView *__restrict__ Vp, int nn, const d
     for (int q = 1; q < 5; q++) f = f + (q < npc ? pc[c + (size_t)(npc * (k - 1) + q) * np] : 0.);
     return f;
   };
-  double *sigint = V.f[F_sigint];
+  gd_t sigint = V.f[F_sigint];
   double sd2_prev = 0.;
   for (int k = 1; k <= ksmx; k++) {                                                   // :317-327
     const double sd1 = eos::sig(V.P, top(pcT, k), top(pcS, k));
@@ -252,7 +252,7 @@ __global__ void k_ale_direct_pre(const DevView *__restrict__ Vp, int nn, const d
     sd2_prev = sd2;
   }
   for (int k = ksmx + 1; k <= kk; k++) PL(sigint, k) = sd2_prev;
-  const double *sigma = V.f[F_sigma] + (size_t)nn * np, *sigmar = V.f[F_sigmar];
+  gcd_t sigma = V.f[F_sigma] + (size_t)nn * np, sigmar = V.f[F_sigmar];
   for (int k = 1; k <= kk; k++) { PL(sgs, k) = PL(sigma, k); PL(sgt, k) = PL(sigmar, k); }              // :330-335
   PL(sgt, kk + 1) = PL(sgt, kk);
   const double beta = ALE_BFSQ_MIN / (ALE_GRAV * ALE_GRAV);
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_ale_nudge(const DevView *__restrict__ V
       if (k0 - u >= 1 && a[u] == pbq) ksmx = k0 - u - 1;
   }
   double sig_max = 0.;                                                                // :591-605
-  double *sigint = V.f[F_sigint];
+  gd_t sigint = V.f[F_sigint];
   {
     double sd2_prev = 0.;
     for (int k0 = 1; k0 <= ksmx; k0 += 4) {
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_ale_nudge(const DevView *__restrict__ V
     }
     for (int k = ksmx + 1; k <= kk; k++) PL(sigint, k) = sd2_prev;
   }
-  const double *sigmar = V.f[F_sigmar];
+  gcd_t sigmar = V.f[F_sigmar];
   {                                                                                   // :608-615
     double st_prev = 0.;
     for (int k0 = 1; k0 <= kk; k0 += 8) {
@@ -745,7 +745,7 @@ __global__ void k_ale_smooth(const DevView *__restrict__ Vp, double smooth_diff_
   const bool cell = j >= 1 - ring && j <= V.jj + ring && i >= 1 - ring && i <= V.ii + ring && V.m[I_ip][c];
   if (cell && k >= 2 && k <= kk) {
     const double delt1 = V.P.delt1;
-    const double *scp2 = V.f[F_scp2], *difmxp = V.f[F_difmxp];
+    gcd_t scp2 = V.f[F_scp2], difmxp = V.f[F_difmxp];
 #define D(x, q) pdst[(x) + (size_t)((q)-1) * np]
 #define SFC(x, q) sfac[(x) + (size_t)((q)-1) * np]
     auto uflux = [&](size_t cc) {                                // u-face between cc-1 and cc, :962-984
@@ -856,12 +856,12 @@ __global__ void k_ale_uv_src_dst(const DevView *__restrict__ Vp, int nn, double 
   const bool col = j >= 1 && j <= V.jj && i >= 1 && i <= V.ii && (isv ? V.m[I_iv][c] : V.m[I_iu][c]);
   active[cc] = col;
   if (!col) return;                                              // the engine leaves the column out; nothing reads its planes
-  const double *pz = isv ? V.f[F_pv] : V.f[F_pu], *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  const double *uz = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
+  gcd_t pz = isv ? V.f[F_pv] : V.f[F_pu], dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gcd_t uz = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
   double a = pz[c];
   pdst[cc] = a;
   for (int k = 0; k < kk; k++) { a = a + dpz[c + (size_t)k * np]; pdst[cc + (size_t)(k + 1) * nc] = a; }
-  const double *u1 = V.f[F_util1];
+  gcd_t u1 = V.f[F_util1];
   const double q = fmin2(u1[isv ? c - V.ni : c - 1], u1[c]) / pz[c + (size_t)kk * np];
   for (int k = 0; k <= kk; k++) psrc[cc + (size_t)k * nc] = pz[c + (size_t)k * np] * q;
   for (int k = 0; k < kk; k++) uin[cc + (size_t)k * nc] = uz[c + (size_t)k * np];

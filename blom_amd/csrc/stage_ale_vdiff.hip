@@ -33,14 +33,14 @@ __device__ __forceinline__ void vdifft_pass(const DevView &V, size_t c, int nn, 
   const size_t np = V.nplane;
   const int kk = V.kk;
   const double cpi = 1. / SPCIFH, dtg = V.P.delt1 * GRAV, cc = GRAV * GRAV * V.P.delt1 / (ALPHA0 * ALPHA0);
-  const double *__restrict__ dp = V.f[F_dp] + (size_t)nn * np;
-  double *__restrict__ temp = V.f[F_temp] + (size_t)nn * np, *__restrict__ saln = V.f[F_saln] + (size_t)nn * np;
-  double *__restrict__ gamT = WK(V, 0), *__restrict__ gamS = WK(V, 1);
-  const double *__restrict__ nut = V.f[F_kdiff_t], *__restrict__ nus = V.f[F_kdiff_s];
+  gcd_t __restrict__ dp = V.f[F_dp] + (size_t)nn * np;
+  gd_t __restrict__ temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
+  gd_t __restrict__ gamT = WK(V, 0), gamS = WK(V, 1);
+  gcd_t __restrict__ nut = V.f[F_kdiff_t], nus = V.f[F_kdiff_s];
   const double hfsw = V.f[F_sswflx][c], hfns = V.f[F_surflx][c] - hfsw, hfrs = V.f[F_surrlx][c];       // :86-93
   const double sfbr = V.f[F_brnflx][c], sfnb = V.f[F_salflx][c] - sfbr, sfrs = V.f[F_salrlx][c];
-  const double *__restrict__ tns = V.f[F_t_ns_nonloc], *__restrict__ tsw = V.f[F_t_sw_nonloc], *__restrict__ trs = V.f[F_t_rs_nonloc];
-  const double *__restrict__ snb = V.f[F_s_nb_nonloc], *__restrict__ sbr = V.f[F_s_br_nonloc], *__restrict__ srs = V.f[F_s_rs_nonloc];
+  gcd_t __restrict__ tns = V.f[F_t_ns_nonloc], tsw = V.f[F_t_sw_nonloc], trs = V.f[F_t_rs_nonloc];
+  gcd_t __restrict__ snb = V.f[F_s_nb_nonloc], sbr = V.f[F_s_br_nonloc], srs = V.f[F_s_rs_nonloc];
   double *xtr[NTB > 0 ? NTB : 1];
   double tf[NTB > 0 ? NTB : 1];
 #pragma unroll
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk, ntr = V.ntr;
-  const double *dp = V.f[F_dp] + (size_t)nn * np;
-  double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *sigma = V.f[F_sigma] + (size_t)nn * np;
+  gcd_t dp = V.f[F_dp] + (size_t)nn * np;
+  gd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np, sigma = V.f[F_sigma] + (size_t)nn * np;
   // T and S with the first tracers, then the remaining tracers four at a time
   const int n0 = ntr < 4 ? ntr : 4;
   switch (n0) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   }
   V.f[F_salt_corr][c] = sc;
   for (int nt = 0; nt < ntr; nt++) {
-    double *x = V.f[F_trc] + ((size_t)nn + (size_t)nt * 2 * kk) * np;
+    gd_t x = V.f[F_trc] + ((size_t)nn + (size_t)nt * 2 * kk) * np;
     double tc = V.f[F_trc_corr][c + (size_t)nt * np];
     for (int k = 1; k <= kk; k++) {
       const double x1 = L(x, k);
@@ -202,9 +202,9 @@ __global__ __launch_bounds__(64) void k_ale_vdiffm(const DevView *__restrict__ V
   const size_t np = V.nplane, mns = isv ? c - V.ni : c - 1;
   const int kk = V.kk;
   const double cc = GRAV * GRAV * V.P.delt1 / (ALPHA0 * ALPHA0);
-  const double *dp = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np, *kv = V.f[F_kvisc_m];
-  double *x = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
-  double *gam = WK(V, isv ? 1 : 0);
+  gcd_t dp = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np, kv = V.f[F_kvisc_m];
+  gd_t x = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
+  gd_t gam = WK(V, isv ? 1 : 0);
   // fp(k) = nuv(k) * fpbase(k) is formed once per level and carried to the next one (the reference forms it as fp(k+1) at level k
   // and again as fp(k) at level k+1: the same product); the next four levels' inputs are loaded ahead
   auto fpv = [&](double kva, double kvb, double dpa, double dpb) {
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(64) void k_ale_forcing(const DevView *__restrict__ 
   // cbra1 = 2**(1/3), cbra2 = cbra1*cbra1/12 as the reference's compiler folds them (:56-57)
   const double cbra1 = __longlong_as_double(0x3FF428A2F98D728BLL), cbra2 = __longlong_as_double(0x3FC0EEA9C37E497ELL);
   const double cpi = 1. / SPCIFH, gaa = GRAV * ALPHA0 * ALPHA0;
-  const double *dp = V.f[F_dp] + (size_t)nn * np, *p = V.f[F_p];
-  double *tsw = V.f[F_t_sw_nonloc], *sbr = V.f[F_s_br_nonloc], *buoyfl = V.f[F_buoyfl];
+  gcd_t dp = V.f[F_dp] + (size_t)nn * np, p = V.f[F_p];
+  gd_t tsw = V.f[F_t_sw_nonloc], sbr = V.f[F_s_br_nonloc], buoyfl = V.f[F_buoyfl];
   {                                                                                    // :66-107 shortwave
     const double pmax = swamxd * ONEM;
     const double lei1 = 1. / (V.f[F_swal1][c] * ONEM), lei2 = 1. / (V.f[F_swal2][c] * ONEM);

@@ -73,8 +73,8 @@ __global__ void k_bt_pvtrop(const DevView *__restrict__ Vp, int n) {
   THREAD_IJ(V);
   const int ii = V.ii, jj = V.jj, ni = V.ni;
   if (j < 0 || j > jj + 1 || i < 0 || i > ii + 1) return;
-  const double *pb_p = V.f[F_pb_p];
-  const int *iu = V.m[I_iu], *iv = V.m[I_iv];
+  gcd_t pb_p = V.f[F_pb_p];
+  gci_t iu = V.m[I_iu], iv = V.m[I_iv];
   const double cq = V.f[F_corioq][c];
   bool have = false;
   double val = 0.;
@@ -131,8 +131,8 @@ __global__ void k_bt_cont(const DevView *__restrict__ Vp, BtArgs a) {
   if (j < a.j0 || j > a.j1 || i < a.i0 || i > a.i1 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane, oml = (size_t)(a.ml - 1) * np, onl = (size_t)(a.nl - 1) * np;
   const double wbaro = V.P.wbaro, dlt = V.P.dlt;
-  const double *ub = V.f[F_ubflx_t] + oml, *vb = V.f[F_vbflx_t] + oml;
-  double *pb = V.f[F_pb_t];
+  gcd_t ub = V.f[F_ubflx_t] + oml, vb = V.f[F_vbflx_t] + oml;
+  gd_t pb = V.f[F_pb_t];
   pb[c + onl] = (1. - wbaro) * pb[c + oml] + wbaro * pb[c + onl] -
                 (1. + wbaro) * dlt * (ub[c + 1] - ub[c] + vb[c + V.ni] - vb[c]) * V.f[F_scp2i][c];
 }
@@ -146,9 +146,9 @@ __global__ void k_bt_umom(const DevView *__restrict__ Vp, BtArgs a) {
   const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
   const int ni = V.ni;
   const double wbaro = V.P.wbaro, dlt = V.P.dlt, wo = a.wo, wm = a.wm, wn = a.wn;
-  double *ub = V.f[F_ubflx_t];
-  const double *vb = V.f[F_vbflx_t] + (size_t)(a.lv - 1) * np, *pb = V.f[F_pb_t] + onl;
-  const double *scvxi = V.f[F_scvxi], *pvo = V.f[F_pvtrop_o], *pvm = V.f[F_pvtrop] + om, *pvn = V.f[F_pvtrop] + on;
+  gd_t ub = V.f[F_ubflx_t];
+  gcd_t vb = V.f[F_vbflx_t] + (size_t)(a.lv - 1) * np, pb = V.f[F_pb_t] + onl;
+  gcd_t scvxi = V.f[F_scvxi], pvo = V.f[F_pvtrop_o], pvm = V.f[F_pvtrop] + om, pvn = V.f[F_pvtrop] + on;
   const double ubml = ub[c + oml], ubnl = ub[c + onl];
   V.f[F_ubflxs_t][c] = V.f[F_ubflxs_t][c] - wbaro * ubnl + (1. + wbaro) * ubml;
   double q;
@@ -181,9 +181,9 @@ __global__ void k_bt_vmom(const DevView *__restrict__ Vp, BtArgs a) {
   const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
   const int ni = V.ni;
   const double wbaro = V.P.wbaro, dlt = V.P.dlt, wo = a.wo, wm = a.wm, wn = a.wn;
-  double *vb = V.f[F_vbflx_t];
-  const double *ub = V.f[F_ubflx_t] + (size_t)(a.lv - 1) * np, *pb = V.f[F_pb_t] + onl;
-  const double *scuyi = V.f[F_scuyi], *pvo = V.f[F_pvtrop_o], *pvm = V.f[F_pvtrop] + om, *pvn = V.f[F_pvtrop] + on;
+  gd_t vb = V.f[F_vbflx_t];
+  gcd_t ub = V.f[F_ubflx_t] + (size_t)(a.lv - 1) * np, pb = V.f[F_pb_t] + onl;
+  gcd_t scuyi = V.f[F_scuyi], pvo = V.f[F_pvtrop_o], pvm = V.f[F_pvtrop] + om, pvn = V.f[F_pvtrop] + on;
   const double vbml = vb[c + oml], vbnl = vb[c + onl];
   V.f[F_vbflxs_t][c] = V.f[F_vbflxs_t][c] - wbaro * vbnl + (1. + wbaro) * vbml;
   double q;
@@ -215,8 +215,8 @@ __global__ void k_bt_epilogue(const DevView *__restrict__ Vp, int nb, int m, int
   const size_t np = V.nplane, om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const size_t oml = (size_t)(ml - 1) * np, onl = (size_t)(nl - 1) * np, o3 = 2 * np;
   const bool wp = V.m[I_ip][c], wu = V.m[I_iu][c], wv = V.m[I_iv][c];
-  const double *pbt = set ? V.f[F_pb_t2] : V.f[F_pb_t], *ubt = set ? V.f[F_ubflx_t2] : V.f[F_ubflx_t];
-  const double *vbt = set ? V.f[F_vbflx_t2] : V.f[F_vbflx_t];
+  gcd_t pbt = set ? V.f[F_pb_t2] : V.f[F_pb_t], ubt = set ? V.f[F_ubflx_t2] : V.f[F_ubflx_t];
+  gcd_t vbt = set ? V.f[F_vbflx_t2] : V.f[F_vbflx_t];
   const double us = V.f[F_ubflxs_t][c], vs = V.f[F_vbflxs_t][c];
   if (nb == 1 || nb == 3) {
     const size_t ol = nb == 1 ? om : on;

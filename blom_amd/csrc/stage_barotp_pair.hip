@@ -101,8 +101,8 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
   const bool inarr = act && gi >= 1 - NBDY && gi <= ii + NBDY && gj >= 1 - NBDY && gj <= jj + NBDY;
   const size_t np = V.nplane;
   const size_t c = inarr ? (size_t)IDX(V, gi, gj) : 0;
-  double *const b_pb[2] = {V.f[F_pb_t], V.f[F_pb_t2]}, *const b_ub[2] = {V.f[F_ubflx_t], V.f[F_ubflx_t2]};
-  double *const b_vb[2] = {V.f[F_vbflx_t], V.f[F_vbflx_t2]};
+  const gd_t b_pb[2] = {V.f[F_pb_t], V.f[F_pb_t2]}, b_ub[2] = {V.f[F_ubflx_t], V.f[F_ubflx_t2]};
+  const gd_t b_vb[2] = {V.f[F_vbflx_t], V.f[F_vbflx_t2]};
   int src = a.src;                       // buffer set that holds the current state
   const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
   // source of the state planes: the point itself, or -- single tile, halo point -- what xctilr

@@ -35,10 +35,10 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqf(const DevView *__restrict__ Vp
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
-  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
-  double *bfsqi = V.f[F_bfsqi] + c, *bfsql = V.f[F_bfsql] + c, *bfsqf = V.f[F_bfsqf] + c;
-  double *gam = WK(V, CM_GAM) + c;
+  gcd_t p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)nn * np, saln = V.f[F_saln] + c + (size_t)nn * np;
+  gcd_t dp = V.f[F_dp] + c + (size_t)nn * np;
+  gd_t bfsqi = V.f[F_bfsqi] + c, bfsql = V.f[F_bfsql] + c, bfsqf = V.f[F_bfsqf] + c;
+  gd_t gam = WK(V, CM_GAM) + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]          /* Fortran level k */
   const double b1 = .5 * GRAV * GRAV * (eos::rho(L(p, 2), L(temp, 2), L(saln, 2)) - eos::rho(L(p, 2), L(temp, 1), L(saln, 1))) /
                     (L(dp, 1) + L(dp, 2));
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(64) void k_cmn_phi(const DevView *__restrict__ Vp, 
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
-  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
-  double *phi = V.f[F_phi] + c;
+  gcd_t p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)nn * np, saln = V.f[F_saln] + c + (size_t)nn * np;
+  gcd_t dp = V.f[F_dp] + c + (size_t)nn * np;
+  gd_t phi = V.f[F_phi] + c;
   double ph = phi[(size_t)kk * np], plo = p[(size_t)kk * np];
   for (int k0 = kk - 1; k0 >= 0; k0 -= COLUMN_U) {             // COLUMN_U levels' loads in flight (blomgpu_internal.h)
     double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U];
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ V
           : (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 2 || !V.m[I_iu][c])) return;
   const size_t np = V.nplane, a_ = isv ? c - V.ni : c - 1, b_ = c;      // scalar points (i-1,j)|(i,j-1) and (i,j)
   const int kk = V.kk;
-  const double *p = V.f[F_p], *phi = V.f[F_phi], *bf = V.f[F_bfsqf];
-  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
-  double *nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c, *nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
+  gcd_t p = V.f[F_p], phi = V.f[F_phi], bf = V.f[F_bfsqf];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np, dp = V.f[F_dp] + (size_t)nn * np;
+  gd_t nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c, nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
   const double sci = (isv ? V.f[F_scvyi] : V.f[F_scuxi])[c];
 #define A(f, x, k) (f)[(x) + (size_t)((k)-1) * np]
 #define O(f, k) (f)[(size_t)((k)-1) * np]
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(64) void k_cmn_z(const DevView *__restrict__ Vp, in
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)mm * np, *saln = V.f[F_saln] + c + (size_t)mm * np;
-  const double *dp = V.f[F_dp] + c + (size_t)mm * np;
-  double *z = V.f[F_z] + c, *dz = V.f[F_dz] + c;
+  gcd_t p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)mm * np, saln = V.f[F_saln] + c + (size_t)mm * np;
+  gcd_t dp = V.f[F_dp] + c + (size_t)mm * np;
+  gd_t z = V.f[F_z] + c, dz = V.f[F_dz] + c;
   double zlo = -V.f[F_phi][c + (size_t)kk * np] / GRAV, plo = p[(size_t)kk * np];
   z[(size_t)kk * np] = zlo;
   for (int k0 = kk - 1; k0 >= 0; k0 -= COLUMN_U) {             // COLUMN_U levels' loads in flight (blomgpu_internal.h)
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqf_ale(const DevView *__restrict_
   if (j < -1 || j > V.jj + 2 || i < -1 || i > V.ii + 2 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *__restrict__ p = V.f[F_p] + c, *__restrict__ temp = V.f[F_temp] + c + (size_t)nn * np, *__restrict__ saln = V.f[F_saln] + c + (size_t)nn * np;
-  double *__restrict__ bfsqi = V.f[F_bfsqi] + c, *__restrict__ bfsql = V.f[F_bfsql] + c, *__restrict__ bfsqf = V.f[F_bfsqf] + c;
-  double *__restrict__ gam = WK(V, CM_GAM) + c;
+  gcd_t __restrict__ p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)nn * np, saln = V.f[F_saln] + c + (size_t)nn * np;
+  gd_t __restrict__ bfsqi = V.f[F_bfsqi] + c, bfsql = V.f[F_bfsql] + c, bfsqf = V.f[F_bfsqf] + c;
+  gd_t __restrict__ gam = WK(V, CM_GAM) + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]
   const double sls2 = SLS0 * SLS0, pbot = L(p, kk + 1);
   double pk = L(p, 2);                                             // p(k) of the level being worked on
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqi_ale(const DevView *__restrict_
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
-  double *bfsqi = V.f[F_bfsqi] + c;
+  gcd_t p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)nn * np, saln = V.f[F_saln] + c + (size_t)nn * np;
+  gd_t bfsqi = V.f[F_bfsqi] + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]
   const double pbot = L(p, kk + 1);
   // the level above travels in registers (bfsqi(1) = bfsqmn while the loop runs), the next four levels' p, T, S are loaded ahead
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(64) void k_cmn_nnslope_ale(const DevView *__restric
           : (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 2 || !V.m[I_iu][c])) return;
   const size_t np = V.nplane, a_ = isv ? c - V.ni : c - 1, b_ = c;
   const int kk = V.kk;
-  const double *p = V.f[F_p], *bf = V.f[F_bfsqf];
-  const double *nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c;
-  double *nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
+  gcd_t p = V.f[F_p], bf = V.f[F_bfsqf];
+  gcd_t nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c;
+  gd_t nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
   const double pba = p[a_ + (size_t)kk * np], pbb = p[b_ + (size_t)kk * np];
   int knnsl = 1;
   double last = 0.;
@@ -493,9 +493,9 @@ __global__ __launch_bounds__(64) void k_cmn_nslope_ale(const DevView *__restrict
           : (j < -1 || j > V.jj + 2 || i < 0 || i > V.ii + 2 || !V.m[I_iu][c])) return;
   const size_t np = V.nplane, a_ = isv ? c - V.ni : c - 1, b_ = c;
   const int kk = V.kk;
-  const double *p = V.f[F_p], *phi = V.f[F_phi], *bf = V.f[F_bfsqf];
-  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
-  double *nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c, *nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
+  gcd_t p = V.f[F_p], phi = V.f[F_phi], bf = V.f[F_bfsqf];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np, dp = V.f[F_dp] + (size_t)nn * np;
+  gd_t nslp = (isv ? V.f[F_nslpy] : V.f[F_nslpx]) + c, nnslp = (isv ? V.f[F_nnslpy] : V.f[F_nnslpx]) + c;
   const double sci = (isv ? V.f[F_scvyi] : V.f[F_scuxi])[c];
 #define A(f, x, k) (f)[(x) + (size_t)((k)-1) * np]
 #define O(f, k) (f)[(size_t)((k)-1) * np]
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(64) void k_cmn_mldl82(const DevView *__restrict__ V
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *z = V.f[F_z] + c, *dz = V.f[F_dz] + c;
-  const double *temp = V.f[F_temp] + c + (size_t)mm * np, *saln = V.f[F_saln] + c + (size_t)mm * np, *dp = V.f[F_dp] + c + (size_t)mm * np;
+  gcd_t p = V.f[F_p] + c, z = V.f[F_z] + c, dz = V.f[F_dz] + c;
+  gcd_t temp = V.f[F_temp] + c + (size_t)mm * np, saln = V.f[F_saln] + c + (size_t)mm * np, dp = V.f[F_dp] + c + (size_t)mm * np;
 #define L(a, k) (a)[(size_t)((k)-1) * np]
   int k = 2;
   double pup = L(p, 1) + .5 * L(dp, 1), zup = L(z, 1) + .5 * L(dz, 1), dbup = 0., mld, dpml;

@@ -33,10 +33,10 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
   const size_t np = V.nplane;
   const double epsilp = 1.e-12;
   // 1-based level k of the time level n: element c + (k - 1 + nn) * np
-  double *ttem = V.f[F_temp] + c + (size_t)nn * np - np, *ssal = V.f[F_saln] + c + (size_t)nn * np - np;
-  double *delp = V.f[F_dp] + c + (size_t)nn * np - np, *dens = V.f[F_sigma] + c + (size_t)nn * np - np;
-  const double *densr = V.f[F_sigmar] + c - np;
-  double *trc = V.f[F_trc] + c + (size_t)nn * np - np;      // tracer nt: + nt * 2 * kk * np
+  gd_t ttem = V.f[F_temp] + c + (size_t)nn * np - np, ssal = V.f[F_saln] + c + (size_t)nn * np - np;
+  gd_t delp = V.f[F_dp] + c + (size_t)nn * np - np, dens = V.f[F_sigma] + c + (size_t)nn * np - np;
+  gcd_t densr = V.f[F_sigmar] + c - np;
+  gd_t trc = V.f[F_trc] + c + (size_t)nn * np - np; // tracer nt: + nt * 2 * kk * np
   const size_t ntl = (size_t)2 * kk * np;
 #define TT(k) ttem[(size_t)(k) * np]
 #define SS(k) ssal[(size_t)(k) * np]
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_convec_column(const DevView *__restrict_
   if (k > kk) DP(2) = DP(2) + dps;
   else DP(k) = DP(k) + dps;
   int kfpl = k;
-  int *kfpla = V.m[I_kfpla] + c + (size_t)(n - 1) * np;
+  gi_t kfpla = V.m[I_kfpla] + c + (size_t)(n - 1) * np;
   const int kfplo = *kfpla;
   // The tracers' share of a mixing event, :118-122 / :160-164 / :213-217, :233-237 and the assignments that follow them: each tracer's
   // thickness-weighted sum over the levels ka..kb in the reference's order (after layer 2's term where the event starts there), times
@@ -238,10 +238,10 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restric
   if (!V.m[isv ? I_iv : I_iu][c]) return;
   const int kk = V.kk;
   const size_t np = V.nplane, cm = isv ? c - V.ni : c - 1;
-  double *vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np - np;       // 1-based level
-  const double *po = V.f[isv ? F_pv : F_pu] + c - np;                   // po(k), k = 2..kk+1; po(1) = 0
-  const double *p = V.f[F_p] - np;
-  double *un = WK(V, CV_UN + (isv ? 1 : 0)) + c - np;
+  gd_t vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np - np; // 1-based level
+  gcd_t po = V.f[isv ? F_pv : F_pu] + c - np; // po(k), k = 2..kk+1; po(1) = 0
+  gcd_t p = V.f[F_p] - np;
+  gd_t un = WK(V, CV_UN + (isv ? 1 : 0)) + c - np;
   const double pbot = po[(size_t)(kk + 1) * np];
   // The old layer ko that holds the new interface moves down with kn, usually by one: its velocity and lower interface
   // are kept in registers together with those of layer ko+1, re-loaded in the background when ko moves; the new
@@ -306,7 +306,7 @@ __global__ void k_convec_dpudpv(const DevView *__restrict__ Vp, int nn) {
   const size_t c = t_;
   const int k = by_;
   const size_t np = V.nplane, o0 = (size_t)k * np, o1 = (size_t)(k + 1) * np, ob = (size_t)V.kk * np;
-  const double *p = V.f[F_p];
+  gcd_t p = V.f[F_p];
   if (V.m[I_iu][c]) {
     const size_t w = c - 1;
     const double q = fmin2(p[c + ob], p[w + ob]);

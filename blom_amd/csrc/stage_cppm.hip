@@ -85,8 +85,8 @@ __global__ void k_cppm_init(const DevView *__restrict__ Vp) {
   for (int q = 0; q < 12; q++) { T.tmc0[c + q * np] = 0.; T.tmcl[c + q * np] = 0.; T.tmcr[c + q * np] = 0.; }
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
   const int sd = dir ? V.ni : 1;
-  const double *dxa = dir ? V.f[F_scpy] : V.f[F_scpx];
-  const int *ip = V.m[I_ip];
+  gcd_t dxa = dir ? V.f[F_scpy] : V.f[F_scpx];
+  gci_t ip = V.m[I_ip];
   const int m1 = ip[c - 2 * sd], m2 = ip[c - sd], m3 = ip[c], m4 = ip[c + sd];
   const double dx1 = dxa[c - 2 * sd], dx2 = dxa[c - sd], dx3 = dxa[c], dx4 = dxa[c + sd];
   const double c1_2 = 1. / 2., c2_3 = 2. / 3., c3_4 = 3. / 4., c1_4 = 1. / 4., c1_5 = 1. / 5., c1_6 = 1. / 6.,
@@ -209,7 +209,7 @@ __global__ void k_cppm_tag_convert(const DevView *__restrict__ Vp, int dir, int 
   const DevView &V = *Vp;
   THREAD_IJ(V);
   (void)i; (void)j;
-  int *st = dir ? V.m[I_cppm_stj] : V.m[I_cppm_sti];
+  gi_t st = dir ? V.m[I_cppm_stj] : V.m[I_cppm_sti];
   if (!back) V.f[F_util1][c] = (double)st[c];
   else st[c] = (int)lround(V.f[F_util1][c]);
 }
@@ -242,10 +242,10 @@ __global__ void k_cppm_arctic_init_swap(const DevView *__restrict__ Vp) {
     const bool beyond = j >= V.jj + 1 && j <= V.jj + NBDY && i >= 1 && i <= V.ii;
     if (!seam && !beyond) return;
   }
-  int *st = which ? V.m[I_cppm_stj] : V.m[I_cppm_sti];
+  gi_t st = which ? V.m[I_cppm_stj] : V.m[I_cppm_sti];
   st[c] = cppm_mirror_tag(st[c]);
-  double *h1 = V.f[which ? F_hevc1j : F_hevc1i], *h2 = V.f[which ? F_hevc2j : F_hevc2i];
-  double *h3 = V.f[which ? F_hevc3j : F_hevc3i], *h4 = V.f[which ? F_hevc4j : F_hevc4i];
+  gd_t h1 = V.f[which ? F_hevc1j : F_hevc1i], h2 = V.f[which ? F_hevc2j : F_hevc2i];
+  gd_t h3 = V.f[which ? F_hevc3j : F_hevc3i], h4 = V.f[which ? F_hevc4j : F_hevc4i];
   double t = h1[c]; h1[c] = h4[c]; h4[c] = t;
   t = h2[c]; h2[c] = h3[c]; h3[c] = t;
 }
@@ -318,7 +318,7 @@ __global__ void k_cppm_hm(const DevView *__restrict__ Vp, int nn, int second_pas
   const size_t np = V.nplane, ok = (size_t)k * np;
   double h = fmax2(0., V.f[F_dp][c + (size_t)(k + nn) * np]) + DPEPS;
   if (second_pass) {                       // divergence of the other direction's Courant number, :1501-1509
-    const double *ca2 = (DIR ? V.f[F_cau] : V.f[F_cav]) + ok;
+    gcd_t ca2 = (DIR ? V.f[F_cau] : V.f[F_cav]) + ok;
     h = h / (1. - (ca2[c + od] - ca2[c]) * V.f[F_scp2i][c]);
   }
   WK(V, W_HM)[c + ok] = h;
@@ -545,14 +545,14 @@ __global__ void k_cppm_parab(const DevView *__restrict__ Vp, int nn, int ntl) {
   const int k = by_;
   const size_t np = V.nplane, ok = (size_t)k * np;
   const CppmTab T = cppm_tab(V, DIR);
-  const double *hmv = WK(V, W_HM) + ok;
+  gcd_t hmv = WK(V, W_HM) + ok;
   const double hm0 = hmv[c];
   double hel0, her0;
   // thickness factors of the tracer parabolas (FC) at s-1, s, s+1; for 'partial' they are constants
   double hf2m[3], hf2l[3], hf2r[3], d2mv[3];
   double hf1m = 6., hf1l = -4., hf1r = -2.;
   if (FC) {
-    const double *helv = V.f[F_hel_3d] + ok, *herv = V.f[F_her_3d] + ok;
+    gcd_t helv = V.f[F_hel_3d] + ok, herv = V.f[F_her_3d] + ok;
     hel0 = helv[c];
     her0 = herv[c];
 #pragma unroll
@@ -670,8 +670,8 @@ __global__ void k_cppm_flux(const DevView *__restrict__ Vp, int n, int mm, int n
   const double c1_2 = 1. / 2., c1_3 = 1. / 3., c1_4 = 1. / 4., c1_5 = 1. / 5.;
   const double ca = (DIR ? V.f[F_cav] : V.f[F_cau])[c + ok];
   const double db = (DIR ? V.f[F_pbv] : V.f[F_pbu])[c + (size_t)(n - 1) * np];
-  const double *ai = V.f[F_scp2i], *p = V.f[F_p];
-  const double *hpc0 = WK(V, W_HPC0) + ok, *hpc1 = WK(V, W_HPC1) + ok, *hpc2 = WK(V, W_HPC2) + ok;
+  gcd_t ai = V.f[F_scp2i], p = V.f[F_p];
+  gcd_t hpc0 = WK(V, W_HPC0) + ok, hpc1 = WK(V, W_HPC1) + ok, hpc2 = WK(V, W_HPC2) + ok;
   double hf, p0, p1, p2;
   size_t up;
   if (ca < 0.) {
@@ -712,8 +712,8 @@ __global__ void k_cppm_flux(const DevView *__restrict__ Vp, int n, int mm, int n
     }
   }
   WK(V, W_HF)[c + ok] = hf;
-  double *mflx = DIR ? V.f[F_vflx] : V.f[F_uflx], *tflx = DIR ? V.f[F_vtflx] : V.f[F_utflx];
-  double *sflx = DIR ? V.f[F_vsflx] : V.f[F_usflx];
+  gd_t mflx = DIR ? V.f[F_vflx] : V.f[F_uflx], tflx = DIR ? V.f[F_vtflx] : V.f[F_utflx];
+  gd_t sflx = DIR ? V.f[F_vsflx] : V.f[F_usflx];
   mflx[c + okm] = mflx[c + okm] + hf;
   for (int nt = 0; nt < ntl; nt++) {
     const double htf = (p0 * WK(V, W_TPC0(ntl) + nt)[up + ok] + p1 * WK(V, W_TPC1(ntl) + nt)[up + ok] +
@@ -735,12 +735,12 @@ __global__ void k_cppm_update(const DevView *__restrict__ Vp, int nn, int ntl) {
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np;
   const double ai = V.f[F_scp2i][c];
   const double ho = fmax2(0., V.f[F_dp][c + okn]) + DPEPS;
-  const double *hf = WK(V, W_HF) + ok;
+  gcd_t hf = WK(V, W_HF) + ok;
   const double hn = ho - (hf[c + sd] - hf[c]) * ai;
   const double hni = 1. / hn;
   for (int nt = 0; nt < ntl; nt++) {
     double *tm = cppm_tracer(V, nt, k, nn);
-    const double *htf = WK(V, W_HTF(ntl) + nt) + ok;
+    gcd_t htf = WK(V, W_HTF(ntl) + nt) + ok;
     tm[c] = (ho * tm[c] - (htf[c + sd] - htf[c]) * ai) * hni;
   }
   V.f[F_dp][c + okn] = fmax2(0., hn - DPEPS);

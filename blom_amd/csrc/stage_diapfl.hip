@@ -98,9 +98,9 @@ __global__ void k_diapfl_momentum(const DevView *__restrict__ Vp, int nn) {
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t np = V.nplane, mns = isv ? c - V.ni : c - 1;
   const int kk = V.kk, sb = isv ? U_NSLOT : 0;
-  double *vel = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
-  const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  const double *p = V.f[F_p], *fpug = V.f[F_fpug], *fplg = V.f[F_fplg];
+  gd_t vel = (isv ? V.f[F_v] : V.f[F_u]) + (size_t)nn * np;
+  gcd_t dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gcd_t p = V.f[F_p], fpug = V.f[F_fpug], fplg = V.f[F_fplg];
 #define LV(a, k) (a)[c + (size_t)((k)-1) * np]
   const int kmin = min(V.m[I_kming][mns], V.m[I_kming][c]);
   int kmax = 1;
@@ -193,7 +193,7 @@ __global__ void k_diapfl_dpudpv(const DevView *__restrict__ Vp, int nn) {
   THREAD_IJ(V);
   const int k = by_;
   const size_t np = V.nplane, o0 = (size_t)k * np, o1 = (size_t)(k + 1) * np, ob = (size_t)V.kk * np;
-  const double *p = V.f[F_p];
+  gcd_t p = V.f[F_p];
   if (V.m[I_iu][c] && j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1) {
     const size_t w = c - 1;
     const double q = fmin2(p[c + ob], p[w + ob]);

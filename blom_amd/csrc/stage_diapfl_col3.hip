@@ -62,12 +62,13 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
   const Params P = V.P;        // by value: the equation-of-state coefficients stay in registers across the stores
   const double dsgmnr = .1, fcmxr = .25, dsgcr0 = .25, dfeps = 1.e-12, gbbl = .2, kappa = .4, ustmin = .0001;
   const double cc = GRAV * GRAV * P.delt1 / (ALPHA0 * ALPHA0);                       // :95
-  const double *__restrict__ sigr = V.f[F_sigmar];
-  double *__restrict__ wb = V.wk + (size_t)blockIdx.x * (kk + 1) * WNS * 64 + threadIdx.x;
-  double *__restrict__ temp = V.f[F_temp] + (size_t)nn * np, *__restrict__ saln = V.f[F_saln] + (size_t)nn * np;
-  double *__restrict__ dp = V.f[F_dp] + (size_t)nn * np, *__restrict__ sigma = V.f[F_sigma] + (size_t)nn * np;
-  double *__restrict__ trc = V.f[F_trc] + (size_t)nn * np, *__restrict__ nu = V.f[F_difdia];
-  double *__restrict__ fpug = V.f[F_fpug], *__restrict__ fplg = V.f[F_fplg];
+  // (address-space typed: blomgpu_internal.h, PtrTable)
+  gcd_t __restrict__ sigr = V.f[F_sigmar];
+  gd_t __restrict__ wb = global_ptr(V.wk) + (size_t)blockIdx.x * (kk + 1) * WNS * 64 + threadIdx.x;
+  gd_t __restrict__ temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
+  gd_t __restrict__ dp = V.f[F_dp] + (size_t)nn * np, sigma = V.f[F_sigma] + (size_t)nn * np;
+  gd_t __restrict__ trc = V.f[F_trc] + (size_t)nn * np, nu = V.f[F_difdia];
+  gd_t __restrict__ fpug = V.f[F_fpug], fplg = V.f[F_fplg];
 
   int kmax = 1;                                                                      // :139-143
   for (int k0 = 2; k0 <= kk; k0 += 2 * DU) {

@@ -40,13 +40,13 @@ __global__ void k_niw_uv(const DevView *__restrict__ Vp, int m, int mm) {
   const size_t np = V.nplane, om = (size_t)(m - 1) * np;
   const int mmm = (m - 1) * 2;
   const double delt1 = V.P.delt1, dlt = V.P.dlt, ipfac = 2., cori10 = 2.5256e-5;
-  const double *coriop = V.f[F_coriop];
+  gcd_t coriop = V.f[F_coriop];
   if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1 && V.m[I_iu][c]) {
     const double ubt = V.f[F_ubflxs_p][c + om] * dlt / (delt1 * V.f[F_scuy][c] * V.f[F_pbu][c + om]);
     const double uml1t = V.f[F_u][c + (size_t)mm * np] + ubt;
     const double uml2t = V.f[F_u][c + (size_t)(1 + mm) * np] + ubt;
     const double q = delt1 * fmax2(cori10, fabs(.5 * (coriop[c - 1] + coriop[c]))) / (ipfac * 2. * PI_BLOM);
-    double *res = V.f[F_umlres] + c, *ml = V.f[F_uml] + c;
+    gd_t res = V.f[F_umlres] + c, ml = V.f[F_uml] + c;
     double r1 = res[0] + uml1t;
     const double uml1a = r1 * q;
     res[0] = r1 * (1. - q);
@@ -64,7 +64,7 @@ __global__ void k_niw_uv(const DevView *__restrict__ Vp, int m, int mm) {
     const double vml1t = V.f[F_v][c + (size_t)mm * np] + vbt;
     const double vml2t = V.f[F_v][c + (size_t)(1 + mm) * np] + vbt;
     const double q = delt1 * fmax2(cori10, fabs(.5 * (coriop[c - V.ni] + coriop[c]))) / (ipfac * 2. * PI_BLOM);
-    double *res = V.f[F_vmlres] + c, *ml = V.f[F_vml] + c;
+    gd_t res = V.f[F_vmlres] + c, ml = V.f[F_vml] + c;
     double r1 = res[0] + vml1t;
     const double vml1a = r1 * q;
     res[0] = r1 * (1. - q);
@@ -84,8 +84,8 @@ __global__ void k_niw_idkedt(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
-  const int *iu = V.m[I_iu], *iv = V.m[I_iv];
-  const double *u1 = V.f[F_util1], *u2 = V.f[F_util2];
+  gci_t iu = V.m[I_iu], iv = V.m[I_iv];
+  gcd_t u1 = V.f[F_util1], u2 = V.f[F_util2];
   const int ni = V.ni;
   const int su = iu[c] + iu[c + 1], sv = iv[c] + iv[c + ni];
   V.f[F_idkedt][c] = fabs((u1[c] * iu[c] + u1[c + 1] * iu[c + 1]) / (su > 1 ? su : 1) + (u2[c] * iv[c] + u2[c + ni] * iv[c + ni]) / (sv > 1 ? sv : 1)) *

@@ -130,11 +130,11 @@ __global__ __launch_bounds__(64) void k_dfi_kmax_kfil(const DevView *__restrict_
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1) return;
-  int *kmax = V.m[I_dfe_kmax], *kfil = V.m[I_dfe_kfil];
+  gi_t kmax = V.m[I_dfe_kmax], kfil = V.m[I_dfe_kfil];
   if (!V.m[I_ip][c]) { kmax[c] = 0; return; }
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *dp = V.f[F_dp] + c + (size_t)nn * np;
+  gcd_t dp = V.f[F_dp] + c + (size_t)nn * np;
   int km = 1;
   for (int k0 = 3; k0 <= kk; k0 += COLUMN_U) {
     double a[COLUMN_U];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void k_dfi_kmax_kfil(const DevView *__restrict_
   int r;
   if (kf >= km) r = kf + 1;
   else {
-    const double *sr = V.f[F_sigmar] + c;
+    gcd_t sr = V.f[F_sigmar] + c;
     if (V.f[F_sigma][c + (size_t)(kf - 1 + nn) * np] < .5 * (sr[(size_t)(kf - 1) * np] + sr[(size_t)kf * np])) r = kf + 1;
     else r = kf + 2;
   }
@@ -161,7 +161,7 @@ __global__ void k_dfi_kfil_util(const DevView *__restrict__ Vp, int back) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (!V.m[I_ip][c]) return;
-  int *kfil = V.m[I_dfe_kfil];
+  gi_t kfil = V.m[I_dfe_kfil];
   if (!back) {
     if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii) V.f[F_util1][c] = (double)kfil[c];
   } else if (j >= 0 && j <= V.jj + 1 && i >= 0 && i <= V.ii + 1)
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(64) void k_dfi_uv2(const DevView *__restrict__ Vp, 
   if (isv ? (j < 1 || j > V.jj + 1 || i < 1 || i > V.ii) : (j < 1 || j > V.jj || i < 1 || i > V.ii + 1)) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  double *d2 = WK(V, isv ? W_DV2 : W_DU2) + c;
-  int *msk = V.m[isv ? I_mskv : I_msku] + c;
+  gd_t d2 = WK(V, isv ? W_DV2 : W_DU2) + c;
+  gi_t msk = V.m[isv ? I_mskv : I_msku] + c;
   if (!V.m[isv ? I_iv : I_iu][c]) {
     for (int k = 0; k < kk; k++) { d2[(size_t)k * np] = 0.; msk[(size_t)k * np] = 0; }
     return;
   }
-  const double *dpz = V.f[isv ? F_dpv : F_dpu] + c + (size_t)nn * np, *vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np;
-  const int *kfil = V.m[I_dfe_kfil];
+  gcd_t dpz = V.f[isv ? F_dpv : F_dpu] + c + (size_t)nn * np, vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np;
+  gci_t kfil = V.m[I_dfe_kfil];
   const int ka = kfil[isv ? c - V.ni : c - 1], kb = kfil[c];
   const int kf = isv ? (ka > kb ? ka : kb) : (ka < kb ? ka : kb);       // max for v (:436), min for u (:482)
   int klpl = 1, kfpl = kk + 1;
@@ -249,7 +249,7 @@ __global__ void k_dfi_common(const DevView *__restrict__ Vp, int nn) {
   const int k1 = kf > 4 ? kf : 4, k2 = km < kk ? km : kk;
   if (k < k1 || k > k2) return;
   const size_t np = V.nplane, o = (size_t)(k - 1) * np + c;
-  const double *p = V.f[F_p], *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
+  gcd_t p = V.f[F_p], temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
   // the density jump across the interface under level kq (< km), :520-531: both densities at the interface's pressure
   auto jump = [&](int kq) {
     const size_t oq = (size_t)(kq - 1) * np + c, o1 = (size_t)(kq < kk ? kq : kk - 1) * np + c;
@@ -266,7 +266,7 @@ __global__ void k_dfi_common(const DevView *__restrict__ Vp, int nn) {
     dr = tup;
   V.f[F_drhol][o] = dr;
   const int mu0 = V.m[I_msku][o], mu1 = V.m[I_msku][o + 1], mv0 = V.m[I_mskv][o], mv1 = V.m[I_mskv][o + ni];
-  const double *du2 = WK(V, W_DU2), *dv2 = WK(V, W_DV2);
+  gcd_t du2 = WK(V, W_DU2), dv2 = WK(V, W_DV2);
   const double d2 = ((double)mu0 * du2[o] + (double)mu1 * du2[o + 1]) / (double)(mu0 + mu1 > 1 ? mu0 + mu1 : 1) +
                     ((double)mv0 * dv2[o] + (double)mv1 * dv2[o + ni]) / (double)(mv0 + mv1 > 1 ? mv0 + mv1 : 1);
   V.f[F_du2l][o] = d2;
@@ -291,10 +291,10 @@ __global__ __launch_bounds__(64) void k_dfi_vert_a(const DevView *__restrict__ V
   const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *dp = V.f[F_dp] + c + (size_t)nn * np;
-  const double *drhol = V.f[F_drhol] + c, *du2l = V.f[F_du2l] + c, *difdia = V.f[F_difdia] + c;
-  double *bvfsq = WK(V, W_BVFSQ) + c, *bvf = WK(V, W_BVF) + c, *ex = V.f[F_wkp1] + c;
-  double *Buoy = V.f[F_Buoy] + c, *Shear2 = V.f[F_Shear2] + c, *Prod = V.f[F_Prod] + c;
+  gcd_t p = V.f[F_p] + c, dp = V.f[F_dp] + c + (size_t)nn * np;
+  gcd_t drhol = V.f[F_drhol] + c, du2l = V.f[F_du2l] + c, difdia = V.f[F_difdia] + c;
+  gd_t bvfsq = WK(V, W_BVFSQ) + c, bvf = WK(V, W_BVF) + c, ex = V.f[F_wkp1] + c;
+  gd_t Buoy = V.f[F_Buoy] + c, Shear2 = V.f[F_Shear2] + c, Prod = V.f[F_Prod] + c;
   const double pbot = p[(size_t)kk * np], q = V.f[F_tdmls][c];
   double bvfbot = 0., dps = 0.;
   if (km - kf >= 1) {
@@ -360,7 +360,7 @@ __global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
   const int kk = V.kk;
   const Params &P = V.P;
   const TkeC &T = D.T;
-  const double *p = V.f[F_p];
+  gcd_t p = V.f[F_p];
   const double pk = p[o], pk1 = p[o + np], pbot = p[c + (size_t)kk * np];
   const double dpk = V.f[F_dp][o + (size_t)nn * np], b2 = WK(V, W_BVFSQ)[o];
   double nub;
@@ -387,8 +387,8 @@ __global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
     } else
       nus = 0.;
   } else {                                                                        // the one-equation closure, :2776-2921
-    double *tke = V.f[F_trc] + o + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
-    double *gls = V.f[F_trc] + o + ((size_t)nn + (size_t)(D.igls - 1) * 2 * kk) * np;
+    gd_t tke = V.f[F_trc] + o + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
+    gd_t gls = V.f[F_trc] + o + ((size_t)nn + (size_t)(D.igls - 1) * 2 * kk) * np;
     const double delt1 = P.delt1;
     const double gls_c3 = b2 > 0. ? GLS_C3MINUS : GLS_C3PLUS;
     const double prod = V.f[F_Prod][o], buoy = V.f[F_Buoy][o];
@@ -441,7 +441,7 @@ __global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
   double nut;                                                                      // tidally driven mixing, :2924-2937
   {
     const double q = V.f[F_tdmls][c];
-    const double *ex = V.f[F_wkp1];
+    gcd_t ex = V.f[F_wkp1];
     const double eb = WK2(V, S2_EXPB)[c];
     double vsf;
     if (dpk < EPSILP) vsf = ex[o] / (q * (eb - 1.));
@@ -468,9 +468,9 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
   const bool any = km - kf >= 1;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  const double *p = V.f[F_p] + c, *dp = V.f[F_dp] + c + (size_t)nn * np;
-  double *difdia = V.f[F_difdia] + c, *Lsc = V.f[F_L_scale] + c;
-  const double *bvfsq = WK(V, W_BVFSQ) + c, *nubw = WK(V, W_NUB) + c;
+  gcd_t p = V.f[F_p] + c, dp = V.f[F_dp] + c + (size_t)nn * np;
+  gd_t difdia = V.f[F_difdia] + c, Lsc = V.f[F_L_scale] + c;
+  gcd_t bvfsq = WK(V, W_BVFSQ) + c, nubw = WK(V, W_NUB) + c;
   double *tke = nullptr, *gls = nullptr;
   if (D.use_tke) {
     tke = V.f[F_trc] + c + ((size_t)nn + (size_t)(D.itke - 1) * 2 * kk) * np;
@@ -605,16 +605,16 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   const size_t np = V.nplane, on = (size_t)(n - 1) * np;
   const int kk = V.kk, ni = V.ni;
   const Params &P = V.P;
-  const int *kmaxa = V.m[I_dfe_kmax];
+  gci_t kmaxa = V.m[I_dfe_kmax];
   const int kf = V.m[I_dfe_kfil][c], km = kmaxa[c];
   const bool any = km - kf >= 1;
-  const double *p = V.f[F_p] + c, *temp = V.f[F_temp] + c + (size_t)nn * np, *saln = V.f[F_saln] + c + (size_t)nn * np;
-  double *difint = V.f[F_difint] + c, *difiso = V.f[F_difiso] + c;
-  double *anisok = WK(V, W_ANISOK) + c;
-  const double *rig = V.f[F_rig] + c;
-  const double *u = V.f[F_u] + c + (size_t)nn * np, *v = V.f[F_v] + c + (size_t)nn * np;
-  const double *dpu = V.f[F_dpu] + c + (size_t)nn * np, *dpv = V.f[F_dpv] + c + (size_t)nn * np;
-  const int *msku = V.m[I_msku] + c, *mskv = V.m[I_mskv] + c;
+  gcd_t p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)nn * np, saln = V.f[F_saln] + c + (size_t)nn * np;
+  gd_t difint = V.f[F_difint] + c, difiso = V.f[F_difiso] + c;
+  gd_t anisok = WK(V, W_ANISOK) + c;
+  gcd_t rig = V.f[F_rig] + c;
+  gcd_t u = V.f[F_u] + c + (size_t)nn * np, v = V.f[F_v] + c + (size_t)nn * np;
+  gcd_t dpu = V.f[F_dpu] + c + (size_t)nn * np, dpv = V.f[F_dpv] + c + (size_t)nn * np;
+  gci_t msku = V.m[I_msku] + c, mskv = V.m[I_mskv] + c;
 #define PL(k) p[(size_t)((k) - 1) * np]
   const double pbot = PL(kk + 1);
   // first baroclinic Rossby radius (WKB, Chelton et al. 1998), :2065-2107
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
         }
       }
     } else {
-      const double *nx = V.f[F_nnslpx] + c, *ny = V.f[F_nnslpy] + c;
+      gcd_t nx = V.f[F_nnslpx] + c, ny = V.f[F_nnslpy] + c;
       const int kmw = kmaxa[c - 1], kme = kmaxa[c + 1], kms = kmaxa[c - ni], kmn = kmaxa[c + ni];
       // the squared large scale slope x buoyancy frequency at interface kq from the four values around the point, :2190-2205 / :2212-2227
       auto slope2 = [&](int kq, double x0, double x1, double y0, double y1) {
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
     dfints = dfints / dps;
     double esfac;
     if (sa) {
-      const int *ip = V.m[I_ip];
+      gci_t ip = V.m[I_ip];
       const size_t o2 = np;
       auto mlvel = [&](const double *w, const double *dw, size_t off) {   // thickness weighted velocity of the two mixed layer layers
         return (w[off] * dw[off] + w[off + o2] * dw[off + o2]) / (dw[off] + dw[off + o2]);
@@ -925,8 +925,8 @@ __global__ void k_dfi_smooth(const DevView *__restrict__ Vp, int nn) {
   if (j < 1 - mrg || j > V.jj + mrg || i < 1 - mrg || i > V.ii + mrg || !V.m[I_ip][c]) return;
   const int k = by_, ni = V.ni;
   const size_t np = V.nplane, o = (size_t)k * np, okn = (size_t)(k + nn) * np;
-  const int *ip = V.m[I_ip];
-  const double *dp = V.f[F_dp] + okn, *u1 = WK(V, W_SM1) + o, *u2 = WK(V, W_SM2) + o;
+  gci_t ip = V.m[I_ip];
+  gcd_t dp = V.f[F_dp] + okn, u1 = WK(V, W_SM1) + o, u2 = WK(V, W_SM2) + o;
   const double ws = .125 * (double)ip[c - ni] * fmin2(ONEM, dp[c - ni]) / ONEM;
   const double ww = .125 * (double)ip[c - 1] * fmin2(ONEM, dp[c - 1]) / ONEM;
   const double we = .125 * (double)ip[c + 1] * fmin2(ONEM, dp[c + 1]) / ONEM;

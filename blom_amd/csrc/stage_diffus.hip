@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
   const int x0 = (bx_ % ntx) * DT_TW, y0 = (bx_ / ntx) * DT_TH;
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np;
-  const double *f_dp = V.f[F_dp] + okn, *f_di = V.f[F_difiso] + ok, *f_s = WK(V, N_S) + ok, *f_t = WK(V, N_T) + ok;
+  gcd_t f_dp = V.f[F_dp] + okn, f_di = V.f[F_difiso] + ok, f_s = WK(V, N_S) + ok, f_t = WK(V, N_T) + ok;
 
   // ---- phase 0 ---------------------------------------------------------------------------------------------------
   double sv[2][4];
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
   const bool live = x < ni && y < nj && j >= -1 && j <= V.jj + 2 && i >= -1 && i <= V.ii + 2;
   const size_t c = live ? (size_t)y * ni + x : (size_t)ni + 1, e = c + 1, nb = c + ni;
   const int q = (ly + 1) * DT_LW + lx + 1;
-  const int *mpk = V.m[I_mpack];
+  gci_t mpk = V.m[I_mpack];
   const int mp_c = live ? mpk[c] : 0, mp_e = live ? mpk[e] : 0, mp_n = live ? mpk[nb] : 0;
   // the reference's loop ranges: u-faces j = 0..jj+1, i = 0..ii+2; v-faces j = 0..jj+2, i = 0..ii+1; cells 0..ii+1, 0..jj+1
   const bool inner = live && i >= 0 && j >= 0;
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
   const double yc = V.f[F_scuy][c], xic = V.f[F_scuxi][c], ye = V.f[F_scuy][e], xie = V.f[F_scuxi][e];
   const double vxc = V.f[F_scvx][c], vyic = V.f[F_scvyi][c], vxn = V.f[F_scvx][nb], vyin = V.f[F_scvyi][nb];
   const double s2 = V.f[F_scp2][c];
-  double *o_us = V.f[F_usflx] + c + okm, *o_ut = V.f[F_utflx] + c + okm, *o_vs = V.f[F_vsflx] + c + okm, *o_vt = V.f[F_vtflx] + c + okm;
+  gd_t o_us = V.f[F_usflx] + c + okm, o_ut = V.f[F_utflx] + c + okm, o_vs = V.f[F_vsflx] + c + okm, o_vt = V.f[F_vtflx] + c + okm;
   const double us_o = *o_us, ut_o = *o_ut, vs_o = *o_vs, vt_o = *o_vt;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(DT_NT) k_diffus_tile(const DevView *__restrict
     for (int b = 0; b < DT_TB; b++) {
       const int nt = nt0 + b;
       if (nt >= ntr) break;
-      double *tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
+      gd_t tr = V.f[F_trc] + okn + (size_t)nt * 2 * V.kk * np;
       if (dif[b]) {
         const double *l_x = sc + (4 + b) * DT_LN;
         if (upd) {                                           // :99-104, :121-126, :147-155

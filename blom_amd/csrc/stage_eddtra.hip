@@ -39,14 +39,14 @@ __global__ void k_eddtra_gm(const DevView *__restrict__ Vp, int n, int mm, int n
   const size_t np = V.nplane, xb = c, xa = isv ? c - V.ni : c - 1;
   const int kk = V.kk, sb = isv ? G_NSLOT : 0;
   const double ffac = .0625, fface = .99 * ffac, eps = 1.e-14, delt1 = V.P.delt1;
-  double *mf = (isv ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
-  const double *nslp = isv ? V.f[F_nslpy] : V.f[F_nslpx], *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  const double *p = V.f[F_p], *dp = V.f[F_dp] + (size_t)nn * np, *difint = V.f[F_difint];
-  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
+  gd_t mf = (isv ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
+  gcd_t nslp = isv ? V.f[F_nslpy] : V.f[F_nslpx], dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gcd_t p = V.f[F_p], dp = V.f[F_dp] + (size_t)nn * np, difint = V.f[F_difint];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
 #define AT(a, x, k) (a)[(x) + (size_t)((k)-1) * np]
   // the column's private arrays mfl(kk+1), dlm, dlp, wavefront-major: level k of the 64 columns of a wavefront in three
   // consecutive rows of 64 doubles (one piece of memory per level instead of three that lie a field apart)
-  double *const wb = V.wk + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * 3) * 64 + threadIdx.x;
+  gd_t const wb = global_ptr(V.wk) + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * 3) * 64 + threadIdx.x;
   (void)sb;
 #define MFL(k) wb[((size_t)((k)-1) * 3 + 0) * 64]
 #define DLM(k) wb[((size_t)((k)-1) * 3 + 1) * 64]
@@ -270,7 +270,7 @@ __global__ void k_eddtra_intdif(const DevView *__restrict__ Vp, int mm, int nn) 
   const int k = by_ + 1, kk = V.kk, ni = V.ni;
   const size_t np = V.nplane;
   const double delt1 = V.P.delt1;
-  const double *dp = V.f[F_dp] + (size_t)nn * np, *p = V.f[F_p], *difint = V.f[F_difint], *scp2 = V.f[F_scp2];
+  gcd_t dp = V.f[F_dp] + (size_t)nn * np, p = V.f[F_p], difint = V.f[F_difint], scp2 = V.f[F_scp2];
   // q of interface k (4 <= k <= kk) between the scalar points xa and c
   auto qk = [&](int kq, size_t xa, double metric) -> double {
     const double flxhi = .125 * fmin2(AT(dp, xa, kq - 1) * scp2[xa], AT(dp, c, kq) * scp2[c]);
@@ -283,7 +283,7 @@ __global__ void k_eddtra_intdif(const DevView *__restrict__ Vp, int mm, int nn) 
     const size_t xa = comp ? c - ni : c - 1;
     // delt1*q*(dp)*scuy*scuxi: the two metric factors multiply left to right in the reference, so
     // they cannot be pre-multiplied; pass them through a two-step product instead
-    double *mf = (comp ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
+    gd_t mf = (comp ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
     const double m1 = comp ? V.f[F_scvx][c] : V.f[F_scuy][c], m2 = comp ? V.f[F_scvyi][c] : V.f[F_scuxi][c];
     auto qk2 = [&](int kq) -> double {
       const double flxhi = .125 * fmin2(AT(dp, xa, kq - 1) * scp2[xa], AT(dp, c, kq) * scp2[c]);
@@ -305,7 +305,7 @@ __global__ void k_eddtra_ts(const DevView *__restrict__ Vp, int mm) {
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
   const size_t np = V.nplane, o = c + (size_t)(by_ + mm) * np;
-  const double *temp = V.f[F_temp], *saln = V.f[F_saln];
+  gcd_t temp = V.f[F_temp], saln = V.f[F_saln];
   if (V.m[I_iu][c]) {
     const double f = V.f[F_umfltd][o];
     V.f[F_utfltd][o] = .5 * f * (temp[o - 1] + temp[o]);

@@ -73,7 +73,7 @@ __global__ void k_eda_mixed_layer(const DevView *__restrict__ Vp, int nn, EdaPar
   V.f[F_hml_tf][c] = hml_tf;
   V.f[F_hml_tfbnd][c] = hml_tfbnd;
   // vertically averaged mixed layer density, :1103-1123
-  const double *p = V.f[F_p], *dp = V.f[F_dp] + (size_t)nn * np, *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
+  gcd_t p = V.f[F_p], dp = V.f[F_dp] + (size_t)nn * np, temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
   const double p1 = p[c];
   const double pml = fmin2(p1 + hml_tfbnd * ONEM, p[c + (size_t)kk * np]);
   const double dpmli = 1. / (pml - p1);
@@ -116,14 +116,14 @@ __global__ void k_eda_column(const DevView *__restrict__ Vp, int n, int mm, int 
   const size_t np = V.nplane, xb = c, xa = isv ? c - V.ni : c - 1;
   const int kk = V.kk;
   const double ffac = .0625, fface = .99 * ffac, eps = 1.e-14, c5_21 = 5. / 21., delt1 = V.P.delt1;
-  double *__restrict__ mfgm = (isv ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
-  double *__restrict__ mfsm = (isv ? V.f[F_vmflsm] : V.f[F_umflsm]) + (size_t)mm * np;
-  const double *__restrict__ nslp = isv ? V.f[F_nslpy] : V.f[F_nslpx], *__restrict__ dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  const double *__restrict__ p = V.f[F_p], *__restrict__ dp = V.f[F_dp] + (size_t)nn * np, *__restrict__ difint = V.f[F_difint];
-  const double *hmlb = V.f[F_hml_tfbnd], *scp2 = V.f[F_scp2];
+  gd_t __restrict__ mfgm = (isv ? V.f[F_vmfltd] : V.f[F_umfltd]) + (size_t)mm * np;
+  gd_t __restrict__ mfsm = (isv ? V.f[F_vmflsm] : V.f[F_umflsm]) + (size_t)mm * np;
+  gcd_t __restrict__ nslp = isv ? V.f[F_nslpy] : V.f[F_nslpx], dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gcd_t __restrict__ p = V.f[F_p], dp = V.f[F_dp] + (size_t)nn * np, difint = V.f[F_difint];
+  gcd_t hmlb = V.f[F_hml_tfbnd], scp2 = V.f[F_scp2];
 #define AT(a, x, k) (a)[(x) + (size_t)((k)-1) * np]
 #define CLK(k, lo, hi) ((k) < (lo) ? (lo) : ((k) > (hi) ? (hi) : (k)))
-  double *__restrict__ const wb = V.wk + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * E_NARR) * 64 + threadIdx.x;
+  gd_t __restrict__ const wb = global_ptr(V.wk) + ((size_t)(by_ * gridDim.x + bx_) * (kk + 2) * E_NARR) * 64 + threadIdx.x;
 #define W(a, k) wb[((size_t)((k)-1) * E_NARR + (a)) * 64]
   const double mfleps = eps * EPSILP * (isv ? V.f[F_scv2] : V.f[F_scu2])[c];           // :1216
   const double et2mf = -GRAV * RHO0 * delt1 * (isv ? V.f[F_scvx] : V.f[F_scuy])[c];    // :1219
@@ -332,7 +332,7 @@ __global__ void k_eda_ts(const DevView *__restrict__ Vp, int mm) {
   THREAD_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
   const size_t np = V.nplane, o = c + (size_t)(by_ + mm) * np;
-  const double *temp = V.f[F_temp], *saln = V.f[F_saln];
+  gcd_t temp = V.f[F_temp], saln = V.f[F_saln];
   if (V.m[I_iu][c]) {
     const double fd = V.f[F_umfltd][o], fs = V.f[F_umflsm][o];
     double q = .5 * (temp[o - 1] + temp[o]);

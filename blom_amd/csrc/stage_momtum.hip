@@ -53,7 +53,7 @@ __global__ void k_mom_drag(const DevView *__restrict__ Vp, int n, int nn) {
   if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane, on = (size_t)(n - 1) * np, e = c + 1, nb = c + V.ni;
   const double thkbop = THKBOT * ONEM, tsfac = V.P.dlt / V.P.delt1;
-  const double *p = V.f[F_p];
+  gcd_t p = V.f[F_p];
   const double pbot = p[c + (size_t)V.kk * np];
   double u1 = 0., u2 = 0.;
   for (int k = 0; k < V.kk; k++) {
@@ -65,7 +65,7 @@ __global__ void k_mom_drag(const DevView *__restrict__ Vp, int n, int nn) {
   }
   V.f[F_util1][c] = u1;
   V.f[F_util2][c] = u2;
-  const double *ubf = V.f[F_ubflxs_p] + on, *vbf = V.f[F_vbflxs_p] + on, *pbu = V.f[F_pbu] + on, *pbv = V.f[F_pbv] + on;
+  gcd_t ubf = V.f[F_ubflxs_p] + on, vbf = V.f[F_vbflxs_p] + on, pbu = V.f[F_pbu] + on, pbv = V.f[F_pbv] + on;
   const double ubot = (ubf[c] / fmax2(EPSILPL, pbu[c] * V.f[F_scuy][c]) + ubf[e] / fmax2(EPSILPL, pbu[e] * V.f[F_scuy][e])) * tsfac +
                       u1 / thkbop;
   const double vbot = (vbf[c] / fmax2(EPSILPL, pbv[c] * V.f[F_scvx][c]) + vbf[nb] / fmax2(EPSILPL, pbv[nb] * V.f[F_scvx][nb])) * tsfac +
@@ -86,7 +86,7 @@ __global__ void k_mom_qplanes(const DevView *__restrict__ Vp, int m, int n) {
   (void)i; (void)j;
   const size_t np = V.nplane, om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const double tsfac = V.P.dlt / V.P.delt1;
-  double *q = WK2(V, S2_QUM);
+  gd_t q = WK2(V, S2_QUM);
   if (V.m[I_iu][c]) {
     const double sy = V.f[F_scuy][c];
     q[c] = V.f[F_ubflxs_p][c + om] * tsfac / (V.f[F_pbu][c + om] * sy);

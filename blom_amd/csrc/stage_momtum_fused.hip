@@ -29,14 +29,8 @@ enum { MF_VISU, MF_VISV, MF_UM, MF_UN, MF_VM, MF_VN, MF_NSLOT };
 // Field pointers come out of the DevView in memory, so the compiler cannot know their address space and would emit
 // flat loads -- which count on lgkmcnt as well as vmcnt, so that every LDS wait (and the wait in front of every
 // barrier) also drains the global loads in flight.  Cast to the global address space: global_load, vmcnt only.
-#ifdef BLOM_HOSTEMU
-#define GLOBAL_AS
-#else
-#define GLOBAL_AS __attribute__((address_space(1)))
-#endif
-typedef const double GLOBAL_AS *gcd_t;
-typedef double GLOBAL_AS *gd_t;
-typedef const int GLOBAL_AS *gci_t;
+// (gcd_t, gd_t, gci_t: blomgpu_internal.h -- since round 6 every kernel of the library gets its pointers that way)
+#define GLOBAL_AS BLOM_GAS
 #define GF(V, id) ((gcd_t)(V).f[id])
 
 // chunk-major work item of this workgroup; XCD x (blockIdx % 8) walks a contiguous eighth of the items so that the
@@ -92,7 +86,7 @@ __device__ inline void sto(gd_t b, unsigned o, double v) { *(gd_t)((gc_t)b + o) 
 #else
 #define CONST_AS __attribute__((address_space(4)))
 #endif
-#define GFV(id) ((gcd_t) * (double *const volatile CONST_AS *)&Vp->f[id])
+#define GFV(id) ((gcd_t) * (double *const volatile CONST_AS *)&Vp->f.p_[id])
 template <int BS>
 __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip) {
   const DevView &V = *Vp;
@@ -721,9 +715,9 @@ __global__ __launch_bounds__(64) void k_mom_column_from(const DevView *__restric
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t np = V.nplane;
   const int kk = V.kk;
-  double *u = isv ? V.f[F_v] : V.f[F_u];
-  const double *sm = WK(V, isv ? MF_VM : MF_UM), *sn = WK(V, isv ? MF_VN : MF_UN);
-  const double *dpu = isv ? V.f[F_dpv] : V.f[F_dpu], *dpuold = isv ? V.f[F_dpvold] : V.f[F_dpuold];
+  gd_t u = isv ? V.f[F_v] : V.f[F_u];
+  gcd_t sm = WK(V, isv ? MF_VM : MF_UM), sn = WK(V, isv ? MF_VN : MF_UN);
+  gcd_t dpu = isv ? V.f[F_dpv] : V.f[F_dpu], dpuold = isv ? V.f[F_dpvold] : V.f[F_dpuold];
   const double umax = (isv ? V.f[F_vmax] : V.f[F_umax])[c];
   const double ub = (isv ? V.f[F_vb] : V.f[F_ub])[c + (size_t)(m - 1) * np];
   const double wuv1 = V.P.wuv1, wuv2 = V.P.wuv2;
@@ -756,7 +750,7 @@ __global__ __launch_bounds__(64) void k_mom_column_from(const DevView *__restric
   }
   tot = tot / (isv ? V.f[F_pbv_p] : V.f[F_pbu_p])[c];
   double pacc = (isv ? V.f[F_pv] : V.f[F_pu])[c];
-  double *pun = (isv ? V.f[F_pv] : V.f[F_pu]) + c;
+  gd_t pun = (isv ? V.f[F_pv] : V.f[F_pu]) + c;
   for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
     double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U], f[COLUMN_U];
 #pragma unroll

@@ -103,7 +103,7 @@ __global__ void k_mxl_bg2_sig(const DevView *__restrict__ Vp, int nn) {
 __global__ void k_mxl_bg2_grad(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
-  const double *u1 = V.f[F_util1];
+  gcd_t u1 = V.f[F_util1];
   if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1 && V.m[I_iu][c]) {
     const double q = (u1[c] - u1[c - 1]) * V.f[F_scuxi][c];
     V.f[F_util2][c] = q * q;
@@ -119,8 +119,8 @@ __global__ void k_mxl_bg2_sum(const DevView *__restrict__ Vp) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
-  const int *ip = V.m[I_ip];
-  const double *u2 = V.f[F_util2], *u3 = V.f[F_util3];
+  gci_t ip = V.m[I_ip];
+  gcd_t u2 = V.f[F_util2], u3 = V.f[F_util3];
   const double slbg0 = 0.;
   double r;
   if (ip[c - 1] + ip[c + 1] == 2) r = .5 * (u2[c] + u2[c + 1]);
@@ -162,13 +162,13 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
   const Params P = V.P;
   const double delt1 = P.delt1;
   // 1-based level k of the time level n: element c + (k - 1 + nn) * np
-  double *ttem = V.f[F_temp] + c + (size_t)nn * np - np, *ssal = V.f[F_saln] + c + (size_t)nn * np - np;
-  double *delp = V.f[F_dp] + c + (size_t)nn * np - np, *dens = V.f[F_sigma] + c + (size_t)nn * np - np;
-  const double *densr = V.f[F_sigmar] + c - np;
-  double *trc = V.f[F_trc] + c + (size_t)nn * np - np;      // tracer nt (0-based): + nt * 2 * kk * np
-  double *pres = V.f[F_wkp1] + c - np, *bc = V.f[F_wkp0] + c - np;
-  const double *uu = V.f[F_u] + c + (size_t)nn * np - np, *vv = V.f[F_v] + c + (size_t)nn * np - np;
-  const double *dpu = V.f[F_dpu] + c + (size_t)nn * np - np, *dpv = V.f[F_dpv] + c + (size_t)nn * np - np;
+  gd_t ttem = V.f[F_temp] + c + (size_t)nn * np - np, ssal = V.f[F_saln] + c + (size_t)nn * np - np;
+  gd_t delp = V.f[F_dp] + c + (size_t)nn * np - np, dens = V.f[F_sigma] + c + (size_t)nn * np - np;
+  gcd_t densr = V.f[F_sigmar] + c - np;
+  gd_t trc = V.f[F_trc] + c + (size_t)nn * np - np; // tracer nt (0-based): + nt * 2 * kk * np
+  gd_t pres = V.f[F_wkp1] + c - np, bc = V.f[F_wkp0] + c - np;
+  gcd_t uu = V.f[F_u] + c + (size_t)nn * np - np, vv = V.f[F_v] + c + (size_t)nn * np - np;
+  gcd_t dpu = V.f[F_dpu] + c + (size_t)nn * np - np, dpv = V.f[F_dpv] + c + (size_t)nn * np - np;
   const size_t ntl = (size_t)2 * kk * np;
 #define TT(k) ttem[(size_t)(k) * np]
 #define SS(k) ssal[(size_t)(k) * np]
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       tkeo = tkew;
       if (fabs(dpmxl) < ONEMM || nitr == MAXITR) break;
     }
-    // (nitr == maxitr: the reference prints the column and goes on, :437-449)
-    if (nitr == MAXITR && fabs(dpmxl) >= ONEMM) atomicAdd(M.maxitr_count, 1);
+    // (nitr == maxitr: the reference prints the column -- 'reached maxitr when detraining', :439-440 -- and goes on; counted as it prints)
+    if (nitr == MAXITR) atomicAdd(M.maxitr_count, 1);
 
     pmxl = fmax2(mltmin * ONEM, pmxl);
     dpfsl = PR(3) - pmxl;
@@ -680,8 +680,8 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
             tkeo = tkew;
             if (fabs(dpmxl) < ONEMM || nitr == MAXITR) break;
           }
-          // (nitr == maxitr: the reference prints the column and goes on, :955-982)
-          if (nitr == MAXITR && fabs(dpmxl) >= ONEMM) atomicAdd(M.maxitr_count + 1, 1);
+          // (nitr == maxitr: the reference prints the column -- 'reached maxitr when entraining', :949-950 -- and goes on; counted as it prints)
+          if (nitr == MAXITR) atomicAdd(M.maxitr_count + 1, 1);
           if (pmxl < presk1 - EPSILP && nitr < MAXITR) {
             tdps = tdps + tk * (pmxl - presk);
             sdps = sdps + sk * (pmxl - presk);
@@ -916,9 +916,9 @@ __global__ __launch_bounds__(64) void k_mxl_clamp(const DevView *__restrict__ Vp
   const int kk = V.kk;
   const size_t np = V.nplane;
   const Params &P = V.P;
-  const double *delp = V.f[F_dp] + c + (size_t)nn * np - np;
+  gcd_t delp = V.f[F_dp] + c + (size_t)nn * np - np;
   const int nt = (int)by_ - 1;
-  double *x = (nt < 0 ? V.f[F_saln] : V.f[F_trc] + (size_t)nt * 2 * kk * np) + c + (size_t)nn * np - np;
+  gd_t x = (nt < 0 ? V.f[F_saln] : V.f[F_trc] + (size_t)nt * 2 * kk * np) + c + (size_t)nn * np - np;
 #define XX(k) x[(size_t)(k) * np]
   const bool is_tke = nt >= 0 && P.itrtke >= 1 && nt + 1 == P.itrtke, is_gls = nt >= 0 && P.itrtke >= 1 && P.gls && nt + 1 == P.itrgls;
   if (is_tke || is_gls) {
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(64) void k_mxl_clamp(const DevView *__restrict__ Vp
     }
     return;
   }
-  double *corr = nt < 0 ? V.f[F_salt_corr] + c : V.f[F_trc_corr] + c + (size_t)nt * np;
+  gd_t corr = nt < 0 ? V.f[F_salt_corr] + c : V.f[F_trc_corr] + c + (size_t)nt * np;
   double tc = 0.;
   bool any = false;
   for (int k0 = 1; k0 <= kk; k0 += 2 * COLUMN_U) {

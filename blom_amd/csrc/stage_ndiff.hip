@@ -159,7 +159,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
   double p_ni_m_prev, p_ni_p_prev, drho_curr = 0., pml = 0.;
   // ---- first search: neutral interfaces anchored at the source interfaces, :225-392 -------------------------------------------
   if (A.surface_align) {
-    const double *dpml = V.f[F_dpml];
+    gcd_t dpml = V.f[F_dpml];
     pml = .5 * (PSM(1, 1) + dpml[cm] + PSP(1, 1) + dpml[cp]);
     kssa_m = 2;
     while (kssa_m <= ksmx_m) {
@@ -620,7 +620,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
   A.rec_n[face] = nrec;
   // ---- neutral slope at the destination interfaces, :923-951 ------------------------------------------------------------------
   if (wedge) {
-    double *nsl = (isv ? V.f[F_nslpy] : V.f[F_nslpx]);
+    gd_t nsl = (isv ? V.f[F_nslpy] : V.f[F_nslpx]);
 #define NSXY(kd_) nsl[cp + (size_t)((kd_)-1) * np]
     if (nns == 0) {
       for (int kd = 1; kd <= kk; kd++) NSXY(kd) = 0.;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64) void k_ndiff_eval(const DevView *__restrict__ V
   const size_t cp = isv ? face - np : face, cm = isv ? cp - V.ni : cp - 1;
   const int kk = V.kk, nn = A.nn, ntr_loc = A.ntr_loc;
   const double cdiff = isv ? V.P.delt1 * V.f[F_scvx][cp] * V.f[F_scvyi][cp] : V.P.delt1 * V.f[F_scuy][cp] * V.f[F_scuxi][cp];   // :1079, :1134
-  const double *difiso = V.f[F_difiso];
+  gcd_t difiso = V.f[F_difiso];
   const double withheld = __builtin_nan("");
   // A flux that passes the sign tests but is itself a NaN (a NaN in difiso or in the polynomial coefficients: the state has blown up)
   // must not look like a withheld one, or it would be dropped where the reference carries it into the tracers: it travels as an
@@ -793,8 +793,8 @@ __global__ __launch_bounds__(64) void k_ndiff_uvflx(const DevView *__restrict__ 
   const size_t cp = isv ? face - np : face;
   const int kk = V.kk, mm = A.mm, ntr_loc = A.ntr_loc;
   const double *puv = A.puv + (isv ? (size_t)(kk + 1) * np : 0);
-  double *ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), *fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
-  double *ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), *fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
+  gd_t ftl = (isv ? V.f[F_vtflld] : V.f[F_utflld]), fsl = (isv ? V.f[F_vsflld] : V.f[F_usflld]);
+  gd_t ftx = (isv ? V.f[F_vtflx] : V.f[F_utflx]), fsx = (isv ? V.f[F_vsflx] : V.f[F_usflx]);
   int kuv = 1;
   // The sums of the layer kuv stay in registers until kuv moves on.  A move must not wait for memory: the lanes of a wave move at
   // different records, so nearly every record some lane moves, and a load in that path -- even one requested long before for the

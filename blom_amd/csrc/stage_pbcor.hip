@@ -34,7 +34,7 @@ __global__ void k_pbc_pscan(const DevView *__restrict__ Vp, int which, int offc,
   THREAD_IJ(V);
   if (j < 0 || j > V.jj + 1 || i < 0 || i > V.ii + 1 || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
-  double *dp = from_remap ? WK(V, R_DP(V.ntr)) : V.f[F_dp] + (size_t)offc * np, *p = V.f[F_p];
+  gd_t dp = from_remap ? WK(V, R_DP(V.ntr)) : V.f[F_dp] + (size_t)offc * np, p = V.f[F_p];
   double acc = p[c];
   int k = 0;
   for (; k + COLUMN_U <= V.kk; k += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
@@ -62,12 +62,12 @@ __global__ void k_pbc_total(const DevView *__restrict__ Vp, int which, int m, in
   THREAD_IJ(V);
   const size_t np = V.nplane;
   const double dlt = V.P.dlt;
-  const double *pbot = V.f[F_p] + (size_t)V.kk * np;
+  gcd_t pbot = V.f[F_p] + (size_t)V.kk * np;
   if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii + 1 && V.m[I_iu][c]) {
-    const double *bfx = which == 1 ? V.f[F_ubflxs_p] + (size_t)(m - 1) * np : V.f[F_ubflxs] + (size_t)(n - 1) * np;
+    gcd_t bfx = which == 1 ? V.f[F_ubflxs_p] + (size_t)(m - 1) * np : V.f[F_ubflxs] + (size_t)(n - 1) * np;
     double t = dlt * bfx[c];
     if (V.P.bmcmth == 1) WK2(V, S2_PBUT)[c] = fmin2(pbot[c], pbot[c - 1]);
-    const double *uflx = V.f[F_uflx] + (size_t)offf * np;
+    gcd_t uflx = V.f[F_uflx] + (size_t)offf * np;
     for (int k0 = 0; k0 < V.kk; k0 += COLUMN_U) {                // COLUMN_U levels' loads in flight (blomgpu_internal.h)
       double a0[COLUMN_U];
 #pragma unroll
@@ -79,10 +79,10 @@ __global__ void k_pbc_total(const DevView *__restrict__ Vp, int which, int m, in
     (which == 1 ? V.f[F_utotm] : V.f[F_utotn])[c] = t;
   }
   if (j >= 1 && j <= V.jj + 1 && i >= 1 && i <= V.ii && V.m[I_iv][c]) {
-    const double *bfx = which == 1 ? V.f[F_vbflxs_p] + (size_t)(m - 1) * np : V.f[F_vbflxs] + (size_t)(n - 1) * np;
+    gcd_t bfx = which == 1 ? V.f[F_vbflxs_p] + (size_t)(m - 1) * np : V.f[F_vbflxs] + (size_t)(n - 1) * np;
     double t = dlt * bfx[c];
     if (V.P.bmcmth == 1) WK2(V, S2_PBVT)[c] = fmin2(pbot[c], pbot[c - V.ni]);
-    const double *vflx = V.f[F_vflx] + (size_t)offf * np;
+    gcd_t vflx = V.f[F_vflx] + (size_t)offf * np;
     for (int k0 = 0; k0 < V.kk; k0 += COLUMN_U) {
       double a0[COLUMN_U];
 #pragma unroll

@@ -73,10 +73,10 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
   const int x0 = (bx_ % ntx) * PT_TW, y0 = (bx_ / ntx) * PT_TH;
   const size_t np = V.nplane, ok = (size_t)k * np, okc = (size_t)(k + offc) * np, okf = (size_t)(k + offf) * np;
-  const double *f_dp = from_remap ? WK(V, R_DP(ntr)) + ok : V.f[F_dp] + okc;
-  const double *f_s = from_remap ? WK(V, R_S(ntr)) + ok : V.f[F_saln] + okc;
-  const double *f_t = from_remap ? WK(V, R_T(ntr)) + ok : V.f[F_temp] + okc;
-  const double *f_tr = V.f[F_trc] + okc;
+  gcd_t f_dp = from_remap ? WK(V, R_DP(ntr)) + ok : V.f[F_dp] + okc;
+  gcd_t f_s = from_remap ? WK(V, R_S(ntr)) + ok : V.f[F_saln] + okc;
+  gcd_t f_t = from_remap ? WK(V, R_T(ntr)) + ok : V.f[F_temp] + okc;
+  gcd_t f_tr = V.f[F_trc] + okc;
   // tracer nt of the level: remap advected it (then it lies in the work space) or left it alone (mod_remap.F90:314-316)
   auto trc_at = [&](int nt, size_t cs) {
     return from_remap && !trc_skip_adv(V.P, nt + 1) ? WK(V, R_TR(ntr, nt))[cs + ok] : f_tr[cs + (size_t)nt * 2 * V.kk * np];
@@ -103,18 +103,18 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
   const bool live = j >= 1 && j <= V.jj + 1 && i >= 1 && i <= V.ii + 1;
   const size_t c = live ? (size_t)y * ni + x : (size_t)ni + 1, e = c + 1, nb = c + ni;
   const int q = (ly + 1) * PT_LW + lx + 1;
-  const int *mpk = V.m[I_mpack];
+  gci_t mpk = V.m[I_mpack];
   const int mp_c = live ? mpk[c] : 0, mp_e = live ? mpk[e] : 0, mp_n = live ? mpk[nb] : 0;
-  const double *utot = which == 1 ? V.f[F_utotm] : V.f[F_utotn], *vtot = which == 1 ? V.f[F_vtotm] : V.f[F_vtotn];
-  const double *pbot = V.f[F_p] + (size_t)V.kk * np;
+  gcd_t utot = which == 1 ? V.f[F_utotm] : V.f[F_utotn], vtot = which == 1 ? V.f[F_vtotm] : V.f[F_vtotn];
+  gcd_t pbot = V.f[F_p] + (size_t)V.kk * np;
   const double ut_c = utot[c], ut_e = utot[e], vt_c = vtot[c], vt_n = vtot[nb];
   const double pb_c = pbot[c], pb_w = pbot[c - 1], pb_e = pbot[e], pb_s = pbot[c - ni], pb_n = pbot[nb];
   const bool dluc = V.P.bmcmth != 0;
   const double pbut_c = dluc ? WK2(V, S2_PBUT)[c] : 0., pbut_e = dluc ? WK2(V, S2_PBUT)[e] : 0.;
   const double pbvt_c = dluc ? WK2(V, S2_PBVT)[c] : 0., pbvt_n = dluc ? WK2(V, S2_PBVT)[nb] : 0.;
   const double s2i = V.f[F_scp2i][c];
-  double *o_uf = V.f[F_uflx] + c + okf, *o_us = V.f[F_usflx] + c + okf, *o_ut = V.f[F_utflx] + c + okf;
-  double *o_vf = V.f[F_vflx] + c + okf, *o_vs = V.f[F_vsflx] + c + okf, *o_vt = V.f[F_vtflx] + c + okf;
+  gd_t o_uf = V.f[F_uflx] + c + okf, o_us = V.f[F_usflx] + c + okf, o_ut = V.f[F_utflx] + c + okf;
+  gd_t o_vf = V.f[F_vflx] + c + okf, o_vs = V.f[F_vsflx] + c + okf, o_vt = V.f[F_vtflx] + c + okf;
   const double uf_o = *o_uf, us_o = *o_us, ut_o = *o_ut, vf_o = *o_vf, vs_o = *o_vs, vt_o = *o_vt;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -228,10 +228,10 @@ __global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restri
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
   const int kk = V.kk, ntr = V.ntr;
-  double *dp = V.f[F_dp] + (size_t)offc * np + c, *p = V.f[F_p] + c;
-  double *saln = V.f[F_saln] + (size_t)offc * np + c, *temp = V.f[F_temp] + (size_t)offc * np + c;
-  double *trc = V.f[F_trc] + (size_t)offc * np + c;
-  const double *ndp = WK(V, N_DP) + c, *ns = WK(V, N_S) + c, *nt_ = WK(V, N_T) + c;
+  gd_t dp = V.f[F_dp] + (size_t)offc * np + c, p = V.f[F_p] + c;
+  gd_t saln = V.f[F_saln] + (size_t)offc * np + c, temp = V.f[F_temp] + (size_t)offc * np + c;
+  gd_t trc = V.f[F_trc] + (size_t)offc * np + c;
+  gcd_t ndp = WK(V, N_DP) + c, ns = WK(V, N_S) + c, nt_ = WK(V, N_T) + c;
   const double ptop = p[0];
   const double psum = column_scan(ptop, ndp, p, np, kk);
   const double pbfac = (which == 1 ? V.f[F_pb_p][c] : V.f[F_pb][c + (size_t)(m - 1) * np]) / psum;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(64) k_pbc_rescale_from(const DevView *__restri
   if (!move) return;
   for (int nt = 0; nt < ntr; nt++) {
     if (which == 1 && trc_skip_adv(V.P, nt + 1)) continue;
-    const double *src = WK(V, N_TR(nt)) + c;
+    gcd_t src = WK(V, N_TR(nt)) + c;
     double *dst = trc + (size_t)nt * 2 * kk * np;
     for (int k0 = 0; k0 < kk; k0 += 2 * RS_U) {
       double a[2 * RS_U];

@@ -61,12 +61,12 @@ __global__ __launch_bounds__(64) void k_pgf_phi(const DevView *__restrict__ Vp, 
   if (j < 0 || j > V.jj || i < 0 || i > V.ii || !V.m[I_ip][t]) return;
   const size_t c = t, np = V.nplane;
   const int kk = V.kk;
-  double *phi = V.f[F_phi], *phip = V.f[F_wkp0];
-  const double *p = V.f[F_p];
+  gd_t phi = V.f[F_phi], phip = V.f[F_wkp0];
+  gcd_t p = V.f[F_p];
   double ph = phi[c + (size_t)kk * np], php = 0.;
   phip[c + (size_t)kk * np] = 0.;
   double plo = p[c + (size_t)kk * np];
-  const double *dpn = V.f[F_dp] + (size_t)nn * np + c, *tn = V.f[F_temp] + (size_t)nn * np + c, *sn = V.f[F_saln] + (size_t)nn * np + c;
+  gcd_t dpn = V.f[F_dp] + (size_t)nn * np + c, tn = V.f[F_temp] + (size_t)nn * np + c, sn = V.f[F_saln] + (size_t)nn * np + c;
   for (int k0 = kk - 1; k0 >= 0; k0 -= COLUMN_U) {            // COLUMN_U levels' loads in flight (blomgpu_internal.h)
     double a[COLUMN_U], b[COLUMN_U], d[COLUMN_U], e[COLUMN_U];
 #pragma unroll
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t mns = isv ? c - V.ni : c - 1;
   const int kk = V.kk;
-  const double *p = V.f[F_p], *phi = V.f[F_phi], *phip = V.f[F_wkp0];
-  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np;
-  const double *pz = isv ? V.f[F_pv] : V.f[F_pu];
-  const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
-  double *pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
+  gcd_t p = V.f[F_p], phi = V.f[F_phi], phip = V.f[F_wkp0];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
+  gcd_t pz = isv ? V.f[F_pv] : V.f[F_pu];
+  gcd_t dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gd_t pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  gd_t pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
   // The layers kp, km of the two scalar columns that hold the pressure of the velocity point's layer centre move
   // upwards with k, usually by one.  What the level needs of layer kp -- p above and below, T, S, phi, phi' -- is kept
   // in registers together with the same record of layer kp-1, re-loaded in the background when kp moves; the fixed-index
@@ -190,6 +190,160 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
   (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
 }
 
+// k_pgf_uv with every load of the level loop statically countable (round 6).  In k_pgf_uv above the record of the layer above
+// (rp1 / rm1) is re-loaded inside the data-dependent `while`: the lanes of a wave take that path at different levels, a wave has ONE
+// load counter, and the compiler cannot count loads through a divergent loop -- so it waits for vmcnt(0) at every level, i.e. for the
+// YOUNGEST load of the wave, the fixed-index prefetch of the next level included: one full memory round trip per level.  Here a
+// level issues, unconditionally and in straight-line code, (a) the fixed-index loads of level k-1 and (b) the record of layer kp-2 /
+// km-2 of the two scalar columns (the one a move by one layer will need NEXT level), into the register set the previous level does
+// not use (the loop is unrolled by two: no copies of registers whose loads are in flight).  A move by one layer is two selects:
+// r0 = r1 now, r1 = that speculative record at the start of the next level, when it has had a level's time to arrive -- the wait
+// is vmcnt(n > 0), for the loads of the PREVIOUS level.  A move by two or more layers in one level (massless layers of the scalar
+// column, the first level over a shallow bottom) takes the slow path: the layer is found with four p-loads in flight per round and
+// its two records are loaded and waited for.  Arithmetic, its order and the selected layers are those of k_pgf_uv: bit-identical.
+struct PgfRec { double pu, t, s, ph, php; };      // layer q of a scalar column: p(q), T(q), S(q), phi(q+1), phi'(q+1); p(q+1) is the layer below's pu
+struct PgfFix { double dpk, pzk, pck1, pmk1, old; };
+#define WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)     // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt, lgkmcnt at their maxima)
+
+// DB: the speculative records and the fixed-index loads double-buffered over two unrolled levels (the level's loads are issued BEFORE
+// the wait for the previous level's: period (latency + arithmetic) / 2 per level, ~50 more VGPRs); !DB: one set (merge, then issue)
+template <bool PAIR, bool COPY, bool DB>
+__global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__ Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  const int t = PAIR ? bx_ * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const bool isv = PAIR ? threadIdx.x >= 64 : blockIdx.y == 1;
+  const size_t c = t, np = V.nplane;
+  if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
+  const size_t mns = isv ? c - V.ni : c - 1;
+  const int kk = V.kk;
+  gcd_t p = V.f[F_p], phi = V.f[F_phi], phip = V.f[F_wkp0];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
+  gcd_t pz = isv ? V.f[F_pv] : V.f[F_pu];
+  gcd_t dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gd_t pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  [[maybe_unused]] gd_t pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
+  auto load_rec = [&](size_t col, int kq) {
+    const int kc = kq < 1 ? 1 : kq;
+    PgfRec r;
+    r.pu = p[col + (size_t)(kc - 1) * np];
+    r.t = temp[col + (size_t)(kc - 1) * np]; r.s = saln[col + (size_t)(kc - 1) * np];
+    r.ph = phi[col + (size_t)kc * np]; r.php = phip[col + (size_t)kc * np];
+    return r;
+  };
+  auto load_fix = [&](int k) {                     // what level k needs at fixed indices
+    const int kc = k < 1 ? 1 : k;
+    PgfFix f;
+    f.dpk = dpz[c + (size_t)(kc - 1) * np]; f.pzk = pz[c + (size_t)kc * np];
+    f.pck1 = p[c + (size_t)(kc - 1) * np]; f.pmk1 = p[mns + (size_t)(kc - 1) * np];
+    f.old = COPY ? pgf[c + (size_t)(kc - 1) * np] : 0.;
+    return f;
+  };
+  auto sel = [](bool a, const PgfRec &x, const PgfRec &y) {
+    PgfRec r;
+    r.pu = a ? x.pu : y.pu; r.t = a ? x.t : y.t; r.s = a ? x.s : y.s; r.ph = a ? x.ph : y.ph; r.php = a ? x.php : y.php;
+    return r;
+  };
+  // the layer of column `col` that holds prs, searched upwards from layer q0 (p(q0+1) > prs is known): the largest q <= q0 with
+  // p(q) <= prs, four interface pressures in flight per round
+  auto find = [&](size_t col, int q0, double prs) {
+    for (;;) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int q = q0 - u < 1 ? 1 : q0 - u; v[u] = p[col + (size_t)(q - 1) * np]; }
+      int nup = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) nup += v[u] > prs ? 1 : 0;
+      if (nup < 4 || q0 - 4 < 1) { const int q = q0 - nup; return q < 1 ? 1 : q; }
+      q0 -= 4;
+    }
+  };
+  int kp = kk, km = kk;                  // kup/kum (1-based layer indices as in the reference)
+  PgfRec rp = load_rec(c, kp), rp1 = load_rec(c, kp - 1), rm = load_rec(mns, km), rm1 = load_rec(mns, km - 1);
+  double pplo = p[c + (size_t)kk * np], pmlo = p[mns + (size_t)kk * np];      // p(kp+1), p(km+1)
+  PgfRec spA = rp1, smA = rm1, spB = rp1, smB = rm1;
+  PgfFix fxA = load_fix(kk), fxB = fxA;
+  bool advp = false, advm = false;
+  double xip = 0., xim = 0., pgfm = 0.;
+  double pck = pplo, pmk = pmlo;
+  auto level = [&](const int k, PgfFix &fx, PgfFix &fxn, PgfRec &spo, PgfRec &smo, PgfRec &spn, PgfRec &smn) {
+    if (DB) {                            // this level's loads, all unconditional, then the previous level's records take their place
+      fxn = load_fix(k - 1);
+      spn = load_rec(c, kp - 2);
+      smn = load_rec(mns, km - 2);
+      rp1 = sel(advp, spo, rp1);
+      rm1 = sel(advm, smo, rm1);
+    } else {
+      rp1 = sel(advp, spo, rp1);
+      rm1 = sel(advm, smo, rm1);
+      fx = fxn;
+      fxn = load_fix(k - 1);
+      spo = load_rec(c, kp - 2);
+      smo = load_rec(mns, km - 2);
+    }
+    if (COPY) pgf_o[c + (size_t)(k - 1) * np] = fx.old;
+    const double dpk = fx.dpk, pck1 = fx.pck1, pmk1 = fx.pmk1;
+    const double prs = fx.pzk - .5 * dpk;
+    const bool a1p = rp.pu > prs, a1m = rm.pu > prs;
+    const bool a2p = a1p && rp1.pu > prs, a2m = a1m && rm1.pu > prs;
+    advp = a1p; advm = a1m;
+    if (a1p) { kp--; pplo = rp.pu; rp = rp1; }
+    if (a1m) { km--; pmlo = rm.pu; rm = rm1; }
+    if (a2p || a2m) {                    // two or more layers at once: the slow path ends with nothing in flight
+      if (a2p) { kp = find(c, kp - 1, prs); rp = load_rec(c, kp); rp1 = load_rec(c, kp - 1); pplo = p[c + (size_t)kp * np]; advp = false; }
+      if (a2m) { km = find(mns, km - 1, prs); rm = load_rec(mns, km); rm1 = load_rec(mns, km - 1); pmlo = p[mns + (size_t)km * np]; advm = false; }
+      WAIT_VM0();
+    }
+    double dphip, alpup, alplp, dphim, alpum, alplm;
+    eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
+    eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    double cp = .25 * (pck + pck1);
+    double cm = .25 * (pmk + pmk1);
+    const double q = prs / (cp + cm);
+    cp = q * cp;
+    cm = q * cm;
+    const double phi_p = rp.ph - dphip;
+    xip = xip + (rp.php + pplo * alplp - cp * (alpup - alpum)) * dpk;
+    const double phi_m = rm.ph - dphim;
+    xim = xim + (rm.php + pmlo * alplm - cm * (alpum - alpup)) * dpk;
+    const double g = -(phi_p - phi_m);
+    pgf[c + (size_t)(k - 1) * np] = g;
+    pgfm = pgfm + g * dpk;
+    pck = pck1; pmk = pmk1;
+  };
+  if (DB) {
+    int k = kk;
+    for (; k >= 2; k -= 2) {
+      level(k, fxA, fxB, spA, smA, spB, smB);
+      level(k - 1, fxB, fxA, spB, smB, spA, smA);
+    }
+    if (k == 1) level(1, fxA, fxB, spA, smA, spB, smB);
+  } else {
+    for (int k = kk; k >= 1; k--) level(k, fxB, fxA, spA, smA, spA, smA);
+  }
+  // :543-589
+  const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
+  pgfm = pgfm * q;
+  xip = xip * q;
+  xim = xim * q;
+  for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
+    double a0[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) a0[u] = pgf[c + (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++)
+      if (k0 + u < kk) pgf[c + (size_t)(k0 + u) * np] = a0[u] - pgfm;
+  }
+  const size_t on = (size_t)(n - 1) * np;
+  (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
+  (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
+  (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+}
+
 // ---- pgforc_dynamic_enthalpy, phy/mod_pgforc.F90:269-412 ---------------------------------------------
 // work-space slots of the layer potentials
 enum { DH_POT = 0, DH_POTPB, DH_A, DH_T, DH_ALPR, DH_NSLOT };
@@ -206,9 +360,9 @@ __global__ void k_pgf_dynh_col(const DevView *__restrict__ Vp, int nn) {
   const size_t c = t, np = V.nplane;
   const int kk = V.kk;
   const double pref = V.P.pref;
-  double *phi = V.f[F_phi];
-  const double *p = V.f[F_p];
-  const double *temp = V.f[F_temp] + (size_t)nn * np, *saln = V.f[F_saln] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
+  gd_t phi = V.f[F_phi];
+  gcd_t p = V.f[F_p];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np, dp = V.f[F_dp] + (size_t)nn * np;
 #define LV(a, k) (a)[c + (size_t)((k)-1) * np]
   double pot, potpb, ph = LV(phi, kk + 1);
   {
@@ -257,11 +411,11 @@ __global__ void k_pgf_dynh_uv(const DevView *__restrict__ Vp, int n, int nn) {
   if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
   const size_t mns = isv ? c - V.ni : c - 1;
   const int kk = V.kk;
-  const double *temp = V.f[F_temp] + (size_t)nn * np, *dp = V.f[F_dp] + (size_t)nn * np;
-  const double *dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
-  double *pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
-  double *pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
-  const double *pot = WK(V, DH_POT), *potpb = WK(V, DH_POTPB), *da = WK(V, DH_A), *dt = WK(V, DH_T), *ar = WK(V, DH_ALPR);
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, dp = V.f[F_dp] + (size_t)nn * np;
+  gcd_t dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gd_t pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  gd_t pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
+  gcd_t pot = WK(V, DH_POT), potpb = WK(V, DH_POTPB), da = WK(V, DH_A), dt = WK(V, DH_T), ar = WK(V, DH_ALPR);
   double xip = 0., xim = 0., pgfm = 0.;
   for (int k = kk; k >= 1; k--) {
     const size_t o = (size_t)(k - 1) * np;
@@ -309,7 +463,17 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
     if (h.P.pgfmth == 0) {
       TimeScope tk(c, "k_pgf_uv");
-      if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
+      if (c->pgf_uv_ring && copy_fused) {
+        // pgf_uv_ring: 1 = separate u / v workgroups, 2 = paired + XCD-contiguous; + 2 = the double-buffered form
+        const dim3 gs = plane_grid(h, 2, 64), gp = plane_grid(h, 1, 64);
+        switch (c->pgf_uv_ring) {
+          case 1: hipLaunchKernelGGL((k_pgf_uv_ring<false, true, false>), gs, dim3(64), 0, c->stream, c->d, n, nn); break;
+          case 2: hipLaunchKernelGGL((k_pgf_uv_ring<true, true, false>), gp, dim3(128), 0, c->stream, c->d, n, nn); break;
+          case 3: hipLaunchKernelGGL((k_pgf_uv_ring<false, true, true>), gs, dim3(64), 0, c->stream, c->d, n, nn); break;
+          default: hipLaunchKernelGGL((k_pgf_uv_ring<true, true, true>), gp, dim3(128), 0, c->stream, c->d, n, nn); break;
+        }
+      }
+      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
       else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
       else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
     }

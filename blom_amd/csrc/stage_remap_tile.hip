@@ -160,8 +160,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   double *const gr = lds;                                   // RT_NG x RT_GN
   double *const cuv = lds + RT_NG(nadv) * RT_GN;            // 2 x RT_GN: cu, cv in phases 0-1, corner velocities after
   int *const mpl = (int *)(cuv + 2 * RT_GN);                // RT_SN masks
-  const int *mpk = V.m[I_mpack];
-  const double *scp2 = V.f[F_scp2], *scp2i = V.f[F_scp2i];
+  gci_t mpk = V.m[I_mpack];
+  gcd_t scp2 = V.f[F_scp2], scp2i = V.f[F_scp2i];
 
   // ---- phase 0 -------------------------------------------------------------------------------------------------
   // (a) the scalar region: one point per thread
@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   int sm;
   size_t cs_keep = 0;
   {
-    const double *f_dp = V.f[F_dp] + okn, *f_p = V.f[F_p] + (size_t)(k + 1) * np, *f_t = V.f[F_temp] + okn;
-    const double *f_s = V.f[F_saln] + okn, *f_tr = V.f[F_trc] + okn;
+    gcd_t f_dp = V.f[F_dp] + okn, f_p = V.f[F_p] + (size_t)(k + 1) * np, f_t = V.f[F_temp] + okn;
+    gcd_t f_s = V.f[F_saln] + okn, f_tr = V.f[F_trc] + okn;
     const int xs = x0 - 2 + t % RT_SW, ys = y0 - 2 + t / RT_SW;
     const bool in = t < RT_SN && xs >= 0 && xs < ni && ys >= 0 && ys < nj;
     const size_t cs = in ? (size_t)ys * ni + xs : 0;
@@ -234,9 +234,9 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   const int mpf = fin ? mpk[fc] : 0;
   const double caf = (uface ? V.f[F_cau] : V.f[F_cav])[fc + ok];
   const double pbf = (uface ? V.f[F_pbu] : V.f[F_pbv])[fc + (size_t)(n - 1) * np];
-  double *const o_f = (uface ? V.f[F_uflx] : V.f[F_vflx]) + fc + okm;
-  double *const o_ft = (uface ? V.f[F_utflx] : V.f[F_vtflx]) + fc + okm;
-  double *const o_fs = (uface ? V.f[F_usflx] : V.f[F_vsflx]) + fc + okm;
+  gd_t const o_f = (uface ? V.f[F_uflx] : V.f[F_vflx]) + fc + okm;
+  gd_t const o_ft = (uface ? V.f[F_utflx] : V.f[F_vtflx]) + fc + okm;
+  gd_t const o_fs = (uface ? V.f[F_usflx] : V.f[F_vsflx]) + fc + okm;
   // old fluxes: the u-face accumulates (:1054-1056), the v-face assigns (:1455-1457).  Inside blomgpu_step init_fluxes has
   // zeroed them earlier in the step and nothing has added to them since (zero_old): 0 + flux without the read
   const bool own = !FOLD || (ft % RT_TW < RT_TW - 1 && ft / RT_TW < RT_TH - 1);
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   }
   if (!MORE) return;
   // ---- the other advected tracers, a batch at a time --------------------------------------------------------------------------
-  const double *f_tr = V.f[F_trc] + okn;
+  gcd_t f_tr = V.f[F_trc] + okn;
   const int off2 = uface ? 0 : 1;
   if constexpr (!FOLD) {
     // A batch of RT_NB tracers in LDS: its scalars S (RT_NB x RT_SN), behind them its limited gradients G (3 RT_NB x RT_GN).

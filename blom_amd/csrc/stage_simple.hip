@@ -112,15 +112,15 @@ __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, i
   const bool old_too = ((flags & 2) && j >= 1 && j <= V.jj && i >= 1 && i <= V.ii) || (flags & 4);
   const bool wu = V.m[I_iu][c] != 0, wv = V.m[I_iv][c] != 0;
   if (!wu && !wv) return;
-  const double *p = V.f[F_p];
+  gcd_t p = V.f[F_p];
   const size_t np = V.nplane, w = c - 1, s = c - V.ni;
   const size_t bot = (size_t)V.kk * np;
   const double pc_b = p[c + bot];
   const double qu = wu ? fmin2(pc_b, p[w + bot]) : 0., qv = wv ? fmin2(pc_b, p[s + bot]) : 0.;
-  double *dpu = V.f[F_dpu] + (size_t)off * np, *dpv = V.f[F_dpv] + (size_t)off * np;
+  gd_t dpu = V.f[F_dpu] + (size_t)off * np, dpv = V.f[F_dpv] + (size_t)off * np;
   double pu = wu ? V.f[F_pu][c] : 0., pv = wv ? V.f[F_pv][c] : 0.;
   double pc0 = p[c], pw0 = wu ? p[w] : 0., ps0 = wv ? p[s] : 0.;
-  double *pug = V.f[F_pu], *pvg = V.f[F_pv];
+  gd_t pug = V.f[F_pu], pvg = V.f[F_pv];
   const size_t wl = wu ? w : c, sl = wv ? s : c;           // a land neighbour's column is not read: take the own one
   const int kk = V.kk;
   for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {              // COLUMN_U levels' loads in flight (blomgpu_internal.h)
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64) void k_tmsmt2_fac(const DevView *__restrict__ V
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane;
-  const double *dpo = V.f[F_dpold] + c + (size_t)nn * np, *dpn = V.f[F_dp] + c + (size_t)nn * np;
-  const double *ndp = dp_in_wk ? WK(V, 0) + c : dpn;
+  gcd_t dpo = V.f[F_dpold] + c + (size_t)nn * np, dpn = V.f[F_dp] + c + (size_t)nn * np;
+  gcd_t ndp = dp_in_wk ? WK(V, 0) + c : dpn;
   double pbfaco = 0., pbfacn = 0., psum = V.f[F_p][c];
   const int kk = V.kk;
   for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
@@ -244,8 +244,8 @@ __global__ void k_tmsmt2(const DevView *__restrict__ Vp, int mm, int nn, int fro
   V.f[F_saln][okm] = snew;
   if (ahead) { V.f[F_dpold][okm] = dpm; V.f[F_told][ok] = tnew; V.f[F_sold][ok] = snew; }
   for (int nt = 0; nt < V.ntr; nt++) {
-    double *tr = V.f[F_trc] + (size_t)nt * 2 * V.kk * np;
-    double *tro = V.f[F_trcold] + (size_t)nt * V.kk * np;
+    gd_t tr = V.f[F_trc] + (size_t)nt * 2 * V.kk * np;
+    gd_t tro = V.f[F_trcold] + (size_t)nt * V.kk * np;
     const double xmid = from_wk ? WK(V, 3 + nt)[ok] : tr[okm];
     const double xnew = (wts1 * pmid * xmid + wts2 * (pold * tro[ok] + pnew * tr[okn])) / (dpm + epsilp);
     tr[okm] = xnew;
@@ -294,7 +294,7 @@ __global__ void k_kfpla_util(const DevView *__restrict__ Vp, int n, int back) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (!V.m[I_ip][c]) return;
-  int *kf = V.m[I_kfpla] + (size_t)(n - 1) * V.nplane;
+  gi_t kf = V.m[I_kfpla] + (size_t)(n - 1) * V.nplane;
   if (!back) {
     if (j >= 1 && j <= V.jj && i >= 1 && i <= V.ii) V.f[F_util1][c] = (double)kf[c];
   } else if (j >= -1 && j <= V.jj + 2 && i >= -1 && i <= V.ii + 2)
@@ -317,7 +317,7 @@ __global__ void k_idlage_step(const DevView *__restrict__ Vp, int nn) {
   if (!V.m[I_ip][c]) return;
   const int k = by_;
   const size_t np = V.nplane;
-  double *t = V.f[F_trc] + c + ((size_t)(k + nn) + (size_t)(V.P.itriag - 1) * 2 * V.kk) * np;
+  gd_t t = V.f[F_trc] + c + ((size_t)(k + nn) + (size_t)(V.P.itriag - 1) * 2 * V.kk) * np;
   if (k == 0) *t = 0.;
   else *t = *t + V.P.delt1 / (86400. * V.P.nday_in_year);
 }

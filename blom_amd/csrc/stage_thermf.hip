@@ -51,7 +51,7 @@ __global__ void k_thermf_channel_flux(const DevView *__restrict__ Vp, ThermfPar 
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
   const size_t np = V.nplane, o1 = c + (size_t)nn * np, o2 = o1 + np, ok1 = c + (size_t)(k1n - 1) * np;
   const int kk = V.kk, ntr = V.ntr;
-  const double *dp = V.f[F_dp], *temp = V.f[F_temp], *saln = V.f[F_saln];
+  gcd_t dp = V.f[F_dp], temp = V.f[F_temp], saln = V.f[F_saln];
   // the ocean top layer and the mixed layer, :103-116
   const double sotl = saln[ok1];
   const double dpmxl = dp[o1] + dp[o2];
@@ -73,14 +73,14 @@ __global__ void k_thermf_channel_flux(const DevView *__restrict__ Vp, ThermfPar 
   V.f[F_sswflx][c] = 0.;
   // tracer fluxes (positive downwards), :165-197
   for (int nt = 0; nt < ntr; nt++) {
-    double *trflx = V.f[F_trflx] + c + (size_t)nt * np;
+    gd_t trflx = V.f[F_trflx] + c + (size_t)nt * np;
     if (V.P.itrtke >= 1 && (nt + 1 == V.P.itrtke || nt + 1 == V.P.itrgls)) { *trflx = 0.; continue; }   // (use_GLS is refused by the host)
     *trflx = -V.f[F_trc][ok1 + (size_t)nt * 2 * kk * np] * fwflx * 1.e-3;
   }
   // relaxation fluxes, :203-255
   double surrlx = 0.;
   if (T.trxday > EPSILT) {
-    const double *sstclm = V.f[F_sstclm] + c, *ricclm = V.f[F_ricclm] + c;
+    gcd_t sstclm = V.f[F_sstclm] + c, ricclm = V.f[F_ricclm] + c;
     double sstc = intp1d(sstclm[(size_t)(T.l1mi - 1) * np], sstclm[(size_t)(T.l2mi - 1) * np], sstclm[(size_t)(T.l3mi - 1) * np],
                          sstclm[(size_t)(T.l4mi - 1) * np], sstclm[(size_t)(T.l5mi - 1) * np], T.xmi);
     const double rice = intp1d(ricclm[(size_t)(T.l1mi - 1) * np], ricclm[(size_t)(T.l2mi - 1) * np], ricclm[(size_t)(T.l3mi - 1) * np],
@@ -92,7 +92,7 @@ __global__ void k_thermf_channel_flux(const DevView *__restrict__ Vp, ThermfPar 
   V.f[F_surrlx][c] = surrlx;
   double salrlx = 0.;
   if (T.srxday > EPSILT) {
-    const double *sssclm = V.f[F_sssclm] + c;
+    gcd_t sssclm = V.f[F_sssclm] + c;
     const double sssc = intp1d(sssclm[(size_t)(T.l1mi - 1) * np], sssclm[(size_t)(T.l2mi - 1) * np], sssclm[(size_t)(T.l3mi - 1) * np],
                                sssclm[(size_t)(T.l4mi - 1) * np], sssclm[(size_t)(T.l5mi - 1) * np], T.xmi);
     const double srxflx = 100. * fmin2(hmxl, T.srxdpt) / (T.srxday * 86400.) * fmin2(T.srxlim, fmax2(-T.srxlim, sssc - smxl));
@@ -117,7 +117,7 @@ __global__ void k_thermf_channel_corr(const DevView *__restrict__ Vp, ThermfPar 
   const double trflxc = 0.;
   for (int nt = 0; nt < V.ntr; nt++) {
     if (V.P.itrtke >= 1 && (nt + 1 == V.P.itrtke || nt + 1 == V.P.itrgls)) continue;
-    double *trflx = V.f[F_trflx] + c + (size_t)nt * np;
+    gd_t trflx = V.f[F_trflx] + c + (size_t)nt * np;
     *trflx = -(*trflx + trflxc) * 1.e2;
   }
 }

@@ -461,10 +461,12 @@ def init_forcing(be, case):
     the open-water friction velocity 0.005 m/s, the climatologies set to constants that the default relaxation time scales of 0
     days never touch), the shortwave absorption of Jerlov water type 3 (phy/mod_swabs.F90:104-107, :262-267: the defaults of
     isopyc_bulkml, cime_config/namelist_definition_blom.xml swamth / jwtype), zero friction velocity and zeroed reservoirs at the
-    start (phy/mod_forcing.F90:310, phy/mod_niw.F90:85-112), the ocean area (mod_grid: area, the xcsum of scp2 over ips)."""
+    start (phy/mod_forcing.F90:310, phy/mod_niw.F90:85-112), the ocean area (mod_grid: area, the xcsum of scp2 over ips).
+    `case.params["ustarw0"]` overrides the friction velocity: thermf_channel multiplies it by 1e2 (channel/mod_thermf_channel.F90:259),
+    so the reference's 0.005 acts as 0.5 m/s on this SI state; bench.py --forcing calm sets 5e-5 (0.005 m/s after the factor)."""
     nj, ni = case.jdm + 2 * NBDY, case.idm + 2 * NBDY
     one = np.ones((1, nj, ni))
-    vals = dict(ustarw=0.005, swa=0.0, nsf=0.0, hmltfz=0.0, lip=0.0, sop=0.0, eva=0.0, rnf=0.0, rfi=0.0, fmltfz=0.0, sfl=0.0,
+    vals = dict(ustarw=float(case.params.get("ustarw0", 0.005)), swa=0.0, nsf=0.0, hmltfz=0.0, lip=0.0, sop=0.0, eva=0.0, rnf=0.0, rfi=0.0, fmltfz=0.0, sfl=0.0,
                 swfc1=0.67, swfc2=1.0 - 0.67, swal1=1.0, swal2=17.0, ustar=0.0, ustar3=0.0, idkedt=0.0,
                 surflx=0.0, sswflx=0.0, surrlx=0.0, salflx=0.0, brnflx=0.0, salrlx=0.0, salt_corr=0.0)
     has = getattr(be, "has_field", lambda nm: True)

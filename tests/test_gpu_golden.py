@@ -127,3 +127,44 @@ def test_device_reproduces_reference_checksums_from_analytic_init(cfg):
     gpu.close()
     assert not bad, "\n".join(bad[:20])
     assert state["checked"] > 600
+
+
+def test_600_steps_of_the_bench_workload_equal_the_reference_long_run():
+    """The long-run question of round 5's review: config 2's step with live diffusivities (what bench.py times) for 600 steps from the
+    bench's initial state, device-resident (blomgpu_step), against the reference's own modules run for the same 600 steps in the build
+    container (tools/longrun_reference.py -> tests/golden/channel_tke_live_long_crc.json): xccrc of dp, temp, saln, u, v, the tracers,
+    difint and difdia over both time levels at steps 100, 200, ..., 600, and the extremes of temp with the cells they are taken in."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import bench
+    from blom_amd.checksum import grid_of
+    from longrun_reference import sample
+    path = os.path.join(HERE, "golden", "channel_tke_live_long_crc.json")
+    gold = json.load(open(path))
+    trace = {t["step"]: t for t in gold["trace"]}
+    case, nreg, masks = bench.build_case("channel", "remap", "default")
+    gpu = bench.device_for_bench(case, nreg, masks, live=True)
+    scp2 = gpu.get("scp2")[0][4:-4, 4:-4]
+    bad, ns = [], 0
+    try:
+        for step in sorted(int(s) for s in gold["crc"]):
+            ns = gpu.step(ns, step - ns)
+            assert ns == step
+            for nm, want in gold["crc"][str(step)].items():
+                got = gpu.crc(nm, 1, gpu.field_info(nm)[0], grid_of(nm))
+                if got != want:
+                    bad.append(f"step {step} {nm}: crc 0x{got:08x} != 0x{want:08x}")
+            smp, g = sample(gpu, case, masks, ns, scp2), trace[step]
+            for k_ in ("tmin", "tmax"):
+                if list(smp[k_]) != list(g[k_]):
+                    bad.append(f"step {step} {k_}: {smp[k_]} != {g[k_]}")
+            for k_ in ("mass", "heat", "salt"):
+                if smp[k_] != g[k_]:
+                    bad.append(f"step {step} {k_}: {smp[k_]!r} != {g[k_]!r}")
+            if bad:
+                break
+    finally:
+        gpu.close()
+    assert not bad, "\n".join(bad[:20])
+    assert ns >= 600
