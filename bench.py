@@ -186,7 +186,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False, difest=False):
+def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False, difest=False, start=None):
     """Runs _cpu_baseline in a thread with a 2 GiB stack: the reference keeps its stage-local
     2-D work arrays (21 in remap, ~30 in momtum) on the stack, which at channel size exceeds the
     default 8 MiB limit (BLOM is normally run with `ulimit -s unlimited`)."""
@@ -195,7 +195,7 @@ def cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full=False
     threading.stack_size(2 << 30)
     def body():
         try:
-            res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full, difest))
+            res.update(_cpu_baseline(cfg, case, masks, nreg, max_seconds, live, full, difest, start))
         except Exception as e:                           # (an exception in a thread would otherwise vanish with its message)
             res["error"] = repr(e)
     th = threading.Thread(target=body)
@@ -250,7 +250,26 @@ def ref_full_init(be, case, xml, xdf):
             be.ref.set(nm, int(v))
 
 
-def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False, difest=False):
+# what a step of config 2 reads of the previous one beside the state arrays of tests/parity.py (the reference's restart file carries
+# them too, phy/mod_restart.F90): cmnfld's fields, the mixed layer's reservoirs and fluxes, the diffusivity closure's arrays
+RESTART_EXTRA = ["bfsqi", "bfsql", "bfsqf", "nslpx", "nslpy", "nnslpx", "nnslpy",
+                 "ustar", "ustar3", "idkedt", "uml", "vml", "umlres", "vmlres", "surflx", "sswflx", "surrlx", "salflx", "brnflx", "salrlx",
+                 "salt_corr", "trc_corr", "trflx", "mtkeus", "mtkeni", "mtkebf", "mtkers", "mtkepe", "mtkeke", "pbrnda", "buoyfl", "fmltfz",
+                 "sfl", "hmltfz", "Prod", "Buoy", "Shear2", "L_scale"]
+
+
+def continue_from_device(be, gpu, ns, case):
+    """Copies the device's state at step count ns into the reference backend `be` so that it continues the run (bench.py --spinup;
+    the GPU suite checks that the two then stay bit-identical: tests/test_xcheck_difest.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from parity import copy_state, STATE_FIELDS, INT_FIELDS
+    gpu.sync()
+    copy_state(gpu, be, fields=[f for f in STATE_FIELDS + INT_FIELDS + RESTART_EXTRA if gpu.has_field(f)])
+    be.set("delt1", 2.0 * case.params["baclin"])
+    return ns
+
+
+def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_physics=False, difest=False, start=None):
     """The reference's own Fortran (preferred) or the C restatement, timed on the host for a bounded number of steps.
     Preferred build: oracle/_ref/<cfg>_omp_xed -- the reference's hot-path modules INCLUDING its real mod_cmnfld_routines and
     mod_eddtra (compiled against the two small stand-in modules of oracle/xcheck/, see there), with its OpenMP directives
@@ -327,7 +346,11 @@ def _cpu_baseline(cfg, case, masks, nreg, max_seconds=45.0, live=True, full_phys
         be = COracle(case.idm, case.jdm, case.kdm, case.ntr, nreg, masks)
         kind = "port"
     ref_full_init(be, case, xml, xdf)
-    ns = dyncore_step(be, 0, case.params["baclin"], stages=stages)          # forward first step (untimed)
+    if start is not None:
+        # --spinup: the reference continues from the state the device holds (every array of the step, both time levels)
+        ns = continue_from_device(be, *start, case)
+    else:
+        ns = dyncore_step(be, 0, case.params["baclin"], stages=stages)          # forward first step (untimed)
     # per-stage host times beside the device's stages_ms: the hook fires before every stage
     per_stage, mark = {}, [None, 0.0]
 
@@ -741,6 +764,19 @@ def main():
     ap.add_argument("--frozen-diffusivities", action="store_true",
                     help="--physics full: leave out the diffusivity estimates of difest_isobml (difint, difiso, difdia, difwgt stay at their "
                          "initial values, as in round 4)")
+    ap.add_argument("--forcing", default="default", choices=sorted(FORCING),
+                    help="default: the channel experiment's own forcing (channel/mod_channel.F90:365: ustarw = 0.005, which "
+                         "thermf_channel's factor 1e2 turns into a friction velocity of 0.5 m/s: the mixed layer reaches 1.6 km within 200 steps); "
+                         "calm: this project's second published set, ustarw = 5e-5 (0.005 m/s after the factor).  The headline uses `default`")
+    ap.add_argument("--spinup", type=int, default=0,
+                    help="steps integrated before the warm-up (default 0: the timed window starts from rest, steps W+1..W+K); with N > 0 the "
+                         "CPU baseline starts from the state the device holds at the end of the run, downloaded")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="the timed region is block 1 (the headline: `value`, `ms_per_step`); blocks 2..B of --steps steps each follow and "
+                         "ms_per_step_median / _min / _max over all B blocks are reported beside it")
+    ap.add_argument("--spunup-steps", type=int, default=1000,
+                    help="one tile, --physics full: after the measurement the run is continued to this step count and --steps steps are "
+                         "timed again (key `spunup`: a state a model run is in, not the transient from rest); 0: leave it out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dyncore-compare", action="store_true",
                     help="leave out the extra steps of the dynamical core alone that follow the measurement (profiling runs)")
@@ -796,7 +832,7 @@ def main():
 
     from blom_amd.gpu import BlomGpu, rccl_unique_id
     from blom_amd import hostinit
-    case, nreg, masks = build_case(args.config, args.advmth, args.tracers)
+    case, nreg, masks = build_case(args.config, args.advmth, args.tracers, args.forcing)
     layout = None
     difest_live = False
     full_req = args.physics == "full" and not args.rccl_self and args.slopes == "live"
@@ -894,7 +930,8 @@ def main():
     baclin = case.params["baclin"]
 
     # ---- warm-up: first (forward) step + W-1 leap-frog steps, with per-class HIP-event timing ----
-    ns = gpu.step(0, 1)
+    ns = gpu.step(0, args.spinup) if args.spinup > 0 else 0
+    ns = gpu.step(ns, 1)
     gpu.set("timing", 1)
     gpu.timer_reset()
     if args.warmup > 1:
@@ -948,6 +985,41 @@ def main():
     # (the checksums of the state the TIMED steps left -- taken before the comparison steps below, on tiles as on one tile, so that
     # state_crc is the same for every N at equal --steps/--warmup)
     my_strips = {nm: gpu.crc_strips(nm, 1, 2 * case.kdm, it) for nm, it in (("dp", 1), ("u", 3))} if layout is not None else None
+    # ---- blocks 2..B: the same number of steps timed again, as the headline block was (round 5's review: the timed region is 0.14 s
+    # and the spread between boxes larger than the changes of a round; median / min / max over the blocks say what a number resolves)
+    def timed_block(nsteps):
+        nonlocal ns
+        barrier()
+        gpu.sync()
+        cuda_sync()
+        t1 = time.perf_counter()
+        ns = gpu.step(ns, nsteps)
+        gpu.sync()
+        cuda_sync()
+        barrier()
+        return launch.max_over_ranks(time.perf_counter() - t1, env, device="cuda" if on_gpu else "cpu") / nsteps * 1e3
+    block_ms = [dt / args.steps * 1e3] + [timed_block(args.steps) for _ in range(max(0, args.blocks - 1))]
+    # ---- a state a model run is in: the run continued to --spunup-steps, then --steps steps timed again and the classes once more
+    spunup = None
+    if full and world == 1 and layout is None and args.spunup_steps > ns:
+        ns = gpu.step(ns, args.spunup_steps - ns)
+        at = ns
+        sp_blocks = [timed_block(args.steps) for _ in range(3)]
+        gpu.set("timing", 1)
+        gpu.timer_reset()
+        ns = gpu.step(ns, min(args.steps, 5))
+        gpu.sync()
+        sp_stages = {}
+        for cl in classes:
+            ms, n = gpu.timer_get(cl)
+            if n:
+                sp_stages[cl] = ms / max(1, min(args.steps, 5))
+        gpu.set("timing", 0)
+        spunup = {"after_steps": at, "ms_per_step": sorted(sp_blocks)[1], "ms_per_step_blocks": [round(x, 4) for x in sp_blocks],
+                  "value": baclin / 86400.0 / (sorted(sp_blocks)[1] * 1e-3), "stages_ms": sp_stages,
+                  "state_finite": bool(np.isfinite(gpu.get("u")).all() and np.isfinite(gpu.get("dp")).all()),
+                  "note": "the same run continued: median of three blocks of --steps steps from this step count on (the headline is timed "
+                          "from rest, in the transient of the mixed layer: profiles/r06_longrun.txt)"}
     dyncore_ms = None
     if full and not args.no_dyncore_compare:
         # the dynamical core alone (the sequence rounds 1-3 timed), in the same run on the same device, for comparison
@@ -1042,6 +1114,14 @@ def main():
         "class_counted_over_alg": ({k: round(traffic[k] / (cb[k] * F), 2) for k in cb if traffic and k in traffic and k in live} or None),
     }
     out["config"]["physics"] = "full" if full else "dyncore"
+    out["config"]["forcing"] = args.forcing
+    out["config"]["spinup_steps"] = args.spinup
+    srt = sorted(block_ms)
+    out["ms_per_step_blocks"] = [round(x, 4) for x in block_ms]
+    out["ms_per_step_median"] = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    out["ms_per_step_min"], out["ms_per_step_max"] = srt[0], srt[-1]
+    if spunup is not None:
+        out["spunup"] = spunup
     if dyncore_ms is not None:
         out["dyncore_only"] = {"ms_per_step": dyncore_ms, "value": baclin / 86400.0 / (dyncore_ms * 1e-3),
                                "note": "the dynamical-core sequence of rounds 1-3 (no thermf, mxlayr, difest part, cmnfld1), timed in this run after the main measurement"}
@@ -1067,7 +1147,8 @@ def main():
         os.dup2(2, 1)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live", full=full, difest=difest_live)
+                out["cpu_baseline"] = cpu_baseline(case.name, case, masks, nreg, live=args.slopes == "live", full=full, difest=difest_live,
+                                                   start=(gpu, ns) if args.spinup > 0 else None)
             except Exception as e:                       # the bench line must still be produced
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -415,6 +415,8 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "eddtra_frozen") { c->eddtra_frozen = v; return 0; }
   if (s == "pgf_uv_pair") { c->pgf_uv_pair = v; return 0; }
   if (s == "pgf_uv_ring") { c->pgf_uv_ring = v; return 0; }
+  if (s == "pgf_reuse") { c->pgf_reuse = v; return 0; }
+  if (s == "scan_reassoc") { c->scan_reassoc = v; return 0; }
   if (s == "pgf_copy_fused") { c->pgf_copy_fused = v; return 0; }
   if (s == "check_period") { c->check_period = v < 1 ? 1 : v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }

@@ -277,6 +277,8 @@ struct blomgpu_ctx {
   int pgf_uv_pair = 0;           // k_pgf_uv, A/B option: 1 = the u- and v-column wavefronts of 64 points in one workgroup with XCD-contiguous
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
+  int scan_reassoc = 0;          // TOLERANCE-MODE EXPERIMENT (off): k_pscan with k on the lanes and a log-step shuffle prefix sum -- NOT bit-identical to the reference (stage_simple.hip)
+  int pgf_reuse = 0;             // k_pgf_uv: skip the equation of state where a level repeats the previous level's inputs (wave-uniform; bit-identical)
   int pgf_uv_ring = 0;           // k_pgf_uv_ring (round 6: every load of the level loop statically countable): 1 = separate u / v workgroups, 2 = paired + XCD-contiguous
   int pgf_copy_fused = 1;        // pgforc: the pgfx_o/pgfy_o copy rides along in k_pgf_uv
   int eddtra_frozen = 0;         // blomgpu_step leaves eddtra out: umfltd, vmfltd, umflsm, vmflsm stay as uploaded

@@ -101,8 +101,13 @@ __global__ __launch_bounds__(64) void k_pgf_phi(const DevView *__restrict__ Vp, 
 // four (the u- and v-columns used to be separate workgroups: 1.44 GB fetched for ~0.5 GB of distinct bytes).
 // COPY: the *_o copy of the previous pressure gradient (:488-522, k_pgf_copy_old3d) rides along -- the kernel overwrites
 // pgfx/pgfy(kn) level by level and takes the old value on the way (one launch and one sweep over the field less)
+#ifdef BLOM_HOSTEMU
+#define PGF_WAVE_ALL(p) false
+#else
+#define PGF_WAVE_ALL(p) (__all(p) != 0)
+#endif
 template <bool PAIR, bool COPY>
-__global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn) {
+__global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn, int reuse) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
   double pck = p[c + (size_t)kk * np], pmk = p[mns + (size_t)kk * np];
   double pck1_n = p[c + (size_t)(kk - 1) * np], pmk1_n = p[mns + (size_t)(kk - 1) * np];
   double old_n = COPY ? pgf[c + (size_t)(kk - 1) * np] : 0.;
+  double prs_prev = -1., dphip = 0., alpup = 0., alplp = 0., dphim = 0., alpum = 0., alplm = 0.;
   for (int k = kk; k >= 1; k--) {
     const double dpk = dpk_n, pzk = pz_n, pck1 = pck1_n, pmk1 = pmk1_n, old = old_n;
     if (k > 1) {                                             // level k-1's fixed-index loads
@@ -153,10 +159,14 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
     const double prs = pzk - .5 * dpk;
     while (rp.pu > prs) { kp--; rp = rp1; rp1 = load_rec(c, kp - 1); }
     while (rm.pu > prs) { km--; rm = rm1; rm1 = load_rec(mns, km - 1); }
-    double dphip, alpup, alplp, dphim, alpum, alplm;
     const double pplo = rp.pl, pmlo = rm.pl;
-    eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
-    eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    // a massless velocity layer repeats the previous level's mid-layer pressure and with it both records: the equation-of-state values
+    // of the previous level are this level's, bit for bit (see k_pgf_uv_ring, REUSE)
+    if (!(reuse && PGF_WAVE_ALL(prs == prs_prev))) {
+      eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
+      eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    }
+    prs_prev = prs;
     double cp = .25 * (pck + pck1);
     double cm = .25 * (pmk + pmk1);
     const double q = prs / (cp + cm);
@@ -207,8 +217,12 @@ struct PgfFix { double dpk, pzk, pck1, pmk1, old; };
 
 // DB: the speculative records and the fixed-index loads double-buffered over two unrolled levels (the level's loads are issued BEFORE
 // the wait for the previous level's: period (latency + arithmetic) / 2 per level, ~50 more VGPRs); !DB: one set (merge, then issue)
-template <bool PAIR, bool COPY, bool DB>
-__global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__ Vp, int n, int nn) {
+// REUSE: where a level's mid-layer pressure equals the previous level's (a massless velocity layer: dp = 0 -- two thirds of all levels
+// of the channel's bench state, and 28 of a wavefront's 53 levels for all of its lanes at once) the two scalar-column records are
+// the previous level's too, so both equation-of-state evaluations would reproduce the previous level's values bit for bit: a
+// wave-uniform branch skips them (the sums still receive their -- zero-thickness -- terms, in the reference's order).
+template <bool PAIR, bool COPY, bool DB, bool REUSE>
+__device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__
   bool advp = false, advm = false;
   double xip = 0., xim = 0., pgfm = 0.;
   double pck = pplo, pmk = pmlo;
+  double prs_prev = -1., dphip = 0., alpup = 0., alplp = 0., dphim = 0., alpum = 0., alplm = 0.;
   auto level = [&](const int k, PgfFix &fx, PgfFix &fxn, PgfRec &spo, PgfRec &smo, PgfRec &spn, PgfRec &smn) {
     if (DB) {                            // this level's loads, all unconditional, then the previous level's records take their place
       fxn = load_fix(k - 1);
@@ -298,9 +313,11 @@ __global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__
       if (a2m) { km = find(mns, km - 1, prs); rm = load_rec(mns, km); rm1 = load_rec(mns, km - 1); pmlo = p[mns + (size_t)km * np]; advm = false; }
       WAIT_VM0();
     }
-    double dphip, alpup, alplp, dphim, alpum, alplm;
-    eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
-    eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    if (!(REUSE && PGF_WAVE_ALL(prs == prs_prev))) {
+      eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
+      eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    }
+    prs_prev = prs;
     double cp = .25 * (pck + pck1);
     double cm = .25 * (pmk + pmk1);
     const double q = prs / (cp + cm);
@@ -342,6 +359,14 @@ __global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__
   (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
   (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
   (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+}
+
+template <bool PAIR, bool COPY, bool DB, bool REUSE>
+__global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__ Vp, int n, int nn) { pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn); }
+// W4: held to 128 VGPRs (four waves per SIMD: all 3 510 wavefronts of the channel resident at once; the compiler spills 26 - 124 registers)
+template <bool PAIR, bool COPY, bool DB, bool REUSE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pgf_uv_ring_w4(const DevView *__restrict__ Vp, int n, int nn) {
+  pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn);
 }
 
 // ---- pgforc_dynamic_enthalpy, phy/mod_pgforc.F90:269-412 ---------------------------------------------
@@ -466,16 +491,25 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
       if (c->pgf_uv_ring && copy_fused) {
         // pgf_uv_ring: 1 = separate u / v workgroups, 2 = paired + XCD-contiguous; + 2 = the double-buffered form
         const dim3 gs = plane_grid(h, 2, 64), gp = plane_grid(h, 1, 64);
-        switch (c->pgf_uv_ring) {
-          case 1: hipLaunchKernelGGL((k_pgf_uv_ring<false, true, false>), gs, dim3(64), 0, c->stream, c->d, n, nn); break;
-          case 2: hipLaunchKernelGGL((k_pgf_uv_ring<true, true, false>), gp, dim3(128), 0, c->stream, c->d, n, nn); break;
-          case 3: hipLaunchKernelGGL((k_pgf_uv_ring<false, true, true>), gs, dim3(64), 0, c->stream, c->d, n, nn); break;
-          default: hipLaunchKernelGGL((k_pgf_uv_ring<true, true, true>), gp, dim3(128), 0, c->stream, c->d, n, nn); break;
+        // + 10: with the reuse of the previous level's equation-of-state values (REUSE); + 100: held to four waves per SIMD (W4)
+        const int var = c->pgf_uv_ring % 10, reuse = (c->pgf_uv_ring / 10) % 10, w4 = c->pgf_uv_ring / 100;
+#define PGF_LAUNCH(P, D, R)                                                                                                   \
+  do {                                                                                                                        \
+    if (w4) hipLaunchKernelGGL((k_pgf_uv_ring_w4<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn);  \
+    else hipLaunchKernelGGL((k_pgf_uv_ring<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn);       \
+  } while (0)
+        if (reuse) {
+          if (var == 1) PGF_LAUNCH(false, false, true); else if (var == 2) PGF_LAUNCH(true, false, true);
+          else if (var == 3) PGF_LAUNCH(false, true, true); else PGF_LAUNCH(true, true, true);
+        } else {
+          if (var == 1) PGF_LAUNCH(false, false, false); else if (var == 2) PGF_LAUNCH(true, false, false);
+          else if (var == 3) PGF_LAUNCH(false, true, false); else PGF_LAUNCH(true, true, false);
         }
+#undef PGF_LAUNCH
       }
-      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn);
-      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
-      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
+      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn, c->pgf_reuse);
+      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse);
+      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse);
     }
     else hipLaunchKernelGGL(k_pgf_dynh_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
   }

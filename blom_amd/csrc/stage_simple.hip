@@ -100,6 +100,49 @@ __global__ void k_pscan(const DevView *__restrict__ Vp, int off, int lo, int hi_
   column_scan(V.f[F_p][c], V.f[F_dp] + (size_t)off * V.nplane + c, V.f[F_p] + c, V.nplane, V.kk);
 }
 
+// ---- the same scan with k ON THE LANES (option scan_reassoc, OFF by default: a measured tolerance-mode experiment, round 6) -------
+// BASELINE.json's north star names "k-layers mapped to the wavefront ... wavefront shuffles" and "a stated floating-point
+// tolerance"; the library holds tolerance zero, which forbids this kernel: a log-step prefix sum adds the layer thicknesses in a
+// different order than the reference's p(k+1) = p(k) + dp(k).  A workgroup of 256 threads takes 64 consecutive points of the
+// plane: all kk planes of dp are loaded coalesced (every level's load in flight at once, where the serial scan has COLUMN_U) into an
+// LDS tile [k][point], each wavefront then takes every fourth column with lane = level, runs the inclusive scan over the lanes with
+// six __shfl_up steps, and the tile goes back coalesced as p(2..kk+1).  kk <= 64.
+#define PSL_PTS 64
+#define PSL_LD (PSL_PTS + 1)        // row stride of the tile in doubles (odd: the lane-per-level reads spread over the banks)
+__global__ __launch_bounds__(256) void k_pscan_lanes(const DevView *__restrict__ Vp, int off, int lo, int hi_off) {
+  const DevView &V = *Vp;
+  __shared__ double tile[64 * PSL_LD];
+  __shared__ double base[PSL_PTS];
+  __shared__ int wet[PSL_PTS];
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  (void)by_;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, kk = V.kk;
+  const int t0 = bx_ * PSL_PTS, t = t0 + lane;
+  const size_t np = V.nplane;
+  const bool inpl = t < V.nplane;
+  const int i = inpl ? t % V.ni - (NBDY - 1) : 0, j = inpl ? t / V.ni - (NBDY - 1) : 0;
+  const bool mine = inpl && !(j < lo || j > V.jj + hi_off || i < lo || i > V.ii + hi_off) && V.m[I_ip][inpl ? t : 0] != 0;
+  gcd_t dp = V.f[F_dp] + (size_t)off * np;
+  gd_t p = V.f[F_p];
+  if (wv == 0) { wet[lane] = mine ? 1 : 0; base[lane] = mine ? p[t] : 0.; }
+  for (int k = wv; k < kk; k += 4) tile[k * PSL_LD + lane] = mine ? dp[t + (size_t)k * np] : 0.;
+  __syncthreads();
+  for (int col = wv; col < PSL_PTS; col += 4) {
+    if (!wet[col]) continue;                       // (wave-uniform)
+    double v = lane < kk ? tile[lane * PSL_LD + col] : 0.;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double u = __shfl_up(v, d);
+      if (lane >= d) v = v + u;
+    }
+    if (lane < kk) tile[lane * PSL_LD + col] = base[col] + v;
+  }
+  __syncthreads();
+  if (mine)
+    for (int k = wv; k < kk; k += 4) p[t + (size_t)(k + 1) * np] = tile[k * PSL_LD + lane];
+}
+
 // ---- dpu,dpv (and optionally pu,pv) from p, j,i = -1..+2 (mod_tmsmt.F90:369-391,
 //      mod_pgforc.F90:463-485, mod_mxlayr.F90:1282-1310) --------------------------------------
 // flags: 1 = pu, pv as well; 2 = the next step's tmsmt1 here (dpuold, dpvold = the new dpu, dpv, at the points of the tile);
@@ -158,8 +201,13 @@ __global__ __launch_bounds__(64) void k_dpudpv(const DevView *__restrict__ Vp, i
   }
 }
 
+static void pscan_any(blomgpu_ctx *c, int off, int lo, int hi_off) {
+  if (c->scan_reassoc && c->h.kk <= 64) hipLaunchKernelGGL(k_pscan_lanes, plane_grid(c->h, 1, PSL_PTS), dim3(256), 0, c->stream, c->d, off, lo, hi_off);
+  else hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, lo, hi_off);
+}
+
 int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int flags) {
-  hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, -2, 2);
+  pscan_any(c, off, -2, 2);
   hipLaunchKernelGGL(k_dpudpv, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, flags);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -172,7 +220,7 @@ int launch_dpudpv(blomgpu_ctx *c, int off, int flags) {
 }
 
 int launch_pscan(blomgpu_ctx *c, int off, int lo, int hi_off) {
-  hipLaunchKernelGGL(k_pscan, plane_grid(c->h, 1, 64), dim3(64), 0, c->stream, c->d, off, lo, hi_off);
+  pscan_any(c, off, lo, hi_off);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

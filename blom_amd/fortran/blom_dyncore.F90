@@ -88,6 +88,7 @@ program blom_dyncore
   call gpu_chksum('dp', 2*kdm, 1, 'dp')          ! blom.F:56-57
   call gpu_chksum('temp', 2*kdm, 1, 'temp')
   call gpu_chksum('u', 2*kdm, 13, 'u')
+  if (difest_estimates) call gpu_chksum('difint', kdm, 1, 'difint')     ! (the estimates ran: see mod_blomgpu)
   open (newunit=u, file='run.status', status='unknown')
   write (u,*) 'success'                          ! blom.F:59-61
   close (u)

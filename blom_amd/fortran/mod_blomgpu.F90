@@ -14,8 +14,10 @@ module mod_blomgpu
 
   use iso_c_binding
   implicit none
-  logical, save :: difest_estimates = .false.   ! see difest_isobml below
   private
+  ! difest_isobml below runs the whole routine when set: public, and also set by gpu_set('difest_live', 1) -- the option that makes
+  ! blomgpu_step estimate the diffusivities -- so that a host sequencing the stages itself and the device-resident loop agree
+  logical, save, public :: difest_estimates = .false.
 
   integer, parameter, public :: nbdy = 4          ! phy/mod_xc.F90:45
   type(c_ptr), save :: ctx = c_null_ptr
@@ -189,6 +191,7 @@ contains
     character(len=*), intent(in) :: name
     integer, intent(in) :: v
     call gpu_check(blomgpu_set_int(ctx, cz(name), v), 'gpu_set')
+    if (name == 'difest_live') difest_estimates = v /= 0
   end subroutine
   subroutine gpu_set_str(name, v)
     character(len=*), intent(in) :: name, v

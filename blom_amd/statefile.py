@@ -18,7 +18,7 @@ def write_state(path, be, case, nsteps, fields):
             f.write(struct.pack("<2i", kind, nlev))
             f.write(payload)
         for nm, v in case.params.items():
-            if nm.endswith("0"):
+            if nm.endswith("0") and nm != "ri0":          # (a trailing 0 marks a parameter of the case generator; ri0 is &DIFFUSION's)
                 continue
             if isinstance(v, str):
                 entry(nm, 4, 0, v.encode().ljust(32)[:32])

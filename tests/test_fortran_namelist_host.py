@@ -206,9 +206,12 @@ def test_reference_limits_file_drives_the_hybrid_step(tmp_path, neutral):
         g.LIB_PATH = old
 
 
-def run_full_physics(tmp_path, exe, BlomGpu, cfg="chan_s_tke", nsteps=6):
+def run_full_physics(tmp_path, exe, BlomGpu, cfg="chan_s_tke", nsteps=6, live=False):
     """the Fortran host sequencing config 2's stages (option record full_physics = 1) against blomgpu_step with that option; a
-    surface heat flux of either sign is switched on"""
+    surface heat flux of either sign is switched on.  live: with the option record difest_live = 1 as well -- gpu_set('difest_live', 1)
+    must make the shim's difest_isobml run the WHOLE routine (mod_blomgpu: difest_estimates; round 5's advisor found the switch
+    private and unreachable), so the host-sequenced run has to reproduce blomgpu_step's checksums with the diffusivities estimated
+    every step, and difint must differ from the frozen run's"""
     import re
     import subprocess
     import numpy as np
@@ -226,15 +229,31 @@ def run_full_physics(tmp_path, exe, BlomGpu, cfg="chan_s_tke", nsteps=6):
     forcing = ["ustarw", "swa", "nsf", "hmltfz", "lip", "sop", "eva", "rnf", "rfi", "fmltfz", "sfl", "swfc1", "swfc2", "swal1", "swal2", "ustar",
                "ustar3", "idkedt", "sstclm", "ricclm", "sssclm", "uml", "vml", "umlres", "vmlres"]
     names = [n for n in STATE_FIELDS + GRID_FIELDS + INT_FIELDS + forcing if gpu.has_field(n) and np.any(gpu.get(n))]
+    if live:
+        hostinit.init_difest(gpu, case, device=True)
+        for d_ in hostinit.DIFEST_NORESM:
+            for nm, v in d_.items():
+                gpu.set(nm, v)
+                case.params[nm] = v
+        case.params["bdml_logc"] = gpu.get_real("bdml_logc")
+        case.params["difest_live"] = 1
+        names += [n for n in ("plat", "cosang", "sinang", "betatp", "hangle", "twedon", "ficem", "tdmls", "bdmlq", "difint", "difiso", "difdia", "difwgt")
+                  if gpu.has_field(n)]
+        frozen_difint = gpu.crc("difint", 1, gpu.field_info("difint")[0], 1)
     names = list(dict.fromkeys(names))
     case.params["full_physics"] = 1
     case.params["area"] = float(np.sum(gpu.get("scp2")[0][4:-4, 4:-4][ip[4:-4, 4:-4] > 0]))
     state = str(tmp_path / "blom_state.bin")
     write_state(state, gpu, case, nsteps, names)
     gpu.set("full_physics", 1)
+    if live:
+        gpu.set("difest_live", 1)
     gpu.set("delt1", case.params["baclin"])
     assert gpu.step(0, nsteps) == nsteps
     want = {"dp": gpu.crc("dp", 1, 2 * case.kdm, 1), "temp": gpu.crc("temp", 1, 2 * case.kdm, 1), "u": gpu.crc("u", 1, 2 * case.kdm, 13)}
+    if live:
+        want["difint"] = gpu.crc("difint", 1, gpu.field_info("difint")[0], 1)
+        assert want["difint"] != frozen_difint, "the estimates did not move difint"
     assert np.abs(gpu.get("surflx")).max() > 0.0
     gpu.close()
     out = subprocess.run([exe, state], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
@@ -251,5 +270,17 @@ def test_fortran_host_sequences_the_full_physics_step(tmp_path):
     g.LIB_PATH = EMU
     try:
         run_full_physics(tmp_path, EXE, g.BlomGpu)
+    finally:
+        g.LIB_PATH = old
+
+
+@pytest.mark.skipif(not (os.path.exists(EMU) and os.path.exists(EXE)), reason="tests/hostemu not built")
+def test_fortran_host_runs_the_whole_difest_isobml_when_difest_live_is_set(tmp_path):
+    """gpu_set('difest_live', 1) reaches the shim's difest_isobml (on the host emulation of the device library)"""
+    import blom_amd.gpu as g
+    old = g.LIB_PATH
+    g.LIB_PATH = EMU
+    try:
+        run_full_physics(tmp_path, EXE, g.BlomGpu, live=True)
     finally:
         g.LIB_PATH = old

@@ -56,6 +56,17 @@ def test_fortran_driver_runs_the_full_physics_sequence(tmp_path):
     run_full_physics(tmp_path, exe, BlomGpu)
 
 
+def test_fortran_driver_estimates_the_diffusivities_when_difest_live_is_set(tmp_path):
+    """gpu_set('difest_live', 1) in the Fortran host makes the shim's difest_isobml the whole routine (mod_blomgpu: difest_estimates,
+    public since round 6): the host-sequenced step reproduces blomgpu_step's checksums with live diffusivities, difint included"""
+    from blom_amd.gpu import BlomGpu
+    from test_fortran_namelist_host import run_full_physics
+    exe = os.path.join(ROOT, "blom_amd", "lib", "blom_dyncore")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built")
+    run_full_physics(tmp_path, exe, BlomGpu, live=True)
+
+
 def test_fortran_hor3map_shim(tmp_path):
     """blom_amd/fortran/mod_hor3map_gpu.F90 (the reference's mod_hor3map names over the C ABI),
     driven by h3m_demo, against the Python binding on the same analytic columns"""

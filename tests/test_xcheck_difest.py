@@ -172,3 +172,40 @@ def test_full_size_channel_step_with_live_diffusivities_equals_the_reference_sta
     defaults for isopyc_bulkml, rhsctp off: hostinit.DIFEST_NORESM)"""
     from test_xcheck_ale import run_with_big_stack
     run_with_big_stack(_live_step_check, "channel_tke", 3, hostinit.DIFEST_NORESM)
+
+
+def _spunup_check(nspin, nsteps):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from oracle.refblom import get_ref_backend, have_ref
+    if not have_ref("channel_tke_omp_xdf"):
+        pytest.skip("oracle/_ref/channel_tke_omp_xdf/libblomref.so not built")
+    case, nreg, masks = bench.build_case("channel", "remap", "default")
+    gpu = bench.device_for_bench(case, nreg, masks, live=True)
+    try:
+        be = get_ref_backend("channel_tke_omp_xdf", case.depth, ntr=case.ntr)
+        be.ref.set("eitmth", "gm")
+        be.has_stage = lambda name: True
+        bench.ref_full_init(be, case, True, True)
+        ns = gpu.step(0, nspin)
+        assert ns == nspin
+        nr = bench.continue_from_device(be, gpu, ns, case)
+        check = [f for f in CHECK if f not in ("utotn", "vtotn")] + [f for f in DFE_OUT if f not in CHECK]
+        for _ in range(nsteps):
+            nr = dyncore_step(be, nr, case.params["baclin"], stages=FULL_STAGES_LIVE)
+            ns = gpu.step(ns, 1)
+            bad = diff_report(be, gpu, fields=check)
+            assert not bad, f"step {nr}\n" + fmt_report(bad[:12])
+    finally:
+        gpu.close()
+
+
+def test_full_size_channel_step_from_a_spun_up_state_equals_the_reference_stage_sequence():
+    """A state a model run is in, not the transient from rest: the bench workload (208x512x53, ntr = 3, NorESM's defaults) after 300
+    device-resident steps -- deep mixed layers, an eddying flow of 2 m/s, massless layers throughout -- handed to the reference's
+    modules (bench.continue_from_device: what `bench.py --spinup N` starts its CPU baseline from); two more steps on both sides,
+    every array of the step equal bit for bit"""
+    from test_xcheck_ale import run_with_big_stack
+    run_with_big_stack(_spunup_check, 300, 2)
