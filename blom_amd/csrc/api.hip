@@ -415,6 +415,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "eddtra_frozen") { c->eddtra_frozen = v; return 0; }
   if (s == "pgf_uv_pair") { c->pgf_uv_pair = v; return 0; }
   if (s == "pgf_uv_ring") { c->pgf_uv_ring = v; return 0; }
+  if (s == "cmn_nslope_nb") { c->cmn_nslope_nb = v; return 0; }
   if (s == "pgf_reuse") { c->pgf_reuse = v; return 0; }
   if (s == "scan_reassoc") { c->scan_reassoc = v; return 0; }
   if (s == "pgf_copy_fused") { c->pgf_copy_fused = v; return 0; }
@@ -961,6 +962,25 @@ int blomgpu_dbg_bt_prof(blomgpu_ctx *c, long long *host, int nwords) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(host, c->bt_prof, sizeof(long long) * nwords, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// debug: per-wavefront phase timestamps of the column kernels that carry KPROF marks (library built with -DBLOM_KPROF: tools/probes;
+// the production build records nothing): host == nullptr allocates and zeroes nwords, otherwise copies them back.  The kernels
+// bound-check their slot against the stored size.
+int blomgpu_dbg_kprof(blomgpu_ctx *c, long long *host, int nwords) {
+  if (!host) {
+    if (c->kprof) (void)hipFree(c->kprof);
+    c->kprof = nullptr; c->kprof_words = 0;
+    if (nwords <= 0) return 0;
+    HIPCHK(c, hipMalloc((void **)&c->kprof, sizeof(long long) * nwords));
+    HIPCHK(c, hipMemset(c->kprof, 0, sizeof(long long) * nwords));
+    c->kprof_words = nwords;
+    return 0;
+  }
+  if (!c->kprof || nwords > c->kprof_words) return ctx_fail(c, "blomgpu_dbg_kprof: no buffer of that size");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host, c->kprof, sizeof(long long) * nwords, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -278,6 +278,7 @@ struct blomgpu_ctx {
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
   int scan_reassoc = 0;          // TOLERANCE-MODE EXPERIMENT (off): k_pscan with k on the lanes and a log-step shuffle prefix sum -- NOT bit-identical to the reference (stage_simple.hip)
+  int cmn_nslope_nb = 4;         // k_cmn_nslope: interfaces in flight in the interior sweep (A/B: 2, 3, 4)
   int pgf_reuse = 0;             // k_pgf_uv: skip the equation of state where a level repeats the previous level's inputs (wave-uniform; bit-identical)
   int pgf_uv_ring = 0;           // k_pgf_uv_ring (round 6: every load of the level loop statically countable): 1 = separate u / v workgroups, 2 = paired + XCD-contiguous
   int pgf_copy_fused = 1;        // pgforc: the pgfx_o/pgfy_o copy rides along in k_pgf_uv
@@ -327,6 +328,8 @@ struct blomgpu_ctx {
   int bt_blocks_per_cu[4] = {-1, -1, -1, -1};   // occupancy query results for the persistent barotp kernel's shapes (-1: not asked yet)
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
+  long long *kprof = nullptr;     // debug (builds with -DBLOM_KPROF): per-wavefront phase timestamps of a column kernel, 8 words a wave (blomgpu_dbg_kprof)
+  int kprof_words = 0;
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int ndiff_rec_per_face = 0;    // neutral diffusion: records per face (0: 6 kk, the bound; stage_ale.hip)
   int ndiff_surface_align = 1;   // phy/mod_diffusion.F90:84 (the namelist default of cime_config is .true.)

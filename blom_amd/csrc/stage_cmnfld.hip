@@ -192,6 +192,9 @@ __global__ __launch_bounds__(64) void k_cmn_phi(const DevView *__restrict__ Vp, 
 }
 
 // ---- slope of the local neutral surface at u- (blockIdx.y = 0) and v-points (1), :465-641 -----------------------------
+// NB interfaces' loads in flight in the interior sweep.  With 4 the kernel needs 164 VGPRs: three wavefronts a SIMD, 3 072 of the
+// channel's 3 442 u- and v-column wavefronts start at once and the launch lasts two rounds; NB = 2 keeps it under 128 (round 6).
+template <int NB>
 __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   COLUMN_IJ(V);
@@ -235,17 +238,17 @@ __global__ __launch_bounds__(64) void k_cmn_nslope(const DevView *__restrict__ V
     const int kf = kintr + 1;
     double tbm = kf <= kmax ? A(temp, b_, kf - 1) : 0., sbm = kf <= kmax ? A(saln, b_, kf - 1) : 0.;
     double tam = kf <= kmax ? A(temp, a_, kf - 1) : 0., sam = kf <= kmax ? A(saln, a_, kf - 1) : 0.;
-    for (int k0 = kf; k0 <= kmax; k0 += 4) {
-      double pa[4], pb[4], tb[4], sb[4], ta[4], sa[4], fb[4], fa[4], ba[4], bb[4];
+    for (int k0 = kf; k0 <= kmax; k0 += NB) {
+      double pa[NB], pb[NB], tb[NB], sb[NB], ta[NB], sa[NB], fb[NB], fa[NB], ba[NB], bb[NB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < NB; u++) {
         const int kq = k0 + u <= kmax ? k0 + u : kmax;
         pa[u] = A(p, a_, kq); pb[u] = A(p, b_, kq);
         tb[u] = A(temp, b_, kq); sb[u] = A(saln, b_, kq); ta[u] = A(temp, a_, kq); sa[u] = A(saln, a_, kq);
         fb[u] = A(phi, b_, kq); fa[u] = A(phi, a_, kq); ba[u] = A(bf, a_, kq); bb[u] = A(bf, b_, kq);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < NB; u++) {
         const int k = k0 + u;
         if (k > kmax) break;
         const double pm = .5 * (pa[u] + pb[u]);
@@ -653,7 +656,11 @@ int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   TimeScope ts(c, "cmnfld");
   hipLaunchKernelGGL(k_cmn_bfsqf, g1, dim3(64), 0, c->stream, c->d, n, nn);
   hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
-  hipLaunchKernelGGL(k_cmn_nslope, g2, dim3(64), 0, c->stream, c->d, n, nn);
+  switch (c->cmn_nslope_nb) {
+    case 4: hipLaunchKernelGGL(k_cmn_nslope<4>, g2, dim3(64), 0, c->stream, c->d, n, nn); break;
+    case 3: hipLaunchKernelGGL(k_cmn_nslope<3>, g2, dim3(64), 0, c->stream, c->d, n, nn); break;
+    default: hipLaunchKernelGGL(k_cmn_nslope<2>, g2, dim3(64), 0, c->stream, c->d, n, nn); break;
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }

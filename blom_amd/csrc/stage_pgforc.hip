@@ -21,6 +21,19 @@ int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int with_pupv);
 #define EPSILP 1.e-12
 #define GRAV 9.806
 
+// per-wavefront phase timestamps (debug builds with -DBLOM_KPROF only; blomgpu_dbg_kprof): wave w writes words 8 w .. 8 w + 7
+#ifdef BLOM_KPROF
+#define KPROF_ARGS , long long *kprof, int kprof_words
+#define KPROF_PASS , c->kprof, c->kprof_words
+#define KPROF_MARK(wave, slot) do { if (kprof && 8 * (wave) + (slot) < kprof_words) kprof[8 * (wave) + (slot)] = wall_clock64(); } while (0)
+#define KPROF_ADD(wave, slot, v) do { if (kprof && 8 * (wave) + (slot) < kprof_words) atomicAdd((unsigned long long *)&kprof[8 * (wave) + (slot)], (unsigned long long)(v)); } while (0)
+#else
+#define KPROF_ARGS
+#define KPROF_PASS
+#define KPROF_MARK(wave, slot) do { } while (0)
+#define KPROF_ADD(wave, slot, v) do { } while (0)
+#endif
+
 __global__ void k_pgf_copy_old2d(const DevView *__restrict__ Vp, int n) {
   const DevView &V = *Vp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(64) void k_pgf_phi(const DevView *__restrict__ Vp, 
 #define PGF_WAVE_ALL(p) (__all(p) != 0)
 #endif
 template <bool PAIR, bool COPY>
-__global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn, int reuse) {
+__global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, int n, int nn, int reuse KPROF_ARGS) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -140,6 +153,8 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
     r.ph = phi[col + (size_t)kc * np]; r.php = phip[col + (size_t)kc * np];
     return r;
   };
+  [[maybe_unused]] const int wid = PAIR ? (int)bx_ * 2 + (int)(threadIdx.x >> 6) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  KPROF_MARK(wid, 0);
   int kp = kk, km = kk;                  // kup/kum (1-based layer indices as in the reference)
   Rec rp = load_rec(c, kp), rp1 = load_rec(c, kp - 1), rm = load_rec(mns, km), rm1 = load_rec(mns, km - 1);
   double xip = 0., xim = 0., pgfm = 0.;
@@ -157,8 +172,16 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
     }
     if (COPY) pgf_o[c + (size_t)(k - 1) * np] = old;
     const double prs = pzk - .5 * dpk;
+#ifdef BLOM_KPROF
+    const int kp0_ = kp, km0_ = km;
+#endif
     while (rp.pu > prs) { kp--; rp = rp1; rp1 = load_rec(c, kp - 1); }
     while (rm.pu > prs) { km--; rm = rm1; rm1 = load_rec(mns, km - 1); }
+#ifdef BLOM_KPROF
+    KPROF_ADD(wid, 4, (kp0_ - kp) + (km0_ - km));
+    if (kp0_ - kp > 1 || km0_ - km > 1) KPROF_ADD(wid, 5, 1);
+    if (k == kk) KPROF_MARK(wid, 1);
+#endif
     const double pplo = rp.pl, pmlo = rm.pl;
     // a massless velocity layer repeats the previous level's mid-layer pressure and with it both records: the equation-of-state values
     // of the previous level are this level's, bit for bit (see k_pgf_uv_ring, REUSE)
@@ -181,6 +204,7 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
     pgfm = pgfm + g * dpk;
     pck = pck1; pmk = pmk1;
   }
+  KPROF_MARK(wid, 2);
   // :543-589
   const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
   pgfm = pgfm * q;
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(128) void k_pgf_uv(const DevView *__restrict__ Vp, 
   (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
   (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
   (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+  KPROF_MARK(wid, 3);
 }
 
 // k_pgf_uv with every load of the level loop statically countable (round 6).  In k_pgf_uv above the record of the layer above
@@ -222,7 +247,7 @@ struct PgfFix { double dpk, pzk, pck1, pmk1, old; };
 // the previous level's too, so both equation-of-state evaluations would reproduce the previous level's values bit for bit: a
 // wave-uniform branch skips them (the sums still receive their -- zero-thickness -- terms, in the reference's order).
 template <bool PAIR, bool COPY, bool DB, bool REUSE>
-__device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp, int n, int nn) {
+__device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp, int n, int nn KPROF_ARGS) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
   xcd_block(bx_, by_);
@@ -276,6 +301,8 @@ __device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp,
       q0 -= 4;
     }
   };
+  [[maybe_unused]] const int wid = PAIR ? (int)bx_ * 2 + (int)(threadIdx.x >> 6) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  KPROF_MARK(wid, 0);
   int kp = kk, km = kk;                  // kup/kum (1-based layer indices as in the reference)
   PgfRec rp = load_rec(c, kp), rp1 = load_rec(c, kp - 1), rm = load_rec(mns, km), rm1 = load_rec(mns, km - 1);
   double pplo = p[c + (size_t)kk * np], pmlo = p[mns + (size_t)kk * np];      // p(kp+1), p(km+1)
@@ -309,10 +336,13 @@ __device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp,
     if (a1p) { kp--; pplo = rp.pu; rp = rp1; }
     if (a1m) { km--; pmlo = rm.pu; rm = rm1; }
     if (a2p || a2m) {                    // two or more layers at once: the slow path ends with nothing in flight
+      KPROF_ADD(wid, 5, 1);
       if (a2p) { kp = find(c, kp - 1, prs); rp = load_rec(c, kp); rp1 = load_rec(c, kp - 1); pplo = p[c + (size_t)kp * np]; advp = false; }
       if (a2m) { km = find(mns, km - 1, prs); rm = load_rec(mns, km); rm1 = load_rec(mns, km - 1); pmlo = p[mns + (size_t)km * np]; advm = false; }
       WAIT_VM0();
     }
+    if (k == kk) KPROF_MARK(wid, 1);
+    KPROF_ADD(wid, 4, (a1p ? 1 : 0) + (a1m ? 1 : 0));
     if (!(REUSE && PGF_WAVE_ALL(prs == prs_prev))) {
       eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
       eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
@@ -342,6 +372,7 @@ __device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp,
   } else {
     for (int k = kk; k >= 1; k--) level(k, fxB, fxA, spA, smA, spA, smA);
   }
+  KPROF_MARK(wid, 2);
   // :543-589
   const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
   pgfm = pgfm * q;
@@ -359,14 +390,154 @@ __device__ __forceinline__ void pgf_uv_ring_body(const DevView *__restrict__ Vp,
   (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
   (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
   (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+  KPROF_MARK(wid, 3);
 }
 
 template <bool PAIR, bool COPY, bool DB, bool REUSE>
-__global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__ Vp, int n, int nn) { pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn); }
+__global__ __launch_bounds__(128) void k_pgf_uv_ring(const DevView *__restrict__ Vp, int n, int nn KPROF_ARGS) {
+#ifdef BLOM_KPROF
+  pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn, kprof, kprof_words);
+#else
+  pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn);
+#endif
+}
 // W4: held to 128 VGPRs (four waves per SIMD: all 3 510 wavefronts of the channel resident at once; the compiler spills 26 - 124 registers)
 template <bool PAIR, bool COPY, bool DB, bool REUSE>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pgf_uv_ring_w4(const DevView *__restrict__ Vp, int n, int nn) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pgf_uv_ring_w4(const DevView *__restrict__ Vp, int n, int nn KPROF_ARGS) {
+#ifdef BLOM_KPROF
+  pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn, kprof, kprof_words);
+#else
   pgf_uv_ring_body<PAIR, COPY, DB, REUSE>(Vp, n, nn);
+#endif
+}
+
+// k_pgf_uv_next: the lean form of the ring (round 6, after the per-wavefront timestamps of tools/kprof_waves.py).  k_pgf_uv_ring's
+// wavefronts live half as long as k_pgf_uv's (216 against 403 us), but at 140 - 176 VGPRs only three of them fit a SIMD: 3 072 of the
+// channel's 3 442 start at once and the launch waits for a second round.  Here a scalar column keeps ONE full record (its current
+// layer kp) and one speculative record, that of layer kp - 1, requested unconditionally every level right after the level's move is
+// known -- a level's time before a move can need it.  A move by one layer copies it; by two or more: the slow path (four interface
+// pressures in flight per round, then both records).  Still every load of the fast path is in straight-line code (counted waits).
+template <bool PAIR, bool COPY>
+__global__ __launch_bounds__(128) void k_pgf_uv_next(const DevView *__restrict__ Vp, int n, int nn KPROF_ARGS) {
+  const DevView &V = *Vp;
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  const int t = PAIR ? bx_ * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V.nplane) return;
+  const int i = t % V.ni - (NBDY - 1), j = t / V.ni - (NBDY - 1);
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const bool isv = PAIR ? threadIdx.x >= 64 : blockIdx.y == 1;
+  const size_t c = t, np = V.nplane;
+  if (!(isv ? V.m[I_iv][c] : V.m[I_iu][c])) return;
+  const size_t mns = isv ? c - V.ni : c - 1;
+  const int kk = V.kk;
+  gcd_t p = V.f[F_p], phi = V.f[F_phi], phip = V.f[F_wkp0];
+  gcd_t temp = V.f[F_temp] + (size_t)nn * np, saln = V.f[F_saln] + (size_t)nn * np;
+  gcd_t pz = isv ? V.f[F_pv] : V.f[F_pu];
+  gcd_t dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
+  gd_t pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
+  [[maybe_unused]] gd_t pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
+  auto load_rec = [&](size_t col, int kq) {
+    const int kc = kq < 1 ? 1 : kq;
+    PgfRec r;
+    r.pu = p[col + (size_t)(kc - 1) * np];
+    r.t = temp[col + (size_t)(kc - 1) * np]; r.s = saln[col + (size_t)(kc - 1) * np];
+    r.ph = phi[col + (size_t)kc * np]; r.php = phip[col + (size_t)kc * np];
+    return r;
+  };
+  auto load_fix = [&](int k) {
+    const int kc = k < 1 ? 1 : k;
+    PgfFix f;
+    f.dpk = dpz[c + (size_t)(kc - 1) * np]; f.pzk = pz[c + (size_t)kc * np];
+    f.pck1 = p[c + (size_t)(kc - 1) * np]; f.pmk1 = p[mns + (size_t)(kc - 1) * np];
+    f.old = COPY ? pgf[c + (size_t)(kc - 1) * np] : 0.;
+    return f;
+  };
+  auto find = [&](size_t col, int q0, double prs) {      // the largest q <= q0 with p(q) <= prs
+    for (;;) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int q = q0 - u < 1 ? 1 : q0 - u; v[u] = p[col + (size_t)(q - 1) * np]; }
+      int nup = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) nup += v[u] > prs ? 1 : 0;
+      if (nup < 4 || q0 - 4 < 1) { const int q = q0 - nup; return q < 1 ? 1 : q; }
+      q0 -= 4;
+    }
+  };
+  [[maybe_unused]] const int wid = PAIR ? (int)bx_ * 2 + (int)(threadIdx.x >> 6) : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  KPROF_MARK(wid, 0);
+  int kp = kk, km = kk;                  // kup/kum (1-based layer indices as in the reference)
+  PgfRec rp = load_rec(c, kp), sp = load_rec(c, kp - 1), rm = load_rec(mns, km), sm = load_rec(mns, km - 1);
+  double pplo = p[c + (size_t)kk * np], pmlo = p[mns + (size_t)kk * np];      // p(kp+1), p(km+1)
+  PgfFix fxn = load_fix(kk);
+  double xip = 0., xim = 0., pgfm = 0.;
+  double pck = pplo, pmk = pmlo, g_prev = 0.;
+  for (int k = kk; k >= 1; k--) {
+    const PgfFix fx = fxn;
+    const double dpk = fx.dpk, pck1 = fx.pck1, pmk1 = fx.pmk1;
+    const double prs = fx.pzk - .5 * dpk;
+    const bool a1p = rp.pu > prs, a1m = rm.pu > prs;
+    const bool a2p = a1p && sp.pu > prs, a2m = a1m && sm.pu > prs;
+    if (a1p) { kp--; pplo = rp.pu; rp = sp; }
+    if (a1m) { km--; pmlo = rm.pu; rm = sm; }
+    if (a2p || a2m) {                    // two or more layers at once
+      KPROF_ADD(wid, 5, 1);
+      if (a2p) { kp = find(c, kp - 1, prs); rp = load_rec(c, kp); pplo = p[c + (size_t)kp * np]; }
+      if (a2m) { km = find(mns, km - 1, prs); rm = load_rec(mns, km); pmlo = p[mns + (size_t)km * np]; }
+      WAIT_VM0();
+    }
+    // the level's stores go out BEFORE its loads -- the previous level's result, kept in a register until here, and the *_o copy --
+    // so that the youngest operations in flight at the next level's top are loads it needs anyway (a store issued at the end of the
+    // level would be the wave's youngest: waiting for the records would wait for its acknowledgement, a write round trip per level)
+    if (k < kk) pgf[c + (size_t)k * np] = g_prev;
+    if (COPY) pgf_o[c + (size_t)(k - 1) * np] = fx.old;
+    // this level's loads: the fixed-index ones of level k - 1 and the records a move at level k - 1 would need
+    fxn = load_fix(k - 1);
+    sp = load_rec(c, kp - 1);
+    sm = load_rec(mns, km - 1);
+    // (the scheduler minimises register pressure: without the barrier it moves these loads below the equation of state, next to
+    // their first use -- the opposite of what they are issued here for)
+    __builtin_amdgcn_sched_barrier(0);
+    if (k == kk) KPROF_MARK(wid, 1);
+    KPROF_ADD(wid, 4, (a1p ? 1 : 0) + (a1m ? 1 : 0));
+    double dphip, alpup, alplp, dphim, alpum, alplm;
+    eos::delphi(prs, pplo, rp.t, rp.s, dphip, alpup, alplp);
+    eos::delphi(prs, pmlo, rm.t, rm.s, dphim, alpum, alplm);
+    double cp = .25 * (pck + pck1);
+    double cm = .25 * (pmk + pmk1);
+    const double q = prs / (cp + cm);
+    cp = q * cp;
+    cm = q * cm;
+    const double phi_p = rp.ph - dphip;
+    xip = xip + (rp.php + pplo * alplp - cp * (alpup - alpum)) * dpk;
+    const double phi_m = rm.ph - dphim;
+    xim = xim + (rm.php + pmlo * alplm - cm * (alpum - alpup)) * dpk;
+    const double g = -(phi_p - phi_m);
+    g_prev = g;
+    pgfm = pgfm + g * dpk;
+    pck = pck1; pmk = pmk1;
+  }
+  pgf[c] = g_prev;
+  KPROF_MARK(wid, 2);
+  // :543-589
+  const double q = 1. / (isv ? V.f[F_pbv_p][c] : V.f[F_pbu_p][c]);
+  pgfm = pgfm * q;
+  xip = xip * q;
+  xim = xim * q;
+  for (int k0 = 0; k0 < kk; k0 += COLUMN_U) {
+    double a0[COLUMN_U];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++) a0[u] = pgf[c + (size_t)(k0 + u < kk ? k0 + u : kk - 1) * np];
+#pragma unroll
+    for (int u = 0; u < COLUMN_U; u++)
+      if (k0 + u < kk) pgf[c + (size_t)(k0 + u) * np] = a0[u] - pgfm;
+  }
+  const size_t on = (size_t)(n - 1) * np;
+  (isv ? V.f[F_pgfym] : V.f[F_pgfxm])[c + on] = pgfm + xip - xim;
+  (isv ? V.f[F_xiyp] : V.f[F_xixp])[c + on] = xip / V.f[F_pb_p][c];
+  (isv ? V.f[F_xiym] : V.f[F_xixm])[c + on] = xim / V.f[F_pb_p][mns];
+  KPROF_MARK(wid, 3);
 }
 
 // ---- pgforc_dynamic_enthalpy, phy/mod_pgforc.F90:269-412 ---------------------------------------------
@@ -488,15 +659,19 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
     if (h.P.pgfmth == 0) {
       TimeScope tk(c, "k_pgf_uv");
-      if (c->pgf_uv_ring && copy_fused) {
+      if ((c->pgf_uv_ring == 5 || c->pgf_uv_ring == 6) && copy_fused) {
+        if (c->pgf_uv_ring == 5) hipLaunchKernelGGL((k_pgf_uv_next<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn KPROF_PASS);
+        else hipLaunchKernelGGL((k_pgf_uv_next<true, true>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn KPROF_PASS);
+      }
+      else if (c->pgf_uv_ring && copy_fused) {
         // pgf_uv_ring: 1 = separate u / v workgroups, 2 = paired + XCD-contiguous; + 2 = the double-buffered form
         const dim3 gs = plane_grid(h, 2, 64), gp = plane_grid(h, 1, 64);
         // + 10: with the reuse of the previous level's equation-of-state values (REUSE); + 100: held to four waves per SIMD (W4)
         const int var = c->pgf_uv_ring % 10, reuse = (c->pgf_uv_ring / 10) % 10, w4 = c->pgf_uv_ring / 100;
 #define PGF_LAUNCH(P, D, R)                                                                                                   \
   do {                                                                                                                        \
-    if (w4) hipLaunchKernelGGL((k_pgf_uv_ring_w4<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn);  \
-    else hipLaunchKernelGGL((k_pgf_uv_ring<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn);       \
+    if (w4) hipLaunchKernelGGL((k_pgf_uv_ring_w4<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn KPROF_PASS);  \
+    else hipLaunchKernelGGL((k_pgf_uv_ring<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn KPROF_PASS);       \
   } while (0)
         if (reuse) {
           if (var == 1) PGF_LAUNCH(false, false, true); else if (var == 2) PGF_LAUNCH(true, false, true);
@@ -507,9 +682,9 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
 #undef PGF_LAUNCH
       }
-      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn, c->pgf_reuse);
-      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse);
-      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse);
+      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS);
+      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS);
+      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS);
     }
     else hipLaunchKernelGGL(k_pgf_dynh_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
   }
