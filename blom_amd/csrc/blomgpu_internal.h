@@ -210,6 +210,20 @@ __host__ __device__ inline double fmin2(double a, double b) { return a < b ? a :
 __host__ __device__ inline double fmax3(double a, double b, double c) { return fmax2(fmax2(a, b), c); }
 __host__ __device__ inline double fmin3(double a, double b, double c) { return fmin2(fmin2(a, b), c); }
 
+// per-wavefront phase timestamps (debug builds with -DBLOM_KPROF only: `make kprof`; blomgpu_dbg_kprof, tools/kprof_waves.py): wave w
+// writes words 8 w .. 8 w + 7; KPROF_PASS(id) hands the buffer to the kernel the option kprof_sel names and nullptr to the others
+#ifdef BLOM_KPROF
+#define KPROF_ARGS , long long *kprof, int kprof_words
+#define KPROF_PASS(id) , (c->kprof_sel == (id) ? c->kprof : nullptr), c->kprof_words
+#define KPROF_MARK(wave, slot) do { if (kprof && 8 * (wave) + (slot) < kprof_words) kprof[8 * (wave) + (slot)] = wall_clock64(); } while (0)
+#define KPROF_ADD(wave, slot, v) do { if (kprof && 8 * (wave) + (slot) < kprof_words) atomicAdd((unsigned long long *)&kprof[8 * (wave) + (slot)], (unsigned long long)(v)); } while (0)
+#else
+#define KPROF_ARGS
+#define KPROF_PASS(id)
+#define KPROF_MARK(wave, slot) do { } while (0)
+#define KPROF_ADD(wave, slot, v) do { } while (0)
+#endif
+
 // ---- context ---------------------------------------------------------------------------
 struct KTimer {
   double ms = 0.0;
@@ -330,6 +344,7 @@ struct blomgpu_ctx {
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   long long *kprof = nullptr;     // debug (builds with -DBLOM_KPROF): per-wavefront phase timestamps of a column kernel, 8 words a wave (blomgpu_dbg_kprof)
   int kprof_words = 0;
+  int kprof_sel = 1;              // which marked kernel writes: 1 k_pgf_uv*, 2 k_diapfl_column3, 3 k_mxl_column, 4 k_convec_column, 5 k_eddtra_gm, 6 k_mom_column_from, 7 k_diapfl_momentum
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int ndiff_rec_per_face = 0;    // neutral diffusion: records per face (0: 6 kk, the bound; stage_ale.hip)
   int ndiff_surface_align = 1;   // phy/mod_diffusion.F90:84 (the namelist default of cime_config is .true.)

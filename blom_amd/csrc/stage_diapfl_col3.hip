@@ -49,7 +49,7 @@ enum { E_SU, E_SL, E_FCU, E_FCL, E_FMAX, E_H, E_R, E_T, E_F, E_FT, E_GTD, E_NSLO
 // up + first guess) carry an equation-of-state evaluation resp. a square root and four divisions per level and are
 // unrolled DH = min(DU, 4) deep: 8 deep they need 255 VGPRs and spill 300 SGPRs
 template <int DU>
-__global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restrict__ Vp, int n, int nn, int *__restrict__ errflag) {
+__global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restrict__ Vp, int n, int nn, int *__restrict__ errflag KPROF_ARGS) {
   const DevView &V = *Vp;
   constexpr int DH = DU < 4 ? DU : 4;
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,6 +62,8 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
   const Params P = V.P;        // by value: the equation-of-state coefficients stay in registers across the stores
   const double dsgmnr = .1, fcmxr = .25, dsgcr0 = .25, dfeps = 1.e-12, gbbl = .2, kappa = .4, ustmin = .0001;
   const double cc = GRAV * GRAV * P.delt1 / (ALPHA0 * ALPHA0);                       // :95
+  [[maybe_unused]] const int wid = blockIdx.x;     // KPROF words: 0 start, 1 limiter starts, 2 solver starts, 3 mixing starts, 4 massless layers start, 5 end; 6 limiter sweeps, 7 solver iterations (summed over lanes)
+  KPROF_MARK(wid, 0);
   // (address-space typed: blomgpu_internal.h, PtrTable)
   gcd_t __restrict__ sigr = V.f[F_sigmar];
   gd_t __restrict__ wb = global_ptr(V.wk) + (size_t)blockIdx.x * (kk + 1) * WNS * 64 + threadIdx.x;
@@ -142,6 +144,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
         fcu_b = fpu_b * su_b;
       }
       // ---- flux limiter, :292-330 ------------------------------------------------------------
+      KPROF_MARK(wid, 1);
       bool done = false, first = true;
       int niter = 0, kfmaxu = 0;
       double dflim = 0.;
@@ -276,10 +279,12 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
 #undef DIAPFL_GUESS
         // the reference tests niter == 100 without ever incrementing niter in this loop (:317),
         // i.e. it never aborts here; we bound the loop defensively and flag it.
+        KPROF_ADD(wid, 6, 1);
         if (++niter > 100000) { atomicOr(errflag, 1); break; }
       }
       dflim = dflim * dfeps;
       // ---- implicit solve by alternating sweeps, :357-533 ------------------------------------
+      KPROF_MARK(wid, 2);
       niter = 0;
       bool dwnwrd = false;
       for (;;) {
@@ -400,6 +405,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
           }
         }
         niter = niter + 1;
+        KPROF_ADD(wid, 7, 1);
         if (maxdf <= dflim) break;
         if (niter == 100) { atomicOr(errflag, 2); break; }                         // :520-532 (xchalt)
       }
@@ -425,6 +431,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
       ST(fplg, kmax) = 0.;
       ST(fpug, kfpl) = fpl1;                                                         // :541
     }
+    KPROF_MARK(wid, 3);
     // ---- implicit mixing of S, T, tracers over positions kmin..kmax, :546-576, fused with the layer
     //      thickness update :572-576 (which only reads fluxes) ------------------------------------
     {
@@ -548,6 +555,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
     if (kmax == kmin + 1 && kmin >= 2) ST(sigma, 2) = ST(sigma, kmin + 1);
   }
   // ---- massless layers, :605-651 ---------------------------------------------------------------
+  KPROF_MARK(wid, 4);
   if (kfpl > kmax) {
     const double t2 = ST(temp, 2);
     for (int k = 3; k <= kk; k++) {
@@ -635,6 +643,7 @@ __global__ void __launch_bounds__(64, 1) k_diapfl_column3(const DevView *__restr
     for (int k = kmax + 1; k <= kk; k++) { ST(fpug, k) = 0.; ST(fplg, k) = 0.; }
   } else
     for (int k = 1; k <= kk; k++) { ST(fpug, k) = 0.; ST(fplg, k) = 0.; }
+  KPROF_MARK(wid, 5);
 }
 
 int diapfl_column3_launch(blomgpu_ctx *c, int n, int nn, int *errflag) {
@@ -643,8 +652,8 @@ int diapfl_column3_launch(blomgpu_ctx *c, int n, int nn, int *errflag) {
   const dim3 g = plane_grid(h, 1, 64);
   if ((size_t)g.x * (h.kk + 1) * WNS * 64 > (size_t)h.nwk * h.kk * h.nplane) return ctx_fail(c, "diapfl: work space too small");
   TimeScope tk(c, "k_diapfl_column3");
-  if (c->diapfl_du == 8) hipLaunchKernelGGL(k_diapfl_column3<8>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);
-  else if (c->diapfl_du == 2) hipLaunchKernelGGL(k_diapfl_column3<2>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);
-  else hipLaunchKernelGGL(k_diapfl_column3<4>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag);
+  if (c->diapfl_du == 8) hipLaunchKernelGGL(k_diapfl_column3<8>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag KPROF_PASS(2));
+  else if (c->diapfl_du == 2) hipLaunchKernelGGL(k_diapfl_column3<2>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag KPROF_PASS(2));
+  else hipLaunchKernelGGL(k_diapfl_column3<4>, g, dim3(64), 0, c->stream, c->d, n, nn, errflag KPROF_PASS(2));
   return 0;
 }

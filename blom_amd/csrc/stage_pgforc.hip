@@ -21,18 +21,6 @@ int launch_p_dpu_dpv(blomgpu_ctx *c, int off, int with_pupv);
 #define EPSILP 1.e-12
 #define GRAV 9.806
 
-// per-wavefront phase timestamps (debug builds with -DBLOM_KPROF only; blomgpu_dbg_kprof): wave w writes words 8 w .. 8 w + 7
-#ifdef BLOM_KPROF
-#define KPROF_ARGS , long long *kprof, int kprof_words
-#define KPROF_PASS , c->kprof, c->kprof_words
-#define KPROF_MARK(wave, slot) do { if (kprof && 8 * (wave) + (slot) < kprof_words) kprof[8 * (wave) + (slot)] = wall_clock64(); } while (0)
-#define KPROF_ADD(wave, slot, v) do { if (kprof && 8 * (wave) + (slot) < kprof_words) atomicAdd((unsigned long long *)&kprof[8 * (wave) + (slot)], (unsigned long long)(v)); } while (0)
-#else
-#define KPROF_ARGS
-#define KPROF_PASS
-#define KPROF_MARK(wave, slot) do { } while (0)
-#define KPROF_ADD(wave, slot, v) do { } while (0)
-#endif
 
 __global__ void k_pgf_copy_old2d(const DevView *__restrict__ Vp, int n) {
   const DevView &V = *Vp;
@@ -417,7 +405,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // layer kp) and one speculative record, that of layer kp - 1, requested unconditionally every level right after the level's move is
 // known -- a level's time before a move can need it.  A move by one layer copies it; by two or more: the slow path (four interface
 // pressures in flight per round, then both records).  Still every load of the fast path is in straight-line code (counted waits).
-template <bool PAIR, bool COPY>
+// LAZY: the speculative record is requested again only by the lanes whose column moved at this level (it is still valid for the
+// others: at two thirds of the levels -- massless velocity layers -- nothing moves); the loads stay in the level's straight-line
+// part, under the lanes' mask.
+template <bool PAIR, bool COPY, bool LAZY>
 __global__ __launch_bounds__(128) void k_pgf_uv_next(const DevView *__restrict__ Vp, int n, int nn KPROF_ARGS) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
@@ -474,6 +465,10 @@ __global__ __launch_bounds__(128) void k_pgf_uv_next(const DevView *__restrict__
   double xip = 0., xim = 0., pgfm = 0.;
   double pck = pplo, pmk = pmlo, g_prev = 0.;
   for (int k = kk; k >= 1; k--) {
+    // the one wait of a level: for the loads the previous level issued before its arithmetic.  Explicit, so that the compiler's own
+    // bookkeeping starts every level with nothing in flight (with the lanes' masks on the loads it would otherwise place
+    // conservative waits between the loads and the arithmetic)
+    WAIT_VM0();
     const PgfFix fx = fxn;
     const double dpk = fx.dpk, pck1 = fx.pck1, pmk1 = fx.pmk1;
     const double prs = fx.pzk - .5 * dpk;
@@ -494,8 +489,8 @@ __global__ __launch_bounds__(128) void k_pgf_uv_next(const DevView *__restrict__
     if (COPY) pgf_o[c + (size_t)(k - 1) * np] = fx.old;
     // this level's loads: the fixed-index ones of level k - 1 and the records a move at level k - 1 would need
     fxn = load_fix(k - 1);
-    sp = load_rec(c, kp - 1);
-    sm = load_rec(mns, km - 1);
+    if (!LAZY || a1p) sp = load_rec(c, kp - 1);
+    if (!LAZY || a1m) sm = load_rec(mns, km - 1);
     // (the scheduler minimises register pressure: without the barrier it moves these loads below the equation of state, next to
     // their first use -- the opposite of what they are issued here for)
     __builtin_amdgcn_sched_barrier(0);
@@ -659,9 +654,11 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc = st_xctilr(c, h.f[F_pb_p], 1, 1, 1, 1, 1)) return rc;
     if (h.P.pgfmth == 0) {
       TimeScope tk(c, "k_pgf_uv");
-      if ((c->pgf_uv_ring == 5 || c->pgf_uv_ring == 6) && copy_fused) {
-        if (c->pgf_uv_ring == 5) hipLaunchKernelGGL((k_pgf_uv_next<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn KPROF_PASS);
-        else hipLaunchKernelGGL((k_pgf_uv_next<true, true>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn KPROF_PASS);
+      if (c->pgf_uv_ring >= 5 && c->pgf_uv_ring <= 8 && copy_fused) {
+        if (c->pgf_uv_ring == 5) hipLaunchKernelGGL((k_pgf_uv_next<false, true, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn KPROF_PASS(1));
+        else if (c->pgf_uv_ring == 6) hipLaunchKernelGGL((k_pgf_uv_next<true, true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn KPROF_PASS(1));
+        else if (c->pgf_uv_ring == 7) hipLaunchKernelGGL((k_pgf_uv_next<false, true, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn KPROF_PASS(1));
+        else hipLaunchKernelGGL((k_pgf_uv_next<true, true, true>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn KPROF_PASS(1));
       }
       else if (c->pgf_uv_ring && copy_fused) {
         // pgf_uv_ring: 1 = separate u / v workgroups, 2 = paired + XCD-contiguous; + 2 = the double-buffered form
@@ -670,8 +667,8 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         const int var = c->pgf_uv_ring % 10, reuse = (c->pgf_uv_ring / 10) % 10, w4 = c->pgf_uv_ring / 100;
 #define PGF_LAUNCH(P, D, R)                                                                                                   \
   do {                                                                                                                        \
-    if (w4) hipLaunchKernelGGL((k_pgf_uv_ring_w4<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn KPROF_PASS);  \
-    else hipLaunchKernelGGL((k_pgf_uv_ring<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn KPROF_PASS);       \
+    if (w4) hipLaunchKernelGGL((k_pgf_uv_ring_w4<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn KPROF_PASS(1));  \
+    else hipLaunchKernelGGL((k_pgf_uv_ring<P, true, D, R>), P ? gp : gs, dim3(P ? 128 : 64), 0, c->stream, c->d, n, nn KPROF_PASS(1));       \
   } while (0)
         if (reuse) {
           if (var == 1) PGF_LAUNCH(false, false, true); else if (var == 2) PGF_LAUNCH(true, false, true);
@@ -682,9 +679,9 @@ int st_pgforc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
         }
 #undef PGF_LAUNCH
       }
-      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS);
-      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS);
-      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS);
+      else if (c->pgf_uv_pair) hipLaunchKernelGGL((k_pgf_uv<true, false>), plane_grid(h, 1, 64), dim3(128), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS(1));
+      else if (copy_fused) hipLaunchKernelGGL((k_pgf_uv<false, true>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS(1));
+      else hipLaunchKernelGGL((k_pgf_uv<false, false>), plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn, c->pgf_reuse KPROF_PASS(1));
     }
     else hipLaunchKernelGGL(k_pgf_dynh_uv, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, n, nn);
   }

@@ -19,6 +19,9 @@ ap.add_argument("--spinup", type=int, default=0)
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--waves", type=int, default=4096)
 ap.add_argument("--save", default=None)
+ap.add_argument("--sel", type=int, default=1, help="which marked kernel writes the buffer: 1 k_pgf_uv*, 2 k_diapfl_column3 (blomgpu_internal.h: kprof_sel)")
+ap.add_argument("--nt", type=int, default=4, help="number of timestamp words (the rest are counters)")
+ap.add_argument("--labels", default=None, help="comma separated names of the phases between consecutive timestamps")
 args = ap.parse_args()
 case, nreg, masks = bench.build_case("channel", "remap", "default")
 gpu = bench.device_for_bench(case, nreg, masks, live=True)
@@ -30,6 +33,7 @@ nw = 8 * args.waves
 gpu.lib.blomgpu_dbg_kprof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 ns = gpu.step(0, args.spinup + args.steps - 1)
 assert gpu.lib.blomgpu_dbg_kprof(gpu.ctx, None, nw) == 0
+gpu.set("kprof_sel", args.sel)
 gpu.set("overlap", 0)                  # (setting an option drops the captured graphs: their launches carry the old buffer pointer)
 ns = gpu.step(ns, 1)
 buf = np.zeros(nw, dtype=np.int64)
@@ -39,19 +43,26 @@ w = buf.reshape(-1, 8)
 w = w[w[:, 0] > 0]
 if args.save:
     np.save(args.save, w)
-t = w[:, :4].astype(np.float64) * 0.01            # us
+nt = args.nt
+t = w[:, :nt].astype(np.float64) * 0.01            # us
+for s_ in range(1, nt):                              # a phase a column skips leaves its word at zero: it takes the previous mark's time
+    t[:, s_] = np.where(w[:, s_] > 0, t[:, s_], t[:, s_ - 1])
 t0 = t[:, 0].min()
-span = t[:, 3].max() - t0
-life = t[:, 3] - t[:, 0]
+span = t[:, nt - 1].max() - t0
+life = t[:, nt - 1] - t[:, 0]
 q = lambda a: " ".join(f"{np.percentile(a, p):8.1f}" for p in (0, 10, 50, 90, 99, 100))
-print(f"step {ns}, options {args.opt}: {len(w)} waves; launch span {span:.1f} us (first start to last end); starts spread over {t[:, 0].max() - t0:.1f} us")
-print("                         min      p10      p50      p90      p99      max   [us]")
-print(f"wave lifetime        {q(life)}   mean {life.mean():.1f}")
-print(f"start .. first level {q(t[:, 1] - t[:, 0])}   mean {(t[:, 1] - t[:, 0]).mean():.1f}")
-print(f"level loop           {q(t[:, 2] - t[:, 1])}   mean {(t[:, 2] - t[:, 1]).mean():.1f}")
-print(f"after the loop       {q(t[:, 3] - t[:, 2])}   mean {(t[:, 3] - t[:, 2]).mean():.1f}")
-print(f"end time - first start {q(t[:, 3] - t0)}")
-print(f"word 4 (moves, summed over lanes) mean {w[:, 4].mean():.1f}   word 5 (levels x lanes moving by more than one layer) mean {w[:, 5].mean():.1f}")
-c = np.corrcoef(life, w[:, 5])[0, 1] if w[:, 5].std() > 0 else float('nan')
-c4 = np.corrcoef(life, w[:, 4])[0, 1] if w[:, 4].std() > 0 else float('nan')
-print(f"correlation of a wave's lifetime with word 5: {c:.2f}, with word 4: {c4:.2f}")
+labels = args.labels.split(",") if args.labels else (["start .. first level", "level loop", "after the loop"] if nt == 4 else [f"phase {s_}" for s_ in range(1, nt)])
+print(f"step {ns}, options {args.opt}, kernel {args.sel}: {len(w)} waves; launch span {span:.1f} us (first start to last end); starts spread over {t[:, 0].max() - t0:.1f} us")
+print("                               min      p10      p50      p90      p99      max   [us]")
+print(f"{'wave lifetime':26s} {q(life)}   mean {life.mean():.1f}")
+for s_ in range(1, nt):
+    d_ = t[:, s_] - t[:, s_ - 1]
+    print(f"{labels[s_ - 1]:26s} {q(d_)}   mean {d_.mean():.1f}")
+print(f"{'end time - first start':26s} {q(t[:, nt - 1] - t0)}")
+# the waves that end last: where their time went
+late = np.argsort(t[:, nt - 1])[-max(1, len(w) // 50):]
+print("the 2 % of the waves that end last, mean of their phases:", " ".join(f"{labels[s_ - 1]} {np.mean(t[late, s_] - t[late, s_ - 1]):.1f}" for s_ in range(1, nt)))
+for s_ in range(nt, 8):
+    if w[:, s_].any():
+        c_ = np.corrcoef(life, w[:, s_])[0, 1] if w[:, s_].std() > 0 else float("nan")
+        print(f"word {s_} (counter, summed over the lanes): mean {w[:, s_].mean():.1f}, max {w[:, s_].max()}, correlation with the wave's lifetime {c_:.2f}; mean over the late waves {w[late, s_].mean():.1f}")
