@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restric
   // are kept in registers together with those of layer ko+1, re-loaded in the background when ko moves; the new
   // interfaces' pressures of CV_U levels are loaded ahead (u is not written before the copy at the end).
 #define CV_U 8
+#define CV_B 6
   int ko = 1;
   double po_lo = 0., po_hi = po[(size_t)2 * np];                         // po(ko), po(ko+1)
   double v_cur = vel[(size_t)1 * np], v_nxt = vel[(size_t)(kk >= 2 ? 2 : 1) * np];       // u(ko), u(ko+1)
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restric
         r = 0.;
       } else {
         double udpn = 0.;
-        while (pn_hi > po_hi) {
+        if (pn_hi > po_hi) {                   // the first old layer the new one leaves behind: its successor is in registers
           udpn = udpn + v_cur * (po_hi - fmax2(po_lo, pn_lo));
           ko = ko + 1;
           po_lo = po_hi;
@@ -277,6 +278,29 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restric
           v_cur = v_nxt;
           v_nxt = vel[(size_t)(ko + 1 <= kk ? ko + 1 : kk) * np];
           po_nx = ko + 1 <= kk ? po[(size_t)(ko + 2) * np] : 1.e300;
+        }
+        // ... and where it leaves more than one behind (a new layer spanning a run of massless old ones: deep mixed layers put
+        // dozens of them between two interfaces) the next CV_B old layers are requested at once and walked from registers -- one
+        // memory round trip per CV_B layers instead of one per layer (round 6); the sum's terms and their order are unchanged
+        while (pn_hi > po_hi) {
+          double w[CV_B], q[CV_B];
+#pragma unroll
+          for (int b = 0; b < CV_B; b++) {
+            const int kv = ko + 2 + b;
+            w[b] = vel[(size_t)(kv <= kk ? kv : kk) * np];
+            q[b] = po[(size_t)(kv <= kk ? kv + 1 : kk + 1) * np];
+          }
+#pragma unroll
+          for (int b = 0; b < CV_B; b++)
+            if (pn_hi > po_hi) {
+              udpn = udpn + v_cur * (po_hi - fmax2(po_lo, pn_lo));
+              ko = ko + 1;
+              po_lo = po_hi;
+              po_hi = ko <= kk ? po_nx : 1.e300;
+              v_cur = v_nxt;
+              v_nxt = w[b];
+              po_nx = ko + 1 <= kk ? q[b] : 1.e300;
+            }
         }
         r = (udpn + v_cur * (pn_hi - fmax2(po_lo, pn_lo))) / (pn_hi - pn_lo);
       }
