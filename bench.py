@@ -654,14 +654,15 @@ def bench_hybrid_step(args):
     if prof_file:
         import ctypes as C
         nw = 6 * 2 * ((gpu.get("p").shape[1] * gpu.get("p").shape[2] + 63) // 64)
-        gpu.lib.blomgpu_dbg_bt_prof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        assert gpu.lib.blomgpu_dbg_bt_prof(gpu.ctx, None, nw) == 0
+        gpu.lib.blomgpu_dbg_kprof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        assert gpu.lib.blomgpu_dbg_kprof(gpu.ctx, None, nw) == 0
+        gpu.set("timing", 0)                       # (setting an option drops the captured graphs: their launches carry the old buffer pointer)
     t0 = time.perf_counter()
     ns = gpu.step(ns, args.steps)
     gpu.sync()
     if prof_file:
         buf = (C.c_longlong * nw)()
-        assert gpu.lib.blomgpu_dbg_bt_prof(gpu.ctx, buf, nw) == 0
+        assert gpu.lib.blomgpu_dbg_kprof(gpu.ctx, buf, nw) == 0
         np.save(prof_file, np.frombuffer(buf, dtype=np.int64).reshape(-1, 6).copy())
     dt = (time.perf_counter() - t0) / args.steps
     # per-class HIP-event times over a few more steps

@@ -416,6 +416,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "pgf_uv_pair") { c->pgf_uv_pair = v; return 0; }
   if (s == "pgf_uv_ring") { c->pgf_uv_ring = v; return 0; }
   if (s == "kprof_sel") { c->kprof_sel = v; return 0; }
+  if (s == "convec_nsingle") { c->convec_nsingle = v; return 0; }
   if (s == "cmn_nslope_nb") { c->cmn_nslope_nb = v; return 0; }
   if (s == "pgf_reuse") { c->pgf_reuse = v; return 0; }
   if (s == "scan_reassoc") { c->scan_reassoc = v; return 0; }
@@ -847,6 +848,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   c->in_sequence = true;
   c->pbcor1_handed_over = c->pbcor2_handed_over = c->pbcor2_dp_in_wk = false;
   c->fluxes_zeroed = false;
+  c->fluxes_lean = false;
   c->remap_handed_over = false;
   c->mom_early_done = c->convec_col_ahead = false;
   if (c->h.P.vcoord_tag != 1) {
@@ -880,6 +882,17 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
     if (c->eddtra_frozen && !strcmp(st, "eddtra")) continue;
     // the step before this one, in the same call, has done this step's tmsmt1 in its tmsmt2
     if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }
+    // The lean init_fluxes zeroes only the ring the tile kernel of remap does not store (stage_simple.hip): until advect has run, every
+    // other plane of uflx .. vsflx (m) holds the PREVIOUS step's fluxes.  Only stages known not to touch them may run in between.
+    if (c->fluxes_lean) {
+      static const char *ok[] = {"tmsmt1", "halo_cmnfld2", "cmnfld2", "halo_difest", "difest_isobml", "difest_isobml_pre", "eddtra", "advect"};
+      bool allowed = false;
+      for (const char *o : ok) allowed = allowed || !strcmp(run, o);
+      if (!allowed) {
+        c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+        return ctx_fail(c, std::string("blomgpu_step: stage ") + run + " between the lean init_fluxes and advect: the flux arrays of level m are not zeroed (set lean_fluxes = 0)");
+      }
+    }
     if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) {
       c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
       return rc;

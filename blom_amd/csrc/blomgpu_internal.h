@@ -292,6 +292,7 @@ struct blomgpu_ctx {
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
   int scan_reassoc = 0;          // TOLERANCE-MODE EXPERIMENT (off): k_pscan with k on the lanes and a log-step shuffle prefix sum -- NOT bit-identical to the reference (stage_simple.hip)
+  int convec_nsingle = 2;        // k_convec_velocity: moves of a level walked singly before chunks of old layers are requested (A/B; 1000 = the kernel of rounds 1-5)
   int cmn_nslope_nb = 4;         // k_cmn_nslope: interfaces in flight in the interior sweep (A/B: 2, 3, 4)
   int pgf_reuse = 0;             // k_pgf_uv: skip the equation of state where a level repeats the previous level's inputs (wave-uniform; bit-identical)
   int pgf_uv_ring = 7;           // k_pgf_uv_ring (round 6: every load of the level loop statically countable): 1 = separate u / v workgroups, 2 = paired + XCD-contiguous
@@ -334,6 +335,7 @@ struct blomgpu_ctx {
   int mlrmth = 1;                                         // 0 none, 1 fox08, 2 bod23 (hybrid coordinate only)
   double eddtra_ce = .06, tau_mlr = 86400., tau_growing_hbl = 300., tau_decaying_hbl = 86400., tau_growing_hml = 3600.,
          tau_decaying_hml = 259200., lfmin = 5.e3, mlbl_max_ratio = 3., eddtra_cl = .25, mstar = .5, nstar = .066, wpup_min = 1.e-3;
+  bool fluxes_lean = false;      // in sequence: init_fluxes zeroed only the ring the storing tile kernel of remap leaves out; cleared by that kernel's launch
   bool fluxes_zeroed = false;    // in sequence: init_fluxes has run and remap has not yet (its u-faces then add to zero)
   bool tmsmt1_ahead = false, tmsmt1_done_ahead = false;
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1

@@ -1016,7 +1016,7 @@ int st_ale_regrid_remap(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, i
     A.scr = A.flx + (size_t)a->ntr_loc * per;
     A.rec_n = a->nd_reck; A.rec_k = a->nd_reck + 2 * np; A.rec_s = A.rec_k + a->nd_nrec * 2 * np; A.rec_g = a->nd_recg;
     A.rec_f = a->nd_rec; A.nrec_max = (int)a->nd_nrec;
-    A.prof = c->bt_prof;
+    A.prof = c->kprof; A.prof_words = c->kprof_words;     // (its own buffer with its size: until round 6 the barotropic profiler's, unchecked)
     A.flux_zero = c->in_sequence && c->fluxes_zeroed ? 1 : 0;
     A.puv = A.scr + ndiff_scratch_planes(h.kk) * 2 * np;
     A.kk = h.kk; A.npc = npc; A.ntr_loc = a->ntr_loc; A.mm = mm; A.nn = nn; A.surface_align = c->ndiff_surface_align;

@@ -21,7 +21,9 @@ struct NdArgs {
   double *rec_f;               // per record ntr_loc fluxes (NaN: withheld by the sign tests)
   int nrec_max;
   int flux_zero;               // utflx .. vsflx (level m) are zero when the stage starts (inside blomgpu_step: init_fluxes, nothing added since)
-  long long *prof;             // debug (blomgpu_dbg_bt_prof): per wave of k_ndiff_flux its start / end timestamp and record count
+  long long *prof;             // debug (blomgpu_dbg_kprof, its own buffer: 6 words a wave, bound-checked against prof_words): per wave of
+                               // k_ndiff_flux its start / end timestamp and record count
+  int prof_words;
   int kk, npc, ntr_loc, mm, nn, surface_align;
 };
 

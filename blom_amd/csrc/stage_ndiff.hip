@@ -291,7 +291,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
   }
 #undef DRHO_CUR
 #ifndef BLOM_HOSTEMU
-  if (A.prof && threadIdx.x == 0) A.prof[6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 3] = wall_clock64();
+  if (A.prof && threadIdx.x == 0 && 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 5 < (size_t)A.prof_words) A.prof[6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 3] = wall_clock64();
 #endif
   // ---- alignment with the surface above the uppermost neutral interface, :394-464 ---------------------------------------------
   if (A.surface_align) {
@@ -368,7 +368,7 @@ __device__ void nd_face(const DevView &V, const NdArgs &A, size_t cm, size_t cp,
     for (int k = kp + 1; k <= kdmx_p + 1; k++) SNP(k) = PDP(k);
   }
 #ifndef BLOM_HOSTEMU
-  if (A.prof && threadIdx.x == 0) A.prof[6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 4] = wall_clock64();
+  if (A.prof && threadIdx.x == 0 && 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 5 < (size_t)A.prof_words) A.prof[6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 4] = wall_clock64();
 #endif
   // ---- second search, :510-921 ------------------------------------------------------------------------------------------------
   {
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(64) void k_ndiff_flux(const DevView *__restrict__ V
   if (!on) A.rec_n[face] = 0;
   else nd_face<NWS, NWP>(V, A, isv ? c - V.ni : c - 1, c, isv, face, A.scr + face, errw);
 #ifndef BLOM_HOSTEMU
-  if (A.prof) {
+  if (A.prof && 6 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 5 < (size_t)A.prof_words) {
     const long long t1 = wall_clock64();
     const size_t w = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0) { A.prof[6 * w] = t0; A.prof[6 * w + 1] = t1; A.prof[6 * w + 2] = 0; }

@@ -648,6 +648,9 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
   if (tsel == 0 || tsel == 2) c->fluxes_zeroed = false;             // (a split launch: tiles 1, then tiles 2)
   if (zeroed) tsel |= 4;
   if (zeroed && !fold && c->lean_fluxes) tsel |= 8;
+  // the lean init_fluxes left last step's fluxes in every plane this launch does not STORE to: any other path would add to them
+  if (c->fluxes_lean && !(tsel & 8)) return ctx_fail(c, "remap: the flux arrays were zeroed on their ring only (lean init_fluxes) but the storing tile path is not taken");
+  if (tsel == (tsel | 8) && ((tsel & 3) == 0 || (tsel & 3) == 2)) c->fluxes_lean = false;
   const DevView &h = c->h;
   const int stx = fold ? RT_TW - 1 : RT_TW, sty = fold ? RT_TH - 1 : RT_TH;
   const int ntx = (h.ni + stx - 1) / stx, nty = (h.nj + sty - 1) / sty;

@@ -51,11 +51,13 @@ int st_init_fluxes(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1
     hipLaunchKernelGGL(k_init_fluxes_ring, dim3((h.ii + h.jj + 6 + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, mm);
     HIPCHK(c, hipGetLastError());
     c->fluxes_zeroed = true;
+    c->fluxes_lean = true;         // the contract: the next toucher of uflx .. vsflx (m) is remap's STORING tile kernel (checked there and in blomgpu_step)
     return 0;
   }
   hipLaunchKernelGGL(k_init_fluxes, plane_grid(c->h, c->h.kk), dim3(256), 0, c->stream, c->d, mm);
   HIPCHK(c, hipGetLastError());
   c->fluxes_zeroed = c->in_sequence;
+  c->fluxes_lean = false;
   return 0;
 }
 

@@ -121,8 +121,8 @@ int  blomgpu_diapfl (blomgpu_ctx *, int n, int nn, int k1n);                    
 int  blomgpu_barotp (blomgpu_ctx *, int m, int n, int mm, int nn, int k1m, int k1n);     /* phy/mod_barotp.F90:148  */
 /* phy/mod_eddtra.F90:1808 eddtra.  vcoord_type = 'isopyc_bulkml': eddtra_intdif_isopyc_bulkml / eddtra_gm_isopyc_bulkml (:153, :228).
  * The other coordinates: eddtra_ale (:1001) -- Gent-McWilliams below the mixed layer, tapered inside it, plus the mixed layer
- * restratification blomgpu_set_str "mlrmth" = "fox08" (default) or "none" ("bod23" is refused: it needs ustar3 / wstar3 of the
- * CVMix-bound mod_difest); blomgpu_set_real "ce", "tau_mlr", "tau_growing_hbl", "tau_decaying_hbl", "tau_growing_hml",
+ * restratification blomgpu_set_str "mlrmth" = "fox08" (default), "bod23" (Bodner et al. 2023, since round 5: ustar3 / wstar3 are
+ * uploaded fields -- their producer for this coordinate is CVMix's KPP, which is not built) or "none"; blomgpu_set_real "ce", "tau_mlr", "tau_growing_hbl", "tau_decaying_hbl", "tau_growing_hml",
  * "tau_decaying_hml", "lfmin", "mlbl_max_ratio" (:53-94, same defaults).  Inputs by name: nslpx, nslpy (interfaces), difint, mld,
  * OBLdepth (mod_difest's boundary layer depth); state: hbl_tf, hml_tf1, hml_tf (the running means), hml_tfbnd.  Writes umfltd,
  * vmfltd, umflsm, vmflsm and the heat and salt components u/v{t,s}fl{td,sm}. */

@@ -12,7 +12,10 @@
 !                   bound, so options are poked directly into their modules)
 !   ref_stage       call one reference stage with the (m,n,mm,nn,k1m,k1n) sextuple
 !   ref_xctilr      the reference halo update
-! Nothing here restates reference arithmetic; it only calls it.
+! The stages are the reference's own routines, called, never restated -- with four exceptions at the end of this file, marked
+! there: the pseudo-stages `difest_ustar3`, `cmnfld2_kfpla`, `difest_p`, `mxlayr_tail` restate a few lines each of routines the PLAIN
+! builds cannot compile (mod_difest / mod_cmnfld_routines / mod_mxlayr need CVMix or netCDF); the `_x*` builds run the real routines
+! for the same pseudo-stages and agree bit for bit (tests/test_xcheck_*.py).
 ! ------------------------------------------------------------------------------
 module ref_harness
 

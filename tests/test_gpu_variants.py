@@ -41,6 +41,21 @@ def test_variants_bit_identical(cfg, nsteps, opt, variants):
 
 
 
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 7), ("tri_s_tke", 6), ("box_s", 6)])
+def test_round6_kernel_variants_bit_identical_down_to_the_sign_of_zero(cfg, nsteps):
+    """The variants this round added or made the default -- pgforc's column kernel (pgf_uv_ring: 0 the kernel of rounds 1-5, 3 the
+    double-buffered ring, 5 / 7 / 8 the lean form without / with the lazy reload / paired), the lean init_fluxes against the full one
+    with the second stream off (advisor, round 5: the contract that only remap's storing tile kernel touches the flux arrays after
+    the ring-only zeroing) -- compared as BYTES: a flux plane that kept last step's values, or a zero of the other sign, would show."""
+    base = _run(cfg, nsteps)
+    skip = {"util1", "util2", "util3", "util4"}
+    for opts in (dict(pgf_uv_ring=0), dict(pgf_uv_ring=3), dict(pgf_uv_ring=5), dict(pgf_uv_ring=8), dict(pgf_uv_ring=0, pgf_reuse=1),
+                 dict(lean_fluxes=0, overlap=0), dict(cmn_nslope_nb=2)):
+        b = _run(cfg, nsteps, **opts)
+        bad = [nm for nm in base if nm not in skip and base[nm].tobytes() != b[nm].tobytes()]
+        assert not bad, (opts, bad)
+
+
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 7), ("tri_s_tke", 6), ("fuk95", 5), ("box_s", 6)])
 def test_tmsmt1_done_by_the_previous_steps_tmsmt2(cfg, nsteps):
     """blomgpu_step with several steps in one call: tmsmt2 also writes dpold, told, sold, trcold, dpuold, dpvold for the step
