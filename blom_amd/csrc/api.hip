@@ -416,6 +416,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "pgf_uv_pair") { c->pgf_uv_pair = v; return 0; }
   if (s == "pgf_uv_ring") { c->pgf_uv_ring = v; return 0; }
   if (s == "kprof_sel") { c->kprof_sel = v; return 0; }
+  if (s == "mom_force_aw") { c->mom_force_aw = v; return 0; }
   if (s == "convec_nsingle") { c->convec_nsingle = v; return 0; }
   if (s == "cmn_nslope_nb") { c->cmn_nslope_nb = v; return 0; }
   if (s == "pgf_reuse") { c->pgf_reuse = v; return 0; }

@@ -292,6 +292,7 @@ struct blomgpu_ctx {
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
   int scan_reassoc = 0;          // TOLERANCE-MODE EXPERIMENT (off): k_pscan with k on the lanes and a log-step shuffle prefix sum -- NOT bit-identical to the reference (stage_simple.hip)
+  int mom_force_aw = 0;          // TIMING EXPERIMENT ONLY: k_mom_visc_march with the mask-free body alone (wrong next to land)
   int convec_nsingle = 2;        // k_convec_velocity: moves of a level walked singly before chunks of old layers are requested (A/B; 1000 = the kernel of rounds 1-5)
   int cmn_nslope_nb = 4;         // k_cmn_nslope: interfaces in flight in the interior sweep (A/B: 2, 3, 4)
   int pgf_reuse = 0;             // k_pgf_uv: skip the equation of state where a level repeats the previous level's inputs (wave-uniform; bit-identical)

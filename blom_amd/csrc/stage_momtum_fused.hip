@@ -87,7 +87,10 @@ __device__ inline void sto(gd_t b, unsigned o, double v) { *(gd_t)((gc_t)b + o) 
 #define CONST_AS __attribute__((address_space(4)))
 #endif
 #define GFV(id) ((gcd_t) * (double *const volatile CONST_AS *)&Vp->f.p_[id])
-template <int BS>
+// AWM: 2 = both bodies of a step, the mask-free one where the strip's stencil window holds no land (the production form); 1 = the mask-free
+// body alone -- a TIMING EXPERIMENT (option mom_force_aw, round 6): what a launch list of all-wet strips of its own would run at; its
+// results are wrong next to land and it is never used by a test or the bench's timed path unless asked for
+template <int BS, int AWM = 2>
 __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip) {
   const DevView &V = *Vp;
   HIP_DYNAMIC_SHARED(double, lds)
@@ -394,7 +397,8 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
     q3 = q3 == 2 ? 0 : q3 + 1;
     awbits = (awbits << 1) | (WAVE_ALL((tn.mk & 15) == 15) ? 1u : 0u);
    };
-   if (aw_on && (awbits & 31u) == 31u) step(std::true_type{});
+   if (AWM == 1) step(std::true_type{});
+   else if (aw_on && (awbits & 31u) == 31u) step(std::true_type{});
    else step(std::false_type{});
   }
 #undef MUa
@@ -780,12 +784,16 @@ static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca
   const int nsa = (h.ii + (BS - 8) - 1) / (BS - 8), nsb = (h.ii + (BS - 4) - 1) / (BS - 4);
   const size_t la = sizeof(double) * 37 * (BS + 4) + c->momtum_lds_pad, lb = sizeof(double) * (h.P.mommth == 2 ? 35 : 21) * (BS + 4) + c->momtum_lds_pad;
   // more than 64 KB of dynamic LDS has to be asked for
-  (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+  (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   if (part != 2) {
     TimeScope tk(c, "k_mom_visc_march");
-    hipLaunchKernelGGL(k_mom_visc_march<BS>, dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
+    if (c->mom_force_aw) {
+      (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+      hipLaunchKernelGGL((k_mom_visc_march<BS, 1>), dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
+    } else
+    hipLaunchKernelGGL((k_mom_visc_march<BS, 2>), dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
   }
   if (part == 1) return;
   TimeScope tk(c, "k_mom_cor_march");

@@ -82,14 +82,26 @@ class FieldsFromRank0:
             return self.whole.get(name)
         import torch
         import torch.distributed as dist
+        # Rank 0 decides the element type and sends its torch name with the shape, so every rank builds the same tensor -- or all of
+        # them fail here, BEFORE the collective (a type a rank could not map used to raise on the other ranks only, after rank 0 had
+        # entered the broadcast, which then hung until its timeout).  The library's fields are float64 or int32; anything else a
+        # backend hands out is converted to one of the two on rank 0.
         meta = [None]
         a = None
         if self.env.rank == 0:
             a = np.ascontiguousarray(self.whole.get(name))
-            meta = [(a.shape, a.dtype.str)]
+            if a.dtype.kind in "iub" and a.dtype != np.int32:
+                a = a.astype(np.int32)
+            elif a.dtype.kind == "f" and a.dtype != np.float64:
+                a = a.astype(np.float64)
+            tname = {"float64": "float64", "int32": "int32"}.get(a.dtype.name)
+            meta = [(a.shape, tname, None if tname else f"FieldsFromRank0: field {name!r} has dtype {a.dtype}")]
         dist.broadcast_object_list(meta, src=0)
-        shape, dt = meta[0]
-        t = torch.from_numpy(a) if self.env.rank == 0 else torch.empty(shape, dtype=getattr(torch, {"<f8": "float64", "<i4": "int32"}[dt]))
+        shape, tname, err = meta[0]
+        if err:
+            raise TypeError(err)
+        # (the array comes back as a host numpy array on every rank: the windows of the tiles are cut on the host)
+        t = torch.from_numpy(a) if self.env.rank == 0 else torch.empty(shape, dtype=getattr(torch, tname))
         if self.device != "cpu":
             t = t.to(self.device)
         dist.broadcast(t, src=0)

@@ -215,7 +215,7 @@ def _bench(tmp_path, ngpus, extra=()):
     box.mkdir()
     env = dict(os.environ, BLOMGPU_LIB=emu, BLOM_HOSTEMU_RCCL_DIR=str(box), OMP_NUM_THREADS="1")
     args = ["bench.py", "--gpus", str(ngpus), "--config", "chan_s", "--steps", "3", "--warmup", "2", "--backend", "gloo", "--no-cpu-baseline",
-            "--no-dyncore-compare", *extra]
+            "--no-dyncore-compare", "--blocks", "1", "--spunup-steps", "0", *extra]
     if ngpus > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + args

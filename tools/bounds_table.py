@@ -19,8 +19,10 @@ import sys
 
 ks, tr, sq = sys.argv[1:4]
 RATE = float(sys.argv[4]) if len(sys.argv) > 4 else 6.0
+import os
+ROUND = os.environ.get("ROUND", "6")
 F = 208 * 512 * 53 * 8.0
-ALG = {"k_remap_tile": 20, "k_mom_cor_march": 24, "k_mom_visc_march": 8, "k_diapfl_column3": 20, "k_pgf_uv": 15, "k_pbc_tile": 24,
+ALG = {"k_remap_tile": 20, "k_mom_cor_march": 24, "k_mom_visc_march": 8, "k_diapfl_column3": 20, "k_pgf_uv": 15, "k_pgf_uv_next": 15, "k_pbc_tile": 24,
        "k_diffus_tile": 21, "k_tmsmt2": 24, "k_remap_update": 18}
 
 
@@ -55,7 +57,7 @@ for ln in open(sq):
         m = re.match(r"\s+(\S+)\s+(\d+)", ln)
         if m and cur:
             ctr[cur][m.group(1)] = float(m.group(2))
-print("# Bounds of the longest kernels (round 5)\n")
+print(f"# Bounds of the longest kernels (round {ROUND})\n")
 print("Channel 208x512x53, ntr = 3, one MI355X; `python3 bench.py` (config 2's step with live diffusivities).  Columns: measured average launch")
 print("(rocprofv3 kernel trace, overlap off), launches per step, and what each bound allows -- see tools/bounds_table.py for the definitions.")
 print("A kernel sits at its floor when `measured` is close to the largest of the bounds; `wait` says how much of the rest is a k-serial chain.\n")
