@@ -1070,7 +1070,7 @@ def main():
                                f"({'TKE, length-scale slot, ideal age: the reference default build' if case.ntr == 3 else 'ideal age' if case.ntr == 1 else f'the default three + {case.ntr - 3} passive tracers'}), "
                                f"baclin={baclin:g}s batrop={case.params['batrop']:g}s lstep={case.params['lstep']}; " +
                                (f"config 2's step (phy/mod_blom_step.F90:96-253: init_fluxes, tmsmt1, cmnfld2, difest_isobml "
-                                f"[{'the whole routine: diffusivities estimated every step (NorESM defaults, rhsctp off)' if difest_live else 'halos, pressure, ustar3, niw_ke_tendency; diffusivities frozen'}], eddtra, advect, pbcor1, "
+                                f"[{'the whole routine: diffusivities estimated every step (NorESM defaults incl. rhsctp; the topographic beta is a synthetic field)' if difest_live else 'halos, pressure, ustar3, niw_ke_tendency; diffusivities frozen'}], eddtra, advect, pbcor1, "
                                 f"diffus, pgforc, momtum, convec, diapfl, thermf, mxlayr, updtrc, barotp, pbcor2, tmsmt2, cmnfld1), the channel "
                                 f"experiment's own forcing (zero fluxes, ustarw = 0.005 m/s), (gm, " if full else
                                 f"full dyncore stage sequence incl. cmnfld2, eddtra and convec (gm, ") +

@@ -3,6 +3,8 @@
 #include "../../include/blomgpu.h"
 #include "blomgpu_internal.h"
 #include "pow_libm.h"
+#include "sin_libm.h"
+#include "atan2_libm.h"
 #include <cstring>
 
 static thread_local std::string g_err;
@@ -104,6 +106,7 @@ __global__ void k_pack_masks(const DevView *__restrict__ Vp) {
   V.m[I_mpack][t] = (V.m[I_ip][t] != 0) | (V.m[I_iu][t] != 0) << 1 | (V.m[I_iv][t] != 0) << 2 | (V.m[I_iq][t] != 0) << 3;
 }
 int ctx_pack_masks(blomgpu_ctx *c) {
+  c->mom_aw_key = -1;              // (the viscous march's launch lists follow the masks: stage_momtum_fused.hip)
   ctx_sync_view(c);
   hipLaunchKernelGGL(k_pack_masks, plane_grid(c->h), dim3(256), 0, c->stream, c->d);
   HIPCHK(c, hipGetLastError());
@@ -253,6 +256,9 @@ int blomgpu_destroy(blomgpu_ctx *c) {
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   for (auto &e : c->ev_side) if (e) (void)hipEventDestroy(e);
   for (int v = 1; v < NVIEW; v++) if (c->dv[v]) (void)hipFree(c->dv[v]);
+  if (c->mom_aw_dev) (void)hipFree(c->mom_aw_dev);
+  if (c->side3) { (void)hipStreamSynchronize(c->side3); (void)hipStreamDestroy(c->side3); }
+  for (auto &e : c->ev_side3) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->wk_mom); (void)hipFree(c->p_alt); (void)hipFree(c->pu_alt); (void)hipFree(c->pv_alt);
   if (c->tiling.rccl) (void)blomgpu_rccl_finalize(c);
   if (c->err_dev) (void)hipFree(c->err_dev);
@@ -376,8 +382,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "redi3d") { c->redi3d = v != 0; return 0; }
   if (s == "edfsmo") { c->edfsmo = v != 0; return 0; }
   if (s == "rhsctp") {
-    if (v) return ctx_fail(c, " difest_lateral_iso: rhsctp = .true. (topographic Rhines scale: sin, atan2 of the flow direction) is not built on the device");
-    c->rhsctp = 0;
+    c->rhsctp = v != 0;          // topographic Rhines scale (round 6: sin_libm.h, atan2_libm.h)
     return 0;
   }
   if (s == "edritp_opt") {                            // 1 'shear', 2 'large scale' (phy/mod_diffusion.F90:113-116)
@@ -416,6 +421,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "pgf_uv_pair") { c->pgf_uv_pair = v; return 0; }
   if (s == "pgf_uv_ring") { c->pgf_uv_ring = v; return 0; }
   if (s == "kprof_sel") { c->kprof_sel = v; return 0; }
+  if (s == "mom_aw_split") { c->mom_aw_split = v; return 0; }
   if (s == "mom_force_aw") { c->mom_force_aw = v; return 0; }
   if (s == "convec_nsingle") { c->convec_nsingle = v; return 0; }
   if (s == "cmn_nslope_nb") { c->cmn_nslope_nb = v; return 0; }
@@ -702,6 +708,31 @@ int blomgpu_pow(blomgpu_ctx *c, int n, const double *x, const double *y, double 
   (void)hipFree(d);
   return rc ? ctx_fail(c, "blomgpu_pow: copy or launch failed") : 0;
 }
+// sin() and atan2() as the kernels evaluate them (sin_libm.h, atan2_libm.h), elementwise on host arrays (tests/test_sin_atan2_libm.py)
+__global__ void k_sin_libm(int n, const double *x, double *z) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) z[t] = sin_libm(x[t]);
+}
+__global__ void k_atan2_libm(int n, const double *y, const double *x, double *z) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) z[t] = atan2_libm(y[t], x[t]);
+}
+static int unary_binary_libm(blomgpu_ctx *c, int n, const double *a, const double *b, double *z, const char *who) {
+  if (n <= 0) return 0;
+  double *d = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d, sizeof(double) * 3 * (size_t)n));
+  int rc = 0;
+  if (hipMemcpyAsync(d, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = 1;
+  if (b && hipMemcpyAsync(d + n, b, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = 1;
+  if (b) hipLaunchKernelGGL(k_atan2_libm, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, d + n, d + 2 * (size_t)n);
+  else hipLaunchKernelGGL(k_sin_libm, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, d + 2 * (size_t)n);
+  if (hipMemcpyAsync(z, d + 2 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = 1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+  (void)hipFree(d);
+  return rc ? ctx_fail(c, std::string(who) + ": copy or launch failed") : 0;
+}
+int blomgpu_sin(blomgpu_ctx *c, int n, const double *x, double *z) { return unary_binary_libm(c, n, x, nullptr, z, "blomgpu_sin"); }
+int blomgpu_atan2(blomgpu_ctx *c, int n, const double *y, const double *x, double *z) { return unary_binary_libm(c, n, y, x, z, "blomgpu_atan2"); }
 int blomgpu_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   (void)k1m; (void)k1n;
   ctx_sync_view(c);

@@ -292,6 +292,11 @@ struct blomgpu_ctx {
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs
                                  // each): the kernel waits on its k-serial chain, not on bytes.  Off.
   int scan_reassoc = 0;          // TOLERANCE-MODE EXPERIMENT (off): k_pscan with k on the lanes and a log-step shuffle prefix sum -- NOT bit-identical to the reference (stage_simple.hip)
+  hipStream_t side3 = nullptr;   // the viscous march's land-side pairs beside its all-wet pairs (mom_aw_split = 2)
+  hipEvent_t ev_side3[2] = {nullptr, nullptr};
+  int mom_aw_split = 0;          // the viscous march's all-wet (chunk, strip) pairs on a launch of their own with the mask-free kernel (round 6): 1 = one after the other, 2 = side by side on a third stream; measured, off
+  int mom_aw_key = -1, mom_aw_n[2] = {0, 0};
+  int *mom_aw_dev = nullptr;     // the two launch lists, device memory
   int mom_force_aw = 0;          // TIMING EXPERIMENT ONLY: k_mom_visc_march with the mask-free body alone (wrong next to land)
   int convec_nsingle = 2;        // k_convec_velocity: moves of a level walked singly before chunks of old layers are requested (A/B; 1000 = the kernel of rounds 1-5)
   int cmn_nslope_nb = 4;         // k_cmn_nslope: interfaces in flight in the interior sweep (A/B: 2, 3, 4)

@@ -17,8 +17,9 @@
 //                     suppression options -> difint, difiso; then the halo updates (and the optional smoothing) of :2577-2614
 // Real powers and exponentials are the host libm's bits (pow_libm.h, exp_libm.h); tanh of the latitude (tidal mixing length
 // scale, :2926-2927) and log of the Coriolis parameter (bdmldp, :2747-2750) depend on the grid only: the host evaluates them once
-// with its own libm into the planes tdmls and bdmlq.  Not built, refused by the option setters: rhsctp (sin, atan2 of the flow
-// direction), the two-equation closure (use_GLS).
+// with its own libm into the planes tdmls and bdmlq.  rhsctp's sin and atan2 of the flow direction are
+// evaluated on the device with the bits of the host libm's (sin_libm.h, atan2_libm.h; round 6).  Not built, refused by the option
+// setter: the two-equation closure (use_GLS).
 // Parity: cross-checked against the reference's REAL mod_difest.F90 compiled against interface-only stand-ins for the CVMix
 // modules it imports but does not call on this path (oracle/xcheck/cvmix_standin.F90; builds *_xdf) -- a cross-check, not a pin.
 // Roofline: HBM, ~60 F of column traffic; the kernels are bound by their k-serial chains like the other column kernels.
@@ -26,6 +27,8 @@
 #include "../../include/blomgpu.h"
 #include "eos.h"
 #include "pow_libm.h"
+#include "sin_libm.h"
+#include "atan2_libm.h"
 #include <cmath>
 
 #define PLANE_IJ(V)                                                        \
@@ -91,7 +94,7 @@ struct TkeC {            // initke's derived constants, phy/mod_tke.F90:133-160
 };
 struct DfePar {
   double egc, eggam, eglsmn, egmndf, egmxdf, egidfq, rhiscf, ri0, tkepf, niwgf, niwbf, niwlf, bdml_logc;
-  int eddf2d, edsprs, edanis, redi3d, edritp, edwmth, use_tke, itke, igls;
+  int eddf2d, edsprs, edanis, redi3d, edritp, edwmth, use_tke, itke, igls, rhsctp;
   TkeC T;
 };
 
@@ -597,6 +600,14 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
 #undef PL
 }
 
+// falign of :2331 -- 1 / max(sin(atan2(y, x) - hangle)**10, 1e-10) -- as a function of its own: inlined four times into the unrolled
+// level loop, sin and atan2 took k_dfi_lateral from 219 to 260 VGPRs with spills and one wave per SIMD (1 755 waves: two rounds)
+__device__ __noinline__ double dfi_falign(double y, double x, double hangle) {
+  const double sa_ = sin_libm(atan2_libm(y, x) - hangle);
+  const double s2 = sa_ * sa_, s4 = s2 * s2, s8 = s4 * s4;      // x**10 as the reference's compiler expands it: x2 = x x, x4 = x2 x2, x8 = x4 x4, x8 x2
+  return 1. / fmax2(s8 * s2, 1.e-10);
+}
+
 // ---- difest_lateral_iso, :2040-2575 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ Vp, DfePar D, int n, int nn) {
   const DevView &V = *Vp;
@@ -663,12 +674,24 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
       difwgt = q <= 2. ? 1. : 0.;
     V.f[F_difwgt][c] = difwgt;
   }
-  // Eady growth rate, :2160-2257, and the layer interface diffusivities, :2283-2375 (rhsctp is refused by the option setter), in ONE sweep
+  // Eady growth rate, :2160-2257, and the layer interface diffusivities, :2283-2375, in ONE sweep
   // over the levels of the range: the reference's second loop reads nothing of the first but egr(k) of the same level (its vertical mean
   // egrs enters only after both), so a level's diffusivity follows its growth rate while the loads of the next levels are in flight, and
   // egr never goes to memory.  Each of the two sets of sums keeps its own order.  Outside the range a level takes the value of the one
   // above it: egmndf above the range, the last level's below it.
   const bool sa = D.edsprs || D.edanis;
+  const bool vel = D.edanis || D.rhsctp;                              // the baroclinic velocities at the p-point are needed (:2308)
+  // rhsctp (round 6): barotropic velocities at the p-point, :2281-2296, and the topographic beta / the angle of the topography
+  double ubt = 0., vbt = 0., betatp = 0., hangle = 0.;
+  if (D.rhsctp) {
+    const double tsfac = P.dlt / P.delt1;
+    gcd_t ubf = V.f[F_ubflxs_p] + c + on, vbf = V.f[F_vbflxs_p] + c + on, pbu = V.f[F_pbu] + c + on, pbv = V.f[F_pbv] + c + on;
+    gcd_t scuyi = V.f[F_scuyi] + c, scvxi = V.f[F_scvxi] + c;
+    ubt = (ubf[0] * scuyi[0] + ubf[1] * scuyi[1]) * tsfac / fmax2(EPSILP, pbu[0] + pbu[1]);
+    vbt = (vbf[0] * scvxi[0] + vbf[ni] * scvxi[ni]) * tsfac / fmax2(EPSILP, pbv[0] + pbv[ni]);
+    betatp = V.f[F_betatp][c];
+    hangle = V.f[F_hangle][c];
+  }
   double egrs = 0., dps_e = 0.;
   const int ka = kf > 2 ? kf : 2, kb = km < kk ? km : kk;            // the levels inside the range (when there are any)
   const double pkf_g = any ? PL(kf) + DPGRAV : 0.;
@@ -680,12 +703,19 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   auto diff_level = [&](int k, double e, double d, double pk, double u0, double u1, double du0, double du1, double v0, double v1, double dv0,
                         double dv1) {
     const size_t o = (size_t)(k - 1) * np;
-    const double rhisc = e / fmax2(1.e-22, betafp);
+    double rhisc = e / fmax2(1.e-22, betafp);
     double speed = 0.;
-    if (D.edanis) {
+    if (vel) {
       const double ubc = (u0 * du0 + u1 * du1) / fmax2(EPSILP, du0 + du1);
       const double vbc = (v0 * dv0 + v1 * dv1) / fmax2(EPSILP, dv0 + dv1);
       speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
+      if (D.rhsctp) {
+        // topographic Rhines scale, masked where the flow is not along the topography, :2320-2337.  sin and atan2 with the bits of
+        // the host's libm (sin_libm.h, atan2_libm.h)
+        const double rhisct = e / fmax2(1.e-22, betatp);
+        const double falign = dfi_falign(vbc + vbt, ubc + ubt, hangle);
+        rhisc = fmin2(rhisc, falign * D.rhiscf * rhisct);
+      }
     }
     const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
     const double di = D.egc * e * els * els;
@@ -714,7 +744,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
         for (int uu = 0; uu < BL; uu++) {
           const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
           a[uu] = rig[o]; d[uu] = p[o + np];
-          if (D.edanis) {
+          if (vel) {
             u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
             v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
           }
@@ -764,7 +794,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
           const int kq = k0 + uu <= kb ? k0 + uu : kb;
           const size_t oi = (size_t)(kq < kk ? kq : kk - 1) * np;            // the interface below the level (not read for the last level)
           x0[uu] = nx[oi]; x1[uu] = nx[oi + 1]; y0[uu] = ny[oi]; y1[uu] = ny[oi + ni]; d[uu] = p[(size_t)kq * np];
-          if (D.edanis) {
+          if (vel) {
             const size_t o = (size_t)(kq - 1) * np;
             u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
             v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
@@ -804,7 +834,8 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   // the surface non-isopycnic layers, :2383-2513
   double urmse = 0., cpse = 0., els_s = 0.;
   if (sa) {
-    const double rhisc = egrs / fmax2(1.e-22, betafp);
+    double rhisc = egrs / fmax2(1.e-22, betafp);
+    if (D.rhsctp) rhisc = fmin2(rhisc, D.rhiscf * (egrs / fmax2(1.e-22, betatp)));       // :2393-2398
     els_s = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
     if (D.edsprs) {
       urmse = 2.86 * D.egc * egrs * els_s;
@@ -960,7 +991,7 @@ int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
   D.egc = c->egc; D.eggam = c->eggam; D.eglsmn = c->eglsmn; D.egmndf = c->egmndf; D.egmxdf = c->egmxdf; D.egidfq = c->egidfq;
   D.rhiscf = c->rhiscf; D.ri0 = c->ri0; D.tkepf = c->tkepf; D.niwgf = c->niwgf; D.niwbf = c->niwbf; D.niwlf = c->niwlf;
   D.bdml_logc = c->bdml_logc;
-  D.eddf2d = c->eddf2d; D.edsprs = c->edsprs; D.edanis = c->edanis; D.redi3d = c->redi3d; D.edritp = c->edritp_opt; D.edwmth = c->edwmth_opt;
+  D.rhsctp = c->rhsctp; D.eddf2d = c->eddf2d; D.edsprs = c->edsprs; D.edanis = c->edanis; D.redi3d = c->redi3d; D.edritp = c->edritp_opt; D.edwmth = c->edwmth_opt;
   D.use_tke = h.P.itrtke >= 1; D.itke = h.P.itrtke; D.igls = h.P.itrgls;
   D.T = tke_consts();
   const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64), b64(64);

@@ -35,12 +35,23 @@ enum { MF_VISU, MF_VISV, MF_UM, MF_UN, MF_VM, MF_VN, MF_NSLOT };
 
 // chunk-major work item of this workgroup; XCD x (blockIdx % 8) walks a contiguous eighth of the items so that the
 // workgroups of one XCD share the 2-D coefficient rows of their chunk in its L2
-__device__ inline void march_item(int kk, int jj, int nchunk_, int nstrip, int &k, int &ja, int &jb, int &strip) {
+// `list` (round 6): the launch covers only the (chunk, strip) pairs it names, chunk * nstrip + strip in ascending order -- the viscous
+// march's all-wet strips and the others are two launches of two kernels (launch_marches)
+__device__ inline void march_item(int kk, int jj, int nchunk_, int nstrip, int &k, int &ja, int &jb, int &strip, const int *list = nullptr) {
   const bool chunk_major = nchunk_ < 0;
   const int nchunk = chunk_major ? -nchunk_ : nchunk_;
   const unsigned nitem = gridDim.x, lin = blockIdx.x;
   const unsigned xq = lin & 7u, sq = lin >> 3, q = nitem >> 3, rr = nitem & 7u;
   unsigned item = xq * q + (xq < rr ? xq : rr) + sq;
+  if (list) {                     // (chunk-major order of the listed pairs: the pair of item / kk, layer item % kk)
+    const int e = list[item / kk];
+    k = item % kk;
+    strip = e % nstrip;
+    const int ch = e / nstrip, rows = (jj + nchunk - 1) / nchunk;
+    ja = 1 + ch * rows;
+    jb = ja + rows - 1 < jj ? ja + rows - 1 : jj;
+    return;
+  }
   strip = item % nstrip;          // the strips of a row chunk are neighbours in the numbering: they share rows in L2
   item /= nstrip;
   // chunk-major: the workgroups of an XCD work on the same rows of different layers at about the same time, so the
@@ -91,12 +102,12 @@ __device__ inline void sto(gd_t b, unsigned o, double v) { *(gd_t)((gc_t)b + o) 
 // body alone -- a TIMING EXPERIMENT (option mom_force_aw, round 6): what a launch list of all-wet strips of its own would run at; its
 // results are wrong next to land and it is never used by a test or the bench's timed path unless asked for
 template <int BS, int AWM = 2>
-__global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip) {
+__global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict__ Vp, int m, int n, int mm, int nn, int nchunk, int nstrip, const int *list) {
   const DevView &V = *Vp;
   HIP_DYNAMIC_SHARED(double, lds)
   const int l = threadIdx.x, ni = V.ni, ii = V.ii, jj = V.jj, kk = V.kk;
   int k, ja, jb, strip;
-  march_item(kk, jj, nchunk, nstrip, k, ja, jb, strip);
+  march_item(kk, jj, nchunk, nstrip, k, ja, jb, strip, list);
   if (ja > jb) return;
   // strip of the row: BS lanes, the outer HL / HR of them only feed their neighbours (stencil reach of the chain in i);
   // owned columns ox0..ox1 (x = i + 3), interior points i = 1..ii shared out over the strips
@@ -778,6 +789,63 @@ __global__ __launch_bounds__(64) void k_mom_column_from(const DevView *__restric
   (isv ? V.f[F_vtotn] : V.f[F_utotn])[c] = tot * (1. / V.P.delt1);
 }
 
+// One wavefront per (chunk, strip) pair of the viscous march: 1 where every packed mask word the march of that pair tests -- its 64 lanes
+// (the march's own clamped column) on the rows ja - 6 .. jb + 4 (its clamped rows) -- is 15, i.e. where EVERY step of the pair's march
+// takes the mask-free body.  Masks are constant: evaluated once per (BS, chunk count) and kept (blomgpu_ctx::mom_aw_*).
+template <int BS>
+__global__ __launch_bounds__(64) void k_mom_classify(const DevView *__restrict__ Vp, int nchunk, int nstrip, int *flags) {
+  const DevView &V = *Vp;
+  const int l = threadIdx.x, ni = V.ni, ii = V.ii, jj = V.jj;
+  const int e = blockIdx.x, strip = e % nstrip, ch = e / nstrip;
+  const int rows = (jj + nchunk - 1) / nchunk, ja = 1 + ch * rows, jb = ja + rows - 1 < jj ? ja + rows - 1 : jj;
+  constexpr int HL = 4, HR = 4, OW = BS - HL - HR;
+  const int ox0 = NBDY + strip * OW;
+  bool all = ja <= jb && ox0 <= ii + NBDY - 1;
+  for (int l0 = 0; l0 < BS; l0 += 64) {
+    const int x = ox0 - HL + l0 + l;
+    const int xl = x < 2 ? 2 : (x > ni - 3 ? ni - 3 : x);
+    for (int r = ja - 6; r <= jb + 4; r++) {
+      const int rc = r < -2 ? -2 : (r > jj + 3 ? jj + 3 : r);
+      if ((V.m[I_mpack][xl + ni * (rc + NBDY - 1)] & 15) != 15) all = false;
+    }
+  }
+  all = WAVE_ALL(all);
+  if (l == 0) flags[e] = all ? 1 : 0;
+}
+
+// the two launch lists of the viscous march (device arrays of chunk * nstrip + strip): [0] the all-wet pairs, [1] the others
+static int mom_aw_lists(blomgpu_ctx *c, int BS, int nca, int nsa, const int **la_, int *na, const int **lb_, int *nb) {
+  const int key = BS * 100000 + nca * 100 + nsa;
+  if (c->mom_aw_key != key) {
+    // (allocations and a read-back: not while the stream is being captured into a graph -- blomgpu_step captures after four plain steps,
+    // by which time the lists exist; a capture that meets them missing takes the one-kernel form)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 1;
+    if (c->mom_aw_dev) { (void)hipFree(c->mom_aw_dev); c->mom_aw_dev = nullptr; }
+    const int n = nca * nsa;
+    int *flags = nullptr;
+    HIPCHK(c, hipMalloc((void **)&flags, sizeof(int) * n));
+    ctx_sync_view(c);
+    if (BS == 64) hipLaunchKernelGGL(k_mom_classify<64>, dim3(n), dim3(64), 0, c->stream, c->d, nca, nsa, flags);
+    else if (BS == 128) hipLaunchKernelGGL(k_mom_classify<128>, dim3(n), dim3(64), 0, c->stream, c->d, nca, nsa, flags);
+    else hipLaunchKernelGGL(k_mom_classify<256>, dim3(n), dim3(64), 0, c->stream, c->d, nca, nsa, flags);
+    std::vector<int> hf(n), lists;
+    HIPCHK(c, hipMemcpyAsync(hf.data(), flags, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(flags);
+    for (int e = 0; e < n; e++) if (hf[e]) lists.push_back(e);
+    c->mom_aw_n[0] = (int)lists.size();
+    for (int e = 0; e < n; e++) if (!hf[e]) lists.push_back(e);
+    c->mom_aw_n[1] = n - c->mom_aw_n[0];
+    HIPCHK(c, hipMalloc((void **)&c->mom_aw_dev, sizeof(int) * (n > 0 ? n : 1)));
+    HIPCHK(c, hipMemcpy(c->mom_aw_dev, lists.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    c->mom_aw_key = key;
+  }
+  *la_ = c->mom_aw_dev; *na = c->mom_aw_n[0];
+  *lb_ = c->mom_aw_dev + c->mom_aw_n[0]; *nb = c->mom_aw_n[1];
+  return 0;
+}
+
 template <int BS>
 static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca, int ncb, int part) {
   const DevView &h = c->h;
@@ -789,11 +857,39 @@ static void launch_marches(blomgpu_ctx *c, int m, int n, int mm, int nn, int nca
   (void)hipFuncSetAttribute((const void *)k_mom_cor_march<BS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
   if (part != 2) {
     TimeScope tk(c, "k_mom_visc_march");
-    if (c->mom_force_aw) {
-      (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
-      hipLaunchKernelGGL((k_mom_visc_march<BS, 1>), dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
+    (void)hipFuncSetAttribute((const void *)k_mom_visc_march<BS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)la);
+    const int *l_aw = nullptr, *l_mx = nullptr;
+    int n_aw = 0, n_mx = 0;
+    // Two kernels, not two bodies (round 6): the (chunk, strip) pairs whose every step is all-wet run the kernel that holds the mask-free body
+    // alone (149 VGPRs, 13 SGPR spills against 175 / 45 with both bodies: 243 against 285 us for the whole layer set), the pairs next to land
+    // the kernel with both bodies.  The lists need chunk-major order (the listed pair is item / kk).
+    const bool split = c->mom_aw_split && h.P.allwet && !c->mom_force_aw && !c->momtum_order && mom_aw_lists(c, BS, nca, nsa, &l_aw, &n_aw, &l_mx, &n_mx) == 0;
+    if (c->mom_force_aw)
+      hipLaunchKernelGGL((k_mom_visc_march<BS, 1>), dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa, (const int *)nullptr);
+    else if (split) {
+      // The two launches must run SIDE BY SIDE: a march's wavefront lives ~240 us whatever the size of the launch (one after the other they
+      // took 226 + 174 us against 288 for the one kernel).  The pairs next to land go to a stream of their own, forked from and joined to the
+      // stream the march is on.
+      const bool third = n_aw && n_mx && c->mom_aw_split == 2;
+      if (third) {
+        if (!c->side3) {
+          if (hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking) != hipSuccess) c->side3 = nullptr;
+          for (auto &e : c->ev_side3) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        }
+      }
+      if (third && c->side3 && c->ev_side3[0] && c->ev_side3[1]) {
+        (void)hipEventRecord(c->ev_side3[0], c->stream);
+        (void)hipStreamWaitEvent(c->side3, c->ev_side3[0], 0);
+        hipLaunchKernelGGL((k_mom_visc_march<BS, 2>), dim3(h.kk * n_mx), dim3(BS), la, c->side3, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, -nca, nsa, l_mx);
+        hipLaunchKernelGGL((k_mom_visc_march<BS, 1>), dim3(h.kk * n_aw), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, -nca, nsa, l_aw);
+        (void)hipEventRecord(c->ev_side3[1], c->side3);
+        (void)hipStreamWaitEvent(c->stream, c->ev_side3[1], 0);
+      } else {
+        if (n_mx) hipLaunchKernelGGL((k_mom_visc_march<BS, 2>), dim3(h.kk * n_mx), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, -nca, nsa, l_mx);
+        if (n_aw) hipLaunchKernelGGL((k_mom_visc_march<BS, 1>), dim3(h.kk * n_aw), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, -nca, nsa, l_aw);
+      }
     } else
-    hipLaunchKernelGGL((k_mom_visc_march<BS, 2>), dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa);
+      hipLaunchKernelGGL((k_mom_visc_march<BS, 2>), dim3(h.kk * nca * nsa), dim3(BS), la, c->stream, ctx_view(c, VIEW_MOM_A), m, n, mm, nn, c->momtum_order ? nca : -nca, nsa, (const int *)nullptr);
   }
   if (part == 1) return;
   TimeScope tk(c, "k_mom_cor_march");

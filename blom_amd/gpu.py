@@ -177,6 +177,23 @@ class BlomGpu:
         self._chk(self.lib.blomgpu_pow(self.ctx, x.size, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)))
         return z
 
+    def sin(self, x):
+        """sin() as the kernels evaluate it (blom_amd/csrc/sin_libm.h), elementwise."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        z = np.empty_like(x)
+        self.lib.blomgpu_sin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.blomgpu_sin(self.ctx, x.size, x.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)))
+        return z
+
+    def atan2(self, y, x):
+        """atan2() as the kernels evaluate it (blom_amd/csrc/atan2_libm.h), elementwise."""
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        z = np.empty_like(x)
+        self.lib.blomgpu_atan2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.blomgpu_atan2(self.ctx, x.size, y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)))
+        return z
+
     def tke_const(self, name):
         """a derived constant of the TKE closure (phy/mod_tke.F90:133-160) as this library evaluates it"""
         v = C.c_double(0.0)

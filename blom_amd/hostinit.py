@@ -570,7 +570,7 @@ def difest_host_planes(plat, coriop):
 
 def init_difest(be, case, twedon0=2.0e-3, ficem0=0.3, device=False):
     """What difest_isobml's diffusivity estimates read beside the model state, for the idealised cases: latitude, the angle of the
-    grid, the topographic beta (unused: rhsctp is off), a smooth tidal dissipation field and a sea ice concentration (synthetic:
+    grid, the topographic beta and the angle of the topography (read with rhsctp), a smooth tidal dissipation field and a sea ice concentration (synthetic:
     the reference reads them from files), zero surface buoyancy flux.  device: also the two host-evaluated planes (the reference
     evaluates them itself)."""
     nj, ni = case.jdm + 2 * NBDY, case.idm + 2 * NBDY
@@ -578,7 +578,11 @@ def init_difest(be, case, twedon0=2.0e-3, ficem0=0.3, device=False):
     x = np.linspace(0.0, 2.0 * np.pi, ni)[None, :] + 0.0 * y
     plat = (55.0 + 24.0 * y)[None]                           # crosses the critical latitude of the M2 tide (74.5 N)
     ang = 0.2 * np.sin(x) * y
-    vals = dict(plat=plat, cosang=np.cos(ang)[None], sinang=np.sin(ang)[None], betatp=np.full((1, nj, ni), 1.0e-10), hangle=np.zeros((1, nj, ni)),
+    # topographic beta and the angle of the topography (the reference reads them from `tbfile`): smooth synthetic fields of the size
+    # that makes the topographic Rhines scale the active one in places (5 egr / betatp ~ 1 - 30 km against a Rossby radius of ~10 km)
+    betatp = (1.0e-9 * (1.0 + 0.8 * np.sin(x) * np.cos(np.pi * y)))[None]
+    hangle = (0.3 + 0.7 * np.sin(2.0 * x) * y)[None]
+    vals = dict(plat=plat, cosang=np.cos(ang)[None], sinang=np.sin(ang)[None], betatp=betatp, hangle=hangle,
                 twedon=(twedon0 * (1.0 + 0.5 * np.cos(2.0 * x)) * (1.0 - 0.3 * y))[None], ficem=(ficem0 * (y > 0.2) * (1.0 + np.sin(x)) * 0.5)[None])
     has = getattr(be, "has_field", lambda nm: True)
     for nm, v in vals.items():
@@ -591,9 +595,9 @@ def init_difest(be, case, twedon0=2.0e-3, ficem0=0.3, device=False):
         be.set("bdml_logc", logc)
 
 
-# &DIFFUSION as far as difest_isobml reads it, NorESM's defaults for vcoord_type = 'isopyc_bulkml' (cime_config/namelist_definition_blom.xml)
-# with rhsctp = .false. (the topographic Rhines scale needs a topographic-beta file, `tbfile`, which the idealised cases do not have:
-# the reference's own tests/fuk95/limits switches it off the same way); what bench.py runs config 2's step with
-DIFEST_NORESM = (dict(egc=2.5, eggam=200.0, eglsmn=4000.0, egmndf=50.0, egmxdf=2500.0, egidfq=1.25, ri0=1.2, tkepf=0.006,
+# &DIFFUSION as far as difest_isobml reads it: NorESM's defaults for vcoord_type = 'isopyc_bulkml' (cime_config/namelist_definition_blom.xml),
+# rhsctp = .true. and rhiscf = 5 included since round 6 (:1677-1715; the topographic beta is a synthetic field here, init_difest); what
+# bench.py runs config 2's step with
+DIFEST_NORESM = (dict(egc=2.5, eggam=200.0, eglsmn=4000.0, egmndf=50.0, egmxdf=2500.0, egidfq=1.25, rhiscf=5.0, ri0=1.2, tkepf=0.006,
                       bdmc1=5.0e-8, bdmc2=1.0e-5, iwdfac=0.06, nubmin=2.0e-6, niwgf=0.0, niwbf=0.35, niwlf=0.5),
-                 dict(eddf2d=1, edsprs=0, edanis=1, redi3d=0, edfsmo=0, edritp_opt=2, edwmth_opt=1, bdmtyp=2, iwdflg=1, bdmldp=1, rhsctp=0))
+                 dict(eddf2d=1, edsprs=0, edanis=1, redi3d=0, edfsmo=0, edritp_opt=2, edwmth_opt=1, bdmtyp=2, iwdflg=1, bdmldp=1, rhsctp=1))

@@ -104,11 +104,16 @@ int  blomgpu_exp(blomgpu_ctx *, int n, const double *x, double *y);
 /* pow() as the kernels evaluate it: likewise the algorithm and bits of glibc's pow (blom_amd/csrc/pow_libm.h; the real powers of the
  * TKE closure and of the surface layer's stability function in difest_vertical_iso, phy/mod_difest.F90:2881-2886, :3056-3058). */
 int  blomgpu_pow(blomgpu_ctx *, int n, const double *x, const double *y, double *z);
+/* sin() and atan2() as the kernels evaluate them: the algorithms and bits of glibc's IBM Accurate Mathematical Library routines
+ * (blom_amd/csrc/sin_libm.h, atan2_libm.h; the alignment of the flow with the topography under rhsctp, phy/mod_difest.F90:2331). */
+int  blomgpu_sin(blomgpu_ctx *, int n, const double *x, double *z);
+int  blomgpu_atan2(blomgpu_ctx *, int n, const double *y, const double *x, double *z);
 /* phy/mod_difest.F90:735 difest_isobml, the whole routine: halo updates, interface pressure, ustar3, niw_ke_tendency (blomgpu_stage
  * "difest_isobml_pre") and the diffusivity estimates difest_common_iso (:353), difest_vertical_iso (:2629), difest_lateral_iso (:2040)
  * -> difint, difiso, difdia, difwgt (and the TKE tracers' source step).  Options: blomgpu_set_real "egc", "eggam", "eglsmn", "egmndf",
  * "egmxdf", "egidfq", "ri0", "tkepf"; blomgpu_set_int "eddf2d", "edsprs", "edanis", "redi3d", "edfsmo", "edritp_opt" (1 shear, 2 large
- * scale), "edwmth_opt" (1 smooth, 2 step), "bdmtyp", "iwdflg", "bdmldp"; rhsctp and the two-equation closure are refused.  Inputs that
+ * scale), "edwmth_opt" (1 smooth, 2 step), "bdmtyp", "iwdflg", "bdmldp", "rhsctp" (with blomgpu_set_real "rhiscf" and the fields
+ * "betatp", "hangle": since round 6); the two-equation closure is refused.  Inputs that
  * depend on the grid only and need the host's libm are uploaded as planes: "tdmls" (tidal mixing length scale, :2926-2927) and, with
  * bdmldp, "bdmlq" = log(2 bvf0 / max(1e-9, |coriop|)) with the option "bdml_logc" = log(2 bvf0 / cori30).
  * PARITY UNPINNED: cross-checked against the reference's real module compiled against interface-only stand-ins for CVMix. */

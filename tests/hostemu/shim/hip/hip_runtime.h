@@ -21,6 +21,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ static thread_local
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)hostemu::dyn_lds();
@@ -101,6 +102,8 @@ typedef struct hostemu_graph *hipGraph_t;
 typedef struct hostemu_graphexec *hipGraphExec_t;
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorUnknown; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone, hipStreamCaptureStatusActive, hipStreamCaptureStatusInvalidated };
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorUnknown; }
 inline hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorUnknown; }
 inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }

@@ -47,3 +47,9 @@ def test_difest_isobml_diffusivity_estimates_on_the_host_emulation(emu_lib):
     _live_step_check("box_s", 3, OPT_SHEAR, stagewise=True)
     _live_step_check("tri_s_tke", 3, OPT_2D, stagewise=True)
     _live_step_check("chan_s_tke", 4, OPT_FUK95)
+    # NorESM's defaults, rhsctp = .true. included (round 6: the topographic Rhines scale through sin_libm.h / atan2_libm.h)
+    from blom_amd import hostinit
+    _live_step_check("chan_s_tke", 3, hostinit.DIFEST_NORESM, stagewise=True)
+    _live_step_check("box_s", 4, hostinit.DIFEST_NORESM)
+    from test_xcheck_difest import test_rhsctp_acts_on_the_layer_interface_diffusivities as rhs_effect
+    rhs_effect("chan_s_tke")

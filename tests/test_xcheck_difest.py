@@ -169,7 +169,7 @@ def test_full_size_channel_step_with_24_tracers_equals_the_reference_stage_seque
 
 def test_full_size_channel_step_with_live_diffusivities_equals_the_reference_stage_sequence():
     """three steps at BASELINE.json's channel size (208x512x53, ntr = 3) with the options bench.py times by default (NorESM's &DIFFUSION
-    defaults for isopyc_bulkml, rhsctp off: hostinit.DIFEST_NORESM)"""
+    defaults for isopyc_bulkml, rhsctp = .true. included: hostinit.DIFEST_NORESM)"""
     from test_xcheck_ale import run_with_big_stack
     run_with_big_stack(_live_step_check, "channel_tke", 3, hostinit.DIFEST_NORESM)
 
@@ -209,3 +209,32 @@ def test_full_size_channel_step_from_a_spun_up_state_equals_the_reference_stage_
     every array of the step equal bit for bit"""
     from test_xcheck_ale import run_with_big_stack
     run_with_big_stack(_spunup_check, 300, 2)
+
+
+@pytest.mark.parametrize("cfg", ["chan_s_tke", "box_s"])
+def test_rhsctp_acts_on_the_layer_interface_diffusivities(cfg):
+    """rhsctp = .true. (NorESM's default; the topographic Rhines scale with sin / atan2 of the flow direction, phy/mod_difest.F90:2281-2340,
+    :2393-2398) is not a no-op on the synthetic slopes and topographic beta of these cases: with the option on, difint differs from the run
+    with it off in a good part of the cells -- and equals the reference's real mod_difest (the NorESM parameter sets of the tests above)"""
+    case, ref, gpu, big = _setup(cfg, hostinit.DIFEST_NORESM)
+    try:
+        nr = dyncore_step(ref, 0, case.params["baclin"], stages=FULL_STAGES_LIVE)        # a state in motion
+        res = {}
+        six = hostinit.step_indices(nr, case.kdm)
+        for nm, ph in (("nnslpx", 0.0), ("nnslpy", 1.1)):
+            a = ref.get(nm)
+            kk_, nj_, ni_ = a.shape
+            kg, jg, ig = np.meshgrid(np.arange(kk_), np.arange(nj_), np.arange(ni_), indexing="ij")
+            a[...] = 3.0e-6 * np.sin(2 * np.pi * ig / 9.0 + ph + 0.3 * kg) * np.cos(2 * np.pi * jg / 7.0 - ph)
+        for rh in (0, 1):
+            copy_state(ref, gpu, fields=STATE_FIELDS + INT_FIELDS + CMN + ML + DFE_OUT)
+            gpu.set("delt1", 2.0 * case.params["baclin"])
+            gpu.set("rhsctp", rh)
+            gpu.stage("difest_isobml", *six)
+            res[rh] = gpu.get("difint").copy()
+        wet = ref.masks["ip"][4:-4, 4:-4] > 0
+        d = (res[0] != res[1])[:, 4:-4, 4:-4][:, wet]
+        assert d.mean() > 0.05, f"rhsctp changed {d.sum()} of {d.size} values"
+        assert np.isfinite(res[1]).all()
+    finally:
+        gpu.close()
