@@ -608,6 +608,32 @@ __device__ __noinline__ double dfi_falign(double y, double x, double hangle) {
   return 1. / fmax2(s8 * s2, 1.e-10);
 }
 
+// falign of every point and level, one thread each (rhsctp): the baroclinic velocities at the p-point (:2311-2316), the barotropic ones
+// (:2286-2295), sin / atan2.  In the column kernel the call cost 97 us a launch (117 -> 215 us: ~300 dependent instructions per level and
+// column); here the same arithmetic runs on 93 000 wavefronts, and the column kernel reads one more plane (work slot W_EGR).
+__global__ void k_dfi_falign(const DevView *__restrict__ Vp, int n, int nn) {
+  const DevView &V = *Vp;
+  unsigned bx_, by_;
+  xcd_block(bx_, by_);
+  const int t_ = bx_ * blockDim.x + threadIdx.x;
+  if (t_ >= V.nplane) return;
+  const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
+  const size_t c = t_;
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
+  const int k = by_ + 1, ni = V.ni;                       // layers 1 .. kk (the column kernel reads 2 .. kk)
+  const size_t np = V.nplane, on = (size_t)(n - 1) * np, o = c + (size_t)(k - 1 + nn) * np;
+  const Params &P = V.P;
+  const double tsfac = P.dlt / P.delt1;
+  gcd_t ubf = V.f[F_ubflxs_p] + c + on, vbf = V.f[F_vbflxs_p] + c + on, pbu = V.f[F_pbu] + c + on, pbv = V.f[F_pbv] + c + on;
+  gcd_t scuyi = V.f[F_scuyi] + c, scvxi = V.f[F_scvxi] + c;
+  const double ubt = (ubf[0] * scuyi[0] + ubf[1] * scuyi[1]) * tsfac / fmax2(EPSILP, pbu[0] + pbu[1]);
+  const double vbt = (vbf[0] * scvxi[0] + vbf[ni] * scvxi[ni]) * tsfac / fmax2(EPSILP, pbv[0] + pbv[ni]);
+  gcd_t u = V.f[F_u], v = V.f[F_v], dpu = V.f[F_dpu], dpv = V.f[F_dpv];
+  const double ubc = (u[o] * dpu[o] + u[o + 1] * dpu[o + 1]) / fmax2(EPSILP, dpu[o] + dpu[o + 1]);
+  const double vbc = (v[o] * dpv[o] + v[o + ni] * dpv[o + ni]) / fmax2(EPSILP, dpv[o] + dpv[o + ni]);
+  WK(V, W_EGR)[c + (size_t)(k - 1) * np] = dfi_falign(vbc + vbt, ubc + ubt, V.f[F_hangle][c]);
+}
+
 // ---- difest_lateral_iso, :2040-2575 -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ Vp, DfePar D, int n, int nn) {
   const DevView &V = *Vp;
@@ -680,18 +706,10 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   // egr never goes to memory.  Each of the two sets of sums keeps its own order.  Outside the range a level takes the value of the one
   // above it: egmndf above the range, the last level's below it.
   const bool sa = D.edsprs || D.edanis;
-  const bool vel = D.edanis || D.rhsctp;                              // the baroclinic velocities at the p-point are needed (:2308)
-  // rhsctp (round 6): barotropic velocities at the p-point, :2281-2296, and the topographic beta / the angle of the topography
-  double ubt = 0., vbt = 0., betatp = 0., hangle = 0.;
-  if (D.rhsctp) {
-    const double tsfac = P.dlt / P.delt1;
-    gcd_t ubf = V.f[F_ubflxs_p] + c + on, vbf = V.f[F_vbflxs_p] + c + on, pbu = V.f[F_pbu] + c + on, pbv = V.f[F_pbv] + c + on;
-    gcd_t scuyi = V.f[F_scuyi] + c, scvxi = V.f[F_scvxi] + c;
-    ubt = (ubf[0] * scuyi[0] + ubf[1] * scuyi[1]) * tsfac / fmax2(EPSILP, pbu[0] + pbu[1]);
-    vbt = (vbf[0] * scvxi[0] + vbf[ni] * scvxi[ni]) * tsfac / fmax2(EPSILP, pbv[0] + pbv[ni]);
-    betatp = V.f[F_betatp][c];
-    hangle = V.f[F_hangle][c];
-  }
+  const bool vel = D.edanis;                                          // the baroclinic velocities at the p-point are needed for the anisotropy (:2308)
+  // rhsctp (round 6): the topographic beta; falign of the level comes from k_dfi_falign's plane
+  const double betatp = D.rhsctp ? V.f[F_betatp][c] : 0.;
+  gcd_t fal = WK(V, W_EGR) + c;
   double egrs = 0., dps_e = 0.;
   const int ka = kf > 2 ? kf : 2, kb = km < kk ? km : kk;            // the levels inside the range (when there are any)
   const double pkf_g = any ? PL(kf) + DPGRAV : 0.;
@@ -701,7 +719,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
   difint[0] = D.egmndf;
   // a level's diffusivity from its growth rate e; d = p(k+1), pk = p(k)
   auto diff_level = [&](int k, double e, double d, double pk, double u0, double u1, double du0, double du1, double v0, double v1, double dv0,
-                        double dv1) {
+                        double dv1, double falign) {
     const size_t o = (size_t)(k - 1) * np;
     double rhisc = e / fmax2(1.e-22, betafp);
     double speed = 0.;
@@ -709,13 +727,11 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
       const double ubc = (u0 * du0 + u1 * du1) / fmax2(EPSILP, du0 + du1);
       const double vbc = (v0 * dv0 + v1 * dv1) / fmax2(EPSILP, dv0 + dv1);
       speed = fmax2(1.e-22, sqrt(ubc * ubc + vbc * vbc));
-      if (D.rhsctp) {
-        // topographic Rhines scale, masked where the flow is not along the topography, :2320-2337.  sin and atan2 with the bits of
-        // the host's libm (sin_libm.h, atan2_libm.h)
-        const double rhisct = e / fmax2(1.e-22, betatp);
-        const double falign = dfi_falign(vbc + vbt, ubc + ubt, hangle);
-        rhisc = fmin2(rhisc, falign * D.rhiscf * rhisct);
-      }
+    }
+    if (D.rhsctp) {
+      // topographic Rhines scale, masked where the flow is not along the topography, :2320-2337 (falign: k_dfi_falign)
+      const double rhisct = e / fmax2(1.e-22, betatp);
+      rhisc = fmin2(rhisc, falign * D.rhiscf * rhisct);
     }
     const double els = fmax2(D.eglsmn, fmin2(bcrrd, rhisc));
     const double di = D.egc * e * els * els;
@@ -739,11 +755,12 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
     if (D.edritp == 1) {
       double pk = PL(ka);
       for (int k0 = ka; k0 <= kb; k0 += BL) {
-        double a[BL], d[BL], u0[BL], u1[BL], du0[BL], du1[BL], v0[BL], v1[BL], dv0[BL], dv1[BL];
+        double a[BL], d[BL], u0[BL], u1[BL], du0[BL], du1[BL], v0[BL], v1[BL], dv0[BL], dv1[BL], fa[BL];
 #pragma unroll
         for (int uu = 0; uu < BL; uu++) {
           const size_t o = (size_t)((k0 + uu <= kb ? k0 + uu : kb) - 1) * np;
           a[uu] = rig[o]; d[uu] = p[o + np];
+          fa[uu] = D.rhsctp ? fal[o] : 0.;
           if (vel) {
             u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
             v0[uu] = v[o]; v1[uu] = v[o + ni]; dv0[uu] = dpv[o]; dv1[uu] = dpv[o + ni];
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
             dps_e = dps_e + q;
             egrs = egrs + e * q;
           }
-          diff_level(k, e, d[uu], pk, u0[uu], u1[uu], du0[uu], du1[uu], v0[uu], v1[uu], dv0[uu], dv1[uu]);
+          diff_level(k, e, d[uu], pk, u0[uu], u1[uu], du0[uu], du1[uu], v0[uu], v1[uu], dv0[uu], dv1[uu], fa[uu]);
           pk = d[uu];
         }
       }
@@ -788,12 +805,13 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
       }
       double pk = PL(ka);
       for (int k0 = ka; k0 <= kb; k0 += BL) {
-        double x0[BL], x1[BL], y0[BL], y1[BL], d[BL], u0[BL], u1[BL], du0[BL], du1[BL], v0[BL], v1[BL], dv0[BL], dv1[BL];
+        double x0[BL], x1[BL], y0[BL], y1[BL], d[BL], u0[BL], u1[BL], du0[BL], du1[BL], v0[BL], v1[BL], dv0[BL], dv1[BL], fa[BL];
 #pragma unroll
         for (int uu = 0; uu < BL; uu++) {
           const int kq = k0 + uu <= kb ? k0 + uu : kb;
           const size_t oi = (size_t)(kq < kk ? kq : kk - 1) * np;            // the interface below the level (not read for the last level)
           x0[uu] = nx[oi]; x1[uu] = nx[oi + 1]; y0[uu] = ny[oi]; y1[uu] = ny[oi + ni]; d[uu] = p[(size_t)kq * np];
+          fa[uu] = D.rhsctp ? fal[(size_t)(kq - 1) * np] : 0.;
           if (vel) {
             const size_t o = (size_t)(kq - 1) * np;
             u0[uu] = u[o]; u1[uu] = u[o + 1]; du0[uu] = dpu[o]; du1[uu] = dpu[o + 1];
@@ -819,7 +837,7 @@ __global__ __launch_bounds__(64) void k_dfi_lateral(const DevView *__restrict__ 
             }
           } else
             e = egr_prev;
-          diff_level(k, e, d[uu], pk, u0[uu], u1[uu], du0[uu], du1[uu], v0[uu], v1[uu], dv0[uu], dv1[uu]);
+          diff_level(k, e, d[uu], pk, u0[uu], u1[uu], du0[uu], du1[uu], v0[uu], v1[uu], dv0[uu], dv1[uu], fa[uu]);
           pk = d[uu];
         }
       }
@@ -1009,6 +1027,7 @@ int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
     hipLaunchKernelGGL(k_dfi_vert_a, g1, b64, 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_vert_b, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_vert_c, g1, b64, 0, c->stream, c->d, D, nn);
+    if (D.rhsctp) hipLaunchKernelGGL(k_dfi_falign, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, n, nn);
     hipLaunchKernelGGL(k_dfi_lateral, g1, b64, 0, c->stream, c->d, D, n, nn);
   }
   HIPCHK(c, hipGetLastError());
