@@ -129,22 +129,26 @@ def test_device_reproduces_reference_checksums_from_analytic_init(cfg):
     assert state["checked"] > 600
 
 
-def test_600_steps_of_the_bench_workload_equal_the_reference_long_run():
+@pytest.mark.parametrize("golden,rhsctp", [("channel_tke_live_long_crc.json", 1), ("channel_tke_live_long_rhsctp0_crc.json", 0)])
+def test_600_steps_of_the_bench_workload_equal_the_reference_long_run(golden, rhsctp):
     """The long-run question of round 5's review: config 2's step with live diffusivities (what bench.py times) for 600 steps from the
     bench's initial state, device-resident (blomgpu_step), against the reference's own modules run for the same 600 steps in the build
     container (tools/longrun_reference.py -> tests/golden/channel_tke_live_long_crc.json): xccrc of dp, temp, saln, u, v, the tracers,
-    difint and difdia over both time levels at steps 100, 200, ..., 600, and the extremes of temp with the cells they are taken in."""
+    difint and difdia over both time levels at steps 100, 200, ..., 600, and the extremes of temp with the cells they are taken in.
+    Twice: with NorESM's defaults as bench.py runs them now (rhsctp = .true.), and with rhsctp off -- the options of round 5, whose
+    -111 degC sample at step 600 this run settled (profiles/r06_longrun.txt)."""
     import sys
     sys.path.insert(0, os.path.join(HERE, ".."))
     sys.path.insert(0, os.path.join(HERE, "..", "tools"))
     import bench
     from blom_amd.checksum import grid_of
     from longrun_reference import sample
-    path = os.path.join(HERE, "golden", "channel_tke_live_long_crc.json")
+    path = os.path.join(HERE, "golden", golden)
     gold = json.load(open(path))
     trace = {t["step"]: t for t in gold["trace"]}
     case, nreg, masks = bench.build_case("channel", "remap", "default")
     gpu = bench.device_for_bench(case, nreg, masks, live=True)
+    gpu.set("rhsctp", rhsctp)
     scp2 = gpu.get("scp2")[0][4:-4, 4:-4]
     bad, ns = [], 0
     try:

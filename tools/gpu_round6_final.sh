@@ -25,6 +25,11 @@ bench tnx1v4s_24tr --steps 10 --no-cpu-baseline --config tnx1v4s --tracers 24
 bench tnx2v1s --steps 10 --no-cpu-baseline --config tnx2v1s
 bench hybrid --steps 10 --no-cpu-baseline --config hybrid
 NTR=24 CONFIG=tnx1v4s tools/gpu_profile_round.sh "${T}_24tr" "--config tnx1v4s --tracers 24 --blocks 1 --spunup-steps 0" > "$O/round_24tr.log" 2>&1 || bad=1
+# the long run against the reference's (profiles/<tag>_longrun.txt is assembled from these): NorESM's defaults (rhsctp on), the options of
+# round 5 (rhsctp off: the run whose extreme samples that round's review asked about) step by step around step 600, the calm forcing
+python3 tools/longrun_full_physics.py --steps 1200 --every 200 --golden tests/golden/channel_tke_live_long_crc.json > "$O/longrun_default.txt" 2> "$O/longrun.err" || bad=1
+python3 tools/longrun_full_physics.py --rhsctp 0 --steps 600 --every 1 --from 588 --budget-step 300 --golden tests/golden/channel_tke_live_long_rhsctp0_crc.json > "$O/longrun_rhsctp0.txt" 2>> "$O/longrun.err" || bad=1
+python3 tools/longrun_full_physics.py --steps 1200 --every 200 --forcing calm > "$O/longrun_calm.txt" 2>> "$O/longrun.err" || bad=1
 tools/probes/copy_rate >> "$O/copy_rate.txt" 2>> "$O/copy_rate.err" || bad=1
 cat "$O/copy_rate.txt" "$O/gpu_suite.txt"
 for f in "$O"/bench_*.json; do python3 - "$f" <<'PY' || bad=1

@@ -29,17 +29,20 @@ ap.add_argument("--from", dest="start", type=int, default=0)
 ap.add_argument("--frozen-diffusivities", action="store_true")
 ap.add_argument("--forcing", default="default")
 ap.add_argument("--golden", default=None)
+ap.add_argument("--rhsctp", type=int, default=1, help="0: rhsctp off, the options of rounds 5 and before (golden: ..._rhsctp0_crc.json)")
 ap.add_argument("--budget-step", type=int, default=0, help="after every stage of this step: the dp-weighted heat sums of both time levels")
 args = ap.parse_args()
 frozen = args.frozen_diffusivities
 case, nreg, masks = bench.build_case("channel", "remap", "default", forcing=args.forcing)
 gpu = bench.device_for_bench(case, nreg, masks, live=not frozen)
+if not args.rhsctp:
+    gpu.set("rhsctp", 0)
 gold = json.load(open(args.golden)) if args.golden else None
 gtrace = {t["step"]: t for t in gold["trace"]} if gold else {}
 wet = masks["ip"][4:-4, 4:-4] > 0
 scp2 = gpu.get("scp2")[0][4:-4, 4:-4]
 kk = case.kdm
-print(f"# channel {case.idm}x{case.jdm}x{kk}, ntr = {case.ntr}, full physics, diffusivities {'frozen' if frozen else 'live (NorESM defaults)'}, forcing {args.forcing}; baclin = {case.params['baclin']} s")
+print(f"# channel {case.idm}x{case.jdm}x{kk}, ntr = {case.ntr}, full physics, diffusivities {'frozen' if frozen else 'live (NorESM defaults' + ('' if args.rhsctp else ', rhsctp off') + ')'}, forcing {args.forcing}; baclin = {case.params['baclin']} s")
 print("# step  Tmin (i j k dp)  Tmax (i j k dp)  mld_min  mld_mean  mld_max [m]  maxitr_detrain/step  maxitr_entrain/step  |u|max  d(mass)/mass  d(heat)/heat  d(salt)/salt  difdia_max  difint_mean  finite  vs reference")
 ns, base, last, bad = 0, None, 0, 0
 gpu.get_real("mxlayr_maxitr_entrain"); gpu.get_real("mxlayr_maxitr_detrain")
