@@ -610,7 +610,8 @@ __device__ __noinline__ double dfi_falign(double y, double x, double hangle) {
 
 // falign of every point and level, one thread each (rhsctp): the baroclinic velocities at the p-point (:2311-2316), the barotropic ones
 // (:2286-2295), sin / atan2.  In the column kernel the call cost 97 us a launch (117 -> 215 us: ~300 dependent instructions per level and
-// column); here the same arithmetic runs on 93 000 wavefronts, and the column kernel reads one more plane (work slot W_EGR).
+// column); here the same arithmetic runs on 93 000 wavefronts -- the levels of a column's range only: evaluated at every level the kernel took
+// 115 us --, and the column kernel reads one more plane (work slot W_EGR).
 __global__ void k_dfi_falign(const DevView *__restrict__ Vp, int n, int nn) {
   const DevView &V = *Vp;
   unsigned bx_, by_;
@@ -620,7 +621,10 @@ __global__ void k_dfi_falign(const DevView *__restrict__ Vp, int n, int nn) {
   const int i = t_ % V.ni - (NBDY - 1), j = t_ / V.ni - (NBDY - 1);
   const size_t c = t_;
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
-  const int k = by_ + 1, ni = V.ni;                       // layers 1 .. kk (the column kernel reads 2 .. kk)
+  const int k = by_ + 1, ni = V.ni;
+  // only the levels the column kernel evaluates a diffusivity at read their value: kfil .. kmax of a column with kmax - kfil >= 1 (:2303-2305)
+  const int kf = V.m[I_dfe_kfil][c], km = V.m[I_dfe_kmax][c];
+  if (km - kf < 1 || k < (kf > 2 ? kf : 2) || k > km) return;
   const size_t np = V.nplane, on = (size_t)(n - 1) * np, o = c + (size_t)(k - 1 + nn) * np;
   const Params &P = V.P;
   const double tsfac = P.dlt / P.delt1;
