@@ -101,6 +101,8 @@ _DIMS = {
     # name: (idm, jdm, kdm, nreg, dx[m], baclin, batrop)
     "chan_s": (20, 24, 6, 1, 10.0e3, 900.0, 18.0),
     "chan_m": (80, 40, 8, 1, 10.0e3, 900.0, 18.0),     # several 32x8 device tiles, periodic in i
+    # the channel over 4 x 3 of barotp's 26 x 16 tiles, the last column 6 wide, the last row 8 high (k_bt_steps4: ragged tiles, periodic seam)
+    "chan_b": (84, 40, 6, 1, 10.0e3, 900.0, 18.0),
     "tri_s": (24, 20, 6, 2, 10.0e3, 900.0, 18.0),      # periodic in i, arctic patch along the last row (nreg = 2)
     # the same topology over several 26 x 16 tiles of barotp's persistent kernel (3 x 3, last column 12 wide, last row 8 high)
     "tri_m": (64, 40, 6, 2, 10.0e3, 900.0, 18.0),
@@ -152,10 +154,10 @@ def _depth_for(name, idm, jdm, dx):
     """Bathymetry [m] on the interior (jdm, idm); 0 = land."""
     ii = np.arange(1, idm + 1)[None, :]
     jj = np.arange(1, jdm + 1)[:, None]
-    if name in ("chan_s", "chan_m", "channel", "chan_t8"):
+    if name in ("chan_s", "chan_m", "chan_b", "channel", "chan_t8"):
         # tanh shelves on both walls (cf. channel/mod_channel.F90:168-207), southern and
         # northern-most rows land
-        sf, sl = (200.0, 800.0) if name in ("chan_s", "chan_m") else (200.0, 3800.0)
+        sf, sl = (200.0, 800.0) if name in ("chan_s", "chan_m", "chan_b") else (200.0, 3800.0)
         width = 0.18 * jdm * dx
         ys = (jj - 0.5) * dx
         yn = (jdm - jj + 0.5) * dx

@@ -150,6 +150,7 @@ static int ale_reset(blomgpu_ctx *c) {
   return rc;
 }
 
+int bt_block_mode(blomgpu_ctx *c);       // stage_barotp_pair.hip
 extern "C" {
 
 const char *blomgpu_last_error(const blomgpu_ctx *ctx) {
@@ -349,6 +350,9 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
 #undef R
   if (s == "area") { *v = c->area; return 0; }
   if (s == "bdml_logc") { *v = c->bdml_logc; return 0; }
+  // which form of the barotropic substep kernel this context runs with its present options: 1 four substeps per hand-off
+  // (k_bt_steps4, persistent), 2 the same kernel with a launch per four substeps, 0 the forms of stage_barotp_pair.hip's head
+  if (s == "barotp_block_mode") { *v = bt_block_mode(c); return 0; }
   // diagnostic counters of mxlayr (stage_mxlayr.hip): columns whose iteration for the mixed layer depth ended at its limit since the last
   // query, named by the message the reference prints for such a column: "mxlayr_maxitr_detrain" = the first iteration
   // (phy/mod_mxlayr.F90:437-449, 'reached maxitr when detraining', :440; word 5), "mxlayr_maxitr_entrain" = the second
@@ -430,6 +434,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "pgf_copy_fused") { c->pgf_copy_fused = v; return 0; }
   if (s == "check_period") { c->check_period = v < 1 ? 1 : v; return 0; }
   if (s == "barotp_persist") { c->barotp_persist = v; return 0; }
+  if (s == "barotp_block") { c->barotp_block = v; return 0; }
   if (s == "barotp_overlap") { c->barotp_overlap = v; return 0; }
   if (s == "barotp_rimbuf") { c->barotp_rimbuf = v; return 0; }
   if (s == "barotp_arctic_fused") { c->barotp_arctic_fused = v; return 0; }

@@ -347,7 +347,10 @@ struct blomgpu_ctx {
   int tmsmt_ahead = 1;           // option: 0 = every step launches its own tmsmt1
   unsigned *bt_flags = nullptr;   // abort word + per-tile completion counts of the persistent barotp kernel
   int num_cus = 0;
+  int bt4_blocks_per_cu[2] = {-1, -1};          // the same for the temporally blocked kernel (k_bt_steps4)
   int bt_blocks_per_cu[4] = {-1, -1, -1, -1};   // occupancy query results for the persistent barotp kernel's shapes (-1: not asked yet)
+  int barotp_block = 1;      // 1: four substeps per hand-off where the persistent form runs (k_bt_steps4: no arctic patch, one process); 2: the same
+                             // kernel with one launch per four substeps (any number of tiles; the host emulation); 0: off
   int barotp_persist = 1;    // 1: one launch per barotropic phase where all tiles are resident (stage_barotp_pair.hip)
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   long long *kprof = nullptr;     // debug (builds with -DBLOM_KPROF): per-wavefront phase timestamps of a column kernel, 8 words a wave (blomgpu_dbg_kprof)

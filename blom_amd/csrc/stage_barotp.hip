@@ -311,6 +311,9 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
                     int last, int src, int *src_out, int *ml_out, int *nl_out);
 int bt_phase_check(blomgpu_ctx *c);
 int bt_overlap_usable(blomgpu_ctx *c);
+int bt_block_mode(blomgpu_ctx *c);
+int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
+                    int last, int src, int *src_out, int *ml_out, int *nl_out);
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
                    int do_odd, int do_even, int src, int tsel, RcclLanded *rim);
 int bt_pair_halo_landed(blomgpu_ctx *c, int set, RcclLanded *landed);
@@ -411,6 +414,11 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
         set ^= 1;
         { const int ll = ml; ml = nl; nl = ll; }
       }
+    } else if (fused && !arctic1 && bt_block_mode(c)) {
+      // four substeps per hand-off (k_bt_steps4)
+      int so, mo, no;
+      if (int rc = bt_block_launch(c, bt_block_mode(c), m, n, ml, nl, woa, wob, wna, wnb, lll0, last, set, &so, &mo, &no)) return rc;
+      set = so; ml = mo; nl = no;
     } else if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
       // their edge values through memory

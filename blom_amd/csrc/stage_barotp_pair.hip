@@ -463,6 +463,288 @@ __global__ void __launch_bounds__(bt_threads(TI, TJ)) k_bt_steps(const DevView *
   PROF_MARK();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Temporal blocking: up to FOUR substeps per hand-off.
+//
+// In k_bt_steps<true> an iteration (one odd+even pair) is 4.3 us of sweeps and 5.5 us of hand-off (stores drained, count
+// published, the neighbours' counts seen, rim re-read): the launch is bound by the latency of 63 hand-offs per step, not by
+// arithmetic.  A substep consumes at most one cell of valid rim on the low side and two on the high side (continuity reads
+// ub(i+1), vb(j+1); the momentum equation that comes second reads the first one's result at i+1 / j+1 again; each reads pb at
+// i-1 / j-1), an odd+even pair two and three -- so with a rim of 4 cells below and 6 above the tile, 36 x 26 points around
+// 26 x 16, FOUR consecutive substeps of either parity run between two hand-offs: 35 instead of 65 iterations per step.
+// The rim cells are computed redundantly, and they are what the neighbour computes for them: the same expressions on the
+// same inputs (the reference relies on the same property between its odd and its even substep, which it runs without a
+// halo update on margins computed redundantly, phy/mod_barotp.F90:387-843).  For that to hold at the edges of the domain
+// every point of the block is identified with its HOME point -- the interior point it is the periodic image of; beyond a
+// closed edge: land -- and coefficients, masks and state all come from there (the arrays' halos are 4 wide and hold some of
+// the coefficients 2 deep only, :271-285); the loop ranges of the reference's substeps, which differ between odd and even
+// substeps by how far they reach into the margins, need no restating then: a margin point is computed whenever its inputs
+// are valid, and is the image of an interior point that is.  936 points are two per thread for 512 threads: 8 wavefronts,
+// two per SIMD, up to 256 VGPRs -- the 31 coefficients of both points stay in registers.  Not for the arctic patch (whose
+// halo update rewrites an interior row), not for the tiles of several processes: k_bt_steps serves those.
+// Launched with a range of at most four substeps the kernel is the non-persistent form (no waiting: option barotp_block = 2,
+// which is how the host emulation runs it).
+#define BT4_RL 4
+#define BT4_RH 6
+#define BT4_NT 512
+struct Bt4Pt {
+  int li, lj;
+  bool act, mine, wp, wu, wv, land;
+  size_t c;
+  double scp2i;
+  double u_pgo, u_xpo, u_xmo, u_pgm, u_xpm, u_xmm, u_pgn, u_xpn, u_xmn, u_scuxi, u_scuy, u_tot, u_glue, u_max, u_min;
+  double v_pgo, v_xpo, v_xmo, v_pgm, v_xpm, v_xmm, v_pgn, v_xpn, v_xmn, v_scvyi, v_scvx, v_tot, v_glue, v_max, v_min;
+  double us_acc, uc_acc, vs_acc, vc_acc;
+};
+
+template <int TI, int TJ>
+__global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict__ Vp, PairArgs a) {
+  constexpr int RL = BT4_RL, RH = BT4_RH, BI = TI + RL + RH, BJ = TJ + RL + RH, NPT = BI * BJ, NT = BT4_NT;
+  static_assert(NPT <= 2 * NT, "two points per thread");
+  const DevView &V = *Vp;
+  __shared__ double s_pb[2][BJ][BI + 1], s_ub[2][BJ][BI + 1], s_vb[2][BJ][BI + 1];
+  __shared__ double s_pvo[BJ][BI + 1], s_pvm[BJ][BI + 1], s_pvn[BJ][BI + 1], s_sx[BJ][BI + 1], s_sy[BJ][BI + 1];
+  __shared__ int s_abort;
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int ii = V.ii, jj = V.jj;
+  const size_t np = V.nplane;
+  const gd_t b_pb[2] = {V.f[F_pb_t], V.f[F_pb_t2]}, b_ub[2] = {V.f[F_ubflx_t], V.f[F_ubflx_t2]};
+  const gd_t b_vb[2] = {V.f[F_vbflx_t], V.f[F_vbflx_t2]};
+  int src = a.src;
+  const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
+  const bool per_i = !(V.nreg == 0 || V.nreg == 4), per_j = V.nreg > 2;
+  const double vland = V.P.vland;
+  Bt4Pt P[2];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    Bt4Pt &q = P[p];
+    const int x = tid + p * NT;
+    q.act = x < NPT;
+    q.li = q.act ? x % BI : 0; q.lj = q.act ? x / BI : 0;
+    const int gi = bx * TI + 1 + q.li - RL, gj = by * TJ + 1 + q.lj - RL;
+    const bool oi = gi < 1 || gi > ii, oj = gj < 1 || gj > jj;
+    q.land = !q.act || (oi && !per_i) || (oj && !per_j);
+    const int hi = ((gi - 1) % ii + ii) % ii + 1, hj = ((gj - 1) % jj + jj) % jj + 1;
+    q.c = q.land ? 0 : (size_t)IDX(V, hi, hj);
+    q.mine = q.act && !oi && !oj && q.li >= RL && q.li < RL + TI && q.lj >= RL && q.lj < RL + TJ;
+    q.wp = !q.land && V.m[I_ip][q.c]; q.wu = !q.land && V.m[I_iu][q.c]; q.wv = !q.land && V.m[I_iv][q.c];
+    const size_t c = q.c;
+    if (q.act) {
+      s_pvo[q.lj][q.li] = q.land ? 0. : V.f[F_pvtrop_o][c];
+      s_pvm[q.lj][q.li] = q.land ? 0. : V.f[F_pvtrop][c + om];
+      s_pvn[q.lj][q.li] = q.land ? 0. : V.f[F_pvtrop][c + on];
+      s_sx[q.lj][q.li] = q.land ? 0. : V.f[F_scvxi][c];
+      s_sy[q.lj][q.li] = q.land ? 0. : V.f[F_scuyi][c];
+    }
+    q.scp2i = 0.;
+    q.u_pgo = q.u_xpo = q.u_xmo = q.u_pgm = q.u_xpm = q.u_xmm = q.u_pgn = q.u_xpn = q.u_xmn = 0.;
+    q.u_scuxi = q.u_scuy = q.u_tot = q.u_glue = q.u_max = q.u_min = 0.;
+    q.v_pgo = q.v_xpo = q.v_xmo = q.v_pgm = q.v_xpm = q.v_xmm = q.v_pgn = q.v_xpn = q.v_xmn = 0.;
+    q.v_scvyi = q.v_scvx = q.v_tot = q.v_glue = q.v_max = q.v_min = 0.;
+    q.us_acc = q.uc_acc = q.vs_acc = q.vc_acc = 0.;
+    if (q.wp) q.scp2i = V.f[F_scp2i][c];
+    if (q.wu) {
+      q.u_pgo = V.f[F_pgfxm_o][c]; q.u_xpo = V.f[F_xixp_o][c]; q.u_xmo = V.f[F_xixm_o][c];
+      q.u_pgm = V.f[F_pgfxm][c + om]; q.u_xpm = V.f[F_xixp][c + om]; q.u_xmm = V.f[F_xixm][c + om];
+      q.u_pgn = V.f[F_pgfxm][c + on]; q.u_xpn = V.f[F_xixp][c + on]; q.u_xmn = V.f[F_xixm][c + on];
+      q.u_scuxi = V.f[F_scuxi][c]; q.u_scuy = V.f[F_scuy][c]; q.u_tot = V.f[F_utotn][c]; q.u_glue = V.f[F_uglue][c];
+      q.u_max = V.f[F_umaxb][c]; q.u_min = V.f[F_uminb][c];
+    }
+    if (q.wv) {
+      q.v_pgo = V.f[F_pgfym_o][c]; q.v_xpo = V.f[F_xiyp_o][c]; q.v_xmo = V.f[F_xiym_o][c];
+      q.v_pgm = V.f[F_pgfym][c + om]; q.v_xpm = V.f[F_xiyp][c + om]; q.v_xmm = V.f[F_xiym][c + om];
+      q.v_pgn = V.f[F_pgfym][c + on]; q.v_xpn = V.f[F_xiyp][c + on]; q.v_xmn = V.f[F_xiym][c + on];
+      q.v_scvyi = V.f[F_scvyi][c]; q.v_scvx = V.f[F_scvx][c]; q.v_tot = V.f[F_vtotn][c]; q.v_glue = V.f[F_vglue][c];
+      q.v_max = V.f[F_vmaxb][c]; q.v_min = V.f[F_vminb][c];
+    }
+    if (q.mine) {
+      if (q.wu) { q.us_acc = V.f[F_ubflxs_t][c]; q.uc_acc = V.f[F_ubcors_t][c]; }
+      if (q.wv) { q.vs_acc = V.f[F_vbflxs_t][c]; q.vc_acc = V.f[F_vbcors_t][c]; }
+    }
+  }
+  auto load_state = [&](bool rim_only) {
+    const double *g_pb = b_pb[src], *g_ub = b_ub[src], *g_vb = b_vb[src];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const Bt4Pt &q = P[p];
+      if (!q.act || (rim_only && q.mine)) continue;
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        s_pb[l][q.lj][q.li] = q.land ? vland : g_pb[q.c + l * np];
+        s_ub[l][q.lj][q.li] = q.land ? vland : g_ub[q.c + l * np];
+        s_vb[l][q.lj][q.li] = q.land ? vland : g_vb[q.c + l * np];
+      }
+    }
+  };
+  load_state(false);
+  __syncthreads();
+
+  int ml = a.ml - 1, nl = a.nl - 1;
+  const double wbaro = V.P.wbaro, dlt = V.P.dlt;
+  const bool mom_scon = V.P.mommth == 0;
+  const int nbx = gridDim.x, nby = gridDim.y;
+  int nb_tile = -1;                     // lanes 0..7 of wave 0 watch one neighbour each
+  if (tid < 8) {
+    const int dx = (tid < 3 ? -1 : (tid < 5 ? 0 : 1)), dy = (tid == 0 || tid == 3 || tid == 5) ? -1 : ((tid == 1 || tid == 6) ? 0 : 1);
+    int qx = bx + dx, qy = by + dy;
+    bool exists = true;
+    if (qx < 0 || qx >= nbx) { if (!per_i) exists = false; else qx = (qx + nbx) % nbx; }
+    if (qy < 0 || qy >= nby) { if (!per_j) exists = false; else qy = (qy + nby) % nby; }
+    if (exists) nb_tile = qy * nbx + qx;
+  }
+  unsigned done_iters = 0;
+  int lll = a.lll0;
+  bool aborted = false;
+
+  do {
+    const int nsub = a.last - lll + 1 < 4 ? a.last - lll + 1 : 4;
+    if (done_iters > 0) {               // wait for the neighbours' previous iteration, then re-read the rim
+      if (tid < 64) {
+        bool ready = nb_tile < 0;
+        unsigned spins = 0;
+        while (true) {
+          if (!ready) ready = __hip_atomic_load(a.flags + nb_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.epoch_base + done_iters;
+          if (__all(ready)) break;
+          if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { aborted = true; break; }
+          if (++spins > 400000u) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        WAIT_VMCNT0();
+      }
+      if (tid == 0) s_abort = aborted ? 1 : 0;
+      __syncthreads();
+      if (s_abort) break;
+      load_state(true);
+      __syncthreads();
+    }
+    // block-local rectangle of what is valid so far (inclusive)
+    int vlo_i = 0, vhi_i = BI - 1, vlo_j = 0, vhi_j = BJ - 1;
+    for (int s = 0; s < nsub; s++) {
+      const int l = lll + s;
+      const bool odd = l % 2 == 1;
+      const double wo = a.woa * l + a.wob, wn = a.wna * l + a.wnb, wm = 1. - wo - wn;        // :352-360
+      // ---- continuity (:400-418 / :625-643): reads ub(i+1), vb(j+1) at level ml
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const Bt4Pt &q = P[p];
+        const int li = q.li, lj = q.lj;
+        if (q.wp && li >= vlo_i && li <= vhi_i - 1 && lj >= vlo_j && lj <= vhi_j - 1)
+          s_pb[nl][lj][li] = (1. - wbaro) * s_pb[ml][lj][li] + wbaro * s_pb[nl][lj][li] -
+                             (1. + wbaro) * dlt *
+                                 (s_ub[ml][lj][li + 1] - s_ub[ml][lj][li] + s_vb[ml][lj + 1][li] - s_vb[ml][lj][li]) * q.scp2i;
+      }
+      __syncthreads();
+      const int p_hi_i = vhi_i - 1, p_hi_j = vhi_j - 1;
+      auto do_u = [&](Bt4Pt &q, int lv, int lo_i, int hi_i, int lo_j, int hi_j) {
+        const int li = q.li, lj = q.lj;
+        if (q.wu && li >= lo_i && li <= hi_i && lj >= lo_j && lj <= hi_j) {
+          const double ubml = s_ub[ml][lj][li], ubnl = s_ub[nl][lj][li];
+          if (q.mine) q.us_acc = q.us_acc - wbaro * ubnl + (1. + wbaro) * ubml;
+          const double vc = s_vb[lv][lj][li], vn = s_vb[lv][lj + 1][li], vw = s_vb[lv][lj][li - 1], vnw = s_vb[lv][lj + 1][li - 1];
+          const double sx_c = s_sx[lj][li], sx_n = s_sx[lj + 1][li], sx_w = s_sx[lj][li - 1], sx_nw = s_sx[lj + 1][li - 1];
+          const double pvo_c = s_pvo[lj][li], pvm_c = s_pvm[lj][li], pvn_c = s_pvn[lj][li];
+          const double pvo_n = s_pvo[lj + 1][li], pvm_n = s_pvm[lj + 1][li], pvn_n = s_pvn[lj + 1][li];
+          double r;
+          if (mom_scon)
+            r = (vc * sx_c + vn * sx_n + vw * sx_w + vnw * sx_nw) *
+                (wo * (pvo_c + pvo_n) + wm * (pvm_c + pvm_n) + wn * (pvn_c + pvn_n)) * .125;
+          else
+            r = .25 * ((vc * sx_c + vw * sx_w) * (wo * pvo_c + wm * pvm_c + wn * pvn_c) +
+                       (vn * sx_n + vnw * sx_nw) * (wo * pvo_n + wm * pvm_n + wn * pvn_n));
+          if (q.mine) q.uc_acc = q.uc_acc + r;
+          const double pbc = s_pb[nl][lj][li], pbw = s_pb[nl][lj][li - 1];
+          const double utndcy = r + (wo * (q.u_pgo - (q.u_xpo * pbc - q.u_xmo * pbw)) + wm * (q.u_pgm - (q.u_xpm * pbc - q.u_xmm * pbw)) +
+                                     wn * (q.u_pgn - (q.u_xpn * pbc - q.u_xmn * pbw))) * q.u_scuxi;
+          const double x = (1. - wbaro) * ubml + wbaro * ubnl +
+                           (1. + wbaro) * dlt * ((utndcy + q.u_tot) * q.u_scuy * fmin2(pbw, pbc) - q.u_glue * ubml);
+          s_ub[nl][lj][li] = fmax2(-q.u_min, fmin2(q.u_max, x));
+        }
+      };
+      auto do_v = [&](Bt4Pt &q, int lu, int lo_i, int hi_i, int lo_j, int hi_j) {
+        const int li = q.li, lj = q.lj;
+        if (q.wv && li >= lo_i && li <= hi_i && lj >= lo_j && lj <= hi_j) {
+          const double vbml = s_vb[ml][lj][li], vbnl = s_vb[nl][lj][li];
+          if (q.mine) q.vs_acc = q.vs_acc - wbaro * vbnl + (1. + wbaro) * vbml;
+          const double uc = s_ub[lu][lj][li], ue = s_ub[lu][lj][li + 1], us = s_ub[lu][lj - 1][li], use = s_ub[lu][lj - 1][li + 1];
+          const double sy_c = s_sy[lj][li], sy_e = s_sy[lj][li + 1], sy_s = s_sy[lj - 1][li], sy_se = s_sy[lj - 1][li + 1];
+          const double pvo_c = s_pvo[lj][li], pvm_c = s_pvm[lj][li], pvn_c = s_pvn[lj][li];
+          const double pvo_e = s_pvo[lj][li + 1], pvm_e = s_pvm[lj][li + 1], pvn_e = s_pvn[lj][li + 1];
+          double r;
+          if (mom_scon)
+            r = -(uc * sy_c + ue * sy_e + us * sy_s + use * sy_se) *
+                (wo * (pvo_c + pvo_e) + wm * (pvm_c + pvm_e) + wn * (pvn_c + pvn_e)) * .125;
+          else
+            r = -.25 * ((uc * sy_c + us * sy_s) * (wo * pvo_c + wm * pvm_c + wn * pvn_c) +
+                        (ue * sy_e + use * sy_se) * (wo * pvo_e + wm * pvm_e + wn * pvn_e));
+          if (q.mine) q.vc_acc = q.vc_acc + r;
+          const double pbc = s_pb[nl][lj][li], pbs = s_pb[nl][lj - 1][li];
+          const double vtndcy = r + (wo * (q.v_pgo - (q.v_xpo * pbc - q.v_xmo * pbs)) + wm * (q.v_pgm - (q.v_xpm * pbc - q.v_xmm * pbs)) +
+                                     wn * (q.v_pgn - (q.v_xpn * pbc - q.v_xmn * pbs))) * q.v_scvyi;
+          const double x = (1. - wbaro) * vbml + wbaro * vbnl +
+                           (1. + wbaro) * dlt * ((vtndcy + q.v_tot) * q.v_scvx * fmin2(pbs, pbc) - q.v_glue * vbml);
+          s_vb[nl][lj][li] = fmax2(-q.v_min, fmin2(q.v_max, x));
+        }
+      };
+      if (odd) {
+        // u (:420-457): pb[nl] at i-1, i; vb[ml] at (i-1..i, j..j+1).  Then v (:520-557): ub[nl] at (i..i+1, j-1..j); pb[nl] at j-1, j
+        const int u_lo_i = vlo_i + 1, u_hi_i = p_hi_i, u_lo_j = vlo_j, u_hi_j = p_hi_j;
+#pragma unroll
+        for (int p = 0; p < 2; p++) do_u(P[p], ml, u_lo_i, u_hi_i, u_lo_j, u_hi_j);
+        __syncthreads();
+        const int v_lo_i = u_lo_i, v_hi_i = u_hi_i - 1, v_lo_j = u_lo_j + 1, v_hi_j = u_hi_j;
+#pragma unroll
+        for (int p = 0; p < 2; p++) do_v(P[p], nl, v_lo_i, v_hi_i, v_lo_j, v_hi_j);
+        __syncthreads();
+        vlo_i = v_lo_i; vhi_i = v_hi_i; vlo_j = v_lo_j; vhi_j = v_hi_j;
+      } else {
+        // v first (:646-682): ub[ml] at (i..i+1, j-1..j); pb[nl] at j-1, j.  Then u (:745-781): vb[nl] at (i-1..i, j..j+1); pb[nl] at i-1, i
+        const int v_lo_i = vlo_i, v_hi_i = p_hi_i, v_lo_j = vlo_j + 1, v_hi_j = p_hi_j;
+#pragma unroll
+        for (int p = 0; p < 2; p++) do_v(P[p], ml, v_lo_i, v_hi_i, v_lo_j, v_hi_j);
+        __syncthreads();
+        const int u_lo_i = v_lo_i + 1, u_hi_i = v_hi_i, u_lo_j = v_lo_j, u_hi_j = v_hi_j - 1;
+#pragma unroll
+        for (int p = 0; p < 2; p++) do_u(P[p], nl, u_lo_i, u_hi_i, u_lo_j, u_hi_j);
+        __syncthreads();
+        vlo_i = u_lo_i; vhi_i = u_hi_i; vlo_j = u_lo_j; vhi_j = u_hi_j;
+      }
+      const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
+    }
+    lll += nsub;
+    // publish the tile in the other buffer set (between iterations the neighbours read all but 14 x 4 of its points)
+    src ^= 1;
+    {
+      double *o_pb = b_pb[src], *o_ub = b_ub[src], *o_vb = b_vb[src];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const Bt4Pt &q = P[p];
+        if (!q.mine) continue;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {        // write-through stores: visible to the other XCDs without a release fence
+          __hip_atomic_store(o_pb + q.c + l * np, s_pb[l][q.lj][q.li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(o_ub + q.c + l * np, s_ub[l][q.lj][q.li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(o_vb + q.c + l * np, s_vb[l][q.lj][q.li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (lll > a.last) break;
+    WAIT_VMCNT0();     // every storing wave drains before the count goes out
+    __syncthreads();
+    done_iters++;
+    if (tid == 0) __hip_atomic_store(a.flags + (by * nbx + bx), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } while (true);
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const Bt4Pt &q = P[p];
+    if (q.mine) {
+      if (q.wu) { V.f[F_ubflxs_t][q.c] = q.us_acc; V.f[F_ubcors_t][q.c] = q.uc_acc; }
+      if (q.wv) { V.f[F_vbflxs_t][q.c] = q.vs_acc; V.f[F_vbcors_t][q.c] = q.vc_acc; }
+    }
+  }
+}
+
 // Halo update of the three subcycling fields of buffer set `set`, both levels, in ONE launch:
 // widths (3,3), a superset of the reference's (2,2),(2,2),(2,3) at :395-397.  Same gather rule as
 // k_xctilr_single (halo.hip): closed direction -> vland, periodic direction -> wrapped source.
@@ -708,6 +990,97 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
     src ^= 1;
     if (!both) { const int t = ml; ml = nl; nl = t; }
     lll += both ? 2 : 1;
+  }
+  *src_out = src; *ml_out = ml; *nl_out = nl;
+  return 0;
+}
+
+// The temporally blocked form (k_bt_steps4): shape 26 x 16 or 26 x 15, no arctic patch, one process; the last tile row and
+// column at least as wide as the high rim (a tile's rim comes from its direct neighbours only).  persistent: all tiles
+// resident.  {0, 0}: not usable.
+static BtShape bt_block_shape(blomgpu_ctx *c, bool persistent) {
+  const DevView &h = c->h;
+  const BtShape none{0, 0};
+  if (c->tiling.multi() || h.nreg == 2) return none;
+  if (persistent && c->num_cus <= 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return none;
+    c->num_cus = prop.multiProcessorCount;
+  }
+  for (int x = 0; x < 2; x++) {
+    const int ti = kPersistShapes[x].ti, tj = kPersistShapes[x].tj;
+    if (c->barotp_tile && c->barotp_tile != 100 * ti + tj) continue;
+    const int nbx = (h.ii + ti - 1) / ti, nby = (h.jj + tj - 1) / tj;
+    if (h.ii - (nbx - 1) * ti < BT4_RH || h.jj - (nby - 1) * tj < BT4_RH) continue;
+    if (persistent) {
+      if (nbx * nby > c->num_cus) continue;
+      if (c->bt4_blocks_per_cu[x] < 0) {
+        int nb = 0;
+        hipError_t e = x == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps4<26, 16>, BT4_NT, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bt_steps4<26, 15>, BT4_NT, 0);
+        c->bt4_blocks_per_cu[x] = e == hipSuccess ? nb : 0;
+      }
+      if (c->bt4_blocks_per_cu[x] < 1) continue;
+    }
+    return BtShape{ti, tj};
+  }
+  return none;
+}
+// 1: the persistent blocked form serves this context, 2: the blocked form with one launch per iteration, 0: neither
+int bt_block_mode(blomgpu_ctx *c) {
+  if (!c->barotp_block || !c->barotp_fused) return 0;
+  if (c->barotp_block == 1) return c->barotp_persist && bt_block_shape(c, true).ti ? 1 : 0;
+  return bt_block_shape(c, false).ti ? 2 : 0;
+}
+// the substeps lll0..last of a phase, four per iteration; mode as bt_block_mode returns it
+int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
+                    int last, int src, int *src_out, int *ml_out, int *nl_out) {
+  const DevView &h = c->h;
+  const BtShape sh = bt_block_shape(c, mode == 1);
+  if (!sh.ti) return ctx_fail(c, "barotp: the blocked form is not usable on this domain");
+  const int nbx = (h.ii + sh.ti - 1) / sh.ti, nby = (h.jj + sh.tj - 1) / sh.tj;
+  const int niter = (last - lll0 + 1 + 3) / 4;
+  PairArgs a;
+  a.m = m; a.n = n;
+  for (int x = 0; x < 2; x++) { a.wo[x] = a.wm[x] = a.wn[x] = 0.; }
+  a.do_odd = a.do_even = 0; a.fold_halo = 1; a.prof = nullptr;
+  a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
+  a.tsel = 0; a.nbx = nbx; a.write_margin = 0;
+  a.pack_on = 0; a.pack_w = a.pack_e = nullptr;
+  a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
+  a.flags = nullptr; a.abort_word = nullptr; a.epoch_base = 0;
+  auto launch = [&]() {
+    if (sh.tj == 16) hipLaunchKernelGGL((k_bt_steps4<26, 16>), dim3(nbx, nby), dim3(BT4_NT), 0, c->stream, c->d, a);
+    else hipLaunchKernelGGL((k_bt_steps4<26, 15>), dim3(nbx, nby), dim3(BT4_NT), 0, c->stream, c->d, a);
+  };
+  if (mode == 1) {
+    if (!c->bt_flags || c->bt_restart) {
+      if (!c->bt_flags) HIPCHK(c, hipMalloc((void **)&c->bt_flags, sizeof(unsigned) * (nbx * nby + 16)));
+      HIPCHK(c, hipMemsetAsync(c->bt_flags, 0, sizeof(unsigned) * (nbx * nby + 16), c->stream));
+      c->bt_epoch = 0;
+      c->bt_restart = false;
+    }
+    a.flags = c->bt_flags + 16;
+    a.epoch_base = c->bt_epoch;
+    c->bt_epoch += (unsigned)niter;
+    if (int rc = ctx_err_words(c)) return rc;
+    a.abort_word = (unsigned *)(c->err_dev + 2);
+    a.ml = ml; a.nl = nl; a.src = src; a.lll0 = lll0; a.last = last;
+    TimeScope tk(c, "k_bt_steps");
+    launch();
+    HIPCHK(c, hipGetLastError());
+    src ^= niter & 1;
+    if ((last - lll0 + 1) & 1) { const int t = ml; ml = nl; nl = t; }
+  } else {
+    TimeScope tk(c, "k_bt_steps");
+    for (int lll = lll0; lll <= last; lll += 4) {
+      const int e = lll + 3 < last ? lll + 3 : last;
+      a.ml = ml; a.nl = nl; a.src = src; a.lll0 = lll; a.last = e;
+      launch();
+      src ^= 1;
+      if ((e - lll + 1) & 1) { const int t = ml; ml = nl; nl = t; }
+    }
+    HIPCHK(c, hipGetLastError());
   }
   *src_out = src; *ml_out = ml; *nl_out = nl;
   return 0;

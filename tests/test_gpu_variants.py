@@ -41,6 +41,26 @@ def test_variants_bit_identical(cfg, nsteps, opt, variants):
 
 
 
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("per_s", 8), ("fuk95", 6), ("chan_b", 8), ("chan_t8", 2), ("channel", 2)])
+def test_four_barotropic_substeps_per_hand_off(cfg, nsteps):
+    """k_bt_steps4 (temporal blocking, the default where the persistent form runs) against one odd+even pair per hand-off, against one
+    kernel per equation, and against itself with a launch per four substeps: one tile, tiles with ragged last rows and columns across the
+    periodic seam, walls in i (fuk95), 4 x 8 and 8 x 32 tiles at the sizes the bench runs."""
+    from blom_amd.gpu import BlomGpu
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    assert gpu.get_real("barotp_block_mode") == 1, "the blocked persistent form should serve this case by default"
+    gpu.close()
+    skip = {"util1", "util2", "util3", "util4"}
+    a = _run(cfg, nsteps)
+    for opts in (dict(barotp_block=0), dict(barotp_block=2), dict(barotp_fused=0, barotp_persist=0)):
+        b = _run(cfg, nsteps, **opts)
+        bad = [nm for nm in a if nm not in skip and a[nm].tobytes() != b[nm].tobytes()]
+        assert not bad, (opts, bad)
+    assert np.isfinite(a["ub"]).all() and np.abs(a["ub"]).max() > 0.0
+
+
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 7), ("tri_s_tke", 6), ("box_s", 6)])
 def test_round6_kernel_variants_bit_identical_down_to_the_sign_of_zero(cfg, nsteps):
     """The variants this round added or made the default -- pgforc's column kernel (pgf_uv_ring: 0 the kernel of rounds 1-5, 3 the

@@ -38,6 +38,8 @@ def _run(cfg, nsteps, ntr=None, **opts):
     hostinit.init_state(gpu, case)
     for k, v in opts.items():
         gpu.set(k, v)
+    if "barotp_block" in opts and opts["barotp_block"]:
+        assert gpu.get_real("barotp_block_mode") == opts["barotp_block"], "the blocked barotp kernel is not usable on this case"
     assert gpu.step(0, nsteps) == nsteps
     out = {nm: gpu.get(nm) for nm in STATE_FIELDS if gpu.has_field(nm)}
     gpu.close()
@@ -47,6 +49,17 @@ def _run(cfg, nsteps, ntr=None, **opts):
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 4), ("box_s", 3), ("tri_s", 3)])
 def test_pair_kernel_equals_one_kernel_per_equation(emu_lib, cfg, nsteps):
     _, new = _run(cfg, nsteps)
+    _, old = _run(cfg, nsteps, **OLD)
+    bad = [nm for nm in new if nm not in SKIP and not np.array_equal(new[nm], old[nm], equal_nan=True)]
+    assert not bad, bad
+    assert np.isfinite(new["u"]).all() and np.abs(new["u"]).max() > 0.0
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s", 4), ("per_s", 3), ("fuk95", 2), ("chan_b", 3)])
+def test_four_substeps_per_tile_launch_equal_one_kernel_per_equation(emu_lib, cfg, nsteps):
+    """k_bt_steps4 (temporal blocking: rim of 4 / 6 cells, every point identified with its home point) with one launch per
+    four substeps -- the form the host emulation can run; the device's default is the same kernel walking a whole phase"""
+    _, new = _run(cfg, nsteps, barotp_block=2)
     _, old = _run(cfg, nsteps, **OLD)
     bad = [nm for nm in new if nm not in SKIP and not np.array_equal(new[nm], old[nm], equal_nan=True)]
     assert not bad, bad
