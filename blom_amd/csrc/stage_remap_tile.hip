@@ -19,13 +19,15 @@
 // of flux planes for k_remap_update).
 #include "remap_common.h"
 
-#define RT_TW 32
+#ifndef RT_TH                             // (tile height / thread count overridable for measurement builds: 16 / 1024 was tried)
 #define RT_TH 8
+#define RT_NT 512                         // threads of a workgroup: >= RT_SN, and two per point of the tile
+#endif
+#define RT_TW 32
 #define RT_GW (RT_TW + 2)                 // gradient region: the tile and a 1-point rim
 #define RT_GN (RT_GW * (RT_TH + 2))
 #define RT_SW (RT_TW + 4)                 // scalar region: the tile and a 2-point rim
 #define RT_SN (RT_SW * (RT_TH + 4))
-#define RT_NT 512                         // threads of a workgroup: >= RT_SN, and two per point of the tile
 #define RT_NB 4                           // tracers of a later batch (MORE)
 #define RT_NSC(ntr) (4 + (ntr))           // scalars: dp, p(k+1), T, S, tracers
 #define RT_NG(ntr) (10 + 3 * (ntr))       // gradient slots (remap_common.h) + dp', pup of the cell
