@@ -18,8 +18,8 @@
 // Real powers and exponentials are the host libm's bits (pow_libm.h, exp_libm.h); tanh of the latitude (tidal mixing length
 // scale, :2926-2927) and log of the Coriolis parameter (bdmldp, :2747-2750) depend on the grid only: the host evaluates them once
 // with its own libm into the planes tdmls and bdmlq.  rhsctp's sin and atan2 of the flow direction are
-// evaluated on the device with the bits of the host libm's (sin_libm.h, atan2_libm.h; round 6).  Not built, refused by the option
-// setter: the two-equation closure (use_GLS).
+// evaluated on the device with the bits of the host libm's (sin_libm.h, atan2_libm.h; round 6).  The two-equation closure (use_GLS:
+// the length-scale variable a prognostic tracer, :2788-2814, :2858-2863, :2921-2927, :2970-2973) with the option gls = 1 (round 6).
 // Parity: cross-checked against the reference's REAL mod_difest.F90 compiled against interface-only stand-ins for the CVMix
 // modules it imports but does not call on this path (oracle/xcheck/cvmix_standin.F90; builds *_xdf) -- a cross-check, not a pin.
 // Roofline: HBM, ~60 F of column traffic; the kernels are bound by their k-serial chains like the other column kernels.
@@ -91,10 +91,11 @@ enum { W_DU2 = 0, W_DV2, W_BVFSQ, W_BVF, W_EGR, W_ANISOK, W_SM1, W_SM2, W_NUB, W
 
 struct TkeC {            // initke's derived constants, phy/mod_tke.F90:133-160
   double sqrt2, cmu_fac1, cmu_fac2, cmu_fac3, tke_exp1, gls_exp1, gls_fac6, s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5, cmu0p3;
+  double gls_qfac, gls_bbc, gls_cmu0p;     // the two-equation closure's constant factors (use_GLS), see tke_consts
 };
 struct DfePar {
   double egc, eggam, eglsmn, egmndf, egmxdf, egidfq, rhiscf, ri0, tkepf, niwgf, niwbf, niwlf, bdml_logc;
-  int eddf2d, edsprs, edanis, redi3d, edritp, edwmth, use_tke, itke, igls, rhsctp;
+  int eddf2d, edsprs, edanis, redi3d, edritp, edwmth, use_tke, use_gls, itke, igls, rhsctp;
   TkeC T;
 };
 
@@ -113,6 +114,11 @@ static TkeC tke_consts() {
   const double c2 = GLS_CMU0 * GLS_CMU0;
   t.gls_fac6 = 8. / (c2 * (c2 * c2));
   t.cmu0p3 = GLS_CMU0 * c2;
+  // use_GLS: .56**(.5*gls_n)*gls_cmu0**gls_p (:2806: two folded real powers and their product), (gls_cmu0**(gls_p-2.*gls_m)) ... *(kappa)**gls_n
+  // (:2859-2862: the first factor is cmu0**0. = 1, the last .4**(-1.)), gls_cmu0**gls_p (:2926)
+  t.gls_qfac = std::pow(.56, .5 * gls_n) * std::pow(GLS_CMU0, gls_p);
+  t.gls_bbc = std::pow(.4, gls_n);
+  t.gls_cmu0p = std::pow(GLS_CMU0, gls_p);
   t.s0 = 1.5 * L1 * (L5 * L5);
   t.s1 = -L4 * (L6 + L7) + 2. * L4 * L5 * (L1 - 1. / 3. * L2 - L3) + 1.5 * L1 * L5 * L8;
   t.s2 = -3. / 8. * L1 * (L6 * L6 - L7 * L7);
@@ -395,9 +401,22 @@ __global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
     const double delt1 = P.delt1;
     const double gls_c3 = b2 > 0. ? GLS_C3MINUS : GLS_C3PLUS;
     const double prod = V.f[F_Prod][o], buoy = V.f[F_Buoy][o];
-    double tk = *tke, gl = fmax2((GLS_C1 * prod + gls_c3 * buoy) / GLS_C2, GLS_PSI_MIN);
+    // one-equation closure: the length-scale slot is diagnosed from production and buoyancy (:2778-2782); two-equation closure
+    // (use_GLS, gls_p = 3, gls_m = 1.5, gls_n = -1: k-epsilon): it is a prognostic tracer, stepped here (:2788-2814)
+    double tk = *tke, gl = D.use_gls ? *gls : fmax2((GLS_C1 * prod + gls_c3 * buoy) / GLS_C2, GLS_PSI_MIN);
     // (the real powers trc**(1.5+gls_m/gls_n), trc**(-1./gls_n) have the exponents 0 and 1: the compiler folds them)
-    const double tke_epsilon = T.cmu_fac2 * gl;
+    double tke_epsilon = T.cmu_fac2 * gl;
+    if (D.use_gls) {
+      const double r = gl / tk;
+      const double gprod = r * GLS_C1 * prod, gbuoy = r * gls_c3 * buoy, gdiss = r * GLS_C2 * tke_epsilon;
+      const double gq = gdiss / gl;
+      if (gprod + gbuoy >= 0.) gl = (gl + delt1 * (gprod + gbuoy)) / (1. + delt1 * gq);
+      else gl = (gl + delt1 * gprod) / (1. + delt1 * (gq - (gbuoy / gl)));
+      gl = fmax2(gl, GLS_PSI_MIN);
+      // q = .56**(.5 gls_n) cmu0**gls_p * tke**(gls_m + .5 gls_n) * bvf**(-gls_n): the last two exponents are 1; gls_n < 0: the larger one
+      gl = fmax2(gl, T.gls_qfac * tk * WK(V, W_BVF)[o]);
+      tke_epsilon = T.cmu_fac2 * gl;
+    }
     const double tke_q = tke_epsilon / tk;
     if (prod + buoy >= 0.) tk = (tk + delt1 * (prod + buoy)) / (1. + delt1 * tke_q);
     else {
@@ -416,9 +435,10 @@ __global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
       const double ust = fmax2(V.f[F_ustarb][c], USTMIN);
       const double r = ust / GLS_CMU0;
       tk = fmax2(TKE_MIN, r * r);
+      if (D.use_gls) gl = fmax2(GLS_PSI_MIN, pow_libm(ust, 3.) * T.gls_bbc);          // cmu0**(p - 2m) ust**(2m) kappa**n, :2858-2863
     }
     *tke = tk;
-    *gls = gl;
+    if (!D.use_gls) *gls = gl;
     // trc(tke)**(-tke_exp1) and, below, trc(tke)**(-gls_m/gls_n): the same base and the same exponent, 1.5 -- one evaluation
     const double tk15 = pow_libm(tk, -T.tke_exp1);
     const double ls_unlmt = fmax2(LS_UNLMT_MIN, T.cmu_fac1 * pow_libm(gl, T.gls_exp1) * tk15);
@@ -439,7 +459,10 @@ __global__ void k_dfi_vert_b(const DevView *__restrict__ Vp, DfePar D, int nn) {
     sh = sh * T.cmu_fac3 / T.cmu0p3;
     const double ql = T.sqrt2 * ls * sqrt(tk);
     nus = fmin2(sh * ql, 4.05 * NUG0);
-    V.f[F_L_scale][o] = fmax2(ls, LS_UNLMT_MIN);
+    const double lsc = fmax2(ls, LS_UNLMT_MIN);
+    V.f[F_L_scale][o] = lsc;
+    // use_GLS: the length-scale variable recomputed from the limited length scale, cmu0**p tke**m L**n (:2921-2927)
+    if (D.use_gls) *gls = fmax2(T.gls_cmu0p * (T.tke_exp1 == -1.5 ? tk15 : pow_libm(tk, 1.5)) * (1. / lsc), GLS_PSI_MIN);
   }
   double nut;                                                                      // tidally driven mixing, :2924-2937
   {
@@ -487,11 +510,12 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
   {
     // levels above the range take the value of the level above them (:2958-2970): difdia = nu0, the TKE and the length scale of layer 1
     const int ka = any ? (kf > 2 ? kf : 2) : kk + 1, kb = any ? (km < kk ? km : kk) : kk;
-    double ld = NU0, lt = D.use_tke ? tke[0] : 0., ll = D.use_tke ? Lsc[0] : 0.;
+    double ld = NU0, lt = D.use_tke ? tke[0] : 0., ll = D.use_tke ? Lsc[0] : 0., lg = D.use_gls ? gls[0] : 0.;
     for (int k = 2; k < ka; k++) {
       const size_t o = (size_t)(k - 1) * np;
       difdia[o] = ld;
       if (D.use_tke) { tke[o] = lt; Lsc[o] = ll; }
+      if (D.use_gls) gls[o] = lg;                                                  // :2970-2973
     }
     if (any) {
       if (D.use_tke) {                        // what the first level inside the range does to the two mixed layer layers, :2857-2860
@@ -519,10 +543,12 @@ __global__ __launch_bounds__(64) void k_dfi_vert_c(const DevView *__restrict__ V
         }
       }
       if (D.use_tke) { lt = tke[(size_t)(kb - 1) * np]; ll = Lsc[(size_t)(kb - 1) * np]; }
+      if (D.use_gls) lg = gls[(size_t)(kb - 1) * np];
       for (int k = kb + 1; k <= kk; k++) {
         const size_t o = (size_t)(k - 1) * np;
         difdia[o] = ld;
         if (D.use_tke) { tke[o] = lt; Lsc[o] = ll; }
+        if (D.use_gls) gls[o] = lg;
       }
     }
   }
@@ -1004,7 +1030,6 @@ extern "C" int blomgpu_tke_const(const char *name, double *v) {
 int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
   const DevView &h = c->h;
   if (h.P.vcoord_tag != 1) return ctx_fail(c, "difest_isobml is the isopycnic coordinate's (phy/mod_blom_step.F90:140)");
-  if (h.P.itrtke >= 1 && h.P.gls) return ctx_fail(c, " difest_vertical_iso: the two-equation closure (use_GLS) is not built on the device");
   if (h.P.itrtke >= 1 && (h.P.itrtke > h.ntr || h.P.itrgls < 1 || h.P.itrgls > h.ntr)) return ctx_fail(c, "difest: itrtke / itrgls outside 1..ntr");
   if (h.P.bdmldp && c->bdml_logc == 0.) return ctx_fail(c, " difest_vertical_iso: bdmldp needs the plane bdmlq and the option bdml_logc (the host's log)");
   if (W_NSLOT > h.nwk) return ctx_fail(c, "difest: work space too small");
@@ -1014,7 +1039,7 @@ int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
   D.rhiscf = c->rhiscf; D.ri0 = c->ri0; D.tkepf = c->tkepf; D.niwgf = c->niwgf; D.niwbf = c->niwbf; D.niwlf = c->niwlf;
   D.bdml_logc = c->bdml_logc;
   D.rhsctp = c->rhsctp; D.eddf2d = c->eddf2d; D.edsprs = c->edsprs; D.edanis = c->edanis; D.redi3d = c->redi3d; D.edritp = c->edritp_opt; D.edwmth = c->edwmth_opt;
-  D.use_tke = h.P.itrtke >= 1; D.itke = h.P.itrtke; D.igls = h.P.itrgls;
+  D.use_tke = h.P.itrtke >= 1; D.use_gls = D.use_tke && h.P.gls; D.itke = h.P.itrtke; D.igls = h.P.itrgls;
   D.T = tke_consts();
   const dim3 g1 = plane_grid(h, 1, 64), g2 = plane_grid(h, 2, 64), b64(64);
   {

@@ -9,10 +9,13 @@
 //   k_thermf_channel_corr   :275-343 the correction that makes the virtual salt flux globally consistent with the reference
 //                           salinity, unit conversion
 // Not built (fail loudly): the diagnosed relaxation fluxes (aptflx, apsflx, ditflx, disflx: four 48-level arrays), the balanced
-// salinity relaxation (srxbal: needs the world ocean mask), the surface flux of the generic length scale (use_GLS: real powers).
+// salinity relaxation (srxbal: needs the world ocean mask).  The surface flux of the generic length scale (use_GLS, :167-175) takes its
+// one real power of a field value, trc(tke)**gls_m, from pow_libm.h; the others are powers of PARAMETERs, folded by the host's pow.
 // On decomposed domains the two sums gather the plane (halo.hip: xcsum_group, comm_rccl.hip: rccl_xcsum_dev).
 // Roofline: HBM, ~20 two-dimensional planes.
 #include "blomgpu_internal.h"
+#include "pow_libm.h"
+#include <cmath>
 
 #define PLANE_IJ(V)                                                        \
   unsigned bx_, by_;                                                       \
@@ -33,6 +36,8 @@
 struct ThermfPar {
   double trxday, srxday, trxdpt, srxdpt, trxlim, srxlim, xmi, sref, area;
   int l1mi, l2mi, l3mi, l4mi, l5mi;
+  int use_gls;                   // use_GLS: gls_cmu0**gls_p, vonKar**gls_n, Zos**(gls_n-1.) (phy/mod_tke.F90:36-58: .527, 3., .4, -1., .0002)
+  double gls_c, gls_vk, gls_z;
 };
 
 // phy/mod_intp1d.F90:29-52
@@ -74,7 +79,11 @@ __global__ void k_thermf_channel_flux(const DevView *__restrict__ Vp, ThermfPar 
   // tracer fluxes (positive downwards), :165-197
   for (int nt = 0; nt < ntr; nt++) {
     gd_t trflx = V.f[F_trflx] + c + (size_t)nt * np;
-    if (V.P.itrtke >= 1 && (nt + 1 == V.P.itrtke || nt + 1 == V.P.itrgls)) { *trflx = 0.; continue; }   // (use_GLS is refused by the host)
+    if (V.P.itrtke >= 1 && T.use_gls && nt + 1 == V.P.itrgls) {                  // :167-175 (-gls_n = 1)
+      *trflx = V.f[F_difdia][c] * T.gls_c * pow_libm(V.f[F_trc][ok1 + (size_t)(V.P.itrtke - 1) * 2 * kk * np], 1.5) * T.gls_vk * T.gls_z;
+      continue;
+    }
+    if (V.P.itrtke >= 1 && (nt + 1 == V.P.itrtke || nt + 1 == V.P.itrgls)) { *trflx = 0.; continue; }
     *trflx = -V.f[F_trc][ok1 + (size_t)nt * 2 * kk * np] * fwflx * 1.e-3;
   }
   // relaxation fluxes, :203-255
@@ -135,10 +144,11 @@ int st_thermf(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   if (c->aptflx || c->apsflx || c->ditflx || c->disflx)
     return ctx_fail(c, "thermf_channel: applying / diagnosing relaxation fluxes (aptflx, apsflx, ditflx, disflx) is not built on the device");
   if (c->srxday > EPSILT && c->srxbal) return ctx_fail(c, "thermf_channel: the balanced salinity relaxation (srxbal) is not built on the device");
-  if (h.P.itrtke >= 1 && h.P.gls) return ctx_fail(c, "thermf_channel: the surface flux of the generic length scale (use_GLS) is not built on the device");
   ThermfPar T;
   T.trxday = c->trxday; T.srxday = c->srxday; T.trxdpt = c->trxdpt; T.srxdpt = c->srxdpt; T.trxlim = c->trxlim; T.srxlim = c->srxlim;
   T.xmi = c->xmi; T.sref = c->sref; T.area = c->area;
+  T.use_gls = h.P.itrtke >= 1 && h.P.gls ? 1 : 0;
+  T.gls_c = std::pow(.527, 3.); T.gls_vk = std::pow(.4, -1.); T.gls_z = std::pow(.0002, -1. - 1.);
   T.l1mi = c->lmi[0]; T.l2mi = c->lmi[1]; T.l3mi = c->lmi[2]; T.l4mi = c->lmi[3]; T.l5mi = c->lmi[4];
   if (c->area <= 0.) return ctx_fail(c, "thermf_channel: the ocean area (mod_grid: area) has not been set");
   TimeScope ts(c, "thermf");

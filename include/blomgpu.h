@@ -113,7 +113,7 @@ int  blomgpu_atan2(blomgpu_ctx *, int n, const double *y, const double *x, doubl
  * -> difint, difiso, difdia, difwgt (and the TKE tracers' source step).  Options: blomgpu_set_real "egc", "eggam", "eglsmn", "egmndf",
  * "egmxdf", "egidfq", "ri0", "tkepf"; blomgpu_set_int "eddf2d", "edsprs", "edanis", "redi3d", "edfsmo", "edritp_opt" (1 shear, 2 large
  * scale), "edwmth_opt" (1 smooth, 2 step), "bdmtyp", "iwdflg", "bdmldp", "rhsctp" (with blomgpu_set_real "rhiscf" and the fields
- * "betatp", "hangle": since round 6); the two-equation closure is refused.  Inputs that
+ * "betatp", "hangle": since round 6), "gls" (use_GLS, the two-equation closure: since round 6).  Inputs that
  * depend on the grid only and need the host's libm are uploaded as planes: "tdmls" (tidal mixing length scale, :2926-2927) and, with
  * bdmldp, "bdmlq" = log(2 bvf0 / max(1e-9, |coriop|)) with the option "bdml_logc" = log(2 bvf0 / cori30).
  * PARITY UNPINNED: cross-checked against the reference's real module compiled against interface-only stand-ins for CVMix. */

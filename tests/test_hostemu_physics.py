@@ -53,3 +53,6 @@ def test_difest_isobml_diffusivity_estimates_on_the_host_emulation(emu_lib):
     _live_step_check("box_s", 4, hostinit.DIFEST_NORESM)
     from test_xcheck_difest import test_rhsctp_acts_on_the_layer_interface_diffusivities as rhs_effect
     rhs_effect("chan_s_tke")
+    # the two-equation closure (use_GLS; round 6): the stage on its own and the whole step against the -DGLS build
+    _live_step_check("chan_s_tk2", 3, OPT_SHEAR, stagewise=True)
+    _live_step_check("chan_s_tk2", 4, hostinit.DIFEST_NORESM)

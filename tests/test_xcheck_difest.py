@@ -141,14 +141,17 @@ def _live_step_check(cfg, nsteps, opts, stagewise=False, ntr=None):
 
 
 @pytest.mark.parametrize("cfg,opts", [("chan_s_tke", OPT_FUK95), ("chan_s_tke", OPT_SHEAR), ("box_s", OPT_SHEAR), ("tri_s_tke", OPT_2D),
-                                      ("box_s", OPT_2D), ("chan_s_tke", hostinit.DIFEST_NORESM), ("tri_s_tke", hostinit.DIFEST_NORESM)])
+                                      ("box_s", OPT_2D), ("chan_s_tke", hostinit.DIFEST_NORESM), ("tri_s_tke", hostinit.DIFEST_NORESM),
+                                      ("chan_s_tk2", OPT_FUK95), ("chan_s_tk2", OPT_SHEAR)])
 def test_difest_isobml_on_its_own_equals_the_real_module(cfg, opts):
+    """(chan_s_tk2: the build with -DGLS, turbclo = twoeq -- the length-scale variable a prognostic tracer stepped by difest_vertical_iso,
+    phy/mod_difest.F90:2788-2814, :2858-2863, :2921-2927, with its surface flux from thermf_channel, channel/mod_thermf_channel.F90:167-175)"""
     _live_step_check(cfg, 4, opts, stagewise=True)
 
 
 @pytest.mark.parametrize("cfg,nsteps,opts", [("chan_s_tke", 8, OPT_FUK95), ("chan_s_tke", 6, OPT_2D), ("box_s", 6, OPT_FUK95), ("box_s", 6, OPT_SHEAR),
                                              ("tri_s_tke", 6, OPT_FUK95), ("tri_s_tke", 6, OPT_SHEAR), ("chan_s_tke", 6, hostinit.DIFEST_NORESM),
-                                             ("box_s", 6, hostinit.DIFEST_NORESM)])
+                                             ("box_s", 6, hostinit.DIFEST_NORESM), ("chan_s_tk2", 8, hostinit.DIFEST_NORESM), ("chan_s_tk2", 6, OPT_2D)])
 def test_full_step_with_live_diffusivities_equals_the_reference_stage_sequence(cfg, nsteps, opts):
     _live_step_check(cfg, nsteps, opts)
 
