@@ -313,7 +313,7 @@ int bt_phase_check(blomgpu_ctx *c);
 int bt_overlap_usable(blomgpu_ctx *c);
 int bt_block_mode(blomgpu_ctx *c);
 int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
-                    int last, int src, int *src_out, int *ml_out, int *nl_out);
+                    int last, int src, int *src_out, int *ml_out, int *nl_out, int nb);
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
                    int do_odd, int do_even, int src, int tsel, RcclLanded *rim);
 int bt_pair_halo_landed(blomgpu_ctx *c, int set, RcclLanded *landed);
@@ -374,7 +374,6 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     } else if (nb == 4) {
       wna = 0.; wnb = 1.;
     }
-    hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
     const int last = lll0 + lstep / 2 - 1;
     // With the arctic patch the halo update also rewrites the seam row jj, an interior row, so it must
     // happen exactly where the reference has it: before odd substeps only.  The fused kernels then publish
@@ -383,6 +382,9 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     const bool arctic1 = h.nreg == 2 && (!c->tiling.multi() || c->barotp_arctic_fused);
     const bool fused = c->barotp_fused && (h.nreg != 2 || arctic1);
     bool halo_done = false;
+    // k_bt_steps4 starts the phase's flux sums at zero and ends with the phase's epilogue itself (three launches less per phase)
+    const bool blocked = fused && !arctic1 && bt_block_mode(c);
+    if (!blocked) hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
     if (fused && arctic1 && !c->tiling.multi() && c->barotp_persist && bt_phase_usable(c)) {
       // arctic patch, single tile: the halo update -- which also rewrites the seam row -- belongs in front of odd substeps
       // only, so the persistent launch takes the whole odd+even pairs of the phase (its tiles re-read rim and seam at the
@@ -417,7 +419,7 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     } else if (fused && !arctic1 && bt_block_mode(c)) {
       // four substeps per hand-off (k_bt_steps4)
       int so, mo, no;
-      if (int rc = bt_block_launch(c, bt_block_mode(c), m, n, ml, nl, woa, wob, wna, wnb, lll0, last, set, &so, &mo, &no)) return rc;
+      if (int rc = bt_block_launch(c, bt_block_mode(c), m, n, ml, nl, woa, wob, wna, wnb, lll0, last, set, &so, &mo, &no, nb)) return rc;
       set = so; ml = mo; nl = no;
     } else if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
@@ -503,6 +505,7 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     }
     lll0 = lll0 + lstep / 2;
     // the epilogue reads pb_t(i-1,j), pb_t(i,j-1); the fused kernels write tile interiors only
+    if (blocked) continue;
     if (fused && !halo_done && !arctic1)
       if (int rc = bt_pair_halo(c, set)) return rc;
     halo_done = false;

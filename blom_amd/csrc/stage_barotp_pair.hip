@@ -53,6 +53,9 @@ struct PairArgs {
   // strips themselves (no pack launch); N/S rim cells of the columns 1..ii then follow the local rule at load
   double *pack_w, *pack_e;
   int pack_on;
+  // k_bt_steps4: the launch starts the phase's flux sums at zero (k_bt_zero_sums, :361-379) instead of loading them, and ends with the
+  // phase's epilogue (k_bt_epilogue, :847-977; 0: none) for its own points
+  int zero_sums = 0, epi_nb = 0;
 };
 
 // PERSIST = false: one odd+even pair (or one half) per launch, neighbours synchronise at the kernel
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
       q.v_scvyi = V.f[F_scvyi][c]; q.v_scvx = V.f[F_scvx][c]; q.v_tot = V.f[F_vtotn][c]; q.v_glue = V.f[F_vglue][c];
       q.v_max = V.f[F_vmaxb][c]; q.v_min = V.f[F_vminb][c];
     }
-    if (q.mine) {
+    if (q.mine && !a.zero_sums) {
       if (q.wu) { q.us_acc = V.f[F_ubflxs_t][c]; q.uc_acc = V.f[F_ubcors_t][c]; }
       if (q.wv) { q.vs_acc = V.f[F_vbflxs_t][c]; q.vc_acc = V.f[F_vbcors_t][c]; }
     }
@@ -738,9 +741,82 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
 #pragma unroll
   for (int p = 0; p < 2; p++) {
     const Bt4Pt &q = P[p];
-    if (q.mine) {
-      if (q.wu) { V.f[F_ubflxs_t][q.c] = q.us_acc; V.f[F_ubcors_t][q.c] = q.uc_acc; }
-      if (q.wv) { V.f[F_vbflxs_t][q.c] = q.vs_acc; V.f[F_vbcors_t][q.c] = q.vc_acc; }
+    if (!q.mine) continue;
+    const size_t c = q.c;
+    if (q.wu) { V.f[F_ubflxs_t][c] = q.us_acc; V.f[F_ubcors_t][c] = q.uc_acc; }
+    if (q.wv) { V.f[F_vbflxs_t][c] = q.vs_acc; V.f[F_vbcors_t][c] = q.vc_acc; }
+    if (!a.epi_nb) continue;
+    // the phase's epilogue (k_bt_epilogue of stage_barotp.hip, phy/mod_barotp.F90:847-977) for this point, from the block in LDS: pb at
+    // i-1 and j-1 lies in the rim (valid one cell further down than the fluxes after any substep) and is what a halo update would bring
+    const int nb = a.epi_nb, li = q.li, lj = q.lj;
+    const size_t oml = (size_t)ml * np, onl = (size_t)nl * np, o3 = 2 * np;
+    const double us = q.us_acc, vs = q.vs_acc;
+    const double pbc = s_pb[ml][lj][li];
+    if (nb == 1 || nb == 3) {
+      const size_t ol = nb == 1 ? om : on;
+      if (q.wp) V.f[F_pb][c + ol] = pbc;
+      if (q.wu) {
+        const double pbu = fmin2(pbc, s_pb[ml][lj][li - 1]);
+        V.f[F_pbu][c + ol] = pbu;
+        const double f = s_ub[ml][lj][li];
+        V.f[F_ubflx][c + ol] = f;
+        V.f[F_ub][c + ol] = f / (pbu * q.u_scuy);
+        if (nb == 1) {
+          V.f[F_ubflxs][c + on] = V.f[F_ubflxs][c + on] + us;
+          V.f[F_ubflxs][c + om] = V.f[F_ubflxs][c + o3] + us;
+        } else {
+          V.f[F_ubflxs_p][c + om] = V.f[F_ubflxs][c + om] + us;
+          V.f[F_ubflxs_p][c + on] = V.f[F_ubflxs_p][c + on] + us;
+          V.f[F_ubcors_p][c] = V.f[F_ubcors_p][c] + q.uc_acc;
+        }
+      }
+      if (q.wv) {
+        const double pbv = fmin2(pbc, s_pb[ml][lj - 1][li]);
+        V.f[F_pbv][c + ol] = pbv;
+        const double f = s_vb[ml][lj][li];
+        V.f[F_vbflx][c + ol] = f;
+        V.f[F_vb][c + ol] = f / (pbv * q.v_scvx);
+        if (nb == 1) {
+          V.f[F_vbflxs][c + on] = V.f[F_vbflxs][c + on] + vs;
+          V.f[F_vbflxs][c + om] = V.f[F_vbflxs][c + o3] + vs;
+        } else {
+          V.f[F_vbflxs_p][c + om] = V.f[F_vbflxs][c + om] + vs;
+          V.f[F_vbflxs_p][c + on] = V.f[F_vbflxs_p][c + on] + vs;
+          V.f[F_vbcors_p][c] = V.f[F_vbcors_p][c] + q.vc_acc;
+        }
+      }
+    } else if (nb == 2) {
+      if (q.wp) { V.f[F_pb_mn][c + oml] = pbc; V.f[F_pb_mn][c + onl] = s_pb[nl][lj][li]; }
+      if (q.wu) {
+        V.f[F_ubflx_mn][c + oml] = s_ub[ml][lj][li];
+        V.f[F_ubflx_mn][c + onl] = s_ub[nl][lj][li];
+        V.f[F_ubflxs][c + om] = V.f[F_ubflxs][c + om] + us;
+        V.f[F_ubflxs][c + o3] = us;
+        V.f[F_ubflxs_p][c + on] = us;
+        V.f[F_ubcors_p][c] = q.uc_acc;
+      }
+      if (q.wv) {
+        V.f[F_vbflx_mn][c + oml] = s_vb[ml][lj][li];
+        V.f[F_vbflx_mn][c + onl] = s_vb[nl][lj][li];
+        V.f[F_vbflxs][c + om] = V.f[F_vbflxs][c + om] + vs;
+        V.f[F_vbflxs][c + o3] = vs;
+        V.f[F_vbflxs_p][c + on] = vs;
+        V.f[F_vbcors_p][c] = q.vc_acc;
+      }
+    } else {
+      if (nb == 5) {
+        if (q.wp) V.f[F_pb_p][c] = pbc;
+        if (q.wu) V.f[F_pbu_p][c] = fmin2(pbc, s_pb[ml][lj][li - 1]);
+        if (q.wv) V.f[F_pbv_p][c] = fmin2(pbc, s_pb[ml][lj - 1][li]);
+      }
+      if (q.wu) {
+        V.f[F_ubflxs_p][c + on] = V.f[F_ubflxs_p][c + on] + us;
+        V.f[F_ubcors_p][c] = V.f[F_ubcors_p][c] + q.uc_acc;
+      }
+      if (q.wv) {
+        V.f[F_vbflxs_p][c + on] = V.f[F_vbflxs_p][c + on] + vs;
+        V.f[F_vbcors_p][c] = V.f[F_vbcors_p][c] + q.vc_acc;
+      }
     }
   }
 }
@@ -1034,7 +1110,7 @@ int bt_block_mode(blomgpu_ctx *c) {
 }
 // the substeps lll0..last of a phase, four per iteration; mode as bt_block_mode returns it
 int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
-                    int last, int src, int *src_out, int *ml_out, int *nl_out) {
+                    int last, int src, int *src_out, int *ml_out, int *nl_out, int nb) {
   const DevView &h = c->h;
   const BtShape sh = bt_block_shape(c, mode == 1);
   if (!sh.ti) return ctx_fail(c, "barotp: the blocked form is not usable on this domain");
@@ -1066,6 +1142,7 @@ int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, doub
     if (int rc = ctx_err_words(c)) return rc;
     a.abort_word = (unsigned *)(c->err_dev + 2);
     a.ml = ml; a.nl = nl; a.src = src; a.lll0 = lll0; a.last = last;
+    a.zero_sums = 1; a.epi_nb = nb;
     TimeScope tk(c, "k_bt_steps");
     launch();
     HIPCHK(c, hipGetLastError());
@@ -1076,6 +1153,7 @@ int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, doub
     for (int lll = lll0; lll <= last; lll += 4) {
       const int e = lll + 3 < last ? lll + 3 : last;
       a.ml = ml; a.nl = nl; a.src = src; a.lll0 = lll; a.last = e;
+      a.zero_sums = lll == lll0 ? 1 : 0; a.epi_nb = e == last ? nb : 0;
       launch();
       src ^= 1;
       if ((e - lll + 1) & 1) { const int t = ml; ml = nl; nl = t; }
