@@ -217,11 +217,14 @@ __host__ __device__ inline double fmin3(double a, double b, double c) { return f
 #define KPROF_PASS(id) , (c->kprof_sel == (id) ? c->kprof : nullptr), c->kprof_words
 #define KPROF_MARK(wave, slot) do { if (kprof && 8 * (wave) + (slot) < kprof_words) kprof[8 * (wave) + (slot)] = wall_clock64(); } while (0)
 #define KPROF_ADD(wave, slot, v) do { if (kprof && 8 * (wave) + (slot) < kprof_words) atomicAdd((unsigned long long *)&kprof[8 * (wave) + (slot)], (unsigned long long)(v)); } while (0)
+// one count per trip of the WAVE through this point (the lowest active lane counts)
+#define KPROF_TRIP(wave, slot) do { if (kprof && 8 * (wave) + (slot) < kprof_words && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) kprof[8 * (wave) + (slot)] += 1; } while (0)
 #else
 #define KPROF_ARGS
 #define KPROF_PASS(id)
 #define KPROF_MARK(wave, slot) do { } while (0)
 #define KPROF_ADD(wave, slot, v) do { } while (0)
+#define KPROF_TRIP(wave, slot) do { } while (0)
 #endif
 
 // ---- context ---------------------------------------------------------------------------

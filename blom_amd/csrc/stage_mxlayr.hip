@@ -139,8 +139,8 @@ __global__ void k_mxl_bg2_sum(const DevView *__restrict__ Vp) {
 // use(nt, x, y, z) computes and stores.  (One tracer per iteration is one exposed memory latency per tracer and loop -- with 24
 // tracers most of the kernel's time.)  What the loop reads besides the tracers is loaded by the caller beforehand.
 template <class L, class U>
-__device__ inline void tracers4(int ntr, L load, U use) {
-  for (int nt0 = 0; nt0 < ntr; nt0 += 4) {
+__device__ inline void tracers4(int ntr, L load, U use, int first = 0) {
+  for (int nt0 = first; nt0 < ntr; nt0 += 4) {
     double x[4], y[4], z[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -153,7 +153,7 @@ __device__ inline void tracers4(int ntr, L load, U use) {
   }
 }
 #define MAXTR_MXL 64     // tracer sums of a column: dynamically indexed (private memory), any tracer count up to this
-__global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ Vp, MxlPar M, int n, int nn) {
+__global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ Vp, MxlPar M, int n, int nn KPROF_ARGS) {
   const DevView &V = *Vp;
   PLANE_IJ(V);
   if (j < 1 || j > V.jj || i < 1 || i > V.ii || !V.m[I_ip][c]) return;
@@ -184,6 +184,10 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
   const double bpdrho = .4, bpmndp = 10. * ONEM, bpmxdp = 500. * ONEM, bpdpmn = 1. * ONEM, dsgmnr = .1;
   const double mltmin = M.mltmin, thktop = M.thktop, rm5 = M.rm5;
 
+  // KPROF words: 0 start, 1 pressure scan done, 2 detrainment's iteration done, 3 detrainment branch done (forcing, fossil layer), 4 entrainment's
+  // walk done, 5 entrainment branch done, 6 end; 7 trips of the wave through the entrainment's inner iteration
+  [[maybe_unused]] const int wid = blockIdx.x;
+  KPROF_MARK(wid, 0);
   // 2-D inputs of the column
   const double surflx = V.f[F_surflx][c], salflx = V.f[F_salflx][c], brnflx = V.f[F_brnflx][c], sswflx = V.f[F_sswflx][c];
   const double surrlx = V.f[F_surrlx][c], salrlx = V.f[F_salrlx][c], swfc2 = V.f[F_swfc2][c], swal2 = V.f[F_swal2][c];
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     }
   }
 
+  KPROF_MARK(wid, 1);
   // ---- turbulent kinetic energy balance of the mixed layer, :313-384 ------------------------------------------------------
   double q = 1. / (DP(1) + DP(2));
   double tmxl = (TT(1) * DP(1) + TT(2) * DP(2)) * q;
@@ -255,6 +260,30 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
          dsgds, bpc, bpmldp, pswbas, pswup, pswlo, ttmp, stmp, sigtmp, sigfsl, tmxl0, smxl0, dpe0, tdps, sdps, dpe, dps, um, vm, dke,
          dke0, tkeu, tkel = 0., uk, vk;
   double trfsl[MAXTR_MXL], trdps[MAXTR_MXL];
+  // the entrainment's sums of the first four tracers in registers (trdps is indexed by a variable: private memory, a memory round trip per
+  // access -- three or four of them in every trip of the entrainment loop); tracers 5.. keep to trdps
+  double trd4[4] = {0., 0., 0., 0.};
+  // sums += tracers of layer kq_ times w_ (every tracer: its own sum, its own order)
+  auto trd_add = [&](int kq_, double w_) {
+    double y_[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) y_[b] = TR(b < ntr ? b : ntr - 1, kq_);
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (b < ntr) trd4[b] = trd4[b] + y_[b] * w_;
+    tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, kq_); },
+             [&](int nt, double x, double y, double) { trdps[nt] = x + y * w_; }, 4);
+  };
+  // sums = tracers of layer 2 times its thickness
+  auto trd_init = [&](double dp2_) {
+    double x_[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) x_[b] = TR(b < ntr ? b : ntr - 1, 2);
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (b < ntr) trd4[b] = x_[b] * dp2_;
+    tracers4(ntr, [&](int nt, double &x, double &, double &) { x = TR(nt, 2); }, [&](int nt, double x, double, double) { trdps[nt] = x * dp2_; }, 4);
+  };
   double pbrnda_out;
 
   if (tkew < 0. && pmxl > mltmin * ONEM) {
@@ -305,6 +334,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     }
     // (nitr == maxitr: the reference prints the column -- 'reached maxitr when detraining', :439-440 -- and goes on; counted as it prints)
     if (nitr == MAXITR) atomicAdd(M.maxitr_count, 1);
+    KPROF_MARK(wid, 2);
 
     pmxl = fmax2(mltmin * ONEM, pmxl);
     dpfsl = PR(3) - pmxl;
@@ -565,6 +595,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       }
     }
 
+    KPROF_MARK(wid, 3);
   } else {
 
     if (tkew < 0.) {                                                                  // :811-834
@@ -573,15 +604,14 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       sdps = SS(2) * DP(2);
       {
         const double dp2 = DP(2);
-        tracers4(ntr, [&](int nt, double &x, double &, double &) { x = TR(nt, 2); }, [&](int nt, double x, double, double) { trdps[nt] = x * dp2; });
+        trd_init(dp2);
       }
       k = kfpl;
       while (k <= kk) {
         q = fmin2(pmxl, PR(k + 1)) - PR(k);
         tdps = tdps + TT(k) * q;
         sdps = sdps + SS(k) * q;
-        tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, k); },
-                 [&](int nt, double x, double y, double) { trdps[nt] = x + y * q; });
+        trd_add(k, q);
         DP(k) = PR(k + 1) - fmin2(pmxl, PR(k + 1));
         if (PR(k + 1) > pmxl) break;
         k = k + 1;
@@ -608,19 +638,29 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       sdps = SS(2) * DP(2);
       {
         const double dp2 = DP(2);
-        tracers4(ntr, [&](int nt, double &x, double &, double &) { x = TR(nt, 2); }, [&](int nt, double x, double, double) { trdps[nt] = x * dp2; });
+        trd_init(dp2);
       }
-      for (;;) {
-        if (k > kk) break;
-        else if (DP(k) < EPSILP) k = k + 1;
-        else {
-          const double presk = PR(k), presk1 = PR(k + 1), tk = TT(k), sk = SS(k), delpk = DP(k);
-          pmxl = presk1;
-          uk = (UU(k, 0) * DPU(k, 0) + UU(k, 1) * DPU(k, 1)) / fmax2(ONECM, DPU(k, 0) + DPU(k, 1));
-          vk = (VV(k, 0) * DPV(k, 0) + VV(k, ni) * DPV(k, ni)) / fmax2(ONECM, DPV(k, 0) + DPV(k, ni));
-          nitr = 0;
-          for (;;) {
+      // One loop, not two nested ones: a wavefront walks a loop nest in step -- while one lane iterates on its partly entrained layer (up to
+      // maxitr trips of ~2 000 instructions, three exp() and four evaluations of the equation of state) the 63 others, done with theirs after
+      // one trip, wait, and at the next layer another lane makes them wait again: the wave's trips were the SUM over the layers of the slowest
+      // lane's iterations (71 trips of 3.8 us in the slowest waves after 1 000 steps, measured per wave: make kprof).  Here a lane carries its
+      // own position -- st 0: at layer k, not entered; 1: iterating on layer k; 2: done -- and a trip does, for every lane, whatever that lane
+      // does next: the wave's trips are the LONGEST lane's own sequence.  A lane's arithmetic and its order are unchanged.
+      // A trip: (1) the loads of the layer the lane may enter next are requested -- k + 1 while it iterates on k, k itself before it has
+      // entered one; (2) one iteration of the lanes that are inside a layer, and when it was the last what follows it; (3) the lanes in front
+      // of a layer enter it, or step over it when it has no mass, with the values requested in (1): their latency lies under (2).
+      {
+        int st = 0;
+        double presk = 0., presk1 = 0., tk = 0., sk = 0., delpk = 0.;
+        while (st != 2) {
+          const int kq = (st == 1 ? k + 1 : k) <= kk ? (st == 1 ? k + 1 : k) : kk;
+          const double l_dp = DP(kq), l_p0 = PR(kq), l_p1 = PR(kq + 1), l_t = TT(kq), l_s = SS(kq);
+          const double l_u0 = UU(kq, 0), l_u1 = UU(kq, 1), l_du0 = DPU(kq, 0), l_du1 = DPU(kq, 1);
+          const double l_v0 = VV(kq, 0), l_v1 = VV(kq, ni), l_dv0 = DPV(kq, 0), l_dv1 = DPV(kq, ni);
+          if (st == 1) {
+            bool fin = false;
             nitr = nitr + 1;
+            KPROF_TRIP(wid, 7);
             tmxl = (tmxl0 * (presk - pres1) + tk * (pmxl - presk)) / (pmxl - pres1);
             smxl = (smxl0 * (presk - pres1) + sk * (pmxl - presk)) / (pmxl - pres1);
             dpe = dpe0 + fmax2(.5 * ALPHA0 * ALPHA0 * mldjmp * (presk - pres1) * (pmxl - presk),
@@ -648,77 +688,96 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
             mtkepe = -dpe;
             mtkeke = dke;
             tkew = mtkeus + mtkeni + mtkebf + mtkers + mtkepe + mtkeke;
-            if (nitr == 1) {
-              if (tkew > 0.) break;
-              else {
+            if (nitr == 1 && tkew > 0.) fin = true;
+            else {
+              if (nitr == 1) {
                 pmxl = presk;
                 dpmxl = fmin2(TENCM, .5 * delpk);
                 tkel = tkew;
                 tkew = tkeu;
-              }
-            } else {
-              dtke = (tkew - tkeo) / dpmxl;
-              bool chngd = false;
-              if (nitr == 2) {
-                if (dtke > -tkew / (presk1 - pmxl)) {
-                  pmxl = presk1;
-                  dpmxl = -fmin2(TENCM, .5 * delpk);
-                  tkew = tkel;
-                  chngd = true;
+              } else {
+                dtke = (tkew - tkeo) / dpmxl;
+                bool chngd = false;
+                if (nitr == 2) {
+                  if (dtke > -tkew / (presk1 - pmxl)) {
+                    pmxl = presk1;
+                    dpmxl = -fmin2(TENCM, .5 * delpk);
+                    tkew = tkel;
+                    chngd = true;
+                  }
+                }
+                if (!chngd) {
+                  if (fabs(dtke) < (fabs(tkew) + 1.e-22) / delpk) {
+                    if (tkew < 0.) dpmxl = .5 * (presk - pmxl);
+                    else dpmxl = presk1 - pmxl;
+                  } else
+                    dpmxl = fmax2(presk - pmxl, fmin2(presk1 - pmxl, -tkew / dtke));
+                  dpmxl = fmax2(fmax2(mltmin * ONEM, presk) - pmxl, dpmxl);
                 }
               }
-              if (!chngd) {
-                if (fabs(dtke) < (fabs(tkew) + 1.e-22) / delpk) {
-                  if (tkew < 0.) dpmxl = .5 * (presk - pmxl);
-                  else dpmxl = presk1 - pmxl;
-                } else
-                  dpmxl = fmax2(presk - pmxl, fmin2(presk1 - pmxl, -tkew / dtke));
-                dpmxl = fmax2(fmax2(mltmin * ONEM, presk) - pmxl, dpmxl);
+              pmxl = pmxl + dpmxl;
+              tkeo = tkew;
+              if (fabs(dpmxl) < ONEMM || nitr == MAXITR) fin = true;
+            }
+            if (fin) {
+              // (nitr == maxitr: the reference prints the column -- 'reached maxitr when entraining', :949-950 -- and goes on; counted as it prints)
+              if (nitr == MAXITR) atomicAdd(M.maxitr_count + 1, 1);
+              if (pmxl < presk1 - EPSILP && nitr < MAXITR) {
+                tdps = tdps + tk * (pmxl - presk);
+                sdps = sdps + sk * (pmxl - presk);
+                {
+                  const double w_ = pmxl - presk;
+                  trd_add(k, w_);
+                }
+                DP(k) = presk1 - pmxl;
+                st = 2;
+              } else {
+                tdps = tdps + tk * delpk;
+                sdps = sdps + sk * delpk;
+                trd_add(k, delpk);
+                // :996-1009: the mixed layer's properties, potential and kinetic energy change with the whole layer entrained.  When the
+                // iteration ended with its first evaluation (the common case: TKE left after the whole layer) that evaluation WAS at
+                // pmxl = pres(k+1), with these very expressions on these very operands: tmxl, smxl, dpe, dke hold the values already
+                if (nitr != 1) {
+                  pmxl = presk1;
+                  tmxl = (tmxl0 * (presk - pres1) + tk * (pmxl - presk)) / (pmxl - pres1);
+                  smxl = (smxl0 * (presk - pres1) + sk * (pmxl - presk)) / (pmxl - pres1);
+                  dpe = dpe0 + fmax2(.5 * ALPHA0 * ALPHA0 * mldjmp * (presk - pres1) * (pmxl - presk),
+                                     eos0::p_p_alpha(pmxl, pres1, tmxl, smxl) - eos0::p_p_alpha(pmxl, presk, tk, sk) -
+                                         eos0::p_p_alpha(presk, pres1, tmxl0, smxl0) - (pres1 - presk) * eos::p_alpha(pmxl, presk, tk, sk)) *
+                                   ALPHA0 / (delt1 * GRAV);
+                  dke = dke0 + .5 * rm5 * (presk - pres1) * (pmxl - presk) * ((uk - um) * (uk - um) + (vk - vm) * (vk - vm)) * ALPHA0 /
+                                   ((pmxl - pres1) * delt1 * GRAV);
+                }
+                dpe0 = dpe;
+                dke0 = dke;
+                tmxl0 = tmxl;
+                smxl0 = smxl;
+                um = (um * (presk - pres1) + uk * (pmxl - presk)) / (pmxl - pres1);
+                vm = (vm * (presk - pres1) + vk * (pmxl - presk)) / (pmxl - pres1);
+                DP(k) = 0.;
+                k = k + 1;
+                st = 0;
               }
             }
-            pmxl = pmxl + dpmxl;
-            tkeo = tkew;
-            if (fabs(dpmxl) < ONEMM || nitr == MAXITR) break;
           }
-          // (nitr == maxitr: the reference prints the column -- 'reached maxitr when entraining', :949-950 -- and goes on; counted as it prints)
-          if (nitr == MAXITR) atomicAdd(M.maxitr_count + 1, 1);
-          if (pmxl < presk1 - EPSILP && nitr < MAXITR) {
-            tdps = tdps + tk * (pmxl - presk);
-            sdps = sdps + sk * (pmxl - presk);
-            {
-              const double w_ = pmxl - presk;
-              tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, k); },
-                       [&](int nt, double x, double y, double) { trdps[nt] = x + y * w_; });
+          if (st == 0) {                 // (the values requested at the top of the trip are layer k's: k + 1 of the layer just left, or k itself)
+            if (k > kk) st = 2;
+            else if (l_dp < EPSILP) k = k + 1;
+            else {
+              presk = l_p0; presk1 = l_p1; tk = l_t; sk = l_s; delpk = l_dp;
+              pmxl = presk1;
+              uk = (l_u0 * l_du0 + l_u1 * l_du1) / fmax2(ONECM, l_du0 + l_du1);
+              vk = (l_v0 * l_dv0 + l_v1 * l_dv1) / fmax2(ONECM, l_dv0 + l_dv1);
+              nitr = 0;
+              st = 1;
             }
-            DP(k) = presk1 - pmxl;
-            break;
-          } else {
-            tdps = tdps + tk * delpk;
-            sdps = sdps + sk * delpk;
-            tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, k); },
-                     [&](int nt, double x, double y, double) { trdps[nt] = x + y * delpk; });
-            pmxl = presk1;
-            tmxl = (tmxl0 * (presk - pres1) + tk * (pmxl - presk)) / (pmxl - pres1);
-            smxl = (smxl0 * (presk - pres1) + sk * (pmxl - presk)) / (pmxl - pres1);
-            dpe = dpe0 + fmax2(.5 * ALPHA0 * ALPHA0 * mldjmp * (presk - pres1) * (pmxl - presk),
-                               eos0::p_p_alpha(pmxl, pres1, tmxl, smxl) - eos0::p_p_alpha(pmxl, presk, tk, sk) -
-                                   eos0::p_p_alpha(presk, pres1, tmxl0, smxl0) - (pres1 - presk) * eos::p_alpha(pmxl, presk, tk, sk)) *
-                             ALPHA0 / (delt1 * GRAV);
-            dpe0 = dpe;
-            dke = dke0 + .5 * rm5 * (presk - pres1) * (pmxl - presk) * ((uk - um) * (uk - um) + (vk - vm) * (vk - vm)) * ALPHA0 /
-                             ((pmxl - pres1) * delt1 * GRAV);
-            dke0 = dke;
-            tmxl0 = tmxl;
-            smxl0 = smxl;
-            um = (um * (presk - pres1) + uk * (pmxl - presk)) / (pmxl - pres1);
-            vm = (vm * (presk - pres1) + vk * (pmxl - presk)) / (pmxl - pres1);
-            DP(k) = 0.;
-            k = k + 1;
           }
         }
       }
     }
 
+    KPROF_MARK(wid, 4);
     {                                                                                 // :1020-1034
       const double p3 = fmin2(PR(kk + 1), pmxl);
       PR(3) = p3;
@@ -726,7 +785,10 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
       q = 1. / DP(2);
       TT(2) = tdps * q;
       SS(2) = sdps * q;
-      tracers4(ntr, [&](int nt, double &x, double &, double &) { x = trdps[nt]; }, [&](int nt, double x, double, double) { TR(nt, 2) = x * q; });
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (b < ntr) TR(b, 2) = trd4[b] * q;
+      tracers4(ntr, [&](int nt, double &x, double &, double &) { x = trdps[nt]; }, [&](int nt, double x, double, double) { TR(nt, 2) = x * q; }, 4);
       kfpl = k;
       for (k = 4; k <= kfpl; k++) PR(k) = p3;
     }
@@ -868,6 +930,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     DN(1) = SIG(TT(1), SS(1));                                                        // :1192-1196
     DN(2) = SIG(TT(2), SS(2));
     for (k = kfpl; k <= kfmax; k++) DN(k) = SIG(TT(k), SS(k));
+    KPROF_MARK(wid, 5);
   }
 
   V.f[F_mtkeus][c] = mtkeus;
@@ -902,6 +965,7 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
   if (k > kk) DP(2) = DP(2) + dps;
   else DP(k) = DP(k) + dps;
   V.m[I_kfpla][c + (size_t)(n - 1) * np] = k;
+  KPROF_MARK(wid, 6);
 }
 
 // ---- the copy-back rules, :1216-1241: negative salinities and tracers are set to zero and what that adds is booked in salt_corr,
@@ -975,7 +1039,7 @@ int st_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc = st_xctilr(c, h.f[F_u] + (size_t)(k1n - 1) * h.nplane, 1, h.kk, 1, 1, 13)) return rc;
     if (int rc = st_xctilr(c, h.f[F_v] + (size_t)(k1n - 1) * h.nplane, 1, h.kk, 1, 1, 14)) return rc;
   }
-  hipLaunchKernelGGL(k_mxl_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, M, n, nn);
+  hipLaunchKernelGGL(k_mxl_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, M, n, nn KPROF_PASS(3));
   hipLaunchKernelGGL(k_mxl_clamp, plane_grid(h, h.ntr + 1, 64), dim3(64), 0, c->stream, c->d, nn);
   HIPCHK(c, hipGetLastError());
   // 'old' interface pressures at the velocity points (:1243-1262), the dp halo, p and the new dpu, dpv (:1264-1310), the
