@@ -274,6 +274,14 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
     tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, kq_); },
              [&](int nt, double x, double y, double) { trdps[nt] = x + y * w_; }, 4);
   };
+  // the same with the first four tracers' values of the layer already in registers
+  auto trd_add_pre = [&](int kq_, double w_, const double *y_) {
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (b < ntr) trd4[b] = trd4[b] + y_[b] * w_;
+    tracers4(ntr, [&](int nt, double &x, double &y, double &) { x = trdps[nt]; y = TR(nt, kq_); },
+             [&](int nt, double x, double y, double) { trdps[nt] = x + y * w_; }, 4);
+  };
   // sums = tracers of layer 2 times its thickness
   auto trd_init = [&](double dp2_) {
     double x_[4];
@@ -657,6 +665,12 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
           const double l_dp = DP(kq), l_p0 = PR(kq), l_p1 = PR(kq + 1), l_t = TT(kq), l_s = SS(kq);
           const double l_u0 = UU(kq, 0), l_u1 = UU(kq, 1), l_du0 = DPU(kq, 0), l_du1 = DPU(kq, 1);
           const double l_v0 = VV(kq, 0), l_v1 = VV(kq, ni), l_dv0 = DPV(kq, 0), l_dv1 = DPV(kq, ni);
+          double l_tr[4];                // the tracers of the layer being iterated on (read when the iteration ends in this trip)
+          {
+            const int kt = k <= kk ? k : kk;
+#pragma unroll
+            for (int b = 0; b < 4; b++) l_tr[b] = TR(b < ntr ? b : ntr - 1, kt);
+          }
           if (st == 1) {
             bool fin = false;
             nitr = nitr + 1;
@@ -727,14 +741,14 @@ __global__ __launch_bounds__(64) void k_mxl_column(const DevView *__restrict__ V
                 sdps = sdps + sk * (pmxl - presk);
                 {
                   const double w_ = pmxl - presk;
-                  trd_add(k, w_);
+                  trd_add_pre(k, w_, l_tr);
                 }
                 DP(k) = presk1 - pmxl;
                 st = 2;
               } else {
                 tdps = tdps + tk * delpk;
                 sdps = sdps + sk * delpk;
-                trd_add(k, delpk);
+                trd_add_pre(k, delpk, l_tr);
                 // :996-1009: the mixed layer's properties, potential and kinetic energy change with the whole layer entrained.  When the
                 // iteration ended with its first evaluation (the common case: TKE left after the whole layer) that evaluation WAS at
                 // pmxl = pres(k+1), with these very expressions on these very operands: tmxl, smxl, dpe, dke hold the values already
