@@ -325,6 +325,98 @@ __global__ __launch_bounds__(64) void k_convec_velocity(const DevView *__restric
   }
 }
 
+// The same remap as ONE loop (round 6; DESIGN.md 3.4 rule 7).  k_convec_velocity is a merge of two sorted interface lists written as a
+// loop nest -- for every new layer, while the old layer ends above the new interface: move on -- and a wavefront pays, for every new
+// layer, its slowest lane's moves, each with a memory round trip in its path.  Here a trip does for every lane what that lane does next,
+// one move or one finished layer (<= 2 kk trips, none of them waiting for memory): a lane's next CVF_W new interfaces and next CVF_W old
+// layers (velocity, lower interface) lie in LDS rings, [slot][lane], which the wave tops up together -- every lane requests what its rings
+// have room for, up to 3 CVF_W loads in flight per lane -- whenever one of its lanes is about to run dry.  The sums' terms and order are
+// the nested form's.  LDS 9 KB per wavefront: all 3 510 waves stay resident.
+#define CVF_W 6
+__global__ __launch_bounds__(64) void k_convec_velocity_flat(const DevView *__restrict__ Vp, int nn) {
+  const DevView &V = *Vp;
+  PLANE_IJ(V);
+  __shared__ double s_pn[CVF_W][64], s_vel[CVF_W][64], s_po[CVF_W][64];
+  if (j < 1 || j > V.jj || i < 1 || i > V.ii) return;
+  const bool isv = by_ == 1;
+  if (!V.m[isv ? I_iv : I_iu][c]) return;
+  const int kk = V.kk, ln = threadIdx.x;
+  const size_t np = V.nplane, cm = isv ? c - V.ni : c - 1;
+  gd_t vel = V.f[isv ? F_v : F_u] + c + (size_t)nn * np - np; // 1-based level
+  gcd_t po = V.f[isv ? F_pv : F_pu] + c - np; // po(k), k = 2..kk+1; po(1) = 0
+  gcd_t p = V.f[F_p] - np;
+  gd_t un = WK(V, CV_UN + (isv ? 1 : 0)) + c - np;
+  const double pbot = po[(size_t)(kk + 1) * np];
+  // old side: layer ko with its velocity and interfaces in registers; ring entries m = ko+1 .. of-1 hold V(m) = u(min(m, kk)) and
+  // Q(m) = po(m+1) (1e300 beyond the bottom: never reached, pn <= po(kk+1)); (v_nx, q_nx) is the entry of m = ko+1 when hv_o
+  int ko = 1, of = 2, so_r = 2 % CVF_W, so_w = 2 % CVF_W;       // slots of the entries ko+1 (read) and of (write)
+  double po_lo = 0., po_hi = po[(size_t)2 * np], v_cur = vel[(size_t)1 * np], v_nx = 0., q_nx = 0.;
+  bool hv_o = false;
+  // new side: ring entries k = kn .. nf-1 hold pn(k+1); pn_hi is the entry of kn when hv_n
+  int kn = 1, nf = 1, sn_r = 1 % CVF_W, sn_w = 1 % CVF_W;
+  double pn_lo = 0., pn_hi = 0., udpn = 0.;
+  bool hv_n = false;
+  while (kn <= kk) {
+    if (__any(!hv_n || !hv_o)) {
+      double a0[CVF_W], a1[CVF_W], w[CVF_W], q[CVF_W];
+#pragma unroll
+      for (int b = 0; b < CVF_W; b++) {
+        const int lv = nf + b <= kk ? nf + b : kk, m = of + b <= kk ? of + b : kk;
+        a0[b] = p[c + (size_t)(lv + 1) * np]; a1[b] = p[cm + (size_t)(lv + 1) * np];
+        w[b] = vel[(size_t)m * np]; q[b] = po[(size_t)(m + 1) * np];
+      }
+#pragma unroll
+      for (int b = 0; b < CVF_W; b++) {
+        if (nf <= kk && nf < kn + CVF_W) {                         // room in the ring and a level left
+          s_pn[sn_w][ln] = .5 * (fmin2(pbot, a0[b]) + fmin2(pbot, a1[b]));
+          nf++; sn_w = sn_w + 1 == CVF_W ? 0 : sn_w + 1;
+        }
+        if (of <= kk + 1 && of <= ko + CVF_W) {
+          s_vel[so_w][ln] = w[b]; s_po[so_w][ln] = of <= kk ? q[b] : 1.e300;
+          of++; so_w = so_w + 1 == CVF_W ? 0 : so_w + 1;
+        }
+      }
+    }
+    if (!hv_n) { pn_hi = s_pn[sn_r][ln]; hv_n = true; }           // (kn <= kk here, and the top-up has put level kn there)
+    if (!hv_o) {
+      if (ko + 1 <= kk + 1) { v_nx = s_vel[so_r][ln]; q_nx = s_po[so_r][ln]; }
+      else { v_nx = 0.; q_nx = 1.e300; }
+      hv_o = true;
+    }
+    const bool massless = pn_hi - pn_lo == 0.;
+    if (!massless && pn_hi > po_hi) {                              // the old layer ends above the new interface: move on
+      udpn = udpn + v_cur * (po_hi - fmax2(po_lo, pn_lo));
+      ko = ko + 1;
+      po_lo = po_hi;
+      po_hi = q_nx;
+      v_cur = v_nx;
+      so_r = so_r + 1 == CVF_W ? 0 : so_r + 1;
+      if (ko + 1 > kk + 1) { v_nx = 0.; q_nx = 1.e300; }           // below the bottom: po_hi is 1e300 by now, no further move
+      else if (ko + 1 < of) { v_nx = s_vel[so_r][ln]; q_nx = s_po[so_r][ln]; }
+      else hv_o = false;
+    } else {                                                       // the new layer is complete
+      const double r = massless ? 0. : (udpn + v_cur * (pn_hi - fmax2(po_lo, pn_lo))) / (pn_hi - pn_lo);
+      un[(size_t)kn * np] = r;
+      pn_lo = pn_hi;
+      udpn = 0.;
+      kn = kn + 1;
+      sn_r = sn_r + 1 == CVF_W ? 0 : sn_r + 1;
+      if (kn <= kk) {
+        if (kn < nf) pn_hi = s_pn[sn_r][ln];
+        else hv_n = false;
+      }
+    }
+  }
+  for (int k0 = 1; k0 <= kk; k0 += CV_U) {
+    double a0[CV_U];
+#pragma unroll
+    for (int u = 0; u < CV_U; u++) a0[u] = un[(size_t)(k0 + u <= kk ? k0 + u : kk) * np];
+#pragma unroll
+    for (int u = 0; u < CV_U; u++)
+      if (k0 + u <= kk) vel[(size_t)(k0 + u) * np] = a0[u];
+  }
+}
+
 // :393-414
 __global__ void k_convec_dpudpv(const DevView *__restrict__ Vp, int nn) {
   const DevView &V = *Vp;
@@ -355,6 +447,7 @@ __global__ void k_convec_dpudpv(const DevView *__restrict__ Vp, int nn) {
 // the velocity remap on its own: mxlayr ends with the same one (phy/mod_mxlayr.F90:1312-1374)
 int st_convec_velocity(blomgpu_ctx *c, int nn) {
   switch (c->convec_nsingle) {
+    case -1: hipLaunchKernelGGL(k_convec_velocity_flat, plane_grid(c->h, 2, 64), dim3(64), 0, c->stream, c->d, nn); break;
     case 0: hipLaunchKernelGGL(k_convec_velocity<0>, plane_grid(c->h, 2, 64), dim3(64), 0, c->stream, c->d, nn); break;
     case 1: hipLaunchKernelGGL(k_convec_velocity<1>, plane_grid(c->h, 2, 64), dim3(64), 0, c->stream, c->d, nn); break;
     case 2: hipLaunchKernelGGL(k_convec_velocity<2>, plane_grid(c->h, 2, 64), dim3(64), 0, c->stream, c->d, nn); break;

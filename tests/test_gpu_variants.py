@@ -70,7 +70,7 @@ def test_round6_kernel_variants_bit_identical_down_to_the_sign_of_zero(cfg, nste
     base = _run(cfg, nsteps)
     skip = {"util1", "util2", "util3", "util4"}
     for opts in (dict(pgf_uv_ring=0), dict(pgf_uv_ring=3), dict(pgf_uv_ring=5), dict(pgf_uv_ring=8), dict(pgf_uv_ring=0, pgf_reuse=1),
-                 dict(lean_fluxes=0, overlap=0), dict(cmn_nslope_nb=2), dict(mom_aw_split=1), dict(mom_aw_split=2), dict(convec_nsingle=1000)):
+                 dict(lean_fluxes=0, overlap=0), dict(cmn_nslope_nb=2), dict(mom_aw_split=1), dict(mom_aw_split=2), dict(convec_nsingle=1000), dict(convec_nsingle=-1)):
         b = _run(cfg, nsteps, **opts)
         bad = [nm for nm in base if nm not in skip and base[nm].tobytes() != b[nm].tobytes()]
         assert not bad, (opts, bad)
