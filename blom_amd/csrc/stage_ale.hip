@@ -449,13 +449,12 @@ __global__ __launch_bounds__(256) void k_ale_nudge(const DevView *__restrict__ V
     return;
   }
   auto pc_at = [&](const double *pc, int k, int q) { return q < npc ? pc[c + (size_t)(npc * (k - 1) + q) * np] : 0.; };
-  auto top = [&](const double *pc, int k) { return pc_at(pc, k, 0); };                               // peval0
+  // (peval0 / dpeval0 -- the polynomial and its derivative at a layer's top, coefficients 0 and 1 -- are not needed by this routine)
   auto bot = [&](const double *pc, int k) {                                                           // peval1
     double f = pc_at(pc, k, 0);
     for (int q = 1; q < 5; q++) f = f + pc_at(pc, k, q);
     return f;
   };
-  auto dtop = [&](const double *pc, int k) { return pc_at(pc, k, 1); };                              // dpeval0
   auto dbot = [&](const double *pc, int k) {                                                          // dpeval1
     return pc_at(pc, k, 1) + 2. * pc_at(pc, k, 2) + 3. * pc_at(pc, k, 3) + 4. * pc_at(pc, k, 4);
   };
