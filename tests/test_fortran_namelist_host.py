@@ -121,11 +121,10 @@ def test_run_length_and_error_behaviour_follow_the_reference(tmp_path, what):
 
 
 def limits_for_hybrid(dst, neutral=False):
-    """the reference's fuk95 limits file as it is -- cntiso_hybrid, cppm, &ALE_REGRID_REMAP with regrid_method = 'nudge' -- but
-    for the pressure gradient method (dynamic enthalpy is not built)"""
+    """the reference's fuk95 limits file as it is -- cntiso_hybrid, cppm, dynamic enthalpy, &ALE_REGRID_REMAP with regrid_method = 'nudge'
+    (until round 6 the test swapped the pressure gradient method for 'geopotential'; nothing required that)"""
     txt = open(os.path.join(HERE, "golden", "fuk95_limits")).read()
-    txt = txt.replace("PGFMTH   = 'dynamic enthalpy'", "PGFMTH   = 'geopotential'")
-    assert "VCOORD_TYPE            = 'cntiso_hybrid'" in txt and "ADVMTH   = 'cppm'" in txt and "'geopotential'" in txt
+    assert "VCOORD_TYPE            = 'cntiso_hybrid'" in txt and "ADVMTH   = 'cppm'" in txt and "PGFMTH   = 'dynamic enthalpy'" in txt
     if neutral:                                           # the reference's default for this coordinate (cime_config), not this file's
         assert "LTEDTP   = 'layer'" in txt and "NDIFF_SURFACE_ALIGN = .false." in txt
         txt = txt.replace("LTEDTP   = 'layer'", "LTEDTP   = 'neutral'").replace("NDIFF_SURFACE_ALIGN = .false.", "NDIFF_SURFACE_ALIGN = .true.")
@@ -170,7 +169,7 @@ def run_case_hybrid(tmp_path, exe, backend_cls, nsteps, neutral=False):
     # the same options by hand, as the namelist file gives them
     gpu.set("delt1", case.params["baclin"])
     gpu.set("pref", 0.0)
-    gpu.set("pgfmth", "geopotential")
+    gpu.set("pgfmth", "dynamic enthalpy")
     gpu.set("vcoord_type", "cntiso_hybrid")
     gpu.set("ale_regrid_method", "nudge")
     gpu.set("ale_k_range_plevel", 4)
