@@ -312,8 +312,8 @@ int bt_phase_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, double woa, do
 int bt_phase_check(blomgpu_ctx *c);
 int bt_overlap_usable(blomgpu_ctx *c);
 int bt_block_mode(blomgpu_ctx *c);
-int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
-                    int last, int src, int *src_out, int *ml_out, int *nl_out, int nb);
+int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, const int *ph_last, const double (*ph_w)[4], int src,
+                    int *src_out, int *ml_out, int *nl_out);
 int bt_pair_launch(blomgpu_ctx *c, int m, int n, int ml, int nl, const double *wo, const double *wm, const double *wn,
                    int do_odd, int do_even, int src, int tsel, RcclLanded *rim);
 int bt_pair_halo_landed(blomgpu_ctx *c, int set, RcclLanded *landed);
@@ -360,6 +360,26 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
   c->bt_restart = true;
   int lll0 = 1, ml = 1, nl = 2, set = 0;     // set: which buffer set (*_t / *_t2) holds the current state
   double woa = 0., wob = 0., wna = 0., wnb = 0.;
+  if (c->barotp_fused && h.nreg != 2 && bt_block_mode(c)) {
+    // k_bt_steps4: ONE launch walks the substeps of all five phases, four per hand-off, zeroing each phase's flux sums and doing its
+    // epilogue itself (the time weights of the phases, :352-360 and below, as a table)
+    int ph_last[5];
+    double ph_w[5][4];
+    for (int nb = 1; nb <= 5; nb++) {
+      if (nb == 1) { lll0 = 1; woa = -1. / lstep; wob = .5 + (lll0 - .5) / lstep; wna = 0.; wnb = 0.; }
+      else if (nb == 2) { woa = 0.; wob = 0.; wna = 1. / lstep; wnb = -(lll0 - .5) / lstep; }
+      else if (nb == 4) { wna = 0.; wnb = 1.; }
+      ph_w[nb - 1][0] = woa; ph_w[nb - 1][1] = wob; ph_w[nb - 1][2] = wna; ph_w[nb - 1][3] = wnb;
+      ph_last[nb - 1] = lll0 + lstep / 2 - 1;
+      lll0 = lll0 + lstep / 2;
+    }
+    hipLaunchKernelGGL(k_bt_load, g, b, 0, c->stream, c->d);
+    int so, mo, no;
+    if (int rc = bt_block_launch(c, bt_block_mode(c), m, n, 1, 2, ph_last, ph_w, 0, &so, &mo, &no)) return rc;
+    HIPCHK(c, hipGetLastError());
+    if (c->barotp_persist && bt_phase_usable(c)) return bt_phase_check(c);
+    return 0;
+  }
   for (int nb = 1; nb <= 5; nb++) {
     if (nb == 1) {
       lll0 = 1; ml = 1; nl = 2;
@@ -382,9 +402,7 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     const bool arctic1 = h.nreg == 2 && (!c->tiling.multi() || c->barotp_arctic_fused);
     const bool fused = c->barotp_fused && (h.nreg != 2 || arctic1);
     bool halo_done = false;
-    // k_bt_steps4 starts the phase's flux sums at zero and ends with the phase's epilogue itself (three launches less per phase)
-    const bool blocked = fused && !arctic1 && bt_block_mode(c);
-    if (!blocked) hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
+    hipLaunchKernelGGL(k_bt_zero_sums, g, b, 0, c->stream, c->d);
     if (fused && arctic1 && !c->tiling.multi() && c->barotp_persist && bt_phase_usable(c)) {
       // arctic patch, single tile: the halo update -- which also rewrites the seam row -- belongs in front of odd substeps
       // only, so the persistent launch takes the whole odd+even pairs of the phase (its tiles re-read rim and seam at the
@@ -416,11 +434,6 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
         set ^= 1;
         { const int ll = ml; ml = nl; nl = ll; }
       }
-    } else if (fused && !arctic1 && bt_block_mode(c)) {
-      // four substeps per hand-off (k_bt_steps4)
-      int so, mo, no;
-      if (int rc = bt_block_launch(c, bt_block_mode(c), m, n, ml, nl, woa, wob, wna, wnb, lll0, last, set, &so, &mo, &no, nb)) return rc;
-      set = so; ml = mo; nl = no;
     } else if (fused && !arctic1 && c->barotp_persist && bt_phase_usable(c)) {
       // the whole phase in one launch (k_bt_steps<true>): coefficients stay on chip, tiles hand each other
       // their edge values through memory
@@ -505,7 +518,6 @@ int st_barotp_on(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n,
     }
     lll0 = lll0 + lstep / 2;
     // the epilogue reads pb_t(i-1,j), pb_t(i,j-1); the fused kernels write tile interiors only
-    if (blocked) continue;
     if (fused && !halo_done && !arctic1)
       if (int rc = bt_pair_halo(c, set)) return rc;
     halo_done = false;

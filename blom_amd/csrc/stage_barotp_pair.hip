@@ -53,9 +53,11 @@ struct PairArgs {
   // strips themselves (no pack launch); N/S rim cells of the columns 1..ii then follow the local rule at load
   double *pack_w, *pack_e;
   int pack_on;
-  // k_bt_steps4: the launch starts the phase's flux sums at zero (k_bt_zero_sums, :361-379) instead of loading them, and ends with the
-  // phase's epilogue (k_bt_epilogue, :847-977; 0: none) for its own points
-  int zero_sums = 0, epi_nb = 0;
+  // k_bt_steps4 walks the substeps of ALL five barotropic phases (:352-977): phase x ends with substep ph_last[x] and has the time weights
+  // wo = ph_w[x][0] l + ph_w[x][1], wn = ph_w[x][2] l + ph_w[x][3]; the kernel starts a phase's flux sums at zero (k_bt_zero_sums, :361-379)
+  // and ends it with its epilogue (k_bt_epilogue, :847-977) itself
+  int ph_last[5] = {0, 0, 0, 0, 0};
+  double ph_w[5][4] = {};
 };
 
 // PERSIST = false: one odd+even pair (or one half) per launch, neighbours synchronise at the kernel
@@ -518,6 +520,8 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
   const size_t om = (size_t)(a.m - 1) * np, on = (size_t)(a.n - 1) * np;
   const bool per_i = !(V.nreg == 0 || V.nreg == 4), per_j = V.nreg > 2;
   const double vland = V.P.vland;
+  // does the launch start with the first substep of a phase?  (then the phase's flux sums start at zero; else they continue from memory)
+  const bool fresh = a.lll0 == 1 || a.lll0 == a.ph_last[0] + 1 || a.lll0 == a.ph_last[1] + 1 || a.lll0 == a.ph_last[2] + 1 || a.lll0 == a.ph_last[3] + 1;
   Bt4Pt P[2];
 #pragma unroll
   for (int p = 0; p < 2; p++) {
@@ -561,7 +565,7 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
       q.v_scvyi = V.f[F_scvyi][c]; q.v_scvx = V.f[F_scvx][c]; q.v_tot = V.f[F_vtotn][c]; q.v_glue = V.f[F_vglue][c];
       q.v_max = V.f[F_vmaxb][c]; q.v_min = V.f[F_vminb][c];
     }
-    if (q.mine && !a.zero_sums) {
+    if (q.mine && !fresh) {
       if (q.wu) { q.us_acc = V.f[F_ubflxs_t][c]; q.uc_acc = V.f[F_ubcors_t][c]; }
       if (q.wv) { q.vs_acc = V.f[F_vbflxs_t][c]; q.vc_acc = V.f[F_vbcors_t][c]; }
     }
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
   }
   unsigned done_iters = 0;
   int lll = a.lll0;
-  bool aborted = false;
+  bool aborted = false, ended_phase = false;
 
   do {
     const int nsub = a.last - lll + 1 < 4 ? a.last - lll + 1 : 4;
@@ -627,7 +631,13 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
     for (int s = 0; s < nsub; s++) {
       const int l = lll + s;
       const bool odd = l % 2 == 1;
-      const double wo = a.woa * l + a.wob, wn = a.wna * l + a.wnb, wm = 1. - wo - wn;        // :352-360
+      int ip = 0;                                                                                // the phase of substep l
+      while (ip < 4 && l > a.ph_last[ip]) ip++;
+      if (l == (ip ? a.ph_last[ip - 1] + 1 : 1)) {                                               // :361-379
+#pragma unroll
+        for (int p = 0; p < 2; p++) P[p].us_acc = P[p].uc_acc = P[p].vs_acc = P[p].vc_acc = 0.;
+      }
+      const double wo = a.ph_w[ip][0] * l + a.ph_w[ip][1], wn = a.ph_w[ip][2] * l + a.ph_w[ip][3], wm = 1. - wo - wn;        // :352-360
       // ---- continuity (:400-418 / :625-643): reads ub(i+1), vb(j+1) at level ml
 #pragma unroll
       for (int p = 0; p < 2; p++) {
@@ -714,6 +724,89 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
         vlo_i = u_lo_i; vhi_i = u_hi_i; vlo_j = u_lo_j; vhi_j = u_hi_j;
       }
       const int t = ml; ml = nl; nl = t;       // :614-616 / :837-839
+      ended_phase = l == a.ph_last[ip];
+      if (ended_phase) {                       // the phase's last substep: its flux sums and its epilogue, for the tile's own points
+      #pragma unroll
+        for (int p = 0; p < 2; p++) {
+          const Bt4Pt &q = P[p];
+          if (!q.mine) continue;
+          const size_t c = q.c;
+          if (q.wu) { V.f[F_ubflxs_t][c] = q.us_acc; V.f[F_ubcors_t][c] = q.uc_acc; }
+          if (q.wv) { V.f[F_vbflxs_t][c] = q.vs_acc; V.f[F_vbcors_t][c] = q.vc_acc; }
+          // the phase's epilogue (k_bt_epilogue of stage_barotp.hip, phy/mod_barotp.F90:847-977) for this point, from the block in LDS: pb at
+          // i-1 and j-1 lies in the rim (valid one cell further down than the fluxes after any substep) and is what a halo update would bring
+          const int nb = ip + 1, li = q.li, lj = q.lj;
+          const size_t oml = (size_t)ml * np, onl = (size_t)nl * np, o3 = 2 * np;
+          const double us = q.us_acc, vs = q.vs_acc;
+          const double pbc = s_pb[ml][lj][li];
+          if (nb == 1 || nb == 3) {
+            const size_t ol = nb == 1 ? om : on;
+            if (q.wp) V.f[F_pb][c + ol] = pbc;
+            if (q.wu) {
+              const double pbu = fmin2(pbc, s_pb[ml][lj][li - 1]);
+              V.f[F_pbu][c + ol] = pbu;
+              const double f = s_ub[ml][lj][li];
+              V.f[F_ubflx][c + ol] = f;
+              V.f[F_ub][c + ol] = f / (pbu * q.u_scuy);
+              if (nb == 1) {
+                V.f[F_ubflxs][c + on] = V.f[F_ubflxs][c + on] + us;
+                V.f[F_ubflxs][c + om] = V.f[F_ubflxs][c + o3] + us;
+              } else {
+                V.f[F_ubflxs_p][c + om] = V.f[F_ubflxs][c + om] + us;
+                V.f[F_ubflxs_p][c + on] = V.f[F_ubflxs_p][c + on] + us;
+                V.f[F_ubcors_p][c] = V.f[F_ubcors_p][c] + q.uc_acc;
+              }
+            }
+            if (q.wv) {
+              const double pbv = fmin2(pbc, s_pb[ml][lj - 1][li]);
+              V.f[F_pbv][c + ol] = pbv;
+              const double f = s_vb[ml][lj][li];
+              V.f[F_vbflx][c + ol] = f;
+              V.f[F_vb][c + ol] = f / (pbv * q.v_scvx);
+              if (nb == 1) {
+                V.f[F_vbflxs][c + on] = V.f[F_vbflxs][c + on] + vs;
+                V.f[F_vbflxs][c + om] = V.f[F_vbflxs][c + o3] + vs;
+              } else {
+                V.f[F_vbflxs_p][c + om] = V.f[F_vbflxs][c + om] + vs;
+                V.f[F_vbflxs_p][c + on] = V.f[F_vbflxs_p][c + on] + vs;
+                V.f[F_vbcors_p][c] = V.f[F_vbcors_p][c] + q.vc_acc;
+              }
+            }
+          } else if (nb == 2) {
+            if (q.wp) { V.f[F_pb_mn][c + oml] = pbc; V.f[F_pb_mn][c + onl] = s_pb[nl][lj][li]; }
+            if (q.wu) {
+              V.f[F_ubflx_mn][c + oml] = s_ub[ml][lj][li];
+              V.f[F_ubflx_mn][c + onl] = s_ub[nl][lj][li];
+              V.f[F_ubflxs][c + om] = V.f[F_ubflxs][c + om] + us;
+              V.f[F_ubflxs][c + o3] = us;
+              V.f[F_ubflxs_p][c + on] = us;
+              V.f[F_ubcors_p][c] = q.uc_acc;
+            }
+            if (q.wv) {
+              V.f[F_vbflx_mn][c + oml] = s_vb[ml][lj][li];
+              V.f[F_vbflx_mn][c + onl] = s_vb[nl][lj][li];
+              V.f[F_vbflxs][c + om] = V.f[F_vbflxs][c + om] + vs;
+              V.f[F_vbflxs][c + o3] = vs;
+              V.f[F_vbflxs_p][c + on] = vs;
+              V.f[F_vbcors_p][c] = q.vc_acc;
+            }
+          } else {
+            if (nb == 5) {
+              if (q.wp) V.f[F_pb_p][c] = pbc;
+              if (q.wu) V.f[F_pbu_p][c] = fmin2(pbc, s_pb[ml][lj][li - 1]);
+              if (q.wv) V.f[F_pbv_p][c] = fmin2(pbc, s_pb[ml][lj - 1][li]);
+            }
+            if (q.wu) {
+              V.f[F_ubflxs_p][c + on] = V.f[F_ubflxs_p][c + on] + us;
+              V.f[F_ubcors_p][c] = V.f[F_ubcors_p][c] + q.uc_acc;
+            }
+            if (q.wv) {
+              V.f[F_vbflxs_p][c + on] = V.f[F_vbflxs_p][c + on] + vs;
+              V.f[F_vbcors_p][c] = V.f[F_vbcors_p][c] + q.vc_acc;
+            }
+          }
+        }
+      }
     }
     lll += nsub;
     // publish the tile in the other buffer set (between iterations the neighbours read all but 14 x 4 of its points)
@@ -738,85 +831,13 @@ __global__ void __launch_bounds__(BT4_NT) k_bt_steps4(const DevView *__restrict_
     done_iters++;
     if (tid == 0) __hip_atomic_store(a.flags + (by * nbx + bx), a.epoch_base + done_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } while (true);
+  if (!ended_phase) {                  // (a launch that stops inside a phase -- barotp_block = 2 -- leaves the sums for the next one)
 #pragma unroll
-  for (int p = 0; p < 2; p++) {
-    const Bt4Pt &q = P[p];
-    if (!q.mine) continue;
-    const size_t c = q.c;
-    if (q.wu) { V.f[F_ubflxs_t][c] = q.us_acc; V.f[F_ubcors_t][c] = q.uc_acc; }
-    if (q.wv) { V.f[F_vbflxs_t][c] = q.vs_acc; V.f[F_vbcors_t][c] = q.vc_acc; }
-    if (!a.epi_nb) continue;
-    // the phase's epilogue (k_bt_epilogue of stage_barotp.hip, phy/mod_barotp.F90:847-977) for this point, from the block in LDS: pb at
-    // i-1 and j-1 lies in the rim (valid one cell further down than the fluxes after any substep) and is what a halo update would bring
-    const int nb = a.epi_nb, li = q.li, lj = q.lj;
-    const size_t oml = (size_t)ml * np, onl = (size_t)nl * np, o3 = 2 * np;
-    const double us = q.us_acc, vs = q.vs_acc;
-    const double pbc = s_pb[ml][lj][li];
-    if (nb == 1 || nb == 3) {
-      const size_t ol = nb == 1 ? om : on;
-      if (q.wp) V.f[F_pb][c + ol] = pbc;
-      if (q.wu) {
-        const double pbu = fmin2(pbc, s_pb[ml][lj][li - 1]);
-        V.f[F_pbu][c + ol] = pbu;
-        const double f = s_ub[ml][lj][li];
-        V.f[F_ubflx][c + ol] = f;
-        V.f[F_ub][c + ol] = f / (pbu * q.u_scuy);
-        if (nb == 1) {
-          V.f[F_ubflxs][c + on] = V.f[F_ubflxs][c + on] + us;
-          V.f[F_ubflxs][c + om] = V.f[F_ubflxs][c + o3] + us;
-        } else {
-          V.f[F_ubflxs_p][c + om] = V.f[F_ubflxs][c + om] + us;
-          V.f[F_ubflxs_p][c + on] = V.f[F_ubflxs_p][c + on] + us;
-          V.f[F_ubcors_p][c] = V.f[F_ubcors_p][c] + q.uc_acc;
-        }
-      }
-      if (q.wv) {
-        const double pbv = fmin2(pbc, s_pb[ml][lj - 1][li]);
-        V.f[F_pbv][c + ol] = pbv;
-        const double f = s_vb[ml][lj][li];
-        V.f[F_vbflx][c + ol] = f;
-        V.f[F_vb][c + ol] = f / (pbv * q.v_scvx);
-        if (nb == 1) {
-          V.f[F_vbflxs][c + on] = V.f[F_vbflxs][c + on] + vs;
-          V.f[F_vbflxs][c + om] = V.f[F_vbflxs][c + o3] + vs;
-        } else {
-          V.f[F_vbflxs_p][c + om] = V.f[F_vbflxs][c + om] + vs;
-          V.f[F_vbflxs_p][c + on] = V.f[F_vbflxs_p][c + on] + vs;
-          V.f[F_vbcors_p][c] = V.f[F_vbcors_p][c] + q.vc_acc;
-        }
-      }
-    } else if (nb == 2) {
-      if (q.wp) { V.f[F_pb_mn][c + oml] = pbc; V.f[F_pb_mn][c + onl] = s_pb[nl][lj][li]; }
-      if (q.wu) {
-        V.f[F_ubflx_mn][c + oml] = s_ub[ml][lj][li];
-        V.f[F_ubflx_mn][c + onl] = s_ub[nl][lj][li];
-        V.f[F_ubflxs][c + om] = V.f[F_ubflxs][c + om] + us;
-        V.f[F_ubflxs][c + o3] = us;
-        V.f[F_ubflxs_p][c + on] = us;
-        V.f[F_ubcors_p][c] = q.uc_acc;
-      }
-      if (q.wv) {
-        V.f[F_vbflx_mn][c + oml] = s_vb[ml][lj][li];
-        V.f[F_vbflx_mn][c + onl] = s_vb[nl][lj][li];
-        V.f[F_vbflxs][c + om] = V.f[F_vbflxs][c + om] + vs;
-        V.f[F_vbflxs][c + o3] = vs;
-        V.f[F_vbflxs_p][c + on] = vs;
-        V.f[F_vbcors_p][c] = q.vc_acc;
-      }
-    } else {
-      if (nb == 5) {
-        if (q.wp) V.f[F_pb_p][c] = pbc;
-        if (q.wu) V.f[F_pbu_p][c] = fmin2(pbc, s_pb[ml][lj][li - 1]);
-        if (q.wv) V.f[F_pbv_p][c] = fmin2(pbc, s_pb[ml][lj - 1][li]);
-      }
-      if (q.wu) {
-        V.f[F_ubflxs_p][c + on] = V.f[F_ubflxs_p][c + on] + us;
-        V.f[F_ubcors_p][c] = V.f[F_ubcors_p][c] + q.uc_acc;
-      }
-      if (q.wv) {
-        V.f[F_vbflxs_p][c + on] = V.f[F_vbflxs_p][c + on] + vs;
-        V.f[F_vbcors_p][c] = V.f[F_vbcors_p][c] + q.vc_acc;
-      }
+    for (int p = 0; p < 2; p++) {
+      const Bt4Pt &q = P[p];
+      if (!q.mine) continue;
+      if (q.wu) { V.f[F_ubflxs_t][q.c] = q.us_acc; V.f[F_ubcors_t][q.c] = q.uc_acc; }
+      if (q.wv) { V.f[F_vbflxs_t][q.c] = q.vs_acc; V.f[F_vbcors_t][q.c] = q.vc_acc; }
     }
   }
 }
@@ -1108,19 +1129,24 @@ int bt_block_mode(blomgpu_ctx *c) {
   if (c->barotp_block == 1) return c->barotp_persist && bt_block_shape(c, true).ti ? 1 : 0;
   return bt_block_shape(c, false).ti ? 2 : 0;
 }
-// the substeps lll0..last of a phase, four per iteration; mode as bt_block_mode returns it
-int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, double woa, double wob, double wna, double wnb, int lll0,
-                    int last, int src, int *src_out, int *ml_out, int *nl_out, int nb) {
+// the substeps of all five phases, four per iteration; mode as bt_block_mode returns it; ph_last / ph_w: PairArgs
+int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, const int *ph_last, const double (*ph_w)[4], int src,
+                    int *src_out, int *ml_out, int *nl_out) {
   const DevView &h = c->h;
   const BtShape sh = bt_block_shape(c, mode == 1);
   if (!sh.ti) return ctx_fail(c, "barotp: the blocked form is not usable on this domain");
   const int nbx = (h.ii + sh.ti - 1) / sh.ti, nby = (h.jj + sh.tj - 1) / sh.tj;
+  const int lll0 = 1, last = ph_last[4];
   const int niter = (last - lll0 + 1 + 3) / 4;
   PairArgs a;
   a.m = m; a.n = n;
   for (int x = 0; x < 2; x++) { a.wo[x] = a.wm[x] = a.wn[x] = 0.; }
   a.do_odd = a.do_even = 0; a.fold_halo = 1; a.prof = nullptr;
-  a.woa = woa; a.wob = wob; a.wna = wna; a.wnb = wnb;
+  a.woa = a.wob = a.wna = a.wnb = 0.;
+  for (int x = 0; x < 5; x++) {
+    a.ph_last[x] = ph_last[x];
+    for (int y = 0; y < 4; y++) a.ph_w[x][y] = ph_w[x][y];
+  }
   a.tsel = 0; a.nbx = nbx; a.write_margin = 0;
   a.pack_on = 0; a.pack_w = a.pack_e = nullptr;
   a.rim_on = 0; a.rim_w = a.rim_e = nullptr; a.rim_has_w = a.rim_has_e = 0; a.rim_per = 0;
@@ -1142,7 +1168,6 @@ int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, doub
     if (int rc = ctx_err_words(c)) return rc;
     a.abort_word = (unsigned *)(c->err_dev + 2);
     a.ml = ml; a.nl = nl; a.src = src; a.lll0 = lll0; a.last = last;
-    a.zero_sums = 1; a.epi_nb = nb;
     TimeScope tk(c, "k_bt_steps");
     launch();
     HIPCHK(c, hipGetLastError());
@@ -1153,7 +1178,6 @@ int bt_block_launch(blomgpu_ctx *c, int mode, int m, int n, int ml, int nl, doub
     for (int lll = lll0; lll <= last; lll += 4) {
       const int e = lll + 3 < last ? lll + 3 : last;
       a.ml = ml; a.nl = nl; a.src = src; a.lll0 = lll; a.last = e;
-      a.zero_sums = lll == lll0 ? 1 : 0; a.epi_nb = e == last ? nb : 0;
       launch();
       src ^= 1;
       if ((e - lll + 1) & 1) { const int t = ml; ml = nl; nl = t; }
