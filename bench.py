@@ -656,7 +656,7 @@ def bench_hybrid_step(args):
         nw = 6 * 2 * ((gpu.get("p").shape[1] * gpu.get("p").shape[2] + 63) // 64)
         gpu.lib.blomgpu_dbg_kprof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         assert gpu.lib.blomgpu_dbg_kprof(gpu.ctx, None, nw) == 0
-        gpu.set("timing", 0)                       # (setting an option drops the captured graphs: their launches carry the old buffer pointer)
+        gpu.set("use_graph", 1)                    # (setting an option drops the captured graphs: their launches carry the old buffer pointer)
     t0 = time.perf_counter()
     ns = gpu.step(ns, args.steps)
     gpu.sync()
@@ -930,22 +930,15 @@ def main():
         gpu.set(nm, int(v))
     baclin = case.params["baclin"]
 
-    # ---- warm-up: first (forward) step + W-1 leap-frog steps, with per-class HIP-event timing ----
+    # ---- warm-up: first (forward) step + W-1 leap-frog steps, in the mode the timed steps run in.  blomgpu_step captures its two
+    # HIP graphs (one per parity of the time levels) in the third step it runs: with W >= 3 the timed region below replays them from its
+    # first step on.  (Until round 6 the warm-up ran with the stage timers on, which use plain launches, and the graphs were captured
+    # INSIDE the first timed block: 4 plain steps + 2 captures of its 20.  Stage times come from the 5 steps after the timed region.)
     ns = gpu.step(0, args.spinup) if args.spinup > 0 else 0
-    ns = gpu.step(ns, 1)
-    gpu.set("timing", 1)
-    gpu.timer_reset()
-    if args.warmup > 1:
-        ns = gpu.step(ns, args.warmup - 1)
+    ns = gpu.step(ns, args.warmup) if args.warmup > 0 else ns
     gpu.sync()
     classes = ["cmnfld", "difest", "eddtra", "remap", "cppm", "diffus", "pgforc", "momtum", "convec", "diapfl", "thermf", "mxlayr", "barotp",
                "pbcor1", "pbcor2", "tmsmt", "init_fluxes", "updtrc"]
-    stage_ms = {}
-    for cl in classes:
-        ms, n = gpu.timer_get(cl)
-        if n:
-            stage_ms[cl] = ms / max(1, args.warmup - 1)       # per STEP: a class brackets its launches in one or several scopes a step
-    gpu.set("timing", 0)
 
     # ---- timed region --------------------------------------------------------------------------
     def barrier():

@@ -372,9 +372,11 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
 }
 
 int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
+  std::string s(name);
+  // (the stage timers select nothing: a step with them runs plain launches beside the graphs, which stay)
+  if (c && s == "timing") { c->timing = v != 0; return 0; }
   if (c) ctx_drop_graphs(c);
   Params &P = c->h.P;
-  std::string s(name);
 #define R(nm) if (s == #nm) { P.nm = v; c->dirty = true; return 0; }
   if (s == "nstep") { P.nstep = v; return 0; }      // host-side only (stage_cppm.hip): the device view is not touched
   R(lstep) R(nday_in_year) R(itriag) R(itrtke) R(itrgls) R(tkeadv) R(tkeidf) R(gls) R(vcoord_tag) R(ltedtp_opt) R(bdmtyp) R(iwdflg) R(bdmldp) R(allwet)
@@ -949,7 +951,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
 
 // A step is ~100 kernel launches, and on the smaller grids most of them are shorter than the time it takes to launch
 // them.  The sequence depends on the step only through the parity of the time levels, so it is captured from the stream
-// once per parity (after two plain steps: work buffers are allocated on first use) and replayed as a HIP graph.
+// for both parities at once (after two plain steps: work buffers are allocated on first use) and replayed as HIP graphs.
 // Single tile only (the RCCL transport and the in-process tile groups synchronise on the host); not while stage timers run.
 int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
   const int kk = c->h.kk;
@@ -961,23 +963,36 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     ctx_sync_view(c);
     c->tmsmt1_ahead = !c->use_graph && !c->csdiag && it < nsteps - 1 && c->tmsmt_ahead;
     // (the hybrid-coordinate sequence too: the engine's status of ale_regrid_remap stays on the device until the check below)
-    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 4;
+    bool graph = c->use_graph && !c->timing && !c->tiling.multi() && c->steps_warm >= 2;
     hipGraphExec_t &ge = c->step_graph[ns & 1];
     if (graph && !ge) {
-      // capture; nothing executes while capturing, so on any failure the step is simply run with plain launches
-      hipGraph_t g = nullptr;
-      bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (ok) {
-        const int rc = step_sequence(c, m, n, mm, nn, k1m, k1n);
+      // Capture; nothing executes while capturing, so on any failure the step is simply run with plain launches.  Both parities are
+      // captured at once -- this step's sequence, then the next step's (time levels swapped) -- so that a caller's warm-up of three
+      // steps leaves nothing but replays to the steps after it.  A capture that fails after it began (a buffer allocated on first
+      // use inside it) is tried again two plain steps later, three times at most; a stream that cannot capture at all is not asked again.
+      bool began = false;
+      auto capture = [&](hipGraphExec_t &out, int m_, int n_, int nstep_) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+        began = true;
+        c->h.P.nstep = nstep_;
+        const int mm_ = (m_ - 1) * kk, nn_ = (n_ - 1) * kk;
+        const int rc = step_sequence(c, m_, n_, mm_, nn_, 1 + mm_, 1 + nn_);
         const hipError_t e = hipStreamEndCapture(c->stream, &g);
-        ok = rc == 0 && e == hipSuccess && g != nullptr;
-        if (ok && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { ge = nullptr; ok = false; }
+        bool ok = rc == 0 && e == hipSuccess && g != nullptr;
+        if (ok && hipGraphInstantiate(&out, g, nullptr, nullptr, 0) != hipSuccess) { out = nullptr; ok = false; }
         if (g) (void)hipGraphDestroy(g);
-      }
+        return ok;
+      };
+      bool ok = capture(ge, m, n, ns + 1);
+      hipGraphExec_t &ge2 = c->step_graph[(ns + 1) & 1];
+      if (ok && !ge2 && !capture(ge2, n, m, ns + 2)) ge2 = nullptr;          // (left to its own step)
+      c->h.P.nstep = ns + 1;
       if (!ok) {
         (void)hipGetLastError();
         c->err.clear();
-        c->use_graph = 0;                              // plain launches from now on
+        if (!began || ++c->graph_failures >= 3) c->use_graph = 0;           // plain launches from now on
+        else c->steps_warm = 0;
         graph = false;
       }
     }

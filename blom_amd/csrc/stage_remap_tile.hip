@@ -95,9 +95,9 @@ struct PolyRec {
   double fd, qx, qy;
   int x;
 };
-struct AdvList {               // model indices of the advected tracers, in order
-  unsigned char idx[64];
-};
+struct AdvList {               // model indices of the advected tracers, in order (ints: an entry at a position the workgroup computes is
+  int idx[64];                 // a scalar load from the kernel arguments; bytes were vector loads, a memory round trip in front of every
+};                             // batch's loads and stores)
 // one polygon's contribution from the donor cell at index x of the gradient region (add_contrib of stage_advect.hip)
 // (rec[slot]: slot 0 / 1 the triangles at the face's two ends where there is one, slot 2 the pentagon -- the order they are added in)
 template <bool MORE>
@@ -132,7 +132,7 @@ __device__ inline void add_contrib_t(const double *g, int ntr, int x, double pbf
 // planes, where pbcor1 -- the next stage, and the only reader before diffus rewrites the fields -- takes them
 // (remap_common.h: R_DP..).  The 12 + 2 ntr flux planes between the two kernels never reach memory.
 template <bool MORE, bool FOLD>
-__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv_all, int nfirst, AdvList L, int tsel) {
+__global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restrict__ Vp, int n, int mm, int nn, int ntx, int nadv_all, int nfirst, AdvList L, int tsel KPROF_ARGS) {
   const DevView &V = *Vp;
   const int nadv = nfirst;               // tracers that ride with dp, T, S (all of them unless MORE)
   const int base = 1;
@@ -157,6 +157,10 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     if (inner != (tsel == 1)) return;
   }
   const size_t np = V.nplane, ok = (size_t)k * np, okn = (size_t)(k + nn) * np, okm = (size_t)(k + mm) * np;
+  // KPROF words of workgroup bx_ of level 10 (thread 0): 0 start, 1 phase 0 done, 2 gradients in LDS, 3 first pass done, 4 first round of the
+  // batch loop done, 5 / 6 after the first / third batch, 7 end
+  [[maybe_unused]] const bool kp_on = t == 0 && k == 10;
+  if (kp_on) KPROF_MARK(bx_, 0);
   // LDS: [ scalars | ... ] then, from phase 2 on, [ gradient slots ] over the same space; cu, cv / corner velocities; masks
   double *const sc = lds;                                   // RT_NSC x RT_SN
   double *const gr = lds;                                   // RT_NG x RT_GN
@@ -255,6 +259,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   }
   if (gthread) { cuv[q] = cu; cuv[RT_GN + q] = cv; }
   __syncthreads();
+  if (kp_on) KPROF_MARK(bx_, 1);
 
   // ---- phase 1: gradients (k_remap_grad) and corner velocities (corner()) of this thread's point ------------------
   double gv[10 + 3 * MAXTR];
@@ -343,6 +348,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     cuv[RT_GN + q] = cvc;
   }
   __syncthreads();
+  if (kp_on) KPROF_MARK(bx_, 2);
   if (!MORE && !FOLD && !fin) return;
 
   // ---- phase 3: flux through this thread's face (k_remap_flux) ---------------------------------------------------------
@@ -506,6 +512,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     };
     fetch(nadv);
     __syncthreads();                                           // the gradient slots of the first pass have been read
+    if (kp_on) KPROF_MARK(bx_, 3);
     for (int b0 = nadv - RT_NB; b0 < nadv_all; b0 += RT_NB) {  // (the first round only fills S and evaluates the first gradients)
       const bool cur = b0 >= nadv, next = b0 + RT_NB < nadv_all;
       const int nb_ = nadv_all - b0 < RT_NB ? nadv_all - b0 : RT_NB;
@@ -542,7 +549,14 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
           }
       }
       __syncthreads();
+      if (kp_on) {
+        const int it_ = (b0 - (nadv - RT_NB)) / RT_NB;
+        if (it_ == 0) KPROF_MARK(bx_, 4);
+        else if (it_ == 1) KPROF_MARK(bx_, 5);
+        else if (it_ == 3) KPROF_MARK(bx_, 6);
+      }
     }
+    if (kp_on) KPROF_MARK(bx_, 7);
     return;
   }
   // (with the update folded in: the batches one after the other, three barriers each)
@@ -665,7 +679,7 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
   for (int nt = 0; nt < h.ntr; nt++)
     if (!trc_skip_adv(h.P, nt + 1)) {
       if (nadv == 64) return ctx_fail(c, "remap: more than 64 advected tracers");
-      L.idx[nadv++] = (unsigned char)nt;
+      L.idx[nadv++] = nt;
     }
   for (int a = nadv; a < 64; a++) L.idx[a] = 0;
   // without the fold, how many of more than MAXTR tracers ride with the first pass is an option (remap_nfirst): with none the first
@@ -679,15 +693,15 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
   if (fold) {
     {
       TimeScope tk(c, "k_remap_tile");
-      if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
-      else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
+      if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel KPROF_PASS(9));
+      else hipLaunchKernelGGL((k_remap_tile<false, true>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel KPROF_PASS(9));
     }
     if ((tsel & 3) != 1)                                // (a split launch: after the second part)
       hipLaunchKernelGGL(k_remap_ring, dim3((6 * (h.ii + 6) + 6 * h.jj + 63) / 64, h.kk), dim3(64), 0, c->stream, c->d, nn, nadv, L);
   } else {
     TimeScope tk(c, "k_remap_tile");
-    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
-    else hipLaunchKernelGGL((k_remap_tile<false, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel);
+    if (nadv > MAXTR) hipLaunchKernelGGL((k_remap_tile<true, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel KPROF_PASS(9));
+    else hipLaunchKernelGGL((k_remap_tile<false, false>), grid, dim3(RT_NT), lds, c->stream, c->d, n, mm, nn, ntx, nadv, nfirst, L, tsel KPROF_PASS(9));
   }
   return 0;
 }

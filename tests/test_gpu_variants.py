@@ -282,7 +282,7 @@ def test_tracer_switch_that_is_not_built_fails_loudly():
 
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("tri_s", 10), ("fuk95", 8)])
 def test_step_replayed_as_a_hip_graph_is_identical(cfg, nsteps):
-    """blomgpu_step captures the stage sequence of a step once per parity of the time levels (after four plain steps) and
+    """blomgpu_step captures the stage sequence of a step for both parities of the time levels at once (after two plain steps) and
     replays it; the persistent barotp kernel's epochs restart with every barotp call so that the launches are the same
     from step to step.  Same bits as plain launches."""
     a = _run(cfg, nsteps, use_graph=0)

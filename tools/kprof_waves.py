@@ -21,9 +21,11 @@ ap.add_argument("--waves", type=int, default=4096)
 ap.add_argument("--save", default=None)
 ap.add_argument("--sel", type=int, default=1, help="which marked kernel writes the buffer: 1 k_pgf_uv*, 2 k_diapfl_column3 (blomgpu_internal.h: kprof_sel)")
 ap.add_argument("--nt", type=int, default=4, help="number of timestamp words (the rest are counters)")
+ap.add_argument("--config", default="channel")
+ap.add_argument("--tracers", default="default")
 ap.add_argument("--labels", default=None, help="comma separated names of the phases between consecutive timestamps")
 args = ap.parse_args()
-case, nreg, masks = bench.build_case("channel", "remap", "default")
+case, nreg, masks = bench.build_case(args.config, "remap", args.tracers)
 gpu = bench.device_for_bench(case, nreg, masks, live=True)
 for o in args.opt:
     nm, v = o.split("=")
