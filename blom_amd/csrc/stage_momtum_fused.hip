@@ -24,7 +24,7 @@
 enum { MF_VISU, MF_VISV, MF_UM, MF_UN, MF_VM, MF_VN, MF_NSLOT };
 #define S2_DRAG 3      // 2-D work plane (written by k_mom_drag, stage_momtum.hip)
 #define S2_QUM 4       // four 2-D work planes (k_mom_qplanes, stage_momtum.hip): ubflxs_p*tsfac/(pbu*scuy) at level m, the same for v, both at level n
-#define WK2V(w) ((gcd_t)((const double *const volatile CONST_AS &)Vp->wk2d + (size_t)(w) * np))
+#define WK2V(w) ((gcd_t) * (double *const volatile CONST_AS *)&Vp->wk2d + (size_t)(w) * np)      // (like GFV below: a scalar load; as a reference cast it was a vector load + v_readfirstlane in front of the step's loads)
 
 // Field pointers come out of the DevView in memory, so the compiler cannot know their address space and would emit
 // flat loads -- which count on lgkmcnt as well as vmcnt, so that every LDS wait (and the wait in front of every

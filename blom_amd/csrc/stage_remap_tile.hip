@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   double *const gr = lds;                                   // RT_NG x RT_GN
   double *const cuv = lds + RT_NG(nadv) * RT_GN;            // 2 x RT_GN: cu, cv in phases 0-1, corner velocities after
   int *const mpl = (int *)(cuv + 2 * RT_GN);                // RT_SN masks
+  double *const m2s = (double *)(mpl + RT_SN);              // 2 x RT_GN: scp2, scp2i of the gradient region (the faces' donor metrics)
   gci_t mpk = V.m[I_mpack];
   gcd_t scp2 = V.f[F_scp2], scp2i = V.f[F_scp2i];
 
@@ -199,28 +200,31 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   const bool gthread = t < RT_GN;
   const int q = gy * RT_GW + gx;                             // index in the gradient region
   const int sidx = (gy + 1) * RT_SW + gx + 1;                // index in the scalar region
-  int mpc;
-  double cu, cv, pm;
-  bool gpoint;
+  // Phase 0 is bound by the NUMBER of load instructions the workgroup issues (measured per workgroup: with a third of them gone it
+  // shrank by a sixth; reordering them into one batch did nothing), so a point loads what only it can: cau, cav, scp2, scp2i and the
+  // limiter's pressure at the point.  Its masks lie in the scalar region's copy (mpl), the metrics of its west and south neighbour
+  // in the neighbours' copies (m2s): the face velocities cu, cv are formed in phase 1, from LDS.
+  double cau_q, cav_q, pm, s2_q, s2i_q;
+  bool gpoint;                                               // (completed in phase 1 with the point's own mask)
   {
     const int x = x0 - 1 + gx, y = y0 - 1 + gy;
     const bool inplane = gthread && x >= 0 && x < ni && y >= 0 && y < nj;
     const int i = x - (NBDY - 1), j = y - (NBDY - 1);
-    // clamped so that c-1, c-ni exist: what a clamped point reads belongs to no point of any sweep's range
+    // clamped into the plane: what a clamped point reads belongs to no point of any sweep's range
     const int xc = x < 1 ? 1 : (x > ni - 1 ? ni - 1 : x), yc = y < 1 ? 1 : (y > nj - 1 ? nj - 1 : y);
     const size_t c = (size_t)yc * ni + xc;
-    mpc = inplane ? mpk[c] : 0;
-    const double cau_c = V.f[F_cau][c + ok], cav_c = V.f[F_cav][c + ok];
-    const double si_w = scp2i[c - 1], si_c = scp2i[c], si_s = scp2i[c - ni];
+    cau_q = V.f[F_cau][c + ok];
+    cav_q = V.f[F_cav][c + ok];
+    s2_q = scp2[c];
+    s2i_q = scp2i[c];
     pm = WK2(V, 0)[c];
-    // non-dimensional face velocities (mod_remap.F90:588-610); zero where no u/v point exists
-    cu = MU(mpc) ? (cau_c > 0. ? cau_c * si_w : cau_c * si_c) : 0.;
-    cv = MV(mpc) ? (cav_c > 0. ? cav_c * si_s : cav_c * si_c) : 0.;
-    gpoint = inplane && j >= -1 && j <= V.jj + 2 && i >= -1 && i <= V.ii + 2 && MP(mpc);
+    gpoint = inplane && j >= -1 && j <= V.jj + 2 && i >= -1 && i <= V.ii + 2;
   }
   // (c) this thread's face: threads 0..255 the u-face, threads 256..511 the v-face of tile point t mod 256.
-  // Metrics of the face's donor cells in face coordinates: m2[a][b] is scp2 at offset (a-1) ACROSS the face's normal
-  // and (b-1) ALONG it -- u-face: (di, dj) = (b-1, a-1); v-face: (di, dj) = (a-1, b-1); b = 2 is never a donor.
+  // Metrics of the face's donor cells, scp2 / scp2i at offset -1..1 ACROSS the face's normal and -1..0 ALONG it, are read in phase 3
+  // from the gradient region's copy in LDS (m2s): as 12 loads of every face thread they were a third of the workgroup's load
+  // instructions in phase 0 and 24 registers carried through the gradient phase.  (A face that is evaluated has 3 <= fx <= ni - 3,
+  // likewise in y: its donors' region points are never the clamped ones.)
   const bool uface = t < RT_TW * RT_TH;
   const int ft = t % (RT_TW * RT_TH);
   const int fq = (ft / RT_TW + 1) * RT_GW + ft % RT_TW + 1;
@@ -228,16 +232,6 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   const bool fin = fx >= 1 && fx < ni - 1 && fy >= 1 && fy < nj - 1;      // every point with a face has neighbours
   const size_t fc = fin ? (size_t)fy * ni + fx : (size_t)ni + 1;
   const int fi = fx - (NBDY - 1), fj = fy - (NBDY - 1);
-  double m2[3][2], m2i[3][2];
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      const size_t cc = uface ? fc + (b - 1) + (ptrdiff_t)(a - 1) * ni : fc + (a - 1) + (ptrdiff_t)(b - 1) * ni;
-      m2[a][b] = scp2[cc];
-      m2i[a][b] = scp2i[cc];
-    }
-  const int mpf = fin ? mpk[fc] : 0;
   const double caf = (uface ? V.f[F_cau] : V.f[F_cav])[fc + ok];
   const double pbf = (uface ? V.f[F_pbu] : V.f[F_pbv])[fc + (size_t)(n - 1) * np];
   gd_t const o_f = (uface ? V.f[F_uflx] : V.f[F_vflx]) + fc + okm;
@@ -248,8 +242,6 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   const bool own = !FOLD || (ft % RT_TW < RT_TW - 1 && ft / RT_TW < RT_TH - 1);
   const bool rd_old = uface && !zero_old && own;
   const double f_o = rd_old ? *o_f : 0., ft_o = rd_old ? *o_ft : 0., fs_o = rd_old ? *o_fs : 0.;
-  const bool fmask = uface ? MU(mpf) : MV(mpf);
-  const double cf = fmask ? (caf > 0. ? caf * m2i[1][0] : caf * m2i[1][1]) : 0.;     // cu resp. cv of the face
 
   if (t < RT_SN) {
     mpl[t] = sm;
@@ -257,7 +249,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     for (int s = 0; s < 4 + MAXTR; s++)
       if (s < 4 + nadv) sc[s * RT_SN + t] = sv[s];
   }
-  if (gthread) { cuv[q] = cu; cuv[RT_GN + q] = cv; }
+  if (gthread) { cuv[q] = cau_q; cuv[RT_GN + q] = cav_q; m2s[q] = s2_q; m2s[RT_GN + q] = s2i_q; }
   __syncthreads();
   if (kp_on) KPROF_MARK(bx_, 1);
 
@@ -266,6 +258,8 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
 #pragma unroll
   for (int s = 0; s < 10 + 3 * MAXTR; s++) gv[s] = 0.;
   double cuc = 0., cvc = 0.;
+  const int mpc = gthread ? mpl[sidx] : 0;                    // (0 outside the plane, as the scalar region stored it)
+  gpoint = gpoint && MP(mpc);
   TNbr nb;
   nb.w = nb.e = nb.s = nb.n = nb.sw = nb.se = nb.nw = nb.ne = 0;
   double k_dxi = 0., k_dyi = 0., k_xd = 0., k_yd = 0.;       // kept for the tracers of later batches (MORE)
@@ -282,8 +276,10 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     nb.nw = MP(mpl[nw]) ? nw : sidx;
     nb.ne = MP(mpl[ne]) ? ne : sidx;
     const int dxw = a + b, dyw = d + e;
-    const double dxi = 1. / (dxw > 1 ? dxw : 1);
-    const double dyi = 1. / (dyw > 1 ? dyw : 1);
+    // 1 / max(1, ie - iw) and 1 / max(1, jn - js) (mod_remap.F90:377-378): the differences are 0, 1 or 2, the quotients 1 or exactly .5 --
+    // selected, not divided (two of the gradient phase's eighteen fp64 divisions per point)
+    const double dxi = dxw > 1 ? .5 : 1.;
+    const double dyi = dyw > 1 ? .5 : 1.;
     const double *dp = sc, *plo = sc + RT_SN;
     // dp' = max(0,dp)+dpeps ; pup = plo - dp' ; lim = max(dpeps, min(pbmin - pup, dp'))
 #define LIM(x) ({ const double d_ = fmax2(0., dp[x]) + DPEPS; fmax2(DPEPS, fmin2(pm - (plo[x] - d_), d_)); })
@@ -321,7 +317,13 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     // corner velocities at the corner common to (x-1,y-1), (x,y-1), (x-1,y), (x,y), mod_remap.F90:623-659
     const int psw = MP(mpl[sidx - 1 - RT_SW]), pse = MP(mpl[sidx - RT_SW]), pnw = MP(mpl[sidx - 1]), pne = MP(mpc);
     const int nw = psw + pse + pnw + pne;
-    const double cus = cuv[q - RT_GW], cun = cu, cvw = cuv[RT_GN + q - 1], cve = cv;
+    // non-dimensional face velocities of the four faces that meet at the corner (mod_remap.F90:588-610): zero where no u- / v-point
+    // exists; u-face of p: cau(p) scp2i(west of p) if it flows eastward, else cau(p) scp2i(p); v-face likewise with the south
+    const double *const s2i = m2s + RT_GN, *const cav_r = cuv + RT_GN;
+    auto cu_at = [&](int p, int mp) { const double ca = cuv[p], sw_ = s2i[p - 1], sc_ = s2i[p]; const double v_ = ca * (ca > 0. ? sw_ : sc_); return MU(mp) ? v_ : 0.; };
+    auto cv_at = [&](int p, int mp) { const double ca = cav_r[p], ss_ = s2i[p - RT_GW], sc_ = s2i[p]; const double v_ = ca * (ca > 0. ? ss_ : sc_); return MV(mp) ? v_ : 0.; };
+    const double cus = cu_at(q - RT_GW, mpl[sidx - RT_SW]), cun = cu_at(q, mpc);
+    const double cvw = cv_at(q - 1, mpl[sidx - 1]), cve = cv_at(q, mpc);
     if (nw == 4) {
       cuc = (cus * cun <= 0.) ? 0. : 2. * cus * cun / (cus + cun);
       cvc = (cvw * cve <= 0.) ? 0. : 2. * cvw * cve / (cvw + cve);
@@ -352,6 +354,9 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
   if (!MORE && !FOLD && !fin) return;
 
   // ---- phase 3: flux through this thread's face (k_remap_flux) ---------------------------------------------------------
+  // (the face point's masks from the scalar region's copy in LDS: one load instruction of phase 0 less)
+  const int mpf = fin ? mpl[(ft / RT_TW + 2) * RT_SW + ft % RT_TW + 2] : 0;
+  const bool fmask = uface ? MU(mpf) : MV(mpf);
   const bool in_f = uface ? (fj >= 0 && fj <= V.jj + 1 && fi >= 0 && fi <= V.ii + 2) : (fj >= 0 && fj <= V.jj + 2 && fi >= 0 && fi <= V.ii + 1);
   if (!MORE && !FOLD && !in_f) return;
   const bool do_face = fin && in_f;
@@ -365,12 +370,16 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
 #pragma unroll
   for (int nt = 0; nt < MAXTR; nt++) A.ftr[nt] = 0.;
   if (do_face) {
+  // cu resp. cv of the face (mod_remap.F90:588-610)
+  const int f_along = uface ? 1 : RT_GW, f_across = uface ? RT_GW : 1;
+  const double cf = fmask ? (caf > 0. ? caf * m2s[RT_GN + fq - f_along] : caf * m2s[RT_GN + fq]) : 0.;
   if (fmask) {
     const double cuc0 = cuv[fq], cvc0 = cuv[RT_GN + fq];
     const bool near = cf > 0.;                       // donor column i-1 (u-face) resp. donor row j-1 (v-face)
     const double sh = near ? .5 : -.5;
-    const double s2_c = near ? m2[1][0] : m2[1][1], s2_m = near ? m2[0][0] : m2[0][1], s2_p = near ? m2[2][0] : m2[2][1];
-    const double s2i_m = near ? m2i[0][0] : m2i[0][1], s2i_p = near ? m2i[2][0] : m2i[2][1];
+    const int fb = near ? fq - f_along : fq;         // the donor cell of the pentagon in the gradient region
+    const double s2_c = m2s[fb], s2_m = m2s[fb - f_across], s2_p = m2s[fb + f_across];
+    const double s2i_m = m2s[RT_GN + fb - f_across], s2i_p = m2s[RT_GN + fb + f_across];
     double a, ax, ay, axx, ayy, axy, x2, y2, x4, y4;
     if (uface) {
       const double cuc1 = cuv[fq + RT_GW], cvc1 = cuv[RT_GN + fq + RT_GW];
@@ -473,7 +482,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     __syncthreads();
     if (upd) {
       const int te = t + 1, ts = RT_TW * RT_TH + t, tn = ts + RT_TW;
-      const double s2i = m2i[1][1];
+      const double s2i = m2s[RT_GN + fq];
       q_dp = fmax2(0., V.f[F_dp][fc + okn]) + DPEPS;
       dpn = q_dp - (fl[te] - fl[t] + fl[tn] - fl[ts]) * s2i;
       const double told = V.f[F_temp][fc + okn], sold = V.f[F_saln][fc + okn];
@@ -489,7 +498,10 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
       WK(V, R_DP(ntr))[fc + ok] = fmax2(0., dpn - DPEPS);
     }
   }
-  if (!MORE) return;
+  if (!MORE) {
+    if (kp_on) KPROF_MARK(bx_, 3);
+    return;
+  }
   // ---- the other advected tracers, a batch at a time --------------------------------------------------------------------------
   gcd_t f_tr = V.f[F_trc] + okn;
   const int off2 = uface ? 0 : 1;
@@ -611,7 +623,7 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     __syncthreads();
     if (upd) {
       const int te = t + 1, ts = RT_TW * RT_TH + t, tn = ts + RT_TW;
-      const double s2i = m2i[1][1];
+      const double s2i = m2s[RT_GN + fq];
 #pragma unroll
       for (int a = 0; a < MAXTR; a++)
         if (a < nb_) {
@@ -687,7 +699,7 @@ int remap_tile_launch(blomgpu_ctx *c, int n, int mm, int nn, int tsel, bool fold
   // the first pass's tracers are cheaper than a batch's: 3.57 ms with four against 3.74 ms with none (24 tracers, tnx1v4s)
   int nfirst = nadv < MAXTR ? nadv : MAXTR;
   if (nadv > MAXTR && !fold) nfirst = c->remap_nfirst < MAXTR ? (c->remap_nfirst > 0 ? c->remap_nfirst : 0) : MAXTR;
-  size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN;
+  size_t lds = sizeof(double) * (RT_NG(nfirst) * RT_GN + 2 * RT_GN) + sizeof(int) * RT_SN + sizeof(double) * 2 * RT_GN;
   if (nadv > MAXTR && !fold && lds < sizeof(double) * RT_NB * (RT_SN + 3 * RT_GN)) lds = sizeof(double) * RT_NB * (RT_SN + 3 * RT_GN);
   const dim3 grid(ntx * nty, h.kk);
   if (fold) {

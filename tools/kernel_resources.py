@@ -23,7 +23,7 @@ def parse(txt):
         g = lambda key: (re.search(r"\." + key + r":\s*(\S+)", blk) or [None, "0"])[1]
         name = g("name")
         name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-        name = re.sub(r"\(.*", "", name).replace("void ", "")
+        name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "")
         ks.append((name, int(g("vgpr_count")), int(blk.split()[0]), int(g("sgpr_count")), int(g("private_segment_fixed_size")),
                    int(g("group_segment_fixed_size")), int(g("max_flat_workgroup_size")), int(g("vgpr_spill_count")), int(g("sgpr_spill_count"))))
     return ks
