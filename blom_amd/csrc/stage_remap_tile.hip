@@ -46,10 +46,18 @@ static_assert(RT_NT >= RT_SN && RT_NT == 2 * RT_TW * RT_TH, "thread count of k_r
 // and the result is used in one place, fmax2(0, max8 - fc) resp. fmin2(0, min8 - fc): a zero of either sign gives a zero of
 // some sign there, the limiter's test (> 0, < 0) fails for both and the gradient is set to zero -- no bit of the output depends
 // on it.  (Inline assembly: the compiler's own maxnum brings a canonicalising instruction per operand with it.)
+// The same instructions for the limiter's other maxima and minima (hmax2 / hmin2), where the same holds -- checked case by case:
+//   max(q1, q2) + max(q3, q4) and the minima: the sums are only compared with tfmx > 0 resp. tfmn < 0 (a zero of either sign loses);
+//   max(tfmx, tgmx), min(tfmn, tgmn) with tfmx > 0 > tfmn: never a tie of zeros; min of the two quotients: both in (0, 1];
+//   max(0, dp) + dpeps: either zero plus dpeps is dpeps; max(dpeps, min(pbmin - pup, dp')): a zero of either sign gives dpeps.
 #ifdef BLOM_HOSTEMU
 #define hmax8 max8
 #define hmin8 min8
+#define hmax2 fmax2
+#define hmin2 fmin2
 #else
+#define hmax2 hw_max
+#define hmin2 hw_min
 __device__ inline double hw_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ inline double hw_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ inline double hmax8(double a, double b, double c, double d, double e, double f, double g, double h) {
@@ -70,13 +78,13 @@ __device__ inline void limited_gradient_t(const double *f, const TNbr &b, int c,
   double tx = (fe - fw) * dxi;
   double ty = (fn - fs) * dyi;
   const double q1 = tx * (-.5 - xd), q2 = tx * (.5 - xd), q3 = ty * (-.5 - yd), q4 = ty * (.5 - yd);
-  const double tgmx = fmax2(q1, q2) + fmax2(q3, q4);
-  const double tgmn = fmin2(q1, q2) + fmin2(q3, q4);
+  const double tgmx = hmax2(q1, q2) + hmax2(q3, q4);
+  const double tgmn = hmin2(q1, q2) + hmin2(q3, q4);
   const double fsw = f[b.sw], fse = f[b.se], fnw = f[b.nw], fne = f[b.ne];
-  const double tfmx = fmax2(0., hmax8(fsw, fs, fse, fw, fe, fnw, fn, fne) - fc);
-  const double tfmn = fmin2(0., hmin8(fsw, fs, fse, fw, fe, fnw, fn, fne) - fc);
+  const double tfmx = hmax2(0., hmax8(fsw, fs, fse, fw, fe, fnw, fn, fne) - fc);
+  const double tfmn = hmin2(0., hmin8(fsw, fs, fse, fw, fe, fnw, fn, fne) - fc);
   if (tfmx > 0. && tfmn < 0.) {
-    const double q = fmin2(tfmx / fmax2(tfmx, tgmx), tfmn / fmin2(tfmn, tgmn));
+    const double q = hmin2(tfmx / hmax2(tfmx, tgmx), tfmn / hmin2(tfmn, tgmn));
     tx = tx * q;
     ty = ty * q;
     gd = fc - tx * xd - ty * yd;
@@ -282,18 +290,18 @@ __global__ void __launch_bounds__(RT_NT, 4) k_remap_tile(const DevView *__restri
     const double dyi = dyw > 1 ? .5 : 1.;
     const double *dp = sc, *plo = sc + RT_SN;
     // dp' = max(0,dp)+dpeps ; pup = plo - dp' ; lim = max(dpeps, min(pbmin - pup, dp'))
-#define LIM(x) ({ const double d_ = fmax2(0., dp[x]) + DPEPS; fmax2(DPEPS, fmin2(pm - (plo[x] - d_), d_)); })
+#define LIM(x) ({ const double d_ = hmax2(0., dp[x]) + DPEPS; hmax2(DPEPS, hmin2(pm - (plo[x] - d_), d_)); })
     const double dpsw = LIM(nb.sw), dps = LIM(nb.s), dpse = LIM(nb.se), dpw = LIM(nb.w), dpc = LIM(sidx);
     const double dpe = LIM(nb.e), dpnw = LIM(nb.nw), dpn = LIM(nb.n), dpne = LIM(nb.ne);
 #undef LIM
     double dx = (dpe - dpw) * dxi, dy = (dpn - dps) * dyi;
     const double dgmx = .5 * (fabs(dx) + fabs(dy));
-    const double dfmx = fmax2(0., hmax8(dpsw, dps, dpse, dpw, dpe, dpnw, dpn, dpne) - dpc);
-    const double dfmn = fmin2(0., hmin8(dpsw, dps, dpse, dpw, dpe, dpnw, dpn, dpne) - dpc);
-    const double dpt = fmax2(0., dp[sidx]) + DPEPS;
+    const double dfmx = hmax2(0., hmax8(dpsw, dps, dpse, dpw, dpe, dpnw, dpn, dpne) - dpc);
+    const double dfmn = hmin2(0., hmin8(dpsw, dps, dpse, dpw, dpe, dpnw, dpn, dpne) - dpc);
+    const double dpt = hmax2(0., dp[sidx]) + DPEPS;
     double xd, yd;
     if (dfmx > 0. && dfmn < 0.) {
-      const double qq = fmin2(dfmx / fmax2(dfmx, dgmx), dfmn / fmin2(dfmn, -dgmx));
+      const double qq = hmin2(dfmx / hmax2(dfmx, dgmx), dfmn / hmin2(dfmn, -dgmx));
       dx = dx * qq;
       dy = dy * qq;
       xd = dx / (12. * dpt);
