@@ -359,7 +359,7 @@ struct blomgpu_ctx {
   long long *bt_prof = nullptr;   // debug: phase timestamps of k_bt_pair
   long long *kprof = nullptr;     // debug (builds with -DBLOM_KPROF): per-wavefront phase timestamps of a column kernel, 8 words a wave (blomgpu_dbg_kprof)
   int kprof_words = 0;
-  int kprof_sel = 1;              // which marked kernel writes: 1 k_pgf_uv*, 2 k_diapfl_column3, 3 k_mxl_column, 4 k_convec_column, 5 k_eddtra_gm, 6 k_mom_column_from, 7 k_diapfl_momentum
+  int kprof_sel = 1;              // which marked kernel writes: 1 k_pgf_uv*, 2 k_diapfl_column3, 3 k_mxl_column, 4 k_convec_column, 5 k_eddtra_gm, 6 k_mom_column_from, 7 k_diapfl_momentum, 9 k_remap_tile, 10 k_pbc_tile (these two: a word set per WORKGROUP of level 10)
   int diffus_shfl = 0;       // A/B: west neighbours of diffus' flux kernel through wavefront shuffles
   int ndiff_rec_per_face = 0;    // neutral diffusion: records per face (0: 6 kk, the bound; stage_ale.hip)
   int ndiff_surface_align = 1;   // phy/mod_diffusion.F90:84 (the namelist default of cime_config is .true.)

@@ -65,7 +65,7 @@ __device__ inline void face_flux(const DevView &V, const double *sc, bool wet, d
 
 // from_remap (pbcor1 inside blomgpu_step): dp, T, S and the advected tracers of the level come from the work-space planes in
 // which remap left them (stage_remap_tile.hip, FOLD), not from their fields
-__global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ Vp, int which, int offc, int offf, int ntx, int from_remap) {
+__global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ Vp, int which, int offc, int offf, int ntx, int from_remap KPROF_ARGS) {
   const DevView &V = *Vp;
   __shared__ double sc[(3 + PT_TB) * PT_LN];                 // dp, saln, temp, one batch of tracers
   unsigned bx_, by_;
@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
   const int k = by_, ni = V.ni, nj = V.nj, ntr = V.ntr, t = threadIdx.x;
   const int x0 = (bx_ % ntx) * PT_TW, y0 = (bx_ / ntx) * PT_TH;
   const size_t np = V.nplane, ok = (size_t)k * np, okc = (size_t)(k + offc) * np, okf = (size_t)(k + offf) * np;
+  // KPROF words of workgroup bx_ of level 10 (thread 0): 0 start, 1 the tile is in LDS, 2 fluxes and S, T done, 3 end
+  [[maybe_unused]] const bool kp_on = t == 0 && k == 10;
+  if (kp_on) KPROF_MARK(bx_, 0);
   gcd_t f_dp = from_remap ? WK(V, R_DP(ntr)) + ok : V.f[F_dp] + okc;
   gcd_t f_s = from_remap ? WK(V, R_S(ntr)) + ok : V.f[F_saln] + okc;
   gcd_t f_t = from_remap ? WK(V, R_T(ntr)) + ok : V.f[F_temp] + okc;
@@ -125,6 +128,7 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
     }
   }
   __syncthreads();
+  if (kp_on) KPROF_MARK(bx_, 1);
 
   // ---- phase 1 ---------------------------------------------------------------------------------------------------
   // faces of the reference's loops: u-faces at j = 1..jj, i = 1..ii+1; v-faces at j = 1..jj+1, i = 1..ii
@@ -172,6 +176,7 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
     }
   }
 
+  if (kp_on) KPROF_MARK(bx_, 2);
   // ---- phase 2: the tracers, PT_TB at a time through the same LDS slots (the first batch came in with phase 0) ----------
   // a batch's values are loaded while the batch before it is worked on: tv is free again once it has gone to LDS
   double tv[2][PT_TB];
@@ -212,6 +217,7 @@ __global__ void __launch_bounds__(PT_NT) k_pbc_tile(const DevView *__restrict__ 
       }
     }
   }
+  if (kp_on) KPROF_MARK(bx_, 3);
 }
 
 // k_pbc_rescale (stage_pbcor.hip) reading the new state from the work space: p scan, pbfac = pb / p(kk+1), dp *= pbfac;
@@ -278,7 +284,7 @@ int pbcor_tile_launch(blomgpu_ctx *c, int which, int m, int offc, int offf, int 
   const int ntx = (h.ni + PT_TW - 1) / PT_TW, nty = (h.nj + PT_TH - 1) / PT_TH;
   {
     TimeScope tk(c, "k_pbc_tile");
-    hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx, from_remap);
+    hipLaunchKernelGGL(k_pbc_tile, dim3(ntx * nty, h.kk), dim3(PT_NT), 0, c->stream, c->d, which, offc, offf, ntx, from_remap KPROF_PASS(10));
   }
   // inside blomgpu_step pbcor1 hands S, T and the tracers to diffus through the work space, pbcor2 to tmsmt2
   // (with ltedtp = 'neutral' diffus is halo updates only: nothing to hand to it)
