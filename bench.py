@@ -656,7 +656,7 @@ def bench_hybrid_step(args):
         nw = 6 * 2 * ((gpu.get("p").shape[1] * gpu.get("p").shape[2] + 63) // 64)
         gpu.lib.blomgpu_dbg_kprof.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         assert gpu.lib.blomgpu_dbg_kprof(gpu.ctx, None, nw) == 0
-        gpu.set("use_graph", 1)                    # (setting an option drops the captured graphs: their launches carry the old buffer pointer)
+        gpu.set("use_graph", 0)                    # (setting an option drops any captured graphs: their launches carry the old buffer pointer)
     t0 = time.perf_counter()
     ns = gpu.step(ns, args.steps)
     gpu.sync()
@@ -930,10 +930,10 @@ def main():
         gpu.set(nm, int(v))
     baclin = case.params["baclin"]
 
-    # ---- warm-up: first (forward) step + W-1 leap-frog steps, in the mode the timed steps run in.  blomgpu_step captures its two
-    # HIP graphs (one per parity of the time levels) in the third step it runs: with W >= 3 the timed region below replays them from its
-    # first step on.  (Until round 6 the warm-up ran with the stage timers on, which use plain launches, and the graphs were captured
-    # INSIDE the first timed block: 4 plain steps + 2 captures of its 20.  Stage times come from the 5 steps after the timed region.)
+    # ---- warm-up: first (forward) step + W-1 leap-frog steps, in the mode the timed steps run in: plain launches without the stage
+    # timers (stage times come from the 5 steps after the timed region).  With the option use_graph = 1 -- off by default: replay measures
+    # 2 % SLOWER than plain launches on ROCm 7.2 -- blomgpu_step captures the graphs of both time-level parities in its fourth step from rest, so a
+    # warm-up of W >= 4 steps would leave nothing but replays to the timed region; `timed_steps_replayed_as_graphs` in the line says how many were.
     ns = gpu.step(0, args.spinup) if args.spinup > 0 else 0
     ns = gpu.step(ns, args.warmup) if args.warmup > 0 else ns
     gpu.sync()
@@ -947,12 +947,14 @@ def main():
     barrier()
     gpu.sync()
     cuda_sync()
+    g0 = gpu.get_real("graph_steps")
     t0 = time.perf_counter()
     ns = gpu.step(ns, args.steps)
     gpu.sync()
     cuda_sync()
     barrier()
     dt = time.perf_counter() - t0
+    graph_steps_timed = int(gpu.get_real("graph_steps") - g0)     # how many of the timed steps were graph replays (0 unless --opt use_graph=1)
     dt = launch.max_over_ranks(dt, env, device="cuda" if on_gpu else "cpu")
 
     # ---- dominant kernel class, timed with HIP events on the library's stream over K more steps
@@ -1112,6 +1114,7 @@ def main():
     out["config"]["spinup_steps"] = args.spinup
     srt = sorted(block_ms)
     out["ms_per_step_blocks"] = [round(x, 4) for x in block_ms]
+    out["timed_steps_replayed_as_graphs"] = graph_steps_timed
     out["ms_per_step_median"] = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     out["ms_per_step_min"], out["ms_per_step_max"] = srt[0], srt[-1]
     if spunup is not None:

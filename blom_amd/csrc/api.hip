@@ -353,6 +353,10 @@ int blomgpu_get_real(blomgpu_ctx *c, const char *name, double *v) {
   // which form of the barotropic substep kernel this context runs with its present options: 1 four substeps per hand-off
   // (k_bt_steps4, persistent), 2 the same kernel with a launch per four substeps, 0 the forms of stage_barotp_pair.hip's head
   if (s == "barotp_block_mode") { *v = bt_block_mode(c); return 0; }
+  // how many steps of this context blomgpu_step has replayed as HIP graphs / how many captures failed (a capture that fails leaves the
+  // sequence on plain launches: correct, and a few per cent slower -- a caller that times steps wants to know)
+  if (s == "graph_steps") { *v = c->graph_steps; return 0; }
+  if (s == "graph_failures") { *v = c->graph_failures; return 0; }
   // diagnostic counters of mxlayr (stage_mxlayr.hip): columns whose iteration for the mixed layer depth ended at its limit since the last
   // query, named by the message the reference prints for such a column: "mxlayr_maxitr_detrain" = the first iteration
   // (phy/mod_mxlayr.F90:437-449, 'reached maxitr when detraining', :440; word 5), "mxlayr_maxitr_entrain" = the second
@@ -967,8 +971,9 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
     hipGraphExec_t &ge = c->step_graph[ns & 1];
     if (graph && !ge) {
       // Capture; nothing executes while capturing, so on any failure the step is simply run with plain launches.  Both parities are
-      // captured at once -- this step's sequence, then the next step's (time levels swapped) -- so that a caller's warm-up of three
-      // steps leaves nothing but replays to the steps after it.  A capture that fails after it began (a buffer allocated on first
+      // captured at once -- this step's sequence, then the next step's (time levels swapped) -- so that a caller's warm-up of four
+      // steps from rest (the time step changes after the first: the view is uploaded again and the count restarts) leaves nothing but replays
+      // to the steps after it.  A capture that fails after it began (a buffer allocated on first
       // use inside it) is tried again two plain steps later, three times at most; a stream that cannot capture at all is not asked again.
       bool began = false;
       auto capture = [&](hipGraphExec_t &out, int m_, int n_, int nstep_) {
@@ -996,7 +1001,7 @@ int blomgpu_step(blomgpu_ctx *c, int *nstep, int nsteps) {
         graph = false;
       }
     }
-    if (graph) HIPCHK(c, hipGraphLaunch(ge, c->stream));
+    if (graph) { HIPCHK(c, hipGraphLaunch(ge, c->stream)); c->graph_steps++; }
     else if (int rc = step_sequence(c, m, n, mm, nn, k1m, k1n)) { c->tmsmt1_done_ahead = false; return rc; }
     c->steps_done++;
     c->steps_warm++;

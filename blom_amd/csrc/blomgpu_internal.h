@@ -291,6 +291,7 @@ struct blomgpu_ctx {
   int tmsmt_fold = 1;                // option: 0 = pbcor2 always runs its column pass
   bool pbcor1_handed_over = false;   // pbcor1 left S, T, tracers of the new level in the work space (slots N_S, N_T, N_TR): diffus starts there
   int steps_warm = 0;            // plain steps since the last option change (graph capture waits for 2: both time levels' buffers exist)
+  long long graph_steps = 0;     // steps replayed as graphs (blomgpu_get_real "graph_steps")
   int graph_failures = 0;        // captures that began and failed (tried again after two more plain steps, three times at most)
   int pgf_uv_pair = 0;           // k_pgf_uv, A/B option: 1 = the u- and v-column wavefronts of 64 points in one workgroup with XCD-contiguous
                                  // numbering: fetch 1.44 -> 0.92 GB per launch, but 0.388 against 0.369 ms for the stage (same box, two runs

@@ -197,9 +197,10 @@ int  blomgpu_stage(blomgpu_ctx *, const char *stage, int m, int n, int mm, int n
 /* Device-resident time stepping: `nsteps` passes of the stage sequence of
  * phy/mod_blom_step.F90:96-253 (hot-path stages only), starting from step count
  * `nstep` (value before step_time).  Returns the new step count in *nstep.
- * On a single tile the sequence is captured in the third step after the last option change -- for both parities of the
- * time levels at once -- and replayed as HIP graphs from then on (option "use_graph", default 1; steps with the stage
- * timers on, "timing" = 1, run plain launches beside the graphs). */
+ * Option "use_graph" = 1 (default 0: replay measures 2 % slower than plain launches on ROCm 7.2): on a single tile the
+ * sequence is captured in the third step after the last change of an option or of the time step (the fourth step from rest) -- for both parities of the time levels at once -- and
+ * replayed as HIP graphs from then on (steps with the stage timers on, "timing" = 1, run plain launches beside the graphs);
+ * blomgpu_get_real "graph_steps" / "graph_failures" count the replays / the captures that failed. */
 int  blomgpu_step(blomgpu_ctx *, int *nstep, int nsteps);
 
 /* Tile decomposition (xcspmd/xctilr, phy/mod_xc.F90:1332-3188).  A context is one tile

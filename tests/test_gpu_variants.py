@@ -280,6 +280,29 @@ def test_tracer_switch_that_is_not_built_fails_loudly():
     gpu.close()
 
 
+def test_graphs_are_captured_inside_a_warm_up_of_three_steps():
+    """Option use_graph: both parities are captured in the third step after the last change of an option or of a parameter in the device's
+    view -- the time step changes after the first step of a run from rest, so its fourth step is the first replay -- and the stage timers
+    do not drop them.  A capture that silently failed would leave the step on plain launches."""
+    from blom_amd.gpu import BlomGpu
+    case = make_case("chan_s")
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm)
+    gpu = BlomGpu(case.idm, case.jdm, case.kdm, case.ntr, nreg, dict(ip=ip, iu=iu, iv=iv, iq=iq))
+    hostinit.init_state(gpu, case)
+    gpu.set("use_graph", 1)                                # (off by default: replay measures slower than plain launches)
+    ns = gpu.step(0, 4)
+    assert gpu.get_real("graph_steps") == 1 and gpu.get_real("graph_failures") == 0      # the capturing step itself is a replay
+    ns = gpu.step(ns, 5)
+    assert gpu.get_real("graph_steps") == 6
+    gpu.set("timing", 1)                                   # plain launches beside the graphs ...
+    ns = gpu.step(ns, 2)
+    assert gpu.get_real("graph_steps") == 6
+    gpu.set("timing", 0)                                   # ... which are still there
+    ns = gpu.step(ns, 2)
+    assert gpu.get_real("graph_steps") == 8 and gpu.get_real("graph_failures") == 0
+    gpu.close()
+
+
 @pytest.mark.parametrize("cfg,nsteps", [("chan_s", 12), ("tri_s", 10), ("fuk95", 8)])
 def test_step_replayed_as_a_hip_graph_is_identical(cfg, nsteps):
     """blomgpu_step captures the stage sequence of a step for both parities of the time levels at once (after two plain steps) and
