@@ -449,6 +449,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "arctic_strips") { c->arctic_strips = v; return 0; }
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "overlap") { c->overlap = v; return 0; }
+  if (s == "phys_dag") { c->phys_dag = v; return 0; }
   if (s == "lean_fluxes") { c->lean_fluxes = v; return 0; }
   if (s == "tmsmt_fold") { c->tmsmt_fold = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
@@ -893,7 +894,8 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   c->fluxes_zeroed = false;
   c->fluxes_lean = false;
   c->remap_handed_over = false;
-  c->mom_early_done = c->convec_col_ahead = false;
+  c->mom_early_done = c->convec_col_ahead = c->cmn_on_side = false;
+  c->diapfl_mom_on_side = c->updtrc_on_side = false;
   if (c->h.P.vcoord_tag != 1) {
     for (const char *st : seq_ale) {
       if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }
@@ -936,9 +938,26 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
         return ctx_fail(c, std::string("blomgpu_step: stage ") + run + " between the lean init_fluxes and advect: the flux arrays of level m are not zeroed (set lean_fluxes = 0)");
       }
     }
+    // what an earlier stage left running on the second stream and this stage needs (st_mxlayr waits for diapfl's momentum mixing itself)
+    if ((c->diapfl_mom_on_side && strcmp(run, "mxlayr")) || (c->updtrc_on_side && !strcmp(st, "pbcor2"))) {
+      const int ev = c->diapfl_mom_on_side ? 7 : 9;
+      c->diapfl_mom_on_side = c->updtrc_on_side = false;
+      if (ctx_side_done(c, ev) || ctx_side_join(c, ev)) {
+        c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+        return 1;
+      }
+    }
     if (int rc = blomgpu_stage(c, run, m, n, mm, nn, k1m, k1n)) {
       c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
       return rc;
+    }
+    // cmnfld2's kernels still alone on the second stream (frozen diffusivities: difest_isobml did not wait for them): eddtra reads the slopes
+    if (!strcmp(st, "halo_difest") && c->cmn_on_side) {
+      c->cmn_on_side = false;
+      if (ctx_side_done(c, 4) || ctx_side_join(c, 4)) {
+        c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
+        return 1;
+      }
     }
     // momtum's viscous chain starts here, on the second stream (stage_momtum.hip: st_momtum_early)
     if (!strcmp(st, "halo_difest"))

@@ -400,12 +400,20 @@ struct blomgpu_ctx {
   int eddf2d = 0, edsprs = 1, edanis = 0, redi3d = 0, rhsctp = 0, edfsmo = 0, edritp_opt = 2, edwmth_opt = 1;
   int difest_live = 0;           // blomgpu_step: 1 = difest_isobml estimates difint, difiso, difdia, difwgt every step (full_physics)
   hipStream_t side = nullptr;    // the second stream
-  hipEvent_t ev_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_side[10] = {};
   DevView hv[4];                 // host copies of the alternative views (hv[0] unused: the main view is h)
   DevView *dv[4] = {nullptr, nullptr, nullptr, nullptr};
   double *wk_mom = nullptr, *p_alt = nullptr, *pu_alt = nullptr, *pv_alt = nullptr;
   bool mom_early_done = false;   // in sequence: momtum's viscous chain of this step is already running on `side`
   bool convec_col_ahead = false; // in sequence: convec's column kernel of this step is already running on `side`
+  // phys_dag: in sequence, cmnfld2's three column kernels run on `side` beside difest's common part and its vertical chain, and
+  // difest's lateral part (falign, lateral) follows them there (stage_cmnfld.hip: st_cmnfld2, stage_difest_iso.hip: st_difest_isobml)
+  int phys_dag = 7;
+  bool cmn_on_side = false;      // in sequence: cmnfld2's kernels of this step are on `side`, nothing has waited for them yet
+  // the same option's bits 2 and 4, small launches beside long ones: diapfl's momentum mixing beside thermf and mxlayr's first kernels (2),
+  // updtrc's ideal-age step beside barotp's first kernels (4).  (pgforc's p / dpu / dpv beside diffus' tile kernel: measured, dropped --
+  // a kernel that fills the chip leaves a second queue only its tail, whatever the queue's priority)
+  bool diapfl_mom_on_side = false, updtrc_on_side = false;
 };
 // alternative device views (see blomgpu_ctx::overlap): MOM_A = momtum's work space + its pu, pv (k_mom_pupv, the viscous
 // march); MOM_B = momtum's work space + its p (k_mom_pscan, k_mom_drag, the Coriolis march); MOM_C = momtum's work space

@@ -20,7 +20,8 @@
 #define SLSELS 2.
 #define BFSQMN 1.e-7
 
-enum { CM_DELP, CM_BFSQ, CM_SLS2, CM_GAM, CM_NSLOT };
+// (CM_GAM behind the nine slots of difest_isobml's kernels, stage_difest_iso.hip: inside blomgpu_step k_cmn_bfsqf runs beside them)
+enum { CM_DELP, CM_BFSQ, CM_SLS2, CM_GAM_ALE, CM_GAM = 9, CM_NSLOT };   // (the hybrid coordinate's kernel keeps its slot)
 
 #define COLUMN_IJ(V)                                                     \
   const int t_ = blockIdx.x * blockDim.x + threadIdx.x;                  \
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64) void k_cmn_bfsqf_ale(const DevView *__restrict_
   const int kk = V.kk;
   gcd_t __restrict__ p = V.f[F_p] + c, temp = V.f[F_temp] + c + (size_t)nn * np, saln = V.f[F_saln] + c + (size_t)nn * np;
   gd_t __restrict__ bfsqi = V.f[F_bfsqi] + c, bfsql = V.f[F_bfsql] + c, bfsqf = V.f[F_bfsqf] + c;
-  gd_t __restrict__ gam = WK(V, CM_GAM) + c;
+  gd_t __restrict__ gam = WK(V, CM_GAM_ALE) + c;
 #define L(a, k) (a)[(size_t)((k)-1) * np]
   const double sls2 = SLS0 * SLS0, pbot = L(p, kk + 1);
   double pk = L(p, 2);                                             // p(k) of the level being worked on
@@ -653,14 +654,26 @@ int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   }
   if (int rc = st_kfpla_halo(c, n)) return rc;                                              // :1176-1196
   if (h.P.eitmth != 2) return 0;
+  // Inside blomgpu_step (phys_dag): the three kernels on the second stream.  They read T, S, dp, p, kfpla and write bfsqi, bfsql, bfsqf, phi,
+  // nslpx/y, nnslpx/y and work slot CM_GAM; what follows on the context's stream until something waits for them -- difest_isobml's halo
+  // updates (u, v, ubflxs_p, pbu ..), its common part and its vertical chain (stage_difest_iso.hip) -- touches none of these.  The first
+  // reader of the slopes is difest's lateral part, which st_difest_isobml puts behind them on the same stream; blomgpu_step joins
+  // before eddtra otherwise.
+  const bool aside = ctx_overlap_on(c) && (c->phys_dag & 1) && !c->tiling.multi();
+  hipStream_t s = c->stream;
+  if (aside) {
+    if (int rc = ctx_side_fork(c, 4)) return rc;
+    s = c->side;
+  }
   TimeScope ts(c, "cmnfld");
-  hipLaunchKernelGGL(k_cmn_bfsqf, g1, dim3(64), 0, c->stream, c->d, n, nn);
-  hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, c->stream, c->d, nn);
+  hipLaunchKernelGGL(k_cmn_bfsqf, g1, dim3(64), 0, s, c->d, n, nn);
+  hipLaunchKernelGGL(k_cmn_phi, g1, dim3(64), 0, s, c->d, nn);
   switch (c->cmn_nslope_nb) {
-    case 4: hipLaunchKernelGGL(k_cmn_nslope<4>, g2, dim3(64), 0, c->stream, c->d, n, nn); break;
-    case 3: hipLaunchKernelGGL(k_cmn_nslope<3>, g2, dim3(64), 0, c->stream, c->d, n, nn); break;
-    default: hipLaunchKernelGGL(k_cmn_nslope<2>, g2, dim3(64), 0, c->stream, c->d, n, nn); break;
+    case 4: hipLaunchKernelGGL(k_cmn_nslope<4>, g2, dim3(64), 0, s, c->d, n, nn); break;
+    case 3: hipLaunchKernelGGL(k_cmn_nslope<3>, g2, dim3(64), 0, s, c->d, n, nn); break;
+    default: hipLaunchKernelGGL(k_cmn_nslope<2>, g2, dim3(64), 0, s, c->d, n, nn); break;
   }
   HIPCHK(c, hipGetLastError());
+  c->cmn_on_side = aside;
   return 0;
 }

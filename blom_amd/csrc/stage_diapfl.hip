@@ -221,11 +221,25 @@ int st_diapfl(blomgpu_ctx *c, int n, int nn, int k1n) {
       if (int rc = st_xctilr_multi(c, 4, ptrs, nl, 1, 1, it)) return rc;
     }
     hipLaunchKernelGGL(k_diapfl_kming, plane_grid(h), dim3(256), 0, c->stream, c->d);
-    hipLaunchKernelGGL(k_diapfl_momentum, plane_grid(h, 2, 64), dim3(64), 0, c->stream, c->d, nn);
+    // Inside blomgpu_step's full step (phys_dag) the momentum mixing and the new dpu, dpv run on the second stream: they read p, pu, pv,
+    // dpu, dpv, the fluxes fpug / fplg and kming, and write u, v, dpu, dpv of level n -- thermf_channel (T, S, dp, forcing fields, util1-4: after
+    // k_diapfl_kming, which reads util1) and mxlayr's first kernels (util1-3) touch none of them and are a dozen launches of ~6 us each.
+    // st_mxlayr waits in front of its halo updates of u, v.
+    const bool aside = ctx_overlap_on(c) && (c->phys_dag & 2) && !c->tiling.multi() && c->full_physics;
+    hipStream_t s = c->stream;
+    if (aside) {
+      if (int rc = ctx_side_fork(c, 6)) return rc;
+      s = c->side;
+    }
+    hipLaunchKernelGGL(k_diapfl_momentum, plane_grid(h, 2, 64), dim3(64), 0, s, c->d, nn);
     // inside blomgpu_step the stage that follows (mxlayr's tail, phy/mod_mxlayr.F90:1266-1310) recomputes dpu, dpv of this
     // level from the same p with the same expression over a larger range before anything reads them: skipped there
     // (with full_physics the real mxlayr follows, which reads them first)
-    if (!c->in_sequence || c->full_physics) hipLaunchKernelGGL(k_diapfl_dpudpv, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    if (!c->in_sequence || c->full_physics) hipLaunchKernelGGL(k_diapfl_dpudpv, plane_grid(h, h.kk), dim3(256), 0, s, c->d, nn);
+    if (aside) {
+      if (int rc = ctx_side_done(c, 7)) return rc;
+      c->diapfl_mom_on_side = true;
+    }
   }
   HIPCHK(c, hipGetLastError());
   // the reference aborts (xchalt) when the implicit solve does not converge, :520-530

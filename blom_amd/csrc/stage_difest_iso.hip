@@ -1053,11 +1053,26 @@ int st_difest_isobml(blomgpu_ctx *c, int m, int n, int mm, int nn) {
     hipLaunchKernelGGL(k_dfi_kfil_util, plane_grid(h), dim3(256), 0, c->stream, c->d, 1);
     hipLaunchKernelGGL(k_dfi_uv2, g2, b64, 0, c->stream, c->d, nn);
     hipLaunchKernelGGL(k_dfi_common, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+    // difest_vertical_iso (vert_a/b/c: reads the common part's drhol, du2l, rig; writes difdia, the closure's tracers and fields, work
+    // slots W_BVFSQ, W_BVF, W_NUB, wkp1, two 2-D slots) and difest_lateral_iso (falign, lateral: reads rig, msku/v, the state, cmnfld2's
+    // nnslpx/y; writes difint, difiso, difwgt, W_EGR, W_ANISOK, W_SM1/2) share no array one of them writes: inside blomgpu_step (phys_dag)
+    // the lateral part runs on the second stream -- behind cmnfld2's kernels if they are there -- beside the vertical chain
+    const bool aside = ctx_overlap_on(c) && (c->phys_dag & 1) && !c->tiling.multi();
+    hipStream_t sl = c->stream;
+    if (aside) {
+      if (int rc = ctx_side_fork(c, 5)) return rc;
+      sl = c->side;
+    }
     hipLaunchKernelGGL(k_dfi_vert_a, g1, b64, 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_vert_b, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, D, nn);
     hipLaunchKernelGGL(k_dfi_vert_c, g1, b64, 0, c->stream, c->d, D, nn);
-    if (D.rhsctp) hipLaunchKernelGGL(k_dfi_falign, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, n, nn);
-    hipLaunchKernelGGL(k_dfi_lateral, g1, b64, 0, c->stream, c->d, D, n, nn);
+    if (D.rhsctp) hipLaunchKernelGGL(k_dfi_falign, plane_grid(h, h.kk), dim3(256), 0, sl, c->d, n, nn);
+    hipLaunchKernelGGL(k_dfi_lateral, g1, b64, 0, sl, c->d, D, n, nn);
+    if (aside) {
+      c->cmn_on_side = false;
+      if (int rc = ctx_side_done(c, 4)) return rc;
+      if (int rc = ctx_side_join(c, 4)) return rc;
+    }
   }
   HIPCHK(c, hipGetLastError());
   const int mrgint = 1, mrgiso = 2;

@@ -1049,6 +1049,10 @@ int st_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   if (int rc = st_xctilr(c, h.f[F_util1], 1, 1, 1, 1, 1)) return rc;
   hipLaunchKernelGGL(k_mxl_bg2_grad, plane_grid(h), dim3(256), 0, c->stream, c->d);
   hipLaunchKernelGGL(k_mxl_bg2_sum, plane_grid(h), dim3(256), 0, c->stream, c->d);
+  if (c->diapfl_mom_on_side) {               // diapfl's momentum mixing on the second stream (stage_diapfl.hip): u, v, dpu, dpv are read from here on
+    c->diapfl_mom_on_side = false;
+    if (int rc = ctx_side_join(c, 7)) return rc;
+  }
   if (c->rm5 > 0.) {                                                                            // :287-290
     if (int rc = st_xctilr(c, h.f[F_u] + (size_t)(k1n - 1) * h.nplane, 1, h.kk, 1, 1, 13)) return rc;
     if (int rc = st_xctilr(c, h.f[F_v] + (size_t)(k1n - 1) * h.nplane, 1, h.kk, 1, 1, 14)) return rc;

@@ -377,9 +377,17 @@ int st_updtrc(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const DevView &h = c->h;
   if (h.P.itriag < 1 || h.P.itriag > h.ntr) return 0;       // no ideal age tracer configured
   if (h.P.nday_in_year < 1) return ctx_fail(c, "updtrc: nday_in_year is not set (mod_time)");
+  // inside blomgpu_step (phys_dag) on the second stream, beside barotp, which reads and writes no tracer; blomgpu_step waits in front of pbcor2
+  const bool aside = ctx_overlap_on(c) && (c->phys_dag & 4) && !c->tiling.multi();
+  if (aside)
+    if (int rc = ctx_side_fork(c, 8)) return rc;
   TimeScope ts(c, "updtrc");
-  hipLaunchKernelGGL(k_idlage_step, plane_grid(h, h.kk), dim3(256), 0, c->stream, c->d, nn);
+  hipLaunchKernelGGL(k_idlage_step, plane_grid(h, h.kk), dim3(256), 0, aside ? c->side : c->stream, c->d, nn);
   HIPCHK(c, hipGetLastError());
+  if (aside) {
+    if (int rc = ctx_side_done(c, 9)) return rc;
+    c->updtrc_on_side = true;
+  }
   return 0;
 }
 

@@ -338,3 +338,33 @@ def test_variants_identical_on_tnx2v1s():
     new = _run("tnx2v1s", 3)
     for nm in keep:
         assert np.array_equal(old[nm], new[nm], equal_nan=True), nm
+
+
+@pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 9), ("tri_s_tke", 7), ("channel_tke", 4)])
+def test_physics_stages_side_by_side_on_the_second_stream(cfg, nsteps):
+    """Round 6, option phys_dag (bits 1 / 2 / 4): inside blomgpu_step's full step with live slopes and diffusivities cmnfld2's column
+    kernels run on the second stream beside difest_isobml's common part and vertical chain, difest's lateral part behind them there;
+    diapfl's momentum mixing beside thermf and mxlayr's first kernels; updtrc's ideal-age step beside barotp's first kernels.  The
+    stages share no array one side writes (stage_cmnfld.hip: st_cmnfld2, stage_difest_iso.hip: st_difest_isobml, stage_diapfl.hip:
+    st_diapfl) -- a missed dependency is a race and shows as differing BYTES against the one-stream order (phys_dag = 0, overlap = 0),
+    at BASELINE.json's channel size too, where thousands of wavefronts of both sides are in flight, and from run to run."""
+    import bench
+    case = make_case(cfg)
+    nreg, _, ip, iu, iv, iq = hostinit.bigrid_np(case.depth, case.idm, case.jdm, arctic=case.nreg == 2)
+    masks = dict(ip=ip, iu=iu, iv=iv, iq=iq)
+    names = STATE_FIELDS + ["difint", "difiso", "difdia", "difwgt", "nslpx", "nslpy", "nnslpx", "nnslpy", "bfsqf", "ustar", "surflx", "trc"]
+
+    def run(**opts):
+        gpu = bench.device_for_bench(case, nreg, masks)
+        for k, v in opts.items():
+            gpu.set(k, v)
+        assert gpu.step(0, nsteps) == nsteps
+        out = {nm: gpu.get(nm).tobytes() for nm in names if gpu.has_field(nm)}
+        gpu.close()
+        return out
+
+    base = run(phys_dag=0, overlap=0)
+    for opts in (dict(phys_dag=7), dict(phys_dag=7), dict(phys_dag=1), dict(phys_dag=6), dict(phys_dag=0)):
+        b = run(**opts)
+        bad = [nm for nm in base if base[nm] != b[nm]]
+        assert not bad, (opts, bad)
