@@ -450,6 +450,7 @@ int blomgpu_set_int(blomgpu_ctx *c, const char *name, int v) {
   if (s == "use_graph") { c->use_graph = v; return 0; }
   if (s == "overlap") { c->overlap = v; return 0; }
   if (s == "phys_dag") { c->phys_dag = v; return 0; }
+  if (s == "mom_early_at") { c->mom_early_at = v; return 0; }
   if (s == "lean_fluxes") { c->lean_fluxes = v; return 0; }
   if (s == "tmsmt_fold") { c->tmsmt_fold = v; return 0; }
   if (s == "tmsmt_ahead") { c->tmsmt_ahead = v; return 0; }
@@ -959,8 +960,10 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
         return 1;
       }
     }
-    // momtum's viscous chain starts here, on the second stream (stage_momtum.hip: st_momtum_early)
-    if (!strcmp(st, "halo_difest"))
+    // momtum's viscous chain starts here, on the second stream (stage_momtum.hip: st_momtum_early) -- or behind a later stage
+    // (option mom_early_at: nothing up to pgforc writes what the chain reads)
+    static const char *early_at[] = {"halo_difest", "eddtra", "advect", "pbcor1", "diffus"};
+    if (!strcmp(st, early_at[c->mom_early_at < 0 || c->mom_early_at > 4 ? 0 : c->mom_early_at]))
       if (int rc = st_momtum_early(c, m, n, mm, nn)) {
         c->defer_checks = false; c->in_sequence = false; c->tmsmt1_done_ahead = false;
         return rc;

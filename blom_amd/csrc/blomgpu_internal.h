@@ -409,6 +409,7 @@ struct blomgpu_ctx {
   // phys_dag: in sequence, cmnfld2's three column kernels run on `side` beside difest's common part and its vertical chain, and
   // difest's lateral part (falign, lateral) follows them there (stage_cmnfld.hip: st_cmnfld2, stage_difest_iso.hip: st_difest_isobml)
   int phys_dag = 7;
+  int mom_early_at = 0;          // momtum's viscous chain forks behind: 0 difest (halo_difest), 1 eddtra, 2 advect, 3 pbcor1, 4 diffus
   bool cmn_on_side = false;      // in sequence: cmnfld2's kernels of this step are on `side`, nothing has waited for them yet
   // the same option's bits 2 and 4, small launches beside long ones: diapfl's momentum mixing beside thermf and mxlayr's first kernels (2),
   // updtrc's ideal-age step beside barotp's first kernels (4).  (pgforc's p / dpu / dpv beside diffus' tile kernel: measured, dropped --
