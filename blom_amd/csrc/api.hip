@@ -837,7 +837,9 @@ int blomgpu_halo_difest(blomgpu_ctx *c, int nn) {     // phy/mod_difest.F90:750-
     const int nl[6] = {2 * kk, 2 * kk, 2, 2, 2, 2}, it[6] = {13, 14, 13, 14, 3, 4};
     if (st_xctilr_multi(c, 6, ptrs, nl, 2, 2, it)) return 1;
   }
-  return launch_pscan(c, nn, -2, 3);                  // interface pressure out to ii+3 for remap (:761-772)
+  // interface pressure out to ii+3 for remap (:761-772) -- unless st_cmnfld2 has done it in front of its kernels on the second stream
+  if (c->pscan_done_ahead) { c->pscan_done_ahead = false; return 0; }
+  return launch_pscan(c, nn, -2, 3);
 }
 
 int blomgpu_stage(blomgpu_ctx *c, const char *stage, int m, int n, int mm, int nn, int k1m, int k1n) {
@@ -896,7 +898,7 @@ static int step_sequence(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, 
   c->fluxes_lean = false;
   c->remap_handed_over = false;
   c->mom_early_done = c->convec_col_ahead = c->cmn_on_side = false;
-  c->diapfl_mom_on_side = c->updtrc_on_side = false;
+  c->diapfl_mom_on_side = c->updtrc_on_side = c->pscan_done_ahead = false;
   if (c->h.P.vcoord_tag != 1) {
     for (const char *st : seq_ale) {
       if (c->tmsmt1_done_ahead && !strcmp(st, "tmsmt1")) { c->tmsmt1_done_ahead = false; continue; }

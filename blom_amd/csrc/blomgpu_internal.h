@@ -415,6 +415,7 @@ struct blomgpu_ctx {
   // updtrc's ideal-age step beside barotp's first kernels (4).  (pgforc's p / dpu / dpv beside diffus' tile kernel: measured, dropped --
   // a kernel that fills the chip leaves a second queue only its tail, whatever the queue's priority)
   bool diapfl_mom_on_side = false, updtrc_on_side = false;
+  bool pscan_done_ahead = false; // in sequence: st_cmnfld2 has launched the pressure scan of difest_isobml's front part (blomgpu_halo_difest)
 };
 // alternative device views (see blomgpu_ctx::overlap): MOM_A = momtum's work space + its pu, pv (k_mom_pupv, the viscous
 // march); MOM_B = momtum's work space + its p (k_mom_pscan, k_mom_drag, the Coriolis march); MOM_C = momtum's work space

@@ -662,6 +662,11 @@ int st_cmnfld2(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
   const bool aside = ctx_overlap_on(c) && (c->phys_dag & 1) && !c->tiling.multi();
   hipStream_t s = c->stream;
   if (aside) {
+    // p is read by the three kernels and rewritten -- with the same values when the state is consistent, out to ii+3 -- by the pressure scan
+    // at the start of difest_isobml (api.hip: blomgpu_halo_difest; nothing in between changes dp or its halo): that scan goes in front of the
+    // fork, so that no kernel writes p while these read it
+    if (int rc = launch_pscan(c, nn, -2, 3)) return rc;
+    c->pscan_done_ahead = true;
     if (int rc = ctx_side_fork(c, 4)) return rc;
     s = c->side;
   }
