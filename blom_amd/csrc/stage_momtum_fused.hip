@@ -119,10 +119,10 @@ __global__ __launch_bounds__(BS) void k_mom_visc_march(const DevView *__restrict
   const int i = x - (NBDY - 1);
   const bool own = x >= ox0 && x <= ox1;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
-  const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
+  [[maybe_unused]] const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   // scalars of the step in registers: left in the DevView they would be re-loaded inside the loop (the kernel stores
   // to memory the compiler cannot tell apart from it)
-  const double tsfac = V.P.dlt / V.P.delt1;
+  [[maybe_unused]] const double tsfac = V.P.dlt / V.P.delt1;
   const double mdv2hi = V.P.mdv2hi, mdv2lo = V.P.mdv2lo, mdv4hi = V.P.mdv4hi, mdv4lo = V.P.mdv4lo;
   const double vsc2hi = V.P.vsc2hi, vsc2lo = V.P.vsc2lo, vsc4hi = V.P.vsc4hi, vsc4lo = V.P.vsc4lo;
   const gci_t mpk = (gci_t)V.m[I_mpack];
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(BS) void k_mom_cor_march(const DevView *__restrict_
   const int i = x - (NBDY - 1);
   const bool own = x >= ox0 && x <= ox1;
   const size_t np = V.nplane, ok = (size_t)k * np, okm = (size_t)(k + mm) * np, okn = (size_t)(k + nn) * np;
-  const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
+  [[maybe_unused]] const size_t om = (size_t)(m - 1) * np, on = (size_t)(n - 1) * np;
   const double delt1 = V.P.delt1, tsfac = V.P.dlt / V.P.delt1, cutoff = ONEM, thkbop = THKBOT * ONEM;
   const double wuv1 = V.P.wuv1, wuv2 = V.P.wuv2;
   const int mommth = V.P.mommth;

@@ -605,7 +605,7 @@ __global__ void k_pgf_dynh_uv(const DevView *__restrict__ Vp, int n, int nn) {
   gcd_t temp = V.f[F_temp] + (size_t)nn * np, dp = V.f[F_dp] + (size_t)nn * np;
   gcd_t dpz = (isv ? V.f[F_dpv] : V.f[F_dpu]) + (size_t)nn * np;
   gd_t pgf = (isv ? V.f[F_pgfy] : V.f[F_pgfx]) + (size_t)nn * np;
-  gd_t pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
+  [[maybe_unused]] gd_t pgf_o = isv ? V.f[F_pgfy_o] : V.f[F_pgfx_o];
   gcd_t pot = WK(V, DH_POT), potpb = WK(V, DH_POTPB), da = WK(V, DH_A), dt = WK(V, DH_T), ar = WK(V, DH_ALPR);
   double xip = 0., xim = 0., pgfm = 0.;
   for (int k = kk; k >= 1; k--) {
