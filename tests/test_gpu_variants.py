@@ -340,8 +340,8 @@ def test_variants_identical_on_tnx2v1s():
         assert np.array_equal(old[nm], new[nm], equal_nan=True), nm
 
 
-@pytest.mark.parametrize("cfg,nsteps", [("chan_s_tke", 9), ("tri_s_tke", 7), ("channel_tke", 4)])
-def test_physics_stages_side_by_side_on_the_second_stream(cfg, nsteps):
+@pytest.mark.parametrize("cfg,nsteps,live", [("chan_s_tke", 9, True), ("tri_s_tke", 7, True), ("channel_tke", 4, True), ("chan_s_tke", 7, False)])
+def test_physics_stages_side_by_side_on_the_second_stream(cfg, nsteps, live):
     """Round 6, option phys_dag (bits 1 / 2 / 4): inside blomgpu_step's full step with live slopes and diffusivities cmnfld2's column
     kernels run on the second stream beside difest_isobml's common part and vertical chain, difest's lateral part behind them there;
     diapfl's momentum mixing beside thermf and mxlayr's first kernels; updtrc's ideal-age step beside barotp's first kernels.  The
@@ -355,7 +355,7 @@ def test_physics_stages_side_by_side_on_the_second_stream(cfg, nsteps):
     names = STATE_FIELDS + ["nslpx", "nslpy", "nnslpx", "nnslpy", "bfsqf", "ustar", "surflx"]
 
     def run(**opts):
-        gpu = bench.device_for_bench(case, nreg, masks)
+        gpu = bench.device_for_bench(case, nreg, masks, live=live)      # (live = False: frozen diffusivities, blomgpu_step joins cmnfld2's kernels itself)
         for k, v in opts.items():
             gpu.set(k, v)
         assert gpu.step(0, nsteps) == nsteps
