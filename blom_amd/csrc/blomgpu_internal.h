@@ -408,11 +408,12 @@ struct blomgpu_ctx {
   bool convec_col_ahead = false; // in sequence: convec's column kernel of this step is already running on `side`
   // phys_dag: in sequence, cmnfld2's three column kernels run on `side` beside difest's common part and its vertical chain, and
   // difest's lateral part (falign, lateral) follows them there (stage_cmnfld.hip: st_cmnfld2, stage_difest_iso.hip: st_difest_isobml)
-  int phys_dag = 7;
+  int phys_dag = 7;              // (bit 8 measured: 0.02 ms on the channel, inside the noise -- off)
   int mom_early_at = 0;          // momtum's viscous chain forks behind: 0 difest (halo_difest), 1 eddtra, 2 advect, 3 pbcor1, 4 diffus
   bool cmn_on_side = false;      // in sequence: cmnfld2's kernels of this step are on `side`, nothing has waited for them yet
   // the same option's bits 2 and 4, small launches beside long ones: diapfl's momentum mixing beside thermf and mxlayr's first kernels (2),
-  // updtrc's ideal-age step beside barotp's first kernels (4).  (pgforc's p / dpu / dpv beside diffus' tile kernel: measured, dropped --
+  // updtrc's ideal-age step beside barotp's first kernels (4), mxlayr's copy-back clamp beside the rest of mxlayr (8; `updtrc_on_side` says that
+  // something on the second stream has to be waited for in front of pbcor2).  (pgforc's p / dpu / dpv beside diffus' tile kernel: measured, dropped --
   // a kernel that fills the chip leaves a second queue only its tail, whatever the queue's priority)
   bool diapfl_mom_on_side = false, updtrc_on_side = false;
   bool pscan_done_ahead = false; // in sequence: st_cmnfld2 has launched the pressure scan of difest_isobml's front part (blomgpu_halo_difest)

@@ -1058,8 +1058,16 @@ int st_mxlayr(blomgpu_ctx *c, int m, int n, int mm, int nn, int k1m, int k1n) {
     if (int rc = st_xctilr(c, h.f[F_v] + (size_t)(k1n - 1) * h.nplane, 1, h.kk, 1, 1, 14)) return rc;
   }
   hipLaunchKernelGGL(k_mxl_column, plane_grid(h, 1, 64), dim3(64), 0, c->stream, c->d, M, n, nn KPROF_PASS(3));
-  hipLaunchKernelGGL(k_mxl_clamp, plane_grid(h, h.ntr + 1, 64), dim3(64), 0, c->stream, c->d, nn);
+  // The copy-back clamp reads dp at the interior points (the halo update below writes halo points) and writes S, the tracers and their correction
+  // planes there; what follows in this stage -- pu, pv, p, dpu, dpv, the velocities onto the new layers -- and barotp read none of them: inside
+  // blomgpu_step (phys_dag bit 8) it runs on the second stream, updtrc's kernel behind it; blomgpu_step waits in front of pbcor2.  Not with the
+  // arctic patch: there the halo update also rewrites the seam row j = jj, which this kernel reads.
+  const bool clamp_aside = ctx_overlap_on(c) && (c->phys_dag & 8) && !c->tiling.multi() && h.nreg != 2;
+  if (clamp_aside)
+    if (int rc = ctx_side_fork(c, 6)) return rc;
+  hipLaunchKernelGGL(k_mxl_clamp, plane_grid(h, h.ntr + 1, 64), dim3(64), 0, clamp_aside ? c->side : c->stream, c->d, nn);
   HIPCHK(c, hipGetLastError());
+  if (clamp_aside) c->updtrc_on_side = true;
   // 'old' interface pressures at the velocity points (:1243-1262), the dp halo, p and the new dpu, dpv (:1264-1310), the
   // velocities onto the new layers (:1312-1374)
   if (int rc = st_mom_pupv(c, nn, 1, 0)) return rc;

@@ -342,9 +342,9 @@ def test_variants_identical_on_tnx2v1s():
 
 @pytest.mark.parametrize("cfg,nsteps,live", [("chan_s_tke", 9, True), ("tri_s_tke", 7, True), ("channel_tke", 4, True), ("chan_s_tke", 7, False)])
 def test_physics_stages_side_by_side_on_the_second_stream(cfg, nsteps, live):
-    """Round 6, option phys_dag (bits 1 / 2 / 4): inside blomgpu_step's full step with live slopes and diffusivities cmnfld2's column
+    """Round 6, option phys_dag (bits 1 / 2 / 4 / 8): inside blomgpu_step's full step with live slopes and diffusivities cmnfld2's column
     kernels run on the second stream beside difest_isobml's common part and vertical chain, difest's lateral part behind them there;
-    diapfl's momentum mixing beside thermf and mxlayr's first kernels; updtrc's ideal-age step beside barotp's first kernels.  The
+    diapfl's momentum mixing beside thermf and mxlayr's first kernels; updtrc's ideal-age step beside barotp's first kernels; mxlayr's copy-back clamp beside the rest of mxlayr (not with the arctic patch).  The
     stages share no array one side writes (stage_cmnfld.hip: st_cmnfld2, stage_difest_iso.hip: st_difest_isobml, stage_diapfl.hip:
     st_diapfl) -- a missed dependency is a race and shows as differing BYTES against the one-stream order (phys_dag = 0, overlap = 0),
     at BASELINE.json's channel size too, where thousands of wavefronts of both sides are in flight, and from run to run."""
@@ -365,7 +365,7 @@ def test_physics_stages_side_by_side_on_the_second_stream(cfg, nsteps, live):
 
     base = run(phys_dag=0, overlap=0)
     # (use_graph: the forks and joins of the second stream inside a captured step)
-    for opts in (dict(phys_dag=7), dict(phys_dag=7), dict(phys_dag=1), dict(phys_dag=6), dict(phys_dag=0), dict(phys_dag=7, use_graph=1)):
+    for opts in (dict(phys_dag=15), dict(phys_dag=15), dict(phys_dag=1), dict(phys_dag=14), dict(phys_dag=7), dict(phys_dag=0), dict(phys_dag=15, use_graph=1)):
         b = run(**opts)
         bad = [nm for nm in base if base[nm] != b[nm]]
         assert not bad, (opts, bad)
