@@ -69,6 +69,11 @@ def test_the_parser_sees_a_known_conflict():
     _, w = rw_sets(os.path.join(CSRC, DFI), "k_dfi_uv2")
     r, _ = rw_sets(os.path.join(CSRC, DFI), "k_dfi_common")
     assert {"wk:0", "wk:1", "I_msku", "I_mskv"} <= (w & r)
+    # a store through a device helper's pointer argument counts: the pressure scan writes p, which cmnfld2's kernels read -- it is why
+    # st_cmnfld2 launches difest's scan in front of the fork
+    _, wp = rw_sets(os.path.join(CSRC, SIM), "k_pscan")
+    rb, _ = rw_sets(os.path.join(CSRC, CMN), "k_cmn_bfsqf")
+    assert "F_p" in wp and "F_p" in rb
     # cmnfld2's work slot lies behind difest's nine (it was slot 3 = difest's W_BVF until the two ran side by side)
     _, wb = rw_sets(os.path.join(CSRC, CMN), "k_cmn_bfsqf")
     assert "wk:9" in wb and not any(x in wb for x in ("wk:%d" % i for i in range(9)))

@@ -57,6 +57,31 @@ def _names(text, val):
                 yield "%s:%s" % (pre, val.get(i, i))
 
 
+# device helpers that store through a pointer argument (blomgpu_internal.h): name -> positions of those arguments
+OUT_ARGS = {"column_scan": [2]}
+
+
+def _call_args(text, start):
+    """the arguments of the call whose opening parenthesis is at text[start]"""
+    args, d, cur = [], 0, ""
+    for ch in text[start:]:
+        if ch == "(":
+            d += 1
+            if d == 1:
+                continue
+        elif ch == ")":
+            d -= 1
+            if d == 0:
+                args.append(cur)
+                return args
+        if ch == "," and d == 1:
+            args.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    return args
+
+
 def rw_sets(path, kernel):
     src = open(path).read()
     val = constants(src)
@@ -68,6 +93,12 @@ def rw_sets(path, kernel):
             writes |= set(_names(m.group(2), val))
         for m in re.finditer(r"(?:V\.[fm]\[[^\]]*\]|WK2?\([^)]*\))(?:\s*\+[^;=\[]*)?\[[^;]*?\]\s*(?:=(?!=)|[-+*/]=)", stmt):
             writes |= set(_names(m.group(0).split("]")[0] + "]" if m.group(0).startswith("V.") else m.group(0), val))
+    for fn, outs in OUT_ARGS.items():
+        for m in re.finditer(r"\b%s\s*\(" % fn, body):
+            args = _call_args(body, m.end() - 1)
+            for o in outs:
+                if o < len(args):
+                    writes |= set(_names(args[o], val))
     return reads - writes, writes
 
 
